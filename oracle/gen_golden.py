@@ -1,0 +1,471 @@
+"""TEST INFRASTRUCTURE ONLY - generates tests/golden/*.npz by running the UNMODIFIED reference.
+
+Run in the authoring container (where /root/reference is mounted):
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+The fixtures are small, committed, and are what pins `oracle/` (and through it the HIP
+engine) to the reference.  /root/reference does not exist on the GPU box, so nothing at test
+time regenerates them.  Each fixture stores inputs AND the reference's outputs; fixtures
+derived from the reference's own tests also store the literal expected vectors of those
+tests (file:line cited next to each).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+import torch  # noqa: E402
+from torch import nn  # noqa: E402
+from torch.distributions import Independent, Normal  # noqa: E402
+
+from tianshou.algorithm import Algorithm  # noqa: E402
+from tianshou.algorithm.modelfree.ppo import PPO  # noqa: E402
+from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy  # noqa: E402
+from tianshou.algorithm.optim import AdamOptimizerFactory  # noqa: E402
+from tianshou.data import (  # noqa: E402
+    Batch,
+    PrioritizedVectorReplayBuffer,
+    ReplayBuffer,
+    SegmentTree,
+    VectorReplayBuffer,
+)
+from tianshou.data.stats import SequenceSummaryStats  # noqa: E402
+from tianshou.utils.net.common import ActorCritic, Net  # noqa: E402
+from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic  # noqa: E402
+from tianshou.utils.torch_utils import policy_within_training_step  # noqa: E402
+import gymnasium as gym  # noqa: E402  (shim stub)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def manager_state(buf) -> dict:
+    """Raw index state of a ReplayBuffer / ReplayBufferManager."""
+    if hasattr(buf, "buffers"):
+        return {
+            "offset": np.array(buf._extend_offset, np.int64),
+            "last_index": np.array(buf.last_index, np.int64),
+            "lengths": np.array(buf._lengths, np.int64),
+            "insertion": np.asarray([b._insertion_idx for b in buf.buffers], np.int64),
+        }
+    return {
+        "offset": np.asarray([0, buf.maxsize], np.int64),
+        "last_index": np.array(buf.last_index, np.int64),
+        "lengths": np.asarray([len(buf)], np.int64),
+        "insertion": np.asarray([buf._insertion_idx], np.int64),
+    }
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_returns_kat() -> None:
+    """GAE / n-step known-answer cases of test/base/test_returns.py."""
+    out: dict[str, np.ndarray] = {}
+    fn = Algorithm.compute_episodic_return
+    # (terminated, truncated, rew, v, gamma, lambda, literal answer, cite)
+    cases = [
+        ([1, 0, 0, 1, 0, 0, 0, 1.0], [0, 0, 0, 0, 0, 1, 0, 0], [0, 1, 2, 3, 4, 5, 6, 7.0], None, 0.1, 1.0,
+         [0, 1.23, 2.3, 3, 4.5, 5, 6.7, 7]),                                    # test_returns.py:27-46
+        ([0, 1, 0, 1, 0, 1, 0.0], [0] * 7, [7, 6, 1, 2, 3, 4, 5.0], None, 0.1, 1.0,
+         [7.6, 6, 1.2, 2, 3.4, 4, 5]),                                          # :48-61
+        ([0, 1, 0, 1, 0, 0, 1.0], [0] * 7, [7, 6, 1, 2, 3, 4, 5.0], None, 0.1, 1.0,
+         [7.6, 6, 1.2, 2, 3.45, 4.5, 5]),                                       # :63-76
+        ([0, 0, 0, 1.0, 0, 0, 0, 1, 0, 0, 0, 1], [0] * 12,
+         [101, 102, 103.0, 200, 104, 105, 106, 201, 107, 108, 109, 202],
+         [2.0, 3.0, 4, -1, 5.0, 6.0, 7, -2, 8.0, 9.0, 10, -3], 0.99, 0.95,
+         [454.8344, 376.1143, 291.298, 200.0, 464.5610, 383.1085, 295.387, 201.0, 474.2876,
+          390.1027, 299.476, 202.0]),                                           # :78-108
+        ([0] * 11 + [1], [0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0],
+         [101, 102, 103.0, 200, 104, 105, 106, 201, 107, 108, 109, 202],
+         [2.0, 3.0, 4, -1, 5.0, 6.0, 7, -2, 8.0, 9.0, 10, -3], 0.99, 0.95,
+         [454.0109, 375.2386, 290.3669, 199.01, 462.9138, 381.3571, 293.5248, 199.02, 474.2876,
+          390.1027, 299.476, 202.0]),                                           # :110-159
+    ]
+    buf = ReplayBuffer(20)
+    for c, (term, trunc, rew, v, gamma, lam, ans) in enumerate(cases):
+        buf.reset()
+        batch = Batch(terminated=np.array(term, float), truncated=np.array(trunc, float),
+                      rew=np.array(rew, float))
+        for b in iter(batch):
+            b.obs = b.act = 1
+            buf.add(b)
+        indices = buf.sample_indices(0)
+        vt = None if v is None else np.array(v, float)
+        returns, adv = fn(batch, buf, indices, vt, gamma=gamma, gae_lambda=lam)
+        assert np.allclose(returns, ans)
+        out[f"gae{c}_terminated"] = np.array(term, bool)
+        out[f"gae{c}_truncated"] = np.array(trunc, bool)
+        out[f"gae{c}_rew"] = np.array(rew, float)
+        out[f"gae{c}_has_v"] = np.array(v is not None)
+        out[f"gae{c}_v_next"] = np.zeros(len(rew)) if v is None else np.array(v, float)
+        out[f"gae{c}_indices"] = indices
+        out[f"gae{c}_unfinished"] = buf.unfinished_index()
+        out[f"gae{c}_gamma_lambda"] = np.array([gamma, lam])
+        out[f"gae{c}_ref_returns"] = returns
+        out[f"gae{c}_ref_adv"] = adv
+        out[f"gae{c}_literal"] = np.array(ans, float)
+    out["n_gae"] = np.array(len(cases))
+
+    # n-step: test_returns.py:197-275 (plain) and :278-357 (time-limit truncation)
+    def target_q_fn(buffer, indices):  # test_returns.py:162-165
+        indices = buffer.next(indices)
+        return torch.tensor(-buffer.rew[indices], dtype=torch.float32)
+
+    def target_q_fn_multidim(buffer, indices):  # :167-168
+        return target_q_fn(buffer, indices).unsqueeze(1).repeat(1, 51)
+
+    literal = {
+        (0, 1): [2.6, 4, 4.4, 5.3, 6.2, 8, 8, 8.9, 9.8, 12],                 # :222
+        (0, 2): [3.4, 4, 5.53, 6.62, 7.8, 8, 9.89, 10.98, 12.2, 12],          # :242
+        (0, 10): [3.4, 4, 5.678, 6.78, 7.8, 8, 10.122, 11.22, 12.2, 12],      # :262
+        (1, 1): [2.6, 3.6, 4.4, 5.3, 6.2, 8, 8, 8.9, 9.8, 12],               # :304
+        (1, 2): [3.36, 3.6, 5.53, 6.62, 7.8, 8, 9.89, 10.98, 12.2, 12],       # :324
+        (1, 10): [3.36, 3.6, 5.678, 6.78, 7.8, 8, 10.122, 11.22, 12.2, 12],   # :344
+    }
+    for variant in (0, 1):
+        buf = ReplayBuffer(10)
+        for i in range(12):
+            if variant == 0:
+                b = Batch(obs=0, act=0, rew=i + 1, terminated=i % 4 == 3, truncated=False)
+            else:
+                b = Batch(obs=0, act=0, rew=i + 1, terminated=i % 4 == 3 and i != 3,
+                          truncated=i == 3, info={"TimeLimit.truncated": i == 3})
+            buf.add(b)
+        batch, indices = buf.sample(0)
+        st = manager_state(buf)
+        pre = f"nstep{variant}_"
+        for k, v in st.items():
+            out[pre + k] = v
+        out[pre + "rew"] = np.asarray(buf.rew, float)
+        out[pre + "terminated"] = np.asarray(buf.terminated, bool)
+        out[pre + "truncated"] = np.asarray(buf.truncated, bool)
+        out[pre + "done"] = np.asarray(buf.done, bool)
+        out[pre + "indices"] = indices
+        for n in (1, 2, 10):
+            r = Algorithm.compute_nstep_return(batch, buf, indices, target_q_fn, gamma=0.1,
+                                               n_step=n).pop("returns")
+            r = r.numpy()
+            assert np.allclose(r.reshape(-1), literal[(variant, n)])
+            rm = Algorithm.compute_nstep_return(batch, buf, indices, target_q_fn_multidim,
+                                                gamma=0.1, n_step=n).pop("returns").numpy()
+            out[pre + f"n{n}_ref"] = r
+            out[pre + f"n{n}_ref_multidim"] = rm
+            out[pre + f"n{n}_literal"] = np.array(literal[(variant, n)], float)
+    np.savez_compressed(os.path.join(OUT, "returns_kat.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_buffer_index() -> None:
+    """Random VectorReplayBuffer histories -> next/prev/unfinished/sample_indices(0) vectors.
+    Also replays the hand-written scenario of test/base/test_buffer.py:740-880 (4 sub-buffers
+    of 5 slots, ragged buffer_ids) whose literal index vectors the reference test pins."""
+    out: dict[str, np.ndarray] = {}
+    rng = np.random.default_rng(1234)
+    scen = 0
+
+    def snapshot(buf, tag):
+        st = manager_state(buf)
+        for k, v in st.items():
+            out[f"{tag}_{k}"] = v
+        B = buf.maxsize
+        out[f"{tag}_done"] = np.asarray(buf.done, bool).copy()
+        q = np.concatenate([np.arange(B), rng.integers(-2 * B, 3 * B, size=64)]).astype(np.int64)
+        out[f"{tag}_query"] = q
+        out[f"{tag}_next"] = np.asarray(buf.next(q), np.int64)
+        out[f"{tag}_prev"] = np.asarray(buf.prev(q), np.int64)
+        out[f"{tag}_unfinished"] = np.asarray(buf.unfinished_index(), np.int64)
+        out[f"{tag}_sample0"] = np.asarray(buf.sample_indices(0), np.int64)
+
+    for (total, E, steps, p_done) in [(20, 4, 3, 0.3), (20, 4, 11, 0.3), (64, 8, 37, 0.1),
+                                      (12, 3, 3, 0.0), (35, 5, 50, 0.5), (16, 1, 23, 0.2)]:
+        buf = VectorReplayBuffer(total, E)
+        for t in range(steps):
+            k = int(rng.integers(1, E + 1))
+            ids = np.sort(rng.choice(E, size=k, replace=False))
+            term = rng.random(k) < p_done
+            trunc = (rng.random(k) < p_done / 3) & ~term
+            buf.add(Batch(obs=np.zeros(k), act=np.zeros(k), rew=rng.normal(size=k),
+                          terminated=term, truncated=trunc, obs_next=np.zeros(k)),
+                    buffer_ids=ids)
+        snapshot(buf, f"s{scen}")
+        scen += 1
+    # literal scenario of test/base/test_buffer.py:740-961: 4 x ReplayBuffer(5), ragged adds
+    buf = VectorReplayBuffer(20, 4)
+    batch = Batch(obs=[1, 2, 3], act=[1, 2, 3], rew=[1, 2, 3], terminated=[0, 0, 1],
+                  truncated=[0, 0, 0])
+    buf.add(batch, buffer_ids=[0, 1, 2])                                       # :752
+    buf.add(Batch(obs=[4], act=[4], rew=[4], terminated=[1], truncated=[0]), buffer_ids=[3])  # :770
+    data = np.array([0, 0, 0, 0])
+    buf.add(Batch(obs=data, act=data, rew=data, terminated=data, truncated=data),
+            buffer_ids=[0, 1, 2, 3])                                           # :786
+    buf.add(Batch(obs=data, act=data, rew=data, terminated=1 - data, truncated=data),
+            buffer_ids=[0, 1, 2, 3])                                           # :793
+    buf.add(Batch(obs=data, act=data, rew=data, terminated=data, truncated=data),
+            buffer_ids=[0, 1, 2, 3])                                           # :801
+    buf.add(Batch(obs=data, act=data, rew=data, terminated=[0, 1, 0, 1], truncated=data),
+            buffer_ids=[0, 1, 2, 3])                                           # :808
+    snapshot(buf, f"s{scen}")
+    out["litA_scen"] = np.array(scen)
+    out["litA_done"] = np.array([0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 1, 0, 1, 0, 0, 1, 0, 1, 0, 1], bool)  # :822-846
+    out["litA_prev"] = np.array([0, 0, 1, 3, 3, 5, 5, 6, 8, 8, 10, 11, 11, 13, 13, 15, 16, 16, 18, 18], np.int64)  # :847-871
+    out["litA_next"] = np.array([1, 2, 2, 4, 4, 6, 7, 7, 9, 9, 10, 12, 12, 14, 14, 15, 17, 17, 19, 19], np.int64)  # :872-896
+    out["litA_unfinished"] = np.array([4, 14], np.int64)                        # :897
+    assert np.array_equal(out[f"s{scen}_next"][:20], out["litA_next"])
+    assert np.array_equal(out[f"s{scen}_prev"][:20], out["litA_prev"])
+    scen += 1
+    buf.add(Batch(obs=[1], act=[1], rew=[1], terminated=[1], truncated=[0]), buffer_ids=[2])  # :898
+    snapshot(buf, f"s{scen}")
+    out["litB_scen"] = np.array(scen)
+    out["litB_prev"] = np.array([0, 0, 1, 3, 3, 5, 5, 6, 8, 8, 14, 11, 11, 13, 13, 15, 16, 16, 18, 18], np.int64)  # :912-936
+    out["litB_next"] = np.array([1, 2, 2, 4, 4, 6, 7, 7, 9, 9, 10, 12, 12, 14, 10, 15, 17, 17, 19, 19], np.int64)  # :937-961
+    out["litB_unfinished"] = np.array([4], np.int64)                            # :909
+    assert np.array_equal(out[f"s{scen}_next"][:20], out["litB_next"])
+    assert np.array_equal(out[f"s{scen}_prev"][:20], out["litB_prev"])
+    scen += 1
+    out["n_scen"] = np.array(scen)
+    np.savez_compressed(os.path.join(OUT, "buffer_index.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_segtree_per() -> None:
+    out: dict[str, np.ndarray] = {}
+    rng = np.random.default_rng(7)
+    for c, size in enumerate([1, 6, 100, 1000]):
+        tree = SegmentTree(size)
+        bound = tree._bound
+        out[f"t{c}_size_bound"] = np.array([size, bound])
+        for r in range(3):
+            k = int(rng.integers(1, max(2, size)))
+            idx = rng.integers(0, size, size=k)
+            val = rng.random(k) * 3.0
+            out[f"t{c}_r{r}_tree_before"] = tree._value.copy()
+            tree[idx] = val
+            out[f"t{c}_r{r}_idx"] = idx.astype(np.int64)
+            out[f"t{c}_r{r}_val"] = val
+            out[f"t{c}_r{r}_tree_after"] = tree._value.copy()
+        total = tree.reduce()
+        q = rng.random(257) * total
+        q[0] = 0.0
+        out[f"t{c}_query"] = q.copy()
+        out[f"t{c}_prefix_idx"] = np.asarray(tree.get_prefix_sum_idx(q.copy()), np.int64)
+        lo = rng.integers(0, size, size=16)
+        hi = np.minimum(lo + rng.integers(1, size + 1, size=16), size)
+        out[f"t{c}_range"] = np.stack([lo, hi]).astype(np.int64)
+        out[f"t{c}_range_sum"] = np.array([tree.reduce(int(a), int(b)) for a, b in zip(lo, hi)])
+    out["n_tree"] = np.array(4)
+
+    # PER: PrioritizedVectorReplayBuffer(64, 4, alpha .6, beta .4)
+    buf = PrioritizedVectorReplayBuffer(64, 4, alpha=0.6, beta=0.4)
+    for t in range(23):
+        buf.add(Batch(obs=np.zeros(4), act=np.zeros(4), rew=rng.normal(size=4),
+                      terminated=rng.random(4) < 0.1, truncated=np.zeros(4, bool),
+                      obs_next=np.zeros(4)))
+    idx = buf.sample_indices(0)
+    out["per_tree0"] = buf.weight._value.copy()
+    out["per_bound"] = np.array(buf.weight._bound)
+    out["per_alpha_beta"] = np.array([0.6, 0.4])
+    td = torch.tensor(rng.normal(size=len(idx)).astype(np.float32))
+    out["per_upd_idx"] = idx.astype(np.int64)
+    out["per_upd_td"] = td.numpy()
+    out["per_prio_before"] = np.array([buf._max_prio, buf._min_prio])
+    buf.update_weight(idx, td)
+    out["per_tree1"] = buf.weight._value.copy()
+    out["per_prio_after"] = np.array([float(buf._max_prio), float(buf._min_prio)])
+    np.random.seed(5)
+    u = np.random.rand(32)
+    out["per_uniform"] = u
+    np.random.seed(5)
+    sidx = buf.sample_indices(32)
+    out["per_sample_idx"] = sidx.astype(np.int64)
+    out["per_is_weight"] = np.asarray(buf[sidx].weight, np.float64)
+    np.savez_compressed(os.path.join(OUT, "segtree_per.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------------------
+def _flat_from_modules(actor, critic) -> np.ndarray:
+    sd_a, sd_c = actor.state_dict(), critic.state_dict()
+    parts = [
+        sd_a["preprocess.model.model.0.weight"], sd_a["preprocess.model.model.0.bias"],
+        sd_a["preprocess.model.model.2.weight"], sd_a["preprocess.model.model.2.bias"],
+        sd_a["mu.model.0.weight"], sd_a["mu.model.0.bias"], sd_a["sigma_param"],
+        sd_c["preprocess.model.model.0.weight"], sd_c["preprocess.model.model.0.bias"],
+        sd_c["preprocess.model.model.2.weight"], sd_c["preprocess.model.model.2.bias"],
+        sd_c["last.model.0.weight"], sd_c["last.model.0.bias"],
+    ]
+    return torch.cat([p.detach().reshape(-1) for p in parts]).numpy().astype(np.float32)
+
+
+def _flat_adam(algorithm, actor, critic, key: str) -> np.ndarray:
+    opt = algorithm.optim._optim
+    named = dict(ActorCritic(actor, critic).named_parameters())
+    order = [
+        "actor.preprocess.model.model.0.weight", "actor.preprocess.model.model.0.bias",
+        "actor.preprocess.model.model.2.weight", "actor.preprocess.model.model.2.bias",
+        "actor.mu.model.0.weight", "actor.mu.model.0.bias", "actor.sigma_param",
+        "critic.preprocess.model.model.0.weight", "critic.preprocess.model.model.0.bias",
+        "critic.preprocess.model.model.2.weight", "critic.preprocess.model.model.2.bias",
+        "critic.last.model.0.weight", "critic.last.model.0.bias",
+    ]
+    return torch.cat([opt.state[named[k]][key].detach().reshape(-1) for k in order]).numpy()
+
+
+def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int,
+            seed: int, n_updates: int = 1, **ppo_kwargs) -> None:
+    """Runs the reference PPO.update() on a synthetic VectorReplayBuffer and dumps every
+    intermediate the engine has to reproduce."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    N = E * T
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    critic = ContinuousCritic(preprocess_net=net_c)
+    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    for m in ActorCritic(actor, critic).modules():
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            nn.init.zeros_(m.bias)
+    for m in actor.mu.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.zeros_(m.bias)
+            m.weight.data.copy_(0.01 * m.weight.data)
+
+    def dist(loc_scale):
+        loc, scale = loc_scale
+        return Independent(Normal(loc, scale), 1)
+
+    space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True,
+                                      action_bound_method="clip", action_space=space)
+    lr = ppo_kwargs.pop("lr", 3e-4)
+    algorithm = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+
+    out: dict[str, np.ndarray] = {}
+    out["flat_params0"] = _flat_from_modules(actor, critic)
+    out["dims"] = np.array([E, T, obs_dim, act_dim, batch_size, repeat, n_updates])
+
+    # capture the global-np.random permutations Batch.split draws and per-step loss sequences
+    perms: list[np.ndarray] = []
+    orig_perm = np.random.permutation
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p, np.int64))
+        return p
+
+    seqs: list[np.ndarray] = []
+    orig_from = SequenceSummaryStats.from_sequence.__func__
+
+    def rec_from(cls, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(cls, seq)
+
+    pre_dump: dict[str, np.ndarray] = {}
+    orig_pre = PPO._preprocess_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        if not pre_dump:
+            pre_dump["v_s"] = b.v_s.numpy().copy()
+            pre_dump["returns"] = b.returns.numpy().copy()
+            pre_dump["adv"] = b.adv.numpy().copy()
+            pre_dump["logp_old"] = b.logp_old.numpy().copy()
+            pre_dump["indices"] = np.asarray(indices, np.int64)
+            pre_dump["unfinished"] = np.asarray(buffer.unfinished_index(), np.int64)
+        return b
+
+    np.random.permutation = rec_perm
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    PPO._preprocess_batch = rec_pre
+    try:
+        for u in range(n_updates):
+            buf = VectorReplayBuffer(N, E)
+            obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+            act = rng.normal(size=(T, E, act_dim)).astype(np.float32)
+            rew = rng.normal(size=(T, E)).astype(np.float32)
+            term = rng.random((T, E)) < 0.02
+            trunc = np.zeros((T, E), bool)
+            trunc[T // 2 - 1 :: T // 2] = True       # a time-limit style truncation pattern
+            trunc &= ~term
+            for t in range(T):
+                buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t],
+                              truncated=trunc[t], obs_next=obs[t + 1]))
+            if u == 0:
+                out["obs"] = np.asarray(buf.obs, np.float32)
+                out["obs_next"] = np.asarray(buf.obs_next, np.float32)
+                out["act"] = np.asarray(buf.act, np.float32)
+                out["rew"] = np.asarray(buf.rew, np.float64)
+                out["terminated"] = np.asarray(buf.terminated, bool)
+                out["truncated"] = np.asarray(buf.truncated, bool)
+                for k, v in manager_state(buf).items():
+                    out["buf_" + k] = v
+            else:
+                out[f"u{u}_obs"] = np.asarray(buf.obs, np.float32)
+                out[f"u{u}_obs_next"] = np.asarray(buf.obs_next, np.float32)
+                out[f"u{u}_act"] = np.asarray(buf.act, np.float32)
+                out[f"u{u}_rew"] = np.asarray(buf.rew, np.float64)
+                out[f"u{u}_terminated"] = np.asarray(buf.terminated, bool)
+                out[f"u{u}_truncated"] = np.asarray(buf.truncated, bool)
+            np.random.seed(seed + 100 + u)
+            n_perm0, n_seq0 = len(perms), len(seqs)
+            with policy_within_training_step(algorithm.policy):
+                stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+            p = perms[n_perm0:]
+            assert len(p) == repeat, (len(p), repeat)
+            out[f"u{u}_perms"] = np.stack(p)
+            s = seqs[n_seq0:]
+            assert len(s) == 4
+            # order of construction in ppo.py:218-222: loss, actor(clip) loss, vf loss, ent loss
+            out[f"u{u}_losses"] = np.stack(s, axis=1)
+            out[f"u{u}_gradient_steps"] = np.array(stats.gradient_steps)
+            out[f"u{u}_flat_params"] = _flat_from_modules(actor, critic)
+            out[f"u{u}_adam_m"] = _flat_adam(algorithm, actor, critic, "exp_avg")
+            out[f"u{u}_adam_v"] = _flat_adam(algorithm, actor, critic, "exp_avg_sq")
+            out[f"u{u}_ret_rms"] = np.array([float(algorithm.ret_rms.mean),
+                                             float(algorithm.ret_rms.var),
+                                             float(algorithm.ret_rms.count)])
+    finally:
+        np.random.permutation = orig_perm
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+        PPO._preprocess_batch = orig_pre
+    for k, v in pre_dump.items():
+        out["pre_" + k] = v
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
+               dual_clip=algorithm.dual_clip or 0.0, value_clip=float(algorithm.value_clip),
+               advantage_normalization=float(algorithm.advantage_normalization),
+               recompute_advantage=float(algorithm.recompute_adv), vf_coef=algorithm.vf_coef,
+               ent_coef=algorithm.ent_coef,
+               max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
+               return_scaling=float(algorithm.return_scaling), lr=lr,
+               max_batchsize=float(algorithm.max_batchsize))
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    gen_returns_kat()
+    gen_buffer_index()
+    gen_segtree_per()
+    # mujoco-example style (examples/mujoco/mujoco_ppo.py:28-62) without recompute
+    gen_ppo("mujoco", E=8, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=3, seed=0,
+            n_updates=2, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25,
+            ent_coef=0.0, return_scaling=True, eps_clip=0.2, value_clip=True, dual_clip=None,
+            advantage_normalization=False, recompute_advantage=False, max_batchsize=256)
+    # library defaults (ppo.py:24-36) + dual clip + recompute_advantage, ragged last minibatch
+    gen_ppo("defaults", E=4, T=75, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=1,
+            n_updates=1, dual_clip=3.0, recompute_advantage=True, lr=1e-3, max_batchsize=64)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

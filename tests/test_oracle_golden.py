@@ -1,0 +1,213 @@
+"""CPU: pins oracle/ (C restatement + torch-fp32 PPO restatement) to the reference.
+
+Sources of truth, both committed under tests/golden/ by oracle/gen_golden.py:
+  * literal known-answer vectors of the reference's own tests (test/base/test_returns.py,
+    test/base/test_buffer.py), and
+  * outputs of the unmodified reference executed in the authoring container.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import oracle_ppo as OP
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+# ------------------------------------------------------------------------------------------ GAE
+def test_gae_known_answers():
+    g = load("returns_kat.npz")
+    for c in range(int(g["n_gae"])):
+        gamma, lam = g[f"gae{c}_gamma_lambda"]
+        v_next = g[f"gae{c}_v_next"] if bool(g[f"gae{c}_has_v"]) else None
+        ret, adv = O.compute_episodic_return(
+            g[f"gae{c}_rew"], g[f"gae{c}_terminated"], g[f"gae{c}_truncated"],
+            g[f"gae{c}_indices"], g[f"gae{c}_unfinished"], v_next, None, gamma, lam)
+        # literal vectors are given to 4-5 significant digits in the reference test (np.allclose)
+        assert np.allclose(ret, g[f"gae{c}_literal"]), c
+        # the reference itself, run here: same f64 arithmetic -> essentially exact
+        np.testing.assert_allclose(ret, g[f"gae{c}_ref_returns"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(adv, g[f"gae{c}_ref_adv"], rtol=1e-13, atol=1e-13)
+
+
+def test_mc_return_to_go_known_answers():
+    # test/base/test_policy.py:26-30
+    assert np.all(O.episode_mc_return_to_go([1, 1, 1], 0.9) == np.array([0.9**2 + 0.9 + 1, 0.9 + 1, 1]))
+    assert O.episode_mc_return_to_go([1, 2, 3], 0.5)[0] == 1 + 0.5 * (2 + 0.5 * 3)
+
+
+# --------------------------------------------------------------------------------------- n-step
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 10])
+def test_nstep_known_answers(variant, n):
+    g = load("returns_kat.npz")
+    pre = f"nstep{variant}_"
+    st = O.BufferState(g[pre + "offset"], g[pre + "last_index"], g[pre + "lengths"],
+                       g[pre + "insertion"], g[pre + "rew"], g[pre + "terminated"],
+                       g[pre + "truncated"], g[pre + "done"])
+    indices = g[pre + "indices"]
+    assert np.array_equal(st.sample_indices_all(), indices)
+
+    def target_q(after):  # test_returns.py:162-165: -rew[next(idx)]
+        return -st.rew[st.next(after)].astype(np.float32)
+
+    ret, _ = O.compute_nstep_return(st, indices, target_q, gamma=0.1, n_step=n)
+    assert np.allclose(ret.reshape(-1), g[pre + f"n{n}_literal"])
+    # reference output is float32 (to_torch_as, algorithm_base.py:811): bit-exact after the cast
+    assert np.array_equal(ret.astype(np.float32).reshape(-1), g[pre + f"n{n}_ref"].reshape(-1))
+
+    def target_q_multi(after):  # :167-168
+        return np.repeat(target_q(after)[:, None], 51, axis=1)
+
+    retm, _ = O.compute_nstep_return(st, indices, target_q_multi, gamma=0.1, n_step=n)
+    assert np.array_equal(retm.astype(np.float32), g[pre + f"n{n}_ref_multidim"])
+
+
+# ---------------------------------------------------------------------------------- index math
+def test_buffer_index_math_bit_exact():
+    g = load("buffer_index.npz")
+    for s in range(int(g["n_scen"])):
+        t = f"s{s}_"
+        args = (g[t + "offset"], g[t + "done"], g[t + "last_index"], g[t + "lengths"])
+        q = g[t + "query"]
+        assert np.array_equal(O._next_index(q, *args), g[t + "next"]), s
+        assert np.array_equal(O._prev_index(q, *args), g[t + "prev"]), s
+        assert np.array_equal(O.unfinished_index(*args), g[t + "unfinished"]), s
+        assert np.array_equal(
+            O.sample_indices_all(g[t + "offset"], g[t + "lengths"], g[t + "insertion"]),
+            g[t + "sample0"]), s
+    # literal vectors of test/base/test_buffer.py:822-961
+    for lit in ("litA", "litB"):
+        t = f"s{int(g[lit + '_scen'])}_"
+        args = (g[t + "offset"], g[t + "done"], g[t + "last_index"], g[t + "lengths"])
+        idx = np.arange(20)
+        assert np.array_equal(O._next_index(idx, *args), g[lit + "_next"])
+        assert np.array_equal(O._prev_index(idx, *args), g[lit + "_prev"])
+        assert np.array_equal(O.unfinished_index(*args), g[lit + "_unfinished"])
+    assert np.array_equal(g[f"s{int(g['litA_scen'])}_done"], g["litA_done"])
+
+
+# ------------------------------------------------------------------------------------ sum tree
+def test_segtree_against_reference():
+    g = load("segtree_per.npz")
+    for c in range(int(g["n_tree"])):
+        size, bound = g[f"t{c}_size_bound"]
+        tree = None
+        for r in range(3):
+            tree = g[f"t{c}_r{r}_tree_before"].copy()
+            O._setitem(tree, g[f"t{c}_r{r}_idx"] + bound, g[f"t{c}_r{r}_val"])
+            assert np.array_equal(tree, g[f"t{c}_r{r}_tree_after"]), (c, r)
+        q = g[f"t{c}_query"].copy()
+        assert np.array_equal(O._get_prefix_sum_idx(q, int(bound), tree), g[f"t{c}_prefix_idx"])
+        for (lo, hi), ref in zip(g[f"t{c}_range"].T, g[f"t{c}_range_sum"]):
+            got = tree[1] if (lo == 0 and hi == size and False) else O._reduce(
+                tree, int(lo) + int(bound) - 1, int(hi) + int(bound))
+            assert got == ref
+
+
+def test_segtree_naive_properties():
+    # mirrors test/base/test_buffer.py:553-633: random updates vs naive sums
+    rng = np.random.default_rng(0)
+    size, bound = 100, 128
+    tree = np.zeros(2 * bound)
+    naive = np.zeros(size)
+    for _ in range(200):
+        k = rng.integers(1, 10)
+        idx = rng.integers(0, size, k)
+        val = rng.random(k)
+        O._setitem(tree, idx + bound, val)
+        naive[idx] = val
+        lo = int(rng.integers(0, size))
+        hi = int(rng.integers(lo + 1, size + 1))
+        assert np.isclose(O._reduce(tree, lo + bound - 1, hi + bound), naive[lo:hi].sum())
+    q = rng.random(64) * tree[1]
+    idx = O._get_prefix_sum_idx(q.copy(), bound, tree)
+    cs = np.cumsum(naive)
+    for v, i in zip(q, idx):
+        assert cs[i] >= v - 1e-9 and (i == 0 or cs[i - 1] < v + 1e-9)
+
+
+def test_per_weights_against_reference():
+    g = load("segtree_per.npz")
+    bound = int(g["per_bound"])
+    alpha, beta = g["per_alpha_beta"]
+    tree = g["per_tree0"].copy()
+    mx, mn = g["per_prio_before"]
+    mx, mn = O.per_update_weight(tree, bound, g["per_upd_idx"], g["per_upd_td"], alpha, mx, mn)
+    # float32 pow: libm powf vs NumPy's SIMD float32 power may differ by an ulp
+    np.testing.assert_allclose(tree, g["per_tree1"], rtol=3e-7)
+    np.testing.assert_allclose([mx, mn], g["per_prio_after"], rtol=1e-7)
+    tree = g["per_tree1"].copy()
+    scalar = g["per_uniform"] * tree[1]               # prio.py:65
+    sidx = O._get_prefix_sum_idx(scalar.copy(), bound, tree)
+    assert np.array_equal(sidx, g["per_sample_idx"])
+    w = O.per_get_weight(tree, bound, sidx, g["per_prio_after"][1], beta, True)
+    np.testing.assert_allclose(w, g["per_is_weight"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------ PPO path
+def _cfg_from(g):
+    c = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    return OP.PPOConfig(
+        gamma=c["gamma"], gae_lambda=c["gae_lambda"], eps_clip=c["eps_clip"],
+        dual_clip=(c["dual_clip"] or None), value_clip=bool(c["value_clip"]),
+        advantage_normalization=bool(c["advantage_normalization"]),
+        recompute_advantage=bool(c["recompute_advantage"]), vf_coef=c["vf_coef"],
+        ent_coef=c["ent_coef"], max_grad_norm=(c["max_grad_norm"] or None),
+        return_scaling=bool(c["return_scaling"]), lr=c["lr"],
+        max_batchsize=int(c["max_batchsize"]))
+
+
+@pytest.mark.parametrize("tag", ["mujoco", "defaults"])
+def test_ppo_restatement_matches_reference(tag):
+    torch.set_num_threads(4)
+    g = load(f"ppo_{tag}.npz")
+    E, T, obs_dim, act_dim, batch_size, repeat, n_updates = [int(x) for x in g["dims"]]
+    cfg = _cfg_from(g)
+    state = OP.PPOState(params=OP.unflatten_params(torch.from_numpy(g["flat_params0"]), obs_dim, act_dim))
+    for u in range(n_updates):
+        pre_ = "" if u == 0 else f"u{u}_"
+        obs = torch.from_numpy(g[pre_ + "obs"])
+        obs_next = torch.from_numpy(g[pre_ + "obs_next"])
+        act = torch.from_numpy(g[pre_ + "act"])
+        rew, term, trunc = g[pre_ + "rew"], g[pre_ + "terminated"], g[pre_ + "truncated"]
+        bs = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"],
+                           g["buf_insertion"], rew, term, trunc)
+        indices = bs.sample_indices_all()
+        unfinished = bs.unfinished_index()
+        if u == 0:
+            assert np.array_equal(indices, g["pre_indices"])
+            assert np.array_equal(unfinished, g["pre_unfinished"])
+        args = (obs[indices], obs_next[indices], act[indices], rew[indices], term[indices],
+                trunc[indices], indices, unfinished)
+        pre = OP.preprocess(state, cfg, *args)
+        if u == 0:
+            np.testing.assert_allclose(pre["v_s"].numpy(), g["pre_v_s"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(pre["returns"].numpy(), g["pre_returns"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(pre["adv"].numpy(), g["pre_adv"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(pre["logp_old"].numpy(), g["pre_logp_old"], rtol=1e-5, atol=1e-6)
+
+        def recompute():
+            return OP.add_returns_and_advantages(state, cfg, args[0], args[1], *args[3:])
+
+        losses = OP.update(state, cfg, {"obs": args[0], "act": args[2]}, pre, batch_size, repeat,
+                           list(g[f"u{u}_perms"]), recompute=recompute)
+        ref = g[f"u{u}_losses"]
+        assert losses.shape == ref.shape and losses.shape[0] == int(g[f"u{u}_gradient_steps"])
+        np.testing.assert_allclose(losses, ref, rtol=2e-5, atol=2e-6)
+        flat = OP.flatten_params(state.params).numpy()
+        np.testing.assert_allclose(flat, g[f"u{u}_flat_params"], rtol=1e-4, atol=2e-6)
+        m = torch.cat([state.adam_m[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+        v = torch.cat([state.adam_v[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+        np.testing.assert_allclose(m, g[f"u{u}_adam_m"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(v, g[f"u{u}_adam_v"], rtol=1e-3, atol=1e-10)
+        np.testing.assert_allclose(
+            [state.ret_rms.mean, state.ret_rms.var, state.ret_rms.count], g[f"u{u}_ret_rms"],
+            rtol=1e-6)
