@@ -1,0 +1,248 @@
+/*
+ * tsengine.h -- C ABI of libtsengine.so, the MI355X (gfx950) update-step engine that drops in
+ * behind the Batch -> learn() hot path of thu-ml/tianshou 2.0.1.
+ *
+ * Boundary rules
+ *   - extern "C", plain pointers + int64 sizes + scalar hyper-parameters + a stream handle.
+ *     No torch / numpy types.  Every data pointer is a DEVICE pointer unless the parameter
+ *     name starts with `h_` (host).  The caller owns every buffer; the library owns only the
+ *     opaque ts_workspace it hands out.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  No entry point
+ *     synchronises the device; results are ordered on `stream`.
+ *   - Return value: TS_OK (0) or a negative TS_ERR_* code; ts_last_error() gives the message
+ *     for the calling thread.  The Python wrapper maps TS_ERR_SHAPE to ValueError (mirrors
+ *     algorithm_base.py:757-758) and the rest to RuntimeError.
+ *   - Re-entrant per stream; no global mutable state except the thread-local error string.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference
+ * checkout, thu-ml/tianshou @ 2.0.1).
+ */
+#ifndef TSENGINE_H
+#define TSENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_OK 0
+#define TS_ERR_INVALID_ARG (-1) /* null pointer, negative size, unsupported flag value      */
+#define TS_ERR_SHAPE (-2)       /* size mismatch between arguments -> ValueError            */
+#define TS_ERR_HIP (-3)         /* a HIP runtime call / kernel launch failed                 */
+#define TS_ERR_UNSUPPORTED (-4) /* valid request the engine does not cover (caller decides)  */
+#define TS_ERR_WORKSPACE (-5)   /* workspace too small / missing                             */
+
+typedef void* ts_stream_t; /* hipStream_t */
+typedef struct ts_workspace ts_workspace;
+
+const char* ts_version(void);
+const char* ts_last_error(void);
+
+/* Opaque scratch (tile aggregates, partial gradients, sum-tree winner table).  Grows on
+ * demand up to `max_bytes` (0 = no limit); never shrinks.  One workspace per stream. */
+int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes);
+int ts_workspace_destroy(ts_workspace* ws);
+
+/* ---------------------------------------------------------------------------------------------
+ * Returns / advantages
+ * ------------------------------------------------------------------------------------------- */
+
+/* Fused Algorithm.compute_episodic_return (tianshou/algorithm/algorithm_base.py:653-719) with
+ * its njit kernel _gae (:1085-1140) and the return-scaling arithmetic around it
+ * (tianshou/algorithm/modelfree/a2c.py:134-148):
+ *     vs  = v_s  * v_scale;  vs_ = v_s_next * v_scale * !terminated          (:711, a2c.py:135-136)
+ *     end = terminated | truncated | (position in cut_pos)                    (:714-715)
+ *     adv_i = (rew_i + gamma*vs__i - vs_i) + (1-end_i)*gamma*lambda*adv_{i+1} (reverse scan)
+ *     ret_i = adv_i + vs_i ;  returns_out = ret_i / ret_div                   (:717, a2c.py:146)
+ * All inputs are the *batch* arrays in batch order (= buffer arrays gathered at `indices`).
+ * `cut_pos` lists the batch positions p with indices[p] in buffer.unfinished_index()
+ * (any order, may be NULL when n_cut == 0); when `d_n_cut` (device int64, nullable) is given
+ * the kernel uses min(*d_n_cut, n_cut) entries, so the count produced by ts_isin_positions
+ * never has to visit the host.  Arithmetic is float64 inside (as numba's), the
+ * outputs are float32 like the reference's to_torch_as casts (a2c.py:151-152).  Optional
+ * float64 outputs (`adv64`, `ret64`, unnormalised returns) serve parity tests.
+ * `ret_partials` (nullable, double[2 * ts_gae_num_tiles(n)]) receives per-tile (sum, sum of
+ * squares) of the unnormalised returns for RunningMeanStd.update (utils/statistics.py:99-114).
+ * rew_dtype: 0 = float32, 1 = float64 (the reference stores rew as float64, buffer_base.py:492). */
+int64_t ts_gae_num_tiles(int64_t n);
+int ts_gae_scan(ts_workspace* ws, const float* v_s, const float* v_s_next, const void* rew,
+                int rew_dtype, const uint8_t* terminated, const uint8_t* truncated,
+                const int64_t* cut_pos, int64_t n_cut, const int64_t* d_n_cut, int64_t n,
+                double gamma, double gae_lambda, double v_scale, double ret_div, float* adv_out,
+                float* returns_out, double* adv64, double* ret64, double* ret_partials,
+                ts_stream_t stream);
+
+/* Positions of unfinished slots inside a batch: for the general (non-identity) `indices`
+ * of compute_episodic_return, algorithm_base.py:715 `np.isin(indices, unfinished_index())`.
+ * Writes the matching batch positions to cut_pos_out (capacity >= n_unfinished * dup, see
+ * `capacity`) in unspecified order and their count to *n_cut_out (device int64). */
+int ts_isin_positions(const int64_t* indices, int64_t n, const int64_t* unfinished,
+                      int64_t n_unfinished, int64_t* cut_pos_out, int64_t capacity,
+                      int64_t* n_cut_out, ts_stream_t stream);
+
+/* _nstep_return (tianshou/algorithm/algorithm_base.py:1160-1222), same arguments:
+ * rew_B float64[B], end_flag_B u8[B], target_q_IA float32[I,A], stacked_indices_NI int64[N,I]
+ * -> out float32[I,A] (the reference returns float64 and casts at :811) and optionally the
+ * float64 values (`out64`, nullable).  Bit-exact float64 arithmetic (no FMA contraction). */
+int ts_nstep_return(const double* rew_B, const uint8_t* end_flag_B, const float* target_q_IA,
+                    const int64_t* stacked_indices_NI, int64_t I, int64_t A, int64_t n_step,
+                    int64_t B, double gamma, float* out, double* out64, ts_stream_t stream);
+
+/* indices_after_n_steps of Algorithm.compute_nstep_return (algorithm_base.py:772-791):
+ * applies ReplayBufferManager.next (n_step - 1) times.  Optionally also writes the whole
+ * stack int64[n_step, I] (`stacked_out`, nullable). */
+int ts_nstep_indices(const int64_t* indices, int64_t I, int64_t n_step, const int64_t* offset,
+                     int64_t E, const uint8_t* done, const int64_t* last_index,
+                     const int64_t* lengths, int64_t* after_out, int64_t* stacked_out,
+                     ts_stream_t stream);
+
+/* Fused remainder of compute_nstep_return (algorithm_base.py:798-811): walks next() itself,
+ * applies value_mask (~terminated[idx_after_n], :798), builds end_flag = done | unfinished
+ * (:799-800) on the fly, evaluates _nstep_return.  No [N,I] index matrix, no O(B) copy.
+ * n_step <= 32. */
+int ts_nstep_return_fused(const int64_t* indices, int64_t I, int64_t n_step,
+                          const int64_t* offset, int64_t E, const uint8_t* done,
+                          const uint8_t* terminated, const int64_t* last_index,
+                          const int64_t* lengths, const double* rew_B, const float* target_q_IA,
+                          int64_t A, double gamma, float* out, double* out64,
+                          ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Replay-buffer index math (bit-exact integers)
+ * ------------------------------------------------------------------------------------------- */
+
+/* _next_index / _prev_index (tianshou/data/buffer/manager.py:339-363 / :311-336), same
+ * arguments.  O(I log E) instead of the reference's O(E * I) masked passes. */
+int ts_next_index(const int64_t* index, int64_t I, const int64_t* offset, int64_t E,
+                  const uint8_t* done, const int64_t* last_index, const int64_t* lengths,
+                  int64_t* out, ts_stream_t stream);
+int ts_prev_index(const int64_t* index, int64_t I, const int64_t* offset, int64_t E,
+                  const uint8_t* done, const int64_t* last_index, const int64_t* lengths,
+                  int64_t* out, ts_stream_t stream);
+
+/* ReplayBufferManager.unfinished_index (manager.py:85-91, buffer_base.py:314-317):
+ * ascending list of last_index[e] with lengths[e] > 0 and !done[last_index[e]].
+ * out int64[E] (capacity E), *n_out device int64. */
+int ts_unfinished_index(const int64_t* offset, int64_t E, const uint8_t* done,
+                        const int64_t* last_index, const int64_t* lengths, int64_t* out,
+                        int64_t* n_out, ts_stream_t stream);
+
+/* ReplayBufferManager.sample_indices(0) (manager.py:216-234, buffer_base.py:518-525):
+ * per sub-buffer [insertion, len) ++ [0, insertion), + offset.  `total` = sum(lengths)
+ * (known to the host, which owns the manager state). out int64[total]. */
+int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
+                          const int64_t* lengths, const int64_t* insertion, int64_t total,
+                          int64_t* out, ts_stream_t stream);
+
+/* ReplayBuffer.__getitem__ row gather (buffer_base.py:605-649): out[i,:] = src[index[i],:]
+ * for a row of `row_bytes` bytes (any dtype).  16-byte vector path when row_bytes % 16 == 0
+ * and both bases are 16-byte aligned. */
+int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const int64_t* index,
+                   int64_t I, void* out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sum tree / prioritized replay
+ * ------------------------------------------------------------------------------------------- */
+
+/* SegmentTree._setitem (tianshou/data/utils/segtree.py:95-101): tree float64[2*bound],
+ * index int64[K] (already + bound), value float64[K] (value_dtype 1) or float32[K] (0).
+ * Duplicate leaves: the later entry wins, as NumPy fancy assignment does.  */
+int ts_segtree_setitem(ts_workspace* ws, double* tree, int64_t bound, const int64_t* index,
+                       const void* value, int value_dtype, int64_t K, ts_stream_t stream);
+
+/* SegmentTree._reduce (segtree.py:104-116) -> *out (device double). */
+int ts_segtree_reduce(const double* tree, int64_t start, int64_t end, double* out,
+                      ts_stream_t stream);
+
+/* SegmentTree._get_prefix_sum_idx (segtree.py:119-134): value float64[K] is mutated in
+ * place exactly as the reference does (:131); out int64[K]. */
+int ts_segtree_prefix_sum_idx(double* value, int64_t K, int64_t bound, const double* sums,
+                              int64_t* out, ts_stream_t stream);
+
+/* PrioritizedReplayBuffer.sample_indices + get_weight + __getitem__ normalisation
+ * (tianshou/data/buffer/prio.py:63-79, 104-106) in one launch: u float64[K] are the
+ * host-supplied np.random.rand(K) draws (:65).  idx_out int64[K], weight_out float64[K]
+ * = (tree[idx+bound]/min_prio)^-beta, divided by its max when weight_norm; min_prio is read
+ * from prio_minmax[1] (device double[2] = {max_prio, min_prio}, prio.py:36). */
+int ts_per_sample(ts_workspace* ws, const double* tree, int64_t bound, const double* u,
+                  int64_t K, const double* prio_minmax, double beta, int weight_norm,
+                  int64_t* idx_out, double* weight_out, ts_stream_t stream);
+
+/* PrioritizedReplayBuffer.update_weight (prio.py:81-90): new_weight float32[K] (TD errors);
+ * tree[index+bound] = (|w| + eps)^alpha (float32 math like NumPy's), then sum-tree repair;
+ * prio_minmax (device double[2] = {max_prio, min_prio}) updated with |w| + eps. */
+int ts_per_update_weight(ts_workspace* ws, double* tree, int64_t bound, const int64_t* index,
+                         const float* new_weight, int64_t K, double alpha, double* prio_minmax,
+                         ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * PPO / A2C actor-critic MLP  (obs -> 64 -> 64 -> {mu[act_dim], V}), tanh, fp32 MFMA
+ * ------------------------------------------------------------------------------------------- */
+
+/* Flat fp32 parameter vector layout (P = ts_ppo_param_count(obs_dim, act_dim)):
+ *   actor : W1[64,obs] b1[64] W2[64,64] b2[64] Wmu[act,64] bmu[act] sigma_param[act]
+ *   critic: W1[64,obs] b1[64] W2[64,64] b2[64] Wv[64] bv[1]
+ * (row-major, torch nn.Linear convention weight[out,in]).  Reference modules:
+ * Net/MLP tianshou/utils/net/common.py:90-178,246-369; ContinuousActorProbabilistic
+ * tianshou/utils/net/continuous.py:172-238 (unbounded, state-independent sigma);
+ * ContinuousCritic continuous.py:99-169. */
+int64_t ts_ppo_param_count(int64_t obs_dim, int64_t act_dim);
+
+typedef struct ts_ppo_hparams {
+    double eps_clip;      /* ppo.py:140 */
+    double dual_clip;     /* ppo.py:141; <= 0 means None */
+    double vf_coef;       /* a2c.py / ppo.py:211 */
+    double ent_coef;      /* ppo.py:211 */
+    double max_grad_norm; /* algorithm_base.py:497-499; <= 0 means None */
+    double lr;            /* optim.py:89-110 */
+    double beta1, beta2;  /* Adam betas */
+    double adam_eps;      /* Adam eps */
+    int32_t value_clip;   /* ppo.py:199-206 */
+    int32_t adv_norm;     /* ppo.py:184-186 */
+} ts_ppo_hparams;
+
+/* No-grad inference passes of PPO._preprocess_batch / _add_returns_and_advantages
+ * (a2c.py:122-129, ppo.py:157-161), whole batch in one launch instead of max_batchsize
+ * chunks: v_out[i] = V(obs_i) (nullable), logp_out[i] = log N(act_i; mu(obs_i), sigma)
+ * (nullable; needs act).  obs float32[n, obs_dim], act float32[n, act_dim]. */
+int ts_ppo_infer(const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
+                 const float* act, int64_t n, float* v_out, float* logp_out,
+                 ts_stream_t stream);
+
+/* PPO._update_with_batch (tianshou/algorithm/modelfree/ppo.py:164-224) + Optimizer.step
+ * (algorithm_base.py:484-500): all `n_steps` minibatch gradient steps of one update() are
+ * enqueued by this one call.  Minibatch s uses rows perm[mb_offset[s] .. mb_offset[s+1])
+ * of the batch arrays (host-supplied np.random.permutation, batch.py:1209; mb_offset is a
+ * HOST array of n_steps+1 int64).  Per step: fused forward + clipped-surrogate / value /
+ * entropy loss + backward (fp32 MFMA), global-norm clip, Adam.  params / adam_m / adam_v
+ * (float32[P]) are updated in place; adam_step0 = number of Adam steps already taken.
+ * losses_out float32[n_steps,4] = (loss, clip_loss, vf_loss, ent_loss) per step (ppo.py:213-216).
+ * grads_out (nullable float32[P]) receives the unclipped gradient of the LAST step (tests). */
+int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
+                  int64_t adam_step0, int64_t obs_dim, int64_t act_dim, const float* obs,
+                  const float* act, const float* adv, const float* returns,
+                  const float* logp_old, const float* v_s, int64_t n, const int64_t* perm,
+                  const int64_t* h_mb_offset, int64_t n_steps, const ts_ppo_hparams* hp,
+                  float* losses_out, float* grads_out, ts_stream_t stream);
+
+/* Data-parallel variant, split around the gradient all-reduce (RCCL, done by the caller on
+ * the same stream between the two calls):
+ *   ts_ppo_grad : forward/backward of ONE minibatch -> grad_out float32[P] (sum over the local
+ *                 rows divided by `global_batch`), loss_parts_out float32[4] (local sums / global_batch)
+ *   ts_ppo_apply: clip by global norm + Adam using the (all-reduced) grad. */
+int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
+                const float* obs, const float* act, const float* adv, const float* returns,
+                const float* logp_old, const float* v_s, int64_t n, const int64_t* perm_rows,
+                int64_t n_rows, int64_t global_batch, double adv_mean, double adv_rstd,
+                const ts_ppo_hparams* hp, float* grad_out, float* loss_parts_out,
+                ts_stream_t stream);
+int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                 int64_t n_params, const float* grad, const ts_ppo_hparams* hp,
+                 ts_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSENGINE_H */

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares
+(no compute calls - there is no GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+from tianshou_amd import _lib
+from tianshou_amd.build import build_library
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build_library()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_symbols_exported(lib):
+    names = _lib.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f"declared in include/tsengine.h but not exported: {missing}"
+
+
+def test_version_and_error_string(lib):
+    lib.ts_version.restype = ctypes.c_char_p
+    lib.ts_last_error.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.ts_version()
+    assert isinstance(lib.ts_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu(lib):
+    # validation happens before any HIP call, so these are safe on a GPU-less host
+    lib.ts_last_error.restype = ctypes.c_char_p
+    rc = lib.ts_gae_scan(None, None, None, None, 0, None, None, None, ctypes.c_int64(0), None,
+                         ctypes.c_int64(-1), ctypes.c_double(0.99), ctypes.c_double(0.95),
+                         ctypes.c_double(1.0), ctypes.c_double(1.0), None, None, None, None, None, None)
+    assert rc == _lib.TS_ERR_INVALID_ARG and b"negative" in lib.ts_last_error()
+    rc = lib.ts_nstep_return(None, None, None, None, ctypes.c_int64(4), ctypes.c_int64(1),
+                             ctypes.c_int64(0), ctypes.c_int64(8), ctypes.c_double(0.9), None, None, None)
+    assert rc == _lib.TS_ERR_INVALID_ARG
+    rc = lib.ts_segtree_setitem(None, None, ctypes.c_int64(6), None, None, 1, ctypes.c_int64(1), None)
+    assert rc == _lib.TS_ERR_INVALID_ARG and b"power of two" in lib.ts_last_error()
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.dirname(_lib.__file__)
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(root, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "ts_oracle" not in text, f

@@ -1,0 +1,146 @@
+"""GPU parity: replay-buffer index math (bit-exact), row gathers, sum tree and PER weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+def test_index_math_against_reference_vectors():
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g = load("buffer_index.npz")
+    for s in range(int(g["n_scen"])):
+        t = f"s{s}_"
+        B = int(g[t + "offset"][-1])
+        done = g[t + "done"]
+        buf = DeviceReplayBuffer(offset=g[t + "offset"], last_index=g[t + "last_index"],
+                                 lengths=g[t + "lengths"], insertion=g[t + "insertion"],
+                                 rew=np.zeros(B), terminated=done, truncated=np.zeros(B, bool))
+        q = dev(g[t + "query"])
+        assert np.array_equal(buf.next(q).cpu().numpy(), g[t + "next"]), s
+        assert np.array_equal(buf.prev(q).cpu().numpy(), g[t + "prev"]), s
+        assert np.array_equal(buf.unfinished_index().cpu().numpy(), g[t + "unfinished"]), s
+        assert np.array_equal(buf.sample_indices(0).cpu().numpy(), g[t + "sample0"]), s
+    for lit in ("litA", "litB"):  # literal vectors of test/base/test_buffer.py:822-961
+        t = f"s{int(g[lit + '_scen'])}_"
+        done = g[t + "done"]
+        buf = DeviceReplayBuffer(offset=g[t + "offset"], last_index=g[t + "last_index"],
+                                 lengths=g[t + "lengths"], insertion=g[t + "insertion"],
+                                 rew=np.zeros(20), terminated=done, truncated=np.zeros(20, bool))
+        idx = dev(np.arange(20))
+        assert np.array_equal(buf.next(idx).cpu().numpy(), g[lit + "_next"])
+        assert np.array_equal(buf.prev(idx).cpu().numpy(), g[lit + "_prev"])
+        assert np.array_equal(buf.unfinished_index().cpu().numpy(), g[lit + "_unfinished"])
+
+
+def test_index_math_large_random_vs_oracle():
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    rng = np.random.default_rng(9)
+    E, T = 512, 2048
+    B = E * T
+    done = rng.random(B) < 0.01
+    lengths = np.full(E, T)
+    lengths[rng.integers(0, E, 40)] = rng.integers(0, T, 40)  # some ragged / empty sub-buffers
+    insertion = np.where(lengths == T, rng.integers(0, T, size=E), lengths)
+    offset = np.arange(E + 1) * T
+    last = offset[:-1] + (insertion - 1) % np.maximum(lengths, 1)
+    buf = DeviceReplayBuffer(offset=offset, last_index=last, lengths=lengths, insertion=insertion % T,
+                             rew=np.zeros(1), terminated=done, truncated=np.zeros(B, bool))
+    q = rng.integers(-B, 2 * B, size=20000)
+    args = (offset, done, last, lengths)
+    assert np.array_equal(buf.next(dev(q)).cpu().numpy(), O._next_index(q, *args))
+    assert np.array_equal(buf.prev(dev(q)).cpu().numpy(), O._prev_index(q, *args))
+    assert np.array_equal(buf.unfinished_index().cpu().numpy(), O.unfinished_index(*args))
+    assert np.array_equal(buf.sample_indices(0).cpu().numpy(),
+                          O.sample_indices_all(offset, lengths, insertion % T))
+    # full C2-shaped buffer: sample_indices(0) is the identity
+    full = DeviceReplayBuffer.from_vector_fill(E, rew=np.zeros(B), terminated=done, truncated=np.zeros(B, bool))
+    assert full.indices_are_identity()
+    assert torch.equal(full.sample_indices(0), torch.arange(B, device="cuda"))
+
+
+@pytest.mark.parametrize("shape,dtype", [((17,), np.float32), ((4, 84, 84), np.uint8), ((6,), np.float32),
+                                         ((), np.float64), ((3,), np.uint8)])
+def test_gather_rows(shape, dtype):
+    from tianshou_amd.buffer import gather_rows
+
+    rng = np.random.default_rng(0)
+    src = (rng.random((300, *shape)) * 255).astype(dtype)
+    idx = rng.integers(-300, 300, size=1000)
+    out = gather_rows(dev(src), dev(idx))
+    assert np.array_equal(out.cpu().numpy(), src[idx])
+    assert gather_rows(dev(src), dev(np.zeros(0, np.int64))).shape[0] == 0
+
+
+def test_segtree_against_reference_vectors():
+    from tianshou_amd import segtree as S
+
+    g = load("segtree_per.npz")
+    for c in range(int(g["n_tree"])):
+        size, bound = [int(x) for x in g[f"t{c}_size_bound"]]
+        tree = None
+        for r in range(3):
+            tree = dev(g[f"t{c}_r{r}_tree_before"])
+            S._setitem(tree, dev(g[f"t{c}_r{r}_idx"] + bound), dev(g[f"t{c}_r{r}_val"]))
+            assert np.array_equal(tree.cpu().numpy(), g[f"t{c}_r{r}_tree_after"]), (c, r)
+        q = dev(g[f"t{c}_query"].copy())
+        assert np.array_equal(S._get_prefix_sum_idx(q, bound, tree).cpu().numpy(), g[f"t{c}_prefix_idx"])
+        for (lo, hi), ref in zip(g[f"t{c}_range"].T, g[f"t{c}_range_sum"]):
+            assert float(S._reduce(tree, int(lo) + bound - 1, int(hi) + bound)) == ref
+
+
+def test_segtree_class_random_vs_oracle_large():
+    from tianshou_amd import segtree as S
+
+    rng = np.random.default_rng(2)
+    size = 1 << 20
+    t = S.SegmentTree(size)
+    ref = np.zeros(2 * t._bound)
+    for K in (1, 512, 4096, 70000):
+        idx = rng.integers(0, size, size=K)
+        idx[K // 2:] = idx[: K - K // 2]          # many duplicates: the later entry must win
+        val = rng.random(K)
+        t[dev(idx)] = dev(val)
+        O._setitem(ref, idx + t._bound, val)
+        assert np.array_equal(t._value.cpu().numpy(), ref)
+    q = rng.random(512) * ref[1]
+    assert np.array_equal(t.get_prefix_sum_idx(dev(q)).cpu().numpy(),
+                          O._get_prefix_sum_idx(q.copy(), t._bound, ref))
+    assert float(t.reduce()) == ref[1]
+    assert float(t.reduce(5, 1000)) == O._reduce(ref, 5 + t._bound - 1, 1000 + t._bound)
+
+
+def test_per_weights_against_reference_vectors():
+    from tianshou_amd import segtree as S
+
+    g = load("segtree_per.npz")
+    bound = int(g["per_bound"])
+    alpha, beta = [float(x) for x in g["per_alpha_beta"]]
+    per = S.PrioritizedWeights(bound, alpha, beta)
+    per.weight._value.copy_(dev(g["per_tree0"]))
+    per.prio_minmax.copy_(dev(g["per_prio_before"]))
+    per.update_weight(dev(g["per_upd_idx"]), dev(g["per_upd_td"]))
+    # float32 pow on the device vs NumPy's: a few ulp of float32
+    np.testing.assert_allclose(per.weight._value.cpu().numpy(), g["per_tree1"], rtol=5e-7)
+    np.testing.assert_allclose(per.prio_minmax.cpu().numpy(), g["per_prio_after"], rtol=1e-7)
+    per.weight._value.copy_(dev(g["per_tree1"]))
+    per.prio_minmax.copy_(dev(g["per_prio_after"]))
+    idx, w = per.sample(g["per_uniform"])
+    assert np.array_equal(idx.cpu().numpy(), g["per_sample_idx"])
+    np.testing.assert_allclose(w.cpu().numpy(), g["per_is_weight"], rtol=1e-12)

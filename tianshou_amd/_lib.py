@@ -1,0 +1,145 @@
+"""ctypes binding of libtsengine.so (the C ABI declared in include/tsengine.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing a kernel
+entry point raises.  Tensors cross the boundary as raw device pointers (`tensor.data_ptr()`),
+sizes as int64 and the current torch HIP stream as a `hipStream_t` handle; torch is only the
+owner of device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libtsengine.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "tsengine.h")
+
+TS_OK = 0
+TS_ERR_INVALID_ARG = -1
+TS_ERR_SHAPE = -2
+TS_ERR_HIP = -3
+TS_ERR_UNSUPPORTED = -4
+TS_ERR_WORKSPACE = -5
+
+
+class EngineError(RuntimeError):
+    """A libtsengine entry point returned a negative status."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libtsengine error {code}: {msg}")
+        self.code = code
+
+
+class PPOHParams(C.Structure):
+    """struct ts_ppo_hparams (include/tsengine.h)."""
+
+    _fields_ = [
+        ("eps_clip", C.c_double),
+        ("dual_clip", C.c_double),
+        ("vf_coef", C.c_double),
+        ("ent_coef", C.c_double),
+        ("max_grad_norm", C.c_double),
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("adam_eps", C.c_double),
+        ("value_clip", C.c_int32),
+        ("adv_norm", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every entry point include/tsengine.h declares (used by the CPU symbol test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", text)))
+
+
+def load() -> C.CDLL:
+    """Loads the library (building it is __graft_entry__.build()'s / tianshou_amd.build's job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run `python -m tianshou_amd.build` "
+            "(needs hipcc, cross-compiles for gfx950 without a GPU). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    lib.ts_version.restype = C.c_char_p
+    lib.ts_last_error.restype = C.c_char_p
+    lib.ts_gae_num_tiles.restype = C.c_int64
+    lib.ts_gae_num_tiles.argtypes = [C.c_int64]
+    if hasattr(lib, "ts_ppo_param_count"):
+        lib.ts_ppo_param_count.restype = C.c_int64
+        lib.ts_ppo_param_count.argtypes = [C.c_int64, C.c_int64]
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code == TS_OK:
+        return
+    msg = load().ts_last_error().decode("utf-8", "replace")
+    if code == TS_ERR_SHAPE:
+        raise ValueError(msg)
+    raise EngineError(code, msg)
+
+
+def ptr(t) -> C.c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def i64(v) -> C.c_int64:
+    return C.c_int64(int(v))
+
+
+def f64(v) -> C.c_double:
+    return C.c_double(float(v))
+
+
+def current_stream(device=None) -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Workspace:
+    """ts_workspace handle bound to one device (one per stream in concurrent use)."""
+
+    def __init__(self, device_index: int = 0, max_bytes: int = 0):
+        self._h = C.c_void_p(0)
+        check(load().ts_workspace_create(C.byref(self._h), C.c_int(device_index), C.c_size_t(max_bytes)))
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def close(self) -> None:
+        if self._h:
+            load().ts_workspace_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ws: dict[int, Workspace] = {}
+
+
+def default_workspace(device_index: int) -> Workspace:
+    ws = _default_ws.get(device_index)
+    if ws is None:
+        ws = _default_ws[device_index] = Workspace(device_index)
+    return ws

@@ -1,0 +1,189 @@
+"""Device-resident mirror of the replay-buffer state the learn() path reads.
+
+Mirrors the read side of ``ReplayBuffer`` / ``ReplayBufferManager`` / ``VectorReplayBuffer``
+(tianshou/data/buffer/buffer_base.py, manager.py, vecbuf.py): same method names, same index
+semantics, torch tensors on an MI355X instead of NumPy arrays.  The write side (``add``) stays
+with the reference's collector; ``from_arrays`` / ``from_tianshou`` take a snapshot.
+
+Layout in HBM (structure of arrays, one allocation per key, row-major):
+    obs, obs_next  [B, ...]   dtype as collected (f32 / u8)
+    act            [B, ...]
+    rew            [B]        float64 (buffer_base.py:492 stores rewards as float)
+    terminated, truncated, done   [B] uint8
+    offset [E+1], last_index [E], lengths [E], insertion [E]   int64  (manager.py:50-52)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _dev_index(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise RuntimeError("tianshou_amd kernels need tensors on an MI355X (cuda/hip device); "
+                           "there is no CPU fallback")
+    return t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+
+def _i64_dev(x, device) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.int64).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.int64)), device=device)
+
+
+def _u8_dev(x, device) -> torch.Tensor:
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device).to(torch.uint8).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x).astype(bool).astype(np.uint8)), device=device)
+
+
+def _next_index(index, offset, done, last_index, lengths) -> torch.Tensor:
+    """manager.py:339-363, same argument order; int64 device tensors in and out."""
+    return _step(True, index, offset, done, last_index, lengths)
+
+
+def _prev_index(index, offset, done, last_index, lengths) -> torch.Tensor:
+    """manager.py:311-336."""
+    return _step(False, index, offset, done, last_index, lengths)
+
+
+def _step(nxt: bool, index, offset, done, last_index, lengths) -> torch.Tensor:
+    dev = done.device
+    index = _i64_dev(index, dev)
+    shape = index.shape
+    index = index.reshape(-1)
+    out = torch.empty_like(index)
+    E = offset.numel() - 1
+    if lengths.numel() != E or last_index.numel() != E:
+        raise ValueError("offset / last_index / lengths size mismatch")
+    fn = _lib.load().ts_next_index if nxt else _lib.load().ts_prev_index
+    _lib.check(fn(_lib.ptr(index), _lib.i64(index.numel()), _lib.ptr(offset), _lib.i64(E),
+                  _lib.ptr(done), _lib.ptr(last_index), _lib.ptr(lengths), _lib.ptr(out),
+                  _lib.current_stream(dev)))
+    return out.reshape(shape)
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """src[index] for a contiguous [B, ...] tensor (buffer_base.py:605-649 fancy-index gather)."""
+    if not src.is_contiguous():
+        raise ValueError("gather_rows needs a contiguous source")
+    index = _i64_dev(index, src.device).reshape(-1)
+    row_bytes = src.element_size() * int(np.prod(src.shape[1:], dtype=np.int64))
+    out = torch.empty((index.numel(), *src.shape[1:]), dtype=src.dtype, device=src.device)
+    _lib.check(_lib.load().ts_gather_rows(_lib.ptr(src), _lib.i64(src.shape[0]), _lib.i64(row_bytes),
+                                          _lib.ptr(index), _lib.i64(index.numel()), _lib.ptr(out),
+                                          _lib.current_stream(src.device)))
+    return out
+
+
+class DeviceReplayBuffer:
+    """Read-side mirror of ReplayBufferManager on one GPU."""
+
+    def __init__(self, *, offset, last_index, lengths, insertion, rew, terminated, truncated,
+                 obs=None, act=None, obs_next=None, device="cuda"):
+        device = torch.device(device)
+        self.device = device
+        # host copy of the (tiny) manager state: the host decides launch sizes from it
+        self.h_offset = np.ascontiguousarray(np.asarray(offset, dtype=np.int64))
+        self.h_last_index = np.ascontiguousarray(np.asarray(last_index, dtype=np.int64))
+        self.h_lengths = np.ascontiguousarray(np.asarray(lengths, dtype=np.int64))
+        self.h_insertion = np.ascontiguousarray(np.asarray(insertion, dtype=np.int64))
+        self.buffer_num = int(self.h_offset.size - 1)
+        self.maxsize = int(self.h_offset[-1])
+        self.offset = _i64_dev(self.h_offset, device)
+        self.last_index = _i64_dev(self.h_last_index, device)
+        self.lengths = _i64_dev(self.h_lengths, device)
+        self.insertion = _i64_dev(self.h_insertion, device)
+        self.rew = (rew.to(device=device, dtype=torch.float64) if isinstance(rew, torch.Tensor)
+                    else torch.as_tensor(np.asarray(rew, dtype=np.float64), device=device)).contiguous()
+        self.terminated = _u8_dev(terminated, device)
+        self.truncated = _u8_dev(truncated, device)
+        self.done = (self.terminated | self.truncated).contiguous()       # manager.py:150
+        to = lambda x: None if x is None else (  # noqa: E731
+            x.to(device) if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), device=device)
+        ).contiguous()
+        self.obs, self.act, self.obs_next = to(obs), to(act), to(obs_next)
+        self._ws = _lib.default_workspace(_dev_index(self.done))
+
+    # -- constructors -------------------------------------------------------------------------
+    @classmethod
+    def from_vector_fill(cls, n_env: int, **arrays):
+        """A VectorReplayBuffer(B, n_env) whose every sub-buffer was written exactly once from
+        slot 0 to T-1 (synthetic rollouts)."""
+        B = int(arrays["rew"].shape[0])
+        T = B // n_env
+        if T * n_env != B:
+            raise ValueError("buffer size must be divisible by n_env")
+        offset = np.arange(n_env + 1, dtype=np.int64) * T
+        return cls(offset=offset, last_index=offset[:-1] + T - 1,
+                   lengths=np.full(n_env, T, np.int64), insertion=np.zeros(n_env, np.int64), **arrays)
+
+    @classmethod
+    def from_tianshou(cls, buffer, device="cuda"):
+        """Snapshot of a reference ReplayBuffer / ReplayBufferManager (duck-typed; only reads
+        public attributes plus _extend_offset/_lengths/_insertion_idx, manager.py:50-52)."""
+        if hasattr(buffer, "buffers"):
+            offset = buffer._extend_offset
+            lengths = buffer._lengths
+            insertion = [b._insertion_idx for b in buffer.buffers]
+        else:
+            offset = [0, buffer.maxsize]
+            lengths = [len(buffer)]
+            insertion = [buffer._insertion_idx]
+        meta = buffer._meta
+        has = lambda k: k in meta.get_keys()  # noqa: E731
+        return cls(offset=offset, last_index=np.array(buffer.last_index), lengths=np.array(lengths),
+                   insertion=insertion, rew=np.asarray(buffer.rew),
+                   terminated=np.asarray(buffer.terminated), truncated=np.asarray(buffer.truncated),
+                   obs=np.asarray(buffer.obs), act=np.asarray(buffer.act),
+                   obs_next=np.asarray(buffer.obs_next) if has("obs_next") else None, device=device)
+
+    # -- reference API ------------------------------------------------------------------------
+    def __len__(self) -> int:
+        return int(self.h_lengths.sum())
+
+    def next(self, index) -> torch.Tensor:
+        return _next_index(index, self.offset, self.done, self.last_index, self.lengths)
+
+    def prev(self, index) -> torch.Tensor:
+        return _prev_index(index, self.offset, self.done, self.last_index, self.lengths)
+
+    def unfinished_index(self) -> torch.Tensor:
+        """manager.py:85-91 -> int64[<=E] device tensor (one tiny D2H for the count)."""
+        out, n = self._unfinished_raw()
+        return out[: int(n.item())]
+
+    def _unfinished_raw(self):
+        out = torch.empty(self.buffer_num, dtype=torch.int64, device=self.device)
+        n = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.check(_lib.load().ts_unfinished_index(
+            _lib.ptr(self.offset), _lib.i64(self.buffer_num), _lib.ptr(self.done),
+            _lib.ptr(self.last_index), _lib.ptr(self.lengths), _lib.ptr(out), _lib.ptr(n),
+            _lib.current_stream(self.device)))
+        return out, n
+
+    def sample_indices(self, batch_size: int | None) -> torch.Tensor:
+        """Only the deterministic branch is on the device: batch_size == 0 -> every valid index,
+        sub-buffer-major and time-ordered (manager.py:216-234).  Random sampling consumes the
+        buffer's own RandomState in the reference (buffer_base.py:98,517) and stays there."""
+        if batch_size != 0:
+            raise NotImplementedError("random sample_indices stays on the host RNG of the reference; "
+                                      "pass its indices to the engine")
+        total = len(self)
+        out = torch.empty(total, dtype=torch.int64, device=self.device)
+        _lib.check(_lib.load().ts_sample_indices_all(
+            self._ws.handle, _lib.ptr(self.offset), _lib.i64(self.buffer_num), _lib.ptr(self.lengths),
+            _lib.ptr(self.insertion), _lib.i64(total), _lib.ptr(out), _lib.current_stream(self.device)))
+        return out
+
+    def indices_are_identity(self) -> bool:
+        """True when sample_indices(0) == arange(B): every sub-buffer full and unwrapped."""
+        size = np.diff(self.h_offset)
+        return bool(np.all(self.h_lengths == size) and np.all(self.h_insertion % size == 0))
+
+    def gather(self, key: str, index) -> torch.Tensor:
+        return gather_rows(getattr(self, key), index)

@@ -1,0 +1,59 @@
+// ts_common.h -- shared host-side helpers of libtsengine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/tsengine.h"
+
+namespace ts {
+
+// thread-local error string returned by ts_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define TS_HIP_CHECK(expr)                                                                 \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ts::fail(TS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                           \
+    } while (0)
+
+#define TS_LAUNCH_CHECK()                                                                  \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess)                                                              \
+            return ts::fail(TS_ERR_HIP, "kernel launch failed: %s (%s:%d)",               \
+                            hipGetErrorString(_e), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define TS_REQUIRE(cond, code, ...)                        \
+    do {                                                   \
+        if (!(cond)) return ts::fail((code), __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t as_stream(ts_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace ts
+
+// Opaque workspace: one growable device allocation carved by the entry points.
+struct ts_workspace {
+    int device;
+    size_t max_bytes;
+    void* base;
+    size_t bytes;
+    // persistent sum-tree winner table (int32[bound], kept at -1 between calls)
+    int32_t* winner;
+    int64_t winner_len;
+};
+
+namespace ts {
+// Ensures ws->base holds at least `bytes`; (re)allocation synchronises the device once.
+int ws_reserve(ts_workspace* ws, size_t bytes);
+int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out);
+}  // namespace ts

@@ -1,0 +1,248 @@
+// ts_index.hip -- replay-buffer index math and row gathers for gfx950 (integer work, bit-exact).
+//
+// Replaces _next_index/_prev_index (tianshou/data/buffer/manager.py:311-363),
+// ReplayBufferManager.unfinished_index (:85-91), sample_indices(0) (:216-234) and the
+// fancy-index gathers of ReplayBuffer.__getitem__ (tianshou/data/buffer/buffer_base.py:605-649).
+// Roofline: HBM / latency (8 B index read + 8 B write + one 1-byte `done` gather per query).
+#include "ts_common.h"
+
+namespace {
+
+__device__ __forceinline__ int64_t pymod(int64_t a, int64_t m) {
+    const int64_t r = a % m;
+    return r < 0 ? r + m : r;
+}
+
+// largest e with offset[e] <= idx; offset ascending with offset[0] == 0 and idx < offset[E]
+__device__ __forceinline__ int64_t find_sub(const int64_t* offset, int64_t E, int64_t idx) {
+    int64_t lo = 0, hi = E;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (offset[mid] <= idx) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool NEXT>
+__global__ void step_index_kernel(const int64_t* index, int64_t I, const int64_t* offset,
+                                  int64_t E, const uint8_t* done, const int64_t* last_index,
+                                  const int64_t* lengths, int64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = offset[E];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < I; i += stride) {
+        const int64_t idx = pymod(index[i], total);         // manager.py:319 / :347
+        const int64_t e = find_sub(offset, E, idx);
+        const int64_t start = offset[e];
+        const int64_t len = lengths[e];
+        const int64_t cur_len = len > 1 ? len : 1;          // max(1, cur_len) :330 / :358
+        if (NEXT) {
+            const int64_t end_flag = (done[idx] != 0) | (idx == last_index[e]);     // :361
+            out[i] = pymod(idx - start + 1 - end_flag, cur_len) + start;            // :362
+        } else {
+            const int64_t subind = pymod(idx - start - 1, cur_len);                 // :333
+            const int64_t end_flag = (done[subind + start] != 0) | (subind + start == last_index[e]);
+            out[i] = pymod(subind + end_flag, cur_len) + start;                     // :335
+        }
+    }
+}
+
+// single workgroup, order-preserving compaction over the E sub-buffers
+__global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
+                                  const int64_t* lengths, int64_t* out, int64_t* n_out) {
+    __shared__ int wave_cnt[16];
+    __shared__ int64_t base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int64_t e0 = 0; e0 < E; e0 += blockDim.x) {
+        const int64_t e = e0 + threadIdx.x;
+        bool keep = false;
+        int64_t last = 0;
+        if (e < E) {
+            last = last_index[e];
+            keep = lengths[e] > 0 && done[last] == 0;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            if (w < wave) woff += wave_cnt[w];
+            tot += wave_cnt[w];
+        }
+        const int64_t base = base_s;
+        if (keep) out[base + woff + before] = last;
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = base_s;
+}
+
+// single workgroup exclusive prefix sum of lengths -> prefix[E+1]
+__global__ void lengths_prefix_kernel(const int64_t* lengths, int64_t E, int64_t* prefix) {
+    __shared__ int64_t wave_sum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t e0 = 0; e0 < E; e0 += blockDim.x) {
+        const int64_t e = e0 + threadIdx.x;
+        const int64_t v = e < E ? lengths[e] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            if (w < wave) woff += wave_sum[w];
+            tot += wave_sum[w];
+        }
+        const int64_t carry = carry_s;
+        if (e < E) prefix[e] = carry + woff + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) prefix[E] = carry_s;
+}
+
+__global__ void sample_all_kernel(const int64_t* offset, int64_t E, const int64_t* lengths,
+                                  const int64_t* insertion, const int64_t* prefix, int64_t total,
+                                  int64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+        // sub-buffer e with prefix[e] <= p < prefix[e+1] (empty sub-buffers have equal bounds)
+        int64_t lo = 0, hi = E;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t e = lo;
+        const int64_t j = p - prefix[e];
+        const int64_t len = lengths[e];
+        // [insertion, len) ++ [0, insertion)   (buffer_base.py:519-524); insertion == len when
+        // the sub-buffer has not wrapped yet, which makes the first range empty.
+        int64_t slot = insertion[e] + j;
+        if (slot >= len) slot -= len;
+        out[p] = offset[e] + slot;
+    }
+}
+
+template <typename V>
+__global__ void gather_rows_vec_kernel(const V* src, int64_t n_src, int64_t row_vecs,
+                                       const int64_t* index, int64_t I, V* out) {
+    const int64_t total = I * row_vecs;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / row_vecs, k = t - i * row_vecs;
+        int64_t r = index[i];
+        if (r < 0) r += n_src;  // NumPy negative indexing
+        out[t] = src[r * row_vecs + k];
+    }
+}
+
+inline int grid_for(int64_t n, int block) {
+    int64_t g = ts::ceil_div(n, block);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int step_index(bool next, const int64_t* index, int64_t I, const int64_t* offset, int64_t E,
+                      const uint8_t* done, const int64_t* last_index, const int64_t* lengths,
+                      int64_t* out, ts_stream_t stream) {
+    TS_REQUIRE(I >= 0 && E >= 1, TS_ERR_INVALID_ARG, "ts_%s_index: bad size", next ? "next" : "prev");
+    if (I == 0) return TS_OK;
+    TS_REQUIRE(index && offset && done && last_index && lengths && out, TS_ERR_INVALID_ARG,
+               "ts_%s_index: NULL array argument", next ? "next" : "prev");
+    hipStream_t s = ts::as_stream(stream);
+    if (next)
+        hipLaunchKernelGGL(step_index_kernel<true>, dim3(grid_for(I, 256)), dim3(256), 0, s, index,
+                           I, offset, E, done, last_index, lengths, out);
+    else
+        hipLaunchKernelGGL(step_index_kernel<false>, dim3(grid_for(I, 256)), dim3(256), 0, s, index,
+                           I, offset, E, done, last_index, lengths, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_next_index(const int64_t* index, int64_t I, const int64_t* offset, int64_t E,
+                  const uint8_t* done, const int64_t* last_index, const int64_t* lengths,
+                  int64_t* out, ts_stream_t stream) {
+    return step_index(true, index, I, offset, E, done, last_index, lengths, out, stream);
+}
+
+int ts_prev_index(const int64_t* index, int64_t I, const int64_t* offset, int64_t E,
+                  const uint8_t* done, const int64_t* last_index, const int64_t* lengths,
+                  int64_t* out, ts_stream_t stream) {
+    return step_index(false, index, I, offset, E, done, last_index, lengths, out, stream);
+}
+
+int ts_unfinished_index(const int64_t* offset, int64_t E, const uint8_t* done,
+                        const int64_t* last_index, const int64_t* lengths, int64_t* out,
+                        int64_t* n_out, ts_stream_t stream) {
+    (void)offset;
+    TS_REQUIRE(E >= 1, TS_ERR_INVALID_ARG, "ts_unfinished_index: E must be >= 1");
+    TS_REQUIRE(done && last_index && lengths && out && n_out, TS_ERR_INVALID_ARG,
+               "ts_unfinished_index: NULL array argument");
+    hipLaunchKernelGGL(unfinished_kernel, dim3(1), dim3(1024), 0, ts::as_stream(stream), E, done,
+                       last_index, lengths, out, n_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
+                          const int64_t* lengths, const int64_t* insertion, int64_t total,
+                          int64_t* out, ts_stream_t stream) {
+    TS_REQUIRE(E >= 1 && total >= 0, TS_ERR_INVALID_ARG, "ts_sample_indices_all: bad size");
+    if (total == 0) return TS_OK;
+    TS_REQUIRE(offset && lengths && insertion && out, TS_ERR_INVALID_ARG,
+               "ts_sample_indices_all: NULL array argument");
+    int rc = ts::ws_reserve(ws, sizeof(int64_t) * (size_t)(E + 1));
+    if (rc != TS_OK) return rc;
+    int64_t* prefix = reinterpret_cast<int64_t*>(ws->base);
+    hipStream_t s = ts::as_stream(stream);
+    hipLaunchKernelGGL(lengths_prefix_kernel, dim3(1), dim3(1024), 0, s, lengths, E, prefix);
+    hipLaunchKernelGGL(sample_all_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, offset, E,
+                       lengths, insertion, prefix, total, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const int64_t* index,
+                   int64_t I, void* out, ts_stream_t stream) {
+    TS_REQUIRE(I >= 0 && row_bytes >= 0 && n_rows_src >= 0, TS_ERR_INVALID_ARG,
+               "ts_gather_rows: negative size");
+    if (I == 0 || row_bytes == 0) return TS_OK;
+    TS_REQUIRE(src && index && out, TS_ERR_INVALID_ARG, "ts_gather_rows: NULL array argument");
+    hipStream_t s = ts::as_stream(stream);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out) |
+                        (uintptr_t)row_bytes;
+    if ((a & 15u) == 0) {
+        const int64_t rv = row_bytes / 16;
+        hipLaunchKernelGGL(gather_rows_vec_kernel<uint4>, dim3(grid_for(I * rv, 256)), dim3(256), 0,
+                           s, (const uint4*)src, n_rows_src, rv, index, I, (uint4*)out);
+    } else if ((a & 3u) == 0) {
+        const int64_t rv = row_bytes / 4;
+        hipLaunchKernelGGL(gather_rows_vec_kernel<uint32_t>, dim3(grid_for(I * rv, 256)), dim3(256),
+                           0, s, (const uint32_t*)src, n_rows_src, rv, index, I, (uint32_t*)out);
+    } else {
+        hipLaunchKernelGGL(gather_rows_vec_kernel<uint8_t>, dim3(grid_for(I * row_bytes, 256)),
+                           dim3(256), 0, s, (const uint8_t*)src, n_rows_src, row_bytes, index, I,
+                           (uint8_t*)out);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // extern "C"
