@@ -227,19 +227,25 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   const int64_t* h_mb_offset, int64_t n_steps, const ts_ppo_hparams* hp,
                   float* losses_out, float* grads_out, ts_stream_t stream);
 
-/* Data-parallel variant, split around the gradient all-reduce (RCCL, done by the caller on
- * the same stream between the two calls):
- *   ts_ppo_grad : forward/backward of ONE minibatch -> grad_out float32[P] (sum over the local
- *                 rows divided by `global_batch`), loss_parts_out float32[4] (local sums / global_batch)
- *   ts_ppo_apply: clip by global norm + Adam using the (all-reduced) grad. */
+/* Data-parallel variant, split around the gradient all-reduce (RCCL, issued by the caller on
+ * the same stream between the two calls; the reference has no equivalent - its only multi-GPU
+ * path is nn.DataParallel, tianshou/utils/net/common.py:473-515):
+ *   ts_ppo_grad : forward/backward of ONE local minibatch shard (rows perm_rows[0..n_rows), or
+ *                 the first n_rows rows when perm_rows is NULL) -> grad_out float32[P] = sum over
+ *                 the local rows / global_batch, loss_parts_out float32[4] = (loss, clip, vf, ent)
+ *                 with clip / vf as local sums / global_batch (all-reduce-sum them too; recompute
+ *                 loss = clip + vf_coef*vf - ent_coef*ent afterwards).  adv_stats (device
+ *                 float32[2] = {mean, std} of the GLOBAL minibatch) is required when hp->adv_norm.
+ *   ts_ppo_apply: clip by global norm + Adam step number `adam_step` (1-based) using the
+ *                 all-reduced gradient; grad_scratch float32[P] is clobbered. */
 int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
                 const float* obs, const float* act, const float* adv, const float* returns,
                 const float* logp_old, const float* v_s, int64_t n, const int64_t* perm_rows,
-                int64_t n_rows, int64_t global_batch, double adv_mean, double adv_rstd,
+                int64_t n_rows, int64_t global_batch, const float* adv_stats,
                 const ts_ppo_hparams* hp, float* grad_out, float* loss_parts_out,
                 ts_stream_t stream);
-int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step,
-                 int64_t n_params, const float* grad, const ts_ppo_hparams* hp,
+int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                 int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
                  ts_stream_t stream);
 
 #ifdef __cplusplus

@@ -260,7 +260,7 @@ def update(state: PPOState, cfg: PPOConfig, data: dict, pre: dict, batch_size: i
            repeat: int, perms: list[np.ndarray], recompute=None, collect_grads: bool = False):
     """ppo.py:164-224.  ``perms[r]`` is the np.random.permutation(N) the reference draws in
     repeat r (batch.py:1209); the engine receives the same host-supplied permutations.
-    Returns per-step arrays (loss, clip, vf, ent) [+ flat grads of the first step]."""
+    Returns per-step arrays (loss, clip, vf, ent) [+ the flat UNCLIPPED gradient of the last step]."""
     obs, act = data["obs"], data["act"]
     n = obs.shape[0]
     size = batch_size or -1
@@ -283,11 +283,11 @@ def update(state: PPOState, cfg: PPOConfig, data: dict, pre: dict, batch_size: i
             for t in plist:
                 if t.grad is None:
                     t.grad = torch.zeros_like(t)
+            if collect_grads:  # unclipped gradient of the most recent step
+                first_grads = torch.cat([p[k].grad.detach().reshape(-1) for k in PARAM_ORDER]).clone()
             if cfg.max_grad_norm is not None:
                 torch.nn.utils.clip_grad_norm_(plist, max_norm=cfg.max_grad_norm)
             grads = {k: p[k].grad.detach() for k in PARAM_ORDER}
-            if collect_grads and first_grads is None:
-                first_grads = torch.cat([grads[k].reshape(-1) for k in PARAM_ORDER]).clone()
             _adam_step(state, cfg, grads)
             losses.append([loss.item(), clip_loss.item(), vf_loss.item(), ent_loss.item()])
     out = np.asarray(losses, dtype=np.float64).reshape(-1, 4)

@@ -1,0 +1,238 @@
+"""GPU parity: fused PPO MLP kernels (fp32 MFMA, through the C ABI) vs
+  (a) the torch-fp32 CPU oracle (oracle/oracle_ppo.py) on seeded inputs, and
+  (b) the committed outputs of the unmodified reference PPO.update() (tests/golden/ppo_*.npz).
+Tolerance: rtol 1e-5 on advantages / log-probs / losses (BASELINE.json north_star), with an
+absolute floor for values that are differences of O(1) quantities."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import oracle_ppo as OP
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x), device="cuda")
+    return t if dtype is None else t.to(dtype)
+
+
+def random_problem(n, obs_dim, act_dim, seed):
+    rng = np.random.default_rng(seed)
+    params = OP.init_params(obs_dim, act_dim, seed=seed)
+    # move away from the symmetric init so that every gradient path is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in params:
+        params[k] = params[k] + 0.05 * torch.randn(params[k].shape, generator=g)
+    data = dict(
+        obs=rng.normal(size=(n, obs_dim)).astype(np.float32),
+        obs_next=rng.normal(size=(n, obs_dim)).astype(np.float32),
+        act=rng.normal(size=(n, act_dim)).astype(np.float32),
+        rew=rng.normal(size=n).astype(np.float32).astype(np.float64),
+        terminated=rng.random(n) < 0.02,
+        truncated=np.zeros(n, bool),
+    )
+    return params, data
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 70001])
+@pytest.mark.parametrize("obs_dim,act_dim", [(17, 6), (4, 2), (11, 3), (27, 8), (31, 1)])
+def test_infer_matches_torch_forward(n, obs_dim, act_dim):
+    from tianshou_amd import ppo as P
+
+    if n == 70001 and (obs_dim, act_dim) != (17, 6):
+        pytest.skip("large size only for the headline shape")
+    params, data = random_problem(n, obs_dim, act_dim, seed=n + obs_dim)
+    flat = OP.flatten_params(params)
+    assert flat.numel() == P.param_count(obs_dim, act_dim)
+    obs, act = torch.from_numpy(data["obs"]), torch.from_numpy(data["act"])
+    with torch.no_grad():
+        v_ref = OP.critic_forward(params, obs).flatten().numpy()
+        mu, sigma = OP.actor_forward(params, obs)
+        lp_ref = OP.dist_of(mu, sigma).log_prob(act).numpy()
+    v, lp = P.infer(flat.cuda(), obs_dim, act_dim, obs.cuda(), act.cuda(), want_v=True, want_logp=True)
+    np.testing.assert_allclose(v.cpu().numpy(), v_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_ref, rtol=1e-5, atol=1e-5)
+
+
+CFGS = {
+    "mujoco": dict(eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, value_clip=True,
+                   advantage_normalization=False, return_scaling=True, lr=3e-4),
+    "defaults": dict(dual_clip=3.0, recompute_advantage=True, lr=1e-3),
+    "plain": dict(value_clip=False, advantage_normalization=True, ent_coef=0.01, vf_coef=0.5,
+                  max_grad_norm=None, lr=1e-3),
+}
+
+
+def both_cfgs(name):
+    from tianshou_amd import ppo as P
+
+    kw = CFGS[name]
+    return OP.PPOConfig(max_batchsize=4096, **kw), P.PPOConfig(**kw)
+
+
+def run_oracle(params, data, ocfg, batch_size, repeat, perms, n_env):
+    st = OP.PPOState(params={k: v.clone() for k, v in params.items()})
+    n = len(data["rew"])
+    bs = O.BufferState.from_vector_fill(data["rew"], data["terminated"], data["truncated"], n_env)
+    idx, unf = bs.sample_indices_all(), bs.unfinished_index()
+    args = (torch.from_numpy(data["obs"]), torch.from_numpy(data["obs_next"]), torch.from_numpy(data["act"]),
+            data["rew"], data["terminated"], data["truncated"], idx, unf)
+    pre = OP.preprocess(st, ocfg, *args)
+
+    def recompute():
+        return OP.add_returns_and_advantages(st, ocfg, args[0], args[1], *args[3:])
+
+    losses, grads = OP.update(st, ocfg, {"obs": args[0], "act": args[2]}, pre, batch_size, repeat, perms,
+                              recompute=recompute, collect_grads=True)
+    return st, pre, losses, grads, unf
+
+
+@pytest.mark.parametrize("cfg_name", ["mujoco", "defaults", "plain"])
+@pytest.mark.parametrize("n,n_env,batch_size,repeat", [(512, 8, 128, 2), (1000, 4, 300, 2), (4096, 16, 4096, 1)])
+def test_update_matches_oracle(cfg_name, n, n_env, batch_size, repeat):
+    from tianshou_amd import ppo as P
+
+    params, data = random_problem(n, 17, 6, seed=n)
+    ocfg, cfg = both_cfgs(cfg_name)
+    rng = np.random.default_rng(n + 1)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    st, pre_o, losses_o, grads_o, unf = run_oracle(params, data, ocfg, batch_size, repeat, perms, n_env)
+
+    eng = P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg)
+    b = eng.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                       dev(data["terminated"]), dev(data["truncated"]), dev(unf))
+    np.testing.assert_allclose(b["v_s"].cpu().numpy(), pre_o["v_s"].numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(b["adv"].cpu().numpy(), pre_o["adv"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b["returns"].cpu().numpy(), pre_o["returns"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b["logp_old"].cpu().numpy(), pre_o["logp_old"].numpy(), rtol=1e-5, atol=1e-5)
+    losses, steps, grads = eng.update(b, batch_size, repeat, perms, want_grad=True)
+    assert steps == losses_o.shape[0]
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-5, atol=2e-6)
+    gscale = float(grads_o.abs().max())
+    np.testing.assert_allclose(grads.cpu().numpy(), grads_o.numpy(), rtol=1e-4, atol=1e-6 * max(gscale, 1.0))
+    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=2e-6)
+    assert eng.adam_step == st.adam_step
+    np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+
+
+def _cfg_from_golden(g):
+    from tianshou_amd import ppo as P
+
+    c = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))
+    return P.PPOConfig(
+        gamma=c["gamma"], gae_lambda=c["gae_lambda"], eps_clip=c["eps_clip"],
+        dual_clip=(c["dual_clip"] or None), value_clip=bool(c["value_clip"]),
+        advantage_normalization=bool(c["advantage_normalization"]),
+        recompute_advantage=bool(c["recompute_advantage"]), vf_coef=c["vf_coef"], ent_coef=c["ent_coef"],
+        max_grad_norm=(c["max_grad_norm"] or None), return_scaling=bool(c["return_scaling"]), lr=c["lr"])
+
+
+@pytest.mark.parametrize("tag", ["mujoco", "defaults"])
+def test_update_matches_reference_golden(tag):
+    """Same Batch inputs, initial weights and permutations as the reference run that produced
+    tests/golden/ppo_<tag>.npz; compares every intermediate the reference exposes."""
+    from tianshou_amd import ppo as P
+    from tianshou_amd.buffer import DeviceReplayBuffer
+    from tianshou_amd.returns import cut_positions
+
+    g = load(f"ppo_{tag}.npz")
+    E, T, obs_dim, act_dim, batch_size, repeat, n_updates = [int(x) for x in g["dims"]]
+    eng = P.PPOEngine(obs_dim, act_dim, dev(g["flat_params0"]), _cfg_from_golden(g))
+    for u in range(n_updates):
+        pre_ = "" if u == 0 else f"u{u}_"
+        buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"],
+                                 lengths=g["buf_lengths"], insertion=g["buf_insertion"],
+                                 rew=g[pre_ + "rew"], terminated=g[pre_ + "terminated"],
+                                 truncated=g[pre_ + "truncated"], obs=g[pre_ + "obs"],
+                                 act=g[pre_ + "act"], obs_next=g[pre_ + "obs_next"])
+        indices = buf.sample_indices(0)
+        cut, d_n = cut_positions(buf, indices)
+        b = eng.preprocess(buf.gather("obs", indices), buf.gather("obs_next", indices),
+                           buf.gather("act", indices), buf.gather("rew", indices),
+                           buf.gather("terminated", indices), buf.gather("truncated", indices), cut, d_n)
+        if u == 0:
+            assert np.array_equal(indices.cpu().numpy(), g["pre_indices"])
+            np.testing.assert_allclose(b["v_s"].cpu().numpy(), g["pre_v_s"], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(b["adv"].cpu().numpy(), g["pre_adv"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(b["returns"].cpu().numpy(), g["pre_returns"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(b["logp_old"].cpu().numpy(), g["pre_logp_old"], rtol=1e-5, atol=1e-5)
+        losses, steps = eng.update(b, batch_size, repeat, list(g[f"u{u}_perms"]))
+        assert steps == int(g[f"u{u}_gradient_steps"])
+        np.testing.assert_allclose(losses.cpu().numpy(), g[f"u{u}_losses"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(eng.params.cpu().numpy(), g[f"u{u}_flat_params"], rtol=1e-4, atol=3e-6)
+        np.testing.assert_allclose(eng.adam_m.cpu().numpy(), g[f"u{u}_adam_m"], rtol=1e-3, atol=1e-7)
+        np.testing.assert_allclose(eng.adam_v.cpu().numpy(), g[f"u{u}_adam_v"], rtol=1e-3, atol=1e-10)
+        np.testing.assert_allclose(eng.ret_rms, g[f"u{u}_ret_rms"], rtol=1e-5)  # stats of fp32-accurate returns
+
+
+def test_update_linearity_property_full_size():
+    """Size-independent property at BASELINE's full minibatch (65536 rows): the gradient of a
+    minibatch equals the row-count-weighted mean of the gradients of its two halves (the loss is a
+    mean over rows when advantage normalisation is off)."""
+    from tianshou_amd import ppo as P
+
+    n = 65536
+    params, data = random_problem(n, 17, 6, seed=7)
+    cfg = P.PPOConfig(**CFGS["mujoco"])
+    cfg.return_scaling = False
+    cfg.lr = 0.0
+    eng = P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg)
+    unf = np.arange(512) * 128 + 127
+    b = eng.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                       dev(data["terminated"]), dev(data["truncated"]), dev(unf))
+    ident = [np.arange(n)]
+    _, _, g_full = eng.update(b, n, 1, ident, want_grad=True)
+    half = {k: (v[: n // 2] if isinstance(v, torch.Tensor) and v.shape[:1] == (n,) else v) for k, v in b.items()}
+    _, _, g_a = eng.update(half, n // 2, 1, [np.arange(n // 2)], want_grad=True)
+    perm_b = [np.arange(n // 2, n)]
+    hp = eng.cfg
+    losses, g_b = eng._run_steps(b, dev(perm_b[0]), [0, n // 2], want_grad=True)
+    np.testing.assert_allclose(g_full.cpu().numpy(), 0.5 * (g_a + g_b).cpu().numpy(), rtol=2e-4, atol=2e-7)
+    assert torch.isfinite(losses).all()
+
+
+@pytest.mark.parametrize("value_clip,dual_clip,adv_norm", [(True, None, False), (True, 3.0, True),
+                                                           (False, 1.5, False), (False, None, True)])
+def test_single_step_all_loss_branches(value_clip, dual_clip, adv_norm):
+    """One gradient step on hand-built batches that hit every branch of the loss: ratios inside and
+    outside the clip range, both advantage signs (dual clip), values inside / outside the value-clip
+    range (including the rounding-level tie region)."""
+    from tianshou_amd import ppo as P
+
+    n = 4096
+    params, data = random_problem(n, 17, 6, seed=99)
+    rng = np.random.default_rng(5)
+    obs, act = torch.from_numpy(data["obs"]), torch.from_numpy(data["act"])
+    with torch.no_grad():
+        v = OP.critic_forward(params, obs).flatten()
+        mu, sigma = OP.actor_forward(params, obs)
+        logp = OP.dist_of(mu, sigma).log_prob(act)
+    v_s = v + torch.from_numpy(rng.normal(scale=0.2, size=n).astype(np.float32))
+    v_s[::7] = v[::7]                                    # exact ties
+    logp_old = logp + torch.from_numpy(rng.normal(scale=0.3, size=n).astype(np.float32))
+    logp_old[::5] = logp[::5]
+    adv = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    returns = v + torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    kw = dict(eps_clip=0.2, dual_clip=dual_clip, value_clip=value_clip, advantage_normalization=adv_norm,
+              vf_coef=0.25, ent_coef=0.01, max_grad_norm=0.5, lr=3e-4)
+    ocfg, cfg = OP.PPOConfig(**kw), P.PPOConfig(**kw)
+    p = {k: t.clone().requires_grad_(True) for k, t in params.items()}
+    loss, clip_loss, vf_loss, ent_loss = OP.ppo_minibatch_loss(p, ocfg, obs, act, adv, returns, logp_old, v_s)
+    loss.backward()
+    g_ref = torch.cat([p[k].grad.reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+    eng = P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg)
+    b = dict(obs=obs.cuda(), act=act.cuda(), adv=adv.cuda(), returns=returns.cuda(), logp_old=logp_old.cuda(),
+             v_s=v_s.cuda())
+    losses, grads = eng._run_steps(b, None, [0, n], want_grad=True)
+    np.testing.assert_allclose(losses.cpu().numpy()[0],
+                               [loss.item(), clip_loss.item(), vf_loss.item(), ent_loss.item()], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(grads.cpu().numpy(), g_ref, rtol=1e-4, atol=2e-6 * float(np.abs(g_ref).max()))
