@@ -1,0 +1,334 @@
+#!/usr/bin/env python
+"""bench.py -- PPO learn() hot path on MI355X (BASELINE.json metric:
+"learn() update-steps/sec + GAE transitions/sec, PPO batch=65536, 1/2/4/8 GPU").
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): synthetic MuJoCo-shape rollout, 512 envs x
+2048 steps = 2^20 transitions per GPU, obs f32[17], act f32[6], MLP[64,64] tanh actor-critic,
+PPO hyper-parameters of examples/mujoco/mujoco_ppo.py (gamma .99, lambda .95, eps .2, vf .25,
+ent 0, max_grad_norm .5, value_clip, return_scaling, lr 3e-4), minibatch 65536, repeat 10.
+
+One bench "step" = one whole update() of the reference (Algorithm._update, algorithm_base.py:586-631)
+on data already resident in HBM: V(s), V(s'), GAE over the 2^20 transitions, logp_old, then
+repeat x 16 = 160 minibatch gradient steps (forward, loss, backward, grad-clip, Adam).
+value = minibatch gradient steps per second over the whole job (all ranks), preprocessing included.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (N > 1, one rank per GPU)
+
+N > 1 (weak scaling): every rank owns its own 2^20-transition shard (buffer sharded by env id,
+SURVEY 8e); per gradient step the flat fp32 gradient (11,085 floats) is all-reduced with RCCL.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ENV, T_STEPS, OBS, ACT = 512, 2048, 17, 6
+N_TRANS = N_ENV * T_STEPS
+MINIBATCH, REPEAT = 65536, 10
+FLOP_PER_SAMPLE_STEP = 60544          # fwd 21,632 + bwd dW 21,632 + dX 17,280
+GAE_BYTES_PER_TRANSITION = 26         # 22 + 4: rew kept float64 as the reference stores it
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def make_rollout(device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    obs = torch.randn(N_TRANS, OBS, device=device, generator=g)
+    obs_next = torch.randn(N_TRANS, OBS, device=device, generator=g)
+    act = torch.randn(N_TRANS, ACT, device=device, generator=g)
+    rew = torch.randn(N_TRANS, device=device, generator=g).double()   # generated f32, stored f64
+    term = (torch.rand(N_TRANS, device=device, generator=g) < 0.005).to(torch.uint8)
+    trunc = torch.zeros(N_TRANS, dtype=torch.uint8, device=device)
+    trunc.view(N_ENV, T_STEPS)[:, 999::1000] = 1                      # MuJoCo 1000-step time limit
+    trunc &= (1 - term)
+    return obs, obs_next, act, rew, term, trunc
+
+
+def mujoco_cfg():
+    from tianshou_amd.ppo import PPOConfig
+
+    return PPOConfig(gamma=0.99, gae_lambda=0.95, eps_clip=0.2, dual_clip=None, value_clip=True,
+                     advantage_normalization=False, recompute_advantage=False, vf_coef=0.25,
+                     ent_coef=0.0, max_grad_norm=0.5, return_scaling=True, lr=3e-4)
+
+
+def init_flat_params(seed=0):
+    """orthogonal(sqrt 2) / zero bias / mu head x0.01 / sigma -0.5 (mujoco_ppo.py:108-120)."""
+    g = torch.Generator().manual_seed(seed)
+
+    def ortho(rows, cols, gain):
+        a = torch.randn(rows, cols, generator=g)
+        flat = a if rows >= cols else a.t()
+        q, r = torch.linalg.qr(flat)
+        q = q * torch.sign(torch.diagonal(r)).unsqueeze(0)
+        return (q if rows >= cols else q.t()) * gain
+
+    s2 = 2.0 ** 0.5
+    parts = [ortho(64, OBS, s2), torch.zeros(64), ortho(64, 64, s2), torch.zeros(64),
+             ortho(ACT, 64, s2) * 0.01, torch.zeros(ACT), torch.full((ACT,), -0.5),
+             ortho(64, OBS, s2), torch.zeros(64), ortho(64, 64, s2), torch.zeros(64),
+             ortho(1, 64, s2), torch.zeros(1)]
+    return torch.cat([p.reshape(-1) for p in parts]).float()
+
+
+class Learner:
+    """One rank: device-resident rollout shard + PPO engine.  world_size > 1 splits every
+    gradient step around an RCCL all-reduce of the flat gradient."""
+
+    def __init__(self, device, rank, world):
+        from tianshou_amd import _lib
+        from tianshou_amd.ppo import PPOEngine
+
+        self.device, self.rank, self.world = device, rank, world
+        self.data = make_rollout(device, seed=1000 + rank)
+        self.cfg = mujoco_cfg()
+        self.eng = PPOEngine(OBS, ACT, init_flat_params(0).to(device), self.cfg)
+        self.cut = (torch.arange(N_ENV, device=device) + 1) * T_STEPS - 1   # last slot of every env
+        self.rng = np.random.default_rng(1234 + rank)
+        self._lib = _lib
+        self.ws = _lib.default_workspace(device.index)
+        if world > 1:
+            self.grad = torch.empty(self.eng.P + 4, dtype=torch.float32, device=device)
+            self.scratch = torch.empty(self.eng.P, dtype=torch.float32, device=device)
+
+    def preprocess(self):
+        obs, obs_next, act, rew, term, trunc = self.data
+        return self.eng.preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
+
+    def update_once(self):
+        """one reference update(): preprocess + REPEAT x (N_TRANS / MINIBATCH) gradient steps."""
+        b = self.preprocess()
+        perms = [self.rng.permutation(N_TRANS) for _ in range(REPEAT)]
+        if self.world == 1:
+            losses, steps = self.eng.update(b, MINIBATCH, REPEAT, perms)
+            return losses, steps
+        return self._update_dp(b, perms)
+
+    def _update_dp(self, b, perms):
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from tianshou_amd.ppo import pack_batch, split_offsets
+
+        lib, eng = self._lib.load(), self.eng
+        rec = pack_batch(b, OBS, ACT)
+        hp = self.cfg.to_c()
+        offs = split_offsets(N_TRANS, MINIBATCH)
+        losses = []
+        stream = self._lib.current_stream(self.device)
+        for r in range(REPEAT):
+            perm = torch.as_tensor(perms[r], device=self.device)
+            for lo, hi in zip(offs[:-1], offs[1:]):
+                rows = perm[lo:hi]
+                n_rows = hi - lo
+                self._lib.check(lib.ts_ppo_grad(
+                    self.ws.handle, self._lib.ptr(eng.params), self._lib.i64(OBS), self._lib.i64(ACT),
+                    self._lib.ptr(rec), self._lib.i64(N_TRANS), self._lib.ptr(rows), self._lib.i64(n_rows),
+                    self._lib.i64(n_rows * self.world), None, C.byref(hp), self._lib.ptr(self.grad),
+                    C.c_void_p(self.grad.data_ptr() + 4 * eng.P), stream))
+                dist.all_reduce(self.grad)            # RCCL over xGMI: grads + (loss, clip, vf, ent)
+                eng.adam_step += 1
+                self._lib.check(lib.ts_ppo_apply(
+                    self._lib.ptr(eng.params), self._lib.ptr(eng.adam_m), self._lib.ptr(eng.adam_v),
+                    self._lib.i64(eng.adam_step), self._lib.i64(OBS), self._lib.i64(ACT),
+                    self._lib.ptr(self.grad), self._lib.ptr(self.scratch), C.byref(hp), stream))
+                losses.append(self.grad[eng.P:eng.P + 4].clone())
+        out = torch.stack(losses)
+        # the entropy term is parameter-only, every rank contributed the same value to the sum
+        out[:, 3] /= self.world
+        out[:, 0] = out[:, 1] + self.cfg.vf_coef * out[:, 2] - self.cfg.ent_coef * out[:, 3]
+        return out, len(losses)
+
+
+def time_gae(learner, iters=50):
+    """GAE scan alone (inputs resident in HBM -> adv, returns), HIP events on the launch stream."""
+    from tianshou_amd.returns import gae_scan
+
+    obs, obs_next, act, rew, term, trunc = learner.data
+    v = torch.randn(N_TRANS, device=learner.device)
+    vn = torch.randn(N_TRANS, device=learner.device)
+    for _ in range(5):
+        gae_scan(v, vn, rew, term, trunc, learner.cut)
+    torch.cuda.synchronize()
+    learner.ws.profile_begin()
+    for _ in range(iters):
+        gae_scan(v, vn, rew, term, trunc, learner.cut)
+    prof = learner.ws.profile_end()
+    ms = (prof["gae_maps"][0] + prof["gae_apply"][0]) / iters
+    return ms * 1e-3
+
+
+def cpu_baseline(sample_steps=3):
+    """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
+    kernels) on the host cores, bounded sample: full preprocess of one 2^20 rollout in
+    max_batchsize=65536 chunks + `sample_steps` minibatch gradient steps of 65536; whole-update
+    steps/s extrapolated as 160 / (t_pre + 160 * t_step)."""
+    from oracle import oracle as O
+    from oracle import oracle_ppo as OP
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    rng = np.random.default_rng(0)
+    obs = torch.from_numpy(rng.normal(size=(N_TRANS, OBS)).astype(np.float32))
+    obs_next = torch.from_numpy(rng.normal(size=(N_TRANS, OBS)).astype(np.float32))
+    act = torch.from_numpy(rng.normal(size=(N_TRANS, ACT)).astype(np.float32))
+    rew = rng.normal(size=N_TRANS).astype(np.float32).astype(np.float64)
+    term = rng.random(N_TRANS) < 0.005
+    trunc = np.zeros(N_TRANS, bool)
+    c = mujoco_cfg()
+    ocfg = OP.PPOConfig(gamma=c.gamma, gae_lambda=c.gae_lambda, eps_clip=c.eps_clip, value_clip=True,
+                        advantage_normalization=False, vf_coef=c.vf_coef, ent_coef=c.ent_coef,
+                        max_grad_norm=c.max_grad_norm, return_scaling=True, lr=c.lr, max_batchsize=65536)
+    flat = init_flat_params(0)
+    st = OP.PPOState(params=OP.unflatten_params(flat, OBS, ACT))
+    idx = np.arange(N_TRANS)
+    unf = (np.arange(N_ENV) + 1) * T_STEPS - 1
+    t0 = time.perf_counter()
+    pre = OP.preprocess(st, ocfg, obs, obs_next, act, rew, term, trunc, idx, unf)
+    t_pre = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.compute_episodic_return(rew, term, trunc, idx, unf, pre["v_s"].numpy(), pre["v_s"].numpy(), 0.99, 0.95)
+    t_gae = time.perf_counter() - t0
+    perm = rng.permutation(N_TRANS)
+    sub = perm[: MINIBATCH * sample_steps]
+    data = {"obs": obs[sub], "act": act[sub]}
+    pre_s = {k: pre[k][sub] for k in ("v_s", "returns", "adv", "logp_old")}
+    t0 = time.perf_counter()
+    OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, [np.arange(MINIBATCH * sample_steps)])
+    t_step = (time.perf_counter() - t0) / sample_steps
+    steps_per_update = REPEAT * (N_TRANS // MINIBATCH)
+    value = steps_per_update / (t_pre + steps_per_update * t_step)
+    return {
+        "value": value, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": (f"oracle (torch-fp32 CPU + C restatement of the njit kernels): 1 full preprocess of 2^20 "
+                   f"transitions ({t_pre:.2f} s, of which GAE scan {t_gae * 1e3:.1f} ms single-thread = "
+                   f"{N_TRANS / t_gae / 1e6:.0f} M transitions/s) + {sample_steps} gradient steps of 65536 "
+                   f"({t_step * 1e3:.1f} ms each); extrapolated to the 160-step update"),
+        "gae_transitions_per_s": N_TRANS / t_gae,
+        "inner_update_steps_per_s": 1.0 / t_step,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    learner = Learner(device, rank, world)
+    for _ in range(args.warmup):
+        learner.update_once()
+    barrier()
+    t0 = time.perf_counter()
+    total_steps = 0
+    for _ in range(args.steps):
+        losses, steps = learner.update_once()
+        total_steps += steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = [float(x) for x in losses[-1].tolist()]
+
+    # per-kernel durations with HIP events on the launch stream, one more update() (N = 1 path)
+    roof, extra = None, {}
+    if rank == 0:
+        b = learner.preprocess()
+        torch.cuda.synchronize()
+        if world == 1:
+            learner.ws.profile_begin()
+            perms = [learner.rng.permutation(N_TRANS) for _ in range(REPEAT)]
+            t1 = time.perf_counter()
+            learner.eng.update(b, MINIBATCH, REPEAT, perms)
+            torch.cuda.synchronize()
+            t_inner = time.perf_counter() - t1
+            prof = learner.ws.profile_end()
+            step_ms, step_n = prof["ppo_step"]
+            avg_s = step_ms / max(step_n, 1) * 1e-3
+            achieved = FLOP_PER_SAMPLE_STEP * MINIBATCH / avg_s / 1e12
+            roof = {"bound": "mfma", "kernel": "ppo_step_kernel", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": step_n,
+                    "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * MINIBATCH}
+            extra["kernel_us"] = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()}
+            extra["inner_update_steps_per_s"] = REPEAT * (N_TRANS // MINIBATCH) / t_inner
+        t_gae = time_gae(learner)
+        gbps = GAE_BYTES_PER_TRANSITION * N_TRANS / t_gae / 1e9
+        extra["gae_transitions_per_s"] = N_TRANS / t_gae
+        extra["roofline_gae"] = {"bound": "hbm", "kernel": "gae_tile_maps+gae_tile_apply", "achieved": gbps,
+                                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                                 "traffic": None, "avg_launch_us": t_gae * 1e6,
+                                 "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * N_TRANS}
+        t1 = time.perf_counter()
+        for _ in range(3):
+            learner.preprocess()
+        torch.cuda.synchronize()
+        extra["preprocess_transitions_per_s"] = 3 * N_TRANS / (time.perf_counter() - t1)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        out = {
+            "metric": "PPO learn() update-steps/sec (minibatch 65536, preprocessing incl.) + GAE transitions/sec",
+            "value": world * total_steps / elapsed,
+            "unit": "update-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 PPO MuJoCo-shape rollout: 512 envs x 2048 steps = 2^20 transitions/GPU, "
+                                   "obs 17, act 6, MLP[64,64] actor-critic, minibatch 65536, repeat 10",
+                       "gradient_steps_per_step": REPEAT * (N_TRANS // MINIBATCH),
+                       "transitions_per_step": N_TRANS, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "final_losses": final_loss,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

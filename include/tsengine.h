@@ -45,6 +45,20 @@ const char* ts_last_error(void);
 int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes);
 int ts_workspace_destroy(ts_workspace* ws);
 
+/* Per-kernel timing for bench.py's roofline figure: between ts_profile_begin and
+ * ts_profile_end every kernel launched through `ws` is bracketed by a HIP event pair recorded
+ * on the launch stream.  ts_profile_end waits for the events and returns, per kernel kind,
+ * the summed duration (ms) and the launch count.  Kinds: */
+#define TS_KIND_PPO_STEP 0   /* fused forward/backward (ppo_step_kernel)      */
+#define TS_KIND_PPO_REDUCE 1 /* slab reduction                                */
+#define TS_KIND_PPO_ADAM 2   /* clip + Adam                                   */
+#define TS_KIND_PPO_INFER 3  /* value / log-prob inference                    */
+#define TS_KIND_GAE_MAPS 4   /* GAE pass 1 (tile maps)                        */
+#define TS_KIND_GAE_APPLY 5  /* GAE pass 2 (carry + outputs)                  */
+#define TS_N_KINDS 6
+int ts_profile_begin(ts_workspace* ws);
+int ts_profile_end(ts_workspace* ws, double* h_ms_by_kind, int64_t* h_count_by_kind, int n_kinds);
+
 /* ---------------------------------------------------------------------------------------------
  * Returns / advantages
  * ------------------------------------------------------------------------------------------- */
@@ -207,7 +221,7 @@ typedef struct ts_ppo_hparams {
  * (a2c.py:122-129, ppo.py:157-161), whole batch in one launch instead of max_batchsize
  * chunks: v_out[i] = V(obs_i) (nullable), logp_out[i] = log N(act_i; mu(obs_i), sigma)
  * (nullable; needs act).  obs float32[n, obs_dim], act float32[n, act_dim]. */
-int ts_ppo_infer(const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
+int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                  const float* act, int64_t n, float* v_out, float* logp_out,
                  ts_stream_t stream);
 
@@ -227,26 +241,42 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   const int64_t* h_mb_offset, int64_t n_steps, const ts_ppo_hparams* hp,
                   float* losses_out, float* grads_out, ts_stream_t stream);
 
+/* Packed minibatch records.  The step kernel gathers minibatch rows by permutation; to make every
+ * touched 128-byte line fully useful the batch is first packed into one 16-byte-aligned record per
+ * sample:  [obs(obs_dim) | act(act_dim) | adv | returns | logp_old | v_s | 0-pad] , W floats with
+ * W = ts_ppo_record_width(obs_dim, act_dim) (multiple of 4).  ts_ppo_update packs internally;
+ * the data-parallel path packs once per update() and passes the records to ts_ppo_grad. */
+int64_t ts_ppo_record_width(int64_t obs_dim, int64_t act_dim);
+int ts_ppo_pack_batch(const float* obs, const float* act, const float* adv, const float* returns,
+                      const float* logp_old, const float* v_s, int64_t n, int64_t obs_dim,
+                      int64_t act_dim, float* rec_out, ts_stream_t stream);
+
 /* Data-parallel variant, split around the gradient all-reduce (RCCL, issued by the caller on
  * the same stream between the two calls; the reference has no equivalent - its only multi-GPU
  * path is nn.DataParallel, tianshou/utils/net/common.py:473-515):
- *   ts_ppo_grad : forward/backward of ONE local minibatch shard (rows perm_rows[0..n_rows), or
- *                 the first n_rows rows when perm_rows is NULL) -> grad_out float32[P] = sum over
- *                 the local rows / global_batch, loss_parts_out float32[4] = (loss, clip, vf, ent)
- *                 with clip / vf as local sums / global_batch (all-reduce-sum them too; recompute
- *                 loss = clip + vf_coef*vf - ent_coef*ent afterwards).  adv_stats (device
- *                 float32[2] = {mean, std} of the GLOBAL minibatch) is required when hp->adv_norm.
+ *   ts_ppo_grad : forward/backward of ONE local minibatch shard (records rec[perm_rows[0..n_rows)],
+ *                 or the first n_rows records when perm_rows is NULL) -> grad_out float32[P] = sum
+ *                 over the local rows / global_batch, loss_parts_out float32[4] = (loss, clip, vf,
+ *                 ent) with clip / vf as local sums / global_batch (all-reduce-sum them too and
+ *                 recompute loss = clip + vf_coef*vf - ent_coef*ent).  adv_stats (device float32[2]
+ *                 = {mean, std} of the GLOBAL minibatch) is required when hp->adv_norm.
  *   ts_ppo_apply: clip by global norm + Adam step number `adam_step` (1-based) using the
- *                 all-reduced gradient; grad_scratch float32[P] is clobbered. */
+ *                 all-reduced gradient (grad_scratch is unused, kept for ABI stability). */
 int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
-                const float* obs, const float* act, const float* adv, const float* returns,
-                const float* logp_old, const float* v_s, int64_t n, const int64_t* perm_rows,
-                int64_t n_rows, int64_t global_batch, const float* adv_stats,
-                const ts_ppo_hparams* hp, float* grad_out, float* loss_parts_out,
-                ts_stream_t stream);
+                const float* rec, int64_t n, const int64_t* perm_rows, int64_t n_rows,
+                int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp,
+                float* grad_out, float* loss_parts_out, ts_stream_t stream);
 int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
                  int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
                  ts_stream_t stream);
+
+/* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
+ * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
+ * the stream. */
+int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
+                             const float* rec, const int64_t* perm_rows, int64_t n_rows,
+                             const ts_ppo_hparams* hp, int64_t* h_cycles, int64_t n_marks,
+                             ts_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,27 @@
+"""Phase timing of one ppo_step_kernel launch (workgroup 0, wave 0), shader-clock cycles."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+import bench
+from tianshou_amd import _lib
+
+dev = torch.device("cuda", 0)
+L = bench.Learner(dev, 0, 1)
+b = L.preprocess()
+lib = _lib.load()
+hp = L.cfg.to_c()
+from tianshou_amd.ppo import pack_batch
+rec = pack_batch(b, 17, 6)
+names = ["start", "staged", "A:trunk", "A:loss", "A:headgrad", "A:dH1", "A:dW2", "A:dW1", "A:pass_end", "A:flushed",
+         "C:trunk", "C:loss", "C:headgrad", "C:dH1", "C:dW2", "C:dW1", "C:pass_end", "end"]
+for trial in range(3):
+    rows = torch.as_tensor(np.random.default_rng(trial).permutation(bench.N_TRANS)[:65536], device=dev)
+    out = (C.c_int64 * 24)()
+    _lib.check(lib.ts_debug_ppo_step_cycles(L.ws.handle, _lib.ptr(L.eng.params), _lib.i64(17), _lib.i64(6),
+        _lib.ptr(rec), _lib.ptr(rows), _lib.i64(65536), C.byref(hp), out, _lib.i64(24), _lib.current_stream(dev)))
+    t = np.array(list(out), dtype=np.int64)
+    print("trial", trial, "total cycles", t[17] - t[0])
+    for k in range(1, 18):
+        print(f"   {names[k]:12s} +{t[k]-t[k-1]:8d}  (at {t[k]-t[0]:8d})")
+    print("   prologue A: fetch issued at", t[18]-t[0], "pre-stage", t[19]-t[0], "staged(no barrier)", t[20]-t[0], "after barrier", t[1]-t[0])
+    print("   prologue C: from A:pass_end", t[21]-t[8], t[22]-t[8], t[23]-t[8], t[9]-t[8])

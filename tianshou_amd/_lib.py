@@ -50,6 +50,7 @@ class PPOHParams(C.Structure):
 
 
 _lib = None
+KERNEL_KINDS = ("ppo_step", "ppo_reduce", "ppo_adam", "ppo_infer", "gae_maps", "gae_apply")
 
 
 def declared_symbols() -> list[str]:
@@ -70,6 +71,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP engine is not built. Run `python -m tianshou_amd.build` "
             "(needs hipcc, cross-compiles for gfx950 without a GPU). There is no CPU fallback."
         )
+    # torch ships its own libamdhip64; it must be in the process before libtsengine resolves its
+    # HIP dependency, otherwise two HIP runtimes get loaded and ours sees no device.
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     lib.ts_version.restype = C.c_char_p
     lib.ts_last_error.restype = C.c_char_p
@@ -122,6 +127,17 @@ class Workspace:
     @property
     def handle(self) -> C.c_void_p:
         return self._h
+
+    def profile_begin(self) -> None:
+        check(load().ts_profile_begin(self._h))
+
+    def profile_end(self) -> dict[str, tuple[float, int]]:
+        """-> {kind: (total_ms, launches)} measured with HIP events on the launch stream."""
+        n = len(KERNEL_KINDS)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        check(load().ts_profile_end(self._h, ms, cnt, C.c_int(n)))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
 
     def close(self) -> None:
         if self._h:

@@ -50,10 +50,24 @@ struct ts_workspace {
     // persistent sum-tree winner table (int32[bound], kept at -1 between calls)
     int32_t* winner;
     int64_t winner_len;
+    // optional per-kernel timing with HIP events on the launch stream (ts_profile_begin/end)
+    int profiling;
+    hipEvent_t* ev;      // [2 * ev_cap] start/stop pairs
+    int* ev_kind;        // [ev_cap]
+    int ev_cap, ev_n;
 };
 
 namespace ts {
 // Ensures ws->base holds at least `bytes`; (re)allocation synchronises the device once.
 int ws_reserve(ts_workspace* ws, size_t bytes);
 int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out);
+
+// Brackets one kernel launch with a start/stop event pair when profiling is enabled.
+struct ProfScope {
+    ts_workspace* ws;
+    hipStream_t stream;
+    int slot;
+    ProfScope(ts_workspace* w, int kind, hipStream_t s);
+    ~ProfScope();
+};
 }  // namespace ts

@@ -58,9 +58,53 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
     return TS_OK;
 }
 
+ProfScope::ProfScope(ts_workspace* w, int kind, hipStream_t s) : ws(w), stream(s), slot(-1) {
+    if (!ws || !ws->profiling || ws->ev_n >= ws->ev_cap) return;
+    slot = ws->ev_n++;
+    ws->ev_kind[slot] = kind;
+    (void)hipEventRecord(ws->ev[2 * slot], stream);
+}
+
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(ws->ev[2 * slot + 1], stream);
+}
+
 }  // namespace ts
 
 extern "C" {
+
+int ts_profile_begin(ts_workspace* ws) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_profile_begin: workspace is NULL");
+    if (!ws->ev) {
+        const int cap = 4096;
+        ws->ev = (hipEvent_t*)calloc(2 * (size_t)cap, sizeof(hipEvent_t));
+        ws->ev_kind = (int*)calloc((size_t)cap, sizeof(int));
+        TS_REQUIRE(ws->ev && ws->ev_kind, TS_ERR_WORKSPACE, "ts_profile_begin: host allocation failed");
+        TS_HIP_CHECK(hipSetDevice(ws->device));
+        for (int i = 0; i < 2 * cap; ++i) TS_HIP_CHECK(hipEventCreate(&ws->ev[i]));
+        ws->ev_cap = cap;
+    }
+    ws->ev_n = 0;
+    ws->profiling = 1;
+    return TS_OK;
+}
+
+int ts_profile_end(ts_workspace* ws, double* ms_by_kind, int64_t* count_by_kind, int n_kinds) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_profile_end: workspace is NULL");
+    TS_REQUIRE(ms_by_kind && count_by_kind && n_kinds >= 1, TS_ERR_INVALID_ARG,
+               "ts_profile_end: bad output arguments");
+    ws->profiling = 0;
+    for (int k = 0; k < n_kinds; ++k) { ms_by_kind[k] = 0.0; count_by_kind[k] = 0; }
+    for (int i = 0; i < ws->ev_n; ++i) {
+        TS_HIP_CHECK(hipEventSynchronize(ws->ev[2 * i + 1]));
+        float ms = 0.f;
+        TS_HIP_CHECK(hipEventElapsedTime(&ms, ws->ev[2 * i], ws->ev[2 * i + 1]));
+        const int k = ws->ev_kind[i];
+        if (k >= 0 && k < n_kinds) { ms_by_kind[k] += (double)ms; count_by_kind[k] += 1; }
+    }
+    ws->ev_n = 0;
+    return TS_OK;
+}
 
 const char* ts_version(void) { return "tsengine 0.1.0 (gfx950)"; }
 
@@ -78,11 +122,16 @@ int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes) {
 
 int ts_workspace_destroy(ts_workspace* ws) {
     if (!ws) return TS_OK;
-    if (ws->base || ws->winner) {
+    if (ws->base || ws->winner || ws->ev) {
         (void)hipSetDevice(ws->device);
         (void)hipDeviceSynchronize();
         if (ws->base) (void)hipFree(ws->base);
         if (ws->winner) (void)hipFree(ws->winner);
+        if (ws->ev) {
+            for (int i = 0; i < 2 * ws->ev_cap; ++i) (void)hipEventDestroy(ws->ev[i]);
+            free(ws->ev);
+            free(ws->ev_kind);
+        }
     }
     free(ws);
     return TS_OK;

@@ -20,6 +20,8 @@
 // weights (A operand, from LDS) are read in that order.  No cross-lane traffic between layers.
 // Weight gradients contract over samples, so dZ and H are transposed once through wave-private
 // LDS tiles ([feature][sample], pitch 36 floats: conflict-free ds_write_b32 and ds_read_b128).
+#include <cstdlib>
+
 #include "ts_common.h"
 
 namespace {
@@ -33,7 +35,7 @@ constexpr int W2_SIZE = HID * W2_PITCH;      // floats per net
 constexpr int ACT_PAD = 8;
 constexpr int TILE_PITCH = 36;               // transposed activation tile pitch (floats)
 constexpr int TILE_SIZE = 32 * TILE_PITCH;   // one 32-feature x 32-sample tile
-constexpr int STEP_THREADS = 512;            // 8 waves, 2 per SIMD
+constexpr int STEP_THREADS = 256;            // 4 waves (one per SIMD); two workgroups per CU
 constexpr int STEP_WAVES = STEP_THREADS / 64;
 constexpr int N_EXTRA = 2;                   // slab tail: clip-loss sum, vf-loss sum
 
@@ -71,66 +73,117 @@ __host__ __device__ inline Dims make_dims(int obs, int act) {
     return d;
 }
 
-// LDS carve (floats) shared by the step and inference kernels
-template <int KS1>
+// LDS carve (floats).  NN = number of nets resident at once: the inference kernel keeps both,
+// the step kernel stages one net at a time so that two 256-thread workgroups fit one CU (<= 80 KB).
+template <int KS1, int NN>
 struct Lds {
-    static constexpr int W2 = 0;                                  // [2][64*68]
-    static constexpr int W1 = W2 + 2 * W2_SIZE;                   // [2][2*KS1][64]  (k-major)
+    static constexpr int W2 = 0;                                  // [NN][64*68]
+    static constexpr int W1 = W2 + NN * W2_SIZE;                  // [NN][2*KS1][64]  (k-major)
     static constexpr int W1_NET = 2 * KS1 * HID;
-    static constexpr int B2 = W1 + 2 * W1_NET;                    // [2][64]
-    static constexpr int WH = B2 + 2 * HID;                       // [2][h][t][r][8]
+    static constexpr int B2 = W1 + NN * W1_NET;                   // [NN][64]
+    static constexpr int WH = B2 + NN * HID;                      // [NN][h][t][r][8]
     static constexpr int WH_NET = 2 * 2 * 16 * ACT_PAD;
-    static constexpr int SMALL = WH + 2 * WH_NET;                 // bmu[8] sig[8] bv[1] pad -> 32
-    static constexpr int INFER_END = SMALL + 32;
-    static constexpr int ACC = INFER_END;                         // net accumulator (flat layout)
+    // SMALL: [0..7] bmu, [8..15] 1/(2 sigma^2), [16..23] log(sigma), [24] bv
+    static constexpr int SMALL = WH + NN * WH_NET;
+    static constexpr int END = SMALL + 32;                        // step kernel appends R + scratch
 };
 
 // ---------------------------------------------------------------------------------------------
 // weight staging: global flat params -> LDS images
-template <int KS1>
+// Staging is written as "issue every global load of a batch, then store": the loads of a batch
+// are independent, so one memory round trip covers the whole batch (a plain load->store loop makes
+// hipcc wait for each load).
+template <int NT, int COUNT, typename SrcFn, typename DstFn>
+__device__ __forceinline__ void stage_batch(const float* __restrict__ params, float* lds, SrcFn src, DstFn dst) {
+    constexpr int PER = (COUNT + NT - 1) / NT;
+    float v[PER];
+    int ok[PER];
+    // unconditional loads from a clamped index + select: a branch around a load makes hipcc wait
+    // for every load separately (s_waitcnt vmcnt(0) per element)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + NT * k;
+        const int sidx = src(idx < COUNT ? idx : COUNT - 1);
+        ok[k] = (idx < COUNT) & (sidx >= 0);
+        v[k] = params[sidx >= 0 ? sidx : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = ok[k] ? v[k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = threadIdx.x + NT * k;
+        if (idx < COUNT) lds[dst(idx)] = v[k];
+    }
+}
+
+template <int KS1, int NN, int NT>
 __device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ params,
-                                              const Dims& d, int nthreads) {
-    using L = Lds<KS1>;
+                                              const Dims& d, int first_net) {
+    using L = Lds<KS1, NN>;
     const int tid = threadIdx.x;
-    for (int net = 0; net < 2; ++net) {
+    for (int slot = 0; slot < NN; ++slot) {
+        const int net = first_net + slot;
         const int w1 = net ? d.c_w1 : d.a_w1, b1 = net ? d.c_b1 : d.a_b1;
         const int w2 = net ? d.c_w2 : d.a_w2, b2 = net ? d.c_b2 : d.a_b2;
-        for (int i = tid; i < HID * HID; i += nthreads) {
-            const int r = i >> 6, c = i & 63;
-            lds[L::W2 + net * W2_SIZE + r * W2_PITCH + c] = params[w2 + i];
-        }
-        for (int i = tid; i < 2 * KS1 * HID; i += nthreads) {
-            const int k = i >> 6, row = i & 63;
-            float v = 0.f;
-            if (k < d.obs) v = params[w1 + row * d.obs + k];
-            else if (k == d.obs) v = params[b1 + row];
-            lds[L::W1 + net * L::W1_NET + i] = v;
-        }
-        for (int i = tid; i < HID; i += nthreads) lds[L::B2 + net * HID + i] = params[b2 + i];
-        for (int i = tid; i < L::WH_NET; i += nthreads) {
-            const int a = i & 7, r = (i >> 3) & 15, t = (i >> 7) & 1, h = (i >> 8) & 1;
-            const int f = 32 * t + featF(r, h);
-            float v = 0.f;
-            if (net == 0) { if (a < d.act) v = params[d.a_wmu + a * HID + f]; }
-            else { if (a == 0) v = params[d.c_wv + f]; }
-            lds[L::WH + net * L::WH_NET + i] = v;
-        }
+        const int obs = d.obs, act = d.act;
+        const int wmu = d.a_wmu, wv = d.c_wv;
+        stage_batch<NT, HID * HID>(params, lds + L::W2 + slot * W2_SIZE,
+                                   [=](int i) { return w2 + i; },
+                                   [=](int i) { return (i >> 6) * W2_PITCH + (i & 63); });
+        stage_batch<NT, 2 * KS1 * HID>(params, lds + L::W1 + slot * L::W1_NET,
+                                       [=](int i) {
+                                           const int k = i >> 6, row = i & 63;
+                                           return k < obs ? w1 + row * obs + k : (k == obs ? b1 + row : -1);
+                                       },
+                                       [=](int i) { return i; });
+        stage_batch<NT, HID>(params, lds + L::B2 + slot * HID, [=](int i) { return b2 + i; },
+                             [=](int i) { return i; });
+        stage_batch<NT, L::WH_NET>(params, lds + L::WH + slot * L::WH_NET,
+                                   [=](int i) {
+                                       const int a = i & 7, r = (i >> 3) & 15, t = (i >> 7) & 1, h = (i >> 8) & 1;
+                                       const int f = 32 * t + featF(r, h);
+                                       if (net == 0) return a < act ? wmu + a * HID + f : -1;
+                                       return a == 0 ? wv + f : -1;
+                                   },
+                                   [=](int i) { return i; });
     }
-    for (int i = tid; i < 32; i += nthreads) {
+    for (int i = tid; i < 32; i += NT) {
         float v = 0.f;
         if (i < 8) { if (i < d.act) v = params[d.a_bmu + i]; }
-        else if (i < 16) { if (i - 8 < d.act) v = params[d.a_sig + (i - 8)]; }
-        else if (i == 16) v = params[d.c_bv];
+        else if (i < 24) {
+            const int k = i & 7;
+            if (k < d.act) {
+                // continuous.py:238 sigma = exp(sigma_param); Normal.log_prob uses var = sigma^2 and log(sigma)
+                const float sigma = expf(params[d.a_sig + k]);
+                v = (i < 16) ? 1.f / (2.f * (sigma * sigma)) : logf(sigma);
+            }
+        } else if (i == 24) v = params[d.c_bv];
         lds[L::SMALL + i] = v;
     }
 }
 
+// tanh with <= 2.1e-7 relative error (about 2 ulp): odd polynomial below 0.5, 1 - 2/(e^{2|x|}+1) above
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    const float x2 = ax * ax;
+    float p = 3.5921280365724810e-3f;                 // 21844/6081075
+    p = p * x2 - 8.8632355299021967e-3f;              // -1382/155925
+    p = p * x2 + 2.1869488536155203e-2f;              // 62/2835
+    p = p * x2 - 5.3968253968253971e-2f;              // -17/315
+    p = p * x2 + 1.3333333333333333e-1f;              // 2/15
+    p = p * x2 - 3.3333333333333331e-1f;              // -1/3
+    const float small = ax + ax * (p * x2);
+    return copysignf(ax < 0.5f ? small : big, x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward trunk of one net for one 32-sample tile: x -> h1 -> h2 (transposed, in registers)
-template <int KS1>
+template <int KS1, int NN>
 __device__ __forceinline__ void trunk_forward(const float* lds, int net, const float (&x)[KS1],
                                               int i, int h, f32x16 (&h1)[2], f32x16 (&h2)[2]) {
-    using L = Lds<KS1>;
+    using L = Lds<KS1, NN>;
     const float* w1 = lds + L::W1 + net * L::W1_NET;
     const float* w2 = lds + L::W2 + net * W2_SIZE;
     const float* b2 = lds + L::B2 + net * HID;
@@ -140,7 +193,7 @@ __device__ __forceinline__ void trunk_forward(const float* lds, int net, const f
 #pragma unroll
         for (int s = 0; s < KS1; ++s) acc = mfma32(w1[(KS1 * h + s) * HID + 32 * t + i], x[s], acc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = tanhf(acc[r]);
+        for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
         h1[t] = acc;
     }
 #pragma unroll
@@ -159,18 +212,19 @@ __device__ __forceinline__ void trunk_forward(const float* lds, int net, const f
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc = mfma32(a[q], h1[t][4 * g + q], acc);
             }
+            __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every operand load
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = tanhf(acc[r]);
+        for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
         h2[t2] = acc;
     }
 }
 
 // head on the VALU: out[a] = sum_f h2[f] * WH[a][f] over the lane's 32 features, halves combined
-template <int KS1, int NA>
+template <int KS1, int NN, int NA>
 __device__ __forceinline__ void head_forward(const float* lds, int net, int h, const f32x16 (&h2)[2],
                                              float (&out)[NA]) {
-    using L = Lds<KS1>;
+    using L = Lds<KS1, NN>;
     const float* wh = lds + L::WH + net * L::WH_NET + h * (2 * 16 * ACT_PAD);
 #pragma unroll
     for (int a = 0; a < NA; ++a) out[a] = 0.f;
@@ -190,6 +244,7 @@ __device__ __forceinline__ void head_forward(const float* lds, int net, int h, c
                     if (a + 4 < NA) out[a + 4] += h2[t][r] * w1[a];
                 }
             }
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
 #pragma unroll
@@ -211,17 +266,16 @@ __device__ __forceinline__ void load_x(const float* __restrict__ obs, int64_t ro
 
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;  // math.log(math.sqrt(2*pi))
 
-// Normal(mu, sigma).log_prob(act).sum(-1)  (torch.distributions.Normal.log_prob, Independent)
+// Normal(mu, sigma).log_prob(act).sum(-1)  (torch.distributions.Normal.log_prob, Independent):
+//   -(x - mu)^2 / (2 var) - log(sigma) - log(sqrt(2 pi));  sm = SMALL block (1/(2var) at 8.., log sigma at 16..)
 __device__ __forceinline__ float gaussian_logp(const float (&mu)[ACT_PAD], const float (&act)[ACT_PAD],
-                                               const float* sig, int act_dim) {
+                                               const float* sm, int act_dim) {
     float lp = 0.f;
 #pragma unroll
     for (int a = 0; a < ACT_PAD; ++a) {
         if (a < act_dim) {
-            const float sigma = expf(sig[a]);
-            const float var = sigma * sigma;
             const float dlt = act[a] - mu[a];
-            lp += -(dlt * dlt) / (2.f * var) - logf(sigma) - LOG_SQRT_2PI;
+            lp += -(dlt * dlt) * sm[8 + a] - sm[16 + a] - LOG_SQRT_2PI;
         }
     }
     return lp;
@@ -236,8 +290,8 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
                                                         float* __restrict__ v_out,
                                                         float* __restrict__ logp_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using L = Lds<KS1>;
-    stage_weights<KS1>(lds, params, d, blockDim.x);
+    using L = Lds<KS1, 2>;
+    stage_weights<KS1, 2, 512>(lds, params, d, 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
@@ -250,21 +304,21 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
         load_x<KS1>(obs, row, d.obs, h, x);
         f32x16 h1[2], h2[2];
         if (v_out) {
-            trunk_forward<KS1>(lds, 1, x, i, h, h1, h2);
+            trunk_forward<KS1, 2>(lds, 1, x, i, h, h1, h2);
             float v[1];
-            head_forward<KS1, 1>(lds, 1, h, h2, v);
-            if (valid && h == 0) v_out[srow] = v[0] + lds[L::SMALL + 16];
+            head_forward<KS1, 2, 1>(lds, 1, h, h2, v);
+            if (valid && h == 0) v_out[srow] = v[0] + lds[L::SMALL + 24];
         }
         if (logp_out) {
-            trunk_forward<KS1>(lds, 0, x, i, h, h1, h2);
+            trunk_forward<KS1, 2>(lds, 0, x, i, h, h1, h2);
             float mu[ACT_PAD], a[ACT_PAD];
-            head_forward<KS1, ACT_PAD>(lds, 0, h, h2, mu);
+            head_forward<KS1, 2, ACT_PAD>(lds, 0, h, h2, mu);
 #pragma unroll
             for (int k = 0; k < ACT_PAD; ++k) {
                 mu[k] += lds[L::SMALL + k];
                 a[k] = (k < d.act) ? act[row * d.act + k] : 0.f;
             }
-            const float lp = gaussian_logp(mu, a, lds + L::SMALL + 8, d.act);
+            const float lp = gaussian_logp(mu, a, lds + L::SMALL, d.act);
             if (valid && h == 0) logp_out[srow] = lp;
         }
     }
@@ -273,12 +327,8 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 struct StepArgs {
     const float* params;
-    const float* obs;
-    const float* act;
-    const float* adv;
-    const float* ret;
-    const float* logp_old;
-    const float* v_old;
+    const float* rec;         // packed per-sample records [n][rec_w]: obs | act | adv ret logp_old v_old | pad
+    int rec_w;                // floats per record, multiple of 4 (16-byte rows)
     const int64_t* rows;      // minibatch row ids (perm slice) or NULL = identity
     int64_t n_rows;           // rows in this minibatch (local)
     float inv_batch;          // 1 / global minibatch size
@@ -287,7 +337,14 @@ struct StepArgs {
     int value_clip, adv_norm;
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
+    long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
+    int dbg_mode;             // diagnostics: 1 = stop after the first prologue, 2 = skip record fetch, 3 = skip staging
 };
+
+#define TS_MARK(g, k)                                                                  \
+    do {                                                                               \
+        if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0) (g).dbg[(k)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
 
 // transposed tile write: lane (j, h) register r -> T[F(r,h)][j]
 __device__ __forceinline__ void tile_write(float* tile, const f32x16& v, int j, int h) {
@@ -311,105 +368,229 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float half_sum32(float v) {  // sum over the 32 lanes of a half
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// sum over lanes 0..31 (the half that owns each sample once), result uniform across the wave.
+// DPP butterflies inside each 16-lane row, then two readlanes.
+__device__ __forceinline__ float sum_half0(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));  // row_half_mirror
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));  // row_mirror
+    x = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+    return r0 + r1;
 }
 
-// One net, one 32-sample tile: forward, loss, backward, weight gradients -> LDS accumulator.
-template <int KS1, bool ACTOR>
-__device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch, const StepArgs& g,
-                                         const Dims& d, int64_t tile, int lane) {
-    using L = Lds<KS1>;
-    constexpr int net = ACTOR ? 0 : 1;
-    const int i = lane & 31, h = lane >> 5;
+// ---------------------------------------------------------------------------------------------
+// Cross-wave reduction of one 16-register tile per wave, deterministic, no atomics:
+// every wave parks its tile in R[wave][r][lane]; after a barrier wave w sums rows
+// r = 4w .. 4w+3 over the 4 slots (fixed order) and owns those 256 results.
+constexpr int RED_SLOT = 16 * 64;   // floats per wave slot
+
+constexpr int RED_ROWS = 16 / STEP_WAVES;   // rows of the tile owned by each wave after the reduction
+
+struct RedOut { float v[RED_ROWS]; };
+
+__device__ __forceinline__ RedOut reduce_tile(float* R, const f32x16& c, int wave, int lane) {
+    __syncthreads();                       // previous slice readers are done with R
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R[wave * RED_SLOT + r * 64 + lane] = c[r];
+    __syncthreads();
+    RedOut o;
+#pragma unroll
+    for (int q = 0; q < RED_ROWS; ++q) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEP_WAVES; ++s) a += R[s * RED_SLOT + (RED_ROWS * wave + q) * 64 + lane];
+        o.v[q] = a;
+    }
+    return o;
+}
+
+__device__ __forceinline__ void slab_put(float* slab, int addr, float v, bool first) {
+    if (first) slab[addr] = v; else slab[addr] += v;
+}
+
+// per-sample inputs of one 32-sample tile.  The wave fetches the 32 packed records with 16-byte
+// loads (consecutive lanes -> consecutive 16-byte pieces of a record: every 128-byte line that is
+// touched is used almost completely), parks them in its LDS tile area and each lane then picks the
+// columns its MFMA operands need.
+template <int KS1>
+struct TileIn {
+    float x[KS1];
+    float act[ACT_PAD];
+    float adv, logp_old, ret, v_old;
+    float w;          // inv_batch for valid rows, 0 for padding rows
+};
+
+// float4 loads per lane for one tile: obs <= 2 KS1 - 1, act <= 8, 4 aux -> parts <= (2 KS1 + 14) / 4
+template <int KS1>
+struct RecFetch {
+    static constexpr int N = (32 * ((2 * KS1 + 14) / 4) + 63) / 64;
+    f32x4 v[N];
+    float w;
+};
+
+// issue the global loads of a tile's records (no waiting here)
+template <int KS1>
+__device__ __forceinline__ RecFetch<KS1> rec_fetch(const StepArgs& g, int64_t tile, int lane) {
+    RecFetch<KS1> f;
+    constexpr int REC_FETCH = RecFetch<KS1>::N;
+    const int i = lane & 31;
     const int64_t srow = tile * 32 + i;
     const bool valid = srow < g.n_rows;
     const int64_t pos = valid ? srow : g.n_rows - 1;
-    const int64_t row = g.rows ? g.rows[pos] : pos;
+    const int64_t rowid = g.rows ? g.rows[pos] : pos;
+    f.w = valid ? g.inv_batch : 0.f;
+    const int parts = g.rec_w >> 2;
+    const int total = 32 * parts;
+    const int lo = (int)(rowid & 0xffffffffLL), hi = (int)(rowid >> 32);
+#pragma unroll
+    for (int k = 0; k < REC_FETCH; ++k) {
+        int q = lane + 64 * k;
+        q = q < total ? q : total - 1;           // unconditional (clamped) load, see stage_batch
+        const int rec = q / parts, part = q - rec * parts;
+        const int64_t rid = ((int64_t)__shfl(hi, rec, 64) << 32) | (uint32_t)__shfl(lo, rec, 64);
+        f.v[k] = *reinterpret_cast<const f32x4*>(g.rec + rid * g.rec_w + part * 4);
+    }
+    return f;
+}
 
-    float x[KS1];
-    load_x<KS1>(g.obs, row, d.obs, h, x);
+// park the fetched records in the wave's LDS area (rb, >= 32 * rec_w floats) and extract the
+// lane's operands
+template <int KS1>
+__device__ __forceinline__ TileIn<KS1> rec_commit(const RecFetch<KS1>& f, const StepArgs& g, const Dims& d,
+                                                   float* rb, int lane) {
+    constexpr int REC_FETCH = RecFetch<KS1>::N;
+    const int i = lane & 31, h = lane >> 5;
+    const int parts = g.rec_w >> 2;
+    const int total = 32 * parts;
+#pragma unroll
+    for (int k = 0; k < REC_FETCH; ++k) {
+        const int q = lane + 64 * k;
+        if (q < total) *reinterpret_cast<f32x4*>(rb + q * 4) = f.v[k];   // rec * rec_w + part * 4 == q * 4
+    }
+    wave_lds_sync();
+    TileIn<KS1> t;
+    const float* r = rb + i * g.rec_w;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+        const int k = KS1 * h + s;
+        float v = 0.f;
+        if (k < d.obs) v = r[k];
+        else if (k == d.obs) v = 1.f;
+        t.x[s] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < ACT_PAD; ++k) t.act[k] = (k < d.act) ? r[d.obs + k] : 0.f;
+    const float* aux = r + d.obs + d.act;
+    t.adv = aux[0];
+    t.ret = aux[1];
+    t.logp_old = aux[2];
+    t.v_old = aux[3];
+    t.w = f.w;
+    wave_lds_sync();
+    return t;
+}
+
+// One net, one 32-sample tile per wave (the 4 waves of the workgroup in lock step): forward,
+// loss, backward, weight gradients reduced over the workgroup into its slab.
+template <int KS1, bool ACTOR>
+__device__ __forceinline__ void net_tile(float* lds, float* R, float* scratch, const StepArgs& g,
+                                         const Dims& d, const TileIn<KS1>& in, int wave, int lane_in,
+                                         float* slab, bool first) {
+    using L = Lds<KS1, 1>;
+    // Make the lane id opaque here: otherwise LLVM hoists every lane-dependent address of this
+    // (fully unrolled) body out of the tile / net loops into the kernel prologue, where they no
+    // longer fit in registers and get spilled (tens of KB of scratch traffic per wave).
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    constexpr int net = ACTOR ? 0 : 1;
+    constexpr int MK = ACTOR ? 2 : 10;
+    const int i = lane & 31, h = lane >> 5;
+
     f32x16 h1[2], h2[2];
-    trunk_forward<KS1>(lds, net, x, i, h, h1, h2);
+    trunk_forward<KS1, 1>(lds, 0, in.x, i, h, h1, h2);
+    TS_MARK(g, MK + 0);
 
-    // flat-layout offsets of this net inside the accumulator
-    const int o_w1 = 0, o_b1 = HID * d.obs, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID;
-    const int o_head = o_b2 + HID;                      // Wmu [act][64] | Wv [64]
-    const int o_hb = o_head + (ACTOR ? d.act * HID : HID);  // bmu [act] | bv [1]
-    const int o_sig = o_hb + d.act;                     // actor only
-    const int p_net = ACTOR ? d.p_actor : (d.p_total - d.p_actor);
+    // flat-layout offsets of this net inside the slab
+    const int base = ACTOR ? 0 : d.p_actor;
+    const int o_w1 = base, o_b1 = o_w1 + HID * d.obs, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID;
+    const int o_head = o_b2 + HID;                          // Wmu [act][64] | Wv [64]
+    const int n_head = ACTOR ? d.act : 1;
+    const int o_hb = o_head + n_head * HID;                 // bmu [act] | bv [1]
+    const int o_sig = o_hb + d.act;                         // actor only
+    const int o_loss = d.p_total + net;
 
     constexpr int NA = ACTOR ? ACT_PAD : 1;
-    float dout[NA];                                      // dL/d(head output) per sample
+    float dout[NA];          // dL/d(head output) per sample
+    // row 9 of the misc tile, built as soon as the (wave-uniform) sums exist so that they do not
+    // stay live in SGPRs: lanes 0..7 head-bias grads, 8..15 sigma grads, 16 loss sum
+    float misc = 0.f;
+    const float w = in.w;
     if constexpr (ACTOR) {
-        float mu[ACT_PAD], a[ACT_PAD];
-        head_forward<KS1, ACT_PAD>(lds, 0, h, h2, mu);
-        const float* sig = lds + L::SMALL + 8;
+        float mu[ACT_PAD];
+        head_forward<KS1, 1, ACT_PAD>(lds, 0, h, h2, mu);
+        const float* sm = lds + L::SMALL;
 #pragma unroll
-        for (int k = 0; k < ACT_PAD; ++k) {
-            mu[k] += lds[L::SMALL + k];
-            a[k] = (k < d.act) ? g.act[row * d.act + k] : 0.f;
-        }
-        const float logp = gaussian_logp(mu, a, sig, d.act);
-        float A = g.adv[row];
+        for (int k = 0; k < ACT_PAD; ++k) mu[k] += sm[k];
+        const float logp = gaussian_logp(mu, in.act, sm, d.act);
+        float A = in.adv;
         if (g.adv_norm) A = (A - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);   // ppo.py:184-186
-        const float ratio = expf(logp - g.logp_old[row]);                     // :187
+        const float ratio = expf(logp - in.logp_old);                         // :187
         const float surr1 = ratio * A;
         const float lo = 1.f - g.eps_clip, hi = 1.f + g.eps_clip;
         const float surr2 = fminf(fmaxf(ratio, lo), hi) * A;                  // :190
-        float term, dterm;  // term = -objective; dterm = d term / d ratio
         const float clip1 = fminf(surr1, surr2);
-        float base = (surr1 <= surr2) ? A : 0.f;
+        // torch.min backward: the smaller branch takes the gradient; inside the clip range both
+        // branches are the same value and together pass the full gradient.
+        float basek = (surr1 <= surr2) ? A : 0.f;
+        float term;
         if (g.dual_clip > 0.f) {                                              // :191-194
             const float clip2 = fmaxf(clip1, g.dual_clip * A);
-            if (A < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * A)) base = 0.f; }
+            if (A < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * A)) basek = 0.f; }
             else term = -clip1;
         } else {
             term = -clip1;                                                    // :196
         }
-        dterm = -base;
-        const float w = valid ? g.inv_batch : 0.f;
-        const float dlogp = dterm * ratio * w;
+        const float dlogp = -basek * ratio * w;
         float dsig[ACT_PAD];
 #pragma unroll
         for (int k = 0; k < ACT_PAD; ++k) {
             if (k < d.act) {
-                const float sigma = expf(sig[k]);
-                const float var = sigma * sigma;
-                const float dlt = a[k] - mu[k];
-                dout[k] = dlogp * dlt / var;
-                dsig[k] = dlogp * (dlt * dlt / var - 1.f) - g.ent_coef * w;   // entropy: d/ds = 1
+                const float inv_var = 2.f * sm[8 + k];
+                const float dlt = in.act[k] - mu[k];
+                dout[k] = dlogp * dlt * inv_var;
+                dsig[k] = dlogp * (dlt * dlt * inv_var - 1.f) - g.ent_coef * w;   // entropy: d/ds = 1
             } else {
                 dout[k] = 0.f;
                 dsig[k] = 0.f;
             }
         }
-        // per-wave sums of the clip loss, d sigma, d bmu (count each sample once: half 0)
-        float lsum = (h == 0) ? term * w : 0.f;
-        lsum = half_sum32(lsum) ;
-        if (lane == 0) atomicAdd(&acc[p_net], lsum);
+        {
+            const float sl = sum_half0(term * w);
+            if (lane == 16) misc = sl;
+        }
 #pragma unroll
         for (int k = 0; k < ACT_PAD; ++k) {
-            if (k < d.act) {
-                const float s1 = half_sum32(dsig[k]);
-                const float s2 = half_sum32(dout[k]);
-                if (lane == 0) {
-                    atomicAdd(&acc[o_sig + k], s1);
-                    atomicAdd(&acc[o_hb + k], s2);
-                }
-            }
+            const float sa = sum_half0(dsig[k]);
+            if (lane == 8 + k) misc = sa;
+            const float sb = sum_half0(dout[k]);
+            if (lane == k) misc = sb;
         }
     } else {
         float v[1];
-        head_forward<KS1, 1>(lds, 1, h, h2, v);
-        const float value = v[0] + lds[L::SMALL + 16];
-        const float ret = g.ret[row];
+        head_forward<KS1, 1, 1>(lds, 0, h, h2, v);
+        const float value = v[0] + lds[L::SMALL + 24];
+        const float ret = in.ret;
         float term, dv;
         const float vf1 = (ret - value) * (ret - value);
         if (g.value_clip) {                                                   // ppo.py:199-206
-            const float vo = g.v_old[row];
+            const float vo = in.v_old;
             const float dvo = value - vo;
             const float vclip = vo + fminf(fmaxf(dvo, -g.eps_clip), g.eps_clip);
             const float vf2 = (ret - vclip) * (ret - vclip);
@@ -424,52 +605,67 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
             term = vf1;                                                       // :208
             dv = -2.f * (ret - value);
         }
-        const float w = valid ? g.inv_batch : 0.f;
         dout[0] = dv * g.vf_coef * w;
-        float lsum = (h == 0) ? term * w : 0.f;
-        lsum = half_sum32(lsum);
-        const float bsum = half_sum32(dout[0]);
-        if (lane == 0) {
-            atomicAdd(&acc[p_net + 1], lsum);
-            atomicAdd(&acc[o_hb], bsum);
+        {
+            const float sl = sum_half0(term * w);
+            if (lane == 16) misc = sl;
+            const float sb = sum_half0(dout[0]);
+            if (lane == 0) misc = sb;
         }
     }
 
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 1);
     float* SA = scratch;               // A-side tile
     float* SB = scratch + TILE_SIZE;   // B-side tile
 
-    // ---- head weight gradient: gW[a][f] = sum_s dout[s][a] * H2[s][f]  (lane = feature f)
+    // ---- head weight gradient: gW[a][f] = sum_s dout[s][a] * H2[s][f]  (lane = feature f).
+    // dout of sample s is broadcast through the 4 padding columns of row s of the two tiles.
+    float gw[NA];
     tile_write(SA, h2[0], i, h);
     tile_write(SB, h2[1], i, h);
+    if (lane < 32) {
+        if constexpr (ACTOR) {
+            f32x4 d0 = {dout[0], dout[1], dout[2], dout[3]};
+            f32x4 d1 = {dout[4], dout[5], dout[6], dout[7]};
+            *reinterpret_cast<f32x4*>(SA + lane * TILE_PITCH + 32) = d0;
+            *reinterpret_cast<f32x4*>(SB + lane * TILE_PITCH + 32) = d1;
+        } else {
+            SA[lane * TILE_PITCH + 32] = dout[0];
+        }
+    }
     wave_lds_sync();
     {
         const float* rowp = (lane < 32 ? SA : SB) + (lane & 31) * TILE_PITCH;
-        float hv[32];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 4 * q);
-            hv[4 * q] = v[0]; hv[4 * q + 1] = v[1]; hv[4 * q + 2] = v[2]; hv[4 * q + 3] = v[3];
-        }
-        float gw[NA];
 #pragma unroll
         for (int a = 0; a < NA; ++a) gw[a] = 0.f;
+#pragma unroll 1
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(rowp + 4 * q);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
+            for (int e = 0; e < 4; ++e) {
+                const int smp = 4 * q + e;
+                if constexpr (ACTOR) {
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(SA + smp * TILE_PITCH + 32);   // uniform address
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(SB + smp * TILE_PITCH + 32);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) {
-                const float ds = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dout[a]), s));
-                gw[a] += ds * hv[s];
+                    for (int a = 0; a < 4; ++a) {
+                        gw[a] += d0[a] * hv[e];
+                        gw[a + 4] += d1[a] * hv[e];
+                    }
+                } else {
+                    gw[0] += SA[smp * TILE_PITCH + 32] * hv[e];
+                }
             }
         }
-#pragma unroll
-        for (int a = 0; a < NA; ++a)
-            if (a < (ACTOR ? d.act : 1)) atomicAdd(&acc[o_head + a * HID + lane], gw[a]);
     }
     wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 2);
 
     // ---- dZ2 = (dout . Whead) * (1 - h2^2)   (in place in h2)
     {
-        const float* wh = lds + L::WH + net * L::WH_NET + h * (2 * 16 * ACT_PAD);
+        const float* wh = lds + L::WH + h * (2 * 16 * ACT_PAD);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -486,6 +682,7 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
                 }
                 const float hv = h2[t][r];
                 h2[t][r] = dh * (1.f - hv * hv);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -493,7 +690,7 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
     // ---- dH1^T = W2^T . dZ2^T, then dZ1 = dH1 * (1 - h1^2)
     f32x16 dz1[2];
     {
-        const float* w2 = lds + L::W2 + net * W2_SIZE;
+        const float* w2 = lds + L::W2;
 #pragma unroll
         for (int t1 = 0; t1 < 2; ++t1) {
             f32x16 accd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -502,6 +699,7 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     accd = mfma32(w2[(32 * t + featF(r, h)) * W2_PITCH + 32 * t1 + i], h2[t][r], accd);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -511,6 +709,8 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
             dz1[t1] = accd;
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 3);
 
     // ---- dW2[f2][f1] = sum_s dZ2[s][f2] H1[s][f1];  db2[f2] = sum_s dZ2[s][f2]
     auto dw2_pair = [&](int tM, int tN) {
@@ -520,26 +720,27 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 16; ++s) c = mfma32(av[s], bv[s], c);
+        const RedOut o = reduce_tile(R, c, wave, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            atomicAdd(&acc[o_w2 + (32 * tM + featF(r, h)) * HID + 32 * tN + i], c[r]);
+        for (int q = 0; q < RED_ROWS; ++q)
+            slab_put(slab, o_w2 + (32 * tM + featF(RED_ROWS * wave + q, h)) * HID + 32 * tN + i, o.v[q], first);
     };
-    auto db2_rows = [&](int tM) {
+    auto db2_rows = [&]() -> float {   // lanes 0..31: row sums of the A tile
+        float s = 0.f;
         if (lane < 32) {
-            float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(SA + lane * TILE_PITCH + 4 * q);
                 s += (v[0] + v[1]) + (v[2] + v[3]);
             }
-            atomicAdd(&acc[o_b2 + 32 * tM + lane], s);
         }
+        return s;
     };
     tile_write(SA, h2[0], i, h);      // dZ2 rows 0..31
     tile_write(SB, h1[0], i, h);
     wave_lds_sync();
+    const float b2s0 = db2_rows();
     dw2_pair(0, 0);
-    db2_rows(0);
     wave_lds_sync();
     tile_write(SB, h1[1], i, h);
     wave_lds_sync();
@@ -547,17 +748,18 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
     wave_lds_sync();
     tile_write(SA, h2[1], i, h);      // dZ2 rows 32..63
     wave_lds_sync();
+    const float b2s1 = db2_rows();
     dw2_pair(1, 1);
-    db2_rows(1);
     wave_lds_sync();
     tile_write(SB, h1[0], i, h);
     wave_lds_sync();
     dw2_pair(1, 0);
     wave_lds_sync();
+    TS_MARK(g, MK + 4);
 
     // ---- dW1aug[f1][k] = sum_s dZ1[s][f1] Xaug[s][k]   (k == obs is the bias column)
 #pragma unroll
-    for (int s = 0; s < KS1; ++s) SB[(KS1 * h + s) * TILE_PITCH + i] = x[s];
+    for (int s = 0; s < KS1; ++s) SB[(KS1 * h + s) * TILE_PITCH + i] = in.x[s];
     if (2 * KS1 < 32) {  // rows never written by x: keep them finite
         for (int r = 2 * KS1 + h; r < 32; r += 2) SB[r * TILE_PITCH + i] = 0.f;
     }
@@ -571,149 +773,208 @@ __device__ __forceinline__ void net_tile(float* lds, float* acc, float* scratch,
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 16; ++s) c = mfma32(av[s], bv[s], c);
+        const RedOut o = reduce_tile(R, c, wave, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f1 = 32 * tM + featF(r, h);
-            if (i < d.obs) atomicAdd(&acc[o_w1 + f1 * d.obs + i], c[r]);
-            else if (i == d.obs) atomicAdd(&acc[o_b1 + f1], c[r]);
+        for (int q = 0; q < RED_ROWS; ++q) {
+            const int f1 = 32 * tM + featF(RED_ROWS * wave + q, h);
+            if (i < d.obs) slab_put(slab, o_w1 + f1 * d.obs + i, o.v[q], first);
+            else if (i == d.obs) slab_put(slab, o_b1 + f1, o.v[q], first);
         }
         wave_lds_sync();
+    }
+    TS_MARK(g, MK + 5);
+
+    // ---- misc tile: head weight grads (rows 0..7), b2 (row 8), head bias / sigma / loss (row 9)
+    {
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NA; ++a) c[a] = gw[a];
+        // row 8: lane l<32 holds db2[l] of tM = 0; lanes 32..63 need db2 of tM = 1 (held by lanes 0..31)
+        const float up = __shfl(b2s1, lane & 31, 64);
+        c[8] = (lane < 32) ? b2s0 : up;
+        c[9] = misc;
+        const RedOut o = reduce_tile(R, c, wave, lane);
+#pragma unroll
+        for (int q = 0; q < RED_ROWS; ++q) {
+            const int r = RED_ROWS * wave + q;
+            const float v = o.v[q];
+            if (r < 8) { if (r < n_head) slab_put(slab, o_head + r * HID + lane, v, first); }
+            else if (r == 8) slab_put(slab, o_b2 + lane, v, first);
+            else if (r == 9) {
+                if (lane < 8) { if (lane < n_head) slab_put(slab, o_hb + lane, v, first); }
+                else if (lane < 16) { if (ACTOR && lane - 8 < d.act) slab_put(slab, o_sig + lane - 8, v, first); }
+                else if (lane == 16) slab_put(slab, o_loss, v, first);
+            }
+        }
     }
 }
 
 template <int KS1>
 __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step_kernel(StepArgs g, Dims d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using L = Lds<KS1>;
-    const int acc_len = d.p_actor + N_EXTRA;           // actor is the larger net
-    const int acc_pad = (acc_len + 3) & ~3;
-    float* acc = lds + L::ACC;
-    float* scratch = lds + L::ACC + acc_pad + (threadIdx.x >> 6) * (2 * TILE_SIZE);
+    using L = Lds<KS1, 1>;
+    float* R = lds + L::END;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    stage_weights<KS1>(lds, g.params, d, STEP_THREADS);
-    for (int k = threadIdx.x; k < acc_pad; k += STEP_THREADS) acc[k] = 0.f;
-    __syncthreads();
+    float* scratch = R + STEP_WAVES * RED_SLOT + wave * (2 * TILE_SIZE);
 
     const int64_t n_tiles = (g.n_rows + 31) / 32;
+    const int64_t per_iter = (int64_t)gridDim.x * STEP_WAVES;
+    const int64_t n_iter = (n_tiles + per_iter - 1) / per_iter;   // same for every wave: barriers inside
+    const int64_t tile0 = (int64_t)blockIdx.x * STEP_WAVES + wave;
     float* slab = g.slabs + (int64_t)blockIdx.x * g.slab_w;
 
-    // ---- actor pass
-    for (int64_t tile = (int64_t)blockIdx.x * STEP_WAVES + wave; tile < n_tiles;
-         tile += (int64_t)gridDim.x * STEP_WAVES)
-        net_tile<KS1, true>(lds, acc, scratch, g, d, tile, lane);
-    __syncthreads();
-    for (int k = threadIdx.x; k < d.p_actor; k += STEP_THREADS) slab[k] = acc[k];
-    if (threadIdx.x == 0) slab[d.p_total] = acc[d.p_actor];           // clip-loss sum
-    __syncthreads();
-    for (int k = threadIdx.x; k < acc_pad; k += STEP_THREADS) acc[k] = 0.f;
-    __syncthreads();
-
-    // ---- critic pass
-    const int p_critic = d.p_total - d.p_actor;
-    for (int64_t tile = (int64_t)blockIdx.x * STEP_WAVES + wave; tile < n_tiles;
-         tile += (int64_t)gridDim.x * STEP_WAVES)
-        net_tile<KS1, false>(lds, acc, scratch, g, d, tile, lane);
-    __syncthreads();
-    for (int k = threadIdx.x; k < p_critic; k += STEP_THREADS) slab[d.p_actor + k] = acc[k];
-    if (threadIdx.x == 0) slab[d.p_total + 1] = acc[p_critic + 1];    // vf-loss sum
+    TS_MARK(g, 0);
+    for (int net = 0; net < 2; ++net) {
+        // the record gathers of the first tile fly while this net's weights are staged
+        RecFetch<KS1> f;
+        if (g.dbg_mode != 2) f = rec_fetch<KS1>(g, tile0, lane);
+        else { for (int k = 0; k < RecFetch<KS1>::N; ++k) f.v[k] = f32x4{0.f, 0.f, 0.f, 0.f}; f.w = 0.f; }
+        TS_MARK(g, net ? 21 : 18);
+        if (net) __syncthreads();           // every wave is done reading the previous net's weights
+        TS_MARK(g, net ? 22 : 19);
+        if (g.dbg_mode != 3) stage_weights<KS1, 1, STEP_THREADS>(lds, g.params, d, net);
+        TS_MARK(g, net ? 23 : 20);
+        __syncthreads();
+        TS_MARK(g, net ? 9 : 1);
+        if (g.dbg_mode == 1 || g.dbg_mode == 4) {
+            if (g.dbg_mode == 4) { const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane); if (in.x[0] == 12345.f) slab[0] = in.adv; }
+            if (f.v[0][0] == 12345.f) slab[1] = f.w;
+            return;
+        }
+        for (int64_t it = 0; it < n_iter; ++it) {
+            if (it > 0) f = rec_fetch<KS1>(g, it * per_iter + tile0, lane);
+            const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
+            if (net == 0) net_tile<KS1, true>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
+            else net_tile<KS1, false>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
+        }
+        if (net == 0) TS_MARK(g, 8);
+    }
+    TS_MARK(g, 17);
 }
 
 // ---------------------------------------------------------------------------------------------
-// slab reduction, stage 1: out[q][col] = sum over the q-th quarter of the slabs
-__global__ __launch_bounds__(256) void ppo_reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                               int n_slabs, int slab_w, int n_cols,
-                                                               float* __restrict__ out) {
-    __shared__ float red[4][64];
+// slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
+// partial sum of squares over the parameter columns (for the global gradient norm).
+constexpr int RED_THREADS = 1024;
+
+__global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const float* __restrict__ slabs,
+                                                                       int n_slabs, int slab_w, int n_cols,
+                                                                       int n_params, float* __restrict__ grad,
+                                                                       float* __restrict__ sumsq_part,
+                                                                       const float* __restrict__ params,
+                                                                       int sig_off, int act,
+                                                                       float* __restrict__ losses) {
+    __shared__ float red[RED_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
-    const int quarter = (n_slabs + gridDim.y - 1) / gridDim.y;
-    const int s0 = blockIdx.y * quarter;
-    const int s1 = min(s0 + quarter, n_slabs);
     float s = 0.f;
     if (col < n_cols) {
 #pragma unroll 16
-        for (int k = s0 + wave; k < s1; k += 4) s += slabs[(int64_t)k * slab_w + col];
+        for (int k = wave; k < n_slabs; k += RED_THREADS / 64) s += slabs[(int64_t)k * slab_w + col];
     }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && col < n_cols)
-        out[blockIdx.y * slab_w + col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
+        if (col < n_cols) grad[col] = t;
+        float q = (col < n_params) ? t * t : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+        if (lane == 0) sumsq_part[blockIdx.x] = q;
+        if (losses && blockIdx.x == 0 && lane == 0) {
+            // Normal.entropy() = 0.5 + 0.5 log(2 pi) + log(sigma), summed over actions; identical
+            // for every sample, so its batch mean (ppo.py:210) is the value itself.  Computed here,
+            // before the Adam kernel touches sigma_param.
+            float ent = 0.f;
+            for (int k = 0; k < act; ++k)
+                ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(params[sig_off + k]));
+            losses[3] = ent;
+        }
+    }
 }
 
 struct AdamArgs {
     float* params;
     float* m;
     float* v;
-    const float* stage;      // [n_stage][slab_w] partial sums (or NULL when grad_in is given)
-    int n_stage, slab_w, n_params;
-    const float* grad_in;    // externally reduced gradient (data-parallel path) or NULL
-    float* grad_out;         // final (unclipped) gradient, always written
+    const float* grad;        // [n_params (+2 loss sums)] reduced, unclipped
+    const float* sumsq_part;  // [n_part] partial sums of squares, or NULL -> computed here (DP path)
+    int n_part, n_params;
     float max_grad_norm, lr_step, bc2_sqrt, beta1, beta2, eps;
     float vf_coef, ent_coef;
-    int sig_off, act;        // for the entropy term
-    float* losses;           // [4] loss, clip, vf, ent (or NULL)
-    int apply;               // 0: only produce grad_out (+ loss parts)
+    float* losses;            // [4] loss, clip, vf, ent (or NULL); grad[n_params], grad[n_params+1] hold clip / vf
+    int apply;                // 0: only losses
 };
 
-__global__ __launch_bounds__(1024) void ppo_adam_kernel(AdamArgs a) {
-    __shared__ float red[16];
-    __shared__ float scale_s;
+constexpr int ADAM_THREADS = 256;
+
+__global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
+    __shared__ float red[ADAM_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // global gradient norm: every workgroup re-reduces the (few) partials in the same order
     float sq = 0.f;
-    for (int p = tid; p < a.n_params; p += 1024) {
-        float g;
-        if (a.grad_in) g = a.grad_in[p];
-        else {
-            g = 0.f;
-            for (int q = 0; q < a.n_stage; ++q) g += a.stage[q * a.slab_w + p];
-        }
-        a.grad_out[p] = g;
-        sq += g * g;
+    if (a.sumsq_part) {
+        for (int k = tid; k < a.n_part; k += ADAM_THREADS) sq += a.sumsq_part[k];
+    } else {
+        for (int p = tid; p < a.n_params; p += ADAM_THREADS) { const float gq = a.grad[p]; sq += gq * gq; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
     if (lane == 0) red[wave] = sq;
     __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < 16; ++w) t += red[w];
-        const float norm = sqrtf(t);
-        float scale = 1.f;
-        if (a.max_grad_norm > 0.f) {
-            // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
-            scale = fminf(a.max_grad_norm / (norm + 1e-6f), 1.f);
-        }
-        scale_s = scale;
-        if (a.losses) {
-            float clip = 0.f, vf = 0.f;
-            if (a.stage) {
-                for (int q = 0; q < a.n_stage; ++q) {
-                    clip += a.stage[q * a.slab_w + a.n_params];
-                    vf += a.stage[q * a.slab_w + a.n_params + 1];
-                }
-            }
-            float ent = 0.f;  // Normal.entropy() = 0.5 + 0.5 log(2 pi) + log(sigma), summed over actions
-            for (int k = 0; k < a.act; ++k)
-                ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(a.params[a.sig_off + k]));
-            a.losses[0] = clip + a.vf_coef * vf - a.ent_coef * ent;   // ppo.py:211
-            a.losses[1] = clip;
-            a.losses[2] = vf;
-            a.losses[3] = ent;
-        }
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < ADAM_THREADS / 64; ++k) total += red[k];
+    const float norm = sqrtf(total);
+    float scale = 1.f;
+    // torch.nn.utils.clip_grad_norm_: clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
+    if (a.max_grad_norm > 0.f) scale = fminf(a.max_grad_norm / (norm + 1e-6f), 1.f);
+
+    if (a.losses && blockIdx.x == 0 && tid == 0) {
+        const float clip = a.grad[a.n_params], vf = a.grad[a.n_params + 1];
+        const float ent = a.losses[3];                            // written by the reduce kernel
+        a.losses[0] = clip + a.vf_coef * vf - a.ent_coef * ent;   // ppo.py:211
+        a.losses[1] = clip;
+        a.losses[2] = vf;
     }
-    __syncthreads();
     if (!a.apply) return;
-    const float scale = scale_s;
-    for (int p = tid; p < a.n_params; p += 1024) {
-        const float g = a.grad_out[p] * scale;
+    const int p = blockIdx.x * ADAM_THREADS + tid;
+    if (p < a.n_params) {
+        const float gq = a.grad[p] * scale;
         float m = a.m[p], v = a.v[p];
-        m = m + (g - m) * (1.f - a.beta1);                 // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * a.beta2 + (1.f - a.beta2) * g * g;         // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        m = m + (gq - m) * (1.f - a.beta1);                // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + (1.f - a.beta2) * gq * gq;       // mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
         a.params[p] = a.params[p] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
         a.m[p] = m;
         a.v[p] = v;
+    }
+}
+
+// packs the batch into per-sample records [n][rec_w]: obs | act | adv ret logp_old v_old | 0-pad
+__global__ __launch_bounds__(256) void ppo_pack_kernel(const float* __restrict__ obs,
+                                                       const float* __restrict__ act,
+                                                       const float* __restrict__ adv,
+                                                       const float* __restrict__ ret,
+                                                       const float* __restrict__ logp_old,
+                                                       const float* __restrict__ v_old, int64_t n,
+                                                       int obs_dim, int act_dim, int rec_w,
+                                                       float* __restrict__ rec) {
+    const int64_t total = n * rec_w;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const int64_t row = t / rec_w;
+        const int c = (int)(t - row * rec_w);
+        float v = 0.f;
+        if (c < obs_dim) v = obs[row * obs_dim + c];
+        else if (c < obs_dim + act_dim) v = act[row * act_dim + (c - obs_dim)];
+        else if (c == obs_dim + act_dim) v = adv[row];
+        else if (c == obs_dim + act_dim + 1) v = ret[row];
+        else if (c == obs_dim + act_dim + 2) v = logp_old[row];
+        else if (c == obs_dim + act_dim + 3) v = v_old[row];
+        rec[t] = v;
     }
 }
 
@@ -751,13 +1012,12 @@ __global__ __launch_bounds__(1024) void ppo_adv_stats_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // host side
 template <int KS1>
-size_t step_lds_bytes(const Dims& d) {
-    const int acc_pad = (d.p_actor + N_EXTRA + 3) & ~3;
-    return sizeof(float) * (size_t)(Lds<KS1>::ACC + acc_pad + STEP_WAVES * 2 * TILE_SIZE);
+size_t step_lds_bytes() {
+    return sizeof(float) * (size_t)(Lds<KS1, 1>::END + STEP_WAVES * RED_SLOT + STEP_WAVES * 2 * TILE_SIZE);
 }
 
 template <int KS1>
-size_t infer_lds_bytes() { return sizeof(float) * (size_t)Lds<KS1>::INFER_END; }
+size_t infer_lds_bytes() { return sizeof(float) * (size_t)Lds<KS1, 2>::END; }
 
 inline int ks1_for(int obs) { return (obs + 2) / 2; }  // ceil((obs + 1) / 2)
 
@@ -772,11 +1032,10 @@ inline int ks1_for(int obs) { return (obs + 2) / 2; }  // ceil((obs + 1) / 2)
         case 12: { constexpr int K = 12; CALL; } break;                                \
         case 14: { constexpr int K = 14; CALL; } break;                                \
         case 16: { constexpr int K = 16; CALL; } break;                                \
-        default: return ts::fail(TS_ERR_UNSUPPORTED, "obs_dim %d not supported by the fused MLP kernels", obs_dim); \
+        default: return ts::fail(TS_ERR_UNSUPPORTED, "obs_dim %d not supported by the fused MLP kernels", (int)obs_dim); \
     }
 
 inline int supported_ks(int ks) {
-    switch (ks) { case 1: case 2: case 3: case 4: case 6: case 9: case 12: case 14: case 16: return ks; }
     // round up to the next instantiated width (extra k-steps multiply zero weights)
     const int avail[] = {1, 2, 3, 4, 6, 9, 12, 14, 16};
     for (int a : avail) if (a >= ks) return a;
@@ -784,16 +1043,18 @@ inline int supported_ks(int ks) {
 }
 
 struct WsLayout {
-    size_t slabs, stage, grad, advstats, total;
+    size_t slabs, grad, sumsq, advstats, total;
+    int n_red_blocks;
 };
 
-inline WsLayout ws_layout(int n_wg, int slab_w, int n_params, int64_t n_steps) {
+inline WsLayout ws_layout(int n_wg, int slab_w, int64_t n_steps) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     WsLayout w;
+    w.n_red_blocks = (slab_w + 63) / 64;
     w.slabs = 0;
-    w.stage = al(w.slabs + sizeof(float) * (size_t)n_wg * slab_w);
-    w.grad = al(w.stage + sizeof(float) * 4 * (size_t)slab_w);
-    w.advstats = al(w.grad + sizeof(float) * (size_t)n_params);
+    w.grad = al(w.slabs + sizeof(float) * (size_t)n_wg * slab_w);
+    w.sumsq = al(w.grad + sizeof(float) * (size_t)slab_w);
+    w.advstats = al(w.sumsq + sizeof(float) * (size_t)w.n_red_blocks);
     w.total = al(w.advstats + sizeof(float) * 2 * (size_t)(n_steps > 0 ? n_steps : 1));
     return w;
 }
@@ -819,17 +1080,23 @@ int n_compute_units() {
     return cus;
 }
 
-// launches forward/backward of one minibatch into the slabs, returns number of workgroups
+// launches forward/backward of one minibatch into the slabs
 template <int KS1>
-int launch_step(const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
-    const size_t lds = step_lds_bytes<KS1>(d);
+int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
+    const size_t lds = step_lds_bytes<KS1>();
+    static int dbg_mode = -1;
+    if (dbg_mode < 0) { const char* e = getenv("TS_PPO_DBG_MODE"); dbg_mode = e ? atoi(e) : 0; }
+    const_cast<StepArgs&>(g).dbg_mode = dbg_mode;
     static bool attr_done = false;
     if (!attr_done) {
         TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step_kernel<KS1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+    {
+        ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
+        hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+    }
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -837,8 +1104,8 @@ int launch_step(const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
 inline int step_grid(int64_t n_rows) {
     const int64_t tiles = (n_rows + 31) / 32;
     int64_t wg = (tiles + STEP_WAVES - 1) / STEP_WAVES;
-    const int cus = n_compute_units();
-    if (wg > cus) wg = cus;
+    const int cap = 2 * n_compute_units();   // two 256-thread workgroups per CU
+    if (wg > cap) wg = cap;
     if (wg < 1) wg = 1;
     return (int)wg;
 }
@@ -863,9 +1130,29 @@ inline AdamArgs adam_args(float* params, float* m, float* v, int64_t step, const
     a.lr_step = (float)(hp->lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.beta1 = (float)hp->beta1; a.beta2 = (float)hp->beta2; a.eps = (float)hp->adam_eps;
-    a.vf_coef = (float)hp->vf_coef; a.ent_coef = (float)hp->ent_coef;
-    a.sig_off = d.a_sig; a.act = d.act;
+    a.vf_coef = (float)hp->vf_coef;
+    a.ent_coef = (float)hp->ent_coef;
     return a;
+}
+
+// forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
+// grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
+int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
+             float* sumsq, float* losses, hipStream_t s) {
+    const int64_t obs_dim = d.obs;
+    int rc = TS_OK;
+    const int n_wg = step_grid(g.n_rows);
+    g.slabs = slabs; g.slab_w = slab_w;
+    TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
+    if (rc != TS_OK) return rc;
+    {
+        ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
+        hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
+                           n_wg, slab_w, d.p_total + N_EXTRA, d.p_total, grad, sumsq, g.params, d.a_sig, d.act,
+                           losses);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
 }
 
 }  // namespace
@@ -877,7 +1164,7 @@ int64_t ts_ppo_param_count(int64_t obs_dim, int64_t act_dim) {
     return make_dims((int)obs_dim, (int)act_dim).p_total;
 }
 
-int ts_ppo_infer(const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
+int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                  const float* act, int64_t n, float* v_out, float* logp_out, ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
@@ -892,10 +1179,40 @@ int ts_ppo_infer(const float* params, int64_t obs_dim, int64_t act_dim, const fl
     int64_t wg = (tiles + 7) / 8;
     const int64_t cap = (int64_t)n_compute_units() * 2;
     if (wg > cap) wg = cap;
-    TS_KS1_DISPATCH(ks, {
-        hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
-                           params, d, obs, act, n, v_out, logp_out);
-    });
+    {
+        ts::ProfScope prof(ws, TS_KIND_PPO_INFER, s);
+        TS_KS1_DISPATCH(ks, {
+            hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
+                               params, d, obs, act, n, v_out, logp_out);
+        });
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+static int rec_width(int64_t obs_dim, int64_t act_dim) { return (int)((obs_dim + act_dim + 4 + 3) & ~(int64_t)3); }
+
+int64_t ts_ppo_record_width(int64_t obs_dim, int64_t act_dim) {
+    if (obs_dim < 1 || act_dim < 1) return -1;
+    return rec_width(obs_dim, act_dim);
+}
+
+int ts_ppo_pack_batch(const float* obs, const float* act, const float* adv, const float* returns,
+                      const float* logp_old, const float* v_s, int64_t n, int64_t obs_dim,
+                      int64_t act_dim, float* rec_out, ts_stream_t stream) {
+    int rc = check_dims(obs_dim, act_dim);
+    if (rc != TS_OK) return rc;
+    TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_ppo_pack_batch: negative n");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(obs && act && adv && returns && logp_old && v_s && rec_out, TS_ERR_INVALID_ARG,
+               "ts_ppo_pack_batch: NULL argument");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(rec_out) & 15u) == 0, TS_ERR_INVALID_ARG,
+               "ts_ppo_pack_batch: rec_out must be 16-byte aligned");
+    const int rw = rec_width(obs_dim, act_dim);
+    int64_t blocks = (n * rw + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ppo_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, ts::as_stream(stream), obs, act,
+                       adv, returns, logp_old, v_s, n, (int)obs_dim, (int)act_dim, rw, rec_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -908,7 +1225,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   float* losses_out, float* grads_out, ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
-    TS_REQUIRE(n >= 0 && n_steps >= 0 && adam_step0 >= 0, TS_ERR_INVALID_ARG, "ts_ppo_update: negative size");
+    TS_REQUIRE(n >= 1 && n_steps >= 0 && adam_step0 >= 0, TS_ERR_INVALID_ARG, "ts_ppo_update: bad size");
     if (n_steps == 0) return TS_OK;
     TS_REQUIRE(ws && params && adam_m && adam_v && obs && act && adv && returns && logp_old && v_s &&
                    h_mb_offset && hp,
@@ -923,117 +1240,151 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
     const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
-    const int max_wg = step_grid(max_rows);
-    const WsLayout wl = ws_layout(max_wg, slab_w, d.p_total, n_steps);
-    // device copy of the minibatch offsets lives behind the stats
-    const size_t off_bytes = sizeof(int64_t) * (size_t)(n_steps + 1);
-    rc = ts::ws_reserve(ws, wl.total + off_bytes + 256);
+    const int rw = rec_width(obs_dim, act_dim);
+    const WsLayout wl = ws_layout(step_grid(max_rows), slab_w, n_steps);
+    // behind the fixed part: device copy of the minibatch offsets, then the packed records
+    const size_t off_bytes = (sizeof(int64_t) * (size_t)(n_steps + 1) + 255) & ~(size_t)255;
+    const size_t rec_bytes = sizeof(float) * (size_t)n * rw;
+    rc = ts::ws_reserve(ws, wl.total + off_bytes + rec_bytes + 256);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     float* slabs = reinterpret_cast<float*>(base + wl.slabs);
-    float* stage = reinterpret_cast<float*>(base + wl.stage);
-    float* grad = grads_out ? grads_out : reinterpret_cast<float*>(base + wl.grad);
+    float* grad = reinterpret_cast<float*>(base + wl.grad);
+    float* sumsq = reinterpret_cast<float*>(base + wl.sumsq);
     float* advstats = reinterpret_cast<float*>(base + wl.advstats);
     int64_t* d_off = reinterpret_cast<int64_t*>(base + wl.total);
+    float* rec = reinterpret_cast<float*>(base + wl.total + off_bytes);
     hipStream_t s = ts::as_stream(stream);
 
+    rc = ts_ppo_pack_batch(obs, act, adv, returns, logp_old, v_s, n, obs_dim, act_dim, rec, stream);
+    if (rc != TS_OK) return rc;
     if (hp->adv_norm) {
-        TS_HIP_CHECK(hipMemcpyAsync(d_off, h_mb_offset, off_bytes, hipMemcpyHostToDevice, s));
+        TS_HIP_CHECK(hipMemcpyAsync(d_off, h_mb_offset, sizeof(int64_t) * (size_t)(n_steps + 1),
+                                    hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(ppo_adv_stats_kernel, dim3((unsigned)n_steps), dim3(1024), 0, s, adv, perm,
                            d_off, advstats);
         TS_LAUNCH_CHECK();
     }
     for (int64_t k = 0; k < n_steps; ++k) {
         StepArgs g{};
-        g.params = params; g.obs = obs; g.act = act; g.adv = adv; g.ret = returns;
-        g.logp_old = logp_old; g.v_old = v_s;
-        g.rows = perm ? perm + h_mb_offset[k] : nullptr;
+        g.params = params;
+        g.rec_w = rw;
         g.n_rows = h_mb_offset[k + 1] - h_mb_offset[k];
-        if (!perm) {  // identity rows: shift the base pointers instead
-            const int64_t o = h_mb_offset[k];
-            g.obs = obs + o * obs_dim; g.act = act + o * act_dim; g.adv = adv + o; g.ret = returns + o;
-            g.logp_old = logp_old + o; g.v_old = v_s + o;
-        }
+        if (perm) { g.rec = rec; g.rows = perm + h_mb_offset[k]; }
+        else { g.rec = rec + h_mb_offset[k] * rw; g.rows = nullptr; }   // identity rows: shift the base
         g.inv_batch = 1.0f / (float)g.n_rows;
         g.adv_stats = hp->adv_norm ? advstats + 2 * k : nullptr;
         fill_hparams(g, hp);
-        g.slabs = slabs; g.slab_w = slab_w;
-        const int n_wg = step_grid(g.n_rows);
-        TS_KS1_DISPATCH(ks, { rc = launch_step<K>(g, d, n_wg, s); });
+        float* losses = losses_out ? losses_out + 4 * k : nullptr;
+        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s);
         if (rc != TS_OK) return rc;
-        const int n_stage = n_wg >= 16 ? 4 : 1;
-        hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64, n_stage), dim3(256), 0, s,
-                           slabs, n_wg, slab_w, d.p_total + N_EXTRA, stage);
+        if (grads_out && k == n_steps - 1)
+            TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total,
+                                        hipMemcpyDeviceToDevice, s));
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
-        a.stage = stage; a.n_stage = n_stage; a.slab_w = slab_w;
-        a.grad_in = nullptr; a.grad_out = grad;
-        a.losses = losses_out ? losses_out + 4 * k : nullptr;
-        a.apply = 1;
-        hipLaunchKernelGGL(ppo_adam_kernel, dim3(1), dim3(1024), 0, s, a);
+        a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
+        a.losses = losses; a.apply = 1;
+        {
+            ts::ProfScope prof(ws, TS_KIND_PPO_ADAM, s);
+            hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
+                               dim3(ADAM_THREADS), 0, s, a);
+        }
         TS_LAUNCH_CHECK();
     }
     return TS_OK;
 }
 
 int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
-                const float* obs, const float* act, const float* adv, const float* returns,
-                const float* logp_old, const float* v_s, int64_t n, const int64_t* perm_rows,
-                int64_t n_rows, int64_t global_batch, const float* adv_stats,
-                const ts_ppo_hparams* hp, float* grad_out, float* loss_parts_out,
-                ts_stream_t stream) {
+                const float* rec, int64_t n, const int64_t* perm_rows, int64_t n_rows,
+                int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp,
+                float* grad_out, float* loss_parts_out, ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
     TS_REQUIRE(n_rows >= 1 && global_batch >= n_rows, TS_ERR_SHAPE, "ts_ppo_grad: bad batch sizes");
-    TS_REQUIRE(ws && params && obs && act && adv && returns && logp_old && v_s && hp && grad_out,
-               TS_ERR_INVALID_ARG, "ts_ppo_grad: NULL argument");
+    TS_REQUIRE(ws && params && rec && hp && grad_out, TS_ERR_INVALID_ARG, "ts_ppo_grad: NULL argument");
     TS_REQUIRE(perm_rows || n_rows <= n, TS_ERR_SHAPE, "ts_ppo_grad: n_rows > n");
     TS_REQUIRE(!hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "ts_ppo_grad: adv_norm needs adv_stats");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(rec) & 15u) == 0, TS_ERR_INVALID_ARG,
+               "ts_ppo_grad: rec must be 16-byte aligned");
+    const Dims d = make_dims((int)obs_dim, (int)act_dim);
+    const int ks = supported_ks(ks1_for((int)obs_dim));
+    const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
+    const WsLayout wl = ws_layout(step_grid(n_rows), slab_w, 1);
+    rc = ts::ws_reserve(ws, wl.total);
+    if (rc != TS_OK) return rc;
+    char* base = reinterpret_cast<char*>(ws->base);
+    hipStream_t s = ts::as_stream(stream);
+    StepArgs g{};
+    g.params = params; g.rec = rec; g.rec_w = rec_width(obs_dim, act_dim);
+    g.rows = perm_rows; g.n_rows = n_rows;
+    g.inv_batch = 1.0f / (float)global_batch;
+    g.adv_stats = hp->adv_norm ? adv_stats : nullptr;
+    fill_hparams(g, hp);
+    float* grad = reinterpret_cast<float*>(base + wl.grad);
+    rc = run_grad(ws, g, d, ks, slab_w, reinterpret_cast<float*>(base + wl.slabs), grad,
+                  reinterpret_cast<float*>(base + wl.sumsq), loss_parts_out, s);
+    if (rc != TS_OK) return rc;
+    TS_HIP_CHECK(hipMemcpyAsync(grad_out, grad, sizeof(float) * (size_t)d.p_total, hipMemcpyDeviceToDevice, s));
+    if (loss_parts_out) {
+        // (loss, clip, vf, ent): clip / vf local sums; loss composed from the local parts
+        AdamArgs a = adam_args(const_cast<float*>(params), nullptr, nullptr, 1, d, hp);
+        a.grad = grad; a.sumsq_part = reinterpret_cast<float*>(base + wl.sumsq); a.n_part = wl.n_red_blocks;
+        a.losses = loss_parts_out; a.apply = 0;
+        hipLaunchKernelGGL(ppo_adam_kernel, dim3(1), dim3(ADAM_THREADS), 0, s, a);
+        TS_LAUNCH_CHECK();
+    }
+    return TS_OK;
+}
+
+int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
+                             const float* rec, const int64_t* perm_rows, int64_t n_rows,
+                             const ts_ppo_hparams* hp, int64_t* h_cycles, int64_t n_marks,
+                             ts_stream_t stream) {
+    int rc = check_dims(obs_dim, act_dim);
+    if (rc != TS_OK) return rc;
+    TS_REQUIRE(ws && params && rec && hp && h_cycles, TS_ERR_INVALID_ARG,
+               "ts_debug_ppo_step_cycles: NULL argument");
+    TS_REQUIRE(n_marks >= 18 && n_rows >= 1, TS_ERR_INVALID_ARG, "ts_debug_ppo_step_cycles: need >= 18 marks");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
     const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
     const int n_wg = step_grid(n_rows);
-    const WsLayout wl = ws_layout(n_wg, slab_w, d.p_total, 1);
-    rc = ts::ws_reserve(ws, wl.total);
+    const WsLayout wl = ws_layout(n_wg, slab_w, 1);
+    rc = ts::ws_reserve(ws, wl.total + sizeof(long long) * 64);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
-    float* slabs = reinterpret_cast<float*>(base + wl.slabs);
-    float* stage = reinterpret_cast<float*>(base + wl.stage);
+    long long* dbg = reinterpret_cast<long long*>(base + wl.total);
     hipStream_t s = ts::as_stream(stream);
+    TS_HIP_CHECK(hipMemsetAsync(dbg, 0, sizeof(long long) * 64, s));
     StepArgs g{};
-    g.params = params; g.obs = obs; g.act = act; g.adv = adv; g.ret = returns;
-    g.logp_old = logp_old; g.v_old = v_s; g.rows = perm_rows; g.n_rows = n_rows;
-    g.inv_batch = 1.0f / (float)global_batch;
-    g.adv_stats = hp->adv_norm ? adv_stats : nullptr;
+    g.params = params; g.rec = rec; g.rec_w = rec_width(obs_dim, act_dim);
+    g.rows = perm_rows; g.n_rows = n_rows;
+    g.inv_batch = 1.0f / (float)n_rows;
     fill_hparams(g, hp);
-    g.slabs = slabs; g.slab_w = slab_w;
-    TS_KS1_DISPATCH(ks, { rc = launch_step<K>(g, d, n_wg, s); });
+    g.adv_norm = 0;
+    g.slabs = reinterpret_cast<float*>(base + wl.slabs); g.slab_w = slab_w; g.dbg = dbg;
+    TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
     if (rc != TS_OK) return rc;
-    const int n_stage = n_wg >= 16 ? 4 : 1;
-    hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64, n_stage), dim3(256), 0, s, slabs,
-                       n_wg, slab_w, d.p_total + N_EXTRA, stage);
-    AdamArgs a = adam_args(nullptr, nullptr, nullptr, 1, d, hp);
-    a.params = const_cast<float*>(params);
-    a.stage = stage; a.n_stage = n_stage; a.slab_w = slab_w;
-    a.grad_in = nullptr; a.grad_out = grad_out; a.losses = loss_parts_out; a.apply = 0;
-    a.max_grad_norm = 0.f;
-    hipLaunchKernelGGL(ppo_adam_kernel, dim3(1), dim3(1024), 0, s, a);
-    TS_LAUNCH_CHECK();
+    long long host[64];
+    TS_HIP_CHECK(hipMemcpyAsync(host, dbg, sizeof(host), hipMemcpyDeviceToHost, s));
+    TS_HIP_CHECK(hipStreamSynchronize(s));
+    for (int64_t k = 0; k < n_marks && k < 64; ++k) h_cycles[k] = host[k];
     return TS_OK;
 }
 
 int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
                  int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
                  ts_stream_t stream) {
+    (void)grad_scratch;
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
-    TS_REQUIRE(params && adam_m && adam_v && grad && grad_scratch && hp, TS_ERR_INVALID_ARG,
-               "ts_ppo_apply: NULL argument");
+    TS_REQUIRE(params && adam_m && adam_v && grad && hp, TS_ERR_INVALID_ARG, "ts_ppo_apply: NULL argument");
     TS_REQUIRE(adam_step >= 1, TS_ERR_INVALID_ARG, "ts_ppo_apply: adam_step counts from 1");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     AdamArgs a = adam_args(params, adam_m, adam_v, adam_step, d, hp);
-    a.stage = nullptr; a.n_stage = 0; a.slab_w = 0;
-    a.grad_in = grad; a.grad_out = grad_scratch; a.losses = nullptr; a.apply = 1;
-    hipLaunchKernelGGL(ppo_adam_kernel, dim3(1), dim3(1024), 0, ts::as_stream(stream), a);
+    a.grad = grad; a.sumsq_part = nullptr; a.n_part = 0; a.losses = nullptr; a.apply = 1;
+    hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
+                       dim3(ADAM_THREADS), 0, ts::as_stream(stream), a);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

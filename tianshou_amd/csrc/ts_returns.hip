@@ -463,18 +463,25 @@ int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g, float* adv_out, float* 
                      (reinterpret_cast<uintptr_t>(g.term) & 7u) == 0 &&
                      (reinterpret_cast<uintptr_t>(g.trunc) & 7u) == 0 && aligned16(adv_out) &&
                      aligned16(ret_out);
-    if (vec) {
-        hipLaunchKernelGGL((gae_tile_maps<RewT, true>), dim3((unsigned)n_tiles), dim3(GAE_THREADS),
-                           0, stream, g, maps);
-        hipLaunchKernelGGL((gae_tile_apply<RewT, true>), dim3((unsigned)n_tiles),
-                           dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out, adv64,
-                           ret64, ret_partials);
-    } else {
-        hipLaunchKernelGGL((gae_tile_maps<RewT, false>), dim3((unsigned)n_tiles),
-                           dim3(GAE_THREADS), 0, stream, g, maps);
-        hipLaunchKernelGGL((gae_tile_apply<RewT, false>), dim3((unsigned)n_tiles),
-                           dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out, adv64,
-                           ret64, ret_partials);
+    {
+        ts::ProfScope prof(ws, TS_KIND_GAE_MAPS, stream);
+        if (vec)
+            hipLaunchKernelGGL((gae_tile_maps<RewT, true>), dim3((unsigned)n_tiles),
+                               dim3(GAE_THREADS), 0, stream, g, maps);
+        else
+            hipLaunchKernelGGL((gae_tile_maps<RewT, false>), dim3((unsigned)n_tiles),
+                               dim3(GAE_THREADS), 0, stream, g, maps);
+    }
+    {
+        ts::ProfScope prof(ws, TS_KIND_GAE_APPLY, stream);
+        if (vec)
+            hipLaunchKernelGGL((gae_tile_apply<RewT, true>), dim3((unsigned)n_tiles),
+                               dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out,
+                               adv64, ret64, ret_partials);
+        else
+            hipLaunchKernelGGL((gae_tile_apply<RewT, false>), dim3((unsigned)n_tiles),
+                               dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out,
+                               adv64, ret64, ret_partials);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;

@@ -122,10 +122,26 @@ def infer(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.Tensor, a
     dev = obs.device
     v = torch.empty(n, dtype=torch.float32, device=dev) if want_v else None
     lp = torch.empty(n, dtype=torch.float32, device=dev) if want_logp else None
+    ws = _lib.default_workspace(_dev_index(params))
     _lib.check(_lib.load().ts_ppo_infer(
-        _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.ptr(obs), _lib.ptr(act),
+        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.ptr(obs), _lib.ptr(act),
         _lib.i64(n), _lib.ptr(v), _lib.ptr(lp), _lib.current_stream(dev)))
     return v, lp
+
+
+def pack_batch(b: dict, obs_dim: int, act_dim: int) -> torch.Tensor:
+    """[n, W] packed per-sample records (obs | act | adv ret logp_old v_s | pad), see
+    include/tsengine.h (ts_ppo_pack_batch); used by the data-parallel path."""
+    n = b["obs"].shape[0]
+    lib = _lib.load()
+    lib.ts_ppo_record_width.restype = C.c_int64
+    w = int(lib.ts_ppo_record_width(_lib.i64(obs_dim), _lib.i64(act_dim)))
+    rec = torch.empty((n, w), dtype=torch.float32, device=b["obs"].device)
+    _lib.check(lib.ts_ppo_pack_batch(
+        _lib.ptr(b["obs"]), _lib.ptr(b["act"]), _lib.ptr(b["adv"]), _lib.ptr(b["returns"]),
+        _lib.ptr(b["logp_old"]), _lib.ptr(b["v_s"]), _lib.i64(n), _lib.i64(obs_dim), _lib.i64(act_dim),
+        _lib.ptr(rec), _lib.current_stream(rec.device)))
+    return rec
 
 
 class PPOEngine:
