@@ -169,7 +169,7 @@ def time_gae(learner, iters=50):
     return ms * 1e-3
 
 
-def cpu_baseline(sample_steps=3):
+def cpu_baseline(sample_steps=2):
     """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
     kernels) on the host cores, bounded sample: full preprocess of one 2^20 rollout in
     max_batchsize=65536 chunks + `sample_steps` minibatch gradient steps of 65536; whole-update
@@ -177,7 +177,9 @@ def cpu_baseline(sample_steps=3):
     from oracle import oracle as O
     from oracle import oracle_ppo as OP
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch's intra-op pool on every hardware thread is far slower than a moderate pool for these
+    # small GEMMs (oversubscription); use at most 32 threads and report the count actually used.
+    torch.set_num_threads(max(1, min(32, (os.cpu_count() or 2) // 2)))
     rng = np.random.default_rng(0)
     obs = torch.from_numpy(rng.normal(size=(N_TRANS, OBS)).astype(np.float32))
     obs_next = torch.from_numpy(rng.normal(size=(N_TRANS, OBS)).astype(np.float32))

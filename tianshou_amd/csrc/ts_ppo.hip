@@ -116,49 +116,65 @@ __device__ __forceinline__ void stage_batch(const float* __restrict__ params, fl
     }
 }
 
+// One batch for everything a net needs (W2, W1 image, b2, head image, small block): every global
+// load is in flight before the first LDS store.  The caller must __syncthreads() and then call
+// finish_small() (sigma -> 1/(2 sigma^2), log sigma) followed by another __syncthreads().
 template <int KS1, int NN, int NT>
 __device__ __forceinline__ void stage_weights(float* lds, const float* __restrict__ params,
                                               const Dims& d, int first_net) {
     using L = Lds<KS1, NN>;
-    const int tid = threadIdx.x;
-    for (int slot = 0; slot < NN; ++slot) {
+    constexpr int N_W2 = HID * HID, N_W1 = 2 * KS1 * HID, N_B2 = HID, N_WH = L::WH_NET;
+    constexpr int PER_NET = N_W2 + N_W1 + N_B2 + N_WH;
+    constexpr int COUNT = NN * PER_NET + 32;
+    const int obs = d.obs, act = d.act;
+    auto src = [&](int idx) -> int {
+        if (idx >= NN * PER_NET) {                       // small block (raw values)
+            const int i = idx - NN * PER_NET;
+            if (i < 8) return i < act ? d.a_bmu + i : -1;
+            if (i < 24) return (i & 7) < act ? d.a_sig + (i & 7) : -1;
+            return i == 24 ? d.c_bv : -1;
+        }
+        const int slot = idx / PER_NET;
+        int i = idx - slot * PER_NET;
         const int net = first_net + slot;
-        const int w1 = net ? d.c_w1 : d.a_w1, b1 = net ? d.c_b1 : d.a_b1;
-        const int w2 = net ? d.c_w2 : d.a_w2, b2 = net ? d.c_b2 : d.a_b2;
-        const int obs = d.obs, act = d.act;
-        const int wmu = d.a_wmu, wv = d.c_wv;
-        stage_batch<NT, HID * HID>(params, lds + L::W2 + slot * W2_SIZE,
-                                   [=](int i) { return w2 + i; },
-                                   [=](int i) { return (i >> 6) * W2_PITCH + (i & 63); });
-        stage_batch<NT, 2 * KS1 * HID>(params, lds + L::W1 + slot * L::W1_NET,
-                                       [=](int i) {
-                                           const int k = i >> 6, row = i & 63;
-                                           return k < obs ? w1 + row * obs + k : (k == obs ? b1 + row : -1);
-                                       },
-                                       [=](int i) { return i; });
-        stage_batch<NT, HID>(params, lds + L::B2 + slot * HID, [=](int i) { return b2 + i; },
-                             [=](int i) { return i; });
-        stage_batch<NT, L::WH_NET>(params, lds + L::WH + slot * L::WH_NET,
-                                   [=](int i) {
-                                       const int a = i & 7, r = (i >> 3) & 15, t = (i >> 7) & 1, h = (i >> 8) & 1;
-                                       const int f = 32 * t + featF(r, h);
-                                       if (net == 0) return a < act ? wmu + a * HID + f : -1;
-                                       return a == 0 ? wv + f : -1;
-                                   },
-                                   [=](int i) { return i; });
-    }
-    for (int i = tid; i < 32; i += NT) {
-        float v = 0.f;
-        if (i < 8) { if (i < d.act) v = params[d.a_bmu + i]; }
-        else if (i < 24) {
-            const int k = i & 7;
-            if (k < d.act) {
-                // continuous.py:238 sigma = exp(sigma_param); Normal.log_prob uses var = sigma^2 and log(sigma)
-                const float sigma = expf(params[d.a_sig + k]);
-                v = (i < 16) ? 1.f / (2.f * (sigma * sigma)) : logf(sigma);
-            }
-        } else if (i == 24) v = params[d.c_bv];
-        lds[L::SMALL + i] = v;
+        if (i < N_W2) return (net ? d.c_w2 : d.a_w2) + i;
+        i -= N_W2;
+        if (i < N_W1) {
+            const int k = i >> 6, row = i & 63;
+            const int w1 = net ? d.c_w1 : d.a_w1, b1 = net ? d.c_b1 : d.a_b1;
+            return k < obs ? w1 + row * obs + k : (k == obs ? b1 + row : -1);
+        }
+        i -= N_W1;
+        if (i < N_B2) return (net ? d.c_b2 : d.a_b2) + i;
+        i -= N_B2;
+        const int a = i & 7, r = (i >> 3) & 15, t = (i >> 7) & 1, h = (i >> 8) & 1;
+        const int f = 32 * t + featF(r, h);
+        if (net == 0) return a < act ? d.a_wmu + a * HID + f : -1;
+        return a == 0 ? d.c_wv + f : -1;
+    };
+    auto dst = [&](int idx) -> int {
+        if (idx >= NN * PER_NET) return L::SMALL + (idx - NN * PER_NET);
+        const int slot = idx / PER_NET;
+        int i = idx - slot * PER_NET;
+        if (i < N_W2) return L::W2 + slot * W2_SIZE + (i >> 6) * W2_PITCH + (i & 63);
+        i -= N_W2;
+        if (i < N_W1) return L::W1 + slot * L::W1_NET + i;
+        i -= N_W1;
+        if (i < N_B2) return L::B2 + slot * HID + i;
+        i -= N_B2;
+        return L::WH + slot * L::WH_NET + i;
+    };
+    stage_batch<NT, COUNT>(params, lds, src, dst);
+}
+
+// sigma = exp(sigma_param) (continuous.py:238); Normal.log_prob uses var = sigma^2 and log(sigma)
+template <int KS1, int NN>
+__device__ __forceinline__ void finish_small(float* lds) {
+    using L = Lds<KS1, NN>;
+    const int i = threadIdx.x;
+    if (i >= 8 && i < 24) {
+        const float sigma = expf(lds[L::SMALL + i]);
+        lds[L::SMALL + i] = (i < 16) ? 1.f / (2.f * (sigma * sigma)) : logf(sigma);
     }
 }
 
@@ -292,6 +308,8 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<KS1, 2>;
     stage_weights<KS1, 2, 512>(lds, params, d, 0);
+    __syncthreads();
+    finish_small<KS1, 2>(lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
@@ -435,20 +453,30 @@ struct RecFetch {
     float w;
 };
 
-// issue the global loads of a tile's records (no waiting here)
-template <int KS1>
-__device__ __forceinline__ RecFetch<KS1> rec_fetch(const StepArgs& g, int64_t tile, int lane) {
-    RecFetch<KS1> f;
-    constexpr int REC_FETCH = RecFetch<KS1>::N;
+// row id of the lane's sample (lanes i and i+32 hold the same sample); issued first so that its
+// latency overlaps the weight staging
+struct RowId { int64_t id; float w; };
+
+__device__ __forceinline__ RowId row_fetch(const StepArgs& g, int64_t tile, int lane) {
     const int i = lane & 31;
     const int64_t srow = tile * 32 + i;
     const bool valid = srow < g.n_rows;
     const int64_t pos = valid ? srow : g.n_rows - 1;
-    const int64_t rowid = g.rows ? g.rows[pos] : pos;
-    f.w = valid ? g.inv_batch : 0.f;
+    RowId r;
+    r.id = g.rows ? g.rows[pos] : pos;
+    r.w = valid ? g.inv_batch : 0.f;
+    return r;
+}
+
+// issue the global loads of a tile's records (no waiting here)
+template <int KS1>
+__device__ __forceinline__ RecFetch<KS1> rec_fetch(const StepArgs& g, const RowId& row, int lane) {
+    RecFetch<KS1> f;
+    constexpr int REC_FETCH = RecFetch<KS1>::N;
+    f.w = row.w;
     const int parts = g.rec_w >> 2;
     const int total = 32 * parts;
-    const int lo = (int)(rowid & 0xffffffffLL), hi = (int)(rowid >> 32);
+    const int lo = (int)(row.id & 0xffffffffLL), hi = (int)(row.id >> 32);
 #pragma unroll
     for (int k = 0; k < REC_FETCH; ++k) {
         int q = lane + 64 * k;
@@ -826,23 +854,20 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step_kernel(StepArgs g, D
     TS_MARK(g, 0);
     for (int net = 0; net < 2; ++net) {
         // the record gathers of the first tile fly while this net's weights are staged
-        RecFetch<KS1> f;
-        if (g.dbg_mode != 2) f = rec_fetch<KS1>(g, tile0, lane);
-        else { for (int k = 0; k < RecFetch<KS1>::N; ++k) f.v[k] = f32x4{0.f, 0.f, 0.f, 0.f}; f.w = 0.f; }
+        // order: row ids (one dependent load) -> weights (independent of everything) -> records
+        const RowId row0 = row_fetch(g, tile0, lane);
         TS_MARK(g, net ? 21 : 18);
         if (net) __syncthreads();           // every wave is done reading the previous net's weights
         TS_MARK(g, net ? 22 : 19);
-        if (g.dbg_mode != 3) stage_weights<KS1, 1, STEP_THREADS>(lds, g.params, d, net);
+        stage_weights<KS1, 1, STEP_THREADS>(lds, g.params, d, net);
+        RecFetch<KS1> f = rec_fetch<KS1>(g, row0, lane);
         TS_MARK(g, net ? 23 : 20);
         __syncthreads();
+        finish_small<KS1, 1>(lds);
+        __syncthreads();
         TS_MARK(g, net ? 9 : 1);
-        if (g.dbg_mode == 1 || g.dbg_mode == 4) {
-            if (g.dbg_mode == 4) { const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane); if (in.x[0] == 12345.f) slab[0] = in.adv; }
-            if (f.v[0][0] == 12345.f) slab[1] = f.w;
-            return;
-        }
         for (int64_t it = 0; it < n_iter; ++it) {
-            if (it > 0) f = rec_fetch<KS1>(g, it * per_iter + tile0, lane);
+            if (it > 0) f = rec_fetch<KS1>(g, row_fetch(g, it * per_iter + tile0, lane), lane);
             const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
             if (net == 0) net_tile<KS1, true>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
             else net_tile<KS1, false>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
