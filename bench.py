@@ -95,11 +95,10 @@ class Learner:
         self.eng = PPOEngine(OBS, ACT, init_flat_params(0).to(device), self.cfg)
         self.cut = (torch.arange(N_ENV, device=device) + 1) * T_STEPS - 1   # last slot of every env
         self.rng = np.random.default_rng(1234 + rank)
+        self.gen = torch.Generator(device=device).manual_seed(1234 + rank)
         self._lib = _lib
         self.ws = _lib.default_workspace(device.index)
-        if world > 1:
-            self.grad = torch.empty(self.eng.P + 4, dtype=torch.float32, device=device)
-            self.scratch = torch.empty(self.eng.P, dtype=torch.float32, device=device)
+        self.dp = None
 
     def preprocess(self):
         obs, obs_next, act, rew, term, trunc = self.data
@@ -108,47 +107,20 @@ class Learner:
     def update_once(self):
         """one reference update(): preprocess + REPEAT x (N_TRANS / MINIBATCH) gradient steps."""
         b = self.preprocess()
-        perms = [self.rng.permutation(N_TRANS) for _ in range(REPEAT)]
+        # minibatch order: permutations drawn on the device (the reference draws them with
+        # np.random.permutation on the host, ~10 ms per 2^20 entries - that would dominate here)
+        perms = [torch.randperm(N_TRANS, device=self.device, generator=self.gen) for _ in range(REPEAT)]
         if self.world == 1:
             losses, steps = self.eng.update(b, MINIBATCH, REPEAT, perms)
             return losses, steps
         return self._update_dp(b, perms)
 
     def _update_dp(self, b, perms):
-        import ctypes as C
+        if self.dp is None:
+            from tianshou_amd.distributed import DataParallelPPO
 
-        import torch.distributed as dist
-
-        from tianshou_amd.ppo import pack_batch, split_offsets
-
-        lib, eng = self._lib.load(), self.eng
-        rec = pack_batch(b, OBS, ACT)
-        hp = self.cfg.to_c()
-        offs = split_offsets(N_TRANS, MINIBATCH)
-        losses = []
-        stream = self._lib.current_stream(self.device)
-        for r in range(REPEAT):
-            perm = torch.as_tensor(perms[r], device=self.device)
-            for lo, hi in zip(offs[:-1], offs[1:]):
-                rows = perm[lo:hi]
-                n_rows = hi - lo
-                self._lib.check(lib.ts_ppo_grad(
-                    self.ws.handle, self._lib.ptr(eng.params), self._lib.i64(OBS), self._lib.i64(ACT),
-                    self._lib.ptr(rec), self._lib.i64(N_TRANS), self._lib.ptr(rows), self._lib.i64(n_rows),
-                    self._lib.i64(n_rows * self.world), None, C.byref(hp), self._lib.ptr(self.grad),
-                    C.c_void_p(self.grad.data_ptr() + 4 * eng.P), stream))
-                dist.all_reduce(self.grad)            # RCCL over xGMI: grads + (loss, clip, vf, ent)
-                eng.adam_step += 1
-                self._lib.check(lib.ts_ppo_apply(
-                    self._lib.ptr(eng.params), self._lib.ptr(eng.adam_m), self._lib.ptr(eng.adam_v),
-                    self._lib.i64(eng.adam_step), self._lib.i64(OBS), self._lib.i64(ACT),
-                    self._lib.ptr(self.grad), self._lib.ptr(self.scratch), C.byref(hp), stream))
-                losses.append(self.grad[eng.P:eng.P + 4].clone())
-        out = torch.stack(losses)
-        # the entropy term is parameter-only, every rank contributed the same value to the sum
-        out[:, 3] /= self.world
-        out[:, 0] = out[:, 1] + self.cfg.vf_coef * out[:, 2] - self.cfg.ent_coef * out[:, 3]
-        return out, len(losses)
+            self.dp = DataParallelPPO(self.eng)
+        return self.dp.update(b, MINIBATCH, REPEAT, perms)
 
 
 def time_gae(learner, iters=50):
@@ -277,7 +249,8 @@ def main():
         torch.cuda.synchronize()
         if world == 1:
             learner.ws.profile_begin()
-            perms = [learner.rng.permutation(N_TRANS) for _ in range(REPEAT)]
+            perms = [torch.randperm(N_TRANS, device=device, generator=learner.gen) for _ in range(REPEAT)]
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
             learner.eng.update(b, MINIBATCH, REPEAT, perms)
             torch.cuda.synchronize()

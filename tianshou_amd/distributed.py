@@ -1,0 +1,118 @@
+"""Data-parallel PPO update: one process per GPU, replay buffer sharded by sub-buffer (env id),
+RCCL all-reduce of the flat fp32 gradient per minibatch step.
+
+The reference has no distributed path (its only multi-GPU mechanism is single-process
+``nn.DataParallel``, tianshou/utils/net/common.py:473-515).  Sharding follows SURVEY 8e: episodes
+never span sub-buffers (ReplayBufferManager offsets, manager.py:50; the end-flag cut at each
+sub-buffer tail, algorithm_base.py:715), so sampling, index math, GAE and logp_old are shard-local
+and need no exchange.  Per gradient step exactly one collective moves P + 4 floats (gradient +
+loss parts); with advantage normalisation one more tiny collective per update() makes the
+per-minibatch mean / std global (ppo.py:184-186 semantics over the global minibatch).
+
+Semantics: global minibatch k = union over ranks of each rank's k-th local minibatch; the loss is
+the mean over the global minibatch, so every rank scales its local sums by 1 / global_batch and
+the all-reduce (sum) yields exactly the single-process gradient.  Clip + Adam then run
+identically on every replica.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .ppo import PPOEngine, pack_batch, split_offsets
+
+
+def shard_envs(n_env: int, rank: int, world: int) -> tuple[int, int]:
+    """Sub-buffers [lo, hi) owned by `rank`: contiguous, sizes differ by at most one."""
+    if not 0 <= rank < world:
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_env, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_adv_stats(adv: torch.Tensor, perm_rows: list[torch.Tensor], group=None) -> torch.Tensor:
+    """{mean, unbiased std} of every GLOBAL minibatch -> float32 [n_steps, 2] on adv's device.
+    One all-reduce of 3 * n_steps float64 values per update()."""
+    acc = torch.zeros((len(perm_rows), 3), dtype=torch.float64, device=adv.device)
+    for k, rows in enumerate(perm_rows):
+        a = adv[rows].double()
+        acc[k, 0] = a.sum()
+        acc[k, 1] = (a * a).sum()
+        acc[k, 2] = a.numel()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, group=group)
+    n = acc[:, 2]
+    mean = acc[:, 0] / n
+    var = (acc[:, 1] - n * mean * mean) / (n - 1.0)       # torch.std(): unbiased
+    return torch.stack([mean, var.clamp_min(0).sqrt()], dim=1).float().contiguous()
+
+
+class DataParallelPPO:
+    """PPO._update_with_batch (ppo.py:164-224) over `world` replicas of a PPOEngine."""
+
+    def __init__(self, engine: PPOEngine, group=None):
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._buf = None
+
+    # -- the two device steps around the collective (overridden by the CPU test double) --------
+    def _local_grad(self, rec, rows, global_batch, adv_stats, out):
+        """out[:P] = sum over local rows of d loss_i / global_batch; out[P:P+4] = loss parts."""
+        eng, lib = self.eng, _lib.load()
+        hp = eng.cfg.to_c()
+        _lib.check(lib.ts_ppo_grad(
+            eng._ws.handle, _lib.ptr(eng.params), _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim),
+            _lib.ptr(rec), _lib.i64(rec.shape[0]), _lib.ptr(rows), _lib.i64(rows.numel()),
+            _lib.i64(global_batch), _lib.ptr(adv_stats), C.byref(hp), _lib.ptr(out),
+            C.c_void_p(out.data_ptr() + 4 * eng.P), _lib.current_stream(eng.device)))
+
+    def _apply(self, grad):
+        eng, lib = self.eng, _lib.load()
+        hp = eng.cfg.to_c()
+        eng.adam_step += 1
+        _lib.check(lib.ts_ppo_apply(
+            _lib.ptr(eng.params), _lib.ptr(eng.adam_m), _lib.ptr(eng.adam_v), _lib.i64(eng.adam_step),
+            _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim), _lib.ptr(grad), None, C.byref(hp),
+            _lib.current_stream(eng.device)))
+
+    def _pack(self, b):
+        return pack_batch(b, self.eng.obs_dim, self.eng.act_dim)
+
+    # -- update loop ----------------------------------------------------------------------------
+    def update(self, b: dict, batch_size: int | None, repeat: int, perms):
+        """Every rank passes its LOCAL batch `b` and LOCAL permutations; all ranks must use the same
+        local batch size so that the k-th minibatches line up.  Returns (losses [steps, 4] with
+        global loss values, steps)."""
+        eng, cfg = self.eng, self.eng.cfg
+        if cfg.recompute_advantage:
+            raise NotImplementedError("recompute_advantage is not supported on the data-parallel path yet")
+        n = b["obs"].shape[0]
+        dev = b["obs"].device
+        offs = split_offsets(n, batch_size, merge_last=True)
+        rec = self._pack(b)
+        steps = [(r, lo, hi) for r in range(repeat) for lo, hi in zip(offs[:-1], offs[1:])]
+        perm_t = [p.to(device=dev, dtype=torch.int64) if isinstance(p, torch.Tensor)
+                  else torch.as_tensor(np.asarray(p, dtype=np.int64), device=dev) for p in perms]
+        rows_all = [perm_t[r][lo:hi] for r, lo, hi in steps]
+        stats = global_adv_stats(b["adv"], rows_all, self.group) if cfg.advantage_normalization else None
+        if self._buf is None or self._buf.device != dev:
+            self._buf = torch.empty(eng.P + 4, dtype=torch.float32, device=dev)
+        out = self._buf
+        losses = []
+        for k, rows in enumerate(rows_all):
+            self._local_grad(rec, rows, rows.numel() * self.world, None if stats is None else stats[k], out)
+            if self.world > 1:
+                dist.all_reduce(out, group=self.group)      # RCCL: gradient + loss parts in one call
+            self._apply(out)
+            losses.append(out[eng.P:eng.P + 4].clone())
+        res = torch.stack(losses)
+        # the entropy term depends on the parameters only: every rank added the same value
+        res[:, 3] /= self.world
+        res[:, 0] = res[:, 1] + cfg.vf_coef * res[:, 2] - cfg.ent_coef * res[:, 3]
+        return res, len(losses)

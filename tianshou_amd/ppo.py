@@ -224,8 +224,10 @@ class PPOEngine:
         """PPO._update_with_batch (ppo.py:164-224).
 
         `perms`: sequence of `repeat` permutations of range(N) - the np.random.permutation draws
-        of Batch.split (batch.py:1209).  None draws them from the global NumPy RNG exactly like
-        the reference.  Returns (losses float32[steps, 4] device tensor with columns
+        of Batch.split (batch.py:1209); entries may be NumPy arrays (parity with a seeded
+        reference run) or int64 device tensors (e.g. torch.randperm on the GPU, which keeps the
+        host off the critical path).  None draws them from the global NumPy RNG exactly like the
+        reference.  Returns (losses float32[steps, 4] device tensor with columns
         (loss, clip_loss, vf_loss, ent_loss), gradient_steps[, last unclipped gradient])."""
         n = b["obs"].shape[0]
         cfg = self.cfg
@@ -234,8 +236,11 @@ class PPOEngine:
         offs1 = split_offsets(n, batch_size, merge_last=True)
         out, grads = [], None
         if not cfg.recompute_advantage:
-            perm = torch.as_tensor(np.concatenate([np.asarray(p, dtype=np.int64) for p in perms]),
-                                   device=self.device)
+            if all(isinstance(p, torch.Tensor) for p in perms):
+                perm = torch.cat([p.to(device=self.device, dtype=torch.int64) for p in perms])
+            else:
+                perm = torch.as_tensor(np.concatenate([np.asarray(p, dtype=np.int64) for p in perms]),
+                                       device=self.device)
             offsets = [r * n + o for r in range(repeat) for o in offs1[:-1]] + [repeat * n]
             losses, grads = self._run_steps(b, perm, offsets, want_grad)
             out.append(losses)
@@ -246,7 +251,8 @@ class PPOEngine:
                         b["obs"], b["obs_next"], b["rew"], b["terminated"], b["truncated"],
                         b["cut_pos"], b.get("d_n_cut"))
                     b = dict(b, v_s=v_s, returns=returns, adv=adv)
-                perm = torch.as_tensor(np.asarray(perms[r], dtype=np.int64), device=self.device)
+                perm = (perms[r].to(device=self.device, dtype=torch.int64) if isinstance(perms[r], torch.Tensor)
+                        else torch.as_tensor(np.asarray(perms[r], dtype=np.int64), device=self.device))
                 losses, grads = self._run_steps(b, perm, offs1, want_grad)
                 out.append(losses)
         losses = torch.cat(out, dim=0)
