@@ -88,6 +88,12 @@ int ts_gae_scan(ts_workspace* ws, const float* v_s, const float* v_s_next, const
                 float* returns_out, double* adv64, double* ret64, double* ret_partials,
                 ts_stream_t stream);
 
+/* The scan is a single launch: workgroups hand their tile maps to each other through a small
+ * persistent area of the workspace (bounded spins, launch-epoch tags).  ts_gae_check reports
+ * (after synchronising the stream) whether any spin ever ran out; 0 = all scans valid.
+ * Setting TS_GAE_TWO_PASS=1 selects the two-launch variant without cross-workgroup hand-off. */
+int ts_gae_check(ts_workspace* ws, int* h_error_out, ts_stream_t stream);
+
 /* Positions of unfinished slots inside a batch: for the general (non-identity) `indices`
  * of compute_episodic_return, algorithm_base.py:715 `np.isin(indices, unfinished_index())`.
  * Writes the matching batch positions to cut_pos_out (capacity >= n_unfinished * dup, see

@@ -239,3 +239,27 @@ def test_nstep_shape_mismatch_raises_value_error():
 
     with pytest.raises(ValueError, match="mismatch"):
         R.compute_nstep_return(B3(), buf, dev(np.arange(4)), lambda b, a: torch.zeros(4, device="cuda"))
+
+
+def test_gae_single_pass_handoff_under_load():
+    """Many tiles (more than can be resident), no episode end at all and gamma*lambda = 1: every
+    workgroup has to fold the maps of ALL following tiles, i.e. the cross-workgroup hand-off is
+    exercised at full depth; repeated launches reuse the persistent hand-off area (epoch tags)."""
+    from tianshou_amd import _lib
+    from tianshou_amd import returns as R
+
+    n = (1 << 23) + 777
+    rng = np.random.default_rng(17)
+    rew = rng.normal(size=n)
+    z = np.zeros(n, np.float32)
+    f = np.zeros(n, bool)
+    ref = O._gae(z, z, rew, f, 1.0, 1.0)
+    dz, drew, df = dev(z), dev(rew), dev(f)
+    for rep in range(3):
+        out = R.gae_scan(dz, dz, drew, df, df, None, gamma=1.0, gae_lambda=1.0, want_f64=True)
+        np.testing.assert_allclose(out["adv64"].cpu().numpy(), ref, rtol=0, atol=1e-7)
+    # a different size right after (ticket base / epoch bookkeeping)
+    m = 123457
+    out = R.gae_scan(dz[:m], dz[:m], drew[:m], df[:m], df[:m], None, gamma=1.0, gae_lambda=1.0, want_f64=True)
+    np.testing.assert_allclose(out["adv64"].cpu().numpy(), O._gae(z[:m], z[:m], rew[:m], f[:m], 1.0, 1.0), rtol=0, atol=1e-8)
+    assert _lib.default_workspace(0).gae_check() == 0

@@ -12,7 +12,7 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libtsengine.so")
+LIB_PATH = os.environ.get("TS_LIB_PATH") or os.path.join(_PKG, "lib", "libtsengine.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "tsengine.h")
 
 TS_OK = 0
@@ -138,6 +138,12 @@ class Workspace:
         cnt = (C.c_int64 * n)()
         check(load().ts_profile_end(self._h, ms, cnt, C.c_int(n)))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
+
+    def gae_check(self) -> int:
+        """0 if every single-pass GAE scan on this workspace completed its hand-offs (synchronises)."""
+        err = C.c_int(0)
+        check(load().ts_gae_check(self._h, C.byref(err), current_stream()))
+        return int(err.value)
 
     def close(self) -> None:
         if self._h:

@@ -20,6 +20,8 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libtsengine.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# per-file extra flags (experiments: TS_EXTRA_FLAGS="ts_ppo.hip:-mllvm -amdgpu-sched-strategy=max-ilp")
+EXTRA_FLAGS: dict[str, list[str]] = {}
 
 
 def _hipcc() -> str:
@@ -39,19 +41,27 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJDIR, exist_ok=True)
+def build_library(force: bool = False, verbose: bool = False, out: str | None = None) -> str:
+    global LIB, OBJDIR
+    extra = dict(EXTRA_FLAGS)
+    env = os.environ.get("TS_EXTRA_FLAGS")
+    if env:
+        name, _, fl = env.partition(":")
+        extra[name] = fl.split()
+    lib_path = out or LIB
+    objdir = OBJDIR if out is None else OBJDIR + "_" + os.path.basename(out).replace(".", "_")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     hdr_m = _deps_mtime()
     jobs = []
     objs = []
     for src in sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         stale = (force or not os.path.exists(obj)
                  or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_m))
         if stale:
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *extra.get(os.path.basename(src), []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -65,10 +75,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB])
-    return LIB
+    if jobs or not os.path.exists(lib_path):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib_path])
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose=True))
+    out = None
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            out = a[6:]
+    print(build_library(force="--force" in sys.argv, verbose=True, out=out))

@@ -50,6 +50,12 @@ struct ts_workspace {
     // persistent sum-tree winner table (int32[bound], kept at -1 between calls)
     int32_t* winner;
     int64_t winner_len;
+    // single-pass GAE scan: persistent cross-workgroup hand-off state (never reset between launches:
+    // tags are launch epochs, tile tickets are offset by the running base)
+    void* gae_sync;              // [ticket u64][error u32][pad] + per tile {a bits, b bits, flag}
+    int64_t gae_sync_tiles;      // capacity in tiles
+    unsigned long long gae_ticket_base[8];
+    unsigned int gae_epoch;
     // optional per-kernel timing with HIP events on the launch stream (ts_profile_begin/end)
     int profiling;
     hipEvent_t* ev;      // [2 * ev_cap] start/stop pairs

@@ -122,9 +122,10 @@ int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes) {
 
 int ts_workspace_destroy(ts_workspace* ws) {
     if (!ws) return TS_OK;
-    if (ws->base || ws->winner || ws->ev) {
+    if (ws->base || ws->winner || ws->ev || ws->gae_sync) {
         (void)hipSetDevice(ws->device);
         (void)hipDeviceSynchronize();
+        if (ws->gae_sync) (void)hipFree(ws->gae_sync);
         if (ws->base) (void)hipFree(ws->base);
         if (ws->winner) (void)hipFree(ws->winner);
         if (ws->ev) {

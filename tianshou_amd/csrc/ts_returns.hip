@@ -16,6 +16,8 @@
 //
 // No FMA contraction in this file: the reference (numba, NumPy) rounds mul and add separately,
 // and the n-step path is required to be bit-exact in float64.
+#include <cstdlib>
+
 #include "ts_common.h"
 
 #pragma clang fp contract(off)
@@ -89,71 +91,88 @@ struct GaeArgs {
     double gamma, gl, v_scale, ret_div;
 };
 
-// Loads the thread's GAE_ITEMS transitions and converts them to per-element (d, c) plus the
-// scaled value vs needed for returns.  Elements past n behave like a finished episode with
-// zero reward (c = 0, d = 0).
-template <typename RewT, bool VEC>
-__device__ __forceinline__ void gae_load_items(const GaeArgs<RewT>& g, int64_t base,
-                                               const uint32_t* cutmask, double (&vs)[GAE_ITEMS],
-                                               double (&d)[GAE_ITEMS], double (&c)[GAE_ITEMS]) {
+// Raw inputs of the thread's GAE_ITEMS transitions (issued before anything that has to wait, so
+// that their HBM latency overlaps the ticket / cut-list round trips).
+struct GaeRaw {
     float fv[GAE_ITEMS], fn[GAE_ITEMS];
     double rw[GAE_ITEMS];
     uint8_t te[GAE_ITEMS], tr[GAE_ITEMS];
+};
+
+template <typename RewT, bool VEC>
+__device__ __forceinline__ void gae_load_raw(const GaeArgs<RewT>& g, int64_t base, GaeRaw& r) {
     const bool full = base + GAE_ITEMS <= g.n;
     if (VEC && full) {
         const float4* pv = reinterpret_cast<const float4*>(g.v_s + base);
         const float4* pn = reinterpret_cast<const float4*>(g.v_n + base);
         float4 a0 = pv[0], a1 = pv[1], b0 = pn[0], b1 = pn[1];
-        fv[0] = a0.x; fv[1] = a0.y; fv[2] = a0.z; fv[3] = a0.w;
-        fv[4] = a1.x; fv[5] = a1.y; fv[6] = a1.z; fv[7] = a1.w;
-        fn[0] = b0.x; fn[1] = b0.y; fn[2] = b0.z; fn[3] = b0.w;
-        fn[4] = b1.x; fn[5] = b1.y; fn[6] = b1.z; fn[7] = b1.w;
+        r.fv[0] = a0.x; r.fv[1] = a0.y; r.fv[2] = a0.z; r.fv[3] = a0.w;
+        r.fv[4] = a1.x; r.fv[5] = a1.y; r.fv[6] = a1.z; r.fv[7] = a1.w;
+        r.fn[0] = b0.x; r.fn[1] = b0.y; r.fn[2] = b0.z; r.fn[3] = b0.w;
+        r.fn[4] = b1.x; r.fn[5] = b1.y; r.fn[6] = b1.z; r.fn[7] = b1.w;
         if constexpr (sizeof(RewT) == 4) {
             const float4* pr = reinterpret_cast<const float4*>(g.rew + base);
             float4 r0 = pr[0], r1 = pr[1];
-            rw[0] = r0.x; rw[1] = r0.y; rw[2] = r0.z; rw[3] = r0.w;
-            rw[4] = r1.x; rw[5] = r1.y; rw[6] = r1.z; rw[7] = r1.w;
+            r.rw[0] = r0.x; r.rw[1] = r0.y; r.rw[2] = r0.z; r.rw[3] = r0.w;
+            r.rw[4] = r1.x; r.rw[5] = r1.y; r.rw[6] = r1.z; r.rw[7] = r1.w;
         } else {
             const double2* pr = reinterpret_cast<const double2*>(g.rew + base);
 #pragma unroll
             for (int k = 0; k < GAE_ITEMS / 2; ++k) {
-                double2 r = pr[k];
-                rw[2 * k] = r.x;
-                rw[2 * k + 1] = r.y;
+                double2 q = pr[k];
+                r.rw[2 * k] = q.x;
+                r.rw[2 * k + 1] = q.y;
             }
         }
         const uint2 t8 = *reinterpret_cast<const uint2*>(g.term + base);
         const uint2 u8 = *reinterpret_cast<const uint2*>(g.trunc + base);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            te[k] = (t8.x >> (8 * k)) & 0xFF;
-            te[4 + k] = (t8.y >> (8 * k)) & 0xFF;
-            tr[k] = (u8.x >> (8 * k)) & 0xFF;
-            tr[4 + k] = (u8.y >> (8 * k)) & 0xFF;
+            r.te[k] = (t8.x >> (8 * k)) & 0xFF;
+            r.te[4 + k] = (t8.y >> (8 * k)) & 0xFF;
+            r.tr[k] = (u8.x >> (8 * k)) & 0xFF;
+            r.tr[4 + k] = (u8.y >> (8 * k)) & 0xFF;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < GAE_ITEMS; ++k) {
             const int64_t i = base + k;
             const bool ok = i < g.n;
-            fv[k] = ok ? g.v_s[i] : 0.f;
-            fn[k] = ok ? g.v_n[i] : 0.f;
-            rw[k] = ok ? (double)g.rew[i] : 0.0;
-            te[k] = ok ? g.term[i] : (uint8_t)1;
-            tr[k] = ok ? g.trunc[i] : (uint8_t)1;
+            r.fv[k] = ok ? g.v_s[i] : 0.f;
+            r.fn[k] = ok ? g.v_n[i] : 0.f;
+            r.rw[k] = ok ? (double)g.rew[i] : 0.0;
+            r.te[k] = ok ? g.term[i] : (uint8_t)1;
+            r.tr[k] = ok ? g.trunc[i] : (uint8_t)1;
         }
     }
+}
+
+// per-element (d, c) plus the scaled value vs needed for returns.  Elements past n behave like
+// a finished episode with zero reward (c = 0, d = 0).
+template <typename RewT>
+__device__ __forceinline__ void gae_convert(const GaeArgs<RewT>& g, int64_t base, const GaeRaw& r,
+                                            const uint32_t* cutmask, double (&vs)[GAE_ITEMS],
+                                            double (&d)[GAE_ITEMS], double (&c)[GAE_ITEMS]) {
     const int local = (int)(base % GAE_TILE);
 #pragma unroll
     for (int k = 0; k < GAE_ITEMS; ++k) {
         const int bit = local + k;
         const bool cut = (cutmask[bit >> 5] >> (bit & 31)) & 1u;
-        const bool end = (te[k] != 0) | (tr[k] != 0) | cut;
-        vs[k] = (double)fv[k] * g.v_scale;
-        const double vn = ((double)fn[k] * g.v_scale) * (te[k] != 0 ? 0.0 : 1.0);
-        d[k] = rw[k] + vn * g.gamma - vs[k];
+        const bool end = (r.te[k] != 0) | (r.tr[k] != 0) | cut;
+        vs[k] = (double)r.fv[k] * g.v_scale;
+        const double vn = ((double)r.fn[k] * g.v_scale) * (r.te[k] != 0 ? 0.0 : 1.0);
+        d[k] = r.rw[k] + vn * g.gamma - vs[k];
         c[k] = end ? 0.0 : g.gl;
     }
+}
+
+template <typename RewT, bool VEC>
+__device__ __forceinline__ void gae_load_items(const GaeArgs<RewT>& g, int64_t base,
+                                               const uint32_t* cutmask, double (&vs)[GAE_ITEMS],
+                                               double (&d)[GAE_ITEMS], double (&c)[GAE_ITEMS]) {
+    GaeRaw r;
+    gae_load_raw<RewT, VEC>(g, base, r);
+    gae_convert(g, base, r, cutmask, vs, d, c);
 }
 
 template <typename RewT>
@@ -196,6 +215,65 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_tile_maps(GaeArgs<RewT> g, do
     gae_load_items<RewT, VEC>(g, tile_start + (int64_t)threadIdx.x * GAE_ITEMS, cutmask, vs, d, c);
     Aff t = block_reduce_aff(items_to_aff(d, c), lds);
     if (threadIdx.x == 0) tile_map[tile] = make_double2(t.a, t.b);
+}
+
+template <bool VEC, typename RewT>
+__device__ __forceinline__ void gae_store_outputs(const GaeArgs<RewT>& g, int64_t base,
+                                                  const double (&adv)[GAE_ITEMS],
+                                                  const double (&ret)[GAE_ITEMS], float* adv_out,
+                                                  float* ret_out, double* adv64, double* ret64) {
+    const bool full = base + GAE_ITEMS <= g.n;
+    if (VEC && full) {
+        float4 a0, a1, r0, r1;
+        a0.x = (float)adv[0]; a0.y = (float)adv[1]; a0.z = (float)adv[2]; a0.w = (float)adv[3];
+        a1.x = (float)adv[4]; a1.y = (float)adv[5]; a1.z = (float)adv[6]; a1.w = (float)adv[7];
+        r0.x = (float)(ret[0] / g.ret_div); r0.y = (float)(ret[1] / g.ret_div);
+        r0.z = (float)(ret[2] / g.ret_div); r0.w = (float)(ret[3] / g.ret_div);
+        r1.x = (float)(ret[4] / g.ret_div); r1.y = (float)(ret[5] / g.ret_div);
+        r1.z = (float)(ret[6] / g.ret_div); r1.w = (float)(ret[7] / g.ret_div);
+        float4* pa = reinterpret_cast<float4*>(adv_out + base);
+        float4* pr = reinterpret_cast<float4*>(ret_out + base);
+        pa[0] = a0; pa[1] = a1;
+        pr[0] = r0; pr[1] = r1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < GAE_ITEMS; ++k)
+            if (base + k < g.n) {
+                adv_out[base + k] = (float)adv[k];
+                ret_out[base + k] = (float)(ret[k] / g.ret_div);
+            }
+    }
+    if (adv64 || ret64) {
+#pragma unroll
+        for (int k = 0; k < GAE_ITEMS; ++k)
+            if (base + k < g.n) {
+                if (adv64) adv64[base + k] = adv[k];
+                if (ret64) ret64[base + k] = ret[k];
+            }
+    }
+}
+
+__device__ __forceinline__ void gae_store_partials(double s1, double s2, int lane, int wave, int64_t tile,
+                                                   double* red, double* ret_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off, 64);
+        s2 += __shfl_down(s2, off, 64);
+    }
+    if (lane == 0) {
+        red[2 * wave] = s1;
+        red[2 * wave + 1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < GAE_WAVES; ++w) {
+            t1 += red[2 * w];
+            t2 += red[2 * w + 1];
+        }
+        ret_partials[2 * tile] = t1;
+        ret_partials[2 * tile + 1] = t2;
+    }
 }
 
 // pass 2: carry-in from later tiles, in-tile suffix scan, outputs
@@ -253,56 +331,141 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_tile_apply(GaeArgs<RewT> g,
             s2 += ret[k] * ret[k];
         }
     }
-    const bool full = base + GAE_ITEMS <= g.n;
-    if (VEC && full) {
-        float4 a0, a1, r0, r1;
-        a0.x = (float)adv[0]; a0.y = (float)adv[1]; a0.z = (float)adv[2]; a0.w = (float)adv[3];
-        a1.x = (float)adv[4]; a1.y = (float)adv[5]; a1.z = (float)adv[6]; a1.w = (float)adv[7];
-        r0.x = (float)(ret[0] / g.ret_div); r0.y = (float)(ret[1] / g.ret_div);
-        r0.z = (float)(ret[2] / g.ret_div); r0.w = (float)(ret[3] / g.ret_div);
-        r1.x = (float)(ret[4] / g.ret_div); r1.y = (float)(ret[5] / g.ret_div);
-        r1.z = (float)(ret[6] / g.ret_div); r1.w = (float)(ret[7] / g.ret_div);
-        float4* pa = reinterpret_cast<float4*>(adv_out + base);
-        float4* pr = reinterpret_cast<float4*>(ret_out + base);
-        pa[0] = a0; pa[1] = a1;
-        pr[0] = r0; pr[1] = r1;
-    } else {
-#pragma unroll
-        for (int k = 0; k < GAE_ITEMS; ++k)
-            if (base + k < g.n) {
-                adv_out[base + k] = (float)adv[k];
-                ret_out[base + k] = (float)(ret[k] / g.ret_div);
-            }
+    gae_store_outputs<VEC>(g, base, adv, ret, adv_out, ret_out, adv64, ret64);
+    if (ret_partials) gae_store_partials(s1, s2, lane, wave, tile, red, ret_partials);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-pass variant: one launch, every input byte read once.  Workgroups claim tiles from the END
+// of the array through a ticket (so a tile only ever waits for tiles claimed before it: no
+// residency assumption, no deadlock), publish their tile map, and fold the maps of the following
+// tiles as soon as those are published.  The maps do not depend on each other (unlike a prefix
+// sum's running prefix), so there is no serial chain across tiles; the wait is normally one
+// flag poll.  Hand-off per MI355X rules: 8-byte agent-scope (sc1, write-through) payload stores,
+// drain, agent-scope flag store; consumer polls the flag relaxed at agent scope and reads the
+// payload with agent-scope loads.  Flags carry the launch epoch, so nothing is reset between
+// launches.
+constexpr int GAE_SHARDS = 8;   // ticket counters (one word saturates at ~88 atomics/us)
+
+struct GaeSyncHeader {
+    unsigned long long ticket[GAE_SHARDS];   // shard k hands out sequence numbers 8 j + k
+    unsigned int error;       // set when a spin ran out (results invalid, no hang)
+    unsigned int pad[3];
+};
+
+struct GaeLaunch {
+    unsigned long long base[GAE_SHARDS];     // running ticket base of every shard
+    int direct;                              // 1: tile = f(blockIdx), grid small enough to be resident
+};
+
+struct GaeTileMsg {
+    unsigned long long a_bits, b_bits;
+    unsigned int flag;
+    unsigned int pad;
+};
+
+constexpr unsigned GAE_SPIN_LIMIT = 1u << 22;
+
+template <typename RewT, bool VEC>
+__global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, GaeSyncHeader* hdr,
+                                                               GaeTileMsg* msg, int64_t n_tiles,
+                                                               GaeLaunch launch,
+                                                               unsigned int epoch, float* adv_out,
+                                                               float* ret_out, double* adv64,
+                                                               double* ret64, double* ret_partials) {
+    __shared__ uint32_t cutmask[GAE_TILE / 32];
+    __shared__ Aff lds[GAE_WAVES];
+    __shared__ double red[2 * GAE_WAVES];
+    __shared__ int64_t tile_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (launch.direct) {
+        // every workgroup of this launch is resident at once (small grid): no ticket needed
+        if (threadIdx.x == 0) tile_s = n_tiles - 1 - (int64_t)blockIdx.x;
+    } else if (threadIdx.x == 0) {
+        const int shard = blockIdx.x & (GAE_SHARDS - 1);
+        const unsigned long long t = __hip_atomic_fetch_add(&hdr->ticket[shard], 1ULL, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t seq = (int64_t)(t - launch.base[shard]) * GAE_SHARDS + shard;
+        tile_s = n_tiles - 1 - seq;                            // sequence 0 -> last tile
     }
-    if (adv64 || ret64) {
-#pragma unroll
-        for (int k = 0; k < GAE_ITEMS; ++k)
-            if (base + k < g.n) {
-                if (adv64) adv64[base + k] = adv[k];
-                if (ret64) ret64[base + k] = ret[k];
-            }
+    __syncthreads();
+    const int64_t tile = tile_s;
+    const int64_t tile_start = tile * GAE_TILE;
+    double vs[GAE_ITEMS], d[GAE_ITEMS], c[GAE_ITEMS];
+    const int64_t base = tile_start + (int64_t)threadIdx.x * GAE_ITEMS;
+    {
+        GaeRaw raw;
+        gae_load_raw<RewT, VEC>(g, base, raw);      // HBM loads in flight ...
+        gae_build_cutmask(g, tile_start, cutmask);    // ... while the cut list is scattered into LDS
+        gae_convert(g, base, raw, cutmask, vs, d, c);
     }
-    if (ret_partials) {
+    const Aff mine = items_to_aff(d, c);
+
+    // in-tile suffix scan first (its wave maps also give the tile map)
+    const Aff incl = wave_suffix_scan_aff(mine, lane);
+    Aff excl = shfl_down_aff(incl, 1);
+    if (lane == 63) excl = aff_identity();
+    if (lane == 0) lds[wave] = incl;
+    __syncthreads();
+    Aff wmap[GAE_WAVES];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s1 += __shfl_down(s1, off, 64);
-            s2 += __shfl_down(s2, off, 64);
-        }
-        if (lane == 0) {
-            red[2 * wave] = s1;
-            red[2 * wave + 1] = s2;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int w = 0; w < GAE_WAVES; ++w) {
-                t1 += red[2 * w];
-                t2 += red[2 * w + 1];
+    for (int w = 0; w < GAE_WAVES; ++w) wmap[w] = lds[w];
+    if (threadIdx.x == 0) {
+        Aff t = wmap[0];
+#pragma unroll
+        for (int w = 1; w < GAE_WAVES; ++w) t = compose(t, wmap[w]);
+        __hip_atomic_store(&msg[tile].a_bits, (unsigned long long)__double_as_longlong(t.a), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&msg[tile].b_bits, (unsigned long long)__double_as_longlong(t.b), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&msg[tile].flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // carry-in: fold the maps of the following tiles until an episode end.  Growing windows
+    // (1, 15, 240, then 256 tiles per round): with episode ends in nearly every tile only the next
+    // tile's flag is ever polled, while the worst case (no end at all) still costs O(n_tiles / 256)
+    // rounds per tile.
+    Aff acc = aff_identity();
+    int64_t t0 = tile + 1;
+    for (int round = 0; t0 < n_tiles; ++round) {
+        const int width = round == 0 ? 1 : (round == 1 ? 15 : (round == 2 ? 240 : GAE_THREADS));
+        Aff f = aff_identity();
+        const int64_t t = t0 + threadIdx.x;
+        if ((int)threadIdx.x < width && t < n_tiles) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&msg[t].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > GAE_SPIN_LIMIT) { hdr->error = 1u; break; }
             }
-            ret_partials[2 * tile] = t1;
-            ret_partials[2 * tile + 1] = t2;
+            const unsigned long long ab = __hip_atomic_load(&msg[t].a_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long bb = __hip_atomic_load(&msg[t].b_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f = Aff{__longlong_as_double((long long)ab), __longlong_as_double((long long)bb)};
+        }
+        acc = compose(acc, block_reduce_aff(f, lds));
+        if (acc.a == 0.0) break;  // an episode ended: nothing further can leak in (uniform)
+        t0 += width;
+    }
+    double wave_carry = acc.b;
+#pragma unroll
+    for (int w = GAE_WAVES - 1; w >= 0; --w)
+        if (w > wave) wave_carry = wmap[w].b + wmap[w].a * wave_carry;
+    double x = excl.b + excl.a * wave_carry;
+
+    double adv[GAE_ITEMS], ret[GAE_ITEMS];
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = GAE_ITEMS - 1; k >= 0; --k) {
+        x = d[k] + c[k] * x;
+        adv[k] = x;
+        ret[k] = x + vs[k];
+        if (base + k < g.n) {
+            s1 += ret[k];
+            s2 += ret[k] * ret[k];
         }
     }
+    gae_store_outputs<VEC>(g, base, adv, ret, adv_out, ret_out, adv64, ret64);
+    if (ret_partials) gae_store_partials(s1, s2, lane, wave, tile, red, ret_partials);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -452,17 +615,73 @@ inline int grid_for(int64_t n, int block) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+int gae_sync_reserve(ts_workspace* ws, int64_t n_tiles, hipStream_t stream) {
+    if (!ws) return ts::fail(TS_ERR_WORKSPACE, "workspace is NULL");
+    if (ws->gae_sync && ws->gae_sync_tiles >= n_tiles && ws->gae_epoch < 0xfffffff0u) return TS_OK;
+    TS_HIP_CHECK(hipSetDevice(ws->device));
+    int64_t cap = ws->gae_sync_tiles > 0 ? ws->gae_sync_tiles : 1024;
+    while (cap < n_tiles) cap *= 2;
+    if (ws->gae_sync) {
+        TS_HIP_CHECK(hipDeviceSynchronize());
+        if (cap != ws->gae_sync_tiles) {
+            TS_HIP_CHECK(hipFree(ws->gae_sync));
+            ws->gae_sync = nullptr;
+        }
+    }
+    const size_t bytes = sizeof(GaeSyncHeader) + sizeof(GaeTileMsg) * (size_t)cap;
+    if (!ws->gae_sync) TS_HIP_CHECK(hipMalloc(&ws->gae_sync, bytes));
+    TS_HIP_CHECK(hipMemsetAsync(ws->gae_sync, 0, bytes, stream));
+    ws->gae_sync_tiles = cap;
+    for (int k = 0; k < GAE_SHARDS; ++k) ws->gae_ticket_base[k] = 0;
+    ws->gae_epoch = 0;
+    return TS_OK;
+}
+
+bool gae_force_two_pass() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("TS_GAE_TWO_PASS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
 template <typename RewT>
 int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g, float* adv_out, float* ret_out,
                double* adv64, double* ret64, double* ret_partials, hipStream_t stream) {
     const int64_t n_tiles = ts::ceil_div(g.n, GAE_TILE);
-    int rc = ts::ws_reserve(ws, sizeof(double2) * (size_t)n_tiles);
-    if (rc != TS_OK) return rc;
-    double2* maps = reinterpret_cast<double2*>(ws->base);
     const bool vec = aligned16(g.v_s) && aligned16(g.v_n) && aligned16(g.rew) &&
                      (reinterpret_cast<uintptr_t>(g.term) & 7u) == 0 &&
                      (reinterpret_cast<uintptr_t>(g.trunc) & 7u) == 0 && aligned16(adv_out) &&
                      aligned16(ret_out);
+    if (!gae_force_two_pass()) {
+        int rc = gae_sync_reserve(ws, n_tiles, stream);
+        if (rc != TS_OK) return rc;
+        GaeSyncHeader* hdr = reinterpret_cast<GaeSyncHeader*>(ws->gae_sync);
+        GaeTileMsg* msg = reinterpret_cast<GaeTileMsg*>(hdr + 1);
+        const unsigned int epoch = ++ws->gae_epoch;
+        GaeLaunch base;
+        // <= 4 workgroups of 256 threads per CU are resident for certain (102 VGPRs -> 4 waves per
+        // SIMD, 0.4 KB LDS): then no workgroup can wait for one that has not started.
+        base.direct = n_tiles <= 1024 ? 1 : 0;
+        for (int k = 0; k < GAE_SHARDS; ++k) {
+            base.base[k] = ws->gae_ticket_base[k];
+            // blocks b with b % 8 == k claim from shard k: as many as sequence numbers = k (mod 8)
+            if (!base.direct)
+                ws->gae_ticket_base[k] += (unsigned long long)((n_tiles - k + GAE_SHARDS - 1) / GAE_SHARDS);
+        }
+        ts::ProfScope prof(ws, TS_KIND_GAE_APPLY, stream);
+        if (vec)
+            hipLaunchKernelGGL((gae_single_pass<RewT, true>), dim3((unsigned)n_tiles), dim3(GAE_THREADS), 0,
+                               stream, g, hdr, msg, n_tiles, base, epoch, adv_out, ret_out, adv64, ret64,
+                               ret_partials);
+        else
+            hipLaunchKernelGGL((gae_single_pass<RewT, false>), dim3((unsigned)n_tiles), dim3(GAE_THREADS), 0,
+                               stream, g, hdr, msg, n_tiles, base, epoch, adv_out, ret_out, adv64, ret64,
+                               ret_partials);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    }
+    int rc = ts::ws_reserve(ws, sizeof(double2) * (size_t)n_tiles);
+    if (rc != TS_OK) return rc;
+    double2* maps = reinterpret_cast<double2*>(ws->base);
     {
         ts::ProfScope prof(ws, TS_KIND_GAE_MAPS, stream);
         if (vec)
@@ -516,6 +735,18 @@ int ts_gae_scan(ts_workspace* ws, const float* v_s, const float* v_s_next, const
     GaeArgs<double> g{v_s, v_s_next, (const double*)rew, terminated, truncated, cut_pos, d_n_cut,
                       n_cut, n, gamma, gamma * gae_lambda, v_scale, ret_div};
     return launch_gae(ws, g, adv_out, returns_out, adv64, ret64, ret_partials, s);
+}
+
+int ts_gae_check(ts_workspace* ws, int* error_out, ts_stream_t stream) {
+    TS_REQUIRE(ws && error_out, TS_ERR_INVALID_ARG, "ts_gae_check: NULL argument");
+    *error_out = 0;
+    if (!ws->gae_sync) return TS_OK;
+    GaeSyncHeader h;
+    hipStream_t s = ts::as_stream(stream);
+    TS_HIP_CHECK(hipMemcpyAsync(&h, ws->gae_sync, sizeof(h), hipMemcpyDeviceToHost, s));
+    TS_HIP_CHECK(hipStreamSynchronize(s));
+    *error_out = (int)h.error;
+    return TS_OK;
 }
 
 int ts_isin_positions(const int64_t* indices, int64_t n, const int64_t* unfinished,
