@@ -221,6 +221,10 @@ typedef struct ts_ppo_hparams {
     double adam_eps;      /* Adam eps */
     int32_t value_clip;   /* ppo.py:199-206 */
     int32_t adv_norm;     /* ppo.py:184-186 */
+    int32_t algo;         /* 0 = PPO clipped surrogate (ppo.py:187-196);
+                             1 = A2C policy gradient -(logp * adv).mean() + plain MSE value loss
+                                 (modelfree/a2c.py:262-273; eps/dual/value clip, adv_norm, logp_old unused) */
+    int32_t reserved;
 } ts_ppo_hparams;
 
 /* No-grad inference passes of PPO._preprocess_batch / _add_returns_and_advantages

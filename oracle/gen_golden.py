@@ -28,6 +28,7 @@ from torch import nn  # noqa: E402
 from torch.distributions import Independent, Normal  # noqa: E402
 
 from tianshou.algorithm import Algorithm  # noqa: E402
+from tianshou.algorithm.modelfree.a2c import A2C  # noqa: E402
 from tianshou.algorithm.modelfree.ppo import PPO  # noqa: E402
 from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy  # noqa: E402
 from tianshou.algorithm.optim import AdamOptimizerFactory  # noqa: E402
@@ -317,7 +318,7 @@ def _flat_adam(algorithm, actor, critic, key: str) -> np.ndarray:
 
 
 def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int,
-            seed: int, n_updates: int = 1, **ppo_kwargs) -> None:
+            seed: int, n_updates: int = 1, algo: str = "ppo", **ppo_kwargs) -> None:
     """Runs the reference PPO.update() on a synthetic VectorReplayBuffer and dumps every
     intermediate the engine has to reproduce."""
     rng = np.random.default_rng(seed)
@@ -345,7 +346,8 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True,
                                       action_bound_method="clip", action_space=space)
     lr = ppo_kwargs.pop("lr", 3e-4)
-    algorithm = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+    cls = PPO if algo == "ppo" else A2C
+    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
 
     out: dict[str, np.ndarray] = {}
     out["flat_params0"] = _flat_from_modules(actor, critic)
@@ -368,7 +370,7 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
         return orig_from(cls, seq)
 
     pre_dump: dict[str, np.ndarray] = {}
-    orig_pre = PPO._preprocess_batch
+    orig_pre = cls._preprocess_batch
 
     def rec_pre(self, batch, buffer, indices):
         b = orig_pre(self, batch, buffer, indices)
@@ -376,14 +378,14 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
             pre_dump["v_s"] = b.v_s.numpy().copy()
             pre_dump["returns"] = b.returns.numpy().copy()
             pre_dump["adv"] = b.adv.numpy().copy()
-            pre_dump["logp_old"] = b.logp_old.numpy().copy()
+            pre_dump["logp_old"] = b.logp_old.numpy().copy() if algo == "ppo" else np.zeros(len(indices), np.float32)
             pre_dump["indices"] = np.asarray(indices, np.int64)
             pre_dump["unfinished"] = np.asarray(buffer.unfinished_index(), np.int64)
         return b
 
     np.random.permutation = rec_perm
     SequenceSummaryStats.from_sequence = classmethod(rec_from)
-    PPO._preprocess_batch = rec_pre
+    cls._preprocess_batch = rec_pre
     try:
         for u in range(n_updates):
             buf = VectorReplayBuffer(N, E)
@@ -434,17 +436,20 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     finally:
         np.random.permutation = orig_perm
         SequenceSummaryStats.from_sequence = classmethod(orig_from)
-        PPO._preprocess_batch = orig_pre
+        cls._preprocess_batch = orig_pre
     for k, v in pre_dump.items():
         out["pre_" + k] = v
-    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
-               dual_clip=algorithm.dual_clip or 0.0, value_clip=float(algorithm.value_clip),
-               advantage_normalization=float(algorithm.advantage_normalization),
-               recompute_advantage=float(algorithm.recompute_adv), vf_coef=algorithm.vf_coef,
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda,
+               eps_clip=getattr(algorithm, "eps_clip", 0.0),
+               dual_clip=getattr(algorithm, "dual_clip", None) or 0.0,
+               value_clip=float(getattr(algorithm, "value_clip", False)),
+               advantage_normalization=float(getattr(algorithm, "advantage_normalization", False)),
+               recompute_advantage=float(getattr(algorithm, "recompute_adv", False)), vf_coef=algorithm.vf_coef,
                ent_coef=algorithm.ent_coef,
                max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
                return_scaling=float(algorithm.return_scaling), lr=lr,
                max_batchsize=float(algorithm.max_batchsize))
+    cfg["is_a2c"] = float(algo == "a2c")
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
@@ -463,6 +468,10 @@ def main() -> None:
     # library defaults (ppo.py:24-36) + dual clip + recompute_advantage, ragged last minibatch
     gen_ppo("defaults", E=4, T=75, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=1,
             n_updates=1, dual_clip=3.0, recompute_advantage=True, lr=1e-3, max_batchsize=64)
+    # A2C (a2c.py:163-290) with the same nets: vf 0.5, ent 0.01, max_grad_norm 0.5, return scaling
+    gen_ppo("a2c", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=2,
+            n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
+            return_scaling=True, lr=7e-4, max_batchsize=256)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

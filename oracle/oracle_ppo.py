@@ -112,6 +112,7 @@ def dist_of(mu, sigma):
 
 @dataclass
 class PPOConfig:
+    algo: str = "ppo"          # "ppo" (ppo.py:164-224) or "a2c" (a2c.py:249-290)
     gamma: float = 0.99
     gae_lambda: float = 0.95
     eps_clip: float = 0.2
@@ -195,6 +196,8 @@ def preprocess(state: PPOState, cfg: PPOConfig, obs, obs_next, act, rew, termina
     """ppo.py:146-162 -> dict(v_s, returns, adv, logp_old)."""
     v_s, returns, adv = add_returns_and_advantages(state, cfg, obs, obs_next, rew, terminated,
                                                    truncated, indices, unfinished)
+    if cfg.algo == "a2c":      # A2C._preprocess_batch (a2c.py:239-247) has no logp_old
+        return {"v_s": v_s, "returns": returns, "adv": adv, "logp_old": torch.zeros_like(adv)}
     logp = []
     with torch.no_grad():
         for lo, hi in split_slices(obs.shape[0], cfg.max_batchsize, merge_last=True):
@@ -256,6 +259,20 @@ def ppo_minibatch_loss(p, cfg: PPOConfig, obs, act, adv, returns, logp_old, v_s)
     return loss, clip_loss, vf_loss, ent_loss
 
 
+def a2c_minibatch_loss(p, cfg: PPOConfig, obs, act, adv, returns):
+    """a2c.py:262-273 on one minibatch -> (loss, actor_loss, vf_loss, ent_loss)."""
+    mu, sigma = actor_forward(p, obs)
+    dist = dist_of(mu, sigma)
+    log_prob = dist.log_prob(act)
+    log_prob = log_prob.reshape(len(adv), -1).transpose(0, 1)
+    actor_loss = -(log_prob * adv).mean()
+    value = critic_forward(p, obs).flatten()
+    vf_loss = torch.nn.functional.mse_loss(returns, value)
+    ent_loss = dist.entropy().mean()
+    loss = actor_loss + cfg.vf_coef * vf_loss - cfg.ent_coef * ent_loss
+    return loss, actor_loss, vf_loss, ent_loss
+
+
 def update(state: PPOState, cfg: PPOConfig, data: dict, pre: dict, batch_size: int | None,
            repeat: int, perms: list[np.ndarray], recompute=None, collect_grads: bool = False):
     """ppo.py:164-224.  ``perms[r]`` is the np.random.permutation(N) the reference draws in
@@ -275,9 +292,13 @@ def update(state: PPOState, cfg: PPOConfig, data: dict, pre: dict, batch_size: i
         for lo, hi in split_slices(n, size, merge_last=True):
             idx = perm[lo:hi]
             p = {k: v.detach().clone().requires_grad_(True) for k, v in state.params.items()}
-            loss, clip_loss, vf_loss, ent_loss = ppo_minibatch_loss(
-                p, cfg, obs[idx], act[idx], pre["adv"][idx], pre["returns"][idx],
-                pre["logp_old"][idx], pre["v_s"][idx])
+            if cfg.algo == "a2c":
+                loss, clip_loss, vf_loss, ent_loss = a2c_minibatch_loss(
+                    p, cfg, obs[idx], act[idx], pre["adv"][idx], pre["returns"][idx])
+            else:
+                loss, clip_loss, vf_loss, ent_loss = ppo_minibatch_loss(
+                    p, cfg, obs[idx], act[idx], pre["adv"][idx], pre["returns"][idx],
+                    pre["logp_old"][idx], pre["v_s"][idx])
             loss.backward()
             plist = [p[k] for k in PARAM_ORDER]
             for t in plist:

@@ -67,6 +67,8 @@ CFGS = {
     "mujoco": dict(eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, value_clip=True,
                    advantage_normalization=False, return_scaling=True, lr=3e-4),
     "defaults": dict(dual_clip=3.0, recompute_advantage=True, lr=1e-3),
+    "a2c": dict(algo="a2c", vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=True, lr=7e-4,
+                advantage_normalization=False),
     "plain": dict(value_clip=False, advantage_normalization=True, ent_coef=0.01, vf_coef=0.5,
                   max_grad_norm=None, lr=1e-3),
 }
@@ -96,7 +98,7 @@ def run_oracle(params, data, ocfg, batch_size, repeat, perms, n_env):
     return st, pre, losses, grads, unf
 
 
-@pytest.mark.parametrize("cfg_name", ["mujoco", "defaults", "plain"])
+@pytest.mark.parametrize("cfg_name", ["mujoco", "defaults", "plain", "a2c"])
 @pytest.mark.parametrize("n,n_env,batch_size,repeat", [(512, 8, 128, 2), (1000, 4, 300, 2), (4096, 16, 4096, 1)])
 def test_update_matches_oracle(cfg_name, n, n_env, batch_size, repeat):
     from tianshou_amd import ppo as P
@@ -133,10 +135,11 @@ def _cfg_from_golden(g):
         dual_clip=(c["dual_clip"] or None), value_clip=bool(c["value_clip"]),
         advantage_normalization=bool(c["advantage_normalization"]),
         recompute_advantage=bool(c["recompute_advantage"]), vf_coef=c["vf_coef"], ent_coef=c["ent_coef"],
-        max_grad_norm=(c["max_grad_norm"] or None), return_scaling=bool(c["return_scaling"]), lr=c["lr"])
+        max_grad_norm=(c["max_grad_norm"] or None), return_scaling=bool(c["return_scaling"]), lr=c["lr"],
+        algo="a2c" if c.get("is_a2c") else "ppo")
 
 
-@pytest.mark.parametrize("tag", ["mujoco", "defaults"])
+@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c"])
 def test_update_matches_reference_golden(tag):
     """Same Batch inputs, initial weights and permutations as the reference run that produced
     tests/golden/ppo_<tag>.npz; compares every intermediate the reference exposes."""
@@ -236,3 +239,30 @@ def test_single_step_all_loss_branches(value_clip, dual_clip, adv_norm):
     np.testing.assert_allclose(losses.cpu().numpy()[0],
                                [loss.item(), clip_loss.item(), vf_loss.item(), ent_loss.item()], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(grads.cpu().numpy(), g_ref, rtol=1e-4, atol=2e-6 * float(np.abs(g_ref).max()))
+
+
+@pytest.mark.parametrize("cfg_name", ["mujoco", "plain"])
+def test_data_parallel_path_world1_matches_fused_update(cfg_name):
+    """ts_ppo_pack_batch + ts_ppo_grad + ts_ppo_apply (the split the RCCL all-reduce sits in) must
+    reproduce ts_ppo_update exactly the same way on one rank (world size 1, no process group)."""
+    from tianshou_amd import ppo as P
+    from tianshou_amd.distributed import DataParallelPPO
+
+    n, batch, repeat = 3000, 700, 2
+    params, data = random_problem(n, 17, 6, seed=31)
+    _, cfg = both_cfgs(cfg_name)
+    cfg.return_scaling = False
+    rng = np.random.default_rng(4)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    unf = np.arange(6) * 500 + 499
+    engs = [P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg) for _ in range(2)]
+    bs = [e.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                       dev(data["terminated"]), dev(data["truncated"]), dev(unf)) for e in engs]
+    l_ref, steps_ref = engs[0].update(bs[0], batch, repeat, perms)
+    l_dp, steps_dp = DataParallelPPO(engs[1]).update(bs[1], batch, repeat, perms)
+    assert steps_ref == steps_dp and engs[0].adam_step == engs[1].adam_step
+    # the apply step re-derives the gradient norm with a different summation order (1 ulp in the
+    # clip factor), hence fp32-rounding-level differences only
+    np.testing.assert_allclose(l_dp.cpu().numpy(), l_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(engs[1].params.cpu().numpy(), engs[0].params.cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(engs[1].adam_v.cpu().numpy(), engs[0].adam_v.cpu().numpy(), rtol=1e-5, atol=1e-12)

@@ -162,10 +162,10 @@ def _cfg_from(g):
         recompute_advantage=bool(c["recompute_advantage"]), vf_coef=c["vf_coef"],
         ent_coef=c["ent_coef"], max_grad_norm=(c["max_grad_norm"] or None),
         return_scaling=bool(c["return_scaling"]), lr=c["lr"],
-        max_batchsize=int(c["max_batchsize"]))
+        max_batchsize=int(c["max_batchsize"]), algo="a2c" if c.get("is_a2c") else "ppo")
 
 
-@pytest.mark.parametrize("tag", ["mujoco", "defaults"])
+@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c"])
 def test_ppo_restatement_matches_reference(tag):
     torch.set_num_threads(4)
     g = load(f"ppo_{tag}.npz")

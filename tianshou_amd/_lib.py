@@ -46,6 +46,8 @@ class PPOHParams(C.Structure):
         ("adam_eps", C.c_double),
         ("value_clip", C.c_int32),
         ("adv_norm", C.c_int32),
+        ("algo", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

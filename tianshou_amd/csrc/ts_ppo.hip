@@ -352,7 +352,7 @@ struct StepArgs {
     float inv_batch;          // 1 / global minibatch size
     const float* adv_stats;   // {mean, std} of this minibatch (device) or NULL
     float eps_clip, dual_clip, vf_coef, ent_coef;
-    int value_clip, adv_norm;
+    int value_clip, adv_norm, a2c;
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
     long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
@@ -569,7 +569,8 @@ __device__ __forceinline__ void net_tile(float* lds, float* R, float* scratch, c
         const float logp = gaussian_logp(mu, in.act, sm, d.act);
         float A = in.adv;
         if (g.adv_norm) A = (A - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);   // ppo.py:184-186
-        const float ratio = expf(logp - in.logp_old);                         // :187
+        // A2C (a2c.py:266-267): term = -logp * adv, d term / d logp = -adv  == "ratio" fixed at 1
+        const float ratio = g.a2c ? 1.f : expf(logp - in.logp_old);           // :187
         const float surr1 = ratio * A;
         const float lo = 1.f - g.eps_clip, hi = 1.f + g.eps_clip;
         const float surr2 = fminf(fmaxf(ratio, lo), hi) * A;                  // :190
@@ -578,7 +579,10 @@ __device__ __forceinline__ void net_tile(float* lds, float* R, float* scratch, c
         // branches are the same value and together pass the full gradient.
         float basek = (surr1 <= surr2) ? A : 0.f;
         float term;
-        if (g.dual_clip > 0.f) {                                              // :191-194
+        if (g.a2c) {
+            term = -logp * A;
+            basek = A;
+        } else if (g.dual_clip > 0.f) {                                       // :191-194
             const float clip2 = fmaxf(clip1, g.dual_clip * A);
             if (A < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * A)) basek = 0.f; }
             else term = -clip1;
@@ -1140,8 +1144,10 @@ inline void fill_hparams(StepArgs& g, const ts_ppo_hparams* hp) {
     g.dual_clip = (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
     g.vf_coef = (float)hp->vf_coef;
     g.ent_coef = (float)hp->ent_coef;
-    g.value_clip = hp->value_clip;
-    g.adv_norm = hp->adv_norm;
+    g.a2c = hp->algo == 1;
+    g.value_clip = g.a2c ? 0 : hp->value_clip;
+    g.adv_norm = g.a2c ? 0 : hp->adv_norm;
+    if (g.a2c) g.dual_clip = 0.f;
 }
 
 inline AdamArgs adam_args(float* params, float* m, float* v, int64_t step, const Dims& d,

@@ -74,7 +74,9 @@ def flat_to_modules(flat: torch.Tensor, actor, critic) -> None:
 
 @dataclass
 class PPOConfig:
-    """Hyper-parameters of PPO.__init__ (ppo.py:24-36) + AdamOptimizerFactory (optim.py:89-110)."""
+    """Hyper-parameters of PPO.__init__ (ppo.py:24-36) / A2C.__init__ (a2c.py:163-237) +
+    AdamOptimizerFactory (optim.py:89-110)."""
+    algo: str = "ppo"            # "ppo" or "a2c"
     gamma: float = 0.99
     gae_lambda: float = 0.95
     eps_clip: float = 0.2
@@ -95,7 +97,8 @@ class PPOConfig:
             eps_clip=self.eps_clip, dual_clip=self.dual_clip or 0.0, vf_coef=self.vf_coef,
             ent_coef=self.ent_coef, max_grad_norm=self.max_grad_norm or 0.0, lr=self.lr,
             beta1=self.betas[0], beta2=self.betas[1], adam_eps=self.adam_eps,
-            value_clip=int(self.value_clip), adv_norm=int(self.advantage_normalization))
+            value_clip=int(self.value_clip), adv_norm=int(self.advantage_normalization),
+            algo={"ppo": 0, "a2c": 1}[self.algo], reserved=0)
 
 
 def split_offsets(n: int, size: int | None, merge_last: bool = True) -> list[int]:
@@ -197,8 +200,11 @@ class PPOEngine:
         obs, obs_next, act = self._f32(obs), self._f32(obs_next), self._f32(act)
         v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated,
                                                             truncated, cut_pos, d_n_cut)
-        _, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=False,
-                            want_logp=True)
+        if self.cfg.algo == "a2c":      # A2C._preprocess_batch (a2c.py:239-247): no logp_old
+            logp_old = torch.zeros_like(adv)
+        else:
+            _, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=False,
+                                want_logp=True)
         return {"obs": obs, "obs_next": obs_next, "act": act, "rew": rew, "terminated": terminated,
                 "truncated": truncated, "cut_pos": cut_pos, "d_n_cut": d_n_cut,
                 "v_s": v_s, "returns": returns, "adv": adv, "logp_old": logp_old}
