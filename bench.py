@@ -95,10 +95,16 @@ class Learner:
         self.eng = PPOEngine(OBS, ACT, init_flat_params(0).to(device), self.cfg)
         self.cut = (torch.arange(N_ENV, device=device) + 1) * T_STEPS - 1   # last slot of every env
         self.rng = np.random.default_rng(1234 + rank)
-        self.gen = torch.Generator(device=device).manual_seed(1234 + rank)
+        self.perm_seed = 1234 + 7919 * rank
         self._lib = _lib
         self.ws = _lib.default_workspace(device.index)
         self.dp = None
+
+    def next_perm(self):
+        from tianshou_amd.buffer import random_permutation
+
+        self.perm_seed += 0x9E3779B97F4A7C15
+        return random_permutation(N_TRANS, self.perm_seed, self.device)
 
     def preprocess(self):
         obs, obs_next, act, rew, term, trunc = self.data
@@ -107,9 +113,10 @@ class Learner:
     def update_once(self):
         """one reference update(): preprocess + REPEAT x (N_TRANS / MINIBATCH) gradient steps."""
         b = self.preprocess()
-        # minibatch order: permutations drawn on the device (the reference draws them with
-        # np.random.permutation on the host, ~10 ms per 2^20 entries - that would dominate here)
-        perms = [torch.randperm(N_TRANS, device=self.device, generator=self.gen) for _ in range(REPEAT)]
+        # minibatch order: keyed device-side permutations (ts_random_permutation); the reference draws
+        # np.random.permutation on the host (~10 ms per 2^20 entries), a sort-based torch.randperm
+        # costs ~0.25 ms - either would be a visible part of the 13 ms update
+        perms = [self.next_perm() for _ in range(REPEAT)]
         if self.world == 1:
             losses, steps = self.eng.update(b, MINIBATCH, REPEAT, perms)
             return losses, steps
@@ -249,7 +256,7 @@ def main():
         torch.cuda.synchronize()
         if world == 1:
             learner.ws.profile_begin()
-            perms = [torch.randperm(N_TRANS, device=device, generator=learner.gen) for _ in range(REPEAT)]
+            perms = [learner.next_perm() for _ in range(REPEAT)]
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             learner.eng.update(b, MINIBATCH, REPEAT, perms)

@@ -156,6 +156,13 @@ int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
                           const int64_t* lengths, const int64_t* insertion, int64_t total,
                           int64_t* out, ts_stream_t stream);
 
+/* Device-side stand-in for the np.random.permutation(len(batch)) that Batch.split draws per repeat
+ * (tianshou/data/batch.py:1209): a keyed bijection of [0, n) (4-round Feistel + cycle walking),
+ * one thread per slot, ~5 us for 2^20 entries (a sort-based randperm costs ~250 us).  Not the
+ * NumPy stream: for bit-for-bit reproduction of a seeded reference run pass the host permutation
+ * to ts_ppo_update instead. */
+int ts_random_permutation(int64_t* out, int64_t n, uint64_t seed, ts_stream_t stream);
+
 /* ReplayBuffer.__getitem__ row gather (buffer_base.py:605-649): out[i,:] = src[index[i],:]
  * for a row of `row_bytes` bytes (any dtype).  16-byte vector path when row_bytes % 16 == 0
  * and both bases are 16-byte aligned. */

@@ -144,3 +144,19 @@ def test_per_weights_against_reference_vectors():
     idx, w = per.sample(g["per_uniform"])
     assert np.array_equal(idx.cpu().numpy(), g["per_sample_idx"])
     np.testing.assert_allclose(w.cpu().numpy(), g["per_is_weight"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 1000, 65536, 1 << 20, (1 << 20) + 12345])
+def test_random_permutation_is_a_bijection(n):
+    from tianshou_amd.buffer import random_permutation
+
+    p = random_permutation(n, seed=12345 + n)
+    q = random_permutation(n, seed=999)
+    assert p.dtype == torch.int64 and p.shape == (n,)
+    assert torch.equal(torch.sort(p).values, torch.arange(n, device="cuda"))
+    assert torch.equal(torch.sort(q).values, torch.arange(n, device="cuda"))
+    if n >= 1000:
+        assert (p != q).float().mean() > 0.9                         # different keys, different order
+        assert (p != torch.arange(n, device="cuda")).float().mean() > 0.9
+        # crude mixing check: neighbours are not mapped to neighbours
+        assert ((p[1:] - p[:-1]).abs() <= 1).float().mean() < 0.01

@@ -80,6 +80,15 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def random_permutation(n: int, seed: int, device="cuda") -> torch.Tensor:
+    """Device-side replacement for np.random.permutation(n) in Batch.split (batch.py:1209): a keyed
+    bijection of range(n), int64 device tensor (ts_random_permutation)."""
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    _lib.check(_lib.load().ts_random_permutation(_lib.ptr(out), _lib.i64(n), C.c_uint64(seed & (2**64 - 1)),
+                                                  _lib.current_stream(out.device)))
+    return out
+
+
 class DeviceReplayBuffer:
     """Read-side mirror of ReplayBufferManager on one GPU."""
 

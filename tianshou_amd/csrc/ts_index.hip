@@ -147,6 +147,37 @@ __global__ void gather_rows_vec_kernel(const V* src, int64_t n_src, int64_t row_
     }
 }
 
+// Keyed bijection of [0, n): 4-round Feistel network on the smallest even bit width covering n,
+// cycle-walked back into range.  One thread per output slot, no sort, no scratch.
+__device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t k) {
+    x ^= k;
+    x *= 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
+}
+
+__global__ void random_permutation_kernel(int64_t* out, int64_t n, int half_bits, uint64_t seed) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), k2 = k0 * 0xC2B2AE3Du + 0x27D4EB2Fu,
+                   k3 = k1 * 0x165667B1u + 0x9E3779B9u;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t v = (uint64_t)i;
+        do {   // cycle walking: the domain is a power of 4 >= n, expected < 4 iterations
+            uint32_t l = (uint32_t)(v >> half_bits) & mask, r = (uint32_t)v & mask;
+            uint32_t t;
+            t = l ^ (feistel_round(r, k0) & mask); l = r; r = t;
+            t = l ^ (feistel_round(r, k1) & mask); l = r; r = t;
+            t = l ^ (feistel_round(r, k2) & mask); l = r; r = t;
+            t = l ^ (feistel_round(r, k3) & mask); l = r; r = t;
+            v = ((uint64_t)l << half_bits) | r;
+        } while ((int64_t)v >= n);
+        out[i] = (int64_t)v;
+    }
+}
+
 inline int grid_for(int64_t n, int block) {
     int64_t g = ts::ceil_div(n, block);
     if (g > 4096) g = 4096;
@@ -215,6 +246,19 @@ int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
     hipLaunchKernelGGL(lengths_prefix_kernel, dim3(1), dim3(1024), 0, s, lengths, E, prefix);
     hipLaunchKernelGGL(sample_all_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, offset, E,
                        lengths, insertion, prefix, total, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_random_permutation(int64_t* out, int64_t n, uint64_t seed, ts_stream_t stream) {
+    TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_random_permutation: negative n");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(out != nullptr, TS_ERR_INVALID_ARG, "ts_random_permutation: out is NULL");
+    TS_REQUIRE(n <= ((int64_t)1 << 40), TS_ERR_UNSUPPORTED, "ts_random_permutation: n too large");
+    int bits = 2;
+    while (((int64_t)1 << bits) < n) bits += 2;        // even width so that both halves are equal
+    hipLaunchKernelGGL(random_permutation_kernel, dim3(grid_for(n, 256)), dim3(256), 0,
+                       ts::as_stream(stream), out, n, bits / 2, seed);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
