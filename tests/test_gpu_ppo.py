@@ -266,3 +266,64 @@ def test_data_parallel_path_world1_matches_fused_update(cfg_name):
     np.testing.assert_allclose(l_dp.cpu().numpy(), l_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(engs[1].params.cpu().numpy(), engs[0].params.cpu().numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(engs[1].adam_v.cpu().numpy(), engs[0].adam_v.cpu().numpy(), rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("obs_dim,act_dim", [(4, 2), (11, 3), (27, 8), (31, 1), (1, 1)])
+def test_update_other_network_shapes(obs_dim, act_dim):
+    """Every instantiated first-layer width (K-steps 1..16) and action counts 1..8 through the whole
+    update path, against the oracle."""
+    from tianshou_amd import ppo as P
+
+    n, n_env, batch, repeat = 640, 4, 200, 2
+    params, data = random_problem(n, obs_dim, act_dim, seed=obs_dim * 10 + act_dim)
+    ocfg, cfg = both_cfgs("mujoco")
+    rng = np.random.default_rng(obs_dim)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    st = OP.PPOState(params={k: v.clone() for k, v in params.items()})
+    bs = O.BufferState.from_vector_fill(data["rew"], data["terminated"], data["truncated"], n_env)
+    idx, unf = bs.sample_indices_all(), bs.unfinished_index()
+    args = (torch.from_numpy(data["obs"]), torch.from_numpy(data["obs_next"]), torch.from_numpy(data["act"]),
+            data["rew"], data["terminated"], data["truncated"], idx, unf)
+    pre = OP.preprocess(st, ocfg, *args)
+    losses_o = OP.update(st, ocfg, {"obs": args[0], "act": args[2]}, pre, batch, repeat, perms)
+    eng = P.PPOEngine(obs_dim, act_dim, OP.flatten_params(params).cuda(), cfg)
+    b = eng.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                       dev(data["terminated"]), dev(data["truncated"]), dev(unf))
+    losses, steps = eng.update(b, batch, repeat, perms)
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_minibatch_larger_than_one_grid_pass():
+    """A minibatch of more than 512 workgroups x 4 waves x 32 rows (merge_last can produce up to
+    2 * batch_size - 1 rows): every wave processes several tiles and the slab is accumulated."""
+    from tianshou_amd import ppo as P
+
+    n = 65536 + 4500
+    params, data = random_problem(n, 17, 6, seed=123)
+    obs, act = torch.from_numpy(data["obs"]), torch.from_numpy(data["act"])
+    rng = np.random.default_rng(8)
+    with torch.no_grad():
+        v = OP.critic_forward(params, obs).flatten()
+        mu, sigma = OP.actor_forward(params, obs)
+        logp = OP.dist_of(mu, sigma).log_prob(act)
+    v_s = v + torch.from_numpy(rng.normal(scale=0.2, size=n).astype(np.float32))
+    logp_old = logp + torch.from_numpy(rng.normal(scale=0.3, size=n).astype(np.float32))
+    adv = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    returns = v + torch.from_numpy(rng.normal(size=n).astype(np.float32))
+    kw = dict(eps_clip=0.2, value_clip=True, advantage_normalization=True, vf_coef=0.25, ent_coef=0.01,
+              max_grad_norm=0.5, lr=3e-4)
+    ocfg, cfg = OP.PPOConfig(**kw), P.PPOConfig(**kw)
+    torch.set_num_threads(8)
+    p = {k: t.clone().requires_grad_(True) for k, t in params.items()}
+    loss, clip_loss, vf_loss, ent_loss = OP.ppo_minibatch_loss(p, ocfg, obs, act, adv, returns, logp_old, v_s)
+    loss.backward()
+    g_ref = torch.cat([p[k].grad.reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+    eng = P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg)
+    b = dict(obs=obs.cuda(), act=act.cuda(), adv=adv.cuda(), returns=returns.cuda(), logp_old=logp_old.cuda(),
+             v_s=v_s.cuda())
+    perm = dev(rng.permutation(n))
+    losses, grads = eng._run_steps(b, perm, [0, n], want_grad=True)
+    np.testing.assert_allclose(losses.cpu().numpy()[0],
+                               [loss.item(), clip_loss.item(), vf_loss.item(), ent_loss.item()], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(grads.cpu().numpy(), g_ref, rtol=1e-4, atol=2e-6 * float(np.abs(g_ref).max()))
