@@ -287,6 +287,16 @@ int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step,
                  int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
                  ts_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Target networks
+ * ------------------------------------------------------------------------------------------- */
+
+/* polyak_parameter_update / full_parameter_update over a flat parameter vector
+ * (tianshou/utils/lagged_network.py:8-18, 81-87): tgt = tau * src + (1 - tau) * tgt, same three
+ * float32 roundings as torch; tau == 1 is the hard copy DQN uses every target_update_freq steps
+ * (modelfree/dqn.py:283-285). */
+int ts_polyak_update(float* tgt, const float* src, int64_t n, double tau, ts_stream_t stream);
+
 /* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
  * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
  * the stream. */

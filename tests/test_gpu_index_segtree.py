@@ -160,3 +160,18 @@ def test_random_permutation_is_a_bijection(n):
         assert (p != torch.arange(n, device="cuda")).float().mean() > 0.9
         # crude mixing check: neighbours are not mapped to neighbours
         assert ((p[1:] - p[:-1]).abs() <= 1).float().mean() < 0.01
+
+
+@pytest.mark.parametrize("n", [1, 5, 1024, 166913, 1687206])
+def test_polyak_update_bit_exact_vs_torch(n):
+    from tianshou_amd.lagged import full_parameter_update, polyak_parameter_update
+
+    g = torch.Generator().manual_seed(n)
+    src, tgt = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    tau = 0.005
+    ref = tau * src + (1 - tau) * tgt            # lagged_network.py:17-18
+    d_tgt, d_src = tgt.cuda(), src.cuda()
+    polyak_parameter_update(d_tgt, d_src, tau)
+    assert torch.equal(d_tgt.cpu(), ref)
+    full_parameter_update(d_tgt, d_src)
+    assert torch.equal(d_tgt.cpu(), src)
