@@ -455,8 +455,109 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
+def gen_dqn(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, batch: int,
+            n_updates: int, seed: int, per: bool, stack: bool, lr: float = 1e-4, **dqn_kwargs) -> None:
+    """Runs the reference DQN.update() (DQNet + DiscreteQLearningPolicy, dqn.py) on a synthetic
+    (Prioritized)VectorReplayBuffer and dumps the sampled indices, n-step returns, TD errors, losses
+    and parameter samples of every update.  `stack`: atari layout (stack_num=c, save_only_last_obs,
+    ignore_obs_next; examples/atari/atari_dqn.py:137-142), else full [c,h,w] observations."""
+    from tianshou.algorithm.modelfree.dqn import DQN, DiscreteQLearningPolicy
+    from tianshou.env.atari.atari_network import DQNet
+    from oracle import oracle_dqn as OD
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net = DQNet(c=c, h=h, w=w, action_shape=n_act)
+    p0 = OD.init_params(c, h, w, n_act, seed)
+    sd = net.state_dict()
+    for k_ref, k in zip(OD.TIANSHOU_KEYS, OD.PARAM_ORDER):
+        assert torch.equal(sd[k_ref], p0[k]), f"oracle init differs from DQNet at {k}"
+    policy = DiscreteQLearningPolicy(model=net, action_space=gym.spaces.Discrete(n_act))
+    algorithm = DQN(policy=policy, optim=AdamOptimizerFactory(lr=lr), **dqn_kwargs)
+
+    kw = dict(stack_num=c, ignore_obs_next=True, save_only_last_obs=True) if stack else dict(ignore_obs_next=True)
+    if per:
+        buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4, **kw)
+    else:
+        buf = VectorReplayBuffer(E * slots, E, **kw)
+    frames = rng.integers(0, 256, size=(steps + 1, E, c, h, w), dtype=np.uint8)
+    # a sparse image so that the fixture compresses: ~6% non-zero pixels
+    frames = np.where(rng.random(frames.shape) < 0.06, frames, 0).astype(np.uint8)
+    act = rng.integers(0, n_act, size=(steps, E))
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.08
+    trunc = (rng.random((steps, E)) < 0.04) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=frames[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t],
+                      obs_next=frames[t + 1]))
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, c, h, w, n_act, batch, n_updates, seed, int(per), int(stack)])
+    out["frames"] = np.asarray(buf.obs, np.uint8)          # [B, h, w] (stack) or [B, c, h, w]
+    out["act"] = np.asarray(buf.act, np.int64)
+    out["rew"] = np.asarray(buf.rew, np.float64)
+    out["terminated"] = np.asarray(buf.terminated, bool)
+    out["truncated"] = np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+    if per:
+        out["tree0"] = np.asarray(buf.weight._value, np.float64).copy()
+
+    rec: list[dict] = []
+    orig_pre, orig_upd = DQN._preprocess_batch, DQN._update_with_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        r = {"indices": np.array(indices, np.int64)}
+        r["obs"] = np.array(batch.obs)
+        if hasattr(batch, "weight"):
+            r["is_weight"] = np.array(batch.weight, np.float64)
+        b = orig_pre(self, batch, buffer, indices)
+        r["returns"] = b.returns.numpy().copy().reshape(-1)
+        rec.append(r)
+        return b
+
+    def rec_upd(self, batch):
+        stats = orig_upd(self, batch)
+        rec[-1]["td"] = batch.weight.detach().numpy().copy()
+        rec[-1]["loss"] = np.array(stats.loss)
+        return stats
+
+    DQN._preprocess_batch, DQN._update_with_batch = rec_pre, rec_upd
+    try:
+        np.random.seed(seed + 7)
+        for u in range(n_updates):
+            with policy_within_training_step(algorithm.policy):
+                algorithm.update(buffer=buf, sample_size=batch)
+            r = rec[-1]
+            flat = torch.cat([net.state_dict()[k].reshape(-1) for k in OD.TIANSHOU_KEYS]).numpy()
+            for k in ("indices", "returns", "td", "loss"):
+                out[f"u{u}_{k}"] = r[k]
+            if "is_weight" in r:
+                out[f"u{u}_is_weight"] = r["is_weight"]
+            if u == 0:
+                out["u0_obs_sample"] = r["obs"][:2]
+            out[f"u{u}_params_strided"] = flat[::61].copy()
+            out[f"u{u}_conv1_w"] = net.state_dict()["net.0.0.weight"].numpy().copy()
+            out[f"u{u}_fc2_w"] = net.state_dict()["net.3.weight"].numpy().copy()
+            out[f"u{u}_biases"] = torch.cat([net.state_dict()[k].reshape(-1) for k in OD.TIANSHOU_KEYS
+                                             if k.endswith("bias")]).numpy().copy()
+            if per:
+                out[f"u{u}_tree"] = np.asarray(buf.weight._value, np.float64).copy()
+                out[f"u{u}_prio_minmax"] = np.array([buf._min_prio, buf._max_prio])
+    finally:
+        DQN._preprocess_batch, DQN._update_with_batch = orig_pre, orig_upd
+    cfg = dict(gamma=algorithm.gamma, n_step=algorithm.n_step, target_update_freq=algorithm.target_update_freq,
+               is_double=float(algorithm.is_double),
+               huber_delta=-1.0 if algorithm.huber_loss_delta is None else algorithm.huber_loss_delta, lr=lr)
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"dqn_{tag}.npz"), **out)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "dqn":
+        gen_dqn_all()
+        return
     gen_returns_kat()
     gen_buffer_index()
     gen_segtree_per()
@@ -472,8 +573,20 @@ def main() -> None:
     gen_ppo("a2c", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=2,
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
+    gen_dqn_all()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def gen_dqn_all() -> None:
+    # atari layout (C3): frame stack through prev(), PER, n-step 3, double-Q with a lagged net, Huber
+    gen_dqn("atari", E=2, slots=40, steps=50, c=4, h=84, w=84, n_act=6, batch=16, n_updates=3, seed=3,
+            per=True, stack=True, gamma=0.99, n_step_return_horizon=3, target_update_freq=2, is_double=True,
+            huber_loss_delta=1.0)
+    # small images, plain buffer with full observations, vanilla max-Q target, MSE loss
+    gen_dqn("small", E=3, slots=24, steps=20, c=2, h=44, w=36, n_act=3, batch=24, n_updates=2, seed=5,
+            per=False, stack=False, lr=3e-4, gamma=0.9, n_step_return_horizon=1, target_update_freq=0,
+            is_double=False, huber_loss_delta=None)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,29 @@
+"""Shared replay of tests/golden/dqn_*.npz (used by the oracle pin test and the GPU parity test)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from oracle import oracle as O
+from oracle import oracle_dqn as OD
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(tag: str):
+    g = np.load(os.path.join(GOLDEN, f"dqn_{tag}.npz"))
+    E, slots, steps, c, h, w, n_act, batch, n_updates, seed, per, stack = (int(x) for x in g["dims"])
+    cfgd = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OD.DQNConfig(gamma=cfgd["gamma"], n_step=int(cfgd["n_step"]),
+                       target_update_freq=int(cfgd["target_update_freq"]), is_double=bool(cfgd["is_double"]),
+                       huber_delta=None if cfgd["huber_delta"] < 0 else cfgd["huber_delta"], lr=cfgd["lr"])
+    dims = dict(E=E, slots=slots, steps=steps, c=c, h=h, w=w, n_act=n_act, batch=batch, n_updates=n_updates,
+                seed=seed, per=bool(per), stack=bool(stack))
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, dims, cfg, bstate
+
+
+def torch_order_flat(p) -> np.ndarray:
+    return OD.flatten_params(p).numpy()

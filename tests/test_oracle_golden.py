@@ -211,3 +211,48 @@ def test_ppo_restatement_matches_reference(tag):
         np.testing.assert_allclose(
             [state.ret_rms.mean, state.ret_rms.var, state.ret_rms.count], g[f"u{u}_ret_rms"],
             rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ DQN path
+@pytest.mark.parametrize("tag", ["atari", "small"])
+def test_dqn_restatement_matches_reference(tag):
+    """oracle_dqn (frame stack, n-step double-Q target, Huber / MSE, Adam, hard sync, PER weights)
+    against the unmodified reference DQN.update() (gen_golden.gen_dqn)."""
+    from oracle import oracle_dqn as OD
+    from tests import dqn_common as DC
+
+    g, d, cfg, bstate = DC.load(tag)
+    stack_num = d["c"] if d["stack"] else 1
+    frames = g["frames"]
+    st = OD.DQNState.create(OD.init_params(d["c"], d["h"], d["w"], d["n_act"], d["seed"]), cfg)
+    if d["per"]:
+        tree = g["tree0"].copy()
+        bound = 1
+        while bound < d["E"] * d["slots"]:
+            bound *= 2
+        np.random.seed(d["seed"] + 7)
+        mx, mn = 1.0, 1.0                                         # prio.py:42-43
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        if d["per"]:
+            scalar = np.random.rand(d["batch"]) * tree[1]       # prio.py:65
+            assert np.array_equal(O._get_prefix_sum_idx(scalar, bound, tree), idx)
+            w = O.per_get_weight(tree, bound, idx, mn, 0.4, True)
+            np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-12)
+        obs = OD.stacked_frames(bstate, frames, idx, stack_num)
+        if u == 0:
+            assert np.array_equal(obs[:2], g["u0_obs_sample"])
+        ret = OD.preprocess(st, cfg, bstate, frames, idx, stack_num)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-6, atol=1e-6)
+        loss, td = OD.update_with_batch(st, cfg, obs, g["act"][idx], ret)
+        np.testing.assert_allclose(td.numpy(), g[f"u{u}_td"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(loss, float(g[f"u{u}_loss"]), rtol=1e-6)
+        flat = DC.torch_order_flat(st.params)
+        np.testing.assert_allclose(flat[::61], g[f"u{u}_params_strided"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.params["conv1.w"].numpy(), g[f"u{u}_conv1_w"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.params["fc2.w"].numpy(), g[f"u{u}_fc2_w"], rtol=1e-6, atol=1e-7)
+        if d["per"]:
+            mx, mn = O.per_update_weight(tree, bound, idx, td.numpy(), 0.6, mx, mn)
+            # priorities are (|td| + eps)^alpha of a float32 TD error that itself carries ~1e-6 rounding
+            np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-5)
+            np.testing.assert_allclose([mn, mx], g[f"u{u}_prio_minmax"], rtol=1e-5)
