@@ -297,6 +297,86 @@ int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step,
  * (modelfree/dqn.py:283-285). */
 int ts_polyak_update(float* tgt, const float* src, int64_t n, double tau, ts_stream_t stream);
 
+/* clip_grad_norm_ + Adam over a flat vector: Optimizer.step (algorithm_base.py:484-500) with
+ * torch.optim.Adam's single-tensor arithmetic (optim.py:89-110).  `step` is the 1-based Adam step
+ * of this call; max_grad_norm <= 0 disables clipping (needs `ws` otherwise). */
+int ts_adam_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, const float* grad, int64_t n,
+                 int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm,
+                 ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Frame-stacked observations (Atari replay layout)
+ * ------------------------------------------------------------------------------------------- */
+
+/* The index part of ReplayBuffer.get(index, "obs") with stack_num > 1 (buffer_base.py:586-596):
+ * out int64[I, stack_num], column stack_num-1-j = prev^j(index) (manager.py:311-336). Bit-exact. */
+int ts_stack_indices(const int64_t* index, int64_t I, int64_t stack_num, const int64_t* offset, int64_t E,
+                     const uint8_t* done, const int64_t* last_index, const int64_t* lengths, int64_t* out,
+                     ts_stream_t stream);
+
+/* The gather + np.stack + torch.as_tensor(float32) of buffer_base.py:590-596 / atari_network.py:121
+ * in one pass: src u8[n_planes, plane_elems] (one image plane per row), plane_index int64[B, C] ->
+ * out float32[B, plane_elems, C] (NHWC).  For a buffer that stores whole [C, H, W] observations
+ * plane_index[b, c] = index[b] * C + c. */
+int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
+                          int64_t B, int64_t C, float* out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution / linear layers on fp32 MFMA (NHWC activations)
+ * ------------------------------------------------------------------------------------------- */
+
+/* h_dims (host int64[8]) = {B, IH, IW, IC, KH, KW, stride, OC}; x float32[B, IH, IW, IC];
+ * wb float32[KH*KW*IC + 1, OC] (row (kh, kw, ic) = torch weight[:, ic, kh, kw], last row = bias);
+ * y float32[B, OH, OW, OC].  nn.Conv2d / nn.Linear (+ ReLU) forward as used by DQNet
+ * (atari_network.py:79-98); a Linear layer is IH = IW = KH = KW = stride = 1.
+ * Shape limits: KH*KW*IC % 32 == 0, OC % 32 == 0, 16-byte aligned im2col runs. */
+int ts_conv_forward(ts_workspace* ws, const float* x, const float* wb, float* y, const int64_t* h_dims, int relu,
+                    ts_stream_t stream);
+/* autograd of the same layer: d_wb float32[KH*KW*IC + 1, OC] = d loss / d wb given dy float32[B, OH, OW, OC];
+ * dx (nullable) float32[B, IH, IW, IC] = d loss / d x, multiplied by (mask > 0) when `mask` (the layer
+ * input as produced by a ReLU, nullable) is given.  dx needs KH % stride == 0 and IC % 32 == 0. */
+int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const float* dy, const float* mask,
+                     float* d_wb, float* dx, const int64_t* h_dims, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DQN on NatureCNN (DQNet, tianshou/env/atari/atari_network.py:60-122)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Flat fp32 parameter vector: five wb matrices (see ts_conv_forward) back to back:
+ *   conv1 [8*8*c + 1, 32] | conv2 [4*4*32 + 1, 64] | conv3 [3*3*64 + 1, 64] | fc1 [F + 1, 512] | fc2 [512 + 1, n_act]
+ * with F = 64 * OH3 * OW3 flattened in (h, w, channel) order (the NHWC flatten; torch flattens
+ * (channel, h, w), tianshou_amd/dqn.py permutes on import / export).  h_offsets6 receives the five
+ * layer offsets and the total; h_geom (nullable, int64[40]) the four ConvGeom rows
+ * {B, IH, IW, IC, KH, KW, S, OH, OW, OC}. */
+int64_t ts_dqn_param_count(int64_t c, int64_t h, int64_t w, int64_t n_act);
+int ts_dqn_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t* h_offsets6, int64_t* h_geom);
+
+/* DQNet.forward + DiscreteQLearningPolicy.forward (dqn.py:101-143): obs float32[B, h, w, c] (NHWC,
+ * raw 0..255 values, no scaling) -> q_out float32[B, n_act], act_out (nullable) int64[B] = argmax_a. */
+int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                   const float* obs_nhwc, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream);
+
+/* DQN._target_q (dqn.py:365-379) given Q_online(s') and Q_target(s') [B, n_act]:
+ * is_double: q_target[b, argmax_a q_online[b, a]], else max_a q_target[b, a] -> out float32[B]. */
+int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
+                    float* out, ts_stream_t stream);
+
+typedef struct ts_dqn_hparams {
+    float lr;            /* < 0: compute the gradient only (no optimizer step) */
+    float beta1, beta2, adam_eps;
+    float huber_delta;   /* > 0: Huber loss, mean, PER weights ignored (dqn.py:392-398); else (td^2 * w).mean() */
+    float max_grad_norm; /* <= 0: no clipping */
+} ts_dqn_hparams;
+
+/* DQN._update_with_batch (dqn.py:381-404) without the periodic target sync (ts_polyak_update, tau = 1):
+ * q = Q(obs)[act]; td = returns - q -> td_out float32[B] (the new PER priorities, :401); loss -> loss_out
+ * float32[1]; backward through DQNet; clip + Adam (adam_step = 1-based step of this call).
+ * weight nullable (= 1.0).  grad_out (nullable) float32[P] receives the unclipped flat gradient. */
+int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                  int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act,
+                  const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
+                  float* loss_out, float* grad_out, ts_stream_t stream);
+
 /* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
  * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
  * the stream. */

@@ -1,0 +1,208 @@
+"""GPU parity of the DQN row: conv / linear layers on fp32 MFMA, frame-stack gather,
+double-Q n-step target, Huber / MSE TD loss, Adam -- through the C ABI, against the oracle
+(oracle/oracle_dqn.py, pinned to the reference by tests/golden/dqn_*.npz).
+Tolerance: 1e-5 relative (north_star), on the scale of each tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle as O
+from oracle import oracle_dqn as OD
+from tests import dqn_common as DC
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def to_wb(w, b):
+    """torch conv weight [oc, ic, kh, kw] + bias -> engine matrix [(kh, kw, ic) + 1, oc]."""
+    return torch.cat([w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]), b[None, :]]).contiguous()
+
+
+LAYERS = [  # (B, IH, IW, IC, K, S, OC, relu-masked input)
+    (5, 84, 84, 4, 8, 4, 32, False),       # conv1 (no dx needed, input is the observation)
+    (3, 44, 36, 2, 8, 4, 32, False),       # conv1 of the small golden net
+    (5, 20, 20, 32, 4, 2, 64, True),       # conv2
+    (7, 10, 8, 32, 4, 2, 64, True),        # conv2, rectangular
+    (5, 9, 9, 64, 3, 1, 64, True),         # conv3
+    (37, 1, 1, 3136, 1, 1, 512, True),     # fc1
+    (512, 1, 1, 128, 1, 1, 512, True),     # fc1 of the small net, full batch
+]
+
+
+@pytest.mark.parametrize("shape", LAYERS)
+def test_layer_forward_backward_vs_torch(shape):
+    from tianshou_amd import dqn as D
+
+    B, IH, IW, IC, K, S, OC, masked = shape
+    g = torch.Generator().manual_seed(B * 1000 + IH)
+    x = torch.randn(B, IC, IH, IW, generator=g)
+    if masked:
+        x = F.relu(x)                                    # a ReLU output: zeros carry the mask
+    w = (torch.randn(OC, IC, K, K, generator=g) / np.sqrt(IC * K * K)).requires_grad_(True)
+    b = torch.randn(OC, generator=g).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(xr, w, b, stride=S))
+    dy = torch.randn(y.shape, generator=g) * (y > 0)     # gradient w.r.t. the pre-activation
+    y.backward(dy)
+
+    dev = "cuda"
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wb = to_wb(w.detach(), b.detach()).to(dev)
+    y_gpu = D.conv_forward(x_nhwc, wb, K, K, S, relu=True)
+    assert rel_err(y_gpu.permute(0, 3, 1, 2).cpu(), y.detach()) < 1e-5
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    need_dx = IC % 32 == 0
+    d_wb, dx = D.conv_backward(x_nhwc, wb, dy_nhwc, K, K, S, mask=x_nhwc if masked else None, need_dx=need_dx)
+    assert rel_err(d_wb.cpu(), to_wb(w.grad, b.grad)) < 1e-5
+    if need_dx:
+        ref_dx = xr.grad * (x > 0) if masked else xr.grad
+        assert rel_err(dx.permute(0, 3, 1, 2).cpu(), ref_dx) < 1e-5
+
+
+def test_layout_round_trip_and_forward_matches_oracle():
+    from tianshou_amd import dqn as D
+
+    c, h, w, A = 4, 84, 84, 6
+    p = OD.init_params(c, h, w, A, seed=11)
+    tensors = [p[k] for k in OD.PARAM_ORDER]
+    flat = D.flat_from_torch(tensors, c, h, w, A)
+    assert flat.numel() == OD.param_count(c, h, w, A) == D.param_count(c, h, w, A) == 1_687_206
+    back = D.flat_to_torch(flat, c, h, w, A)
+    for a, b in zip(back, tensors):
+        assert torch.equal(a.cpu(), b)
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, size=(9, c, h, w), dtype=np.uint8)
+    q_ref = OD.forward(p, obs)
+    eng = D.DQNEngine(c, h, w, A, flat, D.DQNConfig())
+    obs_nhwc = torch.as_tensor(obs).permute(0, 2, 3, 1).float().contiguous().cuda()
+    q, act = eng.forward(obs_nhwc)
+    assert rel_err(q.cpu(), q_ref) < 1e-5
+    assert torch.equal(act.cpu(), q_ref.argmax(dim=1))
+
+
+@pytest.mark.parametrize("tag", ["atari", "small"])
+def test_frame_stack_gather_bit_exact(tag):
+    from tianshou_amd import dqn as D
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, cfg, bstate = DC.load(tag)
+    stack_num = d["c"] if d["stack"] else 1
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"])
+    frames = torch.as_tensor(g["frames"]).cuda()
+    idx = np.arange(d["E"] * d["slots"])
+    ref = OD.stacked_frames(bstate, g["frames"], idx, stack_num)          # [I, C, H, W] uint8
+    out = D.gather_obs_nhwc(frames, buf, idx, stack_num)
+    assert torch.equal(out.cpu(), torch.as_tensor(ref).permute(0, 2, 3, 1).float())
+    if stack_num > 1:
+        st = D.stack_indices(buf, idx, stack_num).cpu().numpy()
+        cur = idx.copy()
+        for j in range(stack_num):
+            assert np.array_equal(st[:, stack_num - 1 - j], cur)
+            cur = bstate.prev(cur)
+
+
+@pytest.mark.parametrize("tag", ["atari", "small"])
+def test_dqn_update_matches_reference_golden(tag):
+    """Replays the reference's DQN.update() sequence (sampled indices from the fixture) on the engine."""
+    from tianshou_amd import dqn as D
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, ocfg, bstate = DC.load(tag)
+    c, h, w, A = d["c"], d["h"], d["w"], d["n_act"]
+    stack_num = c if d["stack"] else 1
+    cfg = D.DQNConfig(gamma=ocfg.gamma, n_step=ocfg.n_step, target_update_freq=ocfg.target_update_freq,
+                      is_double=ocfg.is_double, huber_delta=ocfg.huber_delta, lr=ocfg.lr)
+    p0 = OD.init_params(c, h, w, A, d["seed"])
+    eng = D.DQNEngine(c, h, w, A, D.flat_from_torch([p0[k] for k in OD.PARAM_ORDER], c, h, w, A), cfg)
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"])
+    frames = torch.as_tensor(g["frames"]).cuda()
+    act_all = torch.as_tensor(g["act"]).cuda()
+    for u in range(d["n_updates"]):
+        idx = torch.as_tensor(g[f"u{u}_indices"]).cuda()
+        ret = eng.preprocess(buf, frames, idx, stack_num)
+        np.testing.assert_allclose(ret.cpu().numpy(), g[f"u{u}_returns"], rtol=1e-5, atol=1e-5)
+        obs = D.gather_obs_nhwc(frames, buf, idx, stack_num)
+        loss, td = eng.update_with_batch(obs, act_all[idx], ret)
+        np.testing.assert_allclose(td.cpu().numpy(), g[f"u{u}_td"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(float(loss), float(g[f"u{u}_loss"]), rtol=1e-5)
+        tensors = D.flat_to_torch(eng.params, c, h, w, A)
+        flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+        # Adam's first steps move every weight by ~lr whatever the gradient scale: compare on lr's scale
+        np.testing.assert_allclose(flat[::61], g[f"u{u}_params_strided"], rtol=1e-5, atol=0.02 * cfg.lr)
+        np.testing.assert_allclose(tensors[0].cpu().numpy(), g[f"u{u}_conv1_w"], rtol=1e-5, atol=0.02 * cfg.lr)
+        np.testing.assert_allclose(tensors[8].cpu().numpy(), g[f"u{u}_fc2_w"], rtol=1e-5, atol=0.02 * cfg.lr)
+
+
+@pytest.mark.parametrize("huber,weighted", [(1.0, False), (None, True), (None, False)])
+def test_c3_batch_gradient_vs_oracle(huber, weighted):
+    """Full C3 minibatch (512 x u8[4,84,84], 6 actions): loss, TD errors and the whole gradient."""
+    from tianshou_amd import dqn as D
+
+    c, h, w, A, B = 4, 84, 84, 6, 512
+    rng = np.random.default_rng(7)
+    obs = rng.integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=B)
+    ret = rng.normal(size=B).astype(np.float32) * 3
+    weight = rng.random(B).astype(np.float32) if weighted else None
+    p = OD.init_params(c, h, w, A, seed=2)
+    ocfg = OD.DQNConfig(huber_delta=huber, lr=1e-4)
+    st = OD.DQNState.create(p, ocfg)
+    col: dict = {}
+    loss_ref, td_ref = OD.update_with_batch(st, ocfg, obs, act, ret, weight, collect=col)
+
+    cfg = D.DQNConfig(huber_delta=huber, lr=1e-4)
+    eng = D.DQNEngine(c, h, w, A, D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, A), cfg)
+    obs_nhwc = torch.as_tensor(obs).permute(0, 2, 3, 1).float().contiguous().cuda()
+    grad = torch.empty(eng.P, dtype=torch.float32, device="cuda")
+    loss, td = eng.update_with_batch(obs_nhwc, act, ret, weight, grad_out=grad, apply=False)
+    assert rel_err(td.cpu(), td_ref) < 1e-5
+    assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
+    g_ref = D.flat_from_torch([col["grads"][k] for k in OD.PARAM_ORDER], c, h, w, A, device="cpu")
+    off, _ = D.layer_layout(c, h, w, A)
+    for i in range(5):                                   # per layer, on the layer's own scale
+        assert rel_err(grad[off[i]:off[i + 1]].cpu(), g_ref[off[i]:off[i + 1]]) < 1e-5, f"layer {i}"
+    # the optimizer step on top of the same gradient
+    loss2, _ = eng.update_with_batch(obs_nhwc, act, ret, weight)
+    new = torch.cat([t.reshape(-1) for t in D.flat_to_torch(eng.params, c, h, w, A)]).cpu().numpy()
+    ref = OD.flatten_params(st.params).numpy()
+    # Adam's first step is lr * g / (|g| + eps): for the handful of weights whose gradient is ~eps = 1e-8
+    # (1e-7 of the layer's scale) the rounding of g shows up at full size, bounded by lr
+    bad = np.abs(new - ref) > 1e-5 * np.abs(ref) + 0.02 * cfg.lr
+    assert bad.mean() < 1e-4 and np.abs(new - ref).max() <= 2 * cfg.lr
+
+
+def test_adam_step_vs_torch():
+    """ts_adam_step (clip_grad_norm_ + Adam) on a given gradient: same arithmetic as torch.optim.Adam."""
+    import ctypes as C
+
+    from tianshou_amd import _lib
+
+    n = 1_687_206
+    gen = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-4)
+    dp, dm, dv = p.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ws = _lib.default_workspace(0)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=gen) * 10 ** float(torch.randint(-6, 2, (1,), generator=gen))
+        ref.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        opt.step()
+        _lib.check(_lib.load().ts_adam_step(ws.handle, _lib.ptr(dp), _lib.ptr(dm), _lib.ptr(dv), _lib.ptr(g.cuda()),
+                                            _lib.i64(n), _lib.i64(step), _lib.f64(1e-4), _lib.f64(0.9), _lib.f64(0.999),
+                                            _lib.f64(1e-8), _lib.f64(0.5), _lib.current_stream()))
+        np.testing.assert_allclose(dp.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)
+        st = opt.state[ref]
+        np.testing.assert_allclose(dm.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(dv.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-20)

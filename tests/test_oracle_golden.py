@@ -238,7 +238,7 @@ def test_dqn_restatement_matches_reference(tag):
             scalar = np.random.rand(d["batch"]) * tree[1]       # prio.py:65
             assert np.array_equal(O._get_prefix_sum_idx(scalar, bound, tree), idx)
             w = O.per_get_weight(tree, bound, idx, mn, 0.4, True)
-            np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-5)      # tree carries the td rounding
+            np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-4)      # tree carries the td rounding
         obs = OD.stacked_frames(bstate, frames, idx, stack_num)
         if u == 0:
             assert np.array_equal(obs[:2], g["u0_obs_sample"])
@@ -254,5 +254,7 @@ def test_dqn_restatement_matches_reference(tag):
         if d["per"]:
             mx, mn = O.per_update_weight(tree, bound, idx, td.numpy(), 0.6, mx, mn)
             # priorities are (|td| + eps)^alpha of a float32 TD error that itself carries ~1e-6 rounding
-            np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-5)
-            np.testing.assert_allclose([mn, mx], g[f"u{u}_prio_minmax"], rtol=1e-5)
+            # (a small |td| has a large relative rounding error; torch's CPU conv also changes its
+            # summation order with the thread count)
+            np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-4)
+            np.testing.assert_allclose([mn, mx], g[f"u{u}_prio_minmax"], rtol=1e-4)

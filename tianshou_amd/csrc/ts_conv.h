@@ -1,0 +1,37 @@
+// ts_conv.h -- fp32-MFMA implicit-GEMM convolution / linear layers (internal to libtsengine).
+//
+// Activations are NHWC ("pixel-major") float32: X[B][IH][IW][IC].  A layer's parameters are one
+// row-major matrix Wb[(KH*KW*IC) + 1][OC]: row k = (kh, kw, ic) holds the weights of all output
+// channels for that tap, the last row is the bias.  A Linear layer is the 1x1 case (IH = IW = 1).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace ts {
+
+struct ConvGeom {
+    int B, IH, IW, IC, KH, KW, S, OH, OW, OC;
+    int K() const { return KH * KW * IC; }
+    int64_t in_elems() const { return (int64_t)B * IH * IW * IC; }
+    int64_t out_elems() const { return (int64_t)B * OH * OW * OC; }
+    int64_t param_elems() const { return (int64_t)(K() + 1) * OC; }
+};
+
+// Split plans (deterministic: partial results go to slabs that a second kernel sums in order).
+int conv_fwd_splits(const ConvGeom& g);      // >1 only for layers whose output grid cannot fill the chip
+int conv_wgrad_splits(const ConvGeom& g);
+
+// Y = act(X (*) W + b).  `split_buf` (conv_fwd_splits(g) * out_elems floats) is needed when splits > 1.
+int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
+                 float* split_buf);
+// slabs[s][(K+1)*OC] = partial d(loss)/d(Wb) over the s-th share of the output pixels.
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs);
+// dX = (dY (*)^T W) * (mask > 0); mask = the layer input as produced by the previous ReLU (or null).
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
+               float* dX);
+// out[i] = sum_s slabs[s][i]
+int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
+
+}  // namespace ts

@@ -1,0 +1,533 @@
+// ts_conv.hip -- fp32-MFMA implicit-GEMM convolution / linear layers for gfx950 (NHWC activations).
+//
+// Replaces the torch conv2d / linear forward + autograd backward the reference runs for DQNet
+// (tianshou/env/atari/atari_network.py:79-98, 111-122; loss.backward() at algorithm_base.py:495).
+// Three GEMM shapes per layer, all on v_mfma_f32_32x32x2_f32 (bf16 is not admissible at 1e-5 rtol):
+//   forward  Y[m, oc]  = sum_k  Xcol[m, k] W[k, oc] + b[oc]        m = (b, oh, ow), k = (kh, kw, ic)
+//   wgrad    dW[k, oc] = sum_m  Xcol[m, k] dY[m, oc]               (+ db[oc] = sum_m dY[m, oc])
+//   dgrad    dX[p, ic] = sum_{taps, oc} dY[q(p, tap), oc] W[(tap, ic), oc]   gather form, one launch
+//            slice per stride-parity class so that every row of a tile uses the same taps
+// Xcol is never materialised: with NHWC activations the (kw, ic) part of k is contiguous in memory, so
+// a 32-wide k chunk of one output pixel is one (or a few) 16-byte aligned runs, loaded with clamped
+// unconditional float4 loads and staged through LDS.  Roofline: fp32 MFMA; see DESIGN.md.
+#include "ts_common.h"
+#include "ts_conv.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BK = 32;          // reduction chunk staged per iteration
+constexpr int THREADS = 256;    // 4 waves
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+struct GemmArgs {
+    const float* A;       // forward / wgrad: layer input X;  dgrad: dY
+    const float* Bm;      // forward / dgrad: Wb;             wgrad: dY
+    float* C;             // forward: Y (or split slabs);      wgrad: slabs;  dgrad: dX
+    const float* bias;
+    const float* mask;
+    ts::ConvGeom g;
+    int M;                // forward / wgrad: B*OH*OW;  dgrad: rows per parity class = B*AH*AW
+    int K;                // KH*KW*IC
+    int relu;
+    int chunks;           // reduction chunks per split
+    int total_chunks;
+    int AH, AW, JH, JW;   // dgrad: per-class output grid and taps per class
+    int64_t slab_stride;
+};
+
+// ------------------------------------------------------------------------------------------------
+// rows = pixels: forward (DG = false) and dgrad (DG = true)
+// ------------------------------------------------------------------------------------------------
+template <bool DG, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDA = BK + 1, LDB = DG ? BN + 2 : BN;
+    constexpr int AJ = BM / 32, BJ = BN / 32;
+    static_assert(WM * WN == 4, "four waves");
+    __shared__ float As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    __shared__ int s_in[BM];
+    __shared__ int s_ac[DG ? BM : 1];
+    __shared__ int s_out[DG ? BM : 1];
+    const ts::ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int ph = 0, pw = 0, split = 0;
+    if (DG) { ph = blockIdx.z / g.S; pw = blockIdx.z % g.S; } else { split = blockIdx.z; }
+
+    for (int i = tid; i < BM; i += THREADS) {
+        const int m = m0 + i;
+        const bool ok = m < a.M;
+        const int mc = ok ? m : a.M - 1;
+        if (!DG) {
+            const int b = mc / (g.OH * g.OW), rem = mc - b * g.OH * g.OW;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            s_in[i] = ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC;
+        } else {
+            const int b = mc / (a.AH * a.AW), rem = mc - b * a.AH * a.AW;
+            const int aa = rem / a.AW, cc = rem - aa * a.AW;
+            s_in[i] = ((b * g.OH + aa) * g.OW + cc) * g.OC;
+            s_ac[i] = aa | (cc << 16);
+            const int ih = aa * g.S + ph, iw = cc * g.S + pw;
+            s_out[i] = (ok && ih < g.IH && iw < g.IW) ? ((b * g.IH + ih) * g.IW + iw) * g.IC : -1;
+        }
+    }
+    __syncthreads();
+
+    const int q = tid & 7, rowi = tid >> 3;          // A staging: float4 q of rows rowi + 32 j
+    const int run = g.KW * g.IC, pitch = g.IW * g.IC;
+    f32x4 ar[AJ], br[BJ];
+
+    auto gload = [&](int c) {
+        const int k0 = c * BK;
+        if (!DG) {
+            const int k = k0 + 4 * q, kh = k / run;
+            const int koff = kh * pitch + (k - kh * run);
+#pragma unroll
+            for (int j = 0; j < AJ; ++j)
+                ar[j] = *reinterpret_cast<const f32x4*>(a.A + s_in[rowi + 32 * j] + koff);
+#pragma unroll
+            for (int i = 0; i < BJ; ++i) {
+                const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+                br[i] = *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)(k0 + kk) * g.OC + n0 + 4 * n4);
+            }
+        } else {
+            const int tp = k0 / g.OC, oc0 = k0 - tp * g.OC;
+            const int jh = tp / a.JW, jw = tp - jh * a.JW;
+            const int shift = (jh * g.OW + jw) * g.OC - oc0 - 4 * q;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int i = rowi + 32 * j, ac = s_ac[i];
+                const int oh = (ac & 0xffff) - jh, ow = (ac >> 16) - jw;
+                const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (ok ? s_in[i] - shift : 4 * q));
+                ar[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            const int tapk = ((ph + g.S * jh) * g.KW + pw + g.S * jw) * g.IC;
+#pragma unroll
+            for (int i = 0; i < BJ; ++i) {
+                const int e = tid + THREADS * i, n = e >> 3, kk4 = e & 7;
+                br[i] = *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)(tapk + n0 + n) * g.OC + oc0 + 4 * kk4);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            float* d = &As[(rowi + 32 * j) * LDA + 4 * q];
+            d[0] = ar[j][0]; d[1] = ar[j][1]; d[2] = ar[j][2]; d[3] = ar[j][3];
+        }
+#pragma unroll
+        for (int i = 0; i < BJ; ++i) {
+            const int e = tid + THREADS * i;
+            if (!DG) {
+                const int kk = e / (BN / 4), n4 = e % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[kk * LDB + 4 * n4]) = br[i];
+            } else {
+                const int n = e >> 3, kk4 = e & 7;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) Bs[(4 * kk4 + x) * LDB + n] = br[i][x];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
+
+    const int c_begin = split * a.chunks;
+    const int c_end = min(a.total_chunks, c_begin + a.chunks);
+    if (c_begin < c_end) gload(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (c + 1 < c_end) gload(c + 1);
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 2; ++kk2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[tm] = As[(wm * TM * 32 + tm * 32 + r) * LDA + 2 * kk2 + h];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[tn] = Bs[(2 * kk2 + h) * LDB + wn * TN * 32 + tn * 32 + r];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(av[tm], bv[tn], acc[tm][tn]);
+        }
+    }
+
+    const bool to_slab = !DG && a.slab_stride > 0;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + r;
+            const float bias = (!DG && !to_slab) ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int row = wm * TM * 32 + tm * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                float v = acc[tm][tn][x];
+                if (!DG) {
+                    const int m = m0 + row;
+                    if (m < a.M) {
+                        if (to_slab) {
+                            a.C[split * a.slab_stride + (int64_t)m * g.OC + col] = v;
+                        } else {
+                            v += bias;
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            a.C[(int64_t)m * g.OC + col] = v;
+                        }
+                    }
+                } else {
+                    const int o = s_out[row];
+                    if (o >= 0) {
+                        if (a.mask) v = a.mask[o + col] > 0.f ? v : 0.f;
+                        a.C[o + col] = v;
+                    }
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: rows = k, columns = oc, reduction over output pixels; split over pixel ranges into slabs
+// ------------------------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int AQ = BM / 4;                 // float4 per staged row of A
+    constexpr int ARS = THREADS / AQ;          // row stride between a thread's A loads
+    constexpr int AI = BK / ARS, BJ = BN / 32;
+    static_assert(WM * WN == 4, "four waves");
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+    __shared__ int s_row[2][BK];
+    __shared__ float s_red[THREADS];
+    const ts::ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const int kt = blockIdx.x, n0 = blockIdx.y * BN, split = blockIdx.z;
+    const int run = g.KW * g.IC, pitch = g.IW * g.IC;
+
+    const int k4 = tid % AQ, arow = tid / AQ;
+    const int k = kt * BM + 4 * k4;
+    const int kc = k < a.K ? k : 0;
+    const int kh = kc / run;
+    const int koff = kh * pitch + (kc - kh * run);
+    f32x4 ar[AI], br[BJ];
+
+    auto rowinfo = [&](int c) {
+        if (tid < BK) {
+            const int m = min(c * BK + tid, a.M - 1);
+            const int b = m / (g.OH * g.OW), rem = m - b * g.OH * g.OW;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            s_row[c & 1][tid] = ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC;
+        }
+    };
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            ar[i] = *reinterpret_cast<const f32x4*>(a.A + s_row[c & 1][arow + ARS * i] + koff);
+#pragma unroll
+        for (int i = 0; i < BJ; ++i) {
+            const int e = tid + THREADS * i, mm = e / (BN / 4), n4 = e % (BN / 4);
+            const int m = c * BK + mm;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)min(m, a.M - 1) * g.OC + n0 + 4 * n4);
+            br[i] = m < a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+            *reinterpret_cast<f32x4*>(&As[(arow + ARS * i) * BM + 4 * k4]) = ar[i];
+#pragma unroll
+        for (int i = 0; i < BJ; ++i) {
+            const int e = tid + THREADS * i, mm = e / (BN / 4), n4 = e % (BN / 4);
+            *reinterpret_cast<f32x4*>(&Bs[mm * BN + 4 * n4]) = br[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
+    float bsum = 0.f;
+    const int bn = tid % BN, bp = tid / BN;
+
+    const int c_begin = split * a.chunks;
+    const int c_end = min(a.total_chunks, c_begin + a.chunks);
+    if (c_begin < c_end) rowinfo(c_begin);
+    __syncthreads();
+    if (c_begin < c_end) gload(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();
+        lstore();
+        if (c + 1 < c_end) rowinfo(c + 1);
+        __syncthreads();
+        if (c + 1 < c_end) gload(c + 1);
+#pragma unroll
+        for (int kk2 = 0; kk2 < BK / 2; ++kk2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[tm] = As[(2 * kk2 + h) * BM + wm * TM * 32 + tm * 32 + r];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[tn] = Bs[(2 * kk2 + h) * BN + wn * TN * 32 + tn * 32 + r];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(av[tm], bv[tn], acc[tm][tn]);
+        }
+        if (kt == 0) {
+#pragma unroll
+            for (int mm = bp; mm < BK; mm += THREADS / BN) bsum += Bs[mm * BN + bn];
+        }
+    }
+
+    float* out = a.C + split * a.slab_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + wn * TN * 32 + tn * 32 + r;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int kr = kt * BM + wm * TM * 32 + tm * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                if (kr < a.K) out[(int64_t)kr * g.OC + col] = acc[tm][tn][x];
+            }
+        }
+    if (kt == 0) {
+        s_red[tid] = bsum;
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < THREADS / BN; ++p) s += s_red[p * BN + tid];
+            out[(int64_t)a.K * g.OC + n0 + tid] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab, int64_t n,
+                                                       float* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
+        for (int k = 1; k < nslab; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n + i);
+        *reinterpret_cast<f32x4*>(out + i) = s;
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            float s = slabs[j];
+            for (int k = 1; k < nslab; ++k) s += slabs[(int64_t)k * n + j];
+            out[j] = s;
+        }
+    }
+}
+
+// Y[m, n] = act(sum_s buf[s][m, n] + bias[n])   (finish of a split forward)
+__global__ __launch_bounds__(256) void split_finish_kernel(const float* __restrict__ buf, int nsplit, int64_t mn,
+                                                           int n, const float* __restrict__ bias, int relu,
+                                                           float* __restrict__ y) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= mn) return;                                  // n % 4 == 0, so a float4 never straddles rows
+    f32x4 s = *reinterpret_cast<const f32x4*>(buf + i);
+    for (int k = 1; k < nsplit; ++k) s += *reinterpret_cast<const f32x4*>(buf + (int64_t)k * mn + i);
+    s += *reinterpret_cast<const f32x4*>(bias + (i % n));
+    if (relu) { s[0] = fmaxf(s[0], 0.f); s[1] = fmaxf(s[1], 0.f); s[2] = fmaxf(s[2], 0.f); s[3] = fmaxf(s[3], 0.f); }
+    *reinterpret_cast<f32x4*>(y + i) = s;
+}
+
+int check_geom(const ts::ConvGeom& g) {
+    TS_REQUIRE(g.B > 0 && g.OH > 0 && g.OW > 0, TS_ERR_INVALID_ARG, "conv: empty geometry");
+    TS_REQUIRE(g.OH == (g.IH - g.KH) / g.S + 1 && g.OW == (g.IW - g.KW) / g.S + 1, TS_ERR_INVALID_ARG,
+               "conv: inconsistent output size");
+    TS_REQUIRE(g.K() % BK == 0 && (g.KW * g.IC) % 4 == 0 && (g.IW * g.IC) % 4 == 0 && (g.S * g.IC) % 4 == 0,
+               TS_ERR_INVALID_ARG, "conv: unsupported shape (K %% 32, 16-byte alignment of the im2col runs)");
+    TS_REQUIRE(g.OC % 32 == 0, TS_ERR_INVALID_ARG, "conv: output channels must be a multiple of 32");
+    TS_REQUIRE(g.in_elems() < (1ll << 31) && g.out_elems() < (1ll << 31), TS_ERR_INVALID_ARG,
+               "conv: tensor too large for 32-bit offsets (split the batch)");
+    return TS_OK;
+}
+
+GemmArgs base_args(const ts::ConvGeom& g) {
+    GemmArgs a{};
+    a.g = g;
+    a.M = g.B * g.OH * g.OW;
+    a.K = g.K();
+    return a;
+}
+
+constexpr int TARGET_WGS = 768;    // 256 CUs x ~3 workgroups
+
+}  // namespace
+
+namespace ts {
+
+int conv_fwd_splits(const ConvGeom& g) {
+    const int bn = g.OC % 64 == 0 ? 64 : 32, bm = bn == 64 ? 128 : 256;
+    const int64_t tiles = ceil_div((int64_t)g.B * g.OH * g.OW, bm) * (g.OC / bn);
+    const int chunks = g.K() / BK;
+    if (tiles >= 192 || chunks < 16) return 1;
+    int want = (int)ceil_div(TARGET_WGS / 2, tiles);
+    int per = (int)ceil_div(chunks, want);
+    if (per < 4) per = 4;
+    return (int)ceil_div(chunks, per);
+}
+
+int conv_wgrad_splits(const ConvGeom& g) {
+    const int bn = g.OC % 64 == 0 ? 64 : 32;
+    const int64_t tiles = ceil_div(g.K(), 128) * (g.OC / bn);
+    const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, BK);
+    int want = (int)ceil_div(TARGET_WGS, tiles);
+    int per = (int)ceil_div(chunks, want);
+    if (per < 4) per = 4;
+    return (int)ceil_div(chunks, per);
+}
+
+int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
+                 float* split_buf) {
+    if (int rc = check_geom(g)) return rc;
+    GemmArgs a = base_args(g);
+    a.A = X; a.Bm = Wb; a.bias = Wb + (int64_t)a.K * g.OC; a.relu = relu;
+    a.total_chunks = a.K / BK;
+    const int nsplit = conv_fwd_splits(g);
+    a.chunks = (int)ceil_div(a.total_chunks, nsplit);
+    if (nsplit > 1) {
+        TS_REQUIRE(split_buf, TS_ERR_INVALID_ARG, "conv_forward: split buffer missing");
+        a.C = split_buf; a.slab_stride = g.out_elems();
+    } else {
+        a.C = Y; a.slab_stride = 0;
+    }
+    if (g.OC % 64 == 0) {
+        dim3 grid((unsigned)ceil_div(a.M, 128), g.OC / 64, nsplit);
+        hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    } else {
+        dim3 grid((unsigned)ceil_div(a.M, 256), g.OC / 32, nsplit);
+        hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+    }
+    TS_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        const int64_t mn = g.out_elems();
+        hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)ceil_div(mn, 1024)), dim3(256), 0, s, split_buf,
+                           nsplit, mn, g.OC, a.bias, (int)relu, Y);
+        TS_LAUNCH_CHECK();
+    }
+    return TS_OK;
+}
+
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs) {
+    if (int rc = check_geom(g)) return rc;
+    GemmArgs a = base_args(g);
+    a.A = X; a.Bm = dY; a.C = slabs;
+    a.total_chunks = (int)ceil_div(a.M, BK);
+    const int nsplit = conv_wgrad_splits(g);
+    a.chunks = (int)ceil_div(a.total_chunks, nsplit);
+    a.slab_stride = g.param_elems();
+    if (g.OC % 64 == 0) {
+        dim3 grid((unsigned)ceil_div(a.K, 128), g.OC / 64, nsplit);
+        hipLaunchKernelGGL((conv_wgrad_kernel<2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    } else {
+        dim3 grid((unsigned)ceil_div(a.K, 128), g.OC / 32, nsplit);
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
+               float* dX) {
+    if (int rc = check_geom(g)) return rc;
+    TS_REQUIRE(g.KH % g.S == 0 && g.KW % g.S == 0, TS_ERR_INVALID_ARG,
+               "conv_dgrad: kernel size must be a multiple of the stride");
+    TS_REQUIRE(g.IC % 32 == 0, TS_ERR_INVALID_ARG, "conv_dgrad: input channels must be a multiple of 32");
+    GemmArgs a = base_args(g);
+    a.A = dY; a.Bm = Wb; a.C = dX; a.mask = mask;
+    a.AH = (int)ceil_div(g.IH, g.S); a.AW = (int)ceil_div(g.IW, g.S);
+    a.JH = g.KH / g.S; a.JW = g.KW / g.S;
+    a.M = g.B * a.AH * a.AW;
+    a.total_chunks = a.JH * a.JW * g.OC / BK;
+    a.chunks = a.total_chunks;
+    if (g.IC % 64 == 0) {
+        dim3 grid((unsigned)ceil_div(a.M, 128), g.IC / 64, g.S * g.S);
+        hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    } else {
+        dim3 grid((unsigned)ceil_div(a.M, 256), g.IC / 32, g.S * g.S);
+        hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out) {
+    if (n <= 0) return TS_OK;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, slabs, nslab, n, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace ts
+
+// ---- C ABI: single layers (parity tests, other network shapes) -----------------------------------
+namespace {
+ts::ConvGeom geom_of(const int64_t* d) {
+    ts::ConvGeom g{(int)d[0], (int)d[1], (int)d[2], (int)d[3], (int)d[4], (int)d[5], (int)d[6], 0, 0, (int)d[7]};
+    g.OH = (g.IH - g.KH) / g.S + 1;
+    g.OW = (g.IW - g.KW) / g.S + 1;
+    return g;
+}
+int check_dims(const int64_t* d) {
+    TS_REQUIRE(d != nullptr, TS_ERR_INVALID_ARG, "conv: NULL dims");
+    for (int i = 0; i < 8; ++i) TS_REQUIRE(d[i] >= 1 && d[i] < (1 << 24), TS_ERR_INVALID_ARG, "conv: bad dims");
+    TS_REQUIRE(d[1] >= d[4] && d[2] >= d[5], TS_ERR_INVALID_ARG, "conv: kernel larger than the input");
+    return TS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ts_conv_forward(ts_workspace* ws, const float* x, const float* wb, float* y, const int64_t* h_dims, int relu,
+                    ts_stream_t stream) {
+    if (int rc = check_dims(h_dims)) return rc;
+    TS_REQUIRE(x && wb && y, TS_ERR_INVALID_ARG, "ts_conv_forward: NULL argument");
+    const ts::ConvGeom g = geom_of(h_dims);
+    float* split = nullptr;
+    const int ns = ts::conv_fwd_splits(g);
+    if (ns > 1) {
+        TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_conv_forward: workspace is NULL");
+        if (int rc = ts::ws_reserve(ws, sizeof(float) * (size_t)ns * g.out_elems())) return rc;
+        split = static_cast<float*>(ws->base);
+    }
+    return ts::conv_forward(ts::as_stream(stream), g, x, wb, y, relu != 0, split);
+}
+
+int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const float* dy, const float* mask,
+                     float* d_wb, float* dx, const int64_t* h_dims, ts_stream_t stream) {
+    if (int rc = check_dims(h_dims)) return rc;
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_conv_backward: workspace is NULL");
+    TS_REQUIRE(x && wb && dy && d_wb, TS_ERR_INVALID_ARG, "ts_conv_backward: NULL argument");
+    const ts::ConvGeom g = geom_of(h_dims);
+    const int ns = ts::conv_wgrad_splits(g);
+    if (int rc = ts::ws_reserve(ws, sizeof(float) * (size_t)ns * g.param_elems())) return rc;
+    float* slabs = static_cast<float*>(ws->base);
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::conv_wgrad(s, g, x, dy, slabs)) return rc;
+    if (int rc = ts::slab_sum(s, slabs, ns, g.param_elems(), d_wb)) return rc;
+    if (dx) return ts::conv_dgrad(s, g, dy, wb, mask, dx);
+    return TS_OK;
+}
+
+}  // extern "C"

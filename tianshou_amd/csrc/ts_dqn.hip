@@ -1,0 +1,304 @@
+// ts_dqn.hip -- the DQN learn() step on NatureCNN (DQNet) for gfx950.
+//
+// Replaces, on device-resident NHWC float32 observations:
+//   DQNet.forward                       tianshou/env/atari/atari_network.py:79-98, 111-122
+//   DiscreteQLearningPolicy.forward     tianshou/algorithm/modelfree/dqn.py:101-143 (act = argmax_a Q)
+//   DQN._target_q                       dqn.py:365-379
+//   DQN._update_with_batch              dqn.py:381-404 (+ Optimizer.step algorithm_base.py:484-500)
+// The conv / linear layers run on the fp32-MFMA implicit-GEMM kernels of ts_conv.hip; this file adds
+// the small head (512 -> n_act), the TD loss and the orchestration.  Flat parameter layout: see
+// include/tsengine.h (ts_dqn_param_count).
+#include "ts_common.h"
+#include "ts_conv.h"
+
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+}
+
+namespace {
+
+constexpr int HIDDEN = 512;
+constexpr int MAX_ACT = 64;
+
+struct Net {
+    ts::ConvGeom l[4];          // conv1, conv2, conv3, fc1
+    int n_act;
+    int64_t off[5];             // parameter offsets of the five layers
+    int64_t total;
+};
+
+int make_net(int B, int c, int h, int w, int n_act, Net* n) {
+    TS_REQUIRE(c >= 1 && h >= 1 && w >= 1 && n_act >= 1 && n_act <= MAX_ACT, TS_ERR_INVALID_ARG,
+               "dqn: bad network dimensions");
+    static const int oc[3] = {32, 64, 64}, ks[3] = {8, 4, 3}, st[3] = {4, 2, 1};
+    int ic = c, ih = h, iw = w;
+    for (int i = 0; i < 3; ++i) {
+        TS_REQUIRE(ih >= ks[i] && iw >= ks[i], TS_ERR_INVALID_ARG, "dqn: observation too small for DQNet");
+        ts::ConvGeom& g = n->l[i];
+        g = ts::ConvGeom{B, ih, iw, ic, ks[i], ks[i], st[i], (ih - ks[i]) / st[i] + 1, (iw - ks[i]) / st[i] + 1, oc[i]};
+        ic = oc[i]; ih = g.OH; iw = g.OW;
+    }
+    n->l[3] = ts::ConvGeom{B, 1, 1, ic * ih * iw, 1, 1, 1, 1, 1, HIDDEN};
+    n->n_act = n_act;
+    int64_t o = 0;
+    for (int i = 0; i < 4; ++i) { n->off[i] = o; o += n->l[i].param_elems(); }
+    n->off[4] = o;
+    o += (int64_t)(HIDDEN + 1) * n_act;
+    n->total = o;
+    return TS_OK;
+}
+
+// ---- head: Q = H4 . W5 + b5 (one wave per sample), optional greedy action -----------------------
+__global__ __launch_bounds__(256) void head_forward_kernel(const float* __restrict__ h4, const float* __restrict__ wb,
+                                                           int64_t B, int A, float* __restrict__ q,
+                                                           int64_t* __restrict__ act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float hv[HIDDEN / 64];
+#pragma unroll
+    for (int j = 0; j < HIDDEN / 64; ++j) hv[j] = h4[b * HIDDEN + lane + 64 * j];
+    float best = 0.f;
+    int best_a = 0;
+    for (int a = 0; a < A; ++a) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < HIDDEN / 64; ++j) s += hv[j] * wb[(int64_t)(lane + 64 * j) * A + a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        s += wb[(int64_t)HIDDEN * A + a];
+        if (lane == 0) q[b * A + a] = s;
+        if (a == 0 || s > best) { best = s; best_a = a; }     // first maximum, like torch.argmax
+    }
+    if (act && lane == 0) act[b] = best_a;
+}
+
+// ---- DQN._target_q (dqn.py:365-379) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void target_q_kernel(const float* __restrict__ q_online,
+                                                       const float* __restrict__ q_target, int64_t B, int A,
+                                                       int is_double, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* sel = is_double ? q_online : q_target;
+    float best = sel[b * A];
+    int best_a = 0;
+    for (int a = 1; a < A; ++a) {
+        const float v = sel[b * A + a];
+        if (v > best) { best = v; best_a = a; }
+    }
+    out[b] = q_target[b * A + best_a];
+}
+
+// ---- TD error, loss and d loss / d Q[b, act_b]  (dqn.py:388-401) ----------------------------------
+__global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                                       const float* __restrict__ ret, const float* __restrict__ weight,
+                                                       int64_t B, int A, float huber_delta, float* __restrict__ td,
+                                                       float* __restrict__ dq, float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float lsum = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float t = ret[b] - q[b * A + act[b]];
+        td[b] = t;
+        float l, g;                                  // g = d loss_b / d q
+        if (huber_delta > 0.f) {                     // torch.nn.functional.huber_loss(q, returns)
+            const float ad = fabsf(t);
+            if (ad < huber_delta) { l = 0.5f * t * t; g = -t; }
+            else { l = huber_delta * (ad - 0.5f * huber_delta); g = t > 0.f ? -huber_delta : huber_delta; }
+        } else {                                     // (td_error.pow(2) * weight).mean()
+            const float w = weight ? weight[b] : 1.f;
+            l = t * t * w;
+            g = -2.f * t * w;
+        }
+        dq[b] = g * inv_b;
+        lsum += l;
+    }
+    red[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+}
+
+// dH4[b, k] = dq[b] W5[k, act_b] (H4[b, k] > 0)
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
+                                                         const float* __restrict__ wb, const float* __restrict__ h4,
+                                                         int64_t B, int A, float* __restrict__ dh4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * HIDDEN) return;
+    const int64_t b = i / HIDDEN;
+    const int k = (int)(i - b * HIDDEN);
+    dh4[i] = h4[i] > 0.f ? dq[b] * wb[(int64_t)k * A + act[b]] : 0.f;
+}
+
+// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1); batch order, no atomics
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
+                                                         const float* __restrict__ h4, int64_t B, int A,
+                                                         float* __restrict__ dwb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (HIDDEN + 1) * A) return;
+    const int k = i / A, a = i - k * A;
+    float s = 0.f;
+    for (int64_t b = 0; b < B; ++b) {
+        const float hv = k < HIDDEN ? h4[b * HIDDEN + k] : 1.f;
+        s += act[b] == a ? hv * dq[b] : 0.f;
+    }
+    dwb[i] = s;
+}
+
+struct Scratch {           // carve of the workspace for one network pass over B samples
+    float* h[4];           // activations of conv1..fc1
+    float* q;              // [B, A]
+    float* split;          // forward split buffer (fc1)
+    size_t bytes;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
+
+size_t fwd_scratch_bytes(const Net& n, int64_t B) {
+    size_t s = 0;
+    for (int i = 0; i < 4; ++i) s += align_up(sizeof(float) * n.l[i].out_elems());
+    s += align_up(sizeof(float) * B * n.n_act);
+    size_t sp = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int ns = ts::conv_fwd_splits(n.l[i]);
+        if (ns > 1) sp = std::max(sp, sizeof(float) * (size_t)ns * n.l[i].out_elems());
+    }
+    return s + align_up(sp);
+}
+
+char* carve_fwd(const Net& n, int64_t B, char* p, Scratch* sc) {
+    for (int i = 0; i < 4; ++i) { sc->h[i] = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.l[i].out_elems()); }
+    sc->q = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * B * n.n_act);
+    sc->split = reinterpret_cast<float*>(p);
+    size_t sp = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int ns = ts::conv_fwd_splits(n.l[i]);
+        if (ns > 1) sp = std::max(sp, sizeof(float) * (size_t)ns * n.l[i].out_elems());
+    }
+    return p + align_up(sp);
+}
+
+int net_forward(hipStream_t s, const Net& n, const float* params, const float* obs, int64_t B, const Scratch& sc,
+                float* q_out, int64_t* act_out) {
+    const float* x = obs;
+    for (int i = 0; i < 4; ++i) {
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], sc.h[i], true, sc.split)) return rc;
+        x = sc.h[i];
+    }
+    hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, sc.h[3],
+                       params + n.off[4], B, n.n_act, q_out, act_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ts_dqn_param_count(int64_t c, int64_t h, int64_t w, int64_t n_act) {
+    Net n;
+    if (make_net(1, (int)c, (int)h, (int)w, (int)n_act, &n) != TS_OK) return -1;
+    return n.total;
+}
+
+int ts_dqn_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t* h_offsets6, int64_t* h_geom) {
+    Net n;
+    if (int rc = make_net(1, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    TS_REQUIRE(h_offsets6, TS_ERR_INVALID_ARG, "ts_dqn_layer_offsets: NULL output");
+    for (int i = 0; i < 5; ++i) h_offsets6[i] = n.off[i];
+    h_offsets6[5] = n.total;
+    if (h_geom)
+        for (int i = 0; i < 4; ++i) {
+            const ts::ConvGeom& g = n.l[i];
+            const int64_t v[10] = {g.B, g.IH, g.IW, g.IC, g.KH, g.KW, g.S, g.OH, g.OW, g.OC};
+            for (int j = 0; j < 10; ++j) h_geom[i * 10 + j] = v[j];
+        }
+    return TS_OK;
+}
+
+int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                   const float* obs_nhwc, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_forward: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_dqn_forward: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && obs_nhwc && q_out, TS_ERR_INVALID_ARG, "ts_dqn_forward: NULL argument");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    if (int rc = ts::ws_reserve(ws, fwd_scratch_bytes(n, B))) return rc;
+    Scratch sc;
+    carve_fwd(n, B, static_cast<char*>(ws->base), &sc);
+    return net_forward(ts::as_stream(stream), n, params, obs_nhwc, B, sc, q_out, act_out);
+}
+
+int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
+                    float* out, ts_stream_t stream) {
+    TS_REQUIRE(B >= 0 && n_act >= 1, TS_ERR_INVALID_ARG, "ts_dqn_target_q: bad sizes");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(q_target && out && (q_online || !is_double), TS_ERR_INVALID_ARG, "ts_dqn_target_q: NULL argument");
+    hipLaunchKernelGGL(target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, ts::as_stream(stream),
+                       q_online, q_target, B, (int)n_act, is_double, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                  int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act,
+                  const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
+                  float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_update: workspace is NULL");
+    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_dqn_update: bad batch size / step");
+    TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && returns && hp && td_out && loss_out,
+               TS_ERR_INVALID_ARG, "ts_dqn_update: NULL argument");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+
+    // workspace: forward scratch | dq | dY of every layer | wgrad slabs | flat gradient | norm partials
+    size_t bytes = fwd_scratch_bytes(n, B);
+    bytes += align_up(sizeof(float) * B);
+    for (int i = 0; i < 4; ++i) bytes += align_up(sizeof(float) * n.l[i].out_elems());
+    size_t slab = 0;
+    for (int i = 0; i < 4; ++i)
+        slab = std::max(slab, sizeof(float) * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    bytes += align_up(slab) + align_up(sizeof(float) * n.total) + 4096;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Scratch sc;
+    char* p = carve_fwd(n, B, static_cast<char*>(ws->base), &sc);
+    float* dq = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * B);
+    float* dy[4];
+    for (int i = 0; i < 4; ++i) { dy[i] = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.l[i].out_elems()); }
+    float* slabs = reinterpret_cast<float*>(p); p += align_up(slab);
+    float* grad = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.total);
+    float* norm_part = reinterpret_cast<float*>(p);
+    if (grad_out) grad = grad_out;
+
+    // forward (keeps the activations), loss
+    if (int rc = net_forward(s, n, params, obs_nhwc, B, sc, sc.q, nullptr)) return rc;
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
+                       hp->huber_delta, td_out, dq, loss_out);
+    TS_LAUNCH_CHECK();
+    // head backward
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)ts::ceil_div((HIDDEN + 1) * n.n_act, 256)), dim3(256), 0, s,
+                       dq, act, sc.h[3], B, n.n_act, grad + n.off[4]);
+    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)ts::ceil_div(B * HIDDEN, 256)), dim3(256), 0, s, dq, act,
+                       params + n.off[4], sc.h[3], B, n.n_act, dy[3]);
+    TS_LAUNCH_CHECK();
+    // fc1, conv3, conv2, conv1
+    for (int i = 3; i >= 0; --i) {
+        const float* x = i == 0 ? obs_nhwc : sc.h[i - 1];
+        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs)) return rc;
+        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
+            return rc;
+        if (i > 0)
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1])) return rc;
+    }
+    if (hp->lr < 0.f) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
+    return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
+                         hp->adam_eps, hp->max_grad_norm, norm_part);
+}
+
+}  // extern "C"

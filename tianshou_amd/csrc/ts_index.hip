@@ -46,6 +46,51 @@ __global__ void step_index_kernel(const int64_t* index, int64_t I, const int64_t
     }
 }
 
+// ReplayBuffer.get with stack_num > 1 (buffer_base.py:586-596): column stack-1-j holds prev^j(index)
+__global__ void stack_indices_kernel(const int64_t* index, int64_t I, int64_t stack, const int64_t* offset,
+                                     int64_t E, const uint8_t* done, const int64_t* last_index,
+                                     const int64_t* lengths, int64_t* out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = offset[E];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < I; i += stride) {
+        int64_t idx = index[i];
+        out[i * stack + stack - 1] = idx;                   // val[indices] is taken before prev()
+        for (int64_t j = 1; j < stack; ++j) {
+            idx = pymod(idx, total);
+            const int64_t e = find_sub(offset, E, idx);
+            const int64_t start = offset[e];
+            const int64_t len = lengths[e];
+            const int64_t cur_len = len > 1 ? len : 1;
+            const int64_t subind = pymod(idx - start - 1, cur_len);
+            const int64_t end_flag = (done[subind + start] != 0) | (subind + start == last_index[e]);
+            idx = pymod(subind + end_flag, cur_len) + start;
+            out[i * stack + stack - 1 - j] = idx;
+        }
+    }
+}
+
+// frames u8 [n_planes][plane_elems] -> float32 NHWC [B][plane_elems][C]: out[b, p, c] = src[plane[b, c], p]
+template <int C>
+__global__ __launch_bounds__(256) void gather_planes_kernel(const uint8_t* __restrict__ src, int64_t plane_elems,
+                                                            const int64_t* __restrict__ plane, int64_t B, int Cdyn,
+                                                            float* __restrict__ out) {
+    const int Cn = C > 0 ? C : Cdyn;
+    const int64_t b = blockIdx.y;
+    const int64_t* pl = plane + b * Cn;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < plane_elems; p += (int64_t)gridDim.x * 256) {
+        if (C == 4) {
+            float4 v;
+            v.x = (float)src[pl[0] * plane_elems + p];
+            v.y = (float)src[pl[1] * plane_elems + p];
+            v.z = (float)src[pl[2] * plane_elems + p];
+            v.w = (float)src[pl[3] * plane_elems + p];
+            *reinterpret_cast<float4*>(out + (b * plane_elems + p) * 4) = v;
+        } else {
+            for (int c = 0; c < Cn; ++c) out[(b * plane_elems + p) * Cn + c] = (float)src[pl[c] * plane_elems + p];
+        }
+    }
+}
+
 // single workgroup, order-preserving compaction over the E sub-buffers
 __global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
                                   const int64_t* lengths, int64_t* out, int64_t* n_out) {
@@ -285,6 +330,41 @@ int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const
                            dim3(256), 0, s, (const uint8_t*)src, n_rows_src, row_bytes, index, I,
                            (uint8_t*)out);
     }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_stack_indices(const int64_t* index, int64_t I, int64_t stack_num, const int64_t* offset, int64_t E,
+                     const uint8_t* done, const int64_t* last_index, const int64_t* lengths, int64_t* out,
+                     ts_stream_t stream) {
+    TS_REQUIRE(I >= 0 && stack_num >= 1 && E >= 1, TS_ERR_INVALID_ARG, "ts_stack_indices: bad sizes");
+    if (I == 0) return TS_OK;
+    TS_REQUIRE(index && offset && done && last_index && lengths && out, TS_ERR_INVALID_ARG,
+               "ts_stack_indices: NULL argument");
+    int64_t blocks = ts::ceil_div(I, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(stack_indices_kernel, dim3((unsigned)blocks), dim3(256), 0, ts::as_stream(stream), index, I,
+                       stack_num, offset, E, done, last_index, lengths, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
+                          int64_t B, int64_t C, float* out, ts_stream_t stream) {
+    TS_REQUIRE(B >= 0 && C >= 1 && C <= 64 && plane_elems >= 1 && n_planes >= 1, TS_ERR_INVALID_ARG,
+               "ts_gather_planes_nhwc: bad sizes");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(src && plane_index && out, TS_ERR_INVALID_ARG, "ts_gather_planes_nhwc: NULL argument");
+    TS_REQUIRE(B <= 65535, TS_ERR_UNSUPPORTED, "ts_gather_planes_nhwc: at most 65535 rows per call");
+    int64_t bx = ts::ceil_div(plane_elems, 256);
+    if (bx > 64) bx = 64;
+    dim3 grid((unsigned)bx, (unsigned)B);
+    if (C == 4)
+        hipLaunchKernelGGL(gather_planes_kernel<4>, grid, dim3(256), 0, ts::as_stream(stream), src, plane_elems,
+                           plane_index, B, 4, out);
+    else
+        hipLaunchKernelGGL(gather_planes_kernel<0>, grid, dim3(256), 0, ts::as_stream(stream), src, plane_elems,
+                           plane_index, B, (int)C, out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -3,6 +3,8 @@
 // Replaces polyak_parameter_update / LaggedNetworkCollection.full_parameter_update
 // (tianshou/utils/lagged_network.py:8-18, 81-87), which loop over parameter tensors in Python.
 // Roofline: HBM, 12 B per parameter (read src, read tgt, write tgt).
+#include <cmath>
+
 #include "ts_common.h"
 
 #pragma clang fp contract(off)   // tau * src + (1 - tau) * tgt: two products, one sum, as torch
@@ -27,9 +29,92 @@ __global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ tgt, co
     }
 }
 
+// ---- clip_grad_norm_ + Adam over one flat parameter vector ------------------------------------
+// Optimizer.step (algorithm_base.py:484-500) with torch.optim.Adam's single-tensor arithmetic
+// (optim.py:89-110).  28 B / parameter of HBM traffic (+4 for the norm pass when clipping).
+constexpr int SUMSQ_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += g[i] * g[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct AdamArgs {
+    float* p; float* m; float* v; const float* g; int64_t n;
+    const float* part; int n_part; float max_norm;
+    float lr_step, beta1, beta2, bc2_sqrt, eps;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    float scale = 1.f;
+    if (a.part) {   // every workgroup re-reduces the partials in the same order -> identical scale
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int k = threadIdx.x; k < a.n_part; k += 256) s += a.part[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        scale = fminf(a.max_norm / (norm + 1e-6f), 1.f);     // clip_grad_norm_
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float gq = a.g[i] * scale;
+    float m = a.m[i], v = a.v[i];
+    m = m + (gq - m) * (1.f - a.beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (1.f - a.beta2) * gq * gq;         // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    a.p[i] = a.p[i] + (-a.lr_step * m) / denom;          // addcdiv_(m, denom, -step_size)
+    a.m[i] = m;
+    a.v[i] = v;
+}
+
 }  // namespace
 
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
+    AdamArgs a{};
+    a.p = params; a.m = m; a.v = v; a.g = grad; a.n = n;
+    if (max_grad_norm > 0) {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, n, norm_scratch);
+        a.part = norm_scratch; a.n_part = SUMSQ_BLOCKS; a.max_norm = (float)max_grad_norm;
+    }
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.lr_step = (float)(lr / bc1);
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = (float)eps;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, a);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+}  // namespace ts
+
 extern "C" {
+
+int ts_adam_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, const float* grad, int64_t n,
+                 int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm,
+                 ts_stream_t stream) {
+    TS_REQUIRE(n >= 0 && step >= 1, TS_ERR_INVALID_ARG, "ts_adam_step: bad n / step");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(params && adam_m && adam_v && grad, TS_ERR_INVALID_ARG, "ts_adam_step: NULL argument");
+    float* scratch = nullptr;
+    if (max_grad_norm > 0) {
+        TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_adam_step: clipping needs a workspace");
+        if (int rc = ts::ws_reserve(ws, 4096)) return rc;
+        scratch = static_cast<float*>(ws->base);
+    }
+    return ts::adam_step(ts::as_stream(stream), params, adam_m, adam_v, grad, n, step, lr, beta1, beta2, eps,
+                         max_grad_norm, scratch);
+}
 
 int ts_polyak_update(float* tgt, const float* src, int64_t n, double tau, ts_stream_t stream) {
     TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_polyak_update: negative n");

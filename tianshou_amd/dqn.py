@@ -1,0 +1,275 @@
+"""DQN learn() path on the MI355X engine (NatureCNN / DQNet on fp32 MFMA).
+
+Mirrors, on device tensors:
+    DQNet.forward                        tianshou/env/atari/atari_network.py:111-122
+    DiscreteQLearningPolicy.forward      tianshou/algorithm/modelfree/dqn.py:101-143
+    DQN._target_q / _preprocess_batch    dqn.py:257-275, 365-379 (n-step via tianshou_amd.returns)
+    DQN._update_with_batch               dqn.py:381-404 (+ periodic hard sync :277-285)
+    ReplayBuffer.get with stack_num      data/buffer/buffer_base.py:557-603
+There is no CPU path: every function calls libtsengine.so and raises when it is missing.
+
+Internal layouts (include/tsengine.h): observations NHWC float32; per layer one matrix
+wb[(kh, kw, ic) + bias row, oc]; fc1 rows in (h, w, c) order.  `flat_from_torch` / `flat_to_torch`
+convert from / to the reference's state_dict tensors (and Adam moments) exactly (pure permutations).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .buffer import DeviceReplayBuffer, _i64_dev
+from .lagged import full_parameter_update
+from .returns import compute_nstep_return
+
+TIANSHOU_KEYS = ["net.0.0.weight", "net.0.0.bias", "net.0.2.weight", "net.0.2.bias",
+                 "net.0.4.weight", "net.0.4.bias", "net.1.weight", "net.1.bias",
+                 "net.3.weight", "net.3.bias"]
+
+
+class DQNHParams(C.Structure):
+    """struct ts_dqn_hparams (include/tsengine.h)."""
+
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
+                ("huber_delta", C.c_float), ("max_grad_norm", C.c_float)]
+
+
+def _lib_dqn():
+    lib = _lib.load()
+    lib.ts_dqn_param_count.restype = C.c_int64
+    lib.ts_dqn_param_count.argtypes = [C.c_int64] * 4
+    return lib
+
+
+def layer_layout(c: int, h: int, w: int, n_act: int):
+    """-> (offsets int64[6], geoms int64[4, 10] rows {B, IH, IW, IC, KH, KW, S, OH, OW, OC})."""
+    off = (C.c_int64 * 6)()
+    geom = (C.c_int64 * 40)()
+    _lib.check(_lib_dqn().ts_dqn_layer_offsets(_lib.i64(c), _lib.i64(h), _lib.i64(w), _lib.i64(n_act), off, geom))
+    return np.array(off[:], np.int64), np.array(geom[:], np.int64).reshape(4, 10)
+
+
+def param_count(c: int, h: int, w: int, n_act: int) -> int:
+    n = int(_lib_dqn().ts_dqn_param_count(c, h, w, n_act))
+    if n < 0:
+        raise ValueError("unsupported DQNet dimensions")
+    return n
+
+
+def flat_from_torch(tensors: list[torch.Tensor], c: int, h: int, w: int, n_act: int, device="cuda") -> torch.Tensor:
+    """[conv1.w, conv1.b, conv2.w, ..., fc2.w, fc2.b] in torch layout (DQNet state_dict order, also valid
+    for the matching Adam moments) -> the engine's flat vector."""
+    _, geom = layer_layout(c, h, w, n_act)
+    oh3, ow3 = int(geom[2, 7]), int(geom[2, 8])
+    parts = []
+    for i in range(3):
+        wt, b = tensors[2 * i].detach().float(), tensors[2 * i + 1].detach().float()
+        parts += [wt.permute(2, 3, 1, 0).reshape(-1), b.reshape(-1)]          # [oc, ic, kh, kw] -> [(kh, kw, ic), oc]
+    w4, b4 = tensors[6].detach().float(), tensors[7].detach().float()
+    parts += [w4.reshape(512, 64, oh3, ow3).permute(2, 3, 1, 0).reshape(-1), b4.reshape(-1)]
+    w5, b5 = tensors[8].detach().float(), tensors[9].detach().float()
+    parts += [w5.t().reshape(-1), b5.reshape(-1)]
+    return torch.cat(parts).to(device).contiguous()
+
+
+def flat_to_torch(flat: torch.Tensor, c: int, h: int, w: int, n_act: int) -> list[torch.Tensor]:
+    """Inverse of flat_from_torch -> ten tensors in torch layout (on flat's device)."""
+    off, geom = layer_layout(c, h, w, n_act)
+    out = []
+    for i in range(3):
+        ic, kh, kw, oc = (int(geom[i, j]) for j in (3, 4, 5, 9))
+        k = kh * kw * ic
+        wb = flat[off[i]:off[i + 1]].reshape(k + 1, oc)
+        out += [wb[:k].reshape(kh, kw, ic, oc).permute(3, 2, 0, 1).contiguous(), wb[k].clone()]
+    oh3, ow3 = int(geom[2, 7]), int(geom[2, 8])
+    f = 64 * oh3 * ow3
+    wb = flat[off[3]:off[4]].reshape(f + 1, 512)
+    out += [wb[:f].reshape(oh3, ow3, 64, 512).permute(3, 2, 0, 1).reshape(512, f).contiguous(), wb[f].clone()]
+    wb = flat[off[4]:off[5]].reshape(513, n_act)
+    out += [wb[:512].t().contiguous(), wb[512].clone()]
+    return out
+
+
+# ---- single layers (tests, other shapes) ---------------------------------------------------------
+def _dims(x: torch.Tensor, kh: int, kw: int, stride: int, oc: int):
+    b, ih, iw, ic = x.shape
+    return (C.c_int64 * 8)(b, ih, iw, ic, kh, kw, stride, oc), ((ih - kh) // stride + 1, (iw - kw) // stride + 1)
+
+
+def conv_forward(x: torch.Tensor, wb: torch.Tensor, kh: int, kw: int, stride: int, relu: bool) -> torch.Tensor:
+    """x float32[B, IH, IW, IC] (NHWC), wb float32[kh*kw*IC + 1, OC] -> y float32[B, OH, OW, OC]."""
+    oc = wb.shape[1]
+    dims, (oh, ow) = _dims(x, kh, kw, stride, oc)
+    y = torch.empty((x.shape[0], oh, ow, oc), dtype=torch.float32, device=x.device)
+    ws = _lib.default_workspace(x.device.index or 0)
+    _lib.check(_lib.load().ts_conv_forward(ws.handle, _lib.ptr(x), _lib.ptr(wb), _lib.ptr(y), dims, C.c_int(int(relu)),
+                                           _lib.current_stream(x.device)))
+    return y
+
+
+def conv_backward(x, wb, dy, kh: int, kw: int, stride: int, mask=None, need_dx: bool = True):
+    """-> (d_wb, dx or None); dx is multiplied by (mask > 0) when mask is given."""
+    oc = wb.shape[1]
+    dims, _ = _dims(x, kh, kw, stride, oc)
+    d_wb = torch.empty_like(wb)
+    dx = torch.empty_like(x) if need_dx else None
+    ws = _lib.default_workspace(x.device.index or 0)
+    _lib.check(_lib.load().ts_conv_backward(ws.handle, _lib.ptr(x), _lib.ptr(wb), _lib.ptr(dy), _lib.ptr(mask),
+                                            _lib.ptr(d_wb), _lib.ptr(dx), dims, _lib.current_stream(x.device)))
+    return d_wb, dx
+
+
+# ---- observations ----------------------------------------------------------------------------------
+def stack_indices(buffer: DeviceReplayBuffer, index, stack_num: int) -> torch.Tensor:
+    """int64[I, stack_num]: column stack_num-1-j = prev^j(index) (buffer_base.py:586-596)."""
+    index = _i64_dev(index, buffer.device).reshape(-1)
+    out = torch.empty((index.numel(), stack_num), dtype=torch.int64, device=buffer.device)
+    _lib.check(_lib.load().ts_stack_indices(
+        _lib.ptr(index), _lib.i64(index.numel()), _lib.i64(stack_num), _lib.ptr(buffer.offset),
+        _lib.i64(buffer.buffer_num), _lib.ptr(buffer.done), _lib.ptr(buffer.last_index), _lib.ptr(buffer.lengths),
+        _lib.ptr(out), _lib.current_stream(buffer.device)))
+    return out
+
+
+def gather_obs_nhwc(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, stack_num: int) -> torch.Tensor:
+    """buffer.get(index, "obs") as the float32 NHWC tensor DQNet consumes.
+
+    frames: uint8 [slots, H, W] with stack_num > 1 (save_only_last_obs layout,
+    examples/atari/atari_dqn.py:137-142) or uint8 [slots, C, H, W] with stack_num == 1."""
+    index = _i64_dev(index, buffer.device).reshape(-1)
+    if stack_num > 1:
+        if frames.dim() != 3:
+            raise ValueError("stacked layout expects frames [slots, H, W]")
+        planes = stack_indices(buffer, index, stack_num)
+        c, (hh, ww) = stack_num, frames.shape[1:]
+        n_planes = frames.shape[0]
+    else:
+        if frames.dim() != 4:
+            raise ValueError("unstacked layout expects frames [slots, C, H, W]")
+        c, hh, ww = frames.shape[1:]
+        planes = (index[:, None] * c + torch.arange(c, device=index.device)[None, :]).contiguous()
+        n_planes = frames.shape[0] * c
+    if frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise ValueError("frames must be a contiguous uint8 tensor")
+    out = torch.empty((index.numel(), hh, ww, c), dtype=torch.float32, device=frames.device)
+    step = 32768
+    for lo in range(0, index.numel(), step):
+        hi = min(index.numel(), lo + step)
+        _lib.check(_lib.load().ts_gather_planes_nhwc(
+            _lib.ptr(frames), _lib.i64(n_planes), _lib.i64(hh * ww), _lib.ptr(planes[lo:hi]), _lib.i64(hi - lo),
+            _lib.i64(c), _lib.ptr(out[lo:hi]), _lib.current_stream(frames.device)))
+    return out
+
+
+@dataclass
+class DQNConfig:
+    """Hyper-parameters of the reference DQN (dqn.py:309-363) + Adam (optim.py:89-110)."""
+
+    gamma: float = 0.99
+    n_step: int = 1
+    target_update_freq: int = 0
+    is_double: bool = True
+    huber_delta: float | None = None
+    lr: float = 1e-3
+    betas: tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+    max_grad_norm: float | None = None
+
+    def to_c(self, grad_only: bool = False) -> DQNHParams:
+        return DQNHParams(-1.0 if grad_only else self.lr, self.betas[0], self.betas[1], self.adam_eps,
+                          self.huber_delta if self.huber_delta is not None else -1.0, self.max_grad_norm or 0.0)
+
+
+class DQNEngine:
+    """State of one DQN learner on one GPU: flat parameters, lagged copy, Adam moments, counters."""
+
+    def __init__(self, c: int, h: int, w: int, n_act: int, flat_params: torch.Tensor, cfg: DQNConfig):
+        if not flat_params.is_cuda:
+            raise RuntimeError("DQNEngine needs parameters on an MI355X (no CPU fallback)")
+        self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
+        self.P = param_count(c, h, w, n_act)
+        if flat_params.numel() != self.P:
+            raise ValueError(f"expected {self.P} parameters, got {flat_params.numel()}")
+        self.device = flat_params.device
+        self.params = flat_params.detach().float().contiguous().clone()
+        self.params_old = self.params.clone() if cfg.target_update_freq > 0 else None    # dqn.py:240-246
+        self.adam_m = torch.zeros_like(self.params)
+        self.adam_v = torch.zeros_like(self.params)
+        self.adam_step = 0
+        self.iter = 0
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    # -- DiscreteQLearningPolicy.forward ---------------------------------------------------------
+    def forward(self, obs_nhwc: torch.Tensor, params: torch.Tensor | None = None, want_act: bool = True):
+        """-> (logits float32[B, A], act int64[B] = argmax)."""
+        b = obs_nhwc.shape[0]
+        if tuple(obs_nhwc.shape[1:]) != (self.h, self.w, self.c) or obs_nhwc.dtype != torch.float32:
+            raise ValueError(f"obs must be float32 [B, {self.h}, {self.w}, {self.c}] (NHWC)")
+        obs_nhwc = obs_nhwc.contiguous()
+        q = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
+        act = torch.empty(b, dtype=torch.int64, device=self.device) if want_act else None
+        p = self.params if params is None else params
+        _lib.check(_lib.load().ts_dqn_forward(
+            self._ws.handle, _lib.ptr(p), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act),
+            _lib.ptr(obs_nhwc), _lib.i64(b), _lib.ptr(q), _lib.ptr(act), _lib.current_stream(self.device)))
+        return q, act
+
+    # -- DQN._target_q ---------------------------------------------------------------------------------
+    def target_q(self, obs_next_nhwc: torch.Tensor) -> torch.Tensor:
+        q_on, _ = self.forward(obs_next_nhwc, want_act=False)
+        q_tg = q_on if self.params_old is None else self.forward(obs_next_nhwc, self.params_old, want_act=False)[0]
+        out = torch.empty(q_on.shape[0], dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_dqn_target_q(_lib.ptr(q_on), _lib.ptr(q_tg), _lib.i64(q_on.shape[0]),
+                                               _lib.i64(self.n_act), C.c_int(int(self.cfg.is_double)), _lib.ptr(out),
+                                               _lib.current_stream(self.device)))
+        return out
+
+    # -- DQN._preprocess_batch -----------------------------------------------------------------------
+    def preprocess(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, indices, stack_num: int,
+                   obs_next_frames: torch.Tensor | None = None) -> torch.Tensor:
+        """n-step returns float32[I] with target_q_fn = _target_q (dqn.py:257-275).  When the buffer does
+        not store obs_next, s_{t+n} is read at next(indices_after_n) (buffer_base.py:624-626)."""
+
+        def tq_fn(buf, after):
+            if obs_next_frames is None:
+                on = gather_obs_nhwc(frames, buf, buf.next(after), stack_num)
+            else:
+                on = gather_obs_nhwc(obs_next_frames, buf, after, stack_num)
+            return self.target_q(on)
+
+        class _B:
+            pass
+
+        b = compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step)
+        return b.returns.reshape(-1)
+
+    # -- DQN._update_with_batch -----------------------------------------------------------------------
+    def update_with_batch(self, obs_nhwc, act, returns, weight=None, grad_out: torch.Tensor | None = None,
+                          apply: bool = True):
+        """-> (loss float32[1] device tensor, td_error float32[B]); td_error is the new batch.weight."""
+        cfg = self.cfg
+        if apply:
+            if self.params_old is not None and self.iter % cfg.target_update_freq == 0:    # dqn.py:283-285
+                full_parameter_update(self.params_old, self.params)
+            self.iter += 1
+            self.adam_step += 1
+        b = obs_nhwc.shape[0]
+        act = _i64_dev(act, self.device).reshape(-1)
+        returns = torch.as_tensor(returns, dtype=torch.float32, device=self.device).reshape(-1).contiguous()
+        if weight is not None:
+            weight = torch.as_tensor(weight, device=self.device).to(torch.float32).reshape(-1).contiguous()
+        if act.numel() != b or returns.numel() != b or (weight is not None and weight.numel() != b):
+            raise ValueError("obs / act / returns / weight batch sizes differ")
+        td = torch.empty(b, dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        hp = cfg.to_c(grad_only=not apply)
+        _lib.check(_lib.load().ts_dqn_update(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
+            _lib.i64(max(self.adam_step, 1)), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w),
+            _lib.i64(self.n_act), _lib.ptr(obs_nhwc.contiguous()), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight),
+            _lib.i64(b), C.byref(hp), _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
+            _lib.current_stream(self.device)))
+        return loss, td
