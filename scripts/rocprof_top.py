@@ -1,0 +1,13 @@
+"""Prints the kernel-stats table of a rocprofv3 (rocpd sqlite) result: python scripts/rocprof_top.py x_results.db [csv_out]"""
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+lines = ["Name,Calls,TotalDurationNs,AverageNs,Percentage"]
+for name, calls, tot, avg, pct in rows:
+    lines.append('"%s",%d,%d,%.1f,%.2f' % (name.replace('"', "'"), calls, tot, avg, pct))
+if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write("\n".join(lines) + "\n")
+for name, calls, tot, avg, pct in rows[:40]:
+    print("%-90s %6d %10.1f us avg %6.2f%%" % (name[:90], calls, avg / 1e3 if avg > 1e4 else avg, pct))

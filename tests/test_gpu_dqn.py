@@ -196,13 +196,16 @@ def test_adam_step_vs_torch():
     ws = _lib.default_workspace(0)
     for step in range(1, 4):
         g = torch.randn(n, generator=gen) * 10 ** float(torch.randint(-6, 2, (1,), generator=gen))
-        ref.grad = g.clone()
-        torch.nn.utils.clip_grad_norm_([ref], 0.5)
+        # clip_grad_norm_ (algorithm_base.py:496-499) with the norm accumulated in float64: torch's own
+        # float32 CPU accumulation over 1.7 M elements is only good to ~2e-5, the kernel's tree to ~1e-7
+        coef = min(0.5 / (float(g.double().norm()) + 1e-6), 1.0)
+        ref.grad = g * torch.tensor(coef, dtype=torch.float32)
         opt.step()
-        _lib.check(_lib.load().ts_adam_step(ws.handle, _lib.ptr(dp), _lib.ptr(dm), _lib.ptr(dv), _lib.ptr(g.cuda()),
+        g_dev = g.cuda()
+        _lib.check(_lib.load().ts_adam_step(ws.handle, _lib.ptr(dp), _lib.ptr(dm), _lib.ptr(dv), _lib.ptr(g_dev),
                                             _lib.i64(n), _lib.i64(step), _lib.f64(1e-4), _lib.f64(0.9), _lib.f64(0.999),
                                             _lib.f64(1e-8), _lib.f64(0.5), _lib.current_stream()))
         np.testing.assert_allclose(dp.cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-9)
         st = opt.state[ref]
-        np.testing.assert_allclose(dm.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-5, atol=1e-12)
-        np.testing.assert_allclose(dv.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-20)
+        np.testing.assert_allclose(dm.cpu().numpy(), st["exp_avg"].numpy(), rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(dv.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-20)

@@ -321,21 +321,24 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
     }
 }
 
+// out[i] = sum_s slabs[s][i]: a workgroup owns 64 consecutive floats (16 float4 columns) and splits the
+// slabs over its 16 thread rows; fixed-order tree over the rows (deterministic).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab, int64_t n,
                                                        float* __restrict__ out) {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + i);
-        for (int k = 1; k < nslab; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n + i);
-        *reinterpret_cast<f32x4*>(out + i) = s;
-    } else {
-        for (int64_t j = i; j < n; ++j) {
-            float s = slabs[j];
-            for (int k = 1; k < nslab; ++k) s += slabs[(int64_t)k * n + j];
-            out[j] = s;
-        }
+    __shared__ f32x4 red[256];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)blockIdx.x * 16 + col) * 4;            // n % 4 == 0
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n)
+        for (int k = part; k < nslab; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n + i);
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 8; st > 0; st >>= 1) {
+        if (part < st) red[threadIdx.x] += red[threadIdx.x + 16 * st];
+        __syncthreads();
     }
+    if (part == 0 && i < n) *reinterpret_cast<f32x4*>(out + i) = red[col];
 }
 
 // Y[m, n] = act(sum_s buf[s][m, n] + bias[n])   (finish of a split forward)
@@ -474,7 +477,8 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
 
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out) {
     if (n <= 0) return TS_OK;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 1024)), dim3(256), 0, s, slabs, nslab, n, out);
+    TS_REQUIRE(n % 4 == 0, TS_ERR_INVALID_ARG, "slab_sum: length must be a multiple of 4");
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, s, slabs, nslab, n, out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

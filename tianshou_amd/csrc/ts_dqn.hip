@@ -134,19 +134,34 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     dh4[i] = h4[i] > 0.f ? dq[b] * wb[(int64_t)k * A + act[b]] : 0.f;
 }
 
-// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1); batch order, no atomics
+// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1).  One workgroup per k:
+// thread t owns the samples b = t (mod 256) in batch order, then a fixed-order tree per action.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
                                                          const float* __restrict__ h4, int64_t B, int A,
                                                          float* __restrict__ dwb) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (HIDDEN + 1) * A) return;
-    const int k = i / A, a = i - k * A;
-    float s = 0.f;
-    for (int64_t b = 0; b < B; ++b) {
-        const float hv = k < HIDDEN ? h4[b * HIDDEN + k] : 1.f;
-        s += act[b] == a ? hv * dq[b] : 0.f;
+    __shared__ float red[256];
+    const int k = blockIdx.x;
+    float acc[MAX_ACT];
+#pragma unroll
+    for (int a = 0; a < MAX_ACT; ++a) acc[a] = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+        const float v = (k < HIDDEN ? h4[b * HIDDEN + k] : 1.f) * dq[b];
+        const int ab = (int)act[b];
+#pragma unroll
+        for (int a = 0; a < MAX_ACT; ++a) acc[a] += a == ab ? v : 0.f;
     }
-    dwb[i] = s;
+#pragma unroll
+    for (int a = 0; a < MAX_ACT; ++a) {
+        if (a >= A) break;
+        red[threadIdx.x] = acc[a];
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) dwb[k * A + a] = red[0];
+        __syncthreads();
+    }
 }
 
 struct Scratch {           // carve of the workspace for one network pass over B samples
@@ -282,8 +297,8 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                        hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
     // head backward
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((unsigned)ts::ceil_div((HIDDEN + 1) * n.n_act, 256)), dim3(256), 0, s,
-                       dq, act, sc.h[3], B, n.n_act, grad + n.off[4]);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(HIDDEN + 1), dim3(256), 0, s, dq, act, sc.h[3], B, n.n_act,
+                       grad + n.off[4]);
     hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)ts::ceil_div(B * HIDDEN, 256)), dim3(256), 0, s, dq, act,
                        params + n.off[4], sc.h[3], B, n.n_act, dy[3]);
     TS_LAUNCH_CHECK();
