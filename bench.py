@@ -206,7 +206,17 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["ppo", "dqn"], default="ppo",
+                    help="ppo = BASELINE.json's metric (default); dqn = the C3 row, see bench_dqn.py")
     args = ap.parse_args()
+    if args.workload == "dqn":
+        import bench_dqn
+
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+        print(json.dumps(bench_dqn.run(max(args.steps, 1) * 10, max(args.warmup, 1) * 5,
+                                       with_cpu=not args.no_cpu_baseline)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -1,0 +1,160 @@
+"""C3 workload: DQN updates/s on a synthetic Atari-layout replay (2^20 slots, u8 84x84 frames,
+frame stack 4 through prev(), PER alpha 0.6 / beta 0.4, n-step 3, double-Q with a lagged net, Huber, B=512).
+
+    python bench.py --workload dqn [--steps K] [--warmup W]        (or: python bench_dqn.py)
+
+One "step" = one DQN.update(): PER sample -> frame-stack gather of s and s_{t+n} -> Q_online(s'), Q_target(s')
+-> n-step return -> Q(s), TD loss, backward, Adam -> PER priority update.  Everything device-resident.
+Prints one JSON line with the same keys as bench.py plus per-kernel-kind roofline figures.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C, H, W, N_ACT, BATCH = 4, 84, 84, 6, 512
+PEAK_F32_MFMA_TFLOPS = 157.3
+# algorithmic flop per sample: one forward 18.69 MFLOP; weight gradients the same again;
+# input gradients for every layer but conv1
+FWD_FLOP = 2 * 9_346_048
+CONV1_FLOP = 2 * 3_276_800
+FLOP_BY_KIND = {"conv_fwd": 3 * FWD_FLOP, "conv_wgrad": FWD_FLOP, "conv_dgrad": FWD_FLOP - CONV1_FLOP}
+
+
+def build(slots: int, E: int, seed: int = 0):
+    from tianshou_amd.buffer import DeviceReplayBuffer
+    from tianshou_amd.segtree import PrioritizedWeights
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    frames = torch.empty((slots, H, W), dtype=torch.uint8, device=dev)
+    step = 1 << 16
+    for lo in range(0, slots, step):
+        frames[lo:lo + step] = torch.randint(0, 256, (min(step, slots - lo), H, W), generator=g, device=dev,
+                                             dtype=torch.uint8)
+    rew = torch.randn(slots, generator=g, device=dev).double()
+    term = torch.rand(slots, generator=g, device=dev) < 0.005
+    trunc = torch.zeros(slots, dtype=torch.bool, device=dev)
+    act = torch.randint(0, N_ACT, (slots,), generator=g, device=dev)
+    T = slots // E
+    offset = np.arange(E + 1, dtype=np.int64) * T
+    buf = DeviceReplayBuffer(offset=offset, last_index=offset[:-1] + T - 1, lengths=np.full(E, T, np.int64),
+                             insertion=np.zeros(E, np.int64), rew=rew, terminated=term, truncated=trunc)
+    per = PrioritizedWeights(slots, 0.6, 0.4)
+    per.init_weight(torch.arange(slots, device=dev))
+    return frames, act, buf, per
+
+
+def torch_layers(seed: int = 0):
+    torch.manual_seed(seed)
+    return [torch.nn.Conv2d(C, 32, 8, 4), torch.nn.Conv2d(32, 64, 4, 2), torch.nn.Conv2d(64, 64, 3, 1),
+            torch.nn.Linear(3136, 512), torch.nn.Linear(512, N_ACT)]
+
+
+def cpu_baseline(updates: int = 3):
+    """The oracle's restatement of the same update (torch fp32 on the host cores): two no-grad forwards on
+    s_{t+n}, forward + backward + Adam on s; sampling / gather / n-step excluded (they favour the CPU)."""
+    from oracle import oracle_dqn as OD
+
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    p = OD.init_params(C, H, W, N_ACT, 0)
+    cfg = OD.DQNConfig(gamma=0.99, n_step=3, target_update_freq=500, is_double=True, huber_delta=1.0, lr=1e-4)
+    st = OD.DQNState.create(p, cfg)
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, size=(BATCH, C, H, W), dtype=np.uint8)
+    obs_next = rng.integers(0, 256, size=(BATCH, C, H, W), dtype=np.uint8)
+    act = rng.integers(0, N_ACT, size=BATCH)
+    ret = rng.normal(size=BATCH).astype(np.float32)
+    OD.target_q(st, cfg, obs_next)
+    OD.update_with_batch(st, cfg, obs, act, ret)
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        OD.target_q(st, cfg, obs_next)
+        OD.update_with_batch(st, cfg, obs, act, ret)
+    dt = time.perf_counter() - t0
+    return {"value": updates / dt, "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{updates} updates of B={BATCH} (2 target forwards + fwd/bwd/Adam), torch fp32 CPU oracle"}
+
+
+def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
+    from tianshou_amd import _lib
+    from tianshou_amd import dqn as D
+
+    frames, act, buf, per = build(slots, 16)
+    tensors = [t for m in torch_layers() for t in (m.weight, m.bias)]
+    cfg = D.DQNConfig(gamma=0.99, n_step=3, target_update_freq=500, is_double=True, huber_delta=1.0, lr=1e-4)
+    eng = D.DQNEngine(C, H, W, N_ACT, D.flat_from_torch(tensors, C, H, W, N_ACT), cfg)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def update():
+        u = torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws
+        idx, wt = per.sample(u)
+        ret = eng.preprocess(buf, frames, idx, C)
+        obs = D.gather_obs_nhwc(frames, buf, idx, C)
+        loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
+        per.update_weight(idx, td)
+        return loss
+
+    for _ in range(warmup):
+        update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = update()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    ws = _lib.default_workspace(0)
+    n_prof = 10
+    ws.profile_begin()
+    for _ in range(n_prof):
+        update()
+    torch.cuda.synchronize()
+    prof = ws.profile_end()
+    kinds = {}
+    for k, flop in FLOP_BY_KIND.items():
+        ms, n = prof[k]
+        tf = flop * BATCH * n_prof / (ms * 1e-3) / 1e12
+        kinds[k] = {"achieved": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_per_update": n // n_prof,
+                    "us_per_update": ms * 1e3 / n_prof, "algorithmic_flop_per_update": flop * BATCH}
+    dom = max(kinds, key=lambda k: kinds[k]["us_per_update"])
+    roof = {"bound": "mfma", "kernel": {"conv_fwd": "conv_rows_kernel<false,...> (3 forwards x 4 layers)",
+                                        "conv_wgrad": "conv_wgrad_kernel", "conv_dgrad": "conv_rows_kernel<true,...>"}[dom],
+            "achieved": kinds[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": kinds[dom]["frac"], "traffic": None,
+            "avg_launch_us": kinds[dom]["us_per_update"] / kinds[dom]["launches_per_update"]}
+    total_flop = sum(FLOP_BY_KIND.values()) * BATCH
+    out = {
+        "metric": "DQN learn() updates/sec (B=512, NatureCNN, n-step 3, PER, double-Q, Huber)",
+        "value": steps / dt, "unit": "updates/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C3 DQN Atari-shape replay: {slots} slots of u8[84,84] frames, stack 4, 6 actions, "
+                               "NatureCNN (1,687,206 params), B=512, n-step 3, PER, target sync every 500",
+                   "parallelism": "dp1"},
+        "roofline": roof, "roofline_by_kind": kinds,
+        "whole_update_mfma_frac": total_flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "cpu_baseline": cpu_baseline() if with_cpu else None, "final_loss": float(loss),
+    }
+    return out
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--slots", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.warmup, a.slots, not a.no_cpu_baseline)), flush=True)

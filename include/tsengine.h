@@ -55,7 +55,10 @@ int ts_workspace_destroy(ts_workspace* ws);
 #define TS_KIND_PPO_INFER 3  /* value / log-prob inference                    */
 #define TS_KIND_GAE_MAPS 4   /* GAE pass 1 (tile maps)                        */
 #define TS_KIND_GAE_APPLY 5  /* GAE pass 2 (carry + outputs)                  */
-#define TS_N_KINDS 6
+#define TS_KIND_CONV_FWD 6   /* conv / linear forward (implicit GEMM)           */
+#define TS_KIND_CONV_WGRAD 7 /* conv / linear weight gradient                  */
+#define TS_KIND_CONV_DGRAD 8 /* conv / linear input gradient                   */
+#define TS_N_KINDS 9
 int ts_profile_begin(ts_workspace* ws);
 int ts_profile_end(ts_workspace* ws, double* h_ms_by_kind, int64_t* h_count_by_kind, int n_kinds);
 

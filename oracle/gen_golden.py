@@ -558,6 +558,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "sac":
+        gen_sac_all()
+        return
     gen_returns_kat()
     gen_buffer_index()
     gen_segtree_per()
@@ -574,8 +577,115 @@ def main() -> None:
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
     gen_dqn_all()
+    gen_sac_all()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int,
+            seed: int, auto_alpha: bool, alpha: float = 0.2, n_step: int = 1, tau: float = 0.005,
+            gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4) -> None:
+    """Runs the reference SAC.update() (nets as in examples/mujoco/mujoco_sac.py:82-104) on a synthetic
+    VectorReplayBuffer, recording the rsample() noise of every policy call and the outputs of every update."""
+    import torch.distributions.normal as tdn
+    from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACPolicy
+    from oracle import oracle_sac as OS
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[256, 256])
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
+                                         conditioned_sigma=True)
+    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)
+    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)
+    critic1, critic2 = ContinuousCritic(preprocess_net=net_c1), ContinuousCritic(preprocess_net=net_c2)
+    space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
+    policy = SACPolicy(actor=actor, action_space=space)
+    al = AutoAlpha(float(-act_dim), 0.0, AdamOptimizerFactory(lr=alpha_lr)) if auto_alpha else alpha
+    algorithm = SAC(policy=policy, policy_optim=AdamOptimizerFactory(lr=actor_lr), critic=critic1,
+                    critic_optim=AdamOptimizerFactory(lr=critic_lr), critic2=critic2,
+                    critic2_optim=AdamOptimizerFactory(lr=critic_lr), tau=tau, gamma=gamma, alpha=al,
+                    n_step_return_horizon=n_step)
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step])
+    p0 = OS.init_sac_params(obs_dim, act_dim, seed)
+    for pd, order, mod, keys in ((p0[0], OS.ACTOR_ORDER, actor, OS.TIANSHOU_ACTOR_KEYS),
+                                 (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS),
+                                 (p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS)):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == keys, list(sd.keys())
+        for k_ref, k in zip(keys, order):       # the fixture stores the seed only: the oracle re-creates the init
+            assert torch.equal(sd[k_ref], pd[k]), f"oracle init differs from the reference at {k}"
+
+    buf = VectorReplayBuffer(E * slots, E)
+    obs = rng.normal(size=(steps + 1, E, obs_dim)).astype(np.float32)
+    act = rng.uniform(-1, 1, size=(steps, E, act_dim)).astype(np.float32)
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.05
+    trunc = (rng.random((steps, E)) < 0.03) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t],
+                      obs_next=obs[t + 1]))
+    out["obs"] = np.asarray(buf.obs, np.float32)
+    out["obs_next"] = np.asarray(buf.obs_next, np.float32)
+    out["act"] = np.asarray(buf.act, np.float32)
+    out["rew"] = np.asarray(buf.rew, np.float64)
+    out["terminated"] = np.asarray(buf.terminated, bool)
+    out["truncated"] = np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    noises: list[np.ndarray] = []
+    orig_sn = tdn._standard_normal
+
+    def rec_sn(shape, dtype, device):
+        e = orig_sn(shape, dtype, device)
+        noises.append(e.numpy().copy())
+        return e
+
+    rec: list[dict] = []
+    orig_pre = SAC._preprocess_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        rec.append({"indices": np.array(indices, np.int64), "returns": b.returns.numpy().copy().reshape(-1)})
+        return b
+
+    tdn._standard_normal = rec_sn
+    SAC._preprocess_batch = rec_pre
+    try:
+        for u in range(n_updates):
+            n0 = len(noises)
+            with policy_within_training_step(algorithm.policy):
+                stats = algorithm.update(buffer=buf, sample_size=batch)
+            assert len(noises) - n0 == 2, len(noises) - n0          # target action, actor-loss action
+            out[f"u{u}_noise_target"], out[f"u{u}_noise_actor"] = noises[n0], noises[n0 + 1]
+            out[f"u{u}_indices"], out[f"u{u}_returns"] = rec[-1]["indices"], rec[-1]["returns"]
+            out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic1_loss, stats.critic2_loss,
+                                           stats.alpha if stats.alpha is not None else np.nan,
+                                           stats.alpha_loss if stats.alpha_loss is not None else np.nan])
+            for name, mod, keys in (("actor", actor, OS.TIANSHOU_ACTOR_KEYS),
+                                    ("critic1", critic1, OS.TIANSHOU_CRITIC_KEYS),
+                                    ("critic2", critic2, OS.TIANSHOU_CRITIC_KEYS),
+                                    ("critic1_old", algorithm.critic_old.module, OS.TIANSHOU_CRITIC_KEYS),
+                                    ("critic2_old", algorithm.critic2_old.module, OS.TIANSHOU_CRITIC_KEYS)):
+                sd = mod.state_dict()
+                out[f"u{u}_{name}"] = torch.cat([sd[k].reshape(-1) for k in keys]).numpy()[::61].copy()
+    finally:
+        tdn._standard_normal = orig_sn
+        SAC._preprocess_batch = orig_pre
+    cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
+               target_entropy=float(-act_dim), log_alpha0=0.0, actor_lr=actor_lr, critic_lr=critic_lr,
+               alpha_lr=alpha_lr)
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"sac_{tag}.npz"), **out)
+
+
+def gen_sac_all() -> None:
+    gen_sac("auto", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=4, auto_alpha=True)
+    gen_sac("fixed", E=2, slots=40, steps=40, obs_dim=376, act_dim=17, batch=48, n_updates=2, seed=6,
+            auto_alpha=False, alpha=0.2, n_step=3, tau=0.01, gamma=0.97, actor_lr=3e-4)
 
 
 def gen_dqn_all() -> None:

@@ -1,0 +1,233 @@
+"""TEST INFRASTRUCTURE ONLY - CPU (torch fp32 autograd) restatement of the reference's SAC learn() path.
+
+Never imported by the product (`tianshou_amd/`).  Pinned against the UNMODIFIED reference through
+tests/golden/sac_*.npz (oracle/gen_golden.py::gen_sac), with the reference's rsample() noise recorded
+and replayed ("noise tensors host-supplied").
+
+Follows:
+  ContinuousActorProbabilistic.forward  tianshou/utils/net/continuous.py:220-238 (conditioned sigma,
+                                        unbounded; clamp(SIGMA_MIN=-20, SIGMA_MAX=2).exp(), :22-23)
+  ContinuousCritic.forward              continuous.py:144-169 (concat(obs, act) -> Net -> Linear)
+  Net / MLP (ReLU)                      utils/net/common.py:90-178, 246-369
+  SACPolicy.forward                     algorithm/modelfree/sac.py:108-131
+  correct_log_prob_gaussian_tanh        sac.py:25-39
+  SAC._target_q_compute_value           sac.py:290-296 ; td3.py:94-102 (min of the lagged critics)
+  _minimize_critic_squared_loss         ddpg.py:267-285
+  SAC._update_with_batch                sac.py:298-336
+  AutoAlpha.update                      sac.py:203-209
+  polyak_parameter_update               utils/lagged_network.py:8-18
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.distributions import Independent, Normal
+
+ACTOR_ORDER = ["w1", "b1", "w2", "b2", "wmu", "bmu", "wsig", "bsig"]
+CRITIC_ORDER = ["w1", "b1", "w2", "b2", "wq", "bq"]
+TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                       "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                       "mu.model.0.weight", "mu.model.0.bias", "sigma.model.0.weight", "sigma.model.0.bias"]
+TIANSHOU_CRITIC_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                        "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                        "last.model.0.weight", "last.model.0.bias"]
+SIGMA_MIN, SIGMA_MAX = -20.0, 2.0
+TANH_EPS = float(np.finfo(np.float32).eps)
+
+
+def actor_shapes(obs_dim: int, act_dim: int, hidden: int = 256):
+    return {"w1": (hidden, obs_dim), "b1": (hidden,), "w2": (hidden, hidden), "b2": (hidden,),
+            "wmu": (act_dim, hidden), "bmu": (act_dim,), "wsig": (act_dim, hidden), "bsig": (act_dim,)}
+
+
+def critic_shapes(obs_dim: int, act_dim: int, hidden: int = 256):
+    return {"w1": (hidden, obs_dim + act_dim), "b1": (hidden,), "w2": (hidden, hidden), "b2": (hidden,),
+            "wq": (1, hidden), "bq": (1,)}
+
+
+def init_params(shapes: dict, seed: int) -> dict[str, torch.Tensor]:
+    """torch.nn.Linear default init for every (w, b) pair, in order."""
+    torch.manual_seed(seed)
+    p = {}
+    names = list(shapes)
+    for wn, bn in zip(names[0::2], names[1::2]):
+        lin = torch.nn.Linear(shapes[wn][1], shapes[wn][0])
+        p[wn], p[bn] = lin.weight.detach().clone(), lin.bias.detach().clone()
+    return p
+
+
+def init_sac_params(obs_dim: int, act_dim: int, seed: int, hidden: int = 256):
+    """Same RNG consumption as examples/mujoco/mujoco_sac.py:82-104 after torch.manual_seed(seed):
+    Net(actor), actor mu / sigma heads, Net(critic1), Net(critic2), critic1.last, critic2.last
+    -> (actor, critic1, critic2) parameter dicts."""
+    torch.manual_seed(seed)
+    L = torch.nn.Linear
+    mods = [L(obs_dim, hidden), L(hidden, hidden), L(hidden, act_dim), L(hidden, act_dim),
+            L(obs_dim + act_dim, hidden), L(hidden, hidden), L(obs_dim + act_dim, hidden), L(hidden, hidden),
+            L(hidden, 1), L(hidden, 1)]
+    wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
+    flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
+    actor = dict(zip(ACTOR_ORDER, flat(mods[0:4])))
+    critic1 = dict(zip(CRITIC_ORDER, flat([mods[4], mods[5], mods[8]])))
+    critic2 = dict(zip(CRITIC_ORDER, flat([mods[6], mods[7], mods[9]])))
+    return actor, critic1, critic2
+
+
+def flatten(p: dict, order: list[str]) -> torch.Tensor:
+    return torch.cat([p[k].reshape(-1) for k in order])
+
+
+def actor_forward(p, obs):
+    h = F.relu(F.linear(obs, p["w1"], p["b1"]))
+    h = F.relu(F.linear(h, p["w2"], p["b2"]))
+    mu = F.linear(h, p["wmu"], p["bmu"])
+    sigma = torch.clamp(F.linear(h, p["wsig"], p["bsig"]), min=SIGMA_MIN, max=SIGMA_MAX).exp()
+    return mu, sigma
+
+
+def critic_forward(p, obs, act):
+    x = torch.cat([obs.flatten(1), act.flatten(1)], dim=1)
+    h = F.relu(F.linear(x, p["w1"], p["b1"]))
+    h = F.relu(F.linear(h, p["w2"], p["b2"]))
+    return F.linear(h, p["wq"], p["bq"])
+
+
+def policy_forward(p, obs, noise):
+    """SACPolicy.forward in training mode with rsample() = loc + noise * scale (sac.py:108-131)
+    -> (squashed action [B, A], log_prob [B, 1], mu, sigma)."""
+    mu, sigma = actor_forward(p, obs)
+    dist = Independent(Normal(loc=mu, scale=sigma), 1)
+    act = mu + noise * sigma                                   # Normal.rsample
+    log_prob = dist.log_prob(act).unsqueeze(-1)
+    squashed = torch.tanh(act)
+    log_prob = log_prob - torch.log(1 - squashed.pow(2) + TANH_EPS).sum(-1, keepdim=True)
+    return squashed, log_prob, mu, sigma
+
+
+@dataclass
+class SACConfig:
+    gamma: float = 0.99
+    tau: float = 0.005
+    n_step: int = 1
+    alpha: float = 0.2                  # used when auto_alpha is False
+    auto_alpha: bool = False
+    target_entropy: float = 0.0
+    log_alpha0: float = 0.0
+    actor_lr: float = 1e-3
+    critic_lr: float = 1e-3
+    alpha_lr: float = 3e-4
+    betas: tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+
+
+@dataclass
+class Adam:
+    lr: float
+    betas: tuple[float, float]
+    eps: float
+    m: dict = field(default_factory=dict)
+    v: dict = field(default_factory=dict)
+    step: int = 0
+
+    def apply(self, params: dict, grads: dict) -> dict:
+        """torch.optim.Adam single-tensor arithmetic (optim.py:89-110 -> torch/optim/adam.py)."""
+        self.step += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.step, 1 - b2 ** self.step
+        out = {}
+        for k, g in grads.items():
+            m = self.m.setdefault(k, torch.zeros_like(g))
+            v = self.v.setdefault(k, torch.zeros_like(g))
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            denom = (v.sqrt() / np.sqrt(bc2)).add_(self.eps)
+            out[k] = params[k].addcdiv(m, denom, value=-(self.lr / bc1))
+        return out
+
+
+@dataclass
+class SACState:
+    actor: dict
+    critic1: dict
+    critic2: dict
+    critic1_old: dict
+    critic2_old: dict
+    log_alpha: torch.Tensor
+    opt_actor: Adam
+    opt_c1: Adam
+    opt_c2: Adam
+    opt_alpha: Adam
+
+    @classmethod
+    def create(cls, actor, critic1, critic2, cfg: SACConfig):
+        cp = lambda d: {k: v.clone() for k, v in d.items()}  # noqa: E731
+        mk = lambda lr: Adam(lr, cfg.betas, cfg.adam_eps)    # noqa: E731
+        return cls(cp(actor), cp(critic1), cp(critic2), cp(critic1), cp(critic2),
+                   torch.tensor(cfg.log_alpha0 if cfg.auto_alpha else float(np.log(cfg.alpha))),
+                   mk(cfg.actor_lr), mk(cfg.critic_lr), mk(cfg.critic_lr), mk(cfg.alpha_lr))
+
+
+def alpha_value(st: SACState, cfg: SACConfig) -> float:
+    return float(st.log_alpha.detach().exp().item()) if cfg.auto_alpha else cfg.alpha     # sac.py:199-201
+
+
+def target_q(st: SACState, cfg: SACConfig, obs_next, noise) -> torch.Tensor:
+    """ddpg.py:327-339 + sac.py:290-296 -> [B, 1]."""
+    with torch.no_grad():
+        act, logp, _, _ = policy_forward(st.actor, obs_next, noise)
+        q = torch.min(critic_forward(st.critic1_old, obs_next, act), critic_forward(st.critic2_old, obs_next, act))
+        return q - alpha_value(st, cfg) * logp
+
+
+def _grads(loss, p: dict) -> dict:
+    gs = torch.autograd.grad(loss, list(p.values()))
+    return dict(zip(p.keys(), gs))
+
+
+def update_with_batch(st: SACState, cfg: SACConfig, obs, act, returns, noise, weight=None, collect=None):
+    """sac.py:298-336 -> dict(actor_loss, critic1_loss, critic2_loss, alpha, alpha_loss, weight)."""
+    obs = torch.as_tensor(obs, dtype=torch.float32)
+    act = torch.as_tensor(act, dtype=torch.float32)
+    ret = torch.as_tensor(returns, dtype=torch.float32).flatten()
+    noise = torch.as_tensor(noise, dtype=torch.float32)
+    w = 1.0 if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+    out = {}
+    tds = []
+    for name, opt in (("critic1", st.opt_c1), ("critic2", st.opt_c2)):        # ddpg.py:279-285
+        p = {k: v.clone().requires_grad_(True) for k, v in getattr(st, name).items()}
+        td = critic_forward(p, obs, act).flatten() - ret
+        loss = (td.pow(2) * w).mean()
+        g = _grads(loss, p)
+        if collect is not None:
+            collect[name + "_grads"] = g
+        setattr(st, name, opt.apply(getattr(st, name), g))
+        tds.append(td.detach())
+        out[name + "_loss"] = float(loss.item())
+    out["weight"] = (tds[0] + tds[1]) / 2.0                                       # sac.py:306
+    alpha = alpha_value(st, cfg)
+    p = {k: v.clone().requires_grad_(True) for k, v in st.actor.items()}
+    a, logp, _, _ = policy_forward(p, obs, noise)
+    q1a = critic_forward(st.critic1, obs, a).flatten()
+    q2a = critic_forward(st.critic2, obs, a).flatten()
+    actor_loss = (alpha * logp.flatten() - torch.min(q1a, q2a)).mean()
+    g = _grads(actor_loss, p)
+    if collect is not None:
+        collect["actor_grads"] = g
+    st.actor = st.opt_actor.apply(st.actor, g)
+    out["actor_loss"] = float(actor_loss.item())
+    out["alpha_loss"] = None
+    if cfg.auto_alpha:                                                            # sac.py:203-209
+        entropy = -logp.detach()
+        la = st.log_alpha.clone().requires_grad_(True)
+        alpha_loss = -(la * (cfg.target_entropy - entropy)).mean()
+        (ga,) = torch.autograd.grad(alpha_loss, [la])
+        st.log_alpha = st.opt_alpha.apply({"a": st.log_alpha}, {"a": ga})["a"]
+        out["alpha_loss"] = float(alpha_loss.item())
+    for old, new in ((st.critic1_old, st.critic1), (st.critic2_old, st.critic2)):  # lagged_network.py:17-18
+        for k in old:
+            old[k] = cfg.tau * new[k] + (1 - cfg.tau) * old[k]
+    out["alpha"] = alpha_value(st, cfg)
+    return out

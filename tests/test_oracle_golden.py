@@ -258,3 +258,51 @@ def test_dqn_restatement_matches_reference(tag):
             # summation order with the thread count)
             np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-4)
             np.testing.assert_allclose([mn, mx], g[f"u{u}_prio_minmax"], rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ SAC path
+def load_sac(tag):
+    from oracle import oracle_sac as OS
+
+    g = load(f"sac_{tag}.npz")
+    E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, auto, n_step = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OS.SACConfig(gamma=c["gamma"], tau=c["tau"], n_step=int(c["n_step"]), alpha=c["alpha"],
+                       auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
+                       log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                       alpha_lr=c["alpha_lr"])
+    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed)
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, d, cfg, bstate
+
+
+@pytest.mark.parametrize("tag", ["auto", "fixed"])
+def test_sac_restatement_matches_reference(tag):
+    """oracle_sac (tanh-Gaussian policy, twin lagged critics, n-step target, three Adam steps, auto alpha,
+    Polyak) against the unmodified reference SAC.update() with its rsample() noise replayed."""
+    from oracle import oracle_sac as OS
+
+    g, d, cfg, bstate = load_sac(tag)
+    actor, c1, c2 = OS.init_sac_params(d["obs_dim"], d["act_dim"], d["seed"])
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+
+        def tq_fn(after):
+            return OS.target_q(st, cfg, obs_next_all[after], torch.as_tensor(g[f"u{u}_noise_target"])).numpy()
+
+        ret, _ = O.compute_nstep_return(bstate, idx, tq_fn, cfg.gamma, cfg.n_step)
+        ret = ret.astype(np.float32).reshape(-1)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-5, atol=1e-5)
+        out = OS.update_with_batch(st, cfg, obs_all[idx], g["act"][idx], ret, g[f"u{u}_noise_actor"])
+        ref = g[f"u{u}_stats"]
+        np.testing.assert_allclose([out["actor_loss"], out["critic1_loss"], out["critic2_loss"]], ref[:3], rtol=1e-5)
+        np.testing.assert_allclose(out["alpha"], ref[3], rtol=1e-6)
+        if cfg.auto_alpha:
+            np.testing.assert_allclose(out["alpha_loss"], ref[4], rtol=1e-5, atol=1e-6)
+        for name, order in (("actor", OS.ACTOR_ORDER), ("critic1", OS.CRITIC_ORDER), ("critic2", OS.CRITIC_ORDER),
+                            ("critic1_old", OS.CRITIC_ORDER), ("critic2_old", OS.CRITIC_ORDER)):
+            flat = OS.flatten(getattr(st, name), order).numpy()
+            np.testing.assert_allclose(flat[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)

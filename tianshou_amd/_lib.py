@@ -52,7 +52,8 @@ class PPOHParams(C.Structure):
 
 
 _lib = None
-KERNEL_KINDS = ("ppo_step", "ppo_reduce", "ppo_adam", "ppo_infer", "gae_maps", "gae_apply")
+KERNEL_KINDS = ("ppo_step", "ppo_reduce", "ppo_adam", "ppo_infer", "gae_maps", "gae_apply",
+                "conv_fwd", "conv_wgrad", "conv_dgrad")
 
 
 def declared_symbols() -> list[str]:

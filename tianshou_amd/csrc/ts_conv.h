@@ -9,6 +9,8 @@
 #include <cstddef>
 #include <cstdint>
 
+struct ts_workspace;
+
 namespace ts {
 
 struct ConvGeom {
@@ -25,12 +27,13 @@ int conv_wgrad_splits(const ConvGeom& g);
 
 // Y = act(X (*) W + b).  `split_buf` (conv_fwd_splits(g) * out_elems floats) is needed when splits > 1.
 int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
-                 float* split_buf);
+                 float* split_buf, ts_workspace* prof = nullptr);
 // slabs[s][(K+1)*OC] = partial d(loss)/d(Wb) over the s-th share of the output pixels.
-int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs);
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
+               ts_workspace* prof = nullptr);
 // dX = (dY (*)^T W) * (mask > 0); mask = the layer input as produced by the previous ReLU (or null).
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
-               float* dX);
+               float* dX, ts_workspace* prof = nullptr);
 // out[i] = sum_s slabs[s][i]
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
 

@@ -402,7 +402,7 @@ int conv_wgrad_splits(const ConvGeom& g) {
 }
 
 int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
-                 float* split_buf) {
+                 float* split_buf, ts_workspace* prof) {
     if (int rc = check_geom(g)) return rc;
     GemmArgs a = base_args(g);
     a.A = X; a.Bm = Wb; a.bias = Wb + (int64_t)a.K * g.OC; a.relu = relu;
@@ -415,12 +415,15 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
     } else {
         a.C = Y; a.slab_stride = 0;
     }
-    if (g.OC % 64 == 0) {
-        dim3 grid((unsigned)ceil_div(a.M, 128), g.OC / 64, nsplit);
-        hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
-    } else {
-        dim3 grid((unsigned)ceil_div(a.M, 256), g.OC / 32, nsplit);
-        hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+    {
+        ProfScope scope(prof, TS_KIND_CONV_FWD, s);
+        if (g.OC % 64 == 0) {
+            dim3 grid((unsigned)ceil_div(a.M, 128), g.OC / 64, nsplit);
+            hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+        } else {
+            dim3 grid((unsigned)ceil_div(a.M, 256), g.OC / 32, nsplit);
+            hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+        }
     }
     TS_LAUNCH_CHECK();
     if (nsplit > 1) {
@@ -432,7 +435,8 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
     return TS_OK;
 }
 
-int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs) {
+int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
+               ts_workspace* prof) {
     if (int rc = check_geom(g)) return rc;
     GemmArgs a = base_args(g);
     a.A = X; a.Bm = dY; a.C = slabs;
@@ -440,6 +444,7 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
     const int nsplit = conv_wgrad_splits(g);
     a.chunks = (int)ceil_div(a.total_chunks, nsplit);
     a.slab_stride = g.param_elems();
+    ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
     if (g.OC % 64 == 0) {
         dim3 grid((unsigned)ceil_div(a.K, 128), g.OC / 64, nsplit);
         hipLaunchKernelGGL((conv_wgrad_kernel<2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
@@ -452,7 +457,7 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
 }
 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
-               float* dX) {
+               float* dX, ts_workspace* prof) {
     if (int rc = check_geom(g)) return rc;
     TS_REQUIRE(g.KH % g.S == 0 && g.KW % g.S == 0, TS_ERR_INVALID_ARG,
                "conv_dgrad: kernel size must be a multiple of the stride");
@@ -464,6 +469,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
     a.M = g.B * a.AH * a.AW;
     a.total_chunks = a.JH * a.JW * g.OC / BK;
     a.chunks = a.total_chunks;
+    ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
     if (g.IC % 64 == 0) {
         dim3 grid((unsigned)ceil_div(a.M, 128), g.IC / 64, g.S * g.S);
         hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);

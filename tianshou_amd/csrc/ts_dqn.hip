@@ -197,11 +197,11 @@ char* carve_fwd(const Net& n, int64_t B, char* p, Scratch* sc) {
     return p + align_up(sp);
 }
 
-int net_forward(hipStream_t s, const Net& n, const float* params, const float* obs, int64_t B, const Scratch& sc,
-                float* q_out, int64_t* act_out) {
+int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const float* obs, int64_t B,
+                const Scratch& sc, float* q_out, int64_t* act_out) {
     const float* x = obs;
     for (int i = 0; i < 4; ++i) {
-        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], sc.h[i], true, sc.split)) return rc;
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], sc.h[i], true, sc.split, ws)) return rc;
         x = sc.h[i];
     }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, sc.h[3],
@@ -246,7 +246,7 @@ int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, 
     if (int rc = ts::ws_reserve(ws, fwd_scratch_bytes(n, B))) return rc;
     Scratch sc;
     carve_fwd(n, B, static_cast<char*>(ws->base), &sc);
-    return net_forward(ts::as_stream(stream), n, params, obs_nhwc, B, sc, q_out, act_out);
+    return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, B, sc, q_out, act_out);
 }
 
 int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
@@ -292,7 +292,7 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     if (grad_out) grad = grad_out;
 
     // forward (keeps the activations), loss
-    if (int rc = net_forward(s, n, params, obs_nhwc, B, sc, sc.q, nullptr)) return rc;
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, B, sc, sc.q, nullptr)) return rc;
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
                        hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
@@ -305,11 +305,11 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     // fc1, conv3, conv2, conv1
     for (int i = 3; i >= 0; --i) {
         const float* x = i == 0 ? obs_nhwc : sc.h[i - 1];
-        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs)) return rc;
+        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws)) return rc;
         if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
             return rc;
         if (i > 0)
-            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1])) return rc;
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1], ws)) return rc;
     }
     if (hp->lr < 0.f) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
