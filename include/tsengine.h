@@ -380,6 +380,63 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
                   float* loss_out, float* grad_out, ts_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SAC (tanh-Gaussian actor with state-conditioned sigma, twin critics on concat(obs, act), hidden [256, 256])
+ * nets as in examples/mujoco/mujoco_sac.py:82-104
+ * ------------------------------------------------------------------------------------------- */
+
+/* Flat parameter vectors (wb matrices as in ts_conv_forward, 1x1 case, back to back):
+ *   actor  : L1 [ka + 1, 256] | L2 [257, 256] | head [257, 64]   head columns [0, A) = mu, [32, 32 + A) = the
+ *            pre-clamp log-sigma (ContinuousActorProbabilistic.mu / .sigma, continuous.py:205-213)
+ *   critic : L1 [kc + 1, 256] | L2 [257, 256] | head [257, 32]   head column 0 = Q (ContinuousCritic.last)
+ * with ka = obs_dim and kc = obs_dim + act_dim rounded up to a multiple of 32; padding rows / columns are zero
+ * and stay zero.  h_out8 = {ka, kc, actor count, critic count, actor L2 offset, actor head offset,
+ * critic L2 offset, critic head offset}.  act_dim <= 32. */
+int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8);
+
+/* SACPolicy.forward (sac.py:108-131) with rsample() = loc + noise * scale; noise NULL = dist.mode
+ * (deterministic_eval).  act_out (nullable) float32[B, act_dim] = tanh-squashed action, logp_out float32[B]
+ * (correct_log_prob_gaussian_tanh, sac.py:25-39); aux_out (nullable) float32[B, 3, act_dim] =
+ * {a - mu, sigma, squashed}. */
+int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs, const float* noise, int64_t B,
+                          int64_t obs_dim, int64_t act_dim, float* act_out, float* logp_out, float* aux_out,
+                          ts_stream_t stream);
+
+/* ActorCriticOffPolicyAlgorithm._target_q + SAC._target_q_compute_value (ddpg.py:327-339, td3.py:94-102,
+ * sac.py:290-296): a' ~ pi(s') with `noise`, min(Q1_old, Q2_old)(s', a') - alpha * log_prob -> out float32[B].
+ * alpha = exp(*log_alpha) when log_alpha (device float32[1]) is given, else fixed_alpha. */
+int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                    const float* log_alpha, double fixed_alpha, const float* obs_next, const float* noise, int64_t B,
+                    int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream);
+
+typedef struct ts_sac_state {  /* device pointers, all float32 */
+    float *actor, *actor_m, *actor_v;
+    float *critic1, *critic1_m, *critic1_v;
+    float *critic2, *critic2_m, *critic2_v;
+    float *critic1_old, *critic2_old;
+    float *log_alpha, *log_alpha_m, *log_alpha_v; /* [1] each; used when auto_alpha */
+} ts_sac_state;
+
+typedef struct ts_sac_hparams {
+    double actor_lr, critic_lr, alpha_lr; /* a negative lr skips that optimizer step (gradient only) */
+    double beta1, beta2, adam_eps;
+    double tau;            /* Polyak coefficient (lagged_network.py:17-18); <= 0 skips the target update */
+    double alpha;          /* fixed entropy coefficient when !auto_alpha */
+    double target_entropy; /* AutoAlpha (sac.py:184-209) */
+    int32_t auto_alpha, reserved;
+} ts_sac_hparams;
+
+/* SAC._update_with_batch (sac.py:298-336): critic 1 and 2 steps (ddpg.py:279-285), actor step with the updated
+ * critics, AutoAlpha.update, Polyak update of both lagged critics.  adam_step = 1-based step of this call (all
+ * optimizers advance together).  noise float32[B, act_dim] = the rsample() draws of the actor-loss policy call.
+ * stats_out5 float32[5] = {actor_loss, critic1_loss, critic2_loss, alpha (after the update), alpha_loss};
+ * weight_out (nullable) float32[B] = (td1 + td2) / 2, the new PER weights (sac.py:306);
+ * grads_out (nullable) = the three flat gradients {critic1, critic2, actor}. */
+int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                  const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                  int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
+                  ts_stream_t stream);
+
 /* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
  * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
  * the stream. */

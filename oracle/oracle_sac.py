@@ -231,3 +231,24 @@ def update_with_batch(st: SACState, cfg: SACConfig, obs, act, returns, noise, we
             old[k] = cfg.tau * new[k] + (1 - cfg.tau) * old[k]
     out["alpha"] = alpha_value(st, cfg)
     return out
+
+
+def gradients(actor, critic1, critic2, alpha: float, obs, act, returns, noise, weight=None, dtype=torch.float32):
+    """The three loss gradients of one update with the critics held fixed (what update_with_batch computes when
+    every learning rate is 0), evaluated in `dtype` -- float64 gives the yardstick for float32 rounding noise."""
+    cast = lambda d: {k: v.to(dtype).clone().requires_grad_(True) for k, v in d.items()}  # noqa: E731
+    t = lambda x: torch.as_tensor(x).to(dtype)                                             # noqa: E731
+    obs, act, ret, noise = t(obs), t(act), t(returns).flatten(), t(noise)
+    w = 1.0 if weight is None else t(weight)
+    out = {}
+    for name, p in (("critic1", cast(critic1)), ("critic2", cast(critic2))):
+        td = critic_forward(p, obs, act).flatten() - ret
+        out[name + "_grads"] = _grads((td.pow(2) * w).mean(), p)
+    p = cast(actor)
+    a, logp, _, _ = policy_forward(p, obs, noise)
+    c1 = {k: v.to(dtype) for k, v in critic1.items()}
+    c2 = {k: v.to(dtype) for k, v in critic2.items()}
+    loss = (alpha * logp.flatten() - torch.min(critic_forward(c1, obs, a).flatten(),
+                                               critic_forward(c2, obs, a).flatten())).mean()
+    out["actor_grads"] = _grads(loss, p)
+    return out

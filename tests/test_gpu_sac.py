@@ -1,0 +1,136 @@
+"""GPU parity of the SAC row: tanh-Gaussian policy, twin lagged critics, n-step target,
+three Adam steps, auto alpha, Polyak -- through the C ABI, against the oracle (oracle/oracle_sac.py, pinned to
+the reference by tests/golden/sac_*.npz).  Tolerance 1e-5 relative on each tensor's scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle import oracle_sac as OS
+from tests.test_oracle_golden import load_sac
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_engine(obs_dim, act_dim, seed, cfg):
+    from tianshou_amd import sac as S
+
+    actor, c1, c2 = OS.init_sac_params(obs_dim, act_dim, seed)
+    eng = S.SACEngine(
+        obs_dim, act_dim,
+        S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim),
+        S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
+        S.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
+        S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
+                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}))
+    return eng, (actor, c1, c2)
+
+
+@pytest.mark.parametrize("obs_dim,act_dim", [(376, 17), (23, 5), (32, 32), (7, 1)])
+def test_layout_round_trip(obs_dim, act_dim):
+    from tianshou_amd import sac as S
+
+    actor, c1, _ = OS.init_sac_params(obs_dim, act_dim, 1)
+    fa = S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim)
+    fc = S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim)
+    for a, k in zip(S.actor_flat_to_torch(fa, obs_dim, act_dim), OS.ACTOR_ORDER):
+        assert torch.equal(a.cpu(), actor[k]), k
+    for a, k in zip(S.critic_flat_to_torch(fc, obs_dim, act_dim), OS.CRITIC_ORDER):
+        assert torch.equal(a.cpu(), c1[k]), k
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(376, 17, 300), (23, 5, 64), (7, 1, 33)])
+def test_policy_and_target_q_vs_oracle(obs_dim, act_dim, B):
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.7, target_entropy=-float(act_dim))
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 3, cfg)
+    g = torch.Generator().manual_seed(B)
+    obs = torch.randn(B, obs_dim, generator=g)
+    noise = torch.randn(B, act_dim, generator=g)
+    act_ref, logp_ref, _, _ = OS.policy_forward(actor, obs, noise)
+    act, logp = eng.policy_forward(obs.cuda(), noise.cuda())
+    assert rel_err(act.cpu(), act_ref) < 1e-5
+    np.testing.assert_allclose(logp.cpu().numpy(), logp_ref.numpy(), rtol=1e-5, atol=1e-5 * act_dim)
+    act_det, _ = eng.policy_forward(obs.cuda(), None)                  # dist.mode: tanh(mu)
+    mu, _ = OS.actor_forward(actor, obs)
+    assert rel_err(act_det.cpu(), torch.tanh(mu)) < 1e-5
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    tq_ref = OS.target_q(st, cfg, obs, noise).flatten()
+    tq = eng.target_q(obs.cuda(), noise.cuda())
+    np.testing.assert_allclose(tq.cpu().numpy(), tq_ref.numpy(), rtol=1e-5, atol=1e-5 * act_dim)
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B,auto,weighted", [(376, 17, 4096, True, False), (23, 5, 200, False, True)])
+def test_update_gradients_vs_oracle(obs_dim, act_dim, B, auto, weighted):
+    """All three gradients of one SAC update (learning rates 0, so the actor phase sees the same critics)."""
+    from tianshou_amd import sac as S
+
+    cfg = OS.SACConfig(auto_alpha=auto, log_alpha0=-0.3, alpha=0.15, target_entropy=-float(act_dim),
+                       actor_lr=0.0, critic_lr=0.0, alpha_lr=0.0, tau=0.0)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 5, cfg)
+    g = torch.Generator().manual_seed(7)
+    obs = torch.randn(B, obs_dim, generator=g)
+    act = torch.rand(B, act_dim, generator=g) * 2 - 1
+    ret = torch.randn(B, generator=g) * 2
+    noise = torch.randn(B, act_dim, generator=g)
+    weight = torch.rand(B, generator=g) if weighted else None
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    col: dict = {}
+    ref = OS.update_with_batch(st, cfg, obs, act, ret, noise, weight, collect=col)
+    lay = eng.lay
+    grads = torch.empty(2 * lay["critic_count"] + lay["actor_count"], dtype=torch.float32, device="cuda")
+    stats, w_out = eng.update_with_batch(obs, act, ret, noise, weight, grads_out=grads)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[:3], [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=1e-5)
+    np.testing.assert_allclose(w_out.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+    # yardstick: the same gradients in float64.  The engine must be within 1e-5 of them, or -- where the sum
+    # over the batch cancels heavily (policy-gradient terms) and float32 itself is noisier than that -- at least
+    # as close as the reference's own float32 evaluation.
+    g64 = OS.gradients(actor, c1, c2, OS.alpha_value(st, cfg), obs, act, ret, noise, weight, dtype=torch.float64)
+    pc = lay["critic_count"]
+    got = {"critic1": S.critic_flat_to_torch(grads[:pc], obs_dim, act_dim),
+           "critic2": S.critic_flat_to_torch(grads[pc:2 * pc], obs_dim, act_dim),
+           "actor": S.actor_flat_to_torch(grads[2 * pc:], obs_dim, act_dim)}
+    for name, order in (("critic1", OS.CRITIC_ORDER), ("critic2", OS.CRITIC_ORDER), ("actor", OS.ACTOR_ORDER)):
+        for t, key in zip(got[name], order):
+            exact = g64[name + "_grads"][key]
+            e_gpu = rel_err(t.cpu(), exact)
+            e_ref = rel_err(col[name + "_grads"][key], exact)
+            assert e_gpu < max(1e-5, 2 * e_ref), (name, key, e_gpu, e_ref)
+    # zero padding of the internal layout must receive exactly zero gradient
+    l1 = grads[:lay["critic_l2"]].reshape(lay["kc"] + 1, 256)
+    assert torch.count_nonzero(l1[obs_dim + act_dim:lay["kc"]]) == 0
+
+
+@pytest.mark.parametrize("tag", ["auto", "fixed"])
+def test_sac_update_matches_reference_golden(tag):
+    from tianshou_amd import sac as S
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, cfg, bstate = load_sac(tag)
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg)
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
+    for u in range(d["n_updates"]):
+        idx = torch.as_tensor(g[f"u{u}_indices"]).cuda()
+        ret = eng.preprocess(buf, idx, g[f"u{u}_noise_target"])
+        np.testing.assert_allclose(ret.cpu().numpy(), g[f"u{u}_returns"], rtol=1e-5, atol=2e-5)
+        stats, _ = eng.update_with_batch(buf.obs[idx], buf.act[idx], ret, g[f"u{u}_noise_actor"])
+        s, ref = stats.cpu().numpy(), g[f"u{u}_stats"]
+        np.testing.assert_allclose(s[:3], ref[:3], rtol=2e-5)
+        np.testing.assert_allclose(s[3], ref[3], rtol=1e-5)
+        if cfg.auto_alpha:
+            np.testing.assert_allclose(s[4], ref[4], rtol=1e-5, atol=1e-6)
+        for name, to_torch in (("actor", S.actor_flat_to_torch), ("critic1", S.critic_flat_to_torch),
+                               ("critic2", S.critic_flat_to_torch), ("critic1_old", S.critic_flat_to_torch),
+                               ("critic2_old", S.critic_flat_to_torch)):
+            flat = torch.cat([t.reshape(-1) for t in to_torch(getattr(eng, name), d["obs_dim"], d["act_dim"])])
+            lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
+            # Adam's first steps move every weight by ~lr whatever its gradient: compare on lr's scale
+            np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
+                                       err_msg=name)

@@ -33,7 +33,8 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
                ts_workspace* prof = nullptr);
 // dX = (dY (*)^T W) * (mask > 0); mask = the layer input as produced by the previous ReLU (or null).
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
-               float* dX, ts_workspace* prof = nullptr);
+               float* dX, ts_workspace* prof = nullptr, int col_begin = 0, int col_end = -1);
+// (col_begin, col_end): only the input-channel tiles covering [col_begin, col_end) are computed.
 // out[i] = sum_s slabs[s][i]
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
 

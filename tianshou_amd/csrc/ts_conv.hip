@@ -38,6 +38,7 @@ struct GemmArgs {
     int chunks;           // reduction chunks per split
     int total_chunks;
     int AH, AW, JH, JW;   // dgrad: per-class output grid and taps per class
+    int n_tile0;          // dgrad: first column tile of this launch
     int64_t slab_stride;
 };
 
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
     const ts::ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * BM, n0 = (blockIdx.y + (DG ? a.n_tile0 : 0)) * BN;
     int ph = 0, pw = 0, split = 0;
     if (DG) { ph = blockIdx.z / g.S; pw = blockIdx.z % g.S; } else { split = blockIdx.z; }
 
@@ -376,6 +377,12 @@ GemmArgs base_args(const ts::ConvGeom& g) {
 
 constexpr int TARGET_WGS = 768;    // 256 CUs x ~3 workgroups
 
+// halve the row tile when the full-size tiling would leave CUs without a workgroup
+bool small_rows(int M, int bn, int other_tiles) {
+    const int bm = bn == 64 ? 128 : 256;
+    return ts::ceil_div(M, bm) * other_tiles < 256;
+}
+
 }  // namespace
 
 namespace ts {
@@ -417,13 +424,14 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
     }
     {
         ProfScope scope(prof, TS_KIND_CONV_FWD, s);
-        if (g.OC % 64 == 0) {
-            dim3 grid((unsigned)ceil_div(a.M, 128), g.OC / 64, nsplit);
-            hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
-        } else {
-            dim3 grid((unsigned)ceil_div(a.M, 256), g.OC / 32, nsplit);
-            hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
-        }
+        const int bn = g.OC % 64 == 0 ? 64 : 32;
+        const bool small = small_rows(a.M, bn, g.OC / bn * nsplit);
+        const int bm = (bn == 64 ? 128 : 256) / (small ? 2 : 1);
+        dim3 grid((unsigned)ceil_div(a.M, bm), g.OC / bn, nsplit);
+        if (bn == 64 && !small) hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+        else if (bn == 64) hipLaunchKernelGGL((conv_rows_kernel<false, 1, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+        else if (!small) hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+        else hipLaunchKernelGGL((conv_rows_kernel<false, 1, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
     }
     TS_LAUNCH_CHECK();
     if (nsplit > 1) {
@@ -457,7 +465,7 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
 }
 
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
-               float* dX, ts_workspace* prof) {
+               float* dX, ts_workspace* prof, int col_begin, int col_end) {
     if (int rc = check_geom(g)) return rc;
     TS_REQUIRE(g.KH % g.S == 0 && g.KW % g.S == 0, TS_ERR_INVALID_ARG,
                "conv_dgrad: kernel size must be a multiple of the stride");
@@ -469,14 +477,20 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
     a.M = g.B * a.AH * a.AW;
     a.total_chunks = a.JH * a.JW * g.OC / BK;
     a.chunks = a.total_chunks;
+    if (col_end < 0) col_end = g.IC;
+    TS_REQUIRE(0 <= col_begin && col_begin < col_end && col_end <= g.IC, TS_ERR_INVALID_ARG,
+               "conv_dgrad: bad column range");
     ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
-    if (g.IC % 64 == 0) {
-        dim3 grid((unsigned)ceil_div(a.M, 128), g.IC / 64, g.S * g.S);
-        hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
-    } else {
-        dim3 grid((unsigned)ceil_div(a.M, 256), g.IC / 32, g.S * g.S);
-        hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
-    }
+    const int bn = g.IC % 64 == 0 ? 64 : 32;
+    a.n_tile0 = col_begin / bn;
+    const int n_tiles = (int)ceil_div(col_end, bn) - a.n_tile0;
+    const bool small = small_rows(a.M, bn, n_tiles * g.S * g.S);
+    const int bm = (bn == 64 ? 128 : 256) / (small ? 2 : 1);
+    dim3 grid((unsigned)ceil_div(a.M, bm), n_tiles, g.S * g.S);
+    if (bn == 64 && !small) hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    else if (bn == 64) hipLaunchKernelGGL((conv_rows_kernel<true, 1, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    else if (!small) hipLaunchKernelGGL((conv_rows_kernel<true, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
+    else hipLaunchKernelGGL((conv_rows_kernel<true, 1, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -49,6 +49,7 @@ struct AdamArgs {
     float* p; float* m; float* v; const float* g; int64_t n;
     const float* part; int n_part; float max_norm;
     float lr_step, beta1, beta2, bc2_sqrt, eps;
+    float omb1, omb2;    // (1 - beta) rounded from double, as torch passes them
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -68,8 +69,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     if (i >= a.n) return;
     const float gq = a.g[i] * scale;
     float m = a.m[i], v = a.v[i];
-    m = m + (gq - m) * (1.f - a.beta1);                  // exp_avg.lerp_(grad, 1 - beta1)
-    v = v * a.beta2 + (1.f - a.beta2) * gq * gq;         // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    m = m + (gq - m) * a.omb1;                           // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + a.omb2 * gq * gq;                  // mul_(beta2).addcmul_(g, g, 1 - beta2)
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     a.p[i] = a.p[i] + (-a.lr_step * m) / denom;          // addcdiv_(m, denom, -step_size)
     a.m[i] = m;
@@ -90,6 +91,7 @@ int adam_step(hipStream_t s, float* params, float* m, float* v, const float* gra
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     a.lr_step = (float)(lr / bc1);
     a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.eps = (float)eps;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, a);

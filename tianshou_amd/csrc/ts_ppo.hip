@@ -932,6 +932,7 @@ struct AdamArgs {
     const float* sumsq_part;  // [n_part] partial sums of squares, or NULL -> computed here (DP path)
     int n_part, n_params;
     float max_grad_norm, lr_step, bc2_sqrt, beta1, beta2, eps;
+    float omb1, omb2;            // (1 - beta) rounded from double, as torch passes them
     float vf_coef, ent_coef;
     float* losses;            // [4] loss, clip, vf, ent (or NULL); grad[n_params], grad[n_params+1] hold clip / vf
     int apply;                // 0: only losses
@@ -973,8 +974,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     if (p < a.n_params) {
         const float gq = a.grad[p] * scale;
         float m = a.m[p], v = a.v[p];
-        m = m + (gq - m) * (1.f - a.beta1);                // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * a.beta2 + (1.f - a.beta2) * gq * gq;       // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
         a.params[p] = a.params[p] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
         a.m[p] = m;
@@ -1161,6 +1162,7 @@ inline AdamArgs adam_args(float* params, float* m, float* v, int64_t step, const
     a.lr_step = (float)(hp->lr / bc1);
     a.bc2_sqrt = (float)sqrt(bc2);
     a.beta1 = (float)hp->beta1; a.beta2 = (float)hp->beta2; a.eps = (float)hp->adam_eps;
+    a.omb1 = (float)(1.0 - hp->beta1); a.omb2 = (float)(1.0 - hp->beta2);
     a.vf_coef = (float)hp->vf_coef;
     a.ent_coef = (float)hp->ent_coef;
     return a;

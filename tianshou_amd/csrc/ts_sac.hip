@@ -1,0 +1,498 @@
+// ts_sac.hip -- the SAC learn() step (tanh-Gaussian actor, twin critics, auto alpha, Polyak) for gfx950.
+//
+// Replaces, on device-resident float32 batches:
+//   SACPolicy.forward                    tianshou/algorithm/modelfree/sac.py:108-131
+//   correct_log_prob_gaussian_tanh       sac.py:25-39
+//   SAC._target_q_compute_value          sac.py:290-296, td3.py:94-102
+//   _minimize_critic_squared_loss        ddpg.py:267-285
+//   SAC._update_with_batch               sac.py:298-336 (three optimizer steps, AutoAlpha.update :203-209,
+//                                        polyak_parameter_update utils/lagged_network.py:8-18)
+//   nets: ContinuousActorProbabilistic (conditioned sigma, unbounded) continuous.py:220-238,
+//         ContinuousCritic (concat) continuous.py:144-169, Net/MLP ReLU common.py:90-178
+// All Linear layers run on the fp32-MFMA implicit-GEMM kernels of ts_conv.hip (1x1 case); input widths are
+// zero-padded to a multiple of 32 and the narrow heads to 32-column blocks (the padding stays exactly zero
+// under Adam: zero inputs / zero upstream gradients give zero weight gradients).
+// Roofline: fp32 MFMA for the GEMMs; the sampling / loss kernels are launch-latency sized ([B, act_dim]).
+#include <algorithm>
+#include <cmath>
+
+#include "ts_common.h"
+#include "ts_conv.h"
+
+#pragma clang fp contract(off)   // the elementwise formulas follow torch's operation order
+
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+}
+
+namespace {
+
+constexpr int HID = 256;
+constexpr int SIG_COL = 32;          // sigma block of the actor head starts at column 32
+constexpr float SIGMA_MIN = -20.f, SIGMA_MAX = 2.f;
+constexpr float TANH_EPS = 1.1920928955078125e-07f;     // np.finfo(np.float32).eps
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+inline int pad32(int x) { return (x + 31) / 32 * 32; }
+
+struct Mlp {                  // in -> 256 -> 256 -> head, ReLU between
+    ts::ConvGeom l[3];
+    int64_t off[4];
+};
+
+Mlp make_mlp(int B, int in_pad, int head_cols) {
+    Mlp m;
+    const int dims[4] = {in_pad, HID, HID, head_cols};
+    int64_t o = 0;
+    for (int i = 0; i < 3; ++i) {
+        m.l[i] = ts::ConvGeom{B, 1, 1, dims[i], 1, 1, 1, 1, 1, dims[i + 1]};
+        m.off[i] = o;
+        o += m.l[i].param_elems();
+    }
+    m.off[3] = o;
+    return m;
+}
+
+struct Act { float* h1; float* h2; float* out; };      // forward activations of one pass
+
+int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
+                float* split) {
+    if (int rc = ts::conv_forward(s, m.l[0], x, p + m.off[0], a.h1, true, split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, m.l[1], a.h1, p + m.off[1], a.h2, true, split, ws)) return rc;
+    return ts::conv_forward(s, m.l[2], a.h2, p + m.off[2], a.out, false, split, ws);
+}
+
+size_t split_floats(const Mlp& m) {
+    size_t s = 4;
+    for (int i = 0; i < 3; ++i) {
+        const int ns = ts::conv_fwd_splits(m.l[i]);
+        if (ns > 1) s = std::max(s, (size_t)ns * m.l[i].out_elems());
+    }
+    return s;
+}
+
+struct BwdScratch { float* dh2; float* dh1; float* slabs; };
+
+// d_out = d loss / d head output.  grad (nullable) receives the flat parameter gradient; dx (nullable) the
+// gradient w.r.t. the input columns [col0, col1).
+int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
+                 const float* d_out, float* grad, float* dx, int col0, int col1, const BwdScratch& sc) {
+    const float* xin[3] = {x, a.h1, a.h2};
+    const float* dy[3] = {sc.dh1, sc.dh2, d_out};
+    float* dxl[3] = {dx, sc.dh1, sc.dh2};
+    for (int i = 2; i >= 0; --i) {
+        if (grad) {
+            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
+            if (int rc = ts::slab_sum(s, sc.slabs, ts::conv_wgrad_splits(m.l[i]), m.l[i].param_elems(),
+                                      grad + m.off[i]))
+                return rc;
+        }
+        if (i > 0) {
+            if (int rc = ts::conv_dgrad(s, m.l[i], dy[i], p + m.off[i], xin[i], dxl[i], ws)) return rc;
+        } else if (dx) {
+            if (int rc = ts::conv_dgrad(s, m.l[0], dy[0], p + m.off[0], nullptr, dx, ws, col0, col1)) return rc;
+        }
+    }
+    return TS_OK;
+}
+
+size_t slab_floats(const Mlp& m) {
+    size_t s = 0;
+    for (int i = 0; i < 3; ++i) s = std::max(s, (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems());
+    return s;
+}
+
+// ---- elementwise kernels ----------------------------------------------------------------------------
+// x_a[b] = [obs | 0], x_c[b] = [obs | act | 0]
+__global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
+                                                       int64_t B, int obs_dim, int act_dim, int ka, int kc,
+                                                       float* __restrict__ x_a, float* __restrict__ x_c) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int w = ka + kc;
+    if (i >= B * w) return;
+    const int64_t b = i / w;
+    const int j = (int)(i - b * w);
+    if (j < ka) {
+        if (x_a) x_a[b * ka + j] = j < obs_dim ? obs[b * obs_dim + j] : 0.f;
+    } else if (x_c) {
+        const int k = j - ka;
+        float v = 0.f;
+        if (k < obs_dim) v = obs[b * obs_dim + k];
+        else if (k < obs_dim + act_dim && act) v = act[b * act_dim + k - obs_dim];
+        x_c[b * kc + k] = v;
+    }
+}
+
+// SACPolicy.forward after the actor MLP (sac.py:114-123): one thread per sample.
+// head[b] = [mu (A) .. | raw log-sigma (A) at column 32 ..].  Writes the squashed action into x_c's action
+// columns (nullable), act_out (nullable), logp_out; `keep` (nullable, [B, 3A]) stores {a - mu, sigma, squashed}
+// for the backward pass.
+__global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
+                                                         int64_t B, int A, int head_cols, int obs_dim, int kc,
+                                                         float* __restrict__ x_c, float* __restrict__ act_out,
+                                                         float* __restrict__ logp_out, float* __restrict__ keep) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* hb = head + b * head_cols;
+    float lp = 0.f, corr = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float mu = hb[j];
+        const float sigma = expf(fminf(fmaxf(hb[SIG_COL + j], SIGMA_MIN), SIGMA_MAX));
+        const float e = noise ? noise[b * A + j] : 0.f;
+        const float a = mu + e * sigma;                              // Normal.rsample: loc + eps * scale
+        const float d = a - mu;
+        lp += -(d * d) / (2.f * (sigma * sigma)) - logf(sigma) - LOG_SQRT_2PI;      // Normal.log_prob
+        const float sq = tanhf(a);
+        corr += logf(1.f - sq * sq + TANH_EPS);                      // sac.py:38
+        if (x_c) x_c[b * kc + obs_dim + j] = sq;
+        if (act_out) act_out[b * A + j] = sq;
+        if (keep) { keep[(b * 3 + 0) * A + j] = d; keep[(b * 3 + 1) * A + j] = sigma; keep[(b * 3 + 2) * A + j] = sq; }
+    }
+    logp_out[b] = lp - corr;
+}
+
+// SAC._target_q_compute_value: min(Q1_old, Q2_old) - alpha * log_prob  (q arrays are [B, 32], column 0)
+__global__ __launch_bounds__(256) void sac_target_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                         const float* __restrict__ logp, const float* __restrict__ log_alpha,
+                                                         float fixed_alpha, int64_t B, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    out[b] = fminf(q1[b * 32], q2[b * 32]) - alpha * logp[b];
+}
+
+// block-wide deterministic sum (1024 threads)
+__device__ float block_sum_1024(float v, float* red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// _minimize_critic_squared_loss (ddpg.py:279-284): td = Q - returns; loss = mean(td^2 w); d_out[b, 0] = 2 td w / B
+__global__ __launch_bounds__(1024) void sac_critic_loss_kernel(const float* __restrict__ q, const float* __restrict__ ret,
+                                                               const float* __restrict__ weight, int64_t B,
+                                                               float* __restrict__ td, float* __restrict__ d_out,
+                                                               float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float t = q[b * 32] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        td[b] = t;
+        ls += t * t * w;
+        d_out[b * 32] = 2.f * t * w * inv_b;       // the other 31 columns of d_out stay zero
+    }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss = tot * inv_b;
+}
+
+// actor loss (sac.py:312-314) = mean(alpha log_prob - min(Q1, Q2)); upstream gradients for the two critics
+__global__ __launch_bounds__(1024) void sac_actor_loss_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                              const float* __restrict__ logp,
+                                                              const float* __restrict__ log_alpha, float fixed_alpha,
+                                                              int64_t B, float* __restrict__ d_q1, float* __restrict__ d_q2,
+                                                              float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float a = q1[b * 32], c = q2[b * 32];
+        ls += alpha * logp[b] - fminf(a, c);
+        // torch.minimum backward: ties share the gradient
+        d_q1[b * 32] = a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+        d_q2[b * 32] = c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+    }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss = tot * inv_b;
+}
+
+// backward of sac_policy_kernel: d head[b] from d loss / d squashed action (sum of the two critics' input
+// gradients, action columns of [B, kc]) and from the alpha * log_prob term.  Autograd's formulas, term by term.
+__global__ __launch_bounds__(256) void sac_policy_bwd_kernel(const float* __restrict__ head, const float* __restrict__ noise,
+                                                             const float* __restrict__ keep, const float* __restrict__ dx1,
+                                                             const float* __restrict__ dx2,
+                                                             const float* __restrict__ log_alpha, float fixed_alpha,
+                                                             int64_t B, int A, int head_cols, int obs_dim, int kc,
+                                                             float* __restrict__ d_head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    const int j = (int)(i - b * A);
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float g_lp = alpha / (float)B;                              // d loss / d log_prob[b]
+    const float d = keep[(b * 3 + 0) * A + j], sigma = keep[(b * 3 + 1) * A + j], sq = keep[(b * 3 + 2) * A + j];
+    const float e = noise[b * A + j];
+    const float var = sigma * sigma;
+    const float one_m = 1.f - sq * sq;
+    const float d_sq = dx1[b * kc + obs_dim + j] + dx2[b * kc + obs_dim + j];      // from -min(Q1, Q2)
+    // log_prob = sum_j [-(a-mu)^2 / (2 var) - log sigma - c] - sum_j log(1 - sq^2 + eps)
+    const float g_sq = d_sq + g_lp * (2.f * sq / (one_m + TANH_EPS));
+    const float g_a = g_sq * one_m + g_lp * (-d / var);               // into a = mu + eps * sigma
+    const float g_mu = g_a + g_lp * (d / var);
+    const float g_sigma = g_a * e + g_lp * (d * d / (var * sigma) - 1.f / sigma);
+    const float raw = head[b * head_cols + SIG_COL + j];
+    const float g_raw = (raw >= SIGMA_MIN && raw <= SIGMA_MAX) ? g_sigma * sigma : 0.f;   // clamp().exp()
+    d_head[b * head_cols + j] = g_mu;
+    d_head[b * head_cols + SIG_COL + j] = g_raw;
+}
+
+// AutoAlpha.update (sac.py:203-209) + Adam on the scalar log_alpha; (td1 + td2) / 2 (sac.py:306)
+struct AlphaArgs {
+    const float* logp; int64_t B; float target_entropy;
+    float* log_alpha; float* m; float* v;
+    float lr_step, beta1, beta2, bc2_sqrt, eps, omb1, omb2;
+    float* alpha_loss; float* alpha_out; float fixed_alpha;
+    const float* td1; const float* td2; float* weight_out;
+};
+
+__global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t b = threadIdx.x; b < a.B; b += 1024) {
+        s += a.target_entropy + a.logp[b];                            // entropy_deficit = target - (-log_prob)
+        if (a.weight_out) a.weight_out[b] = (a.td1[b] + a.td2[b]) / 2.f;
+    }
+    const float tot = block_sum_1024(s, red);
+    if (threadIdx.x != 0) return;
+    if (!a.log_alpha) { *a.alpha_out = a.fixed_alpha; *a.alpha_loss = 0.f; return; }
+    const float mean_def = tot / (float)a.B;
+    const float la = *a.log_alpha;
+    *a.alpha_loss = -(la * mean_def);
+    const float g = -mean_def;
+    float m = *a.m, v = *a.v;
+    m = m + (g - m) * a.omb1;
+    v = v * a.beta2 + a.omb2 * g * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    const float nla = la + (-a.lr_step * m) / denom;
+    *a.log_alpha = nla; *a.m = m; *a.v = v;
+    *a.alpha_out = expf(nla);
+}
+
+__global__ __launch_bounds__(256) void polyak2_kernel(float* __restrict__ t1, const float* __restrict__ s1,
+                                                      float* __restrict__ t2, const float* __restrict__ s2, int64_t n,
+                                                      float tau, float omt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    t1[i] = tau * s1[i] + omt * t1[i];
+    t2[i] = tau * s2[i] + omt * t2[i];
+}
+
+size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Carve {
+    char* p;
+    template <class T> T* take(size_t n) { T* r = reinterpret_cast<T*>(p); p += al(sizeof(T) * n); return r; }
+};
+
+struct Dims { int obs, act, ka, kc; };
+
+int make_dims(int64_t obs_dim, int64_t act_dim, Dims* d) {
+    TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && act_dim >= 1 && act_dim <= 32, TS_ERR_INVALID_ARG,
+               "sac: obs_dim must be >= 1 and act_dim in [1, 32]");
+    d->obs = (int)obs_dim; d->act = (int)act_dim;
+    d->ka = pad32(d->obs); d->kc = pad32(d->obs + d->act);
+    return TS_OK;
+}
+
+Act take_act(Carve& c, int64_t B, int head_cols) {
+    Act a;
+    a.h1 = c.take<float>(B * HID); a.h2 = c.take<float>(B * HID); a.out = c.take<float>(B * head_cols);
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8) {
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    TS_REQUIRE(h_out8, TS_ERR_INVALID_ARG, "ts_sac_layout: NULL output");
+    const Mlp a = make_mlp(1, d.ka, 64), c = make_mlp(1, d.kc, 32);
+    h_out8[0] = d.ka; h_out8[1] = d.kc; h_out8[2] = a.off[3]; h_out8[3] = c.off[3];
+    h_out8[4] = a.off[1]; h_out8[5] = a.off[2]; h_out8[6] = c.off[1]; h_out8[7] = c.off[2];
+    return TS_OK;
+}
+
+int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs, const float* noise, int64_t B,
+                          int64_t obs_dim, int64_t act_dim, float* act_out, float* logp_out, float* mu_sigma_out,
+                          ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_policy_forward: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && obs && logp_out, TS_ERR_INVALID_ARG, "ts_sac_policy_forward: bad argument");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 64);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * HID) + al(4 * B * 3 * d.act) +
+                                        al(4 * split_floats(ma)) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    const Act aa = take_act(c, B, 64);
+    float* keep = c.take<float>(B * 3 * d.act);
+    float* split = c.take<float>(split_floats(ma));
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+                       64, d.obs, d.kc, (float*)nullptr, act_out, logp_out, mu_sigma_out ? keep : nullptr);
+    TS_LAUNCH_CHECK();
+    if (mu_sigma_out) {      // {a - mu, sigma, squashed} rows, for diagnostics / tests
+        TS_HIP_CHECK(hipMemcpyAsync(mu_sigma_out, keep, sizeof(float) * B * 3 * d.act, hipMemcpyDeviceToDevice, s));
+    }
+    return TS_OK;
+}
+
+int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                    const float* log_alpha, double fixed_alpha, const float* obs_next, const float* noise, int64_t B,
+                    int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_target_q: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && critic1_old && critic2_old && obs_next && noise && out, TS_ERR_INVALID_ARG,
+               "ts_sac_target_q: bad argument");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const size_t spl = std::max(split_floats(ma), split_floats(mc));
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * B) +
+                                        al(4 * spl) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);
+    const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    float* logp = c.take<float>(B);
+    float* split = c.take<float>(spl);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+                       64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+    if (int rc = mlp_forward(s, ws, mc, critic2_old, x_c, a2, split)) return rc;
+    hipLaunchKernelGGL(sac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, a2.out, logp,
+                       log_alpha, (float)fixed_alpha, B, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                  const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                  int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
+                  ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_update: workspace is NULL");
+    TS_REQUIRE(st && hp && obs && act && returns && noise && stats_out5 && B >= 1 && adam_step >= 1,
+               TS_ERR_INVALID_ARG, "ts_sac_update: bad argument");
+    TS_REQUIRE(st->actor && st->critic1 && st->critic2 && st->critic1_old && st->critic2_old && st->actor_m &&
+                   st->actor_v && st->critic1_m && st->critic1_v && st->critic2_m && st->critic2_v,
+               TS_ERR_INVALID_ARG, "ts_sac_update: NULL state pointer");
+    TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
+               "ts_sac_update: auto alpha needs log_alpha and its Adam moments");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
+    const int64_t pa = ma.off[3], pc = mc.off[3];
+    size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 3 * al(4 * B * 64) +
+                   2 * al(4 * B * HID) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
+                   al(4 * B * 3 * d.act) + 8192;
+    const size_t spl = std::max(split_floats(ma), split_floats(mc));
+    bytes += al(4 * spl);
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);          // [obs | buffer action]
+    float* x_p = c.take<float>(B * d.kc);          // [obs | policy action]
+    float* dx1 = c.take<float>(B * d.kc);
+    const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    float* d_head = c.take<float>(B * 64);         // upstream gradient of a head output (zero-padded columns)
+    float* d_q1 = c.take<float>(B * 64);
+    float* d_q2 = d_q1 + B * 32;
+    float* dx2 = c.take<float>(B * 64 > B * d.kc ? B * 64 : B * d.kc);
+    BwdScratch sc;
+    sc.dh2 = c.take<float>(B * HID); sc.dh1 = c.take<float>(B * HID); sc.slabs = c.take<float>(slab);
+    float* grad = c.take<float>(std::max(pa, pc));
+    float* td1 = c.take<float>(B); float* td2 = c.take<float>(B); float* logp = c.take<float>(B);
+    float* keep = c.take<float>(B * 3 * d.act);
+    float* norm_part = c.take<float>(1024);
+    float* split = c.take<float>(spl);
+    const unsigned gb = (unsigned)ts::ceil_div(B, 256);
+    const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
+    float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
+
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+    TS_HIP_CHECK(hipMemsetAsync(d_q1, 0, sizeof(float) * B * 64, s));
+
+    // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step
+    float* crit[2] = {st->critic1, st->critic2};
+    float* crit_m[2] = {st->critic1_m, st->critic2_m};
+    float* crit_v[2] = {st->critic1_v, st->critic2_v};
+    float* tds[2] = {td1, td2};
+    const Act acts[2] = {a1, a2};
+    for (int k = 0; k < 2; ++k) {
+        if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], split)) return rc;
+        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, s, acts[k].out, returns, weight, B, tds[k],
+                           d_head, stats_out5 + 1 + k);
+        TS_LAUNCH_CHECK();
+        float* gk = g_out[k] ? g_out[k] : grad;
+        if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], d_head, gk, nullptr, 0, 0, sc)) return rc;
+        if (hp->critic_lr >= 0.0)
+            if (int rc = ts::adam_step(s, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
+                return rc;
+    }
+
+    // actor (sac.py:308-315): a ~ pi(s) with the supplied noise, Q1(s, a), Q2(s, a) with the UPDATED critics
+    TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
+    if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(sac_policy_kernel, dim3(gb), dim3(256), 0, s, aa.out, noise, B, d.act, 64, d.obs, d.kc, x_p,
+                       (float*)nullptr, logp, keep);
+    if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
+    if (int rc = mlp_forward(s, ws, mc, st->critic2, x_p, a2, split)) return rc;
+    hipLaunchKernelGGL(sac_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, a2.out, logp, log_alpha, (float)hp->alpha, B,
+                       d_q1, d_q2, stats_out5);
+    TS_LAUNCH_CHECK();
+    if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
+    if (int rc = mlp_backward(s, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc)) return rc;
+    TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+    hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
+                       keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
+    TS_LAUNCH_CHECK();
+    float* ga = g_out[2] ? g_out[2] : grad;
+    if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
+    if (hp->actor_lr >= 0.0)
+        if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, pa, adam_step, hp->actor_lr, hp->beta1,
+                                   hp->beta2, hp->adam_eps, 0.0, norm_part))
+            return rc;
+
+    // alpha (sac.py:317-319), batch.weight (sac.py:306), Polyak (sac.py:321)
+    AlphaArgs aa2{};
+    aa2.logp = logp; aa2.B = B; aa2.target_entropy = (float)hp->target_entropy;
+    aa2.log_alpha = hp->auto_alpha ? st->log_alpha : nullptr; aa2.m = st->log_alpha_m; aa2.v = st->log_alpha_v;
+    const double bc1 = 1.0 - pow(hp->beta1, (double)adam_step), bc2 = 1.0 - pow(hp->beta2, (double)adam_step);
+    aa2.lr_step = (float)(hp->alpha_lr / bc1); aa2.beta1 = (float)hp->beta1; aa2.beta2 = (float)hp->beta2;
+    aa2.omb1 = (float)(1.0 - hp->beta1); aa2.omb2 = (float)(1.0 - hp->beta2);
+    aa2.bc2_sqrt = (float)sqrt(bc2); aa2.eps = (float)hp->adam_eps;
+    aa2.alpha_loss = stats_out5 + 4; aa2.alpha_out = stats_out5 + 3; aa2.fixed_alpha = (float)hp->alpha;
+    aa2.td1 = td1; aa2.td2 = td2; aa2.weight_out = weight_out;
+    hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
+    if (hp->tau > 0.0)
+        hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
+                           st->critic1, st->critic2_old, st->critic2, pc, (float)hp->tau, (float)(1.0 - hp->tau));
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // extern "C"

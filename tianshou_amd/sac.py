@@ -1,0 +1,229 @@
+"""SAC learn() path on the MI355X engine.
+
+Mirrors, on device tensors:
+    SACPolicy.forward                     tianshou/algorithm/modelfree/sac.py:108-131
+    ActorCriticOffPolicyAlgorithm._target_q / _preprocess_batch   ddpg.py:287-339 (n-step via returns.py)
+    SAC._update_with_batch                sac.py:298-336 (critic x2, actor, AutoAlpha, Polyak)
+Networks: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU; actor with state-conditioned sigma,
+unbounded; critics on concat(obs, act)).  rsample() noise is supplied by the caller (host- or
+device-generated), which is what makes the path reproducible against the reference.
+There is no CPU path: every function calls libtsengine.so and raises when it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .buffer import DeviceReplayBuffer, gather_rows
+from .returns import compute_nstep_return
+
+TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                       "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                       "mu.model.0.weight", "mu.model.0.bias", "sigma.model.0.weight", "sigma.model.0.bias"]
+TIANSHOU_CRITIC_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                        "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                        "last.model.0.weight", "last.model.0.bias"]
+HID = 256
+
+
+class SACHParams(C.Structure):
+    """struct ts_sac_hparams (include/tsengine.h)."""
+
+    _fields_ = [("actor_lr", C.c_double), ("critic_lr", C.c_double), ("alpha_lr", C.c_double),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double), ("tau", C.c_double),
+                ("alpha", C.c_double), ("target_entropy", C.c_double), ("auto_alpha", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class SACStateC(C.Structure):
+    """struct ts_sac_state (include/tsengine.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "actor", "actor_m", "actor_v", "critic1", "critic1_m", "critic1_v", "critic2", "critic2_m", "critic2_v",
+        "critic1_old", "critic2_old", "log_alpha", "log_alpha_m", "log_alpha_v")]
+
+
+def layout(obs_dim: int, act_dim: int) -> dict[str, int]:
+    out = (C.c_int64 * 8)()
+    _lib.check(_lib.load().ts_sac_layout(_lib.i64(obs_dim), _lib.i64(act_dim), out))
+    keys = ["ka", "kc", "actor_count", "critic_count", "actor_l2", "actor_head", "critic_l2", "critic_head"]
+    return dict(zip(keys, (int(v) for v in out)))
+
+
+def _l1(w: torch.Tensor, b: torch.Tensor, k_pad: int) -> torch.Tensor:
+    wb = torch.zeros((k_pad + 1, HID), dtype=torch.float32)
+    wb[: w.shape[1]] = w.detach().float().cpu().t()
+    wb[k_pad] = b.detach().float().cpu()
+    return wb.reshape(-1)
+
+
+def _dense(w, b) -> torch.Tensor:
+    return torch.cat([w.detach().float().cpu().t().reshape(-1), b.detach().float().cpu().reshape(-1)])
+
+
+def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
+    """[w1, b1, w2, b2, wmu, bmu, wsig, bsig] (torch nn.Linear layout; also valid for Adam moments)."""
+    lay = layout(obs_dim, act_dim)
+    head = torch.zeros((HID + 1, 64), dtype=torch.float32)
+    head[:HID, :act_dim] = t[4].detach().float().cpu().t()
+    head[HID, :act_dim] = t[5].detach().float().cpu()
+    head[:HID, 32:32 + act_dim] = t[6].detach().float().cpu().t()
+    head[HID, 32:32 + act_dim] = t[7].detach().float().cpu()
+    return torch.cat([_l1(t[0], t[1], lay["ka"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
+
+
+def critic_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
+    """[w1, b1, w2, b2, wq, bq]."""
+    lay = layout(obs_dim, act_dim)
+    head = torch.zeros((HID + 1, 32), dtype=torch.float32)
+    head[:HID, 0] = t[4].detach().float().cpu().reshape(-1)
+    head[HID, 0] = t[5].detach().float().cpu().reshape(())
+    return torch.cat([_l1(t[0], t[1], lay["kc"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
+
+
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
+    lay = layout(obs_dim, act_dim)
+    f = flat.detach()
+    l1 = f[: lay["actor_l2"]].reshape(lay["ka"] + 1, HID)
+    l2 = f[lay["actor_l2"]: lay["actor_head"]].reshape(HID + 1, HID)
+    hd = f[lay["actor_head"]:].reshape(HID + 1, 64)
+    return [l1[:obs_dim].t().contiguous(), l1[lay["ka"]].clone(), l2[:HID].t().contiguous(), l2[HID].clone(),
+            hd[:HID, :act_dim].t().contiguous(), hd[HID, :act_dim].clone(),
+            hd[:HID, 32:32 + act_dim].t().contiguous(), hd[HID, 32:32 + act_dim].clone()]
+
+
+def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
+    lay = layout(obs_dim, act_dim)
+    f = flat.detach()
+    l1 = f[: lay["critic_l2"]].reshape(lay["kc"] + 1, HID)
+    l2 = f[lay["critic_l2"]: lay["critic_head"]].reshape(HID + 1, HID)
+    hd = f[lay["critic_head"]:].reshape(HID + 1, 32)
+    return [l1[: obs_dim + act_dim].t().contiguous(), l1[lay["kc"]].clone(), l2[:HID].t().contiguous(),
+            l2[HID].clone(), hd[:HID, 0].reshape(1, HID).clone(), hd[HID, 0].reshape(1).clone()]
+
+
+@dataclass
+class SACConfig:
+    """Hyper-parameters of the reference SAC (sac.py:222-283) + Adam factories."""
+
+    gamma: float = 0.99
+    tau: float = 0.005
+    n_step: int = 1
+    alpha: float = 0.2
+    auto_alpha: bool = False
+    target_entropy: float = 0.0
+    log_alpha0: float = 0.0
+    actor_lr: float = 1e-3
+    critic_lr: float = 1e-3
+    alpha_lr: float = 3e-4
+    betas: tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+
+    def to_c(self, lr_scale: float = 1.0) -> SACHParams:
+        return SACHParams(self.actor_lr * lr_scale, self.critic_lr * lr_scale, self.alpha_lr * lr_scale,
+                          self.betas[0], self.betas[1], self.adam_eps, self.tau, self.alpha, self.target_entropy,
+                          int(self.auto_alpha), 0)
+
+
+class SACEngine:
+    """State of one SAC learner on one GPU."""
+
+    def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
+                 critic2: torch.Tensor, cfg: SACConfig):
+        if not actor.is_cuda:
+            raise RuntimeError("SACEngine needs parameters on an MI355X (no CPU fallback)")
+        lay = layout(obs_dim, act_dim)
+        if actor.numel() != lay["actor_count"] or critic1.numel() != lay["critic_count"] \
+                or critic2.numel() != lay["critic_count"]:
+            raise ValueError("flat parameter vectors do not match ts_sac_layout")
+        self.obs_dim, self.act_dim, self.cfg, self.lay = obs_dim, act_dim, cfg, lay
+        self.device = actor.device
+        cl = lambda t: t.detach().float().contiguous().clone()  # noqa: E731
+        self.actor, self.critic1, self.critic2 = cl(actor), cl(critic1), cl(critic2)
+        self.critic1_old, self.critic2_old = cl(critic1), cl(critic2)              # ddpg.py:262, td3.py:90-91
+        z = torch.zeros_like
+        self.actor_m, self.actor_v = z(self.actor), z(self.actor)
+        self.critic1_m, self.critic1_v = z(self.critic1), z(self.critic1)
+        self.critic2_m, self.critic2_v = z(self.critic2), z(self.critic2)
+        self.log_alpha = torch.full((1,), cfg.log_alpha0, dtype=torch.float32, device=self.device)
+        self.log_alpha_m, self.log_alpha_v = z(self.log_alpha), z(self.log_alpha)
+        self.adam_step = 0
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    def _state_c(self) -> SACStateC:
+        names = [n for n, _ in SACStateC._fields_]
+        return SACStateC(*[getattr(self, n).data_ptr() for n in names])
+
+    def _f32(self, x, shape=None) -> torch.Tensor:
+        t = torch.as_tensor(x, device=self.device).to(torch.float32).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+    @property
+    def alpha(self) -> torch.Tensor:
+        """Alpha.value (sac.py:164-201) as a device scalar."""
+        if self.cfg.auto_alpha:
+            return self.log_alpha.exp()
+        return torch.full((1,), self.cfg.alpha, dtype=torch.float32, device=self.device)
+
+    # -- SACPolicy.forward ---------------------------------------------------------------------------------
+    def policy_forward(self, obs, noise=None):
+        """-> (act float32[B, A] tanh-squashed, log_prob float32[B, 1]); noise None = deterministic mode."""
+        obs = self._f32(obs)
+        b = obs.shape[0]
+        noise = None if noise is None else self._f32(noise, (b, self.act_dim))
+        act = torch.empty((b, self.act_dim), dtype=torch.float32, device=self.device)
+        logp = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_sac_policy_forward(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim),
+            _lib.i64(self.act_dim), _lib.ptr(act), _lib.ptr(logp), None, _lib.current_stream(self.device)))
+        return act, logp.unsqueeze(-1)
+
+    # -- _target_q ---------------------------------------------------------------------------------------------
+    def target_q(self, obs_next, noise) -> torch.Tensor:
+        obs_next = self._f32(obs_next)
+        b = obs_next.shape[0]
+        noise = self._f32(noise, (b, self.act_dim))
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_sac_target_q(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
+            _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(obs_next),
+            _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim), _lib.ptr(out),
+            _lib.current_stream(self.device)))
+        return out
+
+    # -- _preprocess_batch ---------------------------------------------------------------------------------------
+    def preprocess(self, buffer: DeviceReplayBuffer, indices, noise) -> torch.Tensor:
+        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); needs buffer.obs_next."""
+
+        def tq_fn(buf, after):
+            return self.target_q(gather_rows(buf.obs_next, after), noise)
+
+        class _B:
+            pass
+
+        return compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step).returns.reshape(-1)
+
+    # -- SAC._update_with_batch -----------------------------------------------------------------------------------
+    def update_with_batch(self, obs, act, returns, noise, weight=None, grads_out: torch.Tensor | None = None,
+                          lr_scale: float = 1.0):
+        """-> (stats float32[5] device = {actor_loss, critic1_loss, critic2_loss, alpha, alpha_loss},
+        weight float32[B] = (td1 + td2) / 2)."""
+        obs, act = self._f32(obs), self._f32(act)
+        b = obs.shape[0]
+        returns, noise = self._f32(returns, (b,)), self._f32(noise, (b, self.act_dim))
+        weight = None if weight is None else self._f32(weight, (b,))
+        if act.shape != (b, self.act_dim) or obs.shape != (b, self.obs_dim):
+            raise ValueError("obs / act shapes do not match the engine")
+        self.adam_step += 1
+        stats = torch.empty(5, dtype=torch.float32, device=self.device)
+        w_out = torch.empty(b, dtype=torch.float32, device=self.device)
+        st, hp = self._state_c(), self.cfg.to_c(lr_scale)
+        _lib.check(_lib.load().ts_sac_update(
+            self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
+            _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
+            C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.ptr(grads_out), _lib.current_stream(self.device)))
+        return stats, w_out
