@@ -1,0 +1,135 @@
+"""C5 workload: SAC updates/s on a synthetic Humanoid-shape replay (2^21 slots, obs f32[376],
+act f32[17], twin critics + lagged copies, hidden [256, 256], auto alpha, B=4096).
+
+    python bench.py --workload sac [--steps K] [--warmup W]        (or: python bench_sac.py)
+
+One "step" = one SAC.update(): uniform sample -> gather (obs, act, obs_next) -> a' ~ pi(s'), min Q_old - alpha logp
+-> 1-step return -> critic1, critic2, actor, alpha steps -> Polyak.  Everything device-resident; rsample() noise
+from the device RNG.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+OBS, ACT, BATCH = 376, 17, 4096
+PEAK_F32_MFMA_TFLOPS = 157.3
+FLOP_PER_SAMPLE = 4.76e6          # algorithmic minimum of one update
+
+
+def cpu_baseline(updates: int = 3):
+    from oracle import oracle_sac as OS
+
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    cfg = OS.SACConfig(auto_alpha=True, target_entropy=-float(ACT))
+    st = OS.SACState.create(*OS.init_sac_params(OBS, ACT, 0), cfg)
+    g = torch.Generator().manual_seed(0)
+    obs, obs_next = torch.randn(BATCH, OBS, generator=g), torch.randn(BATCH, OBS, generator=g)
+    act = torch.rand(BATCH, ACT, generator=g) * 2 - 1
+    rew = torch.randn(BATCH, generator=g)
+    noise = torch.randn(BATCH, ACT, generator=g)
+
+    def one():
+        ret = rew + cfg.gamma * OS.target_q(st, cfg, obs_next, noise).flatten()
+        OS.update_with_batch(st, cfg, obs, act, ret, noise)
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": updates / dt, "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{updates} updates of B={BATCH} (target + 3 optimizer steps + Polyak), torch fp32 CPU oracle"}
+
+
+def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) -> dict:
+    from oracle import oracle_sac as OS            # parameter init only (torch nn.Linear default init)
+    from tianshou_amd import _lib
+    from tianshou_amd import sac as S
+    from tianshou_amd.buffer import DeviceReplayBuffer, gather_rows
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    obs = torch.randn(slots, OBS, generator=g, device=dev)
+    obs_next = torch.randn(slots, OBS, generator=g, device=dev)
+    act = torch.rand(slots, ACT, generator=g, device=dev) * 2 - 1
+    rew = torch.randn(slots, generator=g, device=dev).double()
+    term = torch.rand(slots, generator=g, device=dev) < 0.001
+    E = 16
+    T = slots // E
+    offset = np.arange(E + 1, dtype=np.int64) * T
+    buf = DeviceReplayBuffer(offset=offset, last_index=offset[:-1] + T - 1, lengths=np.full(E, T, np.int64),
+                             insertion=np.zeros(E, np.int64), rew=rew, terminated=term,
+                             truncated=torch.zeros(slots, dtype=torch.bool, device=dev), obs=obs, act=act,
+                             obs_next=obs_next)
+    actor, c1, c2 = OS.init_sac_params(OBS, ACT, 0)
+    cfg = S.SACConfig(gamma=0.99, tau=0.005, n_step=1, auto_alpha=True, target_entropy=-float(ACT), log_alpha0=0.0,
+                      actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4)
+    eng = S.SACEngine(OBS, ACT, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], OBS, ACT),
+                      S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], OBS, ACT),
+                      S.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], OBS, ACT), cfg)
+
+    def update():
+        idx = torch.randint(0, slots, (BATCH,), generator=g, device=dev)
+        noise = torch.randn(2, BATCH, ACT, generator=g, device=dev)
+        ret = eng.preprocess(buf, idx, noise[0])
+        stats, _ = eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret, noise[1])
+        return stats
+
+    for _ in range(warmup):
+        update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats = update()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    ws = _lib.default_workspace(0)
+    n_prof = 10
+    ws.profile_begin()
+    for _ in range(n_prof):
+        update()
+    torch.cuda.synchronize()
+    prof = ws.profile_end()
+    gemm_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) / n_prof
+    launches = sum(prof[k][1] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) // n_prof
+    tf = FLOP_PER_SAMPLE * BATCH / (gemm_ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "conv_rows_kernel / conv_wgrad_kernel (all linear-layer GEMMs of one update)",
+            "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+            "traffic": None, "avg_launch_us": gemm_ms * 1e3 / launches, "launches_per_update": launches,
+            "gemm_us_per_update": gemm_ms * 1e3,
+            "kernel_us_per_update": {k: prof[k][0] * 1e3 / n_prof for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")}}
+    return {
+        "metric": "SAC learn() updates/sec (B=4096, obs 376, act 17, hidden 256x256, auto alpha)",
+        "value": steps / dt, "unit": "updates/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+        "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C5 SAC Humanoid-shape replay: {slots} slots, obs f32[376], act f32[17], "
+                               "actor 171,042 + 2 x 166,913 critic parameters, B=4096", "parallelism": "dp1"},
+        "roofline": roof,
+        "whole_update_mfma_frac": FLOP_PER_SAMPLE * BATCH * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "cpu_baseline": cpu_baseline() if with_cpu else None,
+        "final_stats": [float(x) for x in stats.tolist()],
+    }
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--slots", type=int, default=1 << 21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(a.steps, a.warmup, a.slots, not a.no_cpu_baseline)), flush=True)
