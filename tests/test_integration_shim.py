@@ -93,3 +93,116 @@ def test_unsupported_nets_are_rejected():
     critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[128, 128], activation=nn.Tanh))
     with pytest.raises(NotImplementedError):
         _check_supported(actor, critic)
+
+
+# ------------------------------------------------------------------------------------ DQN / SAC subclasses
+@pytest.fixture(scope="module")
+def dqn_algo():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.dqn import DiscreteQLearningPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import DQNet
+    from tianshou_amd.integration import make_hip_dqn
+
+    net = DQNet(c=4, h=84, w=84, action_shape=6)
+    policy = DiscreteQLearningPolicy(model=net, action_space=gym.spaces.Discrete(6))
+    return make_hip_dqn()(policy=policy, optim=AdamOptimizerFactory(lr=1e-4), gamma=0.99, n_step_return_horizon=3,
+                          target_update_freq=500, is_double=True, huber_loss_delta=1.0, device="cpu")
+
+
+@pytest.fixture(scope="module")
+def sac_algo():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.sac import AutoAlpha, SACPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import make_hip_sac
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[256, 256]),
+                                         action_shape=(3,), unbounded=True, conditioned_sigma=True)
+    mk = lambda: ContinuousCritic(preprocess_net=Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[256, 256],  # noqa: E731
+                                                     concat=True))
+    policy = SACPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,)))
+    return make_hip_sac()(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(),
+                          critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=mk(),
+                          critic2_optim=AdamOptimizerFactory(lr=1e-3), tau=0.005, gamma=0.99,
+                          alpha=AutoAlpha(-3.0, 0.0, AdamOptimizerFactory(lr=3e-4)), device="cpu")
+
+
+@pytest.mark.parametrize("which", ["dqn", "sac"])
+def test_offpolicy_hooks_keep_reference_signatures(which, dqn_algo, sac_algo):
+    algo = dqn_algo if which == "dqn" else sac_algo
+    base = type(algo).__mro__[1]
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+
+
+@pytest.mark.parametrize("which", ["dqn", "sac"])
+def test_offpolicy_no_silent_cpu_fallback(which, dqn_algo, sac_algo):
+    from tianshou.data import Batch, VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = dqn_algo if which == "dqn" else sac_algo
+    buf = VectorReplayBuffer(16, 2)
+    shape, act = ((4, 84, 84), np.zeros(2, np.int64)) if which == "dqn" else ((11,), np.zeros((2, 3), np.float32))
+    for _ in range(8):
+        buf.add(Batch(obs=np.zeros((2, *shape), np.uint8 if which == "dqn" else np.float32), act=act, rew=np.zeros(2),
+                      terminated=np.zeros(2, bool), truncated=np.zeros(2, bool),
+                      obs_next=np.zeros((2, *shape), np.uint8 if which == "dqn" else np.float32)))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, sample_size=8)
+
+
+def test_unsupported_dqn_model_is_rejected():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.dqn import DiscreteQLearningPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou_amd.integration import make_hip_dqn
+
+    policy = DiscreteQLearningPolicy(model=Net(state_shape=(4,), action_shape=2, hidden_sizes=[64]),
+                                     action_space=gym.spaces.Discrete(2))
+    with pytest.raises(NotImplementedError):
+        make_hip_dqn()(policy=policy, optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
+
+
+def test_mirror_incremental_sync_tracks_the_reference_buffer():
+    """DeviceReplayBuffer.sync_from_tianshou copies exactly the slots written since the last sync (ring wrap,
+    uneven sub-buffers); host-side logic, checked here on a CPU mirror."""
+    ref_shim.install()
+    from tianshou.data import Batch, VectorReplayBuffer
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    rng = np.random.default_rng(0)
+    buf = VectorReplayBuffer(30, 3)
+
+    def add(n, ids=None):
+        ids = np.arange(3) if ids is None else np.asarray(ids)
+        for _ in range(n):
+            k = len(ids)
+            buf.add(Batch(obs=rng.normal(size=(k, 5)).astype(np.float32), act=rng.normal(size=(k, 2)).astype(np.float32),
+                          rew=rng.normal(size=k), terminated=rng.random(k) < 0.2, truncated=rng.random(k) < 0.1,
+                          obs_next=rng.normal(size=(k, 5)).astype(np.float32)), buffer_ids=ids)
+
+    add(4)
+    m = DeviceReplayBuffer.from_tianshou(buf, device="cpu")
+    total = 0
+    for n, ids in ((3, None), (5, [0, 2]), (9, [1]), (0, None), (4, None)):
+        add(n, ids)
+        total += m.sync_from_tianshou(buf)
+        for key in ("obs", "act", "obs_next"):
+            assert np.array_equal(getattr(m, key).numpy(), np.asarray(getattr(buf, key))), key
+        assert np.array_equal(m.rew.numpy(), np.asarray(buf.rew))
+        assert np.array_equal(m.done.numpy().astype(bool), np.asarray(buf.done))
+        assert np.array_equal(m.last_index.numpy(), np.asarray(buf.last_index))
+        assert np.array_equal(m.lengths.numpy(), np.asarray(buf._lengths))
+    assert 0 < total < 4 * 30            # incremental, not whole-buffer copies

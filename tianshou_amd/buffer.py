@@ -116,7 +116,13 @@ class DeviceReplayBuffer:
             x.to(device) if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), device=device)
         ).contiguous()
         self.obs, self.act, self.obs_next = to(obs), to(act), to(obs_next)
-        self._ws = _lib.default_workspace(_dev_index(self.done))
+        self._ws_cache = None
+
+    @property
+    def _ws(self):
+        if self._ws_cache is None:         # created on first kernel use: raises on a CPU mirror (no CPU fallback)
+            self._ws_cache = _lib.default_workspace(_dev_index(self.done))
+        return self._ws_cache
 
     # -- constructors -------------------------------------------------------------------------
     @classmethod
@@ -150,6 +156,45 @@ class DeviceReplayBuffer:
                    terminated=np.asarray(buffer.terminated), truncated=np.asarray(buffer.truncated),
                    obs=np.asarray(buffer.obs), act=np.asarray(buffer.act),
                    obs_next=np.asarray(buffer.obs_next) if has("obs_next") else None, device=device)
+
+    def sync_from_tianshou(self, buffer) -> int:
+        """Incremental refresh from the reference buffer this mirror was created from: copies only the slots
+        written since the last sync (ring order per sub-buffer, manager.py:162-177) plus the tiny manager state.
+        Assumes fewer than `size` adds per sub-buffer between two syncs.  Returns the number of slots copied."""
+        subs = buffer.buffers if hasattr(buffer, "buffers") else [buffer]
+        if len(subs) != self.buffer_num:
+            raise ValueError("buffer layout changed since the mirror was created")
+        keys = [k for k in ("obs", "act", "obs_next") if getattr(self, k) is not None]
+        host = {k: np.asarray(getattr(buffer, k)) for k in keys}
+        host.update(rew=np.asarray(buffer.rew), terminated=np.asarray(buffer.terminated),
+                    truncated=np.asarray(buffer.truncated))
+        copied = 0
+        for e, sb in enumerate(subs):
+            start, size = int(self.h_offset[e]), int(self.h_offset[e + 1] - self.h_offset[e])
+            new_ins, new_len = int(sb._insertion_idx), len(sb)
+            old_ins, old_len = int(self.h_insertion[e]), int(self.h_lengths[e])
+            grown = new_len - old_len
+            k = grown + (new_ins - old_ins - grown) % size if size else 0
+            k = min(k, size)
+            segs = []
+            a = old_ins % size if size else 0
+            if k == size:
+                segs = [(0, size)]
+            elif k > 0:
+                segs = [(a, min(a + k, size))] + ([(0, a + k - size)] if a + k > size else [])
+            for lo, hi in segs:
+                sl = slice(start + lo, start + hi)
+                for key, arr in host.items():
+                    dst = getattr(self, key)
+                    dst[sl] = torch.as_tensor(np.ascontiguousarray(arr[sl])).to(dst.dtype)
+                self.done[sl] = self.terminated[sl] | self.truncated[sl]
+                copied += hi - lo
+            self.h_insertion[e], self.h_lengths[e] = new_ins, new_len
+        self.h_last_index = np.ascontiguousarray(np.asarray(buffer.last_index, dtype=np.int64).reshape(-1))
+        self.last_index.copy_(torch.as_tensor(self.h_last_index))
+        self.lengths.copy_(torch.as_tensor(self.h_lengths))
+        self.insertion.copy_(torch.as_tensor(self.h_insertion))
+        return copied
 
     # -- reference API ------------------------------------------------------------------------
     def __len__(self) -> int:

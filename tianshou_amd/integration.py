@@ -126,3 +126,194 @@ def make_hip_ppo():
             )
 
     return HipPPO
+
+
+# ---------------------------------------------------------------------------------------------------
+# DQN (dqn.py:288-404) on DQNet
+# ---------------------------------------------------------------------------------------------------
+def _adam_of(optim):
+    opt = optim._optim
+    g = opt.param_groups[0]
+    if type(opt).__name__ != "Adam" or g.get("weight_decay", 0) != 0 or g.get("amsgrad", False):
+        raise NotImplementedError("the HIP engines support torch.optim.Adam without weight decay / amsgrad")
+    return opt, g
+
+
+def _mirror(algorithm, buffer, device):
+    """Device mirror of the host replay buffer, refreshed incrementally on every update()."""
+    from .buffer import DeviceReplayBuffer
+
+    m = getattr(algorithm, "_hip_mirror", None)
+    if m is None or algorithm._hip_mirror_src is not buffer:
+        m = DeviceReplayBuffer.from_tianshou(buffer, device=device)
+        algorithm._hip_mirror, algorithm._hip_mirror_src = m, buffer
+    else:
+        m.sync_from_tianshou(buffer)
+    return m
+
+
+def make_hip_dqn():
+    """Returns HipDQN(DQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, 381-404) on the engine.
+    Supported model: DQNet(c, h, w, n_act) (atari_network.py:60-122), Adam; buffer either stores whole [c, h, w]
+    observations or single frames with stack_num = c (save_only_last_obs); obs_next optional."""
+    from tianshou.algorithm.modelfree.dqn import DQN
+    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+
+    from . import dqn as D
+
+    class HipDQN(DQN):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sd = self.policy.model.state_dict()
+            if list(sd.keys()) != D.TIANSHOU_KEYS:
+                raise NotImplementedError("HipDQN: the model must be DQNet(c, h, w, action_shape) without extra layers")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _engine(self, c, h, w):
+            if self._hip_engine is None:
+                sd = self.policy.model.state_dict()
+                n_act = sd[D.TIANSHOU_KEYS[-1]].numel()
+                opt, g = _adam_of(self.optim)
+                cfg = D.DQNConfig(gamma=self.gamma, n_step=self.n_step, target_update_freq=self.target_update_freq,
+                                  is_double=self.is_double, huber_delta=self.huber_loss_delta, lr=g["lr"],
+                                  betas=tuple(g["betas"]), adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
+                flat = D.flat_from_torch([sd[k] for k in D.TIANSHOU_KEYS], c, h, w, n_act, self._hip_device)
+                self._hip_engine = D.DQNEngine(c, h, w, n_act, flat, cfg)
+                self._hip_engine.iter = self._iter
+            return self._hip_engine
+
+        def _layout(self, buffer):
+            obs = np.asarray(buffer.obs)
+            stack = int(getattr(buffer, "stack_num", 1))
+            if stack > 1:
+                if obs.ndim != 3:
+                    raise NotImplementedError("HipDQN: frame stacking needs single [h, w] frames per slot")
+                return stack, obs.shape[1], obs.shape[2], stack
+            if obs.ndim != 4:
+                raise NotImplementedError("HipDQN: observations must be [c, h, w]")
+            return obs.shape[1], obs.shape[2], obs.shape[3], 1
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            if self._hip_device.type != "cuda":
+                raise RuntimeError("HipDQN needs an MI355X (device='cuda'); there is no CPU fallback")
+            c, h, w, stack = self._layout(buffer)
+            eng = self._engine(c, h, w)
+            m = _mirror(self, buffer, self._hip_device)
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            nxt = m.obs_next if m.obs_next is not None else None
+            batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_frames=nxt).reshape(-1, 1)
+            self._hip_idx, self._hip_stack = idx, stack
+            if hasattr(batch, "weight"):
+                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
+            return batch
+
+        def _update_with_batch(self, batch):
+            eng, m = self._hip_engine, self._hip_mirror
+            weight = batch.pop("weight", None)
+            obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack)
+            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
+            loss, td = eng.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
+            self._iter = eng.iter
+            batch.weight = td                                                     # prio-buffer, dqn.py:401
+            tensors = D.flat_to_torch(eng.params, eng.c, eng.h, eng.w, eng.n_act)
+            with torch.no_grad():
+                for p, t in zip(self.policy.model.parameters(), tensors):
+                    p.copy_(t)
+                if eng.params_old is not None:
+                    old = D.flat_to_torch(eng.params_old, eng.c, eng.h, eng.w, eng.n_act)
+                    for p, t in zip(self.model_old.parameters(), old):
+                        p.copy_(t)
+            return SimpleLossTrainingStats(loss=float(loss.item()))
+
+    return HipDQN
+
+
+# ---------------------------------------------------------------------------------------------------
+# SAC (sac.py:213-336) on the mujoco_sac.py networks
+# ---------------------------------------------------------------------------------------------------
+def make_hip_sac():
+    """Returns HipSAC(SAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, sac.py:298-336) on the
+    engine.  Supported nets: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU, conditioned sigma,
+    unbounded actor; concat critics); the buffer must store obs_next.  rsample() noise is drawn from torch's
+    default generator on the host, in the reference's order (target-policy call, then actor-loss call)."""
+    from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACTrainingStats
+
+    from . import sac as S
+
+    class HipSAC(SAC):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
+            if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != S.TIANSHOU_CRITIC_KEYS \
+                    or list(self.critic2.state_dict().keys()) != S.TIANSHOU_CRITIC_KEYS:
+                raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py")
+            if sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or sa[S.TIANSHOU_ACTOR_KEYS[2]].shape != (256, 256):
+                raise NotImplementedError("HipSAC: hidden sizes must be [256, 256]")
+            for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
+                _adam_of(o)
+            self._hip_engine = None
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                obs_dim = sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1]
+                act_dim = sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                auto = isinstance(self.alpha, AutoAlpha)
+                ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
+                cfg = S.SACConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
+                                  alpha=0.0 if auto else float(self.alpha.value), auto_alpha=auto,
+                                  target_entropy=float(self.alpha._target_entropy) if auto else 0.0,
+                                  log_alpha0=float(self.alpha._log_alpha.item()) if auto else 0.0,
+                                  actor_lr=ga["lr"], critic_lr=gc["lr"],
+                                  alpha_lr=self.alpha._optim._optim.param_groups[0]["lr"] if auto else 0.0,
+                                  betas=tuple(ga["betas"]), adam_eps=ga["eps"])
+                dev = self._hip_device
+                flat_c = lambda mod: S.critic_flat_from_torch(  # noqa: E731
+                    [mod.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS], obs_dim, act_dim, dev)
+                self._hip_engine = S.SACEngine(
+                    obs_dim, act_dim,
+                    S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
+                    flat_c(self.critic), flat_c(self.critic2), cfg)
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            if self._hip_device.type != "cuda":
+                raise RuntimeError("HipSAC needs an MI355X (device='cuda'); there is no CPU fallback")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            if m.obs_next is None:
+                raise NotImplementedError("HipSAC: the replay buffer must store obs_next")
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            noise = torch.randn(len(indices), eng.act_dim)                  # Normal.rsample of the target policy call
+            batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)
+            self._hip_idx = idx
+            return batch
+
+        def _update_with_batch(self, batch):
+            from .buffer import gather_rows
+
+            eng, m = self._hip_engine, self._hip_mirror
+            weight = getattr(batch, "weight", None)
+            noise = torch.randn(len(batch), eng.act_dim)
+            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                                             batch.returns.reshape(-1), noise, weight)
+            batch.weight = w                                                      # prio-buffer, sac.py:306
+            s = stats.cpu().numpy()                                               # one D2H per update()
+            with torch.no_grad():
+                for mod, flat, conv in ((self.policy.actor, eng.actor, S.actor_flat_to_torch),
+                                        (self.critic, eng.critic1, S.critic_flat_to_torch),
+                                        (self.critic2, eng.critic2, S.critic_flat_to_torch),
+                                        (self.critic_old.module, eng.critic1_old, S.critic_flat_to_torch),
+                                        (self.critic2_old.module, eng.critic2_old, S.critic_flat_to_torch)):
+                    for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim)):
+                        p.copy_(t)
+                if eng.cfg.auto_alpha:
+                    self.alpha._log_alpha.copy_(eng.log_alpha[0])
+            auto = eng.cfg.auto_alpha
+            return SACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
+                                    alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
+
+    return HipSAC
