@@ -210,3 +210,25 @@ def test_adam_step_vs_torch():
         m_ref, v_ref = st["exp_avg"].numpy(), st["exp_avg_sq"].numpy()
         np.testing.assert_allclose(dm.cpu().numpy(), m_ref, rtol=2e-6, atol=1e-6 * np.abs(m_ref).max())
         np.testing.assert_allclose(dv.cpu().numpy(), v_ref, rtol=2e-6, atol=1e-6 * np.abs(v_ref).max())
+
+
+def test_gradient_plus_apply_equals_update():
+    """The data-parallel halves (DQNEngine.gradient / apply_gradient) reproduce update_with_batch bit for bit."""
+    from tianshou_amd import dqn as D
+
+    c, h, w, A, B = 2, 44, 36, 3, 40
+    rng = np.random.default_rng(1)
+    p = OD.init_params(c, h, w, A, seed=4)
+    flat = D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, A)
+    cfg = D.DQNConfig(huber_delta=1.0, lr=1e-3, target_update_freq=2, max_grad_norm=0.5)
+    e1, e2 = D.DQNEngine(c, h, w, A, flat, cfg), D.DQNEngine(c, h, w, A, flat, cfg)
+    grad = torch.empty(e2.P, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        obs = torch.as_tensor(rng.integers(0, 256, size=(B, h, w, c)).astype(np.float32)).cuda()
+        act, ret = rng.integers(0, A, size=B), rng.normal(size=B).astype(np.float32)
+        l1, td1 = e1.update_with_batch(obs, act, ret)
+        l2, td2 = e2.gradient(obs, act, ret, None, grad)
+        e2.apply_gradient(grad)
+        assert torch.equal(td1, td2) and torch.equal(l1, l2)
+        assert torch.equal(e1.params, e2.params) and torch.equal(e1.params_old, e2.params_old)
+        assert (e1.iter, e1.adam_step) == (e2.iter, e2.adam_step)
