@@ -365,10 +365,10 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
                     float* out, ts_stream_t stream);
 
 typedef struct ts_dqn_hparams {
-    float lr;            /* < 0: compute the gradient only (no optimizer step) */
-    float beta1, beta2, adam_eps;
-    float huber_delta;   /* > 0: Huber loss, mean, PER weights ignored (dqn.py:392-398); else (td^2 * w).mean() */
-    float max_grad_norm; /* <= 0: no clipping */
+    double lr;            /* < 0: compute the gradient only (no optimizer step) */
+    double beta1, beta2, adam_eps;
+    double huber_delta;   /* > 0: Huber loss, mean, PER weights ignored (dqn.py:392-398); else (td^2 * w).mean() */
+    double max_grad_norm; /* <= 0: no clipping */
 } ts_dqn_hparams;
 
 /* DQN._update_with_batch (dqn.py:381-404) without the periodic target sync (ts_polyak_update, tau = 1):

@@ -10,6 +10,8 @@
 // Xcol is never materialised: with NHWC activations the (kw, ic) part of k is contiguous in memory, so
 // a 32-wide k chunk of one output pixel is one (or a few) 16-byte aligned runs, loaded with clamped
 // unconditional float4 loads and staged through LDS.  Roofline: fp32 MFMA; see DESIGN.md.
+#include <cstdlib>
+
 #include "ts_common.h"
 #include "ts_conv.h"
 
@@ -377,10 +379,16 @@ GemmArgs base_args(const ts::ConvGeom& g) {
 
 constexpr int TARGET_WGS = 768;    // 256 CUs x ~3 workgroups
 
-// halve the row tile when the full-size tiling would leave CUs without a workgroup
+// Row-tile choice.  Measured at the C3 / C5 shapes (scripts/gpu_conv_micro.py): the half-size tiles (128 x 32,
+// 64 x 64) win everywhere (conv1 53.5 -> 46.6 us, conv2 47.7 -> 39.3, fc1 35.5 -> 29.7): with twice as many,
+// shorter workgroups the prologue loads / epilogue stores of one overlap the MFMA phase of another instead of
+// every workgroup of a single resident round hitting them in lock step.  The full-size tiles stay for very large
+// grids, where they halve the weight-tile traffic.
 bool small_rows(int M, int bn, int other_tiles) {
+    static const char* force = getenv("TS_CONV_SMALL");      // experiments: "1" / "0" force the choice
+    if (force) return force[0] == '1';
     const int bm = bn == 64 ? 128 : 256;
-    return ts::ceil_div(M, bm) * other_tiles < 256;
+    return ts::ceil_div(M, bm) * other_tiles < 8192;
 }
 
 }  // namespace

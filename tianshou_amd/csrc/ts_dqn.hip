@@ -134,34 +134,32 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     dh4[i] = h4[i] > 0.f ? dq[b] * wb[(int64_t)k * A + act[b]] : 0.f;
 }
 
-// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1).  One workgroup per k:
-// thread t owns the samples b = t (mod 256) in batch order, then a fixed-order tree per action.
+// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1).  One workgroup per k: thread t
+// owns the samples b = t (mod 256) in batch order; per action a wave shuffle tree, then the 4 wave sums in order.
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
                                                          const float* __restrict__ h4, int64_t B, int A,
                                                          float* __restrict__ dwb) {
-    __shared__ float red[256];
-    const int k = blockIdx.x;
-    float acc[MAX_ACT];
+    __shared__ float red[4][MAX_ACT];
+    const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a0 = 0; a0 < A; a0 += 8) {                     // 8 actions per pass keeps the accumulators in registers
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t b = threadIdx.x; b < B; b += 256) {
+            const float v = (k < HIDDEN ? h4[b * HIDDEN + k] : 1.f) * dq[b];
+            const int ab = (int)act[b] - a0;
 #pragma unroll
-    for (int a = 0; a < MAX_ACT; ++a) acc[a] = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 256) {
-        const float v = (k < HIDDEN ? h4[b * HIDDEN + k] : 1.f) * dq[b];
-        const int ab = (int)act[b];
-#pragma unroll
-        for (int a = 0; a < MAX_ACT; ++a) acc[a] += a == ab ? v : 0.f;
-    }
-#pragma unroll
-    for (int a = 0; a < MAX_ACT; ++a) {
-        if (a >= A) break;
-        red[threadIdx.x] = acc[a];
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-            __syncthreads();
+            for (int a = 0; a < 8; ++a) acc[a] += a == ab ? v : 0.f;
         }
-        if (threadIdx.x == 0) dwb[k * A + a] = red[0];
-        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            float s = acc[a];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) red[wave][a0 + a] = s;
+        }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < A)
+        dwb[k * A + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 struct Scratch {           // carve of the workspace for one network pass over B samples
@@ -294,7 +292,7 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     // forward (keeps the activations), loss
     if (int rc = net_forward(s, ws, n, params, obs_nhwc, B, sc, sc.q, nullptr)) return rc;
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
-                       hp->huber_delta, td_out, dq, loss_out);
+                       (float)hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
     // head backward
     hipLaunchKernelGGL(head_wgrad_kernel, dim3(HIDDEN + 1), dim3(256), 0, s, dq, act, sc.h[3], B, n.n_act,
@@ -311,7 +309,7 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         if (i > 0)
             if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1], ws)) return rc;
     }
-    if (hp->lr < 0.f) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
+    if (hp->lr < 0.0) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);
 }

@@ -33,8 +33,8 @@ TIANSHOU_KEYS = ["net.0.0.weight", "net.0.0.bias", "net.0.2.weight", "net.0.2.bi
 class DQNHParams(C.Structure):
     """struct ts_dqn_hparams (include/tsengine.h)."""
 
-    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("adam_eps", C.c_float),
-                ("huber_delta", C.c_float), ("max_grad_norm", C.c_float)]
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+                ("huber_delta", C.c_double), ("max_grad_norm", C.c_double)]
 
 
 def _lib_dqn():
