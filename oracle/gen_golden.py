@@ -558,6 +558,12 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_cnn":
+        # atari_ppo.py defaults: eps 0.1, vf 0.25, ent 0.01, max_grad_norm 0.5, value_clip, adv norm, no return scaling
+        gen_ppo_cnn(gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=False,
+                    eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
+                    recompute_advantage=False, max_batchsize=32)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sac":
         gen_sac_all()
         return
@@ -578,6 +584,9 @@ def main() -> None:
             return_scaling=True, lr=7e-4, max_batchsize=256)
     gen_dqn_all()
     gen_sac_all()
+    gen_ppo_cnn(gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=False,
+                eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
+                recompute_advantage=False, max_batchsize=32)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
@@ -686,6 +695,97 @@ def gen_sac_all() -> None:
     gen_sac("auto", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=4, auto_alpha=True)
     gen_sac("fixed", E=2, slots=40, steps=40, obs_dim=376, act_dim=17, batch=48, n_updates=2, seed=6,
             auto_alpha=False, alpha=0.2, n_step=3, tau=0.01, gamma=0.97, actor_lr=3e-4)
+
+
+def gen_ppo_cnn(tag: str = "cnn", *, E: int = 3, T: int = 20, c: int = 2, h: int = 44, w: int = 36, n_act: int = 4,
+                batch_size: int = 16, repeat: int = 2, seed: int = 8, **ppo_kwargs) -> None:
+    """Runs the reference PPO.update() with the Atari actor-critic of examples/atari/atari_ppo.py:106-118 (shared
+    DQNet feature trunk, DiscreteActor / DiscreteCritic, Categorical policy) on a synthetic VectorReplayBuffer."""
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy
+    from tianshou.env.atari.atari_network import DQNet
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from oracle import oracle_ppo_cnn as OC
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net = DQNet(c=c, h=h, w=w, action_shape=n_act, features_only=True, output_dim_added_layer=512)
+    actor = DiscreteActor(preprocess_net=net, action_shape=n_act, softmax_output=False)
+    critic = DiscreteCritic(preprocess_net=net)
+    p0 = OC.init_params(c, h, w, n_act, seed)
+    sa, sc = actor.state_dict(), critic.state_dict()
+    ref = [sa[k] for k in OC.TRUNK_KEYS] + [sa[k] for k in OC.HEAD_KEYS] + [sc[k] for k in OC.HEAD_KEYS]
+    for t, k in zip(ref, OC.PARAM_ORDER):
+        assert torch.equal(t, p0[k]), f"oracle init differs from the reference at {k}"
+    policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
+    lr = ppo_kwargs.pop("lr", 2.5e-4)
+    algorithm = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr, eps=1e-5), **ppo_kwargs)
+
+    def flat():
+        sa, sc = actor.state_dict(), critic.state_dict()
+        ts = [sa[k] for k in OC.TRUNK_KEYS] + [sa[k] for k in OC.HEAD_KEYS] + [sc[k] for k in OC.HEAD_KEYS]
+        return torch.cat([t.reshape(-1) for t in ts]).numpy().copy()
+
+    N = E * T
+    buf = VectorReplayBuffer(N, E)
+    frames = rng.integers(0, 256, size=(T + 1, E, c, h, w), dtype=np.uint8)
+    frames = np.where(rng.random(frames.shape) < 0.08, frames, 0).astype(np.uint8)
+    act = rng.integers(0, n_act, size=(T, E))
+    rew = rng.normal(size=(T, E)).astype(np.float32)
+    term = rng.random((T, E)) < 0.06
+    trunc = (rng.random((T, E)) < 0.04) & ~term
+    for t in range(T):
+        buf.add(Batch(obs=frames[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t],
+                      obs_next=frames[t + 1]))
+    out: dict[str, np.ndarray] = {"dims": np.array([E, T, c, h, w, n_act, batch_size, repeat, seed])}
+    out["obs"], out["obs_next"] = np.asarray(buf.obs, np.uint8), np.asarray(buf.obs_next, np.uint8)
+    out["act"], out["rew"] = np.asarray(buf.act, np.int64), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    perms, seqs, pre_dump = [], [], {}
+    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, PPO._preprocess_batch
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p, np.int64))
+        return p
+
+    def rec_from(cls, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(cls, seq)
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        pre_dump.update(v_s=b.v_s.numpy().copy(), returns=b.returns.numpy().copy(), adv=b.adv.numpy().copy(),
+                        logp_old=b.logp_old.numpy().copy(), indices=np.asarray(indices, np.int64),
+                        unfinished=np.asarray(buffer.unfinished_index(), np.int64))
+        return b
+
+    np.random.permutation, PPO._preprocess_batch = rec_perm, rec_pre
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    try:
+        np.random.seed(seed + 100)
+        with policy_within_training_step(algorithm.policy):
+            stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+    finally:
+        np.random.permutation, PPO._preprocess_batch = orig_perm, orig_pre
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+    assert len(perms) == repeat and len(seqs) == 4
+    out["perms"], out["losses"] = np.stack(perms), np.stack(seqs, axis=1)
+    out["gradient_steps"] = np.array(stats.gradient_steps)
+    out["params_strided"] = flat()[::17]
+    out["ret_rms"] = np.array([float(algorithm.ret_rms.mean), float(algorithm.ret_rms.var), float(algorithm.ret_rms.count)])
+    for k, v in pre_dump.items():
+        out["pre_" + k] = v
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
+               dual_clip=algorithm.dual_clip or 0.0, value_clip=float(algorithm.value_clip),
+               advantage_normalization=float(algorithm.advantage_normalization), vf_coef=algorithm.vf_coef,
+               ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
+               return_scaling=float(algorithm.return_scaling), lr=lr, adam_eps=1e-5,
+               max_batchsize=float(algorithm.max_batchsize))
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
 def gen_dqn_all() -> None:

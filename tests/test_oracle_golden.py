@@ -306,3 +306,38 @@ def test_sac_restatement_matches_reference(tag):
                             ("critic1_old", OS.CRITIC_ORDER), ("critic2_old", OS.CRITIC_ORDER)):
             flat = OS.flatten(getattr(st, name), order).numpy()
             np.testing.assert_allclose(flat[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------ PPO on the Atari actor-critic
+def load_ppo_cnn():
+    from oracle import oracle_ppo as OPm
+
+    g = load("ppo_cnn.npz")
+    E, T, c, h, w, n_act, batch_size, repeat, seed = (int(x) for x in g["dims"])
+    cv = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OPm.PPOConfig(gamma=cv["gamma"], gae_lambda=cv["gae_lambda"], eps_clip=cv["eps_clip"],
+                        dual_clip=cv["dual_clip"] or None, value_clip=bool(cv["value_clip"]),
+                        advantage_normalization=bool(cv["advantage_normalization"]), vf_coef=cv["vf_coef"],
+                        ent_coef=cv["ent_coef"], max_grad_norm=cv["max_grad_norm"] or None,
+                        return_scaling=bool(cv["return_scaling"]), lr=cv["lr"], adam_eps=cv["adam_eps"],
+                        max_batchsize=int(cv["max_batchsize"]))
+    return g, dict(E=E, T=T, c=c, h=h, w=w, n_act=n_act, batch_size=batch_size, repeat=repeat, seed=seed), cfg
+
+
+def test_ppo_cnn_restatement_matches_reference():
+    """oracle_ppo_cnn (shared DQNet trunk, Categorical policy, GAE, clipped surrogate + clipped value + entropy,
+    clip_grad_norm_ + Adam) against the unmodified reference PPO.update()."""
+    from oracle import oracle_ppo_cnn as OC
+
+    g, d, cfg = load_ppo_cnn()
+    st = OP.PPOState(params=OC.init_params(d["c"], d["h"], d["w"], d["n_act"], d["seed"]))
+    idx, unf = g["pre_indices"], g["pre_unfinished"]
+    assert np.array_equal(idx, np.arange(d["E"] * d["T"]))
+    pre = OC.preprocess(st, cfg, g["obs"], g["obs_next"], g["act"], g["rew"], g["terminated"], g["truncated"], idx, unf)
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].numpy(), g["pre_" + k], rtol=1e-5, atol=1e-5, err_msg=k)
+    losses = OC.update(st, cfg, g["obs"], g["act"], pre, d["batch_size"], d["repeat"], g["perms"])
+    assert len(losses) == int(g["gradient_steps"])
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(OC.flatten_params(st.params).numpy()[::17], g["params_strided"], rtol=1e-5,
+                               atol=0.02 * cfg.lr)
