@@ -381,6 +381,35 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   float* loss_out, float* grad_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-118): DQNet(features_only=True,
+ * output_dim_added_layer=512) shared by DiscreteActor(softmax_output=False) and DiscreteCritic, Categorical policy
+ * ------------------------------------------------------------------------------------------- */
+
+/* Flat parameter vector: conv1 | conv2 | conv3 | fc [F + 1, 512] (as ts_dqn_param_count) | head [513, 32] with
+ * columns [0, n_act) = DiscreteActor.last (logits), column n_act = DiscreteCritic.last (V), the rest zero.
+ * h_offsets7 = the five layer offsets, the total, and the head width (32); h_geom (nullable) int64[50].
+ * n_act <= 31. */
+int ts_cnn_ac_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t* h_offsets7, int64_t* h_geom);
+
+/* No-grad passes of PPO._preprocess_batch (a2c.py:122-129, ppo.py:157-161) on obs float32[B, h, w, c] (NHWC):
+ * v_out[b] = V(obs_b) (nullable); logp_out[b] = Categorical(logits(obs_b)).log_prob(act_b) (nullable, needs act);
+ * logits_out (nullable) float32[B, n_act].  One trunk pass serves all outputs. */
+int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                    const float* obs_nhwc, const int64_t* act, int64_t B, float* v_out, float* logp_out,
+                    float* logits_out, ts_stream_t stream);
+
+/* One minibatch of PPO._update_with_batch (ppo.py:179-216) + Optimizer.step: forward, Categorical log-prob /
+ * entropy, clipped surrogate (dual clip optional), (clipped) value loss, backward through both heads and the
+ * shared trunk, clip_grad_norm_ + Adam.  adv_stats (device float32[2] = {mean, unbiased std} of this minibatch's
+ * advantages) is used when hp->adv_norm.  losses_out4 = {loss, clip, vf, ent}; hp->lr < 0: gradient only;
+ * grad_out (nullable) float32[P] receives the unclipped gradient.  hp->algo must be 0. */
+int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                    int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act, const float* adv,
+                    const float* returns, const float* logp_old, const float* v_old, int64_t B,
+                    const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4, float* grad_out,
+                    ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * SAC (tanh-Gaussian actor with state-conditioned sigma, twin critics on concat(obs, act), hidden [256, 256])
  * nets as in examples/mujoco/mujoco_sac.py:82-104
  * ------------------------------------------------------------------------------------------- */

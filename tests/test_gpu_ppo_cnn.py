@@ -1,0 +1,105 @@
+"""GPU parity of PPO on the Atari actor-critic (shared NatureCNN trunk, Categorical policy) through the C ABI,
+against oracle/oracle_ppo_cnn.py (pinned to the reference by tests/golden/ppo_cnn.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_ppo as OP
+from oracle import oracle_ppo_cnn as OC
+from tests.test_oracle_golden import load_ppo_cnn
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def engine_cfg(cfg):
+    from tianshou_amd.ppo import PPOConfig
+
+    return PPOConfig(gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, eps_clip=cfg.eps_clip, dual_clip=cfg.dual_clip,
+                     value_clip=cfg.value_clip, advantage_normalization=cfg.advantage_normalization,
+                     vf_coef=cfg.vf_coef, ent_coef=cfg.ent_coef, max_grad_norm=cfg.max_grad_norm,
+                     return_scaling=cfg.return_scaling, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps)
+
+
+@pytest.mark.parametrize("c,h,w,A", [(4, 84, 84, 6), (2, 44, 36, 4), (1, 36, 36, 31)])
+def test_layout_round_trip_and_inference(c, h, w, A):
+    from tianshou_amd import ppo_cnn as PC
+
+    p = OC.init_params(c, h, w, A, seed=3)
+    tensors = [p[k] for k in OC.PARAM_ORDER]
+    flat = PC.flat_from_torch(tensors, c, h, w, A)
+    for a, b in zip(PC.flat_to_torch(flat, c, h, w, A), tensors):
+        assert torch.equal(a.cpu(), b)
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, size=(37, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=37)
+    eng = PC.CnnPPOEngine(c, h, w, A, flat, engine_cfg(OP.PPOConfig()))
+    v, logp, logits = eng.infer(torch.as_tensor(obs).permute(0, 2, 3, 1).float().contiguous().cuda(), act, True)
+    with torch.no_grad():
+        lg_ref = OC.actor_forward(p, obs)
+        v_ref = OC.critic_forward(p, obs).flatten()
+        lp_ref = torch.distributions.Categorical(logits=lg_ref).log_prob(torch.as_tensor(act))
+    assert rel_err(logits.cpu(), lg_ref) < 1e-5 and rel_err(v.cpu(), v_ref) < 1e-5
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_update_matches_reference_golden():
+    from tianshou_amd import ppo_cnn as PC
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, cfg = load_ppo_cnn()
+    c, h, w, A = d["c"], d["h"], d["w"], d["n_act"]
+    p0 = OC.init_params(c, h, w, A, d["seed"])
+    eng = PC.CnnPPOEngine(c, h, w, A, PC.flat_from_torch([p0[k] for k in OC.PARAM_ORDER], c, h, w, A), engine_cfg(cfg))
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"])
+    frames, frames_next = torch.as_tensor(g["obs"]).cuda(), torch.as_tensor(g["obs_next"]).cuda()
+    pre = eng.preprocess(buf, frames, torch.as_tensor(g["act"]).cuda(), 1, obs_next_frames=frames_next, chunk=17)
+    assert np.array_equal(pre["indices"].cpu().numpy(), g["pre_indices"])
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].cpu().numpy(), g["pre_" + k], rtol=1e-5, atol=2e-5, err_msg=k)
+    losses, steps = eng.update(buf, frames, pre, 1, d["batch_size"], d["repeat"], list(g["perms"]))
+    assert steps == int(g["gradient_steps"])
+    np.testing.assert_allclose(losses.cpu().numpy(), g["losses"], rtol=5e-5, atol=2e-6)
+    flat = torch.cat([t.reshape(-1) for t in PC.flat_to_torch(eng.params, c, h, w, A)]).cpu().numpy()
+    np.testing.assert_allclose(flat[::17], g["params_strided"], rtol=1e-5, atol=0.05 * cfg.lr)
+
+
+@pytest.mark.parametrize("adv_norm,dual,vclip", [(True, None, True), (False, 3.0, False)])
+def test_minibatch_gradient_vs_oracle(adv_norm, dual, vclip):
+    """Atari-size observations, B = 192: losses and every layer's gradient of one minibatch."""
+    from tianshou_amd import ppo_cnn as PC
+
+    c, h, w, A, B = 4, 84, 84, 6, 192
+    rng = np.random.default_rng(11)
+    obs = rng.integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=B)
+    adv = torch.as_tensor(rng.normal(size=B).astype(np.float32))
+    ret = torch.as_tensor(rng.normal(size=B).astype(np.float32) * 2)
+    p = OC.init_params(c, h, w, A, seed=6)
+    with torch.no_grad():
+        lg = OC.actor_forward(p, obs)
+        logp_old = torch.distributions.Categorical(logits=lg).log_prob(torch.as_tensor(act)) \
+            + torch.as_tensor(rng.normal(size=B).astype(np.float32) * 0.2)
+        v_old = OC.critic_forward(p, obs).flatten() + torch.as_tensor(rng.normal(size=B).astype(np.float32) * 0.3)
+    cfg = OP.PPOConfig(eps_clip=0.1, dual_clip=dual, value_clip=vclip, advantage_normalization=adv_norm, vf_coef=0.25,
+                       ent_coef=0.01, max_grad_norm=0.5, lr=2.5e-4, adam_eps=1e-5)
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, clip, vf, ent = OC.minibatch_loss(pg, cfg, torch.as_tensor(obs).float(), torch.as_tensor(act), adv, ret,
+                                            logp_old, v_old)
+    loss.backward()
+    eng = PC.CnnPPOEngine(c, h, w, A, PC.flat_from_torch([p[k] for k in OC.PARAM_ORDER], c, h, w, A), engine_cfg(cfg))
+    grad = torch.empty(eng.P, dtype=torch.float32, device="cuda")
+    obs_nhwc = torch.as_tensor(obs).permute(0, 2, 3, 1).float().contiguous().cuda()
+    losses = eng.step(obs_nhwc, act, adv.cuda(), ret.cuda(), logp_old.cuda(), v_old.cuda(), grad_out=grad, apply=False)
+    np.testing.assert_allclose(losses.cpu().numpy(), [loss.item(), clip.item(), vf.item(), ent.item()], rtol=2e-5,
+                               atol=1e-6)
+    g_ref = PC.flat_from_torch([pg[k].grad for k in OC.PARAM_ORDER], c, h, w, A, device="cpu")
+    off, _ = PC.layer_layout(c, h, w, A)
+    for i in range(5):
+        assert rel_err(grad[off[i]:off[i + 1]].cpu(), g_ref[off[i]:off[i + 1]]) < 2e-5, f"layer {i}"
