@@ -206,15 +206,20 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["ppo", "dqn", "sac"], default="ppo",
-                    help="ppo = BASELINE.json's metric (default); dqn / sac = the C3 / C5 rows (bench_dqn.py, "
-                         "bench_sac.py)")
+    ap.add_argument("--workload", choices=["ppo", "dqn", "sac", "ppo_atari"], default="ppo",
+                    help="ppo = BASELINE.json's metric on C2 (default); dqn / sac = the C3 / C5 rows (bench_dqn.py, "
+                         "bench_sac.py); ppo_atari = the north star's Atari-shape PPO (bench_ppo_cnn.py)")
     args = ap.parse_args()
     if args.workload != "ppo":
         import importlib
 
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+        if args.workload == "ppo_atari":
+            import bench_ppo_cnn
+
+            print(json.dumps(bench_ppo_cnn.run(1, 0, with_cpu=not args.no_cpu_baseline)), flush=True)
+            return
         mod = importlib.import_module("bench_" + args.workload)
         print(json.dumps(mod.run(max(args.steps, 1) * 10, max(args.warmup, 1) * 5,
                                  with_cpu=not args.no_cpu_baseline)), flush=True)
