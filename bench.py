@@ -117,7 +117,7 @@ class Learner:
         # np.random.permutation on the host (~10 ms per 2^20 entries), a sort-based torch.randperm
         # costs ~0.25 ms - either would be a visible part of the 13 ms update
         perms = [self.next_perm() for _ in range(REPEAT)]
-        if self.world == 1:
+        if self.world == 1 and not os.environ.get("TS_BENCH_FORCE_DP"):    # (env: time the DP host path at N = 1)
             losses, steps = self.eng.update(b, MINIBATCH, REPEAT, perms)
             return losses, steps
         return self._update_dp(b, perms)

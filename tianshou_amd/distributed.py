@@ -101,21 +101,21 @@ class DataParallelPPO:
                   else torch.as_tensor(np.asarray(p, dtype=np.int64), device=dev) for p in perms]
         rows_all = [perm_t[r][lo:hi] for r, lo, hi in steps]
         stats = global_adv_stats(b["adv"], rows_all, self.group) if cfg.advantage_normalization else None
-        if self._buf is None or self._buf.device != dev:
-            self._buf = torch.empty(eng.P + 4, dtype=torch.float32, device=dev)
-        out = self._buf
-        losses = []
+        # one [P + 4] row per gradient step: no copy of the loss parts, no reuse hazard between steps
+        width = (eng.P + 4 + 3) // 4 * 4                      # 16-byte aligned rows
+        if self._buf is None or self._buf.device != dev or self._buf.shape[0] < len(rows_all):
+            self._buf = torch.empty((len(rows_all), width), dtype=torch.float32, device=dev)
         for k, rows in enumerate(rows_all):
+            out = self._buf[k, : eng.P + 4]
             self._local_grad(rec, rows, rows.numel() * self.world, None if stats is None else stats[k], out)
             if self.world > 1:
                 dist.all_reduce(out, group=self.group)      # RCCL: gradient + loss parts in one call
             self._apply(out)
-            losses.append(out[eng.P:eng.P + 4].clone())
-        res = torch.stack(losses)
+        res = self._buf[: len(rows_all), eng.P:eng.P + 4].clone()
         # the entropy term depends on the parameters only: every rank added the same value
         res[:, 3] /= self.world
         res[:, 0] = res[:, 1] + cfg.vf_coef * res[:, 2] - cfg.ent_coef * res[:, 3]
-        return res, len(losses)
+        return res, len(rows_all)
 
 
 class DataParallelDQN:
