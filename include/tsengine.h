@@ -172,6 +172,22 @@ int ts_random_permutation(int64_t* out, int64_t n, uint64_t seed, ts_stream_t st
 int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const int64_t* index,
                    int64_t I, void* out, ts_stream_t stream);
 
+/* Write side: ReplayBufferManager.add (manager.py:131-198) with
+ * ReplayBuffer._update_state_pre_add (buffer_base.py:360-418) for K transitions addressed to DISTINCT
+ * sub-buffers buffer_ids[k] (NULL = 0..K-1), entirely on the device.  State per sub-buffer, all [E], updated in
+ * place: insertion (next write slot, relative to offset[e]), lengths, last_index (global), ep_return (float64),
+ * ep_len, ep_start (relative).  Writes rew / terminated / truncated / done at the new slots of the [B] columns,
+ * scatters the rows of up to 8 further keys (obs, act, obs_next, ...: h_keys is a HOST array of device
+ * pointers), and returns per entry what add() returns (manager.py:193-198): global index, episode return and
+ * length (0 unless the episode ended), global episode start index.  Bit-exact, float64 returns included. */
+typedef struct ts_scatter_key { void* dst; const void* src; int64_t row_bytes; } ts_scatter_key;
+int ts_buffer_add(const int64_t* buffer_ids, int64_t K, const double* rew, const uint8_t* terminated,
+                  const uint8_t* truncated, const int64_t* offset, int64_t E, int64_t* insertion, int64_t* lengths,
+                  int64_t* last_index, double* ep_return, int64_t* ep_len, int64_t* ep_start, double* rew_B,
+                  uint8_t* terminated_B, uint8_t* truncated_B, uint8_t* done_B, const ts_scatter_key* h_keys,
+                  int n_keys, int64_t* index_out, double* ep_return_out, int64_t* ep_len_out, int64_t* ep_start_out,
+                  ts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Sum tree / prioritized replay
  * ------------------------------------------------------------------------------------------- */

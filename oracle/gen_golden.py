@@ -558,6 +558,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "buffer_add":
+        gen_buffer_add()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_cnn":
         # atari_ppo.py defaults: eps 0.1, vf 0.25, ent 0.01, max_grad_norm 0.5, value_clip, adv norm, no return scaling
         gen_ppo_cnn(gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=False,
@@ -582,6 +585,7 @@ def main() -> None:
     gen_ppo("a2c", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=2,
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
+    gen_buffer_add()
     gen_dqn_all()
     gen_sac_all()
     gen_ppo_cnn(gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=False,
@@ -786,6 +790,43 @@ def gen_ppo_cnn(tag: str = "cnn", *, E: int = 3, T: int = 20, c: int = 2, h: int
                max_batchsize=float(algorithm.max_batchsize))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
+
+
+def gen_buffer_add() -> None:
+    """Random VectorReplayBuffer.add histories (ragged buffer_ids, ring wrap, episode ends): the tuple every
+    add() returns (manager.py:193-198) and the final buffer contents."""
+    out: dict[str, np.ndarray] = {}
+    rng = np.random.default_rng(99)
+    for s, (total, E, steps, p_done, obs_dim) in enumerate([(20, 4, 17, 0.3, 3), (64, 8, 60, 0.1, 5), (15, 3, 9, 0.0, 2),
+                                                           (36, 6, 80, 0.45, 4), (8, 1, 30, 0.2, 1)]):
+        buf = VectorReplayBuffer(total, E)
+        ids_l, cnt, rets = [], [], []
+        cols = {k: [] for k in ("rew", "term", "trunc", "obs", "act", "obs_next")}
+        for t in range(steps):
+            k = E if t % 3 == 0 else int(rng.integers(1, E + 1))
+            ids = np.arange(E) if k == E else np.sort(rng.choice(E, size=k, replace=False))
+            term = rng.random(k) < p_done
+            trunc = (rng.random(k) < p_done / 3) & ~term
+            b = Batch(obs=rng.normal(size=(k, obs_dim)).astype(np.float32), act=rng.integers(0, 5, size=k),
+                      rew=rng.normal(size=k), terminated=term, truncated=trunc,
+                      obs_next=rng.normal(size=(k, obs_dim)).astype(np.float32))
+            r = buf.add(b, buffer_ids=None if (k == E and t % 2 == 0) else ids)
+            ids_l.append(ids); cnt.append(k)
+            rets.append(np.stack([np.asarray(x, np.float64) for x in r], axis=1))
+            for key, v in zip(cols, (b.rew, term, trunc, b.obs, b.act, b.obs_next)):
+                cols[key].append(np.asarray(v))
+        out[f"s{s}_dims"] = np.array([total, E, steps, obs_dim])
+        out[f"s{s}_counts"] = np.array(cnt)
+        out[f"s{s}_ids"] = np.concatenate(ids_l)
+        out[f"s{s}_returned"] = np.concatenate(rets)          # [sum k, 4]: ptr, ep_rew, ep_len, ep_idx
+        for key, v in cols.items():
+            out[f"s{s}_in_{key}"] = np.concatenate(v)
+        for k2, v in manager_state(buf).items():
+            out[f"s{s}_final_{k2}"] = v
+        for key in ("obs", "act", "rew", "terminated", "truncated", "done", "obs_next"):
+            out[f"s{s}_final_{key}"] = np.asarray(getattr(buf, key))
+    out["n_scen"] = np.array(5)
+    np.savez_compressed(os.path.join(OUT, "buffer_add.npz"), **out)
 
 
 def gen_dqn_all() -> None:

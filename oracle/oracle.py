@@ -242,6 +242,34 @@ class BufferState:
         return _prev_index(index, self.offset, self.done, self.last_index, self.lengths)
 
 
+class BufferWriter:
+    """Write-side state of a ReplayBufferManager (manager.py:131-198, buffer_base.py:360-418): per sub-buffer
+    insertion slot, length, last index, running episode return / length / start; plus the scalar columns."""
+
+    def __init__(self, offset):
+        self.offset = _i64(offset)
+        E, B = self.offset.size - 1, int(self.offset[-1])
+        self.insertion, self.lengths = np.zeros(E, np.int64), np.zeros(E, np.int64)
+        self.last_index = self.offset[:-1].copy()                       # manager.py:52
+        self.ep_return, self.ep_len, self.ep_start = np.zeros(E), np.zeros(E, np.int64), np.zeros(E, np.int64)
+        self.rew, self.terminated = np.zeros(B), np.zeros(B, np.uint8)
+        self.truncated, self.done = np.zeros(B, np.uint8), np.zeros(B, np.uint8)
+
+    def add(self, rew, terminated, truncated, buffer_ids=None):
+        """-> (insertion index, episode return, episode length, episode start index), manager.py:193-198."""
+        rew, term, trunc = _f64(rew), _u8(terminated), _u8(truncated)
+        K = rew.size
+        ids = None if buffer_ids is None else _i64(buffer_ids)
+        idx, er = np.zeros(K, np.int64), np.zeros(K)
+        el, es = np.zeros(K, np.int64), np.zeros(K, np.int64)
+        lib().oracle_buffer_add(_p(ids) if ids is not None else None, C.c_int64(K), _p(rew), _p(term), _p(trunc),
+                                _p(self.offset), _p(self.insertion), _p(self.lengths), _p(self.last_index),
+                                _p(self.ep_return), _p(self.ep_len), _p(self.ep_start), _p(self.rew),
+                                _p(self.terminated), _p(self.truncated), _p(self.done), _p(idx), _p(er), _p(el),
+                                _p(es))
+        return idx, er, el, es
+
+
 def compute_episodic_return(rew, terminated, truncated, indices, unfinished, v_s_, v_s,
                             gamma: float = 0.99, gae_lambda: float = 0.95):
     """algorithm_base.py:653-719 on raw arrays -> (returns, advantage) float64[N].

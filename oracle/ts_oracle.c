@@ -338,3 +338,35 @@ void oracle_rms_update(double* state, const double* x, int64_t n) {
     state[1] = m_2 / total_count;
     state[2] = total_count;
 }
+
+/* ReplayBufferManager.add index / episode bookkeeping (tianshou/data/buffer/manager.py:131-198) with
+ * ReplayBuffer._update_state_pre_add (data/buffer/buffer_base.py:360-418) for every entry, in order.
+ * State per sub-buffer e: insertion[e] (next write slot, relative), lengths[e], last_index[e] (global),
+ * ep_return[e], ep_len[e], ep_start[e] (relative).  Outputs per entry: global insertion index, episode
+ * return / length (0 unless done), global episode start index.  Also scatters rew / flags / done. */
+void oracle_buffer_add(const int64_t* buffer_ids, int64_t K, const double* rew, const uint8_t* terminated,
+                       const uint8_t* truncated, const int64_t* offset, int64_t* insertion, int64_t* lengths,
+                       int64_t* last_index, double* ep_return, int64_t* ep_len, int64_t* ep_start,
+                       double* rew_B, uint8_t* terminated_B, uint8_t* truncated_B, uint8_t* done_B,
+                       int64_t* index_out, double* ep_return_out, int64_t* ep_len_out, int64_t* ep_start_out) {
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t e = buffer_ids ? buffer_ids[k] : k;
+        const int64_t maxsize = offset[e + 1] - offset[e];
+        const int done = terminated[k] || truncated[k];                 /* manager.py:150 */
+        const int64_t cur = insertion[e];                               /* buffer_base.py:381 */
+        lengths[e] = lengths[e] + 1 < maxsize ? lengths[e] + 1 : maxsize;   /* :382 */
+        insertion[e] = (cur + 1) % maxsize;                             /* :383 */
+        ep_return[e] += rew[k];                                         /* :385 */
+        ep_len[e] += 1;                                                 /* :386 */
+        index_out[k] = cur + offset[e];                                 /* manager.py:170 */
+        ep_return_out[k] = done ? ep_return[e] : 0.0;                   /* buffer_base.py:397-410 */
+        ep_len_out[k] = done ? ep_len[e] : 0;
+        ep_start_out[k] = ep_start[e] + offset[e];                      /* manager.py:171 */
+        if (done) { ep_return[e] = 0.0; ep_len[e] = 0; ep_start[e] = insertion[e]; }   /* :414-418 */
+        last_index[e] = cur + offset[e];                                /* manager.py:176 */
+        rew_B[index_out[k]] = rew[k];                                   /* manager.py:180: _meta[idx] = batch */
+        terminated_B[index_out[k]] = terminated[k] != 0;
+        truncated_B[index_out[k]] = truncated[k] != 0;
+        done_B[index_out[k]] = (uint8_t)done;
+    }
+}

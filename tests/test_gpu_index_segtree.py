@@ -175,3 +175,35 @@ def test_polyak_update_bit_exact_vs_torch(n):
     assert torch.equal(d_tgt.cpu(), ref)
     full_parameter_update(d_tgt, d_src)
     assert torch.equal(d_tgt.cpu(), src)
+
+
+def test_buffer_add_matches_reference_history_bit_exact():
+    """Device-side VectorReplayBuffer.add replayed over the reference's recorded histories:
+    every returned tuple and the final buffer contents, bit for bit (float64 episode returns included)."""
+    from tests.test_oracle_golden import load, replay_buffer_add
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g = load("buffer_add.npz")
+    for s in range(int(g["n_scen"])):
+        total, E, steps, obs_dim = (int(x) for x in g[f"s{s}_dims"])
+
+        def make(off, d):
+            return DeviceReplayBuffer.empty(total, E, (d,), (), act_dtype=torch.int64)
+
+        def add(buf, rows, ids):
+            full = len(ids) == E and np.array_equal(ids, np.arange(E))
+            out = buf.add(rows["obs"], rows["act"], rows["rew"], rows["term"], rows["trunc"], rows["obs_next"],
+                          None if full else ids)
+            return [t.cpu().numpy() for t in out]
+
+        buf = replay_buffer_add(g, s, make, add)
+        for key in ("obs", "act", "rew", "obs_next"):
+            assert np.array_equal(getattr(buf, key).cpu().numpy(), g[f"s{s}_final_{key}"]), (s, key)
+        for key in ("terminated", "truncated", "done"):
+            assert np.array_equal(getattr(buf, key).cpu().numpy().astype(bool), g[f"s{s}_final_{key}"]), (s, key)
+        for key in ("last_index", "lengths", "insertion"):
+            assert np.array_equal(getattr(buf, key).cpu().numpy(), g[f"s{s}_final_{key}"]), (s, key)
+        assert len(buf) == int(g[f"s{s}_final_lengths"].sum())
+        assert np.array_equal(buf.unfinished_index().cpu().numpy(),
+                              O.unfinished_index(g[f"s{s}_final_offset"], g[f"s{s}_final_done"],
+                                                 g[f"s{s}_final_last_index"], g[f"s{s}_final_lengths"]))

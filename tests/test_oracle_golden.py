@@ -341,3 +341,34 @@ def test_ppo_cnn_restatement_matches_reference():
     np.testing.assert_allclose(losses, g["losses"], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(OC.flatten_params(st.params).numpy()[::17], g["params_strided"], rtol=1e-5,
                                atol=0.02 * cfg.lr)
+
+
+# ------------------------------------------------------------------------------------ write side
+def replay_buffer_add(g, s, make_writer, add):
+    """Replays scenario s of buffer_add.npz through `add(writer, rows, ids)`; returns the writer."""
+    total, E, steps, obs_dim = (int(x) for x in g[f"s{s}_dims"])
+    T = total // E
+    wr = make_writer(np.arange(E + 1) * T, obs_dim)
+    pos = 0
+    for t, k in enumerate(g[f"s{s}_counts"]):
+        k = int(k)
+        sl = slice(pos, pos + k)
+        ret = add(wr, {key: g[f"s{s}_in_{key}"][sl] for key in ("rew", "term", "trunc", "obs", "act", "obs_next")},
+                  g[f"s{s}_ids"][sl])
+        got = np.stack([np.asarray(x, np.float64) for x in ret], axis=1)
+        assert np.array_equal(got, g[f"s{s}_returned"][sl]), (s, t)          # bit-exact, incl. the f64 returns
+        pos += k
+    return wr
+
+
+def test_buffer_add_restatement_matches_reference():
+    g = load("buffer_add.npz")
+    for s in range(int(g["n_scen"])):
+        wr = replay_buffer_add(g, s, lambda off, d: O.BufferWriter(off),
+                               lambda w, rows, ids: w.add(rows["rew"], rows["term"], rows["trunc"], ids))
+        assert np.array_equal(wr.last_index, g[f"s{s}_final_last_index"])
+        assert np.array_equal(wr.lengths, g[f"s{s}_final_lengths"])
+        assert np.array_equal(wr.insertion, g[f"s{s}_final_insertion"])
+        assert np.array_equal(wr.rew, g[f"s{s}_final_rew"])
+        assert np.array_equal(wr.done.astype(bool), g[f"s{s}_final_done"])
+        assert np.array_equal(wr.terminated.astype(bool), g[f"s{s}_final_terminated"])

@@ -117,6 +117,8 @@ class DeviceReplayBuffer:
         ).contiguous()
         self.obs, self.act, self.obs_next = to(obs), to(act), to(obs_next)
         self._ws_cache = None
+        self._ep = None              # (ep_return f64[E], ep_len i64[E], ep_start i64[E] relative), created by add()
+        self._host_stale = False
 
     @property
     def _ws(self):
@@ -136,6 +138,79 @@ class DeviceReplayBuffer:
         offset = np.arange(n_env + 1, dtype=np.int64) * T
         return cls(offset=offset, last_index=offset[:-1] + T - 1,
                    lengths=np.full(n_env, T, np.int64), insertion=np.zeros(n_env, np.int64), **arrays)
+
+    @classmethod
+    def empty(cls, total_size: int, n_env: int, obs_shape, act_shape=(), *, obs_dtype=torch.float32,
+              act_dtype=torch.float32, save_obs_next: bool = True, device="cuda"):
+        """A fresh VectorReplayBuffer(total_size, n_env) (vecbuf.py: equal sub-buffers of
+        ceil(total_size / n_env) slots), to be filled with add()."""
+        size = -(-total_size // n_env)
+        B = size * n_env
+        offset = np.arange(n_env + 1, dtype=np.int64) * size
+        obs = torch.zeros((B, *tuple(obs_shape)), dtype=obs_dtype, device=device)
+        act = torch.zeros((B, *tuple(act_shape)), dtype=act_dtype, device=device)
+        return cls(offset=offset, last_index=offset[:-1].copy(), lengths=np.zeros(n_env, np.int64),
+                   insertion=np.zeros(n_env, np.int64), rew=torch.zeros(B, dtype=torch.float64, device=device),
+                   terminated=torch.zeros(B, dtype=torch.uint8, device=device),
+                   truncated=torch.zeros(B, dtype=torch.uint8, device=device), obs=obs, act=act,
+                   obs_next=torch.zeros_like(obs) if save_obs_next else None, device=device)
+
+    # -- write side (SURVEY 8f N1) -----------------------------------------------------------------
+    def add(self, obs, act, rew, terminated, truncated, obs_next=None, buffer_ids=None):
+        """ReplayBufferManager.add (manager.py:131-198) on device tensors: one transition for each of the
+        distinct sub-buffers `buffer_ids` (None = all, in order).  Returns the reference's tuple
+        (current_index int64, episode_reward float64, episode_length int64, episode_start_index int64) as device
+        tensors; the host copies of the manager state are refreshed lazily (see _sync_host)."""
+        dev = self.device
+        if self._ep is None:
+            E = self.buffer_num
+            self._ep = (torch.zeros(E, dtype=torch.float64, device=dev), torch.zeros(E, dtype=torch.int64, device=dev),
+                        (self.insertion * 0 + torch.as_tensor(self.h_insertion, device=dev)).contiguous())
+        ids = None if buffer_ids is None else _i64_dev(buffer_ids, dev).reshape(-1)
+        rew = torch.as_tensor(rew, device=dev).to(torch.float64).reshape(-1).contiguous()
+        K = rew.numel()
+        if ids is not None and ids.numel() != K:
+            raise ValueError("buffer_ids / batch length mismatch")
+        if ids is None and K != self.buffer_num:
+            raise ValueError("without buffer_ids the batch must have one row per sub-buffer")
+        term, trunc = _u8_dev(terminated, dev).reshape(-1), _u8_dev(truncated, dev).reshape(-1)
+        keys = []
+        rows = {"obs": obs, "act": act, "obs_next": obs_next}
+        hold = []
+        for name, val in rows.items():
+            dst = getattr(self, name)
+            if dst is None or val is None:
+                continue
+            src = torch.as_tensor(val, device=dev).to(dst.dtype).reshape(K, -1).contiguous()
+            hold.append(src)
+            rb = dst.element_size() * int(np.prod(dst.shape[1:], dtype=np.int64))
+            if src.shape[1] * src.element_size() != rb:
+                raise ValueError(f"{name}: row shape does not match the buffer")
+            keys.append((dst.data_ptr(), src.data_ptr(), rb))
+
+        class _Key(C.Structure):
+            _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("row_bytes", C.c_int64)]
+
+        arr = (_Key * max(len(keys), 1))(*[_Key(*k) for k in keys])
+        idx = torch.empty(K, dtype=torch.int64, device=dev)
+        ep_ret = torch.empty(K, dtype=torch.float64, device=dev)
+        ep_len, ep_start = torch.empty_like(idx), torch.empty_like(idx)
+        _lib.check(_lib.load().ts_buffer_add(
+            _lib.ptr(ids), _lib.i64(K), _lib.ptr(rew), _lib.ptr(term), _lib.ptr(trunc), _lib.ptr(self.offset),
+            _lib.i64(self.buffer_num), _lib.ptr(self.insertion), _lib.ptr(self.lengths), _lib.ptr(self.last_index),
+            _lib.ptr(self._ep[0]), _lib.ptr(self._ep[1]), _lib.ptr(self._ep[2]), _lib.ptr(self.rew),
+            _lib.ptr(self.terminated), _lib.ptr(self.truncated), _lib.ptr(self.done), arr, C.c_int(len(keys)),
+            _lib.ptr(idx), _lib.ptr(ep_ret), _lib.ptr(ep_len), _lib.ptr(ep_start), _lib.current_stream(dev)))
+        self._host_stale = True
+        return idx, ep_ret, ep_len, ep_start
+
+    def _sync_host(self) -> None:
+        """Refreshes the host copies of the (tiny) manager state after device-side add() calls."""
+        if self._host_stale:
+            self.h_last_index = self.last_index.cpu().numpy()
+            self.h_lengths = self.lengths.cpu().numpy()
+            self.h_insertion = self.insertion.cpu().numpy()
+            self._host_stale = False
 
     @classmethod
     def from_tianshou(cls, buffer, device="cuda"):
@@ -198,6 +273,7 @@ class DeviceReplayBuffer:
 
     # -- reference API ------------------------------------------------------------------------
     def __len__(self) -> int:
+        self._sync_host()
         return int(self.h_lengths.sum())
 
     def next(self, index) -> torch.Tensor:
@@ -236,6 +312,7 @@ class DeviceReplayBuffer:
 
     def indices_are_identity(self) -> bool:
         """True when sample_indices(0) == arange(B): every sub-buffer full and unwrapped."""
+        self._sync_host()
         size = np.diff(self.h_offset)
         return bool(np.all(self.h_lengths == size) and np.all(self.h_insertion % size == 0))
 

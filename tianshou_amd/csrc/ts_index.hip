@@ -4,6 +4,8 @@
 // ReplayBufferManager.unfinished_index (:85-91), sample_indices(0) (:216-234) and the
 // fancy-index gathers of ReplayBuffer.__getitem__ (tianshou/data/buffer/buffer_base.py:605-649).
 // Roofline: HBM / latency (8 B index read + 8 B write + one 1-byte `done` gather per query).
+#include <algorithm>
+
 #include "ts_common.h"
 
 namespace {
@@ -88,6 +90,64 @@ __global__ __launch_bounds__(256) void gather_planes_kernel(const uint8_t* __res
         } else {
             for (int c = 0; c < Cn; ++c) out[(b * plane_elems + p) * Cn + c] = (float)src[pl[c] * plane_elems + p];
         }
+    }
+}
+
+// ReplayBufferManager.add bookkeeping (manager.py:131-198 + buffer_base.py:360-418), one thread per entry.
+// Entries must address distinct sub-buffers (as every collector step does); then the per-entry updates are
+// independent and the float64 episode-return accumulation is the reference's, bit for bit.
+struct AddArgs {
+    const int64_t* ids; int64_t K;
+    const double* rew; const uint8_t* term; const uint8_t* trunc;
+    const int64_t* offset;
+    int64_t* insertion; int64_t* lengths; int64_t* last_index; double* ep_return; int64_t* ep_len; int64_t* ep_start;
+    double* rew_B; uint8_t* term_B; uint8_t* trunc_B; uint8_t* done_B;
+    int64_t* index_out; double* ep_return_out; int64_t* ep_len_out; int64_t* ep_start_out;
+};
+
+__global__ __launch_bounds__(256) void buffer_add_state_kernel(AddArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.K) return;
+    const int64_t e = a.ids ? a.ids[k] : k;
+    const int64_t start = a.offset[e], maxsize = a.offset[e + 1] - start;
+    const bool done = a.term[k] || a.trunc[k];                        // manager.py:150
+    const int64_t cur = a.insertion[e];                                // buffer_base.py:381
+    const int64_t len = a.lengths[e];
+    a.lengths[e] = len + 1 < maxsize ? len + 1 : maxsize;              // :382
+    const int64_t nxt = (cur + 1) % maxsize;                           // :383
+    a.insertion[e] = nxt;
+    const double er = a.ep_return[e] + a.rew[k];                       // :385
+    const int64_t el = a.ep_len[e] + 1;                                // :386
+    const int64_t idx = cur + start;                                   // manager.py:170
+    a.index_out[k] = idx;
+    a.ep_return_out[k] = done ? er : 0.0;                              // buffer_base.py:397-410
+    a.ep_len_out[k] = done ? el : 0;
+    a.ep_start_out[k] = a.ep_start[e] + start;                         // manager.py:171
+    a.ep_return[e] = done ? 0.0 : er;                                  // :414-418
+    a.ep_len[e] = done ? 0 : el;
+    if (done) a.ep_start[e] = nxt;
+    a.last_index[e] = idx;                                             // manager.py:176
+    a.rew_B[idx] = a.rew[k];
+    a.term_B[idx] = a.term[k] != 0;
+    a.trunc_B[idx] = a.trunc[k] != 0;
+    a.done_B[idx] = done;
+}
+
+struct ScatterKeys { void* dst[8]; const void* src[8]; int64_t row_bytes[8]; int n; };
+
+// dst_key[index[k]] = src_key[k] for up to 8 keys in one launch (blockIdx.y = key); 16-byte path when aligned
+__global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterKeys keys, const int64_t* __restrict__ index, int64_t K) {
+    const int key = blockIdx.y;
+    const int64_t rb = keys.row_bytes[key];
+    char* dst = static_cast<char*>(keys.dst[key]);
+    const char* src = static_cast<const char*>(keys.src[key]);
+    const bool vec = (rb % 16 == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0);
+    const int64_t unit = vec ? 16 : 1, per_row = rb / unit, total = K * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / per_row, j = i - k * per_row;
+        const int64_t row = index[k];
+        if (vec) reinterpret_cast<uint4*>(dst + row * rb)[j] = reinterpret_cast<const uint4*>(src + k * rb)[j];
+        else dst[row * rb + j] = src[k * rb + j];
     }
 }
 
@@ -365,6 +425,42 @@ int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_el
     else
         hipLaunchKernelGGL(gather_planes_kernel<0>, grid, dim3(256), 0, ts::as_stream(stream), src, plane_elems,
                            plane_index, B, (int)C, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_buffer_add(const int64_t* buffer_ids, int64_t K, const double* rew, const uint8_t* terminated,
+                  const uint8_t* truncated, const int64_t* offset, int64_t E, int64_t* insertion, int64_t* lengths,
+                  int64_t* last_index, double* ep_return, int64_t* ep_len, int64_t* ep_start, double* rew_B,
+                  uint8_t* terminated_B, uint8_t* truncated_B, uint8_t* done_B, const ts_scatter_key* h_keys,
+                  int n_keys, int64_t* index_out, double* ep_return_out, int64_t* ep_len_out, int64_t* ep_start_out,
+                  ts_stream_t stream) {
+    TS_REQUIRE(K >= 0 && E >= 1 && n_keys >= 0 && n_keys <= 8, TS_ERR_INVALID_ARG, "ts_buffer_add: bad sizes");
+    TS_REQUIRE(buffer_ids || K <= E, TS_ERR_SHAPE, "ts_buffer_add: more entries than sub-buffers");
+    if (K == 0) return TS_OK;
+    TS_REQUIRE(rew && terminated && truncated && offset && insertion && lengths && last_index && ep_return && ep_len &&
+                   ep_start && rew_B && terminated_B && truncated_B && done_B && index_out && ep_return_out &&
+                   ep_len_out && ep_start_out && (h_keys || n_keys == 0),
+               TS_ERR_INVALID_ARG, "ts_buffer_add: NULL argument");
+    hipStream_t s = ts::as_stream(stream);
+    AddArgs a{buffer_ids, K, rew, terminated, truncated, offset, insertion, lengths, last_index, ep_return, ep_len,
+              ep_start, rew_B, terminated_B, truncated_B, done_B, index_out, ep_return_out, ep_len_out, ep_start_out};
+    hipLaunchKernelGGL(buffer_add_state_kernel, dim3((unsigned)ts::ceil_div(K, 256)), dim3(256), 0, s, a);
+    if (n_keys > 0) {
+        ScatterKeys sk{};
+        sk.n = n_keys;
+        int64_t max_bytes = 0;
+        for (int i = 0; i < n_keys; ++i) {
+            TS_REQUIRE(h_keys[i].dst && h_keys[i].src && h_keys[i].row_bytes >= 1, TS_ERR_INVALID_ARG,
+                       "ts_buffer_add: bad scatter key");
+            sk.dst[i] = h_keys[i].dst; sk.src[i] = h_keys[i].src; sk.row_bytes[i] = h_keys[i].row_bytes;
+            max_bytes = std::max(max_bytes, h_keys[i].row_bytes);
+        }
+        int64_t bx = ts::ceil_div(K * ts::ceil_div(max_bytes, 16), 256);
+        if (bx > 4096) bx = 4096;
+        if (bx < 1) bx = 1;
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)bx, (unsigned)n_keys), dim3(256), 0, s, sk, index_out, K);
+    }
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
