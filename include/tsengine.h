@@ -236,6 +236,15 @@ int ts_per_update_weight(ts_workspace* ws, double* tree, int64_t bound, const in
  * ContinuousCritic continuous.py:99-169. */
 int64_t ts_ppo_param_count(int64_t obs_dim, int64_t act_dim);
 
+/* The collector's inference step: ProbabilisticActorPolicy.forward (reinforce.py:167-192) =
+ * mu(obs), act = mu + exp(sigma_param) * noise (dist.sample(); noise NULL = dist.mode, deterministic_eval), and
+ * Algorithm.map_action (algorithm_base.py:254-287): bound_method 0 none / 1 "clip" / 2 "tanh", then scaling to
+ * [low, high] (device float32[act_dim] each; both NULL = action_scaling False).  act_out float32[n, act_dim] is
+ * what goes into the buffer, mapped_out (nullable) what goes to the env. */
+int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
+                          const float* noise, int64_t n, int bound_method, const float* low, const float* high,
+                          float* act_out, float* mapped_out, ts_stream_t stream);
+
 typedef struct ts_ppo_hparams {
     double eps_clip;      /* ppo.py:140 */
     double dual_clip;     /* ppo.py:141; <= 0 means None */

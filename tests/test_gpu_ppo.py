@@ -327,3 +327,31 @@ def test_minibatch_larger_than_one_grid_pass():
     np.testing.assert_allclose(losses.cpu().numpy()[0],
                                [loss.item(), clip_loss.item(), vf_loss.item(), ent_loss.item()], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(grads.cpu().numpy(), g_ref, rtol=1e-4, atol=2e-6 * float(np.abs(g_ref).max()))
+
+
+@pytest.mark.parametrize("bound,scaled,with_noise", [("clip", True, True), ("tanh", True, True), (None, False, False)])
+def test_collector_policy_forward_and_map_action(bound, scaled, with_noise):
+    """ProbabilisticActorPolicy.forward + Algorithm.map_action for a vector of 512 envs."""
+    from tianshou_amd import ppo as P
+
+    obs_dim, act_dim, n = 17, 6, 512
+    params = OP.init_params(obs_dim, act_dim, seed=3)
+    g = torch.Generator().manual_seed(0)
+    obs = torch.randn(n, obs_dim, generator=g)
+    noise = torch.randn(n, act_dim, generator=g) if with_noise else None
+    low, high = torch.linspace(-2.0, -0.5, act_dim), torch.linspace(0.4, 3.0, act_dim)
+    with torch.no_grad():
+        mu, sigma = OP.actor_forward(params, obs)
+        ref_act = mu + sigma * noise if with_noise else mu
+        m = ref_act.numpy()
+        if bound == "clip":
+            m = np.clip(m, -1.0, 1.0)                              # algorithm_base.py:276-277
+        elif bound == "tanh":
+            m = np.tanh(m)
+        if scaled:
+            m = low.numpy() + (high.numpy() - low.numpy()) * (m + 1.0) / 2.0      # :284-285
+    act, mapped = P.policy_forward(OP.flatten_params(params).cuda(), obs_dim, act_dim, obs.cuda(),
+                                   None if noise is None else noise.cuda(), bound_method=bound,
+                                   low=low if scaled else None, high=high if scaled else None)
+    np.testing.assert_allclose(act.cpu().numpy(), ref_act.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mapped.cpu().numpy(), m, rtol=1e-5, atol=2e-6)

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
                                                         const float* __restrict__ obs,
                                                         const float* __restrict__ act, int64_t n,
                                                         float* __restrict__ v_out,
-                                                        float* __restrict__ logp_out) {
+                                                        float* __restrict__ logp_out,
+                                                        float* __restrict__ mu_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<KS1, 2>;
     stage_weights<KS1, 2, 512>(lds, params, d, 0);
@@ -327,17 +328,24 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
             head_forward<KS1, 2, 1>(lds, 1, h, h2, v);
             if (valid && h == 0) v_out[srow] = v[0] + lds[L::SMALL + 24];
         }
-        if (logp_out) {
+        if (logp_out || mu_out) {
             trunk_forward<KS1, 2>(lds, 0, x, i, h, h1, h2);
             float mu[ACT_PAD], a[ACT_PAD];
             head_forward<KS1, 2, ACT_PAD>(lds, 0, h, h2, mu);
 #pragma unroll
             for (int k = 0; k < ACT_PAD; ++k) {
                 mu[k] += lds[L::SMALL + k];
-                a[k] = (k < d.act) ? act[row * d.act + k] : 0.f;
+                a[k] = (logp_out && k < d.act) ? act[row * d.act + k] : 0.f;
             }
-            const float lp = gaussian_logp(mu, a, lds + L::SMALL, d.act);
-            if (valid && h == 0) logp_out[srow] = lp;
+            if (mu_out && valid && h == 0) {
+#pragma unroll
+                for (int k = 0; k < ACT_PAD; ++k)
+                    if (k < d.act) mu_out[srow * d.act + k] = mu[k];
+            }
+            if (logp_out) {
+                const float lp = gaussian_logp(mu, a, lds + L::SMALL, d.act);
+                if (valid && h == 0) logp_out[srow] = lp;
+            }
         }
     }
 }
@@ -1216,9 +1224,62 @@ int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t
         ts::ProfScope prof(ws, TS_KIND_PPO_INFER, s);
         TS_KS1_DISPATCH(ks, {
             hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
-                               params, d, obs, act, n, v_out, logp_out);
+                               params, d, obs, act, n, v_out, logp_out, (float*)nullptr);
         });
     }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// act = mu + sigma * eps (dist.sample(); eps NULL = dist.mode), then Algorithm.map_action
+// (algorithm_base.py:274-287): optional clip / tanh bounding and scaling to [low, high].
+__global__ __launch_bounds__(256) void ppo_sample_map_kernel(const float* __restrict__ mu, const float* __restrict__ noise,
+                                                             const float* __restrict__ sigma_param, int64_t n, int act_dim,
+                                                             int bound, const float* __restrict__ low,
+                                                             const float* __restrict__ high,
+                                                             float* __restrict__ act_out, float* __restrict__ mapped_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * act_dim) return;
+    const int k = (int)(i % act_dim);
+    float a = mu[i];
+    if (noise) a = a + expf(sigma_param[k]) * noise[i];
+    act_out[i] = a;
+    if (mapped_out) {
+        float m = a;
+        if (bound == 1) m = fminf(fmaxf(m, -1.f), 1.f);            // "clip"
+        else if (bound == 2) m = tanhf(m);                         // "tanh"
+        if (low) m = low[k] + (high[k] - low[k]) * (m + 1.f) / 2.f;
+        mapped_out[i] = m;
+    }
+}
+
+int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
+                          const float* noise, int64_t n, int bound_method, const float* low, const float* high,
+                          float* act_out, float* mapped_out, ts_stream_t stream) {
+    int rc = check_dims(obs_dim, act_dim);
+    if (rc != TS_OK) return rc;
+    TS_REQUIRE(n >= 0 && bound_method >= 0 && bound_method <= 2, TS_ERR_INVALID_ARG, "ts_ppo_policy_forward: bad argument");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(ws && params && obs && act_out && ((low == nullptr) == (high == nullptr)), TS_ERR_INVALID_ARG,
+               "ts_ppo_policy_forward: NULL argument");
+    const Dims d = make_dims((int)obs_dim, (int)act_dim);
+    const int ks = supported_ks(ks1_for((int)obs_dim));
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc2 = ts::ws_reserve(ws, sizeof(float) * (size_t)n * (size_t)act_dim)) return rc2;
+    float* mu = static_cast<float*>(ws->base);
+    const int64_t tiles = (n + 31) / 32;
+    int64_t wg = (tiles + 7) / 8;
+    const int64_t cap = (int64_t)n_compute_units() * 2;
+    if (wg > cap) wg = cap;
+    {
+        ts::ProfScope prof(ws, TS_KIND_PPO_INFER, s);
+        TS_KS1_DISPATCH(ks, {
+            hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
+                               params, d, obs, (const float*)nullptr, n, (float*)nullptr, (float*)nullptr, mu);
+        });
+    }
+    hipLaunchKernelGGL(ppo_sample_map_kernel, dim3((unsigned)ts::ceil_div(n * act_dim, 256)), dim3(256), 0, s, mu, noise,
+                       params + d.a_sig, n, (int)act_dim, bound_method, low, high, act_out, mapped_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

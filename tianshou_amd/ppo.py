@@ -132,6 +132,26 @@ def infer(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.Tensor, a
     return v, lp
 
 
+def policy_forward(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.Tensor, noise=None, *,
+                   bound_method: str | None = "clip", low=None, high=None):
+    """The collector's inference step (collector.py:707-772): ProbabilisticActorPolicy.forward
+    (reinforce.py:167-192) with dist.sample() = mu + sigma * noise (noise None = dist.mode) followed by
+    Algorithm.map_action (algorithm_base.py:254-287).  -> (act for the buffer, mapped act for the env)."""
+    n, dev = obs.shape[0], obs.device
+    obs = obs.to(torch.float32).contiguous()
+    noise = None if noise is None else torch.as_tensor(noise, device=dev).to(torch.float32).reshape(n, act_dim).contiguous()
+    f = lambda x: None if x is None else torch.as_tensor(x, dtype=torch.float32, device=dev).reshape(act_dim).contiguous()  # noqa: E731
+    low, high = f(low), f(high)
+    act = torch.empty((n, act_dim), dtype=torch.float32, device=dev)
+    mapped = torch.empty_like(act)
+    ws = _lib.default_workspace(_dev_index(params))
+    _lib.check(_lib.load().ts_ppo_policy_forward(
+        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(n),
+        C.c_int({None: 0, "clip": 1, "tanh": 2}[bound_method]), _lib.ptr(low), _lib.ptr(high), _lib.ptr(act),
+        _lib.ptr(mapped), _lib.current_stream(dev)))
+    return act, mapped
+
+
 def pack_batch(b: dict, obs_dim: int, act_dim: int) -> torch.Tensor:
     """[n, W] packed per-sample records (obs | act | adv ret logp_old v_s | pad), see
     include/tsengine.h (ts_ppo_pack_batch); used by the data-parallel path."""
