@@ -389,6 +389,12 @@ int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, 
 int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
                     float* out, ts_stream_t stream);
 
+/* DQN._target_q end to end (dqn.py:365-379): Q_online(s') and Q_target(s') (params_old; NULL = no lagged net,
+ * dqn.py:371-374) evaluated concurrently on two streams, then ts_dqn_target_q.  obs_next float32[B, h, w, c]. */
+int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                          int64_t w, int64_t n_act, const float* obs_next_nhwc, int64_t B, int is_double, float* out,
+                          ts_stream_t stream);
+
 typedef struct ts_dqn_hparams {
     double lr;            /* < 0: compute the gradient only (no optimizer step) */
     double beta1, beta2, adam_eps;

@@ -61,12 +61,23 @@ struct ts_workspace {
     hipEvent_t* ev;      // [2 * ev_cap] start/stop pairs
     int* ev_kind;        // [ev_cap]
     int ev_cap, ev_n;
+    // second stream for independent kernels of one entry point (e.g. weight- and input-gradient GEMMs of a layer):
+    // forked from / joined into the caller's stream with events, created on first use
+    hipStream_t side;
+    hipEvent_t side_ev[16];
+    int side_ready;
 };
 
 namespace ts {
 // Ensures ws->base holds at least `bytes`; (re)allocation synchronises the device once.
 int ws_reserve(ts_workspace* ws, size_t bytes);
 int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out);
+
+// Side stream of a workspace (created on first use).  Ordering is expressed with event slots:
+//   ts::stream_wait(ws, from, to, slot): everything enqueued on `to` after this call runs after everything
+//   enqueued on `from` before it.
+int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == main while profiling (clean per-kernel times)
+int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
 
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {

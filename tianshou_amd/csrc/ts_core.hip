@@ -58,6 +58,27 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
     return TS_OK;
 }
 
+int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "side_stream: workspace is NULL");
+    if (ws->profiling) { *out = main; return TS_OK; }      // serial launches: per-kernel event pairs do not overlap
+    if (!ws->side_ready) {
+        TS_HIP_CHECK(hipSetDevice(ws->device));
+        TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        for (int i = 0; i < 16; ++i) TS_HIP_CHECK(hipEventCreateWithFlags(&ws->side_ev[i], hipEventDisableTiming));
+        ws->side_ready = 1;
+    }
+    *out = ws->side;
+    return TS_OK;
+}
+
+int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot) {
+    if (from == to) return TS_OK;
+    TS_REQUIRE(ws && ws->side_ready && slot >= 0 && slot < 16, TS_ERR_WORKSPACE, "stream_wait: bad workspace / slot");
+    TS_HIP_CHECK(hipEventRecord(ws->side_ev[slot], from));
+    TS_HIP_CHECK(hipStreamWaitEvent(to, ws->side_ev[slot], 0));
+    return TS_OK;
+}
+
 ProfScope::ProfScope(ts_workspace* w, int kind, hipStream_t s) : ws(w), stream(s), slot(-1) {
     if (!ws || !ws->profiling || ws->ev_n >= ws->ev_cap) return;
     slot = ws->ev_n++;
@@ -122,6 +143,12 @@ int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes) {
 
 int ts_workspace_destroy(ts_workspace* ws) {
     if (!ws) return TS_OK;
+    if (ws->side_ready) {
+        (void)hipSetDevice(ws->device);
+        (void)hipStreamSynchronize(ws->side);
+        for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ws->side_ev[i]);
+        (void)hipStreamDestroy(ws->side);
+    }
     if (ws->base || ws->winner || ws->ev || ws->gae_sync) {
         (void)hipSetDevice(ws->device);
         (void)hipDeviceSynchronize();

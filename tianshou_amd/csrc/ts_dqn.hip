@@ -247,6 +247,37 @@ int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, 
     return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, B, sc, q_out, act_out);
 }
 
+int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                          int64_t w, int64_t n_act, const float* obs_next_nhwc, int64_t B, int is_double, float* out,
+                          ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_target_q_fused: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_dqn_target_q_fused: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && obs_next_nhwc && out, TS_ERR_INVALID_ARG, "ts_dqn_target_q_fused: NULL argument");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    const size_t one = fwd_scratch_bytes(n, B);
+    if (int rc = ts::ws_reserve(ws, 2 * one)) return rc;
+    Scratch sa, sb;
+    carve_fwd(n, B, static_cast<char*>(ws->base), &sa);
+    carve_fwd(n, B, static_cast<char*>(ws->base) + one, &sb);
+    hipStream_t s = ts::as_stream(stream), side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    const bool two = params_old != nullptr;
+    if (two) {      // Q_target(s') on the side stream, Q_online(s') on the caller's stream (only needed for double-Q)
+        if (int rc = ts::stream_wait(ws, s, side, 9)) return rc;
+        if (int rc = net_forward(side, ws, n, params_old, obs_next_nhwc, B, sb, sb.q, nullptr)) return rc;
+    }
+    if (!two || is_double)
+        if (int rc = net_forward(s, ws, n, params, obs_next_nhwc, B, sa, sa.q, nullptr)) return rc;
+    if (two)
+        if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
+    hipLaunchKernelGGL(target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, sa.q, two ? sb.q : sa.q, B,
+                       (int)n_act, is_double, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
 int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
                     float* out, ts_stream_t stream) {
     TS_REQUIRE(B >= 0 && n_act >= 1, TS_ERR_INVALID_ARG, "ts_dqn_target_q: bad sizes");
@@ -300,15 +331,21 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)ts::ceil_div(B * HIDDEN, 256)), dim3(256), 0, s, dq, act,
                        params + n.off[4], sc.h[3], B, n.n_act, dy[3]);
     TS_LAUNCH_CHECK();
-    // fc1, conv3, conv2, conv1
+    // fc1, conv3, conv2, conv1.  The weight gradient of a layer (+ its slab sum) and the input gradient that feeds
+    // the layer below are independent given dY_i: the first runs on the workspace's side stream, the second on
+    // the caller's stream, so that these small grids share the chip instead of running back to back.
+    hipStream_t side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
     for (int i = 3; i >= 0; --i) {
         const float* x = i == 0 ? obs_nhwc : sc.h[i - 1];
-        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws)) return rc;
-        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
+        if (int rc = ts::stream_wait(ws, s, side, i)) return rc;          // dY_i (and everything before) is ready
+        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws)) return rc;
+        if (int rc = ts::slab_sum(side, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
             return rc;
         if (i > 0)
             if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1], ws)) return rc;
     }
+    if (int rc = ts::stream_wait(ws, side, s, 8)) return rc;               // all weight gradients are in `grad`
     if (hp->lr < 0.0) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);

@@ -407,7 +407,7 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                    2 * al(4 * B * HID) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
                    al(4 * B * 3 * d.act) + 8192;
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    bytes += al(4 * spl);
+    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + al(4 * B * 32);
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -419,9 +419,13 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     float* d_q1 = c.take<float>(B * 64);
     float* d_q2 = d_q1 + B * 32;
     float* dx2 = c.take<float>(B * 64 > B * d.kc ? B * 64 : B * d.kc);
-    BwdScratch sc;
+    BwdScratch sc, sc2;              // one set per stream (the two critics run concurrently)
     sc.dh2 = c.take<float>(B * HID); sc.dh1 = c.take<float>(B * HID); sc.slabs = c.take<float>(slab);
+    sc2.dh2 = c.take<float>(B * HID); sc2.dh1 = c.take<float>(B * HID); sc2.slabs = c.take<float>(slab);
     float* grad = c.take<float>(std::max(pa, pc));
+    float* grad2 = c.take<float>(pc);
+    float* d_head2 = c.take<float>(B * 32);
+    float* split2 = c.take<float>(spl);
     float* td1 = c.take<float>(B); float* td2 = c.take<float>(B); float* logp = c.take<float>(B);
     float* keep = c.take<float>(B * 3 * d.act);
     float* norm_part = c.take<float>(1024);
@@ -435,21 +439,32 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
     TS_HIP_CHECK(hipMemsetAsync(d_q1, 0, sizeof(float) * B * 64, s));
 
-    // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step
+    // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
+    // caller's stream, critic 2 on the workspace's side stream (each of these GEMMs fills only part of the chip).
+    hipStream_t side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
     float* crit_m[2] = {st->critic1_m, st->critic2_m};
     float* crit_v[2] = {st->critic1_v, st->critic2_v};
     float* tds[2] = {td1, td2};
     const Act acts[2] = {a1, a2};
+    float* dheads[2] = {d_head, d_head2};
+    float* splits[2] = {split, split2};
+    float* gbuf[2] = {grad, grad2};
+    const BwdScratch scs[2] = {sc, sc2};
+    TS_HIP_CHECK(hipMemsetAsync(d_head2, 0, sizeof(float) * B * 32, s));
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
     for (int k = 0; k < 2; ++k) {
-        if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], split)) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, s, acts[k].out, returns, weight, B, tds[k],
-                           d_head, stats_out5 + 1 + k);
+        hipStream_t sk = stq[k];
+        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                           dheads[k], stats_out5 + 1 + k);
         TS_LAUNCH_CHECK();
-        float* gk = g_out[k] ? g_out[k] : grad;
-        if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], d_head, gk, nullptr, 0, 0, sc)) return rc;
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
         if (hp->critic_lr >= 0.0)
-            if (int rc = ts::adam_step(s, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
+            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
                 return rc;
     }
@@ -459,14 +474,18 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3(gb), dim3(256), 0, s, aa.out, noise, B, d.act, 64, d.obs, d.kc, x_p,
                        (float*)nullptr, logp, keep);
+    if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;              // x_p ready; critic 2 is already updated there
+    if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
     if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
-    if (int rc = mlp_forward(s, ws, mc, st->critic2, x_p, a2, split)) return rc;
+    if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
     hipLaunchKernelGGL(sac_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, a2.out, logp, log_alpha, (float)hp->alpha, B,
                        d_q1, d_q2, stats_out5);
     TS_LAUNCH_CHECK();
+    if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
+    if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
     if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
-    if (int rc = mlp_backward(s, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc)) return rc;
     TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+    if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
     hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
                        keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
     TS_LAUNCH_CHECK();

@@ -219,12 +219,13 @@ class DQNEngine:
 
     # -- DQN._target_q ---------------------------------------------------------------------------------
     def target_q(self, obs_next_nhwc: torch.Tensor) -> torch.Tensor:
-        q_on, _ = self.forward(obs_next_nhwc, want_act=False)
-        q_tg = q_on if self.params_old is None else self.forward(obs_next_nhwc, self.params_old, want_act=False)[0]
-        out = torch.empty(q_on.shape[0], dtype=torch.float32, device=self.device)
-        _lib.check(_lib.load().ts_dqn_target_q(_lib.ptr(q_on), _lib.ptr(q_tg), _lib.i64(q_on.shape[0]),
-                                               _lib.i64(self.n_act), C.c_int(int(self.cfg.is_double)), _lib.ptr(out),
-                                               _lib.current_stream(self.device)))
+        b = obs_next_nhwc.shape[0]
+        obs_next_nhwc = obs_next_nhwc.contiguous()
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_dqn_target_q_fused(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.params_old), _lib.i64(self.c), _lib.i64(self.h),
+            _lib.i64(self.w), _lib.i64(self.n_act), _lib.ptr(obs_next_nhwc), _lib.i64(b),
+            C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
     # -- DQN._preprocess_batch -----------------------------------------------------------------------
