@@ -178,6 +178,70 @@ __device__ __forceinline__ void finish_small(float* lds) {
     }
 }
 
+// Straight float4 copy of a ready-made LDS image (kept current by ppo_adam_kernel): replaces the per-element
+// index arithmetic of stage_weights in the step kernel's two prologues.
+template <int KS1, int NT>
+__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ img) {
+    constexpr int N4 = Lds<KS1, 1>::END / 4, PER = (N4 + NT - 1) / NT;
+    static_assert(Lds<KS1, 1>::END % 4 == 0, "image size");
+    f32x4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int q = threadIdx.x + NT * k;
+        v[k] = reinterpret_cast<const f32x4*>(img)[q < N4 ? q : N4 - 1];      // unconditional clamped loads
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int q = threadIdx.x + NT * k;
+        if (q < N4) reinterpret_cast<f32x4*>(lds)[q] = v[k];
+    }
+}
+
+// Builds both images (blockIdx.x = net) and the inverse table inv[param] = net * END + slot that lets the Adam
+// kernel refresh the image in place.  sigma_param maps to two derived slots and is handled there explicitly.
+template <int KS1>
+__global__ __launch_bounds__(256) void ppo_build_image_kernel(const float* __restrict__ params, Dims d,
+                                                              float* __restrict__ image, int* __restrict__ inv) {
+    using L = Lds<KS1, 1>;
+    const int net = blockIdx.x;
+    float* img = image + net * L::END;
+    for (int i = threadIdx.x; i < L::END; i += 256) img[i] = 0.f;
+    __syncthreads();
+    stage_weights<KS1, 1, 256>(img, params, d, net);
+    __syncthreads();
+    finish_small<KS1, 1>(img);
+    if (!inv) return;
+    // inverse table: the same (src, dst) enumeration as stage_weights
+    constexpr int N_W2 = HID * HID, N_W1 = 2 * KS1 * HID, N_B2 = HID, N_WH = L::WH_NET;
+    constexpr int PER_NET = N_W2 + N_W1 + N_B2 + N_WH;
+    for (int idx = threadIdx.x; idx < PER_NET + 32; idx += 256) {
+        int src = -1, dst = -1;
+        if (idx >= PER_NET) {
+            const int i = idx - PER_NET;
+            if (net == 0 && i < 8 && i < d.act) { src = d.a_bmu + i; dst = L::SMALL + i; }
+            if (net == 1 && i == 24) { src = d.c_bv; dst = L::SMALL + 24; }
+        } else {
+            int i = idx;
+            if (i < N_W2) { src = (net ? d.c_w2 : d.a_w2) + i; dst = L::W2 + (i >> 6) * W2_PITCH + (i & 63); }
+            else if ((i -= N_W2) < N_W1) {
+                const int k = i >> 6, row = i & 63;
+                if (k < d.obs) src = (net ? d.c_w1 : d.a_w1) + row * d.obs + k;
+                else if (k == d.obs) src = (net ? d.c_b1 : d.a_b1) + row;
+                dst = L::W1 + i;
+            } else if ((i -= N_W1) < N_B2) { src = (net ? d.c_b2 : d.a_b2) + i; dst = L::B2 + i; }
+            else {
+                i -= N_B2;
+                const int a = i & 7, r = (i >> 3) & 15, t = (i >> 7) & 1, h = (i >> 8) & 1;
+                const int f = 32 * t + featF(r, h);
+                if (net == 0) { if (a < d.act) src = d.a_wmu + a * HID + f; }
+                else if (a == 0) src = d.c_wv + f;
+                dst = L::WH + i;
+            }
+        }
+        if (src >= 0) inv[src] = net * L::END + dst;
+    }
+}
+
 // tanh with <= 2.1e-7 relative error (about 2 ulp): odd polynomial below 0.5, 1 - 2/(e^{2|x|}+1) above
 __device__ __forceinline__ float fast_tanh(float x) {
     const float ax = fabsf(x);
@@ -361,6 +425,7 @@ struct StepArgs {
     const float* adv_stats;   // {mean, std} of this minibatch (device) or NULL
     float eps_clip, dual_clip, vf_coef, ent_coef;
     int value_clip, adv_norm, a2c;
+    const float* image;       // [2][Lds<KS1,1>::END] ready-made LDS images of the two nets (ppo_build_image_kernel)
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
     long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
@@ -871,11 +936,9 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step_kernel(StepArgs g, D
         TS_MARK(g, net ? 21 : 18);
         if (net) __syncthreads();           // every wave is done reading the previous net's weights
         TS_MARK(g, net ? 22 : 19);
-        stage_weights<KS1, 1, STEP_THREADS>(lds, g.params, d, net);
+        stage_image<KS1, STEP_THREADS>(lds, g.image + net * L::END);
         RecFetch<KS1> f = rec_fetch<KS1>(g, row0, lane);
         TS_MARK(g, net ? 23 : 20);
-        __syncthreads();
-        finish_small<KS1, 1>(lds);
         __syncthreads();
         TS_MARK(g, net ? 9 : 1);
         for (int64_t it = 0; it < n_iter; ++it) {
@@ -944,6 +1007,9 @@ struct AdamArgs {
     float vf_coef, ent_coef;
     float* losses;            // [4] loss, clip, vf, ent (or NULL); grad[n_params], grad[n_params+1] hold clip / vf
     int apply;                // 0: only losses
+    float* image;             // LDS images of the step kernel to refresh (or NULL)
+    const int* inv;           // param -> image slot (-1: none)
+    int sig_off, act, small0; // sigma_param range and the actor image's SMALL block
 };
 
 constexpr int ADAM_THREADS = 256;
@@ -985,9 +1051,20 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
         v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        a.params[p] = a.params[p] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        const float np_ = a.params[p] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
+        if (a.image) {
+            const int t = a.inv[p];
+            if (t >= 0) a.image[t] = np_;
+            const int k = p - a.sig_off;
+            if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
+                const float sigma = expf(np_);
+                a.image[a.small0 + 8 + k] = 1.f / (2.f * (sigma * sigma));
+                a.image[a.small0 + 16 + k] = logf(sigma);
+            }
+        }
     }
 }
 
@@ -1176,6 +1253,28 @@ inline AdamArgs adam_args(float* params, float* m, float* v, int64_t step, const
     return a;
 }
 
+struct ImageBuf { size_t img_bytes, inv_bytes; int img_end; };
+
+inline ImageBuf image_buf(const Dims& d, int ks) {
+    ImageBuf b;
+    b.img_end = 4960 + 128 * ks;                           // Lds<ks, 1>::END
+    b.img_bytes = (sizeof(float) * 2 * (size_t)b.img_end + 255) & ~(size_t)255;
+    b.inv_bytes = (sizeof(int) * (size_t)d.p_total + 255) & ~(size_t)255;
+    return b;
+}
+
+// LDS images of both nets + the param -> image-slot table (see ppo_build_image_kernel)
+int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float* image, int* inv) {
+    const int64_t obs_dim = d.obs;
+    if (inv) TS_HIP_CHECK(hipMemsetAsync(inv, 0xff, sizeof(int) * (size_t)d.p_total, s));   // -1: no image slot
+    TS_KS1_DISPATCH(ks, {
+        static_assert(Lds<K, 1>::END == 4960 + 128 * K, "image size formula");
+        hipLaunchKernelGGL((ppo_build_image_kernel<K>), dim3(2), dim3(256), 0, s, params, d, image, inv);
+    });
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
 // forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
 // grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
 int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
@@ -1338,10 +1437,15 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     const WsLayout wl = ws_layout(step_grid(max_rows), slab_w, n_steps);
     // behind the fixed part: device copy of the minibatch offsets, then the packed records
     const size_t off_bytes = (sizeof(int64_t) * (size_t)(n_steps + 1) + 255) & ~(size_t)255;
-    const size_t rec_bytes = sizeof(float) * (size_t)n * rw;
-    rc = ts::ws_reserve(ws, wl.total + off_bytes + rec_bytes + 256);
+    const size_t rec_bytes = (sizeof(float) * (size_t)n * rw + 255) & ~(size_t)255;
+    const ImageBuf ib = image_buf(d, ks);
+    const size_t img_bytes = ib.img_bytes, inv_bytes = ib.inv_bytes;
+    const int img_end = ib.img_end;
+    rc = ts::ws_reserve(ws, wl.total + off_bytes + rec_bytes + img_bytes + inv_bytes + 256);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
+    float* image = reinterpret_cast<float*>(base + wl.total + off_bytes + rec_bytes);
+    int* inv = reinterpret_cast<int*>(base + wl.total + off_bytes + rec_bytes + img_bytes);
     float* slabs = reinterpret_cast<float*>(base + wl.slabs);
     float* grad = reinterpret_cast<float*>(base + wl.grad);
     float* sumsq = reinterpret_cast<float*>(base + wl.sumsq);
@@ -1351,6 +1455,8 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     hipStream_t s = ts::as_stream(stream);
 
     rc = ts_ppo_pack_batch(obs, act, adv, returns, logp_old, v_s, n, obs_dim, act_dim, rec, stream);
+    if (rc != TS_OK) return rc;
+    rc = build_image(s, params, d, ks, image, inv);
     if (rc != TS_OK) return rc;
     if (hp->adv_norm) {
         TS_HIP_CHECK(hipMemcpyAsync(d_off, h_mb_offset, sizeof(int64_t) * (size_t)(n_steps + 1),
@@ -1368,6 +1474,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         else { g.rec = rec + h_mb_offset[k] * rw; g.rows = nullptr; }   // identity rows: shift the base
         g.inv_batch = 1.0f / (float)g.n_rows;
         g.adv_stats = hp->adv_norm ? advstats + 2 * k : nullptr;
+        g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
         rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s);
@@ -1378,6 +1485,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
         a.losses = losses; a.apply = 1;
+        a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
         {
             ts::ProfScope prof(ws, TS_KIND_PPO_ADAM, s);
             hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
@@ -1404,13 +1512,17 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
     const int ks = supported_ks(ks1_for((int)obs_dim));
     const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
     const WsLayout wl = ws_layout(step_grid(n_rows), slab_w, 1);
-    rc = ts::ws_reserve(ws, wl.total);
+    const ImageBuf ib = image_buf(d, ks);
+    rc = ts::ws_reserve(ws, wl.total + ib.img_bytes + ib.inv_bytes);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     hipStream_t s = ts::as_stream(stream);
+    float* image = reinterpret_cast<float*>(base + wl.total);
+    rc = build_image(s, params, d, ks, image, nullptr);       // gradient only: nobody refreshes the image
+    if (rc != TS_OK) return rc;
     StepArgs g{};
     g.params = params; g.rec = rec; g.rec_w = rec_width(obs_dim, act_dim);
-    g.rows = perm_rows; g.n_rows = n_rows;
+    g.rows = perm_rows; g.n_rows = n_rows; g.image = image;
     g.inv_batch = 1.0f / (float)global_batch;
     g.adv_stats = hp->adv_norm ? adv_stats : nullptr;
     fill_hparams(g, hp);
@@ -1444,15 +1556,19 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
     const int n_wg = step_grid(n_rows);
     const WsLayout wl = ws_layout(n_wg, slab_w, 1);
-    rc = ts::ws_reserve(ws, wl.total + sizeof(long long) * 64);
+    const ImageBuf ib = image_buf(d, ks);
+    rc = ts::ws_reserve(ws, wl.total + 512 + ib.img_bytes + ib.inv_bytes);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     long long* dbg = reinterpret_cast<long long*>(base + wl.total);
+    float* image = reinterpret_cast<float*>(base + wl.total + 512);
     hipStream_t s = ts::as_stream(stream);
     TS_HIP_CHECK(hipMemsetAsync(dbg, 0, sizeof(long long) * 64, s));
+    rc = build_image(s, params, d, ks, image, nullptr);
+    if (rc != TS_OK) return rc;
     StepArgs g{};
     g.params = params; g.rec = rec; g.rec_w = rec_width(obs_dim, act_dim);
-    g.rows = perm_rows; g.n_rows = n_rows;
+    g.rows = perm_rows; g.n_rows = n_rows; g.image = image;
     g.inv_batch = 1.0f / (float)n_rows;
     fill_hparams(g, hp);
     g.adv_norm = 0;
