@@ -39,6 +39,13 @@ FLOP_PER_SAMPLE_STEP = 60544          # fwd 21,632 + bwd dW 21,632 + 
 GAE_BYTES_PER_TRANSITION = 26         # 22 + 4: rew kept float64 as the reference stores it
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
+# HBM bytes per launch from the TCC counters (profiles/r01_pmc_hbm_traffic.txt: two separate rocprofv3 --pmc passes over
+# this very command, mean per launch; FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte
+# requests of 16-byte-per-lane loads at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM").  Counters cannot be read live
+# from inside bench.py, so the line carries the profiled value of the same workload.
+STEP_HBM_TRAFFIC_BYTES = (2 * 8926 + 22230) * 1024      # records + images read, 512 gradient slabs written
+GAE_HBM_TRAFFIC_BYTES = (2 * 9353 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
+TRAFFIC_SOURCE = "profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
 
 
 def make_rollout(device, seed):
@@ -285,7 +292,8 @@ def main():
             achieved = FLOP_PER_SAMPLE_STEP * MINIBATCH / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "ppo_step_kernel", "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": step_n,
+                    "traffic": STEP_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
+                    "avg_launch_us": avg_s * 1e6, "launches": step_n,
                     "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * MINIBATCH}
             extra["kernel_us"] = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()}
             extra["inner_update_steps_per_s"] = REPEAT * (N_TRANS // MINIBATCH) / t_inner
@@ -294,7 +302,8 @@ def main():
         extra["gae_transitions_per_s"] = N_TRANS / t_gae
         extra["roofline_gae"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps,
                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                                 "traffic": None, "avg_launch_us": t_gae * 1e6,
+                                 "traffic": GAE_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
+                                 "avg_launch_us": t_gae * 1e6,
                                  "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * N_TRANS}
         t1 = time.perf_counter()
         for _ in range(3):
