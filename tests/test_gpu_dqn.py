@@ -232,3 +232,48 @@ def test_gradient_plus_apply_equals_update():
         assert torch.equal(td1, td2) and torch.equal(l1, l2)
         assert torch.equal(e1.params, e2.params) and torch.equal(e1.params_old, e2.params_old)
         assert (e1.iter, e1.adam_step) == (e2.iter, e2.adam_step)
+
+
+@pytest.mark.parametrize("n_act,B", [(18, 3), (1, 5), (64, 2)])
+def test_other_action_counts_and_tiny_batches(n_act, B):
+    """Atari's largest action set (18), a single action, the head limit (64); batches smaller than any tile."""
+    from tianshou_amd import dqn as D
+
+    c, h, w = 4, 84, 84
+    rng = np.random.default_rng(n_act)
+    p = OD.init_params(c, h, w, n_act, seed=n_act)
+    cfg = OD.DQNConfig(huber_delta=None, lr=1e-4, max_grad_norm=10.0)
+    st = OD.DQNState.create(p, cfg)
+    obs = rng.integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    act, ret = rng.integers(0, n_act, size=B), rng.normal(size=B).astype(np.float32)
+    wgt = rng.random(B).astype(np.float32)
+    loss_ref, td_ref = OD.update_with_batch(st, cfg, obs, act, ret, wgt)
+    eng = D.DQNEngine(c, h, w, n_act, D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, n_act),
+                      D.DQNConfig(huber_delta=None, lr=1e-4, max_grad_norm=10.0))
+    loss, td = eng.update_with_batch(torch.as_tensor(obs).permute(0, 2, 3, 1).float().contiguous().cuda(), act, ret, wgt)
+    assert rel_err(td.cpu(), td_ref) < 1e-5
+    np.testing.assert_allclose(float(loss), loss_ref, rtol=1e-5)
+    new = torch.cat([t.reshape(-1) for t in D.flat_to_torch(eng.params, c, h, w, n_act)]).cpu().numpy()
+    ref = OD.flatten_params(st.params).numpy()
+    assert (np.abs(new - ref) > 1e-5 * np.abs(ref) + 0.02 * cfg.lr).mean() < 1e-4
+
+
+def test_bad_arguments_fail_loudly():
+    from tianshou_amd import _lib
+    from tianshou_amd import dqn as D
+
+    with pytest.raises(ValueError):
+        D.param_count(4, 20, 20, 6)                       # observation too small for the three convolutions
+    with pytest.raises(_lib.EngineError):
+        D.layer_layout(4, 84, 84, 65)                     # more actions than the head supports
+    p = OD.init_params(4, 84, 84, 6, seed=0)
+    flat = D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], 4, 84, 84, 6)
+    eng = D.DQNEngine(4, 84, 84, 6, flat, D.DQNConfig())
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros(2, 84, 84, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.update_with_batch(torch.zeros(2, 84, 84, 4, device="cuda"), [0, 1, 2], [0.0, 0.0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D.DQNEngine(4, 84, 84, 6, flat.cpu(), D.DQNConfig())
+    with pytest.raises(_lib.EngineError):                 # conv shape outside the kernel's limits: K % 32 != 0
+        D.conv_forward(torch.zeros(1, 9, 9, 3, device="cuda"), torch.zeros(3 * 3 * 3 + 1, 32, device="cuda"), 3, 3, 1, True)

@@ -134,3 +134,38 @@ def test_sac_update_matches_reference_golden(tag):
             # Adam's first steps move every weight by ~lr whatever its gradient: compare on lr's scale
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
                                        err_msg=name)
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(7, 1, 33), (64, 32, 40), (33, 3, 1)])
+def test_update_other_shapes_vs_oracle(obs_dim, act_dim, B):
+    """Edge shapes: one action, 32 actions (the head's limit), obs widths around the 32-column padding, B = 1."""
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 9, cfg)
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    g = torch.Generator().manual_seed(B)
+    for _ in range(2):
+        obs = torch.randn(B, obs_dim, generator=g)
+        act = torch.rand(B, act_dim, generator=g) * 2 - 1
+        ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+        ref = OS.update_with_batch(st, cfg, obs, act, ret, noise)
+        stats, w = eng.update_with_batch(obs, act, ret, noise)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[:3], [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=2e-5,
+                                   atol=1e-6)
+        np.testing.assert_allclose(s[3], ref["alpha"], rtol=1e-5)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_bad_arguments_fail_loudly():
+    from tianshou_amd import _lib
+    from tianshou_amd import sac as S
+
+    with pytest.raises(_lib.EngineError):
+        S.layout(17, 33)                                  # act_dim > 32 is outside the head layout
+    cfg = OS.SACConfig()
+    eng, _ = make_engine(11, 3, 1, cfg)
+    with pytest.raises(ValueError):
+        eng.update_with_batch(torch.zeros(4, 12), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.SACEngine(11, 3, eng.actor.cpu(), eng.critic1.cpu(), eng.critic2.cpu(), S.SACConfig())
