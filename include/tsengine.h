@@ -497,6 +497,51 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                   int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
                   ts_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,
+ * nets of examples/mujoco/mujoco_td3.py:85-103 / mujoco_ddpg.py
+ * ------------------------------------------------------------------------------------------- */
+
+/* Flat vectors: actor L1 [ka + 1, 256] | L2 [257, 256] | head [257, 32] (columns [0, act_dim) = last);
+ * critics as in ts_sac_layout.  h_out4 = {ka, kc, actor count, critic count}. */
+int ts_td3_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out4);
+
+/* ContinuousDeterministicPolicy.forward (ddpg.py:162-180): act = max_action * tanh(actor(obs)). */
+int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs, int64_t B, int64_t obs_dim,
+                          int64_t act_dim, double max_action, float* act_out, ts_stream_t stream);
+
+/* _target_q (ddpg.py:327-339) with the lagged actor: DDPG (critic2_old NULL, noise NULL; ddpg.py:397-399) or
+ * TD3 (td3.py:94-102, 190-202): a' = actor_old(s') + clamp(noise * policy_noise, +-noise_clip) (noise_clip <= 0:
+ * no clamp), min of the two lagged critics.  noise float32[B, act_dim] = the torch.randn draws. */
+int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* critic1_old, const float* critic2_old,
+                    const float* obs_next, const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim,
+                    double max_action, double policy_noise, double noise_clip, float* out, ts_stream_t stream);
+
+typedef struct ts_td3_state {  /* device pointers, float32; critic2* NULL = DDPG */
+    float *actor, *actor_m, *actor_v;
+    float *critic1, *critic1_m, *critic1_v;
+    float *critic2, *critic2_m, *critic2_v;
+    float *actor_old, *critic1_old, *critic2_old;
+} ts_td3_state;
+
+typedef struct ts_td3_hparams {
+    double actor_lr, critic_lr; /* negative: gradient only */
+    double beta1, beta2, adam_eps;
+    double tau, max_action;
+    int32_t update_actor; /* this call updates the actor and the lagged networks (td3.py:215, _cnt % freq == 0) */
+    int32_t reserved;
+} ts_td3_hparams;
+
+/* TD3._update_with_batch (td3.py:204-226) / DDPG._update_with_batch (ddpg.py:401-411): critic step(s); when
+ * hp->update_actor, actor step on -Q1(s, pi(s)).mean() with the updated critic and the Polyak updates.
+ * critic_step / actor_step = 1-based Adam steps of this call (the actor's counts only its own updates).
+ * stats_out3 = {actor_loss (written only when the actor is updated), critic1_loss, critic2_loss};
+ * weight_out (nullable) = (td1 + td2) / 2 or td1; grads_out (nullable) = {critic1, critic2, actor} gradients. */
+int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step, int64_t actor_step, const float* obs,
+                  const float* act, const float* returns, const float* weight, int64_t B, int64_t obs_dim,
+                  int64_t act_dim, const ts_td3_hparams* hp, float* stats_out3, float* weight_out, float* grads_out,
+                  ts_stream_t stream);
+
 /* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
  * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
  * the stream. */

@@ -567,6 +567,9 @@ def main() -> None:
                     eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
                     recompute_advantage=False, max_batchsize=32)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "td3":
+        gen_td3_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sac":
         gen_sac_all()
         return
@@ -588,6 +591,7 @@ def main() -> None:
     gen_buffer_add()
     gen_dqn_all()
     gen_sac_all()
+    gen_td3_all()
     gen_ppo_cnn(gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=False,
                 eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
                 recompute_advantage=False, max_batchsize=32)
@@ -693,6 +697,113 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"sac_{tag}.npz"), **out)
+
+
+def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int,
+            n_updates: int, seed: int, max_action: float = 1.0, n_step: int = 1, **kw) -> None:
+    """Runs the reference TD3.update() (twin) or DDPG.update() (nets of examples/mujoco/mujoco_td3.py:85-103 /
+    mujoco_ddpg.py) on a synthetic VectorReplayBuffer; TD3's torch.randn smoothing noise is recorded."""
+    from tianshou.algorithm.modelfree import td3 as td3_mod
+    from tianshou.algorithm.modelfree.ddpg import DDPG, ContinuousDeterministicPolicy
+    from tianshou.algorithm.modelfree.td3 import TD3
+    from tianshou.utils.net.continuous import ContinuousActorDeterministic
+    from oracle import oracle_sac as OS
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[256, 256]),
+                                         action_shape=(act_dim,), max_action=max_action)
+    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)  # noqa: E731
+    if twin:
+        n1, n2 = mk_net(), mk_net()
+        critic1, critic2 = ContinuousCritic(preprocess_net=n1), ContinuousCritic(preprocess_net=n2)
+    else:
+        critic1, critic2 = ContinuousCritic(preprocess_net=mk_net()), None
+    p0 = OS.init_td3_params(obs_dim, act_dim, seed, twin)
+    checks = [(p0[0], OS.DET_ACTOR_ORDER, actor, OS.TIANSHOU_DET_ACTOR_KEYS), (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS)]
+    if twin:
+        checks.append((p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS))
+    for pd, order, mod, keys in checks:
+        sd = mod.state_dict()
+        assert list(sd.keys()) == keys, list(sd.keys())
+        for k_ref, k in zip(keys, order):
+            assert torch.equal(sd[k_ref], pd[k]), f"oracle init differs from the reference at {k}"
+    space = gym.spaces.Box(low=-max_action, high=max_action, shape=(act_dim,))
+    policy = ContinuousDeterministicPolicy(actor=actor, action_space=space, exploration_noise=None)
+    common = dict(policy=policy, policy_optim=AdamOptimizerFactory(lr=kw.get("actor_lr", 1e-3)), critic=critic1,
+                  critic_optim=AdamOptimizerFactory(lr=kw.get("critic_lr", 1e-3)), tau=kw.get("tau", 0.005),
+                  gamma=kw.get("gamma", 0.99), n_step_return_horizon=n_step)
+    if twin:
+        algorithm = TD3(critic2=critic2, critic2_optim=AdamOptimizerFactory(lr=kw.get("critic_lr", 1e-3)),
+                        policy_noise=kw.get("policy_noise", 0.2), noise_clip=kw.get("noise_clip", 0.5),
+                        update_actor_freq=kw.get("update_actor_freq", 2), **common)
+    else:
+        algorithm = DDPG(**common)
+    buf = VectorReplayBuffer(E * slots, E)
+    obs = rng.normal(size=(steps + 1, E, obs_dim)).astype(np.float32)
+    act = rng.uniform(-max_action, max_action, size=(steps, E, act_dim)).astype(np.float32)
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.05
+    trunc = (rng.random((steps, E)) < 0.03) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+    out: dict[str, np.ndarray] = {"dims": np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(twin), n_step])}
+    for k2 in ("obs", "obs_next", "act"):
+        out[k2] = np.asarray(getattr(buf, k2), np.float32)
+    out["rew"], out["terminated"], out["truncated"] = np.asarray(buf.rew, np.float64), np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k2, v in manager_state(buf).items():
+        out["buf_" + k2] = v
+    noises, rec = [], []
+    orig_randn, cls = torch.randn, type(algorithm)
+    orig_pre = cls._preprocess_batch
+
+    def rec_randn(*a, **k):
+        e = orig_randn(*a, **k)
+        if "size" in k:
+            noises.append(e.numpy().copy())
+        return e
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        rec.append({"indices": np.array(indices, np.int64), "returns": b.returns.numpy().copy().reshape(-1)})
+        return b
+
+    torch.randn, cls._preprocess_batch = rec_randn, rec_pre
+    try:
+        for u in range(n_updates):
+            n0 = len(noises)
+            with policy_within_training_step(algorithm.policy):
+                stats = algorithm.update(buffer=buf, sample_size=batch)
+            if twin:
+                assert len(noises) - n0 == 1
+                out[f"u{u}_noise"] = noises[n0]
+            out[f"u{u}_indices"], out[f"u{u}_returns"] = rec[-1]["indices"], rec[-1]["returns"]
+            out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic1_loss, stats.critic2_loss] if twin
+                                          else [stats.actor_loss, stats.critic_loss])
+            mods = [("actor", actor, OS.TIANSHOU_DET_ACTOR_KEYS), ("critic1", critic1, OS.TIANSHOU_CRITIC_KEYS),
+                    ("actor_old", algorithm.actor_old.module, OS.TIANSHOU_DET_ACTOR_KEYS),
+                    ("critic1_old", algorithm.critic_old.module, OS.TIANSHOU_CRITIC_KEYS)]
+            if twin:
+                mods += [("critic2", critic2, OS.TIANSHOU_CRITIC_KEYS),
+                         ("critic2_old", algorithm.critic2_old.module, OS.TIANSHOU_CRITIC_KEYS)]
+            for name, mod, keys in mods:
+                sd = mod.state_dict()
+                out[f"u{u}_{name}"] = torch.cat([sd[k2].reshape(-1) for k2 in keys]).numpy()[::61].copy()
+    finally:
+        torch.randn, cls._preprocess_batch = orig_randn, orig_pre
+    cfg = dict(gamma=common["gamma"], tau=common["tau"], n_step=n_step, twin=float(twin),
+               policy_noise=kw.get("policy_noise", 0.2), noise_clip=kw.get("noise_clip", 0.5),
+               update_actor_freq=kw.get("update_actor_freq", 2), max_action=max_action,
+               actor_lr=kw.get("actor_lr", 1e-3), critic_lr=kw.get("critic_lr", 1e-3))
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"td3_{tag}.npz"), **out)
+
+
+def gen_td3_all() -> None:
+    gen_td3("twin", twin=True, E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=4, seed=12,
+            max_action=1.0, actor_lr=3e-4, critic_lr=1e-3)
+    gen_td3("ddpg", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=13,
+            max_action=2.0, n_step=2, tau=0.01, gamma=0.97)
 
 
 def gen_sac_all() -> None:

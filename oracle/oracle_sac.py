@@ -252,3 +252,132 @@ def gradients(actor, critic1, critic2, alpha: float, obs, act, returns, noise, w
                                                critic_forward(c2, obs, a).flatten())).mean()
     out["actor_grads"] = _grads(loss, p)
     return out
+
+
+# =====================================================================================================
+# TD3 / DDPG (deterministic actor) on the same networks -- SURVEY 8f N3
+#   ContinuousActorDeterministic.forward   utils/net/continuous.py:70-85   (max_action * tanh(last(h)))
+#   ActorCriticOffPolicyAlgorithm._target_q      modelfree/ddpg.py:327-339
+#   DDPG._target_q_compute_action / _update_with_batch   ddpg.py:397-411
+#   TD3._target_q_compute_action / _update_with_batch    td3.py:190-226 (policy smoothing noise, delayed actor)
+# =====================================================================================================
+DET_ACTOR_ORDER = ["w1", "b1", "w2", "b2", "wa", "ba"]
+TIANSHOU_DET_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                           "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                           "last.model.0.weight", "last.model.0.bias"]
+
+
+def init_td3_params(obs_dim: int, act_dim: int, seed: int, twin: bool = True, hidden: int = 256):
+    """RNG consumption of examples/mujoco/mujoco_td3.py:85-103 (mujoco_ddpg.py without the second critic):
+    Net(actor), actor.last, Net(critic1)[, Net(critic2)], critic1.last[, critic2.last]."""
+    torch.manual_seed(seed)
+    L = torch.nn.Linear
+    wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
+    flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
+    a = [L(obs_dim, hidden), L(hidden, hidden), L(hidden, act_dim)]
+    if twin:
+        c = [L(obs_dim + act_dim, hidden), L(hidden, hidden), L(obs_dim + act_dim, hidden), L(hidden, hidden),
+             L(hidden, 1), L(hidden, 1)]
+        c1, c2 = [c[0], c[1], c[4]], [c[2], c[3], c[5]]
+    else:
+        c = [L(obs_dim + act_dim, hidden), L(hidden, hidden), L(hidden, 1)]
+        c1, c2 = c, None
+    return (dict(zip(DET_ACTOR_ORDER, flat(a))), dict(zip(CRITIC_ORDER, flat(c1))),
+            dict(zip(CRITIC_ORDER, flat(c2))) if twin else None)
+
+
+def det_actor_forward(p, obs, max_action: float = 1.0):
+    h = F.relu(F.linear(obs, p["w1"], p["b1"]))
+    h = F.relu(F.linear(h, p["w2"], p["b2"]))
+    return max_action * torch.tanh(F.linear(h, p["wa"], p["ba"]))
+
+
+@dataclass
+class TD3Config:
+    gamma: float = 0.99
+    tau: float = 0.005
+    n_step: int = 1
+    twin: bool = True               # False = DDPG
+    policy_noise: float = 0.2
+    noise_clip: float = 0.5
+    update_actor_freq: int = 2
+    max_action: float = 1.0
+    actor_lr: float = 1e-3
+    critic_lr: float = 1e-3
+    betas: tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+
+
+@dataclass
+class TD3State:
+    actor: dict
+    critic1: dict
+    critic2: dict | None
+    actor_old: dict
+    critic1_old: dict
+    critic2_old: dict | None
+    opt_actor: Adam
+    opt_c1: Adam
+    opt_c2: Adam
+    cnt: int = 0
+    last_actor_loss: float = 0.0
+
+    @classmethod
+    def create(cls, actor, critic1, critic2, cfg: TD3Config):
+        cp = lambda d: None if d is None else {k: v.clone() for k, v in d.items()}  # noqa: E731
+        mk = lambda lr: Adam(lr, cfg.betas, cfg.adam_eps)                            # noqa: E731
+        return cls(cp(actor), cp(critic1), cp(critic2), cp(actor), cp(critic1), cp(critic2),
+                   mk(cfg.actor_lr), mk(cfg.critic_lr), mk(cfg.critic_lr))
+
+
+def td3_target_q(st: TD3State, cfg: TD3Config, obs_next, noise=None) -> torch.Tensor:
+    """ddpg.py:327-339 with DDPG's lagged actor (:397-399) or TD3's smoothed one (td3.py:190-202) -> [B, 1]."""
+    with torch.no_grad():
+        act = det_actor_forward(st.actor_old, obs_next, cfg.max_action)
+        if cfg.twin:
+            n = torch.as_tensor(noise, dtype=torch.float32) * cfg.policy_noise
+            if cfg.noise_clip > 0.0:
+                n = n.clamp(-cfg.noise_clip, cfg.noise_clip)
+            act = act + n
+            return torch.min(critic_forward(st.critic1_old, obs_next, act), critic_forward(st.critic2_old, obs_next, act))
+        return critic_forward(st.critic1_old, obs_next, act)
+
+
+def td3_update_with_batch(st: TD3State, cfg: TD3Config, obs, act, returns, weight=None, collect=None):
+    """td3.py:204-226 (twin) / ddpg.py:401-411 -> dict(actor_loss, critic1_loss[, critic2_loss], weight)."""
+    obs = torch.as_tensor(obs, dtype=torch.float32)
+    act = torch.as_tensor(act, dtype=torch.float32)
+    ret = torch.as_tensor(returns, dtype=torch.float32).flatten()
+    w = 1.0 if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+    out, tds = {}, []
+    for name, opt in (("critic1", st.opt_c1), ("critic2", st.opt_c2)):
+        if getattr(st, name) is None:
+            continue
+        p = {k: v.clone().requires_grad_(True) for k, v in getattr(st, name).items()}
+        td = critic_forward(p, obs, act).flatten() - ret
+        loss = (td.pow(2) * w).mean()
+        g = _grads(loss, p)
+        if collect is not None:
+            collect[name + "_grads"] = g
+        setattr(st, name, opt.apply(getattr(st, name), g))
+        tds.append(td.detach())
+        out[name + "_loss"] = float(loss.item())
+    out["weight"] = (tds[0] + tds[1]) / 2.0 if cfg.twin else tds[0]
+    freq = cfg.update_actor_freq if cfg.twin else 1
+    if st.cnt % freq == 0:
+        p = {k: v.clone().requires_grad_(True) for k, v in st.actor.items()}
+        actor_loss = -critic_forward(st.critic1, obs, det_actor_forward(p, obs, cfg.max_action)).mean()
+        g = _grads(actor_loss, p)
+        if collect is not None:
+            collect["actor_grads"] = g
+        st.actor = st.opt_actor.apply(st.actor, g)
+        st.last_actor_loss = float(actor_loss.item())
+        pairs = [(st.actor_old, st.actor), (st.critic1_old, st.critic1)]
+        if cfg.twin:
+            pairs.append((st.critic2_old, st.critic2))
+        for old, new in pairs:                                                  # lagged_network.py:17-18
+            for k in old:
+                old[k] = cfg.tau * new[k] + (1 - cfg.tau) * old[k]
+    st.cnt += 1
+    out["actor_loss"] = st.last_actor_loss
+    return out

@@ -1,0 +1,91 @@
+"""GPU parity of TD3 / DDPG through the C ABI against oracle/oracle_sac.py's TD3 restatement
+(pinned to the reference by tests/golden/td3_*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_sac as OS
+from tests.test_oracle_golden import load_td3
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_engine(obs_dim, act_dim, seed, cfg):
+    from tianshou_amd import td3 as T
+
+    actor, c1, c2 = OS.init_td3_params(obs_dim, act_dim, seed, cfg.twin)
+    eng = T.TD3Engine(
+        obs_dim, act_dim, T.actor_flat_from_torch([actor[k] for k in OS.DET_ACTOR_ORDER], obs_dim, act_dim),
+        T.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
+        T.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim) if cfg.twin else None,
+        T.TD3Config(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "twin", "policy_noise", "noise_clip",
+                                                     "update_actor_freq", "max_action", "actor_lr", "critic_lr")}))
+    return eng, (actor, c1, c2)
+
+
+@pytest.mark.parametrize("twin", [True, False])
+def test_policy_target_and_gradients_vs_oracle(twin):
+    from tianshou_amd import td3 as T
+
+    obs_dim, act_dim, B = 376, 17, 512
+    cfg = OS.TD3Config(twin=twin, max_action=1.5, actor_lr=0.0, critic_lr=0.0, tau=0.0, update_actor_freq=1)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 21, cfg)
+    for a, k in zip(T.actor_flat_to_torch(eng.actor, obs_dim, act_dim), OS.DET_ACTOR_ORDER):
+        assert torch.equal(a.cpu(), actor[k]), k
+    g = torch.Generator().manual_seed(3)
+    obs = torch.randn(B, obs_dim, generator=g)
+    act = torch.rand(B, act_dim, generator=g) * 3 - 1.5
+    ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+    st = OS.TD3State.create(actor, c1, c2, cfg)
+    with torch.no_grad():
+        assert rel_err(eng.policy_forward(obs).cpu(), OS.det_actor_forward(actor, obs, cfg.max_action)) < 1e-5
+    np.testing.assert_allclose(eng.target_q(obs, noise if twin else None).cpu().numpy(),
+                               OS.td3_target_q(st, cfg, obs, noise).flatten().numpy(), rtol=1e-5, atol=1e-5)
+    col: dict = {}
+    ref = OS.td3_update_with_batch(st, cfg, obs, act, ret, collect=col)
+    lay = eng.lay
+    grads = torch.zeros(2 * lay["critic_count"] + lay["actor_count"], dtype=torch.float32, device="cuda")
+    stats, w = eng.update_with_batch(obs, act, ret, grads_out=grads)
+    s = stats.cpu().numpy()
+    np.testing.assert_allclose(s[:2], [ref["actor_loss"], ref["critic1_loss"]], rtol=1e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+    pc = lay["critic_count"]
+    got = {"critic1": T.critic_flat_to_torch(grads[:pc], obs_dim, act_dim),
+           "actor": T.actor_flat_to_torch(grads[2 * pc:], obs_dim, act_dim)}
+    if twin:
+        got["critic2"] = T.critic_flat_to_torch(grads[pc:2 * pc], obs_dim, act_dim)
+    for name, tensors in got.items():
+        order = OS.DET_ACTOR_ORDER if name == "actor" else OS.CRITIC_ORDER
+        for t, key in zip(tensors, order):
+            assert rel_err(t.cpu(), col[name + "_grads"][key]) < 2e-5, (name, key)
+
+
+@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+def test_update_matches_reference_golden(tag):
+    from tianshou_amd import td3 as T
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, cfg, bstate = load_td3(tag)
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg)
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
+    for u in range(d["n_updates"]):
+        idx = torch.as_tensor(g[f"u{u}_indices"]).cuda()
+        ret = eng.preprocess(buf, idx, g[f"u{u}_noise"] if d["twin"] else None)
+        np.testing.assert_allclose(ret.cpu().numpy(), g[f"u{u}_returns"], rtol=1e-5, atol=2e-5)
+        stats, _ = eng.update_with_batch(buf.obs[idx], buf.act[idx], ret)
+        s, ref = stats.cpu().numpy(), g[f"u{u}_stats"]
+        np.testing.assert_allclose(s[:len(ref)], ref, rtol=2e-5, atol=1e-7)
+        names = ["actor", "critic1", "actor_old", "critic1_old"] + (["critic2", "critic2_old"] if d["twin"] else [])
+        for name in names:
+            conv = T.actor_flat_to_torch if name.startswith("actor") else T.critic_flat_to_torch
+            flat = torch.cat([t.reshape(-1) for t in conv(getattr(eng, name), d["obs_dim"], d["act_dim"])])
+            lr = cfg.actor_lr if name.startswith("actor") else cfg.critic_lr
+            np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
+                                       err_msg=name)

@@ -372,3 +372,45 @@ def test_buffer_add_restatement_matches_reference():
         assert np.array_equal(wr.rew, g[f"s{s}_final_rew"])
         assert np.array_equal(wr.done.astype(bool), g[f"s{s}_final_done"])
         assert np.array_equal(wr.terminated.astype(bool), g[f"s{s}_final_terminated"])
+
+
+# ------------------------------------------------------------------------------------ TD3 / DDPG
+def load_td3(tag):
+    from oracle import oracle_sac as OS
+
+    g = load(f"td3_{tag}.npz")
+    E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, twin, n_step = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OS.TD3Config(gamma=c["gamma"], tau=c["tau"], n_step=int(c["n_step"]), twin=bool(c["twin"]),
+                       policy_noise=c["policy_noise"], noise_clip=c["noise_clip"],
+                       update_actor_freq=int(c["update_actor_freq"]), max_action=c["max_action"],
+                       actor_lr=c["actor_lr"], critic_lr=c["critic_lr"])
+    d = dict(obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed, twin=bool(twin))
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, d, cfg, bstate
+
+
+@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+def test_td3_ddpg_restatement_matches_reference(tag):
+    from oracle import oracle_sac as OS
+
+    g, d, cfg, bstate = load_td3(tag)
+    st = OS.TD3State.create(*OS.init_td3_params(d["obs_dim"], d["act_dim"], d["seed"], d["twin"]), cfg)
+    obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        noise = g[f"u{u}_noise"] if d["twin"] else None
+        ret, _ = O.compute_nstep_return(bstate, idx, lambda after: OS.td3_target_q(st, cfg, obs_next_all[after], noise).numpy(),
+                                        cfg.gamma, cfg.n_step)
+        ret = ret.astype(np.float32).reshape(-1)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-5, atol=1e-5)
+        out = OS.td3_update_with_batch(st, cfg, obs_all[idx], g["act"][idx], ret)
+        ref = g[f"u{u}_stats"]
+        got = [out["actor_loss"], out["critic1_loss"]] + ([out["critic2_loss"]] if d["twin"] else [])
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
+        names = ["actor", "critic1", "actor_old", "critic1_old"] + (["critic2", "critic2_old"] if d["twin"] else [])
+        for name in names:
+            order = OS.DET_ACTOR_ORDER if name.startswith("actor") else OS.CRITIC_ORDER
+            np.testing.assert_allclose(OS.flatten(getattr(st, name), order).numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5,
+                                       atol=1e-6, err_msg=name)

@@ -286,6 +286,70 @@ __global__ __launch_bounds__(256) void polyak2_kernel(float* __restrict__ t1, co
     t2[i] = tau * s2[i] + omt * t2[i];
 }
 
+// ---- TD3 / DDPG (deterministic actor) ---------------------------------------------------------------------
+// ContinuousActorDeterministic.forward (continuous.py:70-85): a = max_action * tanh(head); TD3's target policy
+// smoothing (td3.py:195-199): a += clamp(noise * policy_noise, +-noise_clip) (no clamp when noise_clip <= 0)
+__global__ __launch_bounds__(256) void det_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
+                                                         int64_t B, int A, float max_action, float policy_noise,
+                                                         float noise_clip, int obs_dim, int kc, float* __restrict__ x_c,
+                                                         float* __restrict__ act_out, float* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    const int j = (int)(i - b * A);
+    const float t = tanhf(head[b * 32 + j]);
+    float a = max_action * t;
+    if (noise) {
+        float n = noise[i] * policy_noise;
+        if (noise_clip > 0.f) n = fminf(fmaxf(n, -noise_clip), noise_clip);
+        a += n;
+    }
+    if (x_c) x_c[b * kc + obs_dim + j] = a;
+    if (act_out) act_out[i] = a;
+    if (keep) keep[i] = t;
+}
+
+__global__ __launch_bounds__(256) void td3_target_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                         int64_t B, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    out[b] = q2 ? fminf(q1[b * 32], q2[b * 32]) : q1[b * 32];
+}
+
+// actor loss = -Q1(s, pi(s)).mean()  (ddpg.py:407, td3.py:216)
+__global__ __launch_bounds__(1024) void det_actor_loss_kernel(const float* __restrict__ q1, int64_t B,
+                                                              float* __restrict__ d_q1, float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) { ls += q1[b * 32]; d_q1[b * 32] = -inv_b; }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss = -(tot * inv_b);
+}
+
+__global__ __launch_bounds__(256) void det_policy_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ keep,
+                                                             int64_t B, int A, float max_action, int obs_dim, int kc,
+                                                             float* __restrict__ d_head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    const int j = (int)(i - b * A);
+    const float t = keep[i];
+    d_head[b * 32 + j] = dx[b * kc + obs_dim + j] * max_action * (1.f - t * t);
+}
+
+__global__ __launch_bounds__(1024) void td3_weight_kernel(const float* __restrict__ td1, const float* __restrict__ td2,
+                                                          int64_t B, float* __restrict__ out) {
+    for (int64_t b = (int64_t)blockIdx.x * 1024 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 1024)
+        out[b] = td2 ? (td1[b] + td2[b]) / 2.f : td1[b];
+}
+
+__global__ __launch_bounds__(256) void polyak1_kernel(float* __restrict__ t, const float* __restrict__ s, int64_t n, float tau,
+                                                      float omt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) t[i] = tau * s[i] + omt * t[i];
+}
+
 size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Carve {
@@ -510,6 +574,178 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     if (hp->tau > 0.0)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, pc, (float)hp->tau, (float)(1.0 - hp->tau));
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// ---- TD3 / DDPG ------------------------------------------------------------------------------------------------
+int ts_td3_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out4) {
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    TS_REQUIRE(h_out4, TS_ERR_INVALID_ARG, "ts_td3_layout: NULL output");
+    h_out4[0] = d.ka; h_out4[1] = d.kc;
+    h_out4[2] = make_mlp(1, d.ka, 32).off[3]; h_out4[3] = make_mlp(1, d.kc, 32).off[3];
+    return TS_OK;
+}
+
+int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs, int64_t B, int64_t obs_dim,
+                          int64_t act_dim, double max_action, float* act_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_td3_policy_forward: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && obs && act_out, TS_ERR_INVALID_ARG, "ts_td3_policy_forward: bad argument");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 32);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * HID) + al(4 * split_floats(ma)) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    const Act aa = take_act(c, B, 32);
+    float* split = c.take<float>(split_floats(ma));
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out,
+                       (const float*)nullptr, B, d.act, (float)max_action, 0.f, 0.f, d.obs, d.kc, (float*)nullptr, act_out,
+                       (float*)nullptr);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* critic1_old, const float* critic2_old,
+                    const float* obs_next, const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim,
+                    double max_action, double policy_noise, double noise_clip, float* out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_td3_target_q: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor_old && critic1_old && obs_next && out, TS_ERR_INVALID_ARG, "ts_td3_target_q: bad argument");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
+    const size_t spl = std::max(split_floats(ma), split_floats(mc));
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + al(4 * spl) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);
+    const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    float* split = c.take<float>(spl);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    if (int rc = mlp_forward(s, ws, ma, actor_old, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise, B,
+                       d.act, (float)max_action, (float)policy_noise, (float)noise_clip, d.obs, d.kc, x_c, (float*)nullptr,
+                       (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+    if (critic2_old)
+        if (int rc = mlp_forward(s, ws, mc, critic2_old, x_c, a2, split)) return rc;
+    hipLaunchKernelGGL(td3_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out,
+                       critic2_old ? a2.out : (const float*)nullptr, B, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step, int64_t actor_step, const float* obs,
+                  const float* act, const float* returns, const float* weight, int64_t B, int64_t obs_dim,
+                  int64_t act_dim, const ts_td3_hparams* hp, float* stats_out3, float* weight_out, float* grads_out,
+                  ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_td3_update: workspace is NULL");
+    TS_REQUIRE(st && hp && obs && act && returns && stats_out3 && B >= 1 && critic_step >= 1 && actor_step >= 1,
+               TS_ERR_INVALID_ARG, "ts_td3_update: bad argument");
+    TS_REQUIRE(st->actor && st->actor_m && st->actor_v && st->critic1 && st->critic1_m && st->critic1_v &&
+                   st->actor_old && st->critic1_old, TS_ERR_INVALID_ARG, "ts_td3_update: NULL state pointer");
+    const bool twin = st->critic2 != nullptr;
+    TS_REQUIRE(!twin || (st->critic2_m && st->critic2_v && st->critic2_old), TS_ERR_INVALID_ARG,
+               "ts_td3_update: incomplete second critic");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
+    const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
+    const size_t spl = std::max(split_floats(ma), split_floats(mc));
+    const int64_t pa = ma.off[3], pc = mc.off[3];
+    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * B * 32) +
+                         4 * al(4 * B * HID) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
+                         al(4 * B * d.act) + 2 * al(4 * spl) + 8192;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);
+    float* x_p = c.take<float>(B * d.kc);
+    float* dx1 = c.take<float>(B * d.kc);
+    const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    float* dheads[2] = {c.take<float>(B * 32), c.take<float>(B * 32)};
+    BwdScratch scs[2];
+    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * HID); scs[k].dh1 = c.take<float>(B * HID); scs[k].slabs = c.take<float>(slab); }
+    float* gbuf[2] = {c.take<float>(std::max(pa, pc)), c.take<float>(std::max(pa, pc))};
+    float* tds[2] = {c.take<float>(B), c.take<float>(B)};
+    float* keep = c.take<float>(B * d.act);
+    float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
+    float* norm_part = c.take<float>(1024);
+    float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
+
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 32, s));
+    TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 32, s));
+    // critics (ddpg.py:279-285): critic 1 on the caller's stream, critic 2 on the side stream
+    hipStream_t stq[2] = {s, side};
+    float* crit[2] = {st->critic1, st->critic2};
+    float* crit_m[2] = {st->critic1_m, st->critic2_m};
+    float* crit_v[2] = {st->critic1_v, st->critic2_v};
+    const Act acts[2] = {a1, a2};
+    if (twin)
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    for (int k = 0; k < (twin ? 2 : 1); ++k) {
+        hipStream_t sk = stq[k];
+        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                           dheads[k], stats_out3 + 1 + k);
+        TS_LAUNCH_CHECK();
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
+        if (hp->critic_lr >= 0.0)
+            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, critic_step, hp->critic_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
+                return rc;
+    }
+    if (twin)
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    if (weight_out)
+        hipLaunchKernelGGL(td3_weight_kernel, dim3(16), dim3(1024), 0, s, tds[0], twin ? tds[1] : (const float*)nullptr, B,
+                           weight_out);                                          // td3.py:212 / ddpg.py:405
+    if (hp->update_actor) {                                                      // td3.py:215-219, ddpg.py:406-409
+        TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
+        if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, splits[0])) return rc;
+        hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out,
+                           (const float*)nullptr, B, d.act, (float)hp->max_action, 0.f, 0.f, d.obs, d.kc, x_p,
+                           (float*)nullptr, keep);
+        if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, splits[0])) return rc;
+        TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 32, s));
+        hipLaunchKernelGGL(det_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, B, dheads[1], stats_out3);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, dheads[1], nullptr, dx1, d.obs, d.obs + d.act, scs[0]))
+            return rc;
+        TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 32, s));
+        hipLaunchKernelGGL(det_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, dx1, keep, B,
+                           d.act, (float)hp->max_action, d.obs, d.kc, dheads[0]);
+        TS_LAUNCH_CHECK();
+        float* ga = g_out[2] ? g_out[2] : gbuf[0];
+        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, dheads[0], ga, nullptr, 0, 0, scs[0])) return rc;
+        if (hp->actor_lr >= 0.0)
+            if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, pa, actor_step, hp->actor_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
+                return rc;
+        if (hp->tau > 0.0) {                                                     // lagged_network.py:17-18
+            const float tau = (float)hp->tau, omt = (float)(1.0 - hp->tau);
+            hipLaunchKernelGGL(polyak1_kernel, dim3((unsigned)ts::ceil_div(pa, 256)), dim3(256), 0, s, st->actor_old,
+                               st->actor, pa, tau, omt);
+            if (twin)
+                hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
+                                   st->critic1, st->critic2_old, st->critic2, pc, tau, omt);
+            else
+                hipLaunchKernelGGL(polyak1_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
+                                   st->critic1, pc, tau, omt);
+        }
+    }
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
