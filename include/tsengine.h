@@ -305,15 +305,17 @@ int ts_ppo_pack_batch(const float* obs, const float* act, const float* adv, cons
  *                 ent) with clip / vf as local sums / global_batch (all-reduce-sum them too and
  *                 recompute loss = clip + vf_coef*vf - ent_coef*ent).  adv_stats (device float32[2]
  *                 = {mean, std} of the GLOBAL minibatch) is required when hp->adv_norm.
- *   ts_ppo_apply: clip by global norm + Adam step number `adam_step` (1-based) using the
- *                 all-reduced gradient (grad_scratch is unused, kept for ABI stability). */
+ *                 loss_parts_out[0] is written as 0: the caller composes the loss after the all-reduce.
+ *   ts_ppo_apply: clip by global norm + Adam step number `adam_step` (1-based) using the all-reduced gradient;
+ *                 `ws` (nullable) = the workspace ts_ppo_grad runs on: its cached weight images are refreshed in
+ *                 place (otherwise call ts_ppo_invalidate_image after changing the parameters by other means). */
 int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
                 const float* rec, int64_t n, const int64_t* perm_rows, int64_t n_rows,
                 int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp,
                 float* grad_out, float* loss_parts_out, ts_stream_t stream);
-int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
-                 int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
-                 ts_stream_t stream);
+int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                 int64_t act_dim, const float* grad, const ts_ppo_hparams* hp, ts_stream_t stream);
+int ts_ppo_invalidate_image(ts_workspace* ws);
 
 /* ---------------------------------------------------------------------------------------------
  * Target networks

@@ -57,6 +57,9 @@ class OracleBackedDP(DataParallelPPO):
     def _pack(self, b):
         return b
 
+    def _begin_update(self):
+        pass
+
     def _local_grad(self, rec, rows, global_batch, adv_stats, out):
         import dataclasses
 

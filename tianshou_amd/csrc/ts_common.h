@@ -63,6 +63,11 @@ struct ts_workspace {
     int ev_cap, ev_n;
     // second stream for independent kernels of one entry point (e.g. weight- and input-gradient GEMMs of a layer):
     // forked from / joined into the caller's stream with events, created on first use
+    // PPO data-parallel path: persistent LDS images + param -> slot table (see ts_ppo.hip dp_image)
+    void* ppo_image;
+    size_t ppo_image_bytes;
+    const float* ppo_image_params;
+    int ppo_image_key;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;

@@ -149,6 +149,7 @@ int ts_workspace_destroy(ts_workspace* ws) {
         for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ws->side_ev[i]);
         (void)hipStreamDestroy(ws->side);
     }
+    if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }
     if (ws->base || ws->winner || ws->ev || ws->gae_sync) {
         (void)hipSetDevice(ws->device);
         (void)hipDeviceSynchronize();

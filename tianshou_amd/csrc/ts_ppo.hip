@@ -963,7 +963,8 @@ __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const flo
                                                                        float* __restrict__ sumsq_part,
                                                                        const float* __restrict__ params,
                                                                        int sig_off, int act,
-                                                                       float* __restrict__ losses) {
+                                                                       float* __restrict__ losses,
+                                                                       float* __restrict__ parts) {
     __shared__ float red[RED_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -978,19 +979,25 @@ __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const flo
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
-        if (col < n_cols) grad[col] = t;
+        // data-parallel path (parts != NULL): grad holds only the n_params gradient columns, the two loss sums go
+        // to parts[1] (clip) and parts[2] (vf); parts[3] = entropy below, parts[0] is composed by the caller
+        if (col < (parts ? n_params : n_cols)) grad[col] = t;
+        if (parts && col == n_params) parts[1] = t;
+        if (parts && col == n_params + 1) parts[2] = t;
         float q = (col < n_params) ? t * t : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
         if (lane == 0) sumsq_part[blockIdx.x] = q;
-        if (losses && blockIdx.x == 0 && lane == 0) {
+        if (parts && blockIdx.x == 0 && lane == 0) parts[0] = 0.f;
+        if ((losses || parts) && blockIdx.x == 0 && lane == 0) {
             // Normal.entropy() = 0.5 + 0.5 log(2 pi) + log(sigma), summed over actions; identical
             // for every sample, so its batch mean (ppo.py:210) is the value itself.  Computed here,
             // before the Adam kernel touches sigma_param.
             float ent = 0.f;
             for (int k = 0; k < act; ++k)
                 ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(params[sig_off + k]));
-            losses[3] = ent;
+            if (losses) losses[3] = ent;
+            if (parts) parts[3] = ent;
         }
     }
 }
@@ -1275,10 +1282,33 @@ int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float
     return TS_OK;
 }
 
+// Persistent images for the data-parallel path (ts_ppo_grad / ts_ppo_apply): owned by the workspace, rebuilt when
+// the parameter vector, the dimensions or the validity flag change, refreshed in place by ts_ppo_apply's Adam.
+int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d, int ks, float** image, int** inv) {
+    const ImageBuf ib = image_buf(d, ks);
+    const size_t need = ib.img_bytes + ib.inv_bytes;
+    const int key = (d.obs << 8) | d.act;
+    if (ws->ppo_image_bytes < need) {
+        TS_HIP_CHECK(hipSetDevice(ws->device));
+        if (ws->ppo_image) { TS_HIP_CHECK(hipDeviceSynchronize()); TS_HIP_CHECK(hipFree(ws->ppo_image)); }
+        TS_HIP_CHECK(hipMalloc(&ws->ppo_image, need));
+        ws->ppo_image_bytes = need;
+        ws->ppo_image_params = nullptr;
+    }
+    *image = static_cast<float*>(ws->ppo_image);
+    *inv = reinterpret_cast<int*>(static_cast<char*>(ws->ppo_image) + ib.img_bytes);
+    if (ws->ppo_image_params != params || ws->ppo_image_key != key) {
+        if (int rc = build_image(s, params, d, ks, *image, *inv)) return rc;
+        ws->ppo_image_params = params;
+        ws->ppo_image_key = key;
+    }
+    return TS_OK;
+}
+
 // forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
 // grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
 int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
-             float* sumsq, float* losses, hipStream_t s) {
+             float* sumsq, float* losses, hipStream_t s, float* parts = nullptr) {
     const int64_t obs_dim = d.obs;
     int rc = TS_OK;
     const int n_wg = step_grid(g.n_rows);
@@ -1289,7 +1319,7 @@ int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, f
         ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
         hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
                            n_wg, slab_w, d.p_total + N_EXTRA, d.p_total, grad, sumsq, g.params, d.a_sig, d.act,
-                           losses);
+                           losses, parts);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1512,13 +1542,12 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
     const int ks = supported_ks(ks1_for((int)obs_dim));
     const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
     const WsLayout wl = ws_layout(step_grid(n_rows), slab_w, 1);
-    const ImageBuf ib = image_buf(d, ks);
-    rc = ts::ws_reserve(ws, wl.total + ib.img_bytes + ib.inv_bytes);
+    rc = ts::ws_reserve(ws, wl.total);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     hipStream_t s = ts::as_stream(stream);
-    float* image = reinterpret_cast<float*>(base + wl.total);
-    rc = build_image(s, params, d, ks, image, nullptr);       // gradient only: nobody refreshes the image
+    float* image; int* inv;
+    rc = dp_image(ws, s, params, d, ks, &image, &inv);
     if (rc != TS_OK) return rc;
     StepArgs g{};
     g.params = params; g.rec = rec; g.rec_w = rec_width(obs_dim, act_dim);
@@ -1526,20 +1555,10 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
     g.inv_batch = 1.0f / (float)global_batch;
     g.adv_stats = hp->adv_norm ? adv_stats : nullptr;
     fill_hparams(g, hp);
-    float* grad = reinterpret_cast<float*>(base + wl.grad);
-    rc = run_grad(ws, g, d, ks, slab_w, reinterpret_cast<float*>(base + wl.slabs), grad,
-                  reinterpret_cast<float*>(base + wl.sumsq), loss_parts_out, s);
-    if (rc != TS_OK) return rc;
-    TS_HIP_CHECK(hipMemcpyAsync(grad_out, grad, sizeof(float) * (size_t)d.p_total, hipMemcpyDeviceToDevice, s));
-    if (loss_parts_out) {
-        // (loss, clip, vf, ent): clip / vf local sums; loss composed from the local parts
-        AdamArgs a = adam_args(const_cast<float*>(params), nullptr, nullptr, 1, d, hp);
-        a.grad = grad; a.sumsq_part = reinterpret_cast<float*>(base + wl.sumsq); a.n_part = wl.n_red_blocks;
-        a.losses = loss_parts_out; a.apply = 0;
-        hipLaunchKernelGGL(ppo_adam_kernel, dim3(1), dim3(ADAM_THREADS), 0, s, a);
-        TS_LAUNCH_CHECK();
-    }
-    return TS_OK;
+    // the slab reduction writes the gradient straight into grad_out and the loss sums into loss_parts_out
+    float* parts = loss_parts_out ? loss_parts_out : reinterpret_cast<float*>(base + wl.advstats);
+    return run_grad(ws, g, d, ks, slab_w, reinterpret_cast<float*>(base + wl.slabs), grad_out,
+                    reinterpret_cast<float*>(base + wl.sumsq), nullptr, s, parts);
 }
 
 int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
@@ -1582,10 +1601,14 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     return TS_OK;
 }
 
-int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
-                 int64_t act_dim, const float* grad, float* grad_scratch, const ts_ppo_hparams* hp,
-                 ts_stream_t stream) {
-    (void)grad_scratch;
+int ts_ppo_invalidate_image(ts_workspace* ws) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_invalidate_image: workspace is NULL");
+    ws->ppo_image_params = nullptr;
+    return TS_OK;
+}
+
+int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                 int64_t act_dim, const float* grad, const ts_ppo_hparams* hp, ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
     TS_REQUIRE(params && adam_m && adam_v && grad && hp, TS_ERR_INVALID_ARG, "ts_ppo_apply: NULL argument");
@@ -1593,6 +1616,13 @@ int ts_ppo_apply(float* params, float* adam_m, float* adam_v, int64_t adam_step,
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     AdamArgs a = adam_args(params, adam_m, adam_v, adam_step, d, hp);
     a.grad = grad; a.sumsq_part = nullptr; a.n_part = 0; a.losses = nullptr; a.apply = 1;
+    if (ws && ws->ppo_image && ws->ppo_image_params == params && ws->ppo_image_key == ((d.obs << 8) | d.act)) {
+        // keep ts_ppo_grad's images current (same mechanism as ts_ppo_update)
+        const ImageBuf ib = image_buf(d, supported_ks(ks1_for((int)obs_dim)));
+        a.image = static_cast<float*>(ws->ppo_image);
+        a.inv = reinterpret_cast<const int*>(static_cast<char*>(ws->ppo_image) + ib.img_bytes);
+        a.sig_off = d.a_sig; a.act = d.act; a.small0 = ib.img_end - 32;
+    }
     hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
                        dim3(ADAM_THREADS), 0, ts::as_stream(stream), a);
     TS_LAUNCH_CHECK();

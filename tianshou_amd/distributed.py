@@ -77,12 +77,17 @@ class DataParallelPPO:
         hp = eng.cfg.to_c()
         eng.adam_step += 1
         _lib.check(lib.ts_ppo_apply(
-            _lib.ptr(eng.params), _lib.ptr(eng.adam_m), _lib.ptr(eng.adam_v), _lib.i64(eng.adam_step),
-            _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim), _lib.ptr(grad), None, C.byref(hp),
+            eng._ws.handle, _lib.ptr(eng.params), _lib.ptr(eng.adam_m), _lib.ptr(eng.adam_v), _lib.i64(eng.adam_step),
+            _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim), _lib.ptr(grad), C.byref(hp),
             _lib.current_stream(eng.device)))
 
     def _pack(self, b):
         return pack_batch(b, self.eng.obs_dim, self.eng.act_dim)
+
+    def _begin_update(self):
+        # the parameters may have been changed outside ts_ppo_apply since the last update (fused path,
+        # load_state_dict): make ts_ppo_grad rebuild its cached weight images once
+        _lib.check(_lib.load().ts_ppo_invalidate_image(self.eng._ws.handle))
 
     # -- update loop ----------------------------------------------------------------------------
     def update(self, b: dict, batch_size: int | None, repeat: int, perms):
@@ -96,6 +101,7 @@ class DataParallelPPO:
         dev = b["obs"].device
         offs = split_offsets(n, batch_size, merge_last=True)
         rec = self._pack(b)
+        self._begin_update()
         steps = [(r, lo, hi) for r in range(repeat) for lo, hi in zip(offs[:-1], offs[1:])]
         perm_t = [p.to(device=dev, dtype=torch.int64) if isinstance(p, torch.Tensor)
                   else torch.as_tensor(np.asarray(p, dtype=np.int64), device=dev) for p in perms]
