@@ -429,7 +429,6 @@ struct StepArgs {
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
     long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
-    int dbg_mode;             // diagnostics: 1 = stop after the first prologue, 2 = skip record fetch, 3 = skip staging
 };
 
 #define TS_MARK(g, k)                                                                  \
@@ -1206,9 +1205,6 @@ int n_compute_units() {
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
     const size_t lds = step_lds_bytes<KS1>();
-    static int dbg_mode = -1;
-    if (dbg_mode < 0) { const char* e = getenv("TS_PPO_DBG_MODE"); dbg_mode = e ? atoi(e) : 0; }
-    const_cast<StepArgs&>(g).dbg_mode = dbg_mode;
     static bool attr_done = false;
     if (!attr_done) {
         TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step_kernel<KS1>),
