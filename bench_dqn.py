@@ -99,7 +99,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
         u = torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws
         idx, wt = per.sample(u)
         ret = eng.preprocess(buf, frames, idx, C)
-        obs = D.gather_obs_nhwc(frames, buf, idx, C)
+        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
         loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
         per.update_weight(idx, td)
         return loss

@@ -103,7 +103,7 @@ def run(steps: int, warmup: int, repeat: int = 2, with_cpu: bool = True) -> dict
     # per-kernel-kind timing of ONE minibatch step
     pre = eng.preprocess(buf, frames, act, C)
     rows = random_permutation(n, 12345, dev)[:MINIBATCH]
-    obs = PC.gather_obs_nhwc(frames, buf, pre["indices"][rows], C)
+    obs = PC.gather_obs_nhwc(frames, buf, pre["indices"][rows], C, as_u8=True)
     ws = _lib.default_workspace(0)
     torch.cuda.synchronize()
     ws.profile_begin()

@@ -350,6 +350,9 @@ int ts_stack_indices(const int64_t* index, int64_t I, int64_t stack_num, const i
  * plane_index[b, c] = index[b] * C + c. */
 int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
                           int64_t B, int64_t C, float* out, ts_stream_t stream);
+/* Same gather with uint8 output [B, plane_elems, C] for the `obs_u8` mode of the network entry points below. */
+int ts_gather_planes_nhwc_u8(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
+                             int64_t B, int64_t C, uint8_t* out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layers on fp32 MFMA (NHWC activations)
@@ -359,13 +362,15 @@ int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_el
  * wb float32[KH*KW*IC + 1, OC] (row (kh, kw, ic) = torch weight[:, ic, kh, kw], last row = bias);
  * y float32[B, OH, OW, OC].  nn.Conv2d / nn.Linear (+ ReLU) forward as used by DQNet
  * (atari_network.py:79-98); a Linear layer is IH = IW = KH = KW = stride = 1.
- * Shape limits: KH*KW*IC % 32 == 0, OC % 32 == 0, 16-byte aligned im2col runs. */
-int ts_conv_forward(ts_workspace* ws, const float* x, const float* wb, float* y, const int64_t* h_dims, int relu,
-                    ts_stream_t stream);
+ * Shape limits: KH*KW*IC % 32 == 0, OC % 32 == 0, 16-byte aligned im2col runs.
+ * x_u8 != 0: x is uint8[B, IH, IW, IC] (raw frames, e.g. from ts_gather_planes_nhwc_u8); the kernels convert on load
+ * (exact), so the float32 copy of the observations -- 4x the HBM bytes -- is never materialised. */
+int ts_conv_forward(ts_workspace* ws, const void* x, int x_u8, const float* wb, float* y, const int64_t* h_dims,
+                    int relu, ts_stream_t stream);
 /* autograd of the same layer: d_wb float32[KH*KW*IC + 1, OC] = d loss / d wb given dy float32[B, OH, OW, OC];
  * dx (nullable) float32[B, IH, IW, IC] = d loss / d x, multiplied by (mask > 0) when `mask` (the layer
  * input as produced by a ReLU, nullable) is given.  dx needs KH % stride == 0 and IC % 32 == 0. */
-int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const float* dy, const float* mask,
+int ts_conv_backward(ts_workspace* ws, const void* x, int x_u8, const float* wb, const float* dy, const float* mask,
                      float* d_wb, float* dx, const int64_t* h_dims, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -381,10 +386,11 @@ int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const fl
 int64_t ts_dqn_param_count(int64_t c, int64_t h, int64_t w, int64_t n_act);
 int ts_dqn_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t* h_offsets6, int64_t* h_geom);
 
-/* DQNet.forward + DiscreteQLearningPolicy.forward (dqn.py:101-143): obs float32[B, h, w, c] (NHWC,
- * raw 0..255 values, no scaling) -> q_out float32[B, n_act], act_out (nullable) int64[B] = argmax_a. */
+/* DQNet.forward + DiscreteQLearningPolicy.forward (dqn.py:101-143): obs [B, h, w, c] NHWC, raw 0..255 values (no
+ * scaling), float32 (obs_u8 == 0) or uint8 (obs_u8 != 0) -> q_out float32[B, n_act], act_out (nullable)
+ * int64[B] = argmax_a.  The same obs / obs_u8 convention holds for every network entry point below. */
 int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
-                   const float* obs_nhwc, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream);
+                   const void* obs_nhwc, int obs_u8, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream);
 
 /* DQN._target_q (dqn.py:365-379) given Q_online(s') and Q_target(s') [B, n_act]:
  * is_double: q_target[b, argmax_a q_online[b, a]], else max_a q_target[b, a] -> out float32[B]. */
@@ -394,8 +400,8 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
 /* DQN._target_q end to end (dqn.py:365-379): Q_online(s') and Q_target(s') (params_old; NULL = no lagged net,
  * dqn.py:371-374) evaluated concurrently on two streams, then ts_dqn_target_q.  obs_next float32[B, h, w, c]. */
 int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
-                          int64_t w, int64_t n_act, const float* obs_next_nhwc, int64_t B, int is_double, float* out,
-                          ts_stream_t stream);
+                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                          float* out, ts_stream_t stream);
 
 typedef struct ts_dqn_hparams {
     double lr;            /* < 0: compute the gradient only (no optimizer step) */
@@ -409,7 +415,7 @@ typedef struct ts_dqn_hparams {
  * float32[1]; backward through DQNet; clip + Adam (adam_step = 1-based step of this call).
  * weight nullable (= 1.0).  grad_out (nullable) float32[P] receives the unclipped flat gradient. */
 int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
-                  int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act,
+                  int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
                   const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
                   float* loss_out, float* grad_out, ts_stream_t stream);
 
@@ -428,7 +434,7 @@ int ts_cnn_ac_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int6
  * v_out[b] = V(obs_b) (nullable); logp_out[b] = Categorical(logits(obs_b)).log_prob(act_b) (nullable, needs act);
  * logits_out (nullable) float32[B, n_act].  One trunk pass serves all outputs. */
 int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
-                    const float* obs_nhwc, const int64_t* act, int64_t B, float* v_out, float* logp_out,
+                    const void* obs_nhwc, int obs_u8, const int64_t* act, int64_t B, float* v_out, float* logp_out,
                     float* logits_out, ts_stream_t stream);
 
 /* One minibatch of PPO._update_with_batch (ppo.py:179-216) + Optimizer.step: forward, Categorical log-prob /
@@ -437,7 +443,7 @@ int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h,
  * advantages) is used when hp->adv_norm.  losses_out4 = {loss, clip, vf, ent}; hp->lr < 0: gradient only;
  * grad_out (nullable) float32[P] receives the unclipped gradient.  hp->algo must be 0. */
 int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
-                    int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act, const float* adv,
+                    int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act, const float* adv,
                     const float* returns, const float* logp_old, const float* v_old, int64_t B,
                     const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4, float* grad_out,
                     ts_stream_t stream);

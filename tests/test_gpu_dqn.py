@@ -101,6 +101,8 @@ def test_frame_stack_gather_bit_exact(tag):
     ref = OD.stacked_frames(bstate, g["frames"], idx, stack_num)          # [I, C, H, W] uint8
     out = D.gather_obs_nhwc(frames, buf, idx, stack_num)
     assert torch.equal(out.cpu(), torch.as_tensor(ref).permute(0, 2, 3, 1).float())
+    out8 = D.gather_obs_nhwc(frames, buf, idx, stack_num, as_u8=True)
+    assert out8.dtype == torch.uint8 and torch.equal(out8.cpu(), torch.as_tensor(ref).permute(0, 2, 3, 1))
     if stack_num > 1:
         st = D.stack_indices(buf, idx, stack_num).cpu().numpy()
         cur = idx.copy()
@@ -277,3 +279,31 @@ def test_bad_arguments_fail_loudly():
         D.DQNEngine(4, 84, 84, 6, flat.cpu(), D.DQNConfig())
     with pytest.raises(_lib.EngineError):                 # conv shape outside the kernel's limits: K % 32 != 0
         D.conv_forward(torch.zeros(1, 9, 9, 3, device="cuda"), torch.zeros(3 * 3 * 3 + 1, 32, device="cuda"), 3, 3, 1, True)
+
+
+def test_uint8_observations_give_bitwise_identical_results():
+    """obs_u8 mode (frames converted on load inside the conv kernels) vs the float32 copy of the same frames:
+    the conversion is exact, so Q-values, TD errors, loss and the post-Adam parameters are bit-identical."""
+    from tianshou_amd import dqn as D
+
+    c, h, w, A, B = 4, 84, 84, 6, 37
+    rng = np.random.default_rng(5)
+    obs8 = torch.as_tensor(rng.integers(0, 256, size=(B, h, w, c), dtype=np.uint8)).cuda()
+    obs32 = obs8.float()
+    act, ret = rng.integers(0, A, size=B), rng.normal(size=B).astype(np.float32)
+    p = OD.init_params(c, h, w, A, seed=8)
+    flat = D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, A)
+    cfg = D.DQNConfig(huber_delta=1.0, lr=1e-4, target_update_freq=1)
+    e8, e32 = D.DQNEngine(c, h, w, A, flat, cfg), D.DQNEngine(c, h, w, A, flat, cfg)
+    assert torch.equal(e8.forward(obs8)[0], e32.forward(obs32)[0])
+    assert torch.equal(e8.target_q(obs8), e32.target_q(obs32))
+    l8, td8 = e8.update_with_batch(obs8, act, ret)
+    l32, td32 = e32.update_with_batch(obs32, act, ret)
+    assert torch.equal(td8, td32) and torch.equal(l8, l32) and torch.equal(e8.params, e32.params)
+    # single layer, backward included
+    wb = torch.randn(8 * 8 * 4 + 1, 32, device="cuda") * 0.05
+    y8, y32 = D.conv_forward(obs8, wb, 8, 8, 4, True), D.conv_forward(obs32, wb, 8, 8, 4, True)
+    assert torch.equal(y8, y32)
+    dy = torch.randn_like(y8)
+    assert torch.equal(D.conv_backward(obs8, wb, dy, 8, 8, 4, need_dx=False)[0],
+                       D.conv_backward(obs32, wb, dy, 8, 8, 4, need_dx=False)[0])

@@ -103,3 +103,23 @@ def test_minibatch_gradient_vs_oracle(adv_norm, dual, vclip):
     off, _ = PC.layer_layout(c, h, w, A)
     for i in range(5):
         assert rel_err(grad[off[i]:off[i + 1]].cpu(), g_ref[off[i]:off[i + 1]]) < 2e-5, f"layer {i}"
+
+
+def test_uint8_observations_give_bitwise_identical_results():
+    from tianshou_amd import ppo_cnn as PC
+
+    c, h, w, A, B = 4, 84, 84, 6, 50
+    rng = np.random.default_rng(2)
+    obs8 = torch.as_tensor(rng.integers(0, 256, size=(B, h, w, c), dtype=np.uint8)).cuda()
+    act = rng.integers(0, A, size=B)
+    f = lambda: torch.as_tensor(rng.normal(size=B).astype(np.float32)).cuda()  # noqa: E731
+    adv, ret, lp, vo = f(), f(), f() - 2.0, f()
+    p = OC.init_params(c, h, w, A, seed=1)
+    flat = PC.flat_from_torch([p[k] for k in OC.PARAM_ORDER], c, h, w, A)
+    cfg = engine_cfg(OP.PPOConfig(eps_clip=0.1, value_clip=True, max_grad_norm=0.5, lr=2.5e-4, adam_eps=1e-5))
+    e8, e32 = PC.CnnPPOEngine(c, h, w, A, flat, cfg), PC.CnnPPOEngine(c, h, w, A, flat, cfg)
+    v8, lp8 = e8.infer(obs8, act)
+    v32, lp32 = e32.infer(obs8.float(), act)
+    assert torch.equal(v8, v32) and torch.equal(lp8, lp32)
+    assert torch.equal(e8.step(obs8, act, adv, ret, lp, vo), e32.step(obs8.float(), act, adv, ret, lp, vo))
+    assert torch.equal(e8.params, e32.params)

@@ -27,10 +27,11 @@ int conv_wgrad_splits(const ConvGeom& g);
 
 // Y = act(X (*) W + b).  `split_buf` (conv_fwd_splits(g) * out_elems floats) is needed when splits > 1.
 int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
-                 float* split_buf, ts_workspace* prof = nullptr);
+                 float* split_buf, ts_workspace* prof = nullptr, bool x_u8 = false);
+// x_u8: X points to uint8 NHWC data (raw frames) with the same geometry; values are converted on load.
 // slabs[s][(K+1)*OC] = partial d(loss)/d(Wb) over the s-th share of the output pixels.
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
-               ts_workspace* prof = nullptr);
+               ts_workspace* prof = nullptr, bool x_u8 = false);
 // dX = (dY (*)^T W) * (mask > 0); mask = the layer input as produced by the previous ReLU (or null).
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
                float* dX, ts_workspace* prof = nullptr, int col_begin = 0, int col_end = -1);

@@ -41,6 +41,7 @@ struct GemmArgs {
     int total_chunks;
     int AH, AW, JH, JW;   // dgrad: per-class output grid and taps per class
     int n_tile0;          // dgrad: first column tile of this launch
+    int a_u8;             // forward / wgrad: the layer input is uint8 NHWC (raw frames), converted on load
     int64_t slab_stride;
 };
 
@@ -92,9 +93,18 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
         if (!DG) {
             const int k = k0 + 4 * q, kh = k / run;
             const int koff = kh * pitch + (k - kh * run);
+            if (a.a_u8) {          // 4 consecutive uint8 pixels/channels per lane -> 4 floats (exact)
+                const uint8_t* a8 = reinterpret_cast<const uint8_t*>(a.A);
 #pragma unroll
-            for (int j = 0; j < AJ; ++j)
-                ar[j] = *reinterpret_cast<const f32x4*>(a.A + s_in[rowi + 32 * j] + koff);
+                for (int j = 0; j < AJ; ++j) {
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(a8 + s_in[rowi + 32 * j] + koff);
+                    ar[j] = f32x4{(float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)};
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < AJ; ++j)
+                    ar[j] = *reinterpret_cast<const f32x4*>(a.A + s_in[rowi + 32 * j] + koff);
+            }
 #pragma unroll
             for (int i = 0; i < BJ; ++i) {
                 const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
@@ -239,9 +249,18 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
         }
     };
     auto gload = [&](int c) {
+        if (a.a_u8) {
+            const uint8_t* a8 = reinterpret_cast<const uint8_t*>(a.A);
 #pragma unroll
-        for (int i = 0; i < AI; ++i)
-            ar[i] = *reinterpret_cast<const f32x4*>(a.A + s_row[c & 1][arow + ARS * i] + koff);
+            for (int i = 0; i < AI; ++i) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(a8 + s_row[c & 1][arow + ARS * i] + koff);
+                ar[i] = f32x4{(float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AI; ++i)
+                ar[i] = *reinterpret_cast<const f32x4*>(a.A + s_row[c & 1][arow + ARS * i] + koff);
+        }
 #pragma unroll
         for (int i = 0; i < BJ; ++i) {
             const int e = tid + THREADS * i, mm = e / (BN / 4), n4 = e % (BN / 4);
@@ -417,9 +436,10 @@ int conv_wgrad_splits(const ConvGeom& g) {
 }
 
 int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
-                 float* split_buf, ts_workspace* prof) {
+                 float* split_buf, ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
     GemmArgs a = base_args(g);
+    a.a_u8 = x_u8;
     a.A = X; a.Bm = Wb; a.bias = Wb + (int64_t)a.K * g.OC; a.relu = relu;
     a.total_chunks = a.K / BK;
     const int nsplit = conv_fwd_splits(g);
@@ -452,9 +472,10 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
 }
 
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
-               ts_workspace* prof) {
+               ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
     GemmArgs a = base_args(g);
+    a.a_u8 = x_u8;
     a.A = X; a.Bm = dY; a.C = slabs;
     a.total_chunks = (int)ceil_div(a.M, BK);
     const int nsplit = conv_wgrad_splits(g);
@@ -531,8 +552,8 @@ int check_dims(const int64_t* d) {
 
 extern "C" {
 
-int ts_conv_forward(ts_workspace* ws, const float* x, const float* wb, float* y, const int64_t* h_dims, int relu,
-                    ts_stream_t stream) {
+int ts_conv_forward(ts_workspace* ws, const void* x, int x_u8, const float* wb, float* y, const int64_t* h_dims,
+                    int relu, ts_stream_t stream) {
     if (int rc = check_dims(h_dims)) return rc;
     TS_REQUIRE(x && wb && y, TS_ERR_INVALID_ARG, "ts_conv_forward: NULL argument");
     const ts::ConvGeom g = geom_of(h_dims);
@@ -543,10 +564,11 @@ int ts_conv_forward(ts_workspace* ws, const float* x, const float* wb, float* y,
         if (int rc = ts::ws_reserve(ws, sizeof(float) * (size_t)ns * g.out_elems())) return rc;
         split = static_cast<float*>(ws->base);
     }
-    return ts::conv_forward(ts::as_stream(stream), g, x, wb, y, relu != 0, split);
+    return ts::conv_forward(ts::as_stream(stream), g, static_cast<const float*>(x), wb, y, relu != 0, split, nullptr,
+                            x_u8 != 0);
 }
 
-int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const float* dy, const float* mask,
+int ts_conv_backward(ts_workspace* ws, const void* x, int x_u8, const float* wb, const float* dy, const float* mask,
                      float* d_wb, float* dx, const int64_t* h_dims, ts_stream_t stream) {
     if (int rc = check_dims(h_dims)) return rc;
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_conv_backward: workspace is NULL");
@@ -556,7 +578,7 @@ int ts_conv_backward(ts_workspace* ws, const float* x, const float* wb, const fl
     if (int rc = ts::ws_reserve(ws, sizeof(float) * (size_t)ns * g.param_elems())) return rc;
     float* slabs = static_cast<float*>(ws->base);
     hipStream_t s = ts::as_stream(stream);
-    if (int rc = ts::conv_wgrad(s, g, x, dy, slabs)) return rc;
+    if (int rc = ts::conv_wgrad(s, g, static_cast<const float*>(x), dy, slabs, nullptr, x_u8 != 0)) return rc;
     if (int rc = ts::slab_sum(s, slabs, ns, g.param_elems(), d_wb)) return rc;
     if (dx) return ts::conv_dgrad(s, g, dy, wb, mask, dx);
     return TS_OK;

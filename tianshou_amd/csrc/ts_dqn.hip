@@ -195,11 +195,12 @@ char* carve_fwd(const Net& n, int64_t B, char* p, Scratch* sc) {
     return p + align_up(sp);
 }
 
-int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const float* obs, int64_t B,
-                const Scratch& sc, float* q_out, int64_t* act_out) {
-    const float* x = obs;
+int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const void* obs, bool obs_u8,
+                int64_t B, const Scratch& sc, float* q_out, int64_t* act_out) {
+    const float* x = static_cast<const float*>(obs);
     for (int i = 0; i < 4; ++i) {
-        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], sc.h[i], true, sc.split, ws)) return rc;
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], sc.h[i], true, sc.split, ws, i == 0 && obs_u8))
+            return rc;
         x = sc.h[i];
     }
     hipLaunchKernelGGL(head_forward_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, sc.h[3],
@@ -234,7 +235,7 @@ int ts_dqn_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t
 }
 
 int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
-                   const float* obs_nhwc, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream) {
+                   const void* obs_nhwc, int obs_u8, int64_t B, float* q_out, int64_t* act_out, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_forward: workspace is NULL");
     TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_dqn_forward: negative batch");
     if (B == 0) return TS_OK;
@@ -244,12 +245,12 @@ int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, 
     if (int rc = ts::ws_reserve(ws, fwd_scratch_bytes(n, B))) return rc;
     Scratch sc;
     carve_fwd(n, B, static_cast<char*>(ws->base), &sc);
-    return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, B, sc, q_out, act_out);
+    return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, q_out, act_out);
 }
 
 int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
-                          int64_t w, int64_t n_act, const float* obs_next_nhwc, int64_t B, int is_double, float* out,
-                          ts_stream_t stream) {
+                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                          float* out, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_target_q_fused: workspace is NULL");
     TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_dqn_target_q_fused: negative batch");
     if (B == 0) return TS_OK;
@@ -266,10 +267,10 @@ int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* pa
     const bool two = params_old != nullptr;
     if (two) {      // Q_target(s') on the side stream, Q_online(s') on the caller's stream (only needed for double-Q)
         if (int rc = ts::stream_wait(ws, s, side, 9)) return rc;
-        if (int rc = net_forward(side, ws, n, params_old, obs_next_nhwc, B, sb, sb.q, nullptr)) return rc;
+        if (int rc = net_forward(side, ws, n, params_old, obs_next_nhwc, obs_u8 != 0, B, sb, sb.q, nullptr)) return rc;
     }
     if (!two || is_double)
-        if (int rc = net_forward(s, ws, n, params, obs_next_nhwc, B, sa, sa.q, nullptr)) return rc;
+        if (int rc = net_forward(s, ws, n, params, obs_next_nhwc, obs_u8 != 0, B, sa, sa.q, nullptr)) return rc;
     if (two)
         if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
     hipLaunchKernelGGL(target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, sa.q, two ? sb.q : sa.q, B,
@@ -290,7 +291,7 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
 }
 
 int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
-                  int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act,
+                  int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
                   const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
                   float* loss_out, float* grad_out, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_update: workspace is NULL");
@@ -321,7 +322,7 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     if (grad_out) grad = grad_out;
 
     // forward (keeps the activations), loss
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, B, sc, sc.q, nullptr)) return rc;
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, sc.q, nullptr)) return rc;
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
                        (float)hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
@@ -337,9 +338,9 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     hipStream_t side;
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
     for (int i = 3; i >= 0; --i) {
-        const float* x = i == 0 ? obs_nhwc : sc.h[i - 1];
+        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : sc.h[i - 1];
         if (int rc = ts::stream_wait(ws, s, side, i)) return rc;          // dY_i (and everything before) is ready
-        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws)) return rc;
+        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
         if (int rc = ts::slab_sum(side, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
             return rc;
         if (i > 0)

@@ -151,6 +151,26 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterKeys keys, con
     }
 }
 
+// same gather, uint8 out (NHWC uint8 [B][plane_elems][C]): the conv kernels convert on load, so the float32 copy of
+// the observations (4x the bytes) never exists
+template <int C>
+__global__ __launch_bounds__(256) void gather_planes_u8_kernel(const uint8_t* __restrict__ src, int64_t plane_elems,
+                                                               const int64_t* __restrict__ plane, int64_t B, int Cdyn,
+                                                               uint8_t* __restrict__ out) {
+    const int Cn = C > 0 ? C : Cdyn;
+    const int64_t b = blockIdx.y;
+    const int64_t* pl = plane + b * Cn;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < plane_elems; p += (int64_t)gridDim.x * 256) {
+        if (C == 4) {
+            const uint32_t v = (uint32_t)src[pl[0] * plane_elems + p] | ((uint32_t)src[pl[1] * plane_elems + p] << 8) |
+                               ((uint32_t)src[pl[2] * plane_elems + p] << 16) | ((uint32_t)src[pl[3] * plane_elems + p] << 24);
+            *reinterpret_cast<uint32_t*>(out + (b * plane_elems + p) * 4) = v;
+        } else {
+            for (int c = 0; c < Cn; ++c) out[(b * plane_elems + p) * Cn + c] = src[pl[c] * plane_elems + p];
+        }
+    }
+}
+
 // single workgroup, order-preserving compaction over the E sub-buffers
 __global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
                                   const int64_t* lengths, int64_t* out, int64_t* n_out) {
@@ -405,6 +425,26 @@ int ts_stack_indices(const int64_t* index, int64_t I, int64_t stack_num, const i
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(stack_indices_kernel, dim3((unsigned)blocks), dim3(256), 0, ts::as_stream(stream), index, I,
                        stack_num, offset, E, done, last_index, lengths, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_gather_planes_nhwc_u8(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
+                             int64_t B, int64_t C, uint8_t* out, ts_stream_t stream) {
+    TS_REQUIRE(B >= 0 && C >= 1 && C <= 64 && plane_elems >= 1 && n_planes >= 1, TS_ERR_INVALID_ARG,
+               "ts_gather_planes_nhwc_u8: bad sizes");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(src && plane_index && out, TS_ERR_INVALID_ARG, "ts_gather_planes_nhwc_u8: NULL argument");
+    TS_REQUIRE(B <= 65535, TS_ERR_UNSUPPORTED, "ts_gather_planes_nhwc_u8: at most 65535 rows per call");
+    int64_t bx = ts::ceil_div(plane_elems, 256);
+    if (bx > 64) bx = 64;
+    dim3 grid((unsigned)bx, (unsigned)B);
+    if (C == 4)
+        hipLaunchKernelGGL(gather_planes_u8_kernel<4>, grid, dim3(256), 0, ts::as_stream(stream), src, plane_elems,
+                           plane_index, B, 4, out);
+    else
+        hipLaunchKernelGGL(gather_planes_u8_kernel<0>, grid, dim3(256), 0, ts::as_stream(stream), src, plane_elems,
+                           plane_index, B, (int)C, out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

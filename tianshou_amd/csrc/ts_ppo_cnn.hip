@@ -75,10 +75,12 @@ char* carve_acts(const Net& n, char* p, Acts* a) {
     return p + al(4 * split_floats(n));
 }
 
-int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const float* obs, const Acts& a) {
-    const float* x = obs;
+int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const void* obs, bool obs_u8,
+                const Acts& a) {
+    const float* x = static_cast<const float*>(obs);
     for (int i = 0; i < 5; ++i) {
-        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], a.h[i], i < 4, a.split, ws)) return rc;
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], a.h[i], i < 4, a.split, ws, i == 0 && obs_u8))
+            return rc;
         x = a.h[i];
     }
     return TS_OK;
@@ -226,7 +228,7 @@ int ts_cnn_ac_layer_offsets(int64_t c, int64_t h, int64_t w, int64_t n_act, int6
 }
 
 int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
-                    const float* obs_nhwc, const int64_t* act, int64_t B, float* v_out, float* logp_out,
+                    const void* obs_nhwc, int obs_u8, const int64_t* act, int64_t B, float* v_out, float* logp_out,
                     float* logits_out, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_cnn_ac_infer: workspace is NULL");
     TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_cnn_ac_infer: negative batch");
@@ -238,7 +240,7 @@ int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h,
     Acts a;
     carve_acts(n, static_cast<char*>(ws->base), &a);
     hipStream_t s = ts::as_stream(stream);
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, a)) return rc;
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
     hipLaunchKernelGGL(cnn_infer_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a.h[4], act, B, n.n_act,
                        v_out, logp_out, logits_out);
     TS_LAUNCH_CHECK();
@@ -246,7 +248,7 @@ int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h,
 }
 
 int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
-                    int64_t h, int64_t w, int64_t n_act, const float* obs_nhwc, const int64_t* act, const float* adv,
+                    int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act, const float* adv,
                     const float* returns, const float* logp_old, const float* v_old, int64_t B,
                     const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4, float* grad_out,
                     ts_stream_t stream) {
@@ -276,7 +278,7 @@ int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     float* norm_part = reinterpret_cast<float*>(p);
     if (grad_out) grad = grad_out;
 
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, a)) return rc;
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
     LossArgs la{};
     la.head = a.h[4]; la.act = act; la.adv = adv; la.ret = returns; la.logp_old = logp_old; la.v_old = v_old;
     la.adv_stats = hp->adv_norm ? adv_stats : nullptr;
@@ -289,8 +291,8 @@ int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                        (float)hp->ent_coef, losses_out4);
     TS_LAUNCH_CHECK();
     for (int i = 4; i >= 0; --i) {
-        const float* x = i == 0 ? obs_nhwc : a.h[i - 1];
-        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws)) return rc;
+        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.h[i - 1];
+        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
         if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
             return rc;
         if (i > 0)

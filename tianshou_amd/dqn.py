@@ -93,6 +93,15 @@ def flat_to_torch(flat: torch.Tensor, c: int, h: int, w: int, n_act: int) -> lis
     return out
 
 
+def _u8_flag(obs: torch.Tensor) -> C.c_int:
+    """obs_u8 argument of the network entry points: float32 or uint8 NHWC observations."""
+    if obs.dtype == torch.uint8:
+        return C.c_int(1)
+    if obs.dtype == torch.float32:
+        return C.c_int(0)
+    raise ValueError("observations must be float32 or uint8")
+
+
 # ---- single layers (tests, other shapes) ---------------------------------------------------------
 def _dims(x: torch.Tensor, kh: int, kw: int, stride: int, oc: int):
     b, ih, iw, ic = x.shape
@@ -105,8 +114,8 @@ def conv_forward(x: torch.Tensor, wb: torch.Tensor, kh: int, kw: int, stride: in
     dims, (oh, ow) = _dims(x, kh, kw, stride, oc)
     y = torch.empty((x.shape[0], oh, ow, oc), dtype=torch.float32, device=x.device)
     ws = _lib.default_workspace(x.device.index or 0)
-    _lib.check(_lib.load().ts_conv_forward(ws.handle, _lib.ptr(x), _lib.ptr(wb), _lib.ptr(y), dims, C.c_int(int(relu)),
-                                           _lib.current_stream(x.device)))
+    _lib.check(_lib.load().ts_conv_forward(ws.handle, _lib.ptr(x), _u8_flag(x), _lib.ptr(wb), _lib.ptr(y), dims,
+                                           C.c_int(int(relu)), _lib.current_stream(x.device)))
     return y
 
 
@@ -115,9 +124,9 @@ def conv_backward(x, wb, dy, kh: int, kw: int, stride: int, mask=None, need_dx: 
     oc = wb.shape[1]
     dims, _ = _dims(x, kh, kw, stride, oc)
     d_wb = torch.empty_like(wb)
-    dx = torch.empty_like(x) if need_dx else None
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device) if need_dx else None
     ws = _lib.default_workspace(x.device.index or 0)
-    _lib.check(_lib.load().ts_conv_backward(ws.handle, _lib.ptr(x), _lib.ptr(wb), _lib.ptr(dy), _lib.ptr(mask),
+    _lib.check(_lib.load().ts_conv_backward(ws.handle, _lib.ptr(x), _u8_flag(x), _lib.ptr(wb), _lib.ptr(dy), _lib.ptr(mask),
                                             _lib.ptr(d_wb), _lib.ptr(dx), dims, _lib.current_stream(x.device)))
     return d_wb, dx
 
@@ -134,8 +143,10 @@ def stack_indices(buffer: DeviceReplayBuffer, index, stack_num: int) -> torch.Te
     return out
 
 
-def gather_obs_nhwc(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, stack_num: int) -> torch.Tensor:
-    """buffer.get(index, "obs") as the float32 NHWC tensor DQNet consumes.
+def gather_obs_nhwc(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, stack_num: int,
+                    as_u8: bool = False) -> torch.Tensor:
+    """buffer.get(index, "obs") as the NHWC tensor the network entry points consume: float32, or uint8 with
+    as_u8 (the kernels then convert on load and the float32 copy -- 4x the bytes -- never exists).
 
     frames: uint8 [slots, H, W] with stack_num > 1 (save_only_last_obs layout,
     examples/atari/atari_dqn.py:137-142) or uint8 [slots, C, H, W] with stack_num == 1."""
@@ -154,11 +165,12 @@ def gather_obs_nhwc(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, sta
         n_planes = frames.shape[0] * c
     if frames.dtype != torch.uint8 or not frames.is_contiguous():
         raise ValueError("frames must be a contiguous uint8 tensor")
-    out = torch.empty((index.numel(), hh, ww, c), dtype=torch.float32, device=frames.device)
+    out = torch.empty((index.numel(), hh, ww, c), dtype=torch.uint8 if as_u8 else torch.float32, device=frames.device)
     step = 32768
+    fn = _lib.load().ts_gather_planes_nhwc_u8 if as_u8 else _lib.load().ts_gather_planes_nhwc
     for lo in range(0, index.numel(), step):
         hi = min(index.numel(), lo + step)
-        _lib.check(_lib.load().ts_gather_planes_nhwc(
+        _lib.check(fn(
             _lib.ptr(frames), _lib.i64(n_planes), _lib.i64(hh * ww), _lib.ptr(planes[lo:hi]), _lib.i64(hi - lo),
             _lib.i64(c), _lib.ptr(out[lo:hi]), _lib.current_stream(frames.device)))
     return out
@@ -206,15 +218,16 @@ class DQNEngine:
     def forward(self, obs_nhwc: torch.Tensor, params: torch.Tensor | None = None, want_act: bool = True):
         """-> (logits float32[B, A], act int64[B] = argmax)."""
         b = obs_nhwc.shape[0]
-        if tuple(obs_nhwc.shape[1:]) != (self.h, self.w, self.c) or obs_nhwc.dtype != torch.float32:
-            raise ValueError(f"obs must be float32 [B, {self.h}, {self.w}, {self.c}] (NHWC)")
+        if tuple(obs_nhwc.shape[1:]) != (self.h, self.w, self.c) or obs_nhwc.dtype not in (torch.float32, torch.uint8):
+            raise ValueError(f"obs must be float32 or uint8 [B, {self.h}, {self.w}, {self.c}] (NHWC)")
         obs_nhwc = obs_nhwc.contiguous()
         q = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
         act = torch.empty(b, dtype=torch.int64, device=self.device) if want_act else None
         p = self.params if params is None else params
         _lib.check(_lib.load().ts_dqn_forward(
             self._ws.handle, _lib.ptr(p), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act),
-            _lib.ptr(obs_nhwc), _lib.i64(b), _lib.ptr(q), _lib.ptr(act), _lib.current_stream(self.device)))
+            _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.i64(b), _lib.ptr(q), _lib.ptr(act),
+            _lib.current_stream(self.device)))
         return q, act
 
     # -- DQN._target_q ---------------------------------------------------------------------------------
@@ -224,7 +237,7 @@ class DQNEngine:
         out = torch.empty(b, dtype=torch.float32, device=self.device)
         _lib.check(_lib.load().ts_dqn_target_q_fused(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.params_old), _lib.i64(self.c), _lib.i64(self.h),
-            _lib.i64(self.w), _lib.i64(self.n_act), _lib.ptr(obs_next_nhwc), _lib.i64(b),
+            _lib.i64(self.w), _lib.i64(self.n_act), _lib.ptr(obs_next_nhwc), _u8_flag(obs_next_nhwc), _lib.i64(b),
             C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
@@ -236,9 +249,9 @@ class DQNEngine:
 
         def tq_fn(buf, after):
             if obs_next_frames is None:
-                on = gather_obs_nhwc(frames, buf, buf.next(after), stack_num)
+                on = gather_obs_nhwc(frames, buf, buf.next(after), stack_num, as_u8=True)
             else:
-                on = gather_obs_nhwc(obs_next_frames, buf, after, stack_num)
+                on = gather_obs_nhwc(obs_next_frames, buf, after, stack_num, as_u8=True)
             return self.target_q(on)
 
         class _B:
@@ -286,10 +299,11 @@ class DQNEngine:
         td = torch.empty(b, dtype=torch.float32, device=self.device)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         hp = cfg.to_c(grad_only=not apply)
+        obs_nhwc = obs_nhwc.contiguous()
         _lib.check(_lib.load().ts_dqn_update(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
             _lib.i64(max(self.adam_step, 1)), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w),
-            _lib.i64(self.n_act), _lib.ptr(obs_nhwc.contiguous()), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight),
+            _lib.i64(self.n_act), _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight),
             _lib.i64(b), C.byref(hp), _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
             _lib.current_stream(self.device)))
         return loss, td

@@ -212,7 +212,7 @@ def make_hip_dqn():
         def _update_with_batch(self, batch):
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
-            obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack)
+            obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack, as_u8=True)
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
             loss, td = eng.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
             self._iter = eng.iter

@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev
-from .dqn import gather_obs_nhwc
+from .dqn import _u8_flag, gather_obs_nhwc
 from .ppo import PPOConfig, split_offsets
 from .returns import cut_positions, gae_scan
 
@@ -99,8 +99,8 @@ class CnnPPOEngine:
         logits = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device) if want_logits else None
         _lib.check(_lib.load().ts_cnn_ac_infer(
             self._ws.handle, _lib.ptr(self.params), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w),
-            _lib.i64(self.n_act), _lib.ptr(obs_nhwc), _lib.ptr(act), _lib.i64(b), _lib.ptr(v), _lib.ptr(logp),
-            _lib.ptr(logits), _lib.current_stream(self.device)))
+            _lib.i64(self.n_act), _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.ptr(act), _lib.i64(b), _lib.ptr(v),
+            _lib.ptr(logp), _lib.ptr(logits), _lib.current_stream(self.device)))
         return (v, logp, logits) if want_logits else (v, logp)
 
     # -- PPO._preprocess_batch -------------------------------------------------------------------------------
@@ -116,11 +116,11 @@ class CnnPPOEngine:
         act_b = act[idx]
         for lo in range(0, n, chunk):
             sl = slice(lo, min(lo + chunk, n))
-            v_s[sl], logp_old[sl] = self.infer(gather_obs_nhwc(frames, buffer, idx[sl], stack_num), act_b[sl])
+            v_s[sl], logp_old[sl] = self.infer(gather_obs_nhwc(frames, buffer, idx[sl], stack_num, as_u8=True), act_b[sl])
             if obs_next_frames is None:
-                nxt = gather_obs_nhwc(frames, buffer, buffer.next(idx[sl]), stack_num)     # buffer_base.py:624-626
+                nxt = gather_obs_nhwc(frames, buffer, buffer.next(idx[sl]), stack_num, as_u8=True)   # buffer_base.py:624-626
             else:
-                nxt = gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num)
+                nxt = gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num, as_u8=True)
             v_next[sl] = self.infer(nxt)[0]
         cut_pos, d_n_cut = cut_positions(buffer, idx)
         scale = math.sqrt(self.ret_rms[1] + 1e-8) if cfg.return_scaling else 1.0
@@ -153,10 +153,11 @@ class CnnPPOEngine:
             hp.lr = -1.0
         losses = torch.empty(4, dtype=torch.float32, device=self.device)
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        obs_nhwc = obs_nhwc.contiguous()
         _lib.check(_lib.load().ts_cnn_ppo_step(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
             _lib.i64(max(self.adam_step, 1)), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w),
-            _lib.i64(self.n_act), _lib.ptr(obs_nhwc.contiguous()), _lib.ptr(_i64_dev(act, self.device).reshape(-1)),
+            _lib.i64(self.n_act), _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.ptr(_i64_dev(act, self.device).reshape(-1)),
             _lib.ptr(f32(adv)), _lib.ptr(f32(returns)), _lib.ptr(f32(logp_old)), _lib.ptr(f32(v_old)), _lib.i64(b),
             _lib.ptr(stats), C.byref(hp), _lib.ptr(losses), _lib.ptr(grad_out), _lib.current_stream(self.device)))
         return losses
@@ -175,7 +176,7 @@ class CnnPPOEngine:
             perm = _i64_dev(perms[r], self.device)
             for lo, hi in zip(offs[:-1], offs[1:]):
                 rows = perm[lo:hi]
-                obs = gather_obs_nhwc(frames, buffer, pre["indices"][rows], stack_num)
+                obs = gather_obs_nhwc(frames, buffer, pre["indices"][rows], stack_num, as_u8=True)
                 out.append(self.step(obs, pre["act"][rows], pre["adv"][rows], pre["returns"][rows],
                                      pre["logp_old"][rows], pre["v_s"][rows]))
         return torch.stack(out), len(out)
