@@ -16,6 +16,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .checkpoint import adam_state, params_by_keys, store_adam_state
 from .ppo import PPOConfig, PPOEngine, flat_from_modules, flat_to_modules, TIANSHOU_ACTOR_KEYS, TIANSHOU_CRITIC_KEYS
 
 
@@ -71,28 +72,26 @@ def make_hip_ppo():
             if self._hip_engine is None:
                 obs_dim, act_dim = self._hip_dims
                 flat = flat_from_modules(self.policy.actor, self.critic, self._hip_device)
-                self._hip_engine = PPOEngine(obs_dim, act_dim, flat, ppo_config_from(self))
-                self._hip_engine.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var),
-                                            float(self.ret_rms.count)]
+                eng = self._hip_engine = PPOEngine(obs_dim, act_dim, flat, ppo_config_from(self))
+                eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
+                # resume: Adam moments / step of a loaded checkpoint (algorithm_base.py:523-543)
+                ms, vs, step = adam_state(self.optim._optim, self._hip_params())
+                cat = lambda ts: torch.cat([t.reshape(-1).float() for t in ts]).to(self._hip_device)  # noqa: E731
+                eng.adam_m, eng.adam_v, eng.adam_step = cat(ms), cat(vs), step
             return self._hip_engine
+
+        def _hip_params(self):
+            return params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS) + params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
 
         def _sync_back(self) -> None:
             """Engine state -> nn.Parameters, torch.optim.Adam.state, ret_rms (state_dict keeps working,
             algorithm_base.py:523-543)."""
             eng = self._hip_engine
             flat_to_modules(eng.params, self.policy.actor, self.critic)
-            opt = self.optim._optim
-            named = {**{"a." + k: v for k, v in self.policy.actor.named_parameters()},
-                     **{"c." + k: v for k, v in self.critic.named_parameters()}}
-            off = 0
-            for key in ["a." + k for k in TIANSHOU_ACTOR_KEYS] + ["c." + k for k in TIANSHOU_CRITIC_KEYS]:
-                p = named[key]
-                n = p.numel()
-                st = opt.state[p]
-                st["step"] = torch.tensor(float(eng.adam_step))
-                st["exp_avg"] = eng.adam_m[off:off + n].reshape(p.shape).to(p.device).clone()
-                st["exp_avg_sq"] = eng.adam_v[off:off + n].reshape(p.shape).to(p.device).clone()
-                off += n
+            params = self._hip_params()
+            sizes = [p.numel() for p in params]
+            store_adam_state(self.optim._optim, params, torch.split(eng.adam_m, sizes), torch.split(eng.adam_v, sizes),
+                             eng.adam_step)
             self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
 
         # -- hooks ------------------------------------------------------------------------------------
@@ -180,8 +179,15 @@ def make_hip_dqn():
                                   is_double=self.is_double, huber_delta=self.huber_loss_delta, lr=g["lr"],
                                   betas=tuple(g["betas"]), adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
                 flat = D.flat_from_torch([sd[k] for k in D.TIANSHOU_KEYS], c, h, w, n_act, self._hip_device)
-                self._hip_engine = D.DQNEngine(c, h, w, n_act, flat, cfg)
-                self._hip_engine.iter = self._iter
+                eng = self._hip_engine = D.DQNEngine(c, h, w, n_act, flat, cfg)
+                eng.iter = self._iter
+                ms, vs, step = adam_state(opt, list(self.policy.model.parameters()))       # resume from a checkpoint
+                eng.adam_m = D.flat_from_torch(ms, c, h, w, n_act, self._hip_device)
+                eng.adam_v = D.flat_from_torch(vs, c, h, w, n_act, self._hip_device)
+                eng.adam_step = step
+                if eng.params_old is not None:
+                    old = [p.detach() for p in self.model_old.parameters()]
+                    eng.params_old = D.flat_from_torch(old, c, h, w, n_act, self._hip_device)
             return self._hip_engine
 
         def _layout(self, buffer):
@@ -225,6 +231,9 @@ def make_hip_dqn():
                     old = D.flat_to_torch(eng.params_old, eng.c, eng.h, eng.w, eng.n_act)
                     for p, t in zip(self.model_old.parameters(), old):
                         p.copy_(t)
+            dims = (eng.c, eng.h, eng.w, eng.n_act)
+            store_adam_state(self.optim._optim, list(self.policy.model.parameters()), D.flat_to_torch(eng.adam_m, *dims),
+                             D.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
             return SimpleLossTrainingStats(loss=float(loss.item()))
 
     return HipDQN
@@ -273,11 +282,27 @@ def make_hip_sac():
                 dev = self._hip_device
                 flat_c = lambda mod: S.critic_flat_from_torch(  # noqa: E731
                     [mod.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS], obs_dim, act_dim, dev)
-                self._hip_engine = S.SACEngine(
+                eng = self._hip_engine = S.SACEngine(
                     obs_dim, act_dim,
                     S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
                     flat_c(self.critic), flat_c(self.critic2), cfg)
+                # resume: lagged critics, Adam moments / steps of a loaded checkpoint
+                eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
+                for name, mod, optim, keys, conv in self._hip_parts(S):
+                    ms, vs, step = adam_state(optim._optim, params_by_keys(mod, keys))
+                    setattr(eng, name + "_m", conv(ms, obs_dim, act_dim, dev))
+                    setattr(eng, name + "_v", conv(vs, obs_dim, act_dim, dev))
+                    eng.adam_step = max(eng.adam_step, step)
+                if auto:
+                    st = self.alpha._optim._optim.state.get(self.alpha._log_alpha, {})
+                    if "exp_avg" in st:
+                        eng.log_alpha_m[0], eng.log_alpha_v[0] = float(st["exp_avg"]), float(st["exp_avg_sq"])
             return self._hip_engine
+
+        def _hip_parts(self, S):
+            return (("actor", self.policy.actor, self.policy_optim, S.TIANSHOU_ACTOR_KEYS, S.actor_flat_from_torch),
+                    ("critic1", self.critic, self.critic_optim, S.TIANSHOU_CRITIC_KEYS, S.critic_flat_from_torch),
+                    ("critic2", self.critic2, self.critic2_optim, S.TIANSHOU_CRITIC_KEYS, S.critic_flat_from_torch))
 
         def _preprocess_batch(self, batch, buffer, indices):
             if self._hip_device.type != "cuda":
@@ -312,6 +337,14 @@ def make_hip_sac():
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
+            back = {"actor": S.actor_flat_to_torch, "critic1": S.critic_flat_to_torch, "critic2": S.critic_flat_to_torch}
+            for name, mod, optim, keys, _ in self._hip_parts(S):
+                store_adam_state(optim._optim, params_by_keys(mod, keys),
+                                 back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim),
+                                 back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim), eng.adam_step)
+            if eng.cfg.auto_alpha:
+                store_adam_state(self.alpha._optim._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
+                                 [eng.log_alpha_v[0]], eng.adam_step)
             auto = eng.cfg.auto_alpha
             return SACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
                                     alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
