@@ -206,3 +206,73 @@ def test_mirror_incremental_sync_tracks_the_reference_buffer():
         assert np.array_equal(m.last_index.numpy(), np.asarray(buf.last_index))
         assert np.array_equal(m.lengths.numpy(), np.asarray(buf._lengths))
     assert 0 < total < 4 * 30            # incremental, not whole-buffer copies
+
+
+# ------------------------------------------------------------------------------------ Atari PPO, TD3, DDPG subclasses
+def _det_algo(twin):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.ddpg import ContinuousDeterministicPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorDeterministic, ContinuousCritic
+    from tianshou_amd.integration import make_hip_ddpg, make_hip_td3
+
+    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[256, 256]),
+                                         action_shape=(3,), max_action=1.0)
+    mk = lambda: ContinuousCritic(preprocess_net=Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[256, 256],  # noqa: E731
+                                                     concat=True))
+    policy = ContinuousDeterministicPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,)),
+                                           exploration_noise=None)
+    kw = dict(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(),
+              critic_optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
+    if twin:
+        return make_hip_td3()(critic2=mk(), critic2_optim=AdamOptimizerFactory(lr=1e-3), **kw)
+    return make_hip_ddpg()(**kw)
+
+
+def _ppo_cnn_algo():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import DQNet
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from tianshou_amd.integration import make_hip_ppo_cnn
+
+    net = DQNet(c=4, h=84, w=84, action_shape=6, features_only=True, output_dim_added_layer=512)
+    actor = DiscreteActor(preprocess_net=net, action_shape=6, softmax_output=False)
+    critic = DiscreteCritic(preprocess_net=net)
+    policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(6))
+    return make_hip_ppo_cnn()(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=2.5e-4, eps=1e-5),
+                              eps_clip=0.1, value_clip=True, vf_coef=0.25, ent_coef=0.01, max_grad_norm=0.5,
+                              device="cpu")
+
+
+@pytest.mark.parametrize("which", ["td3", "ddpg", "ppo_cnn"])
+def test_more_subclasses_keep_signatures_and_fail_loudly(which):
+    from tianshou.data import Batch, VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _ppo_cnn_algo() if which == "ppo_cnn" else _det_algo(which == "td3")
+    base = type(algo).__mro__[1]
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    for _ in range(8):
+        if which == "ppo_cnn":
+            b = Batch(obs=np.zeros((2, 4, 84, 84), np.uint8), act=np.zeros(2, np.int64), rew=np.zeros(2),
+                      terminated=np.zeros(2, bool), truncated=np.zeros(2, bool), obs_next=np.zeros((2, 4, 84, 84), np.uint8))
+        else:
+            b = Batch(obs=np.zeros((2, 11), np.float32), act=np.zeros((2, 3), np.float32), rew=np.zeros(2),
+                      terminated=np.zeros(2, bool), truncated=np.zeros(2, bool), obs_next=np.zeros((2, 11), np.float32))
+        buf.add(b)
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        if which == "ppo_cnn":
+            algo.update(buffer=buf, batch_size=8, repeat=1)
+        else:
+            algo.update(buffer=buf, sample_size=8)

@@ -350,3 +350,203 @@ def make_hip_sac():
                                     alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
 
     return HipSAC
+
+
+# ---------------------------------------------------------------------------------------------------
+# PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-135)
+# ---------------------------------------------------------------------------------------------------
+def make_hip_ppo_cnn():
+    """Returns HipPPOCnn(PPO) for DQNet(features_only=True, output_dim_added_layer=512) shared by
+    DiscreteActor(softmax_output=False) and DiscreteCritic; Categorical policy; Adam."""
+    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
+    from tianshou.algorithm.modelfree.ppo import PPO
+    from tianshou.data import SequenceSummaryStats
+
+    from . import ppo_cnn as PC
+
+    class HipPPOCnn(PPO):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            actor, critic = self.policy.actor, self.critic
+            sa, sc = actor.state_dict(), critic.state_dict()
+            if list(sa.keys()) != PC.TRUNK_KEYS + PC.HEAD_KEYS or list(sc.keys()) != PC.TRUNK_KEYS + PC.HEAD_KEYS \
+                    or actor.preprocess is not critic.preprocess or getattr(actor, "softmax_output", True):
+                raise NotImplementedError("HipPPOCnn: actor / critic must share one DQNet(features_only=True, "
+                                          "output_dim_added_layer=512) trunk with single-Linear heads (logits)")
+            if self.recompute_adv:
+                raise NotImplementedError("HipPPOCnn: recompute_advantage is not supported")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _hip_params(self):
+            return params_by_keys(self.policy.actor, PC.TRUNK_KEYS + PC.HEAD_KEYS) + params_by_keys(self.critic, PC.HEAD_KEYS)
+
+        def _layout(self, buffer):
+            obs = np.asarray(buffer.obs)
+            stack = int(getattr(buffer, "stack_num", 1))
+            if stack > 1:
+                return stack, obs.shape[1], obs.shape[2], stack
+            if obs.ndim != 4:
+                raise NotImplementedError("HipPPOCnn: observations must be [c, h, w]")
+            return obs.shape[1], obs.shape[2], obs.shape[3], 1
+
+        def _engine(self, c, h, w):
+            if self._hip_engine is None:
+                params = self._hip_params()
+                n_act = params[8].shape[0]
+                dev = self._hip_device
+                eng = self._hip_engine = PC.CnnPPOEngine(c, h, w, n_act, PC.flat_from_torch(params, c, h, w, n_act, dev),
+                                                         ppo_config_from(self))
+                eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
+                ms, vs, step = adam_state(self.optim._optim, params)
+                eng.adam_m, eng.adam_v = PC.flat_from_torch(ms, c, h, w, n_act, dev), PC.flat_from_torch(vs, c, h, w, n_act, dev)
+                eng.adam_step = step
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            if self._hip_device.type != "cuda":
+                raise RuntimeError("HipPPOCnn needs an MI355X (device='cuda'); there is no CPU fallback")
+            c, h, w, stack = self._layout(buffer)
+            eng = self._engine(c, h, w)
+            m = _mirror(self, buffer, self._hip_device)
+            pre = eng.preprocess(m, m.obs, m.act, stack, obs_next_frames=m.obs_next)
+            self._hip_pre, self._hip_stack = pre, stack
+            batch.v_s, batch.returns, batch.adv, batch.logp_old = pre["v_s"], pre["returns"], pre["adv"], pre["logp_old"]
+            return batch
+
+        def _update_with_batch(self, batch, batch_size, repeat):
+            eng, m = self._hip_engine, self._hip_mirror
+            perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
+            losses, steps = eng.update(m, m.obs, self._hip_pre, self._hip_stack, batch_size, repeat, perms)
+            arr = losses.cpu().numpy().astype(np.float64)
+            params = self._hip_params()
+            dims = (eng.c, eng.h, eng.w, eng.n_act)
+            with torch.no_grad():
+                for p, t in zip(params, PC.flat_to_torch(eng.params, *dims)):
+                    p.copy_(t)
+            store_adam_state(self.optim._optim, params, PC.flat_to_torch(eng.adam_m, *dims),
+                             PC.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+            self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
+            return A2CTrainingStats(
+                loss=SequenceSummaryStats.from_sequence(arr[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(arr[:, 1]),
+                vf_loss=SequenceSummaryStats.from_sequence(arr[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(arr[:, 3]),
+                gradient_steps=steps)
+
+    return HipPPOCnn
+
+
+# ---------------------------------------------------------------------------------------------------
+# TD3 / DDPG (td3.py:104-226, ddpg.py:343-411) on the mujoco_td3.py / mujoco_ddpg.py networks
+# ---------------------------------------------------------------------------------------------------
+def _make_hip_det(twin: bool):
+    from tianshou.algorithm.modelfree.ddpg import DDPG, DDPGTrainingStats
+    from tianshou.algorithm.modelfree.td3 import TD3, TD3TrainingStats
+
+    from . import td3 as T
+
+    base = TD3 if twin else DDPG
+
+    class HipDet(base):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sa = self.policy.actor.state_dict()
+            critics = [self.critic] + ([self.critic2] if twin else [])
+            if list(sa.keys()) != T.TIANSHOU_ACTOR_KEYS or any(list(c.state_dict().keys()) != S_KEYS for c in critics):
+                raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py")
+            if sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or sa[T.TIANSHOU_ACTOR_KEYS[2]].shape != (256, 256):
+                raise NotImplementedError("HipTD3 / HipDDPG: hidden sizes must be [256, 256]")
+            for o in [self.policy_optim, self.critic_optim] + ([self.critic2_optim] if twin else []):
+                _adam_of(o)
+            self._hip_engine = None
+
+        def _hip_parts(self):
+            parts = [("actor", self.policy.actor, self.policy_optim, T.TIANSHOU_ACTOR_KEYS, T.actor_flat_from_torch,
+                      T.actor_flat_to_torch, self.actor_old.module),
+                     ("critic1", self.critic, self.critic_optim, S_KEYS, T.critic_flat_from_torch, T.critic_flat_to_torch,
+                      self.critic_old.module)]
+            if twin:
+                parts.append(("critic2", self.critic2, self.critic2_optim, S_KEYS, T.critic_flat_from_torch,
+                              T.critic_flat_to_torch, self.critic2_old.module))
+            return parts
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                obs_dim, act_dim = sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[1], sa[T.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
+                cfg = T.TD3Config(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon, twin=twin,
+                                  policy_noise=getattr(self, "policy_noise", 0.0), noise_clip=getattr(self, "noise_clip", 0.0),
+                                  update_actor_freq=getattr(self, "update_actor_freq", 1),
+                                  max_action=float(self.policy.actor.max_action), actor_lr=ga["lr"], critic_lr=gc["lr"],
+                                  betas=tuple(ga["betas"]), adam_eps=ga["eps"])
+                dev = self._hip_device
+                flats = {n: conv([mod.state_dict()[k] for k in keys], obs_dim, act_dim, dev)
+                         for n, mod, _, keys, conv, _, _ in self._hip_parts()}
+                eng = self._hip_engine = T.TD3Engine(obs_dim, act_dim, flats["actor"], flats["critic1"],
+                                                     flats.get("critic2"), cfg)
+                eng.cnt = getattr(self, "_cnt", 0)
+                for n, mod, optim, keys, conv, _, old in self._hip_parts():           # resume from a checkpoint
+                    setattr(eng, n + "_old", conv([old.state_dict()[k] for k in keys], obs_dim, act_dim, dev))
+                    ms, vs, step = adam_state(optim._optim, params_by_keys(mod, keys))
+                    setattr(eng, n + "_m", conv(ms, obs_dim, act_dim, dev))
+                    setattr(eng, n + "_v", conv(vs, obs_dim, act_dim, dev))
+                    if n == "actor":
+                        eng.actor_steps = step
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            if self._hip_device.type != "cuda":
+                raise RuntimeError("HipTD3 / HipDDPG need an MI355X (device='cuda'); there is no CPU fallback")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            if m.obs_next is None:
+                raise NotImplementedError("HipTD3 / HipDDPG: the replay buffer must store obs_next")
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            noise = torch.randn(size=(len(indices), eng.act_dim)) if twin else None        # td3.py:196
+            batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)
+            self._hip_idx = idx
+            return batch
+
+        def _update_with_batch(self, batch):
+            from .buffer import gather_rows
+
+            eng, m = self._hip_engine, self._hip_mirror
+            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                                             batch.returns.reshape(-1), getattr(batch, "weight", None))
+            batch.weight = w
+            if twin:
+                self._cnt = eng.cnt
+            s = stats.cpu().numpy()
+            with torch.no_grad():
+                for n, mod, optim, keys, _, back, old in self._hip_parts():
+                    params = params_by_keys(mod, keys)
+                    for p, t in zip(params, back(getattr(eng, n), eng.obs_dim, eng.act_dim)):
+                        p.copy_(t)
+                    for p, t in zip(params_by_keys(old, keys), back(getattr(eng, n + "_old"), eng.obs_dim, eng.act_dim)):
+                        p.copy_(t)
+                    step = eng.actor_steps if n == "actor" else eng.cnt
+                    store_adam_state(optim._optim, params, back(getattr(eng, n + "_m"), eng.obs_dim, eng.act_dim),
+                                     back(getattr(eng, n + "_v"), eng.obs_dim, eng.act_dim), step)
+            if twin:
+                self._last = float(s[0])
+                return TD3TrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]))
+            return DDPGTrainingStats(actor_loss=float(s[0]), critic_loss=float(s[1]))
+
+    HipDet.__name__ = "HipTD3" if twin else "HipDDPG"
+    return HipDet
+
+
+S_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
+          "preprocess.model.model.2.bias", "last.model.0.weight", "last.model.0.bias"]
+
+
+def make_hip_td3():
+    """Returns HipTD3(TD3) (hooks td3.py:190-226 on the engine)."""
+    return _make_hip_det(True)
+
+
+def make_hip_ddpg():
+    """Returns HipDDPG(DDPG) (hooks ddpg.py:397-411 on the engine)."""
+    return _make_hip_det(False)
