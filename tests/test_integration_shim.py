@@ -276,3 +276,192 @@ def test_more_subclasses_keep_signatures_and_fail_loudly(which):
             algo.update(buffer=buf, batch_size=8, repeat=1)
         else:
             algo.update(buffer=buf, sample_size=8)
+
+
+# ------------------------------------------------------------------------------------ wrappers run end to end (CPU doubles)
+# The kernels cannot run in this container, so the device engines are replaced by CPU doubles with the engines'
+# interface; what is exercised is the shipped wrapper plumbing: device mirror of the host buffer, hook order and
+# arguments, stats objects, write-back of parameters / lagged networks / Adam state.
+def _patch_for_cpu(monkeypatch):
+    import tianshou_amd.buffer as B
+    import tianshou_amd.integration as I
+
+    monkeypatch.setattr(I, "_require_gpu", lambda device, who: None)
+    monkeypatch.setattr(B, "gather_rows", lambda src, idx: src[idx])
+
+
+def _zeros_like_all(obj, names):
+    for n in names:
+        setattr(obj, n + "_m", torch.zeros_like(getattr(obj, n)))
+        setattr(obj, n + "_v", torch.zeros_like(getattr(obj, n)))
+
+
+def _fill(buf, n, obs_shape, act, dtype=np.float32):
+    from tianshou.data import Batch
+
+    for _ in range(n):
+        buf.add(Batch(obs=(np.random.rand(2, *obs_shape) * 255).astype(dtype), act=act, rew=np.zeros(2),
+                      terminated=np.zeros(2, bool), truncated=np.zeros(2, bool),
+                      obs_next=np.zeros((2, *obs_shape), dtype)))
+
+
+def test_hip_sac_wrapper_runs_with_engine_double(sac_algo, monkeypatch):
+    from tianshou.algorithm.modelfree.sac import SACTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.sac as S
+
+    class FakeSAC:
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg):
+            self.obs_dim, self.act_dim, self.cfg, self.adam_step = obs_dim, act_dim, cfg, 0
+            self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), c2.clone()
+            self.critic1_old, self.critic2_old = c1.clone(), c2.clone()
+            _zeros_like_all(self, ("actor", "critic1", "critic2"))
+            self.log_alpha, self.log_alpha_m, self.log_alpha_v = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+
+        def preprocess(self, m, idx, noise):
+            assert noise.shape == (idx.numel(), self.act_dim) and m.obs_next is not None
+            return torch.zeros(idx.numel())
+
+        def update_with_batch(self, obs, act, ret, noise, weight=None):
+            assert obs.shape == (8, self.obs_dim) and act.shape == (8, self.act_dim)
+            self.adam_step += 1
+            self.actor += 1.0
+            self.actor_m += 0.5
+            self.log_alpha += 0.25
+            return torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]), torch.ones(8)
+
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(S, "SACEngine", FakeSAC)
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (11,), np.zeros((2, 3), np.float32))
+    sac_algo._hip_engine = None
+    first = next(iter(sac_algo.policy.actor.parameters()))
+    before = first.detach().clone()
+    with policy_within_training_step(sac_algo.policy):
+        stats = sac_algo.update(buffer=buf, sample_size=8)
+    assert isinstance(stats, SACTrainingStats) and (stats.actor_loss, stats.critic2_loss, stats.alpha) == (1.0, 3.0, 4.0)
+    assert torch.allclose(first.detach(), before + 1.0)                                   # engine -> nn.Parameter
+    st = sac_algo.policy_optim._optim.state[first]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
+    assert abs(float(sac_algo.alpha._log_alpha) - 0.25) < 1e-6
+
+
+def test_hip_dqn_wrapper_runs_with_engine_double(dqn_algo, monkeypatch):
+    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.dqn as D
+
+    class FakeDQN:
+        def __init__(self, c, h, w, n_act, flat, cfg):
+            self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
+            self.params, self.params_old = flat.clone(), flat.clone()
+            self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
+
+        def preprocess(self, m, frames, idx, stack, obs_next_frames=None):
+            assert frames.dtype == torch.uint8 and stack == 1 and obs_next_frames is not None
+            return torch.zeros(idx.numel())
+
+        def update_with_batch(self, obs, act, ret, weight=None):
+            assert obs.shape == (8, 84, 84, 4) and obs.dtype == torch.uint8
+            self.adam_step += 1
+            self.iter += 1
+            self.params += 2.0
+            self.adam_v += 0.25
+            return torch.tensor([0.75]), torch.arange(8, dtype=torch.float32)
+
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(D, "DQNEngine", FakeDQN)
+    monkeypatch.setattr(D, "gather_obs_nhwc", lambda frames, m, idx, stack, as_u8=False: frames[idx].permute(0, 2, 3, 1))
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    dqn_algo._hip_engine = None
+    first = next(iter(dqn_algo.policy.model.parameters()))
+    before = first.detach().clone()
+    with policy_within_training_step(dqn_algo.policy):
+        stats = dqn_algo.update(buffer=buf, sample_size=8)
+    assert isinstance(stats, SimpleLossTrainingStats) and stats.loss == 0.75
+    assert torch.allclose(first.detach(), before + 2.0)
+    st = dqn_algo.optim._optim.state[first]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.25))
+
+
+@pytest.mark.parametrize("twin", [True, False])
+def test_hip_td3_ddpg_wrapper_runs_with_engine_double(twin, monkeypatch):
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.td3 as T
+
+    class FakeTD3:
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg):
+            self.obs_dim, self.act_dim, self.cfg, self.cnt, self.actor_steps = obs_dim, act_dim, cfg, 0, 0
+            self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), None if c2 is None else c2.clone()
+            names = ("actor", "critic1") + (("critic2",) if c2 is not None else ())
+            for n in names:
+                setattr(self, n + "_old", getattr(self, n).clone())
+            _zeros_like_all(self, names)
+
+        def preprocess(self, m, idx, noise):
+            assert (noise is not None) == self.cfg.twin
+            return torch.zeros(idx.numel())
+
+        def update_with_batch(self, obs, act, ret, weight=None):
+            self.cnt += 1
+            self.actor_steps += 1
+            self.critic1 += 3.0
+            self.actor_old += 1.5
+            return torch.tensor([0.1, 0.2, 0.3]), torch.ones(8)
+
+    algo = _det_algo(twin)
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(T, "TD3Engine", FakeTD3)
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (11,), np.zeros((2, 3), np.float32))
+    c_first = next(iter(algo.critic.parameters()))
+    before = c_first.detach().clone()
+    old_first = next(iter(algo.actor_old.module.parameters()))
+    old_before = old_first.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, sample_size=8)
+    assert abs(stats.actor_loss - 0.1) < 1e-6 and abs((stats.critic1_loss if twin else stats.critic_loss) - 0.2) < 1e-6
+    assert torch.allclose(c_first.detach(), before + 3.0) and torch.allclose(old_first.detach(), old_before + 1.5)
+    assert float(algo.critic_optim._optim.state[c_first]["step"]) == 1.0
+
+
+def test_hip_ppo_cnn_wrapper_runs_with_engine_double(monkeypatch):
+    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.ppo_cnn as PC
+
+    class FakeCnnPPO:
+        def __init__(self, c, h, w, n_act, flat, cfg):
+            self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
+            self.params, self.adam_m, self.adam_v, self.adam_step = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat), 0
+            self.ret_rms = [0.0, 1.0, 0.0]
+
+        def preprocess(self, m, frames, act, stack, obs_next_frames=None):
+            n = len(m)
+            assert frames.dtype == torch.uint8 and act.shape[0] == m.maxsize
+            z = torch.zeros(n)
+            return {"indices": torch.arange(n), "act": act[:n], "v_s": z, "returns": z, "adv": z, "logp_old": z}
+
+        def update(self, m, frames, pre, stack, batch_size, repeat, perms):
+            assert len(perms) == repeat and sorted(perms[0].tolist()) == list(range(pre["indices"].numel()))
+            self.adam_step += 3
+            self.params += 1.0
+            return torch.tensor([[4.0, 3.0, 2.0, 1.0]] * 3), 3
+
+    algo = _ppo_cnn_algo()
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(PC, "CnnPPOEngine", FakeCnnPPO)
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    head = algo.critic.last.model[0].weight
+    before = head.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, batch_size=8, repeat=1)
+    assert isinstance(stats, A2CTrainingStats) and stats.gradient_steps == 3 and stats.loss.mean == 4.0
+    assert torch.allclose(head.detach(), before + 1.0)
+    assert float(algo.optim._optim.state[head]["step"]) == 3.0

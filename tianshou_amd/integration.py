@@ -130,6 +130,11 @@ def make_hip_ppo():
 # ---------------------------------------------------------------------------------------------------
 # DQN (dqn.py:288-404) on DQNet
 # ---------------------------------------------------------------------------------------------------
+def _require_gpu(device: torch.device, who: str) -> None:
+    if device.type != "cuda":
+        raise RuntimeError(f"{who} needs an MI355X (device='cuda'); there is no CPU fallback")
+
+
 def _adam_of(optim):
     opt = optim._optim
     g = opt.param_groups[0]
@@ -202,8 +207,7 @@ def make_hip_dqn():
             return obs.shape[1], obs.shape[2], obs.shape[3], 1
 
         def _preprocess_batch(self, batch, buffer, indices):
-            if self._hip_device.type != "cuda":
-                raise RuntimeError("HipDQN needs an MI355X (device='cuda'); there is no CPU fallback")
+            _require_gpu(self._hip_device, "HipDQN")
             c, h, w, stack = self._layout(buffer)
             eng = self._engine(c, h, w)
             m = _mirror(self, buffer, self._hip_device)
@@ -277,7 +281,7 @@ def make_hip_sac():
                                   target_entropy=float(self.alpha._target_entropy) if auto else 0.0,
                                   log_alpha0=float(self.alpha._log_alpha.item()) if auto else 0.0,
                                   actor_lr=ga["lr"], critic_lr=gc["lr"],
-                                  alpha_lr=self.alpha._optim._optim.param_groups[0]["lr"] if auto else 0.0,
+                                  alpha_lr=self.alpha._optim.param_groups[0]["lr"] if auto else 0.0,
                                   betas=tuple(ga["betas"]), adam_eps=ga["eps"])
                 dev = self._hip_device
                 flat_c = lambda mod: S.critic_flat_from_torch(  # noqa: E731
@@ -294,7 +298,7 @@ def make_hip_sac():
                     setattr(eng, name + "_v", conv(vs, obs_dim, act_dim, dev))
                     eng.adam_step = max(eng.adam_step, step)
                 if auto:
-                    st = self.alpha._optim._optim.state.get(self.alpha._log_alpha, {})
+                    st = self.alpha._optim.state.get(self.alpha._log_alpha, {})
                     if "exp_avg" in st:
                         eng.log_alpha_m[0], eng.log_alpha_v[0] = float(st["exp_avg"]), float(st["exp_avg_sq"])
             return self._hip_engine
@@ -305,8 +309,7 @@ def make_hip_sac():
                     ("critic2", self.critic2, self.critic2_optim, S.TIANSHOU_CRITIC_KEYS, S.critic_flat_from_torch))
 
         def _preprocess_batch(self, batch, buffer, indices):
-            if self._hip_device.type != "cuda":
-                raise RuntimeError("HipSAC needs an MI355X (device='cuda'); there is no CPU fallback")
+            _require_gpu(self._hip_device, "HipSAC")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
             if m.obs_next is None:
@@ -343,7 +346,7 @@ def make_hip_sac():
                                  back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim),
                                  back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim), eng.adam_step)
             if eng.cfg.auto_alpha:
-                store_adam_state(self.alpha._optim._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
+                store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
                                  [eng.log_alpha_v[0]], eng.adam_step)
             auto = eng.cfg.auto_alpha
             return SACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
@@ -405,8 +408,7 @@ def make_hip_ppo_cnn():
             return self._hip_engine
 
         def _preprocess_batch(self, batch, buffer, indices):
-            if self._hip_device.type != "cuda":
-                raise RuntimeError("HipPPOCnn needs an MI355X (device='cuda'); there is no CPU fallback")
+            _require_gpu(self._hip_device, "HipPPOCnn")
             c, h, w, stack = self._layout(buffer)
             eng = self._engine(c, h, w)
             m = _mirror(self, buffer, self._hip_device)
@@ -497,8 +499,7 @@ def _make_hip_det(twin: bool):
             return self._hip_engine
 
         def _preprocess_batch(self, batch, buffer, indices):
-            if self._hip_device.type != "cuda":
-                raise RuntimeError("HipTD3 / HipDDPG need an MI355X (device='cuda'); there is no CPU fallback")
+            _require_gpu(self._hip_device, "HipTD3 / HipDDPG")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
             if m.obs_next is None:
