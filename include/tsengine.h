@@ -420,6 +420,55 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   float* loss_out, float* grad_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Distributional Q-learning on the Atari networks: QRDQN (tianshou/algorithm/modelfree/qrdqn.py) and
+ * C51 (modelfree/c51.py) with QRDQNet / C51Net (tianshou/env/atari/atari_network.py:211-235 / :125-151):
+ * DQNet with n_act * n_atoms outputs viewed [B, n_act, n_atoms] (C51: softmax over the atoms).
+ * Flat parameter vector: the ts_dqn_param_count layout with the head matrix [513, W], W = n_act * n_atoms rounded up to
+ * a multiple of 32; column a * n_atoms + j, the padding columns are (and stay) zero.
+ * `aux` (device float32[n_atoms]): QRDQN -> tau_hat (qrdqn.py:87-91), needed by ts_distq_update only;
+ * C51 -> the support linspace(v_min, v_max, n_atoms) (c51.py:61-64), needed everywhere.
+ * n_act <= 64, 2 <= n_atoms <= 256.
+ * ------------------------------------------------------------------------------------------- */
+#define TS_DISTQ_QR 0
+#define TS_DISTQ_C51 1
+
+int64_t ts_distq_param_count(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms);
+
+/* QRDQNet.forward / C51Net.forward + QRDQNPolicy / C51Policy.compute_q_value (qrdqn.py:19-21, c51.py:66-67) +
+ * DiscreteQLearningPolicy.forward's argmax (dqn.py:141): dist_out float32[B, n_act, n_atoms] (quantile values or
+ * atom probabilities), q_out float32[B, n_act], act_out int64[B]; each nullable. */
+int ts_distq_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                     int64_t n_atoms, int kind, const float* aux, const void* obs_nhwc, int obs_u8, int64_t B,
+                     float* dist_out, float* q_out, int64_t* act_out, ts_stream_t stream);
+
+/* QRDQN._target_q (qrdqn.py:93-104) and the first half of C51._target_dist (c51.py:123-132): greedy action of the
+ * online net on obs_next, its distribution under params_old (NULL: no target network, the online net's own)
+ * -> out float32[B, n_atoms]. */
+int ts_distq_next_dist(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                       int64_t w, int64_t n_act, int64_t n_atoms, int kind, const float* aux,
+                       const void* obs_next_nhwc, int obs_u8, int64_t B, float* out, ts_stream_t stream);
+
+typedef struct ts_distq_hparams {
+    double lr;            /* < 0: compute the gradient only (no optimizer step) */
+    double beta1, beta2, adam_eps;
+    double max_grad_norm; /* <= 0: no clipping */
+    double v_min, v_max;  /* C51 support bounds (c51.py:57-60); delta_z = (v_max - v_min) / (n_atoms - 1) */
+} ts_distq_hparams;
+
+/* QRDQN._update_with_batch (qrdqn.py:106-131) / C51._update_with_batch (c51.py:143-160) after the periodic sync:
+ * forward, loss, backward, clip_grad_norm_ + Adam (algorithm_base.py:484-500).
+ * returns float32[B, n_atoms] = batch.returns; next_dist float32[B, n_atoms] = ts_distq_next_dist on batch.obs_next
+ * (C51 only, NULL for QRDQN); weight float32[B] nullable (PER importance weights);
+ * prio_out float32[B] = the new batch.weight (qrdqn.py:128 / c51.py:157); loss_out float32[1];
+ * target_dist_out float32[B, n_atoms] nullable (C51: the projected target distribution, c51.py:136-141);
+ * grad_out nullable: the flat gradient. */
+int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                    int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, int kind, const float* aux,
+                    const void* obs_nhwc, int obs_u8, const int64_t* act, const float* returns, const float* next_dist,
+                    const float* weight, int64_t B, const ts_distq_hparams* hp, float* prio_out, float* loss_out,
+                    float* target_dist_out, float* grad_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-118): DQNet(features_only=True,
  * output_dim_added_layer=512) shared by DiscreteActor(softmax_output=False) and DiscreteCritic, Categorical policy
  * ------------------------------------------------------------------------------------------- */

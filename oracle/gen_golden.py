@@ -558,6 +558,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "distq":
+        gen_distq_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "buffer_add":
         gen_buffer_add()
         return
@@ -938,6 +941,107 @@ def gen_buffer_add() -> None:
             out[f"s{s}_final_{key}"] = np.asarray(getattr(buf, key))
     out["n_scen"] = np.array(5)
     np.savez_compressed(os.path.join(OUT, "buffer_add.npz"), **out)
+
+
+def gen_distq(kind: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, n_atoms: int,
+              batch: int, n_updates: int, seed: int, lr: float, v_min: float = -2.0, v_max: float = 3.0,
+              **algo_kwargs) -> None:
+    """Runs the reference QRDQN.update() / C51.update() (QRDQNet / C51Net, qrdqn.py, c51.py) on a synthetic
+    PrioritizedVectorReplayBuffer that stores obs and obs_next, and dumps indices, n-step returns
+    [B, n_atoms], the new priorities, losses and parameter samples of every update."""
+    from tianshou.algorithm.modelfree.c51 import C51, C51Policy
+    from tianshou.algorithm.modelfree.qrdqn import QRDQN, QRDQNPolicy
+    from tianshou.env.atari.atari_network import C51Net, QRDQNet
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    if kind == "qr":
+        net = QRDQNet(c=c, h=h, w=w, action_shape=[n_act], num_quantiles=n_atoms)
+        policy = QRDQNPolicy(model=net, action_space=gym.spaces.Discrete(n_act))
+        algorithm = QRDQN(policy=policy, optim=AdamOptimizerFactory(lr=lr), num_quantiles=n_atoms, **algo_kwargs)
+        cls = QRDQN
+    else:
+        net = C51Net(c=c, h=h, w=w, action_shape=[n_act], num_atoms=n_atoms)
+        policy = C51Policy(model=net, action_space=gym.spaces.Discrete(n_act), num_atoms=n_atoms, v_min=v_min,
+                           v_max=v_max)
+        algorithm = C51(policy=policy, optim=AdamOptimizerFactory(lr=lr), **algo_kwargs)
+        cls = C51
+    p0 = OQ.init_params(c, h, w, n_act, n_atoms, seed)
+    sd = net.state_dict()
+    for k_ref, k in zip(OD.TIANSHOU_KEYS, OD.PARAM_ORDER):
+        assert torch.equal(sd[k_ref], p0[k]), f"oracle init differs from the reference net at {k}"
+
+    buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4)
+    frames = rng.integers(0, 256, size=(steps + 1, E, c, h, w), dtype=np.uint8)
+    frames = np.where(rng.random(frames.shape) < 0.06, frames, 0).astype(np.uint8)
+    act = rng.integers(0, n_act, size=(steps, E))
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.08
+    trunc = (rng.random((steps, E)) < 0.04) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=frames[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t],
+                      obs_next=frames[t + 1]))
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, c, h, w, n_act, n_atoms, batch, n_updates, seed])
+    out["frames"] = np.asarray(buf.obs, np.uint8)
+    out["frames_next"] = np.asarray(buf.obs_next, np.uint8)
+    out["act"] = np.asarray(buf.act, np.int64)
+    out["rew"] = np.asarray(buf.rew, np.float64)
+    out["terminated"] = np.asarray(buf.terminated, bool)
+    out["truncated"] = np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+    out["tree0"] = np.asarray(buf.weight._value, np.float64).copy()
+
+    rec: list[dict] = []
+    orig_pre, orig_upd = cls._preprocess_batch, cls._update_with_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        r = {"indices": np.array(indices, np.int64), "is_weight": np.array(batch.weight, np.float64)}
+        b = orig_pre(self, batch, buffer, indices)
+        r["returns"] = b.returns.numpy().copy()
+        rec.append(r)
+        return b
+
+    def rec_upd(self, batch):
+        stats = orig_upd(self, batch)
+        rec[-1]["prio"] = batch.weight.detach().numpy().copy()
+        loss = stats.loss
+        rec[-1]["loss"] = np.array(loss.mean if hasattr(loss, "mean") and not isinstance(loss, float) else loss)
+        return stats
+
+    cls._preprocess_batch, cls._update_with_batch = rec_pre, rec_upd
+    try:
+        np.random.seed(seed + 7)
+        for u in range(n_updates):
+            with policy_within_training_step(algorithm.policy):
+                algorithm.update(buffer=buf, sample_size=batch)
+            r = rec[-1]
+            flat = torch.cat([net.state_dict()[k].reshape(-1) for k in OD.TIANSHOU_KEYS]).numpy()
+            for k in ("indices", "returns", "prio", "loss", "is_weight"):
+                out[f"u{u}_{k}"] = r[k]
+            out[f"u{u}_params_strided"] = flat[::61].copy()
+            out[f"u{u}_conv1_w"] = net.state_dict()["net.0.0.weight"].numpy().copy()
+            out[f"u{u}_fc2_w_strided"] = net.state_dict()["net.3.weight"].numpy().reshape(-1)[::7].copy()
+            out[f"u{u}_biases"] = torch.cat([net.state_dict()[k].reshape(-1) for k in OD.TIANSHOU_KEYS
+                                             if k.endswith("bias")]).numpy().copy()
+            out[f"u{u}_tree"] = np.asarray(buf.weight._value, np.float64).copy()
+    finally:
+        cls._preprocess_batch, cls._update_with_batch = orig_pre, orig_upd
+    cfg = dict(gamma=algorithm.gamma, n_step=algorithm.n_step, target_update_freq=algorithm.target_update_freq,
+               lr=lr, v_min=v_min, v_max=v_max)
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, "qrdqn.npz" if kind == "qr" else "c51.npz"), **out)
+
+
+def gen_distq_all() -> None:
+    gen_distq("qr", E=3, slots=24, steps=30, c=2, h=44, w=36, n_act=3, n_atoms=20, batch=24, n_updates=3, seed=11,
+              lr=3e-4, gamma=0.95, n_step_return_horizon=3, target_update_freq=2)
+    gen_distq("c51", E=3, slots=24, steps=30, c=2, h=44, w=36, n_act=4, n_atoms=11, batch=24, n_updates=3, seed=13,
+              lr=3e-4, gamma=0.9, n_step_return_horizon=2, target_update_freq=0)
 
 
 def gen_dqn_all() -> None:

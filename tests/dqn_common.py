@@ -27,3 +27,19 @@ def load(tag: str):
 
 def torch_order_flat(p) -> np.ndarray:
     return OD.flatten_params(p).numpy()
+
+
+def load_distq(kind: str):
+    """tests/golden/qrdqn.npz | c51.npz (oracle/gen_golden.py::gen_distq)."""
+    from oracle import oracle_distq as OQ
+
+    g = np.load(os.path.join(GOLDEN, "qrdqn.npz" if kind == "qr" else "c51.npz"))
+    E, slots, steps, c, h, w, n_act, n_atoms, batch, n_updates, seed = (int(x) for x in g["dims"])
+    cd = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OQ.DistQConfig(kind=kind, n_atoms=n_atoms, v_min=cd["v_min"], v_max=cd["v_max"], gamma=cd["gamma"],
+                         n_step=int(cd["n_step"]), target_update_freq=int(cd["target_update_freq"]), lr=cd["lr"])
+    dims = dict(E=E, slots=slots, steps=steps, c=c, h=h, w=w, n_act=n_act, n_atoms=n_atoms, batch=batch,
+                n_updates=n_updates, seed=seed)
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, dims, cfg, bstate

@@ -1,0 +1,159 @@
+"""GPU parity of the distributional Q-learning rows (QRDQN, C51) -- through the C ABI, against the
+oracle (oracle/oracle_distq.py, pinned to the reference by tests/golden/qrdqn.npz / c51.npz) and against the
+golden files themselves.  Tolerance: 1e-5 relative (north_star), on the scale of each tensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_distq as OQ
+from oracle import oracle_dqn as OD
+from tests import dqn_common as DC
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _engine(kind, c, h, w, A, N, seed, **kw):
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    p = OQ.init_params(c, h, w, A, N, seed)
+    cfg = Q.DistQConfig(kind=kind, n_atoms=N, **kw)
+    eng = Q.DistQEngine(c, h, w, A, Q.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, A, N), cfg)
+    return p, eng
+
+
+@pytest.mark.parametrize("kind,A,N", [("qr", 6, 200), ("c51", 6, 51), ("qr", 3, 7), ("c51", 5, 130)])
+def test_forward_dist_q_act_vs_oracle(kind, A, N):
+    c, h, w, B = 4, 84, 84, 33
+    p, eng = _engine(kind, c, h, w, A, N, seed=3, v_min=-4.0, v_max=9.0)
+    ocfg = OQ.DistQConfig(kind=kind, n_atoms=N, v_min=-4.0, v_max=9.0)
+    obs = np.random.default_rng(1).integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    d_ref = OQ.dist(p, ocfg, obs, A)
+    q_ref = OQ.q_values(d_ref, ocfg)
+    for as_u8 in (True, False):
+        x = torch.as_tensor(obs).permute(0, 2, 3, 1).contiguous().cuda()
+        dist, q, act = eng.forward(x if as_u8 else x.float())
+        assert rel_err(dist.cpu(), d_ref) < 1e-5
+        assert rel_err(q.cpu(), q_ref) < 1e-5
+        assert torch.equal(act.cpu(), q_ref.argmax(dim=1))
+    if kind == "c51":
+        assert torch.allclose(dist.sum(-1).cpu(), torch.ones(B, A), atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["qr", "c51"])
+@pytest.mark.parametrize("lagged", [True, False])
+def test_next_dist_vs_oracle(kind, lagged):
+    c, h, w, A, N, B = 2, 44, 36, 4, 33, 40
+    p, eng = _engine(kind, c, h, w, A, N, seed=5, target_update_freq=3 if lagged else 0, v_min=-1.0, v_max=2.0)
+    ocfg = OQ.DistQConfig(kind=kind, n_atoms=N, target_update_freq=3 if lagged else 0, v_min=-1.0, v_max=2.0)
+    st = OD.DQNState.create(p, ocfg.dqn())
+    if lagged:                                           # make the lagged net differ from the online one
+        g = torch.Generator().manual_seed(0)
+        st.params_old = {k: v + 0.02 * torch.randn(v.shape, generator=g) for k, v in p.items()}
+        from tianshou_amd import distq as Q
+        eng.params_old = Q.flat_from_torch([st.params_old[k] for k in OD.PARAM_ORDER], c, h, w, A, N)
+    obs = np.random.default_rng(2).integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    ref = OQ.next_dist(st, ocfg, obs, A)
+    out = eng.next_dist(torch.as_tensor(obs).permute(0, 2, 3, 1).contiguous().cuda())
+    assert rel_err(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("kind,A,N,B,weighted", [("qr", 6, 200, 64, True), ("qr", 4, 31, 37, False),
+                                                 ("c51", 6, 51, 64, True), ("c51", 3, 130, 21, False)])
+def test_batch_gradient_vs_oracle(kind, A, N, B, weighted):
+    """loss, new priorities, (C51) projected target and the whole gradient of one minibatch, then the Adam step."""
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    c, h, w = 4, 84, 84
+    rng = np.random.default_rng(9)
+    kw = dict(v_min=-3.0, v_max=5.0, lr=1e-4)
+    p, eng = _engine(kind, c, h, w, A, N, seed=4, **kw)
+    ocfg = OQ.DistQConfig(kind=kind, n_atoms=N, **kw)
+    st = OD.DQNState.create(p, ocfg.dqn())
+    obs = rng.integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    obs_next = rng.integers(0, 256, size=(B, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=B)
+    ret = (rng.normal(size=(B, N)) * 2.5).astype(np.float32)         # some outside [v_min, v_max], some |d| > 1
+    weight = rng.random(B).astype(np.float32) if weighted else None
+    col: dict = {}
+    loss_ref, prio_ref = OQ.update_with_batch(st, ocfg, obs, act, ret, A, weight=weight, obs_next=obs_next, collect=col)
+
+    to_dev = lambda a: torch.as_tensor(a).permute(0, 2, 3, 1).contiguous().cuda()
+    grad = torch.empty(eng.P, dtype=torch.float32, device="cuda")
+    loss, prio, tgt = eng.update_with_batch(to_dev(obs), act, ret, weight, obs_next_nhwc=to_dev(obs_next), grad_out=grad,
+                                            apply=False, want_target=True)
+    assert abs(float(loss) - loss_ref) <= 1e-5 * abs(loss_ref)
+    assert rel_err(prio.cpu(), prio_ref) < 1e-5
+    if kind == "c51":
+        assert rel_err(tgt.cpu(), col["target_dist"]) < 1e-5
+    g_ref = Q.flat_from_torch([col["grads"][k] for k in OD.PARAM_ORDER], c, h, w, A, N, device="cpu")
+    off, _ = D.layer_layout(c, h, w, 1)
+    bounds = list(off[:5]) + [eng.P]
+    for i in range(5):
+        assert rel_err(grad[bounds[i]:bounds[i + 1]].cpu(), g_ref[bounds[i]:bounds[i + 1]]) < 1e-5, f"layer {i}"
+    loss2, _ = eng.update_with_batch(to_dev(obs), act, ret, weight, obs_next_nhwc=to_dev(obs_next))
+    assert float(loss2) == float(loss)
+    new = torch.cat([t.reshape(-1) for t in Q.flat_to_torch(eng.params, c, h, w, A, N)]).cpu().numpy()
+    pad = eng.params[bounds[4]:].reshape(513, -1)[:, A * N:]
+    assert pad.numel() == 0 or float(pad.abs().max()) == 0.0          # padding columns stay exactly zero
+    ref = OD.flatten_params(st.params).numpy()
+    bad = np.abs(new - ref) > 1e-5 * np.abs(ref) + 0.02 * ocfg.lr
+    assert bad.mean() < 1e-4 and np.abs(new - ref).max() <= 2 * ocfg.lr
+
+
+@pytest.mark.parametrize("kind", ["qr", "c51"])
+def test_update_sequence_matches_reference_golden(kind):
+    """Replays the reference's QRDQN.update() / C51.update() sequence (sampled indices and PER weights from the
+    fixture) on the engine: n-step returns of whole distributions, losses, new priorities, parameters."""
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, ocfg, bstate = DC.load_distq(kind)
+    c, h, w, A, N = d["c"], d["h"], d["w"], d["n_act"], d["n_atoms"]
+    p, eng = _engine(kind, c, h, w, A, N, seed=d["seed"], v_min=ocfg.v_min, v_max=ocfg.v_max, gamma=ocfg.gamma,
+                     n_step=ocfg.n_step, target_update_freq=ocfg.target_update_freq, lr=ocfg.lr)
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"])
+    frames, frames_next = torch.as_tensor(g["frames"]).cuda(), torch.as_tensor(g["frames_next"]).cuda()
+    act_all = torch.as_tensor(g["act"]).cuda()
+    for u in range(d["n_updates"]):
+        idx = torch.as_tensor(g[f"u{u}_indices"]).cuda()
+        ret = eng.preprocess(buf, frames, idx, 1, obs_next_frames=frames_next)
+        assert tuple(ret.shape) == (d["batch"], N)
+        np.testing.assert_allclose(ret.cpu().numpy(), g[f"u{u}_returns"], rtol=1e-5, atol=1e-5)
+        obs = D.gather_obs_nhwc(frames, buf, idx, 1, as_u8=True)
+        obs_next = D.gather_obs_nhwc(frames_next, buf, idx, 1, as_u8=True)
+        loss, prio = eng.update_with_batch(obs, act_all[idx], ret, g[f"u{u}_is_weight"], obs_next_nhwc=obs_next)
+        np.testing.assert_allclose(prio.cpu().numpy(), g[f"u{u}_prio"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(float(loss), float(g[f"u{u}_loss"]), rtol=1e-5)
+        tensors = Q.flat_to_torch(eng.params, c, h, w, A, N)
+        flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+        np.testing.assert_allclose(flat[::61], g[f"u{u}_params_strided"], rtol=1e-5, atol=0.02 * ocfg.lr)
+        np.testing.assert_allclose(tensors[0].cpu().numpy(), g[f"u{u}_conv1_w"], rtol=1e-5, atol=0.02 * ocfg.lr)
+        np.testing.assert_allclose(tensors[8].cpu().numpy().reshape(-1)[::7], g[f"u{u}_fc2_w_strided"], rtol=1e-5,
+                                   atol=0.02 * ocfg.lr)
+
+
+def test_argument_errors():
+    from tianshou_amd import distq as Q
+
+    with pytest.raises(ValueError):
+        Q.param_count(4, 84, 84, 6, 257)
+    p, eng = _engine("c51", 2, 44, 36, 3, 11, seed=0)
+    x = torch.zeros((5, 44, 36, 2), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ValueError):                       # C51 without batch.obs_next
+        eng.update_with_batch(x, np.zeros(5, np.int64), np.zeros((5, 11), np.float32))
+    with pytest.raises(ValueError):                       # returns must be [B, n_atoms]
+        eng.update_with_batch(x, np.zeros(5, np.int64), np.zeros(5, np.float32), obs_next_nhwc=x)
+    with pytest.raises(ValueError):
+        eng.forward(torch.zeros((5, 36, 44, 2), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(RuntimeError):
+        Q.DistQEngine(2, 44, 36, 3, torch.zeros(eng.P), Q.DistQConfig(kind="c51", n_atoms=11))

@@ -465,3 +465,101 @@ def test_hip_ppo_cnn_wrapper_runs_with_engine_double(monkeypatch):
     assert isinstance(stats, A2CTrainingStats) and stats.gradient_steps == 3 and stats.loss.mean == 4.0
     assert torch.allclose(head.detach(), before + 1.0)
     assert float(algo.optim._optim.state[head]["step"]) == 3.0
+
+
+# ------------------------------------------------------------------------------------ QRDQN / C51 subclasses
+def _distq_algo(kind):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou_amd.integration import make_hip_c51, make_hip_qrdqn
+
+    if kind == "qr":
+        from tianshou.algorithm.modelfree.qrdqn import QRDQNPolicy
+        from tianshou.env.atari.atari_network import QRDQNet
+
+        net = QRDQNet(c=4, h=84, w=84, action_shape=[6], num_quantiles=20)
+        policy = QRDQNPolicy(model=net, action_space=gym.spaces.Discrete(6))
+        return make_hip_qrdqn()(policy=policy, optim=AdamOptimizerFactory(lr=1e-4), num_quantiles=20,
+                                n_step_return_horizon=3, target_update_freq=500, device="cpu")
+    from tianshou.algorithm.modelfree.c51 import C51Policy
+    from tianshou.env.atari.atari_network import C51Net
+
+    net = C51Net(c=4, h=84, w=84, action_shape=[6], num_atoms=11)
+    policy = C51Policy(model=net, action_space=gym.spaces.Discrete(6), num_atoms=11, v_min=-2.0, v_max=3.0)
+    return make_hip_c51()(policy=policy, optim=AdamOptimizerFactory(lr=1e-4), n_step_return_horizon=2,
+                          target_update_freq=0, device="cpu")
+
+
+@pytest.mark.parametrize("kind", ["qr", "c51"])
+def test_distq_subclasses_keep_signatures_and_fail_loudly(kind):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _distq_algo(kind)
+    base = type(algo).__mro__[1]
+    assert type(algo).__name__ == ("HipQRDQN" if kind == "qr" else "HipC51")
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, sample_size=8)
+
+
+@pytest.mark.parametrize("kind", ["qr", "c51"])
+def test_hip_distq_wrapper_runs_with_engine_double(kind, monkeypatch):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.distq as Q
+    import tianshou_amd.dqn as D
+
+    n_atoms = 20 if kind == "qr" else 11
+
+    class FakeDistQ:
+        def __init__(self, c, h, w, n_act, flat, cfg):
+            assert (c, h, w, n_act) == (4, 84, 84, 6) and cfg.kind == kind and cfg.n_atoms == n_atoms
+            assert flat.numel() == 8224 + 32832 + 36928 + 3137 * 512 + 513 * ((6 * n_atoms + 31) // 32 * 32)
+            if kind == "c51":
+                assert (cfg.v_min, cfg.v_max) == (-2.0, 3.0)
+            self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
+            self.params = flat.clone()
+            self.params_old = flat.clone() if cfg.target_update_freq > 0 else None
+            self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
+
+        def preprocess(self, m, frames, idx, stack, obs_next_frames=None):
+            assert frames.dtype == torch.uint8 and stack == 1 and obs_next_frames is not None
+            return torch.zeros((idx.numel(), n_atoms))
+
+        def update_with_batch(self, obs, act, ret, weight=None, obs_next_nhwc=None):
+            assert obs.shape == (8, 84, 84, 4) and ret.shape == (8, n_atoms)
+            assert (obs_next_nhwc is not None) == (kind == "c51")
+            self.adam_step += 1
+            self.iter += 1
+            self.params += 2.0
+            self.adam_m += 0.125
+            return torch.tensor([0.5]), torch.arange(8, dtype=torch.float32)
+
+    algo = _distq_algo(kind)
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(Q, "DistQEngine", FakeDistQ)
+    monkeypatch.setattr(D, "gather_obs_nhwc", lambda frames, m, idx, stack, as_u8=False: frames[idx].permute(0, 2, 3, 1))
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    first = next(iter(algo.policy.model.parameters()))
+    before = first.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, sample_size=8)
+    loss = stats.loss if kind == "qr" else stats.loss
+    assert float(loss if isinstance(loss, float) else getattr(loss, "mean", loss)) == 0.5
+    assert torch.allclose(first.detach(), before + 2.0)
+    st = algo.optim._optim.state[first]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.125))
+    if kind == "qr":                                       # lagged network written back too
+        old_first = next(iter(algo.model_old.parameters()))
+        assert torch.allclose(old_first.detach(), before)

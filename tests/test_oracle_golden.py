@@ -260,6 +260,46 @@ def test_dqn_restatement_matches_reference(tag):
             np.testing.assert_allclose([mn, mx], g[f"u{u}_prio_minmax"], rtol=1e-4)
 
 
+# ------------------------------------------------------------------------------------ QRDQN / C51 paths
+@pytest.mark.parametrize("kind", ["qr", "c51"])
+def test_distq_restatement_matches_reference(kind):
+    """oracle_distq (quantile Huber / categorical projection + cross entropy, n-step returns of whole
+    distributions, PER weights and new priorities, Adam, hard sync) against the unmodified reference
+    QRDQN.update() / C51.update() (gen_golden.gen_distq)."""
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+    from tests import dqn_common as DC
+
+    g, d, cfg, bstate = DC.load_distq(kind)
+    st = OD.DQNState.create(OQ.init_params(d["c"], d["h"], d["w"], d["n_act"], d["n_atoms"], d["seed"]), cfg.dqn())
+    tree = g["tree0"].copy()
+    bound = 1
+    while bound < d["E"] * d["slots"]:
+        bound *= 2
+    np.random.seed(d["seed"] + 7)
+    mx, mn = 1.0, 1.0
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        scalar = np.random.rand(d["batch"]) * tree[1]
+        assert np.array_equal(O._get_prefix_sum_idx(scalar, bound, tree), idx)
+        w = O.per_get_weight(tree, bound, idx, mn, 0.4, True)
+        np.testing.assert_allclose(w, g[f"u{u}_is_weight"], rtol=1e-4)
+        ret = OQ.preprocess(st, cfg, bstate, g["frames"], idx, d["n_act"], 1, g["frames_next"])
+        assert ret.shape == (d["batch"], d["n_atoms"])
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-6, atol=1e-6)
+        loss, prio = OQ.update_with_batch(st, cfg, g["frames"][idx], g["act"][idx], ret, d["n_act"], weight=w,
+                                          obs_next=g["frames_next"][idx])
+        np.testing.assert_allclose(prio.numpy(), g[f"u{u}_prio"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss, float(g[f"u{u}_loss"]), rtol=1e-5)
+        flat = DC.torch_order_flat(st.params)
+        np.testing.assert_allclose(flat[::61], g[f"u{u}_params_strided"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.params["conv1.w"].numpy(), g[f"u{u}_conv1_w"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.params["fc2.w"].numpy().reshape(-1)[::7], g[f"u{u}_fc2_w_strided"], rtol=1e-6,
+                                   atol=1e-7)
+        mx, mn = O.per_update_weight(tree, bound, idx, prio.numpy(), 0.6, mx, mn)
+        np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------------ SAC path
 def load_sac(tag):
     from oracle import oracle_sac as OS

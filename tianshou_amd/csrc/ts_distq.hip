@@ -1,0 +1,421 @@
+// ts_distq.hip -- distributional Q-learning (QRDQN, C51) on the Atari networks for gfx950.
+//
+// Replaces, on device-resident NHWC observations:
+//   QRDQNet.forward / C51Net.forward          tianshou/env/atari/atari_network.py:227-235 / :141-151
+//   QRDQNPolicy.compute_q_value               tianshou/algorithm/modelfree/qrdqn.py:19-21
+//   C51Policy.compute_q_value                 modelfree/c51.py:66-67
+//   QRDQN._target_q, C51._target_dist (the lagged net's distribution of the online net's greedy action)
+//                                             qrdqn.py:93-104, c51.py:123-132
+//   QRDQN._update_with_batch                  qrdqn.py:106-131 (quantile Huber loss, new priorities)
+//   C51._update_with_batch                    c51.py:133-160  (projection, cross entropy, new priorities)
+//   Optimizer.step                            algorithm_base.py:484-500 (clip_grad_norm_ + Adam)
+// The network is DQNet with n_act * n_atoms outputs: the trunk, fc1 and the head all run on the fp32-MFMA
+// implicit-GEMM kernels of ts_conv.hip; this file adds the per-sample distribution kernels and the orchestration.
+// Flat parameter layout: the ts_dqn layout with the head matrix [513, W], W = n_act * n_atoms rounded up to a multiple
+// of 32 (GEMM tile width); column a * n_atoms + j, the padding columns are and stay exactly zero.
+#include <algorithm>
+
+#include "ts_common.h"
+#include "ts_conv.h"
+
+#pragma clang fp contract(off)
+
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+}
+
+namespace {
+
+constexpr int HIDDEN = 512;
+constexpr int MAX_ATOMS = 256;
+constexpr int MAX_ACT = 64;
+
+struct Net {
+    ts::ConvGeom l[5];          // conv1, conv2, conv3, fc1, head (512 -> W)
+    int64_t off[6];
+    int n_act, n_atoms, ld;     // ld = W: row stride of the head output
+};
+
+int make_net(int B, int c, int h, int w, int n_act, int n_atoms, Net* n) {
+    TS_REQUIRE(c >= 1 && h >= 1 && w >= 1 && n_act >= 1 && n_act <= MAX_ACT && n_atoms >= 2 && n_atoms <= MAX_ATOMS,
+               TS_ERR_INVALID_ARG, "distq: bad network dimensions (n_act <= 64, 2 <= n_atoms <= 256)");
+    static const int oc[3] = {32, 64, 64}, ks[3] = {8, 4, 3}, st[3] = {4, 2, 1};
+    int ic = c, ih = h, iw = w;
+    for (int i = 0; i < 3; ++i) {
+        TS_REQUIRE(ih >= ks[i] && iw >= ks[i], TS_ERR_INVALID_ARG, "distq: observation too small for DQNet");
+        n->l[i] = ts::ConvGeom{B, ih, iw, ic, ks[i], ks[i], st[i], (ih - ks[i]) / st[i] + 1, (iw - ks[i]) / st[i] + 1, oc[i]};
+        ic = oc[i]; ih = n->l[i].OH; iw = n->l[i].OW;
+    }
+    n->l[3] = ts::ConvGeom{B, 1, 1, ic * ih * iw, 1, 1, 1, 1, 1, HIDDEN};
+    n->ld = (n_act * n_atoms + 31) / 32 * 32;
+    n->l[4] = ts::ConvGeom{B, 1, 1, HIDDEN, 1, 1, 1, 1, 1, n->ld};
+    n->n_act = n_act;
+    n->n_atoms = n_atoms;
+    int64_t o = 0;
+    for (int i = 0; i < 5; ++i) { n->off[i] = o; o += n->l[i].param_elems(); }
+    n->off[5] = o;
+    return TS_OK;
+}
+
+size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Acts { float* h[5]; float* split; };
+
+size_t split_floats(const Net& n) {
+    size_t s = 4;
+    for (int i = 0; i < 5; ++i) {
+        const int ns = ts::conv_fwd_splits(n.l[i]);
+        if (ns > 1) s = std::max(s, (size_t)ns * n.l[i].out_elems());
+    }
+    return s;
+}
+
+size_t acts_bytes(const Net& n) {
+    size_t s = al(4 * split_floats(n));
+    for (int i = 0; i < 5; ++i) s += al(4 * (size_t)n.l[i].out_elems());
+    return s;
+}
+
+char* carve_acts(const Net& n, char* p, Acts* a) {
+    for (int i = 0; i < 5; ++i) { a->h[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
+    a->split = reinterpret_cast<float*>(p);
+    return p + al(4 * split_floats(n));
+}
+
+__device__ __forceinline__ float wave_sum(float s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+
+__device__ __forceinline__ float wave_max(float s) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s = fmaxf(s, __shfl_xor(s, off, 64));
+    return s;
+}
+
+// ---- head: one wave per sample.  QR (kind 0): Q[b, a] = mean_j x[b, a, j].  C51 (kind 1): x[b, a, :] is replaced by
+// softmax(x[b, a, :]) in place and Q[b, a] = sum_j p_j support_j.  act = first maximum of Q (torch.argmax, dqn.py:141).
+__global__ __launch_bounds__(256) void distq_head_kernel(int kind, float* __restrict__ x, const float* __restrict__ support,
+                                                         int64_t B, int A, int N, int ld, float* __restrict__ q_out,
+                                                         int64_t* __restrict__ act_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float best = 0.f;
+    int best_a = 0;
+    for (int a = 0; a < A; ++a) {
+        float* row = x + b * ld + a * N;
+        float q;
+        if (kind == 0) {
+            float s = 0.f;
+            for (int j = lane; j < N; j += 64) s += row[j];
+            q = wave_sum(s) / (float)N;
+        } else {
+            float m = -INFINITY;
+            for (int j = lane; j < N; j += 64) m = fmaxf(m, row[j]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int j = lane; j < N; j += 64) s += expf(row[j] - m);
+            s = wave_sum(s);
+            float qs = 0.f;
+            for (int j = lane; j < N; j += 64) {
+                const float p = expf(row[j] - m) / s;
+                row[j] = p;
+                qs += p * support[j];
+            }
+            q = wave_sum(qs);
+        }
+        if (q_out && lane == 0) q_out[b * A + a] = q;
+        if (a == 0 || q > best) { best = q; best_a = a; }
+    }
+    if (act_out && lane == 0) act_out[b] = best_a;
+}
+
+// out[b, :] = dist[b, act[b], :]   (act == nullptr: out[b, k] = dist[b, k], k < N -- unpadding copy)
+__global__ __launch_bounds__(256) void distq_select_kernel(const float* __restrict__ dist, const int64_t* __restrict__ act,
+                                                           int64_t B, int N, int ld, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const int64_t b = i / N;
+    const int j = (int)(i - b * N);
+    out[i] = dist[b * ld + (act ? act[b] * N : 0) + j];
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {      // all threads get the sum (fixed order)
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- QRDQN loss (qrdqn.py:111-128), one workgroup per sample:
+//   theta_i = x[b, act_b, i], T_j = returns[b, j], d_ij = T_j - theta_i
+//   l_ij = smooth_l1(d_ij), w_ij = |tau_hat_i - 1{d_ij <= 0}|
+//   huber_b = (1/N) sum_i sum_j l_ij w_ij,   prio_b = (1/N) sum_i sum_j l_ij,   loss = mean_b(huber_b weight_b)
+//   d loss / d theta_i = -(weight_b / (B N)) sum_j w_ij clamp(d_ij, -1, 1);  all other head outputs get 0.
+__global__ __launch_bounds__(256) void qr_loss_kernel(const float* __restrict__ x, const int64_t* __restrict__ act,
+                                                      const float* __restrict__ ret, const float* __restrict__ weight,
+                                                      const float* __restrict__ tau_hat, int64_t B, int N, int ld,
+                                                      float* __restrict__ d_head, float* __restrict__ prio,
+                                                      float* __restrict__ lw) {
+    __shared__ float th[MAX_ATOMS], T[MAX_ATOMS], red[4];
+    const int64_t b = blockIdx.x;
+    const int a = (int)act[b];
+    for (int j = threadIdx.x; j < N; j += 256) {
+        th[j] = x[b * ld + a * N + j];
+        T[j] = ret[b * N + j];
+    }
+    __syncthreads();
+    const float wb = weight ? weight[b] : 1.f;
+    const float scale = wb / ((float)B * (float)N);
+    float* drow = d_head + b * ld;
+    for (int k = threadIdx.x; k < ld; k += 256)
+        if (k / N != a) drow[k] = 0.f;
+    float wl = 0.f, sl = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float theta = th[i], tau = tau_hat[i];
+        float li = 0.f, ai = 0.f, g = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float d = T[j] - theta, ad = fabsf(d);
+            const bool quad = ad < 1.f;
+            const float l = quad ? 0.5f * d * d : ad - 0.5f;
+            const float w = fabsf(tau - (d <= 0.f ? 1.f : 0.f));
+            li += l * w;
+            ai += l;
+            g += w * (quad ? d : (d > 0.f ? 1.f : -1.f));
+        }
+        drow[a * N + i] = -g * scale;
+        wl += li;
+        sl += ai;
+    }
+    wl = block_sum_256(wl, red);
+    sl = block_sum_256(sl, red);
+    if (threadIdx.x == 0) {
+        const float huber = wl / (float)N;
+        prio[b] = sl / (float)N;
+        lw[b] = huber * wb;
+    }
+}
+
+// ---- C51 loss (c51.py:133-158), one workgroup per sample; p = softmax probabilities of the taken action:
+//   m_i = sum_j clamp(1 - |clamp(returns[b, j], v_min, v_max) - z_i| / delta_z, 0, 1) next_dist[b, j]
+//   ce_b = -sum_i m_i log(p_i + 1e-8),  prio_b = ce_b,  loss = mean_b(ce_b weight_b)
+//   d loss / d logit_k = p_k (g_k - sum_i p_i g_i),  g_i = -(weight_b / B) m_i / (p_i + 1e-8)
+__global__ __launch_bounds__(256) void c51_loss_kernel(const float* __restrict__ p_all, const int64_t* __restrict__ act,
+                                                       const float* __restrict__ ret, const float* __restrict__ next_dist,
+                                                       const float* __restrict__ weight, const float* __restrict__ support,
+                                                       float v_min, float v_max, float delta_z, int64_t B, int N, int ld,
+                                                       float* __restrict__ d_head, float* __restrict__ prio,
+                                                       float* __restrict__ lw, float* __restrict__ target_out) {
+    __shared__ float ts_[MAX_ATOMS], nd[MAX_ATOMS], red[4];
+    const int64_t b = blockIdx.x;
+    const int a = (int)act[b];
+    for (int j = threadIdx.x; j < N; j += 256) {
+        ts_[j] = fminf(fmaxf(ret[b * N + j], v_min), v_max);
+        nd[j] = next_dist[b * N + j];
+    }
+    __syncthreads();
+    const float wb = weight ? weight[b] : 1.f;
+    const float scale = wb / (float)B;
+    float* drow = d_head + b * ld;
+    for (int k = threadIdx.x; k < ld; k += 256)
+        if (k / N != a) drow[k] = 0.f;
+    const int i = threadIdx.x;
+    float p = 0.f, g = 0.f, ce = 0.f;
+    if (i < N) {
+        const float z = support[i];
+        float m = 0.f;
+        for (int j = 0; j < N; ++j) m += fminf(fmaxf(1.f - fabsf(ts_[j] - z) / delta_z, 0.f), 1.f) * nd[j];
+        if (target_out) target_out[b * N + i] = m;
+        p = p_all[b * ld + a * N + i];
+        ce = -(m * logf(p + 1e-8f));
+        g = -(m / (p + 1e-8f)) * scale;
+    }
+    const float s = block_sum_256(p * g, red);
+    const float ce_b = block_sum_256(ce, red);
+    if (i < N) drow[a * N + i] = p * (g - s);
+    if (threadIdx.x == 0) {
+        prio[b] = ce_b;
+        lw[b] = ce_b * wb;
+    }
+}
+
+// loss = mean_b lw[b] (fixed order)
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ v, int64_t B, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) s += v[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0] / (float)B;
+}
+
+int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const void* obs, bool obs_u8,
+                const Acts& a) {
+    const float* x = static_cast<const float*>(obs);
+    for (int i = 0; i < 5; ++i) {
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], a.h[i], i < 4, a.split, ws, i == 0 && obs_u8))
+            return rc;
+        x = a.h[i];
+    }
+    return TS_OK;
+}
+
+int check_kind(int kind, const float* aux, const char* who) {
+    TS_REQUIRE(kind == TS_DISTQ_QR || kind == TS_DISTQ_C51, TS_ERR_INVALID_ARG, "%s: kind must be TS_DISTQ_QR or TS_DISTQ_C51", who);
+    TS_REQUIRE(kind == TS_DISTQ_QR || aux, TS_ERR_INVALID_ARG, "%s: C51 needs the support vector", who);
+    return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ts_distq_param_count(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms) {
+    Net n;
+    if (make_net(1, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n) != TS_OK) return -1;
+    return n.off[5];
+}
+
+int ts_distq_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                     int64_t n_atoms, int kind, const float* aux, const void* obs_nhwc, int obs_u8, int64_t B,
+                     float* dist_out, float* q_out, int64_t* act_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_distq_forward: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_distq_forward: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && obs_nhwc, TS_ERR_INVALID_ARG, "ts_distq_forward: NULL argument");
+    if (int rc = check_kind(kind, aux, "ts_distq_forward")) return rc;
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    if (int rc = ts::ws_reserve(ws, acts_bytes(n))) return rc;
+    Acts a;
+    carve_acts(n, static_cast<char*>(ws->base), &a);
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
+    hipLaunchKernelGGL(distq_head_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, kind, a.h[4], aux, B,
+                       n.n_act, n.n_atoms, n.ld, q_out, act_out);
+    TS_LAUNCH_CHECK();
+    if (dist_out) {
+        const int row = n.n_act * n.n_atoms;
+        hipLaunchKernelGGL(distq_select_kernel, dim3((unsigned)ts::ceil_div(B * row, 256)), dim3(256), 0, s, a.h[4],
+                           (const int64_t*)nullptr, B, row, n.ld, dist_out);
+        TS_LAUNCH_CHECK();
+    }
+    return TS_OK;
+}
+
+int ts_distq_next_dist(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                       int64_t w, int64_t n_act, int64_t n_atoms, int kind, const float* aux,
+                       const void* obs_next_nhwc, int obs_u8, int64_t B, float* out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_distq_next_dist: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_distq_next_dist: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && obs_next_nhwc && out, TS_ERR_INVALID_ARG, "ts_distq_next_dist: NULL argument");
+    if (int rc = check_kind(kind, aux, "ts_distq_next_dist")) return rc;
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    const size_t one = acts_bytes(n);
+    if (int rc = ts::ws_reserve(ws, 2 * one + al(8 * (size_t)B))) return rc;
+    Acts ao, at;
+    char* p = carve_acts(n, static_cast<char*>(ws->base), &ao);
+    p = carve_acts(n, p, &at);
+    int64_t* act = reinterpret_cast<int64_t*>(p);
+    hipStream_t s = ts::as_stream(stream), side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    const bool two = params_old != nullptr;
+    if (two) {          // the lagged net's pass runs beside the online net's
+        if (int rc = ts::stream_wait(ws, s, side, 9)) return rc;
+        if (int rc = net_forward(side, ws, n, params_old, obs_next_nhwc, obs_u8 != 0, at)) return rc;
+        if (kind == TS_DISTQ_C51) {
+            hipLaunchKernelGGL(distq_head_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, side, kind, at.h[4],
+                               aux, B, n.n_act, n.n_atoms, n.ld, (float*)nullptr, (int64_t*)nullptr);
+            TS_LAUNCH_CHECK();
+        }
+    }
+    if (int rc = net_forward(s, ws, n, params, obs_next_nhwc, obs_u8 != 0, ao)) return rc;
+    hipLaunchKernelGGL(distq_head_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, kind, ao.h[4], aux, B,
+                       n.n_act, n.n_atoms, n.ld, (float*)nullptr, act);
+    TS_LAUNCH_CHECK();
+    if (two)
+        if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
+    hipLaunchKernelGGL(distq_select_kernel, dim3((unsigned)ts::ceil_div(B * n.n_atoms, 256)), dim3(256), 0, s,
+                       two ? at.h[4] : ao.h[4], act, B, n.n_atoms, n.ld, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                    int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, int kind, const float* aux,
+                    const void* obs_nhwc, int obs_u8, const int64_t* act, const float* returns, const float* next_dist,
+                    const float* weight, int64_t B, const ts_distq_hparams* hp, float* prio_out, float* loss_out,
+                    float* target_dist_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_distq_update: workspace is NULL");
+    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_distq_update: bad batch size / step");
+    TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && returns && hp && prio_out && loss_out && aux,
+               TS_ERR_INVALID_ARG, "ts_distq_update: NULL argument");
+    if (int rc = check_kind(kind, aux, "ts_distq_update")) return rc;
+    TS_REQUIRE(kind == TS_DISTQ_QR || (next_dist && hp->v_max > hp->v_min), TS_ERR_INVALID_ARG,
+               "ts_distq_update: C51 needs next_dist and v_min < v_max");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+
+    // workspace: activations | dY of every layer | wgrad slabs | flat gradient | per-sample loss terms | norm partials
+    size_t slab = 0;
+    for (int i = 0; i < 5; ++i)
+        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    size_t bytes = acts_bytes(n) + al(slab) + al(4 * (size_t)n.off[5]) + al(4 * (size_t)B) + 4096;
+    for (int i = 0; i < 5; ++i) bytes += al(4 * (size_t)n.l[i].out_elems());
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Acts a;
+    char* p = carve_acts(n, static_cast<char*>(ws->base), &a);
+    float* dy[5];
+    for (int i = 0; i < 5; ++i) { dy[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
+    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
+    float* grad = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.off[5]);
+    float* lw = reinterpret_cast<float*>(p); p += al(4 * (size_t)B);
+    float* norm_part = reinterpret_cast<float*>(p);
+    if (grad_out) grad = grad_out;
+
+    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
+    if (kind == TS_DISTQ_QR) {
+        hipLaunchKernelGGL(qr_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, a.h[4], act, returns, weight, aux, B,
+                           n.n_atoms, n.ld, dy[4], prio_out, lw);
+    } else {
+        hipLaunchKernelGGL(distq_head_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, kind, a.h[4], aux, B,
+                           n.n_act, n.n_atoms, n.ld, (float*)nullptr, (int64_t*)nullptr);
+        const double dz = (hp->v_max - hp->v_min) / (double)(n.n_atoms - 1);
+        hipLaunchKernelGGL(c51_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, a.h[4], act, returns, next_dist, weight,
+                           aux, (float)hp->v_min, (float)hp->v_max, (float)dz, B, n.n_atoms, n.ld, dy[4], prio_out,
+                           lw, target_dist_out);
+    }
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, lw, B, loss_out);
+    TS_LAUNCH_CHECK();
+
+    // head, fc1, conv3, conv2, conv1: the weight gradient of a layer (+ slab sum) on the side stream, the input
+    // gradient that feeds the layer below on the caller's stream (as ts_dqn_update).
+    hipStream_t side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    for (int i = 4; i >= 0; --i) {
+        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.h[i - 1];
+        if (int rc = ts::stream_wait(ws, s, side, i)) return rc;
+        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
+        if (int rc = ts::slab_sum(side, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
+            return rc;
+        if (i > 0)
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], a.h[i - 1], dy[i - 1], ws)) return rc;
+    }
+    if (int rc = ts::stream_wait(ws, side, s, 8)) return rc;
+    if (hp->lr < 0.0) return TS_OK;
+    return ts::adam_step(s, params, adam_m, adam_v, grad, n.off[5], adam_step, hp->lr, hp->beta1, hp->beta2,
+                         hp->adam_eps, hp->max_grad_norm, norm_part);
+}
+
+}  // extern "C"

@@ -61,8 +61,9 @@ def param_count(c: int, h: int, w: int, n_act: int) -> int:
 
 def flat_from_torch(tensors: list[torch.Tensor], c: int, h: int, w: int, n_act: int, device="cuda") -> torch.Tensor:
     """[conv1.w, conv1.b, conv2.w, ..., fc2.w, fc2.b] in torch layout (DQNet state_dict order, also valid
-    for the matching Adam moments) -> the engine's flat vector."""
-    _, geom = layer_layout(c, h, w, n_act)
+    for the matching Adam moments) -> the engine's flat vector.  `n_act` = the number of head outputs (any
+    width: the trunk geometry does not depend on it)."""
+    _, geom = layer_layout(c, h, w, 1)
     oh3, ow3 = int(geom[2, 7]), int(geom[2, 8])
     parts = []
     for i in range(3):
@@ -77,7 +78,7 @@ def flat_from_torch(tensors: list[torch.Tensor], c: int, h: int, w: int, n_act: 
 
 def flat_to_torch(flat: torch.Tensor, c: int, h: int, w: int, n_act: int) -> list[torch.Tensor]:
     """Inverse of flat_from_torch -> ten tensors in torch layout (on flat's device)."""
-    off, geom = layer_layout(c, h, w, n_act)
+    off, geom = layer_layout(c, h, w, 1)
     out = []
     for i in range(3):
         ic, kh, kw, oc = (int(geom[i, j]) for j in (3, 4, 5, 9))
@@ -88,7 +89,7 @@ def flat_to_torch(flat: torch.Tensor, c: int, h: int, w: int, n_act: int) -> lis
     f = 64 * oh3 * ow3
     wb = flat[off[3]:off[4]].reshape(f + 1, 512)
     out += [wb[:f].reshape(oh3, ow3, 64, 512).permute(3, 2, 0, 1).reshape(512, f).contiguous(), wb[f].clone()]
-    wb = flat[off[4]:off[5]].reshape(513, n_act)
+    wb = flat[off[4]:off[4] + 513 * n_act].reshape(513, n_act)
     out += [wb[:512].t().contiguous(), wb[512].clone()]
     return out
 

@@ -244,6 +244,128 @@ def make_hip_dqn():
 
 
 # ---------------------------------------------------------------------------------------------------
+# QRDQN (qrdqn.py) / C51 (c51.py) on QRDQNet / C51Net
+# ---------------------------------------------------------------------------------------------------
+def _make_hip_distq(kind: str):
+    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats, SimpleLossTrainingStats
+
+    from . import distq as Q
+    from . import dqn as D
+
+    if kind == Q.QR:
+        from tianshou.algorithm.modelfree.qrdqn import QRDQN as Base
+    else:
+        from tianshou.algorithm.modelfree.c51 import C51 as Base
+    who = "HipQRDQN" if kind == Q.QR else "HipC51"
+
+    class HipDistQ(Base):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            if list(self.policy.model.state_dict().keys()) != D.TIANSHOU_KEYS:
+                raise NotImplementedError(f"{who}: the model must be QRDQNet / C51Net (DQNet without extra layers)")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _n_atoms(self) -> int:
+            return int(self.num_quantiles if kind == Q.QR else self.policy.num_atoms)
+
+        def _engine(self, c, h, w):
+            if self._hip_engine is None:
+                sd = self.policy.model.state_dict()
+                n_atoms = self._n_atoms()
+                n_out = sd[D.TIANSHOU_KEYS[-1]].numel()
+                if n_out % n_atoms:
+                    raise NotImplementedError(f"{who}: head width {n_out} is not a multiple of {n_atoms} atoms")
+                n_act = n_out // n_atoms
+                opt, g = _adam_of(self.optim)
+                cfg = Q.DistQConfig(kind=kind, n_atoms=n_atoms, gamma=self.gamma, n_step=self.n_step,
+                                    target_update_freq=self.target_update_freq, lr=g["lr"], betas=tuple(g["betas"]),
+                                    adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm,
+                                    v_min=float(getattr(self.policy, "v_min", -10.0)),
+                                    v_max=float(getattr(self.policy, "v_max", 10.0)))
+                dev = self._hip_device
+                flat = Q.flat_from_torch([sd[k] for k in D.TIANSHOU_KEYS], c, h, w, n_act, n_atoms, dev)
+                eng = self._hip_engine = Q.DistQEngine(c, h, w, n_act, flat, cfg)
+                eng.iter = self._iter
+                ms, vs, step = adam_state(opt, list(self.policy.model.parameters()))       # resume from a checkpoint
+                eng.adam_m = Q.flat_from_torch(ms, c, h, w, n_act, n_atoms, dev)
+                eng.adam_v = Q.flat_from_torch(vs, c, h, w, n_act, n_atoms, dev)
+                eng.adam_step = step
+                if eng.params_old is not None:
+                    old = [p.detach() for p in self.model_old.parameters()]
+                    eng.params_old = Q.flat_from_torch(old, c, h, w, n_act, n_atoms, dev)
+            return self._hip_engine
+
+        @staticmethod
+        def _layout(buffer):
+            obs = np.asarray(buffer.obs)
+            stack = int(getattr(buffer, "stack_num", 1))
+            if stack > 1:
+                if obs.ndim != 3:
+                    raise NotImplementedError(f"{who}: frame stacking needs single [h, w] frames per slot")
+                return stack, obs.shape[1], obs.shape[2], stack
+            if obs.ndim != 4:
+                raise NotImplementedError(f"{who}: observations must be [c, h, w]")
+            return obs.shape[1], obs.shape[2], obs.shape[3], 1
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, who)
+            c, h, w, stack = self._layout(buffer)
+            eng = self._engine(c, h, w)
+            m = _mirror(self, buffer, self._hip_device)
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_frames=m.obs_next)
+            self._hip_idx, self._hip_stack = idx, stack
+            if hasattr(batch, "weight"):
+                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
+            return batch
+
+        def _update_with_batch(self, batch):
+            eng, m = self._hip_engine, self._hip_mirror
+            idx, stack = self._hip_idx, self._hip_stack
+            weight = batch.pop("weight", None)
+            obs = D.gather_obs_nhwc(m.obs, m, idx, stack, as_u8=True)
+            obs_next = None
+            if kind == Q.C51:                     # batch.obs_next = buffer[indices].obs_next (buffer_base.py:624-626)
+                if m.obs_next is not None:
+                    obs_next = D.gather_obs_nhwc(m.obs_next, m, idx, stack, as_u8=True)
+                else:
+                    obs_next = D.gather_obs_nhwc(m.obs, m, m.next(idx), stack, as_u8=True)
+            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
+            loss, prio = eng.update_with_batch(obs, act, batch.returns, weight, obs_next_nhwc=obs_next)
+            self._iter = eng.iter
+            batch.weight = prio                                                   # prio-buffer, qrdqn.py:128 / c51.py:157
+            dims = (eng.c, eng.h, eng.w, eng.n_act, eng.cfg.n_atoms)
+            with torch.no_grad():
+                for p, t in zip(self.policy.model.parameters(), Q.flat_to_torch(eng.params, *dims)):
+                    p.copy_(t)
+                if eng.params_old is not None:
+                    for p, t in zip(self.model_old.parameters(), Q.flat_to_torch(eng.params_old, *dims)):
+                        p.copy_(t)
+            store_adam_state(self.optim._optim, list(self.policy.model.parameters()), Q.flat_to_torch(eng.adam_m, *dims),
+                             Q.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+            if kind == Q.QR:
+                return SimpleLossTrainingStats(loss=float(loss.item()))
+            return LossSequenceTrainingStats(loss=float(loss.item()))            # as c51.py:160
+
+    HipDistQ.__name__ = HipDistQ.__qualname__ = who
+    return HipDistQ
+
+
+def make_hip_qrdqn():
+    """Returns HipQRDQN(QRDQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, qrdqn.py:93-131) on the
+    engine.  Supported model: QRDQNet (atari_network.py:211-235), Adam; buffer layouts as HipDQN."""
+    return _make_hip_distq("qr")
+
+
+def make_hip_c51():
+    """Returns HipC51(C51): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, c51.py:120-160) on the engine.
+    Supported model: C51Net (atari_network.py:125-151) with C51Policy's support, Adam; buffer layouts as HipDQN."""
+    return _make_hip_distq("c51")
+
+
+# ---------------------------------------------------------------------------------------------------
 # SAC (sac.py:213-336) on the mujoco_sac.py networks
 # ---------------------------------------------------------------------------------------------------
 def make_hip_sac():
