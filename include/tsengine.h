@@ -555,6 +555,39 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                   ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DiscreteSAC (tianshou/algorithm/modelfree/discrete_sac.py): Categorical policy, twin critics that
+ * output Q(s, .) for every action; nets of test/discrete/test_discrete_sac.py:88-97: Net(obs, [hidden, hidden]) ReLU
+ * under DiscreteActor(softmax_output=False) / DiscreteCritic(last_size=n_act) (utils/net/discrete.py:27-123).
+ * All three nets share one flat layout: L1 [ka + 1, hidden] | L2 [hidden + 1, hidden] | head [hidden + 1, hw]
+ * (ka, hw = obs_dim, n_act rounded up to multiples of 32; last row of each block = bias; padding zero).
+ * n_act in [2, 64]; hidden a multiple of 32 in [32, 2048].
+ * ------------------------------------------------------------------------------------------- */
+
+/* h_out3 = {ka, hw, parameter count of one net}. */
+int ts_dsac_layout(int64_t obs_dim, int64_t n_act, int64_t hidden, int64_t* h_out3);
+
+/* DiscreteSACPolicy.forward (discrete_sac.py:53-67) up to the Categorical: logits_out float32[B, n_act]. */
+int ts_dsac_policy_forward(ts_workspace* ws, const float* actor, const float* obs, int64_t B, int64_t obs_dim,
+                           int64_t n_act, int64_t hidden, float* logits_out, ts_stream_t stream);
+
+/* _target_q (ddpg.py:327-339) with _target_q_compute_value (discrete_sac.py:147-155):
+ * out[b] = sum_a p(a|s') min(Q1_old, Q2_old)(s', a) + alpha H(p(.|s')); log_alpha (device, nullable) selects
+ * alpha = exp(*log_alpha), else fixed_alpha. */
+int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                     const float* log_alpha, double fixed_alpha, const float* obs_next, int64_t B, int64_t obs_dim,
+                     int64_t n_act, int64_t hidden, float* out, ts_stream_t stream);
+
+/* DiscreteSAC._update_with_batch (discrete_sac.py:157-196): critic 1 and 2 steps on (Q(s)[a] - returns)^2 * weight,
+ * actor step on -(alpha H + sum_a p q).mean() with the updated critics, AutoAlpha.update(entropy) (sac.py:203-209),
+ * Polyak update of both lagged critics.  State / hyper-parameters: the SAC structs.  act int64[B];
+ * stats_out5 = {actor_loss, critic1_loss, critic2_loss, alpha (after the update), alpha_loss};
+ * weight_out (nullable) float32[B] = (td1 + td2) / 2 (discrete_sac.py:174);
+ * grads_out (nullable) = the three flat gradients {critic1, critic2, actor}. */
+int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const int64_t* act,
+                   const float* returns, const float* weight, int64_t B, int64_t obs_dim, int64_t n_act, int64_t hidden,
+                   const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,
  * nets of examples/mujoco/mujoco_td3.py:85-103 / mujoco_ddpg.py
  * ------------------------------------------------------------------------------------------- */

@@ -570,6 +570,9 @@ def main() -> None:
                     eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
                     recompute_advantage=False, max_batchsize=32)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "dsac":
+        gen_dsac_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "td3":
         gen_td3_all()
         return
@@ -800,6 +803,102 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
                actor_lr=kw.get("actor_lr", 1e-3), critic_lr=kw.get("critic_lr", 1e-3))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"td3_{tag}.npz"), **out)
+
+
+def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: int, hidden: int, batch: int,
+             n_updates: int, seed: int, auto_alpha: bool, alpha: float = 0.05, n_step: int = 1, tau: float = 0.005,
+             gamma: float = 0.95, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4) -> None:
+    """Runs the reference DiscreteSAC.update() (nets as in test/discrete/test_discrete_sac.py:88-97) on a synthetic
+    PrioritizedVectorReplayBuffer and records the outputs of every update."""
+    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSAC, DiscreteSACPolicy
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from oracle import oracle_dsac as ODS
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]),
+                          action_shape=n_act, softmax_output=False)
+    critic1 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]), last_size=n_act)
+    critic2 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]), last_size=n_act)
+    policy = DiscreteSACPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
+    target_entropy = 0.98 * float(np.log(n_act))
+    al = AutoAlpha(target_entropy, 0.0, AdamOptimizerFactory(lr=alpha_lr)) if auto_alpha else alpha
+    algorithm = DiscreteSAC(policy=policy, policy_optim=AdamOptimizerFactory(lr=actor_lr), critic=critic1,
+                            critic_optim=AdamOptimizerFactory(lr=critic_lr), critic2=critic2,
+                            critic2_optim=AdamOptimizerFactory(lr=critic_lr), tau=tau, gamma=gamma, alpha=al,
+                            n_step_return_horizon=n_step)
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, obs_dim, n_act, hidden, batch, n_updates, seed, int(auto_alpha), n_step])
+    p0 = ODS.init_params(obs_dim, n_act, hidden, seed)
+    for pd, mod in zip(p0, (actor, critic1, critic2)):
+        sd = mod.state_dict()
+        assert list(sd.keys()) == ODS.TIANSHOU_KEYS, list(sd.keys())
+        for k_ref, k in zip(ODS.TIANSHOU_KEYS, ODS.NET_ORDER):
+            assert torch.equal(sd[k_ref], pd[k]), f"oracle init differs from the reference at {k}"
+
+    buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4)
+    obs = rng.normal(size=(steps + 1, E, obs_dim)).astype(np.float32)
+    act = rng.integers(0, n_act, size=(steps, E))
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.05
+    trunc = (rng.random((steps, E)) < 0.03) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t],
+                      obs_next=obs[t + 1]))
+    out["obs"] = np.asarray(buf.obs, np.float32)
+    out["obs_next"] = np.asarray(buf.obs_next, np.float32)
+    out["act"] = np.asarray(buf.act, np.int64)
+    out["rew"] = np.asarray(buf.rew, np.float64)
+    out["terminated"] = np.asarray(buf.terminated, bool)
+    out["truncated"] = np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    rec: list[dict] = []
+    orig_pre, orig_upd = DiscreteSAC._preprocess_batch, DiscreteSAC._update_with_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        r = {"indices": np.array(indices, np.int64), "is_weight": np.array(batch.weight, np.float64)}
+        b = orig_pre(self, batch, buffer, indices)
+        r["returns"] = b.returns.numpy().copy().reshape(-1)
+        rec.append(r)
+        return b
+
+    def rec_upd(self, batch):
+        stats = orig_upd(self, batch)
+        rec[-1]["new_weight"] = batch.weight.detach().numpy().copy()
+        return stats
+
+    DiscreteSAC._preprocess_batch, DiscreteSAC._update_with_batch = rec_pre, rec_upd
+    try:
+        np.random.seed(seed + 7)
+        for u in range(n_updates):
+            with policy_within_training_step(algorithm.policy):
+                stats = algorithm.update(buffer=buf, sample_size=batch)
+            for k in ("indices", "returns", "is_weight", "new_weight"):
+                out[f"u{u}_{k}"] = rec[-1][k]
+            out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic1_loss, stats.critic2_loss,
+                                           stats.alpha if stats.alpha is not None else np.nan,
+                                           stats.alpha_loss if stats.alpha_loss is not None else np.nan])
+            for name, mod in (("actor", actor), ("critic1", critic1), ("critic2", critic2),
+                              ("critic1_old", algorithm.critic_old.module), ("critic2_old", algorithm.critic2_old.module)):
+                sd = mod.state_dict()
+                out[f"u{u}_{name}"] = torch.cat([sd[k].reshape(-1) for k in ODS.TIANSHOU_KEYS]).numpy()[::5].copy()
+    finally:
+        DiscreteSAC._preprocess_batch, DiscreteSAC._update_with_batch = orig_pre, orig_upd
+    cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
+               target_entropy=target_entropy, log_alpha0=0.0, actor_lr=actor_lr, critic_lr=critic_lr, alpha_lr=alpha_lr)
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"dsac_{tag}.npz"), **out)
+
+
+def gen_dsac_all() -> None:
+    gen_dsac("auto", E=3, slots=40, steps=60, obs_dim=11, n_act=5, hidden=64, batch=48, n_updates=3, seed=21,
+             auto_alpha=True, n_step=3)
+    gen_dsac("fixed", E=2, slots=40, steps=50, obs_dim=40, n_act=3, hidden=96, batch=32, n_updates=2, seed=23,
+             auto_alpha=False, alpha=0.05, n_step=1, tau=0.01)
 
 
 def gen_td3_all() -> None:

@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE ONLY - CPU (torch fp32 autograd) restatement of the reference's DiscreteSAC learn() path.
+
+Never imported by the product (`tianshou_amd/`).  Pinned against the UNMODIFIED reference through
+tests/golden/dsac_*.npz (oracle/gen_golden.py::gen_dsac).
+
+Follows:
+  nets      test/discrete/test_discrete_sac.py:88-97: Net(obs, hidden) (utils/net/common.py:343-369, ReLU MLP) under
+            DiscreteActor(softmax_output=False) / DiscreteCritic(last_size=n_act) (utils/net/discrete.py:27-123)
+  policy    DiscreteSACPolicy.forward modelfree/discrete_sac.py:53-67: Categorical(logits=actor(obs))
+  target    _target_q ddpg.py:327-339 + _target_q_compute_value discrete_sac.py:147-155:
+            sum_a p(a|s') min(Q1_old, Q2_old)(s', a) + alpha H(p(.|s'))
+  update    _update_with_batch discrete_sac.py:157-196: two critic steps on (Q(s)[a] - returns)^2 * weight, actor step on
+            -(alpha H + sum_a p q).mean() with the UPDATED critics, AutoAlpha.update(entropy) sac.py:203-209, Polyak
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.distributions import Categorical
+
+from . import oracle_sac as OS
+
+NET_ORDER = ["l1.w", "l1.b", "l2.w", "l2.b", "head.w", "head.b"]
+TIANSHOU_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
+                 "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
+                 "last.model.0.weight", "last.model.0.bias"]
+
+
+def net_shapes(obs_dim: int, n_act: int, hidden: int):
+    return {"l1.w": (hidden, obs_dim), "l1.b": (hidden,), "l2.w": (hidden, hidden), "l2.b": (hidden,),
+            "head.w": (n_act, hidden), "head.b": (n_act,)}
+
+
+def init_params(obs_dim: int, n_act: int, hidden: int, seed: int):
+    """Same RNG consumption as torch.manual_seed(seed) followed by the constructions of
+    test_discrete_sac.py:88-97 (actor net, actor head, critic-1 net, head, critic-2 net, head)."""
+    torch.manual_seed(seed)
+    out = []
+    for _ in range(3):
+        ls = [torch.nn.Linear(obs_dim, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, n_act)]
+        out.append({k: t.detach().clone() for k, t in
+                    zip(NET_ORDER, [x for lin in ls for x in (lin.weight, lin.bias)])})
+    return out                                                # actor, critic1, critic2
+
+
+def net_forward(p, obs) -> torch.Tensor:
+    x = torch.as_tensor(obs, dtype=torch.float32).flatten(1)
+    x = F.relu(F.linear(x, p["l1.w"], p["l1.b"]))
+    x = F.relu(F.linear(x, p["l2.w"], p["l2.b"]))
+    return F.linear(x, p["head.w"], p["head.b"])
+
+
+def target_q(st: OS.SACState, cfg: OS.SACConfig, obs_next) -> torch.Tensor:
+    with torch.no_grad():
+        dist = Categorical(logits=net_forward(st.actor, obs_next))
+        q = dist.probs * torch.min(net_forward(st.critic1_old, obs_next), net_forward(st.critic2_old, obs_next))
+        return q.sum(dim=-1) + OS.alpha_value(st, cfg) * dist.entropy()
+
+
+def update_with_batch(st: OS.SACState, cfg: OS.SACConfig, obs, act, returns, weight=None, collect=None):
+    """discrete_sac.py:157-196 -> dict(actor_loss, critic1_loss, critic2_loss, alpha, alpha_loss, weight)."""
+    obs = torch.as_tensor(obs, dtype=torch.float32)
+    act_t = torch.as_tensor(np.asarray(act), dtype=torch.long)[:, None]
+    ret = torch.as_tensor(returns, dtype=torch.float32).flatten()
+    w = 1.0 if weight is None else torch.as_tensor(weight, dtype=torch.float32)
+    out, tds = {}, []
+    for name, opt in (("critic1", st.opt_c1), ("critic2", st.opt_c2)):
+        p = {k: v.clone().requires_grad_(True) for k, v in getattr(st, name).items()}
+        td = net_forward(p, obs).gather(1, act_t).flatten() - ret
+        loss = (td.pow(2) * w).mean()
+        g = OS._grads(loss, p)
+        if collect is not None:
+            collect[name + "_grads"] = g
+        setattr(st, name, opt.apply(getattr(st, name), g))
+        tds.append(td.detach())
+        out[name + "_loss"] = float(loss.item())
+    out["weight"] = (tds[0] + tds[1]) / 2.0
+    alpha = OS.alpha_value(st, cfg)
+    p = {k: v.clone().requires_grad_(True) for k, v in st.actor.items()}
+    dist = Categorical(logits=net_forward(p, obs))
+    entropy = dist.entropy()
+    with torch.no_grad():
+        q = torch.min(net_forward(st.critic1, obs), net_forward(st.critic2, obs))
+    actor_loss = -(alpha * entropy + (dist.probs * q).sum(dim=-1)).mean()
+    g = OS._grads(actor_loss, p)
+    if collect is not None:
+        collect["actor_grads"] = g
+        collect["entropy"] = entropy.detach().clone()
+    st.actor = st.opt_actor.apply(st.actor, g)
+    out["actor_loss"] = float(actor_loss.item())
+    out["alpha_loss"] = None
+    if cfg.auto_alpha:
+        la = st.log_alpha.clone().requires_grad_(True)
+        alpha_loss = -(la * (cfg.target_entropy - entropy.detach())).mean()
+        (ga,) = torch.autograd.grad(alpha_loss, [la])
+        st.log_alpha = st.opt_alpha.apply({"a": st.log_alpha}, {"a": ga})["a"]
+        out["alpha_loss"] = float(alpha_loss.item())
+    for old, new in ((st.critic1_old, st.critic1), (st.critic2_old, st.critic2)):
+        for k in old:
+            old[k] = cfg.tau * new[k] + (1 - cfg.tau) * old[k]
+    out["alpha"] = OS.alpha_value(st, cfg)
+    return out

@@ -563,3 +563,105 @@ def test_hip_distq_wrapper_runs_with_engine_double(kind, monkeypatch):
     if kind == "qr":                                       # lagged network written back too
         old_first = next(iter(algo.model_old.parameters()))
         assert torch.allclose(old_first.detach(), before)
+
+
+# ------------------------------------------------------------------------------------ DiscreteSAC subclass
+def _dsac_algo(auto=True, hidden=64, **kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSACPolicy
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from tianshou_amd.integration import make_hip_discrete_sac
+
+    mk = lambda: Net(state_shape=(11,), hidden_sizes=[hidden, hidden])  # noqa: E731
+    actor = DiscreteActor(preprocess_net=mk(), action_shape=5, softmax_output=False)
+    c1, c2 = DiscreteCritic(preprocess_net=mk(), last_size=5), DiscreteCritic(preprocess_net=mk(), last_size=5)
+    policy = DiscreteSACPolicy(actor=actor, action_space=gym.spaces.Discrete(5))
+    alpha = AutoAlpha(0.98 * float(np.log(5)), 0.0, AdamOptimizerFactory(lr=3e-4)) if auto else 0.05
+    return make_hip_discrete_sac()(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=c1,
+                                   critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=c2,
+                                   critic2_optim=AdamOptimizerFactory(lr=1e-3), alpha=alpha, n_step_return_horizon=2,
+                                   device="cpu", **kw)
+
+
+def test_discrete_sac_subclass_keeps_signatures_and_fails_loudly():
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _dsac_algo()
+    base = type(algo).__mro__[1]
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (11,), np.zeros(2, np.int64))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, sample_size=8)
+    with pytest.raises(NotImplementedError):
+        _dsac_algo(hidden=48)                              # hidden width must be a multiple of 32
+
+
+@pytest.mark.parametrize("match_rng", [True, False])
+def test_hip_discrete_sac_wrapper_runs_with_engine_double(match_rng, monkeypatch):
+    ref_shim.install()
+    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSACTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.dsac as DS
+    import tianshou_amd.returns as R
+
+    calls = {"policy_forward": 0}
+
+    class FakeDSAC:
+        def __init__(self, obs_dim, n_act, hidden, actor, c1, c2, cfg):
+            assert (obs_dim, n_act, hidden) == (11, 5, 64) and cfg.auto_alpha and cfg.n_step == 2
+            assert abs(cfg.target_entropy - 0.98 * np.log(5)) < 1e-12
+            self.obs_dim, self.n_act, self.hidden, self.cfg, self.adam_step = obs_dim, n_act, hidden, cfg, 0
+            self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), c2.clone()
+            self.critic1_old, self.critic2_old = c1.clone(), c2.clone()
+            _zeros_like_all(self, ("actor", "critic1", "critic2"))
+            self.log_alpha, self.log_alpha_m, self.log_alpha_v = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+
+        def policy_forward(self, obs):
+            calls["policy_forward"] += 1
+            return torch.zeros((obs.shape[0], self.n_act))
+
+        def preprocess(self, m, idx):
+            assert m.obs_next is not None
+            return torch.zeros(idx.numel())
+
+        def update_with_batch(self, obs, act, ret, weight=None):
+            assert obs.shape == (8, 11) and act.shape == (8,) and act.dtype == torch.int64
+            self.adam_step += 1
+            self.critic2 += 1.0
+            self.critic2_old += 0.5
+            self.critic2_v += 0.25
+            self.log_alpha += 0.125
+            return torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]), torch.ones(8)
+
+    algo = _dsac_algo(match_rng_stream=match_rng)
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(DS, "DiscreteSACEngine", FakeDSAC)
+    monkeypatch.setattr(DS, "layout", lambda o, a, h: {"ka": 32, "hw": 32, "count": 33 * h + (h + 1) * h + (h + 1) * 32})
+    monkeypatch.setattr(R, "nstep_indices", lambda m, idx, n: idx)
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (11,), np.zeros(2, np.int64))
+    first = next(iter(algo.critic2.parameters()))
+    before = first.detach().clone()
+    old_first = next(iter(algo.critic2_old.module.parameters()))
+    old_before = old_first.detach().clone()
+    torch.manual_seed(0)
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, sample_size=8)
+    assert isinstance(stats, DiscreteSACTrainingStats) and (stats.actor_loss, stats.critic2_loss, stats.alpha) == (1.0, 3.0, 4.0)
+    assert calls["policy_forward"] == (2 if match_rng else 0)        # the two unused Categorical.sample() draws
+    assert torch.allclose(first.detach(), before + 1.0) and torch.allclose(old_first.detach(), old_before + 0.5)
+    st = algo.critic2_optim._optim.state[first]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.25))
+    assert abs(float(algo.alpha._log_alpha.detach()) - 0.125) < 1e-6

@@ -454,3 +454,51 @@ def test_td3_ddpg_restatement_matches_reference(tag):
             order = OS.DET_ACTOR_ORDER if name.startswith("actor") else OS.CRITIC_ORDER
             np.testing.assert_allclose(OS.flatten(getattr(st, name), order).numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5,
                                        atol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------ DiscreteSAC path
+def load_dsac(tag):
+    from oracle import oracle_sac as OS
+
+    g = load(f"dsac_{tag}.npz")
+    E, slots, steps, obs_dim, n_act, hidden, batch, n_updates, seed, auto, n_step = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OS.SACConfig(gamma=c["gamma"], tau=c["tau"], n_step=int(c["n_step"]), alpha=c["alpha"],
+                       auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
+                       log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
+                       alpha_lr=c["alpha_lr"])
+    d = dict(E=E, slots=slots, obs_dim=obs_dim, n_act=n_act, hidden=hidden, batch=batch, n_updates=n_updates, seed=seed)
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, d, cfg, bstate
+
+
+@pytest.mark.parametrize("tag", ["auto", "fixed"])
+def test_dsac_restatement_matches_reference(tag):
+    """oracle_dsac (categorical target with entropy bonus, gathered-Q critic losses with PER weights, actor step
+    against the updated critics, alpha step, Polyak) against the unmodified reference DiscreteSAC.update()."""
+    from oracle import oracle_dsac as ODS
+    from oracle import oracle_sac as OS
+
+    g, d, cfg, bstate = load_dsac(tag)
+    actor, c1, c2 = ODS.init_params(d["obs_dim"], d["n_act"], d["hidden"], d["seed"])
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+
+        def tq_fn(after):
+            return ODS.target_q(st, cfg, g["obs_next"][after]).numpy().reshape(-1, 1)
+
+        ret, _ = O.compute_nstep_return(bstate, idx, tq_fn, cfg.gamma, cfg.n_step)
+        ret = ret.astype(np.float32).reshape(-1)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-5, atol=1e-6)
+        out = ODS.update_with_batch(st, cfg, g["obs"][idx], g["act"][idx], ret, weight=g[f"u{u}_is_weight"])
+        stats = g[f"u{u}_stats"]
+        np.testing.assert_allclose([out["actor_loss"], out["critic1_loss"], out["critic2_loss"], out["alpha"]],
+                                   stats[:4], rtol=1e-5)
+        if cfg.auto_alpha:
+            np.testing.assert_allclose(out["alpha_loss"], stats[4], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(out["weight"].numpy(), g[f"u{u}_new_weight"], rtol=1e-5, atol=1e-6)
+        for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
+            flat = torch.cat([getattr(st, name)[k].reshape(-1) for k in ODS.NET_ORDER]).numpy()[::5]
+            np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)

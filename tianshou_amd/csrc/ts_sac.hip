@@ -41,9 +41,9 @@ struct Mlp {                  // in -> 256 -> 256 -> head, ReLU between
     int64_t off[4];
 };
 
-Mlp make_mlp(int B, int in_pad, int head_cols) {
+Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID) {
     Mlp m;
-    const int dims[4] = {in_pad, HID, HID, head_cols};
+    const int dims[4] = {in_pad, hid, hid, head_cols};
     int64_t o = 0;
     for (int i = 0; i < 3; ++i) {
         m.l[i] = ts::ConvGeom{B, 1, 1, dims[i], 1, 1, 1, 1, 1, dims[i + 1]};
@@ -350,6 +350,102 @@ __global__ __launch_bounds__(256) void polyak1_kernel(float* __restrict__ t, con
     if (i < n) t[i] = tau * s[i] + omt * t[i];
 }
 
+// ---- DiscreteSAC kernels (one thread per sample; logits / Q rows are [hw] wide, the first A columns are real) -----------
+__device__ __forceinline__ float row_logsumexp(const float* l, int A) {
+    float m = l[0];
+    for (int j = 1; j < A; ++j) m = fmaxf(m, l[j]);
+    float s = 0.f;
+    for (int j = 0; j < A; ++j) s += expf(l[j] - m);
+    return m + logf(s);
+}
+
+// _target_q_compute_value (discrete_sac.py:147-155): sum_a p_a min(Q1_old, Q2_old)_a + alpha H(p)
+__global__ __launch_bounds__(256) void dsac_target_kernel(const float* __restrict__ logits, const float* __restrict__ q1,
+                                                          const float* __restrict__ q2, const float* __restrict__ log_alpha,
+                                                          float fixed_alpha, int64_t B, int A, int hw,
+                                                          float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float* l = logits + b * hw;
+    const float lse = row_logsumexp(l, A);
+    float sq = 0.f, plogp = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float lp = l[j] - lse, p = expf(lp);
+        sq += p * fminf(q1[b * hw + j], q2[b * hw + j]);
+        plogp += lp * p;
+    }
+    out[b] = sq + alpha * -plogp;
+}
+
+// critic step (discrete_sac.py:162-172): td = Q(s)[a] - returns; loss = mean(td^2 w); d_out[b, a_b] = 2 td w / B
+__global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                                                const float* __restrict__ ret, const float* __restrict__ weight,
+                                                                int64_t B, int hw, float* __restrict__ td,
+                                                                float* __restrict__ d_out, float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const int a = (int)act[b];
+        const float t = q[b * hw + a] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        td[b] = t;
+        ls += t * t * w;
+        for (int j = 0; j < hw; ++j) d_out[b * hw + j] = j == a ? 2.f * t * w * inv_b : 0.f;
+    }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss = tot * inv_b;
+}
+
+// actor step (discrete_sac.py:176-184): f_b = alpha H_b + sum_a p_a q_a, q = min(Q1, Q2) (no grad); loss = -mean f.
+// d f / d logit_k = p_k (q_k - sum_a p_a q_a) - alpha p_k (log p_k + H)
+__global__ __launch_bounds__(256) void dsac_actor_kernel(const float* __restrict__ logits, const float* __restrict__ q1,
+                                                         const float* __restrict__ q2, const float* __restrict__ log_alpha,
+                                                         float fixed_alpha, int64_t B, int A, int hw,
+                                                         float* __restrict__ d_head, float* __restrict__ neg_ent,
+                                                         float* __restrict__ f_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float inv_b = 1.f / (float)B;
+    const float* l = logits + b * hw;
+    const float lse = row_logsumexp(l, A);
+    float sq = 0.f, plogp = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float lp = l[j] - lse, p = expf(lp);
+        sq += p * fminf(q1[b * hw + j], q2[b * hw + j]);
+        plogp += lp * p;
+    }
+    const float H = -plogp;
+    for (int j = 0; j < hw; ++j) {
+        float d = 0.f;
+        if (j < A) {
+            const float lp = l[j] - lse, p = expf(lp);
+            d = -inv_b * (p * (fminf(q1[b * hw + j], q2[b * hw + j]) - sq) - alpha * p * (lp + H));
+        }
+        d_head[b * hw + j] = d;
+    }
+    neg_ent[b] = -H;
+    f_out[b] = alpha * H + sq;
+}
+
+__global__ __launch_bounds__(1024) void neg_mean_kernel(const float* __restrict__ v, int64_t B, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) s += v[b];
+    const float tot = block_sum_1024(s, red);
+    if (threadIdx.x == 0) *out = -(tot / (float)B);
+}
+
+__global__ __launch_bounds__(256) void unpad_rows_kernel(const float* __restrict__ src, int64_t B, int A, int hw,
+                                                         float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    dst[i] = src[b * hw + (i - b * A)];
+}
+
 size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Carve {
@@ -367,10 +463,23 @@ int make_dims(int64_t obs_dim, int64_t act_dim, Dims* d) {
     return TS_OK;
 }
 
-Act take_act(Carve& c, int64_t B, int head_cols) {
+Act take_act(Carve& c, int64_t B, int head_cols, int hid = HID) {
     Act a;
-    a.h1 = c.take<float>(B * HID); a.h2 = c.take<float>(B * HID); a.out = c.take<float>(B * head_cols);
+    a.h1 = c.take<float>(B * hid); a.h2 = c.take<float>(B * hid); a.out = c.take<float>(B * head_cols);
     return a;
+}
+
+// ---- DiscreteSAC (discrete_sac.py): three MLPs obs -> hid -> hid -> n_act, Categorical policy ------------------------
+struct DDims { int obs, act, hid, ka, hw; int64_t P; };
+
+int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d) {
+    TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && n_act >= 2 && n_act <= 64 && hidden >= 32 && hidden <= 2048 &&
+                   hidden % 32 == 0, TS_ERR_INVALID_ARG,
+               "dsac: obs_dim >= 1, n_act in [2, 64], hidden a multiple of 32 in [32, 2048]");
+    d->obs = (int)obs_dim; d->act = (int)n_act; d->hid = (int)hidden;
+    d->ka = pad32(d->obs); d->hw = pad32(d->act);
+    d->P = make_mlp(1, d->ka, d->hw, d->hid).off[3];
+    return TS_OK;
 }
 
 }  // namespace
@@ -746,6 +855,163 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
                                    st->critic1, pc, tau, omt);
         }
     }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// ---- DiscreteSAC ---------------------------------------------------------------------------------------------------
+int ts_dsac_layout(int64_t obs_dim, int64_t n_act, int64_t hidden, int64_t* h_out3) {
+    DDims d;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    TS_REQUIRE(h_out3, TS_ERR_INVALID_ARG, "ts_dsac_layout: NULL output");
+    h_out3[0] = d.ka; h_out3[1] = d.hw; h_out3[2] = d.P;
+    return TS_OK;
+}
+
+int ts_dsac_policy_forward(ts_workspace* ws, const float* actor, const float* obs, int64_t B, int64_t obs_dim,
+                           int64_t n_act, int64_t hidden, float* logits_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dsac_policy_forward: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && obs && logits_out, TS_ERR_INVALID_ARG, "ts_dsac_policy_forward: bad argument");
+    DDims d;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 2 * al(4 * B * d.hid) + al(4 * B * d.hw) + al(4 * split_floats(m)) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.take<float>(B * d.ka);
+    const Act a = take_act(c, B, d.hw, d.hid);
+    float* split = c.take<float>(split_floats(m));
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, m, actor, x, a, split)) return rc;
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, a.out, B, d.act, d.hw,
+                       logits_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                     const float* log_alpha, double fixed_alpha, const float* obs_next, int64_t B, int64_t obs_dim,
+                     int64_t n_act, int64_t hidden, float* out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dsac_target_q: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && critic1_old && critic2_old && obs_next && out, TS_ERR_INVALID_ARG,
+               "ts_dsac_target_q: bad argument");
+    DDims d;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
+    const size_t spl = split_floats(m);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 6 * al(4 * B * d.hid) + 3 * al(4 * B * d.hw) + 2 * al(4 * spl) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.take<float>(B * d.ka);
+    const Act aa = take_act(c, B, d.hw, d.hid), a1 = take_act(c, B, d.hw, d.hid), a2 = take_act(c, B, d.hw, d.hid);
+    float* split = c.take<float>(spl);
+    float* split2 = c.take<float>(spl);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    TS_LAUNCH_CHECK();
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    if (int rc = mlp_forward(side, ws, m, critic2_old, x, a2, split2)) return rc;
+    if (int rc = mlp_forward(s, ws, m, actor, x, aa, split)) return rc;
+    if (int rc = mlp_forward(s, ws, m, critic1_old, x, a1, split)) return rc;
+    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    hipLaunchKernelGGL(dsac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, a1.out, a2.out,
+                       log_alpha, (float)fixed_alpha, B, d.act, d.hw, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const int64_t* act,
+                   const float* returns, const float* weight, int64_t B, int64_t obs_dim, int64_t n_act, int64_t hidden,
+                   const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dsac_update: workspace is NULL");
+    TS_REQUIRE(st && hp && obs && act && returns && stats_out5 && B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG,
+               "ts_dsac_update: bad argument");
+    TS_REQUIRE(st->actor && st->critic1 && st->critic2 && st->critic1_old && st->critic2_old && st->actor_m &&
+                   st->actor_v && st->critic1_m && st->critic1_v && st->critic2_m && st->critic2_v,
+               TS_ERR_INVALID_ARG, "ts_dsac_update: NULL state pointer");
+    TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
+               "ts_dsac_update: auto alpha needs log_alpha and its Adam moments");
+    DDims d;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
+    const size_t slab = slab_floats(m), spl = split_floats(m);
+    const int64_t P = d.P;
+    const size_t bytes = al(4 * B * d.ka) + 10 * al(4 * B * d.hid) + 6 * al(4 * B * d.hw) + 2 * al(4 * slab) +
+                         2 * al(4 * P) + 2 * al(4 * spl) + 4 * al(4 * B) + al(4 * 1024) + 4096;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.take<float>(B * d.ka);
+    const Act aa = take_act(c, B, d.hw, d.hid);
+    const Act acts[2] = {take_act(c, B, d.hw, d.hid), take_act(c, B, d.hw, d.hid)};
+    float* dheads[3] = {c.take<float>(B * d.hw), c.take<float>(B * d.hw), c.take<float>(B * d.hw)};   // critic1, critic2, actor
+    BwdScratch scs[2];
+    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    float* gbuf[2] = {c.take<float>(P), c.take<float>(P)};
+    float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
+    float* tds[2] = {c.take<float>(B), c.take<float>(B)};
+    float* neg_ent = c.take<float>(B);
+    float* fval = c.take<float>(B);
+    float* norm_part = c.take<float>(1024);
+    const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
+    float* g_out[3] = {grads_out, grads_out ? grads_out + P : nullptr, grads_out ? grads_out + 2 * P : nullptr};
+
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    TS_LAUNCH_CHECK();
+    // critic 1 on the caller's stream, critic 2 on the side stream (independent chains, as ts_sac_update)
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    hipStream_t stq[2] = {s, side};
+    float* crit[2] = {st->critic1, st->critic2};
+    float* crit_m[2] = {st->critic1_m, st->critic2_m};
+    float* crit_v[2] = {st->critic1_v, st->critic2_v};
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    for (int k = 0; k < 2; ++k) {
+        hipStream_t sk = stq[k];
+        if (int rc = mlp_forward(sk, ws, m, crit[k], x, acts[k], splits[k])) return rc;
+        hipLaunchKernelGGL(dsac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, act, returns, weight, B, d.hw,
+                           tds[k], dheads[k], stats_out5 + 1 + k);
+        TS_LAUNCH_CHECK();
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (int rc = mlp_backward(sk, ws, m, crit[k], x, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
+        if (hp->critic_lr >= 0.0)
+            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, P, adam_step, hp->critic_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part + 512 * k))
+                return rc;
+    }
+    // actor with the UPDATED critics (discrete_sac.py:176-184)
+    if (int rc = mlp_forward(side, ws, m, st->critic2, x, acts[1], splits[1])) return rc;
+    if (int rc = mlp_forward(s, ws, m, st->critic1, x, acts[0], splits[0])) return rc;
+    if (int rc = mlp_forward(s, ws, m, st->actor, x, aa, splits[0])) return rc;
+    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    hipLaunchKernelGGL(dsac_actor_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, acts[0].out,
+                       acts[1].out, log_alpha, (float)hp->alpha, B, d.act, d.hw, dheads[2], neg_ent, fval);
+    hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, fval, B, stats_out5);
+    TS_LAUNCH_CHECK();
+    float* ga = g_out[2] ? g_out[2] : gbuf[0];
+    if (int rc = mlp_backward(s, ws, m, st->actor, x, aa, dheads[2], ga, nullptr, 0, 0, scs[0])) return rc;
+    if (hp->actor_lr >= 0.0)
+        if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, P, adam_step, hp->actor_lr, hp->beta1,
+                                   hp->beta2, hp->adam_eps, 0.0, norm_part))
+            return rc;
+    // alpha (sac.py:203-209 with entropy = H), batch.weight (discrete_sac.py:174), Polyak
+    AlphaArgs al2{};
+    al2.logp = neg_ent; al2.B = B; al2.target_entropy = (float)hp->target_entropy;
+    al2.log_alpha = hp->auto_alpha ? st->log_alpha : nullptr; al2.m = st->log_alpha_m; al2.v = st->log_alpha_v;
+    const double bc1 = 1.0 - pow(hp->beta1, (double)adam_step), bc2 = 1.0 - pow(hp->beta2, (double)adam_step);
+    al2.lr_step = (float)(hp->alpha_lr / bc1); al2.beta1 = (float)hp->beta1; al2.beta2 = (float)hp->beta2;
+    al2.omb1 = (float)(1.0 - hp->beta1); al2.omb2 = (float)(1.0 - hp->beta2);
+    al2.bc2_sqrt = (float)sqrt(bc2); al2.eps = (float)hp->adam_eps;
+    al2.alpha_loss = stats_out5 + 4; al2.alpha_out = stats_out5 + 3; al2.fixed_alpha = (float)hp->alpha;
+    al2.td1 = tds[0]; al2.td2 = tds[1]; al2.weight_out = weight_out;
+    hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, al2);
+    if (hp->tau > 0.0)
+        hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(P, 256)), dim3(256), 0, s, st->critic1_old,
+                           st->critic1, st->critic2_old, st->critic2, P, (float)hp->tau, (float)(1.0 - hp->tau));
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -478,6 +478,131 @@ def make_hip_sac():
 
 
 # ---------------------------------------------------------------------------------------------------
+# DiscreteSAC (discrete_sac.py) on the MLP nets of test/discrete/test_discrete_sac.py
+# ---------------------------------------------------------------------------------------------------
+def make_hip_discrete_sac():
+    """Returns HipDiscreteSAC(DiscreteSAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301,
+    discrete_sac.py:147-196) on the engine.  Supported nets: Net(obs, [h, h]) ReLU under DiscreteActor(softmax_output=
+    False) and DiscreteCritic(last_size=n_act) (test/discrete/test_discrete_sac.py:88-97), h a multiple of 32; the
+    buffer must store obs_next.  `match_rng_stream`: the reference's two policy calls per update draw
+    `Categorical.sample()` values that are never used; with the flag set (default) the same draws are made from the
+    engine's logits so that torch's global generator advances exactly as in the reference."""
+    from torch.distributions import Categorical
+
+    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSAC, DiscreteSACTrainingStats
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+
+    from . import dsac as DS
+    from .sac import SACConfig
+
+    class HipDiscreteSAC(DiscreteSAC):
+        def __init__(self, *args, device="cuda", match_rng_stream: bool = True, **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            self._hip_match_rng = match_rng_stream
+            mods = (self.policy.actor, self.critic, self.critic2)
+            if any(list(m.state_dict().keys()) != DS.TIANSHOU_KEYS for m in mods):
+                raise NotImplementedError("HipDiscreteSAC: networks must be Net(obs, [h, h]) + a single Linear head")
+            sa = self.policy.actor.state_dict()
+            hidden = sa[DS.TIANSHOU_KEYS[0]].shape[0]
+            if hidden % 32 or sa[DS.TIANSHOU_KEYS[2]].shape != (hidden, hidden) or not 2 <= sa[DS.TIANSHOU_KEYS[4]].shape[0] <= 64:
+                raise NotImplementedError("HipDiscreteSAC: hidden sizes [h, h] with h a multiple of 32, 2..64 actions")
+            if getattr(self.policy.actor, "softmax_output", False):
+                raise NotImplementedError("HipDiscreteSAC: the actor must output logits (softmax_output=False)")
+            for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
+                _adam_of(o)
+            self._hip_engine = None
+
+        def _hip_parts(self):
+            return (("actor", self.policy.actor, self.policy_optim), ("critic1", self.critic, self.critic_optim),
+                    ("critic2", self.critic2, self.critic2_optim))
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                hidden, obs_dim = sa[DS.TIANSHOU_KEYS[0]].shape
+                n_act = sa[DS.TIANSHOU_KEYS[4]].shape[0]
+                dims = (obs_dim, n_act, hidden)
+                auto = isinstance(self.alpha, AutoAlpha)
+                ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
+                cfg = SACConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
+                                alpha=0.0 if auto else float(self.alpha.value), auto_alpha=auto,
+                                target_entropy=float(self.alpha._target_entropy) if auto else 0.0,
+                                log_alpha0=float(self.alpha._log_alpha.item()) if auto else 0.0,
+                                actor_lr=ga["lr"], critic_lr=gc["lr"],
+                                alpha_lr=self.alpha._optim.param_groups[0]["lr"] if auto else 0.0,
+                                betas=tuple(ga["betas"]), adam_eps=ga["eps"])
+                dev = self._hip_device
+                flat = lambda mod: DS.net_flat_from_torch(  # noqa: E731
+                    [mod.state_dict()[k] for k in DS.TIANSHOU_KEYS], *dims, dev)
+                eng = self._hip_engine = DS.DiscreteSACEngine(*dims, flat(self.policy.actor), flat(self.critic),
+                                                              flat(self.critic2), cfg)
+                eng.critic1_old, eng.critic2_old = flat(self.critic_old.module), flat(self.critic2_old.module)
+                for name, mod, optim in self._hip_parts():             # resume from a loaded checkpoint
+                    ms, vs, step = adam_state(optim._optim, params_by_keys(mod, DS.TIANSHOU_KEYS))
+                    setattr(eng, name + "_m", DS.net_flat_from_torch(ms, *dims, dev))
+                    setattr(eng, name + "_v", DS.net_flat_from_torch(vs, *dims, dev))
+                    eng.adam_step = max(eng.adam_step, step)
+                if auto:
+                    st = self.alpha._optim.state.get(self.alpha._log_alpha, {})
+                    if "exp_avg" in st:
+                        eng.log_alpha_m[0], eng.log_alpha_v[0] = float(st["exp_avg"]), float(st["exp_avg_sq"])
+            return self._hip_engine
+
+        def _hip_draw(self, obs):
+            if self._hip_match_rng:                  # discrete_sac.py:60-66: dist.sample() inside the training step
+                Categorical(logits=self._hip_engine.policy_forward(obs).cpu()).sample()
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            from .buffer import gather_rows
+
+            _require_gpu(self._hip_device, "HipDiscreteSAC")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            if m.obs_next is None:
+                raise NotImplementedError("HipDiscreteSAC: the replay buffer must store obs_next")
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            if self._hip_match_rng:
+                from .returns import nstep_indices
+
+                self._hip_draw(gather_rows(m.obs_next, nstep_indices(m, idx, eng.cfg.n_step)))
+            batch.returns = eng.preprocess(m, idx).reshape(-1, 1)
+            self._hip_idx = idx
+            return batch
+
+        def _update_with_batch(self, batch):
+            from .buffer import gather_rows
+
+            eng, m = self._hip_engine, self._hip_mirror
+            weight = getattr(batch, "weight", None)
+            obs = gather_rows(m.obs, self._hip_idx)
+            self._hip_draw(obs)
+            stats, w = eng.update_with_batch(obs, gather_rows(m.act, self._hip_idx), batch.returns.reshape(-1), weight)
+            batch.weight = w                                                      # prio-buffer, discrete_sac.py:174
+            s = stats.cpu().numpy()                                               # one D2H per update()
+            dims = (eng.obs_dim, eng.n_act, eng.hidden)
+            with torch.no_grad():
+                for mod, flat in ((self.policy.actor, eng.actor), (self.critic, eng.critic1), (self.critic2, eng.critic2),
+                                  (self.critic_old.module, eng.critic1_old), (self.critic2_old.module, eng.critic2_old)):
+                    for p, t in zip(params_by_keys(mod, DS.TIANSHOU_KEYS), DS.net_flat_to_torch(flat, *dims)):
+                        p.copy_(t)
+                if eng.cfg.auto_alpha:
+                    self.alpha._log_alpha.copy_(eng.log_alpha[0])
+            for name, mod, optim in self._hip_parts():
+                store_adam_state(optim._optim, params_by_keys(mod, DS.TIANSHOU_KEYS),
+                                 DS.net_flat_to_torch(getattr(eng, name + "_m"), *dims),
+                                 DS.net_flat_to_torch(getattr(eng, name + "_v"), *dims), eng.adam_step)
+            if eng.cfg.auto_alpha:
+                store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
+                                 [eng.log_alpha_v[0]], eng.adam_step)
+            auto = eng.cfg.auto_alpha
+            return DiscreteSACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
+                                            alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
+
+    return HipDiscreteSAC
+
+
+# ---------------------------------------------------------------------------------------------------
 # PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-135)
 # ---------------------------------------------------------------------------------------------------
 def make_hip_ppo_cnn():
