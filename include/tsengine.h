@@ -497,6 +497,23 @@ int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4, float* grad_out,
                     ts_stream_t stream);
 
+/* The same three operations for an MLP trunk: Net(obs, [hidden, hidden]) ReLU (utils/net/common.py:343-369) shared by
+ * DiscreteActor and DiscreteCritic -- BASELINE.json configs[0], test/discrete/test_ppo_discrete.py:88-98 (CartPole
+ * shape: obs 4, hidden 64, 2 actions).  The policy is Categorical over the actor's outputs (softmax_output=True with
+ * Categorical(probs) and softmax_output=False with Categorical(logits=) are the same distribution).
+ * Flat parameter vector: L1 [k0 + 1, hidden] | L2 [hidden + 1, hidden] | head [hidden + 1, 32] (columns [0, n_act) =
+ * DiscreteActor.last, column n_act = DiscreteCritic.last; k0 = obs_dim rounded up to 32; last row of a block = bias).
+ * hidden a multiple of 32 in [32, 2048], n_act <= 31.  h_out3 = {k0, head width, parameter count};
+ * obs float32[B, obs_dim]. */
+int ts_mlp_ac_layout(int64_t obs_dim, int64_t hidden, int64_t n_act, int64_t* h_out3);
+int ts_mlp_ac_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t n_act,
+                    const float* obs, const int64_t* act, int64_t B, float* v_out, float* logp_out, float* logits_out,
+                    ts_stream_t stream);
+int ts_mlp_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                    int64_t hidden, int64_t n_act, const float* obs, const int64_t* act, const float* adv,
+                    const float* returns, const float* logp_old, const float* v_old, int64_t B, const float* adv_stats,
+                    const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * SAC (tanh-Gaussian actor with state-conditioned sigma, twin critics on concat(obs, act), hidden [256, 256])
  * nets as in examples/mujoco/mujoco_sac.py:82-104

@@ -570,6 +570,9 @@ def main() -> None:
                     eps_clip=0.1, value_clip=True, dual_clip=None, advantage_normalization=True,
                     recompute_advantage=False, max_batchsize=32)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
+        gen_ppo_discrete_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "dsac":
         gen_dsac_all()
         return
@@ -1003,6 +1006,114 @@ def gen_ppo_cnn(tag: str = "cnn", *, E: int = 3, T: int = 20, c: int = 2, h: int
                max_batchsize=float(algorithm.max_batchsize))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
+
+
+def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_act: int, batch_size: int, repeat: int,
+                     seed: int, softmax_output: bool, lr: float = 3e-4, **ppo_kwargs) -> None:
+    """Runs the reference PPO.update() with the CartPole-shape networks of test/discrete/test_ppo_discrete.py:88-127
+    (BASELINE.json configs[0]): Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, orthogonal init."""
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy
+    from tianshou.utils.net.common import ActorCritic
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from oracle import oracle_ppo_discrete as OD
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net = Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden])
+    actor = DiscreteActor(preprocess_net=net, action_shape=n_act, softmax_output=softmax_output)
+    critic = DiscreteCritic(preprocess_net=net)
+    for m in ActorCritic(actor, critic).modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.orthogonal_(m.weight)
+            torch.nn.init.zeros_(m.bias)
+
+    def tensors():
+        sa, sc = actor.state_dict(), critic.state_dict()
+        return [sa[k] for k in OD.TRUNK_KEYS] + [sa[k] for k in OD.HEAD_KEYS] + [sc[k] for k in OD.HEAD_KEYS]
+
+    p0 = OD.init_params(obs_dim, hidden, n_act, seed)
+    for t, k in zip(tensors(), OD.PARAM_ORDER):
+        assert torch.equal(t, p0[k]), f"oracle init differs from the reference at {k}"
+    if softmax_output:                # test_ppo_discrete.py:104-110: Categorical receives the probabilities
+        policy = DiscreteActorPolicy(actor=actor, dist_fn=torch.distributions.Categorical,
+                                     action_space=gym.spaces.Discrete(n_act))
+    else:
+        policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
+    algorithm = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+
+    N = E * T
+    buf = VectorReplayBuffer(N, E)
+    obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+    act = rng.integers(0, n_act, size=(T, E))
+    rew = rng.normal(size=(T, E)).astype(np.float32)
+    term = rng.random((T, E)) < 0.06
+    trunc = (rng.random((T, E)) < 0.04) & ~term
+    for t in range(T):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+    out: dict[str, np.ndarray] = {"dims": np.array([E, T, obs_dim, hidden, n_act, batch_size, repeat, seed,
+                                                    int(softmax_output)])}
+    out["obs"], out["obs_next"] = np.asarray(buf.obs, np.float32), np.asarray(buf.obs_next, np.float32)
+    out["act"], out["rew"] = np.asarray(buf.act, np.int64), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    perms, seqs, pre_dump = [], [], {}
+    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, PPO._preprocess_batch
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p, np.int64))
+        return p
+
+    def rec_from(cls, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(cls, seq)
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        pre_dump.update(v_s=b.v_s.numpy().copy(), returns=b.returns.numpy().copy(), adv=b.adv.numpy().copy(),
+                        logp_old=b.logp_old.numpy().copy(), indices=np.asarray(indices, np.int64),
+                        unfinished=np.asarray(buffer.unfinished_index(), np.int64))
+        return b
+
+    np.random.permutation, PPO._preprocess_batch = rec_perm, rec_pre
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    try:
+        np.random.seed(seed + 100)
+        with policy_within_training_step(algorithm.policy):
+            stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+    finally:
+        np.random.permutation, PPO._preprocess_batch = orig_perm, orig_pre
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+    assert len(perms) == repeat and len(seqs) == 4
+    out["perms"], out["losses"] = np.stack(perms), np.stack(seqs, axis=1)
+    out["gradient_steps"] = np.array(stats.gradient_steps)
+    out["params"] = torch.cat([t.reshape(-1) for t in tensors()]).numpy().copy()
+    out["ret_rms"] = np.array([float(algorithm.ret_rms.mean), float(algorithm.ret_rms.var), float(algorithm.ret_rms.count)])
+    for k, v in pre_dump.items():
+        out["pre_" + k] = v
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
+               dual_clip=algorithm.dual_clip or 0.0, value_clip=float(algorithm.value_clip),
+               advantage_normalization=float(algorithm.advantage_normalization), vf_coef=algorithm.vf_coef,
+               ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
+               return_scaling=float(algorithm.return_scaling), lr=lr, adam_eps=1e-8,
+               max_batchsize=float(algorithm.max_batchsize))
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"ppo_discrete_{tag}.npz"), **out)
+
+
+def gen_ppo_discrete_all() -> None:
+    # BASELINE.json configs[0] (test/discrete/test_ppo_discrete.py defaults): CartPole shape, MLP[64, 64], batch 64
+    gen_ppo_discrete("c1", E=4, T=60, obs_dim=4, hidden=64, n_act=2, batch_size=64, repeat=3, seed=1626,
+                     softmax_output=True, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.5, ent_coef=0.0,
+                     eps_clip=0.2, return_scaling=False, value_clip=False, dual_clip=None,
+                     advantage_normalization=False, recompute_advantage=False)
+    # every option on, logits actor, other widths
+    gen_ppo_discrete("opts", E=3, T=50, obs_dim=9, hidden=96, n_act=5, batch_size=40, repeat=2, seed=7,
+                     softmax_output=False, gamma=0.97, gae_lambda=0.9, max_grad_norm=0.7, vf_coef=0.25, ent_coef=0.01,
+                     eps_clip=0.15, return_scaling=True, value_clip=True, dual_clip=3.0,
+                     advantage_normalization=True, recompute_advantage=False, max_batchsize=64)
 
 
 def gen_buffer_add() -> None:

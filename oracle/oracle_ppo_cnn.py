@@ -77,6 +77,16 @@ def critic_forward(p, obs) -> torch.Tensor:
     return F.linear(features(p, obs), p["critic.w"], p["critic.b"])
 
 
+def dist(p, obs) -> Categorical:
+    return Categorical(logits=actor_forward(p, obs))          # dist_fn_categorical_from_logits, discrete.py:20-24
+
+
+class _CnnNet:
+    """The network-specific part of this restatement (oracle_ppo_discrete.MlpNet is the other implementation)."""
+    dist = staticmethod(dist)
+    critic_forward = staticmethod(critic_forward)
+
+
 def _chunks(n, size):
     return OP.split_slices(n, size, merge_last=True)          # Batch.split(merge_last=True), a2c.py:125
 
@@ -101,9 +111,10 @@ def _clip_adam(st: OP.PPOState, cfg: OP.PPOConfig, grads: dict) -> None:
 
 
 def preprocess(st: OP.PPOState, cfg: OP.PPOConfig, obs, obs_next, act, rew, terminated, truncated, indices,
-               unfinished):
+               unfinished, net=_CnnNet):
     """a2c.py:115-153 + ppo.py:146-162 with the categorical policy -> dict(v_s, returns, adv, logp_old)."""
     p = st.params
+    critic_forward = net.critic_forward
     with torch.no_grad():
         v_s = torch.cat([critic_forward(p, obs[a:b]) for a, b in _chunks(len(obs), cfg.max_batchsize)]).flatten()
         v_s_ = torch.cat([critic_forward(p, obs_next[a:b]) for a, b in _chunks(len(obs), cfg.max_batchsize)]).flatten()
@@ -121,17 +132,17 @@ def preprocess(st: OP.PPOState, cfg: OP.PPOConfig, obs, obs_next, act, rew, term
         returns = ret
     with torch.no_grad():
         act_t = torch.as_tensor(np.asarray(act), dtype=torch.int64)
-        logp = torch.cat([Categorical(logits=actor_forward(p, obs[a:b])).log_prob(act_t[a:b])
+        logp = torch.cat([net.dist(p, obs[a:b]).log_prob(act_t[a:b])
                           for a, b in _chunks(len(obs), cfg.max_batchsize)])
     return {"v_s": v_s, "returns": torch.as_tensor(returns, dtype=torch.float32),
             "adv": torch.as_tensor(adv, dtype=torch.float32), "logp_old": logp}
 
 
-def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s):
+def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s, net=_CnnNet):
     """ppo.py:179-211 -> (loss, clip_loss, vf_loss, ent_loss)."""
     if cfg.advantage_normalization:
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-    dist = Categorical(logits=actor_forward(p, obs))
+    dist = net.dist(p, obs)
     ratios = (dist.log_prob(act) - logp_old).exp().float()
     ratios = ratios.reshape(ratios.size(0), -1).transpose(0, 1)
     surr1 = ratios * adv
@@ -142,7 +153,7 @@ def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s):
         clip_loss = -torch.where(adv < 0, clip2, clip1).mean()
     else:
         clip_loss = -torch.min(surr1, surr2).mean()
-    value = critic_forward(p, obs).flatten()
+    value = net.critic_forward(p, obs).flatten()
     if cfg.value_clip:
         v_clip = v_s + (value - v_s).clamp(-cfg.eps_clip, cfg.eps_clip)
         vf_loss = torch.max((returns - value).pow(2), (returns - v_clip).pow(2)).mean()
@@ -154,7 +165,7 @@ def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s):
 
 
 def update(st: OP.PPOState, cfg: OP.PPOConfig, obs, act, pre: dict, batch_size, repeat: int, perms,
-           collect: dict | None = None) -> np.ndarray:
+           collect: dict | None = None, net=_CnnNet) -> np.ndarray:
     """ppo.py:164-224 (without recompute_advantage) -> losses [steps, 4]."""
     n = len(obs)
     act_t = torch.as_tensor(np.asarray(act), dtype=torch.int64)
@@ -166,7 +177,7 @@ def update(st: OP.PPOState, cfg: OP.PPOConfig, obs, act, pre: dict, batch_size, 
             rows = perm[lo:hi]
             p = {k: v.clone().requires_grad_(True) for k, v in st.params.items()}
             loss, clip, vf, ent = minibatch_loss(p, cfg, obs_t[rows], act_t[rows], pre["adv"][rows],
-                                                 pre["returns"][rows], pre["logp_old"][rows], pre["v_s"][rows])
+                                                 pre["returns"][rows], pre["logp_old"][rows], pre["v_s"][rows], net=net)
             loss.backward()
             grads = {k: v.grad for k, v in p.items()}
             if collect is not None:

@@ -1,0 +1,120 @@
+"""GPU parity of BASELINE.json configs[0] -- PPO on the CartPole-shape networks (obs 4, MLP[64, 64] trunk shared by a
+discrete actor and a critic, minibatch 64) -- through the C ABI, against oracle/oracle_ppo_discrete.py (pinned to the
+reference by tests/golden/ppo_discrete_*.npz) and against the golden files themselves."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_ppo as OP
+from oracle import oracle_ppo_cnn as OC
+from oracle import oracle_ppo_discrete as OD
+from tests.test_gpu_ppo_cnn import engine_cfg, rel_err
+from tests.test_oracle_golden import load_ppo_discrete
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(obs_dim, hidden, n_act, seed, cfg):
+    from tianshou_amd import ppo_discrete as PD
+
+    p = OD.init_params(obs_dim, hidden, n_act, seed)
+    flat = PD.flat_from_torch([p[k] for k in OD.PARAM_ORDER], obs_dim, hidden, n_act)
+    return p, PD.DiscretePPOEngine(obs_dim, hidden, n_act, flat, engine_cfg(cfg))
+
+
+@pytest.mark.parametrize("obs_dim,hidden,A,B", [(4, 64, 2, 64), (4, 64, 2, 1), (33, 256, 31, 1000), (128, 32, 7, 65536)])
+def test_layout_round_trip_and_inference(obs_dim, hidden, A, B):
+    from tianshou_amd import ppo_discrete as PD
+
+    p, eng = make_engine(obs_dim, hidden, A, 3, OP.PPOConfig())
+    for a, k in zip(PD.flat_to_torch(eng.params, obs_dim, hidden, A), OD.PARAM_ORDER):
+        assert torch.equal(a.cpu(), p[k]), k
+    g = torch.Generator().manual_seed(B)
+    obs = torch.randn(B, obs_dim, generator=g)
+    act = torch.randint(0, A, (B,), generator=g)
+    v, logp, logits = eng.infer(obs, act, True)
+    net = OD.MlpNet(softmax_output=True)
+    with torch.no_grad():
+        lg_ref, v_ref = net.logits(p, obs), net.critic_forward(p, obs).flatten()
+        lp_ref = net.dist(p, obs).log_prob(act)                 # Categorical(probs = softmax), as configs[0]
+    assert rel_err(logits.cpu(), lg_ref) < 1e-5 and rel_err(v.cpu(), v_ref) < 1e-5
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["c1", "opts"])
+def test_update_matches_reference_golden(tag):
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g, d, cfg = load_ppo_discrete(tag)
+    dims = (d["obs_dim"], d["hidden"], d["n_act"])
+    _, eng = make_engine(*dims, d["seed"], cfg)
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
+    pre = eng.preprocess(buf)
+    assert np.array_equal(pre["indices"].cpu().numpy(), g["pre_indices"])
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].cpu().numpy(), g["pre_" + k], rtol=1e-5, atol=2e-5, err_msg=k)
+    losses, steps = eng.update(buf, pre, d["batch_size"], d["repeat"], list(g["perms"]))
+    assert steps == int(g["gradient_steps"])
+    np.testing.assert_allclose(losses.cpu().numpy(), g["losses"], rtol=5e-5, atol=2e-6)
+    flat = torch.cat([t.reshape(-1) for t in PD.flat_to_torch(eng.params, *dims)]).cpu().numpy()
+    np.testing.assert_allclose(flat, g["params"], rtol=1e-5, atol=0.05 * cfg.lr)
+    np.testing.assert_allclose(eng.ret_rms, g["ret_rms"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("obs_dim,hidden,A,B,adv_norm,dual,vclip", [(4, 64, 2, 64, False, None, False),
+                                                                   (4, 64, 2, 65536, True, None, True),
+                                                                   (17, 128, 6, 777, False, 3.0, False)])
+def test_minibatch_gradient_vs_oracle(obs_dim, hidden, A, B, adv_norm, dual, vclip):
+    """losses and every layer's gradient of one minibatch, from the configs[0] minibatch (64) to PPO's 65,536."""
+    from tianshou_amd import ppo_discrete as PD
+
+    g = torch.Generator().manual_seed(B + A)
+    obs = torch.randn(B, obs_dim, generator=g)
+    act = torch.randint(0, A, (B,), generator=g)
+    adv, ret = torch.randn(B, generator=g), torch.randn(B, generator=g) * 2
+    cfg = OP.PPOConfig(eps_clip=0.2, dual_clip=dual, value_clip=vclip, advantage_normalization=adv_norm, vf_coef=0.5,
+                       ent_coef=0.01, max_grad_norm=0.5, lr=3e-4)
+    p, eng = make_engine(obs_dim, hidden, A, 6, cfg)
+    net = OD.MlpNet(softmax_output=False)
+    with torch.no_grad():
+        logp_old = net.dist(p, obs).log_prob(act) + torch.randn(B, generator=g) * 0.2
+        v_old = net.critic_forward(p, obs).flatten() + torch.randn(B, generator=g) * 0.3
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss, clip, vf, ent = OC.minibatch_loss(pg, cfg, obs, act, adv, ret, logp_old, v_old, net=net)
+    loss.backward()
+    grad = torch.empty(eng.P, dtype=torch.float32, device="cuda")
+    losses = eng.step(obs, act, adv, ret, logp_old, v_old, grad_out=grad, apply=False)
+    np.testing.assert_allclose(losses.cpu().numpy(), [loss.item(), clip.item(), vf.item(), ent.item()], rtol=2e-5,
+                               atol=1e-6)
+    got = PD.flat_to_torch(grad, obs_dim, hidden, A)
+    for t, k in zip(got, OD.PARAM_ORDER):
+        assert rel_err(t.cpu(), pg[k].grad) < 2e-5, k
+    lay = PD.layout(obs_dim, hidden, A)
+    l1 = grad[:(lay["k0"] + 1) * hidden].reshape(lay["k0"] + 1, hidden)
+    assert torch.count_nonzero(l1[obs_dim:lay["k0"]]) == 0               # padding rows get exactly zero gradient
+    # the optimizer step on the same minibatch (clip_grad_norm_ + Adam)
+    st = OP.PPOState(params={k: v.clone() for k, v in p.items()})
+    OC._clip_adam(st, cfg, {k: pg[k].grad for k in OD.PARAM_ORDER})
+    eng.step(obs, act, adv, ret, logp_old, v_old)
+    new = torch.cat([t.reshape(-1) for t in PD.flat_to_torch(eng.params, obs_dim, hidden, A)]).cpu().numpy()
+    np.testing.assert_allclose(new, OD.flatten_params(st.params).numpy(), rtol=1e-5, atol=0.05 * cfg.lr)
+
+
+def test_bad_arguments_fail_loudly():
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.ppo import PPOConfig
+
+    with pytest.raises(Exception):
+        PD.layout(4, 48, 2)
+    with pytest.raises(Exception):
+        PD.layout(4, 64, 32)
+    n = PD.layout(4, 64, 2)["count"]
+    with pytest.raises(RuntimeError):
+        PD.DiscretePPOEngine(4, 64, 2, torch.zeros(n), PPOConfig())
+    _, eng = make_engine(4, 64, 2, 0, OP.PPOConfig())
+    z = torch.zeros(8)
+    with pytest.raises(ValueError):
+        eng.step(torch.zeros(8, 4), torch.zeros(7, dtype=torch.int64), z, z, z, z)

@@ -665,3 +665,95 @@ def test_hip_discrete_sac_wrapper_runs_with_engine_double(match_rng, monkeypatch
     st = algo.critic2_optim._optim.state[first]
     assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.25))
     assert abs(float(algo.alpha._log_alpha.detach()) - 0.125) < 1e-6
+
+
+# ------------------------------------------------------------------------------------ PPO, CartPole shape (configs[0])
+def _ppo_discrete_algo(softmax=True, hidden=64, dist="match", **kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from tianshou_amd.integration import make_hip_ppo_discrete
+
+    net = Net(state_shape=(4,), hidden_sizes=[hidden, hidden])
+    actor = DiscreteActor(preprocess_net=net, action_shape=2, softmax_output=softmax)
+    critic = DiscreteCritic(preprocess_net=net)
+    pk = {}
+    if (softmax and dist == "match") or (not softmax and dist == "mismatch"):
+        pk["dist_fn"] = torch.distributions.Categorical
+    policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(2), **pk)
+    return make_hip_ppo_discrete()(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), gamma=0.99,
+                                   max_grad_norm=0.5, eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, gae_lambda=0.95,
+                                   return_scaling=False, dual_clip=None, value_clip=False,
+                                   advantage_normalization=False, recompute_advantage=False, device="cpu", **kw)
+
+
+def test_ppo_discrete_subclass_keeps_signatures_and_fails_loudly():
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    for softmax in (True, False):
+        algo = _ppo_discrete_algo(softmax=softmax)
+        base = type(algo).__mro__[1]
+        for name in ("_preprocess_batch", "_update_with_batch"):
+            mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+            assert list(mine.parameters) == list(ref.parameters), name
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (4,), np.zeros(2, np.int64))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, batch_size=8, repeat=1)
+    with pytest.raises(NotImplementedError):                    # probabilities handed to a logits dist_fn
+        _ppo_discrete_algo(softmax=True, dist="mismatch")
+    with pytest.raises(NotImplementedError):
+        _ppo_discrete_algo(softmax=False, dist="mismatch")
+    with pytest.raises(NotImplementedError):
+        _ppo_discrete_algo(hidden=48)
+
+
+def test_hip_ppo_discrete_wrapper_runs_with_engine_double(monkeypatch):
+    ref_shim.install()
+    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.ppo_discrete as PD
+
+    class FakeDiscretePPO:
+        def __init__(self, obs_dim, hidden, n_act, flat, cfg):
+            assert (obs_dim, hidden, n_act) == (4, 64, 2) and flat.numel() == 33 * 64 + 65 * 64 + 65 * 32
+            assert cfg.vf_coef == 0.5 and cfg.eps_clip == 0.2 and cfg.max_grad_norm == 0.5 and not cfg.value_clip
+            self.obs_dim, self.hidden, self.n_act, self.cfg = obs_dim, hidden, n_act, cfg
+            self.params, self.adam_m, self.adam_v, self.adam_step = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat), 0
+            self.ret_rms = [0.0, 1.0, 0.0]
+
+        def preprocess(self, m):
+            n = len(m)
+            assert m.obs.shape == (m.maxsize, 4) and m.obs_next is not None
+            z = torch.zeros(n)
+            return {"indices": torch.arange(n), "act": m.act[:n], "v_s": z, "returns": z, "adv": z, "logp_old": z}
+
+        def update(self, m, pre, batch_size, repeat, perms):
+            assert batch_size == 8 and len(perms) == repeat == 2
+            self.adam_step += 6
+            self.params += 1.0
+            self.adam_v += 0.5
+            return torch.tensor([[4.0, 3.0, 2.0, 1.0]] * 6), 6
+
+    algo = _ppo_discrete_algo()
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(PD, "DiscretePPOEngine", FakeDiscretePPO)
+    monkeypatch.setattr(PD, "layout", lambda o, h, a: {"k0": 32, "head": 32, "count": 33 * h + (h + 1) * h + (h + 1) * 32})
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (4,), np.zeros(2, np.int64))
+    head = algo.critic.last.model[0].weight
+    trunk = next(iter(algo.policy.actor.preprocess.parameters()))
+    before_h, before_t = head.detach().clone(), trunk.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, batch_size=8, repeat=2)
+    assert isinstance(stats, A2CTrainingStats) and stats.gradient_steps == 6 and stats.loss.mean == 4.0
+    assert torch.allclose(head.detach(), before_h + 1.0) and torch.allclose(trunk.detach(), before_t + 1.0)
+    st = algo.optim._optim.state[head]
+    assert float(st["step"]) == 6.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.5))

@@ -383,6 +383,46 @@ def test_ppo_cnn_restatement_matches_reference():
                                atol=0.02 * cfg.lr)
 
 
+def load_ppo_discrete(tag):
+    from oracle import oracle_ppo as OPm
+
+    g = load(f"ppo_discrete_{tag}.npz")
+    E, T, obs_dim, hidden, n_act, batch_size, repeat, seed, softmax = (int(x) for x in g["dims"])
+    cv = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OPm.PPOConfig(gamma=cv["gamma"], gae_lambda=cv["gae_lambda"], eps_clip=cv["eps_clip"],
+                        dual_clip=cv["dual_clip"] or None, value_clip=bool(cv["value_clip"]),
+                        advantage_normalization=bool(cv["advantage_normalization"]), vf_coef=cv["vf_coef"],
+                        ent_coef=cv["ent_coef"], max_grad_norm=cv["max_grad_norm"] or None,
+                        return_scaling=bool(cv["return_scaling"]), lr=cv["lr"], adam_eps=cv["adam_eps"],
+                        max_batchsize=int(cv["max_batchsize"]))
+    d = dict(E=E, T=T, obs_dim=obs_dim, hidden=hidden, n_act=n_act, batch_size=batch_size, repeat=repeat, seed=seed,
+             softmax=bool(softmax))
+    return g, d, cfg
+
+
+@pytest.mark.parametrize("tag", ["c1", "opts"])
+def test_ppo_discrete_restatement_matches_reference(tag):
+    """BASELINE.json configs[0] (CartPole shape: obs 4, MLP[64, 64] shared by a softmax actor and a critic, batch 64)
+    and an every-option variant: oracle_ppo_discrete against the unmodified reference PPO.update()."""
+    from oracle import oracle_ppo_cnn as OC
+    from oracle import oracle_ppo_discrete as OD
+
+    g, d, cfg = load_ppo_discrete(tag)
+    net = OD.MlpNet(softmax_output=d["softmax"])
+    st = OP.PPOState(params=OD.init_params(d["obs_dim"], d["hidden"], d["n_act"], d["seed"]))
+    idx, unf = g["pre_indices"], g["pre_unfinished"]
+    assert np.array_equal(idx, np.arange(d["E"] * d["T"]))
+    pre = OC.preprocess(st, cfg, g["obs"], g["obs_next"], g["act"], g["rew"], g["terminated"], g["truncated"], idx, unf,
+                        net=net)
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].numpy(), g["pre_" + k], rtol=1e-5, atol=1e-5, err_msg=k)
+    losses = OC.update(st, cfg, g["obs"], g["act"], pre, d["batch_size"], d["repeat"], g["perms"], net=net)
+    assert len(losses) == int(g["gradient_steps"])
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(OD.flatten_params(st.params).numpy(), g["params"], rtol=1e-5, atol=0.02 * cfg.lr)
+    np.testing.assert_allclose([st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], g["ret_rms"], rtol=1e-6)
+
+
 # ------------------------------------------------------------------------------------ write side (SURVEY 8f N1)
 def replay_buffer_add(g, s, make_writer, add):
     """Replays scenario s of buffer_add.npz through `add(writer, rows, ids)`; returns the writer."""

@@ -100,9 +100,14 @@ def check(code: int) -> None:
 
 
 def ptr(t) -> C.c_void_p:
-    """Device pointer of a torch tensor (None -> NULL)."""
+    """Device pointer of a torch tensor (None -> NULL).  A host tensor here would make the kernels fault on a host
+    address, so it is refused up front."""
     if t is None:
         return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("libtsengine entry points take device tensors (got a CPU tensor; there is no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError("libtsengine entry points take contiguous tensors")
     return C.c_void_p(t.data_ptr())
 
 

@@ -26,9 +26,11 @@ namespace {
 constexpr int HIDDEN = 512, HEAD = 32;
 
 struct Net {
-    ts::ConvGeom l[5];          // conv1, conv2, conv3, fc, head (512 -> 32)
-    int64_t off[6];
+    int nl;                     // layers: 5 = conv1, conv2, conv3, fc, head (512 -> 32); 3 = l1, l2, head (MLP trunk)
+    ts::ConvGeom l[5];
+    int64_t off[6];             // off[nl] = parameter count
     int n_act;
+    int obs_dim;                // MLP trunk: unpadded observation width (l[0].IC = obs_dim rounded up to 32); else 0
 };
 
 int make_net(int B, int c, int h, int w, int n_act, Net* n) {
@@ -43,10 +45,32 @@ int make_net(int B, int c, int h, int w, int n_act, Net* n) {
     }
     n->l[3] = ts::ConvGeom{B, 1, 1, ic * ih * iw, 1, 1, 1, 1, 1, HIDDEN};
     n->l[4] = ts::ConvGeom{B, 1, 1, HIDDEN, 1, 1, 1, 1, 1, HEAD};
+    n->nl = 5;
     n->n_act = n_act;
+    n->obs_dim = 0;
     int64_t o = 0;
     for (int i = 0; i < 5; ++i) { n->off[i] = o; o += n->l[i].param_elems(); }
     n->off[5] = o;
+    return TS_OK;
+}
+
+// Net(obs, [hidden, hidden]) ReLU trunk (utils/net/common.py:343-369) shared by DiscreteActor / DiscreteCritic
+// (test/discrete/test_ppo_discrete.py:88-98): Linear layers are the 1x1 case of the conv kernels.
+int make_mlp_net(int B, int64_t obs_dim, int64_t hidden, int64_t n_act, Net* n) {
+    TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && hidden >= 32 && hidden <= 2048 && hidden % 32 == 0 && n_act >= 1 &&
+                   n_act < HEAD, TS_ERR_INVALID_ARG,
+               "mlp actor-critic: obs_dim >= 1, hidden a multiple of 32 in [32, 2048], n_act <= 31");
+    const int k0 = ((int)obs_dim + 31) / 32 * 32, hid = (int)hidden;
+    n->l[0] = ts::ConvGeom{B, 1, 1, k0, 1, 1, 1, 1, 1, hid};
+    n->l[1] = ts::ConvGeom{B, 1, 1, hid, 1, 1, 1, 1, 1, hid};
+    n->l[2] = ts::ConvGeom{B, 1, 1, hid, 1, 1, 1, 1, 1, HEAD};
+    n->nl = 3;
+    n->n_act = (int)n_act;
+    n->obs_dim = (int)obs_dim;
+    int64_t o = 0;
+    for (int i = 0; i < 3; ++i) { n->off[i] = o; o += n->l[i].param_elems(); }
+    n->off[3] = o;
+    for (int i = 4; i <= 5; ++i) n->off[i] = o;
     return TS_OK;
 }
 
@@ -56,7 +80,7 @@ struct Acts { float* h[5]; float* split; };
 
 size_t split_floats(const Net& n) {
     size_t s = 4;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < n.nl; ++i) {
         const int ns = ts::conv_fwd_splits(n.l[i]);
         if (ns > 1) s = std::max(s, (size_t)ns * n.l[i].out_elems());
     }
@@ -65,12 +89,16 @@ size_t split_floats(const Net& n) {
 
 size_t acts_bytes(const Net& n) {
     size_t s = al(4 * split_floats(n));
-    for (int i = 0; i < 5; ++i) s += al(4 * (size_t)n.l[i].out_elems());
+    for (int i = 0; i < n.nl; ++i) s += al(4 * (size_t)n.l[i].out_elems());
     return s;
 }
 
+size_t front_bytes(const Net& n) {      // MLP trunk: the zero-padded copy of the observations
+    return n.obs_dim ? al(4 * (size_t)n.l[0].in_elems()) : 0;
+}
+
 char* carve_acts(const Net& n, char* p, Acts* a) {
-    for (int i = 0; i < 5; ++i) { a->h[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
+    for (int i = 0; i < n.nl; ++i) { a->h[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
     a->split = reinterpret_cast<float*>(p);
     return p + al(4 * split_floats(n));
 }
@@ -78,12 +106,22 @@ char* carve_acts(const Net& n, char* p, Acts* a) {
 int net_forward(hipStream_t s, ts_workspace* ws, const Net& n, const float* params, const void* obs, bool obs_u8,
                 const Acts& a) {
     const float* x = static_cast<const float*>(obs);
-    for (int i = 0; i < 5; ++i) {
-        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], a.h[i], i < 4, a.split, ws, i == 0 && obs_u8))
+    for (int i = 0; i < n.nl; ++i) {
+        if (int rc = ts::conv_forward(s, n.l[i], x, params + n.off[i], a.h[i], i < n.nl - 1, a.split, ws, i == 0 && obs_u8))
             return rc;
         x = a.h[i];
     }
     return TS_OK;
+}
+
+// x[b] = [obs[b] | 0]: the K dimension of the first Linear layer padded to a multiple of 32
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ obs, int64_t B, int obs_dim, int k0,
+                                                       float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * k0) return;
+    const int64_t b = i / k0;
+    const int j = (int)(i - b * k0);
+    x[i] = j < obs_dim ? obs[b * obs_dim + j] : 0.f;
 }
 
 // log-softmax pieces of one sample's logits (A <= 31): returns log-sum-exp
@@ -208,6 +246,80 @@ __global__ __launch_bounds__(256) void cnn_loss_finish_kernel(const float* __res
     }
 }
 
+// Input of the first layer: the observations themselves (CNN trunk, NHWC float32 / uint8) or their zero-padded copy at
+// the front of the workspace (MLP trunk).
+const void* first_input(hipStream_t s, const Net& n, ts_workspace* ws, const void* obs, int64_t B) {
+    if (!n.obs_dim) return obs;
+    float* x = static_cast<float*>(ws->base);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.l[0].IC, 256)), dim3(256), 0, s,
+                       static_cast<const float*>(obs), B, n.obs_dim, n.l[0].IC, x);
+    return x;
+}
+
+int ac_infer(ts_workspace* ws, const Net& n, const float* params, const void* obs, bool obs_u8, const int64_t* act,
+             int64_t B, float* v_out, float* logp_out, float* logits_out, hipStream_t s) {
+    if (int rc = ts::ws_reserve(ws, front_bytes(n) + acts_bytes(n))) return rc;
+    Acts a;
+    carve_acts(n, static_cast<char*>(ws->base) + front_bytes(n), &a);
+    const void* x = first_input(s, n, ws, obs, B);
+    if (int rc = net_forward(s, ws, n, params, x, obs_u8, a)) return rc;
+    hipLaunchKernelGGL(cnn_infer_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a.h[n.nl - 1], act, B,
+                       n.n_act, v_out, logp_out, logits_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ac_ppo_step(ts_workspace* ws, const Net& n, float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                const void* obs, bool obs_u8, const int64_t* act, const float* adv, const float* returns,
+                const float* logp_old, const float* v_old, int64_t B, const float* adv_stats, const ts_ppo_hparams* hp,
+                float* losses_out4, float* grad_out, hipStream_t s, const char* who) {
+    TS_REQUIRE(hp->algo == 0, TS_ERR_UNSUPPORTED, "%s: only the PPO objective (algo 0)", who);
+    TS_REQUIRE(!hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "%s: adv_norm needs adv_stats", who);
+    const int nl = n.nl;
+    const int64_t P = n.off[nl];
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    size_t slab = 0;
+    for (int i = 0; i < nl; ++i)
+        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    size_t bytes = front_bytes(n) + acts_bytes(n) + al(slab) + al(4 * (size_t)P) + al(12 * (size_t)n_blocks) + 4096;
+    for (int i = 0; i < nl; ++i) bytes += al(4 * (size_t)n.l[i].out_elems());
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Acts a;
+    char* p = carve_acts(n, static_cast<char*>(ws->base) + front_bytes(n), &a);
+    float* dy[5] = {};
+    for (int i = 0; i < nl; ++i) { dy[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
+    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
+    float* grad = reinterpret_cast<float*>(p); p += al(4 * (size_t)P);
+    float* partials = reinterpret_cast<float*>(p); p += al(12 * (size_t)n_blocks);
+    float* norm_part = reinterpret_cast<float*>(p);
+    if (grad_out) grad = grad_out;
+
+    const void* x0 = first_input(s, n, ws, obs, B);
+    if (int rc = net_forward(s, ws, n, params, x0, obs_u8, a)) return rc;
+    LossArgs la{};
+    la.head = a.h[nl - 1]; la.act = act; la.adv = adv; la.ret = returns; la.logp_old = logp_old; la.v_old = v_old;
+    la.adv_stats = hp->adv_norm ? adv_stats : nullptr;
+    la.B = B; la.A = n.n_act;
+    la.eps_clip = (float)hp->eps_clip; la.dual_clip = (float)hp->dual_clip; la.vf_coef = (float)hp->vf_coef;
+    la.ent_coef = (float)hp->ent_coef; la.value_clip = hp->value_clip;
+    la.d_head = dy[nl - 1]; la.partials = partials;
+    hipLaunchKernelGGL(cnn_ppo_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, la);
+    hipLaunchKernelGGL(cnn_loss_finish_kernel, dim3(1), dim3(256), 0, s, partials, n_blocks, B, (float)hp->vf_coef,
+                       (float)hp->ent_coef, losses_out4);
+    TS_LAUNCH_CHECK();
+    for (int i = nl - 1; i >= 0; --i) {
+        const float* x = i == 0 ? static_cast<const float*>(x0) : a.h[i - 1];
+        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
+        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
+            return rc;
+        if (i > 0)
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], a.h[i - 1], dy[i - 1], ws)) return rc;
+    }
+    if (hp->lr < 0.0) return TS_OK;
+    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+                         hp->max_grad_norm, norm_part);
+}
+
 }  // namespace
 
 extern "C" {
@@ -236,15 +348,41 @@ int ts_cnn_ac_infer(ts_workspace* ws, const float* params, int64_t c, int64_t h,
     TS_REQUIRE(params && obs_nhwc && (act || !logp_out), TS_ERR_INVALID_ARG, "ts_cnn_ac_infer: NULL argument");
     Net n;
     if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
-    if (int rc = ts::ws_reserve(ws, acts_bytes(n))) return rc;
-    Acts a;
-    carve_acts(n, static_cast<char*>(ws->base), &a);
-    hipStream_t s = ts::as_stream(stream);
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
-    hipLaunchKernelGGL(cnn_infer_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a.h[4], act, B, n.n_act,
-                       v_out, logp_out, logits_out);
-    TS_LAUNCH_CHECK();
+    return ac_infer(ws, n, params, obs_nhwc, obs_u8 != 0, act, B, v_out, logp_out, logits_out, ts::as_stream(stream));
+}
+
+int ts_mlp_ac_layout(int64_t obs_dim, int64_t hidden, int64_t n_act, int64_t* h_out3) {
+    Net n;
+    if (int rc = make_mlp_net(1, obs_dim, hidden, n_act, &n)) return rc;
+    TS_REQUIRE(h_out3, TS_ERR_INVALID_ARG, "ts_mlp_ac_layout: NULL output");
+    h_out3[0] = n.l[0].IC; h_out3[1] = HEAD; h_out3[2] = n.off[3];
     return TS_OK;
+}
+
+int ts_mlp_ac_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t n_act,
+                    const float* obs, const int64_t* act, int64_t B, float* v_out, float* logp_out, float* logits_out,
+                    ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_ac_infer: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_mlp_ac_infer: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && obs && (act || !logp_out), TS_ERR_INVALID_ARG, "ts_mlp_ac_infer: NULL argument");
+    Net n;
+    if (int rc = make_mlp_net((int)B, obs_dim, hidden, n_act, &n)) return rc;
+    return ac_infer(ws, n, params, obs, false, act, B, v_out, logp_out, logits_out, ts::as_stream(stream));
+}
+
+int ts_mlp_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                    int64_t hidden, int64_t n_act, const float* obs, const int64_t* act, const float* adv,
+                    const float* returns, const float* logp_old, const float* v_old, int64_t B, const float* adv_stats,
+                    const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_ppo_step: workspace is NULL");
+    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_mlp_ppo_step: bad batch size / step");
+    TS_REQUIRE(params && adam_m && adam_v && obs && act && adv && returns && logp_old && v_old && hp && losses_out4,
+               TS_ERR_INVALID_ARG, "ts_mlp_ppo_step: NULL argument");
+    Net n;
+    if (int rc = make_mlp_net((int)B, obs_dim, hidden, n_act, &n)) return rc;
+    return ac_ppo_step(ws, n, params, adam_m, adam_v, adam_step, obs, false, act, adv, returns, logp_old, v_old, B,
+                       adv_stats, hp, losses_out4, grad_out, ts::as_stream(stream), "ts_mlp_ppo_step");
 }
 
 int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
@@ -256,51 +394,10 @@ int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_cnn_ppo_step: bad batch size / step");
     TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && adv && returns && logp_old && v_old && hp &&
                    losses_out4, TS_ERR_INVALID_ARG, "ts_cnn_ppo_step: NULL argument");
-    TS_REQUIRE(hp->algo == 0, TS_ERR_UNSUPPORTED, "ts_cnn_ppo_step: only the PPO objective (algo 0)");
-    TS_REQUIRE(!hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "ts_cnn_ppo_step: adv_norm needs adv_stats");
     Net n;
     if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
-    hipStream_t s = ts::as_stream(stream);
-    const int n_blocks = (int)ts::ceil_div(B, 256);
-    size_t slab = 0;
-    for (int i = 0; i < 5; ++i)
-        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
-    size_t bytes = acts_bytes(n) + al(slab) + al(4 * (size_t)n.off[5]) + al(12 * (size_t)n_blocks) + 4096;
-    for (int i = 0; i < 5; ++i) bytes += al(4 * (size_t)n.l[i].out_elems());
-    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
-    Acts a;
-    char* p = carve_acts(n, static_cast<char*>(ws->base), &a);
-    float* dy[5];
-    for (int i = 0; i < 5; ++i) { dy[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
-    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
-    float* grad = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.off[5]);
-    float* partials = reinterpret_cast<float*>(p); p += al(12 * (size_t)n_blocks);
-    float* norm_part = reinterpret_cast<float*>(p);
-    if (grad_out) grad = grad_out;
-
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, a)) return rc;
-    LossArgs la{};
-    la.head = a.h[4]; la.act = act; la.adv = adv; la.ret = returns; la.logp_old = logp_old; la.v_old = v_old;
-    la.adv_stats = hp->adv_norm ? adv_stats : nullptr;
-    la.B = B; la.A = n.n_act;
-    la.eps_clip = (float)hp->eps_clip; la.dual_clip = (float)hp->dual_clip; la.vf_coef = (float)hp->vf_coef;
-    la.ent_coef = (float)hp->ent_coef; la.value_clip = hp->value_clip;
-    la.d_head = dy[4]; la.partials = partials;
-    hipLaunchKernelGGL(cnn_ppo_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, la);
-    hipLaunchKernelGGL(cnn_loss_finish_kernel, dim3(1), dim3(256), 0, s, partials, n_blocks, B, (float)hp->vf_coef,
-                       (float)hp->ent_coef, losses_out4);
-    TS_LAUNCH_CHECK();
-    for (int i = 4; i >= 0; --i) {
-        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.h[i - 1];
-        if (int rc = ts::conv_wgrad(s, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
-        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
-            return rc;
-        if (i > 0)
-            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], a.h[i - 1], dy[i - 1], ws)) return rc;
-    }
-    if (hp->lr < 0.0) return TS_OK;
-    return ts::adam_step(s, params, adam_m, adam_v, grad, n.off[5], adam_step, hp->lr, hp->beta1, hp->beta2,
-                         hp->adam_eps, hp->max_grad_norm, norm_part);
+    return ac_ppo_step(ws, n, params, adam_m, adam_v, adam_step, obs_nhwc, obs_u8 != 0, act, adv, returns, logp_old, v_old,
+                       B, adv_stats, hp, losses_out4, grad_out, ts::as_stream(stream), "ts_cnn_ppo_step");
 }
 
 }  // extern "C"

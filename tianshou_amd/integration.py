@@ -686,6 +686,93 @@ def make_hip_ppo_cnn():
 
 
 # ---------------------------------------------------------------------------------------------------
+# PPO on the CartPole-shape networks (BASELINE.json configs[0], test/discrete/test_ppo_discrete.py:88-127)
+# ---------------------------------------------------------------------------------------------------
+def make_hip_ppo_discrete():
+    """Returns HipPPODiscrete(PPO) for Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, Categorical policy
+    (`softmax_output=True` with `dist_fn=torch.distributions.Categorical`, or `softmax_output=False` with the default
+    logits dist_fn), Adam; h a multiple of 32, at most 31 actions; the buffer must store obs_next."""
+    from torch.distributions import Categorical
+
+    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
+    from tianshou.algorithm.modelfree.ppo import PPO
+    from tianshou.algorithm.modelfree.reinforce import dist_fn_categorical_from_logits
+    from tianshou.data import SequenceSummaryStats
+
+    from . import ppo_discrete as PD
+
+    class HipPPODiscrete(PPO):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            actor, critic = self.policy.actor, self.critic
+            sa, sc = actor.state_dict(), critic.state_dict()
+            keys = PD.TRUNK_KEYS + PD.HEAD_KEYS
+            if list(sa.keys()) != keys or list(sc.keys()) != keys or actor.preprocess is not critic.preprocess:
+                raise NotImplementedError("HipPPODiscrete: actor / critic must share one Net(obs, [h, h]) trunk with "
+                                          "single-Linear heads")
+            hidden, n_act = sa[keys[0]].shape[0], sa[keys[4]].shape[0]
+            if hidden % 32 or sa[keys[2]].shape != (hidden, hidden) or n_act > 31 or sc[keys[4]].shape[0] != 1:
+                raise NotImplementedError("HipPPODiscrete: hidden sizes [h, h] with h a multiple of 32, <= 31 actions")
+            # the actor's outputs must reach Categorical as what they are: probabilities or logits
+            softmax = bool(getattr(actor, "softmax_output", True))
+            dist_fn = self.policy.dist_fn
+            if not ((softmax and dist_fn is Categorical) or (not softmax and dist_fn is dist_fn_categorical_from_logits)):
+                raise NotImplementedError("HipPPODiscrete: softmax_output=True needs dist_fn=Categorical, "
+                                          "softmax_output=False the logits dist_fn")
+            if self.recompute_adv:
+                raise NotImplementedError("HipPPODiscrete: recompute_advantage is not supported")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _hip_params(self):
+            return params_by_keys(self.policy.actor, PD.TRUNK_KEYS + PD.HEAD_KEYS) + params_by_keys(self.critic, PD.HEAD_KEYS)
+
+        def _engine(self):
+            if self._hip_engine is None:
+                params = self._hip_params()
+                hidden, obs_dim = params[0].shape
+                dims, dev = (obs_dim, hidden, params[4].shape[0]), self._hip_device
+                eng = self._hip_engine = PD.DiscretePPOEngine(*dims, PD.flat_from_torch(params, *dims, dev),
+                                                              ppo_config_from(self))
+                eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
+                ms, vs, step = adam_state(self.optim._optim, params)
+                eng.adam_m, eng.adam_v = PD.flat_from_torch(ms, *dims, dev), PD.flat_from_torch(vs, *dims, dev)
+                eng.adam_step = step
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, "HipPPODiscrete")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            if m.obs_next is None:
+                raise NotImplementedError("HipPPODiscrete: the replay buffer must store obs_next")
+            pre = self._hip_pre = eng.preprocess(m)
+            batch.v_s, batch.returns, batch.adv, batch.logp_old = pre["v_s"], pre["returns"], pre["adv"], pre["logp_old"]
+            return batch
+
+        def _update_with_batch(self, batch, batch_size, repeat):
+            eng, m = self._hip_engine, self._hip_mirror
+            perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
+            losses, steps = eng.update(m, self._hip_pre, batch_size, repeat, perms)
+            arr = losses.cpu().numpy().astype(np.float64)
+            params = self._hip_params()
+            dims = (eng.obs_dim, eng.hidden, eng.n_act)
+            with torch.no_grad():
+                for p, t in zip(params, PD.flat_to_torch(eng.params, *dims)):
+                    p.copy_(t)
+            store_adam_state(self.optim._optim, params, PD.flat_to_torch(eng.adam_m, *dims),
+                             PD.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+            self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
+            return A2CTrainingStats(
+                loss=SequenceSummaryStats.from_sequence(arr[:, 0]), actor_loss=SequenceSummaryStats.from_sequence(arr[:, 1]),
+                vf_loss=SequenceSummaryStats.from_sequence(arr[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(arr[:, 3]),
+                gradient_steps=steps)
+
+    return HipPPODiscrete
+
+
+# ---------------------------------------------------------------------------------------------------
 # TD3 / DDPG (td3.py:104-226, ddpg.py:343-411) on the mujoco_td3.py / mujoco_ddpg.py networks
 # ---------------------------------------------------------------------------------------------------
 def _make_hip_det(twin: bool):

@@ -69,6 +69,47 @@ def flat_to_torch(flat: torch.Tensor, c: int, h: int, w: int, n_act: int) -> lis
     return out
 
 
+def gae_and_return_scaling(engine, buffer: DeviceReplayBuffer, idx: torch.Tensor, v_s, v_next) -> dict:
+    """GAE over the whole batch + optional return scaling / RunningMeanStd update (a2c.py:131-153,
+    statistics.py:99-114) for an engine with `.cfg` and `.ret_rms`.  -> {"returns", "adv"}."""
+    cfg, n = engine.cfg, idx.numel()
+    cut_pos, d_n_cut = cut_positions(buffer, idx)
+    scale = math.sqrt(engine.ret_rms[1] + 1e-8) if cfg.return_scaling else 1.0
+    out = gae_scan(v_s, v_next, buffer.rew[idx], buffer.terminated[idx], buffer.truncated[idx], cut_pos,
+                   gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, v_scale=scale, ret_div=scale,
+                   want_ret_stats=cfg.return_scaling, d_n_cut=d_n_cut)
+    if cfg.return_scaling:
+        s1, s2 = float(out["ret_sum"]), float(out["ret_sumsq"])
+        b_mean = s1 / n
+        b_var = max(s2 / n - b_mean * b_mean, 0.0)
+        mean, var, count = engine.ret_rms
+        delta, tot = b_mean - mean, count + n
+        engine.ret_rms = [mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot]
+    return out
+
+
+def adv_stats_of(cfg: PPOConfig, adv: torch.Tensor):
+    """{mean, unbiased std} of a minibatch's advantages (ppo.py:184-186), or None."""
+    if not cfg.advantage_normalization:
+        return None
+    a64 = adv.double()
+    return torch.stack([a64.mean(), a64.std()]).float().contiguous()
+
+
+def run_minibatches(device, n: int, batch_size: int | None, repeat: int, perms, step_rows):
+    """The loop of PPO._update_with_batch (ppo.py:174-178): `repeat` passes over Batch.split(batch_size,
+    merge_last=True); step_rows(rows int64 device) -> losses[4].  -> (losses float32[steps, 4], steps)."""
+    if perms is None:
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+    offs = split_offsets(n, batch_size, merge_last=True)
+    out = []
+    for r in range(repeat):
+        perm = _i64_dev(perms[r], device)
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            out.append(step_rows(perm[lo:hi]))
+    return torch.stack(out), len(out)
+
+
 class CnnPPOEngine:
     """State of one PPO learner (Atari actor-critic) on one GPU."""
 
@@ -122,18 +163,7 @@ class CnnPPOEngine:
             else:
                 nxt = gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num, as_u8=True)
             v_next[sl] = self.infer(nxt)[0]
-        cut_pos, d_n_cut = cut_positions(buffer, idx)
-        scale = math.sqrt(self.ret_rms[1] + 1e-8) if cfg.return_scaling else 1.0
-        out = gae_scan(v_s, v_next, buffer.rew[idx], buffer.terminated[idx], buffer.truncated[idx], cut_pos,
-                       gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, v_scale=scale, ret_div=scale,
-                       want_ret_stats=cfg.return_scaling, d_n_cut=d_n_cut)
-        if cfg.return_scaling:                                                  # statistics.py:99-114
-            s1, s2 = float(out["ret_sum"]), float(out["ret_sumsq"])
-            b_mean = s1 / n
-            b_var = max(s2 / n - b_mean * b_mean, 0.0)
-            mean, var, count = self.ret_rms
-            delta, tot = b_mean - mean, count + n
-            self.ret_rms = [mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot]
+        out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
         return {"indices": idx, "act": act_b, "v_s": v_s, "returns": out["returns"], "adv": out["adv"],
                 "logp_old": logp_old}
 
@@ -142,10 +172,8 @@ class CnnPPOEngine:
         """-> losses float32[4] = {loss, clip, vf, ent} (device)."""
         cfg = self.cfg
         b = obs_nhwc.shape[0]
-        stats = None
-        if cfg.advantage_normalization:                                          # ppo.py:184-186
-            a64 = adv.double()
-            stats = torch.stack([a64.mean(), a64.std()]).float().contiguous()
+        adv = torch.as_tensor(adv, device=self.device)
+        stats = adv_stats_of(cfg, adv)
         if apply:
             self.adam_step += 1
         hp = cfg.to_c()
@@ -167,16 +195,9 @@ class CnnPPOEngine:
                batch_size: int | None, repeat: int, perms=None):
         """ppo.py:164-224.  `perms`: `repeat` permutations of range(N) (NumPy arrays for seed-exact parity with
         Batch.split, batch.py:1209, or int64 device tensors).  -> (losses float32[steps, 4], steps)."""
-        n = pre["indices"].numel()
-        if perms is None:
-            perms = [np.random.permutation(n) for _ in range(repeat)]
-        offs = split_offsets(n, batch_size, merge_last=True)
-        out = []
-        for r in range(repeat):
-            perm = _i64_dev(perms[r], self.device)
-            for lo, hi in zip(offs[:-1], offs[1:]):
-                rows = perm[lo:hi]
-                obs = gather_obs_nhwc(frames, buffer, pre["indices"][rows], stack_num, as_u8=True)
-                out.append(self.step(obs, pre["act"][rows], pre["adv"][rows], pre["returns"][rows],
-                                     pre["logp_old"][rows], pre["v_s"][rows]))
-        return torch.stack(out), len(out)
+        def step_rows(rows):
+            obs = gather_obs_nhwc(frames, buffer, pre["indices"][rows], stack_num, as_u8=True)
+            return self.step(obs, pre["act"][rows], pre["adv"][rows], pre["returns"][rows], pre["logp_old"][rows],
+                             pre["v_s"][rows])
+
+        return run_minibatches(self.device, pre["indices"].numel(), batch_size, repeat, perms, step_rows)
