@@ -1,0 +1,349 @@
+"""Measurement of the rows SURVEY 8f adds to the hot path (N3) and of BASELINE.json configs[0], on the same contract
+as bench.py: TD3 / DDPG / DiscreteSAC (MLP learners), QRDQN / C51 (NatureCNN learners) and the CartPole-shape PPO.
+
+    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
+
+One "step" = one reference update(): sample -> gather -> target / n-step return -> optimizer steps (-> Polyak), everything
+device-resident; for ppo_discrete one update() = preprocessing + repeat x ceil(N / 64) minibatch steps (value = minibatch
+gradient steps/s).  roofline: the linear / conv GEMM kernels (fp32 MFMA), achieved = algorithmic flop of one update (the
+formulas below) / their measured time (HIP events on the launch stream); cpu_baseline: the oracle's restatement of the
+same update on the host cores.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = 157.3                    # fp32 MFMA TFLOP/s (MI355X_MICROARCH.md)
+GEMM_KINDS = ("conv_fwd", "conv_wgrad", "conv_dgrad")
+
+
+# ---- algorithmic flop ------------------------------------------------------------------------------------------------
+def mlp_flop(dims, wgrad=False, dgrad_layers=0, first_dx_cols=0):
+    """2 * MACs per sample of a dense net with layer widths `dims`: forward, + weight gradients (same again),
+    + input gradients of the last `dgrad_layers` layers, + the first layer's input gradient for `first_dx_cols` columns."""
+    macs = [a * b for a, b in zip(dims[:-1], dims[1:])]
+    f = sum(macs)
+    if wgrad:
+        f += sum(macs)
+    f += sum(macs[len(macs) - dgrad_layers:]) if dgrad_layers else 0
+    f += first_dx_cols * dims[1]
+    return 2 * f
+
+
+def cnn_flop(n_out):
+    """NatureCNN trunk + fc1 + a head of n_out outputs: (forward, weight-gradient, input-gradient) flop."""
+    conv = [3_276_800, 2_654_208, 1_806_336]
+    fc, head = 3136 * 512, 512 * n_out
+    fwd = 2 * (sum(conv) + fc + head)
+    return fwd, fwd, fwd - 2 * conv[0]
+
+
+# ---- shared pieces ---------------------------------------------------------------------------------------------------
+def _threads():
+    t = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(t)
+    return t
+
+
+def _flat_buffer(slots, E, dev, g, **cols):
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    T = slots // E
+    offset = np.arange(E + 1, dtype=np.int64) * T
+    rew = torch.randn(slots, generator=g, device=dev).double()
+    term = torch.rand(slots, generator=g, device=dev) < 0.002
+    return DeviceReplayBuffer(offset=offset, last_index=offset[:-1] + T - 1, lengths=np.full(E, T, np.int64),
+                              insertion=np.zeros(E, np.int64), rew=rew, terminated=term,
+                              truncated=torch.zeros(slots, dtype=torch.bool, device=dev), **cols)
+
+
+def _time(update, steps, warmup):
+    from tianshou_amd import _lib
+
+    for _ in range(warmup):
+        update()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = update()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ws = _lib.default_workspace(0)
+    n_prof = 10
+    ws.profile_begin()
+    for _ in range(n_prof):
+        update()
+    torch.cuda.synchronize()
+    prof = ws.profile_end()
+    return dt, last, {k: (prof[k][0] / n_prof, prof[k][1] // n_prof) for k in GEMM_KINDS}
+
+
+def _roofline(prof, flop_per_update, what):
+    ms = sum(prof[k][0] for k in GEMM_KINDS)
+    n = sum(prof[k][1] for k in GEMM_KINDS)
+    tf = flop_per_update / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": f"conv_rows_kernel / conv_wgrad_kernel ({what})", "achieved": tf, "peak": PEAK,
+            "unit": "TFLOP/s", "frac": tf / PEAK, "traffic": None, "avg_launch_us": ms * 1e3 / max(n, 1),
+            "launches_per_update": n, "gemm_us_per_update": ms * 1e3, "algorithmic_flop_per_update": flop_per_update,
+            "kernel_us_per_update": {k: prof[k][0] * 1e3 for k in GEMM_KINDS}}
+
+
+def _line(metric, value, unit, steps, warmup, dt, workload, roof, cpu, extra=None):
+    out = {"metric": metric, "value": value, "unit": unit, "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic", "config": {"workload": workload, "parallelism": "dp1"},
+           "roofline": roof, "cpu_baseline": cpu}
+    out.update(extra or {})
+    return out
+
+
+# ---- TD3 / DDPG (Humanoid shape, as C5) ------------------------------------------------------------------------------
+def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
+    from oracle import oracle_sac as OS
+    from tianshou_amd import td3 as T
+    from tianshou_amd.buffer import gather_rows
+
+    OBS, ACT, B, dev = 376, 17, 4096, torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
+                       act=torch.rand(slots, ACT, generator=g, device=dev) * 2 - 1,
+                       obs_next=torch.randn(slots, OBS, generator=g, device=dev))
+    actor, c1, c2 = OS.init_td3_params(OBS, ACT, 0, twin=twin)
+    cf = lambda c: None if c is None else T.critic_flat_from_torch([c[k] for k in OS.CRITIC_ORDER], OBS, ACT)  # noqa: E731
+    eng = T.TD3Engine(OBS, ACT, T.actor_flat_from_torch([actor[k] for k in OS.DET_ACTOR_ORDER], OBS, ACT), cf(c1), cf(c2),
+                      T.TD3Config(twin=twin))
+
+    def update():
+        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        noise = torch.randn(B, ACT, generator=g, device=dev) if twin else None
+        ret = eng.preprocess(buf, idx, noise)
+        return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret)[0]
+
+    dt, stats, prof = _time(update, steps, warmup)
+    nc = 2 if twin else 1
+    a_dims, c_dims = [OBS, 256, 256, ACT], [OBS + ACT, 256, 256, 1]
+    every = 0.5 if twin else 1.0                                   # delayed actor updates (td3.py:215)
+    flop = B * (mlp_flop(a_dims) + nc * mlp_flop(c_dims)                                   # target
+                + nc * mlp_flop(c_dims, wgrad=True, dgrad_layers=2)                          # critic steps
+                + every * (mlp_flop(a_dims, wgrad=True, dgrad_layers=2)                      # actor step ...
+                           + mlp_flop(c_dims, dgrad_layers=2, first_dx_cols=ACT)))           # ... through critic 1
+    cpu = None
+    if with_cpu:
+        cfg = OS.TD3Config(twin=twin)
+        st = OS.TD3State.create(actor, c1, c2, cfg)
+        gc = torch.Generator().manual_seed(0)
+        obs, obs_next = torch.randn(B, OBS, generator=gc), torch.randn(B, OBS, generator=gc)
+        act, rew, noise = torch.rand(B, ACT, generator=gc) * 2 - 1, torch.randn(B, generator=gc), torch.randn(B, ACT, generator=gc)
+        th = _threads()
+
+        def one():
+            ret = rew + cfg.gamma * OS.td3_target_q(st, cfg, obs_next, noise).flatten()
+            OS.td3_update_with_batch(st, cfg, obs, act, ret)
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            one()
+        cpu = {"value": 40 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"40 updates of B={B} (target + critic steps + delayed actor step + Polyak), torch fp32 CPU oracle"}
+    name = "TD3" if twin else "DDPG"
+    return _line(f"{name} learn() updates/sec (B=4096, obs 376, act 17, hidden 256x256)", steps / dt, "updates/s", steps,
+                 warmup, dt, f"{name} on the C5 Humanoid-shape replay: {slots} slots, obs f32[376], act f32[17], B=4096",
+                 _roofline(prof, flop, "all linear-layer GEMMs of one update"), cpu,
+                 {"final_stats": [float(x) for x in stats.tolist()]})
+
+
+# ---- DiscreteSAC ---------------------------------------------------------------------------------------------------------
+def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
+    from oracle import oracle_dsac as ODS
+    from oracle import oracle_sac as OS
+    from tianshou_amd import dsac as DS
+    from tianshou_amd.buffer import gather_rows
+    from tianshou_amd.sac import SACConfig
+
+    OBS, A, HID, B, dev = 128, 18, 256, 4096, torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
+                       act=torch.randint(0, A, (slots,), generator=g, device=dev),
+                       obs_next=torch.randn(slots, OBS, generator=g, device=dev))
+    nets = ODS.init_params(OBS, A, HID, 0)
+    flats = [DS.net_flat_from_torch([p[k] for k in ODS.NET_ORDER], OBS, A, HID) for p in nets]
+    te = 0.98 * float(np.log(A))
+    eng = DS.DiscreteSACEngine(OBS, A, HID, *flats, SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3))
+
+    def update():
+        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        ret = eng.preprocess(buf, idx)
+        return eng.update_with_batch(gather_rows(buf.obs, idx), buf.act[idx], ret)[0]
+
+    dt, stats, prof = _time(update, steps, warmup)
+    dims = [OBS, HID, HID, A]
+    flop = B * (3 * mlp_flop(dims)                                       # target: actor + 2 lagged critics
+                + 2 * mlp_flop(dims, wgrad=True, dgrad_layers=2)         # critic steps
+                + 2 * mlp_flop(dims) + mlp_flop(dims, wgrad=True, dgrad_layers=2))   # actor step with both critics' Q
+    cpu = None
+    if with_cpu:
+        cfg = OS.SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3)
+        st = OS.SACState.create(*nets, cfg)
+        gc = torch.Generator().manual_seed(0)
+        obs, obs_next = torch.randn(B, OBS, generator=gc), torch.randn(B, OBS, generator=gc)
+        act, rew = torch.randint(0, A, (B,), generator=gc), torch.randn(B, generator=gc)
+        th = _threads()
+
+        def one():
+            ODS.update_with_batch(st, cfg, obs, act, rew + cfg.gamma * ODS.target_q(st, cfg, obs_next))
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(40):
+            one()
+        cpu = {"value": 40 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"40 updates of B={B} (target + 3 optimizer steps + alpha + Polyak), torch fp32 CPU oracle"}
+    return _line("DiscreteSAC learn() updates/sec (B=4096, obs 128, 18 actions, hidden 256x256, auto alpha)", steps / dt,
+                 "updates/s", steps, warmup, dt, f"DiscreteSAC, {slots}-slot replay, obs f32[128], 18 actions, B=4096",
+                 _roofline(prof, flop, "all linear-layer GEMMs of one update"), cpu,
+                 {"final_stats": [float(x) for x in stats.tolist()]})
+
+
+# ---- QRDQN / C51 (Atari shape, as C3) ----------------------------------------------------------------------------------
+def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
+    import bench_dqn as BD
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    C, H, W, A, B = BD.C, BD.H, BD.W, BD.N_ACT, BD.BATCH
+    N = 200 if kind == "qr" else 51
+    frames, act, buf, per = BD.build(slots, 16)
+    p = OQ.init_params(C, H, W, A, N, 0)
+    cfg = Q.DistQConfig(kind=kind, n_atoms=N, gamma=0.99, n_step=3, target_update_freq=500, lr=5e-5, v_min=-10.0, v_max=10.0)
+    eng = Q.DistQEngine(C, H, W, A, Q.flat_from_torch([p[k] for k in OD.PARAM_ORDER], C, H, W, A, N), cfg)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def update():
+        u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
+        idx, wt = per.sample(u)
+        ret = eng.preprocess(buf, frames, idx, C)
+        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
+        obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True) if kind == "c51" else None
+        loss, prio = eng.update_with_batch(obs, act[idx], ret, wt, obs_next_nhwc=obs_next)
+        per.update_weight(idx, prio)
+        return loss
+
+    dt, loss, prof = _time(update, steps, warmup)
+    fwd, wg, dg = cnn_flop(A * N)
+    flop = B * (3 * fwd + wg + dg)             # online + lagged pass on s', forward / backward on s
+    cpu = None
+    if with_cpu:
+        ocfg = OQ.DistQConfig(kind=kind, n_atoms=N, n_step=3, target_update_freq=500, lr=5e-5)
+        st = OD.DQNState.create(p, ocfg.dqn())
+        rng = np.random.default_rng(0)
+        obs = rng.integers(0, 256, size=(B, C, H, W), dtype=np.uint8)
+        obs_next = rng.integers(0, 256, size=(B, C, H, W), dtype=np.uint8)
+        a = rng.integers(0, A, size=B)
+        ret = rng.normal(size=(B, N)).astype(np.float32)
+        th = _threads()
+
+        def one():
+            if kind == "qr":
+                OQ.next_dist(st, ocfg, obs_next, A)
+            OQ.update_with_batch(st, ocfg, obs, a, ret, A, obs_next=obs_next)
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(12):
+            one()
+        cpu = {"value": 12 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"12 updates of B={B} (2 target forwards + fwd/bwd/Adam), torch fp32 CPU oracle"}
+    name = "QRDQN" if kind == "qr" else "C51"
+    return _line(f"{name} learn() updates/sec (B=512, NatureCNN, {N} {'quantiles' if kind == 'qr' else 'atoms'}, n-step 3, PER)",
+                 steps / dt, "updates/s", steps, warmup, dt,
+                 f"{name} on the C3 Atari-shape replay: {slots} slots of u8[84,84] frames, stack 4, 6 actions, B=512",
+                 _roofline(prof, flop, "conv / linear GEMMs of one update"), cpu, {"final_loss": float(loss)})
+
+
+# ---- PPO, CartPole shape (BASELINE.json configs[0]) ------------------------------------------------------------------------
+def run_ppo_discrete(steps, warmup, with_cpu):
+    from oracle import oracle_ppo as OP
+    from oracle import oracle_ppo_cnn as OC
+    from oracle import oracle_ppo_discrete as OD
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.ppo import PPOConfig
+
+    OBS, HID, A, E, T, BS, REPEAT, dev = 4, 64, 2, 20, 100, 64, 10, torch.device("cuda")   # test_ppo_discrete.py defaults
+    n = E * T
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = _flat_buffer(n, E, dev, g, obs=torch.randn(n, OBS, generator=g, device=dev),
+                       act=torch.randint(0, A, (n,), generator=g, device=dev),
+                       obs_next=torch.randn(n, OBS, generator=g, device=dev))
+    p = OD.init_params(OBS, HID, A, 1626)
+    kw = dict(gamma=0.99, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, value_clip=False,
+              advantage_normalization=False, return_scaling=False, lr=3e-4)
+    eng = PD.DiscretePPOEngine(OBS, HID, A, PD.flat_from_torch([p[k] for k in OD.PARAM_ORDER], OBS, HID, A), PPOConfig(**kw))
+    count = [0]
+
+    def update():
+        pre = eng.preprocess(buf)
+        perms = [torch.randperm(n, generator=g, device=dev) for _ in range(REPEAT)]
+        losses, k = eng.update(buf, pre, BS, REPEAT, perms)
+        count[0] = k
+        return losses
+
+    dt, losses, prof = _time(update, steps, warmup)
+    k = count[0]
+    dims = [OBS, HID, HID, A + 1]
+    flop = 2 * n * mlp_flop(dims) + k * BS * mlp_flop(dims, wgrad=True, dgrad_layers=2)
+    cpu = None
+    if with_cpu:
+        cfg = OP.PPOConfig(**kw)
+        st = OP.PPOState(params={kk: v.clone() for kk, v in p.items()})
+        net = OD.MlpNet(True)
+        cb = {kk: (v.cpu().numpy() if torch.is_tensor(v) else v) for kk, v in
+              dict(obs=buf.obs, obs_next=buf.obs_next, act=buf.act, rew=buf.rew, term=buf.terminated).items()}
+        th = _threads()
+        t0 = time.perf_counter()
+        idx = np.arange(n)
+        unf = np.arange(E) * T + T - 1
+        pre = OC.preprocess(st, cfg, cb["obs"], cb["obs_next"], cb["act"], cb["rew"], cb["term"], np.zeros(n, bool), idx, unf,
+                            net=net)
+        OC.update(st, cfg, cb["obs"], cb["act"], pre, BS, REPEAT, [np.random.permutation(n) for _ in range(REPEAT)], net=net)
+        cpu = {"value": k / (time.perf_counter() - t0), "unit": "update-steps/s", "cores": th, "kind": "port",
+               "sample": f"one update(): preprocessing of {n} transitions + {k} minibatch steps of 64, torch fp32 CPU oracle"}
+    return _line("PPO learn() update-steps/sec, CartPole shape (obs 4, MLP[64,64], minibatch 64, preprocessing incl.)",
+                 steps * k / dt, "update-steps/s", steps, warmup, dt,
+                 f"BASELINE configs[0] shape: {E} envs x {T} steps = {n} transitions, obs f32[4], 2 actions, repeat {REPEAT}",
+                 _roofline(prof, flop, "linear-layer GEMMs; launch-latency-bound at this size"), cpu,
+                 {"gradient_steps_per_update": k, "final_loss": float(losses[-1, 0])})
+
+
+RUNNERS = {
+    "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
+    "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),
+    "ppo_discrete": run_ppo_discrete,
+}
+
+
+def run(workload: str, steps: int, warmup: int, with_cpu: bool = True) -> dict:
+    return RUNNERS[workload](steps, warmup, with_cpu)
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=sorted(RUNNERS))
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    print(json.dumps(run(a.workload, a.steps, a.warmup, not a.no_cpu_baseline)), flush=True)
