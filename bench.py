@@ -155,6 +155,28 @@ def time_gae(learner, iters=50):
     return ms * 1e-3
 
 
+def time_gae_large(learner, log2n=24, iters=10):
+    """The same scan at 2^24 transitions (8192 envs x 2048 steps): the bandwidth the kernel reaches once the launch
+    and hand-off latencies are amortised ('also report N = 2^24 ... for asymptotic GB/s')."""
+    from tianshou_amd.returns import gae_scan
+
+    n, dev = 1 << log2n, learner.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    v, vn = torch.randn(n, generator=g, device=dev), torch.randn(n, generator=g, device=dev)
+    rew = torch.randn(n, generator=g, device=dev).double()
+    term = torch.rand(n, generator=g, device=dev) < 0.002
+    trunc = torch.zeros(n, dtype=torch.bool, device=dev)
+    cut = torch.arange(T_STEPS - 1, n, T_STEPS, device=dev, dtype=torch.int64)      # last slot of every sub-buffer
+    for _ in range(2):
+        gae_scan(v, vn, rew, term, trunc, cut)
+    torch.cuda.synchronize()
+    learner.ws.profile_begin()
+    for _ in range(iters):
+        gae_scan(v, vn, rew, term, trunc, cut)
+    prof = learner.ws.profile_end()
+    return n, (prof["gae_maps"][0] + prof["gae_apply"][0]) / iters * 1e-3
+
+
 def cpu_baseline(sample_steps=2):
     """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
     kernels) on the host cores, bounded sample: full preprocess of one 2^20 rollout in
@@ -314,6 +336,13 @@ def main():
                                  "traffic": GAE_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
                                  "avg_launch_us": t_gae * 1e6,
                                  "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * N_TRANS}
+        n_l, t_l = time_gae_large(learner)
+        gbps_l = GAE_BYTES_PER_TRANSITION * n_l / t_l / 1e9
+        extra["roofline_gae_2p24"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps_l,
+                                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_l / PEAK_HBM_GBPS,
+                                      "traffic": None, "avg_launch_us": t_l * 1e6, "transitions": n_l,
+                                      "transitions_per_s": n_l / t_l,
+                                      "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * n_l}
         t1 = time.perf_counter()
         for _ in range(3):
             learner.preprocess()

@@ -57,7 +57,7 @@ def test_gae_known_answers_from_reference_tests():
 
 @pytest.mark.parametrize("n,n_env,rew64", [(1, 1, True), (7, 1, False), (2048, 4, True),
                                            (2049, 1, True), (5000, 5, False), (65536, 64, True),
-                                           (300001, 7, True)])
+                                           (300001, 7, True), (300001, 1500, True), (70000, 9000, False)])
 def test_gae_matches_oracle_ragged_sizes(n, n_env, rew64):
     from tianshou_amd import returns as R
 
@@ -80,6 +80,45 @@ def test_gae_matches_oracle_ragged_sizes(n, n_env, rew64):
     np.testing.assert_allclose(out["returns"].cpu().numpy(), ret_o.astype(np.float32), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(float(out["ret_sum"]), ret_o.sum(), rtol=1e-10, atol=1e-8)
     np.testing.assert_allclose(float(out["ret_sumsq"]), (ret_o**2).sum(), rtol=1e-10)
+
+
+def _long_cut_case():
+    from tianshou_amd import returns as R
+
+    n, valid = 131_071, 3000
+    rng = np.random.default_rng(5)
+    v_s, v_n = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    rew = rng.normal(size=n)
+    term = rng.random(n) < 0.003
+    trunc = np.zeros(n, bool)
+    cuts = rng.permutation(n)[:valid]
+    cuts[:10] = n - 1 - np.arange(10)                                   # cuts in the partial last word
+    padded = np.concatenate([cuts, cuts[:50], rng.integers(0, n, size=1046)])   # duplicates, then ignored garbage
+    d_n = torch.tensor([valid + 50], dtype=torch.int64, device="cuda")
+    ret_o, adv_o = O.compute_episodic_return(rew, term, trunc, np.arange(n), np.unique(cuts), v_n, v_s, 0.99, 0.95)
+    out = R.gae_scan(dev(v_s), dev(v_n), dev(rew), dev(term), dev(trunc), dev(padded), gamma=0.99, gae_lambda=0.95,
+                     want_f64=True, d_n_cut=d_n)
+    scale = max(1.0, float(np.abs(adv_o).max()))
+    np.testing.assert_allclose(out["adv64"].cpu().numpy(), adv_o, rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(out["ret64"].cpu().numpy(), ret_o, rtol=0, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_gae_long_cut_list_with_device_side_count(two_pass):
+    """More than 1024 cuts go through the global cut bitmask; only the first *d_n_cut entries of the (unordered,
+    padded) cut list count, duplicates and the tail of the last word are harmless.  Both scan variants
+    (TS_GAE_TWO_PASS is read once per process, hence the child process)."""
+    if not two_pass:
+        _long_cut_case()
+        return
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_returns as t; t._long_cut_case()"], cwd=root,
+                       env={**os.environ, "TS_GAE_TWO_PASS": "1"}, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_gae_no_episode_end_carries_across_all_tiles():

@@ -16,6 +16,7 @@
 //
 // No FMA contraction in this file: the reference (numba, NumPy) rounds mul and add separately,
 // and the n-step path is required to be bit-exact in float64.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ts_common.h"
@@ -89,6 +90,8 @@ struct GaeArgs {
     int64_t n_cut;
     int64_t n;
     double gamma, gl, v_scale, ret_div;
+    const uint32_t* cutbits;    // nullable: bit i set <=> position i is a cut (built by gae_cutbits_kernel when the
+                                // cut list is too long for every tile to scan it)
 };
 
 // Raw inputs of the thread's GAE_ITEMS transitions (issued before anything that has to wait, so
@@ -175,9 +178,48 @@ __device__ __forceinline__ void gae_load_items(const GaeArgs<RewT>& g, int64_t b
     gae_convert(g, base, r, cutmask, vs, d, c);
 }
 
+constexpr int GAE_CUT_SCAN_MAX = 1024;     // longer cut lists go through the global bitmask
+
+// Bitmask path: the tile's 64 cut words, one per lane (every wave loads the same 256 bytes).
+struct GaeCutPre { uint32_t word; };
+
+template <typename RewT>
+__device__ __forceinline__ GaeCutPre gae_cut_prefetch(const GaeArgs<RewT>& g, int64_t tile_start) {
+    const int64_t w = tile_start / 32 + (threadIdx.x & 63);
+    const int64_t last = (g.n - 1) / 32;
+    GaeCutPre c;
+    c.word = g.cutbits[w < last ? w : last];
+    if (w > last) c.word = 0u;
+    return c;
+}
+
+template <typename RewT>
+__device__ __forceinline__ void gae_cutmask_from_prefetch(const GaeArgs<RewT>&, int64_t, const GaeCutPre& c,
+                                                          uint32_t* cutmask) {
+    if (threadIdx.x < GAE_TILE / 32) cutmask[threadIdx.x] = c.word;
+    __syncthreads();
+}
+
+// bits[i / 32] |= 1 << (i % 32) for every cut position i (the region is zeroed by the caller)
+__global__ __launch_bounds__(256) void gae_cutbits_kernel(const int64_t* __restrict__ cut_pos, int64_t n_cut,
+                                                          const int64_t* __restrict__ d_n_cut, int64_t n,
+                                                          uint32_t* __restrict__ bits) {
+    int64_t m = n_cut;
+    if (d_n_cut) { const int64_t dn = *d_n_cut; m = dn < m ? dn : m; }
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m; k += (int64_t)gridDim.x * 256) {
+        const int64_t p = cut_pos[k];
+        if (p >= 0 && p < n) atomicOr(&bits[p >> 5], 1u << (p & 31));
+    }
+}
+
 template <typename RewT>
 __device__ __forceinline__ void gae_build_cutmask(const GaeArgs<RewT>& g, int64_t tile_start,
                                                   uint32_t* cutmask) {
+    if (g.cutbits) {
+        const GaeCutPre c = gae_cut_prefetch(g, tile_start);
+        gae_cutmask_from_prefetch(g, tile_start, c, cutmask);
+        return;
+    }
     for (int k = threadIdx.x; k < GAE_TILE / 32; k += GAE_THREADS) cutmask[k] = 0u;
     __syncthreads();
     int64_t n_cut = g.n_cut;
@@ -394,9 +436,17 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
     double vs[GAE_ITEMS], d[GAE_ITEMS], c[GAE_ITEMS];
     const int64_t base = tile_start + (int64_t)threadIdx.x * GAE_ITEMS;
     {
+        // the tile's inputs are requested first; the cut information (its 64 words of the global bitmask, or a scan
+        // of the short cut list -- measured faster than prefetching list entries per thread) overlaps their latency
         GaeRaw raw;
-        gae_load_raw<RewT, VEC>(g, base, raw);      // HBM loads in flight ...
-        gae_build_cutmask(g, tile_start, cutmask);    // ... while the cut list is scattered into LDS
+        if (g.cutbits) {
+            const GaeCutPre cuts = gae_cut_prefetch(g, tile_start);
+            gae_load_raw<RewT, VEC>(g, base, raw);
+            gae_cutmask_from_prefetch(g, tile_start, cuts, cutmask);
+        } else {
+            gae_load_raw<RewT, VEC>(g, base, raw);
+            gae_build_cutmask(g, tile_start, cutmask);
+        }
         gae_convert(g, base, raw, cutmask, vs, d, c);
     }
     const Aff mine = items_to_aff(d, c);
@@ -644,9 +694,23 @@ bool gae_force_two_pass() {
 }
 
 template <typename RewT>
-int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g, float* adv_out, float* ret_out,
+int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g_in, float* adv_out, float* ret_out,
                double* adv64, double* ret64, double* ret_partials, hipStream_t stream) {
+    GaeArgs<RewT> g = g_in;
     const int64_t n_tiles = ts::ceil_div(g.n, GAE_TILE);
+    // workspace: [tile maps of the two-pass variant][cut bitmask]
+    const size_t maps_bytes = (sizeof(double2) * (size_t)n_tiles + 255) & ~size_t(255);
+    g.cutbits = nullptr;
+    if (g.n_cut > GAE_CUT_SCAN_MAX) {
+        const size_t words = (size_t)ts::ceil_div(g.n, 32);
+        if (int rc = ts::ws_reserve(ws, maps_bytes + 4 * words)) return rc;
+        uint32_t* bits = reinterpret_cast<uint32_t*>(static_cast<char*>(ws->base) + maps_bytes);
+        TS_HIP_CHECK(hipMemsetAsync(bits, 0, 4 * words, stream));
+        const unsigned blocks = (unsigned)std::min<int64_t>(ts::ceil_div(g.n_cut, 256), 1024);
+        hipLaunchKernelGGL(gae_cutbits_kernel, dim3(blocks), dim3(256), 0, stream, g.cut_pos, g.n_cut, g.d_n_cut, g.n, bits);
+        TS_LAUNCH_CHECK();
+        g.cutbits = bits;
+    }
     const bool vec = aligned16(g.v_s) && aligned16(g.v_n) && aligned16(g.rew) &&
                      (reinterpret_cast<uintptr_t>(g.term) & 7u) == 0 &&
                      (reinterpret_cast<uintptr_t>(g.trunc) & 7u) == 0 && aligned16(adv_out) &&
@@ -679,7 +743,7 @@ int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g, float* adv_out, float* 
         TS_LAUNCH_CHECK();
         return TS_OK;
     }
-    int rc = ts::ws_reserve(ws, sizeof(double2) * (size_t)n_tiles);
+    int rc = ts::ws_reserve(ws, maps_bytes + (g.cutbits ? 4 * (size_t)ts::ceil_div(g.n, 32) : 0));
     if (rc != TS_OK) return rc;
     double2* maps = reinterpret_cast<double2*>(ws->base);
     {
