@@ -1009,7 +1009,7 @@ def gen_ppo_cnn(tag: str = "cnn", *, E: int = 3, T: int = 20, c: int = 2, h: int
 
 
 def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_act: int, batch_size: int, repeat: int,
-                     seed: int, softmax_output: bool, lr: float = 3e-4, **ppo_kwargs) -> None:
+                     seed: int, softmax_output: bool, lr: float = 3e-4, algo: str = "ppo", **ppo_kwargs) -> None:
     """Runs the reference PPO.update() with the CartPole-shape networks of test/discrete/test_ppo_discrete.py:88-127
     (BASELINE.json configs[0]): Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, orthogonal init."""
     from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy
@@ -1039,7 +1039,10 @@ def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_a
                                      action_space=gym.spaces.Discrete(n_act))
     else:
         policy = DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
-    algorithm = PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+    from tianshou.algorithm.modelfree.a2c import A2C
+
+    cls = PPO if algo == "ppo" else A2C
+    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
 
     N = E * T
     buf = VectorReplayBuffer(N, E)
@@ -1059,7 +1062,7 @@ def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_a
         out["buf_" + k] = v
 
     perms, seqs, pre_dump = [], [], {}
-    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, PPO._preprocess_batch
+    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, cls._preprocess_batch
 
     def rec_perm(n):
         p = orig_perm(n)
@@ -1073,18 +1076,19 @@ def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_a
     def rec_pre(self, batch, buffer, indices):
         b = orig_pre(self, batch, buffer, indices)
         pre_dump.update(v_s=b.v_s.numpy().copy(), returns=b.returns.numpy().copy(), adv=b.adv.numpy().copy(),
-                        logp_old=b.logp_old.numpy().copy(), indices=np.asarray(indices, np.int64),
-                        unfinished=np.asarray(buffer.unfinished_index(), np.int64))
+                        indices=np.asarray(indices, np.int64), unfinished=np.asarray(buffer.unfinished_index(), np.int64))
+        if algo == "ppo":
+            pre_dump["logp_old"] = b.logp_old.numpy().copy()
         return b
 
-    np.random.permutation, PPO._preprocess_batch = rec_perm, rec_pre
+    np.random.permutation, cls._preprocess_batch = rec_perm, rec_pre
     SequenceSummaryStats.from_sequence = classmethod(rec_from)
     try:
         np.random.seed(seed + 100)
         with policy_within_training_step(algorithm.policy):
             stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
     finally:
-        np.random.permutation, PPO._preprocess_batch = orig_perm, orig_pre
+        np.random.permutation, cls._preprocess_batch = orig_perm, orig_pre
         SequenceSummaryStats.from_sequence = classmethod(orig_from)
     assert len(perms) == repeat and len(seqs) == 4
     out["perms"], out["losses"] = np.stack(perms), np.stack(seqs, axis=1)
@@ -1093,12 +1097,12 @@ def gen_ppo_discrete(tag: str, *, E: int, T: int, obs_dim: int, hidden: int, n_a
     out["ret_rms"] = np.array([float(algorithm.ret_rms.mean), float(algorithm.ret_rms.var), float(algorithm.ret_rms.count)])
     for k, v in pre_dump.items():
         out["pre_" + k] = v
-    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
-               dual_clip=algorithm.dual_clip or 0.0, value_clip=float(algorithm.value_clip),
-               advantage_normalization=float(algorithm.advantage_normalization), vf_coef=algorithm.vf_coef,
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=getattr(algorithm, "eps_clip", 0.2),
+               dual_clip=getattr(algorithm, "dual_clip", None) or 0.0, value_clip=float(getattr(algorithm, "value_clip", False)),
+               advantage_normalization=float(getattr(algorithm, "advantage_normalization", False)), vf_coef=algorithm.vf_coef,
                ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
                return_scaling=float(algorithm.return_scaling), lr=lr, adam_eps=1e-8,
-               max_batchsize=float(algorithm.max_batchsize))
+               max_batchsize=float(algorithm.max_batchsize), a2c=float(algo == "a2c"))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_discrete_{tag}.npz"), **out)
 
@@ -1114,6 +1118,10 @@ def gen_ppo_discrete_all() -> None:
                      softmax_output=False, gamma=0.97, gae_lambda=0.9, max_grad_norm=0.7, vf_coef=0.25, ent_coef=0.01,
                      eps_clip=0.15, return_scaling=True, value_clip=True, dual_clip=3.0,
                      advantage_normalization=True, recompute_advantage=False, max_batchsize=64)
+    # A2C (a2c.py:249-290) on the same networks
+    gen_ppo_discrete("a2c", E=3, T=40, obs_dim=6, hidden=64, n_act=3, batch_size=32, repeat=2, seed=9, algo="a2c",
+                     softmax_output=True, gamma=0.98, gae_lambda=0.92, max_grad_norm=0.5, vf_coef=0.5, ent_coef=0.02,
+                     return_scaling=True, max_batchsize=64)
 
 
 def gen_buffer_add() -> None:

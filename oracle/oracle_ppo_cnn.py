@@ -139,7 +139,14 @@ def preprocess(st: OP.PPOState, cfg: OP.PPOConfig, obs, obs_next, act, rew, term
 
 
 def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s, net=_CnnNet):
-    """ppo.py:179-211 -> (loss, clip_loss, vf_loss, ent_loss)."""
+    """ppo.py:179-211 (cfg.algo "ppo") or a2c.py:262-273 ("a2c") -> (loss, clip / actor loss, vf_loss, ent_loss)."""
+    if cfg.algo == "a2c":
+        dist = net.dist(p, obs)
+        log_prob = dist.log_prob(act).reshape(len(adv), -1).transpose(0, 1)
+        actor_loss = -(log_prob * adv).mean()
+        vf_loss = F.mse_loss(returns, net.critic_forward(p, obs).flatten())
+        ent_loss = dist.entropy().mean()
+        return actor_loss + cfg.vf_coef * vf_loss - cfg.ent_coef * ent_loss, actor_loss, vf_loss, ent_loss
     if cfg.advantage_normalization:
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     dist = net.dist(p, obs)

@@ -22,7 +22,8 @@ def engine_cfg(cfg):
     return PPOConfig(gamma=cfg.gamma, gae_lambda=cfg.gae_lambda, eps_clip=cfg.eps_clip, dual_clip=cfg.dual_clip,
                      value_clip=cfg.value_clip, advantage_normalization=cfg.advantage_normalization,
                      vf_coef=cfg.vf_coef, ent_coef=cfg.ent_coef, max_grad_norm=cfg.max_grad_norm,
-                     return_scaling=cfg.return_scaling, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps)
+                     return_scaling=cfg.return_scaling, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps,
+                     algo=cfg.algo)
 
 
 @pytest.mark.parametrize("c,h,w,A", [(4, 84, 84, 6), (2, 44, 36, 4), (1, 36, 36, 31)])
@@ -70,9 +71,10 @@ def test_update_matches_reference_golden():
     np.testing.assert_allclose(flat[::17], g["params_strided"], rtol=1e-5, atol=0.05 * cfg.lr)
 
 
-@pytest.mark.parametrize("adv_norm,dual,vclip", [(True, None, True), (False, 3.0, False)])
-def test_minibatch_gradient_vs_oracle(adv_norm, dual, vclip):
-    """Atari-size observations, B = 192: losses and every layer's gradient of one minibatch."""
+@pytest.mark.parametrize("adv_norm,dual,vclip,algo", [(True, None, True, "ppo"), (False, 3.0, False, "ppo"),
+                                                      (False, None, False, "a2c")])
+def test_minibatch_gradient_vs_oracle(adv_norm, dual, vclip, algo):
+    """Atari-size observations, B = 192: losses and every layer's gradient of one minibatch (PPO and A2C objectives)."""
     from tianshou_amd import ppo_cnn as PC
 
     c, h, w, A, B = 4, 84, 84, 6, 192
@@ -88,7 +90,7 @@ def test_minibatch_gradient_vs_oracle(adv_norm, dual, vclip):
             + torch.as_tensor(rng.normal(size=B).astype(np.float32) * 0.2)
         v_old = OC.critic_forward(p, obs).flatten() + torch.as_tensor(rng.normal(size=B).astype(np.float32) * 0.3)
     cfg = OP.PPOConfig(eps_clip=0.1, dual_clip=dual, value_clip=vclip, advantage_normalization=adv_norm, vf_coef=0.25,
-                       ent_coef=0.01, max_grad_norm=0.5, lr=2.5e-4, adam_eps=1e-5)
+                       ent_coef=0.01, max_grad_norm=0.5, lr=2.5e-4, adam_eps=1e-5, algo=algo)
     pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     loss, clip, vf, ent = OC.minibatch_loss(pg, cfg, torch.as_tensor(obs).float(), torch.as_tensor(act), adv, ret,
                                             logp_old, v_old)

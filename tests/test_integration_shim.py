@@ -757,3 +757,48 @@ def test_hip_ppo_discrete_wrapper_runs_with_engine_double(monkeypatch):
     assert torch.allclose(head.detach(), before_h + 1.0) and torch.allclose(trunk.detach(), before_t + 1.0)
     st = algo.optim._optim.state[head]
     assert float(st["step"]) == 6.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.5))
+
+
+# ------------------------------------------------------------------------------------ A2C variants of the on-policy subclasses
+def test_a2c_subclasses_map_hyperparameters_and_fail_loudly():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.a2c import A2C
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy, ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+    from tianshou.utils.torch_utils import policy_within_training_step
+    from tianshou_amd import integration as I
+
+    kw = dict(optim=AdamOptimizerFactory(lr=7e-4), gamma=0.98, gae_lambda=0.9, vf_coef=0.4, ent_coef=0.02, max_grad_norm=0.6,
+              return_scaling=True, device="cpu")
+    net = Net(state_shape=(4,), hidden_sizes=[64, 64])
+    actor = DiscreteActor(preprocess_net=net, action_shape=2, softmax_output=False)
+    disc = I.make_hip_a2c_discrete()(policy=DiscreteActorPolicy(actor=actor, action_space=gym.spaces.Discrete(2)),
+                                     critic=DiscreteCritic(preprocess_net=net), **kw)
+    a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=torch.nn.Tanh),
+                                     action_shape=(6,), unbounded=True)
+    c = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=torch.nn.Tanh))
+
+    def dist_fn(loc_scale):
+        return torch.distributions.Independent(torch.distributions.Normal(*loc_scale), 1)
+
+    pol = ProbabilisticActorPolicy(actor=a, dist_fn=dist_fn, action_space=gym.spaces.Box(-1, 1, (6,)))
+    cont = I.make_hip_a2c()(policy=pol, critic=c, **kw)
+    for algo, name in ((disc, "HipA2CDiscrete"), (cont, "HipA2C")):
+        assert isinstance(algo, A2C) and type(algo).__name__ == name and not hasattr(algo, "eps_clip")
+        cfg = I.ppo_config_from(algo)
+        assert cfg.algo == "a2c" and (cfg.vf_coef, cfg.ent_coef, cfg.max_grad_norm, cfg.lr) == (0.4, 0.02, 0.6, 7e-4)
+        assert (cfg.gamma, cfg.gae_lambda, cfg.return_scaling) == (0.98, 0.9, True) and cfg.to_c().algo == 1
+        for name_ in ("_preprocess_batch", "_update_with_batch"):
+            mine, ref = inspect.signature(getattr(type(algo), name_)), inspect.signature(getattr(A2C, name_))
+            assert list(mine.parameters) == list(ref.parameters), name_
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (4,), np.zeros(2, np.int64))
+    with policy_within_training_step(disc.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        disc.update(buffer=buf, batch_size=8, repeat=1)
+    assert issubclass(I.make_hip_a2c_cnn(), A2C) and I.make_hip_a2c_cnn().__name__ == "HipA2CCnn"

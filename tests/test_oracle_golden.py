@@ -394,13 +394,13 @@ def load_ppo_discrete(tag):
                         advantage_normalization=bool(cv["advantage_normalization"]), vf_coef=cv["vf_coef"],
                         ent_coef=cv["ent_coef"], max_grad_norm=cv["max_grad_norm"] or None,
                         return_scaling=bool(cv["return_scaling"]), lr=cv["lr"], adam_eps=cv["adam_eps"],
-                        max_batchsize=int(cv["max_batchsize"]))
+                        max_batchsize=int(cv["max_batchsize"]), algo="a2c" if cv.get("a2c") else "ppo")
     d = dict(E=E, T=T, obs_dim=obs_dim, hidden=hidden, n_act=n_act, batch_size=batch_size, repeat=repeat, seed=seed,
              softmax=bool(softmax))
     return g, d, cfg
 
 
-@pytest.mark.parametrize("tag", ["c1", "opts"])
+@pytest.mark.parametrize("tag", ["c1", "opts", "a2c"])
 def test_ppo_discrete_restatement_matches_reference(tag):
     """BASELINE.json configs[0] (CartPole shape: obs 4, MLP[64, 64] shared by a softmax actor and a critic, batch 64)
     and an every-option variant: oracle_ppo_discrete against the unmodified reference PPO.update()."""
@@ -414,7 +414,7 @@ def test_ppo_discrete_restatement_matches_reference(tag):
     assert np.array_equal(idx, np.arange(d["E"] * d["T"]))
     pre = OC.preprocess(st, cfg, g["obs"], g["obs_next"], g["act"], g["rew"], g["terminated"], g["truncated"], idx, unf,
                         net=net)
-    for k in ("v_s", "returns", "adv", "logp_old"):
+    for k in ("v_s", "returns", "adv") + (("logp_old",) if cfg.algo == "ppo" else ()):
         np.testing.assert_allclose(pre[k].numpy(), g["pre_" + k], rtol=1e-5, atol=1e-5, err_msg=k)
     losses = OC.update(st, cfg, g["obs"], g["act"], pre, d["batch_size"], d["repeat"], g["perms"], net=net)
     assert len(losses) == int(g["gradient_steps"])

@@ -150,6 +150,7 @@ struct LossArgs {
     const float* adv_stats;      // {mean, std} of this minibatch's advantages (nullable)
     int64_t B; int A;
     float eps_clip, dual_clip, vf_coef, ent_coef; int value_clip;
+    int algo;                    // 0: PPO (ppo.py:184-211), 1: A2C (a2c.py:262-273)
     float* d_head;               // [B, 32]
     float* partials;             // [blocks, 3]: sums of clip term, value term, entropy
 };
@@ -170,20 +171,25 @@ __global__ __launch_bounds__(256) void cnn_ppo_loss_kernel(LossArgs g) {
         const float logp = hb[a] - lse;
         float Ad = g.adv[b];
         if (g.adv_stats) Ad = (Ad - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);            // ppo.py:184-186
-        const float ratio = expf(logp - g.logp_old[b]);
-        const float surr1 = ratio * Ad;
-        const float surr2 = fminf(fmaxf(ratio, 1.f - g.eps_clip), 1.f + g.eps_clip) * Ad;
-        const float clip1 = fminf(surr1, surr2);
-        float basek = (surr1 <= surr2) ? Ad : 0.f;                // torch.min backward (ties: both branches equal)
-        float term;
-        if (g.dual_clip > 0.f) {
-            const float clip2 = fmaxf(clip1, g.dual_clip * Ad);
-            if (Ad < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * Ad)) basek = 0.f; }
-            else term = -clip1;
+        float term, dlogp;
+        if (g.algo == 1) {                                        // actor_loss = -(log_prob * adv).mean()
+            term = -(logp * Ad);
+            dlogp = -Ad * w;
         } else {
-            term = -clip1;
+            const float ratio = expf(logp - g.logp_old[b]);
+            const float surr1 = ratio * Ad;
+            const float surr2 = fminf(fmaxf(ratio, 1.f - g.eps_clip), 1.f + g.eps_clip) * Ad;
+            const float clip1 = fminf(surr1, surr2);
+            float basek = (surr1 <= surr2) ? Ad : 0.f;            // torch.min backward (ties: both branches equal)
+            if (g.dual_clip > 0.f) {
+                const float clip2 = fmaxf(clip1, g.dual_clip * Ad);
+                if (Ad < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * Ad)) basek = 0.f; }
+                else term = -clip1;
+            } else {
+                term = -clip1;
+            }
+            dlogp = -basek * ratio * w;
         }
-        const float dlogp = -basek * ratio * w;
         for (int j = 0; j < HEAD; ++j) {
             float d = 0.f;
             if (j < A) {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void cnn_ppo_loss_kernel(LossArgs g) {
         const float value = hb[A], ret = g.ret[b];
         const float vf1 = (ret - value) * (ret - value);
         float vterm, dv;
-        if (g.value_clip) {                                                   // ppo.py:199-206
+        if (g.value_clip && g.algo == 0) {                                    // ppo.py:199-206
             const float vo = g.v_old[b], dvo = value - vo;
             const float vclip = vo + fminf(fmaxf(dvo, -g.eps_clip), g.eps_clip);
             const float vf2 = (ret - vclip) * (ret - vclip);
@@ -273,8 +279,9 @@ int ac_ppo_step(ts_workspace* ws, const Net& n, float* params, float* adam_m, fl
                 const void* obs, bool obs_u8, const int64_t* act, const float* adv, const float* returns,
                 const float* logp_old, const float* v_old, int64_t B, const float* adv_stats, const ts_ppo_hparams* hp,
                 float* losses_out4, float* grad_out, hipStream_t s, const char* who) {
-    TS_REQUIRE(hp->algo == 0, TS_ERR_UNSUPPORTED, "%s: only the PPO objective (algo 0)", who);
-    TS_REQUIRE(!hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "%s: adv_norm needs adv_stats", who);
+    TS_REQUIRE(hp->algo == 0 || hp->algo == 1, TS_ERR_UNSUPPORTED, "%s: algo must be 0 (PPO) or 1 (A2C)", who);
+    TS_REQUIRE(hp->algo == 1 || (logp_old && v_old), TS_ERR_INVALID_ARG, "%s: PPO needs logp_old and v_old", who);
+    TS_REQUIRE(hp->algo == 1 || !hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "%s: adv_norm needs adv_stats", who);
     const int nl = n.nl;
     const int64_t P = n.off[nl];
     const int n_blocks = (int)ts::ceil_div(B, 256);
@@ -298,10 +305,10 @@ int ac_ppo_step(ts_workspace* ws, const Net& n, float* params, float* adam_m, fl
     if (int rc = net_forward(s, ws, n, params, x0, obs_u8, a)) return rc;
     LossArgs la{};
     la.head = a.h[nl - 1]; la.act = act; la.adv = adv; la.ret = returns; la.logp_old = logp_old; la.v_old = v_old;
-    la.adv_stats = hp->adv_norm ? adv_stats : nullptr;
+    la.adv_stats = (hp->adv_norm && hp->algo == 0) ? adv_stats : nullptr;      // A2C does not normalise
     la.B = B; la.A = n.n_act;
     la.eps_clip = (float)hp->eps_clip; la.dual_clip = (float)hp->dual_clip; la.vf_coef = (float)hp->vf_coef;
-    la.ent_coef = (float)hp->ent_coef; la.value_clip = hp->value_clip;
+    la.ent_coef = (float)hp->ent_coef; la.value_clip = hp->value_clip; la.algo = hp->algo;
     la.d_head = dy[nl - 1]; la.partials = partials;
     hipLaunchKernelGGL(cnn_ppo_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, la);
     hipLaunchKernelGGL(cnn_loss_finish_kernel, dim3(1), dim3(256), 0, s, partials, n_blocks, B, (float)hp->vf_coef,
@@ -377,8 +384,8 @@ int ts_mlp_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_ppo_step: workspace is NULL");
     TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_mlp_ppo_step: bad batch size / step");
-    TS_REQUIRE(params && adam_m && adam_v && obs && act && adv && returns && logp_old && v_old && hp && losses_out4,
-               TS_ERR_INVALID_ARG, "ts_mlp_ppo_step: NULL argument");
+    TS_REQUIRE(params && adam_m && adam_v && obs && act && adv && returns && hp && losses_out4, TS_ERR_INVALID_ARG,
+               "ts_mlp_ppo_step: NULL argument");
     Net n;
     if (int rc = make_mlp_net((int)B, obs_dim, hidden, n_act, &n)) return rc;
     return ac_ppo_step(ws, n, params, adam_m, adam_v, adam_step, obs, false, act, adv, returns, logp_old, v_old, B,
@@ -392,8 +399,8 @@ int ts_cnn_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_cnn_ppo_step: workspace is NULL");
     TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_cnn_ppo_step: bad batch size / step");
-    TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && adv && returns && logp_old && v_old && hp &&
-                   losses_out4, TS_ERR_INVALID_ARG, "ts_cnn_ppo_step: NULL argument");
+    TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && adv && returns && hp && losses_out4, TS_ERR_INVALID_ARG,
+               "ts_cnn_ppo_step: NULL argument");
     Net n;
     if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
     return ac_ppo_step(ws, n, params, adam_m, adam_v, adam_step, obs_nhwc, obs_u8 != 0, act, adv, returns, logp_old, v_old,

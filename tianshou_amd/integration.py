@@ -26,13 +26,26 @@ def ppo_config_from(algorithm) -> PPOConfig:
     g = opt.param_groups[0]
     if type(opt).__name__ != "Adam" or g.get("weight_decay", 0) != 0 or g.get("amsgrad", False):
         raise NotImplementedError("HipPPO supports torch.optim.Adam without weight decay / amsgrad")
+    is_ppo = hasattr(algorithm, "eps_clip")                  # A2C (a2c.py:187-247) has none of the clipping options
     return PPOConfig(
-        gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=algorithm.eps_clip,
-        dual_clip=algorithm.dual_clip, value_clip=algorithm.value_clip,
-        advantage_normalization=algorithm.advantage_normalization,
-        recompute_advantage=algorithm.recompute_adv, vf_coef=algorithm.vf_coef,
+        algo="ppo" if is_ppo else "a2c",
+        gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=getattr(algorithm, "eps_clip", 0.2),
+        dual_clip=getattr(algorithm, "dual_clip", None), value_clip=getattr(algorithm, "value_clip", False),
+        advantage_normalization=getattr(algorithm, "advantage_normalization", False),
+        recompute_advantage=getattr(algorithm, "recompute_adv", False), vf_coef=algorithm.vf_coef,
         ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm,
         return_scaling=algorithm.return_scaling, lr=g["lr"], betas=tuple(g["betas"]), adam_eps=g["eps"])
+
+
+def _on_policy_base(algo: str):
+    """PPO (ppo.py) or A2C (a2c.py:187-290): the hooks and the statistics class are the same."""
+    if algo == "ppo":
+        from tianshou.algorithm.modelfree.ppo import PPO as Base
+    elif algo == "a2c":
+        from tianshou.algorithm.modelfree.a2c import A2C as Base
+    else:
+        raise ValueError("algo must be 'ppo' or 'a2c'")
+    return Base
 
 
 def _check_supported(actor, critic) -> tuple[int, int]:
@@ -53,11 +66,12 @@ def _check_supported(actor, critic) -> tuple[int, int]:
     return int(w1.shape[1]), int(sa["mu.model.0.weight"].shape[0])
 
 
-def make_hip_ppo():
-    """Returns the HipPPO class (imports tianshou lazily)."""
+def make_hip_ppo(algo: str = "ppo"):
+    """Returns the HipPPO class (imports tianshou lazily); algo="a2c": HipA2C(A2C), same networks."""
     from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.algorithm.modelfree.ppo import PPO
     from tianshou.data import SequenceSummaryStats
+
+    PPO = _on_policy_base(algo)
 
     class HipPPO(PPO):
         def __init__(self, *args, device="cuda", **kwargs):
@@ -106,7 +120,9 @@ def make_hip_ppo():
                                t(batch.terminated), t(batch.truncated), t(cut))
             self._hip_batch = b
             batch.v_s, batch.returns, batch.adv = b["v_s"], b["returns"], b["adv"]
-            batch.act, batch.logp_old = b["act"], b["logp_old"]
+            batch.act = b["act"]
+            if b.get("logp_old") is not None:                                  # A2C has none (a2c.py:239-247)
+                batch.logp_old = b["logp_old"]
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
@@ -124,7 +140,24 @@ def make_hip_ppo():
                 gradient_steps=steps,
             )
 
+    if algo == "a2c":
+        HipPPO.__name__ = HipPPO.__qualname__ = "HipA2C"
     return HipPPO
+
+
+def make_hip_a2c():
+    """HipA2C(A2C) on the MuJoCo actor-critic of HipPPO (a2c.py:249-290 = the fused step kernel's algo 1)."""
+    return make_hip_ppo("a2c")
+
+
+def make_hip_a2c_discrete():
+    """HipA2CDiscrete(A2C) on the shared-trunk MLP of HipPPODiscrete."""
+    return make_hip_ppo_discrete("a2c")
+
+
+def make_hip_a2c_cnn():
+    """HipA2CCnn(A2C) on the Atari actor-critic of HipPPOCnn."""
+    return make_hip_ppo_cnn("a2c")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -605,12 +638,13 @@ def make_hip_discrete_sac():
 # ---------------------------------------------------------------------------------------------------
 # PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-135)
 # ---------------------------------------------------------------------------------------------------
-def make_hip_ppo_cnn():
+def make_hip_ppo_cnn(algo: str = "ppo"):
     """Returns HipPPOCnn(PPO) for DQNet(features_only=True, output_dim_added_layer=512) shared by
-    DiscreteActor(softmax_output=False) and DiscreteCritic; Categorical policy; Adam."""
+    DiscreteActor(softmax_output=False) and DiscreteCritic; Categorical policy; Adam.  algo="a2c": HipA2CCnn(A2C)."""
     from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.algorithm.modelfree.ppo import PPO
     from tianshou.data import SequenceSummaryStats
+
+    PPO = _on_policy_base(algo)
 
     from . import ppo_cnn as PC
 
@@ -624,7 +658,7 @@ def make_hip_ppo_cnn():
                     or actor.preprocess is not critic.preprocess or getattr(actor, "softmax_output", True):
                 raise NotImplementedError("HipPPOCnn: actor / critic must share one DQNet(features_only=True, "
                                           "output_dim_added_layer=512) trunk with single-Linear heads (logits)")
-            if self.recompute_adv:
+            if getattr(self, "recompute_adv", False):
                 raise NotImplementedError("HipPPOCnn: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
@@ -682,21 +716,25 @@ def make_hip_ppo_cnn():
                 vf_loss=SequenceSummaryStats.from_sequence(arr[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(arr[:, 3]),
                 gradient_steps=steps)
 
+    if algo == "a2c":
+        HipPPOCnn.__name__ = HipPPOCnn.__qualname__ = "HipA2CCnn"
     return HipPPOCnn
 
 
 # ---------------------------------------------------------------------------------------------------
 # PPO on the CartPole-shape networks (BASELINE.json configs[0], test/discrete/test_ppo_discrete.py:88-127)
 # ---------------------------------------------------------------------------------------------------
-def make_hip_ppo_discrete():
+def make_hip_ppo_discrete(algo: str = "ppo"):
     """Returns HipPPODiscrete(PPO) for Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, Categorical policy
     (`softmax_output=True` with `dist_fn=torch.distributions.Categorical`, or `softmax_output=False` with the default
-    logits dist_fn), Adam; h a multiple of 32, at most 31 actions; the buffer must store obs_next."""
+    logits dist_fn), Adam; h a multiple of 32, at most 31 actions; the buffer must store obs_next.
+    algo="a2c": HipA2CDiscrete(A2C)."""
     from torch.distributions import Categorical
 
     from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.algorithm.modelfree.ppo import PPO
     from tianshou.algorithm.modelfree.reinforce import dist_fn_categorical_from_logits
+
+    PPO = _on_policy_base(algo)
     from tianshou.data import SequenceSummaryStats
 
     from . import ppo_discrete as PD
@@ -720,7 +758,7 @@ def make_hip_ppo_discrete():
             if not ((softmax and dist_fn is Categorical) or (not softmax and dist_fn is dist_fn_categorical_from_logits)):
                 raise NotImplementedError("HipPPODiscrete: softmax_output=True needs dist_fn=Categorical, "
                                           "softmax_output=False the logits dist_fn")
-            if self.recompute_adv:
+            if getattr(self, "recompute_adv", False):
                 raise NotImplementedError("HipPPODiscrete: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
@@ -769,6 +807,8 @@ def make_hip_ppo_discrete():
                 vf_loss=SequenceSummaryStats.from_sequence(arr[:, 2]), ent_loss=SequenceSummaryStats.from_sequence(arr[:, 3]),
                 gradient_steps=steps)
 
+    if algo == "a2c":
+        HipPPODiscrete.__name__ = HipPPODiscrete.__qualname__ = "HipA2CDiscrete"
     return HipPPODiscrete
 
 

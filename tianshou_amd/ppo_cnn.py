@@ -116,8 +116,8 @@ class CnnPPOEngine:
     def __init__(self, c: int, h: int, w: int, n_act: int, flat_params: torch.Tensor, cfg: PPOConfig):
         if not flat_params.is_cuda:
             raise RuntimeError("CnnPPOEngine needs parameters on an MI355X (no CPU fallback)")
-        if cfg.algo != "ppo" or cfg.recompute_advantage:
-            raise NotImplementedError("CnnPPOEngine: PPO objective without recompute_advantage")
+        if cfg.algo not in ("ppo", "a2c") or cfg.recompute_advantage:
+            raise NotImplementedError("CnnPPOEngine: PPO or A2C objective, without recompute_advantage")
         off, _ = layer_layout(c, h, w, n_act)
         self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
         self.P = int(off[5])
@@ -168,8 +168,8 @@ class CnnPPOEngine:
                 "logp_old": logp_old}
 
     # -- one minibatch step ---------------------------------------------------------------------------------------
-    def step(self, obs_nhwc, act, adv, returns, logp_old, v_old, grad_out=None, apply: bool = True) -> torch.Tensor:
-        """-> losses float32[4] = {loss, clip, vf, ent} (device)."""
+    def step(self, obs_nhwc, act, adv, returns, logp_old=None, v_old=None, grad_out=None, apply: bool = True) -> torch.Tensor:
+        """-> losses float32[4] = {loss, clip / actor, vf, ent} (device).  logp_old / v_old: PPO only."""
         cfg = self.cfg
         b = obs_nhwc.shape[0]
         adv = torch.as_tensor(adv, device=self.device)
@@ -180,7 +180,7 @@ class CnnPPOEngine:
         if not apply:
             hp.lr = -1.0
         losses = torch.empty(4, dtype=torch.float32, device=self.device)
-        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        f32 = lambda t: None if t is None else t.to(torch.float32).contiguous()  # noqa: E731
         obs_nhwc = obs_nhwc.contiguous()
         _lib.check(_lib.load().ts_cnn_ppo_step(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),

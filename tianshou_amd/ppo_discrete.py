@@ -61,8 +61,8 @@ class DiscretePPOEngine:
     def __init__(self, obs_dim: int, hidden: int, n_act: int, flat_params: torch.Tensor, cfg: PPOConfig):
         if not flat_params.is_cuda:
             raise RuntimeError("DiscretePPOEngine needs parameters on an MI355X (no CPU fallback)")
-        if cfg.algo != "ppo" or cfg.recompute_advantage:
-            raise NotImplementedError("DiscretePPOEngine: PPO objective without recompute_advantage")
+        if cfg.algo not in ("ppo", "a2c") or cfg.recompute_advantage:
+            raise NotImplementedError("DiscretePPOEngine: PPO or A2C objective, without recompute_advantage")
         self.obs_dim, self.hidden, self.n_act, self.cfg = obs_dim, hidden, n_act, cfg
         self.P = layout(obs_dim, hidden, n_act)["count"]
         if flat_params.numel() != self.P:
@@ -109,13 +109,15 @@ class DiscretePPOEngine:
                 "logp_old": logp_old}
 
     # -- one minibatch step ---------------------------------------------------------------------------------------
-    def step(self, obs, act, adv, returns, logp_old, v_old, grad_out=None, apply: bool = True) -> torch.Tensor:
-        """-> losses float32[4] = {loss, clip, vf, ent} (device)."""
+    def step(self, obs, act, adv, returns, logp_old=None, v_old=None, grad_out=None, apply: bool = True) -> torch.Tensor:
+        """-> losses float32[4] = {loss, clip / actor, vf, ent} (device).  logp_old / v_old: PPO only."""
         obs = self._obs(obs)
         b = obs.shape[0]
-        f32 = lambda t: torch.as_tensor(t, device=self.device).to(torch.float32).reshape(-1).contiguous()  # noqa: E731
+        f32 = lambda t: None if t is None else torch.as_tensor(t, device=self.device).to(torch.float32).reshape(-1).contiguous()  # noqa: E731
         act, adv, returns, logp_old, v_old = _i64_dev(act, self.device).reshape(-1), f32(adv), f32(returns), f32(logp_old), f32(v_old)
-        if not (act.numel() == adv.numel() == returns.numel() == logp_old.numel() == v_old.numel() == b):
+        if self.cfg.algo == "ppo" and (logp_old is None or v_old is None):
+            raise ValueError("the PPO objective needs logp_old and v_old")
+        if any(t is not None and t.numel() != b for t in (act, adv, returns, logp_old, v_old)):
             raise ValueError("minibatch tensors differ in length")
         stats = adv_stats_of(self.cfg, adv)                  # on the device copy
         if apply:
