@@ -537,7 +537,7 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * B) +
-                                        al(4 * spl) + 4096))
+                                        2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -545,13 +545,19 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
     float* logp = c.take<float>(B);
     float* split = c.take<float>(spl);
+    float* split2 = c.take<float>(spl);
+    hipStream_t side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
+    TS_LAUNCH_CHECK();
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;            // the two lagged critics side by side
+    if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
     if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
-    if (int rc = mlp_forward(s, ws, mc, critic2_old, x_c, a2, split)) return rc;
+    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     hipLaunchKernelGGL(sac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, a2.out, logp,
                        log_alpha, (float)fixed_alpha, B, out);
     TS_LAUNCH_CHECK();
@@ -730,21 +736,30 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     hipStream_t s = ts::as_stream(stream);
     const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + al(4 * spl) + 4096)) return rc;
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * spl) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
     const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
     float* split = c.take<float>(spl);
+    float* split2 = c.take<float>(spl);
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
     if (int rc = mlp_forward(s, ws, ma, actor_old, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise, B,
                        d.act, (float)max_action, (float)policy_noise, (float)noise_clip, d.obs, d.kc, x_c, (float*)nullptr,
                        (float*)nullptr);
-    if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
-    if (critic2_old)
-        if (int rc = mlp_forward(s, ws, mc, critic2_old, x_c, a2, split)) return rc;
+    TS_LAUNCH_CHECK();
+    if (critic2_old) {                                                  // the two lagged critics side by side
+        hipStream_t side;
+        if (int rc = ts::side_stream(ws, s, &side)) return rc;
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+        if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
+        if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    } else {
+        if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+    }
     hipLaunchKernelGGL(td3_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out,
                        critic2_old ? a2.out : (const float*)nullptr, B, out);
     TS_LAUNCH_CHECK();
