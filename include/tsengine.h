@@ -605,6 +605,37 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
                    const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * REDQ (tianshou/algorithm/modelfree/redq.py): SAC's tanh-Gaussian policy + an ensemble of E critics whose
+ * Linear layers are EnsembleLinear (utils/net/common.py:518-550), nets of test/continuous/test_redq.py:86-107 with hidden
+ * [256, 256].  The ensemble's parameters are E consecutive blocks in ts_sac_layout's critic layout; actor as SAC's.
+ * ------------------------------------------------------------------------------------------- */
+
+/* _target_q (ddpg.py:327-339) + _target_q_compute_value (redq.py:248-261): a' ~ pi(s') with the supplied rsample() noise,
+ * min (mean_mode 0) or mean (1) over the lagged members h_subset[0..S) (host int32, the np.random.choice draw), minus
+ * alpha * log_prob -> out float32[B]. */
+int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_old, int64_t E, const int32_t* h_subset,
+                     int64_t S, int mean_mode, const float* log_alpha, double fixed_alpha, const float* obs_next,
+                     const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream);
+
+typedef struct ts_redq_state {  /* device pointers, all float32 */
+    float *actor, *actor_m, *actor_v;
+    float *critics, *critics_m, *critics_v; /* E blocks each */
+    float *critics_old;
+    float *log_alpha, *log_alpha_m, *log_alpha_v;
+} ts_redq_state;
+
+/* REDQ._update_with_batch (redq.py:263-304): the ensemble loss mean_{e,b}((Q_e - returns)^2 weight) and ONE Adam step over
+ * all members (critic_step = 1-based count of these steps); when do_actor (every actor_delay-th update) the actor step on
+ * (alpha log_prob - mean_e Q_e).mean() with the updated critics and AutoAlpha.update(-log_prob) (actor_step = 1-based
+ * count of actor updates, used by both optimizers); Polyak update of the lagged ensemble.  E <= 64.
+ * stats_out4 = {actor_loss, critic_loss, alpha, alpha_loss}: slots 0, 2, 3 are written only when do_actor.
+ * weight_out (nullable) float32[B] = mean_e td_e (redq.py:272); grads_out (nullable) = {E critic blocks, actor}. */
+int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t critic_step, int64_t actor_step,
+                   int do_actor, const float* obs, const float* act, const float* returns, const float* weight,
+                   const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp,
+                   float* stats_out4, float* weight_out, float* grads_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,
  * nets of examples/mujoco/mujoco_td3.py:85-103 / mujoco_ddpg.py
  * ------------------------------------------------------------------------------------------- */

@@ -573,6 +573,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "redq":
+        gen_redq_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "dsac":
         gen_dsac_all()
         return
@@ -902,6 +905,120 @@ def gen_dsac_all() -> None:
              auto_alpha=True, n_step=3)
     gen_dsac("fixed", E=2, slots=40, steps=50, obs_dim=40, n_act=3, hidden=96, batch=32, n_updates=2, seed=23,
              auto_alpha=False, alpha=0.05, n_step=1, tau=0.01)
+
+
+def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int, seed: int,
+             ensemble: int, subset: int, actor_delay: int, target_mode: str, auto_alpha: bool, alpha: float = 0.2,
+             n_step: int = 1, tau: float = 0.005, gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3,
+             alpha_lr: float = 3e-4) -> None:
+    """Runs the reference REDQ.update() (nets as in test/continuous/test_redq.py:86-107, hidden [256, 256]) on a synthetic
+    VectorReplayBuffer, recording the rsample() noise, the np.random.choice subsets and the outputs of every update."""
+    import torch.distributions.normal as tdn
+    from tianshou.algorithm.modelfree.redq import REDQ, REDQPolicy
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    from tianshou.utils.net.common import EnsembleLinear
+    from oracle import oracle_redq as OR
+    from oracle import oracle_sac as OS
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[256, 256])
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
+                                         conditioned_sigma=True)
+
+    def linear(x: int, y: int):
+        return EnsembleLinear(ensemble, x, y)
+
+    net_c = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True, linear_layer=linear)
+    critic = ContinuousCritic(preprocess_net=net_c, linear_layer=linear, flatten_input=False)
+    space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
+    policy = REDQPolicy(actor=actor, action_space=space)
+    al = AutoAlpha(float(-act_dim), 0.0, AdamOptimizerFactory(lr=alpha_lr)) if auto_alpha else alpha
+    algorithm = REDQ(policy=policy, policy_optim=AdamOptimizerFactory(lr=actor_lr), critic=critic,
+                     critic_optim=AdamOptimizerFactory(lr=critic_lr), ensemble_size=ensemble, subset_size=subset,
+                     tau=tau, gamma=gamma, alpha=al, n_step_return_horizon=n_step, actor_delay=actor_delay,
+                     target_mode=target_mode)
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step, ensemble,
+                            subset, actor_delay, int(target_mode == "mean")])
+    a0, c0 = OR.init_params(obs_dim, act_dim, ensemble, seed)
+    sa, sc = actor.state_dict(), critic.state_dict()
+    assert list(sc.keys()) == OR.TIANSHOU_CRITIC_KEYS, list(sc.keys())
+    for k_ref, k in zip(OS.TIANSHOU_ACTOR_KEYS, OS.ACTOR_ORDER):
+        assert torch.equal(sa[k_ref], a0[k]), f"oracle actor init differs at {k}"
+    for k_ref, k in zip(OR.TIANSHOU_CRITIC_KEYS, OR.CRITIC_ORDER):
+        assert torch.equal(sc[k_ref], c0[k]), f"oracle critic init differs at {k}"
+
+    buf = VectorReplayBuffer(E * slots, E)
+    obs = rng.normal(size=(steps + 1, E, obs_dim)).astype(np.float32)
+    act = rng.uniform(-1, 1, size=(steps, E, act_dim)).astype(np.float32)
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.05
+    trunc = (rng.random((steps, E)) < 0.03) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+    out["obs"], out["obs_next"] = np.asarray(buf.obs, np.float32), np.asarray(buf.obs_next, np.float32)
+    out["act"], out["rew"] = np.asarray(buf.act, np.float32), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    noises: list[np.ndarray] = []
+    subsets: list[np.ndarray] = []
+    orig_sn, orig_choice, orig_pre = tdn._standard_normal, np.random.choice, REDQ._preprocess_batch
+
+    def rec_sn(shape, dtype, device):
+        e = orig_sn(shape, dtype, device)
+        noises.append(e.numpy().copy())
+        return e
+
+    def rec_choice(*a, **k):
+        r = orig_choice(*a, **k)
+        if k.get("replace", True) is False and len(a) == 2 and a[0] == ensemble:
+            subsets.append(np.asarray(r, np.int64).copy())
+        return r
+
+    rec: list[dict] = []
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        rec.append({"indices": np.array(indices, np.int64), "returns": b.returns.numpy().copy().reshape(-1)})
+        return b
+
+    tdn._standard_normal, np.random.choice, REDQ._preprocess_batch = rec_sn, rec_choice, rec_pre
+    try:
+        np.random.seed(seed + 3)
+        for u in range(n_updates):
+            n0, s0 = len(noises), len(subsets)
+            with policy_within_training_step(algorithm.policy):
+                stats = algorithm.update(buffer=buf, sample_size=batch)
+            did_actor = (u + 1) % actor_delay == 0
+            assert len(noises) - n0 == (2 if did_actor else 1) and len(subsets) - s0 == 1
+            out[f"u{u}_noise_target"] = noises[n0]
+            if did_actor:
+                out[f"u{u}_noise_actor"] = noises[n0 + 1]
+            out[f"u{u}_subset"] = subsets[s0]
+            out[f"u{u}_indices"], out[f"u{u}_returns"] = rec[-1]["indices"], rec[-1]["returns"]
+            out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic_loss, stats.alpha,
+                                           stats.alpha_loss if stats.alpha_loss is not None else np.nan])
+            sa, sc, so = actor.state_dict(), critic.state_dict(), algorithm.critic_old.module.state_dict()
+            out[f"u{u}_actor"] = torch.cat([sa[k].reshape(-1) for k in OS.TIANSHOU_ACTOR_KEYS]).numpy()[::61].copy()
+            out[f"u{u}_critic"] = torch.cat([sc[k].reshape(-1) for k in OR.TIANSHOU_CRITIC_KEYS]).numpy()[::61].copy()
+            out[f"u{u}_critic_old"] = torch.cat([so[k].reshape(-1) for k in OR.TIANSHOU_CRITIC_KEYS]).numpy()[::61].copy()
+    finally:
+        tdn._standard_normal, np.random.choice, REDQ._preprocess_batch = orig_sn, orig_choice, orig_pre
+    cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
+               target_entropy=float(-act_dim), log_alpha0=0.0, actor_lr=actor_lr, critic_lr=critic_lr, alpha_lr=alpha_lr)
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"redq_{tag}.npz"), **out)
+
+
+def gen_redq_all() -> None:
+    gen_redq("min", E=3, slots=30, steps=40, obs_dim=11, act_dim=3, batch=32, n_updates=4, seed=31, ensemble=4, subset=2,
+             actor_delay=2, target_mode="min", auto_alpha=True, n_step=3)
+    gen_redq("mean", E=2, slots=30, steps=40, obs_dim=17, act_dim=6, batch=24, n_updates=3, seed=33, ensemble=3, subset=3,
+             actor_delay=1, target_mode="mean", auto_alpha=False, alpha=0.1, n_step=1, tau=0.01)
 
 
 def gen_td3_all() -> None:

@@ -542,3 +542,53 @@ def test_dsac_restatement_matches_reference(tag):
         for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
             flat = torch.cat([getattr(st, name)[k].reshape(-1) for k in ODS.NET_ORDER]).numpy()[::5]
             np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------ REDQ path
+def load_redq(tag):
+    from oracle import oracle_redq as OR
+
+    g = load(f"redq_{tag}.npz")
+    (E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, auto, n_step, ens, sub, delay, mean) = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OR.REDQConfig(gamma=c["gamma"], tau=c["tau"], n_step=int(c["n_step"]), alpha=c["alpha"],
+                        auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"], log_alpha0=c["log_alpha0"],
+                        actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], alpha_lr=c["alpha_lr"], ensemble_size=ens,
+                        subset_size=sub, actor_delay=delay, target_mode="mean" if mean else "min")
+    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed)
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, d, cfg, bstate
+
+
+@pytest.mark.parametrize("tag", ["min", "mean"])
+def test_redq_restatement_matches_reference(tag):
+    """oracle_redq (EnsembleLinear critics, random-subset min / mean target, one ensemble loss, delayed actor and alpha
+    steps, Polyak) against the unmodified reference REDQ.update()."""
+    from oracle import oracle_redq as OR
+    from oracle import oracle_sac as OS
+
+    g, d, cfg, bstate = load_redq(tag)
+    actor, critic = OR.init_params(d["obs_dim"], d["act_dim"], cfg.ensemble_size, d["seed"])
+    st = OR.REDQState.create(actor, critic, cfg)
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+
+        def tq_fn(after):
+            return OR.target_q(st, cfg, g["obs_next"][after], g[f"u{u}_noise_target"], g[f"u{u}_subset"]).numpy().reshape(-1, 1)
+
+        ret, _ = O.compute_nstep_return(bstate, idx, tq_fn, cfg.gamma, cfg.n_step)
+        ret = ret.astype(np.float32).reshape(-1)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-5, atol=1e-6)
+        noise = g[f"u{u}_noise_actor"] if f"u{u}_noise_actor" in g else None
+        out = OR.update_with_batch(st, cfg, g["obs"][idx], g["act"][idx], ret, noise)
+        stats = g[f"u{u}_stats"]
+        np.testing.assert_allclose([out["actor_loss"], out["critic_loss"], out["alpha"]], stats[:3], rtol=2e-5, atol=1e-7)
+        if out["alpha_loss"] is not None:
+            np.testing.assert_allclose(out["alpha_loss"], stats[3], rtol=1e-5, atol=1e-7)
+        else:
+            assert np.isnan(stats[3])
+        for name, p, order in (("actor", st.actor, OS.ACTOR_ORDER), ("critic", st.critic, OR.CRITIC_ORDER),
+                               ("critic_old", st.critic_old, OR.CRITIC_ORDER)):
+            flat = torch.cat([p[k].reshape(-1) for k in order]).numpy()[::61]
+            np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)

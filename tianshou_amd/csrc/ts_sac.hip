@@ -446,6 +446,87 @@ __global__ __launch_bounds__(256) void unpad_rows_kernel(const float* __restrict
     dst[i] = src[b * hw + (i - b * A)];
 }
 
+// ---- REDQ (redq.py): SAC's policy + an ensemble of critics ------------------------------------------------------------------
+// _target_q_compute_value (redq.py:248-261): min or mean over the sampled subset (qs[k] = out of subset member k, [B, 32]
+// rows, column 0) minus alpha * log_prob
+__global__ __launch_bounds__(256) void redq_target_kernel(const float* __restrict__ qs, int S, int64_t stride,
+                                                          const float* __restrict__ logp, const float* __restrict__ log_alpha,
+                                                          float fixed_alpha, int mean_mode, int64_t B, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    float v = qs[b * 32];
+    for (int k = 1; k < S; ++k) {
+        const float q = qs[k * stride + b * 32];
+        v = mean_mode ? v + q : fminf(v, q);
+    }
+    if (mean_mode) v = v / (float)S;
+    out[b] = v - alpha * logp[b];
+}
+
+// one member's share of the ensemble loss (redq.py:266-270): td_e = Q_e - returns, loss = sum_e sum_b td^2 w / (E B)
+__global__ __launch_bounds__(1024) void redq_critic_loss_kernel(const float* __restrict__ q, const float* __restrict__ ret,
+                                                                const float* __restrict__ weight, int64_t B, float inv_eb,
+                                                                float* __restrict__ td, float* __restrict__ d_out,
+                                                                float* __restrict__ loss_part) {
+    __shared__ float red[1024];
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float t = q[b * 32] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        td[b] = t;
+        ls += t * t * w;
+        d_out[b * 32] = 2.f * t * w * inv_eb;          // the other 31 columns of d_out stay zero
+    }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss_part = tot * inv_eb;
+}
+
+// critic_loss = sum_e loss_part[e]; batch.weight = mean_e td_e (redq.py:272)
+__global__ __launch_bounds__(256) void redq_finish_kernel(const float* __restrict__ tds, const float* __restrict__ loss_parts, int E,
+                                                          int64_t B, float* __restrict__ critic_loss,
+                                                          float* __restrict__ weight_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b == 0) {
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t += loss_parts[e];
+        *critic_loss = t;
+    }
+    if (b >= B || !weight_out) return;
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) s += tds[(int64_t)e * B + b];
+    weight_out[b] = s / (float)E;
+}
+
+// actor loss (redq.py:280-282) = mean_b(alpha log_prob - mean_e Q_e); every member receives d Q_e[b] = -1 / (E B)
+__global__ __launch_bounds__(1024) void redq_actor_loss_kernel(const float* __restrict__ qs, int E, int64_t stride,
+                                                               const float* __restrict__ logp,
+                                                               const float* __restrict__ log_alpha, float fixed_alpha, int64_t B,
+                                                               float* __restrict__ d_q, float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float inv_b = 1.f / (float)B, g = -1.f / ((float)E * (float)B);
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        float qa = 0.f;
+        for (int e = 0; e < E; ++e) qa += qs[e * stride + b * 32];
+        ls += alpha * logp[b] - qa / (float)E;
+        d_q[b * 32] = g;
+    }
+    const float tot = block_sum_1024(ls, red);
+    if (threadIdx.x == 0) *loss = tot * inv_b;
+}
+
+// dst[b, col0 + j] (+)= src[b, col0 + j], j < A: the action columns of an input gradient [B, kc]
+__global__ __launch_bounds__(256) void acc_cols_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t B, int kc,
+                                                       int col0, int A, int first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    const int64_t o = b * kc + col0 + (i - b * A);
+    dst[o] = first ? src[o] : dst[o] + src[o];
+}
+
 size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct Carve {
@@ -1027,6 +1108,180 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
     if (hp->tau > 0.0)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(P, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, P, (float)hp->tau, (float)(1.0 - hp->tau));
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// ---- REDQ ----------------------------------------------------------------------------------------------------------
+int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_old, int64_t E, const int32_t* h_subset,
+                     int64_t S, int mean_mode, const float* log_alpha, double fixed_alpha, const float* obs_next,
+                     const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_redq_target_q: workspace is NULL");
+    TS_REQUIRE(B >= 1 && E >= 1 && S >= 1 && S <= E && actor && critics_old && h_subset && obs_next && noise && out,
+               TS_ERR_INVALID_ARG, "ts_redq_target_q: bad argument");
+    for (int64_t k = 0; k < S; ++k)
+        TS_REQUIRE(h_subset[k] >= 0 && h_subset[k] < E, TS_ERR_INVALID_ARG, "ts_redq_target_q: subset index out of range");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const size_t spl = std::max(split_floats(ma), split_floats(mc));
+    const int64_t pc = mc.off[3];
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * al(4 * B * HID) + al(4 * B * 64) +
+                                        al(4 * (size_t)S * B * 32) + al(4 * B) + 2 * al(4 * spl) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);
+    Act aa; aa.h1 = c.take<float>(B * HID); aa.h2 = c.take<float>(B * HID); aa.out = c.take<float>(B * 64);
+    float* hh[2][2] = {{c.take<float>(B * HID), c.take<float>(B * HID)}, {c.take<float>(B * HID), c.take<float>(B * HID)}};
+    float* qs = c.take<float>((size_t)S * B * 32);
+    float* logp = c.take<float>(B);
+    float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    hipStream_t st2[2] = {s, side};
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, splits[0])) return rc;
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+                       64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
+    TS_LAUNCH_CHECK();
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    for (int64_t k = 0; k < S; ++k) {                 // the subset's members alternate between the two streams
+        const int w = (int)(k & 1);
+        const Act a{hh[w][0], hh[w][1], qs + k * B * 32};
+        if (int rc = mlp_forward(st2[w], ws, mc, critics_old + (int64_t)h_subset[k] * pc, x_c, a, splits[w])) return rc;
+    }
+    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    hipLaunchKernelGGL(redq_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, qs, (int)S, B * 32, logp,
+                       log_alpha, (float)fixed_alpha, mean_mode, B, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t critic_step, int64_t actor_step,
+                   int do_actor, const float* obs, const float* act, const float* returns, const float* weight,
+                   const float* noise, int64_t B, int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp,
+                   float* stats_out4, float* weight_out, float* grads_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_redq_update: workspace is NULL");
+    TS_REQUIRE(st && hp && obs && act && returns && stats_out4 && B >= 1 && E >= 1 && E <= 64 && critic_step >= 1 &&
+                   actor_step >= 1, TS_ERR_INVALID_ARG, "ts_redq_update: bad argument");
+    TS_REQUIRE(st->actor && st->actor_m && st->actor_v && st->critics && st->critics_m && st->critics_v && st->critics_old,
+               TS_ERR_INVALID_ARG, "ts_redq_update: NULL state pointer");
+    TS_REQUIRE(!do_actor || noise, TS_ERR_INVALID_ARG, "ts_redq_update: the actor step needs the rsample() noise");
+    TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
+               "ts_redq_update: auto alpha needs log_alpha and its Adam moments");
+    Dims d;
+    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const size_t slab = std::max(slab_floats(ma), slab_floats(mc)), spl = std::max(split_floats(ma), split_floats(mc));
+    const int64_t pa = ma.off[3], pc = mc.off[3];
+    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 6) * al(4 * B * HID) +
+                         (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + 2 * al(4 * slab) + al(4 * (size_t)E * pc) +
+                         al(4 * pa) + 2 * al(4 * spl) + al(4 * (size_t)E * B) + 2 * al(4 * B) + al(4 * B * 3 * d.act) +
+                         al(256) + al(4 * 1024) + 8192;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    float* x_c = c.take<float>(B * d.kc);
+    float* x_p = c.take<float>(B * d.kc);
+    float* dx = c.take<float>(B * d.kc);
+    float* dx_sum = c.take<float>(B * d.kc);
+    float* zeros = c.take<float>(B * d.kc);
+    Act acts[64];
+    for (int e = 0; e < E; ++e) { acts[e].h1 = c.take<float>(B * HID); acts[e].h2 = c.take<float>(B * HID); acts[e].out = c.take<float>(B * 32); }
+    Act aa; aa.h1 = c.take<float>(B * HID); aa.h2 = c.take<float>(B * HID); aa.out = c.take<float>(B * 64);
+    float* d_head = c.take<float>(B * 64);
+    float* dheads[2] = {c.take<float>(B * 64), c.take<float>(B * 64)};
+    float* d_q = dheads[0];                          // actor phase: the critic-phase gradients are consumed by then
+    BwdScratch scs[2];
+    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * HID); scs[k].dh1 = c.take<float>(B * HID); scs[k].slabs = c.take<float>(slab); }
+    float* gcrit = c.take<float>((size_t)E * pc);
+    float* gact = c.take<float>(pa);
+    float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
+    float* tds = c.take<float>((size_t)E * B);
+    float* logp = c.take<float>(B);
+    float* keep = c.take<float>(B * 3 * d.act);
+    float* loss_parts = c.take<float>(64);
+    float* norm_part = c.take<float>(1024);
+    if (grads_out) { gcrit = grads_out; gact = grads_out + (size_t)E * pc; }
+    const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
+    const float inv_eb = 1.f / ((float)E * (float)B);
+
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 64, s));
+    TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 64, s));
+    // ensemble loss (redq.py:266-271): the members are independent chains, alternating between two streams
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    hipStream_t st2[2] = {s, side};
+    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    for (int e = 0; e < E; ++e) {
+        const int w = e & 1;
+        const float* pe = st->critics + (int64_t)e * pc;
+        if (int rc = mlp_forward(st2[w], ws, mc, pe, x_c, acts[e], splits[w])) return rc;
+        hipLaunchKernelGGL(redq_critic_loss_kernel, dim3(1), dim3(1024), 0, st2[w], acts[e].out, returns, weight, B, inv_eb,
+                           tds + (int64_t)e * B, dheads[w], loss_parts + e);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(st2[w], ws, mc, pe, x_c, acts[e], dheads[w], gcrit + (int64_t)e * pc, nullptr, 0, 0, scs[w]))
+            return rc;
+    }
+    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    hipLaunchKernelGGL(redq_finish_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, tds, loss_parts, (int)E, B,
+                       stats_out4 + 1, weight_out);
+    TS_LAUNCH_CHECK();
+    if (hp->critic_lr >= 0.0)                        // one optimizer over the whole ensemble (test_redq.py:108)
+        if (int rc = ts::adam_step(s, st->critics, st->critics_m, st->critics_v, gcrit, (int64_t)E * pc, critic_step,
+                                   hp->critic_lr, hp->beta1, hp->beta2, hp->adam_eps, 0.0, norm_part))
+            return rc;
+
+    if (do_actor) {                                  // redq.py:277-289, every actor_delay-th update: one stream
+        TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemsetAsync(zeros, 0, sizeof(float) * B * d.kc, s));
+        TS_HIP_CHECK(hipMemsetAsync(d_q, 0, sizeof(float) * B * 32, s));
+        TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+        if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, splits[0])) return rc;
+        hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+                           64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
+        TS_LAUNCH_CHECK();
+        for (int e = 0; e < E; ++e)
+            if (int rc = mlp_forward(s, ws, mc, st->critics + (int64_t)e * pc, x_p, acts[e], splits[0])) return rc;
+        // the member outputs sit at a fixed stride only if carved back to back: gather their column-0 base pointers
+        // through the stride between consecutive Act blocks
+        const int64_t stride = acts[E > 1 ? 1 : 0].out - acts[0].out;
+        hipLaunchKernelGGL(redq_actor_loss_kernel, dim3(1), dim3(1024), 0, s, acts[0].out, (int)E, E > 1 ? stride : 0, logp,
+                           log_alpha, (float)hp->alpha, B, d_q, stats_out4);
+        TS_LAUNCH_CHECK();
+        for (int e = 0; e < E; ++e) {
+            if (int rc = mlp_backward(s, ws, mc, st->critics + (int64_t)e * pc, x_p, acts[e], d_q, nullptr, dx, d.obs,
+                                      d.obs + d.act, scs[0]))
+                return rc;
+            hipLaunchKernelGGL(acc_cols_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, dx_sum, dx, B,
+                               d.kc, d.obs, d.act, e == 0 ? 1 : 0);
+        }
+        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
+                           keep, dx_sum, zeros, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, gact, nullptr, 0, 0, scs[0])) return rc;
+        if (hp->actor_lr >= 0.0)
+            if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, gact, pa, actor_step, hp->actor_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
+                return rc;
+        AlphaArgs al2{};                              // AutoAlpha.update(-log_prob) (redq.py:286-288)
+        al2.logp = logp; al2.B = B; al2.target_entropy = (float)hp->target_entropy;
+        al2.log_alpha = hp->auto_alpha ? st->log_alpha : nullptr; al2.m = st->log_alpha_m; al2.v = st->log_alpha_v;
+        const double bc1 = 1.0 - pow(hp->beta1, (double)actor_step), bc2 = 1.0 - pow(hp->beta2, (double)actor_step);
+        al2.lr_step = (float)(hp->alpha_lr / bc1); al2.beta1 = (float)hp->beta1; al2.beta2 = (float)hp->beta2;
+        al2.omb1 = (float)(1.0 - hp->beta1); al2.omb2 = (float)(1.0 - hp->beta2);
+        al2.bc2_sqrt = (float)sqrt(bc2); al2.eps = (float)hp->adam_eps;
+        al2.alpha_loss = stats_out4 + 3; al2.alpha_out = stats_out4 + 2; al2.fixed_alpha = (float)hp->alpha;
+        al2.td1 = nullptr; al2.td2 = nullptr; al2.weight_out = nullptr;
+        hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, al2);
+    }
+    if (hp->tau > 0.0)
+        hipLaunchKernelGGL(polyak1_kernel, dim3((unsigned)ts::ceil_div((int64_t)E * pc, 256)), dim3(256), 0, s, st->critics_old,
+                           st->critics, (int64_t)E * pc, (float)hp->tau, (float)(1.0 - hp->tau));
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

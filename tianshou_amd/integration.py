@@ -511,6 +511,124 @@ def make_hip_sac():
 
 
 # ---------------------------------------------------------------------------------------------------
+# REDQ (redq.py) on the nets of test/continuous/test_redq.py
+# ---------------------------------------------------------------------------------------------------
+def make_hip_redq():
+    """Returns HipREDQ(REDQ): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, redq.py:248-304) on the engine.
+    Supported nets: SAC's actor (Net[256, 256] ReLU, conditioned sigma, unbounded) and one critic module made of
+    EnsembleLinear layers with hidden [256, 256] (test/continuous/test_redq.py:86-107); the buffer must store obs_next.
+    The rsample() noise comes from torch's default generator and the critic subset from NumPy's global generator, in
+    the reference's order (target call: noise, then np.random.choice; actor step: noise)."""
+    from tianshou.algorithm.modelfree.redq import REDQ, REDQTrainingStats
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+
+    from . import redq as RQ
+    from . import sac as S
+
+    class HipREDQ(REDQ):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
+            if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != RQ.TIANSHOU_CRITIC_KEYS:
+                raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py")
+            w1, w2 = sc[RQ.TIANSHOU_CRITIC_KEYS[0]], sc[RQ.TIANSHOU_CRITIC_KEYS[2]]
+            if sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or w1.dim() != 3 or w1.shape[2] != 256 \
+                    or tuple(w2.shape[1:]) != (256, 256) or w1.shape[0] != self.ensemble_size:
+                raise NotImplementedError("HipREDQ: hidden sizes must be [256, 256], EnsembleLinear critics of ensemble_size")
+            for o in (self.policy_optim, self.critic_optim):
+                _adam_of(o)
+            self._hip_engine = None
+
+        def _critic_tensors(self, mod):
+            return [mod.state_dict()[k] for k in RQ.TIANSHOU_CRITIC_KEYS]
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                obs_dim, act_dim = sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1], sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                auto = isinstance(self.alpha, AutoAlpha)
+                ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
+                cfg = RQ.REDQConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
+                                    alpha=0.0 if auto else float(self.alpha.value), auto_alpha=auto,
+                                    target_entropy=float(self.alpha._target_entropy) if auto else 0.0,
+                                    log_alpha0=float(self.alpha._log_alpha.item()) if auto else 0.0,
+                                    actor_lr=ga["lr"], critic_lr=gc["lr"],
+                                    alpha_lr=self.alpha._optim.param_groups[0]["lr"] if auto else 0.0,
+                                    betas=tuple(ga["betas"]), adam_eps=ga["eps"], ensemble_size=self.ensemble_size,
+                                    subset_size=self.subset_size, actor_delay=self.actor_delay, target_mode=self.target_mode)
+                dev = self._hip_device
+                eng = self._hip_engine = RQ.REDQEngine(
+                    obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
+                    RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev), cfg)
+                # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
+                eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev)
+                eng.critic_gradient_step = int(self.critic_gradient_step)
+                ms, vs, step = adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS))
+                eng.actor_m, eng.actor_v = (S.actor_flat_from_torch(x, obs_dim, act_dim, dev) for x in (ms, vs))
+                eng.actor_steps = step
+                ms, vs, _ = adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS))
+                eng.critics_m, eng.critics_v = (RQ.ensemble_flat_from_torch(x, obs_dim, act_dim, dev) for x in (ms, vs))
+                eng._stats[0] = float(self._last_actor_loss)
+                if auto:
+                    st = self.alpha._optim.state.get(self.alpha._log_alpha, {})
+                    if "exp_avg" in st:
+                        eng.log_alpha_m[0], eng.log_alpha_v[0] = float(st["exp_avg"]), float(st["exp_avg_sq"])
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, "HipREDQ")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            if m.obs_next is None:
+                raise NotImplementedError("HipREDQ: the replay buffer must store obs_next")
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            noise = torch.randn(len(indices), eng.act_dim)                  # Normal.rsample of the target policy call
+            subset = np.random.choice(self.ensemble_size, self.subset_size, replace=False)     # redq.py:252
+            batch.returns = eng.preprocess(m, idx, noise, subset).reshape(-1, 1)
+            self._hip_idx = idx
+            return batch
+
+        def _update_with_batch(self, batch):
+            from .buffer import gather_rows
+
+            eng, m = self._hip_engine, self._hip_mirror
+            weight = getattr(batch, "weight", None)
+            did_actor = eng.will_update_actor()
+            noise = torch.randn(len(batch), eng.act_dim) if did_actor else None
+            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                                             batch.returns.reshape(-1), noise, weight)
+            batch.weight = w                                                      # prio-buffer, redq.py:272
+            s = stats.cpu().numpy()                                               # one D2H per update()
+            self.critic_gradient_step = eng.critic_gradient_step
+            self._last_actor_loss = float(s[0])
+            dims = (eng.obs_dim, eng.act_dim)
+            E = eng.cfg.ensemble_size
+            with torch.no_grad():
+                for p, t in zip(params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS), S.actor_flat_to_torch(eng.actor, *dims)):
+                    p.copy_(t)
+                for mod, flat in ((self.critic, eng.critics), (self.critic_old.module, eng.critics_old)):
+                    for p, t in zip(params_by_keys(mod, RQ.TIANSHOU_CRITIC_KEYS), RQ.ensemble_flat_to_torch(flat, E, *dims)):
+                        p.copy_(t)
+                if eng.cfg.auto_alpha:
+                    self.alpha._log_alpha.copy_(eng.log_alpha[0])
+            store_adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS),
+                             RQ.ensemble_flat_to_torch(eng.critics_m, E, *dims), RQ.ensemble_flat_to_torch(eng.critics_v, E, *dims),
+                             eng.critic_gradient_step)
+            if eng.actor_steps:
+                store_adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS),
+                                 S.actor_flat_to_torch(eng.actor_m, *dims), S.actor_flat_to_torch(eng.actor_v, *dims),
+                                 eng.actor_steps)
+                if eng.cfg.auto_alpha:
+                    store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]], [eng.log_alpha_v[0]],
+                                     eng.actor_steps)
+            return REDQTrainingStats(actor_loss=float(s[0]), critic_loss=float(s[1]), alpha=float(s[2]),
+                                     alpha_loss=None if np.isnan(s[3]) else float(s[3]))
+
+    return HipREDQ
+
+
+# ---------------------------------------------------------------------------------------------------
 # DiscreteSAC (discrete_sac.py) on the MLP nets of test/discrete/test_discrete_sac.py
 # ---------------------------------------------------------------------------------------------------
 def make_hip_discrete_sac():
