@@ -1,7 +1,7 @@
 """Measurement of the rows SURVEY 8f adds to the hot path (N3) and of BASELINE.json configs[0], on the same contract
 as bench.py: TD3 / DDPG / DiscreteSAC (MLP learners), QRDQN / C51 (NatureCNN learners) and the CartPole-shape PPO.
 
-    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
+    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|rainbow|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
 
 One "step" = one reference update(): sample -> gather -> target / n-step return -> optimizer steps (-> Polyak), everything
 device-resident; for ppo_discrete one update() = preprocessing + repeat x ceil(N / 64) minibatch steps (value = minibatch
@@ -272,6 +272,72 @@ def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
                  _roofline(prof, flop, "conv / linear GEMMs of one update"), cpu, {"final_loss": float(loss)})
 
 
+# ---- Rainbow (Atari shape, as C3) -----------------------------------------------------------------------------------------
+def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
+    import bench_dqn as BD
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_rainbow as ORB
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+    from tianshou_amd import rainbow as RB
+
+    C, H, W, A, B, N = BD.C, BD.H, BD.W, BD.N_ACT, BD.BATCH, 51
+    dims = (C, H, W, A, N)
+    frames, act, buf, per = BD.build(slots, 16)
+    p, n0 = ORB.init_params(*dims, 0)
+    order = [f"{L}.{t}" for L in ORB.NOISY for t in ("eps_p", "eps_q")]
+    cfg = Q.DistQConfig(kind="c51", n_atoms=N, gamma=0.99, n_step=3, target_update_freq=500, lr=6.25e-5, v_min=-10.0, v_max=10.0)
+    eng = RB.RainbowEngine(C, H, W, A, RB.flat_from_torch([p[k] for k in ORB.PARAM_ORDER], *dims),
+                           RB.noise_from_torch([n0[k] for k in order], *dims), cfg)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    nn = eng.lay["noise_count"]
+
+    def draw():                                              # f(x) = sign(x) sqrt|x| (discrete.py:357-359), on the device
+        x = torch.randn(nn, generator=gen, device="cuda")
+        return x.sign() * x.abs().sqrt()
+
+    def update():
+        u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
+        idx, wt = per.sample(u)
+        ret = eng.preprocess(buf, idx)
+        eng.set_noise(draw(), draw())
+        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
+        obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True)
+        loss, prio = eng.update_with_batch(obs, act[idx], ret, obs_next, wt)
+        per.update_weight(idx, prio)
+        return loss
+
+    dt, loss, prof = _time(update, steps, warmup)
+    conv = [3_276_800, 2_654_208, 1_806_336]
+    heads = 2 * 3136 * 512 + 512 * A * N + 512 * N
+    fwd = 2 * (sum(conv) + heads)
+    flop = B * (3 * fwd + fwd + (fwd - 2 * conv[0]))
+    cpu = None
+    if with_cpu:
+        ocfg = OQ.DistQConfig(kind="c51", n_atoms=N, n_step=3, target_update_freq=500, lr=6.25e-5)
+        st = ORB.RainbowState(p, n0, ocfg)
+        rng = np.random.default_rng(0)
+        obs = rng.integers(0, 256, size=(B, C, H, W), dtype=np.uint8)
+        obs_next = rng.integers(0, 256, size=(B, C, H, W), dtype=np.uint8)
+        a = rng.integers(0, A, size=B)
+        ret = rng.normal(size=(B, N)).astype(np.float32)
+        th = _threads()
+
+        def one():
+            ORB.update_with_batch(st, ocfg, obs, a, ret, obs_next, A, ORB.sample_noise(H, W, A, N), ORB.sample_noise(H, W, A, N))
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            one()
+        cpu = {"value": 8 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"8 updates of B={B} (noise draws, 2 target forwards, fwd/bwd/Adam), torch fp32 CPU oracle"}
+    return _line("Rainbow learn() updates/sec (B=512, RainbowNet: noisy + dueling, 51 atoms, n-step 3, PER)", steps / dt,
+                 "updates/s", steps, warmup, dt,
+                 f"Rainbow on the C3 Atari-shape replay: {slots} slots of u8[84,84] frames, stack 4, 6 actions, B=512",
+                 _roofline(prof, flop, "conv / linear GEMMs of one update"), cpu, {"final_loss": float(loss)})
+
+
 # ---- PPO, CartPole shape (BASELINE.json configs[0]) ------------------------------------------------------------------------
 def run_ppo_discrete(steps, warmup, with_cpu):
     from oracle import oracle_ppo as OP
@@ -329,7 +395,7 @@ def run_ppo_discrete(steps, warmup, with_cpu):
 RUNNERS = {
     "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
     "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),
-    "ppo_discrete": run_ppo_discrete,
+    "ppo_discrete": run_ppo_discrete, "rainbow": run_rainbow,
 }
 
 

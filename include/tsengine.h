@@ -469,6 +469,43 @@ int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     float* target_dist_out, float* grad_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Rainbow (tianshou/algorithm/modelfree/rainbow.py): C51 on RainbowNet (env/atari/atari_network.py:154-208) -- DQNet
+ * feature trunk, NoisyLinear layers (utils/net/discrete.py:317-374) in a Q branch (F -> 512 -> n_act * n_atoms) and a
+ * dueling V branch (F -> 512 -> n_atoms), logits = q - mean_a q + v, softmax over the atoms.
+ * Flat parameters: conv1 | conv2 | conv3 | Q0.mu [F + 1, 512] | Q0.sigma | Q2.mu [513, ldq] | Q2.sigma | V0.mu | V0.sigma |
+ * V2.mu [513, ldv] | V2.sigma  (mu / sigma = the layer's mu_W + mu_bias / sigma_W + sigma_bias in the engine's matrix
+ * layout; F in (h, w, c) order; ldq / ldv = n_act * n_atoms / n_atoms rounded up to 32, padding zero).
+ * Noise of one network (device float32): Q0.eps_p [F] | Q0.eps_q [512] | Q2.eps_p [512] | Q2.eps_q [ldq] | V0.eps_p [F] |
+ * V0.eps_q [512] | V2.eps_p [512] | V2.eps_q [ldv]; NULL selects eval mode (discrete.py:370-372).
+ * `support` = C51Policy.support (c51.py:61-64), device float32[n_atoms].
+ * h_out20 = {F, ldq, ldv, parameter count, noise count, 3 conv offsets, 4 noisy-layer offsets (mu block; sigma follows),
+ * 8 noise offsets}.
+ * ------------------------------------------------------------------------------------------- */
+int ts_rainbow_layout(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, int64_t* h_out20);
+
+/* RainbowNet.forward + C51Policy.compute_q_value + argmax: dist_out float32[B, n_act, n_atoms] (probabilities),
+ * q_out float32[B, n_act], act_out int64[B]; each nullable. */
+int ts_rainbow_forward(ts_workspace* ws, const float* params, const float* noise, int64_t c, int64_t h, int64_t w,
+                       int64_t n_act, int64_t n_atoms, const float* support, const void* obs_nhwc, int obs_u8, int64_t B,
+                       float* dist_out, float* q_out, int64_t* act_out, ts_stream_t stream);
+
+/* First half of C51._target_dist (c51.py:123-132) with the noisy networks: greedy action of (params, noise) on obs_next,
+ * its distribution under (params_old, noise_old) (params_old NULL: the online net's own) -> out float32[B, n_atoms]. */
+int ts_rainbow_next_dist(ts_workspace* ws, const float* params, const float* noise, const float* params_old,
+                         const float* noise_old, int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms,
+                         const float* support, const void* obs_next_nhwc, int obs_u8, int64_t B, float* out,
+                         ts_stream_t stream);
+
+/* RainbowDQN._update_with_batch (rainbow.py:93-101 -> c51.py:143-160) after the noise draws and the periodic sync:
+ * forward with `noise`, projection + cross entropy, backward through the dueling heads and the NoisyLinear layers
+ * (d mu = d W, d sigma = d W * eps_q x eps_p), clip_grad_norm_ + Adam.  Arguments as ts_distq_update (C51). */
+int ts_rainbow_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, const float* noise,
+                      int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, const float* support,
+                      const void* obs_nhwc, int obs_u8, const int64_t* act, const float* returns, const float* next_dist,
+                      const float* weight, int64_t B, const ts_distq_hparams* hp, float* prio_out, float* loss_out,
+                      float* target_dist_out, float* grad_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-118): DQNet(features_only=True,
  * output_dim_added_layer=512) shared by DiscreteActor(softmax_output=False) and DiscreteCritic, Categorical policy
  * ------------------------------------------------------------------------------------------- */

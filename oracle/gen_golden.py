@@ -558,6 +558,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
+        gen_rainbow_all()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "distq":
         gen_distq_all()
         return
@@ -1377,6 +1380,112 @@ def gen_distq_all() -> None:
               lr=3e-4, gamma=0.95, n_step_return_horizon=3, target_update_freq=2)
     gen_distq("c51", E=3, slots=24, steps=30, c=2, h=44, w=36, n_act=4, n_atoms=11, batch=24, n_updates=3, seed=13,
               lr=3e-4, gamma=0.9, n_step_return_horizon=2, target_update_freq=0)
+
+
+def gen_rainbow(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, n_atoms: int, batch: int,
+                n_updates: int, seed: int, lr: float, v_min: float, v_max: float, **algo_kwargs) -> None:
+    """Runs the reference RainbowDQN.update() (RainbowNet: noisy, dueling; rainbow.py, c51.py) on a synthetic
+    PrioritizedVectorReplayBuffer and dumps, per update: the noise drawn for both networks, indices, n-step returns, new
+    priorities, loss and parameter samples."""
+    from tianshou.algorithm.modelfree.c51 import C51Policy
+    from tianshou.algorithm.modelfree.rainbow import RainbowDQN
+    from tianshou.env.atari.atari_network import RainbowNet
+    from oracle import oracle_rainbow as ORB
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net = RainbowNet(c=c, h=h, w=w, action_shape=[n_act], num_atoms=n_atoms)
+    p0, n0 = ORB.init_params(c, h, w, n_act, n_atoms, seed)
+    sd = net.state_dict()
+    for k_ref, k in zip(ORB.TIANSHOU_KEYS, ORB.PARAM_ORDER):
+        assert torch.equal(sd[k_ref], p0[k]), f"oracle init differs from RainbowNet at {k}"
+    for k_ref, (L, t) in zip(ORB.NOISE_KEYS, [(L, t) for L in ORB.NOISY for t in ("eps_p", "eps_q")]):
+        assert torch.equal(sd[k_ref], n0[f"{L}.{t}"]), f"oracle noise differs at {k_ref}"
+    policy = C51Policy(model=net, action_space=gym.spaces.Discrete(n_act), num_atoms=n_atoms, v_min=v_min, v_max=v_max)
+    algorithm = RainbowDQN(policy=policy, optim=AdamOptimizerFactory(lr=lr), **algo_kwargs)
+
+    buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4)
+    frames = rng.integers(0, 256, size=(steps + 1, E, c, h, w), dtype=np.uint8)
+    frames = np.where(rng.random(frames.shape) < 0.06, frames, 0).astype(np.uint8)
+    act = rng.integers(0, n_act, size=(steps, E))
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.08
+    trunc = (rng.random((steps, E)) < 0.04) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=frames[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=frames[t + 1]))
+    out: dict[str, np.ndarray] = {}
+    out["dims"] = np.array([E, slots, steps, c, h, w, n_act, n_atoms, batch, n_updates, seed])
+    out["frames"], out["frames_next"] = np.asarray(buf.obs, np.uint8), np.asarray(buf.obs_next, np.uint8)
+    out["act"], out["rew"] = np.asarray(buf.act, np.int64), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    rec: list[dict] = []
+    orig_pre, orig_upd, orig_sample = RainbowDQN._preprocess_batch, RainbowDQN._update_with_batch, RainbowDQN._sample_noise
+    drawn: list[dict] = []
+
+    def rec_sample(model):
+        r = orig_sample(model)
+        sdm = model.state_dict()
+        drawn.append({f"{L}.{t}": sdm[k].numpy().copy()
+                      for k, (L, t) in zip(ORB.NOISE_KEYS, [(L, t) for L in ORB.NOISY for t in ("eps_p", "eps_q")])})
+        return r
+
+    def rec_pre(self, batch, buffer, indices):
+        r = {"indices": np.array(indices, np.int64), "is_weight": np.array(batch.weight, np.float64)}
+        b = orig_pre(self, batch, buffer, indices)
+        r["returns"] = b.returns.numpy().copy()
+        rec.append(r)
+        return b
+
+    def rec_upd(self, batch):
+        r = rec[-1]
+        r["old_training"] = bool(self.model_old.training) if self.model_old is not None else False
+        stats = orig_upd(self, batch)
+        r["prio"] = batch.weight.detach().numpy().copy()
+        loss = stats.loss
+        r["loss"] = np.array(loss.mean if hasattr(loss, "mean") and not isinstance(loss, float) else loss)
+        return stats
+
+    RainbowDQN._preprocess_batch, RainbowDQN._update_with_batch = rec_pre, rec_upd
+    RainbowDQN._sample_noise = staticmethod(rec_sample)
+    try:
+        np.random.seed(seed + 7)
+        for u in range(n_updates):
+            d0 = len(drawn)
+            with policy_within_training_step(algorithm.policy):
+                algorithm.update(buffer=buf, sample_size=batch)
+            r = rec[-1]
+            assert len(drawn) - d0 == (2 if algorithm.use_target_network else 1)
+            for k, v in drawn[d0].items():
+                out[f"u{u}_noise_{k}"] = v
+            if algorithm.use_target_network:
+                for k, v in drawn[d0 + 1].items():
+                    out[f"u{u}_noise_old_{k}"] = v
+            for k in ("indices", "returns", "prio", "loss", "is_weight"):
+                out[f"u{u}_{k}"] = r[k]
+            out[f"u{u}_old_training"] = np.array(r["old_training"])
+            sdm = net.state_dict()
+            flat = torch.cat([sdm[k].reshape(-1) for k in ORB.TIANSHOU_KEYS]).numpy()
+            out[f"u{u}_params_strided"] = flat[::97].copy()
+            out[f"u{u}_conv1_w"] = sdm["net.0.weight"].numpy().copy()
+            out[f"u{u}_V2_sigma_W"] = sdm["V.2.sigma_W"].numpy().copy()
+            out[f"u{u}_Q2_mu_b"] = sdm["Q.2.mu_bias"].numpy().copy()
+    finally:
+        RainbowDQN._preprocess_batch, RainbowDQN._update_with_batch = orig_pre, orig_upd
+        RainbowDQN._sample_noise = staticmethod(orig_sample)
+    cfg = dict(gamma=algorithm.gamma, n_step=algorithm.n_step, target_update_freq=algorithm.target_update_freq, lr=lr,
+               v_min=v_min, v_max=v_max)
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"rainbow_{tag}.npz"), **out)
+
+
+def gen_rainbow_all() -> None:
+    gen_rainbow("lagged", E=3, slots=24, steps=30, c=2, h=44, w=36, n_act=3, n_atoms=11, batch=24, n_updates=3, seed=17,
+                lr=3e-4, v_min=-2.0, v_max=3.0, gamma=0.95, n_step_return_horizon=3, target_update_freq=2)
+    gen_rainbow("single", E=3, slots=24, steps=30, c=2, h=44, w=36, n_act=4, n_atoms=7, batch=24, n_updates=2, seed=19,
+                lr=3e-4, v_min=-1.0, v_max=1.5, gamma=0.9, n_step_return_horizon=1, target_update_freq=0)
 
 
 def gen_dqn_all() -> None:

@@ -43,3 +43,25 @@ def load_distq(kind: str):
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, dims, cfg, bstate
+
+
+def load_rainbow(tag: str):
+    """tests/golden/rainbow_*.npz (oracle/gen_golden.py::gen_rainbow)."""
+    from oracle import oracle_distq as OQ
+
+    g = np.load(os.path.join(GOLDEN, f"rainbow_{tag}.npz"))
+    E, slots, steps, c, h, w, n_act, n_atoms, batch, n_updates, seed = (int(x) for x in g["dims"])
+    cd = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OQ.DistQConfig(kind="c51", n_atoms=n_atoms, v_min=cd["v_min"], v_max=cd["v_max"], gamma=cd["gamma"],
+                         n_step=int(cd["n_step"]), target_update_freq=int(cd["target_update_freq"]), lr=cd["lr"])
+    dims = dict(E=E, slots=slots, steps=steps, c=c, h=h, w=w, n_act=n_act, n_atoms=n_atoms, batch=batch,
+                n_updates=n_updates, seed=seed)
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, dims, cfg, bstate
+
+
+def rainbow_noise(g, u: int, old: bool = False):
+    pre = f"u{u}_noise_old_" if old else f"u{u}_noise_"
+    d = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre) and (old or not k.startswith(f"u{u}_noise_old_"))}
+    return d or None

@@ -910,3 +910,107 @@ def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
     assert float(st["step"]) == 2.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
     assert float(algo.policy_optim._optim.state[a_first]["step"]) == 1.0
     assert abs(float(algo.alpha._log_alpha.detach()) - 0.125) < 1e-6
+
+
+# ------------------------------------------------------------------------------------ Rainbow subclass
+def _rainbow_algo(freq=2, **net_kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.c51 import C51Policy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import RainbowNet
+    from tianshou_amd.integration import make_hip_rainbow
+
+    net = RainbowNet(c=4, h=84, w=84, action_shape=[6], num_atoms=11, **net_kw)
+    policy = C51Policy(model=net, action_space=gym.spaces.Discrete(6), num_atoms=11, v_min=-2.0, v_max=3.0)
+    return make_hip_rainbow()(policy=policy, optim=AdamOptimizerFactory(lr=1e-4), n_step_return_horizon=3,
+                              target_update_freq=freq, device="cpu")
+
+
+def test_rainbow_subclass_keeps_signatures_and_fails_loudly():
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _rainbow_algo()
+    base = type(algo).__mro__[1]
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, sample_size=8)
+    with pytest.raises(NotImplementedError):
+        _rainbow_algo(is_dueling=False)
+    with pytest.raises(NotImplementedError):
+        _rainbow_algo(is_noisy=False)
+
+
+def test_hip_rainbow_wrapper_runs_with_engine_double(monkeypatch):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.dqn as D
+    import tianshou_amd.rainbow as RB
+
+    lay = {"F": 3136, "ldq": 96, "ldv": 32}
+    n_noise = 2 * (3136 + 512) + 2 * 512 + 96 + 32
+    count = 8224 + 32832 + 36928 + 2 * (2 * 3137 * 512 + 513 * 96 + 513 * 32)
+    offs, o = [], 0
+    for n in (3136, 512, 512, 96, 3136, 512, 512, 32):
+        offs.append(o)
+        o += n
+    lin, o = [], 8224 + 32832 + 36928
+    for fin, pad in ((3136, 512), (512, 96), (3136, 512), (512, 32)):
+        lin.append(o)
+        o += 2 * (fin + 1) * pad
+    monkeypatch.setattr(RB, "layout", lambda *a: {**lay, "count": count, "noise_count": n_noise, "conv": [0, 8224, 41056],
+                                                  "lin": lin, "noise": offs})
+    seen = {"set_noise": []}
+
+    class FakeRainbow:
+        def __init__(self, c, h, w, n_act, flat, noise, cfg):
+            assert (c, h, w, n_act, cfg.n_atoms, cfg.kind) == (4, 84, 84, 6, 11, "c51") and (cfg.v_min, cfg.v_max) == (-2.0, 3.0)
+            assert flat.numel() == count and noise.numel() == n_noise and cfg.target_update_freq == 2
+            self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
+            self.params, self.params_old, self.noise, self.noise_old = flat.clone(), flat.clone(), noise.clone(), noise.clone()
+            self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
+
+        def preprocess(self, m, idx):
+            return torch.zeros((idx.numel(), 11))
+
+        def set_noise(self, noise, noise_old=None):
+            seen["set_noise"].append((noise.clone(), None if noise_old is None else noise_old.clone()))
+
+        def update_with_batch(self, obs, act, ret, obs_next, weight=None):
+            assert obs.shape == obs_next.shape == (8, 84, 84, 4) and ret.shape == (8, 11)
+            self.adam_step += 1
+            self.iter += 1
+            self.params += 1.0
+            self.adam_v += 0.5
+            return torch.tensor([0.25]), torch.arange(8, dtype=torch.float32)
+
+    algo = _rainbow_algo()
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(RB, "RainbowEngine", FakeRainbow)
+    monkeypatch.setattr(D, "gather_obs_nhwc", lambda frames, m, idx, stack, as_u8=False: frames[idx].permute(0, 2, 3, 1))
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (4, 84, 84), np.zeros(2, np.int64), np.uint8)
+    model = algo.policy.model
+    sig = model.V[2].sigma_W
+    before = sig.detach().clone()
+    eps_before = model.Q[0].eps_q.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, sample_size=8)
+    assert float(getattr(stats.loss, "mean", stats.loss)) == 0.25
+    assert torch.allclose(sig.detach(), before + 1.0)                          # engine -> nn.Parameter (sigma of a noisy layer)
+    assert not torch.equal(model.Q[0].eps_q.detach(), eps_before)              # the torch modules drew fresh noise ...
+    noise, noise_old = seen["set_noise"][0]
+    assert noise_old is not None and not torch.equal(noise, noise_old)
+    assert torch.allclose(noise[3136:3136 + 512], model.Q[0].eps_q.detach())   # ... and the engine received exactly it
+    assert torch.equal(algo.model_old.Q[0].eps_q, model.Q[0].eps_q)            # first update syncs: noise carried along
+    st = algo.optim._optim.state[sig]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.5))

@@ -300,6 +300,33 @@ def test_distq_restatement_matches_reference(kind):
         np.testing.assert_allclose(tree, g[f"u{u}_tree"], rtol=1e-4)
 
 
+# ------------------------------------------------------------------------------------ Rainbow path
+@pytest.mark.parametrize("tag", ["lagged", "single"])
+def test_rainbow_restatement_matches_reference(tag):
+    """oracle_rainbow (NoisyLinear layers with the recorded noise of both networks, dueling heads, C51 projection and
+    cross entropy, hard sync that carries the noise along) against the unmodified reference RainbowDQN.update()."""
+    from oracle import oracle_rainbow as ORB
+    from tests import dqn_common as DC
+
+    g, d, cfg, bstate = DC.load_rainbow(tag)
+    p0, n0 = ORB.init_params(d["c"], d["h"], d["w"], d["n_act"], d["n_atoms"], d["seed"])
+    st = ORB.RainbowState(p0, n0, cfg)
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        ret = ORB.preprocess(cfg, bstate, idx)
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-6, atol=1e-6)
+        loss, prio = ORB.update_with_batch(st, cfg, g["frames"][idx], g["act"][idx], ret, g["frames_next"][idx], d["n_act"],
+                                           DC.rainbow_noise(g, u), DC.rainbow_noise(g, u, old=True),
+                                           weight=g[f"u{u}_is_weight"], old_training=bool(g[f"u{u}_old_training"]))
+        np.testing.assert_allclose(prio.numpy(), g[f"u{u}_prio"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(loss, float(g[f"u{u}_loss"]), rtol=1e-5)
+        flat = ORB.flatten_params(st.dqn.params).numpy()
+        np.testing.assert_allclose(flat[::97], g[f"u{u}_params_strided"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.dqn.params["conv1.w"].numpy(), g[f"u{u}_conv1_w"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.dqn.params["V2.sigma_W"].numpy(), g[f"u{u}_V2_sigma_W"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(st.dqn.params["Q2.mu_b"].numpy(), g[f"u{u}_Q2_mu_b"], rtol=1e-6, atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------ SAC path
 def load_sac(tag):
     from oracle import oracle_sac as OS

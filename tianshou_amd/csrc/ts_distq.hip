@@ -274,6 +274,324 @@ int check_kind(int kind, const float* aux, const char* who) {
     return TS_OK;
 }
 
+// ================================================================================================================
+// Rainbow (modelfree/rainbow.py on RainbowNet, env/atari/atari_network.py:154-208): C51 with NoisyLinear layers
+// (utils/net/discrete.py:317-374) and dueling heads.
+//   flat parameters: conv1 | conv2 | conv3 | Q0.mu [F+1, 512] | Q0.sigma | Q2.mu [513, ldq] | Q2.sigma | V0.mu | V0.sigma |
+//                    V2.mu [513, ldv] | V2.sigma         (F = 64 * OH3 * OW3 in (h, w, c) order, ldq / ldv = n_act * n_atoms /
+//                    n_atoms rounded up to 32; last row of a block = bias; padding zero)
+//   noise of one network: Q0.eps_p [F] | Q0.eps_q [512] | Q2.eps_p [512] | Q2.eps_q [ldq] | V0.eps_p [F] | V0.eps_q [512] |
+//                    V2.eps_p [512] | V2.eps_q [ldv];   NULL = eval mode (mu only)
+// ================================================================================================================
+struct RNet {
+    ts::ConvGeom conv[3];
+    ts::ConvGeom lin[4];         // Q0, Q2, V0, V2
+    int64_t off_conv[3];
+    int64_t off_lin[4];          // mu block; the sigma block follows it
+    int64_t total;
+    int64_t off_noise[8];
+    int64_t noise_total;
+    int F, n_act, n_atoms, ldq, ldv;
+};
+
+int make_rnet(int B, int c, int h, int w, int n_act, int n_atoms, RNet* n) {
+    Net base;
+    if (int rc = make_net(B, c, h, w, n_act, n_atoms, &base)) return rc;
+    for (int i = 0; i < 3; ++i) { n->conv[i] = base.l[i]; n->off_conv[i] = base.off[i]; }
+    n->F = base.l[3].IC;
+    n->n_act = n_act; n->n_atoms = n_atoms;
+    n->ldq = base.ld;
+    n->ldv = (n_atoms + 31) / 32 * 32;
+    const int dims[4][2] = {{n->F, HIDDEN}, {HIDDEN, n->ldq}, {n->F, HIDDEN}, {HIDDEN, n->ldv}};
+    int64_t o = base.off[3], q = 0;
+    for (int i = 0; i < 4; ++i) {
+        n->lin[i] = ts::ConvGeom{B, 1, 1, dims[i][0], 1, 1, 1, 1, 1, dims[i][1]};
+        n->off_lin[i] = o;
+        o += 2 * n->lin[i].param_elems();
+        n->off_noise[2 * i] = q; q += dims[i][0];
+        n->off_noise[2 * i + 1] = q; q += dims[i][1];
+    }
+    n->total = o;
+    n->noise_total = q;
+    return TS_OK;
+}
+
+// NoisyLinear.forward's weights (discrete.py:366-374): eff[k, o] = mu + sigma * (eps_q[o] * eps_p[k]); bias row: mu + sigma * eps_q
+__global__ __launch_bounds__(256) void noisy_eff_kernel(const float* __restrict__ mu, const float* __restrict__ sigma,
+                                                        const float* __restrict__ eps_p, const float* __restrict__ eps_q, int K,
+                                                        int OC, float* __restrict__ eff) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)(K + 1) * OC) return;
+    const int k = (int)(i / OC), o = (int)(i - (int64_t)k * OC);
+    float v = mu[i];
+    if (eps_p) v += sigma[i] * (k < K ? eps_q[o] * eps_p[k] : eps_q[o]);
+    eff[i] = v;
+}
+
+// d mu = d eff; d sigma = d eff * (eps_q x eps_p) (bias row: * eps_q)
+__global__ __launch_bounds__(256) void noisy_grad_kernel(const float* __restrict__ g_eff, const float* __restrict__ eps_p,
+                                                         const float* __restrict__ eps_q, int K, int OC, float* __restrict__ g_mu,
+                                                         float* __restrict__ g_sigma) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)(K + 1) * OC) return;
+    const int k = (int)(i / OC), o = (int)(i - (int64_t)k * OC);
+    const float g = g_eff[i];
+    g_mu[i] = g;
+    g_sigma[i] = g * (k < K ? eps_q[o] * eps_p[k] : eps_q[o]);
+}
+
+// logits[b, a, j] = q[b, a, j] - mean_a q[b, ., j] + v[b, j]  (atari_network.py:203), in place in q
+__global__ __launch_bounds__(256) void dueling_kernel(float* __restrict__ q, const float* __restrict__ v, int64_t B, int A, int N,
+                                                      int ldq, int ldv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * N) return;
+    const int64_t b = i / N;
+    const int j = (int)(i - b * N);
+    float* row = q + b * ldq;
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += row[a * N + j];
+    const float shift = v[b * ldv + j] - s / (float)A;
+    for (int a = 0; a < A; ++a) row[a * N + j] += shift;
+}
+
+// backward of dueling_kernel: dq = dl - mean_a dl (in place), dv = sum_a dl; padding columns of dv zeroed
+__global__ __launch_bounds__(256) void dueling_bwd_kernel(float* __restrict__ dl, float* __restrict__ dv, int64_t B, int A, int N,
+                                                          int ldq, int ldv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * ldv) return;
+    const int64_t b = i / ldv;
+    const int j = (int)(i - b * ldv);
+    if (j >= N) { dv[i] = 0.f; return; }
+    float* row = dl + b * ldq;
+    float s = 0.f;
+    for (int a = 0; a < A; ++a) s += row[a * N + j];
+    dv[i] = s;
+    const float m = s / (float)A;
+    for (int a = 0; a < A; ++a) row[a * N + j] -= m;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+struct RActs {
+    float* eff[4];               // effective weight matrices of the four noisy layers
+    float* c[3];                 // conv activations; c[2] viewed as [B, F] = the features
+    float* hq; float* hv;        // hidden activations of the two branches
+    float* q; float* v;          // Q2 / V2 outputs; q becomes logits, then probabilities
+    float* split;
+};
+
+size_t r_split_floats(const RNet& n) {
+    size_t s = 4;
+    for (int i = 0; i < 3; ++i) { const int ns = ts::conv_fwd_splits(n.conv[i]); if (ns > 1) s = std::max(s, (size_t)ns * n.conv[i].out_elems()); }
+    for (int i = 0; i < 4; ++i) { const int ns = ts::conv_fwd_splits(n.lin[i]); if (ns > 1) s = std::max(s, (size_t)ns * n.lin[i].out_elems()); }
+    return s;
+}
+
+size_t r_acts_bytes(const RNet& n) {
+    size_t s = al(4 * r_split_floats(n));
+    for (int i = 0; i < 4; ++i) s += al(4 * (size_t)n.lin[i].param_elems()) + al(4 * (size_t)n.lin[i].out_elems());
+    for (int i = 0; i < 3; ++i) s += al(4 * (size_t)n.conv[i].out_elems());
+    return s;
+}
+
+char* r_carve(const RNet& n, char* p, RActs* a) {
+    auto take = [&](size_t floats) { float* r = reinterpret_cast<float*>(p); p += al(4 * floats); return r; };
+    for (int i = 0; i < 4; ++i) a->eff[i] = take((size_t)n.lin[i].param_elems());
+    for (int i = 0; i < 3; ++i) a->c[i] = take((size_t)n.conv[i].out_elems());
+    a->hq = take((size_t)n.lin[0].out_elems()); a->q = take((size_t)n.lin[1].out_elems());
+    a->hv = take((size_t)n.lin[2].out_elems()); a->v = take((size_t)n.lin[3].out_elems());
+    a->split = take(r_split_floats(n));
+    return p;
+}
+
+// One pass of RainbowNet.forward: probabilities in a.q ([B, ldq] rows), optional Q values / greedy action.
+int r_forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* params, const float* noise, const void* obs,
+              bool obs_u8, int64_t B, const float* support, const RActs& a, float* q_out, int64_t* act_out) {
+    for (int i = 0; i < 4; ++i) {
+        const int K = n.lin[i].IC, OC = n.lin[i].OC;
+        const float* mu = params + n.off_lin[i];
+        hipLaunchKernelGGL(noisy_eff_kernel, dim3((unsigned)ts::ceil_div((int64_t)(K + 1) * OC, 256)), dim3(256), 0, s, mu,
+                           mu + n.lin[i].param_elems(), noise ? noise + n.off_noise[2 * i] : (const float*)nullptr,
+                           noise ? noise + n.off_noise[2 * i + 1] : (const float*)nullptr, K, OC, a.eff[i]);
+    }
+    TS_LAUNCH_CHECK();
+    const float* x = static_cast<const float*>(obs);
+    for (int i = 0; i < 3; ++i) {
+        if (int rc = ts::conv_forward(s, n.conv[i], x, params + n.off_conv[i], a.c[i], true, a.split, ws, i == 0 && obs_u8)) return rc;
+        x = a.c[i];
+    }
+    if (int rc = ts::conv_forward(s, n.lin[0], a.c[2], a.eff[0], a.hq, true, a.split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, n.lin[1], a.hq, a.eff[1], a.q, false, a.split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, n.lin[2], a.c[2], a.eff[2], a.hv, true, a.split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, n.lin[3], a.hv, a.eff[3], a.v, false, a.split, ws)) return rc;
+    hipLaunchKernelGGL(dueling_kernel, dim3((unsigned)ts::ceil_div(B * n.n_atoms, 256)), dim3(256), 0, s, a.q, a.v, B, n.n_act,
+                       n.n_atoms, n.ldq, n.ldv);
+    hipLaunchKernelGGL(distq_head_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, TS_DISTQ_C51, a.q, support, B,
+                       n.n_act, n.n_atoms, n.ldq, q_out, act_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_rainbow_layout(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, int64_t* h_out20) {
+    RNet n;
+    if (int rc = make_rnet(1, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    TS_REQUIRE(h_out20, TS_ERR_INVALID_ARG, "ts_rainbow_layout: NULL output");
+    h_out20[0] = n.F; h_out20[1] = n.ldq; h_out20[2] = n.ldv; h_out20[3] = n.total; h_out20[4] = n.noise_total;
+    for (int i = 0; i < 3; ++i) h_out20[5 + i] = n.off_conv[i];
+    for (int i = 0; i < 4; ++i) h_out20[8 + i] = n.off_lin[i];
+    for (int i = 0; i < 8; ++i) h_out20[12 + i] = n.off_noise[i];
+    return TS_OK;
+}
+
+int ts_rainbow_forward(ts_workspace* ws, const float* params, const float* noise, int64_t c, int64_t h, int64_t w,
+                       int64_t n_act, int64_t n_atoms, const float* support, const void* obs_nhwc, int obs_u8, int64_t B,
+                       float* dist_out, float* q_out, int64_t* act_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rainbow_forward: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_rainbow_forward: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && support && obs_nhwc, TS_ERR_INVALID_ARG, "ts_rainbow_forward: NULL argument");
+    RNet n;
+    if (int rc = make_rnet((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    if (int rc = ts::ws_reserve(ws, r_acts_bytes(n))) return rc;
+    RActs a;
+    r_carve(n, static_cast<char*>(ws->base), &a);
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = r_forward(s, ws, n, params, noise, obs_nhwc, obs_u8 != 0, B, support, a, q_out, act_out)) return rc;
+    if (dist_out) {
+        const int row = n.n_act * n.n_atoms;
+        hipLaunchKernelGGL(distq_select_kernel, dim3((unsigned)ts::ceil_div(B * row, 256)), dim3(256), 0, s, a.q,
+                           (const int64_t*)nullptr, B, row, n.ldq, dist_out);
+        TS_LAUNCH_CHECK();
+    }
+    return TS_OK;
+}
+
+int ts_rainbow_next_dist(ts_workspace* ws, const float* params, const float* noise, const float* params_old,
+                         const float* noise_old, int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms,
+                         const float* support, const void* obs_next_nhwc, int obs_u8, int64_t B, float* out,
+                         ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rainbow_next_dist: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_rainbow_next_dist: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(params && support && obs_next_nhwc && out, TS_ERR_INVALID_ARG, "ts_rainbow_next_dist: NULL argument");
+    RNet n;
+    if (int rc = make_rnet((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    const size_t one = r_acts_bytes(n);
+    if (int rc = ts::ws_reserve(ws, 2 * one + al(8 * (size_t)B))) return rc;
+    RActs ao, at;
+    char* p = r_carve(n, static_cast<char*>(ws->base), &ao);
+    p = r_carve(n, p, &at);
+    int64_t* act = reinterpret_cast<int64_t*>(p);
+    hipStream_t s = ts::as_stream(stream), side;
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    const bool two = params_old != nullptr;
+    if (two) {
+        if (int rc = ts::stream_wait(ws, s, side, 9)) return rc;
+        if (int rc = r_forward(side, ws, n, params_old, noise_old, obs_next_nhwc, obs_u8 != 0, B, support, at, nullptr, nullptr))
+            return rc;
+    }
+    if (int rc = r_forward(s, ws, n, params, noise, obs_next_nhwc, obs_u8 != 0, B, support, ao, nullptr, act)) return rc;
+    if (two)
+        if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
+    hipLaunchKernelGGL(distq_select_kernel, dim3((unsigned)ts::ceil_div(B * n.n_atoms, 256)), dim3(256), 0, s,
+                       two ? at.q : ao.q, act, B, n.n_atoms, n.ldq, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_rainbow_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, const float* noise,
+                      int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t n_atoms, const float* support,
+                      const void* obs_nhwc, int obs_u8, const int64_t* act, const float* returns, const float* next_dist,
+                      const float* weight, int64_t B, const ts_distq_hparams* hp, float* prio_out, float* loss_out,
+                      float* target_dist_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rainbow_update: workspace is NULL");
+    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_rainbow_update: bad batch size / step");
+    TS_REQUIRE(params && adam_m && adam_v && noise && support && obs_nhwc && act && returns && next_dist && hp && prio_out &&
+                   loss_out && hp->v_max > hp->v_min, TS_ERR_INVALID_ARG, "ts_rainbow_update: bad argument");
+    RNet n;
+    if (int rc = make_rnet((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    // workspace: pass | dY buffers | wgrad slabs | effective-weight gradient | flat gradient | per-sample terms | norm
+    size_t slab = 0, geff = 0;
+    for (int i = 0; i < 3; ++i) slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.conv[i]) * n.conv[i].param_elems());
+    for (int i = 0; i < 4; ++i) {
+        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.lin[i]) * n.lin[i].param_elems());
+        geff = std::max(geff, 4 * (size_t)n.lin[i].param_elems());
+    }
+    size_t bytes = r_acts_bytes(n) + al(slab) + al(geff) + al(4 * (size_t)n.total) + al(4 * (size_t)B) + 4096;
+    for (int i = 0; i < 3; ++i) bytes += al(4 * (size_t)n.conv[i].out_elems());
+    bytes += 2 * al(4 * (size_t)n.lin[0].out_elems()) + al(4 * (size_t)n.lin[1].out_elems()) + al(4 * (size_t)n.lin[3].out_elems()) +
+             al(4 * (size_t)n.conv[2].out_elems());
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    RActs a;
+    char* p = r_carve(n, static_cast<char*>(ws->base), &a);
+    auto take = [&](size_t floats) { float* r = reinterpret_cast<float*>(p); p += al(4 * floats); return r; };
+    float* dc[3];
+    for (int i = 0; i < 3; ++i) dc[i] = take((size_t)n.conv[i].out_elems());
+    float* dhq = take((size_t)n.lin[0].out_elems());
+    float* dhv = take((size_t)n.lin[0].out_elems());
+    float* dq = take((size_t)n.lin[1].out_elems());
+    float* dv = take((size_t)n.lin[3].out_elems());
+    float* dfeat2 = take((size_t)n.conv[2].out_elems());
+    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
+    float* g_eff = reinterpret_cast<float*>(p); p += al(geff);
+    float* grad = take((size_t)n.total);
+    float* lw = take((size_t)B);
+    float* norm_part = reinterpret_cast<float*>(p);
+    if (grad_out) grad = grad_out;
+
+    if (int rc = r_forward(s, ws, n, params, noise, obs_nhwc, obs_u8 != 0, B, support, a, nullptr, nullptr)) return rc;
+    const double dz = (hp->v_max - hp->v_min) / (double)(n.n_atoms - 1);
+    hipLaunchKernelGGL(c51_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, a.q, act, returns, next_dist, weight, support,
+                       (float)hp->v_min, (float)hp->v_max, (float)dz, B, n.n_atoms, n.ldq, dq, prio_out, lw, target_dist_out);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, lw, B, loss_out);
+    hipLaunchKernelGGL(dueling_bwd_kernel, dim3((unsigned)ts::ceil_div(B * n.ldv, 256)), dim3(256), 0, s, dq, dv, B, n.n_act,
+                       n.n_atoms, n.ldq, n.ldv);
+    TS_LAUNCH_CHECK();
+    // the four noisy layers: (input, upstream gradient, input-gradient target, ReLU mask of the input)
+    const float* xin[4] = {a.c[2], a.hq, a.c[2], a.hv};
+    const float* dy[4] = {dhq, dq, dhv, dv};
+    float* dxo[4] = {dc[2], dhq, dfeat2, dhv};
+    const int order[4] = {1, 0, 3, 2};               // Q2, Q0, V2, V0
+    for (int oi = 0; oi < 4; ++oi) {
+        const int i = order[oi];
+        const int K = n.lin[i].IC, OC = n.lin[i].OC;
+        if (int rc = ts::conv_wgrad(s, n.lin[i], xin[i], dy[i], slabs, ws)) return rc;
+        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.lin[i]), n.lin[i].param_elems(), g_eff)) return rc;
+        float* g_mu = grad + n.off_lin[i];
+        hipLaunchKernelGGL(noisy_grad_kernel, dim3((unsigned)ts::ceil_div((int64_t)(K + 1) * OC, 256)), dim3(256), 0, s, g_eff,
+                           noise + n.off_noise[2 * i], noise + n.off_noise[2 * i + 1], K, OC, g_mu,
+                           g_mu + n.lin[i].param_elems());
+        TS_LAUNCH_CHECK();
+        if (int rc = ts::conv_dgrad(s, n.lin[i], dy[i], a.eff[i], xin[i], dxo[i], ws)) return rc;
+    }
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)ts::ceil_div(n.conv[2].out_elems(), 256)), dim3(256), 0, s, dc[2], dfeat2,
+                       n.conv[2].out_elems());
+    TS_LAUNCH_CHECK();
+    for (int i = 2; i >= 0; --i) {
+        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.c[i - 1];
+        if (int rc = ts::conv_wgrad(s, n.conv[i], x, dc[i], slabs, ws, i == 0 && obs_u8)) return rc;
+        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.conv[i]), n.conv[i].param_elems(), grad + n.off_conv[i]))
+            return rc;
+        if (i > 0)
+            if (int rc = ts::conv_dgrad(s, n.conv[i], dc[i], params + n.off_conv[i], a.c[i - 1], dc[i - 1], ws)) return rc;
+    }
+    if (hp->lr < 0.0) return TS_OK;
+    return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+                         hp->max_grad_norm, norm_part);
+}
+
+}  // extern "C"
+
+namespace {
+
 }  // namespace
 
 extern "C" {

@@ -397,6 +397,120 @@ def make_hip_c51():
     Supported model: C51Net (atari_network.py:125-151) with C51Policy's support, Adam; buffer layouts as HipDQN."""
     return _make_hip_distq("c51")
 
+def make_hip_rainbow():
+    """Returns HipRainbow(RainbowDQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, rainbow.py:93-101 ->
+    c51.py:120-160) on the engine.  Supported model: RainbowNet(is_dueling=True, is_noisy=True)
+    (atari_network.py:154-208) with C51Policy's support, Adam; buffer layouts as HipDQN.  The NoisyLinear noise is drawn by
+    the torch modules themselves (`RainbowDQN._sample_noise`, so torch's generator advances as in the reference) and
+    handed to the engine."""
+    from tianshou.algorithm.modelfree.rainbow import RainbowDQN
+    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats
+
+    from . import distq as Q
+    from . import dqn as D
+    from . import rainbow as RB
+
+    class HipRainbow(RainbowDQN):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            keys = list(self.policy.model.state_dict().keys())
+            if sorted(keys) != sorted(RB.TIANSHOU_KEYS + RB.NOISE_KEYS):
+                raise NotImplementedError("HipRainbow: the model must be RainbowNet(is_dueling=True, is_noisy=True)")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _noise_of(self, model, dims):
+            sd = model.state_dict()
+            return RB.noise_from_torch([sd[k] for k in RB.NOISE_KEYS], *dims, self._hip_device)
+
+        def _engine(self, c, h, w):
+            if self._hip_engine is None:
+                model = self.policy.model
+                sd = model.state_dict()
+                n_atoms = int(self.policy.num_atoms)
+                n_act = sd["Q.2.mu_bias"].numel() // n_atoms
+                dims = (c, h, w, n_act, n_atoms)
+                opt, g = _adam_of(self.optim)
+                cfg = Q.DistQConfig(kind=Q.C51, n_atoms=n_atoms, gamma=self.gamma, n_step=self.n_step,
+                                    target_update_freq=self.target_update_freq, lr=g["lr"], betas=tuple(g["betas"]),
+                                    adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm,
+                                    v_min=float(self.policy.v_min), v_max=float(self.policy.v_max))
+                dev = self._hip_device
+                eng = self._hip_engine = RB.RainbowEngine(c, h, w, n_act, RB.flat_from_torch([sd[k] for k in RB.TIANSHOU_KEYS], *dims, dev),
+                                                          self._noise_of(model, dims), cfg)
+                eng.iter = self._iter
+                ms, vs, step = adam_state(opt, params_by_keys(model, RB.TIANSHOU_KEYS))          # resume from a checkpoint
+                eng.adam_m, eng.adam_v = RB.flat_from_torch(ms, *dims, dev), RB.flat_from_torch(vs, *dims, dev)
+                eng.adam_step = step
+                if eng.params_old is not None:
+                    so = self.model_old.state_dict()
+                    eng.params_old = RB.flat_from_torch([so[k] for k in RB.TIANSHOU_KEYS], *dims, dev)
+                    eng.noise_old = self._noise_of(self.model_old, dims)
+            return self._hip_engine
+
+        @staticmethod
+        def _layout(buffer):
+            obs = np.asarray(buffer.obs)
+            stack = int(getattr(buffer, "stack_num", 1))
+            if stack > 1:
+                if obs.ndim != 3:
+                    raise NotImplementedError("HipRainbow: frame stacking needs single [h, w] frames per slot")
+                return stack, obs.shape[1], obs.shape[2], stack
+            if obs.ndim != 4:
+                raise NotImplementedError("HipRainbow: observations must be [c, h, w]")
+            return obs.shape[1], obs.shape[2], obs.shape[3], 1
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, "HipRainbow")
+            c, h, w, stack = self._layout(buffer)
+            eng = self._engine(c, h, w)
+            m = _mirror(self, buffer, self._hip_device)
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            batch.returns = eng.preprocess(m, idx)
+            self._hip_idx, self._hip_stack = idx, stack
+            if hasattr(batch, "weight"):
+                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
+            return batch
+
+        def _update_with_batch(self, batch):
+            eng, m = self._hip_engine, self._hip_mirror
+            idx, stack = self._hip_idx, self._hip_stack
+            dims = (eng.c, eng.h, eng.w, eng.n_act, eng.cfg.n_atoms)
+            self._sample_noise(self.policy.model)                                 # rainbow.py:97-100
+            noise_old = None
+            if self.use_target_network:
+                self._sample_noise(self.model_old)
+                noise_old = self._noise_of(self.model_old, dims)
+            eng.set_noise(self._noise_of(self.policy.model, dims), noise_old)
+            weight = batch.pop("weight", None)
+            obs = D.gather_obs_nhwc(m.obs, m, idx, stack, as_u8=True)
+            if m.obs_next is not None:                     # batch.obs_next = buffer[indices].obs_next (buffer_base.py:624-626)
+                obs_next = D.gather_obs_nhwc(m.obs_next, m, idx, stack, as_u8=True)
+            else:
+                obs_next = D.gather_obs_nhwc(m.obs, m, m.next(idx), stack, as_u8=True)
+            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
+            loss, prio = eng.update_with_batch(obs, act, batch.returns, obs_next, weight)
+            self._iter = eng.iter
+            batch.weight = prio                                                   # prio-buffer, c51.py:157
+            model = self.policy.model
+            with torch.no_grad():
+                for p, t in zip(params_by_keys(model, RB.TIANSHOU_KEYS), RB.flat_to_torch(eng.params, *dims)):
+                    p.copy_(t)
+                if eng.params_old is not None:
+                    for p, t in zip(params_by_keys(self.model_old, RB.TIANSHOU_KEYS), RB.flat_to_torch(eng.params_old, *dims)):
+                        p.copy_(t)
+                    if (eng.iter - 1) % eng.cfg.target_update_freq == 0:          # the sync carried the noise along
+                        so, sn = self.model_old.state_dict(), model.state_dict()
+                        for k in RB.NOISE_KEYS:
+                            so[k].copy_(sn[k])
+            store_adam_state(self.optim._optim, params_by_keys(model, RB.TIANSHOU_KEYS), RB.flat_to_torch(eng.adam_m, *dims),
+                             RB.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+            return LossSequenceTrainingStats(loss=float(loss.item()))            # as c51.py:160
+
+    return HipRainbow
+
+
 
 # ---------------------------------------------------------------------------------------------------
 # SAC (sac.py:213-336) on the mujoco_sac.py networks
