@@ -1,7 +1,7 @@
 """Measurement of the rows SURVEY 8f adds to the hot path (N3) and of BASELINE.json configs[0], on the same contract
 as bench.py: TD3 / DDPG / DiscreteSAC (MLP learners), QRDQN / C51 (NatureCNN learners) and the CartPole-shape PPO.
 
-    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|rainbow|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
+    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|rainbow|npg|trpo|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
 
 One "step" = one reference update(): sample -> gather -> target / n-step return -> optimizer steps (-> Polyak), everything
 device-resident; for ppo_discrete one update() = preprocessing + repeat x ceil(N / 64) minibatch steps (value = minibatch
@@ -338,6 +338,71 @@ def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
                  _roofline(prof, flop, "conv / linear GEMMs of one update"), cpu, {"final_loss": float(loss)})
 
 
+# ---- NPG / TRPO (MuJoCo shape, as C2) ---------------------------------------------------------------------------------------
+def run_natural(steps, warmup, with_cpu, algo="npg"):
+    from oracle import oracle_npg as ON
+    from oracle import oracle_ppo as OP
+    from tianshou_amd import npg as NG
+
+    OBS, ACT, HID, E, T, MB, dev = 17, 6, 64, 512, 512, 65536, torch.device("cuda")         # 2^18 transitions, 4 minibatches
+    n = E * T
+    g = torch.Generator(device=dev).manual_seed(0)
+    obs, obs_next = torch.randn(n, OBS, generator=g, device=dev), torch.randn(n, OBS, generator=g, device=dev)
+    act = torch.randn(n, ACT, generator=g, device=dev) * 0.6
+    rew = torch.randn(n, generator=g, device=dev).double()
+    term = torch.rand(n, generator=g, device=dev) < 0.002
+    trunc = torch.zeros(n, dtype=torch.bool, device=dev)
+    cut = (torch.arange(E, device=dev) + 1) * T - 1
+    p = OP.init_params(OBS, ACT, seed=0)
+    a_keys = ("a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma")
+    c_keys = ("c_w1", "c_b1", "c_w2", "c_b2", "c_wv", "c_bv")
+    cfg = NG.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=5, lr=1e-3)
+    eng = NG.NPGEngine(OBS, ACT, HID, NG.actor_flat_from_torch([p[k] for k in a_keys], OBS, HID, ACT),
+                       NG.critic_flat_from_torch([p[k] for k in c_keys], OBS, HID), cfg)
+    count = [0]
+
+    def update():
+        pre = eng.preprocess(obs, obs_next, act, rew, term, trunc, cut)
+        stats, k = eng.update(pre, MB, 1, [torch.randperm(n, generator=g, device=dev)])
+        count[0] = k
+        return stats
+
+    dt, stats, prof = _time(update, steps, warmup)
+    k = count[0]
+    a_dims, c_dims = [OBS, HID, HID, ACT], [OBS, HID, HID, 1]
+    per_pass = mlp_flop(a_dims)
+    # per minibatch sample: gradient (fwd + bwd), 10 (+1 TRPO) Fisher-vector products (forward-mode pass ~ 2 fwd, reverse pass),
+    # candidate evaluations, 5 critic iterations (fwd + bwd)
+    fvps = 11 if algo == "trpo" else 10
+    evals = 10 if algo == "trpo" else 1
+    flop_mb = MB * (mlp_flop(a_dims, wgrad=True, dgrad_layers=2) + fvps * (2 * per_pass + mlp_flop(a_dims, wgrad=True, dgrad_layers=2)
+                                                                           - per_pass) + evals * per_pass
+                    + 5 * mlp_flop(c_dims, wgrad=True, dgrad_layers=2))
+    flop = k * flop_mb + n * (mlp_flop(a_dims) + 2 * mlp_flop(c_dims))
+    cpu = None
+    if with_cpu:
+        ocfg = ON.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=5, lr=1e-3)
+        st = OP.PPOState(params={kk: v.clone() for kk, v in p.items()})
+        gc = torch.Generator().manual_seed(0)
+        o, a = torch.randn(MB, OBS, generator=gc), torch.randn(MB, ACT, generator=gc) * 0.6
+        adv, ret = torch.randn(MB, generator=gc), torch.randn(MB, generator=gc)
+        with torch.no_grad():
+            lp = OP.dist_of(*OP.actor_forward(p, o)).log_prob(a)
+        th = _threads()
+        ON.minibatch_step(st, ocfg, o[:4096], a[:4096], adv[:4096], ret[:4096], lp[:4096])
+        t0 = time.perf_counter()
+        ON.minibatch_step(st, ocfg, o, a, adv, ret, lp)
+        cpu = {"value": 1 / (time.perf_counter() - t0), "unit": "update-steps/s", "cores": th, "kind": "port",
+               "sample": f"one minibatch step of {MB} samples (gradient, 10 CG iterations by double backward, critic iterations), "
+                         "torch fp32 CPU oracle"}
+    name = algo.upper()
+    return _line(f"{name} learn() update-steps/sec (minibatch 65536, obs 17, act 6, MLP[64,64], preprocessing incl.)",
+                 steps * k / dt, "update-steps/s", steps, warmup, dt,
+                 f"{name} on a C2-shape rollout: {E} envs x {T} steps = {n} transitions, minibatch {MB}, 5 critic iterations",
+                 _roofline(prof, flop, "linear-layer GEMMs of the Fisher-vector products, gradients and critic steps"), cpu,
+                 {"gradient_steps_per_update": k, "final_stats": [float(x) for x in stats[-1].tolist()]})
+
+
 # ---- PPO, CartPole shape (BASELINE.json configs[0]) ------------------------------------------------------------------------
 def run_ppo_discrete(steps, warmup, with_cpu):
     from oracle import oracle_ppo as OP
@@ -396,6 +461,7 @@ RUNNERS = {
     "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
     "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),
     "ppo_discrete": run_ppo_discrete, "rainbow": run_rainbow,
+    "npg": lambda s, w, c: run_natural(s, w, c, "npg"), "trpo": lambda s, w, c: run_natural(s, w, c, "trpo"),
 }
 
 

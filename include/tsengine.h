@@ -673,6 +673,52 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
                    float* stats_out4, float* weight_out, float* grads_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * NPG / TRPO (tianshou/algorithm/modelfree/npg.py, trpo.py) on the MuJoCo actor-critic of
+ * examples/mujoco/mujoco_npg.py:103-128 (= the PPO nets: Net[h, h] tanh, unbounded Gaussian actor with a state-independent
+ * sigma_param, separate critic).
+ * Flat layouts: actor  L1 [k0 + 1, h] | L2 [h + 1, h] | head [h + 1, 32] (columns [0, act_dim) = mu) | log_sigma [32];
+ *               critic L1 | L2 | head [h + 1, 32] (column 0 = V);  k0 = obs_dim rounded up to 32, last row of a block = bias,
+ *               padding zero.  h a multiple of 32 in [32, 1024], act_dim <= 32.
+ * ------------------------------------------------------------------------------------------- */
+
+/* h_out3 = {k0, actor parameter count, critic parameter count}. */
+int ts_npg_layout(int64_t obs_dim, int64_t hidden, int64_t act_dim, int64_t* h_out3);
+
+/* The no-grad passes of NPG._preprocess_batch (npg.py:129-135, a2c.py:122-129) on obs float32[B, obs_dim]:
+ * v_out[b] = V(obs_b) (nullable, needs critic); logp_out[b] = log pi(act_b | obs_b) (nullable, needs actor and act);
+ * mu_out float32[B, act_dim] (nullable). */
+int ts_npg_infer(ts_workspace* ws, const float* actor, const float* critic, int64_t obs_dim, int64_t hidden, int64_t act_dim,
+                 const float* obs, const float* act, int64_t B, float* v_out, float* logp_out, float* mu_out,
+                 ts_stream_t stream);
+
+typedef struct ts_npg_hparams {
+    double damping;            /* npg.py:118 (_MVP adds damping * v) */
+    double trust_region_size;  /* NPG: actor step size (npg.py:174) */
+    double max_kl;             /* TRPO (trpo.py:153-160, :179) */
+    double backtrack_coeff;    /* TRPO line search (trpo.py:184) */
+    double residual_tol;       /* conjugate gradients (npg.py:206, 1e-10) */
+    int32_t algo;              /* 0: NPG, 1: TRPO */
+    int32_t cg_iters;          /* npg.py:167 / trpo.py:150: 10 */
+    int32_t max_backtracks;    /* TRPO, <= 32 */
+    int32_t reserved;
+} ts_npg_hparams;
+
+/* The actor half of one minibatch (npg.py:149-177 / trpo.py:132-191): vanilla gradient of the surrogate, natural gradient
+ * by conjugate gradients on Fisher-vector products, parameter step (NPG) or step size + backtracking line search (TRPO);
+ * `actor` is updated in place.  logp_old: TRPO only.  stats_out3 = {actor_loss, kl(old || new), step_size (TRPO, else 0)}.
+ * dbg_out (nullable) float32[3 P] = {flat gradient, F^-1 g (= -search_direction), F g + damping g}, P = actor count.
+ * No host synchronisation: the early exit of conjugate gradients and the line search are decided on the device. */
+int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t hidden, int64_t act_dim, const float* obs,
+                      const float* act, const float* adv, const float* logp_old, int64_t B, const ts_npg_hparams* hp,
+                      float* stats_out3, float* dbg_out, ts_stream_t stream);
+
+/* One critic iteration (npg.py:180-183): vf_loss = mse_loss(returns, V(obs)), clip_grad_norm_ + Adam on the critic
+ * (algorithm_base.py:484-500).  lr < 0: gradient only.  loss_out float32[1]; grad_out nullable. */
+int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                       int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
+                       double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,
  * nets of examples/mujoco/mujoco_td3.py:85-103 / mujoco_ddpg.py
  * ------------------------------------------------------------------------------------------- */

@@ -455,6 +455,112 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
+def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
+            lr: float = 1e-3, **kwargs) -> None:
+    """Runs the reference NPG.update() / TRPO.update() on the MuJoCo actor-critic (examples/mujoco/mujoco_npg.py:103-128,
+    the PPO nets) over a synthetic VectorReplayBuffer and dumps every intermediate."""
+    from tianshou.algorithm.modelfree.npg import NPG
+    from tianshou.algorithm.modelfree.trpo import TRPO
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    N = E * T
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    critic = ContinuousCritic(preprocess_net=net_c)
+    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    for m in ActorCritic(actor, critic).modules():
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            nn.init.zeros_(m.bias)
+    for m in actor.mu.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.zeros_(m.bias)
+            m.weight.data.copy_(0.01 * m.weight.data)
+
+    def dist(loc_scale):
+        loc, scale = loc_scale
+        return Independent(Normal(loc, scale), 1)
+
+    space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True, action_bound_method="clip",
+                                      action_space=space)
+    cls = NPG if algo == "npg" else TRPO
+    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **kwargs)
+    assert [n for n, _ in actor.named_parameters()][0] == "sigma_param"
+    out: dict[str, np.ndarray] = {"flat_params0": _flat_from_modules(actor, critic),
+                                  "dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat, int(algo == "trpo")])}
+    buf = VectorReplayBuffer(N, E)
+    obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+    act = rng.normal(size=(T, E, act_dim)).astype(np.float32) * 0.7
+    rew = rng.normal(size=(T, E)).astype(np.float32)
+    term = rng.random((T, E)) < 0.02
+    trunc = np.zeros((T, E), bool)
+    trunc[T // 2 - 1:: T // 2] = True
+    trunc &= ~term
+    for t in range(T):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+    out["obs"], out["obs_next"] = np.asarray(buf.obs, np.float32), np.asarray(buf.obs_next, np.float32)
+    out["act"], out["rew"] = np.asarray(buf.act, np.float32), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+
+    perms, seqs, pre_dump = [], [], {}
+    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, cls._preprocess_batch
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p, np.int64))
+        return p
+
+    def rec_from(c_, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(c_, seq)
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        pre_dump.update(v_s=b.v_s.numpy().copy(), returns=b.returns.numpy().copy(), adv=b.adv.numpy().copy(),
+                        logp_old=b.logp_old.numpy().copy(), indices=np.asarray(indices, np.int64),
+                        unfinished=np.asarray(buffer.unfinished_index(), np.int64))
+        return b
+
+    np.random.permutation, cls._preprocess_batch = rec_perm, rec_pre
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    try:
+        np.random.seed(seed + 100)
+        with policy_within_training_step(algorithm.policy):
+            algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+    finally:
+        np.random.permutation, cls._preprocess_batch = orig_perm, orig_pre
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+    assert len(perms) == repeat and len(seqs) == (3 if algo == "npg" else 4)
+    # npg.py:189-193 order: actor_loss, vf_loss, kl; trpo.py:204-207: actor_loss, vf_loss, kl, step_size
+    out["perms"], out["stats"] = np.stack(perms), np.stack(seqs, axis=1)
+    out["flat_params"] = _flat_from_modules(actor, critic)
+    for k, v in pre_dump.items():
+        out["pre_" + k] = v
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, optim_critic_iters=algorithm.optim_critic_iters,
+               trust_region_size=getattr(algorithm, "trust_region_size", 0.5),
+               advantage_normalization=float(algorithm.advantage_normalization),
+               return_scaling=float(algorithm.return_scaling), max_batchsize=float(algorithm.max_batchsize),
+               damping=algorithm._damping, max_kl=getattr(algorithm, "max_kl", 0.01),
+               backtrack_coeff=getattr(algorithm, "backtrack_coeff", 0.8), max_backtracks=getattr(algorithm, "max_backtracks", 10),
+               lr=lr)
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"npg_{tag}.npz"), **out)
+
+
+def gen_npg_all() -> None:
+    gen_npg("npg", algo="npg", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=41, optim_critic_iters=3,
+            trust_region_size=0.1, advantage_normalization=True, gae_lambda=0.95, gamma=0.99, return_scaling=True,
+            max_batchsize=64)
+    gen_npg("trpo", algo="trpo", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=43, optim_critic_iters=2,
+            max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10, advantage_normalization=True, gae_lambda=0.95, gamma=0.99,
+            return_scaling=False, max_batchsize=256)
+
+
 def gen_dqn(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, batch: int,
             n_updates: int, seed: int, per: bool, stack: bool, lr: float = 1e-4, **dqn_kwargs) -> None:
     """Runs the reference DQN.update() (DQNet + DiscreteQLearningPolicy, dqn.py) on a synthetic
@@ -560,6 +666,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
         gen_rainbow_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "npg":
+        gen_npg_all()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "distq":
         gen_distq_all()

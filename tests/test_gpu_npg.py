@@ -1,0 +1,162 @@
+"""GPU parity of the NPG / TRPO rows: natural gradient by conjugate gradients on Fisher-vector products,
+NPG's fixed step and TRPO's step size + line search, critic iterations -- through the C ABI, against the oracle
+(oracle/oracle_npg.py: the reference's autograd double backward, pinned by tests/golden/npg_*.npz).
+
+The engine forms F v as the Gauss-Newton product J^T diag(1 / sigma^2) J v / B, the reference by differentiating the mean KL
+twice; both are the same matrix, evaluated with different float32 rounding, and conjugate gradients amplify that rounding.
+Gradients and single products are held to 1e-5; the conjugate-gradient solution and what follows from it to "within 1e-5
+of the float64 solution or at least as close to it as the reference's own float32 evaluation" (x2), as for SAC's actor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_npg as ON
+from oracle import oracle_ppo as OP
+from tests.test_oracle_golden import load_npg
+
+pytestmark = pytest.mark.gpu
+A_KEYS = ("a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma")
+C_KEYS = ("c_w1", "c_b1", "c_w2", "c_b2", "c_wv", "c_bv")
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def make_engine(p, obs_dim, act_dim, cfg):
+    from tianshou_amd import npg as NG
+
+    ecfg = NG.NPGConfig(**{k: getattr(cfg, k) for k in ("algo", "gamma", "gae_lambda", "optim_critic_iters",
+                                                       "trust_region_size", "advantage_normalization", "return_scaling",
+                                                       "damping", "max_kl", "backtrack_coeff", "max_backtracks", "lr", "betas",
+                                                       "adam_eps", "max_grad_norm")})
+    return NG.NPGEngine(obs_dim, act_dim, 64, NG.actor_flat_from_torch([p[k] for k in A_KEYS], obs_dim, 64, act_dim),
+                        NG.critic_flat_from_torch([p[k] for k in C_KEYS], obs_dim, 64), ecfg)
+
+
+def oracle_order(flat, obs_dim, act_dim):
+    """engine actor vector -> the reference's flat order (sigma_param first)."""
+    from tianshou_amd import npg as NG
+
+    t = NG.actor_flat_to_torch(flat, obs_dim, 64, act_dim)
+    return torch.cat([t[6].reshape(-1)] + [x.reshape(-1) for x in t[:6]]).cpu()
+
+
+def rand_params(obs_dim, act_dim, seed):
+    p = OP.init_params(obs_dim, act_dim, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    p["a_wmu"] = p["a_wmu"] * 30.0                            # a policy whose mean actually depends on the observation
+    p["a_sigma"] = torch.randn(act_dim, generator=g) * 0.3 - 0.5
+    return p
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(17, 6, 1000), (33, 1, 64), (4, 32, 257)])
+def test_infer_vs_oracle(obs_dim, act_dim, B):
+    p = rand_params(obs_dim, act_dim, 1)
+    eng = make_engine(p, obs_dim, act_dim, ON.NPGConfig())
+    g = torch.Generator().manual_seed(B)
+    obs, act = torch.randn(B, obs_dim, generator=g), torch.randn(B, act_dim, generator=g)
+    v, logp, mu = eng.infer(obs, act, want_mu=True)
+    with torch.no_grad():
+        mu_ref, sigma = OP.actor_forward(p, obs)
+        assert rel_err(mu.cpu(), mu_ref) < 1e-5 and rel_err(v.cpu(), OP.critic_forward(p, obs).flatten()) < 1e-5
+        np.testing.assert_allclose(logp.cpu().numpy(), OP.dist_of(mu_ref, sigma).log_prob(act).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("algo,B", [("npg", 4096), ("trpo", 700)])
+def test_actor_step_vs_oracle_and_float64(algo, B):
+    obs_dim, act_dim = 17, 6
+    p = rand_params(obs_dim, act_dim, 3)
+    cfg = ON.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=1)
+    g = torch.Generator().manual_seed(5)
+    obs, act, adv = torch.randn(B, obs_dim, generator=g), torch.randn(B, act_dim, generator=g) * 0.8, torch.randn(B, generator=g)
+    with torch.no_grad():
+        logp_old = OP.dist_of(*OP.actor_forward(p, obs)).log_prob(act)
+    ret = torch.zeros(B)
+    runs = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        st = OP.PPOState(params={k: v.to(dt) for k, v in p.items()})
+        col: dict = {}
+        ON.minibatch_step(st, cfg, obs.to(dt), act.to(dt), adv.to(dt), ret.to(dt), logp_old.to(dt), collect=col)
+        runs[name] = (col, torch.cat([st.params[k].reshape(-1) for k in ON.ACTOR_KEYS]))
+    eng = make_engine(p, obs_dim, act_dim, cfg)
+    stats, dbg = eng.actor_step(obs, act, adv, logp_old, want_debug=True)
+    (c32, new32), (c64, new64) = runs["f32"], runs["f64"]
+    grad = oracle_order(dbg[0], obs_dim, act_dim)
+    assert rel_err(grad, c64["flat_grads"]) < max(1e-5, 2 * rel_err(c32["flat_grads"], c64["flat_grads"]))
+    fg = oracle_order(dbg[2], obs_dim, act_dim)
+    assert rel_err(fg, c64["mvp_of_grad"]) < max(1e-5, 2 * rel_err(c32["mvp_of_grad"], c64["mvp_of_grad"]))
+    sd = -oracle_order(dbg[1], obs_dim, act_dim)
+    e_gpu, e_ref = rel_err(sd, c64["search_direction"]), rel_err(c32["search_direction"], c64["search_direction"])
+    assert e_gpu < max(1e-5, 2 * e_ref), (e_gpu, e_ref)
+    new = oracle_order(eng.actor, obs_dim, act_dim)
+    step64 = (new64 - torch.cat([p[k].reshape(-1) for k in ON.ACTOR_KEYS]).double()).abs().max().item()
+    e_gpu = (new.double() - new64).abs().max().item() / step64
+    e_ref = (new32.double() - new64).abs().max().item() / step64
+    assert e_gpu < max(1e-5, 2 * e_ref), (e_gpu, e_ref)      # the parameter step, on the scale of the step itself
+
+
+def test_critic_step_vs_oracle():
+    obs_dim, act_dim, B = 17, 6, 3000
+    p = rand_params(obs_dim, act_dim, 7)
+    cfg = ON.NPGConfig(lr=1e-3, max_grad_norm=0.5)
+    eng = make_engine(p, obs_dim, act_dim, cfg)
+    g = torch.Generator().manual_seed(2)
+    obs, ret = torch.randn(B, obs_dim, generator=g), torch.randn(B, generator=g) * 2
+    st = OP.PPOState(params={k: v.clone() for k, v in p.items()})
+    from tianshou_amd import npg as NG
+    for _ in range(3):
+        pc = {k: st.params[k].clone().requires_grad_(True) for k in C_KEYS}
+        value = OP.critic_forward({**st.params, **pc}, obs).flatten()
+        vf = torch.nn.functional.mse_loss(ret, value)
+        gs = dict(zip(C_KEYS, torch.autograd.grad(vf, [pc[k] for k in C_KEYS])))
+        grad = torch.empty(eng.lay["critic_count"], device="cuda")
+        loss = eng.critic_step(obs, ret, grad_out=grad, apply=False)
+        assert abs(float(loss) - float(vf)) <= 1e-5 * abs(float(vf))
+        for t, k in zip(NG.critic_flat_to_torch(grad, obs_dim, 64), C_KEYS):
+            assert rel_err(t.cpu(), gs[k]) < 1e-5, k
+        ON._critic_adam(st, cfg, gs)
+        eng.critic_step(obs, ret)
+        for t, k in zip(NG.critic_flat_to_torch(eng.critic, obs_dim, 64), C_KEYS):
+            np.testing.assert_allclose(t.cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.02 * cfg.lr, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["npg", "trpo"])
+def test_update_matches_reference_golden(tag):
+    from tianshou_amd import npg as NG
+
+    g, d, cfg = load_npg(tag)
+    p0 = OP.unflatten_params(torch.as_tensor(g["flat_params0"]), d["obs_dim"], d["act_dim"])
+    eng = make_engine(p0, d["obs_dim"], d["act_dim"], cfg)
+    idx = g["pre_indices"]
+    cut = np.nonzero(np.isin(idx, g["pre_unfinished"]))[0]
+    pre = eng.preprocess(g["obs"], g["obs_next"], g["act"], g["rew"], g["terminated"], g["truncated"], cut)
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].cpu().numpy(), g["pre_" + k], rtol=1e-5, atol=2e-5, err_msg=k)
+    stats, steps = eng.update(pre, d["batch_size"], d["repeat"], list(g["perms"]))
+    s, ref = stats.cpu().numpy(), g["stats"]
+    assert steps == ref.shape[0]
+    # reference (float32 double backward + CG) vs engine (float32 Gauss-Newton + CG): both a few 1e-4 from exact arithmetic
+    np.testing.assert_allclose(s[:, :ref.shape[1]], ref, rtol=2e-3, atol=2e-5)
+    a = NG.actor_flat_to_torch(eng.actor, d["obs_dim"], 64, d["act_dim"])
+    c = NG.critic_flat_to_torch(eng.critic, d["obs_dim"], 64)
+    flat = torch.cat([t.reshape(-1) for t in a + c]).cpu().numpy()            # = oracle_ppo.PARAM_ORDER
+    step = np.abs(g["flat_params"] - g["flat_params0"]).max()
+    assert np.abs(flat - g["flat_params"]).max() < 5e-3 * step
+
+
+def test_bad_arguments_fail_loudly():
+    from tianshou_amd import npg as NG
+
+    with pytest.raises(Exception):
+        NG.layout(17, 48, 6)
+    with pytest.raises(Exception):
+        NG.layout(17, 64, 33)
+    p = rand_params(17, 6, 0)
+    eng = make_engine(p, 17, 6, ON.NPGConfig(algo="trpo"))
+    z = torch.zeros
+    with pytest.raises(ValueError):
+        eng.actor_step(z(8, 17), z(8, 6), z(8))                # TRPO without logp_old
+    with pytest.raises(RuntimeError):
+        NG.NPGEngine(17, 6, 64, eng.actor.cpu(), eng.critic.cpu(), eng.cfg)

@@ -1014,3 +1014,104 @@ def test_hip_rainbow_wrapper_runs_with_engine_double(monkeypatch):
     assert torch.equal(algo.model_old.Q[0].eps_q, model.Q[0].eps_q)            # first update syncs: noise carried along
     st = algo.optim._optim.state[sig]
     assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.5))
+
+
+# ------------------------------------------------------------------------------------ NPG / TRPO subclasses
+def _natural_algo(which, hidden=64, **kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd import integration as I
+
+    a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[hidden, hidden], activation=torch.nn.Tanh),
+                                     action_shape=(6,), unbounded=True)
+    c = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[hidden, hidden], activation=torch.nn.Tanh))
+
+    def dist_fn(loc_scale):
+        return torch.distributions.Independent(torch.distributions.Normal(*loc_scale), 1)
+
+    pol = ProbabilisticActorPolicy(actor=a, dist_fn=dist_fn, action_space=gym.spaces.Box(-1, 1, (6,)))
+    common = dict(policy=pol, critic=c, optim=AdamOptimizerFactory(lr=1e-3), optim_critic_iters=3, gae_lambda=0.9, gamma=0.98,
+                  device="cpu")
+    if which == "npg":
+        return I.make_hip_npg()(trust_region_size=0.2, **common, **kw)
+    return I.make_hip_trpo()(max_kl=0.02, backtrack_coeff=0.7, max_backtracks=8, **common, **kw)
+
+
+@pytest.mark.parametrize("which", ["npg", "trpo"])
+def test_natural_gradient_subclasses_keep_signatures_and_fail_loudly(which):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _natural_algo(which)
+    base = type(algo).__mro__[1]
+    assert type(algo).__name__ == ("HipNPG" if which == "npg" else "HipTRPO")
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (17,), np.zeros((2, 6), np.float32))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, batch_size=8, repeat=1)
+    with pytest.raises(NotImplementedError):
+        _natural_algo(which, hidden=48)
+
+
+@pytest.mark.parametrize("which", ["npg", "trpo"])
+def test_hip_natural_wrapper_runs_with_engine_double(which, monkeypatch):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.npg as NG
+
+    class FakeNPG:
+        def __init__(self, obs_dim, act_dim, hidden, actor, critic, cfg):
+            assert (obs_dim, act_dim, hidden, cfg.algo) == (17, 6, 64, which) and cfg.optim_critic_iters == 3
+            assert (cfg.gamma, cfg.gae_lambda, cfg.damping, cfg.lr) == (0.98, 0.9, 0.1, 1e-3)
+            if which == "npg":
+                assert cfg.trust_region_size == 0.2
+            else:
+                assert (cfg.max_kl, cfg.backtrack_coeff, cfg.max_backtracks) == (0.02, 0.7, 8)
+            self.obs_dim, self.act_dim, self.hidden, self.cfg = obs_dim, act_dim, hidden, cfg
+            self.actor, self.critic = actor.clone(), critic.clone()
+            self.critic_m, self.critic_v, self.adam_step = torch.zeros_like(critic), torch.zeros_like(critic), 0
+            self.ret_rms = [0.0, 1.0, 0.0]
+
+        def preprocess(self, obs, obs_next, act, rew, term, trunc, cut):
+            n = obs.shape[0]
+            assert obs.shape == obs_next.shape == (n, 17) and act.shape == (n, 6) and rew.dtype == torch.float64
+            z = torch.zeros(n)
+            return {"obs": obs, "act": act, "v_s": z, "returns": z, "adv": z, "logp_old": z}
+
+        def update(self, pre, batch_size, repeat, perms):
+            assert batch_size == 8 and len(perms) == repeat == 2
+            self.adam_step += 9
+            self.actor += 1.0
+            self.critic += 2.0
+            self.critic_m += 0.5
+            return torch.tensor([[1.0, 2.0, 3.0, 4.0]] * 6), 6
+
+    algo = _natural_algo(which)
+    monkeypatch.setattr("tianshou_amd.integration._require_gpu", lambda device, who: None)
+    monkeypatch.setattr(NG, "NPGEngine", FakeNPG)
+    monkeypatch.setattr(NG, "layout", lambda o, h, a: {"k0": 32, "actor_count": 33 * h + (h + 1) * h + (h + 1) * 32 + 32,
+                                                       "critic_count": 33 * h + (h + 1) * h + (h + 1) * 32})
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (17,), np.zeros((2, 6), np.float32))
+    sig = algo.policy.actor.sigma_param
+    w1, cw = algo.policy.actor.preprocess.model.model[0].weight, algo.critic.last.model[0].weight
+    s0, w0, c0 = sig.detach().clone(), w1.detach().clone(), cw.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, batch_size=8, repeat=2)
+    assert (stats.actor_loss.mean, stats.vf_loss.mean, stats.kl.mean) == (1.0, 2.0, 3.0)
+    assert (which == "trpo") == hasattr(stats, "step_size") and (which != "trpo" or stats.step_size.mean == 4.0)
+    assert torch.allclose(sig.detach(), s0 + 1.0) and torch.allclose(w1.detach(), w0 + 1.0) and torch.allclose(cw.detach(), c0 + 2.0)
+    st = algo.optim._optim.state[cw]
+    assert float(st["step"]) == 9.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
+    assert not algo.optim._optim.state.get(w1)                      # the actor has no optimizer state (natural-gradient steps)

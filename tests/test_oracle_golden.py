@@ -619,3 +619,37 @@ def test_redq_restatement_matches_reference(tag):
                                ("critic_old", st.critic_old, OR.CRITIC_ORDER)):
             flat = torch.cat([p[k].reshape(-1) for k in order]).numpy()[::61]
             np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------ NPG / TRPO paths
+def load_npg(tag):
+    from oracle import oracle_npg as ON
+
+    g = load(f"npg_{tag}.npz")
+    E, T, obs_dim, act_dim, batch_size, repeat, is_trpo = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = ON.NPGConfig(algo="trpo" if is_trpo else "npg", gamma=c["gamma"], gae_lambda=c["gae_lambda"],
+                       optim_critic_iters=int(c["optim_critic_iters"]), trust_region_size=c["trust_region_size"],
+                       advantage_normalization=bool(c["advantage_normalization"]), return_scaling=bool(c["return_scaling"]),
+                       max_batchsize=int(c["max_batchsize"]), damping=c["damping"], max_kl=c["max_kl"],
+                       backtrack_coeff=c["backtrack_coeff"], max_backtracks=int(c["max_backtracks"]), lr=c["lr"])
+    return g, dict(E=E, T=T, obs_dim=obs_dim, act_dim=act_dim, batch_size=batch_size, repeat=repeat), cfg
+
+
+@pytest.mark.parametrize("tag", ["npg", "trpo"])
+def test_npg_trpo_restatement_matches_reference(tag):
+    """oracle_npg (natural gradient by conjugate gradients on double-backward Fisher-vector products, NPG's fixed step /
+    TRPO's step size + backtracking line search, critic iterations) against the unmodified reference update()."""
+    from oracle import oracle_npg as ON
+
+    g, d, cfg = load_npg(tag)
+    st = OP.PPOState(params=OP.unflatten_params(torch.as_tensor(g["flat_params0"]), d["obs_dim"], d["act_dim"]))
+    obs, obs_next, act = (torch.as_tensor(g[k]) for k in ("obs", "obs_next", "act"))
+    pre = ON.preprocess(st, cfg, obs, obs_next, act, g["rew"], g["terminated"], g["truncated"], g["pre_indices"],
+                        g["pre_unfinished"])
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].numpy(), g["pre_" + k], rtol=1e-5, atol=1e-5, err_msg=k)
+    stats = ON.update(st, cfg, g["obs"], g["act"], pre, d["batch_size"], d["repeat"], g["perms"])
+    assert stats.shape == g["stats"].shape
+    np.testing.assert_allclose(stats, g["stats"], rtol=2e-4, atol=1e-6)         # conjugate gradients amplify fp32 noise
+    np.testing.assert_allclose(OP.flatten_params(st.params).numpy(), g["flat_params"], rtol=1e-4, atol=2e-5)

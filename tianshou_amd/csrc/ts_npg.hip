@@ -1,0 +1,625 @@
+// ts_npg.hip -- natural-gradient policy updates (NPG, TRPO) on the MuJoCo actor-critic for gfx950.
+//
+// Replaces, on device-resident float32 batches:
+//   NPG._preprocess_batch's network passes      tianshou/algorithm/modelfree/npg.py:123-138 (V(s), V(s'), log pi_old)
+//   NPG._update_with_batch (actor part)         npg.py:149-177: vanilla gradient, Fisher-vector products (_MVP :195-200),
+//                                               conjugate gradients (:202-224), step of trust_region_size
+//   TRPO._update_with_batch (actor part)        trpo.py:132-191: ratio surrogate, step size sqrt(2 max_kl / s^T F s),
+//                                               backtracking line search
+//   the critic iterations                       npg.py:179-183 (mse_loss + Optimizer.step, algorithm_base.py:484-500)
+// Networks: examples/mujoco/mujoco_npg.py:103-128 = the PPO nets (Net[h, h] tanh, unbounded Gaussian actor with a
+// state-independent log-sigma parameter, separate critic).
+//
+// The reference forms F v by differentiating the mean KL twice (autograd double backward).  At the expansion point the KL's
+// first derivatives w.r.t. the distribution parameters vanish exactly, so its Hessian is the Gauss-Newton product
+//     F v = (1/B) sum_b J_b^T diag(1 / sigma^2) J_b v   (mean part)   +   2 v_s   (log-sigma part),
+// which is what is computed here: one forward-mode pass (J v), one reverse pass (J^T u).  Linear layers run on the fp32-MFMA
+// GEMM kernels of ts_conv.hip; this file adds the tanh / Gaussian elementwise kernels, the single-workgroup conjugate-
+// gradient update and the orchestration.  The conjugate-gradient early exit (npg.py:217-218) and TRPO's line search are
+// decided on the device (no host round trip): every iteration / candidate is evaluated, a flag or a selection kernel keeps
+// the reference's result.
+//
+// Flat layouts: actor  L1 [k0 + 1, h] | L2 [h + 1, h] | head [h + 1, 32] (columns [0, A) = mu) | log_sigma [32]
+//               critic L1 | L2 | head [h + 1, 32] (column 0 = V)        (k0 = obs_dim rounded up to 32; last row = bias)
+#include <algorithm>
+
+#include "ts_common.h"
+#include "ts_conv.h"
+
+#pragma clang fp contract(off)
+
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+}
+
+namespace {
+
+constexpr int HEAD = 32;
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+struct Net3 {
+    ts::ConvGeom l[3];
+    int64_t off[4];               // off[3] = end of the head block
+    int obs, hid, k0;
+};
+
+int make_net3(int B, int64_t obs_dim, int64_t hidden, Net3* n) {
+    TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && hidden >= 32 && hidden <= 1024 && hidden % 32 == 0, TS_ERR_INVALID_ARG,
+               "npg: obs_dim >= 1, hidden a multiple of 32 in [32, 1024]");
+    n->obs = (int)obs_dim; n->hid = (int)hidden; n->k0 = (n->obs + 31) / 32 * 32;
+    const int dims[4] = {n->k0, n->hid, n->hid, HEAD};
+    int64_t o = 0;
+    for (int i = 0; i < 3; ++i) {
+        n->l[i] = ts::ConvGeom{B, 1, 1, dims[i], 1, 1, 1, 1, 1, dims[i + 1]};
+        n->off[i] = o;
+        o += n->l[i].param_elems();
+    }
+    n->off[3] = o;
+    return TS_OK;
+}
+
+size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Carve {
+    char* p;
+    float* f(size_t n) { float* r = reinterpret_cast<float*>(p); p += al(4 * n); return r; }
+};
+
+struct Act3 { float* h1; float* h2; float* out; };
+
+Act3 take_act(Carve& c, const Net3& n, int64_t B) { return Act3{c.f(B * n.hid), c.f(B * n.hid), c.f(B * HEAD)}; }
+
+size_t act_bytes(const Net3& n, int64_t B) { return 2 * al(4 * B * n.hid) + al(4 * B * HEAD); }
+
+size_t split_floats(const Net3& n) {
+    size_t s = 4;
+    for (int i = 0; i < 3; ++i) { const int ns = ts::conv_fwd_splits(n.l[i]); if (ns > 1) s = std::max(s, (size_t)ns * n.l[i].out_elems()); }
+    return s;
+}
+
+size_t slab_floats(const Net3& n) {
+    size_t s = 0;
+    for (int i = 0; i < 3; ++i) s = std::max(s, (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    return s;
+}
+
+// ---- elementwise kernels ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ obs, int64_t B, int obs_dim, int k0,
+                                                       float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * k0) return;
+    const int64_t b = i / k0;
+    const int j = (int)(i - b * k0);
+    x[i] = j < obs_dim ? obs[b * obs_dim + j] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void tanh_kernel(float* __restrict__ h, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) h[i] = tanhf(h[i]);
+}
+
+// dh *= 1 - h^2   (backward through tanh)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dh[i] = dh[i] * (1.f - h[i] * h[i]);
+}
+
+// forward-mode combine: t = (ta - bias_w[col]) + tb, where ta = dh_prev . W + b_w (the GEMM adds the layer's own bias) and
+// tb = h_prev . V + b_v; out = t * (1 - h^2) for a tanh layer (h != NULL), t for the head
+__global__ __launch_bounds__(256) void jvp_combine_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
+                                                          const float* __restrict__ bias_w, const float* __restrict__ h,
+                                                          int64_t n, int cols, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = (ta[i] - bias_w[i % cols]) + tb[i];
+    out[i] = h ? t * (1.f - h[i] * h[i]) : t;
+}
+
+// Independent(Normal(mu, exp(s)), 1).log_prob(act) for one sample (torch/distributions/normal.py)
+__device__ __forceinline__ float gauss_logp(const float* mu, const float* act, const float* log_sigma, int A) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[j] - mu[j];
+        lp += -(d * d) / (2.f * var) - logf(sigma) - LOG_SQRT_2PI;
+    }
+    return lp;
+}
+
+__global__ __launch_bounds__(256) void infer_out_kernel(const float* __restrict__ mu_head, const float* __restrict__ v_head,
+                                                        const float* __restrict__ act, const float* __restrict__ log_sigma,
+                                                        int64_t B, int A, float* __restrict__ v_out, float* __restrict__ logp_out,
+                                                        float* __restrict__ mu_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    if (v_out) v_out[b] = v_head[b * HEAD];
+    if (logp_out) logp_out[b] = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A);
+    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = mu_head[b * HEAD + j];
+}
+
+// block-wide deterministic sum (256 threads): all threads get the result
+__device__ float block_sum_256(float v, float* red) {
+    __syncthreads();
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// surrogate loss and its gradient w.r.t. the head outputs and log_sigma (npg.py:152-155 / trpo.py:135-138):
+//   NPG  (ratio_mode 0): loss = -mean(logp * adv)             d logp_b = -adv_b / B
+//   TRPO (ratio_mode 1): loss = -mean(exp(logp - logp_old) adv)   d logp_b = -adv_b ratio_b / B
+// per block: partial[blk * (1 + A) + 0] = sum of loss terms, [1 + j] = sum_b d logp_b ((a - mu)^2 / var - 1)
+__global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict__ mu_head, const float* __restrict__ act,
+                                                         const float* __restrict__ adv, const float* __restrict__ logp_old,
+                                                         const float* __restrict__ log_sigma, int ratio_mode, int64_t B, int A,
+                                                         float* __restrict__ d_head, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float inv_b = 1.f / (float)B;
+    float term = 0.f, dlogp = 0.f;
+    if (b < B) {
+        const float lp = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A);
+        if (ratio_mode) {
+            const float ratio = expf(lp - logp_old[b]);
+            term = ratio * adv[b];
+            dlogp = -adv[b] * ratio * inv_b;
+        } else {
+            term = lp * adv[b];
+            dlogp = -adv[b] * inv_b;
+        }
+    }
+    const float tot = block_sum_256(term, red);
+    if (threadIdx.x == 0) partial[blockIdx.x * (1 + A)] = tot;
+    for (int j = 0; j < HEAD; ++j) {
+        float ds = 0.f, dm = 0.f;
+        if (b < B && j < A) {
+            const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[b * A + j] - mu_head[b * HEAD + j];
+            dm = dlogp * d / var;
+            ds = dlogp * (d * d / var - 1.f);
+        }
+        if (b < B) d_head[b * HEAD + j] = dm;
+        if (j < A) {
+            const float t = block_sum_256(ds, red);
+            if (threadIdx.x == 0) partial[blockIdx.x * (1 + A) + 1 + j] = t;
+        }
+    }
+}
+
+// loss = -sum(partial[., 0]) / B; grad[sigma_off + j] = sum(partial[., 1 + j]) (j < A), 0 for the padding entries
+__global__ __launch_bounds__(256) void actor_loss_finish_kernel(const float* __restrict__ partial, int n_blocks, int64_t B, int A,
+                                                                float* __restrict__ loss, float* __restrict__ g_sigma) {
+    __shared__ float red[256];
+    for (int k = 0; k <= A; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += 256) s += partial[i * (1 + A) + k];
+        const float t = block_sum_256(s, red);
+        if (threadIdx.x == 0) {
+            if (k == 0) *loss = -(t / (float)B);
+            else g_sigma[k - 1] = t;
+        }
+    }
+    if ((int)threadIdx.x >= A && threadIdx.x < HEAD) g_sigma[threadIdx.x] = 0.f;
+}
+
+// Fisher upstream: u[b, j] = dmu[b, j] / (sigma_j^2 B) for j < A, 0 for the padding columns
+__global__ __launch_bounds__(256) void fisher_upstream_kernel(const float* __restrict__ dmu, const float* __restrict__ log_sigma,
+                                                              int64_t B, int A, float* __restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * HEAD) return;
+    const int j = (int)(i % HEAD);
+    float v = 0.f;
+    if (j < A) { const float sigma = expf(log_sigma[j]); v = dmu[i] / (sigma * sigma) / (float)B; }
+    u[i] = v;
+}
+
+// z += damping * v; the log-sigma block additionally gets the exact 2 v_s of the KL's Hessian
+__global__ __launch_bounds__(256) void fvp_finish_kernel(float* __restrict__ z, const float* __restrict__ v, int64_t P,
+                                                         int64_t sigma_off, int A, float damping) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float r = z[i] + v[i] * damping;
+    if (i >= sigma_off) r = (i - sigma_off < A ? 2.f * v[i] : 0.f) + v[i] * damping;
+    z[i] = r;
+}
+
+// One conjugate-gradient iteration (npg.py:213-223) in a single workgroup.  sc = {rdotr, done flag, p.z of the last call}.
+// Once new_rdotr < tol the reference leaves the loop: later calls are no-ops.
+__global__ __launch_bounds__(1024) void cg_update_kernel(float* __restrict__ x, float* __restrict__ r, float* __restrict__ p,
+                                                         const float* __restrict__ z, int64_t P, float tol,
+                                                         float* __restrict__ sc) {
+    __shared__ float red[1024];
+    __shared__ float s_val;
+    if (sc[1] != 0.f) return;
+    auto block_sum = [&](float v) {
+        __syncthreads();
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        return red[0];
+    };
+    float pz = 0.f;
+    for (int64_t i = threadIdx.x; i < P; i += 1024) pz += p[i] * z[i];
+    pz = block_sum(pz);
+    const float rdotr = sc[0];
+    const float alpha = rdotr / pz;
+    float nr = 0.f;
+    for (int64_t i = threadIdx.x; i < P; i += 1024) {
+        x[i] += alpha * p[i];
+        const float ri = r[i] - alpha * z[i];
+        r[i] = ri;
+        nr += ri * ri;
+    }
+    nr = block_sum(nr);
+    if (threadIdx.x == 0) s_val = nr;
+    __syncthreads();
+    const float new_rdotr = s_val;
+    if (new_rdotr < tol) {
+        if (threadIdx.x == 0) sc[1] = 1.f;
+        return;
+    }
+    const float beta = new_rdotr / rdotr;
+    for (int64_t i = threadIdx.x; i < P; i += 1024) p[i] = r[i] + beta * p[i];
+    if (threadIdx.x == 0) { sc[0] = new_rdotr; sc[2] = pz; }
+}
+
+// r = p = g, x = 0, sc = {g.g, 0, 0}
+__global__ __launch_bounds__(1024) void cg_init_kernel(const float* __restrict__ g, float* __restrict__ x, float* __restrict__ r,
+                                                       float* __restrict__ p, int64_t P, float* __restrict__ sc) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < P; i += 1024) { const float v = g[i]; x[i] = 0.f; r[i] = v; p[i] = v; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sc[0] = red[0]; sc[1] = 0.f; sc[2] = 0.f; }
+}
+
+// out[0] = sqrt(2 max_kl / (s . Fs)) with s = -x (trpo.py:153-160): the sign cancels in the product
+__global__ __launch_bounds__(1024) void trpo_step_size_kernel(const float* __restrict__ x, const float* __restrict__ fx, int64_t P,
+                                                              float max_kl, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < P; i += 1024) s += x[i] * fx[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sqrtf(2.f * max_kl / red[0]);
+}
+
+// cand = theta + scale * (-x); scale = fixed (NPG) or step[0] * coeff^k (TRPO candidate k)
+__global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict__ theta, const float* __restrict__ x, int64_t P,
+                                                        const float* __restrict__ step, float fixed_scale, float coeff_pow,
+                                                        float* __restrict__ cand) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float scale = step ? step[0] * coeff_pow : fixed_scale;
+    cand[i] = theta[i] + scale * (-x[i]);
+}
+
+// per-block partial sums of kl(old || new) (torch/distributions/kl.py _kl_normal_normal, summed over the action dims) and of
+// the TRPO surrogate term ratio * adv under the candidate parameters
+__global__ __launch_bounds__(256) void kl_eval_kernel(const float* __restrict__ mu_old, const float* __restrict__ ls_old,
+                                                      const float* __restrict__ mu_new, const float* __restrict__ ls_new,
+                                                      const float* __restrict__ act, const float* __restrict__ adv,
+                                                      const float* __restrict__ logp_old, int64_t B, int A,
+                                                      float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float kl = 0.f, term = 0.f;
+    if (b < B) {
+        for (int j = 0; j < A; ++j) {
+            const float so = expf(ls_old[j]), sn = expf(ls_new[j]);
+            const float q = so / sn, var_ratio = q * q;
+            const float d = (mu_old[b * HEAD + j] - mu_new[b * HEAD + j]) / sn, t1 = d * d;
+            kl += 0.5f * (var_ratio + t1 - 1.f - logf(var_ratio));
+        }
+        if (logp_old) term = expf(gauss_logp(mu_new + b * HEAD, act + b * A, ls_new, A) - logp_old[b]) * adv[b];
+    }
+    const float k = block_sum_256(kl, red);
+    const float t = block_sum_256(term, red);
+    if (threadIdx.x == 0) { partial[blockIdx.x * 2] = k; partial[blockIdx.x * 2 + 1] = t; }
+}
+
+// res[cand * 2 + {0, 1}] = {mean kl, -mean(ratio adv)}
+__global__ __launch_bounds__(256) void kl_finish_kernel(const float* __restrict__ partial, int n_blocks, int64_t B,
+                                                        float* __restrict__ res) {
+    __shared__ float red[256];
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += 256) s += partial[i * 2 + k];
+        const float t = block_sum_256(s, red);
+        if (threadIdx.x == 0) res[k] = k == 0 ? t / (float)B : -(t / (float)B);
+    }
+}
+
+// TRPO's line search outcome (trpo.py:167-191) from the evaluated candidates: the first k with kl_k < max_kl and
+// loss_k < loss_0; none: parameters restored, step size 0, kl of the last candidate.  stats = {loss_0 (kept), kl, step_size}
+__global__ __launch_bounds__(256) void trpo_select_kernel(float* __restrict__ theta, const float* __restrict__ cands, int64_t P,
+                                                          const float* __restrict__ res, int n_cand, float max_kl, float coeff,
+                                                          const float* __restrict__ step, float* __restrict__ stats) {
+    __shared__ int s_pick;
+    if (threadIdx.x == 0) {
+        int pick = -1;
+        for (int k = 0; k < n_cand && pick < 0; ++k)
+            if (res[2 * k] < max_kl && res[2 * k + 1] < stats[0]) pick = k;
+        s_pick = pick;
+    }
+    __syncthreads();
+    const int pick = s_pick;
+    if (pick >= 0)
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (int64_t)gridDim.x * 256) theta[i] = cands[(int64_t)pick * P + i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float st = step[0];
+        for (int k = 0; k < pick; ++k) st = st * coeff;
+        stats[1] = res[2 * (pick >= 0 ? pick : n_cand - 1)];
+        stats[2] = pick >= 0 ? st : 0.f;
+    }
+}
+
+// critic: vf_loss = mse_loss(returns, V); d_head[b, 0] = 2 (V - returns) / B
+__global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret, int64_t B,
+                                                           float* __restrict__ d_head, float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float t = v_head[b * HEAD] - ret[b];
+        ls += t * t;
+        for (int j = 0; j < HEAD; ++j) d_head[b * HEAD + j] = j == 0 ? 2.f * t * inv_b : 0.f;
+    }
+    red[threadIdx.x] = ls;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+}
+
+// ---- network passes --------------------------------------------------------------------------------------------------
+int forward(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const float* x, const Act3& a, float* split, int64_t B) {
+    const unsigned gh = (unsigned)ts::ceil_div(B * n.hid, 256);
+    if (int rc = ts::conv_forward(s, n.l[0], x, p + n.off[0], a.h1, false, split, ws)) return rc;
+    hipLaunchKernelGGL(tanh_kernel, dim3(gh), dim3(256), 0, s, a.h1, B * n.hid);
+    if (int rc = ts::conv_forward(s, n.l[1], a.h1, p + n.off[1], a.h2, false, split, ws)) return rc;
+    hipLaunchKernelGGL(tanh_kernel, dim3(gh), dim3(256), 0, s, a.h2, B * n.hid);
+    TS_LAUNCH_CHECK();
+    return ts::conv_forward(s, n.l[2], a.h2, p + n.off[2], a.out, false, split, ws);
+}
+
+struct Bwd { float* dh2; float* dh1; float* slabs; };
+
+// grad[0 .. off[3]) = J^T d_out
+int backward(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const float* x, const Act3& a, const float* d_out,
+             float* grad, const Bwd& sc, int64_t B) {
+    const float* xin[3] = {x, a.h1, a.h2};
+    const float* dy[3] = {sc.dh1, sc.dh2, d_out};
+    float* dxl[3] = {nullptr, sc.dh1, sc.dh2};
+    const unsigned gh = (unsigned)ts::ceil_div(B * n.hid, 256);
+    for (int i = 2; i >= 0; --i) {
+        if (int rc = ts::conv_wgrad(s, n.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
+        if (int rc = ts::slab_sum(s, sc.slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i])) return rc;
+        if (i > 0) {
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], p + n.off[i], nullptr, dxl[i], ws)) return rc;
+            hipLaunchKernelGGL(tanh_bwd_kernel, dim3(gh), dim3(256), 0, s, dxl[i], xin[i], B * n.hid);
+            TS_LAUNCH_CHECK();
+        }
+    }
+    return TS_OK;
+}
+
+struct Jvp { float* ta; float* tb; float* d1; float* d2; float* dmu; };
+
+// dmu = J v for the direction v (same layout as the parameters), given the activations of the forward pass
+int jvp(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const float* v, const float* x, const Act3& a,
+        const Jvp& j, float* split, int64_t B) {
+    const int64_t nh = B * n.hid, no = B * HEAD;
+    const unsigned gh = (unsigned)ts::ceil_div(nh, 256), go = (unsigned)ts::ceil_div(no, 256);
+    // layer 1: t1 = x V1 + b1v
+    if (int rc = ts::conv_forward(s, n.l[0], x, v + n.off[0], j.d1, false, split, ws)) return rc;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(gh), dim3(256), 0, s, j.d1, a.h1, nh);          // d1 = t1 (1 - h1^2)
+    // layer 2: t2 = d1 W2 + h1 V2 + b2v
+    if (int rc = ts::conv_forward(s, n.l[1], j.d1, p + n.off[1], j.ta, false, split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, n.l[1], a.h1, v + n.off[1], j.tb, false, split, ws)) return rc;
+    hipLaunchKernelGGL(jvp_combine_kernel, dim3(gh), dim3(256), 0, s, j.ta, j.tb, p + n.off[1] + (int64_t)n.hid * n.hid, a.h2, nh,
+                       n.hid, j.d2);
+    // head: dmu = d2 W3 + h2 V3 + b3v
+    if (int rc = ts::conv_forward(s, n.l[2], j.d2, p + n.off[2], j.ta, false, split, ws)) return rc;
+    if (int rc = ts::conv_forward(s, n.l[2], a.h2, v + n.off[2], j.tb, false, split, ws)) return rc;
+    hipLaunchKernelGGL(jvp_combine_kernel, dim3(go), dim3(256), 0, s, j.ta, j.tb, p + n.off[2] + (int64_t)n.hid * HEAD,
+                       (const float*)nullptr, no, HEAD, j.dmu);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_npg_layout(int64_t obs_dim, int64_t hidden, int64_t act_dim, int64_t* h_out3) {
+    Net3 n;
+    if (int rc = make_net3(1, obs_dim, hidden, &n)) return rc;
+    TS_REQUIRE(act_dim >= 1 && act_dim <= HEAD && h_out3, TS_ERR_INVALID_ARG, "ts_npg_layout: act_dim must be in [1, 32]");
+    h_out3[0] = n.k0; h_out3[1] = n.off[3] + HEAD; h_out3[2] = n.off[3];
+    return TS_OK;
+}
+
+int ts_npg_infer(ts_workspace* ws, const float* actor, const float* critic, int64_t obs_dim, int64_t hidden, int64_t act_dim,
+                 const float* obs, const float* act, int64_t B, float* v_out, float* logp_out, float* mu_out,
+                 ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_infer: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_npg_infer: negative batch");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(obs && act_dim >= 1 && act_dim <= HEAD && (!v_out || critic) && ((!logp_out && !mu_out) || actor) &&
+                   (!logp_out || act), TS_ERR_INVALID_ARG, "ts_npg_infer: bad argument");
+    Net3 n;
+    if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + 2 * act_bytes(n, B) + al(4 * split_floats(n)) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const Act3 aa = take_act(c, n, B), ac = take_act(c, n, B);
+    float* split = c.f(split_floats(n));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    if (logp_out || mu_out)
+        if (int rc = forward(s, ws, n, actor, x, aa, split, B)) return rc;
+    if (v_out)
+        if (int rc = forward(s, ws, n, critic, x, ac, split, B)) return rc;
+    hipLaunchKernelGGL(infer_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, ac.out, act,
+                       actor ? actor + n.off[3] : (const float*)nullptr, B, (int)act_dim, v_out, logp_out, mu_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t hidden, int64_t act_dim, const float* obs,
+                      const float* act, const float* adv, const float* logp_old, int64_t B, const ts_npg_hparams* hp,
+                      float* stats_out3, float* dbg_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_actor_step: workspace is NULL");
+    TS_REQUIRE(actor && obs && act && adv && hp && stats_out3 && B >= 1 && act_dim >= 1 && act_dim <= HEAD, TS_ERR_INVALID_ARG,
+               "ts_npg_actor_step: bad argument");
+    TS_REQUIRE(hp->algo == 0 || hp->algo == 1, TS_ERR_INVALID_ARG, "ts_npg_actor_step: algo must be 0 (NPG) or 1 (TRPO)");
+    TS_REQUIRE(hp->algo == 0 || (logp_old && hp->max_backtracks >= 1 && hp->max_backtracks <= 32 && hp->max_kl > 0.0),
+               TS_ERR_INVALID_ARG, "ts_npg_actor_step: TRPO needs logp_old, max_kl > 0 and 1 <= max_backtracks <= 32");
+    TS_REQUIRE(hp->cg_iters >= 1 && hp->cg_iters <= 100, TS_ERR_INVALID_ARG, "ts_npg_actor_step: bad cg_iters");
+    Net3 n;
+    if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int A = (int)act_dim;
+    const int64_t P = n.off[3] + HEAD, sig = n.off[3];
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    const int n_cand = hp->algo == 1 ? hp->max_backtracks : 1;
+    const size_t bytes = al(4 * B * n.k0) + 2 * act_bytes(n, B) + 4 * al(4 * B * n.hid) + 3 * al(4 * B * HEAD) +
+                         2 * al(4 * B * n.hid) + al(4 * slab_floats(n)) + al(4 * split_floats(n)) +
+                         (size_t)(6 + n_cand) * al(4 * P) + al(4 * (size_t)n_blocks * (2 + A)) + al(4 * (8 + 2 * n_cand)) + 4096;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const Act3 a0 = take_act(c, n, B), a1 = take_act(c, n, B);           // activations at theta; at a candidate
+    Jvp j{c.f(B * n.hid), c.f(B * n.hid), c.f(B * n.hid), c.f(B * n.hid), c.f(B * HEAD)};
+    float* d_head = c.f(B * HEAD);
+    float* u = c.f(B * HEAD);
+    Bwd bw{c.f(B * n.hid), c.f(B * n.hid), c.f(slab_floats(n))};
+    float* split = c.f(split_floats(n));
+    float* g = c.f(P); float* cx = c.f(P); float* cr = c.f(P); float* cp = c.f(P); float* cz = c.f(P); float* fx = c.f(P);
+    float* cands = c.f((size_t)n_cand * P);
+    float* partial = c.f((size_t)n_blocks * (2 + A));
+    float* sc = c.f(8 + 2 * n_cand);                                       // {rdotr, done, p.z, step, -, -, -, -, res...}
+    float* step = sc + 3;
+    float* res = sc + 8;
+
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    // vanilla gradient of the surrogate (npg.py:152-158 / trpo.py:135-141)
+    if (int rc = forward(s, ws, n, actor, x, a0, split, B)) return rc;
+    hipLaunchKernelGGL(actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a0.out, act, adv, logp_old, actor + sig,
+                       hp->algo, B, A, d_head, partial);
+    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, A, stats_out3, g + sig);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward(s, ws, n, actor, x, a0, d_head, g, bw, B)) return rc;
+
+    // F v (+ damping v) for a direction v -> out
+    auto fvp = [&](const float* v, float* out) -> int {
+        if (int rc = jvp(s, ws, n, actor, v, x, a0, j, split, B)) return rc;
+        hipLaunchKernelGGL(fisher_upstream_kernel, dim3((unsigned)ts::ceil_div(B * HEAD, 256)), dim3(256), 0, s, j.dmu, actor + sig,
+                           B, A, u);
+        TS_LAUNCH_CHECK();
+        if (int rc = backward(s, ws, n, actor, x, a0, u, out, bw, B)) return rc;
+        hipLaunchKernelGGL(fvp_finish_kernel, dim3((unsigned)ts::ceil_div(P, 256)), dim3(256), 0, s, out, v, P, sig, A,
+                           (float)hp->damping);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    };
+
+    // conjugate gradients (npg.py:202-224): x ~ F^-1 g; search direction = -x
+    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, s, g, cx, cr, cp, P, sc);
+    for (int it = 0; it < hp->cg_iters; ++it) {
+        if (int rc = fvp(cp, cz)) return rc;
+        hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, cx, cr, cp, cz, P, (float)hp->residual_tol, sc);
+        TS_LAUNCH_CHECK();
+    }
+    if (dbg_out) {                                    // {gradient, search direction x (sign flipped by the caller), F g + damping g}
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out, g, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out + P, cx, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        if (int rc = fvp(g, fx)) return rc;
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out + 2 * P, fx, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+    }
+    const unsigned gp = (unsigned)ts::ceil_div(P, 256);
+    auto eval = [&](const float* cand, float* out2, bool with_loss) -> int {     // kl(old || cand) [, surrogate at cand]
+        if (int rc = forward(s, ws, n, cand, x, a1, split, B)) return rc;
+        hipLaunchKernelGGL(kl_eval_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a0.out, actor + sig, a1.out, cand + sig, act,
+                           adv, with_loss ? logp_old : (const float*)nullptr, B, A, partial);
+        hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, out2);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    };
+    if (hp->algo == 0) {                              // npg.py:170-177
+        hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, (const float*)nullptr,
+                           (float)hp->trust_region_size, 1.f, cands);
+        if (int rc = eval(cands, res, false)) return rc;
+        TS_HIP_CHECK(hipMemcpyAsync(actor, cands, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemcpyAsync(stats_out3 + 1, res, sizeof(float), hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemsetAsync(stats_out3 + 2, 0, sizeof(float), s));
+        return TS_OK;
+    }
+    // TRPO: step size (trpo.py:153-160), then every backtracking candidate, then the reference's choice among them
+    if (int rc = fvp(cx, fx)) return rc;
+    hipLaunchKernelGGL(trpo_step_size_kernel, dim3(1), dim3(1024), 0, s, cx, fx, P, (float)hp->max_kl, step);
+    float cpow = 1.f;
+    for (int k = 0; k < n_cand; ++k) {
+        hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, step, 0.f, cpow, cands + (size_t)k * P);
+        if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
+        cpow = cpow * (float)hp->backtrack_coeff;
+    }
+    hipLaunchKernelGGL(trpo_select_kernel, dim3((unsigned)std::min<int64_t>(gp, 64)), dim3(256), 0, s, actor, cands, P, res, n_cand,
+                       (float)hp->max_kl, (float)hp->backtrack_coeff, step, stats_out3);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                       int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
+                       double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_critic_step: workspace is NULL");
+    TS_REQUIRE(critic && adam_m && adam_v && obs && returns && loss_out && B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG,
+               "ts_npg_critic_step: bad argument");
+    Net3 n;
+    if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int64_t P = n.off[3];
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) +
+                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * P) + 8192))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const Act3 a = take_act(c, n, B);
+    float* d_head = c.f(B * HEAD);
+    Bwd bw{c.f(B * n.hid), c.f(B * n.hid), c.f(slab_floats(n))};
+    float* split = c.f(split_floats(n));
+    float* grad = c.f(P);
+    float* norm_part = c.f(1024);
+    if (grad_out) grad = grad_out;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
+    hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, returns, B, d_head, loss_out);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward(s, ws, n, critic, x, a, d_head, grad, bw, B)) return rc;
+    if (lr < 0.0) return TS_OK;
+    return ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step, lr, beta1, beta2, adam_eps, max_grad_norm, norm_part);
+}
+
+}  // extern "C"

@@ -145,6 +145,113 @@ def make_hip_ppo(algo: str = "ppo"):
     return HipPPO
 
 
+# ---------------------------------------------------------------------------------------------------
+# NPG (npg.py) / TRPO (trpo.py) on the MuJoCo actor-critic
+# ---------------------------------------------------------------------------------------------------
+def _make_hip_natural(algo: str):
+    from tianshou.data import SequenceSummaryStats
+
+    from . import npg as NG
+
+    if algo == "npg":
+        from tianshou.algorithm.modelfree.npg import NPG as Base
+        from tianshou.algorithm.modelfree.npg import NPGTrainingStats as Stats
+    else:
+        from tianshou.algorithm.modelfree.trpo import TRPO as Base
+        from tianshou.algorithm.modelfree.trpo import TRPOTrainingStats as Stats
+    who = "HipNPG" if algo == "npg" else "HipTRPO"
+
+    class HipNatural(Base):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
+            if set(sa.keys()) != set(TIANSHOU_ACTOR_KEYS) or list(sc.keys()) != list(TIANSHOU_CRITIC_KEYS):
+                raise NotImplementedError(f"{who}: networks must be those of examples/mujoco/mujoco_npg.py (the PPO nets)")
+            hidden = sa[TIANSHOU_ACTOR_KEYS[0]].shape[0]
+            if hidden % 32 or sa[TIANSHOU_ACTOR_KEYS[2]].shape != (hidden, hidden) or sc[TIANSHOU_CRITIC_KEYS[0]].shape[0] != hidden:
+                raise NotImplementedError(f"{who}: hidden sizes [h, h] with h a multiple of 32, the same for actor and critic")
+            if not getattr(self.policy.actor, "_unbounded", False) or getattr(self.policy.actor, "_c_sigma", True):
+                raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                hidden, obs_dim = sa[TIANSHOU_ACTOR_KEYS[0]].shape
+                act_dim = sa[TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                opt, g = _adam_of(self.optim)
+                cfg = NG.NPGConfig(algo=algo, gamma=self.gamma, gae_lambda=self.gae_lambda,
+                                   optim_critic_iters=self.optim_critic_iters,
+                                   trust_region_size=float(getattr(self, "trust_region_size", 0.5)),
+                                   advantage_normalization=self.advantage_normalization, return_scaling=self.return_scaling,
+                                   damping=float(self._damping), max_kl=float(getattr(self, "max_kl", 0.01)),
+                                   backtrack_coeff=float(getattr(self, "backtrack_coeff", 0.8)),
+                                   max_backtracks=int(getattr(self, "max_backtracks", 10)), lr=g["lr"], betas=tuple(g["betas"]),
+                                   adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
+                dev = self._hip_device
+                sc = self.critic.state_dict()
+                eng = self._hip_engine = NG.NPGEngine(
+                    obs_dim, act_dim, hidden, NG.actor_flat_from_torch([sa[k] for k in TIANSHOU_ACTOR_KEYS], obs_dim, hidden, act_dim, dev),
+                    NG.critic_flat_from_torch([sc[k] for k in TIANSHOU_CRITIC_KEYS], obs_dim, hidden, dev), cfg)
+                eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
+                ms, vs, step = adam_state(opt, params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS))     # resume
+                eng.critic_m = NG.critic_flat_from_torch(ms, obs_dim, hidden, dev)
+                eng.critic_v = NG.critic_flat_from_torch(vs, obs_dim, hidden, dev)
+                eng.adam_step = step
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, who)
+            eng = self._engine()
+            dev = self._hip_device
+            t = lambda x, dt=None: torch.as_tensor(np.ascontiguousarray(x), device=dev) if dt is None \
+                else torch.as_tensor(np.ascontiguousarray(x), device=dev).to(dt)  # noqa: E731
+            cut = np.nonzero(np.isin(indices, buffer.unfinished_index()))[0]      # algorithm_base.py:715
+            b = self._hip_pre = eng.preprocess(t(batch.obs, torch.float32), t(batch.obs_next, torch.float32),
+                                               t(batch.act, torch.float32), t(batch.rew, torch.float64), t(batch.terminated),
+                                               t(batch.truncated), t(cut))
+            batch.v_s, batch.returns, batch.adv, batch.logp_old, batch.act = b["v_s"], b["returns"], b["adv"], b["logp_old"], b["act"]
+            return batch
+
+        def _update_with_batch(self, batch, batch_size, repeat):
+            eng = self._hip_engine
+            perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
+            stats, _ = eng.update(self._hip_pre, batch_size, repeat, perms)
+            arr = stats.cpu().numpy().astype(np.float64)                          # one D2H per update()
+            dims = (eng.obs_dim, eng.hidden)
+            with torch.no_grad():
+                for p, t in zip(params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS),
+                                NG.actor_flat_to_torch(eng.actor, eng.obs_dim, eng.hidden, eng.act_dim)):
+                    p.copy_(t.reshape(p.shape))
+                cparams = params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
+                for p, t in zip(cparams, NG.critic_flat_to_torch(eng.critic, *dims)):
+                    p.copy_(t)
+            store_adam_state(self.optim._optim, cparams, NG.critic_flat_to_torch(eng.critic_m, *dims),
+                             NG.critic_flat_to_torch(eng.critic_v, *dims), eng.adam_step)
+            self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
+            seq = SequenceSummaryStats.from_sequence
+            kw = dict(actor_loss=seq(arr[:, 0]), vf_loss=seq(arr[:, 1]), kl=seq(arr[:, 2]))
+            if algo == "trpo":
+                kw["step_size"] = seq(arr[:, 3])
+            return Stats(**kw)
+
+    HipNatural.__name__ = HipNatural.__qualname__ = who
+    return HipNatural
+
+
+def make_hip_npg():
+    """Returns HipNPG(NPG): `_preprocess_batch` / `_update_with_batch` (npg.py:123-193) on the engine.  Supported nets:
+    examples/mujoco/mujoco_npg.py:103-128 (Net[h, h] tanh actor and critic, unbounded Gaussian actor with sigma_param)."""
+    return _make_hip_natural("npg")
+
+
+def make_hip_trpo():
+    """Returns HipTRPO(TRPO): the same hooks with TRPO's step size and line search (trpo.py:123-214)."""
+    return _make_hip_natural("trpo")
+
+
 def make_hip_a2c():
     """HipA2C(A2C) on the MuJoCo actor-critic of HipPPO (a2c.py:249-290 = the fused step kernel's algo 1)."""
     return make_hip_ppo("a2c")
