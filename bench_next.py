@@ -1,7 +1,7 @@
 """Measurement of the rows SURVEY 8f adds to the hot path (N3) and of BASELINE.json configs[0], on the same contract
 as bench.py: TD3 / DDPG / DiscreteSAC (MLP learners), QRDQN / C51 (NatureCNN learners) and the CartPole-shape PPO.
 
-    python bench.py --workload td3|ddpg|dsac|qrdqn|c51|rainbow|npg|trpo|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
+    python bench.py --workload td3|ddpg|redq|dsac|qrdqn|c51|rainbow|npg|trpo|ppo_discrete [--steps K] [--warmup W]   (or: python bench_next.py W)
 
 One "step" = one reference update(): sample -> gather -> target / n-step return -> optimizer steps (-> Polyak), everything
 device-resident; for ppo_discrete one update() = preprocessing + repeat x ceil(N / 64) minibatch steps (value = minibatch
@@ -158,6 +158,61 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
     name = "TD3" if twin else "DDPG"
     return _line(f"{name} learn() updates/sec (B=4096, obs 376, act 17, hidden 256x256)", steps / dt, "updates/s", steps,
                  warmup, dt, f"{name} on the C5 Humanoid-shape replay: {slots} slots, obs f32[376], act f32[17], B=4096",
+                 _roofline(prof, flop, "all linear-layer GEMMs of one update"), cpu,
+                 {"final_stats": [float(x) for x in stats.tolist()]})
+
+
+# ---- REDQ (Humanoid shape, as C5) ------------------------------------------------------------------------------------------
+def run_redq(steps, warmup, with_cpu, slots=1 << 21):
+    from oracle import oracle_redq as OR
+    from oracle import oracle_sac as OS
+    from tianshou_amd import redq as RQ
+    from tianshou_amd import sac as S
+    from tianshou_amd.buffer import gather_rows
+
+    OBS, ACT, B, E, SUB, DELAY, dev = 376, 17, 4096, 10, 2, 20, torch.device("cuda")      # the REDQ paper's ensemble / delay
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
+                       act=torch.rand(slots, ACT, generator=g, device=dev) * 2 - 1,
+                       obs_next=torch.randn(slots, OBS, generator=g, device=dev))
+    actor, critic = OR.init_params(OBS, ACT, E, 0)
+    cfg = RQ.REDQConfig(auto_alpha=True, target_entropy=-float(ACT), ensemble_size=E, subset_size=SUB, actor_delay=DELAY)
+    eng = RQ.REDQEngine(OBS, ACT, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], OBS, ACT),
+                        RQ.ensemble_flat_from_torch([critic[k] for k in OR.CRITIC_ORDER], OBS, ACT), cfg)
+    rng = np.random.default_rng(0)
+
+    def update():
+        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        noise = torch.randn(2, B, ACT, generator=g, device=dev)
+        ret = eng.preprocess(buf, idx, noise[0], rng.choice(E, SUB, replace=False))
+        return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret,
+                                     noise[1] if eng.will_update_actor() else None)[0]
+
+    dt, stats, prof = _time(update, steps, warmup)
+    a_dims, c_dims = [OBS, 256, 256, 2 * ACT], [OBS + ACT, 256, 256, 1]
+    flop = B * (mlp_flop(a_dims) + SUB * mlp_flop(c_dims) + E * mlp_flop(c_dims, wgrad=True, dgrad_layers=2)
+                + (mlp_flop(a_dims, wgrad=True, dgrad_layers=2) + E * mlp_flop(c_dims, dgrad_layers=2, first_dx_cols=ACT)) / DELAY)
+    cpu = None
+    if with_cpu:
+        ocfg = OR.REDQConfig(auto_alpha=True, target_entropy=-float(ACT), ensemble_size=E, subset_size=SUB, actor_delay=DELAY)
+        st = OR.REDQState.create(actor, critic, ocfg)
+        gc = torch.Generator().manual_seed(0)
+        obs, obs_next = torch.randn(B, OBS, generator=gc), torch.randn(B, OBS, generator=gc)
+        act, rew, noise = torch.rand(B, ACT, generator=gc) * 2 - 1, torch.randn(B, generator=gc), torch.randn(B, ACT, generator=gc)
+        th = _threads()
+
+        def one():
+            ret = rew + ocfg.gamma * OR.target_q(st, ocfg, obs_next, noise, rng.choice(E, SUB, replace=False)).flatten()
+            OR.update_with_batch(st, ocfg, obs, act, ret, noise)
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            one()
+        cpu = {"value": 10 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"10 updates of B={B} (subset target, 10-member ensemble step, Polyak), torch fp32 CPU oracle"}
+    return _line("REDQ learn() updates/sec (B=4096, obs 376, act 17, 10 critics, subset 2, actor delay 20)", steps / dt,
+                 "updates/s", steps, warmup, dt, f"REDQ on the C5 Humanoid-shape replay: {slots} slots, B=4096, ensemble 10",
                  _roofline(prof, flop, "all linear-layer GEMMs of one update"), cpu,
                  {"final_stats": [float(x) for x in stats.tolist()]})
 
@@ -460,7 +515,7 @@ def run_ppo_discrete(steps, warmup, with_cpu):
 RUNNERS = {
     "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
     "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),
-    "ppo_discrete": run_ppo_discrete, "rainbow": run_rainbow,
+    "ppo_discrete": run_ppo_discrete, "rainbow": run_rainbow, "redq": run_redq,
     "npg": lambda s, w, c: run_natural(s, w, c, "npg"), "trpo": lambda s, w, c: run_natural(s, w, c, "trpo"),
 }
 

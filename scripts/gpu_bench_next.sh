@@ -1,7 +1,7 @@
 #!/bin/bash
 # Bench lines of the SURVEY 8f rows + configs[0] -> gpurun_out/next/*.json
 mkdir -p gpurun_out/next
-for w in td3 ddpg dsac qrdqn c51 rainbow npg trpo ppo_discrete; do
+for w in td3 ddpg redq dsac qrdqn c51 rainbow npg trpo ppo_discrete; do
   timeout 170 python bench.py --workload $w > gpurun_out/next/bench_$w.json 2> gpurun_out/next/bench_$w.err || echo "$w failed rc=$?"
   tail -c 600 gpurun_out/next/bench_$w.err | tail -3
   python - <<PY
