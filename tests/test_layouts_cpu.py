@@ -1,0 +1,142 @@
+"""Host-side layout logic of every engine (no GPU needed: the layout entry points of libtsengine.so are pure host code):
+reference tensor lists <-> the engines' flat vectors are exact, padding is zero, sizes agree with the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_distq as OQ
+from oracle import oracle_dqn as OD
+from oracle import oracle_dsac as ODS
+from oracle import oracle_ppo as OP
+from oracle import oracle_ppo_cnn as OC
+from oracle import oracle_ppo_discrete as OPD
+from oracle import oracle_rainbow as ORB
+from oracle import oracle_redq as OR
+from oracle import oracle_sac as OS
+
+
+def _same(back, ref):
+    assert len(back) == len(ref)
+    for a, b in zip(back, ref):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+def _perturbed(p: dict, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return {k: v + torch.randn(v.shape, generator=g) for k, v in p.items()}        # biases etc. are not all zero
+
+
+def test_dqn_and_distq_layouts():
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    c, h, w, A = 4, 84, 84, 6
+    p = _perturbed(OD.init_params(c, h, w, A, 1))
+    t = [p[k] for k in OD.PARAM_ORDER]
+    flat = D.flat_from_torch(t, c, h, w, A, device="cpu")
+    assert flat.numel() == D.param_count(c, h, w, A) == OD.param_count(c, h, w, A)
+    _same(D.flat_to_torch(flat, c, h, w, A), t)
+    for N in (200, 51, 7):
+        p = _perturbed(OQ.init_params(c, h, w, A, N, 2))
+        t = [p[k] for k in OD.PARAM_ORDER]
+        flat = Q.flat_from_torch(t, c, h, w, A, N, device="cpu")
+        assert flat.numel() == Q.param_count(c, h, w, A, N)
+        _same(Q.flat_to_torch(flat, c, h, w, A, N), t)
+        head = flat[-513 * Q.head_width(A, N):].reshape(513, -1)
+        assert Q.head_width(A, N) % 32 == 0 and torch.count_nonzero(head[:, A * N:]) == 0
+    with pytest.raises(ValueError):
+        Q.param_count(c, h, w, A, 300)
+
+
+def test_rainbow_layout_and_noise_permutation():
+    from tianshou_amd import rainbow as RB
+
+    c, h, w, A, N = 2, 44, 36, 3, 11
+    p, n = ORB.init_params(c, h, w, A, N, 3)
+    p = _perturbed(p)
+    t = [p[k] for k in ORB.PARAM_ORDER]
+    lay = RB.layout(c, h, w, A, N)
+    flat = RB.flat_from_torch(t, c, h, w, A, N, device="cpu")
+    assert flat.numel() == lay["count"] and lay["F"] == ORB.feature_dim(h, w)
+    _same(RB.flat_to_torch(flat, c, h, w, A, N), t)
+    order = [f"{L}.{k}" for L in ORB.NOISY for k in ("eps_p", "eps_q")]
+    nz = RB.noise_from_torch([n[k] for k in order], c, h, w, A, N, device="cpu")
+    assert nz.numel() == lay["noise_count"]
+    # the engine's F index is (h, w, c); torch flattens (c, h, w): effective weights must agree entry by entry
+    eff_ref = p["Q0.mu_W"] + p["Q0.sigma_W"] * n["Q0.eps_q"].ger(n["Q0.eps_p"])          # [512, F] torch order
+    F = lay["F"]
+    mu = flat[lay["lin"][0]: lay["lin"][0] + (F + 1) * 512].reshape(F + 1, 512)
+    sg = flat[lay["lin"][0] + (F + 1) * 512: lay["lin"][0] + 2 * (F + 1) * 512].reshape(F + 1, 512)
+    eps_p, eps_q = nz[lay["noise"][0]: lay["noise"][0] + F], nz[lay["noise"][1]: lay["noise"][1] + 512]
+    eff = mu[:F] + sg[:F] * (eps_q[None, :] * eps_p[:, None])                             # [F (h, w, c), 512]
+    from tianshou_amd.rainbow import _hwc
+    oh, ow = _hwc(c, h, w)
+    eff_t = eff.t().reshape(512, oh, ow, 64).permute(0, 3, 1, 2).reshape(512, F)
+    assert torch.allclose(eff_t, eff_ref, rtol=0, atol=1e-7)
+
+
+def test_sac_family_layouts():
+    from tianshou_amd import dsac as DS
+    from tianshou_amd import redq as RQ
+    from tianshou_amd import sac as S
+    from tianshou_amd import td3 as T
+
+    for obs_dim, act_dim in ((376, 17), (23, 5), (7, 1)):
+        actor, c1, _ = OS.init_sac_params(obs_dim, act_dim, 0)
+        lay = S.layout(obs_dim, act_dim)
+        fa = S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim, "cpu")
+        fc = S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim, "cpu")
+        assert fa.numel() == lay["actor_count"] and fc.numel() == lay["critic_count"]
+        _same(S.actor_flat_to_torch(fa, obs_dim, act_dim), [actor[k] for k in OS.ACTOR_ORDER])
+        _same(S.critic_flat_to_torch(fc, obs_dim, act_dim), [c1[k] for k in OS.CRITIC_ORDER])
+        da, _, _ = OS.init_td3_params(obs_dim, act_dim, 1)
+        fd = T.actor_flat_from_torch([da[k] for k in OS.DET_ACTOR_ORDER], obs_dim, act_dim, "cpu")
+        assert fd.numel() == T.layout(obs_dim, act_dim)["actor_count"]
+        _same(T.actor_flat_to_torch(fd, obs_dim, act_dim), [da[k] for k in OS.DET_ACTOR_ORDER])
+        _, ens = OR.init_params(obs_dim, act_dim, 5, 2)
+        fe = RQ.ensemble_flat_from_torch([ens[k] for k in OR.CRITIC_ORDER], obs_dim, act_dim, "cpu")
+        assert fe.numel() == 5 * lay["critic_count"]
+        _same(RQ.ensemble_flat_to_torch(fe, 5, obs_dim, act_dim), [ens[k] for k in OR.CRITIC_ORDER])
+    for obs_dim, n_act, hidden in ((11, 5, 64), (128, 18, 256), (40, 64, 96)):
+        nets = ODS.init_params(obs_dim, n_act, hidden, 0)
+        f = DS.net_flat_from_torch([nets[0][k] for k in ODS.NET_ORDER], obs_dim, n_act, hidden, "cpu")
+        assert f.numel() == DS.layout(obs_dim, n_act, hidden)["count"]
+        _same(DS.net_flat_to_torch(f, obs_dim, n_act, hidden), [nets[0][k] for k in ODS.NET_ORDER])
+    for bad in ((11, 5, 48), (11, 65, 64), (11, 1, 64)):
+        with pytest.raises(Exception):
+            DS.layout(*bad)
+
+
+def test_on_policy_layouts():
+    from tianshou_amd import npg as NG
+    from tianshou_amd import ppo_cnn as PC
+    from tianshou_amd import ppo_discrete as PD
+
+    p = _perturbed(OC.init_params(4, 84, 84, 6, 0))
+    t = [p[k] for k in OC.PARAM_ORDER]
+    _same(PC.flat_to_torch(PC.flat_from_torch(t, 4, 84, 84, 6, device="cpu"), 4, 84, 84, 6), t)
+    for obs_dim, hidden, A in ((4, 64, 2), (33, 256, 31)):
+        p = _perturbed(OPD.init_params(obs_dim, hidden, A, 0))
+        t = [p[k] for k in OPD.PARAM_ORDER]
+        f = PD.flat_from_torch(t, obs_dim, hidden, A, device="cpu")
+        assert f.numel() == PD.layout(obs_dim, hidden, A)["count"]
+        _same(PD.flat_to_torch(f, obs_dim, hidden, A), t)
+    p = _perturbed(OP.init_params(17, 6))
+    a_keys = ("a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma")
+    c_keys = ("c_w1", "c_b1", "c_w2", "c_b2", "c_wv", "c_bv")
+    lay = NG.layout(17, 64, 6)
+    fa = NG.actor_flat_from_torch([p[k] for k in a_keys], 17, 64, 6, "cpu")
+    fc = NG.critic_flat_from_torch([p[k] for k in c_keys], 17, 64, "cpu")
+    assert (fa.numel(), fc.numel()) == (lay["actor_count"], lay["critic_count"])
+    _same(NG.actor_flat_to_torch(fa, 17, 64, 6), [p[k] for k in a_keys])
+    _same(NG.critic_flat_to_torch(fc, 17, 64), [p[k] for k in c_keys])
+    assert torch.count_nonzero(fa[-32:][6:]) == 0                                  # log-sigma padding
+
+
+def test_device_pointer_guard():
+    from tianshou_amd import _lib
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.ptr(torch.zeros(4))
+    assert _lib.ptr(None).value in (None, 0)
+    assert np.dtype(np.int64).itemsize == 8
