@@ -712,6 +712,12 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
                       const float* act, const float* adv, const float* logp_old, int64_t B, const ts_npg_hparams* hp,
                       float* stats_out3, float* dbg_out, ts_stream_t stream);
 
+/* The vanilla policy gradient alone: loss = -mean(log pi(act | obs) * weight) and its flat gradient (actor layout) --
+ * Reinforce._update_with_batch (modelfree/reinforce.py:363-382, weight = the discounted returns) before Optimizer.step
+ * (ts_adam_step on the flat actor vector).  loss_out float32[1], grad_out float32[actor count]. */
+int ts_npg_actor_grad(ts_workspace* ws, const float* actor, int64_t obs_dim, int64_t hidden, int64_t act_dim, const float* obs,
+                      const float* act, const float* weight, int64_t B, float* loss_out, float* grad_out, ts_stream_t stream);
+
 /* One critic iteration (npg.py:180-183): vf_loss = mse_loss(returns, V(obs)), clip_grad_norm_ + Adam on the critic
  * (algorithm_base.py:484-500).  lr < 0: gradient only.  loss_out float32[1]; grad_out nullable. */
 int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,

@@ -561,6 +561,98 @@ def gen_npg_all() -> None:
             return_scaling=False, max_batchsize=256)
 
 
+def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
+                  n_updates: int, lr: float = 1e-3, **kwargs) -> None:
+    """Runs the reference Reinforce.update() (actor of examples/mujoco/mujoco_reinforce.py:84-103) on synthetic rollouts."""
+    from tianshou.algorithm.modelfree.reinforce import Reinforce
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    N = E * T
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    for m in actor.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            nn.init.zeros_(m.bias)
+    for m in actor.mu.modules():
+        if isinstance(m, nn.Linear):
+            m.weight.data.copy_(0.3 * m.weight.data)
+
+    def dist(loc_scale):
+        loc, scale = loc_scale
+        return Independent(Normal(loc, scale), 1)
+
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True, action_bound_method="tanh",
+                                      action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,)))
+    algorithm = Reinforce(policy=policy, optim=AdamOptimizerFactory(lr=lr), **kwargs)
+    keys = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
+            "preprocess.model.model.2.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    flat = lambda: torch.cat([actor.state_dict()[k].reshape(-1) for k in keys]).numpy().copy()  # noqa: E731
+    out: dict[str, np.ndarray] = {"actor0": flat(), "dims": np.array([E, T, obs_dim, act_dim, batch_size or 0, repeat, n_updates])}
+    perms, seqs, rets = [], [], []
+    orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, Reinforce._preprocess_batch
+
+    def rec_perm(n):
+        p = orig_perm(n)
+        perms.append(np.asarray(p, np.int64))
+        return p
+
+    def rec_from(c_, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(c_, seq)
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        rets.append((np.asarray(b.returns, np.float64).copy(), np.asarray(indices, np.int64),
+                     np.asarray(buffer.unfinished_index(), np.int64)))
+        return b
+
+    np.random.permutation, Reinforce._preprocess_batch = rec_perm, rec_pre
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    try:
+        for u in range(n_updates):
+            buf = VectorReplayBuffer(N, E)
+            obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+            act = rng.normal(size=(T, E, act_dim)).astype(np.float32) * 0.7
+            rew = rng.normal(size=(T, E)).astype(np.float32) + 0.3
+            term = rng.random((T, E)) < 0.03
+            trunc = np.zeros((T, E), bool)
+            trunc[T // 2 - 1:: T // 2] = True
+            trunc &= ~term
+            for t in range(T):
+                buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+            for k, v in (("obs", buf.obs), ("act", buf.act)):
+                out[f"u{u}_{k}"] = np.asarray(v, np.float32)
+            out[f"u{u}_rew"] = np.asarray(buf.rew, np.float64)
+            out[f"u{u}_terminated"], out[f"u{u}_truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+            np.random.seed(seed + 100 + u)
+            p0, s0 = len(perms), len(seqs)
+            with policy_within_training_step(algorithm.policy):
+                algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+            assert len(perms) - p0 == repeat and len(seqs) - s0 == 1
+            out[f"u{u}_perms"], out[f"u{u}_losses"] = np.stack(perms[p0:]), seqs[s0]
+            out[f"u{u}_returns"], out[f"u{u}_indices"], out[f"u{u}_unfinished"] = rets[-1]
+            out[f"u{u}_actor"] = flat()
+            rms = algorithm.discounted_return_computation.ret_rms
+            out[f"u{u}_ret_rms"] = np.array([float(rms.mean), float(rms.var), float(rms.count)])
+    finally:
+        np.random.permutation, Reinforce._preprocess_batch = orig_perm, orig_pre
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+    cfg = dict(gamma=algorithm.discounted_return_computation.gamma,
+               return_standardization=float(algorithm.discounted_return_computation.return_standardization), lr=lr)
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"reinforce_{tag}.npz"), **out)
+
+
+def gen_reinforce_all() -> None:
+    gen_reinforce("std", E=4, T=48, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=51, n_updates=2, gamma=0.97,
+                  return_standardization=True)
+    gen_reinforce("plain", E=3, T=40, obs_dim=11, act_dim=3, batch_size=None, repeat=1, seed=53, n_updates=1, gamma=0.99,
+                  return_standardization=False)
+
+
 def gen_dqn(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, batch: int,
             n_updates: int, seed: int, per: bool, stack: bool, lr: float = 1e-4, **dqn_kwargs) -> None:
     """Runs the reference DQN.update() (DQNet + DiscreteQLearningPolicy, dqn.py) on a synthetic
@@ -666,6 +758,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
         gen_rainbow_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "reinforce":
+        gen_reinforce_all()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "npg":
         gen_npg_all()

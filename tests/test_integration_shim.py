@@ -1115,3 +1115,92 @@ def test_hip_natural_wrapper_runs_with_engine_double(which, monkeypatch):
     st = algo.optim._optim.state[cw]
     assert float(st["step"]) == 9.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
     assert not algo.optim._optim.state.get(w1)                      # the actor has no optimizer state (natural-gradient steps)
+
+
+def _reinforce_algo(hidden=64, **kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic
+    from tianshou_amd import integration as I
+
+    a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[hidden, hidden], activation=torch.nn.Tanh),
+                                     action_shape=(6,), unbounded=True)
+
+    def dist_fn(loc_scale):
+        return torch.distributions.Independent(torch.distributions.Normal(*loc_scale), 1)
+
+    pol = ProbabilisticActorPolicy(actor=a, dist_fn=dist_fn, action_space=gym.spaces.Box(-1, 1, (6,)))
+    return I.make_hip_reinforce()(policy=pol, optim=AdamOptimizerFactory(lr=2e-3), gamma=0.97, return_standardization=True,
+                                  device="cpu", **kw)
+
+
+def test_reinforce_subclass_keeps_signatures_and_fails_loudly():
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+
+    algo = _reinforce_algo()
+    base = type(algo).__mro__[1]
+    assert type(algo).__name__ == "HipReinforce" and base.__name__ == "Reinforce"
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(16, 2)
+    _fill(buf, 8, (17,), np.zeros((2, 6), np.float32))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, batch_size=8, repeat=1)
+    with pytest.raises(NotImplementedError):
+        _reinforce_algo(hidden=48)
+
+
+def test_hip_reinforce_wrapper_runs_with_engine_double(monkeypatch):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.npg as NG
+    import tianshou_amd.reinforce as RF
+
+    class FakeReinforce:
+        def __init__(self, obs_dim, act_dim, hidden, actor, cfg):
+            assert (obs_dim, act_dim, hidden) == (17, 6, 64)
+            assert (cfg.gamma, cfg.return_standardization, cfg.lr) == (0.97, True, 2e-3)
+            self.actor = actor.clone()
+            self.adam_m, self.adam_v, self.adam_step = torch.zeros_like(actor), torch.zeros_like(actor), 0
+            self.ret_rms = [0.0, 1.0, 0.0]
+
+        def preprocess(self, rew, term, trunc, cut):
+            assert rew.dtype == torch.float64 and rew.shape == term.shape == trunc.shape and cut.dtype == torch.int64
+            self.ret_rms = [0.25, 2.0, float(rew.numel())]
+            return torch.zeros(rew.numel())
+
+        def update(self, obs, act, returns, batch_size, repeat, perms):
+            n = obs.shape[0]
+            assert obs.shape == (n, 17) and act.shape == (n, 6) and returns.shape == (n,)
+            assert batch_size == 8 and len(perms) == repeat == 2
+            self.adam_step += 6
+            self.actor += 1.0
+            self.adam_m += 0.5
+            return torch.tensor([[1.0], [3.0]] * 3), 6
+
+    algo = _reinforce_algo()
+    monkeypatch.setattr("tianshou_amd.integration._require_gpu", lambda device, who: None)
+    monkeypatch.setattr(RF, "ReinforceEngine", FakeReinforce)
+    monkeypatch.setattr(NG, "layout", lambda o, h, a: {"k0": 32, "actor_count": 33 * h + (h + 1) * h + (h + 1) * 32 + 32,
+                                                       "critic_count": 0})
+    buf = VectorReplayBuffer(32, 2)
+    _fill(buf, 12, (17,), np.zeros((2, 6), np.float32))
+    sig, w1 = algo.policy.actor.sigma_param, algo.policy.actor.preprocess.model.model[0].weight
+    s0, w0 = sig.detach().clone(), w1.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, batch_size=8, repeat=2)
+    assert stats.loss.mean == 2.0
+    assert torch.allclose(sig.detach(), s0 + 1.0) and torch.allclose(w1.detach(), w0 + 1.0)
+    st = algo.optim._optim.state[w1]
+    assert float(st["step"]) == 6.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
+    rms = algo.discounted_return_computation.ret_rms
+    assert (rms.mean, rms.var, rms.count) == (0.25, 2.0, 24.0)

@@ -653,3 +653,40 @@ def test_npg_trpo_restatement_matches_reference(tag):
     assert stats.shape == g["stats"].shape
     np.testing.assert_allclose(stats, g["stats"], rtol=2e-4, atol=1e-6)         # conjugate gradients amplify fp32 noise
     np.testing.assert_allclose(OP.flatten_params(st.params).numpy(), g["flat_params"], rtol=1e-4, atol=2e-5)
+
+
+def load_reinforce(tag):
+    from oracle import oracle_reinforce as OR
+
+    g = load(f"reinforce_{tag}.npz")
+    E, T, obs_dim, act_dim, batch_size, repeat, n_updates = (int(x) for x in g["dims"])
+    c = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OR.ReinforceConfig(gamma=c["gamma"], return_standardization=bool(c["return_standardization"]), lr=c["lr"])
+    shapes = OP.param_shapes(obs_dim, act_dim)
+    params, off = {}, 0
+    for k in OR.ACTOR_KEYS:
+        n = int(np.prod(shapes[k]))
+        params[k] = torch.as_tensor(g["actor0"][off:off + n]).reshape(shapes[k]).clone()
+        off += n
+    assert off == len(g["actor0"])
+    return g, dict(E=E, T=T, obs_dim=obs_dim, act_dim=act_dim, batch_size=batch_size or None, repeat=repeat,
+                   n_updates=n_updates), cfg, params
+
+
+@pytest.mark.parametrize("tag", ["std", "plain"])
+def test_reinforce_restatement_matches_reference(tag):
+    """oracle_reinforce (discounted returns against the running-mean bootstrap, optional standardisation + ret_rms update,
+    the vanilla policy-gradient minibatch steps) against the unmodified reference Reinforce.update()."""
+    from oracle import oracle_reinforce as OR
+
+    g, d, cfg, params = load_reinforce(tag)
+    st = OP.PPOState(params=params)
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        ret = OR.preprocess(st, cfg, g[f"u{u}_rew"], g[f"u{u}_terminated"], g[f"u{u}_truncated"], idx, g[f"u{u}_unfinished"])
+        np.testing.assert_allclose(ret.numpy(), g[f"u{u}_returns"].astype(np.float32), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose([st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], g[f"u{u}_ret_rms"], rtol=1e-12)
+        losses = OR.update(st, cfg, g[f"u{u}_obs"][idx], g[f"u{u}_act"][idx], ret, d["batch_size"], d["repeat"], g[f"u{u}_perms"])
+        np.testing.assert_allclose(losses, g[f"u{u}_losses"], rtol=2e-5, atol=1e-6)
+        flat = torch.cat([st.params[k].reshape(-1) for k in OR.ACTOR_KEYS]).numpy()
+        np.testing.assert_allclose(flat, g[f"u{u}_actor"], rtol=1e-4, atol=0.02 * cfg.lr)

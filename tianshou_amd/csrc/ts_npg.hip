@@ -590,6 +590,36 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     return TS_OK;
 }
 
+int ts_npg_actor_grad(ts_workspace* ws, const float* actor, int64_t obs_dim, int64_t hidden, int64_t act_dim, const float* obs,
+                      const float* act, const float* weight, int64_t B, float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_actor_grad: workspace is NULL");
+    TS_REQUIRE(actor && obs && act && weight && loss_out && grad_out && B >= 1 && act_dim >= 1 && act_dim <= HEAD,
+               TS_ERR_INVALID_ARG, "ts_npg_actor_grad: bad argument");
+    Net3 n;
+    if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int A = (int)act_dim;
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) +
+                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * (size_t)n_blocks * (2 + A)) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const Act3 a = take_act(c, n, B);
+    float* d_head = c.f(B * HEAD);
+    Bwd bw{c.f(B * n.hid), c.f(B * n.hid), c.f(slab_floats(n))};
+    float* split = c.f(split_floats(n));
+    float* partial = c.f((size_t)n_blocks * (2 + A));
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    if (int rc = forward(s, ws, n, actor, x, a, split, B)) return rc;
+    hipLaunchKernelGGL(actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, act, weight, (const float*)nullptr,
+                       actor + n.off[3], 0, B, A, d_head, partial);
+    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, A, loss_out, grad_out + n.off[3]);
+    TS_LAUNCH_CHECK();
+    return backward(s, ws, n, actor, x, a, d_head, grad_out, bw, B);
+}
+
 int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
                        int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
                        double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {

@@ -252,6 +252,83 @@ def make_hip_trpo():
     return _make_hip_natural("trpo")
 
 
+def make_hip_reinforce():
+    """Returns HipReinforce(Reinforce): `_preprocess_batch` / `_update_with_batch` (reinforce.py:346-382) on the engine.
+    Supported net: the actor of examples/mujoco/mujoco_reinforce.py:84-103 (Net[h, h] tanh, unbounded Gaussian, sigma_param)."""
+    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats, Reinforce
+    from tianshou.data import SequenceSummaryStats
+
+    from . import npg as NG
+    from . import reinforce as RF
+
+    who = "HipReinforce"
+
+    class HipReinforce(Reinforce):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sa = self.policy.actor.state_dict()
+            if set(sa.keys()) != set(TIANSHOU_ACTOR_KEYS):
+                raise NotImplementedError(f"{who}: the actor must be that of examples/mujoco/mujoco_reinforce.py")
+            hidden = sa[TIANSHOU_ACTOR_KEYS[0]].shape[0]
+            if hidden % 32 or sa[TIANSHOU_ACTOR_KEYS[2]].shape != (hidden, hidden):
+                raise NotImplementedError(f"{who}: hidden sizes [h, h] with h a multiple of 32")
+            if not getattr(self.policy.actor, "_unbounded", False) or getattr(self.policy.actor, "_c_sigma", True):
+                raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _dims(self):
+            sa = self.policy.actor.state_dict()
+            hidden, obs_dim = sa[TIANSHOU_ACTOR_KEYS[0]].shape
+            return obs_dim, hidden, sa[TIANSHOU_ACTOR_KEYS[4]].shape[0]
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sa = self.policy.actor.state_dict()
+                dims = self._dims()
+                opt, g = _adam_of(self.optim)
+                drc = self.discounted_return_computation
+                cfg = RF.ReinforceConfig(gamma=drc.gamma, return_standardization=drc.return_standardization, lr=g["lr"],
+                                         betas=tuple(g["betas"]), adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
+                dev = self._hip_device
+                eng = self._hip_engine = RF.ReinforceEngine(
+                    dims[0], dims[2], dims[1], NG.actor_flat_from_torch([sa[k] for k in TIANSHOU_ACTOR_KEYS], *dims, dev), cfg)
+                eng.ret_rms = [float(drc.ret_rms.mean), float(drc.ret_rms.var), float(drc.ret_rms.count)]
+                ms, vs, step = adam_state(opt, params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS))     # resume
+                eng.adam_m, eng.adam_v = (NG.actor_flat_from_torch(x, *dims, dev) for x in (ms, vs))
+                eng.adam_step = step
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, who)
+            eng = self._engine()
+            dev = self._hip_device
+            t = lambda x: torch.as_tensor(np.ascontiguousarray(x), device=dev)  # noqa: E731
+            cut = np.nonzero(np.isin(indices, buffer.unfinished_index()))[0]      # algorithm_base.py:715
+            batch.returns = eng.preprocess(t(batch.rew).to(torch.float64), t(batch.terminated), t(batch.truncated), t(cut))
+            self._hip_obs, self._hip_act = t(batch.obs).to(torch.float32), t(batch.act).to(torch.float32)
+            drc = self.discounted_return_computation
+            drc.ret_rms.mean, drc.ret_rms.var, drc.ret_rms.count = eng.ret_rms
+            return batch
+
+        def _update_with_batch(self, batch, batch_size, repeat):
+            eng = self._hip_engine
+            perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
+            losses, _ = eng.update(self._hip_obs, self._hip_act, batch.returns, batch_size, repeat, perms)
+            arr = losses.cpu().numpy().astype(np.float64).reshape(-1)              # one D2H per update()
+            dims = self._dims()
+            aparams = params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS)
+            with torch.no_grad():
+                for p, t in zip(aparams, NG.actor_flat_to_torch(eng.actor, *dims)):
+                    p.copy_(t.reshape(p.shape))
+            store_adam_state(self.optim._optim, aparams, NG.actor_flat_to_torch(eng.adam_m, *dims),
+                             NG.actor_flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+            return LossSequenceTrainingStats(loss=SequenceSummaryStats.from_sequence(arr))
+
+    return HipReinforce
+
+
 def make_hip_a2c():
     """HipA2C(A2C) on the MuJoCo actor-critic of HipPPO (a2c.py:249-290 = the fused step kernel's algo 1)."""
     return make_hip_ppo("a2c")

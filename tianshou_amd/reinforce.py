@@ -1,0 +1,111 @@
+"""Reinforce learn() on one MI355X: discounted returns (ts_gae_scan, lambda = 1) + vanilla policy-gradient minibatch steps
+(ts_npg_actor_grad + ts_adam_step) for the reference's Reinforce (tianshou/algorithm/modelfree/reinforce.py) with the actor of
+examples/mujoco/mujoco_reinforce.py:84-103 (Net[h, h] tanh, unbounded Gaussian, state-independent sigma_param).
+
+The actor uses the flat layout of ts_npg_layout (tianshou_amd.npg.actor_flat_from_torch).  No CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .npg import layout
+from .ppo_cnn import run_minibatches
+from .returns import _i64_dev, gae_scan
+
+
+@dataclass
+class ReinforceConfig:
+    gamma: float = 0.99
+    return_standardization: bool = False
+    lr: float = 1e-3
+    betas: tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+    max_grad_norm: float | None = None
+
+
+class ReinforceEngine:
+    """State of one Reinforce learner on one GPU: flat actor + Adam moments + the running return statistics."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden: int, actor: torch.Tensor, cfg: ReinforceConfig):
+        if not actor.is_cuda:
+            raise RuntimeError("ReinforceEngine needs parameters on an MI355X (no CPU fallback)")
+        lay = layout(obs_dim, hidden, act_dim)
+        if actor.numel() != lay["actor_count"]:
+            raise ValueError("flat actor vector does not match ts_npg_layout")
+        self.obs_dim, self.act_dim, self.hidden, self.cfg, self.lay = obs_dim, act_dim, hidden, cfg, lay
+        self.device = actor.device
+        self.actor = actor.detach().float().contiguous().clone()
+        self.adam_m, self.adam_v = torch.zeros_like(self.actor), torch.zeros_like(self.actor)
+        self.adam_step = 0
+        self.ret_rms = [0.0, 1.0, 0.0]
+        self._grad = torch.empty_like(self.actor)
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    def _f32(self, x, shape=None) -> torch.Tensor:
+        t = torch.as_tensor(x, device=self.device).to(torch.float32).contiguous()
+        return t if shape is None else t.reshape(shape)
+
+    # -- DiscountedReturnComputation.add_discounted_returns (reinforce.py:266-310) -------------------------------------
+    def preprocess(self, rew, terminated, truncated, cut_pos=None) -> torch.Tensor:
+        """Batch-order arrays of the whole buffer -> batch.returns float32[N] (standardised when configured)."""
+        cfg = self.cfg
+        term = torch.as_tensor(terminated, device=self.device).reshape(-1)
+        n = term.numel()
+        mean, var, count = self.ret_rms
+        v_next = torch.where(term.bool(), 0.0, float(mean)).to(torch.float32)       # full(ret_rms.mean) * value_mask
+        v_s = torch.roll(v_next, 1)                                                 # algorithm_base.py:712
+        cut = None if cut_pos is None else _i64_dev(cut_pos, self.device)
+        out = gae_scan(v_s, v_next, torch.as_tensor(rew, device=self.device), term,
+                       torch.as_tensor(truncated, device=self.device), cut, gamma=cfg.gamma, gae_lambda=1.0,
+                       want_f64=cfg.return_standardization, want_ret_stats=cfg.return_standardization)
+        if not cfg.return_standardization:
+            return out["returns"]
+        ret = ((out["ret64"] - mean) / float(np.sqrt(var + 1e-8))).to(torch.float32)     # reinforce.py:305-307
+        b_mean = float(out["ret_sum"]) / n                                               # statistics.py:99-114
+        b_var = max(float(out["ret_sumsq"]) / n - b_mean * b_mean, 0.0)
+        delta, tot = b_mean - mean, count + n
+        self.ret_rms = [mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot]
+        return ret
+
+    # -- one minibatch (reinforce.py:371-380) ----------------------------------------------------------------------------
+    def gradient(self, obs, act, returns, grad_out: torch.Tensor | None = None) -> torch.Tensor:
+        """loss float32[1]; the flat gradient lands in grad_out (default: the engine's scratch vector)."""
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        b = obs.shape[0]
+        act, returns = self._f32(act, (b, self.act_dim)), self._f32(returns, (b,))
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        g = self._grad if grad_out is None else grad_out
+        _lib.check(_lib.load().ts_npg_actor_grad(
+            self._ws.handle, _lib.ptr(self.actor), _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.i64(self.act_dim),
+            _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns), _lib.i64(b), _lib.ptr(loss), _lib.ptr(g),
+            _lib.current_stream(self.device)))
+        return loss
+
+    def apply_gradient(self, grad: torch.Tensor | None = None) -> None:
+        """clip_grad_norm_ + Adam on the flat gradient (algorithm_base.py:496-500)."""
+        cfg = self.cfg
+        self.adam_step += 1
+        g = self._grad if grad is None else grad
+        _lib.check(_lib.load().ts_adam_step(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.ptr(g),
+            _lib.i64(self.actor.numel()), _lib.i64(self.adam_step), _lib.f64(cfg.lr), _lib.f64(cfg.betas[0]),
+            _lib.f64(cfg.betas[1]), _lib.f64(cfg.adam_eps), _lib.f64(cfg.max_grad_norm or 0.0),
+            _lib.current_stream(self.device)))
+
+    def step(self, obs, act, returns) -> torch.Tensor:
+        loss = self.gradient(obs, act, returns)
+        self.apply_gradient()
+        return loss
+
+    # -- Reinforce._update_with_batch ------------------------------------------------------------------------------------
+    def update(self, obs, act, returns, batch_size: int | None, repeat: int, perms=None):
+        """-> (losses float32[steps, 1], steps)."""
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        n = obs.shape[0]
+        act, returns = self._f32(act, (n, self.act_dim)), self._f32(returns, (n,))
+        return run_minibatches(self.device, n, batch_size, repeat, perms,
+                               lambda rows: self.step(obs[rows], act[rows], returns[rows]))
