@@ -512,7 +512,55 @@ def run_ppo_discrete(steps, warmup, with_cpu):
                  {"gradient_steps_per_update": k, "final_loss": float(losses[-1, 0])})
 
 
+def run_reinforce(steps, warmup, with_cpu):
+    from oracle import oracle_ppo as OP
+    from oracle import oracle_reinforce as OR
+    from tianshou_amd import npg as NG
+    from tianshou_amd import reinforce as RF
+
+    OBS, ACT, HID, E, T, MB, dev = 17, 6, 64, 512, 2048, 65536, torch.device("cuda")        # the C2 rollout: 2^20 transitions
+    n = E * T
+    g = torch.Generator(device=dev).manual_seed(0)
+    obs = torch.randn(n, OBS, generator=g, device=dev)
+    act = torch.randn(n, ACT, generator=g, device=dev) * 0.6
+    rew = torch.randn(n, generator=g, device=dev).double()
+    term = torch.rand(n, generator=g, device=dev) < 0.002
+    trunc = torch.zeros(n, dtype=torch.bool, device=dev)
+    cut = (torch.arange(E, device=dev) + 1) * T - 1
+    p = OP.init_params(OBS, ACT, seed=0)
+    eng = RF.ReinforceEngine(OBS, ACT, HID, NG.actor_flat_from_torch([p[k] for k in OR.ACTOR_KEYS], OBS, HID, ACT),
+                             RF.ReinforceConfig(return_standardization=True, lr=1e-3))
+    count = [0]
+
+    def update():
+        ret = eng.preprocess(rew, term, trunc, cut)
+        losses, k = eng.update(obs, act, ret, MB, 1, [torch.randperm(n, generator=g, device=dev)])
+        count[0] = k
+        return losses
+
+    dt, losses, prof = _time(update, steps, warmup)
+    k = count[0]
+    flop = k * MB * mlp_flop([OBS, HID, HID, ACT], wgrad=True, dgrad_layers=2)
+    cpu = None
+    if with_cpu:
+        st = OP.PPOState(params={kk: p[kk].clone() for kk in OR.ACTOR_KEYS})
+        gc = torch.Generator().manual_seed(0)
+        o, a, r = torch.randn(4 * MB, OBS, generator=gc), torch.randn(4 * MB, ACT, generator=gc) * 0.6, torch.randn(4 * MB, generator=gc)
+        ocfg = OR.ReinforceConfig(lr=1e-3)
+        OR.update(st, ocfg, o[:4096], a[:4096], r[:4096], None, 1, [np.arange(4096)])
+        t0 = time.perf_counter()
+        OR.update(st, ocfg, o, a, r, MB, 1, [np.arange(4 * MB)])
+        cpu = {"value": 4 / (time.perf_counter() - t0), "unit": "update-steps/s", "cores": _threads(), "kind": "port",
+               "sample": f"4 minibatch steps of {MB} samples, torch fp32 CPU oracle (returns precomputed)"}
+    return _line("Reinforce learn() update-steps/sec (minibatch 65536, obs 17, act 6, MLP[64,64], preprocessing incl.)",
+                 steps * k / dt, "update-steps/s", steps, warmup, dt,
+                 f"Reinforce on the C2 rollout: {E} envs x {T} steps = {n} transitions, minibatch {MB}, return standardisation",
+                 _roofline(prof, flop, "linear-layer GEMMs of the policy-gradient steps"), cpu,
+                 {"gradient_steps_per_update": k, "final_loss": float(losses[-1])})
+
+
 RUNNERS = {
+    "reinforce": run_reinforce,
     "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
     "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),
     "ppo_discrete": run_ppo_discrete, "rainbow": run_rainbow, "redq": run_redq,
