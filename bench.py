@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="ppo",
-                    choices=["ppo", "dqn", "sac", "ppo_atari", "td3", "ddpg", "dsac", "qrdqn", "c51", "rainbow", "npg", "trpo", "redq", "ppo_discrete", "reinforce"],
+                    choices=["ppo", "dqn", "sac", "ppo_atari", "td3", "ddpg", "dsac", "qrdqn", "c51", "rainbow", "npg", "trpo", "redq", "ppo_discrete", "reinforce", "drqn"],
                     help="ppo = BASELINE.json's metric on C2 (default); dqn / sac = the C3 / C5 rows (bench_dqn.py, "
                          "bench_sac.py); ppo_atari = the north star's Atari-shape PPO (bench_ppo_cnn.py); the rest = "
                          "the SURVEY 8f rows and BASELINE configs[0] (bench_next.py)")
@@ -246,7 +246,7 @@ def main():
 
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
-        if args.workload in ("td3", "ddpg", "dsac", "qrdqn", "c51", "rainbow", "npg", "trpo", "redq", "ppo_discrete", "reinforce"):
+        if args.workload in ("td3", "ddpg", "dsac", "qrdqn", "c51", "rainbow", "npg", "trpo", "redq", "ppo_discrete", "reinforce", "drqn"):
             import bench_next
 
             k = 1 if args.workload in ("ppo_discrete", "npg", "trpo", "reinforce") else 10

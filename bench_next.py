@@ -559,7 +559,58 @@ def run_reinforce(steps, warmup, with_cpu):
                  {"gradient_steps_per_update": k, "final_loss": float(losses[-1])})
 
 
+def run_drqn(steps, warmup, with_cpu, slots=20000):
+    """test/discrete/test_drqn.py's learner: Recurrent(2 LSTM layers of 128) on CartPole observations, stack_num 4, batch 128,
+    n-step 3, double-Q with a lagged network, 20000-slot buffer of 16 envs without obs_next."""
+    from oracle import oracle_dqn as OD
+    from oracle import oracle_drqn as ORQ
+    from tianshou_amd import dqn as D
+    from tianshou_amd import drqn as R
+
+    OBS, H, L, A, T, B, dev = 4, 128, 2, 2, 4, 128, torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
+                       act=torch.randint(0, A, (slots,), generator=g, device=dev))
+    gc = torch.Generator().manual_seed(0)
+    shapes = ORQ.param_shapes(OBS, H, L, A)
+    p = {k: (torch.rand(shapes[k], generator=gc) * 2 - 1) / np.sqrt(H if not k.startswith("fc1") else OBS) for k in ORQ.param_keys(L)}
+    kw = dict(gamma=0.95, n_step=3, target_update_freq=320, is_double=True, lr=1e-3)
+    eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch([p[k] for k in ORQ.param_keys(L)], OBS, H, L, A), D.DQNConfig(**kw))
+
+    def update():
+        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        ret = eng.preprocess(buf, buf.obs, idx, T)
+        return eng.update_with_batch(R.gather_stacked_obs(buf.obs, buf, idx, T), buf.act[idx], ret)[0]
+
+    dt, loss, prof = _time(update, steps, warmup)
+    fwd = 2 * (T * OBS * H + L * T * 2 * H * 4 * H + H * A)          # per sample: fc1 per step, W_ih + W_hh per layer and step, fc2
+    flop = B * (2 * fwd + 3 * fwd)                                    # target: online + lagged forward; update: forward + backward
+    cpu = None
+    if with_cpu:
+        ocfg = OD.DQNConfig(**kw)
+        st = OD.DQNState.create(p, ocfg)
+        obs, obs_next = torch.randn(B, T, OBS, generator=gc), torch.randn(B, T, OBS, generator=gc)
+        act, rew = torch.randint(0, A, (B,), generator=gc), torch.randn(B, generator=gc)
+        th = _threads()
+
+        def one():
+            ORQ.update_with_batch(st, ocfg, obs, act, rew + ocfg.gamma * ORQ.target_q(st, ocfg, obs_next))
+
+        one()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            one()
+        cpu = {"value": 100 / (time.perf_counter() - t0), "unit": "updates/s", "cores": th, "kind": "port",
+               "sample": f"100 updates of B={B} (double-Q target + one optimizer step), torch fp32 CPU oracle"}
+    return _line("DRQN learn() updates/sec (B=128, stack 4, obs 4, 2 actions, 2 LSTM layers of 128, n-step 3)", steps / dt,
+                 "updates/s", steps, warmup, dt,
+                 f"DQN on Recurrent (test_drqn.py), {slots}-slot replay of 16 envs, stack_num 4, B=128: launch-latency-bound",
+                 _roofline(prof, flop, "all GEMMs of one update: input / recurrent projections, their gradients, fc1, fc2"), cpu,
+                 {"final_loss": float(loss)})
+
+
 RUNNERS = {
+    "drqn": run_drqn,
     "reinforce": run_reinforce,
     "td3": lambda s, w, c: run_td3(s, w, c, twin=True), "ddpg": lambda s, w, c: run_td3(s, w, c, twin=False),
     "dsac": run_dsac, "qrdqn": lambda s, w, c: run_distq(s, w, c, "qr"), "c51": lambda s, w, c: run_distq(s, w, c, "c51"),

@@ -420,6 +420,32 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   float* loss_out, float* grad_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DQN on a recurrent Q network (DRQN, test/discrete/test_drqn.py:79-101): Recurrent (tianshou/utils/net/common.py:372-452)
+ * = fc1 Linear(obs_dim, H) -> nn.LSTM(H, H, L layers, batch_first) -> fc2 Linear(H, n_act) on the last step.
+ * Flat parameter vector (last row of every block = bias; gate order i, f, g, o as in torch):
+ *   fc1 [k0 + 1, H] | per layer: W_ih [H + 1, 4H] | W_hh [H + 1, 4H] | fc2 [H + 1, 32]
+ * k0 = obs_dim rounded up to 32 (padding rows zero), head columns [0, n_act) = Q (padding columns zero).
+ * H a multiple of 32 in [32, 1024], 1 <= L <= 8, n_act <= 32, T <= 4096, B T <= 2^24.
+ * h_out int64[4 + 2 L] = {k0, count, off_fc1, off_ih[0], off_hh[0], ..., off_fc2}.
+ * ------------------------------------------------------------------------------------------- */
+int ts_rnnq_layout(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t* h_out);
+
+/* Recurrent.forward + DiscreteQLearningPolicy.forward (common.py:400-452, dqn.py:101-143): obs float32[B, T, obs_dim]
+ * (training: T = stack_num, no state; evaluation: T = 1 with the carried state) -> q_out float32[B, n_act] (nullable),
+ * act_out int64[B] = argmax (nullable).  State tensors are LAYER-major float32[L, B, H] (the reference carries
+ * [B, L, H], common.py:441-450; the wrapper transposes): h_in / c_in nullable together (= zeros), h_out / c_out nullable. */
+int ts_rnnq_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                    const float* obs, int64_t B, int64_t T, const float* h_in, const float* c_in, float* q_out, int64_t* act_out,
+                    float* h_out, float* c_out, ts_stream_t stream);
+
+/* DQN._update_with_batch (dqn.py:381-404) on the recurrent network, same contract as ts_dqn_update: TD error -> td_out,
+ * loss -> loss_out, backward through the T steps, clip + Adam (hp->lr < 0: gradient only); grad_out nullable float32[count]. */
+int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                   int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
+                   const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
+                   float* grad_out, ts_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Distributional Q-learning on the Atari networks: QRDQN (tianshou/algorithm/modelfree/qrdqn.py) and
  * C51 (modelfree/c51.py) with QRDQNet / C51Net (tianshou/env/atari/atari_network.py:211-235 / :125-151):
  * DQNet with n_act * n_atoms outputs viewed [B, n_act, n_atoms] (C51: softmax over the atoms).

@@ -653,6 +653,99 @@ def gen_reinforce_all() -> None:
                   return_standardization=False)
 
 
+def gen_drqn(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, hidden: int, layers: int, n_act: int, stack_num: int,
+             batch: int, n_updates: int, seed: int, per: bool, lr: float = 1e-3, **dqn_kwargs) -> None:
+    """Runs the reference DQN.update() with the Recurrent Q network on a stacked, obs_next-free buffer
+    (test/discrete/test_drqn.py:79-108) and dumps indices, n-step returns, TD errors, losses and parameters of every update."""
+    from tianshou.algorithm.modelfree.dqn import DQN, DiscreteQLearningPolicy
+    from tianshou.utils.net.common import Recurrent
+    from oracle import oracle_drqn as ORQ
+
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    net = Recurrent(layer_num=layers, state_shape=(obs_dim,), action_shape=n_act, hidden_layer_size=hidden)
+    keys = ORQ.param_keys(layers)
+    assert list(net.state_dict().keys()) == keys, list(net.state_dict().keys())
+    policy = DiscreteQLearningPolicy(model=net, action_space=gym.spaces.Discrete(n_act))
+    algorithm = DQN(policy=policy, optim=AdamOptimizerFactory(lr=lr), **dqn_kwargs)
+    kw = dict(stack_num=stack_num, ignore_obs_next=True)
+    buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4, **kw) if per else VectorReplayBuffer(E * slots, E, **kw)
+    obs = rng.normal(size=(steps + 1, E, obs_dim)).astype(np.float32)
+    act = rng.integers(0, n_act, size=(steps, E))
+    rew = rng.normal(size=(steps, E)).astype(np.float32)
+    term = rng.random((steps, E)) < 0.08
+    trunc = (rng.random((steps, E)) < 0.04) & ~term
+    for t in range(steps):
+        buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+    flat = lambda: torch.cat([net.state_dict()[k].reshape(-1) for k in keys]).numpy().copy()  # noqa: E731
+    out: dict[str, np.ndarray] = {"dims": np.array([E, slots, steps, obs_dim, hidden, layers, n_act, stack_num, batch, n_updates,
+                                                    seed, int(per)]), "params0": flat()}
+    out["obs_rows"] = np.asarray(buf.obs, np.float32)
+    out["act"], out["rew"] = np.asarray(buf.act, np.int64), np.asarray(buf.rew, np.float64)
+    out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+    for k, v in manager_state(buf).items():
+        out["buf_" + k] = v
+    rec: list[dict] = []
+    orig_pre, orig_upd = DQN._preprocess_batch, DQN._update_with_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        r = {"indices": np.array(indices, np.int64), "obs": np.array(batch.obs)}
+        if hasattr(batch, "weight"):
+            r["is_weight"] = np.array(batch.weight, np.float64)
+        b = orig_pre(self, batch, buffer, indices)
+        r["returns"] = b.returns.numpy().copy().reshape(-1)
+        rec.append(r)
+        return b
+
+    def rec_upd(self, batch):
+        stats = orig_upd(self, batch)
+        rec[-1]["td"] = batch.weight.detach().numpy().copy()
+        rec[-1]["loss"] = np.array(stats.loss)
+        return stats
+
+    DQN._preprocess_batch, DQN._update_with_batch = rec_pre, rec_upd
+    try:
+        np.random.seed(seed + 7)
+        for u in range(n_updates):
+            with policy_within_training_step(algorithm.policy):
+                algorithm.update(buffer=buf, sample_size=batch)
+            r = rec[-1]
+            assert r["obs"].shape == (batch, stack_num, obs_dim)
+            for k in ("indices", "returns", "td", "loss"):
+                out[f"u{u}_{k}"] = r[k]
+            if "is_weight" in r:
+                out[f"u{u}_is_weight"] = r["is_weight"]
+            if u == 0:
+                out["u0_obs"] = r["obs"]
+            out[f"u{u}_params_strided"] = flat()[::17].copy()           # + the small tensors in full
+            sd = net.state_dict()
+            out[f"u{u}_small"] = torch.cat([sd[k].reshape(-1) for k in keys if "weight_" not in k]).numpy().copy()
+    finally:
+        DQN._preprocess_batch, DQN._update_with_batch = orig_pre, orig_upd
+    # evaluation-mode steps with a carried state (Recurrent.forward with obs [B, dim], common.py:419-452)
+    with torch.no_grad():
+        o1, o2 = obs[0, :, :], obs[1, :, :]
+        q1, s1 = net(o1)
+        q2, s2 = net(o2, state=s1)
+    out["eval_obs"] = np.stack([o1, o2])
+    out["eval_q"] = np.stack([q1.numpy(), q2.numpy()])
+    out["eval_hidden"], out["eval_cell"] = s2["hidden"].numpy().copy(), s2["cell"].numpy().copy()      # [B, L, H]
+    cfg = dict(gamma=algorithm.gamma, n_step=algorithm.n_step, target_update_freq=algorithm.target_update_freq,
+               is_double=float(algorithm.is_double),
+               huber_delta=-1.0 if algorithm.huber_loss_delta is None else algorithm.huber_loss_delta, lr=lr)
+    out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"drqn_{tag}.npz"), **out)
+
+
+def gen_drqn_all() -> None:
+    # the test_drqn.py setup: CartPole observations, 2 LSTM layers of 128, stack 4, n-step 3, double-Q with a lagged net
+    gen_drqn("cartpole", E=4, slots=40, steps=60, obs_dim=4, hidden=128, layers=2, n_act=2, stack_num=4, batch=32, n_updates=3,
+             seed=61, per=False, gamma=0.95, n_step_return_horizon=3, target_update_freq=2, is_double=True)
+    # one layer of 64, a wider observation, PER weights with the MSE loss, Huber off, vanilla max-Q target without a lagged net
+    gen_drqn("per", E=3, slots=30, steps=40, obs_dim=37, hidden=64, layers=1, n_act=5, stack_num=3, batch=24, n_updates=2,
+             seed=63, per=True, lr=3e-4, gamma=0.9, n_step_return_horizon=1, target_update_freq=0, is_double=False)
+
+
 def gen_dqn(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int, n_act: int, batch: int,
             n_updates: int, seed: int, per: bool, stack: bool, lr: float = 1e-4, **dqn_kwargs) -> None:
     """Runs the reference DQN.update() (DQNet + DiscreteQLearningPolicy, dqn.py) on a synthetic
@@ -758,6 +851,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
         gen_rainbow_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "drqn":
+        gen_drqn_all()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "reinforce":
         gen_reinforce_all()

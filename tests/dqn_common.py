@@ -65,3 +65,27 @@ def rainbow_noise(g, u: int, old: bool = False):
     pre = f"u{u}_noise_old_" if old else f"u{u}_noise_"
     d = {k[len(pre):]: g[k] for k in g.files if k.startswith(pre) and (old or not k.startswith(f"u{u}_noise_old_"))}
     return d or None
+
+
+def load_drqn(tag: str):
+    """tests/golden/drqn_*.npz (oracle/gen_golden.py::gen_drqn)."""
+    g = np.load(os.path.join(GOLDEN, f"drqn_{tag}.npz"))
+    E, slots, steps, obs_dim, hidden, layers, n_act, stack_num, batch, n_updates, seed, per = (int(x) for x in g["dims"])
+    cd = dict(zip(g["cfg_keys"].tolist(), g["cfg_vals"].tolist()))
+    cfg = OD.DQNConfig(gamma=cd["gamma"], n_step=int(cd["n_step"]), target_update_freq=int(cd["target_update_freq"]),
+                       is_double=bool(cd["is_double"]), huber_delta=None if cd["huber_delta"] < 0 else cd["huber_delta"],
+                       lr=cd["lr"])
+    dims = dict(E=E, slots=slots, steps=steps, obs_dim=obs_dim, hidden=hidden, layers=layers, n_act=n_act, stack_num=stack_num,
+                batch=batch, n_updates=n_updates, seed=seed, per=bool(per))
+    bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
+                           g["rew"], g["terminated"], g["truncated"])
+    return g, dims, cfg, bstate
+
+
+def drqn_small(p: dict, layers: int) -> np.ndarray:
+    """The tensors the fixtures keep in full: everything but the LSTM weight matrices (state_dict order)."""
+    import torch
+
+    from oracle import oracle_drqn as ORQ
+
+    return torch.cat([p[k].detach().reshape(-1) for k in ORQ.param_keys(layers) if "weight_" not in k]).numpy()

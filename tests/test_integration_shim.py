@@ -1204,3 +1204,116 @@ def test_hip_reinforce_wrapper_runs_with_engine_double(monkeypatch):
     assert float(st["step"]) == 6.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
     rms = algo.discounted_return_computation.ret_rms
     assert (rms.mean, rms.var, rms.count) == (0.25, 2.0, 24.0)
+
+
+def _drqn_algo(hidden=64, layers=2, **kw):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.dqn import DiscreteQLearningPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Recurrent
+    from tianshou_amd import integration as I
+
+    net = Recurrent(layer_num=layers, state_shape=(4,), action_shape=2, hidden_layer_size=hidden)
+    pol = DiscreteQLearningPolicy(model=net, action_space=gym.spaces.Discrete(2))
+    return I.make_hip_drqn()(policy=pol, optim=AdamOptimizerFactory(lr=1e-3), gamma=0.95, n_step_return_horizon=3,
+                             target_update_freq=4, device="cpu", **kw)
+
+
+def test_drqn_subclass_keeps_signatures_and_fails_loudly(dqn_algo):
+    ref_shim.install()
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    from tianshou_amd import integration as I
+
+    algo = _drqn_algo()
+    base = type(algo).__mro__[1]
+    assert type(algo).__name__ == "HipDRQN" and base.__name__ == "DQN" and algo._hip_dims == (4, 64, 2, 2)
+    for name in ("_preprocess_batch", "_update_with_batch"):
+        mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
+        assert list(mine.parameters) == list(ref.parameters), name
+        assert getattr(type(algo), name) is not getattr(base, name)
+    buf = VectorReplayBuffer(32, 2, stack_num=4, ignore_obs_next=True)
+    _fill(buf, 8, (4,), np.zeros(2, np.int64))
+    with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
+        algo.update(buffer=buf, sample_size=8)
+    with pytest.raises(NotImplementedError):
+        _drqn_algo(hidden=48)
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+
+    with pytest.raises(NotImplementedError):                  # a DQNet is not a Recurrent model
+        I.make_hip_drqn()(policy=dqn_algo.policy, optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
+
+
+def test_hip_drqn_wrapper_runs_with_engine_double(monkeypatch):
+    ref_shim.install()
+    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+    from tianshou.data import VectorReplayBuffer
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.drqn as R
+
+    class FakeDRQN:
+        def __init__(self, obs_dim, hidden, layers, n_act, flat, cfg):
+            assert (obs_dim, hidden, layers, n_act) == (4, 64, 2, 2)
+            assert (cfg.gamma, cfg.n_step, cfg.target_update_freq, cfg.is_double, cfg.lr) == (0.95, 3, 4, True, 1e-3)
+            self.params, self.params_old = flat.clone(), flat.clone()
+            self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
+
+        def preprocess(self, m, rows, idx, stack, obs_next_rows=None):
+            assert rows.dtype == torch.float32 and rows.shape[1] == 4 and stack == 4 and obs_next_rows is None
+            return torch.zeros(idx.numel())
+
+        def update_with_batch(self, obs, act, ret, weight=None):
+            assert obs.shape == (8, 4, 4) and act.shape == (8,) and ret.shape == (8,)
+            self.adam_step += 1
+            self.iter += 1
+            self.params += 2.0
+            self.params_old += 1.0
+            self.adam_v += 0.25
+            return torch.tensor([0.75]), torch.arange(8, dtype=torch.float32)
+
+    # the real layout converters run on CPU tensors here: only the engine and the two device gathers are doubles
+    def cpu_from_torch(t, obs_dim, hidden, layers, n_act, device="cuda"):
+        return real_from(t, obs_dim, hidden, layers, n_act, "cpu")
+
+    real_from = R.flat_from_torch
+    algo = _drqn_algo()
+    _patch_for_cpu(monkeypatch)
+    monkeypatch.setattr(R, "RecurrentDQNEngine", FakeDRQN)
+    monkeypatch.setattr(R, "flat_from_torch", cpu_from_torch)
+    monkeypatch.setattr(R, "gather_stacked_obs", lambda rows, m, idx, stack: rows[idx][:, None, :].expand(-1, stack, -1))
+    buf = VectorReplayBuffer(32, 2, stack_num=4, ignore_obs_next=True)
+    _fill(buf, 12, (4,), np.zeros(2, np.int64))
+    w_hh = algo.policy.model.nn.weight_hh_l1
+    fc2_b = algo.policy.model.fc2.bias
+    old_b = algo.model_old.module.fc2.bias
+    w0, b0, o0 = w_hh.detach().clone(), fc2_b.detach().clone(), old_b.detach().clone()
+    with policy_within_training_step(algo.policy):
+        stats = algo.update(buffer=buf, sample_size=8)
+    assert isinstance(stats, SimpleLossTrainingStats) and stats.loss == 0.75
+    assert torch.allclose(w_hh.detach(), w0 + 2.0) and torch.allclose(fc2_b.detach(), b0 + 2.0)
+    assert torch.allclose(old_b.detach(), o0 + 1.0)
+    st = algo.optim._optim.state[w_hh]
+    assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.25))
+
+
+def test_drqn_layout_converters_round_trip_on_cpu():
+    from oracle import oracle_drqn as ORQ
+    import tianshou_amd.drqn as R
+
+    g = torch.Generator().manual_seed(0)
+    for obs_dim, hidden, layers, n_act in [(4, 64, 2, 2), (37, 32, 1, 5), (32, 96, 3, 32)]:
+        shapes = ORQ.param_shapes(obs_dim, hidden, layers, n_act)
+        keys = ORQ.param_keys(layers)
+        assert keys == R.state_dict_keys(layers)
+        t = [torch.randn(shapes[k], generator=g) for k in keys]
+        flat = R.flat_from_torch(t, obs_dim, hidden, layers, n_act, device="cpu")
+        k0 = (obs_dim + 31) // 32 * 32
+        assert flat.numel() == (k0 + 1) * hidden + layers * 2 * (hidden + 1) * 4 * hidden + (hidden + 1) * 32
+        back = R.flat_to_torch(flat, obs_dim, hidden, layers, n_act)
+        assert all(torch.equal(a, b) for a, b in zip(back, t))
+        # gate order and transposition: column j of W_ih's block = row j of torch's weight_ih (i, f, g, o stacked)
+        off = (k0 + 1) * hidden
+        w_ih = flat[off:off + (hidden + 1) * 4 * hidden].reshape(hidden + 1, 4 * hidden)
+        assert torch.equal(w_ih[:hidden].t(), t[0]) and torch.equal(w_ih[hidden], t[2])

@@ -690,3 +690,35 @@ def test_reinforce_restatement_matches_reference(tag):
         np.testing.assert_allclose(losses, g[f"u{u}_losses"], rtol=2e-5, atol=1e-6)
         flat = torch.cat([st.params[k].reshape(-1) for k in OR.ACTOR_KEYS]).numpy()
         np.testing.assert_allclose(flat, g[f"u{u}_actor"], rtol=1e-4, atol=0.02 * cfg.lr)
+
+
+@pytest.mark.parametrize("tag", ["cartpole", "per"])
+def test_drqn_restatement_matches_reference(tag):
+    """oracle_drqn (written-out LSTM cell, stacked observations through prev(), n-step double-Q targets, DQN loss, Adam)
+    against the unmodified reference DQN.update() on the Recurrent network, and its evaluation-mode state passing."""
+    from oracle import oracle_dqn as OD
+    from oracle import oracle_drqn as ORQ
+    from tests.dqn_common import drqn_small, load_drqn
+
+    g, d, cfg, bstate = load_drqn(tag)
+    L = d["layers"]
+    st = OD.DQNState.create(ORQ.unflatten(g["params0"], d["obs_dim"], d["hidden"], L, d["n_act"]), cfg)
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        obs = OD.stacked_frames(bstate, g["obs_rows"], idx, d["stack_num"])
+        if u == 0:
+            np.testing.assert_array_equal(obs, g["u0_obs"])
+        ret = ORQ.preprocess(st, cfg, bstate, g["obs_rows"], idx, d["stack_num"])
+        np.testing.assert_allclose(ret, g[f"u{u}_returns"], rtol=1e-5, atol=1e-6)
+        w = g[f"u{u}_is_weight"] if d["per"] else None
+        loss, td = ORQ.update_with_batch(st, cfg, obs, g["act"][idx], ret, w)
+        np.testing.assert_allclose(loss, g[f"u{u}_loss"], rtol=1e-5)
+        np.testing.assert_allclose(td.numpy(), g[f"u{u}_td"], rtol=1e-5, atol=1e-6)
+        tol = dict(rtol=1e-4, atol=0.02 * cfg.lr * (u + 1))
+        np.testing.assert_allclose(ORQ.flatten(st.params, L).numpy()[::17], g[f"u{u}_params_strided"], **tol)
+        np.testing.assert_allclose(drqn_small(st.params, L), g[f"u{u}_small"], **tol)
+    q1, s1 = ORQ.forward(st.params, g["eval_obs"][0], want_state=True)
+    q2, s2 = ORQ.forward(st.params, g["eval_obs"][1], state=s1, want_state=True)
+    np.testing.assert_allclose(torch.stack([q1, q2]).numpy(), g["eval_q"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s2[0].transpose(0, 1).numpy(), g["eval_hidden"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(s2[1].transpose(0, 1).numpy(), g["eval_cell"], rtol=1e-4, atol=1e-5)

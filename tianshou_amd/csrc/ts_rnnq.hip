@@ -1,0 +1,380 @@
+// ts_rnnq.hip -- recurrent Q network for DQN on stacked observations (DRQN) for gfx950.
+//
+// Replaces, on device-resident float32 batches:
+//   Recurrent.forward                       tianshou/utils/net/common.py:400-452: fc1 -> nn.LSTM(L layers, batch_first) -> fc2 on
+//                                           the last step; training obs [B, T, dim] (T = the buffer's stack_num), no initial
+//                                           state; evaluation obs [B, dim] (T = 1) with the carried (hidden, cell) state
+//   DiscreteQLearningPolicy.forward         modelfree/dqn.py:101-143 (argmax)
+//   DQN._update_with_batch                  dqn.py:381-404 on that network: TD error, Huber / weighted-MSE loss, backward
+//                                           through time, clip + Adam (setup: test/discrete/test_drqn.py:79-101)
+// torch's LSTM cell (aten/src/ATen/native/RNN.cpp, gate order i, f, g, o): gates = x W_ih^T + b_ih + h W_hh^T + b_hh,
+// c' = sigmoid(f) c + sigmoid(i) tanh(g), h' = sigmoid(o) tanh(c').
+//
+// Every matrix product runs on the fp32-MFMA GEMM kernels of ts_conv.hip (a Linear layer is their 1x1 case).  Activations are
+// TIME-MAJOR ([T][B][.]) so that each step is one contiguous row block: the input projections of a layer (x_t W_ih for all t)
+// are ONE GEMM over T B rows, as are the weight gradients of W_ih and W_hh (the hidden states are stored with a leading h_{-1}
+// block, so "h_{t-1} for all t" is contiguous too); only the recurrent products h_{t-1} W_hh and their input gradients are
+// per-step GEMMs.  This file adds the cell kernels (forward / backward), the head / loss kernels and the orchestration.
+//
+// Flat layout (last row of every block = bias): fc1 [k0 + 1, H] | per layer: W_ih [H + 1, 4H] | W_hh [H + 1, 4H] | fc2 [H + 1, 32]
+// (k0 = obs_dim rounded up to 32, the padding rows are and stay zero; head columns [0, n_act) = Q, the rest zero).
+#include <algorithm>
+
+#include "ts_common.h"
+#include "ts_conv.h"
+
+#pragma clang fp contract(off)
+
+namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+}
+
+namespace {
+
+constexpr int HEAD = 32;
+constexpr int MAX_LAYERS = 8;
+
+struct RNet {
+    ts::ConvGeom fc1, ih_all, hh_step, head;     // rows: T B, T B, B, B
+    int64_t off_fc1, off_ih[MAX_LAYERS], off_hh[MAX_LAYERS], off_head, count;
+    int obs, k0, H, L, A, T;
+    int64_t B;
+};
+
+int make_rnet(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T, RNet* n) {
+    TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && hidden >= 32 && hidden <= 1024 && hidden % 32 == 0 && layers >= 1 &&
+                   layers <= MAX_LAYERS && n_act >= 1 && n_act <= HEAD,
+               TS_ERR_INVALID_ARG, "rnnq: obs_dim >= 1, hidden a multiple of 32 in [32, 1024], 1..8 layers, n_act <= 32");
+    TS_REQUIRE(B >= 1 && T >= 1 && T <= 4096 && B * T <= (int64_t)1 << 24, TS_ERR_INVALID_ARG, "rnnq: B >= 1, 1 <= T <= 4096, B T <= 2^24");
+    n->obs = (int)obs_dim; n->k0 = (n->obs + 31) / 32 * 32; n->H = (int)hidden; n->L = (int)layers; n->A = (int)n_act;
+    n->T = (int)T; n->B = B;
+    const int rows = (int)(B * T), H = n->H;
+    n->fc1 = ts::ConvGeom{rows, 1, 1, n->k0, 1, 1, 1, 1, 1, H};
+    n->ih_all = ts::ConvGeom{rows, 1, 1, H, 1, 1, 1, 1, 1, 4 * H};
+    n->hh_step = ts::ConvGeom{(int)B, 1, 1, H, 1, 1, 1, 1, 1, 4 * H};
+    n->head = ts::ConvGeom{(int)B, 1, 1, H, 1, 1, 1, 1, 1, HEAD};
+    int64_t o = 0;
+    n->off_fc1 = o; o += n->fc1.param_elems();
+    for (int l = 0; l < n->L; ++l) {
+        n->off_ih[l] = o; o += n->ih_all.param_elems();
+        n->off_hh[l] = o; o += n->ih_all.param_elems();
+    }
+    n->off_head = o; o += n->head.param_elems();
+    n->count = o;
+    return TS_OK;
+}
+
+size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+struct Carve {
+    char* p;
+    float* f(size_t n) { float* r = reinterpret_cast<float*>(p); p += al(4 * n); return r; }
+};
+
+size_t split_floats(const RNet& n) {
+    size_t s = 4;
+    for (const ts::ConvGeom* g : {&n.fc1, &n.ih_all, &n.hh_step, &n.head}) {
+        const int ns = ts::conv_fwd_splits(*g);
+        if (ns > 1) s = std::max(s, (size_t)ns * g->out_elems());
+    }
+    return s;
+}
+
+size_t slab_floats(const RNet& n) {
+    size_t s = 0;
+    for (const ts::ConvGeom* g : {&n.fc1, &n.ih_all, &n.head}) s = std::max(s, (size_t)ts::conv_wgrad_splits(*g) * g->param_elems());
+    return s;
+}
+
+// forward activations kept for the backward pass
+struct Acts {
+    float* x;                      // [T B, k0] time-major padded observations
+    float* x1;                     // [T B, H]  fc1 output = input of layer 0
+    float* hbuf[MAX_LAYERS];       // [(T + 1) B, H]: block 0 = h_{-1}, block t + 1 = h_t
+    float* cbuf[MAX_LAYERS];       // [(T + 1) B, H]: block 0 = c_{-1}
+    float* gact[MAX_LAYERS];       // [T B, 4H] gate activations (i, f, g, o)
+    float* gih;                    // [T B, 4H] input projections of the current layer
+    float* ghh;                    // [B, 4H]   recurrent projection of the current step
+    float* out;                    // [B, 32]   head output
+    float* split;
+};
+
+size_t acts_bytes(const RNet& n) {
+    const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
+    return al(4 * rows * n.k0) + al(4 * rows * H) + n.L * (2 * al(4 * (rows + B) * H) + al(4 * rows * 4 * H)) + al(4 * rows * 4 * H) +
+           al(4 * B * 4 * H) + al(4 * B * HEAD) + al(4 * split_floats(n));
+}
+
+Acts take_acts(Carve& c, const RNet& n) {
+    const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
+    Acts a{};
+    a.x = c.f(rows * n.k0);
+    a.x1 = c.f(rows * H);
+    for (int l = 0; l < n.L; ++l) { a.hbuf[l] = c.f((rows + B) * H); a.cbuf[l] = c.f((rows + B) * H); a.gact[l] = c.f(rows * 4 * H); }
+    a.gih = c.f(rows * 4 * H);
+    a.ghh = c.f(B * 4 * H);
+    a.out = c.f(B * HEAD);
+    a.split = c.f(split_floats(n));
+    return a;
+}
+
+// ---- elementwise kernels ---------------------------------------------------------------------------------------------
+// x[t][b][j] = obs[b][t][j] (j < obs_dim), 0 for the padding columns
+__global__ __launch_bounds__(256) void pad_time_major_kernel(const float* __restrict__ obs, int64_t B, int T, int obs_dim, int k0,
+                                                             float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T * k0) return;
+    const int j = (int)(i % k0);
+    const int64_t row = i / k0, t = row / B, b = row - t * B;
+    x[i] = j < obs_dim ? obs[(b * T + t) * obs_dim + j] : 0.f;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+// one LSTM step for [B, H] units: gates (pre-activations gih + ghh) -> gact = (i, f, g, o), c = f c_prev + i g, h = o tanh(c)
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ gih, const float* __restrict__ ghh,
+                                                        const float* __restrict__ c_prev, int64_t B, int H,
+                                                        float* __restrict__ gact, float* __restrict__ c, float* __restrict__ h) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int64_t b = idx / H;
+    const int j = (int)(idx - b * H);
+    const int64_t g0 = b * 4 * H + j;
+    const float i = sigmoidf_(gih[g0] + ghh[g0]);
+    const float f = sigmoidf_(gih[g0 + H] + ghh[g0 + H]);
+    const float g = tanhf(gih[g0 + 2 * H] + ghh[g0 + 2 * H]);
+    const float o = sigmoidf_(gih[g0 + 3 * H] + ghh[g0 + 3 * H]);
+    gact[g0] = i; gact[g0 + H] = f; gact[g0 + 2 * H] = g; gact[g0 + 3 * H] = o;
+    const float cn = f * c_prev[idx] + i * g;
+    c[idx] = cn;
+    h[idx] = o * tanhf(cn);
+}
+
+// backward of one step: dh = dh_out (from the layer above / the head) + dh_rec (from step t + 1), dc carried in `dc`
+// (in: d loss / d c_t from step t + 1, out: d loss / d c_{t-1}); writes the pre-activation gate gradients dg [B, 4H].
+// last != 0: step T - 1 (no contribution from a later step).
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ dh_out, const float* __restrict__ dh_rec,
+                                                            float* __restrict__ dc, const float* __restrict__ gact,
+                                                            const float* __restrict__ c, const float* __restrict__ c_prev,
+                                                            int64_t B, int H, int last, float* __restrict__ dg) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * H) return;
+    const int64_t b = idx / H;
+    const int j = (int)(idx - b * H);
+    const int64_t g0 = b * 4 * H + j;
+    const float i = gact[g0], f = gact[g0 + H], g = gact[g0 + 2 * H], o = gact[g0 + 3 * H];
+    const float dh = last ? dh_out[idx] : dh_out[idx] + dh_rec[idx];
+    const float tc = tanhf(c[idx]);
+    const float d_o = dh * tc;
+    float dct = dh * o * (1.f - tc * tc);
+    if (!last) dct += dc[idx];
+    dg[g0] = dct * g * (i * (1.f - i));
+    dg[g0 + H] = dct * c_prev[idx] * (f * (1.f - f));
+    dg[g0 + 2 * H] = dct * i * (1.f - g * g);
+    dg[g0 + 3 * H] = d_o * (o * (1.f - o));
+    dc[idx] = dct * f;
+}
+
+// q_out[b, a] = head[b, a]; act_out[b] = argmax_a (first maximum, torch.max)
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ head, int64_t B, int A, float* __restrict__ q_out,
+                                                       int64_t* __restrict__ act_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    int best = 0;
+    float bv = head[b * HEAD];
+    for (int a = 0; a < A; ++a) {
+        const float v = head[b * HEAD + a];
+        if (q_out) q_out[b * A + a] = v;
+        if (v > bv) { bv = v; best = a; }
+    }
+    if (act_out) act_out[b] = best;
+}
+
+// TD error, loss and d loss / d head (dqn.py:388-401)
+__global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__ head, const int64_t* __restrict__ act,
+                                                       const float* __restrict__ ret, const float* __restrict__ weight, int64_t B,
+                                                       float huber_delta, float* __restrict__ td, float* __restrict__ d_head,
+                                                       float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float lsum = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const int a = (int)act[b];
+        const float t = ret[b] - head[b * HEAD + a];
+        td[b] = t;
+        float l, g;
+        if (huber_delta > 0.f) {                     // torch.nn.functional.huber_loss(q, returns), mean
+            const float ad = fabsf(t);
+            if (ad < huber_delta) { l = 0.5f * t * t; g = -t; }
+            else { l = huber_delta * (ad - 0.5f * huber_delta); g = t > 0.f ? -huber_delta : huber_delta; }
+        } else {                                     // (td_error.pow(2) * weight).mean()
+            const float w = weight ? weight[b] : 1.f;
+            l = t * t * w;
+            g = -2.f * t * w;
+        }
+        for (int j = 0; j < HEAD; ++j) d_head[b * HEAD + j] = j == a ? g * inv_b : 0.f;
+        lsum += l;
+    }
+    red[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
+// ---- network passes --------------------------------------------------------------------------------------------------
+// h0 / c0 (nullable): initial state [L][B][H]
+int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, const float* obs, const float* h0, const float* c0,
+            const Acts& a) {
+    const int64_t B = n.B, rows = B * n.T;
+    const int H = n.H;
+    const size_t blk = (size_t)B * H;
+    hipLaunchKernelGGL(pad_time_major_kernel, dim3((unsigned)ts::ceil_div(rows * n.k0, 256)), dim3(256), 0, s, obs, B, n.T, n.obs,
+                       n.k0, a.x);
+    TS_LAUNCH_CHECK();
+    if (int rc = ts::conv_forward(s, n.fc1, a.x, p + n.off_fc1, a.x1, false, a.split, ws)) return rc;
+    for (int l = 0; l < n.L; ++l) {
+        if (h0) TS_HIP_CHECK(hipMemcpyAsync(a.hbuf[l], h0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+        else TS_HIP_CHECK(hipMemsetAsync(a.hbuf[l], 0, 4 * blk, s));
+        if (c0) TS_HIP_CHECK(hipMemcpyAsync(a.cbuf[l], c0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+        else TS_HIP_CHECK(hipMemsetAsync(a.cbuf[l], 0, 4 * blk, s));
+        const float* in = l == 0 ? a.x1 : a.hbuf[l - 1] + blk;
+        if (int rc = ts::conv_forward(s, n.ih_all, in, p + n.off_ih[l], a.gih, false, a.split, ws)) return rc;
+        for (int t = 0; t < n.T; ++t) {
+            if (int rc = ts::conv_forward(s, n.hh_step, a.hbuf[l] + t * blk, p + n.off_hh[l], a.ghh, false, a.split, ws)) return rc;
+            hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)ts::ceil_div((int64_t)blk, 256)), dim3(256), 0, s,
+                               a.gih + (size_t)t * 4 * blk, a.ghh, a.cbuf[l] + t * blk, B, H, a.gact[l] + (size_t)t * 4 * blk,
+                               a.cbuf[l] + (t + 1) * blk, a.hbuf[l] + (t + 1) * blk);
+            TS_LAUNCH_CHECK();
+        }
+    }
+    return ts::conv_forward(s, n.head, a.hbuf[n.L - 1] + (size_t)n.T * blk, p + n.off_head, a.out, false, a.split, ws);
+}
+
+struct Bwd {
+    float* dg;        // [T B, 4H] gate gradients of the current layer
+    float* dout;      // [T B, H]  d loss / d (layer output) at every step
+    float* din;       // [T B, H]  d loss / d (layer input)
+    float* dh_rec;    // [B, H]
+    float* dc;        // [B, H]
+    float* slabs;
+};
+
+size_t bwd_bytes(const RNet& n) {
+    const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
+    return al(4 * rows * 4 * H) + 2 * al(4 * rows * H) + 2 * al(4 * B * H) + al(4 * slab_floats(n));
+}
+
+Bwd take_bwd(Carve& c, const RNet& n) {
+    const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
+    return Bwd{c.f(rows * 4 * H), c.f(rows * H), c.f(rows * H), c.f(B * H), c.f(B * H), c.f(slab_floats(n))};
+}
+
+int wgrad_to(hipStream_t s, ts_workspace* ws, const ts::ConvGeom& g, const float* x, const float* dy, float* slabs, float* out) {
+    if (int rc = ts::conv_wgrad(s, g, x, dy, slabs, ws)) return rc;
+    return ts::slab_sum(s, slabs, ts::conv_wgrad_splits(g), g.param_elems(), out);
+}
+
+// grad[0 .. count) = d loss / d params given d loss / d head output (d_head [B, 32])
+int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, const Acts& a, const float* d_head, float* grad,
+             Bwd bw) {
+    const int64_t B = n.B;
+    const int H = n.H, T = n.T;
+    const size_t blk = (size_t)B * H;
+    const unsigned gcell = (unsigned)ts::ceil_div((int64_t)blk, 256);
+    // head: only the last step of the top layer receives a gradient
+    if (int rc = wgrad_to(s, ws, n.head, a.hbuf[n.L - 1] + (size_t)T * blk, d_head, bw.slabs, grad + n.off_head)) return rc;
+    if (T > 1) TS_HIP_CHECK(hipMemsetAsync(bw.dout, 0, 4 * (size_t)(T - 1) * blk, s));
+    if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) return rc;
+    for (int l = n.L - 1; l >= 0; --l) {
+        for (int t = T - 1; t >= 0; --t) {
+            hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(gcell), dim3(256), 0, s, bw.dout + (size_t)t * blk, bw.dh_rec, bw.dc,
+                               a.gact[l] + (size_t)t * 4 * blk, a.cbuf[l] + (size_t)(t + 1) * blk, a.cbuf[l] + (size_t)t * blk, B, H,
+                               t == T - 1 ? 1 : 0, bw.dg + (size_t)t * 4 * blk);
+            TS_LAUNCH_CHECK();
+            if (t > 0)
+                if (int rc = ts::conv_dgrad(s, n.hh_step, bw.dg + (size_t)t * 4 * blk, p + n.off_hh[l], nullptr, bw.dh_rec, ws)) return rc;
+        }
+        const float* in = l == 0 ? a.x1 : a.hbuf[l - 1] + blk;
+        if (int rc = wgrad_to(s, ws, n.ih_all, in, bw.dg, bw.slabs, grad + n.off_ih[l])) return rc;
+        if (int rc = wgrad_to(s, ws, n.ih_all, a.hbuf[l], bw.dg, bw.slabs, grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
+        if (int rc = ts::conv_dgrad(s, n.ih_all, bw.dg, p + n.off_ih[l], nullptr, bw.din, ws)) return rc;
+        std::swap(bw.dout, bw.din);
+    }
+    return wgrad_to(s, ws, n.fc1, a.x, bw.dout, bw.slabs, grad + n.off_fc1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_rnnq_layout(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t* h_out) {
+    TS_REQUIRE(h_out != nullptr, TS_ERR_INVALID_ARG, "ts_rnnq_layout: h_out is NULL");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, 1, 1, &n)) return rc;
+    h_out[0] = n.k0; h_out[1] = n.count; h_out[2] = n.off_fc1;
+    for (int l = 0; l < n.L; ++l) { h_out[3 + 2 * l] = n.off_ih[l]; h_out[4 + 2 * l] = n.off_hh[l]; }
+    h_out[3 + 2 * n.L] = n.off_head;
+    return TS_OK;
+}
+
+int ts_rnnq_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                    const float* obs, int64_t B, int64_t T, const float* h_in, const float* c_in, float* q_out, int64_t* act_out,
+                    float* h_out, float* c_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_forward: workspace is NULL");
+    TS_REQUIRE(params && obs && (q_out || act_out) && (h_in == nullptr) == (c_in == nullptr), TS_ERR_INVALID_ARG,
+               "ts_rnnq_forward: bad argument (hidden and cell state come together)");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, B, T, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::ws_reserve(ws, acts_bytes(n) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    const Acts a = take_acts(c, n);
+    if (int rc = forward(s, ws, n, params, obs, h_in, c_in, a)) return rc;
+    hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a.out, B, n.A, q_out, act_out);
+    TS_LAUNCH_CHECK();
+    const size_t blk = (size_t)B * n.H;
+    for (int l = 0; l < n.L; ++l) {
+        if (h_out) TS_HIP_CHECK(hipMemcpyAsync(h_out + l * blk, a.hbuf[l] + (size_t)n.T * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+        if (c_out) TS_HIP_CHECK(hipMemcpyAsync(c_out + l * blk, a.cbuf[l] + (size_t)n.T * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+    }
+    return TS_OK;
+}
+
+int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                   int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
+                   const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
+                   float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_update: workspace is NULL");
+    TS_REQUIRE(params && obs && act && returns && hp && td_out && loss_out, TS_ERR_INVALID_ARG, "ts_rnnq_update: NULL argument");
+    TS_REQUIRE(hp->lr < 0.0 || (adam_m && adam_v && adam_step >= 1), TS_ERR_INVALID_ARG, "ts_rnnq_update: Adam state missing");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, B, T, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::ws_reserve(ws, acts_bytes(n) + bwd_bytes(n) + al(4 * B * HEAD) + al(4 * n.count) + 8192)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    const Acts a = take_acts(c, n);
+    const Bwd bw = take_bwd(c, n);
+    float* d_head = c.f(B * HEAD);
+    float* grad = c.f(n.count);
+    float* norm_part = c.f(1024);
+    if (grad_out) grad = grad_out;
+    if (int rc = forward(s, ws, n, params, obs, nullptr, nullptr, a)) return rc;
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, act, returns, weight, B, (float)hp->huber_delta, td_out,
+                       d_head, loss_out);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward(s, ws, n, params, a, d_head, grad, bw)) return rc;
+    if (hp->lr < 0.0) return TS_OK;
+    return ts::adam_step(s, params, adam_m, adam_v, grad, n.count, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+                         hp->max_grad_norm, norm_part);
+}
+
+}  // extern "C"

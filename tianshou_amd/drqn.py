@@ -1,0 +1,197 @@
+"""DQN on a recurrent Q network (DRQN) on the MI355X engine.
+
+Mirrors, on device tensors:
+    Recurrent.forward                    tianshou/utils/net/common.py:400-452 (fc1 -> nn.LSTM -> fc2 on the last step)
+    DiscreteQLearningPolicy.forward      tianshou/algorithm/modelfree/dqn.py:101-143
+    DQN._target_q / _preprocess_batch    dqn.py:257-275, 365-379 (n-step via tianshou_amd.returns)
+    DQN._update_with_batch               dqn.py:381-404 (+ periodic hard sync :277-285)
+    ReplayBuffer.get with stack_num      data/buffer/buffer_base.py:586-596 on vector observations
+Setup: test/discrete/test_drqn.py:79-108.  There is no CPU path: every function calls libtsengine.so.
+
+Flat layout (include/tsengine.h, ts_rnnq_layout): fc1 [k0 + 1, H] | per layer W_ih [H + 1, 4H] | W_hh [H + 1, 4H] |
+fc2 [H + 1, 32]; `flat_from_torch` / `flat_to_torch` convert from / to Recurrent.state_dict() order (and Adam moments).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .buffer import DeviceReplayBuffer, _i64_dev, gather_rows
+from .dqn import DQNConfig, stack_indices
+from .lagged import full_parameter_update
+from .returns import compute_nstep_return
+
+HEAD = 32
+
+
+def state_dict_keys(layers: int) -> list[str]:
+    """Recurrent.state_dict() order (the LSTM is constructed first, common.py:386-393)."""
+    ks = []
+    for k in range(layers):
+        ks += [f"nn.weight_ih_l{k}", f"nn.weight_hh_l{k}", f"nn.bias_ih_l{k}", f"nn.bias_hh_l{k}"]
+    return ks + ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+
+
+def layout(obs_dim: int, hidden: int, layers: int, n_act: int) -> dict:
+    out = (C.c_int64 * (4 + 2 * layers))()
+    _lib.check(_lib.load().ts_rnnq_layout(_lib.i64(obs_dim), _lib.i64(hidden), _lib.i64(layers), _lib.i64(n_act), out))
+    return {"k0": int(out[0]), "count": int(out[1]), "fc1": int(out[2]), "ih": [int(out[3 + 2 * l]) for l in range(layers)],
+            "hh": [int(out[4 + 2 * l]) for l in range(layers)], "fc2": int(out[3 + 2 * layers])}
+
+
+def _block(w: torch.Tensor, b: torch.Tensor, k_pad: int, n_pad: int) -> torch.Tensor:
+    """nn.Linear-layout weight [n, k] + bias [n] -> [k_pad + 1, n_pad] (zero padding, bias in the last row)."""
+    n, k = w.shape
+    m = torch.zeros((k_pad + 1, n_pad), dtype=torch.float32)
+    m[:k, :n] = w.detach().float().cpu().t()
+    m[k_pad, :n] = b.detach().float().cpu().reshape(-1)
+    return m.reshape(-1)
+
+
+def flat_from_torch(t: list[torch.Tensor], obs_dim: int, hidden: int, layers: int, n_act: int, device="cuda") -> torch.Tensor:
+    """Tensors in state_dict_keys(layers) order -> the engine's flat vector."""
+    k0 = (obs_dim + 31) // 32 * 32
+    parts = [_block(t[4 * layers], t[4 * layers + 1], k0, hidden)]
+    for k in range(layers):
+        w_ih, w_hh, b_ih, b_hh = t[4 * k:4 * k + 4]
+        parts += [_block(w_ih, b_ih, hidden, 4 * hidden), _block(w_hh, b_hh, hidden, 4 * hidden)]
+    parts.append(_block(t[4 * layers + 2], t[4 * layers + 3], hidden, HEAD))
+    return torch.cat(parts).to(device).contiguous()
+
+
+def flat_to_torch(flat: torch.Tensor, obs_dim: int, hidden: int, layers: int, n_act: int) -> list[torch.Tensor]:
+    """Inverse of flat_from_torch -> tensors in state_dict_keys(layers) order (on flat's device)."""
+    k0 = (obs_dim + 31) // 32 * 32
+    f, off = flat.detach(), 0
+
+    def take(k_pad, n_pad, k, n):
+        nonlocal off
+        m = f[off:off + (k_pad + 1) * n_pad].reshape(k_pad + 1, n_pad)
+        off += (k_pad + 1) * n_pad
+        return m[:k, :n].t().contiguous(), m[k_pad, :n].clone()
+
+    fc1 = take(k0, hidden, obs_dim, hidden)
+    lstm = []
+    for _ in range(layers):
+        (w_ih, b_ih), (w_hh, b_hh) = take(hidden, 4 * hidden, hidden, 4 * hidden), take(hidden, 4 * hidden, hidden, 4 * hidden)
+        lstm += [w_ih, w_hh, b_ih, b_hh]
+    fc2 = take(hidden, HEAD, hidden, n_act)
+    return lstm + [*fc1, *fc2]
+
+
+def gather_stacked_obs(obs_rows: torch.Tensor, buffer: DeviceReplayBuffer, index, stack_num: int) -> torch.Tensor:
+    """buffer.get(index, "obs") for vector observations: float32 [I, stack_num, obs_dim], oldest step first
+    (buffer_base.py:586-596)."""
+    index = _i64_dev(index, buffer.device).reshape(-1)
+    rows = stack_indices(buffer, index, stack_num) if stack_num > 1 else index.reshape(-1, 1)
+    out = gather_rows(obs_rows, rows.reshape(-1))
+    return out.reshape(index.numel(), stack_num, -1)
+
+
+class RecurrentDQNEngine:
+    """State of one DRQN learner on one GPU: flat parameters, lagged copy, Adam moments, counters."""
+
+    def __init__(self, obs_dim: int, hidden: int, layers: int, n_act: int, flat_params: torch.Tensor, cfg: DQNConfig):
+        if not flat_params.is_cuda:
+            raise RuntimeError("RecurrentDQNEngine needs parameters on an MI355X (no CPU fallback)")
+        self.obs_dim, self.hidden, self.layers, self.n_act, self.cfg = obs_dim, hidden, layers, n_act, cfg
+        self.lay = layout(obs_dim, hidden, layers, n_act)
+        self.P = self.lay["count"]
+        if flat_params.numel() != self.P:
+            raise ValueError(f"expected {self.P} parameters, got {flat_params.numel()}")
+        self.device = flat_params.device
+        self.params = flat_params.detach().float().contiguous().clone()
+        self.params_old = self.params.clone() if cfg.target_update_freq > 0 else None    # dqn.py:240-246
+        self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.adam_step = 0
+        self.iter = 0
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    def _dims(self):
+        return _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.i64(self.layers), _lib.i64(self.n_act)
+
+    def _obs(self, obs) -> torch.Tensor:
+        obs = torch.as_tensor(obs, device=self.device).to(torch.float32)
+        if obs.dim() == 2:
+            obs = obs.unsqueeze(1)                                   # evaluation mode, common.py:425-426
+        if obs.dim() != 3 or obs.shape[2] != self.obs_dim:
+            raise ValueError(f"obs must be [B, T, {self.obs_dim}] or [B, {self.obs_dim}]")
+        return obs.contiguous()
+
+    # -- Recurrent.forward + DiscreteQLearningPolicy.forward ---------------------------------------------------------------
+    def forward(self, obs, state=None, params: torch.Tensor | None = None, want_state: bool = False):
+        """-> (q float32[B, A], act int64[B][, (hidden, cell) each float32[B, L, H] as the reference carries them])."""
+        obs = self._obs(obs)
+        b, t = obs.shape[:2]
+        q = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
+        act = torch.empty(b, dtype=torch.int64, device=self.device)
+        h_in = c_in = h_out = c_out = None
+        if state is not None:
+            h_in, c_in = (torch.as_tensor(s, device=self.device).to(torch.float32).transpose(0, 1).contiguous() for s in state)
+            if h_in.shape != (self.layers, b, self.hidden) or c_in.shape != h_in.shape:
+                raise ValueError("state tensors must be [B, layers, hidden]")
+        if want_state:
+            h_out = torch.empty((self.layers, b, self.hidden), dtype=torch.float32, device=self.device)
+            c_out = torch.empty_like(h_out)
+        p = self.params if params is None else params
+        _lib.check(_lib.load().ts_rnnq_forward(
+            self._ws.handle, _lib.ptr(p), *self._dims(), _lib.ptr(obs), _lib.i64(b), _lib.i64(t), _lib.ptr(h_in), _lib.ptr(c_in),
+            _lib.ptr(q), _lib.ptr(act), _lib.ptr(h_out), _lib.ptr(c_out), _lib.current_stream(self.device)))
+        if want_state:
+            return q, act, (h_out.transpose(0, 1).contiguous(), c_out.transpose(0, 1).contiguous())
+        return q, act
+
+    # -- DQN._target_q ---------------------------------------------------------------------------------------------------------
+    def target_q(self, obs_next) -> torch.Tensor:
+        q_online, _ = self.forward(obs_next)
+        q_target = q_online if self.params_old is None else self.forward(obs_next, params=self.params_old)[0]
+        b = q_online.shape[0]
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_dqn_target_q(_lib.ptr(q_online), _lib.ptr(q_target), _lib.i64(b), _lib.i64(self.n_act),
+                                               C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
+        return out
+
+    # -- DQN._preprocess_batch ---------------------------------------------------------------------------------------------
+    def preprocess(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, indices, stack_num: int,
+                   obs_next_rows: torch.Tensor | None = None) -> torch.Tensor:
+        """n-step returns float32[I] with target_q_fn = _target_q (dqn.py:257-275); without stored obs_next, s_{t+n} is read at
+        next(indices_after_n) (buffer_base.py:624-626)."""
+
+        def tq_fn(buf, after):
+            if obs_next_rows is None:
+                return self.target_q(gather_stacked_obs(obs_rows, buf, buf.next(after), stack_num))
+            return self.target_q(gather_stacked_obs(obs_next_rows, buf, after, stack_num))
+
+        class _B:
+            pass
+
+        return compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step).returns.reshape(-1)
+
+    # -- DQN._update_with_batch ----------------------------------------------------------------------------------------------
+    def update_with_batch(self, obs, act, returns, weight=None, grad_out: torch.Tensor | None = None, apply: bool = True):
+        """-> (loss float32[1] device tensor, td_error float32[B]); td_error is the new batch.weight."""
+        cfg = self.cfg
+        if self.params_old is not None and self.iter % cfg.target_update_freq == 0:    # dqn.py:283-285
+            full_parameter_update(self.params_old, self.params)
+        self.iter += 1
+        obs = self._obs(obs)
+        b, t = obs.shape[:2]
+        act = _i64_dev(act, self.device).reshape(-1)
+        returns = torch.as_tensor(returns, device=self.device).to(torch.float32).reshape(-1).contiguous()
+        if act.numel() != b or returns.numel() != b:
+            raise ValueError("act / returns length mismatch")
+        if weight is not None:
+            weight = torch.as_tensor(weight, device=self.device).to(torch.float32).reshape(-1).contiguous()
+        td = torch.empty(b, dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        if apply:
+            self.adam_step += 1
+        hp = cfg.to_c(grad_only=not apply)
+        _lib.check(_lib.load().ts_rnnq_update(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(max(self.adam_step, 1)),
+            *self._dims(), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight), _lib.i64(b), _lib.i64(t),
+            C.byref(hp), _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out), _lib.current_stream(self.device)))
+        return loss, td

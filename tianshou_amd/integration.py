@@ -461,6 +461,94 @@ def make_hip_dqn():
 
 
 # ---------------------------------------------------------------------------------------------------
+# DQN on the Recurrent Q network (DRQN, test/discrete/test_drqn.py)
+# ---------------------------------------------------------------------------------------------------
+def make_hip_drqn():
+    """Returns HipDRQN(DQN): the DQN hooks (dqn.py:257-275, 381-404) on the engine for a Recurrent model
+    (utils/net/common.py:372-452) over a buffer with stack_num (the LSTM's sequence length) and vector observations."""
+    from tianshou.algorithm.modelfree.dqn import DQN
+    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+
+    from . import dqn as D
+    from . import drqn as R
+
+    class HipDRQN(DQN):
+        def __init__(self, *args, device="cuda", **kwargs):
+            super().__init__(*args, **kwargs)
+            self._hip_device = torch.device(device)
+            sd = self.policy.model.state_dict()
+            layers = sum(1 for k in sd if k.startswith("nn.weight_ih_l"))
+            if layers < 1 or list(sd.keys()) != R.state_dict_keys(layers):
+                raise NotImplementedError("HipDRQN: the model must be Recurrent(layer_num, state_shape, action_shape, hidden)")
+            hidden, obs_dim = sd["fc1.weight"].shape
+            n_act = sd["fc2.weight"].shape[0]
+            if hidden % 32 or not 32 <= hidden <= 1024 or layers > 8 or n_act > 32:
+                raise NotImplementedError("HipDRQN: hidden a multiple of 32 in [32, 1024], at most 8 layers and 32 actions")
+            self._hip_dims = (obs_dim, hidden, layers, n_act)
+            _adam_of(self.optim)
+            self._hip_engine = None
+
+        def _engine(self):
+            if self._hip_engine is None:
+                sd = self.policy.model.state_dict()
+                dims, dev = self._hip_dims, self._hip_device
+                keys = R.state_dict_keys(dims[2])
+                opt, g = _adam_of(self.optim)
+                cfg = D.DQNConfig(gamma=self.gamma, n_step=self.n_step, target_update_freq=self.target_update_freq,
+                                  is_double=self.is_double, huber_delta=self.huber_loss_delta, lr=g["lr"],
+                                  betas=tuple(g["betas"]), adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
+                eng = self._hip_engine = R.RecurrentDQNEngine(*dims, R.flat_from_torch([sd[k] for k in keys], *dims, dev), cfg)
+                eng.iter = self._iter
+                ms, vs, step = adam_state(opt, params_by_keys(self.policy.model, keys))       # resume from a checkpoint
+                eng.adam_m, eng.adam_v = R.flat_from_torch(ms, *dims, dev), R.flat_from_torch(vs, *dims, dev)
+                eng.adam_step = step
+                if eng.params_old is not None:
+                    old = getattr(self.model_old, "module", self.model_old).state_dict()       # EvalModeModuleWrapper
+                    eng.params_old = R.flat_from_torch([old[k] for k in keys], *dims, dev)
+            return self._hip_engine
+
+        def _preprocess_batch(self, batch, buffer, indices):
+            _require_gpu(self._hip_device, "HipDRQN")
+            obs = np.asarray(buffer.obs)
+            if obs.ndim != 2 or obs.shape[1] != self._hip_dims[0]:
+                raise NotImplementedError("HipDRQN: the buffer must hold vector observations of the model's state_shape")
+            eng = self._engine()
+            m = _mirror(self, buffer, self._hip_device)
+            idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            stack = int(getattr(buffer, "stack_num", 1))
+            nxt = m.obs_next if m.obs_next is not None else None
+            batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_rows=nxt).reshape(-1, 1)
+            self._hip_idx, self._hip_stack = idx, stack
+            if hasattr(batch, "weight"):
+                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
+            return batch
+
+        def _update_with_batch(self, batch):
+            eng, m = self._hip_engine, self._hip_mirror
+            weight = batch.pop("weight", None)
+            obs = R.gather_stacked_obs(m.obs, m, self._hip_idx, self._hip_stack)
+            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
+            loss, td = eng.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
+            self._iter = eng.iter
+            batch.weight = td                                                     # prio-buffer, dqn.py:401
+            dims = self._hip_dims
+            keys = R.state_dict_keys(dims[2])
+            params = params_by_keys(self.policy.model, keys)
+            with torch.no_grad():
+                for p, t in zip(params, R.flat_to_torch(eng.params, *dims)):
+                    p.copy_(t)
+                if eng.params_old is not None:
+                    old_mod = getattr(self.model_old, "module", self.model_old)
+                    for p, t in zip(params_by_keys(old_mod, keys), R.flat_to_torch(eng.params_old, *dims)):
+                        p.copy_(t)
+            store_adam_state(self.optim._optim, params, R.flat_to_torch(eng.adam_m, *dims), R.flat_to_torch(eng.adam_v, *dims),
+                             eng.adam_step)
+            return SimpleLossTrainingStats(loss=float(loss.item()))
+
+    return HipDRQN
+
+
+# ---------------------------------------------------------------------------------------------------
 # QRDQN (qrdqn.py) / C51 (c51.py) on QRDQNet / C51Net
 # ---------------------------------------------------------------------------------------------------
 def _make_hip_distq(kind: str):
