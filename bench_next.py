@@ -19,6 +19,8 @@ import time
 import numpy as np
 import torch
 
+import bench_init as BI
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -108,7 +110,6 @@ def _line(metric, value, unit, steps, warmup, dt, workload, roof, cpu, extra=Non
 
 # ---- TD3 / DDPG (Humanoid shape, as C5) ------------------------------------------------------------------------------
 def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
-    from oracle import oracle_sac as OS
     from tianshou_amd import td3 as T
     from tianshou_amd.buffer import gather_rows
 
@@ -117,9 +118,9 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
     buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
                        act=torch.rand(slots, ACT, generator=g, device=dev) * 2 - 1,
                        obs_next=torch.randn(slots, OBS, generator=g, device=dev))
-    actor, c1, c2 = OS.init_td3_params(OBS, ACT, 0, twin=twin)
-    cf = lambda c: None if c is None else T.critic_flat_from_torch([c[k] for k in OS.CRITIC_ORDER], OBS, ACT)  # noqa: E731
-    eng = T.TD3Engine(OBS, ACT, T.actor_flat_from_torch([actor[k] for k in OS.DET_ACTOR_ORDER], OBS, ACT), cf(c1), cf(c2),
+    actor, c1, c2 = BI.td3_nets(OBS, ACT, 0, twin=twin)
+    cf = lambda c: None if c is None else T.critic_flat_from_torch(list(c.values()), OBS, ACT)  # noqa: E731
+    eng = T.TD3Engine(OBS, ACT, T.actor_flat_from_torch(list(actor.values()), OBS, ACT), cf(c1), cf(c2),
                       T.TD3Config(twin=twin))
 
     def update():
@@ -138,6 +139,8 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
                            + mlp_flop(c_dims, dgrad_layers=2, first_dx_cols=ACT)))           # ... through critic 1
     cpu = None
     if with_cpu:
+        from oracle import oracle_sac as OS
+
         cfg = OS.TD3Config(twin=twin)
         st = OS.TD3State.create(actor, c1, c2, cfg)
         gc = torch.Generator().manual_seed(0)
@@ -164,8 +167,6 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
 
 # ---- REDQ (Humanoid shape, as C5) ------------------------------------------------------------------------------------------
 def run_redq(steps, warmup, with_cpu, slots=1 << 21):
-    from oracle import oracle_redq as OR
-    from oracle import oracle_sac as OS
     from tianshou_amd import redq as RQ
     from tianshou_amd import sac as S
     from tianshou_amd.buffer import gather_rows
@@ -175,10 +176,10 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
     buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
                        act=torch.rand(slots, ACT, generator=g, device=dev) * 2 - 1,
                        obs_next=torch.randn(slots, OBS, generator=g, device=dev))
-    actor, critic = OR.init_params(OBS, ACT, E, 0)
+    actor, critic = BI.sac_actor(OBS, ACT, 0), BI.redq_ensemble(OBS, ACT, E, 1)
     cfg = RQ.REDQConfig(auto_alpha=True, target_entropy=-float(ACT), ensemble_size=E, subset_size=SUB, actor_delay=DELAY)
-    eng = RQ.REDQEngine(OBS, ACT, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], OBS, ACT),
-                        RQ.ensemble_flat_from_torch([critic[k] for k in OR.CRITIC_ORDER], OBS, ACT), cfg)
+    eng = RQ.REDQEngine(OBS, ACT, S.actor_flat_from_torch(list(actor.values()), OBS, ACT),
+                        RQ.ensemble_flat_from_torch(list(critic.values()), OBS, ACT), cfg)
     rng = np.random.default_rng(0)
 
     def update():
@@ -194,6 +195,8 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
                 + (mlp_flop(a_dims, wgrad=True, dgrad_layers=2) + E * mlp_flop(c_dims, dgrad_layers=2, first_dx_cols=ACT)) / DELAY)
     cpu = None
     if with_cpu:
+        from oracle import oracle_redq as OR
+
         ocfg = OR.REDQConfig(auto_alpha=True, target_entropy=-float(ACT), ensemble_size=E, subset_size=SUB, actor_delay=DELAY)
         st = OR.REDQState.create(actor, critic, ocfg)
         gc = torch.Generator().manual_seed(0)
@@ -219,8 +222,6 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
 
 # ---- DiscreteSAC ---------------------------------------------------------------------------------------------------------
 def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
-    from oracle import oracle_dsac as ODS
-    from oracle import oracle_sac as OS
     from tianshou_amd import dsac as DS
     from tianshou_amd.buffer import gather_rows
     from tianshou_amd.sac import SACConfig
@@ -230,8 +231,8 @@ def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
     buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
                        act=torch.randint(0, A, (slots,), generator=g, device=dev),
                        obs_next=torch.randn(slots, OBS, generator=g, device=dev))
-    nets = ODS.init_params(OBS, A, HID, 0)
-    flats = [DS.net_flat_from_torch([p[k] for k in ODS.NET_ORDER], OBS, A, HID) for p in nets]
+    nets = BI.dsac_nets(OBS, A, HID, 0)
+    flats = [DS.net_flat_from_torch(list(p.values()), OBS, A, HID) for p in nets]
     te = 0.98 * float(np.log(A))
     eng = DS.DiscreteSACEngine(OBS, A, HID, *flats, SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3))
 
@@ -247,6 +248,9 @@ def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
                 + 2 * mlp_flop(dims) + mlp_flop(dims, wgrad=True, dgrad_layers=2))   # actor step with both critics' Q
     cpu = None
     if with_cpu:
+        from oracle import oracle_dsac as ODS
+        from oracle import oracle_sac as OS
+
         cfg = OS.SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3)
         st = OS.SACState.create(*nets, cfg)
         gc = torch.Generator().manual_seed(0)
@@ -272,17 +276,15 @@ def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
 # ---- QRDQN / C51 (Atari shape, as C3) ----------------------------------------------------------------------------------
 def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
     import bench_dqn as BD
-    from oracle import oracle_distq as OQ
-    from oracle import oracle_dqn as OD
     from tianshou_amd import distq as Q
     from tianshou_amd import dqn as D
 
     C, H, W, A, B = BD.C, BD.H, BD.W, BD.N_ACT, BD.BATCH
     N = 200 if kind == "qr" else 51
     frames, act, buf, per = BD.build(slots, 16)
-    p = OQ.init_params(C, H, W, A, N, 0)
+    p = BI.dqnet(C, H, W, A * N, 0)
     cfg = Q.DistQConfig(kind=kind, n_atoms=N, gamma=0.99, n_step=3, target_update_freq=500, lr=5e-5, v_min=-10.0, v_max=10.0)
-    eng = Q.DistQEngine(C, H, W, A, Q.flat_from_torch([p[k] for k in OD.PARAM_ORDER], C, H, W, A, N), cfg)
+    eng = Q.DistQEngine(C, H, W, A, Q.flat_from_torch(list(p.values()), C, H, W, A, N), cfg)
     gen = torch.Generator(device="cuda").manual_seed(1)
 
     def update():
@@ -300,6 +302,9 @@ def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
     flop = B * (3 * fwd + wg + dg)             # online + lagged pass on s', forward / backward on s
     cpu = None
     if with_cpu:
+        from oracle import oracle_distq as OQ
+        from oracle import oracle_dqn as OD
+
         ocfg = OQ.DistQConfig(kind=kind, n_atoms=N, n_step=3, target_update_freq=500, lr=5e-5)
         st = OD.DQNState.create(p, ocfg.dqn())
         rng = np.random.default_rng(0)
@@ -330,8 +335,6 @@ def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
 # ---- Rainbow (Atari shape, as C3) -----------------------------------------------------------------------------------------
 def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
     import bench_dqn as BD
-    from oracle import oracle_distq as OQ
-    from oracle import oracle_rainbow as ORB
     from tianshou_amd import distq as Q
     from tianshou_amd import dqn as D
     from tianshou_amd import rainbow as RB
@@ -339,11 +342,10 @@ def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
     C, H, W, A, B, N = BD.C, BD.H, BD.W, BD.N_ACT, BD.BATCH, 51
     dims = (C, H, W, A, N)
     frames, act, buf, per = BD.build(slots, 16)
-    p, n0 = ORB.init_params(*dims, 0)
-    order = [f"{L}.{t}" for L in ORB.NOISY for t in ("eps_p", "eps_q")]
+    p, n0 = BI.rainbow_net(*dims, 0)
     cfg = Q.DistQConfig(kind="c51", n_atoms=N, gamma=0.99, n_step=3, target_update_freq=500, lr=6.25e-5, v_min=-10.0, v_max=10.0)
-    eng = RB.RainbowEngine(C, H, W, A, RB.flat_from_torch([p[k] for k in ORB.PARAM_ORDER], *dims),
-                           RB.noise_from_torch([n0[k] for k in order], *dims), cfg)
+    eng = RB.RainbowEngine(C, H, W, A, RB.flat_from_torch(list(p.values()), *dims),
+                           RB.noise_from_torch(list(n0.values()), *dims), cfg)
     gen = torch.Generator(device="cuda").manual_seed(1)
     nn = eng.lay["noise_count"]
 
@@ -369,6 +371,9 @@ def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
     flop = B * (3 * fwd + fwd + (fwd - 2 * conv[0]))
     cpu = None
     if with_cpu:
+        from oracle import oracle_distq as OQ
+        from oracle import oracle_rainbow as ORB
+
         ocfg = OQ.DistQConfig(kind="c51", n_atoms=N, n_step=3, target_update_freq=500, lr=6.25e-5)
         st = ORB.RainbowState(p, n0, ocfg)
         rng = np.random.default_rng(0)
@@ -395,8 +400,6 @@ def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
 
 # ---- NPG / TRPO (MuJoCo shape, as C2) ---------------------------------------------------------------------------------------
 def run_natural(steps, warmup, with_cpu, algo="npg"):
-    from oracle import oracle_npg as ON
-    from oracle import oracle_ppo as OP
     from tianshou_amd import npg as NG
 
     OBS, ACT, HID, E, T, MB, dev = 17, 6, 64, 512, 512, 65536, torch.device("cuda")         # 2^18 transitions, 4 minibatches
@@ -408,7 +411,7 @@ def run_natural(steps, warmup, with_cpu, algo="npg"):
     term = torch.rand(n, generator=g, device=dev) < 0.002
     trunc = torch.zeros(n, dtype=torch.bool, device=dev)
     cut = (torch.arange(E, device=dev) + 1) * T - 1
-    p = OP.init_params(OBS, ACT, seed=0)
+    p = BI.ppo_nets(OBS, ACT, 0)
     a_keys = ("a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma")
     c_keys = ("c_w1", "c_b1", "c_w2", "c_b2", "c_wv", "c_bv")
     cfg = NG.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=5, lr=1e-3)
@@ -436,6 +439,9 @@ def run_natural(steps, warmup, with_cpu, algo="npg"):
     flop = k * flop_mb + n * (mlp_flop(a_dims) + 2 * mlp_flop(c_dims))
     cpu = None
     if with_cpu:
+        from oracle import oracle_npg as ON
+        from oracle import oracle_ppo as OP
+
         ocfg = ON.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=5, lr=1e-3)
         st = OP.PPOState(params={kk: v.clone() for kk, v in p.items()})
         gc = torch.Generator().manual_seed(0)
@@ -460,9 +466,6 @@ def run_natural(steps, warmup, with_cpu, algo="npg"):
 
 # ---- PPO, CartPole shape (BASELINE.json configs[0]) ------------------------------------------------------------------------
 def run_ppo_discrete(steps, warmup, with_cpu):
-    from oracle import oracle_ppo as OP
-    from oracle import oracle_ppo_cnn as OC
-    from oracle import oracle_ppo_discrete as OD
     from tianshou_amd import ppo_discrete as PD
     from tianshou_amd.ppo import PPOConfig
 
@@ -472,10 +475,10 @@ def run_ppo_discrete(steps, warmup, with_cpu):
     buf = _flat_buffer(n, E, dev, g, obs=torch.randn(n, OBS, generator=g, device=dev),
                        act=torch.randint(0, A, (n,), generator=g, device=dev),
                        obs_next=torch.randn(n, OBS, generator=g, device=dev))
-    p = OD.init_params(OBS, HID, A, 1626)
+    p = BI.ppo_discrete_net(OBS, HID, A, 1626)
     kw = dict(gamma=0.99, gae_lambda=0.95, eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, value_clip=False,
               advantage_normalization=False, return_scaling=False, lr=3e-4)
-    eng = PD.DiscretePPOEngine(OBS, HID, A, PD.flat_from_torch([p[k] for k in OD.PARAM_ORDER], OBS, HID, A), PPOConfig(**kw))
+    eng = PD.DiscretePPOEngine(OBS, HID, A, PD.flat_from_torch(list(p.values()), OBS, HID, A), PPOConfig(**kw))
     count = [0]
 
     def update():
@@ -491,6 +494,10 @@ def run_ppo_discrete(steps, warmup, with_cpu):
     flop = 2 * n * mlp_flop(dims) + k * BS * mlp_flop(dims, wgrad=True, dgrad_layers=2)
     cpu = None
     if with_cpu:
+        from oracle import oracle_ppo as OP
+        from oracle import oracle_ppo_cnn as OC
+        from oracle import oracle_ppo_discrete as OD
+
         cfg = OP.PPOConfig(**kw)
         st = OP.PPOState(params={kk: v.clone() for kk, v in p.items()})
         net = OD.MlpNet(True)
@@ -513,8 +520,6 @@ def run_ppo_discrete(steps, warmup, with_cpu):
 
 
 def run_reinforce(steps, warmup, with_cpu):
-    from oracle import oracle_ppo as OP
-    from oracle import oracle_reinforce as OR
     from tianshou_amd import npg as NG
     from tianshou_amd import reinforce as RF
 
@@ -527,8 +532,9 @@ def run_reinforce(steps, warmup, with_cpu):
     term = torch.rand(n, generator=g, device=dev) < 0.002
     trunc = torch.zeros(n, dtype=torch.bool, device=dev)
     cut = (torch.arange(E, device=dev) + 1) * T - 1
-    p = OP.init_params(OBS, ACT, seed=0)
-    eng = RF.ReinforceEngine(OBS, ACT, HID, NG.actor_flat_from_torch([p[k] for k in OR.ACTOR_KEYS], OBS, HID, ACT),
+    p = BI.ppo_nets(OBS, ACT, 0)
+    a_keys = ("a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma")
+    eng = RF.ReinforceEngine(OBS, ACT, HID, NG.actor_flat_from_torch([p[k] for k in a_keys], OBS, HID, ACT),
                              RF.ReinforceConfig(return_standardization=True, lr=1e-3))
     count = [0]
 
@@ -543,6 +549,9 @@ def run_reinforce(steps, warmup, with_cpu):
     flop = k * MB * mlp_flop([OBS, HID, HID, ACT], wgrad=True, dgrad_layers=2)
     cpu = None
     if with_cpu:
+        from oracle import oracle_ppo as OP
+        from oracle import oracle_reinforce as OR
+
         st = OP.PPOState(params={kk: p[kk].clone() for kk in OR.ACTOR_KEYS})
         gc = torch.Generator().manual_seed(0)
         o, a, r = torch.randn(4 * MB, OBS, generator=gc), torch.randn(4 * MB, ACT, generator=gc) * 0.6, torch.randn(4 * MB, generator=gc)
@@ -562,8 +571,6 @@ def run_reinforce(steps, warmup, with_cpu):
 def run_drqn(steps, warmup, with_cpu, slots=20000):
     """test/discrete/test_drqn.py's learner: Recurrent(2 LSTM layers of 128) on CartPole observations, stack_num 4, batch 128,
     n-step 3, double-Q with a lagged network, 20000-slot buffer of 16 envs without obs_next."""
-    from oracle import oracle_dqn as OD
-    from oracle import oracle_drqn as ORQ
     from tianshou_amd import dqn as D
     from tianshou_amd import drqn as R
 
@@ -571,11 +578,9 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     g = torch.Generator(device=dev).manual_seed(0)
     buf = _flat_buffer(slots, 16, dev, g, obs=torch.randn(slots, OBS, generator=g, device=dev),
                        act=torch.randint(0, A, (slots,), generator=g, device=dev))
-    gc = torch.Generator().manual_seed(0)
-    shapes = ORQ.param_shapes(OBS, H, L, A)
-    p = {k: (torch.rand(shapes[k], generator=gc) * 2 - 1) / np.sqrt(H if not k.startswith("fc1") else OBS) for k in ORQ.param_keys(L)}
+    p = BI.recurrent_net(OBS, H, L, A, 0)
     kw = dict(gamma=0.95, n_step=3, target_update_freq=320, is_double=True, lr=1e-3)
-    eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch([p[k] for k in ORQ.param_keys(L)], OBS, H, L, A), D.DQNConfig(**kw))
+    eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch(list(p.values()), OBS, H, L, A), D.DQNConfig(**kw))
 
     def update():
         idx = torch.randint(0, slots, (B,), generator=g, device=dev)
@@ -587,8 +592,12 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     flop = B * (2 * fwd + 3 * fwd)                                    # target: online + lagged forward; update: forward + backward
     cpu = None
     if with_cpu:
+        from oracle import oracle_dqn as OD
+        from oracle import oracle_drqn as ORQ
+
         ocfg = OD.DQNConfig(**kw)
         st = OD.DQNState.create(p, ocfg)
+        gc = torch.Generator().manual_seed(0)
         obs, obs_next = torch.randn(B, T, OBS, generator=gc), torch.randn(B, T, OBS, generator=gc)
         act, rew = torch.randint(0, A, (B,), generator=gc), torch.randn(B, generator=gc)
         th = _threads()

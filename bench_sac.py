@@ -52,7 +52,8 @@ def cpu_baseline(updates: int = 3):
 
 
 def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) -> dict:
-    from oracle import oracle_sac as OS            # parameter init only (torch nn.Linear default init)
+    import bench_init as BI
+
     from tianshou_amd import _lib
     from tianshou_amd import sac as S
     from tianshou_amd.buffer import DeviceReplayBuffer, gather_rows
@@ -71,12 +72,12 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
                              insertion=np.zeros(E, np.int64), rew=rew, terminated=term,
                              truncated=torch.zeros(slots, dtype=torch.bool, device=dev), obs=obs, act=act,
                              obs_next=obs_next)
-    actor, c1, c2 = OS.init_sac_params(OBS, ACT, 0)
+    actor, c1, c2 = BI.sac_nets(OBS, ACT, 0)
     cfg = S.SACConfig(gamma=0.99, tau=0.005, n_step=1, auto_alpha=True, target_entropy=-float(ACT), log_alpha0=0.0,
                       actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4)
-    eng = S.SACEngine(OBS, ACT, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], OBS, ACT),
-                      S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], OBS, ACT),
-                      S.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], OBS, ACT), cfg)
+    eng = S.SACEngine(OBS, ACT, S.actor_flat_from_torch(list(actor.values()), OBS, ACT),
+                      S.critic_flat_from_torch(list(c1.values()), OBS, ACT),
+                      S.critic_flat_from_torch(list(c2.values()), OBS, ACT), cfg)
 
     def update():
         idx = torch.randint(0, slots, (BATCH,), generator=g, device=dev)
