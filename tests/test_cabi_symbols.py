@@ -58,3 +58,16 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "ts_oracle" not in text, f
+
+
+def test_every_entry_point_is_documented_in_integration_md():
+    """INTEGRATION.md's table names every symbol include/tsengine.h declares (so the reference-side binding list is complete)."""
+    import os
+
+    from tianshou_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    expand = text.replace("`ts_profile_begin/end`", "`ts_profile_begin` `ts_profile_end`")
+    missing = [s for s in _lib.declared_symbols() if s not in expand]
+    assert not missing, missing
