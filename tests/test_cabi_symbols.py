@@ -71,3 +71,54 @@ def test_every_entry_point_is_documented_in_integration_md():
     expand = text.replace("`ts_profile_begin/end`", "`ts_profile_begin` `ts_profile_end`")
     missing = [s for s in _lib.declared_symbols() if s not in expand]
     assert not missing, missing
+
+
+def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
+    """ctypes calls without argtypes do not check arity: a wrapper that passes one argument too few marshals garbage into
+    the last parameter.  Static check: every `<lib>.ts_*(...)` call in tianshou_amd/ has exactly the number of positional
+    arguments of its prototype in include/tsengine.h (a `*self._dims()` argument counts as the length of the tuple that
+    method returns)."""
+    import ast
+    import os
+    import re
+
+    from tianshou_amd import _lib
+
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    protos = {}
+    for name, params in re.findall(r"\b(ts_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = params.strip()
+        protos[name] = 0 if params in ("", "void") else params.count(",") + 1
+    assert len(protos) >= 80 and protos["ts_version"] == 0 and protos["ts_polyak_update"] == 5
+
+    pkg = os.path.dirname(_lib.__file__)
+    checked = 0
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        dims_len = {}                                   # class name -> len of the tuple `_dims` returns
+        for cls in [n for n in ast.walk(tree) if isinstance(n, ast.ClassDef)]:
+            for m in cls.body:
+                if isinstance(m, ast.FunctionDef) and m.name == "_dims":
+                    ret = [r for r in ast.walk(m) if isinstance(r, ast.Return)][0].value
+                    assert isinstance(ret, ast.Tuple)
+                    dims_len[cls.name] = len(ret.elts)
+            for call in [n for n in ast.walk(cls) if isinstance(n, ast.Call)]:
+                call._cls = cls.name                    # noqa: SLF001 - remember the enclosing class for star-args
+        for call in [n for n in ast.walk(tree) if isinstance(n, ast.Call)]:
+            f = call.func
+            if not (isinstance(f, ast.Attribute) and f.attr in protos) or call.keywords:
+                continue
+            n = 0
+            for a in call.args:
+                if isinstance(a, ast.Starred):
+                    v = a.value
+                    ok = isinstance(v, ast.Call) and isinstance(v.func, ast.Attribute) and v.func.attr == "_dims"
+                    assert ok and getattr(call, "_cls", None) in dims_len, f"{fn}:{call.lineno}: unsupported star argument"
+                    n += dims_len[call._cls]
+                else:
+                    n += 1
+            assert n == protos[f.attr], f"{fn}:{call.lineno}: {f.attr} takes {protos[f.attr]} arguments, call passes {n}"
+            checked += 1
+    assert checked >= 60, checked
