@@ -170,6 +170,22 @@ class RecurrentDQNEngine:
 
         return compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step).returns.reshape(-1)
 
+    # -- the two halves of an update, for the data-parallel path (tianshou_amd.distributed.DataParallelDQN) --------------------
+    def gradient(self, obs, act, returns, weight, grad_out: torch.Tensor):
+        """Periodic target sync + forward + loss + backward through time; grad_out[:P] = d loss / d params (mean over THIS
+        batch), no optimizer step.  -> (loss, td_error)."""
+        return self.update_with_batch(obs, act, returns, weight, grad_out=grad_out, apply=False)
+
+    def apply_gradient(self, grad: torch.Tensor) -> None:
+        """clip_grad_norm_ + Adam on a flat gradient (algorithm_base.py:496-500)."""
+        cfg = self.cfg
+        self.adam_step += 1
+        _lib.check(_lib.load().ts_adam_step(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.ptr(grad),
+            _lib.i64(self.P), _lib.i64(self.adam_step), _lib.f64(cfg.lr), _lib.f64(cfg.betas[0]),
+            _lib.f64(cfg.betas[1]), _lib.f64(cfg.adam_eps), _lib.f64(cfg.max_grad_norm or 0.0),
+            _lib.current_stream(self.device)))
+
     # -- DQN._update_with_batch ----------------------------------------------------------------------------------------------
     def update_with_batch(self, obs, act, returns, weight=None, grad_out: torch.Tensor | None = None, apply: bool = True):
         """-> (loss float32[1] device tensor, td_error float32[B]); td_error is the new batch.weight."""
