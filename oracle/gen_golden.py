@@ -318,9 +318,13 @@ def _flat_adam(algorithm, actor, critic, key: str) -> np.ndarray:
 
 
 def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int,
-            seed: int, n_updates: int = 1, algo: str = "ppo", **ppo_kwargs) -> None:
+            seed: int, n_updates: int = 1, algo: str = "ppo", lr_decay: tuple[int, int, int] | None = None,
+            **ppo_kwargs) -> None:
     """Runs the reference PPO.update() on a synthetic VectorReplayBuffer and dumps every
-    intermediate the engine has to reproduce."""
+    intermediate the engine has to reproduce.  `lr_decay` = (max_epochs, epoch_num_steps,
+    collection_step_num_env_steps) attaches `LRSchedulerFactoryLinear` exactly like
+    examples/mujoco/mujoco_ppo.py:124-131 (stepped by Algorithm._update after every update(),
+    algorithm_base.py:628-629); the learning rate in force during update u is recorded as `u{u}_lr`."""
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
@@ -347,7 +351,14 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
                                       action_bound_method="clip", action_space=space)
     lr = ppo_kwargs.pop("lr", 3e-4)
     cls = PPO if algo == "ppo" else A2C
-    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+    optim_factory = AdamOptimizerFactory(lr=lr)
+    if lr_decay is not None:
+        from tianshou.algorithm.optim import LRSchedulerFactoryLinear
+
+        optim_factory.with_lr_scheduler_factory(LRSchedulerFactoryLinear(
+            max_epochs=lr_decay[0], epoch_num_steps=lr_decay[1], collection_step_num_env_steps=lr_decay[2]))
+    algorithm = cls(policy=policy, critic=critic, optim=optim_factory, **ppo_kwargs)
+    assert (len(algorithm.lr_schedulers) == 1) == (lr_decay is not None)
 
     out: dict[str, np.ndarray] = {}
     out["flat_params0"] = _flat_from_modules(actor, critic)
@@ -417,6 +428,7 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
                 out[f"u{u}_truncated"] = np.asarray(buf.truncated, bool)
             np.random.seed(seed + 100 + u)
             n_perm0, n_seq0 = len(perms), len(seqs)
+            out[f"u{u}_lr"] = np.array(algorithm.optim._optim.param_groups[0]["lr"], np.float64)
             with policy_within_training_step(algorithm.policy):
                 stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
             p = perms[n_perm0:]
@@ -453,6 +465,16 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
+
+
+def gen_ppo_sched() -> None:
+    """The mujoco_ppo.py configuration WITH its default linear learning-rate decay (lr_decay=True,
+    examples/mujoco/mujoco_ppo.py:48,124-131): 3 epochs x 2 collects -> max_update_num 6, so four updates run at
+    lr x (1, 5/6, 4/6, 3/6)."""
+    gen_ppo("sched", E=4, T=48, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=5, n_updates=4,
+            lr_decay=(3, 384, 192), gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.0,
+            return_scaling=True, eps_clip=0.2, value_clip=True, dual_clip=None, advantage_normalization=False,
+            recompute_advantage=False, max_batchsize=256)
 
 
 def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
@@ -876,6 +898,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_sched":
+        gen_ppo_sched()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "redq":
         gen_redq_all()
         return
@@ -903,6 +928,7 @@ def main() -> None:
     gen_ppo("a2c", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=2,
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
+    gen_ppo_sched()
     gen_buffer_add()
     gen_dqn_all()
     gen_sac_all()

@@ -1,0 +1,377 @@
+"""TEST INFRASTRUCTURE ONLY - minimal stand-ins for the reference classes the Hip* hook bodies touch.
+
+/root/reference does not exist on the GPU box, so the `-m gpu` tests cannot subclass the real `PPO` / `SAC`.
+These classes expose exactly the attribute surface `tianshou_amd/integration.py` reads or writes (names as in the
+reference, cited per class) and nothing else: no losses, no network forward passes, no sampling logic beyond what
+`Algorithm._update` / `VectorReplayBuffer` need to hand data to the hooks.  `tests/test_standin_surface.py` (CPU,
+only where the reference is mounted) checks every stand-in against the real class it replaces: same state_dict keys,
+same attribute names, same buffer bookkeeping after identical `add()` sequences.
+
+Injected through the `ref=` argument of `make_hip_ppo` / `make_hip_sac` (`integration._ref`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+
+# ------------------------------------------------------------------------------------------------ data / stats
+class Batch(SimpleNamespace):
+    """tianshou/data/batch.py:625 - only attribute assignment is used by the hooks."""
+
+    def pop(self, key, default=None):
+        return self.__dict__.pop(key, default)
+
+
+@dataclass
+class SequenceSummaryStats:
+    """tianshou/data/stats.py:17-43 (population std)."""
+    mean: float
+    std: float
+    max: float
+    min: float
+
+    @classmethod
+    def from_sequence(cls, sequence):
+        a = np.asarray(sequence, dtype=np.float64)
+        return cls(mean=float(a.mean()), std=float(a.std()), max=float(a.max()), min=float(a.min()))
+
+
+@dataclass
+class A2CTrainingStats:
+    """tianshou/algorithm/modelfree/a2c.py:23-30."""
+    loss: SequenceSummaryStats
+    actor_loss: SequenceSummaryStats
+    vf_loss: SequenceSummaryStats
+    ent_loss: SequenceSummaryStats
+    gradient_steps: int = 0
+    train_time: float = 0.0
+
+
+@dataclass
+class SACTrainingStats:
+    """tianshou/algorithm/modelfree/sac.py:42-48."""
+    actor_loss: float
+    critic1_loss: float
+    critic2_loss: float
+    alpha: float | None = None
+    alpha_loss: float | None = None
+    train_time: float = 0.0
+
+
+class RunningMeanStd:
+    """tianshou/utils/statistics.py:81-91: the three scalars the wrappers mirror."""
+
+    def __init__(self):
+        self.mean, self.var, self.count = 0.0, 1.0, 0
+
+
+# ------------------------------------------------------------------------------------------------ networks
+class _MLP(nn.Module):
+    """utils/net/common.py MLP: `.model` is the nn.Sequential."""
+
+    def __init__(self, sizes, activation):
+        super().__init__()
+        layers = []
+        for i in range(len(sizes) - 1):
+            layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+            if activation is not None:
+                layers.append(activation())
+        self.model = nn.Sequential(*layers)
+
+
+class Net(nn.Module):
+    """utils/net/common.py:246-369: `.model` is an MLP -> state_dict keys `model.model.{0,2}.{weight,bias}`."""
+
+    def __init__(self, in_dim, hidden_sizes, activation=nn.ReLU):
+        super().__init__()
+        self.model = _MLP([in_dim, *hidden_sizes], activation)
+        self.output_dim = hidden_sizes[-1]
+
+
+class ContinuousActorProbabilistic(nn.Module):
+    """utils/net/continuous.py:172-238: preprocess + mu head (+ sigma head or sigma_param)."""
+
+    def __init__(self, preprocess_net, action_dim, unbounded=True, conditioned_sigma=False):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.mu = _MLP([preprocess_net.output_dim, action_dim], None)
+        self._c_sigma = conditioned_sigma
+        if conditioned_sigma:
+            self.sigma = _MLP([preprocess_net.output_dim, action_dim], None)
+        else:
+            self.sigma_param = nn.Parameter(torch.zeros(action_dim, 1))
+        self._unbounded = unbounded
+        self.max_action = 1.0
+
+
+class ContinuousCritic(nn.Module):
+    """utils/net/continuous.py:88-169: preprocess + `last` head."""
+
+    def __init__(self, preprocess_net):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.last = _MLP([preprocess_net.output_dim, 1], None)
+
+
+class Policy(nn.Module):
+    """algorithm_base.py Policy: `actor`, `is_within_training_step`."""
+
+    def __init__(self, actor):
+        super().__init__()
+        self.actor = actor
+        self.is_within_training_step = False
+
+
+class EvalModeModuleWrapper(nn.Module):
+    """utils/lagged_network.py:21-50: `.module` holds the lagged copy."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+
+# ------------------------------------------------------------------------------------------------ algorithm
+class _Optimizer:
+    """Algorithm.Optimizer (algorithm_base.py:463-507): `_optim`, `_max_grad_norm`, (load_)state_dict."""
+
+    def __init__(self, optim, module, max_grad_norm=None):
+        self._optim, self._module, self._max_grad_norm = optim, module, max_grad_norm
+
+    def state_dict(self):
+        return self._optim.state_dict()
+
+    def load_state_dict(self, sd):
+        self._optim.load_state_dict(sd)
+
+
+class Algorithm(nn.Module):
+    """algorithm_base.py:434-631: optimizer / scheduler bookkeeping, state_dict with the optimizers, `_update`."""
+    _STATE_DICT_KEY_OPTIMIZERS = "_optimizers"
+
+    def __init__(self, policy):
+        super().__init__()
+        self.policy = policy
+        self.lr_schedulers = []
+        self._optimizers = []
+
+    def _create_optimizer(self, module, lr, max_grad_norm=None, lr_lambda=None, eps=1e-8):
+        opt = torch.optim.Adam(module.parameters(), lr=lr, eps=eps)
+        if lr_lambda is not None:                         # optim.py:22-53 (LambdaLR)
+            self.lr_schedulers.append(torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lr_lambda))
+        o = _Optimizer(opt, module, max_grad_norm)
+        self._optimizers.append(o)
+        return o
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        d = super().state_dict(*args, destination=destination, prefix=prefix, keep_vars=keep_vars)
+        d[prefix + self._STATE_DICT_KEY_OPTIMIZERS] = [o.state_dict() for o in self._optimizers]
+        return d
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        state_dict = dict(state_dict)
+        for o, sd in zip(self._optimizers, state_dict.pop(self._STATE_DICT_KEY_OPTIMIZERS)):
+            o.load_state_dict(sd)
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _postprocess_batch(self, batch, buffer, indices):
+        if hasattr(buffer, "update_weight") and hasattr(batch, "weight"):
+            buffer.update_weight(indices, batch.weight)
+
+    def _update(self, sample_size, buffer, update_with_batch_fn):
+        if not self.policy.is_within_training_step:
+            raise RuntimeError("update() was called outside of a training step")
+        batch, indices = buffer.sample(sample_size)
+        batch = self._preprocess_batch(batch, buffer, indices)
+        was = self.training
+        try:
+            self.train(True)
+            stat = update_with_batch_fn(batch)
+        finally:
+            self.train(was)
+        self._postprocess_batch(batch, buffer, indices)
+        for s in self.lr_schedulers:
+            s.step()
+        return stat
+
+
+class _ActorCritic(nn.Module):
+    """utils/net/common.py:457: what `max_grad_norm` clips jointly."""
+
+    def __init__(self, actor, critic):
+        super().__init__()
+        self.actor, self.critic = actor, critic
+
+
+class PPO(Algorithm):
+    """modelfree/ppo.py:24-144 over a2c.py:79-113: hyper-parameter attribute names as the reference stores them."""
+
+    def __init__(self, *, policy, critic, lr=3e-4, lr_lambda=None, eps_clip=0.2, dual_clip=None, value_clip=False,
+                 advantage_normalization=True, recompute_advantage=False, vf_coef=0.5, ent_coef=0.01,
+                 max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, gamma=0.99, return_scaling=False):
+        super().__init__(policy)
+        self.critic = critic
+        self.optim = self._create_optimizer(_ActorCritic(policy.actor, critic), lr, max_grad_norm, lr_lambda)
+        self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
+        self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage
+        self.vf_coef, self.ent_coef, self.gae_lambda, self.gamma = vf_coef, ent_coef, gae_lambda, gamma
+        self.max_batchsize, self.return_scaling = max_batchsize, return_scaling
+        self.ret_rms = RunningMeanStd()
+        self._eps = 1e-8
+
+    def update(self, buffer, batch_size, repeat):
+        return self._update(0, buffer, lambda batch: self._update_with_batch(batch, batch_size, repeat))
+
+
+class A2C(PPO):
+    """modelfree/a2c.py:163-247: no clipping attributes."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        for name in ("eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_adv"):
+            delattr(self, name)
+
+
+class FixedAlpha:
+    """sac.py:161-172."""
+
+    def __init__(self, alpha):
+        self._value = alpha
+
+    @property
+    def value(self):
+        return self._value
+
+
+class AutoAlpha(nn.Module):
+    """sac.py:175-210: `_target_entropy`, `_log_alpha`, `_optim` (a plain torch optimizer)."""
+
+    def __init__(self, target_entropy, log_alpha, lr):
+        super().__init__()
+        self._target_entropy = target_entropy
+        self._log_alpha = nn.Parameter(torch.tensor(float(log_alpha)))
+        self._optim = torch.optim.Adam([self._log_alpha], lr=lr)
+
+    @property
+    def value(self):
+        return self._log_alpha.detach().exp().item()
+
+
+class SAC(Algorithm):
+    """modelfree/sac.py:213-296 over ddpg.py ActorDualCriticsOffPolicyAlgorithm: attribute names as stored."""
+
+    def __init__(self, *, policy, critic, critic2, lr=1e-3, critic_lr=None, lr_lambda=None, tau=0.005, gamma=0.99,
+                 alpha=0.2, n_step_return_horizon=1):
+        import copy
+
+        super().__init__(policy)
+        self.policy_optim = self._create_optimizer(policy, lr, None, lr_lambda)
+        self.critic, self.critic2 = critic, critic2
+        self.critic_old = EvalModeModuleWrapper(copy.deepcopy(critic))
+        self.critic2_old = EvalModeModuleWrapper(copy.deepcopy(critic2))
+        self.critic_optim = self._create_optimizer(critic, critic_lr or lr, None, lr_lambda)
+        self.critic2_optim = self._create_optimizer(critic2, critic_lr or lr, None, lr_lambda)
+        self.tau, self.gamma, self.n_step_return_horizon = tau, gamma, n_step_return_horizon
+        self.alpha = FixedAlpha(alpha) if isinstance(alpha, float) else alpha
+
+    def update(self, buffer, sample_size):
+        return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
+# ------------------------------------------------------------------------------------------------ replay buffer
+class _SubBuffer:
+    """The per-environment ReplayBuffer inside a manager: `_insertion_idx`, `__len__`, `maxsize`."""
+
+    def __init__(self, size):
+        self.maxsize, self._insertion_idx, self._size = size, 0, 0
+
+    def __len__(self):
+        return self._size
+
+
+class _Meta:
+    def __init__(self, keys):
+        self._keys = tuple(keys)
+
+    def get_keys(self):
+        return self._keys
+
+
+class VectorReplayBuffer:
+    """data/buffer/vecbuf.py + manager.py:23-234: `buffer_num` equal sub-buffers of ceil(total / n) slots; the
+    bookkeeping (`_extend_offset`, `_lengths`, `last_index`, sub-buffer `_insertion_idx`), `add`, `reset`,
+    `unfinished_index`, `sample_indices` and `sample` the wrappers rely on."""
+
+    def __init__(self, total_size, buffer_num, *, obs_shape, act_shape, obs_dtype=np.float32, act_dtype=np.float32,
+                 seed=0):
+        size = int(np.ceil(total_size / buffer_num))
+        self.buffer_num, self.maxsize = buffer_num, size * buffer_num
+        self.buffers = [_SubBuffer(size) for _ in range(buffer_num)]
+        self._offset = np.arange(buffer_num, dtype=np.int64) * size
+        self._extend_offset = np.arange(buffer_num + 1, dtype=np.int64) * size
+        self._lengths = np.zeros(buffer_num, dtype=np.int64)
+        self.last_index = self._offset.copy()
+        B = self.maxsize
+        self.obs = np.zeros((B, *obs_shape), obs_dtype)
+        self.obs_next = np.zeros((B, *obs_shape), obs_dtype)
+        self.act = np.zeros((B, *act_shape), act_dtype)
+        self.rew = np.zeros(B, np.float64)                                  # buffer_base.py:492
+        self.terminated = np.zeros(B, bool)
+        self.truncated = np.zeros(B, bool)
+        self.done = np.zeros(B, bool)
+        self._meta = _Meta(("obs", "act", "rew", "terminated", "truncated", "done", "obs_next"))
+        self._rng = np.random.RandomState(seed)
+
+    def __len__(self):
+        return int(self._lengths.sum())
+
+    def reset(self, keep_statistics=False):
+        for b in self.buffers:
+            b._insertion_idx = b._size = 0
+        self._lengths[:] = 0
+        self.last_index = self._offset.copy()
+
+    def add(self, batch, buffer_ids=None):
+        ids = np.arange(self.buffer_num) if buffer_ids is None else np.asarray(buffer_ids)
+        ptrs = []
+        for row, e in enumerate(ids):
+            sb = self.buffers[e]
+            ptr = int(self._offset[e]) + sb._insertion_idx
+            sb._insertion_idx = (sb._insertion_idx + 1) % sb.maxsize
+            sb._size = min(sb._size + 1, sb.maxsize)
+            self._lengths[e] = sb._size
+            self.last_index[e] = ptr
+            for key in ("obs", "act", "rew", "terminated", "truncated", "obs_next"):
+                getattr(self, key)[ptr] = getattr(batch, key)[row]
+            self.done[ptr] = bool(batch.terminated[row]) or bool(batch.truncated[row])
+            ptrs.append(ptr)
+        return np.asarray(ptrs)
+
+    def unfinished_index(self):
+        return np.asarray([int(self.last_index[e]) for e in range(self.buffer_num)
+                           if self._lengths[e] > 0 and not self.done[self.last_index[e]]], dtype=np.int64)
+
+    def sample_indices(self, batch_size):
+        if batch_size == 0:
+            out = []
+            for e, sb in enumerate(self.buffers):
+                n, off = len(sb), int(self._offset[e])
+                if n < sb.maxsize:
+                    out.append(off + np.arange(n))
+                else:
+                    out.append(off + (sb._insertion_idx + np.arange(n)) % sb.maxsize)
+            return np.concatenate(out).astype(np.int64)
+        lens = self._lengths.astype(np.float64)
+        sub = self._rng.choice(self.buffer_num, batch_size, p=lens / lens.sum())
+        cnt = np.bincount(sub, minlength=self.buffer_num)
+        return np.concatenate([int(self._offset[e]) + self._rng.choice(int(self._lengths[e]), c)
+                               for e, c in enumerate(cnt) if c]).astype(np.int64)
+
+    def sample(self, batch_size):
+        idx = self.sample_indices(batch_size)
+        return Batch(obs=self.obs[idx], act=self.act[idx], rew=self.rew[idx], terminated=self.terminated[idx],
+                     truncated=self.truncated[idx], done=self.done[idx], obs_next=self.obs_next[idx]), idx

@@ -1,0 +1,194 @@
+"""GPU: the Hip* hook bodies of tianshou_amd/integration.py driving the REAL engine on an MI355X.
+
+The reference package is absent on the GPU box, so the subclasses are built over the stand-ins of tests/standin.py
+(same attribute surface as the reference classes, verified against them in tests/test_standin_surface.py where the
+reference is mounted).  What runs here is the production glue: device mirror of a host-filled buffer, incremental
+sync, `sample_indices(0)` / gathers / cut positions as kernels, engine creation from torch modules + optimizer,
+the per-update learning-rate refresh (schedulers), parameter write-back, lazy Adam-state flush into
+`state_dict()`, `load_state_dict` invalidation.  Checked against the CPU oracle (oracle/oracle_ppo.py) fed with the
+same host data, permutations and learning rates."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import oracle as O
+from oracle import oracle_ppo as OP
+from tests import standin as SI
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_ppo(obs_dim, act_dim, seed, device, **kw):
+    from tianshou_amd.integration import make_hip_ppo
+
+    HipPPO = make_hip_ppo("ppo", ref=SI)
+    torch.manual_seed(seed)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [64, 64], nn.Tanh), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, [64, 64], nn.Tanh))
+    with torch.no_grad():
+        actor.sigma_param.fill_(-0.5)
+        for p in actor.mu.parameters():
+            p.mul_(0.1)
+    policy = SI.Policy(actor)
+    algo = HipPPO(policy=policy, critic=critic, device=device, **kw)
+    return algo.to(device) if device != "cpu" else algo
+
+
+def _oracle_params(algo):
+    from tianshou_amd.ppo import flat_from_modules
+
+    flat = flat_from_modules(algo.policy.actor, algo.critic, device="cpu")
+    return OP.unflatten_params(flat.clone(), *algo._hip_dims)
+
+
+def _fill(buf, T, obs_dim, act_dim, rng):
+    E = buf.buffer_num
+    obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+    for t in range(T):
+        term = rng.random(E) < 0.03
+        buf.add(SI.Batch(obs=obs[t], act=rng.normal(size=(E, act_dim)).astype(np.float32),
+                         rew=rng.normal(size=E).astype(np.float32), terminated=term,
+                         truncated=(rng.random(E) < 0.02) & ~term, obs_next=obs[t + 1]))
+
+
+def _oracle_update(st, ocfg, buf, batch_size, repeat, perms):
+    idx = buf.sample_indices(0)
+    bs = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths,
+                       np.asarray([b._insertion_idx for b in buf.buffers]), buf.rew, buf.terminated, buf.truncated)
+    assert np.array_equal(bs.sample_indices_all(), idx)
+    unf = bs.unfinished_index()
+    assert np.array_equal(unf, buf.unfinished_index())
+    args = (torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.obs_next[idx]), torch.from_numpy(buf.act[idx]),
+            buf.rew[idx], buf.terminated[idx], buf.truncated[idx], idx, unf)
+    pre = OP.preprocess(st, ocfg, *args)
+    return OP.update(st, ocfg, {"obs": args[0], "act": args[2]}, pre, batch_size, repeat, perms)
+
+
+@pytest.mark.parametrize("module_device", ["cuda", "cpu"])
+def test_hip_ppo_hooks_with_scheduler_against_oracle(module_device):
+    """Four update() calls with a linearly decaying learning rate (mujoco_ppo.py's default), a buffer that is reset
+    and refilled between updates (on-policy pattern) and, once, only partly refilled; torch modules living on the
+    GPU or on the host."""
+    obs_dim, act_dim, E, T, batch_size, repeat = 17, 6, 6, 40, 64, 2
+    kw = dict(eps_clip=0.2, value_clip=True, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, return_scaling=True,
+              advantage_normalization=False, lr=3e-4)
+    algo = _make_ppo(obs_dim, act_dim, 3, "cuda", lr_lambda=lambda k: 1.0 - k / 6.0, **kw)
+    if module_device == "cpu":
+        algo.to("cpu")                       # parameters on the host, engine on the GPU: write-back crosses PCIe
+    st = OP.PPOState(params=_oracle_params(algo))
+    ocfg = OP.PPOConfig(max_batchsize=4096, **kw)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    rng = np.random.default_rng(0)
+    algo.policy.is_within_training_step = True
+    for u in range(4):
+        if u != 2:
+            buf.reset()
+            _fill(buf, T, obs_dim, act_dim, rng)
+        else:
+            _fill(buf, 7, obs_dim, act_dim, rng)          # ring wrap: sample_indices(0) is no longer arange
+        n = len(buf)
+        np.random.seed(100 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        ocfg.lr = 3e-4 * (1.0 - u / 6.0)
+        assert algo.optim._optim.param_groups[0]["lr"] == pytest.approx(ocfg.lr, rel=1e-12)
+        losses_o = _oracle_update(st, ocfg, buf, batch_size, repeat, perms)
+        np.random.seed(100 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert stats.gradient_steps == losses_o.shape[0] and stats.train_time > 0
+        for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(losses_o[:, col])
+            np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=1e-5, atol=2e-6)
+        from tianshou_amd.ppo import flat_from_modules
+
+        flat = flat_from_modules(algo.policy.actor, algo.critic, device="cpu").numpy()
+        np.testing.assert_allclose(flat, OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=3e-6)
+        np.testing.assert_allclose([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count],
+                                   [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+        assert next(algo.policy.actor.parameters()).device.type == module_device
+    # Algorithm.state_dict(): Adam moments arrive lazily, in the reference's per-parameter layout
+    sd = algo.state_dict()
+    opt_state = sd["_optimizers"][0]["state"]
+    params = algo._hip_params()
+    assert len(opt_state) == len(params)
+    m_flat = torch.cat([opt_state[i]["exp_avg"].reshape(-1).cpu() for i in range(len(params))]).numpy()
+    m_ref = torch.cat([st.adam_m[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+    np.testing.assert_allclose(m_flat, m_ref, rtol=1e-3, atol=1e-7)
+    assert float(opt_state[0]["step"]) == st.adam_step
+
+
+def test_hip_ppo_load_state_dict_rebuilds_the_engine():
+    """restoring a checkpoint must not be overwritten by stale engine state at the next write-back."""
+    obs_dim, act_dim, E, T = 11, 3, 4, 32
+    kw = dict(eps_clip=0.2, value_clip=False, vf_coef=0.5, ent_coef=0.01, max_grad_norm=None, return_scaling=False,
+              advantage_normalization=True, lr=1e-3)
+    algo = _make_ppo(obs_dim, act_dim, 9, "cuda", **kw)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    _fill(buf, T, obs_dim, act_dim, np.random.default_rng(1))
+    algo.policy.is_within_training_step = True
+    np.random.seed(0)
+    algo.update(buf, 32, 1)
+    ckpt = copy.deepcopy(algo.state_dict())
+    np.random.seed(1)
+    s1 = algo.update(buf, 32, 2)
+    assert algo._hip_engine is not None
+    algo.load_state_dict(copy.deepcopy(ckpt))
+    assert algo._hip_engine is None                       # dropped; rebuilt from the loaded modules + optimizer
+    np.random.seed(1)
+    s2 = algo.update(buf, 32, 2)                          # same data, same permutations, same restored state
+    assert s1.loss.mean == s2.loss.mean and s1.vf_loss.max == s2.vf_loss.max
+    # loading into a sub-module only (algorithm.policy.load_state_dict) is caught as well
+    algo.policy.load_state_dict(copy.deepcopy(algo.policy.state_dict()))
+    assert algo._hip_engine is None
+
+
+def test_full_c2_configuration_against_oracle():
+    """The exact BASELINE.json configs[1] shape end to end: 512 envs x 2048 steps = 2^20 transitions, obs 17, act 6,
+    one repeat of 16 minibatches of 65,536 with a host permutation, preprocessing included; per-step losses vs the
+    CPU oracle at rtol 1e-5 (north_star), final parameters on the scale of the Adam steps taken."""
+    from tianshou_amd import ppo as P
+
+    E, T, obs_dim, act_dim, batch = 512, 2048, 17, 6, 65536
+    n = E * T
+    rng = np.random.default_rng(2024)
+    params = OP.init_params(obs_dim, act_dim, seed=0)
+    g = torch.Generator().manual_seed(1)
+    for k in params:
+        params[k] = params[k] + 0.02 * torch.randn(params[k].shape, generator=g)
+    data = dict(obs=rng.normal(size=(n, obs_dim)).astype(np.float32),
+                obs_next=rng.normal(size=(n, obs_dim)).astype(np.float32),
+                act=rng.normal(size=(n, act_dim)).astype(np.float32),
+                rew=rng.normal(size=n).astype(np.float32).astype(np.float64),
+                terminated=rng.random(n) < 0.005, truncated=np.zeros(n, bool))
+    data["truncated"].reshape(E, T)[:, 999::1000] = True
+    data["truncated"] &= ~data["terminated"]
+    kw = dict(eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, value_clip=True,
+              advantage_normalization=False, return_scaling=True, lr=3e-4)
+    ocfg, cfg = OP.PPOConfig(max_batchsize=65536, **kw), P.PPOConfig(**kw)
+    perms = [rng.permutation(n)]
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    st = OP.PPOState(params={k: v.clone() for k, v in params.items()})
+    bs = O.BufferState.from_vector_fill(data["rew"], data["terminated"], data["truncated"], E)
+    idx, unf = bs.sample_indices_all(), bs.unfinished_index()
+    args = (torch.from_numpy(data["obs"]), torch.from_numpy(data["obs_next"]), torch.from_numpy(data["act"]),
+            data["rew"], data["terminated"], data["truncated"], idx, unf)
+    pre_o = OP.preprocess(st, ocfg, *args)
+    losses_o = OP.update(st, ocfg, {"obs": args[0], "act": args[2]}, pre_o, batch, 1, perms)
+    assert losses_o.shape == (16, 4)
+
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")   # noqa: E731
+    eng = P.PPOEngine(obs_dim, act_dim, OP.flatten_params(params).cuda(), cfg)
+    b = eng.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                       dev(data["terminated"]), dev(data["truncated"]), dev(unf))
+    np.testing.assert_allclose(b["v_s"].cpu().numpy(), pre_o["v_s"].numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(b["adv"].cpu().numpy(), pre_o["adv"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b["returns"].cpu().numpy(), pre_o["returns"].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b["logp_old"].cpu().numpy(), pre_o["logp_old"].numpy(), rtol=1e-5, atol=1e-5)
+    losses, steps = eng.update(b, batch, 1, perms)
+    eng.check()
+    assert steps == 16
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)

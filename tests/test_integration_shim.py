@@ -95,6 +95,128 @@ def test_unsupported_nets_are_rejected():
         _check_supported(actor, critic)
 
 
+def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):
+    """HipPPO.update over the REAL reference PPO (CPU engine double): same steps as Algorithm._update
+    (algorithm_base.py:586-631) minus the host `buffer.sample(0)`; the scheduler's learning rate reaches the engine on
+    every update (mujoco_ppo.py's default linear decay), Adam moments reach torch.optim lazily through state_dict(),
+    and load_state_dict drops the engine."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch import nn
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory, LRSchedulerFactoryLinear
+    from tianshou.data import Batch, VectorReplayBuffer
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.buffer as B
+    import tianshou_amd.integration as I
+    import tianshou_amd.returns as R
+
+    seen = {"lr": [], "cut": [], "n": []}
+
+    class FakePPO:
+        def __init__(self, obs_dim, act_dim, flat, cfg):
+            assert (obs_dim, act_dim, flat.numel()) == (17, 6, 11085)
+            self.cfg = cfg
+            self.params, self.adam_m, self.adam_v, self.adam_step = flat.clone(), torch.zeros_like(flat), torch.zeros_like(flat), 0
+            self.ret_rms = [0.0, 1.0, 0.0]
+
+        def preprocess(self, obs, obs_next, act, rew, term, trunc, cut, d_n):
+            n = obs.shape[0]
+            assert obs.shape == obs_next.shape == (n, 17) and act.shape == (n, 6) and rew.dtype == torch.float64
+            seen["cut"].append(sorted(int(c) for c in cut[: int(d_n)]))
+            seen["n"].append(n)
+            z = torch.zeros(n)
+            self.ret_rms = [0.5, 2.0, float(n)]
+            return {"obs": obs, "act": act, "v_s": z, "returns": z, "adv": z, "logp_old": z}
+
+        def update(self, b, batch_size, repeat, perms):
+            assert batch_size == 8 and len(perms) == repeat == 2 and all(len(p) == b["obs"].shape[0] for p in perms)
+            seen["lr"].append(self.cfg.lr)
+            self.adam_step += 6
+            self.params = self.params + 1.0
+            self.adam_m = self.adam_m + 0.25
+            return torch.tensor([[4.0, 3.0, 2.0, 1.0]] * 6), 6
+
+        def check(self):
+            pass
+
+    def cpu_sample_all(self, batch_size):
+        assert batch_size == 0
+        return torch.as_tensor(np.concatenate([
+            self.h_offset[e] + (np.arange(self.h_lengths[e]) if self.h_lengths[e] < (self.h_offset[e + 1] - self.h_offset[e])
+                                else (self.h_insertion[e] + np.arange(self.h_lengths[e])) % self.h_lengths[e])
+            for e in range(self.buffer_num)]).astype(np.int64))
+
+    def cpu_cuts(m, idx):
+        unf = [int(m.h_last_index[e]) for e in range(m.buffer_num) if m.h_lengths[e] > 0 and not bool(m.done[m.h_last_index[e]])]
+        pos = np.nonzero(np.isin(idx.numpy(), unf))[0]
+        return torch.as_tensor(pos), torch.tensor([len(pos)])
+
+    monkeypatch.setattr(I, "_require_gpu", lambda device, who: None)
+    monkeypatch.setattr(I, "PPOEngine", FakePPO)
+    monkeypatch.setattr(B, "gather_rows", lambda src, idx: src[idx])
+    monkeypatch.setattr(B.DeviceReplayBuffer, "sample_indices", cpu_sample_all)
+    monkeypatch.setattr(R, "cut_positions", cpu_cuts)
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                         action_shape=(6,), unbounded=True)
+    critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=lambda ls: Independent(Normal(*ls), 1), action_scaling=True,
+                                      action_bound_method="clip", action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    optim = AdamOptimizerFactory(lr=3e-4).with_lr_scheduler_factory(
+        LRSchedulerFactoryLinear(max_epochs=2, epoch_num_steps=40, collection_step_num_env_steps=20))
+    algo = I.make_hip_ppo()(policy=policy, critic=critic, optim=optim, eps_clip=0.2, value_clip=True, vf_coef=0.25,
+                             ent_coef=0.0, max_grad_norm=0.5, return_scaling=True, advantage_normalization=False,
+                             dual_clip=None, device="cpu")
+    buf = VectorReplayBuffer(20, 2)
+    rng = np.random.default_rng(0)
+
+    def fill(n, done_last=False):
+        for i in range(n):
+            term = np.array([done_last and i == n - 1, False])
+            buf.add(Batch(obs=rng.normal(size=(2, 17)).astype(np.float32), act=rng.normal(size=(2, 6)).astype(np.float32),
+                          rew=rng.normal(size=2), terminated=term, truncated=np.zeros(2, bool),
+                          obs_next=rng.normal(size=(2, 17)).astype(np.float32)))
+
+    w1 = actor.preprocess.model.model[0].weight
+    w0 = w1.detach().clone()
+    fill(10, done_last=True)
+    with policy_within_training_step(algo.policy):
+        with pytest.raises(RuntimeError, match="training step"):
+            algo.policy.is_within_training_step = False
+            algo.update(buffer=buf, batch_size=8, repeat=2)
+        algo.policy.is_within_training_step = True
+        s0 = algo.update(buffer=buf, batch_size=8, repeat=2)
+        buf.reset()                          # on-policy pattern: same length, same insertion index afterwards
+        fill(10)
+        s1 = algo.update(buffer=buf, batch_size=8, repeat=2)
+    assert isinstance(s0, A2CTrainingStats) and s0.gradient_steps == 6 and s0.loss.mean == 4.0 and s1.train_time > 0
+    assert seen["lr"] == [3e-4, pytest.approx(3e-4 * 0.75)]                 # max_update_num = ceil(40 / 20) * 2 = 4
+    assert seen["n"] == [20, 20]
+    assert seen["cut"] == [[19], [9, 19]]        # env 0 ended on a termination in the first rollout only
+    m = algo._hip_mirror
+    assert np.array_equal(m.obs.numpy(), np.asarray(buf.obs)) and np.array_equal(m.rew.numpy(), np.asarray(buf.rew))
+    assert torch.allclose(w1.detach(), w0 + 2.0)                             # written back after every update
+    assert (algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count) == (0.5, 2.0, 20.0)
+    assert w1 not in algo.optim._optim.state                                 # Adam moments move lazily ...
+    sd = algo.state_dict()                                                   # ... here
+    st = algo.optim._optim.state[w1]
+    assert float(st["step"]) == 12.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))
+    assert len(sd["_optimizers"][0]["state"]) == 13
+    eng = algo._hip_engine
+    algo.load_state_dict(sd)
+    assert algo._hip_engine is None and eng is not None
+    with policy_within_training_step(algo.policy):
+        algo.update(buffer=buf, batch_size=8, repeat=2)
+    assert algo._hip_engine is not eng and algo._hip_engine.adam_step == 18  # rebuilt from the loaded optimizer state
+    assert torch.allclose(algo._hip_engine.adam_m, torch.full_like(algo._hip_engine.adam_m, 0.75))
+
+
 # ------------------------------------------------------------------------------------ DQN / SAC subclasses
 @pytest.fixture(scope="module")
 def dqn_algo():
@@ -137,7 +259,7 @@ def sac_algo():
 @pytest.mark.parametrize("which", ["dqn", "sac"])
 def test_offpolicy_hooks_keep_reference_signatures(which, dqn_algo, sac_algo):
     algo = dqn_algo if which == "dqn" else sac_algo
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
         assert list(mine.parameters) == list(ref.parameters), name
@@ -207,6 +329,34 @@ def test_mirror_incremental_sync_tracks_the_reference_buffer():
         assert np.array_equal(m.lengths.numpy(), np.asarray(buf._lengths))
     assert 0 < total < 4 * 30            # incremental, not whole-buffer copies
 
+    def same():
+        for key in ("obs", "act", "obs_next"):
+            assert np.array_equal(getattr(m, key).numpy(), np.asarray(getattr(buf, key))), key
+        assert np.array_equal(m.rew.numpy(), np.asarray(buf.rew))
+        assert np.array_equal(m.done.numpy().astype(bool), np.asarray(buf.done))
+
+    # the cases `_insertion_idx` / len() cannot tell apart from "nothing happened" (ADVICE r1):
+    add(10)                              # exactly `size` adds to every (already full) sub-buffer
+    assert m.sync_from_tianshou(buf) == 30
+    same()
+    add(23, [1])                         # more than `size` adds to one sub-buffer
+    assert m.sync_from_tianshou(buf) == 10
+    same()
+    buf.reset()                          # on-policy pattern: reset, then refill to the same length
+    add(10)
+    assert m.sync_from_tianshou(buf) == 30
+    same()
+    assert m.sync_from_tianshou(buf) == 0
+    # the write log is plain data: the buffer still pickles / deep-copies, and a copy keeps counting
+    import copy
+    import pickle
+    buf2 = pickle.loads(pickle.dumps(buf))
+    buf3 = copy.deepcopy(buf)
+    assert np.array_equal(np.asarray(buf2.rew), np.asarray(buf.rew)) and len(buf3) == len(buf)
+    add(2)
+    assert m.sync_from_tianshou(buf) == 6
+    same()
+
 
 # ------------------------------------------------------------------------------------ Atari PPO, TD3, DDPG subclasses
 def _det_algo(twin):
@@ -257,7 +407,7 @@ def test_more_subclasses_keep_signatures_and_fail_loudly(which):
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _ppo_cnn_algo() if which == "ppo_cnn" else _det_algo(which == "td3")
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
         assert list(mine.parameters) == list(ref.parameters), name
@@ -499,7 +649,7 @@ def test_distq_subclasses_keep_signatures_and_fail_loudly(kind):
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _distq_algo(kind)
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     assert type(algo).__name__ == ("HipQRDQN" if kind == "qr" else "HipC51")
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
@@ -594,7 +744,7 @@ def test_discrete_sac_subclass_keeps_signatures_and_fails_loudly():
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _dsac_algo()
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
         assert list(mine.parameters) == list(ref.parameters), name
@@ -698,7 +848,7 @@ def test_ppo_discrete_subclass_keeps_signatures_and_fails_loudly():
 
     for softmax in (True, False):
         algo = _ppo_discrete_algo(softmax=softmax)
-        base = type(algo).__mro__[1]
+        base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
         for name in ("_preprocess_batch", "_update_with_batch"):
             mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
             assert list(mine.parameters) == list(ref.parameters), name
@@ -834,7 +984,7 @@ def test_redq_subclass_keeps_signatures_and_fails_loudly():
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _redq_algo()
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
         assert list(mine.parameters) == list(ref.parameters), name
@@ -934,7 +1084,7 @@ def test_rainbow_subclass_keeps_signatures_and_fails_loudly():
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _rainbow_algo()
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
         assert list(mine.parameters) == list(ref.parameters), name
@@ -1049,7 +1199,7 @@ def test_natural_gradient_subclasses_keep_signatures_and_fail_loudly(which):
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _natural_algo(which)
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     assert type(algo).__name__ == ("HipNPG" if which == "npg" else "HipTRPO")
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
@@ -1144,7 +1294,7 @@ def test_reinforce_subclass_keeps_signatures_and_fails_loudly():
     from tianshou.utils.torch_utils import policy_within_training_step
 
     algo = _reinforce_algo()
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     assert type(algo).__name__ == "HipReinforce" and base.__name__ == "Reinforce"
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
@@ -1169,7 +1319,7 @@ def test_hip_reinforce_wrapper_runs_with_engine_double(monkeypatch):
         def __init__(self, obs_dim, act_dim, hidden, actor, cfg):
             assert (obs_dim, act_dim, hidden) == (17, 6, 64)
             assert (cfg.gamma, cfg.return_standardization, cfg.lr) == (0.97, True, 2e-3)
-            self.actor = actor.clone()
+            self.actor, self.cfg = actor.clone(), cfg
             self.adam_m, self.adam_v, self.adam_step = torch.zeros_like(actor), torch.zeros_like(actor), 0
             self.ret_rms = [0.0, 1.0, 0.0]
 
@@ -1228,7 +1378,7 @@ def test_drqn_subclass_keeps_signatures_and_fails_loudly(dqn_algo):
     from tianshou_amd import integration as I
 
     algo = _drqn_algo()
-    base = type(algo).__mro__[1]
+    base = type(algo).__mro__[2]            # [1] is the _HipGlue mixin
     assert type(algo).__name__ == "HipDRQN" and base.__name__ == "DQN" and algo._hip_dims == (4, 64, 2, 2)
     for name in ("_preprocess_batch", "_update_with_batch"):
         mine, ref = inspect.signature(getattr(type(algo), name)), inspect.signature(getattr(base, name))
@@ -1257,7 +1407,7 @@ def test_hip_drqn_wrapper_runs_with_engine_double(monkeypatch):
         def __init__(self, obs_dim, hidden, layers, n_act, flat, cfg):
             assert (obs_dim, hidden, layers, n_act) == (4, 64, 2, 2)
             assert (cfg.gamma, cfg.n_step, cfg.target_update_freq, cfg.is_double, cfg.lr) == (0.95, 3, 4, True, 1e-3)
-            self.params, self.params_old = flat.clone(), flat.clone()
+            self.params, self.params_old, self.cfg = flat.clone(), flat.clone(), cfg
             self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
 
         def preprocess(self, m, rows, idx, stack, obs_next_rows=None):

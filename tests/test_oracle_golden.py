@@ -165,7 +165,7 @@ def _cfg_from(g):
         max_batchsize=int(c["max_batchsize"]), algo="a2c" if c.get("is_a2c") else "ppo")
 
 
-@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c"])
+@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c", "sched"])
 def test_ppo_restatement_matches_reference(tag):
     torch.set_num_threads(4)
     g = load(f"ppo_{tag}.npz")
@@ -174,6 +174,10 @@ def test_ppo_restatement_matches_reference(tag):
     state = OP.PPOState(params=OP.unflatten_params(torch.from_numpy(g["flat_params0"]), obs_dim, act_dim))
     for u in range(n_updates):
         pre_ = "" if u == 0 else f"u{u}_"
+        if f"u{u}_lr" in g.files:        # "sched": LRSchedulerFactoryLinear stepped after every update()
+            cfg.lr = float(g[f"u{u}_lr"])
+            if tag == "sched":
+                assert cfg.lr == pytest.approx(3e-4 * (1 - u / 6), rel=1e-12)
         obs = torch.from_numpy(g[pre_ + "obs"])
         obs_next = torch.from_numpy(g[pre_ + "obs_next"])
         act = torch.from_numpy(g[pre_ + "act"])
@@ -201,7 +205,7 @@ def test_ppo_restatement_matches_reference(tag):
                            list(g[f"u{u}_perms"]), recompute=recompute)
         ref = g[f"u{u}_losses"]
         assert losses.shape == ref.shape and losses.shape[0] == int(g[f"u{u}_gradient_steps"])
-        np.testing.assert_allclose(losses, ref, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(losses, ref, rtol=1e-5, atol=2e-6)
         flat = OP.flatten_params(state.params).numpy()
         np.testing.assert_allclose(flat, g[f"u{u}_flat_params"], rtol=1e-4, atol=2e-6)
         m = torch.cat([state.adam_m[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()

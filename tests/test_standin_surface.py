@@ -1,0 +1,133 @@
+"""CPU, only where the reference is mounted: the stand-ins of tests/standin.py (which let the GPU box drive the Hip*
+hook bodies without the reference package) expose the same surface as the reference classes they replace - state_dict
+keys and shapes, hyper-parameter attribute names, optimizer wrapper, buffer bookkeeping after identical `add()`
+sequences - and the production subclass built over the REAL reference reads them the same way."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import ref_shim
+from tests import standin as SI
+
+pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="reference not mounted")
+
+
+def _real_ppo(**kw):
+    ref_shim.install()
+    import gymnasium as gym
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.ppo import PPO
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                         action_shape=(6,), unbounded=True)
+    critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=lambda ls: Independent(Normal(*ls), 1), action_scaling=True,
+                                      action_bound_method="clip",
+                                      action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    return PPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), **kw)
+
+
+def _standin_ppo(**kw):
+    actor = SI.ContinuousActorProbabilistic(SI.Net(17, [64, 64], nn.Tanh), 6, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(17, [64, 64], nn.Tanh))
+    return SI.PPO(policy=SI.Policy(actor), critic=critic, lr=3e-4, **kw)
+
+
+def test_ppo_standin_has_the_reference_surface():
+    kw = dict(eps_clip=0.2, dual_clip=None, value_clip=True, advantage_normalization=False, recompute_advantage=False,
+              vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99, return_scaling=True)
+    real, fake = _real_ppo(**kw), _standin_ppo(**kw)
+    for a, b in ((real.policy.actor, fake.policy.actor), (real.critic, fake.critic)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    for name in ("_unbounded", "_c_sigma", "max_action"):
+        assert getattr(real.policy.actor, name) == getattr(fake.policy.actor, name), name
+    # every attribute ppo_config_from() / the hooks read, with equal values
+    for name in ("gamma", "gae_lambda", "eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_adv",
+                 "vf_coef", "ent_coef", "return_scaling", "max_batchsize"):
+        assert getattr(real, name) == getattr(fake, name), name
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm == 0.5
+    g_r, g_f = real.optim._optim.param_groups[0], fake.optim._optim.param_groups[0]
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam
+    assert (g_r["lr"], g_r["betas"], g_r["eps"], g_r["weight_decay"]) == (g_f["lr"], g_f["betas"], g_f["eps"], g_f["weight_decay"])
+    assert (real.ret_rms.mean, real.ret_rms.var, real.ret_rms.count) == (fake.ret_rms.mean, fake.ret_rms.var, fake.ret_rms.count)
+    assert real.lr_schedulers == fake.lr_schedulers == [] and len(real._optimizers) == len(fake._optimizers) == 1
+    assert real.policy.is_within_training_step is False and fake.policy.is_within_training_step is False
+    sd_r, sd_f = real.state_dict(), fake.state_dict()
+    assert "_optimizers" in sd_r and "_optimizers" in sd_f
+    # the optimizer steps the same parameters in the same order (what adam_state / store_adam_state index by)
+    n_r = [p.numel() for p in real.optim._optim.param_groups[0]["params"]]
+    n_f = [p.numel() for p in fake.optim._optim.param_groups[0]["params"]]
+    assert n_r == n_f
+    from tianshou_amd.integration import ppo_config_from
+
+    assert ppo_config_from(real) == ppo_config_from(fake)
+
+
+def test_buffer_standin_keeps_the_reference_bookkeeping():
+    ref_shim.install()
+    from tianshou.data import Batch, VectorReplayBuffer
+
+    rng = np.random.default_rng(0)
+    real = VectorReplayBuffer(30, 3)
+    fake = SI.VectorReplayBuffer(30, 3, obs_shape=(5,), act_shape=(2,))
+
+    def step(ids=None):
+        k = 3 if ids is None else len(ids)
+        term = rng.random(k) < 0.2
+        d = dict(obs=rng.normal(size=(k, 5)).astype(np.float32), act=rng.normal(size=(k, 2)).astype(np.float32),
+                 rew=rng.normal(size=k), terminated=term, truncated=(rng.random(k) < 0.1) & ~term,
+                 obs_next=rng.normal(size=(k, 5)).astype(np.float32))
+        real.add(Batch(**d), buffer_ids=ids)
+        fake.add(SI.Batch(**d), buffer_ids=ids)
+
+    def same():
+        assert len(real) == len(fake) and real.maxsize == fake.maxsize
+        assert np.array_equal(real._extend_offset, fake._extend_offset)
+        assert np.array_equal(real._lengths, fake._lengths)
+        assert np.array_equal(real.last_index, fake.last_index)
+        assert [b._insertion_idx for b in real.buffers] == [b._insertion_idx for b in fake.buffers]
+        assert [len(b) for b in real.buffers] == [len(b) for b in fake.buffers]
+        assert np.array_equal(real.unfinished_index(), fake.unfinished_index())
+        assert np.array_equal(real.sample_indices(0), fake.sample_indices(0))
+        for key in ("obs", "act", "rew", "terminated", "truncated", "done", "obs_next"):
+            assert np.array_equal(np.asarray(getattr(real, key)), getattr(fake, key)), key
+            assert np.asarray(getattr(real, key)).dtype == getattr(fake, key).dtype, key
+        assert set(fake._meta.get_keys()) <= set(real._meta.get_keys())
+
+    for _ in range(4):
+        step()
+    same()
+    for ids in ([0, 2], [1], [1], [2, 0], None, None):
+        for _ in range(3):
+            step(ids)
+        same()
+    for _ in range(9):                    # wrap every ring
+        step()
+    same()
+    real.reset()
+    fake.reset()
+    step()
+    same()
+    b, idx = fake.sample(0)
+    rb, ridx = real.sample(0)
+    assert np.array_equal(idx, ridx) and np.array_equal(b.obs, rb.obs) and np.array_equal(b.rew, rb.rew)
+
+
+def test_real_subclass_and_standin_subclass_are_the_same_hook_code():
+    """make_hip_ppo() over the reference and over the stand-ins yields classes whose hook functions come from the same
+    source lines (the `ref=` argument only swaps the base / statistics classes)."""
+    ref_shim.install()
+    from tianshou_amd.integration import make_hip_ppo
+
+    A, B = make_hip_ppo("ppo"), make_hip_ppo("ppo", ref=SI)
+    for name in ("update", "_preprocess_batch", "_update_with_batch", "_engine", "_sync_back", "_hip_flush"):
+        fa, fb = getattr(A, name), getattr(B, name)
+        assert fa.__code__.co_code == fb.__code__.co_code and fa.__code__.co_firstlineno == fb.__code__.co_firstlineno, name

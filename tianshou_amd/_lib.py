@@ -165,11 +165,21 @@ class Workspace:
             pass
 
 
-_default_ws: dict[int, Workspace] = {}
+_default_ws: dict[tuple[int, int], Workspace] = {}
 
 
 def default_workspace(device_index: int) -> Workspace:
-    ws = _default_ws.get(device_index)
+    """The per-(device, current stream) default workspace: scratch areas (the GAE scan's hand-off messages, the
+    gradient slabs) are written by the kernels of one stream at a time, so work issued on two streams of one
+    process must not share them."""
+    import torch
+
+    try:
+        stream = int(torch.cuda.current_stream(device_index).cuda_stream)
+    except Exception:            # no GPU: Workspace() below raises the real error
+        stream = 0
+    key = (device_index, stream)
+    ws = _default_ws.get(key)
     if ws is None:
-        ws = _default_ws[device_index] = Workspace(device_index)
+        ws = _default_ws[key] = Workspace(device_index)
     return ws

@@ -89,6 +89,89 @@ def random_permutation(n: int, seed: int, device="cuda") -> torch.Tensor:
     return out
 
 
+class AddTracker:
+    """Exact write log of a reference replay buffer: per sub-buffer the number of transitions
+    `ReplayBufferManager.add` (manager.py:131-198: one slot in each of `buffer_ids`, all sub-buffers when None) /
+    `ReplayBuffer.add` (buffer_base.py:420-501) wrote since the mirror last looked, and an `everything` flag for the
+    calls that rewrite the storage wholesale (`reset`, `update`, `set_batch`).  The reference keeps no such counter,
+    and `_insertion_idx` / `len()` are unchanged after exactly `size` adds or after `reset()` + an equal refill (the
+    on-policy pattern, trainer.py:1116-1130).
+
+    Mechanism: the write methods of the buffer's classes are wrapped ONCE per class (every class of the MRO that
+    defines them; nested `super().add(...)` calls are counted once through a depth guard); a buffer takes part only
+    while it carries the plain-data record `_hip_writes` in its `__dict__` (a dict of an int64 array, a bool and an
+    int: survives pickling, deepcopy and the buffer's HDF5 export; nothing callable is stored on the instance).
+    The patch a Tianshou maintainer would add instead is the three counting lines inside those methods
+    (INTEGRATION.md)."""
+    _ATTR = "_hip_writes"
+    _MARK = "_hip_tracked_methods"
+
+    @classmethod
+    def _wrap_class(cls, klass) -> None:
+        done = klass.__dict__.get(cls._MARK, ())
+        for name in ("add", "reset", "update", "set_batch"):
+            fn = klass.__dict__.get(name)
+            if fn is None or name in done or not callable(fn):
+                continue
+            setattr(klass, name, cls._counted(fn, name))
+            done = done + (name,)
+        setattr(klass, cls._MARK, done)
+
+    @classmethod
+    def _counted(cls, fn, name):
+        attr = cls._ATTR
+
+        def method(self, *args, **kwargs):
+            st = self.__dict__.get(attr)
+            if st is None:
+                return fn(self, *args, **kwargs)
+            st["depth"] += 1
+            try:
+                out = fn(self, *args, **kwargs)
+            finally:
+                st["depth"] -= 1
+            if st["depth"] == 0:
+                if name != "add" or st["coarse"]:
+                    st["everything"] = True
+                else:
+                    ids = kwargs.get("buffer_ids", args[1] if len(args) > 1 else None)
+                    counts = st["counts"]
+                    if counts.size == 1:
+                        counts[0] += 1
+                    elif ids is None:
+                        counts += 1
+                    else:
+                        np.add.at(counts, np.asarray(ids, dtype=np.int64).reshape(-1), 1)
+            return out
+
+        method.__name__, method.__doc__, method.__wrapped__ = name, fn.__doc__, fn
+        return method
+
+    @classmethod
+    def of(cls, buffer) -> dict:
+        """The buffer's record, created (with `everything` set: nothing is known about earlier writes) on first use."""
+        st = buffer.__dict__.get(cls._ATTR)
+        if st is None:
+            for klass in type(buffer).__mro__:
+                if klass is not object:
+                    cls._wrap_class(klass)
+            n = len(buffer.buffers) if hasattr(buffer, "buffers") else 1
+            # CachedReplayBuffer (cached.py) moves whole episodes between sub-buffers inside add(): not slot-countable
+            st = {"counts": np.zeros(n, dtype=np.int64), "everything": True, "depth": 0,
+                  "coarse": "Cached" in type(buffer).__name__}
+            buffer.__dict__[cls._ATTR] = st
+        return st
+
+    @classmethod
+    def take(cls, buffer):
+        """-> (counts copy, everything flag) since the previous take(); resets both."""
+        st = cls.of(buffer)
+        out = (st["counts"].copy(), bool(st["everything"]))
+        st["counts"][:] = 0
+        st["everything"] = False
+        return out
+
+
 class DeviceReplayBuffer:
     """Read-side mirror of ReplayBufferManager on one GPU."""
 
@@ -226,6 +309,7 @@ class DeviceReplayBuffer:
             insertion = [buffer._insertion_idx]
         meta = buffer._meta
         has = lambda k: k in meta.get_keys()  # noqa: E731
+        AddTracker.take(buffer)                         # the snapshot below covers everything written so far
         return cls(offset=offset, last_index=np.array(buffer.last_index), lengths=np.array(lengths),
                    insertion=insertion, rew=np.asarray(buffer.rew),
                    terminated=np.asarray(buffer.terminated), truncated=np.asarray(buffer.truncated),
@@ -235,36 +319,48 @@ class DeviceReplayBuffer:
     def sync_from_tianshou(self, buffer) -> int:
         """Incremental refresh from the reference buffer this mirror was created from: copies only the slots
         written since the last sync (ring order per sub-buffer, manager.py:162-177) plus the tiny manager state.
-        Assumes fewer than `size` adds per sub-buffer between two syncs.  Returns the number of slots copied."""
+        How many slots each sub-buffer received comes from the `AddTracker` that `from_tianshou` installed on the
+        buffer object (exact for any number of adds, including whole multiples of the sub-buffer size, and for
+        `reset()` + refill, which leave `_insertion_idx` / `len` unchanged); adjacent ranges of neighbouring
+        sub-buffers are merged so that a fully rewritten VectorReplayBuffer is one copy per key.
+        Returns the number of slots copied."""
         subs = buffer.buffers if hasattr(buffer, "buffers") else [buffer]
         if len(subs) != self.buffer_num:
             raise ValueError("buffer layout changed since the mirror was created")
+        counts, everything = AddTracker.take(buffer)
         keys = [k for k in ("obs", "act", "obs_next") if getattr(self, k) is not None]
         host = {k: np.asarray(getattr(buffer, k)) for k in keys}
         host.update(rew=np.asarray(buffer.rew), terminated=np.asarray(buffer.terminated),
                     truncated=np.asarray(buffer.truncated))
-        copied = 0
+        ranges = []
         for e, sb in enumerate(subs):
             start, size = int(self.h_offset[e]), int(self.h_offset[e + 1] - self.h_offset[e])
             new_ins, new_len = int(sb._insertion_idx), len(sb)
-            old_ins, old_len = int(self.h_insertion[e]), int(self.h_lengths[e])
-            grown = new_len - old_len
-            k = grown + (new_ins - old_ins - grown) % size if size else 0
-            k = min(k, size)
-            segs = []
-            a = old_ins % size if size else 0
-            if k == size:
-                segs = [(0, size)]
-            elif k > 0:
-                segs = [(a, min(a + k, size))] + ([(0, a + k - size)] if a + k > size else [])
-            for lo, hi in segs:
-                sl = slice(start + lo, start + hi)
-                for key, arr in host.items():
-                    dst = getattr(self, key)
-                    dst[sl] = torch.as_tensor(np.ascontiguousarray(arr[sl])).to(dst.dtype)
-                self.done[sl] = self.terminated[sl] | self.truncated[sl]
-                copied += hi - lo
+            k = size if everything else min(int(counts[e]), size)
+            if k >= size > 0:
+                ranges.append((start, start + size))
+            elif k > 0:                      # the k slots before the insertion point, ring order
+                a = (new_ins - k) % size
+                ranges.append((start + a, start + min(a + k, size)))
+                if a + k > size:
+                    ranges.append((start, start + a + k - size))
             self.h_insertion[e], self.h_lengths[e] = new_ins, new_len
+        ranges.sort()
+        merged = []
+        for lo, hi in ranges:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        copied = 0
+        for lo, hi in merged:
+            sl = slice(lo, hi)
+            for key, arr in host.items():
+                dst = getattr(self, key)
+                src = torch.from_numpy(np.ascontiguousarray(arr[sl]))
+                dst[sl].copy_(src if src.dtype == dst.dtype else src.to(dst.dtype), non_blocking=True)
+            self.done[sl] = self.terminated[sl] | self.truncated[sl]
+            copied += hi - lo
         self.h_last_index = np.ascontiguousarray(np.asarray(buffer.last_index, dtype=np.int64).reshape(-1))
         self.last_index.copy_(torch.as_tensor(self.h_last_index))
         self.lengths.copy_(torch.as_tensor(self.h_lengths))
@@ -318,3 +414,7 @@ class DeviceReplayBuffer:
 
     def gather(self, key: str, index) -> torch.Tensor:
         return gather_rows(getattr(self, key), index)
+
+    @staticmethod
+    def gather_tensor(src: torch.Tensor, index) -> torch.Tensor:
+        return gather_rows(src, index)

@@ -20,6 +20,58 @@ from .checkpoint import adam_state, params_by_keys, store_adam_state
 from .ppo import PPOConfig, PPOEngine, flat_from_modules, flat_to_modules, TIANSHOU_ACTOR_KEYS, TIANSHOU_CRITIC_KEYS
 
 
+class _HipGlue:
+    """Mixed in (first base) by every Hip* subclass: the two places where the torch-side state of the
+    reference moves underneath an engine that snapshotted it.
+
+    * Learning rates.  `Algorithm._update` steps every scheduler after each update()
+      (algorithm_base.py:516-518, 628-629; `LambdaLR` only rewrites `param_groups[i]["lr"]`, optim.py:22-53) and
+      examples/mujoco/mujoco_ppo.py:124-131 turns linear decay on by default.  The engines rebuild their
+      hyper-parameter struct from `eng.cfg` on every call, so `_hip_refresh_lr()` at the top of each
+      `_update_with_batch` re-reads the optimizers' current values.
+    * `load_state_dict` (on the algorithm or on any of its sub-modules) replaces parameters / Adam moments /
+      lagged networks / counters: the engine is dropped and rebuilt from the loaded torch state on the next
+      update (a post-hook on every sub-module, so `algorithm.policy.load_state_dict(...)` is caught too).
+    `_HIP_LR`: (engine cfg field, attribute path of the Algorithm.Optimizer wrapper that owns it)."""
+    _HIP_LR: tuple = (("lr", "optim"),)
+
+    def _hip_glue_init(self) -> None:
+        hook = lambda module, incompatible_keys: self._hip_invalidate()  # noqa: E731
+        for m in self.modules():
+            m.register_load_state_dict_post_hook(hook)
+
+    def _hip_invalidate(self) -> None:
+        self._hip_engine = None
+        self._hip_adam_dirty = False
+
+    def _hip_flush(self) -> None:
+        """Engine-side optimizer state -> torch.optim state; the default wrappers store it after every update."""
+
+    def state_dict(self, *args, **kwargs):
+        self._hip_flush()
+        return super().state_dict(*args, **kwargs)
+
+    def _hip_refresh_lr(self) -> None:
+        eng = self._hip_engine
+        if eng is None:
+            return
+        seen: dict[str, float] = {}
+        for field, path in self._HIP_LR:
+            obj = self
+            for part in path.split("."):
+                obj = getattr(obj, part)
+            opt = getattr(obj, "_optim", obj)
+            if not hasattr(opt, "param_groups"):          # FixedAlpha (sac.py:161-172): nothing to learn
+                continue
+            lr = float(opt.param_groups[0]["lr"])
+            if any(float(g["lr"]) != lr for g in opt.param_groups):
+                raise NotImplementedError("the HIP engines take one learning rate per optimizer")
+            if seen.setdefault(field, lr) != lr:
+                raise NotImplementedError(f"the HIP engine has one `{field}`; the optimizers sharing it disagree")
+            setattr(eng.cfg, field, lr)
+            opt._opt_called = True       # the engine performs this optimizer's step (LRScheduler.step's order check)
+
+
 def ppo_config_from(algorithm) -> PPOConfig:
     """Reads the reference PPO's hyper-parameters (ppo.py:126-144, a2c.py:95-113, optim.py:89-110)."""
     opt = algorithm.optim._optim
@@ -37,15 +89,24 @@ def ppo_config_from(algorithm) -> PPOConfig:
         return_scaling=algorithm.return_scaling, lr=g["lr"], betas=tuple(g["betas"]), adam_eps=g["eps"])
 
 
-def _on_policy_base(algo: str):
+def _ref(ref, module: str, name: str):
+    """`module.name` of the reference package - or `ref.name` when a namespace is injected: the GPU parity tests drive
+    the very same hook bodies through minimal stand-ins of the reference classes (tests/standin.py), because
+    /root/reference does not exist on the GPU box."""
+    if ref is not None:
+        return getattr(ref, name)
+    import importlib
+
+    return getattr(importlib.import_module(module), name)
+
+
+def _on_policy_base(algo: str, ref=None):
     """PPO (ppo.py) or A2C (a2c.py:187-290): the hooks and the statistics class are the same."""
     if algo == "ppo":
-        from tianshou.algorithm.modelfree.ppo import PPO as Base
-    elif algo == "a2c":
-        from tianshou.algorithm.modelfree.a2c import A2C as Base
-    else:
-        raise ValueError("algo must be 'ppo' or 'a2c'")
-    return Base
+        return _ref(ref, "tianshou.algorithm.modelfree.ppo", "PPO")
+    if algo == "a2c":
+        return _ref(ref, "tianshou.algorithm.modelfree.a2c", "A2C")
+    raise ValueError("algo must be 'ppo' or 'a2c'")
 
 
 def _check_supported(actor, critic) -> tuple[int, int]:
@@ -66,20 +127,23 @@ def _check_supported(actor, critic) -> tuple[int, int]:
     return int(w1.shape[1]), int(sa["mu.model.0.weight"].shape[0])
 
 
-def make_hip_ppo(algo: str = "ppo"):
-    """Returns the HipPPO class (imports tianshou lazily); algo="a2c": HipA2C(A2C), same networks."""
-    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.data import SequenceSummaryStats
+def make_hip_ppo(algo: str = "ppo", ref=None):
+    """Returns the HipPPO class (imports tianshou lazily); algo="a2c": HipA2C(A2C), same networks.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    A2CTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.a2c", "A2CTrainingStats")
+    SequenceSummaryStats = _ref(ref, "tianshou.data", "SequenceSummaryStats")
+    Batch = _ref(ref, "tianshou.data", "Batch")
+    PPO = _on_policy_base(algo, ref)
 
-    PPO = _on_policy_base(algo)
-
-    class HipPPO(PPO):
+    class HipPPO(_HipGlue, PPO):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             self._hip_dims = _check_supported(self.policy.actor, self.critic)
             self._hip_engine = None
+            self._hip_glue_init()
             self._hip_batch = None
+            self._hip_synced = False
 
         # -- engine life cycle ------------------------------------------------------------------
         def _engine(self) -> PPOEngine:
@@ -98,39 +162,93 @@ def make_hip_ppo(algo: str = "ppo"):
             return params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS) + params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
 
         def _sync_back(self) -> None:
-            """Engine state -> nn.Parameters, torch.optim.Adam.state, ret_rms (state_dict keeps working,
-            algorithm_base.py:523-543)."""
+            """After every update(): engine parameters -> nn.Parameters (the collector acts with the torch modules;
+            device-to-device when they live on the GPU, no host synchronisation) and the three ret_rms scalars.
+            The Adam moments are only needed by `state_dict()` (algorithm_base.py:523-543) and move there
+            (`_hip_flush`)."""
             eng = self._hip_engine
             flat_to_modules(eng.params, self.policy.actor, self.critic)
+            self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
+            self._hip_adam_dirty = True
+
+        def _hip_flush(self) -> None:
+            eng = self._hip_engine
+            if eng is None or not getattr(self, "_hip_adam_dirty", False):
+                return
             params = self._hip_params()
             sizes = [p.numel() for p in params]
             store_adam_state(self.optim._optim, params, torch.split(eng.adam_m, sizes), torch.split(eng.adam_v, sizes),
                              eng.adam_step)
-            self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
+            self._hip_adam_dirty = False
+
+        # -- Algorithm.update ---------------------------------------------------------------------------
+        def update(self, buffer, batch_size, repeat):
+            """`OnPolicyAlgorithm.update` -> `Algorithm._update` (algorithm_base.py:586-631, 854-865), same steps in the
+            same order, with `buffer.sample(0)` - a host fancy-index copy of every key, 1.4 s at 2^20 transitions -
+            replaced by the device mirror of the buffer: only the slots written since the previous update cross PCIe,
+            `sample_indices(0)`, the gathers and the unfinished-slot cuts run as kernels."""
+            _require_gpu(self._hip_device, type(self).__name__)
+            if not self.policy.is_within_training_step:
+                raise RuntimeError(
+                    f"update() was called outside of a training step as signalled by {self.policy.is_within_training_step=} "
+                    "(see tianshou.utils.torch_utils.policy_within_training_step)")
+            if buffer is None:
+                return super().update(buffer, batch_size, repeat)
+            import time
+
+            start = time.time()
+            m = _mirror(self, buffer, self._hip_device)
+            self._hip_synced = True
+            indices = m.sample_indices(0)
+            batch = self._preprocess_batch(Batch(), buffer, indices)
+            was_training = self.training                          # torch_train_mode (torch_utils.py:14-22)
+            try:
+                self.train(True)
+                stat = self._update_with_batch(batch, batch_size, repeat)
+            finally:
+                self.train(was_training)
+            if hasattr(buffer, "update_weight"):
+                self._postprocess_batch(batch, buffer, indices.cpu().numpy())
+            for lr_scheduler in self.lr_schedulers:
+                lr_scheduler.step()
+            stat.train_time = time.time() - start
+            return stat
 
         # -- hooks ------------------------------------------------------------------------------------
         def _preprocess_batch(self, batch, buffer, indices):
+            """a2c.py:239-247 / ppo.py:146-162.  Works on the device mirror at `indices` (the host copies in `batch`,
+            when the caller is the reference's own `Algorithm._update`, are not read)."""
+            from .returns import cut_positions
+
+            _require_gpu(self._hip_device, type(self).__name__)
             eng = self._engine()
-            dev = self._hip_device
-            t = lambda x, dt=None: torch.as_tensor(np.ascontiguousarray(x), device=dev) if dt is None \
-                else torch.as_tensor(np.ascontiguousarray(x), device=dev).to(dt)  # noqa: E731
-            cut = np.nonzero(np.isin(indices, buffer.unfinished_index()))[0]      # algorithm_base.py:715
-            b = eng.preprocess(t(batch.obs, torch.float32), t(batch.obs_next, torch.float32),
-                               t(batch.act, torch.float32), t(batch.rew, torch.float64),
-                               t(batch.terminated), t(batch.truncated), t(cut))
+            if self._hip_synced:
+                m, self._hip_synced = self._hip_mirror, False
+            else:
+                m = _mirror(self, buffer, self._hip_device)
+            idx = indices if isinstance(indices, torch.Tensor) else \
+                torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            whole = idx.numel() == m.maxsize and m.indices_are_identity()     # sample(0) of full, unwrapped sub-buffers
+            take = (lambda x: x) if whole else (lambda x: m.gather_tensor(x, idx))   # noqa: E731
+            obs_next = take(m.obs_next) if m.obs_next is not None else m.gather_tensor(m.obs, m.next(idx))
+            cut, d_n = cut_positions(m, idx)                                   # algorithm_base.py:715
+            b = eng.preprocess(take(m.obs), obs_next, take(m.act), take(m.rew), take(m.terminated), take(m.truncated),
+                               cut, d_n)
             self._hip_batch = b
             batch.v_s, batch.returns, batch.adv = b["v_s"], b["returns"], b["adv"]
             batch.act = b["act"]
-            if b.get("logp_old") is not None:                                  # A2C has none (a2c.py:239-247)
+            if algo == "ppo":                                                  # A2C has none (a2c.py:239-247)
                 batch.logp_old = b["logp_old"]
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
+            self._hip_refresh_lr()
             eng = self._engine()
-            n = len(batch)
+            n = int(self._hip_batch["obs"].shape[0])
             perms = [np.random.permutation(n) for _ in range(repeat)]    # Batch.split, batch.py:1209
             losses, steps = eng.update(self._hip_batch, batch_size, repeat, perms)
             arr = losses.cpu().numpy().astype(np.float64)              # one D2H per update()
+            eng.check()                                                # surfaces a stuck GAE hand-off (never observed)
             self._sync_back()
             return A2CTrainingStats(
                 loss=SequenceSummaryStats.from_sequence(arr[:, 0]),
@@ -161,7 +279,7 @@ def _make_hip_natural(algo: str):
         from tianshou.algorithm.modelfree.trpo import TRPOTrainingStats as Stats
     who = "HipNPG" if algo == "npg" else "HipTRPO"
 
-    class HipNatural(Base):
+    class HipNatural(_HipGlue, Base):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -175,6 +293,7 @@ def _make_hip_natural(algo: str):
                 raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _engine(self):
             if self._hip_engine is None:
@@ -216,6 +335,7 @@ def _make_hip_natural(algo: str):
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
+            self._hip_refresh_lr()
             eng = self._hip_engine
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             stats, _ = eng.update(self._hip_pre, batch_size, repeat, perms)
@@ -263,7 +383,7 @@ def make_hip_reinforce():
 
     who = "HipReinforce"
 
-    class HipReinforce(Reinforce):
+    class HipReinforce(_HipGlue, Reinforce):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -277,6 +397,7 @@ def make_hip_reinforce():
                 raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _dims(self):
             sa = self.policy.actor.state_dict()
@@ -313,6 +434,7 @@ def make_hip_reinforce():
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
+            self._hip_refresh_lr()
             eng = self._hip_engine
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             losses, _ = eng.update(self._hip_obs, self._hip_act, batch.returns, batch_size, repeat, perms)
@@ -382,7 +504,7 @@ def make_hip_dqn():
 
     from . import dqn as D
 
-    class HipDQN(DQN):
+    class HipDQN(_HipGlue, DQN):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -391,6 +513,7 @@ def make_hip_dqn():
                 raise NotImplementedError("HipDQN: the model must be DQNet(c, h, w, action_shape) without extra layers")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _engine(self, c, h, w):
             if self._hip_engine is None:
@@ -437,6 +560,7 @@ def make_hip_dqn():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
             obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack, as_u8=True)
@@ -472,7 +596,7 @@ def make_hip_drqn():
     from . import dqn as D
     from . import drqn as R
 
-    class HipDRQN(DQN):
+    class HipDRQN(_HipGlue, DQN):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -487,6 +611,7 @@ def make_hip_drqn():
             self._hip_dims = (obs_dim, hidden, layers, n_act)
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _engine(self):
             if self._hip_engine is None:
@@ -524,6 +649,7 @@ def make_hip_drqn():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
             obs = R.gather_stacked_obs(m.obs, m, self._hip_idx, self._hip_stack)
@@ -563,7 +689,7 @@ def _make_hip_distq(kind: str):
         from tianshou.algorithm.modelfree.c51 import C51 as Base
     who = "HipQRDQN" if kind == Q.QR else "HipC51"
 
-    class HipDistQ(Base):
+    class HipDistQ(_HipGlue, Base):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -571,6 +697,7 @@ def _make_hip_distq(kind: str):
                 raise NotImplementedError(f"{who}: the model must be QRDQNet / C51Net (DQNet without extra layers)")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _n_atoms(self) -> int:
             return int(self.num_quantiles if kind == Q.QR else self.policy.num_atoms)
@@ -627,6 +754,7 @@ def _make_hip_distq(kind: str):
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             idx, stack = self._hip_idx, self._hip_stack
             weight = batch.pop("weight", None)
@@ -682,7 +810,7 @@ def make_hip_rainbow():
     from . import dqn as D
     from . import rainbow as RB
 
-    class HipRainbow(RainbowDQN):
+    class HipRainbow(_HipGlue, RainbowDQN):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -691,6 +819,7 @@ def make_hip_rainbow():
                 raise NotImplementedError("HipRainbow: the model must be RainbowNet(is_dueling=True, is_noisy=True)")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _noise_of(self, model, dims):
             sd = model.state_dict()
@@ -746,6 +875,7 @@ def make_hip_rainbow():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             idx, stack = self._hip_idx, self._hip_stack
             dims = (eng.c, eng.h, eng.w, eng.n_act, eng.cfg.n_atoms)
@@ -796,7 +926,9 @@ def make_hip_sac():
 
     from . import sac as S
 
-    class HipSAC(SAC):
+    class HipSAC(_HipGlue, SAC):
+        _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("critic_lr", "critic2_optim"),
+                   ("alpha_lr", "alpha"))
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -809,6 +941,7 @@ def make_hip_sac():
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
                 _adam_of(o)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _engine(self):
             if self._hip_engine is None:
@@ -862,6 +995,7 @@ def make_hip_sac():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             from .buffer import gather_rows
 
             eng, m = self._hip_engine, self._hip_mirror
@@ -911,7 +1045,8 @@ def make_hip_redq():
     from . import redq as RQ
     from . import sac as S
 
-    class HipREDQ(REDQ):
+    class HipREDQ(_HipGlue, REDQ):
+        _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("alpha_lr", "alpha"))
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -925,6 +1060,7 @@ def make_hip_redq():
             for o in (self.policy_optim, self.critic_optim):
                 _adam_of(o)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _critic_tensors(self, mod):
             return [mod.state_dict()[k] for k in RQ.TIANSHOU_CRITIC_KEYS]
@@ -976,6 +1112,7 @@ def make_hip_redq():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             from .buffer import gather_rows
 
             eng, m = self._hip_engine, self._hip_mirror
@@ -1032,7 +1169,9 @@ def make_hip_discrete_sac():
     from . import dsac as DS
     from .sac import SACConfig
 
-    class HipDiscreteSAC(DiscreteSAC):
+    class HipDiscreteSAC(_HipGlue, DiscreteSAC):
+        _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("critic_lr", "critic2_optim"),
+                   ("alpha_lr", "alpha"))
         def __init__(self, *args, device="cuda", match_rng_stream: bool = True, **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -1049,6 +1188,7 @@ def make_hip_discrete_sac():
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
                 _adam_of(o)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _hip_parts(self):
             return (("actor", self.policy.actor, self.policy_optim), ("critic1", self.critic, self.critic_optim),
@@ -1108,6 +1248,7 @@ def make_hip_discrete_sac():
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             from .buffer import gather_rows
 
             eng, m = self._hip_engine, self._hip_mirror
@@ -1152,7 +1293,7 @@ def make_hip_ppo_cnn(algo: str = "ppo"):
 
     from . import ppo_cnn as PC
 
-    class HipPPOCnn(PPO):
+    class HipPPOCnn(_HipGlue, PPO):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -1166,6 +1307,7 @@ def make_hip_ppo_cnn(algo: str = "ppo"):
                 raise NotImplementedError("HipPPOCnn: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _hip_params(self):
             return params_by_keys(self.policy.actor, PC.TRUNK_KEYS + PC.HEAD_KEYS) + params_by_keys(self.critic, PC.HEAD_KEYS)
@@ -1203,6 +1345,7 @@ def make_hip_ppo_cnn(algo: str = "ppo"):
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             losses, steps = eng.update(m, m.obs, self._hip_pre, self._hip_stack, batch_size, repeat, perms)
@@ -1243,7 +1386,7 @@ def make_hip_ppo_discrete(algo: str = "ppo"):
 
     from . import ppo_discrete as PD
 
-    class HipPPODiscrete(PPO):
+    class HipPPODiscrete(_HipGlue, PPO):
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -1266,6 +1409,7 @@ def make_hip_ppo_discrete(algo: str = "ppo"):
                 raise NotImplementedError("HipPPODiscrete: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _hip_params(self):
             return params_by_keys(self.policy.actor, PD.TRUNK_KEYS + PD.HEAD_KEYS) + params_by_keys(self.critic, PD.HEAD_KEYS)
@@ -1294,6 +1438,7 @@ def make_hip_ppo_discrete(algo: str = "ppo"):
             return batch
 
         def _update_with_batch(self, batch, batch_size, repeat):
+            self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             losses, steps = eng.update(m, self._hip_pre, batch_size, repeat, perms)
@@ -1327,7 +1472,9 @@ def _make_hip_det(twin: bool):
 
     base = TD3 if twin else DDPG
 
-    class HipDet(base):
+    class HipDet(_HipGlue, base):
+        _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim")) + \
+            ((("critic_lr", "critic2_optim"),) if twin else ())
         def __init__(self, *args, device="cuda", **kwargs):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
@@ -1340,6 +1487,7 @@ def _make_hip_det(twin: bool):
             for o in [self.policy_optim, self.critic_optim] + ([self.critic2_optim] if twin else []):
                 _adam_of(o)
             self._hip_engine = None
+            self._hip_glue_init()
 
         def _hip_parts(self):
             parts = [("actor", self.policy.actor, self.policy_optim, T.TIANSHOU_ACTOR_KEYS, T.actor_flat_from_torch,
@@ -1389,6 +1537,7 @@ def _make_hip_det(twin: bool):
             return batch
 
         def _update_with_batch(self, batch):
+            self._hip_refresh_lr()
             from .buffer import gather_rows
 
             eng, m = self._hip_engine, self._hip_mirror

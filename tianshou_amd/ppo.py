@@ -187,6 +187,12 @@ class PPOEngine:
         self._eps = 1e-8
         self._ws = _lib.default_workspace(_dev_index(self.params))
 
+    def check(self) -> None:
+        """Raises if a single-pass GAE scan on this engine's workspace gave up on a tile hand-off (its outputs would be
+        garbage).  Synchronises the stream: call it where a D2H already happened (after reading the losses)."""
+        if self._ws.gae_check():
+            raise _lib.EngineError(-1, "gae_single_pass: a tile hand-off timed out; advantages / returns are invalid")
+
     # ------------------------------------------------------------------ preprocess
     def _f32(self, x) -> torch.Tensor:
         if not isinstance(x, torch.Tensor):
@@ -202,7 +208,7 @@ class PPOEngine:
         scale = math.sqrt(self.ret_rms[1] + self._eps) if cfg.return_scaling else 1.0
         out = gae_scan(v_s, v_next, rew, terminated, truncated, cut_pos, gamma=cfg.gamma,
                        gae_lambda=cfg.gae_lambda, v_scale=scale, ret_div=scale,
-                       want_ret_stats=cfg.return_scaling, d_n_cut=d_n_cut)
+                       want_ret_stats=cfg.return_scaling, d_n_cut=d_n_cut, ws=self._ws)
         if cfg.return_scaling:
             n = float(v_s.numel())
             s1, s2 = float(out["ret_sum"]), float(out["ret_sumsq"])       # one small D2H

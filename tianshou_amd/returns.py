@@ -23,7 +23,7 @@ def _f32(x, device) -> torch.Tensor:
 
 def gae_scan(v_s, v_s_next, rew, terminated, truncated, cut_pos=None, *, gamma=0.99,
              gae_lambda=0.95, v_scale=1.0, ret_div=1.0, want_f64=False, want_ret_stats=False,
-             d_n_cut=None):
+             d_n_cut=None, ws=None):
     """Fused compute_episodic_return (ts_gae_scan).  Returns dict(adv, returns[, adv64, ret64,
     ret_sum, ret_sumsq]); adv/returns are float32 like the reference's to_torch_as casts."""
     dev = v_s.device
@@ -52,7 +52,8 @@ def gae_scan(v_s, v_s_next, rew, terminated, truncated, cut_pos=None, *, gamma=0
     parts = None
     if want_ret_stats:
         parts = torch.zeros(2 * max(int(lib.ts_gae_num_tiles(n)), 1), dtype=torch.float64, device=dev)
-    ws = _lib.default_workspace(_dev_index(v_s))
+    if ws is None:
+        ws = _lib.default_workspace(_dev_index(v_s))
     _lib.check(lib.ts_gae_scan(
         ws.handle, _lib.ptr(v_s), _lib.ptr(v_s_next), _lib.ptr(rew),
         0 if rew.dtype == torch.float32 else 1, _lib.ptr(terminated), _lib.ptr(truncated),
