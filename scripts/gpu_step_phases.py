@@ -12,8 +12,13 @@ lib = _lib.load()
 hp = L.cfg.to_c()
 from tianshou_amd.ppo import pack_batch
 rec = pack_batch(b, 17, 6)
-names = ["start", "staged", "A:trunk", "A:loss", "A:headgrad", "A:dH1", "A:dW2", "A:dW1", "A:pass_end", "A:flushed",
-         "C:trunk", "C:loss", "C:headgrad", "C:dH1", "C:dW2", "C:dW1", "C:pass_end", "end"]
+V1 = os.environ.get("TS_PPO_STEP_V1", "0") not in ("", "0")
+if V1:
+    names = ["start", "staged", "A:trunk", "A:loss", "A:headgrad", "A:dH1", "A:dW2", "A:dW1", "A:pass_end", "A:flushed",
+             "C:trunk", "C:loss", "C:headgrad", "C:dH1", "C:dW2", "C:dW1", "C:pass_end", "end"]
+else:
+    names = ["start", "staged", "A:trunk", "A:loss", "A:headgrad", "A:dH1", "A:tiles_A", "A:dW2", "A:dW1/misc", "C:staged",
+             "C:trunk", "C:loss", "C:headgrad", "C:dH1", "C:tiles_A", "C:dW2", "C:dW1/misc", "end"]
 NROWS = int(os.environ.get('NROWS', '65536'))
 for trial in range(2):
     rows = torch.as_tensor(np.random.default_rng(trial).permutation(bench.N_TRANS)[:NROWS], device=dev)
@@ -24,6 +29,3 @@ for trial in range(2):
     print("trial", trial, "total cycles", t[17] - t[0])
     for k in range(1, 18):
         print(f"   {names[k]:12s} +{t[k]-t[k-1]:8d}  (at {t[k]-t[0]:8d})")
-    print("   prologue A: fetch issued at", t[18]-t[0], "pre-stage", t[19]-t[0], "staged(no barrier)", t[20]-t[0], "after barrier", t[1]-t[0])
-    print("   actor loss: head_fwd", t[24]-t[2], "logp/ratio", t[25]-t[24], "dsig", t[26]-t[25], "sums", t[3]-t[26])
-    print("   prologue C: from A:pass_end", t[21]-t[8], t[22]-t[8], t[23]-t[8], t[9]-t[8])

@@ -109,14 +109,19 @@ def test_hip_ppo_hooks_with_scheduler_against_oracle(module_device):
                                    [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
         assert next(algo.policy.actor.parameters()).device.type == module_device
     # Algorithm.state_dict(): Adam moments arrive lazily, in the reference's per-parameter layout
-    sd = algo.state_dict()
-    opt_state = sd["_optimizers"][0]["state"]
     params = algo._hip_params()
-    assert len(opt_state) == len(params)
-    m_flat = torch.cat([opt_state[i]["exp_avg"].reshape(-1).cpu() for i in range(len(params))]).numpy()
+    assert all(p not in algo.optim._optim.state for p in params)
+    sd = algo.state_dict()
+    assert len(sd["_optimizers"][0]["state"]) == len(params)
+    state = algo.optim._optim.state               # keyed by parameter (state_dict() numbers them in optimizer order)
+    m_flat = torch.cat([state[p]["exp_avg"].reshape(-1).cpu() for p in params]).numpy()
+    v_flat = torch.cat([state[p]["exp_avg_sq"].reshape(-1).cpu() for p in params]).numpy()
     m_ref = torch.cat([st.adam_m[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()
+    v_ref = torch.cat([st.adam_v[k].reshape(-1) for k in OP.PARAM_ORDER]).numpy()
     np.testing.assert_allclose(m_flat, m_ref, rtol=1e-3, atol=1e-7)
-    assert float(opt_state[0]["step"]) == st.adam_step
+    np.testing.assert_allclose(v_flat, v_ref, rtol=1e-3, atol=1e-10)
+    assert all(float(state[p]["step"]) == st.adam_step for p in params)
+    assert all(state[p]["exp_avg"].device == p.device and state[p]["exp_avg"].shape == p.shape for p in params)
 
 
 def test_hip_ppo_load_state_dict_rebuilds_the_engine():
@@ -190,5 +195,6 @@ def test_full_c2_configuration_against_oracle():
     eng.check()
     assert steps == 16
     np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=3e-6)
+    # 16 Adam steps of lr 3e-4: parameters on the scale of a fraction of one step (atol = 0.02 lr)
+    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=0.02 * 3e-4)
     np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)

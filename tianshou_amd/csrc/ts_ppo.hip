@@ -181,18 +181,18 @@ __device__ __forceinline__ void finish_small(float* lds) {
 // Straight float4 copy of a ready-made LDS image (kept current by ppo_adam_kernel): replaces the per-element
 // index arithmetic of stage_weights in the step kernel's two prologues.
 template <int KS1, int NT>
-__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ img) {
+__device__ __forceinline__ void stage_image(float* lds, const float* __restrict__ img, int tid = threadIdx.x) {
     constexpr int N4 = Lds<KS1, 1>::END / 4, PER = (N4 + NT - 1) / NT;
     static_assert(Lds<KS1, 1>::END % 4 == 0, "image size");
     f32x4 v[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int q = threadIdx.x + NT * k;
+        const int q = tid + NT * k;
         v[k] = reinterpret_cast<const f32x4*>(img)[q < N4 ? q : N4 - 1];      // unconditional clamped loads
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int q = threadIdx.x + NT * k;
+        const int q = tid + NT * k;
         if (q < N4) reinterpret_cast<f32x4*>(lds)[q] = v[k];
     }
 }
@@ -242,20 +242,14 @@ __global__ __launch_bounds__(256) void ppo_build_image_kernel(const float* __res
     }
 }
 
-// tanh with <= 2.1e-7 relative error (about 2 ulp): odd polynomial below 0.5, 1 - 2/(e^{2|x|}+1) above
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): absolute error <= 1.2e-7 over the whole range (one v_exp_f32, one
+// v_rcp_f32, four plain VALU).  The activations enter the next layer as sums of O(1) terms, so the absolute error is
+// what matters; the odd polynomial that used to give 2 ulp RELATIVE accuracy below 0.5 cost 11 more instructions per
+// value (1,408 per wave and launch, a quarter of the step kernel's VALU stream).  Saturates to +-1 for large |x|.
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float ax = fabsf(x);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
-    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-    const float x2 = ax * ax;
-    float p = 3.5921280365724810e-3f;                 // 21844/6081075
-    p = p * x2 - 8.8632355299021967e-3f;              // -1382/155925
-    p = p * x2 + 2.1869488536155203e-2f;              // 62/2835
-    p = p * x2 - 5.3968253968253971e-2f;              // -17/315
-    p = p * x2 + 1.3333333333333333e-1f;              // 2/15
-    p = p * x2 - 3.3333333333333331e-1f;              // -1/3
-    const float small = ax + ax * (p * x2);
-    return copysignf(ax < 0.5f ? small : big, x);
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390081777927f);
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return copysignf(t, x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -324,7 +318,7 @@ __device__ __forceinline__ void head_forward(const float* lds, int net, int h, c
                     if (a + 4 < NA) out[a + 4] += h2[t][r] * w1[a];
                 }
             }
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            if (NA > 1 && (r & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bounds the operand-load hoisting
         }
     }
 #pragma unroll
@@ -951,24 +945,490 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step_kernel(StepArgs g, D
     TS_MARK(g, 17);
 }
 
+// =============================================================================================
+// Step kernel, second generation (round 2).  Same arithmetic per sample as net_tile above; what changes is everything
+// around the MFMA chains, which is where a wave of the first version spent 3/4 of its time (phase timing, round 2):
+//   * the weight gradients contract over the WORKGROUP's 128 samples inside the MFMA accumulator: every wave parks
+//     its transposed activation columns in shared [feature][128-sample] tiles (pitch 132: conflict-free ds_write_b32
+//     and ds_read_b128) and then owns whole 32x32 output tiles (dW2: one tile per wave; dW1: the two tiles go to waves
+//     {0,1} for the actor and {2,3} for the critic, the other pair sums the small head / bias / loss rows), which it
+//     writes straight to the workgroup's slab.  7 cross-wave tile reductions (14 barriers, 224 LDS instructions per
+//     wave) per net become 4 barriers; b2's gradient falls out of the A operands already in registers.
+//     The tiles overlay the weight image and the wave scratch areas, which are dead by then (67.6 KB per workgroup).
+//   * the per-sample records are fetched once per tile, not once per net;
+//   * the loss section is branch-free (action / option flags become selects, LDS reads are batched) and its 17
+//     wave reductions are row sums of one small transposed LDS tile instead of DPP butterflies + readlanes;
+//   * slab columns use the layout [W1aug[64][2 KS1] | W2 | b2 | head W | head b | sigma] per net, so that no store
+//     address depends on obs_dim; ppo_reduce_slabs_kernel maps columns to flat parameter indices.
+constexpr int P128 = 132;                      // pitch (floats) of the 128-sample tiles
+constexpr int T2_FLOATS = 128 * P128;          // phase A: dZ2^T rows 0..63 | H1^T rows 64..127
+constexpr int T2_XROW = 64;                    // phase B: dZ1^T rows 0..63 | X^T rows 64..95 | misc slots behind row 96
+constexpr int MISC_ROWS = 9;                   // rows 0..7 head-weight gradients (lane = feature), row 8 = `misc`
+constexpr int MISC_SLOT = MISC_ROWS * 64;
+constexpr int T2_MISC = 96 * P128;
+static_assert(T2_MISC + STEP_WAVES * MISC_SLOT <= T2_FLOATS, "misc slots must fit behind the phase-B tiles");
+
+struct Slab2 {     // column offsets (floats) inside a workgroup slab, see slab2_layout()
+    int w1[2], w2[2], b2[2], head[2], hb[2], sig, loss, width;
+};
+
+__host__ __device__ inline Slab2 slab2_layout(int act, int kp) {
+    Slab2 L;
+    int o = 0;
+    for (int n = 0; n < 2; ++n) {
+        const int n_head = n ? 1 : act;
+        L.w1[n] = o; o += HID * kp;
+        L.w2[n] = o; o += HID * HID;
+        L.b2[n] = o; o += HID;
+        L.head[n] = o; o += n_head * HID;
+        L.hb[n] = o; o += n_head;
+        if (n == 0) { L.sig = o; o += act; }
+    }
+    L.loss = o; o += N_EXTRA;
+    L.width = (o + 3) & ~3;
+    return L;
+}
+
+// slab column -> flat parameter index (>= p_total: the two loss sums; -1: padding).  kp == 0: first-generation
+// slabs, whose columns are the flat layout itself.
+__device__ __forceinline__ int slab_col_to_param(int col, const Dims& d, int kp) {
+    if (kp == 0) return col < d.p_total + N_EXTRA ? col : -1;
+    const Slab2 L = slab2_layout(d.act, kp);
+    if (col >= L.loss) return col < L.loss + N_EXTRA ? d.p_total + (col - L.loss) : -1;
+    const int n = col >= L.w1[1];
+    const int c = col - L.w1[n];
+    if (c < HID * kp) {
+        const int f = c / kp, k = c - f * kp;
+        const int w1 = n ? d.c_w1 : d.a_w1, b1 = n ? d.c_b1 : d.a_b1;
+        return k < d.obs ? w1 + f * d.obs + k : (k == d.obs ? b1 + f : -1);
+    }
+    return (n ? d.c_w2 : d.a_w2) + (c - HID * kp);       // W2, b2, head W, head b(, sigma) are contiguous in both
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// transposed write of one 32-feature block into a 128-sample tile: lane (j, h) register r -> T[row0 + F(r,h)][col]
+__device__ __forceinline__ void tile128_write(float* T, int row0, const f32x16& v, int col, int h) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(row0 + featF(r, h)) * P128 + col] = v[r];
+}
+
+template <bool FIRST_UNUSED = false>
+__device__ __forceinline__ void store_acc(float* p, float v, bool first) {
+    if (!first) v += *p;
+    *p = v;
+}
+
+// One 32x32 output tile contracted over the workgroup's 128 samples: C[m][n] = sum_s A[rowA + m][s] B[rowB + n][s].
+// `rsum` (optional) returns, in lanes 0..31, the row sums of A (sum over the 128 samples of row rowA + lane).
+template <bool WANT_RSUM>
+__device__ __forceinline__ f32x16 tile128_mma(const float* T, int rowA, int rowB, int i, int h, float* rsum) {
+    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* pa = T + (rowA + i) * P128 + 16 * h;
+    const float* pb = T + (rowB + i) * P128 + 16 * h;
+    float rs = 0.f;
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a[q] = ld4(pa + 4 * q); b[q] = ld4(pb + 4 * q); }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        f32x4 an[4], bn[4];
+        if (ch < 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { an[q] = ld4(pa + 32 * (ch + 1) + 4 * q); bn[q] = ld4(pb + 32 * (ch + 1) + 4 * q); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c = mfma32(a[q][e], b[q][e], c);
+            if (WANT_RSUM) rs += (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
+        }
+        if (ch < 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[q] = an[q]; b[q] = bn[q]; }
+        }
+    }
+    if (WANT_RSUM) *rsum = rs + __shfl_xor(rs, 32, 64);
+    return c;
+}
+
+// forward, loss and backward of one net for the wave's 32 samples, up to dZ2 (returned in h2), dZ1, the head-weight
+// gradients gw (lane = feature) and the `misc` row (lanes 0..7 head-bias gradients, 8..15 sigma gradients, 16 loss sum)
+template <int KS1, bool ACTOR>
+__device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const StepArgs& g, const Dims& d,
+                                            const TileIn<KS1>& in, int lane_in, f32x16 (&h1)[2], f32x16 (&h2)[2],
+                                            f32x16 (&dz1)[2], float (&gw)[ACTOR ? ACT_PAD : 1], float& misc) {
+    using L = Lds<KS1, 1>;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));          // see net_tile: keeps lane-dependent addresses out of the prologue
+    constexpr int MK = ACTOR ? 2 : 10;
+    constexpr int NA = ACTOR ? ACT_PAD : 1;
+    const int i = lane & 31, h = lane >> 5;
+    trunk_forward<KS1, 1>(lds, 0, in.x, i, h, h1, h2);
+    TS_MARK(g, MK + 0);
+
+    float dout[NA];
+    const float w = in.w;
+    const float* sm = lds + L::SMALL;
+    float* Qt = scratch;                     // [17][TILE_PITCH]: per-sample quantities, transposed, for the row sums
+    if constexpr (ACTOR) {
+        float mu[ACT_PAD];
+        head_forward<KS1, 1, ACT_PAD>(lds, 0, h, h2, mu);
+        const f32x4 b0 = ld4(sm), b1 = ld4(sm + 4), v0 = ld4(sm + 8), v1 = ld4(sm + 12), s0 = ld4(sm + 16), s1 = ld4(sm + 20);
+        float dlt[ACT_PAD], inv_var[ACT_PAD];
+        float logp = 0.f;
+        int n_act = d.act;
+        asm volatile("" : "+s"(n_act));      // otherwise the 8 per-action constants are hoisted into (spilled) VGPRs
+#pragma unroll
+        for (int k = 0; k < ACT_PAD; ++k) {
+            // padding actions (k >= act): zero weights, bias 0, sigma_param 0 -> mu = 0, act = 0, log sigma = 0: the
+            // term is an exact -0; only the constant has to be switched off
+            const float bm = k < 4 ? b0[k & 3] : b1[k & 3], iv = k < 4 ? v0[k & 3] : v1[k & 3], ls = k < 4 ? s0[k & 3] : s1[k & 3];
+            const float m = mu[k] + bm;
+            dlt[k] = in.act[k] - m;
+            inv_var[k] = 2.f * iv;
+            logp += -(dlt[k] * dlt[k]) * iv - ls - (k < n_act ? LOG_SQRT_2PI : 0.f);
+        }
+        float mean = 0.f, den = 1.f;
+        if (g.adv_norm) { mean = g.adv_stats[0]; den = g.adv_stats[1] + 1e-8f; }      // uniform scalar loads
+        const float A = (in.adv - mean) / den;                                       // ppo.py:184-186 (x - 0) / 1 is exact
+        const bool a2c = g.a2c != 0;
+        // A2C (a2c.py:266-267): term = -logp * adv, d term / d logp = -adv  == "ratio" fixed at 1
+        const float ratio = a2c ? 1.f : expf(logp - in.logp_old);                    // :187
+        const float surr1 = ratio * A;
+        const float lo = 1.f - g.eps_clip, hi = 1.f + g.eps_clip;
+        const float surr2 = fminf(fmaxf(ratio, lo), hi) * A;                         // :190
+        const float clip1 = fminf(surr1, surr2);
+        // torch.min backward: the smaller branch takes the gradient; inside the clip range both branches are the
+        // same value and together pass the full gradient.
+        float basek = (surr1 <= surr2) ? A : 0.f;
+        const float dA = g.dual_clip * A;
+        const bool dual = (g.dual_clip > 0.f) && (A < 0.f);                          // :191-194
+        float term = dual ? -fmaxf(clip1, dA) : -clip1;                              // :196
+        basek = (dual && !(clip1 >= dA)) ? 0.f : basek;
+        term = a2c ? -logp * A : term;
+        basek = a2c ? A : basek;
+        const float dlogp = -basek * ratio * w;
+        const float ent_w = g.ent_coef * w;
+        float dsig[ACT_PAD];
+#pragma unroll
+        for (int k = 0; k < ACT_PAD; ++k) {
+            dout[k] = dlogp * dlt[k] * inv_var[k];                                   // 0 for padding actions (dlt = 0)
+            const float ds = dlogp * (dlt[k] * dlt[k] * inv_var[k] - 1.f) - ent_w;   // entropy: d/ds = 1
+            dsig[k] = k < n_act ? ds : 0.f;
+        }
+        // rows 0..7 dout, 8..15 dsig, 16 loss term: half 0 writes the dout rows and the loss row, half 1 the dsig rows
+#pragma unroll
+        for (int k = 0; k < ACT_PAD; ++k) Qt[(8 * h + k) * TILE_PITCH + i] = h ? dsig[k] : dout[k];
+        if (h == 0) Qt[16 * TILE_PITCH + i] = term * w;
+    } else {
+        float v[1];
+        head_forward<KS1, 1, 1>(lds, 0, h, h2, v);
+        const float value = v[0] + sm[24];
+        const float ret = in.ret;
+        const float vf1 = (ret - value) * (ret - value);
+        // ppo.py:199-206.  torch.max backward: the larger branch takes the gradient, ties split it; clamp passes the
+        // gradient inside [-eps, eps].  Inside the range v_clip = vo + (v - vo) differs from v by rounding, so either
+        // branch may win there.
+        const float vo = in.v_old;
+        const float dvo = value - vo;
+        const float vclip = vo + fminf(fmaxf(dvo, -g.eps_clip), g.eps_clip);
+        const float vf2 = (ret - vclip) * (ret - vclip);
+        const float g1 = -2.f * (ret - value);
+        const float g2 = (dvo >= -g.eps_clip && dvo <= g.eps_clip) ? -2.f * (ret - vclip) : 0.f;
+        const float dv_clip = (vf1 > vf2) ? g1 : ((vf2 > vf1) ? g2 : 0.5f * (g1 + g2));
+        const bool vc = g.value_clip != 0;
+        const float term = vc ? fmaxf(vf1, vf2) : vf1;                               // :208
+        const float dv = vc ? dv_clip : g1;
+        dout[0] = dv * g.vf_coef * w;
+        Qt[(16 * h) * TILE_PITCH + i] = h ? term * w : dout[0];                      // row 0: dout, row 16: loss term
+    }
+    wave_lds_sync();
+    {
+        const int row = lane < 16 ? lane : 16;
+        const float* rp = Qt + row * TILE_PITCH;
+        f32x4 q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = ld4(rp + 4 * k);
+        float sacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc += (q[k][0] + q[k][1]) + (q[k][2] + q[k][3]);
+        const bool mine = ACTOR ? (lane <= 16) : (lane == 0 || lane == 16);
+        misc = mine ? sacc : 0.f;
+    }
+    wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 1);
+
+    // ---- head weight gradient: gw[a][f] = sum_s dout[s][a] * H2[s][f]  (lane = feature f).
+    // dout of sample s is broadcast through the 4 padding columns of row s of the two tiles.
+    float* SA = scratch;
+    float* SB = scratch + TILE_SIZE;
+    tile_write(SA, h2[0], i, h);
+    tile_write(SB, h2[1], i, h);
+    if (lane < 32) {
+        if constexpr (ACTOR) {
+            const f32x4 d0 = {dout[0], dout[1], dout[2], dout[3]};
+            const f32x4 d1 = {dout[4], dout[5], dout[6], dout[7]};
+            *reinterpret_cast<f32x4*>(SA + lane * TILE_PITCH + 32) = d0;
+            *reinterpret_cast<f32x4*>(SB + lane * TILE_PITCH + 32) = d1;
+        } else {
+            SA[lane * TILE_PITCH + 32] = dout[0];
+        }
+    }
+    wave_lds_sync();
+    {
+        const float* rowp = (lane < 32 ? SA : SB) + (lane & 31) * TILE_PITCH;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) gw[a] = 0.f;
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 hv = ld4(rowp + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int smp = 4 * q + e;
+                if constexpr (ACTOR) {
+                    const f32x4 d0 = ld4(SA + smp * TILE_PITCH + 32);        // uniform address
+                    const f32x4 d1 = ld4(SB + smp * TILE_PITCH + 32);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        gw[a] += d0[a] * hv[e];
+                        gw[a + 4] += d1[a] * hv[e];
+                    }
+                } else {
+                    gw[0] += SA[smp * TILE_PITCH + 32] * hv[e];
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 2);
+
+    // ---- dZ2 = (dout . Whead) * (1 - h2^2)   (in place in h2)
+    {
+        const float* wh = lds + L::WH + h * (2 * 16 * ACT_PAD);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* p = wh + (t * 16 + r) * ACT_PAD;
+                float dh;
+                if constexpr (ACTOR) {
+                    const f32x4 w0 = ld4(p);
+                    const f32x4 w1 = ld4(p + 4);
+                    dh = dout[0] * w0[0] + dout[1] * w0[1] + dout[2] * w0[2] + dout[3] * w0[3] +
+                         dout[4] * w1[0] + dout[5] * w1[1] + dout[6] * w1[2] + dout[7] * w1[3];
+                } else {
+                    dh = dout[0] * p[0];
+                }
+                const float hv = h2[t][r];
+                h2[t][r] = dh * (1.f - hv * hv);
+                if (ACTOR && (r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- dH1^T = W2^T . dZ2^T, then dZ1 = dH1 * (1 - h1^2)
+    {
+        const float* w2 = lds + L::W2;
+#pragma unroll
+        for (int t1 = 0; t1 < 2; ++t1) {
+            f32x16 accd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accd = mfma32(w2[(32 * t + featF(r, h)) * W2_PITCH + 32 * t1 + i], h2[t][r], accd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float hv = h1[t1][r];
+                accd[r] = accd[r] * (1.f - hv * hv);
+            }
+            dz1[t1] = accd;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    TS_MARK(g, MK + 3);
+}
+
+// the weight-gradient half of one net: shared 128-sample tiles, whole output tiles per wave, direct slab stores
+template <int KS1, bool ACTOR>
+__device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const Dims& d, const TileIn<KS1>& in,
+                                          const f32x16 (&h1)[2], const f32x16 (&dz2)[2], const f32x16 (&dz1)[2],
+                                          const float (&gw)[ACTOR ? ACT_PAD : 1], float misc, int wave, int lane_in,
+                                          float* slab, const Slab2& SL, bool first) {
+    constexpr int MK = ACTOR ? 2 : 10;
+    constexpr int NA = ACTOR ? ACT_PAD : 1;
+    constexpr int net = ACTOR ? 0 : 1;
+    constexpr int KP = 2 * KS1;
+    // lane, wave and the slab pointer are made opaque here: otherwise LLVM hoists the (loop-invariant) store and tile
+    // addresses of the fully unrolled body out of the tile loop into the kernel prologue, where they are spilled
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane), "+v"(wave), "+s"(slab));
+    const int i = lane & 31, h = lane >> 5;
+    const int col = 32 * wave + i;
+    float* T = lds;
+    __syncthreads();                       // B1: every wave is done with the weight image and its scratch area
+    tile128_write(T, 0, dz2[0], col, h);
+    tile128_write(T, 32, dz2[1], col, h);
+    tile128_write(T, 64, h1[0], col, h);
+    tile128_write(T, 96, h1[1], col, h);
+    __syncthreads();                       // B2
+    TS_MARK(g, MK + 4);
+    {
+        // dW2[f2][f1] = sum_s dZ2[s][f2] H1[s][f1]: wave (tM, tN) owns rows 32 tM.., columns 32 tN..; db2 = row sums
+        const int tM = wave >> 1, tN = wave & 1;
+        float rs;
+        const f32x16 c = tile128_mma<true>(T, 32 * tM, 64 + 32 * tN, i, h, &rs);
+        float* p = slab + SL.w2[net] + (32 * tM + 4 * h) * HID + 32 * tN + i;
+        if (first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * HID] = c[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * HID] += c[r];
+        }
+        if (tN == 0 && h == 0) store_acc(slab + SL.b2[net] + 32 * tM + i, rs, first);
+    }
+    __syncthreads();                       // B3: all reads of the phase-A tiles are done
+    TS_MARK(g, MK + 5);
+    tile128_write(T, 0, dz1[0], col, h);
+    tile128_write(T, 32, dz1[1], col, h);
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) T[(T2_XROW + KS1 * h + s) * P128 + col] = in.x[s];
+    {
+        float* M = T + T2_MISC + wave * MISC_SLOT;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) M[a * 64 + lane] = gw[a];
+        M[8 * 64 + lane] = misc;
+    }
+    __syncthreads();                       // B4
+    // the two dW1 tiles go to one wave pair, the small rows to the other; the pairs swap roles between the nets so
+    // that every wave issues the same number of MFMAs per launch
+    const bool w1_wave = ACTOR ? (wave < 2) : (wave >= 2);
+    if (w1_wave) {
+        // dW1aug[f1][k] = sum_s dZ1[s][f1] Xaug[s][k]   (k == obs is the bias column; rows of X^T beyond 2 KS1 hold
+        // stale but finite H1 values whose output columns are not stored)
+        const int tM = wave & 1;
+        const f32x16 c = tile128_mma<false>(T, 32 * tM, T2_XROW, i, h, nullptr);
+        if (i < KP) {
+            float* p = slab + SL.w1[net] + (32 * tM + 4 * h) * KP + i;
+            if (first) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * KP] = c[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * KP] += c[r];
+            }
+        }
+    } else {
+        const int part = wave & 1;
+        const float* M = T + T2_MISC;
+        const int n_head = ACTOR ? d.act : 1;
+        if (ACTOR) {
+            // part 0: rows 0..3 and the misc row, part 1: rows 4..7
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 4 * part + q;
+                float v = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + row * 64 + lane];
+                if (row < n_head) store_acc(slab + SL.head[net] + row * HID + lane, v, first);
+            }
+        } else if (part == 1) {
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + lane];
+            store_acc(slab + SL.head[net] + lane, v, first);
+        }
+        if (part == 0) {
+            float v = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + 8 * 64 + lane];
+            if (lane < 8) { if (lane < n_head) store_acc(slab + SL.hb[net] + lane, v, first); }
+            else if (lane < 16) { if (ACTOR && lane - 8 < d.act) store_acc(slab + SL.sig + lane - 8, v, first); }
+            else if (lane == 16) store_acc(slab + SL.loss + net, v, first);
+        }
+    }
+    TS_MARK(g, MK + 6);
+}
+
+template <int KS1>
+__global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, Dims d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = Lds<KS1, 1>;
+    static_assert(L::END + STEP_WAVES * 2 * TILE_SIZE <= T2_FLOATS, "weight image + wave scratch must fit under the tiles");
+    const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+    const Slab2 SL = slab2_layout(d.act, 2 * KS1);
+
+    const int64_t n_tiles = (g.n_rows + 31) / 32;
+    const int64_t per_iter = (int64_t)gridDim.x * STEP_WAVES;
+    const int64_t n_iter = (n_tiles + per_iter - 1) / per_iter;   // same for every wave: barriers inside
+    const int64_t tile0 = (int64_t)blockIdx.x * STEP_WAVES + wave0;
+    float* slab = g.slabs + (int64_t)blockIdx.x * g.slab_w;
+
+    TS_MARK(g, 0);
+    for (int64_t it = 0; it < n_iter; ++it) {
+        // per-iteration opaque copies: nothing lane- / wave-dependent is worth hoisting out of a loop that usually runs
+        // once, and what LLVM hoists here ends up spilled in the prologue
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane), "+v"(wave));
+        float* scratch = lds + L::END + wave * (2 * TILE_SIZE);
+        // order: row ids (one dependent load) -> record gathers -> weight image (independent of both)
+        const RowId row0 = row_fetch(g, it * per_iter + tile0, lane);
+        const RecFetch<KS1> f = rec_fetch<KS1>(g, row0, lane);
+        if (it > 0) __syncthreads();          // the previous iteration's phase-B readers are done
+        stage_image<KS1, STEP_THREADS>(lds, g.image, 64 * wave + lane);
+        const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
+        __syncthreads();
+        TS_MARK(g, 1);
+        const bool first = it == 0;
+        f32x16 h1[2], h2[2], dz1[2];
+        float misc;
+        {
+            float gw[ACT_PAD];
+            net_fwd_bwd<KS1, true>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_wgrad<KS1, true>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
+        }
+        __syncthreads();                      // phase-B readers of the actor are done: the image region is free
+        TS_MARK(g, 18);
+        {
+            int tid = 64 * wave + lane;
+            asm volatile("" : "+v"(tid));       // see above: keeps the six load addresses out of the prologue
+            stage_image<KS1, STEP_THREADS>(lds, g.image + L::END, tid);
+        }
+        __syncthreads();
+        TS_MARK(g, 9);
+        {
+            float gw[1];
+            net_fwd_bwd<KS1, false>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_wgrad<KS1, false>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
+        }
+    }
+    TS_MARK(g, 17);
+}
+
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
 // partial sum of squares over the parameter columns (for the global gradient norm).
 constexpr int RED_THREADS = 1024;
 
 __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                                       int n_slabs, int slab_w, int n_cols,
-                                                                       int n_params, float* __restrict__ grad,
+                                                                       int n_slabs, int slab_w, Dims d, int kp,
+                                                                       float* __restrict__ grad,
                                                                        float* __restrict__ sumsq_part,
                                                                        const float* __restrict__ params,
-                                                                       int sig_off, int act,
                                                                        float* __restrict__ losses,
                                                                        float* __restrict__ parts) {
     __shared__ float red[RED_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const int n_params = d.p_total;
     float s = 0.f;
-    if (col < n_cols) {
+    if (col < slab_w) {
 #pragma unroll 16
         for (int k = wave; k < n_slabs; k += RED_THREADS / 64) s += slabs[(int64_t)k * slab_w + col];
     }
@@ -978,12 +1438,14 @@ __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const flo
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
+        // slab column -> flat parameter index (second-generation slabs keep W1 | b1 as one augmented matrix)
+        const int pidx = col < slab_w ? slab_col_to_param(col, d, kp) : -1;
         // data-parallel path (parts != NULL): grad holds only the n_params gradient columns, the two loss sums go
         // to parts[1] (clip) and parts[2] (vf); parts[3] = entropy below, parts[0] is composed by the caller
-        if (col < (parts ? n_params : n_cols)) grad[col] = t;
-        if (parts && col == n_params) parts[1] = t;
-        if (parts && col == n_params + 1) parts[2] = t;
-        float q = (col < n_params) ? t * t : 0.f;
+        if (pidx >= 0 && pidx < (parts ? n_params : n_params + N_EXTRA)) grad[pidx] = t;
+        if (parts && pidx == n_params) parts[1] = t;
+        if (parts && pidx == n_params + 1) parts[2] = t;
+        float q = (pidx >= 0 && pidx < n_params) ? t * t : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
         if (lane == 0) sumsq_part[blockIdx.x] = q;
@@ -993,8 +1455,8 @@ __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const flo
             // for every sample, so its batch mean (ppo.py:210) is the value itself.  Computed here,
             // before the Adam kernel touches sigma_param.
             float ent = 0.f;
-            for (int k = 0; k < act; ++k)
-                ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(params[sig_off + k]));
+            for (int k = 0; k < d.act; ++k)
+                ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(params[d.a_sig + k]));
             if (losses) losses[3] = ent;
             if (parts) parts[3] = ent;
         }
@@ -1140,6 +1602,17 @@ size_t step_lds_bytes() {
 template <int KS1>
 size_t infer_lds_bytes() { return sizeof(float) * (size_t)Lds<KS1, 2>::END; }
 
+// first-generation step kernel (per-tile cross-wave reductions, flat slab columns): TS_PPO_STEP_V1=1, kept for A/B runs
+inline bool step_v1() {
+    static const bool v1 = [] { const char* e = getenv("TS_PPO_STEP_V1"); return e && atoi(e) != 0; }();
+    return v1;
+}
+
+// floats per workgroup slab
+inline int slab_width(const Dims& d, int ks) {
+    return step_v1() ? ((d.p_total + N_EXTRA + 3) & ~3) : slab2_layout(d.act, 2 * ks).width;
+}
+
 inline int ks1_for(int obs) { return (obs + 2) / 2; }  // ceil((obs + 1) / 2)
 
 #define TS_KS1_DISPATCH(ks, CALL)                                                      \
@@ -1204,16 +1677,19 @@ int n_compute_units() {
 // launches forward/backward of one minibatch into the slabs
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
-    const size_t lds = step_lds_bytes<KS1>();
+    const bool v1 = step_v1();
+    const size_t lds = v1 ? step_lds_bytes<KS1>() : sizeof(float) * (size_t)T2_FLOATS;
+    const void* fn = v1 ? reinterpret_cast<const void*>(&ppo_step_kernel<KS1>)
+                        : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>);
     static bool attr_done = false;
     if (!attr_done) {
-        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step_kernel<KS1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     {
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-        hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        if (v1) hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        else hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1222,7 +1698,8 @@ int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hi
 inline int step_grid(int64_t n_rows) {
     const int64_t tiles = (n_rows + 31) / 32;
     int64_t wg = (tiles + STEP_WAVES - 1) / STEP_WAVES;
-    const int cap = 2 * n_compute_units();   // two 256-thread workgroups per CU
+    static const int per_cu = [] { const char* e = getenv("TS_PPO_WG_PER_CU"); return e ? atoi(e) : 2; }();
+    const int cap = per_cu * n_compute_units();   // two 256-thread workgroups per CU
     if (wg > cap) wg = cap;
     if (wg < 1) wg = 1;
     return (int)wg;
@@ -1314,8 +1791,7 @@ int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, f
     {
         ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
         hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
-                           n_wg, slab_w, d.p_total + N_EXTRA, d.p_total, grad, sumsq, g.params, d.a_sig, d.act,
-                           losses, parts);
+                           n_wg, slab_w, d, step_v1() ? 0 : 2 * ks, grad, sumsq, g.params, losses, parts);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1458,7 +1934,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     }
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
+    const int slab_w = slab_width(d, ks);
     const int rw = rec_width(obs_dim, act_dim);
     const WsLayout wl = ws_layout(step_grid(max_rows), slab_w, n_steps);
     // behind the fixed part: device copy of the minibatch offsets, then the packed records
@@ -1536,7 +2012,7 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
                "ts_ppo_grad: rec must be 16-byte aligned");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
+    const int slab_w = slab_width(d, ks);
     const WsLayout wl = ws_layout(step_grid(n_rows), slab_w, 1);
     rc = ts::ws_reserve(ws, wl.total);
     if (rc != TS_OK) return rc;
@@ -1568,7 +2044,7 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     TS_REQUIRE(n_marks >= 18 && n_rows >= 1, TS_ERR_INVALID_ARG, "ts_debug_ppo_step_cycles: need >= 18 marks");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const int slab_w = (d.p_total + N_EXTRA + 3) & ~3;
+    const int slab_w = slab_width(d, ks);
     const int n_wg = step_grid(n_rows);
     const WsLayout wl = ws_layout(n_wg, slab_w, 1);
     const ImageBuf ib = image_buf(d, ks);
