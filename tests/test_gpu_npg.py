@@ -114,8 +114,15 @@ def test_critic_step_vs_oracle():
         grad = torch.empty(eng.lay["critic_count"], device="cuda")
         loss = eng.critic_step(obs, ret, grad_out=grad, apply=False)
         assert abs(float(loss) - float(vf)) <= 1e-5 * abs(float(vf))
+        # float64 evaluation of the same gradient: the bias gradients are sums of 3000 terms that cancel to ~1e-3 of
+        # their magnitude, so the float32 autograd result itself (whose summation order depends on the host's thread
+        # count) is only good to a few 1e-6..1e-5 there; the bar is 1e-5 or "as close to float64 as the reference"
+        p64 = {k: v.double() for k, v in st.params.items()}
+        pc64 = {k: p64[k].clone().requires_grad_(True) for k in C_KEYS}
+        vf64 = torch.nn.functional.mse_loss(ret.double(), OP.critic_forward({**p64, **pc64}, obs.double()).flatten())
+        gs64 = dict(zip(C_KEYS, torch.autograd.grad(vf64, [pc64[k] for k in C_KEYS])))
         for t, k in zip(NG.critic_flat_to_torch(grad, obs_dim, 64), C_KEYS):
-            assert rel_err(t.cpu(), gs[k]) < 1e-5, k
+            assert rel_err(t.cpu(), gs64[k]) < max(1e-5, 2 * rel_err(gs[k], gs64[k])), k
         ON._critic_adam(st, cfg, gs)
         eng.critic_step(obs, ret)
         for t, k in zip(NG.critic_flat_to_torch(eng.critic, obs_dim, 64), C_KEYS):

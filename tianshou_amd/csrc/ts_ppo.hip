@@ -1013,10 +1013,18 @@ __device__ __forceinline__ void tile128_write(float* T, int row0, const f32x16& 
     for (int r = 0; r < 16; ++r) T[(row0 + featF(r, h)) * P128 + col] = v[r];
 }
 
-template <bool FIRST_UNUSED = false>
+// Slab stores are write-through (relaxed agent-scope atomic store = `global_store_dword ... sc1`): the 23 MB of slabs
+// would otherwise sit dirty in the eight L2s until the kernel boundary and be written back there, in front of the
+// reduction kernel that reads them (MI355X_MICROARCH.md, "boundary" / "publish-large" rows).
+#ifndef TS_SLAB_PLAIN_STORES
+__device__ __forceinline__ void slab_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+__device__ __forceinline__ void slab_st(float* p, float v) { *p = v; }
+#endif
+
 __device__ __forceinline__ void store_acc(float* p, float v, bool first) {
     if (!first) v += *p;
-    *p = v;
+    slab_st(p, v);
 }
 
 // One 32x32 output tile contracted over the workgroup's 128 samples: C[m][n] = sum_s A[rowA + m][s] B[rowB + n][s].
@@ -1286,10 +1294,10 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
         float* p = slab + SL.w2[net] + (32 * tM + 4 * h) * HID + 32 * tN + i;
         if (first) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * HID] = c[r];
+            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, c[r]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * HID] += c[r];
+            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, p[((r & 3) + 8 * (r >> 2)) * HID] + c[r]);
         }
         if (tN == 0 && h == 0) store_acc(slab + SL.b2[net] + 32 * tM + i, rs, first);
     }
@@ -1318,10 +1326,10 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
             float* p = slab + SL.w1[net] + (32 * tM + 4 * h) * KP + i;
             if (first) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * KP] = c[r];
+                for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, c[r]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * KP] += c[r];
+                for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, p[((r & 3) + 8 * (r >> 2)) * KP] + c[r]);
             }
         }
     } else {
@@ -1485,12 +1493,19 @@ constexpr int ADAM_THREADS = 256;
 __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     __shared__ float red[ADAM_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this thread's parameter: issue its (independent) loads before the norm's dependent chain, one memory round
+    // trip instead of two
+    const int p = blockIdx.x * ADAM_THREADS + tid;
+    const bool mine = a.apply && p < a.n_params;
+    const int pc = mine ? p : 0;
+    float g_raw = a.grad[pc], m = a.m[pc], v = a.v[pc], par = a.params[pc];
+    const int slot = (mine && a.image) ? a.inv[pc] : -1;
     // global gradient norm: every workgroup re-reduces the (few) partials in the same order
     float sq = 0.f;
     if (a.sumsq_part) {
         for (int k = tid; k < a.n_part; k += ADAM_THREADS) sq += a.sumsq_part[k];
     } else {
-        for (int p = tid; p < a.n_params; p += ADAM_THREADS) { const float gq = a.grad[p]; sq += gq * gq; }
+        for (int q = tid; q < a.n_params; q += ADAM_THREADS) { const float gq = a.grad[q]; sq += gq * gq; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
@@ -1511,21 +1526,17 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         a.losses[1] = clip;
         a.losses[2] = vf;
     }
-    if (!a.apply) return;
-    const int p = blockIdx.x * ADAM_THREADS + tid;
-    if (p < a.n_params) {
-        const float gq = a.grad[p] * scale;
-        float m = a.m[p], v = a.v[p];
+    if (mine) {
+        const float gq = g_raw * scale;
         m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
         v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
         const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        const float np_ = a.params[p] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        const float np_ = par + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
         a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
         if (a.image) {
-            const int t = a.inv[p];
-            if (t >= 0) a.image[t] = np_;
+            if (slot >= 0) a.image[slot] = np_;
             const int k = p - a.sig_off;
             if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
                 const float sigma = expf(np_);
