@@ -43,9 +43,10 @@ PEAK_HBM_GBPS = 8000.0
 # this very command, mean per launch; FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte
 # requests of 16-byte-per-lane loads at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM").  Counters cannot be read live
 # from inside bench.py, so the line carries the profiled value of the same workload.
-STEP_HBM_TRAFFIC_BYTES = (2 * 8926 + 22230) * 1024      # records + images read, 512 gradient slabs written
-GAE_HBM_TRAFFIC_BYTES = (2 * 9353 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
-TRAFFIC_SOURCE = "profiles/r01_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
+STEP_HBM_TRAFFIC_BYTES = (2 * 8350 + 27920) * 1024      # records + images read; 512 gradient slabs written through (sc1)
+GAE_HBM_TRAFFIC_BYTES = (2 * 9342 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
+TRAFFIC_SOURCE = "profiles/r02_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
+H2D_BYTES_PER_UPDATE = N_TRANS * (2 * OBS * 4 + ACT * 4 + 8 + 2)   # obs, obs_next, act f32; rew f64; two flag bytes
 
 
 def make_rollout(device, seed):
@@ -177,7 +178,7 @@ def time_gae_large(learner, log2n=24, iters=10):
     return n, (prof["gae_maps"][0] + prof["gae_apply"][0]) / iters * 1e-3
 
 
-def cpu_baseline(sample_steps=2):
+def cpu_baseline(sample_steps=8):
     """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
     kernels) on the host cores, bounded sample: full preprocess of one 2^20 rollout in
     max_batchsize=65536 chunks + `sample_steps` minibatch gradient steps of 65536; whole-update
@@ -203,12 +204,18 @@ def cpu_baseline(sample_steps=2):
     st = OP.PPOState(params=OP.unflatten_params(flat, OBS, ACT))
     idx = np.arange(N_TRANS)
     unf = (np.arange(N_ENV) + 1) * T_STEPS - 1
+    O.compute_episodic_return(rew[:4096], term[:4096], trunc[:4096], idx[:4096], unf[:1], np.zeros(4096, np.float32),
+                              np.zeros(4096, np.float32), 0.99, 0.95)       # library load / first-touch outside the clock
+    OP.preprocess(OP.PPOState(params=OP.unflatten_params(flat, OBS, ACT)), ocfg, obs[:65536], obs_next[:65536], act[:65536],
+                  rew[:65536], term[:65536], trunc[:65536], idx[:65536], unf[:32])
     t0 = time.perf_counter()
     pre = OP.preprocess(st, ocfg, obs, obs_next, act, rew, term, trunc, idx, unf)
     t_pre = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.compute_episodic_return(rew, term, trunc, idx, unf, pre["v_s"].numpy(), pre["v_s"].numpy(), 0.99, 0.95)
-    t_gae = time.perf_counter() - t0
+    t_gae = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.compute_episodic_return(rew, term, trunc, idx, unf, pre["v_s"].numpy(), pre["v_s"].numpy(), 0.99, 0.95)
+        t_gae = min(t_gae, time.perf_counter() - t0)
     perm = rng.permutation(N_TRANS)
     sub = perm[: MINIBATCH * sample_steps]
     data = {"obs": obs[sub], "act": act[sub]}
@@ -220,13 +227,146 @@ def cpu_baseline(sample_steps=2):
     value = steps_per_update / (t_pre + steps_per_update * t_step)
     return {
         "value": value, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"oracle (torch-fp32 CPU + C restatement of the njit kernels): 1 full preprocess of 2^20 "
-                   f"transitions ({t_pre:.2f} s, of which GAE scan {t_gae * 1e3:.1f} ms single-thread = "
+        "sample": (f"PORT of the reference path, not the reference itself (oracle/: torch-fp32 CPU ops in the reference's "
+                   f"order + a -O3 C restatement of its numba kernels): 1 full preprocess of 2^20 transitions "
+                   f"({t_pre:.2f} s, of which the GAE scan {t_gae * 1e3:.1f} ms single-thread = "
                    f"{N_TRANS / t_gae / 1e6:.0f} M transitions/s) + {sample_steps} gradient steps of 65536 "
-                   f"({t_step * 1e3:.1f} ms each); extrapolated to the 160-step update"),
+                   f"({t_step * 1e3:.1f} ms each, {torch.get_num_threads()} threads); whole-update rate = 160 / (t_pre + 160 t_step)"),
         "gae_transitions_per_s": N_TRANS / t_gae,
         "inner_update_steps_per_s": 1.0 / t_step,
     }
+
+
+def rocm_eager_baseline(device, steps=16):
+    """SURVEY 8d's second baseline: what a Tianshou user has on this GPU today - the reference's own sequence of torch
+    operations (oracle/oracle_ppo.py, pinned to the reference by tests/golden) with every tensor on the MI355X, i.e.
+    PyTorch-ROCm eager kernels, the GAE recurrence on the host like the reference's numba kernel.  Bounded sample:
+    one preprocess of the 2^20 rollout (data resident) + `steps` minibatch steps of 65536."""
+    from oracle import oracle_ppo as OP
+
+    g = torch.Generator(device=device).manual_seed(5)
+    obs = torch.randn(N_TRANS, OBS, device=device, generator=g)
+    obs_next = torch.randn(N_TRANS, OBS, device=device, generator=g)
+    act = torch.randn(N_TRANS, ACT, device=device, generator=g)
+    rng = np.random.default_rng(0)
+    rew = rng.normal(size=N_TRANS).astype(np.float32).astype(np.float64)
+    term = rng.random(N_TRANS) < 0.005
+    trunc = np.zeros(N_TRANS, bool)
+    c = mujoco_cfg()
+    ocfg = OP.PPOConfig(gamma=c.gamma, gae_lambda=c.gae_lambda, eps_clip=c.eps_clip, value_clip=True,
+                        advantage_normalization=False, vf_coef=c.vf_coef, ent_coef=c.ent_coef,
+                        max_grad_norm=c.max_grad_norm, return_scaling=True, lr=c.lr, max_batchsize=65536)
+    st = OP.PPOState(params={k: v.to(device) for k, v in OP.unflatten_params(init_flat_params(0), OBS, ACT).items()})
+    idx = np.arange(N_TRANS)
+    unf = (np.arange(N_ENV) + 1) * T_STEPS - 1
+    pre = OP.preprocess(st, ocfg, obs, obs_next, act, rew, term, trunc, idx, unf)          # warm-up (kernel loading)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pre = OP.preprocess(st, ocfg, obs, obs_next, act, rew, term, trunc, idx, unf)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter() - t0
+    n_sub = MINIBATCH * 2
+    sub = torch.randperm(N_TRANS, device=device, generator=g)[:n_sub]
+    data = {"obs": obs[sub], "act": act[sub]}
+    pre_s = {k: pre[k][sub] for k in ("v_s", "returns", "adv", "logp_old")}
+    perms = [np.arange(n_sub)] * (steps // 2 + 1)
+    OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, perms[:1])                              # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    OP.update(st, ocfg, data, pre_s, MINIBATCH, steps // 2, perms[:steps // 2])
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / (2 * (steps // 2))
+    n_steps = REPEAT * (N_TRANS // MINIBATCH)
+    return {"value": n_steps / (t_pre + n_steps * t_step), "unit": "update-steps/s", "kind": "port",
+            "device": "MI355X, PyTorch-ROCm eager (same torch build the engine links against)",
+            "sample": (f"oracle_ppo with tensors on cuda: 1 preprocess of 2^20 transitions ({t_pre * 1e3:.0f} ms, GAE "
+                       f"recurrence on the host as in the reference) + {2 * (steps // 2)} gradient steps of 65536 "
+                       f"({t_step * 1e3:.2f} ms each); whole-update rate = 160 / (t_pre + 160 t_step)"),
+            "inner_update_steps_per_s": 1.0 / t_step}
+
+
+def h2d_seconds(device, reps=3):
+    """Wall time of moving one update()'s 2^20-transition batch (obs, obs_next, act, rew, flags: 179 MB) from pinned
+    host memory to HBM - what `value` would additionally pay if the boundary handed over host buffers."""
+    host = [torch.empty((N_TRANS, OBS), dtype=torch.float32).pin_memory(), torch.empty((N_TRANS, OBS), dtype=torch.float32).pin_memory(),
+            torch.empty((N_TRANS, ACT), dtype=torch.float32).pin_memory(), torch.empty(N_TRANS, dtype=torch.float64).pin_memory(),
+            torch.empty(N_TRANS, dtype=torch.uint8).pin_memory(), torch.empty(N_TRANS, dtype=torch.uint8).pin_memory()]
+    dst = [torch.empty_like(h, device=device) for h in host]
+    best = 1e9
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for h, d in zip(host, dst):
+            d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def hook_level(device, updates=3, permutations="device"):
+    """The drop-in as Tianshou calls it: `HipPPO.update(buffer, batch_size, repeat)` (tianshou_amd/integration.py) on a
+    HOST replay buffer of the C2 shape.  The reference package is not on the GPU box, so the subclass is built over the
+    stand-ins of tests/standin.py (same attribute surface, tests/test_standin_surface.py); the hook bodies, the device
+    mirror, the engine and the write-back are the production code.  Reports the first update (whole buffer crosses
+    PCIe: mirror snapshot) and the steady state (nothing new to copy)."""
+    from torch import nn
+
+    from tests import standin as SI
+    from tianshou_amd.integration import make_hip_ppo
+
+    HipPPO = make_hip_ppo("ppo", ref=SI)
+    torch.manual_seed(0)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(OBS, [64, 64], nn.Tanh), ACT, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(OBS, [64, 64], nn.Tanh))
+    with torch.no_grad():
+        actor.sigma_param.fill_(-0.5)
+    c = mujoco_cfg()
+    algo = HipPPO(policy=SI.Policy(actor), critic=critic, device=str(device), permutations=permutations, lr=c.lr, eps_clip=c.eps_clip, value_clip=True,
+                  advantage_normalization=False, vf_coef=c.vf_coef, ent_coef=c.ent_coef, max_grad_norm=c.max_grad_norm,
+                  return_scaling=True, gamma=c.gamma, gae_lambda=c.gae_lambda).to(device)
+    buf = SI.VectorReplayBuffer(N_TRANS, N_ENV, obs_shape=(OBS,), act_shape=(ACT,))
+    rng = np.random.default_rng(3)
+    # filled like N_ENV x T_STEPS add() calls would (env-major storage, every sub-buffer full and unwrapped)
+    buf.obs[:] = rng.standard_normal((N_TRANS, OBS), dtype=np.float32)
+    buf.obs_next[:] = rng.standard_normal((N_TRANS, OBS), dtype=np.float32)
+    buf.act[:] = rng.standard_normal((N_TRANS, ACT), dtype=np.float32)
+    buf.rew[:] = rng.standard_normal(N_TRANS, dtype=np.float32)
+    buf.terminated[:] = rng.random(N_TRANS) < 0.005
+    buf.done[:] = buf.terminated
+    for e, sb in enumerate(buf.buffers):
+        sb._size, sb._insertion_idx = T_STEPS, 0
+        buf._lengths[e] = T_STEPS
+        buf.last_index[e] = (e + 1) * T_STEPS - 1
+    algo.policy.is_within_training_step = True
+    times = []
+    for _ in range(updates + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = algo.update(buf, MINIBATCH, REPEAT)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    n_steps = stats.gradient_steps
+    return {"first_update_steps_per_s": n_steps / times[0], "first_update_ms": times[0] * 1e3,
+            "steady_update_steps_per_s": n_steps / min(times[1:]), "steady_update_ms": min(times[1:]) * 1e3,
+            "permutations": permutations,
+            "note": "HipPPO.update() over a host-filled VectorReplayBuffer stand-in; first = full mirror upload + engine "
+                    "creation, steady = no new slots to copy"}
+
+
+def other_workloads():
+    """Short runs of the C3 / C5 / Atari-shape PPO rows so that they are measured by the same driver command."""
+    out = {}
+    for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 0))):
+        try:
+            import importlib
+
+            r = importlib.import_module(mod).run(*args, with_cpu=False)
+            out[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r.get("ms_per_step"),
+                         "roofline_frac": (r.get("roofline") or {}).get("frac"), "config": r.get("config")}
+        except Exception as e:                                   # a side leg must not take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -235,6 +375,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the ROCm-eager baseline, the hook-level leg, the H2D "
+                    "measurement and the other workloads (profiling runs)")
     ap.add_argument("--workload", default="ppo",
                     choices=["ppo", "dqn", "sac", "ppo_atari", "td3", "ddpg", "dsac", "qrdqn", "c51", "rainbow", "npg", "trpo", "redq", "ppo_discrete", "reinforce", "drqn"],
                     help="ppo = BASELINE.json's metric on C2 (default); dqn / sac = the C3 / C5 rows (bench_dqn.py, "
@@ -321,7 +463,7 @@ def main():
             step_ms, step_n = prof["ppo_step"]
             avg_s = step_ms / max(step_n, 1) * 1e-3
             achieved = FLOP_PER_SAMPLE_STEP * MINIBATCH / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": "ppo_step_kernel", "achieved": achieved,
+            roof = {"bound": "mfma", "kernel": "ppo_step2_kernel", "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": STEP_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
                     "avg_launch_us": avg_s * 1e6, "launches": step_n,
@@ -352,10 +494,24 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_cpu_baseline:
+        t_h2d = h2d_seconds(device)
+        t_update = elapsed / args.steps
+        extra["value_incl_h2d"] = {"value": total_steps / args.steps / (t_update + t_h2d), "unit": "update-steps/s",
+                                   "h2d_ms": t_h2d * 1e3, "bytes": H2D_BYTES_PER_UPDATE,
+                                   "note": "`value` with one pinned-host -> HBM copy of the 2^20-transition batch added to every update()"}
+        extra["rocm_eager_baseline"] = rocm_eager_baseline(device)
+        del learner
+        torch.cuda.empty_cache()
+        extra["hook_level"] = hook_level(device)                                   # device-side minibatch permutations
+        extra["hook_level_host_perms"] = hook_level(device, updates=1, permutations="host")   # the reference's np.random draws
+        torch.cuda.empty_cache()
+        extra["other_workloads"] = other_workloads()
 
     if rank == 0:
         out = {
-            "metric": "PPO learn() update-steps/sec (minibatch 65536, preprocessing incl.) + GAE transitions/sec",
+            "metric": "PPO learn() update-steps/sec (minibatch 65536, preprocessing incl.) + GAE transitions/sec; "
+                      "cpu_baseline / rocm_eager_baseline are PORTS of the reference path (oracle/), kind=port",
             "value": world * total_steps / elapsed,
             "unit": "update-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

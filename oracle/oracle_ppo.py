@@ -173,8 +173,9 @@ def add_returns_and_advantages(state: PPOState, cfg: PPOConfig, obs, obs_next, r
             v_s.append(critic_forward(p, obs[lo:hi]))
             v_s_.append(critic_forward(p, obs_next[lo:hi]))
     v_s_t = torch.cat(v_s, dim=0).flatten()
-    v_s_np = v_s_t.numpy()
-    v_next_np = torch.cat(v_s_, dim=0).flatten().numpy()
+    dev = v_s_t.device              # CPU in the parity tests; "cuda" in bench.py's ROCm-eager baseline leg, where - as in
+    v_s_np = v_s_t.cpu().numpy()    # the reference (to_numpy, a2c.py:130-131) - the value estimates cross to the host
+    v_next_np = torch.cat(v_s_, dim=0).flatten().cpu().numpy()
     if cfg.return_scaling:
         scale = np.sqrt(state.ret_rms.var + 1e-8)
         v_s_np = v_s_np * scale
@@ -187,8 +188,8 @@ def add_returns_and_advantages(state: PPOState, cfg: PPOConfig, obs, obs_next, r
         state.ret_rms = RMS(m, v, c)
     else:
         returns = ret
-    return (v_s_t, torch.from_numpy(returns.astype(np.float32)),
-            torch.from_numpy(adv.astype(np.float32)))
+    return (v_s_t, torch.from_numpy(returns.astype(np.float32)).to(dev),       # to_torch_as(..., batch.v_s), a2c.py:151-152
+            torch.from_numpy(adv.astype(np.float32)).to(dev))
 
 
 def preprocess(state: PPOState, cfg: PPOConfig, obs, obs_next, act, rew, terminated, truncated,
@@ -288,7 +289,7 @@ def update(state: PPOState, cfg: PPOConfig, data: dict, pre: dict, batch_size: i
             assert recompute is not None
             v_s, returns, adv = recompute()
             pre = dict(pre, v_s=v_s, returns=returns, adv=adv)
-        perm = torch.from_numpy(np.asarray(perms[r], dtype=np.int64))
+        perm = torch.from_numpy(np.asarray(perms[r], dtype=np.int64)).to(obs.device)
         for lo, hi in split_slices(n, size, merge_last=True):
             idx = perm[lo:hi]
             p = {k: v.detach().clone().requires_grad_(True) for k, v in state.params.items()}

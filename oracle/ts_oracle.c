@@ -66,13 +66,27 @@ void oracle_compute_episodic_return(const double* v_s, const double* v_s_,
                                     double* returns_out, double* adv_out) {
     double* vnext = (double*)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
     uint8_t* end = (uint8_t*)calloc((size_t)(n > 0 ? n : 1), 1);
+    /* np.isin(indices, unfinished) (:715): NumPy sorts / hashes, it does not compare every pair.  Same result
+     * here with a sorted copy of `unfinished` and a binary search (O((n + E) log E) instead of O(n E): the timed
+     * CPU baseline of bench.py must not be penalised by the restatement). */
+    int64_t* unf = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_unfinished > 0 ? n_unfinished : 1));
+    for (int64_t k = 0; k < n_unfinished; ++k) {            /* insertion sort: `unfinished` arrives ascending */
+        int64_t v = unfinished[k], j = k;
+        while (j > 0 && unf[j - 1] > v) { unf[j] = unf[j - 1]; --j; }
+        unf[j] = v;
+    }
     for (int64_t i = 0; i < n; ++i) {
         vnext[i] = v_s_[i] * (double)(terminated[i] == 0);
         uint8_t e = (uint8_t)((terminated[i] != 0) | (truncated[i] != 0));
-        for (int64_t k = 0; k < n_unfinished && !e; ++k)
-            if (indices[i] == unfinished[k]) e = 1;
+        if (!e && n_unfinished > 0) {
+            int64_t lo = 0, hi = n_unfinished - 1;
+            const int64_t key = indices[i];
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (unf[mid] < key) lo = mid + 1; else hi = mid; }
+            e = (uint8_t)(unf[lo] == key);
+        }
         end[i] = e;
     }
+    free(unf);
     oracle_gae(v_s, vnext, rew, end, n, gamma, gae_lambda, adv_out);
     for (int64_t i = 0; i < n; ++i) returns_out[i] = adv_out[i] + v_s[i];
     free(vnext);

@@ -68,16 +68,16 @@ def test_recurrent_net():
 
 
 def test_measured_legs_do_not_touch_the_oracle():
-    """In every bench script, anything under oracle/ is imported only inside a cpu_baseline function or an `if with_cpu:`
-    block -- never at module level or on the measured path."""
+    """In every bench script, anything under oracle/ is imported only inside a baseline function (`cpu_baseline*`,
+    `*_baseline`) or an `if with_cpu:` block -- never at module level or on the measured path."""
     for name in ("bench.py", "bench_dqn.py", "bench_sac.py", "bench_ppo_cnn.py", "bench_next.py", "bench_init.py"):
         tree = ast.parse(open(os.path.join(ROOT, name)).read())
 
         def visit(node, allowed):
             for child in ast.iter_child_nodes(node):
                 ok = allowed
-                if isinstance(child, ast.FunctionDef) and child.name.startswith("cpu_baseline"):
-                    ok = True
+                if isinstance(child, ast.FunctionDef) and (child.name.startswith("cpu_baseline") or child.name.endswith("_baseline")):
+                    ok = True                     # baseline legs: the CPU port and the ROCm-eager port of the reference path
                 if isinstance(child, ast.If) and isinstance(child.test, ast.Name) and child.test.id == "with_cpu":
                     ok = True
                 if isinstance(child, ast.ImportFrom) and (child.module or "").split(".")[0] == "oracle":

@@ -136,8 +136,15 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
     PPO = _on_policy_base(algo, ref)
 
     class HipPPO(_HipGlue, PPO):
-        def __init__(self, *args, device="cuda", **kwargs):
+        def __init__(self, *args, device="cuda", permutations="host", **kwargs):
+            """`permutations`: "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209;
+            same global-RNG stream as the reference, ~10 ms per 2^20 entries on the host); "device" draws one seed per
+            update() from the same global RNG and expands it with ts_random_permutation on the GPU (a keyed bijection:
+            statistically equivalent minibatches, not the reference's sequence)."""
             super().__init__(*args, **kwargs)
+            if permutations not in ("host", "device"):
+                raise ValueError("permutations must be 'host' or 'device'")
+            self._hip_perms = permutations
             self._hip_device = torch.device(device)
             self._hip_dims = _check_supported(self.policy.actor, self.critic)
             self._hip_engine = None
@@ -245,7 +252,13 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             self._hip_refresh_lr()
             eng = self._engine()
             n = int(self._hip_batch["obs"].shape[0])
-            perms = [np.random.permutation(n) for _ in range(repeat)]    # Batch.split, batch.py:1209
+            if self._hip_perms == "host":
+                perms = [np.random.permutation(n) for _ in range(repeat)]    # Batch.split, batch.py:1209
+            else:
+                from .buffer import random_permutation
+
+                seed = int(np.random.randint(0, 2**31 - 1))
+                perms = [random_permutation(n, seed * 1000003 + r, self._hip_device) for r in range(repeat)]
             losses, steps = eng.update(self._hip_batch, batch_size, repeat, perms)
             arr = losses.cpu().numpy().astype(np.float64)              # one D2H per update()
             eng.check()                                                # surfaces a stuck GAE hand-off (never observed)
