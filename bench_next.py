@@ -124,7 +124,7 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
                       T.TD3Config(twin=twin))
 
     def update():
-        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
         noise = torch.randn(B, ACT, generator=g, device=dev) if twin else None
         ret = eng.preprocess(buf, idx, noise)
         return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret)[0]
@@ -183,7 +183,7 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
     rng = np.random.default_rng(0)
 
     def update():
-        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
         noise = torch.randn(2, B, ACT, generator=g, device=dev)
         ret = eng.preprocess(buf, idx, noise[0], rng.choice(E, SUB, replace=False))
         return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret,
@@ -237,7 +237,7 @@ def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
     eng = DS.DiscreteSACEngine(OBS, A, HID, *flats, SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3))
 
     def update():
-        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
         ret = eng.preprocess(buf, idx)
         return eng.update_with_batch(gather_rows(buf.obs, idx), buf.act[idx], ret)[0]
 
@@ -583,7 +583,7 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch(list(p.values()), OBS, H, L, A), D.DQNConfig(**kw))
 
     def update():
-        idx = torch.randint(0, slots, (B,), generator=g, device=dev)
+        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
         ret = eng.preprocess(buf, buf.obs, idx, T)
         return eng.update_with_batch(R.gather_stacked_obs(buf.obs, buf, idx, T), buf.act[idx], ret)[0]
 

@@ -80,7 +80,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
                       S.critic_flat_from_torch(list(c2.values()), OBS, ACT), cfg)
 
     def update():
-        idx = torch.randint(0, slots, (BATCH,), generator=g, device=dev)
+        idx = buf.sample_indices(BATCH, generator=g)        # manager.py:216-234: sub-buffer by length, uniform inside
         noise = torch.randn(2, BATCH, ACT, generator=g, device=dev)
         ret = eng.preprocess(buf, idx, noise[0])
         stats, _ = eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret, noise[1])

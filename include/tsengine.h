@@ -159,6 +159,17 @@ int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
                           const int64_t* lengths, const int64_t* insertion, int64_t total,
                           int64_t* out, ts_stream_t stream);
 
+/* ReplayBufferManager.sample_indices(batch_size > 0) (manager.py:216-234 + ReplayBuffer.sample_indices
+ * buffer_base.py:503-517, stack_num == 1): sub-buffer by RandomState.choice(E, bs, p = lengths / sum) ==
+ * cdf.searchsorted(u_buffer, side="right"), then `sample_num` uniform slots inside each chosen sub-buffer, output
+ * concatenated in sub-buffer order.  The random draws are INPUTS so that a seeded reference run is reproduced
+ * bit-exactly: u_buffer f64[bs] = the uniforms `choice` consumes; within_i int64[bs] = the children's randint draws
+ * in output order - or within_u f64[bs] uniforms (slot = floor(u * len), device-RNG path); exactly one of the two.
+ * *err_flag (device int, caller zeroes it): 1 = empty buffer, 2 = a within_i draw outside its sub-buffer.  E <= 4096. */
+int ts_sample_indices_random(const int64_t* offset, int64_t E, const int64_t* lengths, const double* u_buffer,
+                             const int64_t* within_i, const double* within_u, int64_t batch_size, int64_t* out,
+                             int* err_flag, ts_stream_t stream);
+
 /* Device-side stand-in for the np.random.permutation(len(batch)) that Batch.split draws per repeat
  * (tianshou/data/batch.py:1209): a keyed bijection of [0, n) (4-round Feistel + cycle walking),
  * one thread per slot, ~5 us for 2^20 entries (a sort-based randperm costs ~250 us).  Not the

@@ -477,6 +477,54 @@ def gen_ppo_sched() -> None:
             recompute_advantage=False, max_batchsize=256)
 
 
+def gen_sample_random() -> None:
+    """ReplayBufferManager.sample_indices(batch_size > 0) (manager.py:216-234) on unevenly filled / wrapped
+    VectorReplayBuffers, with the draws the reference consumed recovered from copies of its RandomStates (the manager's
+    for RandomState.choice(E, bs, p), every sub-buffer's own for choice(len, n)) so that the engine can replay them."""
+    import copy
+
+    rng = np.random.default_rng(11)
+    out: dict[str, np.ndarray] = {}
+    cases = [(60, 4, 10), (64, 8, 37), (4096, 512, 4096), (30, 3, 1)]
+    for c, (size, E, bs) in enumerate(cases):
+        buf = VectorReplayBuffer(size, E)
+        steps = int(rng.integers(3, 3 * size // E))
+        for t in range(steps):
+            ids = np.flatnonzero(rng.random(E) < 0.7)
+            if t == 0 or ids.size == 0:
+                ids = np.arange(E)
+            k = ids.size
+            buf.add(Batch(obs=rng.normal(size=(k, 3)), act=rng.normal(size=(k, 1)), rew=rng.normal(size=k),
+                          terminated=rng.random(k) < 0.1, truncated=np.zeros(k, bool), obs_next=rng.normal(size=(k, 3))),
+                    buffer_ids=ids)
+        for rep in range(2):                                  # consecutive calls advance the generators
+            st = copy.deepcopy(buf._random_state.get_state())
+            child = [copy.deepcopy(b._random_state.get_state()) for b in buf.buffers]
+            res = buf.sample_indices(bs)
+            rs = np.random.RandomState()
+            rs.set_state(st)
+            u = rs.random_sample(bs)
+            L = np.asarray(buf._lengths)
+            p = L / L.sum()
+            cdf = p.cumsum()
+            cdf /= cdf[-1]
+            cnt = np.bincount(cdf.searchsorted(u, side="right"), minlength=E)
+            within = []
+            for e in range(E):
+                if cnt[e]:
+                    r = np.random.RandomState()
+                    r.set_state(child[e])
+                    within.append(r.choice(int(L[e]), int(cnt[e])))
+            within = np.concatenate(within)
+            key = f"c{c}_r{rep}_"
+            out[key + "offset"] = np.asarray(buf._extend_offset, np.int64)
+            out[key + "lengths"] = L.astype(np.int64)
+            out[key + "u"], out[key + "within"] = u, within.astype(np.int64)
+            out[key + "result"] = np.asarray(res, np.int64)
+    out["n_cases"] = np.array([len(cases), 2])
+    np.savez_compressed(os.path.join(OUT, "sample_random.npz"), **out)
+
+
 def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
             lr: float = 1e-3, **kwargs) -> None:
     """Runs the reference NPG.update() / TRPO.update() on the MuJoCo actor-critic (examples/mujoco/mujoco_npg.py:103-128,
@@ -901,6 +949,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_sched":
         gen_ppo_sched()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "sample_random":
+        gen_sample_random()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "redq":
         gen_redq_all()
         return
@@ -929,6 +980,7 @@ def main() -> None:
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
     gen_ppo_sched()
+    gen_sample_random()
     gen_buffer_add()
     gen_dqn_all()
     gen_sac_all()

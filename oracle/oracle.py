@@ -314,3 +314,26 @@ def compute_nstep_return(state: BufferState, indices, target_q_fn, gamma: float 
     end_flag = state.done.copy()                                       # :799
     end_flag[state.unfinished_index()] = True                          # :800
     return _nstep_return(state.rew, end_flag, tq.astype(np.float32), stacked, gamma, n_step), after
+
+
+def sample_indices_random(offset, lengths, u_buffer, within) -> np.ndarray:
+    """ReplayBufferManager.sample_indices(batch_size > 0), stack_num == 1 (manager.py:216-234; children:
+    buffer_base.py:514-517) with the random draws as inputs: `u_buffer` = the uniforms RandomState.choice(E, bs, p)
+    consumes (legacy choice: cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(u, side="right")), `within` = the
+    children's choice(len_e, n_e) draws concatenated in sub-buffer order."""
+    offset, lengths = _i64(offset), _i64(lengths)
+    E = lengths.size
+    p = lengths / lengths.sum()
+    cdf = p.cumsum()
+    cdf /= cdf[-1]
+    buffer_idx = cdf.searchsorted(np.asarray(u_buffer, np.float64), side="right")
+    sample_num = np.bincount(buffer_idx, minlength=E)
+    within = _i64(within)
+    out, pos = [], 0
+    for e in range(E):
+        n = int(sample_num[e])
+        if n == 0:                       # manager.py:227-228: -1 -> the child returns an empty array
+            continue
+        out.append(offset[e] + within[pos:pos + n])
+        pos += n
+    return np.concatenate(out) if out else np.array([], np.int64)

@@ -207,3 +207,50 @@ def test_buffer_add_matches_reference_history_bit_exact():
         assert np.array_equal(buf.unfinished_index().cpu().numpy(),
                               O.unfinished_index(g[f"s{s}_final_offset"], g[f"s{s}_final_done"],
                                                  g[f"s{s}_final_last_index"], g[f"s{s}_final_lengths"]))
+
+
+def test_random_sample_indices_replays_the_reference_draws():
+    """a1, batch_size > 0 (manager.py:216-234): with the reference's own draws as inputs the device sampler returns the
+    reference's indices bit for bit (uneven and wrapped sub-buffers, 512 sub-buffers x 4096 samples included)."""
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g = load("sample_random.npz")
+    for c in range(int(g["n_cases"][0])):
+        for r in range(int(g["n_cases"][1])):
+            k = f"c{c}_r{r}_"
+            off, L = g[k + "offset"], g[k + "lengths"]
+            B = int(off[-1])
+            buf = DeviceReplayBuffer(offset=off, last_index=off[:-1], lengths=L, insertion=np.zeros(L.size, np.int64),
+                                     rew=np.zeros(B), terminated=np.zeros(B, bool), truncated=np.zeros(B, bool))
+            out = buf.sample_indices(int(g[k + "u"].size), u_buffer=g[k + "u"], within=g[k + "within"])
+            assert out.dtype == torch.int64 and np.array_equal(out.cpu().numpy(), g[k + "result"]), k
+            assert np.array_equal(out.cpu().numpy(), O.sample_indices_random(off, L, g[k + "u"], g[k + "within"]))
+    with pytest.raises(ValueError):          # a draw outside its sub-buffer is refused, not silently wrapped
+        bad = g["c0_r0_within"].copy()
+        bad[0] = 10 ** 6
+        off, L = g["c0_r0_offset"], g["c0_r0_lengths"]
+        DeviceReplayBuffer(offset=off, last_index=off[:-1], lengths=L, insertion=np.zeros(L.size, np.int64), rew=np.zeros(int(off[-1])),
+                           terminated=np.zeros(int(off[-1]), bool), truncated=np.zeros(int(off[-1]), bool)
+                           ).sample_indices(bad.size, u_buffer=g["c0_r0_u"], within=bad)
+
+
+def test_random_sample_indices_device_rng_distribution():
+    """Without supplied draws the sampler uses torch's device generator: sub-buffer frequencies follow lengths / sum,
+    every index lies inside the filled part of its sub-buffer, output is grouped by sub-buffer like the reference's."""
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    E, size = 16, 1000
+    L = np.array([0, 10, 1000, 250, 1, 0, 500, 999, 3, 77, 1000, 640, 8, 0, 123, 321], np.int64)
+    off = np.arange(E + 1, dtype=np.int64) * size
+    buf = DeviceReplayBuffer(offset=off, last_index=off[:-1], lengths=L, insertion=np.zeros(E, np.int64), rew=np.zeros(E * size),
+                             terminated=np.zeros(E * size, bool), truncated=np.zeros(E * size, bool))
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    bs = 200000
+    idx = buf.sample_indices(bs, generator=gen).cpu().numpy()
+    e = idx // size
+    assert np.all(np.diff(e) >= 0)                                        # concatenated in sub-buffer order
+    assert np.all(idx - off[e] < L[e]) and np.all(idx >= off[e])          # inside the filled part
+    freq = np.bincount(e, minlength=E) / bs
+    np.testing.assert_allclose(freq, L / L.sum(), atol=4 * np.sqrt(0.25 / bs))
+    big = idx[e == 2] - off[2]                                            # uniform inside a sub-buffer
+    assert abs(big.mean() - 499.5) < 5 * 288.7 / np.sqrt(big.size)

@@ -152,6 +152,17 @@ def test_per_weights_against_reference():
     np.testing.assert_allclose(w, g["per_is_weight"], rtol=1e-12)
 
 
+def test_random_sample_indices_restatement_matches_reference():
+    """manager.py:216-234 with batch_size > 0: the restatement replays the reference's own draws (recovered from copies
+    of its RandomStates by gen_golden.gen_sample_random) on uneven / wrapped buffers, two consecutive calls each."""
+    g = load("sample_random.npz")
+    for c in range(int(g["n_cases"][0])):
+        for r in range(int(g["n_cases"][1])):
+            k = f"c{c}_r{r}_"
+            out = O.sample_indices_random(g[k + "offset"], g[k + "lengths"], g[k + "u"], g[k + "within"])
+            assert out.dtype == np.int64 and np.array_equal(out, g[k + "result"]), k
+
+
 # ------------------------------------------------------------------------------------ PPO path
 def _cfg_from(g):
     c = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))

@@ -392,13 +392,39 @@ class DeviceReplayBuffer:
             _lib.current_stream(self.device)))
         return out, n
 
-    def sample_indices(self, batch_size: int | None) -> torch.Tensor:
-        """Only the deterministic branch is on the device: batch_size == 0 -> every valid index,
-        sub-buffer-major and time-ordered (manager.py:216-234).  Random sampling consumes the
-        buffer's own RandomState in the reference (buffer_base.py:98,517) and stays there."""
-        if batch_size != 0:
-            raise NotImplementedError("random sample_indices stays on the host RNG of the reference; "
-                                      "pass its indices to the engine")
+    def sample_indices(self, batch_size: int | None, *, u_buffer=None, within=None, generator=None) -> torch.Tensor:
+        """ReplayBufferManager.sample_indices (manager.py:200-234) for stack_num == 1.
+
+        batch_size == 0 -> every valid index, sub-buffer-major and time-ordered.
+        batch_size > 0  -> sub-buffer with probability proportional to its length, then uniform inside it, concatenated
+        in sub-buffer order (ts_sample_indices_random).  The reference draws from the buffers' own RandomStates
+        (buffer_base.py:98); to reproduce a seeded reference run pass its draws: `u_buffer` float64[bs] (the uniforms
+        `RandomState.choice(E, bs, p=...)` consumes) and `within` int64[bs] (the children's `choice(len_e, n_e)` values,
+        concatenated in sub-buffer order).  Without them the draws come from torch's device generator (`generator`).
+        batch_size None (all indices, shuffled) and negative sizes stay with the reference."""
+        if batch_size is None or batch_size < 0:
+            raise NotImplementedError("sample_indices(None / negative) is not on the device path")
+        if batch_size > 0:
+            dev = self.device
+            bs = int(batch_size)
+            if (u_buffer is None) != (within is None):
+                raise ValueError("pass both u_buffer and within (the reference's draws) or neither")
+            if u_buffer is None:
+                r = torch.rand(2, bs, dtype=torch.float64, device=dev, generator=generator)
+                u, w_i, w_u = r[0].contiguous(), None, r[1].contiguous()
+            else:
+                u = torch.as_tensor(np.asarray(u_buffer, dtype=np.float64), device=dev).reshape(-1).contiguous()
+                w_i, w_u = _i64_dev(within, dev).reshape(-1), None
+                if u.numel() != bs or w_i.numel() != bs:
+                    raise ValueError("u_buffer / within must have batch_size entries")
+            out = torch.empty(bs, dtype=torch.int64, device=dev)
+            err = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(_lib.load().ts_sample_indices_random(
+                _lib.ptr(self.offset), _lib.i64(self.buffer_num), _lib.ptr(self.lengths), _lib.ptr(u), _lib.ptr(w_i),
+                _lib.ptr(w_u), _lib.i64(bs), _lib.ptr(out), _lib.ptr(err), _lib.current_stream(dev)))
+            if w_i is not None and int(err.item()):            # host-supplied draws are checked (one tiny D2H)
+                raise ValueError("sample_indices: empty buffer or a `within` draw outside its sub-buffer")
+            return out
         total = len(self)
         out = torch.empty(total, dtype=torch.int64, device=self.device)
         _lib.check(_lib.load().ts_sample_indices_all(

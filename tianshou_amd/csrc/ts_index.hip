@@ -259,6 +259,61 @@ __global__ void sample_all_kernel(const int64_t* offset, int64_t E, const int64_
     }
 }
 
+// ReplayBufferManager.sample_indices(batch_size > 0) (manager.py:216-234) on the device, single workgroup:
+//   buffer_idx = RandomState.choice(E, bs, p = lengths / lengths.sum())     == cdf.searchsorted(u, side="right") with
+//                cdf = p.cumsum(); cdf /= cdf[-1]  (NumPy's legacy choice), u = the bs uniform draws it consumes;
+//   sample_num = bincount(buffer_idx);  output = concat over sub-buffers e of offset[e] + child.choice(len_e, n_e),
+//   i.e. position j of the output belongs to the sub-buffer e with start[e] <= j < start[e + 1] (start = exclusive
+//   prefix of sample_num) and takes the j-th within-buffer draw.  The draws are inputs: `within_i` (the reference's own
+//   randint values, for parity) or `within_u` (uniforms in [0, 1): slot = floor(u * len_e), the device-RNG fast path).
+// The cdf is built sequentially in float64 by one thread, in NumPy's operation order (E is at most a few thousand).
+constexpr int SAMPLE_MAX_E = 4096;
+
+__global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __restrict__ offset, int64_t E,
+                                                             const int64_t* __restrict__ lengths,
+                                                             const double* __restrict__ u_buffer,
+                                                             const int64_t* __restrict__ within_i,
+                                                             const double* __restrict__ within_u, int64_t bs,
+                                                             int64_t* __restrict__ out, int* __restrict__ err) {
+    __shared__ double cdf[SAMPLE_MAX_E];
+    __shared__ int count[SAMPLE_MAX_E + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e <= E; e += 1024) count[e] = 0;
+    if (tid == 0) {
+        int64_t total = 0;
+        for (int64_t e = 0; e < E; ++e) total += lengths[e];
+        double acc = 0.0;
+        for (int64_t e = 0; e < E; ++e) { acc += (double)lengths[e] / (double)total; cdf[e] = acc; }   // p.cumsum()
+        const double last = cdf[E - 1];
+        for (int64_t e = 0; e < E; ++e) cdf[e] /= last;                                               // cdf /= cdf[-1]
+        if (total <= 0) *err = 1;
+    }
+    __syncthreads();
+    for (int64_t k = tid; k < bs; k += 1024) {
+        const double u = u_buffer[k];
+        int lo = 0, hi = (int)E;                       // first e with cdf[e] > u  (searchsorted side="right")
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+        if (lo >= (int)E) lo = (int)E - 1;
+        atomicAdd(&count[lo], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {                                    // exclusive prefix, in place
+        int run = 0;
+        for (int64_t e = 0; e <= E; ++e) { const int c = count[e]; count[e] = run; run += c; }
+    }
+    __syncthreads();
+    for (int64_t j = tid; j < bs; j += 1024) {
+        int lo = 0, hi = (int)E;                       // last e with start[e] <= j
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (count[mid] <= (int)j) lo = mid; else hi = mid; }
+        const int64_t len = lengths[lo];
+        int64_t slot;
+        if (within_i) slot = within_i[j];
+        else { slot = (int64_t)(within_u[j] * (double)len); if (slot >= len) slot = len - 1; }
+        if (slot < 0 || slot >= len) *err = 2;
+        out[j] = offset[lo] + slot;
+    }
+}
+
 template <typename V>
 __global__ void gather_rows_vec_kernel(const V* src, int64_t n_src, int64_t row_vecs,
                                        const int64_t* index, int64_t I, V* out) {
@@ -371,6 +426,20 @@ int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
     hipLaunchKernelGGL(lengths_prefix_kernel, dim3(1), dim3(1024), 0, s, lengths, E, prefix);
     hipLaunchKernelGGL(sample_all_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, offset, E,
                        lengths, insertion, prefix, total, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_sample_indices_random(const int64_t* offset, int64_t E, const int64_t* lengths, const double* u_buffer,
+                             const int64_t* within_i, const double* within_u, int64_t batch_size, int64_t* out,
+                             int* err_flag, ts_stream_t stream) {
+    TS_REQUIRE(E >= 1 && E <= SAMPLE_MAX_E, TS_ERR_UNSUPPORTED, "ts_sample_indices_random: 1 <= E <= %d sub-buffers", SAMPLE_MAX_E);
+    TS_REQUIRE(batch_size >= 0, TS_ERR_INVALID_ARG, "ts_sample_indices_random: negative batch_size");
+    if (batch_size == 0) return TS_OK;
+    TS_REQUIRE(offset && lengths && u_buffer && out && err_flag && ((within_i != nullptr) != (within_u != nullptr)),
+               TS_ERR_INVALID_ARG, "ts_sample_indices_random: NULL argument, or not exactly one of within_i / within_u");
+    hipLaunchKernelGGL(sample_random_kernel, dim3(1), dim3(1024), 0, ts::as_stream(stream), offset, E, lengths,
+                       u_buffer, within_i, within_u, batch_size, out, err_flag);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
