@@ -114,8 +114,17 @@ class Learner:
         self.perm_seed += 0x9E3779B97F4A7C15
         return random_permutation(N_TRANS, self.perm_seed, self.device)
 
+    def _dp(self):
+        if self.dp is None:
+            from tianshou_amd.distributed import DataParallelPPO
+
+            self.dp = DataParallelPPO(self.eng)
+        return self.dp
+
     def preprocess(self):
         obs, obs_next, act, rew, term, trunc = self.data
+        if self.world > 1:          # shard-local values / GAE / logp_old; ret_rms from the global return statistics
+            return self._dp().preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
         return self.eng.preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
 
     def update_once(self):
@@ -131,11 +140,7 @@ class Learner:
         return self._update_dp(b, perms)
 
     def _update_dp(self, b, perms):
-        if self.dp is None:
-            from tianshou_amd.distributed import DataParallelPPO
-
-            self.dp = DataParallelPPO(self.eng)
-        return self.dp.update(b, MINIBATCH, REPEAT, perms)
+        return self._dp().update(b, MINIBATCH, REPEAT, perms)
 
 
 def time_gae(learner, iters=50):

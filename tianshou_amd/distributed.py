@@ -36,8 +36,8 @@ def shard_envs(n_env: int, rank: int, world: int) -> tuple[int, int]:
 
 
 def global_adv_stats(adv: torch.Tensor, perm_rows: list[torch.Tensor], group=None) -> torch.Tensor:
-    """{mean, unbiased std} of every GLOBAL minibatch -> float32 [n_steps, 2] on adv's device.
-    One all-reduce of 3 * n_steps float64 values per update()."""
+    """{mean, unbiased std} of every GLOBAL minibatch -> float32 [n_chunks, 2] on adv's device.
+    One all-reduce of 3 * n_chunks float64 values per repeat."""
     acc = torch.zeros((len(perm_rows), 3), dtype=torch.float64, device=adv.device)
     for k, rows in enumerate(perm_rows):
         a = adv[rows].double()
@@ -89,39 +89,101 @@ class DataParallelPPO:
         # load_state_dict): make ts_ppo_grad rebuild its cached weight images once
         _lib.check(_lib.load().ts_ppo_invalidate_image(self.eng._ws.handle))
 
+    # -- preprocessing with global return statistics ----------------------------------------------
+    def _reduce_stats(self, s1: float, s2: float, n: float):
+        """(sum, sum of squares, count) of the unnormalised returns over ALL ranks: one 3-double all-reduce per
+        preprocess, after which every replica performs the same `RunningMeanStd.update` (a2c.py:148)."""
+        if self.world == 1:
+            return s1, s2, n
+        t = torch.tensor([s1, s2, n], dtype=torch.float64, device=self._coll_device())
+        dist.all_reduce(t, group=self.group)
+        s1, s2, n = (float(x) for x in t.tolist())
+        return s1, s2, n
+
+    def _coll_device(self):
+        return self.eng.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+
+    def preprocess(self, obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut=None):
+        """PPO._preprocess_batch (ppo.py:146-162) on this rank's shard: values, GAE and logp_old are shard-local
+        (episodes never span sub-buffers); only the three moments that feed `ret_rms` are exchanged."""
+        return self.eng.preprocess(obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut,
+                                   reduce_stats=self._reduce_stats)
+
+    def _recompute(self, b: dict) -> dict:
+        """ppo.py:174-178 (recompute_advantage) on the shard, again with global return statistics."""
+        v_s, returns, adv = self.eng.add_returns_and_advantages(
+            b["obs"], b["obs_next"], b["rew"], b["terminated"], b["truncated"], b["cut_pos"], b.get("d_n_cut"),
+            reduce_stats=self._reduce_stats)
+        return dict(b, v_s=v_s, returns=returns, adv=adv)
+
+    # -- minibatch line-up across ranks -------------------------------------------------------------
+    def _line_up(self, n_local: int, batch_size: int | None, dev) -> list[int]:
+        """Chunk boundaries of this rank's permutation.  Every rank must run the same number of gradient steps (one
+        all-reduce each), but `shard_envs` may give shards that differ by one sub-buffer: the boundaries of
+        Batch.split (batch.py:1205-1215) are taken on the LARGEST shard and scaled to the local size, so that the k-th
+        local minibatches line up and stay proportional.  Equal shards get exactly Batch.split's boundaries.
+        One int64 MAX all-reduce per update()."""
+        n_ref = n_local
+        if self.world > 1:
+            t = torch.tensor([n_local], dtype=torch.int64, device=self._coll_device())
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            n_ref = int(t.item())
+        if n_local < 1:
+            raise ValueError("every rank needs at least one transition")
+        ref = split_offsets(n_ref, batch_size, merge_last=True)
+        if n_ref == n_local:
+            return ref
+        offs = [min(n_local, (o * n_local + n_ref // 2) // n_ref) for o in ref]
+        offs[0], offs[-1] = 0, n_local
+        if any(b <= a for a, b in zip(offs[:-1], offs[1:])):
+            raise ValueError("a shard is too small for the requested number of minibatches")
+        return offs
+
+    def _global_counts(self, counts: list[int], dev) -> list[int]:
+        """Rows of every GLOBAL minibatch = sum over ranks of the local chunk sizes (one all-reduce per update())."""
+        if self.world == 1:
+            return counts
+        t = torch.tensor(counts, dtype=torch.int64, device=self._coll_device())
+        dist.all_reduce(t, group=self.group)
+        return [int(x) for x in t.tolist()]
+
     # -- update loop ----------------------------------------------------------------------------
     def update(self, b: dict, batch_size: int | None, repeat: int, perms):
-        """Every rank passes its LOCAL batch `b` and LOCAL permutations; all ranks must use the same
-        local batch size so that the k-th minibatches line up.  Returns (losses [steps, 4] with
-        global loss values, steps)."""
+        """Every rank passes its LOCAL batch `b` and LOCAL permutations.  Returns (losses [steps, 4] with global loss
+        values, steps)."""
         eng, cfg = self.eng, self.eng.cfg
-        if cfg.recompute_advantage:
-            raise NotImplementedError("recompute_advantage is not supported on the data-parallel path yet")
         n = b["obs"].shape[0]
         dev = b["obs"].device
-        offs = split_offsets(n, batch_size, merge_last=True)
-        rec = self._pack(b)
+        offs = self._line_up(n, batch_size, dev)
+        chunks = list(zip(offs[:-1], offs[1:]))
+        g_count = self._global_counts([hi - lo for lo, hi in chunks], dev)
         self._begin_update()
-        steps = [(r, lo, hi) for r in range(repeat) for lo, hi in zip(offs[:-1], offs[1:])]
         perm_t = [p.to(device=dev, dtype=torch.int64) if isinstance(p, torch.Tensor)
                   else torch.as_tensor(np.asarray(p, dtype=np.int64), device=dev) for p in perms]
-        rows_all = [perm_t[r][lo:hi] for r, lo, hi in steps]
-        stats = global_adv_stats(b["adv"], rows_all, self.group) if cfg.advantage_normalization else None
+        n_steps = repeat * len(chunks)
         # one [P + 4] row per gradient step: no copy of the loss parts, no reuse hazard between steps
         width = (eng.P + 4 + 3) // 4 * 4                      # 16-byte aligned rows
-        if self._buf is None or self._buf.device != dev or self._buf.shape[0] < len(rows_all):
-            self._buf = torch.empty((len(rows_all), width), dtype=torch.float32, device=dev)
-        for k, rows in enumerate(rows_all):
-            out = self._buf[k, : eng.P + 4]
-            self._local_grad(rec, rows, rows.numel() * self.world, None if stats is None else stats[k], out)
-            if self.world > 1:
-                dist.all_reduce(out, group=self.group)      # RCCL: gradient + loss parts in one call
-            self._apply(out)
-        res = self._buf[: len(rows_all), eng.P:eng.P + 4].clone()
+        if self._buf is None or self._buf.device != dev or self._buf.shape[0] < n_steps:
+            self._buf = torch.empty((n_steps, width), dtype=torch.float32, device=dev)
+        k = 0
+        for r in range(repeat):
+            if cfg.recompute_advantage and r > 0:                  # ppo.py:174-178
+                b = self._recompute(b)
+            rec = self._pack(b)
+            rows_r = [perm_t[r][lo:hi] for lo, hi in chunks]
+            stats = global_adv_stats(b["adv"], rows_r, self.group) if cfg.advantage_normalization else None
+            for c, rows in enumerate(rows_r):
+                out = self._buf[k, : eng.P + 4]
+                self._local_grad(rec, rows, g_count[c], None if stats is None else stats[c], out)
+                if self.world > 1:
+                    dist.all_reduce(out, group=self.group)      # RCCL: gradient + loss parts in one call
+                self._apply(out)
+                k += 1
+        res = self._buf[:n_steps, eng.P:eng.P + 4].clone()
         # the entropy term depends on the parameters only: every rank added the same value
         res[:, 3] /= self.world
         res[:, 0] = res[:, 1] + cfg.vf_coef * res[:, 2] - cfg.ent_coef * res[:, 3]
-        return res, len(rows_all)
+        return res, n_steps
 
 
 class DataParallelDQN:

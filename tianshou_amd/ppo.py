@@ -101,6 +101,18 @@ class PPOConfig:
             algo={"ppo": 0, "a2c": 1}[self.algo], reserved=0)
 
 
+def rms_merge(rms, s1: float, s2: float, n: float) -> list[float]:
+    """RunningMeanStd.update (utils/statistics.py:99-114) from the batch moments (sum, sum of squares, count):
+    [mean, var, count] -> [mean', var', count']."""
+    b_mean = s1 / n
+    b_var = max(s2 / n - b_mean * b_mean, 0.0)
+    mean, var, count = rms
+    delta = b_mean - mean
+    tot = count + n
+    m2 = var * count + b_var * n + delta * delta * count * n / tot
+    return [mean + delta * n / tot, m2 / tot, tot]
+
+
 def split_offsets(n: int, size: int | None, merge_last: bool = True) -> list[int]:
     """Chunk boundaries of Batch.split(size, merge_last) (tianshou/data/batch.py:1205-1215)."""
     if not size or size == -1:
@@ -200,8 +212,12 @@ class PPOEngine:
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     def add_returns_and_advantages(self, obs, obs_next, rew, terminated, truncated, cut_pos,
-                                   d_n_cut=None):
-        """a2c.py:115-153 -> (v_s, returns, adv) float32 device tensors."""
+                                   d_n_cut=None, reduce_stats=None):
+        """a2c.py:115-153 -> (v_s, returns, adv) float32 device tensors.
+
+        `reduce_stats(sum, sumsq, count) -> (sum, sumsq, count)`: data-parallel hook - the three float64 moments of the
+        unnormalised returns summed over all ranks, so that every replica updates `ret_rms` with the statistics of the
+        GLOBAL batch (what `ret_rms.update(unnormalized_returns)` sees in a single process, a2c.py:148)."""
         cfg = self.cfg
         v_s, _ = infer(self.params, self.obs_dim, self.act_dim, obs)
         v_next, _ = infer(self.params, self.obs_dim, self.act_dim, obs_next)
@@ -212,20 +228,16 @@ class PPOEngine:
         if cfg.return_scaling:
             n = float(v_s.numel())
             s1, s2 = float(out["ret_sum"]), float(out["ret_sumsq"])       # one small D2H
-            b_mean = s1 / n
-            b_var = max(s2 / n - b_mean * b_mean, 0.0)
-            mean, var, count = self.ret_rms                                # statistics.py:99-114
-            delta = b_mean - mean
-            tot = count + n
-            m2 = var * count + b_var * n + delta * delta * count * n / tot
-            self.ret_rms = [mean + delta * n / tot, m2 / tot, tot]
+            if reduce_stats is not None:
+                s1, s2, n = reduce_stats(s1, s2, n)
+            self.ret_rms = rms_merge(self.ret_rms, s1, s2, n)
         return v_s, out["returns"], out["adv"]
 
-    def preprocess(self, obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut=None):
+    def preprocess(self, obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut=None, reduce_stats=None):
         """PPO._preprocess_batch (ppo.py:146-162) on batch-order device arrays."""
         obs, obs_next, act = self._f32(obs), self._f32(obs_next), self._f32(act)
         v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated,
-                                                            truncated, cut_pos, d_n_cut)
+                                                            truncated, cut_pos, d_n_cut, reduce_stats)
         if self.cfg.algo == "a2c":      # A2C._preprocess_batch (a2c.py:239-247): no logp_old
             logp_old = torch.zeros_like(adv)
         else:
