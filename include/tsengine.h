@@ -761,6 +761,20 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
                        int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
                        double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream);
 
+/* One minibatch of PPO._update_with_batch / A2C._update_with_batch (ppo.py:179-216, a2c.py:262-283) for ANY Net[h, h]
+ * tanh actor-critic (obs_dim >= 1, hidden a multiple of 32 up to 1024, act_dim <= 32): the shapes the fused kernels behind
+ * ts_ppo_update do not cover (they are specialised to hidden 64, obs <= 31, act <= 8) run on the implicit-GEMM layers
+ * of ts_conv_forward / ts_conv_backward.  `params` = [actor | critic] in the ts_npg_layout order (one contiguous
+ * vector, so that clip_grad_norm_ over ActorCritic (a2c.py:103-107) and Adam are one pass); adam_m / adam_v likewise.
+ * obs .. v_old: the minibatch rows, already gathered ([B, obs_dim], [B, act_dim], [B]...).  global_batch >= B scales
+ * the loss (data-parallel use).  hp->lr < 0: gradient only (grad_out, float32[actor count + critic count]).
+ * losses_out4 = {loss, clip / actor loss, vf loss, entropy}. */
+int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                     int64_t hidden, int64_t act_dim, const float* obs, const float* act, const float* adv, const float* returns,
+                     const float* logp_old, const float* v_old, int64_t B, int64_t global_batch, const float* adv_stats,
+                     const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,
  * nets of examples/mujoco/mujoco_td3.py:85-103 / mujoco_ddpg.py

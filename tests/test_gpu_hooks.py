@@ -21,13 +21,13 @@ from tests import standin as SI
 pytestmark = pytest.mark.gpu
 
 
-def _make_ppo(obs_dim, act_dim, seed, device, **kw):
+def _make_ppo(obs_dim, act_dim, seed, device, hidden=64, **kw):
     from tianshou_amd.integration import make_hip_ppo
 
     HipPPO = make_hip_ppo("ppo", ref=SI)
     torch.manual_seed(seed)
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [64, 64], nn.Tanh), act_dim, unbounded=True)
-    critic = SI.ContinuousCritic(SI.Net(obs_dim, [64, 64], nn.Tanh))
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [hidden, hidden], nn.Tanh), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, [hidden, hidden], nn.Tanh))
     with torch.no_grad():
         actor.sigma_param.fill_(-0.5)
         for p in actor.mu.parameters():
@@ -41,7 +41,8 @@ def _oracle_params(algo):
     from tianshou_amd.ppo import flat_from_modules
 
     flat = flat_from_modules(algo.policy.actor, algo.critic, device="cpu")
-    return OP.unflatten_params(flat.clone(), *algo._hip_dims)
+    obs_dim, act_dim, hidden, _ = algo._hip_dims
+    return OP.unflatten_params(flat.clone(), obs_dim, act_dim, hidden)
 
 
 def _fill(buf, T, obs_dim, act_dim, rng):
@@ -122,6 +123,50 @@ def test_hip_ppo_hooks_with_scheduler_against_oracle(module_device):
     np.testing.assert_allclose(v_flat, v_ref, rtol=1e-3, atol=1e-10)
     assert all(float(state[p]["step"]) == st.adam_step for p in params)
     assert all(state[p]["exp_avg"].device == p.device and state[p]["exp_avg"].shape == p.shape for p in params)
+
+
+def test_hip_ppo_hooks_on_humanoid_shape_use_the_gemm_path():
+    """Net[256, 256], obs 376, act 17 (Humanoid; outside the fused kernels' envelope): HipPPO picks WidePPOEngine and the
+    whole hook path - mirror, preprocess, update, write-back, Adam flush - matches the oracle."""
+    from tianshou_amd.ppo_wide import WidePPOEngine
+
+    obs_dim, act_dim, hidden, E, T, batch_size, repeat = 376, 17, 256, 4, 48, 64, 2
+    kw = dict(eps_clip=0.2, value_clip=True, vf_coef=0.25, ent_coef=0.01, max_grad_norm=0.5, return_scaling=True,
+              advantage_normalization=True, lr=3e-4)
+    algo = _make_ppo(obs_dim, act_dim, 5, "cuda", hidden=hidden, **kw)
+    assert algo._hip_dims == (obs_dim, act_dim, hidden, "wide")
+    sa, sc = algo.policy.actor.state_dict(), algo.critic.state_dict()
+    from tianshou_amd.ppo import TIANSHOU_ACTOR_KEYS, TIANSHOU_CRITIC_KEYS
+
+    params = {k: t.detach().cpu().clone().reshape(OP.param_shapes(obs_dim, act_dim, hidden)[k])
+              for k, t in zip(OP.PARAM_ORDER, [sa[k] for k in TIANSHOU_ACTOR_KEYS] + [sc[k] for k in TIANSHOU_CRITIC_KEYS])}
+    st = OP.PPOState(params=params)
+    ocfg = OP.PPOConfig(max_batchsize=4096, **kw)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    rng = np.random.default_rng(2)
+    algo.policy.is_within_training_step = True
+    for u in range(2):
+        buf.reset()
+        _fill(buf, T, obs_dim, act_dim, rng)
+        np.random.seed(7 + u)
+        perms = [np.random.permutation(len(buf)) for _ in range(repeat)]
+        losses_o = _oracle_update(st, ocfg, buf, batch_size, repeat, perms)
+        np.random.seed(7 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert isinstance(algo._hip_engine, WidePPOEngine) and stats.gradient_steps == losses_o.shape[0]
+        for col, s_ in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(losses_o[:, col])
+            np.testing.assert_allclose([s_.mean, s_.max, s_.min], [ref.mean, ref.max, ref.min], rtol=1e-5, atol=2e-6)
+        sa, sc = algo.policy.actor.state_dict(), algo.critic.state_dict()
+        for k, t in zip(OP.PARAM_ORDER, [sa[k] for k in TIANSHOU_ACTOR_KEYS] + [sc[k] for k in TIANSHOU_CRITIC_KEYS]):
+            np.testing.assert_allclose(t.cpu().numpy().reshape(-1), st.params[k].numpy().reshape(-1), rtol=1e-4,
+                                       atol=0.02 * 3e-4, err_msg=k)
+    algo.state_dict()
+    state = algo.optim._optim.state
+    for p_, k in zip(algo._hip_params(), OP.PARAM_ORDER):
+        np.testing.assert_allclose(state[p_]["exp_avg"].cpu().numpy().reshape(-1), st.adam_m[k].numpy().reshape(-1),
+                                   rtol=1e-3, atol=1e-7, err_msg=k)
+        assert float(state[p_]["step"]) == st.adam_step
 
 
 def test_hip_ppo_load_state_dict_rebuilds_the_engine():

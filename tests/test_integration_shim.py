@@ -88,11 +88,17 @@ def test_unsupported_nets_are_rejected():
     from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
     from tianshou_amd.integration import _check_supported
 
-    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[128, 128], activation=nn.Tanh),
-                                         action_shape=(6,), unbounded=True)
-    critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[128, 128], activation=nn.Tanh))
-    with pytest.raises(NotImplementedError):
-        _check_supported(actor, critic)
+    def nets(hidden, act=nn.Tanh, n_act=6):
+        a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=act),
+                                         action_shape=(n_act,), unbounded=True)
+        return a, ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=act))
+
+    assert _check_supported(*nets([64, 64])) == (17, 6, 64, "fused")
+    assert _check_supported(*nets([128, 128])) == (17, 6, 128, "wide")          # GEMM path (tianshou_amd/ppo_wide.py)
+    assert _check_supported(*nets([64, 64], n_act=12)) == (17, 12, 64, "wide")
+    for bad in (nets([100, 100]), nets([64, 64], act=nn.ReLU), nets([64, 32]), nets([64, 64, 64]), nets([64, 64], n_act=40)):
+        with pytest.raises(NotImplementedError):
+            _check_supported(*bad)
 
 
 def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):

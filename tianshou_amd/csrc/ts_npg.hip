@@ -389,6 +389,104 @@ __global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restri
     if (threadIdx.x == 0) *loss = red[0] * inv_b;
 }
 
+// ---- PPO / A2C on the GEMM path (any Net[h, h] tanh actor-critic: the shapes the fused kernels of ts_ppo.hip do not
+// cover, e.g. Humanoid's obs 376 / act 17 / hidden 256) -----------------------------------------------------------------
+// PPO._update_with_batch (ppo.py:181-211) per sample, same branch / tie semantics as ts_ppo.hip's net_fwd_bwd:
+// term_b and d term_b / d logp_b; d_head = d loss / d mu, per-block partial sums of the loss terms and of d loss / d sigma.
+struct WideLossP { float eps_clip, dual_clip, ent_coef, inv_b; int a2c, adv_norm; };
+
+__global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* __restrict__ mu_head, const float* __restrict__ act,
+                                                                  const float* __restrict__ adv, const float* __restrict__ logp_old,
+                                                                  const float* __restrict__ log_sigma,
+                                                                  const float* __restrict__ adv_stats, WideLossP hp, int64_t B, int A,
+                                                                  float* __restrict__ d_head, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f, dlogp = 0.f;
+    if (b < B) {
+        const float lp = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A);
+        float Ab = adv[b];
+        if (hp.adv_norm) Ab = (Ab - adv_stats[0]) / (adv_stats[1] + 1e-8f);            // ppo.py:184-186
+        if (hp.a2c) {                                                                  // a2c.py:266-267
+            term = -lp * Ab;
+            dlogp = -Ab * hp.inv_b;
+        } else {
+            const float ratio = expf(lp - logp_old[b]);                                // :187
+            const float surr1 = ratio * Ab;
+            const float surr2 = fminf(fmaxf(ratio, 1.f - hp.eps_clip), 1.f + hp.eps_clip) * Ab;   // :190
+            const float clip1 = fminf(surr1, surr2);
+            float basek = (surr1 <= surr2) ? Ab : 0.f;          // torch.min backward (ties: both branches equal)
+            if (hp.dual_clip > 0.f && Ab < 0.f) {                                      // :191-194
+                const float dA = hp.dual_clip * Ab;
+                term = -fmaxf(clip1, dA);
+                if (!(clip1 >= dA)) basek = 0.f;
+            } else {
+                term = -clip1;                                                         // :196
+            }
+            dlogp = -basek * ratio * hp.inv_b;
+        }
+    }
+    // actor_loss_finish_kernel reports -sum / B: park the negated term so that it returns mean(term)
+    const float tot = block_sum_256(-term, red);
+    if (threadIdx.x == 0) partial[blockIdx.x * (1 + A)] = tot;
+    for (int j = 0; j < HEAD; ++j) {
+        float ds = 0.f, dm = 0.f;
+        if (b < B && j < A) {
+            const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[b * A + j] - mu_head[b * HEAD + j];
+            dm = dlogp * d / var;
+            ds = dlogp * (d * d / var - 1.f) - hp.ent_coef * hp.inv_b;                 // entropy: d / d log_sigma = 1
+        }
+        if (b < B) d_head[b * HEAD + j] = dm;
+        if (j < A) {
+            const float t = block_sum_256(ds, red);
+            if (threadIdx.x == 0) partial[blockIdx.x * (1 + A) + 1 + j] = t;
+        }
+    }
+}
+
+// value loss (ppo.py:198-208, a2c.py:270) and its gradient w.r.t. the value head, scaled by vf_coef
+__global__ __launch_bounds__(1024) void ppo_wide_critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret,
+                                                                    const float* __restrict__ v_old, float eps_clip, int value_clip,
+                                                                    float vf_coef, int64_t B, float* __restrict__ d_head,
+                                                                    float* __restrict__ loss) {
+    __shared__ float red[1024];
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float value = v_head[b * HEAD], r = ret[b];
+        const float vf1 = (r - value) * (r - value);
+        const float g1 = -2.f * (r - value);
+        float term = vf1, dv = g1;
+        if (value_clip) {
+            const float vo = v_old[b], dvo = value - vo;
+            const float vclip = vo + fminf(fmaxf(dvo, -eps_clip), eps_clip);
+            const float vf2 = (r - vclip) * (r - vclip);
+            const float g2 = (dvo >= -eps_clip && dvo <= eps_clip) ? -2.f * (r - vclip) : 0.f;
+            term = fmaxf(vf1, vf2);                                                    // torch.max: ties split the gradient
+            dv = (vf1 > vf2) ? g1 : ((vf2 > vf1) ? g2 : 0.5f * (g1 + g2));
+        }
+        ls += term;
+        for (int j = 0; j < HEAD; ++j) d_head[b * HEAD + j] = j == 0 ? dv * vf_coef * inv_b : 0.f;
+    }
+    red[threadIdx.x] = ls;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+}
+
+// losses[3] = Normal.entropy().sum(-1) (identical for every sample), losses[0] = clip + vf_coef vf - ent_coef ent (ppo.py:211)
+__global__ void ppo_wide_total_kernel(float* __restrict__ losses, const float* __restrict__ log_sigma, int A, float vf_coef,
+                                      float ent_coef) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ent = 0.f;
+    for (int k = 0; k < A; ++k) ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(log_sigma[k]));
+    losses[3] = ent;
+    losses[0] = losses[1] + vf_coef * losses[2] - ent_coef * ent;
+}
+
 // ---- network passes --------------------------------------------------------------------------------------------------
 int forward(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const float* x, const Act3& a, float* split, int64_t B) {
     const unsigned gh = (unsigned)ts::ceil_div(B * n.hid, 256);
@@ -650,6 +748,71 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
     if (int rc = backward(s, ws, n, critic, x, a, d_head, grad, bw, B)) return rc;
     if (lr < 0.0) return TS_OK;
     return ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step, lr, beta1, beta2, adam_eps, max_grad_norm, norm_part);
+}
+
+int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                     int64_t hidden, int64_t act_dim, const float* obs, const float* act, const float* adv, const float* returns,
+                     const float* logp_old, const float* v_old, int64_t B, int64_t global_batch, const float* adv_stats,
+                     const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_wide_step: workspace is NULL");
+    TS_REQUIRE(params && obs && act && adv && returns && hp && losses_out4 && B >= 1 && global_batch >= B && act_dim >= 1 &&
+                   act_dim <= HEAD, TS_ERR_INVALID_ARG, "ts_ppo_wide_step: bad argument");
+    const bool a2c = hp->algo == 1;
+    TS_REQUIRE(a2c || logp_old, TS_ERR_INVALID_ARG, "ts_ppo_wide_step: PPO needs logp_old");
+    TS_REQUIRE(a2c || !hp->value_clip || v_old, TS_ERR_INVALID_ARG, "ts_ppo_wide_step: value_clip needs v_old");
+    TS_REQUIRE(a2c || !hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "ts_ppo_wide_step: adv_norm needs adv_stats");
+    const bool apply = hp->lr >= 0.0;
+    TS_REQUIRE(!apply || (adam_m && adam_v && adam_step >= 1), TS_ERR_INVALID_ARG, "ts_ppo_wide_step: Adam state missing");
+    Net3 n;
+    if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int A = (int)act_dim;
+    const int64_t Pa = n.off[3] + HEAD, Pc = n.off[3], P = Pa + Pc;
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) +
+                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * P) +
+                                        al(4 * (size_t)n_blocks * (2 + A)) + 8192))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const Act3 a = take_act(c, n, B);
+    float* d_head = c.f(B * HEAD);
+    Bwd bw{c.f(B * n.hid), c.f(B * n.hid), c.f(slab_floats(n))};
+    float* split = c.f(split_floats(n));
+    float* grad = c.f(P);
+    float* partial = c.f((size_t)n_blocks * (2 + A));
+    float* norm_part = c.f(1024);
+    if (grad_out) grad = grad_out;
+    const float* actor = params;
+    const float* critic = params + Pa;
+    const float inv_b = 1.0f / (float)global_batch;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    // ---- actor: forward, clipped surrogate (+ entropy gradient on log_sigma), backward
+    if (int rc = forward(s, ws, n, actor, x, a, split, B)) return rc;
+    WideLossP lp{};
+    lp.eps_clip = (float)hp->eps_clip; lp.dual_clip = a2c ? 0.f : (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
+    lp.ent_coef = (float)hp->ent_coef; lp.inv_b = inv_b; lp.a2c = a2c; lp.adv_norm = a2c ? 0 : hp->adv_norm;
+    hipLaunchKernelGGL(ppo_wide_actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, act, adv, logp_old,
+                       actor + n.off[3], adv_stats, lp, B, A, d_head, partial);
+    // loss = -sum(-term) / B with B = the LOCAL row count: rescale to the global mean below when they differ
+    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, global_batch, A, losses_out4 + 1,
+                       grad + n.off[3]);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward(s, ws, n, actor, x, a, d_head, grad, bw, B)) return rc;
+    // ---- critic
+    if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
+    hipLaunchKernelGGL(ppo_wide_critic_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, returns, v_old, (float)hp->eps_clip,
+                       a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, d_head, losses_out4 + 2);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward(s, ws, n, critic, x, a, d_head, grad + Pa, bw, B)) return rc;
+    hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + n.off[3], A, (float)hp->vf_coef,
+                       (float)hp->ent_coef);
+    TS_LAUNCH_CHECK();
+    if (!apply) return TS_OK;
+    // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam
+    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+                         hp->max_grad_norm > 0.0 ? hp->max_grad_norm : 0.0, norm_part);
 }
 
 }  // extern "C"

@@ -109,7 +109,10 @@ def _on_policy_base(algo: str, ref=None):
     raise ValueError("algo must be 'ppo' or 'a2c'")
 
 
-def _check_supported(actor, critic) -> tuple[int, int]:
+def _check_supported(actor, critic) -> tuple[int, int, int, str]:
+    """-> (obs_dim, act_dim, hidden, kind).  kind "fused": the MuJoCo example nets (hidden 64 x 64, obs <= 31, act <= 8) on
+    the fused MFMA kernels of ts_ppo.hip; "wide": any other Net[h, h] (h a multiple of 32 up to 1024, act <= 32, e.g.
+    Humanoid's 376 / 17 / 256 x 256) on the implicit-GEMM layer kernels (tianshou_amd/ppo_wide.py)."""
     sa, sc = actor.state_dict(), critic.state_dict()
     for k in TIANSHOU_ACTOR_KEYS:
         if k not in sa:
@@ -118,13 +121,24 @@ def _check_supported(actor, critic) -> tuple[int, int]:
         if k not in sc:
             raise NotImplementedError(f"HipPPO: unsupported critic (missing {k})")
     if len(sa) != len(TIANSHOU_ACTOR_KEYS) or len(sc) != len(TIANSHOU_CRITIC_KEYS):
-        raise NotImplementedError("HipPPO: only Net[64, 64] trunks with linear heads are supported")
-    w1 = sa["preprocess.model.model.0.weight"]
-    if w1.shape[0] != 64 or sa["preprocess.model.model.2.weight"].shape != (64, 64):
-        raise NotImplementedError("HipPPO: hidden sizes must be [64, 64]")
+        raise NotImplementedError("HipPPO: only Net[h, h] trunks (two hidden layers) with linear heads are supported")
+    w1, w2 = sa["preprocess.model.model.0.weight"], sa["preprocess.model.model.2.weight"]
+    hidden, obs_dim = int(w1.shape[0]), int(w1.shape[1])
+    act_dim = int(sa["mu.model.0.weight"].shape[0])
+    cw1, cw2 = sc["preprocess.model.model.0.weight"], sc["preprocess.model.model.2.weight"]
+    if tuple(w2.shape) != (hidden, hidden) or tuple(cw1.shape) != (hidden, obs_dim) or tuple(cw2.shape) != (hidden, hidden):
+        raise NotImplementedError("HipPPO: actor and critic must both be Net[h, h] over the same observation")
+    for net in (actor, critic):                      # Net -> MLP -> Sequential(Linear, act, Linear, act) (common.py:90-178)
+        acts = [m for m in net.preprocess.model.model if not isinstance(m, torch.nn.Linear)]
+        if len(acts) != 2 or not all(isinstance(m, torch.nn.Tanh) for m in acts):
+            raise NotImplementedError("HipPPO: the hidden activations must be nn.Tanh (examples/mujoco/mujoco_ppo.py:108-114)")
     if not getattr(actor, "_unbounded", False) or getattr(actor, "_c_sigma", True):
         raise NotImplementedError("HipPPO: actor must be unbounded with a state-independent sigma_param")
-    return int(w1.shape[1]), int(sa["mu.model.0.weight"].shape[0])
+    if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
+        return obs_dim, act_dim, hidden, "fused"
+    if hidden % 32 == 0 and 32 <= hidden <= 1024 and act_dim <= 32:
+        return obs_dim, act_dim, hidden, "wide"
+    raise NotImplementedError("HipPPO: hidden sizes [h, h] with h a multiple of 32 (<= 1024) and at most 32 actions")
 
 
 def make_hip_ppo(algo: str = "ppo", ref=None):
@@ -153,16 +167,40 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             self._hip_synced = False
 
         # -- engine life cycle ------------------------------------------------------------------
-        def _engine(self) -> PPOEngine:
+        def _hip_flat(self, tensors) -> torch.Tensor:
+            """13 tensors in `_hip_params()` order (parameters or Adam moments) -> the engine's flat vector."""
+            obs_dim, act_dim, hidden, kind = self._hip_dims
+            if kind == "fused":
+                return torch.cat([t.detach().reshape(-1).float() for t in tensors]).to(self._hip_device).contiguous()
+            from .ppo_wide import flat_from_tensors
+
+            return flat_from_tensors(list(tensors[:7]), list(tensors[7:]), obs_dim, hidden, act_dim, self._hip_device)
+
+        def _hip_unflat(self, flat: torch.Tensor) -> list[torch.Tensor]:
+            """The engine's flat vector -> 13 tensors in `_hip_params()` order (shapes as flattened / nn.Linear layout)."""
+            obs_dim, act_dim, hidden, kind = self._hip_dims
+            if kind == "fused":
+                return list(torch.split(flat, [p.numel() for p in self._hip_params()]))
+            from .ppo_wide import flat_to_tensors
+
+            a, c = flat_to_tensors(flat, obs_dim, hidden, act_dim)
+            return a + c
+
+        def _engine(self):
             if self._hip_engine is None:
-                obs_dim, act_dim = self._hip_dims
-                flat = flat_from_modules(self.policy.actor, self.critic, self._hip_device)
-                eng = self._hip_engine = PPOEngine(obs_dim, act_dim, flat, ppo_config_from(self))
+                obs_dim, act_dim, hidden, kind = self._hip_dims
+                flat = self._hip_flat([p.detach() for p in self._hip_params()])
+                if kind == "fused":
+                    eng = PPOEngine(obs_dim, act_dim, flat, ppo_config_from(self))
+                else:
+                    from .ppo_wide import WidePPOEngine
+
+                    eng = WidePPOEngine(obs_dim, act_dim, hidden, flat, ppo_config_from(self))
+                self._hip_engine = eng
                 eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
                 # resume: Adam moments / step of a loaded checkpoint (algorithm_base.py:523-543)
                 ms, vs, step = adam_state(self.optim._optim, self._hip_params())
-                cat = lambda ts: torch.cat([t.reshape(-1).float() for t in ts]).to(self._hip_device)  # noqa: E731
-                eng.adam_m, eng.adam_v, eng.adam_step = cat(ms), cat(vs), step
+                eng.adam_m, eng.adam_v, eng.adam_step = self._hip_flat(ms), self._hip_flat(vs), step
             return self._hip_engine
 
         def _hip_params(self):
@@ -174,7 +212,9 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             The Adam moments are only needed by `state_dict()` (algorithm_base.py:523-543) and move there
             (`_hip_flush`)."""
             eng = self._hip_engine
-            flat_to_modules(eng.params, self.policy.actor, self.critic)
+            with torch.no_grad():
+                for p, t in zip(self._hip_params(), self._hip_unflat(eng.params)):
+                    p.copy_(t.reshape(p.shape).to(p.device))
             self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
             self._hip_adam_dirty = True
 
@@ -182,9 +222,7 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             eng = self._hip_engine
             if eng is None or not getattr(self, "_hip_adam_dirty", False):
                 return
-            params = self._hip_params()
-            sizes = [p.numel() for p in params]
-            store_adam_state(self.optim._optim, params, torch.split(eng.adam_m, sizes), torch.split(eng.adam_v, sizes),
+            store_adam_state(self.optim._optim, self._hip_params(), self._hip_unflat(eng.adam_m), self._hip_unflat(eng.adam_v),
                              eng.adam_step)
             self._hip_adam_dirty = False
 

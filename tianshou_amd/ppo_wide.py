@@ -1,0 +1,170 @@
+"""PPO / A2C learn() path for actor-critic MLPs outside the fused kernels' envelope.
+
+`tianshou_amd.ppo.PPOEngine` drives kernels specialised to the MuJoCo example nets (hidden 64 x 64, obs <= 31,
+act <= 8).  The reference's `Net` / `MLP` accept any `hidden_sizes` (utils/net/common.py:90-178, 246-369) and e.g.
+Humanoid is obs 376 / act 17; this engine runs the same hooks
+    ActorCriticOnPolicyAlgorithm._add_returns_and_advantages   modelfree/a2c.py:115-153
+    PPO._preprocess_batch / PPO._update_with_batch             modelfree/ppo.py:146-224   (A2C: a2c.py:239-290)
+    Algorithm.Optimizer.step                                   algorithm_base.py:484-500
+for Net[h, h] (tanh, h a multiple of 32 up to 1024), act_dim <= 32, on the implicit-GEMM layer kernels
+(ts_ppo_wide_step / ts_npg_infer in csrc/ts_npg.hip over csrc/ts_conv.hip).  Same interface as PPOEngine, so the
+`HipPPO` hooks and `DataParallelPPO`'s preprocessing work with either.  No CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import npg as NG
+from .buffer import gather_rows
+from .ppo import PPOConfig, rms_merge, split_offsets
+from .returns import gae_scan
+
+
+def flat_from_tensors(actor_t: list[torch.Tensor], critic_t: list[torch.Tensor], obs_dim: int, hidden: int, act_dim: int,
+                      device="cuda") -> torch.Tensor:
+    """[actor | critic] in the ts_npg_layout order from nn.Linear-layout tensors
+    ([w1, b1, w2, b2, w_mu, b_mu, sigma_param], [w1, b1, w2, b2, w_v, b_v])."""
+    return torch.cat([NG.actor_flat_from_torch(actor_t, obs_dim, hidden, act_dim, device),
+                      NG.critic_flat_from_torch(critic_t, obs_dim, hidden, device)]).contiguous()
+
+
+def flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: int, act_dim: int):
+    """-> (actor tensors [7], critic tensors [6]) in nn.Linear layout (sigma_param as a flat [act_dim] vector)."""
+    na = NG.layout(obs_dim, hidden, act_dim)["actor_count"]
+    return (NG.actor_flat_to_torch(flat[:na], obs_dim, hidden, act_dim), NG.critic_flat_to_torch(flat[na:], obs_dim, hidden))
+
+
+class WidePPOEngine:
+    """Device-resident state of one PPO / A2C learner on the GEMM path (interface of ppo.PPOEngine)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden: int, flat_params: torch.Tensor, cfg: PPOConfig):
+        if not flat_params.is_cuda:
+            raise RuntimeError("WidePPOEngine needs its parameters on an MI355X; there is no CPU fallback")
+        if hidden % 32 or not 32 <= hidden <= 1024 or not 1 <= act_dim <= 32:
+            raise NotImplementedError("WidePPOEngine: hidden a multiple of 32 in [32, 1024], act_dim <= 32")
+        self.obs_dim, self.act_dim, self.hidden, self.cfg = obs_dim, act_dim, hidden, cfg
+        lay = NG.layout(obs_dim, hidden, act_dim)
+        self.n_actor, self.n_critic = lay["actor_count"], lay["critic_count"]
+        self.P = self.n_actor + self.n_critic
+        if flat_params.numel() != self.P:
+            raise ValueError(f"flat_params has {flat_params.numel()} entries, layout needs {self.P}")
+        self.params = flat_params.detach().to(torch.float32).contiguous().clone()
+        self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.adam_step = 0
+        self.device = self.params.device
+        self.ret_rms = [0.0, 1.0, 0.0]
+        self._eps = 1e-8
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    @property
+    def actor(self) -> torch.Tensor:
+        return self.params[: self.n_actor]
+
+    @property
+    def critic(self) -> torch.Tensor:
+        return self.params[self.n_actor:]
+
+    def check(self) -> None:
+        if self._ws.gae_check():
+            raise _lib.EngineError(-1, "gae_single_pass: a tile hand-off timed out; advantages / returns are invalid")
+
+    def _f32(self, x) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.asarray(x), device=self.device)
+        return x.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _dims(self):
+        return _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.i64(self.act_dim)
+
+    def infer(self, obs, act=None, want_v=True):
+        """-> (V float32[B] or None, log pi(act | obs) float32[B] or None) for the whole array."""
+        b = obs.shape[0]
+        v = torch.empty(b, dtype=torch.float32, device=self.device) if want_v else None
+        logp = torch.empty(b, dtype=torch.float32, device=self.device) if act is not None else None
+        _lib.check(_lib.load().ts_npg_infer(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic), *self._dims(), _lib.ptr(obs), _lib.ptr(act),
+            _lib.i64(b), _lib.ptr(v), _lib.ptr(logp), None, _lib.current_stream(self.device)))
+        return v, logp
+
+    # ------------------------------------------------------------------ preprocess
+    def add_returns_and_advantages(self, obs, obs_next, rew, terminated, truncated, cut_pos, d_n_cut=None,
+                                   reduce_stats=None):
+        """a2c.py:115-153 -> (v_s, returns, adv) float32 device tensors (see PPOEngine.add_returns_and_advantages)."""
+        cfg = self.cfg
+        v_s, _ = self.infer(obs)
+        v_next, _ = self.infer(obs_next)
+        scale = math.sqrt(self.ret_rms[1] + self._eps) if cfg.return_scaling else 1.0
+        out = gae_scan(v_s, v_next, rew, terminated, truncated, cut_pos, gamma=cfg.gamma, gae_lambda=cfg.gae_lambda,
+                       v_scale=scale, ret_div=scale, want_ret_stats=cfg.return_scaling, d_n_cut=d_n_cut, ws=self._ws)
+        if cfg.return_scaling:
+            n = float(v_s.numel())
+            s1, s2 = float(out["ret_sum"]), float(out["ret_sumsq"])
+            if reduce_stats is not None:
+                s1, s2, n = reduce_stats(s1, s2, n)
+            self.ret_rms = rms_merge(self.ret_rms, s1, s2, n)
+        return v_s, out["returns"], out["adv"]
+
+    def preprocess(self, obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut=None, reduce_stats=None):
+        """PPO._preprocess_batch (ppo.py:146-162) on batch-order device arrays."""
+        obs, obs_next = self._f32(obs).reshape(-1, self.obs_dim), self._f32(obs_next).reshape(-1, self.obs_dim)
+        act = self._f32(act).reshape(obs.shape[0], self.act_dim)
+        v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated, truncated, cut_pos, d_n_cut,
+                                                            reduce_stats)
+        if self.cfg.algo == "a2c":          # A2C._preprocess_batch (a2c.py:239-247): no logp_old
+            logp_old = torch.zeros_like(adv)
+        else:
+            _, logp_old = self.infer(obs, act, want_v=False)
+        return {"obs": obs, "obs_next": obs_next, "act": act, "rew": rew, "terminated": terminated, "truncated": truncated,
+                "cut_pos": cut_pos, "d_n_cut": d_n_cut, "v_s": v_s, "returns": returns, "adv": adv, "logp_old": logp_old}
+
+    # ------------------------------------------------------------------ update
+    def step(self, b: dict, rows: torch.Tensor | None, losses_out: torch.Tensor, grad_out: torch.Tensor | None = None,
+             apply: bool = True, global_batch: int | None = None):
+        """One minibatch (rows of `b`; None = all): forward, loss, backward, joint clip + Adam."""
+        cfg = self.cfg
+        take = (lambda t: t) if rows is None else (lambda t: gather_rows(t, rows))       # noqa: E731
+        obs, act = take(b["obs"]), take(b["act"])
+        adv, ret, lp_old, v_old = take(b["adv"]), take(b["returns"]), take(b["logp_old"]), take(b["v_s"])
+        n = obs.shape[0]
+        stats = None
+        if cfg.advantage_normalization and cfg.algo != "a2c":                       # ppo.py:184-186 (unbiased std)
+            a64 = adv.double()
+            stats = torch.stack([a64.mean(), a64.std()]).float().contiguous()
+        hp = cfg.to_c()
+        if not apply:
+            hp.lr = -1.0
+        else:
+            self.adam_step += 1
+        _lib.check(_lib.load().ts_ppo_wide_step(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(max(self.adam_step, 1)),
+            *self._dims(), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(adv), _lib.ptr(ret), _lib.ptr(lp_old), _lib.ptr(v_old),
+            _lib.i64(n), _lib.i64(global_batch or n), _lib.ptr(stats), C.byref(hp), _lib.ptr(losses_out), _lib.ptr(grad_out),
+            _lib.current_stream(self.device)))
+
+    def update(self, b: dict, batch_size: int | None, repeat: int, perms=None, want_grad=False):
+        """PPO._update_with_batch (ppo.py:164-224); same contract as PPOEngine.update."""
+        n = b["obs"].shape[0]
+        cfg = self.cfg
+        if perms is None:
+            perms = [np.random.permutation(n) for _ in range(repeat)]
+        offs = split_offsets(n, batch_size, merge_last=True)
+        n_steps = repeat * (len(offs) - 1)
+        losses = torch.empty((n_steps, 4), dtype=torch.float32, device=self.device)
+        grads = torch.empty(self.P, dtype=torch.float32, device=self.device) if want_grad else None
+        k = 0
+        for r in range(repeat):
+            if cfg.recompute_advantage and r > 0:                                   # ppo.py:174-178
+                v_s, returns, adv = self.add_returns_and_advantages(b["obs"], b["obs_next"], b["rew"], b["terminated"],
+                                                                    b["truncated"], b["cut_pos"], b.get("d_n_cut"))
+                b = dict(b, v_s=v_s, returns=returns, adv=adv)
+            perm = (perms[r].to(device=self.device, dtype=torch.int64) if isinstance(perms[r], torch.Tensor)
+                    else torch.as_tensor(np.asarray(perms[r], dtype=np.int64), device=self.device))
+            for lo, hi in zip(offs[:-1], offs[1:]):
+                self.step(b, perm[lo:hi], losses[k], grads if k == n_steps - 1 else None)
+                k += 1
+        return (losses, n_steps, grads) if want_grad else (losses, n_steps)
