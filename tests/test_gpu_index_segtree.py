@@ -112,7 +112,7 @@ def test_segtree_class_random_vs_oracle_large():
     size = 1 << 20
     t = S.SegmentTree(size)
     ref = np.zeros(2 * t._bound)
-    for K in (1, 512, 4096, 70000):
+    for K in (1, 512, 4096, 70000, 1 << 20, 3 << 19):      # > 8192 entries: chip-wide leaf phase + per-level rebuild
         idx = rng.integers(0, size, size=K)
         idx[K // 2:] = idx[: K - K // 2]          # many duplicates: the later entry must win
         val = rng.random(K)

@@ -44,6 +44,42 @@ __global__ __launch_bounds__(ST_THREADS) void segtree_setitem_kernel(double* tre
     }
 }
 
+// Bulk path (K > SEGTREE_BULK_K leaves, e.g. initialising or re-prioritising a large share of a 2^20-leaf tree): the
+// single-workgroup kernel above walks K entries x log2(bound) levels on one CU (11.5 ms for 2^20 leaves).  Here the leaf
+// phase runs chip-wide and the internal levels are rebuilt one launch per level, bottom up, every node = left child +
+// right child: bit-identical to the incremental repair (a node the update does not reach already equals that sum).
+template <typename ValT>
+__global__ __launch_bounds__(256) void segtree_bulk_claim_kernel(const int64_t* __restrict__ index, int64_t K, int64_t bound,
+                                                                 int32_t* __restrict__ winner) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < K) atomicMax(&winner[index[k] - bound], (int32_t)k);
+}
+
+template <typename ValT>
+__global__ __launch_bounds__(256) void segtree_bulk_leaf_kernel(double* __restrict__ tree, const int64_t* __restrict__ index,
+                                                                const ValT* __restrict__ value, int64_t K, int64_t bound,
+                                                                const int32_t* __restrict__ winner) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < K) {
+        const int64_t leaf = index[k];
+        if (winner[leaf - bound] == (int32_t)k) tree[leaf] = (double)value[k];     // NumPy: the last duplicate wins
+    }
+}
+
+__global__ __launch_bounds__(256) void segtree_bulk_restore_kernel(const int64_t* __restrict__ index, int64_t K, int64_t bound,
+                                                                   int32_t* __restrict__ winner) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < K) winner[index[k] - bound] = -1;
+}
+
+// nodes [first, 2 first) of one level
+__global__ __launch_bounds__(256) void segtree_level_kernel(double* __restrict__ tree, int64_t first) {
+    const int64_t node = first + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (node < 2 * first) tree[node] = tree[2 * node] + tree[2 * node + 1];
+}
+
+constexpr int64_t SEGTREE_BULK_K = 8192;
+
 __global__ void segtree_reduce_kernel(const double* tree, int64_t start, int64_t end, double* out) {
     // segtree.py:108-116, single lane
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -168,6 +204,22 @@ int ts_segtree_setitem(ts_workspace* ws, double* tree, int64_t bound, const int6
     int32_t* winner = nullptr;
     int rc = ts::ws_winner(ws, bound, s, &winner);
     if (rc != TS_OK) return rc;
+    if (K > SEGTREE_BULK_K) {
+        const unsigned gk = (unsigned)ts::ceil_div(K, (int64_t)256);          // one entry per thread: no cap
+        hipLaunchKernelGGL(segtree_bulk_claim_kernel<float>, dim3(gk), dim3(256), 0, s, index, K, bound, winner);
+        if (value_dtype == 1)
+            hipLaunchKernelGGL(segtree_bulk_leaf_kernel<double>, dim3(gk), dim3(256), 0, s, tree, index, (const double*)value,
+                               K, bound, winner);
+        else
+            hipLaunchKernelGGL(segtree_bulk_leaf_kernel<float>, dim3(gk), dim3(256), 0, s, tree, index, (const float*)value, K,
+                               bound, winner);
+        hipLaunchKernelGGL(segtree_bulk_restore_kernel, dim3(gk), dim3(256), 0, s, index, K, bound, winner);
+        for (int64_t first = bound >> 1; first >= 1; first >>= 1)
+            hipLaunchKernelGGL(segtree_level_kernel, dim3((unsigned)ts::ceil_div(first, (int64_t)256)), dim3(256), 0, s, tree,
+                               first);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    }
     if (value_dtype == 1)
         hipLaunchKernelGGL(segtree_setitem_kernel<double>, dim3(1), dim3(ST_THREADS), 0, s, tree,
                            index, (const double*)value, K, bound, winner);
