@@ -90,7 +90,11 @@ def test_wide_update_matches_oracle(obs_dim, act_dim, hidden, cfg_name):
         off += cnt
     pa, pc = flat_to_tensors(eng.params, obs_dim, hidden, act_dim)
     for k, t in zip(OP.PARAM_ORDER, pa + pc):
-        np.testing.assert_allclose(t.cpu().numpy().reshape(-1), st.params[k].numpy().reshape(-1), rtol=1e-4, atol=0.02 * cfg.lr, err_msg=k)
+        # post-Adam parameters on the scale of one step: with no gradient clipping and 65,536-element layers a handful of
+        # elements whose gradient is rounding noise (|g| ~ 1e-9) get m / sqrt(v) of either sign in the first steps
+        got, want = t.cpu().numpy().reshape(-1), st.params[k].numpy().reshape(-1)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=0.1 * cfg.lr, err_msg=k)
+        assert np.mean(np.abs(got - want) > 0.02 * cfg.lr + 1e-4 * np.abs(want)) < 1e-4, k
     np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
 
 
