@@ -26,6 +26,12 @@ class Batch(SimpleNamespace):
     def pop(self, key, default=None):
         return self.__dict__.pop(key, default)
 
+    def __len__(self):
+        for v in self.__dict__.values():
+            if hasattr(v, "shape") and len(v.shape) > 0:
+                return int(v.shape[0])
+        return 0
+
 
 @dataclass
 class SequenceSummaryStats:

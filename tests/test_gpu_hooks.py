@@ -243,3 +243,57 @@ def test_full_c2_configuration_against_oracle():
     # 16 Adam steps of lr 3e-4: parameters on the scale of a fraction of one step (atol = 0.02 lr)
     np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=0.02 * 3e-4)
     np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ HipSAC
+def test_hip_sac_hooks_against_oracle():
+    """HipSAC (integration.make_hip_sac over the stand-ins) on the real engine: incremental device mirror of a growing
+    host buffer, random minibatch from the buffer's own RandomState, n-step-1 target with the lagged critics, twin-critic
+    / actor / auto-alpha steps, Polyak, write-back of five networks + four optimizers - against oracle_sac fed with the
+    same indices and the same torch-generator noise."""
+    from oracle import oracle_sac as OS
+    from tianshou_amd.integration import make_hip_sac
+
+    obs_dim, act_dim, E, B = 23, 5, 4, 64
+    HipSAC = make_hip_sac(ref=SI)
+    torch.manual_seed(11)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+    alpha = SI.AutoAlpha(-float(act_dim), -0.5, 3e-4)
+    algo = HipSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.01, gamma=0.97, alpha=alpha, device="cuda").to("cuda")
+    grab = lambda mod, keys: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(keys, mod.state_dict())}   # noqa: E731
+    cfg = OS.SACConfig(gamma=0.97, tau=0.01, n_step=1, auto_alpha=True, target_entropy=-float(act_dim), log_alpha0=-0.5,
+                       actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4)
+    st = OS.SACState.create(grab(actor, OS.ACTOR_ORDER), grab(c1, OS.CRITIC_ORDER), grab(c2, OS.CRITIC_ORDER), cfg)
+    buf = SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=4)
+    rng = np.random.default_rng(9)
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, rng)              # the mirror follows the growing buffer
+        torch.manual_seed(100 + u)
+        stats = algo.update(buf, B)
+        idx = seen[-1]
+        torch.manual_seed(100 + u)
+        noise_t, noise_u = torch.randn(B, act_dim), torch.randn(B, act_dim)
+        obs, act = torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx])
+        tq = OS.target_q(st, cfg, torch.from_numpy(buf.obs_next[idx]), noise_t).flatten().numpy()
+        ret = (buf.rew[idx] + 0.97 * tq.astype(np.float64) * (~buf.terminated[idx])).astype(np.float32)
+        ref = OS.update_with_batch(st, cfg, obs, act, ret, noise_u)
+        np.testing.assert_allclose([stats.actor_loss, stats.critic1_loss, stats.critic2_loss, stats.alpha, stats.alpha_loss],
+                                   [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"], ref["alpha"], ref["alpha_loss"]],
+                                   rtol=2e-5, atol=2e-6)
+        for mod, want, order in ((actor, st.actor, OS.ACTOR_ORDER), (c1, st.critic1, OS.CRITIC_ORDER), (c2, st.critic2, OS.CRITIC_ORDER),
+                                 (algo.critic_old.module, st.critic1_old, OS.CRITIC_ORDER),
+                                 (algo.critic2_old.module, st.critic2_old, OS.CRITIC_ORDER)):
+            for (name, t), k in zip(mod.state_dict().items(), order):
+                np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3, err_msg=f"update {u}: {name}")
+        assert abs(float(alpha._log_alpha) - float(st.log_alpha)) < 0.02 * 3e-4
+    w = actor.preprocess.model.model[0].weight
+    stt = algo.policy_optim._optim.state[w]
+    assert float(stt["step"]) == 4.0 and stt["exp_avg"].shape == w.shape and stt["exp_avg"].device == w.device
+    np.testing.assert_allclose(stt["exp_avg"].cpu().numpy(), st.opt_actor.m["w1"].numpy(), rtol=1e-3, atol=1e-7)
+    assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.rew.cpu().numpy(), buf.rew)

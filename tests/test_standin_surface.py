@@ -131,3 +131,46 @@ def test_real_subclass_and_standin_subclass_are_the_same_hook_code():
     for name in ("update", "_preprocess_batch", "_update_with_batch", "_engine", "_sync_back", "_hip_flush"):
         fa, fb = getattr(A, name), getattr(B, name)
         assert fa.__code__.co_code == fb.__code__.co_code and fa.__code__.co_firstlineno == fb.__code__.co_firstlineno, name
+
+
+def test_sac_standin_has_the_reference_surface():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[256, 256]), action_shape=(3,),
+                                         unbounded=True, conditioned_sigma=True)
+    mk = lambda: ContinuousCritic(preprocess_net=Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[256, 256], concat=True))  # noqa: E731
+    real = SAC(policy=SACPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,))),
+               policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(), critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=mk(),
+               critic2_optim=AdamOptimizerFactory(lr=1e-3), tau=0.005, gamma=0.99,
+               alpha=AutoAlpha(-3.0, 0.0, AdamOptimizerFactory(lr=3e-4)))
+    f_actor = SI.ContinuousActorProbabilistic(SI.Net(11, [256, 256], nn.ReLU), 3, unbounded=True, conditioned_sigma=True)
+    fake = SI.SAC(policy=SI.Policy(f_actor), critic=SI.ContinuousCritic(SI.Net(14, [256, 256], nn.ReLU)),
+                  critic2=SI.ContinuousCritic(SI.Net(14, [256, 256], nn.ReLU)), lr=1e-3, tau=0.005, gamma=0.99,
+                  alpha=SI.AutoAlpha(-3.0, 0.0, 3e-4))
+    pairs = ((real.policy.actor, fake.policy.actor), (real.critic, fake.critic), (real.critic2, fake.critic2),
+             (real.critic_old.module, fake.critic_old.module), (real.critic2_old.module, fake.critic2_old.module))
+    for a, b in pairs:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    for name in ("tau", "gamma", "n_step_return_horizon"):
+        assert getattr(real, name) == getattr(fake, name), name
+    for name in ("policy_optim", "critic_optim", "critic2_optim"):
+        r, f = getattr(real, name), getattr(fake, name)
+        assert type(r._optim) is type(f._optim) is torch.optim.Adam and r._max_grad_norm == f._max_grad_norm
+        assert [p.numel() for p in r._optim.param_groups[0]["params"]] == [p.numel() for p in f._optim.param_groups[0]["params"]]
+    for name in ("_target_entropy", "_log_alpha", "_optim", "value"):
+        assert hasattr(real.alpha, name) and hasattr(fake.alpha, name), name
+    assert float(real.alpha._log_alpha) == float(fake.alpha._log_alpha) and real.alpha._target_entropy == fake.alpha._target_entropy
+    assert type(real.alpha._optim) is type(fake.alpha._optim)
+    from tianshou_amd.integration import make_hip_sac
+
+    A, B = make_hip_sac(), make_hip_sac(ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name

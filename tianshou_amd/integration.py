@@ -968,12 +968,15 @@ def make_hip_rainbow():
 # ---------------------------------------------------------------------------------------------------
 # SAC (sac.py:213-336) on the mujoco_sac.py networks
 # ---------------------------------------------------------------------------------------------------
-def make_hip_sac():
+def make_hip_sac(ref=None):
     """Returns HipSAC(SAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, sac.py:298-336) on the
     engine.  Supported nets: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU, conditioned sigma,
     unbounded actor; concat critics); the buffer must store obs_next.  rsample() noise is drawn from torch's
-    default generator on the host, in the reference's order (target-policy call, then actor-loss call)."""
-    from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACTrainingStats
+    default generator on the host, in the reference's order (target-policy call, then actor-loss call).
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    SAC = _ref(ref, "tianshou.algorithm.modelfree.sac", "SAC")
+    AutoAlpha = _ref(ref, "tianshou.algorithm.modelfree.sac", "AutoAlpha")
+    SACTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.sac", "SACTrainingStats")
 
     from . import sac as S
 
