@@ -645,6 +645,20 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                   int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
                   ts_stream_t stream);
 
+/* One phase of ts_sac_update, for data-parallel replicas (tianshou_amd/distributed.py DataParallelSAC; the reference
+ * has no distributed path): phase 1 = forward / loss / backward of both critics on the local batch,
+ * 2 = their Adam steps, 4 = actor forward / loss / backward against the updated critics, 8 = actor Adam step,
+ * AutoAlpha.update, weight_out, Polyak.  `grads` is the exchange buffer the caller all-reduces between a "grad"
+ * phase and its "apply" phase: phases 1/2 float32[2 * critic_params] = {critic1, critic2} gradients of the local
+ * mean loss; phases 4/8 float32[actor_params + 1] = {actor gradient, -mean(log_prob)}.  The four calls of one update
+ * use the same workspace, batch pointers and B, in the order 1, 2, 4, 8 (the workspace carries the packed inputs,
+ * TD errors and policy intermediates from one phase to the next); 1, 2, 4, 8 without an exchange in between is
+ * bit-identical to ts_sac_update.  stats_out5 / weight_out as in ts_sac_update (each phase writes its own slots). */
+int ts_sac_update_phase(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                        const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                        int64_t act_dim, const ts_sac_hparams* hp, int phase, float* stats_out5, float* weight_out,
+                        float* grads, ts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DiscreteSAC (tianshou/algorithm/modelfree/discrete_sac.py): Categorical policy, twin critics that
  * output Q(s, .) for every action; nets of test/discrete/test_discrete_sac.py:88-97: Net(obs, [hidden, hidden]) ReLU
@@ -827,6 +841,22 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
                              const float* rec, const int64_t* perm_rows, int64_t n_rows,
                              const ts_ppo_hparams* hp, int64_t* h_cycles, int64_t n_marks,
                              ts_stream_t stream);
+
+/* ---- data-parallel exchange ------------------------------------------------------------------
+ * One process per GPU; the reference has no distributed path (its only multi-GPU mechanism is single-process
+ * nn.DataParallel, tianshou/utils/net/common.py:473-515).  In-place sum all-reduce of a flat fp32 buffer over RCCL
+ * (xGMI inside a node), issued on the caller's stream: ordered after the kernel that wrote the buffer
+ * (ts_ppo_grad / ts_sac_update_phase ...) and before the one that consumes it, without a host synchronisation.
+ * RCCL is resolved at run time; TS_ERR_UNSUPPORTED when librccl.so.1 cannot be loaded.
+ *   rank 0: ts_allreduce_unique_id(id) -> the host ships the 128 bytes to every rank (any rendezvous it has)
+ *   all   : ts_allreduce_init(id, rank, world, device, &comm)           (collective: every rank must call it)
+ *   all   : ts_allreduce(comm, buf, n, stream) per exchange;  ts_allreduce_destroy(comm) at the end.
+ * Hosts inside PyTorch can use torch.distributed (backend "nccl" = RCCL) instead: same collective, same result. */
+typedef struct ts_comm ts_comm;
+int ts_allreduce_unique_id(uint8_t* h_id128);
+int ts_allreduce_init(const uint8_t* h_id128, int64_t rank, int64_t world, int device, ts_comm** out);
+int ts_allreduce(ts_comm* comm, float* buf, int64_t n, ts_stream_t stream);
+int ts_allreduce_destroy(ts_comm* comm);
 
 #ifdef __cplusplus
 }

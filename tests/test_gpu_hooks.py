@@ -291,7 +291,7 @@ def test_hip_sac_hooks_against_oracle():
                                  (algo.critic2_old.module, st.critic2_old, OS.CRITIC_ORDER)):
             for (name, t), k in zip(mod.state_dict().items(), order):
                 np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3, err_msg=f"update {u}: {name}")
-        assert abs(float(alpha._log_alpha) - float(st.log_alpha)) < 0.02 * 3e-4
+        assert abs(float(alpha._log_alpha.detach()) - float(st.log_alpha)) < 0.02 * 3e-4
     w = actor.preprocess.model.model[0].weight
     stt = algo.policy_optim._optim.state[w]
     assert float(stt["step"]) == 4.0 and stt["exp_avg"].shape == w.shape and stt["exp_avg"].device == w.device

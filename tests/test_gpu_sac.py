@@ -169,3 +169,30 @@ def test_bad_arguments_fail_loudly():
         eng.update_with_batch(torch.zeros(4, 12), torch.zeros(4, 3), torch.zeros(4), torch.zeros(4, 3))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         S.SACEngine(11, 3, eng.actor.cpu(), eng.critic1.cpu(), eng.critic2.cpu(), S.SACConfig())
+
+
+@pytest.mark.parametrize("auto,weighted", [(True, True), (False, False)])
+def test_phased_update_is_bit_identical(auto, weighted):
+    """ts_sac_update_phase 1, 2, 4, 8 (DataParallelSAC at world 1: no exchange) == ts_sac_update, bit for bit:
+    parameters, Adam moments, lagged critics, log_alpha, stats and the new PER weights, over three updates."""
+    from tianshou_amd.distributed import DataParallelSAC
+
+    obs_dim, act_dim, B = 23, 5, 300
+    cfg = OS.SACConfig(auto_alpha=auto, log_alpha0=-0.3, alpha=0.15, target_entropy=-float(act_dim), tau=0.01)
+    eng_a, _ = make_engine(obs_dim, act_dim, 5, cfg)
+    eng_b, _ = make_engine(obs_dim, act_dim, 5, cfg)
+    dp = DataParallelSAC(eng_b)
+    g = torch.Generator().manual_seed(3)
+    for _ in range(3):
+        obs = torch.randn(B, obs_dim, generator=g).cuda()
+        act = (torch.rand(B, act_dim, generator=g) * 2 - 1).cuda()
+        ret = (torch.randn(B, generator=g) * 2).cuda()
+        noise = torch.randn(B, act_dim, generator=g).cuda()
+        weight = torch.rand(B, generator=g).cuda() if weighted else None
+        s_a, w_a = eng_a.update_with_batch(obs, act, ret, noise, weight)
+        s_b, w_b = dp.update_with_batch(obs, act, ret, noise, weight)
+        assert torch.equal(s_a, s_b) and torch.equal(w_a, w_b)
+    for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old", "actor_m", "actor_v", "critic1_m",
+                 "critic1_v", "critic2_m", "critic2_v", "log_alpha", "log_alpha_m", "log_alpha_v"):
+        assert torch.equal(getattr(eng_a, name), getattr(eng_b, name)), name
+    assert eng_a.adam_step == eng_b.adam_step == 3

@@ -252,19 +252,22 @@ struct AlphaArgs {
     float lr_step, beta1, beta2, bc2_sqrt, eps, omb1, omb2;
     float* alpha_loss; float* alpha_out; float fixed_alpha;
     const float* td1; const float* td2; float* weight_out;
+    const float* neg_mean_logp;      // data-parallel: -mean(log_prob) over the GLOBAL batch (replaces the local mean)
 };
 
 __global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
     __shared__ float red[1024];
     float s = 0.f;
     for (int64_t b = threadIdx.x; b < a.B; b += 1024) {
-        s += a.target_entropy + a.logp[b];                            // entropy_deficit = target - (-log_prob)
+        s += a.logp[b];
         if (a.weight_out) a.weight_out[b] = (a.td1[b] + a.td2[b]) / 2.f;
     }
     const float tot = block_sum_1024(s, red);
     if (threadIdx.x != 0) return;
     if (!a.log_alpha) { *a.alpha_out = a.fixed_alpha; *a.alpha_loss = 0.f; return; }
-    const float mean_def = tot / (float)a.B;
+    // mean entropy deficit = mean(target - (-log_prob)); written so that the single-call and the phased update
+    // (which receives -mean(log_prob) through the exchange buffer) evaluate the same float operations
+    const float mean_def = a.target_entropy - (a.neg_mean_logp ? *a.neg_mean_logp : -(tot / (float)a.B));
     const float la = *a.log_alpha;
     *a.alpha_loss = -(la * mean_def);
     const float g = -mean_def;
@@ -645,10 +648,21 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     return TS_OK;
 }
 
-int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
-                  const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
-                  int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
-                  ts_stream_t stream) {
+}  // extern "C"
+
+namespace {
+// Phases of one SAC update.  ts_sac_update runs all four in one call; ts_sac_update_phase runs one at a time so
+// that data-parallel replicas can all-reduce the gradients between "grad" and "apply" (the workspace keeps the packed
+// inputs, TD errors, policy intermediates and log-probabilities between the calls).
+enum : int { PH_CRITIC_GRAD = 1, PH_CRITIC_APPLY = 2, PH_ACTOR_GRAD = 4, PH_ACTOR_APPLY = 8, PH_ALL = 15 };
+
+// `grads`: all phases in one call -> optional output [critic1 | critic2 | actor] (ts_sac_update's grads_out);
+// single phases -> the exchange buffer: critic phases [critic1 | critic2], actor phases [actor | -mean(log_prob)].
+int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                    const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                    int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads,
+                    int phases, ts_stream_t stream) {
+    float* const grads_out = phases == PH_ALL ? grads : nullptr;
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_update: workspace is NULL");
     TS_REQUIRE(st && hp && obs && act && returns && noise && stats_out5 && B >= 1 && adam_step >= 1,
                TS_ERR_INVALID_ARG, "ts_sac_update: bad argument");
@@ -694,10 +708,15 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
     float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
 
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
-                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
-    TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
-    TS_HIP_CHECK(hipMemsetAsync(d_q1, 0, sizeof(float) * B * 64, s));
+    if (phases != PH_ALL) {      // exchange-buffer layout of the single phases
+        g_out[0] = grads; g_out[1] = grads + pc; g_out[2] = grads;
+    }
+    if (phases & PH_CRITIC_GRAD) {
+        hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act,
+                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+        TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+    }
+    if (phases & PH_ACTOR_GRAD) TS_HIP_CHECK(hipMemsetAsync(d_q1, 0, sizeof(float) * B * 64, s));
 
     // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
     // caller's stream, critic 2 on the workspace's side stream (each of these GEMMs fills only part of the chip).
@@ -713,44 +732,54 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     float* splits[2] = {split, split2};
     float* gbuf[2] = {grad, grad2};
     const BwdScratch scs[2] = {sc, sc2};
-    TS_HIP_CHECK(hipMemsetAsync(d_head2, 0, sizeof(float) * B * 32, s));
+    if (phases & PH_CRITIC_GRAD) TS_HIP_CHECK(hipMemsetAsync(d_head2, 0, sizeof(float) * B * 32, s));
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
     for (int k = 0; k < 2; ++k) {
         hipStream_t sk = stq[k];
-        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                           dheads[k], stats_out5 + 1 + k);
-        TS_LAUNCH_CHECK();
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
-        if (hp->critic_lr >= 0.0)
+        if (phases & PH_CRITIC_GRAD) {
+            if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+            hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                               dheads[k], stats_out5 + 1 + k);
+            TS_LAUNCH_CHECK();
+            if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
+        }
+        if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0)
             if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
                 return rc;
     }
+    if (!(phases & (PH_ACTOR_GRAD | PH_ACTOR_APPLY))) return ts::stream_wait(ws, side, s, 1);
 
     // actor (sac.py:308-315): a ~ pi(s) with the supplied noise, Q1(s, a), Q2(s, a) with the UPDATED critics
-    TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
-    if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
-    hipLaunchKernelGGL(sac_policy_kernel, dim3(gb), dim3(256), 0, s, aa.out, noise, B, d.act, 64, d.obs, d.kc, x_p,
-                       (float*)nullptr, logp, keep);
-    if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;              // x_p ready; critic 2 is already updated there
-    if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
-    if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
-    if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
-    hipLaunchKernelGGL(sac_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, a2.out, logp, log_alpha, (float)hp->alpha, B,
-                       d_q1, d_q2, stats_out5);
-    TS_LAUNCH_CHECK();
-    if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
-    if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
-    if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
-    TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
-    if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
-    hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
-                       keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
-    TS_LAUNCH_CHECK();
     float* ga = g_out[2] ? g_out[2] : grad;
-    if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
+    if (phases & PH_ACTOR_GRAD) {
+        TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
+        if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
+        hipLaunchKernelGGL(sac_policy_kernel, dim3(gb), dim3(256), 0, s, aa.out, noise, B, d.act, 64, d.obs, d.kc, x_p,
+                           (float*)nullptr, logp, keep);
+        if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;              // x_p ready; critic 2 is already updated there
+        if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
+        if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
+        if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
+        hipLaunchKernelGGL(sac_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, a2.out, logp, log_alpha, (float)hp->alpha, B,
+                           d_q1, d_q2, stats_out5);
+        TS_LAUNCH_CHECK();
+        if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
+        if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
+        if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
+        TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+        if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
+        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
+                           keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
+        if (phases != PH_ALL) {      // the alpha step's only batch statistic, for the all-reduce
+            hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, logp, B, grads + pa);
+            TS_LAUNCH_CHECK();
+        }
+    }
+    if (!(phases & PH_ACTOR_APPLY)) return TS_OK;
     if (hp->actor_lr >= 0.0)
         if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, pa, adam_step, hp->actor_lr, hp->beta1,
                                    hp->beta2, hp->adam_eps, 0.0, norm_part))
@@ -766,12 +795,36 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
     aa2.bc2_sqrt = (float)sqrt(bc2); aa2.eps = (float)hp->adam_eps;
     aa2.alpha_loss = stats_out5 + 4; aa2.alpha_out = stats_out5 + 3; aa2.fixed_alpha = (float)hp->alpha;
     aa2.td1 = td1; aa2.td2 = td2; aa2.weight_out = weight_out;
+    aa2.neg_mean_logp = phases != PH_ALL ? grads + pa : nullptr;
     hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
     if (hp->tau > 0.0)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, pc, (float)hp->tau, (float)(1.0 - hp->tau));
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                  const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                  int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
+                  ts_stream_t stream) {
+    return sac_update_impl(ws, st, adam_step, obs, act, returns, weight, noise, B, obs_dim, act_dim, hp, stats_out5,
+                           weight_out, grads_out, PH_ALL, stream);
+}
+
+int ts_sac_update_phase(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
+                        const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
+                        int64_t act_dim, const ts_sac_hparams* hp, int phase, float* stats_out5, float* weight_out,
+                        float* grads, ts_stream_t stream) {
+    TS_REQUIRE(phase == PH_CRITIC_GRAD || phase == PH_CRITIC_APPLY || phase == PH_ACTOR_GRAD || phase == PH_ACTOR_APPLY,
+               TS_ERR_INVALID_ARG, "ts_sac_update_phase: phase must be 1, 2, 4 or 8");
+    TS_REQUIRE(grads != nullptr, TS_ERR_INVALID_ARG, "ts_sac_update_phase: the exchange buffer is NULL");
+    return sac_update_impl(ws, st, adam_step, obs, act, returns, weight, noise, B, obs_dim, act_dim, hp, stats_out5,
+                           weight_out, grads, phase, stream);
 }
 
 // ---- TD3 / DDPG ------------------------------------------------------------------------------------------------

@@ -55,11 +55,20 @@ def global_adv_stats(adv: torch.Tensor, perm_rows: list[torch.Tensor], group=Non
 class DataParallelPPO:
     """PPO._update_with_batch (ppo.py:164-224) over `world` replicas of a PPOEngine."""
 
-    def __init__(self, engine: PPOEngine, group=None):
+    def __init__(self, engine: PPOEngine, group=None, allreduce=None):
+        """`allreduce` (optional): in-place sum over the ranks of a flat float32 device tensor, e.g.
+        `tianshou_amd.collective.NativeAllReduce` (the C-ABI ts_allreduce); default torch.distributed (RCCL)."""
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._allreduce = allreduce
         self._buf = None
+
+    def _exchange(self, buf):
+        if self._allreduce is not None:
+            self._allreduce(buf)
+        else:
+            dist.all_reduce(buf, group=self.group)
 
     # -- the two device steps around the collective (overridden by the CPU test double) --------
     def _local_grad(self, rec, rows, global_batch, adv_stats, out):
@@ -176,7 +185,7 @@ class DataParallelPPO:
                 out = self._buf[k, : eng.P + 4]
                 self._local_grad(rec, rows, g_count[c], None if stats is None else stats[c], out)
                 if self.world > 1:
-                    dist.all_reduce(out, group=self.group)      # RCCL: gradient + loss parts in one call
+                    self._exchange(out)                          # RCCL: gradient + loss parts in one call
                 self._apply(out)
                 k += 1
         res = self._buf[:n_steps, eng.P:eng.P + 4].clone()
@@ -195,11 +204,18 @@ class DataParallelDQN:
     mean over the global minibatch (equal local batch sizes).  Clip + Adam and the periodic target sync then run
     identically on every replica; PER priorities (td errors) stay shard-local."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, allreduce=None):
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._allreduce = allreduce
         self._buf = None
+
+    def _exchange(self, buf):
+        if self._allreduce is not None:
+            self._allreduce(buf)
+        else:
+            dist.all_reduce(buf, group=self.group)
 
     # -- the two device steps around the collective (overridden by the CPU test double) ------------------
     def _local_grad(self, obs, act, returns, weight, out):
@@ -219,7 +235,67 @@ class DataParallelDQN:
         out = self._buf
         td = self._local_grad(obs, act, returns, weight, out)
         if self.world > 1:
-            dist.all_reduce(out, group=self.group)
+            self._exchange(out)
             out.mul_(1.0 / self.world)
         self._apply(out[: eng.P])
         return out[eng.P:].clone(), td
+
+
+class DataParallelSAC:
+    """SAC._update_with_batch (sac.py:298-336) over `world` replicas of a SACEngine.
+
+    Every rank samples its own minibatch from its shard of the replay buffer (equal local batch sizes) and computes
+    its n-step targets locally (the lagged critics and the actor are replicated).  Per update two collectives:
+    [critic1 | critic2 | loss1 | loss2] after the critics' backward passes and [actor | -mean(log_prob) | actor loss]
+    after the actor's -- the sums * 1/world are the gradients of the mean losses over the global minibatch, so the
+    three Adam steps, the alpha step (sac.py:203-209 needs only the mean log-probability) and the Polyak update run
+    identically on every replica.  PER weights (td errors) stay shard-local."""
+
+    def __init__(self, engine, group=None, allreduce=None):
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._allreduce = allreduce
+        self._bufs = None
+
+    # -- device steps around the collectives (overridden by the CPU test double) -------------------------------
+    def _begin(self, obs, act, returns, noise, weight):
+        return self.eng.begin_phased_update(obs, act, returns, noise, weight)
+
+    def _phase(self, ctx, phase, buf):
+        self.eng.update_phase(ctx, phase, buf)
+
+    def _sizes(self):
+        return self.eng.exchange_floats()
+
+    def _reduce(self, buf):
+        if self.world > 1:
+            if self._allreduce is not None:
+                self._allreduce(buf)
+            else:
+                dist.all_reduce(buf, group=self.group)
+            buf.mul_(1.0 / self.world)
+
+    def update_with_batch(self, obs, act, returns, noise, weight=None):
+        """-> (stats float32[5] with GLOBAL losses, local new PER weights float32[B_local])."""
+        eng = self.eng
+        n_c, n_a = self._sizes()
+        if self._bufs is None:
+            dev = eng.device
+            self._bufs = (torch.empty(n_c + 2, dtype=torch.float32, device=dev),
+                          torch.empty(n_a + 1, dtype=torch.float32, device=dev))
+        buf_c, buf_a = self._bufs
+        ctx = self._begin(obs, act, returns, noise, weight)
+        stats = ctx["stats"]
+        self._phase(ctx, eng.PHASE_CRITIC_GRAD, buf_c)
+        buf_c[n_c:] = stats[1:3]                               # the two critic losses ride along
+        self._reduce(buf_c)
+        self._phase(ctx, eng.PHASE_CRITIC_APPLY, buf_c)
+        self._phase(ctx, eng.PHASE_ACTOR_GRAD, buf_a)
+        buf_a[n_a:] = stats[0:1]
+        self._reduce(buf_a)
+        self._phase(ctx, eng.PHASE_ACTOR_APPLY, buf_a)
+        out = stats.clone()
+        out[1:3] = buf_c[n_c:]
+        out[0] = buf_a[n_a]
+        return out, ctx["w_out"]

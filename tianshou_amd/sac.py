@@ -227,3 +227,31 @@ class SACEngine:
             _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
             C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.ptr(grads_out), _lib.current_stream(self.device)))
         return stats, w_out
+
+    # -- the same update in four phases (data-parallel replicas all-reduce between "grad" and "apply") -----------
+    PHASE_CRITIC_GRAD, PHASE_CRITIC_APPLY, PHASE_ACTOR_GRAD, PHASE_ACTOR_APPLY = 1, 2, 4, 8
+
+    def begin_phased_update(self, obs, act, returns, noise, weight=None, lr_scale: float = 1.0) -> dict:
+        """Checks / converts the minibatch once and advances the optimizer step; the returned context goes to the
+        four `update_phase` calls of this update (order 1, 2, 4, 8; nothing else may use the workspace in between)."""
+        obs, act = self._f32(obs), self._f32(act)
+        b = obs.shape[0]
+        if act.shape != (b, self.act_dim) or obs.shape != (b, self.obs_dim):
+            raise ValueError("obs / act shapes do not match the engine")
+        self.adam_step += 1
+        return {"obs": obs, "act": act, "returns": self._f32(returns, (b,)), "noise": self._f32(noise, (b, self.act_dim)),
+                "weight": None if weight is None else self._f32(weight, (b,)), "b": b, "hp": self.cfg.to_c(lr_scale),
+                "stats": torch.zeros(5, dtype=torch.float32, device=self.device),
+                "w_out": torch.empty(b, dtype=torch.float32, device=self.device)}
+
+    def exchange_floats(self) -> tuple[int, int]:
+        """Sizes of the two exchange buffers: ([critic1 | critic2], [actor | -mean(log_prob)])."""
+        return 2 * self.critic1.numel(), self.actor.numel() + 1
+
+    def update_phase(self, ctx: dict, phase: int, grads: torch.Tensor) -> None:
+        st = self._state_c()
+        _lib.check(_lib.load().ts_sac_update_phase(
+            self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(ctx["obs"]), _lib.ptr(ctx["act"]),
+            _lib.ptr(ctx["returns"]), _lib.ptr(ctx["weight"]), _lib.ptr(ctx["noise"]), _lib.i64(ctx["b"]),
+            _lib.i64(self.obs_dim), _lib.i64(self.act_dim), C.byref(ctx["hp"]), C.c_int(phase), _lib.ptr(ctx["stats"]),
+            _lib.ptr(ctx["w_out"]), _lib.ptr(grads), _lib.current_stream(self.device)))
