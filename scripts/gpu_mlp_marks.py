@@ -1,0 +1,30 @@
+"""Phase marks of one fused-MLP launch (workgroup 0, thread 0; s_memtime ticks, ~2.36 per ns measured against HIP events).
+Build with TS_EXTRA_FLAGS="ts_mlp.hip:-DTS_MLP_MARKS"."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.getcwd())
+import torch
+from tianshou_amd import sac as S, _lib
+
+lib = _lib.load()
+cfg = S.SACConfig()
+lay = S.layout(376, 17)
+g = torch.Generator().manual_seed(0)
+eng = S.SACEngine(376, 17, (torch.randn(lay["actor_count"], generator=g) * 0.05).cuda(), (torch.randn(lay["critic_count"], generator=g) * 0.05).cuda(),
+                  (torch.randn(lay["critic_count"], generator=g) * 0.05).cuda(), cfg)
+obs = torch.randn(4096, 376, device="cuda")
+noise = torch.randn(4096, 17, device="cuda")
+for _ in range(3):
+    eng.policy_forward(obs, noise)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    eng.policy_forward(obs, noise)
+e1.record()
+torch.cuda.synchronize()
+print("policy_forward (pack + fused MLP + policy kernel):", round(e0.elapsed_time(e1) * 1e3 / 20, 1), "us per call")
+out = (C.c_uint64 * 8)()
+lib.ts_debug_mlp_marks(out)
+t = list(out)
+names = ["start", "x in LDS", "layer 1 (wave 0)", "barrier", "layer 2 + barrier", "head"]
+print(" ".join(f"{names[k]}=+{(t[k] - t[k - 1]) / 2.36:.0f}ns" for k in range(1, 6)), "total", round((t[5] - t[0]) / 2.36), "ns")

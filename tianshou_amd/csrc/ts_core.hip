@@ -60,7 +60,8 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
 
 int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "side_stream: workspace is NULL");
-    if (ws->profiling) { *out = main; return TS_OK; }      // serial launches: per-kernel event pairs do not overlap
+    static const bool single = getenv("TS_NO_SIDE_STREAM") != nullptr;      // experiments: everything on one stream
+    if (ws->profiling || single) { *out = main; return TS_OK; }      // serial launches: per-kernel event pairs do not overlap
     if (!ws->side_ready) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
         TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));

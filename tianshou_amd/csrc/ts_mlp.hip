@@ -1,0 +1,266 @@
+// ts_mlp.hip -- the forward pass of the SAC-family MLPs (Net[256, 256] + head, ReLU; tianshou/utils/net/common.py:90-178,
+// continuous.py:144-169,220-238) as ONE launch instead of three GEMM launches.
+//
+// Why: at the C5 batch (4096 rows) a 256 x 256 Linear layer is 0.54 GFLOP -- 4.6 us of MFMA issue on the whole chip --
+// but costs 10-15 us as its own launch (launch, im2col tables, first operand round trip, an epilogue in which all 256
+// workgroups store at once: DESIGN.md 4.4).  A chain of three dependent layers pays that three times and round-trips
+// the 4 MB activations through HBM in between.
+//
+// How: a workgroup owns 16 rows of the batch for all three layers (256 workgroups at B = 4096: one per CU, eight waves
+// = two per SIMD).  Activations stay in LDS ([row][k], pitch K + 4); every wave owns 32 output columns of a hidden
+// layer (two 16 x 16 tiles of v_mfma_f32_16x16x4_f32) and streams exactly its share of the weight matrix from L2
+// straight into the MFMA B-operand layout: lane (n, kq) loads W[k][col0 + n] for the four k of its quarter -- 64-byte
+// segments of four weight rows per load instruction, no LDS staging because no two waves of a workgroup share a
+// weight.  Weight traffic is 256 KB per workgroup per hidden layer out of L2 (64 B/clk/CU: half of the MFMA time); the
+// loads run three 32-deep k groups (48 registers) ahead of the MFMAs that consume them.
+// Summation order: within every 16-wide k block lane quarter kq contributes k = 16 blk + 4 kq + t at step t (a
+// permutation of the block applied to both operands).
+#include "ts_mlp.h"
+
+#include <cstdlib>
+
+#include "ts_common.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int ROWS = 16;             // batch rows per workgroup
+constexpr int THREADS = 512;         // 8 waves
+constexpr int HID = 256;
+constexpr int HP = HID + 4;          // LDS pitch of a hidden activation row
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+#ifdef TS_MLP_MARKS
+__device__ unsigned long long g_mlp_marks[8];
+#define MMARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mlp_marks[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MMARK(k) do {} while (0)
+#endif
+
+struct MlpArgs {
+    const float* x; const float* wb1; const float* wb2; const float* wb3;
+    float* h1; float* h2; float* out;
+    int M, K1;
+};
+
+// Epilogue of a layer
+enum : int { EP_BIAS_RELU = 0, EP_BIAS = 1, EP_MASK = 2, EP_PLAIN = 3 };
+
+// One layer for this wave's TPW column tiles (16 columns each, tiles tile0 .. tile0 + TPW - 1 of `nt`):
+//   TRANS = false: out[:, c] = act(sum_k A[:, k] W[k, c] + b[c])        W[k, c] = wb[k * PITCH + c]   (forward)
+//   TRANS = true : out[:, c] = sum_k A[:, k] W[c0 + c, k] (* mask)       W[r, k] = wb[r * PITCH + k]   (input gradient:
+//                  the rows of the layer matrix are contiguous along the contraction, one dwordx4 per four MFMAs)
+// A = a_lds [16][a_pitch]; K = contraction length (multiple of 32).  The result goes to o_lds ([16][HP], nullable) and
+// to o_g (row pitch o_ld, nullable; rows >= M are not stored).
+template <int PITCH, int TPW, bool TRANS, int EP>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ wb, int K, int nt, int c0, const float* a_lds,
+                                          int a_pitch, float* o_lds, float* __restrict__ o_g, int o_ld,
+                                          const float* __restrict__ mask, int m0, int M, int wave, int lane) {
+    const int n = lane & 15, kq = lane >> 4;
+    const int tile0 = wave * TPW;
+    if (tile0 >= nt) return;                                     // no columns of this layer for this wave
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tiles past `nt` (ragged last wave) recompute the last valid tile and are not stored
+    int tj[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) tj[j] = min(tile0 + j, nt - 1);
+    const float* al = a_lds + n * a_pitch + 4 * kq;                       // + 32 g + 16 blk   (row = lane & 15)
+    const int ng = K / 32;
+    f32x4 st[4][2][TPW];
+    auto gload = [&](int g, f32x4 (&s)[2][TPW]) {
+        const int gg = min(g, ng - 1);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (TRANS) {
+                    s[blk][j] = *reinterpret_cast<const f32x4*>(wb + (size_t)(c0 + tj[j] * 16 + n) * PITCH + 32 * gg + 16 * blk + 4 * kq);
+                } else {
+                    const float* w = wb + (size_t)(32 * gg + 16 * blk + 4 * kq) * PITCH + c0 + tj[j] * 16 + n;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) s[blk][j][t] = w[t * PITCH];
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](int g, const f32x4 (&s)[2][TPW]) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(al + 32 * g + 16 * blk);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < TPW; ++j) acc[j] = mfma16(av[t], s[blk][j][t], acc[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    gload(0, st[0]);
+    gload(1, st[1]);
+    gload(2, st[2]);
+    int g = 0;
+    for (; g + 4 <= ng; g += 4) {
+        gload(g + 3, st[3]); compute(g, st[0]);
+        gload(g + 4, st[0]); compute(g + 1, st[1]);
+        gload(g + 5, st[1]); compute(g + 2, st[2]);
+        gload(g + 6, st[2]); compute(g + 3, st[3]);
+    }
+    if (g < ng) compute(g, st[0]);
+    if (g + 1 < ng) compute(g + 1, st[1]);
+    if (g + 2 < ng) compute(g + 2, st[2]);
+
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (tile0 + j >= nt) break;
+        const int col = c0 + (tile0 + j) * 16 + n;
+        const float bias = (EP == EP_BIAS_RELU || EP == EP_BIAS) ? wb[(size_t)K * PITCH + col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = 4 * kq + v;
+            const bool live = m0 + row < M;
+            float val = acc[j][v] + bias;
+            if (EP == EP_BIAS_RELU) val = fmaxf(val, 0.f);
+            if (EP == EP_MASK) val = (live && mask[(size_t)(m0 + row) * o_ld + col] > 0.f) ? val : 0.f;
+            if (o_lds) o_lds[row * HP + col - c0] = val;
+            if (o_g && live) o_g[(size_t)(m0 + row) * o_ld + col] = val;
+        }
+    }
+}
+
+// x tile / upstream-gradient tile of this workgroup: [16][K] floats -> LDS (rows past M repeat the last row)
+__device__ __forceinline__ void load_rows(const float* __restrict__ src, int K, int m0, int M, float* dst, int pitch, int tid) {
+    const int q4 = K / 4;
+    for (int i = tid; i < ROWS * q4; i += THREADS) {
+        const int row = i / q4, c = i - row * q4;
+        const int m = min(m0 + row, M - 1);
+        *reinterpret_cast<f32x4*>(dst + row * pitch + 4 * c) = *reinterpret_cast<const f32x4*>(src + (size_t)m * K + 4 * c);
+    }
+}
+
+template <int N3>
+__global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * ROWS;
+    const int xp = a.K1 + 4;
+    float* xs = lds;
+    float* h1s = xs + ROWS * xp;
+    float* h2s = h1s + ROWS * HP;
+    MMARK(0);
+    load_rows(a.x, a.K1, m0, a.M, xs, xp, tid);
+    __syncthreads();
+    MMARK(1);
+    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb1, a.K1, HID / 16, 0, xs, xp, h1s, a.h1, HID, nullptr, m0, a.M, wave, lane);
+    MMARK(2);
+    __syncthreads();
+    MMARK(3);
+    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb2, HID, HID / 16, 0, h1s, HP, h2s, a.h2, HID, nullptr, m0, a.M, wave, lane);
+    __syncthreads();
+    MMARK(4);
+    mlp_layer<N3, 1, false, EP_BIAS>(a.wb3, HID, N3 / 16, 0, h2s, HP, nullptr, a.out, N3, nullptr, m0, a.M, wave, lane);
+    MMARK(5);
+}
+
+// Input gradients of the same chain: dh2 = (d_out W3^T) * (h2 > 0), dh1 = (dh2 W2^T) * (h1 > 0) and, when asked for,
+// dx[:, dx_c0 : dx_c0 + 16 dx_nt] = dh1 W1^T restricted to those input columns (SAC / TD3: the action columns of the
+// critic input, ddpg.py / sac.py actor losses).  dh1 / dh2 go to HBM for the weight-gradient GEMMs.
+struct BwdArgs {
+    const float* d_out; const float* wb1; const float* wb2; const float* wb3;
+    const float* h1; const float* h2;
+    float* dh1; float* dh2; float* dx;
+    int M, K1, dx_c0, dx_nt;
+};
+
+template <int N3>
+__global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * ROWS;
+    float* ds = lds;                          // [16][N3 + 4]
+    float* g2s = ds + ROWS * (N3 + 4);        // [16][HP]
+    float* g1s = g2s + ROWS * HP;
+    load_rows(a.d_out, N3, m0, a.M, ds, N3 + 4, tid);
+    __syncthreads();
+    mlp_layer<N3, 2, true, EP_MASK>(a.wb3, N3, HID / 16, 0, ds, N3 + 4, g2s, a.dh2, HID, a.h2, m0, a.M, wave, lane);
+    __syncthreads();
+    mlp_layer<HID, 2, true, EP_MASK>(a.wb2, HID, HID / 16, 0, g2s, HP, g1s, a.dh1, HID, a.h1, m0, a.M, wave, lane);
+    if (a.dx == nullptr) return;
+    __syncthreads();
+    mlp_layer<HID, 1, true, EP_PLAIN>(a.wb1, HID, a.dx_nt, a.dx_c0, g1s, HP, nullptr, a.dx, a.K1, nullptr, m0, a.M, wave, lane);
+}
+
+}  // namespace
+
+#ifdef TS_MLP_MARKS
+extern "C" int ts_debug_mlp_marks(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_marks), sizeof(unsigned long long) * 8);
+}
+#endif
+
+namespace ts {
+
+bool mlp3_supported(int K1, int hidden, int head_cols) {
+    static const bool off = getenv("TS_MLP_PER_LAYER") != nullptr;      // experiments: force the per-layer GEMM path
+    return !off && hidden == HID && (head_cols == 32 || head_cols == 64) && K1 % 32 == 0 && K1 >= 32 && K1 <= 1024;
+}
+
+int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
+                 int head_cols, float* h1, float* h2, float* out, ts_workspace* prof) {
+    TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_forward: unsupported shape");
+    TS_REQUIRE(M >= 1 && x && wb1 && wb2 && wb3 && out, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+    MlpArgs a{x, wb1, wb2, wb3, h1, h2, out, M, K1};
+    const size_t lds = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP);
+    const dim3 grid((unsigned)ceil_div(M, ROWS));
+    ProfScope scope(prof, TS_KIND_CONV_FWD, s);
+    if (head_cols == 32) {
+        if (lds > 64 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_fwd_kernel<32>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            (void)attr;
+        }
+        hipLaunchKernelGGL((mlp3_fwd_kernel<32>), grid, dim3(THREADS), lds, s, a);
+    } else {
+        if (lds > 64 * 1024) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp3_fwd_kernel<64>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            (void)attr;
+        }
+        hipLaunchKernelGGL((mlp3_fwd_kernel<64>), grid, dim3(THREADS), lds, s, a);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
+                  int head_cols, const float* h1, const float* h2, float* dh1, float* dh2, float* dx, int col0, int col1,
+                  ts_workspace* prof) {
+    TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_backward: unsupported shape");
+    TS_REQUIRE(M >= 1 && d_out && wb1 && wb2 && wb3 && h1 && h2 && dh1 && dh2, TS_ERR_INVALID_ARG,
+               "mlp3_backward: bad argument");
+    BwdArgs a{d_out, wb1, wb2, wb3, h1, h2, dh1, dh2, dx, M, K1, 0, 0};
+    if (dx) {
+        TS_REQUIRE(0 <= col0 && col0 < col1 && col1 <= K1, TS_ERR_INVALID_ARG, "mlp3_backward: bad column range");
+        a.dx_c0 = col0 / 16 * 16;
+        a.dx_nt = (int)ceil_div(col1 - a.dx_c0, 16);
+        TS_REQUIRE(a.dx_nt <= 8, TS_ERR_UNSUPPORTED, "mlp3_backward: input-gradient range wider than 128 columns");
+    }
+    const size_t lds = sizeof(float) * (size_t)(ROWS * (head_cols + 4) + 2 * ROWS * HP);
+    const dim3 grid((unsigned)ceil_div(M, ROWS));
+    ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
+    if (head_cols == 32) hipLaunchKernelGGL((mlp3_bwd_kernel<32>), grid, dim3(THREADS), lds, s, a);
+    else hipLaunchKernelGGL((mlp3_bwd_kernel<64>), grid, dim3(THREADS), lds, s, a);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+bool mlp3_backward_supported(int K1, int hidden, int head_cols, bool want_dx, int col0, int col1) {
+    if (!mlp3_supported(K1, hidden, head_cols)) return false;
+    return !want_dx || ceil_div(col1 - col0 / 16 * 16, 16) <= 8;
+}
+
+}  // namespace ts

@@ -18,6 +18,7 @@
 
 #include "ts_common.h"
 #include "ts_conv.h"
+#include "ts_mlp.h"
 
 #pragma clang fp contract(off)   // the elementwise formulas follow torch's operation order
 
@@ -58,6 +59,9 @@ struct Act { float* h1; float* h2; float* out; };      // forward activations of
 
 int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
                 float* split) {
+    if (ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC)       // one launch (ts_mlp.hip)
+        return ts::mlp3_forward(s, x, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC, a.h1,
+                                a.h2, a.out, ws);
     if (int rc = ts::conv_forward(s, m.l[0], x, p + m.off[0], a.h1, true, split, ws)) return rc;
     if (int rc = ts::conv_forward(s, m.l[1], a.h1, p + m.off[1], a.h2, true, split, ws)) return rc;
     return ts::conv_forward(s, m.l[2], a.h2, p + m.off[2], a.out, false, split, ws);
@@ -81,6 +85,19 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
     const float* xin[3] = {x, a.h1, a.h2};
     const float* dy[3] = {sc.dh1, sc.dh2, d_out};
     float* dxl[3] = {dx, sc.dh1, sc.dh2};
+    if (m.l[1].OC == m.l[0].OC &&
+        ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, dx != nullptr, col0, col1)) {
+        // all input gradients in one launch (ts_mlp.hip), then the three weight-gradient GEMMs
+        if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC,
+                                       a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
+            return rc;
+        for (int i = 2; grad && i >= 0; --i) {
+            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
+            if (int rc = ts::slab_sum(s, sc.slabs, ts::conv_wgrad_splits(m.l[i]), m.l[i].param_elems(), grad + m.off[i]))
+                return rc;
+        }
+        return TS_OK;
+    }
     for (int i = 2; i >= 0; --i) {
         if (grad) {
             if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
