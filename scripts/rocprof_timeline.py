@@ -1,5 +1,6 @@
 """Per-dispatch timeline between the last two launches of a marker kernel in a rocprofv3 rocpd database:
-    python scripts/rocprof_timeline.py x_results.db [marker=adam_kernel]"""
+    python scripts/rocprof_timeline.py x_results.db [marker=adam_kernel] [occurrence=-1]
+(occurrence k: the dispatches between the (k-1)-th and the k-th launch of the marker, Python indexing)"""
 import sqlite3
 import sys
 
@@ -8,7 +9,8 @@ marker = sys.argv[2] if len(sys.argv) > 2 else "adam_kernel"
 rows = list(db.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, "
                        "accum_vgpr_count from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if marker in r[0]]
-lo, hi = idx[-2] + 1, idx[-1] + 1
+k = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+lo, hi = idx[k - 1] + 1, idx[k] + 1
 t0 = rows[lo][1]
 busy = 0.0
 for r in rows[lo:hi]:

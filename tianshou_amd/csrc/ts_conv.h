@@ -38,5 +38,8 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
 // (col_begin, col_end): only the input-channel tiles covering [col_begin, col_end) are computed.
 // out[i] = sum_s slabs[s][i]
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
+// the same for up to four independent slab sets in one launch (same summation order per element as slab_sum)
+struct SlabSeg { const float* slabs; int nslab; int64_t n; float* out; };
+int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg);
 
 }  // namespace ts

@@ -363,6 +363,33 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     if (part == 0 && i < n) *reinterpret_cast<f32x4*>(out + i) = red[col];
 }
 
+// The same sum for up to four independent slab sets in one launch (the layers of one network's backward pass)
+struct SlabSegs {
+    const float* slabs[4]; float* out[4]; int64_t n[4]; int nslab[4]; unsigned first_block[5];
+};
+__global__ __launch_bounds__(256) void slab_sum_multi_kernel(SlabSegs a) {
+    __shared__ f32x4 red[256];
+    int sg = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) sg += blockIdx.x >= a.first_block[k] ? 1 : 0;
+    const float* __restrict__ slabs = a.slabs[sg];
+    const int64_t n = a.n[sg];
+    const int nslab = a.nslab[sg];
+    const int col = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int64_t i = ((int64_t)(blockIdx.x - a.first_block[sg]) * 16 + col) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n)
+        for (int k = part; k < nslab; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n + i);
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 8; st > 0; st >>= 1) {
+        if (part < st) red[threadIdx.x] += red[threadIdx.x + 16 * st];
+        __syncthreads();
+    }
+    if (part == 0 && i < n) *reinterpret_cast<f32x4*>(a.out[sg] + i) = red[col];
+}
+
 // Y[m, n] = act(sum_s buf[s][m, n] + bias[n])   (finish of a split forward)
 __global__ __launch_bounds__(256) void split_finish_kernel(const float* __restrict__ buf, int nsplit, int64_t mn,
                                                            int n, const float* __restrict__ bias, int relu,
@@ -528,6 +555,26 @@ int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out
     if (n <= 0) return TS_OK;
     TS_REQUIRE(n % 4 == 0, TS_ERR_INVALID_ARG, "slab_sum: length must be a multiple of 4");
     hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(256), 0, s, slabs, nslab, n, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg) {
+    TS_REQUIRE(nseg >= 1 && nseg <= 4, TS_ERR_INVALID_ARG, "slab_sum_multi: 1..4 segments");
+    SlabSegs a{};
+    unsigned blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        a.first_block[k] = blocks;
+        if (k < nseg) {
+            TS_REQUIRE(segs[k].n % 4 == 0 && segs[k].n > 0, TS_ERR_INVALID_ARG, "slab_sum_multi: lengths must be multiples of 4");
+            a.slabs[k] = segs[k].slabs; a.out[k] = segs[k].out; a.n[k] = segs[k].n; a.nslab[k] = segs[k].nslab;
+            blocks += (unsigned)ceil_div(segs[k].n, 64);
+        } else {
+            a.first_block[k] = 0xffffffffu;
+        }
+    }
+    a.first_block[4] = blocks;
+    hipLaunchKernelGGL(slab_sum_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

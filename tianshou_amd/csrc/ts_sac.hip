@@ -91,12 +91,16 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
         if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC,
                                        a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
             return rc;
-        for (int i = 2; grad && i >= 0; --i) {
-            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
-            if (int rc = ts::slab_sum(s, sc.slabs, ts::conv_wgrad_splits(m.l[i]), m.l[i].param_elems(), grad + m.off[i]))
-                return rc;
+        if (!grad) return TS_OK;
+        ts::SlabSeg seg[3];
+        size_t off = 0;
+        for (int i = 2; i >= 0; --i) {          // three independent GEMMs into their own slab sets, one sum launch
+            const int ns = ts::conv_wgrad_splits(m.l[i]);
+            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs + off, ws)) return rc;
+            seg[2 - i] = ts::SlabSeg{sc.slabs + off, ns, m.l[i].param_elems(), grad + m.off[i]};
+            off += (size_t)ns * m.l[i].param_elems();
         }
-        return TS_OK;
+        return ts::slab_sum_multi(s, seg, 3);
     }
     for (int i = 2; i >= 0; --i) {
         if (grad) {
@@ -114,30 +118,46 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
     return TS_OK;
 }
 
-size_t slab_floats(const Mlp& m) {
+size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by side (one slab_sum_multi launch)
     size_t s = 0;
-    for (int i = 0; i < 3; ++i) s = std::max(s, (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems());
+    for (int i = 0; i < 3; ++i) s += (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems();
     return s;
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
-// x_a[b] = [obs | 0], x_c[b] = [obs | act | 0]
+// x_a[b] = [obs | 0], x_c[b] = [obs | act | 0]; x_p (nullable) = a second copy of x_c's observation columns (its
+// action columns are written by the policy kernel).  Four output columns per thread (ka, kc are multiples of 32).
 __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
                                                        int64_t B, int obs_dim, int act_dim, int ka, int kc,
-                                                       float* __restrict__ x_a, float* __restrict__ x_c) {
+                                                       float* __restrict__ x_a, float* __restrict__ x_c,
+                                                       float* __restrict__ x_p) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int w = ka + kc;
-    if (i >= B * w) return;
-    const int64_t b = i / w;
-    const int j = (int)(i - b * w);
+    const int w4 = (ka + kc) / 4;
+    if (i >= B * w4) return;
+    const int64_t b = i / w4;
+    const int j = (int)(i - b * w4) * 4;
+    const float* ob = obs + b * obs_dim;
     if (j < ka) {
-        if (x_a) x_a[b * ka + j] = j < obs_dim ? obs[b * obs_dim + j] : 0.f;
+        if (!x_a) return;
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = j + t < obs_dim ? ob[j + t] : 0.f;
+        *reinterpret_cast<f32x4*>(x_a + b * ka + j) = v;
     } else if (x_c) {
         const int k = j - ka;
-        float v = 0.f;
-        if (k < obs_dim) v = obs[b * obs_dim + k];
-        else if (k < obs_dim + act_dim && act) v = act[b * act_dim + k - obs_dim];
-        x_c[b * kc + k] = v;
+        f32x4 v, vp;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = k + t;
+            float e = 0.f;
+            if (c < obs_dim) e = ob[c];
+            vp[t] = e;
+            if (c >= obs_dim && c < obs_dim + act_dim && act) e = act[b * act_dim + c - obs_dim];
+            v[t] = e;
+        }
+        *reinterpret_cast<f32x4*>(x_c + b * kc + k) = v;
+        if (x_p) *reinterpret_cast<f32x4*>(x_p + b * kc + k) = vp;
     }
 }
 
@@ -149,24 +169,32 @@ __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict
                                                          int64_t B, int A, int head_cols, int obs_dim, int kc,
                                                          float* __restrict__ x_c, float* __restrict__ act_out,
                                                          float* __restrict__ logp_out, float* __restrict__ keep) {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
-    const float* hb = head + b * head_cols;
+    // half a wavefront per sample, lane j = action dimension j (A <= 32); the two sums over j are butterfly
+    // reductions inside the half-wave (fixed order)
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = t >> 5;
+    const int j = (int)(t & 31);
     float lp = 0.f, corr = 0.f;
-    for (int j = 0; j < A; ++j) {
+    if (b < B && j < A) {
+        const float* hb = head + b * head_cols;
         const float mu = hb[j];
         const float sigma = expf(fminf(fmaxf(hb[SIG_COL + j], SIGMA_MIN), SIGMA_MAX));
         const float e = noise ? noise[b * A + j] : 0.f;
         const float a = mu + e * sigma;                              // Normal.rsample: loc + eps * scale
         const float d = a - mu;
-        lp += -(d * d) / (2.f * (sigma * sigma)) - logf(sigma) - LOG_SQRT_2PI;      // Normal.log_prob
+        lp = -(d * d) / (2.f * (sigma * sigma)) - logf(sigma) - LOG_SQRT_2PI;      // Normal.log_prob
         const float sq = tanhf(a);
-        corr += logf(1.f - sq * sq + TANH_EPS);                      // sac.py:38
+        corr = logf(1.f - sq * sq + TANH_EPS);                       // sac.py:38
         if (x_c) x_c[b * kc + obs_dim + j] = sq;
         if (act_out) act_out[b * A + j] = sq;
         if (keep) { keep[(b * 3 + 0) * A + j] = d; keep[(b * 3 + 1) * A + j] = sigma; keep[(b * 3 + 2) * A + j] = sq; }
     }
-    logp_out[b] = lp - corr;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+        lp += __shfl_xor(lp, o, 32);
+        corr += __shfl_xor(corr, o, 32);
+    }
+    if (b < B && j == 0) logp_out[b] = lp - corr;
 }
 
 // SAC._target_q_compute_value: min(Q1_old, Q2_old) - alpha * log_prob  (q arrays are [B, 32], column 0)
@@ -179,16 +207,16 @@ __global__ __launch_bounds__(256) void sac_target_kernel(const float* __restrict
     out[b] = fminf(q1[b * 32], q2[b * 32]) - alpha * logp[b];
 }
 
-// block-wide deterministic sum (1024 threads)
+// block-wide deterministic sum (1024 threads): butterfly inside each wavefront, then the 16 wave sums
 __device__ float block_sum_1024(float v, float* red) {
-    red[threadIdx.x] = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();                                   // `red` may still be read by a previous call
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float r = red[0];
-    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) r += red[w];
     return r;
 }
 
@@ -614,10 +642,10 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     const Act aa = take_act(c, B, 64);
     float* keep = c.take<float>(B * 3 * d.act);
     float* split = c.take<float>(split_floats(ma));
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
-    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, (float*)nullptr, act_out, logp_out, mu_sigma_out ? keep : nullptr);
     TS_LAUNCH_CHECK();
     if (mu_sigma_out) {      // {a - mu, sigma, squashed} rows, for diagnostics / tests
@@ -649,10 +677,10 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     float* split2 = c.take<float>(spl);
     hipStream_t side;
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
-    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;            // the two lagged critics side by side
@@ -698,7 +726,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
                    2 * al(4 * B * HID) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
                    al(4 * B * 3 * d.act) + 8192;
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + al(4 * B * 32);
+    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32);
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -706,16 +734,20 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* x_p = c.take<float>(B * d.kc);          // [obs | policy action]
     float* dx1 = c.take<float>(B * d.kc);
     const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
-    float* d_head = c.take<float>(B * 64);         // upstream gradient of a head output (zero-padded columns)
-    float* d_q1 = c.take<float>(B * 64);
-    float* d_q2 = d_q1 + B * 32;
+    // upstream gradients of the head outputs: the loss kernels write the live columns, the zero padding of all five
+    // comes from ONE memset at the start of the update
+    float* zeroed = c.take<float>(B * 192);
+    float* d_c1 = zeroed;                          // critic 1 loss      [B, 32]
+    float* d_c2 = zeroed + B * 32;                 // critic 2 loss      [B, 32]
+    float* d_q1 = zeroed + B * 64;                 // actor loss -> Q1   [B, 32]
+    float* d_q2 = zeroed + B * 96;                 // actor loss -> Q2   [B, 32]
+    float* d_head = zeroed + B * 128;              // policy backward    [B, 64]
     float* dx2 = c.take<float>(B * 64 > B * d.kc ? B * 64 : B * d.kc);
     BwdScratch sc, sc2;              // one set per stream (the two critics run concurrently)
     sc.dh2 = c.take<float>(B * HID); sc.dh1 = c.take<float>(B * HID); sc.slabs = c.take<float>(slab);
     sc2.dh2 = c.take<float>(B * HID); sc2.dh1 = c.take<float>(B * HID); sc2.slabs = c.take<float>(slab);
     float* grad = c.take<float>(std::max(pa, pc));
     float* grad2 = c.take<float>(pc);
-    float* d_head2 = c.take<float>(B * 32);
     float* split2 = c.take<float>(spl);
     float* td1 = c.take<float>(B); float* td2 = c.take<float>(B); float* logp = c.take<float>(B);
     float* keep = c.take<float>(B * 3 * d.act);
@@ -729,11 +761,10 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         g_out[0] = grads; g_out[1] = grads + pc; g_out[2] = grads;
     }
     if (phases & PH_CRITIC_GRAD) {
-        hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act,
-                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
-        TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
+        hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
+                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p);
+        TS_HIP_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * B * 192, s));
     }
-    if (phases & PH_ACTOR_GRAD) TS_HIP_CHECK(hipMemsetAsync(d_q1, 0, sizeof(float) * B * 64, s));
 
     // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
     // caller's stream, critic 2 on the workspace's side stream (each of these GEMMs fills only part of the chip).
@@ -745,11 +776,10 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* crit_v[2] = {st->critic1_v, st->critic2_v};
     float* tds[2] = {td1, td2};
     const Act acts[2] = {a1, a2};
-    float* dheads[2] = {d_head, d_head2};
+    float* dheads[2] = {d_c1, d_c2};
     float* splits[2] = {split, split2};
     float* gbuf[2] = {grad, grad2};
     const BwdScratch scs[2] = {sc, sc2};
-    if (phases & PH_CRITIC_GRAD) TS_HIP_CHECK(hipMemsetAsync(d_head2, 0, sizeof(float) * B * 32, s));
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
     for (int k = 0; k < 2; ++k) {
         hipStream_t sk = stq[k];
@@ -771,10 +801,9 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     // actor (sac.py:308-315): a ~ pi(s) with the supplied noise, Q1(s, a), Q2(s, a) with the UPDATED critics
     float* ga = g_out[2] ? g_out[2] : grad;
     if (phases & PH_ACTOR_GRAD) {
-        TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
-        hipLaunchKernelGGL(sac_policy_kernel, dim3(gb), dim3(256), 0, s, aa.out, noise, B, d.act, 64, d.obs, d.kc, x_p,
-                           (float*)nullptr, logp, keep);
+        hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B,
+                           d.act, 64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
         if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;              // x_p ready; critic 2 is already updated there
         if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
         if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
@@ -785,7 +814,6 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
         if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
         if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
-        TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
         if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
         hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
                            keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
@@ -867,8 +895,8 @@ int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     float* x_a = c.take<float>(B * d.ka);
     const Act aa = take_act(c, B, 32);
     float* split = c.take<float>(split_floats(ma));
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out,
                        (const float*)nullptr, B, d.act, (float)max_action, 0.f, 0.f, d.obs, d.kc, (float*)nullptr, act_out,
@@ -894,8 +922,8 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor_old, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise, B,
                        d.act, (float)max_action, (float)policy_noise, (float)noise_clip, d.obs, d.kc, x_c, (float*)nullptr,
@@ -957,8 +985,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* norm_part = c.take<float>(1024);
     float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
 
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
-                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act, B,
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 32, s));
     TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 32, s));
     // critics (ddpg.py:279-285): critic 1 on the caller's stream, critic 2 on the side stream
@@ -1048,8 +1076,8 @@ int ts_dsac_policy_forward(ts_workspace* ws, const float* actor, const float* ob
     float* x = c.take<float>(B * d.ka);
     const Act a = take_act(c, B, d.hw, d.hid);
     float* split = c.take<float>(split_floats(m));
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs,
-                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, m, actor, x, a, split)) return rc;
     hipLaunchKernelGGL(unpad_rows_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, a.out, B, d.act, d.hw,
                        logits_out);
@@ -1075,8 +1103,8 @@ int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_
     const Act aa = take_act(c, B, d.hw, d.hid), a1 = take_act(c, B, d.hw, d.hid), a2 = take_act(c, B, d.hw, d.hid);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs_next,
-                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
     TS_LAUNCH_CHECK();
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
@@ -1126,8 +1154,8 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
     const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
     float* g_out[3] = {grads_out, grads_out ? grads_out + P : nullptr, grads_out ? grads_out + 2 * P : nullptr};
 
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka, 256)), dim3(256), 0, s, obs,
-                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
     TS_LAUNCH_CHECK();
     // critic 1 on the caller's stream, critic 2 on the side stream (independent chains, as ts_sac_update)
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
@@ -1210,10 +1238,10 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
     hipStream_t st2[2] = {s, side};
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs_next,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, splits[0])) return rc;
-    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
@@ -1279,8 +1307,8 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
     const float inv_eb = 1.f / ((float)E * (float)B);
 
-    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc), 256)), dim3(256), 0, s, obs, act, B,
-                       d.obs, d.act, d.ka, d.kc, x_a, x_c);
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act, B,
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 64, s));
     TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 64, s));
     // ensemble loss (redq.py:266-271): the members are independent chains, alternating between two streams
@@ -1312,7 +1340,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
         TS_HIP_CHECK(hipMemsetAsync(d_q, 0, sizeof(float) * B * 32, s));
         TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, splits[0])) return rc;
-        hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+        hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                            64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
         TS_LAUNCH_CHECK();
         for (int e = 0; e < E; ++e)
