@@ -397,7 +397,9 @@ def main():
             import bench_next
 
             k = 1 if args.workload in ("ppo_discrete", "npg", "trpo", "reinforce") else 10
-            print(json.dumps(bench_next.run(args.workload, max(args.steps, 1) * k, max(args.warmup, 1) * 2,
+            # sub-millisecond updates: 20 warm-up updates, so that a 20 ms timed region does not start inside the clock /
+            # allocator / lazy-load transients of a fresh process (2 warm-up updates gave one outlier run in four)
+            print(json.dumps(bench_next.run(args.workload, max(args.steps, 1) * k, max(args.warmup, 1) * (20 if k == 10 else 2),
                                             with_cpu=not args.no_cpu_baseline)), flush=True)
             return
         if args.workload == "ppo_atari":
@@ -406,7 +408,7 @@ def main():
             print(json.dumps(bench_ppo_cnn.run(1, 0, with_cpu=not args.no_cpu_baseline)), flush=True)
             return
         mod = importlib.import_module("bench_" + args.workload)
-        print(json.dumps(mod.run(max(args.steps, 1) * 10, max(args.warmup, 1) * 5,
+        print(json.dumps(mod.run(max(args.steps, 1) * 10, max(args.warmup, 1) * 20,
                                  with_cpu=not args.no_cpu_baseline)), flush=True)
         return
 

@@ -1,5 +1,5 @@
-for v in "" "TS_MLP_PER_LAYER=1"; do
-  env $v python bench.py --workload dsac --no-cpu-baseline 2>/dev/null | python -c "
+for i in 1 2 3 4 5 6; do
+  python bench.py --workload ddpg --no-cpu-baseline --steps 300 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('[$v]', 'dsac', round(d['value'],1), round(d['ms_per_step'],3), d['roofline'].get('kernel_us_per_update'), d['config'])"
+d=json.loads(sys.stdin.read()); print('ddpg steps=300', round(d['value'],1), round(d['ms_per_step'],3))"
 done

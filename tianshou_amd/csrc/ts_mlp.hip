@@ -56,6 +56,10 @@ enum : int { EP_BIAS_RELU = 0, EP_BIAS = 1, EP_MASK = 2, EP_PLAIN = 3 };
 //                  the rows of the layer matrix are contiguous along the contraction, one dwordx4 per four MFMAs)
 // A = a_lds [16][a_pitch]; K = contraction length (multiple of 32).  The result goes to o_lds ([16][HP], nullable) and
 // to o_g (row pitch o_ld, nullable; rows >= M are not stored).
+//   Forward layers with two tiles per wave load COLUMN PAIRS: the wave's 32 columns are split by parity (tile j =
+//   columns c0 + 32 wave + 2 n + j), so that lane n fetches both tiles' weights of one k with a single dwordx2 and a
+//   16-lane group reads one whole 128-byte line.  Half as many loads in flight per byte matters because a wave can
+//   have at most 63 outstanding (vmcnt): with dword loads three 32-deep k groups, with dwordx2 six.
 template <int PITCH, int TPW, bool TRANS, int EP>
 __device__ __forceinline__ void mlp_layer(const float* __restrict__ wb, int K, int nt, int c0, const float* a_lds,
                                           int a_pitch, float* o_lds, float* __restrict__ o_g, int o_ld,
@@ -72,11 +76,24 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ wb, int K, i
     for (int j = 0; j < TPW; ++j) tj[j] = min(tile0 + j, nt - 1);
     const float* al = a_lds + n * a_pitch + 4 * kq;                       // + 32 g + 16 blk   (row = lane & 15)
     const int ng = K / 32;
-    f32x4 st[4][2][TPW];
+    constexpr bool PAIR = !TRANS && TPW == 2;
+    constexpr int NST = PAIR ? 6 : 4;                                     // register stages = groups in flight + 1
+    f32x4 st[NST][2][TPW];
     auto gload = [&](int g, f32x4 (&s)[2][TPW]) {
         const int gg = min(g, ng - 1);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < 2; ++blk) {
+            if (PAIR) {
+                using f32x2 = __attribute__((ext_vector_type(2))) float;
+                const float* w = wb + (size_t)(32 * gg + 16 * blk + 4 * kq) * PITCH + c0 + tile0 * 16 + 2 * n;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const f32x2 v = *reinterpret_cast<const f32x2*>(w + t * PITCH);
+                    s[blk][0][t] = v[0];
+                    s[blk][TPW - 1][t] = v[1];
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < TPW; ++j) {
                 if (TRANS) {
@@ -87,6 +104,7 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ wb, int K, i
                     for (int t = 0; t < 4; ++t) s[blk][j][t] = w[t * PITCH];
                 }
             }
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     auto compute = [&](int g, const f32x4 (&s)[2][TPW]) {
@@ -100,24 +118,26 @@ __device__ __forceinline__ void mlp_layer(const float* __restrict__ wb, int K, i
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    gload(0, st[0]);
-    gload(1, st[1]);
-    gload(2, st[2]);
+    // ring of NST register stages: group g lives in stage g % NST and is loaded NST - 1 groups ahead
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) gload(i, st[i]);
     int g = 0;
-    for (; g + 4 <= ng; g += 4) {
-        gload(g + 3, st[3]); compute(g, st[0]);
-        gload(g + 4, st[0]); compute(g + 1, st[1]);
-        gload(g + 5, st[1]); compute(g + 2, st[2]);
-        gload(g + 6, st[2]); compute(g + 3, st[3]);
+    for (; g + NST <= ng; g += NST) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            gload(g + i + NST - 1, st[(i + NST - 1) % NST]);
+            compute(g + i, st[i]);
+        }
     }
-    if (g < ng) compute(g, st[0]);
-    if (g + 1 < ng) compute(g + 1, st[1]);
-    if (g + 2 < ng) compute(g + 2, st[2]);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i) {         // the last ng % NST groups are already in their stages
+        if (g + i < ng) compute(g + i, st[i]);
+    }
 
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
         if (tile0 + j >= nt) break;
-        const int col = c0 + (tile0 + j) * 16 + n;
+        const int col = PAIR ? c0 + tile0 * 16 + 2 * n + j : c0 + (tile0 + j) * 16 + n;
         const float bias = (EP == EP_BIAS_RELU || EP == EP_BIAS) ? wb[(size_t)K * PITCH + col] : 0.f;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -142,6 +162,16 @@ __device__ __forceinline__ void load_rows(const float* __restrict__ src, int K, 
     }
 }
 
+// [16][HID] tile in LDS (pitch HP) -> rows m0 .. of a [M, HID] matrix, 16 bytes per lane
+__device__ __forceinline__ void store_rows(const float* src, float* __restrict__ dst, int m0, int M, int tid) {
+    if (!dst) return;
+    for (int i = tid; i < ROWS * (HID / 4); i += THREADS) {
+        const int row = i / (HID / 4), c = i % (HID / 4);
+        if (m0 + row < M)
+            *reinterpret_cast<f32x4*>(dst + (size_t)(m0 + row) * HID + 4 * c) = *reinterpret_cast<const f32x4*>(src + row * HP + 4 * c);
+    }
+}
+
 template <int N3>
 __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -155,13 +185,15 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     load_rows(a.x, a.K1, m0, a.M, xs, xp, tid);
     __syncthreads();
     MMARK(1);
-    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb1, a.K1, HID / 16, 0, xs, xp, h1s, a.h1, HID, nullptr, m0, a.M, wave, lane);
+    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb1, a.K1, HID / 16, 0, xs, xp, h1s, nullptr, HID, nullptr, m0, a.M, wave, lane);
     MMARK(2);
     __syncthreads();
     MMARK(3);
-    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb2, HID, HID / 16, 0, h1s, HP, h2s, a.h2, HID, nullptr, m0, a.M, wave, lane);
+    store_rows(h1s, a.h1, m0, a.M, tid);
+    mlp_layer<HID, 2, false, EP_BIAS_RELU>(a.wb2, HID, HID / 16, 0, h1s, HP, h2s, nullptr, HID, nullptr, m0, a.M, wave, lane);
     __syncthreads();
     MMARK(4);
+    store_rows(h2s, a.h2, m0, a.M, tid);
     mlp_layer<N3, 1, false, EP_BIAS>(a.wb3, HID, N3 / 16, 0, h2s, HP, nullptr, a.out, N3, nullptr, m0, a.M, wave, lane);
     MMARK(5);
 }
@@ -186,11 +218,13 @@ __global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
     float* g1s = g2s + ROWS * HP;
     load_rows(a.d_out, N3, m0, a.M, ds, N3 + 4, tid);
     __syncthreads();
-    mlp_layer<N3, 2, true, EP_MASK>(a.wb3, N3, HID / 16, 0, ds, N3 + 4, g2s, a.dh2, HID, a.h2, m0, a.M, wave, lane);
+    mlp_layer<N3, 2, true, EP_MASK>(a.wb3, N3, HID / 16, 0, ds, N3 + 4, g2s, nullptr, HID, a.h2, m0, a.M, wave, lane);
     __syncthreads();
-    mlp_layer<HID, 2, true, EP_MASK>(a.wb2, HID, HID / 16, 0, g2s, HP, g1s, a.dh1, HID, a.h1, m0, a.M, wave, lane);
+    store_rows(g2s, a.dh2, m0, a.M, tid);
+    mlp_layer<HID, 2, true, EP_MASK>(a.wb2, HID, HID / 16, 0, g2s, HP, g1s, nullptr, HID, a.h1, m0, a.M, wave, lane);
+    __syncthreads();
+    store_rows(g1s, a.dh1, m0, a.M, tid);
     if (a.dx == nullptr) return;
-    __syncthreads();
     mlp_layer<HID, 1, true, EP_PLAIN>(a.wb1, HID, a.dx_nt, a.dx_c0, g1s, HP, nullptr, a.dx, a.K1, nullptr, m0, a.M, wave, lane);
 }
 

@@ -79,19 +79,23 @@ size_t split_floats(const Mlp& m) {
 struct BwdScratch { float* dh2; float* dh1; float* slabs; };
 
 // d_out = d loss / d head output.  grad (nullable) receives the flat parameter gradient; dx (nullable) the
-// gradient w.r.t. the input columns [col0, col1).
+// gradient w.r.t. the input columns [col0, col1).  `part`: 1 = the input-gradient chain, 2 = the weight gradients,
+// 3 = both -- callers that run two networks on two streams enqueue part 1 of both before part 2 of either, so that
+// the second stream has work while the host is still submitting the first one's GEMMs (on the per-layer path the two
+// are interleaved and everything happens in part 1).
 int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
-                 const float* d_out, float* grad, float* dx, int col0, int col1, const BwdScratch& sc) {
+                 const float* d_out, float* grad, float* dx, int col0, int col1, const BwdScratch& sc, int part = 3) {
     const float* xin[3] = {x, a.h1, a.h2};
     const float* dy[3] = {sc.dh1, sc.dh2, d_out};
     float* dxl[3] = {dx, sc.dh1, sc.dh2};
     if (m.l[1].OC == m.l[0].OC &&
         ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, dx != nullptr, col0, col1)) {
         // all input gradients in one launch (ts_mlp.hip), then the three weight-gradient GEMMs
-        if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC,
-                                       a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
-            return rc;
-        if (!grad) return TS_OK;
+        if (part & 1)
+            if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2],
+                                           m.l[2].OC, a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
+                return rc;
+        if (!grad || !(part & 2)) return TS_OK;
         ts::SlabSeg seg[3];
         size_t off = 0;
         for (int i = 2; i >= 0; --i) {          // three independent GEMMs into their own slab sets, one sum launch
@@ -102,6 +106,7 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
         }
         return ts::slab_sum_multi(s, seg, 3);
     }
+    if (!(part & 1)) return TS_OK;
     for (int i = 2; i >= 0; --i) {
         if (grad) {
             if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
@@ -122,6 +127,17 @@ size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by s
     size_t s = 0;
     for (int i = 0; i < 3; ++i) s += (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems();
     return s;
+}
+
+// Second stream for the twin critics.  With the one-launch chains of ts_mlp.hip every kernel of a C5-shape critic fills
+// the chip and the twin chains gain nothing side by side: measured on one stream SAC 1,820 vs 1,778 and TD3 2,382 vs
+// 2,302 updates/s (DDPG equal), without the event record / wait pairs.  SAC / TD3 / DDPG therefore stay on the caller's
+// stream when their networks take the fused path; REDQ (ten critics: +17 %) and DiscreteSAC (short chains: +12 %) keep
+// both streams.
+int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t* out) {
+    static const bool force = getenv("TS_TWIN_STREAMS") != nullptr;       // experiments
+    if (!force && ts::mlp3_supported(critic.l[0].IC, critic.l[0].OC, critic.l[2].OC)) { *out = s; return TS_OK; }
+    return ts::side_stream(ws, s, out);
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
@@ -676,7 +692,7 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
     hipStream_t side;
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
@@ -769,7 +785,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
     // caller's stream, critic 2 on the workspace's side stream (each of these GEMMs fills only part of the chip).
     hipStream_t side;
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
     float* crit_m[2] = {st->critic1_m, st->critic2_m};
@@ -781,16 +797,20 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* gbuf[2] = {grad, grad2};
     const BwdScratch scs[2] = {sc, sc2};
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    for (int k = 0; k < 2 && (phases & PH_CRITIC_GRAD); ++k) {
+        hipStream_t sk = stq[k];
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                           dheads[k], stats_out5 + 1 + k);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
+    }
     for (int k = 0; k < 2; ++k) {
         hipStream_t sk = stq[k];
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (phases & PH_CRITIC_GRAD) {
-            if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-            hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                               dheads[k], stats_out5 + 1 + k);
-            TS_LAUNCH_CHECK();
-            if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
-        }
+        if (phases & PH_CRITIC_GRAD)
+            if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 2)) return rc;
         if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0)
             if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
@@ -931,7 +951,7 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     TS_LAUNCH_CHECK();
     if (critic2_old) {                                                  // the two lagged critics side by side
         hipStream_t side;
-        if (int rc = ts::side_stream(ws, s, &side)) return rc;
+        if (int rc = twin_stream(ws, s, mc, &side)) return rc;
         if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
         if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
         if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
@@ -960,8 +980,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     Dims d;
     if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
     const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
+    if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
