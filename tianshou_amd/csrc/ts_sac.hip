@@ -306,6 +306,71 @@ __global__ __launch_bounds__(256) void sac_policy_bwd_kernel(const float* __rest
     d_head[b * head_cols + SIG_COL + j] = g_raw;
 }
 
+// The two loss kernels above run on ONE workgroup (4096 strided Q reads through a single CU: 10 - 17 us).  SAC's update
+// uses these: one thread per sample over ceil(B / 256) workgroups, a partial loss sum per workgroup (`part`), summed in
+// workgroup order by loss_finish (in sac_alpha_kernel at the end of a whole update, in sac_loss_finish_kernel after a
+// single phase) -- a fixed order, so the loss statistics stay deterministic.
+__device__ float block_sum_256(float v, float* red4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red4[0] + red4[1] + red4[2] + red4[3];
+}
+
+__global__ __launch_bounds__(256) void sac_critic_loss_mb_kernel(const float* __restrict__ q, const float* __restrict__ ret,
+                                                                 const float* __restrict__ weight, int64_t B,
+                                                                 float* __restrict__ td, float* __restrict__ d_out,
+                                                                 float* __restrict__ part) {
+    __shared__ float red[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    if (b < B) {
+        const float t = q[b * 32] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        td[b] = t;
+        ls = t * t * w;
+        d_out[b * 32] = 2.f * t * w * inv_b;       // the other 31 columns of d_out stay zero
+    }
+    const float tot = block_sum_256(ls, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void sac_actor_loss_mb_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
+                                                                const float* __restrict__ logp,
+                                                                const float* __restrict__ log_alpha, float fixed_alpha,
+                                                                int64_t B, float* __restrict__ d_q1, float* __restrict__ d_q2,
+                                                                float* __restrict__ part) {
+    __shared__ float red[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float inv_b = 1.f / (float)B;
+    float ls = 0.f;
+    if (b < B) {
+        const float a = q1[b * 32], c = q2[b * 32];
+        ls = alpha * logp[b] - fminf(a, c);
+        // torch.minimum backward: ties share the gradient
+        d_q1[b * 32] = a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+        d_q2[b * 32] = c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+    }
+    const float tot = block_sum_256(ls, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+__device__ __forceinline__ float loss_finish(const float* part, int n, int64_t B) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    return s * (1.f / (float)B);
+}
+
+// mean losses from the partial sums (nullable pointers are skipped); one thread
+__global__ void sac_loss_finish_kernel(const float* p0, float* o0, const float* p1, float* o1, int n, int64_t B) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (p0) *o0 = loss_finish(p0, n, B);
+    if (p1) *o1 = loss_finish(p1, n, B);
+}
+
 // AutoAlpha.update (sac.py:203-209) + Adam on the scalar log_alpha; (td1 + td2) / 2 (sac.py:306)
 struct AlphaArgs {
     const float* logp; int64_t B; float target_entropy;
@@ -314,6 +379,8 @@ struct AlphaArgs {
     float* alpha_loss; float* alpha_out; float fixed_alpha;
     const float* td1; const float* td2; float* weight_out;
     const float* neg_mean_logp;      // data-parallel: -mean(log_prob) over the GLOBAL batch (replaces the local mean)
+    const float* loss_part;          // whole update: partial sums of {actor, critic1, critic2} losses, n_part each
+    float* losses; int n_part;       // -> losses[0 .. 2] (nullable loss_part: already finished by the phases)
 };
 
 __global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
@@ -325,6 +392,8 @@ __global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
     }
     const float tot = block_sum_1024(s, red);
     if (threadIdx.x != 0) return;
+    if (a.loss_part)
+        for (int k = 0; k < 3; ++k) a.losses[k] = loss_finish(a.loss_part + k * a.n_part, a.n_part, a.B);
     if (!a.log_alpha) { *a.alpha_out = a.fixed_alpha; *a.alpha_loss = 0.f; return; }
     // mean entropy deficit = mean(target - (-log_prob)); written so that the single-call and the phased update
     // (which receives -mean(log_prob) through the exchange buffer) evaluate the same float operations
@@ -742,7 +811,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
                    2 * al(4 * B * HID) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
                    al(4 * B * 3 * d.act) + 8192;
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32);
+    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
+             al(4 * 3 * ts::ceil_div(B, 256));
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -770,6 +840,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* norm_part = c.take<float>(1024);
     float* split = c.take<float>(spl);
     const unsigned gb = (unsigned)ts::ceil_div(B, 256);
+    float* loss_part = c.take<float>(3 * (size_t)gb);      // {actor, critic1, critic2} x gb partial sums
     const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
     float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
 
@@ -801,8 +872,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         hipStream_t sk = stq[k];
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
         if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                           dheads[k], stats_out5 + 1 + k);
+        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb), dim3(256), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                           dheads[k], loss_part + (1 + k) * gb);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
     }
@@ -816,6 +887,13 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
                 return rc;
     }
+    if (phases == PH_CRITIC_GRAD) {          // a single phase finishes its own loss statistics
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+        hipLaunchKernelGGL(sac_loss_finish_kernel, dim3(1), dim3(64), 0, s, loss_part + gb, stats_out5 + 1,
+                           loss_part + 2 * gb, stats_out5 + 2, (int)gb, B);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    }
     if (!(phases & (PH_ACTOR_GRAD | PH_ACTOR_APPLY))) return ts::stream_wait(ws, side, s, 1);
 
     // actor (sac.py:308-315): a ~ pi(s) with the supplied noise, Q1(s, a), Q2(s, a) with the UPDATED critics
@@ -828,8 +906,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
         if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
         if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
-        hipLaunchKernelGGL(sac_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, a2.out, logp, log_alpha, (float)hp->alpha, B,
-                           d_q1, d_q2, stats_out5);
+        hipLaunchKernelGGL(sac_actor_loss_mb_kernel, dim3(gb), dim3(256), 0, s, a1.out, a2.out, logp, log_alpha,
+                           (float)hp->alpha, B, d_q1, d_q2, loss_part);
         TS_LAUNCH_CHECK();
         if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
         if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
@@ -839,8 +917,10 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
                            keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
-        if (phases != PH_ALL) {      // the alpha step's only batch statistic, for the all-reduce
+        if (phases != PH_ALL) {      // the alpha step's only batch statistic, for the all-reduce; the actor loss
             hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, logp, B, grads + pa);
+            hipLaunchKernelGGL(sac_loss_finish_kernel, dim3(1), dim3(64), 0, s, loss_part, stats_out5, (const float*)nullptr,
+                               (float*)nullptr, (int)gb, B);
             TS_LAUNCH_CHECK();
         }
     }
@@ -861,6 +941,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     aa2.alpha_loss = stats_out5 + 4; aa2.alpha_out = stats_out5 + 3; aa2.fixed_alpha = (float)hp->alpha;
     aa2.td1 = td1; aa2.td2 = td2; aa2.weight_out = weight_out;
     aa2.neg_mean_logp = phases != PH_ALL ? grads + pa : nullptr;
+    aa2.loss_part = phases == PH_ALL ? loss_part : nullptr; aa2.losses = stats_out5; aa2.n_part = (int)gb;
     hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
     if (hp->tau > 0.0)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
