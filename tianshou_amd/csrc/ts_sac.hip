@@ -1066,7 +1066,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
-    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * B * 32) +
+    const unsigned gb = (unsigned)ts::ceil_div(B, 256);
+    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 4 * al(4 * B * 32) + al(4 * 3 * gb) +
                          4 * al(4 * B * HID) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
                          al(4 * B * d.act) + 2 * al(4 * spl) + 8192;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
@@ -1076,7 +1077,13 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* x_p = c.take<float>(B * d.kc);
     float* dx1 = c.take<float>(B * d.kc);
     const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
-    float* dheads[2] = {c.take<float>(B * 32), c.take<float>(B * 32)};
+    // upstream gradients of the head outputs [B, 32]: live column written by the loss kernels, zero padding from ONE
+    // memset: {critic 1 loss, critic 2 loss, actor loss -> Q1, policy backward}
+    float* zeroed = c.take<float>(B * 128);
+    float* dheads[2] = {zeroed, zeroed + B * 32};
+    float* d_q = zeroed + B * 64;
+    float* d_pol = zeroed + B * 96;
+    float* loss_part = c.take<float>(3 * (size_t)gb);      // {actor, critic1, critic2} x gb partial sums
     BwdScratch scs[2];
     for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * HID); scs[k].dh1 = c.take<float>(B * HID); scs[k].slabs = c.take<float>(slab); }
     float* gbuf[2] = {c.take<float>(std::max(pa, pc)), c.take<float>(std::max(pa, pc))};
@@ -1087,9 +1094,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
 
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act, B,
-                       d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
-    TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 32, s));
-    TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 32, s));
+                       d.obs, d.act, d.ka, d.kc, x_a, x_c, hp->update_actor ? x_p : (float*)nullptr);
+    TS_HIP_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * B * 128, s));
     // critics (ddpg.py:279-285): critic 1 on the caller's stream, critic 2 on the side stream
     hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
@@ -1101,8 +1107,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     for (int k = 0; k < (twin ? 2 : 1); ++k) {
         hipStream_t sk = stq[k];
         if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                           dheads[k], stats_out3 + 1 + k);
+        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb), dim3(256), 0, sk, acts[k].out, returns, weight, B, tds[k],
+                           dheads[k], loss_part + (1 + k) * gb);
         TS_LAUNCH_CHECK();
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
         if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
@@ -1113,27 +1119,26 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     }
     if (twin)
         if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    hipLaunchKernelGGL(sac_loss_finish_kernel, dim3(1), dim3(64), 0, s, loss_part + gb, stats_out3 + 1,
+                       twin ? loss_part + 2 * gb : (const float*)nullptr, stats_out3 + 2, (int)gb, B);
     if (weight_out)
         hipLaunchKernelGGL(td3_weight_kernel, dim3(16), dim3(1024), 0, s, tds[0], twin ? tds[1] : (const float*)nullptr, B,
                            weight_out);                                          // td3.py:212 / ddpg.py:405
     if (hp->update_actor) {                                                      // td3.py:215-219, ddpg.py:406-409
-        TS_HIP_CHECK(hipMemcpyAsync(x_p, x_c, sizeof(float) * B * d.kc, hipMemcpyDeviceToDevice, s));
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, splits[0])) return rc;
         hipLaunchKernelGGL(det_policy_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out,
                            (const float*)nullptr, B, d.act, (float)hp->max_action, 0.f, 0.f, d.obs, d.kc, x_p,
                            (float*)nullptr, keep);
         if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, splits[0])) return rc;
-        TS_HIP_CHECK(hipMemsetAsync(dheads[1], 0, sizeof(float) * B * 32, s));
-        hipLaunchKernelGGL(det_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, B, dheads[1], stats_out3);
+        hipLaunchKernelGGL(det_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, B, d_q, stats_out3);
         TS_LAUNCH_CHECK();
-        if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, dheads[1], nullptr, dx1, d.obs, d.obs + d.act, scs[0]))
+        if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q, nullptr, dx1, d.obs, d.obs + d.act, scs[0]))
             return rc;
-        TS_HIP_CHECK(hipMemsetAsync(dheads[0], 0, sizeof(float) * B * 32, s));
         hipLaunchKernelGGL(det_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, dx1, keep, B,
-                           d.act, (float)hp->max_action, d.obs, d.kc, dheads[0]);
+                           d.act, (float)hp->max_action, d.obs, d.kc, d_pol);
         TS_LAUNCH_CHECK();
         float* ga = g_out[2] ? g_out[2] : gbuf[0];
-        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, dheads[0], ga, nullptr, 0, 0, scs[0])) return rc;
+        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_pol, ga, nullptr, 0, 0, scs[0])) return rc;
         if (hp->actor_lr >= 0.0)
             if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, pa, actor_step, hp->actor_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
