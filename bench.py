@@ -361,7 +361,7 @@ def hook_level(device, updates=3, permutations="device"):
 def other_workloads():
     """Short runs of the C3 / C5 / Atari-shape PPO rows so that they are measured by the same driver command."""
     out = {}
-    for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 0))):
+    for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 1))):
         try:
             import importlib
 
@@ -405,7 +405,7 @@ def main():
         if args.workload == "ppo_atari":
             import bench_ppo_cnn
 
-            print(json.dumps(bench_ppo_cnn.run(1, 0, with_cpu=not args.no_cpu_baseline)), flush=True)
+            print(json.dumps(bench_ppo_cnn.run(1, 1, with_cpu=not args.no_cpu_baseline)), flush=True)
             return
         mod = importlib.import_module("bench_" + args.workload)
         print(json.dumps(mod.run(max(args.steps, 1) * 10, max(args.warmup, 1) * 20,

@@ -1,8 +1,3 @@
-python -m pytest tests/test_gpu_td3.py tests/test_gpu_sac.py tests/test_gpu_hooks.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E " | head
-for i in 1 2; do
-for w in td3 ddpg; do
-  python bench.py --workload $w --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$w', round(d['value'],1), round(d['ms_per_step'],3))"
-done
-done
+export TS_GAE_DIRECT_MAX=1024
+echo "== tickets, one cache line per shard"; PYTHONPATH=. python scripts/gpu_gae_sweep.py 22 24 26 2>&1 | grep "envs=  8192"
+python -m pytest tests/test_gpu_returns.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E " | head -5

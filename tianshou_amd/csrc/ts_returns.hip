@@ -390,7 +390,8 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_tile_apply(GaeArgs<RewT> g,
 constexpr int GAE_SHARDS = 8;   // ticket counters (one word saturates at ~88 atomics/us)
 
 struct GaeSyncHeader {
-    unsigned long long ticket[GAE_SHARDS];   // shard k hands out sequence numbers 8 j + k
+    struct alignas(128) { unsigned long long v; } ticket[GAE_SHARDS];   // shard k hands out sequence numbers 8 j + k;
+                                                                        // one cache line each: atomics serialise per LINE
     unsigned int error;       // set when a spin ran out (results invalid, no hang)
     unsigned int pad[3];
 };
@@ -407,6 +408,7 @@ struct GaeTileMsg {
 };
 
 constexpr unsigned GAE_SPIN_LIMIT = 1u << 22;
+
 
 template <typename RewT, bool VEC>
 __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, GaeSyncHeader* hdr,
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
         if (threadIdx.x == 0) tile_s = n_tiles - 1 - (int64_t)blockIdx.x;
     } else if (threadIdx.x == 0) {
         const int shard = blockIdx.x & (GAE_SHARDS - 1);
-        const unsigned long long t = __hip_atomic_fetch_add(&hdr->ticket[shard], 1ULL, __ATOMIC_RELAXED,
+        const unsigned long long t = __hip_atomic_fetch_add(&hdr->ticket[shard].v, 1ULL, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
         const int64_t seq = (int64_t)(t - launch.base[shard]) * GAE_SHARDS + shard;
         tile_s = n_tiles - 1 - seq;                            // sequence 0 -> last tile
@@ -723,8 +725,11 @@ int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g_in, float* adv_out, floa
         const unsigned int epoch = ++ws->gae_epoch;
         GaeLaunch base;
         // <= 4 workgroups of 256 threads per CU are resident for certain (102 VGPRs -> 4 waves per
-        // SIMD, 0.4 KB LDS): then no workgroup can wait for one that has not started.
-        base.direct = n_tiles <= 1024 ? 1 : 0;
+        // SIMD, 0.4 KB LDS): then no workgroup can wait for one that has not started.  Larger grids take tickets
+        // (forward progress by construction).  TS_GAE_DIRECT_MAX (experiments): blockIdx order for larger grids too --
+        // 5 % faster at 2^24, but correct only while every XCD dispatches its workgroups in index order.
+        static const int64_t direct_max = getenv("TS_GAE_DIRECT_MAX") ? atoll(getenv("TS_GAE_DIRECT_MAX")) : 1024;
+        base.direct = n_tiles <= direct_max ? 1 : 0;
         for (int k = 0; k < GAE_SHARDS; ++k) {
             base.base[k] = ws->gae_ticket_base[k];
             // blocks b with b % 8 == k claim from shard k: as many as sequence numbers = k (mod 8)
