@@ -1,3 +1,2 @@
-export TS_GAE_DIRECT_MAX=1024
-echo "== tickets, one cache line per shard"; PYTHONPATH=. python scripts/gpu_gae_sweep.py 22 24 26 2>&1 | grep "envs=  8192"
-python -m pytest tests/test_gpu_returns.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E " | head -5
+PYTHONPATH=. python scripts/gpu_gae_sweep.py 20 24 2>&1 | grep "envs=  8192\|envs=   512"
+python -m pytest tests/test_gpu_returns.py tests/test_gpu_ppo.py -x -q -m gpu 2>&1 | grep -E "passed|failed|^E " | head -5

@@ -422,18 +422,21 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
     __shared__ double red[2 * GAE_WAVES];
     __shared__ int64_t tile_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t tile;
     if (launch.direct) {
-        // every workgroup of this launch is resident at once (small grid): no ticket needed
-        if (threadIdx.x == 0) tile_s = n_tiles - 1 - (int64_t)blockIdx.x;
-    } else if (threadIdx.x == 0) {
-        const int shard = blockIdx.x & (GAE_SHARDS - 1);
-        const unsigned long long t = __hip_atomic_fetch_add(&hdr->ticket[shard].v, 1ULL, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t seq = (int64_t)(t - launch.base[shard]) * GAE_SHARDS + shard;
-        tile_s = n_tiles - 1 - seq;                            // sequence 0 -> last tile
+        // every workgroup of this launch is resident at once (small grid): no ticket, no broadcast
+        tile = n_tiles - 1 - (int64_t)blockIdx.x;
+    } else {
+        if (threadIdx.x == 0) {
+            const int shard = blockIdx.x & (GAE_SHARDS - 1);
+            const unsigned long long t = __hip_atomic_fetch_add(&hdr->ticket[shard].v, 1ULL, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t seq = (int64_t)(t - launch.base[shard]) * GAE_SHARDS + shard;
+            tile_s = n_tiles - 1 - seq;                        // sequence 0 -> last tile
+        }
+        __syncthreads();
+        tile = tile_s;
     }
-    __syncthreads();
-    const int64_t tile = tile_s;
     const int64_t tile_start = tile * GAE_TILE;
     double vs[GAE_ITEMS], d[GAE_ITEMS], c[GAE_ITEMS];
     const int64_t base = tile_start + (int64_t)threadIdx.x * GAE_ITEMS;
