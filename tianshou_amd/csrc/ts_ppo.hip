@@ -29,6 +29,9 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+#ifndef TS_PPO_STEP_DEFAULT
+#define TS_PPO_STEP_DEFAULT 2
+#endif
 constexpr int HID = 64;
 constexpr int W2_PITCH = 68;                 // conflict-free ds_read_b128 of 4 consecutive k
 constexpr int W2_SIZE = HID * W2_PITCH;      // floats per net
@@ -1419,6 +1422,8 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
     TS_MARK(g, 17);
 }
 
+#include "ts_ppo_step3.h"
+
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
 // partial sum of squares over the parameter columns (for the global gradient norm).
@@ -1486,6 +1491,7 @@ struct AdamArgs {
     float* image;             // LDS images of the step kernel to refresh (or NULL)
     const int* inv;           // param -> image slot (-1: none)
     int sig_off, act, small0; // sigma_param range and the actor image's SMALL block
+    int image3;               // image / inv use the split-bf16 format of ppo_step3_kernel (ts_ppo_step3.h)
 };
 
 constexpr int ADAM_THREADS = 256;
@@ -1499,7 +1505,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     const bool mine = a.apply && p < a.n_params;
     const int pc = mine ? p : 0;
     float g_raw = a.grad[pc], m = a.m[pc], v = a.v[pc], par = a.params[pc];
-    const int slot = (mine && a.image) ? a.inv[pc] : -1;
+    const int slot = (mine && a.image) ? a.inv[pc] : (a.image3 ? 0 : -1);
     // global gradient norm: every workgroup re-reduces the (few) partials in the same order
     float sq = 0.f;
     if (a.sumsq_part) {
@@ -1535,7 +1541,12 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
-        if (a.image) {
+        if (a.image && a.image3) {
+            char* img = reinterpret_cast<char*>(a.image);
+            s3::image_put(img, slot, np_);
+            const int k = p - a.sig_off;
+            if (k >= 0 && k < a.act) s3::image_put_sigma(img, k, np_);
+        } else if (a.image) {
             if (slot >= 0) a.image[slot] = np_;
             const int k = p - a.sig_off;
             if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
@@ -1613,11 +1624,21 @@ size_t step_lds_bytes() {
 template <int KS1>
 size_t infer_lds_bytes() { return sizeof(float) * (size_t)Lds<KS1, 2>::END; }
 
-// first-generation step kernel (per-tile cross-wave reductions, flat slab columns): TS_PPO_STEP_V1=1, kept for A/B runs
-inline bool step_v1() {
-    static const bool v1 = [] { const char* e = getenv("TS_PPO_STEP_V1"); return e && atoi(e) != 0; }();
-    return v1;
+// Step-kernel generation.  1: per-tile cross-wave reductions, flat slab columns (TS_PPO_STEP_V1=1 or TS_PPO_STEP=1);
+// 2: fp32 MFMA, shared 128-sample gradient tiles; 3: split-bf16 MFMA (ts_ppo_step3.h).  ts_ppo_set_step_mode()
+// overrides the environment (A/B runs and tests inside one process).
+int g_step_mode_override = 0;
+inline int step_mode() {
+    static const int env = [] {
+        const char* v1 = getenv("TS_PPO_STEP_V1");
+        if (v1 && atoi(v1) != 0) return 1;
+        const char* e = getenv("TS_PPO_STEP");
+        const int m = e ? atoi(e) : 0;
+        return (m >= 1 && m <= 3) ? m : TS_PPO_STEP_DEFAULT;
+    }();
+    return g_step_mode_override ? g_step_mode_override : env;
 }
+inline bool step_v1() { return step_mode() == 1; }
 
 // floats per workgroup slab
 inline int slab_width(const Dims& d, int ks) {
@@ -1688,18 +1709,21 @@ int n_compute_units() {
 // launches forward/backward of one minibatch into the slabs
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
-    const bool v1 = step_v1();
-    const size_t lds = v1 ? step_lds_bytes<KS1>() : sizeof(float) * (size_t)T2_FLOATS;
-    const void* fn = v1 ? reinterpret_cast<const void*>(&ppo_step_kernel<KS1>)
-                        : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>);
-    static bool attr_done = false;
-    if (!attr_done) {
+    const int mode = step_mode();
+    const size_t lds = mode == 1 ? step_lds_bytes<KS1>()
+                                 : (mode == 3 ? (size_t)s3::LDS_BYTES : sizeof(float) * (size_t)T2_FLOATS);
+    const void* fn = mode == 1 ? reinterpret_cast<const void*>(&ppo_step_kernel<KS1>)
+                               : (mode == 3 ? reinterpret_cast<const void*>(&s3::ppo_step3_kernel<KS1>)
+                                            : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>));
+    static bool attr_done[4] = {false, false, false, false};
+    if (!attr_done[mode]) {
         TS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done[mode] = true;
     }
     {
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-        if (v1) hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        if (mode == 1) hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        else if (mode == 3) hipLaunchKernelGGL((s3::ppo_step3_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
         else hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
     TS_LAUNCH_CHECK();
@@ -1750,6 +1774,7 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
     ImageBuf b;
     b.img_end = 4960 + 128 * ks;                           // Lds<ks, 1>::END
     b.img_bytes = (sizeof(float) * 2 * (size_t)b.img_end + 255) & ~(size_t)255;
+    if (step_mode() == 3) b.img_bytes = (2 * (size_t)s3::IMG_BYTES + 255) & ~(size_t)255;
     b.inv_bytes = (sizeof(int) * (size_t)d.p_total + 255) & ~(size_t)255;
     return b;
 }
@@ -1757,6 +1782,12 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
 // LDS images of both nets + the param -> image-slot table (see ppo_build_image_kernel)
 int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float* image, int* inv) {
     const int64_t obs_dim = d.obs;
+    if (step_mode() == 3) {
+        hipLaunchKernelGGL(s3::ppo_build_image3_kernel, dim3(1), dim3(1024), 0, s, params, d,
+                           reinterpret_cast<char*>(image), inv);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    }
     if (inv) TS_HIP_CHECK(hipMemsetAsync(inv, 0xff, sizeof(int) * (size_t)d.p_total, s));   // -1: no image slot
     TS_KS1_DISPATCH(ks, {
         static_assert(Lds<K, 1>::END == 4960 + 128 * K, "image size formula");
@@ -1771,7 +1802,7 @@ int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float
 int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d, int ks, float** image, int** inv) {
     const ImageBuf ib = image_buf(d, ks);
     const size_t need = ib.img_bytes + ib.inv_bytes;
-    const int key = (d.obs << 8) | d.act;
+    const int key = (step_mode() << 24) | (d.obs << 8) | d.act;
     if (ws->ppo_image_bytes < need) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
         if (ws->ppo_image) { TS_HIP_CHECK(hipDeviceSynchronize()); TS_HIP_CHECK(hipFree(ws->ppo_image)); }
@@ -1999,6 +2030,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
         a.losses = losses; a.apply = 1;
         a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
+        a.image3 = step_mode() == 3;
         {
             ts::ProfScope prof(ws, TS_KIND_PPO_ADAM, s);
             hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
@@ -2084,6 +2116,14 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     return TS_OK;
 }
 
+int ts_ppo_set_step_mode(int mode) {
+    TS_REQUIRE(mode >= 0 && mode <= 3, TS_ERR_INVALID_ARG, "ts_ppo_set_step_mode: mode must be 0 (environment / default) .. 3");
+    g_step_mode_override = mode;
+    return TS_OK;
+}
+
+int ts_ppo_get_step_mode(void) { return step_mode(); }
+
 int ts_ppo_invalidate_image(ts_workspace* ws) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_invalidate_image: workspace is NULL");
     ws->ppo_image_params = nullptr;
@@ -2099,12 +2139,14 @@ int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     AdamArgs a = adam_args(params, adam_m, adam_v, adam_step, d, hp);
     a.grad = grad; a.sumsq_part = nullptr; a.n_part = 0; a.losses = nullptr; a.apply = 1;
-    if (ws && ws->ppo_image && ws->ppo_image_params == params && ws->ppo_image_key == ((d.obs << 8) | d.act)) {
+    if (ws && ws->ppo_image && ws->ppo_image_params == params &&
+        ws->ppo_image_key == ((step_mode() << 24) | (d.obs << 8) | d.act)) {
         // keep ts_ppo_grad's images current (same mechanism as ts_ppo_update)
         const ImageBuf ib = image_buf(d, supported_ks(ks1_for((int)obs_dim)));
         a.image = static_cast<float*>(ws->ppo_image);
         a.inv = reinterpret_cast<const int*>(static_cast<char*>(ws->ppo_image) + ib.img_bytes);
         a.sig_off = d.a_sig; a.act = d.act; a.small0 = ib.img_end - 32;
+        a.image3 = step_mode() == 3;
     }
     hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
                        dim3(ADAM_THREADS), 0, ts::as_stream(stream), a);
