@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     const int64_t obs = argc > 1 ? atoi(argv[1]) : 17, act = argc > 2 ? atoi(argv[2]) : 6;
     const int64_t n = 1 << 17, rows = argc > 3 ? atoll(argv[3]) : 65536;
     const int adv_norm = argc > 4 ? atoi(argv[4]) : 1;
+    setvbuf(stdout, nullptr, _IONBF, 0);
     std::mt19937_64 rng(1234);
     std::normal_distribution<float> N(0.f, 1.f);
     const int64_t P = ts_ppo_param_count(obs, act);

@@ -288,41 +288,81 @@ __device__ __forceinline__ void head_forward3(const float* whb, int h, const f32
     for (int a = 0; a < NA; ++a) out[a] += __shfl_xor(out[a], 32, 64);
 }
 
-// dH1^T = W2^T dZ2^T through 16-bit gathers from the forward image, then dZ1 = dH1 (1 - h1^2)
-__device__ __forceinline__ void dh1_backward3(const char* L, const P3 (&dz2p)[4], const f32x16 (&h1)[2], int lane,
+// A operand of dH1^T = W2^T dZ2^T for chunk C of output tile T1: the lane's column of W2 gathered from the forward
+// image with 16-bit LDS loads.  Written as ONE asm block per
+// chunk -- 24 loads in flight, one wait -- because hipcc serialises the C++ form into 12 load-load-wait-combine round
+// trips per chunk (10 k cycles per net).  Rows F(8u + j, 0), j = 0..7, are 16 u + {0, 1, 2, 3, 8, 9, 10, 11}.
+template <int T1, int C>
+__device__ __forceinline__ void gather_w2_column(unsigned lane_addr, P3& a) {
+    constexpr int t = C >> 1, u = C & 1;
+    constexpr int B0 = ((0 * 2 + t) * 4 + 2 * T1) * CH2 + 256 * u;      // piece 0; pieces are W2P_PIECE apart
+    static_assert(B0 + 2 * W2P_PIECE + 176 < 65536, "DS offset field");
+    unsigned l0, l1, l2, l3, l4, l5, l6, l7, l8, l9, l10, l11, h0, h1, h2, h3, h4, h5, h6, h7, h8, h9, h10, h11;
+    asm volatile(
+        "ds_read_u16 %0, %24 offset:%25\n\t"
+        "ds_read_u16 %1, %24 offset:%25+32\n\t"
+        "ds_read_u16 %2, %24 offset:%25+128\n\t"
+        "ds_read_u16 %3, %24 offset:%25+160\n\t"
+        "ds_read_u16 %4, %24 offset:%26\n\t"
+        "ds_read_u16 %5, %24 offset:%26+32\n\t"
+        "ds_read_u16 %6, %24 offset:%26+128\n\t"
+        "ds_read_u16 %7, %24 offset:%26+160\n\t"
+        "ds_read_u16 %8, %24 offset:%27\n\t"
+        "ds_read_u16 %9, %24 offset:%27+32\n\t"
+        "ds_read_u16 %10, %24 offset:%27+128\n\t"
+        "ds_read_u16 %11, %24 offset:%27+160\n\t"
+        "ds_read_u16 %12, %24 offset:%25+16\n\t"
+        "ds_read_u16 %13, %24 offset:%25+48\n\t"
+        "ds_read_u16 %14, %24 offset:%25+144\n\t"
+        "ds_read_u16 %15, %24 offset:%25+176\n\t"
+        "ds_read_u16 %16, %24 offset:%26+16\n\t"
+        "ds_read_u16 %17, %24 offset:%26+48\n\t"
+        "ds_read_u16 %18, %24 offset:%26+144\n\t"
+        "ds_read_u16 %19, %24 offset:%26+176\n\t"
+        "ds_read_u16 %20, %24 offset:%27+16\n\t"
+        "ds_read_u16 %21, %24 offset:%27+48\n\t"
+        "ds_read_u16 %22, %24 offset:%27+144\n\t"
+        "ds_read_u16 %23, %24 offset:%27+176\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3), "=&v"(l4), "=&v"(l5), "=&v"(l6), "=&v"(l7), "=&v"(l8),
+          "=&v"(l9), "=&v"(l10), "=&v"(l11), "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5),
+          "=&v"(h6), "=&v"(h7), "=&v"(h8), "=&v"(h9), "=&v"(h10), "=&v"(h11)
+        : "v"(lane_addr), "n"(B0), "n"(B0 + W2P_PIECE), "n"(B0 + 2 * W2P_PIECE)
+        : "memory");
+    // (d16 / d16_hi loads would fill the packed registers directly, but with SRAM ECC on -- as on this part -- they
+    // clear the other half instead of preserving it)
+    a.p[0][0] = l0 | (h0 << 16); a.p[0][1] = l1 | (h1 << 16); a.p[0][2] = l2 | (h2 << 16); a.p[0][3] = l3 | (h3 << 16);
+    a.p[1][0] = l4 | (h4 << 16); a.p[1][1] = l5 | (h5 << 16); a.p[1][2] = l6 | (h6 << 16); a.p[1][3] = l7 | (h7 << 16);
+    a.p[2][0] = l8 | (h8 << 16); a.p[2][1] = l9 | (h9 << 16); a.p[2][2] = l10 | (h10 << 16); a.p[2][3] = l11 | (h11 << 16);
+}
+
+template <int T1>
+__device__ __forceinline__ f32x16 dh1_tile(unsigned lane_addr, const P3 (&dz2p)[4]) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    P3 a;
+    gather_w2_column<T1, 0>(lane_addr, a); acc = mma6(a, dz2p[0], acc);
+    gather_w2_column<T1, 1>(lane_addr, a); acc = mma6(a, dz2p[1], acc);
+    gather_w2_column<T1, 2>(lane_addr, a); acc = mma6(a, dz2p[2], acc);
+    gather_w2_column<T1, 3>(lane_addr, a); acc = mma6(a, dz2p[3], acc);
+    return acc;
+}
+
+// dH1^T = W2^T dZ2^T, then dZ1 = dH1 (1 - h1^2).  lds_base = LDS byte address of the image.
+__device__ __forceinline__ void dh1_backward3(unsigned lds_base, const P3 (&dz2p)[4], const f32x16 (&h1)[2], int lane,
                                               f32x16 (&dz1)[2]) {
     const int i = lane & 31, h = lane >> 5;
-    // the lane's own column f1 = 32 t1 + i sits in chunk 2 t1 + (i >> 4), half (i >> 2) & 1, element (i & 3) | (i >> 3 & 1) << 2
+    // the lane's own column f1 = 32 t1 + i sits in chunk 2 t1 + (i >> 4), half (i >> 2) & 1, element (i & 3) | (i >> 3 & 1) << 2;
+    // the rows it needs are F(r, h) = F(r, 0) + 4 h
     const int j2 = (i & 3) | (((i >> 3) & 1) << 2);
-    const char* base0 = L + (i >> 4) * CH2 + ((i >> 2) & 1) * (512 + HP) + j2 * 2 + h * 64;
+    const unsigned lane_addr = lds_base + (i >> 4) * CH2 + ((i >> 2) & 1) * (512 + HP) + j2 * 2 + h * 64;
+    f32x16 acc0 = dh1_tile<0>(lane_addr, dz2p);
 #pragma unroll
-    for (int t1 = 0; t1 < 2; ++t1) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const char* base = base0 + 2 * t1 * CH2;
+    for (int r = 0; r < 16; ++r) { const float hv = h1[0][r]; acc0[r] = acc0[r] * (1.f - hv * hv); }
+    dz1[0] = acc0;
+    f32x16 acc1 = dh1_tile<1>(lane_addr, dz2p);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int t = c >> 1, u = c & 1;
-            P3 a;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r0 = 8 * u + 2 * q;                     // rows F(r0, h), F(r0 + 1, h) of tile t
-                    const int o0 = ((p * 2 + t) * 4) * CH2 + featF(r0, 0) * 16;
-                    const int o1 = ((p * 2 + t) * 4) * CH2 + featF(r0 + 1, 0) * 16;
-                    const unsigned lo = *reinterpret_cast<const u16*>(base + o0);
-                    const unsigned hi = *reinterpret_cast<const u16*>(base + o1);
-                    a.p[p][q] = lo | (hi << 16);
-                }
-            acc = mma6(a, dz2p[c], acc);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float hv = h1[t1][r];
-            acc[r] = acc[r] * (1.f - hv * hv);
-        }
-        dz1[t1] = acc;
-    }
+    for (int r = 0; r < 16; ++r) { const float hv = h1[1][r]; acc1[r] = acc1[r] * (1.f - hv * hv); }
+    dz1[1] = acc1;
 }
 
 // forward, loss and backward of one net for the wave's 32 samples (see net_fwd_bwd: identical loss section)
@@ -501,7 +541,7 @@ __device__ __forceinline__ void net_fwd_bwd3(const char* L, float* scratch, cons
             dz2p[2 * t] = two[0];
             dz2p[2 * t + 1] = two[1];
         }
-        dh1_backward3(L, dz2p, h1, lane, dz1);
+        dh1_backward3((unsigned)(size_t)L, dz2p, h1, lane, dz1);
     }
     __builtin_amdgcn_sched_barrier(0);
     TS_MARK(g, MK + 3);
