@@ -435,6 +435,9 @@ def main():
         torch.cuda.synchronize()
 
     learner = Learner(device, rank, world)
+    import bench_init
+
+    bench_init.warm_clocks(device)            # idle clocks -> load clocks before the W warm-up steps (not an update step)
     for _ in range(args.warmup):
         learner.update_once()
     barrier()

@@ -86,6 +86,7 @@ def cpu_baseline(updates: int = 3):
 
 
 def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
+    import bench_init as BI
     from tianshou_amd import _lib
     from tianshou_amd import dqn as D
 
@@ -104,6 +105,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
         per.update_weight(idx, td)
         return loss
 
+    BI.warm_clocks()
     for _ in range(warmup):
         update()
     torch.cuda.synchronize()

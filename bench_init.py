@@ -154,3 +154,20 @@ def recurrent_net(obs: int, hidden: int, layers: int, n_act: int, seed: int = 0)
     _linear(d, "fc1.weight", "fc1.bias", hidden, obs, g)
     _linear(d, "fc2.weight", "fc2.bias", n_act, hidden, g)
     return d
+
+
+def warm_clocks(device=None, seconds: float = 0.3) -> None:
+    """Keeps the GPU busy for `seconds` before a bench's warm-up steps: a fresh process starts at idle clocks, and a
+    timed region of a few tens of milliseconds that begins inside the ramp measures the ramp (one `--workload sac` run
+    in five came out 3x slow before this).  Dense fp32 work only -- no state of the benchmarked engine is touched."""
+    import time
+
+    dev = torch.device("cuda") if device is None else device
+    a = torch.randn(2048, 2048, device=dev)
+    b = torch.randn(2048, 2048, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            a = torch.mm(a, b).clamp_(-1.0, 1.0)
+        torch.cuda.synchronize(dev)

@@ -69,8 +69,10 @@ def _flat_buffer(slots, E, dev, g, **cols):
 
 
 def _time(update, steps, warmup):
+    import bench_init as BI
     from tianshou_amd import _lib
 
+    BI.warm_clocks()
     for _ in range(warmup):
         update()
     torch.cuda.synchronize()

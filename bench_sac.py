@@ -86,6 +86,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
         stats, _ = eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret, noise[1])
         return stats
 
+    BI.warm_clocks(dev)
     for _ in range(warmup):
         update()
     torch.cuda.synchronize()
