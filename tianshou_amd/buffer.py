@@ -367,6 +367,27 @@ class DeviceReplayBuffer:
         self.insertion.copy_(torch.as_tensor(self.h_insertion))
         return copied
 
+    # -- checkpoints (tianshou_amd/persist.py) ------------------------------------------
+    def to_tianshou(self, buffer) -> None:
+        """Writes the mirror back into a reference buffer of the same layout (then `buffer.save_hdf5(...)` / pickle give
+        the reference's own files)."""
+        from . import persist
+
+        persist.to_tianshou(self, buffer)
+
+    def save_hdf5(self, path: str, compression: str | None = None) -> None:
+        """buffer_base.py:252-256 for the mirror itself, converter.py's dataset / attribute conventions."""
+        from . import persist
+
+        persist.save_hdf5(self, path, compression)
+
+    @classmethod
+    def load_hdf5(cls, path: str, device="cuda"):
+        """buffer_base.py:258-263."""
+        from . import persist
+
+        return persist.load_hdf5(path, device)
+
     # -- reference API ------------------------------------------------------------------------
     def __len__(self) -> int:
         self._sync_host()
