@@ -466,6 +466,33 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
                    const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
                    float* grad_out, ts_stream_t stream);
 
+/* LSTM trunk + one linear head, generic -- the recurrent actor and critic of the continuous-control nets:
+ *   RecurrentActorProb  tianshou/utils/net/continuous.py:241-322: nn.LSTM(obs_dim -> H, L layers, batch_first) on the
+ *                       observation itself (no fc1), mu = Linear(H, act)(h_T), bounded as max_action * tanh(mu) unless
+ *                       `unbounded` (tanh_scale = max_action, or 0 for none); sigma = exp(sigma_param) is state-
+ *                       independent and stays with the caller (conditioned_sigma is not supported);
+ *   RecurrentCritic     continuous.py:325-380: the same trunk, fc2 = Linear(H + act_dim, 1) on [h_T | act]
+ *                       (extra_dim = act_dim, `extra` = the actions, float32[B, extra_dim]);
+ *   has_fc1 = 1         Recurrent (common.py:372-452, the DRQN network of ts_rnnq_*) through the same entry points.
+ * Flat layout (ts_lstm_net_layout: h_out int64[5 + 2 L] = {k0, count, off_fc1 or -1, (off_ih, off_hh) per layer, off_head,
+ * head_in}): [fc1 [k0 + 1, H] if has_fc1] | layer 0: W_ih [(has_fc1 ? H : k0) + 1, 4H] | W_hh [H + 1, 4H] | layers >= 1:
+ * W_ih [H + 1, 4H] | W_hh [H + 1, 4H] | head [head_in + 1, 32], head_in = H (extra_dim = 0) or H + extra_dim rounded up to
+ * a multiple of 32; last row of every block = bias (b_ih / b_hh kept separately, as torch does); padding rows / columns
+ * are and stay zero.  obs float32[B, T, obs_dim]; h_in / c_in (nullable, together) float32[L, B, H].
+ *   forward : out float32[B, out_dim] (after the tanh bound when tanh_scale > 0), h_out / c_out nullable float32[L, B, H].
+ *   backward: d_out float32[B, out_dim] = d loss / d out -> grad_out float32[count] = d loss / d params (forward is
+ *             re-run inside; `out` nullable receives it).  The optimizer step is ts_adam_step. */
+int ts_lstm_net_layout(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim, int64_t has_fc1, int64_t extra_dim,
+                       int64_t* h_out);
+int ts_lstm_net_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim,
+                        int64_t has_fc1, int64_t extra_dim, const float* obs, const float* extra, int64_t B, int64_t T,
+                        const float* h_in, const float* c_in, double tanh_scale, float* out, float* h_out, float* c_out,
+                        ts_stream_t stream);
+int ts_lstm_net_backward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim,
+                         int64_t has_fc1, int64_t extra_dim, const float* obs, const float* extra, int64_t B, int64_t T,
+                         const float* h_in, const float* c_in, double tanh_scale, const float* d_out, float* out, float* grad_out,
+                         ts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Distributional Q-learning on the Atari networks: QRDQN (tianshou/algorithm/modelfree/qrdqn.py) and
  * C51 (modelfree/c51.py) with QRDQNet / C51Net (tianshou/env/atari/atari_network.py:211-235 / :125-151):

@@ -914,8 +914,70 @@ def gen_dqn(tag: str, *, E: int, slots: int, steps: int, c: int, h: int, w: int,
     np.savez_compressed(os.path.join(OUT, f"dqn_{tag}.npz"), **out)
 
 
+
+def gen_recurrent() -> None:
+    """RecurrentActorProb / RecurrentCritic (utils/net/continuous.py:241-380) as the reference's own test builds them
+    (test/base/test_utils.py:99-112: 3 layers on a vector observation), plus a bounded single-layer actor with a carried
+    state: parameters, inputs, outputs and -- through autograd on the reference modules -- parameter gradients of a fixed
+    linear functional of the outputs."""
+    from oracle import oracle_recurrent as OR
+    from tianshou.utils.net.continuous import RecurrentActorProb, RecurrentCritic
+
+    out = {}
+    for tag, (obs_dim, act_dim, hidden, layers, B, T, max_action, unbounded) in {
+        "utils": (6, 5, 32, 3, 7, 4, 1.0, False),               # test_utils.py:99-112: layer_num=3 (hidden 32 keeps the file small)
+        "small": (11, 3, 64, 1, 33, 1, 2.5, False),
+        "free": (37, 17, 32, 2, 9, 6, 1.0, True),
+    }.items():
+        torch.manual_seed(hash(tag) % 1000)
+        rng = np.random.default_rng(len(tag))
+        actor = RecurrentActorProb(layer_num=layers, state_shape=(obs_dim,), action_shape=(act_dim,), hidden_layer_size=hidden,
+                                   max_action=max_action, unbounded=unbounded)
+        critic = RecurrentCritic(layer_num=layers, state_shape=(obs_dim,), action_shape=(act_dim,), hidden_layer_size=hidden)
+        with torch.no_grad():
+            actor.sigma_param.copy_(torch.from_numpy(rng.normal(size=(act_dim, 1)).astype(np.float32)) * 0.3)
+        assert list(actor.state_dict().keys()) == OR.actor_keys(layers), list(actor.state_dict().keys())
+        assert list(critic.state_dict().keys()) == OR.critic_keys(layers), list(critic.state_dict().keys())
+        obs = rng.normal(size=(B, T, obs_dim)).astype(np.float32)
+        act = rng.normal(size=(B, act_dim)).astype(np.float32)
+        state = {"hidden": torch.from_numpy(rng.normal(size=(B, layers, hidden)).astype(np.float32)) * 0.5,
+                 "cell": torch.from_numpy(rng.normal(size=(B, layers, hidden)).astype(np.float32)) * 0.5}
+        w_mu = torch.from_numpy(rng.normal(size=(B, act_dim)).astype(np.float32))
+        w_v = torch.from_numpy(rng.normal(size=(B, 1)).astype(np.float32))
+        (mu, sigma), st = actor(obs)
+        (mu_s, sigma_s), st_s = actor(obs[:, -1], state=state)       # evaluation mode: [B, dim] with a carried state
+        actor.zero_grad()
+        (mu * w_mu).sum().backward()
+        a_grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in actor.named_parameters()}
+        v = critic(obs, act)
+        critic.zero_grad()
+        (v * w_v).sum().backward()
+        c_grads = {k: p.grad for k, p in critic.named_parameters()}
+        pre = f"{tag}_"
+        out[pre + "dims"] = np.array([obs_dim, act_dim, hidden, layers, B, T], np.int64)
+        out[pre + "max_action"], out[pre + "unbounded"] = np.float64(max_action), np.int64(unbounded)
+        for k, t in actor.state_dict().items():
+            out[pre + "actor." + k] = t.detach().numpy().copy()
+        for k, t in critic.state_dict().items():
+            out[pre + "critic." + k] = t.detach().numpy().copy()
+        for k, t in a_grads.items():
+            out[pre + "actor_grad." + k] = t.detach().numpy().copy()
+        for k, t in c_grads.items():
+            out[pre + "critic_grad." + k] = t.detach().numpy().copy()
+        out[pre + "obs"], out[pre + "act"], out[pre + "w_mu"], out[pre + "w_v"] = obs, act, w_mu.numpy(), w_v.numpy()
+        out[pre + "state_hidden"], out[pre + "state_cell"] = state["hidden"].numpy(), state["cell"].numpy()
+        out[pre + "mu"], out[pre + "sigma"] = mu.detach().numpy(), sigma.detach().numpy()
+        out[pre + "hidden"], out[pre + "cell"] = st["hidden"].numpy(), st["cell"].numpy()
+        out[pre + "mu_s"], out[pre + "hidden_s"], out[pre + "cell_s"] = mu_s.detach().numpy(), st_s["hidden"].numpy(), st_s["cell"].numpy()
+        out[pre + "value"] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "recurrent_nets.npz"), **out)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "recurrent":
+        gen_recurrent()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
         return

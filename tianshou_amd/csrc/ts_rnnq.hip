@@ -36,28 +36,37 @@ constexpr int HEAD = 32;
 constexpr int MAX_LAYERS = 8;
 
 struct RNet {
-    ts::ConvGeom fc1, ih_all, hh_step, head;     // rows: T B, T B, B, B
+    ts::ConvGeom fc1, ih0, ih_all, hh_step, head;     // rows: T B, T B, T B, B, B.  ih0 = input projection of layer 0
     int64_t off_fc1, off_ih[MAX_LAYERS], off_hh[MAX_LAYERS], off_head, count;
     int obs, k0, H, L, A, T;
+    int has_fc1;          // Recurrent (common.py:372): fc1 in front of the LSTM; RecurrentActorProb / RecurrentCritic
+                          // (continuous.py:241, 325): the LSTM reads the observation directly
+    int extra, head_in;   // RecurrentCritic: the head reads [h_T | act] (extra = act_dim), padded to a multiple of 32
     int64_t B;
+    const ts::ConvGeom& ih(int l) const { return l == 0 ? ih0 : ih_all; }
 };
 
-int make_rnet(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T, RNet* n) {
+int make_rnet(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T, RNet* n,
+              int has_fc1 = 1, int64_t extra = 0) {
     TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && hidden >= 32 && hidden <= 1024 && hidden % 32 == 0 && layers >= 1 &&
                    layers <= MAX_LAYERS && n_act >= 1 && n_act <= HEAD,
                TS_ERR_INVALID_ARG, "rnnq: obs_dim >= 1, hidden a multiple of 32 in [32, 1024], 1..8 layers, n_act <= 32");
     TS_REQUIRE(B >= 1 && T >= 1 && T <= 4096 && B * T <= (int64_t)1 << 24, TS_ERR_INVALID_ARG, "rnnq: B >= 1, 1 <= T <= 4096, B T <= 2^24");
     n->obs = (int)obs_dim; n->k0 = (n->obs + 31) / 32 * 32; n->H = (int)hidden; n->L = (int)layers; n->A = (int)n_act;
     n->T = (int)T; n->B = B;
+    TS_REQUIRE(extra >= 0 && extra <= 4096, TS_ERR_INVALID_ARG, "rnn: 0 <= extra head inputs <= 4096");
+    n->has_fc1 = has_fc1 != 0; n->extra = (int)extra;
     const int rows = (int)(B * T), H = n->H;
+    n->head_in = n->extra ? (H + n->extra + 31) / 32 * 32 : H;
     n->fc1 = ts::ConvGeom{rows, 1, 1, n->k0, 1, 1, 1, 1, 1, H};
     n->ih_all = ts::ConvGeom{rows, 1, 1, H, 1, 1, 1, 1, 1, 4 * H};
+    n->ih0 = n->has_fc1 ? n->ih_all : ts::ConvGeom{rows, 1, 1, n->k0, 1, 1, 1, 1, 1, 4 * H};
     n->hh_step = ts::ConvGeom{(int)B, 1, 1, H, 1, 1, 1, 1, 1, 4 * H};
-    n->head = ts::ConvGeom{(int)B, 1, 1, H, 1, 1, 1, 1, 1, HEAD};
+    n->head = ts::ConvGeom{(int)B, 1, 1, n->head_in, 1, 1, 1, 1, 1, HEAD};
     int64_t o = 0;
-    n->off_fc1 = o; o += n->fc1.param_elems();
+    n->off_fc1 = o; if (n->has_fc1) o += n->fc1.param_elems();
     for (int l = 0; l < n->L; ++l) {
-        n->off_ih[l] = o; o += n->ih_all.param_elems();
+        n->off_ih[l] = o; o += n->ih(l).param_elems();
         n->off_hh[l] = o; o += n->ih_all.param_elems();
     }
     n->off_head = o; o += n->head.param_elems();
@@ -74,7 +83,7 @@ struct Carve {
 
 size_t split_floats(const RNet& n) {
     size_t s = 4;
-    for (const ts::ConvGeom* g : {&n.fc1, &n.ih_all, &n.hh_step, &n.head}) {
+    for (const ts::ConvGeom* g : {&n.fc1, &n.ih0, &n.ih_all, &n.hh_step, &n.head}) {
         const int ns = ts::conv_fwd_splits(*g);
         if (ns > 1) s = std::max(s, (size_t)ns * g->out_elems());
     }
@@ -83,7 +92,8 @@ size_t split_floats(const RNet& n) {
 
 size_t slab_floats(const RNet& n) {
     size_t s = 0;
-    for (const ts::ConvGeom* g : {&n.fc1, &n.ih_all, &n.head}) s = std::max(s, (size_t)ts::conv_wgrad_splits(*g) * g->param_elems());
+    for (const ts::ConvGeom* g : {&n.fc1, &n.ih0, &n.ih_all, &n.head})
+        s = std::max(s, (size_t)ts::conv_wgrad_splits(*g) * g->param_elems());
     return s;
 }
 
@@ -97,13 +107,14 @@ struct Acts {
     float* gih;                    // [T B, 4H] input projections of the current layer
     float* ghh;                    // [B, 4H]   recurrent projection of the current step
     float* out;                    // [B, 32]   head output
+    float* hcat;                   // [B, head_in] = [h_T | extra | 0] when the head has extra inputs (RecurrentCritic)
     float* split;
 };
 
 size_t acts_bytes(const RNet& n) {
     const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
     return al(4 * rows * n.k0) + al(4 * rows * H) + n.L * (2 * al(4 * (rows + B) * H) + al(4 * rows * 4 * H)) + al(4 * rows * 4 * H) +
-           al(4 * B * 4 * H) + al(4 * B * HEAD) + al(4 * split_floats(n));
+           al(4 * B * 4 * H) + al(4 * B * HEAD) + al(4 * B * n.head_in) + al(4 * split_floats(n));
 }
 
 Acts take_acts(Carve& c, const RNet& n) {
@@ -115,6 +126,7 @@ Acts take_acts(Carve& c, const RNet& n) {
     a.gih = c.f(rows * 4 * H);
     a.ghh = c.f(B * 4 * H);
     a.out = c.f(B * HEAD);
+    a.hcat = c.f(B * n.head_in);
     a.split = c.f(split_floats(n));
     return a;
 }
@@ -225,6 +237,25 @@ __global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__
     if (threadIdx.x == 0) *loss = red[0] * inv_b;
 }
 
+// hcat[b] = [h[b, 0..H) | extra[b, 0..E) | 0-pad]
+__global__ __launch_bounds__(256) void head_concat_kernel(const float* __restrict__ h, const float* __restrict__ extra, int64_t B,
+                                                          int H, int E, int W, float* __restrict__ hcat) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * W) return;
+    const int64_t b = i / W;
+    const int j = (int)(i - b * W);
+    hcat[i] = j < H ? h[b * H + j] : (j < H + E ? extra[b * E + (j - H)] : 0.f);
+}
+
+// dst[b, 0..H) = src[b, 0..H) of a [B, W] matrix
+__global__ __launch_bounds__(256) void take_cols_kernel(const float* __restrict__ src, int64_t B, int H, int W,
+                                                        float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * H) return;
+    const int64_t b = i / H;
+    dst[i] = src[b * W + (i - b * H)];
+}
+
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += src[i];
@@ -233,21 +264,22 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const
 // ---- network passes --------------------------------------------------------------------------------------------------
 // h0 / c0 (nullable): initial state [L][B][H]
 int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, const float* obs, const float* h0, const float* c0,
-            const Acts& a) {
+            const Acts& a, const float* extra = nullptr) {
     const int64_t B = n.B, rows = B * n.T;
     const int H = n.H;
     const size_t blk = (size_t)B * H;
     hipLaunchKernelGGL(pad_time_major_kernel, dim3((unsigned)ts::ceil_div(rows * n.k0, 256)), dim3(256), 0, s, obs, B, n.T, n.obs,
                        n.k0, a.x);
     TS_LAUNCH_CHECK();
-    if (int rc = ts::conv_forward(s, n.fc1, a.x, p + n.off_fc1, a.x1, false, a.split, ws)) return rc;
+    if (n.has_fc1)
+        if (int rc = ts::conv_forward(s, n.fc1, a.x, p + n.off_fc1, a.x1, false, a.split, ws)) return rc;
     for (int l = 0; l < n.L; ++l) {
         if (h0) TS_HIP_CHECK(hipMemcpyAsync(a.hbuf[l], h0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
         else TS_HIP_CHECK(hipMemsetAsync(a.hbuf[l], 0, 4 * blk, s));
         if (c0) TS_HIP_CHECK(hipMemcpyAsync(a.cbuf[l], c0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
         else TS_HIP_CHECK(hipMemsetAsync(a.cbuf[l], 0, 4 * blk, s));
-        const float* in = l == 0 ? a.x1 : a.hbuf[l - 1] + blk;
-        if (int rc = ts::conv_forward(s, n.ih_all, in, p + n.off_ih[l], a.gih, false, a.split, ws)) return rc;
+        const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
+        if (int rc = ts::conv_forward(s, n.ih(l), in, p + n.off_ih[l], a.gih, false, a.split, ws)) return rc;
         for (int t = 0; t < n.T; ++t) {
             if (int rc = ts::conv_forward(s, n.hh_step, a.hbuf[l] + t * blk, p + n.off_hh[l], a.ghh, false, a.split, ws)) return rc;
             hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)ts::ceil_div((int64_t)blk, 256)), dim3(256), 0, s,
@@ -256,7 +288,15 @@ int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, cons
             TS_LAUNCH_CHECK();
         }
     }
-    return ts::conv_forward(s, n.head, a.hbuf[n.L - 1] + (size_t)n.T * blk, p + n.off_head, a.out, false, a.split, ws);
+    const float* h_last = a.hbuf[n.L - 1] + (size_t)n.T * blk;
+    if (n.extra) {
+        TS_REQUIRE(extra != nullptr, TS_ERR_INVALID_ARG, "rnn: this head needs its extra inputs");
+        hipLaunchKernelGGL(head_concat_kernel, dim3((unsigned)ts::ceil_div(B * n.head_in, 256)), dim3(256), 0, s, h_last, extra,
+                           B, H, n.extra, n.head_in, a.hcat);
+        TS_LAUNCH_CHECK();
+        h_last = a.hcat;
+    }
+    return ts::conv_forward(s, n.head, h_last, p + n.off_head, a.out, false, a.split, ws);
 }
 
 struct Bwd {
@@ -291,9 +331,17 @@ int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, con
     const size_t blk = (size_t)B * H;
     const unsigned gcell = (unsigned)ts::ceil_div((int64_t)blk, 256);
     // head: only the last step of the top layer receives a gradient
-    if (int rc = wgrad_to(s, ws, n.head, a.hbuf[n.L - 1] + (size_t)T * blk, d_head, bw.slabs, grad + n.off_head)) return rc;
+    const float* h_last = n.extra ? a.hcat : a.hbuf[n.L - 1] + (size_t)T * blk;
+    if (int rc = wgrad_to(s, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
     if (T > 1) TS_HIP_CHECK(hipMemsetAsync(bw.dout, 0, 4 * (size_t)(T - 1) * blk, s));
-    if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) return rc;
+    if (n.extra) {
+        // d loss / d [h_T | extra | pad] into the (dead) concat buffer, its first H columns are d loss / d h_T
+        if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, a.hcat, ws, 0, H)) return rc;
+        hipLaunchKernelGGL(take_cols_kernel, dim3(gcell), dim3(256), 0, s, a.hcat, B, H, n.head_in, bw.dout + (size_t)(T - 1) * blk);
+        TS_LAUNCH_CHECK();
+    } else if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) {
+        return rc;
+    }
     for (int l = n.L - 1; l >= 0; --l) {
         for (int t = T - 1; t >= 0; --t) {
             hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(gcell), dim3(256), 0, s, bw.dout + (size_t)t * blk, bw.dh_rec, bw.dc,
@@ -303,13 +351,45 @@ int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, con
             if (t > 0)
                 if (int rc = ts::conv_dgrad(s, n.hh_step, bw.dg + (size_t)t * 4 * blk, p + n.off_hh[l], nullptr, bw.dh_rec, ws)) return rc;
         }
-        const float* in = l == 0 ? a.x1 : a.hbuf[l - 1] + blk;
-        if (int rc = wgrad_to(s, ws, n.ih_all, in, bw.dg, bw.slabs, grad + n.off_ih[l])) return rc;
+        const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
+        if (int rc = wgrad_to(s, ws, n.ih(l), in, bw.dg, bw.slabs, grad + n.off_ih[l])) return rc;
         if (int rc = wgrad_to(s, ws, n.ih_all, a.hbuf[l], bw.dg, bw.slabs, grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
+        if (l == 0 && !n.has_fc1) return TS_OK;            // nothing below the first LSTM layer takes a gradient
         if (int rc = ts::conv_dgrad(s, n.ih_all, bw.dg, p + n.off_ih[l], nullptr, bw.din, ws)) return rc;
         std::swap(bw.dout, bw.din);
     }
     return wgrad_to(s, ws, n.fc1, a.x, bw.dout, bw.slabs, grad + n.off_fc1);
+}
+
+// bounded head outputs: mu = max_action tanh(head) (continuous.py:230-231, 313-314), in place on the first A columns
+__global__ __launch_bounds__(256) void head_tanh_kernel(float* __restrict__ head, int64_t B, int A, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    float* p = head + b * HEAD + (i - b * A);
+    *p = scale * tanhf(*p);
+}
+
+// d_head[b, 0..32) from d_out[b, 0..A): through the tanh bound when `bounded` (y = scale tanh(z): dz = dy scale (1 - (y/scale)^2))
+__global__ __launch_bounds__(256) void head_dout_kernel(const float* __restrict__ d_out, const float* __restrict__ head_y, int64_t B,
+                                                        int A, int bounded, float scale, float* __restrict__ d_head) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * HEAD) return;
+    const int64_t b = i / HEAD;
+    const int j = (int)(i - b * HEAD);
+    float g = 0.f;
+    if (j < A) {
+        g = d_out[b * A + j];
+        if (bounded) { const float t = head_y[i] / scale; g = g * scale * (1.f - t * t); }
+    }
+    d_head[i] = g;
+}
+
+__global__ __launch_bounds__(256) void head_copy_kernel(const float* __restrict__ head, int64_t B, int A, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * A) return;
+    const int64_t b = i / A;
+    out[i] = head[b * HEAD + (i - b * A)];
 }
 
 }  // namespace
@@ -375,6 +455,70 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
     if (hp->lr < 0.0) return TS_OK;
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.count, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm, norm_part);
+}
+
+// ---- LSTM trunk + linear head, generic (RecurrentActorProb / RecurrentCritic, continuous.py:241-380) ------------------------
+int ts_lstm_net_layout(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim, int64_t has_fc1, int64_t extra_dim,
+                       int64_t* h_out) {
+    TS_REQUIRE(h_out != nullptr, TS_ERR_INVALID_ARG, "ts_lstm_net_layout: h_out is NULL");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, out_dim, 1, 1, &n, (int)has_fc1, extra_dim)) return rc;
+    h_out[0] = n.k0; h_out[1] = n.count; h_out[2] = n.has_fc1 ? n.off_fc1 : -1;
+    for (int l = 0; l < n.L; ++l) { h_out[3 + 2 * l] = n.off_ih[l]; h_out[4 + 2 * l] = n.off_hh[l]; }
+    h_out[3 + 2 * n.L] = n.off_head;
+    h_out[4 + 2 * n.L] = n.head_in;
+    return TS_OK;
+}
+
+int ts_lstm_net_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim,
+                        int64_t has_fc1, int64_t extra_dim, const float* obs, const float* extra, int64_t B, int64_t T,
+                        const float* h_in, const float* c_in, double tanh_scale, float* out, float* h_out, float* c_out,
+                        ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_lstm_net_forward: workspace is NULL");
+    TS_REQUIRE(params && obs && out && (h_in == nullptr) == (c_in == nullptr), TS_ERR_INVALID_ARG,
+               "ts_lstm_net_forward: bad argument (hidden and cell state come together)");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, out_dim, B, T, &n, (int)has_fc1, extra_dim)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::ws_reserve(ws, acts_bytes(n) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    const Acts a = take_acts(c, n);
+    if (int rc = forward(s, ws, n, params, obs, h_in, c_in, a, extra)) return rc;
+    const unsigned g = (unsigned)ts::ceil_div(B * n.A, 256);
+    if (tanh_scale > 0.0) hipLaunchKernelGGL(head_tanh_kernel, dim3(g), dim3(256), 0, s, a.out, B, n.A, (float)tanh_scale);
+    hipLaunchKernelGGL(head_copy_kernel, dim3(g), dim3(256), 0, s, a.out, B, n.A, out);
+    TS_LAUNCH_CHECK();
+    const size_t blk = (size_t)B * n.H;
+    for (int l = 0; l < n.L; ++l) {
+        if (h_out) TS_HIP_CHECK(hipMemcpyAsync(h_out + l * blk, a.hbuf[l] + (size_t)n.T * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+        if (c_out) TS_HIP_CHECK(hipMemcpyAsync(c_out + l * blk, a.cbuf[l] + (size_t)n.T * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
+    }
+    return TS_OK;
+}
+
+int ts_lstm_net_backward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t out_dim,
+                         int64_t has_fc1, int64_t extra_dim, const float* obs, const float* extra, int64_t B, int64_t T,
+                         const float* h_in, const float* c_in, double tanh_scale, const float* d_out, float* out, float* grad_out,
+                         ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_lstm_net_backward: workspace is NULL");
+    TS_REQUIRE(params && obs && d_out && grad_out && (h_in == nullptr) == (c_in == nullptr), TS_ERR_INVALID_ARG,
+               "ts_lstm_net_backward: bad argument");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, out_dim, B, T, &n, (int)has_fc1, extra_dim)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    if (int rc = ts::ws_reserve(ws, acts_bytes(n) + bwd_bytes(n) + al(4 * B * HEAD) + 8192)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    const Acts a = take_acts(c, n);
+    const Bwd bw = take_bwd(c, n);
+    float* d_head = c.f(B * HEAD);
+    if (int rc = forward(s, ws, n, params, obs, h_in, c_in, a, extra)) return rc;
+    const unsigned g = (unsigned)ts::ceil_div(B * n.A, 256);
+    if (tanh_scale > 0.0) hipLaunchKernelGGL(head_tanh_kernel, dim3(g), dim3(256), 0, s, a.out, B, n.A, (float)tanh_scale);
+    if (out) hipLaunchKernelGGL(head_copy_kernel, dim3(g), dim3(256), 0, s, a.out, B, n.A, out);
+    hipLaunchKernelGGL(head_dout_kernel, dim3((unsigned)ts::ceil_div(B * HEAD, 256)), dim3(256), 0, s, d_out, a.out, B, n.A,
+                       tanh_scale > 0.0 ? 1 : 0, (float)(tanh_scale > 0.0 ? tanh_scale : 1.0), d_head);
+    TS_LAUNCH_CHECK();
+    return backward(s, ws, n, params, a, d_head, grad_out, bw);
 }
 
 }  // extern "C"
