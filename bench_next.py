@@ -125,9 +125,14 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
     eng = T.TD3Engine(OBS, ACT, T.actor_flat_from_torch(list(actor.values()), OBS, ACT), cf(c1), cf(c2),
                       T.TD3Config(twin=twin))
 
+    from tianshou_amd.buffer import normal_noise
+
+    n_upd = [0]
+
     def update():
         idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
-        noise = torch.randn(B, ACT, generator=g, device=dev) if twin else None
+        n_upd[0] += 1
+        noise = normal_noise((B, ACT), 0x7D3, n_upd[0], dev) if twin else None
         ret = eng.preprocess(buf, idx, noise)
         return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret)[0]
 
@@ -184,9 +189,14 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
                         RQ.ensemble_flat_from_torch(list(critic.values()), OBS, ACT), cfg)
     rng = np.random.default_rng(0)
 
+    from tianshou_amd.buffer import normal_noise
+
+    n_upd = [0]
+
     def update():
         idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
-        noise = torch.randn(2, B, ACT, generator=g, device=dev)
+        n_upd[0] += 1
+        noise = normal_noise((2, B, ACT), 0x2ED0, n_upd[0], dev)
         ret = eng.preprocess(buf, idx, noise[0], rng.choice(E, SUB, replace=False))
         return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret,
                                      noise[1] if eng.will_update_actor() else None)[0]

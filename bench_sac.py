@@ -79,9 +79,14 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
                       S.critic_flat_from_torch(list(c1.values()), OBS, ACT),
                       S.critic_flat_from_torch(list(c2.values()), OBS, ACT), cfg)
 
+    from tianshou_amd.buffer import normal_noise
+
+    n_upd = [0]
+
     def update():
         idx = buf.sample_indices(BATCH, generator=g)        # manager.py:216-234: sub-buffer by length, uniform inside
-        noise = torch.randn(2, BATCH, ACT, generator=g, device=dev)
+        n_upd[0] += 1
+        noise = normal_noise((2, BATCH, ACT), 0x5AC, n_upd[0], dev)      # rsample() eps of a' ~ pi(s') and a ~ pi(s)
         ret = eng.preprocess(buf, idx, noise[0])
         stats, _ = eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret, noise[1])
         return stats

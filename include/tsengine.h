@@ -177,6 +177,13 @@ int ts_sample_indices_random(const int64_t* offset, int64_t E, const int64_t* le
  * to ts_ppo_update instead. */
 int ts_random_permutation(int64_t* out, int64_t n, uint64_t seed, ts_stream_t stream);
 
+/* eps ~ N(0, 1) for the reparameterised samples of the continuous policies (torch.distributions.Normal.rsample as used by
+ * SAC / REDQ `forward`, tianshou/algorithm/modelfree/sac.py:228-236; DDPG / TD3 exploration and target noise): out
+ * float32[n] from a counter-based Philox-4x32-10 stream keyed by (seed, offset) + Box-Muller; `offset` = a per-call
+ * counter (e.g. the update number) so that successive calls draw fresh numbers.  Not torch's generator stream: to
+ * reproduce a seeded reference run pass its noise to the update entry points instead (they all take it as an input). */
+int ts_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, ts_stream_t stream);
+
 /* ReplayBuffer.__getitem__ row gather (buffer_base.py:605-649): out[i,:] = src[index[i],:]
  * for a row of `row_bytes` bytes (any dtype).  16-byte vector path when row_bytes % 16 == 0
  * and both bases are 16-byte aligned. */

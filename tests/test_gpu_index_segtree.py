@@ -254,3 +254,26 @@ def test_random_sample_indices_device_rng_distribution():
     np.testing.assert_allclose(freq, L / L.sum(), atol=4 * np.sqrt(0.25 / bs))
     big = idx[e == 2] - off[2]                                            # uniform inside a sub-buffer
     assert abs(big.mean() - 499.5) < 5 * 288.7 / np.sqrt(big.size)
+
+
+@pytest.mark.gpu
+def test_normal_fill_is_a_keyed_standard_normal_stream():
+    """ts_normal_fill: same (seed, offset) -> same numbers whatever the size; fresh numbers per offset; mean / variance /
+    fourth moment / tail mass of N(0, 1) over 2^22 draws (Philox-4x32-10 + Box-Muller)."""
+    from tianshou_amd.buffer import normal_noise
+
+    a = normal_noise((1 << 22,), 7, 3)
+    b = normal_noise((1000,), 7, 3)
+    assert torch.equal(a[:1000], b)                               # prefix property (counter-based)
+    assert not torch.equal(a[:1000], normal_noise((1000,), 7, 4))
+    assert not torch.equal(a[:1000], normal_noise((1000,), 8, 3))
+    x = a.double()
+    n = x.numel()
+    assert abs(float(x.mean())) < 4.0 / np.sqrt(n)
+    assert abs(float(x.var()) - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(float((x ** 4).mean()) - 3.0) < 0.05
+    assert abs(float((x.abs() > 3.0).double().mean()) - 0.0026998) < 3e-4
+    assert torch.isfinite(a).all() and float(a.abs().max()) < 6.5
+    assert normal_noise((5, 3, 7), 1, 1).shape == (5, 3, 7)       # odd sizes: the tail quad is partial
+    # lag-1 correlation of neighbouring outputs (the two Box-Muller partners and adjacent counters)
+    assert abs(float((x[:-1] * x[1:]).mean())) < 4.0 / np.sqrt(n)

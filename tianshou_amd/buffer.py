@@ -89,6 +89,16 @@ def random_permutation(n: int, seed: int, device="cuda") -> torch.Tensor:
     return out
 
 
+def normal_noise(shape, seed: int, offset: int, device="cuda") -> torch.Tensor:
+    """eps ~ N(0, 1), float32 `shape`, from the engine's counter-based generator (ts_normal_fill: Philox-4x32-10 keyed by
+    (seed, offset) + Box-Muller) -- the device-side stand-in for the `rsample()` / exploration noise the reference draws
+    with torch's generator.  `offset` = a per-call counter."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _lib.check(_lib.load().ts_normal_fill(_lib.ptr(out), _lib.i64(out.numel()), C.c_uint64(seed & (2**64 - 1)),
+                                          C.c_uint64(offset & (2**64 - 1)), _lib.current_stream(out.device)))
+    return out
+
+
 class AddTracker:
     """Exact write log of a reference replay buffer: per sub-buffer the number of transitions
     `ReplayBufferManager.add` (manager.py:131-198: one slot in each of `buffer_ids`, all sub-buffers when None) /
