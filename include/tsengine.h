@@ -902,6 +902,17 @@ int ts_allreduce_init(const uint8_t* h_id128, int64_t rank, int64_t world, int d
 int ts_allreduce(ts_comm* comm, float* buf, int64_t n, ts_stream_t stream);
 int ts_allreduce_destroy(ts_comm* comm);
 
+/* One data-parallel PPO / A2C gradient step in one call: ts_ppo_grad on the local minibatch shard ->
+ * ts_allreduce of step_buf[0 .. P + 4) (gradient sums / global_batch and the four loss parts; skipped when comm is NULL =
+ * one rank) -> ts_ppo_apply (clip by the global norm + Adam step number `adam_step`), all on `stream`, no host
+ * synchronisation in between.  step_buf: device float32[>= P + 4], 16-byte aligned, one row per step if the caller
+ * wants to keep the loss parts (step_buf[P .. P + 4) = (0, clip, vf, ent) summed over the ranks: divide ent by the world
+ * size and compose loss = clip + vf_coef * vf - ent_coef * ent).  Arguments as for ts_ppo_grad / ts_ppo_apply. */
+int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                   int64_t obs_dim, int64_t act_dim, const float* rec, int64_t n, const int64_t* perm_rows, int64_t n_rows,
+                   int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp, float* step_buf,
+                   ts_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -286,6 +286,45 @@ def test_data_parallel_path_world1_matches_fused_update(cfg_name):
     np.testing.assert_allclose(engs[1].adam_v.cpu().numpy(), engs[0].adam_v.cpu().numpy(), rtol=1e-5, atol=1e-12)
 
 
+def test_dp_step_entry_point_equals_the_three_separate_calls():
+    """ts_ppo_dp_step (gradient + RCCL exchange + optimizer step behind one call) against ts_ppo_grad / ts_ppo_apply
+    driven from Python, bit for bit: on one rank without a communicator, and through a real one-rank RCCL communicator
+    (ts_allreduce_init with world = 1), which puts ncclAllReduce on the stream between the two kernels."""
+    from tianshou_amd import ppo as P
+    from tianshou_amd.collective import NativeAllReduce
+    from tianshou_amd.distributed import DataParallelPPO
+
+    class Separate(DataParallelPPO):
+        def _native_comm(self):                      # forces the three-call path
+            return None
+
+    n, batch, repeat = 3000, 700, 2
+    params, data = random_problem(n, 17, 6, seed=33)
+    _, cfg = both_cfgs("mujoco")
+    cfg.return_scaling = False
+    rng = np.random.default_rng(5)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    unf = np.arange(6) * 500 + 499
+    ar = NativeAllReduce(torch.device("cuda", 0))
+    try:
+        results = []
+        for make in (lambda e: Separate(e), lambda e: DataParallelPPO(e), lambda e: DataParallelPPO(e, allreduce=ar)):
+            eng = P.PPOEngine(17, 6, OP.flatten_params(params).cuda(), cfg)
+            b = eng.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]),
+                               dev(data["terminated"]), dev(data["truncated"]), dev(unf))
+            dp = make(eng)
+            if dp._allreduce is None and type(dp) is DataParallelPPO:
+                assert dp._native_comm() is not None and not dp._native_comm().value      # NULL communicator: one rank
+            losses, steps = dp.update(b, batch, repeat, perms)
+            results.append((losses.cpu(), eng.params.cpu(), eng.adam_m.cpu(), eng.adam_v.cpu(), steps))
+        for r in results[1:]:
+            assert r[4] == results[0][4]
+            for a, b_ in zip(r[:4], results[0][:4]):
+                assert torch.equal(a, b_)
+    finally:
+        ar.close()
+
+
 @pytest.mark.parametrize("obs_dim,act_dim", [(4, 2), (11, 3), (27, 8), (31, 1), (1, 1)])
 def test_update_other_network_shapes(obs_dim, act_dim):
     """Every instantiated first-layer width (K-steps 1..16) and action counts 1..8 through the whole

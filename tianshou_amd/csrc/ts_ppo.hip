@@ -2116,6 +2116,25 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     return TS_OK;
 }
 
+// One data-parallel gradient step behind ONE call: local gradient -> sum all-reduce of [grad | loss parts] -> clip + Adam.
+int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                   int64_t obs_dim, int64_t act_dim, const float* rec, int64_t n, const int64_t* perm_rows, int64_t n_rows,
+                   int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp, float* step_buf,
+                   ts_stream_t stream) {
+    TS_REQUIRE(step_buf != nullptr, TS_ERR_INVALID_ARG, "ts_ppo_dp_step: step_buf is NULL");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(step_buf) & 15u) == 0, TS_ERR_INVALID_ARG, "ts_ppo_dp_step: step_buf must be 16-byte aligned");
+    const int64_t P = ts_ppo_param_count(obs_dim, act_dim);
+    if (P < 0) return ts::fail(TS_ERR_INVALID_ARG, "ts_ppo_dp_step: bad dimensions");
+    int rc = ts_ppo_grad(ws, params, obs_dim, act_dim, rec, n, perm_rows, n_rows, global_batch, adv_stats, hp, step_buf,
+                         step_buf + P, stream);
+    if (rc != TS_OK) return rc;
+    if (comm) {
+        rc = ts_allreduce(comm, step_buf, P + 4, stream);          // gradient + the four loss parts in one exchange
+        if (rc != TS_OK) return rc;
+    }
+    return ts_ppo_apply(ws, params, adam_m, adam_v, adam_step, obs_dim, act_dim, step_buf, hp, stream);
+}
+
 int ts_ppo_set_step_mode(int mode) {
     TS_REQUIRE(mode >= 0 && mode <= 3, TS_ERR_INVALID_ARG, "ts_ppo_set_step_mode: mode must be 0 (environment / default) .. 3");
     g_step_mode_override = mode;

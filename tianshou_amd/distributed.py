@@ -90,6 +90,27 @@ class DataParallelPPO:
             _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim), _lib.ptr(grad), C.byref(hp),
             _lib.current_stream(eng.device)))
 
+    def _native_comm(self):
+        """The RCCL communicator handle for ts_ppo_dp_step: a NativeAllReduce's, NULL on one rank, or None when the
+        exchange goes through torch.distributed / a test double (then the three calls stay separate)."""
+        comm = getattr(self._allreduce, "_comm", None)
+        if comm is not None:
+            return comm
+        if self.world == 1 and self._allreduce is None and type(self)._local_grad is DataParallelPPO._local_grad:
+            return C.c_void_p()
+        return None
+
+    def _dp_step(self, comm, rec, rows, global_batch, adv_stats, out):
+        """Gradient + exchange + optimizer step of one minibatch behind one C call (ts_ppo_dp_step)."""
+        eng, lib = self.eng, _lib.load()
+        hp = eng.cfg.to_c()
+        eng.adam_step += 1
+        _lib.check(lib.ts_ppo_dp_step(
+            eng._ws.handle, comm, _lib.ptr(eng.params), _lib.ptr(eng.adam_m), _lib.ptr(eng.adam_v), _lib.i64(eng.adam_step),
+            _lib.i64(eng.obs_dim), _lib.i64(eng.act_dim), _lib.ptr(rec), _lib.i64(rec.shape[0]), _lib.ptr(rows),
+            _lib.i64(rows.numel()), _lib.i64(global_batch), _lib.ptr(adv_stats), C.byref(hp), _lib.ptr(out),
+            _lib.current_stream(eng.device)))
+
     def _pack(self, b):
         return pack_batch(b, self.eng.obs_dim, self.eng.act_dim)
 
@@ -174,6 +195,7 @@ class DataParallelPPO:
         width = (eng.P + 4 + 3) // 4 * 4                      # 16-byte aligned rows
         if self._buf is None or self._buf.device != dev or self._buf.shape[0] < n_steps:
             self._buf = torch.empty((n_steps, width), dtype=torch.float32, device=dev)
+        comm = self._native_comm()
         k = 0
         for r in range(repeat):
             if cfg.recompute_advantage and r > 0:                  # ppo.py:174-178
@@ -183,10 +205,14 @@ class DataParallelPPO:
             stats = global_adv_stats(b["adv"], rows_r, self.group) if cfg.advantage_normalization else None
             for c, rows in enumerate(rows_r):
                 out = self._buf[k, : eng.P + 4]
-                self._local_grad(rec, rows, g_count[c], None if stats is None else stats[c], out)
-                if self.world > 1:
-                    self._exchange(out)                          # RCCL: gradient + loss parts in one call
-                self._apply(out)
+                st = None if stats is None else stats[c]
+                if comm is not None:
+                    self._dp_step(comm, rec, rows, g_count[c], st, out)
+                else:
+                    self._local_grad(rec, rows, g_count[c], st, out)
+                    if self.world > 1:
+                        self._exchange(out)                      # RCCL: gradient + loss parts in one call
+                    self._apply(out)
                 k += 1
         res = self._buf[:n_steps, eng.P:eng.P + 4].clone()
         # the entropy term depends on the parameters only: every rank added the same value
