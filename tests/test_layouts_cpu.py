@@ -140,3 +140,40 @@ def test_device_pointer_guard():
         _lib.ptr(torch.zeros(4))
     assert _lib.ptr(None).value in (None, 0)
     assert np.dtype(np.int64).itemsize == 8
+
+
+def test_recurrent_actor_critic_layout_converters_round_trip_and_reject_conditioned_sigma():
+    """tianshou_amd.recurrent: state_dict() order <-> flat engine layout (exact inverses, zero padding), and the
+    unsupported RecurrentActorProb(conditioned_sigma=True) is refused loudly (continuous.py:268-271)."""
+    import types
+
+    from tianshou_amd import recurrent as R
+
+    obs_dim, act_dim, hidden, layers = 37, 5, 64, 2
+    g = torch.Generator().manual_seed(0)
+    shapes = {}
+    for l in range(layers):
+        shapes[f"nn.weight_ih_l{l}"] = (4 * hidden, obs_dim if l == 0 else hidden)
+        shapes[f"nn.weight_hh_l{l}"] = (4 * hidden, hidden)
+        shapes[f"nn.bias_ih_l{l}"] = shapes[f"nn.bias_hh_l{l}"] = (4 * hidden,)
+    a_shapes = dict(shapes, **{"sigma_param": (act_dim, 1), "mu.weight": (act_dim, hidden), "mu.bias": (act_dim,)})
+    c_shapes = dict(shapes, **{"fc2.weight": (1, hidden + act_dim), "fc2.bias": (1,)})
+    ta = [torch.randn(a_shapes[k], generator=g) for k in R.actor_state_dict_keys(layers)]
+    tc = [torch.randn(c_shapes[k], generator=g) for k in R.critic_state_dict_keys(layers)]
+    flat, sigma = R.actor_flat_from_torch(ta, obs_dim, act_dim, hidden, layers, device="cpu")
+    k0 = 64
+    assert flat.numel() == (k0 + 1) * 4 * hidden + (hidden + 1) * 4 * hidden * 3 + (hidden + 1) * 32
+    for a, b in zip(R.actor_flat_to_torch(flat, sigma, obs_dim, act_dim, hidden, layers), ta):
+        assert torch.equal(a, b)
+    w0 = flat[: (k0 + 1) * 4 * hidden].reshape(k0 + 1, 4 * hidden)
+    assert torch.all(w0[obs_dim:k0] == 0) and torch.equal(w0[k0], ta[3])          # zero K padding, b_ih in the last row
+    flat_c = R.critic_flat_from_torch(tc, obs_dim, act_dim, hidden, layers, device="cpu")
+    head_in = 96                                                                 # 64 + 5 rounded up to 32
+    assert flat_c.numel() == flat.numel() - (hidden + 1) * 32 + (head_in + 1) * 32
+    for a, b in zip(R.critic_flat_to_torch(flat_c, obs_dim, act_dim, hidden, layers), tc):
+        assert torch.equal(a, b)
+    head = flat_c[-(head_in + 1) * 32:].reshape(head_in + 1, 32)
+    assert torch.all(head[hidden + act_dim:head_in] == 0) and torch.all(head[:, 1:] == 0)
+    fake = types.SimpleNamespace(_c_sigma=True)
+    with pytest.raises(NotImplementedError, match="conditioned_sigma"):
+        R.RecurrentActorProbEngine.from_module(fake)

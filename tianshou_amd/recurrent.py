@@ -200,6 +200,29 @@ class RecurrentActorProbEngine(_LstmNetEngine):
         if self.sigma_param.numel() != act_dim:
             raise ValueError("sigma_param must have act_dim entries")
 
+    @classmethod
+    def from_module(cls, module, device="cuda", **adam):
+        """From a `RecurrentActorProb` instance (duck-typed: `.nn` = the nn.LSTM, `.mu`, `.sigma_param`, `._c_sigma`,
+        `.max_action`, `._unbounded`, continuous.py:262-274)."""
+        if getattr(module, "_c_sigma", False):
+            raise NotImplementedError("RecurrentActorProb(conditioned_sigma=True) is not supported: sigma must be the "
+                                      "state-independent sigma_param")
+        lstm = module.nn
+        layers, hidden, obs_dim = int(lstm.num_layers), int(lstm.hidden_size), int(lstm.input_size)
+        act_dim = int(module.mu.out_features)
+        sd = module.state_dict()
+        flat, sigma = actor_flat_from_torch([sd[k] for k in actor_state_dict_keys(layers)], obs_dim, act_dim, hidden, layers, device)
+        return cls(obs_dim, act_dim, hidden, layers, flat, sigma, max_action=float(module.max_action),
+                   unbounded=bool(module._unbounded), **adam)
+
+    def to_module(self, module) -> None:
+        """Writes the engine's parameters back into the torch module (checkpoints, the collector's policy)."""
+        t = actor_flat_to_torch(self.params, self.sigma_param, self.obs_dim, self.act_dim, self.hidden, self.layers)
+        sd = module.state_dict()
+        with torch.no_grad():
+            for k, v in zip(actor_state_dict_keys(self.layers), t):
+                sd[k].copy_(v.reshape(sd[k].shape))
+
     @property
     def _scale(self) -> float:
         return 0.0 if self.unbounded else self.max_action
@@ -222,6 +245,23 @@ class RecurrentCriticEngine(_LstmNetEngine):
     def __init__(self, obs_dim: int, act_dim: int, hidden: int, layers: int, flat_params: torch.Tensor, **adam):
         super().__init__(obs_dim, hidden, layers, 1, act_dim, flat_params, **adam)
         self.act_dim = act_dim
+
+    @classmethod
+    def from_module(cls, module, device="cuda", **adam):
+        """From a `RecurrentCritic` instance (`.nn` = the nn.LSTM, `.fc2`, continuous.py:335-344)."""
+        lstm = module.nn
+        layers, hidden, obs_dim = int(lstm.num_layers), int(lstm.hidden_size), int(lstm.input_size)
+        act_dim = int(module.fc2.in_features) - hidden
+        sd = module.state_dict()
+        flat = critic_flat_from_torch([sd[k] for k in critic_state_dict_keys(layers)], obs_dim, act_dim, hidden, layers, device)
+        return cls(obs_dim, act_dim, hidden, layers, flat, **adam)
+
+    def to_module(self, module) -> None:
+        t = critic_flat_to_torch(self.params, self.obs_dim, self.act_dim, self.hidden, self.layers)
+        sd = module.state_dict()
+        with torch.no_grad():
+            for k, v in zip(critic_state_dict_keys(self.layers), t):
+                sd[k].copy_(v.reshape(sd[k].shape))
 
     def _act(self, act, b):
         if self.act_dim == 0:
