@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
     float *d_g[2], *d_parts[2];
     std::vector<float> g[2], parts[2];
     hipEvent_t e0, e1; HK(hipEventCreate(&e0)); HK(hipEventCreate(&e1));
-    const int modes[2] = {2, 3};
+    const int modes[2] = {2, getenv("S3_MODE") ? atoi(getenv("S3_MODE")) : 3};
     for (int m = 0; m < 2; ++m) {
         HK(hipMalloc(&d_g[m], sizeof(float) * (P + 8))); HK(hipMalloc(&d_parts[m], sizeof(float) * 8));
         HK(hipMemset(d_g[m], 0, sizeof(float) * (P + 8)));
@@ -91,6 +91,11 @@ int main(int argc, char** argv) {
                 printf("  mode %d trial %d total %lld cycles:", modes[m], trial, (long long)(cyc[17] - cyc[0]));
                 for (int k = 1; k < 18; ++k) printf(" %s +%lld", names[k], (long long)(cyc[k] - cyc[k - 1]));
                 printf("\n");
+                if (modes[m] == 4) {
+                    printf("    actor phase A (from dH1 mark %lld):", (long long)(cyc[5] - cyc[0]));
+                    for (int k = 20; k < 26; ++k) printf(" m%d @%lld", k, (long long)(cyc[k] - cyc[0]));
+                    printf("\n");
+                }
             }
         }
     }
