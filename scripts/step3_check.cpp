@@ -91,11 +91,6 @@ int main(int argc, char** argv) {
                 printf("  mode %d trial %d total %lld cycles:", modes[m], trial, (long long)(cyc[17] - cyc[0]));
                 for (int k = 1; k < 18; ++k) printf(" %s +%lld", names[k], (long long)(cyc[k] - cyc[k - 1]));
                 printf("\n");
-                if (modes[m] == 4) {
-                    printf("    actor phase A (from dH1 mark %lld):", (long long)(cyc[5] - cyc[0]));
-                    for (int k = 20; k < 26; ++k) printf(" m%d @%lld", k, (long long)(cyc[k] - cyc[0]));
-                    printf("\n");
-                }
             }
         }
     }

@@ -426,8 +426,6 @@ struct StepArgs {
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
     long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
-    int64_t row0;             // ppo_step4_kernel: first minibatch row of this launch (the host loops over launches)
-    int accumulate;           // ppo_step4_kernel: add to the slabs instead of overwriting them (launches after the first)
 };
 
 #define TS_MARK(g, k)                                                                  \
@@ -1425,7 +1423,6 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
 }
 
 #include "ts_ppo_step3.h"
-#include "ts_ppo_step4.h"
 
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
@@ -1494,7 +1491,7 @@ struct AdamArgs {
     float* image;             // LDS images of the step kernel to refresh (or NULL)
     const int* inv;           // param -> image slot (-1: none)
     int sig_off, act, small0; // sigma_param range and the actor image's SMALL block
-    int image3;               // 3 / 4: image and inv use the split-bf16 format of ppo_step3_kernel / ppo_step4_kernel
+    int image3;               // image / inv use the split-bf16 format of ppo_step3_kernel (ts_ppo_step3.h)
 };
 
 constexpr int ADAM_THREADS = 256;
@@ -1509,7 +1506,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     const int pc = mine ? p : 0;
     float g_raw = a.grad[pc], m = a.m[pc], v = a.v[pc], par = a.params[pc];
     const int slot = (mine && a.image) ? a.inv[pc] : (a.image3 ? 0 : -1);
-    const int slot_t = (mine && a.image && a.image3 == 4) ? a.inv[a.n_params + pc] : 0;
     // global gradient norm: every workgroup re-reduces the (few) partials in the same order
     float sq = 0.f;
     if (a.sumsq_part) {
@@ -1545,13 +1541,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
-        if (a.image && a.image3 == 4) {
-            char* img = reinterpret_cast<char*>(a.image);
-            s4::image_put(img, slot, np_);
-            s4::image_put(img, slot_t, np_);
-            const int k = p - a.sig_off;
-            if (k >= 0 && k < a.act) s4::image_put_sigma(img, k, np_);
-        } else if (a.image && a.image3) {
+        if (a.image && a.image3) {
             char* img = reinterpret_cast<char*>(a.image);
             s3::image_put(img, slot, np_);
             const int k = p - a.sig_off;
@@ -1644,7 +1634,7 @@ inline int step_mode() {
         if (v1 && atoi(v1) != 0) return 1;
         const char* e = getenv("TS_PPO_STEP");
         const int m = e ? atoi(e) : 0;
-        return (m >= 1 && m <= 4) ? m : TS_PPO_STEP_DEFAULT;
+        return (m >= 1 && m <= 3) ? m : TS_PPO_STEP_DEFAULT;
     }();
     return g_step_mode_override ? g_step_mode_override : env;
 }
@@ -1721,13 +1711,11 @@ template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
     const int mode = step_mode();
     const size_t lds = mode == 1 ? step_lds_bytes<KS1>()
-                                 : (mode == 3 ? (size_t)s3::LDS_BYTES
-                                              : (mode == 4 ? (size_t)s4::LDS_BYTES : sizeof(float) * (size_t)T2_FLOATS));
+                                 : (mode == 3 ? (size_t)s3::LDS_BYTES : sizeof(float) * (size_t)T2_FLOATS);
     const void* fn = mode == 1 ? reinterpret_cast<const void*>(&ppo_step_kernel<KS1>)
                                : (mode == 3 ? reinterpret_cast<const void*>(&s3::ppo_step3_kernel<KS1>)
-                                            : (mode == 4 ? reinterpret_cast<const void*>(&s4::ppo_step4_kernel<KS1>)
-                                                         : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>)));
-    static bool attr_done[5] = {false, false, false, false, false};
+                                            : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>));
+    static bool attr_done[4] = {false, false, false, false};
     if (!attr_done[mode]) {
         TS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[mode] = true;
@@ -1736,19 +1724,6 @@ int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hi
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
         if (mode == 1) hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
         else if (mode == 3) hipLaunchKernelGGL((s3::ppo_step3_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
-        else if (mode == 4) {
-            // no tile loop inside the kernel (a loop makes LLVM hoist every lane-dependent address into a spilled
-            // prologue): minibatches beyond one grid pass take further launches that accumulate into the same slabs
-            const int64_t per_launch = (int64_t)n_wg * s4::WAVES * s4::SPW;
-            StepArgs gl = g;
-            for (int64_t r0 = 0; r0 < g.n_rows; r0 += per_launch) {
-                gl.row0 = r0;
-                gl.accumulate = r0 > 0;
-                const int64_t rows = g.n_rows - r0 < per_launch ? g.n_rows - r0 : per_launch;
-                const int wg = (int)((rows + s4::WAVES * s4::SPW - 1) / (s4::WAVES * s4::SPW));
-                hipLaunchKernelGGL((s4::ppo_step4_kernel<KS1>), dim3(wg), dim3(s4::THREADS), lds, s, gl, d);
-            }
-        }
         else hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
     TS_LAUNCH_CHECK();
@@ -1756,11 +1731,6 @@ int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hi
 }
 
 inline int step_grid(int64_t n_rows) {
-    if (step_mode() == 4) {                            // 16-sample tiles, 16 waves per workgroup, one workgroup per CU
-        int64_t wg4 = ((n_rows + s4::SPW - 1) / s4::SPW + s4::WAVES - 1) / s4::WAVES;
-        const int cap4 = n_compute_units();
-        return (int)(wg4 > cap4 ? cap4 : (wg4 < 1 ? 1 : wg4));
-    }
     const int64_t tiles = (n_rows + 31) / 32;
     int64_t wg = (tiles + STEP_WAVES - 1) / STEP_WAVES;
     static const int per_cu = [] { const char* e = getenv("TS_PPO_WG_PER_CU"); return e ? atoi(e) : 2; }();
@@ -1805,11 +1775,6 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
     b.img_end = 4960 + 128 * ks;                           // Lds<ks, 1>::END
     b.img_bytes = (sizeof(float) * 2 * (size_t)b.img_end + 255) & ~(size_t)255;
     if (step_mode() == 3) b.img_bytes = (2 * (size_t)s3::IMG_BYTES + 255) & ~(size_t)255;
-    if (step_mode() == 4) {
-        b.img_bytes = (2 * (size_t)s4::IMG_BYTES + 255) & ~(size_t)255;
-        b.inv_bytes = (sizeof(int) * 2 * (size_t)d.p_total + 255) & ~(size_t)255;
-        return b;
-    }
     b.inv_bytes = (sizeof(int) * (size_t)d.p_total + 255) & ~(size_t)255;
     return b;
 }
@@ -1817,12 +1782,6 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
 // LDS images of both nets + the param -> image-slot table (see ppo_build_image_kernel)
 int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float* image, int* inv) {
     const int64_t obs_dim = d.obs;
-    if (step_mode() == 4) {
-        hipLaunchKernelGGL(s4::ppo_build_image4_kernel, dim3(1), dim3(1024), 0, s, params, d,
-                           reinterpret_cast<char*>(image), inv);
-        TS_LAUNCH_CHECK();
-        return TS_OK;
-    }
     if (step_mode() == 3) {
         hipLaunchKernelGGL(s3::ppo_build_image3_kernel, dim3(1), dim3(1024), 0, s, params, d,
                            reinterpret_cast<char*>(image), inv);
@@ -2071,7 +2030,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
         a.losses = losses; a.apply = 1;
         a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
-        a.image3 = step_mode() >= 3 ? step_mode() : 0;
+        a.image3 = step_mode() == 3;
         {
             ts::ProfScope prof(ws, TS_KIND_PPO_ADAM, s);
             hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
@@ -2177,7 +2136,7 @@ int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m
 }
 
 int ts_ppo_set_step_mode(int mode) {
-    TS_REQUIRE(mode >= 0 && mode <= 4, TS_ERR_INVALID_ARG, "ts_ppo_set_step_mode: mode must be 0 (environment / default) .. 4");
+    TS_REQUIRE(mode >= 0 && mode <= 3, TS_ERR_INVALID_ARG, "ts_ppo_set_step_mode: mode must be 0 (environment / default) .. 3");
     g_step_mode_override = mode;
     return TS_OK;
 }
@@ -2206,7 +2165,7 @@ int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
         a.image = static_cast<float*>(ws->ppo_image);
         a.inv = reinterpret_cast<const int*>(static_cast<char*>(ws->ppo_image) + ib.img_bytes);
         a.sig_off = d.a_sig; a.act = d.act; a.small0 = ib.img_end - 32;
-        a.image3 = step_mode() >= 3 ? step_mode() : 0;
+        a.image3 = step_mode() == 3;
     }
     hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
                        dim3(ADAM_THREADS), 0, ts::as_stream(stream), a);
