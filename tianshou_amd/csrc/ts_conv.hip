@@ -14,7 +14,6 @@
 
 #include "ts_common.h"
 #include "ts_conv.h"
-#include "ts_split.h"
 
 namespace {
 
@@ -208,145 +207,6 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
                     if (o >= 0) {
                         if (a.mask) v = a.mask[o + col] > 0.f ? v : 0.f;
                         a.C[o + col] = v;
-                    }
-                }
-            }
-        }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// forward on the bf16 matrix cores (TS_CONV_SPLIT=1): the same implicit GEMM, every operand element split into three
-// bf16 pieces ONCE while its chunk is staged into LDS (5.5 VALU per element, reused by 32-64 MFMAs), six
-// v_mfma_f32_32x32x16_bf16 per 16-deep k step instead of eight v_mfma_f32_32x32x2_f32 (192 against 512 matrix-pipe
-// cycles, and the VALU stays free for the staging).  LDS images are operand-ready: [piece][row or column][32 k] bf16,
-// 80-byte pitch (16-byte reads of 8 consecutive k, conflict-free); the weight tile is transposed in the staging pass
-// (a thread takes two consecutive k rows of a 4-column quad, so that its packed pairs are k-adjacent).
-// ------------------------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(THREADS) void conv_rows_split_kernel(GemmArgs a) {
-    using namespace tsplit;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, PA = 80;
-    constexpr int AJ = BM / 32, BQ = BN / 4;
-    static_assert(WM * WN == 4 && BQ * 16 <= THREADS, "four waves; one k pair of a column quad per thread");
-    __shared__ __attribute__((aligned(16))) char As[3 * BM * PA];
-    __shared__ __attribute__((aligned(16))) char Bs[3 * BN * PA];
-    __shared__ int s_in[BM];
-    const ts::ConvGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
-
-    for (int i = tid; i < BM; i += THREADS) {
-        const int m = m0 + i;
-        const int mc = m < a.M ? m : a.M - 1;
-        const int b = mc / (g.OH * g.OW), rem = mc - b * g.OH * g.OW;
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
-        s_in[i] = ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC;
-    }
-    __syncthreads();
-
-    const int q = tid & 7, rowi = tid >> 3;          // A staging: float4 q (k = 4q .. 4q+3) of rows rowi + 32 j
-    const int bn4 = tid % BQ, bkp = (tid / BQ) & 15; // B staging: column quad bn4, k pair bkp
-    const bool b_on = tid < BQ * 16;
-    const int run = g.KW * g.IC, pitch = g.IW * g.IC;
-    f32x4 ar[AJ], br[2];
-
-    auto gload = [&](int c) {
-        const int k0 = c * BK;
-        const int k = k0 + 4 * q, kh = k / run;
-        const int koff = kh * pitch + (k - kh * run);
-        if (a.a_u8) {
-            const uint8_t* a8 = reinterpret_cast<const uint8_t*>(a.A);
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const uint32_t v = *reinterpret_cast<const uint32_t*>(a8 + s_in[rowi + 32 * j] + koff);
-                ar[j] = f32x4{(float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)};
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) ar[j] = *reinterpret_cast<const f32x4*>(a.A + s_in[rowi + 32 * j] + koff);
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            br[e] = *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)(k0 + 2 * bkp + e) * g.OC + n0 + 4 * bn4);
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            const Pk3 lo = split_pair(ar[j][0], ar[j][1]), hi = split_pair(ar[j][2], ar[j][3]);
-            char* d = As + (rowi + 32 * j) * PA + q * 8;
-            *reinterpret_cast<u32x2*>(d) = u32x2{lo.p0, hi.p0};
-            *reinterpret_cast<u32x2*>(d + BM * PA) = u32x2{lo.p1, hi.p1};
-            *reinterpret_cast<u32x2*>(d + 2 * BM * PA) = u32x2{lo.p2, hi.p2};
-        }
-        if (b_on) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const Pk3 s = split_pair(br[0][x], br[1][x]);           // (k, k + 1) of column 4 bn4 + x
-                char* d = Bs + (4 * bn4 + x) * PA + bkp * 4;
-                *reinterpret_cast<unsigned*>(d) = s.p0;
-                *reinterpret_cast<unsigned*>(d + BN * PA) = s.p1;
-                *reinterpret_cast<unsigned*>(d + 2 * BN * PA) = s.p2;
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
-
-    const int c_begin = split * a.chunks;
-    const int c_end = min(a.total_chunks, c_begin + a.chunks);
-    if (c_begin < c_end) gload(c_begin);
-    for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (c + 1 < c_end) gload(c + 1);
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            P3 av[TM], bv[TN];
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    av[tm].p[p] = *reinterpret_cast<const u32x4*>(As + p * BM * PA + (wm * TM * 32 + tm * 32 + r) * PA + c2 * 32 + h * 16);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bv[tn].p[p] = *reinterpret_cast<const u32x4*>(Bs + p * BN * PA + (wn * TN * 32 + tn * 32 + r) * PA + c2 * 32 + h * 16);
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mma6(av[tm], bv[tn], acc[tm][tn]);
-        }
-    }
-
-    const bool to_slab = a.slab_stride > 0;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = n0 + wn * TN * 32 + tn * 32 + r;
-            const float bias = to_slab ? 0.f : a.bias[col];
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                const int row = wm * TM * 32 + tm * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-                float v = acc[tm][tn][x];
-                const int m = m0 + row;
-                if (m < a.M) {
-                    if (to_slab) {
-                        a.C[split * a.slab_stride + (int64_t)m * g.OC + col] = v;
-                    } else {
-                        v += bias;
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.C[(int64_t)m * g.OC + col] = v;
                     }
                 }
             }
@@ -623,13 +483,6 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
         const bool small = small_rows(a.M, bn, g.OC / bn * nsplit);
         const int bm = (bn == 64 ? 128 : 256) / (small ? 2 : 1);
         dim3 grid((unsigned)ceil_div(a.M, bm), g.OC / bn, nsplit);
-        static const bool split_bf16 = [] { const char* e = getenv("TS_CONV_SPLIT"); return e && atoi(e) != 0; }();
-        if (split_bf16) {
-            if (bn == 64 && !small) hipLaunchKernelGGL((conv_rows_split_kernel<2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
-            else if (bn == 64) hipLaunchKernelGGL((conv_rows_split_kernel<1, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
-            else if (!small) hipLaunchKernelGGL((conv_rows_split_kernel<2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
-            else hipLaunchKernelGGL((conv_rows_split_kernel<1, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
-        } else
         if (bn == 64 && !small) hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
         else if (bn == 64) hipLaunchKernelGGL((conv_rows_kernel<false, 1, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
         else if (!small) hipLaunchKernelGGL((conv_rows_kernel<false, 2, 1, 4, 1>), grid, dim3(THREADS), 0, s, a);
