@@ -223,14 +223,15 @@ class PPOEngine:
         return x.to(device=self.device, dtype=torch.float32).contiguous()
 
     def add_returns_and_advantages(self, obs, obs_next, rew, terminated, truncated, cut_pos,
-                                   d_n_cut=None, reduce_stats=None):
+                                   d_n_cut=None, reduce_stats=None, v_s=None):
         """a2c.py:115-153 -> (v_s, returns, adv) float32 device tensors.
 
         `reduce_stats(sum, sumsq, count) -> (sum, sumsq, count)`: data-parallel hook - the three float64 moments of the
         unnormalised returns summed over all ranks, so that every replica updates `ret_rms` with the statistics of the
         GLOBAL batch (what `ret_rms.update(unnormalized_returns)` sees in a single process, a2c.py:148)."""
         cfg = self.cfg
-        v_s, _ = infer(self.params, self.obs_dim, self.act_dim, obs)
+        if v_s is None:                    # preprocess() passes V(s) from the launch that also produced log pi_old
+            v_s, _ = infer(self.params, self.obs_dim, self.act_dim, obs)
         v_next, _ = infer(self.params, self.obs_dim, self.act_dim, obs_next)
         scale = math.sqrt(self.ret_rms[1] + self._eps) if cfg.return_scaling else 1.0
         out = gae_scan(v_s, v_next, rew, terminated, truncated, cut_pos, gamma=cfg.gamma,
@@ -247,13 +248,16 @@ class PPOEngine:
     def preprocess(self, obs, obs_next, act, rew, terminated, truncated, cut_pos, d_n_cut=None, reduce_stats=None):
         """PPO._preprocess_batch (ppo.py:146-162) on batch-order device arrays."""
         obs, obs_next, act = self._f32(obs), self._f32(obs_next), self._f32(act)
-        v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated,
-                                                            truncated, cut_pos, d_n_cut, reduce_stats)
         if self.cfg.algo == "a2c":      # A2C._preprocess_batch (a2c.py:239-247): no logp_old
+            v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated,
+                                                                truncated, cut_pos, d_n_cut, reduce_stats)
             logp_old = torch.zeros_like(adv)
         else:
-            _, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=False,
-                                want_logp=True)
+            # V(s) and log pi_old(a | s) read the same observations: one launch with both networks resident (the
+            # parameters do not change between ppo.py:157 and :160, so the order of the two passes is immaterial)
+            v_s0, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=True, want_logp=True)
+            v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated, truncated, cut_pos,
+                                                                d_n_cut, reduce_stats, v_s=v_s0)
         return {"obs": obs, "obs_next": obs_next, "act": act, "rew": rew, "terminated": terminated,
                 "truncated": truncated, "cut_pos": cut_pos, "d_n_cut": d_n_cut,
                 "v_s": v_s, "returns": returns, "adv": adv, "logp_old": logp_old}
