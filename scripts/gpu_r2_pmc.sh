@@ -1,14 +1,14 @@
 #!/bin/bash
-# PMC passes over the PPO bench (step kernel focus) + single-wave-per-SIMD timing
+# SQ counters of the PPO step kernel, mean per launch (three separate --pmc passes); TS_PPO_STEP selects the kernel generation:
+#   TS_PPO_STEP=3 bash scripts/gpu_r2_pmc.sh   -> gpurun_out/pmc/pmc_step_mode3.txt
+M=${TS_PPO_STEP:-2}
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc; mkdir -p $O
-cd $GRAFT_REPO_ROOT
-TS_PPO_WG_PER_CU=1 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/b_v2_1wg.log 2>&1
-python scripts/gpu_step_phases.py > gpurun_out/phases_v2b.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VALU -d $O/p1 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/log1.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVE_CYCLES -d $O/p2 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/log2.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_IFETCH SQ_INSTS_VMEM SQ_WAVE_CYCLES -d $O/p3 -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/log3.txt 2>&1
+B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VALU -d $O/p1 -o t -- $B > $O/log1.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAVE_CYCLES -d $O/p2 -o t -- $B > $O/log2.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_IFETCH SQ_INSTS_VMEM SQ_WAVE_CYCLES -d $O/p3 -o t -- $B > $O/log3.txt 2>&1
 cd $GRAFT_REPO_ROOT
-python scripts/rocprof_pmc.py $O/p1/t_results.db $O/p2/t_results.db $O/p3/t_results.db --match ppo_step > $O/pmc_step.txt 2>&1
-find $O -name "*.db" | head; rm -rf $O/p1 $O/p2 $O/p3
-cat $O/pmc_step.txt
+python scripts/rocprof_pmc.py $O/p1/t_results.db $O/p2/t_results.db $O/p3/t_results.db --match ppo_step > $O/pmc_step_mode$M.txt 2>&1
+rm -rf $O/p1 $O/p2 $O/p3
+cat $O/pmc_step_mode$M.txt
