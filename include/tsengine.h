@@ -400,6 +400,13 @@ int ts_conv_forward(ts_workspace* ws, const void* x, int x_u8, const float* wb, 
  * input as produced by a ReLU, nullable) is given.  dx needs KH % stride == 0 and IC % 32 == 0. */
 int ts_conv_backward(ts_workspace* ws, const void* x, int x_u8, const float* wb, const float* dy, const float* mask,
                      float* d_wb, float* dx, const int64_t* h_dims, ts_stream_t stream);
+/* Kernel generation of the layers above and of every network entry point built on them.  Generation 2 (large row
+ * counts: minibatch 65,536 of the Atari-shape PPO update) keeps the weight block resident in LDS and feeds the
+ * activation operand straight from global memory into the MFMA registers; it sums in the same order as generation 1,
+ * so forward results and input gradients are bit-identical.  mode: -1 = generation 1 only, 0 = automatic by row count
+ * (default; the environment variable TS_CONV_V2 = 0 / 1 presets -1 / 1), 1 = generation 2 wherever the shape allows.
+ * Returns the previous mode.  Process-wide; not meant to be flipped while launches are being enqueued from other threads. */
+int ts_conv_set_generation(int mode);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN on NatureCNN (DQNet, tianshou/env/atari/atari_network.py:60-122)

@@ -68,6 +68,9 @@ struct ts_workspace {
     size_t ppo_image_bytes;
     const float* ppo_image_params;
     int ppo_image_key;
+    // transposed weight matrices of linear input-gradient passes (ts_conv2.hip), grown on demand
+    void* conv_scratch;
+    size_t conv_scratch_bytes;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;

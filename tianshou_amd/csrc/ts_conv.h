@@ -42,4 +42,19 @@ int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out
 struct SlabSeg { const float* slabs; int nslab; int64_t n; float* out; };
 int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg);
 
+
+// ---- second generation (ts_conv2.hip): large-M kernels, chosen inside conv_forward / conv_wgrad / conv_dgrad --------
+// (weight block resident in LDS, activation operand straight from global memory into MFMA registers; same k-sequential
+// summation as the first generation, so forward / dgrad results are bit-identical).  TS_CONV_V2=0 / 1 forces the choice.
+bool conv2_use_forward(const ConvGeom& g, bool x_u8);
+bool conv2_use_wgrad(const ConvGeom& g, bool x_u8);
+bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end);
+int conv2_wgrad_splits(const ConvGeom& g);
+int conv2_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
+                  ts_workspace* prof, bool x_u8);
+int conv2_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs, ts_workspace* prof,
+                bool x_u8);
+int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask, float* dX,
+                ts_workspace* ws);
+
 }  // namespace ts

@@ -442,6 +442,7 @@ bool small_rows(int M, int bn, int other_tiles) {
 namespace ts {
 
 int conv_fwd_splits(const ConvGeom& g) {
+    if (conv2_use_forward(g, false)) return 1;       // second generation never splits the reduction
     const int bn = g.OC % 64 == 0 ? 64 : 32, bm = bn == 64 ? 128 : 256;
     const int64_t tiles = ceil_div((int64_t)g.B * g.OH * g.OW, bm) * (g.OC / bn);
     const int chunks = g.K() / BK;
@@ -453,6 +454,7 @@ int conv_fwd_splits(const ConvGeom& g) {
 }
 
 int conv_wgrad_splits(const ConvGeom& g) {
+    if (conv2_use_wgrad(g, false)) return conv2_wgrad_splits(g);
     const int bn = g.OC % 64 == 0 ? 64 : 32;
     const int64_t tiles = ceil_div(g.K(), 128) * (g.OC / bn);
     const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, BK);
@@ -465,6 +467,7 @@ int conv_wgrad_splits(const ConvGeom& g) {
 int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
                  float* split_buf, ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
+    if (conv2_use_forward(g, x_u8)) return conv2_forward(s, g, X, Wb, Y, relu, prof, x_u8);
     GemmArgs a = base_args(g);
     a.a_u8 = x_u8;
     a.A = X; a.Bm = Wb; a.bias = Wb + (int64_t)a.K * g.OC; a.relu = relu;
@@ -501,6 +504,11 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
                ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
+    if (conv2_use_wgrad(g, false)) {
+        // (the split count is a function of the geometry alone: uint8 first layers have 32 channels, see conv2_use_wgrad)
+        if (conv2_use_wgrad(g, x_u8)) return conv2_wgrad(s, g, X, dY, slabs, prof, x_u8);
+        return ts::fail(TS_ERR_UNSUPPORTED, "conv_wgrad: uint8 input with %d output channels", g.OC);
+    }
     GemmArgs a = base_args(g);
     a.a_u8 = x_u8;
     a.A = X; a.Bm = dY; a.C = slabs;
@@ -526,6 +534,7 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
     TS_REQUIRE(g.KH % g.S == 0 && g.KW % g.S == 0, TS_ERR_INVALID_ARG,
                "conv_dgrad: kernel size must be a multiple of the stride");
     TS_REQUIRE(g.IC % 32 == 0, TS_ERR_INVALID_ARG, "conv_dgrad: input channels must be a multiple of 32");
+    if (conv2_use_dgrad(g, prof != nullptr, col_begin, col_end)) return conv2_dgrad(s, g, dY, Wb, mask, dX, prof);
     GemmArgs a = base_args(g);
     a.A = dY; a.Bm = Wb; a.C = dX; a.mask = mask;
     a.AH = (int)ceil_div(g.IH, g.S); a.AW = (int)ceil_div(g.IW, g.S);
@@ -627,7 +636,10 @@ int ts_conv_backward(ts_workspace* ws, const void* x, int x_u8, const float* wb,
     hipStream_t s = ts::as_stream(stream);
     if (int rc = ts::conv_wgrad(s, g, static_cast<const float*>(x), dy, slabs, nullptr, x_u8 != 0)) return rc;
     if (int rc = ts::slab_sum(s, slabs, ns, g.param_elems(), d_wb)) return rc;
-    if (dx) return ts::conv_dgrad(s, g, dy, wb, mask, dx);
+    if (dx) {
+        // conv_dgrad uses ws for event pairs and its own scratch allocation only (never ws->base, which holds the slabs)
+        return ts::conv_dgrad(s, g, dy, wb, mask, dx, ws);
+    }
     return TS_OK;
 }
 

@@ -1,0 +1,780 @@
+// ts_conv2.hip -- second generation of the fp32-MFMA implicit-GEMM layers for gfx950: the large-M regime
+// (minibatch 65,536 of the Atari-shape PPO update, examples/atari/atari_ppo.py:106-118 on
+// tianshou/env/atari/atari_network.py:60-122; autograd backward at algorithm_base.py:495).
+//
+// Same three GEMMs as ts_conv.hip, same operand order, same k-sequential summation (forward / dgrad are
+// bit-identical to the first-generation kernels), different data movement:
+//
+//   rows2 (forward, dgrad)   The weight operand of a column block lives in LDS for the whole lifetime of a
+//       persistent workgroup (conv1 32 KB, conv2 128 KB, conv3 144 KB; wider layers stream 32-deep slices through a
+//       double buffer).  The activation operand never touches LDS: lane (row r, half h) fetches 16 consecutive
+//       reduction elements of its row with 16-byte global loads (a 32-deep chunk of a row is one 128-byte line shared
+//       by the two halves) and eight v_permlane32_swap turn "lane half h holds k = 16h .. 16h+15" into the MFMA's
+//       "k-step j reads k = 2j + h", so the reduction stays in sequential k order.  No barrier in the K loop of the
+//       resident form; eight waves per workgroup drift freely over their own row tiles.
+//
+//   wgrad2   Both operands have the reduction index (output pixel) as their slow axis, so natural row-major copies
+//       of 32-pixel chunks are staged through a double-buffered LDS ring (one barrier per chunk, loads for chunk c+2
+//       in flight behind the MFMAs of chunk c); 2x2 / 3x1 register tiles per wave, four-wave workgroups, two per CU.
+//
+// Roofline: fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TF/s); DESIGN.md section 4.4.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "ts_common.h"
+#include "ts_conv.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+constexpr int CK = 32;      // reduction elements per chunk
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// n / d for n < 2^31 by multiplication: p = 32 + ceil(log2 d), magic = floor(2^p / d) + 1 (33 bits), q = (n * magic) >> p.
+// Exact because n * (magic * d - 2^p) <= n * d < 2^p.
+struct Divisor { unsigned long long magic; int shift; int d; };
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const Divisor& v) {
+    return (unsigned)(((unsigned long long)n * v.magic) >> v.shift);
+}
+Divisor divisor_of(int d) {
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    Divisor v;
+    v.shift = 32 + l;
+    v.magic = (unsigned long long)(((unsigned __int128)1 << v.shift) / (unsigned)d) + 1;
+    v.d = d;
+    return v;
+}
+
+// lanes 0-31 hold k = 0..15 of their row in x[0..15], lanes 32-63 hold k = 16..31:
+// afterwards x[2j] (j < 8) is the operand of k-step j and x[2j+1] of k-step 8 + j (lane half h = k parity).
+__device__ __forceinline__ void kseq_swap(float (&x)[16]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[2 * j]), __float_as_uint(x[2 * j + 1]), false, false);
+        x[2 * j] = __uint_as_float(r[0]);
+        x[2 * j + 1] = __uint_as_float(r[1]);
+    }
+}
+__device__ __forceinline__ constexpr int kstep_reg(int j) { return j < 8 ? 2 * j : 2 * (j - 8) + 1; }
+
+struct Rows2Args {
+    const void* A;            // forward: layer input (float32 / uint8 NHWC); dgrad: dY
+    const float* W;           // forward: Wb[K + 1][OC] (or a transposed copy for linear dgrad); dgrad: Wb
+    float* C;
+    const float* bias;        // forward: bias row (NULL: none)
+    const float* mask;        // dgrad: ReLU mask source (layer input) or NULL
+    ts::ConvGeom g;
+    int M;                    // rows: forward B*OH*OW, dgrad B*AH*AW (per stride-parity class)
+    int K;                    // reduction length: forward KH*KW*IC, dgrad JH*JW*OC
+    int N;                    // columns: forward OC, dgrad IC
+    int ldw;                  // row pitch of W in floats
+    int ldc;                  // forward: row pitch of C
+    int relu;
+    int AH, AW, JH, JW;
+    int tiles;                // workgroup row tiles
+    Divisor plane, wdt;       // / (OH*OW or AH*AW), / (OW or AW)
+};
+
+// ------------------------------------------------------------------------------------------------
+// rows = pixels.  DG: dgrad (gather form, one blockIdx.z per stride-parity class).  U8: uint8 layer input.
+// RES: the whole [K][BN] weight block is resident in LDS, otherwise 32-deep slices are double-buffered.
+// Eight waves as (8 / WN) x WN; a wave owns TM x TN tiles of 32 x 32.
+// ------------------------------------------------------------------------------------------------
+template <bool DG, bool U8, bool RES, int TM, int TN, int WN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, TN == 1 ? 4 : 2)))
+void conv_rows2_kernel(Rows2Args a) {
+    constexpr int WM = 8 / WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(!(DG && U8), "dgrad reads float32 gradients");
+    extern __shared__ __attribute__((aligned(16))) float Bs[];      // RES: [K][BN]; else [2][CK][BN]
+    const ts::ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int nchunks = a.K / CK;
+    int ph = 0, pw = 0;
+    if (DG) { ph = blockIdx.z / g.S; pw = blockIdx.z % g.S; }
+
+    // ---- weight block -> LDS (resident form) -------------------------------------------------------
+    if (RES) {
+        constexpr int UN = 8;                  // loads in flight per thread
+        if (!DG) {
+            const int row4 = BN / 4, total = a.K * row4;
+            for (int e0 = tid; e0 < total; e0 += 512 * UN) {
+                f32x4 v[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int e = min(e0 + 512 * u, total - 1);
+                    const int k = e / row4, n4 = e - k * row4;
+                    const int col = min(n0 + 4 * n4, a.N - 4);
+                    v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)k * a.ldw + col);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int e = e0 + 512 * u;
+                    if (e < total) *reinterpret_cast<f32x4*>(&Bs[4 * e]) = v[u];        // k * BN + 4 * n4 == 4 * e
+                }
+            }
+        } else {
+            // Bs[(j, oc)][ic] = Wb[(tap(j), n0 + ic)][oc]; consecutive threads take consecutive ic (conflict-free stores)
+            const int oc4n = g.OC / 4;
+            const int per_tap = BN * oc4n, total = a.JH * a.JW * per_tap;
+            for (int e0 = tid; e0 < total; e0 += 512 * UN) {
+                f32x4 v[UN];
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int e = min(e0 + 512 * u, total - 1);
+                    const int j = e / per_tap, rem = e - j * per_tap;
+                    const int oc4 = rem / BN, icl = rem - oc4 * BN;
+                    const int jh = j / a.JW, jw = j - jh * a.JW;
+                    const int tapk = ((ph + g.S * jh) * g.KW + pw + g.S * jw) * g.IC;
+                    v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(tapk + n0 + icl) * a.ldw + 4 * oc4);
+                }
+#pragma unroll
+                for (int u = 0; u < UN; ++u) {
+                    const int e = e0 + 512 * u;
+                    if (e < total) {
+                        const int j = e / per_tap, rem = e - j * per_tap;
+                        const int oc4 = rem / BN, icl = rem - oc4 * BN;
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) Bs[(j * g.OC + 4 * oc4 + x) * BN + icl] = v[u][x];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const int t_begin = (int)((int64_t)blockIdx.x * a.tiles / gridDim.x);
+    const int t_end = (int)((int64_t)(blockIdx.x + 1) * a.tiles / gridDim.x);
+    const int run = DG ? 0 : g.KW * g.IC, pitch = DG ? 0 : g.IW * g.IC;
+
+    // streamed form: a thread's share of one 32-deep weight slice
+    constexpr int BJ = RES ? 1 : (CK * BN / 4) / 512;
+    f32x4 breg[BJ];
+    auto gload_b = [&](int c) {
+        if (!RES) {
+#pragma unroll
+            for (int i = 0; i < BJ; ++i) {
+                const int e = tid + 512 * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+                const int col = min(n0 + 4 * n4, a.N - 4);
+                breg[i] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(c * CK + kk) * a.ldw + col);
+            }
+        }
+    };
+    auto lstore_b = [&](int slot) {
+        if (!RES) {
+#pragma unroll
+            for (int i = 0; i < BJ; ++i) {
+                const int e = tid + 512 * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+                *reinterpret_cast<f32x4*>(&Bs[(slot * CK + kk) * BN + 4 * n4]) = breg[i];
+            }
+        }
+    };
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int mrow0 = t * BM + wm * TM * 32;
+        // ---- this lane's rows ------------------------------------------------------------------------
+        int64_t abase[TM];
+        int ac[TM], obase[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m = mrow0 + tm * 32 + r;
+            const bool ok = m < a.M;
+            const unsigned mc = ok ? m : a.M - 1;
+            const unsigned b = fastdiv(mc, a.plane), rem = mc - b * a.plane.d;
+            const unsigned y = fastdiv(rem, a.wdt), x = rem - y * a.wdt.d;
+            if (!DG) {
+                abase[tm] = (int64_t)((b * g.IH + y * g.S) * g.IW + x * g.S) * g.IC + 16 * h;
+                ac[tm] = 0; obase[tm] = 0;
+            } else {
+                abase[tm] = (int64_t)((b * g.OH + y) * g.OW + x) * g.OC + 16 * h;
+                ac[tm] = (int)(y | (x << 16));
+                const int ih = y * g.S + ph, iw = x * g.S + pw;
+                obase[tm] = (ok && ih < g.IH && iw < g.IW) ? (int)(((b * g.IH + ih) * g.IW + iw) * g.IC) : -1;
+            }
+        }
+
+        float areg[2][TM][U8 ? 1 : 16];      // float32 input: the operands themselves
+        u32x4 araw[2][U8 ? TM : 1];          // uint8 input: 16 packed pixels per row, converted when consumed
+        bool aok[2][TM];                     // dgrad: the tap lies inside the output grid (applied when consumed)
+        auto load_a = [&](auto bufc, int c) {
+            constexpr int buf = decltype(bufc)::value;
+            const int k0 = c * CK;
+            if (!DG) {
+                const int kh = k0 / run;
+                const int koff = kh * pitch + (k0 - kh * run);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    if constexpr (U8) {
+                        araw[buf][tm] = *reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(a.A) + abase[tm] + koff);
+                    } else {
+                        const float* p = static_cast<const float*>(a.A) + abase[tm] + koff;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+                            areg[buf][tm][4 * i + 0] = v[0]; areg[buf][tm][4 * i + 1] = v[1];
+                            areg[buf][tm][4 * i + 2] = v[2]; areg[buf][tm][4 * i + 3] = v[3];
+                        }
+                    }
+                }
+            } else {
+                const int tp = k0 / g.OC, oc0 = k0 - tp * g.OC;
+                const int jh = tp / a.JW, jw = tp - jh * a.JW;
+                const int shift = (jh * g.OW + jw) * g.OC - oc0;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int oh = (ac[tm] & 0xffff) - jh, ow = (ac[tm] >> 16) - jw;
+                    const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
+                    const float* p = static_cast<const float*>(a.A) + (ok ? abase[tm] - shift : (int64_t)(16 * h));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
+                        areg[buf][tm][4 * i + 0] = v[0]; areg[buf][tm][4 * i + 1] = v[1];
+                        areg[buf][tm][4 * i + 2] = v[2]; areg[buf][tm][4 * i + 3] = v[3];
+                    }
+                    aok[buf][tm] = ok;
+                }
+            }
+        };
+
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
+
+        auto compute = [&](auto bufc, int c) {
+            constexpr int buf = decltype(bufc)::value;
+            float x[TM][16];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if constexpr (U8) {
+                    const u32x4 v = araw[buf][tm];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        x[tm][4 * i + 0] = (float)(v[i] & 0xffu);
+                        x[tm][4 * i + 1] = (float)((v[i] >> 8) & 0xffu);
+                        x[tm][4 * i + 2] = (float)((v[i] >> 16) & 0xffu);
+                        x[tm][4 * i + 3] = (float)(v[i] >> 24);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) x[tm][i] = (!DG || aok[buf][tm]) ? areg[buf][tm][i] : 0.f;
+                }
+                kseq_swap(x[tm]);
+            }
+            const float* bp = Bs + (RES ? c * CK : (c & 1) * CK) * BN + h * BN + (wn * TN) * 32 + r;
+            float bnext[TN];                       // operands of step j + 1 are fetched before the MFMAs of step j issue
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bnext[tn] = bp[tn * 32];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float bv[TN];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
+                if (j < 15) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) bnext[tn] = bp[2 * (j + 1) * BN + tn * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(x[tm][kstep_reg(j)], bv[tn], acc[tm][tn]);
+            }
+        };
+
+        constexpr std::integral_constant<int, 0> B0{};
+        constexpr std::integral_constant<int, 1> B1{};
+        // Two chunks per iteration with no branch inside (a conditional use would let the compiler sink the prefetch
+        // loads into it); an odd last chunk is peeled.  sched_barrier: the loads of the next chunk stay ahead of the MFMAs.
+        const int npair = nchunks & ~1;
+        if (RES) {
+            load_a(B0, 0);
+            for (int c = 0; c < npair; c += 2) {
+                load_a(B1, c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(B0, c);
+                load_a(B0, min(c + 2, nchunks - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                compute(B1, c + 1);
+            }
+            if (nchunks & 1) compute(B0, nchunks - 1);
+        } else {
+            gload_b(0);
+            load_a(B0, 0);
+            __syncthreads();                       // every wave is done with the previous tile's slices
+            lstore_b(0);
+            gload_b(min(1, nchunks - 1));
+            for (int c = 0; c < npair; c += 2) {
+                __syncthreads();                   // slice c visible; slot 1 free
+                lstore_b(1);
+                gload_b(min(c + 2, nchunks - 1));
+                load_a(B1, c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(B0, c);
+                __syncthreads();                   // slice c + 1 visible; slot 0 free
+                lstore_b(0);                       // (slice min(c + 2, last): harmless when there is no such slice)
+                gload_b(min(c + 3, nchunks - 1));
+                load_a(B0, min(c + 2, nchunks - 1));
+                __builtin_amdgcn_sched_barrier(0);
+                compute(B1, c + 1);
+            }
+            if (nchunks & 1) {
+                __syncthreads();
+                compute(B0, nchunks - 1);
+            }
+        }
+
+        // ---- epilogue (one wave-uniform branch on the mask: a branch per element would serialise the stores) ----
+        auto epilogue = [&](auto maskc) {
+            constexpr bool MASK = decltype(maskc)::value;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int col = n0 + (wn * TN + tn) * 32 + r;
+                    const bool col_ok = col < a.N;
+                    float bias = 0.f;
+                    if (!DG && a.bias) bias = a.bias[col_ok ? col : 0];
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) {
+                        const int row = (x & 3) + 8 * (x >> 2) + 4 * h;
+                        float v = acc[tm][tn][x];
+                        if (!DG) {
+                            const int m = mrow0 + tm * 32 + row;
+                            const bool ok = m < a.M && col_ok;
+                            const int64_t o = ok ? (int64_t)m * a.ldc + col : 0;
+                            v += bias;
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            if (MASK) v = a.mask[o] > 0.f ? v : 0.f;
+                            if (ok) a.C[o] = v;
+                        } else {
+                            const int ob = __shfl(obase[tm], row, 64);
+                            const bool ok = ob >= 0 && col_ok;
+                            const int o = ok ? ob + col : 0;
+                            if (MASK) v = a.mask[o] > 0.f ? v : 0.f;
+                            if (ok) a.C[o] = v;
+                        }
+                    }
+                }
+        };
+        if (a.mask) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad2: rows = k, columns = oc, reduction over output pixels m in chunks of 32 through a double-buffered LDS ring.
+// ------------------------------------------------------------------------------------------------
+struct Wgrad2Args {
+    const void* X;            // layer input (float32 / uint8 NHWC)
+    const float* dY;
+    float* slabs;
+    ts::ConvGeom g;
+    int M, K;
+    int chunks, total_chunks;
+    int64_t slab_stride;
+    Divisor plane, wdt;
+};
+
+template <bool U8, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a) {
+    constexpr int THREADS = WM * WN * 64, BKT = WM * TM * 32, BN = WN * TN * 32;
+    using xel = typename std::conditional<U8, uint8_t, float>::type;
+    constexpr int XPIECE = U8 ? 16 : 4;                       // elements per 16-byte piece
+    constexpr int XROW = BKT / XPIECE;                        // pieces per staged row
+    constexpr int XI = (CK * XROW + THREADS - 1) / THREADS;   // pieces per thread and chunk
+    constexpr int DROW = BN / 4, DI = (CK * DROW + THREADS - 1) / THREADS;
+    __shared__ __attribute__((aligned(16))) xel Xs[2][CK * BKT];
+    __shared__ __attribute__((aligned(16))) float Ds[2][CK * BN];
+    __shared__ int s_row[4][CK];             // im2col row offsets of chunks c .. c + 3 (slot = chunk & 3)
+    __shared__ float s_red[THREADS];
+    const ts::ConvGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
+    const int kt = blockIdx.x, n0 = blockIdx.y * BN, split = blockIdx.z;
+    const int run = g.KW * g.IC, pitch = g.IW * g.IC;
+
+    // this thread's pieces of a staged chunk: (row mm, piece q) -> element offset inside an im2col row
+    int xoff[XI], xmm[XI], xq[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int e = tid + THREADS * i;
+        xmm[i] = e / XROW; xq[i] = e - xmm[i] * XROW;
+        const int k = kt * BKT + XPIECE * xq[i];
+        const int kc = k < a.K ? k : 0;
+        const int kh = kc / run;
+        xoff[i] = kh * pitch + (kc - kh * run);
+    }
+    u32x4 xr[XI];
+    f32x4 dr[DI];
+
+    auto rowinfo = [&](int c) {
+        if (tid < CK) {
+            const unsigned m = min(c * CK + tid, a.M - 1);
+            const unsigned b = fastdiv(m, a.plane), rem = m - b * a.plane.d;
+            const unsigned oh = fastdiv(rem, a.wdt), ow = rem - oh * a.wdt.d;
+            s_row[c & 3][tid] = ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC;
+        }
+    };
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            if (CK * XROW % THREADS == 0 || xmm[i] < CK)
+                xr[i] = *reinterpret_cast<const u32x4*>(static_cast<const xel*>(a.X) + s_row[c & 3][min(xmm[i], CK - 1)] + xoff[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            const int e = tid + THREADS * i, mm = e / DROW, n4 = e - mm * DROW;
+            if (CK * DROW % THREADS == 0 || mm < CK) {
+                const int m = c * CK + mm;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + (int64_t)min(m, a.M - 1) * g.OC + n0 + 4 * n4);
+                dr[i] = m < a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto lstore = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i)
+            if (CK * XROW % THREADS == 0 || xmm[i] < CK)
+                *reinterpret_cast<u32x4*>(&Xs[slot][xmm[i] * BKT + XPIECE * xq[i]]) = xr[i];
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            const int e = tid + THREADS * i, mm = e / DROW, n4 = e - mm * DROW;
+            if (CK * DROW % THREADS == 0 || mm < CK) *reinterpret_cast<f32x4*>(&Ds[slot][mm * BN + 4 * n4]) = dr[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
+    float bsum = 0.f;
+    const int bn = tid % BN, bp = tid / BN;
+
+    const int c_begin = split * a.chunks;
+    const int c_end = min(a.total_chunks, c_begin + a.chunks);
+    const int c_last = c_end - 1;
+    if (c_begin < c_end) {
+        rowinfo(c_begin);
+        rowinfo(min(c_begin + 1, c_last));
+        rowinfo(min(c_begin + 2, c_last));
+        __syncthreads();
+        gload(c_begin);
+        lstore(c_begin & 1);
+        gload(min(c_begin + 1, c_last));
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();                           // slot c & 1 complete; slot (c + 1) & 1 no longer read by anyone;
+                                                   // row offsets of chunk c + 2 (written one iteration ago) visible
+        if (c + 1 < c_end) lstore((c + 1) & 1);
+        gload(min(c + 2, c_last));
+        if (c + 3 < c_end) rowinfo(c + 3);         // slot (c + 3) & 3 was last read for chunk c - 1, three barriers ago
+        const xel* xs = Xs[c & 1] + h * BKT + wm * TM * 32 + r;
+        const float* ds = Ds[c & 1] + h * BN + wn * TN * 32 + r;
+        xel anext[TM];                             // operands of step j + 1 are fetched before the MFMAs of step j issue
+        float bnext[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[tm * 32];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[tn * 32];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) av[tm] = (float)anext[tm];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
+            if (j < 15) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[2 * (j + 1) * BKT + tm * 32];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[2 * (j + 1) * BN + tn * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(av[tm], bv[tn], acc[tm][tn]);
+        }
+        if (kt == 0) {
+#pragma unroll
+            for (int mm = bp; mm < CK; mm += THREADS / BN) bsum += Ds[c & 1][mm * BN + bn];
+        }
+    }
+
+    float* out = a.slabs + split * a.slab_stride;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = n0 + (wn * TN + tn) * 32 + r;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int kr = kt * BKT + (wm * TM + tm) * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+                if (kr < a.K) out[(int64_t)kr * g.OC + col] = acc[tm][tn][x];
+            }
+        }
+    if (kt == 0) {
+        s_red[tid] = bsum;
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+#pragma unroll
+            for (int p = 0; p < THREADS / BN; ++p) s += s_red[p * BN + tid];
+            out[(int64_t)a.K * g.OC + n0 + tid] = s;
+        }
+    }
+}
+
+// out[c][r] = in[r][c]  (linear layers: dgrad is a forward pass with the transposed weight matrix)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(int64_t)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(int64_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+int num_cus() {
+    static int n = [] {
+        int dev = 0, v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess) v = p.multiProcessorCount;
+        }
+        return v;
+    }();
+    return n;
+}
+
+// mode: -1 never, 0 automatic, 1 whenever the shape allows it (ts_conv_set_generation / TS_CONV_V2)
+int& v2_mode_ref() {
+    static int m = [] {
+        const char* e = getenv("TS_CONV_V2");
+        if (!e) return 0;
+        return e[0] == '0' ? -1 : (e[0] == '1' ? 1 : 0);
+    }();
+    return m;
+}
+int v2_mode() { return v2_mode_ref(); }
+
+constexpr size_t LDS_MAX = 160 * 1024;
+constexpr int64_t ROWS2_MIN_M = 1 << 17;       // below this the first-generation kernels win (launch-bound layers)
+constexpr int64_t WGRAD2_MIN_M = 1 << 17;
+
+template <typename F>
+int launch_rows2(F kernel, dim3 grid, size_t lds, hipStream_t s, const Rows2Args& a) {
+    if (lds > 64 * 1024) {
+        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, a);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+bool shape_ok_rows(const ts::ConvGeom& g) {
+    return (g.KW * g.IC) % CK == 0 && g.K() % CK == 0 && g.OC % 32 == 0 && g.OH * g.OW < 65536 && g.OW < 65536 &&
+           g.IH * g.IW < 65536;
+}
+
+}  // namespace
+
+namespace ts {
+
+static bool is_linear(const ConvGeom& g) { return g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1; }
+
+bool conv2_use_forward(const ConvGeom& g, bool x_u8) {
+    const int mode = v2_mode();
+    if (mode < 0 || !shape_ok_rows(g)) return false;
+    if (x_u8 && g.OC != 32) return false;                               // uint8 frames: first layer only (32 channels)
+    return mode > 0 || (int64_t)g.B * g.OH * g.OW >= ROWS2_MIN_M;
+}
+
+bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end) {
+    const int mode = v2_mode();
+    if (mode < 0 || !shape_ok_rows(g) || g.IC % 32 != 0) return false;
+    if (g.KH % g.S != 0 || g.KW % g.S != 0) return false;
+    if (col_begin != 0 || (col_end >= 0 && col_end != g.IC)) return false;      // column ranges: first generation
+    if (is_linear(g)) {
+        if (!have_ws) return false;                                     // needs room for the transposed weights
+    } else {
+        if (g.IC > 64) return false;
+        const size_t lds = (size_t)(g.KH / g.S) * (g.KW / g.S) * g.OC * (g.IC % 64 == 0 ? 64 : 32) * 4;
+        if (lds > LDS_MAX) return false;
+    }
+    const int64_t m = (int64_t)g.B * ceil_div(g.IH, g.S) * ceil_div(g.IW, g.S);
+    return mode > 0 || m >= ROWS2_MIN_M;
+}
+
+bool conv2_use_wgrad(const ConvGeom& g, bool x_u8) {
+    const int mode = v2_mode();
+    if (mode < 0 || !shape_ok_rows(g)) return false;
+    if (x_u8 && g.OC != 32) return false;
+    return mode > 0 || (int64_t)g.B * g.OH * g.OW >= WGRAD2_MIN_M;
+}
+
+// tile plan of wgrad2 (rows of dW x columns per workgroup):
+//   0: 256 x 32, 4 waves (2x1 tiles)      1: 512 x 64, 8 waves (2x2)      2: 192 x 64, 4 waves (3x1, 2x2 waves)
+//   3: 256 x 64, 8 waves (2x1, 4x2 waves)
+static int wgrad2_plan(const ConvGeom& g, int* bkt, int* bn, int* per_cu) {
+    if (g.OC % 64 != 0) { *bkt = 256; *bn = 32; *per_cu = 2; return 0; }
+    static const char* force = getenv("TS_WGRAD2_PLAN");
+    const int k = g.K();
+    const int64_t w512 = ceil_div(k, 512) * 512, w192 = ceil_div(k, 192) * 192, w256 = ceil_div(k, 256) * 256;
+    int plan = (w512 <= w192 && w512 <= w256) ? 1 : (w192 <= w256 ? 2 : 3);
+    if (force && force[0] >= '1' && force[0] <= '3') plan = force[0] - '0';
+    *bn = 64;
+    if (plan == 1) { *bkt = 512; *per_cu = 1; }
+    else if (plan == 2) { *bkt = 192; *per_cu = 2; }
+    else { *bkt = 256; *per_cu = 1; }
+    return plan;
+}
+
+int conv2_wgrad_splits(const ConvGeom& g) {
+    int bkt, bn, per_cu;
+    wgrad2_plan(g, &bkt, &bn, &per_cu);
+    const int64_t tiles = ceil_div(g.K(), bkt) * (g.OC / bn);
+    const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, CK);
+    const int want = (int)std::max<int64_t>(1, (int64_t)per_cu * 256 / tiles);
+    int per = (int)ceil_div(chunks, want);
+    if (per < 8) per = 8;
+    return (int)ceil_div(chunks, per);
+}
+
+// Forward through the rows2 kernel.  `W` / `ldw` / `N` describe the weight matrix actually multiplied (the layer's own
+// Wb, or a transposed copy when a linear dgrad is expressed as a forward pass; `mask` is that pass's ReLU mask).
+static int rows2_forward(hipStream_t s, const ConvGeom& g, const void* X, bool x_u8, const float* W, int ldw, int N,
+                         const float* bias, const float* mask, float* Y, bool relu, ts_workspace* prof, int kind) {
+    Rows2Args a{};
+    a.A = X; a.W = W; a.C = Y; a.bias = bias; a.mask = mask; a.g = g;
+    a.M = g.B * g.OH * g.OW; a.K = g.K(); a.N = N; a.ldw = ldw; a.ldc = N; a.relu = relu;
+    a.plane = divisor_of(g.OH * g.OW); a.wdt = divisor_of(g.OW);
+    ProfScope scope(prof, kind, s);
+    const int cus = num_cus();
+    static const int res_max_nb = [] { const char* e = getenv("TS_CONV2_RES_MAX_NB"); return e ? atoi(e) : 8; }();
+    if (N == 32 && (size_t)a.K * 32 * 4 <= LDS_MAX) {
+        a.tiles = (int)ceil_div(a.M, 512);
+        const size_t lds = (size_t)a.K * 32 * 4;
+        const int wgs = (int)std::min<int64_t>(a.tiles, lds <= 40 * 1024 ? 2 * cus : cus);
+        if (x_u8) return launch_rows2(conv_rows2_kernel<false, true, true, 2, 1, 1>, dim3(wgs, 1, 1), lds, s, a);
+        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 1, 1>, dim3(wgs, 1, 1), lds, s, a);
+    }
+    TS_REQUIRE(!x_u8, TS_ERR_UNSUPPORTED, "conv rows2: uint8 input is instantiated for 32 output channels only");
+    if (N % 128 == 0 && (size_t)a.K * 128 * 4 <= LDS_MAX && N / 128 <= res_max_nb) {
+        a.tiles = (int)ceil_div(a.M, 256);
+        const int nb = N / 128;
+        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
+        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 2, 2>, dim3(wgs, nb, 1), (size_t)a.K * 128 * 4, s, a);
+    }
+    if (N % 64 == 0 && (size_t)a.K * 64 * 4 <= LDS_MAX && N / 64 <= res_max_nb) {
+        a.tiles = (int)ceil_div(a.M, 512);
+        const int nb = N / 64;
+        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
+        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 2, 1>, dim3(wgs, nb, 1), (size_t)a.K * 64 * 4, s, a);
+    }
+    // streamed weight slices, 256 x 128 workgroup tiles (ragged last column block allowed).  The column blocks of one
+    // row range run on different workgroups at the same pace, so the activation rows they share are fetched together.
+    TS_REQUIRE(N % 4 == 0 && N >= 4, TS_ERR_UNSUPPORTED, "conv rows2: unsupported streamed shape");
+    a.tiles = (int)ceil_div(a.M, 256);
+    const int nb = (int)ceil_div(N, 128);
+    const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
+    return launch_rows2(conv_rows2_kernel<false, false, false, 2, 2, 2>, dim3(wgs, nb, 1), (size_t)2 * CK * 128 * 4, s, a);
+}
+
+int conv2_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
+                  ts_workspace* prof, bool x_u8) {
+    return rows2_forward(s, g, X, x_u8, Wb, g.OC, g.OC, Wb + (int64_t)g.K() * g.OC, nullptr, Y, relu, prof, TS_KIND_CONV_FWD);
+}
+
+int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask, float* dX,
+                ts_workspace* ws) {
+    if (is_linear(g)) {
+        // dX[m, ic] = sum_oc dY[m, oc] Wt[oc, ic]: a forward pass over the transposed weights (no bias)
+        TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "conv2_dgrad: workspace (transposed weights) missing");
+        const size_t need = sizeof(float) * (size_t)g.IC * g.OC;
+        if (ws->conv_scratch_bytes < need) {
+            if (ws->conv_scratch) TS_HIP_CHECK(hipFree(ws->conv_scratch));
+            ws->conv_scratch = nullptr; ws->conv_scratch_bytes = 0;
+            TS_HIP_CHECK(hipMalloc(&ws->conv_scratch, need));
+            ws->conv_scratch_bytes = need;
+        }
+        float* wt = static_cast<float*>(ws->conv_scratch);
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(g.OC, 32), (unsigned)ceil_div(g.IC, 32)), dim3(256), 0, s,
+                           Wb, g.IC, g.OC, wt);
+        TS_LAUNCH_CHECK();
+        const ConvGeom t{g.B, 1, 1, g.OC, 1, 1, 1, 1, 1, g.IC};
+        return rows2_forward(s, t, dY, false, wt, g.IC, g.IC, nullptr, mask, dX, false, ws, TS_KIND_CONV_DGRAD);
+    }
+    Rows2Args a{};
+    a.A = dY; a.W = Wb; a.C = dX; a.mask = mask; a.g = g;
+    a.AH = (int)ceil_div(g.IH, g.S); a.AW = (int)ceil_div(g.IW, g.S);
+    a.JH = g.KH / g.S; a.JW = g.KW / g.S;
+    a.M = g.B * a.AH * a.AW; a.K = a.JH * a.JW * g.OC; a.N = g.IC; a.ldw = g.OC;
+    a.plane = divisor_of(a.AH * a.AW); a.wdt = divisor_of(a.AW);
+    ProfScope scope(ws, TS_KIND_CONV_DGRAD, s);
+    const int cus = num_cus(), classes = g.S * g.S;
+    a.tiles = (int)ceil_div(a.M, 512);
+    if (g.IC % 64 == 0) {
+        const size_t lds = (size_t)a.K * 64 * 4;
+        const int nb = g.IC / 64;
+        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / (nb * classes)));
+        return launch_rows2(conv_rows2_kernel<true, false, true, 2, 2, 1>, dim3(wgs, nb, classes), lds, s, a);
+    }
+    const size_t lds = (size_t)a.K * 32 * 4;
+    const int nb = g.IC / 32;
+    const int per_cu = lds <= 40 * 1024 ? 2 : 1;
+    const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, per_cu * cus / (nb * classes)));
+    return launch_rows2(conv_rows2_kernel<true, false, true, 2, 1, 1>, dim3(wgs, nb, classes), lds, s, a);
+}
+
+int conv2_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs, ts_workspace* prof,
+                bool x_u8) {
+    Wgrad2Args a{};
+    a.X = X; a.dY = dY; a.slabs = slabs; a.g = g;
+    a.M = g.B * g.OH * g.OW; a.K = g.K();
+    a.total_chunks = (int)ceil_div(a.M, CK);
+    const int nsplit = conv2_wgrad_splits(g);
+    a.chunks = (int)ceil_div(a.total_chunks, nsplit);
+    a.slab_stride = g.param_elems();
+    a.plane = divisor_of(g.OH * g.OW); a.wdt = divisor_of(g.OW);
+    int bkt, bn, per_cu;
+    const int plan = wgrad2_plan(g, &bkt, &bn, &per_cu);
+    dim3 grid((unsigned)ceil_div(a.K, bkt), g.OC / bn, nsplit);
+    ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
+    if (plan == 0) {
+        if (x_u8) hipLaunchKernelGGL((conv_wgrad2_kernel<true, 4, 1, 2, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 1, 2, 1>), grid, dim3(256), 0, s, a);
+    } else {
+        TS_REQUIRE(!x_u8, TS_ERR_UNSUPPORTED, "conv wgrad2: uint8 input is instantiated for 32 output channels only");
+        if (plan == 1) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 1, 2, 2>), grid, dim3(512), 0, s, a);
+        else if (plan == 2) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 2, 3, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 2, 2, 1>), grid, dim3(512), 0, s, a);
+    }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace ts
+
+extern "C" int ts_conv_set_generation(int mode) {
+    const int prev = v2_mode_ref();
+    v2_mode_ref() = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    return prev;
+}
