@@ -72,7 +72,8 @@ def check():
         e_w1 = float((w1.double() - gw).abs().max() / gw.abs().max())
         e_w2 = float((w2.double() - gw).abs().max() / gw.abs().max())
         e_d = float((dx2.double() - gx).abs().max() / gx.abs().max()) if dx2 is not None else float("nan")
-        ok = f_eq and d_eq and e_f < 5e-6 and e_w2 < max(2e-6, 3 * e_w1) and (dx2 is None or e_d < 5e-6)
+        # (bit equality holds only for the k-sequential variants, TS_R2_KSEQ=1, where generation 1 does not split K)
+        ok = e_f < 5e-6 and e_w2 < max(2e-6, 3 * e_w1) and (dx2 is None or e_d < 5e-6)
         bad += not ok
         print(f"{name:9s} fwd bit-equal {f_eq}  dgrad bit-equal {d_eq}  err64: fwd {e_f:.1e} wgrad v1 {e_w1:.1e} v2 {e_w2:.1e} "
               f"dgrad {e_d:.1e}  {'OK' if ok else 'FAIL'}", flush=True)
@@ -121,17 +122,55 @@ def bench(B):
             t_b = timeit(lambda: D.conv_backward(x, wb, dy, K, K, S, mask=x if can_dx else None, need_dx=can_dx), n)
             t_d = t_b - t_w if can_dx else 0.0
             tot[g][0] += t_f; tot[g][1] += t_w; tot[g][2] += t_d
-            line += f" v{1 if g < 0 else 2}: fwd {t_f:8.1f}us {gf / t_f * 1e-3:6.1f}TF  wgrad {t_w:8.1f}us {gf / t_w * 1e-3:6.1f}TF"
-            line += f"  dgrad {t_d:8.1f}us {gf / t_d * 1e-3:6.1f}TF |" if can_dx else "  dgrad      -- |"
+            line += f" v{1 if g < 0 else 2}: fwd {t_f:8.1f}us {gf / t_f * 1e3:6.1f}TF  wgrad {t_w:8.1f}us {gf / t_w * 1e3:6.1f}TF"
+            line += f"  dgrad {t_d:8.1f}us {gf / t_d * 1e3:6.1f}TF |" if can_dx else "  dgrad      -- |"
         flop[0] += gf; flop[1] += gf; flop[2] += gf if can_dx else 0.0
         print(line, flush=True)
         del x, dy
         torch.cuda.empty_cache()
     for g in (-1, 1):
         t = tot[g]
-        print(f"B={B} total v{1 if g < 0 else 2}: fwd {t[0] / 1e3:.2f} ms ({flop[0] / t[0] * 1e-3:.1f} TF)  wgrad {t[1] / 1e3:.2f} ms "
-              f"({flop[1] / t[1] * 1e-3:.1f} TF)  dgrad {t[2] / 1e3:.2f} ms ({flop[2] / t[2] * 1e-3:.1f} TF)  "
-              f"all {sum(t) / 1e3:.2f} ms = {sum(flop) / sum(t) * 1e-3:.1f} TF/s = {sum(flop) / sum(t) * 1e-3 / 157.3:.3f} of peak")
+        print(f"B={B} total v{1 if g < 0 else 2}: fwd {t[0] / 1e3:.2f} ms ({flop[0] / t[0] * 1e3:.1f} TF)  wgrad {t[1] / 1e3:.2f} ms "
+              f"({flop[1] / t[1] * 1e3:.1f} TF)  dgrad {t[2] / 1e3:.2f} ms ({flop[2] / t[2] * 1e3:.1f} TF)  "
+              f"all {sum(t) / 1e3:.2f} ms = {sum(flop) / sum(t) * 1e3:.1f} TF/s = {sum(flop) / sum(t) * 1e3 / 157.3:.3f} of peak")
+    gen(0)
+
+
+def sweep(B):
+    """rows2 variants (waves per workgroup, row tiles per wave, k order) per layer, forward and input gradient."""
+    layers = [("conv1u8", 84, 84, 4, 8, 4, 32, True), ("conv2", 20, 20, 32, 4, 2, 64, False),
+              ("conv3", 9, 9, 64, 3, 1, 64, False), ("fc1", 1, 1, 3136, 1, 1, 512, False)]
+    gen(1)
+    for name, IH, IW, IC, K, S, OC, u8 in layers:
+        if u8:
+            x = torch.randint(0, 256, (B, IH, IW, IC), device="cuda", dtype=torch.uint8)
+        else:
+            x = torch.randn(B, IH, IW, IC, device="cuda").clamp_(min=0)
+        wb = torch.randn(K * K * IC + 1, OC, device="cuda") * 0.05
+        oh, ow = (IH - K) // S + 1, (IW - K) // S + 1
+        gf = 2.0 * B * oh * ow * OC * K * K * IC / 1e9
+        dy = torch.randn(B, oh, ow, OC, device="cuda")
+        can_dx = IC % 32 == 0
+        t_w = timeit(lambda: D.conv_backward(x, wb, dy, K, K, S, need_dx=False), 5)
+        for waves, tm in ((8, 2), (16, 1), (16, 2)):
+            for kseq in (0,):
+                os.environ["TS_R2_WAVES"], os.environ["TS_R2_TM"], os.environ["TS_R2_KSEQ"] = str(waves), str(tm), str(kseq)
+                t_f = t_d = float("nan")
+                try:
+                    t_f = timeit(lambda: D.conv_forward(x, wb, K, K, S, True), 5)
+                except Exception:  # variant not instantiated for this shape
+                    pass
+                try:
+                    if can_dx:
+                        t_d = timeit(lambda: D.conv_backward(x, wb, dy, K, K, S, mask=x, need_dx=True), 5) - t_w
+                except Exception:
+                    pass
+                print(f"B={B} {name:8s} waves {waves:2d} tm {tm} kseq {kseq}: fwd {t_f:8.1f}us {gf / t_f * 1e3:6.1f}TF  "
+                      f"dgrad {t_d:8.1f}us {gf / t_d * 1e3:6.1f}TF", flush=True)
+        for k in ("TS_R2_WAVES", "TS_R2_TM", "TS_R2_KSEQ"):
+            os.environ.pop(k, None)
+        del x, dy
+        torch.cuda.empty_cache()
     gen(0)
 
 
@@ -140,6 +179,9 @@ if __name__ == "__main__":
     rc = 0
     if what in ("check", "all"):
         rc = check()
+    if what == "sweep":
+        for b in ([int(a) for a in sys.argv[2:]] or [65536]):
+            sweep(b)
     if what in ("bench", "all"):
         for b in ([int(a) for a in sys.argv[2:]] or [65536, 4096, 512]):
             bench(b)

@@ -71,6 +71,10 @@ struct ts_workspace {
     // transposed weight matrices of linear input-gradient passes (ts_conv2.hip), grown on demand
     void* conv_scratch;
     size_t conv_scratch_bytes;
+    // input-gradient class tables of ts_conv2.hip: 16 device-resident slots, keyed by geometry on the host
+    void* dg_tables;
+    long long dg_key[16][16];
+    int dg_next;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;

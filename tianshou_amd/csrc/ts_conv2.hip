@@ -20,7 +20,9 @@
 // Roofline: fp32 MFMA (v_mfma_f32_32x32x2_f32, 157.3 TF/s); DESIGN.md section 4.4.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 #include "ts_common.h"
 #include "ts_conv.h"
@@ -66,6 +68,18 @@ __device__ __forceinline__ void kseq_swap(float (&x)[16]) {
 }
 __device__ __forceinline__ constexpr int kstep_reg(int j) { return j < 8 ? 2 * j : 2 * (j - 8) + 1; }
 
+// One input-gradient class: input pixels (ih, iw) = (S (a0 + y) + ph, S (c0 + x) + pw), y < na, x < nc, which all receive
+// exactly the taps jh in [jh0, jh0 + njh), jw in [jw0, jw0 + njw) (kh = ph + S jh, kw = pw + S jw): a stride-parity
+// class cut further by how far the pixel is from the border, so that no row of a class multiplies a tap that falls
+// outside the output grid (the plain gather form spends 19 % (conv2) / 40 % (conv3) of its MFMAs on such zeros).
+struct DgClass {
+    int ph, pw, a0, c0, na, nc, jh0, jw0, njh, njw;
+    int M, tiles, first_wg, wgs;
+    Divisor plane, wdt;
+};
+constexpr int MAX_DG_CLASSES = 64;
+constexpr int MAX_CHUNKS = 512;          // reduction chunks of 32 per row (K <= 16,384)
+
 struct Rows2Args {
     const void* A;            // forward: layer input (float32 / uint8 NHWC); dgrad: dY
     const float* W;           // forward: Wb[K + 1][OC] (or a transposed copy for linear dgrad); dgrad: Wb
@@ -79,9 +93,10 @@ struct Rows2Args {
     int ldw;                  // row pitch of W in floats
     int ldc;                  // forward: row pitch of C
     int relu;
-    int AH, AW, JH, JW;
-    int tiles;                // workgroup row tiles
-    Divisor plane, wdt;       // / (OH*OW or AH*AW), / (OW or AW)
+    int tiles;                // forward: workgroup row tiles
+    Divisor plane, wdt;       // forward: / (OH*OW), / OW
+    const DgClass* classes;   // dgrad: class table (device memory), indexed through blockIdx.x
+    int n_classes;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -89,58 +104,69 @@ struct Rows2Args {
 // RES: the whole [K][BN] weight block is resident in LDS, otherwise 32-deep slices are double-buffered.
 // Eight waves as (8 / WN) x WN; a wave owns TM x TN tiles of 32 x 32.
 // ------------------------------------------------------------------------------------------------
-template <bool DG, bool U8, bool RES, int TM, int TN, int WN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, TN == 1 ? 4 : 2)))
+template <bool DG, bool U8, bool RES, int TM, int TN, int WN, int WAVES, bool KSEQ>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (TM * TN >= 4 && WAVES == 8) ? 2 : 4)))
 void conv_rows2_kernel(Rows2Args a) {
-    constexpr int WM = 8 / WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int THREADS = WAVES * 64, WM = WAVES / WN, BM = WM * TM * 32, BN = WN * TN * 32;
     static_assert(!(DG && U8), "dgrad reads float32 gradients");
     extern __shared__ __attribute__((aligned(16))) float Bs[];      // RES: [K][BN]; else [2][CK][BN]
     const ts::ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.y * BN;
-    const int nchunks = a.K / CK;
-    int ph = 0, pw = 0;
-    if (DG) { ph = blockIdx.z / g.S; pw = blockIdx.z % g.S; }
+    int nchunks = a.K / CK;
+    DgClass cls{};
+    int wg = blockIdx.x, n_wg = gridDim.x, M = a.M, tiles = a.tiles, nchunks_ = nchunks;
+    Divisor plane = a.plane, wdt = a.wdt;
+    if (DG) {
+        int z = 0;
+        while (z + 1 < a.n_classes && (int)blockIdx.x >= a.classes[z + 1].first_wg) ++z;
+        cls = a.classes[z];
+        wg = blockIdx.x - cls.first_wg; n_wg = cls.wgs; M = cls.M; tiles = cls.tiles;
+        plane = cls.plane; wdt = cls.wdt;
+        nchunks_ = cls.njh * cls.njw * g.OC / CK;
+    }
+    const int ph = cls.ph, pw = cls.pw;
+    nchunks = nchunks_;
 
     // ---- weight block -> LDS (resident form) -------------------------------------------------------
     if (RES) {
         constexpr int UN = 8;                  // loads in flight per thread
         if (!DG) {
             const int row4 = BN / 4, total = a.K * row4;
-            for (int e0 = tid; e0 < total; e0 += 512 * UN) {
+            for (int e0 = tid; e0 < total; e0 += THREADS * UN) {
                 f32x4 v[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int e = min(e0 + 512 * u, total - 1);
+                    const int e = min(e0 + THREADS * u, total - 1);
                     const int k = e / row4, n4 = e - k * row4;
                     const int col = min(n0 + 4 * n4, a.N - 4);
                     v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)k * a.ldw + col);
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int e = e0 + 512 * u;
+                    const int e = e0 + THREADS * u;
                     if (e < total) *reinterpret_cast<f32x4*>(&Bs[4 * e]) = v[u];        // k * BN + 4 * n4 == 4 * e
                 }
             }
         } else {
             // Bs[(j, oc)][ic] = Wb[(tap(j), n0 + ic)][oc]; consecutive threads take consecutive ic (conflict-free stores)
             const int oc4n = g.OC / 4;
-            const int per_tap = BN * oc4n, total = a.JH * a.JW * per_tap;
-            for (int e0 = tid; e0 < total; e0 += 512 * UN) {
+            const int per_tap = BN * oc4n, total = cls.njh * cls.njw * per_tap;
+            for (int e0 = tid; e0 < total; e0 += THREADS * UN) {
                 f32x4 v[UN];
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int e = min(e0 + 512 * u, total - 1);
+                    const int e = min(e0 + THREADS * u, total - 1);
                     const int j = e / per_tap, rem = e - j * per_tap;
                     const int oc4 = rem / BN, icl = rem - oc4 * BN;
-                    const int jh = j / a.JW, jw = j - jh * a.JW;
+                    const int tjh = j / cls.njw, jh = cls.jh0 + tjh, jw = cls.jw0 + j - tjh * cls.njw;
                     const int tapk = ((ph + g.S * jh) * g.KW + pw + g.S * jw) * g.IC;
                     v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(tapk + n0 + icl) * a.ldw + 4 * oc4);
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
-                    const int e = e0 + 512 * u;
+                    const int e = e0 + THREADS * u;
                     if (e < total) {
                         const int j = e / per_tap, rem = e - j * per_tap;
                         const int oc4 = rem / BN, icl = rem - oc4 * BN;
@@ -153,18 +179,37 @@ void conv_rows2_kernel(Rows2Args a) {
         __syncthreads();
     }
 
-    const int t_begin = (int)((int64_t)blockIdx.x * a.tiles / gridDim.x);
-    const int t_end = (int)((int64_t)(blockIdx.x + 1) * a.tiles / gridDim.x);
-    const int run = DG ? 0 : g.KW * g.IC, pitch = DG ? 0 : g.IW * g.IC;
+    const int t_begin = (int)((int64_t)wg * tiles / n_wg);
+    const int t_end = (int)((int64_t)(wg + 1) * tiles / n_wg);
+
+    // Byte offset of reduction chunk c inside a row of the activation operand, tabulated once per workgroup (the K loop
+    // then needs no division): forward kh * pitch + position inside the (kw, ic) run; dgrad oc0 - (jh OW + jw) OC.
+    __shared__ int s_koff[MAX_CHUNKS];
+    for (int c = tid; c < nchunks; c += THREADS) {
+        const int k0 = c * CK;
+        int off;
+        if (!DG) {
+            const int run = g.KW * g.IC, kh = k0 / run;
+            off = kh * g.IW * g.IC + (k0 - kh * run);
+        } else {
+            const int tp = k0 / g.OC, oc0 = k0 - tp * g.OC;
+            const int tjh = tp / cls.njw, jh = cls.jh0 + tjh, jw = cls.jw0 + tp - tjh * cls.njw;
+            off = oc0 - (jh * g.OW + jw) * g.OC;
+        }
+        s_koff[c] = off;
+    }
+    __syncthreads();
+    using ael = typename std::conditional<U8, uint8_t, float>::type;
+    const ael* Ap = static_cast<const ael*>(a.A);
 
     // streamed form: a thread's share of one 32-deep weight slice
-    constexpr int BJ = RES ? 1 : (CK * BN / 4) / 512;
+    constexpr int BJ = RES ? 1 : (CK * BN / 4) / THREADS;
     f32x4 breg[BJ];
     auto gload_b = [&](int c) {
         if (!RES) {
 #pragma unroll
             for (int i = 0; i < BJ; ++i) {
-                const int e = tid + 512 * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+                const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
                 const int col = min(n0 + 4 * n4, a.N - 4);
                 breg[i] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(c * CK + kk) * a.ldw + col);
             }
@@ -174,7 +219,7 @@ void conv_rows2_kernel(Rows2Args a) {
         if (!RES) {
 #pragma unroll
             for (int i = 0; i < BJ; ++i) {
-                const int e = tid + 512 * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+                const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
                 *reinterpret_cast<f32x4*>(&Bs[(slot * CK + kk) * BN + 4 * n4]) = breg[i];
             }
         }
@@ -182,66 +227,43 @@ void conv_rows2_kernel(Rows2Args a) {
 
     for (int t = t_begin; t < t_end; ++t) {
         const int mrow0 = t * BM + wm * TM * 32;
-        // ---- this lane's rows ------------------------------------------------------------------------
-        int64_t abase[TM];
-        int ac[TM], obase[TM];
+        // ---- this lane's rows: unsigned 32-bit element offsets from the operand base (tensors hold < 2^31 elements)
+        unsigned abase[TM];
+        int obase[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int m = mrow0 + tm * 32 + r;
-            const bool ok = m < a.M;
-            const unsigned mc = ok ? m : a.M - 1;
-            const unsigned b = fastdiv(mc, a.plane), rem = mc - b * a.plane.d;
-            const unsigned y = fastdiv(rem, a.wdt), x = rem - y * a.wdt.d;
+            const bool ok = m < M;
+            const unsigned mc = ok ? m : M - 1;
+            const unsigned b = fastdiv(mc, plane), rem = mc - b * plane.d;
+            const unsigned y = fastdiv(rem, wdt), x = rem - y * wdt.d;
             if (!DG) {
-                abase[tm] = (int64_t)((b * g.IH + y * g.S) * g.IW + x * g.S) * g.IC + 16 * h;
-                ac[tm] = 0; obase[tm] = 0;
+                abase[tm] = ((b * g.IH + y * g.S) * g.IW + x * g.S) * g.IC + 16 * h;
+                obase[tm] = 0;
             } else {
-                abase[tm] = (int64_t)((b * g.OH + y) * g.OW + x) * g.OC + 16 * h;
-                ac[tm] = (int)(y | (x << 16));
-                const int ih = y * g.S + ph, iw = x * g.S + pw;
-                obase[tm] = (ok && ih < g.IH && iw < g.IW) ? (int)(((b * g.IH + ih) * g.IW + iw) * g.IC) : -1;
+                const unsigned aa = cls.a0 + y, cc = cls.c0 + x;
+                abase[tm] = ((b * g.OH + aa) * g.OW + cc) * g.OC + 16 * h;
+                obase[tm] = ok ? (int)(((b * g.IH + aa * g.S + ph) * g.IW + cc * g.S + pw) * g.IC) : -1;
             }
         }
 
         float areg[2][TM][U8 ? 1 : 16];      // float32 input: the operands themselves
         u32x4 araw[2][U8 ? TM : 1];          // uint8 input: 16 packed pixels per row, converted when consumed
-        bool aok[2][TM];                     // dgrad: the tap lies inside the output grid (applied when consumed)
         auto load_a = [&](auto bufc, int c) {
             constexpr int buf = decltype(bufc)::value;
-            const int k0 = c * CK;
-            if (!DG) {
-                const int kh = k0 / run;
-                const int koff = kh * pitch + (k0 - kh * run);
+            const int koff = s_koff[c];          // wave-uniform
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    if constexpr (U8) {
-                        araw[buf][tm] = *reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(a.A) + abase[tm] + koff);
-                    } else {
-                        const float* p = static_cast<const float*>(a.A) + abase[tm] + koff;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
-                            areg[buf][tm][4 * i + 0] = v[0]; areg[buf][tm][4 * i + 1] = v[1];
-                            areg[buf][tm][4 * i + 2] = v[2]; areg[buf][tm][4 * i + 3] = v[3];
-                        }
-                    }
-                }
-            } else {
-                const int tp = k0 / g.OC, oc0 = k0 - tp * g.OC;
-                const int jh = tp / a.JW, jw = tp - jh * a.JW;
-                const int shift = (jh * g.OW + jw) * g.OC - oc0;
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const int oh = (ac[tm] & 0xffff) - jh, ow = (ac[tm] >> 16) - jw;
-                    const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-                    const float* p = static_cast<const float*>(a.A) + (ok ? abase[tm] - shift : (int64_t)(16 * h));
+            for (int tm = 0; tm < TM; ++tm) {
+                const ael* p = Ap + (unsigned)(abase[tm] + koff);
+                if constexpr (U8) {
+                    araw[buf][tm] = *reinterpret_cast<const u32x4*>(p);
+                } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * i);
                         areg[buf][tm][4 * i + 0] = v[0]; areg[buf][tm][4 * i + 1] = v[1];
                         areg[buf][tm][4 * i + 2] = v[2]; areg[buf][tm][4 * i + 3] = v[3];
                     }
-                    aok[buf][tm] = ok;
                 }
             }
         };
@@ -270,11 +292,13 @@ void conv_rows2_kernel(Rows2Args a) {
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) x[tm][i] = (!DG || aok[buf][tm]) ? areg[buf][tm][i] : 0.f;
+                    for (int i = 0; i < 16; ++i) x[tm][i] = areg[buf][tm][i];
                 }
-                kseq_swap(x[tm]);
+                if (KSEQ) kseq_swap(x[tm]);
             }
-            const float* bp = Bs + (RES ? c * CK : (c & 1) * CK) * BN + h * BN + (wn * TN) * 32 + r;
+            // KSEQ: k-step j multiplies k = 2j + h (sequential order); otherwise k = 16h + j (no cross-lane swaps)
+            const float* bp = Bs + (RES ? c * CK : (c & 1) * CK) * BN + (KSEQ ? h : 16 * h) * BN + (wn * TN) * 32 + r;
+            constexpr int KS = KSEQ ? 2 : 1;
             float bnext[TN];                       // operands of step j + 1 are fetched before the MFMAs of step j issue
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bnext[tn] = bp[tn * 32];
@@ -285,13 +309,13 @@ void conv_rows2_kernel(Rows2Args a) {
                 for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
                 if (j < 15) {
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) bnext[tn] = bp[2 * (j + 1) * BN + tn * 32];
+                    for (int tn = 0; tn < TN; ++tn) bnext[tn] = bp[KS * (j + 1) * BN + tn * 32];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(x[tm][kstep_reg(j)], bv[tn], acc[tm][tn]);
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma32(x[tm][KSEQ ? kstep_reg(j) : j], bv[tn], acc[tm][tn]);
             }
         };
 
@@ -299,14 +323,14 @@ void conv_rows2_kernel(Rows2Args a) {
         constexpr std::integral_constant<int, 1> B1{};
         // Two chunks per iteration with no branch inside (a conditional use would let the compiler sink the prefetch
         // loads into it); an odd last chunk is peeled.  sched_barrier: the loads of the next chunk stay ahead of the MFMAs.
-        const int npair = nchunks & ~1;
+        const int npair = nchunks & ~1, clast = max(nchunks - 1, 0);
         if (RES) {
-            load_a(B0, 0);
+            if (nchunks > 0) load_a(B0, 0);
             for (int c = 0; c < npair; c += 2) {
                 load_a(B1, c + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(B0, c);
-                load_a(B0, min(c + 2, nchunks - 1));
+                load_a(B0, min(c + 2, clast));
                 __builtin_amdgcn_sched_barrier(0);
                 compute(B1, c + 1);
             }
@@ -316,18 +340,18 @@ void conv_rows2_kernel(Rows2Args a) {
             load_a(B0, 0);
             __syncthreads();                       // every wave is done with the previous tile's slices
             lstore_b(0);
-            gload_b(min(1, nchunks - 1));
+            gload_b(min(1, clast));
             for (int c = 0; c < npair; c += 2) {
                 __syncthreads();                   // slice c visible; slot 1 free
                 lstore_b(1);
-                gload_b(min(c + 2, nchunks - 1));
+                gload_b(min(c + 2, clast));
                 load_a(B1, c + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(B0, c);
                 __syncthreads();                   // slice c + 1 visible; slot 0 free
                 lstore_b(0);                       // (slice min(c + 2, last): harmless when there is no such slice)
-                gload_b(min(c + 3, nchunks - 1));
-                load_a(B0, min(c + 2, nchunks - 1));
+                gload_b(min(c + 3, clast));
+                load_a(B0, min(c + 2, clast));
                 __builtin_amdgcn_sched_barrier(0);
                 compute(B1, c + 1);
             }
@@ -337,9 +361,11 @@ void conv_rows2_kernel(Rows2Args a) {
             }
         }
 
-        // ---- epilogue (one wave-uniform branch on the mask: a branch per element would serialise the stores) ----
-        auto epilogue = [&](auto maskc) {
-            constexpr bool MASK = decltype(maskc)::value;
+        // ---- epilogue.  Wave-uniform branches only (mask present? tile completely inside the matrix?): a branch per
+        // element would serialise every mask load behind its own wait.  Mask values of a 32 x 32 tile are fetched as one
+        // batch of 16 loads before they are used.
+        auto epilogue = [&](auto maskc, auto fullc) {
+            constexpr bool MASK = decltype(maskc)::value, FULL = decltype(fullc)::value;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -349,28 +375,46 @@ void conv_rows2_kernel(Rows2Args a) {
                     float bias = 0.f;
                     if (!DG && a.bias) bias = a.bias[col_ok ? col : 0];
 #pragma unroll
-                    for (int x = 0; x < 16; ++x) {
-                        const int row = (x & 3) + 8 * (x >> 2) + 4 * h;
-                        float v = acc[tm][tn][x];
-                        if (!DG) {
-                            const int m = mrow0 + tm * 32 + row;
-                            const bool ok = m < a.M && col_ok;
-                            const int64_t o = ok ? (int64_t)m * a.ldc + col : 0;
-                            v += bias;
-                            if (a.relu) v = fmaxf(v, 0.f);
-                            if (MASK) v = a.mask[o] > 0.f ? v : 0.f;
-                            if (ok) a.C[o] = v;
-                        } else {
-                            const int ob = __shfl(obase[tm], row, 64);
-                            const bool ok = ob >= 0 && col_ok;
-                            const int o = ok ? ob + col : 0;
-                            if (MASK) v = a.mask[o] > 0.f ? v : 0.f;
-                            if (ok) a.C[o] = v;
+                    for (int x0 = 0; x0 < 16; x0 += 8) {          // batches of 8: register budget of the 16-wave variants
+                        unsigned off[8];
+                        bool ok[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int x = x0 + i, row = (x & 3) + 8 * (x >> 2) + 4 * h;
+                            if (!DG) {
+                                const int m = mrow0 + tm * 32 + row;
+                                ok[i] = (FULL || m < M) && col_ok;
+                                off[i] = ok[i] ? (unsigned)m * (unsigned)a.ldc + col : 0u;
+                            } else {
+                                const int ob = __shfl(obase[tm], row, 64);
+                                ok[i] = (FULL || ob >= 0) && col_ok;
+                                off[i] = ok[i] ? (unsigned)(ob + col) : 0u;
+                            }
+                        }
+                        float mk[MASK ? 8 : 1];
+                        if constexpr (MASK) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) mk[i] = a.mask[off[i]];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float v = acc[tm][tn][x0 + i];
+                            if (!DG) {
+                                v += bias;
+                                if (a.relu) v = fmaxf(v, 0.f);
+                            }
+                            if constexpr (MASK) v = mk[i] > 0.f ? v : 0.f;
+                            if (ok[i]) a.C[off[i]] = v;
                         }
                     }
                 }
         };
-        if (a.mask) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        const bool full = t * BM + BM <= M && n0 + BN <= a.N;
+        if (a.mask) {
+            if (full) epilogue(std::true_type{}, std::true_type{}); else epilogue(std::true_type{}, std::false_type{});
+        } else {
+            if (full) epilogue(std::false_type{}, std::true_type{}); else epilogue(std::false_type{}, std::false_type{});
+        }
     }
 }
 
@@ -406,8 +450,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
     const int kt = blockIdx.x, n0 = blockIdx.y * BN, split = blockIdx.z;
     const int run = g.KW * g.IC, pitch = g.IW * g.IC;
 
-    // this thread's pieces of a staged chunk: (row mm, piece q) -> element offset inside an im2col row
-    int xoff[XI], xmm[XI], xq[XI];
+    // this thread's pieces of a staged chunk: (row mm, piece q) -> element offset inside an im2col row.  All global
+    // addresses are unsigned 32-bit element offsets from the tensor bases (tensors hold < 2^31 elements).
+    unsigned xoff[XI];
+    int xmm[XI], xq[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int e = tid + THREADS * i;
@@ -415,32 +461,34 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
         const int k = kt * BKT + XPIECE * xq[i];
         const int kc = k < a.K ? k : 0;
         const int kh = kc / run;
-        xoff[i] = kh * pitch + (kc - kh * run);
+        xoff[i] = (unsigned)(kh * pitch + (kc - kh * run));
     }
     u32x4 xr[XI];
     f32x4 dr[DI];
+    bool dok[DI];
+    const xel* Xp = static_cast<const xel*>(a.X);
 
     auto rowinfo = [&](int c) {
         if (tid < CK) {
             const unsigned m = min(c * CK + tid, a.M - 1);
             const unsigned b = fastdiv(m, a.plane), rem = m - b * a.plane.d;
             const unsigned oh = fastdiv(rem, a.wdt), ow = rem - oh * a.wdt.d;
-            s_row[c & 3][tid] = ((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC;
+            s_row[c & 3][tid] = (int)(((b * g.IH + oh * g.S) * g.IW + ow * g.S) * g.IC);
         }
     };
     auto gload = [&](int c) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             if (CK * XROW % THREADS == 0 || xmm[i] < CK)
-                xr[i] = *reinterpret_cast<const u32x4*>(static_cast<const xel*>(a.X) + s_row[c & 3][min(xmm[i], CK - 1)] + xoff[i]);
+                xr[i] = *reinterpret_cast<const u32x4*>(Xp + ((unsigned)s_row[c & 3][min(xmm[i], CK - 1)] + xoff[i]));
         }
 #pragma unroll
         for (int i = 0; i < DI; ++i) {
             const int e = tid + THREADS * i, mm = e / DROW, n4 = e - mm * DROW;
             if (CK * DROW % THREADS == 0 || mm < CK) {
                 const int m = c * CK + mm;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + (int64_t)min(m, a.M - 1) * g.OC + n0 + 4 * n4);
-                dr[i] = m < a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                dok[i] = m < a.M;                       // applied when the piece is written to LDS (keeps the load in flight)
+                dr[i] = *reinterpret_cast<const f32x4*>(a.dY + ((unsigned)min(m, a.M - 1) * (unsigned)g.OC + n0 + 4 * n4));
             }
         }
     };
@@ -452,7 +500,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
 #pragma unroll
         for (int i = 0; i < DI; ++i) {
             const int e = tid + THREADS * i, mm = e / DROW, n4 = e - mm * DROW;
-            if (CK * DROW % THREADS == 0 || mm < CK) *reinterpret_cast<f32x4*>(&Ds[slot][mm * BN + 4 * n4]) = dr[i];
+            if (CK * DROW % THREADS == 0 || mm < CK)
+                *reinterpret_cast<f32x4*>(&Ds[slot][mm * BN + 4 * n4]) = dok[i] ? dr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -579,24 +628,156 @@ constexpr size_t LDS_MAX = 160 * 1024;
 constexpr int64_t ROWS2_MIN_M = 1 << 17;       // below this the first-generation kernels win (launch-bound layers)
 constexpr int64_t WGRAD2_MIN_M = 1 << 17;
 
-template <typename F>
-int launch_rows2(F kernel, dim3 grid, size_t lds, hipStream_t s, const Rows2Args& a) {
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+struct DgPlan {                      // host side of an input-gradient launch
+    std::vector<DgClass> classes;
+    ts_workspace* ws;
+    const ts::ConvGeom* g;
+};
+
+// Fills tiles / workgroup shares of the classes for row tiles of `bm`, places the table in a device slot of the workspace
+// (re-used while geometry, tile size and workgroup budget repeat) and returns the total workgroup count.
+int place_classes(DgPlan& plan, int bm, int budget, hipStream_t s, const DgClass** dev, int* total_wgs) {
+    ts_workspace* ws = plan.ws;
+    const ts::ConvGeom& g = *plan.g;
+    // cost of a class = row tiles x (reduction chunks + a fixed per-tile share: row decode, first loads, epilogue)
+    const double overhead = env_int("TS_DG_OVERHEAD", 0);
+    const int n = (int)plan.classes.size();
+    std::vector<double> cost(n);
+    double work = 0.0;
+    for (int i = 0; i < n; ++i) {
+        DgClass& c = plan.classes[i];
+        c.tiles = (int)ts::ceil_div(c.M, bm);
+        cost[i] = (double)c.tiles * (c.njh * c.njw * g.OC / CK + overhead);
+        work += cost[i];
+    }
+    // one workgroup per class, the rest of the budget by work (largest remainder first); the total never exceeds the
+    // budget: a workgroup beyond what the chip holds at once would run as a second round after the first drains
+    const int spare = std::max(0, budget - n);
+    std::vector<double> want(n);
+    int given = 0;
+    for (int i = 0; i < n; ++i) {
+        DgClass& c = plan.classes[i];
+        want[i] = cost[i] / work * spare;
+        c.wgs = 1 + (int)want[i];
+        given += (int)want[i];
+        want[i] -= (int)want[i];
+    }
+    for (int left = spare - given; left > 0; --left) {
+        int best = 0;
+        for (int i = 1; i < n; ++i) if (want[i] > want[best]) best = i;
+        ++plan.classes[best].wgs;
+        want[best] = -1.0;
+    }
+    int first = 0;
+    for (auto& c : plan.classes) {
+        c.wgs = (int)std::max<int64_t>(1, std::min<int64_t>(c.wgs, c.tiles));
+        c.first_wg = first;
+        first += c.wgs;
+    }
+    *total_wgs = first;
+    const long long key[16] = {g.B, g.IH, g.IW, g.IC, g.KH, g.KW, g.S, g.OH, g.OW, g.OC, bm, budget, (long long)plan.classes.size(), 1};
+    if (!ws->dg_tables) {
+        TS_HIP_CHECK(hipMalloc(&ws->dg_tables, sizeof(DgClass) * MAX_DG_CLASSES * 16));
+    }
+    DgClass* base = static_cast<DgClass*>(ws->dg_tables);
+    for (int i = 0; i < 16; ++i)
+        if (memcmp(ws->dg_key[i], key, sizeof(key)) == 0) { *dev = base + (size_t)i * MAX_DG_CLASSES; return TS_OK; }
+    const int slot = ws->dg_next;
+    ws->dg_next = (slot + 1) % 16;
+    memcpy(ws->dg_key[slot], key, sizeof(key));
+    DgClass* d = base + (size_t)slot * MAX_DG_CLASSES;
+    TS_HIP_CHECK(hipMemcpyAsync(d, plan.classes.data(), sizeof(DgClass) * plan.classes.size(), hipMemcpyHostToDevice, s));
+    *dev = d;
+    return TS_OK;
+}
+
+template <bool DG, bool U8, bool RES, int TM, int TN, int WN, int WAVES, bool KSEQ>
+int launch_one(dim3 grid, size_t lds, hipStream_t s, Rows2Args& a, int wgs_per_col, DgPlan* plan) {
+    constexpr int BM = (WAVES / WN) * TM * 32;
+    if (DG) {
+        int total = 0;
+        if (int rc = place_classes(*plan, BM, wgs_per_col, s, &a.classes, &total)) return rc;
+        a.n_classes = (int)plan->classes.size();
+        grid.x = (unsigned)total;
+    } else {
+        a.tiles = (int)ts::ceil_div(a.M, BM);
+        grid.x = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.tiles, wgs_per_col));
+    }
+    auto kernel = conv_rows2_kernel<DG, U8, RES, TM, TN, WN, WAVES, KSEQ>;
     if (lds > 64 * 1024) {
         TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(WAVES * 64), lds, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
 
+// Variant choice.  shape = (TN, WN) is fixed by the layer; (waves, TM) and the k order are tuning knobs
+// (TS_R2_WAVES / TS_R2_TM / TS_R2_KSEQ override the defaults for experiments).
+template <bool DG, bool U8, bool RES, int TN, int WN>
+int launch_rows2(dim3 grid, size_t lds, hipStream_t s, Rows2Args& a, int wgs_per_col, int waves, int tm, bool kseq,
+                 DgPlan* plan = nullptr) {
+    waves = env_int("TS_R2_WAVES", waves); tm = env_int("TS_R2_TM", tm); kseq = env_int("TS_R2_KSEQ", kseq) != 0;
+#define TS_R2_CASE(W, T, Q) \
+    if (waves == W && tm == T && kseq == Q) return launch_one<DG, U8, RES, T, TN, WN, W, Q>(grid, lds, s, a, wgs_per_col, plan);
+    TS_R2_CASE(8, 2, true) TS_R2_CASE(8, 2, false) TS_R2_CASE(16, 1, true) TS_R2_CASE(16, 1, false)
+    if constexpr (TN == 1) { TS_R2_CASE(16, 2, true) TS_R2_CASE(16, 2, false) }
+#undef TS_R2_CASE
+    return ts::fail(TS_ERR_UNSUPPORTED, "conv rows2: variant (waves %d, TM %d) is not instantiated", waves, tm);
+}
+
 bool shape_ok_rows(const ts::ConvGeom& g) {
+    // 32-bit element offsets inside the kernels (check_geom: < 2^31 elements per tensor); chunk-offset table: K <= 16,384
     return (g.KW * g.IC) % CK == 0 && g.K() % CK == 0 && g.OC % 32 == 0 && g.OH * g.OW < 65536 && g.OW < 65536 &&
-           g.IH * g.IW < 65536;
+           g.IH * g.IW < 65536 && g.in_elems() < (1ll << 31) && g.out_elems() < (1ll << 31) &&
+           g.K() <= MAX_CHUNKS * CK && g.OC * (g.KH / std::max(1, g.S)) * (g.KW / std::max(1, g.S)) <= MAX_CHUNKS * CK;
 }
 
 }  // namespace
 
 namespace ts {
+
+// Runs of input positions (index a within one stride-parity class) that receive the same tap interval.
+struct TapSeg { int lo, n, j0, nj; };
+static void tap_segments(int IH, int OH, int KH, int S, int p, std::vector<TapSeg>* out) {
+    out->clear();
+    const int n = IH - p <= 0 ? 0 : (int)ceil_div(IH - p, S), JH = KH / S;
+    for (int a = 0; a < n; ++a) {
+        const int lo = std::max(0, a - (OH - 1)), hi = std::min(JH - 1, a);
+        const int nj = std::max(0, hi - lo + 1), j0 = nj ? lo : 0;
+        if (!out->empty() && out->back().j0 == j0 && out->back().nj == nj) ++out->back().n;
+        else out->push_back(TapSeg{a, 1, j0, nj});
+    }
+}
+
+static int dgrad_classes(const ConvGeom& g, std::vector<DgClass>* out) {
+    out->clear();
+    std::vector<TapSeg> rows, cols;
+    for (int ph = 0; ph < g.S; ++ph) {
+        tap_segments(g.IH, g.OH, g.KH, g.S, ph, &rows);
+        for (int pw = 0; pw < g.S; ++pw) {
+            tap_segments(g.IW, g.OW, g.KW, g.S, pw, &cols);
+            for (const TapSeg& r : rows)
+                for (const TapSeg& c : cols) {
+                    DgClass d{};
+                    d.ph = ph; d.pw = pw; d.a0 = r.lo; d.c0 = c.lo; d.na = r.n; d.nc = c.n;
+                    d.jh0 = r.j0; d.jw0 = c.j0; d.njh = r.nj; d.njw = c.nj;
+                    if (d.njh == 0 || d.njw == 0) d.njh = d.njw = 0;          // no window covers these pixels: dX = 0
+                    d.M = g.B * r.n * c.n;
+                    d.plane = divisor_of(r.n * c.n); d.wdt = divisor_of(c.n);
+                    out->push_back(d);
+                }
+        }
+    }
+    TS_REQUIRE(!out->empty() && (int)out->size() <= MAX_DG_CLASSES, TS_ERR_UNSUPPORTED,
+               "conv2_dgrad: %d border classes (limit %d)", (int)out->size(), MAX_DG_CLASSES);
+    return TS_OK;
+}
 
 static bool is_linear(const ConvGeom& g) { return g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1; }
 
@@ -612,12 +793,16 @@ bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end
     if (mode < 0 || !shape_ok_rows(g) || g.IC % 32 != 0) return false;
     if (g.KH % g.S != 0 || g.KW % g.S != 0) return false;
     if (col_begin != 0 || (col_end >= 0 && col_end != g.IC)) return false;      // column ranges: first generation
-    if (is_linear(g)) {
-        if (!have_ws) return false;                                     // needs room for the transposed weights
-    } else {
+    if (!have_ws) return false;                                         // transposed weights / class tables live there
+    if (!is_linear(g)) {
         if (g.IC > 64) return false;
         const size_t lds = (size_t)(g.KH / g.S) * (g.KW / g.S) * g.OC * (g.IC % 64 == 0 ? 64 : 32) * 4;
         if (lds > LDS_MAX) return false;
+        // at most MAX_DG_CLASSES border classes: S^2 parities x (<= 2 KH/S + 1 row runs) x (<= 2 KW/S + 1 column runs)
+        if ((int64_t)g.S * g.S * (2 * (g.KH / g.S) + 1) * (2 * (g.KW / g.S) + 1) > MAX_DG_CLASSES) {
+            std::vector<DgClass> probe;
+            if (dgrad_classes(g, &probe) != TS_OK) return false;
+        }
     }
     const int64_t m = (int64_t)g.B * ceil_div(g.IH, g.S) * ceil_div(g.IW, g.S);
     return mode > 0 || m >= ROWS2_MIN_M;
@@ -668,34 +853,27 @@ static int rows2_forward(hipStream_t s, const ConvGeom& g, const void* X, bool x
     a.plane = divisor_of(g.OH * g.OW); a.wdt = divisor_of(g.OW);
     ProfScope scope(prof, kind, s);
     const int cus = num_cus();
-    static const int res_max_nb = [] { const char* e = getenv("TS_CONV2_RES_MAX_NB"); return e ? atoi(e) : 8; }();
+    const int res_max_nb = env_int("TS_CONV2_RES_MAX_NB", 8);
     if (N == 32 && (size_t)a.K * 32 * 4 <= LDS_MAX) {
-        a.tiles = (int)ceil_div(a.M, 512);
         const size_t lds = (size_t)a.K * 32 * 4;
-        const int wgs = (int)std::min<int64_t>(a.tiles, lds <= 40 * 1024 ? 2 * cus : cus);
-        if (x_u8) return launch_rows2(conv_rows2_kernel<false, true, true, 2, 1, 1>, dim3(wgs, 1, 1), lds, s, a);
-        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 1, 1>, dim3(wgs, 1, 1), lds, s, a);
+        const int per_cu = lds <= 40 * 1024 ? 2 : 1;
+        if (x_u8) return launch_rows2<false, true, true, 1, 1>(dim3(1, 1, 1), lds, s, a, per_cu * cus, 8, 2, false);
+        return launch_rows2<false, false, true, 1, 1>(dim3(1, 1, 1), lds, s, a, per_cu * cus, 8, 2, false);
     }
     TS_REQUIRE(!x_u8, TS_ERR_UNSUPPORTED, "conv rows2: uint8 input is instantiated for 32 output channels only");
     if (N % 128 == 0 && (size_t)a.K * 128 * 4 <= LDS_MAX && N / 128 <= res_max_nb) {
-        a.tiles = (int)ceil_div(a.M, 256);
         const int nb = N / 128;
-        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
-        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 2, 2>, dim3(wgs, nb, 1), (size_t)a.K * 128 * 4, s, a);
+        return launch_rows2<false, false, true, 2, 2>(dim3(1, nb, 1), (size_t)a.K * 128 * 4, s, a, std::max(1, cus / nb), 16, 1, false);
     }
     if (N % 64 == 0 && (size_t)a.K * 64 * 4 <= LDS_MAX && N / 64 <= res_max_nb) {
-        a.tiles = (int)ceil_div(a.M, 512);
         const int nb = N / 64;
-        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
-        return launch_rows2(conv_rows2_kernel<false, false, true, 2, 2, 1>, dim3(wgs, nb, 1), (size_t)a.K * 64 * 4, s, a);
+        return launch_rows2<false, false, true, 2, 1>(dim3(1, nb, 1), (size_t)a.K * 64 * 4, s, a, std::max(1, cus / nb), 16, 1, false);
     }
     // streamed weight slices, 256 x 128 workgroup tiles (ragged last column block allowed).  The column blocks of one
     // row range run on different workgroups at the same pace, so the activation rows they share are fetched together.
     TS_REQUIRE(N % 4 == 0 && N >= 4, TS_ERR_UNSUPPORTED, "conv rows2: unsupported streamed shape");
-    a.tiles = (int)ceil_div(a.M, 256);
     const int nb = (int)ceil_div(N, 128);
-    const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / nb));
-    return launch_rows2(conv_rows2_kernel<false, false, false, 2, 2, 2>, dim3(wgs, nb, 1), (size_t)2 * CK * 128 * 4, s, a);
+    return launch_rows2<false, false, false, 2, 2>(dim3(1, nb, 1), (size_t)2 * CK * 128 * 4, s, a, std::max(1, cus / nb), 16, 1, false);
 }
 
 int conv2_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* Wb, float* Y, bool relu,
@@ -724,24 +902,23 @@ int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* 
     }
     Rows2Args a{};
     a.A = dY; a.W = Wb; a.C = dX; a.mask = mask; a.g = g;
-    a.AH = (int)ceil_div(g.IH, g.S); a.AW = (int)ceil_div(g.IW, g.S);
-    a.JH = g.KH / g.S; a.JW = g.KW / g.S;
-    a.M = g.B * a.AH * a.AW; a.K = a.JH * a.JW * g.OC; a.N = g.IC; a.ldw = g.OC;
-    a.plane = divisor_of(a.AH * a.AW); a.wdt = divisor_of(a.AW);
+    a.N = g.IC; a.ldw = g.OC;
+    DgPlan plan;
+    plan.ws = ws; plan.g = &g;
+    if (int rc = dgrad_classes(g, &plan.classes)) return rc;
+    int kmax = 0;
+    for (const auto& c : plan.classes) kmax = std::max(kmax, c.njh * c.njw * g.OC);
+    a.K = kmax;
     ProfScope scope(ws, TS_KIND_CONV_DGRAD, s);
-    const int cus = num_cus(), classes = g.S * g.S;
-    a.tiles = (int)ceil_div(a.M, 512);
+    const int cus = num_cus();
     if (g.IC % 64 == 0) {
-        const size_t lds = (size_t)a.K * 64 * 4;
+        const size_t lds = (size_t)kmax * 64 * 4;
         const int nb = g.IC / 64;
-        const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, cus / (nb * classes)));
-        return launch_rows2(conv_rows2_kernel<true, false, true, 2, 2, 1>, dim3(wgs, nb, classes), lds, s, a);
+        return launch_rows2<true, false, true, 2, 1>(dim3(1, nb, 1), lds, s, a, std::max(1, cus / nb), 16, 1, false, &plan);
     }
-    const size_t lds = (size_t)a.K * 32 * 4;
+    const size_t lds = (size_t)kmax * 32 * 4;
     const int nb = g.IC / 32;
-    const int per_cu = lds <= 40 * 1024 ? 2 : 1;
-    const int wgs = (int)std::min<int64_t>(a.tiles, std::max(1, per_cu * cus / (nb * classes)));
-    return launch_rows2(conv_rows2_kernel<true, false, true, 2, 1, 1>, dim3(wgs, nb, classes), lds, s, a);
+    return launch_rows2<true, false, true, 1, 1>(dim3(1, nb, 1), lds, s, a, std::max(1, cus / nb), 16, 2, false, &plan);
 }
 
 int conv2_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs, ts_workspace* prof,

@@ -152,6 +152,7 @@ int ts_workspace_destroy(ts_workspace* ws) {
     }
     if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }
     if (ws->conv_scratch) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->conv_scratch); }
+    if (ws->dg_tables) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->dg_tables); }
     if (ws->base || ws->winner || ws->ev || ws->gae_sync) {
         (void)hipSetDevice(ws->device);
         (void)hipDeviceSynchronize();

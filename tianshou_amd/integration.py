@@ -20,6 +20,11 @@ from .checkpoint import adam_state, params_by_keys, store_adam_state
 from .ppo import PPOConfig, PPOEngine, flat_from_modules, flat_to_modules, TIANSHOU_ACTOR_KEYS, TIANSHOU_CRITIC_KEYS
 
 
+def _algorithm_state_loaded(module, incompatible_keys) -> None:
+    """load_state_dict post-hook of the Hip* algorithms (module level, so that the algorithm stays picklable)."""
+    module._hip_invalidate()
+
+
 class _HipGlue:
     """Mixed in (first base) by every Hip* subclass: the two places where the torch-side state of the
     reference moves underneath an engine that snapshotted it.
@@ -29,19 +34,71 @@ class _HipGlue:
       examples/mujoco/mujoco_ppo.py:124-131 turns linear decay on by default.  The engines rebuild their
       hyper-parameter struct from `eng.cfg` on every call, so `_hip_refresh_lr()` at the top of each
       `_update_with_batch` re-reads the optimizers' current values.
-    * `load_state_dict` (on the algorithm or on any of its sub-modules) replaces parameters / Adam moments /
-      lagged networks / counters: the engine is dropped and rebuilt from the loaded torch state on the next
-      update (a post-hook on every sub-module, so `algorithm.policy.load_state_dict(...)` is caught too).
+    * `load_state_dict` on the algorithm replaces parameters / Adam moments / lagged networks / counters: the engine
+      is dropped and rebuilt from the loaded torch state on the next update.  A load into a sub-module
+      (`algorithm.policy.load_state_dict(best)`) replaces parameters only: it is noticed through the parameters'
+      version counters, the engine's Adam moments are first written into torch.optim and survive the rebuild.
     `_HIP_LR`: (engine cfg field, attribute path of the Algorithm.Optimizer wrapper that owns it)."""
     _HIP_LR: tuple = (("lr", "optim"),)
 
     def _hip_glue_init(self) -> None:
-        hook = lambda module, incompatible_keys: self._hip_invalidate()  # noqa: E731
-        for m in self.modules():
-            m.register_load_state_dict_post_hook(hook)
+        # Only the algorithm itself carries a hook, and it is a module-level function: sub-modules stay free of
+        # closures so that `torch.save(policy)` / `pickle.dumps(algorithm.policy)` (highlevel/persistence.py:106)
+        # and `copy.deepcopy(policy)` keep working.  Loads into sub-modules are caught by the version check below.
+        self.register_load_state_dict_post_hook(_algorithm_state_loaded)
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        f = cls.__dict__.get("_update_with_batch")
+        if f is not None and not getattr(f, "_hip_wrapped", False):
+            import functools
+
+            @functools.wraps(f)
+            def _update_with_batch(self, *a, **k):
+                self.__dict__["_hip_in_update"] = True      # our own write-back must not look like a foreign write
+                try:
+                    out = f(self, *a, **k)
+                finally:
+                    self.__dict__["_hip_in_update"] = False
+                self._hip_mark()          # the engine has just written the parameters back: that is "our" version
+                return out
+
+            _update_with_batch._hip_wrapped = True
+            cls._update_with_batch = _update_with_batch
+
+    # The engine snapshots the torch parameters.  `_hip_engine` is a property so that every access first checks
+    # whether somebody else has written them since (`algorithm.policy.load_state_dict(best)`,
+    # `actor.load_state_dict(...)`, an in-place edit): tensor `_version` counters of all parameters.  If so, the
+    # engine-side Adam moments are flushed into torch.optim (they are still valid: only parameters were replaced) and
+    # the engine is rebuilt from the torch state on the next use.
+    def _hip_current_versions(self) -> tuple:
+        return tuple((id(p), p._version) for p in self.parameters())
+
+    def _hip_mark(self) -> None:
+        if self.__dict__.get("_hip_engine_obj") is not None:
+            self.__dict__["_hip_versions"] = self._hip_current_versions()
+
+    @property
+    def _hip_engine(self):
+        eng = self.__dict__.get("_hip_engine_obj")
+        if eng is not None and not self.__dict__.get("_hip_in_update", False):
+            seen = self.__dict__.get("_hip_versions")
+            if seen is not None and seen != self._hip_current_versions():
+                self._hip_flush()
+                self.__dict__["_hip_engine_obj"] = eng = None
+                self.__dict__["_hip_versions"] = None
+                self._hip_adam_dirty = False
+        return eng
+
+    @_hip_engine.setter
+    def _hip_engine(self, value) -> None:
+        self.__dict__["_hip_engine_obj"] = value
+        self.__dict__["_hip_versions"] = None if value is None else self._hip_current_versions()
 
     def _hip_invalidate(self) -> None:
-        self._hip_engine = None
+        """`Algorithm.load_state_dict` replaced parameters AND optimizer state: drop the engine without flushing."""
+        self.__dict__["_hip_engine_obj"] = None
+        self.__dict__["_hip_versions"] = None
         self._hip_adam_dirty = False
 
     def _hip_flush(self) -> None:
