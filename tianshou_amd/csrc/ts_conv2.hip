@@ -625,8 +625,19 @@ int& v2_mode_ref() {
 int v2_mode() { return v2_mode_ref(); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
-constexpr int64_t ROWS2_MIN_M = 1 << 17;       // below this the first-generation kernels win (launch-bound layers)
-constexpr int64_t WGRAD2_MIN_M = 1 << 17;
+// Row counts from which generation 2 wins (scripts/gpu_conv2_check.py bench, profiles/r03_conv2_thresholds.txt): its
+// persistent workgroups need a few row tiles each.  Convolutions: 2^18 rows (the C3 batch of 512 stays on generation 1,
+// whose summation order the small-batch parity tests pin); linear layers (rows = samples): 16,384 rows of a layer with at
+// least 2^16 weights (narrow heads stay on generation 1 at every size).
+constexpr int64_t CONV2_MIN_ROWS = 1 << 18;
+constexpr int64_t LINEAR2_MIN_ROWS = 1 << 14;
+constexpr int64_t LINEAR2_MIN_WEIGHTS = 1 << 16;
+
+bool big_enough(const ts::ConvGeom& g, int64_t rows) {
+    const bool linear = g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1;
+    if (linear) return rows >= LINEAR2_MIN_ROWS && (int64_t)g.IC * g.OC >= LINEAR2_MIN_WEIGHTS;
+    return rows >= CONV2_MIN_ROWS;
+}
 
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
@@ -785,7 +796,7 @@ bool conv2_use_forward(const ConvGeom& g, bool x_u8) {
     const int mode = v2_mode();
     if (mode < 0 || !shape_ok_rows(g)) return false;
     if (x_u8 && g.OC != 32) return false;                               // uint8 frames: first layer only (32 channels)
-    return mode > 0 || (int64_t)g.B * g.OH * g.OW >= ROWS2_MIN_M;
+    return mode > 0 || big_enough(g, (int64_t)g.B * g.OH * g.OW);
 }
 
 bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end) {
@@ -804,15 +815,14 @@ bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end
             if (dgrad_classes(g, &probe) != TS_OK) return false;
         }
     }
-    const int64_t m = (int64_t)g.B * ceil_div(g.IH, g.S) * ceil_div(g.IW, g.S);
-    return mode > 0 || m >= ROWS2_MIN_M;
+    return mode > 0 || big_enough(g, (int64_t)g.B * g.IH * g.IW);
 }
 
 bool conv2_use_wgrad(const ConvGeom& g, bool x_u8) {
     const int mode = v2_mode();
     if (mode < 0 || !shape_ok_rows(g)) return false;
     if (x_u8 && g.OC != 32) return false;
-    return mode > 0 || (int64_t)g.B * g.OH * g.OW >= WGRAD2_MIN_M;
+    return mode > 0 || big_enough(g, (int64_t)g.B * g.OH * g.OW);
 }
 
 // tile plan of wgrad2 (rows of dW x columns per workgroup):
@@ -823,7 +833,9 @@ static int wgrad2_plan(const ConvGeom& g, int* bkt, int* bn, int* per_cu) {
     static const char* force = getenv("TS_WGRAD2_PLAN");
     const int k = g.K();
     const int64_t w512 = ceil_div(k, 512) * 512, w192 = ceil_div(k, 192) * 192, w256 = ceil_div(k, 256) * 256;
-    int plan = (w512 <= w192 && w512 <= w256) ? 1 : (w192 <= w256 ? 2 : 3);
+    // measured at minibatch 65,536: 512-row tiles (plan 1) win whenever they waste < 15 % (fc1: 3136 -> 3584), the
+    // 192-row plan wins for conv3 (576 = 3 x 192 against 1024), plan 3 never
+    int plan = (w512 * 100 <= (int64_t)k * 115) ? 1 : (w192 <= w256 ? 2 : 3);
     if (force && force[0] >= '1' && force[0] <= '3') plan = force[0] - '0';
     *bn = 64;
     if (plan == 1) { *bkt = 512; *per_cu = 1; }
