@@ -849,10 +849,23 @@ int conv2_wgrad_splits(const ConvGeom& g) {
     wgrad2_plan(g, &bkt, &bn, &per_cu);
     const int64_t tiles = ceil_div(g.K(), bkt) * (g.OC / bn);
     const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, CK);
-    const int want = (int)std::max<int64_t>(1, (int64_t)per_cu * 256 / tiles);
-    int per = (int)ceil_div(chunks, want);
-    if (per < 8) per = 8;
-    return (int)ceil_div(chunks, per);
+    // Split count: every workgroup does the same work, so the launch runs in rounds of (resident workgroups); choose the
+    // count whose last round is the fullest (fc1: 56 tiles x 9 splits = 504 of 2 x 256 slots, against 224 of 256 for the
+    // obvious 4), among counts that leave each split at least 8 chunks and at most ~4 rounds of slabs to sum.
+    const int64_t slots = (int64_t)per_cu * 256;
+    const int max_splits = (int)std::max<int64_t>(1, std::min<int64_t>(chunks / 8, ceil_div(4 * slots, tiles)));
+    auto eff_of = [&](int sp) {
+        const int per = (int)ceil_div(chunks, sp);
+        if ((int)ceil_div(chunks, per) != sp) return 0.0;               // not reachable with equal shares
+        const int64_t wgs = tiles * sp;
+        return (double)wgs / (double)(ceil_div(wgs, slots) * slots);
+    };
+    double top = 0.0;
+    for (int sp = 1; sp <= max_splits; ++sp) top = std::max(top, eff_of(sp));
+    int best = 1;
+    for (int sp = 1; sp <= max_splits; ++sp)
+        if (eff_of(sp) >= top - 0.02) { best = sp; break; }              // the fewest splits within 2 % of the fullest
+    return best;
 }
 
 // Forward through the rows2 kernel.  `W` / `ldw` / `N` describe the weight matrix actually multiplied (the layer's own
@@ -952,7 +965,8 @@ int conv2_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* d
         else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 1, 2, 1>), grid, dim3(256), 0, s, a);
     } else {
         TS_REQUIRE(!x_u8, TS_ERR_UNSUPPORTED, "conv wgrad2: uint8 input is instantiated for 32 output channels only");
-        if (plan == 1) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 1, 2, 2>), grid, dim3(512), 0, s, a);
+        if (plan == 1 && env_int("TS_WGRAD2_W16", 0)) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 2, 2, 1>), grid, dim3(1024), 0, s, a);
+        else if (plan == 1) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 1, 2, 2>), grid, dim3(512), 0, s, a);
         else if (plan == 2) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 2, 3, 1>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 2, 2, 1>), grid, dim3(512), 0, s, a);
     }

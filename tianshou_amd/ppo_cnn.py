@@ -146,7 +146,7 @@ class CnnPPOEngine:
 
     # -- PPO._preprocess_batch -------------------------------------------------------------------------------
     def preprocess(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, act: torch.Tensor, stack_num: int,
-                   obs_next_frames: torch.Tensor | None = None, chunk: int = 16384) -> dict:
+                   obs_next_frames: torch.Tensor | None = None, chunk: int = 65536) -> dict:
         """Whole-buffer pass in sample_indices(0) order: V(s), V(s'), log pi_old(a|s) (one trunk pass per
         observation), GAE, optional return scaling (a2c.py:115-153, ppo.py:146-162)."""
         cfg = self.cfg
