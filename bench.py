@@ -107,6 +107,7 @@ class Learner:
         self._lib = _lib
         self.ws = _lib.default_workspace(device.index)
         self.dp = None
+        self.exchange = "none"
 
     def next_perm(self):
         from tianshou_amd.buffer import random_permutation
@@ -115,15 +116,38 @@ class Learner:
         return random_permutation(N_TRANS, self.perm_seed, self.device)
 
     def _dp(self):
+        """world > 1: every minibatch is ONE C call (ts_ppo_dp_step: gradient -> exchange -> clip + Adam on the stream); the
+        exchange is the C-ABI all-reduce, whose one-shot path (peer buffers mapped through HIP IPC, one single-workgroup
+        kernel) carries the 44 KB payload.  torch.distributed (three Python calls per step) only if that cannot be set up."""
         if self.dp is None:
             from tianshou_amd.distributed import DataParallelPPO
 
-            self.dp = DataParallelPPO(self.eng)
+            ar = None
+            if self.world > 1 and not os.environ.get("TS_BENCH_TORCH_ALLREDUCE"):
+                try:
+                    from tianshou_amd.collective import NativeAllReduce
+
+                    ar = NativeAllReduce(self.device)
+                    self.exchange = "ts_allreduce one-shot (HIP IPC)" if ar.small_capacity >= self.eng.P + 4 else "ts_allreduce (RCCL)"
+                except Exception as e:      # noqa: BLE001 - any failure of the native set-up: the proven path
+                    print(f"[bench] rank {self.rank}: native all-reduce unavailable ({e}); using torch.distributed", file=sys.stderr)
+                    ar = None
+                import torch.distributed as dist
+
+                ok = torch.tensor([0 if ar is None else 1], device=self.device)       # all ranks or none
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and ar is not None:
+                    ar.close()
+                    ar = None
+            if ar is None:
+                self.exchange = "torch.distributed all_reduce (RCCL)" if self.world > 1 else "none"
+            self.dp = DataParallelPPO(self.eng, allreduce=ar)
         return self.dp
 
-    def preprocess(self):
+    def preprocess(self, local_only=False):
+        """local_only: no collective inside (the rank-0-only measurements after the timed region)."""
         obs, obs_next, act, rew, term, trunc = self.data
-        if self.world > 1:          # shard-local values / GAE / logp_old; ret_rms from the global return statistics
+        if self.world > 1 and not local_only:   # shard-local values / GAE / logp_old; ret_rms from the global return statistics
             return self._dp().preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
         return self.eng.preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
 
@@ -455,11 +479,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = [float(x) for x in losses[-1].tolist()]
+    exchange = learner.exchange
+    if world > 1 and learner.dp is not None and getattr(learner.dp, "_allreduce", None) is not None:
+        learner.dp._allreduce.check()           # a one-shot exchange whose peer never arrived would have left stale sums
 
     # per-kernel durations with HIP events on the launch stream, one more update() (N = 1 path)
     roof, extra = None, {}
     if rank == 0:
-        b = learner.preprocess()
+        b = learner.preprocess(local_only=True)
         torch.cuda.synchronize()
         if world == 1:
             learner.ws.profile_begin()
@@ -497,7 +524,7 @@ def main():
                                       "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * n_l}
         t1 = time.perf_counter()
         for _ in range(3):
-            learner.preprocess()
+            learner.preprocess(local_only=True)
         torch.cuda.synchronize()
         extra["preprocess_transitions_per_s"] = 3 * N_TRANS / (time.perf_counter() - t1)
 
@@ -531,7 +558,7 @@ def main():
             "config": {"workload": "C2 PPO MuJoCo-shape rollout: 512 envs x 2048 steps = 2^20 transitions/GPU, "
                                    "obs 17, act 6, MLP[64,64] actor-critic, minibatch 65536, repeat 10",
                        "gradient_steps_per_step": REPEAT * (N_TRANS // MINIBATCH),
-                       "transitions_per_step": N_TRANS, "parallelism": f"dp{world}"},
+                       "transitions_per_step": N_TRANS, "parallelism": f"dp{world}", "exchange": exchange},
             "roofline": roof, "cpu_baseline": cpu, "final_losses": final_loss,
         }
         out.update(extra)

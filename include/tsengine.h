@@ -909,6 +909,32 @@ int ts_allreduce_init(const uint8_t* h_id128, int64_t rank, int64_t world, int d
 int ts_allreduce(ts_comm* comm, float* buf, int64_t n, ts_stream_t stream);
 int ts_allreduce_destroy(ts_comm* comm);
 
+/* One-shot all-reduce for payloads of at most 16,384 floats (64 KB) -- the [gradient | loss parts] vector of a PPO
+ * minibatch step is 44 KB and sits on the critical path between two ~55 us kernels, where a ring collective's
+ * latency is what matters.  Every rank owns one device buffer which the others map through HIP IPC (xGMI peer
+ * access inside a node; also valid between processes sharing one GPU); a call is ONE single-workgroup kernel on
+ * `stream`: publish (system-scope write-through stores + flag), poll the peers' flags, sum the payloads in rank order
+ * 0 .. W-1 -- every replica obtains bit-identical sums (for W = 2 identical to ts_allreduce as well).
+ *   every rank: ts_allreduce_small_create(device, max_floats, &comm, handle64)   -> 64-byte IPC handle of its buffer
+ *   host      : all-gather the handles (any rendezvous) into h_handles[world * 64], rank order
+ *   every rank: ts_allreduce_small_connect(comm, h_handles, rank, world)          (at most 8 ranks)
+ *   per step  : ts_allreduce_small(comm, buf, n, stream)      in place; every rank must call it the same number of times
+ *   optional  : ts_allreduce_small_status(comm, stream)       synchronises; error if a peer never arrived (bounded spin)
+ * Replaces the per-step ncclAllReduce of the data-parallel PPO update (reference: single-process nn.DataParallel,
+ * tianshou/utils/net/common.py:473-515). */
+typedef struct ts_small_comm ts_small_comm;
+int ts_allreduce_small_create(int device, int64_t max_floats, ts_small_comm** out, uint8_t* h_handle64);
+int ts_allreduce_small_connect(ts_small_comm* comm, const uint8_t* h_handles, int64_t rank, int64_t world);
+int ts_allreduce_small(ts_small_comm* comm, float* buf, int64_t n, ts_stream_t stream);
+int ts_allreduce_small_status(ts_small_comm* comm, ts_stream_t stream);
+int ts_allreduce_small_destroy(ts_small_comm* comm);
+int64_t ts_allreduce_small_capacity(const ts_small_comm* comm);
+/* ts_allreduce (and therefore ts_ppo_dp_step) takes the one-shot path for payloads within `small`'s capacity once it is
+ * attached (NULL detaches; not owned: destroy it separately, after the communicator).  ts_allreduce_from_small makes a
+ * communicator that has ONLY the one-shot path (no RCCL; larger payloads are refused) -- e.g. ranks sharing one GPU. */
+int ts_allreduce_attach_small(ts_comm* comm, ts_small_comm* small);
+int ts_allreduce_from_small(ts_small_comm* small, ts_comm** out);
+
 /* One data-parallel PPO / A2C gradient step in one call: ts_ppo_grad on the local minibatch shard ->
  * ts_allreduce of step_buf[0 .. P + 4) (gradient sums / global_batch and the four loss parts; skipped when comm is NULL =
  * one rank) -> ts_ppo_apply (clip by the global norm + Adam step number `adam_step`), all on `stream`, no host

@@ -52,3 +52,79 @@ def test_native_allreduce_as_the_exchange_of_the_dp_wrappers():
     dp._reduce(buf)
     assert torch.equal(buf, torch.full((10,), 1.5, device="cuda"))
     ar.close()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# one-shot all-reduce over HIP-IPC-mapped peer buffers: two PROCESSES sharing the one GPU of the test box
+# --------------------------------------------------------------------------------------------------------------------
+def _one_shot_worker(rank, world, port, sizes, iters, out_q):
+    import os
+    import time
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("TS_SMALL_ALLREDUCE_SPINS", "4000000")       # a peer that never arrives fails in seconds, not minutes
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tianshou_amd.collective import NativeAllReduce
+
+        torch.cuda.set_device(0)
+        ar = NativeAllReduce(torch.device("cuda", 0), rccl=False)       # same GPU: no RCCL communicator possible
+        assert ar.small_capacity == 16384 and (ar.rank, ar.world) == (rank, world)
+        bad = 0
+        rng = np.random.default_rng(100 + rank)
+        load = torch.randn(2048, 2048, device="cuda")
+        for it in range(iters):
+            n = sizes[it % len(sizes)]
+            g = torch.Generator().manual_seed(1000 * it + rank)
+            mine = torch.randn(n, generator=g)
+            parts = [torch.empty(n) for _ in range(world)]
+            dist.all_gather(parts, mine)                                # the reference sum, rank order, on the host
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want += p
+            if rng.random() < 0.5:                                       # uneven load: one rank arrives late / under load
+                time.sleep(float(rng.random()) * 2e-3)
+                load = load @ load * 1e-3
+            x = mine.cuda()
+            ar(x)
+            if rng.random() < 0.3:
+                load = load @ load * 1e-3
+            got = x.cpu()
+            bad += 0 if torch.equal(got, want) else 1                    # every word, bit for bit
+        ar.check()
+        ar.close()
+        out_q.put((rank, bad))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_allreduce_between_two_processes_on_one_gpu():
+    """ts_allreduce_small_*: IPC handles exchanged over gloo, 300 calls of mixed sizes under uneven load, every word compared
+    with the host sum (for two ranks a + b is the same float whatever the order, so this is also what RCCL returns)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    sizes = [11089, 1, 16384, 7, 4096, 11085 + 4, 2]
+    procs = [ctx.Process(target=_one_shot_worker, args=(r, 2, port, sizes, 300, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive, "a rank hung"
+    assert all(p.exitcode == 0 for p in procs)
+    res = dict(q.get(timeout=5) for _ in range(2))
+    assert res == {0: 0, 1: 0}

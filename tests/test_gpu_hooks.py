@@ -33,6 +33,7 @@ def _make_ppo(obs_dim, act_dim, seed, device, hidden=64, **kw):
         for p in actor.mu.parameters():
             p.mul_(0.1)
     policy = SI.Policy(actor)
+    kw.setdefault("permutations", "host")          # the seed-exact mode: np.random.permutation like Batch.split
     algo = HipPPO(policy=policy, critic=critic, device=device, **kw)
     return algo.to(device) if device != "cpu" else algo
 

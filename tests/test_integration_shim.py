@@ -35,7 +35,7 @@ def algo():
                                       action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
     return HipPPO(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), eps_clip=0.2,
                   value_clip=True, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, return_scaling=True,
-                  advantage_normalization=False, dual_clip=None, device="cpu")
+                  advantage_normalization=False, dual_clip=None, device="cpu", permutations="host")
 
 
 def test_hooks_keep_reference_signatures(algo):
@@ -178,7 +178,7 @@ def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):
         LRSchedulerFactoryLinear(max_epochs=2, epoch_num_steps=40, collection_step_num_env_steps=20))
     algo = I.make_hip_ppo()(policy=policy, critic=critic, optim=optim, eps_clip=0.2, value_clip=True, vf_coef=0.25,
                              ent_coef=0.0, max_grad_norm=0.5, return_scaling=True, advantage_normalization=False,
-                             dual_clip=None, device="cpu")
+                             dual_clip=None, device="cpu", permutations="host")
     buf = VectorReplayBuffer(20, 2)
     rng = np.random.default_rng(0)
 

@@ -306,25 +306,47 @@ class DeviceReplayBuffer:
             self._host_stale = False
 
     @classmethod
-    def from_tianshou(cls, buffer, device="cuda"):
+    def from_tianshou(cls, buffer, device="cuda", env_range: tuple[int, int] | None = None):
         """Snapshot of a reference ReplayBuffer / ReplayBufferManager (duck-typed; only reads
-        public attributes plus _extend_offset/_lengths/_insertion_idx, manager.py:50-52)."""
+        public attributes plus _extend_offset/_lengths/_insertion_idx, manager.py:50-52).
+
+        `env_range = (lo, hi)`: mirror only the sub-buffers [lo, hi) -- this rank's shard of a buffer that is sharded by
+        env id across the GPUs of a node (`tianshou_amd.distributed.shard_envs`).  Episodes never span
+        sub-buffers (manager.py:50-60 offsets), so sampling, index math, GAE and n-step returns of the shard need nothing
+        from the others.  Indices of the mirror are LOCAL (slot 0 = first slot of sub-buffer lo); `to_global` adds the
+        shard's base."""
         if hasattr(buffer, "buffers"):
-            offset = buffer._extend_offset
-            lengths = buffer._lengths
-            insertion = [b._insertion_idx for b in buffer.buffers]
+            offset = np.asarray(buffer._extend_offset, dtype=np.int64)
+            lengths = np.asarray(buffer._lengths, dtype=np.int64)
+            insertion = np.asarray([b._insertion_idx for b in buffer.buffers], dtype=np.int64)
         else:
-            offset = [0, buffer.maxsize]
-            lengths = [len(buffer)]
-            insertion = [buffer._insertion_idx]
+            offset = np.asarray([0, buffer.maxsize], dtype=np.int64)
+            lengths = np.asarray([len(buffer)], dtype=np.int64)
+            insertion = np.asarray([buffer._insertion_idx], dtype=np.int64)
+        n_env = offset.size - 1
+        lo, hi = (0, n_env) if env_range is None else (int(env_range[0]), int(env_range[1]))
+        if not 0 <= lo < hi <= n_env:
+            raise ValueError(f"env_range {env_range} outside the {n_env} sub-buffers")
+        base, top = int(offset[lo]), int(offset[hi])
+        sl = slice(base, top)
         meta = buffer._meta
         has = lambda k: k in meta.get_keys()  # noqa: E731
         AddTracker.take(buffer)                         # the snapshot below covers everything written so far
-        return cls(offset=offset, last_index=np.array(buffer.last_index), lengths=np.array(lengths),
-                   insertion=insertion, rew=np.asarray(buffer.rew),
-                   terminated=np.asarray(buffer.terminated), truncated=np.asarray(buffer.truncated),
-                   obs=np.asarray(buffer.obs), act=np.asarray(buffer.act),
-                   obs_next=np.asarray(buffer.obs_next) if has("obs_next") else None, device=device)
+        m = cls(offset=offset[lo:hi + 1] - base, last_index=np.asarray(buffer.last_index, dtype=np.int64).reshape(-1)[lo:hi] - base,
+                lengths=lengths[lo:hi], insertion=insertion[lo:hi], rew=np.asarray(buffer.rew)[sl],
+                terminated=np.asarray(buffer.terminated)[sl], truncated=np.asarray(buffer.truncated)[sl],
+                obs=np.asarray(buffer.obs)[sl], act=np.asarray(buffer.act)[sl],
+                obs_next=np.asarray(buffer.obs_next)[sl] if has("obs_next") else None, device=device)
+        m.env_range, m.base, m.n_env_total = (lo, hi), base, n_env
+        return m
+
+    env_range: tuple[int, int] | None = None      # (lo, hi) of a shard mirror; None: the whole buffer
+    base = 0                                      # first global slot of the mirror
+    n_env_total: int | None = None
+
+    def to_global(self, index):
+        """Local mirror indices -> indices of the host buffer the mirror was taken from."""
+        return index + self.base
 
     def sync_from_tianshou(self, buffer) -> int:
         """Incremental refresh from the reference buffer this mirror was created from: copies only the slots
@@ -332,21 +354,24 @@ class DeviceReplayBuffer:
         How many slots each sub-buffer received comes from the `AddTracker` that `from_tianshou` installed on the
         buffer object (exact for any number of adds, including whole multiples of the sub-buffer size, and for
         `reset()` + refill, which leave `_insertion_idx` / `len` unchanged); adjacent ranges of neighbouring
-        sub-buffers are merged so that a fully rewritten VectorReplayBuffer is one copy per key.
-        Returns the number of slots copied."""
+        sub-buffers are merged so that a fully rewritten VectorReplayBuffer is one copy per key.  A shard mirror
+        (`env_range`) looks at its own sub-buffers only.  Returns the number of slots copied."""
         subs = buffer.buffers if hasattr(buffer, "buffers") else [buffer]
-        if len(subs) != self.buffer_num:
+        lo_e, hi_e = self.env_range if self.env_range is not None else (0, len(subs))
+        if hi_e - lo_e != self.buffer_num or len(subs) != (self.n_env_total or len(subs)):
             raise ValueError("buffer layout changed since the mirror was created")
         counts, everything = AddTracker.take(buffer)
         keys = [k for k in ("obs", "act", "obs_next") if getattr(self, k) is not None]
         host = {k: np.asarray(getattr(buffer, k)) for k in keys}
         host.update(rew=np.asarray(buffer.rew), terminated=np.asarray(buffer.terminated),
                     truncated=np.asarray(buffer.truncated))
+        base = self.base
         ranges = []
-        for e, sb in enumerate(subs):
+        for e in range(self.buffer_num):
+            sb = subs[lo_e + e]
             start, size = int(self.h_offset[e]), int(self.h_offset[e + 1] - self.h_offset[e])
             new_ins, new_len = int(sb._insertion_idx), len(sb)
-            k = size if everything else min(int(counts[e]), size)
+            k = size if everything else min(int(counts[lo_e + e]), size)
             if k >= size > 0:
                 ranges.append((start, start + size))
             elif k > 0:                      # the k slots before the insertion point, ring order
@@ -364,14 +389,15 @@ class DeviceReplayBuffer:
                 merged.append([lo, hi])
         copied = 0
         for lo, hi in merged:
-            sl = slice(lo, hi)
+            sl, hs = slice(lo, hi), slice(base + lo, base + hi)
             for key, arr in host.items():
                 dst = getattr(self, key)
-                src = torch.from_numpy(np.ascontiguousarray(arr[sl]))
+                src = torch.from_numpy(np.ascontiguousarray(arr[hs]))
                 dst[sl].copy_(src if src.dtype == dst.dtype else src.to(dst.dtype), non_blocking=True)
             self.done[sl] = self.terminated[sl] | self.truncated[sl]
             copied += hi - lo
-        self.h_last_index = np.ascontiguousarray(np.asarray(buffer.last_index, dtype=np.int64).reshape(-1))
+        self.h_last_index = np.ascontiguousarray(
+            np.asarray(buffer.last_index, dtype=np.int64).reshape(-1)[lo_e:hi_e] - base)
         self.last_index.copy_(torch.as_tensor(self.h_last_index))
         self.lengths.copy_(torch.as_tensor(self.h_lengths))
         self.insertion.copy_(torch.as_tensor(self.h_insertion))
@@ -438,6 +464,8 @@ class DeviceReplayBuffer:
         if batch_size > 0:
             dev = self.device
             bs = int(batch_size)
+            if len(self) == 0:                               # buffer_base.py:512-513: an empty buffer yields no indices
+                return torch.empty(0, dtype=torch.int64, device=dev)
             if (u_buffer is None) != (within is None):
                 raise ValueError("pass both u_buffer and within (the reference's draws) or neither")
             if u_buffer is None:

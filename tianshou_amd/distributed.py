@@ -95,6 +95,8 @@ class DataParallelPPO:
         exchange goes through torch.distributed / a test double (then the three calls stay separate)."""
         comm = getattr(self._allreduce, "_comm", None)
         if comm is not None:
+            if not comm and self.world > 1:       # NativeAllReduce.close() was called: a NULL handle would skip the exchange
+                raise RuntimeError("DataParallelPPO: the NativeAllReduce communicator has been closed")
             return comm
         if self.world == 1 and self._allreduce is None and type(self)._local_grad is DataParallelPPO._local_grad:
             return C.c_void_p()
@@ -158,15 +160,27 @@ class DataParallelPPO:
             t = torch.tensor([n_local], dtype=torch.int64, device=self._coll_device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             n_ref = int(t.item())
+        # Whether the split is feasible is decided COLLECTIVELY: a rank that raised on its own would leave the others
+        # waiting in the next all-reduce.  One MIN all-reduce of an ok flag, then every rank raises the same error.
+        problem, offs = None, None
         if n_local < 1:
-            raise ValueError("every rank needs at least one transition")
-        ref = split_offsets(n_ref, batch_size, merge_last=True)
-        if n_ref == n_local:
-            return ref
-        offs = [min(n_local, (o * n_local + n_ref // 2) // n_ref) for o in ref]
-        offs[0], offs[-1] = 0, n_local
-        if any(b <= a for a, b in zip(offs[:-1], offs[1:])):
-            raise ValueError("a shard is too small for the requested number of minibatches")
+            problem = "every rank needs at least one transition"
+        else:
+            ref = split_offsets(n_ref, batch_size, merge_last=True)
+            if n_ref == n_local:
+                offs = ref
+            else:
+                offs = [min(n_local, (o * n_local + n_ref // 2) // n_ref) for o in ref]
+                offs[0], offs[-1] = 0, n_local
+                if any(b <= a for a, b in zip(offs[:-1], offs[1:])):
+                    problem = "a shard is too small for the requested number of minibatches"
+        if self.world > 1:
+            ok = torch.tensor([0 if problem else 1], dtype=torch.int64, device=self._coll_device())
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) == 0 and problem is None:
+                problem = "another rank cannot split its shard (too few transitions for the requested minibatches)"
+        if problem:
+            raise ValueError(problem)
         return offs
 
     def _global_counts(self, counts: list[int], dev) -> list[int]:

@@ -95,6 +95,49 @@ class _HipGlue:
         self.__dict__["_hip_engine_obj"] = value
         self.__dict__["_hip_versions"] = None if value is None else self._hip_current_versions()
 
+    # -- data parallelism: one process per GPU, the replay buffer sharded by sub-buffer (env id), one
+    # all-reduce of the flat gradient per minibatch step; replaces the reference's single-process nn.DataParallel
+    # (utils/net/common.py:473-515).  `_hip_dp_setup` is called by the constructors that take `data_parallel=`.
+    def _hip_dp_setup(self, data_parallel: bool, group, allreduce, shard_buffer: bool) -> None:
+        self._hip_dp_on = bool(data_parallel)
+        self._hip_group = group
+        self._hip_allreduce = allreduce          # None: torch.distributed; "native": NativeAllReduce; or a callable
+        self._hip_shard = bool(shard_buffer) and self._hip_dp_on
+        self._hip_dp_obj = None
+
+    def _hip_world(self) -> tuple[int, int]:
+        import torch.distributed as dist
+
+        if not getattr(self, "_hip_dp_on", False) or not dist.is_initialized():
+            return 0, 1
+        return dist.get_rank(self._hip_group), dist.get_world_size(self._hip_group)
+
+    def _hip_shard_range(self, buffer):
+        """This rank's sub-buffers of `buffer` (None: mirror everything)."""
+        rank, world = self._hip_world()
+        if not getattr(self, "_hip_shard", False) or world == 1:
+            return None
+        from .distributed import shard_envs
+
+        n_env = len(buffer.buffers) if hasattr(buffer, "buffers") else 1
+        if n_env < world:
+            raise ValueError(f"cannot shard {n_env} sub-buffers over {world} ranks")
+        return shard_envs(n_env, rank, world)
+
+    def _hip_dp(self, wrapper_cls, eng):
+        """The DataParallel* wrapper around the current engine (rebuilt when the engine is)."""
+        obj = self._hip_dp_obj
+        if obj is None or obj.eng is not eng:
+            ar = self._hip_allreduce
+            if ar == "native":
+                from .collective import NativeAllReduce
+
+                ar = self.__dict__.get("_hip_native_ar")
+                if ar is None:
+                    ar = self.__dict__["_hip_native_ar"] = NativeAllReduce(self._hip_device, group=self._hip_group)
+            obj = self._hip_dp_obj = wrapper_cls(eng, group=self._hip_group, allreduce=ar)
+        return obj
+
     def _hip_invalidate(self) -> None:
         """`Algorithm.load_state_dict` replaced parameters AND optimizer state: drop the engine without flushing."""
         self.__dict__["_hip_engine_obj"] = None
@@ -207,17 +250,31 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
     PPO = _on_policy_base(algo, ref)
 
     class HipPPO(_HipGlue, PPO):
-        def __init__(self, *args, device="cuda", permutations="host", **kwargs):
-            """`permutations`: "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209;
-            same global-RNG stream as the reference, ~10 ms per 2^20 entries on the host); "device" draws one seed per
-            update() from the same global RNG and expands it with ts_random_permutation on the GPU (a keyed bijection:
-            statistically equivalent minibatches, not the reference's sequence)."""
+        def __init__(self, *args, device="cuda", permutations="device", perm_seed=0, data_parallel=False, group=None,
+                     allreduce=None, shard_buffer=True, **kwargs):
+            """`data_parallel=True` (one process per GPU, torch.distributed initialised): `update()` mirrors only this
+            rank's sub-buffers of `buffer` (`shard_buffer`, by env id; pass False when every rank collects into its own
+            buffer), computes values / GAE / log pi_old shard-locally with GLOBAL return statistics, and every minibatch
+            step all-reduces the flat gradient (`tianshou_amd.distributed.DataParallelPPO`); `allreduce`: None =
+            torch.distributed (RCCL), "native" = the C-ABI exchange incl. the one-shot path for the 44 KB payload, or any
+            in-place sum callable.  Replicas stay bit-identical.  `group`: the process group of the replicas.
+
+            `permutations`: "device" (default) expands a private key (`perm_seed`, the update counter, the repeat and the
+            rank) with ts_random_permutation on the GPU: a keyed bijection per repeat, statistically equivalent to
+            Batch.split's shuffles, and NumPy's global generator -- which the collector shares -- is left untouched.
+            "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209): the reference's
+            sequence for a given seed (the mode the parity tests use), at ~10 ms of host time per 2^20 entries -- 100 ms
+            of a 12 ms update(), i.e. ~1.4 k instead of ~14 k update-steps/s at the C2 size."""
             super().__init__(*args, **kwargs)
             if permutations not in ("host", "device"):
                 raise ValueError("permutations must be 'host' or 'device'")
             self._hip_perms = permutations
+            self._hip_perm_seed, self._hip_updates = int(perm_seed), 0
             self._hip_device = torch.device(device)
             self._hip_dims = _check_supported(self.policy.actor, self.critic)
+            self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer)
+            if data_parallel and self._hip_dims[3] != "fused":
+                raise NotImplementedError("HipPPO(data_parallel=True): the fused MuJoCo-shape engine only (Net[64, 64])")
             self._hip_engine = None
             self._hip_glue_init()
             self._hip_batch = None
@@ -262,6 +319,13 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
 
         def _hip_params(self):
             return params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS) + params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
+
+        def _hip_runner(self, eng):
+            if not self._hip_dp_on:
+                return eng
+            from .distributed import DataParallelPPO
+
+            return self._hip_dp(DataParallelPPO, eng)
 
         def _sync_back(self) -> None:
             """After every update(): engine parameters -> nn.Parameters (the collector acts with the torch modules;
@@ -310,7 +374,7 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             finally:
                 self.train(was_training)
             if hasattr(buffer, "update_weight"):
-                self._postprocess_batch(batch, buffer, indices.cpu().numpy())
+                self._postprocess_batch(batch, buffer, m.to_global(indices).cpu().numpy())
             for lr_scheduler in self.lr_schedulers:
                 lr_scheduler.step()
             stat.train_time = time.time() - start
@@ -334,8 +398,9 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             take = (lambda x: x) if whole else (lambda x: m.gather_tensor(x, idx))   # noqa: E731
             obs_next = take(m.obs_next) if m.obs_next is not None else m.gather_tensor(m.obs, m.next(idx))
             cut, d_n = cut_positions(m, idx)                                   # algorithm_base.py:715
-            b = eng.preprocess(take(m.obs), obs_next, take(m.act), take(m.rew), take(m.terminated), take(m.truncated),
-                               cut, d_n)
+            runner = self._hip_runner(eng)                                     # the engine, or its data-parallel wrapper
+            b = runner.preprocess(take(m.obs), obs_next, take(m.act), take(m.rew), take(m.terminated), take(m.truncated),
+                                  cut, d_n)
             self._hip_batch = b
             batch.v_s, batch.returns, batch.adv = b["v_s"], b["returns"], b["adv"]
             batch.act = b["act"]
@@ -352,9 +417,11 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             else:
                 from .buffer import random_permutation
 
-                seed = int(np.random.randint(0, 2**31 - 1))
-                perms = [random_permutation(n, seed * 1000003 + r, self._hip_device) for r in range(repeat)]
-            losses, steps = eng.update(self._hip_batch, batch_size, repeat, perms)
+                self._hip_updates += 1
+                rank = self._hip_world()[0]
+                key = ((self._hip_perm_seed * 0x9E3779B97F4A7C15) ^ (self._hip_updates << 20) ^ (rank << 52)) & (2**64 - 1)
+                perms = [random_permutation(n, key + r, self._hip_device) for r in range(repeat)]
+            losses, steps = self._hip_runner(eng).update(self._hip_batch, batch_size, repeat, perms)
             arr = losses.cpu().numpy().astype(np.float64)              # one D2H per update()
             eng.check()                                                # surfaces a stuck GAE hand-off (never observed)
             self._sync_back()
@@ -596,7 +663,8 @@ def _mirror(algorithm, buffer, device):
 
     m = getattr(algorithm, "_hip_mirror", None)
     if m is None or algorithm._hip_mirror_src is not buffer:
-        m = DeviceReplayBuffer.from_tianshou(buffer, device=device)
+        shard = algorithm._hip_shard_range(buffer) if hasattr(algorithm, "_hip_shard_range") else None
+        m = DeviceReplayBuffer.from_tianshou(buffer, device=device, env_range=shard)
         algorithm._hip_mirror, algorithm._hip_mirror_src = m, buffer
     else:
         m.sync_from_tianshou(buffer)
@@ -613,7 +681,10 @@ def make_hip_dqn():
     from . import dqn as D
 
     class HipDQN(_HipGlue, DQN):
-        def __init__(self, *args, device="cuda", **kwargs):
+        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, **kwargs):
+            """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer (its
+            envs) and `_update_with_batch` all-reduces the flat gradient + loss (`DataParallelDQN`); PER priorities stay
+            rank-local.  `allreduce`: None = torch.distributed, "native" = the C-ABI RCCL exchange, or a callable."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             sd = self.policy.model.state_dict()
@@ -622,6 +693,7 @@ def make_hip_dqn():
             _adam_of(self.optim)
             self._hip_engine = None
             self._hip_glue_init()
+            self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer=False)
 
         def _engine(self, c, h, w):
             if self._hip_engine is None:
@@ -673,7 +745,12 @@ def make_hip_dqn():
             weight = batch.pop("weight", None)
             obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack, as_u8=True)
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
-            loss, td = eng.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
+            runner = eng
+            if self._hip_dp_on:
+                from .distributed import DataParallelDQN
+
+                runner = self._hip_dp(DataParallelDQN, eng)
+            loss, td = runner.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
             self._iter = eng.iter
             batch.weight = td                                                     # prio-buffer, dqn.py:401
             tensors = D.flat_to_torch(eng.params, eng.c, eng.h, eng.w, eng.n_act)
@@ -762,7 +839,12 @@ def make_hip_drqn():
             weight = batch.pop("weight", None)
             obs = R.gather_stacked_obs(m.obs, m, self._hip_idx, self._hip_stack)
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
-            loss, td = eng.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
+            runner = eng
+            if self._hip_dp_on:
+                from .distributed import DataParallelDQN
+
+                runner = self._hip_dp(DataParallelDQN, eng)
+            loss, td = runner.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
             self._iter = eng.iter
             batch.weight = td                                                     # prio-buffer, dqn.py:401
             dims = self._hip_dims
@@ -1040,7 +1122,10 @@ def make_hip_sac(ref=None):
     class HipSAC(_HipGlue, SAC):
         _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("critic_lr", "critic2_optim"),
                    ("alpha_lr", "alpha"))
-        def __init__(self, *args, device="cuda", **kwargs):
+        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, **kwargs):
+            """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer and
+            `_update_with_batch` runs the four phases of `DataParallelSAC` around two all-reduces (critic gradients,
+            actor gradient + mean log-probability); replicas stay identical, PER weights rank-local."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
@@ -1053,6 +1138,7 @@ def make_hip_sac(ref=None):
                 _adam_of(o)
             self._hip_engine = None
             self._hip_glue_init()
+            self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer=False)
 
         def _engine(self):
             if self._hip_engine is None:
@@ -1112,8 +1198,13 @@ def make_hip_sac(ref=None):
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
             noise = torch.randn(len(batch), eng.act_dim)
-            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
-                                             batch.returns.reshape(-1), noise, weight)
+            runner = eng
+            if self._hip_dp_on:
+                from .distributed import DataParallelSAC
+
+                runner = self._hip_dp(DataParallelSAC, eng)
+            stats, w = runner.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                                                batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
             with torch.no_grad():
