@@ -45,7 +45,7 @@ from tianshou.utils.net.continuous import ContinuousActorProbabilistic, Continuo
 from tianshou.utils.torch_utils import policy_within_training_step  # noqa: E402
 import gymnasium as gym  # noqa: E402  (shim stub)
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("TS_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")     # (env: scratch dir of the regeneration test)
 
 
 def manager_state(buf) -> dict:
@@ -525,6 +525,43 @@ def gen_sample_random() -> None:
     np.savez_compressed(os.path.join(OUT, "sample_random.npz"), **out)
 
 
+def gen_sample_stack() -> None:
+    """ReplayBufferManager.sample_indices with frame stacking (manager.py:205-216 -> buffer_base.py:518-545,
+    `stack_num > 1 and sample_avail`): only indices with stack_num - 1 predecessors in their episode are available.
+    batch_size = 0 (all of them) and batch_size > 0 (`RandomState.choice(all_indices, bs)`; the positions the reference
+    drew are recovered from the result, the available indices being distinct)."""
+    rng = np.random.default_rng(23)
+    out: dict[str, np.ndarray] = {}
+    cases = [(40, 4, 2, 9), (48, 3, 4, 16), (4096, 64, 4, 256), (24, 2, 3, 5)]
+    for c, (size, E, stack, bs) in enumerate(cases):
+        buf = VectorReplayBuffer(size, E, stack_num=stack, sample_avail=True)
+        steps = int(rng.integers(size // E // 2, 3 * size // E))
+        for t in range(steps):
+            ids = np.flatnonzero(rng.random(E) < 0.8)
+            if t == 0 or ids.size == 0:
+                ids = np.arange(E)
+            k = ids.size
+            buf.add(Batch(obs=rng.normal(size=(k, 3)), act=rng.normal(size=(k, 1)), rew=rng.normal(size=k),
+                          terminated=rng.random(k) < 0.15, truncated=np.zeros(k, bool), obs_next=rng.normal(size=(k, 3))),
+                    buffer_ids=ids)
+        all_idx = np.asarray(buf.sample_indices(0), np.int64)
+        res = np.asarray(buf.sample_indices(bs), np.int64)
+        pos = np.searchsorted(np.sort(all_idx), res)
+        order = np.argsort(all_idx, kind="stable")
+        positions = order[pos].astype(np.int64)
+        assert np.array_equal(all_idx[positions], res)
+        key = f"c{c}_"
+        out[key + "offset"] = np.asarray(buf._extend_offset, np.int64)
+        out[key + "lengths"] = np.asarray(buf._lengths, np.int64)
+        out[key + "insertion"] = np.asarray([b._insertion_idx for b in buf.buffers], np.int64)
+        out[key + "last_index"] = np.asarray(buf.last_index, np.int64)
+        out[key + "done"] = np.asarray(buf.done, np.uint8)
+        out[key + "stack"] = np.array([stack], np.int64)
+        out[key + "all"], out[key + "positions"], out[key + "result"] = all_idx, positions, res
+    out["n_cases"] = np.array([len(cases)])
+    np.savez_compressed(os.path.join(OUT, "sample_stack.npz"), **out)
+
+
 def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
             lr: float = 1e-3, **kwargs) -> None:
     """Runs the reference NPG.update() / TRPO.update() on the MuJoCo actor-critic (examples/mujoco/mujoco_npg.py:103-128,
@@ -929,7 +966,7 @@ def gen_recurrent() -> None:
         "small": (11, 3, 64, 1, 33, 1, 2.5, False),
         "free": (37, 17, 32, 2, 9, 6, 1.0, True),
     }.items():
-        torch.manual_seed(hash(tag) % 1000)
+        torch.manual_seed(sum(tag.encode()))        # a literal function of the tag (str hashes are randomised per process)
         rng = np.random.default_rng(len(tag))
         actor = RecurrentActorProb(layer_num=layers, state_shape=(obs_dim,), action_shape=(act_dim,), hidden_layer_size=hidden,
                                    max_action=max_action, unbounded=unbounded)
@@ -1011,6 +1048,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_sched":
         gen_ppo_sched()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "sample_stack":
+        gen_sample_stack()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sample_random":
         gen_sample_random()
         return
@@ -1026,9 +1066,11 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "sac":
         gen_sac_all()
         return
-    gen_returns_kat()
-    gen_buffer_index()
-    gen_segtree_per()
+    only_ppo = len(sys.argv) > 1 and sys.argv[1] == "ppo"
+    if not only_ppo:
+        gen_returns_kat()
+        gen_buffer_index()
+        gen_segtree_per()
     # mujoco-example style (examples/mujoco/mujoco_ppo.py:28-62) without recompute
     gen_ppo("mujoco", E=8, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=3, seed=0,
             n_updates=2, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25,
@@ -1041,8 +1083,11 @@ def main() -> None:
     gen_ppo("a2c", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=2,
             n_updates=2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99,
             return_scaling=True, lr=7e-4, max_batchsize=256)
+    if only_ppo:
+        return
     gen_ppo_sched()
     gen_sample_random()
+    gen_sample_stack()
     gen_buffer_add()
     gen_dqn_all()
     gen_sac_all()

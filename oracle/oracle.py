@@ -337,3 +337,16 @@ def sample_indices_random(offset, lengths, u_buffer, within) -> np.ndarray:
         out.append(offset[e] + within[pos:pos + n])
         pos += n
     return np.concatenate(out) if out else np.array([], np.int64)
+
+
+def sample_indices_stack(state: "BufferState", insertion_idx, stack_num: int, positions=None) -> np.ndarray:
+    """ReplayBufferManager.sample_indices with `stack_num > 1 and sample_avail` (manager.py:205-216; per sub-buffer
+    buffer_base.py:532-545): all indices in ring order, minus those whose (stack_num - 2)-fold predecessor equals its own
+    predecessor, i.e. that have fewer than stack_num - 1 earlier frames in their episode.  `positions` (None: batch_size
+    0) = the draws of `RandomState.choice(all_indices, bs)` as positions into the available indices."""
+    all_idx = sample_indices_all(state.offset, state.lengths, insertion_idx)
+    p = all_idx
+    for _ in range(stack_num - 2):
+        p = state.prev(p)
+    avail = all_idx[p != state.prev(p)]
+    return avail if positions is None else avail[_i64(positions)]

@@ -190,9 +190,20 @@ def test_hip_ppo_load_state_dict_rebuilds_the_engine():
     np.random.seed(1)
     s2 = algo.update(buf, 32, 2)                          # same data, same permutations, same restored state
     assert s1.loss.mean == s2.loss.mean and s1.vf_loss.max == s2.vf_loss.max
-    # loading into a sub-module only (algorithm.policy.load_state_dict) is caught as well
+    # loading into a sub-module only (algorithm.policy.load_state_dict) is caught as well (parameter version counters),
+    # and -- ADVICE r2 -- the engine's Adam moments are flushed into torch.optim first, so the rebuilt engine continues
+    # from them instead of restarting the bias correction from zero moments
+    eng = algo._hip_engine
+    step_before, m_before = eng.adam_step, eng.adam_m.clone()
+    assert step_before > 0 and float(m_before.abs().max()) > 0
     algo.policy.load_state_dict(copy.deepcopy(algo.policy.state_dict()))
     assert algo._hip_engine is None
+    rebuilt = algo._engine()
+    assert rebuilt is not eng and rebuilt.adam_step == step_before and torch.equal(rebuilt.adam_m, m_before)
+    import pickle
+
+    pickle.dumps(algo.policy)                             # sub-modules carry no closures (persistence.py:106 saves the policy)
+    assert not algo.policy._load_state_dict_post_hooks
 
 
 def test_full_c2_configuration_against_oracle():

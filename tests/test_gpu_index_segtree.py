@@ -234,6 +234,29 @@ def test_random_sample_indices_replays_the_reference_draws():
                            ).sample_indices(bad.size, u_buffer=g["c0_r0_u"], within=bad)
 
 
+def test_stacked_sample_indices_match_the_reference():
+    """a1, frame-stacking branch (manager.py:205-216, buffer_base.py:532-545): available indices of a stack_num > 1 /
+    sample_avail buffer and the reference's seeded `choice(all_indices, bs)` (its positions replayed), bit for bit."""
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    g = load("sample_stack.npz")
+    for c in range(int(g["n_cases"][0])):
+        k = f"c{c}_"
+        off, L = g[k + "offset"], g[k + "lengths"]
+        B = int(off[-1])
+        buf = DeviceReplayBuffer(offset=off, last_index=g[k + "last_index"], lengths=L, insertion=g[k + "insertion"],
+                                 rew=np.zeros(B), terminated=g[k + "done"], truncated=np.zeros(B, bool))
+        stack = int(g[k + "stack"][0])
+        allv = buf.sample_indices_stacked(0, stack)
+        assert allv.dtype == torch.int64 and np.array_equal(allv.cpu().numpy(), g[k + "all"]), k
+        res = buf.sample_indices_stacked(int(g[k + "positions"].size), stack, positions=g[k + "positions"])
+        assert np.array_equal(res.cpu().numpy(), g[k + "result"]), k
+        drawn = buf.sample_indices_stacked(1000, stack, generator=torch.Generator(device="cuda").manual_seed(c))
+        assert drawn.numel() == 1000 and np.isin(drawn.cpu().numpy(), g[k + "all"]).all()
+    with pytest.raises(ValueError):
+        buf.sample_indices_stacked(3, stack, positions=[0, 1, 10 ** 6])
+
+
 def test_random_sample_indices_device_rng_distribution():
     """Without supplied draws the sampler uses torch's device generator: sub-buffer frequencies follow lengths / sum,
     every index lies inside the filled part of its sub-buffer, output is grouped by sub-buffer like the reference's."""

@@ -163,6 +163,20 @@ def test_random_sample_indices_restatement_matches_reference():
             assert out.dtype == np.int64 and np.array_equal(out, g[k + "result"]), k
 
 
+def test_stacked_sample_indices_restatement_matches_reference():
+    """manager.py:205-216 / buffer_base.py:532-545 (`stack_num > 1 and sample_avail`): available indices (batch_size 0) and
+    the reference's `RandomState.choice(all_indices, bs)` result through the positions it drew."""
+    g = load("sample_stack.npz")
+    for c in range(int(g["n_cases"][0])):
+        k = f"c{c}_"
+        B = int(g[k + "offset"][-1])
+        st = O.BufferState(g[k + "offset"], g[k + "last_index"], g[k + "lengths"], g[k + "insertion"], np.zeros(B),
+                           g[k + "done"], np.zeros(B, np.uint8), done=g[k + "done"])
+        stack = int(g[k + "stack"][0])
+        assert np.array_equal(O.sample_indices_stack(st, g[k + "insertion"], stack), g[k + "all"]), k
+        assert np.array_equal(O.sample_indices_stack(st, g[k + "insertion"], stack, g[k + "positions"]), g[k + "result"]), k
+
+
 # ------------------------------------------------------------------------------------ PPO path
 def _cfg_from(g):
     c = dict(zip([str(k) for k in g["cfg_keys"]], g["cfg_vals"]))

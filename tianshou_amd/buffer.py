@@ -449,8 +449,38 @@ class DeviceReplayBuffer:
             _lib.current_stream(self.device)))
         return out, n
 
+    def sample_indices_stacked(self, batch_size: int, stack_num: int, *, positions=None, generator=None) -> torch.Tensor:
+        """ReplayBufferManager.sample_indices for a frame-stacking buffer (`stack_num > 1 and sample_avail`,
+        manager.py:205-216 -> buffer_base.py:532-545): only indices with stack_num - 1 earlier frames in their episode are
+        available -- all indices in sub-buffer / ring order, minus those whose (stack_num - 2)-fold predecessor equals its
+        own predecessor (the prev() index kernel; the compaction is a device boolean select).
+        batch_size == 0 -> all available indices; > 0 -> `RandomState.choice(all_indices, batch_size)`: pass the reference's
+        draws as `positions` (int64[bs], positions into the available indices) to replay a seeded run, otherwise they come
+        from torch's device generator."""
+        if stack_num < 2:
+            raise ValueError("sample_indices_stacked is the stack_num > 1 branch")
+        if batch_size is None or batch_size < 0:
+            raise NotImplementedError("sample_indices(None / negative) is not on the device path")
+        all_idx = self.sample_indices(0)
+        p = all_idx
+        for _ in range(stack_num - 2):
+            p = self.prev(p)
+        avail = all_idx[p != self.prev(p)]
+        if batch_size == 0:
+            return avail
+        if avail.numel() == 0:
+            return avail
+        if positions is None:
+            positions = torch.randint(0, avail.numel(), (int(batch_size),), device=self.device, generator=generator)
+        else:
+            positions = _i64_dev(positions, self.device).reshape(-1)
+            if positions.numel() != batch_size or int(positions.min()) < 0 or int(positions.max()) >= avail.numel():
+                raise ValueError("positions must be batch_size draws inside the available indices")
+        return avail[positions]
+
     def sample_indices(self, batch_size: int | None, *, u_buffer=None, within=None, generator=None) -> torch.Tensor:
-        """ReplayBufferManager.sample_indices (manager.py:200-234) for stack_num == 1.
+        """ReplayBufferManager.sample_indices (manager.py:200-234) for stack_num == 1 (frame-stacking buffers with
+        `sample_avail`: `sample_indices_stacked`).
 
         batch_size == 0 -> every valid index, sub-buffer-major and time-ordered.
         batch_size > 0  -> sub-buffer with probability proportional to its length, then uniform inside it, concatenated

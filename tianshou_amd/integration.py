@@ -84,9 +84,9 @@ class _HipGlue:
         if eng is not None and not self.__dict__.get("_hip_in_update", False):
             seen = self.__dict__.get("_hip_versions")
             if seen is not None and seen != self._hip_current_versions():
+                self.__dict__["_hip_versions"] = None          # (the flush reads `_hip_engine` itself: no re-entry)
                 self._hip_flush()
                 self.__dict__["_hip_engine_obj"] = eng = None
-                self.__dict__["_hip_versions"] = None
                 self._hip_adam_dirty = False
         return eng
 
