@@ -496,12 +496,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
 #pragma unroll
         for (int i = 0; i < XI; ++i)
             if (CK * XROW % THREADS == 0 || xmm[i] < CK)
-                *reinterpret_cast<u32x4*>(&Xs[slot][xmm[i] * BKT + XPIECE * xq[i]]) = xr[i];
+                *reinterpret_cast<u32x4*>(&Xs[slot][U8 ? xmm[i] * BKT + XPIECE * xq[i]
+                                                           : ((XPIECE * xq[i] / 32) * CK + xmm[i]) * 32 + (XPIECE * xq[i]) % 32]) = xr[i];
 #pragma unroll
         for (int i = 0; i < DI; ++i) {
             const int e = tid + THREADS * i, mm = e / DROW, n4 = e - mm * DROW;
             if (CK * DROW % THREADS == 0 || mm < CK)
-                *reinterpret_cast<f32x4*>(&Ds[slot][mm * BN + 4 * n4]) = dok[i] ? dr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&Ds[slot][((4 * n4 / 32) * CK + mm) * 32 + (4 * n4) % 32]) =
+                    dok[i] ? dr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -533,14 +535,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
         if (c + 1 < c_end) lstore((c + 1) & 1);
         gload(min(c + 2, c_last));
         if (c + 3 < c_end) rowinfo(c + 3);         // slot (c + 3) & 3 was last read for chunk c - 1, three barriers ago
-        const xel* xs = Xs[c & 1] + h * BKT + wm * TM * 32 + r;
-        const float* ds = Ds[c & 1] + h * BN + wn * TN * 32 + r;
+        // LDS tiles are [32-column tile][pixel][32]: the operands of consecutive k-steps of one wave tile lie 256 bytes
+        // apart, so every ds_read carries its address as an immediate offset (row-major [pixel][BKT] put them 2-4 KB
+        // apart and cost a v_add per read -- VALU slots that the fp32 MFMA cannot overlap)
+        // (uint8 frames keep row-major [pixel][BKT] rows: 16-byte pieces of a tiled layout would collide in the banks)
+        constexpr int XT = U8 ? 32 : CK * 32, XS = U8 ? BKT : 32;           // element strides: 32-column tile, pixel row
+        const xel* xs = Xs[c & 1] + wm * TM * XT + h * XS + r;
+        const float* ds = Ds[c & 1] + (wn * TN * CK + h) * 32 + r;
         xel anext[TM];                             // operands of step j + 1 are fetched before the MFMAs of step j issue
         float bnext[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[tm * 32];
+        for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[tm * XT];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[tn * 32];
+        for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[tn * CK * 32];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             float av[TM], bv[TN];
@@ -550,9 +557,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
             for (int tn = 0; tn < TN; ++tn) bv[tn] = bnext[tn];
             if (j < 15) {
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[2 * (j + 1) * BKT + tm * 32];
+                for (int tm = 0; tm < TM; ++tm) anext[tm] = xs[tm * XT + 2 * (j + 1) * XS];
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[2 * (j + 1) * BN + tn * 32];
+                for (int tn = 0; tn < TN; ++tn) bnext[tn] = ds[(tn * CK + 2 * (j + 1)) * 32];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad2_kernel(Wgrad2Args a)
         }
         if (kt == 0) {
 #pragma unroll
-            for (int mm = bp; mm < CK; mm += THREADS / BN) bsum += Ds[c & 1][mm * BN + bn];
+            for (int mm = bp; mm < CK; mm += THREADS / BN) bsum += Ds[c & 1][((bn / 32) * CK + mm) * 32 + bn % 32];
         }
     }
 

@@ -447,10 +447,10 @@ __global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* _
 // value loss (ppo.py:198-208, a2c.py:270) and its gradient w.r.t. the value head, scaled by vf_coef
 __global__ __launch_bounds__(1024) void ppo_wide_critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret,
                                                                     const float* __restrict__ v_old, float eps_clip, int value_clip,
-                                                                    float vf_coef, int64_t B, float* __restrict__ d_head,
-                                                                    float* __restrict__ loss) {
+                                                                    float vf_coef, int64_t B, float inv_b,
+                                                                    float* __restrict__ d_head, float* __restrict__ loss) {
+    // inv_b = 1 / (global minibatch size): the same scale as the actor part (data-parallel shards sum to the batch mean)
     __shared__ float red[1024];
-    const float inv_b = 1.f / (float)B;
     float ls = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += 1024) {
         const float value = v_head[b * HEAD], r = ret[b];
@@ -803,7 +803,7 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
     // ---- critic
     if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
     hipLaunchKernelGGL(ppo_wide_critic_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, returns, v_old, (float)hp->eps_clip,
-                       a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, d_head, losses_out4 + 2);
+                       a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, inv_b, d_head, losses_out4 + 2);
     TS_LAUNCH_CHECK();
     if (int rc = backward(s, ws, n, critic, x, a, d_head, grad + Pa, bw, B)) return rc;
     hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + n.off[3], A, (float)hp->vf_coef,
