@@ -69,6 +69,13 @@ class SACTrainingStats:
     train_time: float = 0.0
 
 
+@dataclass
+class SimpleLossTrainingStats:
+    """tianshou/algorithm/modelfree/reinforce.py:63-66."""
+    loss: float
+    train_time: float = 0.0
+
+
 class RunningMeanStd:
     """tianshou/utils/statistics.py:81-91: the three scalars the wrappers mirror."""
 
@@ -288,6 +295,46 @@ class SAC(Algorithm):
         return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
 
 
+class DQNet(nn.Module):
+    """env/atari/atari_network.py:60-122 without extra layers: `net` = Sequential(Sequential(conv, ReLU, conv, ReLU, conv,
+    ReLU, Flatten), Linear, ReLU, Linear) -- the nesting that yields the reference's state_dict keys."""
+
+    def __init__(self, c, h, w, n_act):
+        super().__init__()
+        cnn = nn.Sequential(nn.Conv2d(c, 32, 8, 4), nn.ReLU(), nn.Conv2d(32, 64, 4, 2), nn.ReLU(), nn.Conv2d(64, 64, 3, 1),
+                            nn.ReLU(), nn.Flatten())
+        with torch.no_grad():
+            feat = int(cnn(torch.zeros(1, c, h, w)).shape[1])
+        self.net = nn.Sequential(cnn, nn.Linear(feat, 512), nn.ReLU(), nn.Linear(512, n_act))
+
+
+class DiscreteQLearningPolicy(nn.Module):
+    """modelfree/dqn.py:39-143: `model`, `is_within_training_step`."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+        self.is_within_training_step = False
+
+
+class DQN(Algorithm):
+    """modelfree/dqn.py:190-285, 330-363: attribute names as the reference stores them."""
+
+    def __init__(self, *, policy, lr=1e-4, gamma=0.99, n_step_return_horizon=1, target_update_freq=0, is_double=True,
+                 huber_loss_delta=None, max_grad_norm=None):
+        import copy
+
+        super().__init__(policy)
+        self.optim = self._create_optimizer(policy, lr, max_grad_norm)
+        self.gamma, self.n_step, self.target_update_freq = gamma, n_step_return_horizon, target_update_freq
+        self.is_double, self.huber_loss_delta = is_double, huber_loss_delta
+        self._iter = 0
+        self.model_old = EvalModeModuleWrapper(copy.deepcopy(policy.model)) if target_update_freq > 0 else None
+
+    def update(self, buffer, sample_size):
+        return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
 # ------------------------------------------------------------------------------------------------ replay buffer
 class _SubBuffer:
     """The per-environment ReplayBuffer inside a manager: `_insertion_idx`, `__len__`, `maxsize`."""
@@ -313,7 +360,8 @@ class VectorReplayBuffer:
     `unfinished_index`, `sample_indices` and `sample` the wrappers rely on."""
 
     def __init__(self, total_size, buffer_num, *, obs_shape, act_shape, obs_dtype=np.float32, act_dtype=np.float32,
-                 seed=0):
+                 seed=0, stack_num=1):
+        self.stack_num = stack_num
         size = int(np.ceil(total_size / buffer_num))
         self.buffer_num, self.maxsize = buffer_num, size * buffer_num
         self.buffers = [_SubBuffer(size) for _ in range(buffer_num)]
@@ -381,3 +429,36 @@ class VectorReplayBuffer:
         idx = self.sample_indices(batch_size)
         return Batch(obs=self.obs[idx], act=self.act[idx], rew=self.rew[idx], terminated=self.terminated[idx],
                      truncated=self.truncated[idx], done=self.done[idx], obs_next=self.obs_next[idx]), idx
+
+
+class PrioritizedVectorReplayBuffer(VectorReplayBuffer):
+    """data/buffer/prio.py:17-107 as the hooks see it: `sample` attaches the importance weights
+    (weight / min_prio) ** -beta / max (prio.py:69-79, 104-106), `update_weight(index, new_weight)` stores
+    (|new_weight| + eps) ** alpha and tracks max / min of the un-exponentiated values (prio.py:81-94); new slots get
+    max_prio ** alpha (prio.py:44-47).  Sampling itself is the uniform stand-in of the base class: the sum-tree descent is
+    pinned elsewhere (tests/golden/segtree_per.npz)."""
+
+    def __init__(self, *a, alpha=0.6, beta=0.4, **kw):
+        super().__init__(*a, **kw)
+        self._alpha, self._beta = alpha, beta
+        self._max_prio = self._min_prio = 1.0
+        self.prio = np.zeros(self.maxsize)
+        self.__eps = np.finfo(np.float32).eps.item()
+        self.weight_updates = []
+
+    def add(self, batch, buffer_ids=None):
+        ptrs = super().add(batch, buffer_ids)
+        self.prio[ptrs] = self._max_prio ** self._alpha
+        return ptrs
+
+    def sample(self, batch_size):
+        batch, idx = super().sample(batch_size)
+        w = (self.prio[idx] / self._min_prio) ** (-self._beta)
+        batch.weight = w / np.max(w)
+        return batch, idx
+
+    def update_weight(self, index, new_weight):
+        w = np.abs(new_weight.detach().cpu().numpy() if isinstance(new_weight, torch.Tensor) else np.asarray(new_weight)) + self.__eps
+        self.prio[np.asarray(index)] = w ** self._alpha
+        self._max_prio, self._min_prio = max(self._max_prio, float(w.max())), min(self._min_prio, float(w.min()))
+        self.weight_updates.append((np.asarray(index).copy(), w.copy()))

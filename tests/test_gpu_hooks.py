@@ -309,3 +309,82 @@ def test_hip_sac_hooks_against_oracle():
     assert float(stt["step"]) == 4.0 and stt["exp_avg"].shape == w.shape and stt["exp_avg"].device == w.device
     np.testing.assert_allclose(stt["exp_avg"].cpu().numpy(), st.opt_actor.m["w1"].numpy(), rtol=1e-3, atol=1e-7)
     assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.rew.cpu().numpy(), buf.rew)
+
+
+# ------------------------------------------------------------------------------------ HipDQN
+def _dqn_hook_run(huber):
+    from oracle import oracle_dqn as OD
+    from tianshou_amd import dqn as D
+    from tianshou_amd.integration import make_hip_dqn
+
+    c, h, w, A, E, size, B = 4, 44, 36, 3, 4, 40, 32
+    HipDQN = make_hip_dqn(ref=SI)
+    torch.manual_seed(5)
+    model = SI.DQNet(c, h, w, A)
+    with torch.no_grad():
+        model.net[0][0].weight.mul_(1.0 / 255.0)     # uint8 frames (0..255) times default-init weights: keep Q values O(1)
+    algo = HipDQN(policy=SI.DiscreteQLearningPolicy(model), lr=1e-4, gamma=0.97, n_step_return_horizon=3, target_update_freq=2,
+                  is_double=True, huber_loss_delta=huber, device="cuda").to("cuda")
+    sd = model.state_dict()
+    p0 = {k: sd[n].detach().cpu().clone() for k, n in zip(OD.PARAM_ORDER, D.TIANSHOU_KEYS)}
+    ocfg = OD.DQNConfig(gamma=0.97, n_step=3, target_update_freq=2, is_double=True, huber_delta=huber, lr=1e-4)
+    st = OD.DQNState.create(p0, ocfg)
+    buf = SI.PrioritizedVectorReplayBuffer(E * size, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                           seed=2, stack_num=c, alpha=0.6, beta=0.4)
+    rng = np.random.default_rng(3)
+
+    def fill(n):
+        for _ in range(n):
+            term = rng.random(E) < 0.08
+            buf.add(SI.Batch(obs=rng.integers(0, 256, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+
+    def sample(bs):
+        batch, idx = orig_sample(bs)
+        seen.append((idx.copy(), np.asarray(batch.weight).copy()))
+        return batch, idx
+
+    buf.sample = sample
+    eps = np.finfo(np.float32).eps.item()
+    for u in range(5):
+        fill(25 if u == 0 else 9)                   # 25 + 4 * 9 = 61 adds per sub-buffer of 40 slots: wrapped by update 2
+        stat = algo.update(buf, B)
+        idx, w_is = seen[-1]
+        m = algo._hip_mirror
+        assert np.array_equal(m.obs.cpu().numpy(), buf.obs) and np.array_equal(m.rew.cpu().numpy(), buf.rew)
+        assert np.array_equal(m.h_insertion, [b._insertion_idx for b in buf.buffers])          # incl. wrap-around
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+        ret = OD.preprocess(st, ocfg, bstate, buf.obs, idx, c, obs_next_frames=buf.obs_next)
+        obs = OD.stacked_frames(bstate, buf.obs, idx, c)
+        loss_o, td_o = OD.update_with_batch(st, ocfg, obs, buf.act[idx], ret, None if huber is not None else w_is)
+        np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5)
+        upd_idx, upd_w = buf.weight_updates[-1]                                       # _postprocess_batch -> update_weight
+        assert np.array_equal(upd_idx, idx)
+        np.testing.assert_allclose(upd_w, np.abs(td_o.numpy()) + eps, rtol=1e-5, atol=2e-5)
+        assert algo._iter == st.iter == u + 1
+    tensors = [p.detach().cpu() for p in model.parameters()]
+    for t, k in zip(tensors, OD.PARAM_ORDER):      # five Adam steps of lr 1e-4: compare on the scale of a fraction of a step
+        np.testing.assert_allclose(t.numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    old = [p.detach().cpu() for p in algo.model_old.parameters()]
+    for t, k in zip(old, OD.PARAM_ORDER):          # the lagged network was synced at updates 0, 2, 4 (dqn.py:283-285)
+        np.testing.assert_allclose(t.numpy(), st.params_old[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    opt_state = algo.optim._optim.state[next(iter(model.parameters()))]
+    assert float(opt_state["step"]) == 5.0
+
+
+@pytest.mark.parametrize("huber", [None, 1.0], ids=["weighted_mse", "huber"])
+def test_hip_dqn_hooks_against_oracle(huber):
+    """HipDQN (integration.make_hip_dqn over the stand-ins) on the real engine, the Atari layout of
+    examples/atari/atari_dqn.py:137-142: single uint8 frames per slot with stack_num = 4, a prioritized buffer, n-step 3,
+    double-Q with a lagged network synced every 2 updates.  Per update: `_preprocess_batch` (n-step target through the
+    device mirror, dqn.py:257-275) -> `_update_with_batch` (importance-weighted MSE or Huber, dqn.py:381-404) ->
+    `_postprocess_batch` (TD errors reach `buffer.update_weight`, prio.py:81-94), against oracle_dqn fed with the same
+    sampled indices.  The host buffer keeps growing between updates until every sub-buffer has wrapped: the mirror's
+    incremental sync (write log) follows."""
+    _dqn_hook_run(huber)

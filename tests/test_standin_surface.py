@@ -174,3 +174,52 @@ def test_sac_standin_has_the_reference_surface():
     A, B = make_hip_sac(), make_hip_sac(ref=SI)
     for name in ("_preprocess_batch", "_update_with_batch", "_engine"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_dqn_standin_has_the_reference_surface():
+    """DQN / DQNet / PrioritizedVectorReplayBuffer stand-ins against the real classes: state_dict keys and shapes, the
+    hyper-parameter attribute names HipDQN reads, the lagged network wrapper, the optimizer, and PER weights after the
+    same add / update_weight sequence."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.dqn import DQN, DiscreteQLearningPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.data import Batch, PrioritizedVectorReplayBuffer
+    from tianshou.env.atari.atari_network import DQNet
+
+    real = DQN(policy=DiscreteQLearningPolicy(model=DQNet(c=4, h=44, w=36, action_shape=3), action_space=gym.spaces.Discrete(3)),
+               optim=AdamOptimizerFactory(lr=1e-4), gamma=0.97, n_step_return_horizon=3, target_update_freq=5, is_double=True,
+               huber_loss_delta=1.0)
+    fake = SI.DQN(policy=SI.DiscreteQLearningPolicy(SI.DQNet(4, 44, 36, 3)), lr=1e-4, gamma=0.97, n_step_return_horizon=3,
+                  target_update_freq=5, is_double=True, huber_loss_delta=1.0)
+    for a, b in ((real.policy.model, fake.policy.model), (real.model_old.module, fake.model_old.module)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    for name in ("gamma", "n_step", "target_update_freq", "is_double", "huber_loss_delta", "_iter"):
+        assert getattr(real, name) == getattr(fake, name), name
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm
+    assert [p.numel() for p in real.optim._optim.param_groups[0]["params"]] == \
+        [p.numel() for p in fake.optim._optim.param_groups[0]["params"]]
+
+    rb = PrioritizedVectorReplayBuffer(24, 2, alpha=0.6, beta=0.4)
+    fb = SI.PrioritizedVectorReplayBuffer(24, 2, obs_shape=(3,), act_shape=(), act_dtype=np.int64, alpha=0.6, beta=0.4)
+    rng = np.random.default_rng(0)
+    for _ in range(9):
+        kw = dict(obs=rng.normal(size=(2, 3)).astype(np.float32), act=rng.integers(0, 3, 2), rew=rng.normal(size=2),
+                  terminated=rng.random(2) < 0.2, truncated=np.zeros(2, bool), obs_next=rng.normal(size=(2, 3)).astype(np.float32))
+        rb.add(Batch(**kw))
+        fb.add(SI.Batch(**kw))
+    idx = np.array([0, 3, 13, 14])
+    td = np.array([0.5, -2.0, 0.01, 3.0])
+    rb.update_weight(idx, td)
+    fb.update_weight(idx, td)
+    assert np.allclose(np.asarray(rb.weight[idx]), fb.prio[idx]) and rb._max_prio == fb._max_prio and rb._min_prio == fb._min_prio
+    assert np.allclose(rb.get_weight(idx) / 1.0, (fb.prio[idx] / fb._min_prio) ** (-0.4))
+    from tianshou_amd.integration import make_hip_dqn
+
+    A, B = make_hip_dqn(), make_hip_dqn(ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_layout"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name

@@ -671,12 +671,13 @@ def _mirror(algorithm, buffer, device):
     return m
 
 
-def make_hip_dqn():
+def make_hip_dqn(ref=None):
     """Returns HipDQN(DQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, 381-404) on the engine.
     Supported model: DQNet(c, h, w, n_act) (atari_network.py:60-122), Adam; buffer either stores whole [c, h, w]
-    observations or single frames with stack_num = c (save_only_last_obs); obs_next optional."""
-    from tianshou.algorithm.modelfree.dqn import DQN
-    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+    observations or single frames with stack_num = c (save_only_last_obs); obs_next optional.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    DQN = _ref(ref, "tianshou.algorithm.modelfree.dqn", "DQN")
+    SimpleLossTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "SimpleLossTrainingStats")
 
     from . import dqn as D
 
