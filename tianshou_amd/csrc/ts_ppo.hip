@@ -1019,14 +1019,20 @@ __device__ __forceinline__ void tile128_write(float* T, int row0, const f32x16& 
 // Slab stores are write-through (relaxed agent-scope atomic store = `global_store_dword ... sc1`): the 23 MB of slabs
 // would otherwise sit dirty in the eight L2s until the kernel boundary and be written back there, in front of the
 // reduction kernel that reads them (MI355X_MICROARCH.md, "boundary" / "publish-large" rows).
+// The slab pointer is laundered through an empty asm in net_wgrad (hoisting, see there), which also hides from the compiler
+// that it points to global memory: without the explicit address-space cast below the stores are FLAT stores, which count on
+// the LDS counter (lgkmcnt) as well and stall the operand reads of the next gradient tile behind them.
+using gfloat_ptr = __attribute__((address_space(1))) float*;
 #ifndef TS_SLAB_PLAIN_STORES
-__device__ __forceinline__ void slab_st(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void slab_st(float* p, float v) {
+    __hip_atomic_store((gfloat_ptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #else
-__device__ __forceinline__ void slab_st(float* p, float v) { *p = v; }
+__device__ __forceinline__ void slab_st(float* p, float v) { *(gfloat_ptr)p = v; }
 #endif
 
 __device__ __forceinline__ void store_acc(float* p, float v, bool first) {
-    if (!first) v += *p;
+    if (!first) v += *(gfloat_ptr)p;
     slab_st(p, v);
 }
 
@@ -1300,7 +1306,7 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
             for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, c[r]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, p[((r & 3) + 8 * (r >> 2)) * HID] + c[r]);
+            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, ((gfloat_ptr)p)[((r & 3) + 8 * (r >> 2)) * HID] + c[r]);
         }
         if (tN == 0 && h == 0) store_acc(slab + SL.b2[net] + 32 * tM + i, rs, first);
     }
@@ -1332,7 +1338,7 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
                 for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, c[r]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, p[((r & 3) + 8 * (r >> 2)) * KP] + c[r]);
+                for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, ((gfloat_ptr)p)[((r & 3) + 8 * (r >> 2)) * KP] + c[r]);
             }
         }
     } else {
