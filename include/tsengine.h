@@ -885,14 +885,6 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
                   int64_t act_dim, const ts_td3_hparams* hp, float* stats_out3, float* weight_out, float* grads_out,
                   ts_stream_t stream);
 
-/* Diagnostics (scripts/ only): shader-clock timestamps of workgroup 0 / wave 0 at the phase
- * boundaries of one ppo_step_kernel launch (h_cycles int64[n_marks >= 18], host).  Synchronises
- * the stream. */
-int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
-                             const float* rec, const int64_t* perm_rows, int64_t n_rows,
-                             const ts_ppo_hparams* hp, int64_t* h_cycles, int64_t n_marks,
-                             ts_stream_t stream);
-
 /* ---- data-parallel exchange ------------------------------------------------------------------
  * One process per GPU; the reference has no distributed path (its only multi-GPU mechanism is single-process
  * nn.DataParallel, tianshou/utils/net/common.py:473-515).  In-place sum all-reduce of a flat fp32 buffer over RCCL

@@ -1,6 +1,11 @@
-"""Phase timing of one ppo_step_kernel launch (workgroup 0, wave 0), shader-clock cycles."""
+"""Phase timing of one ppo_step_kernel launch (workgroup 0, wave 0), shader-clock cycles.
+Builds its own copy of the library with -DTS_PHASE_MARKS (the shipped one carries neither the marks nor the entry point)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.getcwd())
+if "TS_LIB_PATH" not in os.environ:
+    from tianshou_amd import build as _b
+    os.environ["TS_EXTRA_FLAGS"] = "ts_ppo.hip:-DTS_PHASE_MARKS"
+    os.environ["TS_LIB_PATH"] = _b.build_library(out=os.path.join(_b.LIBDIR, "libtsengine_marks.so"))
 import numpy as np, torch
 import bench
 from tianshou_amd import _lib

@@ -125,3 +125,37 @@ def test_uint8_observations_give_bitwise_identical_results():
     assert torch.equal(v8, v32) and torch.equal(lp8, lp32)
     assert torch.equal(e8.step(obs8, act, adv, ret, lp, vo), e32.step(obs8.float(), act, adv, ret, lp, vo))
     assert torch.equal(e8.params, e32.params)
+
+
+def test_values_of_next_observations_through_next_index_equal_a_second_pass():
+    """Atari buffer layout (single frames, stack through prev(), obs_next read as the observation at next(index),
+    buffer_base.py:624-626): `preprocess` takes V(s') of transition i from V(s) of transition next(i) instead of running the
+    trunk a second time (a2c.py:126-128 does).  Bit-identical to the explicit second pass, on a wrapped, partly filled buffer
+    with episode ends -- chunked differently on purpose (a row's value does not depend on its batch)."""
+    from tianshou_amd import ppo_cnn as PC
+    from tianshou_amd.buffer import DeviceReplayBuffer
+    from tianshou_amd.dqn import gather_obs_nhwc
+
+    c, h, w, A, E, size = 4, 44, 36, 5, 3, 40
+    rng = np.random.default_rng(8)
+    B = E * size
+    lengths = np.array([40, 23, 40], np.int64)                  # sub-buffer 1 partly filled
+    insertion = np.array([17, 23, 0], np.int64)                 # sub-buffer 0 wrapped, 2 exactly full
+    offset = np.arange(E + 1, dtype=np.int64) * size
+    last = offset[:-1] + (insertion - 1) % size
+    term = rng.random(B) < 0.07
+    buf = DeviceReplayBuffer(offset=offset, last_index=last, lengths=lengths, insertion=insertion, rew=rng.normal(size=B),
+                             terminated=term, truncated=np.zeros(B, bool))
+    frames = torch.as_tensor(rng.integers(0, 256, size=(B, h, w), dtype=np.uint8)).cuda()
+    act = torch.as_tensor(rng.integers(0, A, size=B)).cuda()
+    p = OC.init_params(c, h, w, A, seed=2)
+    eng = PC.CnnPPOEngine(c, h, w, A, PC.flat_from_torch([p[k] for k in OC.PARAM_ORDER], c, h, w, A),
+                          engine_cfg(OP.PPOConfig(return_scaling=False)))
+    pre = eng.preprocess(buf, frames, act, c, obs_next_frames=None, chunk=29)
+    idx = pre["indices"]
+    assert idx.numel() == int(lengths.sum())
+    v_s = eng.infer(gather_obs_nhwc(frames, buf, idx, c, as_u8=True))[0]
+    v_next = eng.infer(gather_obs_nhwc(frames, buf, buf.next(idx), c, as_u8=True))[0]          # the explicit second pass
+    assert torch.equal(pre["v_s"], v_s)
+    ref = PC.gae_and_return_scaling(eng, buf, idx, v_s, v_next)
+    assert torch.equal(pre["returns"], ref["returns"]) and torch.equal(pre["adv"], ref["adv"])

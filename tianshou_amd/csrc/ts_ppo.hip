@@ -428,10 +428,16 @@ struct StepArgs {
     long long* dbg;           // optional phase timestamps of workgroup 0 / wave 0 (diagnostics)
 };
 
+// Phase timestamps are a build option (-DTS_PHASE_MARKS: scripts/gpu_step_phases.py builds its own copy of the library
+// with it); the shipped kernels carry no s_memtime and the shipped library no diagnostic entry point.
+#ifdef TS_PHASE_MARKS
 #define TS_MARK(g, k)                                                                  \
     do {                                                                               \
         if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0) (g).dbg[(k)] = (long long)__builtin_readcyclecounter(); \
     } while (0)
+#else
+#define TS_MARK(g, k) do { } while (0)
+#endif
 
 // transposed tile write: lane (j, h) register r -> T[F(r,h)][j]
 __device__ __forceinline__ void tile_write(float* tile, const f32x16& v, int j, int h) {
@@ -2082,6 +2088,7 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
                     reinterpret_cast<float*>(base + wl.sumsq), nullptr, s, parts);
 }
 
+#ifdef TS_PHASE_MARKS
 int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim,
                              const float* rec, const int64_t* perm_rows, int64_t n_rows,
                              const ts_ppo_hparams* hp, int64_t* h_cycles, int64_t n_marks,
@@ -2121,6 +2128,7 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     for (int64_t k = 0; k < n_marks && k < 64; ++k) h_cycles[k] = host[k];
     return TS_OK;
 }
+#endif
 
 // One data-parallel gradient step behind ONE call: local gradient -> sum all-reduce of [grad | loss parts] -> clip + Adam.
 int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m, float* adam_v, int64_t adam_step,

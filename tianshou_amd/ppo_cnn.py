@@ -158,11 +158,18 @@ class CnnPPOEngine:
         for lo in range(0, n, chunk):
             sl = slice(lo, min(lo + chunk, n))
             v_s[sl], logp_old[sl] = self.infer(gather_obs_nhwc(frames, buffer, idx[sl], stack_num, as_u8=True), act_b[sl])
-            if obs_next_frames is None:
-                nxt = gather_obs_nhwc(frames, buffer, buffer.next(idx[sl]), stack_num, as_u8=True)   # buffer_base.py:624-626
-            else:
-                nxt = gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num, as_u8=True)
-            v_next[sl] = self.infer(nxt)[0]
+            if obs_next_frames is not None:
+                v_next[sl] = self.infer(gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num, as_u8=True))[0]
+        if obs_next_frames is None:
+            # A buffer that does not store obs_next reads it as the (stacked) observation at next(index)
+            # (buffer_base.py:624-626) -- and next(index) is itself one of the sampled indices (sample_indices(0) yields every
+            # valid slot; next() stays inside the filled part of its sub-buffer).  So V(s') of transition i IS V(s) of
+            # transition next(i): the same network on the same input rows.  The reference evaluates the critic a second time
+            # on those rows (a2c.py:126-128); a row's value does not depend on which batch it sits in, so gathering it is
+            # bit-identical and saves the whole second pass over the rollout.
+            pos = torch.empty(buffer.maxsize, dtype=torch.int64, device=self.device)
+            pos[idx] = torch.arange(n, dtype=torch.int64, device=self.device)
+            v_next = v_s[pos[buffer.next(idx)]]
         out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
         return {"indices": idx, "act": act_b, "v_s": v_s, "returns": out["returns"], "adv": out["adv"],
                 "logp_old": logp_old}
