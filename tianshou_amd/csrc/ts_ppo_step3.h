@@ -547,197 +547,9 @@ __device__ __forceinline__ void net_fwd_bwd3(const char* L, float* scratch, cons
 }
 
 
-// ---- weight gradients on the bf16 cores (stage 2; compiled in with -DTS_STEP3_STAGE2, NOT the default) ---------------
-// Measured (profiles/r02_step3_stage2_phases.txt): correct on every shape of scripts/step3_check.cpp, but SLOWER than
-// the fp32 tiles of net_wgrad -- 68.0 us per ts_ppo_grad against 62.9 (stage 1) and 65.2 (fp32 kernel); the two phases
-// take 22 k cycles per net against 14 k: 336 two-byte scatter stores per wave and net, eight barriers instead of four
-// and the re-split of h1 / dZ1 cost more than the 2.7 x shorter MFMA chains give back (phase A spends 2.3 k of its
-// 8.9 k cycles in MFMAs).  Kept as the record of the experiment; the shipped mode 3 uses net_wgrad.
-// dW contracts over the workgroup's 128 samples, so the operands must have SAMPLES in the lanes' k-slots: every wave
-// scatters the bf16 pieces of its activation columns into shared [feature][sample] tiles (2-byte stores; a packed
-// register holds features f, f + 1 of one sample -> rows f and f + 1 of the lane's column) and then owns whole 32 x 32
-// output tiles whose operands are 16-byte reads of 8 consecutive samples.  Three pieces at 2 B do not fit beside each
-// other for 128 samples (104 KB), so the contraction runs in two halves of 64 samples: waves 0-1 write, all multiply,
-// waves 2-3 write, all multiply into the same accumulators.
-constexpr int TP = 144;                          // tile pitch in bytes: 64 samples x 2 B + 16 (conflict-free ds_read_b128)
-constexpr int TA_ROWS = 128, TA_PIECE = TA_ROWS * TP;     // phase A: dZ2^T rows 0..63 | H1^T rows 64..127
-constexpr int TB_ROWS = 96, TB_PIECE = TB_ROWS * TP;      // phase B: dZ1^T rows 0..63 | X^T rows 64..95 (k-slots)
-constexpr int TB_MISC = 3 * TB_PIECE;                     // fp32 [4 waves][9][64] behind the phase-B tiles
-static_assert(3 * TA_PIECE <= LDS_BYTES && TB_MISC + STEP_WAVES * MISC_SLOT * 4 <= LDS_BYTES, "tiles must fit");
-static_assert(TB_MISC % 16 == 0, "misc alignment");
-
-// one chunk (features 32 t + F(8 u + j, h)) of the lane's column -> rows row0 + 32 t + F(.., h) (+1) of every piece
-__device__ __forceinline__ void tile_put_chunk(char* T, int piece_stride, int row0, int c, const P3& v, int colh, int h) {
-    const int t = c >> 1, u = c & 1;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + 32 * t + featF(8 * u + 2 * q, h);
-            char* a = T + p * piece_stride + row * TP + colh * 2;
-            const unsigned w = v.p[p][q];
-            *reinterpret_cast<u16*>(a) = (u16)w;
-            *reinterpret_cast<u16*>(a + TP) = (u16)(w >> 16);
-        }
-}
-
-__device__ __forceinline__ void tile_get(const char* T, int piece_stride, int row, int c4, int h, P3& out) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        out.p[p] = *reinterpret_cast<const u32x4*>(T + p * piece_stride + row * TP + (16 * c4 + 8 * h) * 2);
-}
-
-template <int KS1, int NC1, bool ACTOR>
-__device__ __forceinline__ void net_wgrad3(char* L, const StepArgs& g, const Dims& d, const P3 (&xp)[NC1],
-                                           const f32x16 (&h1)[2], const P3 (&dz2p)[4], const f32x16 (&dz1)[2],
-                                           const float (&gw)[ACTOR ? ACT_PAD : 1], float misc, int wave, int lane_in,
-                                           float* slab, const Slab2& SL, bool first) {
-    constexpr int MK = ACTOR ? 2 : 10;
-    constexpr int NA = ACTOR ? ACT_PAD : 1;
-    constexpr int net = ACTOR ? 0 : 1;
-    constexpr int KP = 2 * KS1;
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane), "+v"(wave), "+s"(slab));
-    const int i = lane & 31, h = lane >> 5;
-    const int my_half = wave >> 1, colh = 32 * (wave & 1) + i;
-    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};      // bf16 1.0 in every k-slot
-
-    // ---- phase A: dW2[f2][f1] = sum_s dZ2[s][f2] H1[s][f1]; wave (tM, tN) owns rows 32 tM.., columns 32 tN..; db2 = row
-    // sums of dZ2 = the same product against an all-ones B operand (waves with tN == 0)
-    const int tM = wave >> 1, tN = wave & 1;
-    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 cb = c;
-    __syncthreads();                       // B1: every wave is done with the weight image and its scratch area
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (my_half == half) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) tile_put_chunk(L, TA_PIECE, 0, cc, dz2p[cc], colh, h);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                P3 two[2];
-                split_tile(h1[t], two);
-                tile_put_chunk(L, TA_PIECE, 64, 2 * t, two[0], colh, h);
-                tile_put_chunk(L, TA_PIECE, 64, 2 * t + 1, two[1], colh, h);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c4 = 0; c4 < 4; ++c4) {
-            P3 a, b;
-            tile_get(L, TA_PIECE, 32 * tM + i, c4, h, a);
-            tile_get(L, TA_PIECE, 64 + 32 * tN + i, c4, h, b);
-            c = mma6(a, b, c);
-            if (tN == 0) {
-                cb = mfma_bf(a.p[2], ones, cb);
-                cb = mfma_bf(a.p[1], ones, cb);
-                cb = mfma_bf(a.p[0], ones, cb);
-            }
-        }
-        __syncthreads();                   // the tiles are free again (next half / phase B)
-    }
-    TS_MARK(g, MK + 4);
-    {
-        float* p = slab + SL.w2[net] + (32 * tM + 4 * h) * HID + 32 * tN + i;
-        if (first) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, c[r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * HID, p[((r & 3) + 8 * (r >> 2)) * HID] + c[r]);
-        }
-        if (tN == 0 && i == 0) {           // every column of cb holds the row sums: lane 0 of each half stores its 16 rows
-            float* pb = slab + SL.b2[net] + 32 * tM + 4 * h;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) store_acc(pb + (r & 3) + 8 * (r >> 2), cb[r], first);
-        }
-    }
-    TS_MARK(g, MK + 5);
-
-    // ---- phase B: dW1aug[f1][k] = sum_s dZ1[s][f1] Xaug[s][k] on one wave pair, the small rows on the other
-    float* M = reinterpret_cast<float*>(L + TB_MISC);
-    {
-        float* Mw = M + wave * MISC_SLOT;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) Mw[a * 64 + lane] = gw[a];
-        Mw[8 * 64 + lane] = misc;
-    }
-    const bool w1_wave = ACTOR ? (wave < 2) : (wave >= 2);
-    const int tM1 = wave & 1;
-    f32x16 c1 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        if (my_half == half) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                P3 two[2];
-                split_tile(dz1[t], two);
-                tile_put_chunk(L, TB_PIECE, 0, 2 * t, two[0], colh, h);
-                tile_put_chunk(L, TB_PIECE, 0, 2 * t + 1, two[1], colh, h);
-            }
-            // X^T: k-slot (h, j) of chunk cc is input column 16 cc + 8 h + j -> row 64 + that
-#pragma unroll
-            for (int cc = 0; cc < NC1; ++cc)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        char* a = L + p * TB_PIECE + (64 + 16 * cc + 8 * h + 2 * q) * TP + colh * 2;
-                        const unsigned w = xp[cc].p[p][q];
-                        *reinterpret_cast<u16*>(a) = (u16)w;
-                        *reinterpret_cast<u16*>(a + TP) = (u16)(w >> 16);
-                    }
-        }
-        __syncthreads();
-        if (w1_wave) {
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                P3 a, b;
-                tile_get(L, TB_PIECE, 32 * tM1 + i, c4, h, a);
-                tile_get(L, TB_PIECE, 64 + i, c4, h, b);
-                c1 = mma6(a, b, c1);
-            }
-        } else if (half == 0) {
-            const int part = wave & 1;
-            const int n_head = ACTOR ? d.act : 1;
-            if (ACTOR) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = 4 * part + q;
-                    float v = 0.f;
-#pragma unroll
-                    for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + row * 64 + lane];
-                    if (row < n_head) store_acc(slab + SL.head[net] + row * HID + lane, v, first);
-                }
-            } else if (part == 1) {
-                float v = 0.f;
-#pragma unroll
-                for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + lane];
-                store_acc(slab + SL.head[net] + lane, v, first);
-            }
-            if (part == 0) {
-                float v = 0.f;
-#pragma unroll
-                for (int sl = 0; sl < STEP_WAVES; ++sl) v += M[sl * MISC_SLOT + 8 * 64 + lane];
-                if (lane < 8) { if (lane < n_head) store_acc(slab + SL.hb[net] + lane, v, first); }
-                else if (lane < 16) { if (ACTOR && lane - 8 < d.act) store_acc(slab + SL.sig + lane - 8, v, first); }
-                else if (lane == 16) store_acc(slab + SL.loss + net, v, first);
-            }
-        }
-        if (half == 0) __syncthreads();    // half 0 is consumed: waves 2-3 may overwrite the tiles
-    }
-    if (w1_wave && i < KP) {
-        float* p = slab + SL.w1[net] + (32 * tM1 + 4 * h) * KP + i;
-        if (first) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, c1[r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) slab_st(p + ((r & 3) + 8 * (r >> 2)) * KP, p[((r & 3) + 8 * (r >> 2)) * KP] + c1[r]);
-        }
-    }
-    TS_MARK(g, MK + 6);
-}
+// (Stage 2 -- the weight gradients on the bf16 cores as well -- was built, measured slower than the fp32 tiles of net_wgrad
+// (68.0 us per ts_ppo_grad against 62.9, profiles/r02_step3_stage2_phases.txt: 336 two-byte scatter stores per wave and
+// net, eight barriers instead of four) and removed in round 3; `git show 9a55f15:tianshou_amd/csrc/ts_ppo_step3.h` has it.)
 
 template <int KS1>
 __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step3_kernel(StepArgs g, Dims d) {
@@ -806,11 +618,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step3_kernel(StepArgs g, 
         {
             float gw[ACT_PAD];
             net_fwd_bwd3<KS1, NC1, true>(L, scratch, g, d, in, xp, lane, h1, h2, dz2p, dz1, gw, misc);
-#ifdef TS_STEP3_STAGE2
-            net_wgrad3<KS1, NC1, true>(L, g, d, xp, h1, dz2p, dz1, gw, misc, wave, lane, slab, SL, first);
-#else
             net_wgrad<KS1, true>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
-#endif
         }
         __syncthreads();
         TS_MARK(g, 18);
@@ -824,11 +632,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step3_kernel(StepArgs g, 
         {
             float gw[1];
             net_fwd_bwd3<KS1, NC1, false>(L, scratch, g, d, in, xp, lane, h1, h2, dz2p, dz1, gw, misc);
-#ifdef TS_STEP3_STAGE2
-            net_wgrad3<KS1, NC1, false>(L, g, d, xp, h1, dz2p, dz1, gw, misc, wave, lane, slab, SL, first);
-#else
             net_wgrad<KS1, false>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
-#endif
         }
     }
     TS_MARK(g, 17);
