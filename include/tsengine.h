@@ -652,6 +652,13 @@ int ts_mlp_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
  * and stay zero.  h_out8 = {ka, kc, actor count, critic count, actor L2 offset, actor head offset,
  * critic L2 offset, critic head offset}.  act_dim <= 32. */
 int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8);
+/* Net(hidden_sizes=[h, h]) with h other than 256 (utils/net/common.py:246-369 takes any): the hidden width is a property
+ * of the WORKSPACE -- ts_mlp_set_hidden(ws, h) (h a multiple of 32 in [32, 1024]; 0 = 256) applies to every SAC / TD3 /
+ * DDPG / REDQ entry point subsequently called with `ws`; the `_h` layout variants take it explicitly (no workspace there).
+ * 256 runs on the fused three-layer kernels, other widths on the per-layer GEMM kernels; in the layouts above every
+ * "256" / "257" then reads h / h + 1. */
+int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden);
+int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out8);
 
 /* SACPolicy.forward (sac.py:108-131) with rsample() = loc + noise * scale; noise NULL = dist.mode
  * (deterministic_eval).  act_out (nullable) float32[B, act_dim] = tanh-squashed action, logp_out float32[B]
@@ -848,6 +855,7 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
 /* Flat vectors: actor L1 [ka + 1, 256] | L2 [257, 256] | head [257, 32] (columns [0, act_dim) = last);
  * critics as in ts_sac_layout.  h_out4 = {ka, kc, actor count, critic count}. */
 int ts_td3_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out4);
+int ts_td3_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out4);
 
 /* ContinuousDeterministicPolicy.forward (ddpg.py:162-180): act = max_action * tanh(actor(obs)). */
 int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs, int64_t B, int64_t obs_dim,

@@ -17,17 +17,17 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def make_engine(obs_dim, act_dim, seed, cfg):
+def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
     from tianshou_amd import sac as S
 
-    actor, c1, c2 = OS.init_sac_params(obs_dim, act_dim, seed)
+    actor, c1, c2 = OS.init_sac_params(obs_dim, act_dim, seed, hidden)
     eng = S.SACEngine(
         obs_dim, act_dim,
         S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim),
         S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
         S.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
         S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
-                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}))
+                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=hidden)
     return eng, (actor, c1, c2)
 
 
@@ -155,6 +155,43 @@ def test_update_other_shapes_vs_oracle(obs_dim, act_dim, B):
                                    atol=1e-6)
         np.testing.assert_allclose(s[3], ref["alpha"], rtol=1e-5)
         np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,B", [(128, 23, 5, 96), (96, 376, 17, 64), (512, 11, 3, 40)])
+def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B):
+    """Net(hidden_sizes=[h, h]) with h other than the example's 256 (utils/net/common.py:246-369 takes any): the same update
+    on the per-layer GEMM kernels (ts_mlp_set_hidden), two updates against the oracle; a 256-wide engine sharing the
+    device's workspace is interleaved to show that the width travels with each call."""
+    from tianshou_amd import sac as S
+
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 9, cfg, hidden)
+    other, _ = make_engine(7, 2, 1, cfg)                      # hidden 256, same default workspace
+    lay = S.layout(obs_dim, act_dim, hidden)
+    assert eng.actor.numel() == lay["actor_count"] == (lay["ka"] + 1) * hidden + (hidden + 1) * hidden + (hidden + 1) * 64
+    back = S.actor_flat_to_torch(eng.actor, obs_dim, act_dim, hidden)
+    for t, k in zip(back, OS.ACTOR_ORDER):
+        assert torch.equal(t.cpu(), actor[k])
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    g = torch.Generator().manual_seed(B)
+    for _ in range(2):
+        obs = torch.randn(B, obs_dim, generator=g)
+        act = torch.rand(B, act_dim, generator=g) * 2 - 1
+        ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+        other.update_with_batch(torch.randn(8, 7), torch.rand(8, 2), torch.randn(8), torch.randn(8, 2))
+        ref = OS.update_with_batch(st, cfg, obs, act, ret, noise)
+        stats, w = eng.update_with_batch(obs, act, ret, noise)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[:3], [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=2e-5,
+                                   atol=1e-6)
+        np.testing.assert_allclose(s[3], ref["alpha"], rtol=1e-5)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+    a_act, a_logp = eng.policy_forward(obs, noise)
+    r_act, r_logp = OS.policy_forward(st.actor, obs, noise)[:2]
+    assert rel_err(a_act.cpu(), r_act) < 1e-5 and rel_err(a_logp.cpu().flatten(), r_logp.flatten()) < 1e-5
+    with pytest.raises(Exception):
+        make_engine(5, 2, 0, cfg, hidden=100)                 # not a multiple of 32
 
 
 def test_bad_arguments_fail_loudly():

@@ -15,17 +15,40 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def make_engine(obs_dim, act_dim, seed, cfg):
+def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
     from tianshou_amd import td3 as T
 
-    actor, c1, c2 = OS.init_td3_params(obs_dim, act_dim, seed, cfg.twin)
+    actor, c1, c2 = OS.init_td3_params(obs_dim, act_dim, seed, cfg.twin, hidden)
     eng = T.TD3Engine(
         obs_dim, act_dim, T.actor_flat_from_torch([actor[k] for k in OS.DET_ACTOR_ORDER], obs_dim, act_dim),
         T.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
         T.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim) if cfg.twin else None,
         T.TD3Config(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "twin", "policy_noise", "noise_clip",
-                                                     "update_actor_freq", "max_action", "actor_lr", "critic_lr")}))
+                                                     "update_actor_freq", "max_action", "actor_lr", "critic_lr")}),
+        hidden=hidden)
     return eng, (actor, c1, c2)
+
+
+@pytest.mark.parametrize("twin,hidden", [(True, 128), (False, 64)])
+def test_other_hidden_widths_vs_oracle(twin, hidden):
+    """TD3 / DDPG with Net[h, h], h other than 256 (mujoco_td3.py's width): two updates (the second one steps the actor)
+    against the oracle on the per-layer GEMM path."""
+    obs_dim, act_dim, B = 17, 6, 80
+    cfg = OS.TD3Config(twin=twin, max_action=1.0, actor_lr=3e-4, critic_lr=1e-3, tau=0.01, update_actor_freq=2 if twin else 1)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 4, cfg, hidden)
+    st = OS.TD3State.create(actor, c1, c2, cfg)
+    g = torch.Generator().manual_seed(hidden)
+    for _ in range(2):
+        obs = torch.randn(B, obs_dim, generator=g)
+        act = torch.rand(B, act_dim, generator=g) * 2 - 1
+        ret = torch.randn(B, generator=g)
+        ref = OS.td3_update_with_batch(st, cfg, obs, act, ret)
+        stats, w = eng.update_with_batch(obs, act, ret)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[:2], [ref["actor_loss"], ref["critic1_loss"]], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+    with torch.no_grad():
+        assert rel_err(eng.policy_forward(obs).cpu(), OS.det_actor_forward(st.actor, obs, cfg.max_action)) < 1e-5
 
 
 @pytest.mark.parametrize("twin", [True, False])

@@ -468,7 +468,9 @@ def test_hip_sac_wrapper_runs_with_engine_double(sac_algo, monkeypatch):
     import tianshou_amd.sac as S
 
     class FakeSAC:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256):
+            assert hidden == 256
+            self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.adam_step = obs_dim, act_dim, cfg, 0
             self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), c2.clone()
             self.critic1_old, self.critic2_old = c1.clone(), c2.clone()
@@ -550,7 +552,8 @@ def test_hip_td3_ddpg_wrapper_runs_with_engine_double(twin, monkeypatch):
     import tianshou_amd.td3 as T
 
     class FakeTD3:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256):
+            self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.cnt, self.actor_steps = obs_dim, act_dim, cfg, 0, 0
             self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), None if c2 is None else c2.clone()
             names = ("actor", "critic1") + (("critic2",) if c2 is not None else ())

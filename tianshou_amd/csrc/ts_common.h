@@ -75,6 +75,9 @@ struct ts_workspace {
     void* dg_tables;
     long long dg_key[16][16];
     int dg_next;
+    // hidden width of the Net[h, h] MLPs of the SAC / TD3 / DDPG / REDQ entry points called with this workspace
+    // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
+    int mlp_hidden;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;

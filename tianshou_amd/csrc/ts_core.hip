@@ -142,6 +142,14 @@ int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes) {
     return TS_OK;
 }
 
+int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_set_hidden: workspace is NULL");
+    TS_REQUIRE(hidden == 0 || (hidden >= 32 && hidden <= 1024 && hidden % 32 == 0), TS_ERR_INVALID_ARG,
+               "ts_mlp_set_hidden: 0 (default 256) or a multiple of 32 in [32, 1024], got %lld", (long long)hidden);
+    ws->mlp_hidden = (int)hidden;
+    return TS_OK;
+}
+
 int ts_workspace_destroy(ts_workspace* ws) {
     if (!ws) return TS_OK;
     if (ws->side_ready) {

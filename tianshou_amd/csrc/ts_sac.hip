@@ -667,14 +667,24 @@ struct Carve {
     template <class T> T* take(size_t n) { T* r = reinterpret_cast<T*>(p); p += al(sizeof(T) * n); return r; }
 };
 
-struct Dims { int obs, act, ka, kc; };
+struct Dims { int obs, act, ka, kc, hid; };
 
-int make_dims(int64_t obs_dim, int64_t act_dim, Dims* d) {
+// hidden: width of the two hidden layers of every Net[h, h] of the SAC / TD3 / DDPG / REDQ entry points -- a property of
+// the workspace (ts_mlp_set_hidden; 0 = the examples' 256).  Any multiple of 32 up to 1024 runs: 256 on the fused
+// three-layer kernels of ts_mlp.hip, everything else on the per-layer GEMM kernels.
+int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d) {
     TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && act_dim >= 1 && act_dim <= 32, TS_ERR_INVALID_ARG,
                "sac: obs_dim must be >= 1 and act_dim in [1, 32]");
-    d->obs = (int)obs_dim; d->act = (int)act_dim;
+    if (hidden == 0) hidden = HID;
+    TS_REQUIRE(hidden >= 32 && hidden <= 1024 && hidden % 32 == 0, TS_ERR_INVALID_ARG,
+               "sac: hidden width must be a multiple of 32 in [32, 1024], got %lld", (long long)hidden);
+    d->obs = (int)obs_dim; d->act = (int)act_dim; d->hid = (int)hidden;
     d->ka = pad32(d->obs); d->kc = pad32(d->obs + d->act);
     return TS_OK;
+}
+
+int make_dims(const ts_workspace* ws, int64_t obs_dim, int64_t act_dim, Dims* d) {
+    return make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d);
 }
 
 Act take_act(Carve& c, int64_t B, int head_cols, int hid = HID) {
@@ -700,11 +710,13 @@ int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d) {
 
 extern "C" {
 
-int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8) {
+int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8) { return ts_sac_layout_h(obs_dim, act_dim, 0, h_out8); }
+
+int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out8) {
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out8, TS_ERR_INVALID_ARG, "ts_sac_layout: NULL output");
-    const Mlp a = make_mlp(1, d.ka, 64), c = make_mlp(1, d.kc, 32);
+    const Mlp a = make_mlp(1, d.ka, 64, d.hid), c = make_mlp(1, d.kc, 32, d.hid);
     h_out8[0] = d.ka; h_out8[1] = d.kc; h_out8[2] = a.off[3]; h_out8[3] = c.off[3];
     h_out8[4] = a.off[1]; h_out8[5] = a.off[2]; h_out8[6] = c.off[1]; h_out8[7] = c.off[2];
     return TS_OK;
@@ -716,15 +728,15 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_policy_forward: workspace is NULL");
     TS_REQUIRE(B >= 1 && actor && obs && logp_out, TS_ERR_INVALID_ARG, "ts_sac_policy_forward: bad argument");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * HID) + al(4 * B * 3 * d.act) +
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * B * 3 * d.act) +
                                         al(4 * split_floats(ma)) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, 64);
+    const Act aa = take_act(c, B, 64, d.hid);
     float* keep = c.take<float>(B * 3 * d.act);
     float* split = c.take<float>(split_floats(ma));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
@@ -746,17 +758,17 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     TS_REQUIRE(B >= 1 && actor && critic1_old && critic2_old && obs_next && noise && out, TS_ERR_INVALID_ARG,
                "ts_sac_target_q: bad argument");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * B) +
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 2 * al(4 * B) +
                                         2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    const Act aa = take_act(c, B, 64, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
     float* logp = c.take<float>(B);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
@@ -802,16 +814,16 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
                "ts_sac_update: auto alpha needs log_alpha and its Adam moments");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
-    size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 3 * al(4 * B * 64) +
-                   2 * al(4 * B * HID) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
+    size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 3 * al(4 * B * 64) +
+                   2 * al(4 * B * d.hid) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
                    al(4 * B * 3 * d.act) + 8192;
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    bytes += 2 * al(4 * spl) + 2 * al(4 * B * HID) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
+    bytes += 2 * al(4 * spl) + 2 * al(4 * B * d.hid) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
              al(4 * 3 * ts::ceil_div(B, 256));
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -819,7 +831,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* x_c = c.take<float>(B * d.kc);          // [obs | buffer action]
     float* x_p = c.take<float>(B * d.kc);          // [obs | policy action]
     float* dx1 = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 64), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    const Act aa = take_act(c, B, 64, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
     // upstream gradients of the head outputs: the loss kernels write the live columns, the zero padding of all five
     // comes from ONE memset at the start of the update
     float* zeroed = c.take<float>(B * 192);
@@ -830,8 +842,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* d_head = zeroed + B * 128;              // policy backward    [B, 64]
     float* dx2 = c.take<float>(B * 64 > B * d.kc ? B * 64 : B * d.kc);
     BwdScratch sc, sc2;              // one set per stream (the two critics run concurrently)
-    sc.dh2 = c.take<float>(B * HID); sc.dh1 = c.take<float>(B * HID); sc.slabs = c.take<float>(slab);
-    sc2.dh2 = c.take<float>(B * HID); sc2.dh1 = c.take<float>(B * HID); sc2.slabs = c.take<float>(slab);
+    sc.dh2 = c.take<float>(B * d.hid); sc.dh1 = c.take<float>(B * d.hid); sc.slabs = c.take<float>(slab);
+    sc2.dh2 = c.take<float>(B * d.hid); sc2.dh1 = c.take<float>(B * d.hid); sc2.slabs = c.take<float>(slab);
     float* grad = c.take<float>(std::max(pa, pc));
     float* grad2 = c.take<float>(pc);
     float* split2 = c.take<float>(spl);
@@ -974,12 +986,14 @@ int ts_sac_update_phase(ts_workspace* ws, const ts_sac_state* st, int64_t adam_s
 }
 
 // ---- TD3 / DDPG ------------------------------------------------------------------------------------------------
-int ts_td3_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out4) {
+int ts_td3_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out4) { return ts_td3_layout_h(obs_dim, act_dim, 0, h_out4); }
+
+int ts_td3_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out4) {
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out4, TS_ERR_INVALID_ARG, "ts_td3_layout: NULL output");
     h_out4[0] = d.ka; h_out4[1] = d.kc;
-    h_out4[2] = make_mlp(1, d.ka, 32).off[3]; h_out4[3] = make_mlp(1, d.kc, 32).off[3];
+    h_out4[2] = make_mlp(1, d.ka, 32, d.hid).off[3]; h_out4[3] = make_mlp(1, d.kc, 32, d.hid).off[3];
     return TS_OK;
 }
 
@@ -988,13 +1002,13 @@ int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_td3_policy_forward: workspace is NULL");
     TS_REQUIRE(B >= 1 && actor && obs && act_out, TS_ERR_INVALID_ARG, "ts_td3_policy_forward: bad argument");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * HID) + al(4 * split_floats(ma)) + 4096)) return rc;
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * split_floats(ma)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, 32);
+    const Act aa = take_act(c, B, 32, d.hid);
     float* split = c.take<float>(split_floats(ma));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
@@ -1012,15 +1026,15 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_td3_target_q: workspace is NULL");
     TS_REQUIRE(B >= 1 && actor_old && critic1_old && obs_next && out, TS_ERR_INVALID_ARG, "ts_td3_target_q: bad argument");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * HID) + 2 * al(4 * spl) + 4096)) return rc;
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 2 * al(4 * spl) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    const Act aa = take_act(c, B, 32, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
@@ -1059,16 +1073,16 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     TS_REQUIRE(!twin || (st->critic2_m && st->critic2_v && st->critic2_old), TS_ERR_INVALID_ARG,
                "ts_td3_update: incomplete second critic");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 32), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
     const unsigned gb = (unsigned)ts::ceil_div(B, 256);
-    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * HID) + 4 * al(4 * B * 32) + al(4 * 3 * gb) +
-                         4 * al(4 * B * HID) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
+    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 4 * al(4 * B * 32) + al(4 * 3 * gb) +
+                         4 * al(4 * B * d.hid) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
                          al(4 * B * d.act) + 2 * al(4 * spl) + 8192;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -1076,7 +1090,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* x_c = c.take<float>(B * d.kc);
     float* x_p = c.take<float>(B * d.kc);
     float* dx1 = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 32), a1 = take_act(c, B, 32), a2 = take_act(c, B, 32);
+    const Act aa = take_act(c, B, 32, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
     // upstream gradients of the head outputs [B, 32]: live column written by the loss kernels, zero padding from ONE
     // memset: {critic 1 loss, critic 2 loss, actor loss -> Q1, policy backward}
     float* zeroed = c.take<float>(B * 128);
@@ -1085,7 +1099,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* d_pol = zeroed + B * 96;
     float* loss_part = c.take<float>(3 * (size_t)gb);      // {actor, critic1, critic2} x gb partial sums
     BwdScratch scs[2];
-    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * HID); scs[k].dh1 = c.take<float>(B * HID); scs[k].slabs = c.take<float>(slab); }
+    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
     float* gbuf[2] = {c.take<float>(std::max(pa, pc)), c.take<float>(std::max(pa, pc))};
     float* tds[2] = {c.take<float>(B), c.take<float>(B)};
     float* keep = c.take<float>(B * d.act);
@@ -1326,19 +1340,19 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     for (int64_t k = 0; k < S; ++k)
         TS_REQUIRE(h_subset[k] >= 0 && h_subset[k] < E, TS_ERR_INVALID_ARG, "ts_redq_target_q: subset index out of range");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pc = mc.off[3];
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * al(4 * B * HID) + al(4 * B * 64) +
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * al(4 * B * d.hid) + al(4 * B * 64) +
                                         al(4 * (size_t)S * B * 32) + al(4 * B) + 2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    Act aa; aa.h1 = c.take<float>(B * HID); aa.h2 = c.take<float>(B * HID); aa.out = c.take<float>(B * 64);
-    float* hh[2][2] = {{c.take<float>(B * HID), c.take<float>(B * HID)}, {c.take<float>(B * HID), c.take<float>(B * HID)}};
+    Act aa; aa.h1 = c.take<float>(B * d.hid); aa.h2 = c.take<float>(B * d.hid); aa.out = c.take<float>(B * 64);
+    float* hh[2][2] = {{c.take<float>(B * d.hid), c.take<float>(B * d.hid)}, {c.take<float>(B * d.hid), c.take<float>(B * d.hid)}};
     float* qs = c.take<float>((size_t)S * B * 32);
     float* logp = c.take<float>(B);
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
@@ -1376,12 +1390,12 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
                "ts_redq_update: auto alpha needs log_alpha and its Adam moments");
     Dims d;
-    if (int rc = make_dims(obs_dim, act_dim, &d)) return rc;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64), mc = make_mlp((int)B, d.kc, 32);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc)), spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
-    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 6) * al(4 * B * HID) +
+    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 6) * al(4 * B * d.hid) +
                          (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + 2 * al(4 * slab) + al(4 * (size_t)E * pc) +
                          al(4 * pa) + 2 * al(4 * spl) + al(4 * (size_t)E * B) + 2 * al(4 * B) + al(4 * B * 3 * d.act) +
                          al(256) + al(4 * 1024) + 8192;
@@ -1394,13 +1408,13 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     float* dx_sum = c.take<float>(B * d.kc);
     float* zeros = c.take<float>(B * d.kc);
     Act acts[64];
-    for (int e = 0; e < E; ++e) { acts[e].h1 = c.take<float>(B * HID); acts[e].h2 = c.take<float>(B * HID); acts[e].out = c.take<float>(B * 32); }
-    Act aa; aa.h1 = c.take<float>(B * HID); aa.h2 = c.take<float>(B * HID); aa.out = c.take<float>(B * 64);
+    for (int e = 0; e < E; ++e) { acts[e].h1 = c.take<float>(B * d.hid); acts[e].h2 = c.take<float>(B * d.hid); acts[e].out = c.take<float>(B * 32); }
+    Act aa; aa.h1 = c.take<float>(B * d.hid); aa.h2 = c.take<float>(B * d.hid); aa.out = c.take<float>(B * 64);
     float* d_head = c.take<float>(B * 64);
     float* dheads[2] = {c.take<float>(B * 64), c.take<float>(B * 64)};
     float* d_q = dheads[0];                          // actor phase: the critic-phase gradients are consumed by then
     BwdScratch scs[2];
-    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * HID); scs[k].dh1 = c.take<float>(B * HID); scs[k].slabs = c.take<float>(slab); }
+    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
     float* gcrit = c.take<float>((size_t)E * pc);
     float* gact = c.take<float>(pa);
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};

@@ -40,6 +40,7 @@ class _HipGlue:
       version counters, the engine's Adam moments are first written into torch.optim and survive the rebuild.
     `_HIP_LR`: (engine cfg field, attribute path of the Algorithm.Optimizer wrapper that owns it)."""
     _HIP_LR: tuple = (("lr", "optim"),)
+    _hip_dp_on = False            # classes whose constructor takes data_parallel= call _hip_dp_setup
 
     def _hip_glue_init(self) -> None:
         # Only the algorithm itself carries a hook, and it is a module-level function: sub-modules stay free of
@@ -1133,8 +1134,11 @@ def make_hip_sac(ref=None):
             if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != S.TIANSHOU_CRITIC_KEYS \
                     or list(self.critic2.state_dict().keys()) != S.TIANSHOU_CRITIC_KEYS:
                 raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py")
-            if sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or sa[S.TIANSHOU_ACTOR_KEYS[2]].shape != (256, 256):
-                raise NotImplementedError("HipSAC: hidden sizes must be [256, 256]")
+            hid = int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0])
+            if hid % 32 or not 32 <= hid <= 1024 or tuple(sa[S.TIANSHOU_ACTOR_KEYS[2]].shape) != (hid, hid) \
+                    or any(tuple(c.state_dict()[S.TIANSHOU_CRITIC_KEYS[2]].shape) != (hid, hid) for c in (self.critic, self.critic2)):
+                raise NotImplementedError("HipSAC: hidden sizes [h, h], h a multiple of 32 up to 1024, the same for actor and critics")
+            self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
                 _adam_of(o)
             self._hip_engine = None
@@ -1161,7 +1165,7 @@ def make_hip_sac(ref=None):
                 eng = self._hip_engine = S.SACEngine(
                     obs_dim, act_dim,
                     S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
-                    flat_c(self.critic), flat_c(self.critic2), cfg)
+                    flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden)
                 # resume: lagged critics, Adam moments / steps of a loaded checkpoint
                 eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
                 for name, mod, optim, keys, conv in self._hip_parts(S):
@@ -1214,15 +1218,15 @@ def make_hip_sac(ref=None):
                                         (self.critic2, eng.critic2, S.critic_flat_to_torch),
                                         (self.critic_old.module, eng.critic1_old, S.critic_flat_to_torch),
                                         (self.critic2_old.module, eng.critic2_old, S.critic_flat_to_torch)):
-                    for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim)):
+                    for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim, eng.hidden)):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
             back = {"actor": S.actor_flat_to_torch, "critic1": S.critic_flat_to_torch, "critic2": S.critic_flat_to_torch}
             for name, mod, optim, keys, _ in self._hip_parts(S):
                 store_adam_state(optim._optim, params_by_keys(mod, keys),
-                                 back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim),
-                                 back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim), eng.adam_step)
+                                 back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim, eng.hidden),
+                                 back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim, eng.hidden), eng.adam_step)
             if eng.cfg.auto_alpha:
                 store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
                                  [eng.log_alpha_v[0]], eng.adam_step)
@@ -1685,8 +1689,11 @@ def _make_hip_det(twin: bool):
             critics = [self.critic] + ([self.critic2] if twin else [])
             if list(sa.keys()) != T.TIANSHOU_ACTOR_KEYS or any(list(c.state_dict().keys()) != S_KEYS for c in critics):
                 raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py")
-            if sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or sa[T.TIANSHOU_ACTOR_KEYS[2]].shape != (256, 256):
-                raise NotImplementedError("HipTD3 / HipDDPG: hidden sizes must be [256, 256]")
+            hid = int(sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[0])
+            if hid % 32 or not 32 <= hid <= 1024 or tuple(sa[T.TIANSHOU_ACTOR_KEYS[2]].shape) != (hid, hid) \
+                    or any(tuple(c.state_dict()[S_KEYS[2]].shape) != (hid, hid) for c in critics):
+                raise NotImplementedError("HipTD3 / HipDDPG: hidden sizes [h, h], h a multiple of 32 up to 1024, the same for actor and critics")
+            self._hip_hidden = hid
             for o in [self.policy_optim, self.critic_optim] + ([self.critic2_optim] if twin else []):
                 _adam_of(o)
             self._hip_engine = None
@@ -1716,7 +1723,7 @@ def _make_hip_det(twin: bool):
                 flats = {n: conv([mod.state_dict()[k] for k in keys], obs_dim, act_dim, dev)
                          for n, mod, _, keys, conv, _, _ in self._hip_parts()}
                 eng = self._hip_engine = T.TD3Engine(obs_dim, act_dim, flats["actor"], flats["critic1"],
-                                                     flats.get("critic2"), cfg)
+                                                     flats.get("critic2"), cfg, hidden=self._hip_hidden)
                 eng.cnt = getattr(self, "_cnt", 0)
                 for n, mod, optim, keys, conv, _, old in self._hip_parts():           # resume from a checkpoint
                     setattr(eng, n + "_old", conv([old.state_dict()[k] for k in keys], obs_dim, act_dim, dev))
@@ -1753,13 +1760,13 @@ def _make_hip_det(twin: bool):
             with torch.no_grad():
                 for n, mod, optim, keys, _, back, old in self._hip_parts():
                     params = params_by_keys(mod, keys)
-                    for p, t in zip(params, back(getattr(eng, n), eng.obs_dim, eng.act_dim)):
+                    for p, t in zip(params, back(getattr(eng, n), eng.obs_dim, eng.act_dim, eng.hidden)):
                         p.copy_(t)
-                    for p, t in zip(params_by_keys(old, keys), back(getattr(eng, n + "_old"), eng.obs_dim, eng.act_dim)):
+                    for p, t in zip(params_by_keys(old, keys), back(getattr(eng, n + "_old"), eng.obs_dim, eng.act_dim, eng.hidden)):
                         p.copy_(t)
                     step = eng.actor_steps if n == "actor" else eng.cnt
-                    store_adam_state(optim._optim, params, back(getattr(eng, n + "_m"), eng.obs_dim, eng.act_dim),
-                                     back(getattr(eng, n + "_v"), eng.obs_dim, eng.act_dim), step)
+                    store_adam_state(optim._optim, params, back(getattr(eng, n + "_m"), eng.obs_dim, eng.act_dim, eng.hidden),
+                                     back(getattr(eng, n + "_v"), eng.obs_dim, eng.act_dim, eng.hidden), step)
             if twin:
                 self._last = float(s[0])
                 return TD3TrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]))

@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, gather_rows
 from .returns import compute_nstep_return
-from .sac import SACConfig, SACEngine, critic_flat_from_torch, critic_flat_to_torch, layout
+from .sac import SACConfig, SACEngine, critic_flat_from_torch, critic_flat_to_torch, layout, use_hidden
 
 TIANSHOU_CRITIC_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias_weights",
                         "preprocess.model.model.2.weight", "preprocess.model.model.2.bias_weights",
@@ -98,6 +98,7 @@ class REDQEngine:
         if sub.size != self.cfg.subset_size:
             raise ValueError("subset must hold subset_size member indices")
         out = torch.empty(b, dtype=torch.float32, device=self.device)
+        use_hidden(self._ws, 256)          # the ensemble nets of test_redq.py are [256, 256]
         _lib.check(_lib.load().ts_redq_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critics_old), _lib.i64(self.cfg.ensemble_size),
             sub.ctypes.data_as(C.POINTER(C.c_int32)), _lib.i64(sub.size), C.c_int(int(self.cfg.target_mode == "mean")),
@@ -141,6 +142,7 @@ class REDQEngine:
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st = REDQStateC(*[getattr(self, n).data_ptr() for n, _ in REDQStateC._fields_])
         hp = self.cfg.to_c(lr_scale)
+        use_hidden(self._ws, 256)          # the ensemble nets of test_redq.py are [256, 256]
         _lib.check(_lib.load().ts_redq_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cfg.ensemble_size), _lib.i64(self.critic_gradient_step),
             _lib.i64(max(self.actor_steps, 1)), C.c_int(int(do_actor)), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),

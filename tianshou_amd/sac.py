@@ -47,15 +47,22 @@ class SACStateC(C.Structure):
         "critic1_old", "critic2_old", "log_alpha", "log_alpha_m", "log_alpha_v")]
 
 
-def layout(obs_dim: int, act_dim: int) -> dict[str, int]:
+def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
+    """ts_sac_layout_h: offsets / counts of the flat vectors for Net[hidden, hidden] (a multiple of 32 up to 1024)."""
     out = (C.c_int64 * 8)()
-    _lib.check(_lib.load().ts_sac_layout(_lib.i64(obs_dim), _lib.i64(act_dim), out))
+    _lib.check(_lib.load().ts_sac_layout_h(_lib.i64(obs_dim), _lib.i64(act_dim), _lib.i64(hidden), out))
     keys = ["ka", "kc", "actor_count", "critic_count", "actor_l2", "actor_head", "critic_l2", "critic_head"]
     return dict(zip(keys, (int(v) for v in out)))
 
 
+def use_hidden(ws, hidden: int) -> None:
+    """The hidden width is a property of the workspace (ts_mlp_set_hidden): every SAC / TD3 / DDPG / REDQ engine sets its
+    own before each call, since engines of different widths may share the device's default workspace."""
+    _lib.check(_lib.load().ts_mlp_set_hidden(ws.handle, _lib.i64(hidden)))
+
+
 def _l1(w: torch.Tensor, b: torch.Tensor, k_pad: int) -> torch.Tensor:
-    wb = torch.zeros((k_pad + 1, HID), dtype=torch.float32)
+    wb = torch.zeros((k_pad + 1, w.shape[0]), dtype=torch.float32)
     wb[: w.shape[1]] = w.detach().float().cpu().t()
     wb[k_pad] = b.detach().float().cpu()
     return wb.reshape(-1)
@@ -66,8 +73,10 @@ def _dense(w, b) -> torch.Tensor:
 
 
 def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, wmu, bmu, wsig, bsig] (torch nn.Linear layout; also valid for Adam moments)."""
-    lay = layout(obs_dim, act_dim)
+    """[w1, b1, w2, b2, wmu, bmu, wsig, bsig] (torch nn.Linear layout; also valid for Adam moments).  The hidden width is
+    read off the tensors."""
+    HID = int(t[0].shape[0])
+    lay = layout(obs_dim, act_dim, HID)
     head = torch.zeros((HID + 1, 64), dtype=torch.float32)
     head[:HID, :act_dim] = t[4].detach().float().cpu().t()
     head[HID, :act_dim] = t[5].detach().float().cpu()
@@ -78,15 +87,17 @@ def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, dev
 
 def critic_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
     """[w1, b1, w2, b2, wq, bq]."""
-    lay = layout(obs_dim, act_dim)
+    HID = int(t[0].shape[0])
+    lay = layout(obs_dim, act_dim, HID)
     head = torch.zeros((HID + 1, 32), dtype=torch.float32)
     head[:HID, 0] = t[4].detach().float().cpu().reshape(-1)
     head[HID, 0] = t[5].detach().float().cpu().reshape(())
     return torch.cat([_l1(t[0], t[1], lay["kc"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
-    lay = layout(obs_dim, act_dim)
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID) -> list[torch.Tensor]:
+    HID = hidden
+    lay = layout(obs_dim, act_dim, HID)
     f = flat.detach()
     l1 = f[: lay["actor_l2"]].reshape(lay["ka"] + 1, HID)
     l2 = f[lay["actor_l2"]: lay["actor_head"]].reshape(HID + 1, HID)
@@ -96,8 +107,9 @@ def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[
             hd[:HID, 32:32 + act_dim].t().contiguous(), hd[HID, 32:32 + act_dim].clone()]
 
 
-def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
-    lay = layout(obs_dim, act_dim)
+def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID) -> list[torch.Tensor]:
+    HID = hidden
+    lay = layout(obs_dim, act_dim, HID)
     f = flat.detach()
     l1 = f[: lay["critic_l2"]].reshape(lay["kc"] + 1, HID)
     l2 = f[lay["critic_l2"]: lay["critic_head"]].reshape(HID + 1, HID)
@@ -133,10 +145,13 @@ class SACEngine:
     """State of one SAC learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor, cfg: SACConfig):
+                 critic2: torch.Tensor, cfg: SACConfig, hidden: int = HID):
+        """`hidden`: width of the Net[hidden, hidden] trunks (utils/net/common.py:246-369; 256 in mujoco_sac.py): any
+        multiple of 32 up to 1024 -- 256 runs on the fused three-layer kernels, other widths on the per-layer GEMMs."""
         if not actor.is_cuda:
             raise RuntimeError("SACEngine needs parameters on an MI355X (no CPU fallback)")
-        lay = layout(obs_dim, act_dim)
+        self.hidden = int(hidden)
+        lay = layout(obs_dim, act_dim, self.hidden)
         if actor.numel() != lay["actor_count"] or critic1.numel() != lay["critic_count"] \
                 or critic2.numel() != lay["critic_count"]:
             raise ValueError("flat parameter vectors do not match ts_sac_layout")
@@ -177,6 +192,7 @@ class SACEngine:
         noise = None if noise is None else self._f32(noise, (b, self.act_dim))
         act = torch.empty((b, self.act_dim), dtype=torch.float32, device=self.device)
         logp = torch.empty(b, dtype=torch.float32, device=self.device)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_sac_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.ptr(act), _lib.ptr(logp), None, _lib.current_stream(self.device)))
@@ -188,6 +204,7 @@ class SACEngine:
         b = obs_next.shape[0]
         noise = self._f32(noise, (b, self.act_dim))
         out = torch.empty(b, dtype=torch.float32, device=self.device)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_sac_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(obs_next),
@@ -222,6 +239,7 @@ class SACEngine:
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st, hp = self._state_c(), self.cfg.to_c(lr_scale)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_sac_update(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
             _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -250,6 +268,7 @@ class SACEngine:
 
     def update_phase(self, ctx: dict, phase: int, grads: torch.Tensor) -> None:
         st = self._state_c()
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_sac_update_phase(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(ctx["obs"]), _lib.ptr(ctx["act"]),
             _lib.ptr(ctx["returns"]), _lib.ptr(ctx["weight"]), _lib.ptr(ctx["noise"]), _lib.i64(ctx["b"]),

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, gather_rows
 from .returns import compute_nstep_return
-from .sac import HID, _dense, _l1, critic_flat_from_torch, critic_flat_to_torch  # noqa: F401
+from .sac import HID, _dense, _l1, critic_flat_from_torch, critic_flat_to_torch, use_hidden  # noqa: F401
 
 TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
                        "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
@@ -38,23 +38,25 @@ class TD3StateC(C.Structure):
                                           "critic2_m", "critic2_v", "actor_old", "critic1_old", "critic2_old")]
 
 
-def layout(obs_dim: int, act_dim: int) -> dict[str, int]:
+def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
     out = (C.c_int64 * 4)()
-    _lib.check(_lib.load().ts_td3_layout(_lib.i64(obs_dim), _lib.i64(act_dim), out))
+    _lib.check(_lib.load().ts_td3_layout_h(_lib.i64(obs_dim), _lib.i64(act_dim), _lib.i64(hidden), out))
     return dict(zip(["ka", "kc", "actor_count", "critic_count"], (int(v) for v in out)))
 
 
 def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, wa, ba] in torch nn.Linear layout -> flat engine vector."""
-    lay = layout(obs_dim, act_dim)
+    """[w1, b1, w2, b2, wa, ba] in torch nn.Linear layout -> flat engine vector (hidden width read off the tensors)."""
+    HID = int(t[0].shape[0])
+    lay = layout(obs_dim, act_dim, HID)
     head = torch.zeros((HID + 1, 32), dtype=torch.float32)
     head[:HID, :act_dim] = t[4].detach().float().cpu().t()
     head[HID, :act_dim] = t[5].detach().float().cpu()
     return torch.cat([_l1(t[0], t[1], lay["ka"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
-    lay = layout(obs_dim, act_dim)
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID) -> list[torch.Tensor]:
+    HID = hidden
+    lay = layout(obs_dim, act_dim, HID)
     f = flat.detach()
     n1 = (lay["ka"] + 1) * HID
     l1 = f[:n1].reshape(lay["ka"] + 1, HID)
@@ -86,12 +88,14 @@ class TD3Engine:
     """State of one TD3 / DDPG learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor | None, cfg: TD3Config):
+                 critic2: torch.Tensor | None, cfg: TD3Config, hidden: int = HID):
+        """`hidden`: width of the Net[hidden, hidden] trunks (any multiple of 32 up to 1024; 256 in the examples)."""
         if not actor.is_cuda:
             raise RuntimeError("TD3Engine needs parameters on an MI355X (no CPU fallback)")
         if cfg.twin != (critic2 is not None):
             raise ValueError("cfg.twin and critic2 disagree")
-        lay = layout(obs_dim, act_dim)
+        self.hidden = int(hidden)
+        lay = layout(obs_dim, act_dim, self.hidden)
         if actor.numel() != lay["actor_count"] or critic1.numel() != lay["critic_count"]:
             raise ValueError("flat parameter vectors do not match ts_td3_layout")
         self.obs_dim, self.act_dim, self.cfg, self.lay, self.device = obs_dim, act_dim, cfg, lay, actor.device
@@ -113,6 +117,7 @@ class TD3Engine:
     def policy_forward(self, obs) -> torch.Tensor:
         obs = self._f32(obs)
         act = torch.empty((obs.shape[0], self.act_dim), dtype=torch.float32, device=self.device)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_td3_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.i64(obs.shape[0]), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.f64(self.cfg.max_action), _lib.ptr(act), _lib.current_stream(self.device)))
@@ -126,6 +131,7 @@ class TD3Engine:
             raise ValueError("TD3 needs the target-smoothing noise (the torch.randn draws of td3.py:196)")
         noise = self._f32(noise, (b, self.act_dim)) if cfg.twin else None
         out = torch.empty(b, dtype=torch.float32, device=self.device)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_td3_target_q(
             self._ws.handle, _lib.ptr(self.actor_old), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(obs_next), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -162,6 +168,7 @@ class TD3Engine:
         st = TD3StateC(*[None if getattr(self, n) is None else getattr(self, n).data_ptr() for n in names])
         hp = TD3HParams(cfg.actor_lr * lr_scale, cfg.critic_lr * lr_scale, cfg.betas[0], cfg.betas[1], cfg.adam_eps,
                         cfg.tau, cfg.max_action, int(upd), 0)
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_td3_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cnt), _lib.i64(max(self.actor_steps, 1)), _lib.ptr(obs),
             _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight), _lib.i64(b), _lib.i64(self.obs_dim),
