@@ -70,6 +70,23 @@ class SACTrainingStats:
 
 
 @dataclass
+class TD3TrainingStats:
+    """tianshou/algorithm/modelfree/td3.py:20-25."""
+    actor_loss: float
+    critic1_loss: float
+    critic2_loss: float
+    train_time: float = 0.0
+
+
+@dataclass
+class DDPGTrainingStats:
+    """tianshou/algorithm/modelfree/ddpg.py:35-38."""
+    actor_loss: float
+    critic_loss: float
+    train_time: float = 0.0
+
+
+@dataclass
 class SimpleLossTrainingStats:
     """tianshou/algorithm/modelfree/reinforce.py:63-66."""
     loss: float
@@ -293,6 +310,43 @@ class SAC(Algorithm):
 
     def update(self, buffer, sample_size):
         return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
+class ContinuousActorDeterministic(nn.Module):
+    """utils/net/continuous.py:26-85: `preprocess` + `last` (MLP with one Linear), `max_action`."""
+
+    def __init__(self, preprocess_net, act_dim, max_action=1.0):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.last = _MLP([preprocess_net.output_dim, act_dim], None)
+        self.max_action = max_action
+
+
+class TD3(Algorithm):
+    """modelfree/td3.py:104-188 over ddpg.py:213-264: attribute names as the reference stores them."""
+
+    def __init__(self, *, policy, critic, critic2, lr=1e-3, critic_lr=None, tau=0.005, gamma=0.99, policy_noise=0.2,
+                 update_actor_freq=2, noise_clip=0.5, n_step_return_horizon=1):
+        import copy
+
+        super().__init__(policy)
+        self.policy_optim = self._create_optimizer(policy, lr)
+        self.critic, self.critic2 = critic, critic2
+        self.critic_old = EvalModeModuleWrapper(copy.deepcopy(critic))
+        self.critic2_old = EvalModeModuleWrapper(copy.deepcopy(critic2))
+        self.actor_old = EvalModeModuleWrapper(copy.deepcopy(policy.actor))
+        self.critic_optim = self._create_optimizer(critic, critic_lr or lr)
+        self.critic2_optim = self._create_optimizer(critic2, critic_lr or lr)
+        self.tau, self.gamma, self.n_step_return_horizon = tau, gamma, n_step_return_horizon
+        self.policy_noise, self.update_actor_freq, self.noise_clip = policy_noise, update_actor_freq, noise_clip
+        self._cnt, self._last = 0, 0
+
+    def update(self, buffer, sample_size):
+        return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
+class DDPG(Algorithm):
+    """modelfree/ddpg.py:343-395 (only what the factory needs to build the class)."""
 
 
 class DQNet(nn.Module):

@@ -388,3 +388,55 @@ def test_hip_dqn_hooks_against_oracle(huber):
     sampled indices.  The host buffer keeps growing between updates until every sub-buffer has wrapped: the mirror's
     incremental sync (write log) follows."""
     _dqn_hook_run(huber)
+
+
+# ------------------------------------------------------------------------------------ HipTD3
+def test_hip_td3_hooks_against_oracle():
+    """HipTD3 (integration.make_hip_td3 over the stand-ins) on the real engine with Net[128, 128] trunks (a width other than
+    the example's 256): growing host buffer -> incremental mirror, smoothed lagged-actor target (td3.py:190-202, the
+    reference's torch.randn draw replayed), twin critic steps, delayed actor step (every 2nd update), Polyak of three
+    networks, write-back of six networks + three optimizers -- against oracle_sac's TD3 restatement fed with the same
+    sampled indices."""
+    from oracle import oracle_sac as OS
+    from tianshou_amd.integration import make_hip_td3
+
+    obs_dim, act_dim, E, B, H = 17, 6, 4, 64, 128
+    HipTD3 = make_hip_td3(ref=SI)
+    torch.manual_seed(21)
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, [H, H], nn.ReLU), act_dim, max_action=1.0)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [H, H], nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [H, H], nn.ReLU))
+    algo = HipTD3(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=3e-4, critic_lr=1e-3, tau=0.01, gamma=0.98,
+                  policy_noise=0.2, update_actor_freq=2, noise_clip=0.5, device="cuda").to("cuda")
+    grab = lambda mod, keys: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(keys, mod.state_dict())}   # noqa: E731
+    cfg = OS.TD3Config(gamma=0.98, tau=0.01, n_step=1, twin=True, policy_noise=0.2, noise_clip=0.5, update_actor_freq=2,
+                       max_action=1.0, actor_lr=3e-4, critic_lr=1e-3)
+    st = OS.TD3State.create(grab(actor, OS.DET_ACTOR_ORDER), grab(c1, OS.CRITIC_ORDER), grab(c2, OS.CRITIC_ORDER), cfg)
+    buf = SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=6)
+    rng = np.random.default_rng(2)
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, rng)
+        torch.manual_seed(300 + u)
+        stats = algo.update(buf, B)
+        idx = seen[-1]
+        torch.manual_seed(300 + u)
+        noise = torch.randn(B, act_dim)                                           # td3.py:196
+        obs, act = torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx])
+        tq = OS.td3_target_q(st, cfg, torch.from_numpy(buf.obs_next[idx]), noise).flatten().numpy()
+        ret = (buf.rew[idx] + 0.98 * tq.astype(np.float64) * (~buf.terminated[idx])).astype(np.float32)
+        ref = OS.td3_update_with_batch(st, cfg, obs, act, ret)
+        np.testing.assert_allclose([stats.actor_loss, stats.critic1_loss, stats.critic2_loss],
+                                   [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=2e-5, atol=2e-6)
+        assert algo._cnt == st.cnt == u + 1
+    for mod, ref_p, order in ((actor, st.actor, OS.DET_ACTOR_ORDER), (c1, st.critic1, OS.CRITIC_ORDER),
+                              (c2, st.critic2, OS.CRITIC_ORDER), (algo.actor_old.module, st.actor_old, OS.DET_ACTOR_ORDER),
+                              (algo.critic_old.module, st.critic1_old, OS.CRITIC_ORDER)):
+        for (name, t), k in zip(mod.state_dict().items(), order):                  # a few Adam steps: compare on lr's scale
+            np.testing.assert_allclose(t.detach().cpu().numpy(), ref_p[k].numpy(), rtol=1e-5, atol=0.05 * 1e-3, err_msg=name)
+    st_a = algo.policy_optim._optim.state[next(iter(actor.parameters()))]
+    st_c = algo.critic_optim._optim.state[next(iter(c1.parameters()))]
+    assert float(st_a["step"]) == 2.0 and float(st_c["step"]) == 4.0               # the actor stepped at updates 0 and 2

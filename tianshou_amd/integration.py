@@ -1671,9 +1671,11 @@ def make_hip_ppo_discrete(algo: str = "ppo"):
 # ---------------------------------------------------------------------------------------------------
 # TD3 / DDPG (td3.py:104-226, ddpg.py:343-411) on the mujoco_td3.py / mujoco_ddpg.py networks
 # ---------------------------------------------------------------------------------------------------
-def _make_hip_det(twin: bool):
-    from tianshou.algorithm.modelfree.ddpg import DDPG, DDPGTrainingStats
-    from tianshou.algorithm.modelfree.td3 import TD3, TD3TrainingStats
+def _make_hip_det(twin: bool, ref=None):
+    DDPG = _ref(ref, "tianshou.algorithm.modelfree.ddpg", "DDPG")
+    DDPGTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.ddpg", "DDPGTrainingStats")
+    TD3 = _ref(ref, "tianshou.algorithm.modelfree.td3", "TD3")
+    TD3TrainingStats = _ref(ref, "tianshou.algorithm.modelfree.td3", "TD3TrainingStats")
 
     from . import td3 as T
 
@@ -1780,11 +1782,11 @@ S_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "p
           "preprocess.model.model.2.bias", "last.model.0.weight", "last.model.0.bias"]
 
 
-def make_hip_td3():
-    """Returns HipTD3(TD3) (hooks td3.py:190-226 on the engine)."""
-    return _make_hip_det(True)
+def make_hip_td3(ref=None):
+    """Returns HipTD3(TD3) (hooks td3.py:190-226 on the engine).  `ref`: namespace replacing the tianshou imports."""
+    return _make_hip_det(True, ref)
 
 
-def make_hip_ddpg():
+def make_hip_ddpg(ref=None):
     """Returns HipDDPG(DDPG) (hooks ddpg.py:397-411 on the engine)."""
-    return _make_hip_det(False)
+    return _make_hip_det(False, ref)
