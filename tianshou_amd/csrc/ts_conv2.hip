@@ -374,12 +374,15 @@ void conv_rows2_kernel(Rows2Args a) {
                     const bool col_ok = col < a.N;
                     float bias = 0.f;
                     if (!DG && a.bias) bias = a.bias[col_ok ? col : 0];
+                    // mask loads of a tile go out as batches (one dependent round trip each): 16 where the register
+                    // budget allows (32-column variants), 8 for the 16-wave 64-column variants
+                    constexpr int EB = (TM == 1 && TN == 1) ? 16 : 8;
 #pragma unroll
-                    for (int x0 = 0; x0 < 16; x0 += 8) {          // batches of 8: register budget of the 16-wave variants
-                        unsigned off[8];
-                        bool ok[8];
+                    for (int x0 = 0; x0 < 16; x0 += EB) {
+                        unsigned off[EB];
+                        bool ok[EB];
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < EB; ++i) {
                             const int x = x0 + i, row = (x & 3) + 8 * (x >> 2) + 4 * h;
                             if (!DG) {
                                 const int m = mrow0 + tm * 32 + row;
@@ -391,13 +394,13 @@ void conv_rows2_kernel(Rows2Args a) {
                                 off[i] = ok[i] ? (unsigned)(ob + col) : 0u;
                             }
                         }
-                        float mk[MASK ? 8 : 1];
+                        float mk[MASK ? EB : 1];
                         if constexpr (MASK) {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) mk[i] = a.mask[off[i]];
+                            for (int i = 0; i < EB; ++i) mk[i] = a.mask[off[i]];
                         }
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
+                        for (int i = 0; i < EB; ++i) {
                             float v = acc[tm][tn][x0 + i];
                             if (!DG) {
                                 v += bias;
