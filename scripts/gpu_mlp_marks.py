@@ -1,7 +1,11 @@
 """Phase marks of one fused-MLP launch (workgroup 0, thread 0; s_memtime ticks, ~2.36 per ns measured against HIP events).
-Build with TS_EXTRA_FLAGS="ts_mlp.hip:-DTS_MLP_MARKS"."""
+Builds its own copy of the library with -DTS_MLP_MARKS (the shipped one carries neither the marks nor the entry point)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.getcwd())
+if "TS_LIB_PATH" not in os.environ:
+    from tianshou_amd import build as _b
+    os.environ["TS_EXTRA_FLAGS"] = "ts_mlp.hip:-DTS_MLP_MARKS"
+    os.environ["TS_LIB_PATH"] = _b.build_library(out=os.path.join(_b.LIBDIR, "libtsengine_mlpmarks.so"))
 import torch
 from tianshou_amd import sac as S, _lib
 
@@ -27,4 +31,14 @@ out = (C.c_uint64 * 8)()
 lib.ts_debug_mlp_marks(out)
 t = list(out)
 names = ["start", "x in LDS", "layer 1 (wave 0)", "barrier", "layer 2 + barrier", "head"]
+print("raw ticks:", [t[k] - t[0] for k in range(6)])
 print(" ".join(f"{names[k]}=+{(t[k] - t[k - 1]) / 2.36:.0f}ns" for k in range(1, 6)), "total", round((t[5] - t[0]) / 2.36), "ns")
+
+tr = (C.c_uint64 * 320)()
+lib.ts_debug_mlp_trace(tr)
+tr = list(tr)
+ng1 = 384 // 32
+print("per wave: clock (ns after the kernel's first mark) at the start of each 32-deep group; layer 1 =", ng1, "groups, then its end, a gap, layer 2 = 8 groups, its end")
+for w in range(8):
+    row = tr[40 * w: 40 * w + ng1 + 11]
+    print(f"wave {w}:", " ".join(f"{(v - t[0]) / 2.36:6.0f}" if v else "     -" for v in row))

@@ -421,6 +421,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
     __shared__ Aff lds[GAE_WAVES];
     __shared__ double red[2 * GAE_WAVES];
     __shared__ int64_t tile_s;
+    __shared__ int closed_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t tile;
     if (launch.direct) {
@@ -461,7 +462,11 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
     Aff excl = shfl_down_aff(incl, 1);
     if (lane == 63) excl = aff_identity();
     if (lane == 0) lds[wave] = incl;
+    // A tile whose LAST transition ends an episode (or sits on a cut: the end of a sub-buffer, which is where power-of-two
+    // tiles of a [envs x steps] rollout end) takes nothing from the tiles after it: no poll, no second round of barriers.
+    if (threadIdx.x == GAE_THREADS - 1) closed_s = c[GAE_ITEMS - 1] == 0.0 ? 1 : 0;
     __syncthreads();
+    const bool closed = closed_s != 0;
     Aff wmap[GAE_WAVES];
 #pragma unroll
     for (int w = 0; w < GAE_WAVES; ++w) wmap[w] = lds[w];
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(GAE_THREADS) void gae_single_pass(GaeArgs<RewT> g, 
     // rounds per tile.
     Aff acc = aff_identity();
     int64_t t0 = tile + 1;
-    for (int round = 0; t0 < n_tiles; ++round) {
+    for (int round = 0; !closed && t0 < n_tiles; ++round) {
         const int width = round == 0 ? 1 : (round == 1 ? 15 : (round == 2 ? 240 : GAE_THREADS));
         Aff f = aff_identity();
         const int64_t t = t0 + threadIdx.x;
