@@ -1,4 +1,4 @@
 mkdir -p gpurun_out/g1
 export PYTHONPATH=.
-timeout 200 python scripts/gpu_mlp_marks.py > gpurun_out/g1/marks.txt 2>&1
-cat gpurun_out/g1/marks.txt
+timeout 1200 python -m pytest tests/test_gpu_sac.py tests/test_gpu_td3.py tests/test_gpu_redq.py tests/test_gpu_dsac.py tests/test_gpu_dqn.py tests/test_gpu_hooks.py -x -q -m gpu > gpurun_out/g1/pytest.txt 2>&1
+tail -n 5 gpurun_out/g1/pytest.txt

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
 // wgrad: rows = k, columns = oc, reduction over output pixels; split over pixel ranges into slabs
 // ------------------------------------------------------------------------------------------------
 template <int TM, int TN, int WM, int WN>
-__global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const GemmArgs& a, const int kt, const int ny, const int split) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AQ = BM / 4;                 // float4 per staged row of A
     constexpr int ARS = THREADS / AQ;          // row stride between a thread's A loads
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
     const ts::ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
-    const int kt = blockIdx.x, n0 = blockIdx.y * BN, split = blockIdx.z;
+    const int n0 = ny * BN;
     const int run = g.KW * g.IC, pitch = g.IW * g.IC;
 
     const int k4 = tid % AQ, arow = tid / AQ;
@@ -343,6 +343,35 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
     }
 }
 
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
+    conv_wgrad_body<TM, TN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The weight gradients of several layers in ONE launch (the three Linear layers of a SAC-family network, or of both twin
+// critics: 0.07 - 0.9 GFLOP each, 9 - 15 us as launches of their own, most of it launch and tail).  blockIdx.x runs over
+// the layers' (k tile, column tile, split) grids back to back; a layer is the 128 x 64 or the 128 x 32 variant by its
+// output width, exactly as in conv_wgrad, so that the result is bit-identical to separate launches.
+constexpr int WGRAD_GROUP_MAX = 6;
+struct WgradGroup {
+    GemmArgs a[WGRAD_GROUP_MAX];
+    int first[WGRAD_GROUP_MAX + 1];        // first linear block of layer i
+    int gx[WGRAD_GROUP_MAX], gy[WGRAD_GROUP_MAX];
+    int wide[WGRAD_GROUP_MAX];             // 1: <2, 1, 2, 2> (64 columns), 0: <1, 1, 4, 1> (32 columns)
+    int n;
+};
+
+__global__ __launch_bounds__(THREADS) void conv_wgrad_group_kernel(WgradGroup gr) {
+    int i = 0;
+    while (i + 1 < gr.n && (int)blockIdx.x >= gr.first[i + 1]) ++i;
+    const int local = (int)blockIdx.x - gr.first[i];
+    const int per = gr.gx[i] * gr.gy[i];
+    const int split = local / per, rem = local - split * per;
+    const int ny = rem / gr.gx[i], kt = rem - ny * gr.gx[i];
+    if (gr.wide[i]) conv_wgrad_body<2, 1, 2, 2>(gr.a[i], kt, ny, split);
+    else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split);
+}
+
 // out[i] = sum_s slabs[s][i]: a workgroup owns 64 consecutive floats (16 float4 columns) and splits the
 // slabs over its 16 thread rows; fixed-order tree over the rows (deterministic).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab, int64_t n,
@@ -363,15 +392,17 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
     if (part == 0 && i < n) *reinterpret_cast<f32x4*>(out + i) = red[col];
 }
 
-// The same sum for up to four independent slab sets in one launch (the layers of one network's backward pass)
+// The same sum for up to eight independent slab sets in one launch (the layers of one or two networks' backward passes)
+constexpr int SLAB_SEGS_MAX = 8;
 struct SlabSegs {
-    const float* slabs[4]; float* out[4]; int64_t n[4]; int nslab[4]; unsigned first_block[5];
+    const float* slabs[SLAB_SEGS_MAX]; float* out[SLAB_SEGS_MAX]; int64_t n[SLAB_SEGS_MAX]; int nslab[SLAB_SEGS_MAX];
+    unsigned first_block[SLAB_SEGS_MAX + 1];
 };
 __global__ __launch_bounds__(256) void slab_sum_multi_kernel(SlabSegs a) {
     __shared__ f32x4 red[256];
     int sg = 0;
 #pragma unroll
-    for (int k = 1; k < 4; ++k) sg += blockIdx.x >= a.first_block[k] ? 1 : 0;
+    for (int k = 1; k < SLAB_SEGS_MAX; ++k) sg += blockIdx.x >= a.first_block[k] ? 1 : 0;
     const float* __restrict__ slabs = a.slabs[sg];
     const int64_t n = a.n[sg];
     const int nslab = a.nslab[sg];
@@ -528,6 +559,45 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
     return TS_OK;
 }
 
+int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const* X, const float* const* dY,
+                     float* const* slabs, ts_workspace* prof) {
+    TS_REQUIRE(n >= 1 && n <= WGRAD_GROUP_MAX, TS_ERR_INVALID_ARG, "conv_wgrad_group: 1 .. %d layers", WGRAD_GROUP_MAX);
+    bool one_launch = n > 1;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = check_geom(g[i])) return rc;
+        if (conv2_use_wgrad(g[i], false)) one_launch = false;        // large layers have their own kernels (ts_conv2.hip)
+    }
+    static const bool off = getenv("TS_WGRAD_NO_GROUP") != nullptr;     // experiments
+    if (!one_launch || off) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = conv_wgrad(s, g[i], X[i], dY[i], slabs[i], prof, false)) return rc;
+        return TS_OK;
+    }
+    WgradGroup gr;
+    gr.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs a = base_args(g[i]);
+        a.a_u8 = 0;
+        a.A = X[i]; a.Bm = dY[i]; a.C = slabs[i];
+        a.total_chunks = (int)ceil_div(a.M, BK);
+        const int nsplit = conv_wgrad_splits(g[i]);
+        a.chunks = (int)ceil_div(a.total_chunks, nsplit);
+        a.slab_stride = g[i].param_elems();
+        gr.a[i] = a;
+        gr.wide[i] = g[i].OC % 64 == 0 ? 1 : 0;
+        gr.gx[i] = (int)ceil_div(a.K, 128);
+        gr.gy[i] = g[i].OC / (gr.wide[i] ? 64 : 32);
+        gr.first[i] = blocks;
+        blocks += gr.gx[i] * gr.gy[i] * nsplit;
+    }
+    for (int i = n; i <= WGRAD_GROUP_MAX; ++i) gr.first[i] = blocks;
+    ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
+    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, gr);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
 int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* Wb, const float* mask,
                float* dX, ts_workspace* prof, int col_begin, int col_end) {
     if (int rc = check_geom(g)) return rc;
@@ -569,10 +639,10 @@ int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out
 }
 
 int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg) {
-    TS_REQUIRE(nseg >= 1 && nseg <= 4, TS_ERR_INVALID_ARG, "slab_sum_multi: 1..4 segments");
+    TS_REQUIRE(nseg >= 1 && nseg <= SLAB_SEGS_MAX, TS_ERR_INVALID_ARG, "slab_sum_multi: 1..%d segments", SLAB_SEGS_MAX);
     SlabSegs a{};
     unsigned blocks = 0;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < SLAB_SEGS_MAX; ++k) {
         a.first_block[k] = blocks;
         if (k < nseg) {
             TS_REQUIRE(segs[k].n % 4 == 0 && segs[k].n > 0, TS_ERR_INVALID_ARG, "slab_sum_multi: lengths must be multiples of 4");
@@ -582,7 +652,7 @@ int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg) {
             a.first_block[k] = 0xffffffffu;
         }
     }
-    a.first_block[4] = blocks;
+    a.first_block[SLAB_SEGS_MAX] = blocks;
     hipLaunchKernelGGL(slab_sum_multi_kernel, dim3(blocks), dim3(256), 0, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;

@@ -613,7 +613,7 @@ __device__ __forceinline__ void net_tile(float* lds, float* R, float* scratch, c
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     constexpr int net = ACTOR ? 0 : 1;
-    constexpr int MK = ACTOR ? 2 : 10;
+    [[maybe_unused]] constexpr int MK = ACTOR ? 2 : 10;
     const int i = lane & 31, h = lane >> 5;
 
     f32x16 h1[2], h2[2];
@@ -1084,7 +1084,7 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
     using L = Lds<KS1, 1>;
     int lane = lane_in;
     asm volatile("" : "+v"(lane));          // see net_tile: keeps lane-dependent addresses out of the prologue
-    constexpr int MK = ACTOR ? 2 : 10;
+    [[maybe_unused]] constexpr int MK = ACTOR ? 2 : 10;
     constexpr int NA = ACTOR ? ACT_PAD : 1;
     const int i = lane & 31, h = lane >> 5;
     trunk_forward<KS1, 1>(lds, 0, in.x, i, h, h1, h2);
@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
                                           const f32x16 (&h1)[2], const f32x16 (&dz2)[2], const f32x16 (&dz1)[2],
                                           const float (&gw)[ACTOR ? ACT_PAD : 1], float misc, int wave, int lane_in,
                                           float* slab, const Slab2& SL, bool first) {
-    constexpr int MK = ACTOR ? 2 : 10;
+    [[maybe_unused]] constexpr int MK = ACTOR ? 2 : 10;
     constexpr int NA = ACTOR ? ACT_PAD : 1;
     constexpr int net = ACTOR ? 0 : 1;
     constexpr int KP = 2 * KS1;

@@ -373,7 +373,7 @@ __device__ __forceinline__ void net_fwd_bwd3(const char* L, float* scratch, cons
                                              float (&gw)[ACTOR ? ACT_PAD : 1], float& misc) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    constexpr int MK = ACTOR ? 2 : 10;
+    [[maybe_unused]] constexpr int MK = ACTOR ? 2 : 10;
     constexpr int NA = ACTOR ? ACT_PAD : 1;
     const int i = lane & 31, h = lane >> 5;
     const float* f32t = reinterpret_cast<const float*>(L + F32_OFF);

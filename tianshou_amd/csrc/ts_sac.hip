@@ -78,6 +78,35 @@ size_t split_floats(const Mlp& m) {
 
 struct BwdScratch { float* dh2; float* dh1; float* slabs; };
 
+bool fused_backward(const Mlp& m, bool want_dx, int col0, int col1) {
+    return m.l[1].OC == m.l[0].OC && ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, want_dx, col0, col1);
+}
+
+// Weight gradients of n <= 2 networks of the same shape whose input-gradient chains (mlp3_backward) have run on stream
+// s: all 3 n GEMMs in one launch, all 3 n slab sets summed in one launch.
+int mlp_weight_grads(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const float* const* x, const Act* a,
+                     const float* const* d_out, float* const* grad, const BwdScratch* sc) {
+    ts::ConvGeom geoms[6];
+    const float* X[6];
+    const float* dY[6];
+    float* slabs[6];
+    ts::SlabSeg seg[6];
+    for (int k = 0; k < n; ++k) {
+        const float* xin[3] = {x[k], a[k].h1, a[k].h2};
+        const float* dy[3] = {sc[k].dh1, sc[k].dh2, d_out[k]};
+        size_t off = 0;
+        for (int i = 2; i >= 0; --i) {
+            const int j = 3 * k + (2 - i);
+            const int ns = ts::conv_wgrad_splits(m.l[i]);
+            geoms[j] = m.l[i]; X[j] = xin[i]; dY[j] = dy[i]; slabs[j] = sc[k].slabs + off;
+            seg[j] = ts::SlabSeg{sc[k].slabs + off, ns, m.l[i].param_elems(), grad[k] + m.off[i]};
+            off += (size_t)ns * m.l[i].param_elems();
+        }
+    }
+    if (int rc = ts::conv_wgrad_group(s, 3 * n, geoms, X, dY, slabs, ws)) return rc;
+    return ts::slab_sum_multi(s, seg, 3 * n);
+}
+
 // d_out = d loss / d head output.  grad (nullable) receives the flat parameter gradient; dx (nullable) the
 // gradient w.r.t. the input columns [col0, col1).  `part`: 1 = the input-gradient chain, 2 = the weight gradients,
 // 3 = both -- callers that run two networks on two streams enqueue part 1 of both before part 2 of either, so that
@@ -88,23 +117,14 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
     const float* xin[3] = {x, a.h1, a.h2};
     const float* dy[3] = {sc.dh1, sc.dh2, d_out};
     float* dxl[3] = {dx, sc.dh1, sc.dh2};
-    if (m.l[1].OC == m.l[0].OC &&
-        ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, dx != nullptr, col0, col1)) {
-        // all input gradients in one launch (ts_mlp.hip), then the three weight-gradient GEMMs
+    if (fused_backward(m, dx != nullptr, col0, col1)) {
+        // all input gradients in one launch (ts_mlp.hip), then the three weight-gradient GEMMs in one launch
         if (part & 1)
             if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2],
                                            m.l[2].OC, a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
                 return rc;
         if (!grad || !(part & 2)) return TS_OK;
-        ts::SlabSeg seg[3];
-        size_t off = 0;
-        for (int i = 2; i >= 0; --i) {          // three independent GEMMs into their own slab sets, one sum launch
-            const int ns = ts::conv_wgrad_splits(m.l[i]);
-            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs + off, ws)) return rc;
-            seg[2 - i] = ts::SlabSeg{sc.slabs + off, ns, m.l[i].param_elems(), grad + m.off[i]};
-            off += (size_t)ns * m.l[i].param_elems();
-        }
-        return ts::slab_sum_multi(s, seg, 3);
+        return mlp_weight_grads(s, ws, 1, m, &x, &a, &d_out, &grad, &sc);
     }
     if (!(part & 1)) return TS_OK;
     for (int i = 2; i >= 0; --i) {
@@ -889,10 +909,18 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
     }
+    // both critics on one stream (the one-launch chains): their six weight-gradient GEMMs share a launch
+    const bool twin_group = side == s && fused_backward(mc, false, 0, 0);
+    if (twin_group && (phases & PH_CRITIC_GRAD)) {
+        const float* xs2[2] = {x_c, x_c};
+        const float* dh2[2] = {dheads[0], dheads[1]};
+        float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
+        if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
+    }
     for (int k = 0; k < 2; ++k) {
         hipStream_t sk = stq[k];
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (phases & PH_CRITIC_GRAD)
+        if ((phases & PH_CRITIC_GRAD) && !twin_group)
             if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 2)) return rc;
         if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0)
             if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
@@ -1118,6 +1146,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     const Act acts[2] = {a1, a2};
     if (twin)
         if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    const bool twin_group = twin && side == s && fused_backward(mc, false, 0, 0);
     for (int k = 0; k < (twin ? 2 : 1); ++k) {
         hipStream_t sk = stq[k];
         if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
@@ -1125,9 +1154,20 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
                            dheads[k], loss_part + (1 + k) * gb);
         TS_LAUNCH_CHECK();
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
-        if (hp->critic_lr >= 0.0)
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], twin_group ? 1 : 3))
+            return rc;
+        if (!twin_group && hp->critic_lr >= 0.0)
             if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, critic_step, hp->critic_lr, hp->beta1,
+                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
+                return rc;
+    }
+    if (twin_group) {      // both critics on one stream (the one-launch chains): six weight-gradient GEMMs, one launch
+        const float* xs2[2] = {x_c, x_c};
+        const float* dh2[2] = {dheads[0], dheads[1]};
+        float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
+        if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
+        for (int k = 0; k < 2 && hp->critic_lr >= 0.0; ++k)
+            if (int rc = ts::adam_step(s, crit[k], crit_m[k], crit_v[k], gk2[k], pc, critic_step, hp->critic_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
                 return rc;
     }
