@@ -30,15 +30,13 @@ print("policy_forward (pack + fused MLP + policy kernel):", round(e0.elapsed_tim
 out = (C.c_uint64 * 8)()
 lib.ts_debug_mlp_marks(out)
 t = list(out)
-names = ["start", "x in LDS", "layer 1 (wave 0)", "barrier", "layer 2 + barrier", "head"]
-print("raw ticks:", [t[k] - t[0] for k in range(6)])
-print(" ".join(f"{names[k]}=+{(t[k] - t[k - 1]) / 2.36:.0f}ns" for k in range(1, 6)), "total", round((t[5] - t[0]) / 2.36), "ns")
-
+names = ["start", "x in LDS", "layer 1", "layer 2", "head"]
+print("raw ticks:", [t[k] - t[0] for k in range(5)])
+print(" ".join(f"{names[k]}=+{(t[k] - t[k - 1]) / 2.36:.0f}ns" for k in range(1, 5)), "total", round((t[4] - t[0]) / 2.36), "ns")
 tr = (C.c_uint64 * 320)()
 lib.ts_debug_mlp_trace(tr)
 tr = list(tr)
-ng1 = 384 // 32
-print("per wave: clock (ns after the kernel's first mark) at the start of each 32-deep group; layer 1 =", ng1, "groups, then its end, a gap, layer 2 = 8 groups, its end")
+print("per wave: clock (ns after the kernel's first mark) at the start of each 16-deep block: layer 1 slots 0.., layer 2 slots 16.., head 32..")
 for w in range(8):
-    row = tr[40 * w: 40 * w + ng1 + 11]
+    row = tr[40 * w: 40 * w + 36]
     print(f"wave {w}:", " ".join(f"{(v - t[0]) / 2.36:6.0f}" if v else "     -" for v in row))
