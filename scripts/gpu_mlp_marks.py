@@ -40,3 +40,20 @@ print("per wave: clock (ns after the kernel's first mark) at the start of each 1
 for w in range(8):
     row = tr[40 * w: 40 * w + 36]
     print(f"wave {w}:", " ".join(f"{(v - t[0]) / 2.36:6.0f}" if v else "     -" for v in row))
+
+# the same marks after one whole SAC update: the last fused launch is the actor's backward pass (no input gradient)
+act = torch.tanh(torch.randn(4096, 17, device="cuda"))
+ret = torch.randn(4096, device="cuda")
+for _ in range(3):
+    eng.update_with_batch(obs, act, ret, noise)
+torch.cuda.synchronize()
+lib.ts_debug_mlp_marks(out)
+t = list(out)
+names = ["start", "d_out in LDS", "layer 3^T", "layer 2^T"]
+print("backward:", " ".join(f"{names[k]}=+{(t[k] - t[k - 1]) / 2.36:.0f}ns" for k in range(1, 4)), "total", round((t[3] - t[0]) / 2.36), "ns")
+tr2 = (C.c_uint64 * 320)()
+lib.ts_debug_mlp_trace(tr2)
+trl = list(tr2)
+for w in range(8):
+    row = trl[40 * w: 40 * w + 36]
+    print(f"wave {w}:", " ".join(f"{(v - t[0]) / 2.36:6.0f}" if v > t[0] else "     -" for v in row))

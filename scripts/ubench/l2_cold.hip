@@ -1,0 +1,59 @@
+// Micro-benchmark: ONE pass of eight waves per CU over a 704 KB weight matrix in the fused-MLP pattern (dwordx4, sixteen
+// lanes x 16 B = 256 B of a row, four adjacent rows per instruction), every workgroup the same matrix --
+//   warm: the matrix was just read (resident in every XCD's L2);
+//   cold: 512 MB streamed through in between (the matrix comes from HBM / the infinity cache; first touch per XCD).
+// Prints the time of the pass inside workgroup 0 (s_memtime) and by HIP events.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int INFLIGHT>
+__global__ __launch_bounds__(512) void stream(const float* __restrict__ w, int rows, float* out, unsigned long long* clk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const float* p = w + (size_t)(kq + (wave / 4) * (rows / 2)) * 256 + 64 * (wave % 4) + 4 * n;
+    for (int r = 0; r < rows / 2; r += 4 * INFLIGHT) {
+        f32x4 v[INFLIGHT];
+#pragma unroll
+        for (int i = 0; i < INFLIGHT; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(r + 4 * i) * 256);
+#pragma unroll
+        for (int i = 0; i < INFLIGHT; ++i) acc += v[i];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[threadIdx.x] = acc[0];
+}
+
+__global__ void flush(const float4* __restrict__ big, size_t n4, float* out) {
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) s += big[i].x;
+    if (s == 123.456f) out[0] = s;
+}
+
+int main() {
+    const int rows = 704;
+    float *w, *out, *big; unsigned long long* clk;
+    const size_t big_bytes = 512ull << 20;
+    (void)hipMalloc(&w, (size_t)rows * 1024); (void)hipMemset(w, 0, (size_t)rows * 1024);
+    (void)hipMalloc(&big, big_bytes); (void)hipMemset(big, 0, big_bytes);
+    (void)hipMalloc(&out, 4096); (void)hipMalloc(&clk, 8 * 1024);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int blocks : {16, 256}) {
+        for (int cold = 0; cold < 2; ++cold) {
+            float best = 1e9f; unsigned long long bestc = ~0ull;
+            for (int rep = 0; rep < 5; ++rep) {
+                if (cold) hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, 0, (const float4*)big, big_bytes / 16, out);
+                else hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk);
+                (void)hipEventRecord(e0);
+                hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk);
+                (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+                unsigned long long c; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost); if (c < bestc) bestc = c;
+            }
+            printf("blocks %3d  %s : launch %6.1f us, workgroup 0 %6.2f us inside (%5.1f KB/us per CU)\n", blocks, cold ? "cold" : "warm",
+                   best * 1e3f, bestc / 100.0, rows * 1.0 / (bestc / 100.0));
+        }
+    }
+    return 0;
+}

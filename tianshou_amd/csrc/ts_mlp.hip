@@ -128,9 +128,12 @@ struct WStream {
         __builtin_amdgcn_sched_barrier(0);
     }
     // blocks 0 .. NST - 2 into stages 0 .. NST - 2: what a layer expects to find when it starts
+    // (in two parts around the kernel's first barrier: the SIMDs issue oldest wave first, and with all seven blocks of the
+    // four older waves queued ahead of them the younger waves' first block arrives later still)
+    template <int FROM, int TO>
     __device__ __forceinline__ void prime(Stage (&st)[NST]) const {
 #pragma unroll
-        for (int i = 0; i < NST - 1; ++i) load(i, st[i]);
+        for (int i = FROM; i < TO; ++i) load(i, st[i]);
     }
     __device__ __forceinline__ void prime_one(int i, Stage (&st)[NST]) const { load(i, st[i]); }
 };
@@ -285,10 +288,11 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     {
         f32x4 xr[XR];
         load_rows_issue(a.x, a.K1, m0, a.M, tid, xr);
-        w1.prime(st);                              // the first weights travel while the input rows do
+        w1.template prime<0, 2>(st);               // the first weights travel while the input rows do
         load_rows_commit(a.K1, xs, xp, tid, xr);
     }
     __syncthreads();
+    w1.template prime<2, NST - 1>(st);
     MMARK(1);
     mlp_layer<HID, false, 4, EP_BIAS_RELU>(w1, st, w2, xs, xp, part, h1s, a.h1, HID, nullptr, a.wb1 + (size_t)a.K1 * HID, m0,
                                            a.M, tid, 0);
@@ -324,17 +328,24 @@ __global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
     const WStream<N3, true, 4> w3(a.wb3, N3, HID, 0, wave, lane);
     const WStream<HID, true, 4> w2(a.wb2, HID, HID, 0, wave, lane);
     const WStream<HID, true, 4> w1(a.wb1, HID, a.dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane);
+    MMARK(0);
     {
         f32x4 xr[XR];
         load_rows_issue(a.d_out, N3, m0, a.M, tid, xr);
-        w3.prime(st);
+        w3.template prime<0, 2>(st);
         load_rows_commit(N3, ds, N3 + 4, tid, xr);
     }
     __syncthreads();
-    mlp_layer<N3, true, 4, EP_MASK>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2, HID, a.h2, nullptr, m0, a.M, tid);
-    mlp_layer<HID, true, 4, EP_MASK>(w2, st, w1, g2s, HP, part, g1s, a.dh1, HID, a.h1, nullptr, m0, a.M, tid);
-    if (a.dx == nullptr) return;
-    mlp_layer<HID, true, 4, EP_PLAIN>(w1, st, NoNext{}, g1s, HP, part, nullptr, a.dx, a.K1, nullptr, nullptr, m0, a.M, tid);
+    w3.template prime<2, NST - 1>(st);
+    MMARK(1);
+    mlp_layer<N3, true, 4, EP_MASK>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2, HID, a.h2, nullptr, m0, a.M, tid, 0);
+    MMARK(2);
+    mlp_layer<HID, true, 4, EP_MASK>(w2, st, w1, g2s, HP, part, g1s, a.dh1, HID, a.h1, nullptr, m0, a.M, tid, 16);
+    MMARK(3);
+    if (a.dx != nullptr) {
+        mlp_layer<HID, true, 4, EP_PLAIN>(w1, st, NoNext{}, g1s, HP, part, nullptr, a.dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
+        MMARK(4);
+    }
 }
 
 }  // namespace

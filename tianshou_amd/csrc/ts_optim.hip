@@ -77,9 +77,56 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     a.v[i] = v;
 }
 
+// The same step for up to three parameter vectors of equal length in one launch (blockIdx.y = vector), optionally
+// followed by the Polyak update of each vector's lagged copy from the NEW parameters (lagged_network.py:17-18) --
+// per element exactly adam_kernel (without clipping) and polyak_kernel.
+struct AdamMultiArgs {
+    float* p[3]; float* m[3]; float* v[3]; const float* g[3]; float* tgt[3];
+    int64_t n;
+    float lr_step, beta1, beta2, bc2_sqrt, eps, omb1, omb2, tau, one_minus_tau;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
+    const int k = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float gq = a.g[k][i];
+    float m = a.m[k][i], v = a.v[k][i];
+    m = m + (gq - m) * a.omb1;
+    v = v * a.beta2 + a.omb2 * gq * gq;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    const float pn = a.p[k][i] + (-a.lr_step * m) / denom;
+    a.p[k][i] = pn;
+    a.m[k][i] = m;
+    a.v[k][i] = v;
+    if (a.tgt[k]) a.tgt[k][i] = a.tau * pn + a.one_minus_tau * a.tgt[k][i];
+}
+
 }  // namespace
 
 namespace ts {
+int adam_step_multi(hipStream_t s, int nvec, float* const* params, float* const* m, float* const* v,
+                    const float* const* grad, float* const* lagged, int64_t n, int64_t step, double lr, double beta1,
+                    double beta2, double eps, double tau) {
+    TS_REQUIRE(nvec >= 1 && nvec <= 3, TS_ERR_INVALID_ARG, "adam_step_multi: 1..3 vectors");
+    AdamMultiArgs a{};
+    for (int k = 0; k < nvec; ++k) {
+        a.p[k] = params[k]; a.m[k] = m[k]; a.v[k] = v[k]; a.g[k] = grad[k];
+        a.tgt[k] = (lagged && tau > 0.0) ? lagged[k] : nullptr;
+    }
+    a.n = n;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.lr_step = (float)(lr / bc1);
+    a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = (float)eps;
+    a.tau = (float)tau; a.one_minus_tau = (float)(1.0 - tau);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)nvec), dim3(256), 0, s, a);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
 int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
               double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
     AdamArgs a{};

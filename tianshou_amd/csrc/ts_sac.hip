@@ -25,6 +25,9 @@
 namespace ts {
 int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
               double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+int adam_step_multi(hipStream_t s, int nvec, float* const* params, float* const* m, float* const* v,
+                    const float* const* grad, float* const* lagged, int64_t n, int64_t step, double lr, double beta1,
+                    double beta2, double eps, double tau);
 }
 
 namespace {
@@ -161,6 +164,15 @@ int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t*
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
+// row of a 32-column head gradient: [v, 0 x 31] (the whole row is written: the buffer needs no memset)
+__device__ __forceinline__ void store_head_row(float* __restrict__ row, float v) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4* r = reinterpret_cast<f32x4*>(row);
+    r[0] = f32x4{v, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 1; q < 8; ++q) r[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // x_a[b] = [obs | 0], x_c[b] = [obs | act | 0]; x_p (nullable) = a second copy of x_c's observation columns (its
 // action columns are written by the policy kernel).  Four output columns per thread (ka, kc are multiples of 32).
 __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
@@ -289,8 +301,8 @@ __global__ __launch_bounds__(1024) void sac_actor_loss_kernel(const float* __res
         const float a = q1[b * 32], c = q2[b * 32];
         ls += alpha * logp[b] - fminf(a, c);
         // torch.minimum backward: ties share the gradient
-        d_q1[b * 32] = a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
-        d_q2[b * 32] = c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+        store_head_row(d_q1 + b * 32, a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f));
+        store_head_row(d_q2 + b * 32, c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f));
     }
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *loss = tot * inv_b;
@@ -304,10 +316,16 @@ __global__ __launch_bounds__(256) void sac_policy_bwd_kernel(const float* __rest
                                                              const float* __restrict__ log_alpha, float fixed_alpha,
                                                              int64_t B, int A, int head_cols, int obs_dim, int kc,
                                                              float* __restrict__ d_head) {
+    // thread (b, j < 32): columns j and 32 + j of row b; columns past the action dimension are written as zeros
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * A) return;
-    const int64_t b = i / A;
-    const int j = (int)(i - b * A);
+    const int64_t b = i >> 5;
+    const int j = (int)(i & 31);
+    if (b >= B) return;
+    if (j >= A) {
+        d_head[b * head_cols + j] = 0.f;
+        d_head[b * head_cols + SIG_COL + j] = 0.f;
+        return;
+    }
     const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
     const float g_lp = alpha / (float)B;                              // d loss / d log_prob[b]
     const float d = keep[(b * 3 + 0) * A + j], sigma = keep[(b * 3 + 1) * A + j], sq = keep[(b * 3 + 2) * A + j];
@@ -338,23 +356,26 @@ __device__ float block_sum_256(float v, float* red4) {
     return red4[0] + red4[1] + red4[2] + red4[3];
 }
 
-__global__ __launch_bounds__(256) void sac_critic_loss_mb_kernel(const float* __restrict__ q, const float* __restrict__ ret,
-                                                                 const float* __restrict__ weight, int64_t B,
-                                                                 float* __restrict__ td, float* __restrict__ d_out,
-                                                                 float* __restrict__ part) {
+// blockIdx.y = critic (one launch for the twins when both run on one stream; gridDim.y = 1 otherwise)
+struct CriticLossArgs {
+    const float* q[2]; float* td[2]; float* d_out[2]; float* part[2];
+    const float* ret; const float* weight; int64_t B;
+};
+__global__ __launch_bounds__(256) void sac_critic_loss_mb_kernel(CriticLossArgs a) {
     __shared__ float red[4];
+    const int k = blockIdx.y;
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const float inv_b = 1.f / (float)B;
+    const float inv_b = 1.f / (float)a.B;
     float ls = 0.f;
-    if (b < B) {
-        const float t = q[b * 32] - ret[b];
-        const float w = weight ? weight[b] : 1.f;
-        td[b] = t;
+    if (b < a.B) {
+        const float t = a.q[k][b * 32] - a.ret[b];
+        const float w = a.weight ? a.weight[b] : 1.f;
+        a.td[k][b] = t;
         ls = t * t * w;
-        d_out[b * 32] = 2.f * t * w * inv_b;       // the other 31 columns of d_out stay zero
+        store_head_row(a.d_out[k] + b * 32, 2.f * t * w * inv_b);
     }
     const float tot = block_sum_256(ls, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.part[k][blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void sac_actor_loss_mb_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
@@ -371,8 +392,8 @@ __global__ __launch_bounds__(256) void sac_actor_loss_mb_kernel(const float* __r
         const float a = q1[b * 32], c = q2[b * 32];
         ls = alpha * logp[b] - fminf(a, c);
         // torch.minimum backward: ties share the gradient
-        d_q1[b * 32] = a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
-        d_q2[b * 32] = c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f);
+        store_head_row(d_q1 + b * 32, a < c ? -inv_b : (a == c ? -0.5f * inv_b : 0.f));
+        store_head_row(d_q2 + b * 32, c < a ? -inv_b : (a == c ? -0.5f * inv_b : 0.f));
     }
     const float tot = block_sum_256(ls, red);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -475,7 +496,7 @@ __global__ __launch_bounds__(1024) void det_actor_loss_kernel(const float* __res
     __shared__ float red[1024];
     const float inv_b = 1.f / (float)B;
     float ls = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) { ls += q1[b * 32]; d_q1[b * 32] = -inv_b; }
+    for (int64_t b = threadIdx.x; b < B; b += 1024) { ls += q1[b * 32]; store_head_row(d_q1 + b * 32, -inv_b); }
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *loss = -(tot * inv_b);
 }
@@ -483,11 +504,12 @@ __global__ __launch_bounds__(1024) void det_actor_loss_kernel(const float* __res
 __global__ __launch_bounds__(256) void det_policy_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ keep,
                                                              int64_t B, int A, float max_action, int obs_dim, int kc,
                                                              float* __restrict__ d_head) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * A) return;
-    const int64_t b = i / A;
-    const int j = (int)(i - b * A);
-    const float t = keep[i];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // thread (b, j < 32): the whole 32-column row is written
+    const int64_t b = i >> 5;
+    const int j = (int)(i & 31);
+    if (b >= B) return;
+    if (j >= A) { d_head[b * 32 + j] = 0.f; return; }
+    const float t = keep[b * A + j];
     d_head[b * 32 + j] = dx[b * kc + obs_dim + j] * max_action * (1.f - t * t);
 }
 
@@ -882,7 +904,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     if (phases & PH_CRITIC_GRAD) {
         hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
                            B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p);
-        TS_HIP_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * B * 192, s));
+        // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
     }
 
     // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
@@ -900,27 +922,50 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* gbuf[2] = {grad, grad2};
     const BwdScratch scs[2] = {sc, sc2};
     if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-    for (int k = 0; k < 2 && (phases & PH_CRITIC_GRAD); ++k) {
-        hipStream_t sk = stq[k];
-        float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb), dim3(256), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                           dheads[k], loss_part + (1 + k) * gb);
-        TS_LAUNCH_CHECK();
-        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
-    }
-    // both critics on one stream (the one-launch chains): their six weight-gradient GEMMs share a launch
+    // both critics on one stream (the one-launch chains): one loss launch, the six weight-gradient GEMMs in one launch,
+    // one Adam launch that also moves the lagged critics (nothing reads them again in this update)
     const bool twin_group = side == s && fused_backward(mc, false, 0, 0);
-    if (twin_group && (phases & PH_CRITIC_GRAD)) {
+    const bool polyak_with_adam = twin_group && hp->critic_lr >= 0.0 && hp->tau > 0.0;
+    auto critic_loss = [&](hipStream_t sk, int k0, int nk) {
+        CriticLossArgs la{};
+        for (int k = 0; k < nk; ++k) {
+            la.q[k] = acts[k0 + k].out; la.td[k] = tds[k0 + k]; la.d_out[k] = dheads[k0 + k];
+            la.part[k] = loss_part + (1 + k0 + k) * gb;
+        }
+        la.ret = returns; la.weight = weight; la.B = B;
+        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb, (unsigned)nk), dim3(256), 0, sk, la);
+    };
+    if ((phases & PH_CRITIC_GRAD) && twin_group) {
+        for (int k = 0; k < 2; ++k)
+            if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        critic_loss(s, 0, 2);
+        TS_LAUNCH_CHECK();
+        for (int k = 0; k < 2; ++k)
+            if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], dheads[k], nullptr, nullptr, 0, 0, scs[k], 1)) return rc;
         const float* xs2[2] = {x_c, x_c};
         const float* dh2[2] = {dheads[0], dheads[1]};
         float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
         if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 2 && (phases & PH_CRITIC_GRAD) && !twin_group; ++k) {
         hipStream_t sk = stq[k];
         float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if ((phases & PH_CRITIC_GRAD) && !twin_group)
+        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        critic_loss(sk, k, 1);
+        TS_LAUNCH_CHECK();
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
+    }
+    if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0 && twin_group) {
+        const float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
+        float* lag[2] = {st->critic1_old, st->critic2_old};
+        if (int rc = ts::adam_step_multi(s, 2, crit, crit_m, crit_v, gk2, lag, pc, adam_step, hp->critic_lr, hp->beta1, hp->beta2,
+                                         hp->adam_eps, hp->tau))
+            return rc;
+    }
+    for (int k = 0; k < 2 && !twin_group; ++k) {
+        hipStream_t sk = stq[k];
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (phases & PH_CRITIC_GRAD)
             if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 2)) return rc;
         if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0)
             if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, adam_step, hp->critic_lr, hp->beta1,
@@ -953,7 +998,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
         if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
         if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
-        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
+        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
                            keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
@@ -983,7 +1028,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     aa2.neg_mean_logp = phases != PH_ALL ? grads + pa : nullptr;
     aa2.loss_part = phases == PH_ALL ? loss_part : nullptr; aa2.losses = stats_out5; aa2.n_part = (int)gb;
     hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
-    if (hp->tau > 0.0)
+    if (hp->tau > 0.0 && !polyak_with_adam)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, pc, (float)hp->tau, (float)(1.0 - hp->tau));
     TS_LAUNCH_CHECK();
@@ -1137,7 +1182,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
 
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act, B,
                        d.obs, d.act, d.ka, d.kc, x_a, x_c, hp->update_actor ? x_p : (float*)nullptr);
-    TS_HIP_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * B * 128, s));
+    // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
     // critics (ddpg.py:279-285): critic 1 on the caller's stream, critic 2 on the side stream
     hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
@@ -1146,28 +1191,47 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     const Act acts[2] = {a1, a2};
     if (twin)
         if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+    // both critics on one stream (the one-launch chains): one loss launch, six weight-gradient GEMMs in one launch, one
+    // Adam launch that also moves the lagged critics on the updates that move lagged networks (td3.py:215-219)
     const bool twin_group = twin && side == s && fused_backward(mc, false, 0, 0);
-    for (int k = 0; k < (twin ? 2 : 1); ++k) {
-        hipStream_t sk = stq[k];
-        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb), dim3(256), 0, sk, acts[k].out, returns, weight, B, tds[k],
-                           dheads[k], loss_part + (1 + k) * gb);
+    const bool polyak_with_adam = twin_group && hp->critic_lr >= 0.0 && hp->tau > 0.0 && hp->update_actor;
+    auto critic_loss = [&](hipStream_t sk, int k0, int nk) {
+        CriticLossArgs la{};
+        for (int k = 0; k < nk; ++k) {
+            la.q[k] = acts[k0 + k].out; la.td[k] = tds[k0 + k]; la.d_out[k] = dheads[k0 + k];
+            la.part[k] = loss_part + (1 + k0 + k) * gb;
+        }
+        la.ret = returns; la.weight = weight; la.B = B;
+        hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb, (unsigned)nk), dim3(256), 0, sk, la);
+    };
+    if (twin_group) {
+        for (int k = 0; k < 2; ++k)
+            if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        critic_loss(s, 0, 2);
         TS_LAUNCH_CHECK();
-        float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], twin_group ? 1 : 3))
-            return rc;
-        if (!twin_group && hp->critic_lr >= 0.0)
-            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, critic_step, hp->critic_lr, hp->beta1,
-                                       hp->beta2, hp->adam_eps, 0.0, norm_part))
-                return rc;
-    }
-    if (twin_group) {      // both critics on one stream (the one-launch chains): six weight-gradient GEMMs, one launch
+        for (int k = 0; k < 2; ++k)
+            if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], dheads[k], nullptr, nullptr, 0, 0, scs[k], 1)) return rc;
         const float* xs2[2] = {x_c, x_c};
         const float* dh2[2] = {dheads[0], dheads[1]};
         float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
         if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
-        for (int k = 0; k < 2 && hp->critic_lr >= 0.0; ++k)
-            if (int rc = ts::adam_step(s, crit[k], crit_m[k], crit_v[k], gk2[k], pc, critic_step, hp->critic_lr, hp->beta1,
+        if (hp->critic_lr >= 0.0) {
+            const float* gc2[2] = {gk2[0], gk2[1]};
+            float* lag[2] = {st->critic1_old, st->critic2_old};
+            if (int rc = ts::adam_step_multi(s, 2, crit, crit_m, crit_v, gc2, lag, pc, critic_step, hp->critic_lr, hp->beta1,
+                                             hp->beta2, hp->adam_eps, polyak_with_adam ? hp->tau : 0.0))
+                return rc;
+        }
+    }
+    for (int k = 0; k < (twin ? 2 : 1) && !twin_group; ++k) {
+        hipStream_t sk = stq[k];
+        if (int rc = mlp_forward(sk, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        critic_loss(sk, k, 1);
+        TS_LAUNCH_CHECK();
+        float* gk = g_out[k] ? g_out[k] : gbuf[k];
+        if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
+        if (hp->critic_lr >= 0.0)
+            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, pc, critic_step, hp->critic_lr, hp->beta1,
                                        hp->beta2, hp->adam_eps, 0.0, norm_part))
                 return rc;
     }
@@ -1188,7 +1252,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q, nullptr, dx1, d.obs, d.obs + d.act, scs[0]))
             return rc;
-        hipLaunchKernelGGL(det_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, dx1, keep, B,
+        hipLaunchKernelGGL(det_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, dx1, keep, B,
                            d.act, (float)hp->max_action, d.obs, d.kc, d_pol);
         TS_LAUNCH_CHECK();
         float* ga = g_out[2] ? g_out[2] : gbuf[0];
@@ -1201,7 +1265,8 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
             const float tau = (float)hp->tau, omt = (float)(1.0 - hp->tau);
             hipLaunchKernelGGL(polyak1_kernel, dim3((unsigned)ts::ceil_div(pa, 256)), dim3(256), 0, s, st->actor_old,
                                st->actor, pa, tau, omt);
-            if (twin)
+            if (twin && polyak_with_adam) {
+            } else if (twin)
                 hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
                                    st->critic1, st->critic2_old, st->critic2, pc, tau, omt);
             else
@@ -1518,7 +1583,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
             hipLaunchKernelGGL(acc_cols_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, dx_sum, dx, B,
                                d.kc, d.obs, d.act, e == 0 ? 1 : 0);
         }
-        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * d.act, 256)), dim3(256), 0, s, aa.out, noise,
+        hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
                            keep, dx_sum, zeros, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, gact, nullptr, 0, 0, scs[0])) return rc;
