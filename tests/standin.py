@@ -93,6 +93,13 @@ class SimpleLossTrainingStats:
     train_time: float = 0.0
 
 
+@dataclass
+class LossSequenceTrainingStats:
+    """tianshou/algorithm/modelfree/reinforce.py:47-60 as the hooks build it (a single loss)."""
+    loss: float
+    train_time: float = 0.0
+
+
 class RunningMeanStd:
     """tianshou/utils/statistics.py:81-91: the three scalars the wrappers mirror."""
 
@@ -387,6 +394,57 @@ class DQN(Algorithm):
 
     def update(self, buffer, sample_size):
         return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
+class DQNetFeatures(nn.Module):
+    """env/atari/atari_network.py:60-122 with features_only=True, output_dim_added_layer=512 (atari_ppo.py:106-114):
+    `net` = Sequential(Sequential(conv, ReLU, conv, ReLU, conv, ReLU, Flatten), Linear, ReLU); `output_dim`."""
+
+    def __init__(self, c, h, w, output_dim=512):
+        super().__init__()
+        cnn = nn.Sequential(nn.Conv2d(c, 32, 8, 4), nn.ReLU(), nn.Conv2d(32, 64, 4, 2), nn.ReLU(), nn.Conv2d(64, 64, 3, 1),
+                            nn.ReLU(), nn.Flatten())
+        with torch.no_grad():
+            feat = int(cnn(torch.zeros(1, c, h, w)).shape[1])
+        self.net = nn.Sequential(cnn, nn.Linear(feat, output_dim), nn.ReLU())
+        self.output_dim = output_dim
+
+
+class DiscreteActor(nn.Module):
+    """utils/net/discrete.py:22-101: `preprocess`, `last` = MLP without hidden layers, `softmax_output`."""
+
+    def __init__(self, preprocess_net, n_act, softmax_output=True):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.last = _MLP([preprocess_net.output_dim, n_act], None)
+        self.softmax_output = softmax_output
+
+
+class DiscreteCritic(nn.Module):
+    """utils/net/discrete.py:104-163: `preprocess`, `last`."""
+
+    def __init__(self, preprocess_net):
+        super().__init__()
+        self.preprocess = preprocess_net
+        self.last = _MLP([preprocess_net.output_dim, 1], None)
+
+
+class QRDQNet(DQNet):
+    """env/atari/atari_network.py:211-235: DQNet with n_act * num_quantiles outputs (same state_dict keys)."""
+
+    def __init__(self, c, h, w, n_act, num_quantiles):
+        super().__init__(c, h, w, n_act * num_quantiles)
+        self.action_num, self.num_quantiles = n_act, num_quantiles
+
+
+class QRDQN(DQN):
+    """modelfree/qrdqn.py:40-91: DQN's attributes plus `num_quantiles`."""
+
+    def __init__(self, *, policy, lr=1e-4, gamma=0.99, num_quantiles=200, n_step_return_horizon=1, target_update_freq=0,
+                 max_grad_norm=None):
+        super().__init__(policy=policy, lr=lr, gamma=gamma, n_step_return_horizon=n_step_return_horizon,
+                         target_update_freq=target_update_freq, max_grad_norm=max_grad_norm)
+        self.num_quantiles = num_quantiles
 
 
 # ------------------------------------------------------------------------------------------------ replay buffer

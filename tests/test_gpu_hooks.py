@@ -390,6 +390,141 @@ def test_hip_dqn_hooks_against_oracle(huber):
     _dqn_hook_run(huber)
 
 
+# ------------------------------------------------------------------------------------ HipPPOCnn
+def test_hip_ppo_cnn_hooks_against_oracle():
+    """HipPPOCnn (integration.make_hip_ppo_cnn over the stand-ins) on the real engine, the layout of
+    examples/atari/atari_ppo.py:106-135: one DQNet(features_only, 512) trunk shared by a logits actor and a critic, single
+    uint8 frames per slot with stack_num = 4, obs_next stored; PPO with value clipping, advantage normalisation, entropy
+    bonus, gradient clipping and return scaling.  Two update() calls on a buffer that is reset and refilled (on-policy):
+    `_preprocess_batch` (V(s), V(s'), GAE, log pi_old through the device mirror) -> `_update_with_batch` (minibatches from
+    np.random.permutation, replayed for the oracle) -> write-back of the twelve tensors + Adam state, against
+    oracle_ppo_cnn on the host copies of the same frames."""
+    from oracle import oracle_dqn as OD
+    from oracle import oracle_ppo_cnn as OC
+    from tianshou_amd.integration import make_hip_ppo_cnn
+
+    c, h, w, A, E, T, batch_size, repeat = 4, 44, 36, 5, 4, 24, 32, 2
+    HipPPOCnn = make_hip_ppo_cnn("ppo", ref=SI)
+    torch.manual_seed(11)
+    trunk = SI.DQNetFeatures(c, h, w)
+    actor, critic = SI.DiscreteActor(trunk, A, softmax_output=False), SI.DiscreteCritic(trunk)
+    # (frames take values 0..3: with default-init weights the features stay O(1) and the weights large against one Adam
+    # step -- scaling conv1 by 1/255 instead would make every step rewrite it and amplify rounding noise chaotically)
+    kw = dict(eps_clip=0.1, value_clip=True, vf_coef=0.25, ent_coef=0.01, max_grad_norm=0.5, return_scaling=True,
+              advantage_normalization=True, gae_lambda=0.95, gamma=0.99, lr=2.5e-4)
+    algo = HipPPOCnn(policy=SI.Policy(actor), critic=critic, device="cuda", **kw).to("cuda")
+    hip_params = [p.detach().cpu().clone() for p in algo._hip_params()]
+    st = OP.PPOState(params={k: t for k, t in zip(OC.PARAM_ORDER, hip_params)})
+    ocfg = OP.PPOConfig(max_batchsize=4096, **kw)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64, stack_num=c)
+    rng = np.random.default_rng(12)
+    algo.policy.is_within_training_step = True
+    for u in range(2):
+        buf.reset()
+        for _ in range(T):
+            term = rng.random(E) < 0.05
+            buf.add(SI.Batch(obs=rng.integers(0, 4, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E).astype(np.float32), terminated=term,
+                             truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 4, (E, h, w)).astype(np.uint8)))
+        n = len(buf)
+        idx = buf.sample_indices(0)
+        bs = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths,
+                           np.asarray([b._insertion_idx for b in buf.buffers]), buf.rew, buf.terminated, buf.truncated)
+        obs = torch.from_numpy(OD.stacked_frames(bs, buf.obs, idx, c).astype(np.float32))
+        obs_next = torch.from_numpy(OD.stacked_frames(bs, buf.obs_next, idx, c).astype(np.float32))
+        np.random.seed(50 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        pre = OC.preprocess(st, ocfg, obs, obs_next, buf.act[idx], buf.rew[idx], buf.terminated[idx], buf.truncated[idx], idx,
+                            bs.unfinished_index())
+        losses_o = OC.update(st, ocfg, obs, buf.act[idx], pre, batch_size, repeat, perms)
+        np.random.seed(50 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert stats.gradient_steps == losses_o.shape[0]
+        for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(losses_o[:, col])
+            # (minibatches of 32 samples behind four fp32 layers with K up to 3,136; the clip loss is a mean of O(1) normalised
+            # advantages times (ratio - 1), i.e. a small difference of large terms: absolute tolerance)
+            np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=2e-4, atol=3e-5 if col == 1 else 2e-6)
+        np.testing.assert_allclose([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count],
+                                   [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+    for t, k in zip(algo._hip_params(), OC.PARAM_ORDER):      # a few Adam steps of lr 2.5e-4: compare on a fraction of a step
+        np.testing.assert_allclose(t.detach().cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 2.5e-4, err_msg=k)
+    assert trunk.net[1].weight is actor.preprocess.net[1].weight is critic.preprocess.net[1].weight      # still one trunk
+    sd = algo.state_dict()                                     # Adam moments arrive lazily, one entry per tensor (12)
+    assert len(sd["_optimizers"][0]["state"]) == 12
+    state = algo.optim._optim.state
+    assert all(float(state[p]["step"]) == st.adam_step for p in algo._hip_params())
+
+
+# ------------------------------------------------------------------------------------ HipQRDQN
+def test_hip_qrdqn_hooks_against_oracle():
+    """HipQRDQN (integration.make_hip_qrdqn over the stand-ins) on the real engine: single uint8 frames with stack_num = 4,
+    a prioritized buffer, n-step 2, a lagged network synced every 2 updates, 16 quantiles.  Per update: `_preprocess_batch`
+    (the lagged net's quantiles of the online net's greedy action as the n-step target, qrdqn.py:93-104 through
+    dqn.py:257-275) -> `_update_with_batch` (importance-weighted quantile Huber loss, qrdqn.py:106-131) ->
+    `_postprocess_batch` (the new priorities reach `buffer.update_weight`), against oracle_distq fed with the same sampled
+    indices; the host buffer grows and wraps between updates."""
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+    from tianshou_amd import dqn as D
+    from tianshou_amd.integration import make_hip_qrdqn
+
+    c, h, w, A, N, E, size, B = 4, 44, 36, 3, 16, 4, 40, 32
+    HipQRDQN = make_hip_qrdqn(ref=SI)
+    torch.manual_seed(9)
+    model = SI.QRDQNet(c, h, w, A, N)
+    with torch.no_grad():
+        model.net[0][0].weight.mul_(1.0 / 255.0)     # uint8 frames (0..255) times default-init weights: keep quantiles O(1)
+    algo = HipQRDQN(policy=SI.DiscreteQLearningPolicy(model), lr=1e-4, gamma=0.97, num_quantiles=N, n_step_return_horizon=2,
+                    target_update_freq=2, device="cuda").to("cuda")
+    sd = model.state_dict()
+    p0 = {k: sd[n].detach().cpu().clone() for k, n in zip(OD.PARAM_ORDER, D.TIANSHOU_KEYS)}
+    ocfg = OQ.DistQConfig(kind=OQ.QR, n_atoms=N, gamma=0.97, n_step=2, target_update_freq=2, lr=1e-4)
+    st = OD.DQNState.create(p0, ocfg.dqn())
+    buf = SI.PrioritizedVectorReplayBuffer(E * size, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                           seed=4, stack_num=c, alpha=0.6, beta=0.4)
+    rng = np.random.default_rng(8)
+
+    def fill(n):
+        for _ in range(n):
+            term = rng.random(E) < 0.08
+            buf.add(SI.Batch(obs=rng.integers(0, 256, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+
+    def sample(bs):
+        batch, idx = orig_sample(bs)
+        seen.append((idx.copy(), np.asarray(batch.weight).copy()))
+        return batch, idx
+
+    buf.sample = sample
+    eps = np.finfo(np.float32).eps.item()
+    for u in range(4):
+        fill(25 if u == 0 else 9)
+        stat = algo.update(buf, B)
+        idx, w_is = seen[-1]
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+        ret = OQ.preprocess(st, ocfg, bstate, buf.obs, idx, A, c, obs_next_frames=buf.obs_next)
+        obs = OD.stacked_frames(bstate, buf.obs, idx, c)
+        loss_o, prio_o = OQ.update_with_batch(st, ocfg, obs, buf.act[idx], ret, A, weight=w_is)
+        np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5)
+        upd_idx, upd_w = buf.weight_updates[-1]
+        assert np.array_equal(upd_idx, idx)
+        np.testing.assert_allclose(upd_w, np.abs(np.asarray(prio_o)) + eps, rtol=2e-5, atol=2e-5)
+        assert algo._iter == st.iter == u + 1
+    for t, k in zip([p.detach().cpu() for p in model.parameters()], OD.PARAM_ORDER):
+        np.testing.assert_allclose(t.numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    for t, k in zip([p.detach().cpu() for p in algo.model_old.parameters()], OD.PARAM_ORDER):
+        np.testing.assert_allclose(t.numpy(), st.params_old[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    assert float(algo.optim._optim.state[next(iter(model.parameters()))]["step"]) == 4.0
+
+
 # ------------------------------------------------------------------------------------ HipTD3
 def test_hip_td3_hooks_against_oracle():
     """HipTD3 (integration.make_hip_td3 over the stand-ins) on the real engine with Net[128, 128] trunks (a width other than

@@ -225,6 +225,66 @@ def test_dqn_standin_has_the_reference_surface():
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
 
 
+def test_ppo_cnn_standin_has_the_reference_surface():
+    """The Atari actor-critic stand-ins (DQNetFeatures / DiscreteActor / DiscreteCritic) against the real modules:
+    state_dict keys and shapes of actor and critic, the shared trunk, `softmax_output`; the hook bodies of HipPPOCnn are
+    the same code objects over either namespace."""
+    ref_shim.install()
+    from tianshou.env.atari.atari_network import DQNet
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+
+    net = DQNet(c=4, h=44, w=36, action_shape=5, features_only=True, output_dim_added_layer=512)
+    ra, rc = DiscreteActor(preprocess_net=net, action_shape=5, softmax_output=False), DiscreteCritic(preprocess_net=net)
+    trunk = SI.DQNetFeatures(4, 44, 36)
+    fa, fc = SI.DiscreteActor(trunk, 5, softmax_output=False), SI.DiscreteCritic(trunk)
+    for a, b in ((ra, fa), (rc, fc)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    assert ra.softmax_output is fa.softmax_output is False and fa.preprocess is fc.preprocess
+    from tianshou_amd import ppo_cnn as PC
+    from tianshou_amd.integration import make_hip_ppo_cnn
+
+    assert list(fa.state_dict().keys()) == PC.TRUNK_KEYS + PC.HEAD_KEYS
+    A, B = make_hip_ppo_cnn("ppo"), make_hip_ppo_cnn("ppo", ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_layout", "_hip_params"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_qrdqn_standin_has_the_reference_surface():
+    """QRDQN / QRDQNet stand-ins against the real classes: state_dict keys and shapes, the attribute names HipQRDQN reads
+    (`num_quantiles` included), the lagged wrapper; and the hook bodies are the same code objects over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.qrdqn import QRDQN, QRDQNPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import QRDQNet
+
+    real = QRDQN(policy=QRDQNPolicy(model=QRDQNet(c=4, h=44, w=36, action_shape=3, num_quantiles=16),
+                                    action_space=gym.spaces.Discrete(3)),
+                 optim=AdamOptimizerFactory(lr=1e-4), gamma=0.97, num_quantiles=16, n_step_return_horizon=2, target_update_freq=2)
+    fake = SI.QRDQN(policy=SI.DiscreteQLearningPolicy(SI.QRDQNet(4, 44, 36, 3, 16)), lr=1e-4, gamma=0.97, num_quantiles=16,
+                    n_step_return_horizon=2, target_update_freq=2)
+    for a, b in ((real.policy.model, fake.policy.model), (real.model_old.module, fake.model_old.module)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    for name in ("gamma", "n_step", "target_update_freq", "num_quantiles", "_iter"):
+        assert getattr(real, name) == getattr(fake, name), name
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm
+    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats, SimpleLossTrainingStats
+
+    assert SimpleLossTrainingStats(loss=1.5).loss == SI.SimpleLossTrainingStats(loss=1.5).loss
+    assert hasattr(LossSequenceTrainingStats, "__init__") and SI.LossSequenceTrainingStats(loss=2.0).loss == 2.0
+    from tianshou_amd.integration import make_hip_qrdqn
+
+    A, B = make_hip_qrdqn(), make_hip_qrdqn(ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_layout", "_n_atoms"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
 def test_td3_standin_has_the_reference_surface():
     ref_shim.install()
     import gymnasium as gym

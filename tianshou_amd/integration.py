@@ -869,16 +869,16 @@ def make_hip_drqn():
 # ---------------------------------------------------------------------------------------------------
 # QRDQN (qrdqn.py) / C51 (c51.py) on QRDQNet / C51Net
 # ---------------------------------------------------------------------------------------------------
-def _make_hip_distq(kind: str):
-    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats, SimpleLossTrainingStats
-
+def _make_hip_distq(kind: str, ref=None):
     from . import distq as Q
     from . import dqn as D
 
+    SimpleLossTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "SimpleLossTrainingStats")
+    LossSequenceTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "LossSequenceTrainingStats")
     if kind == Q.QR:
-        from tianshou.algorithm.modelfree.qrdqn import QRDQN as Base
+        Base = _ref(ref, "tianshou.algorithm.modelfree.qrdqn", "QRDQN")
     else:
-        from tianshou.algorithm.modelfree.c51 import C51 as Base
+        Base = _ref(ref, "tianshou.algorithm.modelfree.c51", "C51")
     who = "HipQRDQN" if kind == Q.QR else "HipC51"
 
     class HipDistQ(_HipGlue, Base):
@@ -978,16 +978,18 @@ def _make_hip_distq(kind: str):
     return HipDistQ
 
 
-def make_hip_qrdqn():
+def make_hip_qrdqn(ref=None):
     """Returns HipQRDQN(QRDQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, qrdqn.py:93-131) on the
-    engine.  Supported model: QRDQNet (atari_network.py:211-235), Adam; buffer layouts as HipDQN."""
-    return _make_hip_distq("qr")
+    engine.  Supported model: QRDQNet (atari_network.py:211-235), Adam; buffer layouts as HipDQN.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    return _make_hip_distq("qr", ref)
 
 
-def make_hip_c51():
+def make_hip_c51(ref=None):
     """Returns HipC51(C51): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, c51.py:120-160) on the engine.
-    Supported model: C51Net (atari_network.py:125-151) with C51Policy's support, Adam; buffer layouts as HipDQN."""
-    return _make_hip_distq("c51")
+    Supported model: C51Net (atari_network.py:125-151) with C51Policy's support, Adam; buffer layouts as HipDQN.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    return _make_hip_distq("c51", ref)
 
 def make_hip_rainbow():
     """Returns HipRainbow(RainbowDQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, rainbow.py:93-101 ->
@@ -1490,13 +1492,13 @@ def make_hip_discrete_sac():
 # ---------------------------------------------------------------------------------------------------
 # PPO on the Atari actor-critic (examples/atari/atari_ppo.py:106-135)
 # ---------------------------------------------------------------------------------------------------
-def make_hip_ppo_cnn(algo: str = "ppo"):
+def make_hip_ppo_cnn(algo: str = "ppo", ref=None):
     """Returns HipPPOCnn(PPO) for DQNet(features_only=True, output_dim_added_layer=512) shared by
-    DiscreteActor(softmax_output=False) and DiscreteCritic; Categorical policy; Adam.  algo="a2c": HipA2CCnn(A2C)."""
-    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.data import SequenceSummaryStats
-
-    PPO = _on_policy_base(algo)
+    DiscreteActor(softmax_output=False) and DiscreteCritic; Categorical policy; Adam.  algo="a2c": HipA2CCnn(A2C).
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    A2CTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.a2c", "A2CTrainingStats")
+    SequenceSummaryStats = _ref(ref, "tianshou.data", "SequenceSummaryStats")
+    PPO = _on_policy_base(algo, ref)
 
     from . import ppo_cnn as PC
 
