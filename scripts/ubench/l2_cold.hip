@@ -8,10 +8,16 @@
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int INFLIGHT>
-__global__ __launch_bounds__(512) void stream(const float* __restrict__ w, int rows, float* out, unsigned long long* clk) {
+__global__ __launch_bounds__(512) void stream(const float* __restrict__ w, int rows, float* out, unsigned long long* clk, int warm) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, kq = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (warm) {     // every workgroup of an XCD (b, b + 8, ...) touches a different 1/32 of the matrix first, one dword per line
+        const int lines = rows * 8, per = (lines + 31) / 32, slice = (blockIdx.x >> 3) & 31;
+        const int line = slice * per + (int)threadIdx.x;
+        if ((int)threadIdx.x < per && line < lines) acc[0] += w[(size_t)line * 32];
+        if (warm == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    }
     const float* p = w + (size_t)(kq + (wave / 4) * (rows / 2)) * 256 + 64 * (wave % 4) + 4 * n;
     for (int r = 0; r < rows / 2; r += 4 * INFLIGHT) {
         f32x4 v[INFLIGHT];
@@ -40,19 +46,26 @@ int main() {
     (void)hipMalloc(&out, 4096); (void)hipMalloc(&clk, 8 * 1024);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int blocks : {16, 256}) {
-        for (int cold = 0; cold < 2; ++cold) {
+        for (int mode = 0; mode < 6; ++mode) {
+            // 0 warm | 1 cold (512 MB streamed in between) | 2 L2-cold only (48 MB in between) | 3 = 1 + warm-up | 4 = 2 + warm-up
+            // | 5 = 2 + warm-up completed before the stream starts
+            const size_t fl = mode == 0 ? 0 : ((mode == 1 || mode == 3) ? big_bytes : (48ull << 20));
+            const int warm = mode == 5 ? 2 : (mode >= 3 ? 1 : 0);
             float best = 1e9f; unsigned long long bestc = ~0ull;
             for (int rep = 0; rep < 5; ++rep) {
-                if (cold) hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, 0, (const float4*)big, big_bytes / 16, out);
-                else hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk);
+                if (fl) hipLaunchKernelGGL(flush, dim3(2048), dim3(256), 0, 0, (const float4*)big, fl / 16, out);
+                else hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk, 0);
                 (void)hipEventRecord(e0);
-                hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk);
+                hipLaunchKernelGGL((stream<16>), dim3(blocks), dim3(512), 0, 0, w, rows, out, clk, warm);
                 (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
                 float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
                 unsigned long long c; (void)hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost); if (c < bestc) bestc = c;
             }
-            printf("blocks %3d  %s : launch %6.1f us, workgroup 0 %6.2f us inside (%5.1f KB/us per CU)\n", blocks, cold ? "cold" : "warm",
-                   best * 1e3f, bestc / 100.0, rows * 1.0 / (bestc / 100.0));
+            const char* names[6] = {"warm", "cold (512 MB between)", "L2-cold (48 MB between)", "cold + slice warm-up", "L2-cold + slice warm-up",
+                                    "L2-cold + completed warm-up"};
+            const double us = bestc / 100.0;          // s_memtime: 100 MHz
+            printf("blocks %3d  %-28s : launch %6.1f us, workgroup 0 %6.2f us inside (%6.1f KB/us per CU)\n", blocks, names[mode],
+                   best * 1e3f, us, rows * 1.0 / us);
         }
     }
     return 0;
