@@ -43,8 +43,8 @@ PEAK_HBM_GBPS = 8000.0
 # this very command, mean per launch; FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte
 # requests of 16-byte-per-lane loads at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM").  Counters cannot be read live
 # from inside bench.py, so the line carries the profiled value of the same workload.
-STEP_HBM_TRAFFIC_BYTES = (2 * 8093 + 26896) * 1024      # records + images read; 512 gradient slabs written through (sc1)
-GAE_HBM_TRAFFIC_BYTES = (2 * 9348 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
+STEP_HBM_TRAFFIC_BYTES = (2 * 8344 + 27920) * 1024      # records + images read; 512 gradient slabs written through (sc1)
+GAE_HBM_TRAFFIC_BYTES = (2 * 9276 + 8242) * 1024        # 27.4 MB vs 27.3 MB algorithmic: every byte moves once
 TRAFFIC_SOURCE = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
 H2D_BYTES_PER_UPDATE = N_TRANS * (2 * OBS * 4 + ACT * 4 + 8 + 2)   # obs, obs_next, act f32; rew f64; two flag bytes
 
@@ -127,7 +127,7 @@ class Learner:
                 try:
                     from tianshou_amd.collective import NativeAllReduce
 
-                    ar = NativeAllReduce(self.device)
+                    ar = NativeAllReduce(self.device, rccl=not os.environ.get("TS_BENCH_ONE_GPU"))
                     self.exchange = "ts_allreduce one-shot (HIP IPC)" if ar.small_capacity >= self.eng.P + 4 else "ts_allreduce (RCCL)"
                 except Exception as e:      # noqa: BLE001 - any failure of the native set-up: the proven path
                     print(f"[bench] rank {self.rank}: native all-reduce unavailable ({e}); using torch.distributed", file=sys.stderr)
@@ -443,13 +443,22 @@ def main():
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    # TS_BENCH_ONE_GPU=1: a dry run of the N > 1 path on a single GPU (every rank on cuda:0, rendezvous over gloo, the
+    # exchange on the one-shot IPC all-reduce -- ranks that share a GPU cannot form an RCCL communicator).  Not a
+    # measurement: the ranks time-share the chip.
+    one_gpu = bool(os.environ.get("TS_BENCH_ONE_GPU")) and world > 1
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
         if world > 1:

@@ -128,3 +128,31 @@ def test_one_shot_allreduce_between_two_processes_on_one_gpu():
     assert all(p.exitcode == 0 for p in procs)
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: 0, 1: 0}
+
+
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, two ranks), with TS_BENCH_ONE_GPU=1: both ranks on
+    cuda:0, rendezvous over gloo, the gradient exchange of every minibatch step on the one-shot IPC all-reduce inside
+    ts_ppo_dp_step.  Checks the N > 1 code path end to end (shard-local preprocessing with global return statistics, the
+    data-parallel update, max-over-ranks timing, one JSON line from rank 0) -- not a measurement."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TS_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and "one-shot" in d["config"]["exchange"]
