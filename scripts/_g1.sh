@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/g1
 export PYTHONPATH=.
-timeout 600 python -m pytest tests/test_gpu_collective.py -x -q -m gpu > gpurun_out/g1/pytest.txt 2>&1
-tail -n 30 gpurun_out/g1/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_ppo.py tests/test_gpu_hooks.py -x -q -m gpu 2>&1 | grep -E "passed|failed" | tail -3

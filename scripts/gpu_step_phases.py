@@ -27,10 +27,23 @@ else:
 NROWS = int(os.environ.get('NROWS', '65536'))
 for trial in range(2):
     rows = torch.as_tensor(np.random.default_rng(trial).permutation(bench.N_TRANS)[:NROWS], device=dev)
-    out = (C.c_int64 * 32)()
+    out = (C.c_int64 * 2048)()
     _lib.check(lib.ts_debug_ppo_step_cycles(L.ws.handle, _lib.ptr(L.eng.params), _lib.i64(17), _lib.i64(6),
-        _lib.ptr(rec), _lib.ptr(rows), _lib.i64(NROWS), C.byref(hp), out, _lib.i64(32), _lib.current_stream(dev)))
+        _lib.ptr(rec), _lib.ptr(rows), _lib.i64(NROWS), C.byref(hp), out, _lib.i64(2048), _lib.current_stream(dev)))
     t = np.array(list(out), dtype=np.int64)
     print("trial", trial, "total cycles", t[17] - t[0])
     for k in range(1, 18):
         print(f"   {names[k]:12s} +{t[k]-t[k-1]:8d}  (at {t[k]-t[0]:8d})")
+
+    # per-workgroup (start, end) on the chip-wide 100 MHz clock: dispatch skew, body length, drain
+    n_wg = min(512, (NROWS + 127) // 128)
+    se = t[64:64 + 2 * n_wg].reshape(n_wg, 2).astype(np.float64) * 10.0      # ns
+    t00 = se[:, 0].min()
+    st, en = se[:, 0] - t00, se[:, 1] - t00
+    dur = en - st
+    print(f"   {n_wg} workgroups: start min/median/max {st.min():.0f}/{np.median(st):.0f}/{st.max():.0f} ns, "
+          f"body min/median/max {dur.min():.0f}/{np.median(dur):.0f}/{dur.max():.0f} ns, end min/median/max {en.min():.0f}/{np.median(en):.0f}/{en.max():.0f} ns")
+    order = np.argsort(st)
+    print("   start deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(st, np.arange(0, 101, 10))))
+    print("   end   deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(en, np.arange(0, 101, 10))))
+    print("   body  deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(dur, np.arange(0, 101, 10))))

@@ -434,6 +434,8 @@ struct StepArgs {
 #define TS_MARK(g, k)                                                                  \
     do {                                                                               \
         if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0) (g).dbg[(k)] = (long long)__builtin_readcyclecounter(); \
+        if ((g).dbg && threadIdx.x == 0 && ((k) == 0 || (k) == 17))                    \
+            (g).dbg[64 + 2 * blockIdx.x + ((k) == 17)] = (long long)__builtin_amdgcn_s_memrealtime();   /* 100 MHz, chip-wide */ \
     } while (0)
 #else
 #define TS_MARK(g, k) do { } while (0)
@@ -1182,6 +1184,7 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
     wave_lds_sync();
     __builtin_amdgcn_sched_barrier(0);
     TS_MARK(g, MK + 1);
+    __builtin_amdgcn_s_setprio(ACTOR ? 2 : 0);          // see ppo_step2_kernel: priority falls with progress
 
     // ---- head weight gradient: gw[a][f] = sum_s dout[s][a] * H2[s][f]  (lane = feature f).
     // dout of sample s is broadcast through the 4 padding columns of row s of the two tiles.
@@ -1395,6 +1398,14 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
 
     TS_MARK(g, 0);
     for (int64_t it = 0; it < n_iter; ++it) {
+        // Two workgroups share a CU and the SIMDs issue the OLDEST wave first: left alone, the older workgroup of every CU
+        // finishes in 41-45 us and the younger in 53-55 us, alone on its SIMDs for the last 10 us (per-workgroup clocks,
+        // scripts/gpu_step_phases.py).  The waves therefore lower their own priority as they advance (3: actor trunk and
+        // loss, 2: actor gradients, 1: critic trunk and loss, 0: critic gradients) -- whichever workgroup is behind wins
+        // the arbitration: 45-47 / 52-54 us, launch 54.7 -> 53.0 us.  (It does not close the gap: the workgroup that is
+        // behind is mostly waiting on its own latencies, and the other one fills those slots whatever its priority.  A
+        // short last level -- 3 / 2 / 1 and 0 only for the final weight gradients -- measured 53.7 us.)
+        __builtin_amdgcn_s_setprio(3);
         // per-iteration opaque copies: nothing lane- / wave-dependent is worth hoisting out of a loop that usually runs
         // once, and what LLVM hoists here ends up spilled in the prologue
         int lane = lane0, wave = wave0;
@@ -1425,6 +1436,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
         }
         __syncthreads();
         TS_MARK(g, 9);
+        __builtin_amdgcn_s_setprio(1);
         {
             float gw[1];
             net_fwd_bwd<KS1, false>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
@@ -2104,13 +2116,14 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     const int n_wg = step_grid(n_rows);
     const WsLayout wl = ws_layout(n_wg, slab_w, 1);
     const ImageBuf ib = image_buf(d, ks);
-    rc = ts::ws_reserve(ws, wl.total + 512 + ib.img_bytes + ib.inv_bytes);
+    const size_t dbg_bytes = 16384;          // 64 phase marks of workgroup 0 + (start, end) of up to 992 workgroups
+    rc = ts::ws_reserve(ws, wl.total + dbg_bytes + ib.img_bytes + ib.inv_bytes);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     long long* dbg = reinterpret_cast<long long*>(base + wl.total);
-    float* image = reinterpret_cast<float*>(base + wl.total + 512);
+    float* image = reinterpret_cast<float*>(base + wl.total + dbg_bytes);
     hipStream_t s = ts::as_stream(stream);
-    TS_HIP_CHECK(hipMemsetAsync(dbg, 0, sizeof(long long) * 64, s));
+    TS_HIP_CHECK(hipMemsetAsync(dbg, 0, dbg_bytes, s));
     rc = build_image(s, params, d, ks, image, nullptr);
     if (rc != TS_OK) return rc;
     StepArgs g{};
@@ -2122,10 +2135,10 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     g.slabs = reinterpret_cast<float*>(base + wl.slabs); g.slab_w = slab_w; g.dbg = dbg;
     TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
     if (rc != TS_OK) return rc;
-    long long host[64];
+    static long long host[2048];
     TS_HIP_CHECK(hipMemcpyAsync(host, dbg, sizeof(host), hipMemcpyDeviceToHost, s));
     TS_HIP_CHECK(hipStreamSynchronize(s));
-    for (int64_t k = 0; k < n_marks && k < 64; ++k) h_cycles[k] = host[k];
+    for (int64_t k = 0; k < n_marks && k < 2048; ++k) h_cycles[k] = host[k];
     return TS_OK;
 }
 #endif
