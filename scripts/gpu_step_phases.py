@@ -47,3 +47,16 @@ for trial in range(2):
     print("   start deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(st, np.arange(0, 101, 10))))
     print("   end   deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(en, np.arange(0, 101, 10))))
     print("   body  deciles (ns):", " ".join(f"{v:.0f}" for v in np.percentile(dur, np.arange(0, 101, 10))))
+
+    hw = t[64 + 1024:64 + 1024 + n_wg]
+    hwid, xcc = hw & 0xffffffff, (hw >> 32) & 0xf
+    cu, sh, se = (hwid >> 8) & 0xf, (hwid >> 12) & 0x1, (hwid >> 13) & 0x7      # gfx9 HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+    place = {}
+    for b in range(n_wg):
+        place.setdefault((int(xcc[b]), int(se[b]), int(sh[b]), int(cu[b])), []).append(b)
+    sizes = sorted(set(len(v) for v in place.values()))
+    diffs = sorted(set(abs(v[1] - v[0]) for v in place.values() if len(v) == 2))
+    print(f"   placement: {len(place)} distinct (xcc, se, sh, cu), workgroups per CU {sizes}, block-index distance of the two on a CU {diffs[:8]}")
+    slow = dur > np.median(dur)
+    print("   slow half are blocks >= n/2:", float(np.mean(slow[n_wg // 2:])), " (share of the upper block indices that are slow)")
+    print("   xcc of blocks 0..15:", [int(x) for x in xcc[:16]])

@@ -44,7 +44,7 @@ def test_layout_round_trip(obs_dim, act_dim):
         assert torch.equal(a.cpu(), c1[k]), k
 
 
-@pytest.mark.parametrize("obs_dim,act_dim,B", [(376, 17, 300), (23, 5, 64), (7, 1, 33)])
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(376, 17, 300), (23, 5, 64), (7, 1, 33), (1000, 6, 50)])
 def test_policy_and_target_q_vs_oracle(obs_dim, act_dim, B):
     cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.7, target_entropy=-float(act_dim))
     eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 3, cfg)
@@ -136,7 +136,7 @@ def test_sac_update_matches_reference_golden(tag):
                                        err_msg=name)
 
 
-@pytest.mark.parametrize("obs_dim,act_dim,B", [(7, 1, 33), (64, 32, 40), (33, 3, 1)])
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(7, 1, 33), (64, 32, 40), (33, 3, 1), (1000, 6, 50)])
 def test_update_other_shapes_vs_oracle(obs_dim, act_dim, B):
     """Edge shapes: one action, 32 actions (the head's limit), obs widths around the 32-column padding, B = 1."""
     cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
