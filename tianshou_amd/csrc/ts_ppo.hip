@@ -436,6 +436,9 @@ struct StepArgs {
         if ((g).dbg && blockIdx.x == 0 && threadIdx.x == 0) (g).dbg[(k)] = (long long)__builtin_readcyclecounter(); \
         if ((g).dbg && threadIdx.x == 0 && ((k) == 0 || (k) == 17))                    \
             (g).dbg[64 + 2 * blockIdx.x + ((k) == 17)] = (long long)__builtin_amdgcn_s_memrealtime();   /* 100 MHz, chip-wide */ \
+        if ((g).dbg && threadIdx.x == 0 && (k) == 0)      /* where the workgroup runs: HW_ID (CU / SH / SE) and XCC_ID */ \
+            (g).dbg[64 + 1024 + blockIdx.x] = ((long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) | \
+                                              (unsigned)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);          \
     } while (0)
 #else
 #define TS_MARK(g, k) do { } while (0)
