@@ -17,6 +17,11 @@ bool mlp3_supported(int K1, int hidden, int head_cols);
 int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
                  int head_cols, float* h1, float* h2, float* out, ts_workspace* prof = nullptr);
 
+// The same for one or two networks of equal shape on the same input in ONE launch (twin critics: blockIdx.y = network).
+int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const float* const* wb1, const float* const* wb2,
+                   const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
+                   ts_workspace* prof = nullptr);
+
 // The input gradients of the same chain in one launch: dh2 = (d_out W3^T) * (h2 > 0), dh1 = (dh2 W2^T) * (h1 > 0)
 // ([M, 256] each, consumed by the weight-gradient GEMMs), and dx[:, col0:col1) = dh1 W1^T for up to 128 input columns
 // (dx nullable; row pitch K1; the 16-column tiles covering the range are written, as ts::conv_dgrad does).
@@ -24,5 +29,12 @@ bool mlp3_backward_supported(int K1, int hidden, int head_cols, bool want_dx, in
 int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
                   int head_cols, const float* h1, const float* h2, float* dh1, float* dh2, float* dx, int col0, int col1,
                   ts_workspace* prof = nullptr);
+
+// one or two networks of equal shape (each with its own upstream gradient, activations and outputs) in one launch;
+// input gradients (dx) for all of them or for none
+int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, int K1, const float* const* wb1,
+                    const float* const* wb2, const float* const* wb3, int head_cols, const float* const* h1,
+                    const float* const* h2, float* const* dh1, float* const* dh2, float* const* dx, int col0, int col1,
+                    ts_workspace* prof = nullptr);
 
 }  // namespace ts

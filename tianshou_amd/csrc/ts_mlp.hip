@@ -63,9 +63,11 @@ __device__ unsigned long long g_mlp_trace[8][40];        // workgroup 0: per wav
 #define MTRACE(slot) do {} while (0)
 #endif
 
+// blockIdx.y = network: twin critics (same input, same shapes, different weights and outputs) share a launch
 struct MlpArgs {
-    const float* x; const float* wb1; const float* wb2; const float* wb3;
-    float* h1; float* h2; float* out;
+    const float* x;
+    const float* wb1[2]; const float* wb2[2]; const float* wb3[2];
+    float* h1[2]; float* h2[2]; float* out[2];
     int M, K1;
 };
 
@@ -274,6 +276,10 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ROWS;
+    const int net = blockIdx.y;
+    const float* wb1 = a.wb1[net];
+    const float* wb2 = a.wb2[net];
+    const float* wb3 = a.wb3[net];
     const int xp = a.K1 + 4;
     float* xs = lds;
     float* h1s = xs + ROWS * xp;
@@ -281,9 +287,9 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     float* part = h2s + ROWS * HP;
     Stage st[NST];
     constexpr int TP3 = N3 == 32 ? 2 : 4;
-    const WStream<HID, false, 4> w1(a.wb1, a.K1, HID, 0, wave, lane);
-    const WStream<HID, false, 4> w2(a.wb2, HID, HID, 0, wave, lane);
-    const WStream<N3, false, TP3> w3(a.wb3, HID, N3, 0, wave, lane);
+    const WStream<HID, false, 4> w1(wb1, a.K1, HID, 0, wave, lane);
+    const WStream<HID, false, 4> w2(wb2, HID, HID, 0, wave, lane);
+    const WStream<N3, false, TP3> w3(wb3, HID, N3, 0, wave, lane);
     MMARK(0);
     {
         f32x4 xr[XR];
@@ -294,13 +300,13 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     __syncthreads();
     w1.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w1, st, w2, xs, xp, part, h1s, a.h1, HID, nullptr, a.wb1 + (size_t)a.K1 * HID, m0,
+    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w1, st, w2, xs, xp, part, h1s, a.h1[net], HID, nullptr, wb1 + (size_t)a.K1 * HID, m0,
                                            a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w2, st, w3, h1s, HP, part, h2s, a.h2, HID, nullptr, a.wb2 + (size_t)HID * HID, m0,
+    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w2, st, w3, h1s, HP, part, h2s, a.h2[net], HID, nullptr, wb2 + (size_t)HID * HID, m0,
                                            a.M, tid, 16);
     MMARK(3);
-    mlp_layer<N3, false, TP3, EP_BIAS>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out, N3, nullptr, a.wb3 + (size_t)HID * N3,
+    mlp_layer<N3, false, TP3, EP_BIAS>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out[net], N3, nullptr, wb3 + (size_t)HID * N3,
                                        m0, a.M, tid, 32);
     MMARK(4);
 }
@@ -309,9 +315,9 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
 // dx[:, dx_c0 : dx_c0 + 16 dx_nt] = dh1 W1^T restricted to those input columns (SAC / TD3: the action columns of the
 // critic input, ddpg.py / sac.py actor losses).  dh1 / dh2 go to HBM for the weight-gradient GEMMs.
 struct BwdArgs {
-    const float* d_out; const float* wb1; const float* wb2; const float* wb3;
-    const float* h1; const float* h2;
-    float* dh1; float* dh2; float* dx;
+    const float* d_out[2]; const float* wb1[2]; const float* wb2[2]; const float* wb3[2];
+    const float* h1[2]; const float* h2[2];
+    float* dh1[2]; float* dh2[2]; float* dx[2];
     int M, K1, dx_c0, dx_nt;
 };
 
@@ -325,25 +331,27 @@ __global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
     float* g1s = g2s + ROWS * HP;
     float* part = g1s + ROWS * HP;
     Stage st[NST];
-    const WStream<N3, true, 4> w3(a.wb3, N3, HID, 0, wave, lane);
-    const WStream<HID, true, 4> w2(a.wb2, HID, HID, 0, wave, lane);
-    const WStream<HID, true, 4> w1(a.wb1, HID, a.dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane);
+    const int net = blockIdx.y;
+    float* dx = a.dx[net];
+    const WStream<N3, true, 4> w3(a.wb3[net], N3, HID, 0, wave, lane);
+    const WStream<HID, true, 4> w2(a.wb2[net], HID, HID, 0, wave, lane);
+    const WStream<HID, true, 4> w1(a.wb1[net], HID, dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane);
     MMARK(0);
     {
         f32x4 xr[XR];
-        load_rows_issue(a.d_out, N3, m0, a.M, tid, xr);
+        load_rows_issue(a.d_out[net], N3, m0, a.M, tid, xr);
         w3.template prime<0, 2>(st);
         load_rows_commit(N3, ds, N3 + 4, tid, xr);
     }
     __syncthreads();
     w3.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<N3, true, 4, EP_MASK>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2, HID, a.h2, nullptr, m0, a.M, tid, 0);
+    mlp_layer<N3, true, 4, EP_MASK>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2[net], HID, a.h2[net], nullptr, m0, a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, true, 4, EP_MASK>(w2, st, w1, g2s, HP, part, g1s, a.dh1, HID, a.h1, nullptr, m0, a.M, tid, 16);
+    mlp_layer<HID, true, 4, EP_MASK>(w2, st, w1, g2s, HP, part, g1s, a.dh1[net], HID, a.h1[net], nullptr, m0, a.M, tid, 16);
     MMARK(3);
-    if (a.dx != nullptr) {
-        mlp_layer<HID, true, 4, EP_PLAIN>(w1, st, NoNext{}, g1s, HP, part, nullptr, a.dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
+    if (dx != nullptr) {
+        mlp_layer<HID, true, 4, EP_PLAIN>(w1, st, NoNext{}, g1s, HP, part, nullptr, dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
         MMARK(4);
     }
 }
@@ -373,13 +381,21 @@ int allow_lds(K kernel) {
 }
 }  // namespace
 
-int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
-                 int head_cols, float* h1, float* h2, float* out, ts_workspace* prof) {
+int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const float* const* wb1, const float* const* wb2,
+                   const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
+                   ts_workspace* prof) {
     TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_forward: unsupported shape");
-    TS_REQUIRE(M >= 1 && x && wb1 && wb2 && wb3 && out, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
-    MlpArgs a{x, wb1, wb2, wb3, h1, h2, out, M, K1};
+    TS_REQUIRE(nets == 1 || nets == 2, TS_ERR_INVALID_ARG, "mlp3_forward: one or two networks");
+    TS_REQUIRE(M >= 1 && x, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+    MlpArgs a{};
+    a.x = x; a.M = M; a.K1 = K1;
+    for (int k = 0; k < nets; ++k) {
+        TS_REQUIRE(wb1[k] && wb2[k] && wb3[k] && out[k], TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+        a.wb1[k] = wb1[k]; a.wb2[k] = wb2[k]; a.wb3[k] = wb3[k];
+        a.h1[k] = h1 ? h1[k] : nullptr; a.h2[k] = h2 ? h2[k] : nullptr; a.out[k] = out[k];
+    }
     const size_t lds = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + PART_FLOATS);
-    const dim3 grid((unsigned)ceil_div(M, ROWS));
+    const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_FWD, s);
     if (head_cols == 32) {
         static const int once = allow_lds(&mlp3_fwd_kernel<32>);
@@ -394,21 +410,36 @@ int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1,
     return TS_OK;
 }
 
-int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
-                  int head_cols, const float* h1, const float* h2, float* dh1, float* dh2, float* dx, int col0, int col1,
-                  ts_workspace* prof) {
+int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
+                 int head_cols, float* h1, float* h2, float* out, ts_workspace* prof) {
+    return mlp3_forward_n(s, 1, x, M, K1, &wb1, &wb2, &wb3, head_cols, &h1, &h2, &out, prof);
+}
+
+int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, int K1, const float* const* wb1,
+                    const float* const* wb2, const float* const* wb3, int head_cols, const float* const* h1,
+                    const float* const* h2, float* const* dh1, float* const* dh2, float* const* dx, int col0, int col1,
+                    ts_workspace* prof) {
     TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_backward: unsupported shape");
-    TS_REQUIRE(M >= 1 && d_out && wb1 && wb2 && wb3 && h1 && h2 && dh1 && dh2, TS_ERR_INVALID_ARG,
-               "mlp3_backward: bad argument");
-    BwdArgs a{d_out, wb1, wb2, wb3, h1, h2, dh1, dh2, dx, M, K1, 0, 0};
-    if (dx) {
+    TS_REQUIRE(nets == 1 || nets == 2, TS_ERR_INVALID_ARG, "mlp3_backward: one or two networks");
+    TS_REQUIRE(M >= 1, TS_ERR_INVALID_ARG, "mlp3_backward: bad argument");
+    BwdArgs a{};
+    a.M = M; a.K1 = K1;
+    const bool want_dx = dx && dx[0];
+    for (int k = 0; k < nets; ++k) {
+        TS_REQUIRE(d_out[k] && wb1[k] && wb2[k] && wb3[k] && h1[k] && h2[k] && dh1[k] && dh2[k], TS_ERR_INVALID_ARG,
+                   "mlp3_backward: bad argument");
+        TS_REQUIRE(!want_dx || dx[k], TS_ERR_INVALID_ARG, "mlp3_backward: input gradients for all networks or none");
+        a.d_out[k] = d_out[k]; a.wb1[k] = wb1[k]; a.wb2[k] = wb2[k]; a.wb3[k] = wb3[k];
+        a.h1[k] = h1[k]; a.h2[k] = h2[k]; a.dh1[k] = dh1[k]; a.dh2[k] = dh2[k]; a.dx[k] = want_dx ? dx[k] : nullptr;
+    }
+    if (want_dx) {
         TS_REQUIRE(0 <= col0 && col0 < col1 && col1 <= K1, TS_ERR_INVALID_ARG, "mlp3_backward: bad column range");
         a.dx_c0 = col0 / 16 * 16;
         a.dx_nt = (int)ceil_div(col1 - a.dx_c0, 16);
         TS_REQUIRE(a.dx_nt <= 8, TS_ERR_UNSUPPORTED, "mlp3_backward: input-gradient range wider than 128 columns");
     }
     const size_t lds = sizeof(float) * (size_t)(ROWS * (head_cols + 4) + 2 * ROWS * HP + PART_FLOATS);
-    const dim3 grid((unsigned)ceil_div(M, ROWS));
+    const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
     if (head_cols == 32) {
         static const int once = allow_lds(&mlp3_bwd_kernel<32>);
@@ -421,6 +452,12 @@ int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float*
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
+                  int head_cols, const float* h1, const float* h2, float* dh1, float* dh2, float* dx, int col0, int col1,
+                  ts_workspace* prof) {
+    return mlp3_backward_n(s, 1, &d_out, M, K1, &wb1, &wb2, &wb3, head_cols, &h1, &h2, &dh1, &dh2, &dx, col0, col1, prof);
 }
 
 bool mlp3_backward_supported(int K1, int hidden, int head_cols, bool want_dx, int col0, int col1) {

@@ -70,6 +70,24 @@ int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, c
     return ts::conv_forward(s, m.l[2], a.h2, p + m.off[2], a.out, false, split, ws);
 }
 
+// Twin networks of one shape on the same input and the same stream: one launch (blockIdx.y = network) on the fused path,
+// two calls otherwise.
+int mlp_forward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* const* p, const float* x, const Act* a,
+                     float* const* split) {
+    if (ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC) {
+        const float* w1[2] = {p[0] + m.off[0], p[1] + m.off[0]};
+        const float* w2[2] = {p[0] + m.off[1], p[1] + m.off[1]};
+        const float* w3[2] = {p[0] + m.off[2], p[1] + m.off[2]};
+        float* h1[2] = {a[0].h1, a[1].h1};
+        float* h2[2] = {a[0].h2, a[1].h2};
+        float* out[2] = {a[0].out, a[1].out};
+        return ts::mlp3_forward_n(s, 2, x, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, out, ws);
+    }
+    for (int k = 0; k < 2; ++k)
+        if (int rc = mlp_forward(s, ws, m, p[k], x, a[k], split[k])) return rc;
+    return TS_OK;
+}
+
 size_t split_floats(const Mlp& m) {
     size_t s = 4;
     for (int i = 0; i < 3; ++i) {
@@ -143,6 +161,26 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
             if (int rc = ts::conv_dgrad(s, m.l[0], dy[0], p + m.off[0], nullptr, dx, ws, col0, col1)) return rc;
         }
     }
+    return TS_OK;
+}
+
+// The input-gradient chains (part 1 of mlp_backward) of twin networks on one stream: one launch on the fused path.
+int mlp_backward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* const* p, const float* x, const Act* a,
+                      const float* const* d_out, float* const* dx, int col0, int col1, const BwdScratch* sc) {
+    const bool want_dx = dx && dx[0];
+    if (fused_backward(m, want_dx, col0, col1)) {
+        const float* w1[2] = {p[0] + m.off[0], p[1] + m.off[0]};
+        const float* w2[2] = {p[0] + m.off[1], p[1] + m.off[1]};
+        const float* w3[2] = {p[0] + m.off[2], p[1] + m.off[2]};
+        const float* h1[2] = {a[0].h1, a[1].h1};
+        const float* h2[2] = {a[0].h2, a[1].h2};
+        float* dh1[2] = {sc[0].dh1, sc[1].dh1};
+        float* dh2[2] = {sc[0].dh2, sc[1].dh2};
+        return ts::mlp3_backward_n(s, 2, d_out, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, dh1, dh2, dx, col0, col1, ws);
+    }
+    for (int k = 0; k < 2; ++k)
+        if (int rc = mlp_backward(s, ws, m, p[k], x, a[k], d_out[k], nullptr, want_dx ? dx[k] : nullptr, col0, col1, sc[k], 1))
+            return rc;
     return TS_OK;
 }
 
@@ -822,10 +860,17 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
-    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;            // the two lagged critics side by side
-    if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
-    if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
-    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    if (side == s) {                                                    // one stream: both lagged critics in one launch
+        const float* pp[2] = {critic1_old, critic2_old};
+        const Act aa2[2] = {a1, a2};
+        float* sp[2] = {split, split2};
+        if (int rc = mlp_forward_twin(s, ws, mc, pp, x_c, aa2, sp)) return rc;
+    } else {
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;        // the two lagged critics side by side
+        if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
+        if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    }
     hipLaunchKernelGGL(sac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, a2.out, logp,
                        log_alpha, (float)fixed_alpha, B, out);
     TS_LAUNCH_CHECK();
@@ -936,14 +981,12 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb, (unsigned)nk), dim3(256), 0, sk, la);
     };
     if ((phases & PH_CRITIC_GRAD) && twin_group) {
-        for (int k = 0; k < 2; ++k)
-            if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        const float* dh2[2] = {dheads[0], dheads[1]};
+        if (int rc = mlp_forward_twin(s, ws, mc, crit, x_c, acts, splits)) return rc;
         critic_loss(s, 0, 2);
         TS_LAUNCH_CHECK();
-        for (int k = 0; k < 2; ++k)
-            if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], dheads[k], nullptr, nullptr, 0, 0, scs[k], 1)) return rc;
+        if (int rc = mlp_backward_twin(s, ws, mc, crit, x_c, acts, dh2, nullptr, 0, 0, scs)) return rc;
         const float* xs2[2] = {x_c, x_c};
-        const float* dh2[2] = {dheads[0], dheads[1]};
         float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
         if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
     }
@@ -987,17 +1030,28 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
         hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B,
                            d.act, 64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
-        if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;              // x_p ready; critic 2 is already updated there
-        if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
-        if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
-        if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
+        const Act a12[2] = {a1, a2};
+        if (side == s) {                                                      // one stream: both critics in one launch
+            if (int rc = mlp_forward_twin(s, ws, mc, crit, x_p, a12, splits)) return rc;
+        } else {
+            if (int rc = ts::stream_wait(ws, s, side, 1)) return rc;          // x_p ready; critic 2 is already updated there
+            if (int rc = mlp_forward(side, ws, mc, st->critic2, x_p, a2, split2)) return rc;
+            if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, split)) return rc;
+            if (int rc = ts::stream_wait(ws, side, s, 2)) return rc;
+        }
         hipLaunchKernelGGL(sac_actor_loss_mb_kernel, dim3(gb), dim3(256), 0, s, a1.out, a2.out, logp, log_alpha,
                            (float)hp->alpha, B, d_q1, d_q2, loss_part);
         TS_LAUNCH_CHECK();
-        if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
-        if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
-        if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
-        if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
+        if (side == s) {
+            const float* dq[2] = {d_q1, d_q2};
+            float* dxs[2] = {dx1, dx2};
+            if (int rc = mlp_backward_twin(s, ws, mc, crit, x_p, a12, dq, dxs, d.obs, d.obs + d.act, scs)) return rc;
+        } else {
+            if (int rc = ts::stream_wait(ws, s, side, 3)) return rc;
+            if (int rc = mlp_backward(side, ws, mc, st->critic2, x_p, a2, d_q2, nullptr, dx2, d.obs, d.obs + d.act, sc2)) return rc;
+            if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q1, nullptr, dx1, d.obs, d.obs + d.act, sc)) return rc;
+            if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
+        }
         hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
                            keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
         TS_LAUNCH_CHECK();
@@ -1120,10 +1174,17 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     if (critic2_old) {                                                  // the two lagged critics side by side
         hipStream_t side;
         if (int rc = twin_stream(ws, s, mc, &side)) return rc;
-        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-        if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
-        if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
-        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+        if (side == s) {
+            const float* pp[2] = {critic1_old, critic2_old};
+            const Act aa2[2] = {a1, a2};
+            float* sp[2] = {split, split2};
+            if (int rc = mlp_forward_twin(s, ws, mc, pp, x_c, aa2, sp)) return rc;
+        } else {
+            if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+            if (int rc = mlp_forward(side, ws, mc, critic2_old, x_c, a2, split2)) return rc;
+            if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
+            if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+        }
     } else {
         if (int rc = mlp_forward(s, ws, mc, critic1_old, x_c, a1, split)) return rc;
     }
@@ -1205,14 +1266,12 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
         hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb, (unsigned)nk), dim3(256), 0, sk, la);
     };
     if (twin_group) {
-        for (int k = 0; k < 2; ++k)
-            if (int rc = mlp_forward(s, ws, mc, crit[k], x_c, acts[k], splits[k])) return rc;
+        const float* dh2[2] = {dheads[0], dheads[1]};
+        if (int rc = mlp_forward_twin(s, ws, mc, crit, x_c, acts, splits)) return rc;
         critic_loss(s, 0, 2);
         TS_LAUNCH_CHECK();
-        for (int k = 0; k < 2; ++k)
-            if (int rc = mlp_backward(s, ws, mc, crit[k], x_c, acts[k], dheads[k], nullptr, nullptr, 0, 0, scs[k], 1)) return rc;
+        if (int rc = mlp_backward_twin(s, ws, mc, crit, x_c, acts, dh2, nullptr, 0, 0, scs)) return rc;
         const float* xs2[2] = {x_c, x_c};
-        const float* dh2[2] = {dheads[0], dheads[1]};
         float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
         if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
         if (hp->critic_lr >= 0.0) {
