@@ -38,11 +38,11 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
 // (col_begin, col_end): only the input-channel tiles covering [col_begin, col_end) are computed.
 // out[i] = sum_s slabs[s][i]
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
-// The weight gradients of up to six small layers in one launch (bit-identical to conv_wgrad per layer; layers that
+// The weight gradients of up to sixteen small layers in one launch (bit-identical to conv_wgrad per layer; layers that
 // qualify for the large-M kernels are launched on their own).  slabs[i]: conv_wgrad_splits(g[i]) * param_elems floats.
 int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const* X, const float* const* dY,
                      float* const* slabs, ts_workspace* prof = nullptr);
-// the same for up to eight independent slab sets in one launch (same summation order per element as slab_sum)
+// the same for up to sixteen independent slab sets in one launch (same summation order per element as slab_sum)
 struct SlabSeg { const float* slabs; int nslab; int64_t n; float* out; };
 int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg);
 

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
 // critics: 0.07 - 0.9 GFLOP each, 9 - 15 us as launches of their own, most of it launch and tail).  blockIdx.x runs over
 // the layers' (k tile, column tile, split) grids back to back; a layer is the 128 x 64 or the 128 x 32 variant by its
 // output width, exactly as in conv_wgrad, so that the result is bit-identical to separate launches.
-constexpr int WGRAD_GROUP_MAX = 6;
+constexpr int WGRAD_GROUP_MAX = 16;
 struct WgradGroup {
     GemmArgs a[WGRAD_GROUP_MAX];
     int first[WGRAD_GROUP_MAX + 1];        // first linear block of layer i
@@ -360,6 +360,8 @@ struct WgradGroup {
     int wide[WGRAD_GROUP_MAX];             // 1: <2, 1, 2, 2> (64 columns), 0: <1, 1, 4, 1> (32 columns)
     int n;
 };
+
+static_assert(sizeof(WgradGroup) <= 4000, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(THREADS) void conv_wgrad_group_kernel(WgradGroup gr) {
     int i = 0;
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__
 }
 
 // The same sum for up to eight independent slab sets in one launch (the layers of one or two networks' backward passes)
-constexpr int SLAB_SEGS_MAX = 8;
+constexpr int SLAB_SEGS_MAX = 16;
 struct SlabSegs {
     const float* slabs[SLAB_SEGS_MAX]; float* out[SLAB_SEGS_MAX]; int64_t n[SLAB_SEGS_MAX]; int nslab[SLAB_SEGS_MAX];
     unsigned first_block[SLAB_SEGS_MAX + 1];

@@ -17,7 +17,9 @@ bool mlp3_supported(int K1, int hidden, int head_cols);
 int mlp3_forward(hipStream_t s, const float* x, int M, int K1, const float* wb1, const float* wb2, const float* wb3,
                  int head_cols, float* h1, float* h2, float* out, ts_workspace* prof = nullptr);
 
-// The same for one or two networks of equal shape on the same input in ONE launch (twin critics: blockIdx.y = network).
+// The same for up to MLP3_MAX_NETS networks of equal shape on the same input in ONE launch (twin critics, ensemble members:
+// blockIdx.y = network).
+constexpr int MLP3_MAX_NETS = 8;
 int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const float* const* wb1, const float* const* wb2,
                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
                    ts_workspace* prof = nullptr);
@@ -30,7 +32,7 @@ int mlp3_backward(hipStream_t s, const float* d_out, int M, int K1, const float*
                   int head_cols, const float* h1, const float* h2, float* dh1, float* dh2, float* dx, int col0, int col1,
                   ts_workspace* prof = nullptr);
 
-// one or two networks of equal shape (each with its own upstream gradient, activations and outputs) in one launch;
+// up to MLP3_MAX_NETS networks of equal shape (each with its own upstream gradient, activations and outputs) in one launch;
 // input gradients (dx) for all of them or for none
 int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, int K1, const float* const* wb1,
                     const float* const* wb2, const float* const* wb3, int head_cols, const float* const* h1,

@@ -63,11 +63,12 @@ __device__ unsigned long long g_mlp_trace[8][40];        // workgroup 0: per wav
 #define MTRACE(slot) do {} while (0)
 #endif
 
-// blockIdx.y = network: twin critics (same input, same shapes, different weights and outputs) share a launch
+// blockIdx.y = network: networks of one shape on the same input (twin critics, the members of a REDQ ensemble) share a launch
+constexpr int MAXN = ts::MLP3_MAX_NETS;
 struct MlpArgs {
     const float* x;
-    const float* wb1[2]; const float* wb2[2]; const float* wb3[2];
-    float* h1[2]; float* h2[2]; float* out[2];
+    const float* wb1[MAXN]; const float* wb2[MAXN]; const float* wb3[MAXN];
+    float* h1[MAXN]; float* h2[MAXN]; float* out[MAXN];
     int M, K1;
 };
 
@@ -315,9 +316,9 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
 // dx[:, dx_c0 : dx_c0 + 16 dx_nt] = dh1 W1^T restricted to those input columns (SAC / TD3: the action columns of the
 // critic input, ddpg.py / sac.py actor losses).  dh1 / dh2 go to HBM for the weight-gradient GEMMs.
 struct BwdArgs {
-    const float* d_out[2]; const float* wb1[2]; const float* wb2[2]; const float* wb3[2];
-    const float* h1[2]; const float* h2[2];
-    float* dh1[2]; float* dh2[2]; float* dx[2];
+    const float* d_out[MAXN]; const float* wb1[MAXN]; const float* wb2[MAXN]; const float* wb3[MAXN];
+    const float* h1[MAXN]; const float* h2[MAXN];
+    float* dh1[MAXN]; float* dh2[MAXN]; float* dx[MAXN];
     int M, K1, dx_c0, dx_nt;
 };
 
@@ -385,7 +386,7 @@ int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const
                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
                    ts_workspace* prof) {
     TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_forward: unsupported shape");
-    TS_REQUIRE(nets == 1 || nets == 2, TS_ERR_INVALID_ARG, "mlp3_forward: one or two networks");
+    TS_REQUIRE(nets >= 1 && nets <= MLP3_MAX_NETS, TS_ERR_INVALID_ARG, "mlp3_forward: 1 .. %d networks", MLP3_MAX_NETS);
     TS_REQUIRE(M >= 1 && x, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
     MlpArgs a{};
     a.x = x; a.M = M; a.K1 = K1;
@@ -420,7 +421,7 @@ int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, i
                     const float* const* h2, float* const* dh1, float* const* dh2, float* const* dx, int col0, int col1,
                     ts_workspace* prof) {
     TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_backward: unsupported shape");
-    TS_REQUIRE(nets == 1 || nets == 2, TS_ERR_INVALID_ARG, "mlp3_backward: one or two networks");
+    TS_REQUIRE(nets >= 1 && nets <= MLP3_MAX_NETS, TS_ERR_INVALID_ARG, "mlp3_backward: 1 .. %d networks", MLP3_MAX_NETS);
     TS_REQUIRE(M >= 1, TS_ERR_INVALID_ARG, "mlp3_backward: bad argument");
     BwdArgs a{};
     a.M = M; a.K1 = K1;

@@ -70,22 +70,27 @@ int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, c
     return ts::conv_forward(s, m.l[2], a.h2, p + m.off[2], a.out, false, split, ws);
 }
 
-// Twin networks of one shape on the same input and the same stream: one launch (blockIdx.y = network) on the fused path,
-// two calls otherwise.
+// n <= MLP3_MAX_NETS networks of one shape on the same input and the same stream: one launch (blockIdx.y = network) on the
+// fused path, n calls otherwise.
+constexpr int MULTI_MAX = ts::MLP3_MAX_NETS;
+int mlp_forward_multi(hipStream_t s, ts_workspace* ws, const Mlp& m, int n, const float* const* p, const float* x, const Act* a,
+                      float* const* split) {
+    if (n > 1 && n <= MULTI_MAX && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC) {
+        const float *w1[MULTI_MAX], *w2[MULTI_MAX], *w3[MULTI_MAX];
+        float *h1[MULTI_MAX], *h2[MULTI_MAX], *out[MULTI_MAX];
+        for (int k = 0; k < n; ++k) {
+            w1[k] = p[k] + m.off[0]; w2[k] = p[k] + m.off[1]; w3[k] = p[k] + m.off[2];
+            h1[k] = a[k].h1; h2[k] = a[k].h2; out[k] = a[k].out;
+        }
+        return ts::mlp3_forward_n(s, n, x, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, out, ws);
+    }
+    for (int k = 0; k < n; ++k)
+        if (int rc = mlp_forward(s, ws, m, p[k], x, a[k], split[k & 1])) return rc;
+    return TS_OK;
+}
 int mlp_forward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* const* p, const float* x, const Act* a,
                      float* const* split) {
-    if (ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC) {
-        const float* w1[2] = {p[0] + m.off[0], p[1] + m.off[0]};
-        const float* w2[2] = {p[0] + m.off[1], p[1] + m.off[1]};
-        const float* w3[2] = {p[0] + m.off[2], p[1] + m.off[2]};
-        float* h1[2] = {a[0].h1, a[1].h1};
-        float* h2[2] = {a[0].h2, a[1].h2};
-        float* out[2] = {a[0].out, a[1].out};
-        return ts::mlp3_forward_n(s, 2, x, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, out, ws);
-    }
-    for (int k = 0; k < 2; ++k)
-        if (int rc = mlp_forward(s, ws, m, p[k], x, a[k], split[k])) return rc;
-    return TS_OK;
+    return mlp_forward_multi(s, ws, m, 2, p, x, a, split);
 }
 
 size_t split_floats(const Mlp& m) {
@@ -103,15 +108,17 @@ bool fused_backward(const Mlp& m, bool want_dx, int col0, int col1) {
     return m.l[1].OC == m.l[0].OC && ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, want_dx, col0, col1);
 }
 
-// Weight gradients of n <= 2 networks of the same shape whose input-gradient chains (mlp3_backward) have run on stream
+// Weight gradients of n <= 5 networks of the same shape whose input-gradient chains (mlp3_backward) have run on stream
 // s: all 3 n GEMMs in one launch, all 3 n slab sets summed in one launch.
+constexpr int WGRADS_MAX_NETS = 5;
 int mlp_weight_grads(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const float* const* x, const Act* a,
                      const float* const* d_out, float* const* grad, const BwdScratch* sc) {
-    ts::ConvGeom geoms[6];
-    const float* X[6];
-    const float* dY[6];
-    float* slabs[6];
-    ts::SlabSeg seg[6];
+    ts::ConvGeom geoms[3 * WGRADS_MAX_NETS];
+    const float* X[3 * WGRADS_MAX_NETS];
+    const float* dY[3 * WGRADS_MAX_NETS];
+    float* slabs[3 * WGRADS_MAX_NETS];
+    ts::SlabSeg seg[3 * WGRADS_MAX_NETS];
+    TS_REQUIRE(n >= 1 && n <= WGRADS_MAX_NETS, TS_ERR_INVALID_ARG, "mlp_weight_grads: 1 .. %d networks", WGRADS_MAX_NETS);
     for (int k = 0; k < n; ++k) {
         const float* xin[3] = {x[k], a[k].h1, a[k].h2};
         const float* dy[3] = {sc[k].dh1, sc[k].dh2, d_out[k]};
@@ -164,24 +171,27 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
     return TS_OK;
 }
 
-// The input-gradient chains (part 1 of mlp_backward) of twin networks on one stream: one launch on the fused path.
-int mlp_backward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* const* p, const float* x, const Act* a,
-                      const float* const* d_out, float* const* dx, int col0, int col1, const BwdScratch* sc) {
+// The input-gradient chains (part 1 of mlp_backward) of n networks on one stream: one launch on the fused path.
+int mlp_backward_multi(hipStream_t s, ts_workspace* ws, const Mlp& m, int n, const float* const* p, const float* x, const Act* a,
+                       const float* const* d_out, float* const* dx, int col0, int col1, const BwdScratch* sc) {
     const bool want_dx = dx && dx[0];
-    if (fused_backward(m, want_dx, col0, col1)) {
-        const float* w1[2] = {p[0] + m.off[0], p[1] + m.off[0]};
-        const float* w2[2] = {p[0] + m.off[1], p[1] + m.off[1]};
-        const float* w3[2] = {p[0] + m.off[2], p[1] + m.off[2]};
-        const float* h1[2] = {a[0].h1, a[1].h1};
-        const float* h2[2] = {a[0].h2, a[1].h2};
-        float* dh1[2] = {sc[0].dh1, sc[1].dh1};
-        float* dh2[2] = {sc[0].dh2, sc[1].dh2};
-        return ts::mlp3_backward_n(s, 2, d_out, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, dh1, dh2, dx, col0, col1, ws);
+    if (n > 1 && n <= MULTI_MAX && fused_backward(m, want_dx, col0, col1)) {
+        const float *w1[MULTI_MAX], *w2[MULTI_MAX], *w3[MULTI_MAX], *h1[MULTI_MAX], *h2[MULTI_MAX];
+        float *dh1[MULTI_MAX], *dh2[MULTI_MAX];
+        for (int k = 0; k < n; ++k) {
+            w1[k] = p[k] + m.off[0]; w2[k] = p[k] + m.off[1]; w3[k] = p[k] + m.off[2];
+            h1[k] = a[k].h1; h2[k] = a[k].h2; dh1[k] = sc[k].dh1; dh2[k] = sc[k].dh2;
+        }
+        return ts::mlp3_backward_n(s, n, d_out, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, dh1, dh2, dx, col0, col1, ws);
     }
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < n; ++k)
         if (int rc = mlp_backward(s, ws, m, p[k], x, a[k], d_out[k], nullptr, want_dx ? dx[k] : nullptr, col0, col1, sc[k], 1))
             return rc;
     return TS_OK;
+}
+int mlp_backward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* const* p, const float* x, const Act* a,
+                      const float* const* d_out, float* const* dx, int col0, int col1, const BwdScratch* sc) {
+    return mlp_backward_multi(s, ws, m, 2, p, x, a, d_out, dx, col0, col1, sc);
 }
 
 size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by side (one slab_sum_multi launch)
@@ -678,18 +688,22 @@ __global__ __launch_bounds__(256) void redq_target_kernel(const float* __restric
 }
 
 // one member's share of the ensemble loss (redq.py:266-270): td_e = Q_e - returns, loss = sum_e sum_b td^2 w / (E B)
-__global__ __launch_bounds__(1024) void redq_critic_loss_kernel(const float* __restrict__ q, const float* __restrict__ ret,
-                                                                const float* __restrict__ weight, int64_t B, float inv_eb,
-                                                                float* __restrict__ td, float* __restrict__ d_out,
+// (blockIdx.x = member of the launch: Q, td, d_out and the loss part of member k sit k strides after the first one's)
+__global__ __launch_bounds__(1024) void redq_critic_loss_kernel(const float* __restrict__ q, int64_t q_stride,
+                                                                const float* __restrict__ ret, const float* __restrict__ weight,
+                                                                int64_t B, float inv_eb, float* __restrict__ td,
+                                                                float* __restrict__ d_out, int64_t d_stride,
                                                                 float* __restrict__ loss_part) {
     __shared__ float red[1024];
+    const int64_t e = blockIdx.x;
+    q += e * q_stride; td += e * B; d_out += e * d_stride; loss_part += e;
     float ls = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += 1024) {
         const float t = q[b * 32] - ret[b];
         const float w = weight ? weight[b] : 1.f;
         td[b] = t;
         ls += t * t * w;
-        d_out[b * 32] = 2.f * t * w * inv_eb;          // the other 31 columns of d_out stay zero
+        store_head_row(d_out + b * 32, 2.f * t * w * inv_eb);
     }
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *loss_part = tot * inv_eb;
@@ -1528,13 +1542,22 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
-    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-    for (int64_t k = 0; k < S; ++k) {                 // the subset's members alternate between the two streams
-        const int w = (int)(k & 1);
-        const Act a{hh[w][0], hh[w][1], qs + k * B * 32};
-        if (int rc = mlp_forward(st2[w], ws, mc, critics_old + (int64_t)h_subset[k] * pc, x_c, a, splits[w])) return rc;
+    if (S <= MULTI_MAX && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC)) {
+        // the subset's members in one launch (no activations kept: inference)
+        const float* pp[MULTI_MAX];
+        Act as[MULTI_MAX];
+        for (int64_t k = 0; k < S; ++k) { pp[k] = critics_old + (int64_t)h_subset[k] * pc; as[k] = Act{nullptr, nullptr, qs + k * B * 32}; }
+        if (S == 1) { as[0].h1 = hh[0][0]; as[0].h2 = hh[0][1]; }
+        if (int rc = mlp_forward_multi(s, ws, mc, (int)S, pp, x_c, as, splits)) return rc;
+    } else {
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+        for (int64_t k = 0; k < S; ++k) {             // the subset's members alternate between the two streams
+            const int w = (int)(k & 1);
+            const Act a{hh[w][0], hh[w][1], qs + k * B * 32};
+            if (int rc = mlp_forward(st2[w], ws, mc, critics_old + (int64_t)h_subset[k] * pc, x_c, a, splits[w])) return rc;
+        }
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
-    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     hipLaunchKernelGGL(redq_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, qs, (int)S, B * 32, logp,
                        log_alpha, (float)fixed_alpha, mean_mode, B, out);
     TS_LAUNCH_CHECK();
@@ -1559,10 +1582,13 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc)), spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.off[3], pc = mc.off[3];
-    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 6) * al(4 * B * d.hid) +
-                         (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + 2 * al(4 * slab) + al(4 * (size_t)E * pc) +
+    // the critics' chains run CH members per launch on the fused path (ts_mlp.hip): CH scratch sets instead of two
+    const bool batched = fused_backward(mc, false, 0, 0) && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC);
+    const int CH = batched ? (int)std::min<int64_t>(WGRADS_MAX_NETS, E) : 2;
+    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 2 + 2 * CH) * al(4 * B * d.hid) +
+                         (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + (size_t)CH * al(4 * slab) + al(4 * (size_t)E * pc) +
                          al(4 * pa) + 2 * al(4 * spl) + al(4 * (size_t)E * B) + 2 * al(4 * B) + al(4 * B * 3 * d.act) +
-                         al(256) + al(4 * 1024) + 8192;
+                         al(4 * (size_t)CH * B * 32) + al(256) + al(4 * 1024) + 8192;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -1577,8 +1603,9 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     float* d_head = c.take<float>(B * 64);
     float* dheads[2] = {c.take<float>(B * 64), c.take<float>(B * 64)};
     float* d_q = dheads[0];                          // actor phase: the critic-phase gradients are consumed by then
-    BwdScratch scs[2];
-    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    BwdScratch scs[WGRADS_MAX_NETS];
+    for (int k = 0; k < CH; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    float* dheads_ch = c.take<float>((size_t)CH * B * 32);          // batched path: one head gradient per member of a chunk
     float* gcrit = c.take<float>((size_t)E * pc);
     float* gact = c.take<float>(pa);
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
@@ -1598,18 +1625,41 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     // ensemble loss (redq.py:266-271): the members are independent chains, alternating between two streams
     if (int rc = ts::side_stream(ws, s, &side)) return rc;
     hipStream_t st2[2] = {s, side};
-    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-    for (int e = 0; e < E; ++e) {
-        const int w = e & 1;
-        const float* pe = st->critics + (int64_t)e * pc;
-        if (int rc = mlp_forward(st2[w], ws, mc, pe, x_c, acts[e], splits[w])) return rc;
-        hipLaunchKernelGGL(redq_critic_loss_kernel, dim3(1), dim3(1024), 0, st2[w], acts[e].out, returns, weight, B, inv_eb,
-                           tds + (int64_t)e * B, dheads[w], loss_parts + e);
-        TS_LAUNCH_CHECK();
-        if (int rc = mlp_backward(st2[w], ws, mc, pe, x_c, acts[e], dheads[w], gcrit + (int64_t)e * pc, nullptr, 0, 0, scs[w]))
-            return rc;
+    if (batched) {
+        // CH members per launch: forward chains, losses, input-gradient chains, 3 CH weight-gradient GEMMs, 3 CH slab sums
+        // -- five launches per chunk instead of five per member
+        const int64_t q_stride = E > 1 ? acts[1].out - acts[0].out : 0;     // (Act blocks are carved back to back)
+        for (int e0 = 0; e0 < E; e0 += CH) {
+            const int n = (int)std::min<int64_t>(CH, E - e0);
+            const float* pp[WGRADS_MAX_NETS];
+            const float* xs[WGRADS_MAX_NETS];
+            const float* dh[WGRADS_MAX_NETS];
+            float* gk[WGRADS_MAX_NETS];
+            for (int k = 0; k < n; ++k) {
+                pp[k] = st->critics + (int64_t)(e0 + k) * pc; xs[k] = x_c; dh[k] = dheads_ch + (int64_t)k * B * 32;
+                gk[k] = gcrit + (int64_t)(e0 + k) * pc;
+            }
+            if (int rc = mlp_forward_multi(s, ws, mc, n, pp, x_c, acts + e0, splits)) return rc;
+            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3((unsigned)n), dim3(1024), 0, s, acts[e0].out, q_stride, returns, weight,
+                               B, inv_eb, tds + (int64_t)e0 * B, dheads_ch, B * 32, loss_parts + e0);
+            TS_LAUNCH_CHECK();
+            if (int rc = mlp_backward_multi(s, ws, mc, n, pp, x_c, acts + e0, dh, nullptr, 0, 0, scs)) return rc;
+            if (int rc = mlp_weight_grads(s, ws, n, mc, xs, acts + e0, dh, gk, scs)) return rc;
+        }
+    } else {
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+        for (int e = 0; e < E; ++e) {
+            const int w = e & 1;
+            const float* pe = st->critics + (int64_t)e * pc;
+            if (int rc = mlp_forward(st2[w], ws, mc, pe, x_c, acts[e], splits[w])) return rc;
+            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3(1), dim3(1024), 0, st2[w], acts[e].out, (int64_t)0, returns, weight, B,
+                               inv_eb, tds + (int64_t)e * B, dheads[w], (int64_t)0, loss_parts + e);
+            TS_LAUNCH_CHECK();
+            if (int rc = mlp_backward(st2[w], ws, mc, pe, x_c, acts[e], dheads[w], gcrit + (int64_t)e * pc, nullptr, 0, 0, scs[w]))
+                return rc;
+        }
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
-    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     hipLaunchKernelGGL(redq_finish_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, tds, loss_parts, (int)E, B,
                        stats_out4 + 1, weight_out);
     TS_LAUNCH_CHECK();
