@@ -42,12 +42,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int ROWS = 16;             // batch rows per workgroup
-constexpr int THREADS = 512;         // 8 waves
-constexpr int WAVES = THREADS / 64;
 constexpr int HID = 256;
 constexpr int HP = HID + 4;          // LDS pitch of a hidden activation row
 constexpr int NST = 8;               // register stages of the weight ring (blocks in flight + 1)
-constexpr int PART_FLOATS = ROWS * (WAVES * 64 + 4 * WAVES);      // k-split partial sums: splits x 16 x (columns + 4)
+constexpr int part_floats(int nw) { return ROWS * (nw * 64 + 4 * nw); }      // k-split partial sums: splits x 16 x (columns + 4)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -92,12 +90,12 @@ struct WStream {
     const float* wb;
     int c0, ncols, ncw, nks, cw, ks, nbw, b0, n, kq;
     int trow[4];                 // TRANS: row of W (= output column) of tile e for this lane (clamped)
-    __device__ __forceinline__ WStream(const float* w, int K, int ncols_, int c0_, int wave, int lane)
+    __device__ __forceinline__ WStream(const float* w, int K, int ncols_, int c0_, int wave, int lane, int nw)
         : wb(w), c0(c0_), ncols(ncols_), n(lane & 15), kq(lane >> 4) {
         const int per = 16 * TPW;
         const int want = (ncols + per - 1) / per;                    // 1, 2 or 4 (0: no output at all)
         ncw = want <= 1 ? 1 : (want == 2 ? 2 : 4);
-        nks = WAVES / ncw;
+        nks = nw / ncw;
         cw = wave % ncw;
         ks = wave / ncw;
         nbw = ncols > 0 ? K / 16 / nks : 0;
@@ -149,7 +147,7 @@ struct NoNext {
 // nullable) and o_g (row pitch o_ld, nullable; rows >= M are not stored).  A = a_lds [16][a_pitch].  The stream `w` must
 // have been primed into `st`; while the last blocks are consumed the freed stages take the first blocks of `next`.
 // Two barriers: partial sums visible / the output visible (and `part` free again).
-template <int PITCH, bool TRANS, int TPW, int EP, typename Next>
+template <int PITCH, bool TRANS, int TPW, int EP, int TH, typename Next>
 __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, Stage (&st)[NST], const Next& next,
                                           const float* a_lds, int a_pitch, float* part, float* o_lds,
                                           float* __restrict__ o_g, int o_ld, const float* __restrict__ mask,
@@ -160,11 +158,12 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
     // what the finish reads from memory (bias / ReLU mask) is requested now: a load issued after the next layer's
     // prefetches would wait for all of them (loads return in order)
     const int q4 = w.ncols / 4;                       // float4 per output row
-    const int nf4 = ROWS * q4;                        // float4 outputs of the layer: at most 2 per thread
-    f32x4 epi[2];
+    const int nf4 = ROWS * q4;                        // float4 outputs of the layer: at most 1024 / TH per thread
+    constexpr int NQ = 1024 / TH;
+    f32x4 epi[NQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = min(tid + q * THREADS, max(nf4 - 1, 0));
+    for (int q = 0; q < NQ; ++q) {
+        const int i = min(tid + q * TH, max(nf4 - 1, 0));
         const int row = q4 > 0 ? i / q4 : 0, c4 = i - row * q4;
         if (EP == EP_MASK) epi[q] = *reinterpret_cast<const f32x4*>(mask + (size_t)min(m0 + row, M - 1) * o_ld + w.c0 + 4 * c4);
         else if (EP == EP_BIAS_RELU || EP == EP_BIAS) epi[q] = *reinterpret_cast<const f32x4*>(bias + w.c0 + 4 * c4);
@@ -224,8 +223,8 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
     __syncthreads();
     // finish: 16 x ncols outputs, 16 bytes per thread and step, whole rows
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = tid + q * THREADS;
+    for (int q = 0; q < NQ; ++q) {
+        const int i = tid + q * TH;
         if (i < nf4) {
             const int row = i / q4, c4 = i - row * q4;
             f32x4 val = *reinterpret_cast<const f32x4*>(part + row * pp + 4 * c4);
@@ -247,33 +246,43 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
 // x tile / upstream-gradient tile of this workgroup: [16][K] floats -> LDS (rows past M repeat the last row).  Two halves:
 // the global loads are issued BEFORE the first weights are requested and committed to LDS after (loads return in order:
 // behind 28 weight loads the input rows would arrive last although the barrier waits for them first).
-constexpr int XR = 8;                // 16 rows x 1024 floats / 512 threads / 4
-__device__ __forceinline__ void load_rows_issue(const float* __restrict__ src, int K, int m0, int M, int tid, f32x4 (&xr)[XR]) {
+template <int TH> constexpr int xr_count() { return ROWS * 1024 / 4 / TH; }     // 16 rows x 1024 floats / threads / 4
+template <int TH>
+__device__ __forceinline__ void load_rows_issue(const float* __restrict__ src, int K, int m0, int M, int tid,
+                                                f32x4 (&xr)[xr_count<TH>()]) {
+    constexpr int XR = xr_count<TH>();
     const int q4 = K / 4, total = ROWS * q4;
 #pragma unroll
     for (int it = 0; it < XR; ++it) {
-        const int i = min(tid + it * THREADS, total - 1);
+        const int i = min(tid + it * TH, total - 1);
         const int row = i / q4, c = i - row * q4;
         const int m = min(m0 + row, M - 1);
         xr[it] = *reinterpret_cast<const f32x4*>(src + (size_t)m * K + 4 * c);
-        if ((it + 1) * THREADS >= total) break;          // uniform
+        if ((it + 1) * TH >= total) break;          // uniform
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__device__ __forceinline__ void load_rows_commit(int K, float* dst, int pitch, int tid, const f32x4 (&xr)[XR]) {
+template <int TH>
+__device__ __forceinline__ void load_rows_commit(int K, float* dst, int pitch, int tid, const f32x4 (&xr)[xr_count<TH>()]) {
+    constexpr int XR = xr_count<TH>();
     const int q4 = K / 4, total = ROWS * q4;
 #pragma unroll
     for (int it = 0; it < XR; ++it) {
-        const int i = tid + it * THREADS;
+        const int i = tid + it * TH;
         const int row = i / q4, c = i - row * q4;
         if (i < total) *reinterpret_cast<f32x4*>(dst + row * pitch + 4 * c) = xr[it];
-        if ((it + 1) * THREADS >= total) break;
+        if ((it + 1) * TH >= total) break;
     }
 }
 
-template <int N3>
-__global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
+// NW = waves per workgroup.  8: one workgroup per CU, the reduction of a hidden layer split over two wave groups -- single
+// launches (256 workgroups at B = 4096).  4: no k split in the hidden layers, 78 KB of LDS -- TWO workgroups per CU, which in a
+// multi-network launch (blockIdx.y = network) are the same rows of two different networks: their weight streams and MFMA
+// phases interleave on the CU instead of running as two generations.
+template <int N3, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp3_fwd_kernel(MlpArgs a) {
+    constexpr int TH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ROWS;
@@ -288,27 +297,27 @@ __global__ __launch_bounds__(THREADS) void mlp3_fwd_kernel(MlpArgs a) {
     float* part = h2s + ROWS * HP;
     Stage st[NST];
     constexpr int TP3 = N3 == 32 ? 2 : 4;
-    const WStream<HID, false, 4> w1(wb1, a.K1, HID, 0, wave, lane);
-    const WStream<HID, false, 4> w2(wb2, HID, HID, 0, wave, lane);
-    const WStream<N3, false, TP3> w3(wb3, HID, N3, 0, wave, lane);
+    const WStream<HID, false, 4> w1(wb1, a.K1, HID, 0, wave, lane, NW);
+    const WStream<HID, false, 4> w2(wb2, HID, HID, 0, wave, lane, NW);
+    const WStream<N3, false, TP3> w3(wb3, HID, N3, 0, wave, lane, NW);
     MMARK(0);
     {
-        f32x4 xr[XR];
-        load_rows_issue(a.x, a.K1, m0, a.M, tid, xr);
+        f32x4 xr[xr_count<TH>()];
+        load_rows_issue<TH>(a.x, a.K1, m0, a.M, tid, xr);
         w1.template prime<0, 2>(st);               // the first weights travel while the input rows do
-        load_rows_commit(a.K1, xs, xp, tid, xr);
+        load_rows_commit<TH>(a.K1, xs, xp, tid, xr);
     }
     __syncthreads();
     w1.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w1, st, w2, xs, xp, part, h1s, a.h1[net], HID, nullptr, wb1 + (size_t)a.K1 * HID, m0,
-                                           a.M, tid, 0);
+    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH>(w1, st, w2, xs, xp, part, h1s, a.h1[net], HID, nullptr, wb1 + (size_t)a.K1 * HID,
+                                               m0, a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU>(w2, st, w3, h1s, HP, part, h2s, a.h2[net], HID, nullptr, wb2 + (size_t)HID * HID, m0,
-                                           a.M, tid, 16);
+    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH>(w2, st, w3, h1s, HP, part, h2s, a.h2[net], HID, nullptr, wb2 + (size_t)HID * HID,
+                                               m0, a.M, tid, 16);
     MMARK(3);
-    mlp_layer<N3, false, TP3, EP_BIAS>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out[net], N3, nullptr, wb3 + (size_t)HID * N3,
-                                       m0, a.M, tid, 32);
+    mlp_layer<N3, false, TP3, EP_BIAS, TH>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out[net], N3, nullptr,
+                                           wb3 + (size_t)HID * N3, m0, a.M, tid, 32);
     MMARK(4);
 }
 
@@ -322,8 +331,9 @@ struct BwdArgs {
     int M, K1, dx_c0, dx_nt;
 };
 
-template <int N3>
-__global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
+template <int N3, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp3_bwd_kernel(BwdArgs a) {
+    constexpr int TH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ROWS;
@@ -334,25 +344,25 @@ __global__ __launch_bounds__(THREADS) void mlp3_bwd_kernel(BwdArgs a) {
     Stage st[NST];
     const int net = blockIdx.y;
     float* dx = a.dx[net];
-    const WStream<N3, true, 4> w3(a.wb3[net], N3, HID, 0, wave, lane);
-    const WStream<HID, true, 4> w2(a.wb2[net], HID, HID, 0, wave, lane);
-    const WStream<HID, true, 4> w1(a.wb1[net], HID, dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane);
+    const WStream<N3, true, 4> w3(a.wb3[net], N3, HID, 0, wave, lane, NW);
+    const WStream<HID, true, 4> w2(a.wb2[net], HID, HID, 0, wave, lane, NW);
+    const WStream<HID, true, 4> w1(a.wb1[net], HID, dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane, NW);
     MMARK(0);
     {
-        f32x4 xr[XR];
-        load_rows_issue(a.d_out[net], N3, m0, a.M, tid, xr);
+        f32x4 xr[xr_count<TH>()];
+        load_rows_issue<TH>(a.d_out[net], N3, m0, a.M, tid, xr);
         w3.template prime<0, 2>(st);
-        load_rows_commit(N3, ds, N3 + 4, tid, xr);
+        load_rows_commit<TH>(N3, ds, N3 + 4, tid, xr);
     }
     __syncthreads();
     w3.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<N3, true, 4, EP_MASK>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2[net], HID, a.h2[net], nullptr, m0, a.M, tid, 0);
+    mlp_layer<N3, true, 4, EP_MASK, TH>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2[net], HID, a.h2[net], nullptr, m0, a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, true, 4, EP_MASK>(w2, st, w1, g2s, HP, part, g1s, a.dh1[net], HID, a.h1[net], nullptr, m0, a.M, tid, 16);
+    mlp_layer<HID, true, 4, EP_MASK, TH>(w2, st, w1, g2s, HP, part, g1s, a.dh1[net], HID, a.h1[net], nullptr, m0, a.M, tid, 16);
     MMARK(3);
     if (dx != nullptr) {
-        mlp_layer<HID, true, 4, EP_PLAIN>(w1, st, NoNext{}, g1s, HP, part, nullptr, dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
+        mlp_layer<HID, true, 4, EP_PLAIN, TH>(w1, st, NoNext{}, g1s, HP, part, nullptr, dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
         MMARK(4);
     }
 }
@@ -395,18 +405,22 @@ int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const
         a.wb1[k] = wb1[k]; a.wb2[k] = wb2[k]; a.wb3[k] = wb3[k];
         a.h1[k] = h1 ? h1[k] : nullptr; a.h2[k] = h2 ? h2[k] : nullptr; a.out[k] = out[k];
     }
-    const size_t lds = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + PART_FLOATS);
+    // four-wave workgroups (two per CU) when several networks share the launch and two such workgroups fit a CU's LDS
+    static const int force_nw = getenv("TS_MLP_NW") ? atoi(getenv("TS_MLP_NW")) : 0;
+    const size_t lds4 = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(4));
+    const bool four = force_nw ? force_nw == 4 : (nets > 1 && lds4 <= 80 * 1024);
+    const size_t lds = four ? lds4 : sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(8));
     const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_FWD, s);
-    if (head_cols == 32) {
-        static const int once = allow_lds(&mlp3_fwd_kernel<32>);
-        (void)once;
-        hipLaunchKernelGGL((mlp3_fwd_kernel<32>), grid, dim3(THREADS), lds, s, a);
-    } else {
-        static const int once = allow_lds(&mlp3_fwd_kernel<64>);
-        (void)once;
-        hipLaunchKernelGGL((mlp3_fwd_kernel<64>), grid, dim3(THREADS), lds, s, a);
-    }
+#define TS_MLP_FWD(N3_, NW_)                                                                          \
+    do {                                                                                              \
+        static const int once = allow_lds(&mlp3_fwd_kernel<N3_, NW_>);                                \
+        (void)once;                                                                                   \
+        hipLaunchKernelGGL((mlp3_fwd_kernel<N3_, NW_>), grid, dim3(64 * NW_), lds, s, a);             \
+    } while (0)
+    if (head_cols == 32) { if (four) TS_MLP_FWD(32, 4); else TS_MLP_FWD(32, 8); }
+    else { if (four) TS_MLP_FWD(64, 4); else TS_MLP_FWD(64, 8); }
+#undef TS_MLP_FWD
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -439,18 +453,20 @@ int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, i
         a.dx_nt = (int)ceil_div(col1 - a.dx_c0, 16);
         TS_REQUIRE(a.dx_nt <= 8, TS_ERR_UNSUPPORTED, "mlp3_backward: input-gradient range wider than 128 columns");
     }
-    const size_t lds = sizeof(float) * (size_t)(ROWS * (head_cols + 4) + 2 * ROWS * HP + PART_FLOATS);
+    static const int force_nw = getenv("TS_MLP_NW") ? atoi(getenv("TS_MLP_NW")) : 0;
+    const bool four = force_nw ? force_nw == 4 : nets > 1;
+    const size_t lds = sizeof(float) * (size_t)(ROWS * (head_cols + 4) + 2 * ROWS * HP + part_floats(four ? 4 : 8));
     const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
-    if (head_cols == 32) {
-        static const int once = allow_lds(&mlp3_bwd_kernel<32>);
-        (void)once;
-        hipLaunchKernelGGL((mlp3_bwd_kernel<32>), grid, dim3(THREADS), lds, s, a);
-    } else {
-        static const int once = allow_lds(&mlp3_bwd_kernel<64>);
-        (void)once;
-        hipLaunchKernelGGL((mlp3_bwd_kernel<64>), grid, dim3(THREADS), lds, s, a);
-    }
+#define TS_MLP_BWD(N3_, NW_)                                                                          \
+    do {                                                                                              \
+        static const int once = allow_lds(&mlp3_bwd_kernel<N3_, NW_>);                                \
+        (void)once;                                                                                   \
+        hipLaunchKernelGGL((mlp3_bwd_kernel<N3_, NW_>), grid, dim3(64 * NW_), lds, s, a);             \
+    } while (0)
+    if (head_cols == 32) { if (four) TS_MLP_BWD(32, 4); else TS_MLP_BWD(32, 8); }
+    else { if (four) TS_MLP_BWD(64, 4); else TS_MLP_BWD(64, 8); }
+#undef TS_MLP_BWD
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
