@@ -8,7 +8,7 @@
 // the 4 MB activations through HBM in between.
 //
 // How: a workgroup owns 16 rows of the batch for all layers (256 workgroups at B = 4096: one per CU, eight waves = two
-// per SIMD).  Activations stay in LDS ([row][k], pitch K + 4).  What a workgroup has to move is the weights: 720 KB out
+// per SIMD; launches that carry several networks use four-wave workgroups, two per CU: see mlp3_fwd_kernel).  Activations stay in LDS ([row][k], pitch K + 4).  What a workgroup has to move is the weights: 720 KB out
 // of L2 for 12 MFLOP -- the launch is bound by how fast ONE CU streams them, and the access pattern decides that rate
 // (scripts/ubench/l2_stream.hip, one 512-thread workgroup per CU, matrix resident in L2): 16-byte loads in which sixteen
 // lanes cover 256 contiguous bytes, or 4-byte loads over 64-byte pieces, reach 57-66 B/clk/CU; the 8-byte loads of the
