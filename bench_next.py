@@ -95,7 +95,7 @@ def _roofline(prof, flop_per_update, what):
     ms = sum(prof[k][0] for k in GEMM_KINDS)
     n = sum(prof[k][1] for k in GEMM_KINDS)
     tf = flop_per_update / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"conv_rows_kernel / conv_wgrad_kernel ({what})", "achieved": tf, "peak": PEAK,
+    return {"bound": "mfma", "kernel": f"linear / conv layer GEMM kernels: conv_rows / conv_wgrad(_group), fused mlp3_fwd / mlp3_bwd where the shape allows ({what})", "achieved": tf, "peak": PEAK,
             "unit": "TFLOP/s", "frac": tf / PEAK, "traffic": None, "avg_launch_us": ms * 1e3 / max(n, 1),
             "launches_per_update": n, "gemm_us_per_update": ms * 1e3, "algorithmic_flop_per_update": flop_per_update,
             "kernel_us_per_update": {k: prof[k][0] * 1e3 for k in GEMM_KINDS}}

@@ -118,7 +118,7 @@ def run(steps: int, warmup: int, repeat: int = 2, with_cpu: bool = True) -> dict
     gemm_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad"))
     launches = sum(prof[k][1] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad"))
     tf = STEP_FLOP * MINIBATCH / (gemm_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_rows_kernel / conv_wgrad_kernel (14 GEMM launches of one minibatch step)",
+    roof = {"bound": "mfma", "kernel": "conv_rows2_kernel / conv_wgrad2_kernel (14 GEMM launches of one minibatch step; second generation)",
             "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
             "traffic": None, "avg_launch_us": gemm_ms * 1e3 / max(launches, 1), "launches": launches,
             "kernel_ms_per_step": {k: prof[k][0] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")},

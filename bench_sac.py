@@ -111,7 +111,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
     gemm_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) / n_prof
     launches = sum(prof[k][1] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) // n_prof
     tf = FLOP_PER_SAMPLE * BATCH / (gemm_ms * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_rows_kernel / conv_wgrad_kernel (all linear-layer GEMMs of one update)",
+    roof = {"bound": "mfma", "kernel": "mlp3_fwd_kernel / mlp3_bwd_kernel / conv_wgrad_group_kernel (all linear-layer GEMMs of one update)",
             "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
             "traffic": None, "avg_launch_us": gemm_ms * 1e3 / launches, "launches_per_update": launches,
             "gemm_us_per_update": gemm_ms * 1e3,
