@@ -1584,7 +1584,9 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     const int64_t pa = ma.off[3], pc = mc.off[3];
     // the critics' chains run CH members per launch on the fused path (ts_mlp.hip): CH scratch sets instead of two
     const bool batched = fused_backward(mc, false, 0, 0) && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC);
-    const int CH = batched ? (int)std::min<int64_t>(WGRADS_MAX_NETS, E) : 2;
+    static const int ch_env = getenv("TS_REDQ_CHUNK") ? atoi(getenv("TS_REDQ_CHUNK")) : 0;      // experiments
+    const int ch_want = ch_env >= 1 && ch_env <= WGRADS_MAX_NETS ? ch_env : WGRADS_MAX_NETS;
+    const int CH = batched ? (int)std::min<int64_t>(ch_want, E) : 2;
     const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 2 + 2 * CH) * al(4 * B * d.hid) +
                          (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + (size_t)CH * al(4 * slab) + al(4 * (size_t)E * pc) +
                          al(4 * pa) + 2 * al(4 * spl) + al(4 * (size_t)E * B) + 2 * al(4 * B) + al(4 * B * 3 * d.act) +
