@@ -636,16 +636,21 @@ int v2_mode() { return v2_mode_ref(); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
 // Row counts from which generation 2 wins (scripts/gpu_conv2_check.py bench, profiles/r03_conv2_thresholds.txt): its
-// persistent workgroups need a few row tiles each.  Convolutions: 2^18 rows (the C3 batch of 512 stays on generation 1,
-// whose summation order the small-batch parity tests pin); linear layers (rows = samples): 16,384 rows of a layer with at
+// persistent workgroups need a few row tiles each.  Convolutions: 2^18 rows (at the C3 batch of 512 only the first layer
+// qualifies, from 2^17 rows; the shapes of the small-batch parity tests all stay on generation 1); linear layers (rows = samples): 16,384 rows of a layer with at
 // least 2^16 weights (narrow heads stay on generation 1 at every size).
 constexpr int64_t CONV2_MIN_ROWS = 1 << 18;
+constexpr int64_t CONV2_FIRST_MIN_ROWS = 1 << 17;
 constexpr int64_t LINEAR2_MIN_ROWS = 1 << 14;
 constexpr int64_t LINEAR2_MIN_WEIGHTS = 1 << 16;
 
 bool big_enough(const ts::ConvGeom& g, int64_t rows) {
     const bool linear = g.KH == 1 && g.KW == 1 && g.IH == 1 && g.IW == 1;
     if (linear) return rows >= LINEAR2_MIN_ROWS && (int64_t)g.IC * g.OC >= LINEAR2_MIN_WEIGHTS;
+    // 32-channel first layers (resident 32 KB weight block, two workgroups per CU) win from 2^17 rows on -- the C3 batch:
+    // 512 x 20 x 20 = 204,800 rows, forward 47.5 -> 41.1 us, weight gradient 59.7 -> 50.7 us, DQN 1,218 -> 1,250 updates/s
+    static const int64_t first_min = [] { const char* e = getenv("TS_CONV2_FIRST_MIN_ROWS"); return e ? atoll(e) : CONV2_FIRST_MIN_ROWS; }();
+    if (g.OC == 32 && g.K() <= 256) return rows >= first_min;
     return rows >= CONV2_MIN_ROWS;
 }
 
