@@ -211,6 +211,13 @@ int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t*
     return ts::side_stream(ws, s, out);
 }
 
+// DiscreteSAC: its three networks share one shape and one input, so on the fused path they go through the multi-network
+// launches on the caller's stream (TS_TWIN_STREAMS keeps the two-stream per-network chains for comparison).
+bool dsac_one_stream(const Mlp& m) {
+    static const bool force = getenv("TS_TWIN_STREAMS") != nullptr;
+    return !force && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && fused_backward(m, false, 0, 0);
+}
+
 // ---- elementwise kernels ----------------------------------------------------------------------------
 // row of a 32-column head gradient: [v, 0 x 31] (the whole row is written: the buffer needs no memset)
 __device__ __forceinline__ void store_head_row(float* __restrict__ row, float v) {
@@ -602,11 +609,14 @@ __global__ __launch_bounds__(256) void dsac_target_kernel(const float* __restric
 }
 
 // critic step (discrete_sac.py:162-172): td = Q(s)[a] - returns; loss = mean(td^2 w); d_out[b, a_b] = 2 td w / B
-__global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+struct DsacLossArgs { const float* q[2]; float* td[2]; float* d_out[2]; float* loss[2]; };
+__global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(DsacLossArgs la, const int64_t* __restrict__ act,
                                                                 const float* __restrict__ ret, const float* __restrict__ weight,
-                                                                int64_t B, int hw, float* __restrict__ td,
-                                                                float* __restrict__ d_out, float* __restrict__ loss) {
+                                                                int64_t B, int hw) {      // blockIdx.x = critic
     __shared__ float red[1024];
+    const float* __restrict__ q = la.q[blockIdx.x];
+    float* __restrict__ td = la.td[blockIdx.x];
+    float* __restrict__ d_out = la.d_out[blockIdx.x];
     const float inv_b = 1.f / (float)B;
     float ls = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += 1024) {
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(const float* __r
         for (int j = 0; j < hw; ++j) d_out[b * hw + j] = j == a ? 2.f * t * w * inv_b : 0.f;
     }
     const float tot = block_sum_1024(ls, red);
-    if (threadIdx.x == 0) *loss = tot * inv_b;
+    if (threadIdx.x == 0) *la.loss[blockIdx.x] = tot * inv_b;
 }
 
 // actor step (discrete_sac.py:176-184): f_b = alpha H_b + sum_a p_a q_a, q = min(Q1, Q2) (no grad); loss = -mean f.
@@ -1404,12 +1414,19 @@ int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs_next,
                        (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
     TS_LAUNCH_CHECK();
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
-    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-    if (int rc = mlp_forward(side, ws, m, critic2_old, x, a2, split2)) return rc;
-    if (int rc = mlp_forward(s, ws, m, actor, x, aa, split)) return rc;
-    if (int rc = mlp_forward(s, ws, m, critic1_old, x, a1, split)) return rc;
-    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    if (dsac_one_stream(m)) {        // the three networks read the same rows: one launch
+        const float* p3[3] = {actor, critic1_old, critic2_old};
+        const Act a3[3] = {aa, a1, a2};
+        float* sp[2] = {split, split2};
+        if (int rc = mlp_forward_multi(s, ws, m, 3, p3, x, a3, sp)) return rc;
+    } else {
+        if (int rc = ts::side_stream(ws, s, &side)) return rc;
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+        if (int rc = mlp_forward(side, ws, m, critic2_old, x, a2, split2)) return rc;
+        if (int rc = mlp_forward(s, ws, m, actor, x, aa, split)) return rc;
+        if (int rc = mlp_forward(s, ws, m, critic1_old, x, a1, split)) return rc;
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
+    }
     hipLaunchKernelGGL(dsac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, a1.out, a2.out,
                        log_alpha, (float)fixed_alpha, B, d.act, d.hw, out);
     TS_LAUNCH_CHECK();
@@ -1455,31 +1472,62 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs,
                        (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
     TS_LAUNCH_CHECK();
-    // critic 1 on the caller's stream, critic 2 on the side stream (independent chains, as ts_sac_update)
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
-    hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
     float* crit_m[2] = {st->critic1_m, st->critic2_m};
     float* crit_v[2] = {st->critic1_v, st->critic2_v};
-    if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
-    for (int k = 0; k < 2; ++k) {
-        hipStream_t sk = stq[k];
-        if (int rc = mlp_forward(sk, ws, m, crit[k], x, acts[k], splits[k])) return rc;
-        hipLaunchKernelGGL(dsac_critic_loss_kernel, dim3(1), dim3(1024), 0, sk, acts[k].out, act, returns, weight, B, d.hw,
-                           tds[k], dheads[k], stats_out5 + 1 + k);
+    float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
+    const bool one_stream = dsac_one_stream(m);
+    const bool polyak_with_adam = one_stream && hp->critic_lr >= 0.0 && hp->tau > 0.0;
+    auto critic_loss = [&](hipStream_t sk, int k0, int nk) {
+        DsacLossArgs la{};
+        for (int k = 0; k < nk; ++k) {
+            la.q[k] = acts[k0 + k].out; la.td[k] = tds[k0 + k]; la.d_out[k] = dheads[k0 + k];
+            la.loss[k] = stats_out5 + 1 + k0 + k;
+        }
+        hipLaunchKernelGGL(dsac_critic_loss_kernel, dim3((unsigned)nk), dim3(1024), 0, sk, la, act, returns, weight, B, d.hw);
+    };
+    if (one_stream) {
+        // both critics per launch: forward, loss, input-gradient chains, the six weight-gradient GEMMs, Adam (which also
+        // moves the lagged critics: nothing reads them again in this update); then the updated critics and the actor
+        // (discrete_sac.py:176-184) in one three-network forward
+        const float* dh2[2] = {dheads[0], dheads[1]};
+        const float* xs2[2] = {x, x};
+        if (int rc = mlp_forward_twin(s, ws, m, crit, x, acts, splits)) return rc;
+        critic_loss(s, 0, 2);
         TS_LAUNCH_CHECK();
-        float* gk = g_out[k] ? g_out[k] : gbuf[k];
-        if (int rc = mlp_backward(sk, ws, m, crit[k], x, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k])) return rc;
-        if (hp->critic_lr >= 0.0)
-            if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk, P, adam_step, hp->critic_lr, hp->beta1,
-                                       hp->beta2, hp->adam_eps, 0.0, norm_part + 512 * k))
+        if (int rc = mlp_backward_twin(s, ws, m, crit, x, acts, dh2, nullptr, 0, 0, scs)) return rc;
+        if (int rc = mlp_weight_grads(s, ws, 2, m, xs2, acts, dh2, gk2, scs)) return rc;
+        if (hp->critic_lr >= 0.0) {
+            float* lag[2] = {st->critic1_old, st->critic2_old};
+            if (int rc = ts::adam_step_multi(s, 2, crit, crit_m, crit_v, gk2, lag, P, adam_step, hp->critic_lr, hp->beta1,
+                                             hp->beta2, hp->adam_eps, hp->tau))
                 return rc;
+        }
+        const float* p3[3] = {st->critic1, st->critic2, st->actor};
+        const Act a3[3] = {acts[0], acts[1], aa};
+        if (int rc = mlp_forward_multi(s, ws, m, 3, p3, x, a3, splits)) return rc;
+    } else {
+        // critic 1 on the caller's stream, critic 2 on the side stream (independent chains, as ts_sac_update)
+        if (int rc = ts::side_stream(ws, s, &side)) return rc;
+        hipStream_t stq[2] = {s, side};
+        if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
+        for (int k = 0; k < 2; ++k) {
+            hipStream_t sk = stq[k];
+            if (int rc = mlp_forward(sk, ws, m, crit[k], x, acts[k], splits[k])) return rc;
+            critic_loss(sk, k, 1);
+            TS_LAUNCH_CHECK();
+            if (int rc = mlp_backward(sk, ws, m, crit[k], x, acts[k], dheads[k], gk2[k], nullptr, 0, 0, scs[k])) return rc;
+            if (hp->critic_lr >= 0.0)
+                if (int rc = ts::adam_step(sk, crit[k], crit_m[k], crit_v[k], gk2[k], P, adam_step, hp->critic_lr, hp->beta1,
+                                           hp->beta2, hp->adam_eps, 0.0, norm_part + 512 * k))
+                    return rc;
+        }
+        // actor with the UPDATED critics (discrete_sac.py:176-184)
+        if (int rc = mlp_forward(side, ws, m, st->critic2, x, acts[1], splits[1])) return rc;
+        if (int rc = mlp_forward(s, ws, m, st->critic1, x, acts[0], splits[0])) return rc;
+        if (int rc = mlp_forward(s, ws, m, st->actor, x, aa, splits[0])) return rc;
+        if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
-    // actor with the UPDATED critics (discrete_sac.py:176-184)
-    if (int rc = mlp_forward(side, ws, m, st->critic2, x, acts[1], splits[1])) return rc;
-    if (int rc = mlp_forward(s, ws, m, st->critic1, x, acts[0], splits[0])) return rc;
-    if (int rc = mlp_forward(s, ws, m, st->actor, x, aa, splits[0])) return rc;
-    if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     hipLaunchKernelGGL(dsac_actor_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, acts[0].out,
                        acts[1].out, log_alpha, (float)hp->alpha, B, d.act, d.hw, dheads[2], neg_ent, fval);
     hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, fval, B, stats_out5);
@@ -1501,7 +1549,7 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
     al2.alpha_loss = stats_out5 + 4; al2.alpha_out = stats_out5 + 3; al2.fixed_alpha = (float)hp->alpha;
     al2.td1 = tds[0]; al2.td2 = tds[1]; al2.weight_out = weight_out;
     hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, al2);
-    if (hp->tau > 0.0)
+    if (hp->tau > 0.0 && !polyak_with_adam)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(P, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, P, (float)hp->tau, (float)(1.0 - hp->tau));
     TS_LAUNCH_CHECK();
