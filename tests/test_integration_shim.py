@@ -13,6 +13,12 @@ from oracle import ref_shim
 pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="reference not mounted")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _shim():            # every test here imports the reference: no test may depend on another one having installed the shim
+    if ref_shim.reference_available():
+        ref_shim.install()
+
+
 @pytest.fixture(scope="module")
 def algo():
     ref_shim.install()

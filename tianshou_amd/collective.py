@@ -87,7 +87,31 @@ class NativeAllReduce:
             if strict:
                 _lib.check(rc if rc != 0 else _lib.TS_ERR_HIP)
             return
+        if not self._probe_small(lib, small, on):     # mapped, but a trial call did not deliver the sum: not a path to trust
+            lib.ts_allreduce_small_destroy(small)
+            if strict:
+                raise RuntimeError("NativeAllReduce: the one-shot path failed its trial all-reduce")
+            return
         self._small = small
+
+    def _probe_small(self, lib, small, on) -> bool:
+        """One trial call through the freshly connected one-shot path (rank r contributes r + 1 in every slot, so the sum is
+        world (world + 1) / 2 exactly); a peer that never arrives shows up in the status word.  All ranks take the same
+        decision."""
+        n = int(min(lib.ts_allreduce_small_capacity(small), 256))
+        ok = 1
+        try:
+            buf = torch.full((n,), float(self.rank + 1), dtype=torch.float32, device=self.device)
+            stream = _lib.current_stream(self.device)
+            _lib.check(lib.ts_allreduce_small(small, _lib.ptr(buf), _lib.i64(n), stream))
+            _lib.check(lib.ts_allreduce_small_status(small, stream))
+            ok = int(bool((buf == self.world * (self.world + 1) / 2).all().item()))
+        except (_lib.EngineError, RuntimeError, ValueError):
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device=on)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item()) == 1
 
     @property
     def small_capacity(self) -> int:

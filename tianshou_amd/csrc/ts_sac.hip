@@ -203,8 +203,8 @@ size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by s
 // Second stream for the twin critics.  With the one-launch chains of ts_mlp.hip every kernel of a C5-shape critic fills
 // the chip and the twin chains gain nothing side by side: measured on one stream SAC 1,820 vs 1,778 and TD3 2,382 vs
 // 2,302 updates/s (DDPG equal), without the event record / wait pairs.  SAC / TD3 / DDPG therefore stay on the caller's
-// stream when their networks take the fused path; REDQ (ten critics: +17 %) and DiscreteSAC (short chains: +12 %) keep
-// both streams.
+// stream when their networks take the fused path; REDQ (ten critics: +17 %) keeps both streams; DiscreteSAC left them
+// for the multi-network launches (dsac_one_stream below).
 int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t* out) {
     static const bool force = getenv("TS_TWIN_STREAMS") != nullptr;       // experiments
     if (!force && ts::mlp3_supported(critic.l[0].IC, critic.l[0].OC, critic.l[2].OC)) { *out = s; return TS_OK; }
