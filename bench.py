@@ -492,12 +492,13 @@ def main():
     if world > 1 and learner.dp is not None and getattr(learner.dp, "_allreduce", None) is not None:
         learner.dp._allreduce.check()           # a one-shot exchange whose peer never arrived would have left stale sums
 
-    # per-kernel durations with HIP events on the launch stream, one more update() (N = 1 path)
+    # per-kernel durations with HIP events on the launch stream, one more (rank-local) update()
     roof, extra = None, {}
     if rank == 0:
         b = learner.preprocess(local_only=True)
         torch.cuda.synchronize()
-        if world == 1:
+        # every world size: rank 0 times the kernels of one local update() on its own shard (no collective inside)
+        if learner.eng is not None:
             learner.ws.profile_begin()
             perms = [learner.next_perm() for _ in range(REPEAT)]
             torch.cuda.synchronize()

@@ -156,3 +156,4 @@ def test_bench_two_ranks_dry_run_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["parallelism"] == "dp2" and "one-shot" in d["config"]["exchange"]
+    assert d["roofline"]["kernel"] == "ppo_step2_kernel" and 0.0 < d["roofline"]["frac"] < 1.0
