@@ -319,6 +319,14 @@ class SAC(Algorithm):
         return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
 
 
+class DiscreteSACTrainingStats(SACTrainingStats):
+    """modelfree/discrete_sac.py:23-25."""
+
+
+class DiscreteSAC(SAC):
+    """modelfree/discrete_sac.py:81-133 over ddpg.py ActorDualCriticsOffPolicyAlgorithm: the attributes of SAC."""
+
+
 class ContinuousActorDeterministic(nn.Module):
     """utils/net/continuous.py:26-85: `preprocess` + `last` (MLP with one Linear), `max_action`."""
 
@@ -421,12 +429,12 @@ class DiscreteActor(nn.Module):
 
 
 class DiscreteCritic(nn.Module):
-    """utils/net/discrete.py:104-163: `preprocess`, `last`."""
+    """utils/net/discrete.py:104-163: `preprocess`, `last` (`last_size` outputs: 1 for V(s), n_act for DiscreteSAC's Q(s, .))."""
 
-    def __init__(self, preprocess_net):
+    def __init__(self, preprocess_net, last_size=1):
         super().__init__()
         self.preprocess = preprocess_net
-        self.last = _MLP([preprocess_net.output_dim, 1], None)
+        self.last = _MLP([preprocess_net.output_dim, last_size], None)
 
 
 class QRDQNet(DQNet):
@@ -445,6 +453,34 @@ class QRDQN(DQN):
         super().__init__(policy=policy, lr=lr, gamma=gamma, n_step_return_horizon=n_step_return_horizon,
                          target_update_freq=target_update_freq, max_grad_norm=max_grad_norm)
         self.num_quantiles = num_quantiles
+
+
+class C51Net(DQNet):
+    """env/atari/atari_network.py:125-151: DQNet with n_act * num_atoms outputs (same state_dict keys; the softmax of its
+    forward is the engine's business)."""
+
+    def __init__(self, c, h, w, n_act, num_atoms):
+        super().__init__(c, h, w, n_act * num_atoms)
+        self.action_num, self.num_atoms = n_act, num_atoms
+
+
+class C51Policy(DiscreteQLearningPolicy):
+    """modelfree/c51.py:16-67: `num_atoms`, `v_min`, `v_max` and the `support` parameter (requires_grad=False)."""
+
+    def __init__(self, model, num_atoms=51, v_min=-10.0, v_max=10.0):
+        super().__init__(model)
+        self.num_atoms, self.v_min, self.v_max = num_atoms, v_min, v_max
+        self.support = nn.Parameter(torch.linspace(v_min, v_max, num_atoms), requires_grad=False)
+
+
+class C51(DQN):
+    """modelfree/c51.py:70-118: the attributes of QLearningOffPolicyAlgorithm plus `delta_z`; the optimizer is built over
+    the policy, whose only trainable parameters are the model's (the support does not require grad)."""
+
+    def __init__(self, *, policy, lr=1e-4, gamma=0.99, n_step_return_horizon=1, target_update_freq=0, max_grad_norm=None):
+        super().__init__(policy=policy, lr=lr, gamma=gamma, n_step_return_horizon=n_step_return_horizon,
+                         target_update_freq=target_update_freq, max_grad_norm=max_grad_norm)
+        self.delta_z = (policy.v_max - policy.v_min) / (policy.num_atoms - 1)
 
 
 # ------------------------------------------------------------------------------------------------ replay buffer

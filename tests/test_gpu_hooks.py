@@ -311,6 +311,66 @@ def test_hip_sac_hooks_against_oracle():
     assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.rew.cpu().numpy(), buf.rew)
 
 
+def test_hip_discrete_sac_hooks_against_oracle():
+    """HipDiscreteSAC (integration.make_hip_discrete_sac over the stand-ins) on the real engine with Net[128, 128] trunks, 7
+    actions, auto-tuned alpha: incremental device mirror of a growing host buffer, n-step-1 target from the expectation under
+    the actor with the lagged critics (discrete_sac.py:147-155), critic / actor / alpha steps with the UPDATED critics in
+    the actor loss (:157-196), Polyak, write-back of five networks + four optimizers - against oracle_dsac fed with the same
+    sampled indices.  (`match_rng_stream` draws the reference's unused Categorical samples; they touch no result.)"""
+    from oracle import oracle_dsac as ODS
+    from oracle import oracle_sac as OS
+    from tianshou_amd.integration import make_hip_discrete_sac
+
+    obs_dim, n_act, E, B, H = 19, 7, 4, 64, 128
+    HipDSAC = make_hip_discrete_sac(ref=SI)
+    torch.manual_seed(17)
+    actor = SI.DiscreteActor(SI.Net(obs_dim, [H, H], nn.ReLU), n_act, softmax_output=False)
+    c1 = SI.DiscreteCritic(SI.Net(obs_dim, [H, H], nn.ReLU), last_size=n_act)
+    c2 = SI.DiscreteCritic(SI.Net(obs_dim, [H, H], nn.ReLU), last_size=n_act)
+    tgt_ent = 0.98 * float(np.log(n_act))
+    alpha = SI.AutoAlpha(tgt_ent, -0.4, 3e-4)
+    algo = HipDSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.02, gamma=0.96, alpha=alpha, device="cuda").to("cuda")
+    grab = lambda mod: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(ODS.NET_ORDER, ODS.TIANSHOU_KEYS)}   # noqa: E731
+    cfg = OS.SACConfig(gamma=0.96, tau=0.02, n_step=1, auto_alpha=True, target_entropy=tgt_ent, log_alpha0=-0.4, actor_lr=1e-3,
+                       critic_lr=1e-3, alpha_lr=3e-4)
+    st = OS.SACState.create(grab(actor), grab(c1), grab(c2), cfg)
+    buf = SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(), act_dtype=np.int64, seed=12)
+    rng = np.random.default_rng(14)
+
+    def fill(T):
+        obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+        for t in range(T):
+            term = rng.random(E) < 0.05
+            buf.add(SI.Batch(obs=obs[t], act=rng.integers(0, n_act, E), rew=rng.normal(size=E).astype(np.float32), terminated=term,
+                             truncated=(rng.random(E) < 0.03) & ~term, obs_next=obs[t + 1]))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        fill(30 if u == 0 else 7)                                            # the mirror follows the growing buffer
+        stats = algo.update(buf, B)
+        idx = seen[-1]
+        tq = ODS.target_q(st, cfg, torch.from_numpy(buf.obs_next[idx])).flatten().numpy()
+        ret = (buf.rew[idx] + 0.96 * tq.astype(np.float64) * (~buf.terminated[idx])).astype(np.float32)
+        ref = ODS.update_with_batch(st, cfg, torch.from_numpy(buf.obs[idx]), buf.act[idx], ret)
+        np.testing.assert_allclose([stats.actor_loss, stats.critic1_loss, stats.critic2_loss, stats.alpha, stats.alpha_loss],
+                                   [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"], ref["alpha"], ref["alpha_loss"]],
+                                   rtol=2e-5, atol=2e-6)
+        for mod, want in ((actor, st.actor), (c1, st.critic1), (c2, st.critic2), (algo.critic_old.module, st.critic1_old),
+                          (algo.critic2_old.module, st.critic2_old)):
+            for name, k in zip(ODS.TIANSHOU_KEYS, ODS.NET_ORDER):
+                np.testing.assert_allclose(mod.state_dict()[name].cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3,
+                                           err_msg=f"update {u}: {name}")
+        assert abs(float(alpha._log_alpha.detach()) - float(st.log_alpha)) < 0.02 * 3e-4
+    w = c2.preprocess.model.model[0].weight
+    stt = algo.critic2_optim._optim.state[w]
+    assert float(stt["step"]) == 4.0 and stt["exp_avg"].shape == w.shape and stt["exp_avg"].device == w.device
+    np.testing.assert_allclose(stt["exp_avg"].cpu().numpy(), st.opt_c2.m["l1.w"].numpy(), rtol=1e-3, atol=1e-7)
+    assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.act.cpu().numpy(), buf.act)
+
+
 # ------------------------------------------------------------------------------------ HipDQN
 def _dqn_hook_run(huber):
     from oracle import oracle_dqn as OD
@@ -513,6 +573,74 @@ def test_hip_qrdqn_hooks_against_oracle():
         ret = OQ.preprocess(st, ocfg, bstate, buf.obs, idx, A, c, obs_next_frames=buf.obs_next)
         obs = OD.stacked_frames(bstate, buf.obs, idx, c)
         loss_o, prio_o = OQ.update_with_batch(st, ocfg, obs, buf.act[idx], ret, A, weight=w_is)
+        np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5)
+        upd_idx, upd_w = buf.weight_updates[-1]
+        assert np.array_equal(upd_idx, idx)
+        np.testing.assert_allclose(upd_w, np.abs(np.asarray(prio_o)) + eps, rtol=2e-5, atol=2e-5)
+        assert algo._iter == st.iter == u + 1
+    for t, k in zip([p.detach().cpu() for p in model.parameters()], OD.PARAM_ORDER):
+        np.testing.assert_allclose(t.numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    for t, k in zip([p.detach().cpu() for p in algo.model_old.parameters()], OD.PARAM_ORDER):
+        np.testing.assert_allclose(t.numpy(), st.params_old[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+    assert float(algo.optim._optim.state[next(iter(model.parameters()))]["step"]) == 4.0
+
+
+def test_hip_c51_hooks_against_oracle():
+    """HipC51 (integration.make_hip_c51 over the stand-ins) on the real engine: single uint8 frames with stack_num = 4, a
+    prioritized buffer, n-step 2, a lagged network synced every 2 updates, 21 atoms on [-4, 4].  Per update:
+    `_preprocess_batch` (the support as `target_q`, so `returns` are the n-step shifted atoms, c51.py:120-121 through
+    dqn.py:257-275) -> `_update_with_batch` (projection of the lagged net's distribution at `batch.obs_next`, importance-weighted
+    cross-entropy, c51.py:123-160) -> `_postprocess_batch` (the per-sample cross-entropies reach `buffer.update_weight`), against
+    oracle_distq fed with the same sampled indices; the host buffer grows and wraps between updates."""
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+    from tianshou_amd import dqn as D
+    from tianshou_amd.integration import make_hip_c51
+
+    c, h, w, A, N, E, size, B = 4, 44, 36, 3, 21, 4, 40, 32
+    HipC51 = make_hip_c51(ref=SI)
+    torch.manual_seed(13)
+    model = SI.C51Net(c, h, w, A, N)
+    with torch.no_grad():
+        model.net[0][0].weight.mul_(1.0 / 255.0)     # uint8 frames (0..255) times default-init weights: keep logits O(1)
+    algo = HipC51(policy=SI.C51Policy(model, num_atoms=N, v_min=-4.0, v_max=4.0), lr=1e-4, gamma=0.97,
+                  n_step_return_horizon=2, target_update_freq=2, device="cuda").to("cuda")
+    sd = model.state_dict()
+    p0 = {k: sd[n].detach().cpu().clone() for k, n in zip(OD.PARAM_ORDER, D.TIANSHOU_KEYS)}
+    ocfg = OQ.DistQConfig(kind=OQ.C51, n_atoms=N, gamma=0.97, n_step=2, target_update_freq=2, lr=1e-4, v_min=-4.0, v_max=4.0)
+    st = OD.DQNState.create(p0, ocfg.dqn())
+    buf = SI.PrioritizedVectorReplayBuffer(E * size, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                           seed=5, stack_num=c, alpha=0.6, beta=0.4)
+    rng = np.random.default_rng(18)
+
+    def fill(n):
+        for _ in range(n):
+            term = rng.random(E) < 0.08
+            buf.add(SI.Batch(obs=rng.integers(0, 256, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+
+    def sample(bs):
+        batch, idx = orig_sample(bs)
+        seen.append((idx.copy(), np.asarray(batch.weight).copy()))
+        return batch, idx
+
+    buf.sample = sample
+    eps = np.finfo(np.float32).eps.item()
+    for u in range(4):
+        fill(25 if u == 0 else 9)
+        stat = algo.update(buf, B)
+        idx, w_is = seen[-1]
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+        ret = OQ.preprocess(st, ocfg, bstate, buf.obs, idx, A, c, obs_next_frames=buf.obs_next)
+        obs = OD.stacked_frames(bstate, buf.obs, idx, c)
+        obs_next = OD.stacked_frames(bstate, buf.obs_next, idx, c)                # batch.obs_next (buffer_base.py:624-626)
+        loss_o, prio_o = OQ.update_with_batch(st, ocfg, obs, buf.act[idx], ret, A, weight=w_is, obs_next=obs_next)
         np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5)
         upd_idx, upd_w = buf.weight_updates[-1]
         assert np.array_equal(upd_idx, idx)

@@ -285,6 +285,89 @@ def test_qrdqn_standin_has_the_reference_surface():
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
 
 
+def test_discrete_sac_standin_has_the_reference_surface():
+    """DiscreteSAC over Net-based DiscreteActor / DiscreteCritic(last_size = n_act) (test/discrete/test_discrete_sac.py:88-97)
+    against the real classes: state_dict keys and shapes of the five networks, hyper-parameter attributes, optimizers, the
+    alpha object; the hook bodies are the same code objects over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSAC, DiscreteSACPolicy, DiscreteSACTrainingStats
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+
+    actor = DiscreteActor(preprocess_net=Net(state_shape=(19,), hidden_sizes=[128, 128]), action_shape=7, softmax_output=False)
+    mk = lambda: DiscreteCritic(preprocess_net=Net(state_shape=(19,), hidden_sizes=[128, 128]), last_size=7)  # noqa: E731
+    real = DiscreteSAC(policy=DiscreteSACPolicy(actor=actor, action_space=gym.spaces.Discrete(7)),
+                       policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(), critic_optim=AdamOptimizerFactory(lr=1e-3),
+                       critic2=mk(), critic2_optim=AdamOptimizerFactory(lr=1e-3), tau=0.02, gamma=0.96,
+                       alpha=AutoAlpha(1.9, -0.4, AdamOptimizerFactory(lr=3e-4)))
+    f_actor = SI.DiscreteActor(SI.Net(19, [128, 128], nn.ReLU), 7, softmax_output=False)
+    fake = SI.DiscreteSAC(policy=SI.Policy(f_actor), critic=SI.DiscreteCritic(SI.Net(19, [128, 128], nn.ReLU), last_size=7),
+                          critic2=SI.DiscreteCritic(SI.Net(19, [128, 128], nn.ReLU), last_size=7), lr=1e-3, tau=0.02, gamma=0.96,
+                          alpha=SI.AutoAlpha(1.9, -0.4, 3e-4))
+    pairs = ((real.policy.actor, fake.policy.actor), (real.critic, fake.critic), (real.critic2, fake.critic2),
+             (real.critic_old.module, fake.critic_old.module), (real.critic2_old.module, fake.critic2_old.module))
+    for a, b in pairs:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    assert real.policy.actor.softmax_output is fake.policy.actor.softmax_output is False
+    for name in ("tau", "gamma", "n_step_return_horizon"):
+        assert getattr(real, name) == getattr(fake, name), name
+    for name in ("policy_optim", "critic_optim", "critic2_optim"):
+        r, f = getattr(real, name), getattr(fake, name)
+        assert type(r._optim) is type(f._optim) is torch.optim.Adam and r._max_grad_norm == f._max_grad_norm
+        assert [p.numel() for p in r._optim.param_groups[0]["params"]] == [p.numel() for p in f._optim.param_groups[0]["params"]]
+    assert float(real.alpha._log_alpha) == float(fake.alpha._log_alpha) and real.alpha._target_entropy == fake.alpha._target_entropy
+    kw = dict(actor_loss=1.0, critic1_loss=2.0, critic2_loss=3.0, alpha=0.5, alpha_loss=None)
+    a, b = DiscreteSACTrainingStats(**kw), SI.DiscreteSACTrainingStats(**kw)
+    assert all(getattr(a, k) == getattr(b, k) for k in kw)
+    from tianshou_amd.integration import make_hip_discrete_sac
+
+    A, B = make_hip_discrete_sac(), make_hip_discrete_sac(ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_hip_draw", "_hip_parts"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_c51_standin_has_the_reference_surface():
+    """C51 / C51Policy / C51Net stand-ins against the real classes: state_dict keys and shapes (the policy's `support`
+    included), the attributes HipC51 reads (`num_atoms`, `v_min`, `v_max`), the optimizer's parameter list, the lagged wrapper;
+    and the hook bodies are the same code objects over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.c51 import C51, C51Policy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import C51Net
+
+    real = C51(policy=C51Policy(model=C51Net(c=4, h=44, w=36, action_shape=[3], num_atoms=21),
+                                action_space=gym.spaces.Discrete(3), num_atoms=21, v_min=-4.0, v_max=4.0),
+               optim=AdamOptimizerFactory(lr=1e-4), gamma=0.97, n_step_return_horizon=2, target_update_freq=2)
+    fake = SI.C51(policy=SI.C51Policy(SI.C51Net(4, 44, 36, 3, 21), num_atoms=21, v_min=-4.0, v_max=4.0), lr=1e-4, gamma=0.97,
+                  n_step_return_horizon=2, target_update_freq=2)
+    for a, b in ((real.policy, fake.policy), (real.policy.model, fake.policy.model), (real.model_old.module, fake.model_old.module)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    assert torch.equal(real.policy.support, fake.policy.support) and not fake.policy.support.requires_grad
+    for name in ("gamma", "n_step", "target_update_freq", "delta_z", "_iter"):
+        assert getattr(real, name) == getattr(fake, name), name
+    for name in ("num_atoms", "v_min", "v_max"):
+        assert getattr(real.policy, name) == getattr(fake.policy, name), name
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam
+    shapes = lambda o: [tuple(p.shape) for g in o._optim.param_groups for p in g["params"]]   # noqa: E731
+    assert shapes(real.optim) == shapes(fake.optim)
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm
+    from tianshou_amd.integration import make_hip_c51
+
+    A, B = make_hip_c51(), make_hip_c51(ref=SI)
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_layout", "_n_atoms"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
 def test_td3_standin_has_the_reference_surface():
     ref_shim.install()
     import gymnasium as gym

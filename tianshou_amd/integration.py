@@ -1363,17 +1363,19 @@ def make_hip_redq():
 # ---------------------------------------------------------------------------------------------------
 # DiscreteSAC (discrete_sac.py) on the MLP nets of test/discrete/test_discrete_sac.py
 # ---------------------------------------------------------------------------------------------------
-def make_hip_discrete_sac():
+def make_hip_discrete_sac(ref=None):
     """Returns HipDiscreteSAC(DiscreteSAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301,
     discrete_sac.py:147-196) on the engine.  Supported nets: Net(obs, [h, h]) ReLU under DiscreteActor(softmax_output=
     False) and DiscreteCritic(last_size=n_act) (test/discrete/test_discrete_sac.py:88-97), h a multiple of 32; the
     buffer must store obs_next.  `match_rng_stream`: the reference's two policy calls per update draw
     `Categorical.sample()` values that are never used; with the flag set (default) the same draws are made from the
-    engine's logits so that torch's global generator advances exactly as in the reference."""
+    engine's logits so that torch's global generator advances exactly as in the reference.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     from torch.distributions import Categorical
 
-    from tianshou.algorithm.modelfree.discrete_sac import DiscreteSAC, DiscreteSACTrainingStats
-    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    DiscreteSAC = _ref(ref, "tianshou.algorithm.modelfree.discrete_sac", "DiscreteSAC")
+    DiscreteSACTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.discrete_sac", "DiscreteSACTrainingStats")
+    AutoAlpha = _ref(ref, "tianshou.algorithm.modelfree.sac", "AutoAlpha")
 
     from . import dsac as DS
     from .sac import SACConfig
