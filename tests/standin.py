@@ -361,7 +361,21 @@ class TD3(Algorithm):
 
 
 class DDPG(Algorithm):
-    """modelfree/ddpg.py:343-395 (only what the factory needs to build the class)."""
+    """modelfree/ddpg.py:343-395 over :213-264: attribute names as the reference stores them."""
+
+    def __init__(self, *, policy, critic, lr=1e-3, critic_lr=None, tau=0.005, gamma=0.99, n_step_return_horizon=1):
+        import copy
+
+        super().__init__(policy)
+        self.policy_optim = self._create_optimizer(policy, lr)
+        self.critic = critic
+        self.critic_old = EvalModeModuleWrapper(copy.deepcopy(critic))
+        self.critic_optim = self._create_optimizer(critic, critic_lr or lr)
+        self.tau, self.gamma, self.n_step_return_horizon = tau, gamma, n_step_return_horizon
+        self.actor_old = EvalModeModuleWrapper(copy.deepcopy(policy.actor))
+
+    def update(self, buffer, sample_size):
+        return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
 
 
 class DQNet(nn.Module):

@@ -21,10 +21,10 @@ from tests import standin as SI
 pytestmark = pytest.mark.gpu
 
 
-def _make_ppo(obs_dim, act_dim, seed, device, hidden=64, **kw):
+def _make_ppo(obs_dim, act_dim, seed, device, hidden=64, algo="ppo", **kw):
     from tianshou_amd.integration import make_hip_ppo
 
-    HipPPO = make_hip_ppo("ppo", ref=SI)
+    HipPPO = make_hip_ppo(algo, ref=SI)
     torch.manual_seed(seed)
     actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [hidden, hidden], nn.Tanh), act_dim, unbounded=True)
     critic = SI.ContinuousCritic(SI.Net(obs_dim, [hidden, hidden], nn.Tanh))
@@ -124,6 +124,38 @@ def test_hip_ppo_hooks_with_scheduler_against_oracle(module_device):
     np.testing.assert_allclose(v_flat, v_ref, rtol=1e-3, atol=1e-10)
     assert all(float(state[p]["step"]) == st.adam_step for p in params)
     assert all(state[p]["exp_avg"].device == p.device and state[p]["exp_avg"].shape == p.shape for p in params)
+
+
+def test_hip_a2c_hooks_against_oracle():
+    """HipA2C (make_hip_ppo("a2c") over the stand-ins) on the real engine: the same preprocessing as PPO without logp_old
+    (a2c.py:239-247), loss -(logp adv).mean() + vf_coef mse - ent_coef entropy per minibatch (:262-273), joint clipping of the
+    actor-critic gradient, three updates on a refilled buffer."""
+    obs_dim, act_dim, E, T, batch_size, repeat = 11, 3, 6, 40, 48, 2
+    kw = dict(vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=False, gae_lambda=0.9, gamma=0.98, lr=7e-4)
+    algo = _make_ppo(obs_dim, act_dim, 8, "cuda", algo="a2c", **kw)
+    assert type(algo).__name__ == "HipA2C" and not hasattr(algo, "eps_clip")
+    st = OP.PPOState(params=_oracle_params(algo))
+    ocfg = OP.PPOConfig(algo="a2c", max_batchsize=4096, **kw)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    rng = np.random.default_rng(6)
+    algo.policy.is_within_training_step = True
+    for u in range(3):
+        buf.reset()
+        _fill(buf, T - 5 * u, obs_dim, act_dim, rng)
+        n = len(buf)
+        np.random.seed(200 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        losses_o = _oracle_update(st, ocfg, buf, batch_size, repeat, perms)
+        np.random.seed(200 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert stats.gradient_steps == losses_o.shape[0]
+        for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(losses_o[:, col])
+            np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=1e-5, atol=2e-6)
+        from tianshou_amd.ppo import flat_from_modules
+
+        flat = flat_from_modules(algo.policy.actor, algo.critic, device="cpu").numpy()
+        np.testing.assert_allclose(flat, OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=5e-6)
 
 
 def test_hip_ppo_hooks_on_humanoid_shape_use_the_gemm_path():
@@ -703,3 +735,49 @@ def test_hip_td3_hooks_against_oracle():
     st_a = algo.policy_optim._optim.state[next(iter(actor.parameters()))]
     st_c = algo.critic_optim._optim.state[next(iter(c1.parameters()))]
     assert float(st_a["step"]) == 2.0 and float(st_c["step"]) == 4.0               # the actor stepped at updates 0 and 2
+
+
+def test_hip_ddpg_hooks_against_oracle():
+    """HipDDPG (integration.make_hip_ddpg over the stand-ins) on the real engine with Net[64, 64] trunks, n-step 3: the target
+    is the single lagged critic at the lagged actor's action (ddpg.py:397-399), one critic step and one actor step per update
+    (:401-411), Polyak of both networks, write-back of four networks + two optimizers -- against oracle_sac's DDPG
+    restatement (TD3Config(twin=False)) fed with the same sampled indices."""
+    from oracle import oracle_sac as OS
+    from tianshou_amd.integration import make_hip_ddpg
+
+    obs_dim, act_dim, E, B, H, n_step, gamma = 11, 3, 4, 64, 64, 3, 0.95
+    HipDDPG = make_hip_ddpg(ref=SI)
+    torch.manual_seed(23)
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, [H, H], nn.ReLU), act_dim, max_action=1.5)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [H, H], nn.ReLU))
+    algo = HipDDPG(policy=SI.Policy(actor), critic=c1, lr=3e-4, critic_lr=1e-3, tau=0.02, gamma=gamma,
+                   n_step_return_horizon=n_step, device="cuda").to("cuda")
+    grab = lambda mod, keys: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(keys, mod.state_dict())}   # noqa: E731
+    cfg = OS.TD3Config(gamma=gamma, tau=0.02, n_step=n_step, twin=False, max_action=1.5, actor_lr=3e-4, critic_lr=1e-3)
+    st = OS.TD3State.create(grab(actor, OS.DET_ACTOR_ORDER), grab(c1, OS.CRITIC_ORDER), None, cfg)
+    buf = SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=16)
+    rng = np.random.default_rng(22)
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, rng)
+        stats = algo.update(buf, B)
+        idx = seen[-1]
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+        tq_fn = lambda after: OS.td3_target_q(st, cfg, torch.from_numpy(buf.obs_next[after])).numpy()   # noqa: E731
+        ret, _ = O.compute_nstep_return(bstate, idx, tq_fn, gamma, n_step)
+        ref = OS.td3_update_with_batch(st, cfg, torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx]),
+                                       ret.astype(np.float32))
+        np.testing.assert_allclose([stats.actor_loss, stats.critic_loss], [ref["actor_loss"], ref["critic1_loss"]],
+                                   rtol=2e-5, atol=2e-6)
+    for mod, ref_p, order in ((actor, st.actor, OS.DET_ACTOR_ORDER), (c1, st.critic1, OS.CRITIC_ORDER),
+                              (algo.actor_old.module, st.actor_old, OS.DET_ACTOR_ORDER),
+                              (algo.critic_old.module, st.critic1_old, OS.CRITIC_ORDER)):
+        for (name, t), k in zip(mod.state_dict().items(), order):
+            np.testing.assert_allclose(t.detach().cpu().numpy(), ref_p[k].numpy(), rtol=1e-5, atol=0.05 * 1e-3, err_msg=name)
+    st_a = algo.policy_optim._optim.state[next(iter(actor.parameters()))]
+    st_c = algo.critic_optim._optim.state[next(iter(c1.parameters()))]
+    assert float(st_a["step"]) == 4.0 and float(st_c["step"]) == 4.0
