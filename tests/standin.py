@@ -155,12 +155,18 @@ class ContinuousCritic(nn.Module):
         self.last = _MLP([preprocess_net.output_dim, 1], None)
 
 
-class Policy(nn.Module):
-    """algorithm_base.py Policy: `actor`, `is_within_training_step`."""
+def dist_fn_categorical_from_logits(logits):
+    """utils/net/discrete.py: the default `dist_fn` of a discrete ProbabilisticActorPolicy (reinforce.py:200)."""
+    return torch.distributions.Categorical(logits=logits)
 
-    def __init__(self, actor):
+
+class Policy(nn.Module):
+    """algorithm_base.py Policy: `actor`, `is_within_training_step`; `dist_fn` of ProbabilisticActorPolicy (reinforce.py:94-165)."""
+
+    def __init__(self, actor, dist_fn=None):
         super().__init__()
         self.actor = actor
+        self.dist_fn = dist_fn
         self.is_within_training_step = False
 
 
@@ -271,6 +277,69 @@ class A2C(PPO):
         super().__init__(**kw)
         for name in ("eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_adv"):
             delattr(self, name)
+
+
+@dataclass
+class NPGTrainingStats:
+    """modelfree/npg.py:20-24."""
+    actor_loss: SequenceSummaryStats
+    vf_loss: SequenceSummaryStats
+    kl: SequenceSummaryStats
+    train_time: float = 0.0
+
+
+@dataclass
+class TRPOTrainingStats(NPGTrainingStats):
+    """modelfree/trpo.py:18-20."""
+    step_size: SequenceSummaryStats | None = None
+
+
+class NPG(Algorithm):
+    """modelfree/npg.py:27-118 over a2c.py:79-113 with optim_include_actor=False: the optimizer holds the critic only."""
+
+    def __init__(self, *, policy, critic, lr=1e-3, optim_critic_iters=5, trust_region_size=0.5, advantage_normalization=True,
+                 gae_lambda=0.95, max_batchsize=256, gamma=0.99, return_scaling=False):
+        super().__init__(policy)
+        self.critic = critic
+        self.gae_lambda, self.max_batchsize, self.gamma, self.return_scaling = gae_lambda, max_batchsize, gamma, return_scaling
+        self.optim = self._create_optimizer(critic, lr)
+        self.ret_rms = RunningMeanStd()
+        self._eps = 1e-8
+        self.advantage_normalization, self.optim_critic_iters = advantage_normalization, optim_critic_iters
+        self.trust_region_size = trust_region_size
+        self._damping = 0.1
+
+    def update(self, buffer, batch_size, repeat):
+        return self._update(0, buffer, lambda batch: self._update_with_batch(batch, batch_size, repeat))
+
+
+class TRPO(NPG):
+    """modelfree/trpo.py:23-121: NPG's attributes without `trust_region_size`'s role, plus the line-search parameters."""
+
+    def __init__(self, *, max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10, **kw):
+        super().__init__(**kw)
+        self.max_backtracks, self.max_kl, self.backtrack_coeff = max_backtracks, max_kl, backtrack_coeff
+
+
+class DiscountedReturnComputation:
+    """modelfree/reinforce.py:249-271: `gamma`, `return_standardization`, `ret_rms`, `eps`."""
+
+    def __init__(self, gamma=0.99, return_standardization=False):
+        self.gamma, self.return_standardization = gamma, return_standardization
+        self.ret_rms = RunningMeanStd()
+        self.eps = 1e-8
+
+
+class Reinforce(Algorithm):
+    """modelfree/reinforce.py:312-347: `discounted_return_computation`, `optim` over the policy."""
+
+    def __init__(self, *, policy, lr=1e-3, gamma=0.99, return_standardization=False, max_grad_norm=None):
+        super().__init__(policy)
+        self.discounted_return_computation = DiscountedReturnComputation(gamma, return_standardization)
+        self.optim = self._create_optimizer(policy, lr, max_grad_norm)
+
+    def update(self, buffer, batch_size, repeat):
+        return self._update(0, buffer, lambda batch: self._update_with_batch(batch, batch_size, repeat))
 
 
 class FixedAlpha:

@@ -158,6 +158,127 @@ def test_hip_a2c_hooks_against_oracle():
         np.testing.assert_allclose(flat, OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=5e-6)
 
 
+def _mujoco_nets(obs_dim, act_dim, seed):
+    torch.manual_seed(seed)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [64, 64], nn.Tanh), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, [64, 64], nn.Tanh))
+    with torch.no_grad():
+        actor.sigma_param.fill_(-0.5)
+    return actor, critic
+
+
+def _flat_oracle_params(actor, critic, obs_dim, act_dim):
+    from tianshou_amd.ppo import flat_from_modules
+
+    return OP.unflatten_params(flat_from_modules(actor, critic, device="cpu").clone(), obs_dim, act_dim, 64)
+
+
+def _oracle_batch(buf):
+    idx = buf.sample_indices(0)
+    bs = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths,
+                       np.asarray([b._insertion_idx for b in buf.buffers]), buf.rew, buf.terminated, buf.truncated)
+    return idx, bs.unfinished_index()
+
+
+@pytest.mark.parametrize("which", ["npg", "trpo"])
+def test_hip_natural_gradient_hooks_against_oracle(which):
+    """HipNPG / HipTRPO (integration.make_hip_npg / make_hip_trpo over the stand-ins) on the real engine: preprocessing with
+    normalised advantages and log pi_old (npg.py:123-137), per minibatch the conjugate-gradient natural step (TRPO: with the
+    line search, trpo.py:123-214) and `optim_critic_iters` critic steps, write-back of actor + critic + the critic's Adam
+    state; two updates against oracle_npg (tolerances of tests/test_gpu_npg.py: both sides are float32 CG solves)."""
+    from oracle import oracle_npg as ON
+    from tianshou_amd.integration import make_hip_npg, make_hip_trpo
+
+    obs_dim, act_dim, E, T, batch_size, repeat = 17, 6, 6, 60, 128, 1
+    Hip = (make_hip_npg if which == "npg" else make_hip_trpo)(ref=SI)
+    actor, critic = _mujoco_nets(obs_dim, act_dim, 41)
+    kw = dict(lr=1e-3, optim_critic_iters=3, advantage_normalization=True, gae_lambda=0.95, gamma=0.99, return_scaling=True)
+    if which == "npg":
+        kw["trust_region_size"] = 0.1
+    else:
+        kw.update(max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10)
+    algo = Hip(policy=SI.Policy(actor), critic=critic, device="cuda", **kw).to("cuda")
+    assert type(algo).__name__ == ("HipNPG" if which == "npg" else "HipTRPO")
+    st = OP.PPOState(params=_flat_oracle_params(actor, critic, obs_dim, act_dim))
+    ocfg = ON.NPGConfig(algo=which, gamma=0.99, gae_lambda=0.95, optim_critic_iters=3, trust_region_size=0.1,
+                        advantage_normalization=True, return_scaling=True, max_batchsize=4096, lr=1e-3)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    rng = np.random.default_rng(42)
+    algo.policy.is_within_training_step = True
+    for u in range(2):
+        buf.reset()
+        _fill(buf, T - 9 * u, obs_dim, act_dim, rng)
+        n = len(buf)
+        idx, unf = _oracle_batch(buf)
+        p_before = OP.flatten_params(st.params).numpy().copy()
+        np.random.seed(90 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        obs, act = torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx])
+        pre = ON.preprocess(st, ocfg, obs, torch.from_numpy(buf.obs_next[idx]), act, buf.rew[idx], buf.terminated[idx],
+                            buf.truncated[idx], idx, unf)
+        ref = ON.update(st, ocfg, obs, act, pre, batch_size, repeat, perms)
+        np.random.seed(90 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        cols = [stats.actor_loss, stats.vf_loss, stats.kl] + ([stats.step_size] if which == "trpo" else [])
+        for col, s in enumerate(cols):
+            r = SI.SequenceSummaryStats.from_sequence(ref[:, col])
+            np.testing.assert_allclose([s.mean, s.max, s.min], [r.mean, r.max, r.min], rtol=2e-3, atol=2e-5)
+        from tianshou_amd.ppo import flat_from_modules
+
+        flat = flat_from_modules(actor, critic, device="cpu").numpy()
+        want = OP.flatten_params(st.params).numpy()
+        assert np.abs(flat - want).max() < 5e-3 * np.abs(want - p_before).max()
+        np.testing.assert_allclose([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count],
+                                   [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+    state = algo.optim._optim.state
+    w = critic.preprocess.model.model[0].weight
+    assert float(state[w]["step"]) == st.adam_step and state[w]["exp_avg"].shape == w.shape
+    assert all(p not in state for p in actor.parameters())                  # the optimizer holds the critic only
+
+
+def test_hip_reinforce_hooks_against_oracle():
+    """HipReinforce (integration.make_hip_reinforce over the stand-ins) on the real engine: discounted returns with the
+    running standardisation (reinforce.py:273-309), per minibatch -(log pi * G).mean() and clip + Adam on the actor
+    (:346-382); three updates against oracle_reinforce."""
+    from oracle import oracle_reinforce as OR
+    from tianshou_amd.integration import make_hip_reinforce
+
+    obs_dim, act_dim, E, T, batch_size, repeat = 11, 3, 6, 50, 64, 2
+    HipReinforce = make_hip_reinforce(ref=SI)
+    actor, critic = _mujoco_nets(obs_dim, act_dim, 43)                     # (the critic only completes the oracle's parameter set)
+    st = OP.PPOState(params=_flat_oracle_params(actor, critic, obs_dim, act_dim))
+    algo = HipReinforce(policy=SI.Policy(actor), lr=1e-3, gamma=0.97, return_standardization=True, max_grad_norm=0.7,
+                        device="cuda").to("cuda")
+    ocfg = OR.ReinforceConfig(gamma=0.97, return_standardization=True, lr=1e-3, max_grad_norm=0.7)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    rng = np.random.default_rng(44)
+    algo.policy.is_within_training_step = True
+    for u in range(3):
+        buf.reset()
+        _fill(buf, T - 6 * u, obs_dim, act_dim, rng)
+        n = len(buf)
+        idx, unf = _oracle_batch(buf)
+        np.random.seed(110 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        ret = OR.preprocess(st, ocfg, buf.rew[idx], buf.terminated[idx], buf.truncated[idx], idx, unf)
+        ref = OR.update(st, ocfg, torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx]), ret, batch_size, repeat, perms)
+        np.random.seed(110 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        r = SI.SequenceSummaryStats.from_sequence(ref)
+        np.testing.assert_allclose([stats.loss.mean, stats.loss.max, stats.loss.min], [r.mean, r.max, r.min], rtol=2e-5, atol=2e-6)
+        drc = algo.discounted_return_computation
+        np.testing.assert_allclose([drc.ret_rms.mean, drc.ret_rms.var, drc.ret_rms.count],
+                                   [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+    from tianshou_amd.ppo import TIANSHOU_ACTOR_KEYS
+
+    sd = actor.state_dict()
+    for name, k in zip(TIANSHOU_ACTOR_KEYS, ["a_w1", "a_b1", "a_w2", "a_b2", "a_wmu", "a_bmu", "a_sigma"]):
+        np.testing.assert_allclose(sd[name].cpu().numpy().reshape(-1), st.params[k].numpy().reshape(-1), rtol=1e-5,
+                                   atol=0.05 * 1e-3, err_msg=name)
+    state = algo.optim._optim.state
+    assert float(state[actor.sigma_param]["step"]) == st.adam_step
+
+
 def test_hip_ppo_hooks_on_humanoid_shape_use_the_gemm_path():
     """Net[256, 256], obs 376, act 17 (Humanoid; outside the fused kernels' envelope): HipPPO picks WidePPOEngine and the
     whole hook path - mirror, preprocess, update, write-back, Adam flush - matches the oracle."""
@@ -545,6 +666,64 @@ def test_hip_ppo_cnn_hooks_against_oracle():
     assert trunk.net[1].weight is actor.preprocess.net[1].weight is critic.preprocess.net[1].weight      # still one trunk
     sd = algo.state_dict()                                     # Adam moments arrive lazily, one entry per tensor (12)
     assert len(sd["_optimizers"][0]["state"]) == 12
+    state = algo.optim._optim.state
+    assert all(float(state[p]["step"]) == st.adam_step for p in algo._hip_params())
+
+
+def test_hip_ppo_discrete_hooks_against_oracle():
+    """HipPPODiscrete (integration.make_hip_ppo_discrete over the stand-ins) on the real engine, BASELINE.json configs[0]'s
+    layout (test/discrete/test_ppo_discrete.py:88-127): Net(4, [64, 64]) shared by DiscreteActor (softmax_output=True, so
+    dist_fn = Categorical receives probabilities) and DiscreteCritic, minibatch 64, PPO with advantage normalisation, dual
+    clip, value clip and return scaling; three update() calls on a reset-and-refilled buffer against oracle_ppo_discrete."""
+    from torch.distributions import Categorical
+
+    from oracle import oracle_ppo_cnn as OC
+    from oracle import oracle_ppo_discrete as OPD
+    from tianshou_amd.integration import make_hip_ppo_discrete
+
+    obs_dim, hidden, A, E, T, batch_size, repeat = 4, 64, 2, 8, 40, 64, 2
+    HipPPODiscrete = make_hip_ppo_discrete("ppo", ref=SI)
+    torch.manual_seed(31)
+    trunk = SI.Net(obs_dim, [hidden, hidden], nn.ReLU)
+    actor, critic = SI.DiscreteActor(trunk, A, softmax_output=True), SI.DiscreteCritic(trunk)
+    kw = dict(eps_clip=0.2, dual_clip=3.0, value_clip=True, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=True,
+              advantage_normalization=True, gae_lambda=0.95, gamma=0.99, lr=3e-4)
+    algo = HipPPODiscrete(policy=SI.Policy(actor, dist_fn=Categorical), critic=critic, device="cuda", **kw).to("cuda")
+    hip_params = [p.detach().cpu().clone() for p in algo._hip_params()]
+    st = OP.PPOState(params={k: t for k, t in zip(OPD.PARAM_ORDER, hip_params)})
+    ocfg = OP.PPOConfig(max_batchsize=4096, **kw)
+    net = OPD.MlpNet(softmax_output=True)
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(), act_dtype=np.int64)
+    rng = np.random.default_rng(32)
+    algo.policy.is_within_training_step = True
+    for u in range(3):
+        buf.reset()
+        obs_seq = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+        for t in range(T - 4 * u):
+            term = rng.random(E) < 0.05
+            buf.add(SI.Batch(obs=obs_seq[t], act=rng.integers(0, A, E), rew=rng.normal(size=E).astype(np.float32), terminated=term,
+                             truncated=(rng.random(E) < 0.03) & ~term, obs_next=obs_seq[t + 1]))
+        n = len(buf)
+        idx = buf.sample_indices(0)
+        bs = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths,
+                           np.asarray([b._insertion_idx for b in buf.buffers]), buf.rew, buf.terminated, buf.truncated)
+        obs, obs_next = torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.obs_next[idx])
+        np.random.seed(70 + u)
+        perms = [np.random.permutation(n) for _ in range(repeat)]
+        pre = OC.preprocess(st, ocfg, obs, obs_next, buf.act[idx], buf.rew[idx], buf.terminated[idx], buf.truncated[idx], idx,
+                            bs.unfinished_index(), net=net)
+        losses_o = OC.update(st, ocfg, obs, buf.act[idx], pre, batch_size, repeat, perms, net=net)
+        np.random.seed(70 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert stats.gradient_steps == losses_o.shape[0]
+        for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(losses_o[:, col])
+            np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=5e-5, atol=5e-6)
+        np.testing.assert_allclose([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count],
+                                   [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
+    for t, k in zip(algo._hip_params(), OPD.PARAM_ORDER):
+        np.testing.assert_allclose(t.detach().cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 3e-4, err_msg=k)
+    assert actor.preprocess.model.model[0].weight is critic.preprocess.model.model[0].weight             # still one trunk
     state = algo.optim._optim.state
     assert all(float(state[p]["step"]) == st.adam_step for p in algo._hip_params())
 

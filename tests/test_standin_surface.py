@@ -448,3 +448,129 @@ def test_ddpg_standin_has_the_reference_surface():
     A, B = make_hip_ddpg(), make_hip_ddpg(ref=SI)
     for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_hip_parts"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_ppo_discrete_standin_has_the_reference_surface():
+    """The CartPole-shape actor-critic (test/discrete/test_ppo_discrete.py:88-127) over the stand-ins against the real modules
+    and the real ProbabilisticActorPolicy: state_dict keys and shapes, the shared trunk, `softmax_output`, `policy.dist_fn`
+    (and the identity of the default logits dist_fn the hook compares against); the hook bodies are the same code objects."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch.distributions import Categorical
+
+    from tianshou.algorithm.modelfree.reinforce import DiscreteActorPolicy, ProbabilisticActorPolicy, dist_fn_categorical_from_logits
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.discrete import DiscreteActor, DiscreteCritic
+
+    net = Net(state_shape=(4,), hidden_sizes=[64, 64])
+    ra, rc = DiscreteActor(preprocess_net=net, action_shape=2), DiscreteCritic(preprocess_net=net)
+    trunk = SI.Net(4, [64, 64], nn.ReLU)
+    fa, fc = SI.DiscreteActor(trunk, 2), SI.DiscreteCritic(trunk)
+    for a, b in ((ra, fa), (rc, fc)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+    assert ra.softmax_output is fa.softmax_output is True and fa.preprocess is fc.preprocess
+    real = ProbabilisticActorPolicy(actor=ra, dist_fn=Categorical, action_space=gym.spaces.Discrete(2), action_scaling=False)
+    fake = SI.Policy(fa, dist_fn=Categorical)
+    assert real.dist_fn is fake.dist_fn is Categorical
+    default = DiscreteActorPolicy(actor=DiscreteActor(preprocess_net=net, action_shape=2, softmax_output=False),
+                                  action_space=gym.spaces.Discrete(2))
+    assert default.dist_fn is dist_fn_categorical_from_logits
+    lg = torch.randn(5, 2)
+    assert torch.equal(dist_fn_categorical_from_logits(lg).probs, SI.dist_fn_categorical_from_logits(lg).probs)
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.integration import make_hip_ppo_discrete
+
+    assert list(fa.state_dict().keys()) == PD.TRUNK_KEYS + PD.HEAD_KEYS
+    A, B = make_hip_ppo_discrete("ppo"), make_hip_ppo_discrete("ppo", ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_hip_params"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def _real_mujoco_nets():
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                         action_shape=(6,), unbounded=True)
+    critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+    return actor, critic
+
+
+def _fake_mujoco_nets():
+    return (SI.ContinuousActorProbabilistic(SI.Net(17, [64, 64], nn.Tanh), 6, unbounded=True),
+            SI.ContinuousCritic(SI.Net(17, [64, 64], nn.Tanh)))
+
+
+def _same_state_dicts(pairs):
+    for a, b in pairs:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert [tuple(v.shape) for v in sa.values()] == [tuple(v.shape) for v in sb.values()]
+
+
+@pytest.mark.parametrize("which", ["npg", "trpo"])
+def test_natural_gradient_standins_have_the_reference_surface(which):
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.npg import NPG
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.modelfree.trpo import TRPO
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from torch.distributions import Independent, Normal
+
+    ra, rc = _real_mujoco_nets()
+    fa, fc = _fake_mujoco_nets()
+    pol = ProbabilisticActorPolicy(actor=ra, dist_fn=lambda loc_scale: Independent(Normal(*loc_scale), 1),
+                                   action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    kw = dict(optim_critic_iters=3, advantage_normalization=True, gae_lambda=0.9, gamma=0.98, return_scaling=True)
+    if which == "npg":
+        real = NPG(policy=pol, critic=rc, optim=AdamOptimizerFactory(lr=1e-3), trust_region_size=0.1, **kw)
+        fake = SI.NPG(policy=SI.Policy(fa), critic=fc, lr=1e-3, trust_region_size=0.1, **kw)
+        names = ("trust_region_size",)
+    else:
+        real = TRPO(policy=pol, critic=rc, optim=AdamOptimizerFactory(lr=1e-3), max_kl=0.02, backtrack_coeff=0.7, max_backtracks=8, **kw)
+        fake = SI.TRPO(policy=SI.Policy(fa), critic=fc, lr=1e-3, max_kl=0.02, backtrack_coeff=0.7, max_backtracks=8, **kw)
+        names = ("max_kl", "backtrack_coeff", "max_backtracks")
+    _same_state_dicts(((real.policy.actor, fake.policy.actor), (real.critic, fake.critic)))
+    for name in names + ("optim_critic_iters", "advantage_normalization", "gae_lambda", "gamma", "return_scaling", "_damping"):
+        assert getattr(real, name) == getattr(fake, name), name
+    assert (real.ret_rms.mean, real.ret_rms.var, real.ret_rms.count) == (fake.ret_rms.mean, fake.ret_rms.var, fake.ret_rms.count)
+    shapes = lambda o: [tuple(p.shape) for g in o._optim.param_groups for p in g["params"]]   # noqa: E731
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam and shapes(real.optim) == shapes(fake.optim)
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm
+    from tianshou_amd.integration import make_hip_npg, make_hip_trpo
+
+    mk = make_hip_npg if which == "npg" else make_hip_trpo
+    A, B = mk(), mk(ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_reinforce_standin_has_the_reference_surface():
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy, Reinforce
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from torch.distributions import Independent, Normal
+
+    ra, _ = _real_mujoco_nets()
+    fa, _ = _fake_mujoco_nets()
+    pol = ProbabilisticActorPolicy(actor=ra, dist_fn=lambda loc_scale: Independent(Normal(*loc_scale), 1),
+                                   action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    real = Reinforce(policy=pol, optim=AdamOptimizerFactory(lr=1e-3), gamma=0.97, return_standardization=True)
+    fake = SI.Reinforce(policy=SI.Policy(fa), lr=1e-3, gamma=0.97, return_standardization=True)
+    _same_state_dicts(((real.policy.actor, fake.policy.actor),))
+    r, f = real.discounted_return_computation, fake.discounted_return_computation
+    assert (r.gamma, r.return_standardization, r.eps) == (f.gamma, f.return_standardization, f.eps)
+    assert (r.ret_rms.mean, r.ret_rms.var, r.ret_rms.count) == (f.ret_rms.mean, f.ret_rms.var, f.ret_rms.count)
+    shapes = lambda o: [tuple(p.shape) for g in o._optim.param_groups for p in g["params"]]   # noqa: E731
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.Adam and shapes(real.optim) == shapes(fake.optim)
+    from tianshou_amd.integration import make_hip_reinforce
+
+    A, B = make_hip_reinforce(), make_hip_reinforce(ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_dims"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name

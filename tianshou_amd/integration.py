@@ -442,17 +442,17 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
 # ---------------------------------------------------------------------------------------------------
 # NPG (npg.py) / TRPO (trpo.py) on the MuJoCo actor-critic
 # ---------------------------------------------------------------------------------------------------
-def _make_hip_natural(algo: str):
-    from tianshou.data import SequenceSummaryStats
+def _make_hip_natural(algo: str, ref=None):
+    SequenceSummaryStats = _ref(ref, "tianshou.data", "SequenceSummaryStats")
 
     from . import npg as NG
 
     if algo == "npg":
-        from tianshou.algorithm.modelfree.npg import NPG as Base
-        from tianshou.algorithm.modelfree.npg import NPGTrainingStats as Stats
+        Base = _ref(ref, "tianshou.algorithm.modelfree.npg", "NPG")
+        Stats = _ref(ref, "tianshou.algorithm.modelfree.npg", "NPGTrainingStats")
     else:
-        from tianshou.algorithm.modelfree.trpo import TRPO as Base
-        from tianshou.algorithm.modelfree.trpo import TRPOTrainingStats as Stats
+        Base = _ref(ref, "tianshou.algorithm.modelfree.trpo", "TRPO")
+        Stats = _ref(ref, "tianshou.algorithm.modelfree.trpo", "TRPOTrainingStats")
     who = "HipNPG" if algo == "npg" else "HipTRPO"
 
     class HipNatural(_HipGlue, Base):
@@ -537,22 +537,25 @@ def _make_hip_natural(algo: str):
     return HipNatural
 
 
-def make_hip_npg():
+def make_hip_npg(ref=None):
     """Returns HipNPG(NPG): `_preprocess_batch` / `_update_with_batch` (npg.py:123-193) on the engine.  Supported nets:
-    examples/mujoco/mujoco_npg.py:103-128 (Net[h, h] tanh actor and critic, unbounded Gaussian actor with sigma_param)."""
-    return _make_hip_natural("npg")
+    examples/mujoco/mujoco_npg.py:103-128 (Net[h, h] tanh actor and critic, unbounded Gaussian actor with sigma_param).
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    return _make_hip_natural("npg", ref)
 
 
-def make_hip_trpo():
+def make_hip_trpo(ref=None):
     """Returns HipTRPO(TRPO): the same hooks with TRPO's step size and line search (trpo.py:123-214)."""
-    return _make_hip_natural("trpo")
+    return _make_hip_natural("trpo", ref)
 
 
-def make_hip_reinforce():
+def make_hip_reinforce(ref=None):
     """Returns HipReinforce(Reinforce): `_preprocess_batch` / `_update_with_batch` (reinforce.py:346-382) on the engine.
-    Supported net: the actor of examples/mujoco/mujoco_reinforce.py:84-103 (Net[h, h] tanh, unbounded Gaussian, sigma_param)."""
-    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats, Reinforce
-    from tianshou.data import SequenceSummaryStats
+    Supported net: the actor of examples/mujoco/mujoco_reinforce.py:84-103 (Net[h, h] tanh, unbounded Gaussian, sigma_param).
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    LossSequenceTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "LossSequenceTrainingStats")
+    Reinforce = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "Reinforce")
+    SequenceSummaryStats = _ref(ref, "tianshou.data", "SequenceSummaryStats")
 
     from . import npg as NG
     from . import reinforce as RF
@@ -1582,18 +1585,17 @@ def make_hip_ppo_cnn(algo: str = "ppo", ref=None):
 # ---------------------------------------------------------------------------------------------------
 # PPO on the CartPole-shape networks (BASELINE.json configs[0], test/discrete/test_ppo_discrete.py:88-127)
 # ---------------------------------------------------------------------------------------------------
-def make_hip_ppo_discrete(algo: str = "ppo"):
+def make_hip_ppo_discrete(algo: str = "ppo", ref=None):
     """Returns HipPPODiscrete(PPO) for Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, Categorical policy
     (`softmax_output=True` with `dist_fn=torch.distributions.Categorical`, or `softmax_output=False` with the default
     logits dist_fn), Adam; h a multiple of 32, at most 31 actions; the buffer must store obs_next.
-    algo="a2c": HipA2CDiscrete(A2C)."""
+    algo="a2c": HipA2CDiscrete(A2C).  `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     from torch.distributions import Categorical
 
-    from tianshou.algorithm.modelfree.a2c import A2CTrainingStats
-    from tianshou.algorithm.modelfree.reinforce import dist_fn_categorical_from_logits
-
-    PPO = _on_policy_base(algo)
-    from tianshou.data import SequenceSummaryStats
+    A2CTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.a2c", "A2CTrainingStats")
+    dist_fn_categorical_from_logits = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "dist_fn_categorical_from_logits")
+    SequenceSummaryStats = _ref(ref, "tianshou.data", "SequenceSummaryStats")
+    PPO = _on_policy_base(algo, ref)
 
     from . import ppo_discrete as PD
 
