@@ -111,11 +111,11 @@ class RunningMeanStd:
 class _MLP(nn.Module):
     """utils/net/common.py MLP: `.model` is the nn.Sequential."""
 
-    def __init__(self, sizes, activation):
+    def __init__(self, sizes, activation, linear_layer=nn.Linear):
         super().__init__()
         layers = []
         for i in range(len(sizes) - 1):
-            layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+            layers.append(linear_layer(sizes[i], sizes[i + 1]))
             if activation is not None:
                 layers.append(activation())
         self.model = nn.Sequential(*layers)
@@ -124,10 +124,20 @@ class _MLP(nn.Module):
 class Net(nn.Module):
     """utils/net/common.py:246-369: `.model` is an MLP -> state_dict keys `model.model.{0,2}.{weight,bias}`."""
 
-    def __init__(self, in_dim, hidden_sizes, activation=nn.ReLU):
+    def __init__(self, in_dim, hidden_sizes, activation=nn.ReLU, linear_layer=nn.Linear):
         super().__init__()
-        self.model = _MLP([in_dim, *hidden_sizes], activation)
+        self.model = _MLP([in_dim, *hidden_sizes], activation, linear_layer)
         self.output_dim = hidden_sizes[-1]
+
+
+class EnsembleLinear(nn.Module):
+    """utils/net/common.py:518-550: `weight` [E, in, out] and `bias_weights` [E, 1, out], both U(-1/sqrt(in), 1/sqrt(in))."""
+
+    def __init__(self, ensemble_size, in_feature, out_feature):
+        super().__init__()
+        k = (1.0 / in_feature) ** 0.5
+        self.weight = nn.Parameter(torch.rand((ensemble_size, in_feature, out_feature)) * 2 * k - k)
+        self.bias_weights = nn.Parameter(torch.rand((ensemble_size, 1, out_feature)) * 2 * k - k)
 
 
 class ContinuousActorProbabilistic(nn.Module):
@@ -149,10 +159,10 @@ class ContinuousActorProbabilistic(nn.Module):
 class ContinuousCritic(nn.Module):
     """utils/net/continuous.py:88-169: preprocess + `last` head."""
 
-    def __init__(self, preprocess_net):
+    def __init__(self, preprocess_net, linear_layer=nn.Linear):
         super().__init__()
         self.preprocess = preprocess_net
-        self.last = _MLP([preprocess_net.output_dim, 1], None)
+        self.last = _MLP([preprocess_net.output_dim, 1], None, linear_layer)
 
 
 def dist_fn_categorical_from_logits(logits):
@@ -396,6 +406,35 @@ class DiscreteSAC(SAC):
     """modelfree/discrete_sac.py:81-133 over ddpg.py ActorDualCriticsOffPolicyAlgorithm: the attributes of SAC."""
 
 
+@dataclass
+class REDQTrainingStats(DDPGTrainingStats):
+    """modelfree/redq.py:26-31."""
+    alpha: float | None = None
+    alpha_loss: float | None = None
+
+
+class REDQ(Algorithm):
+    """modelfree/redq.py:131-246 over ddpg.py:213-264: one ensemble critic module, its lagged copy, the counters."""
+
+    def __init__(self, *, policy, critic, lr=1e-3, critic_lr=None, ensemble_size=10, subset_size=2, tau=0.005, gamma=0.99,
+                 alpha=0.2, n_step_return_horizon=1, actor_delay=20, target_mode="min"):
+        import copy
+
+        super().__init__(policy)
+        self.policy_optim = self._create_optimizer(policy, lr)
+        self.critic = critic
+        self.critic_old = EvalModeModuleWrapper(copy.deepcopy(critic))
+        self.critic_optim = self._create_optimizer(critic, critic_lr or lr)
+        self.tau, self.gamma, self.n_step_return_horizon = tau, gamma, n_step_return_horizon
+        self.ensemble_size, self.subset_size = ensemble_size, subset_size
+        self.alpha = FixedAlpha(alpha) if isinstance(alpha, float) else alpha
+        self.target_mode, self.critic_gradient_step, self.actor_delay = target_mode, 0, actor_delay
+        self._last_actor_loss = 0.0
+
+    def update(self, buffer, sample_size):
+        return self._update(sample_size, buffer, lambda batch: self._update_with_batch(batch))
+
+
 class ContinuousActorDeterministic(nn.Module):
     """utils/net/continuous.py:26-85: `preprocess` + `last` (MLP with one Linear), `max_action`."""
 
@@ -518,6 +557,16 @@ class DiscreteCritic(nn.Module):
         super().__init__()
         self.preprocess = preprocess_net
         self.last = _MLP([preprocess_net.output_dim, last_size], None)
+
+
+class Recurrent(nn.Module):
+    """utils/net/common.py:372-452: `nn` = LSTM(hidden, hidden, layer_num, batch_first), `fc1`, `fc2` in that order."""
+
+    def __init__(self, layer_num, obs_dim, n_act, hidden):
+        super().__init__()
+        self.nn = nn.LSTM(input_size=hidden, hidden_size=hidden, num_layers=layer_num, batch_first=True)
+        self.fc1 = nn.Linear(obs_dim, hidden)
+        self.fc2 = nn.Linear(hidden, n_act)
 
 
 class QRDQNet(DQNet):

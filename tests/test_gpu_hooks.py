@@ -524,6 +524,67 @@ def test_hip_discrete_sac_hooks_against_oracle():
     assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.act.cpu().numpy(), buf.act)
 
 
+def test_hip_redq_hooks_against_oracle():
+    """HipREDQ (integration.make_hip_redq over the stand-ins) on the real engine, the nets of test/continuous/test_redq.py:86-107
+    with 4 ensemble members: target from a random subset of 2 lagged members (redq.py:248-261; torch.randn then
+    np.random.choice, in the reference's order), one critic step on the whole ensemble, the actor / alpha step every 2nd
+    update against the ensemble mean (:263-304), Polyak, write-back of the actor, both ensembles and three optimizers --
+    against oracle_redq fed with the same sampled indices, noise and subsets."""
+    from oracle import oracle_redq as ORQ
+    from oracle import oracle_sac as OS
+    from tianshou_amd.integration import make_hip_redq
+
+    obs_dim, act_dim, E, S, B, H = 11, 3, 4, 2, 64, 256
+    HipREDQ = make_hip_redq(ref=SI)
+    torch.manual_seed(61)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [H, H], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    lin = lambda x, y: SI.EnsembleLinear(E, x, y)   # noqa: E731
+    critic = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [H, H], nn.ReLU, linear_layer=lin), linear_layer=lin)
+    alpha = SI.AutoAlpha(-float(act_dim), -0.6, 3e-4)
+    algo = HipREDQ(policy=SI.Policy(actor), critic=critic, lr=1e-3, critic_lr=1e-3, ensemble_size=E, subset_size=S, tau=0.01,
+                   gamma=0.97, alpha=alpha, actor_delay=2, target_mode="min", device="cuda").to("cuda")
+    grab = lambda mod, keys: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(keys, mod.state_dict())}   # noqa: E731
+    cfg = ORQ.REDQConfig(gamma=0.97, tau=0.01, n_step=1, auto_alpha=True, target_entropy=-float(act_dim), log_alpha0=-0.6,
+                         actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4, ensemble_size=E, subset_size=S, actor_delay=2,
+                         target_mode="min")
+    st = ORQ.REDQState.create(grab(actor, OS.ACTOR_ORDER), grab(critic, ORQ.CRITIC_ORDER), cfg)
+    buf = SI.VectorReplayBuffer(E * 200, 4, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=62)
+    rng = np.random.default_rng(63)
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, rng)
+        torch.manual_seed(400 + u)
+        np.random.seed(500 + u)
+        stats = algo.update(buf, B)
+        idx = seen[-1]
+        torch.manual_seed(400 + u)
+        np.random.seed(500 + u)
+        noise_t = torch.randn(B, act_dim)
+        subset = np.random.choice(E, S, replace=False)
+        actor_step = (st.critic_gradient_step + 1) % 2 == 0
+        noise_u = torch.randn(B, act_dim) if actor_step else None
+        tq = ORQ.target_q(st, cfg, torch.from_numpy(buf.obs_next[idx]), noise_t, subset).flatten().numpy()
+        ret = (buf.rew[idx] + 0.97 * tq.astype(np.float64) * (~buf.terminated[idx])).astype(np.float32)
+        ref = ORQ.update_with_batch(st, cfg, torch.from_numpy(buf.obs[idx]), torch.from_numpy(buf.act[idx]), ret, noise_u)
+        np.testing.assert_allclose([stats.actor_loss, stats.critic_loss, stats.alpha], [ref["actor_loss"], ref["critic_loss"], ref["alpha"]],
+                                   rtol=2e-5, atol=2e-6)
+        assert (stats.alpha_loss is None) == (ref["alpha_loss"] is None)
+        if ref["alpha_loss"] is not None:
+            np.testing.assert_allclose(stats.alpha_loss, ref["alpha_loss"], rtol=2e-5, atol=2e-6)
+        assert algo.critic_gradient_step == st.critic_gradient_step == u + 1
+    for mod, want, order in ((actor, st.actor, OS.ACTOR_ORDER), (critic, st.critic, ORQ.CRITIC_ORDER),
+                             (algo.critic_old.module, st.critic_old, ORQ.CRITIC_ORDER)):
+        for (name, t), k in zip(mod.state_dict().items(), order):
+            np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3, err_msg=name)
+    assert abs(float(alpha._log_alpha.detach()) - float(st.log_alpha)) < 0.02 * 3e-4
+    st_c = algo.critic_optim._optim.state[critic.last.model[0].weight]
+    st_a = algo.policy_optim._optim.state[actor.mu.model[0].weight]
+    assert float(st_c["step"]) == 4.0 and float(st_a["step"]) == 2.0 and st_c["exp_avg"].shape == (E, H, 1)
+
+
 # ------------------------------------------------------------------------------------ HipDQN
 def _dqn_hook_run(huber):
     from oracle import oracle_dqn as OD
@@ -601,6 +662,62 @@ def test_hip_dqn_hooks_against_oracle(huber):
     sampled indices.  The host buffer keeps growing between updates until every sub-buffer has wrapped: the mirror's
     incremental sync (write log) follows."""
     _dqn_hook_run(huber)
+
+
+def test_hip_drqn_hooks_against_oracle():
+    """HipDRQN (integration.make_hip_drqn over the stand-ins) on the real engine: a two-layer Recurrent Q network over a
+    vector-observation buffer with stack_num = 4 (the LSTM's sequence), n-step 2, double-Q with a lagged network synced every 2
+    updates, plain squared loss; four updates on a growing buffer against oracle_drqn fed with the same sampled indices."""
+    from oracle import oracle_dqn as OD
+    from oracle import oracle_drqn as ODR
+    from tianshou_amd import drqn as R
+    from tianshou_amd.integration import make_hip_drqn
+
+    obs_dim, hidden, layers, A, stack, E, B, gamma, n_step = 6, 64, 2, 3, 4, 4, 32, 0.95, 2
+    HipDRQN = make_hip_drqn(ref=SI)
+    torch.manual_seed(51)
+    model = SI.Recurrent(layers, obs_dim, A, hidden)
+    algo = HipDRQN(policy=SI.DiscreteQLearningPolicy(model), lr=1e-3, gamma=gamma, n_step_return_horizon=n_step,
+                   target_update_freq=2, is_double=True, huber_loss_delta=None, device="cuda").to("cuda")
+    keys = R.state_dict_keys(layers)
+    assert list(model.state_dict().keys()) == keys == ODR.param_keys(layers)
+    p0 = {k: model.state_dict()[k].detach().cpu().clone() for k in keys}
+    ocfg = OD.DQNConfig(gamma=gamma, n_step=n_step, target_update_freq=2, is_double=True, huber_delta=None, lr=1e-3)
+    st = OD.DQNState.create(p0, ocfg)
+    buf = SI.VectorReplayBuffer(E * 60, E, obs_shape=(obs_dim,), act_shape=(), act_dtype=np.int64, seed=52, stack_num=stack)
+    rng = np.random.default_rng(53)
+
+    def fill(T):
+        obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+        for t in range(T):
+            term = rng.random(E) < 0.06
+            buf.add(SI.Batch(obs=obs[t], act=rng.integers(0, A, E), rew=rng.normal(size=E).astype(np.float32), terminated=term,
+                             truncated=(rng.random(E) < 0.03) & ~term, obs_next=obs[t + 1]))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+    buf.sample = lambda bs: (lambda r: (seen.append(r[1]), r)[1])(orig_sample(bs))
+    for u in range(4):
+        fill(25 if u == 0 else 9)
+        stat = algo.update(buf, B)
+        idx = seen[-1]
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+
+        def tq_fn(after):                                        # the buffer stores obs_next: Q(s') from its rows at `after`
+            return ODR.target_q(st, ocfg, OD.stacked_frames(bstate, buf.obs_next, after, stack)).numpy().reshape(-1, 1)
+
+        ret, _ = O.compute_nstep_return(bstate, idx, tq_fn, gamma, n_step)
+        obs = OD.stacked_frames(bstate, buf.obs, idx, stack)
+        loss_o, _ = ODR.update_with_batch(st, ocfg, obs, buf.act[idx], ret.astype(np.float32).reshape(-1))
+        np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5, atol=1e-6)
+        assert algo._iter == st.iter == u + 1
+    for k in keys:
+        np.testing.assert_allclose(model.state_dict()[k].cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.05 * 1e-3, err_msg=k)
+        np.testing.assert_allclose(algo.model_old.module.state_dict()[k].cpu().numpy(), st.params_old[k].numpy(), rtol=1e-5,
+                                   atol=0.05 * 1e-3, err_msg="old " + k)
+    assert float(algo.optim._optim.state[model.fc1.weight]["step"]) == 4.0
 
 
 # ------------------------------------------------------------------------------------ HipPPOCnn

@@ -574,3 +574,79 @@ def test_reinforce_standin_has_the_reference_surface():
     A, B = make_hip_reinforce(), make_hip_reinforce(ref=SI)
     for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_dims"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_recurrent_standin_has_the_reference_surface():
+    """Recurrent (utils/net/common.py:372-452) under DQN: state_dict keys and shapes of the model and its lagged copy; the hook
+    bodies of HipDRQN are the same code objects over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.dqn import DQN, DiscreteQLearningPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Recurrent
+
+    real = DQN(policy=DiscreteQLearningPolicy(model=Recurrent(layer_num=2, state_shape=(6,), action_shape=3, hidden_layer_size=64),
+                                              action_space=gym.spaces.Discrete(3)),
+               optim=AdamOptimizerFactory(lr=1e-3), gamma=0.95, n_step_return_horizon=2, target_update_freq=2)
+    fake = SI.DQN(policy=SI.DiscreteQLearningPolicy(SI.Recurrent(2, 6, 3, 64)), lr=1e-3, gamma=0.95, n_step_return_horizon=2,
+                  target_update_freq=2)
+    _same_state_dicts(((real.policy.model, fake.policy.model), (real.model_old.module, fake.model_old.module)))
+    for name in ("gamma", "n_step", "target_update_freq", "is_double", "huber_loss_delta", "_iter"):
+        assert getattr(real, name) == getattr(fake, name), name
+    from tianshou_amd import drqn as R
+    from tianshou_amd.integration import make_hip_drqn
+
+    assert list(fake.policy.model.state_dict().keys()) == R.state_dict_keys(2)
+    A, B = make_hip_drqn(), make_hip_drqn(ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_redq_standin_has_the_reference_surface():
+    """REDQ over the nets of test/continuous/test_redq.py:86-107 (EnsembleLinear critics) against the real classes."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.redq import REDQ, REDQPolicy, REDQTrainingStats
+    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import EnsembleLinear, Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+
+    E = 4
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[256, 256]), action_shape=(3,),
+                                         unbounded=True, conditioned_sigma=True)
+    lin = lambda x, y: EnsembleLinear(E, x, y)   # noqa: E731
+    critic = ContinuousCritic(preprocess_net=Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[256, 256], concat=True,
+                                                 linear_layer=lin), linear_layer=lin, flatten_input=False)
+    real = REDQ(policy=REDQPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,))),
+                policy_optim=AdamOptimizerFactory(lr=1e-3), critic=critic, critic_optim=AdamOptimizerFactory(lr=1e-3),
+                ensemble_size=E, subset_size=2, tau=0.01, gamma=0.97, alpha=AutoAlpha(-3.0, -0.6, AdamOptimizerFactory(lr=3e-4)),
+                actor_delay=2, target_mode="min")
+    f_actor = SI.ContinuousActorProbabilistic(SI.Net(11, [256, 256], nn.ReLU), 3, unbounded=True, conditioned_sigma=True)
+    flin = lambda x, y: SI.EnsembleLinear(E, x, y)   # noqa: E731
+    f_critic = SI.ContinuousCritic(SI.Net(14, [256, 256], nn.ReLU, linear_layer=flin), linear_layer=flin)
+    fake = SI.REDQ(policy=SI.Policy(f_actor), critic=f_critic, lr=1e-3, critic_lr=1e-3, ensemble_size=E, subset_size=2, tau=0.01,
+                   gamma=0.97, alpha=SI.AutoAlpha(-3.0, -0.6, 3e-4), actor_delay=2, target_mode="min")
+    _same_state_dicts(((real.policy.actor, fake.policy.actor), (real.critic, fake.critic),
+                       (real.critic_old.module, fake.critic_old.module)))
+    for name in ("ensemble_size", "subset_size", "tau", "gamma", "n_step_return_horizon", "actor_delay", "target_mode",
+                 "critic_gradient_step", "_last_actor_loss"):
+        assert getattr(real, name) == getattr(fake, name), name
+    for name in ("policy_optim", "critic_optim"):
+        r, f = getattr(real, name), getattr(fake, name)
+        assert type(r._optim) is type(f._optim) is torch.optim.Adam and r._max_grad_norm == f._max_grad_norm
+        assert [tuple(p.shape) for p in r._optim.param_groups[0]["params"]] == [tuple(p.shape) for p in f._optim.param_groups[0]["params"]]
+    assert float(real.alpha._log_alpha) == float(fake.alpha._log_alpha)
+    kw = dict(actor_loss=1.0, critic_loss=2.0, alpha=0.5, alpha_loss=None)
+    a, b = REDQTrainingStats(**kw), SI.REDQTrainingStats(**kw)
+    assert all(getattr(a, k) == getattr(b, k) for k in kw)
+    # EnsembleLinear's initialisation draws: same shapes, same bound
+    w = SI.EnsembleLinear(E, 14, 256)
+    assert float(w.weight.abs().max()) <= (1.0 / 14) ** 0.5 and tuple(w.bias_weights.shape) == (E, 1, 256)
+    from tianshou_amd.integration import make_hip_redq
+
+    A, B = make_hip_redq(), make_hip_redq(ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_critic_tensors"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name

@@ -777,11 +777,12 @@ def make_hip_dqn(ref=None):
 # ---------------------------------------------------------------------------------------------------
 # DQN on the Recurrent Q network (DRQN, test/discrete/test_drqn.py)
 # ---------------------------------------------------------------------------------------------------
-def make_hip_drqn():
+def make_hip_drqn(ref=None):
     """Returns HipDRQN(DQN): the DQN hooks (dqn.py:257-275, 381-404) on the engine for a Recurrent model
-    (utils/net/common.py:372-452) over a buffer with stack_num (the LSTM's sequence length) and vector observations."""
-    from tianshou.algorithm.modelfree.dqn import DQN
-    from tianshou.algorithm.modelfree.reinforce import SimpleLossTrainingStats
+    (utils/net/common.py:372-452) over a buffer with stack_num (the LSTM's sequence length) and vector observations.
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    DQN = _ref(ref, "tianshou.algorithm.modelfree.dqn", "DQN")
+    SimpleLossTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "SimpleLossTrainingStats")
 
     from . import dqn as D
     from . import drqn as R
@@ -1245,14 +1246,16 @@ def make_hip_sac(ref=None):
 # ---------------------------------------------------------------------------------------------------
 # REDQ (redq.py) on the nets of test/continuous/test_redq.py
 # ---------------------------------------------------------------------------------------------------
-def make_hip_redq():
+def make_hip_redq(ref=None):
     """Returns HipREDQ(REDQ): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, redq.py:248-304) on the engine.
     Supported nets: SAC's actor (Net[256, 256] ReLU, conditioned sigma, unbounded) and one critic module made of
     EnsembleLinear layers with hidden [256, 256] (test/continuous/test_redq.py:86-107); the buffer must store obs_next.
     The rsample() noise comes from torch's default generator and the critic subset from NumPy's global generator, in
-    the reference's order (target call: noise, then np.random.choice; actor step: noise)."""
-    from tianshou.algorithm.modelfree.redq import REDQ, REDQTrainingStats
-    from tianshou.algorithm.modelfree.sac import AutoAlpha
+    the reference's order (target call: noise, then np.random.choice; actor step: noise).
+    `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    REDQ = _ref(ref, "tianshou.algorithm.modelfree.redq", "REDQ")
+    REDQTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.redq", "REDQTrainingStats")
+    AutoAlpha = _ref(ref, "tianshou.algorithm.modelfree.sac", "AutoAlpha")
 
     from . import redq as RQ
     from . import sac as S
