@@ -615,6 +615,74 @@ class C51(DQN):
         self.delta_z = (policy.v_max - policy.v_min) / (policy.num_atoms - 1)
 
 
+class NoisyLinear(nn.Module):
+    """utils/net/discrete.py:317-374: mu / sigma parameters, the factorised noise vectors `eps_p`, `eps_q` (parameters that
+    do not require grad, so they are part of state_dict()), `sample()` redraws them from torch's default generator."""
+
+    def __init__(self, in_features, out_features, noisy_std=0.5):
+        super().__init__()
+        self.mu_W = nn.Parameter(torch.empty(out_features, in_features))
+        self.sigma_W = nn.Parameter(torch.empty(out_features, in_features))
+        self.mu_bias = nn.Parameter(torch.empty(out_features))
+        self.sigma_bias = nn.Parameter(torch.empty(out_features))
+        self.eps_p = nn.Parameter(torch.empty(in_features), requires_grad=False)
+        self.eps_q = nn.Parameter(torch.empty(out_features), requires_grad=False)
+        self.in_features, self.out_features, self.sigma = in_features, out_features, noisy_std
+        bound = 1 / np.sqrt(in_features)
+        self.mu_W.data.uniform_(-bound, bound)
+        self.mu_bias.data.uniform_(-bound, bound)
+        self.sigma_W.data.fill_(noisy_std / np.sqrt(in_features))
+        self.sigma_bias.data.fill_(noisy_std / np.sqrt(in_features))
+        self.sample()
+
+    @staticmethod
+    def f(x):
+        x = torch.randn(x.size(0), device=x.device)
+        return x.sign().mul_(x.abs().sqrt_())
+
+    def sample(self):
+        self.eps_p.copy_(self.f(self.eps_p))
+        self.eps_q.copy_(self.f(self.eps_q))
+
+
+class RainbowNet(nn.Module):
+    """env/atari/atari_network.py:154-208 with is_dueling = is_noisy = True: `net` = the conv stack itself (features_only
+    without an added layer), `Q` and `V` = Sequential(NoisyLinear, ReLU, NoisyLinear)."""
+
+    def __init__(self, c, h, w, n_act, num_atoms, noisy_std=0.5):
+        super().__init__()
+        self.net = nn.Sequential(nn.Conv2d(c, 32, 8, 4), nn.ReLU(), nn.Conv2d(32, 64, 4, 2), nn.ReLU(), nn.Conv2d(64, 64, 3, 1),
+                                 nn.ReLU(), nn.Flatten())
+        with torch.no_grad():
+            feat = int(self.net(torch.zeros(1, c, h, w)).shape[1])
+        self.action_num, self.num_atoms = n_act, num_atoms
+        self.Q = nn.Sequential(NoisyLinear(feat, 512, noisy_std), nn.ReLU(), NoisyLinear(512, n_act * num_atoms, noisy_std))
+        self.V = nn.Sequential(NoisyLinear(feat, 512, noisy_std), nn.ReLU(), NoisyLinear(512, num_atoms, noisy_std))
+        self.output_dim = n_act * num_atoms
+
+
+class RainbowDQN(C51):
+    """modelfree/rainbow.py:18-76: C51 whose `model_old` is the bare module (not the eval-mode wrapper), plus `_sample_noise`."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        if self.use_target_network:
+            self.model_old = self.model_old.module
+
+    @property
+    def use_target_network(self):
+        return self.target_update_freq > 0
+
+    @staticmethod
+    def _sample_noise(model):
+        sampled = False
+        for m in model.modules():
+            if isinstance(m, NoisyLinear):
+                m.sample()
+                sampled = True
+        return sampled
+
+
 # ------------------------------------------------------------------------------------------------ replay buffer
 class _SubBuffer:
     """The per-environment ReplayBuffer inside a manager: `_insertion_idx`, `__len__`, `maxsize`."""

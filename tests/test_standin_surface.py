@@ -650,3 +650,44 @@ def test_redq_standin_has_the_reference_surface():
     A, B = make_hip_redq(), make_hip_redq(ref=SI)
     for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_critic_tensors"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_rainbow_standin_has_the_reference_surface():
+    """RainbowDQN / RainbowNet / NoisyLinear stand-ins against the real classes: state_dict keys and shapes (the eps vectors
+    included), the bare lagged module, `_sample_noise` consuming torch's generator exactly as the reference (same draws ->
+    same noise vectors), the optimizer's parameter list; the hook bodies are the same code objects over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+
+    from tianshou.algorithm.modelfree.c51 import C51Policy
+    from tianshou.algorithm.modelfree.rainbow import RainbowDQN
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.env.atari.atari_network import RainbowNet
+
+    torch.manual_seed(5)
+    real = RainbowDQN(policy=C51Policy(model=RainbowNet(c=4, h=44, w=36, action_shape=[3], num_atoms=21),
+                                       action_space=gym.spaces.Discrete(3), num_atoms=21, v_min=-4.0, v_max=4.0),
+                      optim=AdamOptimizerFactory(lr=1e-4), gamma=0.97, n_step_return_horizon=2, target_update_freq=2)
+    torch.manual_seed(5)
+    fake = SI.RainbowDQN(policy=SI.C51Policy(SI.RainbowNet(4, 44, 36, 3, 21), num_atoms=21, v_min=-4.0, v_max=4.0), lr=1e-4,
+                         gamma=0.97, n_step_return_horizon=2, target_update_freq=2)
+    _same_state_dicts(((real.policy.model, fake.policy.model), (real.model_old, fake.model_old)))
+    for k, v in real.policy.model.state_dict().items():               # same constructor draws: identical tensors
+        assert torch.equal(v, fake.policy.model.state_dict()[k]), k
+    assert real.use_target_network is fake.use_target_network is True
+    torch.manual_seed(6)
+    assert real._sample_noise(real.policy.model) and real._sample_noise(real.model_old)
+    torch.manual_seed(6)
+    assert fake._sample_noise(fake.policy.model) and fake._sample_noise(fake.model_old)
+    for a, b in ((real.policy.model, fake.policy.model), (real.model_old, fake.model_old)):
+        for k in ("Q.0.eps_p", "Q.2.eps_q", "V.0.eps_q", "V.2.eps_p"):
+            assert torch.equal(a.state_dict()[k], b.state_dict()[k]), k
+    shapes = lambda o: [tuple(p.shape) for g in o._optim.param_groups for p in g["params"]]   # noqa: E731
+    assert shapes(real.optim) == shapes(fake.optim)
+    from tianshou_amd import rainbow as RB
+    from tianshou_amd.integration import make_hip_rainbow
+
+    assert sorted(fake.policy.model.state_dict().keys()) == sorted(RB.TIANSHOU_KEYS + RB.NOISE_KEYS)
+    A, B = make_hip_rainbow(), make_hip_rainbow(ref=SI)
+    for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_layout", "_noise_of"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name

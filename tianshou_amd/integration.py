@@ -995,14 +995,14 @@ def make_hip_c51(ref=None):
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     return _make_hip_distq("c51", ref)
 
-def make_hip_rainbow():
+def make_hip_rainbow(ref=None):
     """Returns HipRainbow(RainbowDQN): `_preprocess_batch` / `_update_with_batch` (dqn.py:257-275, rainbow.py:93-101 ->
     c51.py:120-160) on the engine.  Supported model: RainbowNet(is_dueling=True, is_noisy=True)
     (atari_network.py:154-208) with C51Policy's support, Adam; buffer layouts as HipDQN.  The NoisyLinear noise is drawn by
     the torch modules themselves (`RainbowDQN._sample_noise`, so torch's generator advances as in the reference) and
-    handed to the engine."""
-    from tianshou.algorithm.modelfree.rainbow import RainbowDQN
-    from tianshou.algorithm.modelfree.reinforce import LossSequenceTrainingStats
+    handed to the engine.  `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
+    RainbowDQN = _ref(ref, "tianshou.algorithm.modelfree.rainbow", "RainbowDQN")
+    LossSequenceTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "LossSequenceTrainingStats")
 
     from . import distq as Q
     from . import dqn as D
