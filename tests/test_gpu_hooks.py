@@ -981,6 +981,89 @@ def test_hip_c51_hooks_against_oracle():
     assert float(algo.optim._optim.state[next(iter(model.parameters()))]["step"]) == 4.0
 
 
+def test_hip_rainbow_hooks_against_oracle():
+    """HipRainbow (integration.make_hip_rainbow over the stand-ins) on the real engine: RainbowNet (dueling, NoisyLinear) over
+    single uint8 frames with stack_num = 4 on a prioritized buffer, n-step 2, a lagged network synced every 2 updates.  The
+    NoisyLinear noise is drawn by the torch modules (`_sample_noise`, rainbow.py:93-100) and handed to the engine; the test
+    replays the same draws from torch's generator for oracle_rainbow."""
+    import copy
+
+    from oracle import oracle_distq as OQ
+    from oracle import oracle_dqn as OD
+    from oracle import oracle_rainbow as ORB
+    from tianshou_amd import rainbow as RB
+    from tianshou_amd.integration import make_hip_rainbow
+
+    c, h, w, A, N, E, size, B = 4, 44, 36, 3, 11, 4, 40, 32
+    HipRainbow = make_hip_rainbow(ref=SI)
+    torch.manual_seed(71)
+    model = SI.RainbowNet(c, h, w, A, N)
+    with torch.no_grad():
+        model.net[0].weight.mul_(1.0 / 255.0)          # uint8 frames (0..255) times default-init weights: keep logits O(1)
+    # (the torch modules stay on the host: NoisyLinear draws its noise on the module's device, and the host generator is the
+    # one the test can replay; the engine lives on the GPU either way)
+    algo = HipRainbow(policy=SI.C51Policy(model, num_atoms=N, v_min=-4.0, v_max=4.0), lr=1e-4, gamma=0.97,
+                      n_step_return_horizon=2, target_update_freq=2, device="cuda")
+    noise_of = lambda mod: {f"{L}.{t}": mod.state_dict()[f"{m}.{t}"].detach().cpu().clone()   # noqa: E731
+                            for L, m in zip(ORB.NOISY, RB.NOISY) for t in ("eps_p", "eps_q")}
+    sd = model.state_dict()
+    p0 = {k: sd[n].detach().cpu().clone() for k, n in zip(ORB.PARAM_ORDER, RB.TIANSHOU_KEYS)}
+    ocfg = OQ.DistQConfig(kind=OQ.C51, n_atoms=N, gamma=0.97, n_step=2, target_update_freq=2, lr=1e-4, v_min=-4.0, v_max=4.0)
+    st = ORB.RainbowState(p0, noise_of(model), ocfg)
+    scratch, scratch_old = copy.deepcopy(model), copy.deepcopy(model)
+    buf = SI.PrioritizedVectorReplayBuffer(E * size, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                           seed=72, stack_num=c, alpha=0.6, beta=0.4)
+    rng = np.random.default_rng(73)
+
+    def fill(n):
+        for _ in range(n):
+            term = rng.random(E) < 0.08
+            buf.add(SI.Batch(obs=rng.integers(0, 256, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
+
+    algo.policy.is_within_training_step = True
+    seen = []
+    orig_sample = buf.sample
+
+    def sample(bs):
+        batch, idx = orig_sample(bs)
+        seen.append((idx.copy(), np.asarray(batch.weight).copy()))
+        return batch, idx
+
+    buf.sample = sample
+    eps = np.finfo(np.float32).eps.item()
+    for u in range(4):
+        fill(25 if u == 0 else 9)
+        rng_state = torch.get_rng_state()
+        stat = algo.update(buf, B)
+        idx, w_is = seen[-1]
+        torch.set_rng_state(rng_state)                       # the two _sample_noise calls of this update, replayed on the host
+        SI.RainbowDQN._sample_noise(scratch)
+        SI.RainbowDQN._sample_noise(scratch_old)
+        noise, noise_old = noise_of(scratch), noise_of(scratch_old)
+        for k, v in noise_of(model).items():                 # the hook left this update's draws in the torch module
+            assert torch.equal(v, noise[k]), k
+        bstate = O.BufferState(buf._extend_offset, buf.last_index, buf._lengths, [b._insertion_idx for b in buf.buffers],
+                               buf.rew, buf.terminated, buf.truncated)
+        ret = ORB.preprocess(ocfg, bstate, idx)
+        obs = OD.stacked_frames(bstate, buf.obs, idx, c)
+        obs_next = OD.stacked_frames(bstate, buf.obs_next, idx, c)
+        loss_o, prio_o = ORB.update_with_batch(st, ocfg, obs, buf.act[idx], ret, obs_next, A, noise, noise_old, weight=w_is)
+        np.testing.assert_allclose(stat.loss, loss_o, rtol=2e-5)
+        upd_idx, upd_w = buf.weight_updates[-1]
+        assert np.array_equal(upd_idx, idx)
+        np.testing.assert_allclose(upd_w, np.abs(np.asarray(prio_o)) + eps, rtol=2e-5, atol=2e-5)
+        assert algo._iter == st.dqn.iter == u + 1
+        for k, v in noise_of(algo.model_old).items():        # the lagged module's noise: its own draws, or the sync's copy
+            assert torch.equal(v, st.noise_old[k]), k
+    sd, so = model.state_dict(), algo.model_old.state_dict()
+    for k, n in zip(ORB.PARAM_ORDER, RB.TIANSHOU_KEYS):
+        np.testing.assert_allclose(sd[n].cpu().numpy(), st.dqn.params[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
+        np.testing.assert_allclose(so[n].cpu().numpy(), st.dqn.params_old[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg="old " + k)
+    assert float(algo.optim._optim.state[model.Q[0].mu_W]["step"]) == 4.0
+
+
 # ------------------------------------------------------------------------------------ HipTD3
 def test_hip_td3_hooks_against_oracle():
     """HipTD3 (integration.make_hip_td3 over the stand-ins) on the real engine with Net[128, 128] trunks (a width other than
