@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence run (under gpurun): GPU suite, smoke, bench lines + rocprofv3 kernel stats for every workload -> gpurun_out/r2final/
+# Round-3 evidence run (under gpurun): GPU suite, smoke, bench lines + rocprofv3 kernel stats for every workload -> gpurun_out/r3final/
 O=$GRAFT_REPO_ROOT/gpurun_out/r3final; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
