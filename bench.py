@@ -207,11 +207,12 @@ def time_gae_large(learner, log2n=24, iters=10):
     return n, (prof["gae_maps"][0] + prof["gae_apply"][0]) / iters * 1e-3
 
 
-def cpu_baseline(sample_steps=8):
+def cpu_baseline(sample_steps=None):
     """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
-    kernels) on the host cores, bounded sample: full preprocess of one 2^20 rollout in
-    max_batchsize=65536 chunks + `sample_steps` minibatch gradient steps of 65536; whole-update
-    steps/s extrapolated as 160 / (t_pre + 160 * t_step)."""
+    kernels) on the host cores.  Default sample: ONE whole update() = full preprocess of the 2^20
+    rollout in max_batchsize=65536 chunks + all 160 minibatch gradient steps of 65536 (10 repeats
+    over fresh permutations), i.e. one step of this bench (~11 s on 32 threads); `sample_steps` < 160
+    times that many gradient steps and extrapolates 160 / (t_pre + 160 * t_step)."""
     from oracle import oracle as O
     from oracle import oracle_ppo as OP
 
@@ -245,21 +246,26 @@ def cpu_baseline(sample_steps=8):
         t0 = time.perf_counter()
         O.compute_episodic_return(rew, term, trunc, idx, unf, pre["v_s"].numpy(), pre["v_s"].numpy(), 0.99, 0.95)
         t_gae = min(t_gae, time.perf_counter() - t0)
-    perm = rng.permutation(N_TRANS)
-    sub = perm[: MINIBATCH * sample_steps]
-    data = {"obs": obs[sub], "act": act[sub]}
-    pre_s = {k: pre[k][sub] for k in ("v_s", "returns", "adv", "logp_old")}
-    t0 = time.perf_counter()
-    OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, [np.arange(MINIBATCH * sample_steps)])
-    t_step = (time.perf_counter() - t0) / sample_steps
     steps_per_update = REPEAT * (N_TRANS // MINIBATCH)
+    if sample_steps is None or sample_steps >= steps_per_update:       # the whole update(), as the reference runs it
+        sample_steps = steps_per_update
+        perms = [rng.permutation(N_TRANS) for _ in range(REPEAT)]
+        t0 = time.perf_counter()
+        OP.update(st, ocfg, {"obs": obs, "act": act}, pre, MINIBATCH, REPEAT, perms)
+    else:
+        sub = rng.permutation(N_TRANS)[: MINIBATCH * sample_steps]
+        data = {"obs": obs[sub], "act": act[sub]}
+        pre_s = {k: pre[k][sub] for k in ("v_s", "returns", "adv", "logp_old")}
+        t0 = time.perf_counter()
+        OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, [np.arange(MINIBATCH * sample_steps)])
+    t_step = (time.perf_counter() - t0) / sample_steps
     value = steps_per_update / (t_pre + steps_per_update * t_step)
     return {
         "value": value, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": (f"PORT of the reference path, not the reference itself (oracle/: torch-fp32 CPU ops in the reference's "
                    f"order + a -O3 C restatement of its numba kernels): 1 full preprocess of 2^20 transitions "
                    f"({t_pre:.2f} s, of which the GAE scan {t_gae * 1e3:.1f} ms single-thread = "
-                   f"{N_TRANS / t_gae / 1e6:.0f} M transitions/s) + {sample_steps} gradient steps of 65536 "
+                   f"{N_TRANS / t_gae / 1e6:.0f} M transitions/s) + {sample_steps} of the 160 gradient steps of 65536 "
                    f"({t_step * 1e3:.1f} ms each, {torch.get_num_threads()} threads); whole-update rate = 160 / (t_pre + 160 t_step)"),
         "gae_transitions_per_s": N_TRANS / t_gae,
         "inner_update_steps_per_s": 1.0 / t_step,
