@@ -25,7 +25,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 FLOP_PER_SAMPLE = 4.76e6          # algorithmic minimum of one update
 
 
-def cpu_baseline(updates: int = 3):
+def cpu_baseline(updates: int = 3, budget_s: float = 10.0):
     from oracle import oracle_sac as OS
 
     threads = min(os.cpu_count() or 1, 32)
@@ -43,10 +43,11 @@ def cpu_baseline(updates: int = 3):
         OS.update_with_batch(st, cfg, obs, act, ret, noise)
 
     one()
-    t0 = time.perf_counter()
-    for _ in range(updates):
+    t0, done = time.perf_counter(), 0
+    while done < updates or time.perf_counter() - t0 < budget_s:         # at least `updates`, then up to ~budget_s of CPU work
         one()
-    dt = time.perf_counter() - t0
+        done += 1
+    dt, updates = time.perf_counter() - t0, done
     return {"value": updates / dt, "unit": "updates/s", "cores": threads, "kind": "port",
             "sample": f"{updates} updates of B={BATCH} (target + 3 optimizer steps + Polyak), torch fp32 CPU oracle"}
 
