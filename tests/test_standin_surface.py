@@ -691,3 +691,36 @@ def test_rainbow_standin_has_the_reference_surface():
     A, B = make_hip_rainbow(), make_hip_rainbow(ref=SI)
     for name in ("__init__", "_preprocess_batch", "_update_with_batch", "_engine", "_layout", "_noise_of"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_a2c_standin_has_the_reference_surface():
+    """A2C over the MuJoCo nets: the stand-in carries exactly the attributes the real A2C has (none of PPO's clipping ones), and
+    `ppo_config_from` maps both to the same engine configuration; HipA2C's hook bodies are HipPPO's over either namespace."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.a2c import A2C
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+
+    ra, rc = _real_mujoco_nets()
+    fa, fc = _fake_mujoco_nets()
+    pol = ProbabilisticActorPolicy(actor=ra, dist_fn=lambda ls: Independent(Normal(*ls), 1),
+                                   action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    kw = dict(vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.9, gamma=0.98, return_scaling=False)
+    real = A2C(policy=pol, critic=rc, optim=AdamOptimizerFactory(lr=7e-4), **kw)
+    fake = SI.A2C(policy=SI.Policy(fa), critic=fc, lr=7e-4, **kw)
+    _same_state_dicts(((real.policy.actor, fake.policy.actor), (real.critic, fake.critic)))
+    for name in ("vf_coef", "ent_coef", "gae_lambda", "gamma", "return_scaling", "max_batchsize"):
+        assert getattr(real, name) == getattr(fake, name), name
+    for name in ("eps_clip", "dual_clip", "value_clip", "advantage_normalization", "recompute_adv"):
+        assert not hasattr(real, name) and not hasattr(fake, name), name
+    assert real.optim._max_grad_norm == fake.optim._max_grad_norm == 0.5
+    from tianshou_amd.integration import make_hip_ppo, ppo_config_from
+
+    assert ppo_config_from(real) == ppo_config_from(fake)
+    A, B = make_hip_ppo("a2c"), make_hip_ppo("a2c", ref=SI)
+    assert A.__name__ == B.__name__ == "HipA2C"
+    for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_hip_params"):
+        assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
