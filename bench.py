@@ -12,11 +12,16 @@ on data already resident in HBM: V(s), V(s'), GAE over the 2^20 transitions, log
 repeat x 16 = 160 minibatch gradient steps (forward, loss, backward, grad-clip, Adam).
 value = minibatch gradient steps per second over the whole job (all ranks), preprocessing included.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling strong|weak|both]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (N > 1, one rank per GPU)
+    (`python bench.py --gpus N` without WORLD_SIZE in the environment starts that launcher itself)
 
-N > 1 (weak scaling): every rank owns its own 2^20-transition shard (buffer sharded by env id,
-SURVEY 8e); per gradient step the flat fp32 gradient (11,085 floats) is all-reduced with RCCL.
+N > 1, strong scaling (BASELINE.json configs[3], the line's `value`): ONE 2^20-transition rollout whose 512
+sub-buffers are sharded over the ranks by env id (`shard_envs`), global minibatch 65,536 =
+65,536 / N rows per rank per gradient step, 160 gradient steps per update() whatever N; per step the flat
+fp32 gradient + loss parts (11,089 floats) are all-reduced.  The weak-scaling figure (every rank its own
+2^20-transition rollout and a 65,536-row local minibatch: the per-GPU work of N = 1) is measured in the same
+run and printed beside it (`weak_scaling`).
 """
 from __future__ import annotations
 
@@ -49,7 +54,17 @@ TRAFFIC_SOURCE = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE /
 H2D_BYTES_PER_UPDATE = N_TRANS * (2 * OBS * 4 + ACT * 4 + 8 + 2)   # obs, obs_next, act f32; rew f64; two flag bytes
 
 
-def make_rollout(device, seed):
+def make_rollout(device, seed, env_range=None):
+    """The synthetic rollout of `seed` (512 sub-buffers x 2048 slots, env-major); env_range = (lo, hi): only those
+    sub-buffers of the SAME rollout (every rank draws the whole thing and keeps its shard)."""
+    full = _make_rollout(device, seed)
+    if env_range is None or env_range == (0, N_ENV):
+        return full
+    lo, hi = env_range
+    return tuple(t[lo * T_STEPS: hi * T_STEPS].clone() for t in full)
+
+
+def _make_rollout(device, seed):
     g = torch.Generator(device=device).manual_seed(seed)
     obs = torch.randn(N_TRANS, OBS, device=device, generator=g)
     obs_next = torch.randn(N_TRANS, OBS, device=device, generator=g)
@@ -90,58 +105,47 @@ def init_flat_params(seed=0):
 
 
 class Learner:
-    """One rank: device-resident rollout shard + PPO engine.  world_size > 1 splits every
-    gradient step around an RCCL all-reduce of the flat gradient."""
+    """One rank: device-resident rollout shard + PPO engine.  world_size > 1 splits every gradient step around an
+    all-reduce of the flat gradient.  scaling = "strong": this rank's sub-buffers of the one global rollout and its
+    65,536 / world rows of every global minibatch; "weak": a whole rollout of its own and 65,536-row local minibatches."""
 
-    def __init__(self, device, rank, world):
+    def __init__(self, device, rank, world, scaling="strong", allreduce=None, exchange="none"):
         from tianshou_amd import _lib
+        from tianshou_amd.distributed import shard_envs
         from tianshou_amd.ppo import PPOEngine
 
-        self.device, self.rank, self.world = device, rank, world
-        self.data = make_rollout(device, seed=1000 + rank)
+        self.device, self.rank, self.world, self.scaling = device, rank, world, scaling
+        if scaling == "strong" and world > 1:
+            lo, hi = shard_envs(N_ENV, rank, world)
+            self.data = make_rollout(device, seed=1000, env_range=(lo, hi))
+            self.n_env, self.minibatch = hi - lo, MINIBATCH // world
+        else:
+            self.data = make_rollout(device, seed=1000 + rank)
+            self.n_env, self.minibatch = N_ENV, MINIBATCH
+        self.n_trans = self.n_env * T_STEPS
         self.cfg = mujoco_cfg()
         self.eng = PPOEngine(OBS, ACT, init_flat_params(0).to(device), self.cfg)
-        self.cut = (torch.arange(N_ENV, device=device) + 1) * T_STEPS - 1   # last slot of every env
-        self.rng = np.random.default_rng(1234 + rank)
+        self.cut = (torch.arange(self.n_env, device=device) + 1) * T_STEPS - 1   # last slot of every env
         self.perm_seed = 1234 + 7919 * rank
         self._lib = _lib
         self.ws = _lib.default_workspace(device.index)
         self.dp = None
-        self.exchange = "none"
+        self._ar = allreduce
+        self.exchange = exchange
 
     def next_perm(self):
         from tianshou_amd.buffer import random_permutation
 
         self.perm_seed += 0x9E3779B97F4A7C15
-        return random_permutation(N_TRANS, self.perm_seed, self.device)
+        return random_permutation(self.n_trans, self.perm_seed, self.device)
 
     def _dp(self):
         """world > 1: every minibatch is ONE C call (ts_ppo_dp_step: gradient -> exchange -> clip + Adam on the stream); the
-        exchange is the C-ABI all-reduce, whose one-shot path (peer buffers mapped through HIP IPC, one single-workgroup
-        kernel) carries the 44 KB payload.  torch.distributed (three Python calls per step) only if that cannot be set up."""
+        exchange is the C-ABI all-reduce (`make_exchange`), torch.distributed if that could not be set up."""
         if self.dp is None:
             from tianshou_amd.distributed import DataParallelPPO
 
-            ar = None
-            if self.world > 1 and not os.environ.get("TS_BENCH_TORCH_ALLREDUCE"):
-                try:
-                    from tianshou_amd.collective import NativeAllReduce
-
-                    ar = NativeAllReduce(self.device, rccl=not os.environ.get("TS_BENCH_ONE_GPU"))
-                    self.exchange = "ts_allreduce one-shot (HIP IPC)" if ar.small_capacity >= self.eng.P + 4 else "ts_allreduce (RCCL)"
-                except Exception as e:      # noqa: BLE001 - any failure of the native set-up: the proven path
-                    print(f"[bench] rank {self.rank}: native all-reduce unavailable ({e}); using torch.distributed", file=sys.stderr)
-                    ar = None
-                import torch.distributed as dist
-
-                ok = torch.tensor([0 if ar is None else 1], device=self.device)       # all ranks or none
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if int(ok.item()) == 0 and ar is not None:
-                    ar.close()
-                    ar = None
-            if ar is None:
-                self.exchange = "torch.distributed all_reduce (RCCL)" if self.world > 1 else "none"
-            self.dp = DataParallelPPO(self.eng, allreduce=ar)
+            self.dp = DataParallelPPO(self.eng, allreduce=self._ar)
         return self.dp
 
     def preprocess(self, local_only=False):
@@ -152,19 +156,65 @@ class Learner:
         return self.eng.preprocess(obs, obs_next, act, rew, term, trunc, self.cut)
 
     def update_once(self):
-        """one reference update(): preprocess + REPEAT x (N_TRANS / MINIBATCH) gradient steps."""
+        """one reference update(): preprocess + REPEAT x (transitions / minibatch) gradient steps."""
         b = self.preprocess()
         # minibatch order: keyed device-side permutations (ts_random_permutation); the reference draws
         # np.random.permutation on the host (~10 ms per 2^20 entries), a sort-based torch.randperm
         # costs ~0.25 ms - either would be a visible part of the 13 ms update
         perms = [self.next_perm() for _ in range(REPEAT)]
         if self.world == 1 and not os.environ.get("TS_BENCH_FORCE_DP"):    # (env: time the DP host path at N = 1)
-            losses, steps = self.eng.update(b, MINIBATCH, REPEAT, perms)
+            losses, steps = self.eng.update(b, self.minibatch, REPEAT, perms)
             return losses, steps
-        return self._update_dp(b, perms)
+        return self._dp().update(b, self.minibatch, REPEAT, perms)
 
-    def _update_dp(self, b, perms):
-        return self._dp().update(b, MINIBATCH, REPEAT, perms)
+
+def make_exchange(device, rank, world):
+    """The gradient exchange of the N > 1 legs: the C-ABI all-reduce, whose one-shot path (peer buffers mapped through HIP
+    IPC, one single-workgroup kernel) carries the 44 KB payload; torch.distributed (three Python calls per step) only if
+    that cannot be set up on EVERY rank.  -> (allreduce or None, description)"""
+    if world == 1:
+        return None, "none"
+    import torch.distributed as dist
+
+    ar, name = None, "torch.distributed all_reduce (RCCL)"
+    if not os.environ.get("TS_BENCH_TORCH_ALLREDUCE"):
+        try:
+            from tianshou_amd.collective import NativeAllReduce
+
+            ar = NativeAllReduce(device, rccl=not os.environ.get("TS_BENCH_ONE_GPU"))
+        except Exception as e:      # noqa: BLE001 - any failure of the native set-up: the proven path
+            print(f"[bench] rank {rank}: native all-reduce unavailable ({e}); using torch.distributed", file=sys.stderr)
+            ar = None
+        ok = torch.tensor([0 if ar is None else 1], device=device)       # all ranks or none
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and ar is not None:
+            ar.close()
+            ar = None
+    if ar is not None:
+        name = "ts_allreduce one-shot (HIP IPC)" if ar.small_capacity >= 11085 + 4 else "ts_allreduce (RCCL)"
+    return ar, name
+
+
+def time_exchange(device, world, ar, floats, iters=200):
+    """Mean time of one all-reduce of the per-step payload ([gradient | loss parts]), HIP events on the launch stream around
+    `iters` back-to-back calls on every rank (collective: all ranks call it)."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+
+    buf = torch.zeros(floats, dtype=torch.float32, device=device)
+    call = ar if ar is not None else (lambda t: dist.all_reduce(t))
+    for _ in range(20):
+        call(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        call(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
 
 
 def time_gae(learner, iters=50):
@@ -172,8 +222,8 @@ def time_gae(learner, iters=50):
     from tianshou_amd.returns import gae_scan
 
     obs, obs_next, act, rew, term, trunc = learner.data
-    v = torch.randn(N_TRANS, device=learner.device)
-    vn = torch.randn(N_TRANS, device=learner.device)
+    v = torch.randn(learner.n_trans, device=learner.device)
+    vn = torch.randn(learner.n_trans, device=learner.device)
     for _ in range(5):
         gae_scan(v, vn, rew, term, trunc, learner.cut)
     torch.cuda.synchronize()
@@ -185,7 +235,7 @@ def time_gae(learner, iters=50):
     return ms * 1e-3
 
 
-def time_gae_large(learner, log2n=24, iters=10):
+def time_gae_large(learner, log2n=24, iters=10, n_env=8192):
     """The same scan at 2^24 transitions (8192 envs x 2048 steps): the bandwidth the kernel reaches once the launch
     and hand-off latencies are amortised ('also report N = 2^24 ... for asymptotic GB/s')."""
     from tianshou_amd.returns import gae_scan
@@ -196,7 +246,8 @@ def time_gae_large(learner, log2n=24, iters=10):
     rew = torch.randn(n, generator=g, device=dev).double()
     term = torch.rand(n, generator=g, device=dev) < 0.002
     trunc = torch.zeros(n, dtype=torch.bool, device=dev)
-    cut = torch.arange(T_STEPS - 1, n, T_STEPS, device=dev, dtype=torch.int64)      # last slot of every sub-buffer
+    per = n // n_env
+    cut = torch.arange(per - 1, n, per, device=dev, dtype=torch.int64)              # last slot of every sub-buffer
     for _ in range(2):
         gae_scan(v, vn, rew, term, trunc, cut)
     torch.cuda.synchronize()
@@ -409,6 +460,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", default="both", choices=["strong", "weak", "both"],
+                    help="N > 1: strong = one 2^20-transition rollout sharded over the ranks, global minibatch 65536 (BASELINE "
+                         "configs[3]); weak = a 2^20 rollout and 65536 rows per rank; both (default) = strong is `value`, the weak "
+                         "figure is measured in the same run and printed beside it.  N = 1: the two are the same workload.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the ROCm-eager baseline, the hook-level leg, the H2D "
                     "measurement and the other workloads (profiling runs)")
@@ -442,11 +497,21 @@ def main():
                                  with_cpu=not args.no_cpu_baseline)), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the N = 1 bench (`python bench.py --gpus N ...`): become the launcher of the N ranks
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     # TS_BENCH_ONE_GPU=1: a dry run of the N > 1 path on a single GPU (every rank on cuda:0, rendezvous over gloo, the
@@ -473,33 +538,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    learner = Learner(device, rank, world)
     import bench_init
 
-    bench_init.warm_clocks(device)            # idle clocks -> load clocks before the W warm-up steps (not an update step)
-    for _ in range(args.warmup):
-        learner.update_once()
-    barrier()
-    t0 = time.perf_counter()
-    total_steps = 0
-    for _ in range(args.steps):
-        losses, steps = learner.update_once()
-        total_steps += steps
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
+    ar, exchange = make_exchange(device, rank, world)
+    legs = ["strong", "weak"] if (args.scaling == "both" and world > 1) else [("strong" if args.scaling == "both" else args.scaling)]
+
+    def timed_leg(scaling):
+        """W warm-up + exactly K timed update()s, barrier + synchronize on both sides, MAX over the ranks."""
+        learner = Learner(device, rank, world, scaling, allreduce=ar, exchange=exchange)
+        bench_init.warm_clocks(device)        # idle clocks -> load clocks before the W warm-up steps (not an update step)
+        for _ in range(args.warmup):
+            learner.update_once()
+        barrier()
+        t0 = time.perf_counter()
+        total = 0
+        for _ in range(args.steps):
+            losses, steps = learner.update_once()
+            total += steps
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        if ar is not None:
+            ar.check()                        # a one-shot exchange whose peer never arrived would have left stale sums
+        return learner, el, total, [float(x) for x in losses[-1].tolist()]
+
+    learner, elapsed, total_steps, final_loss = timed_leg(legs[0])
+    head = legs[0]
+    # strong: `total_steps` gradient steps of the GLOBAL minibatch; weak: every rank ran that many on its own 65,536 rows
+    value = total_steps / elapsed * (world if head == "weak" else 1)
+    beside = None
+    if len(legs) > 1:
+        keep = learner
+        l2, el2, st2, _ = timed_leg(legs[1])
+        beside = {"scaling": legs[1], "value": world * st2 / el2, "unit": "update-steps/s", "ms_per_step": el2 / args.steps * 1e3,
+                  "workload": f"every rank its own 2^20-transition rollout, local minibatch {MINIBATCH} (the per-GPU work of N = 1)"}
+        del l2
+        torch.cuda.empty_cache()
+        learner = keep
+    exchange_us = time_exchange(device, world, ar, learner.eng.P + 4)
+    rccl_ranks = None
+    if ar is not None:
+        rccl_ranks = {"communicator": ar.ranks()[0], "rccl_reported": ar.ranks()[1]}
+    elif world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final_loss = [float(x) for x in losses[-1].tolist()]
-    exchange = learner.exchange
-    if world > 1 and learner.dp is not None and getattr(learner.dp, "_allreduce", None) is not None:
-        learner.dp._allreduce.check()           # a one-shot exchange whose peer never arrived would have left stale sums
+        rccl_ranks = {"communicator": dist.get_world_size(), "rccl_reported": dist.get_world_size() if dist.get_backend() == "nccl" else 0}
 
     # per-kernel durations with HIP events on the launch stream, one more (rank-local) update()
     roof, extra = None, {}
+    n_chunks = learner.n_trans // learner.minibatch
     if rank == 0:
         b = learner.preprocess(local_only=True)
         torch.cuda.synchronize()
@@ -509,40 +601,44 @@ def main():
             perms = [learner.next_perm() for _ in range(REPEAT)]
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            learner.eng.update(b, MINIBATCH, REPEAT, perms)
+            learner.eng.update(b, learner.minibatch, REPEAT, perms)
             torch.cuda.synchronize()
             t_inner = time.perf_counter() - t1
             prof = learner.ws.profile_end()
             step_ms, step_n = prof["ppo_step"]
             avg_s = step_ms / max(step_n, 1) * 1e-3
-            achieved = FLOP_PER_SAMPLE_STEP * MINIBATCH / avg_s / 1e12
+            achieved = FLOP_PER_SAMPLE_STEP * learner.minibatch / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": "ppo_step2_kernel", "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": STEP_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
-                    "avg_launch_us": avg_s * 1e6, "launches": step_n,
-                    "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * MINIBATCH}
+                    "traffic": STEP_HBM_TRAFFIC_BYTES if learner.minibatch == MINIBATCH else None,
+                    "traffic_source": TRAFFIC_SOURCE,
+                    "avg_launch_us": avg_s * 1e6, "launches": step_n, "rows_per_launch": learner.minibatch,
+                    "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * learner.minibatch}
             extra["kernel_us"] = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()}
-            extra["inner_update_steps_per_s"] = REPEAT * (N_TRANS // MINIBATCH) / t_inner
+            extra["inner_update_steps_per_s"] = REPEAT * n_chunks / t_inner
         t_gae = time_gae(learner)
-        gbps = GAE_BYTES_PER_TRANSITION * N_TRANS / t_gae / 1e9
-        extra["gae_transitions_per_s"] = N_TRANS / t_gae
+        gbps = GAE_BYTES_PER_TRANSITION * learner.n_trans / t_gae / 1e9
+        extra["gae_transitions_per_s"] = learner.n_trans / t_gae
         extra["roofline_gae"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps,
                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                                 "traffic": GAE_HBM_TRAFFIC_BYTES, "traffic_source": TRAFFIC_SOURCE,
-                                 "avg_launch_us": t_gae * 1e6,
-                                 "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * N_TRANS}
-        n_l, t_l = time_gae_large(learner)
-        gbps_l = GAE_BYTES_PER_TRANSITION * n_l / t_l / 1e9
-        extra["roofline_gae_2p24"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps_l,
-                                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_l / PEAK_HBM_GBPS,
-                                      "traffic": None, "avg_launch_us": t_l * 1e6, "transitions": n_l,
-                                      "transitions_per_s": n_l / t_l,
-                                      "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * n_l}
+                                 "traffic": GAE_HBM_TRAFFIC_BYTES if learner.n_trans == N_TRANS else None,
+                                 "traffic_source": TRAFFIC_SOURCE,
+                                 "avg_launch_us": t_gae * 1e6, "transitions": learner.n_trans,
+                                 "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * learner.n_trans}
+        for key, envs in (("roofline_gae_2p24", 8192), ("roofline_gae_2p24_c2_layout", N_ENV)):
+            # 2^24 transitions as 8192 sub-buffers x 2048 slots (C2's slot count) and as C2's own 512 sub-buffers x 32768
+            n_l, t_l = time_gae_large(learner, n_env=envs)
+            gbps_l = GAE_BYTES_PER_TRANSITION * n_l / t_l / 1e9
+            extra[key] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps_l,
+                          "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_l / PEAK_HBM_GBPS,
+                          "traffic": None, "avg_launch_us": t_l * 1e6, "transitions": n_l, "sub_buffers": envs,
+                          "transitions_per_s": n_l / t_l,
+                          "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * n_l}
         t1 = time.perf_counter()
         for _ in range(3):
             learner.preprocess(local_only=True)
         torch.cuda.synchronize()
-        extra["preprocess_transitions_per_s"] = 3 * N_TRANS / (time.perf_counter() - t1)
+        extra["preprocess_transitions_per_s"] = 3 * learner.n_trans / (time.perf_counter() - t1)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -554,6 +650,7 @@ def main():
                                    "h2d_ms": t_h2d * 1e3, "bytes": H2D_BYTES_PER_UPDATE,
                                    "note": "`value` with one pinned-host -> HBM copy of the 2^20-transition batch added to every update()"}
         extra["rocm_eager_baseline"] = rocm_eager_baseline(device)
+        extra["recompute_advantage"] = recompute_leg(learner, args.steps)
         del learner
         torch.cuda.empty_cache()
         extra["hook_level"] = hook_level(device)                                   # device-side minibatch permutations
@@ -562,27 +659,75 @@ def main():
         extra["other_workloads"] = other_workloads()
 
     if rank == 0:
+        if head == "strong":
+            shard = (f"ONE rollout of 512 envs x 2048 steps = 2^20 transitions" +
+                     (f" sharded over {world} ranks by env id ({learner_desc(world)}), global minibatch {MINIBATCH} = "
+                      f"{MINIBATCH // world} rows per rank per step" if world > 1 else f", minibatch {MINIBATCH}"))
+        else:
+            shard = f"512 envs x 2048 steps = 2^20 transitions PER GPU, local minibatch {MINIBATCH}"
         out = {
             "metric": "PPO learn() update-steps/sec (minibatch 65536, preprocessing incl.) + GAE transitions/sec; "
                       "cpu_baseline / rocm_eager_baseline are PORTS of the reference path (oracle/), kind=port",
-            "value": world * total_steps / elapsed,
+            "value": value,
             "unit": "update-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": head, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 PPO MuJoCo-shape rollout: 512 envs x 2048 steps = 2^20 transitions/GPU, "
-                                   "obs 17, act 6, MLP[64,64] actor-critic, minibatch 65536, repeat 10",
-                       "gradient_steps_per_step": REPEAT * (N_TRANS // MINIBATCH),
-                       "transitions_per_step": N_TRANS, "parallelism": f"dp{world}", "exchange": exchange},
+            "config": {"workload": f"C2 PPO MuJoCo-shape rollout ({'BASELINE configs[3]' if world > 1 and head == 'strong' else 'BASELINE configs[1]'}): "
+                                   f"{shard}, obs 17, act 6, MLP[64,64] actor-critic, repeat 10, recompute_advantage off",
+                       "gradient_steps_per_step": total_steps // max(args.steps, 1),
+                       "transitions_per_step": N_TRANS * (world if head == "weak" else 1),
+                       "parallelism": f"dp{world}", "exchange": exchange},
             "roofline": roof, "cpu_baseline": cpu, "final_losses": final_loss,
         }
+        if world > 1:
+            out["exchange_us"] = exchange_us
+            out["exchange_ranks"] = rccl_ranks
+        if beside is not None:
+            out["weak_scaling" if beside["scaling"] == "weak" else "strong_scaling"] = beside
         out.update(extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
 
         dist.destroy_process_group()
+
+
+def learner_desc(world):
+    from tianshou_amd.distributed import shard_envs
+
+    sizes = sorted({shard_envs(N_ENV, r, world)[1] - shard_envs(N_ENV, r, world)[0] for r in range(world)})
+    return " / ".join(str(x) for x in sizes) + " sub-buffers per rank"
+
+
+def recompute_leg(learner, steps):
+    """The same update() with recompute_advantage=True (the default of examples/mujoco/mujoco_ppo.py:56; ppo.py:174-178:
+    V(s), V(s'), GAE and the return normalisation are redone before every repeat after the first).  The headline runs
+    with it off (SURVEY 8d's C2 definition); this is the second number."""
+    import dataclasses
+
+    from tianshou_amd.ppo import PPOEngine
+
+    cfg = dataclasses.replace(learner.cfg, recompute_advantage=True)
+    eng = PPOEngine(OBS, ACT, init_flat_params(0).to(learner.device), cfg)
+    obs, obs_next, act, rew, term, trunc = learner.data
+
+    def once():
+        b = eng.preprocess(obs, obs_next, act, rew, term, trunc, learner.cut)
+        perms = [learner.next_perm() for _ in range(REPEAT)]
+        return eng.update(b, learner.minibatch, REPEAT, perms)
+
+    once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total = 0
+    for _ in range(max(1, steps)):
+        total += once()[1]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"value": total / el, "unit": "update-steps/s", "ms_per_step": el / max(1, steps) * 1e3,
+            "note": "recompute_advantage=True: 9 more passes of V(s), V(s'), GAE, return normalisation per update()"}
 
 
 if __name__ == "__main__":

@@ -908,6 +908,9 @@ int ts_allreduce_unique_id(uint8_t* h_id128);
 int ts_allreduce_init(const uint8_t* h_id128, int64_t rank, int64_t world, int device, ts_comm** out);
 int ts_allreduce(ts_comm* comm, float* buf, int64_t n, ts_stream_t stream);
 int ts_allreduce_destroy(ts_comm* comm);
+/* *world = the rank count the communicator was created with; *rccl_ranks = what RCCL itself reports for it (ncclCommCount;
+ * 0 for a communicator without an RCCL side, see ts_allreduce_from_small). */
+int ts_allreduce_ranks(const ts_comm* comm, int64_t* world, int64_t* rccl_ranks);
 
 /* One-shot all-reduce for payloads of at most 16,384 floats (64 KB) -- the [gradient | loss parts] vector of a PPO
  * minibatch step is 44 KB and sits on the critical path between two ~55 us kernels, where a ring collective's

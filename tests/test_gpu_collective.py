@@ -130,30 +130,57 @@ def test_one_shot_allreduce_between_two_processes_on_one_gpu():
     assert res == {0: 0, 1: 0}
 
 
-def test_bench_two_ranks_dry_run_on_one_gpu():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, two ranks), with TS_BENCH_ONE_GPU=1: both ranks on
-    cuda:0, rendezvous over gloo, the gradient exchange of every minibatch step on the one-shot IPC all-reduce inside
-    ts_ppo_dp_step.  Checks the N > 1 code path end to end (shard-local preprocessing with global return statistics, the
-    data-parallel update, max-over-ranks timing, one JSON line from rank 0) -- not a measurement."""
+def _bench_dry_run(cmd_tail, launcher, timeout):
     import json
     import os
     import socket
     import subprocess
     import sys
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TS_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(launcher), "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    cmd += [os.path.join(root, "bench.py"), *cmd_tail]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, two ranks), with TS_BENCH_ONE_GPU=1: both ranks on
+    cuda:0, rendezvous over gloo, the gradient exchange of every minibatch step on the one-shot IPC all-reduce inside
+    ts_ppo_dp_step.  Checks the N > 1 code path end to end (one rollout sharded by env id, shard-local preprocessing with
+    global return statistics, the data-parallel update on 32,768-row local minibatches, max-over-ranks timing, the weak leg
+    beside it, one JSON line from rank 0) -- not a measurement."""
+    d = _bench_dry_run(["--gpus", "2", "--steps", "1", "--warmup", "1"], launcher=2, timeout=600)
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["gradient_steps_per_step"] == 160 and d["config"]["transitions_per_step"] == 1 << 20
     assert d["config"]["parallelism"] == "dp2" and "one-shot" in d["config"]["exchange"]
+    assert "configs[3]" in d["config"]["workload"] and "32768 rows per rank" in d["config"]["workload"]
+    assert d["weak_scaling"]["scaling"] == "weak" and d["weak_scaling"]["value"] > 0
+    assert d["exchange_us"] > 0 and d["exchange_ranks"] == {"communicator": 2, "rccl_reported": 0}     # one-shot only here
     assert d["roofline"]["kernel"] == "ppo_step2_kernel" and 0.0 < d["roofline"]["frac"] < 1.0
+    assert d["roofline"]["rows_per_launch"] == 32768
+
+
+def test_bench_eight_ranks_spawns_itself_on_one_gpu():
+    """`python bench.py --gpus 8` without a launcher: bench.py starts torch.distributed.run itself.  Eight IPC peers on one
+    device exercise the 8-way rank-ordered sum of the one-shot all-reduce and the 64-sub-buffer shards / 8,192-row local
+    minibatches of BASELINE configs[3] (strong leg only, to bound the time eight time-sharing ranks need)."""
+    d = _bench_dry_run(["--gpus", "8", "--steps", "1", "--warmup", "1", "--scaling", "strong"], launcher=0, timeout=900)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["gradient_steps_per_step"] == 160 and "8192 rows per rank" in d["config"]["workload"]
+    assert "64 sub-buffers per rank" in d["config"]["workload"]
+    assert d["exchange_ranks"]["communicator"] == 8 and d["exchange_us"] > 0
+    assert all(abs(x) < 1e3 for x in d["final_losses"])

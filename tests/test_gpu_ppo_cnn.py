@@ -159,3 +159,61 @@ def test_values_of_next_observations_through_next_index_equal_a_second_pass():
     assert torch.equal(pre["v_s"], v_s)
     ref = PC.gae_and_return_scaling(eng, buf, idx, v_s, v_next)
     assert torch.equal(pre["returns"], ref["returns"]) and torch.equal(pre["adv"], ref["adv"])
+
+
+def test_bench_scale_minibatch_step_and_inference_vs_oracle():
+    """The configuration the Atari-shape bench line is quoted on: ONE minibatch step at B = 65,536 on uint8 [84, 84, 4]
+    frames with the kernels the engine picks by itself at that size (no ts_conv_set_generation: second-generation forward /
+    input-gradient / weight-gradient kernels for every layer, persistent workgroups looping over hundreds of row tiles, 32-bit
+    offsets at 1.85 G input elements), and one inference pass of the same 65,536 rows.
+
+    The CPU oracle cannot run 65,536 Atari frames in test time, so the minibatch is four differently permuted copies of a
+    16,384-sample base set: the batch-mean losses and their gradients are those of the base set (every sample appears four
+    times in a mean over four times as many rows), while the 65,536 rows sit at unrelated positions in the four quarters of
+    the launch -- a row or tile addressed wrongly anywhere in the launch changes per-row outputs and the sums.  Bars: losses
+    rtol 1e-5 (north_star), per-layer gradients 2e-5 of the layer's largest entry (the layer tests' bar), per-row V / logp
+    1e-5."""
+    from tianshou_amd import ppo_cnn as PC
+
+    c, h, w, A, NB, COPIES = 4, 84, 84, 6, 16384, 4
+    B = NB * COPIES
+    torch.set_num_threads(max(1, min(32, (__import__("os").cpu_count() or 2))))
+    rng = np.random.default_rng(65536)
+    obs = rng.integers(0, 256, size=(NB, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=NB)
+    adv = torch.as_tensor(rng.normal(size=NB).astype(np.float32))
+    ret = torch.as_tensor(rng.normal(size=NB).astype(np.float32) * 2)
+    p = OC.init_params(c, h, w, A, seed=6)
+    with torch.no_grad():
+        lg = torch.cat([OC.actor_forward(p, obs[lo:lo + 2048]) for lo in range(0, NB, 2048)])
+        v_ref = torch.cat([OC.critic_forward(p, obs[lo:lo + 2048]).flatten() for lo in range(0, NB, 2048)])
+        lp_ref = torch.distributions.Categorical(logits=lg).log_prob(torch.as_tensor(act))
+        logp_old = lp_ref + torch.as_tensor(rng.normal(size=NB).astype(np.float32) * 0.2)
+        v_old = v_ref + torch.as_tensor(rng.normal(size=NB).astype(np.float32) * 0.3)
+    cfg = OP.PPOConfig(eps_clip=0.1, dual_clip=None, value_clip=True, advantage_normalization=False, vf_coef=0.25,
+                       ent_coef=0.01, max_grad_norm=0.5, lr=2.5e-4, adam_eps=1e-5, algo="ppo")
+    # oracle: the base set in 8 chunks of 2,048 (sum-reduced losses, so that chunk gradients add up to the batch mean's)
+    pg = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    tot = np.zeros(4)
+    for lo in range(0, NB, 2048):
+        sl = slice(lo, lo + 2048)
+        loss, clip, vf, ent = OC.minibatch_loss(pg, cfg, torch.as_tensor(obs[sl]).float(), torch.as_tensor(act[sl]), adv[sl],
+                                                ret[sl], logp_old[sl], v_old[sl])
+        (loss * (2048 / NB)).backward()
+        tot += np.array([loss.item(), clip.item(), vf.item(), ent.item()]) * (2048 / NB)
+    # the launch: four permuted copies
+    perm = np.concatenate([rng.permutation(NB) for _ in range(COPIES)])
+    obs8 = torch.as_tensor(obs).permute(0, 2, 3, 1).contiguous().cuda()[torch.as_tensor(perm).cuda()].contiguous()
+    assert obs8.dtype == torch.uint8 and obs8.numel() == B * h * w * c > (1 << 30)
+    pick = lambda t: t[torch.as_tensor(perm)].cuda()  # noqa: E731
+    eng = PC.CnnPPOEngine(c, h, w, A, PC.flat_from_torch([p[k] for k in OC.PARAM_ORDER], c, h, w, A), engine_cfg(cfg))
+    v, logp = eng.infer(obs8, act[perm])
+    assert rel_err(v.cpu(), v_ref[perm]) < 1e-5
+    np.testing.assert_allclose(logp.cpu().numpy(), lp_ref[perm].numpy(), rtol=1e-5, atol=1e-5)
+    grad = torch.empty(eng.P, dtype=torch.float32, device="cuda")
+    losses = eng.step(obs8, act[perm], pick(adv), pick(ret), pick(logp_old), pick(v_old), grad_out=grad, apply=False)
+    np.testing.assert_allclose(losses.cpu().numpy(), tot, rtol=1e-5, atol=1e-6)
+    g_ref = PC.flat_from_torch([pg[k].grad for k in OC.PARAM_ORDER], c, h, w, A, device="cpu")
+    off, _ = PC.layer_layout(c, h, w, A)
+    for i in range(5):
+        assert rel_err(grad[off[i]:off[i + 1]].cpu(), g_ref[off[i]:off[i + 1]]) < 2e-5, f"layer {i}"

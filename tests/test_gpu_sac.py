@@ -194,6 +194,39 @@ def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B):
         make_engine(5, 2, 0, cfg, hidden=100)                 # not a multiple of 32
 
 
+def test_twin_critics_on_two_streams_with_generation_2():
+    """hidden = 512 is not on the fused-MLP path, so the twin critics run their backward chains concurrently on the caller's
+    stream and the workspace's side stream; with the second-generation kernels forced on, each chain transposes its
+    weights into workspace scratch (ts_conv2.hip conv2_dgrad).  The scratch and the class tables are per launch stream:
+    three updates must agree with the first-generation kernels (different summation order: 2e-5 on parameters)."""
+    from tianshou_amd import _lib
+
+    lib = _lib.load()
+    obs_dim, act_dim, B, hidden = 40, 4, 128, 512
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02)
+    out = {}
+    prev = lib.ts_conv_set_generation(0)
+    try:
+        for gen in (-1, 1):
+            lib.ts_conv_set_generation(gen)
+            eng, _ = make_engine(obs_dim, act_dim, 4, cfg, hidden)
+            g = torch.Generator().manual_seed(77)
+            stats = None
+            for _ in range(3):
+                obs = torch.randn(B, obs_dim, generator=g)
+                act = torch.rand(B, act_dim, generator=g) * 2 - 1
+                ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+                stats, _w = eng.update_with_batch(obs, act, ret, noise)
+            torch.cuda.synchronize()
+            out[gen] = (stats.cpu(), eng.actor.cpu().clone(), eng.critic1.cpu().clone(), eng.critic2.cpu().clone())
+    finally:
+        lib.ts_conv_set_generation(prev)
+    np.testing.assert_allclose(out[1][0].numpy()[:4], out[-1][0].numpy()[:4], rtol=2e-5, atol=1e-6)
+    for a, b in zip(out[1][1:], out[-1][1:]):
+        assert rel_err(a, b) < 2e-5
+
+
 def test_bad_arguments_fail_loudly():
     from tianshou_amd import _lib
     from tianshou_amd import sac as S

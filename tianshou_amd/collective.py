@@ -118,6 +118,12 @@ class NativeAllReduce:
         """Floats per call the one-shot path takes (0: RCCL only)."""
         return int(_lib.load().ts_allreduce_small_capacity(self._small)) if self._small else 0
 
+    def ranks(self) -> tuple[int, int]:
+        """(ranks the communicator was built for, ranks RCCL reports for it -- 0 without an RCCL side)."""
+        w, r = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().ts_allreduce_ranks(self._comm, C.byref(w), C.byref(r)))
+        return int(w.value), int(r.value)
+
     def __call__(self, buf: torch.Tensor) -> torch.Tensor:
         """In-place sum over the ranks, ordered on the current stream of `buf`'s device."""
         if not self._comm:

@@ -36,6 +36,7 @@ struct Rccl {
     ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
     const char* (*get_error_string)(ncclResult_t) = nullptr;
 };
 
@@ -57,6 +58,7 @@ void load_rccl() {
     r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
     r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
     r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    r.comm_count = reinterpret_cast<decltype(r.comm_count)>(dlsym(h, "ncclCommCount"));
     r.get_error_string = reinterpret_cast<decltype(r.get_error_string)>(dlsym(h, "ncclGetErrorString"));
     if (r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy) g_rccl = r;
 }
@@ -110,6 +112,19 @@ int ts_allreduce(ts_comm* comm, float* buf, int64_t n, ts_stream_t stream) {
                "ts_allreduce: %lld floats exceed the one-shot path and this communicator has no RCCL side", (long long)n);
     const ncclResult_t r = g_rccl.all_reduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, comm->comm, ts::as_stream(stream));
     if (r != ncclSuccess) return rccl_fail("ncclAllReduce", r);
+    return TS_OK;
+}
+
+int ts_allreduce_ranks(const ts_comm* comm, int64_t* world, int64_t* rccl_ranks) {
+    TS_REQUIRE(comm && world && rccl_ranks, TS_ERR_INVALID_ARG, "ts_allreduce_ranks: NULL argument");
+    *world = comm->world;
+    *rccl_ranks = 0;
+    if (comm->comm && g_rccl.comm_count) {
+        int n = 0;
+        const ncclResult_t r = g_rccl.comm_count(comm->comm, &n);
+        if (r != ncclSuccess) return rccl_fail("ncclCommCount", r);
+        *rccl_ranks = n;
+    }
     return TS_OK;
 }
 

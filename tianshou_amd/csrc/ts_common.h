@@ -68,13 +68,16 @@ struct ts_workspace {
     size_t ppo_image_bytes;
     const float* ppo_image_params;
     int ppo_image_key;
-    // transposed weight matrices of linear input-gradient passes (ts_conv2.hip), grown on demand
-    void* conv_scratch;
-    size_t conv_scratch_bytes;
-    // input-gradient class tables of ts_conv2.hip: 16 device-resident slots, keyed by geometry on the host
+    // transposed weight matrices of linear input-gradient passes (ts_conv2.hip), grown on demand.  One buffer per
+    // launch stream of the workspace ([0] the caller's stream, [1] ws->side): the twin critics of the SAC family run
+    // their backward chains concurrently on the two streams with the same workspace.
+    void* conv_scratch[2];
+    size_t conv_scratch_bytes[2];
+    // input-gradient class tables of ts_conv2.hip: 16 device-resident slots, keyed by geometry on the host; slots
+    // 0..7 belong to the caller's stream, 8..15 to ws->side (a slot is only ever rewritten in stream order)
     void* dg_tables;
     long long dg_key[16][16];
-    int dg_next;
+    int dg_next[2];
     // hidden width of the Net[h, h] MLPs of the SAC / TD3 / DDPG / REDQ entry points called with this workspace
     // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
     int mlp_hidden;

@@ -216,17 +216,22 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
 // ------------------------------------------------------------------------------------------------
 // wgrad: rows = k, columns = oc, reduction over output pixels; split over pixel ranges into slabs
 // ------------------------------------------------------------------------------------------------
+// LDS of one weight-gradient workgroup: As | Bs | s_red | s_row.  The caller owns the buffer, so that a kernel that inlines
+// several tile variants (conv_wgrad_group_kernel) overlays them instead of adding them up.
 template <int TM, int TN, int WM, int WN>
-__device__ __forceinline__ void conv_wgrad_body(const GemmArgs& a, const int kt, const int ny, const int split) {
+constexpr int wgrad_smem_floats() { return BK * (WM * TM * 32) + BK * (WN * TN * 32) + THREADS + 2 * BK; }
+
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void conv_wgrad_body(const GemmArgs& a, const int kt, const int ny, const int split, float* smem) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int AQ = BM / 4;                 // float4 per staged row of A
     constexpr int ARS = THREADS / AQ;          // row stride between a thread's A loads
     constexpr int AI = BK / ARS, BJ = BN / 32;
     static_assert(WM * WN == 4, "four waves");
-    __shared__ __attribute__((aligned(16))) float As[BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
-    __shared__ int s_row[2][BK];
-    __shared__ float s_red[THREADS];
+    float* As = smem;                          // [BK * BM], 16-byte aligned
+    float* Bs = As + BK * BM;                  // [BK * BN]
+    float* s_red = Bs + BK * BN;               // [THREADS]
+    int (*s_row)[BK] = reinterpret_cast<int (*)[BK]>(s_red + THREADS);      // [2][BK]
     const ts::ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, h = lane >> 5;
@@ -345,7 +350,8 @@ __device__ __forceinline__ void conv_wgrad_body(const GemmArgs& a, const int kt,
 
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
-    conv_wgrad_body<TM, TN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<TM, TN, WM, WN>()];
+    conv_wgrad_body<TM, TN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // The weight gradients of several layers in ONE launch (the three Linear layers of a SAC-family network, or of both twin
@@ -370,8 +376,11 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_group_kernel(WgradGroup gr
     const int per = gr.gx[i] * gr.gy[i];
     const int split = local / per, rem = local - split * per;
     const int ny = rem / gr.gx[i], kt = rem - ny * gr.gx[i];
-    if (gr.wide[i]) conv_wgrad_body<2, 1, 2, 2>(gr.a[i], kt, ny, split);
-    else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split);
+    constexpr int SMEM = wgrad_smem_floats<2, 1, 2, 2>() > wgrad_smem_floats<1, 1, 4, 1>() ? wgrad_smem_floats<2, 1, 2, 2>()
+                                                                                        : wgrad_smem_floats<1, 1, 4, 1>();
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    if (gr.wide[i]) conv_wgrad_body<2, 1, 2, 2>(gr.a[i], kt, ny, split, smem);
+    else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split, smem);
 }
 
 // out[i] = sum_s slabs[s][i]: a workgroup owns 64 consecutive floats (16 float4 columns) and splits the

@@ -654,6 +654,9 @@ bool big_enough(const ts::ConvGeom& g, int64_t rows) {
     return rows >= CONV2_MIN_ROWS;
 }
 
+// 1 for launches on the workspace's side stream, 0 for everything else (the caller's stream)
+int stream_slot(const ts_workspace* ws, hipStream_t s) { return (ws->side_ready && s == ws->side) ? 1 : 0; }
+
 int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
@@ -711,10 +714,13 @@ int place_classes(DgPlan& plan, int bm, int budget, hipStream_t s, const DgClass
         TS_HIP_CHECK(hipMalloc(&ws->dg_tables, sizeof(DgClass) * MAX_DG_CLASSES * 16));
     }
     DgClass* base = static_cast<DgClass*>(ws->dg_tables);
-    for (int i = 0; i < 16; ++i)
+    // the slots are split between the workspace's two launch streams: a slot is read and rewritten on one stream only,
+    // so the copy below is ordered behind every kernel that still reads the table it replaces
+    const int lane = stream_slot(ws, s);
+    for (int i = 8 * lane; i < 8 * lane + 8; ++i)
         if (memcmp(ws->dg_key[i], key, sizeof(key)) == 0) { *dev = base + (size_t)i * MAX_DG_CLASSES; return TS_OK; }
-    const int slot = ws->dg_next;
-    ws->dg_next = (slot + 1) % 16;
+    const int slot = 8 * lane + ws->dg_next[lane];
+    ws->dg_next[lane] = (ws->dg_next[lane] + 1) % 8;
     memcpy(ws->dg_key[slot], key, sizeof(key));
     DgClass* d = base + (size_t)slot * MAX_DG_CLASSES;
     TS_HIP_CHECK(hipMemcpyAsync(d, plan.classes.data(), sizeof(DgClass) * plan.classes.size(), hipMemcpyHostToDevice, s));
@@ -927,13 +933,14 @@ int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* 
         // dX[m, ic] = sum_oc dY[m, oc] Wt[oc, ic]: a forward pass over the transposed weights (no bias)
         TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "conv2_dgrad: workspace (transposed weights) missing");
         const size_t need = sizeof(float) * (size_t)g.IC * g.OC;
-        if (ws->conv_scratch_bytes < need) {
-            if (ws->conv_scratch) TS_HIP_CHECK(hipFree(ws->conv_scratch));
-            ws->conv_scratch = nullptr; ws->conv_scratch_bytes = 0;
-            TS_HIP_CHECK(hipMalloc(&ws->conv_scratch, need));
-            ws->conv_scratch_bytes = need;
+        const int k = stream_slot(ws, s);          // per launch stream: the twin critics run concurrently (ts_common.h)
+        if (ws->conv_scratch_bytes[k] < need) {
+            if (ws->conv_scratch[k]) TS_HIP_CHECK(hipFree(ws->conv_scratch[k]));
+            ws->conv_scratch[k] = nullptr; ws->conv_scratch_bytes[k] = 0;
+            TS_HIP_CHECK(hipMalloc(&ws->conv_scratch[k], need));
+            ws->conv_scratch_bytes[k] = need;
         }
-        float* wt = static_cast<float*>(ws->conv_scratch);
+        float* wt = static_cast<float*>(ws->conv_scratch[k]);
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)ceil_div(g.OC, 32), (unsigned)ceil_div(g.IC, 32)), dim3(256), 0, s,
                            Wb, g.IC, g.OC, wt);
         TS_LAUNCH_CHECK();
