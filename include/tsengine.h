@@ -344,6 +344,10 @@ int ts_ppo_invalidate_image(ts_workspace* ws);
  * Process-wide; not meant to be flipped while launches are being issued from other threads. */
 int ts_ppo_set_step_mode(int mode);
 int ts_ppo_get_step_mode(void);
+/* ts_ppo_update runs the tail of every gradient step (slab reduction, global-norm clip, Adam, optimizer.step() of
+ * algorithm_base.py:484-500) as one launch whose workgroups meet at a bounded grid barrier.  *error = 1 if a launch on this
+ * workspace ever gave up waiting (its parameters were left untouched and its losses are NaN); synchronises `stream`. */
+int ts_ppo_tail_check(ts_workspace* ws, int* error, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Target networks

@@ -250,9 +250,15 @@ __global__ __launch_bounds__(256) void ppo_build_image_kernel(const float* __res
 // what matters; the odd polynomial that used to give 2 ulp RELATIVE accuracy below 0.5 cost 11 more instructions per
 // value (1,408 per wave and launch, a quarter of the step kernel's VALU stream).  Saturates to +-1 for large |x|.
 __device__ __forceinline__ float fast_tanh(float x) {
+#ifdef TS_TANH_NOSIGN
+    // experiment: without the |x| / copysign pair (5 instead of 6 instructions; absolute error <= 2.4e-7 for x < 0)
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+#else
     const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390081777927f);
     const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
     return copysignf(t, x);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1585,6 +1591,112 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused tail of a gradient step (ts_ppo_update): slab reduction + global gradient norm + clip + Adam + image refresh in ONE
+// launch.  Every workgroup owns 64 slab columns as in ppo_reduce_slabs_kernel; the norm needs every workgroup's partial sum
+// of squares, so the workgroups meet at a grid barrier: all of them are resident at once (the host checks that there are
+// no more workgroups than compute units), each publishes its partial with a write-through store, takes a ticket on a
+// monotonic counter (agent-scope atomic; the host advances the target by the grid size per launch, nothing is ever reset)
+// and polls until the launch's target is reached -- the hand-off idiom of the single-pass GAE scan.  The parameter, moment
+// and image-slot loads of the Adam step are issued BEFORE the barrier, so what follows it is one round trip for the partials
+// and the stores.  The spin is bounded: a workgroup that never sees the target raises the workspace's error word and leaves
+// the parameters untouched (checked by ts_ppo_tail_check / the next ts_ppo_update).
+struct TailSync { unsigned long long ticket; unsigned int error; unsigned int pad; };
+
+__global__ __launch_bounds__(RED_THREADS) void ppo_tail_kernel(const float* __restrict__ slabs, int n_slabs, int slab_w, Dims d,
+                                                              int kp, float* __restrict__ grad, float* __restrict__ sumsq_part,
+                                                              AdamArgs a, TailSync* sync, unsigned long long target) {
+    __shared__ float red[RED_THREADS / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int n_params = d.p_total;
+    float s = 0.f;
+    if (col < slab_w) {
+#pragma unroll 16
+        for (int k = wave; k < n_slabs; k += RED_THREADS / 64) s += slabs[(int64_t)k * slab_w + col];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave != 0) return;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
+    const int pidx = col < slab_w ? slab_col_to_param(col, d, kp) : -1;
+    const bool mine = pidx >= 0 && pidx < n_params;
+    // the Adam step's operands: independent of the barrier, in flight while it is crossed
+    const int pc = mine ? pidx : 0;
+    float m = a.m[pc], v = a.v[pc], par = a.params[pc];
+    const int slot = mine ? a.inv[pc] : -1;
+    if (pidx >= 0 && pidx < n_params + N_EXTRA)
+        __hip_atomic_store(grad + pidx, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read across workgroups below
+    float q = mine ? t * t : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
+    float ent = 0.f;
+    if (blockIdx.x == 0 && lane == 0 && a.losses) {
+        // Normal.entropy() summed over actions, from sigma_param BEFORE this launch's Adam step (see ppo_reduce_slabs_kernel)
+        for (int k = 0; k < d.act; ++k) ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(a.params[d.a_sig + k]));
+    }
+    // ---- grid barrier
+    if (lane == 0) {
+        __hip_atomic_store(sumsq_part + blockIdx.x, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&sync->ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int ok = 1;
+    if (lane == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&sync->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { ok = 0; break; }         // ~1 s: a workgroup of this launch never became resident
+        }
+        if (!ok) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ok = __shfl(ok, 0, 64);
+    if (!ok) return;
+    // ---- global norm: the partials in ppo_adam_kernel's order (thread k of 256 holds partial k, k + 256, ...; a shuffle
+    // tree per 64 threads; the four wave sums added in order) so that both tails give the same bits
+    const int n_part = gridDim.x;
+    float total = 0.f;
+#pragma unroll
+    for (int w = 0; w < ADAM_THREADS / 64; ++w) {
+        float sq = 0.f;
+        for (int k = 64 * w + lane; k < n_part; k += ADAM_THREADS)
+            sq += __hip_atomic_load(sumsq_part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        total += __shfl(sq, 0, 64);
+    }
+    const float norm = sqrtf(total);
+    float scale = 1.f;
+    if (a.max_grad_norm > 0.f) scale = fminf(a.max_grad_norm / (norm + 1e-6f), 1.f);
+    if (blockIdx.x == 0 && lane == 0 && a.losses) {
+        const float clip = __hip_atomic_load(grad + n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float vf = __hip_atomic_load(grad + n_params + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.losses[0] = clip + a.vf_coef * vf - a.ent_coef * ent;   // ppo.py:211
+        a.losses[1] = clip;
+        a.losses[2] = vf;
+        a.losses[3] = ent;
+    }
+    if (mine) {
+        const float gq = t * scale;
+        m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        const float np_ = par + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        a.params[pidx] = np_;
+        a.m[pidx] = m;
+        a.v[pidx] = v;
+        if (slot >= 0) a.image[slot] = np_;
+        const int k = pidx - a.sig_off;
+        if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
+            const float sigma = expf(np_);
+            a.image[a.small0 + 8 + k] = 1.f / (2.f * (sigma * sigma));
+            a.image[a.small0 + 16 + k] = logf(sigma);
+        }
+    }
+}
+
 // packs the batch into per-sample records [n][rec_w]: obs | act | adv ret logp_old v_old | 0-pad
 __global__ __launch_bounds__(256) void ppo_pack_kernel(const float* __restrict__ obs,
                                                        const float* __restrict__ act,
@@ -1847,17 +1959,35 @@ int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d
     return TS_OK;
 }
 
+// Tail of a gradient step in ts_ppo_update.  fused (default): ppo_tail_kernel; split (TS_PPO_TAIL=split, more slab-column
+// workgroups than compute units, or the split-bf16 image format): ppo_reduce_slabs_kernel + ppo_adam_kernel.
+inline bool tail_fused(int slab_w) {
+    static const bool split = [] { const char* e = getenv("TS_PPO_TAIL"); return e && e[0] == 's'; }();
+    return !split && step_mode() != 3 && (slab_w + 63) / 64 <= n_compute_units();
+}
+
+int tail_sync(ts_workspace* ws, hipStream_t s, TailSync** out) {
+    if (!ws->ppo_tail_sync) {
+        TS_HIP_CHECK(hipSetDevice(ws->device));
+        TS_HIP_CHECK(hipMalloc(&ws->ppo_tail_sync, sizeof(TailSync)));
+        TS_HIP_CHECK(hipMemsetAsync(ws->ppo_tail_sync, 0, sizeof(TailSync), s));
+        ws->ppo_tail_target = 0;
+    }
+    *out = static_cast<TailSync*>(ws->ppo_tail_sync);
+    return TS_OK;
+}
+
 // forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
 // grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
 int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
-             float* sumsq, float* losses, hipStream_t s, float* parts = nullptr) {
+             float* sumsq, float* losses, hipStream_t s, float* parts = nullptr, bool reduce = true) {
     const int64_t obs_dim = d.obs;
     int rc = TS_OK;
     const int n_wg = step_grid(g.n_rows);
     g.slabs = slabs; g.slab_w = slab_w;
     TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
     if (rc != TS_OK) return rc;
-    {
+    if (reduce) {
         ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
         hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
                            n_wg, slab_w, d, step_v1() ? 0 : 2 * ks, grad, sumsq, g.params, losses, parts);
@@ -2036,6 +2166,9 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                            d_off, advstats);
         TS_LAUNCH_CHECK();
     }
+    const bool fused = tail_fused(slab_w);
+    TailSync* sync = nullptr;
+    if (fused) { rc = tail_sync(ws, s, &sync); if (rc != TS_OK) return rc; }
     for (int64_t k = 0; k < n_steps; ++k) {
         StepArgs g{};
         g.params = params;
@@ -2048,16 +2181,28 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
-        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s);
+        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s, nullptr, !fused);
         if (rc != TS_OK) return rc;
-        if (grads_out && k == n_steps - 1)
-            TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total,
-                                        hipMemcpyDeviceToDevice, s));
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
         a.losses = losses; a.apply = 1;
         a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
         a.image3 = step_mode() == 3;
+        if (fused) {
+            ws->ppo_tail_target += (unsigned long long)wl.n_red_blocks;
+            {
+                ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
+                hipLaunchKernelGGL(ppo_tail_kernel, dim3(wl.n_red_blocks), dim3(RED_THREADS), 0, s, slabs, step_grid(g.n_rows),
+                                   slab_w, d, step_v1() ? 0 : 2 * ks, grad, sumsq, a, sync, ws->ppo_tail_target);
+            }
+            TS_LAUNCH_CHECK();
+            if (grads_out && k == n_steps - 1)
+                TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total, hipMemcpyDeviceToDevice, s));
+            continue;
+        }
+        if (grads_out && k == n_steps - 1)
+            TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total,
+                                        hipMemcpyDeviceToDevice, s));
         {
             ts::ProfScope prof(ws, TS_KIND_PPO_ADAM, s);
             hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
@@ -2163,6 +2308,17 @@ int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m
         if (rc != TS_OK) return rc;
     }
     return ts_ppo_apply(ws, params, adam_m, adam_v, adam_step, obs_dim, act_dim, step_buf, hp, stream);
+}
+
+int ts_ppo_tail_check(ts_workspace* ws, int* error, ts_stream_t stream) {
+    TS_REQUIRE(ws && error, TS_ERR_INVALID_ARG, "ts_ppo_tail_check: NULL argument");
+    *error = 0;
+    if (!ws->ppo_tail_sync) return TS_OK;
+    TailSync h{};
+    TS_HIP_CHECK(hipMemcpyAsync(&h, ws->ppo_tail_sync, sizeof(h), hipMemcpyDeviceToHost, ts::as_stream(stream)));
+    TS_HIP_CHECK(hipStreamSynchronize(ts::as_stream(stream)));
+    *error = (int)h.error;
+    return TS_OK;
 }
 
 int ts_ppo_set_step_mode(int mode) {
