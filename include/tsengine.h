@@ -335,20 +335,6 @@ int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
                  int64_t act_dim, const float* grad, const ts_ppo_hparams* hp, ts_stream_t stream);
 int ts_ppo_invalidate_image(ts_workspace* ws);
 
-/* Generation of the fused MLP step kernel behind ts_ppo_update / ts_ppo_grad (the reference has one arithmetic: torch
- * fp32, ppo.py:179-216):
- *   2 = fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout;
- *   3 = the GEMMs on the bf16 matrix cores through a three-way operand split (x = x0 + x1 + x2, six bf16 products,
- *       fp32 accumulate: products exact, dropped terms <= 2^-26 |a b|, i.e. below one fp32 rounding);
- *   1 = round-1 kernel (A/B only).  0 restores the environment's choice (TS_PPO_STEP, else the build default).
- * Process-wide; not meant to be flipped while launches are being issued from other threads. */
-int ts_ppo_set_step_mode(int mode);
-int ts_ppo_get_step_mode(void);
-/* ts_ppo_update runs the tail of every gradient step (slab reduction, global-norm clip, Adam, optimizer.step() of
- * algorithm_base.py:484-500) as one launch whose workgroups meet at a bounded grid barrier.  *error = 1 if a launch on this
- * workspace ever gave up waiting (its parameters were left untouched and its losses are NaN); synchronises `stream`. */
-int ts_ppo_tail_check(ts_workspace* ws, int* error, ts_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Target networks
  * ------------------------------------------------------------------------------------------- */

@@ -126,22 +126,6 @@ def test_update_matches_oracle(cfg_name, n, n_env, batch_size, repeat):
     np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
 
 
-@pytest.mark.parametrize("cfg_name", ["mujoco", "plain"])
-def test_split_bf16_step_kernel_matches_oracle(cfg_name):
-    """Step mode 3 (ts_ppo_step3.h: the trunk and dH1 GEMMs on the bf16 matrix cores through a three-way operand split,
-    six products, fp32 accumulate) holds the same bars against the oracle as the fp32-MFMA kernel -- over several
-    optimizer steps, i.e. including the Adam kernel's in-place refresh of the split weight image."""
-    from tianshou_amd import ppo as P
-
-    P.set_step_mode(3)
-    try:
-        assert P.get_step_mode() == 3
-        test_update_matches_oracle(cfg_name, 1000, 4, 300, 2)
-        test_update_matches_oracle(cfg_name, 4096, 16, 4096, 1)
-    finally:
-        P.set_step_mode(0)
-
-
 def _cfg_from_golden(g):
     from tianshou_amd import ppo as P
 

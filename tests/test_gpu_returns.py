@@ -103,22 +103,10 @@ def _long_cut_case():
     np.testing.assert_allclose(out["ret64"].cpu().numpy(), ret_o, rtol=0, atol=1e-12 * scale)
 
 
-@pytest.mark.parametrize("two_pass", [False, True])
-def test_gae_long_cut_list_with_device_side_count(two_pass):
+def test_gae_long_cut_list_with_device_side_count():
     """More than 1024 cuts go through the global cut bitmask; only the first *d_n_cut entries of the (unordered,
-    padded) cut list count, duplicates and the tail of the last word are harmless.  Both scan variants
-    (TS_GAE_TWO_PASS is read once per process, hence the child process)."""
-    if not two_pass:
-        _long_cut_case()
-        return
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", "import tests.test_gpu_returns as t; t._long_cut_case()"], cwd=root,
-                       env={**os.environ, "TS_GAE_TWO_PASS": "1"}, capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+    padded) cut list count, duplicates and the tail of the last word are harmless."""
+    _long_cut_case()
 
 
 def test_gae_no_episode_end_carries_across_all_tiles():

@@ -81,9 +81,6 @@ struct ts_workspace {
     // hidden width of the Net[h, h] MLPs of the SAC / TD3 / DDPG / REDQ entry points called with this workspace
     // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
     int mlp_hidden;
-    // fused PPO tail (ts_ppo.hip ppo_tail_kernel): {ticket u64, error u32} of its grid barrier + the running ticket target
-    void* ppo_tail_sync;
-    unsigned long long ppo_tail_target;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;

@@ -161,7 +161,6 @@ int ts_workspace_destroy(ts_workspace* ws) {
     if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }
     for (int k = 0; k < 2; ++k)
         if (ws->conv_scratch[k]) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->conv_scratch[k]); }
-    if (ws->ppo_tail_sync) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_tail_sync); }
     if (ws->dg_tables) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->dg_tables); }
     if (ws->base || ws->winner || ws->ev || ws->gae_sync) {
         (void)hipSetDevice(ws->device);

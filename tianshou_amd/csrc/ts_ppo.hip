@@ -29,9 +29,6 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-#ifndef TS_PPO_STEP_DEFAULT
-#define TS_PPO_STEP_DEFAULT 2
-#endif
 constexpr int HID = 64;
 constexpr int W2_PITCH = 68;                 // conflict-free ds_read_b128 of 4 consecutive k
 constexpr int W2_SIZE = HID * W2_PITCH;      // floats per net
@@ -456,67 +453,11 @@ __device__ __forceinline__ void tile_write(float* tile, const f32x16& v, int j, 
     for (int r = 0; r < 16; ++r) tile[featF(r, h) * TILE_PITCH + j] = v[r];
 }
 
-// 16 k-step operands of lane (i, h): T[i][16h .. 16h+15]
-__device__ __forceinline__ void tile_read16(const float* tile, int i, int h, float (&o)[16]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + i * TILE_PITCH + 16 * h + 4 * q);
-        o[4 * q] = v[0]; o[4 * q + 1] = v[1]; o[4 * q + 2] = v[2]; o[4 * q + 3] = v[3];
-    }
-}
-
 __device__ __forceinline__ void wave_lds_sync() {
     // wave-private LDS hand-off between lanes of one wave: LDS executes a wave's instructions in
     // order; this only stops the compiler from moving accesses across the hand-off.
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-// sum over lanes 0..31 (the half that owns each sample once), result uniform across the wave.
-// DPP butterflies inside each 16-lane row, then two readlanes.
-__device__ __forceinline__ float sum_half0(float v) {
-    int x = __builtin_bit_cast(int, v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-    x = __builtin_bit_cast(int, v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-    x = __builtin_bit_cast(int, v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));  // row_half_mirror
-    x = __builtin_bit_cast(int, v);
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));  // row_mirror
-    x = __builtin_bit_cast(int, v);
-    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
-    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
-    return r0 + r1;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Cross-wave reduction of one 16-register tile per wave, deterministic, no atomics:
-// every wave parks its tile in R[wave][r][lane]; after a barrier wave w sums rows
-// r = 4w .. 4w+3 over the 4 slots (fixed order) and owns those 256 results.
-constexpr int RED_SLOT = 16 * 64;   // floats per wave slot
-
-constexpr int RED_ROWS = 16 / STEP_WAVES;   // rows of the tile owned by each wave after the reduction
-
-struct RedOut { float v[RED_ROWS]; };
-
-__device__ __forceinline__ RedOut reduce_tile(float* R, const f32x16& c, int wave, int lane) {
-    __syncthreads();                       // previous slice readers are done with R
-#pragma unroll
-    for (int r = 0; r < 16; ++r) R[wave * RED_SLOT + r * 64 + lane] = c[r];
-    __syncthreads();
-    RedOut o;
-#pragma unroll
-    for (int q = 0; q < RED_ROWS; ++q) {
-        float a = 0.f;
-#pragma unroll
-        for (int s = 0; s < STEP_WAVES; ++s) a += R[s * RED_SLOT + (RED_ROWS * wave + q) * 64 + lane];
-        o.v[q] = a;
-    }
-    return o;
-}
-
-__device__ __forceinline__ void slab_put(float* slab, int addr, float v, bool first) {
-    if (first) slab[addr] = v; else slab[addr] += v;
 }
 
 // per-sample inputs of one 32-sample tile.  The wave fetches the 32 packed records with 16-byte
@@ -611,375 +552,6 @@ __device__ __forceinline__ TileIn<KS1> rec_commit(const RecFetch<KS1>& f, const 
     return t;
 }
 
-// One net, one 32-sample tile per wave (the 4 waves of the workgroup in lock step): forward,
-// loss, backward, weight gradients reduced over the workgroup into its slab.
-template <int KS1, bool ACTOR>
-__device__ __forceinline__ void net_tile(float* lds, float* R, float* scratch, const StepArgs& g,
-                                         const Dims& d, const TileIn<KS1>& in, int wave, int lane_in,
-                                         float* slab, bool first) {
-    using L = Lds<KS1, 1>;
-    // Make the lane id opaque here: otherwise LLVM hoists every lane-dependent address of this
-    // (fully unrolled) body out of the tile / net loops into the kernel prologue, where they no
-    // longer fit in registers and get spilled (tens of KB of scratch traffic per wave).
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));
-    constexpr int net = ACTOR ? 0 : 1;
-    [[maybe_unused]] constexpr int MK = ACTOR ? 2 : 10;
-    const int i = lane & 31, h = lane >> 5;
-
-    f32x16 h1[2], h2[2];
-    trunk_forward<KS1, 1>(lds, 0, in.x, i, h, h1, h2);
-    TS_MARK(g, MK + 0);
-
-    // flat-layout offsets of this net inside the slab
-    const int base = ACTOR ? 0 : d.p_actor;
-    const int o_w1 = base, o_b1 = o_w1 + HID * d.obs, o_w2 = o_b1 + HID, o_b2 = o_w2 + HID * HID;
-    const int o_head = o_b2 + HID;                          // Wmu [act][64] | Wv [64]
-    const int n_head = ACTOR ? d.act : 1;
-    const int o_hb = o_head + n_head * HID;                 // bmu [act] | bv [1]
-    const int o_sig = o_hb + d.act;                         // actor only
-    const int o_loss = d.p_total + net;
-
-    constexpr int NA = ACTOR ? ACT_PAD : 1;
-    float dout[NA];          // dL/d(head output) per sample
-    // row 9 of the misc tile, built as soon as the (wave-uniform) sums exist so that they do not
-    // stay live in SGPRs: lanes 0..7 head-bias grads, 8..15 sigma grads, 16 loss sum
-    float misc = 0.f;
-    const float w = in.w;
-    if constexpr (ACTOR) {
-        float mu[ACT_PAD];
-        head_forward<KS1, 1, ACT_PAD>(lds, 0, h, h2, mu);
-        const float* sm = lds + L::SMALL;
-#pragma unroll
-        for (int k = 0; k < ACT_PAD; ++k) mu[k] += sm[k];
-        const float logp = gaussian_logp(mu, in.act, sm, d.act);
-        float A = in.adv;
-        if (g.adv_norm) A = (A - g.adv_stats[0]) / (g.adv_stats[1] + 1e-8f);   // ppo.py:184-186
-        // A2C (a2c.py:266-267): term = -logp * adv, d term / d logp = -adv  == "ratio" fixed at 1
-        const float ratio = g.a2c ? 1.f : expf(logp - in.logp_old);           // :187
-        const float surr1 = ratio * A;
-        const float lo = 1.f - g.eps_clip, hi = 1.f + g.eps_clip;
-        const float surr2 = fminf(fmaxf(ratio, lo), hi) * A;                  // :190
-        const float clip1 = fminf(surr1, surr2);
-        // torch.min backward: the smaller branch takes the gradient; inside the clip range both
-        // branches are the same value and together pass the full gradient.
-        float basek = (surr1 <= surr2) ? A : 0.f;
-        float term;
-        if (g.a2c) {
-            term = -logp * A;
-            basek = A;
-        } else if (g.dual_clip > 0.f) {                                       // :191-194
-            const float clip2 = fmaxf(clip1, g.dual_clip * A);
-            if (A < 0.f) { term = -clip2; if (!(clip1 >= g.dual_clip * A)) basek = 0.f; }
-            else term = -clip1;
-        } else {
-            term = -clip1;                                                    // :196
-        }
-        const float dlogp = -basek * ratio * w;
-        float dsig[ACT_PAD];
-#pragma unroll
-        for (int k = 0; k < ACT_PAD; ++k) {
-            if (k < d.act) {
-                const float inv_var = 2.f * sm[8 + k];
-                const float dlt = in.act[k] - mu[k];
-                dout[k] = dlogp * dlt * inv_var;
-                dsig[k] = dlogp * (dlt * dlt * inv_var - 1.f) - g.ent_coef * w;   // entropy: d/ds = 1
-            } else {
-                dout[k] = 0.f;
-                dsig[k] = 0.f;
-            }
-        }
-        {
-            const float sl = sum_half0(term * w);
-            if (lane == 16) misc = sl;
-        }
-#pragma unroll
-        for (int k = 0; k < ACT_PAD; ++k) {
-            const float sa = sum_half0(dsig[k]);
-            if (lane == 8 + k) misc = sa;
-            const float sb = sum_half0(dout[k]);
-            if (lane == k) misc = sb;
-        }
-    } else {
-        float v[1];
-        head_forward<KS1, 1, 1>(lds, 0, h, h2, v);
-        const float value = v[0] + lds[L::SMALL + 24];
-        const float ret = in.ret;
-        float term, dv;
-        const float vf1 = (ret - value) * (ret - value);
-        if (g.value_clip) {                                                   // ppo.py:199-206
-            const float vo = in.v_old;
-            const float dvo = value - vo;
-            const float vclip = vo + fminf(fmaxf(dvo, -g.eps_clip), g.eps_clip);
-            const float vf2 = (ret - vclip) * (ret - vclip);
-            term = fmaxf(vf1, vf2);
-            // torch.max backward: the larger branch takes the gradient, ties split it; clamp
-            // passes the gradient inside [-eps, eps].  Inside the range v_clip = vo + (v - vo)
-            // differs from v by rounding, so either branch may win there.
-            const float g1 = -2.f * (ret - value);
-            const float g2 = (dvo >= -g.eps_clip && dvo <= g.eps_clip) ? -2.f * (ret - vclip) : 0.f;
-            dv = (vf1 > vf2) ? g1 : ((vf2 > vf1) ? g2 : 0.5f * (g1 + g2));
-        } else {
-            term = vf1;                                                       // :208
-            dv = -2.f * (ret - value);
-        }
-        dout[0] = dv * g.vf_coef * w;
-        {
-            const float sl = sum_half0(term * w);
-            if (lane == 16) misc = sl;
-            const float sb = sum_half0(dout[0]);
-            if (lane == 0) misc = sb;
-        }
-    }
-
-    __builtin_amdgcn_sched_barrier(0);
-    TS_MARK(g, MK + 1);
-    float* SA = scratch;               // A-side tile
-    float* SB = scratch + TILE_SIZE;   // B-side tile
-
-    // ---- head weight gradient: gW[a][f] = sum_s dout[s][a] * H2[s][f]  (lane = feature f).
-    // dout of sample s is broadcast through the 4 padding columns of row s of the two tiles.
-    float gw[NA];
-    tile_write(SA, h2[0], i, h);
-    tile_write(SB, h2[1], i, h);
-    if (lane < 32) {
-        if constexpr (ACTOR) {
-            f32x4 d0 = {dout[0], dout[1], dout[2], dout[3]};
-            f32x4 d1 = {dout[4], dout[5], dout[6], dout[7]};
-            *reinterpret_cast<f32x4*>(SA + lane * TILE_PITCH + 32) = d0;
-            *reinterpret_cast<f32x4*>(SB + lane * TILE_PITCH + 32) = d1;
-        } else {
-            SA[lane * TILE_PITCH + 32] = dout[0];
-        }
-    }
-    wave_lds_sync();
-    {
-        const float* rowp = (lane < 32 ? SA : SB) + (lane & 31) * TILE_PITCH;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) gw[a] = 0.f;
-#pragma unroll 1
-        for (int q = 0; q < 8; ++q) {
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(rowp + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int smp = 4 * q + e;
-                if constexpr (ACTOR) {
-                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(SA + smp * TILE_PITCH + 32);   // uniform address
-                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(SB + smp * TILE_PITCH + 32);
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        gw[a] += d0[a] * hv[e];
-                        gw[a + 4] += d1[a] * hv[e];
-                    }
-                } else {
-                    gw[0] += SA[smp * TILE_PITCH + 32] * hv[e];
-                }
-            }
-        }
-    }
-    wave_lds_sync();
-    __builtin_amdgcn_sched_barrier(0);
-    TS_MARK(g, MK + 2);
-
-    // ---- dZ2 = (dout . Whead) * (1 - h2^2)   (in place in h2)
-    {
-        const float* wh = lds + L::WH + h * (2 * 16 * ACT_PAD);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* p = wh + (t * 16 + r) * ACT_PAD;
-                float dh;
-                if constexpr (ACTOR) {
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(p);
-                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(p + 4);
-                    dh = dout[0] * w0[0] + dout[1] * w0[1] + dout[2] * w0[2] + dout[3] * w0[3] +
-                         dout[4] * w1[0] + dout[5] * w1[1] + dout[6] * w1[2] + dout[7] * w1[3];
-                } else {
-                    dh = dout[0] * p[0];
-                }
-                const float hv = h2[t][r];
-                h2[t][r] = dh * (1.f - hv * hv);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    // ---- dH1^T = W2^T . dZ2^T, then dZ1 = dH1 * (1 - h1^2)
-    f32x16 dz1[2];
-    {
-        const float* w2 = lds + L::W2;
-#pragma unroll
-        for (int t1 = 0; t1 < 2; ++t1) {
-            f32x16 accd = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    accd = mfma32(w2[(32 * t + featF(r, h)) * W2_PITCH + 32 * t1 + i], h2[t][r], accd);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hv = h1[t1][r];
-                accd[r] = accd[r] * (1.f - hv * hv);
-            }
-            dz1[t1] = accd;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    TS_MARK(g, MK + 3);
-
-    // ---- dW2[f2][f1] = sum_s dZ2[s][f2] H1[s][f1];  db2[f2] = sum_s dZ2[s][f2]
-    auto dw2_pair = [&](int tM, int tN) {
-        float av[16], bv[16];
-        tile_read16(SA, i, h, av);
-        tile_read16(SB, i, h, bv);
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) c = mfma32(av[s], bv[s], c);
-        const RedOut o = reduce_tile(R, c, wave, lane);
-#pragma unroll
-        for (int q = 0; q < RED_ROWS; ++q)
-            slab_put(slab, o_w2 + (32 * tM + featF(RED_ROWS * wave + q, h)) * HID + 32 * tN + i, o.v[q], first);
-    };
-    auto db2_rows = [&]() -> float {   // lanes 0..31: row sums of the A tile
-        float s = 0.f;
-        if (lane < 32) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(SA + lane * TILE_PITCH + 4 * q);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-        }
-        return s;
-    };
-    tile_write(SA, h2[0], i, h);      // dZ2 rows 0..31
-    tile_write(SB, h1[0], i, h);
-    wave_lds_sync();
-    const float b2s0 = db2_rows();
-    dw2_pair(0, 0);
-    wave_lds_sync();
-    tile_write(SB, h1[1], i, h);
-    wave_lds_sync();
-    dw2_pair(0, 1);
-    wave_lds_sync();
-    tile_write(SA, h2[1], i, h);      // dZ2 rows 32..63
-    wave_lds_sync();
-    const float b2s1 = db2_rows();
-    dw2_pair(1, 1);
-    wave_lds_sync();
-    tile_write(SB, h1[0], i, h);
-    wave_lds_sync();
-    dw2_pair(1, 0);
-    wave_lds_sync();
-    TS_MARK(g, MK + 4);
-
-    // ---- dW1aug[f1][k] = sum_s dZ1[s][f1] Xaug[s][k]   (k == obs is the bias column)
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) SB[(KS1 * h + s) * TILE_PITCH + i] = in.x[s];
-    if (2 * KS1 < 32) {  // rows never written by x: keep them finite
-        for (int r = 2 * KS1 + h; r < 32; r += 2) SB[r * TILE_PITCH + i] = 0.f;
-    }
-#pragma unroll
-    for (int tM = 0; tM < 2; ++tM) {
-        tile_write(SA, dz1[tM], i, h);
-        wave_lds_sync();
-        float av[16], bv[16];
-        tile_read16(SA, i, h, av);
-        tile_read16(SB, i, h, bv);
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 16; ++s) c = mfma32(av[s], bv[s], c);
-        const RedOut o = reduce_tile(R, c, wave, lane);
-#pragma unroll
-        for (int q = 0; q < RED_ROWS; ++q) {
-            const int f1 = 32 * tM + featF(RED_ROWS * wave + q, h);
-            if (i < d.obs) slab_put(slab, o_w1 + f1 * d.obs + i, o.v[q], first);
-            else if (i == d.obs) slab_put(slab, o_b1 + f1, o.v[q], first);
-        }
-        wave_lds_sync();
-    }
-    TS_MARK(g, MK + 5);
-
-    // ---- misc tile: head weight grads (rows 0..7), b2 (row 8), head bias / sigma / loss (row 9)
-    {
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int a = 0; a < NA; ++a) c[a] = gw[a];
-        // row 8: lane l<32 holds db2[l] of tM = 0; lanes 32..63 need db2 of tM = 1 (held by lanes 0..31)
-        const float up = __shfl(b2s1, lane & 31, 64);
-        c[8] = (lane < 32) ? b2s0 : up;
-        c[9] = misc;
-        const RedOut o = reduce_tile(R, c, wave, lane);
-#pragma unroll
-        for (int q = 0; q < RED_ROWS; ++q) {
-            const int r = RED_ROWS * wave + q;
-            const float v = o.v[q];
-            if (r < 8) { if (r < n_head) slab_put(slab, o_head + r * HID + lane, v, first); }
-            else if (r == 8) slab_put(slab, o_b2 + lane, v, first);
-            else if (r == 9) {
-                if (lane < 8) { if (lane < n_head) slab_put(slab, o_hb + lane, v, first); }
-                else if (lane < 16) { if (ACTOR && lane - 8 < d.act) slab_put(slab, o_sig + lane - 8, v, first); }
-                else if (lane == 16) slab_put(slab, o_loss, v, first);
-            }
-        }
-    }
-}
-
-template <int KS1>
-__global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step_kernel(StepArgs g, Dims d) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    using L = Lds<KS1, 1>;
-    float* R = lds + L::END;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* scratch = R + STEP_WAVES * RED_SLOT + wave * (2 * TILE_SIZE);
-
-    const int64_t n_tiles = (g.n_rows + 31) / 32;
-    const int64_t per_iter = (int64_t)gridDim.x * STEP_WAVES;
-    const int64_t n_iter = (n_tiles + per_iter - 1) / per_iter;   // same for every wave: barriers inside
-    const int64_t tile0 = (int64_t)blockIdx.x * STEP_WAVES + wave;
-    float* slab = g.slabs + (int64_t)blockIdx.x * g.slab_w;
-
-    TS_MARK(g, 0);
-    for (int net = 0; net < 2; ++net) {
-        // the record gathers of the first tile fly while this net's weights are staged
-        // order: row ids (one dependent load) -> weights (independent of everything) -> records
-        const RowId row0 = row_fetch(g, tile0, lane);
-        TS_MARK(g, net ? 21 : 18);
-        if (net) __syncthreads();           // every wave is done reading the previous net's weights
-        TS_MARK(g, net ? 22 : 19);
-        stage_image<KS1, STEP_THREADS>(lds, g.image + net * L::END);
-        RecFetch<KS1> f = rec_fetch<KS1>(g, row0, lane);
-        TS_MARK(g, net ? 23 : 20);
-        __syncthreads();
-        TS_MARK(g, net ? 9 : 1);
-        for (int64_t it = 0; it < n_iter; ++it) {
-            if (it > 0) f = rec_fetch<KS1>(g, row_fetch(g, it * per_iter + tile0, lane), lane);
-            const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
-            if (net == 0) net_tile<KS1, true>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
-            else net_tile<KS1, false>(lds, R, scratch, g, d, in, wave, lane, slab, it == 0);
-        }
-        if (net == 0) TS_MARK(g, 8);
-    }
-    TS_MARK(g, 17);
-}
-
-// =============================================================================================
-// Step kernel, second generation (round 2).  Same arithmetic per sample as net_tile above; what changes is everything
-// around the MFMA chains, which is where a wave of the first version spent 3/4 of its time (phase timing, round 2):
-//   * the weight gradients contract over the WORKGROUP's 128 samples inside the MFMA accumulator: every wave parks
-//     its transposed activation columns in shared [feature][128-sample] tiles (pitch 132: conflict-free ds_write_b32
-//     and ds_read_b128) and then owns whole 32x32 output tiles (dW2: one tile per wave; dW1: the two tiles go to waves
-//     {0,1} for the actor and {2,3} for the critic, the other pair sums the small head / bias / loss rows), which it
-//     writes straight to the workgroup's slab.  7 cross-wave tile reductions (14 barriers, 224 LDS instructions per
-//     wave) per net become 4 barriers; b2's gradient falls out of the A operands already in registers.
-//     The tiles overlay the weight image and the wave scratch areas, which are dead by then (67.6 KB per workgroup).
-//   * the per-sample records are fetched once per tile, not once per net;
-//   * the loss section is branch-free (action / option flags become selects, LDS reads are batched) and its 17
-//     wave reductions are row sums of one small transposed LDS tile instead of DPP butterflies + readlanes;
-//   * slab columns use the layout [W1aug[64][2 KS1] | W2 | b2 | head W | head b | sigma] per net, so that no store
-//     address depends on obs_dim; ppo_reduce_slabs_kernel maps columns to flat parameter indices.
 constexpr int P128 = 132;                      // pitch (floats) of the 128-sample tiles
 constexpr int T2_FLOATS = 128 * P128;          // phase A: dZ2^T rows 0..63 | H1^T rows 64..127
 constexpr int T2_XROW = 64;                    // phase B: dZ1^T rows 0..63 | X^T rows 64..95 | misc slots behind row 96
@@ -1009,10 +581,8 @@ __host__ __device__ inline Slab2 slab2_layout(int act, int kp) {
     return L;
 }
 
-// slab column -> flat parameter index (>= p_total: the two loss sums; -1: padding).  kp == 0: first-generation
-// slabs, whose columns are the flat layout itself.
+// slab column -> flat parameter index (>= p_total: the two loss sums; -1: padding)
 __device__ __forceinline__ int slab_col_to_param(int col, const Dims& d, int kp) {
-    if (kp == 0) return col < d.p_total + N_EXTRA ? col : -1;
     const Slab2 L = slab2_layout(d.act, kp);
     if (col >= L.loss) return col < L.loss + N_EXTRA ? d.p_total + (col - L.loss) : -1;
     const int n = col >= L.w1[1];
@@ -1455,8 +1025,6 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
     TS_MARK(g, 17);
 }
 
-#include "ts_ppo_step3.h"
-
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
 // partial sum of squares over the parameter columns (for the global gradient norm).
@@ -1524,7 +1092,6 @@ struct AdamArgs {
     float* image;             // LDS images of the step kernel to refresh (or NULL)
     const int* inv;           // param -> image slot (-1: none)
     int sig_off, act, small0; // sigma_param range and the actor image's SMALL block
-    int image3;               // image / inv use the split-bf16 format of ppo_step3_kernel (ts_ppo_step3.h)
 };
 
 constexpr int ADAM_THREADS = 256;
@@ -1538,7 +1105,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
     const bool mine = a.apply && p < a.n_params;
     const int pc = mine ? p : 0;
     float g_raw = a.grad[pc], m = a.m[pc], v = a.v[pc], par = a.params[pc];
-    const int slot = (mine && a.image) ? a.inv[pc] : (a.image3 ? 0 : -1);
+    const int slot = (mine && a.image) ? a.inv[pc] : -1;
     // global gradient norm: every workgroup re-reduces the (few) partials in the same order
     float sq = 0.f;
     if (a.sumsq_part) {
@@ -1574,12 +1141,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
-        if (a.image && a.image3) {
-            char* img = reinterpret_cast<char*>(a.image);
-            s3::image_put(img, slot, np_);
-            const int k = p - a.sig_off;
-            if (k >= 0 && k < a.act) s3::image_put_sigma(img, k, np_);
-        } else if (a.image) {
+        if (a.image) {
             if (slot >= 0) a.image[slot] = np_;
             const int k = p - a.sig_off;
             if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
@@ -1587,112 +1149,6 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
                 a.image[a.small0 + 8 + k] = 1.f / (2.f * (sigma * sigma));
                 a.image[a.small0 + 16 + k] = logf(sigma);
             }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fused tail of a gradient step (ts_ppo_update): slab reduction + global gradient norm + clip + Adam + image refresh in ONE
-// launch.  Every workgroup owns 64 slab columns as in ppo_reduce_slabs_kernel; the norm needs every workgroup's partial sum
-// of squares, so the workgroups meet at a grid barrier: all of them are resident at once (the host checks that there are
-// no more workgroups than compute units), each publishes its partial with a write-through store, takes a ticket on a
-// monotonic counter (agent-scope atomic; the host advances the target by the grid size per launch, nothing is ever reset)
-// and polls until the launch's target is reached -- the hand-off idiom of the single-pass GAE scan.  The parameter, moment
-// and image-slot loads of the Adam step are issued BEFORE the barrier, so what follows it is one round trip for the partials
-// and the stores.  The spin is bounded: a workgroup that never sees the target raises the workspace's error word and leaves
-// the parameters untouched (checked by ts_ppo_tail_check / the next ts_ppo_update).
-struct TailSync { unsigned long long ticket; unsigned int error; unsigned int pad; };
-
-__global__ __launch_bounds__(RED_THREADS) void ppo_tail_kernel(const float* __restrict__ slabs, int n_slabs, int slab_w, Dims d,
-                                                              int kp, float* __restrict__ grad, float* __restrict__ sumsq_part,
-                                                              AdamArgs a, TailSync* sync, unsigned long long target) {
-    __shared__ float red[RED_THREADS / 64][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;
-    const int n_params = d.p_total;
-    float s = 0.f;
-    if (col < slab_w) {
-#pragma unroll 16
-        for (int k = wave; k < n_slabs; k += RED_THREADS / 64) s += slabs[(int64_t)k * slab_w + col];
-    }
-    red[wave][lane] = s;
-    __syncthreads();
-    if (wave != 0) return;
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
-    const int pidx = col < slab_w ? slab_col_to_param(col, d, kp) : -1;
-    const bool mine = pidx >= 0 && pidx < n_params;
-    // the Adam step's operands: independent of the barrier, in flight while it is crossed
-    const int pc = mine ? pidx : 0;
-    float m = a.m[pc], v = a.v[pc], par = a.params[pc];
-    const int slot = mine ? a.inv[pc] : -1;
-    if (pidx >= 0 && pidx < n_params + N_EXTRA)
-        __hip_atomic_store(grad + pidx, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read across workgroups below
-    float q = mine ? t * t : 0.f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off, 64);
-    float ent = 0.f;
-    if (blockIdx.x == 0 && lane == 0 && a.losses) {
-        // Normal.entropy() summed over actions, from sigma_param BEFORE this launch's Adam step (see ppo_reduce_slabs_kernel)
-        for (int k = 0; k < d.act; ++k) ent += 0.5f + 0.5f * 1.8378770664093453f + logf(expf(a.params[d.a_sig + k]));
-    }
-    // ---- grid barrier
-    if (lane == 0) {
-        __hip_atomic_store(sumsq_part + blockIdx.x, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(&sync->ticket, 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    int ok = 1;
-    if (lane == 0) {
-        int spins = 0;
-        while (__hip_atomic_load(&sync->ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) { ok = 0; break; }         // ~1 s: a workgroup of this launch never became resident
-        }
-        if (!ok) __hip_atomic_store(&sync->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ok = __shfl(ok, 0, 64);
-    if (!ok) return;
-    // ---- global norm: the partials in ppo_adam_kernel's order (thread k of 256 holds partial k, k + 256, ...; a shuffle
-    // tree per 64 threads; the four wave sums added in order) so that both tails give the same bits
-    const int n_part = gridDim.x;
-    float total = 0.f;
-#pragma unroll
-    for (int w = 0; w < ADAM_THREADS / 64; ++w) {
-        float sq = 0.f;
-        for (int k = 64 * w + lane; k < n_part; k += ADAM_THREADS)
-            sq += __hip_atomic_load(sumsq_part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-        total += __shfl(sq, 0, 64);
-    }
-    const float norm = sqrtf(total);
-    float scale = 1.f;
-    if (a.max_grad_norm > 0.f) scale = fminf(a.max_grad_norm / (norm + 1e-6f), 1.f);
-    if (blockIdx.x == 0 && lane == 0 && a.losses) {
-        const float clip = __hip_atomic_load(grad + n_params, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float vf = __hip_atomic_load(grad + n_params + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.losses[0] = clip + a.vf_coef * vf - a.ent_coef * ent;   // ppo.py:211
-        a.losses[1] = clip;
-        a.losses[2] = vf;
-        a.losses[3] = ent;
-    }
-    if (mine) {
-        const float gq = t * scale;
-        m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        const float np_ = par + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
-        a.params[pidx] = np_;
-        a.m[pidx] = m;
-        a.v[pidx] = v;
-        if (slot >= 0) a.image[slot] = np_;
-        const int k = pidx - a.sig_off;
-        if (k >= 0 && k < a.act) {                        // finish_small: 1 / (2 sigma^2), log sigma
-            const float sigma = expf(np_);
-            a.image[a.small0 + 8 + k] = 1.f / (2.f * (sigma * sigma));
-            a.image[a.small0 + 16 + k] = logf(sigma);
         }
     }
 }
@@ -1756,32 +1212,11 @@ __global__ __launch_bounds__(1024) void ppo_adv_stats_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------
 // host side
 template <int KS1>
-size_t step_lds_bytes() {
-    return sizeof(float) * (size_t)(Lds<KS1, 1>::END + STEP_WAVES * RED_SLOT + STEP_WAVES * 2 * TILE_SIZE);
-}
-
-template <int KS1>
 size_t infer_lds_bytes() { return sizeof(float) * (size_t)Lds<KS1, 2>::END; }
-
-// Step-kernel generation.  1: per-tile cross-wave reductions, flat slab columns (TS_PPO_STEP_V1=1 or TS_PPO_STEP=1);
-// 2: fp32 MFMA, shared 128-sample gradient tiles; 3: split-bf16 MFMA (ts_ppo_step3.h).  ts_ppo_set_step_mode()
-// overrides the environment (A/B runs and tests inside one process).
-int g_step_mode_override = 0;
-inline int step_mode() {
-    static const int env = [] {
-        const char* v1 = getenv("TS_PPO_STEP_V1");
-        if (v1 && atoi(v1) != 0) return 1;
-        const char* e = getenv("TS_PPO_STEP");
-        const int m = e ? atoi(e) : 0;
-        return (m >= 1 && m <= 3) ? m : TS_PPO_STEP_DEFAULT;
-    }();
-    return g_step_mode_override ? g_step_mode_override : env;
-}
-inline bool step_v1() { return step_mode() == 1; }
 
 // floats per workgroup slab
 inline int slab_width(const Dims& d, int ks) {
-    return step_v1() ? ((d.p_total + N_EXTRA + 3) & ~3) : slab2_layout(d.act, 2 * ks).width;
+    return slab2_layout(d.act, 2 * ks).width;
 }
 
 inline int ks1_for(int obs) { return (obs + 2) / 2; }  // ceil((obs + 1) / 2)
@@ -1848,22 +1283,16 @@ int n_compute_units() {
 // launches forward/backward of one minibatch into the slabs
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
-    const int mode = step_mode();
-    const size_t lds = mode == 1 ? step_lds_bytes<KS1>()
-                                 : (mode == 3 ? (size_t)s3::LDS_BYTES : sizeof(float) * (size_t)T2_FLOATS);
-    const void* fn = mode == 1 ? reinterpret_cast<const void*>(&ppo_step_kernel<KS1>)
-                               : (mode == 3 ? reinterpret_cast<const void*>(&s3::ppo_step3_kernel<KS1>)
-                                            : reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>));
-    static bool attr_done[4] = {false, false, false, false};
-    if (!attr_done[mode]) {
-        TS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[mode] = true;
+    const size_t lds = sizeof(float) * (size_t)T2_FLOATS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
     }
     {
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-        if (mode == 1) hipLaunchKernelGGL((ppo_step_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
-        else if (mode == 3) hipLaunchKernelGGL((s3::ppo_step3_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
-        else hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1913,7 +1342,6 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
     ImageBuf b;
     b.img_end = 4960 + 128 * ks;                           // Lds<ks, 1>::END
     b.img_bytes = (sizeof(float) * 2 * (size_t)b.img_end + 255) & ~(size_t)255;
-    if (step_mode() == 3) b.img_bytes = (2 * (size_t)s3::IMG_BYTES + 255) & ~(size_t)255;
     b.inv_bytes = (sizeof(int) * (size_t)d.p_total + 255) & ~(size_t)255;
     return b;
 }
@@ -1921,12 +1349,6 @@ inline ImageBuf image_buf(const Dims& d, int ks) {
 // LDS images of both nets + the param -> image-slot table (see ppo_build_image_kernel)
 int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float* image, int* inv) {
     const int64_t obs_dim = d.obs;
-    if (step_mode() == 3) {
-        hipLaunchKernelGGL(s3::ppo_build_image3_kernel, dim3(1), dim3(1024), 0, s, params, d,
-                           reinterpret_cast<char*>(image), inv);
-        TS_LAUNCH_CHECK();
-        return TS_OK;
-    }
     if (inv) TS_HIP_CHECK(hipMemsetAsync(inv, 0xff, sizeof(int) * (size_t)d.p_total, s));   // -1: no image slot
     TS_KS1_DISPATCH(ks, {
         static_assert(Lds<K, 1>::END == 4960 + 128 * K, "image size formula");
@@ -1941,7 +1363,7 @@ int build_image(hipStream_t s, const float* params, const Dims& d, int ks, float
 int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d, int ks, float** image, int** inv) {
     const ImageBuf ib = image_buf(d, ks);
     const size_t need = ib.img_bytes + ib.inv_bytes;
-    const int key = (step_mode() << 24) | (d.obs << 8) | d.act;
+    const int key = (d.obs << 8) | d.act;
     if (ws->ppo_image_bytes < need) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
         if (ws->ppo_image) { TS_HIP_CHECK(hipDeviceSynchronize()); TS_HIP_CHECK(hipFree(ws->ppo_image)); }
@@ -1959,38 +1381,20 @@ int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d
     return TS_OK;
 }
 
-// Tail of a gradient step in ts_ppo_update.  fused (default): ppo_tail_kernel; split (TS_PPO_TAIL=split, more slab-column
-// workgroups than compute units, or the split-bf16 image format): ppo_reduce_slabs_kernel + ppo_adam_kernel.
-inline bool tail_fused(int slab_w) {
-    static const bool split = [] { const char* e = getenv("TS_PPO_TAIL"); return e && e[0] == 's'; }();
-    return !split && step_mode() != 3 && (slab_w + 63) / 64 <= n_compute_units();
-}
-
-int tail_sync(ts_workspace* ws, hipStream_t s, TailSync** out) {
-    if (!ws->ppo_tail_sync) {
-        TS_HIP_CHECK(hipSetDevice(ws->device));
-        TS_HIP_CHECK(hipMalloc(&ws->ppo_tail_sync, sizeof(TailSync)));
-        TS_HIP_CHECK(hipMemsetAsync(ws->ppo_tail_sync, 0, sizeof(TailSync), s));
-        ws->ppo_tail_target = 0;
-    }
-    *out = static_cast<TailSync*>(ws->ppo_tail_sync);
-    return TS_OK;
-}
-
 // forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
 // grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
 int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
-             float* sumsq, float* losses, hipStream_t s, float* parts = nullptr, bool reduce = true) {
+             float* sumsq, float* losses, hipStream_t s, float* parts = nullptr) {
     const int64_t obs_dim = d.obs;
     int rc = TS_OK;
     const int n_wg = step_grid(g.n_rows);
     g.slabs = slabs; g.slab_w = slab_w;
     TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
     if (rc != TS_OK) return rc;
-    if (reduce) {
+    {
         ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
         hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
-                           n_wg, slab_w, d, step_v1() ? 0 : 2 * ks, grad, sumsq, g.params, losses, parts);
+                           n_wg, slab_w, d, 2 * ks, grad, sumsq, g.params, losses, parts);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -2166,9 +1570,6 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                            d_off, advstats);
         TS_LAUNCH_CHECK();
     }
-    const bool fused = tail_fused(slab_w);
-    TailSync* sync = nullptr;
-    if (fused) { rc = tail_sync(ws, s, &sync); if (rc != TS_OK) return rc; }
     for (int64_t k = 0; k < n_steps; ++k) {
         StepArgs g{};
         g.params = params;
@@ -2181,25 +1582,12 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
-        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s, nullptr, !fused);
+        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s);
         if (rc != TS_OK) return rc;
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
         a.losses = losses; a.apply = 1;
         a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
-        a.image3 = step_mode() == 3;
-        if (fused) {
-            ws->ppo_tail_target += (unsigned long long)wl.n_red_blocks;
-            {
-                ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
-                hipLaunchKernelGGL(ppo_tail_kernel, dim3(wl.n_red_blocks), dim3(RED_THREADS), 0, s, slabs, step_grid(g.n_rows),
-                                   slab_w, d, step_v1() ? 0 : 2 * ks, grad, sumsq, a, sync, ws->ppo_tail_target);
-            }
-            TS_LAUNCH_CHECK();
-            if (grads_out && k == n_steps - 1)
-                TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total, hipMemcpyDeviceToDevice, s));
-            continue;
-        }
         if (grads_out && k == n_steps - 1)
             TS_HIP_CHECK(hipMemcpyAsync(grads_out, grad, sizeof(float) * (size_t)d.p_total,
                                         hipMemcpyDeviceToDevice, s));
@@ -2310,25 +1698,6 @@ int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m
     return ts_ppo_apply(ws, params, adam_m, adam_v, adam_step, obs_dim, act_dim, step_buf, hp, stream);
 }
 
-int ts_ppo_tail_check(ts_workspace* ws, int* error, ts_stream_t stream) {
-    TS_REQUIRE(ws && error, TS_ERR_INVALID_ARG, "ts_ppo_tail_check: NULL argument");
-    *error = 0;
-    if (!ws->ppo_tail_sync) return TS_OK;
-    TailSync h{};
-    TS_HIP_CHECK(hipMemcpyAsync(&h, ws->ppo_tail_sync, sizeof(h), hipMemcpyDeviceToHost, ts::as_stream(stream)));
-    TS_HIP_CHECK(hipStreamSynchronize(ts::as_stream(stream)));
-    *error = (int)h.error;
-    return TS_OK;
-}
-
-int ts_ppo_set_step_mode(int mode) {
-    TS_REQUIRE(mode >= 0 && mode <= 3, TS_ERR_INVALID_ARG, "ts_ppo_set_step_mode: mode must be 0 (environment / default) .. 3");
-    g_step_mode_override = mode;
-    return TS_OK;
-}
-
-int ts_ppo_get_step_mode(void) { return step_mode(); }
-
 int ts_ppo_invalidate_image(ts_workspace* ws) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_invalidate_image: workspace is NULL");
     ws->ppo_image_params = nullptr;
@@ -2345,13 +1714,12 @@ int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
     AdamArgs a = adam_args(params, adam_m, adam_v, adam_step, d, hp);
     a.grad = grad; a.sumsq_part = nullptr; a.n_part = 0; a.losses = nullptr; a.apply = 1;
     if (ws && ws->ppo_image && ws->ppo_image_params == params &&
-        ws->ppo_image_key == ((step_mode() << 24) | (d.obs << 8) | d.act)) {
+        ws->ppo_image_key == ((d.obs << 8) | d.act)) {
         // keep ts_ppo_grad's images current (same mechanism as ts_ppo_update)
         const ImageBuf ib = image_buf(d, supported_ks(ks1_for((int)obs_dim)));
         a.image = static_cast<float*>(ws->ppo_image);
         a.inv = reinterpret_cast<const int*>(static_cast<char*>(ws->ppo_image) + ib.img_bytes);
         a.sig_off = d.a_sig; a.act = d.act; a.small0 = ib.img_end - 32;
-        a.image3 = step_mode() == 3;
     }
     hipLaunchKernelGGL(ppo_adam_kernel, dim3((d.p_total + ADAM_THREADS - 1) / ADAM_THREADS),
                        dim3(ADAM_THREADS), 0, ts::as_stream(stream), a);

@@ -245,19 +245,6 @@ __device__ __forceinline__ Aff items_to_aff(const double (&d)[GAE_ITEMS],
     return f;
 }
 
-// pass 1: one affine map per tile
-template <typename RewT, bool VEC>
-__global__ __launch_bounds__(GAE_THREADS) void gae_tile_maps(GaeArgs<RewT> g, double2* tile_map) {
-    __shared__ uint32_t cutmask[GAE_TILE / 32];
-    __shared__ Aff lds[GAE_WAVES];
-    const int64_t tile = blockIdx.x;
-    const int64_t tile_start = tile * GAE_TILE;
-    gae_build_cutmask(g, tile_start, cutmask);
-    double vs[GAE_ITEMS], d[GAE_ITEMS], c[GAE_ITEMS];
-    gae_load_items<RewT, VEC>(g, tile_start + (int64_t)threadIdx.x * GAE_ITEMS, cutmask, vs, d, c);
-    Aff t = block_reduce_aff(items_to_aff(d, c), lds);
-    if (threadIdx.x == 0) tile_map[tile] = make_double2(t.a, t.b);
-}
 
 template <bool VEC, typename RewT>
 __device__ __forceinline__ void gae_store_outputs(const GaeArgs<RewT>& g, int64_t base,
@@ -318,67 +305,8 @@ __device__ __forceinline__ void gae_store_partials(double s1, double s2, int lan
     }
 }
 
-// pass 2: carry-in from later tiles, in-tile suffix scan, outputs
-template <typename RewT, bool VEC>
-__global__ __launch_bounds__(GAE_THREADS) void gae_tile_apply(GaeArgs<RewT> g,
-                                                              const double2* tile_map,
-                                                              int64_t n_tiles, float* adv_out,
-                                                              float* ret_out, double* adv64,
-                                                              double* ret64, double* ret_partials) {
-    __shared__ uint32_t cutmask[GAE_TILE / 32];
-    __shared__ Aff lds[GAE_WAVES];
-    __shared__ double red[2 * GAE_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = blockIdx.x;
-    const int64_t tile_start = tile * GAE_TILE;
-    gae_build_cutmask(g, tile_start, cutmask);
-    double vs[GAE_ITEMS], d[GAE_ITEMS], c[GAE_ITEMS];
-    const int64_t base = tile_start + (int64_t)threadIdx.x * GAE_ITEMS;
-    gae_load_items<RewT, VEC>(g, base, cutmask, vs, d, c);
-    const Aff mine = items_to_aff(d, c);
-
-    // carry-in of the tile: fold the maps of all later tiles, applied to A_n = 0
-    Aff acc = aff_identity();
-    for (int64_t t0 = tile + 1; t0 < n_tiles; t0 += GAE_THREADS) {
-        Aff f = aff_identity();
-        if (t0 + threadIdx.x < n_tiles) {
-            const double2 m = tile_map[t0 + threadIdx.x];
-            f = Aff{m.x, m.y};
-        }
-        acc = compose(acc, block_reduce_aff(f, lds));
-        if (acc.a == 0.0) break;  // an episode ended: nothing further can leak in (uniform)
-    }
-    const double tile_carry = acc.b;
-
-    // suffix scan of the thread maps inside the tile
-    const Aff incl = wave_suffix_scan_aff(mine, lane);
-    Aff excl = shfl_down_aff(incl, 1);
-    if (lane == 63) excl = aff_identity();
-    __syncthreads();
-    if (lane == 0) lds[wave] = incl;
-    __syncthreads();
-    double wave_carry = tile_carry;
-    for (int w = GAE_WAVES - 1; w > wave; --w) wave_carry = lds[w].b + lds[w].a * wave_carry;
-    double x = excl.b + excl.a * wave_carry;  // A of the element right after this thread's items
-
-    double adv[GAE_ITEMS], ret[GAE_ITEMS];
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int k = GAE_ITEMS - 1; k >= 0; --k) {
-        x = d[k] + c[k] * x;
-        adv[k] = x;
-        ret[k] = x + vs[k];
-        if (base + k < g.n) {
-            s1 += ret[k];
-            s2 += ret[k] * ret[k];
-        }
-    }
-    gae_store_outputs<VEC>(g, base, adv, ret, adv_out, ret_out, adv64, ret64);
-    if (ret_partials) gae_store_partials(s1, s2, lane, wave, tile, red, ret_partials);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Single-pass variant: one launch, every input byte read once.  Workgroups claim tiles from the END
+// Single-pass scan: one launch, every input byte read once.  Workgroups claim tiles from the END
 // of the array through a ticket (so a tile only ever waits for tiles claimed before it: no
 // residency assumption, no deadlock), publish their tile map, and fold the maps of the following
 // tiles as soon as those are published.  The maps do not depend on each other (unlike a prefix
@@ -697,24 +625,17 @@ int gae_sync_reserve(ts_workspace* ws, int64_t n_tiles, hipStream_t stream) {
     return TS_OK;
 }
 
-bool gae_force_two_pass() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("TS_GAE_TWO_PASS"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
 template <typename RewT>
 int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g_in, float* adv_out, float* ret_out,
                double* adv64, double* ret64, double* ret_partials, hipStream_t stream) {
     GaeArgs<RewT> g = g_in;
     const int64_t n_tiles = ts::ceil_div(g.n, GAE_TILE);
-    // workspace: [tile maps of the two-pass variant][cut bitmask]
-    const size_t maps_bytes = (sizeof(double2) * (size_t)n_tiles + 255) & ~size_t(255);
+    // workspace: [cut bitmask]
     g.cutbits = nullptr;
     if (g.n_cut > GAE_CUT_SCAN_MAX) {
         const size_t words = (size_t)ts::ceil_div(g.n, 32);
-        if (int rc = ts::ws_reserve(ws, maps_bytes + 4 * words)) return rc;
-        uint32_t* bits = reinterpret_cast<uint32_t*>(static_cast<char*>(ws->base) + maps_bytes);
+        if (int rc = ts::ws_reserve(ws, 4 * words)) return rc;
+        uint32_t* bits = reinterpret_cast<uint32_t*>(ws->base);
         TS_HIP_CHECK(hipMemsetAsync(bits, 0, 4 * words, stream));
         const unsigned blocks = (unsigned)std::min<int64_t>(ts::ceil_div(g.n_cut, 256), 1024);
         hipLaunchKernelGGL(gae_cutbits_kernel, dim3(blocks), dim3(256), 0, stream, g.cut_pos, g.n_cut, g.d_n_cut, g.n, bits);
@@ -725,7 +646,7 @@ int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g_in, float* adv_out, floa
                      (reinterpret_cast<uintptr_t>(g.term) & 7u) == 0 &&
                      (reinterpret_cast<uintptr_t>(g.trunc) & 7u) == 0 && aligned16(adv_out) &&
                      aligned16(ret_out);
-    if (!gae_force_two_pass()) {
+    {
         int rc = gae_sync_reserve(ws, n_tiles, stream);
         if (rc != TS_OK) return rc;
         GaeSyncHeader* hdr = reinterpret_cast<GaeSyncHeader*>(ws->gae_sync);
@@ -756,31 +677,6 @@ int launch_gae(ts_workspace* ws, const GaeArgs<RewT>& g_in, float* adv_out, floa
         TS_LAUNCH_CHECK();
         return TS_OK;
     }
-    int rc = ts::ws_reserve(ws, maps_bytes + (g.cutbits ? 4 * (size_t)ts::ceil_div(g.n, 32) : 0));
-    if (rc != TS_OK) return rc;
-    double2* maps = reinterpret_cast<double2*>(ws->base);
-    {
-        ts::ProfScope prof(ws, TS_KIND_GAE_MAPS, stream);
-        if (vec)
-            hipLaunchKernelGGL((gae_tile_maps<RewT, true>), dim3((unsigned)n_tiles),
-                               dim3(GAE_THREADS), 0, stream, g, maps);
-        else
-            hipLaunchKernelGGL((gae_tile_maps<RewT, false>), dim3((unsigned)n_tiles),
-                               dim3(GAE_THREADS), 0, stream, g, maps);
-    }
-    {
-        ts::ProfScope prof(ws, TS_KIND_GAE_APPLY, stream);
-        if (vec)
-            hipLaunchKernelGGL((gae_tile_apply<RewT, true>), dim3((unsigned)n_tiles),
-                               dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out,
-                               adv64, ret64, ret_partials);
-        else
-            hipLaunchKernelGGL((gae_tile_apply<RewT, false>), dim3((unsigned)n_tiles),
-                               dim3(GAE_THREADS), 0, stream, g, maps, n_tiles, adv_out, ret_out,
-                               adv64, ret64, ret_partials);
-    }
-    TS_LAUNCH_CHECK();
-    return TS_OK;
 }
 
 }  // namespace

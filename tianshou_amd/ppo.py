@@ -101,17 +101,6 @@ class PPOConfig:
             algo={"ppo": 0, "a2c": 1}[self.algo], reserved=0)
 
 
-def set_step_mode(mode: int) -> None:
-    """Generation of the fused step kernel behind `PPOEngine.update` / the data-parallel halves (include/tsengine.h,
-    ts_ppo_set_step_mode): 2 = fp32 MFMA, 3 = split-bf16 MFMA (three bf16 pieces per operand, six products, fp32
-    accumulate), 1 = round-1 kernel, 0 = environment / build default.  Process-wide; for tests and A/B runs."""
-    _lib.check(_lib.load().ts_ppo_set_step_mode(C.c_int(int(mode))))
-
-
-def get_step_mode() -> int:
-    return int(_lib.load().ts_ppo_get_step_mode())
-
-
 def rms_merge(rms, s1: float, s2: float, n: float) -> list[float]:
     """RunningMeanStd.update (utils/statistics.py:99-114) from the batch moments (sum, sum of squares, count):
     [mean, var, count] -> [mean', var', count']."""
