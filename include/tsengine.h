@@ -628,6 +628,22 @@ int ts_mlp_ppo_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     int64_t hidden, int64_t n_act, const float* obs, const int64_t* act, const float* adv,
                     const float* returns, const float* logp_old, const float* v_old, int64_t B, const float* adv_stats,
                     const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream);
+/* The WHOLE `_update_with_batch` of that network in one launch (PPO._update_with_batch, ppo.py:164-224 without
+ * recompute_advantage, + Optimizer.step, algorithm_base.py:484-500) for the small shapes where a gradient step is launch
+ * latency and nothing else (BASELINE.json configs[0]: 310 steps of 64 rows): obs_dim <= 32, hidden == 64, n_act <= 31
+ * (ts_mlp_ppo_update_supported; TS_ERR_UNSUPPORTED otherwise -- the caller loops over ts_mlp_ppo_step).  One persistent
+ * workgroup keeps the weights in LDS and the Adam moments in registers for all n_steps steps.
+ *   obs float32[n, obs_dim], act int64[n], adv / returns / logp_old / v_old float32[n]: the whole preprocessed batch;
+ *   rows int64[h_mb_offset[n_steps]] (device): the concatenated minibatch row lists (the `repeat` permutations of
+ *   Batch.split, batch.py:1205-1215); h_mb_offset (host): step k takes rows[h_mb_offset[k] .. h_mb_offset[k + 1]);
+ *   advantage normalisation uses each minibatch's float64 mean / unbiased std (ppo.py:184-186);
+ *   adam_step0 = optimizer steps taken before this call; losses_out float32[n_steps, 4] = {loss, clip, vf, ent}. */
+int ts_mlp_ppo_update_supported(int64_t obs_dim, int64_t hidden, int64_t n_act);
+int ts_mlp_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step0, int64_t obs_dim,
+                      int64_t hidden, int64_t n_act, const float* obs, const int64_t* act, const float* adv,
+                      const float* returns, const float* logp_old, const float* v_old, int64_t n, const int64_t* rows,
+                      const int64_t* h_mb_offset, int64_t n_steps, const ts_ppo_hparams* hp, float* losses_out,
+                      ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SAC (tanh-Gaussian actor with state-conditioned sigma, twin critics on concat(obs, act), hidden [256, 256])

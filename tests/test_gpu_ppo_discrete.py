@@ -118,3 +118,56 @@ def test_bad_arguments_fail_loudly():
     z = torch.zeros(8)
     with pytest.raises(ValueError):
         eng.step(torch.zeros(8, 4), torch.zeros(7, dtype=torch.int64), z, z, z, z)
+
+
+@pytest.mark.parametrize("obs_dim,A,n,batch,adv_norm,dual,vclip,algo", [
+    (4, 2, 2000, 64, False, None, False, "ppo"),       # configs[0]: the merged last minibatch has 80 rows = two chunks
+    (17, 6, 1500, 150, True, 3.0, True, "ppo"),        # three-chunk minibatches, per-minibatch advantage statistics
+    (32, 31, 500, 64, False, None, False, "a2c"),      # widest observation / head the one-launch kernel takes
+    (3, 1, 70, 64, True, None, True, "ppo")])          # a single merged minibatch of 70 rows, one action
+def test_one_launch_update_equals_the_per_step_path_and_the_oracle(obs_dim, A, n, batch, adv_norm, dual, vclip, algo, monkeypatch):
+    """ts_mlp_ppo_update (ts_mlp_small.hip: every minibatch of every repeat + clip + Adam in one persistent workgroup)
+    against the per-step entry point (ts_mlp_ppo_step per minibatch, the path for networks outside the small envelope) and
+    against the CPU oracle's update(): losses of every gradient step, final parameters and Adam moments."""
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    hidden, repeat = 64, 3
+    cfg = OP.PPOConfig(eps_clip=0.2, dual_clip=dual, value_clip=vclip, advantage_normalization=adv_norm, vf_coef=0.5,
+                       ent_coef=0.01, max_grad_norm=0.5, lr=3e-4, algo=algo)
+    rng = np.random.default_rng(n + obs_dim)
+    obs = rng.normal(size=(n, obs_dim)).astype(np.float32)
+    act = rng.integers(0, A, size=n)
+    pre_np = {"adv": rng.normal(size=n).astype(np.float32), "returns": (rng.normal(size=n) * 2).astype(np.float32),
+              "logp_old": (-np.log(A) + 0.1 * rng.normal(size=n)).astype(np.float32) if A > 1 else (0.05 * rng.normal(size=n)).astype(np.float32),
+              "v_s": rng.normal(size=n).astype(np.float32)}
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    # oracle
+    p0 = OD.init_params(obs_dim, hidden, A, 5)
+    st = OP.PPOState(params={k: v.clone() for k, v in p0.items()})
+    pre_t = {k: torch.as_tensor(v) for k, v in pre_np.items()}
+    losses_o = OC.update(st, cfg, obs, act, pre_t, batch, repeat, perms, net=OD.MlpNet(softmax_output=True))
+    # the two GPU paths
+    buf = DeviceReplayBuffer.from_vector_fill(1, rew=np.zeros(n), terminated=np.zeros(n, bool), truncated=np.zeros(n, bool),
+                                              obs=obs, act=act, obs_next=obs)
+    out = {}
+    for mode in ("one_launch", "per_step"):
+        if mode == "per_step":
+            monkeypatch.setenv("TS_MLP_PPO_PER_STEP", "1")
+        _, eng = make_engine(obs_dim, hidden, A, 5, cfg)
+        pre = {k: torch.as_tensor(v).cuda() for k, v in pre_np.items()}
+        pre["indices"] = torch.arange(n, device="cuda")
+        pre["act"] = torch.as_tensor(act).cuda()
+        losses, steps = eng.update(buf, pre, batch, repeat, perms)
+        torch.cuda.synchronize()
+        out[mode] = (losses.cpu().numpy(), eng.params.cpu().numpy(), eng.adam_m.cpu().numpy(), eng.adam_v.cpu().numpy(), steps,
+                     eng.adam_step)
+    monkeypatch.delenv("TS_MLP_PPO_PER_STEP")
+    a, b = out["one_launch"], out["per_step"]
+    assert a[4] == b[4] == losses_o.shape[0] and a[5] == b[5] == a[4]
+    np.testing.assert_allclose(a[0], np.asarray(losses_o), rtol=5e-5, atol=2e-6)
+    np.testing.assert_allclose(a[0], b[0], rtol=5e-5, atol=2e-6)
+    flat_o = PD.flat_from_torch([st.params[k] for k in OD.PARAM_ORDER], obs_dim, hidden, A, device="cpu").numpy()
+    np.testing.assert_allclose(a[1], flat_o, rtol=1e-5, atol=0.05 * cfg.lr)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=0.05 * cfg.lr)
+    assert rel_err(a[2], b[2]) < 1e-4 and rel_err(a[3], b[3]) < 1e-4

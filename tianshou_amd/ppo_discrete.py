@@ -10,12 +10,14 @@ distribution; the kernels work on the pre-softmax outputs.  No CPU path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
+import numpy as np
 import torch
 
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev, gather_rows
-from .ppo import PPOConfig
+from .ppo import PPOConfig, split_offsets
 from .ppo_cnn import adv_stats_of, gae_and_return_scaling, run_minibatches
 
 TRUNK_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
@@ -138,6 +140,27 @@ class DiscretePPOEngine:
         """ppo.py:164-224.  `perms`: `repeat` permutations of range(N) (NumPy arrays for seed-exact parity with
         Batch.split, batch.py:1209, or int64 device tensors).  -> (losses float32[steps, 4], steps)."""
         obs_all = gather_rows(buffer.obs, pre["indices"])
+        n = pre["indices"].numel()
+        lib = _lib.load()
+        if lib.ts_mlp_ppo_update_supported(*self._dims()) and not os.environ.get("TS_MLP_PPO_PER_STEP"):
+            # small network: the whole loop (every minibatch of every repeat, clip + Adam included) is ONE launch
+            if perms is None:
+                perms = [np.random.permutation(n) for _ in range(repeat)]
+            offs = split_offsets(n, batch_size, merge_last=True)
+            rows = torch.cat([_i64_dev(perms[r], self.device).reshape(-1) for r in range(repeat)]).contiguous()
+            h_off = np.asarray([r * n + o for r in range(repeat) for o in offs[:-1]] + [repeat * n], dtype=np.int64)
+            n_steps = h_off.size - 1
+            f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1).contiguous()  # noqa: E731
+            losses = torch.empty((n_steps, 4), dtype=torch.float32, device=self.device)
+            hp = self.cfg.to_c()
+            _lib.check(lib.ts_mlp_ppo_update(
+                self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step),
+                *self._dims(), _lib.ptr(self._obs(obs_all)), _lib.ptr(_i64_dev(pre["act"], self.device).reshape(-1).contiguous()),
+                _lib.ptr(f32(pre["adv"])), _lib.ptr(f32(pre["returns"])), _lib.ptr(f32(pre["logp_old"])), _lib.ptr(f32(pre["v_s"])),
+                _lib.i64(n), _lib.ptr(rows), h_off.ctypes.data_as(C.c_void_p), _lib.i64(n_steps), C.byref(hp), _lib.ptr(losses),
+                _lib.current_stream(self.device)))
+            self.adam_step += n_steps
+            return losses, n_steps
 
         def step_rows(rows):
             return self.step(obs_all[rows], pre["act"][rows], pre["adv"][rows], pre["returns"][rows],
