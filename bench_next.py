@@ -504,6 +504,16 @@ def run_ppo_discrete(steps, warmup, with_cpu):
     k = count[0]
     dims = [OBS, HID, HID, A + 1]
     flop = 2 * n * mlp_flop(dims) + k * BS * mlp_flop(dims, wgrad=True, dgrad_layers=2)
+    # the one-launch update kernel alone (ts_mlp_ppo_update: every minibatch step of the update in one persistent workgroup)
+    pre = eng.preprocess(buf)
+    perms = [torch.randperm(n, generator=g, device=dev) for _ in range(REPEAT)]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    eng.update(buf, pre, BS, REPEAT, perms)
+    e1.record()
+    torch.cuda.synchronize()
+    upd_us = e0.elapsed_time(e1) * 1e3
     cpu = None
     if with_cpu:
         from oracle import oracle_ppo as OP
@@ -527,8 +537,13 @@ def run_ppo_discrete(steps, warmup, with_cpu):
     return _line("PPO learn() update-steps/sec, CartPole shape (obs 4, MLP[64,64], minibatch 64, preprocessing incl.)",
                  steps * k / dt, "update-steps/s", steps, warmup, dt,
                  f"BASELINE configs[0] shape: {E} envs x {T} steps = {n} transitions, obs f32[4], 2 actions, repeat {REPEAT}",
-                 _roofline(prof, flop, "linear-layer GEMMs; launch-latency-bound at this size"), cpu,
-                 {"gradient_steps_per_update": k, "final_loss": float(losses[-1, 0])})
+                 _roofline(prof, flop, "linear-layer GEMMs of the preprocessing passes; the gradient steps are the one-launch kernel, see `update_launch`"), cpu,
+                 {"gradient_steps_per_update": k, "final_loss": float(losses[-1, 0]),
+                  "update_launch": {"kernel": "mlp_ppo_update_small_kernel (one workgroup, all steps)", "us": upd_us,
+                                    "us_per_gradient_step": upd_us / max(k, 1),
+                                    "algorithmic_flop": k * BS * mlp_flop(dims, wgrad=True, dgrad_layers=2),
+                                    "note": "events around DiscretePPOEngine.update(): row gather + ts_mlp_ppo_update; one CU of 256 -- "
+                                            "a latency figure, not a roofline fraction of the chip"}})
 
 
 def run_reinforce(steps, warmup, with_cpu):

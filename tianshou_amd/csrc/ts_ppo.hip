@@ -242,20 +242,15 @@ __global__ __launch_bounds__(256) void ppo_build_image_kernel(const float* __res
     }
 }
 
-// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): absolute error <= 1.2e-7 over the whole range (one v_exp_f32, one
-// v_rcp_f32, four plain VALU).  The activations enter the next layer as sums of O(1) terms, so the absolute error is
-// what matters; the odd polynomial that used to give 2 ulp RELATIVE accuracy below 0.5 cost 11 more instructions per
-// value (1,408 per wave and launch, a quarter of the step kernel's VALU stream).  Saturates to +-1 for large |x|.
+// tanh(x) = 1 - 2 / (e^{2x} + 1): one v_exp_f32, one v_rcp_f32, three plain VALU.  Absolute error <= 1.2e-7 for x >= 0
+// and <= 2.4e-7 for x < 0 (2 / (e + 1) is rounded in [1, 2) there); saturates to +-1 (e -> inf / 0).  The activations enter
+// the next layer as sums of O(1) terms, so the absolute error is what matters.  History: round 1's odd polynomial below
+// |x| = 0.5 (2 ulp RELATIVE accuracy) cost 11 more instructions per value; rounds 2-3 evaluated the formula on |x| and
+// copied the sign back (6 instructions, symmetric error) -- dropping that pair shortens the step kernel by 0.8 us
+// (profiles/r04_fused_tail_and_tanh_ab.txt) and holds every parity bar of tests/test_gpu_ppo.py / test_gpu_hooks.py.
 __device__ __forceinline__ float fast_tanh(float x) {
-#ifdef TS_TANH_NOSIGN
-    // experiment: without the |x| / copysign pair (5 instead of 6 instructions; absolute error <= 2.4e-7 for x < 0)
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-#else
-    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390081777927f);
-    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-    return copysignf(t, x);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
