@@ -172,13 +172,18 @@ def minibatch_loss(p, cfg: OP.PPOConfig, obs, act, adv, returns, logp_old, v_s, 
 
 
 def update(st: OP.PPOState, cfg: OP.PPOConfig, obs, act, pre: dict, batch_size, repeat: int, perms,
-           collect: dict | None = None, net=_CnnNet) -> np.ndarray:
-    """ppo.py:164-224 (without recompute_advantage) -> losses [steps, 4]."""
+           collect: dict | None = None, net=_CnnNet, recompute=None) -> np.ndarray:
+    """ppo.py:164-224 -> losses [steps, 4].  `recompute` (recompute_advantage, ppo.py:174-178): a callable that runs
+    `_add_returns_and_advantages` again (e.g. `lambda: preprocess(st, cfg, ...)`) and returns the new v_s / returns / adv;
+    it is called before every repeat after the first, log pi_old stays."""
     n = len(obs)
     act_t = torch.as_tensor(np.asarray(act), dtype=torch.int64)
     obs_t = torch.as_tensor(np.asarray(obs), dtype=torch.float32)
     out = []
     for r in range(repeat):
+        if recompute is not None and r > 0:
+            new = recompute()
+            pre = dict(pre, v_s=new["v_s"], returns=new["returns"], adv=new["adv"])
         perm = torch.as_tensor(np.asarray(perms[r], dtype=np.int64))
         for lo, hi in OP.split_slices(n, batch_size or n, merge_last=True):
             rows = perm[lo:hi]

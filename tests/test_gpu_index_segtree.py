@@ -255,6 +255,16 @@ def test_stacked_sample_indices_match_the_reference():
         assert drawn.numel() == 1000 and np.isin(drawn.cpu().numpy(), g[k + "all"]).all()
     with pytest.raises(ValueError):
         buf.sample_indices_stacked(3, stack, positions=[0, 1, 10 ** 6])
+    # manager.py:202-204, 213-214: negative -> no indices; None -> len(all_indices) draws
+    assert buf.sample_indices_stacked(-1, stack).numel() == 0
+    every = buf.sample_indices_stacked(None, stack, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert every.numel() == allv.numel() and np.isin(every.cpu().numpy(), g[k + "all"]).all()
+    # nothing available yet (every episode shorter than the stack): the reference's RandomState.choice([], bs) raises
+    young = DeviceReplayBuffer(offset=np.array([0, 8]), last_index=np.array([1]), lengths=np.array([2]), insertion=np.array([2]),
+                               rew=np.zeros(8), terminated=np.zeros(8, bool), truncated=np.zeros(8, bool))
+    assert young.sample_indices_stacked(0, 4).numel() == 0
+    with pytest.raises(ValueError):
+        young.sample_indices_stacked(5, 4)
 
 
 def test_random_sample_indices_device_rng_distribution():

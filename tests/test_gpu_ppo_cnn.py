@@ -23,7 +23,7 @@ def engine_cfg(cfg):
                      value_clip=cfg.value_clip, advantage_normalization=cfg.advantage_normalization,
                      vf_coef=cfg.vf_coef, ent_coef=cfg.ent_coef, max_grad_norm=cfg.max_grad_norm,
                      return_scaling=cfg.return_scaling, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps,
-                     algo=cfg.algo)
+                     algo=cfg.algo, recompute_advantage=getattr(cfg, "recompute_advantage", False))
 
 
 @pytest.mark.parametrize("c,h,w,A", [(4, 84, 84, 6), (2, 44, 36, 4), (1, 36, 36, 31)])
@@ -233,3 +233,38 @@ def test_bench_scale_minibatch_step_and_inference_vs_oracle():
     # it, holds 1e-6); the bars: largest entry 1e-3, relative L2 error 1e-4 for the trunk, the layer tests' 2e-5 for the heads.
     assert all(e < 1e-3 for e in errs[:4]) and errs[4] < 2e-5, errs
     assert all(e < 1e-4 for e in l2), l2
+
+
+def test_recompute_advantage_matches_oracle():
+    """recompute_advantage=True on the Atari actor-critic (ppo.py:174-178): values, GAE and return scaling redone before every
+    repeat after the first; obs_next read through next(index) (single-frame buffer layout)."""
+    from tianshou_amd import ppo_cnn as PC
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    c, h, w, A, n_env, T, batch, repeat = 2, 44, 36, 4, 3, 30, 32, 3
+    n = n_env * T
+    cfg = OP.PPOConfig(eps_clip=0.1, value_clip=True, advantage_normalization=True, recompute_advantage=True, vf_coef=0.25,
+                       ent_coef=0.01, max_grad_norm=0.5, return_scaling=True, lr=2.5e-4, adam_eps=1e-5, max_batchsize=64)
+    rng = np.random.default_rng(21)
+    obs = rng.integers(0, 256, size=(n, c, h, w), dtype=np.uint8)
+    obs_next = rng.integers(0, 256, size=(n, c, h, w), dtype=np.uint8)
+    act = rng.integers(0, A, size=n)
+    rew, term, trunc = rng.normal(size=n), rng.random(n) < 0.05, np.zeros(n, bool)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    p0 = OC.init_params(c, h, w, A, seed=2)
+    st = OP.PPOState(params={k: v.clone() for k, v in p0.items()})
+    idx, unf = np.arange(n), np.arange(n_env) * T + T - 1
+    o_args = (obs, obs_next, act, rew, term, trunc, idx, unf)
+    pre_o = OC.preprocess(st, cfg, *o_args)
+    losses_o = OC.update(st, cfg, obs, act, pre_o, batch, repeat, perms, recompute=lambda: OC.preprocess(st, cfg, *o_args))
+    eng = PC.CnnPPOEngine(c, h, w, A, PC.flat_from_torch([p0[k] for k in OC.PARAM_ORDER], c, h, w, A), engine_cfg(cfg))
+    buf = DeviceReplayBuffer.from_vector_fill(n_env, rew=rew, terminated=term, truncated=trunc)
+    frames, frames_next = torch.as_tensor(obs).cuda(), torch.as_tensor(obs_next).cuda()
+    pre = eng.preprocess(buf, frames, torch.as_tensor(act).cuda(), 1, obs_next_frames=frames_next, chunk=40)
+    losses, steps = eng.update(buf, frames, pre, 1, batch, repeat, perms)
+    assert steps == losses_o.shape[0] == eng.adam_step
+    np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=5e-5, atol=3e-6)
+    flat = torch.cat([t.reshape(-1) for t in PC.flat_to_torch(eng.params, c, h, w, A)]).cpu().numpy()
+    flat_o = torch.cat([st.params[k].reshape(-1) for k in OC.PARAM_ORDER]).numpy()
+    np.testing.assert_allclose(flat, flat_o, rtol=1e-5, atol=0.05 * cfg.lr)
+    np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)

@@ -171,3 +171,44 @@ def test_one_launch_update_equals_the_per_step_path_and_the_oracle(obs_dim, A, n
     np.testing.assert_allclose(a[1], flat_o, rtol=1e-5, atol=0.05 * cfg.lr)
     np.testing.assert_allclose(a[1], b[1], rtol=1e-5, atol=0.05 * cfg.lr)
     assert rel_err(a[2], b[2]) < 1e-4 and rel_err(a[3], b[3]) < 1e-4
+
+
+@pytest.mark.parametrize("per_step", [False, True])
+def test_recompute_advantage_matches_oracle(per_step, monkeypatch):
+    """recompute_advantage=True (ppo.py:174-178; the default of examples/mujoco/mujoco_ppo.py:56): V(s), V(s'), GAE and the
+    return scaling -- with one more RunningMeanStd update per repeat -- are redone with the current parameters before
+    every repeat after the first.  One-launch path (one launch per repeat) and per-step path against the oracle."""
+    from tianshou_amd import ppo_discrete as PD
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    if per_step:
+        monkeypatch.setenv("TS_MLP_PPO_PER_STEP", "1")
+    obs_dim, hidden, A, n_env, T, batch, repeat = 6, 64, 3, 4, 60, 64, 3
+    n = n_env * T
+    cfg = OP.PPOConfig(eps_clip=0.2, value_clip=True, advantage_normalization=True, recompute_advantage=True, vf_coef=0.5,
+                       ent_coef=0.01, max_grad_norm=0.5, return_scaling=True, lr=1e-3, max_batchsize=4096)
+    rng = np.random.default_rng(12)
+    obs = rng.normal(size=(n, obs_dim)).astype(np.float32)
+    obs_next = rng.normal(size=(n, obs_dim)).astype(np.float32)
+    act = rng.integers(0, A, size=n)
+    rew = rng.normal(size=n)
+    term = rng.random(n) < 0.05
+    trunc = np.zeros(n, bool)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    p0 = OD.init_params(obs_dim, hidden, A, 9)
+    net = OD.MlpNet(softmax_output=True)
+    st = OP.PPOState(params={k: v.clone() for k, v in p0.items()})
+    idx, unf = np.arange(n), np.arange(n_env) * T + T - 1
+    o_args = (obs, obs_next, act, rew, term, trunc, idx, unf)
+    pre_o = OC.preprocess(st, cfg, *o_args, net=net)
+    losses_o = OC.update(st, cfg, obs, act, pre_o, batch, repeat, perms, net=net,
+                         recompute=lambda: OC.preprocess(st, cfg, *o_args, net=net))
+    _, eng = make_engine(obs_dim, hidden, A, 9, cfg)
+    buf = DeviceReplayBuffer.from_vector_fill(n_env, rew=rew, terminated=term, truncated=trunc, obs=obs, act=act, obs_next=obs_next)
+    pre = eng.preprocess(buf)
+    losses, steps = eng.update(buf, pre, batch, repeat, perms)
+    assert steps == losses_o.shape[0] == eng.adam_step
+    np.testing.assert_allclose(losses.cpu().numpy(), np.asarray(losses_o), rtol=5e-5, atol=3e-6)
+    flat_o = PD.flat_from_torch([st.params[k] for k in OD.PARAM_ORDER], obs_dim, hidden, A, device="cpu").numpy()
+    np.testing.assert_allclose(eng.params.cpu().numpy(), flat_o, rtol=1e-5, atol=0.05 * cfg.lr)
+    np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)

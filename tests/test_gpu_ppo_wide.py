@@ -106,3 +106,41 @@ def test_wide_engine_rejects_unsupported_shapes():
         WidePPOEngine(17, 6, 100, torch.zeros(10, device="cuda"), P.PPOConfig())
     with pytest.raises(NotImplementedError):
         WidePPOEngine(17, 33, 64, torch.zeros(10, device="cuda"), P.PPOConfig())
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,hidden,cfg_name", [(376, 17, 256, "mujoco"), (40, 10, 128, "defaults")])
+def test_wide_data_parallel_wrapper_at_world_one_is_bit_identical(obs_dim, act_dim, hidden, cfg_name):
+    """DataParallelWidePPO (ts_ppo_wide_step in gradient-only mode -> exchange -> ts_adam_step) with one rank and no
+    exchange == WidePPOEngine.update (ts_ppo_wide_step with its own clip + Adam): the same kernels on the same buffers,
+    bit for bit -- losses, parameters, Adam moments, ret_rms -- incl. recompute_advantage and advantage normalisation with
+    the wrapper's (global) minibatch statistics.  The multi-rank behaviour of the wrapper's base class is covered on CPU
+    (tests/test_dp_gloo.py)."""
+    from tianshou_amd import ppo as P
+    from tianshou_amd.distributed import DataParallelWidePPO
+    from tianshou_amd.ppo_wide import WidePPOEngine
+
+    n, n_env, batch_size, repeat = 600, 4, 160, 2
+    params, data = problem(n, obs_dim, act_dim, hidden, seed=7)
+    cfg = P.PPOConfig(**CFGS[cfg_name])
+    rng = np.random.default_rng(5)
+    perms = [rng.permutation(n) for _ in range(repeat)]
+    unf = (np.arange(n_env) + 1) * (n // n_env) - 1
+    out = []
+    for wrap in (False, True):
+        eng = WidePPOEngine(obs_dim, act_dim, hidden, engine_flat(params, obs_dim, act_dim, hidden), cfg)
+        runner = DataParallelWidePPO(eng) if wrap else eng
+        b = runner.preprocess(dev(data["obs"]), dev(data["obs_next"]), dev(data["act"]), dev(data["rew"]), dev(data["terminated"]),
+                              dev(data["truncated"]), dev(unf))
+        losses, steps = runner.update(b, batch_size, repeat, perms)
+        torch.cuda.synchronize()
+        out.append((losses.cpu(), eng.params.cpu().clone(), eng.adam_m.cpu().clone(), eng.adam_v.cpu().clone(), steps, eng.adam_step,
+                    list(eng.ret_rms)))
+    a, w = out
+    assert a[4] == w[4] and a[5] == w[5] and a[6] == w[6]
+    for x, y in zip(a[1:4], w[1:4]):
+        if cfg.advantage_normalization:      # the wrapper's statistics come from sums (global_adv_stats), the engine's from
+            np.testing.assert_allclose(y.numpy(), x.numpy(), rtol=1e-5, atol=1e-7)      # torch.std(): last-bit differences
+        else:
+            assert torch.equal(x, y)
+    # the wrapper recomposes loss = clip + vf_coef * vf - ent_coef * ent on the host side of the exchange buffer
+    np.testing.assert_allclose(w[0].numpy(), a[0].numpy(), rtol=1e-5, atol=1e-6)

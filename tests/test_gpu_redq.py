@@ -20,14 +20,14 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def make_engine(obs_dim, act_dim, seed, cfg):
+def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
     from tianshou_amd import redq as RQ
     from tianshou_amd import sac as S
 
-    actor, critic = OR.init_params(obs_dim, act_dim, cfg.ensemble_size, seed)
+    actor, critic = OR.init_params(obs_dim, act_dim, cfg.ensemble_size, seed, hidden)
     eng = RQ.REDQEngine(obs_dim, act_dim, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim),
                         RQ.ensemble_flat_from_torch([critic[k] for k in OR.CRITIC_ORDER], obs_dim, act_dim),
-                        RQ.REDQConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}))
+                        RQ.REDQConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}), hidden=hidden)
     return eng, actor, critic
 
 
@@ -86,6 +86,37 @@ def test_update_gradients_vs_oracle(obs_dim, act_dim, B, E, auto, weighted):
     for t, key in zip(S.actor_flat_to_torch(grads[E * pc:], obs_dim, act_dim), OS.ACTOR_ORDER):
         e_gpu, e_ref = rel_err(t.cpu(), g64[key]), rel_err(col["actor_grads"][key], g64[key])
         assert e_gpu < max(1e-5, 2 * e_ref), (key, e_gpu, e_ref)
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,B,E", [(128, 23, 5, 96, 3), (64, 11, 3, 40, 4)])
+def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B, E):
+    """Net / EnsembleLinear widths other than test_redq.py's 256 (utils/net/common.py:246-369 takes any hidden_sizes): two
+    updates with the actor step (actor_delay = 1) against the oracle -- losses, PER weights, parameters -- on the per-layer
+    GEMM kernels; the width travels with every call (ts_mlp_set_hidden)."""
+    from tianshou_amd import redq as RQ
+    from tianshou_amd import sac as S
+
+    cfg = OR.REDQConfig(auto_alpha=True, log_alpha0=-0.3, target_entropy=-float(act_dim), actor_lr=3e-4, critic_lr=1e-3,
+                        alpha_lr=1e-3, tau=0.02, ensemble_size=E, subset_size=2, actor_delay=1)
+    eng, actor, critic = make_engine(obs_dim, act_dim, 8, cfg, hidden)
+    assert eng.lay == S.layout(obs_dim, act_dim, hidden)
+    for a, k in zip(RQ.ensemble_flat_to_torch(eng.critics, E, obs_dim, act_dim, hidden), OR.CRITIC_ORDER):
+        assert torch.equal(a.cpu(), critic[k]), k
+    st = OR.REDQState.create(actor, critic, cfg)
+    g = torch.Generator().manual_seed(B)
+    for _ in range(2):
+        obs = torch.randn(B, obs_dim, generator=g)
+        act = torch.rand(B, act_dim, generator=g) * 2 - 1
+        ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+        ref = OR.update_with_batch(st, cfg, obs, act, ret, noise, None)
+        stats, w = eng.update_with_batch(obs, act, ret, noise)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[:2], [ref["actor_loss"], ref["critic_loss"]], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5)
+    for t, k in zip(RQ.ensemble_flat_to_torch(eng.critics, E, obs_dim, act_dim, hidden), OR.CRITIC_ORDER):
+        np.testing.assert_allclose(t.cpu().numpy(), st.critic[k].numpy(), rtol=1e-4, atol=0.1 * cfg.critic_lr, err_msg=k)
+    for t, k in zip(S.actor_flat_to_torch(eng.actor, obs_dim, act_dim, hidden), OS.ACTOR_ORDER):
+        np.testing.assert_allclose(t.cpu().numpy(), st.actor[k].numpy(), rtol=1e-4, atol=0.1 * cfg.actor_lr, err_msg=k)
 
 
 @pytest.mark.parametrize("tag", ["min", "mean"])

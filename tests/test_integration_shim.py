@@ -1008,8 +1008,9 @@ def test_redq_subclass_keeps_signatures_and_fails_loudly():
     _fill(buf, 8, (11,), np.zeros((2, 3), np.float32))
     with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
         algo.update(buffer=buf, sample_size=8)
+    assert _redq_algo(hidden=128)._hip_hidden == 128           # any [h, h] with h a multiple of 32 (<= 1024)
     with pytest.raises(NotImplementedError):
-        _redq_algo(hidden=128)
+        _redq_algo(hidden=100)
 
 
 def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
@@ -1022,7 +1023,8 @@ def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
     seen = {"subsets": [], "noise": []}
 
     class FakeREDQ:
-        def __init__(self, obs_dim, act_dim, actor, critics, cfg):
+        def __init__(self, obs_dim, act_dim, actor, critics, cfg, hidden=256):
+            self.hidden = hidden
             assert (obs_dim, act_dim) == (11, 3) and (cfg.ensemble_size, cfg.subset_size, cfg.actor_delay) == (4, 2, 2)
             assert cfg.auto_alpha and cfg.target_mode == "min" and cfg.n_step == 2 and critics.numel() % 4 == 0
             self.obs_dim, self.act_dim, self.cfg = obs_dim, act_dim, cfg
@@ -1482,3 +1484,51 @@ def test_drqn_layout_converters_round_trip_on_cpu():
         off = (k0 + 1) * hidden
         w_ih = flat[off:off + (hidden + 1) * 4 * hidden].reshape(hidden + 1, 4 * hidden)
         assert torch.equal(w_ih[:hidden].t(), t[0]) and torch.equal(w_ih[hidden], t[2])
+
+
+def test_device_permutation_key_follows_numpy_seed_and_travels_in_the_checkpoint():
+    """permutations="device" (HipPPO's default): the shuffle key is one draw from NumPy's global generator at construction
+    -- `np.random.seed` selects it like it selects Batch.split's permutations in the reference -- and (seed, update counter)
+    are part of state_dict(), so a resumed run continues the sequence; a checkpoint of the reference class (no such key)
+    still loads; "host" mode leaves the generator untouched."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch import nn
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.ppo import PPO
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import make_hip_ppo
+
+    def build(cls, **kw):
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                             action_shape=(6,), unbounded=True)
+        critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+        policy = ProbabilisticActorPolicy(actor=actor, dist_fn=lambda ls: Independent(Normal(*ls), 1), action_scaling=True,
+                                          action_bound_method="clip", action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+        return cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), **kw)
+
+    HipPPO = make_hip_ppo()
+    np.random.seed(5)
+    a = build(HipPPO, device="cpu")
+    np.random.seed(5)
+    b = build(HipPPO, device="cpu")
+    np.random.seed(6)
+    c = build(HipPPO, device="cpu")
+    assert a._hip_perm_seed == b._hip_perm_seed != c._hip_perm_seed
+    assert build(HipPPO, device="cpu", perm_seed=11)._hip_perm_seed == 11
+    np.random.seed(5)
+    before = np.random.get_state()[1].copy()
+    build(HipPPO, device="cpu", permutations="host")
+    assert np.array_equal(before, np.random.get_state()[1])            # the reference's stream is not consumed
+    a._hip_updates = 7
+    sd = a.state_dict()
+    assert sd["_hip_perm_state"].tolist() == [a._hip_perm_seed, 7]
+    c.load_state_dict(sd)
+    assert (c._hip_perm_seed, c._hip_updates) == (a._hip_perm_seed, 7)
+    ref_sd = build(PPO).state_dict()
+    c.load_state_dict(ref_sd)                                          # a checkpoint written by the reference class
+    assert (c._hip_perm_seed, c._hip_updates) == (a._hip_perm_seed, 7)

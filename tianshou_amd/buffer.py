@@ -456,11 +456,12 @@ class DeviceReplayBuffer:
         own predecessor (the prev() index kernel; the compaction is a device boolean select).
         batch_size == 0 -> all available indices; > 0 -> `RandomState.choice(all_indices, batch_size)`: pass the reference's
         draws as `positions` (int64[bs], positions into the available indices) to replay a seeded run, otherwise they come
-        from torch's device generator."""
+        from torch's device generator.  None -> len(all_indices) draws (manager.py:213-214); negative -> no indices
+        (manager.py:202-204); batch_size > 0 with nothing available raises ValueError like RandomState.choice([], bs)."""
         if stack_num < 2:
             raise ValueError("sample_indices_stacked is the stack_num > 1 branch")
-        if batch_size is None or batch_size < 0:
-            raise NotImplementedError("sample_indices(None / negative) is not on the device path")
+        if batch_size is not None and batch_size < 0:
+            return torch.empty(0, dtype=torch.int64, device=self.device)
         all_idx = self.sample_indices(0)
         p = all_idx
         for _ in range(stack_num - 2):
@@ -468,8 +469,12 @@ class DeviceReplayBuffer:
         avail = all_idx[p != self.prev(p)]
         if batch_size == 0:
             return avail
+        if batch_size is None:
+            batch_size = int(avail.numel())
+            if batch_size == 0:
+                return avail
         if avail.numel() == 0:
-            return avail
+            raise ValueError("sample_indices: no index has stack_num - 1 earlier frames yet (a must be non-empty)")
         if positions is None:
             positions = torch.randint(0, avail.numel(), (int(batch_size),), device=self.device, generator=generator)
         else:

@@ -235,6 +235,35 @@ class DataParallelPPO:
         return res, n_steps
 
 
+class DataParallelWidePPO(DataParallelPPO):
+    """The same data-parallel update for `tianshou_amd.ppo_wide.WidePPOEngine` (Net[h, h] beyond the fused 64 x 64 kernels,
+    e.g. Humanoid's 376 / 17 / 256 x 256): the local step is ts_ppo_wide_step in gradient-only mode with the global batch
+    size (its loss sums and gradients are already scaled by 1 / global_batch), the exchange moves [gradient | 4 loss
+    parts], clip + Adam run on the summed gradient (ts_adam_step: joint norm over actor + critic, a2c.py:103-107)."""
+
+    def _pack(self, b):
+        return b
+
+    def _begin_update(self):
+        pass
+
+    def _native_comm(self):
+        return None                                   # three calls per step: gradient, exchange, apply
+
+    def _local_grad(self, b, rows, global_batch, adv_stats, out):
+        eng = self.eng
+        eng.step(b, rows, out[eng.P:eng.P + 4], grad_out=out[:eng.P], apply=False, global_batch=global_batch,
+                 adv_stats=adv_stats)
+
+    def _apply(self, grad):
+        eng, cfg = self.eng, self.eng.cfg
+        eng.adam_step += 1
+        _lib.check(_lib.load().ts_adam_step(
+            eng._ws.handle, _lib.ptr(eng.params), _lib.ptr(eng.adam_m), _lib.ptr(eng.adam_v), _lib.ptr(grad), _lib.i64(eng.P),
+            _lib.i64(eng.adam_step), _lib.f64(cfg.lr), _lib.f64(cfg.betas[0]), _lib.f64(cfg.betas[1]), _lib.f64(cfg.adam_eps),
+            _lib.f64(cfg.max_grad_norm or 0.0), _lib.current_stream(eng.device)))
+
+
 class DataParallelDQN:
     """DQN._update_with_batch (dqn.py:381-404) over `world` replicas of a DQNEngine.
 

@@ -38,6 +38,9 @@ class _HipGlue:
       is dropped and rebuilt from the loaded torch state on the next update.  A load into a sub-module
       (`algorithm.policy.load_state_dict(best)`) replaces parameters only: it is noticed through the parameters'
       version counters, the engine's Adam moments are first written into torch.optim and survive the rebuild.
+    Only writes that bump a tensor's version counter are seen (`load_state_dict`, `param.copy_()`, in-place ops on the
+    Parameter); writes through `param.data` (`param.data.copy_()`, optimizer-style `param.data.add_()`, `module.to()`) do
+    NOT bump it -- after such an edit call `algorithm.hip_invalidate()`.
     `_HIP_LR`: (engine cfg field, attribute path of the Algorithm.Optimizer wrapper that owns it)."""
     _HIP_LR: tuple = (("lr", "optim"),)
     _hip_dp_on = False            # classes whose constructor takes data_parallel= call _hip_dp_setup
@@ -145,6 +148,16 @@ class _HipGlue:
         self.__dict__["_hip_versions"] = None
         self._hip_adam_dirty = False
 
+    def hip_invalidate(self, keep_optimizer: bool = True) -> None:
+        """Public: the torch parameters were edited in a way the version check cannot see (`param.data` writes, `.to()`):
+        drop the engine so that the next update rebuilds it from the torch state.  keep_optimizer=True first writes the
+        engine's Adam moments / step counters into torch.optim (they survive the rebuild); False discards them (use after
+        replacing the optimizer state yourself)."""
+        if keep_optimizer and self.__dict__.get("_hip_engine_obj") is not None:
+            self.__dict__["_hip_versions"] = None
+            self._hip_flush()
+        self._hip_invalidate()
+
     def _hip_flush(self) -> None:
         """Engine-side optimizer state -> torch.optim state; the default wrappers store it after every update."""
 
@@ -251,7 +264,7 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
     PPO = _on_policy_base(algo, ref)
 
     class HipPPO(_HipGlue, PPO):
-        def __init__(self, *args, device="cuda", permutations="device", perm_seed=0, data_parallel=False, group=None,
+        def __init__(self, *args, device="cuda", permutations="device", perm_seed=None, data_parallel=False, group=None,
                      allreduce=None, shard_buffer=True, **kwargs):
             """`data_parallel=True` (one process per GPU, torch.distributed initialised): `update()` mirrors only this
             rank's sub-buffers of `buffer` (`shard_buffer`, by env id; pass False when every rank collects into its own
@@ -263,6 +276,9 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             `permutations`: "device" (default) expands a private key (`perm_seed`, the update counter, the repeat and the
             rank) with ts_random_permutation on the GPU: a keyed bijection per repeat, statistically equivalent to
             Batch.split's shuffles, and NumPy's global generator -- which the collector shares -- is left untouched.
+            `perm_seed=None` takes ONE draw from NumPy's global generator at construction, so that `np.random.seed` /
+            `seed_everything` select the shuffle sequence as they do in the reference (pass an int to fix it); the seed and
+            the update counter travel in `state_dict()` (a resumed run continues the sequence).
             "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209): the reference's
             sequence for a given seed (the mode the parity tests use), at ~10 ms of host time per 2^20 entries -- 100 ms
             of a 12 ms update(), i.e. ~1.4 k instead of ~14 k update-steps/s at the C2 size."""
@@ -270,16 +286,31 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             if permutations not in ("host", "device"):
                 raise ValueError("permutations must be 'host' or 'device'")
             self._hip_perms = permutations
+            if perm_seed is None:
+                perm_seed = int(np.random.randint(0, 2**31 - 1)) if permutations == "device" else 0
             self._hip_perm_seed, self._hip_updates = int(perm_seed), 0
             self._hip_device = torch.device(device)
             self._hip_dims = _check_supported(self.policy.actor, self.critic)
             self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer)
-            if data_parallel and self._hip_dims[3] != "fused":
-                raise NotImplementedError("HipPPO(data_parallel=True): the fused MuJoCo-shape engine only (Net[64, 64])")
             self._hip_engine = None
             self._hip_glue_init()
             self._hip_batch = None
             self._hip_synced = False
+
+        # -- the shuffle key is part of the checkpoint -------------------------------------------------
+        def state_dict(self, *args, **kwargs):
+            sd = super().state_dict(*args, **kwargs)
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            sd[prefix + "_hip_perm_state"] = torch.tensor([self._hip_perm_seed, self._hip_updates], dtype=torch.int64)
+            return sd
+
+        def load_state_dict(self, state_dict, *args, **kwargs):
+            state_dict = dict(state_dict)
+            st = state_dict.pop("_hip_perm_state", None)          # absent in checkpoints of the reference class
+            out = super().load_state_dict(state_dict, *args, **kwargs)
+            if st is not None:
+                self._hip_perm_seed, self._hip_updates = int(st[0]), int(st[1])
+            return out
 
         # -- engine life cycle ------------------------------------------------------------------
         def _hip_flat(self, tensors) -> torch.Tensor:
@@ -324,9 +355,9 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
         def _hip_runner(self, eng):
             if not self._hip_dp_on:
                 return eng
-            from .distributed import DataParallelPPO
+            from .distributed import DataParallelPPO, DataParallelWidePPO
 
-            return self._hip_dp(DataParallelPPO, eng)
+            return self._hip_dp(DataParallelPPO if self._hip_dims[3] == "fused" else DataParallelWidePPO, eng)
 
         def _sync_back(self) -> None:
             """After every update(): engine parameters -> nn.Parameters (the collector acts with the torch modules;
@@ -1269,9 +1300,12 @@ def make_hip_redq(ref=None):
             if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != RQ.TIANSHOU_CRITIC_KEYS:
                 raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py")
             w1, w2 = sc[RQ.TIANSHOU_CRITIC_KEYS[0]], sc[RQ.TIANSHOU_CRITIC_KEYS[2]]
-            if sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0] != 256 or w1.dim() != 3 or w1.shape[2] != 256 \
-                    or tuple(w2.shape[1:]) != (256, 256) or w1.shape[0] != self.ensemble_size:
-                raise NotImplementedError("HipREDQ: hidden sizes must be [256, 256], EnsembleLinear critics of ensemble_size")
+            hid = int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0])
+            if hid % 32 or not 32 <= hid <= 1024 or w1.dim() != 3 or w1.shape[2] != hid \
+                    or tuple(w2.shape[1:]) != (hid, hid) or w1.shape[0] != self.ensemble_size:
+                raise NotImplementedError("HipREDQ: hidden sizes [h, h] (h a multiple of 32 up to 1024, the same for the actor "
+                                          "and the EnsembleLinear critics of ensemble_size)")
+            self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim):
                 _adam_of(o)
             self._hip_engine = None
@@ -1297,7 +1331,8 @@ def make_hip_redq(ref=None):
                 dev = self._hip_device
                 eng = self._hip_engine = RQ.REDQEngine(
                     obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
-                    RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev), cfg)
+                    RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev), cfg,
+                    hidden=self._hip_hidden)
                 # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
                 eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev)
                 eng.critic_gradient_step = int(self.critic_gradient_step)
@@ -1340,7 +1375,7 @@ def make_hip_redq(ref=None):
             s = stats.cpu().numpy()                                               # one D2H per update()
             self.critic_gradient_step = eng.critic_gradient_step
             self._last_actor_loss = float(s[0])
-            dims = (eng.obs_dim, eng.act_dim)
+            dims = (eng.obs_dim, eng.act_dim, eng.hidden)
             E = eng.cfg.ensemble_size
             with torch.no_grad():
                 for p, t in zip(params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS), S.actor_flat_to_torch(eng.actor, *dims)):
@@ -1520,8 +1555,6 @@ def make_hip_ppo_cnn(algo: str = "ppo", ref=None):
                     or actor.preprocess is not critic.preprocess or getattr(actor, "softmax_output", True):
                 raise NotImplementedError("HipPPOCnn: actor / critic must share one DQNet(features_only=True, "
                                           "output_dim_added_layer=512) trunk with single-Linear heads (logits)")
-            if getattr(self, "recompute_adv", False):
-                raise NotImplementedError("HipPPOCnn: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
             self._hip_glue_init()
@@ -1621,8 +1654,6 @@ def make_hip_ppo_discrete(algo: str = "ppo", ref=None):
             if not ((softmax and dist_fn is Categorical) or (not softmax and dist_fn is dist_fn_categorical_from_logits)):
                 raise NotImplementedError("HipPPODiscrete: softmax_output=True needs dist_fn=Categorical, "
                                           "softmax_output=False the logits dist_fn")
-            if getattr(self, "recompute_adv", False):
-                raise NotImplementedError("HipPPODiscrete: recompute_advantage is not supported")
             _adam_of(self.optim)
             self._hip_engine = None
             self._hip_glue_init()

@@ -96,14 +96,17 @@ def adv_stats_of(cfg: PPOConfig, adv: torch.Tensor):
     return torch.stack([a64.mean(), a64.std()]).float().contiguous()
 
 
-def run_minibatches(device, n: int, batch_size: int | None, repeat: int, perms, step_rows):
+def run_minibatches(device, n: int, batch_size: int | None, repeat: int, perms, step_rows, recompute=None):
     """The loop of PPO._update_with_batch (ppo.py:174-178): `repeat` passes over Batch.split(batch_size,
-    merge_last=True); step_rows(rows int64 device) -> losses[4].  -> (losses float32[steps, 4], steps)."""
+    merge_last=True); step_rows(rows int64 device) -> losses[4]; `recompute()` (recompute_advantage, ppo.py:175-176) runs
+    before every repeat after the first.  -> (losses float32[steps, 4], steps)."""
     if perms is None:
         perms = [np.random.permutation(n) for _ in range(repeat)]
     offs = split_offsets(n, batch_size, merge_last=True)
     out = []
     for r in range(repeat):
+        if recompute is not None and r > 0:
+            recompute()
         perm = _i64_dev(perms[r], device)
         for lo, hi in zip(offs[:-1], offs[1:]):
             out.append(step_rows(perm[lo:hi]))
@@ -116,8 +119,8 @@ class CnnPPOEngine:
     def __init__(self, c: int, h: int, w: int, n_act: int, flat_params: torch.Tensor, cfg: PPOConfig):
         if not flat_params.is_cuda:
             raise RuntimeError("CnnPPOEngine needs parameters on an MI355X (no CPU fallback)")
-        if cfg.algo not in ("ppo", "a2c") or cfg.recompute_advantage:
-            raise NotImplementedError("CnnPPOEngine: PPO or A2C objective, without recompute_advantage")
+        if cfg.algo not in ("ppo", "a2c"):
+            raise NotImplementedError("CnnPPOEngine: PPO or A2C objective")
         off, _ = layer_layout(c, h, w, n_act)
         self.c, self.h, self.w, self.n_act, self.cfg = c, h, w, n_act, cfg
         self.P = int(off[5])
@@ -145,19 +148,19 @@ class CnnPPOEngine:
         return (v, logp, logits) if want_logits else (v, logp)
 
     # -- PPO._preprocess_batch -------------------------------------------------------------------------------
-    def preprocess(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, act: torch.Tensor, stack_num: int,
-                   obs_next_frames: torch.Tensor | None = None, chunk: int = 65536) -> dict:
-        """Whole-buffer pass in sample_indices(0) order: V(s), V(s'), log pi_old(a|s) (one trunk pass per
-        observation), GAE, optional return scaling (a2c.py:115-153, ppo.py:146-162)."""
-        cfg = self.cfg
-        idx = buffer.sample_indices(0)
+    def _values(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, idx: torch.Tensor, act_b, stack_num: int,
+                obs_next_frames: torch.Tensor | None, chunk: int):
+        """V(s), V(s') (and log pi(a|s) when act_b is given) of the transitions idx, one trunk pass per observation."""
         n = idx.numel()
         v_s = torch.empty(n, dtype=torch.float32, device=self.device)
-        v_next, logp_old = torch.empty_like(v_s), torch.empty_like(v_s)
-        act_b = act[idx]
+        v_next = torch.empty_like(v_s)
+        logp = torch.empty_like(v_s) if act_b is not None else None
         for lo in range(0, n, chunk):
             sl = slice(lo, min(lo + chunk, n))
-            v_s[sl], logp_old[sl] = self.infer(gather_obs_nhwc(frames, buffer, idx[sl], stack_num, as_u8=True), act_b[sl])
+            v, lp = self.infer(gather_obs_nhwc(frames, buffer, idx[sl], stack_num, as_u8=True), None if act_b is None else act_b[sl])
+            v_s[sl] = v
+            if lp is not None:
+                logp[sl] = lp
             if obs_next_frames is not None:
                 v_next[sl] = self.infer(gather_obs_nhwc(obs_next_frames, buffer, idx[sl], stack_num, as_u8=True))[0]
         if obs_next_frames is None:
@@ -170,9 +173,26 @@ class CnnPPOEngine:
             pos = torch.empty(buffer.maxsize, dtype=torch.int64, device=self.device)
             pos[idx] = torch.arange(n, dtype=torch.int64, device=self.device)
             v_next = v_s[pos[buffer.next(idx)]]
+        return v_s, v_next, logp
+
+    def preprocess(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, act: torch.Tensor, stack_num: int,
+                   obs_next_frames: torch.Tensor | None = None, chunk: int = 65536) -> dict:
+        """Whole-buffer pass in sample_indices(0) order: V(s), V(s'), log pi_old(a|s) (one trunk pass per
+        observation), GAE, optional return scaling (a2c.py:115-153, ppo.py:146-162)."""
+        idx = buffer.sample_indices(0)
+        act_b = act[idx]
+        v_s, v_next, logp_old = self._values(buffer, frames, idx, act_b, stack_num, obs_next_frames, chunk)
         out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
         return {"indices": idx, "act": act_b, "v_s": v_s, "returns": out["returns"], "adv": out["adv"],
-                "logp_old": logp_old}
+                "logp_old": logp_old, "obs_next_frames": obs_next_frames, "chunk": chunk}
+
+    def recompute(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, pre: dict, stack_num: int) -> None:
+        """recompute_advantage (ppo.py:174-178): `_add_returns_and_advantages` again with the current parameters -- V(s),
+        V(s'), GAE, return scaling incl. another RunningMeanStd update (a2c.py:148); log pi_old stays.  Updates `pre`."""
+        v_s, v_next, _ = self._values(buffer, frames, pre["indices"], None, stack_num, pre.get("obs_next_frames"),
+                                      pre.get("chunk", 65536))
+        out = gae_and_return_scaling(self, buffer, pre["indices"], v_s, v_next)
+        pre["v_s"], pre["returns"], pre["adv"] = v_s, out["returns"], out["adv"]
 
     # -- one minibatch step ---------------------------------------------------------------------------------------
     def step(self, obs_nhwc, act, adv, returns, logp_old=None, v_old=None, grad_out=None, apply: bool = True) -> torch.Tensor:
@@ -207,4 +227,5 @@ class CnnPPOEngine:
             return self.step(obs, pre["act"][rows], pre["adv"][rows], pre["returns"][rows], pre["logp_old"][rows],
                              pre["v_s"][rows])
 
-        return run_minibatches(self.device, pre["indices"].numel(), batch_size, repeat, perms, step_rows)
+        rec = (lambda: self.recompute(buffer, frames, pre, stack_num)) if self.cfg.recompute_advantage else None
+        return run_minibatches(self.device, pre["indices"].numel(), batch_size, repeat, perms, step_rows, rec)

@@ -63,8 +63,8 @@ class DiscretePPOEngine:
     def __init__(self, obs_dim: int, hidden: int, n_act: int, flat_params: torch.Tensor, cfg: PPOConfig):
         if not flat_params.is_cuda:
             raise RuntimeError("DiscretePPOEngine needs parameters on an MI355X (no CPU fallback)")
-        if cfg.algo not in ("ppo", "a2c") or cfg.recompute_advantage:
-            raise NotImplementedError("DiscretePPOEngine: PPO or A2C objective, without recompute_advantage")
+        if cfg.algo not in ("ppo", "a2c"):
+            raise NotImplementedError("DiscretePPOEngine: PPO or A2C objective")
         self.obs_dim, self.hidden, self.n_act, self.cfg = obs_dim, hidden, n_act, cfg
         self.P = layout(obs_dim, hidden, n_act)["count"]
         if flat_params.numel() != self.P:
@@ -110,6 +110,15 @@ class DiscretePPOEngine:
         return {"indices": idx, "act": act_b, "v_s": v_s, "returns": out["returns"], "adv": out["adv"],
                 "logp_old": logp_old}
 
+    def recompute(self, buffer: DeviceReplayBuffer, pre: dict) -> None:
+        """recompute_advantage (ppo.py:174-178): V(s), V(s'), GAE and the return scaling (incl. another RunningMeanStd update,
+        a2c.py:148) again with the current parameters; log pi_old stays.  Updates `pre` in place."""
+        idx = pre["indices"]
+        v_s, _ = self.infer(gather_rows(buffer.obs, idx))
+        v_next, _ = self.infer(gather_rows(buffer.obs_next, idx))
+        out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
+        pre["v_s"], pre["returns"], pre["adv"] = v_s, out["returns"], out["adv"]
+
     # -- one minibatch step ---------------------------------------------------------------------------------------
     def step(self, obs, act, adv, returns, logp_old=None, v_old=None, grad_out=None, apply: bool = True) -> torch.Tensor:
         """-> losses float32[4] = {loss, clip / actor, vf, ent} (device).  logp_old / v_old: PPO only."""
@@ -147,23 +156,32 @@ class DiscretePPOEngine:
             if perms is None:
                 perms = [np.random.permutation(n) for _ in range(repeat)]
             offs = split_offsets(n, batch_size, merge_last=True)
-            rows = torch.cat([_i64_dev(perms[r], self.device).reshape(-1) for r in range(repeat)]).contiguous()
-            h_off = np.asarray([r * n + o for r in range(repeat) for o in offs[:-1]] + [repeat * n], dtype=np.int64)
-            n_steps = h_off.size - 1
+            per = len(offs) - 1
+            n_steps = repeat * per
             f32 = lambda t: None if t is None else t.to(torch.float32).reshape(-1).contiguous()  # noqa: E731
             losses = torch.empty((n_steps, 4), dtype=torch.float32, device=self.device)
             hp = self.cfg.to_c()
-            _lib.check(lib.ts_mlp_ppo_update(
-                self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step),
-                *self._dims(), _lib.ptr(self._obs(obs_all)), _lib.ptr(_i64_dev(pre["act"], self.device).reshape(-1).contiguous()),
-                _lib.ptr(f32(pre["adv"])), _lib.ptr(f32(pre["returns"])), _lib.ptr(f32(pre["logp_old"])), _lib.ptr(f32(pre["v_s"])),
-                _lib.i64(n), _lib.ptr(rows), h_off.ctypes.data_as(C.c_void_p), _lib.i64(n_steps), C.byref(hp), _lib.ptr(losses),
-                _lib.current_stream(self.device)))
-            self.adam_step += n_steps
+            obs_f, act_i = self._obs(obs_all), _i64_dev(pre["act"], self.device).reshape(-1).contiguous()
+            # recompute_advantage: the batch changes between the repeats, so every repeat is its own launch
+            groups = [[r] for r in range(repeat)] if self.cfg.recompute_advantage else [list(range(repeat))]
+            for grp in groups:
+                if grp[0] > 0 and self.cfg.recompute_advantage:
+                    self.recompute(buffer, pre)                                       # ppo.py:175-176
+                rows = torch.cat([_i64_dev(perms[r], self.device).reshape(-1) for r in grp]).contiguous()
+                h_off = np.asarray([k * n + o for k in range(len(grp)) for o in offs[:-1]] + [len(grp) * n], dtype=np.int64)
+                k0 = grp[0] * per
+                _lib.check(lib.ts_mlp_ppo_update(
+                    self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step),
+                    *self._dims(), _lib.ptr(obs_f), _lib.ptr(act_i), _lib.ptr(f32(pre["adv"])), _lib.ptr(f32(pre["returns"])),
+                    _lib.ptr(f32(pre["logp_old"])), _lib.ptr(f32(pre["v_s"])), _lib.i64(n), _lib.ptr(rows),
+                    h_off.ctypes.data_as(C.c_void_p), _lib.i64(len(grp) * per), C.byref(hp), _lib.ptr(losses[k0:k0 + len(grp) * per]),
+                    _lib.current_stream(self.device)))
+                self.adam_step += len(grp) * per
             return losses, n_steps
 
         def step_rows(rows):
             return self.step(obs_all[rows], pre["act"][rows], pre["adv"][rows], pre["returns"][rows],
                              pre["logp_old"][rows], pre["v_s"][rows])
 
-        return run_minibatches(self.device, pre["indices"].numel(), batch_size, repeat, perms, step_rows)
+        rec = (lambda: self.recompute(buffer, pre)) if self.cfg.recompute_advantage else None
+        return run_minibatches(self.device, pre["indices"].numel(), batch_size, repeat, perms, step_rows, rec)

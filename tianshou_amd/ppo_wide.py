@@ -124,15 +124,17 @@ class WidePPOEngine:
 
     # ------------------------------------------------------------------ update
     def step(self, b: dict, rows: torch.Tensor | None, losses_out: torch.Tensor, grad_out: torch.Tensor | None = None,
-             apply: bool = True, global_batch: int | None = None):
-        """One minibatch (rows of `b`; None = all): forward, loss, backward, joint clip + Adam."""
+             apply: bool = True, global_batch: int | None = None, adv_stats: torch.Tensor | None = None):
+        """One minibatch (rows of `b`; None = all): forward, loss, backward, joint clip + Adam.  `global_batch` /
+        `adv_stats`: the data-parallel path (rows = this rank's share of a global minibatch, {mean, std} of the GLOBAL
+        minibatch's advantages); apply=False leaves the gradient of the global-mean loss in grad_out."""
         cfg = self.cfg
         take = (lambda t: t) if rows is None else (lambda t: gather_rows(t, rows))       # noqa: E731
         obs, act = take(b["obs"]), take(b["act"])
         adv, ret, lp_old, v_old = take(b["adv"]), take(b["returns"]), take(b["logp_old"]), take(b["v_s"])
         n = obs.shape[0]
-        stats = None
-        if cfg.advantage_normalization and cfg.algo != "a2c":                       # ppo.py:184-186 (unbiased std)
+        stats = adv_stats
+        if stats is None and cfg.advantage_normalization and cfg.algo != "a2c":     # ppo.py:184-186 (unbiased std)
             a64 = adv.double()
             stats = torch.stack([a64.mean(), a64.std()]).float().contiguous()
         hp = cfg.to_c()

@@ -42,9 +42,9 @@ def ensemble_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, 
     return torch.cat(blocks).to(device).contiguous()
 
 
-def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int) -> list[torch.Tensor]:
-    pc = layout(obs_dim, act_dim)["critic_count"]
-    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim) for e in range(E)]
+def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int, hidden: int = 256) -> list[torch.Tensor]:
+    pc = layout(obs_dim, act_dim, hidden)["critic_count"]
+    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim, hidden) for e in range(E)]
     st = lambda i, f: torch.stack([f(p[i]) for p in per])  # noqa: E731
     return [st(0, lambda w: w.t()), st(1, lambda b: b[None, :]), st(2, lambda w: w.t()), st(3, lambda b: b[None, :]),
             st(4, lambda w: w.t()), st(5, lambda b: b.reshape(1, 1))]
@@ -63,15 +63,18 @@ class REDQConfig(SACConfig):
 class REDQEngine:
     """State of one REDQ learner on one GPU."""
 
-    def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critics: torch.Tensor, cfg: REDQConfig):
+    def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critics: torch.Tensor, cfg: REDQConfig,
+                 hidden: int = 256):
+        """`hidden`: width h of the actor's Net[h, h] and of the EnsembleLinear critics (test_redq.py uses 256; any
+        multiple of 32 up to 1024, utils/net/common.py:246-369)."""
         if not actor.is_cuda:
             raise RuntimeError("REDQEngine needs parameters on an MI355X (no CPU fallback)")
         if cfg.target_mode not in ("min", "mean") or not 0 < cfg.subset_size <= cfg.ensemble_size <= 64:
             raise ValueError("target_mode must be 'min' or 'mean' and 0 < subset_size <= ensemble_size <= 64")
-        lay = layout(obs_dim, act_dim)
+        lay = layout(obs_dim, act_dim, hidden)
         if actor.numel() != lay["actor_count"] or critics.numel() != cfg.ensemble_size * lay["critic_count"]:
             raise ValueError("flat parameter vectors do not match ts_sac_layout / the ensemble size")
-        self.obs_dim, self.act_dim, self.cfg, self.lay = obs_dim, act_dim, cfg, lay
+        self.obs_dim, self.act_dim, self.cfg, self.lay, self.hidden = obs_dim, act_dim, cfg, lay, int(hidden)
         self.device = actor.device
         cl = lambda t: t.detach().float().contiguous().clone()  # noqa: E731
         self.actor, self.critics = cl(actor), cl(critics)
@@ -98,7 +101,7 @@ class REDQEngine:
         if sub.size != self.cfg.subset_size:
             raise ValueError("subset must hold subset_size member indices")
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, 256)          # the ensemble nets of test_redq.py are [256, 256]
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_redq_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critics_old), _lib.i64(self.cfg.ensemble_size),
             sub.ctypes.data_as(C.POINTER(C.c_int32)), _lib.i64(sub.size), C.c_int(int(self.cfg.target_mode == "mean")),
@@ -142,7 +145,7 @@ class REDQEngine:
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st = REDQStateC(*[getattr(self, n).data_ptr() for n, _ in REDQStateC._fields_])
         hp = self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, 256)          # the ensemble nets of test_redq.py are [256, 256]
+        use_hidden(self._ws, self.hidden)
         _lib.check(_lib.load().ts_redq_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cfg.ensemble_size), _lib.i64(self.critic_gradient_step),
             _lib.i64(max(self.actor_steps, 1)), C.c_int(int(do_actor)), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
