@@ -307,3 +307,19 @@ def test_uint8_observations_give_bitwise_identical_results():
     dy = torch.randn_like(y8)
     assert torch.equal(D.conv_backward(obs8, wb, dy, 8, 8, 4, need_dx=False)[0],
                        D.conv_backward(obs32, wb, dy, 8, 8, 4, need_dx=False)[0])
+
+
+@pytest.mark.parametrize("h,w,B", [(84, 84, 300), (16, 16, 7), (12, 20, 65)])
+def test_u8_plane_gather_vector_path_equals_indexing(h, w, B):
+    """ts_gather_planes_nhwc_u8, C = 4 and plane size a multiple of 16 bytes (the 16-pixel-per-thread kernel with the
+    in-register 4 x 4 byte transposes): bit-identical to torch indexing for arbitrary (repeated, unordered) plane indices."""
+    from tianshou_amd import _lib
+
+    g = torch.Generator().manual_seed(h * w + B)
+    n_planes = 500
+    src = torch.randint(0, 256, (n_planes, h, w), generator=g, dtype=torch.uint8).cuda()
+    planes = torch.randint(0, n_planes, (B, 4), generator=g).cuda()
+    out = torch.empty((B, h, w, 4), dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.load().ts_gather_planes_nhwc_u8(_lib.ptr(src), _lib.i64(n_planes), _lib.i64(h * w), _lib.ptr(planes), _lib.i64(B),
+                                                     _lib.i64(4), _lib.ptr(out), _lib.current_stream(src.device)))
+    assert torch.equal(out, src[planes].permute(0, 2, 3, 1))

@@ -198,7 +198,9 @@ def test_twin_critics_on_two_streams_with_generation_2():
     """hidden = 512 is not on the fused-MLP path, so the twin critics run their backward chains concurrently on the caller's
     stream and the workspace's side stream; with the second-generation kernels forced on, each chain transposes its
     weights into workspace scratch (ts_conv2.hip conv2_dgrad).  The scratch and the class tables are per launch stream:
-    three updates must agree with the first-generation kernels (different summation order: 2e-5 on parameters)."""
+    three updates must agree with the first-generation kernels (different summation order, amplified by three Adam steps
+    whose first updates are lr * sign-like: 1e-4 of the largest parameter; a clobbered scratch buffer would show up as
+    errors of order one)."""
     from tianshou_amd import _lib
 
     lib = _lib.load()
@@ -224,7 +226,7 @@ def test_twin_critics_on_two_streams_with_generation_2():
         lib.ts_conv_set_generation(prev)
     np.testing.assert_allclose(out[1][0].numpy()[:4], out[-1][0].numpy()[:4], rtol=2e-5, atol=1e-6)
     for a, b in zip(out[1][1:], out[-1][1:]):
-        assert rel_err(a, b) < 2e-5
+        assert rel_err(a, b) < 1e-4
 
 
 def test_bad_arguments_fail_loudly():

@@ -171,6 +171,35 @@ __global__ __launch_bounds__(256) void gather_planes_u8_kernel(const uint8_t* __
     }
 }
 
+// The frame-stack case the Atari workloads run (C = 4 planes of plane_elems % 16 == 0 bytes, e.g. 84 x 84): every thread moves
+// 16 pixels of the four planes -- four 16-byte loads, a 4 x 4 byte transpose per dword group (v_perm_b32), four 16-byte stores --
+// instead of four single-byte loads and one 4-byte store per pixel: 16 x fewer memory instructions for the same bytes
+// (round 3 measured the byte-wise kernel at ~2 TB/s of read + write traffic, 8 % of the Atari-shape PPO update).
+__global__ __launch_bounds__(256) void gather_planes_u8x16_kernel(const uint8_t* __restrict__ src, int64_t plane_elems,
+                                                                  const int64_t* __restrict__ plane, int64_t B,
+                                                                  uint8_t* __restrict__ out) {
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+    const int gpp = (int)(plane_elems >> 4);                       // 16-pixel groups per plane
+    const int64_t total = B * gpp;
+    for (int64_t gidx = (int64_t)blockIdx.x * 256 + threadIdx.x; gidx < total; gidx += (int64_t)gridDim.x * 256) {
+        const int64_t b = gidx / gpp;
+        const int q = (int)(gidx - b * gpp);
+        const int64_t* pl = plane + b * 4;
+        u32x4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u32x4*>(src + pl[c] * plane_elems + 16 * q);
+        u32x4* o = reinterpret_cast<u32x4*>(out + (b * plane_elems + 16 * q) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // dwords a, b, c, d hold pixels 4j .. 4j+3 of planes 0 .. 3; output dword p = {a.p, b.p, c.p, d.p}
+            const uint32_t t0 = __builtin_amdgcn_perm(v[1][j], v[0][j], 0x05010400u), t1 = __builtin_amdgcn_perm(v[1][j], v[0][j], 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(v[3][j], v[2][j], 0x05010400u), u1 = __builtin_amdgcn_perm(v[3][j], v[2][j], 0x07030602u);
+            o[j] = u32x4{__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
+                         __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u)};
+        }
+    }
+}
+
 // single workgroup, order-preserving compaction over the E sub-buffers
 __global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
                                   const int64_t* lengths, int64_t* out, int64_t* n_out) {
@@ -552,6 +581,14 @@ int ts_gather_planes_nhwc_u8(const uint8_t* src, int64_t n_planes, int64_t plane
     if (B == 0) return TS_OK;
     TS_REQUIRE(src && plane_index && out, TS_ERR_INVALID_ARG, "ts_gather_planes_nhwc_u8: NULL argument");
     TS_REQUIRE(B <= 65535, TS_ERR_UNSUPPORTED, "ts_gather_planes_nhwc_u8: at most 65535 rows per call");
+    if (C == 4 && plane_elems % 16 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+        const int64_t groups = B * (plane_elems / 16);
+        const unsigned blocks = (unsigned)std::min<int64_t>(ts::ceil_div(groups, 256), 256 * 32);
+        hipLaunchKernelGGL(gather_planes_u8x16_kernel, dim3(blocks), dim3(256), 0, ts::as_stream(stream), src, plane_elems,
+                           plane_index, B, out);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    }
     int64_t bx = ts::ceil_div(plane_elems, 256);
     if (bx > 64) bx = 64;
     dim3 grid((unsigned)bx, (unsigned)B);
