@@ -86,6 +86,9 @@ def cpu_baseline(updates: int = 3, budget_s: float = 10.0):
             "sample": f"{updates} updates of B={BATCH} (2 target forwards + fwd/bwd/Adam), torch fp32 CPU oracle"}
 
 
+PREFETCH = not os.environ.get("TS_DQN_NO_PREFETCH")      # A/B switch of the side-stream forward pass
+
+
 def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
     import bench_init as BI
     from tianshou_amd import _lib
@@ -100,8 +103,10 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     def update():
         u = torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws
         idx, wt = per.sample(u)
-        ret = eng.preprocess(buf, frames, idx, C)
         obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
+        if PREFETCH:
+            eng.prefetch_forward(obs)        # Q_online(s) on a side stream, beside the two s_{t+n} passes of _target_q
+        ret = eng.preprocess(buf, frames, idx, C)
         loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
         per.update_weight(idx, td)
         return loss

@@ -443,6 +443,19 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
                   const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
                   float* loss_out, float* grad_out, ts_stream_t stream);
+/* The forward pass on the batch's own observations does not depend on the target computation (DQN._target_q runs on
+ * obs_next in _preprocess_batch, dqn.py:257-275, before _update_with_batch forwards batch.obs, dqn.py:381-404, with the same
+ * online parameters): ts_dqn_forward_cache runs it ahead of time -- on another stream, beside the two obs_next passes -- and
+ * leaves every layer's activations and Q(s) in the caller's `cache` (ts_dqn_cache_bytes bytes, 256-byte aligned);
+ * ts_dqn_update_cached is ts_dqn_update without its forward pass, reading them from there.  The caller orders the two calls
+ * (stream events) and must not change `params` in between. */
+int64_t ts_dqn_cache_bytes(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t B);
+int ts_dqn_forward_cache(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                         const void* obs_nhwc, int obs_u8, int64_t B, void* cache, int64_t cache_bytes, ts_stream_t stream);
+int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                         int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
+                         const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, void* cache,
+                         float* td_out, float* loss_out, float* grad_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN on a recurrent Q network (DRQN, test/discrete/test_drqn.py:79-101): Recurrent (tianshou/utils/net/common.py:372-452)

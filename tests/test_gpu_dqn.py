@@ -323,3 +323,45 @@ def test_u8_plane_gather_vector_path_equals_indexing(h, w, B):
     _lib.check(_lib.load().ts_gather_planes_nhwc_u8(_lib.ptr(src), _lib.i64(n_planes), _lib.i64(h * w), _lib.ptr(planes), _lib.i64(B),
                                                      _lib.i64(4), _lib.ptr(out), _lib.current_stream(src.device)))
     assert torch.equal(out, src[planes].permute(0, 2, 3, 1))
+
+
+def test_prefetched_forward_gives_bit_identical_updates():
+    """DQNEngine.prefetch_forward (Q_online(batch.obs) on a side stream into a cache, consumed by ts_dqn_update_cached) against
+    the plain update: three updates with interleaved target passes, identical bits in loss, td errors, parameters and Adam
+    moments; a prefetch that does not match the update's tensor, or that predates a parameter write, is ignored."""
+    from tianshou_amd import dqn as D
+
+    c, h, w, A, B = 4, 84, 84, 6, 64
+    p = OD.init_params(c, h, w, A, 3)
+    cfg = D.DQNConfig(gamma=0.99, n_step=1, target_update_freq=2, is_double=True, huber_delta=1.0, lr=1e-4, max_grad_norm=10.0)
+    flat = D.flat_from_torch([p[k] for k in OD.PARAM_ORDER], c, h, w, A)
+    plain, pre = D.DQNEngine(c, h, w, A, flat, cfg), D.DQNEngine(c, h, w, A, flat, cfg)
+    g = torch.Generator().manual_seed(0)
+    for it in range(3):
+        obs = torch.randint(0, 256, (B, h, w, c), generator=g, dtype=torch.uint8).cuda()
+        obs_next = torch.randint(0, 256, (B, h, w, c), generator=g, dtype=torch.uint8).cuda()
+        act = torch.randint(0, A, (B,), generator=g).cuda()
+        rew = torch.randn(B, generator=g).cuda()
+        wt = torch.rand(B, generator=g).cuda()
+        pre.prefetch_forward(obs)
+        outs = []
+        for eng in (plain, pre):
+            ret = rew + 0.99 * eng.target_q(obs_next)
+            outs.append(eng.update_with_batch(obs, act, ret, wt))
+        assert pre._pre is None                                           # consumed
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), it
+        for name in ("params", "adam_m", "adam_v", "params_old"):
+            assert torch.equal(getattr(plain, name), getattr(pre, name)), (it, name)
+    # a prefetch for another tensor is ignored (own forward pass) ...
+    obs2 = obs.clone()
+    pre.prefetch_forward(obs)
+    l1, l0 = pre.update_with_batch(obs2, act, ret, wt), plain.update_with_batch(obs2, act, ret, wt)
+    assert torch.equal(l0[0], l1[0]) and torch.equal(plain.params, pre.params)
+    # ... and so is one that predates a parameter write
+    pre.prefetch_forward(obs)
+    stale, pre._pre = pre._pre, None
+    pre.update_with_batch(obs2, act, ret, wt)
+    plain.update_with_batch(obs2, act, ret, wt)
+    pre._pre = stale
+    a, b = pre.update_with_batch(obs, act, ret, wt), plain.update_with_batch(obs, act, ret, wt)
+    assert torch.equal(a[0], b[0]) and torch.equal(plain.params, pre.params)

@@ -290,20 +290,21 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
     return TS_OK;
 }
 
-int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
-                  int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
-                  const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
-                  float* loss_out, float* grad_out, ts_stream_t stream) {
-    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_update: workspace is NULL");
-    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "ts_dqn_update: bad batch size / step");
+static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                           int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
+                           const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
+                           float* loss_out, float* grad_out, ts_stream_t stream, void* cache, const char* who) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "%s: workspace is NULL", who);
+    TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "%s: bad batch size / step", who);
     TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && returns && hp && td_out && loss_out,
-               TS_ERR_INVALID_ARG, "ts_dqn_update: NULL argument");
+               TS_ERR_INVALID_ARG, "%s: NULL argument", who);
     Net n;
     if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);
 
-    // workspace: forward scratch | dq | dY of every layer | wgrad slabs | flat gradient | norm partials
-    size_t bytes = fwd_scratch_bytes(n, B);
+    // workspace: forward scratch (unless the caller's cache holds the activations) | dq | dY of every layer | wgrad slabs |
+    // flat gradient | norm partials
+    size_t bytes = cache ? 0 : fwd_scratch_bytes(n, B);
     bytes += align_up(sizeof(float) * B);
     for (int i = 0; i < 4; ++i) bytes += align_up(sizeof(float) * n.l[i].out_elems());
     size_t slab = 0;
@@ -312,7 +313,9 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     bytes += align_up(slab) + align_up(sizeof(float) * n.total) + 4096;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Scratch sc;
-    char* p = carve_fwd(n, B, static_cast<char*>(ws->base), &sc);
+    char* p = static_cast<char*>(ws->base);
+    if (cache) carve_fwd(n, B, static_cast<char*>(cache), &sc);
+    else p = carve_fwd(n, B, p, &sc);
     float* dq = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * B);
     float* dy[4];
     for (int i = 0; i < 4; ++i) { dy[i] = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.l[i].out_elems()); }
@@ -321,8 +324,9 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     float* norm_part = reinterpret_cast<float*>(p);
     if (grad_out) grad = grad_out;
 
-    // forward (keeps the activations), loss
-    if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, sc.q, nullptr)) return rc;
+    // forward (keeps the activations) -- or the activations ts_dqn_forward_cache left in `cache` --, loss
+    if (!cache)
+        if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, sc.q, nullptr)) return rc;
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
                        (float)hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
@@ -350,6 +354,44 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     if (hp->lr < 0.0) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);
+}
+
+
+int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                  int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
+                  const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
+                  float* loss_out, float* grad_out, ts_stream_t stream) {
+    return dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, obs_nhwc, obs_u8, act, returns, weight, B, hp,
+                           td_out, loss_out, grad_out, stream, nullptr, "ts_dqn_update");
+}
+
+int64_t ts_dqn_cache_bytes(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t B) {
+    Net n;
+    if (B < 1 || make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n) != TS_OK) return -1;
+    return (int64_t)fwd_scratch_bytes(n, B);
+}
+
+int ts_dqn_forward_cache(ts_workspace* ws, const float* params, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                         const void* obs_nhwc, int obs_u8, int64_t B, void* cache, int64_t cache_bytes, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_forward_cache: workspace is NULL");
+    TS_REQUIRE(B >= 1 && params && obs_nhwc && cache, TS_ERR_INVALID_ARG, "ts_dqn_forward_cache: bad argument");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255u) == 0, TS_ERR_INVALID_ARG, "ts_dqn_forward_cache: cache must be 256-byte aligned");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    TS_REQUIRE(cache_bytes >= (int64_t)fwd_scratch_bytes(n, B), TS_ERR_SHAPE, "ts_dqn_forward_cache: cache holds %lld bytes, %lld needed",
+               (long long)cache_bytes, (long long)fwd_scratch_bytes(n, B));
+    Scratch sc;
+    carve_fwd(n, B, static_cast<char*>(cache), &sc);
+    return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, sc.q, nullptr);
+}
+
+int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
+                         int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
+                         const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, void* cache,
+                         float* td_out, float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(cache != nullptr, TS_ERR_INVALID_ARG, "ts_dqn_update_cached: cache is NULL");
+    return dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, obs_nhwc, obs_u8, act, returns, weight, B, hp,
+                           td_out, loss_out, grad_out, stream, cache, "ts_dqn_update_cached");
 }
 
 }  // extern "C"

@@ -214,6 +214,43 @@ class DQNEngine:
         self.adam_step = 0
         self.iter = 0
         self._ws = _lib.default_workspace(self.device.index or 0)
+        self._pre = None               # (obs tensor, cache, done event, params version) of a prefetched forward pass
+        self._side = None
+
+    # -- the forward pass on batch.obs, ahead of time ------------------------------------------------
+    def prefetch_forward(self, obs_nhwc: torch.Tensor) -> None:
+        """Q_online(batch.obs) of the coming `update_with_batch(obs_nhwc, ...)` on a side stream, beside the two obs_next
+        passes of `_target_q`: it needs nothing from them (same online parameters, dqn.py:257-275 vs 381-404), and at B = 512
+        no single pass fills the chip.  The activations wait in a cache owned by the engine; `update_with_batch` picks them up
+        when it is handed the SAME tensor and the parameters have not been written since (ts_dqn_update_cached), and falls
+        back to its own forward pass otherwise."""
+        lib = _lib.load()
+        lib.ts_dqn_cache_bytes.restype = C.c_int64
+        b = obs_nhwc.shape[0]
+        need = int(lib.ts_dqn_cache_bytes(_lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act), _lib.i64(b)))
+        if need <= 0 or not obs_nhwc.is_contiguous():
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._cache = None
+        if self._cache is None or self._cache.numel() < need:
+            self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = self._cache.data_ptr()
+        cache_ptr = C.c_void_p((base + 255) & ~255)
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                                  # obs (and anything else enqueued so far) is ready
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ready)
+            ws = _lib.default_workspace(self.device.index or 0)          # the side stream's own workspace
+            _lib.check(lib.ts_dqn_forward_cache(
+                ws.handle, _lib.ptr(self.params), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act),
+                _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.i64(b), cache_ptr, _lib.i64(need),
+                _lib.current_stream(self.device)))
+            done.record(self._side)
+        obs_nhwc.record_stream(self._side)
+        self._pre = (obs_nhwc, cache_ptr, done, (self.params._version, self.adam_step), b)
 
     # -- DiscreteQLearningPolicy.forward ---------------------------------------------------------
     def forward(self, obs_nhwc: torch.Tensor, params: torch.Tensor | None = None, want_act: bool = True):
@@ -285,6 +322,7 @@ class DQNEngine:
                           apply: bool = True):
         """-> (loss float32[1] device tensor, td_error float32[B]); td_error is the new batch.weight."""
         cfg = self.cfg
+        params_state = (self.params._version, self.adam_step)          # what a prefetched forward pass was computed with
         if apply:
             if self.params_old is not None and self.iter % cfg.target_update_freq == 0:    # dqn.py:283-285
                 full_parameter_update(self.params_old, self.params)
@@ -300,6 +338,16 @@ class DQNEngine:
         td = torch.empty(b, dtype=torch.float32, device=self.device)
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         hp = cfg.to_c(grad_only=not apply)
+        pre, self._pre = self._pre, None
+        if pre is not None and pre[0] is obs_nhwc and pre[3] == params_state and pre[4] == b:
+            torch.cuda.current_stream(self.device).wait_event(pre[2])          # the prefetched activations are complete
+            _lib.check(_lib.load().ts_dqn_update_cached(
+                self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
+                _lib.i64(max(self.adam_step, 1)), _lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w),
+                _lib.i64(self.n_act), _lib.ptr(obs_nhwc), _u8_flag(obs_nhwc), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight),
+                _lib.i64(b), C.byref(hp), pre[1], _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
+                _lib.current_stream(self.device)))
+            return loss, td
         obs_nhwc = obs_nhwc.contiguous()
         _lib.check(_lib.load().ts_dqn_update(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),

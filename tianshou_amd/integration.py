@@ -769,6 +769,11 @@ def make_hip_dqn(ref=None):
             m = _mirror(self, buffer, self._hip_device)
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             nxt = m.obs_next if m.obs_next is not None else None
+            # the batch's own observations, gathered here so that Q_online(batch.obs) of _update_with_batch can run beside the
+            # two obs_next passes of _target_q (DQNEngine.prefetch_forward); data-parallel runs keep the plain order
+            self._hip_obs = D.gather_obs_nhwc(m.obs, m, idx, stack, as_u8=True)
+            if not self._hip_dp_on and hasattr(eng, "prefetch_forward"):
+                eng.prefetch_forward(self._hip_obs)
             batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_frames=nxt).reshape(-1, 1)
             self._hip_idx, self._hip_stack = idx, stack
             if hasattr(batch, "weight"):
@@ -779,7 +784,7 @@ def make_hip_dqn(ref=None):
             self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
-            obs = D.gather_obs_nhwc(m.obs, m, self._hip_idx, self._hip_stack, as_u8=True)
+            obs = self._hip_obs
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
             runner = eng
             if self._hip_dp_on:
