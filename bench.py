@@ -44,13 +44,13 @@ FLOP_PER_SAMPLE_STEP = 60544          # fwd 21,632 + bwd dW 21,632 + 
 GAE_BYTES_PER_TRANSITION = 26         # 22 + 4: rew kept float64 as the reference stores it
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
-# HBM bytes per launch from the TCC counters (profiles/r03_pmc_hbm_traffic.txt: two separate rocprofv3 --pmc passes over
+# HBM bytes per launch from the TCC counters (profiles/r04_pmc_hbm_traffic.txt: two separate rocprofv3 --pmc passes over
 # this very command, mean per launch; FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte
 # requests of 16-byte-per-lane loads at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM").  Counters cannot be read live
 # from inside bench.py, so the line carries the profiled value of the same workload.
-STEP_HBM_TRAFFIC_BYTES = (2 * 8344 + 27920) * 1024      # records + images read; 512 gradient slabs written through (sc1)
-GAE_HBM_TRAFFIC_BYTES = (2 * 9276 + 8242) * 1024        # 27.4 MB vs 27.3 MB algorithmic: every byte moves once
-TRAFFIC_SOURCE = "profiles/r03_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
+STEP_HBM_TRAFFIC_BYTES = (2 * 8347 + 28944) * 1024      # records + images read; 512 gradient slabs written through (sc1)
+GAE_HBM_TRAFFIC_BYTES = (2 * 9337 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
+TRAFFIC_SOURCE = "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
 H2D_BYTES_PER_UPDATE = N_TRANS * (2 * OBS * 4 + ACT * 4 + 8 + 2)   # obs, obs_next, act f32; rew f64; two flag bytes
 
 

@@ -1,7 +1,6 @@
 #!/bin/bash
-# SQ counters of the PPO step kernel, mean per launch (three separate --pmc passes); TS_PPO_STEP selects the kernel generation:
-#   TS_PPO_STEP=3 bash scripts/gpu_r2_pmc.sh   -> gpurun_out/pmc/pmc_step_mode3.txt
-M=${TS_PPO_STEP:-2}
+# SQ counters of the PPO step kernel, mean per launch (three separate --pmc passes) -> gpurun_out/pmc/pmc_step_mode2.txt
+M=2
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
