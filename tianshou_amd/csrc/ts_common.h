@@ -81,11 +81,6 @@ struct ts_workspace {
     // hidden width of the Net[h, h] MLPs of the SAC / TD3 / DDPG / REDQ entry points called with this workspace
     // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
     int mlp_hidden;
-    // lowest-priority stream for bandwidth work that should only fill the gaps of the caller's stream (ts_ppo.hip: the
-    // permuted record copy of the NEXT repeat), created on first use
-    hipStream_t low;
-    hipEvent_t low_ev[4];
-    int low_ready;
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;
@@ -101,7 +96,6 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
 //   enqueued on `from` before it.
 int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == main while profiling (clean per-kernel times)
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
-int low_stream(ts_workspace* ws, hipStream_t* out);                    // lowest priority, non-blocking; events in ws->low_ev
 
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {

@@ -72,20 +72,6 @@ int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
     return TS_OK;
 }
 
-int low_stream(ts_workspace* ws, hipStream_t* out) {
-    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "low_stream: workspace is NULL");
-    if (!ws->low_ready) {
-        TS_HIP_CHECK(hipSetDevice(ws->device));
-        int least = 0, greatest = 0;
-        TS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        TS_HIP_CHECK(hipStreamCreateWithPriority(&ws->low, hipStreamNonBlocking, least));
-        for (int i = 0; i < 4; ++i) TS_HIP_CHECK(hipEventCreateWithFlags(&ws->low_ev[i], hipEventDisableTiming));
-        ws->low_ready = 1;
-    }
-    *out = ws->low;
-    return TS_OK;
-}
-
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot) {
     if (from == to) return TS_OK;
     TS_REQUIRE(ws && ws->side_ready && slot >= 0 && slot < 16, TS_ERR_WORKSPACE, "stream_wait: bad workspace / slot");
@@ -171,12 +157,6 @@ int ts_workspace_destroy(ts_workspace* ws) {
         (void)hipStreamSynchronize(ws->side);
         for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ws->side_ev[i]);
         (void)hipStreamDestroy(ws->side);
-    }
-    if (ws->low_ready) {
-        (void)hipSetDevice(ws->device);
-        (void)hipStreamSynchronize(ws->low);
-        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ws->low_ev[i]);
-        (void)hipStreamDestroy(ws->low);
     }
     if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }
     for (int k = 0; k < 2; ++k)

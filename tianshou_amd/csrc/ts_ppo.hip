@@ -22,8 +22,6 @@
 // LDS tiles ([feature][sample], pitch 36 floats: conflict-free ds_write_b32 and ds_read_b128).
 #include <cstdlib>
 
-#include <algorithm>
-
 #include "ts_common.h"
 
 namespace {
@@ -1176,21 +1174,6 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(const float* __restrict__
 }
 
 // per-minibatch advantage mean / unbiased std for all steps of one update()
-// out[i] = rec[perm[i]]: the packed records of one repeat in minibatch order (16-byte pieces; consecutive lanes take consecutive
-// pieces of a record, so a 112-byte record is read as one run and the output is written as one stream).  Launched for repeat
-// r + 1 on the workspace's lowest-priority stream while repeat r's gradient steps run: the step kernels leave HBM idle and the
-// tail of every step (slab reduction, Adam) leaves most CUs idle.  With it a step kernel's tile is 32 CONSECUTIVE records --
-// no row ids, one round trip instead of two in its prologue, no records straddling two lines.
-__global__ __launch_bounds__(256) void ppo_gather_records_kernel(const f32x4* __restrict__ rec, const int64_t* __restrict__ perm,
-                                                                 int64_t n, int parts, f32x4* __restrict__ out) {
-    const int64_t total = n * parts;
-    for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
-        const int64_t i = gi / parts;
-        const int p = (int)(gi - i * parts);
-        out[gi] = rec[perm[i] * parts + p];
-    }
-}
-
 __global__ __launch_bounds__(1024) void ppo_adv_stats_kernel(const float* __restrict__ adv,
                                                              const int64_t* __restrict__ perm,
                                                              const int64_t* __restrict__ mb_offset,
@@ -1558,26 +1541,11 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     const ImageBuf ib = image_buf(d, ks);
     const size_t img_bytes = ib.img_bytes, inv_bytes = ib.inv_bytes;
     const int img_end = ib.img_end;
-    // Permuted record copies (see ppo_gather_records_kernel): possible when the steps are `repeat` passes over permutations of
-    // the n rows -- what PPO._update_with_batch runs (ppo.py:174-178, Batch.split) -- i.e. every step lies inside one block
-    // [r n, (r + 1) n) of the concatenated row list.  TS_PPO_PREGATHER=0: the step kernels gather through the row ids.
-    static const bool pregather_on = [] { const char* e = getenv("TS_PPO_PREGATHER"); return !(e && e[0] == '0'); }();
-    bool pre = pregather_on && perm != nullptr && h_mb_offset[0] == 0 && h_mb_offset[n_steps] % n == 0;
-    for (int64_t k = 0; pre && k < n_steps; ++k) pre = h_mb_offset[k] / n == (h_mb_offset[k + 1] - 1) / n;
-    int64_t n_rep = pre ? h_mb_offset[n_steps] / n : 0;
-    if (n_rep < 2) { pre = false; n_rep = 0; }      // nothing to overlap a single pass's copy with
-    rc = ts::ws_reserve(ws, wl.total + off_bytes + (pre ? 3 : 1) * rec_bytes + img_bytes + inv_bytes + 256);
+    rc = ts::ws_reserve(ws, wl.total + off_bytes + rec_bytes + img_bytes + inv_bytes + 256);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
     float* image = reinterpret_cast<float*>(base + wl.total + off_bytes + rec_bytes);
     int* inv = reinterpret_cast<int*>(base + wl.total + off_bytes + rec_bytes + img_bytes);
-    float* recp[2] = {nullptr, nullptr};
-    if (pre) {
-        char* q = base + wl.total + off_bytes + rec_bytes + img_bytes + inv_bytes;
-        q = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255);
-        recp[0] = reinterpret_cast<float*>(q);
-        recp[1] = reinterpret_cast<float*>(q + rec_bytes);
-    }
     float* slabs = reinterpret_cast<float*>(base + wl.slabs);
     float* grad = reinterpret_cast<float*>(base + wl.grad);
     float* sumsq = reinterpret_cast<float*>(base + wl.sumsq);
@@ -1597,38 +1565,12 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                            d_off, advstats);
         TS_LAUNCH_CHECK();
     }
-    hipStream_t low = s;
-    if (pre)
-        if (int rc2 = ts::low_stream(ws, &low)) return rc2;
-    auto gather = [&](hipStream_t st, int64_t r) {
-        const int64_t pieces = n * (rw / 4);
-        const unsigned blocks = (unsigned)std::min<int64_t>((pieces + 255) / 256, 8192);
-        hipLaunchKernelGGL(ppo_gather_records_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const f32x4*>(rec),
-                           perm + r * n, n, rw / 4, reinterpret_cast<f32x4*>(recp[r & 1]));
-    };
-    int64_t cur_rep = -1;
     for (int64_t k = 0; k < n_steps; ++k) {
         StepArgs g{};
         g.params = params;
         g.rec_w = rw;
         g.n_rows = h_mb_offset[k + 1] - h_mb_offset[k];
-        const int64_t rep = pre ? h_mb_offset[k] / n : 0;
-        if (pre && rep != cur_rep) {
-            // the first repeat gathers through the row ids (no copy to wait for); from the second on the copy made during
-            // the previous repeat is complete before the steps start
-            if (cur_rep >= 0) TS_HIP_CHECK(hipStreamWaitEvent(s, ws->low_ev[rep & 1], 0));
-            cur_rep = rep;
-            if (rep + 1 < n_rep) {
-                // buffer (rep + 1) & 1 was last read by the steps of repeat rep - 1, all enqueued on `s` before this point
-                TS_HIP_CHECK(hipEventRecord(ws->low_ev[2 + (rep & 1)], s));
-                TS_HIP_CHECK(hipStreamWaitEvent(low, ws->low_ev[2 + (rep & 1)], 0));
-                gather(low, rep + 1);
-                TS_HIP_CHECK(hipEventRecord(ws->low_ev[(rep + 1) & 1], low));
-            }
-            TS_LAUNCH_CHECK();
-        }
-        if (pre && rep > 0) { g.rec = recp[rep & 1] + (h_mb_offset[k] - rep * n) * rw; g.rows = nullptr; }
-        else if (perm) { g.rec = rec; g.rows = perm + h_mb_offset[k]; }
+        if (perm) { g.rec = rec; g.rows = perm + h_mb_offset[k]; }
         else { g.rec = rec + h_mb_offset[k] * rw; g.rows = nullptr; }   // identity rows: shift the base
         g.inv_batch = 1.0f / (float)g.n_rows;
         g.adv_stats = hp->adv_norm ? advstats + 2 * k : nullptr;
