@@ -253,6 +253,50 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// The same on the 16 accumulator registers of an MFMA tile, two values per VALU instruction where the ISA allows it
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on register pairs; the two transcendentals stay scalar): the fp32 MFMA shares
+// the vector lanes with the VALU (no co-execution), so every VALU instruction saved is matrix issue time returned.
+// Bit-identical to fast_tanh per element.
+#ifndef TS_PK
+#define TS_PK 2          // experiments (profiles/r04_packed_valu_ab.txt): 0 scalar everywhere, 1 packed tanh, 2 + packed tanh', 3 + packed head-gradient dots
+#endif
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ void tanh16(f32x16& a) {
+#if TS_PK < 1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = fast_tanh(a[r]);
+    return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = {a[r], a[r + 1]};
+        const f32x2 y = x * 2.885390081777927f;
+        f32x2 e = {__builtin_amdgcn_exp2f(y[0]), __builtin_amdgcn_exp2f(y[1])};
+        e = e + 1.f;
+        const f32x2 q = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+        const f32x2 t = 1.f - 2.f * q;
+        a[r] = t[0];
+        a[r + 1] = t[1];
+    }
+}
+
+// v[r] = v[r] * (1 - h[r]^2) on register pairs (tanh'), bit-identical to the scalar expression
+__device__ __forceinline__ void dtanh16(f32x16& v, const f32x16& hh) {
+#if TS_PK < 2
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = v[r] * (1.f - hh[r] * hh[r]);
+    return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 hv = {hh[r], hh[r + 1]};
+        const f32x2 g = {v[r], v[r + 1]};
+        const f32x2 o = g * (1.f - hv * hv);
+        v[r] = o[0];
+        v[r + 1] = o[1];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward trunk of one net for one 32-sample tile: x -> h1 -> h2 (transposed, in registers)
 template <int KS1, int NN>
@@ -267,8 +311,7 @@ __device__ __forceinline__ void trunk_forward(const float* lds, int net, const f
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS1; ++s) acc = mfma32(w1[(KS1 * h + s) * HID + 32 * t + i], x[s], acc);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
+        tanh16(acc);
         h1[t] = acc;
     }
 #pragma unroll
@@ -289,8 +332,7 @@ __device__ __forceinline__ void trunk_forward(const float* lds, int net, const f
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from hoisting every operand load
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
+        tanh16(acc);
         h2[t2] = acc;
     }
 }
@@ -805,27 +847,41 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
     __builtin_amdgcn_sched_barrier(0);
     TS_MARK(g, MK + 2);
 
-    // ---- dZ2 = (dout . Whead) * (1 - h2^2)   (in place in h2)
+    // ---- dZ2 = (dout . Whead) * (1 - h2^2)   (in place in h2).  Actor: the eight products of a value run as four packed
+    // multiply-adds over action pairs (even / odd partial sums, added at the end); tanh' on register pairs.
     {
         const float* wh = lds + L::WH + h * (2 * 16 * ACT_PAD);
+        [[maybe_unused]] f32x2 d01, d23, d45, d67;
+        if constexpr (ACTOR) {
+            d01 = f32x2{dout[0], dout[1]}; d23 = f32x2{dout[2], dout[3]};
+            d45 = f32x2{dout[4], dout[5]}; d67 = f32x2{dout[6], dout[7]};
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            f32x16 dhv;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float* p = wh + (t * 16 + r) * ACT_PAD;
-                float dh;
                 if constexpr (ACTOR) {
                     const f32x4 w0 = ld4(p);
                     const f32x4 w1 = ld4(p + 4);
-                    dh = dout[0] * w0[0] + dout[1] * w0[1] + dout[2] * w0[2] + dout[3] * w0[3] +
-                         dout[4] * w1[0] + dout[5] * w1[1] + dout[6] * w1[2] + dout[7] * w1[3];
+#if TS_PK < 3
+                    dhv[r] = dout[0] * w0[0] + dout[1] * w0[1] + dout[2] * w0[2] + dout[3] * w0[3] +
+                             dout[4] * w1[0] + dout[5] * w1[1] + dout[6] * w1[2] + dout[7] * w1[3];
+                    continue;
+#endif
+                    f32x2 sacc = d01 * f32x2{w0[0], w0[1]};
+                    sacc = d23 * f32x2{w0[2], w0[3]} + sacc;
+                    sacc = d45 * f32x2{w1[0], w1[1]} + sacc;
+                    sacc = d67 * f32x2{w1[2], w1[3]} + sacc;
+                    dhv[r] = sacc[0] + sacc[1];
                 } else {
-                    dh = dout[0] * p[0];
+                    dhv[r] = dout[0] * p[0];
                 }
-                const float hv = h2[t][r];
-                h2[t][r] = dh * (1.f - hv * hv);
                 if (ACTOR && (r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
+            dtanh16(dhv, h2[t]);
+            h2[t] = dhv;
         }
     }
 
@@ -842,11 +898,7 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
                     accd = mfma32(w2[(32 * t + featF(r, h)) * W2_PITCH + 32 * t1 + i], h2[t][r], accd);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hv = h1[t1][r];
-                accd[r] = accd[r] * (1.f - hv * hv);
-            }
+            dtanh16(accd, h1[t1]);
             dz1[t1] = accd;
         }
     }
