@@ -541,10 +541,21 @@ def main():
     import bench_init
 
     ar, exchange = make_exchange(device, rank, world)
+    xch = {"ar": ar, "name": exchange, "note": None}
     legs = ["strong", "weak"] if (args.scaling == "both" and world > 1) else [("strong" if args.scaling == "both" else args.scaling)]
 
     def timed_leg(scaling):
-        """W warm-up + exactly K timed update()s, barrier + synchronize on both sides, MAX over the ranks."""
+        """W warm-up + exactly K timed update()s, barrier + synchronize on both sides, MAX over the ranks.  If the native
+        exchange reports a failed hand-off on ANY rank (bounded spin of the one-shot path: never seen on one device, unproven
+        across xGMI), every rank drops it and the leg is measured again on torch.distributed -- a slower number instead of
+        no number."""
+        out = _timed_leg(scaling)
+        if out is None:
+            out = _timed_leg(scaling)
+        return out
+
+    def _timed_leg(scaling):
+        ar, exchange = xch["ar"], xch["name"]
         learner = Learner(device, rank, world, scaling, allreduce=ar, exchange=exchange)
         bench_init.warm_clocks(device)        # idle clocks -> load clocks before the W warm-up steps (not an update step)
         for _ in range(args.warmup):
@@ -564,7 +575,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         if ar is not None:
-            ar.check()                        # a one-shot exchange whose peer never arrived would have left stale sums
+            import torch.distributed as dist
+
+            ok = 1
+            try:
+                ar.check()                    # a one-shot exchange whose peer never arrived would have left stale sums
+            except Exception as e:            # noqa: BLE001
+                ok = 0
+                print(f"[bench] rank {rank}: native exchange failed its check ({e})", file=sys.stderr)
+            t = torch.tensor([ok], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                ar.close()
+                xch["ar"], xch["name"] = None, "torch.distributed all_reduce (RCCL)"
+                xch["note"] = "the native exchange failed its hand-off check; legs re-measured on torch.distributed"
+                return None
         return learner, el, total, [float(x) for x in losses[-1].tolist()]
 
     learner, elapsed, total_steps, final_loss = timed_leg(legs[0])
@@ -580,6 +605,7 @@ def main():
         del l2
         torch.cuda.empty_cache()
         learner = keep
+    ar, exchange = xch["ar"], xch["name"]
     exchange_us = time_exchange(device, world, ar, learner.eng.P + 4)
     rccl_ranks = None
     if ar is not None:
@@ -684,6 +710,8 @@ def main():
         if world > 1:
             out["exchange_us"] = exchange_us
             out["exchange_ranks"] = rccl_ranks
+            if xch["note"]:
+                out["exchange_note"] = xch["note"]
         if beside is not None:
             out["weak_scaling" if beside["scaling"] == "weak" else "strong_scaling"] = beside
         out.update(extra)
