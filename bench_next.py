@@ -68,6 +68,14 @@ def _flat_buffer(slots, E, dev, g, **cols):
                               truncated=torch.zeros(slots, dtype=torch.bool, device=dev), **cols)
 
 
+_TICK = [0]
+
+
+def _tick() -> int:
+    _TICK[0] += 1
+    return _TICK[0]
+
+
 def _time(update, steps, warmup):
     import bench_init as BI
     from tianshou_amd import _lib
@@ -130,7 +138,7 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
     n_upd = [0]
 
     def update():
-        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
+        idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
         n_upd[0] += 1
         noise = normal_noise((B, ACT), 0x7D3, n_upd[0], dev) if twin else None
         ret = eng.preprocess(buf, idx, noise)
@@ -194,7 +202,7 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
     n_upd = [0]
 
     def update():
-        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
+        idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
         n_upd[0] += 1
         noise = normal_noise((2, B, ACT), 0x2ED0, n_upd[0], dev)
         ret = eng.preprocess(buf, idx, noise[0], rng.choice(E, SUB, replace=False))
@@ -249,7 +257,7 @@ def run_dsac(steps, warmup, with_cpu, slots=1 << 21):
     eng = DS.DiscreteSACEngine(OBS, A, HID, *flats, SACConfig(auto_alpha=True, target_entropy=te, actor_lr=1e-4, critic_lr=1e-3))
 
     def update():
-        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
+        idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
         ret = eng.preprocess(buf, idx)
         return eng.update_with_batch(gather_rows(buf.obs, idx), buf.act[idx], ret)[0]
 
@@ -610,7 +618,7 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch(list(p.values()), OBS, H, L, A), D.DQNConfig(**kw))
 
     def update():
-        idx = buf.sample_indices(B, generator=g)        # manager.py:216-234
+        idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
         ret = eng.preprocess(buf, buf.obs, idx, T)
         return eng.update_with_batch(R.gather_stacked_obs(buf.obs, buf, idx, T), buf.act[idx], ret)[0]
 

@@ -85,11 +85,11 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
     n_upd = [0]
 
     def update():
-        idx = buf.sample_indices(BATCH, generator=g)        # manager.py:216-234: sub-buffer by length, uniform inside
         n_upd[0] += 1
+        idx = buf.sample_indices(BATCH, seed=(0x5A7, n_upd[0]))   # manager.py:216-234: sub-buffer by length, uniform inside
         noise = normal_noise((2, BATCH, ACT), 0x5AC, n_upd[0], dev)      # rsample() eps of a' ~ pi(s') and a ~ pi(s)
-        ret = eng.preprocess(buf, idx, noise[0])
-        stats, _ = eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret, noise[1])
+        ret = eng.preprocess(buf, idx, noise[0])                  # n_step 1: gather + _target_q + 1-step return, one sequence
+        stats, _ = eng.update_with_rows(buf, idx, ret, noise[1])  # the input packing reads the rows (TS_SAC_NO_ROWS=1: gathers)
         return stats
 
     BI.warm_clocks(dev)

@@ -169,6 +169,12 @@ int ts_sample_indices_all(ts_workspace* ws, const int64_t* offset, int64_t E,
 int ts_sample_indices_random(const int64_t* offset, int64_t E, const int64_t* lengths, const double* u_buffer,
                              const int64_t* within_i, const double* within_u, int64_t batch_size, int64_t* out,
                              int* err_flag, ts_stream_t stream);
+/* The same sampler drawing its own uniforms: Philox-4x32-10 keyed by `seed`, counter (draw index, `counter`) -- the generator
+ * of ts_normal_fill; 53-bit doubles in [0, 1).  One launch instead of a generator launch + the sampler; the same
+ * (seed, counter) always gives the same indices.  Not the reference's RandomState stream (pass its draws to
+ * ts_sample_indices_random for that). */
+int ts_sample_indices_seeded(const int64_t* offset, int64_t E, const int64_t* lengths, uint64_t seed, uint64_t counter,
+                             int64_t batch_size, int64_t* out, int* err_flag, ts_stream_t stream);
 
 /* Device-side stand-in for the np.random.permutation(len(batch)) that Batch.split draws per repeat
  * (tianshou/data/batch.py:1209): a keyed bijection of [0, n) (4-round Feistel + cycle walking),
@@ -721,6 +727,21 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                   const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
                   int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads_out,
                   ts_stream_t stream);
+/* The same two operations reading their rows straight from the replay buffer's columns (row b of the minibatch = row rows[b] of
+ * obs_buf / act_buf / obs_next_buf, float32 [slots, dim]; rew_buf float64 [slots], terminated_buf uint8 [slots]): the gathers
+ * of ReplayBuffer.__getitem__ (buffer_base.py:605-649) happen inside the input-packing kernel instead of in launches of their
+ * own.  ts_sac_returns_rows = _target_q (ts_sac_target_q) + the 1-STEP return of compute_nstep_return
+ * (algorithm_base.py:785-817 with n_step = 1; the arithmetic of ts_nstep_return_fused: value mask in float32, gamma and
+ * reward in float64) in the same launch sequence: returns_out[b] = float(double(tq[b] * !terminated[rows[b]]) * gamma +
+ * rew[rows[b]]), bit-identical to ts_sac_target_q + ts_nstep_return_fused.  ts_sac_update_rows = ts_sac_update. */
+int ts_sac_returns_rows(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                        const float* log_alpha, double fixed_alpha, const float* obs_next_buf, const double* rew_buf,
+                        const uint8_t* terminated_buf, const int64_t* rows, const float* noise, int64_t B, int64_t obs_dim,
+                        int64_t act_dim, double gamma, float* returns_out, ts_stream_t stream);
+int ts_sac_update_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs_buf, const float* act_buf,
+                       const int64_t* rows, const float* returns, const float* weight, const float* noise, int64_t B,
+                       int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out,
+                       ts_stream_t stream);
 
 /* One phase of ts_sac_update, for data-parallel replicas (tianshou_amd/distributed.py DataParallelSAC; the reference
  * has no distributed path): phase 1 = forward / loss / backward of both critics on the local batch,

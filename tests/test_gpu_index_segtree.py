@@ -310,3 +310,27 @@ def test_normal_fill_is_a_keyed_standard_normal_stream():
     assert normal_noise((5, 3, 7), 1, 1).shape == (5, 3, 7)       # odd sizes: the tail quad is partial
     # lag-1 correlation of neighbouring outputs (the two Box-Muller partners and adjacent counters)
     assert abs(float((x[:-1] * x[1:]).mean())) < 4.0 / np.sqrt(n)
+
+
+def test_seeded_sampler_is_reproducible_and_follows_the_lengths():
+    """ts_sample_indices_seeded (Philox draws inside the sampling kernel): the same (key, counter) gives the same indices,
+    another counter different ones; sub-buffer frequencies follow lengths / sum, indices stay inside the filled parts and come
+    grouped by sub-buffer like the reference's concatenation (manager.py:229-234)."""
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    lengths = np.array([100, 0, 4000, 900, 1], np.int64)
+    off = np.concatenate([[0], np.cumsum(np.full(5, 4096))]).astype(np.int64)
+    B = int(off[-1])
+    buf = DeviceReplayBuffer(offset=off, last_index=off[:-1], lengths=lengths, insertion=np.zeros(5, np.int64), rew=np.zeros(B),
+                             terminated=np.zeros(B, bool), truncated=np.zeros(B, bool))
+    a = buf.sample_indices(50000, seed=(7, 1)).cpu().numpy()
+    b = buf.sample_indices(50000, seed=(7, 1)).cpu().numpy()
+    c = buf.sample_indices(50000, seed=(7, 2)).cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    sub = np.searchsorted(off, a, side="right") - 1
+    assert np.all(np.diff(sub) >= 0)                                       # grouped by sub-buffer
+    assert np.all(a - off[sub] < lengths[sub]) and np.all(a >= off[sub])
+    freq = np.bincount(sub, minlength=5) / a.size
+    np.testing.assert_allclose(freq, lengths / lengths.sum(), atol=0.01)
+    within = (a - off[sub])[sub == 2]
+    assert abs(within.mean() / 4000 - 0.5) < 0.02 and within.min() < 40 and within.max() > 3960

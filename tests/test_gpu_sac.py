@@ -268,3 +268,49 @@ def test_phased_update_is_bit_identical(auto, weighted):
                  "critic1_v", "critic2_m", "critic2_v", "log_alpha", "log_alpha_m", "log_alpha_v"):
         assert torch.equal(getattr(eng_a, name), getattr(eng_b, name)), name
     assert eng_a.adam_step == eng_b.adam_step == 3
+
+
+@pytest.mark.parametrize("auto,weighted", [(True, True), (False, False)])
+def test_row_indexed_entry_points_are_bit_identical(auto, weighted):
+    """ts_sac_returns_rows (gather of obs_next inside the input packing + _target_q + the 1-step return in one launch
+    sequence) == gather_rows + ts_sac_target_q + ts_nstep_return_fused, and ts_sac_update_rows == gather_rows + ts_sac_update:
+    returns, statistics, PER weights, parameters and Adam moments bit for bit over three updates on a buffer with
+    terminations and repeated indices."""
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    obs_dim, act_dim, B, slots, E = 23, 5, 200, 4096, 4
+    cfg = OS.SACConfig(auto_alpha=auto, log_alpha0=-0.2, alpha=0.15, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02, n_step=1)
+    g = torch.Generator().manual_seed(3)
+    T = slots // E
+    off = np.arange(E + 1, dtype=np.int64) * T
+    buf = DeviceReplayBuffer(offset=off, last_index=off[:-1] + T - 1, lengths=np.full(E, T, np.int64),
+                             insertion=np.zeros(E, np.int64), rew=torch.randn(slots, generator=g).double().numpy(),
+                             terminated=(torch.rand(slots, generator=g) < 0.1).numpy(), truncated=np.zeros(slots, bool),
+                             obs=torch.randn(slots, obs_dim, generator=g).numpy(), act=(torch.rand(slots, act_dim, generator=g) * 2 - 1).numpy(),
+                             obs_next=torch.randn(slots, obs_dim, generator=g).numpy())
+    out = {}
+    import os
+    for mode in ("rows", "gather"):
+        if mode == "gather":
+            os.environ["TS_SAC_NO_ROWS"] = "1"
+        try:
+            eng, _ = make_engine(obs_dim, act_dim, 11, cfg)
+            gg = torch.Generator().manual_seed(5)
+            rets = []
+            for _ in range(3):
+                idx = torch.randint(0, slots, (B,), generator=gg)
+                n0, n1 = torch.randn(B, act_dim, generator=gg), torch.randn(B, act_dim, generator=gg)
+                w = torch.rand(B, generator=gg) if weighted else None
+                ret = eng.preprocess(buf, idx, n0)
+                stats, w_out = eng.update_with_rows(buf, idx, ret, n1, w)
+                rets.append((ret.cpu(), stats.cpu(), w_out.cpu()))
+            torch.cuda.synchronize()
+            out[mode] = (rets, [getattr(eng, k).cpu().clone() for k in ("actor", "critic1", "critic2", "critic1_old", "actor_m",
+                                                                          "critic1_v", "log_alpha")])
+        finally:
+            os.environ.pop("TS_SAC_NO_ROWS", None)
+    for (r0, s0, w0), (r1, s1, w1) in zip(out["rows"][0], out["gather"][0]):
+        assert torch.equal(r0, r1) and torch.equal(s0, s1) and torch.equal(w0, w1)
+    for a, b in zip(out["rows"][1], out["gather"][1]):
+        assert torch.equal(a, b)

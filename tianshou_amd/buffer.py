@@ -483,7 +483,7 @@ class DeviceReplayBuffer:
                 raise ValueError("positions must be batch_size draws inside the available indices")
         return avail[positions]
 
-    def sample_indices(self, batch_size: int | None, *, u_buffer=None, within=None, generator=None) -> torch.Tensor:
+    def sample_indices(self, batch_size: int | None, *, u_buffer=None, within=None, generator=None, seed=None) -> torch.Tensor:
         """ReplayBufferManager.sample_indices (manager.py:200-234) for stack_num == 1 (frame-stacking buffers with
         `sample_avail`: `sample_indices_stacked`).
 
@@ -492,7 +492,8 @@ class DeviceReplayBuffer:
         in sub-buffer order (ts_sample_indices_random).  The reference draws from the buffers' own RandomStates
         (buffer_base.py:98); to reproduce a seeded reference run pass its draws: `u_buffer` float64[bs] (the uniforms
         `RandomState.choice(E, bs, p=...)` consumes) and `within` int64[bs] (the children's `choice(len_e, n_e)` values,
-        concatenated in sub-buffer order).  Without them the draws come from torch's device generator (`generator`).
+        concatenated in sub-buffer order).  Without them the draws come from torch's device generator (`generator`), or --
+        `seed=(key, counter)` -- from the engine's counter-based generator inside the sampling kernel (one launch).
         batch_size None (all indices, shuffled) and negative sizes stay with the reference."""
         if batch_size is None or batch_size < 0:
             raise NotImplementedError("sample_indices(None / negative) is not on the device path")
@@ -503,6 +504,17 @@ class DeviceReplayBuffer:
                 return torch.empty(0, dtype=torch.int64, device=dev)
             if (u_buffer is None) != (within is None):
                 raise ValueError("pass both u_buffer and within (the reference's draws) or neither")
+            if u_buffer is None and seed is not None:
+                # the engine's own counter-based draws (`seed` = (key, counter), e.g. (0x5EED, update number)): one launch
+                key, counter = seed
+                out = torch.empty(bs, dtype=torch.int64, device=dev)
+                if getattr(self, "_err", None) is None:
+                    self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(_lib.load().ts_sample_indices_seeded(
+                    _lib.ptr(self.offset), _lib.i64(self.buffer_num), _lib.ptr(self.lengths), C.c_uint64(int(key) & (2**64 - 1)),
+                    C.c_uint64(int(counter) & (2**64 - 1)), _lib.i64(bs), _lib.ptr(out), _lib.ptr(self._err),
+                    _lib.current_stream(dev)))
+                return out
             if u_buffer is None:
                 r = torch.rand(2, bs, dtype=torch.float64, device=dev, generator=generator)
                 u, w_i, w_u = r[0].contiguous(), None, r[1].contiguous()

@@ -298,12 +298,32 @@ __global__ void sample_all_kernel(const int64_t* offset, int64_t E, const int64_
 // The cdf is built sequentially in float64 by one thread, in NumPy's operation order (E is at most a few thousand).
 constexpr int SAMPLE_MAX_E = 4096;
 
+// Philox-4x32-10 (Salmon et al., SC'11): the counter-based generator of ts_normal_fill, here for the engine's own uniform
+// draws.  uniform53: a double in [0, 1) from 53 random bits (NumPy's random_sample recipe) of counter (index, stream).
+__device__ __forceinline__ void philox10(uint32_t (&c)[4], uint64_t seed) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ double uniform53(uint64_t seed, uint64_t stream, int64_t index, int which) {
+    uint32_t c[4] = {(uint32_t)index, (uint32_t)((uint64_t)index >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox10(c, seed);
+    const uint32_t a = c[2 * which] >> 5, b = c[2 * which + 1] >> 6;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
 __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __restrict__ offset, int64_t E,
                                                              const int64_t* __restrict__ lengths,
                                                              const double* __restrict__ u_buffer,
                                                              const int64_t* __restrict__ within_i,
                                                              const double* __restrict__ within_u, int64_t bs,
-                                                             int64_t* __restrict__ out, int* __restrict__ err) {
+                                                             int64_t* __restrict__ out, int* __restrict__ err,
+                                                             uint64_t seed = 0, uint64_t stream = 0) {
     __shared__ double cdf[SAMPLE_MAX_E];
     __shared__ int count[SAMPLE_MAX_E + 1];
     const int tid = threadIdx.x;
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __re
     }
     __syncthreads();
     for (int64_t k = tid; k < bs; k += 1024) {
-        const double u = u_buffer[k];
+        const double u = u_buffer ? u_buffer[k] : uniform53(seed, stream, k, 0);      // NULL: the engine's own draws
         int lo = 0, hi = (int)E;                       // first e with cdf[e] > u  (searchsorted side="right")
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
         if (lo >= (int)E) lo = (int)E - 1;
@@ -337,7 +357,7 @@ __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __re
         const int64_t len = lengths[lo];
         int64_t slot;
         if (within_i) slot = within_i[j];
-        else { slot = (int64_t)(within_u[j] * (double)len); if (slot >= len) slot = len - 1; }
+        else { slot = (int64_t)((within_u ? within_u[j] : uniform53(seed, stream, j, 1)) * (double)len); if (slot >= len) slot = len - 1; }
         if (slot < 0 || slot >= len) *err = 2;
         out[j] = offset[lo] + slot;
     }
@@ -506,6 +526,19 @@ int ts_sample_indices_random(const int64_t* offset, int64_t E, const int64_t* le
                TS_ERR_INVALID_ARG, "ts_sample_indices_random: NULL argument, or not exactly one of within_i / within_u");
     hipLaunchKernelGGL(sample_random_kernel, dim3(1), dim3(1024), 0, ts::as_stream(stream), offset, E, lengths,
                        u_buffer, within_i, within_u, batch_size, out, err_flag);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_sample_indices_seeded(const int64_t* offset, int64_t E, const int64_t* lengths, uint64_t seed, uint64_t counter,
+                             int64_t batch_size, int64_t* out, int* err_flag, ts_stream_t stream) {
+    TS_REQUIRE(E >= 1 && E <= SAMPLE_MAX_E, TS_ERR_UNSUPPORTED, "ts_sample_indices_seeded: 1 <= E <= %d sub-buffers", SAMPLE_MAX_E);
+    TS_REQUIRE(batch_size >= 0, TS_ERR_INVALID_ARG, "ts_sample_indices_seeded: negative batch_size");
+    if (batch_size == 0) return TS_OK;
+    TS_REQUIRE(offset && lengths && out && err_flag, TS_ERR_INVALID_ARG, "ts_sample_indices_seeded: NULL argument");
+    hipLaunchKernelGGL(sample_random_kernel, dim3(1), dim3(1024), 0, ts::as_stream(stream), offset, E, lengths,
+                       (const double*)nullptr, (const int64_t*)nullptr, (const double*)nullptr, batch_size, out, err_flag, seed,
+                       counter);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -230,17 +230,20 @@ __device__ __forceinline__ void store_head_row(float* __restrict__ row, float v)
 
 // x_a[b] = [obs | 0], x_c[b] = [obs | act | 0]; x_p (nullable) = a second copy of x_c's observation columns (its
 // action columns are written by the policy kernel).  Four output columns per thread (ka, kc are multiples of 32).
+// `rows` (nullable): obs / act are whole replay-buffer columns and sample b is their row rows[b] -- the gather of
+// ReplayBuffer.__getitem__ (buffer_base.py:605-649) happens here instead of in launches of its own.
 __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
                                                        int64_t B, int obs_dim, int act_dim, int ka, int kc,
                                                        float* __restrict__ x_a, float* __restrict__ x_c,
-                                                       float* __restrict__ x_p) {
+                                                       float* __restrict__ x_p, const int64_t* __restrict__ rows = nullptr) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int w4 = (ka + kc) / 4;
     if (i >= B * w4) return;
     const int64_t b = i / w4;
     const int j = (int)(i - b * w4) * 4;
-    const float* ob = obs + b * obs_dim;
+    const int64_t src = rows ? rows[b] : b;
+    const float* ob = obs + src * obs_dim;
     if (j < ka) {
         if (!x_a) return;
         f32x4 v;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__
             float e = 0.f;
             if (c < obs_dim) e = ob[c];
             vp[t] = e;
-            if (c >= obs_dim && c < obs_dim + act_dim && act) e = act[b * act_dim + c - obs_dim];
+            if (c >= obs_dim && c < obs_dim + act_dim && act) e = act[src * act_dim + c - obs_dim];
             v[t] = e;
         }
         *reinterpret_cast<f32x4*>(x_c + b * kc + k) = v;
@@ -301,13 +304,24 @@ __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict
 }
 
 // SAC._target_q_compute_value: min(Q1_old, Q2_old) - alpha * log_prob  (q arrays are [B, 32], column 0)
+// `rew` (nullable): also the 1-step return of compute_nstep_return (algorithm_base.py:785-817 with n_step = 1, in
+// ts_returns.hip nstep_fused_kernel's arithmetic: the value mask multiplies in float32, gamma and the reward add in float64):
+// out[b] = float(double(tq * mask) * gamma + rew[rows[b]]), mask = !terminated[rows[b]].
 __global__ __launch_bounds__(256) void sac_target_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
                                                          const float* __restrict__ logp, const float* __restrict__ log_alpha,
-                                                         float fixed_alpha, int64_t B, float* __restrict__ out) {
+                                                         float fixed_alpha, int64_t B, float* __restrict__ out,
+                                                         const double* __restrict__ rew = nullptr,
+                                                         const uint8_t* __restrict__ terminated = nullptr,
+                                                         const int64_t* __restrict__ rows = nullptr, double gamma = 0.0) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
-    out[b] = fminf(q1[b * 32], q2[b * 32]) - alpha * logp[b];
+    const float tq = fminf(q1[b * 32], q2[b * 32]) - alpha * logp[b];
+    if (!rew) { out[b] = tq; return; }
+    const int64_t r = rows ? rows[b] : b;
+    const float tqm = tq * (terminated[r] ? 0.f : 1.f);
+    const double q = (double)tqm * gamma;
+    out[b] = (float)(q + rew[r]);
 }
 
 // block-wide deterministic sum (1024 threads): butterfly inside each wavefront, then the 16 wave sums
@@ -855,9 +869,10 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     return TS_OK;
 }
 
-int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
-                    const float* log_alpha, double fixed_alpha, const float* obs_next, const float* noise, int64_t B,
-                    int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream) {
+static int sac_target_impl(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                           const float* log_alpha, double fixed_alpha, const float* obs_next, const float* noise, int64_t B,
+                           int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream, const int64_t* rows,
+                           const double* rew, const uint8_t* terminated, double gamma) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_target_q: workspace is NULL");
     TS_REQUIRE(B >= 1 && actor && critic1_old && critic2_old && obs_next && noise && out, TS_ERR_INVALID_ARG,
                "ts_sac_target_q: bad argument");
@@ -879,7 +894,7 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
     hipStream_t side;
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
-                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr, rows);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
@@ -896,9 +911,26 @@ int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_o
         if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
     hipLaunchKernelGGL(sac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, a2.out, logp,
-                       log_alpha, (float)fixed_alpha, B, out);
+                       log_alpha, (float)fixed_alpha, B, out, rew, terminated, rows, gamma);
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+int ts_sac_target_q(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                    const float* log_alpha, double fixed_alpha, const float* obs_next, const float* noise, int64_t B,
+                    int64_t obs_dim, int64_t act_dim, float* out, ts_stream_t stream) {
+    return sac_target_impl(ws, actor, critic1_old, critic2_old, log_alpha, fixed_alpha, obs_next, noise, B, obs_dim, act_dim, out,
+                           stream, nullptr, nullptr, nullptr, 0.0);
+}
+
+int ts_sac_returns_rows(ts_workspace* ws, const float* actor, const float* critic1_old, const float* critic2_old,
+                        const float* log_alpha, double fixed_alpha, const float* obs_next_buf, const double* rew_buf,
+                        const uint8_t* terminated_buf, const int64_t* rows, const float* noise, int64_t B, int64_t obs_dim,
+                        int64_t act_dim, double gamma, float* returns_out, ts_stream_t stream) {
+    TS_REQUIRE(obs_next_buf && rew_buf && terminated_buf && rows && returns_out, TS_ERR_INVALID_ARG,
+               "ts_sac_returns_rows: NULL argument");
+    return sac_target_impl(ws, actor, critic1_old, critic2_old, log_alpha, fixed_alpha, obs_next_buf, noise, B, obs_dim, act_dim,
+                           returns_out, stream, rows, rew_buf, terminated_buf, gamma);
 }
 
 }  // extern "C"
@@ -914,7 +946,7 @@ enum : int { PH_CRITIC_GRAD = 1, PH_CRITIC_APPLY = 2, PH_ACTOR_GRAD = 4, PH_ACTO
 int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
                     const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
                     int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads,
-                    int phases, ts_stream_t stream) {
+                    int phases, ts_stream_t stream, const int64_t* rows = nullptr) {
     float* const grads_out = phases == PH_ALL ? grads : nullptr;
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_update: workspace is NULL");
     TS_REQUIRE(st && hp && obs && act && returns && noise && stats_out5 && B >= 1 && adam_step >= 1,
@@ -972,7 +1004,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     }
     if (phases & PH_CRITIC_GRAD) {
         hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
-                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p);
+                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p, rows);
         // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
     }
 
@@ -1123,6 +1155,15 @@ int ts_sac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, c
                   ts_stream_t stream) {
     return sac_update_impl(ws, st, adam_step, obs, act, returns, weight, noise, B, obs_dim, act_dim, hp, stats_out5,
                            weight_out, grads_out, PH_ALL, stream);
+}
+
+int ts_sac_update_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs_buf, const float* act_buf,
+                       const int64_t* rows, const float* returns, const float* weight, const float* noise, int64_t B,
+                       int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out,
+                       ts_stream_t stream) {
+    TS_REQUIRE(rows != nullptr, TS_ERR_INVALID_ARG, "ts_sac_update_rows: rows is NULL");
+    return sac_update_impl(ws, st, adam_step, obs_buf, act_buf, returns, weight, noise, B, obs_dim, act_dim, hp, stats_out5,
+                           weight_out, nullptr, PH_ALL, stream, rows);
 }
 
 int ts_sac_update_phase(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,

@@ -1250,8 +1250,11 @@ def make_hip_sac(ref=None):
                 from .distributed import DataParallelSAC
 
                 runner = self._hip_dp(DataParallelSAC, eng)
-            stats, w = runner.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
-                                                batch.returns.reshape(-1), noise, weight)
+            if runner is eng and hasattr(eng, "update_with_rows"):               # the input packing reads the mirror's rows
+                stats, w = eng.update_with_rows(m, self._hip_idx, batch.returns.reshape(-1), noise, weight)
+            else:
+                stats, w = runner.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                                                    batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
             with torch.no_grad():

@@ -12,13 +12,14 @@ There is no CPU path: every function calls libtsengine.so and raises when it is 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
 from . import _lib
-from .buffer import DeviceReplayBuffer, gather_rows
+from .buffer import DeviceReplayBuffer, _i64_dev, gather_rows
 from .returns import compute_nstep_return
 
 TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
@@ -213,8 +214,32 @@ class SACEngine:
         return out
 
     # -- _preprocess_batch ---------------------------------------------------------------------------------------
+    def _rows_ok(self, buffer: DeviceReplayBuffer) -> bool:
+        """The entry points that read their rows straight from the buffer columns (ts_sac_*_rows) need float32 columns of
+        the engine's widths, float64 rewards and uint8 flags -- what DeviceReplayBuffer keeps."""
+        o, a, n = buffer.obs, buffer.act, buffer.obs_next
+        return (o is not None and a is not None and n is not None and o.dtype == a.dtype == n.dtype == torch.float32
+                and o.is_contiguous() and a.is_contiguous() and n.is_contiguous() and o.dim() == 2 and a.dim() == 2
+                and o.shape[1] == self.obs_dim and a.shape[1] == self.act_dim and buffer.rew.dtype == torch.float64
+                and buffer.terminated.dtype == torch.uint8 and not os.environ.get("TS_SAC_NO_ROWS"))
+
     def preprocess(self, buffer: DeviceReplayBuffer, indices, noise) -> torch.Tensor:
-        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); needs buffer.obs_next."""
+        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); needs buffer.obs_next.
+        n_step = 1 (SAC's default): one launch sequence gathers obs_next inside the input packing and ends with the 1-step
+        return (ts_sac_returns_rows), bit-identical to the general path below."""
+        if self.cfg.n_step == 1 and self._rows_ok(buffer):
+            idx = _i64_dev(indices, self.device).reshape(-1).contiguous()
+            b = idx.numel()
+            noise = self._f32(noise, (b, self.act_dim))
+            out = torch.empty(b, dtype=torch.float32, device=self.device)
+            use_hidden(self._ws, self.hidden)
+            _lib.check(_lib.load().ts_sac_returns_rows(
+                self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
+                _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(buffer.obs_next),
+                _lib.ptr(buffer.rew), _lib.ptr(buffer.terminated), _lib.ptr(idx), _lib.ptr(noise), _lib.i64(b),
+                _lib.i64(self.obs_dim), _lib.i64(self.act_dim), _lib.f64(self.cfg.gamma), _lib.ptr(out),
+                _lib.current_stream(self.device)))
+            return out
 
         def tq_fn(buf, after):
             return self.target_q(gather_rows(buf.obs_next, after), noise)
@@ -244,6 +269,27 @@ class SACEngine:
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
             _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
             C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.ptr(grads_out), _lib.current_stream(self.device)))
+        return stats, w_out
+
+    def update_with_rows(self, buffer: DeviceReplayBuffer, indices, returns, noise, weight=None, lr_scale: float = 1.0):
+        """update_with_batch(buffer.obs[indices], buffer.act[indices], ...) without the two gather launches: the input
+        packing kernel reads the rows (ts_sac_update_rows).  Bit-identical."""
+        if not self._rows_ok(buffer):
+            return self.update_with_batch(gather_rows(buffer.obs, indices), gather_rows(buffer.act, indices), returns, noise,
+                                          weight, lr_scale=lr_scale)
+        idx = _i64_dev(indices, self.device).reshape(-1).contiguous()
+        b = idx.numel()
+        returns, noise = self._f32(returns, (b,)), self._f32(noise, (b, self.act_dim))
+        weight = None if weight is None else self._f32(weight, (b,))
+        self.adam_step += 1
+        stats = torch.empty(5, dtype=torch.float32, device=self.device)
+        w_out = torch.empty(b, dtype=torch.float32, device=self.device)
+        st, hp = self._state_c(), self.cfg.to_c(lr_scale)
+        use_hidden(self._ws, self.hidden)
+        _lib.check(_lib.load().ts_sac_update_rows(
+            self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(buffer.obs), _lib.ptr(buffer.act), _lib.ptr(idx),
+            _lib.ptr(returns), _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
+            C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.current_stream(self.device)))
         return stats, w_out
 
     # -- the same update in four phases (data-parallel replicas all-reduce between "grad" and "apply") -----------
