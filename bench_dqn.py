@@ -103,10 +103,8 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     def update():
         u = torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws
         idx, wt = per.sample(u)
-        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
-        if PREFETCH:
-            eng.prefetch_forward(obs)        # Q_online(s) on a side stream, beside the two s_{t+n} passes of _target_q
-        ret = eng.preprocess(buf, frames, idx, C)
+        # both stacked gathers in one launch, Q_online(s) on a side stream beside the two s_{t+n} passes of _target_q
+        obs, ret = eng.preprocess_with_obs(buf, frames, idx, C, prefetch=PREFETCH)
         loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
         per.update_weight(idx, td)
         return loss

@@ -377,6 +377,15 @@ int ts_gather_planes_nhwc(const uint8_t* src, int64_t n_planes, int64_t plane_el
 /* Same gather with uint8 output [B, plane_elems, C] for the `obs_u8` mode of the network entry points below. */
 int ts_gather_planes_nhwc_u8(const uint8_t* src, int64_t n_planes, int64_t plane_elems, const int64_t* plane_index,
                              int64_t B, int64_t C, uint8_t* out, ts_stream_t stream);
+/* Both frame-stack gathers of a DQN-family update on a frame buffer that stores single frames (stack_num = 4 through prev(),
+ * obs_next read at next(indices_after_n): examples/atari/atari_dqn.py:137-142, buffer_base.py:586-596, 624-626,
+ * algorithm_base.py:772-791) in ONE launch: obs_out[b] = stacked observation at index[b], obs_next_out[b] = stacked observation at
+ * next(next^(n_step - 1)(index[b])), both uint8 NHWC [B, plane_elems, 4].  Bit-identical to ts_nstep_indices + next() +
+ * 2 x (ts_stack_indices + ts_gather_planes_nhwc_u8).  stack_num 4 and plane_elems % 16 == 0 only (TS_ERR_UNSUPPORTED else). */
+int ts_dqn_gather_pair(const uint8_t* frames, int64_t n_planes, int64_t plane_elems, const int64_t* index, int64_t B,
+                       int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,
+                       const int64_t* last_index, const int64_t* lengths, uint8_t* obs_out, uint8_t* obs_next_out,
+                       ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layers on fp32 MFMA (NHWC activations)

@@ -365,3 +365,55 @@ def test_prefetched_forward_gives_bit_identical_updates():
     pre._pre = stale
     a, b = pre.update_with_batch(obs, act, ret, wt), plain.update_with_batch(obs, act, ret, wt)
     assert torch.equal(a[0], b[0]) and torch.equal(plain.params, pre.params)
+
+
+@pytest.mark.parametrize("n_step", [1, 3, 7])
+def test_pair_gather_equals_the_six_launch_path(n_step):
+    """ts_dqn_gather_pair (both stacked gathers of a DQN update in one launch) against nstep_indices -> next() ->
+    2 x (stack_indices + gather): identical bytes over EVERY slot of the reference-generated Atari fixture buffer (two
+    sub-buffers with episode ends and a wrapped write pointer) and of a ragged synthetic one, and the same returns through
+    DQNEngine.preprocess_with_obs as through DQNEngine.preprocess."""
+    from tianshou_amd import dqn as D
+    from tianshou_amd.buffer import DeviceReplayBuffer
+    from tianshou_amd.returns import nstep_indices
+
+    g, d, ocfg, bstate = DC.load("atari")
+    buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
+                             insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
+                             truncated=g["truncated"])
+    frames = torch.as_tensor(g["frames"]).cuda()
+    idx = torch.arange(d["E"] * d["slots"]).cuda()
+    cases = [(buf, frames, idx)]
+    # ragged: 5 sub-buffers of different fill, random episode ends, 16 x 16 frames, repeated / unordered indices
+    rng = np.random.default_rng(n_step)
+    sizes, fill = np.array([9, 1, 30, 17, 4]), np.array([9, 1, 12, 17, 0])
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    total = int(off[-1])
+    term = rng.random(total) < 0.15
+    trunc = rng.random(total) < 0.1
+    last = off[:-1] + np.array([3, 0, 11, 5, 0])
+    rb = DeviceReplayBuffer(offset=off, last_index=last, lengths=fill, insertion=(last + 1 - off[:-1]) % sizes,
+                            rew=rng.standard_normal(total), terminated=term, truncated=trunc)
+    fr = torch.as_tensor(rng.integers(0, 256, (total, 16, 16), dtype=np.uint8)).cuda()
+    valid = np.concatenate([np.arange(off[e], off[e] + fill[e]) for e in range(5)])
+    cases.append((rb, fr, torch.as_tensor(rng.choice(valid, 300)).cuda()))
+    for b, f, ix in cases:
+        pair = D.gather_obs_pair(f, b, ix, n_step, 4)
+        assert pair is not None
+        after = nstep_indices(b, ix, n_step)
+        assert torch.equal(pair[0], D.gather_obs_nhwc(f, b, ix, 4, as_u8=True))
+        assert torch.equal(pair[1], D.gather_obs_nhwc(f, b, b.next(after), 4, as_u8=True))
+    # the engine's two preprocess routes
+    c, h, w, A = d["c"], d["h"], d["w"], d["n_act"]
+    cfg = D.DQNConfig(gamma=0.99, n_step=n_step, target_update_freq=5, is_double=True, huber_delta=1.0, lr=1e-4)
+    p0 = OD.init_params(c, h, w, A, 1)
+    eng = D.DQNEngine(c, h, w, A, D.flat_from_torch([p0[k] for k in OD.PARAM_ORDER], c, h, w, A), cfg)
+    ix = idx[torch.randperm(idx.numel(), device="cuda")[:32]].contiguous()
+    obs, ret = eng.preprocess_with_obs(buf, frames, ix, 4)
+    assert eng._pre is not None and eng._pre[0] is obs
+    assert torch.equal(ret, eng.preprocess(buf, frames, ix, 4))
+    assert torch.equal(obs, D.gather_obs_nhwc(frames, buf, ix, 4, as_u8=True))
+    # layouts outside the kernel's fall back (None), with the same results from preprocess_with_obs
+    odd = torch.zeros((10, 5, 5), dtype=torch.uint8, device="cuda")
+    assert D.gather_obs_pair(odd, rb, torch.zeros(2, dtype=torch.int64).cuda(), n_step, 4) is None
+    assert D.gather_obs_pair(fr, rb, torch.zeros(2, dtype=torch.int64).cuda(), n_step, 2) is None

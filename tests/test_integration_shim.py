@@ -523,9 +523,9 @@ def test_hip_dqn_wrapper_runs_with_engine_double(dqn_algo, monkeypatch):
             self.params, self.params_old = flat.clone(), flat.clone()
             self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
 
-        def preprocess(self, m, frames, idx, stack, obs_next_frames=None):
-            assert frames.dtype == torch.uint8 and stack == 1 and obs_next_frames is not None
-            return torch.zeros(idx.numel())
+        def preprocess_with_obs(self, m, frames, idx, stack, obs_next_frames=None, prefetch=True):
+            assert frames.dtype == torch.uint8 and stack == 1 and obs_next_frames is not None and prefetch
+            return frames[idx].permute(0, 2, 3, 1), torch.zeros(idx.numel())
 
         def update_with_batch(self, obs, act, ret, weight=None):
             assert obs.shape == (8, 84, 84, 4) and obs.dtype == torch.uint8

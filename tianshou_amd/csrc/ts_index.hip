@@ -200,6 +200,67 @@ __global__ __launch_bounds__(256) void gather_planes_u8x16_kernel(const uint8_t*
     }
 }
 
+// Both frame-stack gathers of a DQN-family update on a `save_only_last_obs` buffer in ONE launch: the batch's own stacked
+// observations (ReplayBuffer.get(index, "obs") with stack_num = 4, buffer_base.py:586-596) and the stacked observations at
+// next(indices_after_n) that _target_q reads as obs_next (algorithm_base.py:772-791, buffer_base.py:624-626).  One workgroup
+// per sample: lane 0 of wave 0 walks prev() three times from the index, lane 0 of wave 1 walks next() n_step times and then
+// prev() three times (the same arithmetic as step_index_kernel / stack_indices_kernel / ts_returns.hip next_one -- the two
+// chains run side by side), then all 256 threads copy the eight planes with the 16-pixel transposing copy of
+// gather_planes_u8x16_kernel.  Replaces six launches (n-step indices, next(), two index stacks, two gathers).
+__global__ __launch_bounds__(256) void dqn_gather_pair_kernel(const uint8_t* __restrict__ src, int64_t plane_elems,
+                                                              const int64_t* __restrict__ index, int n_step,
+                                                              const int64_t* __restrict__ offset, int64_t E,
+                                                              const uint8_t* __restrict__ done,
+                                                              const int64_t* __restrict__ last_index,
+                                                              const int64_t* __restrict__ lengths,
+                                                              uint8_t* __restrict__ out_s, uint8_t* __restrict__ out_n) {
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+    __shared__ int64_t planes[2][4];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0 && tid < 128) {
+        const int which = tid >> 6;
+        const int64_t total = offset[E];
+        int64_t idx = index[b];
+        if (which == 1) {
+            for (int n = 0; n < n_step; ++n) {              // n_step - 1 steps to indices_after_n, one more to obs_next's slot
+                idx = pymod(idx, total);
+                const int64_t e = find_sub(offset, E, idx);
+                const int64_t start = offset[e], len = lengths[e], cur_len = len > 1 ? len : 1;
+                const int64_t end_flag = (done[idx] != 0) | (idx == last_index[e]);
+                idx = pymod(idx - start + 1 - end_flag, cur_len) + start;
+            }
+        }
+        planes[which][3] = idx;                              // val[indices] is taken before prev()
+        for (int j = 1; j < 4; ++j) {
+            idx = pymod(idx, total);
+            const int64_t e = find_sub(offset, E, idx);
+            const int64_t start = offset[e], len = lengths[e], cur_len = len > 1 ? len : 1;
+            const int64_t subind = pymod(idx - start - 1, cur_len);
+            const int64_t end_flag = (done[subind + start] != 0) | (subind + start == last_index[e]);
+            idx = pymod(subind + end_flag, cur_len) + start;
+            planes[which][3 - j] = idx;
+        }
+    }
+    __syncthreads();
+    const int gpp = (int)(plane_elems >> 4);
+    for (int gi = tid; gi < 2 * gpp; gi += 256) {
+        const int which = gi >= gpp;
+        const int q = gi - which * gpp;
+        u32x4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const u32x4*>(src + planes[which][c] * plane_elems + 16 * q);
+        u32x4* o = reinterpret_cast<u32x4*>((which ? out_n : out_s) + (b * plane_elems + 16 * q) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t0 = __builtin_amdgcn_perm(v[1][j], v[0][j], 0x05010400u), t1 = __builtin_amdgcn_perm(v[1][j], v[0][j], 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(v[3][j], v[2][j], 0x05010400u), u1 = __builtin_amdgcn_perm(v[3][j], v[2][j], 0x07030602u);
+            o[j] = u32x4{__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
+                         __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u)};
+        }
+    }
+}
+
 // single workgroup, order-preserving compaction over the E sub-buffers
 __global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
                                   const int64_t* lengths, int64_t* out, int64_t* n_out) {
@@ -338,12 +399,26 @@ __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __re
         if (total <= 0) *err = 1;
     }
     __syncthreads();
-    for (int64_t k = tid; k < bs; k += 1024) {
-        const double u = u_buffer ? u_buffer[k] : uniform53(seed, stream, k, 0);      // NULL: the engine's own draws
-        int lo = 0, hi = (int)E;                       // first e with cdf[e] > u  (searchsorted side="right")
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
-        if (lo >= (int)E) lo = (int)E - 1;
-        atomicAdd(&count[lo], 1);
+    // Histogram of the draws over the sub-buffers.  Few sub-buffers (<= 64): one ballot per sub-buffer and wave and ONE LDS
+    // atomic per (wave, sub-buffer) -- 4,096 draws on 16 counters otherwise serialise on the same 16 addresses (8 of this
+    // kernel's 11 us at the C5 batch); many sub-buffers: one atomic per draw, contention is low there.
+    const bool few = E <= 64;
+    for (int64_t k0 = 0; k0 < bs; k0 += 1024) {
+        const int64_t k = k0 + tid;
+        int lo = -1;
+        if (k < bs) {
+            const double u = u_buffer ? u_buffer[k] : uniform53(seed, stream, k, 0);      // NULL: the engine's own draws
+            int l = 0, hi = (int)E;                    // first e with cdf[e] > u  (searchsorted side="right")
+            while (l < hi) { const int mid = (l + hi) >> 1; if (cdf[mid] <= u) l = mid + 1; else hi = mid; }
+            lo = l >= (int)E ? (int)E - 1 : l;
+            if (!few) atomicAdd(&count[lo], 1);
+        }
+        if (few) {
+            for (int e = 0; e < (int)E; ++e) {
+                const unsigned long long m = __ballot(lo == e);
+                if ((tid & 63) == 0 && m) atomicAdd(&count[e], __popcll(m));
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {                                    // exclusive prefix, in place
@@ -603,6 +678,27 @@ int ts_stack_indices(const int64_t* index, int64_t I, int64_t stack_num, const i
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(stack_indices_kernel, dim3((unsigned)blocks), dim3(256), 0, ts::as_stream(stream), index, I,
                        stack_num, offset, E, done, last_index, lengths, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_dqn_gather_pair(const uint8_t* frames, int64_t n_planes, int64_t plane_elems, const int64_t* index, int64_t B,
+                       int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,
+                       const int64_t* last_index, const int64_t* lengths, uint8_t* obs_out, uint8_t* obs_next_out,
+                       ts_stream_t stream) {
+    TS_REQUIRE(B >= 0 && n_step >= 1 && E >= 1 && plane_elems >= 1 && n_planes >= 1, TS_ERR_INVALID_ARG,
+               "ts_dqn_gather_pair: bad sizes");
+    TS_REQUIRE(stack_num == 4 && plane_elems % 16 == 0, TS_ERR_UNSUPPORTED,
+               "ts_dqn_gather_pair: stack_num 4 and plane sizes that are multiples of 16 bytes (use ts_stack_indices + "
+               "ts_gather_planes_nhwc_u8 otherwise)");
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(frames && index && offset && done && last_index && lengths && obs_out && obs_next_out, TS_ERR_INVALID_ARG,
+               "ts_dqn_gather_pair: NULL argument");
+    TS_REQUIRE(((reinterpret_cast<uintptr_t>(frames) | reinterpret_cast<uintptr_t>(obs_out) |
+                 reinterpret_cast<uintptr_t>(obs_next_out)) & 15u) == 0, TS_ERR_INVALID_ARG,
+               "ts_dqn_gather_pair: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(dqn_gather_pair_kernel, dim3((unsigned)B), dim3(256), 0, ts::as_stream(stream), frames, plane_elems, index,
+                       (int)n_step, offset, E, done, last_index, lengths, obs_out, obs_next_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -500,10 +500,13 @@ __global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
         s += a.logp[b];
         if (a.weight_out) a.weight_out[b] = (a.td1[b] + a.td2[b]) / 2.f;
     }
+    // the three loss means: threads 64, 128, 192 (one per wave, beside the log-prob loads), same sequential sums as loss_finish
+    if (a.loss_part && (threadIdx.x == 64 || threadIdx.x == 128 || threadIdx.x == 192)) {
+        const int k = (threadIdx.x >> 6) - 1;
+        a.losses[k] = loss_finish(a.loss_part + k * a.n_part, a.n_part, a.B);
+    }
     const float tot = block_sum_1024(s, red);
     if (threadIdx.x != 0) return;
-    if (a.loss_part)
-        for (int k = 0; k < 3; ++k) a.losses[k] = loss_finish(a.loss_part + k * a.n_part, a.n_part, a.B);
     if (!a.log_alpha) { *a.alpha_out = a.fixed_alpha; *a.alpha_loss = 0.f; return; }
     // mean entropy deficit = mean(target - (-log_prob)); written so that the single-call and the phased update
     // (which receives -mean(log_prob) through the exchange buffer) evaluate the same float operations

@@ -15,6 +15,7 @@ convert from / to the reference's state_dict tensors (and Adam moments) exactly 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -23,7 +24,7 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev
 from .lagged import full_parameter_update
-from .returns import compute_nstep_return
+from .returns import compute_nstep_return, nstep_return_from_target_q
 
 TIANSHOU_KEYS = ["net.0.0.weight", "net.0.0.bias", "net.0.2.weight", "net.0.2.bias",
                  "net.0.4.weight", "net.0.4.bias", "net.1.weight", "net.1.bias",
@@ -177,6 +178,27 @@ def gather_obs_nhwc(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, sta
     return out
 
 
+def gather_obs_pair(frames: torch.Tensor, buffer: DeviceReplayBuffer, index, n_step: int, stack_num: int):
+    """(buffer.get(index, "obs"), the obs_next that `_target_q` reads at next(indices_after_n)) as two uint8 NHWC
+    tensors from ONE launch (ts_dqn_gather_pair), for a buffer that stores single frames and no obs_next
+    (examples/atari/atari_dqn.py:137-142; buffer_base.py:586-596, 624-626; algorithm_base.py:772-791).
+    None when the layout is outside the kernel's (stack_num 4, frame size a multiple of 16 bytes): the caller then
+    takes the index kernels + gather_obs_nhwc."""
+    if (stack_num != 4 or frames.dim() != 3 or frames.dtype != torch.uint8 or not frames.is_contiguous()
+            or (frames.shape[1] * frames.shape[2]) % 16 or frames.data_ptr() % 16 or os.environ.get("TS_DQN_NO_PAIR")):
+        return None
+    index = _i64_dev(index, buffer.device).reshape(-1)
+    b, (hh, ww) = index.numel(), frames.shape[1:]
+    obs = torch.empty((b, hh, ww, 4), dtype=torch.uint8, device=frames.device)
+    obs_next = torch.empty_like(obs)
+    _lib.check(_lib.load().ts_dqn_gather_pair(
+        _lib.ptr(frames), _lib.i64(frames.shape[0]), _lib.i64(hh * ww), _lib.ptr(index), _lib.i64(b), _lib.i64(n_step),
+        _lib.i64(stack_num), _lib.ptr(buffer.offset), _lib.i64(buffer.buffer_num), _lib.ptr(buffer.done),
+        _lib.ptr(buffer.last_index), _lib.ptr(buffer.lengths), _lib.ptr(obs), _lib.ptr(obs_next),
+        _lib.current_stream(frames.device)))
+    return obs, obs_next
+
+
 @dataclass
 class DQNConfig:
     """Hyper-parameters of the reference DQN (dqn.py:309-363) + Adam (optim.py:89-110)."""
@@ -297,6 +319,24 @@ class DQNEngine:
 
         b = compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step)
         return b.returns.reshape(-1)
+
+    def preprocess_with_obs(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, indices, stack_num: int,
+                            obs_next_frames: torch.Tensor | None = None, prefetch: bool = True):
+        """-> (obs uint8 NHWC [I, H, W, C], returns float32[I]): `preprocess` plus the batch's own observations, which
+        `update_with_batch` wants next.  On a frame buffer without obs_next both stacked gathers come from one launch
+        (gather_obs_pair) and the forward pass on obs is started on the side stream before the target passes
+        (prefetch_forward); otherwise this is gather_obs_nhwc + preprocess."""
+        pair = None if obs_next_frames is not None else gather_obs_pair(frames, buffer, indices, self.cfg.n_step, stack_num)
+        if pair is None:
+            obs = gather_obs_nhwc(frames, buffer, indices, stack_num, as_u8=True)
+            if prefetch:
+                self.prefetch_forward(obs)
+            return obs, self.preprocess(buffer, frames, indices, stack_num, obs_next_frames)
+        obs, obs_next = pair
+        if prefetch:
+            self.prefetch_forward(obs)
+        tq = self.target_q(obs_next)
+        return obs, nstep_return_from_target_q(buffer, indices, tq, self.cfg.gamma, self.cfg.n_step).reshape(-1)
 
     # -- the two halves of an update, for the data-parallel path (tianshou_amd.distributed.DataParallelDQN) ----
     def gradient(self, obs_nhwc, act, returns, weight, grad_out: torch.Tensor):

@@ -771,10 +771,10 @@ def make_hip_dqn(ref=None):
             nxt = m.obs_next if m.obs_next is not None else None
             # the batch's own observations, gathered here so that Q_online(batch.obs) of _update_with_batch can run beside the
             # two obs_next passes of _target_q (DQNEngine.prefetch_forward); data-parallel runs keep the plain order
-            self._hip_obs = D.gather_obs_nhwc(m.obs, m, idx, stack, as_u8=True)
-            if not self._hip_dp_on and hasattr(eng, "prefetch_forward"):
-                eng.prefetch_forward(self._hip_obs)
-            batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_frames=nxt).reshape(-1, 1)
+            # (on a frame buffer without obs_next, one launch gathers both stacked observations: DQNEngine.preprocess_with_obs)
+            self._hip_obs, ret = eng.preprocess_with_obs(m, m.obs, idx, stack, obs_next_frames=nxt,
+                                                         prefetch=not self._hip_dp_on)
+            batch.returns = ret.reshape(-1, 1)
             self._hip_idx, self._hip_stack = idx, stack
             if hasattr(batch, "weight"):
                 batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)

@@ -162,6 +162,22 @@ def nstep_indices(buffer: DeviceReplayBuffer, indices, n_step: int, want_stack: 
     return (after, stack) if want_stack else after
 
 
+def nstep_return_from_target_q(buffer: DeviceReplayBuffer, indices, tq: torch.Tensor, gamma: float, n_step: int):
+    """The arithmetic half of compute_nstep_return (algorithm_base.py:793-812) for a caller that already holds
+    target_q(s_{t+n}): float32 tensor shaped like `tq`.  The kernel re-walks next() from `indices` itself."""
+    dev = buffer.device
+    indices = _i64_dev(indices, dev).reshape(-1)
+    I = indices.numel()
+    tq2 = tq.to(torch.float32).reshape(I, -1).contiguous()
+    out = torch.empty_like(tq2)
+    _lib.check(_lib.load().ts_nstep_return_fused(
+        _lib.ptr(indices), _lib.i64(I), _lib.i64(n_step), _lib.ptr(buffer.offset),
+        _lib.i64(buffer.buffer_num), _lib.ptr(buffer.done), _lib.ptr(buffer.terminated),
+        _lib.ptr(buffer.last_index), _lib.ptr(buffer.lengths), _lib.ptr(buffer.rew), _lib.ptr(tq2),
+        _lib.i64(tq2.shape[1]), _lib.f64(gamma), _lib.ptr(out), None, _lib.current_stream(dev)))
+    return out.reshape(tq.shape)
+
+
 def compute_nstep_return(batch, buffer: DeviceReplayBuffer, indices, target_q_fn,
                          gamma: float = 0.99, n_step: int = 1, want_f64: bool = False):
     """Algorithm.compute_nstep_return (algorithm_base.py:721-817): sets batch.returns (float32
