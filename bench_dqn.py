@@ -87,6 +87,7 @@ def cpu_baseline(updates: int = 3, budget_s: float = 10.0):
 
 
 PREFETCH = not os.environ.get("TS_DQN_NO_PREFETCH")      # A/B switch of the side-stream forward pass
+REPLAY_STREAM = not os.environ.get("TS_DQN_NO_REPLAY_STREAM")      # A/B switch: priority update + next batch beside the backward pass
 
 
 def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
@@ -100,13 +101,22 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     eng = D.DQNEngine(C, H, W, N_ACT, D.flat_from_torch(tensors, C, H, W, N_ACT), cfg)
     gen = torch.Generator(device="cuda").manual_seed(1)
 
+    draw = lambda: torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws  # noqa: E731
+    replay = D.ReplayStream(eng, buf, frames, per, C, draw, lambda i: act[i]) if REPLAY_STREAM else None
+
     def update():
-        u = torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws
-        idx, wt = per.sample(u)
+        if replay is None:
+            idx, wt = per.sample(draw())
+            a, pair = act[idx], None
+        else:               # sampled and gathered on the replay stream while the previous update ran its backward pass
+            idx, wt, a, pair = replay.take()
         # both stacked gathers in one launch, Q_online(s) on a side stream beside the two s_{t+n} passes of _target_q
-        obs, ret = eng.preprocess_with_obs(buf, frames, idx, C, prefetch=PREFETCH)
-        loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
-        per.update_weight(idx, td)
+        obs, ret = eng.preprocess_with_obs(buf, frames, idx, C, prefetch=PREFETCH, pair=pair)
+        loss, td = eng.update_with_batch(obs, a, ret, wt)
+        if replay is None:
+            per.update_weight(idx, td)
+        else:
+            replay.give(idx, td)
         return loss
 
     BI.warm_clocks()

@@ -417,3 +417,43 @@ def test_pair_gather_equals_the_six_launch_path(n_step):
     odd = torch.zeros((10, 5, 5), dtype=torch.uint8, device="cuda")
     assert D.gather_obs_pair(odd, rb, torch.zeros(2, dtype=torch.int64).cuda(), n_step, 4) is None
     assert D.gather_obs_pair(fr, rb, torch.zeros(2, dtype=torch.int64).cuda(), n_step, 2) is None
+
+
+def test_replay_stream_cycle_equals_the_sequential_cycle():
+    """dqn.ReplayStream (priority update + next batch's draws, sum-tree descent and frame gathers on a second stream behind
+    ts_dqn_wait_td, beside the update's backward pass) against the reference order sample -> preprocess -> update ->
+    update_weight on one stream: six updates on a 4096-slot prioritized frame buffer, identical indices, weights, losses, TD
+    errors, parameters and sum tree."""
+    import bench_dqn as BD
+    from tianshou_amd import dqn as D
+
+    def cycle(use_stream: bool):
+        frames, act, buf, per = BD.build(4096, 4, seed=3)
+        p0 = OD.init_params(4, 84, 84, 6, 2)
+        cfg = D.DQNConfig(gamma=0.99, n_step=3, target_update_freq=2, is_double=True, huber_delta=1.0, lr=1e-4)
+        eng = D.DQNEngine(4, 84, 84, 6, D.flat_from_torch([p0[k] for k in OD.PARAM_ORDER], 4, 84, 84, 6), cfg)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        draw = lambda: torch.rand(64, generator=gen, device="cuda", dtype=torch.float64)  # noqa: E731
+        rs = D.ReplayStream(eng, buf, frames, per, 4, draw, lambda i: act[i]) if use_stream else None
+        log = []
+        for _ in range(6):
+            if rs is None:
+                idx, wt = per.sample(draw())
+                a, pair = act[idx], None
+            else:
+                idx, wt, a, pair = rs.take()
+            obs, ret = eng.preprocess_with_obs(buf, frames, idx, 4, pair=pair)
+            loss, td = eng.update_with_batch(obs, a, ret, wt)
+            if rs is None:
+                per.update_weight(idx, td)
+            else:
+                rs.give(idx, td)
+            log.append((idx.clone(), wt.clone(), loss.clone(), td.clone()))
+        torch.cuda.synchronize()
+        return log, eng.params.clone(), per.weight._value.clone(), per.prio_minmax.clone()
+
+    a, b = cycle(False), cycle(True)
+    for it, (x, y) in enumerate(zip(a[0], b[0])):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), it
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])

@@ -84,6 +84,10 @@ struct ts_workspace {
     hipStream_t side;
     hipEvent_t side_ev[16];
     int side_ready;
+    // recorded by every ts_dqn_update* call right after its TD-error kernel (ts_dqn_wait_td): the priority update and the
+    // next batch's sampling need nothing else from the update and can run beside its backward pass
+    hipEvent_t td_ev;
+    int td_ev_ready;
 };
 
 namespace ts {

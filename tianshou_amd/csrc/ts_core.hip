@@ -158,6 +158,7 @@ int ts_workspace_destroy(ts_workspace* ws) {
         for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ws->side_ev[i]);
         (void)hipStreamDestroy(ws->side);
     }
+    if (ws->td_ev_ready) { (void)hipSetDevice(ws->device); (void)hipEventDestroy(ws->td_ev); }
     if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }
     for (int k = 0; k < 2; ++k)
         if (ws->conv_scratch[k]) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->conv_scratch[k]); }

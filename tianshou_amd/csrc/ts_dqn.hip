@@ -330,6 +330,11 @@ static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
                        (float)hp->huber_delta, td_out, dq, loss_out);
     TS_LAUNCH_CHECK();
+    if (!ws->td_ev_ready) {
+        TS_HIP_CHECK(hipEventCreateWithFlags(&ws->td_ev, hipEventDisableTiming));
+        ws->td_ev_ready = 1;
+    }
+    TS_HIP_CHECK(hipEventRecord(ws->td_ev, s));          // td_out / loss_out are written: ts_dqn_wait_td
     // head backward
     hipLaunchKernelGGL(head_wgrad_kernel, dim3(HIDDEN + 1), dim3(256), 0, s, dq, act, sc.h[3], B, n.n_act,
                        grad + n.off[4]);
@@ -363,6 +368,13 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
                   float* loss_out, float* grad_out, ts_stream_t stream) {
     return dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, obs_nhwc, obs_u8, act, returns, weight, B, hp,
                            td_out, loss_out, grad_out, stream, nullptr, "ts_dqn_update");
+}
+
+int ts_dqn_wait_td(ts_workspace* ws, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_wait_td: workspace is NULL");
+    TS_REQUIRE(ws->td_ev_ready, TS_ERR_INVALID_ARG, "ts_dqn_wait_td: no ts_dqn_update* call has run on this workspace");
+    TS_HIP_CHECK(hipStreamWaitEvent(ts::as_stream(stream), ws->td_ev, 0));
+    return TS_OK;
 }
 
 int64_t ts_dqn_cache_bytes(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t B) {

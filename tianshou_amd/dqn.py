@@ -274,6 +274,12 @@ class DQNEngine:
         obs_nhwc.record_stream(self._side)
         self._pre = (obs_nhwc, cache_ptr, done, (self.params._version, self.adam_step), b)
 
+    def wait_td(self, stream: torch.cuda.Stream) -> None:
+        """`stream` waits for the TD errors and the loss of the last `update_with_batch` -- not for its backward pass and
+        Adam step (ts_dqn_wait_td).  What `_postprocess_batch` does with them (PrioritizedReplayBuffer.update_weight,
+        prio.py:89-100) and the sampling of the next batch can then run on `stream` beside the rest of the update."""
+        _lib.check(_lib.load().ts_dqn_wait_td(self._ws.handle, C.c_void_p(stream.cuda_stream)))
+
     # -- DiscreteQLearningPolicy.forward ---------------------------------------------------------
     def forward(self, obs_nhwc: torch.Tensor, params: torch.Tensor | None = None, want_act: bool = True):
         """-> (logits float32[B, A], act int64[B] = argmax)."""
@@ -321,12 +327,14 @@ class DQNEngine:
         return b.returns.reshape(-1)
 
     def preprocess_with_obs(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, indices, stack_num: int,
-                            obs_next_frames: torch.Tensor | None = None, prefetch: bool = True):
+                            obs_next_frames: torch.Tensor | None = None, prefetch: bool = True, pair=None):
         """-> (obs uint8 NHWC [I, H, W, C], returns float32[I]): `preprocess` plus the batch's own observations, which
         `update_with_batch` wants next.  On a frame buffer without obs_next both stacked gathers come from one launch
         (gather_obs_pair) and the forward pass on obs is started on the side stream before the target passes
-        (prefetch_forward); otherwise this is gather_obs_nhwc + preprocess."""
-        pair = None if obs_next_frames is not None else gather_obs_pair(frames, buffer, indices, self.cfg.n_step, stack_num)
+        (prefetch_forward); otherwise this is gather_obs_nhwc + preprocess.  `pair`: the two gathers, already done by the
+        caller (ReplayStream)."""
+        if pair is None and obs_next_frames is None:
+            pair = gather_obs_pair(frames, buffer, indices, self.cfg.n_step, stack_num)
         if pair is None:
             obs = gather_obs_nhwc(frames, buffer, indices, stack_num, as_u8=True)
             if prefetch:
@@ -396,3 +404,52 @@ class DQNEngine:
             _lib.i64(b), C.byref(hp), _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
             _lib.current_stream(self.device)))
         return loss, td
+
+
+class ReplayStream:
+    """The replay half of a prioritized off-policy cycle on its own stream.
+
+    Reference order per update (trainer.py:1093 -> algorithm_base.py:583-631): buffer.sample -> _preprocess_batch ->
+    _update_with_batch -> _postprocess_batch (PrioritizedReplayBuffer.update_weight with the TD errors, prio.py:89-100).
+    The TD errors exist right after the forward pass and the loss of `_update_with_batch`; the priority update, the next
+    batch's draws, its sum-tree descent and its frame gathers need nothing from the backward pass or the optimizer step
+    that follow.  Here they are issued on a second stream behind `DQNEngine.wait_td`, so they run beside the backward
+    pass; the caller's stream picks the finished batch up with an event.  Same operations on the same values in the same
+    order as the sequential loop -- only their placement in time differs.
+
+    draw: () -> float64[batch] uniform draws on the device (prio.py:65); act_of: index tensor -> actions."""
+
+    def __init__(self, eng: DQNEngine, buffer: DeviceReplayBuffer, frames: torch.Tensor, per, stack_num: int, draw, act_of):
+        self.eng, self.buffer, self.frames, self.per, self.stack, self.draw, self.act_of = eng, buffer, frames, per, stack_num, draw, act_of
+        self.stream = torch.cuda.Stream(device=eng.device)
+        self._next = None
+        self._ready = None
+
+    def _sample(self):
+        idx, wt = self.per.sample(self.draw())
+        pair = gather_obs_pair(self.frames, self.buffer, idx, self.eng.cfg.n_step, self.stack)
+        self._next = (idx, wt, self.act_of(idx), pair)
+        self._ready = torch.cuda.Event()
+        self._ready.record(self.stream)
+
+    def take(self):
+        """-> (indices, IS weights, actions, (obs, obs_next) or None) of the next batch, ready on the caller's stream."""
+        main = torch.cuda.current_stream(self.eng.device)
+        if self._next is None:
+            self.stream.wait_stream(main)
+            with torch.cuda.stream(self.stream):
+                self._sample()
+        main.wait_event(self._ready)
+        out, self._next = self._next, None
+        for t in (out[0], out[1], out[2]) + (tuple(out[3]) if out[3] is not None else ()):
+            t.record_stream(main)
+        return out
+
+    def give(self, indices: torch.Tensor, td: torch.Tensor) -> None:
+        """After `update_with_batch`: priority update with its TD errors and the next batch, beside the rest of the update."""
+        self.eng.wait_td(self.stream)
+        indices.record_stream(self.stream)
+        td.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.per.update_weight(indices, td)
+            self._sample()

@@ -106,7 +106,12 @@ class PrioritizedWeights:
         self.weight = SegmentTree(size, device)
         # {max_prio, min_prio}, prio.py:36
         self.prio_minmax = torch.ones(2, dtype=torch.float64, device=device)
-        self._ws = _lib.default_workspace(_dev_index(self.weight._value))
+
+    @property
+    def _ws(self):
+        # the scratch of the CURRENT stream (leaf ids / winner table of a priority update): a priority update issued on a
+        # replay stream beside an update's backward pass must not share the update's workspace
+        return _lib.default_workspace(_dev_index(self.weight._value))
 
     def init_weight(self, index) -> None:
         """prio.py:46-47: new transitions get max_prio ** alpha."""
