@@ -107,11 +107,11 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     def update():
         if replay is None:
             idx, wt = per.sample(draw())
-            a, pair = act[idx], None
+            a, pair, coef = act[idx], None, None
         else:               # sampled and gathered on the replay stream while the previous update ran its backward pass
-            idx, wt, a, pair = replay.take()
+            idx, wt, a, pair, coef = replay.take()
         # both stacked gathers in one launch, Q_online(s) on a side stream beside the two s_{t+n} passes of _target_q
-        obs, ret = eng.preprocess_with_obs(buf, frames, idx, C, prefetch=PREFETCH, pair=pair)
+        obs, ret = eng.preprocess_with_obs(buf, frames, idx, C, prefetch=PREFETCH, pair=pair, coef=coef)
         loss, td = eng.update_with_batch(obs, a, ret, wt)
         if replay is None:
             per.update_weight(idx, td)
@@ -126,6 +126,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = update()
+    t_host = time.perf_counter() - t0            # the host's share: enqueueing `steps` updates (no synchronisation inside)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
@@ -159,6 +160,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
                    "parallelism": "dp1"},
         "roofline": roof, "roofline_by_kind": kinds,
         "whole_update_mfma_frac": total_flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "host_enqueue_ms_per_step": t_host / steps * 1e3,
         "cpu_baseline": cpu_baseline() if with_cpu else None, "final_loss": float(loss),
     }
     return out

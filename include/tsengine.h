@@ -132,6 +132,15 @@ int ts_nstep_return_fused(const int64_t* indices, int64_t I, int64_t n_step,
                           int64_t A, double gamma, float* out, double* out64,
                           ts_stream_t stream);
 
+/* The part of ts_nstep_return_fused that does not depend on target_q (the index walk, the reward sums, the masks): per
+ * index mask = value_mask(idx_after_n) as float32 (:798), gpow = gamma^n_eff and mc = the discounted reward sum of
+ * _nstep_return (:1201-1222), both float64, such that returns = float(double(target_q * mask) * gpow + mc).  It can run
+ * before (beside) the target network's passes; ts_dqn_target_returns finishes the returns. */
+int ts_nstep_coefficients(const int64_t* indices, int64_t I, int64_t n_step, const int64_t* offset, int64_t E,
+                          const uint8_t* done_B, const uint8_t* terminated_B, const int64_t* last_index,
+                          const int64_t* lengths, const double* rew_B, double gamma, float* mask_out, double* gpow_out,
+                          double* mc_out, ts_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Replay-buffer index math (bit-exact integers)
  * ------------------------------------------------------------------------------------------- */
@@ -442,6 +451,15 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
 int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
                           int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
                           float* out, ts_stream_t stream);
+
+/* ts_dqn_target_q_fused followed by the arithmetic of compute_nstep_return (algorithm_base.py:798-811) in the same final
+ * kernel: returns_out[b] = float(double(target_q[b] * mask[b]) * gpow[b] + mc[b]) with the coefficients of
+ * ts_nstep_coefficients -- bit-identical to ts_dqn_target_q_fused + ts_nstep_return_fused, one launch less on the path
+ * between the target passes and the loss. */
+int ts_dqn_target_returns(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                          const float* nstep_mask, const double* nstep_gpow, const double* nstep_mc, float* returns_out,
+                          ts_stream_t stream);
 
 typedef struct ts_dqn_hparams {
     double lr;            /* < 0: compute the gradient only (no optimizer step) */

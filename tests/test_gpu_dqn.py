@@ -439,16 +439,16 @@ def test_replay_stream_cycle_equals_the_sequential_cycle():
         for _ in range(6):
             if rs is None:
                 idx, wt = per.sample(draw())
-                a, pair = act[idx], None
+                a, pair, coef = act[idx], None, None
             else:
-                idx, wt, a, pair = rs.take()
-            obs, ret = eng.preprocess_with_obs(buf, frames, idx, 4, pair=pair)
+                idx, wt, a, pair, coef = rs.take()
+            obs, ret = eng.preprocess_with_obs(buf, frames, idx, 4, pair=pair, coef=coef)
             loss, td = eng.update_with_batch(obs, a, ret, wt)
             if rs is None:
                 per.update_weight(idx, td)
             else:
                 rs.give(idx, td)
-            log.append((idx.clone(), wt.clone(), loss.clone(), td.clone()))
+            log.append((idx.clone(), wt.float(), loss.clone(), td.clone()))
         torch.cuda.synchronize()
         return log, eng.params.clone(), per.weight._value.clone(), per.prio_minmax.clone()
 

@@ -82,6 +82,7 @@ struct ts_workspace {
     // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
     int mlp_hidden;
     hipStream_t side;
+    hipStream_t side2;           // second side stream (ts::side_streams): created together with `side`
     hipEvent_t side_ev[16];
     int side_ready;
     // recorded by every ts_dqn_update* call right after its TD-error kernel (ts_dqn_wait_td): the priority update and the
@@ -100,6 +101,7 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
 //   enqueued on `from` before it.
 int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == main while profiling (clean per-kernel times)
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
+int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b);     // both side streams
 
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {

@@ -38,6 +38,16 @@ int conv_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* W
 // (col_begin, col_end): only the input-channel tiles covering [col_begin, col_end) are computed.
 // out[i] = sum_s slabs[s][i]
 int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out);
+// Backward pass of a chain of n layers (layer i reads x[i], x[i + 1] = its output after ReLU; dy[n - 1] = the upstream
+// gradient, already masked): grad[i] = dL/d(weights, bias) of layer i, dy[i - 1] = (dy[i] W_i^T) * (x[i] > 0).
+// The input gradients run down the caller's stream.  The weight gradient of layer i (+ its slab sum) needs dY_i only:
+// layers n-1, n-2, ... alternate between the workspace's two side streams, so none waits for the one above it (with one
+// side stream the four weight gradients of the NatureCNN formed the critical path of the backward pass); the first
+// layer's -- nothing below depends on it -- stays on the caller's stream behind the last input gradient.  slabs[i]:
+// conv_wgrad_splits(l[i]) * param_elems floats, one buffer PER LAYER.  On return the caller's stream has joined both side
+// streams.
+int chain_backward(hipStream_t s, ts_workspace* ws, int n, const ConvGeom* l, const float* const* x, float* const* dy,
+                   const float* const* wb, float* const* slabs, float* const* grad, bool x0_u8);
 // The weight gradients of up to sixteen small layers in one launch (bit-identical to conv_wgrad per layer; layers that
 // qualify for the large-M kernels are launched on their own).  slabs[i]: conv_wgrad_splits(g[i]) * param_elems floats.
 int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const* X, const float* const* dY,

@@ -649,6 +649,23 @@ int slab_sum(hipStream_t s, const float* slabs, int nslab, int64_t n, float* out
     return TS_OK;
 }
 
+int chain_backward(hipStream_t s, ts_workspace* ws, int n, const ConvGeom* l, const float* const* x, float* const* dy,
+                   const float* const* wb, float* const* slabs, float* const* grad, bool x0_u8) {
+    TS_REQUIRE(n >= 1 && n <= 8, TS_ERR_INVALID_ARG, "chain_backward: 1 .. 8 layers");
+    hipStream_t side[2];
+    if (int rc = side_streams(ws, s, &side[0], &side[1])) return rc;
+    for (int i = n - 1; i >= 0; --i) {
+        hipStream_t w = i == 0 ? s : side[(n - 1 - i) & 1];
+        if (int rc = stream_wait(ws, s, w, i)) return rc;                 // dY_i (and everything before it) is ready
+        if (int rc = conv_wgrad(w, l[i], x[i], dy[i], slabs[i], ws, i == 0 && x0_u8)) return rc;
+        if (int rc = slab_sum(w, slabs[i], conv_wgrad_splits(l[i]), l[i].param_elems(), grad[i])) return rc;
+        if (i > 0)
+            if (int rc = conv_dgrad(s, l[i], dy[i], wb[i], x[i], dy[i - 1], ws)) return rc;
+    }
+    if (int rc = stream_wait(ws, side[0], s, 8)) return rc;
+    return stream_wait(ws, side[1], s, 9);
+}
+
 int slab_sum_multi(hipStream_t s, const SlabSeg* segs, int nseg) {
     TS_REQUIRE(nseg >= 1 && nseg <= SLAB_SEGS_MAX, TS_ERR_INVALID_ARG, "slab_sum_multi: 1..%d segments", SLAB_SEGS_MAX);
     SlabSegs a{};

@@ -65,10 +65,17 @@ int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
     if (!ws->side_ready) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
         TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side2, hipStreamNonBlocking));
         for (int i = 0; i < 16; ++i) TS_HIP_CHECK(hipEventCreateWithFlags(&ws->side_ev[i], hipEventDisableTiming));
         ws->side_ready = 1;
     }
     *out = ws->side;
+    return TS_OK;
+}
+
+int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b) {
+    if (int rc = side_stream(ws, main, a)) return rc;
+    *b = *a == main ? main : ws->side2;
     return TS_OK;
 }
 
@@ -156,7 +163,9 @@ int ts_workspace_destroy(ts_workspace* ws) {
         (void)hipSetDevice(ws->device);
         (void)hipStreamSynchronize(ws->side);
         for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ws->side_ev[i]);
+        (void)hipStreamSynchronize(ws->side2);
         (void)hipStreamDestroy(ws->side);
+        (void)hipStreamDestroy(ws->side2);
     }
     if (ws->td_ev_ready) { (void)hipSetDevice(ws->device); (void)hipEventDestroy(ws->td_ev); }
     if (ws->ppo_image) { (void)hipSetDevice(ws->device); (void)hipDeviceSynchronize(); (void)hipFree(ws->ppo_image); }

@@ -686,17 +686,20 @@ int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_
     hipStream_t s = ts::as_stream(stream);
 
     // workspace: activations | dY of every layer | wgrad slabs | flat gradient | per-sample loss terms | norm partials
-    size_t slab = 0;
-    for (int i = 0; i < 5; ++i)
-        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
-    size_t bytes = acts_bytes(n) + al(slab) + al(4 * (size_t)n.off[5]) + al(4 * (size_t)B) + 4096;
+    size_t slab[5], slab_all = 0;
+    for (int i = 0; i < 5; ++i) {          // one slab set per layer: the weight gradients run side by side (ts::chain_backward)
+        slab[i] = al(4 * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+        slab_all += slab[i];
+    }
+    size_t bytes = acts_bytes(n) + slab_all + al(4 * (size_t)n.off[5]) + al(4 * (size_t)B) + 4096;
     for (int i = 0; i < 5; ++i) bytes += al(4 * (size_t)n.l[i].out_elems());
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Acts a;
     char* p = carve_acts(n, static_cast<char*>(ws->base), &a);
     float* dy[5];
     for (int i = 0; i < 5; ++i) { dy[i] = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.l[i].out_elems()); }
-    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
+    float* slabs[5];
+    for (int i = 0; i < 5; ++i) { slabs[i] = reinterpret_cast<float*>(p); p += slab[i]; }
     float* grad = reinterpret_cast<float*>(p); p += al(4 * (size_t)n.off[5]);
     float* lw = reinterpret_cast<float*>(p); p += al(4 * (size_t)B);
     float* norm_part = reinterpret_cast<float*>(p);
@@ -717,20 +720,17 @@ int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, lw, B, loss_out);
     TS_LAUNCH_CHECK();
 
-    // head, fc1, conv3, conv2, conv1: the weight gradient of a layer (+ slab sum) on the side stream, the input
-    // gradient that feeds the layer below on the caller's stream (as ts_dqn_update).
-    hipStream_t side;
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
-    for (int i = 4; i >= 0; --i) {
-        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.h[i - 1];
-        if (int rc = ts::stream_wait(ws, s, side, i)) return rc;
-        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
-        if (int rc = ts::slab_sum(side, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
-            return rc;
-        if (i > 0)
-            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], a.h[i - 1], dy[i - 1], ws)) return rc;
+    // head, fc1, conv3, conv2, conv1: input gradients down the caller's stream, the weight gradients beside them on the
+    // workspace's side streams (ts::chain_backward, as ts_dqn_update)
+    {
+        const float* x[5]; const float* wb[5]; float* g[5];
+        for (int i = 0; i < 5; ++i) {
+            x[i] = i == 0 ? static_cast<const float*>(obs_nhwc) : a.h[i - 1];
+            wb[i] = params + n.off[i];
+            g[i] = grad + n.off[i];
+        }
+        if (int rc = ts::chain_backward(s, ws, 5, n.l, x, dy, wb, slabs, g, obs_u8 != 0)) return rc;
     }
-    if (int rc = ts::stream_wait(ws, side, s, 8)) return rc;
     if (hp->lr < 0.0) return TS_OK;
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.off[5], adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);

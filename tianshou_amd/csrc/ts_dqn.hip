@@ -75,9 +75,14 @@ __global__ __launch_bounds__(256) void head_forward_kernel(const float* __restri
 }
 
 // ---- DQN._target_q (dqn.py:365-379) ----------------------------------------------------------------
+// With the n-step coefficients of ts_nstep_coefficients: out = the n-step return float(double(tq * mask) * gpow + mc)
+// (algorithm_base.py:798-811) instead of tq.
 __global__ __launch_bounds__(256) void target_q_kernel(const float* __restrict__ q_online,
                                                        const float* __restrict__ q_target, int64_t B, int A,
-                                                       int is_double, float* __restrict__ out) {
+                                                       int is_double, float* __restrict__ out,
+                                                       const float* __restrict__ ns_mask = nullptr,
+                                                       const double* __restrict__ ns_gpow = nullptr,
+                                                       const double* __restrict__ ns_mc = nullptr) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const float* sel = is_double ? q_online : q_target;
@@ -87,79 +92,92 @@ __global__ __launch_bounds__(256) void target_q_kernel(const float* __restrict__
         const float v = sel[b * A + a];
         if (v > best) { best = v; best_a = a; }
     }
-    out[b] = q_target[b * A + best_a];
+    const float tq = q_target[b * A + best_a];
+    if (ns_mask == nullptr) { out[b] = tq; return; }
+    const float tqm = tq * ns_mask[b];
+    const double qd = (double)tqm * ns_gpow[b];
+    out[b] = (float)(qd + ns_mc[b]);
 }
 
-// ---- TD error, loss and d loss / d Q[b, act_b]  (dqn.py:388-401) ----------------------------------
-__global__ __launch_bounds__(1024) void td_loss_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
-                                                       const float* __restrict__ ret, const float* __restrict__ weight,
-                                                       int64_t B, int A, float huber_delta, float* __restrict__ td,
-                                                       float* __restrict__ dq, float* __restrict__ loss) {
-    __shared__ float red[1024];
+// ---- TD error, loss, d loss / d Q[b, act_b] and the head layer's backward pass in ONE launch (dqn.py:388-401) ----------
+// d loss_b / d q[b, act_b] (times 1 / B for the mean) and the loss term: a function of one sample -- every workgroup that
+// needs it recomputes it from q / returns / weight instead of reading it from a kernel launched before (three dependent
+// 4 us launches with queue bubbles between them were 35 us of the C3 update's critical path).
+__device__ __forceinline__ float td_terms(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                          const float* __restrict__ ret, const float* __restrict__ weight, int64_t b, int A,
+                                          float huber_delta, float inv_b, float* t_out, float* l_out) {
+    const float t = ret[b] - q[b * A + act[b]];
+    float l, g;                                  // g = d loss_b / d q
+    if (huber_delta > 0.f) {                     // torch.nn.functional.huber_loss(q, returns)
+        const float ad = fabsf(t);
+        if (ad < huber_delta) { l = 0.5f * t * t; g = -t; }
+        else { l = huber_delta * (ad - 0.5f * huber_delta); g = t > 0.f ? -huber_delta : huber_delta; }
+    } else {                                     // (td_error.pow(2) * weight).mean()
+        const float w = weight ? weight[b] : 1.f;
+        l = t * t * w;
+        g = -2.f * t * w;
+    }
+    *t_out = t;
+    *l_out = l;
+    return g * inv_b;
+}
+
+// workgroup 0: td[b], loss = mean_b l_b.  Workgroups 1 .. HIDDEN + 1: dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b] (row
+// HIDDEN: bias, H = 1); thread t owns the samples b = t (mod 256) in batch order, per action a wave shuffle tree, then the
+// 4 wave sums in order.  The rest: dH4[b, k] = dq[b] W5[k, act_b] (H4[b, k] > 0).
+__global__ __launch_bounds__(256) void head_backward_kernel(const float* __restrict__ q, const int64_t* __restrict__ act,
+                                                            const float* __restrict__ ret, const float* __restrict__ weight,
+                                                            const float* __restrict__ h4, const float* __restrict__ wb,
+                                                            int64_t B, int A, float huber_delta, float* __restrict__ td,
+                                                            float* __restrict__ loss, float* __restrict__ dwb,
+                                                            float* __restrict__ dh4) {
+    __shared__ float red[4][MAX_ACT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_b = 1.f / (float)B;
-    float lsum = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) {
-        const float t = ret[b] - q[b * A + act[b]];
-        td[b] = t;
-        float l, g;                                  // g = d loss_b / d q
-        if (huber_delta > 0.f) {                     // torch.nn.functional.huber_loss(q, returns)
-            const float ad = fabsf(t);
-            if (ad < huber_delta) { l = 0.5f * t * t; g = -t; }
-            else { l = huber_delta * (ad - 0.5f * huber_delta); g = t > 0.f ? -huber_delta : huber_delta; }
-        } else {                                     // (td_error.pow(2) * weight).mean()
-            const float w = weight ? weight[b] : 1.f;
-            l = t * t * w;
-            g = -2.f * t * w;
+    float t, l;
+    if (blockIdx.x == 0) {
+        float lsum = 0.f;
+        for (int64_t b = threadIdx.x; b < B; b += 256) {
+            td_terms(q, act, ret, weight, b, A, huber_delta, inv_b, &t, &l);
+            td[b] = t;
+            lsum += l;
         }
-        dq[b] = g * inv_b;
-        lsum += l;
-    }
-    red[threadIdx.x] = lsum;
-    __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lsum += __shfl_down(lsum, off, 64);
+        if (lane == 0) red[wave][0] = lsum;
         __syncthreads();
+        if (threadIdx.x == 0) *loss = ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])) * inv_b;
+        return;
     }
-    if (threadIdx.x == 0) *loss = red[0] * inv_b;
-}
-
-// dH4[b, k] = dq[b] W5[k, act_b] (H4[b, k] > 0)
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
-                                                         const float* __restrict__ wb, const float* __restrict__ h4,
-                                                         int64_t B, int A, float* __restrict__ dh4) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x <= HIDDEN + 1) {
+        const int k = blockIdx.x - 1;
+        for (int a0 = 0; a0 < A; a0 += 8) {                     // 8 actions per pass keeps the accumulators in registers
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int64_t b = threadIdx.x; b < B; b += 256) {
+                const float v = (k < HIDDEN ? h4[b * HIDDEN + k] : 1.f) * td_terms(q, act, ret, weight, b, A, huber_delta, inv_b, &t, &l);
+                const int ab = (int)act[b] - a0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) acc[a] += a == ab ? v : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                float s = acc[a];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+                if (lane == 0) red[wave][a0 + a] = s;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < A)
+            dwb[k * A + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        return;
+    }
+    const int64_t i = (int64_t)(blockIdx.x - HIDDEN - 2) * 256 + threadIdx.x;
     if (i >= B * HIDDEN) return;
     const int64_t b = i / HIDDEN;
     const int k = (int)(i - b * HIDDEN);
-    dh4[i] = h4[i] > 0.f ? dq[b] * wb[(int64_t)k * A + act[b]] : 0.f;
-}
-
-// dWb5[k, a] = sum_{b: act_b = a} H4[b, k] dq[b]   (row HIDDEN: bias, H = 1).  One workgroup per k: thread t
-// owns the samples b = t (mod 256) in batch order; per action a wave shuffle tree, then the 4 wave sums in order.
-__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dq, const int64_t* __restrict__ act,
-                                                         const float* __restrict__ h4, int64_t B, int A,
-                                                         float* __restrict__ dwb) {
-    __shared__ float red[4][MAX_ACT];
-    const int k = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int a0 = 0; a0 < A; a0 += 8) {                     // 8 actions per pass keeps the accumulators in registers
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int64_t b = threadIdx.x; b < B; b += 256) {
-            const float v = (k < HIDDEN ? h4[b * HIDDEN + k] : 1.f) * dq[b];
-            const int ab = (int)act[b] - a0;
-#pragma unroll
-            for (int a = 0; a < 8; ++a) acc[a] += a == ab ? v : 0.f;
-        }
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            float s = acc[a];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) red[wave][a0 + a] = s;
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < A)
-        dwb[k * A + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    const float g = td_terms(q, act, ret, weight, b, A, huber_delta, inv_b, &t, &l);
+    dh4[i] = h4[i] > 0.f ? g * wb[(int64_t)k * A + act[b]] : 0.f;
 }
 
 struct Scratch {           // carve of the workspace for one network pass over B samples
@@ -248,9 +266,9 @@ int ts_dqn_forward(ts_workspace* ws, const float* params, int64_t c, int64_t h, 
     return net_forward(ts::as_stream(stream), ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, q_out, act_out);
 }
 
-int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
-                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
-                          float* out, ts_stream_t stream) {
+static int target_q_impl(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                         int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                         float* out, const float* ns_mask, const double* ns_gpow, const double* ns_mc, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_target_q_fused: workspace is NULL");
     TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_dqn_target_q_fused: negative batch");
     if (B == 0) return TS_OK;
@@ -274,9 +292,25 @@ int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* pa
     if (two)
         if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
     hipLaunchKernelGGL(target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, sa.q, two ? sb.q : sa.q, B,
-                       (int)n_act, is_double, out);
+                       (int)n_act, is_double, out, ns_mask, ns_gpow, ns_mc);
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+int ts_dqn_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                          float* out, ts_stream_t stream) {
+    return target_q_impl(ws, params, params_old, c, h, w, n_act, obs_next_nhwc, obs_u8, B, is_double, out, nullptr, nullptr,
+                         nullptr, stream);
+}
+
+int ts_dqn_target_returns(ts_workspace* ws, const float* params, const float* params_old, int64_t c, int64_t h,
+                          int64_t w, int64_t n_act, const void* obs_next_nhwc, int obs_u8, int64_t B, int is_double,
+                          const float* nstep_mask, const double* nstep_gpow, const double* nstep_mc, float* returns_out,
+                          ts_stream_t stream) {
+    TS_REQUIRE(nstep_mask && nstep_gpow && nstep_mc, TS_ERR_INVALID_ARG, "ts_dqn_target_returns: NULL coefficient array");
+    return target_q_impl(ws, params, params_old, c, h, w, n_act, obs_next_nhwc, obs_u8, B, is_double, returns_out, nstep_mask,
+                         nstep_gpow, nstep_mc, stream);
 }
 
 int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int64_t n_act, int is_double,
@@ -305,21 +339,22 @@ static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float
     // workspace: forward scratch (unless the caller's cache holds the activations) | dq | dY of every layer | wgrad slabs |
     // flat gradient | norm partials
     size_t bytes = cache ? 0 : fwd_scratch_bytes(n, B);
-    bytes += align_up(sizeof(float) * B);
     for (int i = 0; i < 4; ++i) bytes += align_up(sizeof(float) * n.l[i].out_elems());
-    size_t slab = 0;
-    for (int i = 0; i < 4; ++i)
-        slab = std::max(slab, sizeof(float) * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
-    bytes += align_up(slab) + align_up(sizeof(float) * n.total) + 4096;
+    size_t slab[4];
+    for (int i = 0; i < 4; ++i) {          // one slab set per layer: the weight gradients run side by side (ts::chain_backward)
+        slab[i] = align_up(sizeof(float) * (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+        bytes += slab[i];
+    }
+    bytes += align_up(sizeof(float) * n.total) + 4096;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Scratch sc;
     char* p = static_cast<char*>(ws->base);
     if (cache) carve_fwd(n, B, static_cast<char*>(cache), &sc);
     else p = carve_fwd(n, B, p, &sc);
-    float* dq = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * B);
     float* dy[4];
     for (int i = 0; i < 4; ++i) { dy[i] = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.l[i].out_elems()); }
-    float* slabs = reinterpret_cast<float*>(p); p += align_up(slab);
+    float* slabs[4];
+    for (int i = 0; i < 4; ++i) { slabs[i] = reinterpret_cast<float*>(p); p += slab[i]; }
     float* grad = reinterpret_cast<float*>(p); p += align_up(sizeof(float) * n.total);
     float* norm_part = reinterpret_cast<float*>(p);
     if (grad_out) grad = grad_out;
@@ -327,35 +362,27 @@ static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float
     // forward (keeps the activations) -- or the activations ts_dqn_forward_cache left in `cache` --, loss
     if (!cache)
         if (int rc = net_forward(s, ws, n, params, obs_nhwc, obs_u8 != 0, B, sc, sc.q, nullptr)) return rc;
-    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, sc.q, act, returns, weight, B, n.n_act,
-                       (float)hp->huber_delta, td_out, dq, loss_out);
+    // loss, TD errors and the head layer's backward pass: one launch
+    hipLaunchKernelGGL(head_backward_kernel, dim3((unsigned)(HIDDEN + 2 + ts::ceil_div(B * HIDDEN, 256))), dim3(256), 0, s, sc.q, act,
+                       returns, weight, sc.h[3], params + n.off[4], B, n.n_act, (float)hp->huber_delta, td_out, loss_out,
+                       grad + n.off[4], dy[3]);
     TS_LAUNCH_CHECK();
     if (!ws->td_ev_ready) {
         TS_HIP_CHECK(hipEventCreateWithFlags(&ws->td_ev, hipEventDisableTiming));
         ws->td_ev_ready = 1;
     }
     TS_HIP_CHECK(hipEventRecord(ws->td_ev, s));          // td_out / loss_out are written: ts_dqn_wait_td
-    // head backward
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3(HIDDEN + 1), dim3(256), 0, s, dq, act, sc.h[3], B, n.n_act,
-                       grad + n.off[4]);
-    hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)ts::ceil_div(B * HIDDEN, 256)), dim3(256), 0, s, dq, act,
-                       params + n.off[4], sc.h[3], B, n.n_act, dy[3]);
-    TS_LAUNCH_CHECK();
-    // fc1, conv3, conv2, conv1.  The weight gradient of a layer (+ its slab sum) and the input gradient that feeds
-    // the layer below are independent given dY_i: the first runs on the workspace's side stream, the second on
-    // the caller's stream, so that these small grids share the chip instead of running back to back.
-    hipStream_t side;
-    if (int rc = ts::side_stream(ws, s, &side)) return rc;
-    for (int i = 3; i >= 0; --i) {
-        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : sc.h[i - 1];
-        if (int rc = ts::stream_wait(ws, s, side, i)) return rc;          // dY_i (and everything before) is ready
-        if (int rc = ts::conv_wgrad(side, n.l[i], x, dy[i], slabs, ws, i == 0 && obs_u8)) return rc;
-        if (int rc = ts::slab_sum(side, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i]))
-            return rc;
-        if (i > 0)
-            if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], sc.h[i - 1], dy[i - 1], ws)) return rc;
+    // fc1, conv3, conv2, conv1: input gradients down the caller's stream, the weight gradients beside them on the workspace's
+    // side streams (ts::chain_backward)
+    {
+        const float* x[4]; const float* wb[4]; float* g[4];
+        for (int i = 0; i < 4; ++i) {
+            x[i] = i == 0 ? static_cast<const float*>(obs_nhwc) : sc.h[i - 1];
+            wb[i] = params + n.off[i];
+            g[i] = grad + n.off[i];
+        }
+        if (int rc = ts::chain_backward(s, ws, 4, n.l, x, dy, wb, slabs, g, obs_u8 != 0)) return rc;
     }
-    if (int rc = ts::stream_wait(ws, side, s, 8)) return rc;               // all weight gradients are in `grad`
     if (hp->lr < 0.0) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);

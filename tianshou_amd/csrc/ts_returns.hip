@@ -594,6 +594,44 @@ __global__ void nstep_fused_kernel(const int64_t* indices, int64_t I, int64_t N,
     }
 }
 
+// The part of nstep_fused_kernel that does not depend on target_q: per index the value mask, gamma^n_eff and the
+// discounted reward sum, so that  returns = float(double(target_q * mask) * gpow + mc)  -- the same three operations on the
+// same values -- can be finished by whoever produces target_q (ts_dqn_target_returns), and the walk itself can run ahead of
+// the target network's passes.
+__global__ void nstep_coef_kernel(const int64_t* indices, int64_t I, int64_t N, const int64_t* offset, int64_t E,
+                                  const uint8_t* done, const uint8_t* terminated, const int64_t* last_index,
+                                  const int64_t* lengths, const double* rew, double gamma, float* mask_out,
+                                  double* gpow_out, double* mc_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < I; i += stride) {
+        double r[NSTEP_MAX];
+        bool e[NSTEP_MAX];
+        int64_t cur = indices[i];
+        for (int n = 0; n < (int)N; ++n) {
+            bool is_end;
+            const int64_t nxt = next_one(cur, offset, E, done, last_index, lengths, &is_end);
+            r[n] = rew[cur];
+            e[n] = is_end;
+            if (n + 1 < (int)N) cur = nxt;
+        }
+        double mc = 0.0;
+        int64_t gammas = N;
+        for (int n = (int)N - 1; n >= 0; --n) {
+            if (e[n]) {
+                gammas = n + 1;
+                mc = 0.0;
+            }
+            const double tmp = gamma * mc;
+            mc = r[n] + tmp;
+        }
+        double gpow = 1.0;
+        for (int64_t k = 0; k < gammas; ++k) gpow = gpow * gamma;
+        mask_out[i] = terminated[cur] ? 0.f : 1.f;
+        gpow_out[i] = gpow;
+        mc_out[i] = mc;
+    }
+}
+
 inline int grid_for(int64_t n, int block) {
     int64_t g = ts::ceil_div(n, block);
     if (g > 2048) g = 2048;
@@ -789,6 +827,21 @@ int ts_nstep_return_fused(const int64_t* indices, int64_t I, int64_t n_step,
     hipLaunchKernelGGL(nstep_fused_kernel, dim3(grid_for(I, 128)), dim3(128), 0,
                        ts::as_stream(stream), indices, I, n_step, offset, E, done, terminated,
                        last_index, lengths, rew_B, target_q_IA, A, gamma, out, out64);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_nstep_coefficients(const int64_t* indices, int64_t I, int64_t n_step, const int64_t* offset, int64_t E,
+                          const uint8_t* done_B, const uint8_t* terminated_B, const int64_t* last_index,
+                          const int64_t* lengths, const double* rew_B, double gamma, float* mask_out, double* gpow_out,
+                          double* mc_out, ts_stream_t stream) {
+    TS_REQUIRE(I >= 0 && E >= 1, TS_ERR_INVALID_ARG, "ts_nstep_coefficients: bad size");
+    TS_REQUIRE(n_step >= 1 && n_step <= NSTEP_MAX, TS_ERR_INVALID_ARG, "ts_nstep_coefficients: 1 <= n_step <= %d", NSTEP_MAX);
+    if (I == 0) return TS_OK;
+    TS_REQUIRE(indices && offset && done_B && terminated_B && last_index && lengths && rew_B && mask_out && gpow_out && mc_out,
+               TS_ERR_INVALID_ARG, "ts_nstep_coefficients: NULL array argument");
+    hipLaunchKernelGGL(nstep_coef_kernel, dim3(grid_for(I, 128)), dim3(128), 0, ts::as_stream(stream), indices, I, n_step,
+                       offset, E, done_B, terminated_B, last_index, lengths, rew_B, gamma, mask_out, gpow_out, mc_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -24,7 +24,7 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev
 from .lagged import full_parameter_update
-from .returns import compute_nstep_return, nstep_return_from_target_q
+from .returns import compute_nstep_return, nstep_coefficients, nstep_return_from_target_q
 
 TIANSHOU_KEYS = ["net.0.0.weight", "net.0.0.bias", "net.0.2.weight", "net.0.2.bias",
                  "net.0.4.weight", "net.0.4.bias", "net.1.weight", "net.1.bias",
@@ -307,6 +307,22 @@ class DQNEngine:
             C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
+    def target_returns(self, obs_next_nhwc: torch.Tensor, coef) -> torch.Tensor:
+        """_target_q followed by the n-step return arithmetic in the same final kernel (ts_dqn_target_returns); coef =
+        returns.nstep_coefficients(buffer, indices, gamma, n_step)."""
+        b = obs_next_nhwc.shape[0]
+        obs_next_nhwc = obs_next_nhwc.contiguous()
+        mask, gpow, mc = coef
+        if mask.numel() != b or gpow.numel() != b or mc.numel() != b:
+            raise ValueError("n-step coefficients / obs_next batch sizes differ")
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_dqn_target_returns(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.params_old), _lib.i64(self.c), _lib.i64(self.h),
+            _lib.i64(self.w), _lib.i64(self.n_act), _lib.ptr(obs_next_nhwc), _u8_flag(obs_next_nhwc), _lib.i64(b),
+            C.c_int(int(self.cfg.is_double)), _lib.ptr(mask), _lib.ptr(gpow), _lib.ptr(mc), _lib.ptr(out),
+            _lib.current_stream(self.device)))
+        return out
+
     # -- DQN._preprocess_batch -----------------------------------------------------------------------
     def preprocess(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, indices, stack_num: int,
                    obs_next_frames: torch.Tensor | None = None) -> torch.Tensor:
@@ -327,12 +343,12 @@ class DQNEngine:
         return b.returns.reshape(-1)
 
     def preprocess_with_obs(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, indices, stack_num: int,
-                            obs_next_frames: torch.Tensor | None = None, prefetch: bool = True, pair=None):
+                            obs_next_frames: torch.Tensor | None = None, prefetch: bool = True, pair=None, coef=None):
         """-> (obs uint8 NHWC [I, H, W, C], returns float32[I]): `preprocess` plus the batch's own observations, which
         `update_with_batch` wants next.  On a frame buffer without obs_next both stacked gathers come from one launch
         (gather_obs_pair) and the forward pass on obs is started on the side stream before the target passes
         (prefetch_forward); otherwise this is gather_obs_nhwc + preprocess.  `pair`: the two gathers, already done by the
-        caller (ReplayStream)."""
+        caller (ReplayStream), as are the n-step coefficients `coef` (returns.nstep_coefficients)."""
         if pair is None and obs_next_frames is None:
             pair = gather_obs_pair(frames, buffer, indices, self.cfg.n_step, stack_num)
         if pair is None:
@@ -343,8 +359,9 @@ class DQNEngine:
         obs, obs_next = pair
         if prefetch:
             self.prefetch_forward(obs)
-        tq = self.target_q(obs_next)
-        return obs, nstep_return_from_target_q(buffer, indices, tq, self.cfg.gamma, self.cfg.n_step).reshape(-1)
+        if coef is None:
+            coef = nstep_coefficients(buffer, indices, self.cfg.gamma, self.cfg.n_step)
+        return obs, self.target_returns(obs_next, coef)
 
     # -- the two halves of an update, for the data-parallel path (tianshou_amd.distributed.DataParallelDQN) ----
     def gradient(self, obs_nhwc, act, returns, weight, grad_out: torch.Tensor):
@@ -427,13 +444,17 @@ class ReplayStream:
 
     def _sample(self):
         idx, wt = self.per.sample(self.draw())
-        pair = gather_obs_pair(self.frames, self.buffer, idx, self.eng.cfg.n_step, self.stack)
-        self._next = (idx, wt, self.act_of(idx), pair)
+        wt = wt.to(torch.float32)               # what update_with_batch converts the importance weights to
+        cfg = self.eng.cfg
+        pair = gather_obs_pair(self.frames, self.buffer, idx, cfg.n_step, self.stack)
+        coef = nstep_coefficients(self.buffer, idx, cfg.gamma, cfg.n_step) if pair is not None else None
+        self._next = (idx, wt, self.act_of(idx), pair, coef)
         self._ready = torch.cuda.Event()
         self._ready.record(self.stream)
 
     def take(self):
-        """-> (indices, IS weights, actions, (obs, obs_next) or None) of the next batch, ready on the caller's stream."""
+        """-> (indices, IS weights float32, actions, (obs, obs_next) or None, n-step coefficients or None) of the next batch,
+        ready on the caller's stream."""
         main = torch.cuda.current_stream(self.eng.device)
         if self._next is None:
             self.stream.wait_stream(main)
@@ -441,7 +462,7 @@ class ReplayStream:
                 self._sample()
         main.wait_event(self._ready)
         out, self._next = self._next, None
-        for t in (out[0], out[1], out[2]) + (tuple(out[3]) if out[3] is not None else ()):
+        for t in (out[0], out[1], out[2]) + tuple(out[3] or ()) + tuple(out[4] or ()):
             t.record_stream(main)
         return out
 

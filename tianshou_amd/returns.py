@@ -178,6 +178,22 @@ def nstep_return_from_target_q(buffer: DeviceReplayBuffer, indices, tq: torch.Te
     return out.reshape(tq.shape)
 
 
+def nstep_coefficients(buffer: DeviceReplayBuffer, indices, gamma: float, n_step: int):
+    """(mask float32[I], gpow float64[I], mc float64[I]) with returns = float(double(target_q * mask) * gpow + mc): the part
+    of compute_nstep_return (algorithm_base.py:772-811) that does not need target_q (ts_nstep_coefficients)."""
+    dev = buffer.device
+    indices = _i64_dev(indices, dev).reshape(-1)
+    I = indices.numel()
+    mask = torch.empty(I, dtype=torch.float32, device=dev)
+    gpow = torch.empty(I, dtype=torch.float64, device=dev)
+    mc = torch.empty(I, dtype=torch.float64, device=dev)
+    _lib.check(_lib.load().ts_nstep_coefficients(
+        _lib.ptr(indices), _lib.i64(I), _lib.i64(n_step), _lib.ptr(buffer.offset), _lib.i64(buffer.buffer_num),
+        _lib.ptr(buffer.done), _lib.ptr(buffer.terminated), _lib.ptr(buffer.last_index), _lib.ptr(buffer.lengths),
+        _lib.ptr(buffer.rew), _lib.f64(gamma), _lib.ptr(mask), _lib.ptr(gpow), _lib.ptr(mc), _lib.current_stream(dev)))
+    return mask, gpow, mc
+
+
 def compute_nstep_return(batch, buffer: DeviceReplayBuffer, indices, target_q_fn,
                          gamma: float = 0.99, n_step: int = 1, want_f64: bool = False):
     """Algorithm.compute_nstep_return (algorithm_base.py:721-817): sets batch.returns (float32
