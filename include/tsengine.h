@@ -45,6 +45,14 @@ const char* ts_last_error(void);
 int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes);
 int ts_workspace_destroy(ts_workspace* ws);
 
+/* The workspace's two internal side streams (hipStreamNonBlocking, created on first use; which = 0 or 1): the streams on
+ * which entry points called with `ws` place work that is independent of the caller's stream (the lagged network's pass of
+ * ts_dqn_target_q_fused, the weight gradients of a backward chain).  A caller with independent work of its own (the
+ * forward pass that ts_dqn_forward_cache runs ahead of an update) can put it there instead of on one more stream of its
+ * own: the runtime multiplexes streams onto four hardware queues, and a fifth stream shares a queue -- and its order --
+ * with another one. */
+int ts_workspace_side_stream(ts_workspace* ws, int which, ts_stream_t* stream_out);
+
 /* Per-kernel timing for bench.py's roofline figure: between ts_profile_begin and
  * ts_profile_end every kernel launched through `ws` is bracketed by a HIP event pair recorded
  * on the launch stream.  ts_profile_end waits for the events and returns, per kernel kind,

@@ -58,10 +58,7 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
     return TS_OK;
 }
 
-int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
-    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "side_stream: workspace is NULL");
-    static const bool single = getenv("TS_NO_SIDE_STREAM") != nullptr;      // experiments: everything on one stream
-    if (ws->profiling || single) { *out = main; return TS_OK; }      // serial launches: per-kernel event pairs do not overlap
+static int side_create(ts_workspace* ws) {
     if (!ws->side_ready) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
         TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
@@ -69,6 +66,14 @@ int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
         for (int i = 0; i < 16; ++i) TS_HIP_CHECK(hipEventCreateWithFlags(&ws->side_ev[i], hipEventDisableTiming));
         ws->side_ready = 1;
     }
+    return TS_OK;
+}
+
+int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "side_stream: workspace is NULL");
+    static const bool single = getenv("TS_NO_SIDE_STREAM") != nullptr;      // experiments: everything on one stream
+    if (ws->profiling || single) { *out = main; return TS_OK; }      // serial launches: per-kernel event pairs do not overlap
+    if (int rc = side_create(ws)) return rc;
     *out = ws->side;
     return TS_OK;
 }
@@ -146,6 +151,14 @@ int ts_workspace_create(ts_workspace** out, int device, size_t max_bytes) {
     ws->device = device;
     ws->max_bytes = max_bytes;
     *out = ws;
+    return TS_OK;
+}
+
+int ts_workspace_side_stream(ts_workspace* ws, int which, ts_stream_t* stream_out) {
+    TS_REQUIRE(ws != nullptr && stream_out != nullptr, TS_ERR_WORKSPACE, "ts_workspace_side_stream: NULL argument");
+    TS_REQUIRE(which == 0 || which == 1, TS_ERR_INVALID_ARG, "ts_workspace_side_stream: which = 0 or 1");
+    if (int rc = ts::side_create(ws)) return rc;
+    *stream_out = reinterpret_cast<ts_stream_t>(which == 0 ? ws->side : ws->side2);
     return TS_OK;
 }
 

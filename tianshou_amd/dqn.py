@@ -253,7 +253,11 @@ class DQNEngine:
         if need <= 0 or not obs_nhwc.is_contiguous():
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # the workspace's second side stream (idle during the forward passes; the backward chain uses it later): a stream
+            # of our own would be the fifth of the update on four hardware queues (ts_workspace_side_stream)
+            h = C.c_void_p()
+            _lib.check(lib.ts_workspace_side_stream(self._ws.handle, C.c_int(1), C.byref(h)))
+            self._side = torch.cuda.ExternalStream(h.value, device=self.device)
             self._cache = None
         if self._cache is None or self._cache.numel() < need:
             self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
