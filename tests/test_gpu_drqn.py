@@ -12,6 +12,14 @@ from tests import dqn_common as DC
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["layer_kernels", "per_step"], autouse=True)
+def lstm_path(request, monkeypatch):
+    """Every test runs on both recurrent paths: a whole LSTM layer per launch (lstm_layer_fwd / bwd_kernel, H = 32, 64, 128)
+    and one GEMM + one cell launch per step (TS_RNN_PER_STEP, the path of the other widths)."""
+    if request.param == "per_step":
+        monkeypatch.setenv("TS_RNN_PER_STEP", "1")
+
+
 def rand_params(obs_dim, hidden, layers, n_act, seed):
     g = torch.Generator().manual_seed(seed)
     shapes = ORQ.param_shapes(obs_dim, hidden, layers, n_act)

@@ -19,6 +19,7 @@
 // Flat layout (last row of every block = bias): fc1 [k0 + 1, H] | per layer: W_ih [H + 1, 4H] | W_hh [H + 1, 4H] | fc2 [H + 1, 32]
 // (k0 = obs_dim rounded up to 32, the padding rows are and stay zero; head columns [0, n_act) = Q, the rest zero).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ts_common.h"
 #include "ts_conv.h"
@@ -188,6 +189,164 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
     dc[idx] = dct * f;
 }
 
+// ---- a whole LSTM layer in one launch (H = 32, 64, 128) -----------------------------------------------------------------------
+// Per step the recurrent product h_{t-1} W_hh is a [B, H] x [H, 4H] GEMM -- 33 MFLOP at the DRQN shape (B = 128, H = 128) --
+// and was one GEMM launch + one cell launch per step: 8 launches of ~5 us per layer and pass, three passes per update,
+// 51 GEMM launches in all for 1.3 GFLOP.  The recurrence only couples the units of ONE batch row, so a workgroup that owns
+// 16 batch rows and ALL 4H gate columns can run the T steps of a layer by itself:
+//   * wave w owns the hidden units [16 w, 16 w + 16): its four 16 x 16 accumulator tiles (v_mfma_f32_16x16x4_f32) are the four
+//     gates (i, f, g, o) of those units, so the cell arithmetic happens on the accumulator registers of the lane that owns
+//     (rows 4 q .. 4 q + 3, unit n) -- c_t never leaves them;
+//   * the wave's share of W_hh (H x 64 floats = H VGPRs per lane) is loaded ONCE and stays in registers for all T steps;
+//   * h_t goes to a [16][H + 4] LDS tile (the A operand of the next step: one ds_read_b128 per sixteen k) and to HBM together
+//     with c_t and the gate activations (the backward pass and the layer above read them).
+// k order inside a product: MFMA (j, t) sums k = 16 j + 4 q + t over the lane quarters q; j ascending, t ascending.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_layer_fwd_kernel(const float* __restrict__ gih, const float* __restrict__ whh,
+                                                              float* __restrict__ hbuf, float* __restrict__ cbuf,
+                                                              float* __restrict__ gact, int B, int T) {
+    constexpr int KB = H / 16, HP = H + 4;
+    __shared__ __attribute__((aligned(16))) float hs[16 * HP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16, unit = 16 * w + n;
+    const size_t blk = (size_t)B * H;
+    float wreg[KB][4][4];
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wreg[j][t][e] = whh[(size_t)(16 * j + 4 * q + t) * 4 * H + e * H + unit];
+    float bias[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[e] = whh[(size_t)H * 4 * H + e * H + unit];
+    int row[4];
+    bool live[4];
+    float c[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        live[v] = b0 + 4 * q + v < B;
+        row[v] = min(b0 + 4 * q + v, B - 1);
+        c[v] = cbuf[(size_t)row[v] * H + unit];
+        hs[(4 * q + v) * HP + unit] = hbuf[(size_t)row[v] * H + unit];
+    }
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();                                   // h_{t-1} is in hs
+        f32x4 acc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the input projections of this step travel while the products run
+        float pre[4][4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[e][v] = gih[((size_t)t * B + row[v]) * 4 * H + e * H + unit];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(hs + n * HP + 16 * j + 4 * q);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt], wreg[j][tt][e], acc[e], 0, 0, 0);
+        }
+        __syncthreads();                                   // every wave has read hs
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float gi = sigmoidf_(pre[0][v] + (acc[0][v] + bias[0]));
+            const float gf = sigmoidf_(pre[1][v] + (acc[1][v] + bias[1]));
+            const float gg = tanhf(pre[2][v] + (acc[2][v] + bias[2]));
+            const float go = sigmoidf_(pre[3][v] + (acc[3][v] + bias[3]));
+            const float cn = gf * c[v] + gi * gg;
+            const float hn = go * tanhf(cn);
+            c[v] = cn;
+            hs[(4 * q + v) * HP + unit] = hn;
+            if (live[v]) {
+                float* ga = gact + ((size_t)t * B + row[v]) * 4 * H + unit;
+                ga[0] = gi; ga[H] = gf; ga[2 * H] = gg; ga[3 * H] = go;
+                cbuf[(size_t)(t + 1) * blk + (size_t)row[v] * H + unit] = cn;
+                hbuf[(size_t)(t + 1) * blk + (size_t)row[v] * H + unit] = hn;
+            }
+        }
+    }
+}
+
+// Backward through time of the same layer in one launch: per step the cell's backward arithmetic (lstm_cell_bwd_kernel) on
+// the registers of the lane that owns (rows 4 q .. 4 q + 3, unit n), the pre-activation gate gradients to HBM (the weight-
+// gradient GEMMs and the layer below read them) and to a [16][4H + 4] LDS tile, then dh_{t-1} = dg_t W_hh^T with the wave's 16
+// rows of W_hh (4H floats per lane) resident in registers; dc and the recurrent dh never leave the registers.
+template <int H>
+__global__ __launch_bounds__(H * 4) void lstm_layer_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ whh,
+                                                              const float* __restrict__ gact, const float* __restrict__ cbuf,
+                                                              float* __restrict__ dg, int B, int T) {
+    constexpr int KB = 4 * H / 16, GP = 4 * H + 4;
+    __shared__ __attribute__((aligned(16))) float gs[16 * GP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    const int b0 = blockIdx.x * 16, unit = 16 * w + n;
+    const size_t blk = (size_t)B * H;
+    // B operand of dh = dg W_hh^T: B[k][n] = W_hh[unit n of this wave][gate column k], k = 16 j + 4 q + t
+    f32x4 wreg[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) wreg[j] = *reinterpret_cast<const f32x4*>(whh + (size_t)unit * 4 * H + 16 * j + 4 * q);
+    int row[4];
+    bool live[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { live[v] = b0 + 4 * q + v < B; row[v] = min(b0 + 4 * q + v, B - 1); }
+    float dc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dh_rec = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t == T - 1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const size_t i1 = (size_t)row[v] * H + unit;
+            const float* ga = gact + ((size_t)t * B + row[v]) * 4 * H + unit;
+            const float i = ga[0], f = ga[H], g = ga[2 * H], o = ga[3 * H];
+            const float dho = dout[(size_t)t * blk + i1];
+            const float dh = last ? dho : dho + dh_rec[v];
+            const float tc = tanhf(cbuf[(size_t)(t + 1) * blk + i1]);
+            const float d_o = dh * tc;
+            float dct = dh * o * (1.f - tc * tc);
+            if (!last) dct += dc[v];
+            const float d0 = dct * g * (i * (1.f - i));
+            const float d1 = dct * cbuf[(size_t)t * blk + i1] * (f * (1.f - f));
+            const float d2 = dct * i * (1.f - g * g);
+            const float d3 = d_o * (o * (1.f - o));
+            dc[v] = dct * f;
+            float* gl = gs + (4 * q + v) * GP + unit;
+            gl[0] = d0; gl[H] = d1; gl[2 * H] = d2; gl[3 * H] = d3;
+            if (live[v]) {
+                float* go = dg + ((size_t)t * B + row[v]) * 4 * H + unit;
+                go[0] = d0; go[H] = d1; go[2 * H] = d2; go[3 * H] = d3;
+            }
+        }
+        if (t == 0) break;
+        __syncthreads();                                   // dg_t is in gs
+        dh_rec = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(gs + n * GP + 16 * j + 4 * q);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) dh_rec = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt], wreg[j][tt], dh_rec, 0, 0, 0);
+        }
+        __syncthreads();                                   // every wave has read gs
+    }
+}
+
+bool lstm_fused_ok(int H) {
+    const bool off = getenv("TS_RNN_PER_STEP") != nullptr;      // A/B and tests: one GEMM + one cell launch per step (read per call)
+    return !off && (H == 32 || H == 64 || H == 128);
+}
+
+template <int H>
+void launch_layer_fwd(hipStream_t s, const float* gih, const float* whh, float* hbuf, float* cbuf, float* gact, int B, int T) {
+    hipLaunchKernelGGL(lstm_layer_fwd_kernel<H>, dim3((unsigned)ts::ceil_div(B, 16)), dim3(H * 4), 0, s, gih, whh, hbuf, cbuf, gact, B, T);
+}
+template <int H>
+void launch_layer_bwd(hipStream_t s, const float* dout, const float* whh, const float* gact, const float* cbuf, float* dg, int B, int T) {
+    hipLaunchKernelGGL(lstm_layer_bwd_kernel<H>, dim3((unsigned)ts::ceil_div(B, 16)), dim3(H * 4), 0, s, dout, whh, gact, cbuf, dg, B, T);
+}
+
 // q_out[b, a] = head[b, a]; act_out[b] = argmax_a (first maximum, torch.max)
 __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ head, int64_t B, int A, float* __restrict__ q_out,
                                                        int64_t* __restrict__ act_out) {
@@ -280,6 +439,13 @@ int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, cons
         else TS_HIP_CHECK(hipMemsetAsync(a.cbuf[l], 0, 4 * blk, s));
         const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
         if (int rc = ts::conv_forward(s, n.ih(l), in, p + n.off_ih[l], a.gih, false, a.split, ws)) return rc;
+        if (lstm_fused_ok(H)) {            // the T steps of the layer in one launch
+            if (H == 128) launch_layer_fwd<128>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
+            else if (H == 64) launch_layer_fwd<64>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
+            else launch_layer_fwd<32>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
+            TS_LAUNCH_CHECK();
+            continue;
+        }
         for (int t = 0; t < n.T; ++t) {
             if (int rc = ts::conv_forward(s, n.hh_step, a.hbuf[l] + t * blk, p + n.off_hh[l], a.ghh, false, a.split, ws)) return rc;
             hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)ts::ceil_div((int64_t)blk, 256)), dim3(256), 0, s,
@@ -343,6 +509,12 @@ int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, con
         return rc;
     }
     for (int l = n.L - 1; l >= 0; --l) {
+        if (lstm_fused_ok(H)) {            // backward through time of the layer in one launch
+            if (H == 128) launch_layer_bwd<128>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
+            else if (H == 64) launch_layer_bwd<64>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
+            else launch_layer_bwd<32>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
+            TS_LAUNCH_CHECK();
+        } else
         for (int t = T - 1; t >= 0; --t) {
             hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(gcell), dim3(256), 0, s, bw.dout + (size_t)t * blk, bw.dh_rec, bw.dc,
                                a.gact[l] + (size_t)t * 4 * blk, a.cbuf[l] + (size_t)(t + 1) * blk, a.cbuf[l] + (size_t)t * blk, B, H,
