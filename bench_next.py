@@ -76,6 +76,9 @@ def _tick() -> int:
     return _TICK[0]
 
 
+_HOST_MS = [None]
+
+
 def _time(update, steps, warmup):
     import bench_init as BI
     from tianshou_amd import _lib
@@ -87,6 +90,7 @@ def _time(update, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         last = update()
+    _HOST_MS[0] = (time.perf_counter() - t0) / steps * 1e3          # the host's share: enqueueing (no synchronisation inside)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ws = _lib.default_workspace(0)
@@ -113,7 +117,7 @@ def _line(metric, value, unit, steps, warmup, dt, workload, roof, cpu, extra=Non
     out = {"metric": metric, "value": value, "unit": unit, "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic", "config": {"workload": workload, "parallelism": "dp1"},
-           "roofline": roof, "cpu_baseline": cpu}
+           "roofline": roof, "cpu_baseline": cpu, "host_enqueue_ms_per_step": _HOST_MS[0]}
     out.update(extra or {})
     return out
 
@@ -619,8 +623,9 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
 
     def update():
         idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
-        ret = eng.preprocess(buf, buf.obs, idx, T)
-        return eng.update_with_batch(R.gather_stacked_obs(buf.obs, buf, idx, T), buf.act[idx], ret)[0]
+        # batch.obs first: its forward pass runs on a side stream beside the two s_{t+n} passes of _target_q
+        obs, ret = eng.preprocess_with_obs(buf, buf.obs, idx, T, prefetch=not os.environ.get("TS_DRQN_NO_PREFETCH"))
+        return eng.update_with_batch(obs, buf.act[idx], ret)[0]
 
     dt, loss, prof = _time(update, steps, warmup)
     fwd = 2 * (T * OBS * H + L * T * 2 * H * 4 * H + H * A)          # per sample: fc1 per step, W_ih + W_hh per layer and step, fc2

@@ -530,6 +530,26 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
                    const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
                    float* grad_out, ts_stream_t stream);
 
+/* DQN._target_q end to end on the recurrent network (dqn.py:365-379), as ts_dqn_target_q_fused: Q_online(s') and
+ * Q_target(s') (params_old; NULL = no lagged network) on two streams, then the arg-max / gather -> out float32[B].
+ * obs_next float32[B, T, obs_dim]. */
+int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
+                           ts_stream_t stream);
+
+/* The forward pass of ts_rnnq_update ahead of time (as ts_dqn_forward_cache / ts_dqn_update_cached for the NatureCNN): it
+ * needs nothing from the two obs_next passes of _target_q (same online parameters, dqn.py:257-275 vs 381-404), and a pass at
+ * B = 128 occupies eight CUs.  ts_rnnq_forward_cache leaves every activation of the pass in the caller's `cache`
+ * (ts_rnnq_cache_bytes bytes, 256-byte aligned); ts_rnnq_update_cached is ts_rnnq_update without its forward pass.  The
+ * caller orders the two calls (stream events) and must not change `params` in between. */
+int64_t ts_rnnq_cache_bytes(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T);
+int ts_rnnq_forward_cache(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                          const float* obs, int64_t B, int64_t T, void* cache, int64_t cache_bytes, ts_stream_t stream);
+int ts_rnnq_update_cached(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                          int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
+                          const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, void* cache, float* td_out,
+                          float* loss_out, float* grad_out, ts_stream_t stream);
+
 /* LSTM trunk + one linear head, generic -- the recurrent actor and critic of the continuous-control nets:
  *   RecurrentActorProb  tianshou/utils/net/continuous.py:241-322: nn.LSTM(obs_dim -> H, L layers, batch_first) on the
  *                       observation itself (no fc1), mu = Linear(H, act)(h_T), bounded as max_action * tanh(mu) unless

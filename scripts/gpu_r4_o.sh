@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 timeout 900 python -m pytest tests/test_gpu_drqn.py tests/test_gpu_recurrent_nets.py tests/test_gpu_hooks.py -m gpu -q -x > $O/pytest.txt 2>&1; tail -15 $O/pytest.txt
 for rep in 1 2; do
   timeout 200 python bench.py --workload drqn --no-cpu-baseline > $O/drqn_layer_$rep.json 2>> $O/err.txt
-  TS_RNN_PER_STEP=1 timeout 200 python bench.py --workload drqn --no-cpu-baseline > $O/drqn_step_$rep.json 2>> $O/err.txt
+  TS_DRQN_NO_PREFETCH=1 timeout 200 python bench.py --workload drqn --no-cpu-baseline > $O/drqn_noprefetch_$rep.json 2>> $O/err.txt
 done
 python - <<'PY'
 import json,os,glob

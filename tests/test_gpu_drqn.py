@@ -164,3 +164,43 @@ def test_bad_arguments_fail_loudly():
         eng.forward(torch.zeros(3, 2, 5))
     with pytest.raises(ValueError):
         eng.forward(torch.zeros(3, 4), state=(torch.zeros(3, 2, 32), torch.zeros(3, 2, 32)))
+
+
+def test_prefetched_forward_and_concurrent_target_pass_give_identical_updates():
+    """RecurrentDQNEngine.preprocess_with_obs (batch.obs gathered first, its forward pass on the workspace's second side stream
+    into a cache that ts_rnnq_update_cached consumes; the lagged network's pass of _target_q on the first side stream) against
+    the plain order preprocess -> update_with_batch: four updates with a target sync in between, identical returns, losses, TD
+    errors, parameters and Adam moments; a stale prefetch (parameters written since) is ignored."""
+    from tianshou_amd import drqn as R
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    obs_dim, hidden, layers, n_act, B, T, slots, E = 4, 128, 2, 2, 96, 4, 2048, 4
+    p = rand_params(obs_dim, hidden, layers, n_act, 4)
+    ocfg = OD.DQNConfig(gamma=0.95, n_step=3, target_update_freq=2, is_double=True, lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    Tn = slots // E
+    off = np.arange(E + 1, dtype=np.int64) * Tn
+    buf = DeviceReplayBuffer(offset=off, last_index=off[:-1] + Tn - 1, lengths=np.full(E, Tn, np.int64), insertion=np.zeros(E, np.int64),
+                             rew=torch.randn(slots, generator=g).double().numpy(), terminated=(torch.rand(slots, generator=g) < 0.05).numpy(),
+                             truncated=np.zeros(slots, bool), obs=torch.randn(slots, obs_dim, generator=g).numpy(),
+                             act=torch.randint(0, n_act, (slots,), generator=g).numpy())
+    plain, pre = make_engine(p, obs_dim, hidden, layers, n_act, ocfg), make_engine(p, obs_dim, hidden, layers, n_act, ocfg)
+    for it in range(4):
+        idx = torch.randint(0, slots, (B,), generator=g).cuda()
+        ret0 = plain.preprocess(buf, buf.obs, idx, T)
+        out0 = plain.update_with_batch(R.gather_stacked_obs(buf.obs, buf, idx, T), buf.act[idx], ret0)
+        obs, ret1 = pre.preprocess_with_obs(buf, buf.obs, idx, T)
+        assert pre._pre is not None and pre._pre[0] is obs
+        out1 = pre.update_with_batch(obs, buf.act[idx], ret1)
+        assert pre._pre is None
+        assert torch.equal(ret0, ret1) and torch.equal(out0[0], out1[0]) and torch.equal(out0[1], out1[1]), it
+        for name in ("params", "adam_m", "adam_v", "params_old"):
+            assert torch.equal(getattr(plain, name), getattr(pre, name)), (it, name)
+    # a prefetch that predates a parameter write is ignored (own forward pass)
+    obs = pre.prefetch_forward(R.gather_stacked_obs(buf.obs, buf, idx, T))
+    stale, pre._pre = pre._pre, None
+    pre.update_with_batch(obs.clone(), buf.act[idx], ret1)
+    plain.update_with_batch(obs.clone(), buf.act[idx], ret1)
+    pre._pre = stale
+    a, b = pre.update_with_batch(obs, buf.act[idx], ret1), plain.update_with_batch(obs, buf.act[idx], ret1)
+    assert torch.equal(a[0], b[0]) and torch.equal(plain.params, pre.params)

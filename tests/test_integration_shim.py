@@ -1427,9 +1427,9 @@ def test_hip_drqn_wrapper_runs_with_engine_double(monkeypatch):
             self.params, self.params_old, self.cfg = flat.clone(), flat.clone(), cfg
             self.adam_m, self.adam_v, self.adam_step, self.iter = torch.zeros_like(flat), torch.zeros_like(flat), 0, 0
 
-        def preprocess(self, m, rows, idx, stack, obs_next_rows=None):
-            assert rows.dtype == torch.float32 and rows.shape[1] == 4 and stack == 4 and obs_next_rows is None
-            return torch.zeros(idx.numel())
+        def preprocess_with_obs(self, m, rows, idx, stack, obs_next_rows=None, prefetch=True):
+            assert rows.dtype == torch.float32 and rows.shape[1] == 4 and stack == 4 and obs_next_rows is None and prefetch
+            return R.gather_stacked_obs(rows, m, idx, stack), torch.zeros(idx.numel())
 
         def update_with_batch(self, obs, act, ret, weight=None):
             assert obs.shape == (8, 4, 4) and act.shape == (8,) and ret.shape == (8,)

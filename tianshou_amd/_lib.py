@@ -119,10 +119,23 @@ def f64(v) -> C.c_double:
     return C.c_double(float(v))
 
 
-def current_stream(device=None) -> C.c_void_p:
+def _raw_stream(device=None) -> int:
+    """hipStream_t of torch's current stream on `device` as an integer.  torch.cuda.current_stream() builds a Stream object
+    through several layers of Python device-index resolution (4-5 us per call, twenty calls in a launch-bound update); the
+    binding underneath it takes the index and returns the handle."""
     import torch
 
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    if isinstance(device, int):
+        idx = device
+    else:
+        idx = getattr(device, "index", None)
+        if idx is None:
+            idx = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+def current_stream(device=None) -> C.c_void_p:
+    return C.c_void_p(_raw_stream(device))
 
 
 class Workspace:
@@ -175,7 +188,7 @@ def default_workspace(device_index: int) -> Workspace:
     import torch
 
     try:
-        stream = int(torch.cuda.current_stream(device_index).cuda_stream)
+        stream = int(_raw_stream(device_index))
     except Exception:            # no GPU: Workspace() below raises the real error
         stream = 0
     key = (device_index, stream)

@@ -203,10 +203,17 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restr
 // k order inside a product: MFMA (j, t) sums k = 16 j + 4 q + t over the lane quarters q; j ascending, t ascending.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// gate functions of the layer kernels on the hardware exp / rcp (v_exp_f32, v_rcp_f32: absolute error <= 2.5e-7, the same
+// forms as the PPO step kernel's tanh); the per-step kernels keep expf / tanhf.  128 units x 16 rows x 5 functions per step on
+// one CU: the libm forms cost as many issue cycles as the step's 256 MFMAs.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh_(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f); }
+
+// zero_init: no initial state -- h_{-1} = c_{-1} = 0 are written to block 0 of hbuf / cbuf here (the backward pass reads them)
 template <int H>
 __global__ __launch_bounds__(H * 4) void lstm_layer_fwd_kernel(const float* __restrict__ gih, const float* __restrict__ whh,
                                                               float* __restrict__ hbuf, float* __restrict__ cbuf,
-                                                              float* __restrict__ gact, int B, int T) {
+                                                              float* __restrict__ gact, int B, int T, int zero_init) {
     constexpr int KB = H / 16, HP = H + 4;
     __shared__ __attribute__((aligned(16))) float hs[16 * HP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
@@ -229,8 +236,14 @@ __global__ __launch_bounds__(H * 4) void lstm_layer_fwd_kernel(const float* __re
     for (int v = 0; v < 4; ++v) {
         live[v] = b0 + 4 * q + v < B;
         row[v] = min(b0 + 4 * q + v, B - 1);
-        c[v] = cbuf[(size_t)row[v] * H + unit];
-        hs[(4 * q + v) * HP + unit] = hbuf[(size_t)row[v] * H + unit];
+        if (zero_init) {
+            c[v] = 0.f;
+            hs[(4 * q + v) * HP + unit] = 0.f;
+            if (live[v]) { cbuf[(size_t)row[v] * H + unit] = 0.f; hbuf[(size_t)row[v] * H + unit] = 0.f; }
+        } else {
+            c[v] = cbuf[(size_t)row[v] * H + unit];
+            hs[(4 * q + v) * HP + unit] = hbuf[(size_t)row[v] * H + unit];
+        }
     }
     for (int t = 0; t < T; ++t) {
         __syncthreads();                                   // h_{t-1} is in hs
@@ -254,12 +267,12 @@ __global__ __launch_bounds__(H * 4) void lstm_layer_fwd_kernel(const float* __re
         __syncthreads();                                   // every wave has read hs
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float gi = sigmoidf_(pre[0][v] + (acc[0][v] + bias[0]));
-            const float gf = sigmoidf_(pre[1][v] + (acc[1][v] + bias[1]));
-            const float gg = tanhf(pre[2][v] + (acc[2][v] + bias[2]));
-            const float go = sigmoidf_(pre[3][v] + (acc[3][v] + bias[3]));
+            const float gi = fast_sigmoid(pre[0][v] + (acc[0][v] + bias[0]));
+            const float gf = fast_sigmoid(pre[1][v] + (acc[1][v] + bias[1]));
+            const float gg = fast_tanh_(pre[2][v] + (acc[2][v] + bias[2]));
+            const float go = fast_sigmoid(pre[3][v] + (acc[3][v] + bias[3]));
             const float cn = gf * c[v] + gi * gg;
-            const float hn = go * tanhf(cn);
+            const float hn = go * fast_tanh_(cn);
             c[v] = cn;
             hs[(4 * q + v) * HP + unit] = hn;
             if (live[v]) {
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(H * 4) void lstm_layer_bwd_kernel(const float* __re
             const float i = ga[0], f = ga[H], g = ga[2 * H], o = ga[3 * H];
             const float dho = dout[(size_t)t * blk + i1];
             const float dh = last ? dho : dho + dh_rec[v];
-            const float tc = tanhf(cbuf[(size_t)(t + 1) * blk + i1]);
+            const float tc = fast_tanh_(cbuf[(size_t)(t + 1) * blk + i1]);
             const float d_o = dh * tc;
             float dct = dh * o * (1.f - tc * tc);
             if (!last) dct += dc[v];
@@ -339,8 +352,10 @@ bool lstm_fused_ok(int H) {
 }
 
 template <int H>
-void launch_layer_fwd(hipStream_t s, const float* gih, const float* whh, float* hbuf, float* cbuf, float* gact, int B, int T) {
-    hipLaunchKernelGGL(lstm_layer_fwd_kernel<H>, dim3((unsigned)ts::ceil_div(B, 16)), dim3(H * 4), 0, s, gih, whh, hbuf, cbuf, gact, B, T);
+void launch_layer_fwd(hipStream_t s, const float* gih, const float* whh, float* hbuf, float* cbuf, float* gact, int B, int T,
+                      int zero_init) {
+    hipLaunchKernelGGL(lstm_layer_fwd_kernel<H>, dim3((unsigned)ts::ceil_div(B, 16)), dim3(H * 4), 0, s, gih, whh, hbuf, cbuf, gact, B, T,
+                       zero_init);
 }
 template <int H>
 void launch_layer_bwd(hipStream_t s, const float* dout, const float* whh, const float* gact, const float* cbuf, float* dg, int B, int T) {
@@ -360,6 +375,22 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
         if (v > bv) { bv = v; best = a; }
     }
     if (act_out) act_out[b] = best;
+}
+
+// DQN._target_q (dqn.py:365-379) from the two head outputs [B, 32]: q_target[b, argmax_a q_online[b, a]] (double Q) or
+// max_a q_target[b, a]
+__global__ __launch_bounds__(256) void rnn_target_q_kernel(const float* __restrict__ head_online, const float* __restrict__ head_target,
+                                                           int64_t B, int A, int is_double, float* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* sel = is_double ? head_online : head_target;
+    float best = sel[b * HEAD];
+    int best_a = 0;
+    for (int a = 1; a < A; ++a) {
+        const float v = sel[b * HEAD + a];
+        if (v > best) { best = v; best_a = a; }
+    }
+    out[b] = head_target[b * HEAD + best_a];
 }
 
 // TD error, loss and d loss / d head (dqn.py:388-401)
@@ -432,17 +463,19 @@ int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, cons
     TS_LAUNCH_CHECK();
     if (n.has_fc1)
         if (int rc = ts::conv_forward(s, n.fc1, a.x, p + n.off_fc1, a.x1, false, a.split, ws)) return rc;
+    const bool fused = lstm_fused_ok(H);
     for (int l = 0; l < n.L; ++l) {
+        const int zero_init = fused && !h0 && !c0;          // the layer kernel writes the zero state itself
         if (h0) TS_HIP_CHECK(hipMemcpyAsync(a.hbuf[l], h0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
-        else TS_HIP_CHECK(hipMemsetAsync(a.hbuf[l], 0, 4 * blk, s));
+        else if (!zero_init) TS_HIP_CHECK(hipMemsetAsync(a.hbuf[l], 0, 4 * blk, s));
         if (c0) TS_HIP_CHECK(hipMemcpyAsync(a.cbuf[l], c0 + (size_t)l * blk, 4 * blk, hipMemcpyDeviceToDevice, s));
-        else TS_HIP_CHECK(hipMemsetAsync(a.cbuf[l], 0, 4 * blk, s));
+        else if (!zero_init) TS_HIP_CHECK(hipMemsetAsync(a.cbuf[l], 0, 4 * blk, s));
         const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
         if (int rc = ts::conv_forward(s, n.ih(l), in, p + n.off_ih[l], a.gih, false, a.split, ws)) return rc;
-        if (lstm_fused_ok(H)) {            // the T steps of the layer in one launch
-            if (H == 128) launch_layer_fwd<128>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
-            else if (H == 64) launch_layer_fwd<64>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
-            else launch_layer_fwd<32>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T);
+        if (fused) {                       // the T steps of the layer in one launch
+            if (H == 128) launch_layer_fwd<128>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T, zero_init);
+            else if (H == 64) launch_layer_fwd<64>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T, zero_init);
+            else launch_layer_fwd<32>(s, a.gih, p + n.off_hh[l], a.hbuf[l], a.cbuf[l], a.gact[l], (int)B, n.T, zero_init);
             TS_LAUNCH_CHECK();
             continue;
         }
@@ -466,7 +499,8 @@ int forward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, cons
 }
 
 struct Bwd {
-    float* dg;        // [T B, 4H] gate gradients of the current layer
+    float* dg;        // [T B, 4H] gate gradients of the current layer (layer l: dg + l * T B 4H -- the weight gradients of a layer
+                      // run on a side stream while the layer below already writes its own)
     float* dout;      // [T B, H]  d loss / d (layer output) at every step
     float* din;       // [T B, H]  d loss / d (layer input)
     float* dh_rec;    // [B, H]
@@ -476,12 +510,12 @@ struct Bwd {
 
 size_t bwd_bytes(const RNet& n) {
     const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
-    return al(4 * rows * 4 * H) + 2 * al(4 * rows * H) + 2 * al(4 * B * H) + al(4 * slab_floats(n));
+    return al(4 * n.L * rows * 4 * H) + 2 * al(4 * rows * H) + 2 * al(4 * B * H) + al(4 * slab_floats(n));
 }
 
 Bwd take_bwd(Carve& c, const RNet& n) {
     const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
-    return Bwd{c.f(rows * 4 * H), c.f(rows * H), c.f(rows * H), c.f(B * H), c.f(B * H), c.f(slab_floats(n))};
+    return Bwd{c.f(n.L * rows * 4 * H), c.f(rows * H), c.f(rows * H), c.f(B * H), c.f(B * H), c.f(slab_floats(n))};
 }
 
 int wgrad_to(hipStream_t s, ts_workspace* ws, const ts::ConvGeom& g, const float* x, const float* dy, float* slabs, float* out) {
@@ -489,47 +523,58 @@ int wgrad_to(hipStream_t s, ts_workspace* ws, const ts::ConvGeom& g, const float
     return ts::slab_sum(s, slabs, ts::conv_wgrad_splits(g), g.param_elems(), out);
 }
 
-// grad[0 .. count) = d loss / d params given d loss / d head output (d_head [B, 32])
+// grad[0 .. count) = d loss / d params given d loss / d head output (d_head [B, 32]).
+// The chain head -> (backward through time, input gradient) per layer runs down the caller's stream; the weight-gradient
+// GEMMs (+ slab sums) of the head and of every layer need only that layer's gate gradients and run, in order, on the
+// workspace's side stream beside the chain (they were 40 % of the serial launches of a DRQN update).
 int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, const Acts& a, const float* d_head, float* grad,
              Bwd bw) {
     const int64_t B = n.B;
     const int H = n.H, T = n.T;
     const size_t blk = (size_t)B * H;
     const unsigned gcell = (unsigned)ts::ceil_div((int64_t)blk, 256);
+    hipStream_t w;
+    if (int rc = ts::side_stream(ws, s, &w)) return rc;
     // head: only the last step of the top layer receives a gradient
     const float* h_last = n.extra ? a.hcat : a.hbuf[n.L - 1] + (size_t)T * blk;
-    if (int rc = wgrad_to(s, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
     if (T > 1) TS_HIP_CHECK(hipMemsetAsync(bw.dout, 0, 4 * (size_t)(T - 1) * blk, s));
     if (n.extra) {
-        // d loss / d [h_T | extra | pad] into the (dead) concat buffer, its first H columns are d loss / d h_T
+        // d loss / d [h_T | extra | pad] needs the (then dead) concat buffer: its weight gradient first, on this stream
+        if (int rc = wgrad_to(s, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
         if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, a.hcat, ws, 0, H)) return rc;
         hipLaunchKernelGGL(take_cols_kernel, dim3(gcell), dim3(256), 0, s, a.hcat, B, H, n.head_in, bw.dout + (size_t)(T - 1) * blk);
         TS_LAUNCH_CHECK();
-    } else if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) {
-        return rc;
+        if (int rc = ts::stream_wait(ws, s, w, 0)) return rc;                 // (orders the side stream's use of `slabs`)
+    } else {
+        if (int rc = ts::stream_wait(ws, s, w, 0)) return rc;                 // d_head is ready
+        if (int rc = wgrad_to(w, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
+        if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) return rc;
     }
     for (int l = n.L - 1; l >= 0; --l) {
+        float* dg = bw.dg + (size_t)l * T * 4 * blk;
         if (lstm_fused_ok(H)) {            // backward through time of the layer in one launch
-            if (H == 128) launch_layer_bwd<128>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
-            else if (H == 64) launch_layer_bwd<64>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
-            else launch_layer_bwd<32>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], bw.dg, (int)B, T);
+            if (H == 128) launch_layer_bwd<128>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], dg, (int)B, T);
+            else if (H == 64) launch_layer_bwd<64>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], dg, (int)B, T);
+            else launch_layer_bwd<32>(s, bw.dout, p + n.off_hh[l], a.gact[l], a.cbuf[l], dg, (int)B, T);
             TS_LAUNCH_CHECK();
         } else
         for (int t = T - 1; t >= 0; --t) {
             hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(gcell), dim3(256), 0, s, bw.dout + (size_t)t * blk, bw.dh_rec, bw.dc,
                                a.gact[l] + (size_t)t * 4 * blk, a.cbuf[l] + (size_t)(t + 1) * blk, a.cbuf[l] + (size_t)t * blk, B, H,
-                               t == T - 1 ? 1 : 0, bw.dg + (size_t)t * 4 * blk);
+                               t == T - 1 ? 1 : 0, dg + (size_t)t * 4 * blk);
             TS_LAUNCH_CHECK();
             if (t > 0)
-                if (int rc = ts::conv_dgrad(s, n.hh_step, bw.dg + (size_t)t * 4 * blk, p + n.off_hh[l], nullptr, bw.dh_rec, ws)) return rc;
+                if (int rc = ts::conv_dgrad(s, n.hh_step, dg + (size_t)t * 4 * blk, p + n.off_hh[l], nullptr, bw.dh_rec, ws)) return rc;
         }
+        if (int rc = ts::stream_wait(ws, s, w, 1 + l)) return rc;             // the layer's gate gradients are complete
         const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
-        if (int rc = wgrad_to(s, ws, n.ih(l), in, bw.dg, bw.slabs, grad + n.off_ih[l])) return rc;
-        if (int rc = wgrad_to(s, ws, n.ih_all, a.hbuf[l], bw.dg, bw.slabs, grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
-        if (l == 0 && !n.has_fc1) return TS_OK;            // nothing below the first LSTM layer takes a gradient
-        if (int rc = ts::conv_dgrad(s, n.ih_all, bw.dg, p + n.off_ih[l], nullptr, bw.din, ws)) return rc;
+        if (int rc = wgrad_to(w, ws, n.ih(l), in, dg, bw.slabs, grad + n.off_ih[l])) return rc;
+        if (int rc = wgrad_to(w, ws, n.ih_all, a.hbuf[l], dg, bw.slabs, grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
+        if (l == 0 && !n.has_fc1) return ts::stream_wait(ws, w, s, 15);       // nothing below the first LSTM layer takes a gradient
+        if (int rc = ts::conv_dgrad(s, n.ih_all, dg, p + n.off_ih[l], nullptr, bw.din, ws)) return rc;
         std::swap(bw.dout, bw.din);
     }
+    if (int rc = ts::stream_wait(ws, w, s, 15)) return rc;                   // `slabs` is free again, every gradient block above is written
     return wgrad_to(s, ws, n.fc1, a.x, bw.dout, bw.slabs, grad + n.off_fc1);
 }
 
@@ -601,10 +646,37 @@ int ts_rnnq_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int6
     return TS_OK;
 }
 
-int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
+                           ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_target_q_fused: workspace is NULL");
+    TS_REQUIRE(params && obs_next && out, TS_ERR_INVALID_ARG, "ts_rnnq_target_q_fused: NULL argument");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, B, T, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream), side;
+    if (int rc = ts::ws_reserve(ws, 2 * acts_bytes(n) + 8192)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    const Acts a1 = take_acts(c, n), a2 = take_acts(c, n);
+    if (int rc = ts::side_stream(ws, s, &side)) return rc;
+    const bool two = params_old != nullptr;
+    if (two) {      // Q_target(s') on the side stream beside Q_online(s') (a pass at B = 128 occupies eight CUs)
+        if (int rc = ts::stream_wait(ws, s, side, 9)) return rc;
+        if (int rc = forward(side, ws, n, params_old, obs_next, nullptr, nullptr, a2)) return rc;
+    }
+    if (!two || is_double)
+        if (int rc = forward(s, ws, n, params, obs_next, nullptr, nullptr, a1)) return rc;
+    if (two)
+        if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
+    hipLaunchKernelGGL(rnn_target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, two ? a2.out : a1.out, B,
+                       n.A, is_double, out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+static int rnnq_update_impl(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
                    int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
                    const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
-                   float* grad_out, ts_stream_t stream) {
+                   float* grad_out, ts_stream_t stream, void* cache) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_update: workspace is NULL");
     TS_REQUIRE(params && obs && act && returns && hp && td_out && loss_out, TS_ERR_INVALID_ARG, "ts_rnnq_update: NULL argument");
     TS_REQUIRE(hp->lr < 0.0 || (adam_m && adam_v && adam_step >= 1), TS_ERR_INVALID_ARG, "ts_rnnq_update: Adam state missing");
@@ -613,13 +685,18 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
     hipStream_t s = ts::as_stream(stream);
     if (int rc = ts::ws_reserve(ws, acts_bytes(n) + bwd_bytes(n) + al(4 * B * HEAD) + al(4 * n.count) + 8192)) return rc;
     Carve c{static_cast<char*>(ws->base)};
-    const Acts a = take_acts(c, n);
+    Acts a = take_acts(c, n);
     const Bwd bw = take_bwd(c, n);
     float* d_head = c.f(B * HEAD);
     float* grad = c.f(n.count);
     float* norm_part = c.f(1024);
     if (grad_out) grad = grad_out;
-    if (int rc = forward(s, ws, n, params, obs, nullptr, nullptr, a)) return rc;
+    if (cache) {            // the activations ts_rnnq_forward_cache left there
+        Carve cc{static_cast<char*>(cache)};
+        a = take_acts(cc, n);
+    } else if (int rc = forward(s, ws, n, params, obs, nullptr, nullptr, a)) {
+        return rc;
+    }
     hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, act, returns, weight, B, (float)hp->huber_delta, td_out,
                        d_head, loss_out);
     TS_LAUNCH_CHECK();
@@ -627,6 +704,43 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
     if (hp->lr < 0.0) return TS_OK;
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.count, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm, norm_part);
+}
+
+int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                   int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
+                   const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, float* td_out, float* loss_out,
+                   float* grad_out, ts_stream_t stream) {
+    return rnnq_update_impl(ws, params, adam_m, adam_v, adam_step, obs_dim, hidden, layers, n_act, obs, act, returns, weight, B, T,
+                            hp, td_out, loss_out, grad_out, stream, nullptr);
+}
+
+int64_t ts_rnnq_cache_bytes(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T) {
+    RNet n;
+    if (make_rnet(obs_dim, hidden, layers, n_act, B, T, &n) != TS_OK) return -1;
+    return (int64_t)acts_bytes(n);
+}
+
+int ts_rnnq_forward_cache(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                          const float* obs, int64_t B, int64_t T, void* cache, int64_t cache_bytes, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_forward_cache: workspace is NULL");
+    TS_REQUIRE(params && obs && cache, TS_ERR_INVALID_ARG, "ts_rnnq_forward_cache: NULL argument");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(cache) & 255u) == 0, TS_ERR_INVALID_ARG, "ts_rnnq_forward_cache: cache must be 256-byte aligned");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, B, T, &n)) return rc;
+    TS_REQUIRE(cache_bytes >= (int64_t)acts_bytes(n), TS_ERR_SHAPE, "ts_rnnq_forward_cache: cache holds %lld bytes, %lld needed",
+               (long long)cache_bytes, (long long)acts_bytes(n));
+    Carve cc{static_cast<char*>(cache)};
+    const Acts a = take_acts(cc, n);
+    return forward(ts::as_stream(stream), ws, n, params, obs, nullptr, nullptr, a);
+}
+
+int ts_rnnq_update_cached(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                          int64_t hidden, int64_t layers, int64_t n_act, const float* obs, const int64_t* act, const float* returns,
+                          const float* weight, int64_t B, int64_t T, const ts_dqn_hparams* hp, void* cache, float* td_out,
+                          float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(cache != nullptr, TS_ERR_INVALID_ARG, "ts_rnnq_update_cached: cache is NULL");
+    return rnnq_update_impl(ws, params, adam_m, adam_v, adam_step, obs_dim, hidden, layers, n_act, obs, act, returns, weight, B, T,
+                            hp, td_out, loss_out, grad_out, stream, cache);
 }
 
 // ---- LSTM trunk + linear head, generic (RecurrentActorProb / RecurrentCritic, continuous.py:241-380) ------------------------

@@ -109,6 +109,19 @@ class RecurrentDQNEngine:
         self.adam_step = 0
         self.iter = 0
         self._ws = _lib.default_workspace(self.device.index or 0)
+        self._streams = {}
+        self._pre = None               # (obs tensor, cache pointer, done event, parameter state, B, T) of a prefetched forward pass
+        self._cache = None
+
+    def _side(self, which: int) -> torch.cuda.Stream:
+        """The workspace's side stream `which` (ts_workspace_side_stream) as a torch stream: independent passes go there
+        instead of on streams of our own (four hardware queues)."""
+        st = self._streams.get(which)
+        if st is None:
+            h = C.c_void_p()
+            _lib.check(_lib.load().ts_workspace_side_stream(self._ws.handle, C.c_int(which), C.byref(h)))
+            st = self._streams[which] = torch.cuda.ExternalStream(h.value, device=self.device)
+        return st
 
     def _dims(self):
         return _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.i64(self.layers), _lib.i64(self.n_act)
@@ -137,8 +150,9 @@ class RecurrentDQNEngine:
             h_out = torch.empty((self.layers, b, self.hidden), dtype=torch.float32, device=self.device)
             c_out = torch.empty_like(h_out)
         p = self.params if params is None else params
+        ws = _lib.default_workspace(self.device.index or 0)          # the CURRENT stream's scratch (target_q runs two passes at once)
         _lib.check(_lib.load().ts_rnnq_forward(
-            self._ws.handle, _lib.ptr(p), *self._dims(), _lib.ptr(obs), _lib.i64(b), _lib.i64(t), _lib.ptr(h_in), _lib.ptr(c_in),
+            ws.handle, _lib.ptr(p), *self._dims(), _lib.ptr(obs), _lib.i64(b), _lib.i64(t), _lib.ptr(h_in), _lib.ptr(c_in),
             _lib.ptr(q), _lib.ptr(act), _lib.ptr(h_out), _lib.ptr(c_out), _lib.current_stream(self.device)))
         if want_state:
             return q, act, (h_out.transpose(0, 1).contiguous(), c_out.transpose(0, 1).contiguous())
@@ -146,13 +160,52 @@ class RecurrentDQNEngine:
 
     # -- DQN._target_q ---------------------------------------------------------------------------------------------------------
     def target_q(self, obs_next) -> torch.Tensor:
-        q_online, _ = self.forward(obs_next)
-        q_target = q_online if self.params_old is None else self.forward(obs_next, params=self.params_old)[0]
-        b = q_online.shape[0]
+        """Both passes on obs_next (the lagged network's on the workspace's side stream) and the arg-max / gather in one call
+        (ts_rnnq_target_q_fused)."""
+        obs_next = self._obs(obs_next)
+        b, t = obs_next.shape[:2]
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        _lib.check(_lib.load().ts_dqn_target_q(_lib.ptr(q_online), _lib.ptr(q_target), _lib.i64(b), _lib.i64(self.n_act),
-                                               C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
+        _lib.check(_lib.load().ts_rnnq_target_q_fused(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.params_old), *self._dims(), _lib.ptr(obs_next), _lib.i64(b),
+            _lib.i64(t), C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
+
+    # -- the update's own forward pass, ahead of time -----------------------------------------------------------------------------
+    def prefetch_forward(self, obs) -> torch.Tensor:
+        """Q_online(batch.obs) of the coming `update_with_batch(obs, ...)` on the workspace's second side stream, beside the two
+        obs_next passes of `_target_q` (as DQNEngine.prefetch_forward).  Returns the tensor to hand to `update_with_batch`
+        (the SAME object: the cached activations are used only then, and only while the parameters are unchanged)."""
+        lib = _lib.load()
+        lib.ts_rnnq_cache_bytes.restype = C.c_int64
+        obs = self._obs(obs)
+        b, t = obs.shape[:2]
+        need = int(lib.ts_rnnq_cache_bytes(*self._dims(), _lib.i64(b), _lib.i64(t)))
+        if need <= 0:
+            return obs
+        if self._cache is None or self._cache.numel() < need + 256:
+            self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        cache_ptr = C.c_void_p((self._cache.data_ptr() + 255) & ~255)
+        main, side = torch.cuda.current_stream(self.device), self._side(1)
+        ready, done = torch.cuda.Event(), torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            ws = _lib.default_workspace(self.device.index or 0)
+            _lib.check(lib.ts_rnnq_forward_cache(ws.handle, _lib.ptr(self.params), *self._dims(), _lib.ptr(obs), _lib.i64(b),
+                                                 _lib.i64(t), cache_ptr, _lib.i64(need), _lib.current_stream(self.device)))
+            done.record(side)
+        obs.record_stream(side)
+        self._pre = (obs, cache_ptr, done, (self.params._version, self.adam_step), b, t)
+        return obs
+
+    def preprocess_with_obs(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, indices, stack_num: int,
+                            obs_next_rows: torch.Tensor | None = None, prefetch: bool = True):
+        """-> (batch.obs float32[I, T, obs_dim], returns float32[I]): the batch's own stacked observations first, their forward
+        pass started on a side stream (prefetch_forward), then `preprocess`."""
+        obs = self._obs(gather_stacked_obs(obs_rows, buffer, indices, stack_num))
+        if prefetch:
+            obs = self.prefetch_forward(obs)
+        return obs, self.preprocess(buffer, obs_rows, indices, stack_num, obs_next_rows)
 
     # -- DQN._preprocess_batch ---------------------------------------------------------------------------------------------
     def preprocess(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, indices, stack_num: int,
@@ -193,8 +246,12 @@ class RecurrentDQNEngine:
         if self.params_old is not None and self.iter % cfg.target_update_freq == 0:    # dqn.py:283-285
             full_parameter_update(self.params_old, self.params)
         self.iter += 1
+        params_state = (self.params._version, self.adam_step)          # what a prefetched forward pass was computed with
+        pre, self._pre = self._pre, None
+        cached = pre is not None and pre[0] is obs
         obs = self._obs(obs)
         b, t = obs.shape[:2]
+        cached = cached and pre[3] == params_state and pre[4] == b and pre[5] == t
         act = _i64_dev(act, self.device).reshape(-1)
         returns = torch.as_tensor(returns, device=self.device).to(torch.float32).reshape(-1).contiguous()
         if act.numel() != b or returns.numel() != b:
@@ -206,6 +263,14 @@ class RecurrentDQNEngine:
         if apply:
             self.adam_step += 1
         hp = cfg.to_c(grad_only=not apply)
+        if cached:
+            torch.cuda.current_stream(self.device).wait_event(pre[2])          # the prefetched activations are complete
+            _lib.check(_lib.load().ts_rnnq_update_cached(
+                self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v),
+                _lib.i64(max(self.adam_step, 1)), *self._dims(), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight),
+                _lib.i64(b), _lib.i64(t), C.byref(hp), pre[1], _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
+                _lib.current_stream(self.device)))
+            return loss, td
         _lib.check(_lib.load().ts_rnnq_update(
             self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(max(self.adam_step, 1)),
             *self._dims(), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight), _lib.i64(b), _lib.i64(t),

@@ -869,7 +869,10 @@ def make_hip_drqn(ref=None):
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             stack = int(getattr(buffer, "stack_num", 1))
             nxt = m.obs_next if m.obs_next is not None else None
-            batch.returns = eng.preprocess(m, m.obs, idx, stack, obs_next_rows=nxt).reshape(-1, 1)
+            # the batch's own stacked observations are gathered here, so that their forward pass (the one _update_with_batch needs)
+            # can run on a side stream beside the two obs_next passes of _target_q; data-parallel runs keep the plain order
+            self._hip_obs, ret = eng.preprocess_with_obs(m, m.obs, idx, stack, obs_next_rows=nxt, prefetch=not self._hip_dp_on)
+            batch.returns = ret.reshape(-1, 1)
             self._hip_idx, self._hip_stack = idx, stack
             if hasattr(batch, "weight"):
                 batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
@@ -879,7 +882,7 @@ def make_hip_drqn(ref=None):
             self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
-            obs = R.gather_stacked_obs(m.obs, m, self._hip_idx, self._hip_stack)
+            obs = self._hip_obs
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
             runner = eng
             if self._hip_dp_on:
