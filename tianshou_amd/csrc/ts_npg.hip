@@ -369,24 +369,44 @@ __global__ __launch_bounds__(256) void trpo_select_kernel(float* __restrict__ th
     }
 }
 
-// critic: vf_loss = mse_loss(returns, V); d_head[b, 0] = 2 (V - returns) / B
-__global__ __launch_bounds__(1024) void critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret, int64_t B,
-                                                           float* __restrict__ d_head, float* __restrict__ loss) {
-    __shared__ float red[1024];
+// per-workgroup sum of one value per thread (256 threads), fixed order: wave shuffle trees, then the four wave sums in order
+__device__ __forceinline__ float block_sum256(float v, float* red4) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+// out = scale * sum_i partial[i] in a fixed order (thread t: i = t, t + 256, ...; then block_sum256)
+__global__ __launch_bounds__(256) void sum_finish_kernel(const float* __restrict__ partial, int n, float scale, float* __restrict__ out) {
+    __shared__ float red4[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];
+    const float t = block_sum256(v, red4);
+    if (threadIdx.x == 0) *out = t * scale;
+}
+
+// critic: vf_loss = mse_loss(returns, V); d_head[b, 0] = 2 (V - returns) / B.  One sample per thread, per-workgroup partial
+// sums of the loss (sum_finish_kernel adds them up): as ONE workgroup over 65,536 samples -- which also writes their 8 MB of
+// d_head rows -- this kernel was 412 us, a third of an NPG update.
+__global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret, int64_t B,
+                                                          float* __restrict__ d_head, float* __restrict__ partial) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ float red4[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const float inv_b = 1.f / (float)B;
     float ls = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    if (b < B) {
         const float t = v_head[b * HEAD] - ret[b];
-        ls += t * t;
-        for (int j = 0; j < HEAD; ++j) d_head[b * HEAD + j] = j == 0 ? 2.f * t * inv_b : 0.f;
+        ls = t * t;
+        f32x4* row = reinterpret_cast<f32x4*>(d_head + b * HEAD);
+        row[0] = f32x4{2.f * t * inv_b, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 1; j < HEAD / 4; ++j) row[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    red[threadIdx.x] = ls;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+    const float tot = block_sum256(ls, red4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
 // ---- PPO / A2C on the GEMM path (any Net[h, h] tanh actor-critic: the shapes the fused kernels of ts_ppo.hip do not
@@ -444,19 +464,23 @@ __global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* _
     }
 }
 
-// value loss (ppo.py:198-208, a2c.py:270) and its gradient w.r.t. the value head, scaled by vf_coef
-__global__ __launch_bounds__(1024) void ppo_wide_critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret,
-                                                                    const float* __restrict__ v_old, float eps_clip, int value_clip,
-                                                                    float vf_coef, int64_t B, float inv_b,
-                                                                    float* __restrict__ d_head, float* __restrict__ loss) {
+// value loss (ppo.py:198-208, a2c.py:270) and its gradient w.r.t. the value head, scaled by vf_coef; one sample per thread,
+// per-workgroup partial sums (sum_finish_kernel)
+__global__ __launch_bounds__(256) void ppo_wide_critic_loss_kernel(const float* __restrict__ v_head, const float* __restrict__ ret,
+                                                                   const float* __restrict__ v_old, float eps_clip, int value_clip,
+                                                                   float vf_coef, int64_t B, float inv_b,
+                                                                   float* __restrict__ d_head, float* __restrict__ partial) {
     // inv_b = 1 / (global minibatch size): the same scale as the actor part (data-parallel shards sum to the batch mean)
-    __shared__ float red[1024];
-    float ls = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ float red4[4];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f;
+    if (b < B) {
         const float value = v_head[b * HEAD], r = ret[b];
         const float vf1 = (r - value) * (r - value);
         const float g1 = -2.f * (r - value);
-        float term = vf1, dv = g1;
+        float dv = g1;
+        term = vf1;
         if (value_clip) {
             const float vo = v_old[b], dvo = value - vo;
             const float vclip = vo + fminf(fmaxf(dvo, -eps_clip), eps_clip);
@@ -465,16 +489,13 @@ __global__ __launch_bounds__(1024) void ppo_wide_critic_loss_kernel(const float*
             term = fmaxf(vf1, vf2);                                                    // torch.max: ties split the gradient
             dv = (vf1 > vf2) ? g1 : ((vf2 > vf1) ? g2 : 0.5f * (g1 + g2));
         }
-        ls += term;
-        for (int j = 0; j < HEAD; ++j) d_head[b * HEAD + j] = j == 0 ? dv * vf_coef * inv_b : 0.f;
+        f32x4* row = reinterpret_cast<f32x4*>(d_head + b * HEAD);
+        row[0] = f32x4{dv * vf_coef * inv_b, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 1; j < HEAD / 4; ++j) row[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    red[threadIdx.x] = ls;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *loss = red[0] * inv_b;
+    const float tot = block_sum256(term, red4);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
 // losses[3] = Normal.entropy().sum(-1) (identical for every sample), losses[0] = clip + vf_coef vf - ent_coef ent (ppo.py:211)
@@ -729,7 +750,7 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
     hipStream_t s = ts::as_stream(stream);
     const int64_t P = n.off[3];
     if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) +
-                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * P) + 8192))
+                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * P) + al(4 * ts::ceil_div(B, 256)) + 8192))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.f(B * n.k0);
@@ -739,11 +760,14 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
     float* split = c.f(split_floats(n));
     float* grad = c.f(P);
     float* norm_part = c.f(1024);
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    float* lpart = c.f(n_blocks);
     if (grad_out) grad = grad_out;
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
     TS_LAUNCH_CHECK();
     if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
-    hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, returns, B, d_head, loss_out);
+    hipLaunchKernelGGL(critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, returns, B, d_head, lpart);
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, lpart, n_blocks, 1.f / (float)B, loss_out);
     TS_LAUNCH_CHECK();
     if (int rc = backward(s, ws, n, critic, x, a, d_head, grad, bw, B)) return rc;
     if (lr < 0.0) return TS_OK;
@@ -802,8 +826,9 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
     if (int rc = backward(s, ws, n, actor, x, a, d_head, grad, bw, B)) return rc;
     // ---- critic
     if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
-    hipLaunchKernelGGL(ppo_wide_critic_loss_kernel, dim3(1), dim3(1024), 0, s, a.out, returns, v_old, (float)hp->eps_clip,
-                       a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, inv_b, d_head, losses_out4 + 2);
+    hipLaunchKernelGGL(ppo_wide_critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, returns, v_old, (float)hp->eps_clip,
+                       a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, inv_b, d_head, partial);
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, inv_b, losses_out4 + 2);
     TS_LAUNCH_CHECK();
     if (int rc = backward(s, ws, n, critic, x, a, d_head, grad + Pa, bw, B)) return rc;
     hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + n.off[3], A, (float)hp->vf_coef,

@@ -568,7 +568,12 @@ __global__ __launch_bounds__(1024) void det_actor_loss_kernel(const float* __res
     __shared__ float red[1024];
     const float inv_b = 1.f / (float)B;
     float ls = 0.f;
-    for (int64_t b = threadIdx.x; b < B; b += 1024) { ls += q1[b * 32]; store_head_row(d_q1 + b * 32, -inv_b); }
+    if (blockIdx.x > 0) {            // workgroups 1..: the d_q1 rows (workgroup 0 keeps the sum and its order)
+        const int64_t b = (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x;
+        if (b < B) store_head_row(d_q1 + b * 32, -inv_b);
+        return;
+    }
+    for (int64_t b = threadIdx.x; b < B; b += 1024) ls += q1[b * 32];
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *loss = -(tot * inv_b);
 }
@@ -716,6 +721,9 @@ __global__ __launch_bounds__(256) void redq_target_kernel(const float* __restric
 
 // one member's share of the ensemble loss (redq.py:266-270): td_e = Q_e - returns, loss = sum_e sum_b td^2 w / (E B)
 // (blockIdx.x = member of the launch: Q, td, d_out and the loss part of member k sit k strides after the first one's)
+// grid (members, 1 + ceil(B / 1024)): row 0 of the grid sums the loss and writes td (one workgroup per member: the summation
+// order of a single 1,024-thread workgroup), rows 1.. write the 128-byte d_out rows -- as one workgroup per member those 512 KB
+// of stores made this a 28 us launch.
 __global__ __launch_bounds__(1024) void redq_critic_loss_kernel(const float* __restrict__ q, int64_t q_stride,
                                                                 const float* __restrict__ ret, const float* __restrict__ weight,
                                                                 int64_t B, float inv_eb, float* __restrict__ td,
@@ -724,13 +732,20 @@ __global__ __launch_bounds__(1024) void redq_critic_loss_kernel(const float* __r
     __shared__ float red[1024];
     const int64_t e = blockIdx.x;
     q += e * q_stride; td += e * B; d_out += e * d_stride; loss_part += e;
+    if (blockIdx.y > 0) {
+        const int64_t b = (int64_t)(blockIdx.y - 1) * 1024 + threadIdx.x;
+        if (b >= B) return;
+        const float t = q[b * 32] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        store_head_row(d_out + b * 32, 2.f * t * w * inv_eb);
+        return;
+    }
     float ls = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += 1024) {
         const float t = q[b * 32] - ret[b];
         const float w = weight ? weight[b] : 1.f;
         td[b] = t;
         ls += t * t * w;
-        store_head_row(d_out + b * 32, 2.f * t * w * inv_eb);
     }
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *loss_part = tot * inv_eb;
@@ -1375,7 +1390,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
                            (const float*)nullptr, B, d.act, (float)hp->max_action, 0.f, 0.f, d.obs, d.kc, x_p,
                            (float*)nullptr, keep);
         if (int rc = mlp_forward(s, ws, mc, st->critic1, x_p, a1, splits[0])) return rc;
-        hipLaunchKernelGGL(det_actor_loss_kernel, dim3(1), dim3(1024), 0, s, a1.out, B, d_q, stats_out3);
+        hipLaunchKernelGGL(det_actor_loss_kernel, dim3(1 + (unsigned)ts::ceil_div(B, 1024)), dim3(1024), 0, s, a1.out, B, d_q, stats_out3);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, mc, st->critic1, x_p, a1, d_q, nullptr, dx1, d.obs, d.obs + d.act, scs[0]))
             return rc;
@@ -1734,7 +1749,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
                 gk[k] = gcrit + (int64_t)(e0 + k) * pc;
             }
             if (int rc = mlp_forward_multi(s, ws, mc, n, pp, x_c, acts + e0, splits)) return rc;
-            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3((unsigned)n), dim3(1024), 0, s, acts[e0].out, q_stride, returns, weight,
+            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3((unsigned)n, 1 + (unsigned)ts::ceil_div(B, 1024)), dim3(1024), 0, s, acts[e0].out, q_stride, returns, weight,
                                B, inv_eb, tds + (int64_t)e0 * B, dheads_ch, B * 32, loss_parts + e0);
             TS_LAUNCH_CHECK();
             if (int rc = mlp_backward_multi(s, ws, mc, n, pp, x_c, acts + e0, dh, nullptr, 0, 0, scs)) return rc;
@@ -1746,7 +1761,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
             const int w = e & 1;
             const float* pe = st->critics + (int64_t)e * pc;
             if (int rc = mlp_forward(st2[w], ws, mc, pe, x_c, acts[e], splits[w])) return rc;
-            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3(1), dim3(1024), 0, st2[w], acts[e].out, (int64_t)0, returns, weight, B,
+            hipLaunchKernelGGL(redq_critic_loss_kernel, dim3(1, 1 + (unsigned)ts::ceil_div(B, 1024)), dim3(1024), 0, st2[w], acts[e].out, (int64_t)0, returns, weight, B,
                                inv_eb, tds + (int64_t)e * B, dheads[w], (int64_t)0, loss_parts + e);
             TS_LAUNCH_CHECK();
             if (int rc = mlp_backward(st2[w], ws, mc, pe, x_c, acts[e], dheads[w], gcrit + (int64_t)e * pc, nullptr, 0, 0, scs[w]))
