@@ -99,6 +99,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
     t0 = time.perf_counter()
     for _ in range(steps):
         stats = update()
+    t_host = time.perf_counter() - t0            # the host's share: enqueueing `steps` updates (no synchronisation inside)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
 
@@ -126,6 +127,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
                                "actor 171,042 + 2 x 166,913 critic parameters, B=4096", "parallelism": "dp1"},
         "roofline": roof,
         "whole_update_mfma_frac": FLOP_PER_SAMPLE * BATCH * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "host_enqueue_ms_per_step": t_host / steps * 1e3,
         "cpu_baseline": cpu_baseline() if with_cpu else None,
         "final_stats": [float(x) for x in stats.tolist()],
     }
