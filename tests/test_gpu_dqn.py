@@ -453,6 +453,23 @@ def test_replay_stream_cycle_equals_the_sequential_cycle():
         return log, eng.params.clone(), per.weight._value.clone(), per.prio_minmax.clone()
 
     a, b = cycle(False), cycle(True)
+    # reset() drops the prepared batch (transitions were added): the next take() samples afresh on the current tree
+    frames, act, buf, per = BD.build(4096, 4, seed=3)
+    p0 = OD.init_params(4, 84, 84, 6, 2)
+    eng = D.DQNEngine(4, 84, 84, 6, D.flat_from_torch([p0[k] for k in OD.PARAM_ORDER], 4, 84, 84, 6),
+                      D.DQNConfig(gamma=0.99, n_step=3, target_update_freq=2, is_double=True, huber_delta=1.0, lr=1e-4))
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rs = D.ReplayStream(eng, buf, frames, per, 4, lambda: torch.rand(64, generator=gen, device="cuda", dtype=torch.float64),
+                        lambda i: act[i])
+    first = rs.take()
+    obs, ret = eng.preprocess_with_obs(buf, frames, first[0], 4, pair=first[3], coef=first[4])
+    _, td = eng.update_with_batch(obs, first[2], ret, first[1])
+    rs.give(first[0], td)
+    assert rs._next is not None
+    rs.reset()
+    assert rs._next is None
+    again = rs.take()
+    assert again[0].shape == first[0].shape and bool((again[0] >= 0).all())
     for it, (x, y) in enumerate(zip(a[0], b[0])):
         for u, v in zip(x, y):
             assert torch.equal(u, v), it

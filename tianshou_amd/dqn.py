@@ -456,6 +456,11 @@ class ReplayStream:
         self._ready = torch.cuda.Event()
         self._ready.record(self.stream)
 
+    def reset(self) -> None:
+        """Drops the batch prepared ahead of time (call it after transitions were added to the buffer: the prepared indices
+        and priorities predate them); the next `take` samples afresh."""
+        self._next = None
+
     def take(self):
         """-> (indices, IS weights float32, actions, (obs, obs_next) or None, n-step coefficients or None) of the next batch,
         ready on the caller's stream."""
