@@ -87,39 +87,59 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
     const int q = tid & 7, rowi = tid >> 3;          // A staging: float4 q of rows rowi + 32 j
     const int run = g.KW * g.IC, pitch = g.IW * g.IC;
     f32x4 ar[AJ], br[BJ];
+    // loop invariants of the staging loads in registers (they sit behind barriers, the compiler re-reads LDS otherwise), and
+    // the (kh, k - kh run) split of this thread's k advanced by BK per chunk instead of a division per chunk: the B = 512
+    // launches issued 4.3 VALU + 4.3 SALU instructions per MFMA (profiles/r04_pmc_dqn_kernels.txt)
+    int sin_r[AJ], sac_r[AJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) { sin_r[j] = s_in[rowi + 32 * j]; sac_r[j] = DG ? s_ac[rowi + 32 * j] : 0; }
+    const int c_first = (DG ? 0 : split) * a.chunks;
+    int kh_r = 0, krem_r = 0;
+    if (!DG) { const int k = c_first * BK + 4 * q; kh_r = k / run; krem_r = k - kh_r * run; }
+    const float* bptr[BJ];
+    if (!DG) {
+#pragma unroll
+        for (int i = 0; i < BJ; ++i) {
+            const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
+            bptr[i] = a.Bm + (int64_t)(c_first * BK + kk) * g.OC + n0 + 4 * n4;
+        }
+    }
+    const int64_t bstep = (int64_t)BK * g.OC;
+    int dg_oc0 = 0, dg_jh = 0, dg_jw = 0;            // dgrad: (tap, first output channel) of the next chunk (chunks start at 0)
 
-    auto gload = [&](int c) {
-        const int k0 = c * BK;
+    auto gload = [&](int) {                          // chunks are requested in order, once each
         if (!DG) {
-            const int k = k0 + 4 * q, kh = k / run;
-            const int koff = kh * pitch + (k - kh * run);
+            const int koff = kh_r * pitch + krem_r;
+            krem_r += BK;                            // next chunk (chunks are loaded in order, once each)
+            while (krem_r >= run) { krem_r -= run; ++kh_r; }
             if (a.a_u8) {          // 4 consecutive uint8 pixels/channels per lane -> 4 floats (exact)
                 const uint8_t* a8 = reinterpret_cast<const uint8_t*>(a.A);
 #pragma unroll
                 for (int j = 0; j < AJ; ++j) {
-                    const uint32_t v = *reinterpret_cast<const uint32_t*>(a8 + s_in[rowi + 32 * j] + koff);
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(a8 + sin_r[j] + koff);
                     ar[j] = f32x4{(float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24)};
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < AJ; ++j)
-                    ar[j] = *reinterpret_cast<const f32x4*>(a.A + s_in[rowi + 32 * j] + koff);
+                    ar[j] = *reinterpret_cast<const f32x4*>(a.A + sin_r[j] + koff);
             }
 #pragma unroll
             for (int i = 0; i < BJ; ++i) {
-                const int e = tid + THREADS * i, kk = e / (BN / 4), n4 = e % (BN / 4);
-                br[i] = *reinterpret_cast<const f32x4*>(a.Bm + (int64_t)(k0 + kk) * g.OC + n0 + 4 * n4);
+                br[i] = *reinterpret_cast<const f32x4*>(bptr[i]);
+                bptr[i] += bstep;
             }
         } else {
-            const int tp = k0 / g.OC, oc0 = k0 - tp * g.OC;
-            const int jh = tp / a.JW, jw = tp - jh * a.JW;
+            const int oc0 = dg_oc0, jh = dg_jh, jw = dg_jw;          // k0 = (jh JW + jw) OC + oc0, advanced per chunk
+            dg_oc0 += BK;
+            if (dg_oc0 >= g.OC) { dg_oc0 -= g.OC; if (++dg_jw == a.JW) { dg_jw = 0; ++dg_jh; } }
             const int shift = (jh * g.OW + jw) * g.OC - oc0 - 4 * q;
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
-                const int i = rowi + 32 * j, ac = s_ac[i];
+                const int ac = sac_r[j];
                 const int oh = (ac & 0xffff) - jh, ow = (ac >> 16) - jw;
                 const bool ok = oh >= 0 && oh < g.OH && ow >= 0 && ow < g.OW;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (ok ? s_in[i] - shift : 4 * q));
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (ok ? sin_r[j] - shift : 4 * q));
                 ar[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             const int tapk = ((ph + g.S * jh) * g.KW + pw + g.S * jw) * g.IC;
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(THREADS) void conv_rows_kernel(GemmArgs a) {
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[tm][tn][x] = 0.f;
 
-    const int c_begin = split * a.chunks;
+    const int c_begin = split * a.chunks;            // (== c_first for the forward pass; dgrad launches are not split)
     const int c_end = min(a.total_chunks, c_begin + a.chunks);
     if (c_begin < c_end) gload(c_begin);
     for (int c = c_begin; c < c_end; ++c) {
