@@ -77,6 +77,7 @@ def _tick() -> int:
 
 
 _HOST_MS = [None]
+_LAST_PROF: dict = {}
 
 
 def _time(update, steps, warmup):
@@ -100,6 +101,8 @@ def _time(update, steps, warmup):
         update()
     torch.cuda.synchronize()
     prof = ws.profile_end()
+    _LAST_PROF.clear()
+    _LAST_PROF.update({k: (v[0] / n_prof, v[1] // n_prof) for k, v in prof.items()})       # every kernel kind, per update
     return dt, last, {k: (prof[k][0] / n_prof, prof[k][1] // n_prof) for k in GEMM_KINDS}
 
 
@@ -600,11 +603,20 @@ def run_reinforce(steps, warmup, with_cpu):
         OR.update(st, ocfg, o, a, r, MB, 1, [np.arange(4 * MB)])
         cpu = {"value": 4 / (time.perf_counter() - t0), "unit": "update-steps/s", "cores": _threads(), "kind": "port",
                "sample": f"4 minibatch steps of {MB} samples, torch fp32 CPU oracle (returns precomputed)"}
+    if eng.fused_supported():       # the minibatch loop runs on ts_ppo.hip's fused step kernel (A2C actor loss, zero critic beside it)
+        ms, launches = _LAST_PROF["ppo_step"]
+        tf = flop / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "ppo_step2_kernel (algo a2c, adv := returns, vf_coef 0; the launch also evaluates a zero "
+                                           "critic, which the algorithmic flops do not count)",
+                "achieved": tf, "peak": PEAK, "unit": "TFLOP/s", "frac": tf / PEAK, "traffic": None,
+                "avg_launch_us": ms * 1e3 / max(launches, 1), "launches_per_update": launches, "algorithmic_flop_per_update": flop}
+    else:
+        roof = _roofline(prof, flop, "linear-layer GEMMs of the policy-gradient steps")
     return _line("Reinforce learn() update-steps/sec (minibatch 65536, obs 17, act 6, MLP[64,64], preprocessing incl.)",
                  steps * k / dt, "update-steps/s", steps, warmup, dt,
                  f"Reinforce on the C2 rollout: {E} envs x {T} steps = {n} transitions, minibatch {MB}, return standardisation",
-                 _roofline(prof, flop, "linear-layer GEMMs of the policy-gradient steps"), cpu,
-                 {"gradient_steps_per_update": k, "final_loss": float(losses[-1])})
+                 roof, cpu, {"gradient_steps_per_update": k, "final_loss": float(losses[-1]),
+                             "path": "fused step kernel" if eng.fused_supported() else "per-layer GEMMs"})
 
 
 def run_drqn(steps, warmup, with_cpu, slots=20000):

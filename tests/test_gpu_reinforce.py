@@ -55,10 +55,16 @@ def test_gradient_and_step_vs_oracle(obs_dim, act_dim, B, clip):
     np.testing.assert_allclose(torch_order(eng.actor, obs_dim, act_dim), after, rtol=1e-4, atol=0.02 * cfg.lr)
 
 
+@pytest.mark.parametrize("path", ["fused_step_kernel", "per_layer_gemms"])
 @pytest.mark.parametrize("tag", ["std", "plain"])
-def test_update_matches_reference_fixture(tag):
+def test_update_matches_reference_fixture(tag, path, monkeypatch):
+    """Both routes of ReinforceEngine.update: the minibatch loop on the fused actor-critic step kernel of ts_ppo.hip (A2C's
+    actor loss with adv := returns, a zero critic beside it) and the per-layer GEMM path (TS_REINFORCE_GEMM=1)."""
+    if path == "per_layer_gemms":
+        monkeypatch.setenv("TS_REINFORCE_GEMM", "1")
     g, d, cfg, params = load_reinforce(tag)
     eng = make_engine(params, d["obs_dim"], d["act_dim"], cfg)
+    assert eng.fused_supported() == (path == "fused_step_kernel" and d["obs_dim"] <= 31 and d["act_dim"] <= 8)
     st = OP.PPOState(params={k: v.clone() for k, v in params.items()})
     for u in range(d["n_updates"]):
         idx, unfinished = g[f"u{u}_indices"], g[f"u{u}_unfinished"]
@@ -79,6 +85,10 @@ def test_update_matches_reference_fixture(tag):
         np.testing.assert_allclose(got, g[f"u{u}_actor"], rtol=1e-4, atol=0.02 * cfg.lr * steps_so_far)
         oracle_flat = torch.cat([st.params[k].reshape(-1) for k in OR.ACTOR_KEYS]).numpy()
         np.testing.assert_allclose(got, oracle_flat, rtol=1e-4, atol=0.02 * cfg.lr * steps_so_far)
+    if eng.fused_supported():           # the critic half of the fused engine never moves
+        fe = eng._fused[0]
+        n_actor = int(eng._fused[2].numel())
+        assert float(fe.params[n_actor:].abs().max()) == 0.0 and float(fe.adam_v[n_actor:].abs().max()) == 0.0
 
 
 def test_host_tensor_is_refused():

@@ -6,13 +6,15 @@ The actor uses the flat layout of ts_npg_layout (tianshou_amd.npg.actor_flat_fro
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 
 import numpy as np
 import torch
 
 from . import _lib
-from .npg import layout
+from . import ppo as _ppo
+from .npg import actor_flat_from_torch, layout
 from .ppo_cnn import run_minibatches
 from .returns import _i64_dev, gae_scan
 
@@ -44,6 +46,7 @@ class ReinforceEngine:
         self.ret_rms = [0.0, 1.0, 0.0]
         self._grad = torch.empty_like(self.actor)
         self._ws = _lib.default_workspace(self.device.index or 0)
+        self._fused = None               # (PPOEngine, positions in the actor vector, indices in its parameter vector)
 
     def _f32(self, x, shape=None) -> torch.Tensor:
         t = torch.as_tensor(x, device=self.device).to(torch.float32).contiguous()
@@ -101,11 +104,54 @@ class ReinforceEngine:
         self.apply_gradient()
         return loss
 
+    # -- the whole minibatch loop on the fused actor-critic step kernel ------------------------------------------------------
+    def fused_supported(self) -> bool:
+        """Net[64, 64], obs_dim <= 31, act_dim <= 8: the shapes of ts_ppo.hip's step kernel (TS_REINFORCE_GEMM=1 keeps the
+        per-layer GEMM path; read per call)."""
+        return (self.hidden == _ppo.HIDDEN and self.obs_dim <= 31 and self.act_dim <= 8
+                and not os.environ.get("TS_REINFORCE_GEMM"))
+
+    def _fused_engine(self):
+        """Reinforce's loss -(log_prob * returns).mean() (reinforce.py:371-380) is A2C's actor loss (a2c.py:266-267) with
+        adv := returns, vf_coef = ent_coef = 0 and no advantage normalisation: the fused step kernel (ts_ppo.hip, algo a2c)
+        computes it, its gradient, the global-norm clip and Adam in three launches per minibatch instead of ~30 per-layer
+        ones.  The critic half of that engine is a block of zeros whose gradient is exactly zero (vf_coef = 0), so its Adam
+        moments and parameters stay zero.  The actor and its moments are copied between the two flat layouts around every
+        update (one indexed copy each: `pos` / `idx` come from running the layout converter on an index vector)."""
+        if self._fused is None:
+            cfg = self.cfg
+            pc = _ppo.PPOConfig(algo="a2c", vf_coef=0.0, ent_coef=0.0, advantage_normalization=False,
+                                max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps)
+            eng = _ppo.PPOEngine(self.obs_dim, self.act_dim,
+                                 torch.zeros(_ppo.param_count(self.obs_dim, self.act_dim), device=self.device), pc)
+            shapes, off, t = _ppo.param_shapes(self.obs_dim, self.act_dim), 0, []
+            for k in _ppo.PARAM_ORDER[:7]:                       # the actor's seven tensors, numbered 1 .. in flat order
+                n = int(np.prod(shapes[k]))
+                t.append((torch.arange(off, off + n, dtype=torch.float32) + 1.0).reshape(shapes[k]))
+                off += n
+            marks = actor_flat_from_torch(t, self.obs_dim, self.hidden, self.act_dim, device="cpu")
+            pos = torch.nonzero(marks > 0).reshape(-1)
+            idx = (marks[pos] - 1.0).long()
+            self._fused = (eng, pos.to(self.device), idx.to(self.device))
+        return self._fused
+
     # -- Reinforce._update_with_batch ------------------------------------------------------------------------------------
     def update(self, obs, act, returns, batch_size: int | None, repeat: int, perms=None):
         """-> (losses float32[steps, 1], steps)."""
         obs = self._f32(obs).reshape(-1, self.obs_dim)
         n = obs.shape[0]
         act, returns = self._f32(act, (n, self.act_dim)), self._f32(returns, (n,))
+        if self.fused_supported():
+            eng, pos, idx = self._fused_engine()
+            for src, dst in ((self.actor, eng.params), (self.adam_m, eng.adam_m), (self.adam_v, eng.adam_v)):
+                dst[idx] = src[pos]
+            eng.adam_step, eng.cfg.lr = self.adam_step, self.cfg.lr
+            zeros = torch.zeros(n, dtype=torch.float32, device=self.device)
+            b = {"obs": obs, "act": act, "adv": returns, "returns": zeros, "logp_old": zeros, "v_s": zeros}
+            losses, steps = eng.update(b, batch_size, repeat, perms)[:2]
+            for dst, src in ((self.actor, eng.params), (self.adam_m, eng.adam_m), (self.adam_v, eng.adam_v)):
+                dst[pos] = src[idx]
+            self.adam_step = eng.adam_step
+            return losses[:, :1].contiguous(), steps
         return run_minibatches(self.device, n, batch_size, repeat, perms,
                                lambda rows: self.step(obs[rows], act[rows], returns[rows]))
