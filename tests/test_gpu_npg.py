@@ -129,10 +129,15 @@ def test_critic_step_vs_oracle():
             np.testing.assert_allclose(t.cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.02 * cfg.lr, err_msg=k)
 
 
+@pytest.mark.parametrize("critic_path", ["fused_step_kernel", "per_layer_gemms"])
 @pytest.mark.parametrize("tag", ["npg", "trpo"])
-def test_update_matches_reference_golden(tag):
+def test_update_matches_reference_golden(tag, critic_path, monkeypatch):
+    """(both routes of the critic iterations: A2C steps with a zero advantage on the fused step kernel of ts_ppo.hip, and
+    ts_npg_critic_step -- TS_NPG_CRITIC_GEMM=1)"""
     from tianshou_amd import npg as NG
 
+    if critic_path == "per_layer_gemms":
+        monkeypatch.setenv("TS_NPG_CRITIC_GEMM", "1")
     g, d, cfg = load_npg(tag)
     p0 = OP.unflatten_params(torch.as_tensor(g["flat_params0"]), d["obs_dim"], d["act_dim"])
     eng = make_engine(p0, d["obs_dim"], d["act_dim"], cfg)
@@ -151,6 +156,10 @@ def test_update_matches_reference_golden(tag):
     flat = torch.cat([t.reshape(-1) for t in a + c]).cpu().numpy()            # = oracle_ppo.PARAM_ORDER
     step = np.abs(g["flat_params"] - g["flat_params0"]).max()
     assert np.abs(flat - g["flat_params"]).max() < 5e-3 * step
+    assert eng.critic_fused_supported() == (critic_path == "fused_step_kernel" and d["obs_dim"] <= 31 and d["act_dim"] <= 8)
+    if eng._fused is not None:          # the zero actor beside the critic never moves
+        n_actor = eng._fused[0].P - int(eng._fused[2].numel())
+        assert float(eng._fused[0].params[:n_actor].abs().max()) == 0.0 and float(eng._fused[0].adam_v[:n_actor].abs().max()) == 0.0
 
 
 def test_bad_arguments_fail_loudly():
