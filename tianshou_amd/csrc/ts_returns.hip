@@ -551,46 +551,61 @@ __global__ void nstep_indices_kernel(const int64_t* indices, int64_t I, int64_t 
 
 constexpr int NSTEP_MAX = 32;
 
-__global__ void nstep_fused_kernel(const int64_t* indices, int64_t I, int64_t N,
+// One thread walks one index (rewards, end flags, value mask, gamma^n_eff, reward sum); the A columns of the block's SB
+// indices are then written by all 128 threads together, consecutive threads on consecutive columns.  SB (<= 128, chosen by
+// the host: fewer indices per block the more columns there are) keeps the column work spread over the chip: with one thread
+// per index looping over its columns, QRDQN's 200 quantile columns were 200 strided stores per thread of four workgroups
+// (55 us per update).
+__global__ __launch_bounds__(128) void nstep_fused_kernel(const int64_t* indices, int64_t I, int64_t N,
                                    const int64_t* offset, int64_t E, const uint8_t* done,
                                    const uint8_t* terminated, const int64_t* last_index,
                                    const int64_t* lengths, const double* rew, const float* tq,
-                                   int64_t A, double gamma, float* out, double* out64) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < I; i += stride) {
-        // forward walk: reward and end flag of each of the N stacked transitions.
-        // indices[i] itself is used un-wrapped as in the reference (stacked_indices_NI[0] = indices).
-        double r[NSTEP_MAX];
-        bool e[NSTEP_MAX];
-        int64_t cur = indices[i];
-        for (int n = 0; n < (int)N; ++n) {
-            bool is_end;
-            const int64_t nxt = next_one(cur, offset, E, done, last_index, lengths, &is_end);
-            r[n] = rew[cur];
-            e[n] = is_end;
-            if (n + 1 < (int)N) cur = nxt;
-        }
-        const double mask = terminated[cur] ? 0.0 : 1.0;  // value_mask(idx_after_n), :798
-        double mc = 0.0;
-        int64_t gammas = N;
-        for (int n = (int)N - 1; n >= 0; --n) {
-            if (e[n]) {
-                gammas = n + 1;
-                mc = 0.0;
+                                   int64_t A, double gamma, float* out, double* out64, int SB) {
+    __shared__ float s_mask[128];
+    __shared__ double s_gpow[128], s_mc[128];
+    for (int64_t base = (int64_t)blockIdx.x * SB; base < I; base += (int64_t)gridDim.x * SB) {
+        const int64_t i = base + threadIdx.x;
+        if ((int)threadIdx.x < SB && i < I) {
+            // forward walk: reward and end flag of each of the N stacked transitions.
+            // indices[i] itself is used un-wrapped as in the reference (stacked_indices_NI[0] = indices).
+            double r[NSTEP_MAX];
+            bool e[NSTEP_MAX];
+            int64_t cur = indices[i];
+            for (int n = 0; n < (int)N; ++n) {
+                bool is_end;
+                const int64_t nxt = next_one(cur, offset, E, done, last_index, lengths, &is_end);
+                r[n] = rew[cur];
+                e[n] = is_end;
+                if (n + 1 < (int)N) cur = nxt;
             }
-            const double tmp = gamma * mc;
-            mc = r[n] + tmp;
+            double mc = 0.0;
+            int64_t gammas = N;
+            for (int n = (int)N - 1; n >= 0; --n) {
+                if (e[n]) {
+                    gammas = n + 1;
+                    mc = 0.0;
+                }
+                const double tmp = gamma * mc;
+                mc = r[n] + tmp;
+            }
+            double gpow = 1.0;
+            for (int64_t k = 0; k < gammas; ++k) gpow = gpow * gamma;
+            s_mask[threadIdx.x] = terminated[cur] ? 0.f : 1.f;  // value_mask(idx_after_n), :798
+            s_gpow[threadIdx.x] = gpow;
+            s_mc[threadIdx.x] = mc;
         }
-        double gpow = 1.0;
-        for (int64_t k = 0; k < gammas; ++k) gpow = gpow * gamma;
-        for (int64_t a = 0; a < A; ++a) {
+        __syncthreads();
+        const int64_t rows = (I - base) < SB ? (I - base) : SB;
+        for (int64_t el = threadIdx.x; el < rows * A; el += 128) {
+            const int64_t sr = el / A;
             // target_q_IA *= mask happens in float32 in the reference (f32 array * bool)
-            const float tqm = tq[i * A + a] * (float)mask;
-            const double q = (double)tqm * gpow;
-            const double v = q + mc;
-            out[i * A + a] = (float)v;
-            if (out64) out64[i * A + a] = v;
+            const float tqm = tq[base * A + el] * s_mask[sr];
+            const double q = (double)tqm * s_gpow[sr];
+            const double v = q + s_mc[sr];
+            out[base * A + el] = (float)v;
+            if (out64) out64[base * A + el] = v;
         }
+        __syncthreads();
     }
 }
 
@@ -824,9 +839,10 @@ int ts_nstep_return_fused(const int64_t* indices, int64_t I, int64_t n_step,
     TS_REQUIRE(indices && offset && done && terminated && last_index && lengths && rew_B &&
                    target_q_IA && out,
                TS_ERR_INVALID_ARG, "ts_nstep_return_fused: NULL array argument");
-    hipLaunchKernelGGL(nstep_fused_kernel, dim3(grid_for(I, 128)), dim3(128), 0,
+    const int sb = A >= 64 ? 4 : (A >= 8 ? 16 : 128);          // indices per workgroup: ~1,000 output elements each
+    hipLaunchKernelGGL(nstep_fused_kernel, dim3(grid_for(I, sb)), dim3(128), 0,
                        ts::as_stream(stream), indices, I, n_step, offset, E, done, terminated,
-                       last_index, lengths, rew_B, target_q_IA, A, gamma, out, out64);
+                       last_index, lengths, rew_B, target_q_IA, A, gamma, out, out64, sb);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

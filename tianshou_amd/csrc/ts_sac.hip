@@ -635,11 +635,24 @@ struct DsacLossArgs { const float* q[2]; float* td[2]; float* d_out[2]; float* l
 __global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(DsacLossArgs la, const int64_t* __restrict__ act,
                                                                 const float* __restrict__ ret, const float* __restrict__ weight,
                                                                 int64_t B, int hw) {      // blockIdx.x = critic
+    // grid (critics, 1 + ceil(B hw / 1024)): row 0 sums the loss and writes td (the order of one 1,024-thread workgroup),
+    // rows 1.. write d_out, one element per thread -- as one workgroup per critic whose threads each wrote whole 128-byte rows
+    // this was a 43 us launch
     __shared__ float red[1024];
     const float* __restrict__ q = la.q[blockIdx.x];
     float* __restrict__ td = la.td[blockIdx.x];
     float* __restrict__ d_out = la.d_out[blockIdx.x];
     const float inv_b = 1.f / (float)B;
+    if (blockIdx.y > 0) {
+        const int64_t el = (int64_t)(blockIdx.y - 1) * 1024 + threadIdx.x;
+        if (el >= B * hw) return;
+        const int64_t b = el / hw;
+        const int j = (int)(el - b * hw), a = (int)act[b];
+        const float t = q[b * hw + a] - ret[b];
+        const float w = weight ? weight[b] : 1.f;
+        d_out[el] = j == a ? 2.f * t * w * inv_b : 0.f;
+        return;
+    }
     float ls = 0.f;
     for (int64_t b = threadIdx.x; b < B; b += 1024) {
         const int a = (int)act[b];
@@ -647,10 +660,68 @@ __global__ __launch_bounds__(1024) void dsac_critic_loss_kernel(DsacLossArgs la,
         const float w = weight ? weight[b] : 1.f;
         td[b] = t;
         ls += t * t * w;
-        for (int j = 0; j < hw; ++j) d_out[b * hw + j] = j == a ? 2.f * t * w * inv_b : 0.f;
     }
     const float tot = block_sum_1024(ls, red);
     if (threadIdx.x == 0) *la.loss[blockIdx.x] = tot * inv_b;
+}
+
+// ---- the same two per-sample kernels with 32 lanes per sample (hw = 32: lane j = column j, two samples per wave): coalesced
+// rows, the row reductions as five-step shuffles inside the half wave.  One thread per sample walked its 128-byte row alone
+// (29 us for the actor step, 13 us for the target at B = 4096).
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 32));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    return v;
+}
+struct RowSoftmax { float lp, p, sq, plogp; };
+__device__ __forceinline__ RowSoftmax row_softmax32(const float* __restrict__ logits, const float* __restrict__ q1,
+                                                    const float* __restrict__ q2, int64_t b, int j, int A) {
+    const bool live = j < A;
+    const float l = live ? logits[b * 32 + j] : -3.0e38f;
+    const float m = half_max(l);
+    const float lse = m + logf(half_sum(live ? expf(l - m) : 0.f));
+    RowSoftmax r;
+    r.lp = live ? l - lse : 0.f;
+    r.p = live ? expf(r.lp) : 0.f;
+    const float qm = live ? fminf(q1[b * 32 + j], q2[b * 32 + j]) : 0.f;
+    r.sq = half_sum(r.p * qm);
+    r.plogp = half_sum(r.lp * r.p);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void dsac_target32_kernel(const float* __restrict__ logits, const float* __restrict__ q1,
+                                                            const float* __restrict__ q2, const float* __restrict__ log_alpha,
+                                                            float fixed_alpha, int64_t B, int A, float* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t b = g >> 5 < B ? g >> 5 : B - 1;
+    const int j = (int)(g & 31);
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const RowSoftmax r = row_softmax32(logits, q1, q2, b, j, A);
+    if (j == 0 && (g >> 5) < B) out[b] = r.sq + alpha * -r.plogp;
+}
+
+__global__ __launch_bounds__(256) void dsac_actor32_kernel(const float* __restrict__ logits, const float* __restrict__ q1,
+                                                           const float* __restrict__ q2, const float* __restrict__ log_alpha,
+                                                           float fixed_alpha, int64_t B, int A, float* __restrict__ d_head,
+                                                           float* __restrict__ neg_ent, float* __restrict__ f_out) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = (g >> 5) < B;
+    const int64_t b = in ? g >> 5 : B - 1;
+    const int j = (int)(g & 31);
+    const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
+    const float inv_b = 1.f / (float)B;
+    const RowSoftmax r = row_softmax32(logits, q1, q2, b, j, A);
+    const float H = -r.plogp;
+    if (!in) return;
+    float d = 0.f;
+    if (j < A) d = -inv_b * (r.p * (fminf(q1[b * 32 + j], q2[b * 32 + j]) - r.sq) - alpha * r.p * (r.lp + H));
+    d_head[b * 32 + j] = d;
+    if (j == 0) { neg_ent[b] = -H; f_out[b] = alpha * H + r.sq; }
 }
 
 // actor step (discrete_sac.py:176-184): f_b = alpha H_b + sum_a p_a q_a, q = min(Q1, Q2) (no grad); loss = -mean f.
@@ -1486,8 +1557,12 @@ int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_
         if (int rc = mlp_forward(s, ws, m, critic1_old, x, a1, split)) return rc;
         if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
-    hipLaunchKernelGGL(dsac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, a1.out, a2.out,
-                       log_alpha, (float)fixed_alpha, B, d.act, d.hw, out);
+    if (d.hw == 32)
+        hipLaunchKernelGGL(dsac_target32_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, a1.out, a2.out,
+                           log_alpha, (float)fixed_alpha, B, d.act, out);
+    else
+        hipLaunchKernelGGL(dsac_target_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, a1.out, a2.out,
+                           log_alpha, (float)fixed_alpha, B, d.act, d.hw, out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -1543,7 +1618,8 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
             la.q[k] = acts[k0 + k].out; la.td[k] = tds[k0 + k]; la.d_out[k] = dheads[k0 + k];
             la.loss[k] = stats_out5 + 1 + k0 + k;
         }
-        hipLaunchKernelGGL(dsac_critic_loss_kernel, dim3((unsigned)nk), dim3(1024), 0, sk, la, act, returns, weight, B, d.hw);
+        hipLaunchKernelGGL(dsac_critic_loss_kernel, dim3((unsigned)nk, 1 + (unsigned)ts::ceil_div(B * d.hw, 1024)), dim3(1024), 0, sk, la,
+                           act, returns, weight, B, d.hw);
     };
     if (one_stream) {
         // both critics per launch: forward, loss, input-gradient chains, the six weight-gradient GEMMs, Adam (which also
@@ -1587,8 +1663,12 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
         if (int rc = mlp_forward(s, ws, m, st->actor, x, aa, splits[0])) return rc;
         if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
     }
-    hipLaunchKernelGGL(dsac_actor_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, acts[0].out,
-                       acts[1].out, log_alpha, (float)hp->alpha, B, d.act, d.hw, dheads[2], neg_ent, fval);
+    if (d.hw == 32)
+        hipLaunchKernelGGL(dsac_actor32_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, acts[0].out,
+                           acts[1].out, log_alpha, (float)hp->alpha, B, d.act, dheads[2], neg_ent, fval);
+    else
+        hipLaunchKernelGGL(dsac_actor_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.out, acts[0].out,
+                           acts[1].out, log_alpha, (float)hp->alpha, B, d.act, d.hw, dheads[2], neg_ent, fval);
     hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, fval, B, stats_out5);
     TS_LAUNCH_CHECK();
     float* ga = g_out[2] ? g_out[2] : gbuf[0];

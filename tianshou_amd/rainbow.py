@@ -143,9 +143,19 @@ class RainbowEngine:
 
     def set_noise(self, noise: torch.Tensor, noise_old: torch.Tensor | None = None) -> None:
         """The result of RainbowDQN._sample_noise on the online (and the lagged) network (rainbow.py:97-100)."""
-        self.noise.copy_(noise.to(self.device))
+        self.noise = self._own(noise, self.noise)
         if noise_old is not None and self.noise_old is not None:
-            self.noise_old.copy_(noise_old.to(self.device))
+            self.noise_old = self._own(noise_old, self.noise_old)
+
+    def _own(self, new: torch.Tensor, cur: torch.Tensor) -> torch.Tensor:
+        """A float32 device vector of the right length is KEPT (the engine only reads it; the caller draws a fresh one per
+        update) -- a 6 MB device-to-device copy through the runtime's blit kernel took 45 us, twice per update; anything
+        else is converted into the engine's own buffer."""
+        if (isinstance(new, torch.Tensor) and new.is_cuda and new.device == cur.device and new.dtype == torch.float32
+                and new.is_contiguous() and new.numel() == cur.numel()):
+            return new.reshape(cur.shape)
+        cur.copy_(torch.as_tensor(new).to(self.device).reshape(cur.shape))
+        return cur
 
     def forward(self, obs_nhwc: torch.Tensor, training: bool = True, want_dist: bool = True):
         """-> (probabilities float32[B, A, N] or None, q float32[B, A], act int64[B]); training=False: eval-mode layers."""
