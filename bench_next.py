@@ -77,6 +77,7 @@ def _tick() -> int:
 
 
 _HOST_MS = [None]
+DISTQ_REPLAY_STREAM = not os.environ.get("TS_DISTQ_NO_REPLAY_STREAM")   # A/B switch (QRDQN / C51 / Rainbow), as bench_dqn's
 _LAST_PROF: dict = {}
 
 
@@ -314,14 +315,27 @@ def run_distq(steps, warmup, with_cpu, kind, slots=1 << 20):
     eng = Q.DistQEngine(C, H, W, A, Q.flat_from_torch(list(p.values()), C, H, W, A, N), cfg)
     gen = torch.Generator(device="cuda").manual_seed(1)
 
+    draw = lambda: torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws  # noqa: E731
+    # priority update + the next batch (draws, sum-tree descent, both gathers, C51's support returns) beside the backward pass
+    replay = (D.ReplayStream(eng, buf, frames, per, C, draw, lambda i: act[i], prepare=Q.replay_prepare(eng, buf, frames, C))
+              if DISTQ_REPLAY_STREAM else None)
+
     def update():
-        u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
-        idx, wt = per.sample(u)
-        ret = eng.preprocess(buf, frames, idx, C)
-        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
-        obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True) if kind == "c51" else None
-        loss, prio = eng.update_with_batch(obs, act[idx], ret, wt, obs_next_nhwc=obs_next)
-        per.update_weight(idx, prio)
+        if replay is None:
+            idx, wt = per.sample(draw())
+            ret = eng.preprocess(buf, frames, idx, C)
+            obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
+            obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True) if kind == "c51" else None
+            a = act[idx]
+        else:
+            idx, wt, a, obs, obs_next, ret = replay.take()
+            if kind == "qr":
+                ret, obs_next = eng.returns_from_obs_next(buf, idx, obs_next), None
+        loss, prio = eng.update_with_batch(obs, a, ret, wt, obs_next_nhwc=obs_next)
+        if replay is None:
+            per.update_weight(idx, prio)
+        else:
+            replay.give(idx, prio)
         return loss
 
     dt, loss, prof = _time(update, steps, warmup)
@@ -380,15 +394,29 @@ def run_rainbow(steps, warmup, with_cpu, slots=1 << 20):
         x = torch.randn(nn, generator=gen, device="cuda")
         return x.sign() * x.abs().sqrt()
 
+    base = Q.replay_prepare(eng, buf, frames, C)
+    # the two noise draws of an update (rainbow.py:97-100) need no network either: they join the batch on the replay stream
+    replay = (D.ReplayStream(eng, buf, frames, per, C, lambda: torch.rand(B, generator=gen, device="cuda", dtype=torch.float64),
+                             lambda i: act[i], prepare=lambda i: base(i) + (draw(), draw()))
+              if DISTQ_REPLAY_STREAM else None)
+
     def update():
-        u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
-        idx, wt = per.sample(u)
-        ret = eng.preprocess(buf, idx)
-        eng.set_noise(draw(), draw())
-        obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
-        obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True)
-        loss, prio = eng.update_with_batch(obs, act[idx], ret, obs_next, wt)
-        per.update_weight(idx, prio)
+        if replay is None:
+            u = torch.rand(B, generator=gen, device="cuda", dtype=torch.float64)
+            idx, wt = per.sample(u)
+            ret = eng.preprocess(buf, idx)
+            eng.set_noise(draw(), draw())
+            obs = D.gather_obs_nhwc(frames, buf, idx, C, as_u8=True)
+            obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), C, as_u8=True)
+            a = act[idx]
+        else:
+            idx, wt, a, obs, obs_next, ret, n1, n2 = replay.take()
+            eng.set_noise(n1, n2)
+        loss, prio = eng.update_with_batch(obs, a, ret, obs_next, wt)
+        if replay is None:
+            per.update_weight(idx, prio)
+        else:
+            replay.give(idx, prio)
         return loss
 
     dt, loss, prof = _time(update, steps, warmup)

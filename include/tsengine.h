@@ -498,8 +498,9 @@ int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* 
                          const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, void* cache,
                          float* td_out, float* loss_out, float* grad_out, ts_stream_t stream);
 
-/* Makes `stream` wait until the TD errors (td_out) and the loss of the most recent ts_dqn_update / ts_dqn_update_cached call
- * on `ws` are written -- not for the rest of that update.  PrioritizedReplayBuffer.update_weight (prio.py:89-100,
+/* Makes `stream` wait until the TD errors (td_out; prio_out of the distributional engines) and the loss of the most recent
+ * ts_dqn_update / ts_dqn_update_cached / ts_distq_update / ts_rainbow_update call on `ws` are written -- not for the rest
+ * of that update.  PrioritizedReplayBuffer.update_weight (prio.py:89-100,
  * _postprocess_batch algorithm_base.py:562-581) and the sampling / gathering of the next batch need nothing else from the
  * update: issued on another stream behind this wait they run beside its backward pass and optimizer step. */
 int ts_dqn_wait_td(ts_workspace* ws, ts_stream_t stream);

@@ -157,3 +157,61 @@ def test_argument_errors():
         eng.forward(torch.zeros((5, 36, 44, 2), dtype=torch.uint8, device="cuda"))
     with pytest.raises(RuntimeError):
         Q.DistQEngine(2, 44, 36, 3, torch.zeros(eng.P), Q.DistQConfig(kind="c51", n_atoms=11))
+
+
+@pytest.mark.parametrize("kind,N", [("qr", 40), ("c51", 51)])
+def test_replay_stream_cycle_equals_the_sequential_cycle(kind, N):
+    """dqn.ReplayStream with distq.replay_prepare (priority update, next batch's draws, sum-tree descent, pair gather and --
+    C51 -- the support's n-step returns on a second stream behind ts_dqn_wait_td) against the reference order sample ->
+    preprocess -> update -> update_weight on one stream: six updates on a 4096-slot prioritized frame buffer, identical
+    indices, weights, returns, losses, priorities, parameters and sum tree."""
+    import bench_dqn as BD
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    def cycle(use_stream: bool):
+        frames, act, buf, per = BD.build(4096, 4, seed=3)
+        _, eng = _engine(kind, 4, 84, 84, 6, N, seed=2, gamma=0.99, n_step=3, target_update_freq=2, lr=1e-4)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        draw = lambda: torch.rand(64, generator=gen, device="cuda", dtype=torch.float64)  # noqa: E731
+        rs = (D.ReplayStream(eng, buf, frames, per, 4, draw, lambda i: act[i], prepare=Q.replay_prepare(eng, buf, frames, 4))
+              if use_stream else None)
+        log = []
+        for _ in range(6):
+            if rs is None:
+                idx, wt = per.sample(draw())
+                ret = eng.preprocess(buf, frames, idx, 4)
+                obs = D.gather_obs_nhwc(frames, buf, idx, 4, as_u8=True)
+                obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), 4, as_u8=True) if kind == "c51" else None
+                a = act[idx]
+            else:
+                idx, wt, a, obs, obs_next, ret = rs.take()
+                if kind == "qr":
+                    ret, obs_next = eng.returns_from_obs_next(buf, idx, obs_next), None
+            loss, prio = eng.update_with_batch(obs, a, ret, wt, obs_next_nhwc=obs_next)
+            if rs is None:
+                per.update_weight(idx, prio)
+            else:
+                rs.give(idx, prio)
+            log.append((idx.clone(), wt.float(), ret.clone(), loss.clone(), prio.clone()))
+        torch.cuda.synchronize()
+        return log, eng.params.clone(), per.weight._value.clone(), per.prio_minmax.clone()
+
+    a, b = cycle(False), cycle(True)
+    for it, (x, y) in enumerate(zip(a[0], b[0])):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), it
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    # layouts outside the pair kernel (16-byte frame rows, stack 4): replay_prepare falls back to the index kernels + gathers
+    frames, act, buf, per = BD.build(4096, 4, seed=3)
+    _, eng = _engine(kind, 4, 84, 84, 6, N, seed=2, gamma=0.99, n_step=3)
+    idx = torch.arange(100, 164, device="cuda")
+    import os
+    os.environ["TS_DQN_NO_PAIR"] = "1"
+    try:
+        slow = Q.replay_prepare(eng, buf, frames, 4)(idx)
+    finally:
+        del os.environ["TS_DQN_NO_PAIR"]
+    fast = Q.replay_prepare(eng, buf, frames, 4)(idx)
+    assert torch.equal(slow[0], fast[0]) and torch.equal(slow[1], fast[1])
+    assert (slow[2] is None and fast[2] is None) or torch.equal(slow[2], fast[2])

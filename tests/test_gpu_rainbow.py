@@ -143,3 +143,53 @@ def test_argument_errors():
         RB.RainbowEngine(2, 44, 36, 3, eng.params.cpu(), eng.noise.cpu(), eng.cfg)
     with pytest.raises(ValueError):
         RB.RainbowEngine(2, 44, 36, 3, eng.params[:-1], eng.noise, eng.cfg)
+
+
+def test_replay_stream_cycle_equals_the_sequential_cycle():
+    """Rainbow's update with its backward pass spread over the workspace's streams, in a dqn.ReplayStream cycle (priority
+    update, next batch, support returns and both noise draws on the replay stream) against the sequential order on one
+    stream: five updates, identical indices, returns, losses, priorities, parameters and sum tree."""
+    import bench_dqn as BD
+    from tianshou_amd import distq as Q
+    from tianshou_amd import dqn as D
+
+    def cycle(use_stream: bool):
+        frames, act, buf, per = BD.build(4096, 4, seed=3)
+        _, _, eng = make_engine(4, 84, 84, 6, 51, seed=2, gamma=0.99, n_step=3, target_update_freq=2, lr=1e-4)
+        gen = torch.Generator(device="cuda").manual_seed(11)
+        nn = eng.lay["noise_count"]
+
+        def noise():
+            x = torch.randn(nn, generator=gen, device="cuda")
+            return x.sign() * x.abs().sqrt()
+
+        draw = lambda: torch.rand(64, generator=gen, device="cuda", dtype=torch.float64)  # noqa: E731
+        base = Q.replay_prepare(eng, buf, frames, 4)
+        rs = (D.ReplayStream(eng, buf, frames, per, 4, draw, lambda i: act[i], prepare=lambda i: base(i) + (noise(), noise()))
+              if use_stream else None)
+        log = []
+        for _ in range(5):
+            if rs is None:
+                idx, wt = per.sample(draw())
+                ret = eng.preprocess(buf, idx)
+                eng.set_noise(noise(), noise())
+                obs = D.gather_obs_nhwc(frames, buf, idx, 4, as_u8=True)
+                obs_next = D.gather_obs_nhwc(frames, buf, buf.next(idx), 4, as_u8=True)
+                a = act[idx]
+            else:
+                idx, wt, a, obs, obs_next, ret, n1, n2 = rs.take()
+                eng.set_noise(n1, n2)
+            loss, prio = eng.update_with_batch(obs, a, ret, obs_next, wt)
+            if rs is None:
+                per.update_weight(idx, prio)
+            else:
+                rs.give(idx, prio)
+            log.append((idx.clone(), wt.float(), ret.clone(), loss.clone(), prio.clone()))
+        torch.cuda.synchronize()
+        return log, eng.params.clone(), per.weight._value.clone(), per.prio_minmax.clone()
+
+    a, b = cycle(False), cycle(True)
+    for it, (x, y) in enumerate(zip(a[0], b[0])):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), it
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])

@@ -85,8 +85,9 @@ struct ts_workspace {
     hipStream_t side2;           // second side stream (ts::side_streams): created together with `side`
     hipEvent_t side_ev[16];
     int side_ready;
-    // recorded by every ts_dqn_update* call right after its TD-error kernel (ts_dqn_wait_td): the priority update and the
-    // next batch's sampling need nothing else from the update and can run beside its backward pass
+    // recorded by every ts_dqn_update* / ts_distq_update / ts_rainbow_update call right after its TD-error (priority) kernel
+    // (ts::record_td, waited for by ts_dqn_wait_td): the priority update and the next batch's sampling need nothing else
+    // from the update and can run beside its backward pass
     hipEvent_t td_ev;
     int td_ev_ready;
 };
@@ -102,6 +103,7 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
 int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == main while profiling (clean per-kernel times)
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
 int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b);     // both side streams
+int record_td(ts_workspace* ws, hipStream_t s);       // the new priorities / the loss of an update are written on `s`
 
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {

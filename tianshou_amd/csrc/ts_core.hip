@@ -92,6 +92,17 @@ int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot) {
     return TS_OK;
 }
 
+int record_td(ts_workspace* ws, hipStream_t s) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "record_td: workspace is NULL");
+    if (!ws->td_ev_ready) {
+        TS_HIP_CHECK(hipSetDevice(ws->device));
+        TS_HIP_CHECK(hipEventCreateWithFlags(&ws->td_ev, hipEventDisableTiming));
+        ws->td_ev_ready = 1;
+    }
+    TS_HIP_CHECK(hipEventRecord(ws->td_ev, s));
+    return TS_OK;
+}
+
 ProfScope::ProfScope(ts_workspace* w, int kind, hipStream_t s) : ws(w), stream(s), slot(-1) {
     if (!ws || !ws->profiling || ws->ev_n >= ws->ev_cap) return;
     slot = ws->ev_n++;

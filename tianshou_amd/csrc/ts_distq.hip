@@ -519,13 +519,14 @@ int ts_rainbow_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     if (int rc = make_rnet((int)B, (int)c, (int)h, (int)w, (int)n_act, (int)n_atoms, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);
     // workspace: pass | dY buffers | wgrad slabs | effective-weight gradient | flat gradient | per-sample terms | norm
-    size_t slab = 0, geff = 0;
-    for (int i = 0; i < 3; ++i) slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.conv[i]) * n.conv[i].param_elems());
+    // (one slab set per layer and one effective-weight gradient per noisy layer: their weight gradients run side by side)
+    size_t slab_c[3], slab_l[4], geff_l[4], slab_all = 0;
+    for (int i = 0; i < 3; ++i) slab_all += slab_c[i] = al(4 * (size_t)ts::conv_wgrad_splits(n.conv[i]) * n.conv[i].param_elems());
     for (int i = 0; i < 4; ++i) {
-        slab = std::max(slab, 4 * (size_t)ts::conv_wgrad_splits(n.lin[i]) * n.lin[i].param_elems());
-        geff = std::max(geff, 4 * (size_t)n.lin[i].param_elems());
+        slab_all += slab_l[i] = al(4 * (size_t)ts::conv_wgrad_splits(n.lin[i]) * n.lin[i].param_elems());
+        slab_all += geff_l[i] = al(4 * (size_t)n.lin[i].param_elems());
     }
-    size_t bytes = r_acts_bytes(n) + al(slab) + al(geff) + al(4 * (size_t)n.total) + al(4 * (size_t)B) + 4096;
+    size_t bytes = r_acts_bytes(n) + slab_all + al(4 * (size_t)n.total) + al(4 * (size_t)B) + 4096;
     for (int i = 0; i < 3; ++i) bytes += al(4 * (size_t)n.conv[i].out_elems());
     bytes += 2 * al(4 * (size_t)n.lin[0].out_elems()) + al(4 * (size_t)n.lin[1].out_elems()) + al(4 * (size_t)n.lin[3].out_elems()) +
              al(4 * (size_t)n.conv[2].out_elems());
@@ -540,8 +541,10 @@ int ts_rainbow_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     float* dq = take((size_t)n.lin[1].out_elems());
     float* dv = take((size_t)n.lin[3].out_elems());
     float* dfeat2 = take((size_t)n.conv[2].out_elems());
-    float* slabs = reinterpret_cast<float*>(p); p += al(slab);
-    float* g_eff = reinterpret_cast<float*>(p); p += al(geff);
+    float *slabs_c[3], *slabs_l[4], *g_eff[4];
+    for (int i = 0; i < 3; ++i) { slabs_c[i] = reinterpret_cast<float*>(p); p += slab_c[i]; }
+    for (int i = 0; i < 4; ++i) { slabs_l[i] = reinterpret_cast<float*>(p); p += slab_l[i]; }
+    for (int i = 0; i < 4; ++i) { g_eff[i] = reinterpret_cast<float*>(p); p += geff_l[i]; }
     float* grad = take((size_t)n.total);
     float* lw = take((size_t)B);
     float* norm_part = reinterpret_cast<float*>(p);
@@ -552,36 +555,58 @@ int ts_rainbow_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     hipLaunchKernelGGL(c51_loss_kernel, dim3((unsigned)B), dim3(256), 0, s, a.q, act, returns, next_dist, weight, support,
                        (float)hp->v_min, (float)hp->v_max, (float)dz, B, n.n_atoms, n.ldq, dq, prio_out, lw, target_dist_out);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, lw, B, loss_out);
+    TS_LAUNCH_CHECK();
+    if (int rc = ts::record_td(ws, s)) return rc;        // prio_out / loss_out are written: ts_dqn_wait_td
     hipLaunchKernelGGL(dueling_bwd_kernel, dim3((unsigned)ts::ceil_div(B * n.ldv, 256)), dim3(256), 0, s, dq, dv, B, n.n_act,
                        n.n_atoms, n.ldq, n.ldv);
     TS_LAUNCH_CHECK();
-    // the four noisy layers: (input, upstream gradient, input-gradient target, ReLU mask of the input)
+    // The four noisy layers: (input, upstream gradient, input-gradient target, ReLU mask of the input).  The advantage
+    // branch (Q2 -> Q0) sends its input gradients down the caller's stream, the value branch (V2 -> V0) down the workspace's
+    // first side stream (the two streams that own input-gradient scratch); the weight gradients of the advantage branch go
+    // to the second side stream, those of the value branch follow its input gradients.  Same launches on the same
+    // operands as the sequential order: only their placement in time differs.
     const float* xin[4] = {a.c[2], a.hq, a.c[2], a.hv};
     const float* dy[4] = {dhq, dq, dhv, dv};
     float* dxo[4] = {dc[2], dhq, dfeat2, dhv};
-    const int order[4] = {1, 0, 3, 2};               // Q2, Q0, V2, V0
-    for (int oi = 0; oi < 4; ++oi) {
-        const int i = order[oi];
+    hipStream_t sv, sw;
+    if (int rc = ts::side_streams(ws, s, &sv, &sw)) return rc;
+    auto noisy_wgrad = [&](hipStream_t st, int i) -> int {
         const int K = n.lin[i].IC, OC = n.lin[i].OC;
-        if (int rc = ts::conv_wgrad(s, n.lin[i], xin[i], dy[i], slabs, ws)) return rc;
-        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.lin[i]), n.lin[i].param_elems(), g_eff)) return rc;
+        if (int rc = ts::conv_wgrad(st, n.lin[i], xin[i], dy[i], slabs_l[i], ws)) return rc;
+        if (int rc = ts::slab_sum(st, slabs_l[i], ts::conv_wgrad_splits(n.lin[i]), n.lin[i].param_elems(), g_eff[i])) return rc;
         float* g_mu = grad + n.off_lin[i];
-        hipLaunchKernelGGL(noisy_grad_kernel, dim3((unsigned)ts::ceil_div((int64_t)(K + 1) * OC, 256)), dim3(256), 0, s, g_eff,
-                           noise + n.off_noise[2 * i], noise + n.off_noise[2 * i + 1], K, OC, g_mu,
+        hipLaunchKernelGGL(noisy_grad_kernel, dim3((unsigned)ts::ceil_div((int64_t)(K + 1) * OC, 256)), dim3(256), 0, st,
+                           g_eff[i], noise + n.off_noise[2 * i], noise + n.off_noise[2 * i + 1], K, OC, g_mu,
                            g_mu + n.lin[i].param_elems());
         TS_LAUNCH_CHECK();
-        if (int rc = ts::conv_dgrad(s, n.lin[i], dy[i], a.eff[i], xin[i], dxo[i], ws)) return rc;
-    }
+        return TS_OK;
+    };
+    auto noisy_dgrad = [&](hipStream_t st, int i) -> int {
+        return ts::conv_dgrad(st, n.lin[i], dy[i], a.eff[i], xin[i], dxo[i], ws);
+    };
+    if (int rc = ts::stream_wait(ws, s, sv, 11)) return rc;              // dq, dv
+    if (int rc = ts::stream_wait(ws, s, sw, 12)) return rc;
+    if (int rc = noisy_dgrad(sv, 3)) return rc;                          // V2: dv -> dhv
+    if (int rc = noisy_dgrad(sv, 2)) return rc;                          // V0: dhv -> dfeat2
+    if (int rc = noisy_wgrad(sw, 1)) return rc;                          // Q2
+    if (int rc = noisy_dgrad(s, 1)) return rc;                           // Q2: dq -> dhq
+    if (int rc = ts::stream_wait(ws, s, sw, 13)) return rc;              // dhq
+    if (int rc = noisy_wgrad(sw, 0)) return rc;                          // Q0
+    if (int rc = noisy_dgrad(s, 0)) return rc;                           // Q0: dhq -> dc[2]
+    if (int rc = ts::stream_wait(ws, sv, s, 14)) return rc;              // dfeat2 (and dhv)
+    if (int rc = noisy_wgrad(sv, 3)) return rc;                          // V2, V0 behind the value branch's input gradients
+    if (int rc = noisy_wgrad(sv, 2)) return rc;
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)ts::ceil_div(n.conv[2].out_elems(), 256)), dim3(256), 0, s, dc[2], dfeat2,
                        n.conv[2].out_elems());
     TS_LAUNCH_CHECK();
-    for (int i = 2; i >= 0; --i) {
-        const float* x = i == 0 ? static_cast<const float*>(obs_nhwc) : a.c[i - 1];
-        if (int rc = ts::conv_wgrad(s, n.conv[i], x, dc[i], slabs, ws, i == 0 && obs_u8)) return rc;
-        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.conv[i]), n.conv[i].param_elems(), grad + n.off_conv[i]))
-            return rc;
-        if (i > 0)
-            if (int rc = ts::conv_dgrad(s, n.conv[i], dc[i], params + n.off_conv[i], a.c[i - 1], dc[i - 1], ws)) return rc;
+    {   // conv3, conv2, conv1 (ts::chain_backward joins both side streams into the caller's at its end)
+        const float* x[3]; const float* wb[3]; float* g[3];
+        for (int i = 0; i < 3; ++i) {
+            x[i] = i == 0 ? static_cast<const float*>(obs_nhwc) : a.c[i - 1];
+            wb[i] = params + n.off_conv[i];
+            g[i] = grad + n.off_conv[i];
+        }
+        if (int rc = ts::chain_backward(s, ws, 3, n.conv, x, dc, wb, slabs_c, g, obs_u8 != 0)) return rc;
     }
     if (hp->lr < 0.0) return TS_OK;
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
@@ -719,6 +744,7 @@ int ts_distq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_
     }
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, lw, B, loss_out);
     TS_LAUNCH_CHECK();
+    if (int rc = ts::record_td(ws, s)) return rc;        // prio_out / loss_out are written: ts_dqn_wait_td
 
     // head, fc1, conv3, conv2, conv1: input gradients down the caller's stream, the weight gradients beside them on the
     // workspace's side streams (ts::chain_backward, as ts_dqn_update)

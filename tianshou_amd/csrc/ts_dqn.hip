@@ -367,11 +367,7 @@ static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float
                        returns, weight, sc.h[3], params + n.off[4], B, n.n_act, (float)hp->huber_delta, td_out, loss_out,
                        grad + n.off[4], dy[3]);
     TS_LAUNCH_CHECK();
-    if (!ws->td_ev_ready) {
-        TS_HIP_CHECK(hipEventCreateWithFlags(&ws->td_ev, hipEventDisableTiming));
-        ws->td_ev_ready = 1;
-    }
-    TS_HIP_CHECK(hipEventRecord(ws->td_ev, s));          // td_out / loss_out are written: ts_dqn_wait_td
+    if (int rc = ts::record_td(ws, s)) return rc;        // td_out / loss_out are written: ts_dqn_wait_td
     // fc1, conv3, conv2, conv1: input gradients down the caller's stream, the weight gradients beside them on the workspace's
     // side streams (ts::chain_backward)
     {
@@ -399,7 +395,7 @@ int ts_dqn_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
 
 int ts_dqn_wait_td(ts_workspace* ws, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dqn_wait_td: workspace is NULL");
-    TS_REQUIRE(ws->td_ev_ready, TS_ERR_INVALID_ARG, "ts_dqn_wait_td: no ts_dqn_update* call has run on this workspace");
+    TS_REQUIRE(ws->td_ev_ready, TS_ERR_INVALID_ARG, "ts_dqn_wait_td: no update call has run on this workspace");
     TS_HIP_CHECK(hipStreamWaitEvent(ts::as_stream(stream), ws->td_ev, 0));
     return TS_OK;
 }

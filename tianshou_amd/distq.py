@@ -21,11 +21,11 @@ import torch
 
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev
-from .dqn import _u8_flag, gather_obs_nhwc
+from .dqn import _u8_flag, gather_obs_nhwc, gather_obs_pair
 from .dqn import flat_from_torch as flat_from_torch_dqn
 from .dqn import flat_to_torch as flat_to_torch_dqn
 from .lagged import full_parameter_update
-from .returns import compute_nstep_return
+from .returns import compute_nstep_return, nstep_indices, nstep_return_from_target_q
 
 QR, C51 = "qr", "c51"
 _KIND = {QR: 0, C51: 1}          # TS_DISTQ_QR / TS_DISTQ_C51
@@ -170,6 +170,25 @@ class DistQEngine:
 
         return compute_nstep_return(_B(), buffer, indices, tq_fn, self.cfg.gamma, self.cfg.n_step).returns
 
+    def support_returns(self, buffer: DeviceReplayBuffer, indices) -> torch.Tensor:
+        """C51's `preprocess` without the frames: n-step returns of the support need no network (c51.py:120-121)."""
+        if self.cfg.kind != C51:
+            raise ValueError("support_returns: C51 only (QRDQN's target is the lagged net's output)")
+        return self.preprocess(buffer, None, indices, 0)
+
+    def returns_from_obs_next(self, buffer: DeviceReplayBuffer, indices, obs_next_nhwc: torch.Tensor) -> torch.Tensor:
+        """QRDQN's `preprocess` for a caller that already holds the observations `_target_q` reads
+        (buffer[indices_after_n].obs_next, e.g. dqn.gather_obs_pair's second tensor): next_dist + the arithmetic half of
+        compute_nstep_return (algorithm_base.py:793-812) -> float32[I, N]."""
+        if self.cfg.kind != QR:
+            raise ValueError("returns_from_obs_next: QRDQN only")
+        return nstep_return_from_target_q(buffer, indices, self.next_dist(obs_next_nhwc), self.cfg.gamma, self.cfg.n_step)
+
+    def wait_td(self, stream: torch.cuda.Stream) -> None:
+        """`stream` waits for the new priorities and the loss of the last `update_with_batch`, not for its backward pass and
+        Adam step (ts_dqn_wait_td; see dqn.ReplayStream)."""
+        _lib.check(_lib.load().ts_dqn_wait_td(self._ws.handle, C.c_void_p(stream.cuda_stream)))
+
     # -- _update_with_batch ------------------------------------------------------------------------------
     def update_with_batch(self, obs_nhwc, act, returns, weight=None, obs_next_nhwc=None,
                           grad_out: torch.Tensor | None = None, apply: bool = True, want_target: bool = False):
@@ -203,3 +222,23 @@ class DistQEngine:
             _lib.ptr(returns), _lib.ptr(nd), _lib.ptr(weight), _lib.i64(b), C.byref(hp), _lib.ptr(prio), _lib.ptr(loss),
             _lib.ptr(tgt), _lib.ptr(grad_out), _lib.current_stream(self.device)))
         return (loss, prio, tgt) if want_target else (loss, prio)
+
+
+def replay_prepare(eng, buffer: DeviceReplayBuffer, frames: torch.Tensor, stack_num: int):
+    """`prepare` callable of dqn.ReplayStream for DistQEngine / rainbow.RainbowEngine: what the next batch needs from the
+    replay buffer alone -> (obs, obs_next, returns or None), uint8 NHWC observations.
+    C51 / Rainbow: obs_next = batch.obs_next (buffer_base.py:624-626) and the n-step returns of the support (c51.py:120-121).
+    QRDQN: obs_next = the observations `_target_q` reads n steps on (algorithm_base.py:772-791); the returns follow on
+    the caller's stream (`DistQEngine.returns_from_obs_next`: they need both networks)."""
+    c51 = eng.cfg.kind == C51
+    n = 1 if c51 else eng.cfg.n_step
+
+    def prepare(idx):
+        pair = gather_obs_pair(frames, buffer, idx, n, stack_num)
+        if pair is None:                                    # layouts outside the pair kernel: the index kernels + two gathers
+            after = buffer.next(idx) if c51 else buffer.next(nstep_indices(buffer, idx, n))
+            pair = (gather_obs_nhwc(frames, buffer, idx, stack_num, as_u8=True),
+                    gather_obs_nhwc(frames, buffer, after, stack_num, as_u8=True))
+        return pair[0], pair[1], (eng.support_returns(buffer, idx) if c51 else None)
+
+    return prepare

@@ -438,23 +438,38 @@ class ReplayStream:
     pass; the caller's stream picks the finished batch up with an event.  Same operations on the same values in the same
     order as the sequential loop -- only their placement in time differs.
 
-    draw: () -> float64[batch] uniform draws on the device (prio.py:65); act_of: index tensor -> actions."""
+    draw: () -> float64[batch] uniform draws on the device (prio.py:65); act_of: index tensor -> actions.
+    prepare: index tensor -> tuple of (nested tuples of) device tensors or None, everything else of the batch that needs
+    neither network (default: DQN's observation pair and n-step coefficients; distq.replay_prepare for QRDQN / C51 /
+    Rainbow).  `eng` is any engine with `wait_td` (its update records the event behind its priority kernel)."""
 
-    def __init__(self, eng: DQNEngine, buffer: DeviceReplayBuffer, frames: torch.Tensor, per, stack_num: int, draw, act_of):
+    def __init__(self, eng, buffer: DeviceReplayBuffer, frames: torch.Tensor, per, stack_num: int, draw, act_of, prepare=None):
         self.eng, self.buffer, self.frames, self.per, self.stack, self.draw, self.act_of = eng, buffer, frames, per, stack_num, draw, act_of
+        self.prepare = prepare if prepare is not None else self._dqn_prepare
         self.stream = torch.cuda.Stream(device=eng.device)
         self._next = None
         self._ready = None
 
-    def _sample(self):
-        idx, wt = self.per.sample(self.draw())
-        wt = wt.to(torch.float32)               # what update_with_batch converts the importance weights to
+    def _dqn_prepare(self, idx):
         cfg = self.eng.cfg
         pair = gather_obs_pair(self.frames, self.buffer, idx, cfg.n_step, self.stack)
         coef = nstep_coefficients(self.buffer, idx, cfg.gamma, cfg.n_step) if pair is not None else None
-        self._next = (idx, wt, self.act_of(idx), pair, coef)
+        return pair, coef
+
+    def _sample(self):
+        idx, wt = self.per.sample(self.draw())
+        wt = wt.to(torch.float32)               # what update_with_batch converts the importance weights to
+        self._next = (idx, wt, self.act_of(idx)) + tuple(self.prepare(idx))
         self._ready = torch.cuda.Event()
         self._ready.record(self.stream)
+
+    @staticmethod
+    def _tensors(x):
+        if isinstance(x, torch.Tensor):
+            yield x
+        elif isinstance(x, (tuple, list)):
+            for y in x:
+                yield from ReplayStream._tensors(y)
 
     def reset(self) -> None:
         """Drops the batch prepared ahead of time (call it after transitions were added to the buffer: the prepared indices
@@ -462,8 +477,8 @@ class ReplayStream:
         self._next = None
 
     def take(self):
-        """-> (indices, IS weights float32, actions, (obs, obs_next) or None, n-step coefficients or None) of the next batch,
-        ready on the caller's stream."""
+        """-> (indices, IS weights float32, actions, *prepare(indices)) of the next batch, ready on the caller's stream; with
+        the default `prepare`: (..., (obs, obs_next) or None, n-step coefficients or None)."""
         main = torch.cuda.current_stream(self.eng.device)
         if self._next is None:
             self.stream.wait_stream(main)
@@ -471,7 +486,7 @@ class ReplayStream:
                 self._sample()
         main.wait_event(self._ready)
         out, self._next = self._next, None
-        for t in (out[0], out[1], out[2]) + tuple(out[3] or ()) + tuple(out[4] or ()):
+        for t in self._tensors(out):
             t.record_stream(main)
         return out
 

@@ -189,6 +189,13 @@ class RainbowEngine:
         fn = lambda buf, after: self.support.repeat(after.numel(), 1)  # noqa: E731
         return compute_nstep_return(_B(), buffer, indices, fn, self.cfg.gamma, self.cfg.n_step).returns
 
+    support_returns = preprocess          # the name distq.replay_prepare calls (same as DistQEngine.support_returns)
+
+    def wait_td(self, stream: torch.cuda.Stream) -> None:
+        """`stream` waits for the new priorities and the loss of the last `update_with_batch`, not for its backward pass and
+        Adam step (ts_dqn_wait_td; see dqn.ReplayStream)."""
+        _lib.check(_lib.load().ts_dqn_wait_td(self._ws.handle, C.c_void_p(stream.cuda_stream)))
+
     def update_with_batch(self, obs_nhwc, act, returns, obs_next_nhwc, weight=None, grad_out: torch.Tensor | None = None,
                           apply: bool = True, want_target: bool = False):
         """Call set_noise first (rainbow.py:97-100).  -> (loss float32[1], new batch.weight float32[B][, target_dist])."""
