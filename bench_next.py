@@ -661,11 +661,28 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     kw = dict(gamma=0.95, n_step=3, target_update_freq=320, is_double=True, lr=1e-3)
     eng = R.RecurrentDQNEngine(OBS, H, L, A, R.flat_from_torch(list(p.values()), OBS, H, L, A), D.DQNConfig(**kw))
 
+    draw = lambda: buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel  # noqa: E731
+    prefetch = not os.environ.get("TS_DRQN_NO_PREFETCH")
+    # uniform buffer: the next batch (indices, both stacked gathers, actions, n-step coefficients) depends on nothing of the
+    # update and is prepared on a second stream beside it
+    replay = (D.ReplayStream(eng, buf, buf.obs, None, T, draw, None, prepare=R.replay_prepare(eng, buf, buf.obs, T, buf.act))
+              if not os.environ.get("TS_DRQN_NO_REPLAY_STREAM") else None)
+
+    one_call = not os.environ.get("TS_DRQN_NO_LEARN_STEP")      # sample + preprocess + update as ONE library call (default)
+
     def update():
-        idx = buf.sample_indices(B, seed=(0x5A7, _tick()))  # manager.py:216-234; draws inside the sampling kernel
-        # batch.obs first: its forward pass runs on a side stream beside the two s_{t+n} passes of _target_q
-        obs, ret = eng.preprocess_with_obs(buf, buf.obs, idx, T, prefetch=not os.environ.get("TS_DRQN_NO_PREFETCH"))
-        return eng.update_with_batch(obs, buf.act[idx], ret)[0]
+        if one_call:
+            return eng.learn_step(buf, buf.obs, buf.act, B, T, (0x5A7, _tick()))[0]
+        if replay is None:
+            idx = draw()
+            # batch.obs first: its forward pass runs on a side stream beside the two s_{t+n} passes of _target_q
+            obs, ret = eng.preprocess_with_obs(buf, buf.obs, idx, T, prefetch=prefetch)
+            return eng.update_with_batch(obs, buf.act[idx], ret)[0]
+        idx, _, _, pair, coef = replay.take()
+        obs, ret = eng.preprocess_with_obs(buf, buf.obs, idx, T, prefetch=prefetch, pair=pair, coef=coef)
+        loss = eng.update_with_batch(obs, pair[2], ret)[0]
+        replay.give(idx, None)
+        return loss
 
     dt, loss, prof = _time(update, steps, warmup)
     fwd = 2 * (T * OBS * H + L * T * 2 * H * 4 * H + H * A)          # per sample: fc1 per step, W_ih + W_hh per layer and step, fc2

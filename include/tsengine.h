@@ -403,6 +403,17 @@ int ts_dqn_gather_pair(const uint8_t* frames, int64_t n_planes, int64_t plane_el
                        int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,
                        const int64_t* last_index, const int64_t* lengths, uint8_t* obs_out, uint8_t* obs_next_out,
                        ts_stream_t stream);
+/* The same pair for vector observations stored as float32 rows [n_rows, row_elems] with frame stacking (DRQN,
+ * test/discrete/test_drqn.py:79-101): obs_out[b] = rows at prev^(stack_num-1-t)(index[b]), t = 0 .. stack_num-1 (oldest first,
+ * buffer_base.py:586-596); obs_next_out[b] likewise from `rows_next` at indices_after_n = next^(n_step-1)(index[b]) when the
+ * buffer stores obs_next, else (rows_next NULL) from `rows` at next(indices_after_n) (buffer_base.py:624-626,
+ * algorithm_base.py:772-791); both float32 [B, stack_num, row_elems].  act_col / act_out (both or neither): batch.act =
+ * act_col[index].  Bit-identical to ts_nstep_indices + next() + 2 x (ts_stack_indices + ts_gather_rows).
+ * 1 <= stack_num <= 16 (TS_ERR_UNSUPPORTED else). */
+int ts_stacked_rows_pair(const float* rows, const float* rows_next, int64_t n_rows, int64_t row_elems, const int64_t* index,
+                         int64_t B, int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,
+                         const int64_t* last_index, const int64_t* lengths, const int64_t* act_col, float* obs_out,
+                         float* obs_next_out, int64_t* act_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution / linear layers on fp32 MFMA (NHWC activations)
@@ -537,6 +548,48 @@ int ts_rnnq_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v
 int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
                            int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
                            ts_stream_t stream);
+/* ts_rnnq_target_q_fused with the arithmetic half of compute_nstep_return (algorithm_base.py:793-812) folded into its last
+ * kernel, on ts_nstep_coefficients' outputs (as ts_dqn_target_returns): returns_out[b] =
+ * float(double(target_q[b] * ns_mask[b]) * ns_gpow[b] + ns_mc[b]). */
+int ts_rnnq_target_returns(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double,
+                           const float* ns_mask, const double* ns_gpow, const double* ns_mc, float* returns_out,
+                           ts_stream_t stream);
+
+/* A uniform (no priorities) device-resident replay buffer of float32 observation rows, as DeviceReplayBuffer holds the
+ * reference's ReplayBufferManager columns (data/buffer/manager.py:25-60, buffer_base.py:60-110). */
+typedef struct ts_rows_replay {
+    const int64_t* offset;      /* int64[E + 1] sub-buffer offsets                                   */
+    int64_t E;
+    const int64_t* lengths;     /* int64[E]                                                          */
+    const int64_t* last_index;  /* int64[E]                                                          */
+    const uint8_t* done;        /* uint8[slots]                                                      */
+    const uint8_t* terminated;  /* uint8[slots]                                                      */
+    const double* rew;          /* float64[slots]                                                    */
+    const float* obs_rows;      /* float32[slots, obs_dim]                                           */
+    const float* obs_next_rows; /* float32[slots, obs_dim] or NULL (obs_next read at next(index))    */
+    const int64_t* act_col;     /* int64[slots]                                                      */
+    int64_t slots;
+} ts_rows_replay;
+
+/* OffPolicyAlgorithm.update (algorithm_base.py:583-631: buffer.sample -> _preprocess_batch -> _update_with_batch; no
+ * priorities to write back) of DQN on `Recurrent` for such a buffer in ONE call: update number `counter` draws its indices as
+ * ts_sample_indices_seeded(seed, counter), gathers batch.obs / obs_next / act (ts_stacked_rows_pair), computes the n-step
+ * returns (ts_nstep_coefficients + ts_rnnq_target_returns) and runs ts_rnnq_update_cached on a forward pass started beside
+ * the target passes; the batch of update counter + 1 is prepared on a side stream beside it and left in `scratch`
+ * (double-buffered by counter parity).  prepared != 0: the previous call (counter - 1, same scratch, buffer unchanged since)
+ * left this update's batch there; 0: it is sampled now.  Every value equals what the separate calls produce.
+ * scratch: ts_rnnq_learn_scratch_bytes bytes, 256-byte aligned, zeroed once by the caller; ws_aux: a second workspace (the
+ * ahead-of-time forward pass runs concurrently with the target passes).  sync_target != 0: params_old := params between the
+ * returns and the update, where the reference's periodic hard sync sits (dqn.py:283-285: the first statement of
+ * _update_with_batch, after _preprocess_batch used the lagged network); the caller keeps the counter.
+ * idx_out nullable int64[B]: the update's indices. */
+int64_t ts_rnnq_learn_scratch_bytes(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T);
+int ts_rnnq_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                       float* adam_v, int64_t adam_step, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                       const ts_rows_replay* replay, int64_t B, int64_t T, int64_t n_step, double gamma, int is_double,
+                       const ts_dqn_hparams* hp, uint64_t seed, uint64_t counter, int prepared, void* scratch,
+                       int64_t scratch_bytes, float* td_out, float* loss_out, int64_t* idx_out, ts_stream_t stream);
 
 /* The forward pass of ts_rnnq_update ahead of time (as ts_dqn_forward_cache / ts_dqn_update_cached for the NatureCNN): it
  * needs nothing from the two obs_next passes of _target_q (same online parameters, dqn.py:257-275 vs 381-404), and a pass at

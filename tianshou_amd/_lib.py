@@ -196,3 +196,13 @@ def default_workspace(device_index: int) -> Workspace:
     if ws is None:
         ws = _default_ws[key] = Workspace(device_index)
     return ws
+
+
+def aux_workspace(device_index: int) -> Workspace:
+    """A second process-lifetime workspace per device for entry points that run two passes at once inside one call
+    (ts_rnnq_learn_step's ahead-of-time forward pass beside the target passes)."""
+    key = (device_index, -1)
+    ws = _default_ws.get(key)
+    if ws is None:
+        ws = _default_ws[key] = Workspace(device_index)
+    return ws

@@ -261,6 +261,62 @@ __global__ __launch_bounds__(256) void dqn_gather_pair_kernel(const uint8_t* __r
     }
 }
 
+// The vector-observation counterpart of dqn_gather_pair_kernel (DRQN, test/discrete/test_drqn.py:79-101: float rows, stack_num
+// steps per sample): ReplayBuffer.get(index, "obs") and the stacked observations `_target_q` reads n steps on -- from
+// `rows_next` at indices_after_n when the buffer stores obs_next, else from `rows` at next(indices_after_n)
+// (buffer_base.py:586-596, 624-626; algorithm_base.py:772-791) -- and, optionally, batch.act = act_col[index].  One wave per
+// sample: lanes 0 and 32 walk the two index chains side by side, then the 64 lanes copy the 2 x T rows of D floats.
+// Replaces seven launches (n-step indices, next(), two index stacks, two row gathers, the action gather).
+constexpr int ROWS_T_MAX = 16;
+__global__ __launch_bounds__(256) void stacked_rows_pair_kernel(const float* __restrict__ rows, const float* __restrict__ rows_next,
+                                                                int D, const int64_t* __restrict__ index, int64_t B, int n_step,
+                                                                int T, const int64_t* __restrict__ offset, int64_t E,
+                                                                const uint8_t* __restrict__ done,
+                                                                const int64_t* __restrict__ last_index,
+                                                                const int64_t* __restrict__ lengths,
+                                                                const int64_t* __restrict__ act_col, float* __restrict__ out_s,
+                                                                float* __restrict__ out_n, int64_t* __restrict__ act_out) {
+    __shared__ int64_t slot[4][2][ROWS_T_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b < B && (lane & 31) == 0) {
+        const int which = lane >> 5;
+        const int64_t total = offset[E];
+        int64_t idx = index[b];
+        if (which == 1) {
+            const int walk = rows_next ? n_step - 1 : n_step;     // to indices_after_n, and one more to obs_next's slot
+            for (int n = 0; n < walk; ++n) {
+                idx = pymod(idx, total);
+                const int64_t e = find_sub(offset, E, idx);
+                const int64_t start = offset[e], len = lengths[e], cur_len = len > 1 ? len : 1;
+                const int64_t end_flag = (done[idx] != 0) | (idx == last_index[e]);
+                idx = pymod(idx - start + 1 - end_flag, cur_len) + start;
+            }
+        }
+        slot[wave][which][T - 1] = idx;                      // val[indices] is taken before prev()
+        for (int j = 1; j < T; ++j) {
+            idx = pymod(idx, total);
+            const int64_t e = find_sub(offset, E, idx);
+            const int64_t start = offset[e], len = lengths[e], cur_len = len > 1 ? len : 1;
+            const int64_t subind = pymod(idx - start - 1, cur_len);
+            const int64_t end_flag = (done[subind + start] != 0) | (subind + start == last_index[e]);
+            idx = pymod(subind + end_flag, cur_len) + start;
+            slot[wave][which][T - 1 - j] = idx;
+        }
+    }
+    if (b < B && lane == 1 && act_col) act_out[b] = act_col[index[b]];
+    __syncthreads();
+    if (b >= B) return;
+    const int per = T * D;
+    for (int e = lane; e < 2 * per; e += 64) {
+        const int which = e >= per;
+        const int r = e - which * per;
+        const int t = r / D, d = r - t * D;
+        const float* src = (which && rows_next) ? rows_next : rows;
+        (which ? out_n : out_s)[b * per + r] = src[slot[wave][which][t] * D + d];
+    }
+}
+
 // single workgroup, order-preserving compaction over the E sub-buffers
 __global__ void unfinished_kernel(int64_t E, const uint8_t* done, const int64_t* last_index,
                                   const int64_t* lengths, int64_t* out, int64_t* n_out) {
@@ -699,6 +755,24 @@ int ts_dqn_gather_pair(const uint8_t* frames, int64_t n_planes, int64_t plane_el
                "ts_dqn_gather_pair: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(dqn_gather_pair_kernel, dim3((unsigned)B), dim3(256), 0, ts::as_stream(stream), frames, plane_elems, index,
                        (int)n_step, offset, E, done, last_index, lengths, obs_out, obs_next_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_stacked_rows_pair(const float* rows, const float* rows_next, int64_t n_rows, int64_t row_elems, const int64_t* index,
+                         int64_t B, int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,
+                         const int64_t* last_index, const int64_t* lengths, const int64_t* act_col, float* obs_out,
+                         float* obs_next_out, int64_t* act_out, ts_stream_t stream) {
+    TS_REQUIRE(B >= 0 && n_step >= 1 && E >= 1 && row_elems >= 1 && n_rows >= 1, TS_ERR_INVALID_ARG,
+               "ts_stacked_rows_pair: bad sizes");
+    TS_REQUIRE(stack_num >= 1 && stack_num <= ROWS_T_MAX && row_elems * stack_num <= (1 << 20), TS_ERR_UNSUPPORTED,
+               "ts_stacked_rows_pair: 1 <= stack_num <= %d (use ts_stack_indices + ts_gather_rows otherwise)", ROWS_T_MAX);
+    if (B == 0) return TS_OK;
+    TS_REQUIRE(rows && index && offset && done && last_index && lengths && obs_out && obs_next_out &&
+                   (act_col == nullptr) == (act_out == nullptr), TS_ERR_INVALID_ARG, "ts_stacked_rows_pair: NULL argument");
+    hipLaunchKernelGGL(stacked_rows_pair_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, ts::as_stream(stream), rows,
+                       rows_next, (int)row_elems, index, B, (int)n_step, (int)stack_num, offset, E, done, last_index, lengths,
+                       act_col, obs_out, obs_next_out, act_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -380,7 +380,9 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
 // DQN._target_q (dqn.py:365-379) from the two head outputs [B, 32]: q_target[b, argmax_a q_online[b, a]] (double Q) or
 // max_a q_target[b, a]
 __global__ __launch_bounds__(256) void rnn_target_q_kernel(const float* __restrict__ head_online, const float* __restrict__ head_target,
-                                                           int64_t B, int A, int is_double, float* __restrict__ out) {
+                                                           int64_t B, int A, int is_double, float* __restrict__ out,
+                                                           const float* __restrict__ ns_mask, const double* __restrict__ ns_gpow,
+                                                           const double* __restrict__ ns_mc) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const float* sel = is_double ? head_online : head_target;
@@ -390,7 +392,12 @@ __global__ __launch_bounds__(256) void rnn_target_q_kernel(const float* __restri
         const float v = sel[b * HEAD + a];
         if (v > best) { best = v; best_a = a; }
     }
-    out[b] = head_target[b * HEAD + best_a];
+    const float tq = head_target[b * HEAD + best_a];
+    if (ns_mask == nullptr) { out[b] = tq; return; }
+    // the arithmetic half of compute_nstep_return on ts_nstep_coefficients' outputs (as ts_dqn.hip target_q_kernel)
+    const float tqm = tq * ns_mask[b];
+    const double qd = (double)tqm * ns_gpow[b];
+    out[b] = (float)(qd + ns_mc[b]);
 }
 
 // TD error, loss and d loss / d head (dqn.py:388-401)
@@ -646,9 +653,9 @@ int ts_rnnq_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int6
     return TS_OK;
 }
 
-int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
-                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
-                           ts_stream_t stream) {
+static int rnnq_target_impl(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                            int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
+                            const float* ns_mask, const double* ns_gpow, const double* ns_mc, ts_stream_t stream) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_rnnq_target_q_fused: workspace is NULL");
     TS_REQUIRE(params && obs_next && out, TS_ERR_INVALID_ARG, "ts_rnnq_target_q_fused: NULL argument");
     RNet n;
@@ -668,9 +675,25 @@ int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* p
     if (two)
         if (int rc = ts::stream_wait(ws, side, s, 10)) return rc;
     hipLaunchKernelGGL(rnn_target_q_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, a1.out, two ? a2.out : a1.out, B,
-                       n.A, is_double, out);
+                       n.A, is_double, out, ns_mask, ns_gpow, ns_mc);
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+int ts_rnnq_target_q_fused(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double, float* out,
+                           ts_stream_t stream) {
+    return rnnq_target_impl(ws, params, params_old, obs_dim, hidden, layers, n_act, obs_next, B, T, is_double, out, nullptr,
+                            nullptr, nullptr, stream);
+}
+
+int ts_rnnq_target_returns(ts_workspace* ws, const float* params, const float* params_old, int64_t obs_dim, int64_t hidden,
+                           int64_t layers, int64_t n_act, const float* obs_next, int64_t B, int64_t T, int is_double,
+                           const float* ns_mask, const double* ns_gpow, const double* ns_mc, float* returns_out,
+                           ts_stream_t stream) {
+    TS_REQUIRE(ns_mask && ns_gpow && ns_mc, TS_ERR_INVALID_ARG, "ts_rnnq_target_returns: NULL coefficient array");
+    return rnnq_target_impl(ws, params, params_old, obs_dim, hidden, layers, n_act, obs_next, B, T, is_double, returns_out,
+                            ns_mask, ns_gpow, ns_mc, stream);
 }
 
 static int rnnq_update_impl(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
@@ -805,6 +828,98 @@ int ts_lstm_net_backward(ts_workspace* ws, const float* params, int64_t obs_dim,
                        tanh_scale > 0.0 ? 1 : 0, (float)(tanh_scale > 0.0 ? tanh_scale : 1.0), d_head);
     TS_LAUNCH_CHECK();
     return backward(s, ws, n, params, a, d_head, grad_out, bw);
+}
+
+// ---- one call per update on a uniform device-resident replay buffer -------------------------------------------------------
+namespace {
+struct LearnBatch { int64_t* idx; int64_t* act; float* obs; float* obs_next; float* mask; double* gpow; double* mc; };
+struct LearnScratch { LearnBatch b[2]; float* returns; int* err; void* cache; size_t cache_bytes; };
+
+size_t learn_carve(char* base, const RNet& n, int64_t B, int64_t T, int64_t D, LearnScratch* out) {
+    Carve c{base};
+    auto bytes = [&](size_t nbytes) { char* p = c.p; c.p += al(nbytes); return p; };
+    LearnScratch sc{};
+    for (int k = 0; k < 2; ++k) {
+        sc.b[k].idx = reinterpret_cast<int64_t*>(bytes(8 * (size_t)B));
+        sc.b[k].act = reinterpret_cast<int64_t*>(bytes(8 * (size_t)B));
+        sc.b[k].obs = reinterpret_cast<float*>(bytes(4 * (size_t)(B * T * D)));
+        sc.b[k].obs_next = reinterpret_cast<float*>(bytes(4 * (size_t)(B * T * D)));
+        sc.b[k].mask = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+        sc.b[k].gpow = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+        sc.b[k].mc = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+    }
+    sc.returns = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+    sc.err = reinterpret_cast<int*>(bytes(256));
+    sc.cache_bytes = acts_bytes(n);
+    sc.cache = bytes(sc.cache_bytes);
+    if (out) *out = sc;
+    return (size_t)(c.p - base);
+}
+}  // namespace
+
+int64_t ts_rnnq_learn_scratch_bytes(int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act, int64_t B, int64_t T) {
+    RNet n;
+    if (make_rnet(obs_dim, hidden, layers, n_act, B, T, &n) != TS_OK) return -1;
+    return (int64_t)learn_carve(reinterpret_cast<char*>((uintptr_t)256), n, B, T, obs_dim, nullptr);
+}
+
+int ts_rnnq_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                       float* adam_v, int64_t adam_step, int64_t obs_dim, int64_t hidden, int64_t layers, int64_t n_act,
+                       const ts_rows_replay* rb, int64_t B, int64_t T, int64_t n_step, double gamma, int is_double,
+                       const ts_dqn_hparams* hp, uint64_t seed, uint64_t counter, int prepared, void* scratch,
+                       int64_t scratch_bytes, float* td_out, float* loss_out, int64_t* idx_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr && ws_aux != nullptr && ws != ws_aux, TS_ERR_WORKSPACE,
+               "ts_rnnq_learn_step: two distinct workspaces (the update's and the ahead-of-time forward pass's)");
+    TS_REQUIRE(params && adam_m && adam_v && rb && hp && scratch && td_out && loss_out && B >= 1 && adam_step >= 1,
+               TS_ERR_INVALID_ARG, "ts_rnnq_learn_step: bad argument");
+    TS_REQUIRE(rb->offset && rb->lengths && rb->last_index && rb->done && rb->terminated && rb->rew && rb->obs_rows &&
+                   rb->act_col && rb->E >= 1 && rb->slots >= 1, TS_ERR_INVALID_ARG, "ts_rnnq_learn_step: incomplete replay view");
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255u) == 0, TS_ERR_INVALID_ARG,
+               "ts_rnnq_learn_step: scratch must be 256-byte aligned");
+    RNet n;
+    if (int rc = make_rnet(obs_dim, hidden, layers, n_act, B, T, &n)) return rc;
+    LearnScratch sc;
+    const size_t need = learn_carve(static_cast<char*>(scratch), n, B, T, obs_dim, &sc);
+    TS_REQUIRE(scratch_bytes >= (int64_t)need, TS_ERR_SHAPE, "ts_rnnq_learn_step: scratch holds %lld bytes, %lld needed",
+               (long long)scratch_bytes, (long long)need);
+    hipStream_t s = ts::as_stream(stream), side, side2;
+    if (int rc = ts::side_streams(ws, s, &side, &side2)) return rc;
+    // buffer.sample_indices -> batch.obs / obs_next / act -> the network-free half of compute_nstep_return, for update `ctr`
+    auto prepare = [&](hipStream_t st, const LearnBatch& b, uint64_t ctr) -> int {
+        if (int rc = ts_sample_indices_seeded(rb->offset, rb->E, rb->lengths, seed, ctr, B, b.idx, sc.err, st)) return rc;
+        if (int rc = ts_stacked_rows_pair(rb->obs_rows, rb->obs_next_rows, rb->slots, obs_dim, b.idx, B, n_step, T, rb->offset,
+                                          rb->E, rb->done, rb->last_index, rb->lengths, rb->act_col, b.obs, b.obs_next, b.act, st))
+            return rc;
+        return ts_nstep_coefficients(b.idx, B, n_step, rb->offset, rb->E, rb->done, rb->terminated, rb->last_index, rb->lengths,
+                                     rb->rew, gamma, b.mask, b.gpow, b.mc, st);
+    };
+    const LearnBatch& cur = sc.b[counter & 1];
+    const LearnBatch& nxt = sc.b[(counter + 1) & 1];
+    if (!prepared)
+        if (int rc = prepare(s, cur, counter)) return rc;
+    // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
+    if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
+    if (int rc = ts_rnnq_forward_cache(ws_aux, params, obs_dim, hidden, layers, n_act, cur.obs, B, T, sc.cache,
+                                       (int64_t)sc.cache_bytes, side2))
+        return rc;
+    if (!params_old)        // no lagged pass whose wait on `s` would order the side stream behind the previous update
+        if (int rc = ts::stream_wait(ws, s, side, 5)) return rc;
+    if (int rc = ts_rnnq_target_returns(ws, params, params_old, obs_dim, hidden, layers, n_act, cur.obs_next, B, T, is_double,
+                                        cur.mask, cur.gpow, cur.mc, sc.returns, s))
+        return rc;
+    // the next update's batch behind the lagged network's pass on the first side stream (ordered behind the previous update by
+    // that pass's wait on `s`; the update's closing join orders the next call behind it)
+    if (int rc = prepare(side, nxt, counter + 1)) return rc;
+    if (sync_target && params_old)       // the periodic hard sync sits between _preprocess_batch and the update (dqn.py:283-285)
+        TS_HIP_CHECK(hipMemcpyAsync(params_old, params, 4 * (size_t)n.count, hipMemcpyDeviceToDevice, s));
+    if (int rc = ts::stream_wait(ws, side2, s, 7)) return rc;
+    if (int rc = rnnq_update_impl(ws, params, adam_m, adam_v, adam_step, obs_dim, hidden, layers, n_act, cur.obs, cur.act, sc.returns,
+                                  nullptr, B, T, hp, td_out, loss_out, nullptr, stream, sc.cache))
+        return rc;
+    // (the backward pass's closing join of the side stream -- stream order behind `prepare` -- makes the next batch visible to
+    // the next call on `s`)
+    if (idx_out) TS_HIP_CHECK(hipMemcpyAsync(idx_out, cur.idx, 8 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return TS_OK;
 }
 
 }  // extern "C"

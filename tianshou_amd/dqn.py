@@ -438,7 +438,9 @@ class ReplayStream:
     pass; the caller's stream picks the finished batch up with an event.  Same operations on the same values in the same
     order as the sequential loop -- only their placement in time differs.
 
-    draw: () -> float64[batch] uniform draws on the device (prio.py:65); act_of: index tensor -> actions.
+    draw: () -> float64[batch] uniform draws on the device (prio.py:65); act_of: index tensor -> actions (or None).
+    per: the device-resident priorities (segtree.PrioritizedWeights) or None for a uniform buffer -- `draw` then returns the
+    sampled indices themselves (ReplayBuffer.sample_indices) and `give` only prepares the next batch.
     prepare: index tensor -> tuple of (nested tuples of) device tensors or None, everything else of the batch that needs
     neither network (default: DQN's observation pair and n-step coefficients; distq.replay_prepare for QRDQN / C51 /
     Rainbow).  `eng` is any engine with `wait_td` (its update records the event behind its priority kernel)."""
@@ -457,9 +459,12 @@ class ReplayStream:
         return pair, coef
 
     def _sample(self):
-        idx, wt = self.per.sample(self.draw())
-        wt = wt.to(torch.float32)               # what update_with_batch converts the importance weights to
-        self._next = (idx, wt, self.act_of(idx)) + tuple(self.prepare(idx))
+        if self.per is None:                        # uniform sampling: `draw` returns the indices themselves
+            idx, wt = self.draw(), None
+        else:
+            idx, wt = self.per.sample(self.draw())
+            wt = wt.to(torch.float32)               # what update_with_batch converts the importance weights to
+        self._next = (idx, wt, self.act_of(idx) if self.act_of is not None else None) + tuple(self.prepare(idx))
         self._ready = torch.cuda.Event()
         self._ready.record(self.stream)
 
@@ -491,7 +496,12 @@ class ReplayStream:
         return out
 
     def give(self, indices: torch.Tensor, td: torch.Tensor) -> None:
-        """After `update_with_batch`: priority update with its TD errors and the next batch, beside the rest of the update."""
+        """After `update_with_batch`: priority update with its TD errors and the next batch, beside the rest of the update.
+        Without priorities (`per` None) only the next batch: it depends on nothing of the update."""
+        if self.per is None:
+            with torch.cuda.stream(self.stream):
+                self._sample()
+            return
         self.eng.wait_td(self.stream)
         indices.record_stream(self.stream)
         td.record_stream(self.stream)

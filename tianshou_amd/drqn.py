@@ -14,6 +14,7 @@ fc2 [H + 1, 32]; `flat_from_torch` / `flat_to_torch` convert from / to Recurrent
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -22,7 +23,7 @@ from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev, gather_rows
 from .dqn import DQNConfig, stack_indices
 from .lagged import full_parameter_update
-from .returns import compute_nstep_return
+from .returns import compute_nstep_return, nstep_coefficients, nstep_indices
 
 HEAD = 32
 
@@ -91,6 +92,59 @@ def gather_stacked_obs(obs_rows: torch.Tensor, buffer: DeviceReplayBuffer, index
     return out.reshape(index.numel(), stack_num, -1)
 
 
+class RowsReplay(C.Structure):
+    """struct ts_rows_replay (include/tsengine.h)."""
+
+    _fields_ = [("offset", C.c_void_p), ("E", C.c_int64), ("lengths", C.c_void_p), ("last_index", C.c_void_p),
+                ("done", C.c_void_p), ("terminated", C.c_void_p), ("rew", C.c_void_p), ("obs_rows", C.c_void_p),
+                ("obs_next_rows", C.c_void_p), ("act_col", C.c_void_p), ("slots", C.c_int64)]
+
+
+def gather_stacked_obs_pair(obs_rows: torch.Tensor, buffer: DeviceReplayBuffer, index, n_step: int, stack_num: int,
+                            obs_next_rows: torch.Tensor | None = None, act_col: torch.Tensor | None = None):
+    """(buffer.get(index, "obs"), the stacked obs_next `_target_q` reads n steps on, batch.act or None) from ONE launch
+    (ts_stacked_rows_pair; buffer_base.py:586-596, 624-626, algorithm_base.py:772-791), each observation tensor float32
+    [I, stack_num, obs_dim].  None when the layout is outside the kernel's (float32 contiguous [slots, obs_dim] rows, int64
+    action column, stack_num <= 16): the caller then takes the index kernels + gather_stacked_obs."""
+
+    def rows_ok(t):
+        return t.dim() == 2 and t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+
+    if (not rows_ok(obs_rows) or stack_num > 16 or os.environ.get("TS_DRQN_NO_PAIR")
+            or (obs_next_rows is not None and (not rows_ok(obs_next_rows) or obs_next_rows.shape != obs_rows.shape))
+            or (act_col is not None and not (act_col.dim() == 1 and act_col.dtype == torch.int64 and act_col.is_contiguous()))):
+        return None
+    index = _i64_dev(index, buffer.device).reshape(-1)
+    b, d = index.numel(), obs_rows.shape[1]
+    obs = torch.empty((b, stack_num, d), dtype=torch.float32, device=obs_rows.device)
+    obs_next = torch.empty_like(obs)
+    act = torch.empty(b, dtype=torch.int64, device=obs_rows.device) if act_col is not None else None
+    _lib.check(_lib.load().ts_stacked_rows_pair(
+        _lib.ptr(obs_rows), _lib.ptr(obs_next_rows), _lib.i64(obs_rows.shape[0]), _lib.i64(d), _lib.ptr(index), _lib.i64(b),
+        _lib.i64(n_step), _lib.i64(stack_num), _lib.ptr(buffer.offset), _lib.i64(buffer.buffer_num), _lib.ptr(buffer.done),
+        _lib.ptr(buffer.last_index), _lib.ptr(buffer.lengths), _lib.ptr(act_col), _lib.ptr(obs), _lib.ptr(obs_next),
+        _lib.ptr(act), _lib.current_stream(obs_rows.device)))
+    return obs, obs_next, act
+
+
+def replay_prepare(eng, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, stack_num: int, act_col: torch.Tensor,
+                   obs_next_rows: torch.Tensor | None = None):
+    """`prepare` callable of dqn.ReplayStream for RecurrentDQNEngine: what the next batch needs from the replay buffer alone
+    -> ((obs, obs_next, act), n-step coefficients)."""
+    cfg = eng.cfg
+
+    def prepare(idx):
+        pair = gather_stacked_obs_pair(obs_rows, buffer, idx, cfg.n_step, stack_num, obs_next_rows, act_col)
+        if pair is None:
+            after = nstep_indices(buffer, idx, cfg.n_step)
+            nxt = (gather_stacked_obs(obs_rows, buffer, buffer.next(after), stack_num) if obs_next_rows is None
+                   else gather_stacked_obs(obs_next_rows, buffer, after, stack_num))
+            pair = (gather_stacked_obs(obs_rows, buffer, idx, stack_num), nxt, act_col[idx])
+        return pair, nstep_coefficients(buffer, idx, cfg.gamma, cfg.n_step)
+
+    return prepare
+
+
 class RecurrentDQNEngine:
     """State of one DRQN learner on one GPU: flat parameters, lagged copy, Adam moments, counters."""
 
@@ -110,6 +164,7 @@ class RecurrentDQNEngine:
         self.iter = 0
         self._ws = _lib.default_workspace(self.device.index or 0)
         self._streams = {}
+        self._learn = None             # learn_step's scratch, replay view and second workspace
         self._pre = None               # (obs tensor, cache pointer, done event, parameter state, B, T) of a prefetched forward pass
         self._cache = None
 
@@ -170,6 +225,19 @@ class RecurrentDQNEngine:
             _lib.i64(t), C.c_int(int(self.cfg.is_double)), _lib.ptr(out), _lib.current_stream(self.device)))
         return out
 
+    def target_returns(self, obs_next, coef) -> torch.Tensor:
+        """`preprocess` for a caller that holds the stacked obs_next and the n-step coefficients (returns.nstep_coefficients):
+        `_target_q` with float(double(target_q * mask) * gamma^n + sum gamma^k r) in its last kernel (ts_rnnq_target_returns)."""
+        obs_next = self._obs(obs_next)
+        b, t = obs_next.shape[:2]
+        mask, gpow, mc = coef
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_rnnq_target_returns(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.params_old), *self._dims(), _lib.ptr(obs_next), _lib.i64(b),
+            _lib.i64(t), C.c_int(int(self.cfg.is_double)), _lib.ptr(mask), _lib.ptr(gpow), _lib.ptr(mc), _lib.ptr(out),
+            _lib.current_stream(self.device)))
+        return out
+
     # -- the update's own forward pass, ahead of time -----------------------------------------------------------------------------
     def prefetch_forward(self, obs) -> torch.Tensor:
         """Q_online(batch.obs) of the coming `update_with_batch(obs, ...)` on the workspace's second side stream, beside the two
@@ -199,13 +267,87 @@ class RecurrentDQNEngine:
         return obs
 
     def preprocess_with_obs(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, indices, stack_num: int,
-                            obs_next_rows: torch.Tensor | None = None, prefetch: bool = True):
+                            obs_next_rows: torch.Tensor | None = None, prefetch: bool = True, pair=None, coef=None):
         """-> (batch.obs float32[I, T, obs_dim], returns float32[I]): the batch's own stacked observations first, their forward
-        pass started on a side stream (prefetch_forward), then `preprocess`."""
-        obs = self._obs(gather_stacked_obs(obs_rows, buffer, indices, stack_num))
+        pass started on a side stream (prefetch_forward), then `_target_q` and the n-step returns.  Both stacked gathers come
+        from one launch (gather_stacked_obs_pair) and the returns from the target passes' last kernel (target_returns) where
+        the layout allows; `pair` / `coef`: those results when the caller already holds them (dqn.ReplayStream with
+        drqn.replay_prepare)."""
+        if pair is None:
+            pair = gather_stacked_obs_pair(obs_rows, buffer, indices, self.cfg.n_step, stack_num, obs_next_rows)
+        if pair is None:
+            obs = self._obs(gather_stacked_obs(obs_rows, buffer, indices, stack_num))
+            if prefetch:
+                obs = self.prefetch_forward(obs)
+            return obs, self.preprocess(buffer, obs_rows, indices, stack_num, obs_next_rows)
+        obs = self._obs(pair[0])
         if prefetch:
             obs = self.prefetch_forward(obs)
-        return obs, self.preprocess(buffer, obs_rows, indices, stack_num, obs_next_rows)
+        if coef is None:
+            coef = nstep_coefficients(buffer, indices, self.cfg.gamma, self.cfg.n_step)
+        return obs, self.target_returns(pair[1], coef)
+
+    # -- sample + preprocess + update in one call (uniform device-resident buffer) ---------------------------------------------
+    def learn_step(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, act_col: torch.Tensor, batch_size: int,
+                   stack_num: int, seed, obs_next_rows: torch.Tensor | None = None):
+        """OffPolicyAlgorithm.update (algorithm_base.py:583-631) on a buffer without priorities as ONE library call
+        (ts_rnnq_learn_step): indices = buffer.sample_indices(batch_size, seed=seed), then what `preprocess_with_obs` and
+        `update_with_batch` do -- the same kernels on the same values -- with the batch of seed (key, counter + 1) prepared
+        beside the update for the next call.  -> (loss float32[1], td_error float32[B]).
+        seed = (key, counter), counter advancing by one per call; call `learn_reset()` after writing to the buffer (the
+        prepared batch predates the write).  float32 contiguous rows / int64 actions only (no fallback: use the separate
+        calls otherwise)."""
+        lib = _lib.load()
+        key, counter = int(seed[0]) & (2**64 - 1), int(seed[1]) & (2**64 - 1)
+        b, t = int(batch_size), int(stack_num)
+        st = self._learn
+        ident = (id(buffer), obs_rows.data_ptr(), act_col.data_ptr(), None if obs_next_rows is None else obs_next_rows.data_ptr(), b, t)
+        if st is None or st["ident"] != ident:
+            for r in (obs_rows, obs_next_rows):
+                if r is not None and not (r.is_cuda and r.dim() == 2 and r.dtype == torch.float32 and r.is_contiguous()
+                                          and r.shape[1] == self.obs_dim):
+                    raise ValueError(f"learn_step: observation rows must be float32 contiguous [slots, {self.obs_dim}] on the device")
+            if not (act_col.is_cuda and act_col.dim() == 1 and act_col.dtype == torch.int64 and act_col.is_contiguous()):
+                raise ValueError("learn_step: actions must be an int64 contiguous device column")
+            if len(buffer) == 0:                             # buffer_base.py:512-513
+                raise ValueError("learn_step: empty buffer")
+            lib.ts_rnnq_learn_scratch_bytes.restype = C.c_int64
+            need = int(lib.ts_rnnq_learn_scratch_bytes(*self._dims(), _lib.i64(b), _lib.i64(t)))
+            if need <= 0:
+                raise ValueError("learn_step: unsupported network / batch dimensions")
+            scratch = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)
+            view = RowsReplay(_lib.ptr(buffer.offset), buffer.buffer_num, _lib.ptr(buffer.lengths), _lib.ptr(buffer.last_index),
+                              _lib.ptr(buffer.done), _lib.ptr(buffer.terminated), _lib.ptr(buffer.rew), _lib.ptr(obs_rows),
+                              _lib.ptr(obs_next_rows), _lib.ptr(act_col), obs_rows.shape[0])
+            st = self._learn = {"ident": ident, "scratch": scratch, "ptr": C.c_void_p((scratch.data_ptr() + 255) & ~255),
+                                "bytes": _lib.i64(need), "view": view, "aux": _lib.aux_workspace(self.device.index or 0), "last": None,
+                                "keep": (buffer, obs_rows, act_col, obs_next_rows), "B": _lib.i64(b), "T": _lib.i64(t),
+                                }
+        cfg = self.cfg
+        sync = self.params_old is not None and self.iter % cfg.target_update_freq == 0    # dqn.py:283-285, applied inside the call
+        self.iter += 1
+        self.adam_step += 1
+        self._pre = None
+        td = torch.empty(b, dtype=torch.float32, device=self.device)
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        hp = st.get("hp")
+        if hp is None or st.get("hp_of") != (cfg.lr, cfg.betas, cfg.adam_eps, cfg.huber_delta, cfg.max_grad_norm):
+            hp = st["hp"] = cfg.to_c()
+            st["hp_of"] = (cfg.lr, cfg.betas, cfg.adam_eps, cfg.huber_delta, cfg.max_grad_norm)
+        prepared = st["last"] == (key, (counter - 1) & (2**64 - 1))
+        _lib.check(lib.ts_rnnq_learn_step(
+            self._ws.handle, st["aux"].handle, _lib.ptr(self.params), _lib.ptr(self.params_old), C.c_int(int(sync)), _lib.ptr(self.adam_m),
+            _lib.ptr(self.adam_v), _lib.i64(self.adam_step), *self._dims(), C.byref(st["view"]), st["B"], st["T"],
+            _lib.i64(cfg.n_step), _lib.f64(cfg.gamma), C.c_int(int(cfg.is_double)), C.byref(hp), C.c_uint64(key),
+            C.c_uint64(counter), C.c_int(int(prepared)), st["ptr"], st["bytes"], _lib.ptr(td), _lib.ptr(loss), None,
+            _lib.current_stream(self.device)))
+        st["last"] = (key, counter)
+        return loss, td
+
+    def learn_reset(self) -> None:
+        """Drops the batch `learn_step` prepared ahead of time (call it after transitions were written to the buffer)."""
+        if self._learn is not None:
+            self._learn["last"] = None
 
     # -- DQN._preprocess_batch ---------------------------------------------------------------------------------------------
     def preprocess(self, buffer: DeviceReplayBuffer, obs_rows: torch.Tensor, indices, stack_num: int,
