@@ -76,6 +76,15 @@ def _tick() -> int:
     return _TICK[0]
 
 
+def _perm(n: int, dev) -> torch.Tensor:
+    """Minibatch order of one repeat: the engine's keyed device permutation (ts_random_permutation, as bench.py's next_perm) --
+    the device stand-in for Batch.split's np.random.permutation (batch.py:1209); a sort-based torch.randperm costs ~250 us at
+    2^20 entries."""
+    from tianshou_amd.buffer import random_permutation
+
+    return random_permutation(n, 0x51ED + 0x9E3779B97F4A7C15 * _tick(), dev)
+
+
 _HOST_MS = [None]
 DISTQ_REPLAY_STREAM = not os.environ.get("TS_DISTQ_NO_REPLAY_STREAM")   # A/B switch (QRDQN / C51 / Rainbow), as bench_dqn's
 _LAST_PROF: dict = {}
@@ -476,7 +485,7 @@ def run_natural(steps, warmup, with_cpu, algo="npg"):
 
     def update():
         pre = eng.preprocess(obs, obs_next, act, rew, term, trunc, cut)
-        stats, k = eng.update(pre, MB, 1, [torch.randperm(n, generator=g, device=dev)])
+        stats, k = eng.update(pre, MB, 1, [_perm(n, dev)])
         count[0] = k
         return stats
 
@@ -538,7 +547,7 @@ def run_ppo_discrete(steps, warmup, with_cpu):
 
     def update():
         pre = eng.preprocess(buf)
-        perms = [torch.randperm(n, generator=g, device=dev) for _ in range(REPEAT)]
+        perms = [_perm(n, dev) for _ in range(REPEAT)]
         losses, k = eng.update(buf, pre, BS, REPEAT, perms)
         count[0] = k
         return losses
@@ -549,7 +558,7 @@ def run_ppo_discrete(steps, warmup, with_cpu):
     flop = 2 * n * mlp_flop(dims) + k * BS * mlp_flop(dims, wgrad=True, dgrad_layers=2)
     # the one-launch update kernel alone (ts_mlp_ppo_update: every minibatch step of the update in one persistent workgroup)
     pre = eng.preprocess(buf)
-    perms = [torch.randperm(n, generator=g, device=dev) for _ in range(REPEAT)]
+    perms = [_perm(n, dev) for _ in range(REPEAT)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -610,7 +619,7 @@ def run_reinforce(steps, warmup, with_cpu):
 
     def update():
         ret = eng.preprocess(rew, term, trunc, cut)
-        losses, k = eng.update(obs, act, ret, MB, 1, [torch.randperm(n, generator=g, device=dev)])
+        losses, k = eng.update(obs, act, ret, MB, 1, [_perm(n, dev)])
         count[0] = k
         return losses
 

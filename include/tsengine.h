@@ -300,7 +300,11 @@ typedef struct ts_ppo_hparams {
     int32_t algo;         /* 0 = PPO clipped surrogate (ppo.py:187-196);
                              1 = A2C policy gradient -(logp * adv).mean() + plain MSE value loss
                                  (modelfree/a2c.py:262-273; eps/dual/value clip, adv_norm, logp_old unused) */
-    int32_t reserved;
+    int32_t nets;         /* 0 (or 3): actor and critic.  1: the actor's half of every step only, 2: the critic's -- the other
+                             network's gradient and loss sum are zeros (it still takes its Adam step on that zero gradient).
+                             For callers whose other network is a stand-in: Reinforce (reinforce.py:371-380 = A2C's actor
+                             loss with adv := returns) and the critic iterations of NPG / TRPO (npg.py:142-150 = A2C steps
+                             with a zero advantage).  Honoured by ts_ppo_update / ts_ppo_grad (obs_dim <= 31 kernels) */
 } ts_ppo_hparams;
 
 /* No-grad inference passes of PPO._preprocess_batch / _add_returns_and_advantages

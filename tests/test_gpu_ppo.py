@@ -120,7 +120,9 @@ def test_update_matches_oracle(cfg_name, n, n_env, batch_size, repeat):
     assert steps == losses_o.shape[0]
     np.testing.assert_allclose(losses.cpu().numpy(), losses_o, rtol=1e-5, atol=2e-6)
     gscale = float(grads_o.abs().max())
-    np.testing.assert_allclose(grads.cpu().numpy(), grads_o.numpy(), rtol=1e-4, atol=1e-6 * max(gscale, 1.0))
+    # 5e-6 of the largest entry (half the 1e-5 bar): the oracle's fp32 sums run on however many host threads the box has, and
+    # one of the 11,085 entries has been seen 2.6e-6 off on one box with the bound at 1e-6 (the kernels were bit-identical)
+    np.testing.assert_allclose(grads.cpu().numpy(), grads_o.numpy(), rtol=1e-4, atol=5e-6 * max(gscale, 1.0))
     np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=2e-6)
     assert eng.adam_step == st.adam_step
     np.testing.assert_allclose(eng.ret_rms, [st.ret_rms.mean, st.ret_rms.var, st.ret_rms.count], rtol=1e-5)
@@ -396,3 +398,46 @@ def test_collector_policy_forward_and_map_action(bound, scaled, with_noise):
                                    low=low if scaled else None, high=high if scaled else None)
     np.testing.assert_allclose(act.cpu().numpy(), ref_act.numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(mapped.cpu().numpy(), m, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("nets", [1, 2])
+def test_one_network_steps_equal_that_networks_half_of_the_two_network_step(nets):
+    """ts_ppo_hparams.nets = 1 / 2 (ppo_step1_kernel: only the actor's / the critic's half of every step, zeros for the
+    other network) against the two-network kernel on a problem whose other half is exactly zero anyway (A2C with vf_coef 0
+    and a zero critic; a zero advantage with a zero actor): three minibatch steps, bit-identical parameters, Adam moments and
+    losses of the live network; the absent network stays zero."""
+    from tianshou_amd import ppo as P
+
+    obs_dim, act_dim, n = 17, 6, 4096 + 77
+    g = torch.Generator(device="cuda").manual_seed(3)
+    obs = torch.randn(n, obs_dim, generator=g, device="cuda")
+    act = torch.randn(n, act_dim, generator=g, device="cuda") * 0.5
+    sig = torch.randn(n, generator=g, device="cuda")
+    zeros = torch.zeros(n, device="cuda")
+    shapes = P.param_shapes(obs_dim, act_dim)
+    n_actor = sum(int(np.prod(shapes[k])) for k in P.PARAM_ORDER[:7])
+    flat = torch.randn(P.param_count(obs_dim, act_dim), generator=g, device="cuda") * 0.1
+    if nets == 1:
+        flat[n_actor:] = 0.0
+        kw = dict(vf_coef=0.0)
+        b = {"obs": obs, "act": act, "adv": sig, "returns": zeros, "logp_old": zeros, "v_s": zeros}
+    else:
+        flat[:n_actor] = 0.0
+        kw = dict(vf_coef=1.0)
+        b = {"obs": obs, "act": act, "adv": zeros, "returns": sig, "logp_old": zeros, "v_s": zeros}
+    perm = torch.randperm(n, generator=g, device="cuda")
+    out = []
+    for which in (0, nets):
+        cfg = P.PPOConfig(algo="a2c", ent_coef=0.0, advantage_normalization=False, max_grad_norm=0.5, lr=1e-3, nets=which, **kw)
+        eng = P.PPOEngine(obs_dim, act_dim, flat.clone(), cfg)
+        losses, steps = eng.update(b, 2048, 1, [perm])
+        assert steps == 2
+        out.append((eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), losses.clone()))
+    both, one = out
+    live = slice(0, n_actor) if nets == 1 else slice(n_actor, None)
+    dead = slice(n_actor, None) if nets == 1 else slice(0, n_actor)
+    for a, c in zip(both[:3], one[:3]):
+        assert torch.equal(a[live], c[live])
+        assert bool((c[dead] == 0).all()) and bool((a[dead] == 0).all())
+    col = 1 if nets == 1 else 2                      # (loss, clip / pg loss, vf loss, entropy)
+    assert torch.equal(both[3][:, col], one[3][:, col]) and torch.equal(both[3][:, 0], one[3][:, 0])

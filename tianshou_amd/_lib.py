@@ -47,7 +47,7 @@ class PPOHParams(C.Structure):
         ("value_clip", C.c_int32),
         ("adv_norm", C.c_int32),
         ("algo", C.c_int32),
-        ("reserved", C.c_int32),
+        ("nets", C.c_int32),
     ]
 
 

@@ -462,6 +462,7 @@ struct StepArgs {
     const float* adv_stats;   // {mean, std} of this minibatch (device) or NULL
     float eps_clip, dual_clip, vf_coef, ent_coef;
     int value_clip, adv_norm, a2c;
+    int nets;                 // 0 / 3: both networks (ppo_step2_kernel); 1: actor only, 2: critic only (ppo_step1_kernel)
     const float* image;       // [2][Lds<KS1,1>::END] ready-made LDS images of the two nets (ppo_build_image_kernel)
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
@@ -1072,6 +1073,54 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
     TS_MARK(g, 17);
 }
 
+// One of the two networks only (ts_ppo_hparams.nets = 1: actor, 2: critic): the same phases on the same operands as the
+// corresponding half of ppo_step2_kernel; the other network's gradient columns and loss sum are written as zeros, so the
+// slab reduction, the global norm and Adam see a zero gradient for it.  For callers whose other network is a stand-in:
+// Reinforce's minibatch steps (A2C's actor loss with adv := returns; no critic exists) and the critic iterations of
+// NPG / TRPO (A2C steps with a zero advantage; the actor takes no gradient there).
+template <int KS1>
+__global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, Dims d, int net) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using L = Lds<KS1, 1>;
+    const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+    const Slab2 SL = slab2_layout(d.act, 2 * KS1);
+
+    const int64_t n_tiles = (g.n_rows + 31) / 32;
+    const int64_t per_iter = (int64_t)gridDim.x * STEP_WAVES;
+    const int64_t n_iter = (n_tiles + per_iter - 1) / per_iter;   // same for every wave: barriers inside
+    const int64_t tile0 = (int64_t)blockIdx.x * STEP_WAVES + wave0;
+    float* slab = g.slabs + (int64_t)blockIdx.x * g.slab_w;
+    {   // the absent network's columns: [0, w1[1]) = actor incl. sigma, [w1[1], loss) = critic; its loss sum
+        const int z0 = net == 0 ? SL.w1[1] : 0, z1 = net == 0 ? SL.loss : SL.w1[1];
+        for (int c = z0 + (int)threadIdx.x; c < z1; c += STEP_THREADS) slab_st(slab + c, 0.f);
+        if (threadIdx.x == 0) slab_st(slab + SL.loss + (1 - net), 0.f);
+    }
+    for (int64_t it = 0; it < n_iter; ++it) {
+        __builtin_amdgcn_s_setprio(3);
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane), "+v"(wave));
+        float* scratch = lds + L::END + wave * (2 * TILE_SIZE);
+        const RowId row0 = row_fetch(g, it * per_iter + tile0, lane);
+        const RecFetch<KS1> f = rec_fetch<KS1>(g, row0, lane);
+        if (it > 0) __syncthreads();          // the previous iteration's phase-B readers are done
+        stage_image<KS1, STEP_THREADS>(lds, g.image + (net ? L::END : 0), 64 * wave + lane);
+        const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
+        __syncthreads();
+        const bool first = it == 0;
+        f32x16 h1[2], h2[2], dz1[2];
+        float misc;
+        if (net == 0) {
+            float gw[ACT_PAD];
+            net_fwd_bwd<KS1, true>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_wgrad<KS1, true>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
+        } else {
+            float gw[1];
+            net_fwd_bwd<KS1, false>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_wgrad<KS1, false>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
 // partial sum of squares over the parameter columns (for the global gradient norm).
@@ -1337,7 +1386,16 @@ int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hi
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    {
+    if (g.nets == 1 || g.nets == 2) {            // one network only (ts_ppo_hparams.nets)
+        static bool attr1_done = false;
+        if (!attr1_done) {
+            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr1_done = true;
+        }
+        ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
+        hipLaunchKernelGGL((ppo_step1_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d, g.nets - 1);
+    } else {
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
         hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
@@ -1361,6 +1419,7 @@ inline void fill_hparams(StepArgs& g, const ts_ppo_hparams* hp) {
     g.vf_coef = (float)hp->vf_coef;
     g.ent_coef = (float)hp->ent_coef;
     g.a2c = hp->algo == 1;
+    g.nets = hp->nets;
     g.value_clip = g.a2c ? 0 : hp->value_clip;
     g.adv_norm = g.a2c ? 0 : hp->adv_norm;
     if (g.a2c) g.dual_clip = 0.f;

@@ -152,7 +152,8 @@ class NPGEngine:
 
             cfg = self.cfg
             pc = P.PPOConfig(algo="a2c", vf_coef=1.0, ent_coef=0.0, advantage_normalization=False,
-                             max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps)
+                             max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps,
+                             nets=0 if os.environ.get("TS_NPG_BOTH_NETS") else 2)              # 2: the critic's half of the step only
             eng = P.PPOEngine(self.obs_dim, self.act_dim, torch.zeros(P.param_count(self.obs_dim, self.act_dim), device=self.device), pc)
             shapes = P.param_shapes(self.obs_dim, self.act_dim)
             off = sum(int(np.prod(shapes[k])) for k in P.PARAM_ORDER[:7])          # the critic's tensors follow the actor's

@@ -91,6 +91,8 @@ class PPOConfig:
     lr: float = 1e-3
     betas: tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
+    nets: int = 0                # 0: actor and critic; 1 / 2: only the actor's / the critic's half of every step (the other
+                                 # network is a stand-in and takes a zero gradient: reinforce.py / npg.py; ts_ppo_hparams.nets)
 
     def to_c(self) -> _lib.PPOHParams:
         return _lib.PPOHParams(
@@ -98,7 +100,7 @@ class PPOConfig:
             ent_coef=self.ent_coef, max_grad_norm=self.max_grad_norm or 0.0, lr=self.lr,
             beta1=self.betas[0], beta2=self.betas[1], adam_eps=self.adam_eps,
             value_clip=int(self.value_clip), adv_norm=int(self.advantage_normalization),
-            algo={"ppo": 0, "a2c": 1}[self.algo], reserved=0)
+            algo={"ppo": 0, "a2c": 1}[self.algo], nets=int(self.nets))
 
 
 def rms_merge(rms, s1: float, s2: float, n: float) -> list[float]:

@@ -43,10 +43,22 @@ class ReinforceEngine:
         self.actor = actor.detach().float().contiguous().clone()
         self.adam_m, self.adam_v = torch.zeros_like(self.actor), torch.zeros_like(self.actor)
         self.adam_step = 0
-        self.ret_rms = [0.0, 1.0, 0.0]
+        self._rms_host, self._rms_dev = [0.0, 1.0, 0.0], None
         self._grad = torch.empty_like(self.actor)
         self._ws = _lib.default_workspace(self.device.index or 0)
         self._fused = None               # (PPOEngine, positions in the actor vector, indices in its parameter vector)
+
+    # RunningMeanStd (mean, var, count; statistics.py:60-114).  `preprocess` keeps it on the device -- reading it here is the
+    # only host synchronisation of an update loop; assigning it (hooks, checkpoints) replaces the device copy.
+    @property
+    def ret_rms(self) -> list:
+        if self._rms_dev is not None:
+            self._rms_host = [float(x) for x in self._rms_dev.tolist()]
+        return list(self._rms_host)
+
+    @ret_rms.setter
+    def ret_rms(self, value) -> None:
+        self._rms_host, self._rms_dev = [float(x) for x in value], None
 
     def _f32(self, x, shape=None) -> torch.Tensor:
         t = torch.as_tensor(x, device=self.device).to(torch.float32).contiguous()
@@ -58,8 +70,10 @@ class ReinforceEngine:
         cfg = self.cfg
         term = torch.as_tensor(terminated, device=self.device).reshape(-1)
         n = term.numel()
-        mean, var, count = self.ret_rms
-        v_next = torch.where(term.bool(), 0.0, float(mean)).to(torch.float32)       # full(ret_rms.mean) * value_mask
+        if self._rms_dev is None:
+            self._rms_dev = torch.tensor(self._rms_host, dtype=torch.float64, device=self.device)
+        mean, var, count = self._rms_dev[0], self._rms_dev[1], self._rms_dev[2]           # float64 device scalars
+        v_next = torch.where(term.bool(), 0.0, mean).to(torch.float32)              # full(ret_rms.mean) * value_mask
         v_s = torch.roll(v_next, 1)                                                 # algorithm_base.py:712
         cut = None if cut_pos is None else _i64_dev(cut_pos, self.device)
         out = gae_scan(v_s, v_next, torch.as_tensor(rew, device=self.device), term,
@@ -67,11 +81,13 @@ class ReinforceEngine:
                        want_f64=cfg.return_standardization, want_ret_stats=cfg.return_standardization)
         if not cfg.return_standardization:
             return out["returns"]
-        ret = ((out["ret64"] - mean) / float(np.sqrt(var + 1e-8))).to(torch.float32)     # reinforce.py:305-307
-        b_mean = float(out["ret_sum"]) / n                                               # statistics.py:99-114
-        b_var = max(float(out["ret_sumsq"]) / n - b_mean * b_mean, 0.0)
+        ret = ((out["ret64"] - mean) / torch.sqrt(var + 1e-8)).to(torch.float32)          # reinforce.py:305-307
+        # ret_rms.update(unnormalised returns), statistics.py:99-114: the same float64 operations in the same order, on the
+        # device (no host round trip between two updates)
+        b_mean = out["ret_sum"] / n
+        b_var = torch.clamp(out["ret_sumsq"] / n - b_mean * b_mean, min=0.0)
         delta, tot = b_mean - mean, count + n
-        self.ret_rms = [mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot]
+        self._rms_dev = torch.stack([mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot])
         return ret
 
     # -- one minibatch (reinforce.py:371-380) ----------------------------------------------------------------------------
@@ -121,7 +137,8 @@ class ReinforceEngine:
         if self._fused is None:
             cfg = self.cfg
             pc = _ppo.PPOConfig(algo="a2c", vf_coef=0.0, ent_coef=0.0, advantage_normalization=False,
-                                max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps)
+                                max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps,
+                                nets=0 if os.environ.get("TS_REINFORCE_BOTH_NETS") else 1)    # 1: the actor's half of the step only
             eng = _ppo.PPOEngine(self.obs_dim, self.act_dim,
                                  torch.zeros(_ppo.param_count(self.obs_dim, self.act_dim), device=self.device), pc)
             shapes, off, t = _ppo.param_shapes(self.obs_dim, self.act_dim), 0, []
