@@ -899,7 +899,8 @@ int ts_rnnq_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, fl
         if (int rc = prepare(s, cur, counter)) return rc;
     // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
     if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
-    if (int rc = ts_rnnq_forward_cache(ws_aux, params, obs_dim, hidden, layers, n_act, cur.obs, B, T, sc.cache,
+    // (while ts_profile_begin is active everything above runs on `s` in sequence: the pass then uses -- and is timed by -- `ws`)
+    if (int rc = ts_rnnq_forward_cache(ws->profiling ? ws : ws_aux, params, obs_dim, hidden, layers, n_act, cur.obs, B, T, sc.cache,
                                        (int64_t)sc.cache_bytes, side2))
         return rc;
     if (!params_old)        // no lagged pass whose wait on `s` would order the side stream behind the previous update
