@@ -512,17 +512,25 @@ struct Bwd {
     float* din;       // [T B, H]  d loss / d (layer input)
     float* dh_rec;    // [B, H]
     float* dc;        // [B, H]
-    float* slabs;
+    float* slabs[3];  // split-K partials of the weight gradients: one buffer per stream that runs them ([0] first side stream,
+                      // [1] second side stream, [2] the caller's)
 };
 
 size_t bwd_bytes(const RNet& n) {
     const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
-    return al(4 * n.L * rows * 4 * H) + 2 * al(4 * rows * H) + 2 * al(4 * B * H) + al(4 * slab_floats(n));
+    return al(4 * n.L * rows * 4 * H) + 2 * al(4 * rows * H) + 2 * al(4 * B * H) + 3 * al(4 * slab_floats(n));
 }
 
 Bwd take_bwd(Carve& c, const RNet& n) {
     const size_t rows = (size_t)n.B * n.T, H = n.H, B = n.B;
-    return Bwd{c.f(n.L * rows * 4 * H), c.f(rows * H), c.f(rows * H), c.f(B * H), c.f(B * H), c.f(slab_floats(n))};
+    Bwd b;
+    b.dg = c.f(n.L * rows * 4 * H);
+    b.dout = c.f(rows * H);
+    b.din = c.f(rows * H);
+    b.dh_rec = c.f(B * H);
+    b.dc = c.f(B * H);
+    for (int k = 0; k < 3; ++k) b.slabs[k] = c.f(slab_floats(n));
+    return b;
 }
 
 int wgrad_to(hipStream_t s, ts_workspace* ws, const ts::ConvGeom& g, const float* x, const float* dy, float* slabs, float* out) {
@@ -532,29 +540,29 @@ int wgrad_to(hipStream_t s, ts_workspace* ws, const ts::ConvGeom& g, const float
 
 // grad[0 .. count) = d loss / d params given d loss / d head output (d_head [B, 32]).
 // The chain head -> (backward through time, input gradient) per layer runs down the caller's stream; the weight-gradient
-// GEMMs (+ slab sums) of the head and of every layer need only that layer's gate gradients and run, in order, on the
-// workspace's side stream beside the chain (they were 40 % of the serial launches of a DRQN update).
+// GEMMs (+ slab sums) of the head and of every layer need only that layer's gate gradients and run beside the chain on the
+// workspace's two side streams -- W_ih's on the first, W_hh's on the second, each with its own partial-sum buffer -- (they were
+// 40 % of the serial launches of a DRQN update); fc1's, the last one, follows the chain on the caller's stream.
 int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, const Acts& a, const float* d_head, float* grad,
              Bwd bw) {
     const int64_t B = n.B;
     const int H = n.H, T = n.T;
     const size_t blk = (size_t)B * H;
     const unsigned gcell = (unsigned)ts::ceil_div((int64_t)blk, 256);
-    hipStream_t w;
-    if (int rc = ts::side_stream(ws, s, &w)) return rc;
+    hipStream_t w, w2;
+    if (int rc = ts::side_streams(ws, s, &w, &w2)) return rc;
     // head: only the last step of the top layer receives a gradient
     const float* h_last = n.extra ? a.hcat : a.hbuf[n.L - 1] + (size_t)T * blk;
     if (T > 1) TS_HIP_CHECK(hipMemsetAsync(bw.dout, 0, 4 * (size_t)(T - 1) * blk, s));
     if (n.extra) {
         // d loss / d [h_T | extra | pad] needs the (then dead) concat buffer: its weight gradient first, on this stream
-        if (int rc = wgrad_to(s, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
+        if (int rc = wgrad_to(s, ws, n.head, h_last, d_head, bw.slabs[2], grad + n.off_head)) return rc;
         if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, a.hcat, ws, 0, H)) return rc;
         hipLaunchKernelGGL(take_cols_kernel, dim3(gcell), dim3(256), 0, s, a.hcat, B, H, n.head_in, bw.dout + (size_t)(T - 1) * blk);
         TS_LAUNCH_CHECK();
-        if (int rc = ts::stream_wait(ws, s, w, 0)) return rc;                 // (orders the side stream's use of `slabs`)
     } else {
         if (int rc = ts::stream_wait(ws, s, w, 0)) return rc;                 // d_head is ready
-        if (int rc = wgrad_to(w, ws, n.head, h_last, d_head, bw.slabs, grad + n.off_head)) return rc;
+        if (int rc = wgrad_to(w, ws, n.head, h_last, d_head, bw.slabs[0], grad + n.off_head)) return rc;
         if (int rc = ts::conv_dgrad(s, n.head, d_head, p + n.off_head, nullptr, bw.dout + (size_t)(T - 1) * blk, ws)) return rc;
     }
     for (int l = n.L - 1; l >= 0; --l) {
@@ -574,15 +582,18 @@ int backward(hipStream_t s, ts_workspace* ws, const RNet& n, const float* p, con
                 if (int rc = ts::conv_dgrad(s, n.hh_step, dg + (size_t)t * 4 * blk, p + n.off_hh[l], nullptr, bw.dh_rec, ws)) return rc;
         }
         if (int rc = ts::stream_wait(ws, s, w, 1 + l)) return rc;             // the layer's gate gradients are complete
+        if (w2 != s) TS_HIP_CHECK(hipStreamWaitEvent(w2, ws->side_ev[1 + l], 0));   // the same event: one record on `s`
         const float* in = l == 0 ? (n.has_fc1 ? a.x1 : a.x) : a.hbuf[l - 1] + blk;
-        if (int rc = wgrad_to(w, ws, n.ih(l), in, dg, bw.slabs, grad + n.off_ih[l])) return rc;
-        if (int rc = wgrad_to(w, ws, n.ih_all, a.hbuf[l], dg, bw.slabs, grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
-        if (l == 0 && !n.has_fc1) return ts::stream_wait(ws, w, s, 15);       // nothing below the first LSTM layer takes a gradient
+        if (int rc = wgrad_to(w, ws, n.ih(l), in, dg, bw.slabs[0], grad + n.off_ih[l])) return rc;
+        if (int rc = wgrad_to(w2, ws, n.ih_all, a.hbuf[l], dg, bw.slabs[1], grad + n.off_hh[l])) return rc;   // rows t: h_{t-1}
+        if (l == 0 && !n.has_fc1) break;                                      // nothing below the first LSTM layer takes a gradient
         if (int rc = ts::conv_dgrad(s, n.ih_all, dg, p + n.off_ih[l], nullptr, bw.din, ws)) return rc;
         std::swap(bw.dout, bw.din);
     }
-    if (int rc = ts::stream_wait(ws, w, s, 15)) return rc;                   // `slabs` is free again, every gradient block above is written
-    return wgrad_to(s, ws, n.fc1, a.x, bw.dout, bw.slabs, grad + n.off_fc1);
+    if (n.has_fc1)
+        if (int rc = wgrad_to(s, ws, n.fc1, a.x, bw.dout, bw.slabs[2], grad + n.off_fc1)) return rc;
+    if (int rc = ts::stream_wait(ws, w, s, 15)) return rc;                   // every gradient block is written
+    return ts::stream_wait(ws, w2, s, 7);
 }
 
 // bounded head outputs: mu = max_action tanh(head) (continuous.py:230-231, 313-314), in place on the first A columns
