@@ -412,7 +412,7 @@ int ts_dqn_gather_pair(const uint8_t* frames, int64_t n_planes, int64_t plane_el
  * buffer_base.py:586-596); obs_next_out[b] likewise from `rows_next` at indices_after_n = next^(n_step-1)(index[b]) when the
  * buffer stores obs_next, else (rows_next NULL) from `rows` at next(indices_after_n) (buffer_base.py:624-626,
  * algorithm_base.py:772-791); both float32 [B, stack_num, row_elems].  act_col / act_out (both or neither): batch.act =
- * act_col[index].  Bit-identical to ts_nstep_indices + next() + 2 x (ts_stack_indices + ts_gather_rows).
+ * act_col[index] (negative indices count from the end, as the index walks take them).  Bit-identical to ts_nstep_indices + next() + 2 x (ts_stack_indices + ts_gather_rows).
  * 1 <= stack_num <= 16 (TS_ERR_UNSUPPORTED else). */
 int ts_stacked_rows_pair(const float* rows, const float* rows_next, int64_t n_rows, int64_t row_elems, const int64_t* index,
                          int64_t B, int64_t n_step, int64_t stack_num, const int64_t* offset, int64_t E, const uint8_t* done,

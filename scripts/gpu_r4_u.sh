@@ -1,5 +1,6 @@
 #!/bin/bash
 # DRQN: W_ih / W_hh weight gradients on the two side streams, fc1's ahead of the join -- recurrent tests + A/B vs the committed library
+# (build the previous commit's library into gpurun_keep/libtsengine_prev.so first: git stash; build; cp; git stash pop; build)
 O=$GRAFT_REPO_ROOT/gpurun_out/r4u; rm -rf $O; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 200 python -m pytest tests/test_gpu_drqn.py tests/test_gpu_recurrent_nets.py tests/test_gpu_hooks.py -m gpu -q > $O/pytest.txt 2>&1; grep -n "passed\|failed" $O/pytest.txt | tail -2

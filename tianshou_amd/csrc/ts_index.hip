@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void stacked_rows_pair_kernel(const float* __r
             slot[wave][which][T - 1 - j] = idx;
         }
     }
-    if (b < B && lane == 1 && act_col) act_out[b] = act_col[index[b]];
+    if (b < B && lane == 1 && act_col) act_out[b] = act_col[pymod(index[b], offset[E])];    // act[index] with Python's negative indices
     __syncthreads();
     if (b >= B) return;
     const int per = T * D;
