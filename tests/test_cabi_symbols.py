@@ -122,3 +122,39 @@ def test_python_call_sites_pass_as_many_arguments_as_the_header_declares():
             assert n == protos[f.attr], f"{fn}:{call.lineno}: {f.attr} takes {protos[f.attr]} arguments, call passes {n}"
             checked += 1
     assert checked >= 60, checked
+
+
+def test_ctypes_structures_match_the_header_structs():
+    """Every `typedef struct ts_* { ... }` of include/tsengine.h against its ctypes mirror in the package: the same number of
+    members with the same sizes in the same order (a renamed / added / reordered member on one side only would shift
+    every later one -- nothing else would notice until a kernel read a wrong hyper-parameter)."""
+    import ctypes as C
+    import re
+
+    from tianshou_amd import _lib, distq, dqn, drqn, npg, redq, sac, td3
+
+    mirrors = {"ts_ppo_hparams": _lib.PPOHParams, "ts_dqn_hparams": dqn.DQNHParams, "ts_distq_hparams": distq.DistQHParams,
+               "ts_rows_replay": drqn.RowsReplay, "ts_npg_hparams": npg.NPGHParams, "ts_sac_hparams": sac.SACHParams,
+               "ts_sac_state": sac.SACStateC, "ts_redq_state": redq.REDQStateC, "ts_td3_hparams": td3.TD3HParams,
+               "ts_td3_state": td3.TD3StateC}
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    sizes = {"double": 8, "float": 4, "int64_t": 8, "uint64_t": 8, "int32_t": 4, "int": 4, "uint8_t": 1}
+    seen = set()
+    for body, name in re.findall(r"typedef\s+struct\s+ts_\w+\s*\{(.*?)\}\s*(ts_\w+)\s*;", text, flags=re.S):
+        if name == "ts_scatter_key":                      # built inline in buffer.py
+            continue
+        assert name in mirrors, f"{name}: no ctypes mirror registered in this test"
+        seen.add(name)
+        want = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            base = re.match(r"(?:const\s+)?(\w+)", decl).group(1)
+            for item in decl[decl.index(base) + len(base):].split(","):
+                item = item.strip()
+                want.append((item.lstrip("* ").strip(), 8 if "*" in item else sizes[base]))        # pointers: 8 bytes
+        got = [(f[0], C.sizeof(f[1])) for f in mirrors[name]._fields_]
+        assert [w[1] for w in want] == [g[1] for g in got], (name, want, got)
+        assert len(want) == len(got)
+        # members carry the same names on both sides, except where the Python side groups pointers under its own names
+        if not name.endswith("_state"):
+            assert [w[0] for w in want] == [g[0] for g in got], (name, want, got)
+    assert seen == set(mirrors)
