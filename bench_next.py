@@ -674,10 +674,9 @@ def run_drqn(steps, warmup, with_cpu, slots=20000):
     prefetch = not os.environ.get("TS_DRQN_NO_PREFETCH")
     # uniform buffer: the next batch (indices, both stacked gathers, actions, n-step coefficients) depends on nothing of the
     # update and is prepared on a second stream beside it
-    replay = (D.ReplayStream(eng, buf, buf.obs, None, T, draw, None, prepare=R.replay_prepare(eng, buf, buf.obs, T, buf.act))
-              if not os.environ.get("TS_DRQN_NO_REPLAY_STREAM") else None)
-
     one_call = not os.environ.get("TS_DRQN_NO_LEARN_STEP")      # sample + preprocess + update as ONE library call (default)
+    replay = (D.ReplayStream(eng, buf, buf.obs, None, T, draw, None, prepare=R.replay_prepare(eng, buf, buf.obs, T, buf.act))
+              if not one_call and not os.environ.get("TS_DRQN_NO_REPLAY_STREAM") else None)
 
     def update():
         if one_call:
