@@ -1,4 +1,6 @@
 """Phase timing of one ppo_step_kernel launch (workgroup 0, wave 0), shader-clock cycles.
+NETS=1 | 2 in the environment: the one-network kernel (ts_ppo_hparams.nets) on the actor / the critic alone -- only that half's
+marks are written (the other half's slots stay 0, read the "(at ...)" column); NROWS: rows per launch.
 Builds its own copy of the library with -DTS_PHASE_MARKS (the shipped one carries neither the marks nor the entry point)."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.getcwd())
@@ -15,6 +17,7 @@ L = bench.Learner(dev, 0, 1)
 b = L.preprocess()
 lib = _lib.load()
 hp = L.cfg.to_c()
+hp.nets = int(os.environ.get("NETS", "0"))      # NETS=1 / 2: ppo_step1_kernel on the actor / the critic alone (one half's phases)
 from tianshou_amd.ppo import pack_batch
 rec = pack_batch(b, 17, 6)
 V1 = os.environ.get("TS_PPO_STEP_V1", "0") not in ("", "0")

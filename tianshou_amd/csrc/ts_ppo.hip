@@ -1090,6 +1090,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
     const int64_t n_iter = (n_tiles + per_iter - 1) / per_iter;   // same for every wave: barriers inside
     const int64_t tile0 = (int64_t)blockIdx.x * STEP_WAVES + wave0;
     float* slab = g.slabs + (int64_t)blockIdx.x * g.slab_w;
+    TS_MARK(g, 0);
     {   // the absent network's columns: [0, w1[1]) = actor incl. sigma, [w1[1], loss) = critic; its loss sum
         const int z0 = net == 0 ? SL.w1[1] : 0, z1 = net == 0 ? SL.loss : SL.w1[1];
         for (int c = z0 + (int)threadIdx.x; c < z1; c += STEP_THREADS) slab_st(slab + c, 0.f);
@@ -1106,6 +1107,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
         stage_image<KS1, STEP_THREADS>(lds, g.image + (net ? L::END : 0), 64 * wave + lane);
         const TileIn<KS1> in = rec_commit<KS1>(f, g, d, scratch, lane);
         __syncthreads();
+        TS_MARK(g, 1);
         const bool first = it == 0;
         f32x16 h1[2], h2[2], dz1[2];
         float misc;
@@ -1119,6 +1121,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
             net_wgrad<KS1, false>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
         }
     }
+    TS_MARK(g, 17);     // (-DTS_PHASE_MARKS builds only; the phases in between are marked inside net_fwd_bwd / net_wgrad)
 }
 
 // ---------------------------------------------------------------------------------------------
