@@ -177,3 +177,26 @@ def test_recurrent_actor_critic_layout_converters_round_trip_and_reject_conditio
     fake = types.SimpleNamespace(_c_sigma=True)
     with pytest.raises(NotImplementedError, match="conditioned_sigma"):
         R.RecurrentActorProbEngine.from_module(fake)
+
+
+def test_replay_stream_flattens_nested_batches_and_reinforce_statistics_round_trip():
+    """Host logic that needs no GPU: dqn.ReplayStream._tensors walks the nested tuples a `prepare` callable returns (every
+    tensor gets its record_stream call, None entries are skipped); ReinforceEngine.ret_rms is a plain list on the host until
+    `preprocess` moves it to the device (assigning it replaces the device copy)."""
+    from tianshou_amd import reinforce as RF
+    from tianshou_amd.dqn import ReplayStream
+
+    a, b, c, d = (torch.zeros(k + 1) for k in range(4))
+    nested = (a, None, (b, (c, None)), [d], 3, "x")
+    assert [t.numel() for t in ReplayStream._tensors(nested)] == [1, 2, 3, 4]
+    assert list(ReplayStream._tensors(None)) == []
+    eng = RF.ReinforceEngine.__new__(RF.ReinforceEngine)        # the statistics property alone (the constructor needs a GPU)
+    eng._rms_host, eng._rms_dev = [0.0, 1.0, 0.0], None
+    assert eng.ret_rms == [0.0, 1.0, 0.0]
+    eng.ret_rms = (0.5, 2, 7)
+    assert eng.ret_rms == [0.5, 2.0, 7.0] and eng._rms_dev is None
+    eng._rms_dev = torch.tensor([1.5, 0.25, 9.0], dtype=torch.float64)          # what preprocess leaves behind
+    assert eng.ret_rms == [1.5, 0.25, 9.0]
+    got = eng.ret_rms
+    got[0] = -1.0                                                # a copy: callers cannot edit the engine's state through it
+    assert eng.ret_rms[0] == 1.5
