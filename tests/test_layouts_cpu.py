@@ -200,3 +200,23 @@ def test_replay_stream_flattens_nested_batches_and_reinforce_statistics_round_tr
     got = eng.ret_rms
     got[0] = -1.0                                                # a copy: callers cannot edit the engine's state through it
     assert eng.ret_rms[0] == 1.5
+
+
+def test_tensor_form_of_the_running_statistics_update_equals_the_host_form():
+    """reinforce.rms_merge_tensors (what Reinforce's preprocess runs on the device) against ppo.rms_merge (Python floats, the
+    form every other engine uses and the oracle pins): bit-identical over a chain of updates, including a zero-variance batch."""
+    from tianshou_amd.ppo import rms_merge
+    from tianshou_amd.reinforce import rms_merge_tensors
+
+    rng = np.random.default_rng(0)
+    host = [0.0, 1.0, 0.0]
+    dev = torch.tensor(host, dtype=torch.float64)
+    for it in range(40):
+        n = int(rng.integers(1, 5000))
+        x = rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4) + rng.standard_normal() * 5
+        if it == 7:
+            x = np.full(n, 3.25)
+        s1, s2 = float(x.sum()), float((x * x).sum())
+        host = rms_merge(host, s1, s2, float(n))
+        dev = rms_merge_tensors(dev, torch.tensor(s1, dtype=torch.float64), torch.tensor(s2, dtype=torch.float64), n)
+        assert dev.tolist() == host, it

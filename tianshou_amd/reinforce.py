@@ -29,6 +29,17 @@ class ReinforceConfig:
     max_grad_norm: float | None = None
 
 
+def rms_merge_tensors(rms: torch.Tensor, s1: torch.Tensor, s2: torch.Tensor, n: int) -> torch.Tensor:
+    """ppo.rms_merge (RunningMeanStd.update, utils/statistics.py:99-114) on float64 tensors: rms = [mean, var, count], s1 / s2
+    = sum and sum of squares of the batch (0-dim) -> the new [mean, var, count].  The same IEEE operations in the same order
+    as the host version, wherever the tensors live."""
+    mean, var, count = rms[0], rms[1], rms[2]
+    b_mean = s1 / n
+    b_var = torch.clamp(s2 / n - b_mean * b_mean, min=0.0)
+    delta, tot = b_mean - mean, count + n
+    return torch.stack([mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot])
+
+
 class ReinforceEngine:
     """State of one Reinforce learner on one GPU: flat actor + Adam moments + the running return statistics."""
 
@@ -84,10 +95,7 @@ class ReinforceEngine:
         ret = ((out["ret64"] - mean) / torch.sqrt(var + 1e-8)).to(torch.float32)          # reinforce.py:305-307
         # ret_rms.update(unnormalised returns), statistics.py:99-114: the same float64 operations in the same order, on the
         # device (no host round trip between two updates)
-        b_mean = out["ret_sum"] / n
-        b_var = torch.clamp(out["ret_sumsq"] / n - b_mean * b_mean, min=0.0)
-        delta, tot = b_mean - mean, count + n
-        self._rms_dev = torch.stack([mean + delta * n / tot, (var * count + b_var * n + delta * delta * count * n / tot) / tot, tot])
+        self._rms_dev = rms_merge_tensors(self._rms_dev, out["ret_sum"], out["ret_sumsq"], n)
         return ret
 
     # -- one minibatch (reinforce.py:371-380) ----------------------------------------------------------------------------
