@@ -29,7 +29,7 @@ timeout 300 python scripts/gpu_conv2_check.py bench 65536 16384 4096 512 > $O/co
 bash scripts/gpu_conv2_pmc.sh 65536 conv1u8,conv2,conv3,fc1 > $O/conv2_pmc_log.txt 2>&1
 cp gpurun_out/pmc_conv2/pmc_conv2.txt $O/pmc_conv2.txt 2>/dev/null
 # SQ counters + HBM traffic of the PPO step kernel at HEAD
-TS_PPO_STEP=2 bash scripts/gpu_r2_pmc.sh > $O/pmc_step_log.txt 2>&1
+bash scripts/gpu_r2_pmc.sh > $O/pmc_step_log.txt 2>&1
 cp gpurun_out/pmc/pmc_step_mode2.txt $O/pmc_ppo_step2.txt 2>/dev/null
 bash scripts/gpu_pmc_traffic.sh > $O/pmc_traffic_log.txt 2>&1
 ls gpurun_out/ | head -30

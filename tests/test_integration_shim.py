@@ -1526,9 +1526,16 @@ def test_device_permutation_key_follows_numpy_seed_and_travels_in_the_checkpoint
     assert np.array_equal(before, np.random.get_state()[1])            # the reference's stream is not consumed
     a._hip_updates = 7
     sd = a.state_dict()
-    assert sd["_hip_perm_state"].tolist() == [a._hip_perm_seed, 7]
-    c.load_state_dict(sd)
+    ref = build(PPO)
+    assert set(sd) == set(ref.state_dict())                            # the reference's checkpoint format, nothing added
+    ref.load_state_dict(dict(sd), strict=True)                         # a HipPPO checkpoint loads into the reference class
+    c.load_state_dict(dict(sd))                                        # (the reference's load pops `_optimizers`: copies)
+    c.load_hip_extra_state(a.hip_extra_state())
     assert (c._hip_perm_seed, c._hip_updates) == (a._hip_perm_seed, 7)
+    legacy = dict(sd); legacy["_hip_perm_state"] = torch.tensor([3, 9])  # round-4 checkpoints carried the pair inline
+    c.load_state_dict(legacy)
+    assert (c._hip_perm_seed, c._hip_updates) == (3, 9)
+    c.load_hip_extra_state(a.hip_extra_state())
     ref_sd = build(PPO).state_dict()
     c.load_state_dict(ref_sd)                                          # a checkpoint written by the reference class
     assert (c._hip_perm_seed, c._hip_updates) == (a._hip_perm_seed, 7)

@@ -458,12 +458,16 @@ int ts_mlp_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     if (int rc = ts::ws_reserve(ws, b_chunks + b_coef + b_off + b_stats)) return rc;
     char* base = static_cast<char*>(ws->base);
     hipStream_t s = ts::as_stream(stream);
-    // pageable sources: the runtime stages them before returning, the vectors may go out of scope
+    // pageable sources: an event behind the copies is waited for before returning (the vectors go out of scope)
     TS_HIP_CHECK(hipMemcpyAsync(base, chunks.data(), sizeof(Chunk) * chunks.size(), hipMemcpyHostToDevice, s));
     TS_HIP_CHECK(hipMemcpyAsync(base + b_chunks, coef.data(), sizeof(StepCoef) * coef.size(), hipMemcpyHostToDevice, s));
     float* stats = nullptr;
-    if (norm) {
+    if (norm)
         TS_HIP_CHECK(hipMemcpyAsync(base + b_chunks + b_coef, off.data(), sizeof(long long) * off.size(), hipMemcpyHostToDevice, s));
+    hipEvent_t copied;
+    TS_HIP_CHECK(hipEventCreateWithFlags(&copied, hipEventDisableTiming));
+    TS_HIP_CHECK(hipEventRecord(copied, s));
+    if (norm) {
         stats = reinterpret_cast<float*>(base + b_chunks + b_coef + b_off);
         hipLaunchKernelGGL(small_adv_stats_kernel, dim3((unsigned)n_steps), dim3(256), 0, s, adv, rows,
                            reinterpret_cast<const long long*>(base + b_chunks + b_coef), stats);
@@ -490,9 +494,11 @@ int ts_mlp_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     }
     hipLaunchKernelGGL(mlp_ppo_update_small_kernel, dim3(1), dim3(NT), lds, s, a);
     TS_LAUNCH_CHECK();
-    // the staged host vectors must outlive the copies: pageable hipMemcpyAsync returns after staging on ROCm, but the
-    // contract is not documented for every case -- synchronise the (sub-millisecond) copies' stream position instead
+    // the host vectors above are pageable stack objects: wait until the three table copies have read them (the event
+    // sits right behind the copies, in front of the kernels -- the update itself stays asynchronous)
     (void)n;
+    TS_HIP_CHECK(hipEventSynchronize(copied));
+    TS_HIP_CHECK(hipEventDestroy(copied));
     return TS_OK;
 }
 

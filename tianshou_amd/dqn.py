@@ -259,7 +259,9 @@ class DQNEngine:
             _lib.check(lib.ts_workspace_side_stream(self._ws.handle, C.c_int(1), C.byref(h)))
             self._side = torch.cuda.ExternalStream(h.value, device=self.device)
             self._cache = None
-        if self._cache is None or self._cache.numel() < need:
+        if self._cache is None or self._cache.numel() < need + 256:       # + 256: the pointer is aligned up below
+            if self._cache is not None:
+                self._cache.record_stream(self._side)                     # a side-stream kernel may still be reading it
             self._cache = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
         base = self._cache.data_ptr()
         cache_ptr = C.c_void_p((base + 255) & ~255)
@@ -446,6 +448,9 @@ class ReplayStream:
     Rainbow).  `eng` is any engine with `wait_td` (its update records the event behind its priority kernel)."""
 
     def __init__(self, eng, buffer: DeviceReplayBuffer, frames: torch.Tensor, per, stack_num: int, draw, act_of, prepare=None):
+        if per is not None and not hasattr(eng, "wait_td"):
+            raise NotImplementedError(f"{type(eng).__name__} records no TD-error event (wait_td): prioritized replay needs "
+                                      "an engine whose update calls ts::record_td (DQN / QRDQN / C51 / Rainbow)")
         self.eng, self.buffer, self.frames, self.per, self.stack, self.draw, self.act_of = eng, buffer, frames, per, stack_num, draw, act_of
         self.prepare = prepare if prepare is not None else self._dqn_prepare
         self.stream = torch.cuda.Stream(device=eng.device)
@@ -499,6 +504,7 @@ class ReplayStream:
         """After `update_with_batch`: priority update with its TD errors and the next batch, beside the rest of the update.
         Without priorities (`per` None) only the next batch: it depends on nothing of the update."""
         if self.per is None:
+            self.stream.wait_stream(torch.cuda.current_stream(self.eng.device))    # buffer writes enqueued so far
             with torch.cuda.stream(self.stream):
                 self._sample()
             return

@@ -278,7 +278,8 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             Batch.split's shuffles, and NumPy's global generator -- which the collector shares -- is left untouched.
             `perm_seed=None` takes ONE draw from NumPy's global generator at construction, so that `np.random.seed` /
             `seed_everything` select the shuffle sequence as they do in the reference (pass an int to fix it); the seed and
-            the update counter travel in `state_dict()` (a resumed run continues the sequence).
+            the update counter are saved with `hip_extra_state()` / restored with `load_hip_extra_state()` (a resumed run
+            continues the sequence); `state_dict()` itself keeps the reference's format.
             "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209): the reference's
             sequence for a given seed (the mode the parity tests use), at ~10 ms of host time per 2^20 entries -- 100 ms
             of a 12 ms update(), i.e. ~1.4 k instead of ~14 k update-steps/s at the C2 size."""
@@ -297,20 +298,22 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             self._hip_batch = None
             self._hip_synced = False
 
-        # -- the shuffle key is part of the checkpoint -------------------------------------------------
-        def state_dict(self, *args, **kwargs):
-            sd = super().state_dict(*args, **kwargs)
-            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
-            sd[prefix + "_hip_perm_state"] = torch.tensor([self._hip_perm_seed, self._hip_updates], dtype=torch.int64)
-            return sd
+        # -- the shuffle key travels BESIDE the checkpoint ---------------------------------------------
+        # state_dict() stays in the reference's format (a HipPPO checkpoint loads into the reference PPO / A2C class with
+        # strict=True, nested in a parent module or not); the (seed, update counter) pair of the device permutations is
+        # saved / restored explicitly, e.g. torch.save({"model": algo.state_dict(), "hip": algo.hip_extra_state()}, f).
+        def hip_extra_state(self) -> dict:
+            return {"perm_seed": int(self._hip_perm_seed), "updates": int(self._hip_updates)}
+
+        def load_hip_extra_state(self, state: dict) -> None:
+            self._hip_perm_seed, self._hip_updates = int(state["perm_seed"]), int(state["updates"])
 
         def load_state_dict(self, state_dict, *args, **kwargs):
-            state_dict = dict(state_dict)
-            st = state_dict.pop("_hip_perm_state", None)          # absent in checkpoints of the reference class
-            out = super().load_state_dict(state_dict, *args, **kwargs)
-            if st is not None:
+            if "_hip_perm_state" in state_dict:                   # checkpoints of round-4 builds carried the pair inline
+                state_dict = dict(state_dict)
+                st = state_dict.pop("_hip_perm_state")
                 self._hip_perm_seed, self._hip_updates = int(st[0]), int(st[1])
-            return out
+            return super().load_state_dict(state_dict, *args, **kwargs)
 
         # -- engine life cycle ------------------------------------------------------------------
         def _hip_flat(self, tensors) -> torch.Tensor:

@@ -170,10 +170,13 @@ class DiscretePPOEngine:
                 rows = torch.cat([_i64_dev(perms[r], self.device).reshape(-1) for r in grp]).contiguous()
                 h_off = np.asarray([k * n + o for k in range(len(grp)) for o in offs[:-1]] + [len(grp) * n], dtype=np.int64)
                 k0 = grp[0] * per
+                # converted copies stay bound until the call has enqueued its kernels (a temporary's block could be handed
+                # to the next conversion before the launch)
+                adv_f, ret_f, lp_f, vs_f = f32(pre["adv"]), f32(pre["returns"]), f32(pre["logp_old"]), f32(pre["v_s"])
                 _lib.check(lib.ts_mlp_ppo_update(
                     self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step),
-                    *self._dims(), _lib.ptr(obs_f), _lib.ptr(act_i), _lib.ptr(f32(pre["adv"])), _lib.ptr(f32(pre["returns"])),
-                    _lib.ptr(f32(pre["logp_old"])), _lib.ptr(f32(pre["v_s"])), _lib.i64(n), _lib.ptr(rows),
+                    *self._dims(), _lib.ptr(obs_f), _lib.ptr(act_i), _lib.ptr(adv_f), _lib.ptr(ret_f),
+                    _lib.ptr(lp_f), _lib.ptr(vs_f), _lib.i64(n), _lib.ptr(rows),
                     h_off.ctypes.data_as(C.c_void_p), _lib.i64(len(grp) * per), C.byref(hp), _lib.ptr(losses[k0:k0 + len(grp) * per]),
                     _lib.current_stream(self.device)))
                 self.adam_step += len(grp) * per
