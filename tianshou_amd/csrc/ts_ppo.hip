@@ -1124,13 +1124,15 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
     TS_MARK(g, 17);     // (-DTS_PHASE_MARKS builds only; the phases in between are marked inside net_fwd_bwd / net_wgrad)
 }
 
+#include "ts_ppo_q.h"
+
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
 // partial sum of squares over the parameter columns (for the global gradient norm).
 constexpr int RED_THREADS = 1024;
 
 __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const float* __restrict__ slabs,
-                                                                       int n_slabs, int slab_w, Dims d, int kp,
+                                                                       int n_slabs, int slab_w, Dims d, int kp, int k1q,
                                                                        float* __restrict__ grad,
                                                                        float* __restrict__ sumsq_part,
                                                                        const float* __restrict__ params,
@@ -1152,7 +1154,8 @@ __global__ __launch_bounds__(RED_THREADS) void ppo_reduce_slabs_kernel(const flo
 #pragma unroll
         for (int k = 0; k < RED_THREADS / 64; ++k) t += red[k][lane];
         // slab column -> flat parameter index (second-generation slabs keep W1 | b1 as one augmented matrix)
-        const int pidx = col < slab_w ? slab_col_to_param(col, d, kp) : -1;
+        // (k1q > 0: the slabs come from ppo_stepq_kernel, transposed sections, see ts_ppo_q.h)
+        const int pidx = col < slab_w ? (k1q > 0 ? q4::slab3_col_to_param(col, d, k1q) : slab_col_to_param(col, d, kp)) : -1;
         // data-parallel path (parts != NULL): grad holds only the n_params gradient columns, the two loss sums go
         // to parts[1] (clip) and parts[2] (vf); parts[3] = entropy below, parts[0] is composed by the caller
         if (pidx >= 0 && pidx < (parts ? n_params : n_params + N_EXTRA)) grad[pidx] = t;
@@ -1416,6 +1419,56 @@ inline int step_grid(int64_t n_rows) {
     return (int)wg;
 }
 
+// Which step kernel runs a minibatch of `n_rows` rows, and the slab geometry that goes with it.
+//   variant 0: ppo_step2_kernel / ppo_step1_kernel (128-sample workgroups, LDS weight image, 2 workgroups per CU)
+//   variant 1: ppo_stepq_kernel (ts_ppo_q.h: 32-sample tiles split by features over 4 waves, one network per
+//              workgroup, persistent over tiles, 4 workgroups per CU); n_slabs = workgroup PAIRS
+// TS_PPO_STEPQ=0 / 1 forces a variant (A/B runs); TS_PPO_STEPQ_PAIRS caps the pairs (slab count / tiles per workgroup).
+struct StepPlan { int variant, grid, n_slabs, slab_w, k1s; };
+
+inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
+    // (read per call, not cached: A/B scripts flip them inside one process)
+    const char* e_force = getenv("TS_PPO_STEPQ");
+    const char* e_pairs = getenv("TS_PPO_STEPQ_PAIRS");
+    const int force = e_force ? atoi(e_force) : -1, pairs_cap = e_pairs ? atoi(e_pairs) : 0;
+    StepPlan pl{};
+    const int k1s = q4::k1s_for(d.obs);
+    const bool q = force < 0 ? k1s > 0 : (force != 0 && k1s > 0);
+    if (!q) {
+        pl.variant = 0;
+        pl.grid = pl.n_slabs = step_grid(n_rows);
+        pl.slab_w = slab_width(d, ks);
+        return pl;
+    }
+    pl.variant = 1;
+    pl.k1s = k1s;
+    pl.slab_w = q4::slab3_layout(4 * k1s).width;
+    const int64_t tiles = (n_rows + 31) / 32;
+    // four 256-thread workgroups per CU (<= 128 VGPRs, <= 40 KB LDS): half of them per network
+    int64_t pairs = 2 * (int64_t)n_compute_units();
+    if (pairs_cap > 0 && pairs > pairs_cap) pairs = pairs_cap;
+    if (pairs > tiles) pairs = tiles;
+    if (pairs < 1) pairs = 1;
+    pl.n_slabs = (int)pairs;
+    pl.grid = (nets == 1 || nets == 2) ? (int)pairs : 2 * (int)pairs;
+    return pl;
+}
+
+template <int K1S>
+int launch_stepq(ts_workspace* ws, const StepArgs& g, const Dims& d, const StepPlan& pl, hipStream_t s) {
+    const size_t lds = q4::stepq_lds_bytes<K1S>(g.rec_w);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::ppo_stepq_kernel<K1S>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
+    hipLaunchKernelGGL((q4::ppo_stepq_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
 inline void fill_hparams(StepArgs& g, const ts_ppo_hparams* hp) {
     g.eps_clip = (float)hp->eps_clip;
     g.dual_clip = (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
@@ -1492,18 +1545,28 @@ int dp_image(ts_workspace* ws, hipStream_t s, const float* params, const Dims& d
 
 // forward/backward + slab reduction of one minibatch: grad[0..P) unclipped gradient,
 // grad[P], grad[P+1] clip / vf loss sums, sumsq partials, losses[3] = entropy (if losses)
-int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, int slab_w, float* slabs, float* grad,
+int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, const StepPlan& pl, float* slabs, float* grad,
              float* sumsq, float* losses, hipStream_t s, float* parts = nullptr) {
     const int64_t obs_dim = d.obs;
     int rc = TS_OK;
-    const int n_wg = step_grid(g.n_rows);
-    g.slabs = slabs; g.slab_w = slab_w;
-    TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
+    g.slabs = slabs; g.slab_w = pl.slab_w;
+    if (pl.variant == 1) {
+        switch (pl.k1s) {
+            case 2: rc = launch_stepq<2>(ws, g, d, pl, s); break;
+            case 3: rc = launch_stepq<3>(ws, g, d, pl, s); break;
+            case 5: rc = launch_stepq<5>(ws, g, d, pl, s); break;
+            case 8: rc = launch_stepq<8>(ws, g, d, pl, s); break;
+            default: return ts::fail(TS_ERR_UNSUPPORTED, "obs_dim %d not supported by the feature-split step kernel", d.obs);
+        }
+    } else {
+        TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, pl.grid, s); });
+    }
     if (rc != TS_OK) return rc;
     {
         ts::ProfScope prof(ws, TS_KIND_PPO_REDUCE, s);
-        hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
-                           n_wg, slab_w, d, 2 * ks, grad, sumsq, g.params, losses, parts);
+        hipLaunchKernelGGL(ppo_reduce_slabs_kernel, dim3((pl.slab_w + 63) / 64), dim3(RED_THREADS), 0, s, slabs,
+                           pl.n_slabs, pl.slab_w, d, 2 * ks, pl.variant == 1 ? 4 * pl.k1s : 0, grad, sumsq, g.params, losses,
+                           parts);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1646,9 +1709,10 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     }
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const int slab_w = slab_width(d, ks);
+    const StepPlan pl_max = plan_step(d, ks, max_rows, hp->nets);      // the largest minibatch sizes the slab area
+    const int slab_w = pl_max.slab_w;
     const int rw = rec_width(obs_dim, act_dim);
-    const WsLayout wl = ws_layout(step_grid(max_rows), slab_w, n_steps);
+    const WsLayout wl = ws_layout(pl_max.n_slabs, slab_w, n_steps);
     // behind the fixed part: device copy of the minibatch offsets, then the packed records
     const size_t off_bytes = (sizeof(int64_t) * (size_t)(n_steps + 1) + 255) & ~(size_t)255;
     const size_t rec_bytes = (sizeof(float) * (size_t)n * rw + 255) & ~(size_t)255;
@@ -1691,7 +1755,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
-        rc = run_grad(ws, g, d, ks, slab_w, slabs, grad, sumsq, losses, s);
+        rc = run_grad(ws, g, d, ks, plan_step(d, ks, g.n_rows, hp->nets), slabs, grad, sumsq, losses, s);
         if (rc != TS_OK) return rc;
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
         a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
@@ -1724,8 +1788,8 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
                "ts_ppo_grad: rec must be 16-byte aligned");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const int slab_w = slab_width(d, ks);
-    const WsLayout wl = ws_layout(step_grid(n_rows), slab_w, 1);
+    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets);
+    const WsLayout wl = ws_layout(pl.n_slabs, pl.slab_w, 1);
     rc = ts::ws_reserve(ws, wl.total);
     if (rc != TS_OK) return rc;
     char* base = reinterpret_cast<char*>(ws->base);
@@ -1741,7 +1805,7 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
     fill_hparams(g, hp);
     // the slab reduction writes the gradient straight into grad_out and the loss sums into loss_parts_out
     float* parts = loss_parts_out ? loss_parts_out : reinterpret_cast<float*>(base + wl.advstats);
-    return run_grad(ws, g, d, ks, slab_w, reinterpret_cast<float*>(base + wl.slabs), grad_out,
+    return run_grad(ws, g, d, ks, pl, reinterpret_cast<float*>(base + wl.slabs), grad_out,
                     reinterpret_cast<float*>(base + wl.sumsq), nullptr, s, parts);
 }
 
