@@ -68,6 +68,10 @@ def check():
                                                 advantage_normalization=False, lr=3e-4)),
         ("obs 27 act 8", 1024, 27, 8, 1024, 1, dict(eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, value_clip=True,
                                                    advantage_normalization=False, lr=3e-4)),
+        ("obs 21 act 1 (last k-step leaves the record)", 1000, 21, 1, 500, 1, dict(eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5,
+                                                                                  value_clip=True, advantage_normalization=False, lr=3e-4)),
+        ("obs 13 act 4", 900, 13, 4, 300, 1, dict(eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, value_clip=False,
+                                                 advantage_normalization=True, lr=3e-4)),
         ("one tile", 20, 17, 6, 20, 1, dict(eps_clip=0.2, vf_coef=0.5, ent_coef=0.0, max_grad_norm=0.5, value_clip=True,
                                            advantage_normalization=False, lr=3e-4)),
         ("many tiles per workgroup", 65536 + 40, 17, 6, 65536 + 40, 1, dict(eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5,
@@ -88,10 +92,10 @@ def check():
         lo, go = OP.update(st, OP.PPOConfig(**okw), {"obs": tb["obs"], "act": tb["act"]},
                            {k: tb[k] for k in ("adv", "returns", "logp_old", "v_s")}, batch, repeat, perms, collect_grads=True)
         go = go.numpy()
-        res = {v: run_engine(v, params, b, obs_dim, act_dim, kw, batch, repeat, perms) for v in (0, 1)}
+        res = {v: run_engine(v, params, b, obs_dim, act_dim, kw, batch, repeat, perms) for v in (0, 1, 2)}
         print(f"== {name}: n={n} obs={obs_dim} act={act_dim} batch={batch} steps={len(lo)}")
         nets = kw.get("nets", 0)
-        for v in (0, 1):
+        for v in (0, 1, 2):
             l, g, p = res[v]
             line = []
             worst = 0.0
@@ -111,8 +115,8 @@ def check():
             flag = "" if worst < 2e-4 and lerr < 2e-5 else "   <<<<<< MISMATCH"
             bad += bool(flag)
             print(f"  variant {v}: loss rel err {lerr:.1e}; grad rel err per block  " + " ".join(line) + flag)
-        d01 = np.abs(res[0][2] - res[1][2]).max()
-        print(f"  params after {len(lo)} steps: max |variant0 - variant1| = {d01:.2e}")
+        d01, d02 = np.abs(res[0][2] - res[1][2]).max(), np.abs(res[0][2] - res[2][2]).max()
+        print(f"  params after {len(lo)} steps: max |variant0 - variant1| = {d01:.2e}, |variant0 - variant2| = {d02:.2e}")
     print("CHECK", "FAILED" if bad else "ok", f"({bad} mismatching lines)")
     return bad
 
@@ -128,7 +132,7 @@ def timing():
     perm = torch.randperm(n_total, device=DEV, generator=g)
     print("rows      variant pairs  step_us  reduce_us  adam_us   wall_us_per_step (16 steps back to back)")
     for rows in (65536, 32768, 16384, 8192, 4096):
-        for variant, pairs in ((0, 0), (1, 0), (1, 256), (1, 128), (1, 64)):
+        for variant, pairs in ((0, 0), (1, 0), (1, 256), (2, 0), (2, 384), (2, 128), (2, 64)):
             if pairs * 32 > rows:
                 continue
             os.environ["TS_PPO_STEPQ"] = str(variant)

@@ -1423,8 +1423,8 @@ inline int step_grid(int64_t n_rows) {
 //   variant 0: ppo_step2_kernel / ppo_step1_kernel (128-sample workgroups, LDS weight image, 2 workgroups per CU)
 //   variant 1: ppo_stepq_kernel (ts_ppo_q.h: 32-sample tiles split by features over 4 waves, one network per
 //              workgroup, persistent over tiles, 4 workgroups per CU); n_slabs = workgroup PAIRS
-// TS_PPO_STEPQ=0 / 1 forces a variant (A/B runs); TS_PPO_STEPQ_PAIRS caps the pairs (slab count / tiles per workgroup).
-struct StepPlan { int variant, grid, n_slabs, slab_w, k1s; };
+// TS_PPO_STEPQ=0 / 1 / 2 forces a variant (A/B runs); TS_PPO_STEPQ_PAIRS caps the pairs (slab count / tiles per workgroup).
+struct StepPlan { int variant, grid, n_slabs, slab_w, k1s, big; };
 
 inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
     // (read per call, not cached: A/B scripts flip them inside one process)
@@ -1444,9 +1444,11 @@ inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
     pl.k1s = k1s;
     pl.slab_w = q4::slab3_layout(4 * k1s).width;
     const int64_t tiles = (n_rows + 31) / 32;
-    // four 256-thread workgroups per CU (<= 128 VGPRs, <= 40 KB LDS): half of them per network
-    int64_t pairs = 2 * (int64_t)n_compute_units();
-    if (pairs_cap > 0 && pairs > pairs_cap) pairs = pairs_cap;
+    // TS_PPO_STEPQ=1: the 128-register build, four workgroups per CU; 2 (default): the 256-register build, two per CU --
+    // half of them per network
+    pl.big = force != 1;
+    int64_t pairs = (pl.big ? 1 : 2) * (int64_t)n_compute_units();
+    if (pairs_cap > 0) pairs = pairs_cap;
     if (pairs > tiles) pairs = tiles;
     if (pairs < 1) pairs = 1;
     pl.n_slabs = (int)pairs;
@@ -1456,15 +1458,18 @@ inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
 
 template <int K1S>
 int launch_stepq(ts_workspace* ws, const StepArgs& g, const Dims& d, const StepPlan& pl, hipStream_t s) {
-    const size_t lds = q4::stepq_lds_bytes<K1S>(g.rec_w);
+    const size_t lds = q4::stepq_lds_bytes(g.rec_w);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::ppo_stepq_kernel<K1S>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::ppo_stepq2_kernel<K1S>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
     ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-    hipLaunchKernelGGL((q4::ppo_stepq_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
+    if (pl.big) hipLaunchKernelGGL((q4::ppo_stepq2_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
+    else hipLaunchKernelGGL((q4::ppo_stepq_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -38,16 +38,17 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 struct Slab3 {
-    int w2t[2], w1t[2], b2[2], head[2], hb[2], sig, loss, width;
+    int w2t[2], w1t[2], b1[2], b2[2], head[2], hb[2], sig, loss, width;
 };
 
-// k1 = 4 * K1S (layer-1 contraction length incl. the bias column, zero-padded)
+// k1 = 4 * K1S (layer-1 contraction length: obs rounded up, zero weights beyond obs)
 __host__ __device__ inline Slab3 slab3_layout(int k1) {
     Slab3 L;
     int o = 0;
     for (int n = 0; n < 2; ++n) {
         L.w2t[n] = o; o += HID * HID;           // [f1][f2]
-        L.w1t[n] = o; o += k1 * HID;            // [k][f1]
+        L.w1t[n] = o; o += k1 * HID;            // [k][f1]  (columns k >= obs: products with the record's other fields, unused)
+        L.b1[n] = o; o += HID;
         L.b2[n] = o; o += HID;
         L.head[n] = o; o += n ? HID : HID * ACT_PAD;   // actor [f][8], critic [f]
         L.hb[n] = o; o += n ? 4 : ACT_PAD;
@@ -68,9 +69,11 @@ __device__ __forceinline__ int slab3_col_to_param(int col, const Dims& d, int k1
     c -= HID * HID;
     if (c < k1 * HID) {
         const int k = c >> 6, f = c & 63;
-        return k < d.obs ? (n ? d.c_w1 : d.a_w1) + f * d.obs + k : (k == d.obs ? (n ? d.c_b1 : d.a_b1) + f : -1);
+        return k < d.obs ? (n ? d.c_w1 : d.a_w1) + f * d.obs + k : -1;
     }
     c -= k1 * HID;
+    if (c < HID) return (n ? d.c_b1 : d.a_b1) + c;
+    c -= HID;
     if (c < HID) return (n ? d.c_b2 : d.a_b2) + c;
     c -= HID;
     if (n == 0) {
@@ -85,20 +88,18 @@ __device__ __forceinline__ int slab3_col_to_param(int col, const Dims& d, int k1
     return c == 0 ? d.c_bv : -1;
 }
 
-// LDS carve (floats).  REC (the tile's packed records, [32][rec_w]) comes last: its size is a run-time value.
-template <int K1S>
+// LDS carve (floats).  REC (the tile's packed records, [2][32][rec_w], double-buffered) comes last: its size is a run-time
+// value.
 struct LdsQ {
     static constexpr int R1 = 0;                       // sample-major: H1, later dout (own columns) and dZ2
     static constexpr int R2 = R1 + 32 * PS;            // feature-major, rows private to the owning wave: H2, dZ2, dZ1
     static constexpr int R3 = R2 + HID * PF;           // feature-major H1 (read by every wave in the weight gradients)
-    static constexpr int XF = R3 + HID * PF;           // feature-major Xaug [4 K1S][PF]
-    static constexpr int PP = XF + 4 * K1S * PF;       // head partials
+    static constexpr int PP = R3 + HID * PF;           // head partials
     static constexpr int SM = PP + P_FLOATS;           // [0..7] bmu, [8..15] 1/(2 sigma^2), [16..23] log sigma, [24] bv
     static constexpr int REC = SM + 32;
 };
 
-template <int K1S>
-inline size_t stepq_lds_bytes(int rec_w) { return sizeof(float) * (size_t)(LdsQ<K1S>::REC + 32 * rec_w); }
+inline size_t stepq_lds_bytes(int rec_w) { return sizeof(float) * (size_t)(LdsQ::REC + 2 * 32 * rec_w); }
 
 __device__ __forceinline__ void tanh4(f32x4& a) {
 #pragma unroll
@@ -131,7 +132,10 @@ __device__ __forceinline__ void st4(float* p, const f32x4& v) { *reinterpret_cas
 // 16-byte write-through store (global_store_dwordx4 ... sc1): the slabs are read by the reduction kernel right behind
 // the boundary; left dirty in the eight L2s they would be written back there
 __device__ __forceinline__ void slab_st4(float* p, const f32x4& v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"((gfloat_ptr)p), "v"(v) : "memory");
+    // s_nop 1: gfx940+ needs two wait states between a store of more than 8 bytes and a VALU write of its data registers;
+    // the hazard recognizer does not look inside inline asm, and the accumulators stored here are dead behind the store --
+    // LLVM reuses them at once (observed: the next store's address arithmetic landed in the previous store's data)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gfloat_ptr)p), "v"(v) : "memory");
 }
 
 // sum over the 16 lanes of a row (lanes that differ in bits 0..3)
@@ -200,12 +204,14 @@ using cgfloat_ptr = const __attribute__((address_space(1))) float*;
     [[maybe_unused]] const int n = lane & 15;        \
     [[maybe_unused]] const int gq = lane >> 4
 
-template <int K1S, bool ACTOR>
+// BIG: the 256-register build (two workgroups per CU): both operand forms of W2 and H1 stay in registers and the next
+// tile's records are fetched two phases earlier; !BIG: the 128-register build (four workgroups per CU).
+template <int K1S, bool ACTOR, bool BIG>
 __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, float* lds, int p, int n_pairs, float* slab,
                                           const Slab3& SL, bool zero_other) {
-    using L = LdsQ<K1S>;
+    using L = LdsQ;
     constexpr int net = ACTOR ? 0 : 1;
-    constexpr int NB1 = (4 * K1S + 15) / 16;               // 16-column blocks of dW1aug^T
+    constexpr int NB1 = (4 * K1S + 15) / 16;               // 16-column blocks of dW1^T
     const int lane0 = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), fb = 16 * w;     // wave index: scalar
     const int obs = d.obs, n_act = d.act, rec_w = g.rec_w;
@@ -215,7 +221,6 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
     float* R1 = lds + L::R1;
     float* R2 = lds + L::R2;
     float* R3 = lds + L::R3;
-    float* XF = lds + L::XF;
     float* PP = lds + L::PP;
     float* SM = lds + L::SM;
     float* REC = lds + L::REC;
@@ -223,24 +228,36 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ---- the wave's resident weights: MFMA A operands (lane = (row m = n, k = gq))
-    float W1a[K1S];                 // W1aug[fb + n][4 j + gq]
-    f32x4 B2;                       // b2[fb + 4 gq + r]: the accumulator rows of this lane
+    float W1a[K1S];                 // W1[fb + n][4 j + gq]  (0 beyond obs: those k-steps multiply the record's other fields)
+    f32x4 B1, B2;                   // b1 / b2[fb + 4 gq + r]: the accumulator rows of this lane (bias = initial accumulator)
     float WH[4];                    // actor: Wmu[n][fb + 4 gq + r] (rows >= act: 0);   critic: wv[fb + 4 gq + r]
     [[maybe_unused]] float WHb[2];  // actor: Wmu[4 r + gq][fb + n] (head backward, k = action)
     // W2 is NOT resident (its two operand forms are 32 registers: 3 waves per SIMD): every tile re-reads the forward form
     // W2[fb + n][.] during phase 1 and the backward form W2[.][fb + n] during phase 3, one phase ahead of their use (L2).
     int64_t rid;
+    [[maybe_unused]] float W2fr[16], W2tr[16];      // BIG: resident copies
     {
         TS_Q_LANE();
         rid = rowq_fetch(g, p, lane);           // first tile's row ids before anything else: the record gather depends on them
+        if constexpr (BIG) {
+#pragma unroll
+            for (int jr = 0; jr < 16; ++jr) {
+                const int f = 16 * (jr >> 2) + 4 * gq + (jr & 3);
+                W2fr[jr] = prm[o_w2 + (fb + n) * HID + f];
+                W2tr[jr] = prm[o_w2 + f * HID + fb + n];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < K1S; ++j) {
             const int k = 4 * j + gq;
-            const float v = prm[k < obs ? o_w1 + (fb + n) * obs + k : o_b1 + fb + n];
-            W1a[j] = k <= obs ? v : 0.f;
+            const float v = prm[o_w1 + (fb + n) * obs + (k < obs ? k : 0)];
+            W1a[j] = k < obs ? v : 0.f;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) B2[r] = prm[o_b2 + fb + 4 * gq + r];
+        for (int r = 0; r < 4; ++r) {
+            B1[r] = prm[o_b1 + fb + 4 * gq + r];
+            B2[r] = prm[o_b2 + fb + 4 * gq + r];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if constexpr (ACTOR) {
@@ -278,7 +295,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
             if (tid == 0) slab_st(slab + SL.loss + (1 - net), 0.f);
         }
         const RecQ<K1S> f0 = recq_fetch<K1S>(g, rid, tid, lane);
-        recq_commit<K1S>(f0, g, REC, tid);
+        recq_commit<K1S>(f0, g, REC, tid);              // tile 0 -> buffer 0
     }
 
     // ---- persistent accumulators (MFMA C layout: lane (col n, group gq) register r = row 4 gq + r)
@@ -288,32 +305,44 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
 #pragma unroll
     for (int c = 0; c < NB1; ++c) gW1[c] = zero4;
     f32x4 gH = zero4;               // actor: dWmu[4 gq + r][fb + n];  critic: lane-partial of dwv[fb + 4 gq + r]
-    float rs = 0.f;                 // lane-partial of db2[fb + n]
+    float rs = 0.f, rs1 = 0.f;      // lane-partials of db2[fb + n], db1[fb + n]
     float sD0 = 0.f, sD1 = 0.f, sS0 = 0.f, sS1 = 0.f, sL = 0.f;    // head-bias / sigma / loss partial sums
     __syncthreads();                                     // B0 of the first tile
+    int cur = 0;
 
     for (int64_t t = p; t < n_tiles; t += n_pairs) {
         const int64_t t_next = t + n_pairs;
         const bool has_next = t_next < n_tiles;          // uniform
+        const float* RC = REC + cur * 32 * rec_w;        // this tile's records; the other buffer receives the next tile's
+        float* RN = REC + (cur ^ 1) * 32 * rec_w;
         float W2f[16];                                   // W2[fb + n][16 jj + 4 gq + r]       (phase 2)
+        [[maybe_unused]] f32x4 h1[2];                    // BIG: H1 stays in registers for tanh' in phase 4
+        [[maybe_unused]] RecQ<K1S> fnext_big;
 
         // ================= phase 1: H1 = tanh(W1aug Xaug^T), own 16 features x 32 samples
         {
             TS_Q_LANE();
-            f32x4 acc[2] = {zero4, zero4};
+            if constexpr (BIG) rid = rowq_fetch(g, has_next ? t_next : t, lane);     // next tile's row ids
+            // B operands straight from the records: lane (sample 16 b + n, k = gq) reads field 4 j + gq (every read issued
+            // before the first MFMA; fields >= obs meet zero weights)
+            float xv[2][K1S];
 #pragma unroll
             for (int j = 0; j < K1S; ++j) {
                 const int k = 4 * j + gq;
-                const int kc = k < rec_w ? k : rec_w - 1;
+                const int kc = (4 * j + 3 < K1S * 4 - 4) ? k : (k < rec_w ? k : rec_w - 1);   // only the last k-step can leave the row
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float xv = REC[(16 * b + n) * rec_w + kc];
-                    if (4 * j + 3 >= obs) xv = k < obs ? xv : (k == obs ? 1.f : 0.f);
-                    acc[b] = mfma16(W1a[j], xv, acc[b]);
-                    if ((j & 3) == w) XF[k * PF + 16 * b + n] = xv;       // scalar condition: one wave writes each k-step
-                }
+                for (int b = 0; b < 2; ++b) xv[b][j] = RC[(16 * b + n) * rec_w + kc];
             }
-            {
+            f32x4 acc[2] = {B1, B1};
+#pragma unroll
+            for (int j = 0; j < K1S; ++j) {
+                acc[0] = mfma16(W1a[j], xv[0][j], acc[0]);
+                acc[1] = mfma16(W1a[j], xv[1][j], acc[1]);
+            }
+            if constexpr (BIG) {
+#pragma unroll
+                for (int jr = 0; jr < 16; ++jr) W2f[jr] = W2fr[jr];
+            } else {
                 const cgfloat_ptr pw = prm + o_w2 + (fb + n) * HID + 4 * gq;
 #pragma unroll
                 for (int jr = 0; jr < 16; ++jr) W2f[jr] = pw[16 * (jr >> 2) + (jr & 3)];
@@ -321,6 +350,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 tanh4(acc[b]);
+                if constexpr (BIG) h1[b] = acc[b];
                 st4(R1 + (16 * b + n) * PS + fb + 4 * gq, acc[b]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) R3[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][r];
@@ -332,6 +362,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
         f32x4 h2[2];
         {
             TS_Q_LANE();
+            if constexpr (BIG) fnext_big = recq_fetch<K1S>(g, rid, tid, lane);     // in flight during phases 2-4
             f32x4 acc[2] = {B2, B2};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -377,7 +408,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
         float W2t[16];                                   // W2[16 jj + 4 gq + r][fb + n]       (phase 4)
         {
             TS_Q_LANE();
-            rid = rowq_fetch(g, has_next ? t_next : t, lane);    // next tile's row ids: in flight during phase 3
+            if constexpr (!BIG) rid = rowq_fetch(g, has_next ? t_next : t, lane);    // next tile's row ids: in flight during phase 3
             f32x4 dz2[2];
             if constexpr (ACTOR) {
                 const int a0 = gq, a1 = 4 + gq;
@@ -391,7 +422,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int s = 16 * b + n;
-                    const float* rp = REC + s * rec_w;
+                    const float* rp = RC + s * rec_w;
                     float mu0 = bm0, mu1 = bm1;
 #pragma unroll
                     for (int ww = 0; ww < 4; ++ww) {
@@ -408,7 +439,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                     // Normal.log_prob summed over the action dimension (padding actions contribute an exact 0)
                     float logp = (-(d0 * d0) * iv0 - ls0 - c0) + (-(d1 * d1) * iv1 - ls1 - c1);
                     logp = group4_sum(logp);
-                    const float A = (adv - mean) / den;                                      // ppo.py:184-186
+                    const float A = g.adv_norm ? (adv - mean) / den : adv;                   // ppo.py:184-186 ((x - 0) / 1 == x)
                     const float ratio = a2c ? 1.f : expf(logp - logp_old);                   // :187
                     const float surr1 = ratio * A;
                     const float surr2 = fminf(fmaxf(ratio, lo), hi) * A;                     // :190
@@ -455,7 +486,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int s = 16 * b + n;
-                    const float* aux = REC + s * rec_w + obs + n_act;
+                    const float* aux = RC + s * rec_w + obs + n_act;
                     const float ret = aux[1], vo = aux[3];
                     const float wgt = (t * 32 + s < g.n_rows) ? g.inv_batch : 0.f;
                     float value = bv;
@@ -486,7 +517,10 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            {
+            if constexpr (BIG) {
+#pragma unroll
+                for (int jr = 0; jr < 16; ++jr) W2t[jr] = W2tr[jr];
+            } else {
                 const cgfloat_ptr pw = prm + o_w2 + fb + n + 4 * gq * HID;
 #pragma unroll
                 for (int jr = 0; jr < 16; ++jr) W2t[jr] = pw[(16 * (jr >> 2) + (jr & 3)) * HID];
@@ -505,7 +539,9 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
             TS_Q_LANE();
             // next tile's records: in flight during phase 4 (the longest one: 80 MFMAs), committed at its end -- nobody
             // reads REC behind B3
-            const RecQ<K1S> fnext = recq_fetch<K1S>(g, rid, tid, lane);
+            RecQ<K1S> fnext;
+            if constexpr (BIG) fnext = fnext_big;
+            else fnext = recq_fetch<K1S>(g, rid, tid, lane);
             f32x4 acc[2] = {zero4, zero4};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -519,10 +555,13 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {                // H1 back from the wave's own rows of R3 (not held in registers)
+            for (int b = 0; b < 2; ++b) {                // !BIG: H1 back from the wave's own rows of R3
                 f32x4 hv;
+                if constexpr (BIG) hv = h1[b];
+                else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = R3[(fb + 4 * gq + r) * PF + 16 * b + n];
+                    for (int r = 0; r < 4; ++r) hv[r] = R3[(fb + 4 * gq + r) * PF + 16 * b + n];
+                }
                 dtanh4(acc[b], hv);
             }
             // dW2[f2 own][f1] += sum_s dZ2[s][f2] H1[s][f1];  db2[f2] += sum_s dZ2[s][f2]
@@ -545,21 +584,27 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                 for (int r = 0; r < 4; ++r) R2[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][r];
             }
             wave_lds_sync();
-            // dW1aug[f1 own][k] += sum_s dZ1[s][f1] Xaug[s][k]   (k == obs: the bias column)
+            // dW1[f1 own][k] += sum_s dZ1[s][f1] X[s][k];  db1[f1] += sum_s dZ1[s][f1].  B operand from the records:
+            // lane (column k = 16 c + n, gq) reads field k of samples 16 J + 4 gq + r (columns >= obs are not stored)
 #pragma unroll
             for (int J = 0; J < 2; ++J) {
                 const f32x4 av = ld4(R2 + (fb + n) * PF + 16 * J + 4 * gq);
+                rs1 += (av[0] + av[1]) + (av[2] + av[3]);
 #pragma unroll
                 for (int c = 0; c < NB1; ++c) {
-                    const int k = 16 * c + n < 4 * K1S ? 16 * c + n : 4 * K1S - 1;      // rows beyond K1: repeats, not stored
-                    const f32x4 bv = ld4(XF + k * PF + 16 * J + 4 * gq);
+                    const int k = 16 * c + n < rec_w ? 16 * c + n : rec_w - 1;
+                    const float* xp = RC + (16 * J + 4 * gq) * rec_w + k;
+                    float bv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = xp[r * rec_w];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) gW1[c] = mfma16(av[r], bv[r], gW1[c]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (has_next) recq_commit<K1S>(fnext, g, REC, tid);
+            if (has_next) recq_commit<K1S>(fnext, g, RN, tid);
         }
+        cur ^= 1;
         __syncthreads();                                 // B0 of the next tile
     }
 
@@ -571,7 +616,11 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
     for (int c = 0; c < NB1; ++c)
         if (16 * c + n < 4 * K1S) slab_st4(slab + SL.w1t[net] + (16 * c + n) * HID + fb + 4 * gq, gW1[c]);
     rs = group4_sum(rs);
-    if (gq == 0) slab_st(slab + SL.b2[net] + fb + n, rs);
+    rs1 = group4_sum(rs1);
+    if (gq == 0) {
+        slab_st(slab + SL.b2[net] + fb + n, rs);
+        slab_st(slab + SL.b1[net] + fb + n, rs1);
+    }
     if constexpr (ACTOR) {
         if (gq < 2) slab_st4(slab + SL.head[0] + (fb + n) * ACT_PAD + 4 * gq, gH);
         sD0 = row16_sum(sD0); sD1 = row16_sum(sD1); sS0 = row16_sum(sS0); sS1 = row16_sum(sS1); sL = row16_sum(sL);
@@ -597,21 +646,32 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
 #undef TS_Q_LANE
 
 // grid: nets == 0 / 3: 2 P workgroups (b < P: actor of pair b, b >= P: critic of pair b - P); nets == 1 / 2: P workgroups
-template <int K1S>
-__global__ __launch_bounds__(QT, 4) void ppo_stepq_kernel(StepArgs g, Dims d, int n_pairs) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int K1S, bool BIG>
+__device__ __forceinline__ void stepq_body(const StepArgs& g, const Dims& d, int n_pairs, float* lds) {
     const Slab3 SL = slab3_layout(4 * K1S);
     const bool one = g.nets == 1 || g.nets == 2;
     const int b = blockIdx.x;
     const int net = one ? g.nets - 1 : (b >= n_pairs);
     const int p = (!one && b >= n_pairs) ? b - n_pairs : b;
     float* slab = g.slabs + (int64_t)p * g.slab_w;
-    if (net == 0) stepq_run<K1S, true>(g, d, lds, p, n_pairs, slab, SL, one);
-    else stepq_run<K1S, false>(g, d, lds, p, n_pairs, slab, SL, one);
+    if (net == 0) stepq_run<K1S, true, BIG>(g, d, lds, p, n_pairs, slab, SL, one);
+    else stepq_run<K1S, false, BIG>(g, d, lds, p, n_pairs, slab, SL, one);
 }
 
-inline int k1s_for(int obs) {      // instantiated layer-1 depths (k-steps of 4, bias column included)
-    const int need = (obs + 1 + 3) / 4;
+template <int K1S>
+__global__ __launch_bounds__(QT, 4) void ppo_stepq_kernel(StepArgs g, Dims d, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stepq_body<K1S, false>(g, d, n_pairs, lds);
+}
+
+template <int K1S>
+__global__ __launch_bounds__(QT, 2) void ppo_stepq2_kernel(StepArgs g, Dims d, int n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stepq_body<K1S, true>(g, d, n_pairs, lds);
+}
+
+inline int k1s_for(int obs) {      // instantiated layer-1 depths (k-steps of 4 observation fields)
+    const int need = (obs + 3) / 4;
     const int avail[] = {2, 3, 5, 8};
     for (int a : avail) if (a >= need) return a;
     return -1;
