@@ -258,6 +258,57 @@ def time_gae_large(learner, log2n=24, iters=10, n_env=8192):
     return n, (prof["gae_maps"][0] + prof["gae_apply"][0]) / iters * 1e-3
 
 
+def step_plan(learner, rows):
+    """(kernel name, workgroups, gradient slabs) of the fused step for a minibatch of `rows` rows (ts_ppo_step_plan)."""
+    import ctypes as C
+
+    v, g, sl = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    learner._lib.check(learner._lib.load().ts_ppo_step_plan(learner._lib.i64(OBS), learner._lib.i64(ACT), learner._lib.i64(rows),
+                                                          C.c_int32(0), C.byref(v), C.byref(g), C.byref(sl)))
+    return ("ppo_step2_kernel", "ppo_stepq_kernel", "ppo_stepq2_kernel")[v.value], g.value, sl.value
+
+
+def strong_scaling_projection(learner, b, steps=16):
+    """BASELINE configs[3] on the one GPU that is here: a rank of an N-GPU strong-scaling run takes 65,536 / N rows of
+    every global minibatch, so its per-step device time is the step kernel + slab reduction + Adam at that row count (plus
+    the gradient exchange, which needs the node).  Measured per row count: the three kernels by HIP events (ts_profile)
+    and the wall time per step of `steps` back-to-back steps on the stream, with the slab count the reduction reads."""
+    from tianshou_amd.ppo import split_offsets  # noqa: F401  (same module as the engine; keeps the import local)
+
+    out = []
+    eng = learner.eng
+    for world in (1, 2, 4, 8):
+        rows = MINIBATCH // world
+        n = rows * steps
+        sub = {k: b[k][:n] for k in ("obs", "act", "adv", "returns", "logp_old", "v_s")}
+        full = learner.next_perm()
+        perm = full[full < n].contiguous()                  # a permutation of range(n)
+        offs = [k * rows for k in range(steps + 1)]
+        saved = (eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.adam_step)
+        eng._run_steps(sub, perm, offs)                     # warm-up
+        torch.cuda.synchronize()
+        learner.ws.profile_begin()
+        eng._run_steps(sub, perm, offs)
+        prof = learner.ws.profile_end()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(4):
+            eng._run_steps(sub, perm, offs)
+        t1.record()
+        torch.cuda.synchronize()
+        eng.params.copy_(saved[0]); eng.adam_m.copy_(saved[1]); eng.adam_v.copy_(saved[2]); eng.adam_step = saved[3]
+        us = lambda k: prof[k][0] / max(prof[k][1], 1) * 1e3     # noqa: E731
+        wall = t0.elapsed_time(t1) * 1e3 / (4 * steps)
+        kernel, grid, slabs = step_plan(learner, rows)
+        out.append({"n_gpus": world, "rows_per_rank": rows, "step_kernel": kernel, "workgroups": grid, "slabs": slabs,
+                    "step_kernel_us": us("ppo_step"), "reduce_us": us("ppo_reduce"), "adam_us": us("ppo_adam"),
+                    "wall_us_per_step": wall, "speedup_over_n1_without_exchange": None})
+    for e in out:
+        e["speedup_over_n1_without_exchange"] = out[0]["wall_us_per_step"] / e["wall_us_per_step"]
+    return {"what": "per-rank device time of one gradient step at 65,536 / N rows, measured on ONE GPU (no gradient exchange: "
+                    "add `exchange_us` of a --gpus N run)", "steps_timed": steps, "by_world_size": out}
+
+
 def cpu_baseline(sample_steps=None):
     """The oracle (CPU port of the reference path: torch-fp32 ops + C restatement of the numba
     kernels) on the host cores.  Default sample: ONE whole update() = full preprocess of the 2^20
@@ -634,7 +685,7 @@ def main():
             step_ms, step_n = prof["ppo_step"]
             avg_s = step_ms / max(step_n, 1) * 1e-3
             achieved = FLOP_PER_SAMPLE_STEP * learner.minibatch / avg_s / 1e12
-            roof = {"bound": "mfma", "kernel": "ppo_step2_kernel", "achieved": achieved,
+            roof = {"bound": "mfma", "kernel": step_plan(learner, learner.minibatch)[0], "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": STEP_HBM_TRAFFIC_BYTES if learner.minibatch == MINIBATCH else None,
                     "traffic_source": TRAFFIC_SOURCE,
@@ -642,6 +693,8 @@ def main():
                     "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * learner.minibatch}
             extra["kernel_us"] = {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in prof.items()}
             extra["inner_update_steps_per_s"] = REPEAT * n_chunks / t_inner
+            if world == 1:
+                extra["strong_scaling_projection"] = strong_scaling_projection(learner, b)
         t_gae = time_gae(learner)
         gbps = GAE_BYTES_PER_TRANSITION * learner.n_trans / t_gae / 1e9
         extra["gae_transitions_per_s"] = learner.n_trans / t_gae

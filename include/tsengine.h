@@ -362,6 +362,14 @@ int ts_ppo_apply(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
                  int64_t act_dim, const float* grad, const ts_ppo_hparams* hp, ts_stream_t stream);
 int ts_ppo_invalidate_image(ts_workspace* ws);
 
+/* Which fused step kernel ts_ppo_update / ts_ppo_grad launch for a minibatch of `n_rows` rows and its geometry (reporting
+ * only: bench.py's roofline line and strong-scaling projection).  variant_out: 0 = 128-sample workgroups with an LDS weight
+ * image (ppo_step2_kernel), 1 / 2 = 32-sample tiles split by features over 4 waves, one network per persistent workgroup, in
+ * the 128- / 168-register build (ppo_stepq_kernel / ppo_stepq2_kernel); grid_out = workgroups, slabs_out = gradient slabs
+ * the reduction kernel reads.  Any out pointer may be NULL. */
+int ts_ppo_step_plan(int64_t obs_dim, int64_t act_dim, int64_t n_rows, int32_t nets, int32_t* variant_out,
+                     int32_t* grid_out, int32_t* slabs_out);
+
 /* ---------------------------------------------------------------------------------------------
  * Target networks
  * ------------------------------------------------------------------------------------------- */

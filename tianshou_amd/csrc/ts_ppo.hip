@@ -1433,7 +1433,11 @@ inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
     const int force = e_force ? atoi(e_force) : -1, pairs_cap = e_pairs ? atoi(e_pairs) : 0;
     StepPlan pl{};
     const int k1s = q4::k1s_for(d.obs);
-    const bool q = force < 0 ? k1s > 0 : (force != 0 && k1s > 0);
+    // Default: the feature-split kernel up to 3 tiles per workgroup (24,576 rows on 256 CUs), the 128-sample kernel above.
+    // Measured on MI355X (profiles/r05_step_kernel_by_rows.txt): 8,192 rows 17.6 vs 32.3 us, 16,384 rows 23.5 vs 32.2 us,
+    // 32,768 rows 35.2 vs 34.5 us, 65,536 rows 57.1 vs 52.6 us (two workgroups gather every record there).
+    const int64_t tiles_all = (n_rows + 31) / 32;
+    const bool q = force < 0 ? (k1s > 0 && tiles_all <= 3 * (int64_t)n_compute_units()) : (force != 0 && k1s > 0);
     if (!q) {
         pl.variant = 0;
         pl.grid = pl.n_slabs = step_grid(n_rows);
@@ -1828,7 +1832,7 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     const int ks = supported_ks(ks1_for((int)obs_dim));
     const int slab_w = slab_width(d, ks);
     const int n_wg = step_grid(n_rows);
-    const WsLayout wl = ws_layout(n_wg, slab_w, 1);
+    const WsLayout wl = ws_layout(n_wg > 512 ? n_wg : 512, slab_w > 12288 ? slab_w : 12288, 1);
     const ImageBuf ib = image_buf(d, ks);
     const size_t dbg_bytes = 16384;          // 64 phase marks of workgroup 0 + (start, end) of up to 992 workgroups
     rc = ts::ws_reserve(ws, wl.total + dbg_bytes + ib.img_bytes + ib.inv_bytes);
@@ -1847,7 +1851,18 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     fill_hparams(g, hp);
     g.adv_norm = 0;
     g.slabs = reinterpret_cast<float*>(base + wl.slabs); g.slab_w = slab_w; g.dbg = dbg;
-    TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
+    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets);
+    if (pl.variant == 1) {
+        g.slab_w = pl.slab_w;        // (the slab area above is sized for the 128-sample kernel: n_wg x slab_w >= pairs x slab3_w)
+        switch (pl.k1s) {
+            case 2: rc = launch_stepq<2>(ws, g, d, pl, s); break;
+            case 3: rc = launch_stepq<3>(ws, g, d, pl, s); break;
+            case 5: rc = launch_stepq<5>(ws, g, d, pl, s); break;
+            default: rc = launch_stepq<8>(ws, g, d, pl, s); break;
+        }
+    } else {
+        TS_KS1_DISPATCH(ks, { rc = launch_step<K>(ws, g, d, n_wg, s); });
+    }
     if (rc != TS_OK) return rc;
     static long long host[2048];
     TS_HIP_CHECK(hipMemcpyAsync(host, dbg, sizeof(host), hipMemcpyDeviceToHost, s));
@@ -1874,6 +1889,19 @@ int ts_ppo_dp_step(ts_workspace* ws, ts_comm* comm, float* params, float* adam_m
         if (rc != TS_OK) return rc;
     }
     return ts_ppo_apply(ws, params, adam_m, adam_v, adam_step, obs_dim, act_dim, step_buf, hp, stream);
+}
+
+int ts_ppo_step_plan(int64_t obs_dim, int64_t act_dim, int64_t n_rows, int32_t nets, int32_t* variant_out,
+                     int32_t* grid_out, int32_t* slabs_out) {
+    int rc = check_dims(obs_dim, act_dim);
+    if (rc != TS_OK) return rc;
+    TS_REQUIRE(n_rows >= 1, TS_ERR_INVALID_ARG, "ts_ppo_step_plan: n_rows must be >= 1");
+    const Dims d = make_dims((int)obs_dim, (int)act_dim);
+    const StepPlan pl = plan_step(d, supported_ks(ks1_for((int)obs_dim)), n_rows, nets);
+    if (variant_out) *variant_out = pl.variant == 0 ? 0 : (pl.big ? 2 : 1);
+    if (grid_out) *grid_out = pl.grid;
+    if (slabs_out) *slabs_out = pl.n_slabs;
+    return TS_OK;
 }
 
 int ts_ppo_invalidate_image(ts_workspace* ws) {

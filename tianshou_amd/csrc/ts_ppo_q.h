@@ -138,19 +138,38 @@ __device__ __forceinline__ void slab_st4(float* p, const f32x4& v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((gfloat_ptr)p), "v"(v) : "memory");
 }
 
-// sum over the 16 lanes of a row (lanes that differ in bits 0..3)
+// sum over the 16 lanes of a row (lanes that differ in bits 0..3) on DPP: xor 1, xor 2 as quad permutes; row_half_mirror and
+// row_mirror act as xor 4 / xor 8 once the value is uniform within quads / half rows.  (__shfl_xor is ds_bpermute_b32: an LDS
+// round trip per step.)
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    switch (ctrl_sel) {
+        case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); break;      // quad_perm [1,0,3,2]
+        case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true); break;      // quad_perm [2,3,0,1]
+        case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true); break;     // row_half_mirror
+        default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true); break;    // row_mirror
+    }
+    return v + __builtin_bit_cast(float, y);
+}
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v = dpp_add(v, 0);
+    v = dpp_add(v, 1);
+    v = dpp_add(v, 2);
+    v = dpp_add(v, 3);
     return v;
 }
-// sum over the four lane groups (lanes that differ in bits 4..5)
+// sum over the four lane groups (lanes that differ in bits 4..5): gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// rows (16 lanes) / halves between two registers -- with both holding v, the sum of the two results is the xor-16 / xor-32
+// butterfly.  Inline asm: the builtins' second result is mis-selected by this compiler (both extracts read the first
+// register); s_nop 1 covers the VALU-write -> permlane-swap read hazard on either side.
 __device__ __forceinline__ float group4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a = a + b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 template <int K1S>
@@ -206,6 +225,24 @@ using cgfloat_ptr = const __attribute__((address_space(1))) float*;
 
 // BIG: the 256-register build (two workgroups per CU): both operand forms of W2 and H1 stay in registers and the next
 // tile's records are fetched two phases earlier; !BIG: the 128-register build (four workgroups per CU).
+// -DTS_PHASE_MARKS builds (scripts/gpu_stepq_phases.py): shader-clock stamps of wave 0 of pair 0's two workgroups
+// (dbg[64 net + k]: k = 0 entry, 1 first barrier, then 2 + 4 tile + phase behind each phase's barrier) and the 100 MHz
+// start / end stamps of every workgroup (dbg[128 + 2 b], dbg[129 + 2 b]).
+#ifdef TS_PHASE_MARKS
+#define TS_QMARK(k)                                                                                          \
+    do {                                                                                                     \
+        if (g.dbg && p == 0 && threadIdx.x == 0 && (k) < 64) g.dbg[64 * net + (k)] = (long long)__builtin_readcyclecounter(); \
+    } while (0)
+#define TS_QREAL(which)                                                                                      \
+    do {                                                                                                     \
+        if (g.dbg && threadIdx.x == 0 && blockIdx.x < 960)                                                   \
+            g.dbg[128 + 2 * blockIdx.x + (which)] = (long long)__builtin_amdgcn_s_memrealtime();             \
+    } while (0)
+#else
+#define TS_QMARK(k) do { } while (0)
+#define TS_QREAL(which) do { } while (0)
+#endif
+
 template <int K1S, bool ACTOR, bool BIG>
 __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, float* lds, int p, int n_pairs, float* slab,
                                           const Slab3& SL, bool zero_other) {
@@ -226,6 +263,8 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
     float* REC = lds + L::REC;
     const int64_t n_tiles = (g.n_rows + 31) / 32;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    TS_QREAL(0);
+    TS_QMARK(0);
 
     // ---- the wave's resident weights: MFMA A operands (lane = (row m = n, k = gq))
     float W1a[K1S];                 // W1[fb + n][4 j + gq]  (0 beyond obs: those k-steps multiply the record's other fields)
@@ -308,7 +347,9 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
     float rs = 0.f, rs1 = 0.f;      // lane-partials of db2[fb + n], db1[fb + n]
     float sD0 = 0.f, sD1 = 0.f, sS0 = 0.f, sS1 = 0.f, sL = 0.f;    // head-bias / sigma / loss partial sums
     __syncthreads();                                     // B0 of the first tile
+    TS_QMARK(1);
     int cur = 0;
+    [[maybe_unused]] int mk = 2;
 
     for (int64_t t = p; t < n_tiles; t += n_pairs) {
         const int64_t t_next = t + n_pairs;
@@ -357,12 +398,12 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
             }
         }
         __syncthreads();                                 // B1: H1 tiles complete
+        TS_QMARK(mk + 0);
 
         // ================= phase 2: H2 = tanh(W2 H1 + b2); head forward partials
         f32x4 h2[2];
         {
             TS_Q_LANE();
-            if constexpr (BIG) fnext_big = recq_fetch<K1S>(g, rid, tid, lane);     // in flight during phases 2-4
             f32x4 acc[2] = {B2, B2};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -403,12 +444,14 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
             }
         }
         __syncthreads();                                 // B2: head partials complete; R1 (H1) is free
+        TS_QMARK(mk + 1);
 
         // ================= phase 3: loss, dout, head gradients, dZ2
         float W2t[16];                                   // W2[16 jj + 4 gq + r][fb + n]       (phase 4)
         {
             TS_Q_LANE();
             if constexpr (!BIG) rid = rowq_fetch(g, has_next ? t_next : t, lane);    // next tile's row ids: in flight during phase 3
+            else fnext_big = recq_fetch<K1S>(g, rid, tid, lane);       // row ids have had phases 1-2; records: phases 3-4
             f32x4 dz2[2];
             if constexpr (ACTOR) {
                 const int a0 = gq, a1 = 4 + gq;
@@ -462,16 +505,25 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                     // dout, sample-major, into this wave's own columns of R1 (A operand of the head gradient)
                     R1[s * PS + fb + a0] = dout0[b];
                     R1[s * PS + fb + a1] = dout1[b];
-                    __builtin_amdgcn_sched_barrier(0);       // one block's loss at a time (register pressure)
+                    if constexpr (!BIG) __builtin_amdgcn_sched_barrier(0);       // one block's loss at a time (register pressure)
                 }
                 wave_lds_sync();
                 // head weight gradient: gH[a][f] += sum_s dout[s][a] H2[s][f]   (rows a = n & 7; rows 8..15 repeat them, unused)
+                {
+                    const f32x4 bv0 = ld4(R2 + (fb + n) * PF + 4 * gq), bv1 = ld4(R2 + (fb + n) * PF + 16 + 4 * gq);
+                    float av0[4], av1[4];
 #pragma unroll
-                for (int J = 0; J < 2; ++J) {
-                    const f32x4 bv = ld4(R2 + (fb + n) * PF + 16 * J + 4 * gq);
+                    for (int r = 0; r < 4; ++r) {
+                        av0[r] = R1[(4 * gq + r) * PS + fb + (n & 7)];
+                        av1[r] = R1[(16 + 4 * gq + r) * PS + fb + (n & 7)];
+                    }
+                    f32x4 g1 = zero4;                    // second chain: the 40-cycle dependent latency of a lone chain
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gH = mfma16(R1[(16 * J + 4 * gq + r) * PS + fb + (n & 7)], bv[r], gH);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int r = 0; r < 4; ++r) {
+                        gH = mfma16(av0[r], bv0[r], gH);
+                        g1 = mfma16(av1[r], bv1[r], g1);
+                    }
+                    gH = gH + g1;
                 }
                 // dH2 = Wmu^T dout (k = action 4 r + gq), dZ2 = dH2 * (1 - H2^2)
 #pragma unroll
@@ -514,7 +566,7 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                     }
                     dtanh4(dh, h2[b]);
                     dz2[b] = dh;
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!BIG) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if constexpr (BIG) {
@@ -532,7 +584,8 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
                 for (int r = 0; r < 4; ++r) R2[(fb + 4 * gq + r) * PF + 16 * b + n] = dz2[b][r];
             }
         }
-        __syncthreads();                                 // B3: dZ2 (sample-major) complete; nobody reads REC any more
+        __syncthreads();                                 // B3: dZ2 (sample-major) complete
+        TS_QMARK(mk + 2);
 
         // ================= phase 4: dZ1, weight gradients
         {
@@ -606,6 +659,10 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
         }
         cur ^= 1;
         __syncthreads();                                 // B0 of the next tile
+        TS_QMARK(mk + 3);
+#ifdef TS_PHASE_MARKS
+        mk += 4;
+#endif
     }
 
     // ---- epilogue: the workgroup's gradient sums leave once, 16 bytes per store
@@ -641,7 +698,8 @@ __device__ __forceinline__ void stepq_run(const StepArgs& g, const Dims& d, floa
             slab_st(slab + SL.loss + 1, sL);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TS_QMARK(mk);
+    TS_QREAL(1);
 }
 #undef TS_Q_LANE
 
@@ -665,7 +723,7 @@ __global__ __launch_bounds__(QT, 4) void ppo_stepq_kernel(StepArgs g, Dims d, in
 }
 
 template <int K1S>
-__global__ __launch_bounds__(QT, 2) void ppo_stepq2_kernel(StepArgs g, Dims d, int n_pairs) {
+__global__ __launch_bounds__(QT, 3) void ppo_stepq2_kernel(StepArgs g, Dims d, int n_pairs) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stepq_body<K1S, true>(g, d, n_pairs, lds);
 }
