@@ -44,13 +44,27 @@ FLOP_PER_SAMPLE_STEP = 60544          # fwd 21,632 + bwd dW 21,632 + 
 GAE_BYTES_PER_TRANSITION = 26         # 22 + 4: rew kept float64 as the reference stores it
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBPS = 8000.0
-# HBM bytes per launch from the TCC counters (profiles/r04_pmc_hbm_traffic.txt: two separate rocprofv3 --pmc passes over
-# this very command, mean per launch; FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte
-# requests of 16-byte-per-lane loads at 64 bytes -> doubled, MI355X_MICROARCH.md "HBM").  Counters cannot be read live
-# from inside bench.py, so the line carries the profiled value of the same workload.
-STEP_HBM_TRAFFIC_BYTES = (2 * 8347 + 28944) * 1024      # records + images read; 512 gradient slabs written through (sc1)
-GAE_HBM_TRAFFIC_BYTES = (2 * 9337 + 8242) * 1024        # 27.6 MB vs 27.3 MB algorithmic: every byte moves once
-TRAFFIC_SOURCE = "profiles/r04_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload)"
+# HBM bytes per launch from the TCC counters: profiles/r05_pmc_hbm_traffic.json, written by scripts/gpu_pmc_traffic.sh (two
+# separate rocprofv3 --pmc passes over this very command, mean per launch per kernel; scripts/rocprof_pmc.py --json).
+# FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane loads at
+# 64 bytes -> doubled (MI355X_MICROARCH.md "HBM").  Counters cannot be read live from inside bench.py, so the line carries
+# the profiled value of the same workload, looked up by the name of the kernel that ran; no entry -> null.
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
+TRAFFIC_SOURCE = "profiles/r05_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload, scripts/gpu_pmc_traffic.sh)"
+
+
+def hbm_traffic_bytes(kernel):
+    """(2 * FETCH_SIZE + WRITE_SIZE) KiB of the profiled `kernel`, or None when the profile has no such kernel."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            e = json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
+        return None
+    return int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+
+
 H2D_BYTES_PER_UPDATE = N_TRANS * (2 * OBS * 4 + ACT * 4 + 8 + 2)   # obs, obs_next, act f32; rew f64; two flag bytes
 
 
@@ -687,7 +701,7 @@ def main():
             achieved = FLOP_PER_SAMPLE_STEP * learner.minibatch / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": step_plan(learner, learner.minibatch)[0], "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": STEP_HBM_TRAFFIC_BYTES if learner.minibatch == MINIBATCH else None,
+                    "traffic": hbm_traffic_bytes(step_plan(learner, learner.minibatch)[0]) if learner.minibatch == MINIBATCH else None,
                     "traffic_source": TRAFFIC_SOURCE,
                     "avg_launch_us": avg_s * 1e6, "launches": step_n, "rows_per_launch": learner.minibatch,
                     "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * learner.minibatch}
@@ -700,7 +714,7 @@ def main():
         extra["gae_transitions_per_s"] = learner.n_trans / t_gae
         extra["roofline_gae"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps,
                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                                 "traffic": GAE_HBM_TRAFFIC_BYTES if learner.n_trans == N_TRANS else None,
+                                 "traffic": hbm_traffic_bytes("gae_single_pass") if learner.n_trans == N_TRANS else None,
                                  "traffic_source": TRAFFIC_SOURCE,
                                  "avg_launch_us": t_gae * 1e6, "transitions": learner.n_trans,
                                  "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * learner.n_trans}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the PPO step kernel, mean per launch (three separate --pmc passes) -> gpurun_out/pmc/pmc_step_mode2.txt
-M=2
+M=2   # (file-name suffix kept from the round-2 script)
 O=$GRAFT_REPO_ROOT/gpurun_out/pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"

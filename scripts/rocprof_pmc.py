@@ -1,16 +1,22 @@
 """Mean PMC counter values per launch, grouped by kernel name + grid, from rocprofv3 rocpd databases:
-    python scripts/rocprof_pmc.py a_results.db [b_results.db ...] [--match conv]"""
+    python scripts/rocprof_pmc.py a_results.db [b_results.db ...] [--match conv] [--json out.json]
+--json also writes {kernel name: {"grid": [x, y, z], "launches": n, counter: mean per launch, ...}} (the heaviest grid of a
+name wins) -- bench.py reads profiles/r05_pmc_hbm_traffic.json, produced this way, for its `roofline.traffic` fields."""
 import collections
+import json
 import sqlite3
 import sys
 
 match = None
+json_out = None
 dbs = []
 args = sys.argv[1:]
 while args:
     a = args.pop(0)
     if a == "--match":
         match = args.pop(0)
+    elif a == "--json":
+        json_out = args.pop(0)
     else:
         dbs.append(a)
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
@@ -43,3 +49,15 @@ for key in sorted(acc):
         print("    mfma_busy/ (busy_cycles*4 simd-ish):", round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_BUSY_CYCLES"], 1), 3),
               " wait_any/wave_cycles:", round(c.get("SQ_WAIT_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3),
               " wait_inst/wave_cycles:", round(c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3))
+
+if json_out:
+    best = {}
+    for key in acc:
+        name = key[0].split("<")[0].split("(")[0].strip().split("::")[-1]
+        c = {k: v[0] / v[1] for k, v in acc[key].items()}
+        n = next(iter(acc[key].values()))[1]
+        weight = n * key[1] * max(key[2], 1) * max(key[3], 1)
+        if name not in best or weight > best[name][0]:
+            best[name] = (weight, {"grid": list(key[1:]), "launches": n, **{k: v for k, v in sorted(c.items())}})
+    with open(json_out, "w") as f:
+        json.dump({k: v[1] for k, v in sorted(best.items())}, f, indent=1)

@@ -115,7 +115,8 @@ def test_default_dispatch_by_row_count(monkeypatch):
         return v.value, g.value, s.value
 
     assert plan(32 * 3 * cus) == (2, 2 * cus, cus)
-    assert plan(8192) == (2, 2 * min(256, cus), min(256, cus))
+    assert plan(32 * cus + 32) == (2, 2 * cus, cus)
+    assert plan(32 * cus) == (2, cus, cus // 2)            # up to one tile per CU and network: one workgroup per CU
     assert plan(64) == (2, 4, 2)
     v, g, s = plan(65536)
     assert v == 0 and g == s == min(512, 2 * cus)

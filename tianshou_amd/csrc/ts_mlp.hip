@@ -32,6 +32,7 @@
 // (+ ...) + bias.
 #include "ts_mlp.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "ts_common.h"
@@ -41,11 +42,11 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 
-constexpr int ROWS = 16;             // batch rows per workgroup
 constexpr int HID = 256;
 constexpr int HP = HID + 4;          // LDS pitch of a hidden activation row
 constexpr int NST = 8;               // register stages of the weight ring (blocks in flight + 1)
-constexpr int part_floats(int nw) { return ROWS * (nw * 64 + 4 * nw); }      // k-split partial sums: splits x 16 x (columns + 4)
+// A workgroup owns 16 RB batch rows (RB = 1 or 2 row blocks: MFMA M tiles that share every weight operand).
+constexpr int part_floats(int nw, int rows) { return rows * (nw * 64 + 4 * nw); }      // k-split partial sums: splits x rows x (columns + 4)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -147,7 +148,7 @@ struct NoNext {
 // nullable) and o_g (row pitch o_ld, nullable; rows >= M are not stored).  A = a_lds [16][a_pitch].  The stream `w` must
 // have been primed into `st`; while the last blocks are consumed the freed stages take the first blocks of `next`.
 // Two barriers: partial sums visible / the output visible (and `part` free again).
-template <int PITCH, bool TRANS, int TPW, int EP, int TH, typename Next>
+template <int PITCH, bool TRANS, int TPW, int EP, int TH, int RB, typename Next>
 __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, Stage (&st)[NST], const Next& next,
                                           const float* a_lds, int a_pitch, float* part, float* o_lds,
                                           float* __restrict__ o_g, int o_ld, const float* __restrict__ mask,
@@ -158,8 +159,9 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
     // what the finish reads from memory (bias / ReLU mask) is requested now: a load issued after the next layer's
     // prefetches would wait for all of them (loads return in order)
     const int q4 = w.ncols / 4;                       // float4 per output row
-    const int nf4 = ROWS * q4;                        // float4 outputs of the layer: at most 1024 / TH per thread
-    constexpr int NQ = 1024 / TH;
+    constexpr int ROWS = 16 * RB;
+    const int nf4 = ROWS * q4;                        // float4 outputs of the layer: at most RB * 1024 / TH per thread
+    constexpr int NQ = RB * 1024 / TH;
     f32x4 epi[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -171,22 +173,33 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x4 acc[4];
+    f32x4 acc[RB][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* al = a_lds + n * a_pitch + 16 * w.b0 + 4 * kq;                   // + 16 j   (row = lane & 15)
+    for (int mt = 0; mt < RB; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* al = a_lds + n * a_pitch + 16 * w.b0 + 4 * kq;                   // + 16 j   (row = lane & 15 of row block mt)
     // the activation operand of a block is read from LDS one block ahead of the MFMAs that use it (a wave that waits for
     // an LDS round trip before every sixteen MFMAs leaves the matrix pipe idle, and so does its partner on the SIMD)
-    f32x4 a_cur = *reinterpret_cast<const f32x4*>(al);
+    f32x4 a_cur[RB];
+#pragma unroll
+    for (int mt = 0; mt < RB; ++mt) a_cur[mt] = *reinterpret_cast<const f32x4*>(al + 16 * mt * a_pitch);
     auto compute = [&](int j, const Stage& s) {
         MTRACE(trace0 + j);
-        const f32x4 a_nxt = *reinterpret_cast<const f32x4*>(al + 16 * min(j + 1, max(nbw - 1, 0)));
+        f32x4 a_nxt[RB];
+#pragma unroll
+        for (int mt = 0; mt < RB; ++mt)
+            a_nxt[mt] = *reinterpret_cast<const f32x4*>(al + 16 * mt * a_pitch + 16 * min(j + 1, max(nbw - 1, 0)));
         __builtin_amdgcn_sched_barrier(0);
+        // every weight operand meets the RB row blocks back to back: one stream of weights per 16 RB rows
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < TPW; ++e) acc[e] = mfma16(a_cur[t], TRANS ? s[e][t] : s[t][e], acc[e]);
-        a_cur = a_nxt;
+            for (int e = 0; e < TPW; ++e)
+#pragma unroll
+                for (int mt = 0; mt < RB; ++mt) acc[mt][e] = mfma16(a_cur[mt][t], TRANS ? s[e][t] : s[t][e], acc[mt][e]);
+#pragma unroll
+        for (int mt = 0; mt < RB; ++mt) a_cur[mt] = a_nxt[mt];
         __builtin_amdgcn_sched_barrier(0);
     };
     // ring of NST register stages: block j lives in stage j % NST and is loaded NST - 1 blocks ahead
@@ -208,17 +221,19 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
     if (nbw > 0) {
         float* pw = part + (size_t)(w.ks * ROWS) * pp;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float* pr = pw + (4 * kq + v) * pp;
-            if (TRANS) {
+        for (int mt = 0; mt < RB; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pr[64 * w.cw + 16 * e + n] = acc[e][v];
-            } else if (TPW == 4) {
-                *reinterpret_cast<f32x4*>(pr + 64 * w.cw + 4 * n) = f32x4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
-            } else {
-                *reinterpret_cast<f32x2*>(pr + 32 * w.cw + 2 * n) = f32x2{acc[0][v], acc[1][v]};
+            for (int v = 0; v < 4; ++v) {
+                float* pr = pw + (16 * mt + 4 * kq + v) * pp;
+                if (TRANS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pr[64 * w.cw + 16 * e + n] = acc[mt][e][v];
+                } else if (TPW == 4) {
+                    *reinterpret_cast<f32x4*>(pr + 64 * w.cw + 4 * n) = f32x4{acc[mt][0][v], acc[mt][1][v], acc[mt][2][v], acc[mt][3][v]};
+                } else {
+                    *reinterpret_cast<f32x2*>(pr + 32 * w.cw + 2 * n) = f32x2{acc[mt][0][v], acc[mt][1][v]};
+                }
             }
-        }
     }
     __syncthreads();
     // finish: 16 x ncols outputs, 16 bytes per thread and step, whole rows
@@ -246,12 +261,12 @@ __device__ __forceinline__ void mlp_layer(const WStream<PITCH, TRANS, TPW>& w, S
 // x tile / upstream-gradient tile of this workgroup: [16][K] floats -> LDS (rows past M repeat the last row).  Two halves:
 // the global loads are issued BEFORE the first weights are requested and committed to LDS after (loads return in order:
 // behind 28 weight loads the input rows would arrive last although the barrier waits for them first).
-template <int TH> constexpr int xr_count() { return ROWS * 1024 / 4 / TH; }     // 16 rows x 1024 floats / threads / 4
-template <int TH>
+template <int TH, int RB> constexpr int xr_count() { return 16 * RB * 1024 / 4 / TH; }     // rows x 1024 floats / threads / 4
+template <int TH, int RB>
 __device__ __forceinline__ void load_rows_issue(const float* __restrict__ src, int K, int m0, int M, int tid,
-                                                f32x4 (&xr)[xr_count<TH>()]) {
-    constexpr int XR = xr_count<TH>();
-    const int q4 = K / 4, total = ROWS * q4;
+                                                f32x4 (&xr)[xr_count<TH, RB>()]) {
+    constexpr int XR = xr_count<TH, RB>();
+    const int q4 = K / 4, total = 16 * RB * q4;
 #pragma unroll
     for (int it = 0; it < XR; ++it) {
         const int i = min(tid + it * TH, total - 1);
@@ -263,10 +278,10 @@ __device__ __forceinline__ void load_rows_issue(const float* __restrict__ src, i
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int TH>
-__device__ __forceinline__ void load_rows_commit(int K, float* dst, int pitch, int tid, const f32x4 (&xr)[xr_count<TH>()]) {
-    constexpr int XR = xr_count<TH>();
-    const int q4 = K / 4, total = ROWS * q4;
+template <int TH, int RB>
+__device__ __forceinline__ void load_rows_commit(int K, float* dst, int pitch, int tid, const f32x4 (&xr)[xr_count<TH, RB>()]) {
+    constexpr int XR = xr_count<TH, RB>();
+    const int q4 = K / 4, total = 16 * RB * q4;
 #pragma unroll
     for (int it = 0; it < XR; ++it) {
         const int i = tid + it * TH;
@@ -280,9 +295,14 @@ __device__ __forceinline__ void load_rows_commit(int K, float* dst, int pitch, i
 // launches (256 workgroups at B = 4096).  4: no k split in the hidden layers, 78 KB of LDS -- TWO workgroups per CU, which in a
 // multi-network launch (blockIdx.y = network) are the same rows of two different networks: their weight streams and MFMA
 // phases interleave on the CU instead of running as two generations.
-template <int N3, int NW>
+// RB = 2 (multi-network launches that still fill the chip with 32-row workgroups: the twin critics at B = 4096): ONE
+// eight-wave workgroup per CU owns 32 rows of one network -- a CU streams one network's weights for 32 rows instead of two
+// networks' weights for 16 rows each, half the bytes through its vector memory path for the same matrix work.  LDS: the
+// second hidden activation overlays the input rows (dead after layer 1's products).
+template <int N3, int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void mlp3_fwd_kernel(MlpArgs a) {
     constexpr int TH = 64 * NW;
+    constexpr int ROWS = 16 * RB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ROWS;
@@ -292,9 +312,10 @@ __global__ __launch_bounds__(64 * NW) void mlp3_fwd_kernel(MlpArgs a) {
     const float* wb3 = a.wb3[net];
     const int xp = a.K1 + 4;
     float* xs = lds;
-    float* h1s = xs + ROWS * xp;
-    float* h2s = h1s + ROWS * HP;
-    float* part = h2s + ROWS * HP;
+    const int x_floats = RB == 1 ? ROWS * xp : max(ROWS * xp, ROWS * HP);
+    float* h1s = xs + x_floats;
+    float* h2s = RB == 1 ? h1s + ROWS * HP : xs;
+    float* part = RB == 1 ? h2s + ROWS * HP : h1s + ROWS * HP;
     Stage st[NST];
     constexpr int TP3 = N3 == 32 ? 2 : 4;
     const WStream<HID, false, 4> w1(wb1, a.K1, HID, 0, wave, lane, NW);
@@ -302,21 +323,21 @@ __global__ __launch_bounds__(64 * NW) void mlp3_fwd_kernel(MlpArgs a) {
     const WStream<N3, false, TP3> w3(wb3, HID, N3, 0, wave, lane, NW);
     MMARK(0);
     {
-        f32x4 xr[xr_count<TH>()];
-        load_rows_issue<TH>(a.x, a.K1, m0, a.M, tid, xr);
+        f32x4 xr[xr_count<TH, RB>()];
+        load_rows_issue<TH, RB>(a.x, a.K1, m0, a.M, tid, xr);
         w1.template prime<0, 2>(st);               // the first weights travel while the input rows do
-        load_rows_commit<TH>(a.K1, xs, xp, tid, xr);
+        load_rows_commit<TH, RB>(a.K1, xs, xp, tid, xr);
     }
     __syncthreads();
     w1.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH>(w1, st, w2, xs, xp, part, h1s, a.h1[net], HID, nullptr, wb1 + (size_t)a.K1 * HID,
+    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH, RB>(w1, st, w2, xs, xp, part, h1s, a.h1[net], HID, nullptr, wb1 + (size_t)a.K1 * HID,
                                                m0, a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH>(w2, st, w3, h1s, HP, part, h2s, a.h2[net], HID, nullptr, wb2 + (size_t)HID * HID,
+    mlp_layer<HID, false, 4, EP_BIAS_RELU, TH, RB>(w2, st, w3, h1s, HP, part, h2s, a.h2[net], HID, nullptr, wb2 + (size_t)HID * HID,
                                                m0, a.M, tid, 16);
     MMARK(3);
-    mlp_layer<N3, false, TP3, EP_BIAS, TH>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out[net], N3, nullptr,
+    mlp_layer<N3, false, TP3, EP_BIAS, TH, RB>(w3, st, NoNext{}, h2s, HP, part, nullptr, a.out[net], N3, nullptr,
                                            wb3 + (size_t)HID * N3, m0, a.M, tid, 32);
     MMARK(4);
 }
@@ -331,9 +352,10 @@ struct BwdArgs {
     int M, K1, dx_c0, dx_nt;
 };
 
-template <int N3, int NW>
+template <int N3, int NW, int RB>
 __global__ __launch_bounds__(64 * NW) void mlp3_bwd_kernel(BwdArgs a) {
     constexpr int TH = 64 * NW;
+    constexpr int ROWS = 16 * RB;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * ROWS;
@@ -349,20 +371,20 @@ __global__ __launch_bounds__(64 * NW) void mlp3_bwd_kernel(BwdArgs a) {
     const WStream<HID, true, 4> w1(a.wb1[net], HID, dx ? 16 * a.dx_nt : 0, a.dx_c0, wave, lane, NW);
     MMARK(0);
     {
-        f32x4 xr[xr_count<TH>()];
-        load_rows_issue<TH>(a.d_out[net], N3, m0, a.M, tid, xr);
+        f32x4 xr[xr_count<TH, RB>()];
+        load_rows_issue<TH, RB>(a.d_out[net], N3, m0, a.M, tid, xr);
         w3.template prime<0, 2>(st);
-        load_rows_commit<TH>(N3, ds, N3 + 4, tid, xr);
+        load_rows_commit<TH, RB>(N3, ds, N3 + 4, tid, xr);
     }
     __syncthreads();
     w3.template prime<2, NST - 1>(st);
     MMARK(1);
-    mlp_layer<N3, true, 4, EP_MASK, TH>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2[net], HID, a.h2[net], nullptr, m0, a.M, tid, 0);
+    mlp_layer<N3, true, 4, EP_MASK, TH, RB>(w3, st, w2, ds, N3 + 4, part, g2s, a.dh2[net], HID, a.h2[net], nullptr, m0, a.M, tid, 0);
     MMARK(2);
-    mlp_layer<HID, true, 4, EP_MASK, TH>(w2, st, w1, g2s, HP, part, g1s, a.dh1[net], HID, a.h1[net], nullptr, m0, a.M, tid, 16);
+    mlp_layer<HID, true, 4, EP_MASK, TH, RB>(w2, st, w1, g2s, HP, part, g1s, a.dh1[net], HID, a.h1[net], nullptr, m0, a.M, tid, 16);
     MMARK(3);
     if (dx != nullptr) {
-        mlp_layer<HID, true, 4, EP_PLAIN, TH>(w1, st, NoNext{}, g1s, HP, part, nullptr, dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
+        mlp_layer<HID, true, 4, EP_PLAIN, TH, RB>(w1, st, NoNext{}, g1s, HP, part, nullptr, dx, a.K1, nullptr, nullptr, m0, a.M, tid, 32);
         MMARK(4);
     }
 }
@@ -386,6 +408,16 @@ bool mlp3_supported(int K1, int hidden, int head_cols) {
 }
 
 namespace {
+int n_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
 template <typename K>
 int allow_lds(K kernel) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -407,19 +439,30 @@ int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const
     }
     // four-wave workgroups (two per CU) when several networks share the launch and two such workgroups fit a CU's LDS
     static const int force_nw = getenv("TS_MLP_NW") ? atoi(getenv("TS_MLP_NW")) : 0;
-    const size_t lds4 = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(4));
+    constexpr int ROWS = 16;
+    // four-wave 16-row workgroups (two per CU) for several networks when two of them fit a CU's LDS, eight-wave 16-row
+    // workgroups for one network; TS_MLP_RB=2: 32-row workgroups (eight waves, one per CU) when several networks share the
+    // launch and 32-row workgroups still fill the chip
+    static const int force_rb = getenv("TS_MLP_RB") ? atoi(getenv("TS_MLP_RB")) : 0;
+    const size_t lds32 = sizeof(float) * (size_t)(std::max(32 * (K1 + 4), 32 * HP) + 32 * HP + part_floats(8, 32));
+    // Measured (profiles/r05_mlp3_32_row_workgroups.txt): SAC C5 2,619 -> 2,660, TD3 / DDPG +0.6 / +1.1 %, DiscreteSAC
+    // 3,724 -> 3,589 updates/s -- the twin launches are at 62 % of the fp32-MFMA issue rate already (2.95 GFLOP in 34 us), not
+    // bound by the weight stream; off unless TS_MLP_RB=2.
+    const bool two = force_rb == 2 && nets > 1 && (int64_t)nets * ceil_div(M, 32) >= 3 * n_cus() / 4 &&
+                     lds32 <= 160 * 1024 && !force_nw;
+    const size_t lds4 = sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(4, ROWS));
     const bool four = force_nw ? force_nw == 4 : (nets > 1 && lds4 <= 80 * 1024);
-    const size_t lds = four ? lds4 : sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(8));
-    const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
+    const size_t lds = two ? lds32 : four ? lds4 : sizeof(float) * (size_t)(ROWS * (K1 + 4) + 2 * ROWS * HP + part_floats(8, ROWS));
+    const dim3 grid((unsigned)ceil_div(M, two ? 32 : ROWS), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_FWD, s);
-#define TS_MLP_FWD(N3_, NW_)                                                                          \
+#define TS_MLP_FWD(N3_, NW_, RB_)                                                                     \
     do {                                                                                              \
-        static const int once = allow_lds(&mlp3_fwd_kernel<N3_, NW_>);                                \
+        static const int once = allow_lds(&mlp3_fwd_kernel<N3_, NW_, RB_>);                           \
         (void)once;                                                                                   \
-        hipLaunchKernelGGL((mlp3_fwd_kernel<N3_, NW_>), grid, dim3(64 * NW_), lds, s, a);             \
+        hipLaunchKernelGGL((mlp3_fwd_kernel<N3_, NW_, RB_>), grid, dim3(64 * NW_), lds, s, a);        \
     } while (0)
-    if (head_cols == 32) { if (four) TS_MLP_FWD(32, 4); else TS_MLP_FWD(32, 8); }
-    else { if (four) TS_MLP_FWD(64, 4); else TS_MLP_FWD(64, 8); }
+    if (head_cols == 32) { if (two) TS_MLP_FWD(32, 8, 2); else if (four) TS_MLP_FWD(32, 4, 1); else TS_MLP_FWD(32, 8, 1); }
+    else { if (two) TS_MLP_FWD(64, 8, 2); else if (four) TS_MLP_FWD(64, 4, 1); else TS_MLP_FWD(64, 8, 1); }
 #undef TS_MLP_FWD
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -454,18 +497,22 @@ int mlp3_backward_n(hipStream_t s, int nets, const float* const* d_out, int M, i
         TS_REQUIRE(a.dx_nt <= 8, TS_ERR_UNSUPPORTED, "mlp3_backward: input-gradient range wider than 128 columns");
     }
     static const int force_nw = getenv("TS_MLP_NW") ? atoi(getenv("TS_MLP_NW")) : 0;
+    static const int force_rb = getenv("TS_MLP_RB") ? atoi(getenv("TS_MLP_RB")) : 0;
+    constexpr int ROWS = 16;
+    const bool two = force_rb == 2 && nets > 1 && (int64_t)nets * ceil_div(M, 32) >= 3 * n_cus() / 4 && !force_nw;
     const bool four = force_nw ? force_nw == 4 : nets > 1;
-    const size_t lds = sizeof(float) * (size_t)(ROWS * (head_cols + 4) + 2 * ROWS * HP + part_floats(four ? 4 : 8));
-    const dim3 grid((unsigned)ceil_div(M, ROWS), (unsigned)nets);
+    const int rows = two ? 32 : ROWS;
+    const size_t lds = sizeof(float) * (size_t)(rows * (head_cols + 4) + 2 * rows * HP + part_floats(two ? 8 : four ? 4 : 8, rows));
+    const dim3 grid((unsigned)ceil_div(M, rows), (unsigned)nets);
     ProfScope scope(prof, TS_KIND_CONV_DGRAD, s);
-#define TS_MLP_BWD(N3_, NW_)                                                                          \
+#define TS_MLP_BWD(N3_, NW_, RB_)                                                                     \
     do {                                                                                              \
-        static const int once = allow_lds(&mlp3_bwd_kernel<N3_, NW_>);                                \
+        static const int once = allow_lds(&mlp3_bwd_kernel<N3_, NW_, RB_>);                           \
         (void)once;                                                                                   \
-        hipLaunchKernelGGL((mlp3_bwd_kernel<N3_, NW_>), grid, dim3(64 * NW_), lds, s, a);             \
+        hipLaunchKernelGGL((mlp3_bwd_kernel<N3_, NW_, RB_>), grid, dim3(64 * NW_), lds, s, a);        \
     } while (0)
-    if (head_cols == 32) { if (four) TS_MLP_BWD(32, 4); else TS_MLP_BWD(32, 8); }
-    else { if (four) TS_MLP_BWD(64, 4); else TS_MLP_BWD(64, 8); }
+    if (head_cols == 32) { if (two) TS_MLP_BWD(32, 8, 2); else if (four) TS_MLP_BWD(32, 4, 1); else TS_MLP_BWD(32, 8, 1); }
+    else { if (two) TS_MLP_BWD(64, 8, 2); else if (four) TS_MLP_BWD(64, 4, 1); else TS_MLP_BWD(64, 8, 1); }
 #undef TS_MLP_BWD
     TS_LAUNCH_CHECK();
     return TS_OK;
