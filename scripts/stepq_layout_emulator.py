@@ -10,7 +10,7 @@ import numpy as np
 rng = np.random.default_rng(0)
 OBS, ACT, HID, K1S = 17, 6, 64, 5
 K1 = 4 * K1S
-PS, PF, ACT_PAD = 68, 36, 8
+PS, PF, ACT_PAD = 68, 40, 8
 LANE = np.arange(64)
 N_, G_ = LANE & 15, LANE >> 4
 

@@ -314,3 +314,39 @@ def test_row_indexed_entry_points_are_bit_identical(auto, weighted):
         assert torch.equal(r0, r1) and torch.equal(s0, s1) and torch.equal(w0, w1)
     for a, b in zip(out["rows"][1], out["gather"][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_step", [1, 3])
+def test_returns_without_a_stored_obs_next_read_obs_of_the_next_slot(n_step):
+    """save_obs_next=False (buffer_base.py:622-626): batch.obs_next = obs[next(index)].  A buffer without the obs_next column
+    gives the same n-step returns as one whose obs_next column was filled with obs[next(.)] for every slot (next() from the
+    oracle's restatement of _next_index, manager.py:340-363: an episode's last / newest transition maps to itself)."""
+    from oracle import oracle as O
+    from tianshou_amd.buffer import DeviceReplayBuffer
+
+    obs_dim, act_dim, B, slots, E = 23, 5, 300, 2048, 4
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4, critic_lr=1e-3,
+                       alpha_lr=1e-3, tau=0.02, n_step=n_step)
+    g = torch.Generator().manual_seed(7)
+    T = slots // E
+    off = np.arange(E + 1, dtype=np.int64) * T
+    term = (torch.rand(slots, generator=g) < 0.05).numpy()
+    trunc = (torch.rand(slots, generator=g) < 0.03).numpy() & ~term
+    obs = torch.randn(slots, obs_dim, generator=g).numpy()
+    last, lengths = off[:-1] + T - 1, np.full(E, T, np.int64)
+    nxt = O._next_index(np.arange(slots), off, term | trunc, last, lengths)
+    assert (nxt != np.arange(slots) + 1).any() and (nxt == np.arange(slots)).any()
+    common = dict(offset=off, last_index=last, lengths=lengths, insertion=np.zeros(E, np.int64),
+                  rew=torch.randn(slots, generator=g).double().numpy(), terminated=term, truncated=trunc, obs=obs,
+                  act=(torch.rand(slots, act_dim, generator=g) * 2 - 1).numpy())
+    with_col = DeviceReplayBuffer(obs_next=obs[nxt], **common)
+    without = DeviceReplayBuffer(obs_next=None, **common)
+    idx = torch.randint(0, slots, (B,), generator=g)
+    assert torch.equal(without.obs_next_rows(idx).cpu(), torch.from_numpy(obs[nxt[idx.numpy()]]))
+    noise = torch.randn(B, act_dim, generator=g)
+    eng, _ = make_engine(obs_dim, act_dim, 11, cfg)
+    ret_a = eng.preprocess(with_col, idx, noise)
+    ret_b = eng.preprocess(without, idx, noise)
+    torch.cuda.synchronize()
+    # n_step = 1 with the stored column runs the row-indexed launch sequence, the other three the general path: same values
+    np.testing.assert_allclose(ret_b.cpu().numpy(), ret_a.cpu().numpy(), rtol=1e-6, atol=1e-6)

@@ -435,6 +435,16 @@ class DeviceReplayBuffer:
     def prev(self, index) -> torch.Tensor:
         return _prev_index(index, self.offset, self.done, self.last_index, self.lengths)
 
+    def obs_next_rows(self, index) -> torch.Tensor:
+        """The `obs_next` column of `buffer[index]` (buffer_base.py:622-626): the stored rows when the buffer saves them,
+        otherwise `obs[next(index)]` (save_obs_next=False: the next slot of the episode; an episode's last / newest
+        transition maps to itself, as in the reference)."""
+        if self.obs_next is not None:
+            return gather_rows(self.obs_next, index)
+        if self.obs is None:
+            raise ValueError("the device buffer holds neither obs_next nor obs")
+        return gather_rows(self.obs, self.next(index))
+
     def unfinished_index(self) -> torch.Tensor:
         """manager.py:85-91 -> int64[<=E] device tensor (one tiny D2H for the count)."""
         out, n = self._unfinished_raw()

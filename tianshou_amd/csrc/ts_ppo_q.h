@@ -30,7 +30,7 @@ namespace q4 {
 
 constexpr int QT = 256;          // threads per workgroup (4 waves)
 constexpr int PS = 68;           // sample-major tile pitch  [32][PS]   (ds_read_b128 of 4 consecutive features)
-constexpr int PF = 36;           // feature-major tile pitch [64][PF]   (ds_read_b128 of 4 consecutive samples)
+constexpr int PF = 40;           // feature-major tile pitch [64][PF]   (conflict-free ds_read_b128 of 4 consecutive samples: 36 costs 2x)
 constexpr int P_FLOATS = 4 * 2 * 8 * 16;   // head partials [wave][block][action][16]
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {

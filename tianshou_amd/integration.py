@@ -1160,7 +1160,8 @@ def make_hip_rainbow(ref=None):
 def make_hip_sac(ref=None):
     """Returns HipSAC(SAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, sac.py:298-336) on the
     engine.  Supported nets: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU, conditioned sigma,
-    unbounded actor; concat critics); the buffer must store obs_next.  rsample() noise is drawn from torch's
+    unbounded actor; concat critics);
+    obs_next is the buffer's stored column or, with save_obs_next=False, obs[next(index)] (buffer_base.py:622-626).  rsample() noise is drawn from torch's
     default generator on the host, in the reference's order (target-policy call, then actor-loss call).
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     SAC = _ref(ref, "tianshou.algorithm.modelfree.sac", "SAC")
@@ -1236,8 +1237,6 @@ def make_hip_sac(ref=None):
             _require_gpu(self._hip_device, "HipSAC")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
-            if m.obs_next is None:
-                raise NotImplementedError("HipSAC: the replay buffer must store obs_next")
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             noise = torch.randn(len(indices), eng.act_dim)                  # Normal.rsample of the target policy call
             batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)
@@ -1294,7 +1293,8 @@ def make_hip_sac(ref=None):
 def make_hip_redq(ref=None):
     """Returns HipREDQ(REDQ): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, redq.py:248-304) on the engine.
     Supported nets: SAC's actor (Net[256, 256] ReLU, conditioned sigma, unbounded) and one critic module made of
-    EnsembleLinear layers with hidden [256, 256] (test/continuous/test_redq.py:86-107); the buffer must store obs_next.
+    EnsembleLinear layers with hidden [256, 256] (test/continuous/test_redq.py:86-107);
+    obs_next is the buffer's stored column or, with save_obs_next=False, obs[next(index)] (buffer_base.py:622-626).
     The rsample() noise comes from torch's default generator and the critic subset from NumPy's global generator, in
     the reference's order (target call: noise, then np.random.choice; actor step: noise).
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
@@ -1366,8 +1366,6 @@ def make_hip_redq(ref=None):
             _require_gpu(self._hip_device, "HipREDQ")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
-            if m.obs_next is None:
-                raise NotImplementedError("HipREDQ: the replay buffer must store obs_next")
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             noise = torch.randn(len(indices), eng.act_dim)                  # Normal.rsample of the target policy call
             subset = np.random.choice(self.ensemble_size, self.subset_size, replace=False)     # redq.py:252
@@ -1422,7 +1420,7 @@ def make_hip_discrete_sac(ref=None):
     """Returns HipDiscreteSAC(DiscreteSAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301,
     discrete_sac.py:147-196) on the engine.  Supported nets: Net(obs, [h, h]) ReLU under DiscreteActor(softmax_output=
     False) and DiscreteCritic(last_size=n_act) (test/discrete/test_discrete_sac.py:88-97), h a multiple of 32; the
-    buffer must store obs_next.  `match_rng_stream`: the reference's two policy calls per update draw
+    obs_next is the buffer's stored column or obs[next(index)] (buffer_base.py:622-626).  `match_rng_stream`: the reference's two policy calls per update draw
     `Categorical.sample()` values that are never used; with the flag set (default) the same draws are made from the
     engine's logits so that torch's global generator advances exactly as in the reference.
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
@@ -1502,8 +1500,6 @@ def make_hip_discrete_sac(ref=None):
             _require_gpu(self._hip_device, "HipDiscreteSAC")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
-            if m.obs_next is None:
-                raise NotImplementedError("HipDiscreteSAC: the replay buffer must store obs_next")
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             if self._hip_match_rng:
                 from .returns import nstep_indices
@@ -1638,7 +1634,8 @@ def make_hip_ppo_cnn(algo: str = "ppo", ref=None):
 def make_hip_ppo_discrete(algo: str = "ppo", ref=None):
     """Returns HipPPODiscrete(PPO) for Net(obs, [h, h]) shared by DiscreteActor and DiscreteCritic, Categorical policy
     (`softmax_output=True` with `dist_fn=torch.distributions.Categorical`, or `softmax_output=False` with the default
-    logits dist_fn), Adam; h a multiple of 32, at most 31 actions; the buffer must store obs_next.
+    logits dist_fn), Adam; h a multiple of 32, at most 31 actions;
+    obs_next is the buffer's stored column or, with save_obs_next=False, obs[next(index)] (buffer_base.py:622-626).
     algo="a2c": HipA2CDiscrete(A2C).  `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     from torch.distributions import Categorical
 
@@ -1692,8 +1689,6 @@ def make_hip_ppo_discrete(algo: str = "ppo", ref=None):
             _require_gpu(self._hip_device, "HipPPODiscrete")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
-            if m.obs_next is None:
-                raise NotImplementedError("HipPPODiscrete: the replay buffer must store obs_next")
             pre = self._hip_pre = eng.preprocess(m)
             batch.v_s, batch.returns, batch.adv, batch.logp_old = pre["v_s"], pre["returns"], pre["adv"], pre["logp_old"]
             return batch
@@ -1794,8 +1789,6 @@ def _make_hip_det(twin: bool, ref=None):
             _require_gpu(self._hip_device, "HipTD3 / HipDDPG")
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
-            if m.obs_next is None:
-                raise NotImplementedError("HipTD3 / HipDDPG: the replay buffer must store obs_next")
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
             noise = torch.randn(size=(len(indices), eng.act_dim)) if twin else None        # td3.py:196
             batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)

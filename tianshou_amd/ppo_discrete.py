@@ -99,13 +99,13 @@ class DiscretePPOEngine:
     # -- PPO._preprocess_batch -------------------------------------------------------------------------------
     def preprocess(self, buffer: DeviceReplayBuffer) -> dict:
         """Whole-buffer pass in sample_indices(0) order: V(s), V(s'), log pi_old(a|s), GAE, optional return scaling
-        (a2c.py:115-153, ppo.py:146-162).  Needs buffer.obs, buffer.act and buffer.obs_next."""
-        if buffer.obs is None or buffer.act is None or buffer.obs_next is None:
-            raise ValueError("the device buffer must hold obs, act and obs_next")
+        (a2c.py:115-153, ppo.py:146-162).  Needs buffer.obs and buffer.act; obs_next is the stored column or obs[next(index)] (buffer_base.py:622-626)."""
+        if buffer.obs is None or buffer.act is None:
+            raise ValueError("the device buffer must hold obs and act")
         idx = buffer.sample_indices(0)
         act_b = buffer.act[idx].reshape(-1)
         v_s, logp_old = self.infer(gather_rows(buffer.obs, idx), act_b)
-        v_next, _ = self.infer(gather_rows(buffer.obs_next, idx))
+        v_next, _ = self.infer(buffer.obs_next_rows(idx))
         out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
         return {"indices": idx, "act": act_b, "v_s": v_s, "returns": out["returns"], "adv": out["adv"],
                 "logp_old": logp_old}
@@ -115,7 +115,7 @@ class DiscretePPOEngine:
         a2c.py:148) again with the current parameters; log pi_old stays.  Updates `pre` in place."""
         idx = pre["indices"]
         v_s, _ = self.infer(gather_rows(buffer.obs, idx))
-        v_next, _ = self.infer(gather_rows(buffer.obs_next, idx))
+        v_next, _ = self.infer(buffer.obs_next_rows(idx))
         out = gae_and_return_scaling(self, buffer, idx, v_s, v_next)
         pre["v_s"], pre["returns"], pre["adv"] = v_s, out["returns"], out["adv"]
 

@@ -111,10 +111,10 @@ class REDQEngine:
         return out
 
     def preprocess(self, buffer: DeviceReplayBuffer, indices, noise, subset) -> torch.Tensor:
-        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); needs buffer.obs_next."""
+        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); obs_next from the buffer's stored column or obs[next(index)] (buffer_base.py:622-626)."""
 
         def tq_fn(buf, after):
-            return self.target_q(gather_rows(buf.obs_next, after), noise, subset)
+            return self.target_q(buf.obs_next_rows(after), noise, subset)
 
         class _B:
             pass

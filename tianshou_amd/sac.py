@@ -224,7 +224,7 @@ class SACEngine:
                 and buffer.terminated.dtype == torch.uint8 and not os.environ.get("TS_SAC_NO_ROWS"))
 
     def preprocess(self, buffer: DeviceReplayBuffer, indices, noise) -> torch.Tensor:
-        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); needs buffer.obs_next.
+        """n-step returns float32[I] with target_q_fn = _target_q (ddpg.py:287-301); obs_next from the buffer's stored column or obs[next(index)] (buffer_base.py:622-626).
         n_step = 1 (SAC's default): one launch sequence gathers obs_next inside the input packing and ends with the 1-step
         return (ts_sac_returns_rows), bit-identical to the general path below."""
         if self.cfg.n_step == 1 and self._rows_ok(buffer):
@@ -242,7 +242,7 @@ class SACEngine:
             return out
 
         def tq_fn(buf, after):
-            return self.target_q(gather_rows(buf.obs_next, after), noise)
+            return self.target_q(buf.obs_next_rows(after), noise)
 
         class _B:
             pass

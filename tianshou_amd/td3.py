@@ -145,7 +145,7 @@ class TD3Engine:
         class _B:
             pass
 
-        fn = lambda buf, after: self.target_q(gather_rows(buf.obs_next, after), noise)  # noqa: E731
+        fn = lambda buf, after: self.target_q(buf.obs_next_rows(after), noise)  # noqa: E731
         return compute_nstep_return(_B(), buffer, indices, fn, self.cfg.gamma, self.cfg.n_step).returns.reshape(-1)
 
     def update_with_batch(self, obs, act, returns, weight=None, grads_out=None, lr_scale: float = 1.0):
