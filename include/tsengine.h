@@ -1013,6 +1013,33 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
                      const float* logp_old, const float* v_old, int64_t B, int64_t global_batch, const float* adv_stats,
                      const ts_ppo_hparams* hp, float* losses_out4, float* grad_out, ts_stream_t stream);
 
+/* The same minibatch step and the inference passes for actor-critics with ANY trunk the reference's Net / MLP builds from
+ * `hidden_sizes` and one activation (utils/net/common.py:90-178, 246-369): 1 .. TS_NET_MAX_HIDDEN hidden layers of any
+ * widths (stored padded to multiples of 32: a padding unit has zero weights on both sides and keeps them), activation tanh /
+ * ReLU / none, actor and critic described separately (they are separate Net instances in examples/mujoco/mujoco_ppo.py:
+ * 108-114).  Per layer one block [K_pad + 1, N_pad] (last row = bias) as in ts_npg_layout; actor = blocks | head
+ * [h_last + 1, 32] (columns [0, act) = mu) | log_sigma[32]; critic = blocks | head [h_last + 1, 32] (column 0 = V).
+ * ts_net_layout: h_out3 = {k0 (obs padded to 32), floats of an actor with this trunk, floats of a critic with this trunk}. */
+#define TS_NET_MAX_HIDDEN 7
+#define TS_NET_ACT_TANH 0
+#define TS_NET_ACT_RELU 1
+#define TS_NET_ACT_NONE 2
+typedef struct ts_net_desc {
+    int64_t obs_dim;
+    int32_t n_hidden;                  /* 1 .. TS_NET_MAX_HIDDEN */
+    int32_t activation;                /* TS_NET_ACT_* after every hidden layer */
+    int64_t hidden[TS_NET_MAX_HIDDEN]; /* widths as configured (1 .. 1024 each) */
+} ts_net_desc;
+int ts_net_layout(const ts_net_desc* net, int64_t act_dim, int64_t* h_out3);
+int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, const ts_net_desc* actor_net,
+                     const ts_net_desc* critic_net, int64_t act_dim, const float* obs, const float* act, int64_t B,
+                     float* v_out, float* logp_out, float* mu_out, ts_stream_t stream);
+int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                    const ts_net_desc* actor_net, const ts_net_desc* critic_net, int64_t act_dim, const float* obs,
+                    const float* act, const float* adv, const float* returns, const float* logp_old, const float* v_old,
+                    int64_t B, int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4,
+                    float* grad_out, ts_stream_t stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * TD3 / DDPG: ContinuousActorDeterministic (utils/net/continuous.py:26-85) + the SAC critics,

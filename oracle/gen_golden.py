@@ -467,6 +467,142 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
+def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_a: list[int], hidden_c: list[int], activation,
+                batch_size: int, repeat: int, seed: int, algo: str = "ppo", **ppo_kwargs) -> None:
+    """The reference PPO / A2C update() for actor-critics whose trunks are Net(hidden_sizes=..., activation=...) of any depth
+    (utils/net/common.py:90-178, 246-369; `activation` = nn.Tanh, nn.ReLU or None): inputs, Batch.split's permutations,
+    per-step losses and the parameters / Adam moments after the update, as lists of tensors in module order
+    (trunk (w, b)*, head w, head b[, sigma_param]).  Replayed by tests/test_gpu_ppo_net.py on the engine's per-layer path."""
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    N = E * T
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden_a, activation=activation)
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=hidden_c, activation=activation)
+    critic = ContinuousCritic(preprocess_net=net_c)
+    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    for m in ActorCritic(actor, critic).modules():
+        if isinstance(m, nn.Linear):
+            nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
+            nn.init.normal_(m.bias, std=0.1)
+
+    def dist(loc_scale):
+        loc, scale = loc_scale
+        return Independent(Normal(loc, scale), 1)
+
+    policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True, action_bound_method="clip",
+                                      action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,)))
+    lr = ppo_kwargs.pop("lr", 3e-4)
+    cls = PPO if algo == "ppo" else A2C
+    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+
+    def tensors(mod, head):
+        lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)]
+        out = []
+        for m in lin + [m for m in head.modules() if isinstance(m, nn.Linear)]:
+            out += [m.weight, m.bias]
+        return out
+
+    a_par = tensors(actor, actor.mu) + [actor.sigma_param]
+    c_par = tensors(critic, critic.last)
+    out: dict[str, np.ndarray] = {"dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat]),
+                                  "hidden_a": np.array(hidden_a), "hidden_c": np.array(hidden_c),
+                                  "activation": np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation])}
+    for i, t in enumerate(a_par):
+        out[f"a{i}_0"] = t.detach().numpy().copy()
+    for i, t in enumerate(c_par):
+        out[f"c{i}_0"] = t.detach().numpy().copy()
+    perms: list[np.ndarray] = []
+    orig_perm = np.random.permutation
+
+    def rec_perm(n):
+        q = orig_perm(n)
+        perms.append(np.asarray(q, np.int64))
+        return q
+
+    seqs: list[np.ndarray] = []
+    orig_from = SequenceSummaryStats.from_sequence.__func__
+
+    def rec_from(c_, seq):
+        seqs.append(np.asarray(seq, np.float64))
+        return orig_from(c_, seq)
+
+    pre_dump: dict[str, np.ndarray] = {}
+    orig_pre = cls._preprocess_batch
+
+    def rec_pre(self, batch, buffer, indices):
+        b = orig_pre(self, batch, buffer, indices)
+        pre_dump["v_s"] = b.v_s.numpy().copy()
+        pre_dump["returns"] = b.returns.numpy().copy()
+        pre_dump["adv"] = b.adv.numpy().copy()
+        pre_dump["logp_old"] = b.logp_old.numpy().copy() if algo == "ppo" else np.zeros(len(indices), np.float32)
+        pre_dump["indices"] = np.asarray(indices, np.int64)
+        pre_dump["unfinished"] = np.asarray(buffer.unfinished_index(), np.int64)
+        return b
+
+    np.random.permutation = rec_perm
+    SequenceSummaryStats.from_sequence = classmethod(rec_from)
+    cls._preprocess_batch = rec_pre
+    try:
+        buf = VectorReplayBuffer(N, E)
+        obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
+        act = rng.normal(size=(T, E, act_dim)).astype(np.float32)
+        rew = rng.normal(size=(T, E)).astype(np.float32)
+        term = rng.random((T, E)) < 0.03
+        trunc = np.zeros((T, E), bool)
+        for t in range(T):
+            buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
+        for k in ("obs", "obs_next", "act"):
+            out[k] = np.asarray(getattr(buf, k), np.float32)
+        out["rew"] = np.asarray(buf.rew, np.float64)
+        out["terminated"], out["truncated"] = np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
+        np.random.seed(seed + 100)
+        with policy_within_training_step(algorithm.policy):
+            stats = algorithm.update(buffer=buf, batch_size=batch_size, repeat=repeat)
+        assert len(perms) == repeat and len(seqs) == 4
+        out["perms"] = np.stack(perms)
+        out["losses"] = np.stack(seqs, axis=1)              # loss, clip / actor loss, vf loss, entropy (ppo.py:218-222)
+        out["gradient_steps"] = np.array(stats.gradient_steps)
+    finally:
+        np.random.permutation = orig_perm
+        SequenceSummaryStats.from_sequence = classmethod(orig_from)
+        cls._preprocess_batch = orig_pre
+    opt = algorithm.optim._optim
+    for i, t in enumerate(a_par):
+        out[f"a{i}_1"] = t.detach().numpy().copy()
+        out[f"a{i}_m"] = opt.state[t]["exp_avg"].numpy().copy()
+        out[f"a{i}_v"] = opt.state[t]["exp_avg_sq"].numpy().copy()
+    for i, t in enumerate(c_par):
+        out[f"c{i}_1"] = t.detach().numpy().copy()
+        out[f"c{i}_m"] = opt.state[t]["exp_avg"].numpy().copy()
+        out[f"c{i}_v"] = opt.state[t]["exp_avg_sq"].numpy().copy()
+    for k, v in pre_dump.items():
+        out["pre_" + k] = v
+    cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=getattr(algorithm, "eps_clip", 0.0),
+               dual_clip=getattr(algorithm, "dual_clip", None) or 0.0, value_clip=float(getattr(algorithm, "value_clip", False)),
+               advantage_normalization=float(getattr(algorithm, "advantage_normalization", False)), vf_coef=algorithm.vf_coef,
+               ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
+               return_scaling=float(algorithm.return_scaling), lr=lr, is_a2c=float(algo == "a2c"))
+    out["cfg_keys"] = np.array(list(cfg.keys()))
+    out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
+    np.savez_compressed(os.path.join(OUT, f"ppo_net_{tag}.npz"), **out)
+
+
+def gen_ppo_net_all() -> None:
+    # a three-layer ReLU trunk with unequal widths (none a multiple of 32) and different actor / critic trunks
+    gen_ppo_net("relu3", E=4, T=50, obs_dim=11, act_dim=3, hidden_a=[96, 72, 40], hidden_c=[64, 48], activation=nn.ReLU,
+                batch_size=64, repeat=2, seed=11, eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, value_clip=True,
+                advantage_normalization=True, return_scaling=False, gae_lambda=0.95, gamma=0.99)
+    # one hidden layer, tanh; A2C
+    gen_ppo_net("tanh1_a2c", algo="a2c", E=3, T=40, obs_dim=5, act_dim=2, hidden_a=[48], hidden_c=[48], activation=nn.Tanh,
+                batch_size=60, repeat=1, seed=12, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=False,
+                gae_lambda=0.9, gamma=0.99)
+    # no activation (a linear trunk), four layers
+    gen_ppo_net("linear4", E=2, T=64, obs_dim=20, act_dim=5, hidden_a=[32, 32, 32, 32], hidden_c=[33, 17, 9, 5], activation=None,
+                batch_size=128, repeat=1, seed=13, eps_clip=0.1, dual_clip=2.0, vf_coef=0.25, ent_coef=0.0, max_grad_norm=None,
+                value_clip=False, advantage_normalization=False, return_scaling=True, gae_lambda=0.95, gamma=0.99)
+
+
 def gen_ppo_sched() -> None:
     """The mujoco_ppo.py configuration WITH its default linear learning-rate decay (lr_decay=True,
     examples/mujoco/mujoco_ppo.py:48,124-131): 3 epochs x 2 collects -> max_update_num 6, so four updates run at
@@ -1017,6 +1153,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "dqn":
         gen_dqn_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_net":
+        gen_ppo_net_all()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
         gen_rainbow_all()

@@ -1,5 +1,5 @@
 """Lane-level NumPy emulation of ts_ppo_q.h's data movement (v_mfma_f32_16x16x4_f32 operand / accumulator layouts, the
-LDS tiles R1 / R2 / R3 / XF / PP with the kernel's index expressions, the slab layout and slab3_col_to_param) for one
+LDS tiles R1 / R2 / R3 / PP and the record tile with the kernel's index expressions, the slab layout and slab3_col_to_param) for one
 32-sample tile of both networks, checked against plain matrix algebra.  A design / review tool (CPU only): it validates
 the index arithmetic the kernel was written from, not the HIP source itself.
 
@@ -45,14 +45,15 @@ def run(actor: bool):
     dW2 = dZ2.T @ H1; db2 = dZ2.sum(0); dW1aug = dZ1.T @ Xaug; dWH = dout_true.T @ H2
 
     # ---- emulation: 4 waves, LDS tiles as flat arrays
-    R1 = np.zeros(32 * PS); R2 = np.zeros(64 * PF); R3 = np.zeros(64 * PF); XF = np.zeros(K1 * PF)
+    R1 = np.zeros(32 * PS); R2 = np.zeros(64 * PF); R3 = np.zeros(64 * PF)
     PP = np.zeros(4 * 2 * 8 * 16)
     REC_W = 28
-    REC = np.zeros(32 * REC_W); REC.reshape(32, REC_W)[:, :OBS] = X
+    REC = rng.normal(size=32 * REC_W); REC.reshape(32, REC_W)[:, :OBS] = X      # act / adv / ... behind the observation: finite junk
     n, gq = N_, G_
     W = range(4)
     # resident weights per wave
-    W1a = {w: [np.where(4 * j + gq <= OBS, W1aug[16 * w + n, np.minimum(4 * j + gq, K1 - 1)], 0.0) for j in range(K1S)] for w in W}
+    W1a = {w: [np.where(4 * j + gq < OBS, W1[16 * w + n, np.minimum(4 * j + gq, OBS - 1)], 0.0) for j in range(K1S)] for w in W}
+    B1 = {w: np.stack([b1[16 * w + 4 * gq + r] for r in range(4)], 1) for w in W}
     W2f = {w: [W2[16 * w + n, 16 * (jr >> 2) + 4 * gq + (jr & 3)] for jr in range(16)] for w in W}
     W2t = {w: [W2[16 * (jr >> 2) + 4 * gq + (jr & 3), 16 * w + n] for jr in range(16)] for w in W}
     B2 = {w: np.stack([b2[16 * w + 4 * gq + r] for r in range(4)], 1) for w in W}
@@ -64,17 +65,12 @@ def run(actor: bool):
     # phase 1
     for w in W:
         fb = 16 * w
-        acc = [np.zeros((64, 4)), np.zeros((64, 4))]
+        acc = [B1[w].copy(), B1[w].copy()]                   # bias = initial accumulator
         for j in range(K1S):
             k = 4 * j + gq
             kc = np.minimum(k, REC_W - 1)
             for b in range(2):
-                xv = REC[(16 * b + n) * REC_W + kc]
-                if 4 * j + 3 >= OBS:
-                    xv = np.where(k < OBS, xv, np.where(k == OBS, 1.0, 0.0))
-                acc[b] = mfma16(W1a[w][j], xv, acc[b])
-                if (j & 3) == w:
-                    XF[k * PF + 16 * b + n] = xv
+                acc[b] = mfma16(W1a[w][j], REC[(16 * b + n) * REC_W + kc], acc[b])     # fields >= obs meet zero weights
         for b in range(2):
             acc[b] = np.tanh(acc[b])
             for r in range(4):
@@ -82,7 +78,6 @@ def run(actor: bool):
                 R3[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][:, r]
     assert np.allclose(R1.reshape(32, PS)[:, :64], H1)
     assert np.allclose(R3.reshape(64, PF)[:, :32], H1.T)
-    assert np.allclose(XF.reshape(K1, PF)[:, :32], Xaug.T)
     # phase 2
     h2 = {}
     for w in W:
@@ -187,20 +182,22 @@ def run(actor: bool):
             for r in range(4):
                 R2[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][:, r]
         gW1 = [np.zeros((64, 4)) for _ in range(NB1)]
+        rs1 = np.zeros(64)
         for J in range(2):
             av = np.stack([R2[(fb + n) * PF + 16 * J + 4 * gq + r] for r in range(4)], 1)
+            rs1 += av.sum(1)
             for c in range(NB1):
-                k = np.minimum(16 * c + n, K1 - 1)
-                bv = np.stack([XF[k * PF + 16 * J + 4 * gq + r] for r in range(4)], 1)
+                k = np.minimum(16 * c + n, REC_W - 1)
+                bv = np.stack([REC[(16 * J + 4 * gq + r) * REC_W + k] for r in range(4)], 1)      # field k of four samples
                 for r in range(4):
                     gW1[c] = mfma16(av[:, r], bv[:, r], gW1[c])
-        slab[w] = (gW2, gW1, rs)
+        slab[w] = (gW2, gW1, rs, rs1)
     # epilogue into a Slab3-shaped vector, then back through slab3_col_to_param's mapping
-    W2T = np.zeros((64, 64)); W1T = np.zeros((K1, 64)); B2g = np.zeros(64)
+    W2T = np.zeros((64, 64)); W1T = np.zeros((K1, 64)); B2g = np.zeros(64); B1g = np.zeros(64)
     HEAD = np.zeros((64, 8)) if actor else np.zeros(64)
     for w in W:
         fb = 16 * w
-        gW2, gW1, rs = slab[w]
+        gW2, gW1, rs, rs1 = slab[w]
         for c in range(4):
             for r in range(4):
                 W2T[16 * c + n, fb + 4 * gq + r] = gW2[c][:, r]
@@ -210,6 +207,8 @@ def run(actor: bool):
                 W1T[(16 * c + n)[ok], (fb + 4 * gq + r)[ok]] = gW1[c][ok, r]
         rsum = rs + rs[LANE ^ 16]; rsum = rsum + rsum[LANE ^ 32]
         B2g[(fb + n)[gq == 0]] = rsum[gq == 0]
+        r1 = rs1 + rs1[LANE ^ 16]; r1 = r1 + r1[LANE ^ 32]
+        B1g[(fb + n)[gq == 0]] = r1[gq == 0]
         if actor:
             sel = gq < 2
             for r in range(4):
@@ -222,7 +221,8 @@ def run(actor: bool):
             for r in range(4):
                 HEAD[(fb + 4 * gq + r)[sel]] = g[sel, r]
     assert np.allclose(W2T.T, dW2)                        # slab [f1][f2] -> W2[f2][f1]
-    assert np.allclose(W1T.T, dW1aug)                     # slab [k][f1]
+    assert np.allclose(W1T.T[:, :OBS], dW1aug[:, :OBS])   # slab [k][f1]; columns >= obs are not parameters
+    assert np.allclose(B1g, dW1aug[:, OBS])
     assert np.allclose(B2g, db2)
     if actor:
         assert np.allclose(HEAD[:, :ACT].T, dWH) and np.allclose(HEAD[:, ACT:], 0)

@@ -1,0 +1,98 @@
+"""PPO / A2C on actor-critics with trunks of any depth / width / activation (ts_ppo_net_step, ts_ppo_net_infer;
+tianshou_amd.ppo_wide.NetPPOEngine) against what the REFERENCE itself produced: tests/golden/ppo_net_*.npz are written by
+oracle/gen_golden.py::gen_ppo_net, which runs the unmodified tianshou PPO / A2C update() on Net(hidden_sizes=...,
+activation=...) actor-critics (utils/net/common.py:90-178, 246-369) and records inputs, Batch.split's permutations, the
+preprocessing outputs, per-step losses, final parameters and Adam moments."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TAGS = ["relu3", "tanh1_a2c", "linear4"]
+
+
+def _load(tag):
+    g = dict(np.load(os.path.join(GOLDEN, f"ppo_net_{tag}.npz"), allow_pickle=False))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
+    na, nc = 2 * (len(ha) + 1) + 1, 2 * (len(hc) + 1)
+    return g, cfg, ha, hc, na, nc
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_flat_layout_roundtrip(tag):
+    """CPU: nn.Linear tensors -> ts_net_layout vector -> tensors; padding entries are zero; sizes match ts_net_layout."""
+    import ctypes as C
+
+    from tianshou_amd import _lib
+    from tianshou_amd.ppo_wide import net_flat_from_tensors, net_flat_to_tensors
+
+    g, cfg, ha, hc, na, nc = _load(tag)
+    obs_dim, act_dim = int(g["dims"][2]), int(g["dims"][3])
+    act_name = {0: "tanh", 1: "relu", 2: "none"}[int(g["activation"])]
+    a = [torch.from_numpy(g[f"a{i}_0"]) for i in range(na)]
+    c = [torch.from_numpy(g[f"c{i}_0"]) for i in range(nc)]
+    fa = net_flat_from_tensors(a, obs_dim, ha, act_dim, "cpu")
+    fc = net_flat_from_tensors(c, obs_dim, hc, None, "cpu")
+    out = (C.c_int64 * 3)()
+    _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, ha, act_name)), _lib.i64(act_dim), out))
+    assert fa.numel() == out[1]
+    _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, hc, act_name)), _lib.i64(act_dim), out))
+    assert fc.numel() == out[2]
+    for t0, t1 in zip(a, net_flat_to_tensors(fa, obs_dim, ha, act_dim, True)):
+        assert torch.equal(t0.reshape(t1.shape), t1)
+    for t0, t1 in zip(c, net_flat_to_tensors(fc, obs_dim, hc, 1, False)):
+        assert torch.equal(t0.reshape(t1.shape), t1)
+    assert int((fa != 0).sum()) <= sum(t.numel() for t in a)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_update_matches_the_reference(tag):
+    from tianshou_amd import ppo as P
+    from tianshou_amd.ppo_wide import NetPPOEngine, net_flat_from_tensors
+
+    g, cfg, ha, hc, na, nc = _load(tag)
+    E, T, obs_dim, act_dim, batch_size, repeat = (int(x) for x in g["dims"])
+    act_name = {0: "tanh", 1: "relu", 2: "none"}[int(g["activation"])]
+    a2c = cfg["is_a2c"] > 0
+    pcfg = P.PPOConfig(algo="a2c" if a2c else "ppo", gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"], eps_clip=cfg["eps_clip"],
+                       dual_clip=cfg["dual_clip"] or None, value_clip=bool(cfg["value_clip"]),
+                       advantage_normalization=bool(cfg["advantage_normalization"]), vf_coef=cfg["vf_coef"], ent_coef=cfg["ent_coef"],
+                       max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), lr=cfg["lr"])
+    a0 = [torch.from_numpy(g[f"a{i}_0"]) for i in range(na)]
+    c0 = [torch.from_numpy(g[f"c{i}_0"]) for i in range(nc)]
+    flat = torch.cat([net_flat_from_tensors(a0, obs_dim, ha, act_dim), net_flat_from_tensors(c0, obs_dim, hc, None)])
+    eng = NetPPOEngine(obs_dim, act_dim, ha, hc, act_name, flat, pcfg)
+    idx = g["pre_indices"]
+    dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")          # noqa: E731
+    cut = np.searchsorted(idx, g["pre_unfinished"])
+    assert np.array_equal(idx[cut], g["pre_unfinished"])
+    b = eng.preprocess(dev(g["obs"][idx]), dev(g["obs_next"][idx]), dev(g["act"][idx]), dev(g["rew"][idx]),
+                       dev(g["terminated"][idx]), dev(g["truncated"][idx]), dev(cut))
+    for k in ("v_s", "returns", "adv") + (() if a2c else ("logp_old",)):
+        np.testing.assert_allclose(b[k].cpu().numpy(), g["pre_" + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    losses, steps = eng.update(b, batch_size, repeat, [p for p in g["perms"]])
+    torch.cuda.synchronize()
+    assert steps == int(g["gradient_steps"])
+    np.testing.assert_allclose(losses.cpu().numpy(), g["losses"], rtol=2e-5, atol=2e-6)
+    fa, fc = eng.flat_to_tensors(eng.params.cpu())
+    ma, mc = eng.flat_to_tensors(eng.adam_m.cpu())
+    va, vc = eng.flat_to_tensors(eng.adam_v.cpu())
+    lr = cfg["lr"]
+    for i in range(na):
+        np.testing.assert_allclose(fa[i].numpy().reshape(g[f"a{i}_1"].shape), g[f"a{i}_1"], rtol=1e-4, atol=0.02 * lr, err_msg=f"a{i}")
+        np.testing.assert_allclose(ma[i].numpy().reshape(g[f"a{i}_m"].shape), g[f"a{i}_m"], rtol=1e-3, atol=1e-6, err_msg=f"a{i} m")
+        np.testing.assert_allclose(va[i].numpy().reshape(g[f"a{i}_v"].shape), g[f"a{i}_v"], rtol=2e-3, atol=1e-9, err_msg=f"a{i} v")
+    for i in range(nc):
+        np.testing.assert_allclose(fc[i].numpy().reshape(g[f"c{i}_1"].shape), g[f"c{i}_1"], rtol=1e-4, atol=0.02 * lr, err_msg=f"c{i}")
+        np.testing.assert_allclose(mc[i].numpy().reshape(g[f"c{i}_m"].shape), g[f"c{i}_m"], rtol=1e-3, atol=1e-6, err_msg=f"c{i} m")
+        np.testing.assert_allclose(vc[i].numpy().reshape(g[f"c{i}_v"].shape), g[f"c{i}_v"], rtol=2e-3, atol=1e-9, err_msg=f"c{i} v")
+    # padding entries of the flat vector (widths rounded up to 32) stay exactly zero through the update
+    pad = torch.ones(eng.P, dtype=torch.bool)
+    mask_src = [torch.ones_like(t) for t in a0], [torch.ones_like(t) for t in c0]
+    pad &= (torch.cat([net_flat_from_tensors(mask_src[0], obs_dim, ha, act_dim, "cpu"),
+                       net_flat_from_tensors(mask_src[1], obs_dim, hc, None, "cpu")]) == 0)
+    assert torch.all(eng.params.cpu()[pad] == 0)

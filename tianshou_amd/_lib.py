@@ -51,6 +51,25 @@ class PPOHParams(C.Structure):
     ]
 
 
+class NetDesc(C.Structure):
+    """struct ts_net_desc (include/tsengine.h): a Net / MLP trunk of any depth -- `hidden_sizes` and one activation
+    (utils/net/common.py:90-178, 246-369)."""
+
+    MAX_HIDDEN = 7
+    ACTIVATIONS = {"tanh": 0, "relu": 1, "none": 2}
+    _fields_ = [("obs_dim", C.c_int64), ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden", C.c_int64 * 7)]
+
+    @classmethod
+    def make(cls, obs_dim: int, hidden, activation: str) -> "NetDesc":
+        hidden = [int(h) for h in hidden]
+        if not 1 <= len(hidden) <= cls.MAX_HIDDEN:
+            raise NotImplementedError(f"trunks of 1 .. {cls.MAX_HIDDEN} hidden layers are supported, got {len(hidden)}")
+        if activation not in cls.ACTIVATIONS:
+            raise NotImplementedError(f"activation must be one of {sorted(cls.ACTIVATIONS)}, got {activation!r}")
+        d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))))
+        return d
+
+
 _lib = None
 KERNEL_KINDS = ("ppo_step", "ppo_reduce", "ppo_adam", "ppo_infer", "gae_maps", "gae_apply",
                 "conv_fwd", "conv_wgrad", "conv_dgrad")

@@ -564,6 +564,109 @@ int jvp(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const fl
     return TS_OK;
 }
 
+
+// ---- trunks of any depth / width / activation (ts_net_desc): the PPO / A2C step and the inference passes of ppo_wide on the
+// same layer kernels.  Net / MLP: Sequential(Linear, act, Linear, act, ...) (utils/net/common.py:90-178), linear heads.
+constexpr int MAXL = TS_NET_MAX_HIDDEN + 1;          // linear layers incl. the head
+
+struct NetL {
+    ts::ConvGeom l[MAXL];
+    int64_t off[MAXL + 1];        // off[L] = end of the head block
+    int L, obs, k0, act_fn, wmax;
+    int width[MAXL + 1];          // width[0] = k0, width[i] = padded width of hidden layer i - 1, width[L] = HEAD
+};
+
+int make_netl(int B, const ts_net_desc* d, NetL* n) {
+    TS_REQUIRE(d != nullptr, TS_ERR_INVALID_ARG, "net: descriptor is NULL");
+    TS_REQUIRE(d->obs_dim >= 1 && d->obs_dim <= 65536 && d->n_hidden >= 1 && d->n_hidden <= TS_NET_MAX_HIDDEN, TS_ERR_INVALID_ARG,
+               "net: obs_dim >= 1 and 1 .. %d hidden layers", TS_NET_MAX_HIDDEN);
+    TS_REQUIRE(d->activation >= TS_NET_ACT_TANH && d->activation <= TS_NET_ACT_NONE, TS_ERR_UNSUPPORTED,
+               "net: activation must be tanh, ReLU or none");
+    n->L = d->n_hidden + 1; n->obs = (int)d->obs_dim; n->k0 = (n->obs + 31) / 32 * 32; n->act_fn = d->activation;
+    n->width[0] = n->k0;
+    n->wmax = HEAD;
+    for (int i = 0; i < d->n_hidden; ++i) {
+        TS_REQUIRE(d->hidden[i] >= 1 && d->hidden[i] <= 1024, TS_ERR_UNSUPPORTED, "net: hidden widths must be in [1, 1024]");
+        n->width[i + 1] = ((int)d->hidden[i] + 31) / 32 * 32;
+        n->wmax = std::max(n->wmax, n->width[i + 1]);
+    }
+    n->width[n->L] = HEAD;
+    int64_t o = 0;
+    for (int i = 0; i < n->L; ++i) {
+        n->l[i] = ts::ConvGeom{B, 1, 1, n->width[i], 1, 1, 1, 1, 1, n->width[i + 1]};
+        n->off[i] = o;
+        o += n->l[i].param_elems();
+    }
+    n->off[n->L] = o;
+    return TS_OK;
+}
+
+struct ActL { float* h[MAXL]; };              // h[i] = output of layer i (h[L - 1] = the head's 32 columns)
+
+ActL take_actl(Carve& c, const NetL& n, int64_t B) {
+    ActL a{};
+    for (int i = 0; i < n.L; ++i) a.h[i] = c.f(B * n.width[i + 1]);
+    return a;
+}
+size_t actl_bytes(const NetL& n, int64_t B) {
+    size_t s = 0;
+    for (int i = 0; i < n.L; ++i) s += al(4 * B * n.width[i + 1]);
+    return s;
+}
+size_t split_floats(const NetL& n) {
+    size_t s = 4;
+    for (int i = 0; i < n.L; ++i) { const int ns = ts::conv_fwd_splits(n.l[i]); if (ns > 1) s = std::max(s, (size_t)ns * n.l[i].out_elems()); }
+    return s;
+}
+size_t slab_floats(const NetL& n) {
+    size_t s = 0;
+    for (int i = 0; i < n.L; ++i) s = std::max(s, (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    return s;
+}
+
+// dh *= (h > 0)   (backward through ReLU; h is the layer's OUTPUT, torch's threshold_backward uses the same sign test)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dh[i] = h[i] > 0.f ? dh[i] : 0.f;
+}
+
+int forward_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, const float* x, const ActL& a, float* split, int64_t B) {
+    const float* in = x;
+    for (int i = 0; i < n.L; ++i) {
+        const bool hidden = i + 1 < n.L;
+        if (int rc = ts::conv_forward(s, n.l[i], in, p + n.off[i], a.h[i], hidden && n.act_fn == TS_NET_ACT_RELU, split, ws)) return rc;
+        if (hidden && n.act_fn == TS_NET_ACT_TANH) {
+            const int64_t cnt = B * n.width[i + 1];
+            hipLaunchKernelGGL(tanh_kernel, dim3((unsigned)ts::ceil_div(cnt, 256)), dim3(256), 0, s, a.h[i], cnt);
+            TS_LAUNCH_CHECK();
+        }
+        in = a.h[i];
+    }
+    return TS_OK;
+}
+
+// grad[0 .. off[L]) = J^T d_out; dha / dhb: two [B, wmax] scratch buffers (the hidden gradients ping-pong between them)
+int backward_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, const float* x, const ActL& a, const float* d_out,
+               float* grad, float* dha, float* dhb, float* slabs, int64_t B) {
+    const float* dy = d_out;
+    for (int i = n.L - 1; i >= 0; --i) {
+        const float* xin = i == 0 ? x : a.h[i - 1];
+        if (int rc = ts::conv_wgrad(s, n.l[i], xin, dy, slabs, ws)) return rc;
+        if (int rc = ts::slab_sum(s, slabs, ts::conv_wgrad_splits(n.l[i]), n.l[i].param_elems(), grad + n.off[i])) return rc;
+        if (i > 0) {
+            float* dx = (dy == dha) ? dhb : dha;
+            if (int rc = ts::conv_dgrad(s, n.l[i], dy, p + n.off[i], nullptr, dx, ws)) return rc;
+            const int64_t cnt = B * n.width[i];
+            const unsigned g = (unsigned)ts::ceil_div(cnt, 256);
+            if (n.act_fn == TS_NET_ACT_TANH) hipLaunchKernelGGL(tanh_bwd_kernel, dim3(g), dim3(256), 0, s, dx, a.h[i - 1], cnt);
+            else if (n.act_fn == TS_NET_ACT_RELU) hipLaunchKernelGGL(relu_bwd_kernel, dim3(g), dim3(256), 0, s, dx, a.h[i - 1], cnt);
+            TS_LAUNCH_CHECK();
+            dy = dx;
+        }
+    }
+    return TS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -832,6 +935,125 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
     TS_LAUNCH_CHECK();
     if (int rc = backward(s, ws, n, critic, x, a, d_head, grad + Pa, bw, B)) return rc;
     hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + n.off[3], A, (float)hp->vf_coef,
+                       (float)hp->ent_coef);
+    TS_LAUNCH_CHECK();
+    if (!apply) return TS_OK;
+    // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam
+    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+                         hp->max_grad_norm > 0.0 ? hp->max_grad_norm : 0.0, norm_part);
+}
+
+int ts_net_layout(const ts_net_desc* net, int64_t act_dim, int64_t* h_out3) {
+    NetL n;
+    if (int rc = make_netl(1, net, &n)) return rc;
+    TS_REQUIRE(act_dim >= 1 && act_dim <= HEAD && h_out3, TS_ERR_INVALID_ARG, "ts_net_layout: act_dim must be in [1, 32]");
+    h_out3[0] = n.k0; h_out3[1] = n.off[n.L] + HEAD; h_out3[2] = n.off[n.L];
+    return TS_OK;
+}
+
+int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, const ts_net_desc* actor_net,
+                     const ts_net_desc* critic_net, int64_t act_dim, const float* obs, const float* act, int64_t B,
+                     float* v_out, float* logp_out, float* mu_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_net_infer: workspace is NULL");
+    TS_REQUIRE(B >= 0, TS_ERR_INVALID_ARG, "ts_ppo_net_infer: negative batch");
+    if (B == 0) return TS_OK;
+    const bool want_a = logp_out || mu_out;
+    TS_REQUIRE(obs && act_dim >= 1 && act_dim <= HEAD && (!v_out || (critic && critic_net)) && (!want_a || (actor && actor_net)) &&
+                   (!logp_out || act), TS_ERR_INVALID_ARG, "ts_ppo_net_infer: bad argument");
+    NetL na{}, nc{};
+    if (want_a) if (int rc = make_netl((int)B, actor_net, &na)) return rc;
+    if (v_out) if (int rc = make_netl((int)B, critic_net, &nc)) return rc;
+    const NetL& any = want_a ? na : nc;
+    TS_REQUIRE(!(want_a && v_out) || na.obs == nc.obs, TS_ERR_SHAPE, "ts_ppo_net_infer: actor and critic read different observations");
+    hipStream_t s = ts::as_stream(stream);
+    const size_t sp = std::max(want_a ? split_floats(na) : 4, v_out ? split_floats(nc) : 4);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * any.k0) + (want_a ? actl_bytes(na, B) : 0) + (v_out ? actl_bytes(nc, B) : 0) + al(4 * sp) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * any.k0);
+    ActL aa{}, ac{};
+    if (want_a) aa = take_actl(c, na, B);
+    if (v_out) ac = take_actl(c, nc, B);
+    float* split = c.f(sp);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * any.k0, 256)), dim3(256), 0, s, obs, B, any.obs, any.k0, x);
+    TS_LAUNCH_CHECK();
+    if (want_a) if (int rc = forward_l(s, ws, na, actor, x, aa, split, B)) return rc;
+    if (v_out) if (int rc = forward_l(s, ws, nc, critic, x, ac, split, B)) return rc;
+    hipLaunchKernelGGL(infer_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, want_a ? aa.h[na.L - 1] : nullptr,
+                       v_out ? ac.h[nc.L - 1] : nullptr, act, want_a ? actor + na.off[na.L] : (const float*)nullptr, B, (int)act_dim,
+                       v_out, logp_out, mu_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step,
+                    const ts_net_desc* actor_net, const ts_net_desc* critic_net, int64_t act_dim, const float* obs,
+                    const float* act, const float* adv, const float* returns, const float* logp_old, const float* v_old,
+                    int64_t B, int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4,
+                    float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_ppo_net_step: workspace is NULL");
+    TS_REQUIRE(params && obs && act && adv && returns && hp && losses_out4 && B >= 1 && global_batch >= B && act_dim >= 1 &&
+                   act_dim <= HEAD, TS_ERR_INVALID_ARG, "ts_ppo_net_step: bad argument");
+    const bool a2c = hp->algo == 1;
+    TS_REQUIRE(a2c || logp_old, TS_ERR_INVALID_ARG, "ts_ppo_net_step: PPO needs logp_old");
+    TS_REQUIRE(a2c || !hp->value_clip || v_old, TS_ERR_INVALID_ARG, "ts_ppo_net_step: value_clip needs v_old");
+    TS_REQUIRE(a2c || !hp->adv_norm || adv_stats, TS_ERR_INVALID_ARG, "ts_ppo_net_step: adv_norm needs adv_stats");
+    const bool apply = hp->lr >= 0.0;
+    TS_REQUIRE(!apply || (adam_m && adam_v && adam_step >= 1), TS_ERR_INVALID_ARG, "ts_ppo_net_step: Adam state missing");
+    NetL na, nc;
+    if (int rc = make_netl((int)B, actor_net, &na)) return rc;
+    if (int rc = make_netl((int)B, critic_net, &nc)) return rc;
+    TS_REQUIRE(na.obs == nc.obs, TS_ERR_SHAPE, "ts_ppo_net_step: actor and critic read different observations");
+    hipStream_t s = ts::as_stream(stream);
+    const int A = (int)act_dim;
+    const int64_t Pa = na.off[na.L] + HEAD, Pc = nc.off[nc.L], P = Pa + Pc;
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    const int wmax = std::max(na.wmax, nc.wmax);
+    const size_t sp = std::max(split_floats(na), split_floats(nc)), sl = std::max(slab_floats(na), slab_floats(nc));
+    if (int rc = ts::ws_reserve(ws, al(4 * B * na.k0) + std::max(actl_bytes(na, B), actl_bytes(nc, B)) + al(4 * B * HEAD) +
+                                        2 * al(4 * B * wmax) + al(4 * sl) + al(4 * sp) + al(4 * P) +
+                                        al(4 * (size_t)n_blocks * (2 + A)) + 8192))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * na.k0);
+    char* act_base = c.p;                                   // the two networks run one after the other: same activation area
+    const ActL aa = take_actl(c, na, B);
+    Carve c2{act_base};
+    const ActL ac = take_actl(c2, nc, B);
+    if (c2.p > c.p) c.p = c2.p;
+    float* d_head = c.f(B * HEAD);
+    float* dha = c.f(B * wmax);
+    float* dhb = c.f(B * wmax);
+    float* slabs = c.f(sl);
+    float* split = c.f(sp);
+    float* grad = c.f(P);
+    float* partial = c.f((size_t)n_blocks * (2 + A));
+    float* norm_part = c.f(1024);
+    if (grad_out) grad = grad_out;
+    const float* actor = params;
+    const float* critic = params + Pa;
+    const float inv_b = 1.0f / (float)global_batch;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * na.k0, 256)), dim3(256), 0, s, obs, B, na.obs, na.k0, x);
+    TS_LAUNCH_CHECK();
+    // ---- actor: forward, clipped surrogate (+ entropy gradient on log_sigma), backward   (ppo.py:181-196, a2c.py:262-268)
+    if (int rc = forward_l(s, ws, na, actor, x, aa, split, B)) return rc;
+    WideLossP lp{};
+    lp.eps_clip = (float)hp->eps_clip; lp.dual_clip = a2c ? 0.f : (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
+    lp.ent_coef = (float)hp->ent_coef; lp.inv_b = inv_b; lp.a2c = a2c; lp.adv_norm = a2c ? 0 : hp->adv_norm;
+    hipLaunchKernelGGL(ppo_wide_actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, aa.h[na.L - 1], act, adv, logp_old,
+                       actor + na.off[na.L], adv_stats, lp, B, A, d_head, partial);
+    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, global_batch, A, losses_out4 + 1,
+                       grad + na.off[na.L]);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward_l(s, ws, na, actor, x, aa, d_head, grad, dha, dhb, slabs, B)) return rc;
+    // ---- critic   (ppo.py:198-208, a2c.py:270)
+    if (int rc = forward_l(s, ws, nc, critic, x, ac, split, B)) return rc;
+    hipLaunchKernelGGL(ppo_wide_critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, ac.h[nc.L - 1], returns, v_old,
+                       (float)hp->eps_clip, a2c ? 0 : hp->value_clip, (float)hp->vf_coef, B, inv_b, d_head, partial);
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, inv_b, losses_out4 + 2);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward_l(s, ws, nc, critic, x, ac, d_head, grad + Pa, dha, dhb, slabs, B)) return rc;
+    hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + na.off[na.L], A, (float)hp->vf_coef,
                        (float)hp->ent_coef);
     TS_LAUNCH_CHECK();
     if (!apply) return TS_OK;

@@ -170,3 +170,111 @@ class WidePPOEngine:
                 self.step(b, perm[lo:hi], losses[k], grads if k == n_steps - 1 else None)
                 k += 1
         return (losses, n_steps, grads) if want_grad else (losses, n_steps)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Trunks of any depth / width / activation (ts_net_desc): Net(hidden_sizes=[...], activation=Tanh | ReLU | None),
+# utils/net/common.py:90-178, 246-369 -- the same hooks on ts_ppo_net_step / ts_ppo_net_infer.
+
+def _pad32(n: int) -> int:
+    return (int(n) + 31) // 32 * 32
+
+
+def net_flat_from_tensors(t: list[torch.Tensor], obs_dim: int, hidden: list[int], n_out: int | None, device="cuda") -> torch.Tensor:
+    """nn.Linear-layout tensors [w1, b1, ..., w_L, b_L, w_head, b_head(, sigma_param)] -> the ts_net_layout vector: per layer
+    one block [K_pad + 1, N_pad] (last row = bias; widths padded to 32 with zeros), the head padded to 32 columns, and for
+    an actor (n_out = act_dim) log_sigma padded to 32."""
+    dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
+    parts = [NG._block(t[2 * i], t[2 * i + 1], dims[i], dims[i + 1]) for i in range(len(hidden) + 1)]
+    if n_out is not None:
+        ls = torch.zeros(NG.HEAD, dtype=torch.float32)
+        ls[:n_out] = t[2 * (len(hidden) + 1)].detach().float().cpu().reshape(-1)
+        parts.append(ls)
+    return torch.cat(parts).to(device).contiguous()
+
+
+def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_head: int, actor: bool) -> list[torch.Tensor]:
+    """Inverse of net_flat_from_tensors (nn.Linear layout; n_head = act_dim for an actor, 1 for a critic)."""
+    true = [obs_dim] + list(hidden) + [n_head]
+    dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
+    f, off, out = flat.detach(), 0, []
+    for i in range(len(hidden) + 1):
+        n = (dims[i] + 1) * dims[i + 1]
+        blk = f[off:off + n].reshape(dims[i] + 1, dims[i + 1])
+        out += [blk[: true[i], : true[i + 1]].t().contiguous(), blk[dims[i], : true[i + 1]].clone()]
+        off += n
+    if actor:
+        out.append(f[off:off + NG.HEAD][:n_head].clone())
+    return out
+
+
+class NetPPOEngine(WidePPOEngine):
+    """WidePPOEngine's interface (preprocess / step / update / infer) for actor-critics whose trunks have any number of
+    hidden layers of any widths and a tanh / ReLU / no activation; actor and critic trunks may differ."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden_actor, hidden_critic, activation: str, flat_params: torch.Tensor,
+                 cfg: PPOConfig):
+        if not flat_params.is_cuda:
+            raise RuntimeError("NetPPOEngine needs its parameters on an MI355X; there is no CPU fallback")
+        if not 1 <= act_dim <= 32:
+            raise NotImplementedError("NetPPOEngine: act_dim <= 32")
+        self.obs_dim, self.act_dim, self.cfg = obs_dim, act_dim, cfg
+        self.hidden_actor, self.hidden_critic, self.activation = [int(h) for h in hidden_actor], [int(h) for h in hidden_critic], activation
+        self.hidden = None
+        self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation)
+        self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation)
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().ts_net_layout(C.byref(self._na), _lib.i64(act_dim), out))
+        self.n_actor = int(out[1])
+        _lib.check(_lib.load().ts_net_layout(C.byref(self._nc), _lib.i64(act_dim), out))
+        self.n_critic = int(out[2])
+        self.P = self.n_actor + self.n_critic
+        if flat_params.numel() != self.P:
+            raise ValueError(f"flat_params has {flat_params.numel()} entries, layout needs {self.P}")
+        self.params = flat_params.detach().to(torch.float32).contiguous().clone()
+        self.adam_m, self.adam_v = torch.zeros_like(self.params), torch.zeros_like(self.params)
+        self.adam_step = 0
+        self.device = self.params.device
+        self.ret_rms = [0.0, 1.0, 0.0]
+        self._eps = 1e-8
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    def flat_from_tensors(self, actor_t, critic_t) -> torch.Tensor:
+        return torch.cat([net_flat_from_tensors(actor_t, self.obs_dim, self.hidden_actor, self.act_dim, self.device),
+                          net_flat_from_tensors(critic_t, self.obs_dim, self.hidden_critic, None, self.device)]).contiguous()
+
+    def flat_to_tensors(self, flat: torch.Tensor):
+        return (net_flat_to_tensors(flat[: self.n_actor], self.obs_dim, self.hidden_actor, self.act_dim, True),
+                net_flat_to_tensors(flat[self.n_actor:], self.obs_dim, self.hidden_critic, 1, False))
+
+    def infer(self, obs, act=None, want_v=True):
+        b = obs.shape[0]
+        v = torch.empty(b, dtype=torch.float32, device=self.device) if want_v else None
+        logp = torch.empty(b, dtype=torch.float32, device=self.device) if act is not None else None
+        _lib.check(_lib.load().ts_ppo_net_infer(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic), C.byref(self._na), C.byref(self._nc),
+            _lib.i64(self.act_dim), _lib.ptr(obs), _lib.ptr(act), _lib.i64(b), _lib.ptr(v), _lib.ptr(logp), None,
+            _lib.current_stream(self.device)))
+        return v, logp
+
+    def step(self, b: dict, rows, losses_out: torch.Tensor, grad_out=None, apply: bool = True, global_batch=None, adv_stats=None):
+        """One minibatch (see WidePPOEngine.step) on ts_ppo_net_step."""
+        cfg = self.cfg
+        take = (lambda t: t) if rows is None else (lambda t: gather_rows(t, rows))       # noqa: E731
+        obs, act = take(b["obs"]), take(b["act"])
+        adv, ret, lp_old, v_old = take(b["adv"]), take(b["returns"]), take(b["logp_old"]), take(b["v_s"])
+        n = obs.shape[0]
+        stats = adv_stats
+        if stats is None and cfg.advantage_normalization and cfg.algo != "a2c":     # ppo.py:184-186 (unbiased std)
+            a64 = adv.double()
+            stats = torch.stack([a64.mean(), a64.std()]).float().contiguous()
+        hp = cfg.to_c()
+        if not apply:
+            hp.lr = -1.0
+        else:
+            self.adam_step += 1
+        _lib.check(_lib.load().ts_ppo_net_step(
+            self._ws.handle, _lib.ptr(self.params), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(max(self.adam_step, 1)),
+            C.byref(self._na), C.byref(self._nc), _lib.i64(self.act_dim), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(adv), _lib.ptr(ret),
+            _lib.ptr(lp_old), _lib.ptr(v_old), _lib.i64(n), _lib.i64(global_batch or n), _lib.ptr(stats), C.byref(hp),
+            _lib.ptr(losses_out), _lib.ptr(grad_out), _lib.current_stream(self.device)))
