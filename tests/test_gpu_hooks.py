@@ -1160,3 +1160,67 @@ def test_hip_ddpg_hooks_against_oracle():
     st_a = algo.policy_optim._optim.state[next(iter(actor.parameters()))]
     st_c = algo.critic_optim._optim.state[next(iter(c1.parameters()))]
     assert float(st_a["step"]) == 4.0 and float(st_c["step"]) == 4.0
+
+
+@pytest.mark.parametrize("tag", ["relu3", "linear4"])
+def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
+    """Net trunks outside [h, h] tanh (three ReLU layers of unequal widths with a different critic trunk; four linear layers):
+    HipPPO picks the per-layer engine (kind "net", ppo_wide.NetPPOEngine) and the whole hook path -- mirror, preprocess, the
+    host-drawn Batch.split permutations, update, write-back, Adam flush -- reproduces what the REFERENCE's PPO.update()
+    produced on the same buffer contents, weights and NumPy seed (tests/golden/ppo_net_*.npz, oracle/gen_golden.py::gen_ppo_net)."""
+    import os
+
+    from tianshou_amd.integration import make_hip_ppo
+    from tianshou_amd.ppo_wide import NetPPOEngine
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", f"ppo_net_{tag}.npz")))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    E, T, obs_dim, act_dim, batch_size, repeat = (int(x) for x in g["dims"])
+    ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
+    act_cls = {0: nn.Tanh, 1: nn.ReLU, 2: None}[int(g["activation"])]
+    seed = {"relu3": 11, "linear4": 13}[tag]
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, act_cls))
+
+    def params(mod, head, extra=()):
+        lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)] + [m for m in head.modules() if isinstance(m, nn.Linear)]
+        out = []
+        for m in lin:
+            out += [m.weight, m.bias]
+        return out + list(extra)
+
+    pa, pc = params(actor, actor.mu, [actor.sigma_param]), params(critic, critic.last)
+    with torch.no_grad():
+        for i, p in enumerate(pa):
+            p.copy_(torch.from_numpy(g[f"a{i}_0"]))
+        for i, p in enumerate(pc):
+            p.copy_(torch.from_numpy(g[f"c{i}_0"]))
+    kw = dict(eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"] or None, value_clip=bool(cfg["value_clip"]),
+              advantage_normalization=bool(cfg["advantage_normalization"]), vf_coef=cfg["vf_coef"], ent_coef=cfg["ent_coef"],
+              max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), gae_lambda=cfg["gae_lambda"],
+              gamma=cfg["gamma"], lr=cfg["lr"])
+    algo = make_hip_ppo("ppo", ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", permutations="host", **kw).to("cuda")
+    assert algo._hip_dims == (obs_dim, act_dim, (tuple(ha), tuple(hc), {nn.Tanh: "tanh", nn.ReLU: "relu", None: "none"}[act_cls]), "net")
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    size = buf.maxsize // E
+    for t in range(T):                                   # slot e * size + t of the fixture's buffer = env e, step t
+        rows = np.arange(E) * size + t
+        buf.add(SI.Batch(obs=g["obs"][rows], act=g["act"][rows], rew=g["rew"][rows], terminated=g["terminated"][rows],
+                         truncated=g["truncated"][rows], obs_next=g["obs_next"][rows]))
+    assert np.array_equal(buf.sample_indices(0), g["pre_indices"])
+    algo.policy.is_within_training_step = True
+    np.random.seed(seed + 100)
+    stats = algo.update(buf, batch_size, repeat)
+    assert isinstance(algo._hip_engine, NetPPOEngine) and stats.gradient_steps == int(g["gradient_steps"])
+    for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+        ref = SI.SequenceSummaryStats.from_sequence(g["losses"][:, col])
+        np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=2e-5, atol=2e-6)
+    for i, p in enumerate(pa):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"a{i}_1"], rtol=1e-4, atol=0.02 * cfg["lr"], err_msg=f"a{i}")
+    for i, p in enumerate(pc):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"c{i}_1"], rtol=1e-4, atol=0.02 * cfg["lr"], err_msg=f"c{i}")
+    algo.state_dict()                                     # Adam moments arrive lazily, per parameter
+    state = algo.optim._optim.state
+    for i, p in enumerate(pa):
+        np.testing.assert_allclose(state[p]["exp_avg"].cpu().numpy(), g[f"a{i}_m"], rtol=1e-3, atol=1e-6)
+        assert state[p]["exp_avg"].shape == p.shape and float(state[p]["step"]) == stats.gradient_steps

@@ -102,7 +102,22 @@ def test_unsupported_nets_are_rejected():
     assert _check_supported(*nets([64, 64])) == (17, 6, 64, "fused")
     assert _check_supported(*nets([128, 128])) == (17, 6, 128, "wide")          # GEMM path (tianshou_amd/ppo_wide.py)
     assert _check_supported(*nets([64, 64], n_act=12)) == (17, 12, 64, "wide")
-    for bad in (nets([100, 100]), nets([64, 64], act=nn.ReLU), nets([64, 32]), nets([64, 64, 64]), nets([64, 64], n_act=40)):
+    # every other trunk Net builds from hidden_sizes + one activation: the per-layer engine (ppo_wide.NetPPOEngine)
+    assert _check_supported(*nets([100, 100])) == (17, 6, ((100, 100), (100, 100), "tanh"), "net")
+    assert _check_supported(*nets([64, 64], act=nn.ReLU)) == (17, 6, ((64, 64), (64, 64), "relu"), "net")
+    assert _check_supported(*nets([64, 32])) == (17, 6, ((64, 32), (64, 32), "tanh"), "net")
+    assert _check_supported(*nets([256, 128, 64], act=None)) == (17, 6, ((256, 128, 64), (256, 128, 64), "none"), "net")
+    a3, _ = nets([96, 72, 40], act=nn.ReLU)
+    _, c2 = nets([64, 48], act=nn.ReLU)
+    assert _check_supported(a3, c2) == (17, 6, ((96, 72, 40), (64, 48), "relu"), "net")
+    a_cs = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                        action_shape=(6,), unbounded=True, conditioned_sigma=True)
+    a_norm = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh,
+                                                             norm_layer=nn.LayerNorm), action_shape=(6,), unbounded=True)
+    a_mixed, _ = nets([64, 64], act=nn.ELU)
+    _, c_relu = nets([64, 64], act=nn.ReLU)
+    for bad in (nets([64, 64], n_act=40), nets([32] * 8), nets([2048, 64]), (a_cs, nets([64, 64])[1]), (a_norm, nets([64, 64])[1]),
+                (a_mixed, nets([64, 64])[1]), (nets([64, 64])[0], c_relu)):
         with pytest.raises(NotImplementedError):
             _check_supported(*bad)
 

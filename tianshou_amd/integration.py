@@ -223,36 +223,77 @@ def _on_policy_base(algo: str, ref=None):
     raise ValueError("algo must be 'ppo' or 'a2c'")
 
 
-def _check_supported(actor, critic) -> tuple[int, int, int, str]:
-    """-> (obs_dim, act_dim, hidden, kind).  kind "fused": the MuJoCo example nets (hidden 64 x 64, obs <= 31, act <= 8) on
-    the fused MFMA kernels of ts_ppo.hip; "wide": any other Net[h, h] (h a multiple of 32 up to 1024, act <= 32, e.g.
-    Humanoid's 376 / 17 / 256 x 256) on the implicit-GEMM layer kernels (tianshou_amd/ppo_wide.py)."""
+def _trunk_spec(net, who: str):
+    """Net -> MLP -> Sequential(Linear, act, Linear, act, ...) (utils/net/common.py:90-178): -> (linear-layer key stems,
+    hidden sizes, activation name).  One activation class for all layers (nn.Tanh / nn.ReLU) or none; norm layers and other
+    activations are outside the engine's envelope."""
+    try:
+        seq = list(net.preprocess.model.model)
+    except AttributeError as e:
+        raise NotImplementedError(f"HipPPO: unsupported {who} (no preprocess.model.model Sequential)") from e
+    stems, hidden, acts = [], [], set()
+    for i, m in enumerate(seq):
+        if isinstance(m, torch.nn.Linear):
+            stems.append(f"preprocess.model.model.{i}")
+            hidden.append(int(m.out_features))
+        elif isinstance(m, torch.nn.Tanh):
+            acts.add("tanh")
+        elif isinstance(m, torch.nn.ReLU):
+            acts.add("relu")
+        elif isinstance(m, torch.nn.Identity):
+            pass
+        else:
+            raise NotImplementedError(f"HipPPO: {who} trunk contains {type(m).__name__}; Linear layers with nn.Tanh, nn.ReLU "
+                                      "or no activation are supported (no norm layers)")
+    if not stems or len(acts) > 1:
+        raise NotImplementedError(f"HipPPO: {who} trunk needs at least one Linear layer and a single activation class")
+    return stems, hidden, (acts.pop() if acts else "none")
+
+
+def _net_keys(actor, critic):
+    """state_dict keys of an actor / critic over Net trunks of any depth, in the engine's flat order:
+    actor trunk (w, b)*, mu (w, b), sigma_param | critic trunk (w, b)*, last (w, b)."""
+    sa, _, _ = _trunk_spec(actor, "actor")
+    sc, _, _ = _trunk_spec(critic, "critic")
+    ka = [f"{st}.{x}" for st in sa for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    kc = [f"{st}.{x}" for st in sc for x in ("weight", "bias")] + ["last.model.0.weight", "last.model.0.bias"]
+    return ka, kc
+
+
+def _check_supported(actor, critic):
+    """-> (obs_dim, act_dim, hidden, kind).  kind "fused": the MuJoCo example nets (hidden 64 x 64 tanh, obs <= 31, act <= 8) on
+    the fused MFMA kernels of ts_ppo.hip; "wide": any other Net[h, h] tanh (h a multiple of 32 up to 1024, act <= 32, e.g.
+    Humanoid's 376 / 17 / 256 x 256) on the implicit-GEMM layer kernels (tianshou_amd/ppo_wide.py); "net": every other trunk
+    the reference's Net builds from `hidden_sizes` and one activation (1 .. 7 hidden layers of any widths up to 1024, nn.Tanh /
+    nn.ReLU / none, actor and critic trunks may differ) on the same layer kernels (ppo_wide.NetPPOEngine) -- `hidden` is then
+    (actor hidden sizes, critic hidden sizes, activation)."""
+    ka, kc = _net_keys(actor, critic)
     sa, sc = actor.state_dict(), critic.state_dict()
-    for k in TIANSHOU_ACTOR_KEYS:
-        if k not in sa:
-            raise NotImplementedError(f"HipPPO: unsupported actor (missing {k}); see tianshou_amd/integration.py")
-    for k in TIANSHOU_CRITIC_KEYS:
-        if k not in sc:
-            raise NotImplementedError(f"HipPPO: unsupported critic (missing {k})")
-    if len(sa) != len(TIANSHOU_ACTOR_KEYS) or len(sc) != len(TIANSHOU_CRITIC_KEYS):
-        raise NotImplementedError("HipPPO: only Net[h, h] trunks (two hidden layers) with linear heads are supported")
-    w1, w2 = sa["preprocess.model.model.0.weight"], sa["preprocess.model.model.2.weight"]
-    hidden, obs_dim = int(w1.shape[0]), int(w1.shape[1])
-    act_dim = int(sa["mu.model.0.weight"].shape[0])
-    cw1, cw2 = sc["preprocess.model.model.0.weight"], sc["preprocess.model.model.2.weight"]
-    if tuple(w2.shape) != (hidden, hidden) or tuple(cw1.shape) != (hidden, obs_dim) or tuple(cw2.shape) != (hidden, hidden):
-        raise NotImplementedError("HipPPO: actor and critic must both be Net[h, h] over the same observation")
-    for net in (actor, critic):                      # Net -> MLP -> Sequential(Linear, act, Linear, act) (common.py:90-178)
-        acts = [m for m in net.preprocess.model.model if not isinstance(m, torch.nn.Linear)]
-        if len(acts) != 2 or not all(isinstance(m, torch.nn.Tanh) for m in acts):
-            raise NotImplementedError("HipPPO: the hidden activations must be nn.Tanh (examples/mujoco/mujoco_ppo.py:108-114)")
+    if set(sa.keys()) != set(ka):
+        raise NotImplementedError(f"HipPPO: unsupported actor (keys {sorted(set(sa) ^ set(ka))} differ from a Net trunk + linear mu "
+                                  "head + sigma_param); see tianshou_amd/integration.py")
+    if set(sc.keys()) != set(kc):
+        raise NotImplementedError(f"HipPPO: unsupported critic (keys {sorted(set(sc) ^ set(kc))} differ from a Net trunk + linear head)")
     if not getattr(actor, "_unbounded", False) or getattr(actor, "_c_sigma", True):
         raise NotImplementedError("HipPPO: actor must be unbounded with a state-independent sigma_param")
-    if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
-        return obs_dim, act_dim, hidden, "fused"
-    if hidden % 32 == 0 and 32 <= hidden <= 1024 and act_dim <= 32:
-        return obs_dim, act_dim, hidden, "wide"
-    raise NotImplementedError("HipPPO: hidden sizes [h, h] with h a multiple of 32 (<= 1024) and at most 32 actions")
+    _, ha, act_a = _trunk_spec(actor, "actor")
+    _, hc, act_c = _trunk_spec(critic, "critic")
+    obs_dim, act_dim = int(sa[ka[0]].shape[1]), int(sa["mu.model.0.weight"].shape[0])
+    if int(sc[kc[0]].shape[1]) != obs_dim or act_a != act_c:
+        raise NotImplementedError("HipPPO: actor and critic must read the same observation and use the same activation")
+    if sa["mu.model.0.weight"].shape[1] != ha[-1] or tuple(sc["last.model.0.weight"].shape) != (1, hc[-1]):
+        raise NotImplementedError("HipPPO: the heads must be single Linear layers on the trunks' outputs")
+    if act_dim > 32:
+        raise NotImplementedError("HipPPO: at most 32 actions")
+    if act_a == "tanh" and ha == hc and len(ha) == 2 and ha[0] == ha[1]:
+        hidden = ha[0]
+        if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
+            return obs_dim, act_dim, hidden, "fused"
+        if hidden % 32 == 0 and 32 <= hidden <= 1024:
+            return obs_dim, act_dim, hidden, "wide"
+    if max(len(ha), len(hc)) > 7 or max(ha + hc) > 1024:
+        raise NotImplementedError("HipPPO: trunks of up to 7 hidden layers of at most 1024 units")
+    return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a), "net"
 
 
 def make_hip_ppo(algo: str = "ppo", ref=None):
@@ -321,6 +362,12 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             obs_dim, act_dim, hidden, kind = self._hip_dims
             if kind == "fused":
                 return torch.cat([t.detach().reshape(-1).float() for t in tensors]).to(self._hip_device).contiguous()
+            if kind == "net":
+                from .ppo_wide import net_flat_from_tensors
+
+                na = 2 * (len(hidden[0]) + 1) + 1
+                return torch.cat([net_flat_from_tensors(list(tensors[:na]), obs_dim, list(hidden[0]), act_dim, self._hip_device),
+                                  net_flat_from_tensors(list(tensors[na:]), obs_dim, list(hidden[1]), None, self._hip_device)]).contiguous()
             from .ppo_wide import flat_from_tensors
 
             return flat_from_tensors(list(tensors[:7]), list(tensors[7:]), obs_dim, hidden, act_dim, self._hip_device)
@@ -330,6 +377,9 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             obs_dim, act_dim, hidden, kind = self._hip_dims
             if kind == "fused":
                 return list(torch.split(flat, [p.numel() for p in self._hip_params()]))
+            if kind == "net":
+                a, c = self._engine().flat_to_tensors(flat)
+                return a + c
             from .ppo_wide import flat_to_tensors
 
             a, c = flat_to_tensors(flat, obs_dim, hidden, act_dim)
@@ -341,6 +391,10 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
                 flat = self._hip_flat([p.detach() for p in self._hip_params()])
                 if kind == "fused":
                     eng = PPOEngine(obs_dim, act_dim, flat, ppo_config_from(self))
+                elif kind == "net":
+                    from .ppo_wide import NetPPOEngine
+
+                    eng = NetPPOEngine(obs_dim, act_dim, hidden[0], hidden[1], hidden[2], flat, ppo_config_from(self))
                 else:
                     from .ppo_wide import WidePPOEngine
 
@@ -353,7 +407,8 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             return self._hip_engine
 
         def _hip_params(self):
-            return params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS) + params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
+            ka, kc = _net_keys(self.policy.actor, self.critic)      # == TIANSHOU_ACTOR_KEYS / _CRITIC_KEYS for Net[h, h]
+            return params_by_keys(self.policy.actor, ka) + params_by_keys(self.critic, kc)
 
         def _hip_runner(self, eng):
             if not self._hip_dp_on:
