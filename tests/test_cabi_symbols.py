@@ -136,7 +136,7 @@ def test_ctypes_structures_match_the_header_structs():
     mirrors = {"ts_ppo_hparams": _lib.PPOHParams, "ts_dqn_hparams": dqn.DQNHParams, "ts_distq_hparams": distq.DistQHParams,
                "ts_rows_replay": drqn.RowsReplay, "ts_npg_hparams": npg.NPGHParams, "ts_sac_hparams": sac.SACHParams,
                "ts_sac_state": sac.SACStateC, "ts_redq_state": redq.REDQStateC, "ts_td3_hparams": td3.TD3HParams,
-               "ts_td3_state": td3.TD3StateC}
+               "ts_td3_state": td3.TD3StateC, "ts_net_desc": _lib.NetDesc}
     text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
     sizes = {"double": 8, "float": 4, "int64_t": 8, "uint64_t": 8, "int32_t": 4, "int": 4, "uint8_t": 1}
     seen = set()
@@ -150,7 +150,12 @@ def test_ctypes_structures_match_the_header_structs():
             base = re.match(r"(?:const\s+)?(\w+)", decl).group(1)
             for item in decl[decl.index(base) + len(base):].split(","):
                 item = item.strip()
-                want.append((item.lstrip("* ").strip(), 8 if "*" in item else sizes[base]))        # pointers: 8 bytes
+                count = 1
+                arr = re.match(r"(.*?)\[(\w+)\]$", item)          # fixed-size array member: name[N] / name[SOME_DEFINE]
+                if arr:
+                    item, n = arr.group(1).strip(), arr.group(2)
+                    count = int(n) if n.isdigit() else int(re.search(rf"#define\s+{n}\s+(\d+)", text).group(1))
+                want.append((item.lstrip("* ").strip(), count * (8 if "*" in item else sizes[base])))        # pointers: 8 bytes
         got = [(f[0], C.sizeof(f[1])) for f in mirrors[name]._fields_]
         assert [w[1] for w in want] == [g[1] for g in got], (name, want, got)
         assert len(want) == len(got)
