@@ -376,13 +376,26 @@ def cpu_baseline(sample_steps=None):
         OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, [np.arange(MINIBATCH * sample_steps)])
     t_step = (time.perf_counter() - t0) / sample_steps
     value = steps_per_update / (t_pre + steps_per_update * t_step)
+    # the port calibrated against the reference itself where the reference can run (the authoring container, 4 threads):
+    # profiles/r05_cpu_reference_vs_port.json, written by scripts/cpu_reference_vs_port.py
+    calib = ""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_cpu_reference_vs_port.json")) as f:
+            c = json.load(f)
+        calib = (f"; calibration against tianshou's own PPO.update() on the same buffer / weights / seed ({c['threads']} threads of a "
+                 f"{c['host_cpus']}-CPU container, {c['shape']['transitions']} transitions, {c['port']['gradient_steps']} steps): reference "
+                 f"{c['reference_gae_compiled']['steps_per_s']:.1f} steps/s (njit bodies compiled), port {c['port']['steps_per_s']:.1f} = "
+                 f"{c['ratio_port_over_reference_compiled']:.2f} x the reference, final parameters differ by "
+                 f"{c['max_abs_param_diff_reference_vs_port']:.1e} (profiles/r05_cpu_reference_vs_port.json)")
+    except (OSError, ValueError, KeyError):
+        pass
     return {
         "value": value, "unit": "update-steps/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": (f"PORT of the reference path, not the reference itself (oracle/: torch-fp32 CPU ops in the reference's "
                    f"order + a -O3 C restatement of its numba kernels): 1 full preprocess of 2^20 transitions "
                    f"({t_pre:.2f} s, of which the GAE scan {t_gae * 1e3:.1f} ms single-thread = "
                    f"{N_TRANS / t_gae / 1e6:.0f} M transitions/s) + {sample_steps} of the 160 gradient steps of 65536 "
-                   f"({t_step * 1e3:.1f} ms each, {torch.get_num_threads()} threads); whole-update rate = 160 / (t_pre + 160 t_step)"),
+                   f"({t_step * 1e3:.1f} ms each, {torch.get_num_threads()} threads); whole-update rate = 160 / (t_pre + 160 t_step)" + calib),
         "gae_transitions_per_s": N_TRANS / t_gae,
         "inner_update_steps_per_s": 1.0 / t_step,
     }
