@@ -209,6 +209,47 @@ def make_exchange(device, rank, world):
     return ar, name
 
 
+def exchange_selftest(device, rank, world, ar, floats, rounds):
+    """Before anything is timed at N > 1: `rounds` all-reduces of per-rank random payloads through the exchange the legs
+    will use, each checked bit for bit against torch.distributed's all_reduce of the same payload (integer-valued floats:
+    every summation order gives the same bits).  A mismatch or an error on ANY rank makes EVERY rank drop the native
+    exchange (the caller falls back to torch.distributed / RCCL).  Also collected per rank for the JSON line: the device,
+    hipDeviceCanAccessPeer to every other visible device, whether the one-shot IPC path came up.
+    -> (ok on every rank, report dict on rank 0 / None elsewhere)."""
+    import torch.distributed as dist
+
+    on_gpu = dist.get_backend() == "nccl"
+    bad, err = 0, None
+    if ar is not None:
+        g = torch.Generator(device=device).manual_seed(977 * rank + 13)
+        try:
+            for r in range(rounds):
+                x = torch.randint(-1024, 1025, (floats,), generator=g, device=device).float()
+                want = x.clone() if on_gpu else x.cpu()
+                dist.all_reduce(want)
+                ar(x)
+                if not torch.equal(x.cpu(), want.cpu()):
+                    bad += 1
+                    if bad >= 3:
+                        break
+        except Exception as e:      # noqa: BLE001 - a failed hand-off of the one-shot path raises: same consequence
+            err = repr(e)
+            bad += 1
+    flag = torch.tensor([1 if bad == 0 else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    n_dev = torch.cuda.device_count()
+    me = {"rank": rank, "device": str(device), "visible_devices": n_dev,
+          "can_access_peer": [bool(torch.cuda.can_device_access_peer(device.index, j)) if j != device.index else None
+                              for j in range(n_dev)],
+          "one_shot_ipc": bool(ar is not None and ar.small_capacity > 0), "native": ar is not None,
+          "mismatching_rounds": bad, "error": err}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, me)
+    ok = int(flag.item()) == 1
+    report = {"rounds": rounds if ar is not None else 0, "floats": floats, "passed_on_every_rank": ok, "ranks": gathered} if rank == 0 else None
+    return ok, report
+
+
 def time_exchange(device, world, ar, floats, iters=200):
     """Mean time of one all-reduce of the per-step payload ([gradient | loss parts]), HIP events on the launch stream around
     `iters` back-to-back calls on every rank (collective: all ranks call it)."""
@@ -543,6 +584,9 @@ def main():
                          "configs[3]); weak = a 2^20 rollout and 65536 rows per rank; both (default) = strong is `value`, the weak "
                          "figure is measured in the same run and printed beside it.  N = 1: the two are the same workload.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--selftest-rounds", type=int, default=1000,
+                    help="N > 1: all-reduces of random payloads checked against torch.distributed before the timed legs "
+                         "(a mismatch on any rank drops the native exchange on every rank)")
     ap.add_argument("--no-extras", action="store_true", help="skip the ROCm-eager baseline, the hook-level leg, the H2D "
                     "measurement and the other workloads (profiling runs)")
     ap.add_argument("--workload", default="ppo",
@@ -620,6 +664,16 @@ def main():
 
     ar, exchange = make_exchange(device, rank, world)
     xch = {"ar": ar, "name": exchange, "note": None}
+    selftest = None
+    if world > 1:
+        ok, selftest = exchange_selftest(device, rank, world, ar, 11085 + 4, args.selftest_rounds)
+        if not ok and ar is not None:
+            try:
+                ar.close()
+            except Exception:       # noqa: BLE001
+                pass
+            xch["ar"], xch["name"] = None, "torch.distributed all_reduce (RCCL)"
+            xch["note"] = "the native exchange failed the pre-flight self-test; every leg runs on torch.distributed"
     legs = ["strong", "weak"] if (args.scaling == "both" and world > 1) else [("strong" if args.scaling == "both" else args.scaling)]
 
     def timed_leg(scaling):
@@ -790,6 +844,7 @@ def main():
         if world > 1:
             out["exchange_us"] = exchange_us
             out["exchange_ranks"] = rccl_ranks
+            out["exchange_selftest"] = selftest
             if xch["note"]:
                 out["exchange_note"] = xch["note"]
         if beside is not None:
