@@ -19,7 +19,6 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int BK = 32;          // reduction chunk staged per iteration
 constexpr int THREADS = 256;    // 4 waves
@@ -404,136 +403,6 @@ __global__ __launch_bounds__(THREADS) void conv_wgrad_group_kernel(WgradGroup gr
     else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split, smem);
 }
 
-// ---- Weight gradients of Linear layers at replay-batch sizes (SAC family: M = 4096 rows, K, N <= 1024) ------------------
-// dWb[k, n] = sum_m X[m, k] dY[m, n]  (+ row K = sum_m dY[m, n]).  Both operands are row-major over the REDUCTION index m, which
-// is exactly what the 32x32x2 MFMA wants from a lane: A[i][kk] = X[m + kk][k0 + col(i)], B[kk][j] = dY[m + kk][n0 + col(j)] --
-// a lane reads its operands straight from global memory (8 bytes of a row of X: two of the 64 rows of the tile, columns
-// {2 i + e}; 16 bytes of a row of dY: four of its 128 columns, {4 j + e}), no LDS staging, no barrier in the loop; one pair of
-// rows feeds eight MFMAs (a 64 x 128 tile of dWb in 128 accumulator registers), four pairs of loads are in flight.  The four
-// waves of a workgroup take a quarter of the workgroup's rows each and meet once, at the end, in LDS (two 32 KB buffers); one
-// slab per workgroup, written as 16-byte rows.  The generic conv_wgrad_kernel stages 32-row chunks through LDS with two
-// barriers per chunk and runs at 54 TF/s on these shapes (37 % of the fp32-MFMA rate): profiles/r05_lin_wgrad.txt.
-constexpr int LW_K = 64, LW_N = 128, LW_DEPTH = 4;
-constexpr int LW_LDS_FLOATS = 2 * 8192 + 4 * 256;
-
-struct LinWgradLayer {
-    const float* X; const float* dY; float* out;      // out: slabs [S][(K + 1) N]
-    long long slab_stride;
-    int M, K, N, tk, tn, S, rpw;                       // rpw: rows per wave (even)
-};
-struct LinWgradGroup {
-    LinWgradLayer l[WGRAD_GROUP_MAX];
-    int first[WGRAD_GROUP_MAX + 1];
-    int n;
-};
-static_assert(sizeof(LinWgradGroup) <= 4000, "kernel arguments are limited to 4 KB");
-
-__global__ __launch_bounds__(THREADS, 2) void lin_wgrad_kernel(LinWgradGroup gr) {
-    extern __shared__ __attribute__((aligned(16))) float lw_lds[];
-    int li = 0;
-    while (li + 1 < gr.n && (int)blockIdx.x >= gr.first[li + 1]) ++li;
-    const LinWgradLayer& L = gr.l[li];
-    const int local = (int)blockIdx.x - gr.first[li];
-    const int per = L.tk * L.tn;
-    const int split = local / per, rem = local - split * per;
-    const int nt = rem / L.tk, kt = rem - nt * L.tk;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
-    const int K = L.K, N = L.N;
-    const int k0 = kt * LW_K, n0 = nt * LW_N;
-    const int kcol = min(k0 + 2 * c, K - 2), ncol = min(n0 + 4 * c, N - 4);       // columns past the matrix: repeats, not stored
-    const int m_begin = (split * 4 + wave) * L.rpw;
-    const int m_end = min(L.M, m_begin + L.rpw);
-    const int n_pairs = m_end > m_begin ? (m_end - m_begin) / 2 : 0;
-    const int last = max(n_pairs - 1, 0);
-    const int m_safe = min(m_begin, L.M - 2);                                      // an empty share still issues (unused) loads
-    const float* xp = L.X + (int64_t)(m_safe + h) * K + kcol;
-    const float* yp = L.dY + (int64_t)(m_safe + h) * N + ncol;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int x = 0; x < 16; ++x) acc[a][b][x] = 0.f;
-    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-    f32x2 ra[LW_DEPTH];
-    f32x4 rb[LW_DEPTH];
-#pragma unroll
-    for (int d = 0; d < LW_DEPTH; ++d) {
-        const int q = min(d, last);
-        ra[d] = *reinterpret_cast<const f32x2*>(xp + (int64_t)(2 * q) * K);
-        rb[d] = *reinterpret_cast<const f32x4*>(yp + (int64_t)(2 * q) * N);
-    }
-    for (int p = 0; p < n_pairs; p += LW_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < LW_DEPTH; ++d) {
-            if (p + d < n_pairs) {                     // uniform
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] = mfma32(ra[d][a], rb[d][b], acc[a][b]);
-                bs += rb[d];
-            }
-            const int q = min(p + d + LW_DEPTH, last);
-            ra[d] = *reinterpret_cast<const f32x2*>(xp + (int64_t)(2 * q) * K);
-            rb[d] = *reinterpret_cast<const f32x4*>(yp + (int64_t)(2 * q) * N);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- the four waves' partial tiles meet in LDS: (2, 3) -> buffers, (0, 1) add, 1 -> buffer, 0 adds and stores
-    float* buf0 = lw_lds;
-    float* buf1 = lw_lds + 8192;
-    float* sb = lw_lds + 2 * 8192;                     // bias partials [wave][lane][4]
-    *reinterpret_cast<f32x4*>(sb + (wave * 64 + lane) * 4) = bs;
-    auto put = [&](float* buf) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int x = 0; x < 16; ++x) buf[((a * 4 + b) * 16 + x) * 64 + lane] = acc[a][b][x];
-    };
-    auto add = [&](const float* buf) {
-#pragma unroll
-        for (int ab = 0; ab < 8; ++ab) {
-#pragma unroll
-            for (int x = 0; x < 16; ++x) acc[ab >> 2][ab & 3][x] += buf[(ab * 16 + x) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);         // one accumulator's sixteen reads at a time (register pressure)
-        }
-    };
-    if (wave == 2) put(buf0);
-    if (wave == 3) put(buf1);
-    __syncthreads();
-    if (wave == 0) add(buf0);
-    if (wave == 1) add(buf1);
-    __syncthreads();
-    if (wave == 1) put(buf0);
-    __syncthreads();
-    if (wave != 0) return;
-    add(buf0);
-    float* out = L.out + (int64_t)split * L.slab_stride;
-    const bool col_ok = n0 + 4 * c < N;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int x = 0; x < 16; ++x) {
-            const int row = k0 + 2 * ((x & 3) + 8 * (x >> 2) + 4 * h) + a;
-            if (col_ok && row < K)
-                *reinterpret_cast<f32x4*>(out + (int64_t)row * N + n0 + 4 * c) = f32x4{acc[a][0][x], acc[a][1][x], acc[a][2][x], acc[a][3][x]};
-        }
-    if (kt == 0 && h == 0 && col_ok) {                 // bias row: sum over the rows of all waves and both lane halves
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            t += *reinterpret_cast<const f32x4*>(sb + (w * 64 + c) * 4);
-            t += *reinterpret_cast<const f32x4*>(sb + (w * 64 + 32 + c) * 4);
-        }
-        *reinterpret_cast<f32x4*>(out + (int64_t)K * N + n0 + 4 * c) = t;
-    }
-}
-
 // out[i] = sum_s slabs[s][i]: a workgroup owns 64 consecutive floats (16 float4 columns) and splits the
 // slabs over its 16 thread rows; fixed-order tree over the rows (deterministic).
 __global__ __launch_bounds__(256) void slab_sum_kernel(const float* __restrict__ slabs, int nslab, int64_t n,
@@ -646,33 +515,14 @@ int conv_fwd_splits(const ConvGeom& g) {
     return (int)ceil_div(chunks, per);
 }
 
-// Linear layers whose reduction runs over 1,024 .. 16,384 rows go to lin_wgrad_kernel (TS_LIN_WGRAD=0: the generic kernels)
-bool lin_wgrad_ok(const ConvGeom& g) {
-    static const bool off = getenv("TS_LIN_WGRAD") && atoi(getenv("TS_LIN_WGRAD")) == 0;
-    return !off && g.IH == 1 && g.IW == 1 && g.KH == 1 && g.KW == 1 && g.S == 1 && g.OH == 1 && g.OW == 1 && g.B % 2 == 0 &&
-           g.B >= 1024 && g.B <= 16384 && g.K() % 2 == 0 && g.OC % 4 == 0 && g.K() >= 2 && g.OC >= 4;
-}
-int lin_wgrad_rows_per_wave(const ConvGeom& g, int* splits) {
-    static const int target = getenv("TS_LIN_WGRAD_ROWS") ? atoi(getenv("TS_LIN_WGRAD_ROWS")) : 128;
-    const int S = (int)ceil_div(g.B, 4 * target);
-    int rpw = (int)ceil_div(g.B, 4 * S);
-    rpw += rpw & 1;
-    if (splits) *splits = S;
-    return rpw;
-}
-
 int conv_wgrad_splits(const ConvGeom& g) {
     if (conv2_use_wgrad(g, false)) return conv2_wgrad_splits(g);
-    if (lin_wgrad_ok(g)) { int S; lin_wgrad_rows_per_wave(g, &S); return S; }
     const int bn = g.OC % 64 == 0 ? 64 : 32;
     const int64_t tiles = ceil_div(g.K(), 128) * (g.OC / bn);
     const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, BK);
-    // (TS_WGRAD_TARGET / TS_WGRAD_MIN_CHUNKS: experiments on the split of the reduction, profiles/r05_wgrad_splits.txt)
-    static const int target = getenv("TS_WGRAD_TARGET") ? atoi(getenv("TS_WGRAD_TARGET")) : TARGET_WGS;
-    static const int min_chunks = getenv("TS_WGRAD_MIN_CHUNKS") ? atoi(getenv("TS_WGRAD_MIN_CHUNKS")) : 4;
-    int want = (int)ceil_div(target, tiles);
+    int want = (int)ceil_div(TARGET_WGS, tiles);
     int per = (int)ceil_div(chunks, want);
-    if (per < min_chunks) per = min_chunks;
+    if (per < 4) per = 4;
     return (int)ceil_div(chunks, per);
 }
 
@@ -713,31 +563,6 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
     return TS_OK;
 }
 
-static int lin_wgrad_launch(hipStream_t s, int n, const ConvGeom* g, const float* const* X, const float* const* dY,
-                            float* const* slabs, ts_workspace* prof) {
-    LinWgradGroup gr;
-    gr.n = n;
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        LinWgradLayer& L = gr.l[i];
-        L.X = X[i]; L.dY = dY[i]; L.out = slabs[i];
-        L.slab_stride = g[i].param_elems();
-        L.M = g[i].B; L.K = g[i].K(); L.N = g[i].OC;
-        L.tk = (int)ceil_div(L.K, LW_K); L.tn = (int)ceil_div(L.N, LW_N);
-        L.rpw = lin_wgrad_rows_per_wave(g[i], &L.S);
-        gr.first[i] = blocks;
-        blocks += L.tk * L.tn * L.S;
-    }
-    for (int i = n; i <= WGRAD_GROUP_MAX; ++i) gr.first[i] = blocks;
-    static const int once = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&lin_wgrad_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * LW_LDS_FLOATS));
-    (void)once;
-    ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
-    hipLaunchKernelGGL(lin_wgrad_kernel, dim3((unsigned)blocks), dim3(THREADS), sizeof(float) * LW_LDS_FLOATS, s, gr);
-    TS_LAUNCH_CHECK();
-    return TS_OK;
-}
-
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
                ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
@@ -746,7 +571,6 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
         if (conv2_use_wgrad(g, x_u8)) return conv2_wgrad(s, g, X, dY, slabs, prof, x_u8);
         return ts::fail(TS_ERR_UNSUPPORTED, "conv_wgrad: uint8 input with %d output channels", g.OC);
     }
-    if (!x_u8 && lin_wgrad_ok(g)) return lin_wgrad_launch(s, 1, &g, &X, &dY, &slabs, prof);
     GemmArgs a = base_args(g);
     a.a_u8 = x_u8;
     a.A = X; a.Bm = dY; a.C = slabs;
@@ -770,13 +594,10 @@ int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const
                      float* const* slabs, ts_workspace* prof) {
     TS_REQUIRE(n >= 1 && n <= WGRAD_GROUP_MAX, TS_ERR_INVALID_ARG, "conv_wgrad_group: 1 .. %d layers", WGRAD_GROUP_MAX);
     bool one_launch = n > 1;
-    bool all_lin = true;
     for (int i = 0; i < n; ++i) {
         if (int rc = check_geom(g[i])) return rc;
         if (conv2_use_wgrad(g[i], false)) one_launch = false;        // large layers have their own kernels (ts_conv2.hip)
-        if (conv2_use_wgrad(g[i], false) || !lin_wgrad_ok(g[i])) all_lin = false;
     }
-    if (all_lin) return lin_wgrad_launch(s, n, g, X, dY, slabs, prof);
     static const bool off = getenv("TS_WGRAD_NO_GROUP") != nullptr;     // experiments
     if (!one_launch || off) {
         for (int i = 0; i < n; ++i)
