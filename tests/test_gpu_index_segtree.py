@@ -69,6 +69,10 @@ def test_index_math_large_random_vs_oracle():
     assert np.array_equal(buf.unfinished_index().cpu().numpy(), O.unfinished_index(*args))
     assert np.array_equal(buf.sample_indices(0).cpu().numpy(),
                           O.sample_indices_all(offset, lengths, insertion % T))
+    # manager.py:200-218 for stack_num == 1: None passes 0 to every child (all indices, in order); a negative size gives none
+    assert torch.equal(buf.sample_indices(None), buf.sample_indices(0))
+    neg = buf.sample_indices(-3)
+    assert neg.numel() == 0 and neg.dtype == torch.int64 and neg.is_cuda
     # full C2-shaped buffer: sample_indices(0) is the identity
     full = DeviceReplayBuffer.from_vector_fill(E, rew=np.zeros(B), terminated=done, truncated=np.zeros(B, bool))
     assert full.indices_are_identity()

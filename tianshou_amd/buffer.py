@@ -504,9 +504,12 @@ class DeviceReplayBuffer:
         `RandomState.choice(E, bs, p=...)` consumes) and `within` int64[bs] (the children's `choice(len_e, n_e)` values,
         concatenated in sub-buffer order).  Without them the draws come from torch's device generator (`generator`), or --
         `seed=(key, counter)` -- from the engine's counter-based generator inside the sampling kernel (one launch).
-        batch_size None (all indices, shuffled) and negative sizes stay with the reference."""
-        if batch_size is None or batch_size < 0:
-            raise NotImplementedError("sample_indices(None / negative) is not on the device path")
+        batch_size None -> the manager passes 0 to every child (manager.py:217-218): all indices in order, like 0;
+        batch_size < 0  -> an empty index array (manager.py:202-204)."""
+        if batch_size is not None and batch_size < 0:
+            return torch.empty(0, dtype=torch.int64, device=self.device)
+        if batch_size is None:
+            batch_size = 0
         if batch_size > 0:
             dev = self.device
             bs = int(batch_size)
