@@ -1029,7 +1029,12 @@ typedef struct ts_net_desc {
     int32_t n_hidden;                  /* 1 .. TS_NET_MAX_HIDDEN */
     int32_t activation;                /* TS_NET_ACT_* after every hidden layer */
     int64_t hidden[TS_NET_MAX_HIDDEN]; /* widths as configured (1 .. 1024 each) */
+    int64_t flags;                     /* actor only: TS_NET_CONDITIONED_SIGMA -- sigma = exp(clamp(Linear(h), -20, 2)) per sample
+                                          (ContinuousActorProbabilistic(conditioned_sigma=True), utils/net/continuous.py:212-234):
+                                          the head block's columns [16, 16 + act) are that Linear layer (act_dim <= 16), the
+                                          trailing log_sigma[32] block is unused and stays zero */
 } ts_net_desc;
+#define TS_NET_CONDITIONED_SIGMA 1
 int ts_net_layout(const ts_net_desc* net, int64_t act_dim, int64_t* h_out3);
 int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, const ts_net_desc* actor_net,
                      const ts_net_desc* critic_net, int64_t act_dim, const float* obs, const float* act, int64_t B,

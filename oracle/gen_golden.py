@@ -468,7 +468,7 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
 
 
 def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_a: list[int], hidden_c: list[int], activation,
-                batch_size: int, repeat: int, seed: int, algo: str = "ppo", **ppo_kwargs) -> None:
+                batch_size: int, repeat: int, seed: int, algo: str = "ppo", conditioned_sigma: bool = False, **ppo_kwargs) -> None:
     """The reference PPO / A2C update() for actor-critics whose trunks are Net(hidden_sizes=..., activation=...) of any depth
     (utils/net/common.py:90-178, 246-369; `activation` = nn.Tanh, nn.ReLU or None): inputs, Batch.split's permutations,
     per-step losses and the parameters / Adam moments after the update, as lists of tensors in module order
@@ -477,14 +477,20 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
     torch.manual_seed(seed)
     N = E * T
     net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden_a, activation=activation)
-    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
+                                         conditioned_sigma=conditioned_sigma)
     net_c = Net(state_shape=(obs_dim,), hidden_sizes=hidden_c, activation=activation)
     critic = ContinuousCritic(preprocess_net=net_c)
-    torch.nn.init.constant_(actor.sigma_param, -0.5)
+    if not conditioned_sigma:
+        torch.nn.init.constant_(actor.sigma_param, -0.5)
     for m in ActorCritic(actor, critic).modules():
         if isinstance(m, nn.Linear):
             nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
             nn.init.normal_(m.bias, std=0.1)
+    if conditioned_sigma:                       # a sigma head whose outputs straddle the upper clamp (SIGMA_MAX = 2)
+        with torch.no_grad():
+            actor.sigma.model[0].weight.mul_(0.3)
+            actor.sigma.model[0].bias.add_(1.8)
 
     def dist(loc_scale):
         loc, scale = loc_scale
@@ -503,11 +509,13 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
             out += [m.weight, m.bias]
         return out
 
-    a_par = tensors(actor, actor.mu) + [actor.sigma_param]
+    a_par = tensors(actor, actor.mu) + ([actor.sigma.model[0].weight, actor.sigma.model[0].bias] if conditioned_sigma
+                                        else [actor.sigma_param])
     c_par = tensors(critic, critic.last)
     out: dict[str, np.ndarray] = {"dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat]),
                                   "hidden_a": np.array(hidden_a), "hidden_c": np.array(hidden_c),
-                                  "activation": np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation])}
+                                  "activation": np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation]),
+                                  "conditioned_sigma": np.array(int(conditioned_sigma))}
     for i, t in enumerate(a_par):
         out[f"a{i}_0"] = t.detach().numpy().copy()
     for i, t in enumerate(c_par):
@@ -597,6 +605,10 @@ def gen_ppo_net_all() -> None:
     gen_ppo_net("tanh1_a2c", algo="a2c", E=3, T=40, obs_dim=5, act_dim=2, hidden_a=[48], hidden_c=[48], activation=nn.Tanh,
                 batch_size=60, repeat=1, seed=12, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=False,
                 gae_lambda=0.9, gamma=0.99)
+    # conditioned sigma (a second linear head, clamped to [-20, 2] before exp), two tanh layers
+    gen_ppo_net("csigma", E=4, T=48, obs_dim=9, act_dim=4, hidden_a=[64, 64], hidden_c=[64, 64], activation=nn.Tanh,
+                conditioned_sigma=True, batch_size=64, repeat=2, seed=14, eps_clip=0.2, vf_coef=0.5, ent_coef=0.02,
+                max_grad_norm=0.5, value_clip=True, advantage_normalization=True, return_scaling=False, gae_lambda=0.95, gamma=0.99)
     # no activation (a linear trunk), four layers
     gen_ppo_net("linear4", E=2, T=64, obs_dim=20, act_dim=5, hidden_a=[32, 32, 32, 32], hidden_c=[33, 17, 9, 5], activation=None,
                 batch_size=128, repeat=1, seed=13, eps_clip=0.1, dual_clip=2.0, vf_coef=0.25, ent_coef=0.0, max_grad_norm=None,

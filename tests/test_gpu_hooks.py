@@ -1162,7 +1162,7 @@ def test_hip_ddpg_hooks_against_oracle():
     assert float(st_a["step"]) == 4.0 and float(st_c["step"]) == 4.0
 
 
-@pytest.mark.parametrize("tag", ["relu3", "linear4"])
+@pytest.mark.parametrize("tag", ["relu3", "linear4", "csigma"])
 def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     """Net trunks outside [h, h] tanh (three ReLU layers of unequal widths with a different critic trunk; four linear layers):
     HipPPO picks the per-layer engine (kind "net", ppo_wide.NetPPOEngine) and the whole hook path -- mirror, preprocess, the
@@ -1178,8 +1178,9 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     E, T, obs_dim, act_dim, batch_size, repeat = (int(x) for x in g["dims"])
     ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
     act_cls = {0: nn.Tanh, 1: nn.ReLU, 2: None}[int(g["activation"])]
-    seed = {"relu3": 11, "linear4": 13}[tag]
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls), act_dim, unbounded=True)
+    seed = {"relu3": 11, "linear4": 13, "csigma": 14}[tag]
+    cs = bool(int(g["conditioned_sigma"]))
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls), act_dim, unbounded=True, conditioned_sigma=cs)
     critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, act_cls))
 
     def params(mod, head, extra=()):
@@ -1189,7 +1190,8 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
             out += [m.weight, m.bias]
         return out + list(extra)
 
-    pa, pc = params(actor, actor.mu, [actor.sigma_param]), params(critic, critic.last)
+    pa = params(actor, actor.mu, list(actor.sigma.model[0].parameters()) if cs else [actor.sigma_param])
+    pc = params(critic, critic.last)
     with torch.no_grad():
         for i, p in enumerate(pa):
             p.copy_(torch.from_numpy(g[f"a{i}_0"]))
@@ -1200,7 +1202,8 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
               max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), gae_lambda=cfg["gae_lambda"],
               gamma=cfg["gamma"], lr=cfg["lr"])
     algo = make_hip_ppo("ppo", ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", permutations="host", **kw).to("cuda")
-    assert algo._hip_dims == (obs_dim, act_dim, (tuple(ha), tuple(hc), {nn.Tanh: "tanh", nn.ReLU: "relu", None: "none"}[act_cls]), "net")
+    assert algo._hip_dims == (obs_dim, act_dim, (tuple(ha), tuple(hc), {nn.Tanh: "tanh", nn.ReLU: "relu", None: "none"}[act_cls]) +
+                              (("conditioned_sigma",) if cs else ()), "net")
     buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     size = buf.maxsize // E
     for t in range(T):                                   # slot e * size + t of the fixture's buffer = env e, step t

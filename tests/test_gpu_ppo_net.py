@@ -10,14 +10,16 @@ import pytest
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TAGS = ["relu3", "tanh1_a2c", "linear4"]
+TAGS = ["relu3", "tanh1_a2c", "linear4", "csigma"]
 
 
 def _load(tag):
     g = dict(np.load(os.path.join(GOLDEN, f"ppo_net_{tag}.npz"), allow_pickle=False))
     cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
     ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
-    na, nc = 2 * (len(ha) + 1) + 1, 2 * (len(hc) + 1)
+    cs = bool(int(g["conditioned_sigma"])) if "conditioned_sigma" in g else False
+    g["_cs"] = cs
+    na, nc = 2 * (len(ha) + 1) + (2 if cs else 1), 2 * (len(hc) + 1)
     return g, cfg, ha, hc, na, nc
 
 
@@ -34,14 +36,14 @@ def test_flat_layout_roundtrip(tag):
     act_name = {0: "tanh", 1: "relu", 2: "none"}[int(g["activation"])]
     a = [torch.from_numpy(g[f"a{i}_0"]) for i in range(na)]
     c = [torch.from_numpy(g[f"c{i}_0"]) for i in range(nc)]
-    fa = net_flat_from_tensors(a, obs_dim, ha, act_dim, "cpu")
+    fa = net_flat_from_tensors(a, obs_dim, ha, act_dim, "cpu", conditioned_sigma=g["_cs"])
     fc = net_flat_from_tensors(c, obs_dim, hc, None, "cpu")
     out = (C.c_int64 * 3)()
-    _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, ha, act_name)), _lib.i64(act_dim), out))
+    _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, ha, act_name, int(g["_cs"]))), _lib.i64(act_dim), out))
     assert fa.numel() == out[1]
     _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, hc, act_name)), _lib.i64(act_dim), out))
     assert fc.numel() == out[2]
-    for t0, t1 in zip(a, net_flat_to_tensors(fa, obs_dim, ha, act_dim, True)):
+    for t0, t1 in zip(a, net_flat_to_tensors(fa, obs_dim, ha, act_dim, True, g["_cs"])):
         assert torch.equal(t0.reshape(t1.shape), t1)
     for t0, t1 in zip(c, net_flat_to_tensors(fc, obs_dim, hc, 1, False)):
         assert torch.equal(t0.reshape(t1.shape), t1)
@@ -64,8 +66,9 @@ def test_update_matches_the_reference(tag):
                        max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), lr=cfg["lr"])
     a0 = [torch.from_numpy(g[f"a{i}_0"]) for i in range(na)]
     c0 = [torch.from_numpy(g[f"c{i}_0"]) for i in range(nc)]
-    flat = torch.cat([net_flat_from_tensors(a0, obs_dim, ha, act_dim), net_flat_from_tensors(c0, obs_dim, hc, None)])
-    eng = NetPPOEngine(obs_dim, act_dim, ha, hc, act_name, flat, pcfg)
+    flat = torch.cat([net_flat_from_tensors(a0, obs_dim, ha, act_dim, conditioned_sigma=g["_cs"]),
+                      net_flat_from_tensors(c0, obs_dim, hc, None)])
+    eng = NetPPOEngine(obs_dim, act_dim, ha, hc, act_name, flat, pcfg, conditioned_sigma=g["_cs"])
     idx = g["pre_indices"]
     dev = lambda x: torch.as_tensor(np.ascontiguousarray(x), device="cuda")          # noqa: E731
     cut = np.searchsorted(idx, g["pre_unfinished"])
@@ -93,6 +96,6 @@ def test_update_matches_the_reference(tag):
     # padding entries of the flat vector (widths rounded up to 32) stay exactly zero through the update
     pad = torch.ones(eng.P, dtype=torch.bool)
     mask_src = [torch.ones_like(t) for t in a0], [torch.ones_like(t) for t in c0]
-    pad &= (torch.cat([net_flat_from_tensors(mask_src[0], obs_dim, ha, act_dim, "cpu"),
+    pad &= (torch.cat([net_flat_from_tensors(mask_src[0], obs_dim, ha, act_dim, "cpu", conditioned_sigma=g["_cs"]),
                        net_flat_from_tensors(mask_src[1], obs_dim, hc, None, "cpu")]) == 0)
     assert torch.all(eng.params.cpu()[pad] == 0)

@@ -116,7 +116,10 @@ def test_unsupported_nets_are_rejected():
                                                              norm_layer=nn.LayerNorm), action_shape=(6,), unbounded=True)
     a_mixed, _ = nets([64, 64], act=nn.ELU)
     _, c_relu = nets([64, 64], act=nn.ReLU)
-    for bad in (nets([64, 64], n_act=40), nets([32] * 8), nets([2048, 64]), (a_cs, nets([64, 64])[1]), (a_norm, nets([64, 64])[1]),
+    assert _check_supported(a_cs, nets([64, 64])[1]) == (17, 6, ((64, 64), (64, 64), "tanh", "conditioned_sigma"), "net")
+    a_cs20 = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                          action_shape=(20,), unbounded=True, conditioned_sigma=True)
+    for bad in (nets([64, 64], n_act=40), nets([32] * 8), nets([2048, 64]), (a_cs20, nets([64, 64])[1]), (a_norm, nets([64, 64])[1]),
                 (a_mixed, nets([64, 64])[1]), (nets([64, 64])[0], c_relu)):
         with pytest.raises(NotImplementedError):
             _check_supported(*bad)

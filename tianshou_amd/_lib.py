@@ -57,16 +57,18 @@ class NetDesc(C.Structure):
 
     MAX_HIDDEN = 7
     ACTIVATIONS = {"tanh": 0, "relu": 1, "none": 2}
-    _fields_ = [("obs_dim", C.c_int64), ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden", C.c_int64 * 7)]
+    CONDITIONED_SIGMA = 1
+    _fields_ = [("obs_dim", C.c_int64), ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden", C.c_int64 * 7),
+                ("flags", C.c_int64)]
 
     @classmethod
-    def make(cls, obs_dim: int, hidden, activation: str) -> "NetDesc":
+    def make(cls, obs_dim: int, hidden, activation: str, flags: int = 0) -> "NetDesc":
         hidden = [int(h) for h in hidden]
         if not 1 <= len(hidden) <= cls.MAX_HIDDEN:
             raise NotImplementedError(f"trunks of 1 .. {cls.MAX_HIDDEN} hidden layers are supported, got {len(hidden)}")
         if activation not in cls.ACTIVATIONS:
             raise NotImplementedError(f"activation must be one of {sorted(cls.ACTIVATIONS)}, got {activation!r}")
-        d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))))
+        d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))), int(flags))
         return d
 
 

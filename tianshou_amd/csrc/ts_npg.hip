@@ -508,6 +508,104 @@ __global__ void ppo_wide_total_kernel(float* __restrict__ losses, const float* _
     losses[0] = losses[1] + vf_coef * losses[2] - ent_coef * ent;
 }
 
+// ---- conditioned sigma (ContinuousActorProbabilistic(conditioned_sigma=True), utils/net/continuous.py:212-234): the head's
+// columns [CS_COL, CS_COL + A) hold Linear(h) = the un-clamped log sigma of every sample; sigma = exp(clamp(., -20, 2)).
+constexpr int CS_COL = 16;
+constexpr float CS_MIN = -20.f, CS_MAX = 2.f;
+
+__device__ __forceinline__ float gauss_logp_cs(const float* head, const float* act, int A) {
+    float lp = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float ls = fminf(fmaxf(head[CS_COL + j], CS_MIN), CS_MAX);
+        const float sigma = expf(ls), var = sigma * sigma, d = act[j] - head[j];
+        lp += -(d * d) / (2.f * var) - logf(sigma) - LOG_SQRT_2PI;
+    }
+    return lp;
+}
+
+__global__ __launch_bounds__(256) void infer_out_cs_kernel(const float* __restrict__ mu_head, const float* __restrict__ v_head,
+                                                           const float* __restrict__ act, int64_t B, int A,
+                                                           float* __restrict__ v_out, float* __restrict__ logp_out,
+                                                           float* __restrict__ mu_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    if (v_out) v_out[b] = v_head[b * HEAD];
+    if (logp_out) logp_out[b] = gauss_logp_cs(mu_head + b * HEAD, act + b * A, A);
+    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = mu_head[b * HEAD + j];
+}
+
+// The clipped-surrogate / A2C actor loss of ppo_wide_actor_loss_kernel with a per-sample sigma: the gradient w.r.t. log sigma
+// goes back through the clamp (torch: passes where min <= x <= max) into the head's sigma columns instead of into a
+// parameter; the entropy is a per-sample quantity (partial[., 1] = its per-block sums).  partial: [n_blocks][2].
+__global__ __launch_bounds__(256) void ppo_net_actor_loss_cs_kernel(const float* __restrict__ head, const float* __restrict__ act,
+                                                                    const float* __restrict__ adv, const float* __restrict__ logp_old,
+                                                                    const float* __restrict__ adv_stats, WideLossP hp, int64_t B, int A,
+                                                                    float* __restrict__ d_head, float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f, dlogp = 0.f, ent = 0.f;
+    if (b < B) {
+        const float* hrow = head + b * HEAD;
+        const float lp = gauss_logp_cs(hrow, act + b * A, A);
+        float Ab = adv[b];
+        if (hp.adv_norm) Ab = (Ab - adv_stats[0]) / (adv_stats[1] + 1e-8f);
+        if (hp.a2c) {
+            term = -lp * Ab;
+            dlogp = -Ab * hp.inv_b;
+        } else {
+            const float ratio = expf(lp - logp_old[b]);
+            const float surr1 = ratio * Ab;
+            const float surr2 = fminf(fmaxf(ratio, 1.f - hp.eps_clip), 1.f + hp.eps_clip) * Ab;
+            const float clip1 = fminf(surr1, surr2);
+            float basek = (surr1 <= surr2) ? Ab : 0.f;
+            if (hp.dual_clip > 0.f && Ab < 0.f) {
+                const float dA = hp.dual_clip * Ab;
+                term = -fmaxf(clip1, dA);
+                if (!(clip1 >= dA)) basek = 0.f;
+            } else {
+                term = -clip1;
+            }
+            dlogp = -basek * ratio * hp.inv_b;
+        }
+        float* drow = d_head + b * HEAD;
+        for (int j = 0; j < HEAD; ++j) drow[j] = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float raw = hrow[CS_COL + j];
+            const float ls = fminf(fmaxf(raw, CS_MIN), CS_MAX);
+            const float sigma = expf(ls), var = sigma * sigma, d = act[b * A + j] - hrow[j];
+            ent += 0.5f + 0.5f * 1.8378770664093453f + logf(sigma);                     // Normal.entropy()
+            drow[j] = dlogp * d / var;
+            const float dls = dlogp * (d * d / var - 1.f) - hp.ent_coef * hp.inv_b;
+            drow[CS_COL + j] = (raw >= CS_MIN && raw <= CS_MAX) ? dls : 0.f;
+        }
+    }
+    const float tot = block_sum_256(-term, red);
+    const float et = block_sum_256(ent, red);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = tot; partial[2 * blockIdx.x + 1] = et; }
+}
+
+// loss[1] (clip / actor loss) = -sum(partial[., 0]) / B, loss[3] (entropy) = sum(partial[., 1]) / B; the log_sigma block of the
+// gradient (unused parameters) is zero
+__global__ __launch_bounds__(256) void ppo_net_cs_finish_kernel(const float* __restrict__ partial, int n_blocks, int64_t B,
+                                                                float* __restrict__ losses4, float* __restrict__ g_sigma) {
+    __shared__ float red[256];
+    for (int k = 0; k < 2; ++k) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_blocks; i += 256) s += partial[2 * i + k];
+        const float t = block_sum_256(s, red);
+        if (threadIdx.x == 0) {
+            if (k == 0) losses4[1] = -(t / (float)B);
+            else losses4[3] = t / (float)B;
+        }
+    }
+    if (threadIdx.x < HEAD) g_sigma[threadIdx.x] = 0.f;
+}
+
+// losses[0] = clip + vf_coef vf - ent_coef ent with the entropy already in losses[3]
+__global__ void ppo_net_total_cs_kernel(float* __restrict__ losses, float vf_coef, float ent_coef) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) losses[0] = losses[1] + vf_coef * losses[2] - ent_coef * losses[3];
+}
+
 // ---- network passes --------------------------------------------------------------------------------------------------
 int forward(hipStream_t s, ts_workspace* ws, const Net3& n, const float* p, const float* x, const Act3& a, float* split, int64_t B) {
     const unsigned gh = (unsigned)ts::ceil_div(B * n.hid, 256);
@@ -572,7 +670,7 @@ constexpr int MAXL = TS_NET_MAX_HIDDEN + 1;          // linear layers incl. the 
 struct NetL {
     ts::ConvGeom l[MAXL];
     int64_t off[MAXL + 1];        // off[L] = end of the head block
-    int L, obs, k0, act_fn, wmax;
+    int L, obs, k0, act_fn, wmax, csigma;
     int width[MAXL + 1];          // width[0] = k0, width[i] = padded width of hidden layer i - 1, width[L] = HEAD
 };
 
@@ -583,6 +681,7 @@ int make_netl(int B, const ts_net_desc* d, NetL* n) {
     TS_REQUIRE(d->activation >= TS_NET_ACT_TANH && d->activation <= TS_NET_ACT_NONE, TS_ERR_UNSUPPORTED,
                "net: activation must be tanh, ReLU or none");
     n->L = d->n_hidden + 1; n->obs = (int)d->obs_dim; n->k0 = (n->obs + 31) / 32 * 32; n->act_fn = d->activation;
+    n->csigma = (d->flags & TS_NET_CONDITIONED_SIGMA) ? 1 : 0;
     n->width[0] = n->k0;
     n->wmax = HEAD;
     for (int i = 0; i < d->n_hidden; ++i) {
@@ -979,9 +1078,15 @@ int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, 
     TS_LAUNCH_CHECK();
     if (want_a) if (int rc = forward_l(s, ws, na, actor, x, aa, split, B)) return rc;
     if (v_out) if (int rc = forward_l(s, ws, nc, critic, x, ac, split, B)) return rc;
-    hipLaunchKernelGGL(infer_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, want_a ? aa.h[na.L - 1] : nullptr,
-                       v_out ? ac.h[nc.L - 1] : nullptr, act, want_a ? actor + na.off[na.L] : (const float*)nullptr, B, (int)act_dim,
-                       v_out, logp_out, mu_out);
+    if (want_a && na.csigma) {
+        TS_REQUIRE(act_dim <= CS_COL, TS_ERR_UNSUPPORTED, "conditioned sigma: at most %d actions", CS_COL);
+        hipLaunchKernelGGL(infer_out_cs_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.h[na.L - 1],
+                           v_out ? ac.h[nc.L - 1] : nullptr, act, B, (int)act_dim, v_out, logp_out, mu_out);
+    } else {
+        hipLaunchKernelGGL(infer_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, want_a ? aa.h[na.L - 1] : nullptr,
+                           v_out ? ac.h[nc.L - 1] : nullptr, act, want_a ? actor + na.off[na.L] : (const float*)nullptr, B, (int)act_dim,
+                           v_out, logp_out, mu_out);
+    }
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -1040,10 +1145,18 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     WideLossP lp{};
     lp.eps_clip = (float)hp->eps_clip; lp.dual_clip = a2c ? 0.f : (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
     lp.ent_coef = (float)hp->ent_coef; lp.inv_b = inv_b; lp.a2c = a2c; lp.adv_norm = a2c ? 0 : hp->adv_norm;
-    hipLaunchKernelGGL(ppo_wide_actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, aa.h[na.L - 1], act, adv, logp_old,
-                       actor + na.off[na.L], adv_stats, lp, B, A, d_head, partial);
-    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, global_batch, A, losses_out4 + 1,
-                       grad + na.off[na.L]);
+    if (na.csigma) {
+        TS_REQUIRE(A <= CS_COL, TS_ERR_UNSUPPORTED, "conditioned sigma: at most %d actions", CS_COL);
+        hipLaunchKernelGGL(ppo_net_actor_loss_cs_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, aa.h[na.L - 1], act, adv, logp_old,
+                           adv_stats, lp, B, A, d_head, partial);
+        hipLaunchKernelGGL(ppo_net_cs_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, global_batch, losses_out4,
+                           grad + na.off[na.L]);
+    } else {
+        hipLaunchKernelGGL(ppo_wide_actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, aa.h[na.L - 1], act, adv, logp_old,
+                           actor + na.off[na.L], adv_stats, lp, B, A, d_head, partial);
+        hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, global_batch, A, losses_out4 + 1,
+                           grad + na.off[na.L]);
+    }
     TS_LAUNCH_CHECK();
     if (int rc = backward_l(s, ws, na, actor, x, aa, d_head, grad, dha, dhb, slabs, B)) return rc;
     // ---- critic   (ppo.py:198-208, a2c.py:270)
@@ -1053,8 +1166,9 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, inv_b, losses_out4 + 2);
     TS_LAUNCH_CHECK();
     if (int rc = backward_l(s, ws, nc, critic, x, ac, d_head, grad + Pa, dha, dhb, slabs, B)) return rc;
-    hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + na.off[na.L], A, (float)hp->vf_coef,
-                       (float)hp->ent_coef);
+    if (na.csigma) hipLaunchKernelGGL(ppo_net_total_cs_kernel, dim3(1), dim3(64), 0, s, losses_out4, (float)hp->vf_coef, (float)hp->ent_coef);
+    else hipLaunchKernelGGL(ppo_wide_total_kernel, dim3(1), dim3(64), 0, s, losses_out4, actor + na.off[na.L], A, (float)hp->vf_coef,
+                            (float)hp->ent_coef);
     TS_LAUNCH_CHECK();
     if (!apply) return TS_OK;
     // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam

@@ -229,8 +229,10 @@ class DataParallelPPO:
                     self._apply(out)
                 k += 1
         res = self._buf[:n_steps, eng.P:eng.P + 4].clone()
-        # the entropy term depends on the parameters only: every rank added the same value
-        res[:, 3] /= self.world
+        # the entropy term depends on the parameters only: every rank added the same value (a conditioned-sigma actor's
+        # entropy is a per-sample quantity: its parts are sums over the local rows / global batch like the other two)
+        if not getattr(eng, "entropy_is_batch_sum", False):
+            res[:, 3] /= self.world
         res[:, 0] = res[:, 1] + cfg.vf_coef * res[:, 2] - cfg.ent_coef * res[:, 3]
         return res, n_steps
 

@@ -255,7 +255,8 @@ def _net_keys(actor, critic):
     actor trunk (w, b)*, mu (w, b), sigma_param | critic trunk (w, b)*, last (w, b)."""
     sa, _, _ = _trunk_spec(actor, "actor")
     sc, _, _ = _trunk_spec(critic, "critic")
-    ka = [f"{st}.{x}" for st in sa for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    ka = [f"{st}.{x}" for st in sa for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias"]
+    ka += ["sigma.model.0.weight", "sigma.model.0.bias"] if getattr(actor, "_c_sigma", False) else ["sigma_param"]
     kc = [f"{st}.{x}" for st in sc for x in ("weight", "bias")] + ["last.model.0.weight", "last.model.0.bias"]
     return ka, kc
 
@@ -266,7 +267,8 @@ def _check_supported(actor, critic):
     Humanoid's 376 / 17 / 256 x 256) on the implicit-GEMM layer kernels (tianshou_amd/ppo_wide.py); "net": every other trunk
     the reference's Net builds from `hidden_sizes` and one activation (1 .. 7 hidden layers of any widths up to 1024, nn.Tanh /
     nn.ReLU / none, actor and critic trunks may differ) on the same layer kernels (ppo_wide.NetPPOEngine) -- `hidden` is then
-    (actor hidden sizes, critic hidden sizes, activation)."""
+    (actor hidden sizes, critic hidden sizes, activation[, "conditioned_sigma"]: the actor's sigma is a second linear head,
+    continuous.py:212-234)."""
     ka, kc = _net_keys(actor, critic)
     sa, sc = actor.state_dict(), critic.state_dict()
     if set(sa.keys()) != set(ka):
@@ -274,8 +276,9 @@ def _check_supported(actor, critic):
                                   "head + sigma_param); see tianshou_amd/integration.py")
     if set(sc.keys()) != set(kc):
         raise NotImplementedError(f"HipPPO: unsupported critic (keys {sorted(set(sc) ^ set(kc))} differ from a Net trunk + linear head)")
-    if not getattr(actor, "_unbounded", False) or getattr(actor, "_c_sigma", True):
-        raise NotImplementedError("HipPPO: actor must be unbounded with a state-independent sigma_param")
+    if not getattr(actor, "_unbounded", False):
+        raise NotImplementedError("HipPPO: actor must be unbounded (the tanh bound on mu is not built)")
+    c_sigma = bool(getattr(actor, "_c_sigma", False))
     _, ha, act_a = _trunk_spec(actor, "actor")
     _, hc, act_c = _trunk_spec(critic, "critic")
     obs_dim, act_dim = int(sa[ka[0]].shape[1]), int(sa["mu.model.0.weight"].shape[0])
@@ -283,9 +286,11 @@ def _check_supported(actor, critic):
         raise NotImplementedError("HipPPO: actor and critic must read the same observation and use the same activation")
     if sa["mu.model.0.weight"].shape[1] != ha[-1] or tuple(sc["last.model.0.weight"].shape) != (1, hc[-1]):
         raise NotImplementedError("HipPPO: the heads must be single Linear layers on the trunks' outputs")
-    if act_dim > 32:
-        raise NotImplementedError("HipPPO: at most 32 actions")
-    if act_a == "tanh" and ha == hc and len(ha) == 2 and ha[0] == ha[1]:
+    if act_dim > (16 if c_sigma else 32):
+        raise NotImplementedError("HipPPO: at most 32 actions (16 with conditioned_sigma)")
+    if c_sigma and tuple(sa["sigma.model.0.weight"].shape) != (act_dim, ha[-1]):
+        raise NotImplementedError("HipPPO: the sigma head must be a single Linear layer on the trunk's output")
+    if not c_sigma and act_a == "tanh" and ha == hc and len(ha) == 2 and ha[0] == ha[1]:
         hidden = ha[0]
         if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
             return obs_dim, act_dim, hidden, "fused"
@@ -293,7 +298,7 @@ def _check_supported(actor, critic):
             return obs_dim, act_dim, hidden, "wide"
     if max(len(ha), len(hc)) > 7 or max(ha + hc) > 1024:
         raise NotImplementedError("HipPPO: trunks of up to 7 hidden layers of at most 1024 units")
-    return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a), "net"
+    return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a) + (("conditioned_sigma",) if c_sigma else ()), "net"
 
 
 def make_hip_ppo(algo: str = "ppo", ref=None):
@@ -365,8 +370,10 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             if kind == "net":
                 from .ppo_wide import net_flat_from_tensors
 
-                na = 2 * (len(hidden[0]) + 1) + 1
-                return torch.cat([net_flat_from_tensors(list(tensors[:na]), obs_dim, list(hidden[0]), act_dim, self._hip_device),
+                cs = len(hidden) > 3
+                na = 2 * (len(hidden[0]) + 1) + (2 if cs else 1)
+                return torch.cat([net_flat_from_tensors(list(tensors[:na]), obs_dim, list(hidden[0]), act_dim, self._hip_device,
+                                                        conditioned_sigma=cs),
                                   net_flat_from_tensors(list(tensors[na:]), obs_dim, list(hidden[1]), None, self._hip_device)]).contiguous()
             from .ppo_wide import flat_from_tensors
 
@@ -394,7 +401,8 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
                 elif kind == "net":
                     from .ppo_wide import NetPPOEngine
 
-                    eng = NetPPOEngine(obs_dim, act_dim, hidden[0], hidden[1], hidden[2], flat, ppo_config_from(self))
+                    eng = NetPPOEngine(obs_dim, act_dim, hidden[0], hidden[1], hidden[2], flat, ppo_config_from(self),
+                                       conditioned_sigma=len(hidden) > 3)
                 else:
                     from .ppo_wide import WidePPOEngine
 

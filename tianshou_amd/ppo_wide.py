@@ -180,20 +180,37 @@ def _pad32(n: int) -> int:
     return (int(n) + 31) // 32 * 32
 
 
-def net_flat_from_tensors(t: list[torch.Tensor], obs_dim: int, hidden: list[int], n_out: int | None, device="cuda") -> torch.Tensor:
+CS_COL = 16          # conditioned sigma: the head block's columns [16, 16 + act) are the sigma head (csrc/ts_npg.hip)
+
+
+def net_flat_from_tensors(t: list[torch.Tensor], obs_dim: int, hidden: list[int], n_out: int | None, device="cuda",
+                          conditioned_sigma: bool = False) -> torch.Tensor:
     """nn.Linear-layout tensors [w1, b1, ..., w_L, b_L, w_head, b_head(, sigma_param)] -> the ts_net_layout vector: per layer
     one block [K_pad + 1, N_pad] (last row = bias; widths padded to 32 with zeros), the head padded to 32 columns, and for
-    an actor (n_out = act_dim) log_sigma padded to 32."""
+    an actor (n_out = act_dim) log_sigma padded to 32.  conditioned_sigma: the tensors end with [..., w_mu, b_mu, w_sigma,
+    b_sigma] instead (ContinuousActorProbabilistic(conditioned_sigma=True), continuous.py:212-218): the sigma head goes into
+    the head block's columns [16, 16 + act), the log_sigma block stays zero."""
+    nl = len(hidden)
     dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
-    parts = [NG._block(t[2 * i], t[2 * i + 1], dims[i], dims[i + 1]) for i in range(len(hidden) + 1)]
+    parts = [NG._block(t[2 * i], t[2 * i + 1], dims[i], dims[i + 1]) for i in range(nl)]
+    head = NG._block(t[2 * nl], t[2 * nl + 1], dims[nl], NG.HEAD).reshape(dims[nl] + 1, NG.HEAD)
+    ls = torch.zeros(NG.HEAD, dtype=torch.float32)
+    if n_out is not None and conditioned_sigma:
+        if n_out > CS_COL:
+            raise NotImplementedError("conditioned_sigma: at most 16 actions")
+        w_s, b_s = t[2 * nl + 2].detach().float().cpu(), t[2 * nl + 3].detach().float().cpu()
+        head[: w_s.shape[1], CS_COL:CS_COL + n_out] = w_s.t()
+        head[dims[nl], CS_COL:CS_COL + n_out] = b_s
+    elif n_out is not None:
+        ls[:n_out] = t[2 * nl + 2].detach().float().cpu().reshape(-1)
+    parts.append(head.reshape(-1))
     if n_out is not None:
-        ls = torch.zeros(NG.HEAD, dtype=torch.float32)
-        ls[:n_out] = t[2 * (len(hidden) + 1)].detach().float().cpu().reshape(-1)
         parts.append(ls)
     return torch.cat(parts).to(device).contiguous()
 
 
-def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_head: int, actor: bool) -> list[torch.Tensor]:
+def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_head: int, actor: bool,
+                        conditioned_sigma: bool = False) -> list[torch.Tensor]:
     """Inverse of net_flat_from_tensors (nn.Linear layout; n_head = act_dim for an actor, 1 for a critic)."""
     true = [obs_dim] + list(hidden) + [n_head]
     dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
@@ -202,8 +219,10 @@ def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_h
         n = (dims[i] + 1) * dims[i + 1]
         blk = f[off:off + n].reshape(dims[i] + 1, dims[i + 1])
         out += [blk[: true[i], : true[i + 1]].t().contiguous(), blk[dims[i], : true[i + 1]].clone()]
+        if actor and conditioned_sigma and i == len(hidden):
+            out += [blk[: true[i], CS_COL:CS_COL + n_head].t().contiguous(), blk[dims[i], CS_COL:CS_COL + n_head].clone()]
         off += n
-    if actor:
+    if actor and not conditioned_sigma:
         out.append(f[off:off + NG.HEAD][:n_head].clone())
     return out
 
@@ -213,15 +232,18 @@ class NetPPOEngine(WidePPOEngine):
     hidden layers of any widths and a tanh / ReLU / no activation; actor and critic trunks may differ."""
 
     def __init__(self, obs_dim: int, act_dim: int, hidden_actor, hidden_critic, activation: str, flat_params: torch.Tensor,
-                 cfg: PPOConfig):
+                 cfg: PPOConfig, conditioned_sigma: bool = False):
         if not flat_params.is_cuda:
             raise RuntimeError("NetPPOEngine needs its parameters on an MI355X; there is no CPU fallback")
-        if not 1 <= act_dim <= 32:
-            raise NotImplementedError("NetPPOEngine: act_dim <= 32")
+        if not 1 <= act_dim <= (CS_COL if conditioned_sigma else 32):
+            raise NotImplementedError("NetPPOEngine: act_dim <= 32 (<= 16 with conditioned_sigma)")
         self.obs_dim, self.act_dim, self.cfg = obs_dim, act_dim, cfg
         self.hidden_actor, self.hidden_critic, self.activation = [int(h) for h in hidden_actor], [int(h) for h in hidden_critic], activation
         self.hidden = None
-        self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation)
+        self.conditioned_sigma = bool(conditioned_sigma)
+        self.entropy_is_batch_sum = self.conditioned_sigma           # (DataParallelPPO: the entropy part is summed, not repeated)
+        self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation,
+                                     _lib.NetDesc.CONDITIONED_SIGMA if conditioned_sigma else 0)
         self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation)
         out = (C.c_int64 * 3)()
         _lib.check(_lib.load().ts_net_layout(C.byref(self._na), _lib.i64(act_dim), out))
@@ -240,11 +262,12 @@ class NetPPOEngine(WidePPOEngine):
         self._ws = _lib.default_workspace(self.device.index or 0)
 
     def flat_from_tensors(self, actor_t, critic_t) -> torch.Tensor:
-        return torch.cat([net_flat_from_tensors(actor_t, self.obs_dim, self.hidden_actor, self.act_dim, self.device),
+        return torch.cat([net_flat_from_tensors(actor_t, self.obs_dim, self.hidden_actor, self.act_dim, self.device,
+                                                conditioned_sigma=self.conditioned_sigma),
                           net_flat_from_tensors(critic_t, self.obs_dim, self.hidden_critic, None, self.device)]).contiguous()
 
     def flat_to_tensors(self, flat: torch.Tensor):
-        return (net_flat_to_tensors(flat[: self.n_actor], self.obs_dim, self.hidden_actor, self.act_dim, True),
+        return (net_flat_to_tensors(flat[: self.n_actor], self.obs_dim, self.hidden_actor, self.act_dim, True, self.conditioned_sigma),
                 net_flat_to_tensors(flat[self.n_actor:], self.obs_dim, self.hidden_critic, 1, False))
 
     def infer(self, obs, act=None, want_v=True):
