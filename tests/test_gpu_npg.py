@@ -64,8 +64,11 @@ def test_infer_vs_oracle(obs_dim, act_dim, B):
         np.testing.assert_allclose(logp.cpu().numpy(), OP.dist_of(mu_ref, sigma).log_prob(act).numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("fvp_path", ["one_launch_kernel", "per_layer_gemms"])
 @pytest.mark.parametrize("algo,B", [("npg", 4096), ("trpo", 700)])
-def test_actor_step_vs_oracle_and_float64(algo, B):
+def test_actor_step_vs_oracle_and_float64(algo, B, fvp_path, monkeypatch):
+    """(both routes of the Fisher-vector product: ts_npg_q.h's one-launch kernel and the per-layer GEMM passes)"""
+    monkeypatch.setenv("TS_NPG_FVP", "1" if fvp_path == "one_launch_kernel" else "0")
     obs_dim, act_dim = 17, 6
     p = rand_params(obs_dim, act_dim, 3)
     cfg = ON.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=1)
@@ -95,6 +98,36 @@ def test_actor_step_vs_oracle_and_float64(algo, B):
     e_gpu = (new.double() - new64).abs().max().item() / step64
     e_ref = (new32.double() - new64).abs().max().item() / step64
     assert e_gpu < max(1e-5, 2 * e_ref), (e_gpu, e_ref)      # the parameter step, on the scale of the step itself
+
+
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(17, 6, 1000), (3, 1, 33), (11, 3, 4101), (27, 8, 20000), (32, 2, 64),
+                                               (8, 4, 65536)])
+def test_one_launch_fvp_matches_the_per_layer_passes(obs_dim, act_dim, B, monkeypatch):
+    """F g + damping g from npg_fvp_kernel (every instantiated layer-1 depth, ragged last tiles, one tile .. several tiles per
+    workgroup) against the forward-mode + reverse GEMM passes it replaces, and against the float64 double backward."""
+    p = rand_params(obs_dim, act_dim, 11 + obs_dim)
+    cfg = ON.NPGConfig(algo="npg", trust_region_size=0.1, optim_critic_iters=1)
+    g = torch.Generator().manual_seed(B)
+    obs, act, adv = torch.randn(B, obs_dim, generator=g), torch.randn(B, act_dim, generator=g) * 0.8, torch.randn(B, generator=g)
+    out = {}
+    for path in ("1", "0"):
+        monkeypatch.setenv("TS_NPG_FVP", path)
+        eng = make_engine(p, obs_dim, act_dim, cfg)
+        _, dbg = eng.actor_step(obs, act, adv, None, want_debug=True)
+        out[path] = (dbg.cpu(), eng.actor.cpu())
+    np.testing.assert_array_equal(out["1"][0][0].numpy(), out["0"][0][0].numpy())          # the same gradient kernels
+    assert rel_err(out["1"][0][2], out["0"][0][2]) < 1e-5
+    st = OP.PPOState(params={k: v.double() for k, v in p.items()})
+    col: dict = {}
+    ON.minibatch_step(st, cfg, obs.double(), act.double(), adv.double(), torch.zeros(B).double(),
+                      torch.zeros(B).double(), collect=col)
+    e1 = rel_err(oracle_order(out["1"][0][2].cuda(), obs_dim, act_dim), col["mvp_of_grad"])
+    e0 = rel_err(oracle_order(out["0"][0][2].cuda(), obs_dim, act_dim), col["mvp_of_grad"])
+    assert e1 < max(1e-5, 2 * e0), (e1, e0)
+    sd1 = -oracle_order(out["1"][0][1].cuda(), obs_dim, act_dim)
+    sd0 = -oracle_order(out["0"][0][1].cuda(), obs_dim, act_dim)
+    e1, e0 = rel_err(sd1, col["search_direction"]), rel_err(sd0, col["search_direction"])
+    assert e1 < max(1e-4, 2 * e0), (e1, e0)
 
 
 def test_critic_step_vs_oracle():

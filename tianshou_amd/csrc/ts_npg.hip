@@ -31,6 +31,11 @@
 namespace ts {
 int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
               double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+// ts_ppo.hip / ts_npg_q.h: the one-launch Fisher-vector product of the 64-64 actor
+bool npg_fvp_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim);
+size_t npg_fvp_slab_floats(int64_t obs_dim, int64_t B);
+int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* v, const float* x, int obs, int k0, int act,
+                  int64_t B, float damping, float* slabs, float* out);
 }
 
 namespace {
@@ -826,7 +831,9 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     const size_t bytes = al(4 * B * n.k0) + 2 * act_bytes(n, B) + 4 * al(4 * B * n.hid) + 3 * al(4 * B * HEAD) +
                          2 * al(4 * B * n.hid) + al(4 * slab_floats(n)) + al(4 * split_floats(n)) +
                          (size_t)(6 + n_cand) * al(4 * P) + al(4 * (size_t)n_blocks * (2 + A)) + al(4 * (8 + 2 * n_cand)) + 4096;
-    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
+    const bool fused_fvp = ts::npg_fvp_supported(obs_dim, hidden, act_dim);
+    const size_t fvp_floats = fused_fvp ? ts::npg_fvp_slab_floats(obs_dim, B) : 0;
+    if (int rc = ts::ws_reserve(ws, bytes + al(4 * fvp_floats))) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.f(B * n.k0);
     const Act3 a0 = take_act(c, n, B), a1 = take_act(c, n, B);           // activations at theta; at a candidate
@@ -839,6 +846,7 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     float* cands = c.f((size_t)n_cand * P);
     float* partial = c.f((size_t)n_blocks * (2 + A));
     float* sc = c.f(8 + 2 * n_cand);                                       // {rdotr, done, p.z, step, -, -, -, -, res...}
+    float* fvp_slabs = fused_fvp ? c.f(fvp_floats) : nullptr;
     float* step = sc + 3;
     float* res = sc + 8;
 
@@ -854,6 +862,8 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
 
     // F v (+ damping v) for a direction v -> out
     auto fvp = [&](const float* v, float* out) -> int {
+        if (fused_fvp)                                // hidden 64, obs <= 32, act <= 8: one kernel + the slab sum (ts_npg_q.h)
+            return ts::npg_fvp_fused(s, ws, actor, v, x, n.obs, n.k0, A, B, (float)hp->damping, fvp_slabs, out);
         if (int rc = jvp(s, ws, n, actor, v, x, a0, j, split, B)) return rc;
         hipLaunchKernelGGL(fisher_upstream_kernel, dim3((unsigned)ts::ceil_div(B * HEAD, 256)), dim3(256), 0, s, j.dmu, actor + sig,
                            B, A, u);

@@ -1125,6 +1125,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
 }
 
 #include "ts_ppo_q.h"
+#include "ts_npg_q.h"
 
 // ---------------------------------------------------------------------------------------------
 // slab reduction: grad[col] = sum over all workgroup slabs (fixed order), plus the block's
@@ -1585,6 +1586,67 @@ int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, const StepPla
 }
 
 }  // namespace
+
+// ---- the fused Fisher-vector product of ts_npg_q.h, for ts_npg.hip (same library, not part of the C ABI)
+namespace ts {
+
+bool npg_fvp_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim) {
+    const char* e = getenv("TS_NPG_FVP");                       // 0: the per-layer GEMM path (A/B runs)
+    if (e && atoi(e) == 0) return false;
+    return hidden == HID && obs_dim >= 1 && obs_dim <= 32 && act_dim >= 1 && act_dim <= ACT_PAD;
+}
+
+static int npg_fvp_grid(int64_t B) {
+    const char* e = getenv("TS_NPG_FVP_WGS");
+    const int64_t tiles = (B + 31) / 32;
+    int64_t n = e && atoi(e) > 0 ? atoi(e) : 2 * (int64_t)n_compute_units();
+    if (n > tiles) n = tiles;
+    return (int)(n < 1 ? 1 : n);
+}
+
+size_t npg_fvp_slab_floats(int64_t obs_dim, int64_t B) {
+    return (size_t)npg_fvp_grid(B) * (size_t)q4::fvp_slab_width(q4::k1s_for((int)obs_dim));
+}
+
+// out = F v + damping v on B rows of x ([B][k0] zero-padded observations); theta / v / out in ts_npg.hip's block layout
+int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* v, const float* x, int obs, int k0, int act,
+                  int64_t B, float damping, float* slabs, float* out) {
+    const int k1s = q4::k1s_for(obs);
+    TS_REQUIRE(k1s > 0 && B >= 1, TS_ERR_UNSUPPORTED, "npg_fvp_fused: unsupported shape");
+    q4::FvpArgs g{};
+    g.theta = theta; g.dir = v; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
+    g.slabs = slabs; g.slab_w = q4::fvp_slab_width(k1s);
+    g.obs = obs; g.act = act; g.k0 = k0;
+    const int grid = npg_fvp_grid(B);
+    const size_t lds = q4::fvp_lds_bytes(k1s);
+#define TS_FVP_CASE(K)                                                                                              \
+    case K: {                                                                                                       \
+        static bool attr = false;                                                                                   \
+        if (!attr) {                                                                                                \
+            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::npg_fvp_kernel<K>),                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+            attr = true;                                                                                            \
+        }                                                                                                           \
+        ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);                                                                \
+        hipLaunchKernelGGL((q4::npg_fvp_kernel<K>), dim3(grid), dim3(q4::QT), lds, s, g);                          \
+    } break;
+    switch (k1s) {
+        TS_FVP_CASE(2)
+        TS_FVP_CASE(3)
+        TS_FVP_CASE(5)
+        TS_FVP_CASE(8)
+        default: TS_REQUIRE(false, TS_ERR_UNSUPPORTED, "npg_fvp_fused: unsupported obs_dim");
+    }
+#undef TS_FVP_CASE
+    TS_LAUNCH_CHECK();
+    const int P = (k0 + 1) * HID + (HID + 1) * HID + (HID + 1) * 32 + 32;
+    hipLaunchKernelGGL(q4::npg_fvp_reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w, obs, act,
+                       k0, 4 * k1s, v, out, P, damping);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+}  // namespace ts
 
 extern "C" {
 
