@@ -116,14 +116,15 @@ def _time(update, steps, warmup):
     return dt, last, {k: (prof[k][0] / n_prof, prof[k][1] // n_prof) for k in GEMM_KINDS}
 
 
-def _roofline(prof, flop_per_update, what):
-    ms = sum(prof[k][0] for k in GEMM_KINDS)
-    n = sum(prof[k][1] for k in GEMM_KINDS)
+def _roofline(prof, flop_per_update, what, kinds=GEMM_KINDS, kernel=None):
+    ms = sum(prof[k][0] for k in kinds)
+    n = sum(prof[k][1] for k in kinds)
     tf = flop_per_update / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": f"linear / conv layer GEMM kernels: conv_rows / conv_wgrad(_group), fused mlp3_fwd / mlp3_bwd where the shape allows ({what})", "achieved": tf, "peak": PEAK,
+    kernel = kernel or "linear / conv layer GEMM kernels: conv_rows / conv_wgrad(_group), fused mlp3_fwd / mlp3_bwd where the shape allows"
+    return {"bound": "mfma", "kernel": f"{kernel} ({what})", "achieved": tf, "peak": PEAK,
             "unit": "TFLOP/s", "frac": tf / PEAK, "traffic": None, "avg_launch_us": ms * 1e3 / max(n, 1),
             "launches_per_update": n, "gemm_us_per_update": ms * 1e3, "algorithmic_flop_per_update": flop_per_update,
-            "kernel_us_per_update": {k: prof[k][0] * 1e3 for k in GEMM_KINDS}}
+            "kernel_us_per_update": {k: prof[k][0] * 1e3 for k in kinds}}
 
 
 def _line(metric, value, unit, steps, warmup, dt, workload, roof, cpu, extra=None):
@@ -524,7 +525,11 @@ def run_natural(steps, warmup, with_cpu, algo="npg"):
     return _line(f"{name} learn() update-steps/sec (minibatch 65536, obs 17, act 6, MLP[64,64], preprocessing incl.)",
                  steps * k / dt, "update-steps/s", steps, warmup, dt,
                  f"{name} on a C2-shape rollout: {E} envs x {T} steps = {n} transitions, minibatch {MB}, 5 critic iterations",
-                 _roofline(prof, flop, "linear-layer GEMMs of the Fisher-vector products, gradients and critic steps"), cpu,
+                 _roofline({kk: _LAST_PROF[kk] for kk in GEMM_KINDS + ("ppo_step",)}, flop,
+                           "gradient, Fisher-vector products, candidate evaluations, critic steps; preprocessing passes",
+                           kinds=GEMM_KINDS + ("ppo_step",),
+                           kernel="npg_fvp_kernel / npg_grad_kernel / npg_eval_kernel (ts_npg_q.h: one launch per pass of the actor), "
+                                  "ppo_step1_kernel (critic iterations), conv_rows GEMMs (preprocessing)"), cpu,
                  {"gradient_steps_per_update": k, "final_stats": [float(x) for x in stats[-1].tolist()]})
 
 

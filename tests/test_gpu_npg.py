@@ -100,34 +100,50 @@ def test_actor_step_vs_oracle_and_float64(algo, B, fvp_path, monkeypatch):
     assert e_gpu < max(1e-5, 2 * e_ref), (e_gpu, e_ref)      # the parameter step, on the scale of the step itself
 
 
+@pytest.mark.parametrize("algo", ["npg", "trpo"])
 @pytest.mark.parametrize("obs_dim,act_dim,B", [(17, 6, 1000), (3, 1, 33), (11, 3, 4101), (27, 8, 20000), (32, 2, 64),
                                                (8, 4, 65536)])
-def test_one_launch_fvp_matches_the_per_layer_passes(obs_dim, act_dim, B, monkeypatch):
-    """F g + damping g from npg_fvp_kernel (every instantiated layer-1 depth, ragged last tiles, one tile .. several tiles per
-    workgroup) against the forward-mode + reverse GEMM passes it replaces, and against the float64 double backward."""
+def test_one_launch_actor_passes_match_the_per_layer_passes(obs_dim, act_dim, B, algo, monkeypatch):
+    """The surrogate's gradient, F g + damping g, the conjugate-gradient solution, the step's statistics and the new
+    parameters from ts_npg_q.h's kernels (every instantiated layer-1 depth, ragged last tiles, one tile .. several tiles per
+    workgroup, NPG's single candidate and TRPO's ten in one launch) against the GEMM passes they replace, and against the
+    float64 evaluation of the reference's formulation."""
     p = rand_params(obs_dim, act_dim, 11 + obs_dim)
-    cfg = ON.NPGConfig(algo="npg", trust_region_size=0.1, optim_critic_iters=1)
+    cfg = ON.NPGConfig(algo=algo, trust_region_size=0.1, optim_critic_iters=1)
     g = torch.Generator().manual_seed(B)
     obs, act, adv = torch.randn(B, obs_dim, generator=g), torch.randn(B, act_dim, generator=g) * 0.8, torch.randn(B, generator=g)
+    with torch.no_grad():
+        logp_old = OP.dist_of(*OP.actor_forward(p, obs)).log_prob(act)
     out = {}
     for path in ("1", "0"):
         monkeypatch.setenv("TS_NPG_FVP", path)
         eng = make_engine(p, obs_dim, act_dim, cfg)
-        _, dbg = eng.actor_step(obs, act, adv, None, want_debug=True)
-        out[path] = (dbg.cpu(), eng.actor.cpu())
-    np.testing.assert_array_equal(out["1"][0][0].numpy(), out["0"][0][0].numpy())          # the same gradient kernels
-    assert rel_err(out["1"][0][2], out["0"][0][2]) < 1e-5
+        stats, dbg = eng.actor_step(obs, act, adv, logp_old, want_debug=True)
+        out[path] = (dbg.cpu(), eng.actor.cpu(), stats.cpu())
+    assert rel_err(out["1"][0][0], out["0"][0][0]) < 1e-5                                   # gradient
+    assert rel_err(out["1"][0][2], out["0"][0][2]) < 1e-5                                   # F g + damping g
     st = OP.PPOState(params={k: v.double() for k, v in p.items()})
     col: dict = {}
-    ON.minibatch_step(st, cfg, obs.double(), act.double(), adv.double(), torch.zeros(B).double(),
-                      torch.zeros(B).double(), collect=col)
-    e1 = rel_err(oracle_order(out["1"][0][2].cuda(), obs_dim, act_dim), col["mvp_of_grad"])
-    e0 = rel_err(oracle_order(out["0"][0][2].cuda(), obs_dim, act_dim), col["mvp_of_grad"])
-    assert e1 < max(1e-5, 2 * e0), (e1, e0)
+    ON.minibatch_step(st, cfg, obs.double(), act.double(), adv.double(), torch.zeros(B).double(), logp_old.double(), collect=col)
+    new64 = torch.cat([st.params[k].reshape(-1) for k in ON.ACTOR_KEYS])
+    for key, row in (("flat_grads", 0), ("mvp_of_grad", 2)):
+        e1 = rel_err(oracle_order(out["1"][0][row].cuda(), obs_dim, act_dim), col[key])
+        e0 = rel_err(oracle_order(out["0"][0][row].cuda(), obs_dim, act_dim), col[key])
+        assert e1 < max(1e-5, 2 * e0), (key, e1, e0)
     sd1 = -oracle_order(out["1"][0][1].cuda(), obs_dim, act_dim)
     sd0 = -oracle_order(out["0"][0][1].cuda(), obs_dim, act_dim)
     e1, e0 = rel_err(sd1, col["search_direction"]), rel_err(sd0, col["search_direction"])
     assert e1 < max(1e-4, 2 * e0), (e1, e0)
+    # the surrogate, the chosen candidate's kl and the step size; the parameter step on the scale of the step itself
+    s1, s0 = out["1"][2].double().numpy(), out["0"][2].double().numpy()
+    np.testing.assert_allclose(s1[0], s0[0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(s1[1:], s0[1:], rtol=2e-3, atol=1e-7)
+    old = torch.cat([p[k].reshape(-1) for k in ON.ACTOR_KEYS]).double()
+    step64 = (new64 - old).abs().max().item()
+    if step64 > 0:
+        e1 = (oracle_order(out["1"][1].cuda(), obs_dim, act_dim).double() - new64).abs().max().item() / step64
+        e0 = (oracle_order(out["0"][1].cuda(), obs_dim, act_dim).double() - new64).abs().max().item() / step64
+        assert e1 < max(1e-4, 2 * e0), (e1, e0)
 
 
 def test_critic_step_vs_oracle():

@@ -31,11 +31,18 @@
 namespace ts {
 int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
               double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
-// ts_ppo.hip / ts_npg_q.h: the one-launch Fisher-vector product of the 64-64 actor
-bool npg_fvp_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim);
-size_t npg_fvp_slab_floats(int64_t obs_dim, int64_t B);
+// ts_ppo.hip / ts_npg_q.h: the one-launch gradient / Fisher-vector product / candidate evaluation passes of the 64-64 actor
+bool npg_fused_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim);
+size_t npg_fused_slab_floats(int64_t obs_dim, int64_t B);
+size_t npg_fused_eval_floats(int64_t B, int n_cand);
 int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* v, const float* x, int obs, int k0, int act,
                   int64_t B, float damping, float* slabs, float* out);
+int npg_grad_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* x, const float* actions, const float* adv,
+                   const float* logp_old, int obs, int k0, int act, int64_t B, float* slabs, float* grad, float* loss_out,
+                   float* mu);
+int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, const float* cands, int64_t cand_stride, int n_cand,
+                   const float* x, const float* actions, const float* adv, const float* logp_old, const float* mu, int obs, int k0,
+                   int act, int64_t B, float* partial, float* res);
 }
 
 namespace {
@@ -831,9 +838,12 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     const size_t bytes = al(4 * B * n.k0) + 2 * act_bytes(n, B) + 4 * al(4 * B * n.hid) + 3 * al(4 * B * HEAD) +
                          2 * al(4 * B * n.hid) + al(4 * slab_floats(n)) + al(4 * split_floats(n)) +
                          (size_t)(6 + n_cand) * al(4 * P) + al(4 * (size_t)n_blocks * (2 + A)) + al(4 * (8 + 2 * n_cand)) + 4096;
-    const bool fused_fvp = ts::npg_fvp_supported(obs_dim, hidden, act_dim);
-    const size_t fvp_floats = fused_fvp ? ts::npg_fvp_slab_floats(obs_dim, B) : 0;
-    if (int rc = ts::ws_reserve(ws, bytes + al(4 * fvp_floats))) return rc;
+    // hidden 64, obs <= 32, act <= 8: gradient, Fisher-vector products and candidate evaluations are one kernel + one small
+    // sum each (ts_npg_q.h); other shapes: per-layer GEMM passes
+    const bool fused = ts::npg_fused_supported(obs_dim, hidden, act_dim);
+    const size_t fvp_floats = fused ? ts::npg_fused_slab_floats(obs_dim, B) : 0;
+    const size_t eval_floats = fused ? ts::npg_fused_eval_floats(B, n_cand) : 0;
+    if (int rc = ts::ws_reserve(ws, bytes + al(4 * fvp_floats) + al(4 * eval_floats) + (fused ? al(4 * B * 8) : 0))) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.f(B * n.k0);
     const Act3 a0 = take_act(c, n, B), a1 = take_act(c, n, B);           // activations at theta; at a candidate
@@ -846,23 +856,31 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     float* cands = c.f((size_t)n_cand * P);
     float* partial = c.f((size_t)n_blocks * (2 + A));
     float* sc = c.f(8 + 2 * n_cand);                                       // {rdotr, done, p.z, step, -, -, -, -, res...}
-    float* fvp_slabs = fused_fvp ? c.f(fvp_floats) : nullptr;
+    float* fvp_slabs = fused ? c.f(fvp_floats) : nullptr;
+    float* eval_part = fused ? c.f(eval_floats) : nullptr;
+    float* mu_old = fused ? c.f(B * 8) : nullptr;
     float* step = sc + 3;
     float* res = sc + 8;
 
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
     TS_LAUNCH_CHECK();
     // vanilla gradient of the surrogate (npg.py:152-158 / trpo.py:135-141)
-    if (int rc = forward(s, ws, n, actor, x, a0, split, B)) return rc;
-    hipLaunchKernelGGL(actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a0.out, act, adv, logp_old, actor + sig,
-                       hp->algo, B, A, d_head, partial);
-    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, A, stats_out3, g + sig);
-    TS_LAUNCH_CHECK();
-    if (int rc = backward(s, ws, n, actor, x, a0, d_head, g, bw, B)) return rc;
+    if (fused) {
+        if (int rc = ts::npg_grad_fused(s, ws, actor, x, act, adv, hp->algo == 1 ? logp_old : (const float*)nullptr, n.obs, n.k0, A, B,
+                                        fvp_slabs, g, stats_out3, mu_old))
+            return rc;
+    } else {
+        if (int rc = forward(s, ws, n, actor, x, a0, split, B)) return rc;
+        hipLaunchKernelGGL(actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a0.out, act, adv, logp_old, actor + sig,
+                           hp->algo, B, A, d_head, partial);
+        hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, A, stats_out3, g + sig);
+        TS_LAUNCH_CHECK();
+        if (int rc = backward(s, ws, n, actor, x, a0, d_head, g, bw, B)) return rc;
+    }
 
     // F v (+ damping v) for a direction v -> out
     auto fvp = [&](const float* v, float* out) -> int {
-        if (fused_fvp)                                // hidden 64, obs <= 32, act <= 8: one kernel + the slab sum (ts_npg_q.h)
+        if (fused)
             return ts::npg_fvp_fused(s, ws, actor, v, x, n.obs, n.k0, A, B, (float)hp->damping, fvp_slabs, out);
         if (int rc = jvp(s, ws, n, actor, v, x, a0, j, split, B)) return rc;
         hipLaunchKernelGGL(fisher_upstream_kernel, dim3((unsigned)ts::ceil_div(B * HEAD, 256)), dim3(256), 0, s, j.dmu, actor + sig,
@@ -900,7 +918,10 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     if (hp->algo == 0) {                              // npg.py:170-177
         hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, (const float*)nullptr,
                            (float)hp->trust_region_size, 1.f, cands);
-        if (int rc = eval(cands, res, false)) return rc;
+        if (fused) {
+            if (int rc = ts::npg_eval_fused(s, ws, actor, cands, P, 1, x, act, adv, nullptr, mu_old, n.obs, n.k0, A, B, eval_part, res))
+                return rc;
+        } else if (int rc = eval(cands, res, false)) return rc;
         TS_HIP_CHECK(hipMemcpyAsync(actor, cands, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
         TS_HIP_CHECK(hipMemcpyAsync(stats_out3 + 1, res, sizeof(float), hipMemcpyDeviceToDevice, s));
         TS_HIP_CHECK(hipMemsetAsync(stats_out3 + 2, 0, sizeof(float), s));
@@ -912,9 +933,13 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     float cpow = 1.f;
     for (int k = 0; k < n_cand; ++k) {
         hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, step, 0.f, cpow, cands + (size_t)k * P);
-        if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
+        if (!fused)
+            if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
         cpow = cpow * (float)hp->backtrack_coeff;
     }
+    if (fused)                                        // every backtracking candidate in one launch (blockIdx.y = candidate)
+        if (int rc = ts::npg_eval_fused(s, ws, actor, cands, P, n_cand, x, act, adv, logp_old, mu_old, n.obs, n.k0, A, B, eval_part, res))
+            return rc;
     hipLaunchKernelGGL(trpo_select_kernel, dim3((unsigned)std::min<int64_t>(gp, 64)), dim3(256), 0, s, actor, cands, P, res, n_cand,
                        (float)hp->max_kl, (float)hp->backtrack_coeff, step, stats_out3);
     TS_LAUNCH_CHECK();

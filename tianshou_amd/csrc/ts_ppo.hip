@@ -1587,64 +1587,118 @@ int run_grad(ts_workspace* ws, StepArgs& g, const Dims& d, int ks, const StepPla
 
 }  // namespace
 
-// ---- the fused Fisher-vector product of ts_npg_q.h, for ts_npg.hip (same library, not part of the C ABI)
+// ---- the one-launch actor passes of ts_npg_q.h, for ts_npg.hip (same library, not part of the C ABI)
 namespace ts {
 
-bool npg_fvp_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim) {
+bool npg_fused_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim) {
     const char* e = getenv("TS_NPG_FVP");                       // 0: the per-layer GEMM path (A/B runs)
     if (e && atoi(e) == 0) return false;
     return hidden == HID && obs_dim >= 1 && obs_dim <= 32 && act_dim >= 1 && act_dim <= ACT_PAD;
 }
 
-static int npg_fvp_grid(int64_t B) {
+static int npg_grid(int64_t B, int per_cu) {
     const char* e = getenv("TS_NPG_FVP_WGS");
     const int64_t tiles = (B + 31) / 32;
-    int64_t n = e && atoi(e) > 0 ? atoi(e) : 2 * (int64_t)n_compute_units();
+    int64_t n = e && atoi(e) > 0 ? atoi(e) : per_cu * (int64_t)n_compute_units();
+    if (n > tiles) n = tiles;
+    return (int)(n < 1 ? 1 : n);
+}
+static int npg_eval_grid(int64_t B, int n_cand) {
+    const int64_t tiles = (B + 31) / 32;
+    int64_t n = (4 * (int64_t)n_compute_units() + n_cand - 1) / n_cand;
     if (n > tiles) n = tiles;
     return (int)(n < 1 ? 1 : n);
 }
 
-size_t npg_fvp_slab_floats(int64_t obs_dim, int64_t B) {
-    return (size_t)npg_fvp_grid(B) * (size_t)q4::fvp_slab_width(q4::k1s_for((int)obs_dim));
+// floats of slab scratch for the GRAD / FVP launches on B rows; of partial sums for an EVAL launch
+size_t npg_fused_slab_floats(int64_t obs_dim, int64_t B) {
+    return (size_t)npg_grid(B, 3) * (size_t)q4::actor_slab_width(q4::k1s_for((int)obs_dim));
 }
+size_t npg_fused_eval_floats(int64_t B, int n_cand) { return (size_t)n_cand * (size_t)npg_eval_grid(B, n_cand) * 2; }
+
+#define TS_NPG_LAUNCH(KERNEL, MODE, K, GRID)                                                                        \
+    case K: {                                                                                                       \
+        static bool attr = false;                                                                                   \
+        const size_t lds = q4::actor_lds_bytes<MODE>(K);                                                            \
+        if (!attr) {                                                                                                \
+            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::KERNEL<K>),                        \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+            attr = true;                                                                                            \
+        }                                                                                                           \
+        ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);                                                                \
+        hipLaunchKernelGGL((q4::KERNEL<K>), GRID, dim3(q4::QT), lds, s, g);                                         \
+    } break;
+#define TS_NPG_DISPATCH(KERNEL, MODE, GRID)                                                                         \
+    switch (k1s) {                                                                                                  \
+        TS_NPG_LAUNCH(KERNEL, MODE, 2, GRID)                                                                        \
+        TS_NPG_LAUNCH(KERNEL, MODE, 3, GRID)                                                                        \
+        TS_NPG_LAUNCH(KERNEL, MODE, 5, GRID)                                                                        \
+        TS_NPG_LAUNCH(KERNEL, MODE, 8, GRID)                                                                        \
+        default: TS_REQUIRE(false, TS_ERR_UNSUPPORTED, "npg fused pass: unsupported obs_dim");                      \
+    }                                                                                                               \
+    TS_LAUNCH_CHECK();
+
+static int npg_param_count(int k0) { return (k0 + 1) * HID + (HID + 1) * HID + (HID + 1) * 32 + 32; }
 
 // out = F v + damping v on B rows of x ([B][k0] zero-padded observations); theta / v / out in ts_npg.hip's block layout
 int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* v, const float* x, int obs, int k0, int act,
                   int64_t B, float damping, float* slabs, float* out) {
     const int k1s = q4::k1s_for(obs);
     TS_REQUIRE(k1s > 0 && B >= 1, TS_ERR_UNSUPPORTED, "npg_fvp_fused: unsupported shape");
-    q4::FvpArgs g{};
+    q4::ActorArgs g{};
     g.theta = theta; g.dir = v; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
-    g.slabs = slabs; g.slab_w = q4::fvp_slab_width(k1s);
+    g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
     g.obs = obs; g.act = act; g.k0 = k0;
-    const int grid = npg_fvp_grid(B);
-    const size_t lds = q4::fvp_lds_bytes(k1s);
-#define TS_FVP_CASE(K)                                                                                              \
-    case K: {                                                                                                       \
-        static bool attr = false;                                                                                   \
-        if (!attr) {                                                                                                \
-            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::npg_fvp_kernel<K>),                \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-            attr = true;                                                                                            \
-        }                                                                                                           \
-        ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);                                                                \
-        hipLaunchKernelGGL((q4::npg_fvp_kernel<K>), dim3(grid), dim3(q4::QT), lds, s, g);                          \
-    } break;
-    switch (k1s) {
-        TS_FVP_CASE(2)
-        TS_FVP_CASE(3)
-        TS_FVP_CASE(5)
-        TS_FVP_CASE(8)
-        default: TS_REQUIRE(false, TS_ERR_UNSUPPORTED, "npg_fvp_fused: unsupported obs_dim");
-    }
-#undef TS_FVP_CASE
-    TS_LAUNCH_CHECK();
-    const int P = (k0 + 1) * HID + (HID + 1) * HID + (HID + 1) * 32 + 32;
-    hipLaunchKernelGGL(q4::npg_fvp_reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w, obs, act,
-                       k0, 4 * k1s, v, out, P, damping);
+    const int grid = npg_grid(B, 2);
+    TS_NPG_DISPATCH(npg_fvp_kernel, q4::NPG_FVP, dim3(grid))
+    const int P = npg_param_count(k0);
+    hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w, obs,
+                       act, k0, 4 * k1s, v, out, P, damping, (float*)nullptr, (float)B);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
+
+// grad = d surrogate / d theta (logp_old == NULL: -mean(logp adv), else -mean(exp(logp - logp_old) adv)), loss_out[0] = the
+// surrogate, mu[B][8] = the policy mean at theta
+int npg_grad_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* x, const float* actions, const float* adv,
+                   const float* logp_old, int obs, int k0, int act, int64_t B, float* slabs, float* grad, float* loss_out,
+                   float* mu) {
+    const int k1s = q4::k1s_for(obs);
+    TS_REQUIRE(k1s > 0 && B >= 1, TS_ERR_UNSUPPORTED, "npg_grad_fused: unsupported shape");
+    q4::ActorArgs g{};
+    g.theta = theta; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
+    g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
+    g.obs = obs; g.act = act; g.k0 = k0;
+    g.actions = actions; g.adv = adv; g.logp_old = logp_old; g.mu = mu;
+    const int grid = npg_grid(B, 3);
+    TS_NPG_DISPATCH(npg_grad_kernel, q4::NPG_GRAD, dim3(grid))
+    const int P = npg_param_count(k0);
+    hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 1 + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w,
+                       obs, act, k0, 4 * k1s, (const float*)nullptr, grad, P, 0.f, loss_out, (float)B);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// res[2 c + {0, 1}] = {mean kl(old || candidate c), -mean(ratio adv) at candidate c (logp_old != NULL)}; candidates at
+// cands + c * cand_stride; mu = the old mean per sample (npg_grad_fused)
+int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, const float* cands, int64_t cand_stride, int n_cand,
+                   const float* x, const float* actions, const float* adv, const float* logp_old, const float* mu, int obs, int k0,
+                   int act, int64_t B, float* partial, float* res) {
+    const int k1s = q4::k1s_for(obs);
+    TS_REQUIRE(k1s > 0 && B >= 1 && n_cand >= 1 && n_cand <= 32, TS_ERR_UNSUPPORTED, "npg_eval_fused: unsupported shape");
+    q4::ActorArgs g{};
+    g.theta = cands; g.cand_stride = cand_stride; g.theta_old = theta_old; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
+    g.slabs = partial;
+    g.obs = obs; g.act = act; g.k0 = k0;
+    g.actions = actions; g.adv = adv; g.logp_old = logp_old; g.mu = const_cast<float*>(mu);
+    const int grid = npg_eval_grid(B, n_cand);
+    TS_NPG_DISPATCH(npg_eval_kernel, q4::NPG_EVAL, dim3(grid, n_cand))
+    hipLaunchKernelGGL(q4::npg_eval_finish_kernel, dim3(n_cand), dim3(256), 0, s, partial, grid, (float)B, res);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+#undef TS_NPG_DISPATCH
+#undef TS_NPG_LAUNCH
 
 }  // namespace ts
 
