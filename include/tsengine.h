@@ -1000,6 +1000,13 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
                        int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
                        double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream);
 
+/* The optim_critic_iters iterations of a minibatch (npg.py:179-183: the same obs / returns every iteration) in one call:
+ * iteration k takes Adam step number adam_step + k.  loss_out float32[1] / grad_out (nullable) hold the LAST iteration's
+ * loss and gradient.  Hidden 64 and obs_dim <= 32: one kernel + one small sum per gradient (csrc/ts_npg_q.h). */
+int ts_npg_critic_steps(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                        int64_t hidden, const float* obs, const float* returns, int64_t B, int64_t iters, double lr, double beta1,
+                        double beta2, double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream);
+
 /* One minibatch of PPO._update_with_batch / A2C._update_with_batch (ppo.py:179-216, a2c.py:262-283) for ANY Net[h, h]
  * tanh actor-critic (obs_dim >= 1, hidden a multiple of 32 up to 1024, act_dim <= 32): the shapes the fused kernels behind
  * ts_ppo_update do not cover (they are specialised to hidden 64, obs <= 31, act <= 8) run on the implicit-GEMM layers

@@ -51,7 +51,8 @@ def rand_params(obs_dim, act_dim, seed):
     return p
 
 
-@pytest.mark.parametrize("obs_dim,act_dim,B", [(17, 6, 1000), (33, 1, 64), (4, 32, 257)])
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(17, 6, 1000), (33, 1, 64), (4, 32, 257), (3, 1, 33), (27, 8, 5000), (8, 3, 70001),
+                                               (32, 2, 31)])
 def test_infer_vs_oracle(obs_dim, act_dim, B):
     p = rand_params(obs_dim, act_dim, 1)
     eng = make_engine(p, obs_dim, act_dim, ON.NPGConfig())
@@ -146,8 +147,11 @@ def test_one_launch_actor_passes_match_the_per_layer_passes(obs_dim, act_dim, B,
         assert e1 < max(1e-4, 2 * e0), (e1, e0)
 
 
-def test_critic_step_vs_oracle():
-    obs_dim, act_dim, B = 17, 6, 3000
+@pytest.mark.parametrize("path", ["one_launch_kernel", "per_layer_gemms"])
+@pytest.mark.parametrize("obs_dim,B", [(17, 3000), (3, 33), (30, 40000)])
+def test_critic_step_vs_oracle(obs_dim, B, path, monkeypatch):
+    monkeypatch.setenv("TS_NPG_FVP", "0" if path == "per_layer_gemms" else "1")
+    act_dim = 6
     p = rand_params(obs_dim, act_dim, 7)
     cfg = ON.NPGConfig(lr=1e-3, max_grad_norm=0.5)
     eng = make_engine(p, obs_dim, act_dim, cfg)
@@ -170,23 +174,44 @@ def test_critic_step_vs_oracle():
         pc64 = {k: p64[k].clone().requires_grad_(True) for k in C_KEYS}
         vf64 = torch.nn.functional.mse_loss(ret.double(), OP.critic_forward({**p64, **pc64}, obs.double()).flatten())
         gs64 = dict(zip(C_KEYS, torch.autograd.grad(vf64, [pc64[k] for k in C_KEYS])))
+        # (40,000 samples: the head bias gradient is a mean of 40,000 terms of magnitude ~4 that cancels to ~1e-3 -- float32
+        # sums of that length are good to ~2e-5 of the result in any order)
+        bar = 1e-5 if B <= 10000 else 3e-5
         for t, k in zip(NG.critic_flat_to_torch(grad, obs_dim, 64), C_KEYS):
-            assert rel_err(t.cpu(), gs64[k]) < max(1e-5, 2 * rel_err(gs[k], gs64[k])), k
+            assert rel_err(t.cpu(), gs64[k]) < max(bar, 2 * rel_err(gs[k], gs64[k])), k
         ON._critic_adam(st, cfg, gs)
         eng.critic_step(obs, ret)
         for t, k in zip(NG.critic_flat_to_torch(eng.critic, obs_dim, 64), C_KEYS):
             np.testing.assert_allclose(t.cpu().numpy(), st.params[k].numpy(), rtol=1e-5, atol=0.02 * cfg.lr, err_msg=k)
 
 
-@pytest.mark.parametrize("critic_path", ["fused_step_kernel", "per_layer_gemms"])
+@pytest.mark.parametrize("path", ["one_launch_kernel", "per_layer_gemms"])
+def test_critic_steps_is_the_loop_of_critic_step(path, monkeypatch):
+    """ts_npg_critic_steps (all optim_critic_iters iterations of a minibatch in one call) == the same number of
+    ts_npg_critic_step calls: bit-identical parameters, moments and last loss."""
+    monkeypatch.setenv("TS_NPG_FVP", "0" if path == "per_layer_gemms" else "1")
+    obs_dim, act_dim, B = 17, 6, 5000
+    p = rand_params(obs_dim, act_dim, 9)
+    cfg = ON.NPGConfig(lr=1e-3, max_grad_norm=0.5)
+    g = torch.Generator().manual_seed(4)
+    obs, ret = torch.randn(B, obs_dim, generator=g), torch.randn(B, generator=g) * 2
+    a, b = make_engine(p, obs_dim, act_dim, cfg), make_engine(p, obs_dim, act_dim, cfg)
+    la = a.critic_steps(obs, ret, 5)
+    for _ in range(5):
+        lb = b.critic_step(obs, ret)
+    assert a.adam_step == b.adam_step == 5
+    for x, y in ((a.critic, b.critic), (a.critic_m, b.critic_m), (a.critic_v, b.critic_v), (la, lb)):
+        np.testing.assert_array_equal(x.cpu().numpy(), y.cpu().numpy())
+
+
+@pytest.mark.parametrize("critic_path", ["one_launch_passes", "per_layer_gemms"])
 @pytest.mark.parametrize("tag", ["npg", "trpo"])
 def test_update_matches_reference_golden(tag, critic_path, monkeypatch):
-    """(both routes of the critic iterations: A2C steps with a zero advantage on the fused step kernel of ts_ppo.hip, and
-    ts_npg_critic_step -- TS_NPG_CRITIC_GEMM=1)"""
+    """(both routes of every network pass -- preprocessing, gradient, Fisher-vector products, candidate evaluations, critic
+    iterations: the one-launch kernels of csrc/ts_npg_q.h and the per-layer GEMM passes, TS_NPG_FVP=0)"""
     from tianshou_amd import npg as NG
 
-    if critic_path == "per_layer_gemms":
-        monkeypatch.setenv("TS_NPG_CRITIC_GEMM", "1")
+    monkeypatch.setenv("TS_NPG_FVP", "0" if critic_path == "per_layer_gemms" else "1")
     g, d, cfg = load_npg(tag)
     p0 = OP.unflatten_params(torch.as_tensor(g["flat_params0"]), d["obs_dim"], d["act_dim"])
     eng = make_engine(p0, d["obs_dim"], d["act_dim"], cfg)
@@ -205,10 +230,6 @@ def test_update_matches_reference_golden(tag, critic_path, monkeypatch):
     flat = torch.cat([t.reshape(-1) for t in a + c]).cpu().numpy()            # = oracle_ppo.PARAM_ORDER
     step = np.abs(g["flat_params"] - g["flat_params0"]).max()
     assert np.abs(flat - g["flat_params"]).max() < 5e-3 * step
-    assert eng.critic_fused_supported() == (critic_path == "fused_step_kernel" and d["obs_dim"] <= 31 and d["act_dim"] <= 8)
-    if eng._fused is not None:          # the zero actor beside the critic never moves
-        n_actor = eng._fused[0].P - int(eng._fused[2].numel())
-        assert float(eng._fused[0].params[:n_actor].abs().max()) == 0.0 and float(eng._fused[0].adam_v[:n_actor].abs().max()) == 0.0
 
 
 def test_bad_arguments_fail_loudly():

@@ -40,6 +40,10 @@ int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const flo
 int npg_grad_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* x, const float* actions, const float* adv,
                    const float* logp_old, int obs, int k0, int act, int64_t B, float* slabs, float* grad, float* loss_out,
                    float* mu);
+int npg_infer_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* x, const float* actions, int obs, int k0,
+                    int act, int64_t B, float* head_out, int head_stride, float* logp_out);
+int npg_critic_grad_fused(hipStream_t s, ts_workspace* ws, const float* critic, const float* x, const float* returns, int obs,
+                          int k0, int64_t B, float* slabs, float* grad, float* loss_out);
 int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, const float* cands, int64_t cand_stride, int n_cand,
                    const float* x, const float* actions, const float* adv, const float* logp_old, const float* mu, int obs, int k0,
                    int act, int64_t B, float* partial, float* res);
@@ -801,6 +805,18 @@ int ts_npg_infer(ts_workspace* ws, const float* actor, const float* critic, int6
     Net3 n;
     if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);
+    if (act_dim <= 8 && ts::npg_fused_supported(obs_dim, hidden, act_dim)) {      // one forward kernel per network (ts_npg_q.h)
+        if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + 4096)) return rc;
+        float* x = static_cast<float*>(ws->base);
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+        TS_LAUNCH_CHECK();
+        if (logp_out || mu_out)
+            if (int rc = ts::npg_infer_fused(s, ws, actor, x, act, n.obs, n.k0, (int)act_dim, B, mu_out, (int)act_dim, logp_out))
+                return rc;
+        if (v_out)
+            if (int rc = ts::npg_infer_fused(s, ws, critic, x, nullptr, n.obs, n.k0, 1, B, v_out, 1, nullptr)) return rc;
+        return TS_OK;
+    }
     if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + 2 * act_bytes(n, B) + al(4 * split_floats(n)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.f(B * n.k0);
@@ -976,21 +992,41 @@ int ts_npg_actor_grad(ts_workspace* ws, const float* actor, int64_t obs_dim, int
     return backward(s, ws, n, actor, x, a, d_head, grad_out, bw, B);
 }
 
-int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
-                       int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
-                       double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {
-    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_critic_step: workspace is NULL");
-    TS_REQUIRE(critic && adam_m && adam_v && obs && returns && loss_out && B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG,
-               "ts_npg_critic_step: bad argument");
+int ts_npg_critic_steps(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                        int64_t hidden, const float* obs, const float* returns, int64_t B, int64_t iters, double lr, double beta1,
+                        double beta2, double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_critic_steps: workspace is NULL");
+    TS_REQUIRE(critic && adam_m && adam_v && obs && returns && loss_out && B >= 1 && adam_step >= 1 && iters >= 1 && iters <= 4096,
+               TS_ERR_INVALID_ARG, "ts_npg_critic_steps: bad argument");
     Net3 n;
     if (int rc = make_net3((int)B, obs_dim, hidden, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);
     const int64_t P = n.off[3];
-    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) +
-                                        al(4 * slab_floats(n)) + al(4 * split_floats(n)) + al(4 * P) + al(4 * ts::ceil_div(B, 256)) + 8192))
-        return rc;
+    // hidden 64, obs <= 32: one kernel + one small sum per iteration's gradient (ts_npg_q.h, CRITIC pass)
+    const bool fused = ts::npg_fused_supported(obs_dim, hidden, 1);
+    const size_t slab_fl = fused ? ts::npg_fused_slab_floats(obs_dim, B) : 0;
+    const size_t bytes = fused ? al(4 * B * n.k0) + al(4 * slab_fl) + al(4 * P) + 8192
+                               : al(4 * B * n.k0) + act_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.hid) + al(4 * slab_floats(n)) +
+                                     al(4 * split_floats(n)) + al(4 * P) + al(4 * ts::ceil_div(B, 256)) + 8192;
+    if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.f(B * n.k0);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    if (fused) {
+        float* slabs = c.f(slab_fl);
+        float* grad = c.f(P);
+        float* norm_part = c.f(1024);
+        if (grad_out) grad = grad_out;
+        for (int64_t it = 0; it < iters; ++it) {
+            if (int rc = ts::npg_critic_grad_fused(s, ws, critic, x, returns, n.obs, n.k0, B, slabs, grad, loss_out)) return rc;
+            if (lr < 0.0) continue;
+            if (int rc = ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step + it, lr, beta1, beta2, adam_eps, max_grad_norm,
+                                       norm_part))
+                return rc;
+        }
+        return TS_OK;
+    }
     const Act3 a = take_act(c, n, B);
     float* d_head = c.f(B * HEAD);
     Bwd bw{c.f(B * n.hid), c.f(B * n.hid), c.f(slab_floats(n))};
@@ -1000,15 +1036,25 @@ int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* ad
     const int n_blocks = (int)ts::ceil_div(B, 256);
     float* lpart = c.f(n_blocks);
     if (grad_out) grad = grad_out;
-    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
-    TS_LAUNCH_CHECK();
-    if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
-    hipLaunchKernelGGL(critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, returns, B, d_head, lpart);
-    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, lpart, n_blocks, 1.f / (float)B, loss_out);
-    TS_LAUNCH_CHECK();
-    if (int rc = backward(s, ws, n, critic, x, a, d_head, grad, bw, B)) return rc;
-    if (lr < 0.0) return TS_OK;
-    return ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step, lr, beta1, beta2, adam_eps, max_grad_norm, norm_part);
+    for (int64_t it = 0; it < iters; ++it) {
+        if (int rc = forward(s, ws, n, critic, x, a, split, B)) return rc;
+        hipLaunchKernelGGL(critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.out, returns, B, d_head, lpart);
+        hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, lpart, n_blocks, 1.f / (float)B, loss_out);
+        TS_LAUNCH_CHECK();
+        if (int rc = backward(s, ws, n, critic, x, a, d_head, grad, bw, B)) return rc;
+        if (lr < 0.0) continue;
+        if (int rc = ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step + it, lr, beta1, beta2, adam_eps, max_grad_norm,
+                                   norm_part))
+            return rc;
+    }
+    return TS_OK;
+}
+
+int ts_npg_critic_step(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,
+                       int64_t hidden, const float* obs, const float* returns, int64_t B, double lr, double beta1, double beta2,
+                       double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {
+    return ts_npg_critic_steps(ws, critic, adam_m, adam_v, adam_step, obs_dim, hidden, obs, returns, B, 1, lr, beta1, beta2, adam_eps,
+                               max_grad_norm, loss_out, grad_out, stream);
 }
 
 int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t obs_dim,

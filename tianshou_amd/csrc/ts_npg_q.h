@@ -1,7 +1,7 @@
 // ts_npg_q.h -- one-launch passes over the obs -> 64 -> 64 -> mu tanh Gaussian actor for NPG / TRPO on gfx950 (included by
 // ts_ppo.hip behind ts_ppo_q.h, inside its anonymous namespace; called from ts_npg.hip through ts::npg_*_fused).
 //
-// Three passes of NPG._update_with_batch / TRPO._update_with_batch on one minibatch, each ONE kernel over 32-sample tiles
+// Passes of NPG / TRPO's learn() on one (mini)batch, each ONE kernel over 32-sample tiles
 // plus one small sum, where the per-layer path takes 8 - 20 GEMM / elementwise launches:
 //   GRAD  the vanilla gradient of the surrogate (npg.py:152-158: -mean(logp adv); trpo.py:135-141: -mean(ratio adv)):
 //         forward, per-sample loss, reverse pass.  Also leaves mu(theta) per sample for the KL evaluations.
@@ -11,6 +11,10 @@
 //           forward  H1 = tanh(W1 x + b1), H2 = tanh(W2 H1 + b2)                              (activations at theta)
 //           tangent  T1 = (V1 x + vb1)(1 - H1^2), T2 = (W2 T1 + V2 H1 + vb2)(1 - H2^2), dmu = Wmu T2 + Vmu H2 + vbmu
 //           u = dmu / sigma^2 / B;   reverse pass with u as the head gradient                  (J^T u)
+//   CRITIC one critic iteration's gradient (npg.py:179-183: mse_loss(returns, V)): GRAD on the critic's vector, whose head
+//         has one column.
+//   INFER forward only: the head's outputs (an actor's mu, a critic's V -- the same 64-64 trunk with one head column) and
+//         log pi(a | s) per sample: the network passes of NPG._preprocess_batch (npg.py:123-138).
 //   EVAL  kl(old || candidate) and the surrogate at up to 32 candidate parameter vectors (npg.py:170-177's kl,
 //         trpo.py:167-191's line search: every backtracking candidate in the same launch, blockIdx.y = candidate):
 //         forward only, per-workgroup partial sums.
@@ -25,7 +29,7 @@
 
 namespace q4 {
 
-enum { NPG_FVP = 0, NPG_GRAD = 1, NPG_EVAL = 2 };
+enum { NPG_FVP = 0, NPG_GRAD = 1, NPG_EVAL = 2, NPG_INFER = 3, NPG_CRITIC = 4 };
 
 struct ActorArgs {
     const float* theta;       // parameters (EVAL: candidate c at theta + c * cand_stride)
@@ -42,6 +46,8 @@ struct ActorArgs {
     float* mu;                // [n_rows][8]: GRAD writes mu(theta), EVAL reads it (the old mean)
     const float* theta_old;   // EVAL: the old parameters (log_sigma)
     int64_t cand_stride;
+    float* logp_out;          // INFER: [n_rows] log pi(actions) or NULL; mu (or NULL) receives the head's first `act` outputs
+    int mu_stride;            //        per row at this stride (a critic: act = 1, stride 1 -> V)
 };
 
 template <int MODE>
@@ -49,10 +55,11 @@ struct LdsA {
     static constexpr int R1 = 0;                                               // sample-major H1; later u / dout and dZ2
     static constexpr int R1T = R1 + 32 * PS;                                   // FVP: sample-major T1 (tangent of H1)
     static constexpr int R2 = R1T + (MODE == NPG_FVP ? 32 * PS : 0);           // feature-major, rows private to the wave
-    static constexpr int R3 = R2 + (MODE == NPG_EVAL ? 0 : HID * PF);          // feature-major H1
-    static constexpr int PP = R3 + (MODE == NPG_EVAL ? 0 : HID * PF);          // head partials
+    static constexpr int R3 = R2 + (MODE == NPG_EVAL || MODE == NPG_INFER ? 0 : HID * PF);          // feature-major H1
+    static constexpr int PP = R3 + (MODE == NPG_EVAL || MODE == NPG_INFER ? 0 : HID * PF);          // head partials
     static constexpr int SM = PP + P_FLOATS;                                   // per-action constants
-    static constexpr int REC = SM + 64;                                        // [2][32][4 K1S] observation tiles
+    static constexpr int BI = SM + 64;                                         // biases [4][64]: b1, b2, (FVP) vb1, vb2
+    static constexpr int REC = BI + 4 * HID;                                   // [2][32][4 K1S] observation tiles
 };
 
 template <int MODE>
@@ -82,7 +89,9 @@ struct SampleIn { float act0[2], act1[2], adv[2], lpo[2], mu0[2], mu1[2]; };
 template <int K1S, int MODE>
 __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
     using L = LdsA<MODE>;
-    constexpr bool FVP = MODE == NPG_FVP, GRAD = MODE == NPG_GRAD, EVAL = MODE == NPG_EVAL;
+    constexpr bool FVP = MODE == NPG_FVP, GRAD = MODE == NPG_GRAD, EVAL = MODE == NPG_EVAL, INFER = MODE == NPG_INFER;
+    constexpr bool CRITIC = MODE == NPG_CRITIC;            // GRAD with the critic's loss: mse_loss(returns, V), one head column
+    constexpr bool FWD = EVAL || INFER;                    // forward only: no reverse pass, no gradient tiles
     constexpr int NB1 = (4 * K1S + 15) / 16;
     constexpr int RW = 4 * K1S;                            // floats per observation record in LDS
     const Slab3 SL = slab3_layout(4 * K1S);
@@ -100,6 +109,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
     [[maybe_unused]] float* R3 = lds + L::R3;
     float* PP = lds + L::PP;
     float* SM = lds + L::SM;
+    float* BIA = lds + L::BI;
     float* REC = lds + L::REC;
     [[maybe_unused]] float* slab = g.slabs + (int64_t)p * g.slab_w;
     const int64_t n_tiles = (g.n_rows + 31) / 32;
@@ -115,8 +125,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
     float WH[4];                                  // Wmu[n][fb + 4 gq + r] (rows >= act: 0)
     [[maybe_unused]] float VH[4];
     [[maybe_unused]] float WHb[2];                // Wmu[4 r + gq][fb + n]
-    f32x4 B1, B2;                                 // biases of the lane's accumulator rows (initial accumulators)
-    [[maybe_unused]] f32x4 VB1, VB2;
+    // (the biases -- initial accumulators of the lane's rows -- come back from LDS every tile: 16 registers fewer)
     {
         TS_Q_LANE();
 #pragma unroll
@@ -124,7 +133,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
             const int f = 16 * (jr >> 2) + 4 * gq + (jr & 3);
             W2f[jr] = th[o2 + f * HID + fb + n];
             if constexpr (FVP) V2f[jr] = dv[o2 + f * HID + fb + n];
-            if constexpr (!EVAL) W2t[jr] = th[o2 + (fb + n) * HID + f];
+            if constexpr (!FWD) W2t[jr] = th[o2 + (fb + n) * HID + f];
         }
 #pragma unroll
         for (int j = 0; j < K1S; ++j) {
@@ -140,18 +149,14 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
         for (int r = 0; r < 4; ++r) {
             const int f = fb + 4 * gq + r;
             const int a = n < n_act ? n : 0;
-            B1[r] = th[o_b1 + f];
-            B2[r] = th[o_b2 + f];
             const float x0 = th[o3 + f * 32 + a];
             WH[r] = n < n_act ? x0 : 0.f;
             if constexpr (FVP) {
-                VB1[r] = dv[o_b1 + f];
-                VB2[r] = dv[o_b2 + f];
                 const float x1 = dv[o3 + f * 32 + a];
                 VH[r] = n < n_act ? x1 : 0.f;
             }
         }
-        if constexpr (!EVAL) {
+        if constexpr (!FWD) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int a = 4 * r + gq;
@@ -159,11 +164,19 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                 WHb[r] = a < n_act ? x0 : 0.f;
             }
         }
+        if (tid < HID) {
+            BIA[tid] = th[o_b1 + tid];
+            BIA[HID + tid] = th[o_b2 + tid];
+            if constexpr (FVP) {
+                BIA[2 * HID + tid] = dv[o_b1 + tid];
+                BIA[3 * HID + tid] = dv[o_b2 + tid];
+            }
+        }
         // per-action constants (torch: sigma = exp(log_sigma); Normal.log_prob uses var = sigma^2 and log(sigma))
         if (tid < 8) {
             const int a = tid;
             const bool live = a < n_act;
-            const float ls = live ? th[o_sig + a] : 0.f;
+            const float ls = (live && !CRITIC && (!INFER || g.actions)) ? th[o_sig + a] : 0.f;    // (a critic's vector has no log_sigma block)
             const float sigma = expf(ls), var = sigma * sigma;
             if constexpr (FVP) {
                 SM[a] = live ? dv[o_bmu + a] : 0.f;                    // vbmu
@@ -187,7 +200,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
 
     // ---- persistent accumulators (MFMA C layout: lane (col n, group gq) register r = row 4 gq + r)
     [[maybe_unused]] f32x4 gW2[4], gW1[NB1];
-    if constexpr (!EVAL) {
+    if constexpr (!FWD) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) gW2[c] = zero4;
 #pragma unroll
@@ -219,10 +232,17 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                     int64_t row = t * 32 + 16 * b + n;
                     row = row < g.n_rows ? row : g.n_rows - 1;
                     const int a0 = gq < n_act ? gq : 0, a1 = 4 + gq < n_act ? 4 + gq : 0;
-                    in.act0[b] = g.actions[row * n_act + a0];
-                    in.act1[b] = g.actions[row * n_act + a1];
-                    in.adv[b] = g.adv[row];
-                    in.lpo[b] = ratio_mode ? g.logp_old[row] : 0.f;
+                    if constexpr (CRITIC) {
+                        in.adv[b] = g.adv[row];                          // the return of the sample
+                    } else if constexpr (INFER) {
+                        in.act0[b] = g.actions ? g.actions[row * n_act + a0] : 0.f;
+                        in.act1[b] = g.actions ? g.actions[row * n_act + a1] : 0.f;
+                    } else {
+                        in.act0[b] = g.actions[row * n_act + a0];
+                        in.act1[b] = g.actions[row * n_act + a1];
+                        in.adv[b] = g.adv[row];
+                        in.lpo[b] = ratio_mode ? g.logp_old[row] : 0.f;
+                    }
                     if constexpr (EVAL) {
                         in.mu0[b] = g.mu[row * ACT_PAD + gq];
                         in.mu1[b] = g.mu[row * ACT_PAD + 4 + gq];
@@ -235,9 +255,10 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) xv[b][j] = RC[(16 * b + n) * RW + 4 * j + gq];
             }
-            f32x4 acc[2] = {B1, B1};
+            f32x4 acc[2];
+            acc[0] = acc[1] = ld4(BIA + fb + 4 * gq);
             [[maybe_unused]] f32x4 tac[2];
-            if constexpr (FVP) { tac[0] = VB1; tac[1] = VB1; }
+            if constexpr (FVP) tac[0] = tac[1] = ld4(BIA + 2 * HID + fb + 4 * gq);
 #pragma unroll
             for (int j = 0; j < K1S; ++j) {
                 acc[0] = mfma16(W1a[j], xv[0][j], acc[0]);
@@ -255,7 +276,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                     dtanh4(tac[b], acc[b]);
                     st4(R1T + (16 * b + n) * PS + fb + 4 * gq, tac[b]);
                 }
-                if constexpr (!EVAL) {
+                if constexpr (!FWD) {
                     h1[b] = acc[b];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) R3[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][r];
@@ -268,9 +289,10 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
         [[maybe_unused]] f32x4 h2[2];
         {
             TS_Q_LANE();
-            f32x4 acc[2] = {B2, B2};
+            f32x4 acc[2];
+            acc[0] = acc[1] = ld4(BIA + HID + fb + 4 * gq);
             [[maybe_unused]] f32x4 tac[2];
-            if constexpr (FVP) { tac[0] = VB2; tac[1] = VB2; }
+            if constexpr (FVP) tac[0] = tac[1] = ld4(BIA + 3 * HID + fb + 4 * gq);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 const f32x4 b0 = ld4(R1 + n * PS + 16 * jj + 4 * gq);
@@ -298,7 +320,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 tanh4(acc[b]);
-                if constexpr (!EVAL) {
+                if constexpr (!FWD) {
                     h2[b] = acc[b];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) R2[(fb + 4 * gq + r) * PF + 16 * b + n] = acc[b][r];   // for the head gradient
@@ -347,6 +369,13 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                     u1[b] = m1 * iv1 * wgt;
                     sD0 += u0[b];
                     sD1 += u1[b];
+                } else if constexpr (CRITIC) {
+                    // npg.py:180: mse_loss(returns, V) -- lane (sample, action 0) holds V
+                    const float td = m0 - in.adv[b];
+                    u0[b] = a0 == 0 ? 2.f * td * wgt : 0.f;
+                    u1[b] = 0.f;
+                    sD0 += u0[b];
+                    sL += (valid && gq == 0) ? td * td : 0.f;
                 } else {
                     const float ls0 = SM[16 + a0], ls1 = SM[16 + a1];
                     const float c0 = a0 < n_act ? LOG_SQRT_2PI : 0.f, c1 = a1 < n_act ? LOG_SQRT_2PI : 0.f;
@@ -354,9 +383,21 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                     // Normal.log_prob summed over the action dimension (padding actions contribute an exact 0)
                     float logp = (-(d0 * d0) * iv0 - ls0 - c0) + (-(d1 * d1) * iv1 - ls1 - c1);
                     logp = group4_sum(logp);
-                    const float ratio = ratio_mode ? expf(logp - in.lpo[b]) : 1.f;
-                    const float term = ratio_mode ? ratio * in.adv[b] : logp * in.adv[b];
-                    if constexpr (GRAD) {
+                    [[maybe_unused]] float ratio = 1.f, term = 0.f;
+                    if constexpr (!INFER) {
+                        ratio = ratio_mode ? expf(logp - in.lpo[b]) : 1.f;
+                        term = ratio_mode ? ratio * in.adv[b] : logp * in.adv[b];
+                    }
+                    if constexpr (INFER) {
+                        if (valid && w == 0) {
+                            const int64_t row = t * 32 + s;
+                            if (g.mu) {
+                                if (a0 < n_act) g.mu[row * g.mu_stride + a0] = m0;
+                                if (a1 < n_act) g.mu[row * g.mu_stride + a1] = m1;
+                            }
+                            if (g.logp_out && gq == 0) g.logp_out[row] = logp;
+                        }
+                    } else if constexpr (GRAD) {
                         const float dlogp = -in.adv[b] * ratio * wgt;
                         const float v0 = SM[24 + a0], v1 = SM[24 + a1];
                         u0[b] = dlogp * d0 * v0;
@@ -378,12 +419,12 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
                         sD1 += (valid && gq == 0 && ratio_mode) ? term : 0.f;             // one lane per sample
                     }
                 }
-                if constexpr (!EVAL) {
+                if constexpr (!FWD) {
                     R1[s * PS + fb + a0] = u0[b];        // sample-major, own columns (A operand of the head gradient)
                     R1[s * PS + fb + a1] = u1[b];
                 }
             }
-            if constexpr (!EVAL) {
+            if constexpr (!FWD) {
                 f32x4 dz2[2];
                 wave_lds_sync();
                 {
@@ -423,7 +464,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
         __syncthreads();                                 // B3: dZ2 (sample-major) complete   (EVAL: B0 of the next tile)
 
         // ================= phase 4: dZ1, weight gradients
-        if constexpr (!EVAL) {
+        if constexpr (!FWD) {
             TS_Q_LANE();
             f32x4 acc[2] = {zero4, zero4};
 #pragma unroll
@@ -484,7 +525,8 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
 
     // ---- epilogue: the workgroup's sums leave once
     TS_Q_LANE();
-    if constexpr (EVAL) {
+    if constexpr (INFER) {
+    } else if constexpr (EVAL) {
         // every wave sees every sample: wave 0's sums are the workgroup's (fixed order: 16 lanes of a row on DPP, then the
         // four rows)
         sD0 = group4_sum(row16_sum(sD0));
@@ -513,7 +555,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
             slab_st(slab + SL.hb[0] + gq, sD0);
             slab_st(slab + SL.hb[0] + 4 + gq, sD1);
         }
-        if constexpr (GRAD) {
+        if constexpr (GRAD || CRITIC) {
             // every wave sees every sample: the log_sigma and loss sums come from wave 0 alone
             sS0 = row16_sum(sS0);
             sS1 = row16_sum(sS1);
@@ -529,7 +571,7 @@ __device__ __forceinline__ void actor_run(const ActorArgs& g, float* lds) {
 #undef TS_Q_LANE
 
 template <int K1S>
-__global__ __launch_bounds__(QT, 2) void npg_fvp_kernel(ActorArgs g) {
+__global__ __launch_bounds__(QT, 3) void npg_fvp_kernel(ActorArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     actor_run<K1S, NPG_FVP>(g, lds);
 }
@@ -541,18 +583,31 @@ __global__ __launch_bounds__(QT, 3) void npg_grad_kernel(ActorArgs g) {
 }
 
 template <int K1S>
+__global__ __launch_bounds__(QT, 3) void npg_critic_kernel(ActorArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    actor_run<K1S, NPG_CRITIC>(g, lds);
+}
+
+template <int K1S>
 __global__ __launch_bounds__(QT, 4) void npg_eval_kernel(ActorArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     actor_run<K1S, NPG_EVAL>(g, lds);
 }
 
+template <int K1S>
+__global__ __launch_bounds__(QT, 4) void npg_infer_kernel(ActorArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    actor_run<K1S, NPG_INFER>(g, lds);
+}
+
 // out[i] = sum over slabs of the column that holds parameter i (fixed order).  One workgroup = 64 parameters x 16 slab
 // groups.  v != NULL (FVP): + damping v[i], and the log-sigma block gets the exact 2 v_s of the KL's Hessian (ts_npg.hip:
-// fvp_finish_kernel).  v == NULL (GRAD): the log-sigma block takes its slab columns and loss_out[0] = -(loss sum) / B.
+// fvp_finish_kernel).  v == NULL (GRAD / CRITIC): the log-sigma block (if P holds one) takes its slab columns and
+// loss_out[0] = loss_sign (loss sum) / B.
 __global__ __launch_bounds__(1024) void npg_actor_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int slab_w, int obs,
                                                                 int act, int k0, int k1, const float* __restrict__ v,
                                                                 float* __restrict__ out, int P, float damping,
-                                                                float* __restrict__ loss_out, float n_rows) {
+                                                                float* __restrict__ loss_out, float n_rows, float loss_sign) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
@@ -593,7 +648,7 @@ __global__ __launch_bounds__(1024) void npg_actor_reduce_kernel(const float* __r
             }
         } else {
             if (i < P) out[i] = t;
-            else if (i == P) loss_out[0] = -(t / n_rows);
+            else if (i == P) loss_out[0] = loss_sign * (t / n_rows);
         }
     }
 }

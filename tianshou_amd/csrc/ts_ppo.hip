@@ -1649,11 +1649,11 @@ int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const flo
     g.theta = theta; g.dir = v; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
     g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
     g.obs = obs; g.act = act; g.k0 = k0;
-    const int grid = npg_grid(B, 2);
+    const int grid = npg_grid(B, 3);
     TS_NPG_DISPATCH(npg_fvp_kernel, q4::NPG_FVP, dim3(grid))
     const int P = npg_param_count(k0);
     hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w, obs,
-                       act, k0, 4 * k1s, v, out, P, damping, (float*)nullptr, (float)B);
+                       act, k0, 4 * k1s, v, out, P, damping, (float*)nullptr, (float)B, 0.f);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -1674,7 +1674,26 @@ int npg_grad_fused(hipStream_t s, ts_workspace* ws, const float* theta, const fl
     TS_NPG_DISPATCH(npg_grad_kernel, q4::NPG_GRAD, dim3(grid))
     const int P = npg_param_count(k0);
     hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 1 + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w,
-                       obs, act, k0, 4 * k1s, (const float*)nullptr, grad, P, 0.f, loss_out, (float)B);
+                       obs, act, k0, 4 * k1s, (const float*)nullptr, grad, P, 0.f, loss_out, (float)B, -1.f);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+// grad = d mse_loss(returns, V) / d critic (block layout without a log_sigma block), loss_out[0] = the loss
+int npg_critic_grad_fused(hipStream_t s, ts_workspace* ws, const float* critic, const float* x, const float* returns, int obs,
+                          int k0, int64_t B, float* slabs, float* grad, float* loss_out) {
+    const int k1s = q4::k1s_for(obs);
+    TS_REQUIRE(k1s > 0 && B >= 1, TS_ERR_UNSUPPORTED, "npg_critic_grad_fused: unsupported shape");
+    q4::ActorArgs g{};
+    g.theta = critic; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
+    g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
+    g.obs = obs; g.act = 1; g.k0 = k0;
+    g.adv = returns;
+    const int grid = npg_grid(B, 3);
+    TS_NPG_DISPATCH(npg_critic_kernel, q4::NPG_CRITIC, dim3(grid))
+    const int P = npg_param_count(k0) - 32;
+    hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 1 + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w,
+                       obs, 1, k0, 4 * k1s, (const float*)nullptr, grad, P, 0.f, loss_out, (float)B, 1.f);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -1695,6 +1714,20 @@ int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, cons
     TS_NPG_DISPATCH(npg_eval_kernel, q4::NPG_EVAL, dim3(grid, n_cand))
     hipLaunchKernelGGL(q4::npg_eval_finish_kernel, dim3(n_cand), dim3(256), 0, s, partial, grid, (float)B, res);
     TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+// forward pass on B rows: head_out[row * head_stride + a] = the head's output a < act (NULL: skipped), logp_out[row] =
+// log pi(actions[row]) (NULL: skipped; needs actions and an actor's vector).  A critic: act = 1, head_stride = 1.
+int npg_infer_fused(hipStream_t s, ts_workspace* ws, const float* theta, const float* x, const float* actions, int obs, int k0,
+                    int act, int64_t B, float* head_out, int head_stride, float* logp_out) {
+    const int k1s = q4::k1s_for(obs);
+    TS_REQUIRE(k1s > 0 && B >= 1 && (!logp_out || actions), TS_ERR_UNSUPPORTED, "npg_infer_fused: unsupported shape");
+    q4::ActorArgs g{};
+    g.theta = theta; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
+    g.obs = obs; g.act = act; g.k0 = k0;
+    g.actions = logp_out ? actions : nullptr; g.mu = head_out; g.mu_stride = head_stride; g.logp_out = logp_out;
+    const int grid = npg_eval_grid(B, 1);
+    TS_NPG_DISPATCH(npg_infer_kernel, q4::NPG_INFER, dim3(grid))
     return TS_OK;
 }
 #undef TS_NPG_DISPATCH

@@ -127,71 +127,28 @@ class NPGEngine:
         self.adam_step = 0
         self.ret_rms = [0.0, 1.0, 0.0]
         self._ws = _lib.default_workspace(self.device.index or 0)
-        self._fused = None               # (PPOEngine for the critic iterations, positions, indices, scratch)
 
     def _dims(self):
         return _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.i64(self.act_dim)
 
-    # -- the critic iterations of a minibatch on the fused actor-critic step kernel ------------------------------------------
-    def critic_fused_supported(self) -> bool:
-        """Net[64, 64], obs_dim <= 31, act_dim <= 8 (ts_ppo.hip's shapes); TS_NPG_CRITIC_GEMM=1 keeps ts_npg_critic_step
-        (read per call)."""
-        from . import ppo as P
-
-        return (self.hidden == P.HIDDEN and self.obs_dim <= 31 and self.act_dim <= 8
-                and not os.environ.get("TS_NPG_CRITIC_GEMM"))
-
-    def _critic_fused(self):
-        """The critic iterations (npg.py:179-183: mse_loss(returns, V) + Optimizer.step, optim_critic_iters times on the same
-        minibatch) are A2C steps with a zero advantage: with adv = 0 and ent_coef = 0 the actor half of the fused step kernel
-        (ts_ppo.hip, algo a2c, vf_coef 1) receives an exactly zero gradient and a zero actor beside the real critic never
-        moves.  One call runs all iterations (an identity permutation per iteration); the critic and its Adam moments are
-        copied between the two flat layouts around it (one indexed copy per vector)."""
-        if self._fused is None:
-            from . import ppo as P
-
-            cfg = self.cfg
-            pc = P.PPOConfig(algo="a2c", vf_coef=1.0, ent_coef=0.0, advantage_normalization=False,
-                             max_grad_norm=cfg.max_grad_norm, lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps,
-                             nets=0 if os.environ.get("TS_NPG_BOTH_NETS") else 2)              # 2: the critic's half of the step only
-            eng = P.PPOEngine(self.obs_dim, self.act_dim, torch.zeros(P.param_count(self.obs_dim, self.act_dim), device=self.device), pc)
-            shapes = P.param_shapes(self.obs_dim, self.act_dim)
-            off = sum(int(np.prod(shapes[k])) for k in P.PARAM_ORDER[:7])          # the critic's tensors follow the actor's
-            t = []
-            for k in P.PARAM_ORDER[7:]:
-                n = int(np.prod(shapes[k]))
-                t.append((torch.arange(off, off + n, dtype=torch.float32) + 1.0).reshape(shapes[k]))
-                off += n
-            marks = critic_flat_from_torch(t, self.obs_dim, self.hidden, device="cpu")
-            pos = torch.nonzero(marks > 0).reshape(-1)
-            self._fused = (eng, pos.to(self.device), (marks[pos] - 1.0).long().to(self.device), {})
-        return self._fused
-
+    # -- the critic iterations of a minibatch --------------------------------------------------------------------------------
     def critic_steps(self, obs, returns, iters: int) -> torch.Tensor:
-        """`iters` critic iterations on one minibatch -> the last vf_loss float32[1]."""
-        if not self.critic_fused_supported():
-            vf = None
-            for _ in range(iters):
-                vf = self.critic_step(obs, returns)
-            return vf
-        eng, pos, idx, cache = self._critic_fused()
+        """`iters` critic iterations on one minibatch (npg.py:179-183) in one library call -> the last vf_loss float32[1].
+        Net[64, 64] with obs_dim <= 32: one kernel + one small sum per gradient (csrc/ts_npg_q.h; TS_NPG_FVP=0 keeps the
+        per-layer GEMM passes)."""
         obs = self._f32(obs).reshape(-1, self.obs_dim)
-        n = obs.shape[0]
-        returns = self._f32(returns, (n,))
-        for src, dst in ((self.critic, eng.params), (self.critic_m, eng.adam_m), (self.critic_v, eng.adam_v)):
-            dst[idx] = src[pos]
-        eng.adam_step, eng.cfg.lr = self.adam_step, self.cfg.lr
-        if cache.get("n") != n:
-            cache.update(n=n, zeros=torch.zeros(n, dtype=torch.float32, device=self.device),
-                         act=torch.zeros((n, self.act_dim), dtype=torch.float32, device=self.device),
-                         perm=torch.arange(n, dtype=torch.int64, device=self.device))
-        z = cache["zeros"]
-        b = {"obs": obs, "act": cache["act"], "adv": z, "returns": returns, "logp_old": z, "v_s": z}
-        losses, _ = eng.update(b, None, iters, [cache["perm"]] * iters)[:2]
-        for dst, src in ((self.critic, eng.params), (self.critic_m, eng.adam_m), (self.critic_v, eng.adam_v)):
-            dst[pos] = src[idx]
-        self.adam_step = eng.adam_step
-        return losses[-1, 2:3]
+        b = obs.shape[0]
+        returns = self._f32(returns, (b,))
+        cfg = self.cfg
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_npg_critic_steps(
+            self._ws.handle, _lib.ptr(self.critic), _lib.ptr(self.critic_m), _lib.ptr(self.critic_v),
+            _lib.i64(self.adam_step + 1), _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.ptr(obs), _lib.ptr(returns),
+            _lib.i64(b), _lib.i64(iters), _lib.f64(cfg.lr), _lib.f64(cfg.betas[0]), _lib.f64(cfg.betas[1]),
+            _lib.f64(cfg.adam_eps), _lib.f64(cfg.max_grad_norm or 0.0), _lib.ptr(loss), _lib.ptr(None),
+            _lib.current_stream(self.device)))
+        self.adam_step += iters
+        return loss
 
     def _f32(self, x, shape=None) -> torch.Tensor:
         t = torch.as_tensor(x, device=self.device).to(torch.float32).contiguous()
