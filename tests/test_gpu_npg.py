@@ -174,11 +174,16 @@ def test_critic_step_vs_oracle(obs_dim, B, path, monkeypatch):
         pc64 = {k: p64[k].clone().requires_grad_(True) for k in C_KEYS}
         vf64 = torch.nn.functional.mse_loss(ret.double(), OP.critic_forward({**p64, **pc64}, obs.double()).flatten())
         gs64 = dict(zip(C_KEYS, torch.autograd.grad(vf64, [pc64[k] for k in C_KEYS])))
-        # (40,000 samples: the head bias gradient is a mean of 40,000 terms of magnitude ~4 that cancels to ~1e-3 -- float32
-        # sums of that length are good to ~2e-5 of the result in any order)
-        bar = 1e-5 if B <= 10000 else 3e-5
+        # (40,000 samples: the head bias gradient is a mean of 40,000 terms of magnitude ~4 that cancels to ~1e-3: 4e-5 of it
+        # is 0.1 ulp of a mean term.  The head bias gradient is also accepted within eps32 * mean |term|: the forward error
+        # bound of a float32 tree summation is log2(n) times that)
+        with torch.no_grad():
+            mean_abs_term = float((2 * (OP.critic_forward(p64, obs.double()).flatten() - ret.double())).abs().mean())
         for t, k in zip(NG.critic_flat_to_torch(grad, obs_dim, 64), C_KEYS):
-            assert rel_err(t.cpu(), gs64[k]) < max(bar, 2 * rel_err(gs[k], gs64[k])), k
+            ok = rel_err(t.cpu(), gs64[k]) < max(1e-5, 2 * rel_err(gs[k], gs64[k]))
+            if k == "c_bv":
+                ok = ok or abs(float(t.cpu().reshape(-1)[0]) - float(gs64[k].reshape(-1)[0])) < 1.19e-7 * mean_abs_term
+            assert ok, k
         ON._critic_adam(st, cfg, gs)
         eng.critic_step(obs, ret)
         for t, k in zip(NG.critic_flat_to_torch(eng.critic, obs_dim, 64), C_KEYS):

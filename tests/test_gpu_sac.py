@@ -270,6 +270,37 @@ def test_phased_update_is_bit_identical(auto, weighted):
     assert eng_a.adam_step == eng_b.adam_step == 3
 
 
+@pytest.mark.parametrize("obs_dim,act_dim,B", [(376, 17, 4096), (23, 5, 300)])
+def test_one_launch_slab_sums_and_adam_are_bit_identical(obs_dim, act_dim, B, monkeypatch):
+    """slab_adam_kernel (weight-gradient slab sums + Adam + Polyak of both critics in one launch; the actor's + the alpha step
+    in another) == the separate slab_sum_multi / adam / alpha launches (TS_SAC_SPLIT_ADAM=1), bit for bit, over three
+    updates: parameters, moments, lagged critics, log_alpha, stats and PER weights."""
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.3, target_entropy=-float(act_dim), tau=0.01)
+    out = {}
+    for split in ("", "1"):
+        if split:
+            monkeypatch.setenv("TS_SAC_SPLIT_ADAM", "1")
+        else:
+            monkeypatch.delenv("TS_SAC_SPLIT_ADAM", raising=False)
+        eng, _ = make_engine(obs_dim, act_dim, 5, cfg)
+        g = torch.Generator().manual_seed(3)
+        stats = []
+        for _ in range(3):
+            obs = torch.randn(B, obs_dim, generator=g).cuda()
+            act = (torch.rand(B, act_dim, generator=g) * 2 - 1).cuda()
+            ret = (torch.randn(B, generator=g) * 2).cuda()
+            noise = torch.randn(B, act_dim, generator=g).cuda()
+            weight = torch.rand(B, generator=g).cuda()
+            stats.append(eng.update_with_batch(obs, act, ret, noise, weight))
+        out[split] = (eng, stats)
+    (ea, sa), (eb, sb) = out[""], out["1"]
+    for (s_a, w_a), (s_b, w_b) in zip(sa, sb):
+        assert torch.equal(s_a, s_b) and torch.equal(w_a, w_b)
+    for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old", "actor_m", "actor_v", "critic1_m",
+                 "critic1_v", "critic2_m", "critic2_v", "log_alpha", "log_alpha_m", "log_alpha_v"):
+        assert torch.equal(getattr(ea, name), getattr(eb, name)), name
+
+
 @pytest.mark.parametrize("auto,weighted", [(True, True), (False, False)])
 def test_row_indexed_entry_points_are_bit_identical(auto, weighted):
     """ts_sac_returns_rows (gather of obs_next inside the input packing + _target_q + the 1-step return in one launch

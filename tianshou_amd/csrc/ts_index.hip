@@ -427,12 +427,17 @@ __device__ __forceinline__ void philox10(uint32_t (&c)[4], uint64_t seed) {
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+__device__ __forceinline__ double uniform53_of(uint32_t w0, uint32_t w1) {
+    const uint32_t a = w0 >> 5, b = w1 >> 6;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
 __device__ __forceinline__ double uniform53(uint64_t seed, uint64_t stream, int64_t index, int which) {
     uint32_t c[4] = {(uint32_t)index, (uint32_t)((uint64_t)index >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
     philox10(c, seed);
-    const uint32_t a = c[2 * which] >> 5, b = c[2 * which + 1] >> 6;
-    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+    return uniform53_of(c[2 * which], c[2 * which + 1]);
 }
+
+constexpr int SAMPLE_STAGED_E = 512;      // lengths / offsets of up to this many sub-buffers are staged in LDS
 
 __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __restrict__ offset, int64_t E,
                                                              const int64_t* __restrict__ lengths,
@@ -443,37 +448,86 @@ __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __re
                                                              uint64_t seed = 0, uint64_t stream = 0) {
     __shared__ double cdf[SAMPLE_MAX_E];
     __shared__ int count[SAMPLE_MAX_E + 1];
-    const int tid = threadIdx.x;
+    __shared__ int64_t len_s[SAMPLE_STAGED_E], off_s[SAMPLE_STAGED_E];
+    __shared__ int64_t wsum[16];
+    __shared__ int wave_count[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool staged = E <= SAMPLE_STAGED_E;           // the output loop reads lengths / offsets from LDS
+    // total = lengths.sum(): exact in any order (integers) -- every thread its strided share, wave shuffles, 16 wave sums
+    int64_t part = 0;
+    for (int e = tid; e < E; e += 1024) {
+        const int64_t l = lengths[e];
+        part += l;
+        if (staged) { len_s[e] = l; off_s[e] = offset[e]; }
+    }
     for (int e = tid; e <= E; e += 1024) count[e] = 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    int64_t total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) total += wsum[w];
+    // p = lengths / total in parallel; p.cumsum() by ONE thread in NumPy's order (sequential float64 adds: the rounding of
+    // a parallel scan would differ); cdf /= cdf[-1] in parallel.  (The serial pass used to load lengths[e] from global
+    // memory inside its loop: 160 ns per sub-buffer, 80 us at 512 sub-buffers.)
+    for (int e = tid; e < E; e += 1024) cdf[e] = (double)(staged ? len_s[e] : lengths[e]) / (double)total;
+    __syncthreads();
     if (tid == 0) {
-        int64_t total = 0;
-        for (int64_t e = 0; e < E; ++e) total += lengths[e];
         double acc = 0.0;
-        for (int64_t e = 0; e < E; ++e) { acc += (double)lengths[e] / (double)total; cdf[e] = acc; }   // p.cumsum()
-        const double last = cdf[E - 1];
-        for (int64_t e = 0; e < E; ++e) cdf[e] /= last;                                               // cdf /= cdf[-1]
+        for (int64_t e = 0; e < E; ++e) { acc += cdf[e]; cdf[e] = acc; }
         if (total <= 0) *err = 1;
     }
     __syncthreads();
-    // Histogram of the draws over the sub-buffers.  Few sub-buffers (<= 64): one ballot per sub-buffer and wave and ONE LDS
-    // atomic per (wave, sub-buffer) -- 4,096 draws on 16 counters otherwise serialise on the same 16 addresses (8 of this
-    // kernel's 11 us at the C5 batch); many sub-buffers: one atomic per draw, contention is low there.
+    const double last = cdf[E - 1];
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) cdf[e] /= last;
+    __syncthreads();
+    // Histogram of the draws over the sub-buffers.  Few sub-buffers (<= 64): lane e of every wave counts the wave's draws of
+    // sub-buffer e in a register (one ballot per sub-buffer), the 16 waves' counts meet in LDS once at the end -- LDS
+    // atomics on 16 counters serialise on their addresses (11 of this kernel's 19 us at the C5 batch); many sub-buffers:
+    // one atomic per draw, contention is low there.
     const bool few = E <= 64;
-    for (int64_t k0 = 0; k0 < bs; k0 += 1024) {
-        const int64_t k = k0 + tid;
-        int lo = -1;
-        if (k < bs) {
-            const double u = u_buffer ? u_buffer[k] : uniform53(seed, stream, k, 0);      // NULL: the engine's own draws
-            int l = 0, hi = (int)E;                    // first e with cdf[e] > u  (searchsorted side="right")
-            while (l < hi) { const int mid = (l + hi) >> 1; if (cdf[mid] <= u) l = mid + 1; else hi = mid; }
-            lo = l >= (int)E ? (int)E - 1 : l;
-            if (!few) atomicAdd(&count[lo], 1);
-        }
-        if (few) {
-            for (int e = 0; e < (int)E; ++e) {
-                const unsigned long long m = __ballot(lo == e);
-                if ((tid & 63) == 0 && m) atomicAdd(&count[e], __popcll(m));
+    int mine = 0;
+    // the engine's own draws: one Philox block per index holds both of its uniforms (words 0-1: the sub-buffer draw, words
+    // 2-3: the within-buffer draw of output position k) -- the first four rounds' second halves are kept for the output loop
+    uint32_t keep[4][2] = {};
+    for (int64_t k0 = 0; k0 < bs; k0 += 4096) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                  // (compile-time q: `keep` stays in registers)
+            if (k0 + 1024 * q >= bs) break;            // uniform
+            const int64_t k = k0 + 1024 * q + tid;
+            int lo = -1;
+            if (k < bs) {
+                double u;
+                if (u_buffer) u = u_buffer[k];
+                else {
+                    uint32_t c[4] = {(uint32_t)k, (uint32_t)((uint64_t)k >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+                    philox10(c, seed);
+                    u = uniform53_of(c[0], c[1]);
+                    if (k0 == 0) { keep[q][0] = c[2]; keep[q][1] = c[3]; }
+                }
+                int l = 0, hi = (int)E;                // first e with cdf[e] > u  (searchsorted side="right")
+                while (l < hi) { const int mid = (l + hi) >> 1; if (cdf[mid] <= u) l = mid + 1; else hi = mid; }
+                lo = l >= (int)E ? (int)E - 1 : l;
+                if (!few) atomicAdd(&count[lo], 1);
             }
+            if (few) {
+                for (int e = 0; e < (int)E; ++e) {
+                    const unsigned long long m = __ballot(lo == e);
+                    mine += lane == e ? __popcll(m) : 0;
+                }
+            }
+        }
+    }
+    if (few) {
+        wave_count[wave][lane] = mine;
+        __syncthreads();
+        if (tid < E) {
+            int c = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) c += wave_count[w][tid];
+            count[tid] = c;
         }
     }
     __syncthreads();
@@ -482,15 +536,40 @@ __global__ __launch_bounds__(1024) void sample_random_kernel(const int64_t* __re
         for (int64_t e = 0; e <= E; ++e) { const int c = count[e]; count[e] = run; run += c; }
     }
     __syncthreads();
-    for (int64_t j = tid; j < bs; j += 1024) {
-        int lo = 0, hi = (int)E;                       // last e with start[e] <= j
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (count[mid] <= (int)j) lo = mid; else hi = mid; }
-        const int64_t len = lengths[lo];
-        int64_t slot;
-        if (within_i) slot = within_i[j];
-        else { slot = (int64_t)((within_u ? within_u[j] : uniform53(seed, stream, j, 1)) * (double)len); if (slot >= len) slot = len - 1; }
-        if (slot < 0 || slot >= len) *err = 2;
-        out[j] = offset[lo] + slot;
+    // four outputs per thread and round: the sub-buffer searches first, then the four draws' loads side by side
+    for (int64_t j0 = 0; j0 < bs; j0 += 4096) {
+        int los[4];
+        int64_t lens[4], offs[4], wi[4];
+        double wu[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + 1024 * q + tid;
+            int lo = 0, hi = (int)E;                   // last e with start[e] <= j
+            if (j < bs)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (count[mid] <= (int)j) lo = mid; else hi = mid; }
+            los[q] = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + 1024 * q + tid;
+            const int64_t jc = j < bs ? j : bs - 1;
+            lens[q] = staged ? len_s[los[q]] : lengths[los[q]];
+            offs[q] = staged ? off_s[los[q]] : offset[los[q]];
+            wi[q] = within_i ? within_i[jc] : 0;
+            wu[q] = within_i ? 0.0 : (within_u ? within_u[jc] : (j0 == 0 && !u_buffer ? uniform53_of(keep[q][0], keep[q][1])
+                                                                                      : uniform53(seed, stream, jc, 1)));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + 1024 * q + tid;
+            if (j >= bs) continue;
+            const int64_t len = lens[q];
+            int64_t slot;
+            if (within_i) slot = wi[q];
+            else { slot = (int64_t)(wu[q] * (double)len); if (slot >= len) slot = len - 1; }
+            if (slot < 0 || slot >= len) *err = 2;
+            out[j] = offs[q] + slot;
+        }
     }
 }
 

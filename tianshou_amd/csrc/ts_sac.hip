@@ -244,23 +244,31 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__
     const int j = (int)(i - b * w4) * 4;
     const int64_t src = rows ? rows[b] : b;
     const float* ob = obs + src * obs_dim;
+    // observation rows of 4 k floats from a 16-byte aligned base: whole 16-byte groups
+    const bool vec = (obs_dim & 3) == 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0;
     if (j < ka) {
         if (!x_a) return;
         f32x4 v;
+        if (vec && j + 4 <= obs_dim) v = *reinterpret_cast<const f32x4*>(ob + j);
+        else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = j + t < obs_dim ? ob[j + t] : 0.f;
+            for (int t = 0; t < 4; ++t) v[t] = j + t < obs_dim ? ob[j + t] : 0.f;
+        }
         *reinterpret_cast<f32x4*>(x_a + b * ka + j) = v;
     } else if (x_c) {
         const int k = j - ka;
         f32x4 v, vp;
+        if (vec && k + 4 <= obs_dim) v = vp = *reinterpret_cast<const f32x4*>(ob + k);
+        else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int c = k + t;
-            float e = 0.f;
-            if (c < obs_dim) e = ob[c];
-            vp[t] = e;
-            if (c >= obs_dim && c < obs_dim + act_dim && act) e = act[src * act_dim + c - obs_dim];
-            v[t] = e;
+            for (int t = 0; t < 4; ++t) {
+                const int c = k + t;
+                float e = 0.f;
+                if (c < obs_dim) e = ob[c];
+                vp[t] = e;
+                if (c >= obs_dim && c < obs_dim + act_dim && act) e = act[src * act_dim + c - obs_dim];
+                v[t] = e;
+            }
         }
         *reinterpret_cast<f32x4*>(x_c + b * kc + k) = v;
         if (x_p) *reinterpret_cast<f32x4*>(x_p + b * kc + k) = vp;
@@ -493,19 +501,38 @@ struct AlphaArgs {
     float* losses; int n_part;       // -> losses[0 .. 2] (nullable loss_part: already finished by the phases)
 };
 
-__global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
-    __shared__ float red[1024];
-    float s = 0.f;
-    for (int64_t b = threadIdx.x; b < a.B; b += 1024) {
-        s += a.logp[b];
-        if (a.weight_out) a.weight_out[b] = (a.td1[b] + a.td2[b]) / 2.f;
+// NT = 1024 threads, or 256 threads that each play four of the 1024 (thread t: t, t + 256, t + 512, t + 768 -- whole waves
+// map to whole waves, so the butterfly sums and the order of the sixteen wave sums are those of the 1024-thread form)
+template <int NT>
+__device__ __forceinline__ void sac_alpha_body(const AlphaArgs& a, float* red) {     // red[16]
+    constexpr int J = 1024 / NT;
+    float s[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        s[j] = 0.f;
+        for (int64_t b = threadIdx.x + NT * j; b < a.B; b += 1024) {
+            s[j] += a.logp[b];
+            if (a.weight_out) a.weight_out[b] = (a.td1[b] + a.td2[b]) / 2.f;
+        }
     }
     // the three loss means: threads 64, 128, 192 (one per wave, beside the log-prob loads), same sequential sums as loss_finish
     if (a.loss_part && (threadIdx.x == 64 || threadIdx.x == 128 || threadIdx.x == 192)) {
         const int k = (threadIdx.x >> 6) - 1;
         a.losses[k] = loss_finish(a.loss_part + k * a.n_part, a.n_part, a.B);
     }
-    const float tot = block_sum_1024(s, red);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[j] += __shfl_xor(s[j], o, 64);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+        if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) + (NT / 64) * j] = s[j];
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
     if (threadIdx.x != 0) return;
     if (!a.log_alpha) { *a.alpha_out = a.fixed_alpha; *a.alpha_loss = 0.f; return; }
     // mean entropy deficit = mean(target - (-log_prob)); written so that the single-call and the phased update
@@ -521,6 +548,129 @@ __global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
     const float nla = la + (-a.lr_step * m) / denom;
     *a.log_alpha = nla; *a.m = m; *a.v = v;
     *a.alpha_out = expf(nla);
+}
+
+__global__ __launch_bounds__(1024) void sac_alpha_kernel(AlphaArgs a) {
+    __shared__ float red[16];
+    sac_alpha_body<1024>(a, red);
+}
+
+// Weight-gradient slab sums + Adam (+ Polyak of the lagged copy) of up to two networks' three layers in ONE launch, and
+// optionally the alpha step as one more workgroup: per element the operations of ts::slab_sum_multi (same slab order, same
+// tree), ts_optim.hip's adam_multi_kernel and sac_alpha_kernel -- bit-identical to the three launches it replaces.
+// Workgroups of 256 threads = slab_sum_multi's (many short workgroups in flight hide the Adam tail that only 16 of a
+// workgroup's threads run); the alpha workgroup plays its 1024-thread form on 256.
+constexpr int SLAB_ADAM_SEGS = 6;
+struct SlabAdamArgs {
+    const float* slabs[SLAB_ADAM_SEGS]; int64_t n[SLAB_ADAM_SEGS]; int nslab[SLAB_ADAM_SEGS];
+    float* grad[SLAB_ADAM_SEGS]; float* p[SLAB_ADAM_SEGS]; float* m[SLAB_ADAM_SEGS]; float* v[SLAB_ADAM_SEGS];
+    float* tgt[SLAB_ADAM_SEGS];
+    unsigned first_vb[SLAB_ADAM_SEGS + 1];
+    float lr_step, beta1, beta2, bc2_sqrt, eps, omb1, omb2, tau, one_minus_tau;
+};
+
+template <bool ALPHA>
+__global__ __launch_bounds__(256) void slab_adam_kernel(SlabAdamArgs a, AlphaArgs al) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    __shared__ f32x4 red[256];
+    if (ALPHA && blockIdx.x == 0) {               // the longest workgroup (a serial pass over the batch) starts first
+        sac_alpha_body<256>(al, reinterpret_cast<float*>(red));
+        return;
+    }
+    const int t = threadIdx.x;
+    const unsigned vb = blockIdx.x - (ALPHA ? 1 : 0);
+    int sg = 0;
+#pragma unroll
+    for (int k = 1; k < SLAB_ADAM_SEGS; ++k) sg += vb >= a.first_vb[k] ? 1 : 0;
+    const float* __restrict__ slabs = a.slabs[sg];
+    const int64_t n = a.n[sg];
+    const int nslab = a.nslab[sg];
+    const int col = t & 15, part = t >> 4;
+    const int64_t i = ((int64_t)(vb - a.first_vb[sg]) * 16 + col) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    f32x4 p4 = s, m4 = s, v4 = s, t4 = s;
+    const bool owner = part == 0 && i < n;                    // the Adam operands of the chunk: in flight beside the slab loads
+    if (owner) {
+        p4 = *reinterpret_cast<const f32x4*>(a.p[sg] + i);
+        m4 = *reinterpret_cast<const f32x4*>(a.m[sg] + i);
+        v4 = *reinterpret_cast<const f32x4*>(a.v[sg] + i);
+        if (a.tgt[sg]) t4 = *reinterpret_cast<const f32x4*>(a.tgt[sg] + i);
+    }
+    if (i < n)
+        for (int k = part; k < nslab; k += 16) s += *reinterpret_cast<const f32x4*>(slabs + (int64_t)k * n + i);
+    red[threadIdx.x] = s;
+    __syncthreads();
+#pragma unroll
+    for (int st = 8; st > 0; st >>= 1) {
+        if (part < st) red[threadIdx.x] += red[threadIdx.x + 16 * st];
+        __syncthreads();
+    }
+    if (!owner) return;
+    const f32x4 g4 = red[threadIdx.x];
+    *reinterpret_cast<f32x4*>(a.grad[sg] + i) = g4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float gq = g4[e];
+        float m = m4[e], v = v4[e];
+        m = m + (gq - m) * a.omb1;                           // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * a.beta2 + a.omb2 * gq * gq;                  // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+        const float pn = p4[e] + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        p4[e] = pn; m4[e] = m; v4[e] = v;
+        t4[e] = a.tau * pn + a.one_minus_tau * t4[e];        // lagged_network.py:17-18
+    }
+    *reinterpret_cast<f32x4*>(a.p[sg] + i) = p4;
+    *reinterpret_cast<f32x4*>(a.m[sg] + i) = m4;
+    *reinterpret_cast<f32x4*>(a.v[sg] + i) = v4;
+    if (a.tgt[sg]) *reinterpret_cast<f32x4*>(a.tgt[sg] + i) = t4;
+}
+
+// mlp_weight_grads + the Adam step (+ Polyak, + alpha) behind it: the 3 n weight-gradient GEMMs in one launch, then
+// slab_adam_kernel.  p / m / v / lag: the n networks' flat vectors (lag nullable); alpha (nullable): the alpha step rides along.
+struct AdamSpec { int64_t step; double lr, beta1, beta2, eps, tau; };
+int mlp_weight_grads_adam(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const float* const* x, const Act* a,
+                          const float* const* d_out, float* const* grad, const BwdScratch* sc, float* const* p, float* const* pm,
+                          float* const* pv, float* const* lag, const AdamSpec& sp, const AlphaArgs* alpha) {
+    TS_REQUIRE(n >= 1 && 3 * n <= SLAB_ADAM_SEGS, TS_ERR_INVALID_ARG, "mlp_weight_grads_adam: 1 .. 2 networks");
+    ts::ConvGeom geoms[SLAB_ADAM_SEGS];
+    const float* X[SLAB_ADAM_SEGS];
+    const float* dY[SLAB_ADAM_SEGS];
+    float* slabs[SLAB_ADAM_SEGS];
+    SlabAdamArgs g{};
+    unsigned vbs = 0;
+    for (int j = 0; j < SLAB_ADAM_SEGS; ++j) g.first_vb[j] = 0xffffffffu;
+    for (int k = 0; k < n; ++k) {
+        const float* xin[3] = {x[k], a[k].h1, a[k].h2};
+        const float* dy[3] = {sc[k].dh1, sc[k].dh2, d_out[k]};
+        size_t off = 0;
+        for (int i = 2; i >= 0; --i) {
+            const int j = 3 * k + (2 - i);
+            const int ns = ts::conv_wgrad_splits(m.l[i]);
+            const int64_t pe = m.l[i].param_elems();
+            TS_REQUIRE(pe % 4 == 0, TS_ERR_INVALID_ARG, "mlp_weight_grads_adam: layer sizes must be multiples of 4");
+            geoms[j] = m.l[i]; X[j] = xin[i]; dY[j] = dy[i]; slabs[j] = sc[k].slabs + off;
+            g.slabs[j] = sc[k].slabs + off; g.nslab[j] = ns; g.n[j] = pe;
+            g.grad[j] = grad[k] + m.off[i]; g.p[j] = p[k] + m.off[i]; g.m[j] = pm[k] + m.off[i]; g.v[j] = pv[k] + m.off[i];
+            g.tgt[j] = (lag && lag[k] && sp.tau > 0.0) ? lag[k] + m.off[i] : nullptr;
+            g.first_vb[j] = vbs;
+            vbs += (unsigned)ts::ceil_div(pe, 64);
+            off += (size_t)ns * pe;
+        }
+    }
+    for (int j = 3 * n; j <= SLAB_ADAM_SEGS; ++j) g.first_vb[j] = j == SLAB_ADAM_SEGS ? vbs : 0xffffffffu;
+    g.first_vb[SLAB_ADAM_SEGS] = vbs;
+    const double bc1 = 1.0 - pow(sp.beta1, (double)sp.step), bc2 = 1.0 - pow(sp.beta2, (double)sp.step);
+    g.lr_step = (float)(sp.lr / bc1);
+    g.beta1 = (float)sp.beta1; g.beta2 = (float)sp.beta2;
+    g.omb1 = (float)(1.0 - sp.beta1); g.omb2 = (float)(1.0 - sp.beta2);
+    g.bc2_sqrt = (float)sqrt(bc2);
+    g.eps = (float)sp.eps;
+    g.tau = (float)sp.tau; g.one_minus_tau = (float)(1.0 - sp.tau);
+    if (int rc = ts::conv_wgrad_group(s, 3 * n, geoms, X, dY, slabs, ws)) return rc;
+    if (alpha) hipLaunchKernelGGL(slab_adam_kernel<true>, dim3(vbs + 1), dim3(256), 0, s, g, *alpha);
+    else hipLaunchKernelGGL(slab_adam_kernel<false>, dim3(vbs), dim3(256), 0, s, g, AlphaArgs{});
+    TS_LAUNCH_CHECK();
+    return TS_OK;
 }
 
 __global__ __launch_bounds__(256) void polyak2_kernel(float* __restrict__ t1, const float* __restrict__ s1,
@@ -1091,16 +1241,18 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     if (phases != PH_ALL) {      // exchange-buffer layout of the single phases
         g_out[0] = grads; g_out[1] = grads + pc; g_out[2] = grads;
     }
-    if (phases & PH_CRITIC_GRAD) {
-        hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
-                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p, rows);
-        // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
-    }
-
     // critic 1 & 2 (ddpg.py:279-285), each with its own Adam step.  The two chains are independent: critic 1 on the
     // caller's stream, critic 2 on the workspace's side stream (each of these GEMMs fills only part of the chip).
     hipStream_t side;
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
+    // one stream: every reader of [obs | buffer action] (the critics' passes) is done before the policy kernel writes the
+    // policy's action, so the actor pass reuses x_c instead of a second packed copy of the observations
+    if (side == s) x_p = x_c;
+    if (phases & PH_CRITIC_GRAD) {
+        hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
+                           B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p == x_c ? (float*)nullptr : x_p, rows);
+        // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
+    }
     hipStream_t stq[2] = {s, side};
     float* crit[2] = {st->critic1, st->critic2};
     float* crit_m[2] = {st->critic1_m, st->critic2_m};
@@ -1116,6 +1268,10 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     // one Adam launch that also moves the lagged critics (nothing reads them again in this update)
     const bool twin_group = side == s && fused_backward(mc, false, 0, 0);
     const bool polyak_with_adam = twin_group && hp->critic_lr >= 0.0 && hp->tau > 0.0;
+    // whole updates on the one-launch chains: each network group's slab sums + Adam (+ Polyak; + the alpha step behind the
+    // actor's) are one launch (slab_adam_kernel; TS_SAC_SPLIT_ADAM=1 keeps the separate launches)
+    const bool fuse_adam = twin_group && phases == PH_ALL && hp->critic_lr >= 0.0 && hp->actor_lr >= 0.0 &&
+                           fused_backward(ma, false, 0, 0) && !getenv("TS_SAC_SPLIT_ADAM");
     auto critic_loss = [&](hipStream_t sk, int k0, int nk) {
         CriticLossArgs la{};
         for (int k = 0; k < nk; ++k) {
@@ -1133,7 +1289,12 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         if (int rc = mlp_backward_twin(s, ws, mc, crit, x_c, acts, dh2, nullptr, 0, 0, scs)) return rc;
         const float* xs2[2] = {x_c, x_c};
         float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
-        if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
+        if (fuse_adam) {       // slab sums, both Adam steps and the lagged critics' Polyak update in one launch
+            float* lag[2] = {st->critic1_old, st->critic2_old};
+            const AdamSpec sp{adam_step, hp->critic_lr, hp->beta1, hp->beta2, hp->adam_eps, hp->tau};
+            if (int rc = mlp_weight_grads_adam(s, ws, 2, mc, xs2, acts, dh2, gk2, scs, crit, crit_m, crit_v, lag, sp, nullptr))
+                return rc;
+        } else if (int rc = mlp_weight_grads(s, ws, 2, mc, xs2, acts, dh2, gk2, scs)) return rc;
     }
     for (int k = 0; k < 2 && (phases & PH_CRITIC_GRAD) && !twin_group; ++k) {
         hipStream_t sk = stq[k];
@@ -1143,7 +1304,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(sk, ws, mc, crit[k], x_c, acts[k], dheads[k], gk, nullptr, 0, 0, scs[k], 1)) return rc;
     }
-    if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0 && twin_group) {
+    if ((phases & PH_CRITIC_APPLY) && hp->critic_lr >= 0.0 && twin_group && !fuse_adam) {
         const float* gk2[2] = {g_out[0] ? g_out[0] : gbuf[0], g_out[1] ? g_out[1] : gbuf[1]};
         float* lag[2] = {st->critic1_old, st->critic2_old};
         if (int rc = ts::adam_step_multi(s, 2, crit, crit_m, crit_v, gk2, lag, pc, adam_step, hp->critic_lr, hp->beta1, hp->beta2,
@@ -1200,7 +1361,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
                            keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
         TS_LAUNCH_CHECK();
-        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc)) return rc;
+        if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc, fuse_adam ? 1 : 3)) return rc;
         if (phases != PH_ALL) {      // the alpha step's only batch statistic, for the all-reduce; the actor loss
             hipLaunchKernelGGL(neg_mean_kernel, dim3(1), dim3(1024), 0, s, logp, B, grads + pa);
             hipLaunchKernelGGL(sac_loss_finish_kernel, dim3(1), dim3(64), 0, s, loss_part, stats_out5, (const float*)nullptr,
@@ -1209,7 +1370,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         }
     }
     if (!(phases & PH_ACTOR_APPLY)) return TS_OK;
-    if (hp->actor_lr >= 0.0)
+    if (hp->actor_lr >= 0.0 && !fuse_adam)
         if (int rc = ts::adam_step(s, st->actor, st->actor_m, st->actor_v, ga, pa, adam_step, hp->actor_lr, hp->beta1,
                                    hp->beta2, hp->adam_eps, 0.0, norm_part))
             return rc;
@@ -1226,7 +1387,15 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     aa2.td1 = td1; aa2.td2 = td2; aa2.weight_out = weight_out;
     aa2.neg_mean_logp = phases != PH_ALL ? grads + pa : nullptr;
     aa2.loss_part = phases == PH_ALL ? loss_part : nullptr; aa2.losses = stats_out5; aa2.n_part = (int)gb;
-    hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
+    if (fuse_adam) {           // the actor's weight gradients, slab sums, Adam step and the alpha step: two launches
+        const float* xa = x_a;
+        const float* dh = d_head;
+        float* pp[1] = {st->actor}; float* pm[1] = {st->actor_m}; float* pv[1] = {st->actor_v};
+        const AdamSpec sp{adam_step, hp->actor_lr, hp->beta1, hp->beta2, hp->adam_eps, 0.0};
+        if (int rc = mlp_weight_grads_adam(s, ws, 1, ma, &xa, &aa, &dh, &ga, &sc, pp, pm, pv, nullptr, sp, &aa2)) return rc;
+    } else {
+        hipLaunchKernelGGL(sac_alpha_kernel, dim3(1), dim3(1024), 0, s, aa2);
+    }
     if (hp->tau > 0.0 && !polyak_with_adam)
         hipLaunchKernelGGL(polyak2_kernel, dim3((unsigned)ts::ceil_div(pc, 256)), dim3(256), 0, s, st->critic1_old,
                            st->critic1, st->critic2_old, st->critic2, pc, (float)hp->tau, (float)(1.0 - hp->tau));
