@@ -120,3 +120,33 @@ def test_default_dispatch_by_row_count(monkeypatch):
     assert plan(64) == (2, 4, 2)
     v, g, s = plan(65536)
     assert v == 0 and g == s == min(512, 2 * cus)
+
+
+def test_update_whose_minibatches_run_both_kernels(monkeypatch):
+    """Default dispatch inside ONE update: Batch.split(merge_last=True) makes the last minibatch the largest -- here 20,000-row
+    minibatches on the feature-split kernel (256 slabs of 11,608 floats, 182 reduction workgroups) and a 28,000-row last one
+    on the 128-sample kernel (219 slabs of 11,088, 174 workgroups).  The slab area must hold the largest NEED (not the
+    largest minibatch's), and every step's clip_grad_norm_ factor must come from the partial sums of ITS reduction.
+    Oracle: losses of every step, gradient of the last step, parameters."""
+    from tianshou_amd import ppo as P
+
+    monkeypatch.delenv("TS_PPO_STEPQ", raising=False)
+    n, obs_dim, act_dim, batch, repeat = 68000, 17, 6, 20000, 2
+    kw = dict(PPO_KW, max_grad_norm=0.05)                  # small enough that every step is clipped
+    params, b = _make(n, obs_dim, act_dim, seed=3)
+    perms = [np.random.default_rng(4 + r).permutation(n) for r in range(repeat)]
+    st = OP.PPOState(params={k: v.clone() for k, v in params.items()})
+    tb = {k: torch.from_numpy(v) for k, v in b.items()}
+    lo, go = OP.update(st, OP.PPOConfig(**kw), {"obs": tb["obs"], "act": tb["act"]},
+                       {k: tb[k] for k in ("adv", "returns", "logp_old", "v_s")}, batch, repeat, perms, collect_grads=True)
+    eng = P.PPOEngine(obs_dim, act_dim, OP.flatten_params(params).cuda(), P.PPOConfig(**kw))
+    db = {k: torch.as_tensor(v, device="cuda") for k, v in b.items()}
+    losses, steps, grads = eng.update(db, batch, repeat, perms, want_grad=True)
+    assert steps == 6
+    np.testing.assert_allclose(losses.cpu().numpy().astype(np.float64), lo, rtol=1e-5, atol=2e-6)
+    g, ref = grads.cpu().numpy(), go.numpy()
+    assert np.abs(g - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(eng.params.cpu().numpy(), OP.flatten_params(st.params).numpy(), rtol=1e-4, atol=0.02 * kw["lr"])
+    # Adam's first steps move every parameter by ~lr whatever the clip factor is; a wrong factor shows up in the moments
+    mm = torch.cat([st.adam_m[k].reshape(-1) for k in P.PARAM_ORDER]).numpy()
+    assert np.abs(eng.adam_m.cpu().numpy() - mm).max() <= 1e-3 * np.abs(mm).max()

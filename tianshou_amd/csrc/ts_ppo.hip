@@ -1861,19 +1861,27 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
     TS_REQUIRE(ws && params && adam_m && adam_v && obs && act && adv && returns && logp_old && v_s &&
                    h_mb_offset && hp,
                TS_ERR_INVALID_ARG, "ts_ppo_update: NULL argument");
-    int64_t max_rows = 0;
+    const Dims d = make_dims((int)obs_dim, (int)act_dim);
+    const int ks = supported_ks(ks1_for((int)obs_dim));
+    // The slab area, the gradient vector and the partial sums of squares are sized by the LARGEST need over the update's
+    // minibatches -- not by the largest minibatch: Batch.split(merge_last=True) makes the last one the largest, and the
+    // others may run the other step kernel, whose slabs are wider and whose grid is its own (e.g. 20,000-row minibatches on
+    // the feature-split kernel: 256 slabs of 11,608 floats; the 28,000-row last one on the 128-sample kernel: 219 of 11,088).
+    size_t slab_floats = 0;
+    int slab_w = 0;
+    int64_t last_rows = -1;
     for (int64_t k = 0; k < n_steps; ++k) {
         const int64_t rows = h_mb_offset[k + 1] - h_mb_offset[k];
         TS_REQUIRE(rows >= 1, TS_ERR_SHAPE, "ts_ppo_update: minibatch %lld is empty", (long long)k);
         TS_REQUIRE(perm || h_mb_offset[k + 1] <= n, TS_ERR_SHAPE, "ts_ppo_update: minibatch beyond n");
-        if (rows > max_rows) max_rows = rows;
+        if (rows == last_rows) continue;
+        last_rows = rows;
+        const StepPlan pl = plan_step(d, ks, rows, hp->nets);
+        slab_floats = std::max(slab_floats, (size_t)pl.n_slabs * (size_t)pl.slab_w);
+        slab_w = std::max(slab_w, pl.slab_w);
     }
-    const Dims d = make_dims((int)obs_dim, (int)act_dim);
-    const int ks = supported_ks(ks1_for((int)obs_dim));
-    const StepPlan pl_max = plan_step(d, ks, max_rows, hp->nets);      // the largest minibatch sizes the slab area
-    const int slab_w = pl_max.slab_w;
     const int rw = rec_width(obs_dim, act_dim);
-    const WsLayout wl = ws_layout(pl_max.n_slabs, slab_w, n_steps);
+    const WsLayout wl = ws_layout((int)((slab_floats + slab_w - 1) / slab_w), slab_w, n_steps);
     // behind the fixed part: device copy of the minibatch offsets, then the packed records
     const size_t off_bytes = (sizeof(int64_t) * (size_t)(n_steps + 1) + 255) & ~(size_t)255;
     const size_t rec_bytes = (sizeof(float) * (size_t)n * rw + 255) & ~(size_t)255;
@@ -1916,10 +1924,13 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
-        rc = run_grad(ws, g, d, ks, plan_step(d, ks, g.n_rows, hp->nets), slabs, grad, sumsq, losses, s);
+        const StepPlan pl = plan_step(d, ks, g.n_rows, hp->nets);
+        rc = run_grad(ws, g, d, ks, pl, slabs, grad, sumsq, losses, s);
         if (rc != TS_OK) return rc;
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
-        a.grad = grad; a.sumsq_part = sumsq; a.n_part = wl.n_red_blocks;
+        // the partial sums of squares THIS step's reduction wrote: a ragged last minibatch may run the other step kernel,
+        // whose slabs are wider (182 vs 174 reduction workgroups at obs 17 / act 6)
+        a.grad = grad; a.sumsq_part = sumsq; a.n_part = (pl.slab_w + 63) / 64;
         a.losses = losses; a.apply = 1;
         a.image = image; a.inv = inv; a.sig_off = d.a_sig; a.act = d.act; a.small0 = img_end - 32;
         if (grads_out && k == n_steps - 1)
