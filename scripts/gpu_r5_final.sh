@@ -15,6 +15,15 @@ rocprofv3 --kernel-trace --stats -d $O/prof_ppo -o ppo -- python $GRAFT_REPO_ROO
 cd $GRAFT_REPO_ROOT
 python scripts/rocprof_top.py $O/prof_ppo/ppo_results.db $O/rocprofv3_kernel_stats.csv > $O/ppo_top.txt 2>&1
 rm -rf $O/prof_ppo
+# NPG / SAC: kernel tables of one bench run each (the one-launch actor passes; the SAC update's small kernels)
+for w in npg trpo sac; do
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$w -o $w -- python $GRAFT_REPO_ROOT/bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 2 > /dev/null 2>> $O/err.txt
+  cd $GRAFT_REPO_ROOT
+  python scripts/rocprof_top.py $O/prof_$w/${w}_results.db $O/${w}_kernel_stats.csv 2>&1 | head -32 > $O/${w}_top_kernels.txt
+  rm -rf $O/prof_$w
+done
+PYTHONPATH=. python scripts/gpu_sample_ubench.py 2>&1 | grep -v amdgpu.ids > $O/sample_kernel_by_phases.txt
 bash scripts/gpu_r2_pmc.sh > $O/pmc_step_log.txt 2>&1
 cp gpurun_out/pmc/pmc_step_mode2.txt $O/pmc_ppo_step.txt 2>/dev/null
 bash scripts/gpu_pmc_traffic.sh > $O/pmc_traffic_log.txt 2>&1
