@@ -170,8 +170,11 @@ class Workspace:
     def handle(self) -> C.c_void_p:
         return self._h
 
+    profiling = False          # between profile_begin and profile_end: engines keep their work on this workspace's stream
+
     def profile_begin(self) -> None:
         check(load().ts_profile_begin(self._h))
+        self.profiling = True
 
     def profile_end(self) -> dict[str, tuple[float, int]]:
         """-> {kind: (total_ms, launches)} measured with HIP events on the launch stream."""
@@ -179,6 +182,7 @@ class Workspace:
         ms = (C.c_double * n)()
         cnt = (C.c_int64 * n)()
         check(load().ts_profile_end(self._h, ms, cnt, C.c_int(n)))
+        self.profiling = False
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_KINDS)}
 
     def gae_check(self) -> int:

@@ -1596,8 +1596,8 @@ bool npg_fused_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim) {
     return hidden == HID && obs_dim >= 1 && obs_dim <= 32 && act_dim >= 1 && act_dim <= ACT_PAD;
 }
 
-static int npg_grid(int64_t B, int per_cu) {
-    const char* e = getenv("TS_NPG_FVP_WGS");
+static int npg_grid(int64_t B, int per_cu, const char* env = "TS_NPG_FVP_WGS") {
+    const char* e = getenv(env);
     const int64_t tiles = (B + 31) / 32;
     int64_t n = e && atoi(e) > 0 ? atoi(e) : per_cu * (int64_t)n_compute_units();
     if (n > tiles) n = tiles;
@@ -1612,7 +1612,8 @@ static int npg_eval_grid(int64_t B, int n_cand) {
 
 // floats of slab scratch for the GRAD / FVP launches on B rows; of partial sums for an EVAL launch
 size_t npg_fused_slab_floats(int64_t obs_dim, int64_t B) {
-    return (size_t)npg_grid(B, 3) * (size_t)q4::actor_slab_width(q4::k1s_for((int)obs_dim));
+    const int grid = std::max(npg_grid(B, 2), npg_grid(B, 2, "TS_NPG_CRITIC_WGS"));
+    return (size_t)grid * (size_t)q4::actor_slab_width(q4::k1s_for((int)obs_dim));
 }
 size_t npg_fused_eval_floats(int64_t B, int n_cand) { return (size_t)n_cand * (size_t)npg_eval_grid(B, n_cand) * 2; }
 
@@ -1649,7 +1650,7 @@ int npg_fvp_fused(hipStream_t s, ts_workspace* ws, const float* theta, const flo
     g.theta = theta; g.dir = v; g.x = x; g.n_rows = B; g.inv_batch = 1.f / (float)B;
     g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
     g.obs = obs; g.act = act; g.k0 = k0;
-    const int grid = npg_grid(B, 3);
+    const int grid = npg_grid(B, 2);
     TS_NPG_DISPATCH(npg_fvp_kernel, q4::NPG_FVP, dim3(grid))
     const int P = npg_param_count(k0);
     hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w, obs,
@@ -1670,7 +1671,7 @@ int npg_grad_fused(hipStream_t s, ts_workspace* ws, const float* theta, const fl
     g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
     g.obs = obs; g.act = act; g.k0 = k0;
     g.actions = actions; g.adv = adv; g.logp_old = logp_old; g.mu = mu;
-    const int grid = npg_grid(B, 3);
+    const int grid = npg_grid(B, 2);
     TS_NPG_DISPATCH(npg_grad_kernel, q4::NPG_GRAD, dim3(grid))
     const int P = npg_param_count(k0);
     hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 1 + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w,
@@ -1689,7 +1690,7 @@ int npg_critic_grad_fused(hipStream_t s, ts_workspace* ws, const float* critic, 
     g.slabs = slabs; g.slab_w = q4::actor_slab_width(k1s);
     g.obs = obs; g.act = 1; g.k0 = k0;
     g.adv = returns;
-    const int grid = npg_grid(B, 3);
+    const int grid = npg_grid(B, 2, "TS_NPG_CRITIC_WGS");
     TS_NPG_DISPATCH(npg_critic_kernel, q4::NPG_CRITIC, dim3(grid))
     const int P = npg_param_count(k0) - 32;
     hipLaunchKernelGGL(q4::npg_actor_reduce_kernel, dim3((unsigned)((P + 1 + 63) / 64)), dim3(1024), 0, s, slabs, grid, g.slab_w,

@@ -141,8 +141,9 @@ class NPGEngine:
         returns = self._f32(returns, (b,))
         cfg = self.cfg
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        ws = _lib.default_workspace(self.device.index or 0)         # the CALLING stream's workspace (update() runs this on a side stream)
         _lib.check(_lib.load().ts_npg_critic_steps(
-            self._ws.handle, _lib.ptr(self.critic), _lib.ptr(self.critic_m), _lib.ptr(self.critic_v),
+            ws.handle, _lib.ptr(self.critic), _lib.ptr(self.critic_m), _lib.ptr(self.critic_v),
             _lib.i64(self.adam_step + 1), _lib.i64(self.obs_dim), _lib.i64(self.hidden), _lib.ptr(obs), _lib.ptr(returns),
             _lib.i64(b), _lib.i64(iters), _lib.f64(cfg.lr), _lib.f64(cfg.betas[0]), _lib.f64(cfg.betas[1]),
             _lib.f64(cfg.adam_eps), _lib.f64(cfg.max_grad_norm or 0.0), _lib.ptr(loss), _lib.ptr(None),
@@ -232,10 +233,32 @@ class NPGEngine:
     def update(self, pre: dict, batch_size: int | None, repeat: int, perms=None):
         """npg.py:140-193 / trpo.py:123-214 -> (stats float32[steps, 4] = {actor_loss, vf_loss, kl, step_size}, steps)."""
 
+        # The actor's step and the critic's iterations of a minibatch share nothing but their inputs (npg.py:149-183: two
+        # networks, two optimisers), and half of the actor's launches are one-workgroup kernels (conjugate-gradient updates,
+        # slab sums) that leave the chip idle: the critic iterations run on a second stream beside them, with that stream's
+        # own workspace (TS_NPG_ONE_STREAM=1: one after the other on the caller's stream).  65,536-row minibatches: NPG 1,057 -> 1,107,
+        # TRPO 887 -> 904 update-steps/s -- the chip-filling kernels of the two chains still take turns.
+        # (one stream too while the workspace is timing its kernels: the event pairs of two streams would overlap)
+        side = None if os.environ.get("TS_NPG_ONE_STREAM") or self._ws.profiling else self._critic_stream()
+
         def step_rows(rows):
             obs, ret = pre["obs"][rows], pre["returns"][rows]
-            st = self.actor_step(obs, pre["act"][rows], pre["adv"][rows], pre["logp_old"][rows])
-            vf = self.critic_steps(obs, ret, self.cfg.optim_critic_iters)
+            act, adv, lpo = pre["act"][rows], pre["adv"][rows], pre["logp_old"][rows]
+            if side is None:
+                st = self.actor_step(obs, act, adv, lpo)
+                vf = self.critic_steps(obs, ret, self.cfg.optim_critic_iters)
+            else:
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)                      # the minibatch's rows are gathered
+                with torch.cuda.stream(side):
+                    vf = self.critic_steps(obs, ret, self.cfg.optim_critic_iters)
+                st = self.actor_step(obs, act, adv, lpo)
+                main.wait_stream(side)                      # (also keeps obs / ret alive until the side stream is done)
             return torch.stack([st[0], vf[0], st[1], st[2]])
 
         return run_minibatches(self.device, pre["obs"].shape[0], batch_size, repeat, perms, step_rows)
+
+    def _critic_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
