@@ -1596,6 +1596,9 @@ bool npg_fused_supported(int64_t obs_dim, int64_t hidden, int64_t act_dim) {
     return hidden == HID && obs_dim >= 1 && obs_dim <= 32 && act_dim >= 1 && act_dim <= ACT_PAD;
 }
 
+// Workgroups of a gradient / Fisher-vector-product / critic launch: TWO per CU although three fit (<= 168 registers) -- the
+// third of every SIMD's registers left over is where the OTHER chain's kernel runs when NPGEngine.update has the critic
+// iterations on a second stream (profiles/r05_npg_two_streams_grid_sweep.txt: 768 / 768 1,103, 512 / 512 1,170 steps/s).
 static int npg_grid(int64_t B, int per_cu, const char* env = "TS_NPG_FVP_WGS") {
     const char* e = getenv(env);
     const int64_t tiles = (B + 31) / 32;
