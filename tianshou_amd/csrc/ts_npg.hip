@@ -325,6 +325,18 @@ __global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict_
     cand[i] = theta[i] + scale * (-x[i]);
 }
 
+// every backtracking candidate of TRPO's line search in one launch (blockIdx.y = k): candidate_kernel's arithmetic with
+// coeff^k formed by the host loop's k multiplications
+__global__ __launch_bounds__(256) void candidates_all_kernel(const float* __restrict__ theta, const float* __restrict__ x, int64_t P,
+                                                             const float* __restrict__ step, float coeff, float* __restrict__ cands) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    float cpow = 1.f;
+    for (unsigned k = 0; k < blockIdx.y; ++k) cpow = cpow * coeff;
+    const float scale = step[0] * cpow;
+    cands[(int64_t)blockIdx.y * P + i] = theta[i] + scale * (-x[i]);
+}
+
 // per-block partial sums of kl(old || new) (torch/distributions/kl.py _kl_normal_normal, summed over the action dims) and of
 // the TRPO surrogate term ratio * adv under the candidate parameters
 __global__ __launch_bounds__(256) void kl_eval_kernel(const float* __restrict__ mu_old, const float* __restrict__ ls_old,
@@ -947,13 +959,17 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     if (int rc = fvp(cx, fx)) return rc;
     hipLaunchKernelGGL(trpo_step_size_kernel, dim3(1), dim3(1024), 0, s, cx, fx, P, (float)hp->max_kl, step);
     float cpow = 1.f;
-    for (int k = 0; k < n_cand; ++k) {
+    for (int k = 0; k < n_cand && !fused; ++k) {
         hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, step, 0.f, cpow, cands + (size_t)k * P);
-        if (!fused)
-            if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
+        if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
         cpow = cpow * (float)hp->backtrack_coeff;
     }
-    if (fused)                                        // every backtracking candidate in one launch (blockIdx.y = candidate)
+    if (fused) {                                      // every backtracking candidate: one launch to form them, one to evaluate them
+        hipLaunchKernelGGL(candidates_all_kernel, dim3(gp, (unsigned)n_cand), dim3(256), 0, s, actor, cx, P, step,
+                           (float)hp->backtrack_coeff, cands);
+        TS_LAUNCH_CHECK();
+    }
+    if (fused)
         if (int rc = ts::npg_eval_fused(s, ws, actor, cands, P, n_cand, x, act, adv, logp_old, mu_old, n.obs, n.k0, A, B, eval_part, res))
             return rc;
     hipLaunchKernelGGL(trpo_select_kernel, dim3((unsigned)std::min<int64_t>(gp, 64)), dim3(256), 0, s, actor, cands, P, res, n_cand,
