@@ -213,6 +213,12 @@ int ts_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, ts_str
 int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const int64_t* index,
                    int64_t I, void* out, ts_stream_t stream);
 
+/* The same for up to 8 keys of a batch at once -- Batch.__getitem__ (data/batch.py:714-738) gathers EVERY key at the same
+ * indices; one launch instead of one per key.  h_src / h_out / h_row_bytes: HOST arrays of n_keys device pointers / row sizes
+ * (multiples of 4 bytes, 4-byte aligned); every source has n_rows_src rows. */
+int ts_gather_rows_multi(int64_t n_keys, const void* const* h_src, const int64_t* h_row_bytes, int64_t n_rows_src,
+                         const int64_t* index, int64_t I, void* const* h_out, ts_stream_t stream);
+
 /* Write side: ReplayBufferManager.add (manager.py:131-198) with
  * ReplayBuffer._update_state_pre_add (buffer_base.py:360-418) for K transitions addressed to DISTINCT
  * sub-buffers buffer_ids[k] (NULL = 0..K-1), entirely on the device.  State per sub-buffer, all [E], updated in

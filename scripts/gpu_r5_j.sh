@@ -2,7 +2,7 @@
 # round 5, call J: the one-launch actor passes of NPG / TRPO (ts_npg_q.h) -- parity + bench A/B (per-layer passes; one / two streams) + kernel table
 O=$GRAFT_REPO_ROOT/gpurun_out/r5j; rm -rf $O; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_npg.py tests/test_gpu_hooks.py -x -q > $O/pytest.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_npg.py tests/test_gpu_hooks.py tests/test_gpu_index_segtree.py -x -q > $O/pytest.txt 2>&1
 tail -5 $O/pytest.txt
 for w in npg trpo; do
   TS_NPG_FVP=0 timeout 200 python bench.py --workload $w --no-cpu-baseline > $O/b_${w}_per_layer.json 2>> $O/err.txt

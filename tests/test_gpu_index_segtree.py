@@ -338,3 +338,24 @@ def test_seeded_sampler_is_reproducible_and_follows_the_lengths():
     np.testing.assert_allclose(freq, lengths / lengths.sum(), atol=0.01)
     within = (a - off[sub])[sub == 2]
     assert abs(within.mean() / 4000 - 0.5) < 0.02 and within.min() < 40 and within.max() > 3960
+
+
+def test_gather_rows_multi_is_fancy_indexing_of_every_key():
+    """ts_gather_rows_multi (Batch.__getitem__ over several keys, batch.py:714-738, one launch) == src[index] per key: mixed
+    dtypes and row shapes, negative indices, the per-key fallback for rows that are not whole 4-byte words."""
+    from tianshou_amd.buffer import gather_rows_multi
+
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    srcs = [torch.randn(n, 17, generator=g), torch.randn(n, generator=g), torch.randn(n, 6, generator=g).double(),
+            torch.randint(0, 1 << 40, (n, 3), generator=g), torch.randn(n, 2, 5, generator=g)]
+    index = torch.randint(-n, n, (7001,), generator=g)
+    dev = [s.cuda() for s in srcs]
+    outs = gather_rows_multi(dev, index.cuda())
+    for s, o in zip(srcs, outs):
+        assert o.dtype == s.dtype and torch.equal(o.cpu(), s[index])
+    odd = [torch.randint(0, 255, (n, 3), generator=g, dtype=torch.uint8), srcs[0]]          # 3-byte rows: per-key gathers
+    outs = gather_rows_multi([s.cuda() for s in odd], index.cuda())
+    for s, o in zip(odd, outs):
+        assert torch.equal(o.cpu(), s[index])
+    assert gather_rows_multi([], index.cuda()) == []

@@ -80,6 +80,31 @@ def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_rows_multi(srcs, index: torch.Tensor) -> list[torch.Tensor]:
+    """[src[index] for src in srcs] -- Batch.__getitem__ over several keys (batch.py:714-738) -- in ONE launch for up to 8
+    contiguous tensors with the same number of rows whose rows are whole 4-byte words (ts_gather_rows_multi); other inputs
+    fall back to gather_rows per key."""
+    srcs = list(srcs)
+    if not srcs:
+        return []
+    dev = srcs[0].device
+    index = _i64_dev(index, dev).reshape(-1)
+    n = srcs[0].shape[0]
+    rb = [s.element_size() * int(np.prod(s.shape[1:], dtype=np.int64)) for s in srcs]
+    ok = (len(srcs) <= 8 and all(s.is_contiguous() and s.shape[0] == n and s.device == dev and s.data_ptr() % 4 == 0 for s in srcs)
+          and all(b >= 4 and b % 4 == 0 for b in rb))
+    if not ok:
+        return [gather_rows(s, index) for s in srcs]
+    outs = [torch.empty((index.numel(), *s.shape[1:]), dtype=s.dtype, device=dev) for s in srcs]
+    k = len(srcs)
+    h_src = (C.c_void_p * k)(*[s.data_ptr() for s in srcs])
+    h_out = (C.c_void_p * k)(*[o.data_ptr() for o in outs])
+    h_rb = (C.c_int64 * k)(*rb)
+    _lib.check(_lib.load().ts_gather_rows_multi(_lib.i64(k), h_src, h_rb, _lib.i64(n), _lib.ptr(index), _lib.i64(index.numel()),
+                                                h_out, _lib.current_stream(dev)))
+    return outs
+
+
 def random_permutation(n: int, seed: int, device="cuda") -> torch.Tensor:
     """Device-side replacement for np.random.permutation(n) in Batch.split (batch.py:1209): a keyed
     bijection of range(n), int64 device tensor (ts_random_permutation)."""

@@ -586,6 +586,25 @@ __global__ void gather_rows_vec_kernel(const V* src, int64_t n_src, int64_t row_
     }
 }
 
+// Batch.__getitem__ over several keys (data/batch.py:714-738: every key gathered at the same indices) in ONE launch:
+// blockIdx.y = key, 4-byte words.
+constexpr int GATHER_MULTI_MAX = 8;
+struct GatherMulti { const uint32_t* src[GATHER_MULTI_MAX]; uint32_t* out[GATHER_MULTI_MAX]; int64_t row_words[GATHER_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void gather_rows_multi_kernel(GatherMulti g, int64_t n_src, const int64_t* __restrict__ index,
+                                                                int64_t I) {
+    const int a = blockIdx.y;
+    const int64_t rw = g.row_words[a], total = I * rw;
+    const uint32_t* __restrict__ src = g.src[a];
+    uint32_t* __restrict__ out = g.out[a];
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int64_t i = t / rw, k = t - i * rw;
+        int64_t r = index[i];
+        if (r < 0) r += n_src;  // NumPy negative indexing
+        out[t] = src[r * rw + k];
+    }
+}
+
 // Keyed bijection of [0, n): 4-round Feistel network on the smallest even bit width covering n,
 // cycle-walked back into range.  One thread per output slot, no sort, no scratch.
 __device__ __forceinline__ uint32_t feistel_round(uint32_t x, uint32_t k) {
@@ -798,6 +817,29 @@ int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const
                            dim3(256), 0, s, (const uint8_t*)src, n_rows_src, row_bytes, index, I,
                            (uint8_t*)out);
     }
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_gather_rows_multi(int64_t n_keys, const void* const* h_src, const int64_t* h_row_bytes, int64_t n_rows_src,
+                         const int64_t* index, int64_t I, void* const* h_out, ts_stream_t stream) {
+    TS_REQUIRE(n_keys >= 1 && n_keys <= GATHER_MULTI_MAX && I >= 0 && n_rows_src >= 0, TS_ERR_INVALID_ARG,
+               "ts_gather_rows_multi: 1 .. %d keys, non-negative sizes", GATHER_MULTI_MAX);
+    if (I == 0) return TS_OK;
+    TS_REQUIRE(h_src && h_row_bytes && h_out && index, TS_ERR_INVALID_ARG, "ts_gather_rows_multi: NULL argument");
+    GatherMulti g{};
+    int64_t max_words = 0;
+    for (int k = 0; k < (int)n_keys; ++k) {
+        TS_REQUIRE(h_src[k] && h_out[k] && h_row_bytes[k] >= 4 && h_row_bytes[k] % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(h_src[k]) | reinterpret_cast<uintptr_t>(h_out[k])) & 3u) == 0,
+                   TS_ERR_INVALID_ARG, "ts_gather_rows_multi: key %d: rows of whole, 4-byte aligned words only", k);
+        g.src[k] = static_cast<const uint32_t*>(h_src[k]);
+        g.out[k] = static_cast<uint32_t*>(h_out[k]);
+        g.row_words[k] = h_row_bytes[k] / 4;
+        max_words = std::max(max_words, g.row_words[k]);
+    }
+    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(grid_for(I * max_words, 256), (unsigned)n_keys), dim3(256), 0,
+                       ts::as_stream(stream), g, n_rows_src, index, I);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -46,7 +46,7 @@ int npg_critic_grad_fused(hipStream_t s, ts_workspace* ws, const float* critic, 
                           int k0, int64_t B, float* slabs, float* grad, float* loss_out);
 int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, const float* cands, int64_t cand_stride, int n_cand,
                    const float* x, const float* actions, const float* adv, const float* logp_old, const float* mu, int obs, int k0,
-                   int act, int64_t B, float* partial, float* res);
+                   int act, int64_t B, float* partial, float* res, float* apply_theta = nullptr, float* apply_stats3 = nullptr);
 }
 
 namespace {
@@ -946,10 +946,10 @@ int ts_npg_actor_step(ts_workspace* ws, float* actor, int64_t obs_dim, int64_t h
     if (hp->algo == 0) {                              // npg.py:170-177
         hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, (const float*)nullptr,
                            (float)hp->trust_region_size, 1.f, cands);
-        if (fused) {
-            if (int rc = ts::npg_eval_fused(s, ws, actor, cands, P, 1, x, act, adv, nullptr, mu_old, n.obs, n.k0, A, B, eval_part, res))
-                return rc;
-        } else if (int rc = eval(cands, res, false)) return rc;
+        if (fused)          // the evaluation's finish kernel takes the step as well (theta <- candidate, kl, step size 0)
+            return ts::npg_eval_fused(s, ws, actor, cands, P, 1, x, act, adv, nullptr, mu_old, n.obs, n.k0, A, B, eval_part, res, actor,
+                                      stats_out3);
+        if (int rc = eval(cands, res, false)) return rc;
         TS_HIP_CHECK(hipMemcpyAsync(actor, cands, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
         TS_HIP_CHECK(hipMemcpyAsync(stats_out3 + 1, res, sizeof(float), hipMemcpyDeviceToDevice, s));
         TS_HIP_CHECK(hipMemsetAsync(stats_out3 + 2, 0, sizeof(float), s));

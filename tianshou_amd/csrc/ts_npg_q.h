@@ -654,8 +654,10 @@ __global__ __launch_bounds__(1024) void npg_actor_reduce_kernel(const float* __r
 }
 
 // res[2 c + {0, 1}] = {mean kl, -mean(ratio adv)} of candidate c from the EVAL partial sums [n_cand][n_wg][2]
+// NPG (one candidate, always taken -- npg.py:170-177): theta <- the candidate, stats[1] = its kl, stats[2] = 0 in the same launch
+struct NpgApply { float* theta; const float* cand; int P; float* stats3; };
 __global__ __launch_bounds__(256) void npg_eval_finish_kernel(const float* __restrict__ partial, int n_wg, float n_rows,
-                                                              float* __restrict__ res) {
+                                                              float* __restrict__ res, NpgApply ap) {
     __shared__ float red[4][2];
     const int c = blockIdx.x;
     float s0 = 0.f, s1 = 0.f;
@@ -672,8 +674,12 @@ __global__ __launch_bounds__(256) void npg_eval_finish_kernel(const float* __res
     __syncthreads();
     if (threadIdx.x < 2) {
         const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        res[2 * c + threadIdx.x] = threadIdx.x == 0 ? t / n_rows : -(t / n_rows);
+        const float v = threadIdx.x == 0 ? t / n_rows : -(t / n_rows);
+        res[2 * c + threadIdx.x] = v;
+        if (ap.theta && threadIdx.x == 0) { ap.stats3[1] = v; ap.stats3[2] = 0.f; }
     }
+    if (ap.theta)
+        for (int i = threadIdx.x; i < ap.P; i += 256) ap.theta[i] = ap.cand[i];
 }
 
 }  // namespace q4

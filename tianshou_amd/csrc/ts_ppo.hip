@@ -1703,10 +1703,11 @@ int npg_critic_grad_fused(hipStream_t s, ts_workspace* ws, const float* critic, 
 }
 
 // res[2 c + {0, 1}] = {mean kl(old || candidate c), -mean(ratio adv) at candidate c (logp_old != NULL)}; candidates at
-// cands + c * cand_stride; mu = the old mean per sample (npg_grad_fused)
+// cands + c * cand_stride; mu = the old mean per sample (npg_grad_fused).  apply_theta (NPG, n_cand == 1): the finish kernel
+// also copies the candidate over theta and writes stats3[1] = kl, stats3[2] = 0
 int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, const float* cands, int64_t cand_stride, int n_cand,
                    const float* x, const float* actions, const float* adv, const float* logp_old, const float* mu, int obs, int k0,
-                   int act, int64_t B, float* partial, float* res) {
+                   int act, int64_t B, float* partial, float* res, float* apply_theta, float* apply_stats3) {
     const int k1s = q4::k1s_for(obs);
     TS_REQUIRE(k1s > 0 && B >= 1 && n_cand >= 1 && n_cand <= 32, TS_ERR_UNSUPPORTED, "npg_eval_fused: unsupported shape");
     q4::ActorArgs g{};
@@ -1716,7 +1717,9 @@ int npg_eval_fused(hipStream_t s, ts_workspace* ws, const float* theta_old, cons
     g.actions = actions; g.adv = adv; g.logp_old = logp_old; g.mu = const_cast<float*>(mu);
     const int grid = npg_eval_grid(B, n_cand);
     TS_NPG_DISPATCH(npg_eval_kernel, q4::NPG_EVAL, dim3(grid, n_cand))
-    hipLaunchKernelGGL(q4::npg_eval_finish_kernel, dim3(n_cand), dim3(256), 0, s, partial, grid, (float)B, res);
+    TS_REQUIRE(!apply_theta || n_cand == 1, TS_ERR_INVALID_ARG, "npg_eval_fused: only a single candidate can be applied");
+    hipLaunchKernelGGL(q4::npg_eval_finish_kernel, dim3(n_cand), dim3(256), 0, s, partial, grid, (float)B, res,
+                       q4::NpgApply{apply_theta, cands, npg_param_count(k0), apply_stats3});
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .buffer import _i64_dev
+from .buffer import _i64_dev, gather_rows_multi
 from .ppo_cnn import run_minibatches
 from .returns import gae_scan
 
@@ -242,8 +242,7 @@ class NPGEngine:
         side = None if os.environ.get("TS_NPG_ONE_STREAM") or self._ws.profiling else self._critic_stream()
 
         def step_rows(rows):
-            obs, ret = pre["obs"][rows], pre["returns"][rows]
-            act, adv, lpo = pre["act"][rows], pre["adv"][rows], pre["logp_old"][rows]
+            obs, ret, act, adv, lpo = gather_rows_multi([pre[k] for k in ("obs", "returns", "act", "adv", "logp_old")], rows)
             if side is None:
                 st = self.actor_step(obs, act, adv, lpo)
                 vf = self.critic_steps(obs, ret, self.cfg.optim_critic_iters)
