@@ -139,7 +139,7 @@ def _line(metric, value, unit, steps, warmup, dt, workload, roof, cpu, extra=Non
 # ---- TD3 / DDPG (Humanoid shape, as C5) ------------------------------------------------------------------------------
 def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
     from tianshou_amd import td3 as T
-    from tianshou_amd.buffer import gather_rows
+    from tianshou_amd.buffer import gather_rows_multi
 
     OBS, ACT, B, dev = 376, 17, 4096, torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(0)
@@ -160,7 +160,7 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
         n_upd[0] += 1
         noise = normal_noise((B, ACT), 0x7D3, n_upd[0], dev) if twin else None
         ret = eng.preprocess(buf, idx, noise)
-        return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret)[0]
+        return eng.update_with_batch(*gather_rows_multi([buf.obs, buf.act], idx), ret)[0]    # Batch.__getitem__: both keys, one launch
 
     dt, stats, prof = _time(update, steps, warmup)
     nc = 2 if twin else 1
@@ -202,7 +202,7 @@ def run_td3(steps, warmup, with_cpu, twin=True, slots=1 << 21):
 def run_redq(steps, warmup, with_cpu, slots=1 << 21):
     from tianshou_amd import redq as RQ
     from tianshou_amd import sac as S
-    from tianshou_amd.buffer import gather_rows
+    from tianshou_amd.buffer import gather_rows_multi
 
     OBS, ACT, B, E, SUB, DELAY, dev = 376, 17, 4096, 10, 2, 20, torch.device("cuda")      # the REDQ paper's ensemble / delay
     g = torch.Generator(device=dev).manual_seed(0)
@@ -224,7 +224,7 @@ def run_redq(steps, warmup, with_cpu, slots=1 << 21):
         n_upd[0] += 1
         noise = normal_noise((2, B, ACT), 0x2ED0, n_upd[0], dev)
         ret = eng.preprocess(buf, idx, noise[0], rng.choice(E, SUB, replace=False))
-        return eng.update_with_batch(gather_rows(buf.obs, idx), gather_rows(buf.act, idx), ret,
+        return eng.update_with_batch(*gather_rows_multi([buf.obs, buf.act], idx), ret,
                                      noise[1] if eng.will_update_actor() else None)[0]
 
     dt, stats, prof = _time(update, steps, warmup)

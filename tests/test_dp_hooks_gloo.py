@@ -101,6 +101,7 @@ def _worker(rank, world, port, q):
         I.PPOEngine = FakeEngine
         DD.DataParallelPPO = FakeDP
         B.gather_rows = lambda src, idx: src[idx]
+        B.gather_rows_multi = lambda srcs, idx: [s[idx] for s in srcs]
         B.DeviceReplayBuffer.sample_indices = cpu_sample_all
         R.cut_positions = cpu_cuts
 

@@ -190,6 +190,7 @@ def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):
     monkeypatch.setattr(I, "_require_gpu", lambda device, who: None)
     monkeypatch.setattr(I, "PPOEngine", FakePPO)
     monkeypatch.setattr(B, "gather_rows", lambda src, idx: src[idx])
+    monkeypatch.setattr(B, "gather_rows_multi", lambda srcs, idx: [s[idx] for s in srcs])
     monkeypatch.setattr(B.DeviceReplayBuffer, "sample_indices", cpu_sample_all)
     monkeypatch.setattr(R, "cut_positions", cpu_cuts)
 
@@ -468,6 +469,7 @@ def _patch_for_cpu(monkeypatch):
 
     monkeypatch.setattr(I, "_require_gpu", lambda device, who: None)
     monkeypatch.setattr(B, "gather_rows", lambda src, idx: src[idx])
+    monkeypatch.setattr(B, "gather_rows_multi", lambda srcs, idx: [s[idx] for s in srcs])
 
 
 def _zeros_like_all(obj, names):

@@ -1308,7 +1308,7 @@ def make_hip_sac(ref=None):
 
         def _update_with_batch(self, batch):
             self._hip_refresh_lr()
-            from .buffer import gather_rows
+            from .buffer import gather_rows_multi
 
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
@@ -1321,7 +1321,7 @@ def make_hip_sac(ref=None):
             if runner is eng and hasattr(eng, "update_with_rows"):               # the input packing reads the mirror's rows
                 stats, w = eng.update_with_rows(m, self._hip_idx, batch.returns.reshape(-1), noise, weight)
             else:
-                stats, w = runner.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+                stats, w = runner.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),
                                                     batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
@@ -1438,13 +1438,13 @@ def make_hip_redq(ref=None):
 
         def _update_with_batch(self, batch):
             self._hip_refresh_lr()
-            from .buffer import gather_rows
+            from .buffer import gather_rows_multi
 
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
             did_actor = eng.will_update_actor()
             noise = torch.randn(len(batch), eng.act_dim) if did_actor else None
-            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+            stats, w = eng.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),
                                              batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, redq.py:272
             s = stats.cpu().numpy()                                               # one D2H per update()
@@ -1860,10 +1860,10 @@ def _make_hip_det(twin: bool, ref=None):
 
         def _update_with_batch(self, batch):
             self._hip_refresh_lr()
-            from .buffer import gather_rows
+            from .buffer import gather_rows_multi
 
             eng, m = self._hip_engine, self._hip_mirror
-            stats, w = eng.update_with_batch(gather_rows(m.obs, self._hip_idx), gather_rows(m.act, self._hip_idx),
+            stats, w = eng.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),
                                              batch.returns.reshape(-1), getattr(batch, "weight", None))
             batch.weight = w
             if twin:
