@@ -559,7 +559,7 @@ def hook_level(device, updates=3, permutations="device"):
 
 
 def other_workloads():
-    """Short runs of the C3 / C5 / Atari-shape PPO rows so that they are measured by the same driver command."""
+    """Short runs of the C3 / C5 / Atari-shape PPO / NPG / TRPO rows so that they are measured by the same driver command."""
     out = {}
     for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 1))):
         try:
@@ -569,6 +569,17 @@ def other_workloads():
             out[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r.get("ms_per_step"),
                          "roofline_frac": (r.get("roofline") or {}).get("frac"), "config": r.get("config")}
         except Exception as e:                                   # a side leg must not take the headline line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    # NPG / TRPO on the C2 shape (bench_next.py): the rows whose network passes became one-launch kernels in round 5
+    for name in ("npg", "trpo"):
+        try:
+            import bench_next
+
+            r = bench_next.RUNNERS[name](5, 2, False)
+            out[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r.get("ms_per_step"),
+                         "roofline_frac": (r.get("roofline") or {}).get("frac"), "config": r.get("config")}
+        except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
     return out
