@@ -247,22 +247,23 @@ __global__ __launch_bounds__(256) void fvp_finish_kernel(float* __restrict__ z, 
 __global__ __launch_bounds__(1024) void cg_update_kernel(float* __restrict__ x, float* __restrict__ r, float* __restrict__ p,
                                                          const float* __restrict__ z, int64_t P, float tol,
                                                          float* __restrict__ sc) {
-    __shared__ float red[1024];
-    __shared__ float s_val;
+    __shared__ float red[2][16];
     if (sc[1] != 0.f) return;
-    auto block_sum = [&](float v) {
+    // workgroup sum in a fixed order: butterfly inside each wavefront, then the sixteen wave sums in order -- two barriers
+    // per sum (the kernel is ten iterations' worth of pure latency per minibatch; a 10-level LDS tree cost 22 barriers a sum)
+    auto block_sum = [&](float v, int slot) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[slot][threadIdx.x >> 6] = v;
         __syncthreads();
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 512; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
-        }
-        return red[0];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[slot][w];
+        return t;
     };
     float pz = 0.f;
     for (int64_t i = threadIdx.x; i < P; i += 1024) pz += p[i] * z[i];
-    pz = block_sum(pz);
+    pz = block_sum(pz, 0);
     const float rdotr = sc[0];
     const float alpha = rdotr / pz;
     float nr = 0.f;
@@ -272,10 +273,7 @@ __global__ __launch_bounds__(1024) void cg_update_kernel(float* __restrict__ x, 
         r[i] = ri;
         nr += ri * ri;
     }
-    nr = block_sum(nr);
-    if (threadIdx.x == 0) s_val = nr;
-    __syncthreads();
-    const float new_rdotr = s_val;
+    const float new_rdotr = block_sum(nr, 1);
     if (new_rdotr < tol) {
         if (threadIdx.x == 0) sc[1] = 1.f;
         return;
