@@ -30,7 +30,11 @@ namespace q4 {
 
 constexpr int QT = 256;          // threads per workgroup (4 waves)
 constexpr int PS = 68;           // sample-major tile pitch  [32][PS]   (ds_read_b128 of 4 consecutive features)
-constexpr int PF = 40;           // feature-major tile pitch [64][PF]   (conflict-free ds_read_b128 of 4 consecutive samples: 36 costs 2x)
+#ifndef TS_Q_PF
+#define TS_Q_PF 40
+#endif
+constexpr int PF = TS_Q_PF;      // feature-major tile pitch [64][PF].  36 / 40 / 44 / 52 measured alike (profiles/r05_lds_pitch_sweep.txt):
+                                 // the bank-conflict cycles the counters show (0.3 of the LDS cycles) are not this pitch's
 constexpr int P_FLOATS = 4 * 2 * 8 * 16;   // head partials [wave][block][action][16]
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
