@@ -291,6 +291,10 @@ int64_t ts_ppo_param_count(int64_t obs_dim, int64_t act_dim);
 int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                           const float* noise, int64_t n, int bound_method, const float* low, const float* high,
                           float* act_out, float* mapped_out, ts_stream_t stream);
+/* ... with the tanh bound of a bounded actor (max_action > 0) and mu_out (nullable) = the distribution's mean. */
+int ts_ppo_policy_forward_bounded(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, double max_action,
+                                  const float* obs, const float* noise, int64_t n, int bound_method, const float* low,
+                                  const float* high, float* act_out, float* mapped_out, float* mu_out, ts_stream_t stream);
 
 typedef struct ts_ppo_hparams {
     double eps_clip;      /* ppo.py:140 */
@@ -311,7 +315,19 @@ typedef struct ts_ppo_hparams {
                              For callers whose other network is a stand-in: Reinforce (reinforce.py:371-380 = A2C's actor
                              loss with adv := returns) and the critic iterations of NPG / TRPO (npg.py:142-150 = A2C steps
                              with a zero advantage).  Honoured by ts_ppo_update / ts_ppo_grad (obs_dim <= 31 kernels) */
+    /* -- round 6 (appended: a zero-initialised tail is torch.optim.Adam without weight decay on an unbounded actor) -- */
+    int32_t optimizer;    /* TS_OPT_ADAM (optim.py:89-110) / TS_OPT_RMSPROP (optim.py:113-140; examples/mujoco/mujoco_a2c.py:117):
+                             torch.optim.RMSprop's single-tensor arithmetic, square_avg in the `adam_v` vector, the momentum
+                             buffer (rms_momentum > 0) or grad_avg (rms_centered) in `adam_m`; lr, adam_eps are shared */
+    int32_t rms_centered; /* RMSprop(centered=True); not together with rms_momentum > 0 (one auxiliary vector) */
+    double weight_decay;  /* both optimizers: grad += weight_decay * param after clipping (torch: inside optimizer.step) */
+    double rms_alpha;     /* RMSprop smoothing constant */
+    double rms_momentum;  /* RMSprop momentum (0: none) */
+    double max_action;    /* > 0: ContinuousActorProbabilistic(unbounded=False), the constructor default
+                             (utils/net/continuous.py:194, 230-231): mu = max_action * tanh(Linear(h)); 0: unbounded */
 } ts_ppo_hparams;
+#define TS_OPT_ADAM 0
+#define TS_OPT_RMSPROP 1
 
 /* No-grad inference passes of PPO._preprocess_batch / _add_returns_and_advantages
  * (a2c.py:122-129, ppo.py:157-161), whole batch in one launch instead of max_batchsize
@@ -320,6 +336,12 @@ typedef struct ts_ppo_hparams {
 int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                  const float* act, int64_t n, float* v_out, float* logp_out,
                  ts_stream_t stream);
+/* The same for ContinuousActorProbabilistic(unbounded=False) -- the constructor default (utils/net/continuous.py:194,
+ * 230-231): mu = max_action * tanh(Linear(h)) (max_action = 0: unbounded); mu_out (nullable) float32[n, act_dim] receives
+ * `logits[0]` of ProbabilisticActorPolicy.forward (reinforce.py:183-190). */
+int ts_ppo_infer_bounded(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, double max_action,
+                         const float* obs, const float* act, int64_t n, float* v_out, float* logp_out, float* mu_out,
+                         ts_stream_t stream);
 
 /* PPO._update_with_batch (tianshou/algorithm/modelfree/ppo.py:164-224) + Optimizer.step
  * (algorithm_base.py:484-500): all `n_steps` minibatch gradient steps of one update() are
@@ -392,6 +414,15 @@ int ts_polyak_update(float* tgt, const float* src, int64_t n, double tau, ts_str
 int ts_adam_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, const float* grad, int64_t n,
                  int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm,
                  ts_stream_t stream);
+
+/* Optimizer.step (algorithm_base.py:484-500) for the other optimizer factories of tianshou/algorithm/optim.py: `kind`
+ * TS_OPT_ADAM = torch.optim.Adam incl. weight_decay (optim.py:89-110), TS_OPT_RMSPROP = torch.optim.RMSprop (optim.py:113-140:
+ * alpha, eps, weight_decay, momentum, centered -- the optimizer of examples/mujoco/mujoco_a2c.py:117).  Single-tensor
+ * arithmetic of torch.optim, applied after clip_grad_norm_(max_grad_norm) (<= 0: none).  state_m / state_v: Adam's exp_avg /
+ * exp_avg_sq; RMSprop's momentum buffer (or grad_avg when centered; both together are not supported) / square_avg. */
+int ts_optim_step(ts_workspace* ws, int32_t kind, float* params, float* state_m, float* state_v, const float* grad, int64_t n,
+                  int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double rms_alpha,
+                  double rms_momentum, int32_t rms_centered, double max_grad_norm, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Frame-stacked observations (Atari replay layout)
@@ -1046,6 +1077,9 @@ typedef struct ts_net_desc {
                                           (ContinuousActorProbabilistic(conditioned_sigma=True), utils/net/continuous.py:212-234):
                                           the head block's columns [16, 16 + act) are that Linear layer (act_dim <= 16), the
                                           trailing log_sigma[32] block is unused and stays zero */
+    double max_action;                 /* actor only (round 6): > 0 = ContinuousActorProbabilistic(unbounded=False), the constructor
+                                          default (utils/net/continuous.py:194, 230-231): mu = max_action * tanh(Linear(h)), and
+                                          the gradient goes back through it; 0 = unbounded */
 } ts_net_desc;
 #define TS_NET_CONDITIONED_SIGMA 1
 int ts_net_layout(const ts_net_desc* net, int64_t act_dim, int64_t* h_out3);

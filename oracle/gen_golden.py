@@ -319,17 +319,25 @@ def _flat_adam(algorithm, actor, critic, key: str) -> np.ndarray:
 
 def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int,
             seed: int, n_updates: int = 1, algo: str = "ppo", lr_decay: tuple[int, int, int] | None = None,
-            **ppo_kwargs) -> None:
+            max_action: float | None = None, optim: tuple[str, dict] | None = None, **ppo_kwargs) -> None:
     """Runs the reference PPO.update() on a synthetic VectorReplayBuffer and dumps every
     intermediate the engine has to reproduce.  `lr_decay` = (max_epochs, epoch_num_steps,
     collection_step_num_env_steps) attaches `LRSchedulerFactoryLinear` exactly like
     examples/mujoco/mujoco_ppo.py:124-131 (stepped by Algorithm._update after every update(),
-    algorithm_base.py:628-629); the learning rate in force during update u is recorded as `u{u}_lr`."""
+    algorithm_base.py:628-629); the learning rate in force during update u is recorded as `u{u}_lr`.
+    `max_action` (round 6): ContinuousActorProbabilistic(unbounded=False, max_action=...) -- the constructor default
+    (utils/net/continuous.py:194, 230-231) -- with a mu head large enough for tanh to matter.  `optim` = ("rmsprop" | "adam",
+    factory kwargs): RMSpropOptimizerFactory / AdamOptimizerFactory of tianshou/algorithm/optim.py:89-140 (the state vectors
+    are recorded under the names u{u}_adam_m / u{u}_adam_v: momentum buffer or grad_avg / square_avg for RMSprop)."""
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
     net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
-    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    if max_action is None:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    else:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action)
+        assert not actor._unbounded
     net_c = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
     critic = ContinuousCritic(preprocess_net=net_c)
     torch.nn.init.constant_(actor.sigma_param, -0.5)
@@ -340,7 +348,8 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
     for m in actor.mu.modules():
         if isinstance(m, nn.Linear):
             nn.init.zeros_(m.bias)
-            m.weight.data.copy_(0.01 * m.weight.data)
+            # (bounded actor: a head whose outputs reach into tanh's curved range, so that the bound and its derivative matter)
+            m.weight.data.copy_((0.01 if max_action is None else 0.6) * m.weight.data)
 
     def dist(loc_scale):
         loc, scale = loc_scale
@@ -351,7 +360,14 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
                                       action_bound_method="clip", action_space=space)
     lr = ppo_kwargs.pop("lr", 3e-4)
     cls = PPO if algo == "ppo" else A2C
-    optim_factory = AdamOptimizerFactory(lr=lr)
+    if optim is None:
+        optim_factory = AdamOptimizerFactory(lr=lr)
+    elif optim[0] == "rmsprop":
+        from tianshou.algorithm.optim import RMSpropOptimizerFactory
+
+        optim_factory = RMSpropOptimizerFactory(lr=lr, **optim[1])
+    else:
+        optim_factory = AdamOptimizerFactory(lr=lr, **optim[1])
     if lr_decay is not None:
         from tianshou.algorithm.optim import LRSchedulerFactoryLinear
 
@@ -440,8 +456,14 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
             out[f"u{u}_losses"] = np.stack(s, axis=1)
             out[f"u{u}_gradient_steps"] = np.array(stats.gradient_steps)
             out[f"u{u}_flat_params"] = _flat_from_modules(actor, critic)
-            out[f"u{u}_adam_m"] = _flat_adam(algorithm, actor, critic, "exp_avg")
-            out[f"u{u}_adam_v"] = _flat_adam(algorithm, actor, critic, "exp_avg_sq")
+            if optim is not None and optim[0] == "rmsprop":
+                aux = "momentum_buffer" if optim[1].get("momentum", 0) > 0 else ("grad_avg" if optim[1].get("centered") else None)
+                out[f"u{u}_adam_m"] = (_flat_adam(algorithm, actor, critic, aux) if aux
+                                       else np.zeros_like(out[f"u{u}_flat_params"]))
+                out[f"u{u}_adam_v"] = _flat_adam(algorithm, actor, critic, "square_avg")
+            else:
+                out[f"u{u}_adam_m"] = _flat_adam(algorithm, actor, critic, "exp_avg")
+                out[f"u{u}_adam_v"] = _flat_adam(algorithm, actor, critic, "exp_avg_sq")
             out[f"u{u}_ret_rms"] = np.array([float(algorithm.ret_rms.mean),
                                              float(algorithm.ret_rms.var),
                                              float(algorithm.ret_rms.count)])
@@ -462,13 +484,22 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
                return_scaling=float(algorithm.return_scaling), lr=lr,
                max_batchsize=float(algorithm.max_batchsize))
     cfg["is_a2c"] = float(algo == "a2c")
+    g0 = algorithm.optim._optim.param_groups[0]
+    cfg["max_action"] = float(max_action or 0.0)                                  # 0: unbounded
+    cfg["opt_rmsprop"] = float(type(algorithm.optim._optim).__name__ == "RMSprop")
+    cfg["weight_decay"] = float(g0.get("weight_decay", 0.0))
+    cfg["opt_eps"] = float(g0["eps"])
+    cfg["rms_alpha"] = float(g0.get("alpha", 0.99))
+    cfg["rms_momentum"] = float(g0.get("momentum", 0.0))
+    cfg["rms_centered"] = float(g0.get("centered", False))
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_{tag}.npz"), **out)
 
 
 def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_a: list[int], hidden_c: list[int], activation,
-                batch_size: int, repeat: int, seed: int, algo: str = "ppo", conditioned_sigma: bool = False, **ppo_kwargs) -> None:
+                batch_size: int, repeat: int, seed: int, algo: str = "ppo", conditioned_sigma: bool = False,
+                max_action: float | None = None, optim: tuple[str, dict] | None = None, **ppo_kwargs) -> None:
     """The reference PPO / A2C update() for actor-critics whose trunks are Net(hidden_sizes=..., activation=...) of any depth
     (utils/net/common.py:90-178, 246-369; `activation` = nn.Tanh, nn.ReLU or None): inputs, Batch.split's permutations,
     per-step losses and the parameters / Adam moments after the update, as lists of tensors in module order
@@ -477,8 +508,12 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
     torch.manual_seed(seed)
     N = E * T
     net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden_a, activation=activation)
-    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
-                                         conditioned_sigma=conditioned_sigma)
+    if max_action is None:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
+                                             conditioned_sigma=conditioned_sigma)
+    else:       # the constructor default: mu = max_action * tanh(Linear(h)) (continuous.py:194, 230-231)
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action,
+                                             conditioned_sigma=conditioned_sigma)
     net_c = Net(state_shape=(obs_dim,), hidden_sizes=hidden_c, activation=activation)
     critic = ContinuousCritic(preprocess_net=net_c)
     if not conditioned_sigma:
@@ -500,7 +535,13 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
                                       action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,)))
     lr = ppo_kwargs.pop("lr", 3e-4)
     cls = PPO if algo == "ppo" else A2C
-    algorithm = cls(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=lr), **ppo_kwargs)
+    if optim is not None and optim[0] == "rmsprop":
+        from tianshou.algorithm.optim import RMSpropOptimizerFactory
+
+        optim_factory = RMSpropOptimizerFactory(lr=lr, **optim[1])
+    else:
+        optim_factory = AdamOptimizerFactory(lr=lr, **(optim[1] if optim else {}))
+    algorithm = cls(policy=policy, critic=critic, optim=optim_factory, **ppo_kwargs)
 
     def tensors(mod, head):
         lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)]
@@ -515,7 +556,8 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
     out: dict[str, np.ndarray] = {"dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat]),
                                   "hidden_a": np.array(hidden_a), "hidden_c": np.array(hidden_c),
                                   "activation": np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation]),
-                                  "conditioned_sigma": np.array(int(conditioned_sigma))}
+                                  "conditioned_sigma": np.array(int(conditioned_sigma)),
+                                  "max_action": np.array(float(max_action or 0.0))}
     for i, t in enumerate(a_par):
         out[f"a{i}_0"] = t.detach().numpy().copy()
     for i, t in enumerate(c_par):
@@ -576,21 +618,28 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
         SequenceSummaryStats.from_sequence = classmethod(orig_from)
         cls._preprocess_batch = orig_pre
     opt = algorithm.optim._optim
+    rms = type(opt).__name__ == "RMSprop"
+    g0 = opt.param_groups[0]
+    k_m = ("momentum_buffer" if g0.get("momentum", 0) > 0 else ("grad_avg" if g0.get("centered") else None)) if rms else "exp_avg"
+    k_v = "square_avg" if rms else "exp_avg_sq"
     for i, t in enumerate(a_par):
         out[f"a{i}_1"] = t.detach().numpy().copy()
-        out[f"a{i}_m"] = opt.state[t]["exp_avg"].numpy().copy()
-        out[f"a{i}_v"] = opt.state[t]["exp_avg_sq"].numpy().copy()
+        out[f"a{i}_m"] = opt.state[t][k_m].numpy().copy() if k_m else np.zeros_like(out[f"a{i}_1"])
+        out[f"a{i}_v"] = opt.state[t][k_v].numpy().copy()
     for i, t in enumerate(c_par):
         out[f"c{i}_1"] = t.detach().numpy().copy()
-        out[f"c{i}_m"] = opt.state[t]["exp_avg"].numpy().copy()
-        out[f"c{i}_v"] = opt.state[t]["exp_avg_sq"].numpy().copy()
+        out[f"c{i}_m"] = opt.state[t][k_m].numpy().copy() if k_m else np.zeros_like(out[f"c{i}_1"])
+        out[f"c{i}_v"] = opt.state[t][k_v].numpy().copy()
     for k, v in pre_dump.items():
         out["pre_" + k] = v
     cfg = dict(gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=getattr(algorithm, "eps_clip", 0.0),
                dual_clip=getattr(algorithm, "dual_clip", None) or 0.0, value_clip=float(getattr(algorithm, "value_clip", False)),
                advantage_normalization=float(getattr(algorithm, "advantage_normalization", False)), vf_coef=algorithm.vf_coef,
                ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm or 0.0,
-               return_scaling=float(algorithm.return_scaling), lr=lr, is_a2c=float(algo == "a2c"))
+               return_scaling=float(algorithm.return_scaling), lr=lr, is_a2c=float(algo == "a2c"),
+               opt_rmsprop=float(rms), weight_decay=float(g0.get("weight_decay", 0.0)), opt_eps=float(g0["eps"]),
+               rms_alpha=float(g0.get("alpha", 0.99)), rms_momentum=float(g0.get("momentum", 0.0)),
+               rms_centered=float(g0.get("centered", False)))
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"ppo_net_{tag}.npz"), **out)
@@ -613,6 +662,42 @@ def gen_ppo_net_all() -> None:
     gen_ppo_net("linear4", E=2, T=64, obs_dim=20, act_dim=5, hidden_a=[32, 32, 32, 32], hidden_c=[33, 17, 9, 5], activation=None,
                 batch_size=128, repeat=1, seed=13, eps_clip=0.1, dual_clip=2.0, vf_coef=0.25, ent_coef=0.0, max_grad_norm=None,
                 value_clip=False, advantage_normalization=False, return_scaling=True, gae_lambda=0.95, gamma=0.99)
+
+
+def gen_ppo_round6() -> None:
+    """Round 6: the reference's DEFAULT Gaussian actor (unbounded=False: mu = max_action * tanh(.), continuous.py:194,
+    230-231) and the other optimizer factories of tianshou/algorithm/optim.py (RMSprop: the optimizer of
+    examples/mujoco/mujoco_a2c.py:117; Adam with weight decay, optim.py:95-109)."""
+    # PPO, MuJoCo nets, bounded actor with the default max_action = 1
+    gen_ppo("bounded", E=6, T=64, obs_dim=17, act_dim=6, batch_size=96, repeat=2, seed=21, n_updates=2, max_action=1.0,
+            gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.01, return_scaling=True, eps_clip=0.2,
+            value_clip=True, dual_clip=None, advantage_normalization=True, recompute_advantage=False, max_batchsize=256)
+    # A2C exactly as examples/mujoco/mujoco_a2c.py:117-121 builds its optimizer: RMSprop(lr=7e-4, eps=1e-5, alpha=0.99)
+    gen_ppo("a2c_rmsprop", algo="a2c", E=4, T=60, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=22, n_updates=2,
+            optim=("rmsprop", dict(eps=1e-5, alpha=0.99)), vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95,
+            gamma=0.99, return_scaling=True, lr=7e-4, max_batchsize=256)
+    # PPO with Adam(weight_decay) and a bounded actor with max_action = 2
+    gen_ppo("adam_wd", E=4, T=48, obs_dim=17, act_dim=6, batch_size=64, repeat=2, seed=23, n_updates=2, max_action=2.0,
+            optim=("adam", dict(weight_decay=1e-2)), gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, vf_coef=0.25, ent_coef=0.0,
+            return_scaling=False, eps_clip=0.2, value_clip=False, dual_clip=None, advantage_normalization=True,
+            recompute_advantage=False, max_batchsize=256, lr=1e-3)
+    # RMSprop with momentum and weight decay; centered RMSprop (two short A2C runs)
+    gen_ppo("rms_momentum", algo="a2c", E=3, T=40, obs_dim=17, act_dim=6, batch_size=60, repeat=1, seed=24, n_updates=2,
+            optim=("rmsprop", dict(eps=1e-5, alpha=0.95, momentum=0.9, weight_decay=1e-3)), vf_coef=0.5, ent_coef=0.0,
+            max_grad_norm=None, gae_lambda=0.95, gamma=0.99, return_scaling=False, lr=5e-4, max_batchsize=256)
+    gen_ppo("rms_centered", algo="a2c", E=3, T=40, obs_dim=17, act_dim=6, batch_size=60, repeat=1, seed=25, n_updates=2,
+            optim=("rmsprop", dict(eps=1e-5, alpha=0.9, centered=True)), vf_coef=0.5, ent_coef=0.0,
+            max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99, return_scaling=False, lr=5e-4, max_batchsize=256)
+    # per-layer engine: bounded actor over a three-layer ReLU trunk (max_action 1.5), RMSprop
+    gen_ppo_net("bounded_relu3", E=4, T=50, obs_dim=11, act_dim=3, hidden_a=[96, 72, 40], hidden_c=[64, 48], activation=nn.ReLU,
+                max_action=1.5, optim=("rmsprop", dict(eps=1e-5, alpha=0.99)), batch_size=64, repeat=2, seed=26, eps_clip=0.2,
+                vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, value_clip=True, advantage_normalization=True, return_scaling=False,
+                gae_lambda=0.95, gamma=0.99)
+    # per-layer engine: bounded actor with conditioned sigma, Net[128, 128] tanh (the "wide" shape), Adam + weight decay
+    gen_ppo_net("bounded_cs", E=4, T=48, obs_dim=9, act_dim=4, hidden_a=[128, 128], hidden_c=[128, 128], activation=nn.Tanh,
+                conditioned_sigma=True, max_action=1.0, optim=("adam", dict(weight_decay=5e-3)), batch_size=64, repeat=2, seed=27,
+                eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=0.5, value_clip=True, advantage_normalization=True,
+                return_scaling=False, gae_lambda=0.95, gamma=0.99)
 
 
 def gen_ppo_sched() -> None:
@@ -1195,6 +1280,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_round6":
+        gen_ppo_round6()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_sched":
         gen_ppo_sched()

@@ -93,9 +93,12 @@ def _trunk(obs, w1, b1, w2, b2):
     return torch.tanh(torch.nn.functional.linear(h, w2, b2))
 
 
-def actor_forward(p, obs):
+def actor_forward(p, obs, max_action: float | None = None):
+    """ContinuousActorProbabilistic.forward (continuous.py:220-238); max_action = None: unbounded=True."""
     h = _trunk(obs, p["a_w1"], p["a_b1"], p["a_w2"], p["a_b2"])
     mu = torch.nn.functional.linear(h, p["a_wmu"], p["a_bmu"])
+    if max_action is not None:
+        mu = max_action * torch.tanh(mu)                     # continuous.py:230-231 (unbounded=False, the default)
     # continuous.py:236-238: sigma = (sigma_param.view(1,-1) + zeros_like(mu)).exp()
     sigma = (p["a_sigma"].view(1, -1) + torch.zeros_like(mu)).exp()
     return mu, sigma
@@ -128,6 +131,13 @@ class PPOConfig:
     betas: tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
     max_batchsize: int = 256
+    # optim.py:89-140: "adam" (AdamOptimizerFactory) or "rmsprop" (RMSpropOptimizerFactory; lr / adam_eps shared)
+    optimizer: str = "adam"
+    weight_decay: float = 0.0
+    rms_alpha: float = 0.99
+    rms_momentum: float = 0.0
+    rms_centered: bool = False
+    max_action: float | None = None    # the actor's tanh bound (None: unbounded=True)
 
 
 @dataclass
@@ -202,7 +212,7 @@ def preprocess(state: PPOState, cfg: PPOConfig, obs, obs_next, act, rew, termina
     logp = []
     with torch.no_grad():
         for lo, hi in split_slices(obs.shape[0], cfg.max_batchsize, merge_last=True):
-            mu, sigma = actor_forward(state.params, obs[lo:hi])
+            mu, sigma = actor_forward(state.params, obs[lo:hi], cfg.max_action)
             logp.append(dist_of(mu, sigma).log_prob(act[lo:hi]))
     return {"v_s": v_s, "returns": returns, "adv": adv, "logp_old": torch.cat(logp).flatten()}
 
@@ -211,6 +221,8 @@ def _adam_step(state: PPOState, cfg: PPOConfig, grads: dict):
     """torch.optim.Adam (optim.py:104-110: lr, betas, eps, weight_decay=0; no amsgrad),
     single-tensor formulation: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
     p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)."""
+    if cfg.optimizer == "rmsprop":
+        return _rmsprop_step(state, cfg, grads)
     b1, b2 = cfg.betas
     state.adam_step += 1
     t = state.adam_step
@@ -220,6 +232,8 @@ def _adam_step(state: PPOState, cfg: PPOConfig, grads: dict):
     bc2_sqrt = math.sqrt(bc2)
     for k in PARAM_ORDER:
         g = grads[k]
+        if cfg.weight_decay != 0:
+            g = g.add(state.params[k], alpha=cfg.weight_decay)      # torch/optim/adam.py _single_tensor_adam
         if k not in state.adam_m:
             state.adam_m[k] = torch.zeros_like(g)
             state.adam_v[k] = torch.zeros_like(g)
@@ -230,9 +244,39 @@ def _adam_step(state: PPOState, cfg: PPOConfig, grads: dict):
         state.params[k] = state.params[k].addcdiv(m, denom, value=-step_size)
 
 
+def _rmsprop_step(state: PPOState, cfg: PPOConfig, grads: dict):
+    """torch.optim.RMSprop (optim.py:113-140), torch/optim/rmsprop.py `_single_tensor_rmsprop` operation by operation;
+    square_avg lives in state.adam_v, the momentum buffer (momentum > 0) or grad_avg (centered) in state.adam_m."""
+    assert not (cfg.rms_centered and cfg.rms_momentum > 0), "one auxiliary state vector"
+    state.adam_step += 1
+    alpha = cfg.rms_alpha
+    for k in PARAM_ORDER:
+        g = grads[k]
+        if cfg.weight_decay != 0:
+            g = g.add(state.params[k], alpha=cfg.weight_decay)
+        if k not in state.adam_v:
+            state.adam_m[k] = torch.zeros_like(g)
+            state.adam_v[k] = torch.zeros_like(g)
+        sq = state.adam_v[k]
+        sq.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        if cfg.rms_centered:
+            ga = state.adam_m[k]
+            ga.lerp_(g, 1 - alpha)
+            avg = sq.addcmul(ga, ga, value=-1).sqrt_()
+        else:
+            avg = sq.sqrt()
+        avg = avg.add_(cfg.adam_eps)
+        if cfg.rms_momentum > 0:
+            buf = state.adam_m[k]
+            buf.mul_(cfg.rms_momentum).addcdiv_(g, avg)
+            state.params[k] = state.params[k].add(buf, alpha=-cfg.lr)
+        else:
+            state.params[k] = state.params[k].addcdiv(g, avg, value=-cfg.lr)
+
+
 def ppo_minibatch_loss(p, cfg: PPOConfig, obs, act, adv, returns, logp_old, v_s):
     """ppo.py:181-211 on one minibatch -> (loss, clip_loss, vf_loss, ent_loss)."""
-    mu, sigma = actor_forward(p, obs)
+    mu, sigma = actor_forward(p, obs, cfg.max_action)
     dist = dist_of(mu, sigma)
     if cfg.advantage_normalization:
         mean, std = adv.mean(), adv.std()
@@ -262,7 +306,7 @@ def ppo_minibatch_loss(p, cfg: PPOConfig, obs, act, adv, returns, logp_old, v_s)
 
 def a2c_minibatch_loss(p, cfg: PPOConfig, obs, act, adv, returns):
     """a2c.py:262-273 on one minibatch -> (loss, actor_loss, vf_loss, ent_loss)."""
-    mu, sigma = actor_forward(p, obs)
+    mu, sigma = actor_forward(p, obs, cfg.max_action)
     dist = dist_of(mu, sigma)
     log_prob = dist.log_prob(act)
     log_prob = log_prob.reshape(len(adv), -1).transpose(0, 1)

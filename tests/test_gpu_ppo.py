@@ -138,10 +138,20 @@ def _cfg_from_golden(g):
         advantage_normalization=bool(c["advantage_normalization"]),
         recompute_advantage=bool(c["recompute_advantage"]), vf_coef=c["vf_coef"], ent_coef=c["ent_coef"],
         max_grad_norm=(c["max_grad_norm"] or None), return_scaling=bool(c["return_scaling"]), lr=c["lr"],
-        algo="a2c" if c.get("is_a2c") else "ppo")
+        algo="a2c" if c.get("is_a2c") else "ppo",
+        # round 6 (absent from the older fixtures: Adam without weight decay, unbounded actor)
+        optimizer="rmsprop" if c.get("opt_rmsprop") else "adam", weight_decay=float(c.get("weight_decay", 0.0)),
+        adam_eps=float(c.get("opt_eps", 1e-8)), rms_alpha=float(c.get("rms_alpha", 0.99)),
+        rms_momentum=float(c.get("rms_momentum", 0.0)), rms_centered=bool(c.get("rms_centered", 0.0)),
+        max_action=(float(c["max_action"]) if c.get("max_action") else None))
 
 
-@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c", "sched"])
+# round 6: the reference's default (bounded) Gaussian actor (continuous.py:194, 230-231), RMSprop as in
+# examples/mujoco/mujoco_a2c.py:117, Adam with weight decay (optim.py:95-109), RMSprop with momentum / centered
+R6_TAGS = ["bounded", "a2c_rmsprop", "adam_wd", "rms_momentum", "rms_centered"]
+
+
+@pytest.mark.parametrize("tag", ["mujoco", "defaults", "a2c", "sched"] + R6_TAGS)
 def test_update_matches_reference_golden(tag):
     """Same Batch inputs, initial weights and permutations as the reference run that produced
     tests/golden/ppo_<tag>.npz; compares every intermediate the reference exposes."""
@@ -176,7 +186,11 @@ def test_update_matches_reference_golden(tag):
         assert steps == int(g[f"u{u}_gradient_steps"])
         np.testing.assert_allclose(losses.cpu().numpy(), g[f"u{u}_losses"], rtol=1e-5, atol=2e-6)
         np.testing.assert_allclose(eng.params.cpu().numpy(), g[f"u{u}_flat_params"], rtol=1e-4, atol=3e-6)
-        np.testing.assert_allclose(eng.adam_m.cpu().numpy(), g[f"u{u}_adam_m"], rtol=1e-3, atol=1e-7)
+        # (RMSprop's momentum buffer sums g / sqrt(E[g^2]): every gradient component enters NORMALISED, as a term of O(1..5)
+        # whatever its size, so a component at the gradient's rounding floor -- relative error ~1e-5 of the block's scale,
+        # the bar of the gradient tests -- moves its entry by ~1e-5 of the buffer's scale)
+        np.testing.assert_allclose(eng.adam_m.cpu().numpy(), g[f"u{u}_adam_m"], rtol=1e-3,
+                                   atol=max(1e-7, (1e-5 if eng.cfg.rms_momentum else 2e-7) * float(np.abs(g[f"u{u}_adam_m"]).max())))
         np.testing.assert_allclose(eng.adam_v.cpu().numpy(), g[f"u{u}_adam_v"], rtol=1e-3, atol=1e-10)
         np.testing.assert_allclose(eng.ret_rms, g[f"u{u}_ret_rms"], rtol=1e-5)  # stats of fp32-accurate returns
 

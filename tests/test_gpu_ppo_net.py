@@ -10,7 +10,9 @@ import pytest
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TAGS = ["relu3", "tanh1_a2c", "linear4", "csigma"]
+# round 6: "bounded_*" = the reference's default actor (unbounded=False: mu = max_action * tanh(.), continuous.py:230-231)
+# on the per-layer engine, with RMSprop (optim.py:113-140) / Adam + weight decay (optim.py:95-109)
+TAGS = ["relu3", "tanh1_a2c", "linear4", "csigma", "bounded_relu3", "bounded_cs"]
 
 
 def _load(tag):
@@ -19,6 +21,7 @@ def _load(tag):
     ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
     cs = bool(int(g["conditioned_sigma"])) if "conditioned_sigma" in g else False
     g["_cs"] = cs
+    g["_max_action"] = float(g["max_action"]) if "max_action" in g and float(g["max_action"]) > 0 else None
     na, nc = 2 * (len(ha) + 1) + (2 if cs else 1), 2 * (len(hc) + 1)
     return g, cfg, ha, hc, na, nc
 
@@ -63,7 +66,11 @@ def test_update_matches_the_reference(tag):
     pcfg = P.PPOConfig(algo="a2c" if a2c else "ppo", gamma=cfg["gamma"], gae_lambda=cfg["gae_lambda"], eps_clip=cfg["eps_clip"],
                        dual_clip=cfg["dual_clip"] or None, value_clip=bool(cfg["value_clip"]),
                        advantage_normalization=bool(cfg["advantage_normalization"]), vf_coef=cfg["vf_coef"], ent_coef=cfg["ent_coef"],
-                       max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), lr=cfg["lr"])
+                       max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), lr=cfg["lr"],
+                       optimizer="rmsprop" if cfg.get("opt_rmsprop") else "adam", weight_decay=cfg.get("weight_decay", 0.0),
+                       adam_eps=cfg.get("opt_eps", 1e-8), rms_alpha=cfg.get("rms_alpha", 0.99),
+                       rms_momentum=cfg.get("rms_momentum", 0.0), rms_centered=bool(cfg.get("rms_centered", 0.0)),
+                       max_action=g["_max_action"])
     a0 = [torch.from_numpy(g[f"a{i}_0"]) for i in range(na)]
     c0 = [torch.from_numpy(g[f"c{i}_0"]) for i in range(nc)]
     flat = torch.cat([net_flat_from_tensors(a0, obs_dim, ha, act_dim, conditioned_sigma=g["_cs"]),

@@ -125,6 +125,70 @@ def test_unsupported_nets_are_rejected():
             _check_supported(*bad)
 
 
+def test_trunks_that_are_not_linear_activation_pairs_are_rejected():
+    """a Net built with action_shape > 0 (MLP output_dim > 0, utils/net/common.py:169-170) ends in a bare Linear
+    layer, Net(softmax=True) appends a softmax; the engines apply the activation after EVERY trunk layer, so both must be
+    refused instead of silently training a different network.  Without an activation the trailing Linear IS just another
+    linear layer (same function): accepted."""
+    ref_shim.install()
+    from torch import nn
+
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import _check_supported, _trunk_spec
+
+    def actor(net):
+        return ContinuousActorProbabilistic(preprocess_net=net, action_shape=(6,), unbounded=True)
+
+    critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+    with_out = Net(state_shape=(17,), action_shape=24, hidden_sizes=[64, 64], activation=nn.Tanh)
+    assert isinstance(list(with_out.model.model)[-1], nn.Linear)
+    with pytest.raises(NotImplementedError, match="followed by its activation"):
+        _check_supported(actor(with_out), critic)
+    with pytest.raises(NotImplementedError, match="softmax"):
+        _trunk_spec(actor(Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh, softmax=True)), "actor")
+    lin = Net(state_shape=(17,), action_shape=24, hidden_sizes=[64, 64], activation=None)
+    assert _trunk_spec(actor(lin), "actor")[1:] == ([64, 64, 24], "none")
+
+
+def test_default_bounded_actor_and_rmsprop_are_inside_the_envelope():
+    """ContinuousActorProbabilistic's constructor default is unbounded=False (continuous.py:194,
+    230-231) and examples/mujoco/mujoco_a2c.py:117 trains with RMSprop: both map onto the engine configuration."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch import nn
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory, RMSpropOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import _check_supported, make_hip_ppo, ppo_config_from
+
+    def build(algo, hidden, optim, **actor_kw):
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=nn.Tanh),
+                                             action_shape=(6,), **actor_kw)
+        critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=nn.Tanh))
+        policy = ProbabilisticActorPolicy(actor=actor, dist_fn=lambda ls: Independent(Normal(*ls), 1), action_scaling=False,
+                                          action_bound_method=None, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+        return make_hip_ppo(algo)(policy=policy, critic=critic, optim=optim, device="cpu", permutations="host")
+
+    a = build("a2c", [64, 64], RMSpropOptimizerFactory(lr=7e-4, eps=1e-5, alpha=0.99))            # mujoco_a2c.py:117-121
+    assert a._hip_dims == (17, 6, 64, "fused")
+    c = ppo_config_from(a)
+    assert (c.algo, c.optimizer, c.lr, c.adam_eps, c.rms_alpha, c.rms_momentum, c.rms_centered, c.weight_decay) == \
+        ("a2c", "rmsprop", 7e-4, 1e-5, 0.99, 0.0, False, 0.0)
+    assert c.max_action == 1.0 and c.to_c().optimizer == 1 and c.to_c().max_action == 1.0          # default actor: bounded
+    b = build("ppo", [128, 128], AdamOptimizerFactory(lr=1e-3, weight_decay=1e-2), max_action=2.5)
+    assert b._hip_dims == (17, 6, ((128, 128), (128, 128), "tanh"), "net")       # bounded: the per-layer engine, not "wide"
+    cb = ppo_config_from(b)
+    assert (cb.optimizer, cb.weight_decay, cb.max_action) == ("adam", 1e-2, 2.5)
+    u = build("ppo", [128, 128], AdamOptimizerFactory(lr=1e-3), unbounded=True)
+    assert u._hip_dims == (17, 6, 128, "wide") and ppo_config_from(u).max_action is None
+    with pytest.raises(NotImplementedError, match="one auxiliary"):
+        ppo_config_from(build("a2c", [64, 64], RMSpropOptimizerFactory(lr=1e-3, momentum=0.9, centered=True)))
+
+
 def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):
     """HipPPO.update over the REAL reference PPO (CPU engine double): same steps as Algorithm._update
     (algorithm_base.py:586-631) minus the host `buffer.sample(0)`; the scheduler's learning rate reaches the engine on

@@ -48,6 +48,12 @@ class PPOHParams(C.Structure):
         ("adv_norm", C.c_int32),
         ("algo", C.c_int32),
         ("nets", C.c_int32),
+        ("optimizer", C.c_int32),
+        ("rms_centered", C.c_int32),
+        ("weight_decay", C.c_double),
+        ("rms_alpha", C.c_double),
+        ("rms_momentum", C.c_double),
+        ("max_action", C.c_double),
     ]
 
 
@@ -59,16 +65,17 @@ class NetDesc(C.Structure):
     ACTIVATIONS = {"tanh": 0, "relu": 1, "none": 2}
     CONDITIONED_SIGMA = 1
     _fields_ = [("obs_dim", C.c_int64), ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden", C.c_int64 * 7),
-                ("flags", C.c_int64)]
+                ("flags", C.c_int64), ("max_action", C.c_double)]
 
     @classmethod
-    def make(cls, obs_dim: int, hidden, activation: str, flags: int = 0) -> "NetDesc":
+    def make(cls, obs_dim: int, hidden, activation: str, flags: int = 0, max_action: float = 0.0) -> "NetDesc":
         hidden = [int(h) for h in hidden]
         if not 1 <= len(hidden) <= cls.MAX_HIDDEN:
             raise NotImplementedError(f"trunks of 1 .. {cls.MAX_HIDDEN} hidden layers are supported, got {len(hidden)}")
         if activation not in cls.ACTIVATIONS:
             raise NotImplementedError(f"activation must be one of {sorted(cls.ACTIVATIONS)}, got {activation!r}")
-        d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))), int(flags))
+        d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))), int(flags),
+                float(max_action or 0.0))
         return d
 
 

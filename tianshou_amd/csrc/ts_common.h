@@ -105,6 +105,24 @@ int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
 int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b);     // both side streams
 int record_td(ts_workspace* ws, hipStream_t s);       // the new priorities / the loss of an update are written on `s`
 
+// Optimizer.step over one flat parameter vector (ts_optim.hip): torch.optim.Adam (optim.py:89-110) or torch.optim.RMSprop
+// (optim.py:113-140), both with the optional L2 term `grad += weight_decay * param` that torch applies inside step(),
+// after clip_grad_norm_.  State vectors: Adam exp_avg -> m, exp_avg_sq -> v; RMSprop square_avg -> v and the momentum
+// buffer (momentum > 0) or grad_avg (centered) -> m.
+struct OptimDesc {
+    int kind = TS_OPT_ADAM;
+    int centered = 0;
+    double weight_decay = 0.0, alpha = 0.99, momentum = 0.0;
+};
+inline OptimDesc optim_from(const ts_ppo_hparams* hp) {
+    OptimDesc o;
+    o.kind = hp->optimizer; o.centered = hp->rms_centered;
+    o.weight_decay = hp->weight_decay; o.alpha = hp->rms_alpha; o.momentum = hp->rms_momentum;
+    return o;
+}
+int optim_step(hipStream_t s, const OptimDesc& o, float* params, float* m, float* v, const float* grad, int64_t n,
+               int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {
     ts_workspace* ws;

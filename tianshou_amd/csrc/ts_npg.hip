@@ -133,10 +133,14 @@ __global__ __launch_bounds__(256) void jvp_combine_kernel(const float* __restric
 }
 
 // Independent(Normal(mu, exp(s)), 1).log_prob(act) for one sample (torch/distributions/normal.py)
-__device__ __forceinline__ float gauss_logp(const float* mu, const float* act, const float* log_sigma, int A) {
+// mu_bound > 0: ContinuousActorProbabilistic(unbounded=False), the constructor default (utils/net/continuous.py:230-231):
+// the distribution's mean is max_action * tanh(head output)
+__device__ __forceinline__ float bounded_mu(float raw, float mu_bound) { return mu_bound > 0.f ? mu_bound * tanhf(raw) : raw; }
+
+__device__ __forceinline__ float gauss_logp(const float* mu, const float* act, const float* log_sigma, int A, float mu_bound = 0.f) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) {
-        const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[j] - mu[j];
+        const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[j] - bounded_mu(mu[j], mu_bound);
         lp += -(d * d) / (2.f * var) - logf(sigma) - LOG_SQRT_2PI;
     }
     return lp;
@@ -145,12 +149,12 @@ __device__ __forceinline__ float gauss_logp(const float* mu, const float* act, c
 __global__ __launch_bounds__(256) void infer_out_kernel(const float* __restrict__ mu_head, const float* __restrict__ v_head,
                                                         const float* __restrict__ act, const float* __restrict__ log_sigma,
                                                         int64_t B, int A, float* __restrict__ v_out, float* __restrict__ logp_out,
-                                                        float* __restrict__ mu_out) {
+                                                        float* __restrict__ mu_out, float mu_bound = 0.f) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     if (v_out) v_out[b] = v_head[b * HEAD];
-    if (logp_out) logp_out[b] = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A);
-    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = mu_head[b * HEAD + j];
+    if (logp_out) logp_out[b] = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A, mu_bound);
+    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = bounded_mu(mu_head[b * HEAD + j], mu_bound);
 }
 
 // block-wide deterministic sum (256 threads): all threads get the result
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void critic_loss_kernel(const float* __restric
 // cover, e.g. Humanoid's obs 376 / act 17 / hidden 256) -----------------------------------------------------------------
 // PPO._update_with_batch (ppo.py:181-211) per sample, same branch / tie semantics as ts_ppo.hip's net_fwd_bwd:
 // term_b and d term_b / d logp_b; d_head = d loss / d mu, per-block partial sums of the loss terms and of d loss / d sigma.
-struct WideLossP { float eps_clip, dual_clip, ent_coef, inv_b; int a2c, adv_norm; };
+struct WideLossP { float eps_clip, dual_clip, ent_coef, inv_b; int a2c, adv_norm; float mu_bound; };
 
 __global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* __restrict__ mu_head, const float* __restrict__ act,
                                                                   const float* __restrict__ adv, const float* __restrict__ logp_old,
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* _
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float term = 0.f, dlogp = 0.f;
     if (b < B) {
-        const float lp = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A);
+        const float lp = gauss_logp(mu_head + b * HEAD, act + b * A, log_sigma, A, hp.mu_bound);
         float Ab = adv[b];
         if (hp.adv_norm) Ab = (Ab - adv_stats[0]) / (adv_stats[1] + 1e-8f);            // ppo.py:184-186
         if (hp.a2c) {                                                                  // a2c.py:266-267
@@ -478,8 +482,11 @@ __global__ __launch_bounds__(256) void ppo_wide_actor_loss_kernel(const float* _
     for (int j = 0; j < HEAD; ++j) {
         float ds = 0.f, dm = 0.f;
         if (b < B && j < A) {
-            const float sigma = expf(log_sigma[j]), var = sigma * sigma, d = act[b * A + j] - mu_head[b * HEAD + j];
+            const float raw = mu_head[b * HEAD + j], tb = hp.mu_bound > 0.f ? tanhf(raw) : 0.f;
+            const float sigma = expf(log_sigma[j]), var = sigma * sigma;
+            const float d = act[b * A + j] - (hp.mu_bound > 0.f ? hp.mu_bound * tb : raw);
             dm = dlogp * d / var;
+            if (hp.mu_bound > 0.f) dm = (dm * hp.mu_bound) * (1.f - tb * tb);          // MulBackward, then TanhBackward
             ds = dlogp * (d * d / var - 1.f) - hp.ent_coef * hp.inv_b;                 // entropy: d / d log_sigma = 1
         }
         if (b < B) d_head[b * HEAD + j] = dm;
@@ -539,11 +546,11 @@ __global__ void ppo_wide_total_kernel(float* __restrict__ losses, const float* _
 constexpr int CS_COL = 16;
 constexpr float CS_MIN = -20.f, CS_MAX = 2.f;
 
-__device__ __forceinline__ float gauss_logp_cs(const float* head, const float* act, int A) {
+__device__ __forceinline__ float gauss_logp_cs(const float* head, const float* act, int A, float mu_bound = 0.f) {
     float lp = 0.f;
     for (int j = 0; j < A; ++j) {
         const float ls = fminf(fmaxf(head[CS_COL + j], CS_MIN), CS_MAX);
-        const float sigma = expf(ls), var = sigma * sigma, d = act[j] - head[j];
+        const float sigma = expf(ls), var = sigma * sigma, d = act[j] - bounded_mu(head[j], mu_bound);
         lp += -(d * d) / (2.f * var) - logf(sigma) - LOG_SQRT_2PI;
     }
     return lp;
@@ -552,12 +559,12 @@ __device__ __forceinline__ float gauss_logp_cs(const float* head, const float* a
 __global__ __launch_bounds__(256) void infer_out_cs_kernel(const float* __restrict__ mu_head, const float* __restrict__ v_head,
                                                            const float* __restrict__ act, int64_t B, int A,
                                                            float* __restrict__ v_out, float* __restrict__ logp_out,
-                                                           float* __restrict__ mu_out) {
+                                                           float* __restrict__ mu_out, float mu_bound = 0.f) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     if (v_out) v_out[b] = v_head[b * HEAD];
-    if (logp_out) logp_out[b] = gauss_logp_cs(mu_head + b * HEAD, act + b * A, A);
-    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = mu_head[b * HEAD + j];
+    if (logp_out) logp_out[b] = gauss_logp_cs(mu_head + b * HEAD, act + b * A, A, mu_bound);
+    if (mu_out) for (int j = 0; j < A; ++j) mu_out[b * A + j] = bounded_mu(mu_head[b * HEAD + j], mu_bound);
 }
 
 // The clipped-surrogate / A2C actor loss of ppo_wide_actor_loss_kernel with a per-sample sigma: the gradient w.r.t. log sigma
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(256) void ppo_net_actor_loss_cs_kernel(const float*
     float term = 0.f, dlogp = 0.f, ent = 0.f;
     if (b < B) {
         const float* hrow = head + b * HEAD;
-        const float lp = gauss_logp_cs(hrow, act + b * A, A);
+        const float lp = gauss_logp_cs(hrow, act + b * A, A, hp.mu_bound);
         float Ab = adv[b];
         if (hp.adv_norm) Ab = (Ab - adv_stats[0]) / (adv_stats[1] + 1e-8f);
         if (hp.a2c) {
@@ -598,9 +605,11 @@ __global__ __launch_bounds__(256) void ppo_net_actor_loss_cs_kernel(const float*
         for (int j = 0; j < A; ++j) {
             const float raw = hrow[CS_COL + j];
             const float ls = fminf(fmaxf(raw, CS_MIN), CS_MAX);
-            const float sigma = expf(ls), var = sigma * sigma, d = act[b * A + j] - hrow[j];
+            const float tb = hp.mu_bound > 0.f ? tanhf(hrow[j]) : 0.f;
+            const float sigma = expf(ls), var = sigma * sigma, d = act[b * A + j] - (hp.mu_bound > 0.f ? hp.mu_bound * tb : hrow[j]);
             ent += 0.5f + 0.5f * 1.8378770664093453f + logf(sigma);                     // Normal.entropy()
             drow[j] = dlogp * d / var;
+            if (hp.mu_bound > 0.f) drow[j] = (drow[j] * hp.mu_bound) * (1.f - tb * tb);
             const float dls = dlogp * (d * d / var - 1.f) - hp.ent_coef * hp.inv_b;
             drow[CS_COL + j] = (raw >= CS_MIN && raw <= CS_MAX) ? dls : 0.f;
         }
@@ -1133,7 +1142,7 @@ int ts_ppo_wide_step(ts_workspace* ws, float* params, float* adam_m, float* adam
     TS_LAUNCH_CHECK();
     if (!apply) return TS_OK;
     // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam
-    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+    return ts::optim_step(s, ts::optim_from(hp), params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm > 0.0 ? hp->max_grad_norm : 0.0, norm_part);
 }
 
@@ -1154,6 +1163,7 @@ int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, 
     const bool want_a = logp_out || mu_out;
     TS_REQUIRE(obs && act_dim >= 1 && act_dim <= HEAD && (!v_out || (critic && critic_net)) && (!want_a || (actor && actor_net)) &&
                    (!logp_out || act), TS_ERR_INVALID_ARG, "ts_ppo_net_infer: bad argument");
+    const float mu_bound = (want_a && actor_net->max_action > 0.0) ? (float)actor_net->max_action : 0.f;
     NetL na{}, nc{};
     if (want_a) if (int rc = make_netl((int)B, actor_net, &na)) return rc;
     if (v_out) if (int rc = make_netl((int)B, critic_net, &nc)) return rc;
@@ -1176,11 +1186,11 @@ int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, 
     if (want_a && na.csigma) {
         TS_REQUIRE(act_dim <= CS_COL, TS_ERR_UNSUPPORTED, "conditioned sigma: at most %d actions", CS_COL);
         hipLaunchKernelGGL(infer_out_cs_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, aa.h[na.L - 1],
-                           v_out ? ac.h[nc.L - 1] : nullptr, act, B, (int)act_dim, v_out, logp_out, mu_out);
+                           v_out ? ac.h[nc.L - 1] : nullptr, act, B, (int)act_dim, v_out, logp_out, mu_out, mu_bound);
     } else {
         hipLaunchKernelGGL(infer_out_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, s, want_a ? aa.h[na.L - 1] : nullptr,
                            v_out ? ac.h[nc.L - 1] : nullptr, act, want_a ? actor + na.off[na.L] : (const float*)nullptr, B, (int)act_dim,
-                           v_out, logp_out, mu_out);
+                           v_out, logp_out, mu_out, mu_bound);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
@@ -1240,6 +1250,7 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     WideLossP lp{};
     lp.eps_clip = (float)hp->eps_clip; lp.dual_clip = a2c ? 0.f : (float)(hp->dual_clip > 0.0 ? hp->dual_clip : 0.0);
     lp.ent_coef = (float)hp->ent_coef; lp.inv_b = inv_b; lp.a2c = a2c; lp.adv_norm = a2c ? 0 : hp->adv_norm;
+    lp.mu_bound = (float)(actor_net->max_action > 0.0 ? actor_net->max_action : 0.0);      // ts_net_desc.max_action
     if (na.csigma) {
         TS_REQUIRE(A <= CS_COL, TS_ERR_UNSUPPORTED, "conditioned sigma: at most %d actions", CS_COL);
         hipLaunchKernelGGL(ppo_net_actor_loss_cs_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, aa.h[na.L - 1], act, adv, logp_old,
@@ -1267,7 +1278,7 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     TS_LAUNCH_CHECK();
     if (!apply) return TS_OK;
     // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam
-    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+    return ts::optim_step(s, ts::optim_from(hp), params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm > 0.0 ? hp->max_grad_norm : 0.0, norm_part);
 }
 

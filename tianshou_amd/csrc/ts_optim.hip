@@ -77,6 +77,69 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     a.v[i] = v;
 }
 
+// ---- the general step: Adam or RMSprop, optional L2 weight decay -------------------------------
+// torch/optim/adam.py `_single_tensor_adam` and torch/optim/rmsprop.py `_single_tensor_rmsprop`, operation by operation
+// (the reference builds both through optim.py:89-140; examples/mujoco/mujoco_a2c.py:117 is RMSprop(eps=1e-5, alpha=0.99)).
+struct OptimArgs {
+    float* p; float* m; float* v; const float* g; int64_t n;
+    const float* part; int n_part; float max_norm;
+    int kind, centered;
+    float wd;
+    float lr, lr_step, beta2, bc2_sqrt, eps, omb1, omb2;     // Adam (lr_step = lr / bias_correction1)
+    float alpha, oma, momentum;                              // RMSprop (oma = 1 - alpha rounded from double)
+};
+
+__global__ __launch_bounds__(256) void optim_kernel(OptimArgs a) {
+    float scale = 1.f;
+    if (a.part) {
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int k = threadIdx.x; k < a.n_part; k += 256) s += a.part[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        scale = fminf(a.max_norm / (norm + 1e-6f), 1.f);     // clip_grad_norm_
+    }
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float par = a.p[i];
+    float gq = a.g[i] * scale;
+    if (a.wd != 0.f) gq = gq + a.wd * par;                   // grad.add(param, alpha=weight_decay)
+    if (a.kind == TS_OPT_RMSPROP) {
+        float sq = a.v[i];
+        sq = sq * a.alpha + a.oma * gq * gq;                 // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
+        float avg;
+        if (a.centered) {
+            float ga = a.m[i];
+            ga = ga + (gq - ga) * a.oma;                     // grad_avg.lerp_(grad, 1 - alpha)
+            a.m[i] = ga;
+            avg = sqrtf(sq + -1.f * ga * ga);                // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_()
+        } else {
+            avg = sqrtf(sq);
+        }
+        avg = avg + a.eps;
+        if (a.momentum > 0.f) {
+            float buf = a.m[i];
+            buf = buf * a.momentum + gq / avg;               // buf.mul_(momentum).addcdiv_(grad, avg)
+            a.m[i] = buf;
+            a.p[i] = par + -a.lr * buf;                      // param.add_(buf, alpha=-lr)
+        } else {
+            a.p[i] = par + (-a.lr * gq) / avg;               // param.addcdiv_(grad, avg, value=-lr)
+        }
+        a.v[i] = sq;
+        return;
+    }
+    float m = a.m[i], v = a.v[i];
+    m = m + (gq - m) * a.omb1;
+    v = v * a.beta2 + a.omb2 * gq * gq;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    a.p[i] = par + (-a.lr_step * m) / denom;
+    a.m[i] = m;
+    a.v[i] = v;
+}
+
 // The same step for up to three parameter vectors of equal length in one launch (blockIdx.y = vector), optionally
 // followed by the Polyak update of each vector's lagged copy from the NEW parameters (lagged_network.py:17-18) --
 // per element exactly adam_kernel (without clipping) and polyak_kernel.
@@ -105,6 +168,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamMultiArgs a) {
 }  // namespace
 
 namespace ts {
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
 int adam_step_multi(hipStream_t s, int nvec, float* const* params, float* const* m, float* const* v,
                     const float* const* grad, float* const* lagged, int64_t n, int64_t step, double lr, double beta1,
                     double beta2, double eps, double tau) {
@@ -123,6 +188,30 @@ int adam_step_multi(hipStream_t s, int nvec, float* const* params, float* const*
     a.eps = (float)eps;
     a.tau = (float)tau; a.one_minus_tau = (float)(1.0 - tau);
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)ceil_div(n, 256), (unsigned)nvec), dim3(256), 0, s, a);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int optim_step(hipStream_t s, const OptimDesc& o, float* params, float* m, float* v, const float* grad, int64_t n,
+               int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
+    if (o.kind == TS_OPT_ADAM && o.weight_decay == 0.0)       // the plain step keeps its own (leaner) kernel
+        return adam_step(s, params, m, v, grad, n, step, lr, beta1, beta2, eps, max_grad_norm, norm_scratch);
+    TS_REQUIRE(o.kind == TS_OPT_ADAM || o.kind == TS_OPT_RMSPROP, TS_ERR_UNSUPPORTED, "optimizer kind %d", o.kind);
+    TS_REQUIRE(!(o.kind == TS_OPT_RMSPROP && o.centered && o.momentum > 0.0), TS_ERR_UNSUPPORTED,
+               "RMSprop: centered together with momentum needs two auxiliary vectors (one is provided)");
+    OptimArgs a{};
+    a.p = params; a.m = m; a.v = v; a.g = grad; a.n = n;
+    if (max_grad_norm > 0) {
+        hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, n, norm_scratch);
+        a.part = norm_scratch; a.n_part = SUMSQ_BLOCKS; a.max_norm = (float)max_grad_norm;
+    }
+    a.kind = o.kind; a.centered = o.centered; a.wd = (float)o.weight_decay;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.lr = (float)lr; a.lr_step = (float)(lr / bc1);
+    a.beta2 = (float)beta2; a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+    a.bc2_sqrt = (float)sqrt(bc2); a.eps = (float)eps;
+    a.alpha = (float)o.alpha; a.oma = (float)(1.0 - o.alpha); a.momentum = (float)o.momentum;
+    hipLaunchKernelGGL(optim_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -163,6 +252,24 @@ int ts_adam_step(ts_workspace* ws, float* params, float* adam_m, float* adam_v, 
     }
     return ts::adam_step(ts::as_stream(stream), params, adam_m, adam_v, grad, n, step, lr, beta1, beta2, eps,
                          max_grad_norm, scratch);
+}
+
+int ts_optim_step(ts_workspace* ws, int32_t kind, float* params, float* state_m, float* state_v, const float* grad, int64_t n,
+                  int64_t step, double lr, double beta1, double beta2, double eps, double weight_decay, double rms_alpha,
+                  double rms_momentum, int32_t rms_centered, double max_grad_norm, ts_stream_t stream) {
+    TS_REQUIRE(n >= 0 && step >= 1, TS_ERR_INVALID_ARG, "ts_optim_step: bad n / step");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(params && state_m && state_v && grad, TS_ERR_INVALID_ARG, "ts_optim_step: NULL argument");
+    float* scratch = nullptr;
+    if (max_grad_norm > 0) {
+        TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_optim_step: clipping needs a workspace");
+        if (int rc = ts::ws_reserve(ws, 4096)) return rc;
+        scratch = static_cast<float*>(ws->base);
+    }
+    ts::OptimDesc o;
+    o.kind = kind; o.centered = rms_centered; o.weight_decay = weight_decay; o.alpha = rms_alpha; o.momentum = rms_momentum;
+    return ts::optim_step(ts::as_stream(stream), o, params, state_m, state_v, grad, n, step, lr, beta1, beta2, eps,
+                          max_grad_norm, scratch);
 }
 
 int ts_polyak_update(float* tgt, const float* src, int64_t n, double tau, ts_stream_t stream) {

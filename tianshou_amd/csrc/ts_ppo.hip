@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
                                                         const float* __restrict__ act, int64_t n,
                                                         float* __restrict__ v_out,
                                                         float* __restrict__ logp_out,
-                                                        float* __restrict__ mu_out) {
+                                                        float* __restrict__ mu_out, float mu_bound) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<KS1, 2>;
     stage_weights<KS1, 2, 512>(lds, params, d, 0);
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(512) void ppo_infer_kernel(const float* __restrict_
 #pragma unroll
             for (int k = 0; k < ACT_PAD; ++k) {
                 mu[k] += lds[L::SMALL + k];
+                if (mu_bound > 0.f) mu[k] = mu_bound * fast_tanh(mu[k]);          // continuous.py:230-231
                 a[k] = (logp_out && k < d.act) ? act[row * d.act + k] : 0.f;
             }
             if (mu_out && valid && h == 0) {
@@ -463,6 +464,7 @@ struct StepArgs {
     float eps_clip, dual_clip, vf_coef, ent_coef;
     int value_clip, adv_norm, a2c;
     int nets;                 // 0 / 3: both networks (ppo_step2_kernel); 1: actor only, 2: critic only (ppo_step1_kernel)
+    float mu_bound;           // > 0: mu = mu_bound * tanh(head) (ContinuousActorProbabilistic(unbounded=False), continuous.py:230-231)
     const float* image;       // [2][Lds<KS1,1>::END] ready-made LDS images of the two nets (ppo_build_image_kernel)
     float* slabs;             // [gridDim.x][slab_w]
     int slab_w;
@@ -718,6 +720,8 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
         head_forward<KS1, 1, ACT_PAD>(lds, 0, h, h2, mu);
         const f32x4 b0 = ld4(sm), b1 = ld4(sm + 4), v0 = ld4(sm + 8), v1 = ld4(sm + 12), s0 = ld4(sm + 16), s1 = ld4(sm + 20);
         float dlt[ACT_PAD], inv_var[ACT_PAD];
+        [[maybe_unused]] float bgrad[ACT_PAD];              // bounded actor: 1 - tanh^2 of the head output
+        const bool bounded = g.mu_bound > 0.f;
         float logp = 0.f;
         int n_act = d.act;
         asm volatile("" : "+s"(n_act));      // otherwise the 8 per-action constants are hoisted into (spilled) VGPRs
@@ -726,7 +730,12 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
             // padding actions (k >= act): zero weights, bias 0, sigma_param 0 -> mu = 0, act = 0, log sigma = 0: the
             // term is an exact -0; only the constant has to be switched off
             const float bm = k < 4 ? b0[k & 3] : b1[k & 3], iv = k < 4 ? v0[k & 3] : v1[k & 3], ls = k < 4 ? s0[k & 3] : s1[k & 3];
-            const float m = mu[k] + bm;
+            float m = mu[k] + bm;
+            if (bounded) {                                   // uniform (kernel argument): no cost on the unbounded path
+                const float t = fast_tanh(m);
+                m = g.mu_bound * t;
+                bgrad[k] = 1.f - t * t;
+            }
             dlt[k] = in.act[k] - m;
             inv_var[k] = 2.f * iv;
             logp += -(dlt[k] * dlt[k]) * iv - ls - (k < n_act ? LOG_SQRT_2PI : 0.f);
@@ -756,6 +765,7 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
 #pragma unroll
         for (int k = 0; k < ACT_PAD; ++k) {
             dout[k] = dlogp * dlt[k] * inv_var[k];                                   // 0 for padding actions (dlt = 0)
+            if (bounded) dout[k] = (dout[k] * g.mu_bound) * bgrad[k];               // MulBackward, then TanhBackward
             const float ds = dlogp * (dlt[k] * dlt[k] * inv_var[k] - 1.f) - ent_w;   // entropy: d/ds = 1
             dsig[k] = k < n_act ? ds : 0.f;
         }
@@ -1190,6 +1200,8 @@ struct AdamArgs {
     float max_grad_norm, lr_step, bc2_sqrt, beta1, beta2, eps;
     float omb1, omb2;            // (1 - beta) rounded from double, as torch passes them
     float vf_coef, ent_coef;
+    int opt_kind, centered;      // ts_ppo_hparams.optimizer / rms_centered (TS_OPT_*)
+    float wd, lr, alpha, oma, momentum;   // weight decay (both optimizers); RMSprop: lr, alpha, 1 - alpha, momentum
     float* losses;            // [4] loss, clip, vf, ent (or NULL); grad[n_params], grad[n_params+1] hold clip / vf
     int apply;                // 0: only losses
     float* image;             // LDS images of the step kernel to refresh (or NULL)
@@ -1236,11 +1248,32 @@ __global__ __launch_bounds__(ADAM_THREADS) void ppo_adam_kernel(AdamArgs a) {
         a.losses[2] = vf;
     }
     if (mine) {
-        const float gq = g_raw * scale;
-        m = m + (gq - m) * a.omb1;                         // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * a.beta2 + a.omb2 * gq * gq;                // mul_(beta2).addcmul_(g, g, 1 - beta2)
-        const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
-        const float np_ = par + (-a.lr_step * m) / denom;   // addcdiv_(m, denom, -step_size)
+        float gq = g_raw * scale;
+        if (a.wd != 0.f) gq = gq + a.wd * par;             // grad.add(param, alpha=weight_decay), inside optimizer.step
+        float np_;
+        if (a.opt_kind == TS_OPT_RMSPROP) {
+            // torch/optim/rmsprop.py _single_tensor_rmsprop (optim.py:113-140): v = square_avg, m = momentum buffer / grad_avg
+            v = v * a.alpha + a.oma * gq * gq;             // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
+            float avg;
+            if (a.centered) {
+                m = m + (gq - m) * a.oma;                  // grad_avg.lerp_(grad, 1 - alpha)
+                avg = sqrtf(v + -1.f * m * m);             // square_avg.addcmul(grad_avg, grad_avg, value=-1).sqrt_()
+            } else {
+                avg = sqrtf(v);
+            }
+            avg = avg + a.eps;
+            if (a.momentum > 0.f) {
+                m = m * a.momentum + gq / avg;             // buf.mul_(momentum).addcdiv_(grad, avg)
+                np_ = par + -a.lr * m;                     // param.add_(buf, alpha=-lr)
+            } else {
+                np_ = par + (-a.lr * gq) / avg;            // param.addcdiv_(grad, avg, value=-lr)
+            }
+        } else {
+            m = m + (gq - m) * a.omb1;                     // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * a.beta2 + a.omb2 * gq * gq;            // mul_(beta2).addcmul_(g, g, 1 - beta2)
+            const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+            np_ = par + (-a.lr_step * m) / denom;          // addcdiv_(m, denom, -step_size)
+        }
         a.params[p] = np_;
         a.m[p] = m;
         a.v[p] = v;
@@ -1427,7 +1460,7 @@ inline int step_grid(int64_t n_rows) {
 // TS_PPO_STEPQ=0 / 1 / 2 forces a variant (A/B runs); TS_PPO_STEPQ_PAIRS caps the pairs (slab count / tiles per workgroup).
 struct StepPlan { int variant, grid, n_slabs, slab_w, k1s, big; };
 
-inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
+inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets, bool bounded = false) {
     // (read per call, not cached: A/B scripts flip them inside one process)
     const char* e_force = getenv("TS_PPO_STEPQ");
     const char* e_pairs = getenv("TS_PPO_STEPQ_PAIRS");
@@ -1438,7 +1471,9 @@ inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets) {
     // Measured on MI355X (profiles/r05_step_kernel_by_rows.txt): 8,192 rows 17.6 vs 32.3 us, 16,384 rows 23.5 vs 32.2 us,
     // 32,768 rows 35.2 vs 34.5 us, 65,536 rows 57.1 vs 52.6 us (two workgroups gather every record there).
     const int64_t tiles_all = (n_rows + 31) / 32;
-    const bool q = force < 0 ? (k1s > 0 && tiles_all <= 3 * (int64_t)n_compute_units()) : (force != 0 && k1s > 0);
+    // (a bounded actor -- ts_ppo_hparams.max_action > 0 -- runs on the 128-sample kernel at every row count: the tanh bound on
+    // mu and its derivative are built into ppo_step2_kernel / ppo_step1_kernel only)
+    const bool q = !bounded && (force < 0 ? (k1s > 0 && tiles_all <= 3 * (int64_t)n_compute_units()) : (force != 0 && k1s > 0));
     if (!q) {
         pl.variant = 0;
         pl.grid = pl.n_slabs = step_grid(n_rows);
@@ -1489,6 +1524,7 @@ inline void fill_hparams(StepArgs& g, const ts_ppo_hparams* hp) {
     g.ent_coef = (float)hp->ent_coef;
     g.a2c = hp->algo == 1;
     g.nets = hp->nets;
+    g.mu_bound = (float)(hp->max_action > 0.0 ? hp->max_action : 0.0);
     g.value_clip = g.a2c ? 0 : hp->value_clip;
     g.adv_norm = g.a2c ? 0 : hp->adv_norm;
     if (g.a2c) g.dual_clip = 0.f;
@@ -1508,6 +1544,9 @@ inline AdamArgs adam_args(float* params, float* m, float* v, int64_t step, const
     a.omb1 = (float)(1.0 - hp->beta1); a.omb2 = (float)(1.0 - hp->beta2);
     a.vf_coef = (float)hp->vf_coef;
     a.ent_coef = (float)hp->ent_coef;
+    a.opt_kind = hp->optimizer; a.centered = hp->rms_centered;
+    a.wd = (float)hp->weight_decay; a.lr = (float)hp->lr;
+    a.alpha = (float)hp->rms_alpha; a.oma = (float)(1.0 - hp->rms_alpha); a.momentum = (float)hp->rms_momentum;
     return a;
 }
 
@@ -1751,10 +1790,16 @@ int64_t ts_ppo_param_count(int64_t obs_dim, int64_t act_dim) {
 
 int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                  const float* act, int64_t n, float* v_out, float* logp_out, ts_stream_t stream) {
+    return ts_ppo_infer_bounded(ws, params, obs_dim, act_dim, 0.0, obs, act, n, v_out, logp_out, nullptr, stream);
+}
+
+int ts_ppo_infer_bounded(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, double max_action,
+                         const float* obs, const float* act, int64_t n, float* v_out, float* logp_out, float* mu_out,
+                         ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
-    TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_ppo_infer: negative n");
-    if (n == 0 || (!v_out && !logp_out)) return TS_OK;
+    TS_REQUIRE(n >= 0 && max_action >= 0.0, TS_ERR_INVALID_ARG, "ts_ppo_infer: negative n / max_action");
+    if (n == 0 || (!v_out && !logp_out && !mu_out)) return TS_OK;
     TS_REQUIRE(params && obs, TS_ERR_INVALID_ARG, "ts_ppo_infer: NULL params / obs");
     TS_REQUIRE(!logp_out || act, TS_ERR_INVALID_ARG, "ts_ppo_infer: logp_out needs act");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
@@ -1768,7 +1813,7 @@ int ts_ppo_infer(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t
         ts::ProfScope prof(ws, TS_KIND_PPO_INFER, s);
         TS_KS1_DISPATCH(ks, {
             hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
-                               params, d, obs, act, n, v_out, logp_out, (float*)nullptr);
+                               params, d, obs, act, n, v_out, logp_out, mu_out, (float)max_action);
         });
     }
     TS_LAUNCH_CHECK();
@@ -1800,17 +1845,28 @@ __global__ __launch_bounds__(256) void ppo_sample_map_kernel(const float* __rest
 int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, const float* obs,
                           const float* noise, int64_t n, int bound_method, const float* low, const float* high,
                           float* act_out, float* mapped_out, ts_stream_t stream) {
+    return ts_ppo_policy_forward_bounded(ws, params, obs_dim, act_dim, 0.0, obs, noise, n, bound_method, low, high, act_out,
+                                         mapped_out, nullptr, stream);
+}
+
+int ts_ppo_policy_forward_bounded(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, double max_action,
+                                  const float* obs, const float* noise, int64_t n, int bound_method, const float* low,
+                                  const float* high, float* act_out, float* mapped_out, float* mu_out, ts_stream_t stream) {
     int rc = check_dims(obs_dim, act_dim);
     if (rc != TS_OK) return rc;
-    TS_REQUIRE(n >= 0 && bound_method >= 0 && bound_method <= 2, TS_ERR_INVALID_ARG, "ts_ppo_policy_forward: bad argument");
+    TS_REQUIRE(n >= 0 && bound_method >= 0 && bound_method <= 2 && max_action >= 0.0, TS_ERR_INVALID_ARG,
+               "ts_ppo_policy_forward: bad argument");
     if (n == 0) return TS_OK;
     TS_REQUIRE(ws && params && obs && act_out && ((low == nullptr) == (high == nullptr)), TS_ERR_INVALID_ARG,
                "ts_ppo_policy_forward: NULL argument");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
     hipStream_t s = ts::as_stream(stream);
-    if (int rc2 = ts::ws_reserve(ws, sizeof(float) * (size_t)n * (size_t)act_dim)) return rc2;
-    float* mu = static_cast<float*>(ws->base);
+    float* mu = mu_out;                                   // the caller's `logits[0]`, or scratch
+    if (!mu) {
+        if (int rc2 = ts::ws_reserve(ws, sizeof(float) * (size_t)n * (size_t)act_dim)) return rc2;
+        mu = static_cast<float*>(ws->base);
+    }
     const int64_t tiles = (n + 31) / 32;
     int64_t wg = (tiles + 7) / 8;
     const int64_t cap = (int64_t)n_compute_units() * 2;
@@ -1819,7 +1875,8 @@ int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim
         ts::ProfScope prof(ws, TS_KIND_PPO_INFER, s);
         TS_KS1_DISPATCH(ks, {
             hipLaunchKernelGGL((ppo_infer_kernel<K>), dim3((unsigned)wg), dim3(512), infer_lds_bytes<K>(), s,
-                               params, d, obs, (const float*)nullptr, n, (float*)nullptr, (float*)nullptr, mu);
+                               params, d, obs, (const float*)nullptr, n, (float*)nullptr, (float*)nullptr, mu,
+                               (float)max_action);
         });
     }
     hipLaunchKernelGGL(ppo_sample_map_kernel, dim3((unsigned)ts::ceil_div(n * act_dim, 256)), dim3(256), 0, s, mu, noise,
@@ -1883,7 +1940,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         TS_REQUIRE(perm || h_mb_offset[k + 1] <= n, TS_ERR_SHAPE, "ts_ppo_update: minibatch beyond n");
         if (rows == last_rows) continue;
         last_rows = rows;
-        const StepPlan pl = plan_step(d, ks, rows, hp->nets);
+        const StepPlan pl = plan_step(d, ks, rows, hp->nets, hp->max_action > 0.0);
         slab_floats = std::max(slab_floats, (size_t)pl.n_slabs * (size_t)pl.slab_w);
         slab_w = std::max(slab_w, pl.slab_w);
     }
@@ -1931,7 +1988,7 @@ int ts_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* adam_v,
         g.image = image;
         fill_hparams(g, hp);
         float* losses = losses_out ? losses_out + 4 * k : nullptr;
-        const StepPlan pl = plan_step(d, ks, g.n_rows, hp->nets);
+        const StepPlan pl = plan_step(d, ks, g.n_rows, hp->nets, hp->max_action > 0.0);
         rc = run_grad(ws, g, d, ks, pl, slabs, grad, sumsq, losses, s);
         if (rc != TS_OK) return rc;
         AdamArgs a = adam_args(params, adam_m, adam_v, adam_step0 + k + 1, d, hp);
@@ -1967,7 +2024,7 @@ int ts_ppo_grad(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t 
                "ts_ppo_grad: rec must be 16-byte aligned");
     const Dims d = make_dims((int)obs_dim, (int)act_dim);
     const int ks = supported_ks(ks1_for((int)obs_dim));
-    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets);
+    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets, hp->max_action > 0.0);
     const WsLayout wl = ws_layout(pl.n_slabs, pl.slab_w, 1);
     rc = ts::ws_reserve(ws, wl.total);
     if (rc != TS_OK) return rc;
@@ -2021,7 +2078,7 @@ int ts_debug_ppo_step_cycles(ts_workspace* ws, const float* params, int64_t obs_
     fill_hparams(g, hp);
     g.adv_norm = 0;
     g.slabs = reinterpret_cast<float*>(base + wl.slabs); g.slab_w = slab_w; g.dbg = dbg;
-    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets);
+    const StepPlan pl = plan_step(d, ks, n_rows, hp->nets, hp->max_action > 0.0);
     if (pl.variant == 1) {
         g.slab_w = pl.slab_w;        // (the slab area above is sized for the 128-sample kernel: n_wg x slab_w >= pairs x slab3_w)
         switch (pl.k1s) {

@@ -323,7 +323,7 @@ int ac_ppo_step(ts_workspace* ws, const Net& n, float* params, float* adam_m, fl
             if (int rc = ts::conv_dgrad(s, n.l[i], dy[i], params + n.off[i], a.h[i - 1], dy[i - 1], ws)) return rc;
     }
     if (hp->lr < 0.0) return TS_OK;
-    return ts::adam_step(s, params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
+    return ts::optim_step(s, ts::optim_from(hp), params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm, norm_part);
 }
 

@@ -186,21 +186,45 @@ class _HipGlue:
             opt._opt_called = True       # the engine performs this optimizer's step (LRScheduler.step's order check)
 
 
-def ppo_config_from(algorithm) -> PPOConfig:
-    """Reads the reference PPO's hyper-parameters (ppo.py:126-144, a2c.py:95-113, optim.py:89-110)."""
-    opt = algorithm.optim._optim
+def optimizer_fields(opt) -> dict:
+    """The PPOConfig fields of a torch optimizer built by tianshou/algorithm/optim.py: AdamOptimizerFactory (:89-110, incl.
+    weight_decay) or RMSpropOptimizerFactory (:113-140: alpha, eps, weight_decay, momentum, centered -- the optimizer of
+    examples/mujoco/mujoco_a2c.py:117).  Everything else (amsgrad, maximize, other classes) raises."""
     g = opt.param_groups[0]
-    if type(opt).__name__ != "Adam" or g.get("weight_decay", 0) != 0 or g.get("amsgrad", False):
-        raise NotImplementedError("HipPPO supports torch.optim.Adam without weight decay / amsgrad")
+    name = type(opt).__name__
+    if g.get("maximize", False) or g.get("amsgrad", False):
+        raise NotImplementedError("the HIP engines do not implement amsgrad / maximize")
+    if any(any(gi.get(k) != g.get(k) for k in g if k not in ("params", "lr", "initial_lr")) for gi in opt.param_groups):
+        raise NotImplementedError("the HIP engines take one hyper-parameter set per optimizer")
+    if name == "Adam":
+        return dict(optimizer="adam", lr=g["lr"], betas=tuple(g["betas"]), adam_eps=g["eps"],
+                    weight_decay=float(g.get("weight_decay", 0) or 0.0))
+    if name == "RMSprop":
+        if g.get("centered", False) and g.get("momentum", 0) > 0:
+            raise NotImplementedError("RMSprop(centered=True, momentum > 0): the engines keep one auxiliary state vector")
+        return dict(optimizer="rmsprop", lr=g["lr"], adam_eps=g["eps"], weight_decay=float(g.get("weight_decay", 0) or 0.0),
+                    rms_alpha=float(g["alpha"]), rms_momentum=float(g.get("momentum", 0) or 0.0),
+                    rms_centered=bool(g.get("centered", False)))
+    raise NotImplementedError(f"the HIP engines implement torch.optim.Adam and torch.optim.RMSprop, not {name}")
+
+
+def ppo_config_from(algorithm) -> PPOConfig:
+    """Reads the reference PPO's hyper-parameters (ppo.py:126-144, a2c.py:95-113, optim.py:89-140) and the actor's bound
+    (ContinuousActorProbabilistic.max_action / _unbounded, utils/net/continuous.py:194-231)."""
+    opt = algorithm.optim._optim
+    of = optimizer_fields(opt)
     is_ppo = hasattr(algorithm, "eps_clip")                  # A2C (a2c.py:187-247) has none of the clipping options
+    actor = getattr(algorithm.policy, "actor", None)
+    bounded = actor is not None and hasattr(actor, "_unbounded") and not actor._unbounded
     return PPOConfig(
+        max_action=float(actor.max_action) if bounded else None, **of,
         algo="ppo" if is_ppo else "a2c",
         gamma=algorithm.gamma, gae_lambda=algorithm.gae_lambda, eps_clip=getattr(algorithm, "eps_clip", 0.2),
         dual_clip=getattr(algorithm, "dual_clip", None), value_clip=getattr(algorithm, "value_clip", False),
         advantage_normalization=getattr(algorithm, "advantage_normalization", False),
         recompute_advantage=getattr(algorithm, "recompute_adv", False), vf_coef=algorithm.vf_coef,
         ent_coef=algorithm.ent_coef, max_grad_norm=algorithm.optim._max_grad_norm,
-        return_scaling=algorithm.return_scaling, lr=g["lr"], betas=tuple(g["betas"]), adam_eps=g["eps"])
+        return_scaling=algorithm.return_scaling)
 
 
 def _ref(ref, module: str, name: str):
@@ -231,15 +255,17 @@ def _trunk_spec(net, who: str):
         seq = list(net.preprocess.model.model)
     except AttributeError as e:
         raise NotImplementedError(f"HipPPO: unsupported {who} (no preprocess.model.model Sequential)") from e
-    stems, hidden, acts = [], [], set()
+    stems, hidden, acts, followed = [], [], set(), []
     for i, m in enumerate(seq):
         if isinstance(m, torch.nn.Linear):
             stems.append(f"preprocess.model.model.{i}")
             hidden.append(int(m.out_features))
-        elif isinstance(m, torch.nn.Tanh):
-            acts.add("tanh")
-        elif isinstance(m, torch.nn.ReLU):
-            acts.add("relu")
+            followed.append(False)
+        elif isinstance(m, (torch.nn.Tanh, torch.nn.ReLU)):
+            acts.add("tanh" if isinstance(m, torch.nn.Tanh) else "relu")
+            if not followed or followed[-1]:
+                raise NotImplementedError(f"HipPPO: {who} trunk has an activation that does not follow a Linear layer")
+            followed[-1] = True
         elif isinstance(m, torch.nn.Identity):
             pass
         else:
@@ -247,6 +273,14 @@ def _trunk_spec(net, who: str):
                                       "or no activation are supported (no norm layers)")
     if not stems or len(acts) > 1:
         raise NotImplementedError(f"HipPPO: {who} trunk needs at least one Linear layer and a single activation class")
+    # The engines apply the activation after EVERY trunk layer.  A Net built with action_shape > 0 (MLP output_dim > 0,
+    # utils/net/common.py:169-170) ends in a bare Linear layer and Net(softmax=True) appends a softmax (common.py:366-367):
+    # neither is a (Linear, activation) pair, so they are outside the envelope rather than silently a different network.
+    if acts and not all(followed):
+        raise NotImplementedError(f"HipPPO: every Linear layer of the {who} trunk must be followed by its activation "
+                                  "(a Net with action_shape / MLP output_dim > 0 ends in a bare Linear layer)")
+    if getattr(net.preprocess, "softmax", False):
+        raise NotImplementedError(f"HipPPO: the {who} trunk applies a softmax (Net(softmax=True)); not supported")
     return stems, hidden, (acts.pop() if acts else "none")
 
 
@@ -276,8 +310,12 @@ def _check_supported(actor, critic):
                                   "head + sigma_param); see tianshou_amd/integration.py")
     if set(sc.keys()) != set(kc):
         raise NotImplementedError(f"HipPPO: unsupported critic (keys {sorted(set(sc) ^ set(kc))} differ from a Net trunk + linear head)")
-    if not getattr(actor, "_unbounded", False):
-        raise NotImplementedError("HipPPO: actor must be unbounded (the tanh bound on mu is not built)")
+    # ContinuousActorProbabilistic(unbounded=False) is the constructor default (continuous.py:194): mu = max_action * tanh(.)
+    # -- built into the fused step / inference kernels (ts_ppo_hparams.max_action) and into the per-layer engine
+    # (ts_net_desc.max_action); the Net[h, h] GEMM engine ("wide") stays unbounded, such actors take the per-layer engine
+    bounded = not getattr(actor, "_unbounded", False)
+    if bounded and not float(getattr(actor, "max_action", 1.0)) > 0.0:
+        raise NotImplementedError("HipPPO: a bounded actor needs max_action > 0")
     c_sigma = bool(getattr(actor, "_c_sigma", False))
     _, ha, act_a = _trunk_spec(actor, "actor")
     _, hc, act_c = _trunk_spec(critic, "critic")
@@ -294,7 +332,7 @@ def _check_supported(actor, critic):
         hidden = ha[0]
         if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
             return obs_dim, act_dim, hidden, "fused"
-        if hidden % 32 == 0 and 32 <= hidden <= 1024:
+        if hidden % 32 == 0 and 32 <= hidden <= 1024 and not bounded:
             return obs_dim, act_dim, hidden, "wide"
     if max(len(ha), len(hc)) > 7 or max(ha + hc) > 1024:
         raise NotImplementedError("HipPPO: trunks of up to 7 hidden layers of at most 1024 units")
@@ -1628,7 +1666,7 @@ def make_hip_ppo_cnn(algo: str = "ppo", ref=None):
                     or actor.preprocess is not critic.preprocess or getattr(actor, "softmax_output", True):
                 raise NotImplementedError("HipPPOCnn: actor / critic must share one DQNet(features_only=True, "
                                           "output_dim_added_layer=512) trunk with single-Linear heads (logits)")
-            _adam_of(self.optim)
+            optimizer_fields(self.optim._optim)                # Adam / RMSprop incl. weight decay (ts::optim_step)
             self._hip_engine = None
             self._hip_glue_init()
 
@@ -1728,7 +1766,7 @@ def make_hip_ppo_discrete(algo: str = "ppo", ref=None):
             if not ((softmax and dist_fn is Categorical) or (not softmax and dist_fn is dist_fn_categorical_from_logits)):
                 raise NotImplementedError("HipPPODiscrete: softmax_output=True needs dist_fn=Categorical, "
                                           "softmax_output=False the logits dist_fn")
-            _adam_of(self.optim)
+            optimizer_fields(self.optim._optim)                # Adam / RMSprop incl. weight decay (ts::optim_step)
             self._hip_engine = None
             self._hip_glue_init()
 

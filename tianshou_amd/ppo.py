@@ -93,14 +93,35 @@ class PPOConfig:
     adam_eps: float = 1e-8
     nets: int = 0                # 0: actor and critic; 1 / 2: only the actor's / the critic's half of every step (the other
                                  # network is a stand-in and takes a zero gradient: reinforce.py / npg.py; ts_ppo_hparams.nets)
+    # optimizer factories of tianshou/algorithm/optim.py: "adam" (AdamOptimizerFactory, :89-110) or "rmsprop"
+    # (RMSpropOptimizerFactory, :113-140 -- examples/mujoco/mujoco_a2c.py:117); lr / adam_eps (= eps) are shared.
+    # State vectors: `adam_v` holds RMSprop's square_avg, `adam_m` its momentum buffer (or grad_avg when centered).
+    optimizer: str = "adam"
+    weight_decay: float = 0.0
+    rms_alpha: float = 0.99
+    rms_momentum: float = 0.0
+    rms_centered: bool = False
+    max_action: float | None = None   # ContinuousActorProbabilistic(unbounded=False): mu = max_action * tanh(.) (continuous.py:230-231)
 
     def to_c(self) -> _lib.PPOHParams:
+        if self.optimizer not in ("adam", "rmsprop"):
+            raise NotImplementedError(f"optimizer {self.optimizer!r}: the engines implement torch.optim.Adam and torch.optim.RMSprop")
+        if self.optimizer == "rmsprop" and self.rms_centered and self.rms_momentum > 0:
+            raise NotImplementedError("RMSprop(centered=True, momentum > 0) needs two auxiliary state vectors; one is provided")
         return _lib.PPOHParams(
             eps_clip=self.eps_clip, dual_clip=self.dual_clip or 0.0, vf_coef=self.vf_coef,
             ent_coef=self.ent_coef, max_grad_norm=self.max_grad_norm or 0.0, lr=self.lr,
             beta1=self.betas[0], beta2=self.betas[1], adam_eps=self.adam_eps,
             value_clip=int(self.value_clip), adv_norm=int(self.advantage_normalization),
-            algo={"ppo": 0, "a2c": 1}[self.algo], nets=int(self.nets))
+            algo={"ppo": 0, "a2c": 1}[self.algo], nets=int(self.nets),
+            optimizer={"adam": 0, "rmsprop": 1}[self.optimizer], rms_centered=int(self.rms_centered),
+            weight_decay=float(self.weight_decay), rms_alpha=float(self.rms_alpha), rms_momentum=float(self.rms_momentum),
+            max_action=float(self.max_action or 0.0))
+
+    @property
+    def plain_adam(self) -> bool:
+        """torch.optim.Adam without weight decay: what the one-launch update kernels (ts_mlp_small.hip) have built in."""
+        return self.optimizer == "adam" and not self.weight_decay
 
 
 def rms_merge(rms, s1: float, s2: float, n: float) -> list[float]:
@@ -132,25 +153,27 @@ def split_offsets(n: int, size: int | None, merge_last: bool = True) -> list[int
 
 
 def infer(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.Tensor, act=None, *,
-          want_v: bool = True, want_logp: bool = False):
+          want_v: bool = True, want_logp: bool = False, max_action: float | None = None):
     """V(obs) and/or log pi(act|obs) for the whole array in one launch (a2c.py:122-129,
-    ppo.py:157-161 without the max_batchsize chunk loop)."""
+    ppo.py:157-161 without the max_batchsize chunk loop).  max_action: the tanh bound of a bounded actor."""
     n = obs.shape[0]
     dev = obs.device
     v = torch.empty(n, dtype=torch.float32, device=dev) if want_v else None
     lp = torch.empty(n, dtype=torch.float32, device=dev) if want_logp else None
     ws = _lib.default_workspace(_dev_index(params))
-    _lib.check(_lib.load().ts_ppo_infer(
-        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.ptr(obs), _lib.ptr(act),
-        _lib.i64(n), _lib.ptr(v), _lib.ptr(lp), _lib.current_stream(dev)))
+    _lib.check(_lib.load().ts_ppo_infer_bounded(
+        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.f64(max_action or 0.0), _lib.ptr(obs),
+        _lib.ptr(act), _lib.i64(n), _lib.ptr(v), _lib.ptr(lp), None, _lib.current_stream(dev)))
     return v, lp
 
 
 def policy_forward(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.Tensor, noise=None, *,
-                   bound_method: str | None = "clip", low=None, high=None):
+                   bound_method: str | None = "clip", low=None, high=None, max_action: float | None = None,
+                   want_mu: bool = False):
     """The collector's inference step (collector.py:707-772): ProbabilisticActorPolicy.forward
     (reinforce.py:167-192) with dist.sample() = mu + sigma * noise (noise None = dist.mode) followed by
-    Algorithm.map_action (algorithm_base.py:254-287).  -> (act for the buffer, mapped act for the env)."""
+    Algorithm.map_action (algorithm_base.py:254-287).  -> (act for the buffer, mapped act for the env[, mu]).
+    max_action: the tanh bound on mu of ContinuousActorProbabilistic(unbounded=False) (continuous.py:230-231)."""
     n, dev = obs.shape[0], obs.device
     obs = obs.to(torch.float32).contiguous()
     noise = None if noise is None else torch.as_tensor(noise, device=dev).to(torch.float32).reshape(n, act_dim).contiguous()
@@ -158,12 +181,13 @@ def policy_forward(params: torch.Tensor, obs_dim: int, act_dim: int, obs: torch.
     low, high = f(low), f(high)
     act = torch.empty((n, act_dim), dtype=torch.float32, device=dev)
     mapped = torch.empty_like(act)
+    mu = torch.empty_like(act) if want_mu else None
     ws = _lib.default_workspace(_dev_index(params))
-    _lib.check(_lib.load().ts_ppo_policy_forward(
-        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(n),
-        C.c_int({None: 0, "clip": 1, "tanh": 2}[bound_method]), _lib.ptr(low), _lib.ptr(high), _lib.ptr(act),
-        _lib.ptr(mapped), _lib.current_stream(dev)))
-    return act, mapped
+    _lib.check(_lib.load().ts_ppo_policy_forward_bounded(
+        ws.handle, _lib.ptr(params), _lib.i64(obs_dim), _lib.i64(act_dim), _lib.f64(max_action or 0.0), _lib.ptr(obs),
+        _lib.ptr(noise), _lib.i64(n), C.c_int({None: 0, "clip": 1, "tanh": 2}[bound_method]), _lib.ptr(low), _lib.ptr(high),
+        _lib.ptr(act), _lib.ptr(mapped), _lib.ptr(mu), _lib.current_stream(dev)))
+    return (act, mapped, mu) if want_mu else (act, mapped)
 
 
 def pack_batch(b: dict, obs_dim: int, act_dim: int) -> torch.Tensor:
@@ -223,7 +247,7 @@ class PPOEngine:
         cfg = self.cfg
         if v_s is None:                    # preprocess() passes V(s) from the launch that also produced log pi_old
             v_s, _ = infer(self.params, self.obs_dim, self.act_dim, obs)
-        v_next, _ = infer(self.params, self.obs_dim, self.act_dim, obs_next)
+        v_next, _ = infer(self.params, self.obs_dim, self.act_dim, obs_next)     # (critic only: the actor's bound is not involved)
         scale = math.sqrt(self.ret_rms[1] + self._eps) if cfg.return_scaling else 1.0
         out = gae_scan(v_s, v_next, rew, terminated, truncated, cut_pos, gamma=cfg.gamma,
                        gae_lambda=cfg.gae_lambda, v_scale=scale, ret_div=scale,
@@ -246,7 +270,8 @@ class PPOEngine:
         else:
             # V(s) and log pi_old(a | s) read the same observations: one launch with both networks resident (the
             # parameters do not change between ppo.py:157 and :160, so the order of the two passes is immaterial)
-            v_s0, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=True, want_logp=True)
+            v_s0, logp_old = infer(self.params, self.obs_dim, self.act_dim, obs, act, want_v=True, want_logp=True,
+                                   max_action=self.cfg.max_action)
             v_s, returns, adv = self.add_returns_and_advantages(obs, obs_next, rew, terminated, truncated, cut_pos,
                                                                 d_n_cut, reduce_stats, v_s=v_s0)
         return {"obs": obs, "obs_next": obs_next, "act": act, "rew": rew, "terminated": terminated,

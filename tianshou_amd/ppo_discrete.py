@@ -151,7 +151,10 @@ class DiscretePPOEngine:
         obs_all = gather_rows(buffer.obs, pre["indices"])
         n = pre["indices"].numel()
         lib = _lib.load()
-        if lib.ts_mlp_ppo_update_supported(*self._dims()) and not os.environ.get("TS_MLP_PPO_PER_STEP"):
+        # (the one-launch kernel keeps the Adam moments in registers and has torch.optim.Adam's step built in: RMSprop /
+        # weight decay run on the per-step path, whose optimizer step is ts_optim's general kernel)
+        if (lib.ts_mlp_ppo_update_supported(*self._dims()) and not os.environ.get("TS_MLP_PPO_PER_STEP")
+                and self.cfg.plain_adam):
             # small network: the whole loop (every minibatch of every repeat, clip + Adam included) is ONE launch
             if perms is None:
                 perms = [np.random.permutation(n) for _ in range(repeat)]

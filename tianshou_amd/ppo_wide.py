@@ -47,6 +47,8 @@ class WidePPOEngine:
             raise RuntimeError("WidePPOEngine needs its parameters on an MI355X; there is no CPU fallback")
         if hidden % 32 or not 32 <= hidden <= 1024 or not 1 <= act_dim <= 32:
             raise NotImplementedError("WidePPOEngine: hidden a multiple of 32 in [32, 1024], act_dim <= 32")
+        if cfg.max_action:
+            raise NotImplementedError("WidePPOEngine: unbounded actors only (a bounded actor runs on NetPPOEngine)")
         self.obs_dim, self.act_dim, self.hidden, self.cfg = obs_dim, act_dim, hidden, cfg
         lay = NG.layout(obs_dim, hidden, act_dim)
         self.n_actor, self.n_critic = lay["actor_count"], lay["critic_count"]
@@ -243,7 +245,7 @@ class NetPPOEngine(WidePPOEngine):
         self.conditioned_sigma = bool(conditioned_sigma)
         self.entropy_is_batch_sum = self.conditioned_sigma           # (DataParallelPPO: the entropy part is summed, not repeated)
         self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation,
-                                     _lib.NetDesc.CONDITIONED_SIGMA if conditioned_sigma else 0)
+                                     _lib.NetDesc.CONDITIONED_SIGMA if conditioned_sigma else 0, max_action=cfg.max_action or 0.0)
         self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation)
         out = (C.c_int64 * 3)()
         _lib.check(_lib.load().ts_net_layout(C.byref(self._na), _lib.i64(act_dim), out))
