@@ -49,17 +49,23 @@ PEAK_HBM_GBPS = 8000.0
 # FETCH_SIZE / WRITE_SIZE are in KiB and, on gfx950, FETCH_SIZE counts the 128-byte requests of 16-byte-per-lane loads at
 # 64 bytes -> doubled (MI355X_MICROARCH.md "HBM").  Counters cannot be read live from inside bench.py, so the line carries
 # the profiled value of the same workload, looked up by the name of the kernel that ran; no entry -> null.
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_hbm_traffic.json")
-TRAFFIC_SOURCE = "profiles/r05_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload, scripts/gpu_pmc_traffic.sh)"
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_hbm_traffic.json")
+TRAFFIC_SOURCE = "profiles/r06_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, C2 workload, scripts/gpu_pmc_traffic.sh)"
 
 
-def hbm_traffic_bytes(kernel):
-    """(2 * FETCH_SIZE + WRITE_SIZE) KiB of the profiled `kernel`, or None when the profile has no such kernel."""
+def hbm_traffic_bytes(kernel, grid_threads=None, path=None):
+    """(2 * FETCH_SIZE + WRITE_SIZE) KiB of the profiled `kernel`, or None when the profile has no such kernel.
+    `grid_threads`: total work-items of the launch that is being quoted -- the profile keeps every launch geometry of a kernel
+    name apart (`by_grid`), and a line about the 2^20-transition scan must not quote the 2^24 one's counters (round 5's file
+    did: VERDICT r5).  With a grid given, ONLY that geometry is accepted (None rather than another size's bytes)."""
     try:
-        with open(TRAFFIC_JSON) as f:
+        with open(path or TRAFFIC_JSON) as f:
             e = json.load(f).get(kernel)
     except (OSError, ValueError):
         return None
+    if e and grid_threads is not None:
+        e = next((v for k, v in (e.get("by_grid") or {}).items() if int(np.prod([int(x) for x in k.split(",")])) == int(grid_threads)),
+                 None)
     if not e or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
         return None
     return int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
@@ -417,17 +423,22 @@ def cpu_baseline(sample_steps=None):
         OP.update(st, ocfg, data, pre_s, MINIBATCH, 1, [np.arange(MINIBATCH * sample_steps)])
     t_step = (time.perf_counter() - t0) / sample_steps
     value = steps_per_update / (t_pre + steps_per_update * t_step)
-    # the port calibrated against the reference itself where the reference can run (the authoring container, 4 threads):
-    # profiles/r05_cpu_reference_vs_port.json, written by scripts/cpu_reference_vs_port.py
+    # the port calibrated against the reference itself where the reference can run (the authoring container: 8 CPUs, so 4
+    # threads in round 5 and all 8 in round 6): profiles/r0{5,6}_cpu_reference_vs_port.json, scripts/cpu_reference_vs_port.py
     calib = ""
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_cpu_reference_vs_port.json")) as f:
+        cal_name = next(n for n in ("r06_cpu_reference_vs_port.json", "r05_cpu_reference_vs_port.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        with open(os.path.join(ROOT, "profiles", cal_name)) as f:
             c = json.load(f)
         calib = (f"; calibration against tianshou's own PPO.update() on the same buffer / weights / seed ({c['threads']} threads of a "
                  f"{c['host_cpus']}-CPU container, {c['shape']['transitions']} transitions, {c['port']['gradient_steps']} steps): reference "
                  f"{c['reference_gae_compiled']['steps_per_s']:.1f} steps/s (njit bodies compiled), port {c['port']['steps_per_s']:.1f} = "
                  f"{c['ratio_port_over_reference_compiled']:.2f} x the reference, final parameters differ by "
-                 f"{c['max_abs_param_diff_reference_vs_port']:.1e} (profiles/r05_cpu_reference_vs_port.json)")
+                 f"{c['max_abs_param_diff_reference_vs_port']:.1e} (profiles/{cal_name}); CAVEAT: the calibration ran at "
+                 f"{c['threads']} threads, this line at {torch.get_num_threads()} -- the reference's share of Python / "
+                 "single-thread NumPy work grows with the thread count, so the port's advantage at this line's thread count is "
+                 "at least the calibrated ratio, not equal to it")
     except (OSError, ValueError, KeyError):
         pass
     return {
@@ -526,7 +537,8 @@ def hook_level(device, updates=3, permutations="device"):
     with torch.no_grad():
         actor.sigma_param.fill_(-0.5)
     c = mujoco_cfg()
-    algo = HipPPO(policy=SI.Policy(actor), critic=critic, device=str(device), permutations=permutations, lr=c.lr, eps_clip=c.eps_clip, value_clip=True,
+    policy = SI.Policy(actor, action_space=SI.Box(-1.0, 1.0, (ACT,)), action_scaling=True, action_bound_method="clip")
+    algo = HipPPO(policy=policy, critic=critic, device=str(device), permutations=permutations, lr=c.lr, eps_clip=c.eps_clip, value_clip=True,
                   advantage_normalization=False, vf_coef=c.vf_coef, ent_coef=c.ent_coef, max_grad_norm=c.max_grad_norm,
                   return_scaling=True, gamma=c.gamma, gae_lambda=c.gae_lambda).to(device)
     buf = SI.VectorReplayBuffer(N_TRANS, N_ENV, obs_shape=(OBS,), act_shape=(ACT,))
@@ -551,23 +563,63 @@ def hook_level(device, updates=3, permutations="device"):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     n_steps = stats.gradient_steps
+    # the Collector's step on the other side of the buffer (data/collector.py:735-744) for the C2 vector of 512
+    # environments -- policy(batch) (host observations in, sampled action out) + policy.map_action(act) -- with the forward on
+    # the engine's inference kernels reading the engine's parameters (tianshou_amd/policy.py; the default), beside the same
+    # sequence as the reference's torch modules run it on the GPU (ROCm eager: Net -> mu head -> Normal.sample -> NumPy clip /
+    # scale on the host)
+    obs_np = rng.standard_normal((N_ENV, OBS), dtype=np.float32)
+    batch = SI.Batch(obs=obs_np, info={})
+
+    def engine_step():
+        res = algo.policy(batch, None)
+        return algo.policy.map_action(res.act.detach().cpu().numpy())
+
+    def eager_step():
+        with torch.no_grad():
+            h = actor.preprocess.model.model(torch.as_tensor(obs_np, device=device, dtype=torch.float32))
+            mu = actor.mu.model(h)
+            sigma = (actor.sigma_param.view(1, -1) + torch.zeros_like(mu)).exp()
+            act = torch.distributions.Independent(torch.distributions.Normal(mu, sigma), 1).sample()
+        return SI.Policy.map_action(algo.policy, act.detach().cpu().numpy())
+
+    def per_step_us(fn, n=300):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    collector = {"envs": N_ENV, "engine_forward_us_per_step": per_step_us(engine_step), "torch_eager_us_per_step": per_step_us(eager_step),
+                 "policy_class": type(algo.policy).__name__, "reads_engine_parameters": algo.policy._hip_engine() is algo._hip_engine,
+                 "note": "policy(batch) + policy.map_action(act) for one vector step of 512 environments, host observations in, "
+                         "host actions out; engine = ts_ppo_policy_forward_bounded (forward, sample, bound, scale: 2 launches, "
+                         "1 H2D, 1 D2H)"}
     return {"first_update_steps_per_s": n_steps / times[0], "first_update_ms": times[0] * 1e3,
             "steady_update_steps_per_s": n_steps / min(times[1:]), "steady_update_ms": min(times[1:]) * 1e3,
-            "permutations": permutations,
+            "permutations": permutations, "collector_step": collector,
             "note": "HipPPO.update() over a host-filled VectorReplayBuffer stand-in; first = full mirror upload + engine "
                     "creation, steady = no new slots to copy"}
 
 
-def other_workloads():
+def other_workloads(with_cpu: bool = True):
     """Short runs of the C3 / C5 / Atari-shape PPO / NPG / TRPO rows so that they are measured by the same driver command."""
     out = {}
     for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 1))):
         try:
             import importlib
 
-            r = importlib.import_module(mod).run(*args, with_cpu=False)
+            # C3 / C5 carry their own `cpu_baseline` (the torch-fp32 CPU port, a bounded sample of ~10 s each) and
+            # `roofline.traffic` (TCC counters of their own commands, profiles/r06_pmc_{dqn,sac}.json) -- SURVEY 8d asks for
+            # both per configuration; the Atari-shape PPO port needs ~50 s per gradient step and stays out of the default run
+            r = importlib.import_module(mod).run(*args, with_cpu=with_cpu and name in ("dqn", "sac"))
             out[name] = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r.get("ms_per_step"),
-                         "roofline_frac": (r.get("roofline") or {}).get("frac"), "config": r.get("config")}
+                         "roofline_frac": (r.get("roofline") or {}).get("frac"), "roofline": r.get("roofline"),
+                         "cpu_baseline": r.get("cpu_baseline"), "host_enqueue_ms_per_step": r.get("host_enqueue_ms_per_step"),
+                         "config": r.get("config")}
         except Exception as e:                                   # a side leg must not take the headline line down
             out[name] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
@@ -779,7 +831,9 @@ def main():
             achieved = FLOP_PER_SAMPLE_STEP * learner.minibatch / avg_s / 1e12
             roof = {"bound": "mfma", "kernel": step_plan(learner, learner.minibatch)[0], "achieved": achieved,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": hbm_traffic_bytes(step_plan(learner, learner.minibatch)[0]) if learner.minibatch == MINIBATCH else None,
+                    # (looked up by kernel name AND launch geometry: workgroups of the plan x 256 threads)
+                    "traffic": hbm_traffic_bytes(step_plan(learner, learner.minibatch)[0], step_plan(learner, learner.minibatch)[1] * 256)
+                    if learner.minibatch == MINIBATCH else None,
                     "traffic_source": TRAFFIC_SOURCE,
                     "avg_launch_us": avg_s * 1e6, "launches": step_n, "rows_per_launch": learner.minibatch,
                     "algorithmic_flop_per_launch": FLOP_PER_SAMPLE_STEP * learner.minibatch}
@@ -792,7 +846,8 @@ def main():
         extra["gae_transitions_per_s"] = learner.n_trans / t_gae
         extra["roofline_gae"] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps,
                                  "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                                 "traffic": hbm_traffic_bytes("gae_single_pass") if learner.n_trans == N_TRANS else None,
+                                 # (the 2^20 launch's own counters: tiles of 2,048 transitions x 256 threads)
+                                 "traffic": hbm_traffic_bytes("gae_single_pass", -(-learner.n_trans // 2048) * 256),
                                  "traffic_source": TRAFFIC_SOURCE,
                                  "avg_launch_us": t_gae * 1e6, "transitions": learner.n_trans,
                                  "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * learner.n_trans}
@@ -802,7 +857,8 @@ def main():
             gbps_l = GAE_BYTES_PER_TRANSITION * n_l / t_l / 1e9
             extra[key] = {"bound": "hbm", "kernel": "gae_single_pass", "achieved": gbps_l,
                           "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps_l / PEAK_HBM_GBPS,
-                          "traffic": None, "avg_launch_us": t_l * 1e6, "transitions": n_l, "sub_buffers": envs,
+                          "traffic": hbm_traffic_bytes("gae_single_pass", -(-n_l // 2048) * 256),
+                          "traffic_source": TRAFFIC_SOURCE, "avg_launch_us": t_l * 1e6, "transitions": n_l, "sub_buffers": envs,
                           "transitions_per_s": n_l / t_l,
                           "algorithmic_bytes_per_launch": GAE_BYTES_PER_TRANSITION * n_l}
         t1 = time.perf_counter()

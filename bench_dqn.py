@@ -144,10 +144,16 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
         kinds[k] = {"achieved": tf, "frac": tf / PEAK_F32_MFMA_TFLOPS, "launches_per_update": n // n_prof,
                     "us_per_update": ms * 1e3 / n_prof, "algorithmic_flop_per_update": flop * BATCH}
     dom = max(kinds, key=lambda k: kinds[k]["us_per_update"])
+    # HBM bytes per launch of the dominant kind's kernels from the TCC counters of this very command (profiles/r06_pmc_dqn.json,
+    # scripts/gpu_r6_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), launch-weighted
+    names = {"conv_fwd": ("conv_rows_kernel<false", "conv_rows_kernel<0"), "conv_wgrad": ("conv_wgrad",),
+             "conv_dgrad": ("conv_rows_kernel<true", "conv_rows_kernel<1")}[dom]
+    traffic, traffic_parts = BI.pmc_traffic(os.path.join(ROOT, "profiles", "r06_pmc_dqn.json"), names)
     roof = {"bound": "mfma", "kernel": {"conv_fwd": "conv_rows_kernel<false,...> (3 forwards x 4 layers)",
                                         "conv_wgrad": "conv_wgrad_kernel", "conv_dgrad": "conv_rows_kernel<true,...>"}[dom],
             "achieved": kinds[dom]["achieved"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": kinds[dom]["frac"], "traffic": None,
+            "frac": kinds[dom]["frac"], "traffic": traffic, "traffic_by_kernel": traffic_parts,
+            "traffic_source": "profiles/r06_pmc_dqn.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --workload dqn`)",
             "avg_launch_us": kinds[dom]["us_per_update"] / kinds[dom]["launches_per_update"]}
     total_flop = sum(FLOP_BY_KIND.values()) * BATCH
     out = {

@@ -171,3 +171,37 @@ def warm_clocks(device=None, seconds: float = 0.3) -> None:
         for _ in range(8):
             a = torch.mm(a, b).clamp_(-1.0, 1.0)
         torch.cuda.synchronize(dev)
+
+
+def pmc_traffic(json_path: str, match: tuple, grid_threads=None):
+    """`roofline.traffic` of the bench lines whose figure covers several kernels (C3: the conv kernels of a kind, C5: every
+    linear-layer GEMM of an update): launch-weighted mean of (2 * FETCH_SIZE + WRITE_SIZE) KiB per launch over the kernels of
+    a scripts/rocprof_pmc.py --json file whose name contains one of `match` -- per launch, like `achieved`.  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md "HBM" prescribes for gfx950.  -> (bytes per launch, {kernel: [launches, bytes]}) or
+    (None, {}) when the profile is absent."""
+    import json
+
+    try:
+        with open(json_path) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
+        return None, {}
+    tot_b = tot_n = 0.0
+    parts = {}
+    for name, e in prof.items():
+        if not any(m in name for m in match):
+            continue
+        for gk, g in (e.get("by_grid") or {"": e}).items():
+            if "FETCH_SIZE" not in g or "WRITE_SIZE" not in g:
+                continue
+            if grid_threads is not None and gk and int(np.prod([int(x) for x in gk.split(",")])) != int(grid_threads):
+                continue
+            b = (2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024.0
+            tot_b += b * g["launches"]
+            tot_n += g["launches"]
+            k = parts.setdefault(name, [0, 0.0])
+            k[0] += int(g["launches"])
+            k[1] += b * g["launches"]
+    if not tot_n:
+        return None, {}
+    return int(tot_b / tot_n), {k: [v[0], int(v[1] / v[0])] for k, v in parts.items()}

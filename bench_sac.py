@@ -113,9 +113,14 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
     gemm_ms = sum(prof[k][0] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) / n_prof
     launches = sum(prof[k][1] for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")) // n_prof
     tf = FLOP_PER_SAMPLE * BATCH / (gemm_ms * 1e-3) / 1e12
+    # HBM bytes per GEMM launch from the TCC counters of this very command (profiles/r06_pmc_sac.json, written by
+    # scripts/gpu_r6_pmc.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes), launch-weighted over the same kernels
+    traffic, traffic_parts = BI.pmc_traffic(os.path.join(ROOT, "profiles", "r06_pmc_sac.json"), ("mlp3_fwd", "mlp3_bwd", "conv_wgrad_group"))
     roof = {"bound": "mfma", "kernel": "mlp3_fwd_kernel / mlp3_bwd_kernel / conv_wgrad_group_kernel (all linear-layer GEMMs of one update)",
             "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
-            "traffic": None, "avg_launch_us": gemm_ms * 1e3 / launches, "launches_per_update": launches,
+            "traffic": traffic, "traffic_by_kernel": traffic_parts,
+            "traffic_source": "profiles/r06_pmc_sac.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --workload sac`)",
+            "avg_launch_us": gemm_ms * 1e3 / launches, "launches_per_update": launches,
             "gemm_us_per_update": gemm_ms * 1e3,
             "kernel_us_per_update": {k: prof[k][0] * 1e3 / n_prof for k in ("conv_fwd", "conv_wgrad", "conv_dgrad")}}
     return {

@@ -295,6 +295,13 @@ int ts_ppo_policy_forward(ts_workspace* ws, const float* params, int64_t obs_dim
 int ts_ppo_policy_forward_bounded(ts_workspace* ws, const float* params, int64_t obs_dim, int64_t act_dim, double max_action,
                                   const float* obs, const float* noise, int64_t n, int bound_method, const float* low,
                                   const float* high, float* act_out, float* mapped_out, float* mu_out, ts_stream_t stream);
+/* dist.sample() + Algorithm.map_action (algorithm_base.py:254-287) for a mean that is already on the device (the per-layer
+ * engine's ts_ppo_net_infer mu_out, or a squashed SAC action with noise = NULL): act_out = mu + exp(log_sigma) * noise
+ * (noise NULL: act_out = mu), mapped_out (nullable) = clip / tanh bounding (bound_method 1 / 2) and scaling to
+ * [low, high] (nullable pair).  log_sigma float32[act_dim] (needed with noise). */
+int ts_gauss_sample_map(const float* mu, const float* noise, const float* log_sigma, int64_t n, int64_t act_dim,
+                        int bound_method, const float* low, const float* high, float* act_out, float* mapped_out,
+                        ts_stream_t stream);
 
 typedef struct ts_ppo_hparams {
     double eps_clip;      /* ppo.py:140 */
@@ -856,6 +863,11 @@ int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
 int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs, const float* noise, int64_t B,
                           int64_t obs_dim, int64_t act_dim, float* act_out, float* logp_out, float* aux_out,
                           ts_stream_t stream);
+/* The same pass as the collector calls it (data/collector.py:735-741): mu_out / sigma_out (nullable) float32[B, act_dim] =
+ * `logits` = (loc, scale) of the returned batch (sac.py:114, 125); no backward state is kept. */
+int ts_sac_policy_forward_logits(ts_workspace* ws, const float* actor, const float* obs, const float* noise, int64_t B,
+                                 int64_t obs_dim, int64_t act_dim, float* act_out, float* logp_out, float* mu_out,
+                                 float* sigma_out, ts_stream_t stream);
 
 /* ActorCriticOffPolicyAlgorithm._target_q + SAC._target_q_compute_value (ddpg.py:327-339, td3.py:94-102,
  * sac.py:290-296): a' ~ pi(s') with `noise`, min(Q1_old, Q2_old)(s', a') - alpha * log_prob -> out float32[B].

@@ -700,6 +700,145 @@ def gen_ppo_round6() -> None:
                 return_scaling=False, gae_lambda=0.95, gamma=0.99)
 
 
+def gen_policy_forward() -> None:
+    """what the Collector computes once per vector step (data/collector.py:735-744) -- `policy(batch)` =
+    Policy.forward, then `policy.map_action(act)` (algorithm_base.py:254-287) -- run through the UNMODIFIED reference for the
+    three policy families the engine overrides:
+      * `ProbabilisticActorPolicy` over ContinuousActorProbabilistic (reinforce.py:167-192): every action_bound_method
+        (clip / tanh / None) x action_scaling into an asymmetric Box, the unbounded actor and the reference's default bounded
+        one (max_action * tanh), the MuJoCo nets and a three-layer ReLU trunk, sampling (within a training step) and
+        dist.mode (deterministic_eval outside of one);
+      * `SACPolicy` (sac.py:108-131): rsample, tanh squashing, corrected log-probability, scaling;
+      * `DiscreteQLearningPolicy` over DQNet (dqn.py:101-143): logits, greedy action, with and without an action mask.
+    dist.sample() / rsample() consume torch's CPU generator through N(0, 1) draws that are scaled and shifted
+    (torch.normal(mean, std) / _standard_normal): the draws are recovered by re-running `normal_()` from the saved
+    generator state and stored as `noise` (asserted to reproduce the reference's action)."""
+    from tianshou.algorithm.modelfree.dqn import DiscreteQLearningPolicy
+    from tianshou.algorithm.modelfree.sac import SACPolicy
+    from tianshou.env.atari.atari_network import DQNet
+
+    out: dict[str, np.ndarray] = {}
+
+    def dist(loc_scale):
+        loc, scale = loc_scale
+        return Independent(Normal(loc, scale), 1)
+
+    def run_gauss(tag, *, obs_dim, act_dim, hidden, activation, max_action, bound, scaling, n, seed, training, det_eval):
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        net = Net(state_shape=(obs_dim,), hidden_sizes=hidden, activation=activation)
+        if max_action is None:
+            actor = ContinuousActorProbabilistic(preprocess_net=net, action_shape=(act_dim,), unbounded=True)
+        else:
+            actor = ContinuousActorProbabilistic(preprocess_net=net, action_shape=(act_dim,), max_action=max_action)
+        torch.nn.init.normal_(actor.sigma_param, mean=-0.7, std=0.3)
+        low, high = np.linspace(-2.0, -0.5, act_dim).astype(np.float32), np.linspace(0.4, 3.0, act_dim).astype(np.float32)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=scaling, action_bound_method=bound,
+                                              action_space=gym.spaces.Box(low=low, high=high, shape=(act_dim,)),
+                                              deterministic_eval=det_eval)
+        obs = (rng.normal(size=(n, obs_dim)) * 1.5).astype(np.float32)
+        st = torch.get_rng_state()
+        ctx = policy_within_training_step(policy) if training else contextlib.nullcontext()
+        with ctx, torch.no_grad():
+            res = policy(Batch(obs=obs, info={}), None)
+        mu, sigma = (t.numpy().copy() for t in res.logits)
+        act = res.act.numpy().copy()
+        sampled = training or not det_eval
+        if sampled:
+            torch.set_rng_state(st)
+            noise = torch.empty(n, act_dim).normal_().numpy()
+            assert np.allclose(mu + sigma * noise, act, rtol=0, atol=1e-6), "noise stream of dist.sample() not reproduced"
+        else:
+            noise = np.zeros((0, act_dim), np.float32)
+            assert np.array_equal(act, mu)
+        mapped = policy.map_action(act.copy())
+        sa = actor.state_dict()
+        keys = [k for k in sa if k != "sigma_param"] + ["sigma_param"]
+        for i, k in enumerate(keys):
+            out[f"{tag}_p{i}"] = sa[k].numpy().copy()
+        out[f"{tag}_keys"] = np.array(keys)
+        out[f"{tag}_obs"], out[f"{tag}_noise"], out[f"{tag}_mu"], out[f"{tag}_sigma"] = obs, noise, mu, sigma
+        out[f"{tag}_act"], out[f"{tag}_mapped"] = act, np.asarray(mapped, np.float32)
+        out[f"{tag}_low"], out[f"{tag}_high"] = low, high
+        out[f"{tag}_cfg"] = np.array([obs_dim, act_dim, {None: 0, "clip": 1, "tanh": 2}[bound], int(scaling), max_action or 0.0,
+                                      {nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation], seed, int(training), int(det_eval), int(sampled)],
+                                     np.float64)
+        out[f"{tag}_hidden"] = np.array(hidden)
+
+    import contextlib
+
+    mj = dict(obs_dim=17, act_dim=6, hidden=[64, 64], activation=nn.Tanh, n=96)
+    run_gauss("g_clip", max_action=None, bound="clip", scaling=True, seed=31, training=True, det_eval=False, **mj)
+    run_gauss("g_tanh", max_action=None, bound="tanh", scaling=True, seed=32, training=True, det_eval=True, **mj)
+    run_gauss("g_none", max_action=None, bound=None, scaling=False, seed=33, training=False, det_eval=True, **mj)      # dist.mode
+    run_gauss("g_bounded", max_action=1.0, bound="clip", scaling=True, seed=34, training=True, det_eval=False, **mj)  # default actor
+    run_gauss("g_bounded2", max_action=2.5, bound=None, scaling=False, seed=35, training=False, det_eval=False, **mj)
+    run_gauss("g_net", obs_dim=11, act_dim=3, hidden=[96, 72, 40], activation=nn.ReLU, n=70, max_action=1.5, bound="tanh",
+              scaling=True, seed=36, training=True, det_eval=False)
+    run_gauss("g_wide", obs_dim=40, act_dim=12, hidden=[128, 128], activation=nn.Tanh, n=65, max_action=None, bound="clip",
+              scaling=True, seed=37, training=True, det_eval=False)
+
+    # ---- SACPolicy (nets of examples/mujoco/mujoco_sac.py:82-104)
+    for tag, obs_dim, act_dim, hid, n, seed, training in (("s_train", 23, 5, 256, 80, 41, True), ("s_eval", 23, 5, 256, 33, 42, False),
+                                                         ("s_h128", 376, 17, 128, 48, 43, True)):
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hid, hid]),
+                                             action_shape=(act_dim,), unbounded=True, conditioned_sigma=True)
+        low, high = np.linspace(-3.0, -1.0, act_dim).astype(np.float32), np.linspace(0.5, 2.0, act_dim).astype(np.float32)
+        policy = SACPolicy(actor=actor, action_space=gym.spaces.Box(low=low, high=high, shape=(act_dim,)))
+        obs = rng.normal(size=(n, obs_dim)).astype(np.float32)
+        st = torch.get_rng_state()
+        ctx = policy_within_training_step(policy) if training else contextlib.nullcontext()
+        with ctx, torch.no_grad():
+            res = policy(Batch(obs=obs, info={}), None)
+        mu, sigma = (t.numpy().copy() for t in res.logits)
+        act = res.act.numpy().copy()
+        if training:
+            torch.set_rng_state(st)
+            noise = torch.empty(n, act_dim).normal_().numpy()
+            assert np.allclose(np.tanh(mu + sigma * noise), act, rtol=0, atol=1e-6), "noise stream of rsample() not reproduced"
+        else:
+            noise = np.zeros((0, act_dim), np.float32)
+        sa = actor.state_dict()
+        for i, (k, v) in enumerate(sa.items()):
+            out[f"{tag}_p{i}"] = v.numpy().copy()
+        out[f"{tag}_obs"], out[f"{tag}_noise"], out[f"{tag}_mu"], out[f"{tag}_sigma"] = obs, noise, mu, sigma
+        out[f"{tag}_act"], out[f"{tag}_logp"] = act, res.log_prob.numpy().copy()
+        out[f"{tag}_mapped"] = np.asarray(policy.map_action(act.copy()), np.float32)
+        out[f"{tag}_low"], out[f"{tag}_high"] = low, high
+        out[f"{tag}_cfg"] = np.array([obs_dim, act_dim, hid, seed, int(training)], np.float64)
+
+    # ---- DiscreteQLearningPolicy over DQNet (uint8 frames as the Atari wrappers deliver them: [n, c, h, w])
+    for tag, c, h, w, n_act, n, seed, masked in (("q_plain", 4, 44, 44, 6, 24, 51, False), ("q_mask", 2, 44, 36, 5, 17, 52, True)):
+        rng = np.random.default_rng(seed)
+        torch.manual_seed(seed)
+        model = DQNet(c=c, h=h, w=w, action_shape=n_act)
+        policy = DiscreteQLearningPolicy(model=model, action_space=gym.spaces.Discrete(n_act))
+        frames = rng.integers(0, 256, size=(n, c, h, w), dtype=np.uint8)
+        frames = np.where(rng.random(frames.shape) < 0.2, frames, 0).astype(np.uint8)
+        if masked:
+            mask = rng.random((n, n_act)) < 0.6
+            mask[np.arange(n), rng.integers(0, n_act, n)] = True
+            b = Batch(obs=Batch(obs=frames, mask=mask), info={})
+            out[f"{tag}_mask"] = mask
+        else:
+            b = Batch(obs=frames, info={})
+        with torch.no_grad():
+            res = policy(b, None)
+        for i, (k, v) in enumerate(model.state_dict().items()):
+            out[f"{tag}_p{i}"] = v.numpy().copy()
+        out[f"{tag}_obs"] = frames
+        out[f"{tag}_logits"] = res.logits.numpy().copy()
+        out[f"{tag}_act"] = np.asarray(res.act, np.int64)
+        out[f"{tag}_cfg"] = np.array([c, h, w, n_act, seed, int(masked)], np.float64)
+    np.savez_compressed(os.path.join(OUT, "policy_forward.npz"), **out)
+
+
 def gen_ppo_sched() -> None:
     """The mujoco_ppo.py configuration WITH its default linear learning-rate decay (lr_decay=True,
     examples/mujoco/mujoco_ppo.py:48,124-131): 3 epochs x 2 collects -> max_update_num 6, so four updates run at
@@ -1280,6 +1419,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "policy_forward":
+        gen_policy_forward()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_round6":
         gen_ppo_round6()

@@ -1,7 +1,10 @@
 """Mean PMC counter values per launch, grouped by kernel name + grid, from rocprofv3 rocpd databases:
     python scripts/rocprof_pmc.py a_results.db [b_results.db ...] [--match conv] [--json out.json]
---json also writes {kernel name: {"grid": [x, y, z], "launches": n, counter: mean per launch, ...}} (the heaviest grid of a
-name wins) -- bench.py reads profiles/r05_pmc_hbm_traffic.json, produced this way, for its `roofline.traffic` fields."""
+--json also writes {kernel name: {"grid": [x, y, z], "launches": n, counter: mean per launch, ...,
+"by_grid": {"x,y,z": {"launches": n, counter: mean, ...}, ...}}}: the top-level fields are those of the heaviest grid of the
+name, `by_grid` keeps EVERY launch geometry apart (round 5's file had the 2^24 launches of `gae_single_pass` overwrite the 2^20
+ones, so the bench line quoted a 16x over-fetch that does not exist) -- bench.py reads profiles/r06_pmc_hbm_traffic.json,
+produced this way, for its `roofline.traffic` fields and looks its kernels up by (name, grid)."""
 import collections
 import json
 import sqlite3
@@ -51,13 +54,22 @@ for key in sorted(acc):
               " wait_inst/wave_cycles:", round(c.get("SQ_WAIT_INST_ANY", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3))
 
 if json_out:
-    best = {}
+    best, grids = {}, collections.defaultdict(dict)
     for key in acc:
         name = key[0].split("<")[0].split("(")[0].strip().split("::")[-1]
+        if name == "conv_rows_kernel" and "<" in key[0]:      # <false, ...> forward / <true, ...> input gradient: two bench kinds
+            name += "<" + key[0].split("<", 1)[1].split(",")[0].strip()
         c = {k: v[0] / v[1] for k, v in acc[key].items()}
         n = next(iter(acc[key].values()))[1]
         weight = n * key[1] * max(key[2], 1) * max(key[3], 1)
+        entry = {"launches": n, **{k: v for k, v in sorted(c.items())}}
+        gkey = ",".join(str(int(x)) for x in key[1:])
+        if gkey in grids[name]:                               # template instantiations of one name with the same grid: pool them
+            old = grids[name][gkey]
+            tot = old["launches"] + n
+            entry = {"launches": tot, **{k: (old.get(k, v) * old["launches"] + v * n) / tot for k, v in sorted(c.items())}}
+        grids[name][gkey] = entry
         if name not in best or weight > best[name][0]:
-            best[name] = (weight, {"grid": list(key[1:]), "launches": n, **{k: v for k, v in sorted(c.items())}})
+            best[name] = (weight, {"grid": list(key[1:]), **entry})
     with open(json_out, "w") as f:
-        json.dump({k: v[1] for k, v in sorted(best.items())}, f, indent=1)
+        json.dump({k: {**v[1], "by_grid": grids[k]} for k, v in sorted(best.items())}, f, indent=1)

@@ -143,7 +143,7 @@ class EnsembleLinear(nn.Module):
 class ContinuousActorProbabilistic(nn.Module):
     """utils/net/continuous.py:172-238: preprocess + mu head (+ sigma head or sigma_param)."""
 
-    def __init__(self, preprocess_net, action_dim, unbounded=True, conditioned_sigma=False):
+    def __init__(self, preprocess_net, action_dim, unbounded=True, conditioned_sigma=False, max_action=1.0):
         super().__init__()
         self.preprocess = preprocess_net
         self.mu = _MLP([preprocess_net.output_dim, action_dim], None)
@@ -153,7 +153,7 @@ class ContinuousActorProbabilistic(nn.Module):
         else:
             self.sigma_param = nn.Parameter(torch.zeros(action_dim, 1))
         self._unbounded = unbounded
-        self.max_action = 1.0
+        self.max_action = 1.0 if unbounded else max_action          # continuous.py:199-201: discarded when unbounded
 
 
 class ContinuousCritic(nn.Module):
@@ -170,14 +170,41 @@ def dist_fn_categorical_from_logits(logits):
     return torch.distributions.Categorical(logits=logits)
 
 
-class Policy(nn.Module):
-    """algorithm_base.py Policy: `actor`, `is_within_training_step`; `dist_fn` of ProbabilisticActorPolicy (reinforce.py:94-165)."""
+class Box:
+    """gymnasium.spaces.Box as far as Algorithm.map_action reads it: `low`, `high`, `shape`."""
 
-    def __init__(self, actor, dist_fn=None):
+    def __init__(self, low, high, shape):
+        self.low = np.broadcast_to(np.asarray(low, np.float32), shape).copy()
+        self.high = np.broadcast_to(np.asarray(high, np.float32), shape).copy()
+        self.shape = tuple(shape)
+
+
+class Policy(nn.Module):
+    """algorithm_base.py Policy: `actor`, `is_within_training_step`; `dist_fn` / `deterministic_eval` of ProbabilisticActorPolicy
+    (reinforce.py:94-165); `action_space` / `action_scaling` / `action_bound_method` and `map_action` (algorithm_base.py:254-287,
+    restated line by line: the Collector calls it right behind forward, collector.py:744)."""
+
+    def __init__(self, actor, dist_fn=None, action_space=None, action_scaling=False, action_bound_method=None,
+                 deterministic_eval=False):
         super().__init__()
         self.actor = actor
         self.dist_fn = dist_fn
         self.is_within_training_step = False
+        self.action_space, self.action_scaling, self.action_bound_method = action_space, action_scaling, action_bound_method
+        self.deterministic_eval = deterministic_eval
+
+    def map_action(self, act):
+        act = act.detach().cpu().numpy() if isinstance(act, torch.Tensor) else np.asarray(act)
+        if isinstance(self.action_space, Box):
+            if self.action_bound_method == "clip":
+                act = np.clip(act, -1.0, 1.0)
+            elif self.action_bound_method == "tanh":
+                act = np.tanh(act)
+            if self.action_scaling:
+                assert np.min(act) >= -1.0 and np.max(act) <= 1.0
+                low, high = self.action_space.low, self.action_space.high
+                act = low + (high - low) * (act + 1.0) / 2.0
+        return act
 
 
 class EvalModeModuleWrapper(nn.Module):
@@ -212,8 +239,10 @@ class Algorithm(nn.Module):
         self.lr_schedulers = []
         self._optimizers = []
 
-    def _create_optimizer(self, module, lr, max_grad_norm=None, lr_lambda=None, eps=1e-8):
-        opt = torch.optim.Adam(module.parameters(), lr=lr, eps=eps)
+    def _create_optimizer(self, module, lr, max_grad_norm=None, lr_lambda=None, eps=1e-8, optim=None):
+        # `optim` = (torch.optim class, kwargs): what an OptimizerFactory of tianshou/algorithm/optim.py:89-140 builds
+        # (AdamOptimizerFactory incl. weight_decay, RMSpropOptimizerFactory); default AdamOptimizerFactory(lr, eps)
+        opt = torch.optim.Adam(module.parameters(), lr=lr, eps=eps) if optim is None else optim[0](module.parameters(), lr=lr, **optim[1])
         if lr_lambda is not None:                         # optim.py:22-53 (LambdaLR)
             self.lr_schedulers.append(torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lr_lambda))
         o = _Optimizer(opt, module, max_grad_norm)
@@ -265,10 +294,10 @@ class PPO(Algorithm):
 
     def __init__(self, *, policy, critic, lr=3e-4, lr_lambda=None, eps_clip=0.2, dual_clip=None, value_clip=False,
                  advantage_normalization=True, recompute_advantage=False, vf_coef=0.5, ent_coef=0.01,
-                 max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, gamma=0.99, return_scaling=False):
+                 max_grad_norm=None, gae_lambda=0.95, max_batchsize=256, gamma=0.99, return_scaling=False, optim=None):
         super().__init__(policy)
         self.critic = critic
-        self.optim = self._create_optimizer(_ActorCritic(policy.actor, critic), lr, max_grad_norm, lr_lambda)
+        self.optim = self._create_optimizer(_ActorCritic(policy.actor, critic), lr, max_grad_norm, lr_lambda, optim=optim)
         self.eps_clip, self.dual_clip, self.value_clip = eps_clip, dual_clip, value_clip
         self.advantage_normalization, self.recompute_adv = advantage_normalization, recompute_advantage
         self.vf_coef, self.ent_coef, self.gae_lambda, self.gamma = vf_coef, ent_coef, gae_lambda, gamma
@@ -506,6 +535,13 @@ class DiscreteQLearningPolicy(nn.Module):
         super().__init__()
         self.model = model
         self.is_within_training_step = False
+
+    def compute_q_value(self, logits, mask):
+        """dqn.py:145-151."""
+        if mask is not None:
+            min_value = logits.min() - logits.max() - 1.0
+            logits = logits + torch.as_tensor(1 - np.asarray(mask), dtype=logits.dtype, device=logits.device) * min_value
+        return logits
 
 
 class DQN(Algorithm):

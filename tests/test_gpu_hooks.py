@@ -1227,3 +1227,142 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     for i, p in enumerate(pa):
         np.testing.assert_allclose(state[p]["exp_avg"].cpu().numpy(), g[f"a{i}_m"], rtol=1e-3, atol=1e-6)
         assert state[p]["exp_avg"].shape == p.shape and float(state[p]["step"]) == stats.gradient_steps
+
+
+
+def _r6_optim(cfg):
+    """(torch.optim class, kwargs) of the factory that wrote a round-6 fixture (cfg = its cfg_keys / cfg_vals)."""
+    if cfg.get("opt_rmsprop"):
+        return torch.optim.RMSprop, dict(eps=cfg["opt_eps"], alpha=cfg["rms_alpha"], weight_decay=cfg["weight_decay"],
+                                         momentum=cfg["rms_momentum"], centered=bool(cfg["rms_centered"]))
+    return torch.optim.Adam, dict(eps=cfg["opt_eps"], weight_decay=cfg["weight_decay"])
+
+
+@pytest.mark.parametrize("tag", ["bounded", "a2c_rmsprop", "adam_wd"])
+def test_hip_ppo_hooks_replay_the_reference_with_its_default_actor_and_other_optimizers(tag):
+    """VERDICT r5 items 2 / 4 at hook level: `ContinuousActorProbabilistic(unbounded=False)` -- the constructor default,
+    mu = max_action * tanh(.) (utils/net/continuous.py:194, 230-231) -- and the optimizer of examples/mujoco/mujoco_a2c.py:117
+    (RMSprop(eps=1e-5, alpha=0.99), optim.py:113-140) / Adam with weight decay (optim.py:95-109).  HipPPO / HipA2C over the
+    stand-ins, production hook code on the fused engine: two update() calls on the buffer contents, weights and NumPy seeds of
+    the REFERENCE's own run (tests/golden/ppo_<tag>.npz, oracle/gen_golden.py::gen_ppo_round6) reproduce its per-step losses,
+    parameters, optimizer state (through state_dict()'s lazy flush, in torch.optim's own keys) and return statistics."""
+    import os
+
+    from tianshou_amd.integration import make_hip_ppo
+    from tianshou_amd.ppo import PPOEngine, flat_from_modules
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"ppo_{tag}.npz"))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    E, T, obs_dim, act_dim, batch_size, repeat, n_updates = (int(x) for x in g["dims"])
+    seed = {"bounded": 21, "a2c_rmsprop": 22, "adam_wd": 23}[tag]
+    a2c = cfg["is_a2c"] > 0
+    bounded = cfg["max_action"] > 0
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [64, 64], nn.Tanh), act_dim, unbounded=not bounded,
+                                            max_action=cfg["max_action"] or 1.0)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, [64, 64], nn.Tanh))
+    p0 = OP.unflatten_params(torch.from_numpy(g["flat_params0"]), obs_dim, act_dim)
+    from tianshou_amd.ppo import TIANSHOU_ACTOR_KEYS, TIANSHOU_CRITIC_KEYS
+
+    with torch.no_grad():
+        for mod, keys, names in ((actor, TIANSHOU_ACTOR_KEYS, OP.PARAM_ORDER[:7]), (critic, TIANSHOU_CRITIC_KEYS, OP.PARAM_ORDER[7:])):
+            named = dict(mod.named_parameters())
+            for k, nme in zip(keys, names):
+                named[k].copy_(p0[nme].reshape(named[k].shape))
+    kw = dict(vf_coef=cfg["vf_coef"], ent_coef=cfg["ent_coef"], max_grad_norm=cfg["max_grad_norm"] or None,
+              return_scaling=bool(cfg["return_scaling"]), gae_lambda=cfg["gae_lambda"], gamma=cfg["gamma"], lr=cfg["lr"],
+              optim=_r6_optim(cfg))
+    if not a2c:
+        kw.update(eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"] or None, value_clip=bool(cfg["value_clip"]),
+                  advantage_normalization=bool(cfg["advantage_normalization"]))
+    algo = make_hip_ppo("a2c" if a2c else "ppo", ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda",
+                                                          permutations="host", **kw).to("cuda")
+    assert algo._hip_dims == (obs_dim, act_dim, 64, "fused")
+    algo.policy.is_within_training_step = True
+    for u in range(n_updates):
+        pre_ = "" if u == 0 else f"u{u}_"
+        buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+        size = buf.maxsize // E
+        for t in range(T):                                   # slot e * size + t of the fixture's buffer = env e, step t
+            rows = np.arange(E) * size + t
+            buf.add(SI.Batch(obs=g[pre_ + "obs"][rows], act=g[pre_ + "act"][rows], rew=g[pre_ + "rew"][rows],
+                             terminated=g[pre_ + "terminated"][rows], truncated=g[pre_ + "truncated"][rows],
+                             obs_next=g[pre_ + "obs_next"][rows]))
+        np.random.seed(seed + 100 + u)
+        stats = algo.update(buf, batch_size, repeat)
+        assert isinstance(algo._hip_engine, PPOEngine) and stats.gradient_steps == int(g[f"u{u}_gradient_steps"])
+        assert (algo._hip_engine.cfg.max_action or 0.0) == cfg["max_action"]
+        for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+            ref = SI.SequenceSummaryStats.from_sequence(g[f"u{u}_losses"][:, col])
+            np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=1e-5, atol=2e-6)
+        flat = flat_from_modules(algo.policy.actor, algo.critic, device="cpu").numpy()
+        np.testing.assert_allclose(flat, g[f"u{u}_flat_params"], rtol=1e-4, atol=3e-6)
+        np.testing.assert_allclose([algo.ret_rms.mean, algo.ret_rms.var, algo.ret_rms.count], g[f"u{u}_ret_rms"], rtol=1e-5)
+    algo.state_dict()                                         # optimizer state arrives lazily, under torch.optim's own keys
+    state, params = algo.optim._optim.state, algo._hip_params()
+    k_m, k_v = ("exp_avg", "exp_avg_sq") if not cfg["opt_rmsprop"] else (None, "square_avg")
+    v_flat = torch.cat([state[p][k_v].reshape(-1).cpu() for p in params]).numpy()
+    np.testing.assert_allclose(v_flat, g[f"u{n_updates - 1}_adam_v"], rtol=1e-3, atol=1e-10)
+    if k_m:
+        m_flat = torch.cat([state[p][k_m].reshape(-1).cpu() for p in params]).numpy()
+        np.testing.assert_allclose(m_flat, g[f"u{n_updates - 1}_adam_m"], rtol=1e-3, atol=1e-7)
+    else:
+        assert all("momentum_buffer" not in state[p] and "grad_avg" not in state[p] for p in params)
+    assert all(float(state[p]["step"]) == sum(int(g[f"u{u}_gradient_steps"]) for u in range(n_updates)) for p in params)
+
+
+def test_hip_ppo_hooks_replay_a_bounded_actor_on_the_per_layer_engine():
+    """The reference's default (bounded) actor over a three-layer ReLU trunk with RMSprop: HipPPO picks the per-layer engine
+    (ts_net_desc.max_action) and reproduces the REFERENCE's update (tests/golden/ppo_net_bounded_relu3.npz)."""
+    import os
+
+    from tianshou_amd.integration import make_hip_ppo
+    from tianshou_amd.ppo_wide import NetPPOEngine
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ppo_net_bounded_relu3.npz")))
+    cfg = dict(zip([str(k) for k in g["cfg_keys"]], [float(v) for v in g["cfg_vals"]]))
+    E, T, obs_dim, act_dim, batch_size, repeat = (int(x) for x in g["dims"])
+    ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, nn.ReLU), act_dim, unbounded=False, max_action=float(g["max_action"]))
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, nn.ReLU))
+
+    def params(mod, head, extra=()):
+        lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)] + [m for m in head.modules() if isinstance(m, nn.Linear)]
+        out = []
+        for m in lin:
+            out += [m.weight, m.bias]
+        return out + list(extra)
+
+    pa, pc = params(actor, actor.mu, [actor.sigma_param]), params(critic, critic.last)
+    with torch.no_grad():
+        for i, p in enumerate(pa):
+            p.copy_(torch.from_numpy(g[f"a{i}_0"]))
+        for i, p in enumerate(pc):
+            p.copy_(torch.from_numpy(g[f"c{i}_0"]))
+    kw = dict(eps_clip=cfg["eps_clip"], dual_clip=cfg["dual_clip"] or None, value_clip=bool(cfg["value_clip"]),
+              advantage_normalization=bool(cfg["advantage_normalization"]), vf_coef=cfg["vf_coef"], ent_coef=cfg["ent_coef"],
+              max_grad_norm=cfg["max_grad_norm"] or None, return_scaling=bool(cfg["return_scaling"]), gae_lambda=cfg["gae_lambda"],
+              gamma=cfg["gamma"], lr=cfg["lr"], optim=_r6_optim(cfg))
+    algo = make_hip_ppo("ppo", ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", permutations="host", **kw).to("cuda")
+    assert algo._hip_dims[3] == "net"
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    size = buf.maxsize // E
+    for t in range(T):
+        rows = np.arange(E) * size + t
+        buf.add(SI.Batch(obs=g["obs"][rows], act=g["act"][rows], rew=g["rew"][rows], terminated=g["terminated"][rows],
+                         truncated=g["truncated"][rows], obs_next=g["obs_next"][rows]))
+    algo.policy.is_within_training_step = True
+    np.random.seed(26 + 100)
+    stats = algo.update(buf, batch_size, repeat)
+    assert isinstance(algo._hip_engine, NetPPOEngine) and stats.gradient_steps == int(g["gradient_steps"])
+    for col, s in enumerate((stats.loss, stats.actor_loss, stats.vf_loss, stats.ent_loss)):
+        ref = SI.SequenceSummaryStats.from_sequence(g["losses"][:, col])
+        np.testing.assert_allclose([s.mean, s.max, s.min], [ref.mean, ref.max, ref.min], rtol=2e-5, atol=2e-6)
+    for i, p in enumerate(pa):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"a{i}_1"], rtol=1e-4, atol=0.02 * cfg["lr"], err_msg=f"a{i}")
+    for i, p in enumerate(pc):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"c{i}_1"], rtol=1e-4, atol=0.02 * cfg["lr"], err_msg=f"c{i}")
+    algo.state_dict()
+    state = algo.optim._optim.state
+    for i, p in enumerate(pa):
+        np.testing.assert_allclose(state[p]["square_avg"].cpu().numpy(), g[f"a{i}_v"], rtol=2e-3, atol=1e-9)
+        assert "momentum_buffer" not in state[p] and float(state[p]["step"]) == stats.gradient_steps

@@ -73,6 +73,13 @@ def test_index_math_large_random_vs_oracle():
     assert torch.equal(buf.sample_indices(None), buf.sample_indices(0))
     neg = buf.sample_indices(-3)
     assert neg.numel() == 0 and neg.dtype == torch.int64 and neg.is_cuda
+    # the mirror of a PLAIN ReplayBuffer (buffer_base.py:513-517): None = len(self) random draws with replacement
+    plain = DeviceReplayBuffer(offset=np.array([0, 50]), last_index=np.array([29]), lengths=np.array([30]), insertion=np.array([30]),
+                               rew=np.zeros(50), terminated=np.zeros(50, bool), truncated=np.zeros(50, bool))
+    plain.is_manager = False
+    drawn = plain.sample_indices(None, seed=(7, 1)).cpu().numpy()
+    assert drawn.shape == (30,) and drawn.min() >= 0 and drawn.max() < 30 and len(np.unique(drawn)) < 30
+    assert np.array_equal(plain.sample_indices(0).cpu().numpy(), np.arange(30))
     # full C2-shaped buffer: sample_indices(0) is the identity
     full = DeviceReplayBuffer.from_vector_fill(E, rew=np.zeros(B), terminated=done, truncated=np.zeros(B, bool))
     assert full.indices_are_identity()

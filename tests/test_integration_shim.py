@@ -189,6 +189,101 @@ def test_default_bounded_actor_and_rmsprop_are_inside_the_envelope():
         ppo_config_from(build("a2c", [64, 64], RMSpropOptimizerFactory(lr=1e-3, momentum=0.9, centered=True)))
 
 
+def test_collector_side_policies_become_engine_backed_subclasses_of_the_real_classes():
+    """SURVEY 8f N2 on the REAL reference classes (CPU: no kernel runs): HipPPO / HipSAC / HipDQN give `algorithm.policy` --
+    the object the Collector calls (data/collector.py:735-744) -- a subclass of its own class whose forward / map_action are
+    the engine's; everything else (isinstance, state_dict keys, compute_action, add_exploration_noise, pickling as
+    highlevel/persistence.py:106 does it) is the reference's, `policy_forward="torch"` leaves the object alone, and without a
+    GPU the forward raises instead of computing on the CPU."""
+    ref_shim.install()
+    import io
+    import pickle
+
+    import gymnasium as gym
+    from torch import nn
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.dqn import DiscreteQLearningPolicy
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.modelfree.sac import SACPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.data import Batch
+    from tianshou.env.atari.atari_network import DQNet
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd import policy as HP
+    from tianshou_amd.integration import make_hip_dqn, make_hip_ppo, make_hip_sac
+
+    def ppo(hidden, **kw):
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=nn.Tanh),
+                                             action_shape=(6,), unbounded=True)
+        critic = ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=hidden, activation=nn.Tanh))
+        policy = ProbabilisticActorPolicy(actor=actor, dist_fn=_normal_dist, action_scaling=True, action_bound_method="clip",
+                                          action_space=gym.spaces.Box(low=-2.0, high=2.0, shape=(6,)))
+        return make_hip_ppo()(policy=policy, critic=critic, optim=AdamOptimizerFactory(lr=3e-4), device="cpu", **kw)
+
+    for hidden, fam in (([64, 64], "gauss"), ([128, 128], "gauss_wide"), ([96, 40], "gauss_net")):
+        a = ppo(hidden)
+        p = a.policy
+        assert isinstance(p, ProbabilisticActorPolicy) and isinstance(p, HP._HipForward) and p._hip_family == fam
+        assert type(p).__mro__[2] is ProbabilisticActorPolicy and p._hip_owner() is a
+        assert list(p.state_dict().keys()) == list(ProbabilisticActorPolicy.state_dict(p).keys())
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            p(Batch(obs=np.zeros((3, 17), np.float32), info={}), None)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            p.compute_action(np.zeros(17, np.float32))                       # algorithm_base.py:307-329 goes through forward
+        # map_action on an array that did not come from the last forward: the reference's own code
+        np.testing.assert_allclose(p.map_action(np.full((2, 6), 0.5, np.float32)), np.full((2, 6), 1.0))
+        import copy
+
+        from tests import standin as SI
+
+        pc = copy.deepcopy(p)
+        assert type(pc) is type(p) and pc._hip_owner() is None
+        pc.action_space = SI.Box(-2.0, 2.0, (6,))          # (the shim's gymnasium stub defines Box locally: not picklable by name)
+        buf = io.BytesIO()
+        torch.save(pc, buf)                                                   # persistence.py:106
+        buf.seek(0)
+        q = torch.load(buf, weights_only=False)
+        assert type(q) is type(p) and q._hip_owner() is None and q._hip_spec == p._hip_spec
+        assert all(torch.equal(x, y) for x, y in zip(q.state_dict().values(), p.state_dict().values()))
+        assert isinstance(pickle.loads(pickle.dumps(pc)), ProbabilisticActorPolicy)
+    t = ppo([64, 64], policy_forward="torch")
+    assert type(t.policy) is ProbabilisticActorPolicy
+    with torch.no_grad():
+        assert t.policy(Batch(obs=np.zeros((3, 17), np.float32), info={}), None).act.shape == (3, 6)       # the reference's forward
+
+    # SAC
+    def sac_net():
+        return Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[256, 256], concat=True)
+
+    actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[256, 256]), action_shape=(3,),
+                                         unbounded=True, conditioned_sigma=True)
+    sp = SACPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,)))
+    s = make_hip_sac()(policy=sp, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=ContinuousCritic(preprocess_net=sac_net()),
+                       critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=ContinuousCritic(preprocess_net=sac_net()),
+                       critic2_optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
+    assert isinstance(s.policy, SACPolicy) and s.policy._hip_family == "sac" and s.policy._hip_spec == dict(obs_dim=11, act_dim=3, hidden=256)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.policy(Batch(obs=np.zeros((2, 11), np.float32), info={}), None)
+    # DQN
+    qp = DiscreteQLearningPolicy(model=DQNet(c=2, h=44, w=36, action_shape=5), action_space=gym.spaces.Discrete(5), eps_training=0.3)
+    d = make_hip_dqn()(policy=qp, optim=AdamOptimizerFactory(lr=1e-4), device="cpu")
+    assert isinstance(d.policy, DiscreteQLearningPolicy) and d.policy._hip_family == "q" and d.policy._hip_spec == {"n_act": 5}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        d.policy(Batch(obs=np.zeros((2, 2, 44, 36), np.uint8), info={}), None)
+    d.policy.is_within_training_step = True                                  # epsilon-greedy stays the reference's (dqn.py:153-174)
+    np.random.seed(0)
+    acts = d.policy.add_exploration_noise(np.zeros(2000, np.int64), Batch(obs=np.zeros((2000, 1)), info={}))
+    assert 0.15 < float((acts != 0).mean()) < 0.3                             # eps * (1 - 1 / n_act) = 0.24
+
+
+def _normal_dist(loc_scale):
+    from torch.distributions import Independent, Normal
+
+    return Independent(Normal(*loc_scale), 1)
+
+
 def test_hip_ppo_update_orchestration_with_engine_double(monkeypatch):
     """HipPPO.update over the REAL reference PPO (CPU engine double): same steps as Algorithm._update
     (algorithm_base.py:586-631) minus the host `buffer.sample(0)`; the scheduler's learning rate reaches the engine on

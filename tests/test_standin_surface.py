@@ -39,6 +39,47 @@ def _standin_ppo(**kw):
     return SI.PPO(policy=SI.Policy(actor), critic=critic, lr=3e-4, **kw)
 
 
+def test_bounded_actor_and_rmsprop_standins_have_the_reference_surface():
+    """Round 6: the stand-ins of the reference's DEFAULT actor (unbounded=False, max_action) and of an Algorithm whose
+    optimizer comes from RMSpropOptimizerFactory (optim.py:113-140) expose what ppo_config_from / optimizer_fields read."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch.distributions import Independent, Normal
+
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import RMSpropOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import make_hip_ppo, ppo_config_from
+
+    def real_nets():
+        a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                         action_shape=(6,), max_action=1.7)
+        return a, ContinuousCritic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh))
+
+    ra, rc = real_nets()
+    fa = SI.ContinuousActorProbabilistic(SI.Net(17, [64, 64], nn.Tanh), 6, unbounded=False, max_action=1.7)
+    assert (ra._unbounded, ra.max_action) == (fa._unbounded, fa.max_action) == (False, 1.7)
+    assert list(ra.state_dict().keys()) == list(fa.state_dict().keys())
+    ru = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[64, 64], activation=nn.Tanh),
+                                      action_shape=(6,), unbounded=True, max_action=1.7)          # discarded (continuous.py:199-201)
+    assert ru.max_action == SI.ContinuousActorProbabilistic(SI.Net(17, [64, 64], nn.Tanh), 6, unbounded=True, max_action=1.7).max_action == 1.0
+    policy = ProbabilisticActorPolicy(actor=ra, dist_fn=lambda ls: Independent(Normal(*ls), 1), action_scaling=False,
+                                      action_bound_method=None, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(6,)))
+    kw = dict(vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99, return_scaling=True)
+    real = make_hip_ppo("a2c")(policy=policy, critic=rc, optim=RMSpropOptimizerFactory(lr=7e-4, eps=1e-5, alpha=0.99),
+                               device="cpu", **kw)
+    fake = make_hip_ppo("a2c", ref=SI)(policy=SI.Policy(fa), critic=SI.ContinuousCritic(SI.Net(17, [64, 64], nn.Tanh)), lr=7e-4,
+                                       optim=(torch.optim.RMSprop, dict(eps=1e-5, alpha=0.99)), device="cpu", **kw)
+    assert type(real.optim._optim) is type(fake.optim._optim) is torch.optim.RMSprop
+    g_r, g_f = real.optim._optim.param_groups[0], fake.optim._optim.param_groups[0]
+    for k in ("lr", "alpha", "eps", "weight_decay", "momentum", "centered"):
+        assert g_r[k] == g_f[k], k
+    assert ppo_config_from(real) == ppo_config_from(fake)
+    assert ppo_config_from(real).max_action == 1.7 and ppo_config_from(real).optimizer == "rmsprop"
+    assert real._hip_dims == fake._hip_dims == (17, 6, 64, "fused")
+
+
 def test_ppo_standin_has_the_reference_surface():
     kw = dict(eps_clip=0.2, dual_clip=None, value_clip=True, advantage_normalization=False, recompute_advantage=False,
               vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, gae_lambda=0.95, gamma=0.99, return_scaling=True)

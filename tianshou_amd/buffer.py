@@ -363,8 +363,10 @@ class DeviceReplayBuffer:
                 obs=np.asarray(buffer.obs)[sl], act=np.asarray(buffer.act)[sl],
                 obs_next=np.asarray(buffer.obs_next)[sl] if has("obs_next") else None, device=device)
         m.env_range, m.base, m.n_env_total = (lo, hi), base, n_env
+        m.is_manager = hasattr(buffer, "buffers")
         return m
 
+    is_manager = True                             # False: the mirror of a plain ReplayBuffer (sample_indices(None) differs)
     env_range: tuple[int, int] | None = None      # (lo, hi) of a shard mirror; None: the whole buffer
     base = 0                                      # first global slot of the mirror
     n_env_total: int | None = None
@@ -529,12 +531,14 @@ class DeviceReplayBuffer:
         `RandomState.choice(E, bs, p=...)` consumes) and `within` int64[bs] (the children's `choice(len_e, n_e)` values,
         concatenated in sub-buffer order).  Without them the draws come from torch's device generator (`generator`), or --
         `seed=(key, counter)` -- from the engine's counter-based generator inside the sampling kernel (one launch).
-        batch_size None -> the manager passes 0 to every child (manager.py:217-218): all indices in order, like 0;
+        batch_size None -> the manager passes 0 to every child (manager.py:217-218): all indices in order, like 0; the mirror
+        of a PLAIN ReplayBuffer (`is_manager` False) follows buffer_base.py:513-517 instead: batch_size = len(self), i.e.
+        len(self) random draws with replacement (through the same draw arguments as any batch_size > 0);
         batch_size < 0  -> an empty index array (manager.py:202-204)."""
         if batch_size is not None and batch_size < 0:
             return torch.empty(0, dtype=torch.int64, device=self.device)
         if batch_size is None:
-            batch_size = 0
+            batch_size = 0 if self.is_manager else len(self)
         if batch_size > 0:
             dev = self.device
             bs = int(batch_size)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -104,6 +105,24 @@ int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == m
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
 int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b);     // both side streams
 int record_td(ts_workspace* ws, hipStream_t s);       // the new priorities / the loss of an update are written on `s`
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: a process-wide "done" flag would skip it on
+// the second GPU a process drives (tests iterating devices, threaded data parallelism).  One of these per kernel (a function-
+// local static): remembers, per device, the largest size already granted; racing host threads at worst set it twice.
+struct DynLds {
+    std::atomic<int> granted[16] = {};
+    int allow(const void* fn, size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+        std::atomic<int>& g = granted[dev & 15];
+        if ((int)bytes <= g.load(std::memory_order_acquire)) return TS_OK;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(TS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize, %zu) failed: %s", bytes, hipGetErrorString(e));
+        int cur = g.load(std::memory_order_relaxed);
+        while (cur < (int)bytes && !g.compare_exchange_weak(cur, (int)bytes, std::memory_order_release)) {}
+        return TS_OK;
+    }
+};
 
 // Optimizer.step over one flat parameter vector (ts_optim.hip): torch.optim.Adam (optim.py:89-110) or torch.optim.RMSprop
 // (optim.py:113-140), both with the optional L2 term `grad += weight_decay * param` that torch applies inside step(),

@@ -42,8 +42,21 @@ struct GemmArgs {
     int AH, AW, JH, JW;   // dgrad: per-class output grid and taps per class
     int n_tile0;          // dgrad: first column tile of this launch
     int a_u8;             // forward / wgrad: the layer input is uint8 NHWC (raw frames), converted on load
+    int xcd;              // wgrad: 1 = XCD-aware block -> (tile, split) map (xcd_item)
     int64_t slab_stride;
 };
+
+// Workgroup b of a launch runs on XCD b % 8 (observed dispatch rule, MI355X_MICROARCH.md "Workgroup dispatch": used for speed
+// only), and every XCD has its own L2.  The weight-gradient grids order their work items tile-fastest: the (k tile, column
+// tile) items of ONE reduction split -- which all read the same rows of X and dY -- are neighbours, i.e. land on eight
+// DIFFERENT XCDs, and every XCD fetches those rows from HBM / the Infinity Cache for itself (C5 critics: 70 % L2 misses,
+// 189 MB fetched for 12 MB of operands, profiles/r06_pmc_sac_tcc.txt).  xcd_item gives XCD x the x-th CONTIGUOUS range of the
+// item sequence instead: block b takes item start(x) + b / 8 with x = b % 8, so a split's tiles share an L2 and run at about
+// the same time.  A bijection on [0, n): results are bit-identical, any other block -> XCD placement is merely no faster.
+__device__ __forceinline__ int xcd_item(int b, int n) {
+    const int q = n >> 3, rem = n & 7, x = b & 7;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
+}
 
 // ------------------------------------------------------------------------------------------------
 // rows = pixels: forward (DG = false) and dgrad (DG = true)
@@ -371,7 +384,16 @@ __device__ __forceinline__ void conv_wgrad_body(const GemmArgs& a, const int kt,
 template <int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[wgrad_smem_floats<TM, TN, WM, WN>()];
-    conv_wgrad_body<TM, TN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    int kt = blockIdx.x, ny = blockIdx.y, split = blockIdx.z;
+    if (a.xcd) {          // (dispatch order of a 3-D grid: x fastest)
+        const int per = gridDim.x * gridDim.y;
+        const int item = xcd_item((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), per * (int)gridDim.z);
+        split = item / per;
+        const int rem = item - split * per;
+        ny = rem / (int)gridDim.x;
+        kt = rem - ny * (int)gridDim.x;
+    }
+    conv_wgrad_body<TM, TN, WM, WN>(a, kt, ny, split, smem);
 }
 
 // The weight gradients of several layers in ONE launch (the three Linear layers of a SAC-family network, or of both twin
@@ -383,24 +405,37 @@ struct WgradGroup {
     GemmArgs a[WGRAD_GROUP_MAX];
     int first[WGRAD_GROUP_MAX + 1];        // first linear block of layer i
     int gx[WGRAD_GROUP_MAX], gy[WGRAD_GROUP_MAX];
-    int wide[WGRAD_GROUP_MAX];             // 1: <2, 1, 2, 2> (64 columns), 0: <1, 1, 4, 1> (32 columns)
+    int wide[WGRAD_GROUP_MAX];             // 1: 64 columns (<2, 1, 2, 2>, or <1, 1, 2, 2> in the SMALL kernel), 0: <1, 1, 4, 1> (32 columns)
     int n;
+    int xcd;                               // 1: XCD-aware block -> item map (xcd_item)
 };
 
 static_assert(sizeof(WgradGroup) <= 4000, "kernel arguments are limited to 4 KB");
 
+template <bool SMALL>
 __global__ __launch_bounds__(THREADS) void conv_wgrad_group_kernel(WgradGroup gr) {
+    const int item = gr.xcd ? xcd_item((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     int i = 0;
-    while (i + 1 < gr.n && (int)blockIdx.x >= gr.first[i + 1]) ++i;
-    const int local = (int)blockIdx.x - gr.first[i];
+    while (i + 1 < gr.n && item >= gr.first[i + 1]) ++i;
+    const int local = item - gr.first[i];
     const int per = gr.gx[i] * gr.gy[i];
     const int split = local / per, rem = local - split * per;
     const int ny = rem / gr.gx[i], kt = rem - ny * gr.gx[i];
-    constexpr int SMEM = wgrad_smem_floats<2, 1, 2, 2>() > wgrad_smem_floats<1, 1, 4, 1>() ? wgrad_smem_floats<2, 1, 2, 2>()
-                                                                                        : wgrad_smem_floats<1, 1, 4, 1>();
+    constexpr int S1 = wgrad_smem_floats<2, 1, 2, 2>() > wgrad_smem_floats<1, 1, 4, 1>() ? wgrad_smem_floats<2, 1, 2, 2>()
+                                                                                      : wgrad_smem_floats<1, 1, 4, 1>();
+    // SMALL: only the 64 x 64 and 128 x 32 variants are inlined -- 65 registers instead of 98 (the kernel's allocation is its
+    // largest variant's): 7 instead of 4 waves per SIMD
+    constexpr int S2 = wgrad_smem_floats<1, 1, 2, 2>() > wgrad_smem_floats<1, 1, 4, 1>() ? wgrad_smem_floats<1, 1, 2, 2>()
+                                                                                      : wgrad_smem_floats<1, 1, 4, 1>();
+    constexpr int SMEM = SMALL ? S2 : S1;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
-    if (gr.wide[i]) conv_wgrad_body<2, 1, 2, 2>(gr.a[i], kt, ny, split, smem);
-    else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split, smem);
+    if constexpr (SMALL) {
+        if (gr.wide[i]) conv_wgrad_body<1, 1, 2, 2>(gr.a[i], kt, ny, split, smem);
+        else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split, smem);
+    } else {
+        if (gr.wide[i]) conv_wgrad_body<2, 1, 2, 2>(gr.a[i], kt, ny, split, smem);
+        else conv_wgrad_body<1, 1, 4, 1>(gr.a[i], kt, ny, split, smem);
+    }
 }
 
 // out[i] = sum_s slabs[s][i]: a workgroup owns 64 consecutive floats (16 float4 columns) and splits the
@@ -515,8 +550,23 @@ int conv_fwd_splits(const ConvGeom& g) {
     return (int)ceil_div(chunks, per);
 }
 
+// 64 x 64 tiles (k rows x columns) instead of 128 x 64 for 64-column layers.  Round 6 (profiles/r06_wgrad_ab.txt): the
+// weight-gradient kernels at these sizes are bound by how many workgroups hide each other's load -> LDS -> MFMA latencies (matrix
+// pipe busy 37 % of the cycles, waves parked at waitcnt / barriers 43-50 %: profiles/r06_pmc_sac_sq.txt), not by operand traffic
+// (the XCD-aware block order removed the 70 % L2-miss re-reads and bought 7 %) and not by MFMAs per barrier (128 x 128 tiles:
+// 17 % slower).  The 64 x 64 variant needs 65 registers instead of 98: 7 instead of 4 waves per SIMD.  Default ON inside the
+// grouped launch (the SAC family: -6 % on the launch, REDQ -9 %), OFF for single launches (DQN's weight gradients run beside
+// the input-gradient chain on side streams: 151 -> 141 us of kernels, no change of the update).  TS_WGRAD_TILE64=0 / 1 forces
+// it (A/B runs; read per call).  Every tiling sums the same chunks in the same order: results are bit-identical.
+static bool wgrad_tile64(const ConvGeom& g, bool grouped) {
+    const char* e = getenv("TS_WGRAD_TILE64");
+    return g.OC % 64 == 0 && (e ? atoi(e) != 0 : grouped);
+}
+
 int conv_wgrad_splits(const ConvGeom& g) {
     if (conv2_use_wgrad(g, false)) return conv2_wgrad_splits(g);
+    // (the split count follows the 128 x 64 tile count whatever the tile variant: every output element sums the same chunks in
+    // the same order -- bit-identical results)
     const int bn = g.OC % 64 == 0 ? 64 : 32;
     const int64_t tiles = ceil_div(g.K(), 128) * (g.OC / bn);
     const int chunks = (int)ceil_div((int64_t)g.B * g.OH * g.OW, BK);
@@ -563,6 +613,12 @@ int conv_forward(hipStream_t s, const ConvGeom& g, const float* X, const float* 
     return TS_OK;
 }
 
+// TS_WGRAD_XCD=0: the plain block order (A/B runs; read per call)
+static int wgrad_xcd() {
+    const char* e = getenv("TS_WGRAD_XCD");
+    return e ? atoi(e) != 0 : 1;
+}
+
 int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY, float* slabs,
                ts_workspace* prof, bool x_u8) {
     if (int rc = check_geom(g)) return rc;
@@ -578,8 +634,12 @@ int conv_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* dY
     const int nsplit = conv_wgrad_splits(g);
     a.chunks = (int)ceil_div(a.total_chunks, nsplit);
     a.slab_stride = g.param_elems();
+    a.xcd = wgrad_xcd();
     ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
-    if (g.OC % 64 == 0) {
+    if (wgrad_tile64(g, false)) {
+        dim3 grid((unsigned)ceil_div(a.K, 64), g.OC / 64, nsplit);
+        hipLaunchKernelGGL((conv_wgrad_kernel<1, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
+    } else if (g.OC % 64 == 0) {
         dim3 grid((unsigned)ceil_div(a.K, 128), g.OC / 64, nsplit);
         hipLaunchKernelGGL((conv_wgrad_kernel<2, 1, 2, 2>), grid, dim3(THREADS), 0, s, a);
     } else {
@@ -607,6 +667,8 @@ int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const
     WgradGroup gr;
     gr.n = n;
     int blocks = 0;
+    bool small = false;
+    for (int i = 0; i < n; ++i) small = small || wgrad_tile64(g[i], true);
     for (int i = 0; i < n; ++i) {
         GemmArgs a = base_args(g[i]);
         a.a_u8 = 0;
@@ -617,14 +679,16 @@ int conv_wgrad_group(hipStream_t s, int n, const ConvGeom* g, const float* const
         a.slab_stride = g[i].param_elems();
         gr.a[i] = a;
         gr.wide[i] = g[i].OC % 64 == 0 ? 1 : 0;
-        gr.gx[i] = (int)ceil_div(a.K, 128);
+        gr.gx[i] = (int)ceil_div(a.K, (small && gr.wide[i]) ? 64 : 128);
         gr.gy[i] = g[i].OC / (gr.wide[i] ? 64 : 32);
         gr.first[i] = blocks;
         blocks += gr.gx[i] * gr.gy[i] * nsplit;
     }
     for (int i = n; i <= WGRAD_GROUP_MAX; ++i) gr.first[i] = blocks;
+    gr.xcd = wgrad_xcd();
     ProfScope scope(prof, TS_KIND_CONV_WGRAD, s);
-    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, s, gr);
+    if (small) hipLaunchKernelGGL(conv_wgrad_group_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, s, gr);
+    else hipLaunchKernelGGL(conv_wgrad_group_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, s, gr);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

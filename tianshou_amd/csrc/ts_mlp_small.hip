@@ -486,12 +486,8 @@ int ts_mlp_ppo_update(ts_workspace* ws, float* params, float* adam_m, float* ada
     a.omb1 = (float)(1.0 - hp->beta1); a.omb2 = (float)(1.0 - hp->beta2);
     a.losses = losses_out;
     const size_t lds = sizeof(float) * (size_t)L_END;
-    static bool attr_done = false;
-    if (!attr_done) {
-        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ppo_update_small_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static ts::DynLds attr;                      // per device (ts_common.h)
+    if (int rc = attr.allow(reinterpret_cast<const void*>(&mlp_ppo_update_small_kernel), lds)) return rc;
     hipLaunchKernelGGL(mlp_ppo_update_small_kernel, dim3(1), dim3(NT), lds, s, a);
     TS_LAUNCH_CHECK();
     // the host vectors above are pageable stack objects: wait until the three table copies have read them (the event

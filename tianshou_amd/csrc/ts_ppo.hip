@@ -1420,19 +1420,10 @@ int n_compute_units() {
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)T2_FLOATS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    static ts::DynLds attr2, attr1;              // per device (ts_common.h)
+    if (int rc = attr2.allow(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>), lds)) return rc;
     if (g.nets == 1 || g.nets == 2) {            // one network only (ts_ppo_hparams.nets)
-        static bool attr1_done = false;
-        if (!attr1_done) {
-            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr1_done = true;
-        }
+        if (int rc = attr1.allow(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1>), lds)) return rc;
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
         hipLaunchKernelGGL((ppo_step1_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d, g.nets - 1);
     } else {
@@ -1502,14 +1493,9 @@ inline StepPlan plan_step(const Dims& d, int ks, int64_t n_rows, int nets, bool 
 template <int K1S>
 int launch_stepq(ts_workspace* ws, const StepArgs& g, const Dims& d, const StepPlan& pl, hipStream_t s) {
     const size_t lds = q4::stepq_lds_bytes(g.rec_w);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::ppo_stepq_kernel<K1S>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::ppo_stepq2_kernel<K1S>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    static ts::DynLds attr_q, attr_q2;           // per device, the largest size granted so far (ts_common.h)
+    if (int rc = attr_q.allow(reinterpret_cast<const void*>(&q4::ppo_stepq_kernel<K1S>), lds)) return rc;
+    if (int rc = attr_q2.allow(reinterpret_cast<const void*>(&q4::ppo_stepq2_kernel<K1S>), lds)) return rc;
     ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
     if (pl.big) hipLaunchKernelGGL((q4::ppo_stepq2_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
     else hipLaunchKernelGGL((q4::ppo_stepq_kernel<K1S>), dim3(pl.grid), dim3(q4::QT), lds, s, g, d, pl.n_slabs);
@@ -1661,13 +1647,9 @@ size_t npg_fused_eval_floats(int64_t B, int n_cand) { return (size_t)n_cand * (s
 
 #define TS_NPG_LAUNCH(KERNEL, MODE, K, GRID)                                                                        \
     case K: {                                                                                                       \
-        static bool attr = false;                                                                                   \
+        static ts::DynLds attr;                                                                                     \
         const size_t lds = q4::actor_lds_bytes<MODE>(K);                                                            \
-        if (!attr) {                                                                                                \
-            TS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&q4::KERNEL<K>),                        \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-            attr = true;                                                                                            \
-        }                                                                                                           \
+        if (int rc_a = attr.allow(reinterpret_cast<const void*>(&q4::KERNEL<K>), lds)) return rc_a;                \
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);                                                                \
         hipLaunchKernelGGL((q4::KERNEL<K>), GRID, dim3(q4::QT), lds, s, g);                                         \
     } break;
@@ -1881,6 +1863,19 @@ int ts_ppo_policy_forward_bounded(ts_workspace* ws, const float* params, int64_t
     }
     hipLaunchKernelGGL(ppo_sample_map_kernel, dim3((unsigned)ts::ceil_div(n * act_dim, 256)), dim3(256), 0, s, mu, noise,
                        params + d.a_sig, n, (int)act_dim, bound_method, low, high, act_out, mapped_out);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_gauss_sample_map(const float* mu, const float* noise, const float* log_sigma, int64_t n, int64_t act_dim,
+                        int bound_method, const float* low, const float* high, float* act_out, float* mapped_out,
+                        ts_stream_t stream) {
+    TS_REQUIRE(n >= 0 && act_dim >= 1 && bound_method >= 0 && bound_method <= 2, TS_ERR_INVALID_ARG, "ts_gauss_sample_map: bad argument");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(mu && act_out && (!noise || log_sigma) && ((low == nullptr) == (high == nullptr)), TS_ERR_INVALID_ARG,
+               "ts_gauss_sample_map: NULL argument");
+    hipLaunchKernelGGL(ppo_sample_map_kernel, dim3((unsigned)ts::ceil_div(n * act_dim, 256)), dim3(256), 0, ts::as_stream(stream),
+                       mu, noise, log_sigma, n, (int)act_dim, bound_method, low, high, act_out, mapped_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -282,7 +282,9 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
                                                          int64_t B, int A, int head_cols, int obs_dim, int kc,
                                                          float* __restrict__ x_c, float* __restrict__ act_out,
-                                                         float* __restrict__ logp_out, float* __restrict__ keep) {
+                                                         float* __restrict__ logp_out, float* __restrict__ keep,
+                                                         float* __restrict__ mu_out = nullptr,
+                                                         float* __restrict__ sigma_out = nullptr) {
     // half a wavefront per sample, lane j = action dimension j (A <= 32); the two sums over j are butterfly
     // reductions inside the half-wave (fixed order)
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -302,6 +304,8 @@ __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict
         if (x_c) x_c[b * kc + obs_dim + j] = sq;
         if (act_out) act_out[b * A + j] = sq;
         if (keep) { keep[(b * 3 + 0) * A + j] = d; keep[(b * 3 + 1) * A + j] = sigma; keep[(b * 3 + 2) * A + j] = sq; }
+        if (mu_out) mu_out[b * A + j] = mu;                          // `logits` of SACPolicy.forward (sac.py:114, 125)
+        if (sigma_out) sigma_out[b * A + j] = sigma;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) {
@@ -1105,6 +1109,29 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     if (mu_sigma_out) {      // {a - mu, sigma, squashed} rows, for diagnostics / tests
         TS_HIP_CHECK(hipMemcpyAsync(mu_sigma_out, keep, sizeof(float) * B * 3 * d.act, hipMemcpyDeviceToDevice, s));
     }
+    return TS_OK;
+}
+
+int ts_sac_policy_forward_logits(ts_workspace* ws, const float* actor, const float* obs, const float* noise, int64_t B,
+                                 int64_t obs_dim, int64_t act_dim, float* act_out, float* logp_out, float* mu_out,
+                                 float* sigma_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_policy_forward_logits: workspace is NULL");
+    TS_REQUIRE(B >= 1 && actor && obs && logp_out, TS_ERR_INVALID_ARG, "ts_sac_policy_forward_logits: bad argument");
+    Dims d;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * split_floats(ma)) + 4096)) return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x_a = c.take<float>(B * d.ka);
+    const Act aa = take_act(c, B, 64, d.hid);
+    float* split = c.take<float>(split_floats(ma));
+    hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
+                       (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
+    if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
+    hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
+                       64, d.obs, d.kc, (float*)nullptr, act_out, logp_out, (float*)nullptr, mu_out, sigma_out);
+    TS_LAUNCH_CHECK();
     return TS_OK;
 }
 

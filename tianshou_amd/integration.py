@@ -339,6 +339,38 @@ def _check_supported(actor, critic):
     return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a) + (("conditioned_sigma",) if c_sigma else ()), "net"
 
 
+def _attach_gauss_policy(algorithm, policy_forward: str, sampling: str, noise_seed) -> None:
+    """the collector's `policy(batch)` / `policy.map_action(act)` (data/collector.py:735-744) on the engine's
+    inference kernels -- `tianshou_amd.policy.attach` gives `algorithm.policy` a subclass of its own class whose forward reads
+    the engine's device-resident parameters.  policy_forward="torch" keeps the reference's torch forward."""
+    if policy_forward not in ("hip", "torch"):
+        raise ValueError("policy_forward must be 'hip' or 'torch'")
+    if policy_forward == "torch":
+        return
+    from . import policy as HP
+
+    obs_dim, act_dim, hidden, kind = algorithm._hip_dims
+    actor = algorithm.policy.actor
+    ka, _ = _net_keys(actor, algorithm.critic)
+    max_action = None if getattr(actor, "_unbounded", False) else float(actor.max_action)
+    kw = dict(device=str(algorithm._hip_device), sampling=sampling, noise_seed=noise_seed, obs_dim=obs_dim, act_dim=act_dim,
+              max_action=max_action, actor_keys=tuple(ka))
+    if kind == "fused":
+        HP.attach(algorithm.policy, "gauss", algorithm, **kw)
+    elif kind == "wide":
+        from . import npg as NG
+
+        HP.attach(algorithm.policy, "gauss_wide", algorithm, hidden=int(hidden), n_actor=int(NG.layout(obs_dim, hidden, act_dim)["actor_count"]), **kw)
+    elif len(hidden) == 3:                                   # "net" without conditioned sigma (that head keeps the torch forward)
+        import ctypes as C
+
+        from . import _lib
+
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, list(hidden[0]), hidden[2])), _lib.i64(act_dim), out))
+        HP.attach(algorithm.policy, "gauss_net", algorithm, hidden=tuple(hidden[0]), activation=hidden[2], n_actor=int(out[1]), **kw)
+
+
 def make_hip_ppo(algo: str = "ppo", ref=None):
     """Returns the HipPPO class (imports tianshou lazily); algo="a2c": HipA2C(A2C), same networks.
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
@@ -349,7 +381,7 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
 
     class HipPPO(_HipGlue, PPO):
         def __init__(self, *args, device="cuda", permutations="device", perm_seed=None, data_parallel=False, group=None,
-                     allreduce=None, shard_buffer=True, **kwargs):
+                     allreduce=None, shard_buffer=True, policy_forward="hip", sampling="device", noise_seed=None, **kwargs):
             """`data_parallel=True` (one process per GPU, torch.distributed initialised): `update()` mirrors only this
             rank's sub-buffers of `buffer` (`shard_buffer`, by env id; pass False when every rank collects into its own
             buffer), computes values / GAE / log pi_old shard-locally with GLOBAL return statistics, and every minibatch
@@ -366,7 +398,13 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             continues the sequence); `state_dict()` itself keeps the reference's format.
             "host" draws np.random.permutation(N) per repeat exactly like Batch.split (batch.py:1209): the reference's
             sequence for a given seed (the mode the parity tests use), at ~10 ms of host time per 2^20 entries -- 100 ms
-            of a 12 ms update(), i.e. ~1.4 k instead of ~14 k update-steps/s at the C2 size."""
+            of a 12 ms update(), i.e. ~1.4 k instead of ~14 k update-steps/s at the C2 size.
+
+            `policy_forward="hip"` (default): `self.policy` -- what the Collector calls once per vector step
+            (collector.py:735-744) -- gets a subclass of its own class whose `forward` and `map_action` run on the engine's
+            inference kernels and read its device-resident parameters (`tianshou_amd.policy`); "torch" keeps the reference's
+            forward.  `sampling`: "device" draws dist.sample()'s noise with the engine's counter-based generator
+            (`noise_seed`; torch's generator untouched), "torch" from torch's CPU generator in the reference's order."""
             super().__init__(*args, **kwargs)
             if permutations not in ("host", "device"):
                 raise ValueError("permutations must be 'host' or 'device'")
@@ -381,6 +419,7 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             self._hip_glue_init()
             self._hip_batch = None
             self._hip_synced = False
+            _attach_gauss_policy(self, policy_forward, sampling, noise_seed)
 
         # -- the shuffle key travels BESIDE the checkpoint ---------------------------------------------
         # state_dict() stays in the reference's format (a HipPPO checkpoint loads into the reference PPO / A2C class with
@@ -391,13 +430,27 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
 
         def load_hip_extra_state(self, state: dict) -> None:
             self._hip_perm_seed, self._hip_updates = int(state["perm_seed"]), int(state["updates"])
+            self._hip_key_loaded = True
 
         def load_state_dict(self, state_dict, *args, **kwargs):
-            if "_hip_perm_state" in state_dict:                   # checkpoints of round-4 builds carried the pair inline
+            # checkpoints of round-4 builds carried the pair inline -- under "_hip_perm_state", or "<prefix>_hip_perm_state"
+            # when the algorithm was saved as a sub-module of a parent: taken out so that strict loading sees the reference's keys
+            legacy = [k for k in state_dict if k == "_hip_perm_state" or k.endswith("._hip_perm_state")]
+            if legacy:
                 state_dict = dict(state_dict)
-                st = state_dict.pop("_hip_perm_state")
-                self._hip_perm_seed, self._hip_updates = int(st[0]), int(st[1])
-            return super().load_state_dict(state_dict, *args, **kwargs)
+                for k in legacy:
+                    st = state_dict.pop(k)
+                    if k == "_hip_perm_state":
+                        self._hip_perm_seed, self._hip_updates = int(st[0]), int(st[1])
+            out = super().load_state_dict(state_dict, *args, **kwargs)
+            self._hip_key_loaded = "_hip_perm_state" in legacy        # (checked at the next update, see _update_with_batch)
+            return out
+
+        def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+            # the same legacy key when THIS module is loaded as part of a parent's state_dict (nn.Module.load_state_dict recurses
+            # through _load_from_state_dict, not through load_state_dict)
+            state_dict.pop(prefix + "_hip_perm_state", None)
+            return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
         # -- engine life cycle ------------------------------------------------------------------
         def _hip_flat(self, tensors) -> torch.Tensor:
@@ -553,6 +606,14 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             else:
                 from .buffer import random_permutation
 
+                if self.__dict__.get("_hip_key_loaded") is False and eng.adam_step > 0:
+                    # a trained checkpoint came in through load_state_dict alone: the optimizer continues, the shuffle key does not
+                    import warnings
+
+                    warnings.warn("HipPPO: resuming from a checkpoint without its device-permutation key: the shuffle sequence "
+                                  "restarts from this object's own (perm_seed, 0).  Save `hip_extra_state()` beside `state_dict()` "
+                                  "and restore it with `load_hip_extra_state()` to continue the sequence.", stacklevel=2)
+                self.__dict__["_hip_key_loaded"] = None
                 self._hip_updates += 1
                 rank = self._hip_world()[0]
                 key = ((self._hip_perm_seed * 0x9E3779B97F4A7C15) ^ (self._hip_updates << 20) ^ (rank << 52)) & (2**64 - 1)
@@ -821,10 +882,13 @@ def make_hip_dqn(ref=None):
     from . import dqn as D
 
     class HipDQN(_HipGlue, DQN):
-        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, **kwargs):
+        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, policy_forward="hip", **kwargs):
             """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer (its
             envs) and `_update_with_batch` all-reduces the flat gradient + loss (`DataParallelDQN`); PER priorities stay
-            rank-local.  `allreduce`: None = torch.distributed, "native" = the C-ABI RCCL exchange, or a callable."""
+            rank-local.  `allreduce`: None = torch.distributed, "native" = the C-ABI RCCL exchange, or a callable.
+            `policy_forward="hip"`: `DiscreteQLearningPolicy.forward` (dqn.py:101-143), which the Collector
+            calls per vector step, runs on `ts_dqn_forward` with the engine's parameters (`tianshou_amd.policy`); the
+            epsilon-greedy `add_exploration_noise` stays the reference's."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             sd = self.policy.model.state_dict()
@@ -834,6 +898,12 @@ def make_hip_dqn(ref=None):
             self._hip_engine = None
             self._hip_glue_init()
             self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer=False)
+            if policy_forward not in ("hip", "torch"):
+                raise ValueError("policy_forward must be 'hip' or 'torch'")
+            if policy_forward == "hip":
+                from . import policy as HP
+
+                HP.attach(self.policy, "q", self, device=str(self._hip_device), n_act=int(sd[D.TIANSHOU_KEYS[-1]].numel()))
 
         def _engine(self, c, h, w):
             if self._hip_engine is None:
@@ -1274,10 +1344,14 @@ def make_hip_sac(ref=None):
     class HipSAC(_HipGlue, SAC):
         _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("critic_lr", "critic2_optim"),
                    ("alpha_lr", "alpha"))
-        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, **kwargs):
+        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, policy_forward="hip",
+                     sampling="device", noise_seed=None, **kwargs):
             """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer and
             `_update_with_batch` runs the four phases of `DataParallelSAC` around two all-reduces (critic gradients,
-            actor gradient + mean log-probability); replicas stay identical, PER weights rank-local."""
+            actor gradient + mean log-probability); replicas stay identical, PER weights rank-local.
+            `policy_forward="hip"`: `SACPolicy.forward` (sac.py:108-131) as the Collector calls it runs on
+            `ts_sac_policy_forward_logits` with the engine's actor (`tianshou_amd.policy`; `sampling` / `noise_seed` as in
+            HipPPO)."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
@@ -1294,6 +1368,14 @@ def make_hip_sac(ref=None):
             self._hip_engine = None
             self._hip_glue_init()
             self._hip_dp_setup(data_parallel, group, allreduce, shard_buffer=False)
+            if policy_forward not in ("hip", "torch"):
+                raise ValueError("policy_forward must be 'hip' or 'torch'")
+            if policy_forward == "hip":
+                from . import policy as HP
+
+                HP.attach(self.policy, "sac", self, device=str(self._hip_device), sampling=sampling, noise_seed=noise_seed,
+                          obs_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1]), act_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]),
+                          hidden=hid)
 
         def _engine(self):
             if self._hip_engine is None:
