@@ -698,7 +698,7 @@ __device__ __forceinline__ f32x16 tile128_mma(const float* T, int rowA, int rowB
 
 // forward, loss and backward of one net for the wave's 32 samples, up to dZ2 (returned in h2), dZ1, the head-weight
 // gradients gw (lane = feature) and the `misc` row (lanes 0..7 head-bias gradients, 8..15 sigma gradients, 16 loss sum)
-template <int KS1, bool ACTOR>
+template <int KS1, bool ACTOR, bool BOUNDED = false>
 __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const StepArgs& g, const Dims& d,
                                             const TileIn<KS1>& in, int lane_in, f32x16 (&h1)[2], f32x16 (&h2)[2],
                                             f32x16 (&dz1)[2], float (&gw)[ACTOR ? ACT_PAD : 1], float& misc) {
@@ -721,7 +721,9 @@ __device__ __forceinline__ void net_fwd_bwd(float* lds, float* scratch, const St
         const f32x4 b0 = ld4(sm), b1 = ld4(sm + 4), v0 = ld4(sm + 8), v1 = ld4(sm + 12), s0 = ld4(sm + 16), s1 = ld4(sm + 20);
         float dlt[ACT_PAD], inv_var[ACT_PAD];
         [[maybe_unused]] float bgrad[ACT_PAD];              // bounded actor: 1 - tanh^2 of the head output
-        const bool bounded = g.mu_bound > 0.f;
+        // ContinuousActorProbabilistic(unbounded=False): a template parameter, not a kernel argument -- the uniform branch
+        // alone cost the unbounded (headline) kernel 1.4 us per launch through register allocation (profiles/r06_bounded_branch_ab.txt)
+        constexpr bool bounded = BOUNDED;
         float logp = 0.f;
         int n_act = d.act;
         asm volatile("" : "+s"(n_act));      // otherwise the 8 per-action constants are hoisted into (spilled) VGPRs
@@ -1019,7 +1021,7 @@ __device__ __forceinline__ void net_wgrad(float* lds, const StepArgs& g, const D
     TS_MARK(g, MK + 6);
 }
 
-template <int KS1>
+template <int KS1, bool BOUNDED = false>
 __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, Dims d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<KS1, 1>;
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
         float misc;
         {
             float gw[ACT_PAD];
-            net_fwd_bwd<KS1, true>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_fwd_bwd<KS1, true, BOUNDED>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
             net_wgrad<KS1, true>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
         }
         __syncthreads();                      // phase-B readers of the actor are done: the image region is free
@@ -1088,7 +1090,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step2_kernel(StepArgs g, 
 // slab reduction, the global norm and Adam see a zero gradient for it.  For callers whose other network is a stand-in:
 // Reinforce's minibatch steps (A2C's actor loss with adv := returns; no critic exists) and the critic iterations of
 // NPG / TRPO (A2C steps with a zero advantage; the actor takes no gradient there).
-template <int KS1>
+template <int KS1, bool BOUNDED = false>
 __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, Dims d, int net) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using L = Lds<KS1, 1>;
@@ -1123,7 +1125,7 @@ __global__ __launch_bounds__(STEP_THREADS, 2) void ppo_step1_kernel(StepArgs g, 
         float misc;
         if (net == 0) {
             float gw[ACT_PAD];
-            net_fwd_bwd<KS1, true>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
+            net_fwd_bwd<KS1, true, BOUNDED>(lds, scratch, g, d, in, lane, h1, h2, dz1, gw, misc);
             net_wgrad<KS1, true>(lds, g, d, in, h1, h2, dz1, gw, misc, wave, lane, slab, SL, first);
         } else {
             float gw[1];
@@ -1420,15 +1422,26 @@ int n_compute_units() {
 template <int KS1>
 int launch_step(ts_workspace* ws, const StepArgs& g, const Dims& d, int n_wg, hipStream_t s) {
     const size_t lds = sizeof(float) * (size_t)T2_FLOATS;
-    static ts::DynLds attr2, attr1;              // per device (ts_common.h)
-    if (int rc = attr2.allow(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1>), lds)) return rc;
+    static ts::DynLds attr2, attr1, attr2b, attr1b;      // per device (ts_common.h)
+    const bool bounded = g.mu_bound > 0.f;               // (its own instantiation: see net_fwd_bwd)
     if (g.nets == 1 || g.nets == 2) {            // one network only (ts_ppo_hparams.nets)
-        if (int rc = attr1.allow(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1>), lds)) return rc;
+        if (bounded) {
+            if (int rc = attr1b.allow(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1, true>), lds)) return rc;
+        } else {
+            if (int rc = attr1.allow(reinterpret_cast<const void*>(&ppo_step1_kernel<KS1, false>), lds)) return rc;
+        }
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-        hipLaunchKernelGGL((ppo_step1_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d, g.nets - 1);
+        if (bounded) hipLaunchKernelGGL((ppo_step1_kernel<KS1, true>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d, g.nets - 1);
+        else hipLaunchKernelGGL((ppo_step1_kernel<KS1, false>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d, g.nets - 1);
     } else {
+        if (bounded) {
+            if (int rc = attr2b.allow(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1, true>), lds)) return rc;
+        } else {
+            if (int rc = attr2.allow(reinterpret_cast<const void*>(&ppo_step2_kernel<KS1, false>), lds)) return rc;
+        }
         ts::ProfScope prof(ws, TS_KIND_PPO_STEP, s);
-        hipLaunchKernelGGL((ppo_step2_kernel<KS1>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        if (bounded) hipLaunchKernelGGL((ppo_step2_kernel<KS1, true>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
+        else hipLaunchKernelGGL((ppo_step2_kernel<KS1, false>), dim3(n_wg), dim3(STEP_THREADS), lds, s, g, d);
     }
     TS_LAUNCH_CHECK();
     return TS_OK;
