@@ -130,6 +130,121 @@ def test_one_shot_allreduce_between_two_processes_on_one_gpu():
     assert res == {0: 0, 1: 0}
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# DataParallelPPO between two PROCESSES on the one GPU against the single-process update, at the full C2 minibatch
+# --------------------------------------------------------------------------------------------------------------------
+DP_OBS, DP_ACT, DP_N, DP_MB, DP_REPEAT = 17, 6, 2 * 65536, 65536, 2
+
+
+def _dp_problem():
+    """The same synthetic batch, weights and per-rank permutations in every process (seeded)."""
+    import numpy as np
+    import torch
+
+    from oracle import oracle_ppo as OP
+
+    rng = np.random.default_rng(42)
+    data = dict(obs=rng.standard_normal((DP_N, DP_OBS), dtype=np.float32), act=rng.standard_normal((DP_N, DP_ACT), dtype=np.float32) * 0.5,
+                adv=rng.standard_normal(DP_N, dtype=np.float32), returns=rng.standard_normal(DP_N, dtype=np.float32),
+                logp_old=(rng.standard_normal(DP_N, dtype=np.float32) * 0.1 - 5.0), v_s=rng.standard_normal(DP_N, dtype=np.float32) * 0.3)
+    flat = OP.flatten_params(OP.init_params(DP_OBS, DP_ACT, seed=9))
+    half = DP_N // 2
+    perms = [[np.random.default_rng(100 * r + rep).permutation(half) for rep in range(DP_REPEAT)] for r in range(2)]
+    return data, flat, perms
+
+
+def _dp_cfg():
+    from tianshou_amd import ppo as P
+
+    return P.PPOConfig(eps_clip=0.2, vf_coef=0.25, ent_coef=0.0, max_grad_norm=0.5, value_clip=True, advantage_normalization=True,
+                       return_scaling=False, lr=3e-4)
+
+
+def _dp_worker(rank, world, port, out_q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("TS_SMALL_ALLREDUCE_SPINS", "40000000")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tianshou_amd import ppo as P
+        from tianshou_amd.collective import NativeAllReduce
+        from tianshou_amd.distributed import DataParallelPPO
+
+        torch.cuda.set_device(0)
+        data, flat, perms = _dp_problem()
+        half = DP_N // 2
+        lo = rank * half
+        b = {k: torch.as_tensor(v[lo:lo + half]).cuda().contiguous() for k, v in data.items()}
+        eng = P.PPOEngine(DP_OBS, DP_ACT, flat.cuda(), _dp_cfg())
+        ar = NativeAllReduce(torch.device("cuda", 0), rccl=False)          # one device: the one-shot IPC exchange
+        dp = DataParallelPPO(eng, allreduce=ar)
+        losses, steps = dp.update(b, DP_MB // world, DP_REPEAT, perms[rank])
+        torch.cuda.synchronize()
+        ar.check()
+        out_q.put((rank, steps, losses.cpu().numpy(), eng.params.cpu().numpy(), eng.adam_m.cpu().numpy()))
+        dist.barrier()
+        ar.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_update_on_one_gpu_equals_the_single_process_update():
+    """BASELINE configs[3] as far as one GPU can show it: two processes share the device, each holds half of
+    a 131,072-row batch and takes 32,768 rows of every 65,536-row GLOBAL minibatch (`ppo_step2_kernel` launches, per-minibatch
+    advantage statistics and the gradient summed over the ranks through `ts_ppo_dp_step`'s one-shot IPC all-reduce); the single
+    process runs the same four minibatches -- the union of the two ranks' rows -- through `ts_ppo_update`.  Same global batches,
+    same weights: losses agree to 1e-6, parameters and Adam moments to the rounding of a differently partitioned fp32 sum, and
+    the two replicas are bit-identical."""
+    import socket
+
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    from tianshou_amd import ppo as P
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(120)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs)
+    # the two replicas: identical losses, parameters and moments, bit for bit
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+    # single process on the union batches
+    data, flat, perms = _dp_problem()
+    half, mb = DP_N // 2, DP_MB // 2
+    eng = P.PPOEngine(DP_OBS, DP_ACT, flat.cuda(), _dp_cfg())
+    b = {k: torch.as_tensor(v).cuda().contiguous() for k, v in data.items()}
+    union = [np.concatenate([np.concatenate([perms[0][rep][c * mb:(c + 1) * mb], perms[1][rep][c * mb:(c + 1) * mb] + half])
+                             for c in range(half // mb)]) for rep in range(DP_REPEAT)]
+    assert all(len(u) == DP_N and len(np.unique(u)) == DP_N for u in union)
+    losses, steps = eng.update(b, DP_MB, DP_REPEAT, union)
+    torch.cuda.synchronize()
+    assert steps == res[0][0] == DP_REPEAT * (DP_N // DP_MB)
+    np.testing.assert_allclose(res[0][1], losses.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(res[0][2], eng.params.cpu().numpy(), rtol=1e-5, atol=0.02 * 3e-4)
+    ref_m = eng.adam_m.cpu().numpy()
+    np.testing.assert_allclose(res[0][3], ref_m, rtol=1e-4, atol=1e-6 * float(np.abs(ref_m).max()))
+
+
 def _bench_dry_run(cmd_tail, launcher, timeout):
     import json
     import os

@@ -1366,3 +1366,193 @@ def test_hip_ppo_hooks_replay_a_bounded_actor_on_the_per_layer_engine():
     for i, p in enumerate(pa):
         np.testing.assert_allclose(state[p]["square_avg"].cpu().numpy(), g[f"a{i}_v"], rtol=2e-3, atol=1e-9)
         assert "momentum_buffer" not in state[p] and float(state[p]["step"]) == stats.gradient_steps
+
+
+
+@pytest.mark.parametrize("tag", ["auto", "fixed"])
+def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
+    """VERDICT r5 item 8 for the SAC family: the HOOK path -- device mirror of a host buffer, `_preprocess_batch` (n-step
+    target with the lagged critics; n = 1 and 3), `_update_with_batch` (twin critics, actor, alpha, Polyak), write-back -- on the
+    real engine against what the unmodified REFERENCE's SAC.update() produced (tests/golden/sac_{auto,fixed}.npz,
+    oracle/gen_golden.py::gen_sac): same buffer contents and initial weights, the reference's own minibatch indices and the
+    rsample() noise it drew (the hooks draw `torch.randn` where the reference draws: the two calls per update are served from
+    the fixture)."""
+    from oracle import oracle_sac as OS
+    from tests.test_oracle_golden import load_sac
+    from tianshou_amd.integration import make_hip_sac
+
+    g, d, cfg, _ = load_sac(tag)
+    obs_dim, act_dim, E, B = d["obs_dim"], d["act_dim"], d["E"], d["batch"]
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+    p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"])                  # == the reference's initial weights (asserted by gen_sac)
+    for mod, pd, order in ((actor, p0[0], OS.ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER), (c2, p0[2], OS.CRITIC_ORDER)):
+        mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
+    alpha = SI.AutoAlpha(cfg.target_entropy, cfg.log_alpha0, cfg.alpha_lr) if cfg.auto_alpha else SI.FixedAlpha(cfg.alpha)
+    algo = make_hip_sac(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
+                                gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda").to("cuda")
+    buf = SI.VectorReplayBuffer(E * d["slots"], E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    lengths = g["buf_lengths"]
+    for t in range(int(lengths.max())):                                   # slot e * slots + t of the fixture's buffer = env e, step t
+        rows = np.arange(E) * d["slots"] + t
+        buf.add(SI.Batch(obs=g["obs"][rows], act=g["act"][rows], rew=g["rew"][rows], terminated=g["terminated"][rows],
+                         truncated=g["truncated"][rows], obs_next=g["obs_next"][rows]))
+    assert np.array_equal(buf._lengths, lengths) and np.array_equal(buf.last_index, g["buf_last_index"])
+    algo.policy.is_within_training_step = True
+    real_randn = torch.randn
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        monkeypatch.setattr(buf, "sample_indices", lambda bs, idx=idx: idx)
+        served = [torch.from_numpy(g[f"u{u}_noise_target"]), torch.from_numpy(g[f"u{u}_noise_actor"])]
+
+        def randn(*a, **k):
+            if not served or k.get("device") is not None:
+                return real_randn(*a, **k)
+            return served.pop(0).clone()
+
+        monkeypatch.setattr(torch, "randn", randn)
+        stats = algo.update(buf, B)
+        monkeypatch.setattr(torch, "randn", real_randn)
+        assert not served                                                 # both draws were consumed, in the reference's order
+        ref = g[f"u{u}_stats"]
+        np.testing.assert_allclose([stats.actor_loss, stats.critic1_loss, stats.critic2_loss], ref[:3], rtol=2e-5)
+        np.testing.assert_allclose(stats.alpha, ref[3], rtol=1e-5)
+        if cfg.auto_alpha:
+            np.testing.assert_allclose(stats.alpha_loss, ref[4], rtol=1e-5, atol=1e-6)
+        for name, mod in (("actor", actor), ("critic1", c1), ("critic2", c2), ("critic1_old", algo.critic_old.module),
+                          ("critic2_old", algo.critic2_old.module)):
+            flat = torch.cat([t.reshape(-1) for t in mod.state_dict().values()]).cpu().numpy()
+            lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
+            np.testing.assert_allclose(flat[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr, err_msg=f"update {u}: {name}")
+
+
+
+def test_hip_dqn_hooks_replay_the_reference():
+    """VERDICT r5 item 8 for the DQN family: the HOOK path on the real engine against what the unmodified REFERENCE's
+    DQN.update() produced on the Atari layout of examples/atari/atari_dqn.py:137-142 (tests/golden/dqn_atari.npz,
+    oracle/gen_golden.py::gen_dqn: single uint8 frames per slot, stack_num 4, no stored obs_next, wrapped sub-buffers, a
+    prioritized buffer, n-step 3, double-Q with a lagged network, Huber): the buffer state is the fixture's, `sample` returns the
+    reference's own minibatch indices, and per update the importance weights the stand-in buffer attaches, the TD errors that
+    reach `update_weight`, the loss and the parameters equal the reference's."""
+    from oracle import oracle_dqn as OD
+    from tests import dqn_common as DC
+    from tianshou_amd import dqn as D
+    from tianshou_amd.integration import make_hip_dqn
+
+    g, d, ocfg, _ = DC.load("atari")
+    c, h, w, A, E, B = d["c"], d["h"], d["w"], d["n_act"], d["E"], d["batch"]
+    assert d["per"] and d["stack"]
+    model = SI.DQNet(c, h, w, A)
+    p0 = OD.init_params(c, h, w, A, d["seed"])                            # == the reference's initial weights (asserted by gen_dqn)
+    model.load_state_dict({name: p0[k] for name, k in zip(D.TIANSHOU_KEYS, OD.PARAM_ORDER)})
+    algo = make_hip_dqn(ref=SI)(policy=SI.DiscreteQLearningPolicy(model), lr=ocfg.lr, gamma=ocfg.gamma,
+                                n_step_return_horizon=ocfg.n_step, target_update_freq=ocfg.target_update_freq,
+                                is_double=ocfg.is_double, huber_loss_delta=ocfg.huber_delta, device="cuda").to("cuda")
+    buf = SI.PrioritizedVectorReplayBuffer(E * d["slots"], E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                           stack_num=c, alpha=0.6, beta=0.4)
+    buf._meta = SI._Meta(("obs", "act", "rew", "terminated", "truncated", "done"))        # ignore_obs_next=True
+    buf.obs[:], buf.act[:], buf.rew[:] = g["frames"], g["act"], g["rew"]
+    buf.terminated[:], buf.truncated[:] = g["terminated"], g["truncated"]
+    buf.done[:] = g["terminated"] | g["truncated"]
+    buf._lengths[:], buf.last_index[:] = g["buf_lengths"], g["buf_last_index"]
+    for e, sb in enumerate(buf.buffers):
+        sb._size, sb._insertion_idx = int(g["buf_lengths"][e]), int(g["buf_insertion"][e])
+    assert bool((g["buf_insertion"] > 0).any()) and int(g["buf_lengths"].min()) == d["slots"]      # every sub-buffer has wrapped
+    n_leaf = E * d["slots"]
+    bound = 1
+    while bound < n_leaf:
+        bound *= 2
+    buf.prio[:] = g["tree0"][bound:bound + n_leaf]                        # the reference's sum-tree leaves before the first update
+    assert np.all(buf.prio == 1.0)                                        # new slots: max_prio ** alpha with max_prio = 1
+    algo.policy.is_within_training_step = True
+    eps = np.finfo(np.float32).eps.item()
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        buf.sample_indices = lambda bs, idx=idx: idx
+        seen = {}
+        orig = SI.PrioritizedVectorReplayBuffer.sample
+
+        def sample(bs, seen=seen):
+            batch, i = orig(buf, bs)
+            seen["w"] = np.asarray(batch.weight).copy()
+            return batch, i
+
+        buf.sample = sample
+        stat = algo.update(buf, B)
+        np.testing.assert_allclose(seen["w"], g[f"u{u}_is_weight"], rtol=1e-6)                   # prio.py:69-79 on the same priorities
+        np.testing.assert_allclose(stat.loss, float(g[f"u{u}_loss"]), rtol=1e-5)
+        upd_idx, upd_w = buf.weight_updates[-1]
+        assert np.array_equal(upd_idx, idx)
+        np.testing.assert_allclose(upd_w, np.abs(g[f"u{u}_td"]) + eps, rtol=1e-5, atol=2e-5)
+        tensors = [p.detach().cpu() for p in model.parameters()]
+        flat = torch.cat([t.reshape(-1) for t in tensors]).numpy()
+        np.testing.assert_allclose(flat[::61], g[f"u{u}_params_strided"], rtol=1e-5, atol=0.02 * ocfg.lr)
+        np.testing.assert_allclose(tensors[0].numpy(), g[f"u{u}_conv1_w"], rtol=1e-5, atol=0.02 * ocfg.lr)
+        lo, hi = g[f"u{u}_prio_minmax"]
+        np.testing.assert_allclose([buf._min_prio, buf._max_prio], sorted([float(lo), float(hi)]), rtol=1e-4)
+
+
+
+@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
+    """VERDICT r5 item 8 for the deterministic-actor family: HipTD3 / HipDDPG hook paths on the real engine against what the
+    unmodified REFERENCE's TD3.update() / DDPG.update() produced (tests/golden/td3_{twin,ddpg}.npz,
+    oracle/gen_golden.py::gen_td3): its minibatch indices, its target-policy smoothing noise (the hooks' one `torch.randn` per
+    update is served from the fixture), max_action 2 and n-step 2 for DDPG, the delayed actor step and the three / two Polyak
+    updates."""
+    from oracle import oracle_sac as OS
+    from tests.test_oracle_golden import load_td3
+    from tianshou_amd.integration import make_hip_ddpg, make_hip_td3
+
+    g, d, cfg, _ = load_td3(tag)
+    obs_dim, act_dim, B, twin = d["obs_dim"], d["act_dim"], d["batch"], d["twin"]
+    E, slots = int(g["dims"][0]), int(g["dims"][1])
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, max_action=cfg.max_action)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU)) if twin else None
+    p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin)            # == the reference's initial weights (asserted by gen_td3)
+    for mod, pd, order in ((actor, p0[0], OS.DET_ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER)) + (((c2, p0[2], OS.CRITIC_ORDER),) if twin else ()):
+        mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
+    if twin:
+        algo = make_hip_td3(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
+                                    gamma=cfg.gamma, policy_noise=cfg.policy_noise, update_actor_freq=cfg.update_actor_freq,
+                                    noise_clip=cfg.noise_clip, n_step_return_horizon=cfg.n_step, device="cuda").to("cuda")
+    else:
+        algo = make_hip_ddpg(ref=SI)(policy=SI.Policy(actor), critic=c1, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
+                                     gamma=cfg.gamma, n_step_return_horizon=cfg.n_step, device="cuda").to("cuda")
+    buf = SI.VectorReplayBuffer(E * slots, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    for k in ("obs", "obs_next", "act", "rew", "terminated", "truncated"):
+        getattr(buf, k)[:] = g[k]
+    buf.done[:] = g["terminated"] | g["truncated"]
+    buf._lengths[:], buf.last_index[:] = g["buf_lengths"], g["buf_last_index"]
+    for e, sb in enumerate(buf.buffers):
+        sb._size, sb._insertion_idx = int(g["buf_lengths"][e]), int(g["buf_insertion"][e])
+    algo.policy.is_within_training_step = True
+    real_randn = torch.randn
+    for u in range(d["n_updates"]):
+        idx = g[f"u{u}_indices"]
+        buf.sample_indices = lambda bs, idx=idx: idx
+        served = [torch.from_numpy(g[f"u{u}_noise"])] if twin else []
+
+        def randn(*a, **k):
+            if not served or k.get("device") is not None:
+                return real_randn(*a, **k)
+            return served.pop(0).clone()
+
+        monkeypatch.setattr(torch, "randn", randn)
+        stats = algo.update(buf, B)
+        monkeypatch.setattr(torch, "randn", real_randn)
+        assert not served
+        ref = g[f"u{u}_stats"]
+        got = [stats.actor_loss, stats.critic1_loss, stats.critic2_loss] if twin else [stats.actor_loss, stats.critic_loss]
+        np.testing.assert_allclose(got, ref[:len(got)], rtol=2e-5, atol=2e-6)
+        mods = [("actor", actor, cfg.actor_lr), ("critic1", c1, cfg.critic_lr), ("actor_old", algo.actor_old.module, cfg.actor_lr),
+                ("critic1_old", algo.critic_old.module, cfg.critic_lr)]
+        if twin:
+            mods += [("critic2", c2, cfg.critic_lr), ("critic2_old", algo.critic2_old.module, cfg.critic_lr)]
+        for name, mod, lr in mods:
+            flat = torch.cat([t.reshape(-1) for t in mod.state_dict().values()]).cpu().numpy()
+            want = g[f"u{u}_{name}"]
+            np.testing.assert_allclose(flat[::61] if want.shape != flat.shape else flat, want, rtol=1e-5, atol=0.02 * lr,
+                                       err_msg=f"update {u}: {name}")
