@@ -1041,15 +1041,23 @@ def gen_npg_all() -> None:
 
 
 def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
-                  n_updates: int, lr: float = 1e-3, **kwargs) -> None:
-    """Runs the reference Reinforce.update() (actor of examples/mujoco/mujoco_reinforce.py:84-103) on synthetic rollouts."""
+                  n_updates: int, lr: float = 1e-3, hidden=(64, 64), activation=nn.Tanh, max_action: float | None = None,
+                  optim: tuple[str, dict] | None = None, **kwargs) -> None:
+    """Runs the reference Reinforce.update() (actor of examples/mujoco/mujoco_reinforce.py:84-103) on synthetic rollouts.
+    Round 6: `hidden` / `activation` = any Net trunk (utils/net/common.py:90-178), `max_action` = the bounded (default) actor,
+    `optim` = ("rmsprop" | "adam", factory kwargs) -- the fixtures of the per-layer engine path (keys `a{i}_0 / a{i}_{u}`)."""
     from tianshou.algorithm.modelfree.reinforce import Reinforce
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
-    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    hidden = list(hidden)
+    generic = hidden != [64, 64] or activation is not nn.Tanh or max_action is not None or optim is not None
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden, activation=activation)
+    if max_action is None:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
+    else:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action)
     torch.nn.init.constant_(actor.sigma_param, -0.5)
     for m in actor.modules():
         if isinstance(m, nn.Linear):
@@ -1065,11 +1073,28 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
 
     policy = ProbabilisticActorPolicy(actor=actor, dist_fn=dist, action_scaling=True, action_bound_method="tanh",
                                       action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,)))
-    algorithm = Reinforce(policy=policy, optim=AdamOptimizerFactory(lr=lr), **kwargs)
-    keys = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
-            "preprocess.model.model.2.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    if optim is not None and optim[0] == "rmsprop":
+        from tianshou.algorithm.optim import RMSpropOptimizerFactory
+
+        optim_factory = RMSpropOptimizerFactory(lr=lr, **optim[1])
+    else:
+        optim_factory = AdamOptimizerFactory(lr=lr, **(optim[1] if optim else {}))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        algorithm = Reinforce(policy=policy, optim=optim_factory, **kwargs)
+    keys = [k for k in actor.state_dict() if k != "sigma_param"] + ["sigma_param"]
+    if not generic:
+        assert keys == ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
+                        "preprocess.model.model.2.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
     flat = lambda: torch.cat([actor.state_dict()[k].reshape(-1) for k in keys]).numpy().copy()  # noqa: E731
     out: dict[str, np.ndarray] = {"actor0": flat(), "dims": np.array([E, T, obs_dim, act_dim, batch_size or 0, repeat, n_updates])}
+    if generic:
+        out["hidden"], out["activation"] = np.array(hidden), np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation])
+        out["max_action"], out["keys"] = np.array(float(max_action or 0.0)), np.array(keys)
+        for i, k in enumerate(keys):
+            out[f"a{i}_0"] = actor.state_dict()[k].numpy().copy()
     perms, seqs, rets = [], [], []
     orig_perm, orig_from, orig_pre = np.random.permutation, SequenceSummaryStats.from_sequence.__func__, Reinforce._preprocess_batch
 
@@ -1114,6 +1139,13 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
             out[f"u{u}_perms"], out[f"u{u}_losses"] = np.stack(perms[p0:]), seqs[s0]
             out[f"u{u}_returns"], out[f"u{u}_indices"], out[f"u{u}_unfinished"] = rets[-1]
             out[f"u{u}_actor"] = flat()
+            if generic:
+                opt = algorithm.optim._optim
+                rmsp = type(opt).__name__ == "RMSprop"
+                named = dict(actor.named_parameters())
+                for i, k in enumerate(keys):
+                    out[f"u{u}_a{i}"] = actor.state_dict()[k].numpy().copy()
+                    out[f"u{u}_a{i}_v"] = opt.state[named[k]]["square_avg" if rmsp else "exp_avg_sq"].numpy().copy()
             rms = algorithm.discounted_return_computation.ret_rms
             out[f"u{u}_ret_rms"] = np.array([float(rms.mean), float(rms.var), float(rms.count)])
     finally:
@@ -1121,8 +1153,24 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
         SequenceSummaryStats.from_sequence = classmethod(orig_from)
     cfg = dict(gamma=algorithm.discounted_return_computation.gamma,
                return_standardization=float(algorithm.discounted_return_computation.return_standardization), lr=lr)
+    if generic:
+        g0 = algorithm.optim._optim.param_groups[0]
+        cfg.update(max_grad_norm=float(algorithm.optim._max_grad_norm or 0.0),
+                   opt_rmsprop=float(type(algorithm.optim._optim).__name__ == "RMSprop"), weight_decay=float(g0.get("weight_decay", 0.0)),
+                   opt_eps=float(g0["eps"]), rms_alpha=float(g0.get("alpha", 0.99)), rms_momentum=float(g0.get("momentum", 0.0)),
+                   rms_centered=float(g0.get("centered", False)))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"reinforce_{tag}.npz"), **out)
+
+
+def gen_reinforce_net() -> None:
+    """Round 6: Reinforce outside Net[h, h] tanh -- a three-layer ReLU trunk under the reference's default bounded actor with
+    RMSprop; a single wide tanh layer with Adam + weight decay, unbounded."""
+    gen_reinforce("net_relu3", E=4, T=48, obs_dim=11, act_dim=3, batch_size=64, repeat=2, seed=55, n_updates=2, gamma=0.97,
+                  return_standardization=True, hidden=(96, 72, 40), activation=nn.ReLU, max_action=1.5,
+                  optim=("rmsprop", dict(eps=1e-5, alpha=0.99)), lr=7e-4)
+    gen_reinforce("net_tanh1", E=3, T=40, obs_dim=20, act_dim=5, batch_size=None, repeat=1, seed=56, n_updates=2, gamma=0.99,
+                  return_standardization=False, hidden=(200,), activation=nn.Tanh, optim=("adam", dict(weight_decay=1e-2)), lr=1e-3)
 
 
 def gen_reinforce_all() -> None:
@@ -1398,6 +1446,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "drqn":
         gen_drqn_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "reinforce_net":
+        gen_reinforce_net()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "reinforce":
         gen_reinforce_all()

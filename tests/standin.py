@@ -372,10 +372,10 @@ class DiscountedReturnComputation:
 class Reinforce(Algorithm):
     """modelfree/reinforce.py:312-347: `discounted_return_computation`, `optim` over the policy."""
 
-    def __init__(self, *, policy, lr=1e-3, gamma=0.99, return_standardization=False, max_grad_norm=None):
+    def __init__(self, *, policy, lr=1e-3, gamma=0.99, return_standardization=False, max_grad_norm=None, optim=None):
         super().__init__(policy)
         self.discounted_return_computation = DiscountedReturnComputation(gamma, return_standardization)
-        self.optim = self._create_optimizer(policy, lr, max_grad_norm)
+        self.optim = self._create_optimizer(policy, lr, max_grad_norm, optim=optim)
 
     def update(self, buffer, batch_size, repeat):
         return self._update(0, buffer, lambda batch: self._update_with_batch(batch, batch_size, repeat))

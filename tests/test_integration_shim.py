@@ -1486,6 +1486,7 @@ def _reinforce_algo(hidden=64, **kw):
 
 def test_reinforce_subclass_keeps_signatures_and_fails_loudly():
     ref_shim.install()
+    import gymnasium as gym
     from tianshou.data import VectorReplayBuffer
     from tianshou.utils.torch_utils import policy_within_training_step
 
@@ -1500,8 +1501,29 @@ def test_reinforce_subclass_keeps_signatures_and_fails_loudly():
     _fill(buf, 8, (17,), np.zeros((2, 6), np.float32))
     with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
         algo.update(buffer=buf, batch_size=8, repeat=1)
+    assert algo._hip_kind == "legacy"
+    # round 6: trunks outside Net[h, h] with h a multiple of 32 take the per-layer engine instead of raising; what the engines do
+    # not model still raises at construction
+    assert _reinforce_algo(hidden=48)._hip_kind == "net"
+    from tianshou.algorithm.modelfree.reinforce import ProbabilisticActorPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory, RMSpropOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic
+    from tianshou_amd import integration as I
+
+    def build(optim, net_kw=None, **actor_kw):
+        a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(17,), hidden_sizes=[96, 40, 24], activation=torch.nn.ReLU, **(net_kw or {})),
+                                         action_shape=(6,), **actor_kw)
+        pol = ProbabilisticActorPolicy(actor=a, dist_fn=_normal_dist, action_space=gym.spaces.Box(-1, 1, (6,)))
+        return I.make_hip_reinforce()(policy=pol, optim=optim, gamma=0.97, device="cpu")
+
+    b = build(RMSpropOptimizerFactory(lr=1e-3, eps=1e-5), max_action=1.5)                    # the default (bounded) actor + RMSprop
+    assert b._hip_kind == "net" and b._hip_net[:3] == ([96, 40, 24], "relu", 1.5) and b._hip_net[3]["optimizer"] == "rmsprop"
+    assert build(AdamOptimizerFactory(lr=1e-3), unbounded=True)._hip_kind == "net"
     with pytest.raises(NotImplementedError):
-        _reinforce_algo(hidden=48)
+        build(AdamOptimizerFactory(lr=1e-3), unbounded=True, conditioned_sigma=True)
+    with pytest.raises(NotImplementedError):
+        build(AdamOptimizerFactory(lr=1e-3), net_kw=dict(norm_layer=torch.nn.LayerNorm), unbounded=True)
 
 
 def test_hip_reinforce_wrapper_runs_with_engine_double(monkeypatch):

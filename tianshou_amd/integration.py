@@ -760,39 +760,74 @@ def make_hip_reinforce(ref=None):
 
     class HipReinforce(_HipGlue, Reinforce):
         def __init__(self, *args, device="cuda", **kwargs):
+            """Net[h, h] tanh (h a multiple of 32) under an unbounded actor with plain Adam -- the nets of
+            examples/mujoco/mujoco_reinforce.py -- runs on the fused step kernel / the Net[h, h] GEMM path as before; every
+            other `Net(hidden_sizes=[...], activation=Tanh | ReLU | None)` trunk, the reference's default bounded actor
+            (max_action * tanh), Adam with weight decay and RMSprop (optim.py:89-140) take the per-layer engine
+            (`reinforce.NetReinforceEngine`, round 6).  conditioned_sigma and norm layers raise."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
-            sa = self.policy.actor.state_dict()
-            if set(sa.keys()) != set(TIANSHOU_ACTOR_KEYS):
-                raise NotImplementedError(f"{who}: the actor must be that of examples/mujoco/mujoco_reinforce.py")
-            hidden = sa[TIANSHOU_ACTOR_KEYS[0]].shape[0]
-            if hidden % 32 or sa[TIANSHOU_ACTOR_KEYS[2]].shape != (hidden, hidden):
-                raise NotImplementedError(f"{who}: hidden sizes [h, h] with h a multiple of 32")
-            if not getattr(self.policy.actor, "_unbounded", False) or getattr(self.policy.actor, "_c_sigma", True):
-                raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
-            _adam_of(self.optim)
+            actor = self.policy.actor
+            sa = actor.state_dict()
+            if getattr(actor, "_c_sigma", True):
+                raise NotImplementedError(f"{who}: the actor needs a state-independent sigma_param (no conditioned sigma)")
+            stems, hidden_sizes, act_name = _trunk_spec(actor, "actor")              # (raises for anything but Linear + Tanh / ReLU)
+            self._hip_keys = [f"{st}.{x}" for st in stems for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+            if set(sa.keys()) != set(self._hip_keys) or sa["mu.model.0.weight"].shape[1] != hidden_sizes[-1]:
+                raise NotImplementedError(f"{who}: the actor must be ContinuousActorProbabilistic over a Net trunk with a single-Linear mu head")
+            of = optimizer_fields(self.optim._optim)
+            bounded = not getattr(actor, "_unbounded", False)
+            plain = of["optimizer"] == "adam" and not of["weight_decay"]
+            legacy = (act_name == "tanh" and len(hidden_sizes) == 2 and hidden_sizes[0] == hidden_sizes[1] and hidden_sizes[0] % 32 == 0
+                      and not bounded and plain and self._hip_keys == list(TIANSHOU_ACTOR_KEYS))
+            if not legacy and (len(hidden_sizes) > 7 or max(hidden_sizes) > 1024 or sa["mu.model.0.weight"].shape[0] > 32):
+                raise NotImplementedError(f"{who}: trunks of up to 7 hidden layers of at most 1024 units, at most 32 actions")
+            self._hip_kind = "legacy" if legacy else "net"
+            self._hip_net = (hidden_sizes, act_name, float(actor.max_action) if bounded else None, of)
             self._hip_engine = None
             self._hip_glue_init()
 
         def _dims(self):
             sa = self.policy.actor.state_dict()
-            hidden, obs_dim = sa[TIANSHOU_ACTOR_KEYS[0]].shape
-            return obs_dim, hidden, sa[TIANSHOU_ACTOR_KEYS[4]].shape[0]
+            hidden, obs_dim = sa[self._hip_keys[0]].shape
+            return obs_dim, hidden, sa["mu.model.0.weight"].shape[0]
+
+        def _to_flat(self, tensors):
+            obs_dim, hidden, act_dim = self._dims()
+            if self._hip_kind == "legacy":
+                return NG.actor_flat_from_torch(tensors, obs_dim, hidden, act_dim, self._hip_device)
+            from .ppo_wide import net_flat_from_tensors
+
+            return net_flat_from_tensors(list(tensors), obs_dim, list(self._hip_net[0]), act_dim, self._hip_device)
+
+        def _from_flat(self, flat):
+            obs_dim, hidden, act_dim = self._dims()
+            if self._hip_kind == "legacy":
+                return NG.actor_flat_to_torch(flat, obs_dim, hidden, act_dim)
+            from .ppo_wide import net_flat_to_tensors
+
+            return net_flat_to_tensors(flat, obs_dim, list(self._hip_net[0]), act_dim, True)
 
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
                 dims = self._dims()
-                opt, g = _adam_of(self.optim)
+                opt = self.optim._optim
+                of = self._hip_net[3]
                 drc = self.discounted_return_computation
-                cfg = RF.ReinforceConfig(gamma=drc.gamma, return_standardization=drc.return_standardization, lr=g["lr"],
-                                         betas=tuple(g["betas"]), adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
-                dev = self._hip_device
-                eng = self._hip_engine = RF.ReinforceEngine(
-                    dims[0], dims[2], dims[1], NG.actor_flat_from_torch([sa[k] for k in TIANSHOU_ACTOR_KEYS], *dims, dev), cfg)
+                cfg = RF.ReinforceConfig(gamma=drc.gamma, return_standardization=drc.return_standardization, lr=of["lr"],
+                                         betas=tuple(of.get("betas", (0.9, 0.999))), adam_eps=of["adam_eps"],
+                                         max_grad_norm=self.optim._max_grad_norm)
+                flat = self._to_flat([sa[k] for k in self._hip_keys])
+                if self._hip_kind == "legacy":
+                    eng = self._hip_engine = RF.ReinforceEngine(dims[0], dims[2], dims[1], flat, cfg)
+                else:
+                    hidden_sizes, act_name, max_action, _ = self._hip_net
+                    eng = self._hip_engine = RF.NetReinforceEngine(dims[0], dims[2], hidden_sizes, act_name, flat, cfg,
+                                                                   max_action=max_action, optimizer=of)
                 eng.ret_rms = [float(drc.ret_rms.mean), float(drc.ret_rms.var), float(drc.ret_rms.count)]
-                ms, vs, step = adam_state(opt, params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS))     # resume
-                eng.adam_m, eng.adam_v = (NG.actor_flat_from_torch(x, *dims, dev) for x in (ms, vs))
+                ms, vs, step = adam_state(opt, params_by_keys(self.policy.actor, self._hip_keys))     # resume
+                eng.adam_m, eng.adam_v = self._to_flat(ms), self._to_flat(vs)
                 eng.adam_step = step
             return self._hip_engine
 
@@ -814,13 +849,11 @@ def make_hip_reinforce(ref=None):
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             losses, _ = eng.update(self._hip_obs, self._hip_act, batch.returns, batch_size, repeat, perms)
             arr = losses.cpu().numpy().astype(np.float64).reshape(-1)              # one D2H per update()
-            dims = self._dims()
-            aparams = params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS)
+            aparams = params_by_keys(self.policy.actor, self._hip_keys)
             with torch.no_grad():
-                for p, t in zip(aparams, NG.actor_flat_to_torch(eng.actor, *dims)):
-                    p.copy_(t.reshape(p.shape))
-            store_adam_state(self.optim._optim, aparams, NG.actor_flat_to_torch(eng.adam_m, *dims),
-                             NG.actor_flat_to_torch(eng.adam_v, *dims), eng.adam_step)
+                for p, t in zip(aparams, self._from_flat(eng.actor)):
+                    p.copy_(t.reshape(p.shape).to(p.device))
+            store_adam_state(self.optim._optim, aparams, self._from_flat(eng.adam_m), self._from_flat(eng.adam_v), eng.adam_step)
             return LossSequenceTrainingStats(loss=SequenceSummaryStats.from_sequence(arr))
 
     return HipReinforce

@@ -6,6 +6,7 @@ The actor uses the flat layout of ts_npg_layout (tianshou_amd.npg.actor_flat_fro
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from dataclasses import dataclass
 
@@ -180,3 +181,84 @@ class ReinforceEngine:
             return losses[:, :1].contiguous(), steps
         return run_minibatches(self.device, n, batch_size, repeat, perms,
                                lambda rows: self.step(obs[rows], act[rows], returns[rows]))
+
+
+class NetReinforceEngine(ReinforceEngine):
+    """ReinforceEngine's interface for actors outside Net[h, h] tanh (round 6): any `Net(hidden_sizes=[...], activation=Tanh |
+    ReLU | None)` trunk (utils/net/common.py:90-178, 246-369), the reference's DEFAULT bounded actor (max_action * tanh on mu,
+    utils/net/continuous.py:194, 230-231), Adam with weight decay or RMSprop (algorithm/optim.py:89-140).
+
+    Reinforce's loss -(log_prob * returns).mean() (reinforce.py:371-380) is A2C's actor loss (a2c.py:266-267) with adv := returns,
+    vf_coef = ent_coef = 0 and no advantage normalisation, so the minibatch loop runs on the per-layer actor-critic engine
+    (ppo_wide.NetPPOEngine: ts_ppo_net_step) beside a one-layer critic of zeros whose gradient is exactly zero (vf_coef = 0,
+    returns = 0): its parameters and optimizer state stay zero under Adam and RMSprop alike, the joint gradient norm is the
+    actor's.  `actor` / `adam_m` / `adam_v` are views of that engine's vectors (ts_net_layout order)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden, activation: str, actor: torch.Tensor, cfg: ReinforceConfig,
+                 max_action: float | None = None, optimizer: dict | None = None):
+        from .ppo_wide import NetPPOEngine
+
+        if not actor.is_cuda:
+            raise RuntimeError("NetReinforceEngine needs parameters on an MI355X (no CPU fallback)")
+        self.obs_dim, self.act_dim, self.hidden, self.cfg = obs_dim, act_dim, None, cfg
+        self.hidden_sizes, self.activation = [int(h) for h in hidden], activation
+        self.device = actor.device
+        opt = dict(optimizer or {})
+        pc = _ppo.PPOConfig(algo="a2c", vf_coef=0.0, ent_coef=0.0, advantage_normalization=False, max_grad_norm=cfg.max_grad_norm,
+                            lr=cfg.lr, betas=cfg.betas, adam_eps=cfg.adam_eps, max_action=max_action,
+                            optimizer=opt.get("optimizer", "adam"), weight_decay=opt.get("weight_decay", 0.0),
+                            rms_alpha=opt.get("rms_alpha", 0.99), rms_momentum=opt.get("rms_momentum", 0.0),
+                            rms_centered=opt.get("rms_centered", False))
+        probe = _lib.NetDesc.make(obs_dim, [32], activation)
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().ts_net_layout(C.byref(probe), _lib.i64(act_dim), out))
+        n_critic = int(out[2])
+        flat = torch.cat([actor.detach().float().reshape(-1), torch.zeros(n_critic, device=self.device)]).contiguous()
+        self._net = NetPPOEngine(obs_dim, act_dim, self.hidden_sizes, [32], activation, flat, pc)
+        if self._net.n_actor != actor.numel():
+            raise ValueError("flat actor vector does not match ts_net_layout")
+        self._rms_host, self._rms_dev = [0.0, 1.0, 0.0], None
+        self._ws = self._net._ws
+
+    # the learner's state lives in the per-layer engine's vectors
+    @property
+    def actor(self) -> torch.Tensor:
+        return self._net.params[: self._net.n_actor]
+
+    @property
+    def adam_m(self) -> torch.Tensor:
+        return self._net.adam_m[: self._net.n_actor]
+
+    @adam_m.setter
+    def adam_m(self, v) -> None:
+        self._net.adam_m[: self._net.n_actor] = v
+
+    @property
+    def adam_v(self) -> torch.Tensor:
+        return self._net.adam_v[: self._net.n_actor]
+
+    @adam_v.setter
+    def adam_v(self, v) -> None:
+        self._net.adam_v[: self._net.n_actor] = v
+
+    @property
+    def adam_step(self) -> int:
+        return self._net.adam_step
+
+    @adam_step.setter
+    def adam_step(self, v) -> None:
+        self._net.adam_step = int(v)
+
+    def fused_supported(self) -> bool:
+        return False
+
+    def update(self, obs, act, returns, batch_size: int | None, repeat: int, perms=None):
+        """-> (losses float32[steps, 1], steps)."""
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        n = obs.shape[0]
+        act, returns = self._f32(act, (n, self.act_dim)), self._f32(returns, (n,))
+        self._net.cfg.lr = self.cfg.lr                                    # (schedulers: the hooks refresh cfg.lr per update)
+        zeros = torch.zeros(n, dtype=torch.float32, device=self.device)
+        b = {"obs": obs, "act": act, "adv": returns, "returns": zeros, "logp_old": zeros, "v_s": zeros}
+        losses, steps = self._net.update(b, batch_size, repeat, perms)[:2]
+        return losses[:, :1].contiguous(), steps
