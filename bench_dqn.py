@@ -88,6 +88,7 @@ def cpu_baseline(updates: int = 3, budget_s: float = 10.0):
 
 PREFETCH = not os.environ.get("TS_DQN_NO_PREFETCH")      # A/B switch of the side-stream forward pass
 REPLAY_STREAM = not os.environ.get("TS_DQN_NO_REPLAY_STREAM")      # A/B switch: priority update + next batch beside the backward pass
+LEARN_STEP = not os.environ.get("TS_DQN_NO_LEARN_STEP")      # A/B switch: the whole update as one library call (ts_dqn_learn_step)
 
 
 def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
@@ -102,9 +103,13 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
     gen = torch.Generator(device="cuda").manual_seed(1)
 
     draw = lambda: torch.rand(BATCH, generator=gen, device="cuda", dtype=torch.float64)   # prio.py:65 draws  # noqa: E731
-    replay = D.ReplayStream(eng, buf, frames, per, C, draw, lambda i: act[i]) if REPLAY_STREAM else None
+    replay = D.ReplayStream(eng, buf, frames, per, C, draw, lambda i: act[i]) if REPLAY_STREAM and not LEARN_STEP else None
+    count = [0]
 
     def update():
+        if LEARN_STEP:      # the same cycle as below in one call: draws from the engine's Philox stream (key 1, update number)
+            count[0] += 1
+            return eng.learn_step(buf, frames, act, per, BATCH, (1, count[0]))[0]
         if replay is None:
             idx, wt = per.sample(draw())
             a, pair, coef = act[idx], None, None
@@ -167,6 +172,8 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
         "roofline": roof, "roofline_by_kind": kinds,
         "whole_update_mfma_frac": total_flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
         "host_enqueue_ms_per_step": t_host / steps * 1e3,
+        "update_path": "ts_dqn_learn_step (one library call per update)" if LEARN_STEP else
+                       "separate calls" + (" + replay stream" if REPLAY_STREAM else ""),
         "cpu_baseline": cpu_baseline() if with_cpu else None, "final_loss": float(loss),
     }
     return out

@@ -206,6 +206,10 @@ int ts_random_permutation(int64_t* out, int64_t n, uint64_t seed, ts_stream_t st
  * counter (e.g. the update number) so that successive calls draw fresh numbers.  Not torch's generator stream: to
  * reproduce a seeded reference run pass its noise to the update entry points instead (they all take it as an input). */
 int ts_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, ts_stream_t stream);
+/* np.random.rand(n) of the engine's own stream (the draws of PrioritizedReplayBuffer.sample_indices, prio.py:65, when the
+ * caller does not supply the reference's): out float64[n], out[i] = the 53-bit double in [0, 1) of Philox-4x32-10 keyed by
+ * `seed` at counter (i, `counter`) -- the draw ts_sample_indices_seeded makes for its buffer choice. */
+int ts_uniform_fill_f64(double* out, int64_t n, uint64_t seed, uint64_t counter, ts_stream_t stream);
 
 /* ReplayBuffer.__getitem__ row gather (buffer_base.py:605-649): out[i,:] = src[index[i],:]
  * for a row of `row_bytes` bytes (any dtype).  16-byte vector path when row_bytes % 16 == 0
@@ -571,6 +575,52 @@ int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* 
  * _postprocess_batch algorithm_base.py:562-581) and the sampling / gathering of the next batch need nothing else from the
  * update: issued on another stream behind this wait they run beside its backward pass and optimizer step. */
 int ts_dqn_wait_td(ts_workspace* ws, ts_stream_t stream);
+
+/* A device-resident Atari-layout replay buffer: one uint8 frame per slot, the observation of a transition being the stack of
+ * the `c` frames ending at it (ReplayBuffer(stack_num = c, save_only_last_obs = True, ignore_obs_next = True),
+ * buffer_base.py:60-110, 605-649; examples/atari/atari_dqn.py), held as DeviceReplayBuffer holds the reference's
+ * ReplayBufferManager columns; with a sum tree (`tree` != NULL) it is a PrioritizedVectorReplayBuffer (prio.py:25-47). */
+typedef struct ts_frame_replay {
+    const int64_t* offset;      /* int64[E + 1] sub-buffer offsets                                   */
+    int64_t E;
+    const int64_t* lengths;     /* int64[E]                                                          */
+    const int64_t* last_index;  /* int64[E]                                                          */
+    const uint8_t* done;        /* uint8[slots]                                                      */
+    const uint8_t* terminated;  /* uint8[slots]                                                      */
+    const double* rew;          /* float64[slots]                                                    */
+    const uint8_t* frames;      /* uint8[slots, plane_elems] (plane_elems = h * w)                   */
+    int64_t plane_elems;
+    const int64_t* act_col;     /* int64[slots]                                                      */
+    int64_t slots;
+    double* tree;               /* float64[2 * bound] sum tree (SegmentTree, segtree.py) or NULL     */
+    int64_t bound;
+    double* prio_minmax;        /* float64[2] = {max_prio, min_prio} (prio.py:36)                    */
+    double alpha, beta;         /* prio.py:32-33                                                     */
+    int32_t weight_norm;        /* prio.py:78-79                                                     */
+    int32_t reserved;
+} ts_frame_replay;
+
+/* OffPolicyAlgorithm.update (algorithm_base.py:583-631: buffer.sample -> _preprocess_batch -> _update_with_batch ->
+ * _postprocess_batch) of DQN on DQNet for such a buffer in ONE call.  Update number `counter` draws its batch as
+ * PrioritizedReplayBuffer.sample_indices does (prio.py:63-67) from u = ts_uniform_fill_f64(seed, counter) through
+ * ts_per_sample (indices + importance weights, prio.py:69-79) -- or, without a tree, as ts_sample_indices_seeded(seed,
+ * counter) --, gathers batch.act / obs / obs_next (ts_gather_rows, ts_dqn_gather_pair), computes the n-step returns
+ * (ts_nstep_coefficients + ts_dqn_target_returns) and runs ts_dqn_update_cached on a forward pass started beside the target
+ * passes (ts_dqn_forward_cache).  On a replay stream behind the loss kernel (ts_dqn_wait_td), beside the backward pass and the
+ * optimizer step: the priority update with the TD errors (ts_per_update_weight, prio.py:81-100) and the batch of update
+ * counter + 1, left in `scratch` (double-buffered by counter parity).  prepared != 0: the previous call (counter - 1, same
+ * scratch, buffer unchanged since) left this update's batch there; 0: it is sampled now.  Every value equals what the
+ * separate calls in that order produce.
+ * scratch: ts_dqn_learn_scratch_bytes bytes, 256-byte aligned, zeroed once by the caller; ws_aux: a second workspace -- the
+ * ahead-of-time forward pass and the replay stream (its first side stream) use it.  sync_target != 0: params_old := params
+ * between the returns and the update (dqn.py:283-285).  td_out nullable float32[B], idx_out nullable int64[B]: copies of the
+ * update's TD errors / indices on `stream`.  Frame stack 4 and plane sizes that are multiples of 16 bytes (ts_dqn_gather_pair). */
+int64_t ts_dqn_learn_scratch_bytes(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t B);
+int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                      float* adam_v, int64_t adam_step, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                      const ts_frame_replay* replay, int64_t B, int64_t n_step, double gamma, int is_double,
+                      const ts_dqn_hparams* hp, uint64_t seed, uint64_t counter, int prepared, void* scratch,
+                      int64_t scratch_bytes, float* td_out, float* loss_out, int64_t* idx_out, ts_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN on a recurrent Q network (DRQN, test/discrete/test_drqn.py:79-101): Recurrent (tianshou/utils/net/common.py:372-452)

@@ -474,3 +474,81 @@ def test_replay_stream_cycle_equals_the_sequential_cycle():
         for u, v in zip(x, y):
             assert torch.equal(u, v), it
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("prioritized,huber", [(True, 1.0), (True, 0.0), (False, 1.0)])
+def test_learn_step_equals_sample_preprocess_update_postprocess(prioritized, huber):
+    """DQNEngine.learn_step (ts_dqn_learn_step: the draws, the sum-tree descent and importance weights, the pair gather, n-step
+    coefficients, target passes, the periodic sync, the cached update and the priority update of one OffPolicyAlgorithm.update in
+    one library call, the next batch prepared on the replay stream) against the separate calls in the reference's order on one
+    stream with the same draws: seven updates on a 4096-slot frame buffer -- identical losses, TD errors, parameters, lagged
+    parameters, optimizer state, sum tree and running max / min priority; then learn_reset() and a changed seed key."""
+    import bench_dqn as BD
+    from tianshou_amd import dqn as D
+    B = 64
+
+    def make():
+        frames, act, buf, per = BD.build(4096, 4, seed=3)
+        p0 = OD.init_params(4, 84, 84, 6, 2)
+        cfg = D.DQNConfig(gamma=0.99, n_step=3, target_update_freq=3, is_double=True, huber_delta=huber, lr=1e-4)
+        eng = D.DQNEngine(4, 84, 84, 6, D.flat_from_torch([p0[k] for k in OD.PARAM_ORDER], 4, 84, 84, 6), cfg)
+        return frames, act, buf, (per if prioritized else None), eng
+
+    def seeds():
+        for it in range(7):
+            yield (77, it) if it < 5 else (78, it)      # a new key: nothing prepared for it
+
+    def separate():
+        frames, act, buf, per, eng = make()
+        log = []
+        for sd in seeds():
+            if per is not None:
+                idx, wt = per.sample(D.uniform_draws(B, sd))
+            else:
+                idx, wt = buf.sample_indices(B, seed=sd), None
+            obs, ret = eng.preprocess_with_obs(buf, frames, idx, 4)
+            loss, td = eng.update_with_batch(obs, act[idx], ret, wt)
+            if per is not None:
+                per.update_weight(idx, td)
+            log.append((loss.clone(), td.clone()))
+        torch.cuda.synchronize()
+        return log, eng, per
+
+    def one_call():
+        frames, act, buf, per, eng = make()
+        log = []
+        for k, sd in enumerate(seeds()):
+            if k == 3:
+                eng.learn_reset()                        # the prepared batch is dropped and drawn again: same values
+            loss, td = eng.learn_step(buf, frames, act, per, B, sd, want_td=True)
+            log.append((loss.clone(), td.clone()))
+        torch.cuda.synchronize()
+        return log, eng, per
+
+    a, b = separate(), one_call()
+    for it, (x, y) in enumerate(zip(a[0], b[0])):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), it
+    for name in ("params", "params_old", "adam_m", "adam_v"):
+        assert torch.equal(getattr(a[1], name), getattr(b[1], name)), name
+    assert a[1].adam_step == b[1].adam_step == 7 and a[1].iter == b[1].iter
+    if prioritized:
+        assert torch.equal(a[2].weight._value, b[2].weight._value) and torch.equal(a[2].prio_minmax, b[2].prio_minmax)
+    # layouts outside the call's are refused, not converted
+    frames, act, buf, per, eng = make()
+    with pytest.raises(ValueError):
+        eng.learn_step(buf, frames.float(), act, per, B, (1, 0))
+    with pytest.raises(ValueError):
+        eng.learn_step(buf, frames, act.int(), per, B, (1, 0))
+
+
+def test_uniform_draws_are_a_counter_based_stream():
+    """ts_uniform_fill_f64: doubles in [0, 1), a pure function of (key, counter, position) -- the prefix of a longer fill equals
+    the shorter one, different counters / keys give different streams --, uniform to sampling error."""
+    from tianshou_amd import dqn as D
+    u = D.uniform_draws(1 << 16, (5, 9))
+    assert u.dtype == torch.float64 and float(u.min()) >= 0.0 and float(u.max()) < 1.0
+    assert torch.equal(u[:100], D.uniform_draws(100, (5, 9)))
+    assert not torch.equal(u[:100], D.uniform_draws(100, (5, 10))) and not torch.equal(u[:100], D.uniform_draws(100, (6, 9)))
+    assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1 / 12) < 0.005
+    hist = torch.histc(u.float(), bins=16, min=0.0, max=1.0)
+    assert float((hist - 4096).abs().max()) < 400

@@ -230,6 +230,16 @@ def default_workspace(device_index: int) -> Workspace:
     return ws
 
 
+class FrameReplay(C.Structure):
+    """struct ts_frame_replay (include/tsengine.h)."""
+
+    _fields_ = [("offset", C.c_void_p), ("E", C.c_int64), ("lengths", C.c_void_p), ("last_index", C.c_void_p),
+                ("done", C.c_void_p), ("terminated", C.c_void_p), ("rew", C.c_void_p), ("frames", C.c_void_p),
+                ("plane_elems", C.c_int64), ("act_col", C.c_void_p), ("slots", C.c_int64), ("tree", C.c_void_p),
+                ("bound", C.c_int64), ("prio_minmax", C.c_void_p), ("alpha", C.c_double), ("beta", C.c_double),
+                ("weight_norm", C.c_int32), ("reserved", C.c_int32)]
+
+
 def aux_workspace(device_index: int) -> Workspace:
     """A second process-lifetime workspace per device for entry points that run two passes at once inside one call
     (ts_rnnq_learn_step's ahead-of-time forward pass beside the target passes)."""

@@ -429,4 +429,128 @@ int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* 
                            td_out, loss_out, grad_out, stream, cache, "ts_dqn_update_cached");
 }
 
+// ---- one call per update on a device-resident frame replay (uniform or prioritized) -----------------------------------------
+namespace {
+struct LearnBatch { int64_t* idx; int64_t* act; uint8_t* obs; uint8_t* obs_next; float* mask; double* gpow; double* mc; double* u;
+                    double* w64; float* w32; };
+struct LearnScratch { LearnBatch b[2]; float* returns; float* td; int* err; void* cache; size_t cache_bytes; };
+
+static size_t dqn_learn_carve(char* base, const Net& n, int64_t B, int64_t obs_elems, LearnScratch* out) {
+    char* p = base;
+    auto bytes = [&](size_t nbytes) { char* q = p; p += align_up(nbytes); return q; };
+    LearnScratch sc{};
+    for (int k = 0; k < 2; ++k) {
+        sc.b[k].idx = reinterpret_cast<int64_t*>(bytes(8 * (size_t)B));
+        sc.b[k].act = reinterpret_cast<int64_t*>(bytes(8 * (size_t)B));
+        sc.b[k].obs = reinterpret_cast<uint8_t*>(bytes((size_t)(B * obs_elems)));
+        sc.b[k].obs_next = reinterpret_cast<uint8_t*>(bytes((size_t)(B * obs_elems)));
+        sc.b[k].mask = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+        sc.b[k].gpow = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+        sc.b[k].mc = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+        sc.b[k].u = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+        sc.b[k].w64 = reinterpret_cast<double*>(bytes(8 * (size_t)B));
+        sc.b[k].w32 = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+    }
+    sc.returns = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+    sc.td = reinterpret_cast<float*>(bytes(4 * (size_t)B));
+    sc.err = reinterpret_cast<int*>(bytes(256));
+    sc.cache_bytes = fwd_scratch_bytes(n, B);
+    sc.cache = bytes(sc.cache_bytes);
+    if (out) *out = sc;
+    return (size_t)(p - base);
+}
+
+// batch.weight as `_update_with_batch` sees it: to_torch_as(weight float64, q float32) (dqn.py:392-394)
+static __global__ __launch_bounds__(256) void dqn_weight_f32_kernel(const double* __restrict__ w64, int64_t n, float* __restrict__ w32) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) w32[i] = (float)w64[i];
+}
+}  // namespace
+
+int64_t ts_dqn_learn_scratch_bytes(int64_t c, int64_t h, int64_t w, int64_t n_act, int64_t B) {
+    Net n;
+    if (B < 1 || make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n) != TS_OK) return -1;
+    return (int64_t)dqn_learn_carve(reinterpret_cast<char*>((uintptr_t)256), n, B, c * h * w, nullptr);
+}
+
+int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                      float* adam_v, int64_t adam_step, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                      const ts_frame_replay* rb, int64_t B, int64_t n_step, double gamma, int is_double, const ts_dqn_hparams* hp,
+                      uint64_t seed, uint64_t counter, int prepared, void* scratch, int64_t scratch_bytes, float* td_out,
+                      float* loss_out, int64_t* idx_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr && ws_aux != nullptr && ws != ws_aux, TS_ERR_WORKSPACE,
+               "ts_dqn_learn_step: two distinct workspaces (the update's, and the one of the ahead-of-time forward pass and the replay "
+               "stream)");
+    TS_REQUIRE(params && adam_m && adam_v && rb && hp && scratch && loss_out && B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG,
+               "ts_dqn_learn_step: bad argument");
+    TS_REQUIRE(rb->offset && rb->lengths && rb->last_index && rb->done && rb->terminated && rb->rew && rb->frames && rb->act_col &&
+                   rb->E >= 1 && rb->slots >= 1, TS_ERR_INVALID_ARG, "ts_dqn_learn_step: incomplete replay view");
+    TS_REQUIRE(rb->tree == nullptr || (rb->prio_minmax && rb->bound >= 1), TS_ERR_INVALID_ARG,
+               "ts_dqn_learn_step: a sum tree needs its bound and its {max, min} priority pair");
+    TS_REQUIRE(rb->plane_elems == h * w, TS_ERR_SHAPE, "ts_dqn_learn_step: frames of %lld elements for a %lld x %lld network input",
+               (long long)rb->plane_elems, (long long)h, (long long)w);
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255u) == 0, TS_ERR_INVALID_ARG,
+               "ts_dqn_learn_step: scratch must be 256-byte aligned");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    LearnScratch sc;
+    const size_t need = dqn_learn_carve(static_cast<char*>(scratch), n, B, c * h * w, &sc);
+    TS_REQUIRE(scratch_bytes >= (int64_t)need, TS_ERR_SHAPE, "ts_dqn_learn_step: scratch holds %lld bytes, %lld needed",
+               (long long)scratch_bytes, (long long)need);
+    hipStream_t s = ts::as_stream(stream), side, side2, replay;
+    if (int rc = ts::side_streams(ws, s, &side, &side2)) return rc;
+    // the replay stream: the aux workspace's own first side stream (== s while ts_profile_begin is active on `ws`)
+    if (ws->profiling) replay = s;
+    else if (int rc = ts::side_stream(ws_aux, s, &replay)) return rc;
+    // buffer.sample_indices (prio.py:63-67 / buffer_base.py:505-533) + get_weight (prio.py:69-79) -> batch.act / obs / obs_next ->
+    // the network-free half of compute_nstep_return, for update `ctr`
+    auto prepare = [&](hipStream_t st, const LearnBatch& b, uint64_t ctr) -> int {
+        if (rb->tree) {
+            if (int rc = ts_uniform_fill_f64(b.u, B, seed, ctr, st)) return rc;
+            if (int rc = ts_per_sample(ws_aux, rb->tree, rb->bound, b.u, B, rb->prio_minmax, rb->beta, rb->weight_norm, b.idx, b.w64, st))
+                return rc;
+            hipLaunchKernelGGL(dqn_weight_f32_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, st, b.w64, B, b.w32);
+            TS_LAUNCH_CHECK();
+        } else if (int rc = ts_sample_indices_seeded(rb->offset, rb->E, rb->lengths, seed, ctr, B, b.idx, sc.err, st)) {
+            return rc;
+        }
+        if (int rc = ts_gather_rows(rb->act_col, rb->slots, 8, b.idx, B, b.act, st)) return rc;
+        if (int rc = ts_dqn_gather_pair(rb->frames, rb->slots, rb->plane_elems, b.idx, B, n_step, c, rb->offset, rb->E, rb->done,
+                                        rb->last_index, rb->lengths, b.obs, b.obs_next, st))
+            return rc;
+        return ts_nstep_coefficients(b.idx, B, n_step, rb->offset, rb->E, rb->done, rb->terminated, rb->last_index, rb->lengths,
+                                     rb->rew, gamma, b.mask, b.gpow, b.mc, st);
+    };
+    const LearnBatch& cur = sc.b[counter & 1];
+    const LearnBatch& nxt = sc.b[(counter + 1) & 1];
+    // behind everything the previous call left on the replay stream: its priority update and this update's batch
+    if (int rc = ts::stream_wait(ws_aux, replay, s, 8)) return rc;
+    if (!prepared)
+        if (int rc = prepare(s, cur, counter)) return rc;
+    // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
+    if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
+    if (int rc = ts_dqn_forward_cache(ws->profiling ? ws : ws_aux, params, c, h, w, n_act, cur.obs, 1, B, sc.cache,
+                                      (int64_t)sc.cache_bytes, side2))
+        return rc;
+    if (int rc = ts_dqn_target_returns(ws, params, params_old, c, h, w, n_act, cur.obs_next, 1, B, is_double, cur.mask, cur.gpow,
+                                       cur.mc, sc.returns, s))
+        return rc;
+    if (sync_target && params_old)       // the periodic hard sync sits between _preprocess_batch and the update (dqn.py:283-285)
+        TS_HIP_CHECK(hipMemcpyAsync(params_old, params, sizeof(float) * (size_t)n.total, hipMemcpyDeviceToDevice, s));
+    if (int rc = ts::stream_wait(ws, side2, s, 7)) return rc;
+    if (int rc = dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, cur.obs, 1, cur.act, sc.returns,
+                                 rb->tree ? cur.w32 : nullptr, B, hp, sc.td, loss_out, nullptr, stream, sc.cache, "ts_dqn_learn_step"))
+        return rc;
+    // _postprocess_batch (prio.py:81-100: update_weight with the TD errors) and the next update's batch on the replay stream, behind
+    // the loss kernel (ts::record_td) and beside the backward pass and the optimizer step
+    if (replay != s) TS_HIP_CHECK(hipStreamWaitEvent(replay, ws->td_ev, 0));
+    if (rb->tree)
+        if (int rc = ts_per_update_weight(ws_aux, rb->tree, rb->bound, cur.idx, sc.td, B, rb->alpha, rb->prio_minmax, replay)) return rc;
+    if (int rc = prepare(replay, nxt, counter + 1)) return rc;
+    // (the TD errors stay in `scratch` for the replay stream: the caller's copy may be released before that stream is done)
+    if (td_out) TS_HIP_CHECK(hipMemcpyAsync(td_out, sc.td, 4 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (idx_out) TS_HIP_CHECK(hipMemcpyAsync(idx_out, cur.idx, 8 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return TS_OK;
+}
+
 }  // extern "C"

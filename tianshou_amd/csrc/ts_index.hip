@@ -646,6 +646,13 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
     c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
 }
 
+// np.random.rand(n) of the engine's own stream: u[i] = uniform53(seed, counter, i, 0) (PrioritizedReplayBuffer.sample_indices,
+// prio.py:65, inside ts_dqn_learn_step)
+__global__ __launch_bounds__(256) void uniform_fill_f64_kernel(double* __restrict__ out, int64_t n, uint64_t seed, uint64_t counter) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = uniform53(seed, counter, i, 0);
+}
+
 __global__ __launch_bounds__(256) void normal_fill_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (4 * q >= n) return;
@@ -791,6 +798,15 @@ int ts_normal_fill(float* out, int64_t n, uint64_t seed, uint64_t offset, ts_str
     TS_REQUIRE(out != nullptr, TS_ERR_INVALID_ARG, "ts_normal_fill: out is NULL");
     hipLaunchKernelGGL(normal_fill_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, ts::as_stream(stream), out, n,
                        seed, offset);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_uniform_fill_f64(double* out, int64_t n, uint64_t seed, uint64_t counter, ts_stream_t stream) {
+    TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_uniform_fill_f64: negative n");
+    if (n == 0) return TS_OK;
+    TS_REQUIRE(out != nullptr, TS_ERR_INVALID_ARG, "ts_uniform_fill_f64: out is NULL");
+    hipLaunchKernelGGL(uniform_fill_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ts::as_stream(stream), out, n, seed, counter);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }

@@ -238,6 +238,7 @@ class DQNEngine:
         self._ws = _lib.default_workspace(self.device.index or 0)
         self._pre = None               # (obs tensor, cache, done event, params version) of a prefetched forward pass
         self._side = None
+        self._learn = None             # state of `learn_step` (scratch, replay view, the seed of the batch prepared ahead)
 
     # -- the forward pass on batch.obs, ahead of time ------------------------------------------------
     def prefetch_forward(self, obs_nhwc: torch.Tensor) -> None:
@@ -427,6 +428,86 @@ class DQNEngine:
             _lib.i64(b), C.byref(hp), _lib.ptr(td), _lib.ptr(loss), _lib.ptr(grad_out),
             _lib.current_stream(self.device)))
         return loss, td
+
+    # -- sample + preprocess + update + priority update in one call (device-resident Atari-layout buffer) -------------------------
+    def learn_step(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, act_col: torch.Tensor, per, batch_size: int, seed,
+                   want_td: bool = False):
+        """OffPolicyAlgorithm.update (algorithm_base.py:583-631) as ONE library call (ts_dqn_learn_step): what `ReplayStream.take`
+        -> `preprocess_with_obs(prefetch=True)` -> `update_with_batch` -> `ReplayStream.give` do -- the same kernels on the same
+        values in the same order -- with the draws of update number `counter` taken from the engine's own Philox stream
+        (`uniform_draws(batch_size, seed)`; without priorities `buffer.sample_indices(batch_size, seed=seed)`).
+        -> (loss float32[1], td_error float32[B] or None).
+        per: segtree.PrioritizedWeights or None.  seed = (key, counter), counter advancing by one per call; call `learn_reset()`
+        after writing to the buffer or its priorities (the batch prepared ahead of time predates the write).  uint8 contiguous
+        frames [slots, h, w], frame stack = the network's channel count = 4, int64 actions (no fallback: use the separate calls
+        otherwise)."""
+        lib = _lib.load()
+        key, counter = int(seed[0]) & (2**64 - 1), int(seed[1]) & (2**64 - 1)
+        b = int(batch_size)
+        st = self._learn
+        ident = (id(buffer), frames.data_ptr(), act_col.data_ptr(), id(per), b)
+        if st is None or st["ident"] != ident:
+            if not (frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 3
+                    and tuple(frames.shape[1:]) == (self.h, self.w)):
+                raise ValueError(f"learn_step: frames must be uint8 contiguous [slots, {self.h}, {self.w}] on the device")
+            if not (act_col.is_cuda and act_col.dim() == 1 and act_col.dtype == torch.int64 and act_col.is_contiguous()):
+                raise ValueError("learn_step: actions must be an int64 contiguous device column")
+            if self.c != 4 or (self.h * self.w) % 16:
+                raise NotImplementedError("learn_step: frame stack 4 and planes of a multiple of 16 bytes (ts_dqn_gather_pair)")
+            if len(buffer) == 0:                             # buffer_base.py:512-513
+                raise ValueError("learn_step: empty buffer")
+            lib.ts_dqn_learn_scratch_bytes.restype = C.c_int64
+            need = int(lib.ts_dqn_learn_scratch_bytes(_lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act),
+                                                      _lib.i64(b)))
+            if need <= 0:
+                raise ValueError("learn_step: unsupported network / batch dimensions")
+            scratch = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)
+            tree = per.weight._value if per is not None else None
+            view = _lib.FrameReplay(
+                _lib.ptr(buffer.offset), buffer.buffer_num, _lib.ptr(buffer.lengths), _lib.ptr(buffer.last_index),
+                _lib.ptr(buffer.done), _lib.ptr(buffer.terminated), _lib.ptr(buffer.rew), _lib.ptr(frames), self.h * self.w,
+                _lib.ptr(act_col), frames.shape[0], _lib.ptr(tree), per.weight._bound if per is not None else 0,
+                _lib.ptr(per.prio_minmax) if per is not None else None, per._alpha if per is not None else 0.0,
+                per._beta if per is not None else 0.0, int(per._weight_norm) if per is not None else 0, 0)
+            st = self._learn = {"ident": ident, "scratch": scratch, "ptr": C.c_void_p((scratch.data_ptr() + 255) & ~255),
+                                "bytes": _lib.i64(need), "view": view, "aux": _lib.aux_workspace(self.device.index or 0),
+                                "last": None, "keep": (buffer, frames, act_col, per), "B": _lib.i64(b),
+                                "dims": (_lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act))}
+        cfg = self.cfg
+        sync = self.params_old is not None and self.iter % cfg.target_update_freq == 0    # dqn.py:283-285, applied inside the call
+        self.iter += 1
+        self.adam_step += 1
+        self._pre = None
+        td = torch.empty(b, dtype=torch.float32, device=self.device) if want_td else None
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        hp_of = (cfg.lr, cfg.betas, cfg.adam_eps, cfg.huber_delta, cfg.max_grad_norm)
+        if st.get("hp_of") != hp_of:
+            st["hp"], st["hp_of"] = cfg.to_c(), hp_of
+        prepared = st["last"] == (key, (counter - 1) & (2**64 - 1))
+        dims = st["dims"]
+        _lib.check(lib.ts_dqn_learn_step(
+            self._ws.handle, st["aux"].handle, _lib.ptr(self.params), _lib.ptr(self.params_old), C.c_int(int(sync)),
+            _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step), dims[0], dims[1], dims[2], dims[3],
+            C.byref(st["view"]), st["B"],
+            _lib.i64(cfg.n_step), _lib.f64(cfg.gamma), C.c_int(int(cfg.is_double)), C.byref(st["hp"]), C.c_uint64(key),
+            C.c_uint64(counter), C.c_int(int(prepared)), st["ptr"], st["bytes"], _lib.ptr(td), _lib.ptr(loss), None,
+            _lib.current_stream(self.device)))
+        st["last"] = (key, counter)
+        return loss, td
+
+    def learn_reset(self) -> None:
+        """Drops the batch `learn_step` prepared ahead of time (call it after transitions were written to the buffer)."""
+        if self._learn is not None:
+            self._learn["last"] = None
+
+
+def uniform_draws(n: int, seed, device="cuda") -> torch.Tensor:
+    """float64[n] in [0, 1): the draws `DQNEngine.learn_step` makes for update seed = (key, counter) in place of the reference's
+    np.random.rand(batch_size) (prio.py:65) -- ts_uniform_fill_f64."""
+    out = torch.empty(int(n), dtype=torch.float64, device=device)
+    _lib.check(_lib.load().ts_uniform_fill_f64(_lib.ptr(out), _lib.i64(n), C.c_uint64(int(seed[0]) & (2**64 - 1)),
+                                               C.c_uint64(int(seed[1]) & (2**64 - 1)), _lib.current_stream(out.device)))
+    return out
 
 
 class ReplayStream:
