@@ -621,6 +621,14 @@ int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, flo
                       const ts_frame_replay* replay, int64_t B, int64_t n_step, double gamma, int is_double,
                       const ts_dqn_hparams* hp, uint64_t seed, uint64_t counter, int prepared, void* scratch,
                       int64_t scratch_bytes, float* td_out, float* loss_out, int64_t* idx_out, ts_stream_t stream);
+/* With TS_DQN_GRAPH=1 in the environment ts_dqn_learn_step replays its steady state (same arguments as the two calls before,
+ * batch prepared ahead, priorities present) from a HIP graph captured from its own stream enqueue, one per (counter parity,
+ * sync_target): one graph launch + one scalar kernel (the Philox counter and Adam's step-dependent scalars move to device
+ * memory) instead of ~45 kernel launches and ~20 event operations; bit-identical.  Off by default: on ROCm 7.2 hipGraphLaunch
+ * costs the host as much as the launches it replaces and the replay is slower than the hand-placed streams
+ * (profiles/r06_dqn_learn_step_ab.txt).  A failed capture falls back to the streams for the rest of the process.
+ * -> updates replayed from a graph on `ws` so far (-1: capture failed). */
+int64_t ts_dqn_learn_graph_launches(ts_workspace* ws);
 
 /* ---------------------------------------------------------------------------------------------
  * DQN on a recurrent Q network (DRQN, test/discrete/test_drqn.py:79-101): Recurrent (tianshou/utils/net/common.py:372-452)

@@ -2,6 +2,8 @@
 double-Q n-step target, Huber / MSE TD loss, Adam -- through the C ABI, against the oracle
 (oracle/oracle_dqn.py, pinned to the reference by tests/golden/dqn_*.npz).
 Tolerance: 1e-5 relative (north_star), on the scale of each tensor."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -476,16 +478,18 @@ def test_replay_stream_cycle_equals_the_sequential_cycle():
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
-@pytest.mark.parametrize("prioritized,huber", [(True, 1.0), (True, 0.0), (False, 1.0)])
-def test_learn_step_equals_sample_preprocess_update_postprocess(prioritized, huber):
+@pytest.mark.parametrize("prioritized,huber,graph", [(True, 1.0, False), (True, 0.0, False), (False, 1.0, False), (True, 1.0, True)])
+def test_learn_step_equals_sample_preprocess_update_postprocess(prioritized, huber, graph, monkeypatch):
     """DQNEngine.learn_step (ts_dqn_learn_step: the draws, the sum-tree descent and importance weights, the pair gather, n-step
     coefficients, target passes, the periodic sync, the cached update and the priority update of one OffPolicyAlgorithm.update in
     one library call, the next batch prepared on the replay stream) against the separate calls in the reference's order on one
-    stream with the same draws: seven updates on a 4096-slot frame buffer -- identical losses, TD errors, parameters, lagged
-    parameters, optimizer state, sum tree and running max / min priority; then learn_reset() and a changed seed key."""
+    stream with the same draws: fourteen updates on a 4096-slot frame buffer -- identical losses, TD errors, parameters, lagged
+    parameters, optimizer state, sum tree and running max / min priority; with learn_reset() and a changed seed key on the way.  graph: the opt-in replay of the
+    steady state from captured HIP graphs (TS_DQN_GRAPH=1), same values."""
     import bench_dqn as BD
     from tianshou_amd import dqn as D
     B = 64
+    monkeypatch.setenv("TS_DQN_GRAPH", "1" if graph else "0")
 
     def make():
         frames, act, buf, per = BD.build(4096, 4, seed=3)
@@ -495,8 +499,8 @@ def test_learn_step_equals_sample_preprocess_update_postprocess(prioritized, hub
         return frames, act, buf, (per if prioritized else None), eng
 
     def seeds():
-        for it in range(7):
-            yield (77, it) if it < 5 else (78, it)      # a new key: nothing prepared for it
+        for it in range(14):
+            yield (77, it) if it < 11 else (78, it)     # a new key: nothing prepared for it
 
     def separate():
         frames, act, buf, per, eng = make()
@@ -516,21 +520,25 @@ def test_learn_step_equals_sample_preprocess_update_postprocess(prioritized, hub
 
     def one_call():
         frames, act, buf, per, eng = make()
-        log = []
+        log, before = [], eng.learn_graph_launches()
         for k, sd in enumerate(seeds()):
-            if k == 3:
+            if k == 6:
                 eng.learn_reset()                        # the prepared batch is dropped and drawn again: same values
             loss, td = eng.learn_step(buf, frames, act, per, B, sd, want_td=True)
             log.append((loss.clone(), td.clone()))
         torch.cuda.synchronize()
+        graphs.append(eng.learn_graph_launches() - before if before >= 0 else -1)
         return log, eng, per
 
+    graphs = []
     a, b = separate(), one_call()
     for it, (x, y) in enumerate(zip(a[0], b[0])):
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), it
     for name in ("params", "params_old", "adam_m", "adam_v"):
         assert torch.equal(getattr(a[1], name), getattr(b[1], name)), name
-    assert a[1].adam_step == b[1].adam_step == 7 and a[1].iter == b[1].iter
+    assert a[1].adam_step == b[1].adam_step == 14 and a[1].iter == b[1].iter
+    # TS_DQN_GRAPH=1: the steady-state updates (from the third call with unchanged arguments on) are replayed from captured graphs
+    assert graphs[0] == (9 if graph else 0), graphs
     if prioritized:
         assert torch.equal(a[2].weight._value, b[2].weight._value) and torch.equal(a[2].prio_minmax, b[2].prio_minmax)
     # layouts outside the call's are refused, not converted

@@ -91,6 +91,9 @@ struct ts_workspace {
     // from the update and can run beside its backward pass
     hipEvent_t td_ev;
     int td_ev_ready;
+    // captured update graphs of ts_dqn_learn_step (host state owned by ts_dqn.hip; released through the hook)
+    void* learn_graphs;
+    void (*learn_graphs_free)(void*);
 };
 
 namespace ts {
@@ -105,6 +108,13 @@ int side_stream(ts_workspace* ws, hipStream_t main, hipStream_t* out);   // == m
 int stream_wait(ts_workspace* ws, hipStream_t from, hipStream_t to, int slot);
 int side_streams(ts_workspace* ws, hipStream_t main, hipStream_t* a, hipStream_t* b);     // both side streams
 int record_td(ts_workspace* ws, hipStream_t s);       // the new priorities / the loss of an update are written on `s`
+// Adam with its two per-step scalars {step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t)} (adam_step_scalars: the float32 values
+// adam_step passes by value) read from device memory: a captured launch replayed with a new step number (ts_dqn_learn_step)
+void adam_step_scalars(int64_t step, double lr, double beta1, double beta2, float out[2]);
+int adam_step_dev(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, const float* step_dev,
+                  double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
+// ts_uniform_fill_f64 with the Philox counter read from device memory when counter_dev != NULL (same use)
+int uniform_fill_f64(double* out, int64_t n, uint64_t seed, uint64_t counter, const uint64_t* counter_dev, hipStream_t s);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: a process-wide "done" flag would skip it on
 // the second GPU a process drives (tests iterating devices, threaded data parallelism).  One of these per kernel (a function-

@@ -183,6 +183,7 @@ int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
 
 int ts_workspace_destroy(ts_workspace* ws) {
     if (!ws) return TS_OK;
+    if (ws->learn_graphs && ws->learn_graphs_free) { (void)hipSetDevice(ws->device); ws->learn_graphs_free(ws->learn_graphs); }
     if (ws->side_ready) {
         (void)hipSetDevice(ws->device);
         (void)hipStreamSynchronize(ws->side);

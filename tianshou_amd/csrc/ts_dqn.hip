@@ -8,6 +8,7 @@
 // The conv / linear layers run on the fp32-MFMA implicit-GEMM kernels of ts_conv.hip; this file adds
 // the small head (512 -> n_act), the TD loss and the orchestration.  Flat parameter layout: see
 // include/tsengine.h (ts_dqn_param_count).
+#include <cstring>
 #include "ts_common.h"
 #include "ts_conv.h"
 
@@ -327,7 +328,8 @@ int ts_dqn_target_q(const float* q_online, const float* q_target, int64_t B, int
 static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float* adam_v, int64_t adam_step, int64_t c,
                            int64_t h, int64_t w, int64_t n_act, const void* obs_nhwc, int obs_u8, const int64_t* act,
                            const float* returns, const float* weight, int64_t B, const ts_dqn_hparams* hp, float* td_out,
-                           float* loss_out, float* grad_out, ts_stream_t stream, void* cache, const char* who) {
+                           float* loss_out, float* grad_out, ts_stream_t stream, void* cache, const char* who,
+                           const float* adam_dev = nullptr) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "%s: workspace is NULL", who);
     TS_REQUIRE(B >= 1 && adam_step >= 1, TS_ERR_INVALID_ARG, "%s: bad batch size / step", who);
     TS_REQUIRE(params && adam_m && adam_v && obs_nhwc && act && returns && hp && td_out && loss_out,
@@ -380,6 +382,9 @@ static int dqn_update_impl(ts_workspace* ws, float* params, float* adam_m, float
         if (int rc = ts::chain_backward(s, ws, 4, n.l, x, dy, wb, slabs, g, obs_u8 != 0)) return rc;
     }
     if (hp->lr < 0.0) return TS_OK;      // gradient-only mode (tests, data-parallel all-reduce)
+    if (adam_dev)       // a captured update: the step-dependent scalars live on the device (ts_dqn_learn_step)
+        return ts::adam_step_dev(s, params, adam_m, adam_v, grad, n.total, adam_dev, hp->beta1, hp->beta2, hp->adam_eps,
+                                 hp->max_grad_norm, norm_part);
     return ts::adam_step(s, params, adam_m, adam_v, grad, n.total, adam_step, hp->lr, hp->beta1, hp->beta2,
                          hp->adam_eps, hp->max_grad_norm, norm_part);
 }
@@ -433,7 +438,10 @@ int ts_dqn_update_cached(ts_workspace* ws, float* params, float* adam_m, float* 
 namespace {
 struct LearnBatch { int64_t* idx; int64_t* act; uint8_t* obs; uint8_t* obs_next; float* mask; double* gpow; double* mc; double* u;
                     double* w64; float* w32; };
-struct LearnScratch { LearnBatch b[2]; float* returns; float* td; int* err; void* cache; size_t cache_bytes; };
+// the per-update scalars of a captured update, on the device: the Philox counter of the batch prepared ahead, Adam's two
+// step-dependent scalars (ts::adam_step_scalars), and the loss before it is copied to the caller
+struct LearnCtl { uint64_t counter_next; float adam[2]; float loss; };
+struct LearnScratch { LearnBatch b[2]; float* returns; float* td; int* err; LearnCtl* ctl; void* cache; size_t cache_bytes; };
 
 static size_t dqn_learn_carve(char* base, const Net& n, int64_t B, int64_t obs_elems, LearnScratch* out) {
     char* p = base;
@@ -454,6 +462,7 @@ static size_t dqn_learn_carve(char* base, const Net& n, int64_t B, int64_t obs_e
     sc.returns = reinterpret_cast<float*>(bytes(4 * (size_t)B));
     sc.td = reinterpret_cast<float*>(bytes(4 * (size_t)B));
     sc.err = reinterpret_cast<int*>(bytes(256));
+    sc.ctl = reinterpret_cast<LearnCtl*>(bytes(256));
     sc.cache_bytes = fwd_scratch_bytes(n, B);
     sc.cache = bytes(sc.cache_bytes);
     if (out) *out = sc;
@@ -464,6 +473,38 @@ static size_t dqn_learn_carve(char* base, const Net& n, int64_t B, int64_t obs_e
 static __global__ __launch_bounds__(256) void dqn_weight_f32_kernel(const double* __restrict__ w64, int64_t n, float* __restrict__ w32) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) w32[i] = (float)w64[i];
+}
+
+static __global__ void dqn_learn_ctl_kernel(LearnCtl* ctl, uint64_t counter_next, float lr_step, float bc2_sqrt) {
+    ctl->counter_next = counter_next;
+    ctl->adam[0] = lr_step;
+    ctl->adam[1] = bc2_sqrt;
+}
+
+// Everything a captured update has baked in: a call whose key differs drops the graphs and captures afresh.
+struct LearnKey {
+    ts_workspace* ws; ts_workspace* ws_aux; float* params; float* params_old; float* adam_m; float* adam_v;
+    int64_t c, h, w, n_act, B, n_step; double gamma; int64_t is_double; ts_frame_replay rb; ts_dqn_hparams hp; uint64_t seed;
+    void* scratch; hipStream_t stream;
+};
+struct LearnGraphs {
+    LearnKey key;
+    int warm;                       // calls run through the streams with this key (allocations and attributes are settled after two)
+    bool disabled;                  // a capture failed once: the streams from now on
+    hipGraphExec_t exec[2][2];      // [counter parity][periodic target sync]
+    int64_t launches;               // updates replayed from a graph so far (ts_dqn_learn_graph_launches)
+    hipStream_t origin;             // the stream the enqueue is captured from
+};
+static void learn_graphs_drop(LearnGraphs* g) {
+    for (auto& row : g->exec)
+        for (auto& e : row)
+            if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+}
+static void learn_graphs_free(void* p) {
+    auto* g = static_cast<LearnGraphs*>(p);
+    learn_graphs_drop(g);
+    if (g->origin) (void)hipStreamDestroy(g->origin);
+    delete g;
 }
 }  // namespace
 
@@ -502,55 +543,146 @@ int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, flo
     // the replay stream: the aux workspace's own first side stream (== s while ts_profile_begin is active on `ws`)
     if (ws->profiling) replay = s;
     else if (int rc = ts::side_stream(ws_aux, s, &replay)) return rc;
-    // buffer.sample_indices (prio.py:63-67 / buffer_base.py:505-533) + get_weight (prio.py:69-79) -> batch.act / obs / obs_next ->
-    // the network-free half of compute_nstep_return, for update `ctr`
-    auto prepare = [&](hipStream_t st, const LearnBatch& b, uint64_t ctr) -> int {
-        if (rb->tree) {
-            if (int rc = ts_uniform_fill_f64(b.u, B, seed, ctr, st)) return rc;
-            if (int rc = ts_per_sample(ws_aux, rb->tree, rb->bound, b.u, B, rb->prio_minmax, rb->beta, rb->weight_norm, b.idx, b.w64, st))
+
+    // One update, enqueued on the streams.  captured: the same enqueue under stream capture -- the per-update scalars come from
+    // sc.ctl, the loss stays in sc.ctl, and the replay stream joins `s` at the end (a graph has one end).
+    auto body = [&](bool captured, hipStream_t s) -> int {
+        // buffer.sample_indices (prio.py:63-67 / buffer_base.py:505-533) + get_weight (prio.py:69-79) -> batch.act / obs / obs_next
+        // -> the network-free half of compute_nstep_return, for update `ctr`
+        auto prepare = [&](hipStream_t st, const LearnBatch& b, uint64_t ctr, bool ctr_from_ctl) -> int {
+            if (rb->tree) {
+                if (int rc = ts::uniform_fill_f64(b.u, B, seed, ctr, ctr_from_ctl ? &sc.ctl->counter_next : nullptr, st)) return rc;
+                if (int rc = ts_per_sample(ws_aux, rb->tree, rb->bound, b.u, B, rb->prio_minmax, rb->beta, rb->weight_norm, b.idx,
+                                           b.w64, st))
+                    return rc;
+                hipLaunchKernelGGL(dqn_weight_f32_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, st, b.w64, B, b.w32);
+                TS_LAUNCH_CHECK();
+            } else if (int rc = ts_sample_indices_seeded(rb->offset, rb->E, rb->lengths, seed, ctr, B, b.idx, sc.err, st)) {
                 return rc;
-            hipLaunchKernelGGL(dqn_weight_f32_kernel, dim3((unsigned)ts::ceil_div(B, 256)), dim3(256), 0, st, b.w64, B, b.w32);
-            TS_LAUNCH_CHECK();
-        } else if (int rc = ts_sample_indices_seeded(rb->offset, rb->E, rb->lengths, seed, ctr, B, b.idx, sc.err, st)) {
+            }
+            if (int rc = ts_gather_rows(rb->act_col, rb->slots, 8, b.idx, B, b.act, st)) return rc;
+            if (int rc = ts_dqn_gather_pair(rb->frames, rb->slots, rb->plane_elems, b.idx, B, n_step, c, rb->offset, rb->E, rb->done,
+                                            rb->last_index, rb->lengths, b.obs, b.obs_next, st))
+                return rc;
+            return ts_nstep_coefficients(b.idx, B, n_step, rb->offset, rb->E, rb->done, rb->terminated, rb->last_index, rb->lengths,
+                                         rb->rew, gamma, b.mask, b.gpow, b.mc, st);
+        };
+        const LearnBatch& cur = sc.b[counter & 1];
+        const LearnBatch& nxt = sc.b[(counter + 1) & 1];
+        if (!prepared)
+            if (int rc = prepare(s, cur, counter, false)) return rc;
+        // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
+        if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
+        if (int rc = ts_dqn_forward_cache(ws->profiling ? ws : ws_aux, params, c, h, w, n_act, cur.obs, 1, B, sc.cache,
+                                          (int64_t)sc.cache_bytes, side2))
             return rc;
-        }
-        if (int rc = ts_gather_rows(rb->act_col, rb->slots, 8, b.idx, B, b.act, st)) return rc;
-        if (int rc = ts_dqn_gather_pair(rb->frames, rb->slots, rb->plane_elems, b.idx, B, n_step, c, rb->offset, rb->E, rb->done,
-                                        rb->last_index, rb->lengths, b.obs, b.obs_next, st))
+        if (int rc = ts_dqn_target_returns(ws, params, params_old, c, h, w, n_act, cur.obs_next, 1, B, is_double, cur.mask, cur.gpow,
+                                           cur.mc, sc.returns, s))
             return rc;
-        return ts_nstep_coefficients(b.idx, B, n_step, rb->offset, rb->E, rb->done, rb->terminated, rb->last_index, rb->lengths,
-                                     rb->rew, gamma, b.mask, b.gpow, b.mc, st);
+        if (sync_target && params_old)       // the periodic hard sync sits between _preprocess_batch and the update (dqn.py:283-285)
+            TS_HIP_CHECK(hipMemcpyAsync(params_old, params, sizeof(float) * (size_t)n.total, hipMemcpyDeviceToDevice, s));
+        if (int rc = ts::stream_wait(ws, side2, s, 7)) return rc;
+        if (int rc = dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, cur.obs, 1, cur.act, sc.returns,
+                                     rb->tree ? cur.w32 : nullptr, B, hp, sc.td, captured ? &sc.ctl->loss : loss_out, nullptr, reinterpret_cast<ts_stream_t>(s),
+                                     sc.cache, "ts_dqn_learn_step", captured ? sc.ctl->adam : nullptr))
+            return rc;
+        // _postprocess_batch (prio.py:81-100: update_weight with the TD errors) and the next update's batch on the replay stream,
+        // behind the loss kernel (ts::record_td) and beside the backward pass and the optimizer step
+        if (replay != s) TS_HIP_CHECK(hipStreamWaitEvent(replay, ws->td_ev, 0));
+        if (rb->tree)
+            if (int rc = ts_per_update_weight(ws_aux, rb->tree, rb->bound, cur.idx, sc.td, B, rb->alpha, rb->prio_minmax, replay))
+                return rc;
+        if (int rc = prepare(replay, nxt, counter + 1, captured)) return rc;
+        if (captured) return ts::stream_wait(ws_aux, replay, s, 9);
+        return TS_OK;
     };
-    const LearnBatch& cur = sc.b[counter & 1];
-    const LearnBatch& nxt = sc.b[(counter + 1) & 1];
+    // (the TD errors stay in `scratch` for the replay stream: the caller's copy may be released before that stream is done)
+    auto copies = [&](bool captured) -> int {
+        const LearnBatch& cur = sc.b[counter & 1];
+        if (captured) TS_HIP_CHECK(hipMemcpyAsync(loss_out, &sc.ctl->loss, 4, hipMemcpyDeviceToDevice, s));
+        if (td_out) TS_HIP_CHECK(hipMemcpyAsync(td_out, sc.td, 4 * (size_t)B, hipMemcpyDeviceToDevice, s));
+        if (idx_out) TS_HIP_CHECK(hipMemcpyAsync(idx_out, cur.idx, 8 * (size_t)B, hipMemcpyDeviceToDevice, s));
+        return TS_OK;
+    };
+
     // behind everything the previous call left on the replay stream: its priority update and this update's batch
     if (int rc = ts::stream_wait(ws_aux, replay, s, 8)) return rc;
-    if (!prepared)
-        if (int rc = prepare(s, cur, counter)) return rc;
-    // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
-    if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
-    if (int rc = ts_dqn_forward_cache(ws->profiling ? ws : ws_aux, params, c, h, w, n_act, cur.obs, 1, B, sc.cache,
-                                      (int64_t)sc.cache_bytes, side2))
-        return rc;
-    if (int rc = ts_dqn_target_returns(ws, params, params_old, c, h, w, n_act, cur.obs_next, 1, B, is_double, cur.mask, cur.gpow,
-                                       cur.mc, sc.returns, s))
-        return rc;
-    if (sync_target && params_old)       // the periodic hard sync sits between _preprocess_batch and the update (dqn.py:283-285)
-        TS_HIP_CHECK(hipMemcpyAsync(params_old, params, sizeof(float) * (size_t)n.total, hipMemcpyDeviceToDevice, s));
-    if (int rc = ts::stream_wait(ws, side2, s, 7)) return rc;
-    if (int rc = dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, cur.obs, 1, cur.act, sc.returns,
-                                 rb->tree ? cur.w32 : nullptr, B, hp, sc.td, loss_out, nullptr, stream, sc.cache, "ts_dqn_learn_step"))
-        return rc;
-    // _postprocess_batch (prio.py:81-100: update_weight with the TD errors) and the next update's batch on the replay stream, behind
-    // the loss kernel (ts::record_td) and beside the backward pass and the optimizer step
-    if (replay != s) TS_HIP_CHECK(hipStreamWaitEvent(replay, ws->td_ev, 0));
-    if (rb->tree)
-        if (int rc = ts_per_update_weight(ws_aux, rb->tree, rb->bound, cur.idx, sc.td, B, rb->alpha, rb->prio_minmax, replay)) return rc;
-    if (int rc = prepare(replay, nxt, counter + 1)) return rc;
-    // (the TD errors stay in `scratch` for the replay stream: the caller's copy may be released before that stream is done)
-    if (td_out) TS_HIP_CHECK(hipMemcpyAsync(td_out, sc.td, 4 * (size_t)B, hipMemcpyDeviceToDevice, s));
-    if (idx_out) TS_HIP_CHECK(hipMemcpyAsync(idx_out, cur.idx, 8 * (size_t)B, hipMemcpyDeviceToDevice, s));
-    return TS_OK;
+
+    // Steady state (same arguments as the calls before, batch prepared ahead): the update can be captured once per (counter
+    // parity, periodic sync) and replayed -- one graph launch instead of ~45 kernel launches and ~20 event operations per update.
+    // Measured on ROCm 7.2 (profiles/r06_dqn_learn_step_ab.txt): hipGraphLaunch spends as long on the host as the launches it
+    // replaces (0.60 vs 0.56 ms) and the replay runs slower than the hand-placed streams (1,520 vs 1,615 updates/s), so the
+    // graphs are opt-in: TS_DQN_GRAPH=1.
+    const char* graph_env = getenv("TS_DQN_GRAPH");
+    const bool graphs_on = graph_env && graph_env[0] == '1';
+    if (!ws->learn_graphs) {
+        ws->learn_graphs = new LearnGraphs();
+        ws->learn_graphs_free = learn_graphs_free;
+    }
+    auto* lg = static_cast<LearnGraphs*>(ws->learn_graphs);
+    LearnKey key;
+    memset(&key, 0, sizeof(key));
+    key.ws = ws; key.ws_aux = ws_aux; key.params = params; key.params_old = params_old; key.adam_m = adam_m; key.adam_v = adam_v;
+    key.c = c; key.h = h; key.w = w; key.n_act = n_act; key.B = B; key.n_step = n_step; key.gamma = gamma; key.is_double = is_double;
+    key.rb = *rb; key.rb.reserved = 0; key.hp = *hp; key.seed = seed; key.scratch = scratch; key.stream = s;
+    if (memcmp(&key, &lg->key, sizeof(key)) != 0) {
+        learn_graphs_drop(lg);
+        lg->key = key;
+        lg->warm = 0;
+    }
+    const bool steady = graphs_on && !lg->disabled && !ws->profiling && prepared && rb->tree && replay != s && side != s &&
+                        side2 != s && hp->lr >= 0.0;
+    if (!steady || lg->warm < 2) {
+        if (int rc = body(false, s)) return rc;
+        ++lg->warm;
+        return copies(false);
+    }
+    hipGraphExec_t& exec = lg->exec[counter & 1][sync_target && params_old ? 1 : 0];
+    if (!exec) {
+        hipGraph_t graph = nullptr;
+        const bool verbose = getenv("TS_DQN_GRAPH_VERBOSE") != nullptr;
+        // (the caller's stream may be the null stream, which cannot capture: the enqueue is recorded from a stream of our own --
+        // a graph does not remember its origin stream)
+        if (!lg->origin) TS_HIP_CHECK(hipStreamCreateWithFlags(&lg->origin, hipStreamNonBlocking));
+        hipError_t e = hipStreamBeginCapture(lg->origin, hipStreamCaptureModeThreadLocal);
+        bool ok = e == hipSuccess;
+        if (!ok && verbose) fprintf(stderr, "ts_dqn_learn_step: hipStreamBeginCapture: %s\n", hipGetErrorString(e));
+        if (ok) {
+            const int rc = body(true, lg->origin);
+            e = hipStreamEndCapture(lg->origin, &graph);
+            ok = rc == TS_OK && e == hipSuccess && graph != nullptr;
+            if (!ok && verbose)
+                fprintf(stderr, "ts_dqn_learn_step: capture body rc %d (%s), hipStreamEndCapture: %s\n", rc, ts_last_error(),
+                        hipGetErrorString(e));
+        }
+        if (ok) {
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            ok = e == hipSuccess;
+            if (!ok && verbose) fprintf(stderr, "ts_dqn_learn_step: hipGraphInstantiate: %s\n", hipGetErrorString(e));
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) {            // nothing of the capture ran: the streams, from now on
+            (void)hipGetLastError();
+            exec = nullptr;
+            lg->disabled = true;
+            if (getenv("TS_DQN_GRAPH_VERBOSE")) fprintf(stderr, "ts_dqn_learn_step: stream capture failed, staying on the streams\n");
+            if (int rc = body(false, s)) return rc;
+            return copies(false);
+        }
+    }
+    float sc2[2];
+    ts::adam_step_scalars(adam_step, hp->lr, hp->beta1, hp->beta2, sc2);
+    hipLaunchKernelGGL(dqn_learn_ctl_kernel, dim3(1), dim3(1), 0, s, sc.ctl, counter + 1, sc2[0], sc2[1]);
+    TS_LAUNCH_CHECK();
+    TS_HIP_CHECK(hipGraphLaunch(exec, s));
+    ++lg->launches;
+    return copies(true);
+}
+
+int64_t ts_dqn_learn_graph_launches(ts_workspace* ws) {
+    if (!ws || !ws->learn_graphs) return 0;
+    auto* lg = static_cast<LearnGraphs*>(ws->learn_graphs);
+    return lg->disabled ? -1 : lg->launches;
 }
 
 }  // extern "C"

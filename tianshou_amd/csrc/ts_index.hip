@@ -648,8 +648,10 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 
 // np.random.rand(n) of the engine's own stream: u[i] = uniform53(seed, counter, i, 0) (PrioritizedReplayBuffer.sample_indices,
 // prio.py:65, inside ts_dqn_learn_step)
-__global__ __launch_bounds__(256) void uniform_fill_f64_kernel(double* __restrict__ out, int64_t n, uint64_t seed, uint64_t counter) {
+__global__ __launch_bounds__(256) void uniform_fill_f64_kernel(double* __restrict__ out, int64_t n, uint64_t seed, uint64_t counter,
+                                                               const uint64_t* __restrict__ counter_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (counter_dev) counter = *counter_dev;
     if (i < n) out[i] = uniform53(seed, counter, i, 0);
 }
 
@@ -688,6 +690,14 @@ inline int grid_for(int64_t n, int block) {
 }
 
 }  // namespace
+
+namespace ts {
+int uniform_fill_f64(double* out, int64_t n, uint64_t seed, uint64_t counter, const uint64_t* counter_dev, hipStream_t s) {
+    hipLaunchKernelGGL(uniform_fill_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, out, n, seed, counter, counter_dev);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+}  // namespace ts
 
 extern "C" {
 
@@ -806,9 +816,7 @@ int ts_uniform_fill_f64(double* out, int64_t n, uint64_t seed, uint64_t counter,
     TS_REQUIRE(n >= 0, TS_ERR_INVALID_ARG, "ts_uniform_fill_f64: negative n");
     if (n == 0) return TS_OK;
     TS_REQUIRE(out != nullptr, TS_ERR_INVALID_ARG, "ts_uniform_fill_f64: out is NULL");
-    hipLaunchKernelGGL(uniform_fill_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, ts::as_stream(stream), out, n, seed, counter);
-    TS_LAUNCH_CHECK();
-    return TS_OK;
+    return ts::uniform_fill_f64(out, n, seed, counter, nullptr, ts::as_stream(stream));
 }
 
 int ts_gather_rows(const void* src, int64_t n_rows_src, int64_t row_bytes, const int64_t* index,

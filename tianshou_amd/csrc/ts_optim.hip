@@ -50,9 +50,11 @@ struct AdamArgs {
     const float* part; int n_part; float max_norm;
     float lr_step, beta1, beta2, bc2_sqrt, eps;
     float omb1, omb2;    // (1 - beta) rounded from double, as torch passes them
+    const float* step_dev;      // {lr_step, bc2_sqrt} on the device instead (a captured launch replayed with a new step number)
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    if (a.step_dev) { a.lr_step = a.step_dev[0]; a.bc2_sqrt = a.step_dev[1]; }
     float scale = 1.f;
     if (a.part) {   // every workgroup re-reduces the partials in the same order -> identical scale
         __shared__ float red[4];
@@ -216,23 +218,42 @@ int optim_step(hipStream_t s, const OptimDesc& o, float* params, float* m, float
     return TS_OK;
 }
 
-int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
-              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
+void adam_step_scalars(int64_t step, double lr, double beta1, double beta2, float out[2]) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    out[0] = (float)(lr / bc1);          // step_size
+    out[1] = (float)sqrt(bc2);           // bias_correction2_sqrt
+}
+
+static int adam_launch(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, const float sc[2],
+                       const float* step_dev, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
     AdamArgs a{};
     a.p = params; a.m = m; a.v = v; a.g = grad; a.n = n;
     if (max_grad_norm > 0) {
         hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grad, n, norm_scratch);
         a.part = norm_scratch; a.n_part = SUMSQ_BLOCKS; a.max_norm = (float)max_grad_norm;
     }
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    a.lr_step = (float)(lr / bc1);
+    a.lr_step = sc[0];
     a.beta1 = (float)beta1; a.beta2 = (float)beta2;
     a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
-    a.bc2_sqrt = (float)sqrt(bc2);
+    a.bc2_sqrt = sc[1];
     a.eps = (float)eps;
+    a.step_dev = step_dev;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, a);
     TS_LAUNCH_CHECK();
     return TS_OK;
+}
+
+int adam_step(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, int64_t step,
+              double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
+    float sc[2];
+    adam_step_scalars(step, lr, beta1, beta2, sc);
+    return adam_launch(s, params, m, v, grad, n, sc, nullptr, beta1, beta2, eps, max_grad_norm, norm_scratch);
+}
+
+int adam_step_dev(hipStream_t s, float* params, float* m, float* v, const float* grad, int64_t n, const float* step_dev,
+                  double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch) {
+    const float sc[2] = {0.f, 1.f};
+    return adam_launch(s, params, m, v, grad, n, sc, step_dev, beta1, beta2, eps, max_grad_norm, norm_scratch);
 }
 }  // namespace ts
 

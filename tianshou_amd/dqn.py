@@ -500,6 +500,12 @@ class DQNEngine:
         if self._learn is not None:
             self._learn["last"] = None
 
+    def learn_graph_launches(self) -> int:
+        """Updates `learn_step` replayed from a captured HIP graph so far (-1: a capture failed, the streams are used)."""
+        lib = _lib.load()
+        lib.ts_dqn_learn_graph_launches.restype = C.c_int64
+        return int(lib.ts_dqn_learn_graph_launches(self._ws.handle))
+
 
 def uniform_draws(n: int, seed, device="cuda") -> torch.Tensor:
     """float64[n] in [0, 1): the draws `DQNEngine.learn_step` makes for update seed = (key, counter) in place of the reference's
