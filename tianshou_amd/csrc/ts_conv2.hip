@@ -848,7 +848,7 @@ bool conv2_use_wgrad(const ConvGeom& g, bool x_u8) {
 
 // tile plan of wgrad2 (rows of dW x columns per workgroup):
 //   0: 256 x 32, 4 waves (2x1 tiles)      1: 512 x 64, 8 waves (2x2)      2: 192 x 64, 4 waves (3x1, 2x2 waves)
-//   3: 256 x 64, 8 waves (2x1, 4x2 waves)
+//   3: 256 x 64, 8 waves (2x1, 4x2 waves)   4: 256 x 128, 8 waves (2x2, 4x2 waves; OC % 128 == 0) -- 1.5 x the flops per staged byte of 1
 static int wgrad2_plan(const ConvGeom& g, int* bkt, int* bn, int* per_cu) {
     if (g.OC % 64 != 0) { *bkt = 256; *bn = 32; *per_cu = 2; return 0; }
     static const char* force = getenv("TS_WGRAD2_PLAN");
@@ -857,9 +857,14 @@ static int wgrad2_plan(const ConvGeom& g, int* bkt, int* bn, int* per_cu) {
     // measured at minibatch 65,536: 512-row tiles (plan 1) win whenever they waste < 15 % (fc1: 3136 -> 3584), the
     // 192-row plan wins for conv3 (576 = 3 x 192 against 1024), plan 3 never
     int plan = (w512 * 100 <= (int64_t)k * 115) ? 1 : (w192 <= w256 ? 2 : 3);
+    // round 6: 256 x 128 tiles wherever the layer has the columns and 256-row tiles waste < 15 % (fc1 at 65,536 rows: 2.02 -> 1.87 ms,
+    // 104 -> 113 TF/s, profiles/r06_wgrad2_plan4.txt): 1.5 x the flops per byte staged through LDS
+    if (g.OC % 128 == 0 && w256 * 100 <= (int64_t)k * 115) plan = 4;
     if (force && force[0] >= '1' && force[0] <= '3') plan = force[0] - '0';
+    if (force && force[0] == '4' && g.OC % 128 == 0) plan = 4;
     *bn = 64;
-    if (plan == 1) { *bkt = 512; *per_cu = 1; }
+    if (plan == 4) { *bkt = 256; *bn = 128; *per_cu = 1; }
+    else if (plan == 1) { *bkt = 512; *per_cu = 1; }
     else if (plan == 2) { *bkt = 192; *per_cu = 2; }
     else { *bkt = 256; *per_cu = 1; }
     return plan;
@@ -989,6 +994,7 @@ int conv2_wgrad(hipStream_t s, const ConvGeom& g, const float* X, const float* d
         TS_REQUIRE(!x_u8, TS_ERR_UNSUPPORTED, "conv wgrad2: uint8 input is instantiated for 32 output channels only");
         if (plan == 1 && env_int("TS_WGRAD2_W16", 0)) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 2, 2, 1>), grid, dim3(1024), 0, s, a);
         else if (plan == 1) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 8, 1, 2, 2>), grid, dim3(512), 0, s, a);
+        else if (plan == 4) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 2, 2, 2>), grid, dim3(512), 0, s, a);
         else if (plan == 2) hipLaunchKernelGGL((conv_wgrad2_kernel<false, 2, 2, 3, 1>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((conv_wgrad2_kernel<false, 4, 2, 2, 1>), grid, dim3(512), 0, s, a);
     }

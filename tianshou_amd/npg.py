@@ -26,6 +26,8 @@ from .returns import gae_scan
 HEAD = 32
 
 
+_CRITIC_STREAMS: dict = {}     # device index -> the side stream of the critic iterations (NPGEngine._critic_stream)
+
 class NPGHParams(C.Structure):
     """struct ts_npg_hparams (include/tsengine.h)."""
 
@@ -251,6 +253,7 @@ class NPGEngine:
                 side.wait_stream(main)                      # the minibatch's rows are gathered
                 with torch.cuda.stream(side):
                     vf = self.critic_steps(obs, ret, self.cfg.optim_critic_iters)
+                vf.record_stream(main)                      # allocated on the side stream, read on the caller's
                 st = self.actor_step(obs, act, adv, lpo)
                 main.wait_stream(side)                      # (also keeps obs / ret alive until the side stream is done)
             return torch.stack([st[0], vf[0], st[1], st[2]])
@@ -258,6 +261,10 @@ class NPGEngine:
         return run_minibatches(self.device, pre["obs"].shape[0], batch_size, repeat, perms, step_rows)
 
     def _critic_stream(self):
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        return self._side
+        # ONE side stream per device for every engine of the process: the library keeps a workspace per launch stream
+        # (_lib.default_workspace), so a stream per engine would leave a workspace per engine behind
+        idx = self.device.index or 0
+        side = _CRITIC_STREAMS.get(idx)
+        if side is None:
+            side = _CRITIC_STREAMS[idx] = torch.cuda.Stream(device=self.device)
+        return side
