@@ -61,8 +61,19 @@ int ws_winner(ts_workspace* ws, int64_t bound, hipStream_t stream, int32_t** out
 static int side_create(ts_workspace* ws) {
     if (!ws->side_ready) {
         TS_HIP_CHECK(hipSetDevice(ws->device));
-        TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
-        TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side2, hipStreamNonBlocking));
+        // TS_SIDE_PRIORITY=low|high (experiments): the workspace's side streams below / above the caller's stream in the
+        // hardware scheduler's order (profiles/r06_side_priority_ab.txt)
+        const char* pe = getenv("TS_SIDE_PRIORITY");
+        if (pe && (pe[0] == 'l' || pe[0] == 'h')) {
+            int least = 0, greatest = 0;
+            TS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int prio = pe[0] == 'l' ? least : greatest;
+            TS_HIP_CHECK(hipStreamCreateWithPriority(&ws->side, hipStreamNonBlocking, prio));
+            TS_HIP_CHECK(hipStreamCreateWithPriority(&ws->side2, hipStreamNonBlocking, prio));
+        } else {
+            TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+            TS_HIP_CHECK(hipStreamCreateWithFlags(&ws->side2, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 16; ++i) TS_HIP_CHECK(hipEventCreateWithFlags(&ws->side_ev[i], hipEventDisableTiming));
         ws->side_ready = 1;
     }
