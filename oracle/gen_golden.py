@@ -935,7 +935,7 @@ def gen_sample_stack() -> None:
 
 
 def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
-            lr: float = 1e-3, **kwargs) -> None:
+            lr: float = 1e-3, hidden_a=(64, 64), hidden_c=(64, 64), **kwargs) -> None:
     """Runs the reference NPG.update() / TRPO.update() on the MuJoCo actor-critic (examples/mujoco/mujoco_npg.py:103-128,
     the PPO nets) over a synthetic VectorReplayBuffer and dumps every intermediate."""
     from tianshou.algorithm.modelfree.npg import NPG
@@ -944,9 +944,9 @@ def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_a), activation=nn.Tanh)
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
-    net_c = Net(state_shape=(obs_dim,), hidden_sizes=[64, 64], activation=nn.Tanh)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_c), activation=nn.Tanh)
     critic = ContinuousCritic(preprocess_net=net_c)
     torch.nn.init.constant_(actor.sigma_param, -0.5)
     for m in ActorCritic(actor, critic).modules():
@@ -970,6 +970,9 @@ def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, 
     assert [n for n, _ in actor.named_parameters()][0] == "sigma_param"
     out: dict[str, np.ndarray] = {"flat_params0": _flat_from_modules(actor, critic),
                                   "dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat, int(algo == "trpo")])}
+    if tuple(hidden_a) != (64, 64) or tuple(hidden_c) != (64, 64):
+        out["hidden"] = np.array(list(hidden_a) + list(hidden_c), np.int64)
+        out["seed"] = np.array(seed)
     buf = VectorReplayBuffer(N, E)
     obs = rng.normal(size=(T + 1, E, obs_dim)).astype(np.float32)
     act = rng.normal(size=(T, E, act_dim)).astype(np.float32) * 0.7
@@ -1471,6 +1474,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "widths":
+        gen_widths()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "policy_forward":
         gen_policy_forward()
         return
@@ -1533,20 +1539,22 @@ def main() -> None:
 
 def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int,
             seed: int, auto_alpha: bool, alpha: float = 0.2, n_step: int = 1, tau: float = 0.005,
-            gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4) -> None:
+            gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4, hidden=256) -> None:
     """Runs the reference SAC.update() (nets as in examples/mujoco/mujoco_sac.py:82-104) on a synthetic
-    VectorReplayBuffer, recording the rsample() noise of every policy call and the outputs of every update."""
+    VectorReplayBuffer, recording the rsample() noise of every policy call and the outputs of every update.
+    hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- Net(hidden_sizes=...) takes any widths."""
     import torch.distributions.normal as tdn
     from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACPolicy
     from oracle import oracle_sac as OS
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[256, 256])
+    hw = OS.hidden_widths(hidden)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2]))
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                          conditioned_sigma=True)
-    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)
-    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)
+    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)
+    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)
     critic1, critic2 = ContinuousCritic(preprocess_net=net_c1), ContinuousCritic(preprocess_net=net_c2)
     space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
     policy = SACPolicy(actor=actor, action_space=space)
@@ -1557,7 +1565,8 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
                     n_step_return_horizon=n_step)
     out: dict[str, np.ndarray] = {}
     out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step])
-    p0 = OS.init_sac_params(obs_dim, act_dim, seed)
+    out["hidden"] = np.array(hw, np.int64)
+    p0 = OS.init_sac_params(obs_dim, act_dim, seed, hw)
     for pd, order, mod, keys in ((p0[0], OS.ACTOR_ORDER, actor, OS.TIANSHOU_ACTOR_KEYS),
                                  (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS),
                                  (p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS)):
@@ -1632,7 +1641,7 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
 
 
 def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int,
-            n_updates: int, seed: int, max_action: float = 1.0, n_step: int = 1, **kw) -> None:
+            n_updates: int, seed: int, max_action: float = 1.0, n_step: int = 1, hidden=256, **kw) -> None:
     """Runs the reference TD3.update() (twin) or DDPG.update() (nets of examples/mujoco/mujoco_td3.py:85-103 /
     mujoco_ddpg.py) on a synthetic VectorReplayBuffer; TD3's torch.randn smoothing noise is recorded."""
     from tianshou.algorithm.modelfree import td3 as td3_mod
@@ -1643,15 +1652,16 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[256, 256]),
+    hw = OS.hidden_widths(hidden)
+    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2])),
                                          action_shape=(act_dim,), max_action=max_action)
-    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True)  # noqa: E731
+    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)  # noqa: E731
     if twin:
         n1, n2 = mk_net(), mk_net()
         critic1, critic2 = ContinuousCritic(preprocess_net=n1), ContinuousCritic(preprocess_net=n2)
     else:
         critic1, critic2 = ContinuousCritic(preprocess_net=mk_net()), None
-    p0 = OS.init_td3_params(obs_dim, act_dim, seed, twin)
+    p0 = OS.init_td3_params(obs_dim, act_dim, seed, twin, hw)
     checks = [(p0[0], OS.DET_ACTOR_ORDER, actor, OS.TIANSHOU_DET_ACTOR_KEYS), (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS)]
     if twin:
         checks.append((p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS))
@@ -1679,7 +1689,8 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
     trunc = (rng.random((steps, E)) < 0.03) & ~term
     for t in range(steps):
         buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
-    out: dict[str, np.ndarray] = {"dims": np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(twin), n_step])}
+    out: dict[str, np.ndarray] = {"dims": np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(twin), n_step]),
+                                  "hidden": np.array(hw, np.int64)}
     for k2 in ("obs", "obs_next", "act"):
         out[k2] = np.asarray(getattr(buf, k2), np.float32)
     out["rew"], out["terminated"], out["truncated"] = np.asarray(buf.rew, np.float64), np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
@@ -1731,7 +1742,7 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
     np.savez_compressed(os.path.join(OUT, f"td3_{tag}.npz"), **out)
 
 
-def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: int, hidden: int, batch: int,
+def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: int, hidden, batch: int,
              n_updates: int, seed: int, auto_alpha: bool, alpha: float = 0.05, n_step: int = 1, tau: float = 0.005,
              gamma: float = 0.95, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4) -> None:
     """Runs the reference DiscreteSAC.update() (nets as in test/discrete/test_discrete_sac.py:88-97) on a synthetic
@@ -1743,10 +1754,13 @@ def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: i
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]),
+    from oracle import oracle_sac as OS_
+
+    hw = OS_.hidden_widths(hidden)          # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
+    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2])),
                           action_shape=n_act, softmax_output=False)
-    critic1 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]), last_size=n_act)
-    critic2 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[hidden, hidden]), last_size=n_act)
+    critic1 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[2:])), last_size=n_act)
+    critic2 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[2:])), last_size=n_act)
     policy = DiscreteSACPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
     target_entropy = 0.98 * float(np.log(n_act))
     al = AutoAlpha(target_entropy, 0.0, AdamOptimizerFactory(lr=alpha_lr)) if auto_alpha else alpha
@@ -1755,8 +1769,10 @@ def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: i
                             critic2_optim=AdamOptimizerFactory(lr=critic_lr), tau=tau, gamma=gamma, alpha=al,
                             n_step_return_horizon=n_step)
     out: dict[str, np.ndarray] = {}
-    out["dims"] = np.array([E, slots, steps, obs_dim, n_act, hidden, batch, n_updates, seed, int(auto_alpha), n_step])
-    p0 = ODS.init_params(obs_dim, n_act, hidden, seed)
+    out["dims"] = np.array([E, slots, steps, obs_dim, n_act, max(hw), batch, n_updates, seed, int(auto_alpha), n_step])
+    if len(set(hw)) > 1:
+        out["hidden"] = np.array(hw, np.int64)
+    p0 = ODS.init_params(obs_dim, n_act, hw, seed)
     for pd, mod in zip(p0, (actor, critic1, critic2)):
         sd = mod.state_dict()
         assert list(sd.keys()) == ODS.TIANSHOU_KEYS, list(sd.keys())
@@ -1830,7 +1846,7 @@ def gen_dsac_all() -> None:
 def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int, seed: int,
              ensemble: int, subset: int, actor_delay: int, target_mode: str, auto_alpha: bool, alpha: float = 0.2,
              n_step: int = 1, tau: float = 0.005, gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3,
-             alpha_lr: float = 3e-4) -> None:
+             alpha_lr: float = 3e-4, hidden=256) -> None:
     """Runs the reference REDQ.update() (nets as in test/continuous/test_redq.py:86-107, hidden [256, 256]) on a synthetic
     VectorReplayBuffer, recording the rsample() noise, the np.random.choice subsets and the outputs of every update."""
     import torch.distributions.normal as tdn
@@ -1842,14 +1858,15 @@ def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim:
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=[256, 256])
+    hw = OS.hidden_widths(hidden)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2]))
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                          conditioned_sigma=True)
 
     def linear(x: int, y: int):
         return EnsembleLinear(ensemble, x, y)
 
-    net_c = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256], concat=True, linear_layer=linear)
+    net_c = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True, linear_layer=linear)
     critic = ContinuousCritic(preprocess_net=net_c, linear_layer=linear, flatten_input=False)
     space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
     policy = REDQPolicy(actor=actor, action_space=space)
@@ -1861,7 +1878,9 @@ def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim:
     out: dict[str, np.ndarray] = {}
     out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step, ensemble,
                             subset, actor_delay, int(target_mode == "mean")])
-    a0, c0 = OR.init_params(obs_dim, act_dim, ensemble, seed)
+    if hidden != 256:
+        out["hidden"] = np.array(hw, np.int64)
+    a0, c0 = OR.init_params(obs_dim, act_dim, ensemble, seed, hw)
     sa, sc = actor.state_dict(), critic.state_dict()
     assert list(sc.keys()) == OR.TIANSHOU_CRITIC_KEYS, list(sc.keys())
     for k_ref, k in zip(OS.TIANSHOU_ACTOR_KEYS, OS.ACTOR_ORDER):
@@ -1946,6 +1965,28 @@ def gen_td3_all() -> None:
             max_action=1.0, actor_lr=3e-4, critic_lr=1e-3)
     gen_td3("ddpg", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=13,
             max_action=2.0, n_step=2, tau=0.01, gamma=0.97)
+
+
+def gen_widths() -> None:
+    """Round 6: two-hidden-layer networks of unequal widths / widths that are no multiple of 32 (the engines embed them by zero
+    padding, tianshou_amd/widths.py): SAC with actor [48, 80] and critics [72, 40]; TD3 with the papers' [400, 300]; DDPG with
+    [24, 56]."""
+    gen_sac("widths", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=21, auto_alpha=True,
+            hidden=(48, 80, 72, 40))
+    gen_td3("widths", twin=True, E=4, slots=32, steps=30, obs_dim=17, act_dim=6, batch=64, n_updates=4, seed=22,
+            max_action=1.0, actor_lr=3e-4, critic_lr=1e-3, hidden=(400, 300))
+    gen_td3("ddpg_widths", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=23,
+            max_action=2.0, n_step=2, tau=0.01, gamma=0.97, hidden=(24, 56, 40, 24))
+    gen_dsac("widths", E=3, slots=30, steps=40, obs_dim=13, n_act=5, hidden=(40, 72, 56, 24), batch=32, n_updates=3, seed=24,
+             auto_alpha=True, n_step=2)
+    gen_redq("widths", E=3, slots=30, steps=40, obs_dim=11, act_dim=3, batch=32, n_updates=4, seed=25, ensemble=4, subset=2,
+             actor_delay=2, target_mode="min", auto_alpha=True, n_step=2, hidden=(48, 80, 72, 40))
+    gen_npg("npg_widths", algo="npg", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=26, optim_critic_iters=3,
+            trust_region_size=0.1, advantage_normalization=True, gae_lambda=0.95, gamma=0.99, return_scaling=True,
+            max_batchsize=64, hidden_a=(48, 80), hidden_c=(40, 56))
+    gen_npg("trpo_widths", algo="trpo", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=27, optim_critic_iters=2,
+            max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10, advantage_normalization=True, gae_lambda=0.95, gamma=0.99,
+            return_scaling=False, max_batchsize=256, hidden_a=(100, 60), hidden_c=(60, 100))
 
 
 def gen_sac_all() -> None:

@@ -32,13 +32,15 @@ def net_shapes(obs_dim: int, n_act: int, hidden: int):
             "head.w": (n_act, hidden), "head.b": (n_act,)}
 
 
-def init_params(obs_dim: int, n_act: int, hidden: int, seed: int):
+def init_params(obs_dim: int, n_act: int, hidden, seed: int):
     """Same RNG consumption as torch.manual_seed(seed) followed by the constructions of
     test_discrete_sac.py:88-97 (actor net, actor head, critic-1 net, head, critic-2 net, head)."""
     torch.manual_seed(seed)
     out = []
-    for _ in range(3):
-        ls = [torch.nn.Linear(obs_dim, hidden), torch.nn.Linear(hidden, hidden), torch.nn.Linear(hidden, n_act)]
+    hw = OS.hidden_widths(hidden)           # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
+    for net in range(3):
+        h1, h2 = hw[:2] if net == 0 else hw[2:]
+        ls = [torch.nn.Linear(obs_dim, h1), torch.nn.Linear(h1, h2), torch.nn.Linear(h2, n_act)]
         out.append({k: t.detach().clone() for k, t in
                     zip(NET_ORDER, [x for lin in ls for x in (lin.weight, lin.bias)])})
     return out                                                # actor, critic1, critic2

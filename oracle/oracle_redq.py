@@ -44,13 +44,14 @@ def _ensemble_linear(E: int, fin: int, fout: int):
     return w, b
 
 
-def init_params(obs_dim: int, act_dim: int, E: int, seed: int, hidden: int = 256):
+def init_params(obs_dim: int, act_dim: int, E: int, seed: int, hidden=256):
     """Same RNG consumption as torch.manual_seed(seed) followed by test_redq.py:86-107."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
-    mods = [L(obs_dim, hidden), L(hidden, hidden), L(hidden, act_dim), L(hidden, act_dim)]
+    a1, a2, c1, c2 = OS.hidden_widths(hidden)          # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
+    mods = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim), L(a2, act_dim)]
     actor = dict(zip(OS.ACTOR_ORDER, [t.detach().clone() for m in mods for t in (m.weight, m.bias)]))
-    ts = [t for dims in ((obs_dim + act_dim, hidden), (hidden, hidden), (hidden, 1)) for t in _ensemble_linear(E, *dims)]
+    ts = [t for dims in ((obs_dim + act_dim, c1), (c1, c2), (c2, 1)) for t in _ensemble_linear(E, *dims)]
     return actor, dict(zip(CRITIC_ORDER, ts))
 
 

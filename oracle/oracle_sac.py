@@ -59,15 +59,25 @@ def init_params(shapes: dict, seed: int) -> dict[str, torch.Tensor]:
     return p
 
 
-def init_sac_params(obs_dim: int, act_dim: int, seed: int, hidden: int = 256):
+def hidden_widths(hidden) -> tuple[int, int, int, int]:
+    """(actor h1, actor h2, critic h1, critic h2) from an int (all equal), a pair (actor = critics) or four widths:
+    Net(hidden_sizes=[h1, h2]) of the reference takes any widths (utils/net/common.py:246-369)."""
+    if isinstance(hidden, (int, np.integer)):
+        return (int(hidden),) * 4
+    h = tuple(int(x) for x in hidden)
+    return h + h if len(h) == 2 else h
+
+
+def init_sac_params(obs_dim: int, act_dim: int, seed: int, hidden=256):
     """Same RNG consumption as examples/mujoco/mujoco_sac.py:82-104 after torch.manual_seed(seed):
     Net(actor), actor mu / sigma heads, Net(critic1), Net(critic2), critic1.last, critic2.last
     -> (actor, critic1, critic2) parameter dicts."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
-    mods = [L(obs_dim, hidden), L(hidden, hidden), L(hidden, act_dim), L(hidden, act_dim),
-            L(obs_dim + act_dim, hidden), L(hidden, hidden), L(obs_dim + act_dim, hidden), L(hidden, hidden),
-            L(hidden, 1), L(hidden, 1)]
+    a1, a2, c1_, c2_ = hidden_widths(hidden)
+    mods = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim), L(a2, act_dim),
+            L(obs_dim + act_dim, c1_), L(c1_, c2_), L(obs_dim + act_dim, c1_), L(c1_, c2_),
+            L(c2_, 1), L(c2_, 1)]
     wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
     flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
     actor = dict(zip(ACTOR_ORDER, flat(mods[0:4])))
@@ -267,20 +277,21 @@ TIANSHOU_DET_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.
                            "last.model.0.weight", "last.model.0.bias"]
 
 
-def init_td3_params(obs_dim: int, act_dim: int, seed: int, twin: bool = True, hidden: int = 256):
+def init_td3_params(obs_dim: int, act_dim: int, seed: int, twin: bool = True, hidden=256):
     """RNG consumption of examples/mujoco/mujoco_td3.py:85-103 (mujoco_ddpg.py without the second critic):
     Net(actor), actor.last, Net(critic1)[, Net(critic2)], critic1.last[, critic2.last]."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
     wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
     flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
-    a = [L(obs_dim, hidden), L(hidden, hidden), L(hidden, act_dim)]
+    a1, a2, h1, h2 = hidden_widths(hidden)
+    a = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim)]
     if twin:
-        c = [L(obs_dim + act_dim, hidden), L(hidden, hidden), L(obs_dim + act_dim, hidden), L(hidden, hidden),
-             L(hidden, 1), L(hidden, 1)]
+        c = [L(obs_dim + act_dim, h1), L(h1, h2), L(obs_dim + act_dim, h1), L(h1, h2),
+             L(h2, 1), L(h2, 1)]
         c1, c2 = [c[0], c[1], c[4]], [c[2], c[3], c[5]]
     else:
-        c = [L(obs_dim + act_dim, hidden), L(hidden, hidden), L(hidden, 1)]
+        c = [L(obs_dim + act_dim, h1), L(h1, h2), L(h2, 1)]
         c1, c2 = c, None
     return (dict(zip(DET_ACTOR_ORDER, flat(a))), dict(zip(CRITIC_ORDER, flat(c1))),
             dict(zip(CRITIC_ORDER, flat(c2))) if twin else None)

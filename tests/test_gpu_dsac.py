@@ -24,9 +24,12 @@ def make_engine(obs_dim, n_act, hidden, seed, cfg):
     from tianshou_amd import dsac as DS
     from tianshou_amd.sac import SACConfig
 
-    nets = ODS.init_params(obs_dim, n_act, hidden, seed)
-    flats = [DS.net_flat_from_torch([p[k] for k in ODS.NET_ORDER], obs_dim, n_act, hidden) for p in nets]
-    eng = DS.DiscreteSACEngine(obs_dim, n_act, hidden, *flats, SACConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}))
+    from tianshou_amd import widths as W
+
+    nets = ODS.init_params(obs_dim, n_act, hidden, seed)            # hidden: int or (actor h1, actor h2, critic h1, critic h2)
+    H = W.common_hidden(*[[p[k] for k in ODS.NET_ORDER] for p in nets])
+    flats = [DS.net_flat_from_torch([p[k] for k in ODS.NET_ORDER], obs_dim, n_act, H) for p in nets]
+    eng = DS.DiscreteSACEngine(obs_dim, n_act, H, *flats, SACConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}))
     return eng, nets
 
 
@@ -85,12 +88,15 @@ def test_update_gradients_vs_oracle(obs_dim, n_act, hidden, B, auto, weighted):
     assert torch.count_nonzero(head[:, n_act:]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
 def test_dsac_update_matches_reference_golden(tag):
+    """(`widths`: actor Net[40, 72], critics Net[56, 24] in the reference, embedded in Net[96, 96]: tianshou_amd.widths.)"""
     from tianshou_amd import dsac as DS
+    from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_dsac(tag)
+    hw = OS.hidden_widths(d["hidden"])
     eng, _ = make_engine(d["obs_dim"], d["n_act"], d["hidden"], d["seed"], cfg)
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
@@ -107,8 +113,10 @@ def test_dsac_update_matches_reference_golden(tag):
             np.testing.assert_allclose(s[4], ref[4], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(w.cpu().numpy(), g[f"u{u}_new_weight"], rtol=1e-5, atol=2e-5)
         for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
-            flat = torch.cat([t.reshape(-1) for t in DS.net_flat_to_torch(getattr(eng, name), d["obs_dim"], d["n_act"],
-                                                                          d["hidden"])])
+            sz = hw[:2] if name == "actor" else hw[2:]
+            full = DS.net_flat_to_torch(getattr(eng, name), d["obs_dim"], d["n_act"], eng.hidden)
+            assert W.padding_is_zero(full, *sz), name
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sz)])
             lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
             np.testing.assert_allclose(flat.cpu().numpy()[::5], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr, err_msg=name)
 

@@ -1369,7 +1369,79 @@ def test_hip_ppo_hooks_replay_a_bounded_actor_on_the_per_layer_engine():
 
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed"])
+@pytest.mark.parametrize("tag", ["npg_widths", "trpo_widths"])
+def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
+    """HipNPG / HipTRPO on two-hidden-layer tanh networks whose widths are neither equal nor multiples of 32 (actor [48, 80] /
+    critic [40, 56]; actor [100, 60] / critic [60, 100]) against what the unmodified REFERENCE's NPG.update() / TRPO.update()
+    produced on them (tests/golden/npg_{npg,trpo}_widths.npz, oracle/gen_golden.py::gen_npg): the engine runs the networks
+    embedded in Net[96, 96] / Net[128, 128] by zero padding (tianshou_amd/widths.py) -- conjugate gradients, Fisher-vector
+    products, TRPO's line search and the critic's Adam steps never move a padding entry.  Same buffer, initial weights and
+    `np.random.permutation` stream; tolerances of tests/test_gpu_npg.py (both sides are float32 CG solves)."""
+    from tests.test_oracle_golden import load_npg
+    from tianshou_amd.integration import make_hip_npg, make_hip_trpo
+
+    g, d, cfg = load_npg(tag)
+    obs_dim, act_dim, E, T = d["obs_dim"], d["act_dim"], d["E"], d["T"]
+    ha, hc = [int(x) for x in g["hidden"][:2]], [int(x) for x in g["hidden"][2:]]
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, nn.Tanh), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, nn.Tanh))
+    keys_a = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
+              "preprocess.model.model.2.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    keys_c = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
+              "preprocess.model.model.2.bias", "last.model.0.weight", "last.model.0.bias"]
+
+    def load_flat(flat):
+        off = 0
+        for mod, keys in ((actor, keys_a), (critic, keys_c)):
+            sd = mod.state_dict()
+            for k in keys:
+                n = sd[k].numel()
+                sd[k].copy_(torch.as_tensor(flat[off:off + n]).reshape(sd[k].shape))
+                off += n
+        assert off == flat.size
+
+    def dump_flat():
+        return torch.cat([mod.state_dict()[k].reshape(-1).cpu() for mod, keys in ((actor, keys_a), (critic, keys_c)) for k in keys]).numpy()
+
+    load_flat(g["flat_params0"])
+    which = "trpo" if cfg.algo == "trpo" else "npg"
+    kw = dict(lr=cfg.lr, optim_critic_iters=cfg.optim_critic_iters, advantage_normalization=cfg.advantage_normalization,
+              gae_lambda=cfg.gae_lambda, gamma=cfg.gamma, return_scaling=cfg.return_scaling, max_batchsize=cfg.max_batchsize)
+    if which == "npg":
+        kw["trust_region_size"] = cfg.trust_region_size
+    else:
+        kw.update(max_kl=cfg.max_kl, backtrack_coeff=cfg.backtrack_coeff, max_backtracks=cfg.max_backtracks)
+    algo = (make_hip_npg if which == "npg" else make_hip_trpo)(ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", **kw).to("cuda")
+    assert algo._hip_hidden % 32 == 0 and algo._hip_sizes == {"actor": tuple(ha), "critic": tuple(hc)}
+    buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
+    for k in ("obs", "obs_next", "act", "rew", "terminated", "truncated"):
+        getattr(buf, k)[:] = g[k]
+    buf.done[:] = g["terminated"] | g["truncated"]
+    buf._lengths[:], buf.last_index[:] = g["buf_lengths"], g["buf_last_index"]
+    for e, sb in enumerate(buf.buffers):
+        sb._size, sb._insertion_idx = int(g["buf_lengths"][e]), int(g["buf_insertion"][e])
+    assert np.array_equal(buf.sample_indices(0), g["pre_indices"])
+    algo.policy.is_within_training_step = True
+    np.random.seed(int(g["seed"]) + 100)                                 # gen_npg: the reference's permutation stream
+    stats = algo.update(buf, d["batch_size"], d["repeat"])
+    cols = [stats.actor_loss, stats.vf_loss, stats.kl] + ([stats.step_size] if which == "trpo" else [])
+    for col, s_ in enumerate(cols):
+        r = SI.SequenceSummaryStats.from_sequence(g["stats"][:, col])
+        np.testing.assert_allclose([s_.mean, s_.max, s_.min], [r.mean, r.max, r.min], rtol=2e-3, atol=2e-5)
+    got, want, before = dump_flat(), g["flat_params"], g["flat_params0"]
+    moved = np.abs(want - before).max()
+    assert moved > 0 and np.abs(got - want).max() <= 2e-3 * moved + 1e-6, (np.abs(got - want).max(), moved)
+    # the embedding stayed an embedding: every padding entry of the engine's vectors is still exactly zero
+    from tianshou_amd import npg as NG
+    from tianshou_amd import widths as W
+
+    eng = algo._hip_engine
+    assert W.padding_is_zero(NG.actor_flat_to_torch(eng.actor, obs_dim, eng.hidden, act_dim)[:6], *ha)
+    for vec in (eng.critic, eng.critic_m, eng.critic_v):
+        assert W.padding_is_zero(NG.critic_flat_to_torch(vec, obs_dim, eng.hidden), *hc)
+
+
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
 def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the SAC family: the HOOK path -- device mirror of a host buffer, `_preprocess_batch` (n-step
     target with the lagged critics; n = 1 and 3), `_update_with_batch` (twin critics, actor, alpha, Polyak), write-back -- on the
@@ -1383,10 +1455,11 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
 
     g, d, cfg, _ = load_sac(tag)
     obs_dim, act_dim, E, B = d["obs_dim"], d["act_dim"], d["E"], d["batch"]
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
-    p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"])                  # == the reference's initial weights (asserted by gen_sac)
+    hw = OS.hidden_widths(d["hidden"])          # `widths`: actor Net[48, 80], critics Net[72, 40] -- run embedded in Net[96, 96]
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(hw[:2]), nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
+    p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"], hw)              # == the reference's initial weights (asserted by gen_sac)
     for mod, pd, order in ((actor, p0[0], OS.ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER), (c2, p0[2], OS.CRITIC_ORDER)):
         mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
     alpha = SI.AutoAlpha(cfg.target_entropy, cfg.log_alpha0, cfg.alpha_lr) if cfg.auto_alpha else SI.FixedAlpha(cfg.alpha)
@@ -1494,7 +1567,7 @@ def test_hip_dqn_hooks_replay_the_reference():
 
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
 def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the deterministic-actor family: HipTD3 / HipDDPG hook paths on the real engine against what the
     unmodified REFERENCE's TD3.update() / DDPG.update() produced (tests/golden/td3_{twin,ddpg}.npz,
@@ -1508,10 +1581,11 @@ def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     g, d, cfg, _ = load_td3(tag)
     obs_dim, act_dim, B, twin = d["obs_dim"], d["act_dim"], d["batch"], d["twin"]
     E, slots = int(g["dims"][0]), int(g["dims"][1])
-    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, max_action=cfg.max_action)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU)) if twin else None
-    p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin)            # == the reference's initial weights (asserted by gen_td3)
+    hw = OS.hidden_widths(d["hidden"])          # `widths`: Net[400, 300] (embedded in 416); `ddpg_widths`: actor [24, 56], critic [40, 24]
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, list(hw[:2]), nn.ReLU), act_dim, max_action=cfg.max_action)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU)) if twin else None
+    p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin, hw)        # == the reference's initial weights (asserted by gen_td3)
     for mod, pd, order in ((actor, p0[0], OS.DET_ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER)) + (((c2, p0[2], OS.CRITIC_ORDER),) if twin else ()):
         mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
     if twin:

@@ -18,16 +18,20 @@ def rel_err(a, b):
 
 
 def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
+    """hidden: int, or (actor h1, actor h2, critic h1, critic h2) -- embedded by zero padding (tianshou_amd.widths)."""
     from tianshou_amd import sac as S
+    from tianshou_amd import widths as W
 
     actor, c1, c2 = OS.init_sac_params(obs_dim, act_dim, seed, hidden)
+    lists = [[actor[k] for k in OS.ACTOR_ORDER], [c1[k] for k in OS.CRITIC_ORDER], [c2[k] for k in OS.CRITIC_ORDER]]
+    H = W.common_hidden(*lists)
     eng = S.SACEngine(
         obs_dim, act_dim,
-        S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim),
-        S.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
-        S.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
+        S.actor_flat_from_torch(lists[0], obs_dim, act_dim, hidden=H),
+        S.critic_flat_from_torch(lists[1], obs_dim, act_dim, hidden=H),
+        S.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H),
         S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
-                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=hidden)
+                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=H)
     return eng, (actor, c1, c2)
 
 
@@ -106,13 +110,18 @@ def test_update_gradients_vs_oracle(obs_dim, act_dim, B, auto, weighted):
     assert torch.count_nonzero(l1[obs_dim + act_dim:lay["kc"]]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
 def test_sac_update_matches_reference_golden(tag):
+    """(`widths`: actor Net[48, 80], critics Net[72, 40] in the reference; the engine runs them embedded in Net[96, 96] and every
+    padding entry of parameters, lagged parameters and Adam moments stays exactly zero.)"""
     from tianshou_amd import sac as S
+    from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_sac(tag)
-    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg)
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
+    hw = OS.hidden_widths(d["hidden"])
+    sizes = {"actor": hw[:2], "critic1": hw[2:], "critic2": hw[2:], "critic1_old": hw[2:], "critic2_old": hw[2:]}
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
                              truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
@@ -129,7 +138,12 @@ def test_sac_update_matches_reference_golden(tag):
         for name, to_torch in (("actor", S.actor_flat_to_torch), ("critic1", S.critic_flat_to_torch),
                                ("critic2", S.critic_flat_to_torch), ("critic1_old", S.critic_flat_to_torch),
                                ("critic2_old", S.critic_flat_to_torch)):
-            flat = torch.cat([t.reshape(-1) for t in to_torch(getattr(eng, name), d["obs_dim"], d["act_dim"])])
+            full = to_torch(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden)
+            assert W.padding_is_zero(full, *sizes[name]), name
+            for sfx in ("_m", "_v"):
+                if hasattr(eng, name + sfx):
+                    assert W.padding_is_zero(to_torch(getattr(eng, name + sfx), d["obs_dim"], d["act_dim"], eng.hidden), *sizes[name])
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sizes[name])])
             lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
             # Adam's first steps move every weight by ~lr whatever its gradient: compare on lr's scale
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
@@ -190,8 +204,9 @@ def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B):
     a_act, a_logp = eng.policy_forward(obs, noise)
     r_act, r_logp = OS.policy_forward(st.actor, obs, noise)[:2]
     assert rel_err(a_act.cpu(), r_act) < 1e-5 and rel_err(a_logp.cpu().flatten(), r_logp.flatten()) < 1e-5
-    with pytest.raises(Exception):
-        make_engine(5, 2, 0, cfg, hidden=100)                 # not a multiple of 32
+    assert make_engine(5, 2, 0, cfg, hidden=100)[0].hidden == 128       # no multiple of 32: embedded by zero padding (round 6)
+    with pytest.raises(NotImplementedError):
+        make_engine(5, 2, 0, cfg, hidden=1100)                # beyond the kernels' 1024
 
 
 def test_twin_critics_on_two_streams_with_generation_2():

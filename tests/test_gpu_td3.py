@@ -16,16 +16,20 @@ def rel_err(a, b):
 
 
 def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
+    """hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- embedded by zero padding (tianshou_amd.widths)."""
     from tianshou_amd import td3 as T
+    from tianshou_amd import widths as W
 
     actor, c1, c2 = OS.init_td3_params(obs_dim, act_dim, seed, cfg.twin, hidden)
+    lists = [[actor[k] for k in OS.DET_ACTOR_ORDER], [c1[k] for k in OS.CRITIC_ORDER]] + ([[c2[k] for k in OS.CRITIC_ORDER]] if cfg.twin else [])
+    H = W.common_hidden(*lists)
     eng = T.TD3Engine(
-        obs_dim, act_dim, T.actor_flat_from_torch([actor[k] for k in OS.DET_ACTOR_ORDER], obs_dim, act_dim),
-        T.critic_flat_from_torch([c1[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim),
-        T.critic_flat_from_torch([c2[k] for k in OS.CRITIC_ORDER], obs_dim, act_dim) if cfg.twin else None,
+        obs_dim, act_dim, T.actor_flat_from_torch(lists[0], obs_dim, act_dim, hidden=H),
+        T.critic_flat_from_torch(lists[1], obs_dim, act_dim, hidden=H),
+        T.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H) if cfg.twin else None,
         T.TD3Config(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "twin", "policy_noise", "noise_clip",
                                                      "update_actor_freq", "max_action", "actor_lr", "critic_lr")}),
-        hidden=hidden)
+        hidden=H)
     return eng, (actor, c1, c2)
 
 
@@ -88,13 +92,17 @@ def test_policy_target_and_gradients_vs_oracle(twin):
             assert rel_err(t.cpu(), col[name + "_grads"][key]) < 2e-5, (name, key)
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
 def test_update_matches_reference_golden(tag):
+    """(`widths`: the TD3 paper's Net[400, 300] embedded in Net[416, 416]; `ddpg_widths`: actor [24, 56], critic [40, 24] in 64.)"""
     from tianshou_amd import td3 as T
     from tianshou_amd.buffer import DeviceReplayBuffer
 
+    from tianshou_amd import widths as W
+
     g, d, cfg, bstate = load_td3(tag)
-    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg)
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
+    hw = OS.hidden_widths(d["hidden"])
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
                              truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
@@ -108,7 +116,10 @@ def test_update_matches_reference_golden(tag):
         names = ["actor", "critic1", "actor_old", "critic1_old"] + (["critic2", "critic2_old"] if d["twin"] else [])
         for name in names:
             conv = T.actor_flat_to_torch if name.startswith("actor") else T.critic_flat_to_torch
-            flat = torch.cat([t.reshape(-1) for t in conv(getattr(eng, name), d["obs_dim"], d["act_dim"])])
+            sz = hw[:2] if name.startswith("actor") else hw[2:]
+            full = conv(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden)
+            assert W.padding_is_zero(full, *sz), name            # the embedding of Net[h1, h2] in Net[h, h] stays an embedding
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sz)])
             lr = cfg.actor_lr if name.startswith("actor") else cfg.critic_lr
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
                                        err_msg=name)

@@ -947,8 +947,10 @@ def test_discrete_sac_subclass_keeps_signatures_and_fails_loudly():
     _fill(buf, 8, (11,), np.zeros(2, np.int64))
     with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
         algo.update(buffer=buf, sample_size=8)
+    a48 = _dsac_algo(hidden=48)                            # other widths: embedded by zero padding (round 6, widths.py)
+    assert a48._hip_hidden == 64 and a48._hip_sizes["actor"] == (48, 48)
     with pytest.raises(NotImplementedError):
-        _dsac_algo(hidden=48)                              # hidden width must be a multiple of 32
+        _dsac_algo(hidden=1100)
 
 
 @pytest.mark.parametrize("match_rng", [True, False])
@@ -1188,8 +1190,9 @@ def test_redq_subclass_keeps_signatures_and_fails_loudly():
     with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
         algo.update(buffer=buf, sample_size=8)
     assert _redq_algo(hidden=128)._hip_hidden == 128           # any [h, h] with h a multiple of 32 (<= 1024)
+    assert _redq_algo(hidden=100)._hip_hidden == 128           # other widths: embedded by zero padding (round 6, widths.py)
     with pytest.raises(NotImplementedError):
-        _redq_algo(hidden=100)
+        _redq_algo(hidden=1100)
 
 
 def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
@@ -1405,8 +1408,10 @@ def test_natural_gradient_subclasses_keep_signatures_and_fail_loudly(which):
     _fill(buf, 8, (17,), np.zeros((2, 6), np.float32))
     with policy_within_training_step(algo.policy), pytest.raises(RuntimeError, match="no CPU fallback"):
         algo.update(buffer=buf, batch_size=8, repeat=1)
+    a48 = _natural_algo(which, hidden=48)                  # other widths: embedded by zero padding (round 6, widths.py)
+    assert a48._hip_hidden == 64 and a48._hip_sizes == {"actor": (48, 48), "critic": (48, 48)}
     with pytest.raises(NotImplementedError):
-        _natural_algo(which, hidden=48)
+        _natural_algo(which, hidden=1100)
 
 
 @pytest.mark.parametrize("which", ["npg", "trpo"])

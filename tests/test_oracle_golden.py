@@ -377,20 +377,21 @@ def load_sac(tag):
                        auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
                        alpha_lr=c["alpha_lr"])
-    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed)
+    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
+             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)       # (actor h1, h2, critic h1, h2)
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
 def test_sac_restatement_matches_reference(tag):
     """oracle_sac (tanh-Gaussian policy, twin lagged critics, n-step target, three Adam steps, auto alpha,
     Polyak) against the unmodified reference SAC.update() with its rsample() noise replayed."""
     from oracle import oracle_sac as OS
 
     g, d, cfg, bstate = load_sac(tag)
-    actor, c1, c2 = OS.init_sac_params(d["obs_dim"], d["act_dim"], d["seed"])
+    actor, c1, c2 = OS.init_sac_params(d["obs_dim"], d["act_dim"], d["seed"], d["hidden"])
     st = OS.SACState.create(actor, c1, c2, cfg)
     obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
     for u in range(d["n_updates"]):
@@ -531,18 +532,19 @@ def load_td3(tag):
                        policy_noise=c["policy_noise"], noise_clip=c["noise_clip"],
                        update_actor_freq=int(c["update_actor_freq"]), max_action=c["max_action"],
                        actor_lr=c["actor_lr"], critic_lr=c["critic_lr"])
-    d = dict(obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed, twin=bool(twin))
+    d = dict(obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed, twin=bool(twin),
+             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
 def test_td3_ddpg_restatement_matches_reference(tag):
     from oracle import oracle_sac as OS
 
     g, d, cfg, bstate = load_td3(tag)
-    st = OS.TD3State.create(*OS.init_td3_params(d["obs_dim"], d["act_dim"], d["seed"], d["twin"]), cfg)
+    st = OS.TD3State.create(*OS.init_td3_params(d["obs_dim"], d["act_dim"], d["seed"], d["twin"], d["hidden"]), cfg)
     obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
     for u in range(d["n_updates"]):
         idx = g[f"u{u}_indices"]
@@ -573,13 +575,15 @@ def load_dsac(tag):
                        auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
                        alpha_lr=c["alpha_lr"])
+    if "hidden" in g:                       # (actor h1, actor h2, critic h1, critic h2): unequal widths (round 6)
+        hidden = tuple(int(x) for x in g["hidden"])
     d = dict(E=E, slots=slots, obs_dim=obs_dim, n_act=n_act, hidden=hidden, batch=batch, n_updates=n_updates, seed=seed)
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
 def test_dsac_restatement_matches_reference(tag):
     """oracle_dsac (categorical target with entropy bonus, gathered-Q critic losses with PER weights, actor step
     against the updated critics, alpha step, Polyak) against the unmodified reference DiscreteSAC.update()."""
@@ -621,13 +625,14 @@ def load_redq(tag):
                         auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"], log_alpha0=c["log_alpha0"],
                         actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], alpha_lr=c["alpha_lr"], ensemble_size=ens,
                         subset_size=sub, actor_delay=delay, target_mode="mean" if mean else "min")
-    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed)
+    d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
+             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["min", "mean"])
+@pytest.mark.parametrize("tag", ["min", "mean", "widths"])
 def test_redq_restatement_matches_reference(tag):
     """oracle_redq (EnsembleLinear critics, random-subset min / mean target, one ensemble loss, delayed actor and alpha
     steps, Polyak) against the unmodified reference REDQ.update()."""
@@ -635,7 +640,7 @@ def test_redq_restatement_matches_reference(tag):
     from oracle import oracle_sac as OS
 
     g, d, cfg, bstate = load_redq(tag)
-    actor, critic = OR.init_params(d["obs_dim"], d["act_dim"], cfg.ensemble_size, d["seed"])
+    actor, critic = OR.init_params(d["obs_dim"], d["act_dim"], cfg.ensemble_size, d["seed"], d["hidden"])
     st = OR.REDQState.create(actor, critic, cfg)
     for u in range(d["n_updates"]):
         idx = g[f"u{u}_indices"]

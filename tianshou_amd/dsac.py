@@ -38,13 +38,21 @@ def _block(w: torch.Tensor, b: torch.Tensor, k_pad: int, n_pad: int) -> torch.Te
 
 
 def net_flat_from_torch(t: list[torch.Tensor], obs_dim: int, n_act: int, hidden: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, w_head, b_head] (torch nn.Linear layout; also valid for Adam moments) -> flat vector."""
+    """[w1, b1, w2, b2, w_head, b_head] (torch nn.Linear layout; also valid for Adam moments) -> flat vector.  Widths other
+    than [hidden, hidden] are embedded by zero padding (`tianshou_amd.widths`)."""
+    from . import widths as W
+
+    t = W.pad_two_layer(t, hidden)
     lay = layout(obs_dim, n_act, hidden)
     return torch.cat([_block(t[0], t[1], lay["ka"], hidden), _block(t[2], t[3], hidden, hidden),
                       _block(t[4], t[5], hidden, lay["hw"])]).to(device).contiguous()
 
 
-def net_flat_to_torch(flat: torch.Tensor, obs_dim: int, n_act: int, hidden: int) -> list[torch.Tensor]:
+def net_flat_to_torch(flat: torch.Tensor, obs_dim: int, n_act: int, hidden: int, sizes=None) -> list[torch.Tensor]:
+    if sizes is not None:
+        from . import widths as W
+
+        return W.unpad_two_layer(net_flat_to_torch(flat, obs_dim, n_act, hidden), *sizes)
     lay = layout(obs_dim, n_act, hidden)
     f = flat.detach()
     n1, n2 = (lay["ka"] + 1) * hidden, (hidden + 1) * hidden

@@ -658,9 +658,14 @@ def _make_hip_natural(algo: str, ref=None):
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
             if set(sa.keys()) != set(TIANSHOU_ACTOR_KEYS) or list(sc.keys()) != list(TIANSHOU_CRITIC_KEYS):
                 raise NotImplementedError(f"{who}: networks must be those of examples/mujoco/mujoco_npg.py (the PPO nets)")
-            hidden = sa[TIANSHOU_ACTOR_KEYS[0]].shape[0]
-            if hidden % 32 or sa[TIANSHOU_ACTOR_KEYS[2]].shape != (hidden, hidden) or sc[TIANSHOU_CRITIC_KEYS[0]].shape[0] != hidden:
-                raise NotImplementedError(f"{who}: hidden sizes [h, h] with h a multiple of 32, the same for actor and critic")
+            from . import widths as WD
+
+            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
+                la, lc = [sa[k] for k in TIANSHOU_ACTOR_KEYS[:6]], [sc[k] for k in TIANSHOU_CRITIC_KEYS]
+                self._hip_sizes = {"actor": WD.two_layer_widths(la), "critic": WD.two_layer_widths(lc)}
+                self._hip_hidden = WD.common_hidden(la, lc)
+            except NotImplementedError as e:
+                raise NotImplementedError(f"{who}: two hidden layers of widths up to 1024 per network ({e})") from None
             if not getattr(self.policy.actor, "_unbounded", False) or getattr(self.policy.actor, "_c_sigma", True):
                 raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
             _adam_of(self.optim)
@@ -670,7 +675,7 @@ def _make_hip_natural(algo: str, ref=None):
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                hidden, obs_dim = sa[TIANSHOU_ACTOR_KEYS[0]].shape
+                hidden, obs_dim = self._hip_hidden, sa[TIANSHOU_ACTOR_KEYS[0]].shape[1]
                 act_dim = sa[TIANSHOU_ACTOR_KEYS[4]].shape[0]
                 opt, g = _adam_of(self.optim)
                 cfg = NG.NPGConfig(algo=algo, gamma=self.gamma, gae_lambda=self.gae_lambda,
@@ -715,13 +720,14 @@ def _make_hip_natural(algo: str, ref=None):
             dims = (eng.obs_dim, eng.hidden)
             with torch.no_grad():
                 for p, t in zip(params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS),
-                                NG.actor_flat_to_torch(eng.actor, eng.obs_dim, eng.hidden, eng.act_dim)):
+                                NG.actor_flat_to_torch(eng.actor, eng.obs_dim, eng.hidden, eng.act_dim, sizes=self._hip_sizes["actor"])):
                     p.copy_(t.reshape(p.shape))
                 cparams = params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
-                for p, t in zip(cparams, NG.critic_flat_to_torch(eng.critic, *dims)):
+                szc = self._hip_sizes["critic"]
+                for p, t in zip(cparams, NG.critic_flat_to_torch(eng.critic, *dims, sizes=szc)):
                     p.copy_(t)
-            store_adam_state(self.optim._optim, cparams, NG.critic_flat_to_torch(eng.critic_m, *dims),
-                             NG.critic_flat_to_torch(eng.critic_v, *dims), eng.adam_step)
+            store_adam_state(self.optim._optim, cparams, NG.critic_flat_to_torch(eng.critic_m, *dims, sizes=szc),
+                             NG.critic_flat_to_torch(eng.critic_v, *dims, sizes=szc), eng.adam_step)
             self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
             seq = SequenceSummaryStats.from_sequence
             kw = dict(actor_loss=seq(arr[:, 0]), vf_loss=seq(arr[:, 1]), kl=seq(arr[:, 2]))
@@ -1391,10 +1397,17 @@ def make_hip_sac(ref=None):
             if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != S.TIANSHOU_CRITIC_KEYS \
                     or list(self.critic2.state_dict().keys()) != S.TIANSHOU_CRITIC_KEYS:
                 raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py")
-            hid = int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0])
-            if hid % 32 or not 32 <= hid <= 1024 or tuple(sa[S.TIANSHOU_ACTOR_KEYS[2]].shape) != (hid, hid) \
-                    or any(tuple(c.state_dict()[S.TIANSHOU_CRITIC_KEYS[2]].shape) != (hid, hid) for c in (self.critic, self.critic2)):
-                raise NotImplementedError("HipSAC: hidden sizes [h, h], h a multiple of 32 up to 1024, the same for actor and critics")
+            # any two hidden widths per network (round 6): embedded by zero padding into the engine's Net[h, h], h = the largest
+            # width of the three networks rounded up to 32 (tianshou_amd.widths)
+            from . import widths as WD
+
+            lists = {"actor": [sa[k] for k in S.TIANSHOU_ACTOR_KEYS], "critic1": [sc[k] for k in S.TIANSHOU_CRITIC_KEYS],
+                     "critic2": [self.critic2.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS]}
+            try:
+                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
+                hid = WD.common_hidden(*lists.values())
+            except NotImplementedError as e:
+                raise NotImplementedError(f"HipSAC: two hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
                 _adam_of(o)
@@ -1425,11 +1438,12 @@ def make_hip_sac(ref=None):
                                   alpha_lr=self.alpha._optim.param_groups[0]["lr"] if auto else 0.0,
                                   betas=tuple(ga["betas"]), adam_eps=ga["eps"])
                 dev = self._hip_device
+                hid = self._hip_hidden
                 flat_c = lambda mod: S.critic_flat_from_torch(  # noqa: E731
-                    [mod.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS], obs_dim, act_dim, dev)
+                    [mod.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS], obs_dim, act_dim, dev, hidden=hid)
                 eng = self._hip_engine = S.SACEngine(
                     obs_dim, act_dim,
-                    S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
+                    S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev, hidden=hid),
                     flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden)
                 # resume: lagged critics, Adam moments / steps of a loaded checkpoint
                 eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
@@ -1445,9 +1459,13 @@ def make_hip_sac(ref=None):
             return self._hip_engine
 
         def _hip_parts(self, S):
-            return (("actor", self.policy.actor, self.policy_optim, S.TIANSHOU_ACTOR_KEYS, S.actor_flat_from_torch),
-                    ("critic1", self.critic, self.critic_optim, S.TIANSHOU_CRITIC_KEYS, S.critic_flat_from_torch),
-                    ("critic2", self.critic2, self.critic2_optim, S.TIANSHOU_CRITIC_KEYS, S.critic_flat_from_torch))
+            import functools
+
+            fa = functools.partial(S.actor_flat_from_torch, hidden=self._hip_hidden)
+            fc = functools.partial(S.critic_flat_from_torch, hidden=self._hip_hidden)
+            return (("actor", self.policy.actor, self.policy_optim, S.TIANSHOU_ACTOR_KEYS, fa),
+                    ("critic1", self.critic, self.critic_optim, S.TIANSHOU_CRITIC_KEYS, fc),
+                    ("critic2", self.critic2, self.critic2_optim, S.TIANSHOU_CRITIC_KEYS, fc))
 
         def _preprocess_batch(self, batch, buffer, indices):
             _require_gpu(self._hip_device, "HipSAC")
@@ -1479,20 +1497,22 @@ def make_hip_sac(ref=None):
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
             with torch.no_grad():
-                for mod, flat, conv in ((self.policy.actor, eng.actor, S.actor_flat_to_torch),
-                                        (self.critic, eng.critic1, S.critic_flat_to_torch),
-                                        (self.critic2, eng.critic2, S.critic_flat_to_torch),
-                                        (self.critic_old.module, eng.critic1_old, S.critic_flat_to_torch),
-                                        (self.critic2_old.module, eng.critic2_old, S.critic_flat_to_torch)):
-                    for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim, eng.hidden)):
+                sz = self._hip_sizes
+                for mod, flat, conv, name in ((self.policy.actor, eng.actor, S.actor_flat_to_torch, "actor"),
+                                              (self.critic, eng.critic1, S.critic_flat_to_torch, "critic1"),
+                                              (self.critic2, eng.critic2, S.critic_flat_to_torch, "critic2"),
+                                              (self.critic_old.module, eng.critic1_old, S.critic_flat_to_torch, "critic1"),
+                                              (self.critic2_old.module, eng.critic2_old, S.critic_flat_to_torch, "critic2")):
+                    for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim, eng.hidden, sizes=sz[name])):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
             back = {"actor": S.actor_flat_to_torch, "critic1": S.critic_flat_to_torch, "critic2": S.critic_flat_to_torch}
             for name, mod, optim, keys, _ in self._hip_parts(S):
                 store_adam_state(optim._optim, params_by_keys(mod, keys),
-                                 back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim, eng.hidden),
-                                 back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim, eng.hidden), eng.adam_step)
+                                 back[name](getattr(eng, name + "_m"), eng.obs_dim, eng.act_dim, eng.hidden, sizes=self._hip_sizes[name]),
+                                 back[name](getattr(eng, name + "_v"), eng.obs_dim, eng.act_dim, eng.hidden, sizes=self._hip_sizes[name]),
+                                 eng.adam_step)
             if eng.cfg.auto_alpha:
                 store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
                                  [eng.log_alpha_v[0]], eng.adam_step)
@@ -1530,11 +1550,18 @@ def make_hip_redq(ref=None):
             if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != RQ.TIANSHOU_CRITIC_KEYS:
                 raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py")
             w1, w2 = sc[RQ.TIANSHOU_CRITIC_KEYS[0]], sc[RQ.TIANSHOU_CRITIC_KEYS[2]]
-            hid = int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[0])
-            if hid % 32 or not 32 <= hid <= 1024 or w1.dim() != 3 or w1.shape[2] != hid \
-                    or tuple(w2.shape[1:]) != (hid, hid) or w1.shape[0] != self.ensemble_size:
-                raise NotImplementedError("HipREDQ: hidden sizes [h, h] (h a multiple of 32 up to 1024, the same for the actor "
-                                          "and the EnsembleLinear critics of ensemble_size)")
+            from . import widths as WD
+
+            if w1.dim() != 3 or w2.dim() != 3 or w1.shape[0] != self.ensemble_size or w2.shape[1] != w1.shape[2]:
+                raise NotImplementedError("HipREDQ: EnsembleLinear critics of ensemble_size with two hidden layers")
+            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
+                self._hip_sizes = {"actor": WD.two_layer_widths([sa[k] for k in S.TIANSHOU_ACTOR_KEYS]),
+                                   "critic": (int(w1.shape[2]), int(w2.shape[2]))}
+                hid = WD.round32(max(self._hip_sizes["actor"] + self._hip_sizes["critic"]))
+                if not 32 <= hid <= WD.MAX_HIDDEN:
+                    raise NotImplementedError(f"hidden widths up to {WD.MAX_HIDDEN}")
+            except NotImplementedError as e:
+                raise NotImplementedError(f"HipREDQ: two hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim):
                 _adam_of(o)
@@ -1559,18 +1586,19 @@ def make_hip_redq(ref=None):
                                     betas=tuple(ga["betas"]), adam_eps=ga["eps"], ensemble_size=self.ensemble_size,
                                     subset_size=self.subset_size, actor_delay=self.actor_delay, target_mode=self.target_mode)
                 dev = self._hip_device
+                hid = self._hip_hidden
                 eng = self._hip_engine = RQ.REDQEngine(
-                    obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev),
-                    RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev), cfg,
+                    obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev, hidden=hid),
+                    RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev, hidden=hid), cfg,
                     hidden=self._hip_hidden)
                 # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
-                eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev)
+                eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev, hidden=hid)
                 eng.critic_gradient_step = int(self.critic_gradient_step)
                 ms, vs, step = adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS))
-                eng.actor_m, eng.actor_v = (S.actor_flat_from_torch(x, obs_dim, act_dim, dev) for x in (ms, vs))
+                eng.actor_m, eng.actor_v = (S.actor_flat_from_torch(x, obs_dim, act_dim, dev, hidden=hid) for x in (ms, vs))
                 eng.actor_steps = step
                 ms, vs, _ = adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS))
-                eng.critics_m, eng.critics_v = (RQ.ensemble_flat_from_torch(x, obs_dim, act_dim, dev) for x in (ms, vs))
+                eng.critics_m, eng.critics_v = (RQ.ensemble_flat_from_torch(x, obs_dim, act_dim, dev, hidden=hid) for x in (ms, vs))
                 eng._stats[0] = float(self._last_actor_loss)
                 if auto:
                     st = self.alpha._optim.state.get(self.alpha._log_alpha, {})
@@ -1606,19 +1634,22 @@ def make_hip_redq(ref=None):
             dims = (eng.obs_dim, eng.act_dim, eng.hidden)
             E = eng.cfg.ensemble_size
             with torch.no_grad():
-                for p, t in zip(params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS), S.actor_flat_to_torch(eng.actor, *dims)):
+                sa_, sc_ = self._hip_sizes["actor"], self._hip_sizes["critic"]
+                for p, t in zip(params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS), S.actor_flat_to_torch(eng.actor, *dims, sizes=sa_)):
                     p.copy_(t)
                 for mod, flat in ((self.critic, eng.critics), (self.critic_old.module, eng.critics_old)):
-                    for p, t in zip(params_by_keys(mod, RQ.TIANSHOU_CRITIC_KEYS), RQ.ensemble_flat_to_torch(flat, E, *dims)):
+                    for p, t in zip(params_by_keys(mod, RQ.TIANSHOU_CRITIC_KEYS), RQ.ensemble_flat_to_torch(flat, E, *dims, sizes=sc_)):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
             store_adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS),
-                             RQ.ensemble_flat_to_torch(eng.critics_m, E, *dims), RQ.ensemble_flat_to_torch(eng.critics_v, E, *dims),
+                             RQ.ensemble_flat_to_torch(eng.critics_m, E, *dims, sizes=self._hip_sizes["critic"]),
+                             RQ.ensemble_flat_to_torch(eng.critics_v, E, *dims, sizes=self._hip_sizes["critic"]),
                              eng.critic_gradient_step)
             if eng.actor_steps:
                 store_adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS),
-                                 S.actor_flat_to_torch(eng.actor_m, *dims), S.actor_flat_to_torch(eng.actor_v, *dims),
+                                 S.actor_flat_to_torch(eng.actor_m, *dims, sizes=self._hip_sizes["actor"]),
+                                 S.actor_flat_to_torch(eng.actor_v, *dims, sizes=self._hip_sizes["actor"]),
                                  eng.actor_steps)
                 if eng.cfg.auto_alpha:
                     store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]], [eng.log_alpha_v[0]],
@@ -1660,9 +1691,16 @@ def make_hip_discrete_sac(ref=None):
             if any(list(m.state_dict().keys()) != DS.TIANSHOU_KEYS for m in mods):
                 raise NotImplementedError("HipDiscreteSAC: networks must be Net(obs, [h, h]) + a single Linear head")
             sa = self.policy.actor.state_dict()
-            hidden = sa[DS.TIANSHOU_KEYS[0]].shape[0]
-            if hidden % 32 or sa[DS.TIANSHOU_KEYS[2]].shape != (hidden, hidden) or not 2 <= sa[DS.TIANSHOU_KEYS[4]].shape[0] <= 64:
-                raise NotImplementedError("HipDiscreteSAC: hidden sizes [h, h] with h a multiple of 32, 2..64 actions")
+            from . import widths as WD
+
+            lists = {n: [m.state_dict()[k] for k in DS.TIANSHOU_KEYS] for n, m in zip(("actor", "critic1", "critic2"), mods)}
+            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
+                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
+                self._hip_hidden = WD.common_hidden(*lists.values())
+            except NotImplementedError as e:
+                raise NotImplementedError(f"HipDiscreteSAC: two hidden layers of widths up to 1024 per network ({e})") from None
+            if not 2 <= sa[DS.TIANSHOU_KEYS[4]].shape[0] <= 64:
+                raise NotImplementedError("HipDiscreteSAC: 2..64 actions")
             if getattr(self.policy.actor, "softmax_output", False):
                 raise NotImplementedError("HipDiscreteSAC: the actor must output logits (softmax_output=False)")
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
@@ -1677,9 +1715,9 @@ def make_hip_discrete_sac(ref=None):
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                hidden, obs_dim = sa[DS.TIANSHOU_KEYS[0]].shape
+                obs_dim = sa[DS.TIANSHOU_KEYS[0]].shape[1]
                 n_act = sa[DS.TIANSHOU_KEYS[4]].shape[0]
-                dims = (obs_dim, n_act, hidden)
+                dims = (obs_dim, n_act, self._hip_hidden)
                 auto = isinstance(self.alpha, AutoAlpha)
                 ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
                 cfg = SACConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
@@ -1738,16 +1776,18 @@ def make_hip_discrete_sac(ref=None):
             s = stats.cpu().numpy()                                               # one D2H per update()
             dims = (eng.obs_dim, eng.n_act, eng.hidden)
             with torch.no_grad():
-                for mod, flat in ((self.policy.actor, eng.actor), (self.critic, eng.critic1), (self.critic2, eng.critic2),
-                                  (self.critic_old.module, eng.critic1_old), (self.critic2_old.module, eng.critic2_old)):
-                    for p, t in zip(params_by_keys(mod, DS.TIANSHOU_KEYS), DS.net_flat_to_torch(flat, *dims)):
+                sz = self._hip_sizes
+                for mod, flat, nm in ((self.policy.actor, eng.actor, "actor"), (self.critic, eng.critic1, "critic1"),
+                                      (self.critic2, eng.critic2, "critic2"), (self.critic_old.module, eng.critic1_old, "critic1"),
+                                      (self.critic2_old.module, eng.critic2_old, "critic2")):
+                    for p, t in zip(params_by_keys(mod, DS.TIANSHOU_KEYS), DS.net_flat_to_torch(flat, *dims, sizes=sz[nm])):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
             for name, mod, optim in self._hip_parts():
                 store_adam_state(optim._optim, params_by_keys(mod, DS.TIANSHOU_KEYS),
-                                 DS.net_flat_to_torch(getattr(eng, name + "_m"), *dims),
-                                 DS.net_flat_to_torch(getattr(eng, name + "_v"), *dims), eng.adam_step)
+                                 DS.net_flat_to_torch(getattr(eng, name + "_m"), *dims, sizes=self._hip_sizes[name]),
+                                 DS.net_flat_to_torch(getattr(eng, name + "_v"), *dims, sizes=self._hip_sizes[name]), eng.adam_step)
             if eng.cfg.auto_alpha:
                 store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
                                  [eng.log_alpha_v[0]], eng.adam_step)
@@ -1956,10 +1996,17 @@ def _make_hip_det(twin: bool, ref=None):
             critics = [self.critic] + ([self.critic2] if twin else [])
             if list(sa.keys()) != T.TIANSHOU_ACTOR_KEYS or any(list(c.state_dict().keys()) != S_KEYS for c in critics):
                 raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py")
-            hid = int(sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[0])
-            if hid % 32 or not 32 <= hid <= 1024 or tuple(sa[T.TIANSHOU_ACTOR_KEYS[2]].shape) != (hid, hid) \
-                    or any(tuple(c.state_dict()[S_KEYS[2]].shape) != (hid, hid) for c in critics):
-                raise NotImplementedError("HipTD3 / HipDDPG: hidden sizes [h, h], h a multiple of 32 up to 1024, the same for actor and critics")
+            # any two hidden widths per network, e.g. the [400, 300] of the TD3 / DDPG papers (round 6, tianshou_amd.widths)
+            from . import widths as WD
+
+            lists = {"actor": [sa[k] for k in T.TIANSHOU_ACTOR_KEYS]}
+            for i, c in enumerate(critics):
+                lists[f"critic{i + 1}"] = [c.state_dict()[k] for k in S_KEYS]
+            try:
+                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
+                hid = WD.common_hidden(*lists.values())
+            except NotImplementedError as e:
+                raise NotImplementedError(f"HipTD3 / HipDDPG: two hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in [self.policy_optim, self.critic_optim] + ([self.critic2_optim] if twin else []):
                 _adam_of(o)
@@ -1967,13 +2014,16 @@ def _make_hip_det(twin: bool, ref=None):
             self._hip_glue_init()
 
         def _hip_parts(self):
-            parts = [("actor", self.policy.actor, self.policy_optim, T.TIANSHOU_ACTOR_KEYS, T.actor_flat_from_torch,
-                      T.actor_flat_to_torch, self.actor_old.module),
-                     ("critic1", self.critic, self.critic_optim, S_KEYS, T.critic_flat_from_torch, T.critic_flat_to_torch,
-                      self.critic_old.module)]
+            import functools
+
+            P, hid, sz = functools.partial, self._hip_hidden, self._hip_sizes
+            parts = [("actor", self.policy.actor, self.policy_optim, T.TIANSHOU_ACTOR_KEYS, P(T.actor_flat_from_torch, hidden=hid),
+                      P(T.actor_flat_to_torch, sizes=sz["actor"]), self.actor_old.module),
+                     ("critic1", self.critic, self.critic_optim, S_KEYS, P(T.critic_flat_from_torch, hidden=hid),
+                      P(T.critic_flat_to_torch, sizes=sz["critic1"]), self.critic_old.module)]
             if twin:
-                parts.append(("critic2", self.critic2, self.critic2_optim, S_KEYS, T.critic_flat_from_torch,
-                              T.critic_flat_to_torch, self.critic2_old.module))
+                parts.append(("critic2", self.critic2, self.critic2_optim, S_KEYS, P(T.critic_flat_from_torch, hidden=hid),
+                              P(T.critic_flat_to_torch, sizes=sz["critic2"]), self.critic2_old.module))
             return parts
 
         def _engine(self):

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import widths as W
 from .buffer import _i64_dev, gather_rows_multi
 from .ppo_cnn import run_minibatches
 from .returns import gae_scan
@@ -50,7 +51,9 @@ def _block(w: torch.Tensor, b: torch.Tensor, k_pad: int, n_pad: int) -> torch.Te
 
 
 def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, hidden: int, act_dim: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, w_mu, b_mu, sigma_param] (nn.Linear layout; sigma_param of any shape with act_dim elements)."""
+    """[w1, b1, w2, b2, w_mu, b_mu, sigma_param] (nn.Linear layout; sigma_param of any shape with act_dim elements).  Widths
+    other than [hidden, hidden] are embedded by zero padding (`tianshou_amd.widths`: tanh(0) = 0, so a padding unit is inert)."""
+    t = W.pad_two_layer(list(t[:6]), hidden) + list(t[6:])
     k0 = layout(obs_dim, hidden, act_dim)["k0"]
     ls = torch.zeros(HEAD, dtype=torch.float32)
     ls[:act_dim] = t[6].detach().float().cpu().reshape(-1)
@@ -59,7 +62,8 @@ def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, hidden: int, act_
 
 
 def critic_flat_from_torch(t: list[torch.Tensor], obs_dim: int, hidden: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, w_v [1, h], b_v [1]]."""
+    """[w1, b1, w2, b2, w_v [1, h], b_v [1]] (widths as in `actor_flat_from_torch`)."""
+    t = W.pad_two_layer(list(t), hidden)
     k0 = layout(obs_dim, hidden, 1)["k0"]
     return torch.cat([_block(t[0], t[1], k0, hidden), _block(t[2], t[3], hidden, hidden),
                       _block(t[4], t[5], hidden, HEAD)]).to(device).contiguous()
@@ -74,15 +78,18 @@ def _unblocks(flat: torch.Tensor, obs_dim: int, hidden: int, k0: int, n_out: int
             hd[:hidden, :n_out].t().contiguous(), hd[hidden, :n_out].clone()]
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, hidden: int, act_dim: int) -> list[torch.Tensor]:
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, hidden: int, act_dim: int, sizes=None) -> list[torch.Tensor]:
+    """sizes = (h1, h2): the widths of the torch network embedded in Net[hidden, hidden]."""
     k0 = layout(obs_dim, hidden, act_dim)["k0"]
     f = flat.detach()
-    return _unblocks(f, obs_dim, hidden, k0, act_dim) + [f[-HEAD:][:act_dim].clone()]
+    body = _unblocks(f, obs_dim, hidden, k0, act_dim)
+    return (W.unpad_two_layer(body, *sizes) if sizes is not None else body) + [f[-HEAD:][:act_dim].clone()]
 
 
-def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, hidden: int) -> list[torch.Tensor]:
+def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, hidden: int, sizes=None) -> list[torch.Tensor]:
     k0 = layout(obs_dim, hidden, 1)["k0"]
-    return _unblocks(flat.detach(), obs_dim, hidden, k0, 1)
+    body = _unblocks(flat.detach(), obs_dim, hidden, k0, 1)
+    return W.unpad_two_layer(body, *sizes) if sizes is not None else body
 
 
 @dataclass

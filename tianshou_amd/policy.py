@@ -318,7 +318,7 @@ def _sac_forward(policy, batch, state=None, **kwargs):
         actor = eng.actor
     else:
         actor = policy._hip_cached([policy.actor], lambda: S.actor_flat_from_torch(
-            [policy.actor.state_dict()[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, a, dev))
+            [policy.actor.state_dict()[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, a, dev, hidden=hid))
     obs = _dev_f32(_obs_array(batch), dev, obs_dim)
     n = obs.shape[0]
     deterministic = bool(getattr(policy, "deterministic_eval", False)) and not policy.is_within_training_step

@@ -33,18 +33,19 @@ class REDQStateC(C.Structure):
                                           "log_alpha", "log_alpha_m", "log_alpha_v")]
 
 
-def ensemble_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
-    """[w1 [E, in, 256], b1 [E, 1, 256], w2, b2, wq [E, 256, 1], bq [E, 1, 1]] (EnsembleLinear layout; also valid for the
-    matching Adam moments) -> E consecutive critic blocks of ts_sac_layout."""
+def ensemble_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
+    """[w1 [E, in, h1], b1 [E, 1, h1], w2 [E, h1, h2], b2, wq [E, h2, 1], bq [E, 1, 1]] (EnsembleLinear layout; also valid for the
+    matching Adam moments) -> E consecutive critic blocks of ts_sac_layout (any widths: embedded by zero padding into
+    Net[hidden, hidden], `tianshou_amd.widths`)."""
     E = t[0].shape[0]
     blocks = [critic_flat_from_torch([t[0][e].t(), t[1][e, 0], t[2][e].t(), t[3][e, 0], t[4][e].t(), t[5][e, 0]],
-                                     obs_dim, act_dim, "cpu") for e in range(E)]
+                                     obs_dim, act_dim, "cpu", hidden=hidden) for e in range(E)]
     return torch.cat(blocks).to(device).contiguous()
 
 
-def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int, hidden: int = 256) -> list[torch.Tensor]:
+def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int, hidden: int = 256, sizes=None) -> list[torch.Tensor]:
     pc = layout(obs_dim, act_dim, hidden)["critic_count"]
-    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim, hidden) for e in range(E)]
+    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim, hidden, sizes=sizes) for e in range(E)]
     st = lambda i, f: torch.stack([f(p[i]) for p in per])  # noqa: E731
     return [st(0, lambda w: w.t()), st(1, lambda b: b[None, :]), st(2, lambda w: w.t()), st(3, lambda b: b[None, :]),
             st(4, lambda w: w.t()), st(5, lambda b: b.reshape(1, 1))]

@@ -14,6 +14,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
+from . import widths as W
 from .buffer import DeviceReplayBuffer, gather_rows
 from .returns import compute_nstep_return
 from .sac import HID, _dense, _l1, critic_flat_from_torch, critic_flat_to_torch, use_hidden  # noqa: F401
@@ -44,8 +45,10 @@ def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
     return dict(zip(["ka", "kc", "actor_count", "critic_count"], (int(v) for v in out)))
 
 
-def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, wa, ba] in torch nn.Linear layout -> flat engine vector (hidden width read off the tensors)."""
+def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
+    """[w1, b1, w2, b2, wa, ba] in torch nn.Linear layout -> flat engine vector (hidden width read off the tensors; unequal
+    widths / no multiple of 32: embedded by zero padding into Net[hidden, hidden], `tianshou_amd.widths`)."""
+    t = W.pad_two_layer(t, hidden or W.common_hidden(t))
     HID = int(t[0].shape[0])
     lay = layout(obs_dim, act_dim, HID)
     head = torch.zeros((HID + 1, 32), dtype=torch.float32)
@@ -54,7 +57,9 @@ def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, dev
     return torch.cat([_l1(t[0], t[1], lay["ka"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID) -> list[torch.Tensor]:
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None) -> list[torch.Tensor]:
+    if sizes is not None:
+        return W.unpad_two_layer(actor_flat_to_torch(flat, obs_dim, act_dim, hidden), *sizes)
     HID = hidden
     lay = layout(obs_dim, act_dim, HID)
     f = flat.detach()
