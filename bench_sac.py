@@ -52,6 +52,61 @@ def cpu_baseline(updates: int = 3, budget_s: float = 10.0):
             "sample": f"{updates} updates of B={BATCH} (target + 3 optimizer steps + Polyak), torch fp32 CPU oracle"}
 
 
+def hook_level(updates: int = 200, slots: int = 1 << 14) -> dict:
+    """The drop-in as Tianshou calls it: `HipSAC.update(buffer, 4096)` (tianshou_amd/integration.py) on a HOST replay buffer of
+    the C5 shape -- `sample_indices`, `_preprocess_batch`, `_update_with_batch`, `_postprocess_batch`, statistics as Python
+    floats (one device synchronisation per update, as the reference's `.item()` calls have).  The reference package is not on the
+    GPU box, so the subclass is built over the stand-ins of tests/standin.py (same attribute surface,
+    tests/test_standin_surface.py); hook bodies, device mirror, engine and write-back are the production code.  Two modes: the
+    defaults (index-only sampling, engine noise, write-back when the torch state is read) and the reference-exact mode
+    (`host_batch=True, update_noise="torch", write_back="eager"`: the reference's own `Algorithm._update` with its host copy of
+    the batch, torch's host generator, five networks + four optimizers written back after every update)."""
+    from torch import nn
+
+    from tests import standin as SI
+    from tianshou_amd.integration import make_hip_sac
+
+    E = 16
+    n = E * slots
+    rng = np.random.default_rng(0)
+    out = {}
+    for mode, kw in (("default", {}), ("reference_exact", dict(host_batch=True, update_noise="torch", write_back="eager"))):
+        torch.manual_seed(0)
+        actor = SI.ContinuousActorProbabilistic(SI.Net(OBS, [256, 256], nn.ReLU), ACT, unbounded=True, conditioned_sigma=True)
+        c1 = SI.ContinuousCritic(SI.Net(OBS + ACT, [256, 256], nn.ReLU))
+        c2 = SI.ContinuousCritic(SI.Net(OBS + ACT, [256, 256], nn.ReLU))
+        algo = make_hip_sac(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, critic_lr=1e-3, tau=0.005, gamma=0.99,
+                                    alpha=SI.AutoAlpha(-float(ACT), 0.0, 3e-4), n_step_return_horizon=1, device="cuda", **kw).to("cuda")
+        buf = SI.VectorReplayBuffer(n, E, obs_shape=(OBS,), act_shape=(ACT,))
+        buf.obs[:] = rng.standard_normal((n, OBS), dtype=np.float32)
+        buf.obs_next[:] = rng.standard_normal((n, OBS), dtype=np.float32)
+        buf.act[:] = rng.uniform(-1, 1, (n, ACT)).astype(np.float32)
+        buf.rew[:] = rng.standard_normal(n, dtype=np.float32)
+        buf.terminated[:] = rng.random(n) < 0.001
+        buf.done[:] = buf.terminated
+        for e, sb in enumerate(buf.buffers):
+            sb._size, sb._insertion_idx = slots, 0
+            buf._lengths[e] = slots
+            buf.last_index[e] = (e + 1) * slots - 1
+        algo.policy.is_within_training_step = True
+        for _ in range(20):
+            algo.update(buf, BATCH)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(updates):
+            stats = algo.update(buf, BATCH)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        algo.hip_sync()
+        torch.cuda.synchronize()
+        out[mode] = {"updates_per_s": updates / dt, "ms_per_update": dt / updates * 1e3, "sync_ms_after": (time.perf_counter() - t1) * 1e3,
+                     "critic1_loss": float(stats.critic1_loss)}
+    out["note"] = ("HipSAC.update() over a host-filled VectorReplayBuffer stand-in (production hook code); `sync_ms_after` = one "
+                   "hip_sync() (the deferred write-back of five networks and four optimizers) after the timed loop")
+    return out
+
+
 def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) -> dict:
     import bench_init as BI
 
@@ -134,6 +189,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
         "whole_update_mfma_frac": FLOP_PER_SAMPLE * BATCH * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
         "host_enqueue_ms_per_step": t_host / steps * 1e3,
         "cpu_baseline": cpu_baseline() if with_cpu else None,
+        "hook_level": hook_level() if with_cpu else None,
         "final_stats": [float(x) for x in stats.tolist()],
     }
 

@@ -426,7 +426,11 @@ def test_hip_sac_hooks_against_oracle():
     c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
     c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
     alpha = SI.AutoAlpha(-float(act_dim), -0.5, 3e-4)
-    algo = HipSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.01, gamma=0.97, alpha=alpha, device="cuda").to("cuda")
+    # the reference-exact mode: torch's host generator for the rsample() noise, the reference's own Algorithm._update with its host
+    # batch, write-back after every update (the defaults -- engine noise, index-only sampling, lazy write-back -- are compared
+    # with this mode in test_hip_sac_default_mode_equals_the_reference_exact_mode)
+    algo = HipSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.01, gamma=0.97, alpha=alpha, device="cuda",
+                  update_noise="torch", host_batch=True, write_back="eager").to("cuda")
     grab = lambda mod, keys: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(keys, mod.state_dict())}   # noqa: E731
     cfg = OS.SACConfig(gamma=0.97, tau=0.01, n_step=1, auto_alpha=True, target_entropy=-float(act_dim), log_alpha0=-0.5,
                        actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4)
@@ -462,6 +466,82 @@ def test_hip_sac_hooks_against_oracle():
     assert float(stt["step"]) == 4.0 and stt["exp_avg"].shape == w.shape and stt["exp_avg"].device == w.device
     np.testing.assert_allclose(stt["exp_avg"].cpu().numpy(), st.opt_actor.m["w1"].numpy(), rtol=1e-3, atol=1e-7)
     assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.rew.cpu().numpy(), buf.rew)
+
+
+def test_hip_sac_default_mode_equals_the_reference_exact_mode(monkeypatch):
+    """The defaults of HipSAC since round 6 -- `update()` samples indices only (no host copy of the batch), write-back of the five
+    networks / four optimizers deferred until the torch state is read -- against the reference-exact mode on the same indices
+    and noise: identical statistics every update, identical torch state after `hip_sync()`.  And what lazy means: the torch
+    modules do not move between syncs; `policy.state_dict()`, `algorithm.state_dict()`, pickling the policy and `hip_sync()`
+    are readers that sync; a foreign write to ONE module (`critic.load_state_dict`) keeps the engine's progress on the others."""
+    import copy
+    import pickle
+
+    from tianshou_amd.integration import make_hip_sac
+
+    obs_dim, act_dim, E, B = 23, 5, 4, 64
+    HipSAC = make_hip_sac(ref=SI)
+
+    def build(**kw):
+        torch.manual_seed(11)
+        actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+        c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+        c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+        algo = HipSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.01, gamma=0.97,
+                      alpha=SI.AutoAlpha(-float(act_dim), -0.5, 3e-4), device="cuda", update_noise="torch", **kw).to("cuda")
+        algo.policy.is_within_training_step = True
+        return algo
+
+    ref, lazy = build(host_batch=True, write_back="eager"), build()
+    assert lazy.__dict__["_hip_lazy"] and not ref.__dict__["_hip_lazy"]
+    bufs = [SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=4) for _ in range(2)]
+    rng = [np.random.default_rng(9) for _ in range(2)]
+    flat = lambda algo: torch.cat([p.detach().reshape(-1).float().cpu() for p in algo.parameters()])  # noqa: E731
+    start = flat(lazy)
+    for u in range(4):
+        out = []
+        for algo, buf, r in zip((ref, lazy), bufs, rng):
+            _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, r)
+            torch.manual_seed(100 + u)
+            out.append(algo.update(buf, B))
+        for f in ("actor_loss", "critic1_loss", "critic2_loss", "alpha", "alpha_loss"):
+            assert getattr(out[0], f) == getattr(out[1], f), (u, f)
+        assert torch.equal(flat(lazy), start)                      # nothing was written back yet
+    assert lazy.__dict__["_hip_stale"]
+    sd = lazy.policy.state_dict()                                  # a reader: syncs
+    assert not lazy.__dict__["_hip_stale"] and torch.equal(flat(lazy), flat(ref)) and not torch.equal(flat(lazy), start)
+    assert all(torch.equal(v.cpu(), ref.policy.state_dict()[k].cpu()) for k, v in sd.items())
+    w = lazy.policy.actor.preprocess.model.model[0].weight
+    st_l, st_r = lazy.policy_optim._optim.state[w], ref.policy_optim._optim.state[ref.policy.actor.preprocess.model.model[0].weight]
+    assert float(st_l["step"]) == 4.0 and torch.equal(st_l["exp_avg"], st_r["exp_avg"]) and torch.equal(st_l["exp_avg_sq"], st_r["exp_avg_sq"])
+    # one more update each, then: pickling the policy syncs; algorithm.state_dict() syncs
+    for algo, buf in zip((ref, lazy), bufs):
+        torch.manual_seed(200)
+        algo.update(buf, B)
+    twin = pickle.loads(pickle.dumps(lazy.policy))
+    assert not lazy.__dict__["_hip_stale"] and torch.equal(flat(lazy), flat(ref))
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(twin.state_dict().values(), ref.policy.state_dict().values()))
+    for algo, buf in zip((ref, lazy), bufs):
+        torch.manual_seed(201)
+        algo.update(buf, B)
+    assert lazy.__dict__["_hip_stale"]
+    sd_l, sd_r = lazy.state_dict(), ref.state_dict()
+    assert not lazy.__dict__["_hip_stale"]
+    for k in sd_r:
+        if isinstance(sd_r[k], torch.Tensor):
+            assert torch.equal(sd_l[k].cpu(), sd_r[k].cpu()), k
+    # a foreign write to one module while updates are pending: that module keeps what was loaded, the others what the engine learnt
+    for algo, buf in zip((ref, lazy), bufs):
+        torch.manual_seed(202)
+        algo.update(buf, B)
+    loaded = {k: torch.full_like(v, 0.01) for k, v in lazy.critic.state_dict().items()}
+    lazy.critic.load_state_dict(copy.deepcopy(loaded))
+    ref.critic.load_state_dict(copy.deepcopy(loaded))
+    for algo, buf in zip((ref, lazy), bufs):                       # the next hook sees the foreign write and rebuilds the engine
+        torch.manual_seed(203)
+        algo.update(buf, B)
+    lazy.hip_sync()
+    assert torch.equal(flat(lazy), flat(ref))
 
 
 def test_hip_discrete_sac_hooks_against_oracle():
@@ -1464,7 +1544,8 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
         mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
     alpha = SI.AutoAlpha(cfg.target_entropy, cfg.log_alpha0, cfg.alpha_lr) if cfg.auto_alpha else SI.FixedAlpha(cfg.alpha)
     algo = make_hip_sac(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
-                                gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda").to("cuda")
+                                gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda",
+                                update_noise="torch").to("cuda")         # (index-only sampling + lazy write-back: the defaults)
     buf = SI.VectorReplayBuffer(E * d["slots"], E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     lengths = g["buf_lengths"]
     for t in range(int(lengths.max())):                                   # slot e * slots + t of the fixture's buffer = env e, step t
@@ -1493,6 +1574,7 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
         np.testing.assert_allclose(stats.alpha, ref[3], rtol=1e-5)
         if cfg.auto_alpha:
             np.testing.assert_allclose(stats.alpha_loss, ref[4], rtol=1e-5, atol=1e-6)
+        algo.hip_sync()                                                   # lazy write-back: the torch modules are read below
         for name, mod in (("actor", actor), ("critic1", c1), ("critic2", c2), ("critic1_old", algo.critic_old.module),
                           ("critic2_old", algo.critic2_old.module)):
             flat = torch.cat([t.reshape(-1) for t in mod.state_dict().values()]).cpu().numpy()

@@ -443,7 +443,8 @@ def sac_algo():
     return make_hip_sac()(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(),
                           critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=mk(),
                           critic2_optim=AdamOptimizerFactory(lr=1e-3), tau=0.005, gamma=0.99,
-                          alpha=AutoAlpha(-3.0, 0.0, AdamOptimizerFactory(lr=3e-4)), device="cpu")
+                          alpha=AutoAlpha(-3.0, 0.0, AdamOptimizerFactory(lr=3e-4)), device="cpu",
+                          update_noise="torch")        # (the engine's Philox noise needs the GPU library)
 
 
 @pytest.mark.parametrize("which", ["dqn", "sac"])
@@ -684,6 +685,8 @@ def test_hip_sac_wrapper_runs_with_engine_double(sac_algo, monkeypatch):
     with policy_within_training_step(sac_algo.policy):
         stats = sac_algo.update(buffer=buf, sample_size=8)
     assert isinstance(stats, SACTrainingStats) and (stats.actor_loss, stats.critic2_loss, stats.alpha) == (1.0, 3.0, 4.0)
+    assert torch.equal(first.detach(), before)                    # write_back="auto" + the engine's policy forward: lazy
+    sac_algo.policy.state_dict()                                  # a reader of the torch state: syncs
     assert torch.allclose(first.detach(), before + 1.0)                                   # engine -> nn.Parameter
     st = sac_algo.policy_optim._optim.state[first]
     assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg"], torch.full_like(st["exp_avg"], 0.5))

@@ -76,28 +76,118 @@ class _HipGlue:
     # engine-side Adam moments are flushed into torch.optim (they are still valid: only parameters were replaced) and
     # the engine is rebuilt from the torch state on the next use.
     def _hip_current_versions(self) -> tuple:
-        return tuple((id(p), p._version) for p in self.parameters())
+        # the modules' own `_parameters` dicts, collected once per engine (walking `self.parameters()` costs 0.16 ms on a SAC
+        # algorithm and runs on every hook); a Parameter object replaced inside a module is still seen (the dict is live), a
+        # sub-module added afterwards is not -- `hip_invalidate()` covers that
+        dicts = self.__dict__.get("_hip_pdicts")
+        if dicts is None:
+            dicts = self.__dict__["_hip_pdicts"] = [m._parameters for m in self.modules() if m._parameters]
+        return tuple((id(p), p._version) for d in dicts for p in d.values() if p is not None)
 
     def _hip_mark(self) -> None:
-        if self.__dict__.get("_hip_engine_obj") is not None:
+        if self.__dict__.get("_hip_engine_obj") is not None and not self.__dict__.get("_hip_clean_mark", False):
             self.__dict__["_hip_versions"] = self._hip_current_versions()
+        self.__dict__["_hip_clean_mark"] = False
 
     @property
     def _hip_engine(self):
         eng = self.__dict__.get("_hip_engine_obj")
         if eng is not None and not self.__dict__.get("_hip_in_update", False):
             seen = self.__dict__.get("_hip_versions")
-            if seen is not None and seen != self._hip_current_versions():
-                self.__dict__["_hip_versions"] = None          # (the flush reads `_hip_engine` itself: no re-entry)
-                self._hip_flush()
-                self.__dict__["_hip_engine_obj"] = eng = None
-                self._hip_adam_dirty = False
+            if seen is not None:
+                now = self._hip_current_versions()
+                if seen != now:
+                    self.__dict__["_hip_versions"] = None          # (the flush reads `_hip_engine` itself: no re-entry)
+                    if self.__dict__.get("_hip_stale", False):
+                        # lazy write-back: what the engine learnt since the last sync goes to every parameter that was NOT
+                        # written by somebody else (theirs wins), then the engine is rebuilt from the torch state
+                        old = dict(seen)
+                        self.__dict__["_hip_skip_ids"] = {i for i, v in now if old.get(i, v) != v} | (set(dict(now)) - set(old))
+                        try:
+                            self._hip_write_back()
+                        finally:
+                            self.__dict__["_hip_skip_ids"] = None
+                            self.__dict__["_hip_stale"] = False
+                    self._hip_flush()
+                    self.__dict__["_hip_engine_obj"] = eng = None
+                    self._hip_adam_dirty = False
         return eng
 
     @_hip_engine.setter
     def _hip_engine(self, value) -> None:
         self.__dict__["_hip_engine_obj"] = value
+        self.__dict__["_hip_pdicts"] = None
         self.__dict__["_hip_versions"] = None if value is None else self._hip_current_versions()
+
+    # -- write-back of what the engine learnt (off-policy subclasses) ---------------------------------------------------
+    # "eager": after every update (the torch modules are always current: what round 5 did).  "lazy": when somebody reads
+    # them -- `state_dict()` of the algorithm or of the attached policy, pickling, `hip_sync()`, a foreign write, a
+    # rebuild.  The collector does not: with `policy_forward="hip"` it acts with the engine's parameters
+    # (tianshou_amd/policy.py).  An eager write-back is ~600 small torch ops (2 ms per SAC update against 0.36 ms of GPU work).
+    def _hip_put(self, p, t) -> None:
+        skip = self.__dict__.get("_hip_skip_ids")
+        if skip and id(p) in skip:
+            return
+        p.copy_(t.reshape(p.shape) if t.shape != p.shape else t)
+
+    def _hip_write_back(self) -> None:
+        """Engine parameters / lagged parameters / optimizer state -> the torch modules (subclasses with lazy write-back)."""
+
+    def _hip_after_update(self) -> None:
+        if self.__dict__.get("_hip_lazy", False):
+            self.__dict__["_hip_stale"] = True
+            self.__dict__["_hip_clean_mark"] = True          # nothing was written to the torch parameters: the mark stands
+        else:
+            self._hip_write_back()
+
+    def hip_sync(self) -> None:
+        """Public: make the torch modules and optimizers current (no-op unless updates are pending under write_back="lazy")."""
+        if self.__dict__.get("_hip_stale", False) and self.__dict__.get("_hip_engine_obj") is not None:
+            self.__dict__["_hip_stale"] = False
+            self.__dict__["_hip_in_update"] = True
+            try:
+                self._hip_write_back()
+            finally:
+                self.__dict__["_hip_in_update"] = False
+            self.__dict__["_hip_versions"] = self._hip_current_versions()
+
+    def _hip_set_write_back(self, write_back: str, attached: bool) -> None:
+        if write_back not in ("auto", "lazy", "eager"):
+            raise ValueError("write_back must be 'auto', 'lazy' or 'eager'")
+        self.__dict__["_hip_lazy"] = write_back == "lazy" or (write_back == "auto" and attached)
+
+    def _hip_offpolicy_update(self, buffer, sample_size, Batch, TrainingStats=None):
+        """`OffPolicyAlgorithm.update` -> `Algorithm._update` (algorithm_base.py:586-631, 893-903): the same steps in the same
+        order, except that `buffer.sample(sample_size)` -- `sample_indices` + a host fancy-index copy of every key of the batch
+        (1.5 ms for 4,096 Humanoid transitions) -- keeps only its first half: the hooks read the rows from the device mirror
+        by index.  A prioritized buffer's importance weights are attached as its `__getitem__` does (prio.py:103-106)."""
+        import time
+
+        if not self.policy.is_within_training_step:
+            raise RuntimeError(
+                f"update() was called outside of a training step as signalled by {self.policy.is_within_training_step=} "
+                "(see tianshou.utils.torch_utils.policy_within_training_step)")
+        if buffer is None:
+            return TrainingStats() if TrainingStats is not None else None
+        start = time.time()
+        indices = buffer.sample_indices(sample_size)
+        batch = Batch()
+        if hasattr(buffer, "get_weight"):
+            w = buffer.get_weight(indices)
+            batch.weight = w / np.max(w) if getattr(buffer, "_weight_norm", True) else w
+        batch = self._preprocess_batch(batch, buffer, indices)
+        # torch_train_mode (torch_utils.py:14-22) is `train(True)` ... `train(was_training)` around the update; the engine reads
+        # no module flag, so only the second call is observable (each walks ~60 modules: 0.24 ms)
+        was_training = self.training
+        try:
+            stat = self._update_with_batch(batch)
+        finally:
+            self.train(was_training)
+        self._postprocess_batch(batch, buffer, indices)
+        for lr_scheduler in self.lr_schedulers:
+            lr_scheduler.step()
+        stat.train_time = time.time() - start
+        return stat
 
     # -- data parallelism (SURVEY 8e): one process per GPU, the replay buffer sharded by sub-buffer (env id), one
     # all-reduce of the flat gradient per minibatch step; replaces the reference's single-process nn.DataParallel
@@ -146,6 +236,8 @@ class _HipGlue:
         """`Algorithm.load_state_dict` replaced parameters AND optimizer state: drop the engine without flushing."""
         self.__dict__["_hip_engine_obj"] = None
         self.__dict__["_hip_versions"] = None
+        self.__dict__["_hip_pdicts"] = None
+        self.__dict__["_hip_stale"] = False
         self._hip_adam_dirty = False
 
     def hip_invalidate(self, keep_optimizer: bool = True) -> None:
@@ -156,12 +248,13 @@ class _HipGlue:
         if keep_optimizer and self.__dict__.get("_hip_engine_obj") is not None:
             self.__dict__["_hip_versions"] = None
             self._hip_flush()
-        self._hip_invalidate()
+        self._hip_invalidate()          # (pending lazy updates are dropped with the engine: the caller's edit of the torch state wins)
 
     def _hip_flush(self) -> None:
         """Engine-side optimizer state -> torch.optim state; the default wrappers store it after every update."""
 
     def state_dict(self, *args, **kwargs):
+        self.hip_sync()
         self._hip_flush()
         return super().state_dict(*args, **kwargs)
 
@@ -1371,12 +1464,14 @@ def make_hip_sac(ref=None):
     """Returns HipSAC(SAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, sac.py:298-336) on the
     engine.  Supported nets: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU, conditioned sigma,
     unbounded actor; concat critics);
-    obs_next is the buffer's stored column or, with save_obs_next=False, obs[next(index)] (buffer_base.py:622-626).  rsample() noise is drawn from torch's
-    default generator on the host, in the reference's order (target-policy call, then actor-loss call).
+    obs_next is the buffer's stored column or, with save_obs_next=False, obs[next(index)] (buffer_base.py:622-626).  rsample() noise: the engine's
+    Philox stream by default, or (`update_noise="torch"`) torch's default generator on the host in the reference's order
+    (target-policy call, then actor-loss call) -- the seed-exact mode the fixture replays use.
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     SAC = _ref(ref, "tianshou.algorithm.modelfree.sac", "SAC")
     AutoAlpha = _ref(ref, "tianshou.algorithm.modelfree.sac", "AutoAlpha")
     SACTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.sac", "SACTrainingStats")
+    Batch = _ref(ref, "tianshou.data", "Batch")
 
     from . import sac as S
 
@@ -1384,14 +1479,24 @@ def make_hip_sac(ref=None):
         _HIP_LR = (("actor_lr", "policy_optim"), ("critic_lr", "critic_optim"), ("critic_lr", "critic2_optim"),
                    ("alpha_lr", "alpha"))
         def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, policy_forward="hip",
-                     sampling="device", noise_seed=None, **kwargs):
+                     sampling="device", noise_seed=None, write_back="auto", update_noise="device", host_batch=False, **kwargs):
             """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer and
             `_update_with_batch` runs the four phases of `DataParallelSAC` around two all-reduces (critic gradients,
             actor gradient + mean log-probability); replicas stay identical, PER weights rank-local.
             `policy_forward="hip"`: `SACPolicy.forward` (sac.py:108-131) as the Collector calls it runs on
             `ts_sac_policy_forward_logits` with the engine's actor (`tianshou_amd.policy`; `sampling` / `noise_seed` as in
-            HipPPO)."""
+            HipPPO).
+            Hook-level throughput (round 6; `bench.py --workload sac` `hook_level`): `write_back="auto"` keeps the updates in the
+            engine until somebody reads the torch modules (lazy whenever the policy forward is the engine's; "eager" = after every
+            update; `hip_sync()` forces it); `update_noise="device"` draws the two rsample() noises of an update from the
+            engine's Philox stream instead of torch's host generator ("torch" = the reference's stream, seed-exact);
+            `host_batch=False` lets `update()` sample indices only -- the hooks read the rows from the device mirror, the host
+            copy `buffer.sample()` makes of them is never looked at (True: the reference's own `Algorithm._update`)."""
             super().__init__(*args, **kwargs)
+            if update_noise not in ("device", "torch"):
+                raise ValueError("update_noise must be 'device' or 'torch'")
+            self._hip_update_noise, self._hip_host_batch, self._hip_noise_calls = update_noise, bool(host_batch), 0
+            self._hip_noise_key = int(torch.initial_seed() % (2**31 - 1)) if noise_seed is None else int(noise_seed)
             self._hip_device = torch.device(device)
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
             if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != S.TIANSHOU_CRITIC_KEYS \
@@ -1422,6 +1527,22 @@ def make_hip_sac(ref=None):
                 HP.attach(self.policy, "sac", self, device=str(self._hip_device), sampling=sampling, noise_seed=noise_seed,
                           obs_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1]), act_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]),
                           hidden=hid)
+            self._hip_set_write_back(write_back, attached=policy_forward == "hip")
+
+        def update(self, buffer, sample_size):
+            if self._hip_host_batch or buffer is None:
+                return super().update(buffer, sample_size)
+            return self._hip_offpolicy_update(buffer, sample_size, Batch)
+
+        def _hip_rsample_noise(self, n, a):
+            """eps of one Normal.rsample() call of the reference (sac.py:124-131): torch's host generator ("torch": the
+            reference's own stream) or the engine's Philox stream keyed by (noise key, call number)."""
+            if self._hip_update_noise == "torch":
+                return torch.randn(n, a)
+            from .buffer import normal_noise
+
+            self._hip_noise_calls += 1
+            return normal_noise((n, a), self._hip_noise_key ^ 0x5AC, self._hip_noise_calls, self._hip_device)
 
         def _engine(self):
             if self._hip_engine is None:
@@ -1472,7 +1593,7 @@ def make_hip_sac(ref=None):
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
-            noise = torch.randn(len(indices), eng.act_dim)                  # Normal.rsample of the target policy call
+            noise = self._hip_rsample_noise(len(indices), eng.act_dim)      # Normal.rsample of the target policy call
             batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)
             self._hip_idx = idx
             return batch
@@ -1483,7 +1604,7 @@ def make_hip_sac(ref=None):
 
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
-            noise = torch.randn(len(batch), eng.act_dim)
+            noise = self._hip_rsample_noise(int(self._hip_idx.numel()), eng.act_dim)
             runner = eng
             if self._hip_dp_on:
                 from .distributed import DataParallelSAC
@@ -1496,6 +1617,15 @@ def make_hip_sac(ref=None):
                                                     batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
+            self._hip_after_update()                                              # write-back now ("eager") or when read ("lazy")
+            auto = eng.cfg.auto_alpha
+            return SACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
+                                    alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
+
+        def _hip_write_back(self) -> None:
+            eng = self.__dict__.get("_hip_engine_obj")
+            if eng is None:
+                return
             with torch.no_grad():
                 sz = self._hip_sizes
                 for mod, flat, conv, name in ((self.policy.actor, eng.actor, S.actor_flat_to_torch, "actor"),
@@ -1504,9 +1634,9 @@ def make_hip_sac(ref=None):
                                               (self.critic_old.module, eng.critic1_old, S.critic_flat_to_torch, "critic1"),
                                               (self.critic2_old.module, eng.critic2_old, S.critic_flat_to_torch, "critic2")):
                     for p, t in zip(mod.parameters(), conv(flat, eng.obs_dim, eng.act_dim, eng.hidden, sizes=sz[name])):
-                        p.copy_(t)
+                        self._hip_put(p, t)
                 if eng.cfg.auto_alpha:
-                    self.alpha._log_alpha.copy_(eng.log_alpha[0])
+                    self._hip_put(self.alpha._log_alpha, eng.log_alpha[0])
             back = {"actor": S.actor_flat_to_torch, "critic1": S.critic_flat_to_torch, "critic2": S.critic_flat_to_torch}
             for name, mod, optim, keys, _ in self._hip_parts(S):
                 store_adam_state(optim._optim, params_by_keys(mod, keys),
@@ -1516,9 +1646,6 @@ def make_hip_sac(ref=None):
             if eng.cfg.auto_alpha:
                 store_adam_state(self.alpha._optim, [self.alpha._log_alpha], [eng.log_alpha_m[0]],
                                  [eng.log_alpha_v[0]], eng.adam_step)
-            auto = eng.cfg.auto_alpha
-            return SACTrainingStats(actor_loss=float(s[0]), critic1_loss=float(s[1]), critic2_loss=float(s[2]),
-                                    alpha=float(s[3]), alpha_loss=float(s[4]) if auto else None)
 
     return HipSAC
 

@@ -45,8 +45,20 @@ class _HipForward:
     _hip_family = ""
 
     def __reduce__(self):
+        self._hip_sync_owner()             # pickle / deepcopy / torch.save read the torch parameters
         state = {k: v for k, v in self.__dict__.items() if not k.startswith("_hip_rt_")}       # (run-time handles: weakrefs, caches)
         return _rebuild, (type(self).__mro__[2], self._hip_family), state
+
+    def _hip_sync_owner(self) -> None:
+        """An owner with `write_back="lazy"` keeps its updates in the engine until somebody reads the torch parameters: this
+        policy's `state_dict()` / pickling are such readers (`_HipGlue.hip_sync`)."""
+        owner = self._hip_owner()
+        if owner is not None and hasattr(owner, "hip_sync"):
+            owner.hip_sync()
+
+    def state_dict(self, *args, **kwargs):
+        self._hip_sync_owner()
+        return super().state_dict(*args, **kwargs)
 
     # -- where the parameters come from -----------------------------------------------------------------------
     def _hip_owner(self):
