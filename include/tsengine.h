@@ -913,6 +913,19 @@ int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8);
  * "256" / "257" then reads h / h + 1. */
 int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden);
 int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out8);
+/* Net(hidden_sizes=[h] * depth) for depth other than 2 (utils/net/common.py:246-369 takes any list; round 6): the number of
+ * hidden layers is a property of the workspace too -- ts_mlp_set_trunk(ws, h, depth) (depth in [1, TS_MLP_MAX_HIDDEN_LAYERS];
+ * 0 = 2) applies to every SAC / TD3 / DDPG / REDQ / DiscreteSAC entry point subsequently called with `ws`;
+ * ts_mlp_set_hidden resets the depth to 2.  Flat vectors then hold depth + 1 wb matrices back to back:
+ *   L1 [k + 1, h] | L2 .. Ldepth [h + 1, h] each | head [h + 1, head_cols]
+ * (k = the input width rounded up to 32; head_cols = 64 for SAC's / REDQ's Gaussian actor, 32 otherwise) -- for depth 2
+ * exactly the layouts above.  ts_mlp_layout: h_out[0] = k, h_out[1 + i] = offset of linear layer i (i = 0 .. depth; the
+ * head is layer `depth`), h_out[depth + 2] = the element count; h_out has depth + 3 entries.  Depth 2 at the widths the
+ * fused three-layer kernels take runs on them; every other trunk runs layer by layer on the GEMM kernels (ReLU fused
+ * into the forward GEMM's epilogue and into the input-gradient GEMM's mask). */
+#define TS_MLP_MAX_HIDDEN_LAYERS 6
+int ts_mlp_set_trunk(ts_workspace* ws, int64_t hidden, int64_t depth);
+int ts_mlp_layout(int64_t in_dim, int64_t hidden, int64_t depth, int64_t head_cols, int64_t* h_out);
 
 /* SACPolicy.forward (sac.py:108-131) with rsample() = loc + noise * scale; noise NULL = dist.mode
  * (deterministic_eval).  act_out (nullable) float32[B, act_dim] = tanh-squashed action, logp_out float32[B]

@@ -82,6 +82,8 @@ struct ts_workspace {
     // hidden width of the Net[h, h] MLPs of the SAC / TD3 / DDPG / REDQ entry points called with this workspace
     // (ts_mlp_set_hidden; 0 = 256, the width of examples/mujoco/mujoco_sac.py)
     int mlp_hidden;
+    // number of hidden layers of those MLPs (ts_mlp_set_trunk; 0 = 2, the depth of the examples' nets)
+    int mlp_depth;
     hipStream_t side;
     hipStream_t side2;           // second side stream (ts::side_streams): created together with `side`
     hipEvent_t side_ev[16];

@@ -189,6 +189,15 @@ int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
     TS_REQUIRE(hidden == 0 || (hidden >= 32 && hidden <= 1024 && hidden % 32 == 0), TS_ERR_INVALID_ARG,
                "ts_mlp_set_hidden: 0 (default 256) or a multiple of 32 in [32, 1024], got %lld", (long long)hidden);
     ws->mlp_hidden = (int)hidden;
+    ws->mlp_depth = 0;
+    return TS_OK;
+}
+
+int ts_mlp_set_trunk(ts_workspace* ws, int64_t hidden, int64_t depth) {
+    TS_REQUIRE(depth == 0 || (depth >= 1 && depth <= TS_MLP_MAX_HIDDEN_LAYERS), TS_ERR_INVALID_ARG,
+               "ts_mlp_set_trunk: 0 (default 2) or 1 .. %d hidden layers, got %lld", TS_MLP_MAX_HIDDEN_LAYERS, (long long)depth);
+    if (int rc = ts_mlp_set_hidden(ws, hidden)) return rc;
+    ws->mlp_depth = (int)depth;
     return TS_OK;
 }
 

@@ -40,34 +40,49 @@ constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
 inline int pad32(int x) { return (x + 31) / 32 * 32; }
 
-struct Mlp {                  // in -> 256 -> 256 -> head, ReLU between
-    ts::ConvGeom l[3];
-    int64_t off[4];
+constexpr int MAXD = TS_MLP_MAX_HIDDEN_LAYERS;      // hidden layers of a trunk (ts_mlp_set_trunk)
+constexpr int MAXL = MAXD + 1;                      // linear layers incl. the head
+
+struct Mlp {                  // in -> hid x depth -> head, ReLU between (depth 2 / width 256: the examples' nets)
+    ts::ConvGeom l[MAXL];
+    int64_t off[MAXL + 1];
+    int L;                    // linear layers = depth + 1; the head is l[L - 1]
+    int64_t total() const { return off[L]; }
+    const ts::ConvGeom& head() const { return l[L - 1]; }
+    // the one-launch three-layer kernels of ts_mlp.hip are written for two hidden layers of one width
+    bool three() const { return L == 3 && l[1].OC == l[0].OC; }
 };
 
-Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID) {
-    Mlp m;
-    const int dims[4] = {in_pad, hid, hid, head_cols};
+Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID, int depth = 2) {
+    Mlp m{};
+    if (depth < 1 || depth > MAXD) depth = 2;       // (validated by ts_mlp_set_trunk / the layout entry points)
+    m.L = depth + 1;
     int64_t o = 0;
-    for (int i = 0; i < 3; ++i) {
-        m.l[i] = ts::ConvGeom{B, 1, 1, dims[i], 1, 1, 1, 1, 1, dims[i + 1]};
+    for (int i = 0; i < m.L; ++i) {
+        m.l[i] = ts::ConvGeom{B, 1, 1, i == 0 ? in_pad : hid, 1, 1, 1, 1, 1, i + 1 == m.L ? head_cols : hid};
         m.off[i] = o;
         o += m.l[i].param_elems();
     }
-    m.off[3] = o;
+    m.off[m.L] = o;
     return m;
 }
 
-struct Act { float* h1; float* h2; float* out; };      // forward activations of one pass
+struct Act { float* h[MAXD]; float* out; };      // forward activations of one pass: h[i] = output of hidden layer i
+inline Act act_of(float* h1, float* h2, float* out) { Act a{}; a.h[0] = h1; a.h[1] = h2; a.out = out; return a; }
+inline float* act_out(const Mlp& m, const Act& a, int i) { return i + 1 == m.L ? a.out : a.h[i]; }      // output of layer i
 
 int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
                 float* split) {
-    if (ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC)       // one launch (ts_mlp.hip)
-        return ts::mlp3_forward(s, x, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC, a.h1,
-                                a.h2, a.out, ws);
-    if (int rc = ts::conv_forward(s, m.l[0], x, p + m.off[0], a.h1, true, split, ws)) return rc;
-    if (int rc = ts::conv_forward(s, m.l[1], a.h1, p + m.off[1], a.h2, true, split, ws)) return rc;
-    return ts::conv_forward(s, m.l[2], a.h2, p + m.off[2], a.out, false, split, ws);
+    if (m.three() && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC))       // one launch (ts_mlp.hip)
+        return ts::mlp3_forward(s, x, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2], m.l[2].OC, a.h[0],
+                                a.h[1], a.out, ws);
+    const float* in = x;
+    for (int i = 0; i < m.L; ++i) {
+        float* out = act_out(m, a, i);
+        if (int rc = ts::conv_forward(s, m.l[i], in, p + m.off[i], out, i + 1 < m.L, split, ws)) return rc;
+        in = out;
+    }
+    return TS_OK;
 }
 
 // n <= MLP3_MAX_NETS networks of one shape on the same input and the same stream: one launch (blockIdx.y = network) on the
@@ -75,12 +90,12 @@ int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, c
 constexpr int MULTI_MAX = ts::MLP3_MAX_NETS;
 int mlp_forward_multi(hipStream_t s, ts_workspace* ws, const Mlp& m, int n, const float* const* p, const float* x, const Act* a,
                       float* const* split) {
-    if (n > 1 && n <= MULTI_MAX && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && m.l[1].OC == m.l[0].OC) {
+    if (n > 1 && n <= MULTI_MAX && m.three() && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC)) {
         const float *w1[MULTI_MAX], *w2[MULTI_MAX], *w3[MULTI_MAX];
         float *h1[MULTI_MAX], *h2[MULTI_MAX], *out[MULTI_MAX];
         for (int k = 0; k < n; ++k) {
             w1[k] = p[k] + m.off[0]; w2[k] = p[k] + m.off[1]; w3[k] = p[k] + m.off[2];
-            h1[k] = a[k].h1; h2[k] = a[k].h2; out[k] = a[k].out;
+            h1[k] = a[k].h[0]; h2[k] = a[k].h[1]; out[k] = a[k].out;
         }
         return ts::mlp3_forward_n(s, n, x, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, out, ws);
     }
@@ -95,17 +110,17 @@ int mlp_forward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float*
 
 size_t split_floats(const Mlp& m) {
     size_t s = 4;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < m.L; ++i) {
         const int ns = ts::conv_fwd_splits(m.l[i]);
         if (ns > 1) s = std::max(s, (size_t)ns * m.l[i].out_elems());
     }
     return s;
 }
 
-struct BwdScratch { float* dh2; float* dh1; float* slabs; };
+struct BwdScratch { float* dh[MAXD]; float* slabs; };        // dh[i] = gradient w.r.t. the output of hidden layer i
 
 bool fused_backward(const Mlp& m, bool want_dx, int col0, int col1) {
-    return m.l[1].OC == m.l[0].OC && ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, want_dx, col0, col1);
+    return m.three() && ts::mlp3_backward_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC, want_dx, col0, col1);
 }
 
 // Weight gradients of n <= 5 networks of the same shape whose input-gradient chains (mlp3_backward) have run on stream
@@ -118,10 +133,11 @@ int mlp_weight_grads(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const
     const float* dY[3 * WGRADS_MAX_NETS];
     float* slabs[3 * WGRADS_MAX_NETS];
     ts::SlabSeg seg[3 * WGRADS_MAX_NETS];
-    TS_REQUIRE(n >= 1 && n <= WGRADS_MAX_NETS, TS_ERR_INVALID_ARG, "mlp_weight_grads: 1 .. %d networks", WGRADS_MAX_NETS);
+    TS_REQUIRE(n >= 1 && n <= WGRADS_MAX_NETS && m.L == 3, TS_ERR_INVALID_ARG, "mlp_weight_grads: 1 .. %d three-layer networks",
+               WGRADS_MAX_NETS);
     for (int k = 0; k < n; ++k) {
-        const float* xin[3] = {x[k], a[k].h1, a[k].h2};
-        const float* dy[3] = {sc[k].dh1, sc[k].dh2, d_out[k]};
+        const float* xin[3] = {x[k], a[k].h[0], a[k].h[1]};
+        const float* dy[3] = {sc[k].dh[0], sc[k].dh[1], d_out[k]};
         size_t off = 0;
         for (int i = 2; i >= 0; --i) {
             const int j = 3 * k + (2 - i);
@@ -142,30 +158,29 @@ int mlp_weight_grads(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const
 // are interleaved and everything happens in part 1).
 int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, const float* x, const Act& a,
                  const float* d_out, float* grad, float* dx, int col0, int col1, const BwdScratch& sc, int part = 3) {
-    const float* xin[3] = {x, a.h1, a.h2};
-    const float* dy[3] = {sc.dh1, sc.dh2, d_out};
-    float* dxl[3] = {dx, sc.dh1, sc.dh2};
     if (fused_backward(m, dx != nullptr, col0, col1)) {
         // all input gradients in one launch (ts_mlp.hip), then the three weight-gradient GEMMs in one launch
         if (part & 1)
             if (int rc = ts::mlp3_backward(s, d_out, m.l[0].B, m.l[0].IC, p + m.off[0], p + m.off[1], p + m.off[2],
-                                           m.l[2].OC, a.h1, a.h2, sc.dh1, sc.dh2, dx, col0, col1, ws))
+                                           m.l[2].OC, a.h[0], a.h[1], sc.dh[0], sc.dh[1], dx, col0, col1, ws))
                 return rc;
         if (!grad || !(part & 2)) return TS_OK;
         return mlp_weight_grads(s, ws, 1, m, &x, &a, &d_out, &grad, &sc);
     }
     if (!(part & 1)) return TS_OK;
-    for (int i = 2; i >= 0; --i) {
+    for (int i = m.L - 1; i >= 0; --i) {            // layer i: input xin, upstream gradient dy
+        const float* xin = i == 0 ? x : a.h[i - 1];
+        const float* dy = i + 1 == m.L ? d_out : sc.dh[i];
         if (grad) {
-            if (int rc = ts::conv_wgrad(s, m.l[i], xin[i], dy[i], sc.slabs, ws)) return rc;
+            if (int rc = ts::conv_wgrad(s, m.l[i], xin, dy, sc.slabs, ws)) return rc;
             if (int rc = ts::slab_sum(s, sc.slabs, ts::conv_wgrad_splits(m.l[i]), m.l[i].param_elems(),
                                       grad + m.off[i]))
                 return rc;
         }
-        if (i > 0) {
-            if (int rc = ts::conv_dgrad(s, m.l[i], dy[i], p + m.off[i], xin[i], dxl[i], ws)) return rc;
+        if (i > 0) {                                  // (xin = the ReLU output the gradient is masked with)
+            if (int rc = ts::conv_dgrad(s, m.l[i], dy, p + m.off[i], xin, sc.dh[i - 1], ws)) return rc;
         } else if (dx) {
-            if (int rc = ts::conv_dgrad(s, m.l[0], dy[0], p + m.off[0], nullptr, dx, ws, col0, col1)) return rc;
+            if (int rc = ts::conv_dgrad(s, m.l[0], dy, p + m.off[0], nullptr, dx, ws, col0, col1)) return rc;
         }
     }
     return TS_OK;
@@ -180,7 +195,7 @@ int mlp_backward_multi(hipStream_t s, ts_workspace* ws, const Mlp& m, int n, con
         float *dh1[MULTI_MAX], *dh2[MULTI_MAX];
         for (int k = 0; k < n; ++k) {
             w1[k] = p[k] + m.off[0]; w2[k] = p[k] + m.off[1]; w3[k] = p[k] + m.off[2];
-            h1[k] = a[k].h1; h2[k] = a[k].h2; dh1[k] = sc[k].dh1; dh2[k] = sc[k].dh2;
+            h1[k] = a[k].h[0]; h2[k] = a[k].h[1]; dh1[k] = sc[k].dh[0]; dh2[k] = sc[k].dh[1];
         }
         return ts::mlp3_backward_n(s, n, d_out, m.l[0].B, m.l[0].IC, w1, w2, w3, m.l[2].OC, h1, h2, dh1, dh2, dx, col0, col1, ws);
     }
@@ -194,9 +209,9 @@ int mlp_backward_twin(hipStream_t s, ts_workspace* ws, const Mlp& m, const float
     return mlp_backward_multi(s, ws, m, 2, p, x, a, d_out, dx, col0, col1, sc);
 }
 
-size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by side (one slab_sum_multi launch)
+size_t slab_floats(const Mlp& m) {      // the layers' slab sets side by side (one slab_sum_multi launch)
     size_t s = 0;
-    for (int i = 0; i < 3; ++i) s += (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems();
+    for (int i = 0; i < m.L; ++i) s += (size_t)ts::conv_wgrad_splits(m.l[i]) * m.l[i].param_elems();
     return s;
 }
 
@@ -207,7 +222,7 @@ size_t slab_floats(const Mlp& m) {      // the three layers' slab sets side by s
 // for the multi-network launches (dsac_one_stream below).
 int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t* out) {
     static const bool force = getenv("TS_TWIN_STREAMS") != nullptr;       // experiments
-    if (!force && ts::mlp3_supported(critic.l[0].IC, critic.l[0].OC, critic.l[2].OC)) { *out = s; return TS_OK; }
+    if (!force && critic.three() && ts::mlp3_supported(critic.l[0].IC, critic.l[0].OC, critic.l[2].OC)) { *out = s; return TS_OK; }
     return ts::side_stream(ws, s, out);
 }
 
@@ -215,7 +230,7 @@ int twin_stream(ts_workspace* ws, hipStream_t s, const Mlp& critic, hipStream_t*
 // launches on the caller's stream (TS_TWIN_STREAMS keeps the two-stream per-network chains for comparison).
 bool dsac_one_stream(const Mlp& m) {
     static const bool force = getenv("TS_TWIN_STREAMS") != nullptr;
-    return !force && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && fused_backward(m, false, 0, 0);
+    return !force && m.three() && ts::mlp3_supported(m.l[0].IC, m.l[0].OC, m.l[2].OC) && fused_backward(m, false, 0, 0);
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
@@ -635,7 +650,7 @@ struct AdamSpec { int64_t step; double lr, beta1, beta2, eps, tau; };
 int mlp_weight_grads_adam(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, const float* const* x, const Act* a,
                           const float* const* d_out, float* const* grad, const BwdScratch* sc, float* const* p, float* const* pm,
                           float* const* pv, float* const* lag, const AdamSpec& sp, const AlphaArgs* alpha) {
-    TS_REQUIRE(n >= 1 && 3 * n <= SLAB_ADAM_SEGS, TS_ERR_INVALID_ARG, "mlp_weight_grads_adam: 1 .. 2 networks");
+    TS_REQUIRE(n >= 1 && 3 * n <= SLAB_ADAM_SEGS && m.L == 3, TS_ERR_INVALID_ARG, "mlp_weight_grads_adam: 1 .. 2 three-layer networks");
     ts::ConvGeom geoms[SLAB_ADAM_SEGS];
     const float* X[SLAB_ADAM_SEGS];
     const float* dY[SLAB_ADAM_SEGS];
@@ -644,8 +659,8 @@ int mlp_weight_grads_adam(hipStream_t s, ts_workspace* ws, int n, const Mlp& m, 
     unsigned vbs = 0;
     for (int j = 0; j < SLAB_ADAM_SEGS; ++j) g.first_vb[j] = 0xffffffffu;
     for (int k = 0; k < n; ++k) {
-        const float* xin[3] = {x[k], a[k].h1, a[k].h2};
-        const float* dy[3] = {sc[k].dh1, sc[k].dh2, d_out[k]};
+        const float* xin[3] = {x[k], a[k].h[0], a[k].h[1]};
+        const float* dy[3] = {sc[k].dh[0], sc[k].dh[1], d_out[k]};
         size_t off = 0;
         for (int i = 2; i >= 0; --i) {
             const int j = 3 * k + (2 - i);
@@ -1028,42 +1043,57 @@ struct Carve {
     template <class T> T* take(size_t n) { T* r = reinterpret_cast<T*>(p); p += al(sizeof(T) * n); return r; }
 };
 
-struct Dims { int obs, act, ka, kc, hid; };
+struct Dims { int obs, act, ka, kc, hid, depth; };
 
 // hidden: width of the two hidden layers of every Net[h, h] of the SAC / TD3 / DDPG / REDQ entry points -- a property of
 // the workspace (ts_mlp_set_hidden; 0 = the examples' 256).  Any multiple of 32 up to 1024 runs: 256 on the fused
 // three-layer kernels of ts_mlp.hip, everything else on the per-layer GEMM kernels.
-int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d) {
+int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d, int64_t depth = 0) {
     TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && act_dim >= 1 && act_dim <= 32, TS_ERR_INVALID_ARG,
                "sac: obs_dim must be >= 1 and act_dim in [1, 32]");
     if (hidden == 0) hidden = HID;
     TS_REQUIRE(hidden >= 32 && hidden <= 1024 && hidden % 32 == 0, TS_ERR_INVALID_ARG,
                "sac: hidden width must be a multiple of 32 in [32, 1024], got %lld", (long long)hidden);
-    d->obs = (int)obs_dim; d->act = (int)act_dim; d->hid = (int)hidden;
+    if (depth == 0) depth = 2;
+    TS_REQUIRE(depth >= 1 && depth <= MAXD, TS_ERR_INVALID_ARG, "sac: 1 .. %d hidden layers, got %lld", MAXD, (long long)depth);
+    d->obs = (int)obs_dim; d->act = (int)act_dim; d->hid = (int)hidden; d->depth = (int)depth;
     d->ka = pad32(d->obs); d->kc = pad32(d->obs + d->act);
     return TS_OK;
 }
 
+// hidden width and depth: properties of the workspace (ts_mlp_set_hidden / ts_mlp_set_trunk)
 int make_dims(const ts_workspace* ws, int64_t obs_dim, int64_t act_dim, Dims* d) {
-    return make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d);
+    return make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d, ws ? ws->mlp_depth : 0);
 }
 
-Act take_act(Carve& c, int64_t B, int head_cols, int hid = HID) {
-    Act a;
-    a.h1 = c.take<float>(B * hid); a.h2 = c.take<float>(B * hid); a.out = c.take<float>(B * head_cols);
+Act take_act(Carve& c, int64_t B, int head_cols, int hid = HID, int depth = 2) {
+    Act a{};
+    for (int i = 0; i < depth; ++i) a.h[i] = c.take<float>(B * hid);
+    a.out = c.take<float>(B * head_cols);
     return a;
 }
+BwdScratch take_scratch(Carve& c, int64_t B, int hid, int depth, size_t slab) {
+    BwdScratch sc{};
+    for (int i = depth - 1; i >= 0; --i) sc.dh[i] = c.take<float>(B * hid);
+    sc.slabs = c.take<float>(slab);
+    return sc;
+}
+// bytes of one PAIR of hidden-width buffers' share in the workspace formulas below, which count two buffers per network and
+// pass (h1, h2 / dh1, dh2): a trunk of `depth` hidden layers needs depth of them, i.e. ceil(depth / 2) per counted pair member
+template <class D> inline size_t hbytes(int64_t B, const D& d) { return al(4 * B * d.hid) * (size_t)((d.depth + 1) / 2); }
 
 // ---- DiscreteSAC (discrete_sac.py): three MLPs obs -> hid -> hid -> n_act, Categorical policy ------------------------
-struct DDims { int obs, act, hid, ka, hw; int64_t P; };
+struct DDims { int obs, act, hid, ka, hw, depth; int64_t P; };
 
-int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d) {
+int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d, int64_t depth = 0) {
     TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && n_act >= 2 && n_act <= 64 && hidden >= 32 && hidden <= 2048 &&
                    hidden % 32 == 0, TS_ERR_INVALID_ARG,
                "dsac: obs_dim >= 1, n_act in [2, 64], hidden a multiple of 32 in [32, 2048]");
-    d->obs = (int)obs_dim; d->act = (int)n_act; d->hid = (int)hidden;
+    if (depth == 0) depth = 2;
+    TS_REQUIRE(depth >= 1 && depth <= MAXD, TS_ERR_INVALID_ARG, "dsac: 1 .. %d hidden layers, got %lld", MAXD, (long long)depth);
+    d->obs = (int)obs_dim; d->act = (int)n_act; d->hid = (int)hidden; d->depth = (int)depth;
     d->ka = pad32(d->obs); d->hw = pad32(d->act);
-    d->P = make_mlp(1, d->ka, d->hw, d->hid).off[3];
+    d->P = make_mlp(1, d->ka, d->hw, d->hid, d->depth).total();
     return TS_OK;
 }
 
@@ -1073,12 +1103,26 @@ extern "C" {
 
 int ts_sac_layout(int64_t obs_dim, int64_t act_dim, int64_t* h_out8) { return ts_sac_layout_h(obs_dim, act_dim, 0, h_out8); }
 
+int ts_mlp_layout(int64_t in_dim, int64_t hidden, int64_t depth, int64_t head_cols, int64_t* h_out) {
+    TS_REQUIRE(h_out, TS_ERR_INVALID_ARG, "ts_mlp_layout: NULL output");
+    TS_REQUIRE(in_dim >= 1 && in_dim <= 65536 + 32 && (head_cols == 32 || head_cols == 64), TS_ERR_INVALID_ARG,
+               "ts_mlp_layout: in_dim >= 1, head_cols 32 or 64");
+    if (hidden == 0) hidden = HID;
+    if (depth == 0) depth = 2;
+    TS_REQUIRE(hidden >= 32 && hidden <= 2048 && hidden % 32 == 0 && depth >= 1 && depth <= MAXD, TS_ERR_INVALID_ARG,
+               "ts_mlp_layout: hidden a multiple of 32, 1 .. %d hidden layers", MAXD);
+    const Mlp m = make_mlp(1, pad32((int)in_dim), (int)head_cols, (int)hidden, (int)depth);
+    h_out[0] = pad32((int)in_dim);
+    for (int i = 0; i <= m.L; ++i) h_out[1 + i] = m.off[i];
+    return TS_OK;
+}
+
 int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h_out8) {
     Dims d;
     if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out8, TS_ERR_INVALID_ARG, "ts_sac_layout: NULL output");
-    const Mlp a = make_mlp(1, d.ka, 64, d.hid), c = make_mlp(1, d.kc, 32, d.hid);
-    h_out8[0] = d.ka; h_out8[1] = d.kc; h_out8[2] = a.off[3]; h_out8[3] = c.off[3];
+    const Mlp a = make_mlp(1, d.ka, 64, d.hid, d.depth), c = make_mlp(1, d.kc, 32, d.hid, d.depth);
+    h_out8[0] = d.ka; h_out8[1] = d.kc; h_out8[2] = a.total(); h_out8[3] = c.total();
     h_out8[4] = a.off[1]; h_out8[5] = a.off[2]; h_out8[6] = c.off[1]; h_out8[7] = c.off[2];
     return TS_OK;
 }
@@ -1091,13 +1135,13 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * B * 3 * d.act) +
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * B * 3 * d.act) +
                                         al(4 * split_floats(ma)) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, 64, d.hid);
+    const Act aa = take_act(c, B, 64, d.hid, d.depth);
     float* keep = c.take<float>(B * 3 * d.act);
     float* split = c.take<float>(split_floats(ma));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
@@ -1120,11 +1164,11 @@ int ts_sac_policy_forward_logits(ts_workspace* ws, const float* actor, const flo
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * split_floats(ma)) + 4096)) return rc;
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * split_floats(ma)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, 64, d.hid);
+    const Act aa = take_act(c, B, 64, d.hid, d.depth);
     float* split = c.take<float>(split_floats(ma));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
@@ -1145,15 +1189,15 @@ static int sac_target_impl(ts_workspace* ws, const float* actor, const float* cr
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 2 * al(4 * B) +
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * hbytes(B, d) + 2 * al(4 * B) +
                                         2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 64, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
+    const Act aa = take_act(c, B, 64, d.hid, d.depth), a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
     float* logp = c.take<float>(B);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
@@ -1225,14 +1269,14 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
-    const int64_t pa = ma.off[3], pc = mc.off[3];
-    size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 3 * al(4 * B * 64) +
-                   2 * al(4 * B * d.hid) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
+    const int64_t pa = ma.total(), pc = mc.total();
+    size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * hbytes(B, d) + 3 * al(4 * B * 64) +
+                   2 * hbytes(B, d) + al(4 * slab) + al(4 * std::max(pa, pc)) + 6 * al(4 * B) +
                    al(4 * B * 3 * d.act) + 8192;
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    bytes += 2 * al(4 * spl) + 2 * al(4 * B * d.hid) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
+    bytes += 2 * al(4 * spl) + 2 * hbytes(B, d) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
              al(4 * 3 * ts::ceil_div(B, 256));
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -1240,7 +1284,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* x_c = c.take<float>(B * d.kc);          // [obs | buffer action]
     float* x_p = c.take<float>(B * d.kc);          // [obs | policy action]
     float* dx1 = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 64, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
+    const Act aa = take_act(c, B, 64, d.hid, d.depth), a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
     // upstream gradients of the head outputs: the loss kernels write the live columns, the zero padding of all five
     // comes from ONE memset at the start of the update
     float* zeroed = c.take<float>(B * 192);
@@ -1251,8 +1295,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* d_head = zeroed + B * 128;              // policy backward    [B, 64]
     float* dx2 = c.take<float>(B * 64 > B * d.kc ? B * 64 : B * d.kc);
     BwdScratch sc, sc2;              // one set per stream (the two critics run concurrently)
-    sc.dh2 = c.take<float>(B * d.hid); sc.dh1 = c.take<float>(B * d.hid); sc.slabs = c.take<float>(slab);
-    sc2.dh2 = c.take<float>(B * d.hid); sc2.dh1 = c.take<float>(B * d.hid); sc2.slabs = c.take<float>(slab);
+    sc = take_scratch(c, B, d.hid, d.depth, slab);
+    sc2 = take_scratch(c, B, d.hid, d.depth, slab);
     float* grad = c.take<float>(std::max(pa, pc));
     float* grad2 = c.take<float>(pc);
     float* split2 = c.take<float>(spl);
@@ -1470,7 +1514,7 @@ int ts_td3_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
     if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out4, TS_ERR_INVALID_ARG, "ts_td3_layout: NULL output");
     h_out4[0] = d.ka; h_out4[1] = d.kc;
-    h_out4[2] = make_mlp(1, d.ka, 32, d.hid).off[3]; h_out4[3] = make_mlp(1, d.kc, 32, d.hid).off[3];
+    h_out4[2] = make_mlp(1, d.ka, 32, d.hid, d.depth).total(); h_out4[3] = make_mlp(1, d.kc, 32, d.hid, d.depth).total();
     return TS_OK;
 }
 
@@ -1481,11 +1525,11 @@ int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * al(4 * B * d.hid) + al(4 * split_floats(ma)) + 4096)) return rc;
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * split_floats(ma)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, 32, d.hid);
+    const Act aa = take_act(c, B, 32, d.hid, d.depth);
     float* split = c.take<float>(split_floats(ma));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs,
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
@@ -1505,13 +1549,13 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 2 * al(4 * spl) + 4096)) return rc;
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * hbytes(B, d) + 2 * al(4 * spl) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 32, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
+    const Act aa = take_act(c, B, 32, d.hid, d.depth), a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs_next,
@@ -1559,14 +1603,14 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    const int64_t pa = ma.off[3], pc = mc.off[3];
+    const int64_t pa = ma.total(), pc = mc.total();
     const unsigned gb = (unsigned)ts::ceil_div(B, 256);
-    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * al(4 * B * d.hid) + 4 * al(4 * B * 32) + al(4 * 3 * gb) +
-                         4 * al(4 * B * d.hid) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
+    const size_t bytes = al(4 * B * d.ka) + 3 * al(4 * B * d.kc) + 9 * hbytes(B, d) + 4 * al(4 * B * 32) + al(4 * 3 * gb) +
+                         4 * hbytes(B, d) + 2 * al(4 * slab) + 2 * al(4 * std::max(pa, pc)) + 2 * al(4 * B) +
                          al(4 * B * d.act) + 2 * al(4 * spl) + 8192;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -1574,7 +1618,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* x_c = c.take<float>(B * d.kc);
     float* x_p = c.take<float>(B * d.kc);
     float* dx1 = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 32, d.hid), a1 = take_act(c, B, 32, d.hid), a2 = take_act(c, B, 32, d.hid);
+    const Act aa = take_act(c, B, 32, d.hid, d.depth), a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
     // upstream gradients of the head outputs [B, 32]: live column written by the loss kernels, zero padding from ONE
     // memset: {critic 1 loss, critic 2 loss, actor loss -> Q1, policy backward}
     float* zeroed = c.take<float>(B * 128);
@@ -1583,7 +1627,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     float* d_pol = zeroed + B * 96;
     float* loss_part = c.take<float>(3 * (size_t)gb);      // {actor, critic1, critic2} x gb partial sums
     BwdScratch scs[2];
-    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    for (int k = 0; k < 2; ++k) scs[k] = take_scratch(c, B, d.hid, d.depth, slab);
     float* gbuf[2] = {c.take<float>(std::max(pa, pc)), c.take<float>(std::max(pa, pc))};
     float* tds[2] = {c.take<float>(B), c.take<float>(B)};
     float* keep = c.take<float>(B * d.act);
@@ -1690,7 +1734,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
 // ---- DiscreteSAC ---------------------------------------------------------------------------------------------------
 int ts_dsac_layout(int64_t obs_dim, int64_t n_act, int64_t hidden, int64_t* h_out3) {
     DDims d;
-    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d, 0)) return rc;
     TS_REQUIRE(h_out3, TS_ERR_INVALID_ARG, "ts_dsac_layout: NULL output");
     h_out3[0] = d.ka; h_out3[1] = d.hw; h_out3[2] = d.P;
     return TS_OK;
@@ -1701,14 +1745,14 @@ int ts_dsac_policy_forward(ts_workspace* ws, const float* actor, const float* ob
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_dsac_policy_forward: workspace is NULL");
     TS_REQUIRE(B >= 1 && actor && obs && logits_out, TS_ERR_INVALID_ARG, "ts_dsac_policy_forward: bad argument");
     DDims d;
-    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 2 * al(4 * B * d.hid) + al(4 * B * d.hw) + al(4 * split_floats(m)) + 4096))
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 2 * hbytes(B, d) + al(4 * B * d.hw) + al(4 * split_floats(m)) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.take<float>(B * d.ka);
-    const Act a = take_act(c, B, d.hw, d.hid);
+    const Act a = take_act(c, B, d.hw, d.hid, d.depth);
     float* split = c.take<float>(split_floats(m));
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs,
                        (const float*)nullptr, B, d.obs, 0, d.ka, 0, x, (float*)nullptr, (float*)nullptr);
@@ -1726,15 +1770,15 @@ int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_
     TS_REQUIRE(B >= 1 && actor && critic1_old && critic2_old && obs_next && out, TS_ERR_INVALID_ARG,
                "ts_dsac_target_q: bad argument");
     DDims d;
-    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
     const size_t spl = split_floats(m);
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 6 * al(4 * B * d.hid) + 3 * al(4 * B * d.hw) + 2 * al(4 * spl) + 4096))
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 6 * hbytes(B, d) + 3 * al(4 * B * d.hw) + 2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, d.hw, d.hid), a1 = take_act(c, B, d.hw, d.hid), a2 = take_act(c, B, d.hw, d.hid);
+    const Act aa = take_act(c, B, d.hw, d.hid, d.depth), a1 = take_act(c, B, d.hw, d.hid, d.depth), a2 = take_act(c, B, d.hw, d.hid, d.depth);
     float* split = c.take<float>(spl);
     float* split2 = c.take<float>(spl);
     hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * d.ka / 4, 256)), dim3(256), 0, s, obs_next,
@@ -1775,21 +1819,21 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
     TS_REQUIRE(!hp->auto_alpha || (st->log_alpha && st->log_alpha_m && st->log_alpha_v), TS_ERR_INVALID_ARG,
                "ts_dsac_update: auto alpha needs log_alpha and its Adam moments");
     DDims d;
-    if (int rc = make_ddims(obs_dim, n_act, hidden, &d)) return rc;
+    if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
     const size_t slab = slab_floats(m), spl = split_floats(m);
     const int64_t P = d.P;
-    const size_t bytes = al(4 * B * d.ka) + 10 * al(4 * B * d.hid) + 6 * al(4 * B * d.hw) + 2 * al(4 * slab) +
+    const size_t bytes = al(4 * B * d.ka) + 10 * hbytes(B, d) + 6 * al(4 * B * d.hw) + 2 * al(4 * slab) +
                          2 * al(4 * P) + 2 * al(4 * spl) + 4 * al(4 * B) + al(4 * 1024) + 4096;
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x = c.take<float>(B * d.ka);
-    const Act aa = take_act(c, B, d.hw, d.hid);
-    const Act acts[2] = {take_act(c, B, d.hw, d.hid), take_act(c, B, d.hw, d.hid)};
+    const Act aa = take_act(c, B, d.hw, d.hid, d.depth);
+    const Act acts[2] = {take_act(c, B, d.hw, d.hid, d.depth), take_act(c, B, d.hw, d.hid, d.depth)};
     float* dheads[3] = {c.take<float>(B * d.hw), c.take<float>(B * d.hw), c.take<float>(B * d.hw)};   // critic1, critic2, actor
     BwdScratch scs[2];
-    for (int k = 0; k < 2; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    for (int k = 0; k < 2; ++k) scs[k] = take_scratch(c, B, d.hid, d.depth, slab);
     float* gbuf[2] = {c.take<float>(P), c.take<float>(P)};
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
     float* tds[2] = {c.take<float>(B), c.take<float>(B)};
@@ -1903,17 +1947,17 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
-    const int64_t pc = mc.off[3];
-    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * al(4 * B * d.hid) + al(4 * B * 64) +
+    const int64_t pc = mc.total();
+    if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * hbytes(B, d) + al(4 * B * 64) +
                                         al(4 * (size_t)S * B * 32) + al(4 * B) + 2 * al(4 * spl) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
     float* x_c = c.take<float>(B * d.kc);
-    Act aa; aa.h1 = c.take<float>(B * d.hid); aa.h2 = c.take<float>(B * d.hid); aa.out = c.take<float>(B * 64);
-    float* hh[2][2] = {{c.take<float>(B * d.hid), c.take<float>(B * d.hid)}, {c.take<float>(B * d.hid), c.take<float>(B * d.hid)}};
+    const Act aa = take_act(c, B, 64, d.hid, d.depth);
+    Act hh[2] = {take_act(c, B, 0, d.hid, d.depth), take_act(c, B, 0, d.hid, d.depth)};      // hidden buffers of the two streams
     float* qs = c.take<float>((size_t)S * B * 32);
     float* logp = c.take<float>(B);
     float* splits[2] = {c.take<float>(spl), c.take<float>(spl)};
@@ -1925,18 +1969,19 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
                        64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
-    if (S <= MULTI_MAX && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC)) {
+    if (S <= MULTI_MAX && mc.three() && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC)) {
         // the subset's members in one launch (no activations kept: inference)
         const float* pp[MULTI_MAX];
         Act as[MULTI_MAX];
-        for (int64_t k = 0; k < S; ++k) { pp[k] = critics_old + (int64_t)h_subset[k] * pc; as[k] = Act{nullptr, nullptr, qs + k * B * 32}; }
-        if (S == 1) { as[0].h1 = hh[0][0]; as[0].h2 = hh[0][1]; }
+        for (int64_t k = 0; k < S; ++k) { pp[k] = critics_old + (int64_t)h_subset[k] * pc; as[k] = act_of(nullptr, nullptr, qs + k * B * 32); }
+        if (S == 1) { as[0] = hh[0]; as[0].out = qs; }
         if (int rc = mlp_forward_multi(s, ws, mc, (int)S, pp, x_c, as, splits)) return rc;
     } else {
         if (int rc = ts::stream_wait(ws, s, side, 0)) return rc;
         for (int64_t k = 0; k < S; ++k) {             // the subset's members alternate between the two streams
             const int w = (int)(k & 1);
-            const Act a{hh[w][0], hh[w][1], qs + k * B * 32};
+            Act a = hh[w];
+            a.out = qs + k * B * 32;
             if (int rc = mlp_forward(st2[w], ws, mc, critics_old + (int64_t)h_subset[k] * pc, x_c, a, splits[w])) return rc;
         }
         if (int rc = ts::stream_wait(ws, side, s, 1)) return rc;
@@ -1962,15 +2007,15 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid), mc = make_mlp((int)B, d.kc, 32, d.hid);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc)), spl = std::max(split_floats(ma), split_floats(mc));
-    const int64_t pa = ma.off[3], pc = mc.off[3];
+    const int64_t pa = ma.total(), pc = mc.total();
     // the critics' chains run CH members per launch on the fused path (ts_mlp.hip): CH scratch sets instead of two
     const bool batched = fused_backward(mc, false, 0, 0) && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC);
     static const int ch_env = getenv("TS_REDQ_CHUNK") ? atoi(getenv("TS_REDQ_CHUNK")) : 0;      // experiments
     const int ch_want = ch_env >= 1 && ch_env <= WGRADS_MAX_NETS ? ch_env : WGRADS_MAX_NETS;
     const int CH = batched ? (int)std::min<int64_t>(ch_want, E) : 2;
-    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 2 + 2 * CH) * al(4 * B * d.hid) +
+    const size_t bytes = al(4 * B * d.ka) + 5 * al(4 * B * d.kc) + (size_t)(2 * E + 2 + 2 * CH) * hbytes(B, d) +
                          (size_t)E * al(4 * B * 32) + 4 * al(4 * B * 64) + (size_t)CH * al(4 * slab) + al(4 * (size_t)E * pc) +
                          al(4 * pa) + 2 * al(4 * spl) + al(4 * (size_t)E * B) + 2 * al(4 * B) + al(4 * B * 3 * d.act) +
                          al(4 * (size_t)CH * B * 32) + al(256) + al(4 * 1024) + 8192;
@@ -1983,13 +2028,13 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     float* dx_sum = c.take<float>(B * d.kc);
     float* zeros = c.take<float>(B * d.kc);
     Act acts[64];
-    for (int e = 0; e < E; ++e) { acts[e].h1 = c.take<float>(B * d.hid); acts[e].h2 = c.take<float>(B * d.hid); acts[e].out = c.take<float>(B * 32); }
-    Act aa; aa.h1 = c.take<float>(B * d.hid); aa.h2 = c.take<float>(B * d.hid); aa.out = c.take<float>(B * 64);
+    for (int e = 0; e < E; ++e) acts[e] = take_act(c, B, 32, d.hid, d.depth);
+    const Act aa = take_act(c, B, 64, d.hid, d.depth);
     float* d_head = c.take<float>(B * 64);
     float* dheads[2] = {c.take<float>(B * 64), c.take<float>(B * 64)};
     float* d_q = dheads[0];                          // actor phase: the critic-phase gradients are consumed by then
     BwdScratch scs[WGRADS_MAX_NETS];
-    for (int k = 0; k < CH; ++k) { scs[k].dh2 = c.take<float>(B * d.hid); scs[k].dh1 = c.take<float>(B * d.hid); scs[k].slabs = c.take<float>(slab); }
+    for (int k = 0; k < CH; ++k) scs[k] = take_scratch(c, B, d.hid, d.depth, slab);
     float* dheads_ch = c.take<float>((size_t)CH * B * 32);          // batched path: one head gradient per member of a chunk
     float* gcrit = c.take<float>((size_t)E * pc);
     float* gact = c.take<float>(pa);

@@ -116,7 +116,7 @@ class _HipGlue:
     @_hip_engine.setter
     def _hip_engine(self, value) -> None:
         self.__dict__["_hip_engine_obj"] = value
-        self.__dict__["_hip_pdicts"] = None
+        self.__dict__["_hip_pdicts"] = self.__dict__["_hip_modules"] = None
         self.__dict__["_hip_versions"] = None if value is None else self._hip_current_versions()
 
     # -- write-back of what the engine learnt (off-policy subclasses) ---------------------------------------------------
@@ -177,12 +177,17 @@ class _HipGlue:
             batch.weight = w / np.max(w) if getattr(buffer, "_weight_norm", True) else w
         batch = self._preprocess_batch(batch, buffer, indices)
         # torch_train_mode (torch_utils.py:14-22) is `train(True)` ... `train(was_training)` around the update; the engine reads
-        # no module flag, so only the second call is observable (each walks ~60 modules: 0.24 ms)
+        # no module flag, so only the second call is observable: every sub-module ends in the algorithm's mode.  `train()` walks
+        # ~60 modules through `Module.__setattr__` (0.24 ms); reading their flags costs 5 us and is almost always enough
         was_training = self.training
         try:
             stat = self._update_with_batch(batch)
         finally:
-            self.train(was_training)
+            mods = self.__dict__.get("_hip_modules")
+            if mods is None:
+                mods = self.__dict__["_hip_modules"] = list(self.modules())
+            if any(m.training != was_training for m in mods):
+                self.train(was_training)
         self._postprocess_batch(batch, buffer, indices)
         for lr_scheduler in self.lr_schedulers:
             lr_scheduler.step()
@@ -236,7 +241,7 @@ class _HipGlue:
         """`Algorithm.load_state_dict` replaced parameters AND optimizer state: drop the engine without flushing."""
         self.__dict__["_hip_engine_obj"] = None
         self.__dict__["_hip_versions"] = None
-        self.__dict__["_hip_pdicts"] = None
+        self.__dict__["_hip_pdicts"] = self.__dict__["_hip_modules"] = None
         self.__dict__["_hip_stale"] = False
         self._hip_adam_dirty = False
 
