@@ -1474,6 +1474,9 @@ def main() -> None:
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_discrete":
         gen_ppo_discrete_all()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "depth":
+        gen_depth()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "widths":
         gen_widths()
         return
@@ -1549,12 +1552,13 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    hw = OS.hidden_widths(hidden)
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2]))
+    sa_, sc_ = OS.layer_sizes(hidden)              # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
+    AK, CK = OS.trunk_keys(len(sa_), ("mu", "sigma")), OS.trunk_keys(len(sc_), ("last",))
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(sa_))
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                          conditioned_sigma=True)
-    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)
-    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)
+    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
+    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
     critic1, critic2 = ContinuousCritic(preprocess_net=net_c1), ContinuousCritic(preprocess_net=net_c2)
     space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
     policy = SACPolicy(actor=actor, action_space=space)
@@ -1565,11 +1569,14 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
                     n_step_return_horizon=n_step)
     out: dict[str, np.ndarray] = {}
     out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step])
-    out["hidden"] = np.array(hw, np.int64)
-    p0 = OS.init_sac_params(obs_dim, act_dim, seed, hw)
-    for pd, order, mod, keys in ((p0[0], OS.ACTOR_ORDER, actor, OS.TIANSHOU_ACTOR_KEYS),
-                                 (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS),
-                                 (p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS)):
+    if len(sa_) == 2 and len(sc_) == 2:
+        out["hidden"] = np.array(sa_ + sc_, np.int64)
+    else:
+        out["hidden_actor"], out["hidden_critic"] = np.array(sa_, np.int64), np.array(sc_, np.int64)
+    p0 = OS.init_sac_params(obs_dim, act_dim, seed, (sa_, sc_))
+    for pd, order, mod, keys in ((p0[0], OS.actor_order(len(sa_)), actor, AK),
+                                 (p0[1], OS.critic_order(len(sc_)), critic1, CK),
+                                 (p0[2], OS.critic_order(len(sc_)), critic2, CK)):
         sd = mod.state_dict()
         assert list(sd.keys()) == keys, list(sd.keys())
         for k_ref, k in zip(keys, order):       # the fixture stores the seed only: the oracle re-creates the init
@@ -1622,11 +1629,9 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
             out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic1_loss, stats.critic2_loss,
                                            stats.alpha if stats.alpha is not None else np.nan,
                                            stats.alpha_loss if stats.alpha_loss is not None else np.nan])
-            for name, mod, keys in (("actor", actor, OS.TIANSHOU_ACTOR_KEYS),
-                                    ("critic1", critic1, OS.TIANSHOU_CRITIC_KEYS),
-                                    ("critic2", critic2, OS.TIANSHOU_CRITIC_KEYS),
-                                    ("critic1_old", algorithm.critic_old.module, OS.TIANSHOU_CRITIC_KEYS),
-                                    ("critic2_old", algorithm.critic2_old.module, OS.TIANSHOU_CRITIC_KEYS)):
+            for name, mod, keys in (("actor", actor, AK), ("critic1", critic1, CK), ("critic2", critic2, CK),
+                                    ("critic1_old", algorithm.critic_old.module, CK),
+                                    ("critic2_old", algorithm.critic2_old.module, CK)):
                 sd = mod.state_dict()
                 out[f"u{u}_{name}"] = torch.cat([sd[k].reshape(-1) for k in keys]).numpy()[::61].copy()
     finally:
@@ -1652,19 +1657,21 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    hw = OS.hidden_widths(hidden)
-    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2])),
+    sa_, sc_ = OS.layer_sizes(hidden)              # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
+    AK, CK = OS.trunk_keys(len(sa_), ("last",)), OS.trunk_keys(len(sc_), ("last",))
+    AO, CO = OS.det_actor_order(len(sa_)), OS.critic_order(len(sc_))
+    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sa_)),
                                          action_shape=(act_dim,), max_action=max_action)
-    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True)  # noqa: E731
+    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)  # noqa: E731
     if twin:
         n1, n2 = mk_net(), mk_net()
         critic1, critic2 = ContinuousCritic(preprocess_net=n1), ContinuousCritic(preprocess_net=n2)
     else:
         critic1, critic2 = ContinuousCritic(preprocess_net=mk_net()), None
-    p0 = OS.init_td3_params(obs_dim, act_dim, seed, twin, hw)
-    checks = [(p0[0], OS.DET_ACTOR_ORDER, actor, OS.TIANSHOU_DET_ACTOR_KEYS), (p0[1], OS.CRITIC_ORDER, critic1, OS.TIANSHOU_CRITIC_KEYS)]
+    p0 = OS.init_td3_params(obs_dim, act_dim, seed, twin, (sa_, sc_))
+    checks = [(p0[0], AO, actor, AK), (p0[1], CO, critic1, CK)]
     if twin:
-        checks.append((p0[2], OS.CRITIC_ORDER, critic2, OS.TIANSHOU_CRITIC_KEYS))
+        checks.append((p0[2], CO, critic2, CK))
     for pd, order, mod, keys in checks:
         sd = mod.state_dict()
         assert list(sd.keys()) == keys, list(sd.keys())
@@ -1690,7 +1697,8 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
     for t in range(steps):
         buf.add(Batch(obs=obs[t], act=act[t], rew=rew[t], terminated=term[t], truncated=trunc[t], obs_next=obs[t + 1]))
     out: dict[str, np.ndarray] = {"dims": np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(twin), n_step]),
-                                  "hidden": np.array(hw, np.int64)}
+                                  **({"hidden": np.array(sa_ + sc_, np.int64)} if len(sa_) == 2 and len(sc_) == 2 else
+                                     {"hidden_actor": np.array(sa_, np.int64), "hidden_critic": np.array(sc_, np.int64)})}
     for k2 in ("obs", "obs_next", "act"):
         out[k2] = np.asarray(getattr(buf, k2), np.float32)
     out["rew"], out["terminated"], out["truncated"] = np.asarray(buf.rew, np.float64), np.asarray(buf.terminated, bool), np.asarray(buf.truncated, bool)
@@ -1723,12 +1731,10 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
             out[f"u{u}_indices"], out[f"u{u}_returns"] = rec[-1]["indices"], rec[-1]["returns"]
             out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic1_loss, stats.critic2_loss] if twin
                                           else [stats.actor_loss, stats.critic_loss])
-            mods = [("actor", actor, OS.TIANSHOU_DET_ACTOR_KEYS), ("critic1", critic1, OS.TIANSHOU_CRITIC_KEYS),
-                    ("actor_old", algorithm.actor_old.module, OS.TIANSHOU_DET_ACTOR_KEYS),
-                    ("critic1_old", algorithm.critic_old.module, OS.TIANSHOU_CRITIC_KEYS)]
+            mods = [("actor", actor, AK), ("critic1", critic1, CK), ("actor_old", algorithm.actor_old.module, AK),
+                    ("critic1_old", algorithm.critic_old.module, CK)]
             if twin:
-                mods += [("critic2", critic2, OS.TIANSHOU_CRITIC_KEYS),
-                         ("critic2_old", algorithm.critic2_old.module, OS.TIANSHOU_CRITIC_KEYS)]
+                mods += [("critic2", critic2, CK), ("critic2_old", algorithm.critic2_old.module, CK)]
             for name, mod, keys in mods:
                 sd = mod.state_dict()
                 out[f"u{u}_{name}"] = torch.cat([sd[k2].reshape(-1) for k2 in keys]).numpy()[::61].copy()
@@ -1987,6 +1993,21 @@ def gen_widths() -> None:
     gen_npg("trpo_widths", algo="trpo", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=27, optim_critic_iters=2,
             max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10, advantage_normalization=True, gae_lambda=0.95, gamma=0.99,
             return_scaling=False, max_batchsize=256, hidden_a=(100, 60), hidden_c=(60, 100))
+
+
+def gen_depth() -> None:
+    """Round 6: trunks of other depths than two hidden layers (Net(hidden_sizes=[...]) takes any list; the engines run them layer
+    by layer on the GEMM kernels, `ts_mlp_set_trunk`): SAC with a three-layer actor [64, 48, 32] and three-layer critics
+    [40, 56, 24] (unequal widths, none but one a multiple of 32: embedded by zero padding) and SAC with ONE hidden layer [96];
+    TD3 with four layers; DDPG with one."""
+    gen_sac("depth3", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=31, auto_alpha=True,
+            hidden=((64, 48, 32), (40, 56, 24)))
+    gen_sac("depth1", E=3, slots=30, steps=30, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=32, auto_alpha=False, alpha=0.15,
+            n_step=2, hidden=((96,), (96,)))
+    gen_td3("depth4", twin=True, E=4, slots=32, steps=30, obs_dim=17, act_dim=6, batch=64, n_updates=4, seed=33,
+            hidden=((64, 64, 32, 32), (48, 64, 64, 40)), max_action=1.5)
+    gen_td3("ddpg_depth1", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=34,
+            hidden=((128,), (64,)))
 
 
 def gen_sac_all() -> None:

@@ -59,6 +59,79 @@ def init_params(shapes: dict, seed: int) -> dict[str, torch.Tensor]:
     return p
 
 
+def trunk_order(depth: int, heads: tuple[str, ...]) -> list[str]:
+    """Parameter names of an MLP trunk of `depth` hidden layers + single-Linear heads: w1, b1, ..., wd, bd, then w<head>, b<head>."""
+    ks = []
+    for i in range(1, depth + 1):
+        ks += [f"w{i}", f"b{i}"]
+    for h in heads:
+        ks += [f"w{h}", f"b{h}"]
+    return ks
+
+
+def trunk_keys(depth: int, heads: tuple[str, ...]) -> list[str]:
+    """The reference's state_dict keys of the same network: Net's Sequential holds its Linears at even positions
+    (utils/net/common.py:90-178), heads are one-Linear MLPs."""
+    ks = []
+    for i in range(depth):
+        ks += [f"preprocess.model.model.{2 * i}.weight", f"preprocess.model.model.{2 * i}.bias"]
+    for h in heads:
+        ks += [f"{h}.model.0.weight", f"{h}.model.0.bias"]
+    return ks
+
+
+def actor_order(depth: int = 2) -> list[str]:
+    return trunk_order(depth, ("mu", "sig"))
+
+
+def critic_order(depth: int = 2) -> list[str]:
+    return trunk_order(depth, ("q",))
+
+
+def det_actor_order(depth: int = 2) -> list[str]:
+    return trunk_order(depth, ("a",))
+
+
+def depth_of(p: dict) -> int:
+    """Number of hidden layers of a parameter dict (w1 .. wd)."""
+    d = 0
+    while f"w{d + 1}" in p:
+        d += 1
+    return d
+
+
+def order_of(p: dict) -> list[str]:
+    """The dict's own parameter order (dicts are built in order: trunk, then heads)."""
+    return list(p.keys())
+
+
+def trunk_forward(p, x):
+    """Net / MLP with the default activation: ReLU after every hidden Linear (utils/net/common.py:90-178)."""
+    for i in range(1, depth_of(p) + 1):
+        x = F.relu(F.linear(x, p[f"w{i}"], p[f"b{i}"]))
+    return x
+
+
+def layer_sizes(hidden) -> tuple[list[int], list[int]]:
+    """(actor hidden sizes, critic hidden sizes) from an int (Net[h, h] everywhere), a flat pair (actor = critics), four
+    widths (actor h1, h2, critic h1, h2) or a nested pair (actor sizes, critic sizes) of any depth >= 1."""
+    if isinstance(hidden, (int, np.integer)):
+        return [int(hidden)] * 2, [int(hidden)] * 2
+    h = tuple(hidden)
+    if len(h) == 2 and not isinstance(h[0], (int, np.integer)):
+        return [int(x) for x in h[0]], [int(x) for x in h[1]]
+    h = tuple(int(x) for x in h)
+    return (list(h), list(h)) if len(h) == 2 else (list(h[:2]), list(h[2:]))
+
+
+def _linears(sizes_in: int, sizes: list[int]):
+    L, out, k = torch.nn.Linear, [], sizes_in
+    for h in sizes:
+        out.append(L(k, h))
+        k = h
+    return out
+
+
 def hidden_widths(hidden) -> tuple[int, int, int, int]:
     """(actor h1, actor h2, critic h1, critic h2) from an int (all equal), a pair (actor = critics) or four widths:
     Net(hidden_sizes=[h1, h2]) of the reference takes any widths (utils/net/common.py:246-369)."""
@@ -71,18 +144,19 @@ def hidden_widths(hidden) -> tuple[int, int, int, int]:
 def init_sac_params(obs_dim: int, act_dim: int, seed: int, hidden=256):
     """Same RNG consumption as examples/mujoco/mujoco_sac.py:82-104 after torch.manual_seed(seed):
     Net(actor), actor mu / sigma heads, Net(critic1), Net(critic2), critic1.last, critic2.last
-    -> (actor, critic1, critic2) parameter dicts."""
+    -> (actor, critic1, critic2) parameter dicts.  `hidden`: see `layer_sizes` (any depth since round 6)."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
-    a1, a2, c1_, c2_ = hidden_widths(hidden)
-    mods = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim), L(a2, act_dim),
-            L(obs_dim + act_dim, c1_), L(c1_, c2_), L(obs_dim + act_dim, c1_), L(c1_, c2_),
-            L(c2_, 1), L(c2_, 1)]
+    sa, sc = layer_sizes(hidden)
+    na = _linears(obs_dim, sa)
+    mu, sig = L(sa[-1], act_dim), L(sa[-1], act_dim)
+    n1, n2 = _linears(obs_dim + act_dim, sc), _linears(obs_dim + act_dim, sc)
+    q1, q2 = L(sc[-1], 1), L(sc[-1], 1)
     wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
     flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
-    actor = dict(zip(ACTOR_ORDER, flat(mods[0:4])))
-    critic1 = dict(zip(CRITIC_ORDER, flat([mods[4], mods[5], mods[8]])))
-    critic2 = dict(zip(CRITIC_ORDER, flat([mods[6], mods[7], mods[9]])))
+    actor = dict(zip(actor_order(len(sa)), flat(na + [mu, sig])))
+    critic1 = dict(zip(critic_order(len(sc)), flat(n1 + [q1])))
+    critic2 = dict(zip(critic_order(len(sc)), flat(n2 + [q2])))
     return actor, critic1, critic2
 
 
@@ -91,8 +165,7 @@ def flatten(p: dict, order: list[str]) -> torch.Tensor:
 
 
 def actor_forward(p, obs):
-    h = F.relu(F.linear(obs, p["w1"], p["b1"]))
-    h = F.relu(F.linear(h, p["w2"], p["b2"]))
+    h = trunk_forward(p, obs)
     mu = F.linear(h, p["wmu"], p["bmu"])
     sigma = torch.clamp(F.linear(h, p["wsig"], p["bsig"]), min=SIGMA_MIN, max=SIGMA_MAX).exp()
     return mu, sigma
@@ -100,9 +173,7 @@ def actor_forward(p, obs):
 
 def critic_forward(p, obs, act):
     x = torch.cat([obs.flatten(1), act.flatten(1)], dim=1)
-    h = F.relu(F.linear(x, p["w1"], p["b1"]))
-    h = F.relu(F.linear(h, p["w2"], p["b2"]))
-    return F.linear(h, p["wq"], p["bq"])
+    return F.linear(trunk_forward(p, x), p["wq"], p["bq"])
 
 
 def policy_forward(p, obs, noise):
@@ -279,28 +350,23 @@ TIANSHOU_DET_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.
 
 def init_td3_params(obs_dim: int, act_dim: int, seed: int, twin: bool = True, hidden=256):
     """RNG consumption of examples/mujoco/mujoco_td3.py:85-103 (mujoco_ddpg.py without the second critic):
-    Net(actor), actor.last, Net(critic1)[, Net(critic2)], critic1.last[, critic2.last]."""
+    Net(actor), actor.last, Net(critic1)[, Net(critic2)], critic1.last[, critic2.last].  `hidden`: see `layer_sizes`."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
     wb = lambda m: (m.weight.detach().clone(), m.bias.detach().clone())  # noqa: E731
     flat = lambda ms: [t for m in ms for t in wb(m)]                      # noqa: E731
-    a1, a2, h1, h2 = hidden_widths(hidden)
-    a = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim)]
-    if twin:
-        c = [L(obs_dim + act_dim, h1), L(h1, h2), L(obs_dim + act_dim, h1), L(h1, h2),
-             L(h2, 1), L(h2, 1)]
-        c1, c2 = [c[0], c[1], c[4]], [c[2], c[3], c[5]]
-    else:
-        c = [L(obs_dim + act_dim, h1), L(h1, h2), L(h2, 1)]
-        c1, c2 = c, None
-    return (dict(zip(DET_ACTOR_ORDER, flat(a))), dict(zip(CRITIC_ORDER, flat(c1))),
-            dict(zip(CRITIC_ORDER, flat(c2))) if twin else None)
+    sa, sc = layer_sizes(hidden)
+    a = _linears(obs_dim, sa) + [L(sa[-1], act_dim)]
+    n1 = _linears(obs_dim + act_dim, sc)
+    n2 = _linears(obs_dim + act_dim, sc) if twin else None
+    q1 = L(sc[-1], 1)
+    q2 = L(sc[-1], 1) if twin else None
+    return (dict(zip(det_actor_order(len(sa)), flat(a))), dict(zip(critic_order(len(sc)), flat(n1 + [q1]))),
+            dict(zip(critic_order(len(sc)), flat(n2 + [q2]))) if twin else None)
 
 
 def det_actor_forward(p, obs, max_action: float = 1.0):
-    h = F.relu(F.linear(obs, p["w1"], p["b1"]))
-    h = F.relu(F.linear(h, p["w2"], p["b2"]))
-    return max_action * torch.tanh(F.linear(h, p["wa"], p["ba"]))
+    return max_action * torch.tanh(F.linear(trunk_forward(p, obs), p["wa"], p["ba"]))
 
 
 @dataclass

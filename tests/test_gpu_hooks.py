@@ -1521,7 +1521,7 @@ def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
         assert W.padding_is_zero(NG.critic_flat_to_torch(vec, obs_dim, eng.hidden), *hc)
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
 def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the SAC family: the HOOK path -- device mirror of a host buffer, `_preprocess_batch` (n-step
     target with the lagged critics; n = 1 and 3), `_update_with_batch` (twin critics, actor, alpha, Polyak), write-back -- on the
@@ -1535,17 +1535,20 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
 
     g, d, cfg, _ = load_sac(tag)
     obs_dim, act_dim, E, B = d["obs_dim"], d["act_dim"], d["E"], d["batch"]
-    hw = OS.hidden_widths(d["hidden"])          # `widths`: actor Net[48, 80], critics Net[72, 40] -- run embedded in Net[96, 96]
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(hw[:2]), nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
-    p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"], hw)              # == the reference's initial weights (asserted by gen_sac)
-    for mod, pd, order in ((actor, p0[0], OS.ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER), (c2, p0[2], OS.CRITIC_ORDER)):
-        mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
+    # `widths`: actor Net[48, 80], critics Net[72, 40] -- run embedded in Net[96, 96]; `depth3`: actor [64, 48, 32], critics
+    # [40, 56, 24]; `depth1`: one hidden layer [96] (round 6: any depth, layer by layer on the GEMM kernels)
+    sa, sc = OS.layer_sizes(d["hidden"])
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
+    p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"], (sa, sc))        # == the reference's initial weights (asserted by gen_sac)
+    for mod, pd in ((actor, p0[0]), (c1, p0[1]), (c2, p0[2])):            # (both in layer order: trunk, then heads)
+        mod.load_state_dict(dict(zip(mod.state_dict(), pd.values())))
     alpha = SI.AutoAlpha(cfg.target_entropy, cfg.log_alpha0, cfg.alpha_lr) if cfg.auto_alpha else SI.FixedAlpha(cfg.alpha)
     algo = make_hip_sac(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
                                 gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda",
                                 update_noise="torch").to("cuda")         # (index-only sampling + lazy write-back: the defaults)
+    assert algo._hip_depth == len(sa) and algo._hip_sizes["actor"] == tuple(sa)
     buf = SI.VectorReplayBuffer(E * d["slots"], E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     lengths = g["buf_lengths"]
     for t in range(int(lengths.max())):                                   # slot e * slots + t of the fixture's buffer = env e, step t
@@ -1649,7 +1652,7 @@ def test_hip_dqn_hooks_replay_the_reference():
 
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
 def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the deterministic-actor family: HipTD3 / HipDDPG hook paths on the real engine against what the
     unmodified REFERENCE's TD3.update() / DDPG.update() produced (tests/golden/td3_{twin,ddpg}.npz,
@@ -1663,13 +1666,15 @@ def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     g, d, cfg, _ = load_td3(tag)
     obs_dim, act_dim, B, twin = d["obs_dim"], d["act_dim"], d["batch"], d["twin"]
     E, slots = int(g["dims"][0]), int(g["dims"][1])
-    hw = OS.hidden_widths(d["hidden"])          # `widths`: Net[400, 300] (embedded in 416); `ddpg_widths`: actor [24, 56], critic [40, 24]
-    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, list(hw[:2]), nn.ReLU), act_dim, max_action=cfg.max_action)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(hw[2:]), nn.ReLU)) if twin else None
-    p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin, hw)        # == the reference's initial weights (asserted by gen_td3)
-    for mod, pd, order in ((actor, p0[0], OS.DET_ACTOR_ORDER), (c1, p0[1], OS.CRITIC_ORDER)) + (((c2, p0[2], OS.CRITIC_ORDER),) if twin else ()):
-        mod.load_state_dict({name: pd[k] for name, k in zip(mod.state_dict(), order)})
+    # `widths`: Net[400, 300] (embedded in 416); `ddpg_widths`: actor [24, 56], critic [40, 24]; `depth4`: four hidden layers, actor
+    # [64, 64, 32, 32], critics [48, 64, 64, 40]; `ddpg_depth1`: one hidden layer, actor [128], critic [64] (round 6)
+    sa, sc = OS.layer_sizes(d["hidden"])
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, max_action=cfg.max_action)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU)) if twin else None
+    p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin, (sa, sc))  # == the reference's initial weights (asserted by gen_td3)
+    for mod, pd in ((actor, p0[0]), (c1, p0[1])) + (((c2, p0[2]),) if twin else ()):
+        mod.load_state_dict(dict(zip(mod.state_dict(), pd.values())))
     if twin:
         algo = make_hip_td3(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
                                     gamma=cfg.gamma, policy_noise=cfg.policy_noise, update_actor_freq=cfg.update_actor_freq,

@@ -23,15 +23,16 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
     from tianshou_amd import widths as W
 
     actor, c1, c2 = OS.init_sac_params(obs_dim, act_dim, seed, hidden)
-    lists = [[actor[k] for k in OS.ACTOR_ORDER], [c1[k] for k in OS.CRITIC_ORDER], [c2[k] for k in OS.CRITIC_ORDER]]
-    H = W.common_hidden(*lists)
+    lists = [list(actor.values()), list(c1.values()), list(c2.values())]            # (dicts are in layer order)
+    H = W.engine_hidden([W.layer_widths(t, 2 if i == 0 else 1) for i, t in enumerate(lists)])
     eng = S.SACEngine(
         obs_dim, act_dim,
         S.actor_flat_from_torch(lists[0], obs_dim, act_dim, hidden=H),
         S.critic_flat_from_torch(lists[1], obs_dim, act_dim, hidden=H),
         S.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H),
         S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
-                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=H)
+                                                     "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=H,
+        depth=OS.depth_of(actor))
     return eng, (actor, c1, c2)
 
 
@@ -110,18 +111,21 @@ def test_update_gradients_vs_oracle(obs_dim, act_dim, B, auto, weighted):
     assert torch.count_nonzero(l1[obs_dim + act_dim:lay["kc"]]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
 def test_sac_update_matches_reference_golden(tag):
     """(`widths`: actor Net[48, 80], critics Net[72, 40] in the reference; the engine runs them embedded in Net[96, 96] and every
-    padding entry of parameters, lagged parameters and Adam moments stays exactly zero.)"""
+    padding entry of parameters, lagged parameters and Adam moments stays exactly zero.  `depth3`: THREE hidden layers, actor
+    [64, 48, 32] and critics [40, 56, 24] in Net[64] * 3; `depth1`: ONE hidden layer [96], fixed alpha, 2-step returns --
+    fixtures the unmodified reference wrote, gen_golden.py::gen_depth; the engine runs them layer by layer, ts_mlp_set_trunk.)"""
     from tianshou_amd import sac as S
     from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_sac(tag)
     eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
-    hw = OS.hidden_widths(d["hidden"])
-    sizes = {"actor": hw[:2], "critic1": hw[2:], "critic2": hw[2:], "critic1_old": hw[2:], "critic2_old": hw[2:]}
+    sa, sc = OS.layer_sizes(d["hidden"])
+    assert eng.depth == len(sa) == len(sc)
+    sizes = {"actor": sa, "critic1": sc, "critic2": sc, "critic1_old": sc, "critic2_old": sc}
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
                              truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
@@ -138,12 +142,13 @@ def test_sac_update_matches_reference_golden(tag):
         for name, to_torch in (("actor", S.actor_flat_to_torch), ("critic1", S.critic_flat_to_torch),
                                ("critic2", S.critic_flat_to_torch), ("critic1_old", S.critic_flat_to_torch),
                                ("critic2_old", S.critic_flat_to_torch)):
-            full = to_torch(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden)
-            assert W.padding_is_zero(full, *sizes[name]), name
+            full = to_torch(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden, depth=eng.depth)
+            assert W.padding_is_zero_layers(full, sizes[name]), name
             for sfx in ("_m", "_v"):
                 if hasattr(eng, name + sfx):
-                    assert W.padding_is_zero(to_torch(getattr(eng, name + sfx), d["obs_dim"], d["act_dim"], eng.hidden), *sizes[name])
-            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sizes[name])])
+                    assert W.padding_is_zero_layers(to_torch(getattr(eng, name + sfx), d["obs_dim"], d["act_dim"], eng.hidden,
+                                                             depth=eng.depth), sizes[name])
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_layers(full, sizes[name])])
             lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
             # Adam's first steps move every weight by ~lr whatever its gradient: compare on lr's scale
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
@@ -207,6 +212,77 @@ def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B):
     assert make_engine(5, 2, 0, cfg, hidden=100)[0].hidden == 128       # no multiple of 32: embedded by zero padding (round 6)
     with pytest.raises(NotImplementedError):
         make_engine(5, 2, 0, cfg, hidden=1100)                # beyond the kernels' 1024
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,B", [(((256, 256, 256), (256, 256, 256)), 376, 17, 512), (((64,), (96,)), 23, 5, 200),
+                                                      (((40, 72, 56, 24, 88), (32, 32, 64, 64, 32)), 11, 3, 65),
+                                                      (((128,) * 6, (128,) * 6), 17, 6, 96)])
+def test_other_depths_vs_oracle(hidden, obs_dim, act_dim, B):
+    """Net(hidden_sizes=[...]) of 1, 3, 5 and 6 hidden layers (utils/net/common.py:246-369 takes any list; round 6): the update
+    runs layer by layer on the GEMM kernels (ts_mlp_set_trunk).  Gradients of the first update against the float64 yardstick
+    as in test_update_gradients_vs_oracle, two more updates against the oracle, the policy / target entry points, and a
+    two-layer engine on the same workspace in between (the depth travels with each call)."""
+    from tianshou_amd import sac as S
+    from tianshou_amd import widths as W
+
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 9, cfg, hidden)
+    other, _ = make_engine(7, 2, 1, cfg)                      # Net[256, 256], same default workspace
+    sa, sc = OS.layer_sizes(hidden)
+    assert eng.depth == len(sa)
+    for t, k in zip(S.actor_flat_to_torch(eng.actor, obs_dim, act_dim, eng.hidden, sizes=sa), actor):
+        assert torch.equal(t.cpu(), actor[k]), k
+    for t, k in zip(S.critic_flat_to_torch(eng.critic2, obs_dim, act_dim, eng.hidden, sizes=sc), c2):
+        assert torch.equal(t.cpu(), c2[k]), k
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    g = torch.Generator().manual_seed(B)
+    for u in range(3):
+        obs = torch.randn(B, obs_dim, generator=g)
+        act = torch.rand(B, act_dim, generator=g) * 2 - 1
+        ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+        weight = torch.rand(B, generator=g) + 0.5 if u == 1 else None
+        other.update_with_batch(torch.randn(8, 7), torch.rand(8, 2), torch.randn(8), torch.randn(8, 2))
+        pc = eng.critic1.numel()
+        grads = torch.empty(2 * pc + eng.actor.numel(), dtype=torch.float32, device="cuda") if u == 0 else None
+        col = {}
+        before = (dict(st.actor), dict(st.critic1), dict(st.critic2), OS.alpha_value(st, cfg))
+        ref = OS.update_with_batch(st, cfg, obs, act, ret, noise, weight, collect=col)
+        stats, w = eng.update_with_batch(obs, act, ret, noise, weight, grads_out=grads)
+        s = stats.cpu().numpy()
+        np.testing.assert_allclose(s[:3], [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(s[3], ref["alpha"], rtol=1e-5)
+        # TD errors: float32-exact on the first update (measured 1e-7 .. 4e-7); afterwards the two implementations' parameters
+        # differ where Adam's sign-like first steps (lr * g / (|g| + eps)) amplify the rounding noise of near-zero gradients --
+        # the reason the fixture replays compare parameters at 0.02 * lr -- and the TD errors follow (3e-5 after two updates)
+        np.testing.assert_allclose(w.cpu().numpy(), ref["weight"].numpy(), rtol=1e-5, atol=1e-5 if u == 0 else 2e-4)
+        if u == 0:
+            # (the actor's gradient is taken against the UPDATED critics: evaluate the float64 yardstick with them)
+            g64c = OS.gradients(before[0], before[1], before[2], before[3], obs, act, ret, noise, weight, dtype=torch.float64)
+            g64a = OS.gradients(before[0], st.critic1, st.critic2, before[3], obs, act, ret, noise, weight, dtype=torch.float64)
+            got = {"critic1": S.critic_flat_to_torch(grads[:pc], obs_dim, act_dim, eng.hidden, sizes=sc),
+                   "critic2": S.critic_flat_to_torch(grads[pc:2 * pc], obs_dim, act_dim, eng.hidden, sizes=sc),
+                   "actor": S.actor_flat_to_torch(grads[2 * pc:], obs_dim, act_dim, eng.hidden, sizes=sa)}
+            for name in ("critic1", "critic2", "actor"):
+                exact_all = (g64a if name == "actor" else g64c)[name + "_grads"]
+                for t, key in zip(got[name], exact_all):
+                    e_gpu, e_ref = rel_err(t.cpu(), exact_all[key]), rel_err(col[name + "_grads"][key], exact_all[key])
+                    assert e_gpu < max(1e-5, 2 * e_ref), (name, key, e_gpu, e_ref)
+            # padding entries of the embedded network receive exactly zero gradient
+            assert W.padding_is_zero_layers(S.actor_flat_to_torch(grads[2 * pc:], obs_dim, act_dim, eng.hidden, depth=eng.depth), sa)
+            assert W.padding_is_zero_layers(S.critic_flat_to_torch(grads[:pc], obs_dim, act_dim, eng.hidden, depth=eng.depth), sc)
+    a_act, a_logp = eng.policy_forward(obs, noise)
+    r_act, r_logp = OS.policy_forward(st.actor, obs, noise)[:2]
+    assert rel_err(a_act.cpu(), r_act) < 1e-5 and rel_err(a_logp.cpu().flatten(), r_logp.flatten()) < 1e-5
+    tq = eng.target_q(obs, noise)
+    assert rel_err(tq.cpu(), OS.target_q(st, cfg, obs, noise).flatten()) < 2e-5
+    for name, sizes, conv in (("actor", sa, S.actor_flat_to_torch), ("critic1", sc, S.critic_flat_to_torch), ("critic2_old", sc, S.critic_flat_to_torch)):
+        for t, k in zip(conv(getattr(eng, name), obs_dim, act_dim, eng.hidden, sizes=sizes), getattr(st, name)):
+            lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
+            # (every entry of every tensor after three Adam steps: the same sign-like amplification, up to 0.04 * lr on one entry in 10^5)
+            np.testing.assert_allclose(t.cpu().numpy(), getattr(st, name)[k].numpy(), rtol=1e-5, atol=0.1 * lr, err_msg=f"{name}.{k}")
+    with pytest.raises(NotImplementedError):
+        make_engine(5, 2, 0, cfg, hidden=((32,) * 7, (32,) * 7))          # beyond TS_MLP_MAX_HIDDEN_LAYERS
 
 
 def test_twin_critics_on_two_streams_with_generation_2():

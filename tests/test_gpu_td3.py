@@ -21,15 +21,15 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
     from tianshou_amd import widths as W
 
     actor, c1, c2 = OS.init_td3_params(obs_dim, act_dim, seed, cfg.twin, hidden)
-    lists = [[actor[k] for k in OS.DET_ACTOR_ORDER], [c1[k] for k in OS.CRITIC_ORDER]] + ([[c2[k] for k in OS.CRITIC_ORDER]] if cfg.twin else [])
-    H = W.common_hidden(*lists)
+    lists = [list(actor.values()), list(c1.values())] + ([list(c2.values())] if cfg.twin else [])          # (dicts are in layer order)
+    H = W.engine_hidden([W.layer_widths(t, 1) for t in lists])
     eng = T.TD3Engine(
         obs_dim, act_dim, T.actor_flat_from_torch(lists[0], obs_dim, act_dim, hidden=H),
         T.critic_flat_from_torch(lists[1], obs_dim, act_dim, hidden=H),
         T.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H) if cfg.twin else None,
         T.TD3Config(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "twin", "policy_noise", "noise_clip",
                                                      "update_actor_freq", "max_action", "actor_lr", "critic_lr")}),
-        hidden=H)
+        hidden=H, depth=OS.depth_of(actor))
     return eng, (actor, c1, c2)
 
 
@@ -92,9 +92,11 @@ def test_policy_target_and_gradients_vs_oracle(twin):
             assert rel_err(t.cpu(), col[name + "_grads"][key]) < 2e-5, (name, key)
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
 def test_update_matches_reference_golden(tag):
-    """(`widths`: the TD3 paper's Net[400, 300] embedded in Net[416, 416]; `ddpg_widths`: actor [24, 56], critic [40, 24] in 64.)"""
+    """(`widths`: the TD3 paper's Net[400, 300] embedded in Net[416, 416]; `ddpg_widths`: actor [24, 56], critic [40, 24] in 64;
+    `depth4`: FOUR hidden layers, actor [64, 64, 32, 32] and critics [48, 64, 64, 40] in Net[64] * 4, max_action 1.5;
+    `ddpg_depth1`: ONE hidden layer, actor [128], critic [64] -- fixtures the unmodified reference wrote, gen_golden.py::gen_depth.)"""
     from tianshou_amd import td3 as T
     from tianshou_amd.buffer import DeviceReplayBuffer
 
@@ -102,7 +104,8 @@ def test_update_matches_reference_golden(tag):
 
     g, d, cfg, bstate = load_td3(tag)
     eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
-    hw = OS.hidden_widths(d["hidden"])
+    sa, sc = OS.layer_sizes(d["hidden"])
+    assert eng.depth == len(sa) == len(sc)
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
                              truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
@@ -116,10 +119,10 @@ def test_update_matches_reference_golden(tag):
         names = ["actor", "critic1", "actor_old", "critic1_old"] + (["critic2", "critic2_old"] if d["twin"] else [])
         for name in names:
             conv = T.actor_flat_to_torch if name.startswith("actor") else T.critic_flat_to_torch
-            sz = hw[:2] if name.startswith("actor") else hw[2:]
-            full = conv(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden)
-            assert W.padding_is_zero(full, *sz), name            # the embedding of Net[h1, h2] in Net[h, h] stays an embedding
-            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sz)])
+            sz = sa if name.startswith("actor") else sc
+            full = conv(getattr(eng, name), d["obs_dim"], d["act_dim"], eng.hidden, depth=eng.depth)
+            assert W.padding_is_zero_layers(full, sz), name       # the embedding of Net[h1, ...] in Net[h] * d stays an embedding
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_layers(full, sz)])
             lr = cfg.actor_lr if name.startswith("actor") else cfg.critic_lr
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr,
                                        err_msg=name)

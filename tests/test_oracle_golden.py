@@ -367,6 +367,14 @@ def test_rainbow_restatement_matches_reference(tag):
 
 
 # ------------------------------------------------------------------------------------ SAC path
+def _fixture_hidden(g):
+    """`hidden` of a SAC / TD3 fixture: 256 (the early fixtures), four widths (actor h1, h2, critic h1, h2), or -- other depths,
+    round 6 -- the nested pair (actor sizes, critic sizes) that oracle_sac.layer_sizes takes."""
+    if "hidden_actor" in g:
+        return (tuple(int(x) for x in g["hidden_actor"]), tuple(int(x) for x in g["hidden_critic"]))
+    return tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256
+
+
 def load_sac(tag):
     from oracle import oracle_sac as OS
 
@@ -378,13 +386,13 @@ def load_sac(tag):
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
                        alpha_lr=c["alpha_lr"])
     d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
-             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)       # (actor h1, h2, critic h1, h2)
+             hidden=_fixture_hidden(g))
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
 def test_sac_restatement_matches_reference(tag):
     """oracle_sac (tanh-Gaussian policy, twin lagged critics, n-step target, three Adam steps, auto alpha,
     Polyak) against the unmodified reference SAC.update() with its rsample() noise replayed."""
@@ -409,9 +417,8 @@ def test_sac_restatement_matches_reference(tag):
         np.testing.assert_allclose(out["alpha"], ref[3], rtol=1e-6)
         if cfg.auto_alpha:
             np.testing.assert_allclose(out["alpha_loss"], ref[4], rtol=1e-5, atol=1e-6)
-        for name, order in (("actor", OS.ACTOR_ORDER), ("critic1", OS.CRITIC_ORDER), ("critic2", OS.CRITIC_ORDER),
-                            ("critic1_old", OS.CRITIC_ORDER), ("critic2_old", OS.CRITIC_ORDER)):
-            flat = OS.flatten(getattr(st, name), order).numpy()
+        for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
+            flat = OS.flatten(getattr(st, name), OS.order_of(getattr(st, name))).numpy()
             np.testing.assert_allclose(flat[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
 
 
@@ -533,13 +540,13 @@ def load_td3(tag):
                        update_actor_freq=int(c["update_actor_freq"]), max_action=c["max_action"],
                        actor_lr=c["actor_lr"], critic_lr=c["critic_lr"])
     d = dict(obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed, twin=bool(twin),
-             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)
+             hidden=_fixture_hidden(g))
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
 def test_td3_ddpg_restatement_matches_reference(tag):
     from oracle import oracle_sac as OS
 
@@ -559,7 +566,7 @@ def test_td3_ddpg_restatement_matches_reference(tag):
         np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7)
         names = ["actor", "critic1", "actor_old", "critic1_old"] + (["critic2", "critic2_old"] if d["twin"] else [])
         for name in names:
-            order = OS.DET_ACTOR_ORDER if name.startswith("actor") else OS.CRITIC_ORDER
+            order = OS.order_of(getattr(st, name))
             np.testing.assert_allclose(OS.flatten(getattr(st, name), order).numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5,
                                        atol=1e-6, err_msg=name)
 

@@ -186,8 +186,10 @@ int ts_workspace_side_stream(ts_workspace* ws, int which, ts_stream_t* stream_ou
 
 int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_set_hidden: workspace is NULL");
-    TS_REQUIRE(hidden == 0 || (hidden >= 32 && hidden <= 1024 && hidden % 32 == 0), TS_ERR_INVALID_ARG,
-               "ts_mlp_set_hidden: 0 (default 256) or a multiple of 32 in [32, 1024], got %lld", (long long)hidden);
+    // (the SAC / TD3 / DDPG / REDQ entry points take widths up to 1024 and check that themselves; DiscreteSAC's, which
+    // receive the width as an argument and read only the depth from the workspace, up to 2048)
+    TS_REQUIRE(hidden == 0 || (hidden >= 32 && hidden <= 2048 && hidden % 32 == 0), TS_ERR_INVALID_ARG,
+               "ts_mlp_set_hidden: 0 (default 256) or a multiple of 32 in [32, 2048], got %lld", (long long)hidden);
     ws->mlp_hidden = (int)hidden;
     ws->mlp_depth = 0;
     return TS_OK;

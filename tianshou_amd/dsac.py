@@ -16,17 +16,21 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, _i64_dev, gather_rows
 from .returns import compute_nstep_return
-from .sac import SACConfig, SACStateC
+from .sac import SACConfig, SACStateC, keys_depth, mlp_layout, trunk_flat, trunk_keys, trunk_unflat, use_hidden  # noqa: F401
 
 TIANSHOU_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
                  "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
                  "last.model.0.weight", "last.model.0.bias"]
 
 
-def layout(obs_dim: int, n_act: int, hidden: int) -> dict[str, int]:
-    out = (C.c_int64 * 3)()
-    _lib.check(_lib.load().ts_dsac_layout(_lib.i64(obs_dim), _lib.i64(n_act), _lib.i64(hidden), out))
-    return dict(zip(["ka", "hw", "count"], (int(v) for v in out)))
+def net_keys(depth: int = 2) -> list[str]:
+    return trunk_keys(depth, ("last",))
+
+
+def layout(obs_dim: int, n_act: int, hidden: int, depth: int = 2) -> dict[str, int]:
+    _lib.check(_lib.load().ts_dsac_layout(_lib.i64(obs_dim), _lib.i64(n_act), _lib.i64(hidden), (C.c_int64 * 3)()))      # argument checks
+    k, offs = mlp_layout(obs_dim, hidden, depth, (n_act + 31) // 32 * 32)
+    return {"ka": k, "hw": (n_act + 31) // 32 * 32, "count": offs[-1], "offs": offs}
 
 
 def _block(w: torch.Tensor, b: torch.Tensor, k_pad: int, n_pad: int) -> torch.Tensor:
@@ -38,39 +42,36 @@ def _block(w: torch.Tensor, b: torch.Tensor, k_pad: int, n_pad: int) -> torch.Te
 
 
 def net_flat_from_torch(t: list[torch.Tensor], obs_dim: int, n_act: int, hidden: int, device="cuda") -> torch.Tensor:
-    """[w1, b1, w2, b2, w_head, b_head] (torch nn.Linear layout; also valid for Adam moments) -> flat vector.  Widths other
-    than [hidden, hidden] are embedded by zero padding (`tianshou_amd.widths`)."""
+    """[w1, b1, ..., wd, bd, w_head, b_head] (torch nn.Linear layout; also valid for Adam moments) -> flat vector.  Widths other
+    than [hidden] * d are embedded by zero padding (`tianshou_amd.widths`)."""
     from . import widths as W
 
-    t = W.pad_two_layer(t, hidden)
-    lay = layout(obs_dim, n_act, hidden)
-    return torch.cat([_block(t[0], t[1], lay["ka"], hidden), _block(t[2], t[3], hidden, hidden),
-                      _block(t[4], t[5], hidden, lay["hw"])]).to(device).contiguous()
+    d = W.depth_of(t, 1)
+    t = W.pad_layers(t, hidden, 1)
+    lay = layout(obs_dim, n_act, hidden, d)
+    return torch.cat(trunk_flat(t, d, lay["ka"]) + [_block(t[2 * d], t[2 * d + 1], hidden, lay["hw"])]).to(device).contiguous()
 
 
-def net_flat_to_torch(flat: torch.Tensor, obs_dim: int, n_act: int, hidden: int, sizes=None) -> list[torch.Tensor]:
-    if sizes is not None:
-        from . import widths as W
+def net_flat_to_torch(flat: torch.Tensor, obs_dim: int, n_act: int, hidden: int, sizes=None, depth: int | None = None) -> list[torch.Tensor]:
+    from . import widths as W
 
-        return W.unpad_two_layer(net_flat_to_torch(flat, obs_dim, n_act, hidden), *sizes)
-    lay = layout(obs_dim, n_act, hidden)
-    f = flat.detach()
-    n1, n2 = (lay["ka"] + 1) * hidden, (hidden + 1) * hidden
-    l1 = f[:n1].reshape(lay["ka"] + 1, hidden)
-    l2 = f[n1:n1 + n2].reshape(hidden + 1, hidden)
-    hd = f[n1 + n2:].reshape(hidden + 1, lay["hw"])
-    return [l1[:obs_dim].t().contiguous(), l1[lay["ka"]].clone(), l2[:hidden].t().contiguous(), l2[hidden].clone(),
-            hd[:hidden, :n_act].t().contiguous(), hd[hidden, :n_act].clone()]
+    d = len(sizes) if sizes is not None else int(depth or 2)
+    lay = layout(obs_dim, n_act, hidden, d)
+    f, offs = flat.detach(), lay["offs"]
+    hd = f[offs[d]: offs[d + 1]].reshape(hidden + 1, lay["hw"])
+    out = trunk_unflat(f, obs_dim, lay["ka"], hidden, d, offs) + [hd[:hidden, :n_act].t().contiguous(), hd[hidden, :n_act].clone()]
+    return W.unpad_layers(out, sizes) if sizes is not None else out
 
 
 class DiscreteSACEngine:
     """State of one DiscreteSAC learner on one GPU (hyper-parameters: tianshou_amd.sac.SACConfig)."""
 
     def __init__(self, obs_dim: int, n_act: int, hidden: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor, cfg: SACConfig):
+                 critic2: torch.Tensor, cfg: SACConfig, depth: int = 2):
         if not actor.is_cuda:
             raise RuntimeError("DiscreteSACEngine needs parameters on an MI355X (no CPU fallback)")
-        lay = layout(obs_dim, n_act, hidden)
+        self.depth = int(depth)
+        lay = layout(obs_dim, n_act, hidden, self.depth)
         if any(t.numel() != lay["count"] for t in (actor, critic1, critic2)):
             raise ValueError("flat parameter vectors do not match ts_dsac_layout")
         self.obs_dim, self.n_act, self.hidden, self.cfg, self.lay = obs_dim, n_act, hidden, cfg, lay
@@ -95,6 +96,7 @@ class DiscreteSACEngine:
         return t if shape is None else t.reshape(shape)
 
     def _dims(self):
+        use_hidden(self._ws, self.hidden, self.depth)          # (the entry points read the depth from the workspace)
         return _lib.i64(self.obs_dim), _lib.i64(self.n_act), _lib.i64(self.hidden)
 
     @property

@@ -1465,6 +1465,27 @@ def make_hip_rainbow(ref=None):
 # ---------------------------------------------------------------------------------------------------
 # SAC (sac.py:213-336) on the mujoco_sac.py networks
 # ---------------------------------------------------------------------------------------------------
+def _require_relu_trunk(mod, who: str) -> None:
+    """The off-policy engines compute a `Net` trunk as Sequential(Linear, ReLU, Linear, ReLU, ...) -- `Net`'s default activation
+    (utils/net/common.py:246-369).  The state_dict keys only pin the Linear layers' positions; whatever sits between them
+    (another activation, dropout) has no parameters and would be silently replaced by ReLU, so it is checked here."""
+    seq = getattr(getattr(getattr(mod, "preprocess", None), "model", None), "model", None)
+    mods = list(seq) if seq is not None else []
+    ok = len(mods) >= 2 and len(mods) % 2 == 0 and all(
+        type(mods[i]).__name__ in ("Linear", "EnsembleLinear") and isinstance(mods[i + 1], torch.nn.ReLU) for i in range(0, len(mods), 2))
+    if not ok:
+        raise NotImplementedError(f"{who}: the trunk must be Net(hidden_sizes=[...]) with nn.ReLU after every Linear layer "
+                                  f"(got {[type(m).__name__ for m in mods]})")
+
+
+def _require_unbounded_actor(actor, who: str) -> None:
+    """SAC's / REDQ's engine squashes tanh(mu + sigma * eps) with an unbounded mu (examples/mujoco/mujoco_sac.py:88-94 pass
+    `unbounded=True`); the class default `unbounded=False` (continuous.py:194, 230-231: mu = max_action * tanh(mu)) is a
+    different network and raises."""
+    if not getattr(actor, "_unbounded", False):
+        raise NotImplementedError(f"{who}: ContinuousActorProbabilistic(unbounded=True) is required (as in examples/mujoco/mujoco_sac.py)")
+
+
 def make_hip_sac(ref=None):
     """Returns HipSAC(SAC): `_preprocess_batch` / `_update_with_batch` (ddpg.py:287-301, sac.py:298-336) on the
     engine.  Supported nets: examples/mujoco/mujoco_sac.py:82-104 (Net[256, 256] ReLU, conditioned sigma,
@@ -1504,20 +1525,25 @@ def make_hip_sac(ref=None):
             self._hip_noise_key = int(torch.initial_seed() % (2**31 - 1)) if noise_seed is None else int(noise_seed)
             self._hip_device = torch.device(device)
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
-            if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != S.TIANSHOU_CRITIC_KEYS \
-                    or list(self.critic2.state_dict().keys()) != S.TIANSHOU_CRITIC_KEYS:
-                raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py")
-            # any two hidden widths per network (round 6): embedded by zero padding into the engine's Net[h, h], h = the largest
+            depth = S.keys_depth(sa.keys(), ("mu", "sigma"))
+            if depth is None or any(S.keys_depth(c.state_dict().keys(), ("last",)) != depth for c in (self.critic, self.critic2)):
+                raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py (Net trunks of one depth, "
+                                          "1 .. 6 hidden layers, single-Linear mu / sigma / Q heads)")
+            self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), S.critic_keys(depth)
+            for mod in (self.policy.actor, self.critic, self.critic2):
+                _require_relu_trunk(mod, "HipSAC")
+            _require_unbounded_actor(self.policy.actor, "HipSAC")
+            # any hidden widths per network (round 6): embedded by zero padding into the engine's Net[h] * depth, h = the largest
             # width of the three networks rounded up to 32 (tianshou_amd.widths)
             from . import widths as WD
 
-            lists = {"actor": [sa[k] for k in S.TIANSHOU_ACTOR_KEYS], "critic1": [sc[k] for k in S.TIANSHOU_CRITIC_KEYS],
-                     "critic2": [self.critic2.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS]}
+            lists = {"actor": [sa[k] for k in self._hip_akeys], "critic1": [sc[k] for k in self._hip_ckeys],
+                     "critic2": [self.critic2.state_dict()[k] for k in self._hip_ckeys]}
             try:
-                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
-                hid = WD.common_hidden(*lists.values())
+                self._hip_sizes = {n: WD.layer_widths(t, 2 if n == "actor" else 1) for n, t in lists.items()}
+                hid = WD.engine_hidden(self._hip_sizes.values())
             except NotImplementedError as e:
-                raise NotImplementedError(f"HipSAC: two hidden layers of widths up to 1024 per network ({e})") from None
+                raise NotImplementedError(f"HipSAC: hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim, self.critic2_optim):
                 _adam_of(o)
@@ -1530,8 +1556,8 @@ def make_hip_sac(ref=None):
                 from . import policy as HP
 
                 HP.attach(self.policy, "sac", self, device=str(self._hip_device), sampling=sampling, noise_seed=noise_seed,
-                          obs_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1]), act_dim=int(sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]),
-                          hidden=hid)
+                          obs_dim=int(sa[self._hip_akeys[0]].shape[1]), act_dim=int(sa[self._hip_akeys[2 * self._hip_depth]].shape[0]),
+                          hidden=hid, depth=depth)
             self._hip_set_write_back(write_back, attached=policy_forward == "hip")
 
         def update(self, buffer, sample_size):
@@ -1552,8 +1578,8 @@ def make_hip_sac(ref=None):
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                obs_dim = sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1]
-                act_dim = sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                obs_dim = sa[self._hip_akeys[0]].shape[1]
+                act_dim = sa[self._hip_akeys[2 * self._hip_depth]].shape[0]
                 auto = isinstance(self.alpha, AutoAlpha)
                 ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
                 cfg = S.SACConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
@@ -1566,11 +1592,11 @@ def make_hip_sac(ref=None):
                 dev = self._hip_device
                 hid = self._hip_hidden
                 flat_c = lambda mod: S.critic_flat_from_torch(  # noqa: E731
-                    [mod.state_dict()[k] for k in S.TIANSHOU_CRITIC_KEYS], obs_dim, act_dim, dev, hidden=hid)
+                    [mod.state_dict()[k] for k in self._hip_ckeys], obs_dim, act_dim, dev, hidden=hid)
                 eng = self._hip_engine = S.SACEngine(
                     obs_dim, act_dim,
-                    S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev, hidden=hid),
-                    flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden)
+                    S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
+                    flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden, depth=self._hip_depth)
                 # resume: lagged critics, Adam moments / steps of a loaded checkpoint
                 eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
                 for name, mod, optim, keys, conv in self._hip_parts(S):
@@ -1589,9 +1615,9 @@ def make_hip_sac(ref=None):
 
             fa = functools.partial(S.actor_flat_from_torch, hidden=self._hip_hidden)
             fc = functools.partial(S.critic_flat_from_torch, hidden=self._hip_hidden)
-            return (("actor", self.policy.actor, self.policy_optim, S.TIANSHOU_ACTOR_KEYS, fa),
-                    ("critic1", self.critic, self.critic_optim, S.TIANSHOU_CRITIC_KEYS, fc),
-                    ("critic2", self.critic2, self.critic2_optim, S.TIANSHOU_CRITIC_KEYS, fc))
+            return (("actor", self.policy.actor, self.policy_optim, self._hip_akeys, fa),
+                    ("critic1", self.critic, self.critic_optim, self._hip_ckeys, fc),
+                    ("critic2", self.critic2, self.critic2_optim, self._hip_ckeys, fc))
 
         def _preprocess_batch(self, batch, buffer, indices):
             _require_gpu(self._hip_device, "HipSAC")
@@ -1679,21 +1705,25 @@ def make_hip_redq(ref=None):
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
-            if list(sa.keys()) != S.TIANSHOU_ACTOR_KEYS or list(sc.keys()) != RQ.TIANSHOU_CRITIC_KEYS:
-                raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py")
-            w1, w2 = sc[RQ.TIANSHOU_CRITIC_KEYS[0]], sc[RQ.TIANSHOU_CRITIC_KEYS[2]]
+            depth = S.keys_depth(sa.keys(), ("mu", "sigma"))
+            if depth is None or RQ.keys_depth(sc.keys()) != depth:
+                raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py (SAC's actor; a critic of "
+                                          "EnsembleLinear layers; trunks of one depth, 1 .. 6 hidden layers)")
+            self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), RQ.critic_keys(depth)
+            for mod in (self.policy.actor, self.critic):
+                _require_relu_trunk(mod, "HipREDQ")
+            _require_unbounded_actor(self.policy.actor, "HipREDQ")
             from . import widths as WD
 
-            if w1.dim() != 3 or w2.dim() != 3 or w1.shape[0] != self.ensemble_size or w2.shape[1] != w1.shape[2]:
-                raise NotImplementedError("HipREDQ: EnsembleLinear critics of ensemble_size with two hidden layers")
-            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
-                self._hip_sizes = {"actor": WD.two_layer_widths([sa[k] for k in S.TIANSHOU_ACTOR_KEYS]),
-                                   "critic": (int(w1.shape[2]), int(w2.shape[2]))}
-                hid = WD.round32(max(self._hip_sizes["actor"] + self._hip_sizes["critic"]))
-                if not 32 <= hid <= WD.MAX_HIDDEN:
-                    raise NotImplementedError(f"hidden widths up to {WD.MAX_HIDDEN}")
+            try:        # any hidden widths (round 6): embedded by zero padding (tianshou_amd.widths)
+                cw = [sc[k] for k in self._hip_ckeys[:2 * depth:2]]          # EnsembleLinear weights [E, in, out]
+                if any(w.dim() != 3 or w.shape[0] != self.ensemble_size or (i > 0 and w.shape[1] != cw[i - 1].shape[2]) for i, w in enumerate(cw)):
+                    raise NotImplementedError("EnsembleLinear weights [ensemble_size, in, out] are required")
+                self._hip_sizes = {"actor": WD.layer_widths([sa[k] for k in self._hip_akeys], 2),
+                                   "critic": tuple(int(w.shape[2]) for w in cw)}
+                hid = WD.engine_hidden(self._hip_sizes.values())
             except NotImplementedError as e:
-                raise NotImplementedError(f"HipREDQ: two hidden layers of widths up to 1024 per network ({e})") from None
+                raise NotImplementedError(f"HipREDQ: hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in (self.policy_optim, self.critic_optim):
                 _adam_of(o)
@@ -1701,12 +1731,12 @@ def make_hip_redq(ref=None):
             self._hip_glue_init()
 
         def _critic_tensors(self, mod):
-            return [mod.state_dict()[k] for k in RQ.TIANSHOU_CRITIC_KEYS]
+            return [mod.state_dict()[k] for k in self._hip_ckeys]
 
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                obs_dim, act_dim = sa[S.TIANSHOU_ACTOR_KEYS[0]].shape[1], sa[S.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                obs_dim, act_dim = sa[self._hip_akeys[0]].shape[1], sa[self._hip_akeys[2 * self._hip_depth]].shape[0]
                 auto = isinstance(self.alpha, AutoAlpha)
                 ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
                 cfg = RQ.REDQConfig(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon,
@@ -1720,16 +1750,16 @@ def make_hip_redq(ref=None):
                 dev = self._hip_device
                 hid = self._hip_hidden
                 eng = self._hip_engine = RQ.REDQEngine(
-                    obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, act_dim, dev, hidden=hid),
+                    obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
                     RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev, hidden=hid), cfg,
-                    hidden=self._hip_hidden)
+                    hidden=self._hip_hidden, depth=self._hip_depth)
                 # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
                 eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev, hidden=hid)
                 eng.critic_gradient_step = int(self.critic_gradient_step)
-                ms, vs, step = adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS))
+                ms, vs, step = adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, self._hip_akeys))
                 eng.actor_m, eng.actor_v = (S.actor_flat_from_torch(x, obs_dim, act_dim, dev, hidden=hid) for x in (ms, vs))
                 eng.actor_steps = step
-                ms, vs, _ = adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS))
+                ms, vs, _ = adam_state(self.critic_optim._optim, params_by_keys(self.critic, self._hip_ckeys))
                 eng.critics_m, eng.critics_v = (RQ.ensemble_flat_from_torch(x, obs_dim, act_dim, dev, hidden=hid) for x in (ms, vs))
                 eng._stats[0] = float(self._last_actor_loss)
                 if auto:
@@ -1767,19 +1797,19 @@ def make_hip_redq(ref=None):
             E = eng.cfg.ensemble_size
             with torch.no_grad():
                 sa_, sc_ = self._hip_sizes["actor"], self._hip_sizes["critic"]
-                for p, t in zip(params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS), S.actor_flat_to_torch(eng.actor, *dims, sizes=sa_)):
+                for p, t in zip(params_by_keys(self.policy.actor, self._hip_akeys), S.actor_flat_to_torch(eng.actor, *dims, sizes=sa_)):
                     p.copy_(t)
                 for mod, flat in ((self.critic, eng.critics), (self.critic_old.module, eng.critics_old)):
-                    for p, t in zip(params_by_keys(mod, RQ.TIANSHOU_CRITIC_KEYS), RQ.ensemble_flat_to_torch(flat, E, *dims, sizes=sc_)):
+                    for p, t in zip(params_by_keys(mod, self._hip_ckeys), RQ.ensemble_flat_to_torch(flat, E, *dims, sizes=sc_)):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
-            store_adam_state(self.critic_optim._optim, params_by_keys(self.critic, RQ.TIANSHOU_CRITIC_KEYS),
+            store_adam_state(self.critic_optim._optim, params_by_keys(self.critic, self._hip_ckeys),
                              RQ.ensemble_flat_to_torch(eng.critics_m, E, *dims, sizes=self._hip_sizes["critic"]),
                              RQ.ensemble_flat_to_torch(eng.critics_v, E, *dims, sizes=self._hip_sizes["critic"]),
                              eng.critic_gradient_step)
             if eng.actor_steps:
-                store_adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, S.TIANSHOU_ACTOR_KEYS),
+                store_adam_state(self.policy_optim._optim, params_by_keys(self.policy.actor, self._hip_akeys),
                                  S.actor_flat_to_torch(eng.actor_m, *dims, sizes=self._hip_sizes["actor"]),
                                  S.actor_flat_to_torch(eng.actor_v, *dims, sizes=self._hip_sizes["actor"]),
                                  eng.actor_steps)
@@ -1820,18 +1850,23 @@ def make_hip_discrete_sac(ref=None):
             self._hip_device = torch.device(device)
             self._hip_match_rng = match_rng_stream
             mods = (self.policy.actor, self.critic, self.critic2)
-            if any(list(m.state_dict().keys()) != DS.TIANSHOU_KEYS for m in mods):
-                raise NotImplementedError("HipDiscreteSAC: networks must be Net(obs, [h, h]) + a single Linear head")
+            depth = DS.keys_depth(mods[0].state_dict().keys(), ("last",))
+            if depth is None or any(DS.keys_depth(m.state_dict().keys(), ("last",)) != depth for m in mods):
+                raise NotImplementedError("HipDiscreteSAC: networks must be Net(obs, [h, ...]) of one depth (1 .. 6 hidden layers) + a "
+                                          "single Linear head")
+            self._hip_depth, self._hip_keys = depth, DS.net_keys(depth)
+            for mod in mods:
+                _require_relu_trunk(mod, "HipDiscreteSAC")
             sa = self.policy.actor.state_dict()
             from . import widths as WD
 
-            lists = {n: [m.state_dict()[k] for k in DS.TIANSHOU_KEYS] for n, m in zip(("actor", "critic1", "critic2"), mods)}
-            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
-                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
-                self._hip_hidden = WD.common_hidden(*lists.values())
+            lists = {n: [m.state_dict()[k] for k in self._hip_keys] for n, m in zip(("actor", "critic1", "critic2"), mods)}
+            try:        # any hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
+                self._hip_sizes = {n: WD.layer_widths(t, 1) for n, t in lists.items()}
+                self._hip_hidden = WD.engine_hidden(self._hip_sizes.values())
             except NotImplementedError as e:
-                raise NotImplementedError(f"HipDiscreteSAC: two hidden layers of widths up to 1024 per network ({e})") from None
-            if not 2 <= sa[DS.TIANSHOU_KEYS[4]].shape[0] <= 64:
+                raise NotImplementedError(f"HipDiscreteSAC: hidden layers of widths up to 1024 per network ({e})") from None
+            if not 2 <= sa[self._hip_keys[2 * self._hip_depth]].shape[0] <= 64:
                 raise NotImplementedError("HipDiscreteSAC: 2..64 actions")
             if getattr(self.policy.actor, "softmax_output", False):
                 raise NotImplementedError("HipDiscreteSAC: the actor must output logits (softmax_output=False)")
@@ -1847,8 +1882,8 @@ def make_hip_discrete_sac(ref=None):
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                obs_dim = sa[DS.TIANSHOU_KEYS[0]].shape[1]
-                n_act = sa[DS.TIANSHOU_KEYS[4]].shape[0]
+                obs_dim = sa[self._hip_keys[0]].shape[1]
+                n_act = sa[self._hip_keys[2 * self._hip_depth]].shape[0]
                 dims = (obs_dim, n_act, self._hip_hidden)
                 auto = isinstance(self.alpha, AutoAlpha)
                 ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
@@ -1861,12 +1896,12 @@ def make_hip_discrete_sac(ref=None):
                                 betas=tuple(ga["betas"]), adam_eps=ga["eps"])
                 dev = self._hip_device
                 flat = lambda mod: DS.net_flat_from_torch(  # noqa: E731
-                    [mod.state_dict()[k] for k in DS.TIANSHOU_KEYS], *dims, dev)
+                    [mod.state_dict()[k] for k in self._hip_keys], *dims, dev)
                 eng = self._hip_engine = DS.DiscreteSACEngine(*dims, flat(self.policy.actor), flat(self.critic),
-                                                              flat(self.critic2), cfg)
+                                                              flat(self.critic2), cfg, depth=self._hip_depth)
                 eng.critic1_old, eng.critic2_old = flat(self.critic_old.module), flat(self.critic2_old.module)
                 for name, mod, optim in self._hip_parts():             # resume from a loaded checkpoint
-                    ms, vs, step = adam_state(optim._optim, params_by_keys(mod, DS.TIANSHOU_KEYS))
+                    ms, vs, step = adam_state(optim._optim, params_by_keys(mod, self._hip_keys))
                     setattr(eng, name + "_m", DS.net_flat_from_torch(ms, *dims, dev))
                     setattr(eng, name + "_v", DS.net_flat_from_torch(vs, *dims, dev))
                     eng.adam_step = max(eng.adam_step, step)
@@ -1912,12 +1947,12 @@ def make_hip_discrete_sac(ref=None):
                 for mod, flat, nm in ((self.policy.actor, eng.actor, "actor"), (self.critic, eng.critic1, "critic1"),
                                       (self.critic2, eng.critic2, "critic2"), (self.critic_old.module, eng.critic1_old, "critic1"),
                                       (self.critic2_old.module, eng.critic2_old, "critic2")):
-                    for p, t in zip(params_by_keys(mod, DS.TIANSHOU_KEYS), DS.net_flat_to_torch(flat, *dims, sizes=sz[nm])):
+                    for p, t in zip(params_by_keys(mod, self._hip_keys), DS.net_flat_to_torch(flat, *dims, sizes=sz[nm])):
                         p.copy_(t)
                 if eng.cfg.auto_alpha:
                     self.alpha._log_alpha.copy_(eng.log_alpha[0])
             for name, mod, optim in self._hip_parts():
-                store_adam_state(optim._optim, params_by_keys(mod, DS.TIANSHOU_KEYS),
+                store_adam_state(optim._optim, params_by_keys(mod, self._hip_keys),
                                  DS.net_flat_to_torch(getattr(eng, name + "_m"), *dims, sizes=self._hip_sizes[name]),
                                  DS.net_flat_to_torch(getattr(eng, name + "_v"), *dims, sizes=self._hip_sizes[name]), eng.adam_step)
             if eng.cfg.auto_alpha:
@@ -2126,19 +2161,24 @@ def _make_hip_det(twin: bool, ref=None):
             self._hip_device = torch.device(device)
             sa = self.policy.actor.state_dict()
             critics = [self.critic] + ([self.critic2] if twin else [])
-            if list(sa.keys()) != T.TIANSHOU_ACTOR_KEYS or any(list(c.state_dict().keys()) != S_KEYS for c in critics):
-                raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py")
-            # any two hidden widths per network, e.g. the [400, 300] of the TD3 / DDPG papers (round 6, tianshou_amd.widths)
+            depth = T.keys_depth(sa.keys(), ("last",))
+            if depth is None or any(T.keys_depth(c.state_dict().keys(), ("last",)) != depth for c in critics):
+                raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py (Net trunks of "
+                                          "one depth, 1 .. 6 hidden layers, single-Linear action / Q heads)")
+            self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, T.actor_keys(depth), T.critic_keys(depth)
+            for mod in [self.policy.actor] + critics:
+                _require_relu_trunk(mod, "HipTD3 / HipDDPG")
+            # any hidden widths per network, e.g. the [400, 300] of the TD3 / DDPG papers (round 6, tianshou_amd.widths)
             from . import widths as WD
 
-            lists = {"actor": [sa[k] for k in T.TIANSHOU_ACTOR_KEYS]}
+            lists = {"actor": [sa[k] for k in self._hip_akeys]}
             for i, c in enumerate(critics):
-                lists[f"critic{i + 1}"] = [c.state_dict()[k] for k in S_KEYS]
+                lists[f"critic{i + 1}"] = [c.state_dict()[k] for k in self._hip_ckeys]
             try:
-                self._hip_sizes = {n: WD.two_layer_widths(t) for n, t in lists.items()}
-                hid = WD.common_hidden(*lists.values())
+                self._hip_sizes = {n: WD.layer_widths(t, 1) for n, t in lists.items()}
+                hid = WD.engine_hidden(self._hip_sizes.values())
             except NotImplementedError as e:
-                raise NotImplementedError(f"HipTD3 / HipDDPG: two hidden layers of widths up to 1024 per network ({e})") from None
+                raise NotImplementedError(f"HipTD3 / HipDDPG: hidden layers of widths up to 1024 per network ({e})") from None
             self._hip_hidden = hid
             for o in [self.policy_optim, self.critic_optim] + ([self.critic2_optim] if twin else []):
                 _adam_of(o)
@@ -2149,19 +2189,19 @@ def _make_hip_det(twin: bool, ref=None):
             import functools
 
             P, hid, sz = functools.partial, self._hip_hidden, self._hip_sizes
-            parts = [("actor", self.policy.actor, self.policy_optim, T.TIANSHOU_ACTOR_KEYS, P(T.actor_flat_from_torch, hidden=hid),
+            parts = [("actor", self.policy.actor, self.policy_optim, self._hip_akeys, P(T.actor_flat_from_torch, hidden=hid),
                       P(T.actor_flat_to_torch, sizes=sz["actor"]), self.actor_old.module),
-                     ("critic1", self.critic, self.critic_optim, S_KEYS, P(T.critic_flat_from_torch, hidden=hid),
+                     ("critic1", self.critic, self.critic_optim, self._hip_ckeys, P(T.critic_flat_from_torch, hidden=hid),
                       P(T.critic_flat_to_torch, sizes=sz["critic1"]), self.critic_old.module)]
             if twin:
-                parts.append(("critic2", self.critic2, self.critic2_optim, S_KEYS, P(T.critic_flat_from_torch, hidden=hid),
+                parts.append(("critic2", self.critic2, self.critic2_optim, self._hip_ckeys, P(T.critic_flat_from_torch, hidden=hid),
                               P(T.critic_flat_to_torch, sizes=sz["critic2"]), self.critic2_old.module))
             return parts
 
         def _engine(self):
             if self._hip_engine is None:
                 sa = self.policy.actor.state_dict()
-                obs_dim, act_dim = sa[T.TIANSHOU_ACTOR_KEYS[0]].shape[1], sa[T.TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                obs_dim, act_dim = sa[self._hip_akeys[0]].shape[1], sa[self._hip_akeys[2 * self._hip_depth]].shape[0]
                 ga, gc = _adam_of(self.policy_optim)[1], _adam_of(self.critic_optim)[1]
                 cfg = T.TD3Config(gamma=self.gamma, tau=self.tau, n_step=self.n_step_return_horizon, twin=twin,
                                   policy_noise=getattr(self, "policy_noise", 0.0), noise_clip=getattr(self, "noise_clip", 0.0),
@@ -2172,7 +2212,7 @@ def _make_hip_det(twin: bool, ref=None):
                 flats = {n: conv([mod.state_dict()[k] for k in keys], obs_dim, act_dim, dev)
                          for n, mod, _, keys, conv, _, _ in self._hip_parts()}
                 eng = self._hip_engine = T.TD3Engine(obs_dim, act_dim, flats["actor"], flats["critic1"],
-                                                     flats.get("critic2"), cfg, hidden=self._hip_hidden)
+                                                     flats.get("critic2"), cfg, hidden=self._hip_hidden, depth=self._hip_depth)
                 eng.cnt = getattr(self, "_cnt", 0)
                 for n, mod, optim, keys, conv, _, old in self._hip_parts():           # resume from a checkpoint
                     setattr(eng, n + "_old", conv([old.state_dict()[k] for k in keys], obs_dim, act_dim, dev))
@@ -2221,10 +2261,6 @@ def _make_hip_det(twin: bool, ref=None):
 
     HipDet.__name__ = "HipTD3" if twin else "HipDDPG"
     return HipDet
-
-
-S_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
-          "preprocess.model.model.2.bias", "last.model.0.weight", "last.model.0.bias"]
 
 
 def make_hip_td3(ref=None):

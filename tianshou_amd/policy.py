@@ -324,13 +324,13 @@ def _sac_forward(policy, batch, state=None, **kwargs):
     from . import sac as S
 
     dev, spec = policy._hip_device(), policy._hip_spec
-    obs_dim, a, hid = spec["obs_dim"], spec["act_dim"], spec["hidden"]
+    obs_dim, a, hid, depth = spec["obs_dim"], spec["act_dim"], spec["hidden"], int(spec.get("depth", 2))
     eng = policy._hip_engine()
     if eng is not None:
         actor = eng.actor
     else:
         actor = policy._hip_cached([policy.actor], lambda: S.actor_flat_from_torch(
-            [policy.actor.state_dict()[k] for k in S.TIANSHOU_ACTOR_KEYS], obs_dim, a, dev, hidden=hid))
+            [policy.actor.state_dict()[k] for k in S.actor_keys(depth)], obs_dim, a, dev, hidden=hid))
     obs = _dev_f32(_obs_array(batch), dev, obs_dim)
     n = obs.shape[0]
     deterministic = bool(getattr(policy, "deterministic_eval", False)) and not policy.is_within_training_step
@@ -339,7 +339,7 @@ def _sac_forward(policy, batch, state=None, **kwargs):
     logp = torch.empty(n, dtype=torch.float32, device=dev)
     mu, sigma = torch.empty_like(act), torch.empty_like(act)
     ws = _lib.default_workspace(dev.index or 0)
-    S.use_hidden(ws, hid)
+    S.use_hidden(ws, hid, depth)
     _lib.check(_lib.load().ts_sac_policy_forward_logits(
         ws.handle, _lib.ptr(actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(n), _lib.i64(obs_dim), _lib.i64(a), _lib.ptr(act),
         _lib.ptr(logp), _lib.ptr(mu), _lib.ptr(sigma), _lib.current_stream(dev)))

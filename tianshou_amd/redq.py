@@ -19,7 +19,7 @@ import torch
 from . import _lib
 from .buffer import DeviceReplayBuffer, gather_rows
 from .returns import compute_nstep_return
-from .sac import SACConfig, SACEngine, critic_flat_from_torch, critic_flat_to_torch, layout, use_hidden
+from .sac import SACConfig, SACEngine, critic_flat_from_torch, critic_flat_to_torch, layout, mlp_layout, use_hidden  # noqa: F401
 
 TIANSHOU_CRITIC_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias_weights",
                         "preprocess.model.model.2.weight", "preprocess.model.model.2.bias_weights",
@@ -33,22 +33,42 @@ class REDQStateC(C.Structure):
                                           "log_alpha", "log_alpha_m", "log_alpha_v")]
 
 
+def critic_keys(depth: int = 2) -> list[str]:
+    """state_dict keys of the EnsembleLinear critic (utils/net/common.py:518-550: `weight`, `bias_weights`)."""
+    ks = []
+    for i in range(depth):
+        ks += [f"preprocess.model.model.{2 * i}.weight", f"preprocess.model.model.{2 * i}.bias_weights"]
+    return ks + ["last.model.0.weight", "last.model.0.bias_weights"]
+
+
+def keys_depth(keys) -> int | None:
+    keys = list(keys)
+    for d in range(1, 7):
+        if keys == critic_keys(d):
+            return d
+    return None
+
+
 def ensemble_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
-    """[w1 [E, in, h1], b1 [E, 1, h1], w2 [E, h1, h2], b2, wq [E, h2, 1], bq [E, 1, 1]] (EnsembleLinear layout; also valid for the
-    matching Adam moments) -> E consecutive critic blocks of ts_sac_layout (any widths: embedded by zero padding into
-    Net[hidden, hidden], `tianshou_amd.widths`)."""
+    """[w1 [E, in, h1], b1 [E, 1, h1], ..., wd [E, h(d-1), hd], bd, wq [E, hd, 1], bq [E, 1, 1]] (EnsembleLinear layout; also valid
+    for the matching Adam moments) -> E consecutive critic blocks of ts_mlp_layout (any widths: embedded by zero padding into
+    Net[hidden] * d, `tianshou_amd.widths`)."""
     E = t[0].shape[0]
-    blocks = [critic_flat_from_torch([t[0][e].t(), t[1][e, 0], t[2][e].t(), t[3][e, 0], t[4][e].t(), t[5][e, 0]],
+    blocks = [critic_flat_from_torch([x[e].t() if i % 2 == 0 else x[e, 0] for i, x in enumerate(t)],
                                      obs_dim, act_dim, "cpu", hidden=hidden) for e in range(E)]
     return torch.cat(blocks).to(device).contiguous()
 
 
-def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int, hidden: int = 256, sizes=None) -> list[torch.Tensor]:
-    pc = layout(obs_dim, act_dim, hidden)["critic_count"]
-    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim, hidden, sizes=sizes) for e in range(E)]
+def ensemble_flat_to_torch(flat: torch.Tensor, E: int, obs_dim: int, act_dim: int, hidden: int = 256, sizes=None,
+                           depth: int | None = None) -> list[torch.Tensor]:
+    d = len(sizes) if sizes is not None else int(depth or 2)
+    pc = mlp_layout(obs_dim + act_dim, hidden, d, 32)[1][-1]
+    per = [critic_flat_to_torch(flat[e * pc:(e + 1) * pc], obs_dim, act_dim, hidden, sizes=sizes, depth=d) for e in range(E)]
     st = lambda i, f: torch.stack([f(p[i]) for p in per])  # noqa: E731
-    return [st(0, lambda w: w.t()), st(1, lambda b: b[None, :]), st(2, lambda w: w.t()), st(3, lambda b: b[None, :]),
-            st(4, lambda w: w.t()), st(5, lambda b: b.reshape(1, 1))]
+    out = []
+    for i in range(d):
+        out += [st(2 * i, lambda w: w.t()), st(2 * i + 1, lambda b: b[None, :])]
+    return out + [st(2 * d, lambda w: w.t()), st(2 * d + 1, lambda b: b.reshape(1, 1))]
 
 
 @dataclass
@@ -65,17 +85,19 @@ class REDQEngine:
     """State of one REDQ learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critics: torch.Tensor, cfg: REDQConfig,
-                 hidden: int = 256):
-        """`hidden`: width h of the actor's Net[h, h] and of the EnsembleLinear critics (test_redq.py uses 256; any
-        multiple of 32 up to 1024, utils/net/common.py:246-369)."""
+                 hidden: int = 256, depth: int = 2):
+        """`hidden` / `depth`: width h and number of hidden layers of the actor's Net[h] * depth and of the EnsembleLinear critics
+        (test_redq.py uses [256, 256]; any multiple of 32 up to 1024, 1 .. 6 layers, utils/net/common.py:246-369)."""
         if not actor.is_cuda:
             raise RuntimeError("REDQEngine needs parameters on an MI355X (no CPU fallback)")
         if cfg.target_mode not in ("min", "mean") or not 0 < cfg.subset_size <= cfg.ensemble_size <= 64:
             raise ValueError("target_mode must be 'min' or 'mean' and 0 < subset_size <= ensemble_size <= 64")
-        lay = layout(obs_dim, act_dim, hidden)
-        if actor.numel() != lay["actor_count"] or critics.numel() != cfg.ensemble_size * lay["critic_count"]:
-            raise ValueError("flat parameter vectors do not match ts_sac_layout / the ensemble size")
-        self.obs_dim, self.act_dim, self.cfg, self.lay, self.hidden = obs_dim, act_dim, cfg, lay, int(hidden)
+        self.depth = int(depth)
+        n_actor, n_critic = mlp_layout(obs_dim, hidden, self.depth, 64)[1][-1], mlp_layout(obs_dim + act_dim, hidden, self.depth, 32)[1][-1]
+        if actor.numel() != n_actor or critics.numel() != cfg.ensemble_size * n_critic:
+            raise ValueError("flat parameter vectors do not match ts_mlp_layout / the ensemble size")
+        self.obs_dim, self.act_dim, self.cfg, self.hidden = obs_dim, act_dim, cfg, int(hidden)
+        self.lay = layout(obs_dim, act_dim, hidden) if self.depth == 2 else {"actor_count": n_actor, "critic_count": n_critic}
         self.device = actor.device
         cl = lambda t: t.detach().float().contiguous().clone()  # noqa: E731
         self.actor, self.critics = cl(actor), cl(critics)
@@ -102,7 +124,7 @@ class REDQEngine:
         if sub.size != self.cfg.subset_size:
             raise ValueError("subset must hold subset_size member indices")
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_redq_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critics_old), _lib.i64(self.cfg.ensemble_size),
             sub.ctypes.data_as(C.POINTER(C.c_int32)), _lib.i64(sub.size), C.c_int(int(self.cfg.target_mode == "mean")),
@@ -146,7 +168,7 @@ class REDQEngine:
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st = REDQStateC(*[getattr(self, n).data_ptr() for n, _ in REDQStateC._fields_])
         hp = self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_redq_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cfg.ensemble_size), _lib.i64(self.critic_gradient_step),
             _lib.i64(max(self.actor_steps, 1)), C.c_int(int(do_actor)), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),

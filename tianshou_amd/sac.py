@@ -28,7 +28,7 @@ TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.mode
                        "mu.model.0.weight", "mu.model.0.bias", "sigma.model.0.weight", "sigma.model.0.bias"]
 TIANSHOU_CRITIC_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
                         "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
-                        "last.model.0.weight", "last.model.0.bias"]
+                        "last.model.0.weight", "last.model.0.bias"]          # (two hidden layers: actor_keys(2) / critic_keys(2))
 HID = 256
 
 
@@ -49,6 +49,34 @@ class SACStateC(C.Structure):
         "critic1_old", "critic2_old", "log_alpha", "log_alpha_m", "log_alpha_v")]
 
 
+def trunk_keys(depth: int, heads: tuple[str, ...]) -> list[str]:
+    """state_dict keys of Net(hidden_sizes=[...] * depth) (Sequential(Linear, ReLU, ...): the Linears sit at even positions,
+    utils/net/common.py:90-178) under an actor / critic with the given single-Linear heads."""
+    ks = []
+    for i in range(depth):
+        ks += [f"preprocess.model.model.{2 * i}.weight", f"preprocess.model.model.{2 * i}.bias"]
+    for h in heads:
+        ks += [f"{h}.model.0.weight", f"{h}.model.0.bias"]
+    return ks
+
+
+def keys_depth(keys, heads: tuple[str, ...]) -> int | None:
+    """Number of hidden layers if `keys` are exactly those of a trunk + the heads, else None."""
+    keys = list(keys)
+    for d in range(1, W.MAX_DEPTH + 1):
+        if keys == trunk_keys(d, heads):
+            return d
+    return None
+
+
+def actor_keys(depth: int = 2) -> list[str]:
+    return trunk_keys(depth, ("mu", "sigma"))
+
+
+def critic_keys(depth: int = 2) -> list[str]:
+    return trunk_keys(depth, ("last",))
+
+
 def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
     """ts_sac_layout_h: offsets / counts of the flat vectors for Net[hidden, hidden] (a multiple of 32 up to 1024)."""
     out = (C.c_int64 * 8)()
@@ -57,10 +85,18 @@ def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
     return dict(zip(keys, (int(v) for v in out)))
 
 
-def use_hidden(ws, hidden: int) -> None:
-    """The hidden width is a property of the workspace (ts_mlp_set_hidden): every SAC / TD3 / DDPG / REDQ engine sets its
-    own before each call, since engines of different widths may share the device's default workspace."""
-    _lib.check(_lib.load().ts_mlp_set_hidden(ws.handle, _lib.i64(hidden)))
+def mlp_layout(in_dim: int, hidden: int, depth: int, head_cols: int) -> tuple[int, list[int]]:
+    """ts_mlp_layout: (k = in_dim rounded up to 32, offsets of the depth + 1 linear layers followed by the element count) of a
+    flat Net[hidden] * depth vector with a `head_cols`-column head block."""
+    out = (C.c_int64 * (depth + 3))()
+    _lib.check(_lib.load().ts_mlp_layout(_lib.i64(in_dim), _lib.i64(hidden), _lib.i64(depth), _lib.i64(head_cols), out))
+    return int(out[0]), [int(v) for v in out[1:]]
+
+
+def use_hidden(ws, hidden: int, depth: int = 2) -> None:
+    """Hidden width and depth are properties of the workspace (ts_mlp_set_trunk): every SAC / TD3 / DDPG / REDQ / DiscreteSAC
+    engine sets its own before each call, since engines of different trunks may share the device's default workspace."""
+    _lib.check(_lib.load().ts_mlp_set_trunk(ws.handle, _lib.i64(hidden), _lib.i64(depth)))
 
 
 def _l1(w: torch.Tensor, b: torch.Tensor, k_pad: int) -> torch.Tensor:
@@ -74,58 +110,69 @@ def _dense(w, b) -> torch.Tensor:
     return torch.cat([w.detach().float().cpu().t().reshape(-1), b.detach().float().cpu().reshape(-1)])
 
 
+def trunk_flat(t: list[torch.Tensor], depth: int, k_pad: int) -> list[torch.Tensor]:
+    """The hidden layers' wb blocks of [w1, b1, ..., wd, bd, ...] (all of one width)."""
+    return [_l1(t[0], t[1], k_pad)] + [_dense(t[2 * i], t[2 * i + 1]) for i in range(1, depth)]
+
+
+def trunk_unflat(f: torch.Tensor, in_dim: int, k_pad: int, H: int, depth: int, offs: list[int]) -> list[torch.Tensor]:
+    l1 = f[: offs[1]].reshape(k_pad + 1, H)
+    out = [l1[:in_dim].t().contiguous(), l1[k_pad].clone()]
+    for i in range(1, depth):
+        li = f[offs[i]: offs[i + 1]].reshape(H + 1, H)
+        out += [li[:H].t().contiguous(), li[H].clone()]
+    return out
+
+
 def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
-    """[w1, b1, w2, b2, wmu, bmu, wsig, bsig] (torch nn.Linear layout; also valid for Adam moments).  The hidden width is
+    """[w1, b1, ..., wd, bd, wmu, bmu, wsig, bsig] (torch nn.Linear layout; also valid for Adam moments).  Depth and widths are
     read off the tensors; unequal widths / widths that are no multiple of 32 are embedded by zero padding into
-    Net[hidden, hidden] (`tianshou_amd.widths`; hidden = the larger width rounded up to 32 unless given)."""
-    t = W.pad_two_layer(t, hidden or W.common_hidden(t))
-    HID = int(t[0].shape[0])
-    lay = layout(obs_dim, act_dim, HID)
-    head = torch.zeros((HID + 1, 64), dtype=torch.float32)
-    head[:HID, :act_dim] = t[4].detach().float().cpu().t()
-    head[HID, :act_dim] = t[5].detach().float().cpu()
-    head[:HID, 32:32 + act_dim] = t[6].detach().float().cpu().t()
-    head[HID, 32:32 + act_dim] = t[7].detach().float().cpu()
-    return torch.cat([_l1(t[0], t[1], lay["ka"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
+    Net[hidden] * d (`tianshou_amd.widths`; hidden = the largest width rounded up to 32 unless given)."""
+    d = W.depth_of(t, 2)
+    H = int(hidden or W.engine_hidden([W.layer_widths(t, 2)]))
+    t = W.pad_layers(t, H, 2)
+    k, _ = mlp_layout(obs_dim, H, d, 64)
+    head = torch.zeros((H + 1, 64), dtype=torch.float32)
+    head[:H, :act_dim] = t[2 * d].detach().float().cpu().t()
+    head[H, :act_dim] = t[2 * d + 1].detach().float().cpu()
+    head[:H, 32:32 + act_dim] = t[2 * d + 2].detach().float().cpu().t()
+    head[H, 32:32 + act_dim] = t[2 * d + 3].detach().float().cpu()
+    return torch.cat(trunk_flat(t, d, k) + [head.reshape(-1)]).to(device).contiguous()
 
 
 def critic_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
-    """[w1, b1, w2, b2, wq, bq] (widths as in `actor_flat_from_torch`)."""
-    t = W.pad_two_layer(t, hidden or W.common_hidden(t))
-    HID = int(t[0].shape[0])
-    lay = layout(obs_dim, act_dim, HID)
-    head = torch.zeros((HID + 1, 32), dtype=torch.float32)
-    head[:HID, 0] = t[4].detach().float().cpu().reshape(-1)
-    head[HID, 0] = t[5].detach().float().cpu().reshape(())
-    return torch.cat([_l1(t[0], t[1], lay["kc"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
+    """[w1, b1, ..., wd, bd, wq, bq] (depth / widths as in `actor_flat_from_torch`)."""
+    d = W.depth_of(t, 1)
+    H = int(hidden or W.engine_hidden([W.layer_widths(t, 1)]))
+    t = W.pad_layers(t, H, 1)
+    k, _ = mlp_layout(obs_dim + act_dim, H, d, 32)
+    head = torch.zeros((H + 1, 32), dtype=torch.float32)
+    head[:H, 0] = t[2 * d].detach().float().cpu().reshape(-1)
+    head[H, 0] = t[2 * d + 1].detach().float().cpu().reshape(())
+    return torch.cat(trunk_flat(t, d, k) + [head.reshape(-1)]).to(device).contiguous()
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None) -> list[torch.Tensor]:
-    """sizes = (h1, h2): the widths of the torch network embedded in Net[hidden, hidden] (`tianshou_amd.widths`)."""
-    if sizes is not None:
-        return W.unpad_two_layer(actor_flat_to_torch(flat, obs_dim, act_dim, hidden), *sizes)
-    HID = hidden
-    lay = layout(obs_dim, act_dim, HID)
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None, depth: int | None = None) -> list[torch.Tensor]:
+    """sizes = (h1, ..., hd): the widths of the torch network embedded in Net[hidden] * d (`tianshou_amd.widths`); without
+    sizes the depth is `depth` (default 2)."""
+    d = len(sizes) if sizes is not None else int(depth or 2)
+    H = int(hidden)
+    k, offs = mlp_layout(obs_dim, H, d, 64)
     f = flat.detach()
-    l1 = f[: lay["actor_l2"]].reshape(lay["ka"] + 1, HID)
-    l2 = f[lay["actor_l2"]: lay["actor_head"]].reshape(HID + 1, HID)
-    hd = f[lay["actor_head"]:].reshape(HID + 1, 64)
-    return [l1[:obs_dim].t().contiguous(), l1[lay["ka"]].clone(), l2[:HID].t().contiguous(), l2[HID].clone(),
-            hd[:HID, :act_dim].t().contiguous(), hd[HID, :act_dim].clone(),
-            hd[:HID, 32:32 + act_dim].t().contiguous(), hd[HID, 32:32 + act_dim].clone()]
+    hd = f[offs[d]: offs[d + 1]].reshape(H + 1, 64)
+    out = trunk_unflat(f, obs_dim, k, H, d, offs) + [hd[:H, :act_dim].t().contiguous(), hd[H, :act_dim].clone(),
+                                                     hd[:H, 32:32 + act_dim].t().contiguous(), hd[H, 32:32 + act_dim].clone()]
+    return W.unpad_layers(out, sizes) if sizes is not None else out
 
 
-def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None) -> list[torch.Tensor]:
-    if sizes is not None:
-        return W.unpad_two_layer(critic_flat_to_torch(flat, obs_dim, act_dim, hidden), *sizes)
-    HID = hidden
-    lay = layout(obs_dim, act_dim, HID)
+def critic_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None, depth: int | None = None) -> list[torch.Tensor]:
+    d = len(sizes) if sizes is not None else int(depth or 2)
+    H = int(hidden)
+    k, offs = mlp_layout(obs_dim + act_dim, H, d, 32)
     f = flat.detach()
-    l1 = f[: lay["critic_l2"]].reshape(lay["kc"] + 1, HID)
-    l2 = f[lay["critic_l2"]: lay["critic_head"]].reshape(HID + 1, HID)
-    hd = f[lay["critic_head"]:].reshape(HID + 1, 32)
-    return [l1[: obs_dim + act_dim].t().contiguous(), l1[lay["kc"]].clone(), l2[:HID].t().contiguous(),
-            l2[HID].clone(), hd[:HID, 0].reshape(1, HID).clone(), hd[HID, 0].reshape(1).clone()]
+    hd = f[offs[d]: offs[d + 1]].reshape(H + 1, 32)
+    out = trunk_unflat(f, obs_dim + act_dim, k, H, d, offs) + [hd[:H, 0].reshape(1, H).clone(), hd[H, 0].reshape(1).clone()]
+    return W.unpad_layers(out, sizes) if sizes is not None else out
 
 
 @dataclass
@@ -155,17 +202,18 @@ class SACEngine:
     """State of one SAC learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor, cfg: SACConfig, hidden: int = HID):
-        """`hidden`: width of the Net[hidden, hidden] trunks (utils/net/common.py:246-369; 256 in mujoco_sac.py): any
-        multiple of 32 up to 1024 -- 256 runs on the fused three-layer kernels, other widths on the per-layer GEMMs."""
+                 critic2: torch.Tensor, cfg: SACConfig, hidden: int = HID, depth: int = 2):
+        """`hidden`: width of the Net[hidden] * depth trunks (utils/net/common.py:246-369; [256, 256] in mujoco_sac.py): any
+        multiple of 32 up to 1024, 1 .. 6 hidden layers -- [256, 256] runs on the fused three-layer kernels, everything else on the
+        per-layer GEMMs."""
         if not actor.is_cuda:
             raise RuntimeError("SACEngine needs parameters on an MI355X (no CPU fallback)")
-        self.hidden = int(hidden)
-        lay = layout(obs_dim, act_dim, self.hidden)
-        if actor.numel() != lay["actor_count"] or critic1.numel() != lay["critic_count"] \
-                or critic2.numel() != lay["critic_count"]:
-            raise ValueError("flat parameter vectors do not match ts_sac_layout")
-        self.obs_dim, self.act_dim, self.cfg, self.lay = obs_dim, act_dim, cfg, lay
+        self.hidden, self.depth = int(hidden), int(depth)
+        n_actor, n_critic = mlp_layout(obs_dim, self.hidden, self.depth, 64)[1][-1], mlp_layout(obs_dim + act_dim, self.hidden, self.depth, 32)[1][-1]
+        if actor.numel() != n_actor or critic1.numel() != n_critic or critic2.numel() != n_critic:
+            raise ValueError("flat parameter vectors do not match ts_mlp_layout")
+        self.obs_dim, self.act_dim, self.cfg = obs_dim, act_dim, cfg
+        self.lay = layout(obs_dim, act_dim, self.hidden) if self.depth == 2 else None       # (ts_sac_layout_h: two hidden layers)
         self.device = actor.device
         cl = lambda t: t.detach().float().contiguous().clone()  # noqa: E731
         self.actor, self.critic1, self.critic2 = cl(actor), cl(critic1), cl(critic2)
@@ -202,7 +250,7 @@ class SACEngine:
         noise = None if noise is None else self._f32(noise, (b, self.act_dim))
         act = torch.empty((b, self.act_dim), dtype=torch.float32, device=self.device)
         logp = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_sac_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.ptr(act), _lib.ptr(logp), None, _lib.current_stream(self.device)))
@@ -214,7 +262,7 @@ class SACEngine:
         b = obs_next.shape[0]
         noise = self._f32(noise, (b, self.act_dim))
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_sac_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(obs_next),
@@ -241,7 +289,7 @@ class SACEngine:
             b = idx.numel()
             noise = self._f32(noise, (b, self.act_dim))
             out = torch.empty(b, dtype=torch.float32, device=self.device)
-            use_hidden(self._ws, self.hidden)
+            use_hidden(self._ws, self.hidden, self.depth)
             _lib.check(_lib.load().ts_sac_returns_rows(
                 self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
                 _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(buffer.obs_next),
@@ -273,7 +321,7 @@ class SACEngine:
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st, hp = self._state_c(), self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_sac_update(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
             _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -294,7 +342,7 @@ class SACEngine:
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st, hp = self._state_c(), self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_sac_update_rows(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(buffer.obs), _lib.ptr(buffer.act), _lib.ptr(idx),
             _lib.ptr(returns), _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -323,7 +371,7 @@ class SACEngine:
 
     def update_phase(self, ctx: dict, phase: int, grads: torch.Tensor) -> None:
         st = self._state_c()
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_sac_update_phase(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(ctx["obs"]), _lib.ptr(ctx["act"]),
             _lib.ptr(ctx["returns"]), _lib.ptr(ctx["weight"]), _lib.ptr(ctx["noise"]), _lib.i64(ctx["b"]),

@@ -17,7 +17,8 @@ from . import _lib
 from . import widths as W
 from .buffer import DeviceReplayBuffer, gather_rows
 from .returns import compute_nstep_return
-from .sac import HID, _dense, _l1, critic_flat_from_torch, critic_flat_to_torch, use_hidden  # noqa: F401
+from .sac import (HID, _dense, _l1, critic_flat_from_torch, critic_flat_to_torch, critic_keys, mlp_layout,  # noqa: F401
+                  keys_depth, trunk_flat, trunk_keys, trunk_unflat, use_hidden)
 
 TIANSHOU_ACTOR_KEYS = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias",
                        "preprocess.model.model.2.weight", "preprocess.model.model.2.bias",
@@ -45,30 +46,31 @@ def layout(obs_dim: int, act_dim: int, hidden: int = HID) -> dict[str, int]:
     return dict(zip(["ka", "kc", "actor_count", "critic_count"], (int(v) for v in out)))
 
 
+def actor_keys(depth: int = 2) -> list[str]:
+    return trunk_keys(depth, ("last",))
+
+
 def actor_flat_from_torch(t: list[torch.Tensor], obs_dim: int, act_dim: int, device="cuda", hidden: int | None = None) -> torch.Tensor:
-    """[w1, b1, w2, b2, wa, ba] in torch nn.Linear layout -> flat engine vector (hidden width read off the tensors; unequal
-    widths / no multiple of 32: embedded by zero padding into Net[hidden, hidden], `tianshou_amd.widths`)."""
-    t = W.pad_two_layer(t, hidden or W.common_hidden(t))
-    HID = int(t[0].shape[0])
-    lay = layout(obs_dim, act_dim, HID)
-    head = torch.zeros((HID + 1, 32), dtype=torch.float32)
-    head[:HID, :act_dim] = t[4].detach().float().cpu().t()
-    head[HID, :act_dim] = t[5].detach().float().cpu()
-    return torch.cat([_l1(t[0], t[1], lay["ka"]), _dense(t[2], t[3]), head.reshape(-1)]).to(device).contiguous()
+    """[w1, b1, ..., wd, bd, wa, ba] in torch nn.Linear layout -> flat engine vector (depth and widths read off the tensors; unequal
+    widths / no multiple of 32: embedded by zero padding into Net[hidden] * d, `tianshou_amd.widths`)."""
+    d = W.depth_of(t, 1)
+    H = int(hidden or W.engine_hidden([W.layer_widths(t, 1)]))
+    t = W.pad_layers(t, H, 1)
+    k, _ = mlp_layout(obs_dim, H, d, 32)
+    head = torch.zeros((H + 1, 32), dtype=torch.float32)
+    head[:H, :act_dim] = t[2 * d].detach().float().cpu().t()
+    head[H, :act_dim] = t[2 * d + 1].detach().float().cpu()
+    return torch.cat(trunk_flat(t, d, k) + [head.reshape(-1)]).to(device).contiguous()
 
 
-def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None) -> list[torch.Tensor]:
-    if sizes is not None:
-        return W.unpad_two_layer(actor_flat_to_torch(flat, obs_dim, act_dim, hidden), *sizes)
-    HID = hidden
-    lay = layout(obs_dim, act_dim, HID)
+def actor_flat_to_torch(flat: torch.Tensor, obs_dim: int, act_dim: int, hidden: int = HID, sizes=None, depth: int | None = None) -> list[torch.Tensor]:
+    d = len(sizes) if sizes is not None else int(depth or 2)
+    H = int(hidden)
+    k, offs = mlp_layout(obs_dim, H, d, 32)
     f = flat.detach()
-    n1 = (lay["ka"] + 1) * HID
-    l1 = f[:n1].reshape(lay["ka"] + 1, HID)
-    l2 = f[n1:n1 + (HID + 1) * HID].reshape(HID + 1, HID)
-    hd = f[n1 + (HID + 1) * HID:].reshape(HID + 1, 32)
-    return [l1[:obs_dim].t().contiguous(), l1[lay["ka"]].clone(), l2[:HID].t().contiguous(), l2[HID].clone(),
-            hd[:HID, :act_dim].t().contiguous(), hd[HID, :act_dim].clone()]
+    hd = f[offs[d]: offs[d + 1]].reshape(H + 1, 32)
+    out = trunk_unflat(f, obs_dim, k, H, d, offs) + [hd[:H, :act_dim].t().contiguous(), hd[H, :act_dim].clone()]
+    return W.unpad_layers(out, sizes) if sizes is not None else out
 
 
 @dataclass
@@ -93,17 +95,19 @@ class TD3Engine:
     """State of one TD3 / DDPG learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor | None, cfg: TD3Config, hidden: int = HID):
-        """`hidden`: width of the Net[hidden, hidden] trunks (any multiple of 32 up to 1024; 256 in the examples)."""
+                 critic2: torch.Tensor | None, cfg: TD3Config, hidden: int = HID, depth: int = 2):
+        """`hidden` / `depth`: the Net[hidden] * depth trunks (any multiple of 32 up to 1024, 1 .. 6 hidden layers; [256, 256]
+        in the examples)."""
         if not actor.is_cuda:
             raise RuntimeError("TD3Engine needs parameters on an MI355X (no CPU fallback)")
         if cfg.twin != (critic2 is not None):
             raise ValueError("cfg.twin and critic2 disagree")
-        self.hidden = int(hidden)
-        lay = layout(obs_dim, act_dim, self.hidden)
-        if actor.numel() != lay["actor_count"] or critic1.numel() != lay["critic_count"]:
-            raise ValueError("flat parameter vectors do not match ts_td3_layout")
-        self.obs_dim, self.act_dim, self.cfg, self.lay, self.device = obs_dim, act_dim, cfg, lay, actor.device
+        self.hidden, self.depth = int(hidden), int(depth)
+        if actor.numel() != mlp_layout(obs_dim, self.hidden, self.depth, 32)[1][-1] \
+                or critic1.numel() != mlp_layout(obs_dim + act_dim, self.hidden, self.depth, 32)[1][-1]:
+            raise ValueError("flat parameter vectors do not match ts_mlp_layout")
+        self.obs_dim, self.act_dim, self.cfg, self.device = obs_dim, act_dim, cfg, actor.device
+        self.lay = layout(obs_dim, act_dim, self.hidden) if self.depth == 2 else None       # (ts_td3_layout_h: two hidden layers)
         cl = lambda t: None if t is None else t.detach().float().contiguous().clone()   # noqa: E731
         z = lambda t: None if t is None else torch.zeros_like(t)                         # noqa: E731
         self.actor, self.critic1, self.critic2 = cl(actor), cl(critic1), cl(critic2)
@@ -122,7 +126,7 @@ class TD3Engine:
     def policy_forward(self, obs) -> torch.Tensor:
         obs = self._f32(obs)
         act = torch.empty((obs.shape[0], self.act_dim), dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_td3_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.i64(obs.shape[0]), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.f64(self.cfg.max_action), _lib.ptr(act), _lib.current_stream(self.device)))
@@ -136,7 +140,7 @@ class TD3Engine:
             raise ValueError("TD3 needs the target-smoothing noise (the torch.randn draws of td3.py:196)")
         noise = self._f32(noise, (b, self.act_dim)) if cfg.twin else None
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_td3_target_q(
             self._ws.handle, _lib.ptr(self.actor_old), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(obs_next), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -173,7 +177,7 @@ class TD3Engine:
         st = TD3StateC(*[None if getattr(self, n) is None else getattr(self, n).data_ptr() for n in names])
         hp = TD3HParams(cfg.actor_lr * lr_scale, cfg.critic_lr * lr_scale, cfg.betas[0], cfg.betas[1], cfg.adam_eps,
                         cfg.tau, cfg.max_action, int(upd), 0)
-        use_hidden(self._ws, self.hidden)
+        use_hidden(self._ws, self.hidden, self.depth)
         _lib.check(_lib.load().ts_td3_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cnt), _lib.i64(max(self.actor_steps, 1)), _lib.ptr(obs),
             _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight), _lib.i64(b), _lib.i64(self.obs_dim),
