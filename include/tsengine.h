@@ -925,6 +925,11 @@ int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
  * into the forward GEMM's epilogue and into the input-gradient GEMM's mask). */
 #define TS_MLP_MAX_HIDDEN_LAYERS 6
 int ts_mlp_set_trunk(ts_workspace* ws, int64_t hidden, int64_t depth);
+/* ContinuousActorProbabilistic(unbounded=False) -- the class default, utils/net/continuous.py:194, 230-231: mu = max_action *
+ * tanh(mu) in front of SAC's / REDQ's Gaussian (the examples pass unbounded=True).  A property of the workspace like the trunk:
+ * applies to every ts_sac_* / ts_redq_* entry point subsequently called with `ws` -- forward, target, update (the gradient goes
+ * back through max_action * (1 - tanh^2)).  0 = unbounded (the default). */
+int ts_sac_set_actor_bound(ts_workspace* ws, double max_action);
 int ts_mlp_layout(int64_t in_dim, int64_t hidden, int64_t depth, int64_t head_cols, int64_t* h_out);
 
 /* SACPolicy.forward (sac.py:108-131) with rsample() = loc + noise * scale; noise NULL = dist.mode

@@ -1542,10 +1542,13 @@ def main() -> None:
 
 def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int,
             seed: int, auto_alpha: bool, alpha: float = 0.2, n_step: int = 1, tau: float = 0.005,
-            gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4, hidden=256) -> None:
+            gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4, hidden=256,
+            max_action: float = 0.0) -> None:
     """Runs the reference SAC.update() (nets as in examples/mujoco/mujoco_sac.py:82-104) on a synthetic
     VectorReplayBuffer, recording the rsample() noise of every policy call and the outputs of every update.
-    hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- Net(hidden_sizes=...) takes any widths."""
+    hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- Net(hidden_sizes=...) takes any widths.
+    max_action > 0: the actor is built with the class default `unbounded=False` (mu = max_action * tanh(mu)) instead of the
+    examples' `unbounded=True`."""
     import torch.distributions.normal as tdn
     from tianshou.algorithm.modelfree.sac import SAC, AutoAlpha, SACPolicy
     from oracle import oracle_sac as OS
@@ -1555,8 +1558,13 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
     sa_, sc_ = OS.layer_sizes(hidden)              # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
     AK, CK = OS.trunk_keys(len(sa_), ("mu", "sigma")), OS.trunk_keys(len(sc_), ("last",))
     net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(sa_))
-    actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
-                                         conditioned_sigma=True)
+    if max_action > 0.0:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action,
+                                             conditioned_sigma=True)           # unbounded=False: the class default
+        assert not actor._unbounded
+    else:
+        actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
+                                             conditioned_sigma=True)
     net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
     net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
     critic1, critic2 = ContinuousCritic(preprocess_net=net_c1), ContinuousCritic(preprocess_net=net_c2)
@@ -1639,7 +1647,7 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
         SAC._preprocess_batch = orig_pre
     cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
                target_entropy=float(-act_dim), log_alpha0=0.0, actor_lr=actor_lr, critic_lr=critic_lr,
-               alpha_lr=alpha_lr)
+               alpha_lr=alpha_lr, **({"max_action": max_action} if max_action > 0.0 else {}))
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"sac_{tag}.npz"), **out)
@@ -1762,11 +1770,14 @@ def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: i
     torch.manual_seed(seed)
     from oracle import oracle_sac as OS_
 
-    hw = OS_.hidden_widths(hidden)          # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
-    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2])),
+    sa_, sc_ = OS_.layer_sizes(hidden)      # int, (h1, h2), (actor h1, actor h2, critic h1, critic h2) or a nested pair of any depth
+    hw = tuple(sa_) + tuple(sc_)
+    DK = OS_.trunk_keys(len(sa_), ("last",))
+    assert len(sa_) == len(sc_)
+    actor = DiscreteActor(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sa_)),
                           action_shape=n_act, softmax_output=False)
-    critic1 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[2:])), last_size=n_act)
-    critic2 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(hw[2:])), last_size=n_act)
+    critic1 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sc_)), last_size=n_act)
+    critic2 = DiscreteCritic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sc_)), last_size=n_act)
     policy = DiscreteSACPolicy(actor=actor, action_space=gym.spaces.Discrete(n_act))
     target_entropy = 0.98 * float(np.log(n_act))
     al = AutoAlpha(target_entropy, 0.0, AdamOptimizerFactory(lr=alpha_lr)) if auto_alpha else alpha
@@ -1776,13 +1787,15 @@ def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: i
                             n_step_return_horizon=n_step)
     out: dict[str, np.ndarray] = {}
     out["dims"] = np.array([E, slots, steps, obs_dim, n_act, max(hw), batch, n_updates, seed, int(auto_alpha), n_step])
-    if len(set(hw)) > 1:
+    if len(sa_) != 2:
+        out["hidden_actor"], out["hidden_critic"] = np.array(sa_, np.int64), np.array(sc_, np.int64)
+    elif len(set(hw)) > 1:
         out["hidden"] = np.array(hw, np.int64)
-    p0 = ODS.init_params(obs_dim, n_act, hw, seed)
+    p0 = ODS.init_params(obs_dim, n_act, (sa_, sc_), seed)
     for pd, mod in zip(p0, (actor, critic1, critic2)):
         sd = mod.state_dict()
-        assert list(sd.keys()) == ODS.TIANSHOU_KEYS, list(sd.keys())
-        for k_ref, k in zip(ODS.TIANSHOU_KEYS, ODS.NET_ORDER):
+        assert list(sd.keys()) == DK, list(sd.keys())
+        for k_ref, k in zip(DK, ODS.net_order(len(sa_))):
             assert torch.equal(sd[k_ref], pd[k]), f"oracle init differs from the reference at {k}"
 
     buf = PrioritizedVectorReplayBuffer(E * slots, E, alpha=0.6, beta=0.4)
@@ -1832,7 +1845,7 @@ def gen_dsac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, n_act: i
             for name, mod in (("actor", actor), ("critic1", critic1), ("critic2", critic2),
                               ("critic1_old", algorithm.critic_old.module), ("critic2_old", algorithm.critic2_old.module)):
                 sd = mod.state_dict()
-                out[f"u{u}_{name}"] = torch.cat([sd[k].reshape(-1) for k in ODS.TIANSHOU_KEYS]).numpy()[::5].copy()
+                out[f"u{u}_{name}"] = torch.cat([sd[k].reshape(-1) for k in DK]).numpy()[::5].copy()
     finally:
         DiscreteSAC._preprocess_batch, DiscreteSAC._update_with_batch = orig_pre, orig_upd
     cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
@@ -1864,15 +1877,18 @@ def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim:
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
-    hw = OS.hidden_widths(hidden)
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hw[:2]))
+    sa_, sc_ = OS.layer_sizes(hidden)       # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
+    hw = tuple(sa_) + tuple(sc_)
+    AK = OS.trunk_keys(len(sa_), ("mu", "sigma"))
+    CK = [k.replace(".bias", ".bias_weights") for k in OS.trunk_keys(len(sc_), ("last",))]
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(sa_))
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                          conditioned_sigma=True)
 
     def linear(x: int, y: int):
         return EnsembleLinear(ensemble, x, y)
 
-    net_c = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(hw[2:]), concat=True, linear_layer=linear)
+    net_c = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True, linear_layer=linear)
     critic = ContinuousCritic(preprocess_net=net_c, linear_layer=linear, flatten_input=False)
     space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
     policy = REDQPolicy(actor=actor, action_space=space)
@@ -1884,14 +1900,16 @@ def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim:
     out: dict[str, np.ndarray] = {}
     out["dims"] = np.array([E, slots, steps, obs_dim, act_dim, batch, n_updates, seed, int(auto_alpha), n_step, ensemble,
                             subset, actor_delay, int(target_mode == "mean")])
-    if hidden != 256:
+    if len(sa_) != 2 or len(sc_) != 2:
+        out["hidden_actor"], out["hidden_critic"] = np.array(sa_, np.int64), np.array(sc_, np.int64)
+    elif hidden != 256:
         out["hidden"] = np.array(hw, np.int64)
-    a0, c0 = OR.init_params(obs_dim, act_dim, ensemble, seed, hw)
+    a0, c0 = OR.init_params(obs_dim, act_dim, ensemble, seed, (sa_, sc_))
     sa, sc = actor.state_dict(), critic.state_dict()
-    assert list(sc.keys()) == OR.TIANSHOU_CRITIC_KEYS, list(sc.keys())
-    for k_ref, k in zip(OS.TIANSHOU_ACTOR_KEYS, OS.ACTOR_ORDER):
+    assert list(sc.keys()) == CK, list(sc.keys())
+    for k_ref, k in zip(AK, OS.actor_order(len(sa_))):
         assert torch.equal(sa[k_ref], a0[k]), f"oracle actor init differs at {k}"
-    for k_ref, k in zip(OR.TIANSHOU_CRITIC_KEYS, OR.CRITIC_ORDER):
+    for k_ref, k in zip(CK, OS.critic_order(len(sc_))):
         assert torch.equal(sc[k_ref], c0[k]), f"oracle critic init differs at {k}"
 
     buf = VectorReplayBuffer(E * slots, E)
@@ -1947,9 +1965,9 @@ def gen_redq(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim:
             out[f"u{u}_stats"] = np.array([stats.actor_loss, stats.critic_loss, stats.alpha,
                                            stats.alpha_loss if stats.alpha_loss is not None else np.nan])
             sa, sc, so = actor.state_dict(), critic.state_dict(), algorithm.critic_old.module.state_dict()
-            out[f"u{u}_actor"] = torch.cat([sa[k].reshape(-1) for k in OS.TIANSHOU_ACTOR_KEYS]).numpy()[::61].copy()
-            out[f"u{u}_critic"] = torch.cat([sc[k].reshape(-1) for k in OR.TIANSHOU_CRITIC_KEYS]).numpy()[::61].copy()
-            out[f"u{u}_critic_old"] = torch.cat([so[k].reshape(-1) for k in OR.TIANSHOU_CRITIC_KEYS]).numpy()[::61].copy()
+            out[f"u{u}_actor"] = torch.cat([sa[k].reshape(-1) for k in AK]).numpy()[::61].copy()
+            out[f"u{u}_critic"] = torch.cat([sc[k].reshape(-1) for k in CK]).numpy()[::61].copy()
+            out[f"u{u}_critic_old"] = torch.cat([so[k].reshape(-1) for k in CK]).numpy()[::61].copy()
     finally:
         tdn._standard_normal, np.random.choice, REDQ._preprocess_batch = orig_sn, orig_choice, orig_pre
     cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
@@ -2008,6 +2026,15 @@ def gen_depth() -> None:
             hidden=((64, 64, 32, 32), (48, 64, 64, 40)), max_action=1.5)
     gen_td3("ddpg_depth1", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=34,
             hidden=((128,), (64,)))
+    # SAC with the class-default BOUNDED actor (unbounded=False, max_action 1.5) on a two-layer and a three-layer trunk
+    gen_sac("bounded", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=37, auto_alpha=True, max_action=1.5)
+    gen_sac("bounded_depth3", E=3, slots=30, steps=30, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=38, auto_alpha=False,
+            alpha=0.1, hidden=((48, 64, 40), (64, 32, 32)), max_action=0.8)
+    # DiscreteSAC with three hidden layers (actor [40, 72, 24], critics [56, 24, 48]); REDQ with one (actor [64], ensemble [48])
+    gen_dsac("depth3", E=3, slots=30, steps=40, obs_dim=13, n_act=5, hidden=((40, 72, 24), (56, 24, 48)), batch=32, n_updates=3, seed=35,
+             auto_alpha=True)
+    gen_redq("depth1", E=3, slots=30, steps=40, obs_dim=11, act_dim=3, batch=32, n_updates=4, seed=36, ensemble=4, subset=2,
+             actor_delay=2, target_mode="mean", auto_alpha=True, hidden=((64,), (48,)))
 
 
 def gen_sac_all() -> None:

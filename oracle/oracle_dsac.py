@@ -32,24 +32,38 @@ def net_shapes(obs_dim: int, n_act: int, hidden: int):
             "head.w": (n_act, hidden), "head.b": (n_act,)}
 
 
+def net_order(depth: int = 2) -> list[str]:
+    ks = []
+    for i in range(1, depth + 1):
+        ks += [f"l{i}.w", f"l{i}.b"]
+    return ks + ["head.w", "head.b"]
+
+
 def init_params(obs_dim: int, n_act: int, hidden, seed: int):
     """Same RNG consumption as torch.manual_seed(seed) followed by the constructions of
-    test_discrete_sac.py:88-97 (actor net, actor head, critic-1 net, head, critic-2 net, head)."""
+    test_discrete_sac.py:88-97 (actor net, actor head, critic-1 net, head, critic-2 net, head).  `hidden`: see
+    oracle_sac.layer_sizes (any depth since round 6)."""
     torch.manual_seed(seed)
     out = []
-    hw = OS.hidden_widths(hidden)           # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
+    sa, sc = OS.layer_sizes(hidden)
     for net in range(3):
-        h1, h2 = hw[:2] if net == 0 else hw[2:]
-        ls = [torch.nn.Linear(obs_dim, h1), torch.nn.Linear(h1, h2), torch.nn.Linear(h2, n_act)]
-        out.append({k: t.detach().clone() for k, t in
-                    zip(NET_ORDER, [x for lin in ls for x in (lin.weight, lin.bias)])})
+        sizes = sa if net == 0 else sc
+        ls, k = [], obs_dim
+        for h in sizes:
+            ls.append(torch.nn.Linear(k, h))
+            k = h
+        ls.append(torch.nn.Linear(k, n_act))
+        out.append({k2: t.detach().clone() for k2, t in
+                    zip(net_order(len(sizes)), [x for lin in ls for x in (lin.weight, lin.bias)])})
     return out                                                # actor, critic1, critic2
 
 
 def net_forward(p, obs) -> torch.Tensor:
     x = torch.as_tensor(obs, dtype=torch.float32).flatten(1)
-    x = F.relu(F.linear(x, p["l1.w"], p["l1.b"]))
-    x = F.relu(F.linear(x, p["l2.w"], p["l2.b"]))
+    i = 1
+    while f"l{i}.w" in p:
+        x = F.relu(F.linear(x, p[f"l{i}.w"], p[f"l{i}.b"]))
+        i += 1
     return F.linear(x, p["head.w"], p["head.b"])
 
 

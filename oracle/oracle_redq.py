@@ -45,21 +45,23 @@ def _ensemble_linear(E: int, fin: int, fout: int):
 
 
 def init_params(obs_dim: int, act_dim: int, E: int, seed: int, hidden=256):
-    """Same RNG consumption as torch.manual_seed(seed) followed by test_redq.py:86-107."""
+    """Same RNG consumption as torch.manual_seed(seed) followed by test_redq.py:86-107.  `hidden`: see oracle_sac.layer_sizes
+    (any depth since round 6)."""
     torch.manual_seed(seed)
     L = torch.nn.Linear
-    a1, a2, c1, c2 = OS.hidden_widths(hidden)          # int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2)
-    mods = [L(obs_dim, a1), L(a1, a2), L(a2, act_dim), L(a2, act_dim)]
-    actor = dict(zip(OS.ACTOR_ORDER, [t.detach().clone() for m in mods for t in (m.weight, m.bias)]))
-    ts = [t for dims in ((obs_dim + act_dim, c1), (c1, c2), (c2, 1)) for t in _ensemble_linear(E, *dims)]
-    return actor, dict(zip(CRITIC_ORDER, ts))
+    sa, sc = OS.layer_sizes(hidden)
+    mods = OS._linears(obs_dim, sa) + [L(sa[-1], act_dim), L(sa[-1], act_dim)]
+    actor = dict(zip(OS.actor_order(len(sa)), [t.detach().clone() for m in mods for t in (m.weight, m.bias)]))
+    dims = list(zip([obs_dim + act_dim] + list(sc[:-1]), sc)) + [(sc[-1], 1)]
+    ts = [t for dm in dims for t in _ensemble_linear(E, *dm)]
+    return actor, dict(zip(OS.critic_order(len(sc)), ts))
 
 
 def critic_forward(p, obs, act) -> torch.Tensor:
     """-> [E, B, 1]"""
-    x = torch.cat([obs.flatten(1), act.flatten(1)], dim=1)
-    h = F.relu(torch.matmul(x, p["w1"]) + p["b1"])
-    h = F.relu(torch.matmul(h, p["w2"]) + p["b2"])
+    h = torch.cat([obs.flatten(1), act.flatten(1)], dim=1)
+    for i in range(1, OS.depth_of(p) + 1):
+        h = F.relu(torch.matmul(h, p[f"w{i}"]) + p[f"b{i}"])
     return torch.matmul(h, p["wq"]) + p["bq"]
 
 
@@ -87,7 +89,7 @@ class REDQState:
 def target_q(st: REDQState, cfg: REDQConfig, obs_next, noise, subset) -> torch.Tensor:
     with torch.no_grad():
         obs_next = torch.as_tensor(obs_next, dtype=torch.float32)
-        act, logp, _, _ = OS.policy_forward(st.actor, obs_next, torch.as_tensor(noise, dtype=torch.float32))
+        act, logp, _, _ = OS.policy_forward(st.actor, obs_next, torch.as_tensor(noise, dtype=torch.float32), cfg.max_action)
         qs = critic_forward(st.critic_old, obs_next, act)[np.asarray(subset), ...]
         tq = torch.min(qs, dim=0)[0] if cfg.target_mode == "min" else torch.mean(qs, dim=0)
         return tq - OS.alpha_value(st, cfg) * logp
@@ -110,7 +112,7 @@ def update_with_batch(st: REDQState, cfg: REDQConfig, obs, act, returns, noise=N
     if st.critic_gradient_step % cfg.actor_delay == 0:
         alpha = OS.alpha_value(st, cfg)
         pa = {k: v.clone().requires_grad_(True) for k, v in st.actor.items()}
-        a, logp, _, _ = OS.policy_forward(pa, obs, torch.as_tensor(noise, dtype=torch.float32))
+        a, logp, _, _ = OS.policy_forward(pa, obs, torch.as_tensor(noise, dtype=torch.float32), cfg.max_action)
         qa = critic_forward(st.critic, obs, a).mean(dim=0).flatten()
         actor_loss = (alpha * logp.flatten() - qa).mean()
         ga = OS._grads(actor_loss, pa)

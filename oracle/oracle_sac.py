@@ -164,9 +164,13 @@ def flatten(p: dict, order: list[str]) -> torch.Tensor:
     return torch.cat([p[k].reshape(-1) for k in order])
 
 
-def actor_forward(p, obs):
+def actor_forward(p, obs, max_action: float = 0.0):
+    """max_action > 0: ContinuousActorProbabilistic(unbounded=False), the class default -- mu = max_action * tanh(mu)
+    (continuous.py:230-231); 0: unbounded=True as in examples/mujoco/mujoco_sac.py."""
     h = trunk_forward(p, obs)
     mu = F.linear(h, p["wmu"], p["bmu"])
+    if max_action > 0.0:
+        mu = max_action * torch.tanh(mu)
     sigma = torch.clamp(F.linear(h, p["wsig"], p["bsig"]), min=SIGMA_MIN, max=SIGMA_MAX).exp()
     return mu, sigma
 
@@ -176,10 +180,10 @@ def critic_forward(p, obs, act):
     return F.linear(trunk_forward(p, x), p["wq"], p["bq"])
 
 
-def policy_forward(p, obs, noise):
+def policy_forward(p, obs, noise, max_action: float = 0.0):
     """SACPolicy.forward in training mode with rsample() = loc + noise * scale (sac.py:108-131)
     -> (squashed action [B, A], log_prob [B, 1], mu, sigma)."""
-    mu, sigma = actor_forward(p, obs)
+    mu, sigma = actor_forward(p, obs, max_action)
     dist = Independent(Normal(loc=mu, scale=sigma), 1)
     act = mu + noise * sigma                                   # Normal.rsample
     log_prob = dist.log_prob(act).unsqueeze(-1)
@@ -202,6 +206,7 @@ class SACConfig:
     alpha_lr: float = 3e-4
     betas: tuple[float, float] = (0.9, 0.999)
     adam_eps: float = 1e-8
+    max_action: float = 0.0             # > 0: bounded actor (unbounded=False, the class default); 0: unbounded=True
 
 
 @dataclass
@@ -258,7 +263,7 @@ def alpha_value(st: SACState, cfg: SACConfig) -> float:
 def target_q(st: SACState, cfg: SACConfig, obs_next, noise) -> torch.Tensor:
     """ddpg.py:327-339 + sac.py:290-296 -> [B, 1]."""
     with torch.no_grad():
-        act, logp, _, _ = policy_forward(st.actor, obs_next, noise)
+        act, logp, _, _ = policy_forward(st.actor, obs_next, noise, cfg.max_action)
         q = torch.min(critic_forward(st.critic1_old, obs_next, act), critic_forward(st.critic2_old, obs_next, act))
         return q - alpha_value(st, cfg) * logp
 
@@ -290,7 +295,7 @@ def update_with_batch(st: SACState, cfg: SACConfig, obs, act, returns, noise, we
     out["weight"] = (tds[0] + tds[1]) / 2.0                                       # sac.py:306
     alpha = alpha_value(st, cfg)
     p = {k: v.clone().requires_grad_(True) for k, v in st.actor.items()}
-    a, logp, _, _ = policy_forward(p, obs, noise)
+    a, logp, _, _ = policy_forward(p, obs, noise, cfg.max_action)
     q1a = critic_forward(st.critic1, obs, a).flatten()
     q2a = critic_forward(st.critic2, obs, a).flatten()
     actor_loss = (alpha * logp.flatten() - torch.min(q1a, q2a)).mean()
@@ -314,7 +319,8 @@ def update_with_batch(st: SACState, cfg: SACConfig, obs, act, returns, noise, we
     return out
 
 
-def gradients(actor, critic1, critic2, alpha: float, obs, act, returns, noise, weight=None, dtype=torch.float32):
+def gradients(actor, critic1, critic2, alpha: float, obs, act, returns, noise, weight=None, dtype=torch.float32,
+              max_action: float = 0.0):
     """The three loss gradients of one update with the critics held fixed (what update_with_batch computes when
     every learning rate is 0), evaluated in `dtype` -- float64 gives the yardstick for float32 rounding noise."""
     cast = lambda d: {k: v.to(dtype).clone().requires_grad_(True) for k, v in d.items()}  # noqa: E731
@@ -326,7 +332,7 @@ def gradients(actor, critic1, critic2, alpha: float, obs, act, returns, noise, w
         td = critic_forward(p, obs, act).flatten() - ret
         out[name + "_grads"] = _grads((td.pow(2) * w).mean(), p)
     p = cast(actor)
-    a, logp, _, _ = policy_forward(p, obs, noise)
+    a, logp, _, _ = policy_forward(p, obs, noise, max_action)
     c1 = {k: v.to(dtype) for k, v in critic1.items()}
     c2 = {k: v.to(dtype) for k, v in critic2.items()}
     loss = (alpha * logp.flatten() - torch.min(critic_forward(c1, obs, a).flatten(),

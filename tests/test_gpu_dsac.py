@@ -26,10 +26,11 @@ def make_engine(obs_dim, n_act, hidden, seed, cfg):
 
     from tianshou_amd import widths as W
 
-    nets = ODS.init_params(obs_dim, n_act, hidden, seed)            # hidden: int or (actor h1, actor h2, critic h1, critic h2)
-    H = W.common_hidden(*[[p[k] for k in ODS.NET_ORDER] for p in nets])
-    flats = [DS.net_flat_from_torch([p[k] for k in ODS.NET_ORDER], obs_dim, n_act, H) for p in nets]
-    eng = DS.DiscreteSACEngine(obs_dim, n_act, H, *flats, SACConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}))
+    nets = ODS.init_params(obs_dim, n_act, hidden, seed)            # hidden: int, (actor h1, actor h2, critic h1, critic h2) or a nested pair
+    H = W.engine_hidden([W.layer_widths(list(p.values()), 1) for p in nets])
+    flats = [DS.net_flat_from_torch(list(p.values()), obs_dim, n_act, H) for p in nets]
+    eng = DS.DiscreteSACEngine(obs_dim, n_act, H, *flats, SACConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}),
+                               depth=(len(nets[0]) - 2) // 2)
     return eng, nets
 
 
@@ -88,16 +89,18 @@ def test_update_gradients_vs_oracle(obs_dim, n_act, hidden, B, auto, weighted):
     assert torch.count_nonzero(head[:, n_act:]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3"])
 def test_dsac_update_matches_reference_golden(tag):
-    """(`widths`: actor Net[40, 72], critics Net[56, 24] in the reference, embedded in Net[96, 96]: tianshou_amd.widths.)"""
+    """(`widths`: actor Net[40, 72], critics Net[56, 24] in the reference, embedded in Net[96, 96]: tianshou_amd.widths.  `depth3`:
+    THREE hidden layers, actor [40, 72, 24], critics [56, 24, 48], embedded in Net[96] * 3 -- gen_golden.py::gen_depth.)"""
     from tianshou_amd import dsac as DS
     from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_dsac(tag)
-    hw = OS.hidden_widths(d["hidden"])
+    sa, sc = OS.layer_sizes(d["hidden"])
     eng, _ = make_engine(d["obs_dim"], d["n_act"], d["hidden"], d["seed"], cfg)
+    assert eng.depth == len(sa)
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
                              truncated=g["truncated"], obs=g["obs"], act=g["act"], obs_next=g["obs_next"])
@@ -113,10 +116,10 @@ def test_dsac_update_matches_reference_golden(tag):
             np.testing.assert_allclose(s[4], ref[4], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(w.cpu().numpy(), g[f"u{u}_new_weight"], rtol=1e-5, atol=2e-5)
         for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
-            sz = hw[:2] if name == "actor" else hw[2:]
-            full = DS.net_flat_to_torch(getattr(eng, name), d["obs_dim"], d["n_act"], eng.hidden)
-            assert W.padding_is_zero(full, *sz), name
-            flat = torch.cat([t.reshape(-1) for t in W.unpad_two_layer(full, *sz)])
+            sz = sa if name == "actor" else sc
+            full = DS.net_flat_to_torch(getattr(eng, name), d["obs_dim"], d["n_act"], eng.hidden, depth=eng.depth)
+            assert W.padding_is_zero_layers(full, sz), name
+            flat = torch.cat([t.reshape(-1) for t in W.unpad_layers(full, sz)])
             lr = cfg.actor_lr if name == "actor" else cfg.critic_lr
             np.testing.assert_allclose(flat.cpu().numpy()[::5], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr, err_msg=name)
 

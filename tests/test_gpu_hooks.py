@@ -544,8 +544,10 @@ def test_hip_sac_default_mode_equals_the_reference_exact_mode(monkeypatch):
     assert torch.equal(flat(lazy), flat(ref))
 
 
-def test_hip_discrete_sac_hooks_against_oracle():
-    """HipDiscreteSAC (integration.make_hip_discrete_sac over the stand-ins) on the real engine with Net[128, 128] trunks, 7
+@pytest.mark.parametrize("sizes", [((128, 128), (128, 128)), ((96, 40, 72), (56, 64, 24))], ids=["net_128_128", "three_layers"])
+def test_hip_discrete_sac_hooks_against_oracle(sizes):
+    """(`three_layers`: round 6, any depth -- actor Net[96, 40, 72], critics Net[56, 64, 24], embedded in Net[96] * 3.)
+    HipDiscreteSAC (integration.make_hip_discrete_sac over the stand-ins) on the real engine with Net[128, 128] trunks, 7
     actions, auto-tuned alpha: incremental device mirror of a growing host buffer, n-step-1 target from the expectation under
     the actor with the lagged critics (discrete_sac.py:147-155), critic / actor / alpha steps with the UPDATED critics in
     the actor loss (:157-196), Polyak, write-back of five networks + four optimizers - against oracle_dsac fed with the same
@@ -554,16 +556,18 @@ def test_hip_discrete_sac_hooks_against_oracle():
     from oracle import oracle_sac as OS
     from tianshou_amd.integration import make_hip_discrete_sac
 
-    obs_dim, n_act, E, B, H = 19, 7, 4, 64, 128
+    obs_dim, n_act, E, B = 19, 7, 4, 64
     HipDSAC = make_hip_discrete_sac(ref=SI)
     torch.manual_seed(17)
-    actor = SI.DiscreteActor(SI.Net(obs_dim, [H, H], nn.ReLU), n_act, softmax_output=False)
-    c1 = SI.DiscreteCritic(SI.Net(obs_dim, [H, H], nn.ReLU), last_size=n_act)
-    c2 = SI.DiscreteCritic(SI.Net(obs_dim, [H, H], nn.ReLU), last_size=n_act)
+    actor = SI.DiscreteActor(SI.Net(obs_dim, list(sizes[0]), nn.ReLU), n_act, softmax_output=False)
+    c1 = SI.DiscreteCritic(SI.Net(obs_dim, list(sizes[1]), nn.ReLU), last_size=n_act)
+    c2 = SI.DiscreteCritic(SI.Net(obs_dim, list(sizes[1]), nn.ReLU), last_size=n_act)
+    NET_ORDER = ODS.net_order(len(sizes[0]))
     tgt_ent = 0.98 * float(np.log(n_act))
     alpha = SI.AutoAlpha(tgt_ent, -0.4, 3e-4)
     algo = HipDSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.02, gamma=0.96, alpha=alpha, device="cuda").to("cuda")
-    grab = lambda mod: {k: mod.state_dict()[n].detach().cpu().clone() for k, n in zip(ODS.NET_ORDER, ODS.TIANSHOU_KEYS)}   # noqa: E731
+    assert algo._hip_depth == len(sizes[0]) and algo._hip_sizes["critic2"] == tuple(sizes[1])
+    grab = lambda mod: {k: t.detach().cpu().clone() for k, t in zip(NET_ORDER, mod.state_dict().values())}   # noqa: E731
     cfg = OS.SACConfig(gamma=0.96, tau=0.02, n_step=1, auto_alpha=True, target_entropy=tgt_ent, log_alpha0=-0.4, actor_lr=1e-3,
                        critic_lr=1e-3, alpha_lr=3e-4)
     st = OS.SACState.create(grab(actor), grab(c1), grab(c2), cfg)
@@ -593,8 +597,8 @@ def test_hip_discrete_sac_hooks_against_oracle():
                                    rtol=2e-5, atol=2e-6)
         for mod, want in ((actor, st.actor), (c1, st.critic1), (c2, st.critic2), (algo.critic_old.module, st.critic1_old),
                           (algo.critic2_old.module, st.critic2_old)):
-            for name, k in zip(ODS.TIANSHOU_KEYS, ODS.NET_ORDER):
-                np.testing.assert_allclose(mod.state_dict()[name].cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3,
+            for (name, t), k in zip(mod.state_dict().items(), NET_ORDER):
+                np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3,
                                            err_msg=f"update {u}: {name}")
         assert abs(float(alpha._log_alpha.detach()) - float(st.log_alpha)) < 0.02 * 3e-4
     w = c2.preprocess.model.model[0].weight
@@ -604,8 +608,10 @@ def test_hip_discrete_sac_hooks_against_oracle():
     assert len(algo._hip_mirror) == len(buf) and np.array_equal(algo._hip_mirror.act.cpu().numpy(), buf.act)
 
 
-def test_hip_redq_hooks_against_oracle():
-    """HipREDQ (integration.make_hip_redq over the stand-ins) on the real engine, the nets of test/continuous/test_redq.py:86-107
+@pytest.mark.parametrize("sizes", [((256, 256), (256, 256)), ((64,), (48,))], ids=["net_256_256", "one_layer"])
+def test_hip_redq_hooks_against_oracle(sizes):
+    """(`one_layer`: round 6, any depth -- actor Net[64], EnsembleLinear critic [48], embedded in Net[64].)
+    HipREDQ (integration.make_hip_redq over the stand-ins) on the real engine, the nets of test/continuous/test_redq.py:86-107
     with 4 ensemble members: target from a random subset of 2 lagged members (redq.py:248-261; torch.randn then
     np.random.choice, in the reference's order), one critic step on the whole ensemble, the actor / alpha step every 2nd
     update against the ensemble mean (:263-304), Polyak, write-back of the actor, both ensembles and three optimizers --
@@ -614,12 +620,13 @@ def test_hip_redq_hooks_against_oracle():
     from oracle import oracle_sac as OS
     from tianshou_amd.integration import make_hip_redq
 
-    obs_dim, act_dim, E, S, B, H = 11, 3, 4, 2, 64, 256
+    obs_dim, act_dim, E, S, B, H = 11, 3, 4, 2, 64, sizes[1][-1]
     HipREDQ = make_hip_redq(ref=SI)
     torch.manual_seed(61)
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [H, H], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sizes[0]), nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
     lin = lambda x, y: SI.EnsembleLinear(E, x, y)   # noqa: E731
-    critic = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [H, H], nn.ReLU, linear_layer=lin), linear_layer=lin)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sizes[1]), nn.ReLU, linear_layer=lin), linear_layer=lin)
+    A_ORDER, C_ORDER = OS.actor_order(len(sizes[0])), OS.critic_order(len(sizes[1]))
     alpha = SI.AutoAlpha(-float(act_dim), -0.6, 3e-4)
     algo = HipREDQ(policy=SI.Policy(actor), critic=critic, lr=1e-3, critic_lr=1e-3, ensemble_size=E, subset_size=S, tau=0.01,
                    gamma=0.97, alpha=alpha, actor_delay=2, target_mode="min", device="cuda").to("cuda")
@@ -627,7 +634,8 @@ def test_hip_redq_hooks_against_oracle():
     cfg = ORQ.REDQConfig(gamma=0.97, tau=0.01, n_step=1, auto_alpha=True, target_entropy=-float(act_dim), log_alpha0=-0.6,
                          actor_lr=1e-3, critic_lr=1e-3, alpha_lr=3e-4, ensemble_size=E, subset_size=S, actor_delay=2,
                          target_mode="min")
-    st = ORQ.REDQState.create(grab(actor, OS.ACTOR_ORDER), grab(critic, ORQ.CRITIC_ORDER), cfg)
+    assert algo._hip_depth == len(sizes[0]) and algo._hip_sizes == {"actor": tuple(sizes[0]), "critic": tuple(sizes[1])}
+    st = ORQ.REDQState.create(grab(actor, A_ORDER), grab(critic, C_ORDER), cfg)
     buf = SI.VectorReplayBuffer(E * 200, 4, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=62)
     rng = np.random.default_rng(63)
     algo.policy.is_within_training_step = True
@@ -655,8 +663,8 @@ def test_hip_redq_hooks_against_oracle():
         if ref["alpha_loss"] is not None:
             np.testing.assert_allclose(stats.alpha_loss, ref["alpha_loss"], rtol=2e-5, atol=2e-6)
         assert algo.critic_gradient_step == st.critic_gradient_step == u + 1
-    for mod, want, order in ((actor, st.actor, OS.ACTOR_ORDER), (critic, st.critic, ORQ.CRITIC_ORDER),
-                             (algo.critic_old.module, st.critic_old, ORQ.CRITIC_ORDER)):
+    for mod, want, order in ((actor, st.actor, A_ORDER), (critic, st.critic, C_ORDER),
+                             (algo.critic_old.module, st.critic_old, C_ORDER)):
         for (name, t), k in zip(mod.state_dict().items(), order):
             np.testing.assert_allclose(t.cpu().numpy(), want[k].numpy(), rtol=1e-4, atol=0.02 * 1e-3, err_msg=name)
     assert abs(float(alpha._log_alpha.detach()) - float(st.log_alpha)) < 0.02 * 3e-4
@@ -1521,7 +1529,7 @@ def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
         assert W.padding_is_zero(NG.critic_flat_to_torch(vec, obs_dim, eng.hidden), *hc)
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
 def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the SAC family: the HOOK path -- device mirror of a host buffer, `_preprocess_batch` (n-step
     target with the lagged critics; n = 1 and 3), `_update_with_batch` (twin critics, actor, alpha, Polyak), write-back -- on the
@@ -1538,7 +1546,9 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     # `widths`: actor Net[48, 80], critics Net[72, 40] -- run embedded in Net[96, 96]; `depth3`: actor [64, 48, 32], critics
     # [40, 56, 24]; `depth1`: one hidden layer [96] (round 6: any depth, layer by layer on the GEMM kernels)
     sa, sc = OS.layer_sizes(d["hidden"])
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+    # `bounded*`: the class-default actor, unbounded=False with max_action 1.5 / 0.8 (mu = max_action * tanh(mu))
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, unbounded=cfg.max_action == 0.0,
+                                            conditioned_sigma=True, max_action=cfg.max_action or 1.0)
     c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
     c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
     p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"], (sa, sc))        # == the reference's initial weights (asserted by gen_sac)
@@ -1548,7 +1558,7 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     algo = make_hip_sac(ref=SI)(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=cfg.actor_lr, critic_lr=cfg.critic_lr, tau=cfg.tau,
                                 gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda",
                                 update_noise="torch").to("cuda")         # (index-only sampling + lazy write-back: the defaults)
-    assert algo._hip_depth == len(sa) and algo._hip_sizes["actor"] == tuple(sa)
+    assert algo._hip_depth == len(sa) and algo._hip_sizes["actor"] == tuple(sa) and algo._hip_bound == cfg.max_action
     buf = SI.VectorReplayBuffer(E * d["slots"], E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     lengths = g["buf_lengths"]
     for t in range(int(lengths.max())):                                   # slot e * slots + t of the fixture's buffer = env e, step t

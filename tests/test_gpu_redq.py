@@ -26,11 +26,11 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
 
     from tianshou_amd import widths as W
 
-    actor, critic = OR.init_params(obs_dim, act_dim, cfg.ensemble_size, seed, hidden)     # hidden: int or four widths
-    H = W.round32(max(OS.hidden_widths(hidden)))
-    eng = RQ.REDQEngine(obs_dim, act_dim, S.actor_flat_from_torch([actor[k] for k in OS.ACTOR_ORDER], obs_dim, act_dim, hidden=H),
-                        RQ.ensemble_flat_from_torch([critic[k] for k in OR.CRITIC_ORDER], obs_dim, act_dim, hidden=H),
-                        RQ.REDQConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}), hidden=H)
+    actor, critic = OR.init_params(obs_dim, act_dim, cfg.ensemble_size, seed, hidden)     # hidden: int, four widths or a nested pair
+    H = W.round32(max(max(x) for x in OS.layer_sizes(hidden)))
+    eng = RQ.REDQEngine(obs_dim, act_dim, S.actor_flat_from_torch(list(actor.values()), obs_dim, act_dim, hidden=H),
+                        RQ.ensemble_flat_from_torch(list(critic.values()), obs_dim, act_dim, hidden=H),
+                        RQ.REDQConfig(**{k: getattr(cfg, k) for k in CFG_KEYS}), hidden=H, depth=OS.depth_of(actor))
     return eng, actor, critic
 
 
@@ -122,16 +122,17 @@ def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B, E):
         np.testing.assert_allclose(t.cpu().numpy(), st.actor[k].numpy(), rtol=1e-4, atol=0.1 * cfg.actor_lr, err_msg=k)
 
 
-@pytest.mark.parametrize("tag", ["min", "mean", "widths"])
+@pytest.mark.parametrize("tag", ["min", "mean", "widths", "depth1"])
 def test_redq_update_matches_reference_golden(tag):
-    """(`widths`: actor Net[48, 80], EnsembleLinear critics [72, 40] in the reference, embedded in Net[96, 96].)"""
+    """(`widths`: actor Net[48, 80], EnsembleLinear critics [72, 40] in the reference, embedded in Net[96, 96].  `depth1`: ONE hidden
+    layer, actor [64], ensemble [48], mean target -- gen_golden.py::gen_depth.)"""
     from tianshou_amd import redq as RQ
     from tianshou_amd import sac as S
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_redq(tag)
     eng, _, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
-    hw = OS.hidden_widths(d["hidden"])
+    sa, sc = OS.layer_sizes(d["hidden"])
     od, ad, H = d["obs_dim"], d["act_dim"], eng.hidden
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],
                              insertion=g["buf_insertion"], rew=g["rew"], terminated=g["terminated"],
@@ -150,9 +151,9 @@ def test_redq_update_matches_reference_golden(tag):
             np.testing.assert_allclose(s[3], ref[3], rtol=1e-5, atol=1e-6)
         E = cfg.ensemble_size
         cat = lambda ts: torch.cat([t.reshape(-1) for t in ts])  # noqa: E731
-        for name, flat, lr in (("actor", cat(S.actor_flat_to_torch(eng.actor, od, ad, H, sizes=hw[:2])), cfg.actor_lr),
-                               ("critic", cat(RQ.ensemble_flat_to_torch(eng.critics, E, od, ad, H, sizes=hw[2:])), cfg.critic_lr),
-                               ("critic_old", cat(RQ.ensemble_flat_to_torch(eng.critics_old, E, od, ad, H, sizes=hw[2:])), cfg.critic_lr)):
+        for name, flat, lr in (("actor", cat(S.actor_flat_to_torch(eng.actor, od, ad, H, sizes=sa)), cfg.actor_lr),
+                               ("critic", cat(RQ.ensemble_flat_to_torch(eng.critics, E, od, ad, H, sizes=sc)), cfg.critic_lr),
+                               ("critic_old", cat(RQ.ensemble_flat_to_torch(eng.critics_old, E, od, ad, H, sizes=sc)), cfg.critic_lr)):
             np.testing.assert_allclose(flat.cpu().numpy()[::61], g[f"u{u}_{name}"], rtol=1e-5, atol=0.02 * lr, err_msg=name)
 
 

@@ -32,7 +32,7 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
         S.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H),
         S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
                                                      "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=H,
-        depth=OS.depth_of(actor))
+        depth=OS.depth_of(actor), max_action=getattr(cfg, "max_action", 0.0))
     return eng, (actor, c1, c2)
 
 
@@ -111,12 +111,14 @@ def test_update_gradients_vs_oracle(obs_dim, act_dim, B, auto, weighted):
     assert torch.count_nonzero(l1[obs_dim + act_dim:lay["kc"]]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
 def test_sac_update_matches_reference_golden(tag):
     """(`widths`: actor Net[48, 80], critics Net[72, 40] in the reference; the engine runs them embedded in Net[96, 96] and every
     padding entry of parameters, lagged parameters and Adam moments stays exactly zero.  `depth3`: THREE hidden layers, actor
     [64, 48, 32] and critics [40, 56, 24] in Net[64] * 3; `depth1`: ONE hidden layer [96], fixed alpha, 2-step returns --
-    fixtures the unmodified reference wrote, gen_golden.py::gen_depth; the engine runs them layer by layer, ts_mlp_set_trunk.)"""
+    fixtures the unmodified reference wrote, gen_golden.py::gen_depth; the engine runs them layer by layer, ts_mlp_set_trunk.
+    `bounded` / `bounded_depth3`: the class-default actor `unbounded=False` -- mu = max_action * tanh(mu), max_action 1.5 / 0.8,
+    ts_sac_set_actor_bound -- on Net[256, 256] (the fused kernels) and on actor [48, 64, 40] / critics [64, 32, 32].)"""
     from tianshou_amd import sac as S
     from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
@@ -283,6 +285,45 @@ def test_other_depths_vs_oracle(hidden, obs_dim, act_dim, B):
             np.testing.assert_allclose(t.cpu().numpy(), getattr(st, name)[k].numpy(), rtol=1e-5, atol=0.1 * lr, err_msg=f"{name}.{k}")
     with pytest.raises(NotImplementedError):
         make_engine(5, 2, 0, cfg, hidden=((32,) * 7, (32,) * 7))          # beyond TS_MLP_MAX_HIDDEN_LAYERS
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,B", [(256, 376, 17, 1024), (((64, 32, 48), (32, 64, 32)), 23, 5, 130)])
+def test_bounded_actor_vs_oracle(hidden, obs_dim, act_dim, B):
+    """ContinuousActorProbabilistic(unbounded=False) -- the class default: mu = max_action * tanh(mu), continuous.py:230-231 --
+    under SAC (ts_sac_set_actor_bound): the policy / target entry points, the three gradients against the float64 yardstick
+    (the actor's goes back through max_action * (1 - tanh^2)), and an unbounded engine on the same workspace in between."""
+    from tianshou_amd import sac as S
+
+    cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.3, target_entropy=-float(act_dim), actor_lr=0.0, critic_lr=0.0, alpha_lr=0.0,
+                       tau=0.0, max_action=1.3)
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 5, cfg, hidden)
+    other, _ = make_engine(7, 2, 1, OS.SACConfig())                # unbounded, same default workspace
+    assert eng.max_action == 1.3 and other.max_action == 0.0
+    sa, sc = OS.layer_sizes(hidden)
+    st = OS.SACState.create(actor, c1, c2, cfg)
+    g = torch.Generator().manual_seed(B)
+    obs = torch.randn(B, obs_dim, generator=g) * 2
+    act = torch.rand(B, act_dim, generator=g) * 2 - 1
+    ret, noise = torch.randn(B, generator=g), torch.randn(B, act_dim, generator=g)
+    a_act, a_logp = eng.policy_forward(obs, noise)
+    other.policy_forward(torch.randn(8, 7), torch.randn(8, 2))
+    r_act, r_logp, r_mu, _ = OS.policy_forward(st.actor, obs, noise, cfg.max_action)
+    assert float(r_mu.abs().max()) <= 1.3 and float(r_mu.abs().max()) > 0.05           # the bound is live
+    assert rel_err(a_act.cpu(), r_act) < 1e-5 and rel_err(a_logp.cpu().flatten(), r_logp.flatten()) < 1e-5
+    u_act, _, _, _ = OS.policy_forward(st.actor, obs, noise, 0.0)
+    assert rel_err(a_act.cpu(), u_act) > 1e-3                                           # and differs from the unbounded actor
+    assert rel_err(eng.target_q(obs, noise).cpu(), OS.target_q(st, cfg, obs, noise).flatten()) < 2e-5
+    pc = eng.critic1.numel()
+    grads = torch.empty(2 * pc + eng.actor.numel(), dtype=torch.float32, device="cuda")
+    col = {}
+    ref = OS.update_with_batch(st, cfg, obs, act, ret, noise, None, collect=col)
+    stats, _ = eng.update_with_batch(obs, act, ret, noise, None, grads_out=grads)
+    np.testing.assert_allclose(stats.cpu().numpy()[:3], [ref["actor_loss"], ref["critic1_loss"], ref["critic2_loss"]], rtol=1e-5)
+    g64 = OS.gradients(actor, c1, c2, OS.alpha_value(st, cfg), obs, act, ret, noise, None, dtype=torch.float64, max_action=cfg.max_action)
+    got = S.actor_flat_to_torch(grads[2 * pc:], obs_dim, act_dim, eng.hidden, sizes=sa)
+    for t, key in zip(got, g64["actor_grads"]):
+        e_gpu, e_ref = rel_err(t.cpu(), g64["actor_grads"][key]), rel_err(col["actor_grads"][key], g64["actor_grads"][key])
+        assert e_gpu < max(1e-5, 2 * e_ref), (key, e_gpu, e_ref)
 
 
 def test_twin_critics_on_two_streams_with_generation_2():

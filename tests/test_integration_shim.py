@@ -263,7 +263,7 @@ def test_collector_side_policies_become_engine_backed_subclasses_of_the_real_cla
     s = make_hip_sac()(policy=sp, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=ContinuousCritic(preprocess_net=sac_net()),
                        critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=ContinuousCritic(preprocess_net=sac_net()),
                        critic2_optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
-    assert isinstance(s.policy, SACPolicy) and s.policy._hip_family == "sac" and s.policy._hip_spec == dict(obs_dim=11, act_dim=3, hidden=256, depth=2)
+    assert isinstance(s.policy, SACPolicy) and s.policy._hip_family == "sac" and s.policy._hip_spec == dict(obs_dim=11, act_dim=3, hidden=256, depth=2, max_action=0.0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         s.policy(Batch(obs=np.zeros((2, 11), np.float32), info={}), None)
     # DQN
@@ -654,7 +654,7 @@ def test_hip_sac_wrapper_runs_with_engine_double(sac_algo, monkeypatch):
     import tianshou_amd.sac as S
 
     class FakeSAC:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0):
             assert hidden == 256
             self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.adam_step = obs_dim, act_dim, cfg, 0
@@ -740,7 +740,7 @@ def test_hip_td3_ddpg_wrapper_runs_with_engine_double(twin, monkeypatch):
     import tianshou_amd.td3 as T
 
     class FakeTD3:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0):
             self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.cnt, self.actor_steps = obs_dim, act_dim, cfg, 0, 0
             self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), None if c2 is None else c2.clone()
@@ -1209,7 +1209,7 @@ def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
     seen = {"subsets": [], "noise": []}
 
     class FakeREDQ:
-        def __init__(self, obs_dim, act_dim, actor, critics, cfg, hidden=256, depth=2):
+        def __init__(self, obs_dim, act_dim, actor, critics, cfg, hidden=256, depth=2, max_action=0.0):
             self.hidden = hidden
             assert (obs_dim, act_dim) == (11, 3) and (cfg.ensemble_size, cfg.subset_size, cfg.actor_delay) == (4, 2, 2)
             assert cfg.auto_alpha and cfg.target_mode == "min" and cfg.n_step == 2 and critics.numel() % 4 == 0

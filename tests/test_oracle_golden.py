@@ -384,7 +384,7 @@ def load_sac(tag):
     cfg = OS.SACConfig(gamma=c["gamma"], tau=c["tau"], n_step=int(c["n_step"]), alpha=c["alpha"],
                        auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
-                       alpha_lr=c["alpha_lr"])
+                       alpha_lr=c["alpha_lr"], max_action=c.get("max_action", 0.0))      # (> 0: the bounded class-default actor)
     d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
              hidden=_fixture_hidden(g))
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
@@ -392,7 +392,7 @@ def load_sac(tag):
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
 def test_sac_restatement_matches_reference(tag):
     """oracle_sac (tanh-Gaussian policy, twin lagged critics, n-step target, three Adam steps, auto alpha,
     Polyak) against the unmodified reference SAC.update() with its rsample() noise replayed."""
@@ -582,15 +582,15 @@ def load_dsac(tag):
                        auto_alpha=bool(c["auto_alpha"]), target_entropy=c["target_entropy"],
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
                        alpha_lr=c["alpha_lr"])
-    if "hidden" in g:                       # (actor h1, actor h2, critic h1, critic h2): unequal widths (round 6)
-        hidden = tuple(int(x) for x in g["hidden"])
+    if "hidden" in g or "hidden_actor" in g:   # (actor h1, actor h2, critic h1, critic h2): unequal widths; other depths: a nested pair
+        hidden = _fixture_hidden(g)
     d = dict(E=E, slots=slots, obs_dim=obs_dim, n_act=n_act, hidden=hidden, batch=batch, n_updates=n_updates, seed=seed)
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3"])
 def test_dsac_restatement_matches_reference(tag):
     """oracle_dsac (categorical target with entropy bonus, gathered-Q critic losses with PER weights, actor step
     against the updated critics, alpha step, Polyak) against the unmodified reference DiscreteSAC.update()."""
@@ -617,7 +617,7 @@ def test_dsac_restatement_matches_reference(tag):
             np.testing.assert_allclose(out["alpha_loss"], stats[4], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(out["weight"].numpy(), g[f"u{u}_new_weight"], rtol=1e-5, atol=1e-6)
         for name in ("actor", "critic1", "critic2", "critic1_old", "critic2_old"):
-            flat = torch.cat([getattr(st, name)[k].reshape(-1) for k in ODS.NET_ORDER]).numpy()[::5]
+            flat = torch.cat([t.reshape(-1) for t in getattr(st, name).values()]).numpy()[::5]          # (dicts are in layer order)
             np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
 
 
@@ -633,13 +633,13 @@ def load_redq(tag):
                         actor_lr=c["actor_lr"], critic_lr=c["critic_lr"], alpha_lr=c["alpha_lr"], ensemble_size=ens,
                         subset_size=sub, actor_delay=delay, target_mode="mean" if mean else "min")
     d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
-             hidden=tuple(int(x) for x in g["hidden"]) if "hidden" in g else 256)
+             hidden=_fixture_hidden(g))
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["min", "mean", "widths"])
+@pytest.mark.parametrize("tag", ["min", "mean", "widths", "depth1"])
 def test_redq_restatement_matches_reference(tag):
     """oracle_redq (EnsembleLinear critics, random-subset min / mean target, one ensemble loss, delayed actor and alpha
     steps, Polyak) against the unmodified reference REDQ.update()."""
@@ -666,8 +666,8 @@ def test_redq_restatement_matches_reference(tag):
             np.testing.assert_allclose(out["alpha_loss"], stats[3], rtol=1e-5, atol=1e-7)
         else:
             assert np.isnan(stats[3])
-        for name, p, order in (("actor", st.actor, OS.ACTOR_ORDER), ("critic", st.critic, OR.CRITIC_ORDER),
-                               ("critic_old", st.critic_old, OR.CRITIC_ORDER)):
+        for name, p, order in (("actor", st.actor, list(st.actor)), ("critic", st.critic, list(st.critic)),
+                               ("critic_old", st.critic_old, list(st.critic_old))):
             flat = torch.cat([p[k].reshape(-1) for k in order]).numpy()[::61]
             np.testing.assert_allclose(flat, g[f"u{u}_{name}"], rtol=1e-5, atol=1e-6, err_msg=name)
 

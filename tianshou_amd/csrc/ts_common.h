@@ -84,6 +84,9 @@ struct ts_workspace {
     int mlp_hidden;
     // number of hidden layers of those MLPs (ts_mlp_set_trunk; 0 = 2, the depth of the examples' nets)
     int mlp_depth;
+    // max_action of a BOUNDED Gaussian actor (mu = max_action * tanh(mu), continuous.py:230-231) of the SAC / REDQ entry
+    // points (ts_sac_set_actor_bound; 0 = unbounded, the actors of the examples)
+    float sac_actor_bound;
     hipStream_t side;
     hipStream_t side2;           // second side stream (ts::side_streams): created together with `side`
     hipEvent_t side_ev[16];

@@ -195,6 +195,13 @@ int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
     return TS_OK;
 }
 
+int ts_sac_set_actor_bound(ts_workspace* ws, double max_action) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_set_actor_bound: workspace is NULL");
+    TS_REQUIRE(max_action >= 0.0 && max_action < 1e30, TS_ERR_INVALID_ARG, "ts_sac_set_actor_bound: max_action >= 0 (0 = unbounded)");
+    ws->sac_actor_bound = (float)max_action;
+    return TS_OK;
+}
+
 int ts_mlp_set_trunk(ts_workspace* ws, int64_t hidden, int64_t depth) {
     TS_REQUIRE(depth == 0 || (depth >= 1 && depth <= TS_MLP_MAX_HIDDEN_LAYERS), TS_ERR_INVALID_ARG,
                "ts_mlp_set_trunk: 0 (default 2) or 1 .. %d hidden layers, got %lld", TS_MLP_MAX_HIDDEN_LAYERS, (long long)depth);

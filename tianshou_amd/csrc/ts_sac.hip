@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__
 // columns (nullable), act_out (nullable), logp_out; `keep` (nullable, [B, 3A]) stores {a - mu, sigma, squashed}
 // for the backward pass.
 __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
-                                                         int64_t B, int A, int head_cols, int obs_dim, int kc,
+                                                         int64_t B, int A, int head_cols, int obs_dim, int kc, float bound,
                                                          float* __restrict__ x_c, float* __restrict__ act_out,
                                                          float* __restrict__ logp_out, float* __restrict__ keep,
                                                          float* __restrict__ mu_out = nullptr,
@@ -308,7 +308,9 @@ __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict
     float lp = 0.f, corr = 0.f;
     if (b < B && j < A) {
         const float* hb = head + b * head_cols;
-        const float mu = hb[j];
+        // `bound` > 0: ContinuousActorProbabilistic(unbounded=False), the class default -- mu = max_action * tanh(mu)
+        // (continuous.py:230-231) in front of the Gaussian; 0 = the examples' unbounded actor
+        const float mu = bound > 0.f ? bound * tanhf(hb[j]) : hb[j];
         const float sigma = expf(fminf(fmaxf(hb[SIG_COL + j], SIGMA_MIN), SIGMA_MAX));
         const float e = noise ? noise[b * A + j] : 0.f;
         const float a = mu + e * sigma;                              // Normal.rsample: loc + eps * scale
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void sac_policy_bwd_kernel(const float* __rest
                                                              const float* __restrict__ keep, const float* __restrict__ dx1,
                                                              const float* __restrict__ dx2,
                                                              const float* __restrict__ log_alpha, float fixed_alpha,
-                                                             int64_t B, int A, int head_cols, int obs_dim, int kc,
+                                                             int64_t B, int A, int head_cols, int obs_dim, int kc, float bound,
                                                              float* __restrict__ d_head) {
     // thread (b, j < 32): columns j and 32 + j of row b; columns past the action dimension are written as zeros
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -436,7 +438,12 @@ __global__ __launch_bounds__(256) void sac_policy_bwd_kernel(const float* __rest
     const float g_sigma = g_a * e + g_lp * (d * d / (var * sigma) - 1.f / sigma);
     const float raw = head[b * head_cols + SIG_COL + j];
     const float g_raw = (raw >= SIGMA_MIN && raw <= SIGMA_MAX) ? g_sigma * sigma : 0.f;   // clamp().exp()
-    d_head[b * head_cols + j] = g_mu;
+    float g_mu_raw = g_mu;
+    if (bound > 0.f) {                                                // through mu = bound * tanh(raw mu)
+        const float tm = tanhf(head[b * head_cols + j]);
+        g_mu_raw = g_mu * (bound * (1.f - tm * tm));
+    }
+    d_head[b * head_cols + j] = g_mu_raw;
     d_head[b * head_cols + SIG_COL + j] = g_raw;
 }
 
@@ -1043,7 +1050,7 @@ struct Carve {
     template <class T> T* take(size_t n) { T* r = reinterpret_cast<T*>(p); p += al(sizeof(T) * n); return r; }
 };
 
-struct Dims { int obs, act, ka, kc, hid, depth; };
+struct Dims { int obs, act, ka, kc, hid, depth; float bound; };
 
 // hidden: width of the two hidden layers of every Net[h, h] of the SAC / TD3 / DDPG / REDQ entry points -- a property of
 // the workspace (ts_mlp_set_hidden; 0 = the examples' 256).  Any multiple of 32 up to 1024 runs: 256 on the fused
@@ -1058,12 +1065,15 @@ int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d, int64
     TS_REQUIRE(depth >= 1 && depth <= MAXD, TS_ERR_INVALID_ARG, "sac: 1 .. %d hidden layers, got %lld", MAXD, (long long)depth);
     d->obs = (int)obs_dim; d->act = (int)act_dim; d->hid = (int)hidden; d->depth = (int)depth;
     d->ka = pad32(d->obs); d->kc = pad32(d->obs + d->act);
+    d->bound = 0.f;
     return TS_OK;
 }
 
 // hidden width and depth: properties of the workspace (ts_mlp_set_hidden / ts_mlp_set_trunk)
 int make_dims(const ts_workspace* ws, int64_t obs_dim, int64_t act_dim, Dims* d) {
-    return make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d, ws ? ws->mlp_depth : 0);
+    if (int rc = make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d, ws ? ws->mlp_depth : 0)) return rc;
+    d->bound = ws ? ws->sac_actor_bound : 0.f;          // ts_sac_set_actor_bound (SAC's / REDQ's Gaussian actor only)
+    return TS_OK;
 }
 
 Act take_act(Carve& c, int64_t B, int head_cols, int hid = HID, int depth = 2) {
@@ -1148,7 +1158,7 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
-                       64, d.obs, d.kc, (float*)nullptr, act_out, logp_out, mu_sigma_out ? keep : nullptr);
+                       64, d.obs, d.kc, d.bound, (float*)nullptr, act_out, logp_out, mu_sigma_out ? keep : nullptr);
     TS_LAUNCH_CHECK();
     if (mu_sigma_out) {      // {a - mu, sigma, squashed} rows, for diagnostics / tests
         TS_HIP_CHECK(hipMemcpyAsync(mu_sigma_out, keep, sizeof(float) * B * 3 * d.act, hipMemcpyDeviceToDevice, s));
@@ -1174,7 +1184,7 @@ int ts_sac_policy_forward_logits(ts_workspace* ws, const float* actor, const flo
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, (float*)nullptr, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
-                       64, d.obs, d.kc, (float*)nullptr, act_out, logp_out, (float*)nullptr, mu_out, sigma_out);
+                       64, d.obs, d.kc, d.bound, (float*)nullptr, act_out, logp_out, (float*)nullptr, mu_out, sigma_out);
     TS_LAUNCH_CHECK();
     return TS_OK;
 }
@@ -1207,7 +1217,7 @@ static int sac_target_impl(ts_workspace* ws, const float* actor, const float* cr
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr, rows);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, split)) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
-                       64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
+                       64, d.obs, d.kc, d.bound, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
     if (side == s) {                                                    // one stream: both lagged critics in one launch
         const float* pp[2] = {critic1_old, critic2_old};
@@ -1406,7 +1416,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     if (phases & PH_ACTOR_GRAD) {
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
         hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B,
-                           d.act, 64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
+                           d.act, 64, d.obs, d.kc, d.bound, x_p, (float*)nullptr, logp, keep);
         const Act a12[2] = {a1, a2};
         if (side == s) {                                                      // one stream: both critics in one launch
             if (int rc = mlp_forward_twin(s, ws, mc, crit, x_p, a12, splits)) return rc;
@@ -1430,7 +1440,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
             if (int rc = ts::stream_wait(ws, side, s, 4)) return rc;
         }
         hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
-                           keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
+                           keep, dx1, dx2, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d.bound, d_head);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, ga, nullptr, 0, 0, sc, fuse_adam ? 1 : 3)) return rc;
         if (phases != PH_ALL) {      // the alpha step's only batch statistic, for the all-reduce; the actor loss
@@ -1967,7 +1977,7 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
                        (const float*)nullptr, B, d.obs, d.act, d.ka, d.kc, x_a, x_c, (float*)nullptr);
     if (int rc = mlp_forward(s, ws, ma, actor, x_a, aa, splits[0])) return rc;
     hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
-                       64, d.obs, d.kc, x_c, (float*)nullptr, logp, (float*)nullptr);
+                       64, d.obs, d.kc, d.bound, x_c, (float*)nullptr, logp, (float*)nullptr);
     TS_LAUNCH_CHECK();
     if (S <= MULTI_MAX && mc.three() && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC)) {
         // the subset's members in one launch (no activations kept: inference)
@@ -2105,7 +2115,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
         TS_HIP_CHECK(hipMemsetAsync(d_head, 0, sizeof(float) * B * 64, s));
         if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, splits[0])) return rc;
         hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B, d.act,
-                           64, d.obs, d.kc, x_p, (float*)nullptr, logp, keep);
+                           64, d.obs, d.kc, d.bound, x_p, (float*)nullptr, logp, keep);
         TS_LAUNCH_CHECK();
         for (int e = 0; e < E; ++e)
             if (int rc = mlp_forward(s, ws, mc, st->critics + (int64_t)e * pc, x_p, acts[e], splits[0])) return rc;
@@ -2123,7 +2133,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
                                d.kc, d.obs, d.act, e == 0 ? 1 : 0);
         }
         hipLaunchKernelGGL(sac_policy_bwd_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise,
-                           keep, dx_sum, zeros, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d_head);
+                           keep, dx_sum, zeros, log_alpha, (float)hp->alpha, B, d.act, 64, d.obs, d.kc, d.bound, d_head);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward(s, ws, ma, st->actor, x_a, aa, d_head, gact, nullptr, 0, 0, scs[0])) return rc;
         if (hp->actor_lr >= 0.0)

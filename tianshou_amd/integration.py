@@ -1478,12 +1478,10 @@ def _require_relu_trunk(mod, who: str) -> None:
                                   f"(got {[type(m).__name__ for m in mods]})")
 
 
-def _require_unbounded_actor(actor, who: str) -> None:
-    """SAC's / REDQ's engine squashes tanh(mu + sigma * eps) with an unbounded mu (examples/mujoco/mujoco_sac.py:88-94 pass
-    `unbounded=True`); the class default `unbounded=False` (continuous.py:194, 230-231: mu = max_action * tanh(mu)) is a
-    different network and raises."""
-    if not getattr(actor, "_unbounded", False):
-        raise NotImplementedError(f"{who}: ContinuousActorProbabilistic(unbounded=True) is required (as in examples/mujoco/mujoco_sac.py)")
+def _actor_bound(actor) -> float:
+    """max_action of SAC's / REDQ's Gaussian actor for the engine: 0 for `unbounded=True` (examples/mujoco/mujoco_sac.py:88-94),
+    `actor.max_action` for the class default `unbounded=False` (continuous.py:194, 230-231: mu = max_action * tanh(mu))."""
+    return 0.0 if getattr(actor, "_unbounded", False) else float(getattr(actor, "max_action", 1.0))
 
 
 def make_hip_sac(ref=None):
@@ -1532,7 +1530,7 @@ def make_hip_sac(ref=None):
             self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), S.critic_keys(depth)
             for mod in (self.policy.actor, self.critic, self.critic2):
                 _require_relu_trunk(mod, "HipSAC")
-            _require_unbounded_actor(self.policy.actor, "HipSAC")
+            self._hip_bound = _actor_bound(self.policy.actor)
             # any hidden widths per network (round 6): embedded by zero padding into the engine's Net[h] * depth, h = the largest
             # width of the three networks rounded up to 32 (tianshou_amd.widths)
             from . import widths as WD
@@ -1557,7 +1555,7 @@ def make_hip_sac(ref=None):
 
                 HP.attach(self.policy, "sac", self, device=str(self._hip_device), sampling=sampling, noise_seed=noise_seed,
                           obs_dim=int(sa[self._hip_akeys[0]].shape[1]), act_dim=int(sa[self._hip_akeys[2 * self._hip_depth]].shape[0]),
-                          hidden=hid, depth=depth)
+                          hidden=hid, depth=depth, max_action=self._hip_bound)
             self._hip_set_write_back(write_back, attached=policy_forward == "hip")
 
         def update(self, buffer, sample_size):
@@ -1596,7 +1594,8 @@ def make_hip_sac(ref=None):
                 eng = self._hip_engine = S.SACEngine(
                     obs_dim, act_dim,
                     S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
-                    flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden, depth=self._hip_depth)
+                    flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden, depth=self._hip_depth,
+                    max_action=self._hip_bound)
                 # resume: lagged critics, Adam moments / steps of a loaded checkpoint
                 eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
                 for name, mod, optim, keys, conv in self._hip_parts(S):
@@ -1712,7 +1711,7 @@ def make_hip_redq(ref=None):
             self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), RQ.critic_keys(depth)
             for mod in (self.policy.actor, self.critic):
                 _require_relu_trunk(mod, "HipREDQ")
-            _require_unbounded_actor(self.policy.actor, "HipREDQ")
+            self._hip_bound = _actor_bound(self.policy.actor)
             from . import widths as WD
 
             try:        # any hidden widths (round 6): embedded by zero padding (tianshou_amd.widths)
@@ -1752,7 +1751,7 @@ def make_hip_redq(ref=None):
                 eng = self._hip_engine = RQ.REDQEngine(
                     obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
                     RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev, hidden=hid), cfg,
-                    hidden=self._hip_hidden, depth=self._hip_depth)
+                    hidden=self._hip_hidden, depth=self._hip_depth, max_action=self._hip_bound)
                 # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
                 eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev, hidden=hid)
                 eng.critic_gradient_step = int(self.critic_gradient_step)
