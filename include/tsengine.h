@@ -1179,6 +1179,18 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
                     const float* act, const float* adv, const float* returns, const float* logp_old, const float* v_old,
                     int64_t B, int64_t global_batch, const float* adv_stats, const ts_ppo_hparams* hp, float* losses_out4,
                     float* grad_out, ts_stream_t stream);
+/* NPG / TRPO (modelfree/npg.py:123-224, trpo.py:123-214) on the same generic trunks (round 6): ts_npg_actor_step /
+ * ts_npg_critic_steps with a ts_net_desc in place of the single hidden width -- any 1 .. TS_NET_MAX_HIDDEN hidden layers of any
+ * widths, tanh / ReLU / no activation (the actor: unbounded, state-independent sigma, i.e. flags = 0 and max_action = 0).  Flat
+ * layouts as ts_net_layout (critic: its first h_out3[2] entries -- trunk + head -- without the log_sigma block).  The
+ * Fisher-vector product is the Gauss-Newton form J^T diag(1 / sigma^2) J v / B + 2 v_sigma with one forward-mode pass (layer i:
+ * d_i = (d_{i-1} W_i + h_{i-1} V_i + bv_i) act'(h_i)) and one reverse pass per product; inference: ts_ppo_net_infer. */
+int ts_npg_net_actor_step(ts_workspace* ws, float* actor, const ts_net_desc* net, int64_t act_dim, const float* obs, const float* act,
+                          const float* adv, const float* logp_old, int64_t B, const ts_npg_hparams* hp, float* stats_out3,
+                          float* dbg_out, ts_stream_t stream);
+int ts_npg_net_critic_steps(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, const ts_net_desc* net,
+                            const float* obs, const float* returns, int64_t B, int64_t iters, double lr, double beta1, double beta2,
+                            double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------

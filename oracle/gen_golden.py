@@ -291,15 +291,12 @@ def gen_segtree_per() -> None:
 
 # ---------------------------------------------------------------------------------------------
 def _flat_from_modules(actor, critic) -> np.ndarray:
+    """Actor trunk (w, b)*, mu (w, b), sigma_param | critic trunk (w, b)*, last (w, b) -- Net trunks of any depth (the Linears of
+    the Sequential in order)."""
     sd_a, sd_c = actor.state_dict(), critic.state_dict()
-    parts = [
-        sd_a["preprocess.model.model.0.weight"], sd_a["preprocess.model.model.0.bias"],
-        sd_a["preprocess.model.model.2.weight"], sd_a["preprocess.model.model.2.bias"],
-        sd_a["mu.model.0.weight"], sd_a["mu.model.0.bias"], sd_a["sigma_param"],
-        sd_c["preprocess.model.model.0.weight"], sd_c["preprocess.model.model.0.bias"],
-        sd_c["preprocess.model.model.2.weight"], sd_c["preprocess.model.model.2.bias"],
-        sd_c["last.model.0.weight"], sd_c["last.model.0.bias"],
-    ]
+    trunk = lambda sd: [sd[k] for k in sd if k.startswith("preprocess.model.model.")]      # noqa: E731 (weight, bias per Linear, in order)
+    parts = trunk(sd_a) + [sd_a["mu.model.0.weight"], sd_a["mu.model.0.bias"], sd_a["sigma_param"]] + \
+        trunk(sd_c) + [sd_c["last.model.0.weight"], sd_c["last.model.0.bias"]]
     return torch.cat([p.detach().reshape(-1) for p in parts]).numpy().astype(np.float32)
 
 
@@ -935,18 +932,19 @@ def gen_sample_stack() -> None:
 
 
 def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
-            lr: float = 1e-3, hidden_a=(64, 64), hidden_c=(64, 64), **kwargs) -> None:
+            lr: float = 1e-3, hidden_a=(64, 64), hidden_c=(64, 64), activation=nn.Tanh, **kwargs) -> None:
     """Runs the reference NPG.update() / TRPO.update() on the MuJoCo actor-critic (examples/mujoco/mujoco_npg.py:103-128,
-    the PPO nets) over a synthetic VectorReplayBuffer and dumps every intermediate."""
+    the PPO nets) over a synthetic VectorReplayBuffer and dumps every intermediate.  Round 6: `hidden_a` / `hidden_c` of any
+    length and `activation` (nn.Tanh, nn.ReLU or None) = any Net trunk (utils/net/common.py:90-178)."""
     from tianshou.algorithm.modelfree.npg import NPG
     from tianshou.algorithm.modelfree.trpo import TRPO
 
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_a), activation=nn.Tanh)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_a), activation=activation)
     actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
-    net_c = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_c), activation=nn.Tanh)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=list(hidden_c), activation=activation)
     critic = ContinuousCritic(preprocess_net=net_c)
     torch.nn.init.constant_(actor.sigma_param, -0.5)
     for m in ActorCritic(actor, critic).modules():
@@ -970,7 +968,11 @@ def gen_npg(tag: str, *, algo: str, E: int, T: int, obs_dim: int, act_dim: int, 
     assert [n for n, _ in actor.named_parameters()][0] == "sigma_param"
     out: dict[str, np.ndarray] = {"flat_params0": _flat_from_modules(actor, critic),
                                   "dims": np.array([E, T, obs_dim, act_dim, batch_size, repeat, int(algo == "trpo")])}
-    if tuple(hidden_a) != (64, 64) or tuple(hidden_c) != (64, 64):
+    if len(hidden_a) != 2 or len(hidden_c) != 2 or activation is not nn.Tanh:
+        out["hidden_a"], out["hidden_c"] = np.array(list(hidden_a), np.int64), np.array(list(hidden_c), np.int64)
+        out["activation"] = np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation])
+        out["seed"] = np.array(seed)
+    elif tuple(hidden_a) != (64, 64) or tuple(hidden_c) != (64, 64):
         out["hidden"] = np.array(list(hidden_a) + list(hidden_c), np.int64)
         out["seed"] = np.array(seed)
     buf = VectorReplayBuffer(N, E)
@@ -2026,6 +2028,13 @@ def gen_depth() -> None:
             hidden=((64, 64, 32, 32), (48, 64, 64, 40)), max_action=1.5)
     gen_td3("ddpg_depth1", twin=False, E=2, slots=40, steps=40, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=34,
             hidden=((128,), (64,)))
+    # NPG on three ReLU layers (actor [64, 48, 32], critic [40, 56]: different depths too); TRPO on one tanh layer [96] / [80]
+    gen_npg("npg_relu3", algo="npg", E=4, T=64, obs_dim=17, act_dim=6, batch_size=128, repeat=2, seed=28, optim_critic_iters=3,
+            trust_region_size=0.1, advantage_normalization=True, gae_lambda=0.95, gamma=0.99, return_scaling=True, max_batchsize=64,
+            hidden_a=(64, 48, 32), hidden_c=(40, 56), activation=nn.ReLU)
+    gen_npg("trpo_tanh1", algo="trpo", E=4, T=64, obs_dim=11, act_dim=3, batch_size=128, repeat=2, seed=29, optim_critic_iters=2,
+            max_kl=0.01, backtrack_coeff=0.8, max_backtracks=10, advantage_normalization=True, gae_lambda=0.95, gamma=0.99,
+            return_scaling=False, max_batchsize=256, hidden_a=(96,), hidden_c=(80,))
     # SAC with the class-default BOUNDED actor (unbounded=False, max_action 1.5) on a two-layer and a three-layer trunk
     gen_sac("bounded", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=37, auto_alpha=True, max_action=1.5)
     gen_sac("bounded_depth3", E=3, slots=30, steps=30, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=38, auto_alpha=False,

@@ -1457,26 +1457,32 @@ def test_hip_ppo_hooks_replay_a_bounded_actor_on_the_per_layer_engine():
 
 
 
-@pytest.mark.parametrize("tag", ["npg_widths", "trpo_widths"])
+@pytest.mark.parametrize("tag", ["npg_widths", "trpo_widths", "npg_relu3", "trpo_tanh1"])
 def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
     """HipNPG / HipTRPO on two-hidden-layer tanh networks whose widths are neither equal nor multiples of 32 (actor [48, 80] /
     critic [40, 56]; actor [100, 60] / critic [60, 100]) against what the unmodified REFERENCE's NPG.update() / TRPO.update()
     produced on them (tests/golden/npg_{npg,trpo}_widths.npz, oracle/gen_golden.py::gen_npg): the engine runs the networks
     embedded in Net[96, 96] / Net[128, 128] by zero padding (tianshou_amd/widths.py) -- conjugate gradients, Fisher-vector
     products, TRPO's line search and the critic's Adam steps never move a padding entry.  Same buffer, initial weights and
-    `np.random.permutation` stream; tolerances of tests/test_gpu_npg.py (both sides are float32 CG solves)."""
+    `np.random.permutation` stream; tolerances of tests/test_gpu_npg.py (both sides are float32 CG solves).
+    `npg_relu3` / `trpo_tanh1` (round 6): trunks outside two tanh layers -- NPG on three ReLU layers (actor [64, 48, 32], critic
+    [40, 56]), TRPO on one tanh layer ([96] / [80]) -- pick NetNPGEngine (layer by layer on the GEMM kernels)."""
     from tests.test_oracle_golden import load_npg
     from tianshou_amd.integration import make_hip_npg, make_hip_trpo
 
     g, d, cfg = load_npg(tag)
     obs_dim, act_dim, E, T = d["obs_dim"], d["act_dim"], d["E"], d["T"]
-    ha, hc = [int(x) for x in g["hidden"][:2]], [int(x) for x in g["hidden"][2:]]
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, nn.Tanh), act_dim, unbounded=True)
-    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, nn.Tanh))
-    keys_a = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
-              "preprocess.model.model.2.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
-    keys_c = ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.2.weight",
-              "preprocess.model.model.2.bias", "last.model.0.weight", "last.model.0.bias"]
+    generic = "hidden_a" in g
+    if generic:
+        ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
+        act_cls = {0: nn.Tanh, 1: nn.ReLU, 2: None}[int(g["activation"])]
+    else:
+        ha, hc, act_cls = [int(x) for x in g["hidden"][:2]], [int(x) for x in g["hidden"][2:]], nn.Tanh
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls), act_dim, unbounded=True)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, act_cls))
+    trunk = lambda n: [f"preprocess.model.model.{2 * i}.{x}" for i in range(n) for x in ("weight", "bias")]      # noqa: E731
+    keys_a = trunk(len(ha)) + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+    keys_c = trunk(len(hc)) + ["last.model.0.weight", "last.model.0.bias"]
 
     def load_flat(flat):
         off = 0
@@ -1500,7 +1506,10 @@ def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
     else:
         kw.update(max_kl=cfg.max_kl, backtrack_coeff=cfg.backtrack_coeff, max_backtracks=cfg.max_backtracks)
     algo = (make_hip_npg if which == "npg" else make_hip_trpo)(ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", **kw).to("cuda")
-    assert algo._hip_hidden % 32 == 0 and algo._hip_sizes == {"actor": tuple(ha), "critic": tuple(hc)}
+    if generic:
+        assert not algo._hip_two and algo._hip_trunks[:2] == (ha, hc)
+    else:
+        assert algo._hip_hidden % 32 == 0 and algo._hip_sizes == {"actor": tuple(ha), "critic": tuple(hc)}
     buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     for k in ("obs", "obs_next", "act", "rew", "terminated", "truncated"):
         getattr(buf, k)[:] = g[k]
@@ -1524,6 +1533,9 @@ def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
     from tianshou_amd import widths as W
 
     eng = algo._hip_engine
+    if generic:
+        assert isinstance(eng, NG.NetNPGEngine)
+        return
     assert W.padding_is_zero(NG.actor_flat_to_torch(eng.actor, obs_dim, eng.hidden, act_dim)[:6], *ha)
     for vec in (eng.critic, eng.critic_m, eng.critic_v):
         assert W.padding_is_zero(NG.critic_flat_to_torch(vec, obs_dim, eng.hidden), *hc)

@@ -237,6 +237,110 @@ def test_update_matches_reference_golden(tag, critic_path, monkeypatch):
     assert np.abs(flat - g["flat_params"]).max() < 5e-3 * step
 
 
+def _split_flat(flat, obs_dim, act_dim, ha, hc):
+    """A fixture's flat vector (gen_golden._flat_from_modules: actor trunk (w, b)*, mu (w, b), sigma_param | critic trunk
+    (w, b)*, last (w, b)) -> (actor tensors, critic tensors) in nn.Linear layout."""
+    flat = torch.as_tensor(flat)
+    shapes_a, k = [], obs_dim
+    for h in ha:
+        shapes_a += [(h, k), (h,)]
+        k = h
+    shapes_a += [(act_dim, k), (act_dim,), (act_dim,)]
+    shapes_c, k = [], obs_dim
+    for h in hc:
+        shapes_c += [(h, k), (h,)]
+        k = h
+    shapes_c += [(1, k), (1,)]
+    out, off = [], 0
+    for shp in shapes_a + shapes_c:
+        n = int(np.prod(shp))
+        out.append(flat[off:off + n].reshape(shp).clone())
+        off += n
+    assert off == flat.numel()
+    return out[:len(shapes_a)], out[len(shapes_a):]
+
+
+@pytest.mark.parametrize("tag", ["npg_relu3", "trpo_tanh1"])
+def test_generic_trunks_match_reference_golden(tag):
+    """Round 6: NPG / TRPO on `Net` trunks outside [h1, h2] tanh -- NPG on THREE ReLU layers (actor [64, 48, 32]) beside a critic
+    of another depth ([40, 56]); TRPO on ONE tanh layer (actor [96], critic [80]) -- NetNPGEngine, layer by layer on the GEMM
+    kernels (ts_npg_net_actor_step / ts_npg_net_critic_steps), against what the unmodified REFERENCE's update() produced
+    (tests/golden/npg_{npg_relu3,trpo_tanh1}.npz, oracle/gen_golden.py::gen_depth): preprocessing, per-step statistics, parameters."""
+    from tianshou_amd import npg as NG
+    from tianshou_amd.ppo_wide import net_flat_from_tensors as nf
+
+    g, d, cfg = load_npg(tag)
+    obs_dim, act_dim = d["obs_dim"], d["act_dim"]
+    ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
+    act_name = {0: "tanh", 1: "relu", 2: "none"}[int(g["activation"])]
+    ta, tc = _split_flat(g["flat_params0"], obs_dim, act_dim, ha, hc)
+    ecfg = NG.NPGConfig(**{k: getattr(cfg, k) for k in ("algo", "gamma", "gae_lambda", "optim_critic_iters", "trust_region_size",
+                                                       "advantage_normalization", "return_scaling", "damping", "max_kl",
+                                                       "backtrack_coeff", "max_backtracks", "lr")})
+    eng = NG.NetNPGEngine(obs_dim, act_dim, ha, hc, act_name, nf(ta, obs_dim, ha, act_dim), nf(tc, obs_dim, hc, None), ecfg)
+    for got, want in zip(eng.actor_to_tensors(eng.actor) + eng.critic_to_tensors(eng.critic), ta + tc):        # layout round trip
+        assert torch.equal(got.cpu().reshape(want.shape), want)
+    idx = g["pre_indices"]
+    cut = np.nonzero(np.isin(idx, g["pre_unfinished"]))[0]
+    pre = eng.preprocess(g["obs"], g["obs_next"], g["act"], g["rew"], g["terminated"], g["truncated"], cut)
+    for k in ("v_s", "returns", "adv", "logp_old"):
+        np.testing.assert_allclose(pre[k].cpu().numpy(), g["pre_" + k], rtol=1e-5, atol=2e-5, err_msg=k)
+    stats, steps = eng.update(pre, d["batch_size"], d["repeat"], list(g["perms"]))
+    s, ref = stats.cpu().numpy(), g["stats"]
+    assert steps == ref.shape[0]
+    np.testing.assert_allclose(s[:, :ref.shape[1]], ref, rtol=2e-3, atol=2e-5)       # (float32 CG solves on both sides, as above)
+    flat = torch.cat([t.reshape(-1) for t in eng.actor_to_tensors(eng.actor) + eng.critic_to_tensors(eng.critic)]).cpu().numpy()
+    step = np.abs(g["flat_params"] - g["flat_params0"]).max()
+    assert step > 0 and np.abs(flat - g["flat_params"]).max() < 5e-3 * step
+
+
+@pytest.mark.parametrize("act_name,ha", [("relu", [64, 48, 32]), ("tanh", [96]), ("none", [32, 32]), ("tanh", [64, 64])])
+def test_generic_trunk_fisher_vector_product_vs_float64(act_name, ha):
+    """The three vectors an actor step exposes -- gradient, conjugate-gradient solution, F g + damping g -- of the per-layer path
+    (one forward-mode + one reverse pass per product) against float64 autograd of the same network: the gradient of the
+    surrogate and the DOUBLE-BACKWARD Fisher-vector product of the mean KL the reference computes (npg.py:195-200) at the
+    expansion point, where it equals the Gauss-Newton form the engine evaluates."""
+    from torch.distributions import Independent, Normal, kl_divergence
+
+    from tianshou_amd import npg as NG
+    from tianshou_amd.ppo_wide import net_flat_from_tensors as nf
+
+    obs_dim, act_dim, B = 13, 4, 600
+    gen = torch.Generator().manual_seed(3)
+    ta, k = [], obs_dim
+    for h in ha:
+        ta += [torch.randn(h, k, generator=gen) / np.sqrt(k), torch.randn(h, generator=gen) * 0.1]
+        k = h
+    ta += [torch.randn(act_dim, k, generator=gen) * 0.3 / np.sqrt(k), torch.randn(act_dim, generator=gen) * 0.1,
+           torch.full((act_dim,), -0.5) + 0.1 * torch.randn(act_dim, generator=gen)]
+    tc = [torch.randn(32, obs_dim, generator=gen) * 0.1, torch.zeros(32), torch.randn(1, 32, generator=gen) * 0.1, torch.zeros(1)]
+    cfg = NG.NPGConfig(algo="npg", damping=0.1, trust_region_size=0.05)
+    eng = NG.NetNPGEngine(obs_dim, act_dim, ha, [32], act_name, nf(ta, obs_dim, ha, act_dim), nf(tc, obs_dim, [32], None), cfg)
+    obs, act = torch.randn(B, obs_dim, generator=gen), torch.randn(B, act_dim, generator=gen) * 0.7
+    adv = torch.randn(B, generator=gen)
+    _, dbg = eng.actor_step(obs, act, adv, want_debug=True)
+    fn = {"relu": torch.relu, "tanh": torch.tanh, "none": lambda x: x}[act_name]
+    p64 = [t.double().requires_grad_(True) for t in ta]
+
+    def dist_of(params):
+        h = obs.double()
+        for i in range(len(ha)):
+            h = fn(torch.nn.functional.linear(h, params[2 * i], params[2 * i + 1]))
+        mu = torch.nn.functional.linear(h, params[2 * len(ha)], params[2 * len(ha) + 1])
+        return Independent(Normal(mu, (params[-1].view(1, -1) + torch.zeros_like(mu)).exp()), 1)
+
+    dist = dist_of(p64)
+    loss = -(dist.log_prob(act.double()) * adv.double()).mean()
+    g64 = torch.cat([x.reshape(-1) for x in torch.autograd.grad(loss, p64, retain_graph=True)])
+    kl = kl_divergence(dist_of([t.detach() for t in p64]), dist).mean()
+    gk = torch.cat([x.reshape(-1) for x in torch.autograd.grad(kl, p64, create_graph=True)])
+    fg64 = torch.cat([x.reshape(-1) for x in torch.autograd.grad((gk * g64).sum(), p64)]) + 0.1 * g64
+    got_g = torch.cat([t.reshape(-1) for t in eng.actor_to_tensors(dbg[0])]).cpu()
+    got_fg = torch.cat([t.reshape(-1) for t in eng.actor_to_tensors(dbg[2])]).cpu()
+    assert rel_err(got_g, g64) < 2e-5, rel_err(got_g, g64)
+    assert rel_err(got_fg, fg64) < 5e-5, rel_err(got_fg, fg64)
+
+
 def test_bad_arguments_fail_loudly():
     from tianshou_amd import npg as NG
 

@@ -801,6 +801,41 @@ int backward_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, c
     return TS_OK;
 }
 
+// forward-mode combine of a generic trunk's layer: t = (ta - bias_w[col]) + tb (see jvp_combine_kernel); out = t * act'(h) with the
+// layer's own output h: 1 - h^2 (tanh), [h > 0] (ReLU: torch's threshold_backward sign test), 1 (no activation / the head)
+__global__ __launch_bounds__(256) void jvp_combine_act_kernel(const float* __restrict__ ta, const float* __restrict__ tb,
+                                                              const float* __restrict__ bias_w, const float* __restrict__ h,
+                                                              int64_t n, int cols, int act_fn, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = (ta ? ta[i] - bias_w[i % cols] : 0.f) + tb[i];
+    float d = 1.f;
+    if (h) d = act_fn == TS_NET_ACT_TANH ? 1.f - h[i] * h[i] : (act_fn == TS_NET_ACT_RELU ? (h[i] > 0.f ? 1.f : 0.f) : 1.f);
+    out[i] = t * d;
+}
+
+// dmu = J v for a direction v (same layout as the parameters) of a generic trunk, given the forward pass's activations:
+// d_0 = (x V_0 + bv_0) act'(h_0);  d_i = (d_{i-1} W_i + h_{i-1} V_i + bv_i) act'(h_i);  head: no activation.
+// ta / tb: [B, wmax] scratch; d[2]: the directional derivatives ping-pong; dmu: [B, HEAD].
+int jvp_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, const float* v, const float* x, const ActL& a, float* ta,
+          float* tb, float* const* d, float* dmu, float* split, int64_t B) {
+    const float* dprev = nullptr;
+    for (int i = 0; i < n.L; ++i) {
+        const bool head = i + 1 == n.L;
+        const int64_t cnt = B * n.width[i + 1];
+        const float* hin = i == 0 ? x : a.h[i - 1];
+        if (dprev) if (int rc = ts::conv_forward(s, n.l[i], dprev, p + n.off[i], ta, false, split, ws)) return rc;
+        if (int rc = ts::conv_forward(s, n.l[i], hin, v + n.off[i], tb, false, split, ws)) return rc;
+        float* out = head ? dmu : d[i & 1];
+        hipLaunchKernelGGL(jvp_combine_act_kernel, dim3((unsigned)ts::ceil_div(cnt, 256)), dim3(256), 0, s, dprev ? ta : (const float*)nullptr,
+                           tb, p + n.off[i] + (int64_t)n.width[i] * n.width[i + 1], head ? (const float*)nullptr : a.h[i], cnt,
+                           n.width[i + 1], n.act_fn, out);
+        TS_LAUNCH_CHECK();
+        dprev = out;
+    }
+    return TS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1280,6 +1315,157 @@ int ts_ppo_net_step(ts_workspace* ws, float* params, float* adam_m, float* adam_
     // joint clip_grad_norm_ over actor + critic (a2c.py:103-107) + Adam
     return ts::optim_step(s, ts::optim_from(hp), params, adam_m, adam_v, grad, P, adam_step, hp->lr, hp->beta1, hp->beta2, hp->adam_eps,
                          hp->max_grad_norm > 0.0 ? hp->max_grad_norm : 0.0, norm_part);
+}
+
+
+// ---- NPG / TRPO on trunks of any depth / widths / activation (ts_net_desc; round 6) -----------------------------------------
+// The per-layer path of ts_npg_actor_step / ts_npg_critic_steps over forward_l / backward_l / jvp_l: the same loss, Fisher,
+// conjugate-gradient, candidate and selection kernels on the head's 32 columns.
+int ts_npg_net_actor_step(ts_workspace* ws, float* actor, const ts_net_desc* net, int64_t act_dim, const float* obs, const float* act,
+                          const float* adv, const float* logp_old, int64_t B, const ts_npg_hparams* hp, float* stats_out3,
+                          float* dbg_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_net_actor_step: workspace is NULL");
+    TS_REQUIRE(actor && net && obs && act && adv && hp && stats_out3 && B >= 1 && act_dim >= 1 && act_dim <= HEAD, TS_ERR_INVALID_ARG,
+               "ts_npg_net_actor_step: bad argument");
+    TS_REQUIRE(hp->algo == 0 || hp->algo == 1, TS_ERR_INVALID_ARG, "ts_npg_net_actor_step: algo must be 0 (NPG) or 1 (TRPO)");
+    TS_REQUIRE(hp->algo == 0 || (logp_old && hp->max_backtracks >= 1 && hp->max_backtracks <= 32 && hp->max_kl > 0.0),
+               TS_ERR_INVALID_ARG, "ts_npg_net_actor_step: TRPO needs logp_old, max_kl > 0 and 1 <= max_backtracks <= 32");
+    TS_REQUIRE(hp->cg_iters >= 1 && hp->cg_iters <= 100, TS_ERR_INVALID_ARG, "ts_npg_net_actor_step: bad cg_iters");
+    TS_REQUIRE(!(net->flags & TS_NET_CONDITIONED_SIGMA) && !(net->max_action > 0.0), TS_ERR_UNSUPPORTED,
+               "ts_npg_net_actor_step: an unbounded actor with a state-independent sigma_param is required");
+    NetL n;
+    if (int rc = make_netl((int)B, net, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int A = (int)act_dim;
+    const int64_t P = n.off[n.L] + HEAD, sig = n.off[n.L];
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    const int n_cand = hp->algo == 1 ? hp->max_backtracks : 1;
+    const size_t sl = slab_floats(n), sp = split_floats(n);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + 2 * actl_bytes(n, B) + 6 * al(4 * B * n.wmax) + 3 * al(4 * B * HEAD) + al(4 * sl) +
+                                        al(4 * sp) + (size_t)(6 + n_cand) * al(4 * P) + al(4 * (size_t)n_blocks * (2 + A)) +
+                                        al(4 * (8 + 2 * n_cand)) + 4096))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const ActL a0 = take_actl(c, n, B), a1 = take_actl(c, n, B);         // activations at theta; at a candidate
+    float* ta = c.f(B * n.wmax); float* tb = c.f(B * n.wmax);
+    float* dd[2] = {c.f(B * n.wmax), c.f(B * n.wmax)};
+    float* dha = c.f(B * n.wmax); float* dhb = c.f(B * n.wmax);
+    float* dmu = c.f(B * HEAD); float* d_head = c.f(B * HEAD); float* u = c.f(B * HEAD);
+    float* slabs = c.f(sl);
+    float* split = c.f(sp);
+    float* g = c.f(P); float* cx = c.f(P); float* cr = c.f(P); float* cp = c.f(P); float* cz = c.f(P); float* fx = c.f(P);
+    float* cands = c.f((size_t)n_cand * P);
+    float* partial = c.f((size_t)n_blocks * (2 + A));
+    float* sc = c.f(8 + 2 * n_cand);                                       // {rdotr, done, p.z, step, -, -, -, -, res...}
+    float* step = sc + 3;
+    float* res = sc + 8;
+    const float* out0 = a0.h[n.L - 1];
+
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    // vanilla gradient of the surrogate (npg.py:152-158 / trpo.py:135-141)
+    if (int rc = forward_l(s, ws, n, actor, x, a0, split, B)) return rc;
+    hipLaunchKernelGGL(actor_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, out0, act, adv, logp_old, actor + sig, hp->algo, B, A,
+                       d_head, partial);
+    hipLaunchKernelGGL(actor_loss_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, A, stats_out3, g + sig);
+    TS_LAUNCH_CHECK();
+    if (int rc = backward_l(s, ws, n, actor, x, a0, d_head, g, dha, dhb, slabs, B)) return rc;
+
+    auto fvp = [&](const float* v, float* out) -> int {                   // F v (+ damping v) for a direction v
+        if (int rc = jvp_l(s, ws, n, actor, v, x, a0, ta, tb, dd, dmu, split, B)) return rc;
+        hipLaunchKernelGGL(fisher_upstream_kernel, dim3((unsigned)ts::ceil_div(B * HEAD, 256)), dim3(256), 0, s, dmu, actor + sig, B, A, u);
+        TS_LAUNCH_CHECK();
+        if (int rc = backward_l(s, ws, n, actor, x, a0, u, out, dha, dhb, slabs, B)) return rc;
+        hipLaunchKernelGGL(fvp_finish_kernel, dim3((unsigned)ts::ceil_div(P, 256)), dim3(256), 0, s, out, v, P, sig, A, (float)hp->damping);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    };
+    // conjugate gradients (npg.py:202-224): x ~ F^-1 g; search direction = -x
+    hipLaunchKernelGGL(cg_init_kernel, dim3(1), dim3(1024), 0, s, g, cx, cr, cp, P, sc);
+    for (int it = 0; it < hp->cg_iters; ++it) {
+        if (int rc = fvp(cp, cz)) return rc;
+        hipLaunchKernelGGL(cg_update_kernel, dim3(1), dim3(1024), 0, s, cx, cr, cp, cz, P, (float)hp->residual_tol, sc);
+        TS_LAUNCH_CHECK();
+    }
+    if (dbg_out) {                                    // {gradient, search direction x (sign flipped by the caller), F g + damping g}
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out, g, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out + P, cx, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        if (int rc = fvp(g, fx)) return rc;
+        TS_HIP_CHECK(hipMemcpyAsync(dbg_out + 2 * P, fx, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+    }
+    const unsigned gp = (unsigned)ts::ceil_div(P, 256);
+    auto eval = [&](const float* cand, float* out2, bool with_loss) -> int {     // kl(old || cand) [, surrogate at cand]
+        if (int rc = forward_l(s, ws, n, cand, x, a1, split, B)) return rc;
+        hipLaunchKernelGGL(kl_eval_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, out0, actor + sig, a1.h[n.L - 1], cand + sig, act, adv,
+                           with_loss ? logp_old : (const float*)nullptr, B, A, partial);
+        hipLaunchKernelGGL(kl_finish_kernel, dim3(1), dim3(256), 0, s, partial, n_blocks, B, out2);
+        TS_LAUNCH_CHECK();
+        return TS_OK;
+    };
+    if (hp->algo == 0) {                              // npg.py:170-177
+        hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, (const float*)nullptr, (float)hp->trust_region_size,
+                           1.f, cands);
+        if (int rc = eval(cands, res, false)) return rc;
+        TS_HIP_CHECK(hipMemcpyAsync(actor, cands, sizeof(float) * P, hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemcpyAsync(stats_out3 + 1, res, sizeof(float), hipMemcpyDeviceToDevice, s));
+        TS_HIP_CHECK(hipMemsetAsync(stats_out3 + 2, 0, sizeof(float), s));
+        return TS_OK;
+    }
+    // TRPO: step size (trpo.py:153-160), then every backtracking candidate, then the reference's choice among them
+    if (int rc = fvp(cx, fx)) return rc;
+    hipLaunchKernelGGL(trpo_step_size_kernel, dim3(1), dim3(1024), 0, s, cx, fx, P, (float)hp->max_kl, step);
+    float cpow = 1.f;
+    for (int k = 0; k < n_cand; ++k) {
+        hipLaunchKernelGGL(candidate_kernel, dim3(gp), dim3(256), 0, s, actor, cx, P, step, 0.f, cpow, cands + (size_t)k * P);
+        if (int rc = eval(cands + (size_t)k * P, res + 2 * k, true)) return rc;
+        cpow = cpow * (float)hp->backtrack_coeff;
+    }
+    hipLaunchKernelGGL(trpo_select_kernel, dim3((unsigned)std::min<int64_t>(gp, 64)), dim3(256), 0, s, actor, cands, P, res, n_cand,
+                       (float)hp->max_kl, (float)hp->backtrack_coeff, step, stats_out3);
+    TS_LAUNCH_CHECK();
+    return TS_OK;
+}
+
+int ts_npg_net_critic_steps(ts_workspace* ws, float* critic, float* adam_m, float* adam_v, int64_t adam_step, const ts_net_desc* net,
+                            const float* obs, const float* returns, int64_t B, int64_t iters, double lr, double beta1, double beta2,
+                            double adam_eps, double max_grad_norm, float* loss_out, float* grad_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_net_critic_steps: workspace is NULL");
+    TS_REQUIRE(critic && adam_m && adam_v && net && obs && returns && loss_out && B >= 1 && adam_step >= 1 && iters >= 1 && iters <= 4096,
+               TS_ERR_INVALID_ARG, "ts_npg_net_critic_steps: bad argument");
+    NetL n;
+    if (int rc = make_netl((int)B, net, &n)) return rc;
+    hipStream_t s = ts::as_stream(stream);
+    const int64_t P = n.off[n.L];
+    const int n_blocks = (int)ts::ceil_div(B, 256);
+    const size_t sl = slab_floats(n), sp = split_floats(n);
+    if (int rc = ts::ws_reserve(ws, al(4 * B * n.k0) + actl_bytes(n, B) + al(4 * B * HEAD) + 2 * al(4 * B * n.wmax) + al(4 * sl) + al(4 * sp) +
+                                        al(4 * P) + al(4 * n_blocks) + 8192))
+        return rc;
+    Carve c{static_cast<char*>(ws->base)};
+    float* x = c.f(B * n.k0);
+    const ActL a = take_actl(c, n, B);
+    float* d_head = c.f(B * HEAD);
+    float* dha = c.f(B * n.wmax); float* dhb = c.f(B * n.wmax);
+    float* slabs = c.f(sl);
+    float* split = c.f(sp);
+    float* grad = c.f(P);
+    float* norm_part = c.f(1024);
+    float* lpart = c.f(n_blocks);
+    if (grad_out) grad = grad_out;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)ts::ceil_div(B * n.k0, 256)), dim3(256), 0, s, obs, B, n.obs, n.k0, x);
+    TS_LAUNCH_CHECK();
+    for (int64_t it = 0; it < iters; ++it) {                              // npg.py:179-187: MSE to the returns, clip + Adam
+        if (int rc = forward_l(s, ws, n, critic, x, a, split, B)) return rc;
+        hipLaunchKernelGGL(critic_loss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, a.h[n.L - 1], returns, B, d_head, lpart);
+        hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, s, lpart, n_blocks, 1.f / (float)B, loss_out);
+        TS_LAUNCH_CHECK();
+        if (int rc = backward_l(s, ws, n, critic, x, a, d_head, grad, dha, dhb, slabs, B)) return rc;
+        if (lr < 0.0) continue;
+        if (int rc = ts::adam_step(s, critic, adam_m, adam_v, grad, P, adam_step + it, lr, beta1, beta2, adam_eps, max_grad_norm, norm_part))
+            return rc;
+    }
+    return TS_OK;
 }
 
 }  // extern "C"

@@ -751,30 +751,47 @@ def _make_hip_natural(algo: str, ref=None):
 
     class HipNatural(_HipGlue, Base):
         def __init__(self, *args, device="cuda", **kwargs):
+            """Net[h1, h2] tanh actor and critic (the nets of examples/mujoco/mujoco_npg.py, any two widths): the fused / GEMM
+            passes of NPGEngine.  Every other `Net(hidden_sizes=[...], activation=Tanh | ReLU | None)` trunk -- other depths,
+            ReLU, actor and critic trunks that differ -- (round 6): NetNPGEngine, layer by layer on the GEMM kernels."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
-            sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
-            if set(sa.keys()) != set(TIANSHOU_ACTOR_KEYS) or list(sc.keys()) != list(TIANSHOU_CRITIC_KEYS):
-                raise NotImplementedError(f"{who}: networks must be those of examples/mujoco/mujoco_npg.py (the PPO nets)")
-            from . import widths as WD
-
-            try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
-                la, lc = [sa[k] for k in TIANSHOU_ACTOR_KEYS[:6]], [sc[k] for k in TIANSHOU_CRITIC_KEYS]
-                self._hip_sizes = {"actor": WD.two_layer_widths(la), "critic": WD.two_layer_widths(lc)}
-                self._hip_hidden = WD.common_hidden(la, lc)
-            except NotImplementedError as e:
-                raise NotImplementedError(f"{who}: two hidden layers of widths up to 1024 per network ({e})") from None
-            if not getattr(self.policy.actor, "_unbounded", False) or getattr(self.policy.actor, "_c_sigma", True):
+            actor, critic = self.policy.actor, self.critic
+            sa, sc = actor.state_dict(), critic.state_dict()
+            if getattr(actor, "_c_sigma", True) or not getattr(actor, "_unbounded", False):
                 raise NotImplementedError(f"{who}: actor must be unbounded with a state-independent sigma_param")
+            _, ha, act_a = _trunk_spec(actor, "actor")               # (raises for anything but Linear + Tanh / ReLU / nothing)
+            _, hc, act_c = _trunk_spec(critic, "critic")
+            ka, kc = _net_keys(actor, critic)                        # == TIANSHOU_ACTOR_KEYS / _CRITIC_KEYS for two hidden layers
+            if set(sa.keys()) != set(ka) or list(sc.keys()) != list(kc) or act_a != act_c:
+                raise NotImplementedError(f"{who}: actor and critic must be Net trunks with one activation + a linear mu / value head "
+                                          "(examples/mujoco/mujoco_npg.py)")
+            self._hip_akeys, self._hip_ckeys = ka, kc
+            self._hip_two = len(ha) == 2 and len(hc) == 2 and act_a == "tanh"
+            if not 1 <= int(sa["mu.model.0.weight"].shape[0]) <= 32:
+                raise NotImplementedError(f"{who}: at most 32 actions")
+            if self._hip_two:
+                from . import widths as WD
+
+                try:        # any two hidden widths per network (round 6): embedded by zero padding (tianshou_amd.widths)
+                    la, lc = [sa[k] for k in ka[:6]], [sc[k] for k in kc]
+                    self._hip_sizes = {"actor": WD.two_layer_widths(la), "critic": WD.two_layer_widths(lc)}
+                    self._hip_hidden = WD.common_hidden(la, lc)
+                except NotImplementedError as e:
+                    raise NotImplementedError(f"{who}: hidden layers of widths up to 1024 per network ({e})") from None
+            else:
+                if max(ha + hc) > 1024 or not 1 <= len(ha) <= 7 or not 1 <= len(hc) <= 7:
+                    raise NotImplementedError(f"{who}: 1 .. 7 hidden layers of widths up to 1024 per network")
+                self._hip_trunks = (list(ha), list(hc), act_a)
             _adam_of(self.optim)
             self._hip_engine = None
             self._hip_glue_init()
 
         def _engine(self):
             if self._hip_engine is None:
-                sa = self.policy.actor.state_dict()
-                hidden, obs_dim = self._hip_hidden, sa[TIANSHOU_ACTOR_KEYS[0]].shape[1]
-                act_dim = sa[TIANSHOU_ACTOR_KEYS[4]].shape[0]
+                sa, sc = self.policy.actor.state_dict(), self.critic.state_dict()
+                ka, kc = self._hip_akeys, self._hip_ckeys
+                obs_dim, act_dim = sa[ka[0]].shape[1], sa["mu.model.0.weight"].shape[0]
                 opt, g = _adam_of(self.optim)
                 cfg = NG.NPGConfig(algo=algo, gamma=self.gamma, gae_lambda=self.gae_lambda,
                                    optim_critic_iters=self.optim_critic_iters,
@@ -785,14 +802,23 @@ def _make_hip_natural(algo: str, ref=None):
                                    max_backtracks=int(getattr(self, "max_backtracks", 10)), lr=g["lr"], betas=tuple(g["betas"]),
                                    adam_eps=g["eps"], max_grad_norm=self.optim._max_grad_norm)
                 dev = self._hip_device
-                sc = self.critic.state_dict()
-                eng = self._hip_engine = NG.NPGEngine(
-                    obs_dim, act_dim, hidden, NG.actor_flat_from_torch([sa[k] for k in TIANSHOU_ACTOR_KEYS], obs_dim, hidden, act_dim, dev),
-                    NG.critic_flat_from_torch([sc[k] for k in TIANSHOU_CRITIC_KEYS], obs_dim, hidden, dev), cfg)
+                ms, vs, step = adam_state(opt, params_by_keys(self.critic, kc))     # resume
+                if self._hip_two:
+                    hidden = self._hip_hidden
+                    eng = self._hip_engine = NG.NPGEngine(
+                        obs_dim, act_dim, hidden, NG.actor_flat_from_torch([sa[k] for k in ka], obs_dim, hidden, act_dim, dev),
+                        NG.critic_flat_from_torch([sc[k] for k in kc], obs_dim, hidden, dev), cfg)
+                    eng.critic_m = NG.critic_flat_from_torch(ms, obs_dim, hidden, dev)
+                    eng.critic_v = NG.critic_flat_from_torch(vs, obs_dim, hidden, dev)
+                else:
+                    from .ppo_wide import net_flat_from_tensors as nf
+
+                    ha, hc, act_name = self._hip_trunks
+                    eng = self._hip_engine = NG.NetNPGEngine(
+                        obs_dim, act_dim, ha, hc, act_name, nf([sa[k] for k in ka], obs_dim, ha, act_dim, dev),
+                        nf([sc[k] for k in kc], obs_dim, hc, None, dev), cfg)
+                    eng.critic_m, eng.critic_v = eng.critic_from_tensors(ms), eng.critic_from_tensors(vs)
                 eng.ret_rms = [float(self.ret_rms.mean), float(self.ret_rms.var), float(self.ret_rms.count)]
-                ms, vs, step = adam_state(opt, params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS))     # resume
-                eng.critic_m = NG.critic_flat_from_torch(ms, obs_dim, hidden, dev)
-                eng.critic_v = NG.critic_flat_from_torch(vs, obs_dim, hidden, dev)
                 eng.adam_step = step
             return self._hip_engine
 
@@ -815,17 +841,21 @@ def _make_hip_natural(algo: str, ref=None):
             perms = [np.random.permutation(len(batch)) for _ in range(repeat)]     # Batch.split, batch.py:1209
             stats, _ = eng.update(self._hip_pre, batch_size, repeat, perms)
             arr = stats.cpu().numpy().astype(np.float64)                          # one D2H per update()
-            dims = (eng.obs_dim, eng.hidden)
+            if self._hip_two:
+                dims, szc = (eng.obs_dim, eng.hidden), self._hip_sizes["critic"]
+                actor_t = NG.actor_flat_to_torch(eng.actor, eng.obs_dim, eng.hidden, eng.act_dim, sizes=self._hip_sizes["actor"])
+                critic_t, m_t, v_t = (NG.critic_flat_to_torch(x, *dims, sizes=szc) for x in (eng.critic, eng.critic_m, eng.critic_v))
+            else:
+                actor_t = eng.actor_to_tensors(eng.actor)
+                critic_t, m_t, v_t = (eng.critic_to_tensors(x) for x in (eng.critic, eng.critic_m, eng.critic_v))
+            cparams = params_by_keys(self.critic, self._hip_ckeys)
             with torch.no_grad():
-                for p, t in zip(params_by_keys(self.policy.actor, TIANSHOU_ACTOR_KEYS),
-                                NG.actor_flat_to_torch(eng.actor, eng.obs_dim, eng.hidden, eng.act_dim, sizes=self._hip_sizes["actor"])):
+                for p, t in zip(params_by_keys(self.policy.actor, self._hip_akeys), actor_t):
                     p.copy_(t.reshape(p.shape))
-                cparams = params_by_keys(self.critic, TIANSHOU_CRITIC_KEYS)
-                szc = self._hip_sizes["critic"]
-                for p, t in zip(cparams, NG.critic_flat_to_torch(eng.critic, *dims, sizes=szc)):
-                    p.copy_(t)
-            store_adam_state(self.optim._optim, cparams, NG.critic_flat_to_torch(eng.critic_m, *dims, sizes=szc),
-                             NG.critic_flat_to_torch(eng.critic_v, *dims, sizes=szc), eng.adam_step)
+                for p, t in zip(cparams, critic_t):
+                    p.copy_(t.reshape(p.shape))
+            store_adam_state(self.optim._optim, cparams, [t.reshape(p.shape) for p, t in zip(cparams, m_t)],
+                             [t.reshape(p.shape) for p, t in zip(cparams, v_t)], eng.adam_step)
             self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = eng.ret_rms
             seq = SequenceSummaryStats.from_sequence
             kw = dict(actor_loss=seq(arr[:, 0]), vf_loss=seq(arr[:, 1]), kl=seq(arr[:, 2]))

@@ -275,3 +275,108 @@ class NPGEngine:
         if side is None:
             side = _CRITIC_STREAMS[idx] = torch.cuda.Stream(device=self.device)
         return side
+
+
+class NetNPGEngine(NPGEngine):
+    """NPGEngine's interface for actor / critic trunks of any depth, widths and activation (round 6): `Net(hidden_sizes=[...],
+    activation=nn.Tanh | nn.ReLU | None)` (utils/net/common.py:246-369), actor and critic trunks independent.  Runs layer by layer on
+    the GEMM kernels (ts_npg_net_actor_step / ts_npg_net_critic_steps / ts_ppo_net_infer); the Fisher-vector product is one
+    forward-mode and one reverse pass through the trunk.  Flat vectors: `ppo_wide.net_flat_from_tensors` (ts_net_layout)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, hidden_actor, hidden_critic, activation: str, actor: torch.Tensor,
+                 critic: torch.Tensor, cfg: NPGConfig):
+        if not actor.is_cuda:
+            raise RuntimeError("NetNPGEngine needs parameters on an MI355X (no CPU fallback)")
+        if cfg.algo not in ("npg", "trpo"):
+            raise ValueError("algo must be 'npg' or 'trpo'")
+        self.hidden_actor, self.hidden_critic, self.activation = [int(h) for h in hidden_actor], [int(h) for h in hidden_critic], activation
+        self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation)
+        self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation)
+        out = (C.c_int64 * 3)()
+        _lib.check(_lib.load().ts_net_layout(C.byref(self._na), _lib.i64(act_dim), out))
+        k0, n_actor = int(out[0]), int(out[1])
+        _lib.check(_lib.load().ts_net_layout(C.byref(self._nc), _lib.i64(act_dim), out))
+        n_critic = int(out[2])
+        if actor.numel() != n_actor or critic.numel() != n_critic:
+            raise ValueError("flat parameter vectors do not match ts_net_layout")
+        self.obs_dim, self.act_dim, self.hidden, self.cfg = obs_dim, act_dim, None, cfg
+        self.lay = {"k0": k0, "actor_count": n_actor, "critic_count": n_critic}
+        self.device = actor.device
+        cl = lambda t: t.detach().float().contiguous().clone()  # noqa: E731
+        self.actor, self.critic = cl(actor), cl(critic)
+        self.critic_m, self.critic_v = torch.zeros_like(self.critic), torch.zeros_like(self.critic)
+        self.adam_step = 0
+        self.ret_rms = [0.0, 1.0, 0.0]
+        self._ws = _lib.default_workspace(self.device.index or 0)
+
+    # -- converters (nn.Linear-layout tensor lists <-> flat vectors) ----------------------------------------------------------
+    def actor_from_tensors(self, t, device=None) -> torch.Tensor:
+        from .ppo_wide import net_flat_from_tensors
+
+        return net_flat_from_tensors(t, self.obs_dim, self.hidden_actor, self.act_dim, device or self.device)
+
+    def critic_from_tensors(self, t, device=None) -> torch.Tensor:
+        from .ppo_wide import net_flat_from_tensors
+
+        return net_flat_from_tensors(t, self.obs_dim, self.hidden_critic, None, device or self.device)
+
+    def actor_to_tensors(self, flat):
+        from .ppo_wide import net_flat_to_tensors
+
+        return net_flat_to_tensors(flat, self.obs_dim, self.hidden_actor, self.act_dim, True)
+
+    def critic_to_tensors(self, flat):
+        from .ppo_wide import net_flat_to_tensors
+
+        return net_flat_to_tensors(flat, self.obs_dim, self.hidden_critic, 1, False)
+
+    def infer(self, obs, act=None, want_v: bool = True, want_mu: bool = False):
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        b = obs.shape[0]
+        act = None if act is None else self._f32(act, (b, self.act_dim))
+        v = torch.empty(b, dtype=torch.float32, device=self.device) if want_v else None
+        logp = torch.empty(b, dtype=torch.float32, device=self.device) if act is not None else None
+        mu = torch.empty((b, self.act_dim), dtype=torch.float32, device=self.device) if want_mu else None
+        _lib.check(_lib.load().ts_ppo_net_infer(
+            self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic), C.byref(self._na), C.byref(self._nc), _lib.i64(self.act_dim),
+            _lib.ptr(obs), _lib.ptr(act), _lib.i64(b), _lib.ptr(v), _lib.ptr(logp), _lib.ptr(mu), _lib.current_stream(self.device)))
+        return (v, logp, mu) if want_mu else (v, logp)
+
+    def _critic_call(self, ws, obs, returns, iters: int, first_step: int, apply: bool, grad_out=None) -> torch.Tensor:
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        b = obs.shape[0]
+        returns = self._f32(returns, (b,))
+        cfg = self.cfg
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load().ts_npg_net_critic_steps(
+            ws.handle, _lib.ptr(self.critic), _lib.ptr(self.critic_m), _lib.ptr(self.critic_v), _lib.i64(first_step), C.byref(self._nc),
+            _lib.ptr(obs), _lib.ptr(returns), _lib.i64(b), _lib.i64(iters), _lib.f64(cfg.lr if apply else -1.0), _lib.f64(cfg.betas[0]),
+            _lib.f64(cfg.betas[1]), _lib.f64(cfg.adam_eps), _lib.f64(cfg.max_grad_norm or 0.0), _lib.ptr(loss), _lib.ptr(grad_out),
+            _lib.current_stream(self.device)))
+        return loss
+
+    def critic_steps(self, obs, returns, iters: int) -> torch.Tensor:
+        ws = _lib.default_workspace(self.device.index or 0)         # the CALLING stream's workspace (update() runs this on a side stream)
+        loss = self._critic_call(ws, obs, returns, iters, self.adam_step + 1, True)
+        self.adam_step += iters
+        return loss
+
+    def critic_step(self, obs, returns, grad_out: torch.Tensor | None = None, apply: bool = True) -> torch.Tensor:
+        if apply:
+            self.adam_step += 1
+        return self._critic_call(self._ws, obs, returns, 1, max(self.adam_step, 1), apply, grad_out)
+
+    def actor_step(self, obs, act, adv, logp_old=None, want_debug: bool = False):
+        obs = self._f32(obs).reshape(-1, self.obs_dim)
+        b = obs.shape[0]
+        act, adv = self._f32(act, (b, self.act_dim)), self._f32(adv, (b,))
+        logp_old = None if logp_old is None else self._f32(logp_old, (b,))
+        if self.cfg.algo == "trpo" and logp_old is None:
+            raise ValueError("TRPO needs logp_old")
+        stats = torch.empty(3, dtype=torch.float32, device=self.device)
+        dbg = torch.empty((3, self.lay["actor_count"]), dtype=torch.float32, device=self.device) if want_debug else None
+        hp = self.cfg.to_c()
+        _lib.check(_lib.load().ts_npg_net_actor_step(
+            self._ws.handle, _lib.ptr(self.actor), C.byref(self._na), _lib.i64(self.act_dim), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(adv),
+            _lib.ptr(logp_old), _lib.i64(b), C.byref(hp), _lib.ptr(stats), _lib.ptr(dbg), _lib.current_stream(self.device)))
+        return (stats, dbg) if want_debug else stats
