@@ -925,6 +925,10 @@ int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
  * into the forward GEMM's epilogue and into the input-gradient GEMM's mask). */
 #define TS_MLP_MAX_HIDDEN_LAYERS 6
 int ts_mlp_set_trunk(ts_workspace* ws, int64_t hidden, int64_t depth);
+/* Net(activation=nn.Tanh) in place of the default nn.ReLU (utils/net/common.py:246-369) for the same entry points: TS_NET_ACT_RELU
+ * (default; ts_mlp_set_hidden / ts_mlp_set_trunk reset to it) or TS_NET_ACT_TANH after every hidden layer.  Tanh trunks always run
+ * layer by layer (the fused three-layer kernels are ReLU). */
+int ts_mlp_set_activation(ts_workspace* ws, int activation);
 /* ContinuousActorProbabilistic(unbounded=False) -- the class default, utils/net/continuous.py:194, 230-231: mu = max_action *
  * tanh(mu) in front of SAC's / REDQ's Gaussian (the examples pass unbounded=True).  A property of the workspace like the trunk:
  * applies to every ts_sac_* / ts_redq_* entry point subsequently called with `ws` -- forward, target, update (the gradient goes

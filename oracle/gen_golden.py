@@ -1545,7 +1545,7 @@ def main() -> None:
 def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int, n_updates: int,
             seed: int, auto_alpha: bool, alpha: float = 0.2, n_step: int = 1, tau: float = 0.005,
             gamma: float = 0.99, actor_lr: float = 1e-3, critic_lr: float = 1e-3, alpha_lr: float = 3e-4, hidden=256,
-            max_action: float = 0.0) -> None:
+            max_action: float = 0.0, activation=nn.ReLU) -> None:
     """Runs the reference SAC.update() (nets as in examples/mujoco/mujoco_sac.py:82-104) on a synthetic
     VectorReplayBuffer, recording the rsample() noise of every policy call and the outputs of every update.
     hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- Net(hidden_sizes=...) takes any widths.
@@ -1559,7 +1559,7 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
     torch.manual_seed(seed)
     sa_, sc_ = OS.layer_sizes(hidden)              # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
     AK, CK = OS.trunk_keys(len(sa_), ("mu", "sigma")), OS.trunk_keys(len(sc_), ("last",))
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(sa_))
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=list(sa_), activation=activation)
     if max_action > 0.0:
         actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action,
                                              conditioned_sigma=True)           # unbounded=False: the class default
@@ -1567,8 +1567,8 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
     else:
         actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                              conditioned_sigma=True)
-    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
-    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)
+    net_c1 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True, activation=activation)
+    net_c2 = Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True, activation=activation)
     critic1, critic2 = ContinuousCritic(preprocess_net=net_c1), ContinuousCritic(preprocess_net=net_c2)
     space = gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,))
     policy = SACPolicy(actor=actor, action_space=space)
@@ -1649,14 +1649,15 @@ def gen_sac(tag: str, *, E: int, slots: int, steps: int, obs_dim: int, act_dim: 
         SAC._preprocess_batch = orig_pre
     cfg = dict(gamma=gamma, tau=tau, n_step=n_step, alpha=alpha, auto_alpha=float(auto_alpha),
                target_entropy=float(-act_dim), log_alpha0=0.0, actor_lr=actor_lr, critic_lr=critic_lr,
-               alpha_lr=alpha_lr, **({"max_action": max_action} if max_action > 0.0 else {}))
+               alpha_lr=alpha_lr, **({"max_action": max_action} if max_action > 0.0 else {}),
+               **({"tanh_trunks": 1.0} if activation is nn.Tanh else {}))
     out["cfg_keys"] = np.array(list(cfg.keys()))
     out["cfg_vals"] = np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"sac_{tag}.npz"), **out)
 
 
 def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: int, act_dim: int, batch: int,
-            n_updates: int, seed: int, max_action: float = 1.0, n_step: int = 1, hidden=256, **kw) -> None:
+            n_updates: int, seed: int, max_action: float = 1.0, n_step: int = 1, hidden=256, activation=nn.ReLU, **kw) -> None:
     """Runs the reference TD3.update() (twin) or DDPG.update() (nets of examples/mujoco/mujoco_td3.py:85-103 /
     mujoco_ddpg.py) on a synthetic VectorReplayBuffer; TD3's torch.randn smoothing noise is recorded."""
     from tianshou.algorithm.modelfree import td3 as td3_mod
@@ -1670,9 +1671,9 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
     sa_, sc_ = OS.layer_sizes(hidden)              # (any depth since round 6: a nested (actor sizes, critic sizes) pair)
     AK, CK = OS.trunk_keys(len(sa_), ("last",)), OS.trunk_keys(len(sc_), ("last",))
     AO, CO = OS.det_actor_order(len(sa_)), OS.critic_order(len(sc_))
-    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sa_)),
+    actor = ContinuousActorDeterministic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=list(sa_), activation=activation),
                                          action_shape=(act_dim,), max_action=max_action)
-    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True)  # noqa: E731
+    mk_net = lambda: Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=list(sc_), concat=True, activation=activation)  # noqa: E731
     if twin:
         n1, n2 = mk_net(), mk_net()
         critic1, critic2 = ContinuousCritic(preprocess_net=n1), ContinuousCritic(preprocess_net=n2)
@@ -1753,7 +1754,8 @@ def gen_td3(tag: str, *, twin: bool, E: int, slots: int, steps: int, obs_dim: in
     cfg = dict(gamma=common["gamma"], tau=common["tau"], n_step=n_step, twin=float(twin),
                policy_noise=kw.get("policy_noise", 0.2), noise_clip=kw.get("noise_clip", 0.5),
                update_actor_freq=kw.get("update_actor_freq", 2), max_action=max_action,
-               actor_lr=kw.get("actor_lr", 1e-3), critic_lr=kw.get("critic_lr", 1e-3))
+               actor_lr=kw.get("actor_lr", 1e-3), critic_lr=kw.get("critic_lr", 1e-3),
+               **({"tanh_trunks": 1.0} if activation is nn.Tanh else {}))
     out["cfg_keys"], out["cfg_vals"] = np.array(list(cfg.keys())), np.array(list(cfg.values()), np.float64)
     np.savez_compressed(os.path.join(OUT, f"td3_{tag}.npz"), **out)
 
@@ -2039,6 +2041,11 @@ def gen_depth() -> None:
     gen_sac("bounded", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=37, auto_alpha=True, max_action=1.5)
     gen_sac("bounded_depth3", E=3, slots=30, steps=30, obs_dim=11, act_dim=3, batch=48, n_updates=3, seed=38, auto_alpha=False,
             alpha=0.1, hidden=((48, 64, 40), (64, 32, 32)), max_action=0.8)
+    # nn.Tanh trunks (Net's default is nn.ReLU): SAC on actor [64, 48] / critics [40, 72]; TD3 on three layers
+    gen_sac("tanh", E=4, slots=32, steps=30, obs_dim=23, act_dim=5, batch=64, n_updates=3, seed=39, auto_alpha=True,
+            hidden=(64, 48, 40, 72), activation=nn.Tanh)
+    gen_td3("tanh3", twin=True, E=4, slots=32, steps=30, obs_dim=17, act_dim=6, batch=64, n_updates=4, seed=40,
+            hidden=((64, 32, 32), (48, 64, 40)), activation=nn.Tanh)
     # DiscreteSAC with three hidden layers (actor [40, 72, 24], critics [56, 24, 48]); REDQ with one (actor [64], ensemble [48])
     gen_dsac("depth3", E=3, slots=30, steps=40, obs_dim=13, n_act=5, hidden=((40, 72, 24), (56, 24, 48)), batch=32, n_updates=3, seed=35,
              auto_alpha=True)

@@ -62,7 +62,7 @@ def net_forward(p, obs) -> torch.Tensor:
     x = torch.as_tensor(obs, dtype=torch.float32).flatten(1)
     i = 1
     while f"l{i}.w" in p:
-        x = F.relu(F.linear(x, p[f"l{i}.w"], p[f"l{i}.b"]))
+        x = OS._ACT["fn"](F.linear(x, p[f"l{i}.w"], p[f"l{i}.b"]))
         i += 1
     return F.linear(x, p["head.w"], p["head.b"])
 

@@ -61,7 +61,7 @@ def critic_forward(p, obs, act) -> torch.Tensor:
     """-> [E, B, 1]"""
     h = torch.cat([obs.flatten(1), act.flatten(1)], dim=1)
     for i in range(1, OS.depth_of(p) + 1):
-        h = F.relu(torch.matmul(h, p[f"w{i}"]) + p[f"b{i}"])
+        h = OS._ACT["fn"](torch.matmul(h, p[f"w{i}"]) + p[f"b{i}"])
     return torch.matmul(h, p["wq"]) + p["bq"]
 
 

@@ -105,10 +105,27 @@ def order_of(p: dict) -> list[str]:
     return list(p.keys())
 
 
+_ACT = {"fn": F.relu}
+
+
+class activation:
+    """`with oracle_sac.activation("tanh"):` -- Net(activation=nn.Tanh) instead of the default nn.ReLU for every trunk evaluated
+    inside the block (test infrastructure: the parameter dicts carry no module structure)."""
+
+    def __init__(self, name: str):
+        self.fn = {"relu": F.relu, "tanh": torch.tanh}[name]
+
+    def __enter__(self):
+        self.old, _ACT["fn"] = _ACT["fn"], self.fn
+
+    def __exit__(self, *exc):
+        _ACT["fn"] = self.old
+
+
 def trunk_forward(p, x):
-    """Net / MLP with the default activation: ReLU after every hidden Linear (utils/net/common.py:90-178)."""
+    """Net / MLP: the activation (default ReLU) after every hidden Linear (utils/net/common.py:90-178)."""
     for i in range(1, depth_of(p) + 1):
-        x = F.relu(F.linear(x, p[f"w{i}"], p[f"b{i}"]))
+        x = _ACT["fn"](F.linear(x, p[f"w{i}"], p[f"b{i}"]))
     return x
 
 

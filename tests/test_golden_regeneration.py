@@ -23,7 +23,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
     ("sample_random", ["sample_random.npz"]),
     ("ppo_sched", ["ppo_sched.npz"]),
     ("depth", ["sac_depth3.npz", "sac_depth1.npz", "td3_depth4.npz", "td3_ddpg_depth1.npz", "dsac_depth3.npz", "redq_depth1.npz",
-               "sac_bounded.npz", "sac_bounded_depth3.npz", "npg_npg_relu3.npz", "npg_trpo_tanh1.npz"]),
+               "sac_bounded.npz", "sac_bounded_depth3.npz", "npg_npg_relu3.npz", "npg_trpo_tanh1.npz", "sac_tanh.npz", "td3_tanh3.npz"]),
 ])
 def test_fixture_regenerates_bit_for_bit(tmp_path, what, files):
     env = dict(os.environ, TS_GOLDEN_OUT=str(tmp_path), PYTHONHASHSEED="random")

@@ -1541,7 +1541,7 @@ def test_hip_natural_gradient_hooks_replay_the_reference_on_other_widths(tag):
         assert W.padding_is_zero(NG.critic_flat_to_torch(vec, obs_dim, eng.hidden), *hc)
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3", "tanh"])
 def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the SAC family: the HOOK path -- device mirror of a host buffer, `_preprocess_batch` (n-step
     target with the lagged critics; n = 1 and 3), `_update_with_batch` (twin critics, actor, alpha, Polyak), write-back -- on the
@@ -1559,10 +1559,11 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
     # [40, 56, 24]; `depth1`: one hidden layer [96] (round 6: any depth, layer by layer on the GEMM kernels)
     sa, sc = OS.layer_sizes(d["hidden"])
     # `bounded*`: the class-default actor, unbounded=False with max_action 1.5 / 0.8 (mu = max_action * tanh(mu))
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, unbounded=cfg.max_action == 0.0,
+    fn = nn.Tanh if d["activation"] == "tanh" else nn.ReLU             # (`tanh`: Net(activation=nn.Tanh) trunks)
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, list(sa), fn), act_dim, unbounded=cfg.max_action == 0.0,
                                             conditioned_sigma=True, max_action=cfg.max_action or 1.0)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), fn))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), fn))
     p0 = OS.init_sac_params(obs_dim, act_dim, d["seed"], (sa, sc))        # == the reference's initial weights (asserted by gen_sac)
     for mod, pd in ((actor, p0[0]), (c1, p0[1]), (c2, p0[2])):            # (both in layer order: trunk, then heads)
         mod.load_state_dict(dict(zip(mod.state_dict(), pd.values())))
@@ -1571,6 +1572,7 @@ def test_hip_sac_hooks_replay_the_reference(tag, monkeypatch):
                                 gamma=cfg.gamma, alpha=alpha, n_step_return_horizon=cfg.n_step, device="cuda",
                                 update_noise="torch").to("cuda")         # (index-only sampling + lazy write-back: the defaults)
     assert algo._hip_depth == len(sa) and algo._hip_sizes["actor"] == tuple(sa) and algo._hip_bound == cfg.max_action
+    assert algo._hip_actfn == d["activation"]
     buf = SI.VectorReplayBuffer(E * d["slots"], E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     lengths = g["buf_lengths"]
     for t in range(int(lengths.max())):                                   # slot e * slots + t of the fixture's buffer = env e, step t
@@ -1674,7 +1676,7 @@ def test_hip_dqn_hooks_replay_the_reference():
 
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1", "tanh3"])
 def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     """VERDICT r5 item 8 for the deterministic-actor family: HipTD3 / HipDDPG hook paths on the real engine against what the
     unmodified REFERENCE's TD3.update() / DDPG.update() produced (tests/golden/td3_{twin,ddpg}.npz,
@@ -1691,9 +1693,10 @@ def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
     # `widths`: Net[400, 300] (embedded in 416); `ddpg_widths`: actor [24, 56], critic [40, 24]; `depth4`: four hidden layers, actor
     # [64, 64, 32, 32], critics [48, 64, 64, 40]; `ddpg_depth1`: one hidden layer, actor [128], critic [64] (round 6)
     sa, sc = OS.layer_sizes(d["hidden"])
-    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, list(sa), nn.ReLU), act_dim, max_action=cfg.max_action)
-    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU))
-    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), nn.ReLU)) if twin else None
+    fn = nn.Tanh if d["activation"] == "tanh" else nn.ReLU             # (`tanh3`: three nn.Tanh layers per network)
+    actor = SI.ContinuousActorDeterministic(SI.Net(obs_dim, list(sa), fn), act_dim, max_action=cfg.max_action)
+    c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), fn))
+    c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, list(sc), fn)) if twin else None
     p0 = OS.init_td3_params(obs_dim, act_dim, d["seed"], twin, (sa, sc))  # == the reference's initial weights (asserted by gen_td3)
     for mod, pd in ((actor, p0[0]), (c1, p0[1])) + (((c2, p0[2]),) if twin else ()):
         mod.load_state_dict(dict(zip(mod.state_dict(), pd.values())))

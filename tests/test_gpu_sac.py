@@ -17,7 +17,7 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
+def make_engine(obs_dim, act_dim, seed, cfg, hidden=256, activation="relu"):
     """hidden: int, or (actor h1, actor h2, critic h1, critic h2) -- embedded by zero padding (tianshou_amd.widths)."""
     from tianshou_amd import sac as S
     from tianshou_amd import widths as W
@@ -32,7 +32,7 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
         S.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H),
         S.SACConfig(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "alpha", "auto_alpha", "target_entropy",
                                                      "log_alpha0", "actor_lr", "critic_lr", "alpha_lr")}), hidden=H,
-        depth=OS.depth_of(actor), max_action=getattr(cfg, "max_action", 0.0))
+        depth=OS.depth_of(actor), max_action=getattr(cfg, "max_action", 0.0), activation=activation)
     return eng, (actor, c1, c2)
 
 
@@ -111,20 +111,21 @@ def test_update_gradients_vs_oracle(obs_dim, act_dim, B, auto, weighted):
     assert torch.count_nonzero(l1[obs_dim + act_dim:lay["kc"]]) == 0
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3", "tanh"])
 def test_sac_update_matches_reference_golden(tag):
     """(`widths`: actor Net[48, 80], critics Net[72, 40] in the reference; the engine runs them embedded in Net[96, 96] and every
     padding entry of parameters, lagged parameters and Adam moments stays exactly zero.  `depth3`: THREE hidden layers, actor
     [64, 48, 32] and critics [40, 56, 24] in Net[64] * 3; `depth1`: ONE hidden layer [96], fixed alpha, 2-step returns --
     fixtures the unmodified reference wrote, gen_golden.py::gen_depth; the engine runs them layer by layer, ts_mlp_set_trunk.
     `bounded` / `bounded_depth3`: the class-default actor `unbounded=False` -- mu = max_action * tanh(mu), max_action 1.5 / 0.8,
-    ts_sac_set_actor_bound -- on Net[256, 256] (the fused kernels) and on actor [48, 64, 40] / critics [64, 32, 32].)"""
+    ts_sac_set_actor_bound -- on Net[256, 256] (the fused kernels) and on actor [48, 64, 40] / critics [64, 32, 32].
+    `tanh`: Net(activation=nn.Tanh) trunks, actor [64, 48] / critics [40, 72] -- ts_mlp_set_activation.)"""
     from tianshou_amd import sac as S
     from tianshou_amd import widths as W
     from tianshou_amd.buffer import DeviceReplayBuffer
 
     g, d, cfg, bstate = load_sac(tag)
-    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"], d["activation"])
     sa, sc = OS.layer_sizes(d["hidden"])
     assert eng.depth == len(sa) == len(sc)
     sizes = {"actor": sa, "critic1": sc, "critic2": sc, "critic1_old": sc, "critic2_old": sc}
@@ -220,6 +221,18 @@ def test_other_hidden_widths_vs_oracle(hidden, obs_dim, act_dim, B):
                                                       (((40, 72, 56, 24, 88), (32, 32, 64, 64, 32)), 11, 3, 65),
                                                       (((128,) * 6, (128,) * 6), 17, 6, 96)])
 def test_other_depths_vs_oracle(hidden, obs_dim, act_dim, B):
+    _other_depths(hidden, obs_dim, act_dim, B, "relu")
+
+
+@pytest.mark.parametrize("hidden,obs_dim,act_dim,B", [(((256, 256), (256, 256)), 376, 17, 512), (((40, 72, 56), (32, 64, 32)), 11, 3, 65)])
+def test_tanh_trunks_vs_oracle(hidden, obs_dim, act_dim, B):
+    """Net(activation=nn.Tanh) trunks (ts_mlp_set_activation): the same checks as test_other_depths_vs_oracle -- at [256, 256] too,
+    where ReLU trunks take the fused kernels and tanh trunks the per-layer path."""
+    with OS.activation("tanh"):
+        _other_depths(hidden, obs_dim, act_dim, B, "tanh")
+
+
+def _other_depths(hidden, obs_dim, act_dim, B, activation):
     """Net(hidden_sizes=[...]) of 1, 3, 5 and 6 hidden layers (utils/net/common.py:246-369 takes any list; round 6): the update
     runs layer by layer on the GEMM kernels (ts_mlp_set_trunk).  Gradients of the first update against the float64 yardstick
     as in test_update_gradients_vs_oracle, two more updates against the oracle, the policy / target entry points, and a
@@ -229,8 +242,8 @@ def test_other_depths_vs_oracle(hidden, obs_dim, act_dim, B):
 
     cfg = OS.SACConfig(auto_alpha=True, log_alpha0=-0.2, target_entropy=-float(act_dim), actor_lr=3e-4,
                        critic_lr=1e-3, alpha_lr=1e-3, tau=0.02)
-    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 9, cfg, hidden)
-    other, _ = make_engine(7, 2, 1, cfg)                      # Net[256, 256], same default workspace
+    eng, (actor, c1, c2) = make_engine(obs_dim, act_dim, 9, cfg, hidden, activation)
+    other, _ = make_engine(7, 2, 1, cfg)                      # Net[256, 256] ReLU, same default workspace
     sa, sc = OS.layer_sizes(hidden)
     assert eng.depth == len(sa)
     for t, k in zip(S.actor_flat_to_torch(eng.actor, obs_dim, act_dim, eng.hidden, sizes=sa), actor):

@@ -15,7 +15,7 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
+def make_engine(obs_dim, act_dim, seed, cfg, hidden=256, activation="relu"):
     """hidden: int, (h1, h2) or (actor h1, actor h2, critic h1, critic h2) -- embedded by zero padding (tianshou_amd.widths)."""
     from tianshou_amd import td3 as T
     from tianshou_amd import widths as W
@@ -29,7 +29,7 @@ def make_engine(obs_dim, act_dim, seed, cfg, hidden=256):
         T.critic_flat_from_torch(lists[2], obs_dim, act_dim, hidden=H) if cfg.twin else None,
         T.TD3Config(**{k: getattr(cfg, k) for k in ("gamma", "tau", "n_step", "twin", "policy_noise", "noise_clip",
                                                      "update_actor_freq", "max_action", "actor_lr", "critic_lr")}),
-        hidden=H, depth=OS.depth_of(actor))
+        hidden=H, depth=OS.depth_of(actor), activation=activation)
     return eng, (actor, c1, c2)
 
 
@@ -92,7 +92,7 @@ def test_policy_target_and_gradients_vs_oracle(twin):
             assert rel_err(t.cpu(), col[name + "_grads"][key]) < 2e-5, (name, key)
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1", "tanh3"])
 def test_update_matches_reference_golden(tag):
     """(`widths`: the TD3 paper's Net[400, 300] embedded in Net[416, 416]; `ddpg_widths`: actor [24, 56], critic [40, 24] in 64;
     `depth4`: FOUR hidden layers, actor [64, 64, 32, 32] and critics [48, 64, 64, 40] in Net[64] * 4, max_action 1.5;
@@ -103,7 +103,7 @@ def test_update_matches_reference_golden(tag):
     from tianshou_amd import widths as W
 
     g, d, cfg, bstate = load_td3(tag)
-    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"])
+    eng, _ = make_engine(d["obs_dim"], d["act_dim"], d["seed"], cfg, d["hidden"], d["activation"])      # (`tanh3`: three nn.Tanh layers)
     sa, sc = OS.layer_sizes(d["hidden"])
     assert eng.depth == len(sa) == len(sc)
     buf = DeviceReplayBuffer(offset=g["buf_offset"], last_index=g["buf_last_index"], lengths=g["buf_lengths"],

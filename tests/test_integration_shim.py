@@ -263,7 +263,7 @@ def test_collector_side_policies_become_engine_backed_subclasses_of_the_real_cla
     s = make_hip_sac()(policy=sp, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=ContinuousCritic(preprocess_net=sac_net()),
                        critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=ContinuousCritic(preprocess_net=sac_net()),
                        critic2_optim=AdamOptimizerFactory(lr=1e-3), device="cpu")
-    assert isinstance(s.policy, SACPolicy) and s.policy._hip_family == "sac" and s.policy._hip_spec == dict(obs_dim=11, act_dim=3, hidden=256, depth=2, max_action=0.0)
+    assert isinstance(s.policy, SACPolicy) and s.policy._hip_family == "sac" and s.policy._hip_spec == dict(obs_dim=11, act_dim=3, hidden=256, depth=2, max_action=0.0, activation="relu")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         s.policy(Batch(obs=np.zeros((2, 11), np.float32), info={}), None)
     # DQN
@@ -654,7 +654,7 @@ def test_hip_sac_wrapper_runs_with_engine_double(sac_algo, monkeypatch):
     import tianshou_amd.sac as S
 
     class FakeSAC:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0, activation="relu"):
             assert hidden == 256
             self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.adam_step = obs_dim, act_dim, cfg, 0
@@ -740,7 +740,7 @@ def test_hip_td3_ddpg_wrapper_runs_with_engine_double(twin, monkeypatch):
     import tianshou_amd.td3 as T
 
     class FakeTD3:
-        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0):
+        def __init__(self, obs_dim, act_dim, actor, c1, c2, cfg, hidden=256, depth=2, max_action=0.0, activation="relu"):
             self.hidden = hidden
             self.obs_dim, self.act_dim, self.cfg, self.cnt, self.actor_steps = obs_dim, act_dim, cfg, 0, 0
             self.actor, self.critic1, self.critic2 = actor.clone(), c1.clone(), None if c2 is None else c2.clone()
@@ -968,7 +968,7 @@ def test_hip_discrete_sac_wrapper_runs_with_engine_double(match_rng, monkeypatch
     calls = {"policy_forward": 0}
 
     class FakeDSAC:
-        def __init__(self, obs_dim, n_act, hidden, actor, c1, c2, cfg, depth=2):
+        def __init__(self, obs_dim, n_act, hidden, actor, c1, c2, cfg, depth=2, activation="relu"):
             assert (obs_dim, n_act, hidden) == (11, 5, 64) and cfg.auto_alpha and cfg.n_step == 2
             assert abs(cfg.target_entropy - 0.98 * np.log(5)) < 1e-12
             self.obs_dim, self.n_act, self.hidden, self.cfg, self.adam_step = obs_dim, n_act, hidden, cfg, 0
@@ -1209,7 +1209,7 @@ def test_hip_redq_wrapper_runs_with_engine_double(monkeypatch):
     seen = {"subsets": [], "noise": []}
 
     class FakeREDQ:
-        def __init__(self, obs_dim, act_dim, actor, critics, cfg, hidden=256, depth=2, max_action=0.0):
+        def __init__(self, obs_dim, act_dim, actor, critics, cfg, hidden=256, depth=2, max_action=0.0, activation="relu"):
             self.hidden = hidden
             assert (obs_dim, act_dim) == (11, 3) and (cfg.ensemble_size, cfg.subset_size, cfg.actor_delay) == (4, 2, 2)
             assert cfg.auto_alpha and cfg.target_mode == "min" and cfg.n_step == 2 and critics.numel() % 4 == 0
@@ -1749,3 +1749,34 @@ def test_device_permutation_key_follows_numpy_seed_and_travels_in_the_checkpoint
     ref_sd = build(PPO).state_dict()
     c.load_state_dict(ref_sd)                                          # a checkpoint written by the reference class
     assert (c._hip_perm_seed, c._hip_updates) == (a._hip_perm_seed, 7)
+
+
+def test_off_policy_hooks_refuse_activations_the_engine_does_not_compute():
+    """The state_dict keys of Net(hidden_sizes=[h, h], activation=X) are the same for every X: the off-policy hooks look at the
+    modules -- nn.ReLU (Net's default) and nn.Tanh are computed, anything else raises instead of silently becoming ReLU."""
+    ref_shim.install()
+    import gymnasium as gym
+    from torch import nn
+
+    from tianshou.algorithm.modelfree.sac import SACPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou_amd.integration import make_hip_sac
+
+    def build(act_cls, **kw):
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[64, 64, 32], activation=act_cls),
+                                             action_shape=(3,), conditioned_sigma=True, **kw)
+        mk = lambda: ContinuousCritic(preprocess_net=Net(state_shape=(11,), action_shape=(3,), hidden_sizes=[48, 64, 64],  # noqa: E731
+                                                         concat=True, activation=act_cls))
+        policy = SACPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(3,)))
+        return make_hip_sac()(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(),
+                              critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=mk(), critic2_optim=AdamOptimizerFactory(lr=1e-3),
+                              device="cpu")
+
+    a = build(nn.Tanh, unbounded=True)
+    assert (a._hip_depth, a._hip_actfn, a._hip_bound, a._hip_hidden) == (3, "tanh", 0.0, 64)
+    b = build(nn.ReLU, max_action=2.0)                        # the class default: unbounded=False
+    assert (b._hip_actfn, b._hip_bound) == ("relu", 2.0) and b.policy._hip_spec["max_action"] == 2.0
+    with pytest.raises(NotImplementedError, match="nn.ReLU or nn.Tanh"):
+        build(nn.ELU, unbounded=True)

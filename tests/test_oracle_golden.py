@@ -386,13 +386,13 @@ def load_sac(tag):
                        log_alpha0=c["log_alpha0"], actor_lr=c["actor_lr"], critic_lr=c["critic_lr"],
                        alpha_lr=c["alpha_lr"], max_action=c.get("max_action", 0.0))      # (> 0: the bounded class-default actor)
     d = dict(E=E, slots=slots, obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed,
-             hidden=_fixture_hidden(g))
+             hidden=_fixture_hidden(g), activation="tanh" if c.get("tanh_trunks") else "relu")
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3"])
+@pytest.mark.parametrize("tag", ["auto", "fixed", "widths", "depth3", "depth1", "bounded", "bounded_depth3", "tanh"])
 def test_sac_restatement_matches_reference(tag):
     """oracle_sac (tanh-Gaussian policy, twin lagged critics, n-step target, three Adam steps, auto alpha,
     Polyak) against the unmodified reference SAC.update() with its rsample() noise replayed."""
@@ -402,6 +402,13 @@ def test_sac_restatement_matches_reference(tag):
     actor, c1, c2 = OS.init_sac_params(d["obs_dim"], d["act_dim"], d["seed"], d["hidden"])
     st = OS.SACState.create(actor, c1, c2, cfg)
     obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
+    with OS.activation(d["activation"]):          # (`tanh`: Net(activation=nn.Tanh) trunks)
+        _sac_restatement_updates(g, d, cfg, bstate, st, obs_all, obs_next_all)
+
+
+def _sac_restatement_updates(g, d, cfg, bstate, st, obs_all, obs_next_all):
+    from oracle import oracle_sac as OS
+
     for u in range(d["n_updates"]):
         idx = g[f"u{u}_indices"]
 
@@ -540,19 +547,26 @@ def load_td3(tag):
                        update_actor_freq=int(c["update_actor_freq"]), max_action=c["max_action"],
                        actor_lr=c["actor_lr"], critic_lr=c["critic_lr"])
     d = dict(obs_dim=obs_dim, act_dim=act_dim, batch=batch, n_updates=n_updates, seed=seed, twin=bool(twin),
-             hidden=_fixture_hidden(g))
+             hidden=_fixture_hidden(g), activation="tanh" if c.get("tanh_trunks") else "relu")
     bstate = O.BufferState(g["buf_offset"], g["buf_last_index"], g["buf_lengths"], g["buf_insertion"],
                            g["rew"], g["terminated"], g["truncated"])
     return g, d, cfg, bstate
 
 
-@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1"])
+@pytest.mark.parametrize("tag", ["twin", "ddpg", "widths", "ddpg_widths", "depth4", "ddpg_depth1", "tanh3"])
 def test_td3_ddpg_restatement_matches_reference(tag):
     from oracle import oracle_sac as OS
 
     g, d, cfg, bstate = load_td3(tag)
     st = OS.TD3State.create(*OS.init_td3_params(d["obs_dim"], d["act_dim"], d["seed"], d["twin"], d["hidden"]), cfg)
     obs_all, obs_next_all = torch.as_tensor(g["obs"]), torch.as_tensor(g["obs_next"])
+    with OS.activation(d["activation"]):
+        _td3_restatement_updates(g, d, cfg, bstate, st, obs_all, obs_next_all)
+
+
+def _td3_restatement_updates(g, d, cfg, bstate, st, obs_all, obs_next_all):
+    from oracle import oracle_sac as OS
+
     for u in range(d["n_updates"]):
         idx = g[f"u{u}_indices"]
         noise = g[f"u{u}_noise"] if d["twin"] else None

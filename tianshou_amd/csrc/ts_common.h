@@ -84,6 +84,8 @@ struct ts_workspace {
     int mlp_hidden;
     // number of hidden layers of those MLPs (ts_mlp_set_trunk; 0 = 2, the depth of the examples' nets)
     int mlp_depth;
+    // 1: nn.Tanh after every hidden layer of those MLPs instead of Net's default nn.ReLU (ts_mlp_set_activation)
+    int mlp_act_tanh;
     // max_action of a BOUNDED Gaussian actor (mu = max_action * tanh(mu), continuous.py:230-231) of the SAC / REDQ entry
     // points (ts_sac_set_actor_bound; 0 = unbounded, the actors of the examples)
     float sac_actor_bound;

@@ -192,6 +192,15 @@ int ts_mlp_set_hidden(ts_workspace* ws, int64_t hidden) {
                "ts_mlp_set_hidden: 0 (default 256) or a multiple of 32 in [32, 2048], got %lld", (long long)hidden);
     ws->mlp_hidden = (int)hidden;
     ws->mlp_depth = 0;
+    ws->mlp_act_tanh = 0;
+    return TS_OK;
+}
+
+int ts_mlp_set_activation(ts_workspace* ws, int activation) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_mlp_set_activation: workspace is NULL");
+    TS_REQUIRE(activation == TS_NET_ACT_RELU || activation == TS_NET_ACT_TANH, TS_ERR_UNSUPPORTED,
+               "ts_mlp_set_activation: TS_NET_ACT_RELU or TS_NET_ACT_TANH");
+    ws->mlp_act_tanh = activation == TS_NET_ACT_TANH ? 1 : 0;
     return TS_OK;
 }
 

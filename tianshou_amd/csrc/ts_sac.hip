@@ -47,16 +47,18 @@ struct Mlp {                  // in -> hid x depth -> head, ReLU between (depth 
     ts::ConvGeom l[MAXL];
     int64_t off[MAXL + 1];
     int L;                    // linear layers = depth + 1; the head is l[L - 1]
+    int act;                  // TS_NET_ACT_RELU (Net's default, the examples) or TS_NET_ACT_TANH after every hidden layer
     int64_t total() const { return off[L]; }
     const ts::ConvGeom& head() const { return l[L - 1]; }
-    // the one-launch three-layer kernels of ts_mlp.hip are written for two hidden layers of one width
-    bool three() const { return L == 3 && l[1].OC == l[0].OC; }
+    // the one-launch three-layer kernels of ts_mlp.hip are written for two ReLU hidden layers of one width
+    bool three() const { return L == 3 && l[1].OC == l[0].OC && act == TS_NET_ACT_RELU; }
 };
 
-Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID, int depth = 2) {
+Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID, int depth = 2, int act = TS_NET_ACT_RELU) {
     Mlp m{};
     if (depth < 1 || depth > MAXD) depth = 2;       // (validated by ts_mlp_set_trunk / the layout entry points)
     m.L = depth + 1;
+    m.act = act == TS_NET_ACT_TANH ? TS_NET_ACT_TANH : TS_NET_ACT_RELU;
     int64_t o = 0;
     for (int i = 0; i < m.L; ++i) {
         m.l[i] = ts::ConvGeom{B, 1, 1, i == 0 ? in_pad : hid, 1, 1, 1, 1, 1, i + 1 == m.L ? head_cols : hid};
@@ -65,6 +67,16 @@ Mlp make_mlp(int B, int in_pad, int head_cols, int hid = HID, int depth = 2) {
     }
     m.off[m.L] = o;
     return m;
+}
+
+__global__ __launch_bounds__(256) void mlp_tanh_kernel(float* __restrict__ h, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) h[i] = tanhf(h[i]);
+}
+// dh *= 1 - h^2   (backward through tanh; h = the layer's output)
+__global__ __launch_bounds__(256) void mlp_tanh_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dh[i] = dh[i] * (1.f - h[i] * h[i]);
 }
 
 struct Act { float* h[MAXD]; float* out; };      // forward activations of one pass: h[i] = output of hidden layer i
@@ -79,7 +91,13 @@ int mlp_forward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, c
     const float* in = x;
     for (int i = 0; i < m.L; ++i) {
         float* out = act_out(m, a, i);
-        if (int rc = ts::conv_forward(s, m.l[i], in, p + m.off[i], out, i + 1 < m.L, split, ws)) return rc;
+        const bool hidden = i + 1 < m.L;
+        if (int rc = ts::conv_forward(s, m.l[i], in, p + m.off[i], out, hidden && m.act == TS_NET_ACT_RELU, split, ws)) return rc;
+        if (hidden && m.act == TS_NET_ACT_TANH) {
+            const int64_t cnt = (int64_t)m.l[i].B * m.l[i].OC;
+            hipLaunchKernelGGL(mlp_tanh_kernel, dim3((unsigned)ts::ceil_div(cnt, 256)), dim3(256), 0, s, out, cnt);
+            TS_LAUNCH_CHECK();
+        }
         in = out;
     }
     return TS_OK;
@@ -177,8 +195,14 @@ int mlp_backward(hipStream_t s, ts_workspace* ws, const Mlp& m, const float* p, 
                                       grad + m.off[i]))
                 return rc;
         }
-        if (i > 0) {                                  // (xin = the ReLU output the gradient is masked with)
-            if (int rc = ts::conv_dgrad(s, m.l[i], dy, p + m.off[i], xin, sc.dh[i - 1], ws)) return rc;
+        if (i > 0) {                                  // (xin = the ReLU output the gradient is masked with / the tanh output)
+            const bool relu = m.act == TS_NET_ACT_RELU;
+            if (int rc = ts::conv_dgrad(s, m.l[i], dy, p + m.off[i], relu ? xin : nullptr, sc.dh[i - 1], ws)) return rc;
+            if (!relu) {
+                const int64_t cnt = (int64_t)m.l[i].B * m.l[i].IC;
+                hipLaunchKernelGGL(mlp_tanh_bwd_kernel, dim3((unsigned)ts::ceil_div(cnt, 256)), dim3(256), 0, s, sc.dh[i - 1], xin, cnt);
+                TS_LAUNCH_CHECK();
+            }
         } else if (dx) {
             if (int rc = ts::conv_dgrad(s, m.l[0], dy, p + m.off[0], nullptr, dx, ws, col0, col1)) return rc;
         }
@@ -1050,7 +1074,7 @@ struct Carve {
     template <class T> T* take(size_t n) { T* r = reinterpret_cast<T*>(p); p += al(sizeof(T) * n); return r; }
 };
 
-struct Dims { int obs, act, ka, kc, hid, depth; float bound; };
+struct Dims { int obs, act, ka, kc, hid, depth, fn; float bound; };     // fn: TS_NET_ACT_* of the trunks
 
 // hidden: width of the two hidden layers of every Net[h, h] of the SAC / TD3 / DDPG / REDQ entry points -- a property of
 // the workspace (ts_mlp_set_hidden; 0 = the examples' 256).  Any multiple of 32 up to 1024 runs: 256 on the fused
@@ -1066,6 +1090,7 @@ int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d, int64
     d->obs = (int)obs_dim; d->act = (int)act_dim; d->hid = (int)hidden; d->depth = (int)depth;
     d->ka = pad32(d->obs); d->kc = pad32(d->obs + d->act);
     d->bound = 0.f;
+    d->fn = TS_NET_ACT_RELU;
     return TS_OK;
 }
 
@@ -1073,6 +1098,7 @@ int make_dims_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, Dims* d, int64
 int make_dims(const ts_workspace* ws, int64_t obs_dim, int64_t act_dim, Dims* d) {
     if (int rc = make_dims_h(obs_dim, act_dim, ws ? ws->mlp_hidden : 0, d, ws ? ws->mlp_depth : 0)) return rc;
     d->bound = ws ? ws->sac_actor_bound : 0.f;          // ts_sac_set_actor_bound (SAC's / REDQ's Gaussian actor only)
+    d->fn = ws && ws->mlp_act_tanh ? TS_NET_ACT_TANH : TS_NET_ACT_RELU;       // ts_mlp_set_activation
     return TS_OK;
 }
 
@@ -1093,7 +1119,7 @@ BwdScratch take_scratch(Carve& c, int64_t B, int hid, int depth, size_t slab) {
 template <class D> inline size_t hbytes(int64_t B, const D& d) { return al(4 * B * d.hid) * (size_t)((d.depth + 1) / 2); }
 
 // ---- DiscreteSAC (discrete_sac.py): three MLPs obs -> hid -> hid -> n_act, Categorical policy ------------------------
-struct DDims { int obs, act, hid, ka, hw, depth; int64_t P; };
+struct DDims { int obs, act, hid, ka, hw, depth, fn; int64_t P; };
 
 int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d, int64_t depth = 0) {
     TS_REQUIRE(obs_dim >= 1 && obs_dim <= 65536 && n_act >= 2 && n_act <= 64 && hidden >= 32 && hidden <= 2048 &&
@@ -1101,7 +1127,7 @@ int make_ddims(int64_t obs_dim, int64_t n_act, int64_t hidden, DDims* d, int64_t
                "dsac: obs_dim >= 1, n_act in [2, 64], hidden a multiple of 32 in [32, 2048]");
     if (depth == 0) depth = 2;
     TS_REQUIRE(depth >= 1 && depth <= MAXD, TS_ERR_INVALID_ARG, "dsac: 1 .. %d hidden layers, got %lld", MAXD, (long long)depth);
-    d->obs = (int)obs_dim; d->act = (int)n_act; d->hid = (int)hidden; d->depth = (int)depth;
+    d->obs = (int)obs_dim; d->act = (int)n_act; d->hid = (int)hidden; d->depth = (int)depth; d->fn = TS_NET_ACT_RELU;
     d->ka = pad32(d->obs); d->hw = pad32(d->act);
     d->P = make_mlp(1, d->ka, d->hw, d->hid, d->depth).total();
     return TS_OK;
@@ -1131,7 +1157,7 @@ int ts_sac_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
     Dims d;
     if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out8, TS_ERR_INVALID_ARG, "ts_sac_layout: NULL output");
-    const Mlp a = make_mlp(1, d.ka, 64, d.hid, d.depth), c = make_mlp(1, d.kc, 32, d.hid, d.depth);
+    const Mlp a = make_mlp(1, d.ka, 64, d.hid, d.depth, d.fn), c = make_mlp(1, d.kc, 32, d.hid, d.depth, d.fn);
     h_out8[0] = d.ka; h_out8[1] = d.kc; h_out8[2] = a.total(); h_out8[3] = c.total();
     h_out8[4] = a.off[1]; h_out8[5] = a.off[2]; h_out8[6] = c.off[1]; h_out8[7] = c.off[2];
     return TS_OK;
@@ -1145,7 +1171,7 @@ int ts_sac_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn);
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * B * 3 * d.act) +
                                         al(4 * split_floats(ma)) + 4096))
         return rc;
@@ -1174,7 +1200,7 @@ int ts_sac_policy_forward_logits(ts_workspace* ws, const float* actor, const flo
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn);
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * split_floats(ma)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -1199,7 +1225,7 @@ static int sac_target_impl(ts_workspace* ws, const float* actor, const float* cr
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * hbytes(B, d) + 2 * al(4 * B) +
                                         2 * al(4 * spl) + 4096))
@@ -1279,7 +1305,7 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const int64_t pa = ma.total(), pc = mc.total();
     size_t bytes = al(4 * B * d.ka) + 4 * al(4 * B * d.kc) + 9 * hbytes(B, d) + 3 * al(4 * B * 64) +
@@ -1524,7 +1550,7 @@ int ts_td3_layout_h(int64_t obs_dim, int64_t act_dim, int64_t hidden, int64_t* h
     if (int rc = make_dims_h(obs_dim, act_dim, hidden, &d)) return rc;
     TS_REQUIRE(h_out4, TS_ERR_INVALID_ARG, "ts_td3_layout: NULL output");
     h_out4[0] = d.ka; h_out4[1] = d.kc;
-    h_out4[2] = make_mlp(1, d.ka, 32, d.hid, d.depth).total(); h_out4[3] = make_mlp(1, d.kc, 32, d.hid, d.depth).total();
+    h_out4[2] = make_mlp(1, d.ka, 32, d.hid, d.depth, d.fn).total(); h_out4[3] = make_mlp(1, d.kc, 32, d.hid, d.depth, d.fn).total();
     return TS_OK;
 }
 
@@ -1535,7 +1561,7 @@ int ts_td3_policy_forward(ts_workspace* ws, const float* actor, const float* obs
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth, d.fn);
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 3 * hbytes(B, d) + al(4 * split_floats(ma)) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
     float* x_a = c.take<float>(B * d.ka);
@@ -1559,7 +1585,7 @@ int ts_td3_target_q(ts_workspace* ws, const float* actor_old, const float* criti
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 9 * hbytes(B, d) + 2 * al(4 * spl) + 4096)) return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -1613,7 +1639,7 @@ int ts_td3_update(ts_workspace* ws, const ts_td3_state* st, int64_t critic_step,
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 32, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc));
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
@@ -1756,8 +1782,9 @@ int ts_dsac_policy_forward(ts_workspace* ws, const float* actor, const float* ob
     TS_REQUIRE(B >= 1 && actor && obs && logits_out, TS_ERR_INVALID_ARG, "ts_dsac_policy_forward: bad argument");
     DDims d;
     if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
+    d.fn = ws->mlp_act_tanh ? TS_NET_ACT_TANH : TS_NET_ACT_RELU;
     hipStream_t s = ts::as_stream(stream);
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth, d.fn);
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 2 * hbytes(B, d) + al(4 * B * d.hw) + al(4 * split_floats(m)) + 4096))
         return rc;
     Carve c{static_cast<char*>(ws->base)};
@@ -1781,8 +1808,9 @@ int ts_dsac_target_q(ts_workspace* ws, const float* actor, const float* critic1_
                "ts_dsac_target_q: bad argument");
     DDims d;
     if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
+    d.fn = ws->mlp_act_tanh ? TS_NET_ACT_TANH : TS_NET_ACT_RELU;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth, d.fn);
     const size_t spl = split_floats(m);
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + 6 * hbytes(B, d) + 3 * al(4 * B * d.hw) + 2 * al(4 * spl) + 4096))
         return rc;
@@ -1830,8 +1858,9 @@ int ts_dsac_update(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, 
                "ts_dsac_update: auto alpha needs log_alpha and its Adam moments");
     DDims d;
     if (int rc = make_ddims(obs_dim, n_act, hidden, &d, ws->mlp_depth)) return rc;
+    d.fn = ws->mlp_act_tanh ? TS_NET_ACT_TANH : TS_NET_ACT_RELU;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth);
+    const Mlp m = make_mlp((int)B, d.ka, d.hw, d.hid, d.depth, d.fn);
     const size_t slab = slab_floats(m), spl = split_floats(m);
     const int64_t P = d.P;
     const size_t bytes = al(4 * B * d.ka) + 10 * hbytes(B, d) + 6 * al(4 * B * d.hw) + 2 * al(4 * slab) +
@@ -1957,7 +1986,7 @@ int ts_redq_target_q(ts_workspace* ws, const float* actor, const float* critics_
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pc = mc.total();
     if (int rc = ts::ws_reserve(ws, al(4 * B * d.ka) + al(4 * B * d.kc) + 6 * hbytes(B, d) + al(4 * B * 64) +
@@ -2017,7 +2046,7 @@ int ts_redq_update(ts_workspace* ws, const ts_redq_state* st, int64_t E, int64_t
     Dims d;
     if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
     hipStream_t s = ts::as_stream(stream), side;
-    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth);
+    const Mlp ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn), mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn);
     const size_t slab = std::max(slab_floats(ma), slab_floats(mc)), spl = std::max(split_floats(ma), split_floats(mc));
     const int64_t pa = ma.total(), pc = mc.total();
     // the critics' chains run CH members per launch on the fused path (ts_mlp.hip): CH scratch sets instead of two

@@ -67,10 +67,10 @@ class DiscreteSACEngine:
     """State of one DiscreteSAC learner on one GPU (hyper-parameters: tianshou_amd.sac.SACConfig)."""
 
     def __init__(self, obs_dim: int, n_act: int, hidden: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor, cfg: SACConfig, depth: int = 2):
+                 critic2: torch.Tensor, cfg: SACConfig, depth: int = 2, activation: str = "relu"):
         if not actor.is_cuda:
             raise RuntimeError("DiscreteSACEngine needs parameters on an MI355X (no CPU fallback)")
-        self.depth = int(depth)
+        self.depth, self.activation = int(depth), activation
         lay = layout(obs_dim, n_act, hidden, self.depth)
         if any(t.numel() != lay["count"] for t in (actor, critic1, critic2)):
             raise ValueError("flat parameter vectors do not match ts_dsac_layout")
@@ -96,7 +96,7 @@ class DiscreteSACEngine:
         return t if shape is None else t.reshape(shape)
 
     def _dims(self):
-        use_hidden(self._ws, self.hidden, self.depth)          # (the entry points read the depth from the workspace)
+        use_hidden(self._ws, self.hidden, self.depth, 0.0, self.activation)          # (the entry points read the depth from the workspace)
         return _lib.i64(self.obs_dim), _lib.i64(self.n_act), _lib.i64(self.hidden)
 
     @property

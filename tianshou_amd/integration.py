@@ -1495,17 +1495,24 @@ def make_hip_rainbow(ref=None):
 # ---------------------------------------------------------------------------------------------------
 # SAC (sac.py:213-336) on the mujoco_sac.py networks
 # ---------------------------------------------------------------------------------------------------
-def _require_relu_trunk(mod, who: str) -> None:
-    """The off-policy engines compute a `Net` trunk as Sequential(Linear, ReLU, Linear, ReLU, ...) -- `Net`'s default activation
-    (utils/net/common.py:246-369).  The state_dict keys only pin the Linear layers' positions; whatever sits between them
-    (another activation, dropout) has no parameters and would be silently replaced by ReLU, so it is checked here."""
-    seq = getattr(getattr(getattr(mod, "preprocess", None), "model", None), "model", None)
-    mods = list(seq) if seq is not None else []
-    ok = len(mods) >= 2 and len(mods) % 2 == 0 and all(
-        type(mods[i]).__name__ in ("Linear", "EnsembleLinear") and isinstance(mods[i + 1], torch.nn.ReLU) for i in range(0, len(mods), 2))
-    if not ok:
-        raise NotImplementedError(f"{who}: the trunk must be Net(hidden_sizes=[...]) with nn.ReLU after every Linear layer "
-                                  f"(got {[type(m).__name__ for m in mods]})")
+def _trunk_activation(mods, who: str) -> str:
+    """The off-policy engines compute a `Net` trunk as Sequential(Linear, act, Linear, act, ...) with act = nn.ReLU -- `Net`'s
+    default activation (utils/net/common.py:246-369) -- or nn.Tanh, the same for every network of the algorithm.  The state_dict
+    keys only pin the Linear layers' positions; whatever sits between them (another activation, dropout, a norm layer without
+    affine parameters) would be silently replaced, so the modules are checked here.  -> "relu" | "tanh"."""
+    names = set()
+    for mod in mods:
+        seq = getattr(getattr(getattr(mod, "preprocess", None), "model", None), "model", None)
+        ms = list(seq) if seq is not None else []
+        ok = len(ms) >= 2 and len(ms) % 2 == 0 and all(
+            type(ms[i]).__name__ in ("Linear", "EnsembleLinear") and type(ms[i + 1]) in (torch.nn.ReLU, torch.nn.Tanh) for i in range(0, len(ms), 2))
+        if not ok:
+            raise NotImplementedError(f"{who}: the trunk must be Net(hidden_sizes=[...]) with nn.ReLU or nn.Tanh after every Linear "
+                                      f"layer (got {[type(m).__name__ for m in ms]})")
+        names |= {"relu" if isinstance(ms[i], torch.nn.ReLU) else "tanh" for i in range(1, len(ms), 2)}
+    if len(names) != 1:
+        raise NotImplementedError(f"{who}: one activation class for all networks (got {sorted(names)})")
+    return names.pop()
 
 
 def _actor_bound(actor) -> float:
@@ -1558,8 +1565,7 @@ def make_hip_sac(ref=None):
                 raise NotImplementedError("HipSAC: networks must be those of examples/mujoco/mujoco_sac.py (Net trunks of one depth, "
                                           "1 .. 6 hidden layers, single-Linear mu / sigma / Q heads)")
             self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), S.critic_keys(depth)
-            for mod in (self.policy.actor, self.critic, self.critic2):
-                _require_relu_trunk(mod, "HipSAC")
+            self._hip_actfn = _trunk_activation((self.policy.actor, self.critic, self.critic2), "HipSAC")
             self._hip_bound = _actor_bound(self.policy.actor)
             # any hidden widths per network (round 6): embedded by zero padding into the engine's Net[h] * depth, h = the largest
             # width of the three networks rounded up to 32 (tianshou_amd.widths)
@@ -1585,7 +1591,7 @@ def make_hip_sac(ref=None):
 
                 HP.attach(self.policy, "sac", self, device=str(self._hip_device), sampling=sampling, noise_seed=noise_seed,
                           obs_dim=int(sa[self._hip_akeys[0]].shape[1]), act_dim=int(sa[self._hip_akeys[2 * self._hip_depth]].shape[0]),
-                          hidden=hid, depth=depth, max_action=self._hip_bound)
+                          hidden=hid, depth=depth, max_action=self._hip_bound, activation=self._hip_actfn)
             self._hip_set_write_back(write_back, attached=policy_forward == "hip")
 
         def update(self, buffer, sample_size):
@@ -1625,7 +1631,7 @@ def make_hip_sac(ref=None):
                     obs_dim, act_dim,
                     S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
                     flat_c(self.critic), flat_c(self.critic2), cfg, hidden=self._hip_hidden, depth=self._hip_depth,
-                    max_action=self._hip_bound)
+                    max_action=self._hip_bound, activation=self._hip_actfn)
                 # resume: lagged critics, Adam moments / steps of a loaded checkpoint
                 eng.critic1_old, eng.critic2_old = flat_c(self.critic_old.module), flat_c(self.critic2_old.module)
                 for name, mod, optim, keys, conv in self._hip_parts(S):
@@ -1739,8 +1745,7 @@ def make_hip_redq(ref=None):
                 raise NotImplementedError("HipREDQ: networks must be those of test/continuous/test_redq.py (SAC's actor; a critic of "
                                           "EnsembleLinear layers; trunks of one depth, 1 .. 6 hidden layers)")
             self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, S.actor_keys(depth), RQ.critic_keys(depth)
-            for mod in (self.policy.actor, self.critic):
-                _require_relu_trunk(mod, "HipREDQ")
+            self._hip_actfn = _trunk_activation((self.policy.actor, self.critic), "HipREDQ")
             self._hip_bound = _actor_bound(self.policy.actor)
             from . import widths as WD
 
@@ -1781,7 +1786,7 @@ def make_hip_redq(ref=None):
                 eng = self._hip_engine = RQ.REDQEngine(
                     obs_dim, act_dim, S.actor_flat_from_torch([sa[k] for k in self._hip_akeys], obs_dim, act_dim, dev, hidden=hid),
                     RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic), obs_dim, act_dim, dev, hidden=hid), cfg,
-                    hidden=self._hip_hidden, depth=self._hip_depth, max_action=self._hip_bound)
+                    hidden=self._hip_hidden, depth=self._hip_depth, max_action=self._hip_bound, activation=self._hip_actfn)
                 # resume: lagged ensemble, counters, Adam moments / steps of a loaded checkpoint
                 eng.critics_old = RQ.ensemble_flat_from_torch(self._critic_tensors(self.critic_old.module), obs_dim, act_dim, dev, hidden=hid)
                 eng.critic_gradient_step = int(self.critic_gradient_step)
@@ -1884,8 +1889,7 @@ def make_hip_discrete_sac(ref=None):
                 raise NotImplementedError("HipDiscreteSAC: networks must be Net(obs, [h, ...]) of one depth (1 .. 6 hidden layers) + a "
                                           "single Linear head")
             self._hip_depth, self._hip_keys = depth, DS.net_keys(depth)
-            for mod in mods:
-                _require_relu_trunk(mod, "HipDiscreteSAC")
+            self._hip_actfn = _trunk_activation(mods, "HipDiscreteSAC")
             sa = self.policy.actor.state_dict()
             from . import widths as WD
 
@@ -1927,7 +1931,7 @@ def make_hip_discrete_sac(ref=None):
                 flat = lambda mod: DS.net_flat_from_torch(  # noqa: E731
                     [mod.state_dict()[k] for k in self._hip_keys], *dims, dev)
                 eng = self._hip_engine = DS.DiscreteSACEngine(*dims, flat(self.policy.actor), flat(self.critic),
-                                                              flat(self.critic2), cfg, depth=self._hip_depth)
+                                                              flat(self.critic2), cfg, depth=self._hip_depth, activation=self._hip_actfn)
                 eng.critic1_old, eng.critic2_old = flat(self.critic_old.module), flat(self.critic2_old.module)
                 for name, mod, optim in self._hip_parts():             # resume from a loaded checkpoint
                     ms, vs, step = adam_state(optim._optim, params_by_keys(mod, self._hip_keys))
@@ -2195,8 +2199,7 @@ def _make_hip_det(twin: bool, ref=None):
                 raise NotImplementedError("HipTD3 / HipDDPG: networks must be those of examples/mujoco/mujoco_td3.py (Net trunks of "
                                           "one depth, 1 .. 6 hidden layers, single-Linear action / Q heads)")
             self._hip_depth, self._hip_akeys, self._hip_ckeys = depth, T.actor_keys(depth), T.critic_keys(depth)
-            for mod in [self.policy.actor] + critics:
-                _require_relu_trunk(mod, "HipTD3 / HipDDPG")
+            self._hip_actfn = _trunk_activation([self.policy.actor] + critics, "HipTD3 / HipDDPG")
             # any hidden widths per network, e.g. the [400, 300] of the TD3 / DDPG papers (round 6, tianshou_amd.widths)
             from . import widths as WD
 
@@ -2241,7 +2244,8 @@ def _make_hip_det(twin: bool, ref=None):
                 flats = {n: conv([mod.state_dict()[k] for k in keys], obs_dim, act_dim, dev)
                          for n, mod, _, keys, conv, _, _ in self._hip_parts()}
                 eng = self._hip_engine = T.TD3Engine(obs_dim, act_dim, flats["actor"], flats["critic1"],
-                                                     flats.get("critic2"), cfg, hidden=self._hip_hidden, depth=self._hip_depth)
+                                                     flats.get("critic2"), cfg, hidden=self._hip_hidden, depth=self._hip_depth,
+                                                     activation=self._hip_actfn)
                 eng.cnt = getattr(self, "_cnt", 0)
                 for n, mod, optim, keys, conv, _, old in self._hip_parts():           # resume from a checkpoint
                     setattr(eng, n + "_old", conv([old.state_dict()[k] for k in keys], obs_dim, act_dim, dev))

@@ -339,7 +339,7 @@ def _sac_forward(policy, batch, state=None, **kwargs):
     logp = torch.empty(n, dtype=torch.float32, device=dev)
     mu, sigma = torch.empty_like(act), torch.empty_like(act)
     ws = _lib.default_workspace(dev.index or 0)
-    S.use_hidden(ws, hid, depth, float(spec.get("max_action") or 0.0))
+    S.use_hidden(ws, hid, depth, float(spec.get("max_action") or 0.0), spec.get("activation", "relu"))
     _lib.check(_lib.load().ts_sac_policy_forward_logits(
         ws.handle, _lib.ptr(actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(n), _lib.i64(obs_dim), _lib.i64(a), _lib.ptr(act),
         _lib.ptr(logp), _lib.ptr(mu), _lib.ptr(sigma), _lib.current_stream(dev)))

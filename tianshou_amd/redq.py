@@ -85,14 +85,14 @@ class REDQEngine:
     """State of one REDQ learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critics: torch.Tensor, cfg: REDQConfig,
-                 hidden: int = 256, depth: int = 2, max_action: float = 0.0):
+                 hidden: int = 256, depth: int = 2, max_action: float = 0.0, activation: str = "relu"):
         """`hidden` / `depth`: width h and number of hidden layers of the actor's Net[h] * depth and of the EnsembleLinear critics
         (test_redq.py uses [256, 256]; any multiple of 32 up to 1024, 1 .. 6 layers, utils/net/common.py:246-369)."""
         if not actor.is_cuda:
             raise RuntimeError("REDQEngine needs parameters on an MI355X (no CPU fallback)")
         if cfg.target_mode not in ("min", "mean") or not 0 < cfg.subset_size <= cfg.ensemble_size <= 64:
             raise ValueError("target_mode must be 'min' or 'mean' and 0 < subset_size <= ensemble_size <= 64")
-        self.depth, self.max_action = int(depth), float(max_action)      # (max_action > 0: bounded actor, as in SACEngine)
+        self.depth, self.max_action, self.activation = int(depth), float(max_action), activation      # (as in SACEngine)
         n_actor, n_critic = mlp_layout(obs_dim, hidden, self.depth, 64)[1][-1], mlp_layout(obs_dim + act_dim, hidden, self.depth, 32)[1][-1]
         if actor.numel() != n_actor or critics.numel() != cfg.ensemble_size * n_critic:
             raise ValueError("flat parameter vectors do not match ts_mlp_layout / the ensemble size")
@@ -124,7 +124,7 @@ class REDQEngine:
         if sub.size != self.cfg.subset_size:
             raise ValueError("subset must hold subset_size member indices")
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_redq_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critics_old), _lib.i64(self.cfg.ensemble_size),
             sub.ctypes.data_as(C.POINTER(C.c_int32)), _lib.i64(sub.size), C.c_int(int(self.cfg.target_mode == "mean")),
@@ -168,7 +168,7 @@ class REDQEngine:
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st = REDQStateC(*[getattr(self, n).data_ptr() for n, _ in REDQStateC._fields_])
         hp = self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_redq_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cfg.ensemble_size), _lib.i64(self.critic_gradient_step),
             _lib.i64(max(self.actor_steps, 1)), C.c_int(int(do_actor)), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),

@@ -93,13 +93,18 @@ def mlp_layout(in_dim: int, hidden: int, depth: int, head_cols: int) -> tuple[in
     return int(out[0]), [int(v) for v in out[1:]]
 
 
-def use_hidden(ws, hidden: int, depth: int = 2, max_action: float = 0.0) -> None:
+ACTIVATIONS = {"relu": 1, "tanh": 0}      # TS_NET_ACT_* (include/tsengine.h)
+
+
+def use_hidden(ws, hidden: int, depth: int = 2, max_action: float = 0.0, activation: str = "relu") -> None:
     """Hidden width, depth and the Gaussian actor's tanh bound are properties of the workspace (ts_mlp_set_trunk,
     ts_sac_set_actor_bound): every SAC / TD3 / DDPG / REDQ / DiscreteSAC engine sets its own before each call, since engines of
     different networks may share the device's default workspace."""
     lib = _lib.load()
     _lib.check(lib.ts_mlp_set_trunk(ws.handle, _lib.i64(hidden), _lib.i64(depth)))
     _lib.check(lib.ts_sac_set_actor_bound(ws.handle, _lib.f64(max_action)))
+    if activation != "relu":                  # (ts_mlp_set_trunk has just reset it to ReLU)
+        _lib.check(lib.ts_mlp_set_activation(ws.handle, C.c_int(ACTIVATIONS[activation])))
 
 
 def _l1(w: torch.Tensor, b: torch.Tensor, k_pad: int) -> torch.Tensor:
@@ -205,14 +210,17 @@ class SACEngine:
     """State of one SAC learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor, cfg: SACConfig, hidden: int = HID, depth: int = 2, max_action: float = 0.0):
+                 critic2: torch.Tensor, cfg: SACConfig, hidden: int = HID, depth: int = 2, max_action: float = 0.0,
+                 activation: str = "relu"):
         """`hidden`: width of the Net[hidden] * depth trunks (utils/net/common.py:246-369; [256, 256] in mujoco_sac.py): any
         multiple of 32 up to 1024, 1 .. 6 hidden layers -- [256, 256] runs on the fused three-layer kernels, everything else on the
         per-layer GEMMs.  `max_action` > 0: the class-default BOUNDED actor, mu = max_action * tanh(mu) (continuous.py:230-231);
         0 = `unbounded=True` as in the examples."""
         if not actor.is_cuda:
             raise RuntimeError("SACEngine needs parameters on an MI355X (no CPU fallback)")
-        self.hidden, self.depth, self.max_action = int(hidden), int(depth), float(max_action)
+        if activation not in ACTIVATIONS:
+            raise NotImplementedError("activation must be 'relu' (Net's default) or 'tanh'")
+        self.hidden, self.depth, self.max_action, self.activation = int(hidden), int(depth), float(max_action), activation
         n_actor, n_critic = mlp_layout(obs_dim, self.hidden, self.depth, 64)[1][-1], mlp_layout(obs_dim + act_dim, self.hidden, self.depth, 32)[1][-1]
         if actor.numel() != n_actor or critic1.numel() != n_critic or critic2.numel() != n_critic:
             raise ValueError("flat parameter vectors do not match ts_mlp_layout")
@@ -254,7 +262,7 @@ class SACEngine:
         noise = None if noise is None else self._f32(noise, (b, self.act_dim))
         act = torch.empty((b, self.act_dim), dtype=torch.float32, device=self.device)
         logp = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_sac_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.ptr(act), _lib.ptr(logp), None, _lib.current_stream(self.device)))
@@ -266,7 +274,7 @@ class SACEngine:
         b = obs_next.shape[0]
         noise = self._f32(noise, (b, self.act_dim))
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_sac_target_q(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(obs_next),
@@ -293,7 +301,7 @@ class SACEngine:
             b = idx.numel()
             noise = self._f32(noise, (b, self.act_dim))
             out = torch.empty(b, dtype=torch.float32, device=self.device)
-            use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+            use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
             _lib.check(_lib.load().ts_sac_returns_rows(
                 self._ws.handle, _lib.ptr(self.actor), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
                 _lib.ptr(self.log_alpha if self.cfg.auto_alpha else None), _lib.f64(self.cfg.alpha), _lib.ptr(buffer.obs_next),
@@ -325,7 +333,7 @@ class SACEngine:
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st, hp = self._state_c(), self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_sac_update(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(returns),
             _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -346,7 +354,7 @@ class SACEngine:
         stats = torch.empty(5, dtype=torch.float32, device=self.device)
         w_out = torch.empty(b, dtype=torch.float32, device=self.device)
         st, hp = self._state_c(), self.cfg.to_c(lr_scale)
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_sac_update_rows(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(buffer.obs), _lib.ptr(buffer.act), _lib.ptr(idx),
             _lib.ptr(returns), _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -375,7 +383,7 @@ class SACEngine:
 
     def update_phase(self, ctx: dict, phase: int, grads: torch.Tensor) -> None:
         st = self._state_c()
-        use_hidden(self._ws, self.hidden, self.depth, self.max_action)
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
         _lib.check(_lib.load().ts_sac_update_phase(
             self._ws.handle, C.byref(st), _lib.i64(self.adam_step), _lib.ptr(ctx["obs"]), _lib.ptr(ctx["act"]),
             _lib.ptr(ctx["returns"]), _lib.ptr(ctx["weight"]), _lib.ptr(ctx["noise"]), _lib.i64(ctx["b"]),

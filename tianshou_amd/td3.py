@@ -95,14 +95,14 @@ class TD3Engine:
     """State of one TD3 / DDPG learner on one GPU."""
 
     def __init__(self, obs_dim: int, act_dim: int, actor: torch.Tensor, critic1: torch.Tensor,
-                 critic2: torch.Tensor | None, cfg: TD3Config, hidden: int = HID, depth: int = 2):
+                 critic2: torch.Tensor | None, cfg: TD3Config, hidden: int = HID, depth: int = 2, activation: str = "relu"):
         """`hidden` / `depth`: the Net[hidden] * depth trunks (any multiple of 32 up to 1024, 1 .. 6 hidden layers; [256, 256]
         in the examples)."""
         if not actor.is_cuda:
             raise RuntimeError("TD3Engine needs parameters on an MI355X (no CPU fallback)")
         if cfg.twin != (critic2 is not None):
             raise ValueError("cfg.twin and critic2 disagree")
-        self.hidden, self.depth = int(hidden), int(depth)
+        self.hidden, self.depth, self.activation = int(hidden), int(depth), activation
         if actor.numel() != mlp_layout(obs_dim, self.hidden, self.depth, 32)[1][-1] \
                 or critic1.numel() != mlp_layout(obs_dim + act_dim, self.hidden, self.depth, 32)[1][-1]:
             raise ValueError("flat parameter vectors do not match ts_mlp_layout")
@@ -126,7 +126,7 @@ class TD3Engine:
     def policy_forward(self, obs) -> torch.Tensor:
         obs = self._f32(obs)
         act = torch.empty((obs.shape[0], self.act_dim), dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden, self.depth)
+        use_hidden(self._ws, self.hidden, self.depth, 0.0, self.activation)
         _lib.check(_lib.load().ts_td3_policy_forward(
             self._ws.handle, _lib.ptr(self.actor), _lib.ptr(obs), _lib.i64(obs.shape[0]), _lib.i64(self.obs_dim),
             _lib.i64(self.act_dim), _lib.f64(self.cfg.max_action), _lib.ptr(act), _lib.current_stream(self.device)))
@@ -140,7 +140,7 @@ class TD3Engine:
             raise ValueError("TD3 needs the target-smoothing noise (the torch.randn draws of td3.py:196)")
         noise = self._f32(noise, (b, self.act_dim)) if cfg.twin else None
         out = torch.empty(b, dtype=torch.float32, device=self.device)
-        use_hidden(self._ws, self.hidden, self.depth)
+        use_hidden(self._ws, self.hidden, self.depth, 0.0, self.activation)
         _lib.check(_lib.load().ts_td3_target_q(
             self._ws.handle, _lib.ptr(self.actor_old), _lib.ptr(self.critic1_old), _lib.ptr(self.critic2_old),
             _lib.ptr(obs_next), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
@@ -177,7 +177,7 @@ class TD3Engine:
         st = TD3StateC(*[None if getattr(self, n) is None else getattr(self, n).data_ptr() for n in names])
         hp = TD3HParams(cfg.actor_lr * lr_scale, cfg.critic_lr * lr_scale, cfg.betas[0], cfg.betas[1], cfg.adam_eps,
                         cfg.tau, cfg.max_action, int(upd), 0)
-        use_hidden(self._ws, self.hidden, self.depth)
+        use_hidden(self._ws, self.hidden, self.depth, 0.0, self.activation)
         _lib.check(_lib.load().ts_td3_update(
             self._ws.handle, C.byref(st), _lib.i64(self.cnt), _lib.i64(max(self.actor_steps, 1)), _lib.ptr(obs),
             _lib.ptr(act), _lib.ptr(returns), _lib.ptr(weight), _lib.i64(b), _lib.i64(self.obs_dim),
