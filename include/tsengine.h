@@ -1172,8 +1172,14 @@ typedef struct ts_net_desc {
     double max_action;                 /* actor only (round 6): > 0 = ContinuousActorProbabilistic(unbounded=False), the constructor
                                           default (utils/net/continuous.py:194, 230-231): mu = max_action * tanh(Linear(h)), and
                                           the gradient goes back through it; 0 = unbounded */
+    double ln_eps;                     /* TS_NET_LAYERNORM: the LayerNorm modules' eps (0 = torch's default 1e-5) */
 } ts_net_desc;
 #define TS_NET_CONDITIONED_SIGMA 1
+/* flags | TS_NET_LAYERNORM (round 6): MLP(norm_layer=nn.LayerNorm) -- every hidden layer is Linear -> LayerNorm(width) ->
+ * activation (utils/net/common.py:25-39, 99-137; elementwise affine, biased variance over the layer's configured width).  The
+ * flat vector then holds, behind every hidden layer's wb block, gamma[N_pad] | beta[N_pad] (padding entries zero), and the
+ * gradients follow the same layout.  PPO / A2C entry points (ts_ppo_net_infer, ts_ppo_net_step); not the NPG / TRPO ones. */
+#define TS_NET_LAYERNORM 2
 int ts_net_layout(const ts_net_desc* net, int64_t act_dim, int64_t* h_out3);
 int ts_ppo_net_infer(ts_workspace* ws, const float* actor, const float* critic, const ts_net_desc* actor_net,
                      const ts_net_desc* critic_net, int64_t act_dim, const float* obs, const float* act, int64_t B,

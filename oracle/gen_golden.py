@@ -496,22 +496,26 @@ def gen_ppo(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size:
 
 def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_a: list[int], hidden_c: list[int], activation,
                 batch_size: int, repeat: int, seed: int, algo: str = "ppo", conditioned_sigma: bool = False,
-                max_action: float | None = None, optim: tuple[str, dict] | None = None, **ppo_kwargs) -> None:
+                max_action: float | None = None, optim: tuple[str, dict] | None = None, layer_norm: bool = False,
+                norm_args: dict | None = None, **ppo_kwargs) -> None:
     """The reference PPO / A2C update() for actor-critics whose trunks are Net(hidden_sizes=..., activation=...) of any depth
     (utils/net/common.py:90-178, 246-369; `activation` = nn.Tanh, nn.ReLU or None): inputs, Batch.split's permutations,
     per-step losses and the parameters / Adam moments after the update, as lists of tensors in module order
-    (trunk (w, b)*, head w, head b[, sigma_param]).  Replayed by tests/test_gpu_ppo_net.py on the engine's per-layer path."""
+    (trunk (w, b)*, head w, head b[, sigma_param]).  Replayed by tests/test_gpu_ppo_net.py on the engine's per-layer path.
+    layer_norm: Net(norm_layer=nn.LayerNorm, norm_args=...) -- Linear -> LayerNorm -> activation per hidden layer
+    (common.py:25-39); the trunk's tensors are then (w, b, gamma, beta)* and gamma / beta start away from (1, 0)."""
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     N = E * T
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden_a, activation=activation)
+    nkw = dict(norm_layer=nn.LayerNorm, norm_args=norm_args) if layer_norm else {}
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden_a, activation=activation, **nkw)
     if max_action is None:
         actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True,
                                              conditioned_sigma=conditioned_sigma)
     else:       # the constructor default: mu = max_action * tanh(Linear(h)) (continuous.py:194, 230-231)
         actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), max_action=max_action,
                                              conditioned_sigma=conditioned_sigma)
-    net_c = Net(state_shape=(obs_dim,), hidden_sizes=hidden_c, activation=activation)
+    net_c = Net(state_shape=(obs_dim,), hidden_sizes=hidden_c, activation=activation, **nkw)
     critic = ContinuousCritic(preprocess_net=net_c)
     if not conditioned_sigma:
         torch.nn.init.constant_(actor.sigma_param, -0.5)
@@ -519,6 +523,9 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
         if isinstance(m, nn.Linear):
             nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
             nn.init.normal_(m.bias, std=0.1)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.normal_(m.bias, std=0.2)
     if conditioned_sigma:                       # a sigma head whose outputs straddle the upper clamp (SIGMA_MAX = 2)
         with torch.no_grad():
             actor.sigma.model[0].weight.mul_(0.3)
@@ -541,7 +548,7 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
     algorithm = cls(policy=policy, critic=critic, optim=optim_factory, **ppo_kwargs)
 
     def tensors(mod, head):
-        lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)]
+        lin = [m for m in mod.preprocess.model.model if isinstance(m, (nn.Linear, nn.LayerNorm))]
         out = []
         for m in lin + [m for m in head.modules() if isinstance(m, nn.Linear)]:
             out += [m.weight, m.bias]
@@ -555,6 +562,9 @@ def gen_ppo_net(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, hidden_
                                   "activation": np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation]),
                                   "conditioned_sigma": np.array(int(conditioned_sigma)),
                                   "max_action": np.array(float(max_action or 0.0))}
+    if layer_norm:                                              # (only then: the other fixtures keep their key set)
+        out["layer_norm"] = np.array(1)
+        out["ln_eps"] = np.array(float((norm_args or {}).get("eps", 1e-5)))
     for i, t in enumerate(a_par):
         out[f"a{i}_0"] = t.detach().numpy().copy()
     for i, t in enumerate(c_par):
@@ -695,6 +705,19 @@ def gen_ppo_round6() -> None:
                 conditioned_sigma=True, max_action=1.0, optim=("adam", dict(weight_decay=5e-3)), batch_size=64, repeat=2, seed=27,
                 eps_clip=0.2, vf_coef=0.5, ent_coef=0.02, max_grad_norm=0.5, value_clip=True, advantage_normalization=True,
                 return_scaling=False, gae_lambda=0.95, gamma=0.99)
+
+
+def gen_ppo_layernorm() -> None:
+    """Round 6: MLP(norm_layer=nn.LayerNorm) trunks (utils/net/common.py:25-39, 99-137) under PPO / A2C on the per-layer engine."""
+    # three ReLU layers with LayerNorm, unequal widths (none a multiple of 32), different actor / critic trunks, PPO
+    gen_ppo_net("ln_relu3", E=4, T=50, obs_dim=11, act_dim=3, hidden_a=[96, 72, 40], hidden_c=[64, 48], activation=nn.ReLU,
+                layer_norm=True, batch_size=64, repeat=2, seed=31, eps_clip=0.2, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5,
+                value_clip=True, advantage_normalization=True, return_scaling=False, gae_lambda=0.95, gamma=0.99)
+    # one tanh layer with LayerNorm(eps=1e-3), the bounded actor (the class default), A2C with RMSprop + weight decay
+    gen_ppo_net("ln_tanh1_a2c", algo="a2c", E=3, T=40, obs_dim=5, act_dim=2, hidden_a=[48], hidden_c=[80], activation=nn.Tanh,
+                layer_norm=True, norm_args=dict(eps=1e-3), max_action=2.0, optim=("rmsprop", dict(eps=1e-5, alpha=0.99, weight_decay=1e-3)),
+                batch_size=60, repeat=1, seed=32, vf_coef=0.5, ent_coef=0.01, max_grad_norm=0.5, return_scaling=False,
+                gae_lambda=0.9, gamma=0.99)
 
 
 def gen_policy_forward() -> None:
@@ -1445,6 +1468,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "ppo_net":
         gen_ppo_net_all()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "ppo_layernorm":
+        gen_ppo_layernorm()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "rainbow":
         gen_rainbow_all()

@@ -111,11 +111,13 @@ class RunningMeanStd:
 class _MLP(nn.Module):
     """utils/net/common.py MLP: `.model` is the nn.Sequential."""
 
-    def __init__(self, sizes, activation, linear_layer=nn.Linear):
+    def __init__(self, sizes, activation, linear_layer=nn.Linear, norm_layer=None, norm_args=None):
         super().__init__()
         layers = []
         for i in range(len(sizes) - 1):
             layers.append(linear_layer(sizes[i], sizes[i + 1]))
+            if norm_layer is not None:                        # miniblock, common.py:25-39: Linear -> norm -> activation
+                layers.append(norm_layer(sizes[i + 1], **(norm_args or {})))
             if activation is not None:
                 layers.append(activation())
         self.model = nn.Sequential(*layers)
@@ -124,9 +126,9 @@ class _MLP(nn.Module):
 class Net(nn.Module):
     """utils/net/common.py:246-369: `.model` is an MLP -> state_dict keys `model.model.{0,2}.{weight,bias}`."""
 
-    def __init__(self, in_dim, hidden_sizes, activation=nn.ReLU, linear_layer=nn.Linear):
+    def __init__(self, in_dim, hidden_sizes, activation=nn.ReLU, linear_layer=nn.Linear, norm_layer=None, norm_args=None):
         super().__init__()
-        self.model = _MLP([in_dim, *hidden_sizes], activation, linear_layer)
+        self.model = _MLP([in_dim, *hidden_sizes], activation, linear_layer, norm_layer, norm_args)
         self.output_dim = hidden_sizes[-1]
 
 

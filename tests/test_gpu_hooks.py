@@ -472,8 +472,8 @@ def test_hip_sac_default_mode_equals_the_reference_exact_mode(monkeypatch):
     """The defaults of HipSAC since round 6 -- `update()` samples indices only (no host copy of the batch), write-back of the five
     networks / four optimizers deferred until the torch state is read -- against the reference-exact mode on the same indices
     and noise: identical statistics every update, identical torch state after `hip_sync()`.  And what lazy means: the torch
-    modules do not move between syncs; `policy.state_dict()`, `algorithm.state_dict()`, pickling the policy and `hip_sync()`
-    are readers that sync; a foreign write to ONE module (`critic.load_state_dict`) keeps the engine's progress on the others."""
+    modules do not move between syncs; `policy.state_dict()`, `algorithm.state_dict()`, any sub-module's `state_dict()`, pickling
+    the policy and `hip_sync()` are readers that sync; a foreign write to ONE module (`critic.load_state_dict`) keeps the engine's progress on the others."""
     import copy
     import pickle
 
@@ -523,6 +523,12 @@ def test_hip_sac_default_mode_equals_the_reference_exact_mode(monkeypatch):
     assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(twin.state_dict().values(), ref.policy.state_dict().values()))
     for algo, buf in zip((ref, lazy), bufs):
         torch.manual_seed(201)
+        algo.update(buf, B)
+    assert lazy.__dict__["_hip_stale"]
+    c2 = lazy.critic2.state_dict()                                 # a SUB-module's state_dict() is a reader too (pre-hook): syncs
+    assert not lazy.__dict__["_hip_stale"] and all(torch.equal(v.cpu(), ref.critic2.state_dict()[k].cpu()) for k, v in c2.items())
+    for algo, buf in zip((ref, lazy), bufs):
+        torch.manual_seed(204)
         algo.update(buf, B)
     assert lazy.__dict__["_hip_stale"]
     sd_l, sd_r = lazy.state_dict(), ref.state_dict()
@@ -1250,12 +1256,13 @@ def test_hip_ddpg_hooks_against_oracle():
     assert float(st_a["step"]) == 4.0 and float(st_c["step"]) == 4.0
 
 
-@pytest.mark.parametrize("tag", ["relu3", "linear4", "csigma"])
+@pytest.mark.parametrize("tag", ["relu3", "linear4", "csigma", "ln_relu3"])
 def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     """Net trunks outside [h, h] tanh (three ReLU layers of unequal widths with a different critic trunk; four linear layers):
     HipPPO picks the per-layer engine (kind "net", ppo_wide.NetPPOEngine) and the whole hook path -- mirror, preprocess, the
     host-drawn Batch.split permutations, update, write-back, Adam flush -- reproduces what the REFERENCE's PPO.update()
-    produced on the same buffer contents, weights and NumPy seed (tests/golden/ppo_net_*.npz, oracle/gen_golden.py::gen_ppo_net)."""
+    produced on the same buffer contents, weights and NumPy seed (tests/golden/ppo_net_*.npz, oracle/gen_golden.py::gen_ppo_net).
+    ln_relu3: Net(norm_layer=nn.LayerNorm) (utils/net/common.py:25-39) -- Linear -> LayerNorm -> ReLU per hidden layer."""
     import os
 
     from tianshou_amd.integration import make_hip_ppo
@@ -1266,13 +1273,15 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     E, T, obs_dim, act_dim, batch_size, repeat = (int(x) for x in g["dims"])
     ha, hc = [int(x) for x in g["hidden_a"]], [int(x) for x in g["hidden_c"]]
     act_cls = {0: nn.Tanh, 1: nn.ReLU, 2: None}[int(g["activation"])]
-    seed = {"relu3": 11, "linear4": 13, "csigma": 14}[tag]
+    seed = {"relu3": 11, "linear4": 13, "csigma": 14, "ln_relu3": 31}[tag]
     cs = bool(int(g["conditioned_sigma"]))
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls), act_dim, unbounded=True, conditioned_sigma=cs)
-    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, act_cls))
+    ln = "layer_norm" in g
+    nkw = dict(norm_layer=nn.LayerNorm, norm_args=dict(eps=float(g["ln_eps"]))) if ln else {}
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, ha, act_cls, **nkw), act_dim, unbounded=True, conditioned_sigma=cs)
+    critic = SI.ContinuousCritic(SI.Net(obs_dim, hc, act_cls, **nkw))
 
     def params(mod, head, extra=()):
-        lin = [m for m in mod.preprocess.model.model if isinstance(m, nn.Linear)] + [m for m in head.modules() if isinstance(m, nn.Linear)]
+        lin = [m for m in mod.preprocess.model.model if isinstance(m, (nn.Linear, nn.LayerNorm))] + [m for m in head.modules() if isinstance(m, nn.Linear)]
         out = []
         for m in lin:
             out += [m.weight, m.bias]
@@ -1291,7 +1300,7 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
               gamma=cfg["gamma"], lr=cfg["lr"])
     algo = make_hip_ppo("ppo", ref=SI)(policy=SI.Policy(actor), critic=critic, device="cuda", permutations="host", **kw).to("cuda")
     assert algo._hip_dims == (obs_dim, act_dim, (tuple(ha), tuple(hc), {nn.Tanh: "tanh", nn.ReLU: "relu", None: "none"}[act_cls]) +
-                              (("conditioned_sigma",) if cs else ()), "net")
+                              (("conditioned_sigma",) if cs else ()) + ((("layer_norm", float(g["ln_eps"])),) if ln else ()), "net")
     buf = SI.VectorReplayBuffer(E * T, E, obs_shape=(obs_dim,), act_shape=(act_dim,))
     size = buf.maxsize // E
     for t in range(T):                                   # slot e * size + t of the fixture's buffer = env e, step t
@@ -1315,6 +1324,13 @@ def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     for i, p in enumerate(pa):
         np.testing.assert_allclose(state[p]["exp_avg"].cpu().numpy(), g[f"a{i}_m"], rtol=1e-3, atol=1e-6)
         assert state[p]["exp_avg"].shape == p.shape and float(state[p]["step"]) == stats.gradient_steps
+    if not cs:      # the collector's forward on the engine (tianshou_amd.policy, "gauss_net") == the written-back torch modules'
+        obs = g["obs"][:33]
+        out = algo.policy(SI.Batch(obs=obs, info={}))
+        with torch.no_grad():
+            h = actor.preprocess.model.model(torch.as_tensor(obs, device="cuda"))       # (the stand-in MLPs are containers)
+            mu_t = actor.mu.model(h)
+        np.testing.assert_allclose(out.logits[0].cpu().numpy(), mu_t.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 

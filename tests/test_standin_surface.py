@@ -765,3 +765,42 @@ def test_a2c_standin_has_the_reference_surface():
     assert A.__name__ == B.__name__ == "HipA2C"
     for name in ("_preprocess_batch", "_update_with_batch", "_engine", "_hip_params"):
         assert getattr(A, name).__code__.co_code == getattr(B, name).__code__.co_code, name
+
+
+def test_layer_norm_trunks_reference_and_standin_agree():
+    """Round 6: MLP(norm_layer=nn.LayerNorm) (utils/net/common.py:25-39).  The REAL Net and the stand-in build the same module
+    sequence / state_dict keys; `_check_supported` describes both as the per-layer engine's ("net", ..., ("layer_norm", eps))
+    with the key order (w, b, gamma, beta)* the flat layout stores; trunks the engine does not cover raise: a norm layer on
+    one network only, BatchNorm, NPG's hooks (no forward-mode pass through a layer norm)."""
+    ref_shim.install()
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+
+    from tianshou_amd.integration import _check_supported, _net_keys, _trunk_spec
+
+    def real(norm=nn.LayerNorm, norm_c="same", args=None):
+        a = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[96, 40], activation=nn.ReLU,
+                                                            norm_layer=norm, norm_args=args), action_shape=(3,), unbounded=True)
+        c = ContinuousCritic(preprocess_net=Net(state_shape=(11,), hidden_sizes=[64], activation=nn.ReLU,
+                                                norm_layer=norm if norm_c == "same" else norm_c, norm_args=args))
+        return a, c
+
+    ra, rc = real(args=dict(eps=1e-3))
+    fa = SI.ContinuousActorProbabilistic(SI.Net(11, [96, 40], nn.ReLU, norm_layer=nn.LayerNorm, norm_args=dict(eps=1e-3)), 3, unbounded=True)
+    fc = SI.ContinuousCritic(SI.Net(11, [64], nn.ReLU, norm_layer=nn.LayerNorm, norm_args=dict(eps=1e-3)))
+    assert list(ra.state_dict().keys()) == list(fa.state_dict().keys()) and list(rc.state_dict().keys()) == list(fc.state_dict().keys())
+    for a, c in ((ra, rc), (fa, fc)):
+        assert _check_supported(a, c) == (11, 3, ((96, 40), (64,), "relu", ("layer_norm", 1e-3)), "net")
+        ka, kc = _net_keys(a, c)
+        assert ka == ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.1.weight",
+                      "preprocess.model.model.1.bias", "preprocess.model.model.3.weight", "preprocess.model.model.3.bias",
+                      "preprocess.model.model.4.weight", "preprocess.model.model.4.bias", "mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+        assert kc == ["preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.1.weight",
+                      "preprocess.model.model.1.bias", "last.model.0.weight", "last.model.0.bias"]
+        with pytest.raises(NotImplementedError):            # the hooks of the other families pass norm=False
+            _trunk_spec(a, "actor")
+    with pytest.raises(NotImplementedError):
+        _check_supported(*real(norm_c=None))                # LayerNorm on the actor only
+    with pytest.raises(NotImplementedError):
+        _check_supported(*real(norm=nn.BatchNorm1d))
+    assert _check_supported(*real(norm=None))[2] == ((96, 40), (64,), "relu")

@@ -64,18 +64,19 @@ class NetDesc(C.Structure):
     MAX_HIDDEN = 7
     ACTIVATIONS = {"tanh": 0, "relu": 1, "none": 2}
     CONDITIONED_SIGMA = 1
+    LAYERNORM = 2                # MLP(norm_layer=nn.LayerNorm): Linear -> LayerNorm -> activation per hidden layer
     _fields_ = [("obs_dim", C.c_int64), ("n_hidden", C.c_int32), ("activation", C.c_int32), ("hidden", C.c_int64 * 7),
-                ("flags", C.c_int64), ("max_action", C.c_double)]
+                ("flags", C.c_int64), ("max_action", C.c_double), ("ln_eps", C.c_double)]
 
     @classmethod
-    def make(cls, obs_dim: int, hidden, activation: str, flags: int = 0, max_action: float = 0.0) -> "NetDesc":
+    def make(cls, obs_dim: int, hidden, activation: str, flags: int = 0, max_action: float = 0.0, ln_eps: float = 0.0) -> "NetDesc":
         hidden = [int(h) for h in hidden]
         if not 1 <= len(hidden) <= cls.MAX_HIDDEN:
             raise NotImplementedError(f"trunks of 1 .. {cls.MAX_HIDDEN} hidden layers are supported, got {len(hidden)}")
         if activation not in cls.ACTIVATIONS:
             raise NotImplementedError(f"activation must be one of {sorted(cls.ACTIVATIONS)}, got {activation!r}")
         d = cls(int(obs_dim), len(hidden), cls.ACTIVATIONS[activation], (C.c_int64 * 7)(*(hidden + [0] * (7 - len(hidden)))), int(flags),
-                float(max_action or 0.0))
+                float(max_action or 0.0), float(ln_eps or 0.0))
         return d
 
 

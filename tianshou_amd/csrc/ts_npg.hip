@@ -705,8 +705,11 @@ constexpr int MAXL = TS_NET_MAX_HIDDEN + 1;          // linear layers incl. the 
 struct NetL {
     ts::ConvGeom l[MAXL];
     int64_t off[MAXL + 1];        // off[L] = end of the head block
-    int L, obs, k0, act_fn, wmax, csigma;
+    int64_t ln_off[MAXL];         // layer norm: offset of hidden layer i's gamma[width] | beta[width] (behind its wb block)
+    int L, obs, k0, act_fn, wmax, csigma, ln;
+    float ln_eps;
     int width[MAXL + 1];          // width[0] = k0, width[i] = padded width of hidden layer i - 1, width[L] = HEAD
+    int tw[MAXL + 1];             // the same widths as configured (unpadded): what a LayerNorm normalises over
 };
 
 int make_netl(int B, const ts_net_desc* d, NetL* n) {
@@ -717,34 +720,45 @@ int make_netl(int B, const ts_net_desc* d, NetL* n) {
                "net: activation must be tanh, ReLU or none");
     n->L = d->n_hidden + 1; n->obs = (int)d->obs_dim; n->k0 = (n->obs + 31) / 32 * 32; n->act_fn = d->activation;
     n->csigma = (d->flags & TS_NET_CONDITIONED_SIGMA) ? 1 : 0;
-    n->width[0] = n->k0;
+    n->ln = (d->flags & TS_NET_LAYERNORM) ? 1 : 0;
+    n->ln_eps = n->ln ? (float)(d->ln_eps > 0.0 ? d->ln_eps : 1e-5) : 0.f;
+    n->width[0] = n->k0; n->tw[0] = n->obs;
     n->wmax = HEAD;
     for (int i = 0; i < d->n_hidden; ++i) {
         TS_REQUIRE(d->hidden[i] >= 1 && d->hidden[i] <= 1024, TS_ERR_UNSUPPORTED, "net: hidden widths must be in [1, 1024]");
+        n->tw[i + 1] = (int)d->hidden[i];
         n->width[i + 1] = ((int)d->hidden[i] + 31) / 32 * 32;
         n->wmax = std::max(n->wmax, n->width[i + 1]);
     }
-    n->width[n->L] = HEAD;
+    n->width[n->L] = HEAD; n->tw[n->L] = HEAD;
     int64_t o = 0;
     for (int i = 0; i < n->L; ++i) {
         n->l[i] = ts::ConvGeom{B, 1, 1, n->width[i], 1, 1, 1, 1, 1, n->width[i + 1]};
         n->off[i] = o;
         o += n->l[i].param_elems();
+        n->ln_off[i] = o;
+        if (n->ln && i + 1 < n->L) o += 2 * (int64_t)n->width[i + 1];
     }
     n->off[n->L] = o;
     return TS_OK;
 }
 
-struct ActL { float* h[MAXL]; };              // h[i] = output of layer i (h[L - 1] = the head's 32 columns)
+// h[i] = output of layer i (h[L - 1] = the head's 32 columns); layer norm: xh[i] = the normalised pre-activation of hidden layer
+// i, rs[i] = 1 / sqrt(var + eps) per row (what the backward pass needs)
+struct ActL { float* h[MAXL]; float* xh[MAXL]; float* rs[MAXL]; };
 
 ActL take_actl(Carve& c, const NetL& n, int64_t B) {
     ActL a{};
     for (int i = 0; i < n.L; ++i) a.h[i] = c.f(B * n.width[i + 1]);
+    if (n.ln)
+        for (int i = 0; i + 1 < n.L; ++i) { a.xh[i] = c.f(B * n.width[i + 1]); a.rs[i] = c.f(B); }
     return a;
 }
 size_t actl_bytes(const NetL& n, int64_t B) {
     size_t s = 0;
     for (int i = 0; i < n.L; ++i) s += al(4 * B * n.width[i + 1]);
+    if (n.ln)
+        for (int i = 0; i + 1 < n.L; ++i) s += al(4 * B * n.width[i + 1]) + al(4 * B);
     return s;
 }
 size_t split_floats(const NetL& n) {
@@ -752,9 +766,11 @@ size_t split_floats(const NetL& n) {
     for (int i = 0; i < n.L; ++i) { const int ns = ts::conv_fwd_splits(n.l[i]); if (ns > 1) s = std::max(s, (size_t)ns * n.l[i].out_elems()); }
     return s;
 }
+constexpr int LN_PART_BLOCKS = 256;            // workgroups (= partial sums of d gamma / d beta) of the layer-norm backward pass
 size_t slab_floats(const NetL& n) {
     size_t s = 0;
     for (int i = 0; i < n.L; ++i) s = std::max(s, (size_t)ts::conv_wgrad_splits(n.l[i]) * n.l[i].param_elems());
+    if (n.ln) s = std::max(s, (size_t)LN_PART_BLOCKS * 2 * n.wmax);      // (the slab area doubles as that pass's partial sums)
     return s;
 }
 
@@ -764,12 +780,106 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, c
     if (i < n) dh[i] = h[i] > 0.f ? dh[i] : 0.f;
 }
 
+// ---- layer norm between a hidden Linear and its activation: MLP(norm_layer=nn.LayerNorm), utils/net/common.py:25-39 ----------
+// One wavefront per row.  In place on the GEMM's output: h <- act(gamma * xhat + beta), xhat = (z - mean) * rstd over the layer's
+// `n` configured features (torch.nn.LayerNorm: biased variance, eps inside the square root); columns [n, pitch) stay zero.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void ln_fwd_kernel(float* __restrict__ h, float* __restrict__ xhat, float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, int64_t B, int n,
+                                                     int pitch, float eps, int act_fn) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float* r = h + row * pitch;
+    float sm = 0.f;
+    for (int j = lane; j < n; j += 64) sm += r[j];
+    const float mean = wave_sum(sm) / (float)n;
+    float q = 0.f;
+    for (int j = lane; j < n; j += 64) { const float d = r[j] - mean; q += d * d; }
+    const float rs = 1.f / sqrtf(wave_sum(q) / (float)n + eps);
+    for (int j = lane; j < pitch; j += 64) {
+        float xh = 0.f, out = 0.f;
+        if (j < n) {
+            xh = (r[j] - mean) * rs;
+            const float y = xh * gamma[j] + beta[j];
+            out = act_fn == TS_NET_ACT_TANH ? tanhf(y) : (act_fn == TS_NET_ACT_RELU ? fmaxf(y, 0.f) : y);
+        }
+        if (xhat) xhat[row * pitch + j] = xh;
+        r[j] = out;
+    }
+    if (lane == 0 && rstd) rstd[row] = rs;
+}
+
+// Backward through the layer norm.  dy (in: gradient w.r.t. gamma * xhat + beta, i.e. behind the activation's derivative; out: the
+// gradient w.r.t. the GEMM's output): dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.  Every workgroup also sums
+// dy * xhat and dy over its rows (wave-strided, fixed order) into part[block][2][pitch]; ln_bwd_finish_kernel adds the workgroups'
+// partial sums in order -> d gamma, d beta.  pitch <= 1024: at most 16 columns per lane.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, int64_t B, int n, int pitch,
+                                                     float* __restrict__ part) {
+    __shared__ float red[2][4][1024];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float ag[16], ab[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < B; row += (int64_t)gridDim.x * 4) {
+        float* d = dy + row * pitch;
+        const float* xh = xhat + row * pitch;
+        float g[16], x[16], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = lane + 64 * k;
+            g[k] = 0.f; x[k] = 0.f;
+            if (j < n) {
+                const float dv = d[j];
+                x[k] = xh[j];
+                g[k] = dv * gamma[j];
+                ag[k] += dv * x[k];
+                ab[k] += dv;
+                s1 += g[k];
+                s2 += g[k] * x[k];
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n, rs = rstd[row];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = lane + 64 * k;
+            if (j < pitch) d[j] = j < n ? rs * (g[k] - m1 - x[k] * m2) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { red[0][wave][lane + 64 * k] = ag[k]; red[1][wave][lane + 64 * k] = ab[k]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < pitch; j += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * pitch + j] = ((red[0][0][j] + red[0][1][j]) + red[0][2][j]) + red[0][3][j];
+        part[((int64_t)blockIdx.x * 2 + 1) * pitch + j] = ((red[1][0][j] + red[1][1][j]) + red[1][2][j]) + red[1][3][j];
+    }
+}
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ part, int n_blocks, int pitch,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= pitch) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < n_blocks; ++k) { a += part[((int64_t)k * 2 + 0) * pitch + j]; b += part[((int64_t)k * 2 + 1) * pitch + j]; }
+    dgamma[j] = a; dbeta[j] = b;
+}
+
 int forward_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, const float* x, const ActL& a, float* split, int64_t B) {
     const float* in = x;
     for (int i = 0; i < n.L; ++i) {
         const bool hidden = i + 1 < n.L;
-        if (int rc = ts::conv_forward(s, n.l[i], in, p + n.off[i], a.h[i], hidden && n.act_fn == TS_NET_ACT_RELU, split, ws)) return rc;
-        if (hidden && n.act_fn == TS_NET_ACT_TANH) {
+        const bool ln = hidden && n.ln;
+        if (int rc = ts::conv_forward(s, n.l[i], in, p + n.off[i], a.h[i], hidden && !ln && n.act_fn == TS_NET_ACT_RELU, split, ws)) return rc;
+        if (ln) {                                      // Linear -> LayerNorm -> activation (one kernel for the last two)
+            const int w = n.width[i + 1];
+            hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)ts::ceil_div(B, 4)), dim3(256), 0, s, a.h[i], a.xh[i], a.rs[i], p + n.ln_off[i],
+                               p + n.ln_off[i] + w, B, n.tw[i + 1], w, n.ln_eps, n.act_fn);
+            TS_LAUNCH_CHECK();
+        } else if (hidden && n.act_fn == TS_NET_ACT_TANH) {
             const int64_t cnt = B * n.width[i + 1];
             hipLaunchKernelGGL(tanh_kernel, dim3((unsigned)ts::ceil_div(cnt, 256)), dim3(256), 0, s, a.h[i], cnt);
             TS_LAUNCH_CHECK();
@@ -795,6 +905,15 @@ int backward_l(hipStream_t s, ts_workspace* ws, const NetL& n, const float* p, c
             if (n.act_fn == TS_NET_ACT_TANH) hipLaunchKernelGGL(tanh_bwd_kernel, dim3(g), dim3(256), 0, s, dx, a.h[i - 1], cnt);
             else if (n.act_fn == TS_NET_ACT_RELU) hipLaunchKernelGGL(relu_bwd_kernel, dim3(g), dim3(256), 0, s, dx, a.h[i - 1], cnt);
             TS_LAUNCH_CHECK();
+            if (n.ln) {                                // ... and back through hidden layer i - 1's layer norm (slabs: its partial sums)
+                const int w = n.width[i];
+                const int nb = (int)std::min<int64_t>(LN_PART_BLOCKS, ts::ceil_div(B, 4));
+                hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, dx, a.xh[i - 1], a.rs[i - 1], p + n.ln_off[i - 1], B,
+                                   n.tw[i], w, slabs);
+                hipLaunchKernelGGL(ln_bwd_finish_kernel, dim3((unsigned)ts::ceil_div(w, 256)), dim3(256), 0, s, slabs, nb, w,
+                                   grad + n.ln_off[i - 1], grad + n.ln_off[i - 1] + w);
+                TS_LAUNCH_CHECK();
+            }
             dy = dx;
         }
     }
@@ -1333,6 +1452,7 @@ int ts_npg_net_actor_step(ts_workspace* ws, float* actor, const ts_net_desc* net
     TS_REQUIRE(hp->cg_iters >= 1 && hp->cg_iters <= 100, TS_ERR_INVALID_ARG, "ts_npg_net_actor_step: bad cg_iters");
     TS_REQUIRE(!(net->flags & TS_NET_CONDITIONED_SIGMA) && !(net->max_action > 0.0), TS_ERR_UNSUPPORTED,
                "ts_npg_net_actor_step: an unbounded actor with a state-independent sigma_param is required");
+    TS_REQUIRE(!(net->flags & TS_NET_LAYERNORM), TS_ERR_UNSUPPORTED, "ts_npg_net_actor_step: no forward-mode pass through a layer norm");
     NetL n;
     if (int rc = make_netl((int)B, net, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);
@@ -1433,6 +1553,7 @@ int ts_npg_net_critic_steps(ts_workspace* ws, float* critic, float* adam_m, floa
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_npg_net_critic_steps: workspace is NULL");
     TS_REQUIRE(critic && adam_m && adam_v && net && obs && returns && loss_out && B >= 1 && adam_step >= 1 && iters >= 1 && iters <= 4096,
                TS_ERR_INVALID_ARG, "ts_npg_net_critic_steps: bad argument");
+    TS_REQUIRE(!(net->flags & TS_NET_LAYERNORM), TS_ERR_UNSUPPORTED, "ts_npg_net_critic_steps: layer-norm trunks are a PPO / A2C feature");
     NetL n;
     if (int rc = make_netl((int)B, net, &n)) return rc;
     hipStream_t s = ts::as_stream(stream);

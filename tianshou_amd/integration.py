@@ -13,6 +13,8 @@ state-independent sigma, ContinuousCritic); anything else raises at construction
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -23,6 +25,19 @@ from .ppo import PPOConfig, PPOEngine, flat_from_modules, flat_to_modules, TIANS
 def _algorithm_state_loaded(module, incompatible_keys) -> None:
     """load_state_dict post-hook of the Hip* algorithms (module level, so that the algorithm stays picklable)."""
     module._hip_invalidate()
+
+
+# Sub-modules of an algorithm with lazy write-back -> that algorithm.  `actor.state_dict()` / `torch.save(critic.state_dict())`
+# on a SUB-module reads torch parameters the engine may be ahead of; a state_dict pre-hook on every sub-module syncs first.
+# The hook is a module-level function (picklable by reference) and finds its owner through this process-local weak table, so
+# the modules carry no closure; in another process (an unpickled copy) the lookup misses and the hook is a no-op.
+_LAZY_OWNERS: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
+
+
+def _sync_owner_before_state_dict(module, prefix, keep_vars) -> None:
+    owner = _LAZY_OWNERS.get(id(module))
+    if owner is not None and not owner.__dict__.get("_hip_in_update", False):
+        owner.hip_sync()
 
 
 class _HipGlue:
@@ -155,6 +170,11 @@ class _HipGlue:
         if write_back not in ("auto", "lazy", "eager"):
             raise ValueError("write_back must be 'auto', 'lazy' or 'eager'")
         self.__dict__["_hip_lazy"] = write_back == "lazy" or (write_back == "auto" and attached)
+        if self.__dict__["_hip_lazy"]:
+            for m in self.modules():                      # (the algorithm's own state_dict() / hip_sync() are overridden)
+                if m is not self and id(m) not in _LAZY_OWNERS:
+                    _LAZY_OWNERS[id(m)] = self
+                    m.register_state_dict_pre_hook(_sync_owner_before_state_dict)
 
     def _hip_offpolicy_update(self, buffer, sample_size, Batch, TrainingStats=None):
         """`OffPolicyAlgorithm.update` -> `Algorithm._update` (algorithm_base.py:586-631, 893-903): the same steps in the same
@@ -345,10 +365,11 @@ def _on_policy_base(algo: str, ref=None):
     raise ValueError("algo must be 'ppo' or 'a2c'")
 
 
-def _trunk_spec(net, who: str):
+def _trunk_spec(net, who: str, norm: bool = False):
     """Net -> MLP -> Sequential(Linear, act, Linear, act, ...) (utils/net/common.py:90-178): -> (linear-layer key stems,
-    hidden sizes, activation name).  One activation class for all layers (nn.Tanh / nn.ReLU) or none; norm layers and other
-    activations are outside the engine's envelope."""
+    hidden sizes, activation name).  One activation class for all layers (nn.Tanh / nn.ReLU) or none; other activations are
+    outside the engine's envelope.  `norm=True` (the PPO / A2C hooks): MLP(norm_layer=nn.LayerNorm) -- Linear -> LayerNorm ->
+    activation in every hidden layer (common.py:25-39) -- is accepted as well, see `_trunk_norm`; elsewhere a norm layer raises."""
     try:
         seq = list(net.preprocess.model.model)
     except AttributeError as e:
@@ -366,9 +387,11 @@ def _trunk_spec(net, who: str):
             followed[-1] = True
         elif isinstance(m, torch.nn.Identity):
             pass
+        elif norm and isinstance(m, torch.nn.LayerNorm):
+            pass                                              # (position, shape and affine-ness are checked by _trunk_norm)
         else:
             raise NotImplementedError(f"HipPPO: {who} trunk contains {type(m).__name__}; Linear layers with nn.Tanh, nn.ReLU "
-                                      "or no activation are supported (no norm layers)")
+                                      "or no activation are supported (nn.LayerNorm under PPO / A2C only, no other norm layers)")
     if not stems or len(acts) > 1:
         raise NotImplementedError(f"HipPPO: {who} trunk needs at least one Linear layer and a single activation class")
     # The engines apply the activation after EVERY trunk layer.  A Net built with action_shape > 0 (MLP output_dim > 0,
@@ -382,14 +405,47 @@ def _trunk_spec(net, who: str):
     return stems, hidden, (acts.pop() if acts else "none")
 
 
+def _trunk_norm(net, who: str):
+    """-> None for a trunk without norm layers, else (key stems of the LayerNorm modules, one per Linear layer, eps): every
+    Linear layer is DIRECTLY followed by an nn.LayerNorm over its own width with an elementwise affine map (weight and bias) and
+    one eps for all of them -- what MLP(norm_layer=nn.LayerNorm[, norm_args]) builds (utils/net/common.py:25-39, 123-137)."""
+    seq = list(net.preprocess.model.model)
+    norms = [(i, m) for i, m in enumerate(seq) if isinstance(m, torch.nn.LayerNorm)]
+    if not norms:
+        return None
+    lin = [i for i, m in enumerate(seq) if isinstance(m, torch.nn.Linear)]
+    if [i for i, _ in norms] != [i + 1 for i in lin]:
+        raise NotImplementedError(f"HipPPO: {who} trunk: a LayerNorm must follow every Linear layer directly (Linear -> LayerNorm "
+                                  "-> activation), or none")
+    eps = {float(m.eps) for _, m in norms}
+    for (i, m), j in zip(norms, lin):
+        if tuple(m.normalized_shape) != (seq[j].out_features,) or m.weight is None or m.bias is None:
+            raise NotImplementedError(f"HipPPO: {who} trunk: LayerNorm must normalise the layer's width with weight and bias")
+    if len(eps) != 1:
+        raise NotImplementedError(f"HipPPO: {who} trunk: one eps for all LayerNorm modules")
+    return [f"preprocess.model.model.{i}" for i, _ in norms], eps.pop()
+
+
+def _ln_eps_of(hidden):
+    """The ("layer_norm", eps) tag of `_check_supported`'s "net" description -> eps, or None."""
+    for tag in hidden[3:] if isinstance(hidden, tuple) else ():
+        if isinstance(tag, tuple) and tag[0] == "layer_norm":
+            return float(tag[1])
+    return None
+
+
 def _net_keys(actor, critic):
     """state_dict keys of an actor / critic over Net trunks of any depth, in the engine's flat order:
-    actor trunk (w, b)*, mu (w, b), sigma_param | critic trunk (w, b)*, last (w, b)."""
-    sa, _, _ = _trunk_spec(actor, "actor")
-    sc, _, _ = _trunk_spec(critic, "critic")
-    ka = [f"{st}.{x}" for st in sa for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias"]
+    actor trunk (w, b[, gamma, beta])*, mu (w, b), sigma_param | critic trunk (w, b[, gamma, beta])*, last (w, b)."""
+    def trunk(net, who):
+        st, _, _ = _trunk_spec(net, who, norm=True)
+        nm = _trunk_norm(net, who)
+        if nm is None:
+            return [f"{x}.{y}" for x in st for y in ("weight", "bias")]
+        return [f"{x}.{y}" for a, b in zip(st, nm[0]) for x in (a, b) for y in ("weight", "bias")]
+    ka = trunk(actor, "actor") + ["mu.model.0.weight", "mu.model.0.bias"]
     ka += ["sigma.model.0.weight", "sigma.model.0.bias"] if getattr(actor, "_c_sigma", False) else ["sigma_param"]
-    kc = [f"{st}.{x}" for st in sc for x in ("weight", "bias")] + ["last.model.0.weight", "last.model.0.bias"]
+    kc = trunk(critic, "critic") + ["last.model.0.weight", "last.model.0.bias"]
     return ka, kc
 
 
@@ -399,8 +455,8 @@ def _check_supported(actor, critic):
     Humanoid's 376 / 17 / 256 x 256) on the implicit-GEMM layer kernels (tianshou_amd/ppo_wide.py); "net": every other trunk
     the reference's Net builds from `hidden_sizes` and one activation (1 .. 7 hidden layers of any widths up to 1024, nn.Tanh /
     nn.ReLU / none, actor and critic trunks may differ) on the same layer kernels (ppo_wide.NetPPOEngine) -- `hidden` is then
-    (actor hidden sizes, critic hidden sizes, activation[, "conditioned_sigma"]: the actor's sigma is a second linear head,
-    continuous.py:212-234)."""
+    (actor hidden sizes, critic hidden sizes, activation[, "conditioned_sigma"][, ("layer_norm", eps)]): the actor's sigma is
+    a second linear head (continuous.py:212-234); every hidden layer is Linear -> LayerNorm -> activation (common.py:25-39)."""
     ka, kc = _net_keys(actor, critic)
     sa, sc = actor.state_dict(), critic.state_dict()
     if set(sa.keys()) != set(ka):
@@ -415,18 +471,21 @@ def _check_supported(actor, critic):
     if bounded and not float(getattr(actor, "max_action", 1.0)) > 0.0:
         raise NotImplementedError("HipPPO: a bounded actor needs max_action > 0")
     c_sigma = bool(getattr(actor, "_c_sigma", False))
-    _, ha, act_a = _trunk_spec(actor, "actor")
-    _, hc, act_c = _trunk_spec(critic, "critic")
+    _, ha, act_a = _trunk_spec(actor, "actor", norm=True)
+    _, hc, act_c = _trunk_spec(critic, "critic", norm=True)
+    nm_a, nm_c = _trunk_norm(actor, "actor"), _trunk_norm(critic, "critic")
     obs_dim, act_dim = int(sa[ka[0]].shape[1]), int(sa["mu.model.0.weight"].shape[0])
     if int(sc[kc[0]].shape[1]) != obs_dim or act_a != act_c:
         raise NotImplementedError("HipPPO: actor and critic must read the same observation and use the same activation")
+    if (nm_a is None) != (nm_c is None) or (nm_a is not None and nm_a[1] != nm_c[1]):
+        raise NotImplementedError("HipPPO: actor and critic trunks must both have LayerNorm (one eps) or neither")
     if sa["mu.model.0.weight"].shape[1] != ha[-1] or tuple(sc["last.model.0.weight"].shape) != (1, hc[-1]):
         raise NotImplementedError("HipPPO: the heads must be single Linear layers on the trunks' outputs")
     if act_dim > (16 if c_sigma else 32):
         raise NotImplementedError("HipPPO: at most 32 actions (16 with conditioned_sigma)")
     if c_sigma and tuple(sa["sigma.model.0.weight"].shape) != (act_dim, ha[-1]):
         raise NotImplementedError("HipPPO: the sigma head must be a single Linear layer on the trunk's output")
-    if not c_sigma and act_a == "tanh" and ha == hc and len(ha) == 2 and ha[0] == ha[1]:
+    if nm_a is None and not c_sigma and act_a == "tanh" and ha == hc and len(ha) == 2 and ha[0] == ha[1]:
         hidden = ha[0]
         if hidden == 64 and obs_dim <= 31 and act_dim <= 8:
             return obs_dim, act_dim, hidden, "fused"
@@ -434,7 +493,8 @@ def _check_supported(actor, critic):
             return obs_dim, act_dim, hidden, "wide"
     if max(len(ha), len(hc)) > 7 or max(ha + hc) > 1024:
         raise NotImplementedError("HipPPO: trunks of up to 7 hidden layers of at most 1024 units")
-    return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a) + (("conditioned_sigma",) if c_sigma else ()), "net"
+    tags = (("conditioned_sigma",) if c_sigma else ()) + ((("layer_norm", nm_a[1]),) if nm_a is not None else ())
+    return obs_dim, act_dim, (tuple(ha), tuple(hc), act_a) + tags, "net"
 
 
 def _attach_gauss_policy(algorithm, policy_forward: str, sampling: str, noise_seed) -> None:
@@ -459,14 +519,17 @@ def _attach_gauss_policy(algorithm, policy_forward: str, sampling: str, noise_se
         from . import npg as NG
 
         HP.attach(algorithm.policy, "gauss_wide", algorithm, hidden=int(hidden), n_actor=int(NG.layout(obs_dim, hidden, act_dim)["actor_count"]), **kw)
-    elif len(hidden) == 3:                                   # "net" without conditioned sigma (that head keeps the torch forward)
+    elif "conditioned_sigma" not in hidden[3:]:              # "net" without conditioned sigma (that head keeps the torch forward)
         import ctypes as C
 
         from . import _lib
 
+        ln_eps = _ln_eps_of(hidden)
         out = (C.c_int64 * 3)()
-        _lib.check(_lib.load().ts_net_layout(C.byref(_lib.NetDesc.make(obs_dim, list(hidden[0]), hidden[2])), _lib.i64(act_dim), out))
-        HP.attach(algorithm.policy, "gauss_net", algorithm, hidden=tuple(hidden[0]), activation=hidden[2], n_actor=int(out[1]), **kw)
+        desc = _lib.NetDesc.make(obs_dim, list(hidden[0]), hidden[2], _lib.NetDesc.LAYERNORM if ln_eps is not None else 0, ln_eps=ln_eps or 0.0)
+        _lib.check(_lib.load().ts_net_layout(C.byref(desc), _lib.i64(act_dim), out))
+        HP.attach(algorithm.policy, "gauss_net", algorithm, hidden=tuple(hidden[0]), activation=hidden[2], n_actor=int(out[1]),
+                  ln_eps=ln_eps, **kw)
 
 
 def make_hip_ppo(algo: str = "ppo", ref=None):
@@ -559,11 +622,12 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
             if kind == "net":
                 from .ppo_wide import net_flat_from_tensors
 
-                cs = len(hidden) > 3
-                na = 2 * (len(hidden[0]) + 1) + (2 if cs else 1)
+                cs, ln = "conditioned_sigma" in hidden[3:], _ln_eps_of(hidden) is not None
+                na = (4 if ln else 2) * len(hidden[0]) + 2 + (2 if cs else 1)
                 return torch.cat([net_flat_from_tensors(list(tensors[:na]), obs_dim, list(hidden[0]), act_dim, self._hip_device,
-                                                        conditioned_sigma=cs),
-                                  net_flat_from_tensors(list(tensors[na:]), obs_dim, list(hidden[1]), None, self._hip_device)]).contiguous()
+                                                        conditioned_sigma=cs, layer_norm=ln),
+                                  net_flat_from_tensors(list(tensors[na:]), obs_dim, list(hidden[1]), None, self._hip_device,
+                                                        layer_norm=ln)]).contiguous()
             from .ppo_wide import flat_from_tensors
 
             return flat_from_tensors(list(tensors[:7]), list(tensors[7:]), obs_dim, hidden, act_dim, self._hip_device)
@@ -590,8 +654,10 @@ def make_hip_ppo(algo: str = "ppo", ref=None):
                 elif kind == "net":
                     from .ppo_wide import NetPPOEngine
 
+                    ln_eps = _ln_eps_of(hidden)
                     eng = NetPPOEngine(obs_dim, act_dim, hidden[0], hidden[1], hidden[2], flat, ppo_config_from(self),
-                                       conditioned_sigma=len(hidden) > 3)
+                                       conditioned_sigma="conditioned_sigma" in hidden[3:], layer_norm=ln_eps is not None,
+                                       ln_eps=ln_eps or 1e-5)
                 else:
                     from .ppo_wide import WidePPOEngine
 

@@ -200,7 +200,8 @@ def _gauss_params(policy):
             return NG.actor_flat_from_torch(t, spec["obs_dim"], spec["hidden"], spec["act_dim"], dev)
         from .ppo_wide import net_flat_from_tensors
 
-        return net_flat_from_tensors(t, spec["obs_dim"], list(spec["hidden"]), spec["act_dim"], dev)
+        return net_flat_from_tensors(t, spec["obs_dim"], list(spec["hidden"]), spec["act_dim"], dev,
+                                     layer_norm=spec.get("ln_eps") is not None)
     return policy._hip_cached([actor], build)
 
 
@@ -237,7 +238,9 @@ def _gauss_forward(policy, batch, state=None, **kwargs):
             _lib.check(lib.ts_npg_infer(ws.handle, _lib.ptr(actor_flat), None, _lib.i64(obs_dim), _lib.i64(spec["hidden"]), _lib.i64(a),
                                         _lib.ptr(obs), None, _lib.i64(n), None, None, _lib.ptr(mu), _lib.current_stream(dev)))
         else:
-            na = _lib.NetDesc.make(obs_dim, list(spec["hidden"]), spec["activation"], 0, max_action=spec.get("max_action") or 0.0)
+            ln_eps = spec.get("ln_eps")                  # MLP(norm_layer=nn.LayerNorm) trunks: TS_NET_LAYERNORM
+            na = _lib.NetDesc.make(obs_dim, list(spec["hidden"]), spec["activation"], _lib.NetDesc.LAYERNORM if ln_eps is not None else 0,
+                                   max_action=spec.get("max_action") or 0.0, ln_eps=ln_eps or 0.0)
             _lib.check(lib.ts_ppo_net_infer(ws.handle, _lib.ptr(actor_flat), None, C.byref(na), None, _lib.i64(a), _lib.ptr(obs), None,
                                             _lib.i64(n), None, None, _lib.ptr(mu), _lib.current_stream(dev)))
         log_sigma = actor_flat[n_actor - 32:n_actor - 32 + a].contiguous()       # the vector's last block: log_sigma padded to 32

@@ -186,25 +186,36 @@ CS_COL = 16          # conditioned sigma: the head block's columns [16, 16 + act
 
 
 def net_flat_from_tensors(t: list[torch.Tensor], obs_dim: int, hidden: list[int], n_out: int | None, device="cuda",
-                          conditioned_sigma: bool = False) -> torch.Tensor:
+                          conditioned_sigma: bool = False, layer_norm: bool = False) -> torch.Tensor:
     """nn.Linear-layout tensors [w1, b1, ..., w_L, b_L, w_head, b_head(, sigma_param)] -> the ts_net_layout vector: per layer
     one block [K_pad + 1, N_pad] (last row = bias; widths padded to 32 with zeros), the head padded to 32 columns, and for
     an actor (n_out = act_dim) log_sigma padded to 32.  conditioned_sigma: the tensors end with [..., w_mu, b_mu, w_sigma,
     b_sigma] instead (ContinuousActorProbabilistic(conditioned_sigma=True), continuous.py:212-218): the sigma head goes into
-    the head block's columns [16, 16 + act), the log_sigma block stays zero."""
+    the head block's columns [16, 16 + act), the log_sigma block stays zero.  layer_norm (MLP(norm_layer=nn.LayerNorm),
+    utils/net/common.py:25-39): every hidden layer brings four tensors [w, b, gamma, beta] (module order) and its block is
+    followed by gamma[N_pad] | beta[N_pad] (padding entries zero)."""
     nl = len(hidden)
+    per = 4 if layer_norm else 2
     dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
-    parts = [NG._block(t[2 * i], t[2 * i + 1], dims[i], dims[i + 1]) for i in range(nl)]
-    head = NG._block(t[2 * nl], t[2 * nl + 1], dims[nl], NG.HEAD).reshape(dims[nl] + 1, NG.HEAD)
+    parts = []
+    for i in range(nl):
+        parts.append(NG._block(t[per * i], t[per * i + 1], dims[i], dims[i + 1]))
+        if layer_norm:
+            gb = torch.zeros(2, dims[i + 1], dtype=torch.float32)
+            gb[0, : hidden[i]] = t[per * i + 2].detach().float().cpu().reshape(-1)
+            gb[1, : hidden[i]] = t[per * i + 3].detach().float().cpu().reshape(-1)
+            parts.append(gb.reshape(-1))
+    o = per * nl
+    head = NG._block(t[o], t[o + 1], dims[nl], NG.HEAD).reshape(dims[nl] + 1, NG.HEAD)
     ls = torch.zeros(NG.HEAD, dtype=torch.float32)
     if n_out is not None and conditioned_sigma:
         if n_out > CS_COL:
             raise NotImplementedError("conditioned_sigma: at most 16 actions")
-        w_s, b_s = t[2 * nl + 2].detach().float().cpu(), t[2 * nl + 3].detach().float().cpu()
+        w_s, b_s = t[o + 2].detach().float().cpu(), t[o + 3].detach().float().cpu()
         head[: w_s.shape[1], CS_COL:CS_COL + n_out] = w_s.t()
         head[dims[nl], CS_COL:CS_COL + n_out] = b_s
     elif n_out is not None:
-        ls[:n_out] = t[2 * nl + 2].detach().float().cpu().reshape(-1)
+        ls[:n_out] = t[o + 2].detach().float().cpu().reshape(-1)
     parts.append(head.reshape(-1))
     if n_out is not None:
         parts.append(ls)
@@ -212,7 +223,7 @@ def net_flat_from_tensors(t: list[torch.Tensor], obs_dim: int, hidden: list[int]
 
 
 def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_head: int, actor: bool,
-                        conditioned_sigma: bool = False) -> list[torch.Tensor]:
+                        conditioned_sigma: bool = False, layer_norm: bool = False) -> list[torch.Tensor]:
     """Inverse of net_flat_from_tensors (nn.Linear layout; n_head = act_dim for an actor, 1 for a critic)."""
     true = [obs_dim] + list(hidden) + [n_head]
     dims = [_pad32(obs_dim)] + [_pad32(h) for h in hidden] + [NG.HEAD]
@@ -224,6 +235,9 @@ def net_flat_to_tensors(flat: torch.Tensor, obs_dim: int, hidden: list[int], n_h
         if actor and conditioned_sigma and i == len(hidden):
             out += [blk[: true[i], CS_COL:CS_COL + n_head].t().contiguous(), blk[dims[i], CS_COL:CS_COL + n_head].clone()]
         off += n
+        if layer_norm and i < len(hidden):
+            out += [f[off: off + true[i + 1]].clone(), f[off + dims[i + 1]: off + dims[i + 1] + true[i + 1]].clone()]
+            off += 2 * dims[i + 1]
     if actor and not conditioned_sigma:
         out.append(f[off:off + NG.HEAD][:n_head].clone())
     return out
@@ -234,7 +248,7 @@ class NetPPOEngine(WidePPOEngine):
     hidden layers of any widths and a tanh / ReLU / no activation; actor and critic trunks may differ."""
 
     def __init__(self, obs_dim: int, act_dim: int, hidden_actor, hidden_critic, activation: str, flat_params: torch.Tensor,
-                 cfg: PPOConfig, conditioned_sigma: bool = False):
+                 cfg: PPOConfig, conditioned_sigma: bool = False, layer_norm: bool = False, ln_eps: float = 1e-5):
         if not flat_params.is_cuda:
             raise RuntimeError("NetPPOEngine needs its parameters on an MI355X; there is no CPU fallback")
         if not 1 <= act_dim <= (CS_COL if conditioned_sigma else 32):
@@ -244,9 +258,12 @@ class NetPPOEngine(WidePPOEngine):
         self.hidden = None
         self.conditioned_sigma = bool(conditioned_sigma)
         self.entropy_is_batch_sum = self.conditioned_sigma           # (DataParallelPPO: the entropy part is summed, not repeated)
+        self.layer_norm, self.ln_eps = bool(layer_norm), float(ln_eps)
+        ln = _lib.NetDesc.LAYERNORM if layer_norm else 0
         self._na = _lib.NetDesc.make(obs_dim, self.hidden_actor, activation,
-                                     _lib.NetDesc.CONDITIONED_SIGMA if conditioned_sigma else 0, max_action=cfg.max_action or 0.0)
-        self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation)
+                                     (_lib.NetDesc.CONDITIONED_SIGMA if conditioned_sigma else 0) | ln,
+                                     max_action=cfg.max_action or 0.0, ln_eps=ln_eps)
+        self._nc = _lib.NetDesc.make(obs_dim, self.hidden_critic, activation, ln, ln_eps=ln_eps)
         out = (C.c_int64 * 3)()
         _lib.check(_lib.load().ts_net_layout(C.byref(self._na), _lib.i64(act_dim), out))
         self.n_actor = int(out[1])
@@ -265,12 +282,14 @@ class NetPPOEngine(WidePPOEngine):
 
     def flat_from_tensors(self, actor_t, critic_t) -> torch.Tensor:
         return torch.cat([net_flat_from_tensors(actor_t, self.obs_dim, self.hidden_actor, self.act_dim, self.device,
-                                                conditioned_sigma=self.conditioned_sigma),
-                          net_flat_from_tensors(critic_t, self.obs_dim, self.hidden_critic, None, self.device)]).contiguous()
+                                                conditioned_sigma=self.conditioned_sigma, layer_norm=self.layer_norm),
+                          net_flat_from_tensors(critic_t, self.obs_dim, self.hidden_critic, None, self.device,
+                                                layer_norm=self.layer_norm)]).contiguous()
 
     def flat_to_tensors(self, flat: torch.Tensor):
-        return (net_flat_to_tensors(flat[: self.n_actor], self.obs_dim, self.hidden_actor, self.act_dim, True, self.conditioned_sigma),
-                net_flat_to_tensors(flat[self.n_actor:], self.obs_dim, self.hidden_critic, 1, False))
+        return (net_flat_to_tensors(flat[: self.n_actor], self.obs_dim, self.hidden_actor, self.act_dim, True, self.conditioned_sigma,
+                                    self.layer_norm),
+                net_flat_to_tensors(flat[self.n_actor:], self.obs_dim, self.hidden_critic, 1, False, layer_norm=self.layer_norm))
 
     def infer(self, obs, act=None, want_v=True):
         b = obs.shape[0]
