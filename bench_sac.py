@@ -139,10 +139,14 @@ def run(steps: int, warmup: int, slots: int = 1 << 21, with_cpu: bool = True) ->
 
     n_upd = [0]
 
+    two_calls = bool(os.environ.get("TS_SAC_TWO_CALLS"))         # A/B: the separate entry points of rounds 2-5
+
     def update():
         n_upd[0] += 1
         idx = buf.sample_indices(BATCH, seed=(0x5A7, n_upd[0]))   # manager.py:216-234: sub-buffer by length, uniform inside
-        noise = normal_noise((2, BATCH, ACT), 0x5AC, n_upd[0], dev)      # rsample() eps of a' ~ pi(s') and a ~ pi(s)
+        if not two_calls:     # one library call (ts_sac_learn_rows): rsample() eps of a' ~ pi(s') and a ~ pi(s) drawn inside the packing
+            return eng.learn_rows(buf, idx, noise_key=(0x5AC, n_upd[0]))[0]      # launch, target pass, 1-step return, update
+        noise = normal_noise((2, BATCH, ACT), 0x5AC, n_upd[0], dev)
         ret = eng.preprocess(buf, idx, noise[0])                  # n_step 1: gather + _target_q + 1-step return, one sequence
         stats, _ = eng.update_with_rows(buf, idx, ret, noise[1])  # the input packing reads the rows (TS_SAC_NO_ROWS=1: gathers)
         return stats

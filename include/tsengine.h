@@ -998,6 +998,26 @@ int ts_sac_update_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_st
                        const int64_t* rows, const float* returns, const float* weight, const float* noise, int64_t B,
                        int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out,
                        ts_stream_t stream);
+/* One call per SAC update with n_step = 1 (round 6): OffPolicyAlgorithm.update's _preprocess_batch -> _update_with_batch
+ * (algorithm_base.py:586-631; sac.py:281-336, ddpg.py:287-301, algorithm_base.py:785-817) = ts_sac_returns_rows(noise2[0]) followed
+ * by ts_sac_update_rows(noise2[1]) on the same rows, bit-identical to the two calls (tests/test_gpu_sac.py).  On the one-launch
+ * chains (Net[h, h] at the fused kernels' widths) three launches of the 22 go away: both input-packing passes (obs / act and
+ * obs_next of the sampled rows) and, with fill_noise != 0, the noise draw ts_normal_fill(noise2, 2 * B * act_dim, noise_seed,
+ * noise_offset) share ONE launch, and the 1-step return is formed inside the critic-loss launch from the lagged critics' outputs
+ * (no launch of its own).  Other trunks run the two sequences back to back.  noise2: float32[2, B, act_dim] (input, or output
+ * when fill_noise); returns_out: float32[B] (always written: what ts_sac_returns_rows returns); weight: nullable PER weights;
+ * weight_out: nullable (td1 + td2) / 2. */
+typedef struct ts_sac_replay {
+    const float* obs;             /* [slots, obs_dim] */
+    const float* act;             /* [slots, act_dim] */
+    const float* obs_next;        /* [slots, obs_dim] */
+    const double* rew;            /* [slots] */
+    const uint8_t* terminated;    /* [slots] */
+} ts_sac_replay;
+int ts_sac_learn_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const ts_sac_replay* replay,
+                      const int64_t* rows, const float* weight, float* noise2, int fill_noise, uint64_t noise_seed,
+                      uint64_t noise_offset, int64_t B, int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp, double gamma,
+                      float* returns_out, float* stats_out5, float* weight_out, ts_stream_t stream);
 
 /* One phase of ts_sac_update, for data-parallel replicas (tianshou_amd/distributed.py DataParallelSAC; the reference
  * has no distributed path): phase 1 = forward / loss / backward of both critics on the local batch,

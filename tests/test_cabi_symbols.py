@@ -135,7 +135,7 @@ def test_ctypes_structures_match_the_header_structs():
 
     mirrors = {"ts_ppo_hparams": _lib.PPOHParams, "ts_dqn_hparams": dqn.DQNHParams, "ts_distq_hparams": distq.DistQHParams,
                "ts_rows_replay": drqn.RowsReplay, "ts_npg_hparams": npg.NPGHParams, "ts_sac_hparams": sac.SACHParams,
-               "ts_sac_state": sac.SACStateC, "ts_redq_state": redq.REDQStateC, "ts_td3_hparams": td3.TD3HParams,
+               "ts_sac_state": sac.SACStateC, "ts_sac_replay": sac.SACReplayC, "ts_redq_state": redq.REDQStateC, "ts_td3_hparams": td3.TD3HParams,
                "ts_td3_state": td3.TD3StateC, "ts_net_desc": _lib.NetDesc, "ts_frame_replay": _lib.FrameReplay}
     text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
     sizes = {"double": 8, "float": 4, "int64_t": 8, "uint64_t": 8, "int32_t": 4, "int": 4, "uint8_t": 1}

@@ -492,6 +492,55 @@ def test_row_indexed_entry_points_are_bit_identical(auto, weighted):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("auto,weighted,hidden,activation,fill", [(True, True, 256, "relu", False), (False, False, 256, "relu", True),
+                                                                  (True, False, ((64, 48, 32), (40, 56, 24)), "relu", True), (True, True, 256, "tanh", False)])
+def test_one_call_update_is_bit_identical(auto, weighted, hidden, activation, fill):
+    """ts_sac_learn_rows (one call: both packing passes + the noise draw in one launch, the target pass, the 1-step return
+    formed inside the critic-loss launch, the update) == normal_noise + ts_sac_returns_rows + ts_sac_update_rows: noise, returns,
+    statistics, PER weights, every parameter vector, lagged critic and Adam moment bit for bit over four updates on a buffer with
+    terminations and repeated indices.  Net[256, 256] ReLU rides on the fused sequence; three hidden layers / a tanh trunk run the
+    two sequences back to back inside the call."""
+    from tianshou_amd.buffer import DeviceReplayBuffer, normal_noise
+
+    obs_dim, act_dim, B, slots, E = 23, 5, 300, 4096, 4
+    cfg = OS.SACConfig(auto_alpha=auto, log_alpha0=-0.2, alpha=0.15, target_entropy=-float(act_dim), actor_lr=3e-4,
+                       critic_lr=1e-3, alpha_lr=1e-3, tau=0.02, n_step=1)
+    g = torch.Generator().manual_seed(3)
+    T = slots // E
+    off = np.arange(E + 1, dtype=np.int64) * T
+    buf = DeviceReplayBuffer(offset=off, last_index=off[:-1] + T - 1, lengths=np.full(E, T, np.int64),
+                             insertion=np.zeros(E, np.int64), rew=torch.randn(slots, generator=g).double().numpy(),
+                             terminated=(torch.rand(slots, generator=g) < 0.1).numpy(), truncated=np.zeros(slots, bool),
+                             obs=torch.randn(slots, obs_dim, generator=g).numpy(), act=(torch.rand(slots, act_dim, generator=g) * 2 - 1).numpy(),
+                             obs_next=torch.randn(slots, obs_dim, generator=g).numpy())
+    names = ("actor", "critic1", "critic2", "critic1_old", "critic2_old", "actor_m", "actor_v", "critic1_m", "critic1_v", "critic2_m",
+             "critic2_v", "log_alpha")
+    out = {}
+    for mode in ("one", "two"):
+        eng, _ = make_engine(obs_dim, act_dim, 11, cfg, hidden=hidden, activation=activation)
+        gg = torch.Generator().manual_seed(5)
+        rec = []
+        for u in range(4):
+            idx = torch.randint(0, slots, (B,), generator=gg)
+            noise = torch.randn(2, B, act_dim, generator=gg)
+            w = torch.rand(B, generator=gg) if weighted else None
+            if mode == "one":
+                stats, w_out, ret, nz = eng.learn_rows(buf, idx, None if fill else noise, noise_key=(0x5AC, u) if fill else None, weight=w)
+            else:
+                nz = normal_noise((2, B, act_dim), 0x5AC, u) if fill else noise.cuda()
+                ret = eng.preprocess(buf, idx, nz[0])
+                stats, w_out = eng.update_with_rows(buf, idx, ret, nz[1], w)
+            rec.append((nz.cpu(), ret.cpu(), stats.cpu(), w_out.cpu()))
+        torch.cuda.synchronize()
+        assert eng.adam_step == 4
+        out[mode] = (rec, [getattr(eng, k).cpu().clone() for k in names])
+    for u, (a, b) in enumerate(zip(out["one"][0], out["two"][0])):
+        for what, x, y in zip(("noise", "returns", "stats", "weight"), a, b):
+            assert torch.equal(x, y), (u, what)
+    for k, a, b in zip(names, out["one"][1], out["two"][1]):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("n_step", [1, 3])
 def test_returns_without_a_stored_obs_next_read_obs_of_the_next_slot(n_step):
     """save_obs_next=False (buffer_base.py:622-626): batch.obs_next = obs[next(index)].  A buffer without the obs_next column

@@ -159,6 +159,34 @@ inline OptimDesc optim_from(const ts_ppo_hparams* hp) {
 int optim_step(hipStream_t s, const OptimDesc& o, float* params, float* m, float* v, const float* grad, int64_t n,
                int64_t step, double lr, double beta1, double beta2, double eps, double max_grad_norm, float* norm_scratch);
 
+// Counter-based normal noise (ts_normal_fill; rsample()'s eps): Philox-4x32-10 keyed by `seed`, counter = (element quad q,
+// stream offset), two Box-Muller pairs per counter -> z[0..3] = elements 4q .. 4q + 3 of the stream.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void normal4(int64_t q, uint64_t seed, uint64_t offset, float (&z)[4]) {
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        // u1 in (0, 1], u2 in [0, 1): 24 random bits each
+        const float u1 = ((float)(c[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+        const float u2 = (float)(c[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
+        const float rad = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        z[2 * p] = rad * cs;
+        z[2 * p + 1] = rad * sn;
+    }
+}
+
 // Brackets one kernel launch with a start/stop event pair when profiling is enabled.
 struct ProfScope {
     ts_workspace* ws;

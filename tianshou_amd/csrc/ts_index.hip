@@ -640,11 +640,8 @@ __global__ void random_permutation_kernel(int64_t* out, int64_t n, int half_bits
 // sac.py:228-236 draws one [B, act_dim] block per forward): counter-based Philox-4x32-10 (Salmon et al., SC'11) keyed by
 // `seed`, counter = (element quad, stream offset), two Box-Muller pairs per counter -> four floats per thread.  The same
 // (seed, offset) always gives the same numbers whatever the launch shape; not torch's generator stream.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
-}
+// (ts::philox_round / ts::normal4 live in ts_common.h: ts_sac_learn_rows' packing launch draws the same numbers)
+using ts::philox_round;
 
 // np.random.rand(n) of the engine's own stream: u[i] = uniform53(seed, counter, i, 0) (PrioritizedReplayBuffer.sample_indices,
 // prio.py:65, inside ts_dqn_learn_step)
@@ -658,25 +655,8 @@ __global__ __launch_bounds__(256) void uniform_fill_f64_kernel(double* __restric
 __global__ __launch_bounds__(256) void normal_fill_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (4 * q >= n) return;
-    uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
     float z[4];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        // u1 in (0, 1], u2 in [0, 1): 24 random bits each
-        const float u1 = ((float)(c[2 * p] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-        const float u2 = (float)(c[2 * p + 1] >> 8) * (1.0f / 16777216.0f);
-        const float rad = sqrtf(-2.0f * logf(u1));
-        float sn, cs;
-        sincosf(6.28318530717958647692f * u2, &sn, &cs);
-        z[2 * p] = rad * cs;
-        z[2 * p + 1] = rad * sn;
-    }
+    ts::normal4(q, seed, offset, z);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
         if (4 * q + e < n) out[4 * q + e] = z[e];

@@ -23,6 +23,11 @@ constexpr int MLP3_MAX_NETS = 8;
 int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const float* const* wb1, const float* const* wb2,
                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
                    ts_workspace* prof = nullptr);
+// ... each network on its OWN input rows xs[k] ([M, K1] each; ts_sac_learn_rows: the lagged critics on (s', a') beside the live
+// critics on (s, a)).  Per-row results do not depend on which networks share a launch.
+int mlp3_forward_nx(hipStream_t s, int nets, const float* const* xs, int M, int K1, const float* const* wb1, const float* const* wb2,
+                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
+                    ts_workspace* prof = nullptr);
 
 // The input gradients of the same chain in one launch: dh2 = (d_out W3^T) * (h2 > 0), dh1 = (dh2 W2^T) * (h1 > 0)
 // ([M, 256] each, consumed by the weight-gradient GEMMs), and dx[:, col0:col1) = dh1 W1^T for up to 128 input columns

@@ -65,7 +65,7 @@ __device__ unsigned long long g_mlp_trace[8][40];        // workgroup 0: per wav
 // blockIdx.y = network: networks of one shape on the same input (twin critics, the members of a REDQ ensemble) share a launch
 constexpr int MAXN = ts::MLP3_MAX_NETS;
 struct MlpArgs {
-    const float* x;
+    const float* x[MAXN];           // input rows per network (the same pointer for networks that share their input)
     const float* wb1[MAXN]; const float* wb2[MAXN]; const float* wb3[MAXN];
     float* h1[MAXN]; float* h2[MAXN]; float* out[MAXN];
     int M, K1;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void mlp3_fwd_kernel(MlpArgs a) {
     MMARK(0);
     {
         f32x4 xr[xr_count<TH, RB>()];
-        load_rows_issue<TH, RB>(a.x, a.K1, m0, a.M, tid, xr);
+        load_rows_issue<TH, RB>(a.x[net], a.K1, m0, a.M, tid, xr);
         w1.template prime<0, 2>(st);               // the first weights travel while the input rows do
         load_rows_commit<TH, RB>(a.K1, xs, xp, tid, xr);
     }
@@ -427,13 +427,22 @@ int allow_lds(K kernel) {
 int mlp3_forward_n(hipStream_t s, int nets, const float* x, int M, int K1, const float* const* wb1, const float* const* wb2,
                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
                    ts_workspace* prof) {
+    const float* xs[MLP3_MAX_NETS];
+    for (int k = 0; k < MLP3_MAX_NETS; ++k) xs[k] = x;
+    return mlp3_forward_nx(s, nets, xs, M, K1, wb1, wb2, wb3, head_cols, h1, h2, out, prof);
+}
+
+int mlp3_forward_nx(hipStream_t s, int nets, const float* const* xs, int M, int K1, const float* const* wb1, const float* const* wb2,
+                    const float* const* wb3, int head_cols, float* const* h1, float* const* h2, float* const* out,
+                    ts_workspace* prof) {
     TS_REQUIRE(mlp3_supported(K1, HID, head_cols), TS_ERR_UNSUPPORTED, "mlp3_forward: unsupported shape");
     TS_REQUIRE(nets >= 1 && nets <= MLP3_MAX_NETS, TS_ERR_INVALID_ARG, "mlp3_forward: 1 .. %d networks", MLP3_MAX_NETS);
-    TS_REQUIRE(M >= 1 && x, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+    TS_REQUIRE(M >= 1 && xs, TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
     MlpArgs a{};
-    a.x = x; a.M = M; a.K1 = K1;
+    a.M = M; a.K1 = K1;
     for (int k = 0; k < nets; ++k) {
-        TS_REQUIRE(wb1[k] && wb2[k] && wb3[k] && out[k], TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+        TS_REQUIRE(xs[k] && wb1[k] && wb2[k] && wb3[k] && out[k], TS_ERR_INVALID_ARG, "mlp3_forward: bad argument");
+        a.x[k] = xs[k];
         a.wb1[k] = wb1[k]; a.wb2[k] = wb2[k]; a.wb3[k] = wb3[k];
         a.h1[k] = h1 ? h1[k] : nullptr; a.h2[k] = h2 ? h2[k] : nullptr; a.out[k] = out[k];
     }

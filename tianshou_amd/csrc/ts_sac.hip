@@ -271,12 +271,11 @@ __device__ __forceinline__ void store_head_row(float* __restrict__ row, float v)
 // action columns are written by the policy kernel).  Four output columns per thread (ka, kc are multiples of 32).
 // `rows` (nullable): obs / act are whole replay-buffer columns and sample b is their row rows[b] -- the gather of
 // ReplayBuffer.__getitem__ (buffer_base.py:605-649) happens here instead of in launches of its own.
-__global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
-                                                       int64_t B, int obs_dim, int act_dim, int ka, int kc,
-                                                       float* __restrict__ x_a, float* __restrict__ x_c,
-                                                       float* __restrict__ x_p, const int64_t* __restrict__ rows = nullptr) {
+__device__ __forceinline__ void sac_pack_item(int64_t i, const float* __restrict__ obs, const float* __restrict__ act,
+                                              int64_t B, int obs_dim, int act_dim, int ka, int kc,
+                                              float* __restrict__ x_a, float* __restrict__ x_c,
+                                              float* __restrict__ x_p, const int64_t* __restrict__ rows) {
     using f32x4 = __attribute__((ext_vector_type(4))) float;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int w4 = (ka + kc) / 4;
     if (i >= B * w4) return;
     const int64_t b = i / w4;
@@ -314,19 +313,54 @@ __global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__
     }
 }
 
+__global__ __launch_bounds__(256) void sac_pack_kernel(const float* __restrict__ obs, const float* __restrict__ act,
+                                                       int64_t B, int obs_dim, int act_dim, int ka, int kc,
+                                                       float* __restrict__ x_a, float* __restrict__ x_c,
+                                                       float* __restrict__ x_p, const int64_t* __restrict__ rows = nullptr) {
+    sac_pack_item((int64_t)blockIdx.x * 256 + threadIdx.x, obs, act, B, obs_dim, act_dim, ka, kc, x_a, x_c, x_p, rows);
+}
+
+// ts_sac_learn_rows: both packing passes of an update -- [obs | act] of the sampled rows for the critics / the actor, and
+// obs_next of the same rows for the target pass -- and (nullable) the update's rsample() noise in ONE launch: blocks
+// [0, pack_blocks) pack (obs, act) -> x_a, x_c, x_p (the observation columns again: the policy's action goes there while x_c
+// still holds the buffer's); [pack_blocks, 2 pack_blocks) pack obs_next -> xn_a, xn_c (action columns left to the policy
+// kernel, padding zero); the remaining blocks are ts_normal_fill(noise, noise_n, seed, offset).
+struct Pack2Args {
+    const float* obs; const float* act; const float* obs_next; const int64_t* rows;
+    int64_t B; int obs_dim, act_dim, ka, kc;
+    float* x_a; float* x_c; float* x_p; float* xn_a; float* xn_c;
+    unsigned pack_blocks;
+    float* noise; int64_t noise_n; uint64_t seed, offset;
+};
+__global__ __launch_bounds__(256) void sac_pack2_kernel(Pack2Args a) {
+    const unsigned blk = blockIdx.x;
+    if (blk < a.pack_blocks) {
+        sac_pack_item((int64_t)blk * 256 + threadIdx.x, a.obs, a.act, a.B, a.obs_dim, a.act_dim, a.ka, a.kc, a.x_a, a.x_c, a.x_p, a.rows);
+    } else if (blk < 2 * a.pack_blocks) {
+        sac_pack_item((int64_t)(blk - a.pack_blocks) * 256 + threadIdx.x, a.obs_next, nullptr, a.B, a.obs_dim, a.act_dim, a.ka, a.kc,
+                      a.xn_a, a.xn_c, nullptr, a.rows);
+    } else {
+        const int64_t q = (int64_t)(blk - 2 * a.pack_blocks) * 256 + threadIdx.x;
+        if (4 * q >= a.noise_n) return;
+        float z[4];
+        ts::normal4(q, a.seed, a.offset, z);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < a.noise_n) a.noise[4 * q + e] = z[e];
+    }
+}
+
 // SACPolicy.forward after the actor MLP (sac.py:114-123): one thread per sample.
 // head[b] = [mu (A) .. | raw log-sigma (A) at column 32 ..].  Writes the squashed action into x_c's action
 // columns (nullable), act_out (nullable), logp_out; `keep` (nullable, [B, 3A]) stores {a - mu, sigma, squashed}
 // for the backward pass.
-__global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
-                                                         int64_t B, int A, int head_cols, int obs_dim, int kc, float bound,
-                                                         float* __restrict__ x_c, float* __restrict__ act_out,
-                                                         float* __restrict__ logp_out, float* __restrict__ keep,
-                                                         float* __restrict__ mu_out = nullptr,
-                                                         float* __restrict__ sigma_out = nullptr) {
+__device__ __forceinline__ void sac_policy_item(int64_t t, const float* __restrict__ head, const float* __restrict__ noise,
+                                                int64_t B, int A, int head_cols, int obs_dim, int kc, float bound,
+                                                float* __restrict__ x_c, float* __restrict__ act_out,
+                                                float* __restrict__ logp_out, float* __restrict__ keep,
+                                                float* __restrict__ mu_out, float* __restrict__ sigma_out) {
     // half a wavefront per sample, lane j = action dimension j (A <= 32); the two sums over j are butterfly
     // reductions inside the half-wave (fixed order)
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t b = t >> 5;
     const int j = (int)(t & 31);
     float lp = 0.f, corr = 0.f;
@@ -355,11 +389,41 @@ __global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict
     }
     if (b < B && j == 0) logp_out[b] = lp - corr;
 }
+__global__ __launch_bounds__(256) void sac_policy_kernel(const float* __restrict__ head, const float* __restrict__ noise,
+                                                         int64_t B, int A, int head_cols, int obs_dim, int kc, float bound,
+                                                         float* __restrict__ x_c, float* __restrict__ act_out,
+                                                         float* __restrict__ logp_out, float* __restrict__ keep,
+                                                         float* __restrict__ mu_out = nullptr,
+                                                         float* __restrict__ sigma_out = nullptr) {
+    sac_policy_item((int64_t)blockIdx.x * 256 + threadIdx.x, head, noise, B, A, head_cols, obs_dim, kc, bound, x_c, act_out, logp_out,
+                    keep, mu_out, sigma_out);
+}
+// ts_sac_learn_rows: the actor ran ONCE on [obs_next rows | obs rows] (its parameters do not change between the target pass and
+// the actor pass of one update); blocks [0, nb) are the target pass's policy step (a' into xn_c, log pi(a'|s')), blocks
+// [nb, 2 nb) the actor pass's (a into x_p, log pi(a|s), `keep` for the backward pass).  Workgroups never straddle the halves.
+struct Policy2Args {
+    const float* head; const float* noise_next; const float* noise; int64_t B; int A, obs_dim, kc; float bound; unsigned nb;
+    float* xn_c; float* logp_n; float* x_p; float* logp; float* keep;
+};
+__global__ __launch_bounds__(256) void sac_policy2_kernel(Policy2Args a) {
+    if (blockIdx.x < a.nb)
+        sac_policy_item((int64_t)blockIdx.x * 256 + threadIdx.x, a.head, a.noise_next, a.B, a.A, 64, a.obs_dim, a.kc, a.bound, a.xn_c,
+                        nullptr, a.logp_n, nullptr, nullptr, nullptr);
+    else
+        sac_policy_item((int64_t)(blockIdx.x - a.nb) * 256 + threadIdx.x, a.head + a.B * 64, a.noise, a.B, a.A, 64, a.obs_dim, a.kc,
+                        a.bound, a.x_p, nullptr, a.logp, a.keep, nullptr, nullptr);
+}
 
 // SAC._target_q_compute_value: min(Q1_old, Q2_old) - alpha * log_prob  (q arrays are [B, 32], column 0)
 // `rew` (nullable): also the 1-step return of compute_nstep_return (algorithm_base.py:785-817 with n_step = 1, in
 // ts_returns.hip nstep_fused_kernel's arithmetic: the value mask multiplies in float32, gamma and the reward add in float64):
 // out[b] = float(double(tq * mask) * gamma + rew[rows[b]]), mask = !terminated[rows[b]].
+__device__ __forceinline__ float sac_target_value(float q1, float q2, float alpha, float logp) { return fminf(q1, q2) - alpha * logp; }
+__device__ __forceinline__ float sac_one_step_return(float tq, uint8_t terminated, double gamma, double rew) {
+    const float tqm = tq * (terminated ? 0.f : 1.f);
+    const double q = (double)tqm * gamma;
+    return (float)(q + rew);
+}
 __global__ __launch_bounds__(256) void sac_target_kernel(const float* __restrict__ q1, const float* __restrict__ q2,
                                                          const float* __restrict__ logp, const float* __restrict__ log_alpha,
                                                          float fixed_alpha, int64_t B, float* __restrict__ out,
@@ -369,12 +433,10 @@ __global__ __launch_bounds__(256) void sac_target_kernel(const float* __restrict
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const float alpha = log_alpha ? expf(*log_alpha) : fixed_alpha;
-    const float tq = fminf(q1[b * 32], q2[b * 32]) - alpha * logp[b];
+    const float tq = sac_target_value(q1[b * 32], q2[b * 32], alpha, logp[b]);
     if (!rew) { out[b] = tq; return; }
     const int64_t r = rows ? rows[b] : b;
-    const float tqm = tq * (terminated[r] ? 0.f : 1.f);
-    const double q = (double)tqm * gamma;
-    out[b] = (float)(q + rew[r]);
+    out[b] = sac_one_step_return(tq, terminated[r], gamma, rew[r]);
 }
 
 // block-wide deterministic sum (1024 threads): butterfly inside each wavefront, then the 16 wave sums
@@ -487,6 +549,10 @@ __device__ float block_sum_256(float v, float* red4) {
 struct CriticLossArgs {
     const float* q[2]; float* td[2]; float* d_out[2]; float* part[2];
     const float* ret; const float* weight; int64_t B;
+    // ts_sac_learn_rows (rew != NULL): the 1-step return is formed here from the lagged critics' outputs instead of being read
+    // -- sac_target_kernel's arithmetic (the same device functions); critic 0's blocks also write it to ret_out (nullable)
+    const float* tq[2]; const float* logp_n; const float* log_alpha; float fixed_alpha;
+    const double* rew; const uint8_t* terminated; const int64_t* rows; double gamma; float* ret_out;
 };
 __global__ __launch_bounds__(256) void sac_critic_loss_mb_kernel(CriticLossArgs a) {
     __shared__ float red[4];
@@ -495,7 +561,14 @@ __global__ __launch_bounds__(256) void sac_critic_loss_mb_kernel(CriticLossArgs 
     const float inv_b = 1.f / (float)a.B;
     float ls = 0.f;
     if (b < a.B) {
-        const float t = a.q[k][b * 32] - a.ret[b];
+        float ret;
+        if (a.rew) {
+            const float alpha = a.log_alpha ? expf(*a.log_alpha) : a.fixed_alpha;
+            const int64_t r = a.rows[b];
+            ret = sac_one_step_return(sac_target_value(a.tq[0][b * 32], a.tq[1][b * 32], alpha, a.logp_n[b]), a.terminated[r], a.gamma, a.rew[r]);
+            if (k == 0 && a.ret_out) a.ret_out[b] = ret;
+        } else ret = a.ret[b];
+        const float t = a.q[k][b * 32] - ret;
         const float w = a.weight ? a.weight[b] : 1.f;
         a.td[k][b] = t;
         ls = t * t * w;
@@ -1287,15 +1360,24 @@ namespace {
 // inputs, TD errors, policy intermediates and log-probabilities between the calls).
 enum : int { PH_CRITIC_GRAD = 1, PH_CRITIC_APPLY = 2, PH_ACTOR_GRAD = 4, PH_ACTOR_APPLY = 8, PH_ALL = 15 };
 
+// ts_sac_learn_rows: the target pass of SAC._target_q / compute_nstep_return (n_step = 1) in front of the update, in the same
+// launch sequence.  `returns` of sac_update_impl is then ignored (the critic-loss launch forms the return itself).
+struct LearnExt {
+    const float* obs_next; const double* rew; const uint8_t* terminated; double gamma;
+    const float* noise_next;                                  // rsample() eps of a' ~ pi(s')
+    float* noise_fill; int64_t noise_n; uint64_t seed, offset; // nullable: the packing launch draws ts_normal_fill(noise_fill, ...) first
+    float* returns_out;                                       // nullable
+};
+
 // `grads`: all phases in one call -> optional output [critic1 | critic2 | actor] (ts_sac_update's grads_out);
 // single phases -> the exchange buffer: critic phases [critic1 | critic2], actor phases [actor | -mean(log_prob)].
 int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,
                     const float* returns, const float* weight, const float* noise, int64_t B, int64_t obs_dim,
                     int64_t act_dim, const ts_sac_hparams* hp, float* stats_out5, float* weight_out, float* grads,
-                    int phases, ts_stream_t stream, const int64_t* rows = nullptr) {
+                    int phases, ts_stream_t stream, const int64_t* rows = nullptr, const LearnExt* ext = nullptr) {
     float* const grads_out = phases == PH_ALL ? grads : nullptr;
     TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_update: workspace is NULL");
-    TS_REQUIRE(st && hp && obs && act && returns && noise && stats_out5 && B >= 1 && adam_step >= 1,
+    TS_REQUIRE(st && hp && obs && act && (returns || ext) && noise && stats_out5 && B >= 1 && adam_step >= 1,
                TS_ERR_INVALID_ARG, "ts_sac_update: bad argument");
     TS_REQUIRE(st->actor && st->critic1 && st->critic2 && st->critic1_old && st->critic2_old && st->actor_m &&
                    st->actor_v && st->critic1_m && st->critic1_v && st->critic2_m && st->critic2_v,
@@ -1314,13 +1396,23 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     const size_t spl = std::max(split_floats(ma), split_floats(mc));
     bytes += 2 * al(4 * spl) + 2 * hbytes(B, d) + al(4 * slab) + al(4 * pc) + 2 * al(4 * B * 32) +
              al(4 * 3 * ts::ceil_div(B, 256));
+    if (ext) bytes += al(4 * B * d.ka) + al(4 * B * d.kc) + 2 * al(4 * B * 32) + al(4 * B) + 2 * hbytes(B, d) + al(4 * B * 64);
     if (int rc = ts::ws_reserve(ws, bytes)) return rc;
     Carve c{static_cast<char*>(ws->base)};
-    float* x_a = c.take<float>(B * d.ka);
+    // (ext: the actor's two forward passes of an update -- on obs_next for the target, on obs for its own loss -- see the same
+    // parameters, so they are ONE launch over [obs_next rows | obs rows]; x_a / aa are the second halves)
+    float* x_a2 = c.take<float>((ext ? 2 : 1) * B * d.ka);
+    float* x_a = ext ? x_a2 + B * d.ka : x_a2;
     float* x_c = c.take<float>(B * d.kc);          // [obs | buffer action]
     float* x_p = c.take<float>(B * d.kc);          // [obs | policy action]
     float* dx1 = c.take<float>(B * d.kc);
-    const Act aa = take_act(c, B, 64, d.hid, d.depth), a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
+    const Act aa_all = take_act(c, ext ? 2 * B : B, 64, d.hid, d.depth);
+    Act aa = aa_all;
+    if (ext) {
+        for (int i = 0; i < d.depth; ++i) aa.h[i] += B * d.hid;
+        aa.out += B * 64;
+    }
+    const Act a1 = take_act(c, B, 32, d.hid, d.depth), a2 = take_act(c, B, 32, d.hid, d.depth);
     // upstream gradients of the head outputs: the loss kernels write the live columns, the zero padding of all five
     // comes from ONE memset at the start of the update
     float* zeroed = c.take<float>(B * 192);
@@ -1342,6 +1434,11 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     float* split = c.take<float>(spl);
     const unsigned gb = (unsigned)ts::ceil_div(B, 256);
     float* loss_part = c.take<float>(3 * (size_t)gb);      // {actor, critic1, critic2} x gb partial sums
+    float* xn_a = x_a2; float* xn_c = nullptr; float* tq_out[2] = {nullptr, nullptr}; float* logp_n = nullptr;
+    if (ext) {                                             // the target pass's inputs and results
+        xn_c = c.take<float>(B * d.kc);
+        tq_out[0] = c.take<float>(B * 32); tq_out[1] = c.take<float>(B * 32); logp_n = c.take<float>(B);
+    }
     const float* log_alpha = hp->auto_alpha ? st->log_alpha : nullptr;
     float* g_out[3] = {grads_out, grads_out ? grads_out + pc : nullptr, grads_out ? grads_out + 2 * pc : nullptr};
 
@@ -1354,8 +1451,38 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     if (int rc = twin_stream(ws, s, mc, &side)) return rc;
     // one stream: every reader of [obs | buffer action] (the critics' passes) is done before the policy kernel writes the
     // policy's action, so the actor pass reuses x_c instead of a second packed copy of the observations
-    if (side == s) x_p = x_c;
-    if (phases & PH_CRITIC_GRAD) {
+    if (side == s && !ext) x_p = x_c;
+    if (ext) {
+        // one stream, one-launch chains (the caller checked): packing of both passes + the noise in one launch, then the target
+        // pass -- actor on obs_next, a' and its log-probability, the two lagged critics in one launch; their outputs wait in
+        // tq_out for the critic-loss launch
+        TS_REQUIRE(side == s && phases == PH_ALL && rows, TS_ERR_UNSUPPORTED, "ts_sac_learn_rows: fused path needs one stream");
+        Pack2Args pk{};
+        pk.obs = obs; pk.act = act; pk.obs_next = ext->obs_next; pk.rows = rows; pk.B = B; pk.obs_dim = d.obs; pk.act_dim = d.act;
+        pk.ka = d.ka; pk.kc = d.kc; pk.x_a = x_a; pk.x_c = x_c; pk.x_p = x_p; pk.xn_a = xn_a; pk.xn_c = xn_c;
+        pk.pack_blocks = (unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256);
+        pk.noise = ext->noise_fill; pk.noise_n = ext->noise_fill ? ext->noise_n : 0; pk.seed = ext->seed; pk.offset = ext->offset;
+        const unsigned nz = (unsigned)ts::ceil_div(ts::ceil_div(pk.noise_n, 4), 256);
+        hipLaunchKernelGGL(sac_pack2_kernel, dim3(2 * pk.pack_blocks + nz), dim3(256), 0, s, pk);
+        const Mlp ma2 = make_mlp((int)(2 * B), d.ka, 64, d.hid, d.depth, d.fn);
+        if (int rc = mlp_forward(s, ws, ma2, st->actor, x_a2, aa_all, split)) return rc;
+        Policy2Args pa{};
+        pa.head = aa_all.out; pa.noise_next = ext->noise_next; pa.noise = noise; pa.B = B; pa.A = d.act; pa.obs_dim = d.obs; pa.kc = d.kc;
+        pa.bound = d.bound; pa.nb = (unsigned)ts::ceil_div(B * 32, 256);
+        pa.xn_c = xn_c; pa.logp_n = logp_n; pa.x_p = x_p; pa.logp = logp; pa.keep = keep;
+        hipLaunchKernelGGL(sac_policy2_kernel, dim3(2 * pa.nb), dim3(256), 0, s, pa);
+        TS_LAUNCH_CHECK();
+        // the lagged critics on (s', a') and the live critics on (s, a) in ONE launch of four networks (the lagged pair keeps no
+        // hidden activations)
+        const float* xs4[4] = {xn_c, xn_c, x_c, x_c};
+        const float* w1[4]; const float* w2[4]; const float* w3[4];
+        const float* p4[4] = {st->critic1_old, st->critic2_old, st->critic1, st->critic2};
+        for (int k = 0; k < 4; ++k) { w1[k] = p4[k] + mc.off[0]; w2[k] = p4[k] + mc.off[1]; w3[k] = p4[k] + mc.off[2]; }
+        float* h1[4] = {nullptr, nullptr, a1.h[0], a2.h[0]};
+        float* h2[4] = {nullptr, nullptr, a1.h[1], a2.h[1]};
+        float* o4[4] = {tq_out[0], tq_out[1], a1.out, a2.out};
+        if (int rc = ts::mlp3_forward_nx(s, 4, xs4, mc.l[0].B, mc.l[0].IC, w1, w2, w3, mc.l[2].OC, h1, h2, o4, ws)) return rc;
+    } else if (phases & PH_CRITIC_GRAD) {
         hipLaunchKernelGGL(sac_pack_kernel, dim3((unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256)), dim3(256), 0, s, obs, act,
                            B, d.obs, d.act, d.ka, d.kc, x_a, x_c, x_p == x_c ? (float*)nullptr : x_p, rows);
         // (`zeroed`: every kernel that fills a head-gradient buffer writes whole rows, padding columns included)
@@ -1386,11 +1513,16 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
             la.part[k] = loss_part + (1 + k0 + k) * gb;
         }
         la.ret = returns; la.weight = weight; la.B = B;
+        if (ext) {
+            la.tq[0] = tq_out[0]; la.tq[1] = tq_out[1]; la.logp_n = logp_n; la.log_alpha = log_alpha; la.fixed_alpha = (float)hp->alpha;
+            la.rew = ext->rew; la.terminated = ext->terminated; la.rows = rows; la.gamma = ext->gamma; la.ret_out = ext->returns_out;
+        }
         hipLaunchKernelGGL(sac_critic_loss_mb_kernel, dim3(gb, (unsigned)nk), dim3(256), 0, sk, la);
     };
     if ((phases & PH_CRITIC_GRAD) && twin_group) {
         const float* dh2[2] = {dheads[0], dheads[1]};
-        if (int rc = mlp_forward_twin(s, ws, mc, crit, x_c, acts, splits)) return rc;
+        if (!ext)            // (ext: part of the four-network launch above)
+            if (int rc = mlp_forward_twin(s, ws, mc, crit, x_c, acts, splits)) return rc;
         critic_loss(s, 0, 2);
         TS_LAUNCH_CHECK();
         if (int rc = mlp_backward_twin(s, ws, mc, crit, x_c, acts, dh2, nullptr, 0, 0, scs)) return rc;
@@ -1440,9 +1572,11 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
     // actor (sac.py:308-315): a ~ pi(s) with the supplied noise, Q1(s, a), Q2(s, a) with the UPDATED critics
     float* ga = g_out[2] ? g_out[2] : grad;
     if (phases & PH_ACTOR_GRAD) {
-        if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
-        hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B,
-                           d.act, 64, d.obs, d.kc, d.bound, x_p, (float*)nullptr, logp, keep);
+        if (!ext) {          // (ext: done in front of the target pass, in the same two launches)
+            if (int rc = mlp_forward(s, ws, ma, st->actor, x_a, aa, split)) return rc;
+            hipLaunchKernelGGL(sac_policy_kernel, dim3((unsigned)ts::ceil_div(B * 32, 256)), dim3(256), 0, s, aa.out, noise, B,
+                               d.act, 64, d.obs, d.kc, d.bound, x_p, (float*)nullptr, logp, keep);
+        }
         const Act a12[2] = {a1, a2};
         if (side == s) {                                                      // one stream: both critics in one launch
             if (int rc = mlp_forward_twin(s, ws, mc, crit, x_p, a12, splits)) return rc;
@@ -1529,6 +1663,44 @@ int ts_sac_update_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_st
     TS_REQUIRE(rows != nullptr, TS_ERR_INVALID_ARG, "ts_sac_update_rows: rows is NULL");
     return sac_update_impl(ws, st, adam_step, obs_buf, act_buf, returns, weight, noise, B, obs_dim, act_dim, hp, stats_out5,
                            weight_out, nullptr, PH_ALL, stream, rows);
+}
+
+int ts_sac_learn_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const ts_sac_replay* replay,
+                      const int64_t* rows, const float* weight, float* noise2, int fill_noise, uint64_t noise_seed,
+                      uint64_t noise_offset, int64_t B, int64_t obs_dim, int64_t act_dim, const ts_sac_hparams* hp, double gamma,
+                      float* returns_out, float* stats_out5, float* weight_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr, TS_ERR_WORKSPACE, "ts_sac_learn_rows: workspace is NULL");
+    TS_REQUIRE(st && hp && replay && replay->obs && replay->act && replay->obs_next && replay->rew && replay->terminated && rows &&
+                   noise2 && returns_out && stats_out5 && B >= 1 && adam_step >= 1,
+               TS_ERR_INVALID_ARG, "ts_sac_learn_rows: bad argument");
+    TS_REQUIRE(st->actor && st->critic1_old && st->critic2_old && (!hp->auto_alpha || st->log_alpha), TS_ERR_INVALID_ARG,
+               "ts_sac_learn_rows: NULL state pointer");
+    Dims d;
+    if (int rc = make_dims(ws, obs_dim, act_dim, &d)) return rc;
+    const Mlp mc = make_mlp((int)B, d.kc, 32, d.hid, d.depth, d.fn), ma = make_mlp((int)B, d.ka, 64, d.hid, d.depth, d.fn);
+    float* noise_next = noise2;
+    float* noise_upd = noise2 + B * act_dim;
+    // the fused sequence rides on the one-stream, one-launch chains; every other trunk (depth, tanh, widths outside the fused
+    // kernels, TS_TWIN_STREAMS) runs the same two entry points one after the other -- same results, no launch saved
+    static const bool twin_streams = getenv("TS_TWIN_STREAMS") != nullptr, unfused = getenv("TS_SAC_LEARN_UNFUSED") != nullptr;
+    const bool fused = !unfused && !twin_streams && mc.three() && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC) &&
+                       fused_backward(mc, false, 0, 0) && ma.three() && ts::mlp3_supported(ma.l[0].IC, ma.l[0].OC, ma.l[2].OC);
+    if (!fused) {
+        if (fill_noise)
+            if (int rc = ts_normal_fill(noise2, 2 * B * act_dim, noise_seed, noise_offset, stream)) return rc;
+        if (int rc = sac_target_impl(ws, st->actor, st->critic1_old, st->critic2_old, hp->auto_alpha ? st->log_alpha : nullptr, hp->alpha,
+                                     replay->obs_next, noise_next, B, obs_dim, act_dim, returns_out, stream, rows, replay->rew,
+                                     replay->terminated, gamma))
+            return rc;
+        return sac_update_impl(ws, st, adam_step, replay->obs, replay->act, returns_out, weight, noise_upd, B, obs_dim, act_dim, hp,
+                               stats_out5, weight_out, nullptr, PH_ALL, stream, rows);
+    }
+    LearnExt ext{};
+    ext.obs_next = replay->obs_next; ext.rew = replay->rew; ext.terminated = replay->terminated; ext.gamma = gamma;
+    ext.noise_next = noise_next; ext.noise_fill = fill_noise ? noise2 : nullptr; ext.noise_n = 2 * B * act_dim;
+    ext.seed = noise_seed; ext.offset = noise_offset; ext.returns_out = returns_out;
+    return sac_update_impl(ws, st, adam_step, replay->obs, replay->act, nullptr, weight, noise_upd, B, obs_dim, act_dim, hp, stats_out5,
+                           weight_out, nullptr, PH_ALL, stream, rows, &ext);
 }
 
 int ts_sac_update_phase(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step, const float* obs, const float* act,

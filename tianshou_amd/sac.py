@@ -49,6 +49,12 @@ class SACStateC(C.Structure):
         "critic1_old", "critic2_old", "log_alpha", "log_alpha_m", "log_alpha_v")]
 
 
+class SACReplayC(C.Structure):
+    """struct ts_sac_replay (include/tsengine.h): the replay buffer's columns as ts_sac_learn_rows reads them."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "act", "obs_next", "rew", "terminated")]
+
+
 def trunk_keys(depth: int, heads: tuple[str, ...]) -> list[str]:
     """state_dict keys of Net(hidden_sizes=[...] * depth) (Sequential(Linear, ReLU, ...): the Linears sit at even positions,
     utils/net/common.py:90-178) under an actor / critic with the given single-Linear heads."""
@@ -360,6 +366,38 @@ class SACEngine:
             _lib.ptr(returns), _lib.ptr(weight), _lib.ptr(noise), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
             C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.current_stream(self.device)))
         return stats, w_out
+
+    def learn_rows(self, buffer: DeviceReplayBuffer, indices, noise=None, noise_key=None, weight=None, lr_scale: float = 1.0):
+        """`preprocess(buffer, indices, noise[0])` + `update_with_rows(buffer, indices, returns, noise[1])` as ONE library call
+        (ts_sac_learn_rows; n_step = 1): -> (stats float32[5], weight float32[B], returns float32[B], noise float32[2, B, act]),
+        bit-identical to the two calls.  `noise`: float32[2, B, act_dim], or None with `noise_key = (seed, offset)`: the engine
+        draws `normal_noise((2, B, act_dim), seed, offset)` inside its first launch.  On the one-launch chains the call saves three
+        of the update's 22 launches (one packing pass, the noise draw, the return kernel)."""
+        if self.cfg.n_step != 1 or not self._rows_ok(buffer):
+            raise NotImplementedError("learn_rows: n_step = 1 on float32 replay columns (use preprocess + update_with_rows)")
+        idx = _i64_dev(indices, self.device).reshape(-1).contiguous()
+        b = idx.numel()
+        if noise is None:
+            if noise_key is None:
+                raise ValueError("learn_rows: pass noise or noise_key=(seed, offset)")
+            noise2 = torch.empty((2, b, self.act_dim), dtype=torch.float32, device=self.device)
+            fill, seed, off = 1, int(noise_key[0]) & (2**64 - 1), int(noise_key[1]) & (2**64 - 1)
+        else:
+            noise2, fill, seed, off = self._f32(noise, (2, b, self.act_dim)), 0, 0, 0
+        weight = None if weight is None else self._f32(weight, (b,))
+        self.adam_step += 1
+        stats = torch.empty(5, dtype=torch.float32, device=self.device)
+        w_out = torch.empty(b, dtype=torch.float32, device=self.device)
+        ret = torch.empty(b, dtype=torch.float32, device=self.device)
+        st, hp = self._state_c(), self.cfg.to_c(lr_scale)
+        rp = SACReplayC(buffer.obs.data_ptr(), buffer.act.data_ptr(), buffer.obs_next.data_ptr(), buffer.rew.data_ptr(),
+                        buffer.terminated.data_ptr())
+        use_hidden(self._ws, self.hidden, self.depth, self.max_action, self.activation)
+        _lib.check(_lib.load().ts_sac_learn_rows(
+            self._ws.handle, C.byref(st), _lib.i64(self.adam_step), C.byref(rp), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(noise2),
+            C.c_int(fill), C.c_uint64(seed), C.c_uint64(off), _lib.i64(b), _lib.i64(self.obs_dim), _lib.i64(self.act_dim),
+            C.byref(hp), _lib.f64(self.cfg.gamma), _lib.ptr(ret), _lib.ptr(stats), _lib.ptr(w_out), _lib.current_stream(self.device)))
+        return stats, w_out, ret, noise2
 
     # -- the same update in four phases (data-parallel replicas all-reduce between "grad" and "apply") -----------
     PHASE_CRITIC_GRAD, PHASE_CRITIC_APPLY, PHASE_ACTOR_GRAD, PHASE_ACTOR_APPLY = 1, 2, 4, 8
