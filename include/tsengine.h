@@ -1002,8 +1002,9 @@ int ts_sac_update_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_st
  * (algorithm_base.py:586-631; sac.py:281-336, ddpg.py:287-301, algorithm_base.py:785-817) = ts_sac_returns_rows(noise2[0]) followed
  * by ts_sac_update_rows(noise2[1]) on the same rows, bit-identical to the two calls (tests/test_gpu_sac.py).  On the one-launch
  * chains (Net[h, h] at the fused kernels' widths) three launches of the 22 go away: both input-packing passes (obs / act and
- * obs_next of the sampled rows) and, with fill_noise != 0, the noise draw ts_normal_fill(noise2, 2 * B * act_dim, noise_seed,
- * noise_offset) share ONE launch, and the 1-step return is formed inside the critic-loss launch from the lagged critics' outputs
+ * obs_next of the sampled rows) and, with fill_noise != 0, the noise draw -- fill_noise = 1: ts_normal_fill(noise2, 2 * B * act_dim,
+ * noise_seed, noise_offset); fill_noise = 2: the two halves as draws of their own, ts_normal_fill(noise2[h], B * act_dim,
+ * noise_seed, noise_offset + h) -- share ONE launch, and the 1-step return is formed inside the critic-loss launch from the lagged critics' outputs
  * (no launch of its own).  Other trunks run the two sequences back to back.  noise2: float32[2, B, act_dim] (input, or output
  * when fill_noise); returns_out: float32[B] (always written: what ts_sac_returns_rows returns); weight: nullable PER weights;
  * weight_out: nullable (td1 + td2) / 2. */

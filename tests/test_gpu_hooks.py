@@ -1256,6 +1256,55 @@ def test_hip_ddpg_hooks_against_oracle():
     assert float(st_a["step"]) == 4.0 and float(st_c["step"]) == 4.0
 
 
+@pytest.mark.parametrize("prio", [False, True])
+def test_hip_sac_update_as_one_library_call_equals_the_two_hook_calls(monkeypatch, prio):
+    """HipSAC.update() with its defaults (index-only sampling, the engine's rsample noise): `_preprocess_batch` defers the
+    target pass and `_update_with_batch` makes ONE call (ts_sac_learn_rows) -- against the same algorithm with the two
+    entry points kept apart (TS_SAC_TWO_CALLS=1): identical statistics every update, identical returns on the batch,
+    identical priorities written to a prioritized buffer, identical torch state after hip_sync()."""
+    from tianshou_amd.integration import make_hip_sac
+
+    obs_dim, act_dim, E, B = 23, 5, 4, 96
+    HipSAC = make_hip_sac(ref=SI)
+
+    def build():
+        torch.manual_seed(11)
+        actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, [256, 256], nn.ReLU), act_dim, unbounded=True, conditioned_sigma=True)
+        c1 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+        c2 = SI.ContinuousCritic(SI.Net(obs_dim + act_dim, [256, 256], nn.ReLU))
+        algo = HipSAC(policy=SI.Policy(actor), critic=c1, critic2=c2, lr=1e-3, tau=0.01, gamma=0.97,
+                      alpha=SI.AutoAlpha(-float(act_dim), -0.5, 3e-4), device="cuda", noise_seed=77).to("cuda")
+        algo.policy.is_within_training_step = True
+        return algo
+
+    def make_buf():
+        if prio:
+            return SI.PrioritizedVectorReplayBuffer(E * 200, E, alpha=0.6, beta=0.4, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=4)
+        return SI.VectorReplayBuffer(E * 200, E, obs_shape=(obs_dim,), act_shape=(act_dim,), seed=4)
+
+    flat = lambda algo: torch.cat([p.detach().reshape(-1).float().cpu() for p in algo.parameters()])  # noqa: E731
+    runs = {}
+    for mode in ("one", "two"):
+        if mode == "two":
+            monkeypatch.setenv("TS_SAC_TWO_CALLS", "1")
+        algo, buf, r = build(), make_buf(), np.random.default_rng(9)
+        calls = []
+        orig = algo._engine().learn_rows
+        algo._hip_engine.learn_rows = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        out = []
+        for u in range(4):
+            _fill(buf, 30 if u == 0 else 7, obs_dim, act_dim, r)
+            st = algo.update(buf, B)
+            out.append([getattr(st, f) for f in ("actor_loss", "critic1_loss", "critic2_loss", "alpha", "alpha_loss")])
+        assert len(calls) == (4 if mode == "one" else 0)
+        algo.hip_sync()
+        runs[mode] = (out, flat(algo), (np.array(buf.prio), len(buf.weight_updates)) if prio else None)
+    assert runs["one"][0] == runs["two"][0]
+    assert torch.equal(runs["one"][1], runs["two"][1])
+    if prio:
+        assert np.array_equal(runs["one"][2][0], runs["two"][2][0]) and runs["one"][2][1] == runs["two"][2][1] == 4
+
+
 @pytest.mark.parametrize("tag", ["relu3", "linear4", "csigma", "ln_relu3"])
 def test_hip_ppo_hooks_on_deep_trunks_replay_the_reference(tag):
     """Net trunks outside [h, h] tanh (three ReLU layers of unequal widths with a different critic trunk; four linear layers):

@@ -330,7 +330,7 @@ struct Pack2Args {
     int64_t B; int obs_dim, act_dim, ka, kc;
     float* x_a; float* x_c; float* x_p; float* xn_a; float* xn_c;
     unsigned pack_blocks;
-    float* noise; int64_t noise_n; uint64_t seed, offset;
+    float* noise; int64_t noise_n; uint64_t seed, offset; int noise_halves;
 };
 __global__ __launch_bounds__(256) void sac_pack2_kernel(Pack2Args a) {
     const unsigned blk = blockIdx.x;
@@ -340,13 +340,20 @@ __global__ __launch_bounds__(256) void sac_pack2_kernel(Pack2Args a) {
         sac_pack_item((int64_t)(blk - a.pack_blocks) * 256 + threadIdx.x, a.obs_next, nullptr, a.B, a.obs_dim, a.act_dim, a.ka, a.kc,
                       a.xn_a, a.xn_c, nullptr, a.rows);
     } else {
-        const int64_t q = (int64_t)(blk - 2 * a.pack_blocks) * 256 + threadIdx.x;
+        // noise_halves = 1: ONE stream of noise_n elements at `offset`; 2: the two halves of `noise` are streams of their own at
+        // offset and offset + 1 (noise_n elements each: two ts_normal_fill calls with consecutive counters, as the hooks draw)
+        unsigned nb = blk - 2 * a.pack_blocks;
+        const unsigned per = (unsigned)((((a.noise_n + 3) >> 2) + 255) >> 8);
+        const unsigned half = nb >= per ? 1u : 0u;
+        nb -= half * per;
+        const int64_t q = (int64_t)nb * 256 + threadIdx.x;
         if (4 * q >= a.noise_n) return;
         float z[4];
-        ts::normal4(q, a.seed, a.offset, z);
+        ts::normal4(q, a.seed, a.offset + half, z);
+        float* out = a.noise + (int64_t)half * a.noise_n;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (4 * q + e < a.noise_n) a.noise[4 * q + e] = z[e];
+            if (4 * q + e < a.noise_n) out[4 * q + e] = z[e];
     }
 }
 
@@ -1366,6 +1373,7 @@ struct LearnExt {
     const float* obs_next; const double* rew; const uint8_t* terminated; double gamma;
     const float* noise_next;                                  // rsample() eps of a' ~ pi(s')
     float* noise_fill; int64_t noise_n; uint64_t seed, offset; // nullable: the packing launch draws ts_normal_fill(noise_fill, ...) first
+    int noise_halves;                                         // 1: one stream of noise_n; 2: two streams of noise_n each (offset, offset + 1)
     float* returns_out;                                       // nullable
 };
 
@@ -1462,7 +1470,8 @@ int sac_update_impl(ts_workspace* ws, const ts_sac_state* st, int64_t adam_step,
         pk.ka = d.ka; pk.kc = d.kc; pk.x_a = x_a; pk.x_c = x_c; pk.x_p = x_p; pk.xn_a = xn_a; pk.xn_c = xn_c;
         pk.pack_blocks = (unsigned)ts::ceil_div(B * (d.ka + d.kc) / 4, 256);
         pk.noise = ext->noise_fill; pk.noise_n = ext->noise_fill ? ext->noise_n : 0; pk.seed = ext->seed; pk.offset = ext->offset;
-        const unsigned nz = (unsigned)ts::ceil_div(ts::ceil_div(pk.noise_n, 4), 256);
+        pk.noise_halves = ext->noise_halves;
+        const unsigned nz = (unsigned)ts::ceil_div(ts::ceil_div(pk.noise_n, 4), 256) * (unsigned)ext->noise_halves;
         hipLaunchKernelGGL(sac_pack2_kernel, dim3(2 * pk.pack_blocks + nz), dim3(256), 0, s, pk);
         const Mlp ma2 = make_mlp((int)(2 * B), d.ka, 64, d.hid, d.depth, d.fn);
         if (int rc = mlp_forward(s, ws, ma2, st->actor, x_a2, aa_all, split)) return rc;
@@ -1673,6 +1682,7 @@ int ts_sac_learn_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_ste
     TS_REQUIRE(st && hp && replay && replay->obs && replay->act && replay->obs_next && replay->rew && replay->terminated && rows &&
                    noise2 && returns_out && stats_out5 && B >= 1 && adam_step >= 1,
                TS_ERR_INVALID_ARG, "ts_sac_learn_rows: bad argument");
+    TS_REQUIRE(fill_noise >= 0 && fill_noise <= 2, TS_ERR_INVALID_ARG, "ts_sac_learn_rows: fill_noise must be 0, 1 or 2");
     TS_REQUIRE(st->actor && st->critic1_old && st->critic2_old && (!hp->auto_alpha || st->log_alpha), TS_ERR_INVALID_ARG,
                "ts_sac_learn_rows: NULL state pointer");
     Dims d;
@@ -1686,8 +1696,12 @@ int ts_sac_learn_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_ste
     const bool fused = !unfused && !twin_streams && mc.three() && ts::mlp3_supported(mc.l[0].IC, mc.l[0].OC, mc.l[2].OC) &&
                        fused_backward(mc, false, 0, 0) && ma.three() && ts::mlp3_supported(ma.l[0].IC, ma.l[0].OC, ma.l[2].OC);
     if (!fused) {
-        if (fill_noise)
+        if (fill_noise == 1)
             if (int rc = ts_normal_fill(noise2, 2 * B * act_dim, noise_seed, noise_offset, stream)) return rc;
+        if (fill_noise == 2) {
+            if (int rc = ts_normal_fill(noise2, B * act_dim, noise_seed, noise_offset, stream)) return rc;
+            if (int rc = ts_normal_fill(noise2 + B * act_dim, B * act_dim, noise_seed, noise_offset + 1, stream)) return rc;
+        }
         if (int rc = sac_target_impl(ws, st->actor, st->critic1_old, st->critic2_old, hp->auto_alpha ? st->log_alpha : nullptr, hp->alpha,
                                      replay->obs_next, noise_next, B, obs_dim, act_dim, returns_out, stream, rows, replay->rew,
                                      replay->terminated, gamma))
@@ -1697,7 +1711,8 @@ int ts_sac_learn_rows(ts_workspace* ws, const ts_sac_state* st, int64_t adam_ste
     }
     LearnExt ext{};
     ext.obs_next = replay->obs_next; ext.rew = replay->rew; ext.terminated = replay->terminated; ext.gamma = gamma;
-    ext.noise_next = noise_next; ext.noise_fill = fill_noise ? noise2 : nullptr; ext.noise_n = 2 * B * act_dim;
+    ext.noise_next = noise_next; ext.noise_fill = fill_noise ? noise2 : nullptr;
+    ext.noise_halves = fill_noise == 2 ? 2 : 1; ext.noise_n = (fill_noise == 2 ? 1 : 2) * B * act_dim;
     ext.seed = noise_seed; ext.offset = noise_offset; ext.returns_out = returns_out;
     return sac_update_impl(ws, st, adam_step, replay->obs, replay->act, nullptr, weight, noise_upd, B, obs_dim, act_dim, hp, stats_out5,
                            weight_out, nullptr, PH_ALL, stream, rows, &ext);

@@ -13,6 +13,7 @@ state-independent sigma, ContinuousCritic); anything else raises at construction
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import numpy as np
@@ -195,7 +196,11 @@ class _HipGlue:
         if hasattr(buffer, "get_weight"):
             w = buffer.get_weight(indices)
             batch.weight = w / np.max(w) if getattr(buffer, "_weight_norm", True) else w
-        batch = self._preprocess_batch(batch, buffer, indices)
+        self.__dict__["_hip_own_sequence"] = True        # (HipSAC: preprocess + update of an n_step = 1 batch become one library call)
+        try:
+            batch = self._preprocess_batch(batch, buffer, indices)
+        finally:
+            self.__dict__["_hip_own_sequence"] = False
         # torch_train_mode (torch_utils.py:14-22) is `train(True)` ... `train(was_training)` around the update; the engine reads
         # no module flag, so only the second call is observable: every sub-module ends in the algorithm's mode.  `train()` walks
         # ~60 modules through `Module.__setattr__` (0.24 ms); reading their flags costs 5 us and is almost always enough
@@ -1725,9 +1730,18 @@ def make_hip_sac(ref=None):
             eng = self._engine()
             m = _mirror(self, buffer, self._hip_device)
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            self._hip_idx = idx
+            # Inside HipSAC.update()'s own sequence (`_hip_offpolicy_update`: nobody reads the batch between the two hooks) an
+            # n_step = 1 update with the engine's noise is ONE library call, made by `_update_with_batch` (ts_sac_learn_rows: the
+            # target pass in front of the update, 16 launches instead of 22); `batch.returns` is attached there.  Called on its own
+            # (the reference's `_update`, `host_batch=True`, "torch" noise, data parallel) the hook computes the returns here.
+            self.__dict__["_hip_deferred"] = (self.__dict__.get("_hip_own_sequence", False) and self._hip_update_noise == "device"
+                                              and not self._hip_dp_on and eng.cfg.n_step == 1 and eng._rows_ok(m)
+                                              and not os.environ.get("TS_SAC_TWO_CALLS"))
+            if self.__dict__["_hip_deferred"]:
+                return batch
             noise = self._hip_rsample_noise(len(indices), eng.act_dim)      # Normal.rsample of the target policy call
             batch.returns = eng.preprocess(m, idx, noise).reshape(-1, 1)
-            self._hip_idx = idx
             return batch
 
         def _update_with_batch(self, batch):
@@ -1736,13 +1750,23 @@ def make_hip_sac(ref=None):
 
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
-            noise = self._hip_rsample_noise(int(self._hip_idx.numel()), eng.act_dim)
             runner = eng
-            if self._hip_dp_on:
-                from .distributed import DataParallelSAC
+            deferred = self.__dict__.pop("_hip_deferred", False)
+            if deferred:
+                # the two rsample() draws keep their call numbers (target: c + 1, update: c + 2)
+                key, c = self._hip_noise_key ^ 0x5AC, self._hip_noise_calls
+                self._hip_noise_calls += 2
+                stats, w, ret, _ = eng.learn_rows(m, self._hip_idx, noise_key=(key, c + 1), weight=weight, noise_streams=2)
+                batch.returns = ret.reshape(-1, 1)
+            else:
+                noise = self._hip_rsample_noise(int(self._hip_idx.numel()), eng.act_dim)
+                if self._hip_dp_on:
+                    from .distributed import DataParallelSAC
 
-                runner = self._hip_dp(DataParallelSAC, eng)
-            if runner is eng and hasattr(eng, "update_with_rows"):               # the input packing reads the mirror's rows
+                    runner = self._hip_dp(DataParallelSAC, eng)
+            if deferred:
+                pass
+            elif runner is eng and hasattr(eng, "update_with_rows"):             # the input packing reads the mirror's rows
                 stats, w = eng.update_with_rows(m, self._hip_idx, batch.returns.reshape(-1), noise, weight)
             else:
                 stats, w = runner.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),

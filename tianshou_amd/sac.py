@@ -367,11 +367,13 @@ class SACEngine:
             C.byref(hp), _lib.ptr(stats), _lib.ptr(w_out), _lib.current_stream(self.device)))
         return stats, w_out
 
-    def learn_rows(self, buffer: DeviceReplayBuffer, indices, noise=None, noise_key=None, weight=None, lr_scale: float = 1.0):
+    def learn_rows(self, buffer: DeviceReplayBuffer, indices, noise=None, noise_key=None, weight=None, lr_scale: float = 1.0,
+                   noise_streams: int = 1):
         """`preprocess(buffer, indices, noise[0])` + `update_with_rows(buffer, indices, returns, noise[1])` as ONE library call
         (ts_sac_learn_rows; n_step = 1): -> (stats float32[5], weight float32[B], returns float32[B], noise float32[2, B, act]),
         bit-identical to the two calls.  `noise`: float32[2, B, act_dim], or None with `noise_key = (seed, offset)`: the engine
-        draws `normal_noise((2, B, act_dim), seed, offset)` inside its first launch.  On the one-launch chains the call saves three
+        draws `normal_noise((2, B, act_dim), seed, offset)` inside its first launch (`noise_streams=2`: the two halves as
+        `normal_noise((B, act_dim), seed, offset)` and `(..., offset + 1)`, the hooks' two consecutive draws).  On the one-launch chains the call saves three
         of the update's 22 launches (one packing pass, the noise draw, the return kernel)."""
         if self.cfg.n_step != 1 or not self._rows_ok(buffer):
             raise NotImplementedError("learn_rows: n_step = 1 on float32 replay columns (use preprocess + update_with_rows)")
@@ -381,7 +383,7 @@ class SACEngine:
             if noise_key is None:
                 raise ValueError("learn_rows: pass noise or noise_key=(seed, offset)")
             noise2 = torch.empty((2, b, self.act_dim), dtype=torch.float32, device=self.device)
-            fill, seed, off = 1, int(noise_key[0]) & (2**64 - 1), int(noise_key[1]) & (2**64 - 1)
+            fill, seed, off = (2 if noise_streams == 2 else 1), int(noise_key[0]) & (2**64 - 1), int(noise_key[1]) & (2**64 - 1)
         else:
             noise2, fill, seed, off = self._f32(noise, (2, b, self.act_dim)), 0, 0, 0
         weight = None if weight is None else self._f32(weight, (b,))
