@@ -608,7 +608,7 @@ def hook_level(device, updates=3, permutations="device"):
 def other_workloads(with_cpu: bool = True):
     """Short runs of the C3 / C5 / Atari-shape PPO / NPG / TRPO rows so that they are measured by the same driver command."""
     out = {}
-    for name, mod, args in (("dqn", "bench_dqn", (30, 10)), ("sac", "bench_sac", (30, 10)), ("ppo_atari", "bench_ppo_cnn", (1, 1))):
+    for name, mod, args in (("dqn", "bench_dqn", (150, 30)), ("sac", "bench_sac", (300, 50)), ("ppo_atari", "bench_ppo_cnn", (1, 1))):
         try:
             import importlib
 
