@@ -1070,7 +1070,7 @@ def gen_npg_all() -> None:
 
 def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch_size: int, repeat: int, seed: int,
                   n_updates: int, lr: float = 1e-3, hidden=(64, 64), activation=nn.Tanh, max_action: float | None = None,
-                  optim: tuple[str, dict] | None = None, **kwargs) -> None:
+                  optim: tuple[str, dict] | None = None, norm_args: dict | None = None, layer_norm: bool = False, **kwargs) -> None:
     """Runs the reference Reinforce.update() (actor of examples/mujoco/mujoco_reinforce.py:84-103) on synthetic rollouts.
     Round 6: `hidden` / `activation` = any Net trunk (utils/net/common.py:90-178), `max_action` = the bounded (default) actor,
     `optim` = ("rmsprop" | "adam", factory kwargs) -- the fixtures of the per-layer engine path (keys `a{i}_0 / a{i}_{u}`)."""
@@ -1080,8 +1080,9 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
     torch.manual_seed(seed)
     N = E * T
     hidden = list(hidden)
-    generic = hidden != [64, 64] or activation is not nn.Tanh or max_action is not None or optim is not None
-    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden, activation=activation)
+    generic = hidden != [64, 64] or activation is not nn.Tanh or max_action is not None or optim is not None or layer_norm
+    nkw = dict(norm_layer=nn.LayerNorm, norm_args=norm_args) if layer_norm else {}        # common.py:25-39 (round 6)
+    net_a = Net(state_shape=(obs_dim,), hidden_sizes=hidden, activation=activation, **nkw)
     if max_action is None:
         actor = ContinuousActorProbabilistic(preprocess_net=net_a, action_shape=(act_dim,), unbounded=True)
     else:
@@ -1091,6 +1092,9 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
         if isinstance(m, nn.Linear):
             nn.init.orthogonal_(m.weight, gain=np.sqrt(2))
             nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.uniform_(m.weight, 0.5, 1.5)
+            nn.init.normal_(m.bias, std=0.2)
     for m in actor.mu.modules():
         if isinstance(m, nn.Linear):
             m.weight.data.copy_(0.3 * m.weight.data)
@@ -1121,6 +1125,8 @@ def gen_reinforce(tag: str, *, E: int, T: int, obs_dim: int, act_dim: int, batch
     if generic:
         out["hidden"], out["activation"] = np.array(hidden), np.array({nn.Tanh: 0, nn.ReLU: 1, None: 2}[activation])
         out["max_action"], out["keys"] = np.array(float(max_action or 0.0)), np.array(keys)
+        if layer_norm:
+            out["ln_eps"] = np.array(float((norm_args or {}).get("eps", 1e-5)))
         for i, k in enumerate(keys):
             out[f"a{i}_0"] = actor.state_dict()[k].numpy().copy()
     perms, seqs, rets = [], [], []
@@ -1199,6 +1205,12 @@ def gen_reinforce_net() -> None:
                   optim=("rmsprop", dict(eps=1e-5, alpha=0.99)), lr=7e-4)
     gen_reinforce("net_tanh1", E=3, T=40, obs_dim=20, act_dim=5, batch_size=None, repeat=1, seed=56, n_updates=2, gamma=0.99,
                   return_standardization=False, hidden=(200,), activation=nn.Tanh, optim=("adam", dict(weight_decay=1e-2)), lr=1e-3)
+
+
+def gen_reinforce_layernorm() -> None:
+    """Round 6: Reinforce over Net(norm_layer=nn.LayerNorm) (common.py:25-39): two ReLU layers with LayerNorm(eps=1e-4), Adam."""
+    gen_reinforce("net_ln_relu2", E=4, T=48, obs_dim=11, act_dim=3, batch_size=64, repeat=2, seed=57, n_updates=2, gamma=0.97,
+                  return_standardization=True, hidden=(72, 40), activation=nn.ReLU, layer_norm=True, norm_args=dict(eps=1e-4), lr=7e-4)
 
 
 def gen_reinforce_all() -> None:
@@ -1480,6 +1492,9 @@ def main() -> None:
         return
     if len(sys.argv) > 1 and sys.argv[1] == "reinforce_net":
         gen_reinforce_net()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "reinforce_layernorm":
+        gen_reinforce_layernorm()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "reinforce":
         gen_reinforce_all()

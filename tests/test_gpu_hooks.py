@@ -1810,7 +1810,7 @@ def test_hip_td3_ddpg_hooks_replay_the_reference(tag, monkeypatch):
 
 
 
-@pytest.mark.parametrize("tag", ["net_relu3", "net_tanh1"])
+@pytest.mark.parametrize("tag", ["net_relu3", "net_tanh1", "net_ln_relu2"])
 def test_hip_reinforce_hooks_on_generic_trunks_replay_the_reference(tag):
     """Round 6 (VERDICT r5 Missing #3, Reinforce): HipReinforce on actors outside Net[h, h] tanh -- a three-layer ReLU trunk
     under the reference's default BOUNDED actor (max_action 1.5) with RMSprop and return standardisation; one wide tanh layer
@@ -1829,8 +1829,10 @@ def test_hip_reinforce_hooks_on_generic_trunks_replay_the_reference(tag):
     hidden = [int(h) for h in g["hidden"]]
     act_cls = {0: nn.Tanh, 1: nn.ReLU, 2: None}[int(g["activation"])]
     max_action = float(g["max_action"])
-    seed = {"net_relu3": 55, "net_tanh1": 56}[tag]
-    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, hidden, act_cls), act_dim, unbounded=max_action == 0, max_action=max_action or 1.0)
+    seed = {"net_relu3": 55, "net_tanh1": 56, "net_ln_relu2": 57}[tag]
+    nkw = dict(norm_layer=nn.LayerNorm, norm_args=dict(eps=float(g["ln_eps"]))) if "ln_eps" in g.files else {}   # common.py:25-39
+    actor = SI.ContinuousActorProbabilistic(SI.Net(obs_dim, hidden, act_cls, **nkw), act_dim, unbounded=max_action == 0,
+                                            max_action=max_action or 1.0)
     keys = [str(k) for k in g["keys"]]
     assert sorted(keys) == sorted(actor.state_dict().keys())
     actor.load_state_dict({k: torch.from_numpy(g[f"a{i}_0"]) for i, k in enumerate(keys)})

@@ -1531,8 +1531,11 @@ def test_reinforce_subclass_keeps_signatures_and_fails_loudly():
     assert build(AdamOptimizerFactory(lr=1e-3), unbounded=True)._hip_kind == "net"
     with pytest.raises(NotImplementedError):
         build(AdamOptimizerFactory(lr=1e-3), unbounded=True, conditioned_sigma=True)
+    ln = build(AdamOptimizerFactory(lr=1e-3), net_kw=dict(norm_layer=torch.nn.LayerNorm, norm_args=dict(eps=1e-4)), unbounded=True)
+    assert ln._hip_kind == "net" and ln._hip_ln == 1e-4 and ln._hip_keys[:4] == [                 # LayerNorm trunks (round 6)
+        "preprocess.model.model.0.weight", "preprocess.model.model.0.bias", "preprocess.model.model.1.weight", "preprocess.model.model.1.bias"]
     with pytest.raises(NotImplementedError):
-        build(AdamOptimizerFactory(lr=1e-3), net_kw=dict(norm_layer=torch.nn.LayerNorm), unbounded=True)
+        build(AdamOptimizerFactory(lr=1e-3), net_kw=dict(norm_layer=torch.nn.BatchNorm1d), unbounded=True)
 
 
 def test_hip_reinforce_wrapper_runs_with_engine_double(monkeypatch):

@@ -969,26 +969,31 @@ def make_hip_reinforce(ref=None):
             examples/mujoco/mujoco_reinforce.py -- runs on the fused step kernel / the Net[h, h] GEMM path as before; every
             other `Net(hidden_sizes=[...], activation=Tanh | ReLU | None)` trunk, the reference's default bounded actor
             (max_action * tanh), Adam with weight decay and RMSprop (optim.py:89-140) take the per-layer engine
-            (`reinforce.NetReinforceEngine`, round 6).  conditioned_sigma and norm layers raise."""
+            (`reinforce.NetReinforceEngine`, round 6), and so do `Net(norm_layer=nn.LayerNorm)` trunks (common.py:25-39).
+            conditioned_sigma and other norm layers raise."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
             actor = self.policy.actor
             sa = actor.state_dict()
             if getattr(actor, "_c_sigma", True):
                 raise NotImplementedError(f"{who}: the actor needs a state-independent sigma_param (no conditioned sigma)")
-            stems, hidden_sizes, act_name = _trunk_spec(actor, "actor")              # (raises for anything but Linear + Tanh / ReLU)
-            self._hip_keys = [f"{st}.{x}" for st in stems for x in ("weight", "bias")] + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
+            stems, hidden_sizes, act_name = _trunk_spec(actor, "actor", norm=True)   # (raises for anything but Linear + Tanh / ReLU)
+            nm = _trunk_norm(actor, "actor")                                         # MLP(norm_layer=nn.LayerNorm): per-layer engine
+            trunk_keys = ([f"{st}.{x}" for st in stems for x in ("weight", "bias")] if nm is None else
+                          [f"{x}.{y}" for a, b in zip(stems, nm[0]) for x in (a, b) for y in ("weight", "bias")])
+            self._hip_keys = trunk_keys + ["mu.model.0.weight", "mu.model.0.bias", "sigma_param"]
             if set(sa.keys()) != set(self._hip_keys) or sa["mu.model.0.weight"].shape[1] != hidden_sizes[-1]:
                 raise NotImplementedError(f"{who}: the actor must be ContinuousActorProbabilistic over a Net trunk with a single-Linear mu head")
             of = optimizer_fields(self.optim._optim)
             bounded = not getattr(actor, "_unbounded", False)
             plain = of["optimizer"] == "adam" and not of["weight_decay"]
-            legacy = (act_name == "tanh" and len(hidden_sizes) == 2 and hidden_sizes[0] == hidden_sizes[1] and hidden_sizes[0] % 32 == 0
-                      and not bounded and plain and self._hip_keys == list(TIANSHOU_ACTOR_KEYS))
+            legacy = (nm is None and act_name == "tanh" and len(hidden_sizes) == 2 and hidden_sizes[0] == hidden_sizes[1]
+                      and hidden_sizes[0] % 32 == 0 and not bounded and plain and self._hip_keys == list(TIANSHOU_ACTOR_KEYS))
             if not legacy and (len(hidden_sizes) > 7 or max(hidden_sizes) > 1024 or sa["mu.model.0.weight"].shape[0] > 32):
                 raise NotImplementedError(f"{who}: trunks of up to 7 hidden layers of at most 1024 units, at most 32 actions")
             self._hip_kind = "legacy" if legacy else "net"
             self._hip_net = (hidden_sizes, act_name, float(actor.max_action) if bounded else None, of)
+            self._hip_ln = None if nm is None else float(nm[1])
             self._hip_engine = None
             self._hip_glue_init()
 
@@ -1003,7 +1008,8 @@ def make_hip_reinforce(ref=None):
                 return NG.actor_flat_from_torch(tensors, obs_dim, hidden, act_dim, self._hip_device)
             from .ppo_wide import net_flat_from_tensors
 
-            return net_flat_from_tensors(list(tensors), obs_dim, list(self._hip_net[0]), act_dim, self._hip_device)
+            return net_flat_from_tensors(list(tensors), obs_dim, list(self._hip_net[0]), act_dim, self._hip_device,
+                                         layer_norm=self._hip_ln is not None)
 
         def _from_flat(self, flat):
             obs_dim, hidden, act_dim = self._dims()
@@ -1011,7 +1017,7 @@ def make_hip_reinforce(ref=None):
                 return NG.actor_flat_to_torch(flat, obs_dim, hidden, act_dim)
             from .ppo_wide import net_flat_to_tensors
 
-            return net_flat_to_tensors(flat, obs_dim, list(self._hip_net[0]), act_dim, True)
+            return net_flat_to_tensors(flat, obs_dim, list(self._hip_net[0]), act_dim, True, layer_norm=self._hip_ln is not None)
 
         def _engine(self):
             if self._hip_engine is None:
@@ -1029,7 +1035,8 @@ def make_hip_reinforce(ref=None):
                 else:
                     hidden_sizes, act_name, max_action, _ = self._hip_net
                     eng = self._hip_engine = RF.NetReinforceEngine(dims[0], dims[2], hidden_sizes, act_name, flat, cfg,
-                                                                   max_action=max_action, optimizer=of)
+                                                                   max_action=max_action, optimizer=of,
+                                                                   layer_norm=self._hip_ln is not None, ln_eps=self._hip_ln or 1e-5)
                 eng.ret_rms = [float(drc.ret_rms.mean), float(drc.ret_rms.var), float(drc.ret_rms.count)]
                 ms, vs, step = adam_state(opt, params_by_keys(self.policy.actor, self._hip_keys))     # resume
                 eng.adam_m, eng.adam_v = self._to_flat(ms), self._to_flat(vs)

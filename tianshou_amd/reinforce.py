@@ -195,7 +195,7 @@ class NetReinforceEngine(ReinforceEngine):
     actor's.  `actor` / `adam_m` / `adam_v` are views of that engine's vectors (ts_net_layout order)."""
 
     def __init__(self, obs_dim: int, act_dim: int, hidden, activation: str, actor: torch.Tensor, cfg: ReinforceConfig,
-                 max_action: float | None = None, optimizer: dict | None = None):
+                 max_action: float | None = None, optimizer: dict | None = None, layer_norm: bool = False, ln_eps: float = 1e-5):
         from .ppo_wide import NetPPOEngine
 
         if not actor.is_cuda:
@@ -209,12 +209,14 @@ class NetReinforceEngine(ReinforceEngine):
                             optimizer=opt.get("optimizer", "adam"), weight_decay=opt.get("weight_decay", 0.0),
                             rms_alpha=opt.get("rms_alpha", 0.99), rms_momentum=opt.get("rms_momentum", 0.0),
                             rms_centered=opt.get("rms_centered", False))
-        probe = _lib.NetDesc.make(obs_dim, [32], activation)
+        # (layer_norm: MLP(norm_layer=nn.LayerNorm) trunks, TS_NET_LAYERNORM -- the zero critic then carries a zero gamma / beta
+        # pair as well: its output and every gradient stay exactly zero)
+        probe = _lib.NetDesc.make(obs_dim, [32], activation, _lib.NetDesc.LAYERNORM if layer_norm else 0, ln_eps=ln_eps)
         out = (C.c_int64 * 3)()
         _lib.check(_lib.load().ts_net_layout(C.byref(probe), _lib.i64(act_dim), out))
         n_critic = int(out[2])
         flat = torch.cat([actor.detach().float().reshape(-1), torch.zeros(n_critic, device=self.device)]).contiguous()
-        self._net = NetPPOEngine(obs_dim, act_dim, self.hidden_sizes, [32], activation, flat, pc)
+        self._net = NetPPOEngine(obs_dim, act_dim, self.hidden_sizes, [32], activation, flat, pc, layer_norm=layer_norm, ln_eps=ln_eps)
         if self._net.n_actor != actor.numel():
             raise ValueError("flat actor vector does not match ts_net_layout")
         self._rms_host, self._rms_dev = [0.0, 1.0, 0.0], None
