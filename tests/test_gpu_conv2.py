@@ -86,3 +86,25 @@ def test_generation_knob_round_trips(gen2):
     assert gen2.ts_conv_set_generation(0) == 1
     assert gen2.ts_conv_set_generation(-5) == 0
     assert gen2.ts_conv_set_generation(1) == -1
+
+
+@pytest.mark.parametrize("B,masked", [(53, True), (300, False)])
+def test_pixel_shuffle_input_gradient_is_bit_identical(gen2, monkeypatch, B, masked):
+    """conv2's input gradient with the four stride parities of a super-pixel as the column blocks of ONE GEMM (Rows2Args.ps: 128
+    columns, every dY operand fetched once for four MFMAs) against one GEMM per parity (TS_DGRAD_PS=0): the same taps in the same
+    order per output element, so the results are equal bit for bit -- with and without the ReLU mask."""
+    from tianshou_amd import dqn as D
+
+    torch.manual_seed(5)
+    IH = IW = 20; IC = 32; K = 4; S = 2; OC = 64
+    x = torch.randn(B, IH, IW, IC, device="cuda")
+    wb = torch.randn(K * K * IC + 1, OC, device="cuda") * 0.05
+    mask = (torch.rand(x.shape, device="cuda") > 0.5).float() if masked else None
+    dy = torch.randn(B, 9, 9, OC, device="cuda")
+    out = {}
+    for ps in ("1", "0"):
+        monkeypatch.setenv("TS_DGRAD_PS", ps)
+        out[ps] = D.conv_backward(x, wb, dy, K, K, S, mask=mask, need_dx=True)[1].clone()
+    assert torch.equal(out["1"], out["0"])
+    _, gx, _ = _ref64(x, wb, K, S, dy, mask)
+    assert float((out["1"].double() - gx).abs().max()) <= 5e-6 * float(gx.abs().max())

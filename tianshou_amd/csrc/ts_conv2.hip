@@ -97,6 +97,10 @@ struct Rows2Args {
     Divisor plane, wdt;       // forward: / (OH*OW), / OW
     const DgClass* classes;   // dgrad: class table (device memory), indexed through blockIdx.x
     int n_classes;
+    int ps;                   // dgrad, "pixel-shuffle" form: the S x S stride parities of an input super-pixel (a, c) read the SAME
+                              // dY pixels (a - jh, c - jw), each through its own taps -- so they are the COLUMN blocks of one GEMM
+                              // (N = S S IC, column (ph S + pw) IC + ic) instead of S S GEMMs of IC columns: every activation
+                              // operand fetched from L2 feeds S S times the MFMAs (conv2 of the Nature CNN: 128 columns)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -161,8 +165,13 @@ void conv_rows2_kernel(Rows2Args a) {
                     const int j = e / per_tap, rem = e - j * per_tap;
                     const int oc4 = rem / BN, icl = rem - oc4 * BN;
                     const int tjh = j / cls.njw, jh = cls.jh0 + tjh, jw = cls.jw0 + j - tjh * cls.njw;
-                    const int tapk = ((ph + g.S * jh) * g.KW + pw + g.S * jw) * g.IC;
-                    v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(tapk + n0 + icl) * a.ldw + 4 * oc4);
+                    int pph = ph, ppw = pw, ic = n0 + icl;
+                    if (a.ps) {                // column -> (parity, input channel)
+                        const int par = ic / g.IC;
+                        ic -= par * g.IC; pph = par / g.S; ppw = par - pph * g.S;
+                    }
+                    const int tapk = ((pph + g.S * jh) * g.KW + ppw + g.S * jw) * g.IC;
+                    v[u] = *reinterpret_cast<const f32x4*>(a.W + (int64_t)(tapk + ic) * a.ldw + 4 * oc4);
                 }
 #pragma unroll
                 for (int u = 0; u < UN; ++u) {
@@ -372,6 +381,11 @@ void conv_rows2_kernel(Rows2Args a) {
                 for (int tn = 0; tn < TN; ++tn) {
                     const int col = n0 + (wn * TN + tn) * 32 + r;
                     const bool col_ok = col < a.N;
+                    int ocol = col;            // dgrad: element offset of this column from the row's pixel
+                    if (DG && a.ps) {
+                        const int par = col / g.IC, pph = par / g.S;
+                        ocol = (pph * g.IW + (par - pph * g.S)) * g.IC + (col - par * g.IC);
+                    }
                     float bias = 0.f;
                     if (!DG && a.bias) bias = a.bias[col_ok ? col : 0];
                     // mask loads of a tile go out as batches (one dependent round trip each): 16 where the register
@@ -391,7 +405,7 @@ void conv_rows2_kernel(Rows2Args a) {
                             } else {
                                 const int ob = __shfl(obase[tm], row, 64);
                                 ok[i] = (FULL || ob >= 0) && col_ok;
-                                off[i] = ok[i] ? (unsigned)(ob + col) : 0u;
+                                off[i] = ok[i] ? (unsigned)(ob + ocol) : 0u;
                             }
                         }
                         float mk[MASK ? EB : 1];
@@ -963,6 +977,35 @@ int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* 
     a.K = kmax;
     ProfScope scope(ws, TS_KIND_CONV_DGRAD, s);
     const int cus = num_cus();
+    // Pixel-shuffle form (Rows2Args.ps): S S IC = 128 columns, the parities' tap runs coincide (every parity of a super-pixel row
+    // sees the same output rows: IH, IW multiples of S), the [kmax][128] weight block fits LDS.  conv2 of the Nature CNN at the
+    // Atari-shape minibatch.  TS_DGRAD_PS=0 keeps one GEMM per parity.
+    if (g.S >= 2 && g.IC == 32 && g.S * g.S * g.IC == 128 && g.IH % g.S == 0 && g.IW % g.S == 0 &&
+        (size_t)kmax * 128 * 4 <= LDS_MAX && env_int("TS_DGRAD_PS", 1)) {
+        std::vector<TapSeg> r0, c0, rp, cp;
+        tap_segments(g.IH, g.OH, g.KH, g.S, 0, &r0);
+        tap_segments(g.IW, g.OW, g.KW, g.S, 0, &c0);
+        bool same = true;
+        auto eq = [](const std::vector<TapSeg>& x, const std::vector<TapSeg>& y) {
+            if (x.size() != y.size()) return false;
+            for (size_t i = 0; i < x.size(); ++i)
+                if (x[i].lo != y[i].lo || x[i].n != y[i].n || x[i].j0 != y[i].j0 || x[i].nj != y[i].nj) return false;
+            return true;
+        };
+        for (int p = 1; p < g.S && same; ++p) {
+            tap_segments(g.IH, g.OH, g.KH, g.S, p, &rp);
+            tap_segments(g.IW, g.OW, g.KW, g.S, p, &cp);
+            same = eq(r0, rp) && eq(c0, cp);
+        }
+        if (same) {
+            std::vector<DgClass> merged;
+            for (const auto& c : plan.classes)
+                if (c.ph == 0 && c.pw == 0) merged.push_back(c);          // parity (0, 0)'s classes stand for all S S parities
+            plan.classes.swap(merged);
+            a.N = g.S * g.S * g.IC; a.ps = 1;
+            return launch_rows2<true, false, true, 2, 2>(dim3(1, 1, 1), (size_t)kmax * 128 * 4, s, a, cus, 16, 1, false, &plan);
+        }
+    }
     if (g.IC % 64 == 0) {
         const size_t lds = (size_t)kmax * 64 * 4;
         const int nb = g.IC / 64;

@@ -1757,27 +1757,24 @@ def make_hip_sac(ref=None):
 
             eng, m = self._hip_engine, self._hip_mirror
             weight = getattr(batch, "weight", None)
-            runner = eng
-            deferred = self.__dict__.pop("_hip_deferred", False)
-            if deferred:
-                # the two rsample() draws keep their call numbers (target: c + 1, update: c + 2)
+            if self.__dict__.pop("_hip_deferred", False):
+                # target pass + update as one call; the two rsample() draws keep their call numbers (target: c + 1, update: c + 2)
                 key, c = self._hip_noise_key ^ 0x5AC, self._hip_noise_calls
                 self._hip_noise_calls += 2
                 stats, w, ret, _ = eng.learn_rows(m, self._hip_idx, noise_key=(key, c + 1), weight=weight, noise_streams=2)
                 batch.returns = ret.reshape(-1, 1)
             else:
                 noise = self._hip_rsample_noise(int(self._hip_idx.numel()), eng.act_dim)
+                runner = eng
                 if self._hip_dp_on:
                     from .distributed import DataParallelSAC
 
                     runner = self._hip_dp(DataParallelSAC, eng)
-            if deferred:
-                pass
-            elif runner is eng and hasattr(eng, "update_with_rows"):             # the input packing reads the mirror's rows
-                stats, w = eng.update_with_rows(m, self._hip_idx, batch.returns.reshape(-1), noise, weight)
-            else:
-                stats, w = runner.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),
-                                                    batch.returns.reshape(-1), noise, weight)
+                if runner is eng and hasattr(eng, "update_with_rows"):           # the input packing reads the mirror's rows
+                    stats, w = eng.update_with_rows(m, self._hip_idx, batch.returns.reshape(-1), noise, weight)
+                else:
+                    stats, w = runner.update_with_batch(*gather_rows_multi([m.obs, m.act], self._hip_idx),
+                                                        batch.returns.reshape(-1), noise, weight)
             batch.weight = w                                                      # prio-buffer, sac.py:306
             s = stats.cpu().numpy()                                               # one D2H per update()
             self._hip_after_update()                                              # write-back now ("eager") or when read ("lazy")
