@@ -834,6 +834,30 @@ bool conv2_use_forward(const ConvGeom& g, bool x_u8) {
     return mode > 0 || big_enough(g, (int64_t)g.B * g.OH * g.OW);
 }
 
+// Pixel-shuffle form of a strided layer's input gradient (Rows2Args.ps): S S IC = 128 columns, the parities' tap runs coincide
+// (IH, IW multiples of S: every parity of a super-pixel row sees the same output rows), the [K / S^2][128] weight block fits LDS.
+// conv2 of the Nature CNN.  TS_DGRAD_PS=0 keeps one GEMM per parity.
+static bool dgrad_ps_ok(const ConvGeom& g) {
+    if (!(g.S >= 2 && g.IC == 32 && g.S * g.S * g.IC == 128 && g.IH % g.S == 0 && g.IW % g.S == 0 && g.KH % g.S == 0 &&
+          g.KW % g.S == 0 && (size_t)(g.KH / g.S) * (g.KW / g.S) * g.OC * 128 * 4 <= LDS_MAX && env_int("TS_DGRAD_PS", 1)))
+        return false;
+    std::vector<TapSeg> r0, c0, rp, cp;
+    tap_segments(g.IH, g.OH, g.KH, g.S, 0, &r0);
+    tap_segments(g.IW, g.OW, g.KW, g.S, 0, &c0);
+    auto eq = [](const std::vector<TapSeg>& x, const std::vector<TapSeg>& y) {
+        if (x.size() != y.size()) return false;
+        for (size_t i = 0; i < x.size(); ++i)
+            if (x[i].lo != y[i].lo || x[i].n != y[i].n || x[i].j0 != y[i].j0 || x[i].nj != y[i].nj) return false;
+        return true;
+    };
+    for (int p = 1; p < g.S; ++p) {
+        tap_segments(g.IH, g.OH, g.KH, g.S, p, &rp);
+        tap_segments(g.IW, g.OW, g.KW, g.S, p, &cp);
+        if (!eq(r0, rp) || !eq(c0, cp)) return false;
+    }
+    return true;
+}
+
 bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end) {
     const int mode = v2_mode();
     if (mode < 0 || !shape_ok_rows(g) || g.IC % 32 != 0) return false;
@@ -850,7 +874,10 @@ bool conv2_use_dgrad(const ConvGeom& g, bool have_ws, int col_begin, int col_end
             if (dgrad_classes(g, &probe) != TS_OK) return false;
         }
     }
-    return mode > 0 || big_enough(g, (int64_t)g.B * g.IH * g.IW);
+    if (mode > 0 || big_enough(g, (int64_t)g.B * g.IH * g.IW)) return true;
+    // the pixel-shuffle form pays from fewer rows on (the C3 batch: 512 x 20 x 20 input pixels; TS_DGRAD_PS_MIN_ROWS)
+    static const int64_t ps_min = [] { const char* e = getenv("TS_DGRAD_PS_MIN_ROWS"); return e ? atoll(e) : (int64_t)1 << 62; }();
+    return !is_linear(g) && (int64_t)g.B * g.IH * g.IW >= ps_min && dgrad_ps_ok(g);
 }
 
 bool conv2_use_wgrad(const ConvGeom& g, bool x_u8) {
@@ -977,34 +1004,13 @@ int conv2_dgrad(hipStream_t s, const ConvGeom& g, const float* dY, const float* 
     a.K = kmax;
     ProfScope scope(ws, TS_KIND_CONV_DGRAD, s);
     const int cus = num_cus();
-    // Pixel-shuffle form (Rows2Args.ps): S S IC = 128 columns, the parities' tap runs coincide (every parity of a super-pixel row
-    // sees the same output rows: IH, IW multiples of S), the [kmax][128] weight block fits LDS.  conv2 of the Nature CNN at the
-    // Atari-shape minibatch.  TS_DGRAD_PS=0 keeps one GEMM per parity.
-    if (g.S >= 2 && g.IC == 32 && g.S * g.S * g.IC == 128 && g.IH % g.S == 0 && g.IW % g.S == 0 &&
-        (size_t)kmax * 128 * 4 <= LDS_MAX && env_int("TS_DGRAD_PS", 1)) {
-        std::vector<TapSeg> r0, c0, rp, cp;
-        tap_segments(g.IH, g.OH, g.KH, g.S, 0, &r0);
-        tap_segments(g.IW, g.OW, g.KW, g.S, 0, &c0);
-        bool same = true;
-        auto eq = [](const std::vector<TapSeg>& x, const std::vector<TapSeg>& y) {
-            if (x.size() != y.size()) return false;
-            for (size_t i = 0; i < x.size(); ++i)
-                if (x[i].lo != y[i].lo || x[i].n != y[i].n || x[i].j0 != y[i].j0 || x[i].nj != y[i].nj) return false;
-            return true;
-        };
-        for (int p = 1; p < g.S && same; ++p) {
-            tap_segments(g.IH, g.OH, g.KH, g.S, p, &rp);
-            tap_segments(g.IW, g.OW, g.KW, g.S, p, &cp);
-            same = eq(r0, rp) && eq(c0, cp);
-        }
-        if (same) {
-            std::vector<DgClass> merged;
-            for (const auto& c : plan.classes)
-                if (c.ph == 0 && c.pw == 0) merged.push_back(c);          // parity (0, 0)'s classes stand for all S S parities
-            plan.classes.swap(merged);
-            a.N = g.S * g.S * g.IC; a.ps = 1;
-            return launch_rows2<true, false, true, 2, 2>(dim3(1, 1, 1), (size_t)kmax * 128 * 4, s, a, cus, 16, 1, false, &plan);
-        }
+    if (dgrad_ps_ok(g)) {          // pixel-shuffle form: parity (0, 0)'s classes stand for all S S parities
+        std::vector<DgClass> merged;
+        for (const auto& c : plan.classes)
+            if (c.ph == 0 && c.pw == 0) merged.push_back(c);
+        plan.classes.swap(merged);
+        a.N = g.S * g.S * g.IC; a.ps = 1;
+        return launch_rows2<true, false, true, 2, 2>(dim3(1, 1, 1), (size_t)kmax * 128 * 4, s, a, cus, 16, 1, false, &plan);
     }
     if (g.IC % 64 == 0) {
         const size_t lds = (size_t)kmax * 64 * 4;
