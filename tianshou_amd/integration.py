@@ -37,7 +37,9 @@ _LAZY_OWNERS: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDict
 
 def _sync_owner_before_state_dict(module, prefix, keep_vars) -> None:
     owner = _LAZY_OWNERS.get(id(module))
-    if owner is not None and not owner.__dict__.get("_hip_in_update", False):
+    # (the table is keyed by id(): an entry may outlive its module -- a replaced sub-module whose id a foreign module took over --
+    # so the owner is asked whether the module is still one of its own)
+    if owner is not None and not owner.__dict__.get("_hip_in_update", False) and any(m is module for m in owner.modules()):
         owner.hip_sync()
 
 
@@ -173,8 +175,10 @@ class _HipGlue:
         self.__dict__["_hip_lazy"] = write_back == "lazy" or (write_back == "auto" and attached)
         if self.__dict__["_hip_lazy"]:
             for m in self.modules():                      # (the algorithm's own state_dict() / hip_sync() are overridden)
-                if m is not self and id(m) not in _LAZY_OWNERS:
-                    _LAZY_OWNERS[id(m)] = self
+                if m is self:
+                    continue
+                _LAZY_OWNERS[id(m)] = self                # (latest owner wins: a stale entry under a recycled id is replaced)
+                if _sync_owner_before_state_dict not in m._state_dict_pre_hooks.values():
                     m.register_state_dict_pre_hook(_sync_owner_before_state_dict)
 
     def _hip_offpolicy_update(self, buffer, sample_size, Batch, TrainingStats=None):
