@@ -1783,3 +1783,98 @@ def test_off_policy_hooks_refuse_activations_the_engine_does_not_compute():
     assert (b._hip_actfn, b._hip_bound) == ("relu", 2.0) and b.policy._hip_spec["max_action"] == 2.0
     with pytest.raises(NotImplementedError, match="nn.ReLU or nn.Tanh"):
         build(nn.ELU, unbounded=True)
+
+
+def test_hip_sac_one_call_update_on_the_real_reference_classes(monkeypatch):
+    """Round 6: HipSAC.update() on tianshou's OWN SAC / SACPolicy / PrioritizedVectorReplayBuffer with an engine double (CPU: no
+    kernel runs).  With the defaults the two hooks of an n_step = 1 update make ONE engine call (`learn_rows`: ts_sac_learn_rows) --
+    on the indices `buffer.sample_indices` drew, with the importance weights `PrioritizedReplayBuffer.__getitem__` would attach
+    (prio.py:69-79, 103-106), the two rsample() draws' counters in order -- and `_postprocess_batch` hands the engine's TD weights
+    to `buffer.update_weight` (prio.py:81-100).  With torch's noise (`update_noise="torch"`) the hooks stay two calls."""
+    ref_shim.install()
+    import gymnasium as gym
+    from tianshou.algorithm.modelfree.sac import AutoAlpha, SACPolicy
+    from tianshou.algorithm.optim import AdamOptimizerFactory
+    from tianshou.data import Batch, PrioritizedVectorReplayBuffer
+    from tianshou.utils.net.common import Net
+    from tianshou.utils.net.continuous import ContinuousActorProbabilistic, ContinuousCritic
+    from tianshou.utils.torch_utils import policy_within_training_step
+    import tianshou_amd.integration as I
+
+    monkeypatch.setattr(I, "_require_gpu", lambda device, who: None)
+    obs_dim, act_dim, B = 11, 3, 8
+
+    class Cfg:
+        n_step, auto_alpha = 1, True
+
+    class Engine:                                     # the interface of tianshou_amd.sac.SACEngine the hooks use
+        cfg, act_dim = Cfg(), 3
+
+        def __init__(self):
+            self.calls = []
+
+        def _rows_ok(self, m):
+            return True
+
+        def learn_rows(self, m, idx, noise=None, noise_key=None, weight=None, lr_scale=1.0, noise_streams=1):
+            self.calls.append(("learn_rows", idx.clone(), noise_key, None if weight is None else np.asarray(weight).copy(), noise_streams))
+            n = idx.numel()
+            return torch.arange(5.0), torch.linspace(0.5, 1.5, n), torch.full((n,), 7.0), None
+
+        def preprocess(self, m, idx, noise):
+            self.calls.append(("preprocess", idx.clone(), tuple(noise.shape)))
+            return torch.full((idx.numel(),), 7.0)
+
+        def update_with_rows(self, m, idx, returns, noise, weight=None, lr_scale=1.0):
+            self.calls.append(("update_with_rows", idx.clone(), tuple(noise.shape)))
+            return torch.arange(5.0), torch.linspace(0.5, 1.5, idx.numel())
+
+    def build(**kw):
+        actor = ContinuousActorProbabilistic(preprocess_net=Net(state_shape=(obs_dim,), hidden_sizes=[256, 256]), action_shape=(act_dim,),
+                                             unbounded=True, conditioned_sigma=True)
+        mk = lambda: ContinuousCritic(preprocess_net=Net(state_shape=(obs_dim,), action_shape=(act_dim,), hidden_sizes=[256, 256],  # noqa: E731
+                                                         concat=True))
+        policy = SACPolicy(actor=actor, action_space=gym.spaces.Box(low=-1.0, high=1.0, shape=(act_dim,)))
+        algo = I.make_hip_sac()(policy=policy, policy_optim=AdamOptimizerFactory(lr=1e-3), critic=mk(),
+                                critic_optim=AdamOptimizerFactory(lr=1e-3), critic2=mk(), critic2_optim=AdamOptimizerFactory(lr=1e-3),
+                                alpha=AutoAlpha(-3.0, 0.0, AdamOptimizerFactory(lr=3e-4)), device="cpu", policy_forward="torch",
+                                write_back="lazy", noise_seed=5, **kw)
+        algo._hip_engine = Engine()
+        return algo
+
+    def buffer():
+        buf = PrioritizedVectorReplayBuffer(32, 2, alpha=0.6, beta=0.4)
+        rng = np.random.default_rng(1)
+        for _ in range(12):
+            buf.add(Batch(obs=rng.normal(size=(2, obs_dim)).astype(np.float32), act=rng.normal(size=(2, act_dim)).astype(np.float32),
+                          rew=rng.normal(size=2), terminated=np.zeros(2, bool), truncated=np.zeros(2, bool),
+                          obs_next=rng.normal(size=(2, obs_dim)).astype(np.float32)))
+        buf.update_weight(np.arange(6), np.linspace(0.1, 2.0, 6))           # uneven priorities: the weights are not all 1
+        return buf
+
+    algo, buf = build(), buffer()
+    drawn = []
+    orig = buf.sample_indices
+    monkeypatch.setattr(buf, "sample_indices", lambda n: (drawn.append(orig(n)), drawn[-1])[1])
+    with policy_within_training_step(algo.policy):
+        for _ in range(2):
+            stats = algo.update(buffer=buf, sample_size=B)
+    calls = algo._hip_engine.calls
+    assert [c[0] for c in calls] == ["learn_rows", "learn_rows"]
+    key = 5 ^ 0x5AC
+    for u, c in enumerate(calls):
+        assert np.array_equal(c[1].numpy(), drawn[u])
+        assert c[2] == (key, 2 * u + 1) and c[4] == 2                       # target draw 2u + 1, update draw 2u + 2
+    w0 = buffer().get_weight(drawn[0])                                      # (a fresh buffer: update 0 has rewritten these priorities)
+    np.testing.assert_allclose(calls[0][3], w0 / np.max(w0))
+    assert (stats.actor_loss, stats.critic1_loss, stats.critic2_loss, stats.alpha, stats.alpha_loss) == (0.0, 1.0, 2.0, 3.0, 4.0)
+    eps = np.finfo(np.float32).eps.item()                                  # prio.py:81-94: (|w| + eps) ** alpha
+    last = {int(i): k for k, i in enumerate(drawn[1])}                      # (an index drawn twice keeps its last weight)
+    np.testing.assert_allclose(buf.weight[np.array(list(last))], (np.linspace(0.5, 1.5, B)[list(last.values())] + eps) ** 0.6, rtol=1e-6)
+    assert algo.__dict__["_hip_stale"]                                     # lazy write-back: nothing touched the torch modules
+
+    two, buf2 = build(update_noise="torch"), buffer()
+    with policy_within_training_step(two.policy):
+        two.update(buffer=buf2, sample_size=B)
+    assert [c[0] for c in two._hip_engine.calls] == ["preprocess", "update_with_rows"]
+    assert two._hip_engine.calls[0][2] == (B, act_dim) and two._hip_engine.calls[1][2] == (B, act_dim)
