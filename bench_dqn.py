@@ -91,6 +91,60 @@ REPLAY_STREAM = not os.environ.get("TS_DQN_NO_REPLAY_STREAM")      # A/B switch:
 LEARN_STEP = not os.environ.get("TS_DQN_NO_LEARN_STEP")      # A/B switch: the whole update as one library call (ts_dqn_learn_step)
 
 
+def hook_level(updates: int = 200, slots: int = 1 << 12) -> dict:
+    """The drop-in as Tianshou calls it: `HipDQN.update(buffer, 512)` (tianshou_amd/integration.py) on a HOST prioritized frame
+    buffer of the C3 layout (single uint8 frames, stack_num 4, 16 sub-buffers) -- `sample_indices`, importance weights,
+    `_preprocess_batch`, `_update_with_batch`, `_postprocess_batch` (priorities back into the host buffer), the loss as a Python
+    float (one device synchronisation per update, as the reference's `.item()` has).  The reference package is not on the GPU
+    box: the subclass is built over tests/standin.py (same attribute surface, tests/test_standin_surface.py); hook bodies, device
+    mirror, engine and write-back are the production code.  Two modes: the defaults (index-only sampling, write-back when the
+    torch state is read) and the reference-exact mode (`host_batch=True, write_back="eager"`: the reference's own
+    `Algorithm._update` with its host copy of the batch -- two stacked observations per transition -- and both networks + the
+    optimizer state written back after every update)."""
+    from tests import standin as SI
+    from tianshou_amd.integration import make_hip_dqn
+
+    E = 16
+    n = E * slots
+    rng = np.random.default_rng(0)
+    out = {}
+    for mode, kw, n_upd in (("default", {}, updates), ("reference_exact", dict(host_batch=True, write_back="eager"), max(updates // 8, 10))):
+        torch.manual_seed(0)
+        algo = make_hip_dqn(ref=SI)(policy=SI.DiscreteQLearningPolicy(SI.DQNet(C, H, W, N_ACT)), lr=1e-4, gamma=0.99,
+                                    n_step_return_horizon=3, target_update_freq=500, is_double=True, huber_loss_delta=1.0,
+                                    device="cuda", **kw).to("cuda")
+        buf = SI.PrioritizedVectorReplayBuffer(n, E, obs_shape=(H, W), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                               stack_num=C, alpha=0.6, beta=0.4)
+        buf.obs[:] = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+        buf.obs_next[:] = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+        buf.act[:] = rng.integers(0, N_ACT, n)
+        buf.rew[:] = rng.standard_normal(n)
+        buf.terminated[:] = rng.random(n) < 0.002
+        buf.done[:] = buf.terminated
+        buf.prio[:] = 1.0
+        for e, sb in enumerate(buf.buffers):
+            sb._size, sb._insertion_idx = slots, 0
+            buf._lengths[e] = slots
+            buf.last_index[e] = (e + 1) * slots - 1
+        algo.policy.is_within_training_step = True
+        for _ in range(5):
+            algo.update(buf, BATCH)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_upd):
+            stats = algo.update(buf, BATCH)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        algo.hip_sync()
+        torch.cuda.synchronize()
+        out[mode] = {"updates_per_s": n_upd / dt, "ms_per_update": dt / n_upd * 1e3, "updates": n_upd,
+                     "sync_ms_after": (time.perf_counter() - t1) * 1e3, "loss": float(stats.loss)}
+    out["note"] = ("HipDQN.update() over a host-filled PrioritizedVectorReplayBuffer stand-in (production hook code); `sync_ms_after` = "
+                   "one hip_sync() (the deferred write-back of two networks and the optimizer state) after the timed loop")
+    return out
+
+
 def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) -> dict:
     import bench_init as BI
     from tianshou_amd import _lib
@@ -175,6 +229,7 @@ def run(steps: int, warmup: int, slots: int = 1 << 20, with_cpu: bool = True) ->
         "update_path": "ts_dqn_learn_step (one library call per update)" if LEARN_STEP else
                        "separate calls" + (" + replay stream" if REPLAY_STREAM else ""),
         "cpu_baseline": cpu_baseline() if with_cpu else None, "final_loss": float(loss),
+        "hook_level": hook_level() if with_cpu else None,
     }
     return out
 

@@ -837,9 +837,15 @@ class PrioritizedVectorReplayBuffer(VectorReplayBuffer):
         self.prio[ptrs] = self._max_prio ** self._alpha
         return ptrs
 
+    _weight_norm = True
+
+    def get_weight(self, index):
+        """prio.py:69-79."""
+        return (self.prio[index] / self._min_prio) ** (-self._beta)
+
     def sample(self, batch_size):
         batch, idx = super().sample(batch_size)
-        w = (self.prio[idx] / self._min_prio) ** (-self._beta)
+        w = self.get_weight(idx)
         batch.weight = w / np.max(w)
         return batch, idx
 

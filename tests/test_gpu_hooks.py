@@ -692,7 +692,9 @@ def _dqn_hook_run(huber):
     with torch.no_grad():
         model.net[0][0].weight.mul_(1.0 / 255.0)     # uint8 frames (0..255) times default-init weights: keep Q values O(1)
     algo = HipDQN(policy=SI.DiscreteQLearningPolicy(model), lr=1e-4, gamma=0.97, n_step_return_horizon=3, target_update_freq=2,
-                  is_double=True, huber_loss_delta=huber, device="cuda").to("cuda")
+                  is_double=True, huber_loss_delta=huber, device="cuda", host_batch=True, write_back="eager").to("cuda")
+    # (the reference-exact mode: `Algorithm._update` with its host batch, write-back after every update; the defaults --
+    # index-only sampling, lazy write-back -- are compared with it in test_hip_dqn_default_mode_equals_the_reference_exact_mode)
     sd = model.state_dict()
     p0 = {k: sd[n].detach().cpu().clone() for k, n in zip(OD.PARAM_ORDER, D.TIANSHOU_KEYS)}
     ocfg = OD.DQNConfig(gamma=0.97, n_step=3, target_update_freq=2, is_double=True, huber_delta=huber, lr=1e-4)
@@ -744,6 +746,79 @@ def _dqn_hook_run(huber):
         np.testing.assert_allclose(t.numpy(), st.params_old[k].numpy(), rtol=1e-5, atol=0.05 * 1e-4, err_msg=k)
     opt_state = algo.optim._optim.state[next(iter(model.parameters()))]
     assert float(opt_state["step"]) == 5.0
+
+
+def test_hip_dqn_default_mode_equals_the_reference_exact_mode():
+    """HipDQN's defaults -- `update()` samples indices only (`buffer.sample()`'s host copy of two stacked observations per
+    transition is never made; frames, actions, rewards are read from the device mirror), write-back of the two networks and the
+    optimizer deferred until the torch state is read -- against the reference-exact mode (`host_batch=True,
+    write_back="eager"`: the reference's own `Algorithm._update`) on the same prioritized buffer history: identical loss and
+    identical priorities written back every update, identical torch state after a sync (`policy.state_dict()`, `hip_sync()`),
+    and the torch modules do not move in between.  The collector-side forward reads the engine's parameters either way."""
+    from tianshou_amd.integration import make_hip_dqn
+
+    c, h, w, A, E, size, B = 4, 44, 36, 3, 4, 40, 32
+    HipDQN = make_hip_dqn(ref=SI)
+
+    def build(**kw):
+        torch.manual_seed(5)
+        model = SI.DQNet(c, h, w, A)
+        with torch.no_grad():
+            model.net[0][0].weight.mul_(1.0 / 255.0)
+        algo = HipDQN(policy=SI.DiscreteQLearningPolicy(model), lr=1e-4, gamma=0.97, n_step_return_horizon=3, target_update_freq=2,
+                      is_double=True, huber_loss_delta=None, device="cuda", **kw).to("cuda")
+        algo.policy.is_within_training_step = True
+        return algo
+
+    ref, lazy = build(host_batch=True, write_back="eager"), build()
+    assert lazy.__dict__["_hip_lazy"] and not ref.__dict__["_hip_lazy"]
+    bufs = [SI.PrioritizedVectorReplayBuffer(E * size, E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
+                                             seed=2, stack_num=c, alpha=0.6, beta=0.4) for _ in range(2)]
+    rngs = [np.random.default_rng(3) for _ in range(2)]
+
+    def fill(buf, rng, n):
+        for _ in range(n):
+            term = rng.random(E) < 0.08
+            buf.add(SI.Batch(obs=rng.integers(0, 256, (E, h, w)).astype(np.uint8), act=rng.integers(0, A, E),
+                             rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
+                             obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
+
+    made = []
+    orig = bufs[1].sample
+    bufs[1].sample = lambda bs: (made.append(bs), orig(bs))[1]          # the default mode must not ask for the host batch
+    flat = lambda algo: torch.cat([p.detach().reshape(-1).float().cpu() for p in algo.parameters()])  # noqa: E731
+    start = flat(lazy)
+    for u in range(5):
+        out = []
+        for algo, buf, r in zip((ref, lazy), bufs, rngs):
+            fill(buf, r, 25 if u == 0 else 9)
+            out.append(algo.update(buf, B))
+        assert out[0].loss == out[1].loss, u
+        (i0, w0), (i1, w1) = bufs[0].weight_updates[-1], bufs[1].weight_updates[-1]
+        assert np.array_equal(i0, i1) and np.array_equal(w0, w1)         # same draws, same TD errors -> same priorities
+        assert torch.equal(flat(lazy), start)                            # nothing was written back yet
+        assert lazy._iter == ref._iter == u + 1
+    assert not made and lazy.__dict__["_hip_stale"]
+    obs = np.random.default_rng(8).integers(0, 256, (8, c, h, w)).astype(np.uint8)
+    q_l = lazy.policy(SI.Batch(obs=obs, info={})).logits
+    q_r = ref.policy(SI.Batch(obs=obs, info={})).logits
+    assert torch.equal(torch.as_tensor(q_l).cpu(), torch.as_tensor(q_r).cpu())        # the collector sees the engine's parameters
+    sd = lazy.policy.state_dict()                                        # a reader: syncs
+    assert not lazy.__dict__["_hip_stale"] and torch.equal(flat(lazy), flat(ref)) and not torch.equal(flat(lazy), start)
+    assert all(torch.equal(v.cpu(), ref.policy.state_dict()[k].cpu()) for k, v in sd.items())
+    p_l, p_r = next(iter(lazy.policy.model.parameters())), next(iter(ref.policy.model.parameters()))
+    st_l, st_r = lazy.optim._optim.state[p_l], ref.optim._optim.state[p_r]
+    assert float(st_l["step"]) == 5.0 and torch.equal(st_l["exp_avg"], st_r["exp_avg"]) and torch.equal(st_l["exp_avg_sq"], st_r["exp_avg_sq"])
+    for algo, buf, r in zip((ref, lazy), bufs, rngs):
+        fill(buf, r, 5)
+        algo.update(buf, B)
+    assert lazy.__dict__["_hip_stale"]
+    lazy.hip_sync()
+    assert not lazy.__dict__["_hip_stale"] and torch.equal(flat(lazy), flat(ref))
+    sd_l, sd_r = lazy.state_dict(), ref.state_dict()
+    for k in sd_r:
+        if isinstance(sd_r[k], torch.Tensor):
+            assert torch.equal(sd_l[k].cpu(), sd_r[k].cpu()), k
 
 
 @pytest.mark.parametrize("huber", [None, 1.0], ids=["weighted_mse", "huber"])
@@ -1695,7 +1770,8 @@ def test_hip_dqn_hooks_replay_the_reference():
     model.load_state_dict({name: p0[k] for name, k in zip(D.TIANSHOU_KEYS, OD.PARAM_ORDER)})
     algo = make_hip_dqn(ref=SI)(policy=SI.DiscreteQLearningPolicy(model), lr=ocfg.lr, gamma=ocfg.gamma,
                                 n_step_return_horizon=ocfg.n_step, target_update_freq=ocfg.target_update_freq,
-                                is_double=ocfg.is_double, huber_loss_delta=ocfg.huber_delta, device="cuda").to("cuda")
+                                is_double=ocfg.is_double, huber_loss_delta=ocfg.huber_delta, device="cuda", host_batch=True,
+                                write_back="eager").to("cuda")
     buf = SI.PrioritizedVectorReplayBuffer(E * d["slots"], E, obs_shape=(h, w), act_shape=(), obs_dtype=np.uint8, act_dtype=np.int64,
                                            stack_num=c, alpha=0.6, beta=0.4)
     buf._meta = SI._Meta(("obs", "act", "rew", "terminated", "truncated", "done"))        # ignore_obs_next=True

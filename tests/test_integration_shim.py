@@ -728,6 +728,10 @@ def test_hip_dqn_wrapper_runs_with_engine_double(dqn_algo, monkeypatch):
     with policy_within_training_step(dqn_algo.policy):
         stats = dqn_algo.update(buffer=buf, sample_size=8)
     assert isinstance(stats, SimpleLossTrainingStats) and stats.loss == 0.75
+    # defaults since round 6: index-only sampling, write-back when the torch state is read (the policy forward is the engine's)
+    assert dqn_algo.__dict__["_hip_lazy"] and dqn_algo.__dict__["_hip_stale"] and torch.equal(first.detach(), before)
+    sd = dqn_algo.policy.state_dict()                       # a reader (the real reference module's state_dict()): syncs
+    assert not dqn_algo.__dict__["_hip_stale"] and torch.allclose(sd["model.net.0.0.weight"], before + 2.0)
     assert torch.allclose(first.detach(), before + 2.0)
     st = dqn_algo.optim._optim.state[first]
     assert float(st["step"]) == 1.0 and torch.allclose(st["exp_avg_sq"], torch.full_like(st["exp_avg_sq"], 0.25))

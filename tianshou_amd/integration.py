@@ -1127,19 +1127,28 @@ def make_hip_dqn(ref=None):
     `ref`: optional namespace replacing the tianshou imports (see `_ref`)."""
     DQN = _ref(ref, "tianshou.algorithm.modelfree.dqn", "DQN")
     SimpleLossTrainingStats = _ref(ref, "tianshou.algorithm.modelfree.reinforce", "SimpleLossTrainingStats")
+    Batch = _ref(ref, "tianshou.data", "Batch")
 
     from . import dqn as D
 
     class HipDQN(_HipGlue, DQN):
-        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, policy_forward="hip", **kwargs):
+        def __init__(self, *args, device="cuda", data_parallel=False, group=None, allreduce=None, policy_forward="hip",
+                     write_back="auto", host_batch=False, **kwargs):
             """`data_parallel=True`: one process per GPU, every rank samples its own minibatch from its own buffer (its
             envs) and `_update_with_batch` all-reduces the flat gradient + loss (`DataParallelDQN`); PER priorities stay
             rank-local.  `allreduce`: None = torch.distributed, "native" = the C-ABI RCCL exchange, or a callable.
             `policy_forward="hip"`: `DiscreteQLearningPolicy.forward` (dqn.py:101-143), which the Collector
             calls per vector step, runs on `ts_dqn_forward` with the engine's parameters (`tianshou_amd.policy`); the
-            epsilon-greedy `add_exploration_noise` stays the reference's."""
+            epsilon-greedy `add_exploration_noise` stays the reference's.
+            Hook-level throughput (as HipSAC's): `host_batch=False` lets `update()` sample indices only -- the hooks read frames,
+            actions and rewards from the device mirror by index, the host copy `buffer.sample()` makes of the batch (two stacked
+            observations per transition: 29 MB for 512 Atari transitions) is never looked at (True: the reference's own
+            `Algorithm._update`); `write_back="auto"` keeps the updates in the engine until somebody reads the torch modules (lazy
+            whenever the policy forward is the engine's; "eager" = the two networks and the optimizer state after every update,
+            27 MB of device copies in ~40 torch ops; `hip_sync()` forces it)."""
             super().__init__(*args, **kwargs)
             self._hip_device = torch.device(device)
+            self._hip_host_batch = bool(host_batch)
             sd = self.policy.model.state_dict()
             if list(sd.keys()) != D.TIANSHOU_KEYS:
                 raise NotImplementedError("HipDQN: the model must be DQNet(c, h, w, action_shape) without extra layers")
@@ -1153,6 +1162,12 @@ def make_hip_dqn(ref=None):
                 from . import policy as HP
 
                 HP.attach(self.policy, "q", self, device=str(self._hip_device), n_act=int(sd[D.TIANSHOU_KEYS[-1]].numel()))
+            self._hip_set_write_back(write_back, attached=policy_forward == "hip")
+
+        def update(self, buffer, sample_size):
+            if self._hip_host_batch or buffer is None:
+                return super().update(buffer, sample_size)
+            return self._hip_offpolicy_update(buffer, sample_size, Batch)
 
         def _engine(self, c, h, w):
             if self._hip_engine is None:
@@ -1208,7 +1223,8 @@ def make_hip_dqn(ref=None):
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
             obs = self._hip_obs
-            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device)
+            # (index-only sampling: the batch carries no host copy of the actions; the mirror's rows are the same values)
+            act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device) if hasattr(batch, "act") else m.act[self._hip_idx]
             runner = eng
             if self._hip_dp_on:
                 from .distributed import DataParallelDQN
@@ -1217,18 +1233,22 @@ def make_hip_dqn(ref=None):
             loss, td = runner.update_with_batch(obs, act, batch.returns.reshape(-1), weight)
             self._iter = eng.iter
             batch.weight = td                                                     # prio-buffer, dqn.py:401
-            tensors = D.flat_to_torch(eng.params, eng.c, eng.h, eng.w, eng.n_act)
-            with torch.no_grad():
-                for p, t in zip(self.policy.model.parameters(), tensors):
-                    p.copy_(t)
-                if eng.params_old is not None:
-                    old = D.flat_to_torch(eng.params_old, eng.c, eng.h, eng.w, eng.n_act)
-                    for p, t in zip(self.model_old.parameters(), old):
-                        p.copy_(t)
+            self._hip_after_update()                                              # write-back now ("eager") or when read ("lazy")
+            return SimpleLossTrainingStats(loss=float(loss.item()))
+
+        def _hip_write_back(self) -> None:
+            eng = self.__dict__.get("_hip_engine_obj")
+            if eng is None:
+                return
             dims = (eng.c, eng.h, eng.w, eng.n_act)
+            with torch.no_grad():
+                for p, t in zip(self.policy.model.parameters(), D.flat_to_torch(eng.params, *dims)):
+                    self._hip_put(p, t)
+                if eng.params_old is not None:
+                    for p, t in zip(self.model_old.parameters(), D.flat_to_torch(eng.params_old, *dims)):
+                        self._hip_put(p, t)
             store_adam_state(self.optim._optim, list(self.policy.model.parameters()), D.flat_to_torch(eng.adam_m, *dims),
                              D.flat_to_torch(eng.adam_v, *dims), eng.adam_step)
-            return SimpleLossTrainingStats(loss=float(loss.item()))
 
     return HipDQN
 
