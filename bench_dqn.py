@@ -122,6 +122,7 @@ def hook_level(updates: int = 200, slots: int = 1 << 12) -> dict:
         buf.terminated[:] = rng.random(n) < 0.002
         buf.done[:] = buf.terminated
         buf.prio[:] = 1.0
+        buf._meta = SI._Meta(("obs", "act", "rew", "terminated", "truncated", "done"))   # ignore_obs_next=True (atari_dqn.py)
         for e, sb in enumerate(buf.buffers):
             sb._size, sb._insertion_idx = slots, 0
             buf._lengths[e] = slots

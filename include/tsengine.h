@@ -621,6 +621,18 @@ int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, flo
                       const ts_frame_replay* replay, int64_t B, int64_t n_step, double gamma, int is_double,
                       const ts_dqn_hparams* hp, uint64_t seed, uint64_t counter, int prepared, void* scratch,
                       int64_t scratch_bytes, float* td_out, float* loss_out, int64_t* idx_out, ts_stream_t stream);
+/* The update of ts_dqn_learn_step for a batch the CALLER drew -- `indices` int64[B] and (nullable) importance weights float32[B]
+ * from a host PrioritizedVectorReplayBuffer's sample_indices / get_weight (prio.py:63-79), as HipDQN.update() has them at hook
+ * level (OffPolicyAlgorithm.update, algorithm_base.py:586-631; DQN._preprocess_batch / _update_with_batch, dqn.py:257-275, 381-404):
+ * batch.act / obs / obs_next gathered by index, n-step returns with the lagged network, the update with a forward pass started
+ * beside the target passes -- the same kernels on the same values as the separate calls.  No sampling, no priority update
+ * (`replay->tree` is not looked at): the TD errors return in td_out for the caller's _postprocess_batch (prio.py:81-100).
+ * returns_out nullable float32[B] (batch.returns).  scratch / ws_aux / sync_target as in ts_dqn_learn_step. */
+int ts_dqn_learn_rows(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                      float* adam_v, int64_t adam_step, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                      const ts_frame_replay* replay, const int64_t* indices, const float* weight, int64_t B, int64_t n_step,
+                      double gamma, int is_double, const ts_dqn_hparams* hp, void* scratch, int64_t scratch_bytes,
+                      float* returns_out, float* td_out, float* loss_out, ts_stream_t stream);
 /* With TS_DQN_GRAPH=1 in the environment ts_dqn_learn_step replays its steady state (same arguments as the two calls before,
  * batch prepared ahead, priorities present) from a HIP graph captured from its own stream enqueue, one per (counter parity,
  * sync_target): one graph launch + one scalar kernel (the Philox counter and Adam's step-dependent scalars move to device

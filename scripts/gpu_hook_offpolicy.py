@@ -36,6 +36,7 @@ if WHICH == "dqn":
     buf.terminated[:] = rng.random(N) < 0.002
     buf.done[:] = buf.terminated
     buf.prio[:] = 1.0
+    buf._meta = SI._Meta(("obs", "act", "rew", "terminated", "truncated", "done"))   # ignore_obs_next=True (atari_dqn.py)
     for e, sb in enumerate(buf.buffers):
         sb._size, sb._insertion_idx = SLOTS, 0
         buf._lengths[e] = SLOTS

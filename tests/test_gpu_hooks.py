@@ -748,13 +748,18 @@ def _dqn_hook_run(huber):
     assert float(opt_state["step"]) == 5.0
 
 
-def test_hip_dqn_default_mode_equals_the_reference_exact_mode():
+@pytest.mark.parametrize("layout", ["stored_obs_next", "atari_frames"])
+def test_hip_dqn_default_mode_equals_the_reference_exact_mode(layout):
     """HipDQN's defaults -- `update()` samples indices only (`buffer.sample()`'s host copy of two stacked observations per
     transition is never made; frames, actions, rewards are read from the device mirror), write-back of the two networks and the
     optimizer deferred until the torch state is read -- against the reference-exact mode (`host_batch=True,
     write_back="eager"`: the reference's own `Algorithm._update`) on the same prioritized buffer history: identical loss and
     identical priorities written back every update, identical torch state after a sync (`policy.state_dict()`, `hip_sync()`),
-    and the torch modules do not move in between.  The collector-side forward reads the engine's parameters either way."""
+    and the torch modules do not move in between.  The collector-side forward reads the engine's parameters either way.
+    `atari_frames`: the buffer does not store obs_next (ReplayBuffer(ignore_obs_next=True, save_only_last_obs=True),
+    examples/atari/atari_dqn.py) -- there the two hooks of the default mode are ONE library call (ts_dqn_learn_rows: gathers, n-step
+    returns and update for the indices and importance weights the host buffer drew) and must equal the reference-exact mode's
+    separate calls bit for bit."""
     from tianshou_amd.integration import make_hip_dqn
 
     c, h, w, A, E, size, B = 4, 44, 36, 3, 4, 40, 32
@@ -783,6 +788,9 @@ def test_hip_dqn_default_mode_equals_the_reference_exact_mode():
                              rew=rng.normal(size=E), terminated=term, truncated=(rng.random(E) < 0.03) & ~term,
                              obs_next=rng.integers(0, 256, (E, h, w)).astype(np.uint8)))
 
+    if layout == "atari_frames":
+        for b in bufs:
+            b._meta = SI._Meta(("obs", "act", "rew", "terminated", "truncated", "done"))        # ignore_obs_next=True
     made = []
     orig = bufs[1].sample
     bufs[1].sample = lambda bs: (made.append(bs), orig(bs))[1]          # the default mode must not ask for the host batch
@@ -799,6 +807,8 @@ def test_hip_dqn_default_mode_equals_the_reference_exact_mode():
         assert torch.equal(flat(lazy), start)                            # nothing was written back yet
         assert lazy._iter == ref._iter == u + 1
     assert not made and lazy.__dict__["_hip_stale"]
+    assert (lazy.__dict__["_hip_engine_obj"]._rows is not None) == (layout == "atari_frames")      # the one-call path ran / did not
+    assert ref.__dict__["_hip_engine_obj"]._rows is None
     obs = np.random.default_rng(8).integers(0, 256, (8, c, h, w)).astype(np.uint8)
     q_l = lazy.policy(SI.Batch(obs=obs, info={})).logits
     q_r = ref.policy(SI.Batch(obs=obs, info={})).logits

@@ -679,6 +679,60 @@ int ts_dqn_learn_step(ts_workspace* ws, ts_workspace* ws_aux, float* params, flo
     return copies(true);
 }
 
+// The same update for a batch the CALLER drew (a host PrioritizedVectorReplayBuffer's sample_indices + get_weight: HipDQN.update()
+// at hook level): batch.act / obs / obs_next gathered by index, n-step returns, the update -- what ts_dqn_learn_step does between
+// its sampling and its priority update, as one call.  `rb->tree` is not looked at; TD errors go to td_out (the caller's
+// _postprocess_batch hands them to buffer.update_weight).
+int ts_dqn_learn_rows(ts_workspace* ws, ts_workspace* ws_aux, float* params, float* params_old, int sync_target, float* adam_m,
+                      float* adam_v, int64_t adam_step, int64_t c, int64_t h, int64_t w, int64_t n_act,
+                      const ts_frame_replay* rb, const int64_t* indices, const float* weight, int64_t B, int64_t n_step,
+                      double gamma, int is_double, const ts_dqn_hparams* hp, void* scratch, int64_t scratch_bytes,
+                      float* returns_out, float* td_out, float* loss_out, ts_stream_t stream) {
+    TS_REQUIRE(ws != nullptr && ws_aux != nullptr && ws != ws_aux, TS_ERR_WORKSPACE,
+               "ts_dqn_learn_rows: two distinct workspaces (the update's, and the one of the forward pass beside the target passes)");
+    TS_REQUIRE(params && adam_m && adam_v && rb && hp && scratch && loss_out && indices && B >= 1 && adam_step >= 1,
+               TS_ERR_INVALID_ARG, "ts_dqn_learn_rows: bad argument");
+    TS_REQUIRE(rb->offset && rb->lengths && rb->last_index && rb->done && rb->terminated && rb->rew && rb->frames && rb->act_col &&
+                   rb->E >= 1 && rb->slots >= 1, TS_ERR_INVALID_ARG, "ts_dqn_learn_rows: incomplete replay view");
+    TS_REQUIRE(rb->plane_elems == h * w, TS_ERR_SHAPE, "ts_dqn_learn_rows: frames of %lld elements for a %lld x %lld network input",
+               (long long)rb->plane_elems, (long long)h, (long long)w);
+    TS_REQUIRE((reinterpret_cast<uintptr_t>(scratch) & 255u) == 0, TS_ERR_INVALID_ARG,
+               "ts_dqn_learn_rows: scratch must be 256-byte aligned");
+    Net n;
+    if (int rc = make_net((int)B, (int)c, (int)h, (int)w, (int)n_act, &n)) return rc;
+    LearnScratch sc;
+    const size_t need = dqn_learn_carve(static_cast<char*>(scratch), n, B, c * h * w, &sc);
+    TS_REQUIRE(scratch_bytes >= (int64_t)need, TS_ERR_SHAPE, "ts_dqn_learn_rows: scratch holds %lld bytes, %lld needed",
+               (long long)scratch_bytes, (long long)need);
+    hipStream_t s = ts::as_stream(stream), side, side2;
+    if (int rc = ts::side_streams(ws, s, &side, &side2)) return rc;
+    const LearnBatch& cur = sc.b[0];
+    if (int rc = ts_gather_rows(rb->act_col, rb->slots, 8, indices, B, cur.act, s)) return rc;
+    if (int rc = ts_dqn_gather_pair(rb->frames, rb->slots, rb->plane_elems, indices, B, n_step, c, rb->offset, rb->E, rb->done,
+                                    rb->last_index, rb->lengths, cur.obs, cur.obs_next, s))
+        return rc;
+    if (int rc = ts_nstep_coefficients(indices, B, n_step, rb->offset, rb->E, rb->done, rb->terminated, rb->last_index, rb->lengths,
+                                       rb->rew, gamma, cur.mask, cur.gpow, cur.mc, s))
+        return rc;
+    // Q_online(batch.obs) of the update on the second side stream, beside the two obs_next passes of _target_q
+    if (int rc = ts::stream_wait(ws, s, side2, 6)) return rc;
+    if (int rc = ts_dqn_forward_cache(ws->profiling ? ws : ws_aux, params, c, h, w, n_act, cur.obs, 1, B, sc.cache,
+                                      (int64_t)sc.cache_bytes, side2))
+        return rc;
+    if (int rc = ts_dqn_target_returns(ws, params, params_old, c, h, w, n_act, cur.obs_next, 1, B, is_double, cur.mask, cur.gpow,
+                                       cur.mc, sc.returns, s))
+        return rc;
+    if (sync_target && params_old)       // the periodic hard sync sits between _preprocess_batch and the update (dqn.py:283-285)
+        TS_HIP_CHECK(hipMemcpyAsync(params_old, params, sizeof(float) * (size_t)n.total, hipMemcpyDeviceToDevice, s));
+    if (int rc = ts::stream_wait(ws, side2, s, 7)) return rc;
+    if (int rc = dqn_update_impl(ws, params, adam_m, adam_v, adam_step, c, h, w, n_act, cur.obs, 1, cur.act, sc.returns, weight, B, hp,
+                                 sc.td, loss_out, nullptr, reinterpret_cast<ts_stream_t>(s), sc.cache, "ts_dqn_learn_rows", nullptr))
+        return rc;
+    if (returns_out) TS_HIP_CHECK(hipMemcpyAsync(returns_out, sc.returns, 4 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (td_out) TS_HIP_CHECK(hipMemcpyAsync(td_out, sc.td, 4 * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return TS_OK;
+}
+
 int64_t ts_dqn_learn_graph_launches(ts_workspace* ws) {
     if (!ws || !ws->learn_graphs) return 0;
     auto* lg = static_cast<LearnGraphs*>(ws->learn_graphs);

@@ -238,6 +238,7 @@ class DQNEngine:
         self._ws = _lib.default_workspace(self.device.index or 0)
         self._pre = None               # (obs tensor, cache, done event, params version) of a prefetched forward pass
         self._side = None
+        self._rows = None              # state of `learn_rows` (scratch, replay view)
         self._learn = None             # state of `learn_step` (scratch, replay view, the seed of the batch prepared ahead)
 
     # -- the forward pass on batch.obs, ahead of time ------------------------------------------------
@@ -494,6 +495,64 @@ class DQNEngine:
             _lib.current_stream(self.device)))
         st["last"] = (key, counter)
         return loss, td
+
+    def rows_ok(self, buffer: DeviceReplayBuffer, frames, act_col) -> bool:
+        """Whether `learn_rows` applies: uint8 contiguous single frames, frame stack 4 = the network's channels, no stored obs_next
+        (ReplayBuffer(stack_num=4, ignore_obs_next=True, save_only_last_obs=True), examples/atari/atari_dqn.py), int64 actions."""
+        return (self.c == 4 and (self.h * self.w) % 16 == 0 and frames is not None and frames.is_cuda and frames.dtype == torch.uint8
+                and frames.dim() == 3 and tuple(frames.shape[1:]) == (self.h, self.w) and frames.is_contiguous()
+                and buffer.obs_next is None and act_col is not None and act_col.is_cuda and act_col.dim() == 1
+                and act_col.dtype == torch.int64 and act_col.is_contiguous())
+
+    def learn_rows(self, buffer: DeviceReplayBuffer, frames: torch.Tensor, act_col: torch.Tensor, indices: torch.Tensor, weight=None,
+                   want_returns: bool = True):
+        """`preprocess_with_obs(prefetch=True)` -> `update_with_batch` for a batch the CALLER drew, as ONE library call
+        (ts_dqn_learn_rows): the two hooks of `HipDQN.update()` over a host buffer whose sample_indices / get_weight made `indices`
+        int64[B] and `weight` (importance weights, or None).  Same kernels on the same values as the two calls.
+        -> (loss float32[1], td_error float32[B], returns float32[B] or None).  Requires `rows_ok`."""
+        lib = _lib.load()
+        b = int(indices.numel())
+        st = self._rows
+        ident = (id(buffer), frames.data_ptr(), act_col.data_ptr(), b, buffer.offset.data_ptr(), buffer.rew.data_ptr(), buffer.done.data_ptr())
+        if st is None or st["ident"] != ident:
+            if not self.rows_ok(buffer, frames, act_col):
+                raise ValueError("learn_rows: uint8 contiguous [slots, h, w] frames, frame stack 4, no stored obs_next, int64 actions")
+            lib.ts_dqn_learn_scratch_bytes.restype = C.c_int64
+            need = int(lib.ts_dqn_learn_scratch_bytes(_lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act), _lib.i64(b)))
+            if need <= 0:
+                raise ValueError("learn_rows: unsupported network / batch dimensions")
+            scratch = torch.zeros(need + 256, dtype=torch.uint8, device=self.device)
+            view = _lib.FrameReplay(
+                _lib.ptr(buffer.offset), buffer.buffer_num, _lib.ptr(buffer.lengths), _lib.ptr(buffer.last_index),
+                _lib.ptr(buffer.done), _lib.ptr(buffer.terminated), _lib.ptr(buffer.rew), _lib.ptr(frames), self.h * self.w,
+                _lib.ptr(act_col), frames.shape[0], None, 0, None, 0.0, 0.0, 0, 0)
+            st = self._rows = {"ident": ident, "scratch": scratch, "ptr": C.c_void_p((scratch.data_ptr() + 255) & ~255),
+                               "bytes": _lib.i64(need), "view": view, "aux": _lib.aux_workspace(self.device.index or 0),
+                               "keep": (buffer, frames, act_col), "B": _lib.i64(b),
+                               "dims": (_lib.i64(self.c), _lib.i64(self.h), _lib.i64(self.w), _lib.i64(self.n_act))}
+        if not (indices.is_cuda and indices.dtype == torch.int64 and indices.is_contiguous()):
+            raise ValueError("learn_rows: indices must be an int64 contiguous device tensor")
+        if weight is not None:
+            weight = weight.to(device=self.device, dtype=torch.float32).contiguous().reshape(b)
+        cfg = self.cfg
+        sync = self.params_old is not None and self.iter % cfg.target_update_freq == 0    # dqn.py:283-285, applied inside the call
+        self.iter += 1
+        self.adam_step += 1
+        self._pre = None
+        td = torch.empty(b, dtype=torch.float32, device=self.device)
+        ret = torch.empty(b, dtype=torch.float32, device=self.device) if want_returns else None
+        loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        hp_of = (cfg.lr, cfg.betas, cfg.adam_eps, cfg.huber_delta, cfg.max_grad_norm)
+        if st.get("hp_of") != hp_of:
+            st["hp"], st["hp_of"] = cfg.to_c(), hp_of
+        dims = st["dims"]
+        _lib.check(lib.ts_dqn_learn_rows(
+            self._ws.handle, st["aux"].handle, _lib.ptr(self.params), _lib.ptr(self.params_old), C.c_int(int(sync)),
+            _lib.ptr(self.adam_m), _lib.ptr(self.adam_v), _lib.i64(self.adam_step), dims[0], dims[1], dims[2], dims[3],
+            C.byref(st["view"]), _lib.ptr(indices), _lib.ptr(weight), st["B"], _lib.i64(cfg.n_step), _lib.f64(cfg.gamma),
+            C.c_int(int(cfg.is_double)), C.byref(st["hp"]), st["ptr"], st["bytes"], _lib.ptr(ret), _lib.ptr(td), _lib.ptr(loss),
+            _lib.current_stream(self.device)))
+        return loss, td, ret
 
     def learn_reset(self) -> None:
         """Drops the batch `learn_step` prepared ahead of time (call it after transitions were written to the buffer)."""

@@ -1206,6 +1206,18 @@ def make_hip_dqn(ref=None):
             eng = self._engine(c, h, w)
             m = _mirror(self, buffer, self._hip_device)
             idx = torch.as_tensor(np.asarray(indices, np.int64), device=self._hip_device)
+            self._hip_idx, self._hip_stack = idx, stack
+            if hasattr(batch, "weight"):
+                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
+            # Inside HipDQN.update()'s own sequence (`_hip_offpolicy_update`: nobody reads the batch between the two hooks) on the
+            # Atari layout (single uint8 frames, stack 4, no stored obs_next) the two hooks are ONE library call, made by
+            # `_update_with_batch` (ts_dqn_learn_rows; `batch.returns` is attached there).  Called on its own (the reference's
+            # `_update`, `host_batch=True`, data parallel, other layouts) the hook computes the returns here.
+            self.__dict__["_hip_deferred"] = (self.__dict__.get("_hip_own_sequence", False) and not self._hip_dp_on and stack == c
+                                              and hasattr(eng, "rows_ok") and eng.rows_ok(m, m.obs, m.act)
+                                              and not os.environ.get("TS_DQN_TWO_CALLS"))
+            if self.__dict__["_hip_deferred"]:
+                return batch
             nxt = m.obs_next if m.obs_next is not None else None
             # the batch's own observations, gathered here so that Q_online(batch.obs) of _update_with_batch can run beside the
             # two obs_next passes of _target_q (DQNEngine.prefetch_forward); data-parallel runs keep the plain order
@@ -1213,15 +1225,19 @@ def make_hip_dqn(ref=None):
             self._hip_obs, ret = eng.preprocess_with_obs(m, m.obs, idx, stack, obs_next_frames=nxt,
                                                          prefetch=not self._hip_dp_on)
             batch.returns = ret.reshape(-1, 1)
-            self._hip_idx, self._hip_stack = idx, stack
-            if hasattr(batch, "weight"):
-                batch.weight = torch.as_tensor(np.asarray(batch.weight), dtype=torch.float32, device=self._hip_device)
             return batch
 
         def _update_with_batch(self, batch):
             self._hip_refresh_lr()
             eng, m = self._hip_engine, self._hip_mirror
             weight = batch.pop("weight", None)
+            if self.__dict__.pop("_hip_deferred", False):
+                loss, td, ret = eng.learn_rows(m, m.obs, m.act, self._hip_idx, weight)
+                batch.returns = ret.reshape(-1, 1)
+                self._iter = eng.iter
+                batch.weight = td                                                 # prio-buffer, dqn.py:401
+                self._hip_after_update()
+                return SimpleLossTrainingStats(loss=float(loss.item()))
             obs = self._hip_obs
             # (index-only sampling: the batch carries no host copy of the actions; the mirror's rows are the same values)
             act = torch.as_tensor(np.asarray(batch.act), device=self._hip_device) if hasattr(batch, "act") else m.act[self._hip_idx]
